@@ -1,0 +1,745 @@
+/*
+ * s3a_host.c -- host C side of libcmusphinx_amd: error reporting, the S3
+ * binary file envelope, integer log-domain arithmetic, acoustic-model
+ * loading + precomputation and transition-matrix conversion.
+ *
+ * Behavioural parity with the reference (paths relative to cjac/cmusphinx):
+ *   envelope        sphinxbase/src/libsphinxbase/util/bio.c:187-262, 265-296, 491-504
+ *   logmath         sphinxbase/src/libsphinxbase/util/logmath.c:61-161, 391-483
+ *   logs3           sphinx3/src/libs3decoder/libcommon/logs3.c:101-119
+ *   means/variances sphinx3/src/libs3decoder/libam/cont_mgau.c:148-429
+ *   mixture weights cont_mgau.c:507-683
+ *   compaction/floor/precompute   cont_mgau.c:700-894, order of cont_mgau.c:938-951
+ *   tmat            sphinx3/src/libs3decoder/libam/tmat.c:155-270
+ *
+ * libm's log() is used only here, at initialisation, exactly where the
+ * reference uses it, so table entries and lrd terms carry the same bits.
+ * This file must be compiled without -ffast-math and with -ffp-contract=off.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <math.h>
+
+#include "s3a_internal.h"
+
+/* ------------------------------------------------------------------ */
+/* errors                                                              */
+/* ------------------------------------------------------------------ */
+static __thread char g_err[512];
+
+void
+s3a_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+const char *
+s3a_last_error(void)
+{
+    return g_err;
+}
+
+const char *
+s3a_version(void)
+{
+    return "cmusphinx_amd 0.1 (gfx950)";
+}
+
+/* ------------------------------------------------------------------ */
+/* S3 binary envelope                                                  */
+/* ------------------------------------------------------------------ */
+static uint32_t
+bswap32(uint32_t v)
+{
+    return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24);
+}
+
+int32_t
+s3a_bio_read(const char *path, const char *expect_version, uint32_t **words, size_t *n_words)
+{
+    FILE *fp;
+    long fsize;
+    unsigned char *buf = NULL;
+    size_t pos, hdr_end = 0, n, i;
+    int have_chksum = 0, swap;
+    uint32_t magic, *w;
+
+    *words = NULL;
+    *n_words = 0;
+    if ((fp = fopen(path, "rb")) == NULL) {
+        s3a_set_error("cannot open %s", path);
+        return S3A_EIO;
+    }
+    fseek(fp, 0, SEEK_END);
+    fsize = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    if (fsize < 12 || (buf = (unsigned char *)malloc((size_t)fsize + 1)) == NULL) {
+        fclose(fp);
+        s3a_set_error("%s: empty file or out of memory", path);
+        return fsize < 12 ? S3A_EIO : S3A_ENOMEM;
+    }
+    if (fread(buf, 1, (size_t)fsize, fp) != (size_t)fsize) {
+        fclose(fp);
+        free(buf);
+        s3a_set_error("%s: short read", path);
+        return S3A_EIO;
+    }
+    fclose(fp);
+    buf[fsize] = 0;
+
+    /* header: "s3\n" then "name value\n" lines up to "endhdr\n" */
+    if (memcmp(buf, "s3\n", 3) != 0) {
+        free(buf);
+        s3a_set_error("%s: not an s3 binary file (old headerless format unsupported)", path);
+        return S3A_EIO;
+    }
+    pos = 3;
+    for (;;) {
+        char *line = (char *)buf + pos, *nl = memchr(line, '\n', (size_t)fsize - pos);
+        char name[256] = "", val[256] = "";
+        if (nl == NULL) {
+            free(buf);
+            s3a_set_error("%s: premature EOF in header", path);
+            return S3A_EIO;
+        }
+        *nl = 0;
+        pos = (size_t)(nl - (char *)buf) + 1;
+        if (sscanf(line, "%255s %255s", name, val) < 1)
+            continue;
+        if (strcmp(name, "endhdr") == 0) {
+            hdr_end = pos;
+            break;
+        }
+        if (name[0] == '#')
+            continue;
+        if (strcmp(name, "chksum0") == 0)
+            have_chksum = 1;
+        else if (strcmp(name, "version") == 0 && expect_version
+                 && strcmp(val, expect_version) != 0)
+            fprintf(stderr, "WARNING: %s: version %s, expecting %s\n", path, val,
+                    expect_version);
+    }
+    if ((size_t)fsize < hdr_end + 4 || (((size_t)fsize - hdr_end) & 3) != 0) {
+        free(buf);
+        s3a_set_error("%s: payload is not a whole number of 32-bit words", path);
+        return S3A_EIO;
+    }
+    memcpy(&magic, buf + hdr_end, 4);
+    if (magic == 0x11223344u)
+        swap = 0;
+    else if (bswap32(magic) == 0x11223344u)
+        swap = 1;
+    else {
+        free(buf);
+        s3a_set_error("%s: bad byte-order magic %08x", path, magic);
+        return S3A_EIO;
+    }
+    n = ((size_t)fsize - hdr_end - 4) / 4;
+    if ((w = (uint32_t *)malloc(4 * (n ? n : 1))) == NULL) {
+        free(buf);
+        return S3A_ENOMEM;
+    }
+    memcpy(w, buf + hdr_end + 4, 4 * n);
+    free(buf);
+    if (swap)
+        for (i = 0; i < n; i++)
+            w[i] = bswap32(w[i]);
+    if (have_chksum) {
+        uint32_t sum = 0;
+        if (n < 1) {
+            free(w);
+            s3a_set_error("%s: checksum announced but missing", path);
+            return S3A_EIO;
+        }
+        n -= 1;
+        for (i = 0; i < n; i++)
+            sum = ((sum << 20) | (sum >> 12)) + w[i];
+        if (sum != w[n]) {
+            s3a_set_error("%s: checksum error; file-checksum %08x, computed %08x", path,
+                          w[n], sum);
+            free(w);
+            return S3A_EIO;
+        }
+    }
+    *words = w;
+    *n_words = n;
+    return S3A_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* logmath                                                             */
+/* ------------------------------------------------------------------ */
+static int32_t
+addtab_entry(const s3a_logmath_t *lm, double byx)
+{
+    /* round(log_base(1 + base^-d)) at the table's resolution */
+    double lobyx = log(1.0 + byx) * lm->inv_log_of_base;
+    return (int32_t)(lobyx + 0.5 * (1 << lm->shift)) >> lm->shift;
+}
+
+s3a_logmath_t *
+s3a_logmath_init(double base, int32_t shift, int32_t use_table)
+{
+    s3a_logmath_t *lm;
+    uint32_t maxyx, cap, n_raw, n, i;
+    int32_t *raw;
+    double byx;
+
+    if (base <= 1.0) {
+        s3a_set_error("logmath base must be greater than 1.0");
+        return NULL;
+    }
+    if ((lm = (s3a_logmath_t *)calloc(1, sizeof *lm)) == NULL)
+        return NULL;
+    lm->base = base;
+    lm->log_of_base = log(base);
+    lm->log10_of_base = log10(base);
+    lm->inv_log_of_base = 1.0 / lm->log_of_base;
+    lm->inv_log10_of_base = 1.0 / lm->log10_of_base;
+    lm->shift = shift;
+    lm->zero = S3A_MAX_NEG_INT32 >> (shift + 2);
+    if (!use_table)
+        return lm;
+
+    maxyx = (uint32_t)(log(2.0) / log(base) + 0.5) >> shift;
+    lm->width = (maxyx < 256) ? 1 : (maxyx < 65536) ? 2 : 4;
+
+    /* generate the un-shifted sequence k(d), d = 0,1,... until it hits 0,
+     * dividing by base each step exactly as the reference does */
+    cap = 1u << 16;
+    raw = (int32_t *)malloc(sizeof(int32_t) * cap);
+    byx = 1.0;
+    for (n_raw = 0;; n_raw++) {
+        if (n_raw == cap) {
+            cap *= 2;
+            raw = (int32_t *)realloc(raw, sizeof(int32_t) * cap);
+        }
+        raw[n_raw] = addtab_entry(lm, byx);
+        if (raw[n_raw] <= 0)
+            break;
+        byx /= base;
+    }
+    /* n_raw = index of the first non-positive entry */
+    n = n_raw >> shift;
+    if (n < 255)
+        n = 255;
+    lm->table_size = n + 1;
+    lm->table = (uint32_t *)calloc(lm->table_size, sizeof(uint32_t));
+    /* slot j keeps the first value that maps to it unless that value is 0 */
+    for (i = 0; i <= n_raw; i++) {
+        uint32_t j = i >> shift, v = (uint32_t)raw[i];
+        if (lm->width == 1) v &= 0xffu;
+        else if (lm->width == 2) v &= 0xffffu;
+        if (lm->table[j] == 0)
+            lm->table[j] = v;
+    }
+    free(raw);
+    return lm;
+}
+
+s3a_logmath_t *
+s3a_logs3_init(double base, int32_t breport, int32_t blogtable)
+{
+    s3a_logmath_t *lm = s3a_logmath_init(base, 0, blogtable);
+    if (lm && breport)
+        fprintf(stderr, "INFO: Log-Add table size = %u x %d >> %d\n", lm->table_size,
+                lm->width, lm->shift);
+    return lm;
+}
+
+void
+s3a_logmath_free(s3a_logmath_t *lm)
+{
+    if (lm) {
+        free(lm->table);
+        free(lm);
+    }
+}
+
+int32_t
+s3a_logmath_log(const s3a_logmath_t *lm, double p)
+{
+    if (p <= 0)
+        return lm->zero;
+    return (int32_t)(log(p) * lm->inv_log_of_base) >> lm->shift;
+}
+
+double
+s3a_logmath_exp(const s3a_logmath_t *lm, int32_t logb_p)
+{
+    return pow(lm->base, (double)(int32_t)((uint32_t)logb_p << lm->shift));
+}
+
+int32_t
+s3a_logmath_add(const s3a_logmath_t *lm, int32_t x, int32_t y)
+{
+    int32_t hi, lo, d;
+    if (x <= lm->zero)
+        return y;
+    if (y <= lm->zero)
+        return x;
+    if (lm->table == NULL)
+        return s3a_logmath_log(lm, s3a_logmath_exp(lm, x) + s3a_logmath_exp(lm, y));
+    hi = x > y ? x : y;
+    lo = x > y ? y : x;
+    d = (int32_t)((uint32_t)hi - (uint32_t)lo);
+    if (d < 0 || (uint32_t)d >= lm->table_size)
+        return hi;
+    return hi + (int32_t)lm->table[d];
+}
+
+int32_t
+s3a_logmath_ln_to_log(const s3a_logmath_t *lm, double log_p)
+{
+    return (int32_t)(log_p * lm->inv_log_of_base) >> lm->shift;
+}
+
+double
+s3a_logmath_log_to_ln(const s3a_logmath_t *lm, int32_t logb_p)
+{
+    return (double)(int32_t)((uint32_t)logb_p << lm->shift) * lm->log_of_base;
+}
+
+int32_t
+s3a_logmath_log10_to_log(const s3a_logmath_t *lm, double log_p)
+{
+    return (int32_t)(log_p * lm->inv_log10_of_base) >> lm->shift;
+}
+
+double
+s3a_logmath_get_base(const s3a_logmath_t *lm)
+{
+    return lm->base;
+}
+
+int32_t
+s3a_logmath_get_zero(const s3a_logmath_t *lm)
+{
+    return lm->zero;
+}
+
+int32_t
+s3a_logmath_get_table_shape(const s3a_logmath_t *lm, uint32_t *out_size, uint32_t *out_width,
+                            uint32_t *out_shift)
+{
+    if (lm->table == NULL)
+        return S3A_EINVAL;
+    if (out_size) *out_size = lm->table_size;
+    if (out_width) *out_width = (uint32_t)lm->width;
+    if (out_shift) *out_shift = (uint32_t)lm->shift;
+    return S3A_OK;
+}
+
+int32_t
+s3a_logmath_copy_table(const s3a_logmath_t *lm, uint32_t *out, uint32_t size)
+{
+    if (lm->table == NULL || size < lm->table_size)
+        return S3A_EINVAL;
+    memcpy(out, lm->table, sizeof(uint32_t) * lm->table_size);
+    return S3A_OK;
+}
+
+int32_t
+s3a_logs3(const s3a_logmath_t *lm, double p)
+{
+    if (p <= 0.0)
+        return S3A_LOGPROB_ZERO;
+    return s3a_logmath_log(lm, p);
+}
+
+/* ------------------------------------------------------------------ */
+/* acoustic model: host half of mgau_init                              */
+/* ------------------------------------------------------------------ */
+static int
+all_zero(const float *v, int32_t n)
+{
+    int32_t i;
+    for (i = 0; i < n; i++)
+        if (v[i] != 0.0)
+            return 0;
+    return 1;
+}
+
+static int
+any_nan(const float *v, int32_t n)
+{
+    int32_t i;
+    for (i = 0; i < n; i++)
+        if (isnan(v[i]))
+            return 1;
+    return 0;
+}
+
+/* sum-normalise in double, store back as float (vector.c:105-123) */
+static double
+normalise(float *v, int32_t n)
+{
+    double sum = 0.0, f;
+    int32_t i;
+    for (i = 0; i < n; i++)
+        sum += v[i];
+    if (sum != 0.0) {
+        f = 1.0 / sum;
+        for (i = 0; i < n; i++)
+            v[i] = (float)((double)v[i] * f);
+    }
+    return sum;
+}
+
+/* floor the non-zero entries (vector.c:138-145) */
+static void
+floor_nonzero(float *v, int32_t n, double flr)
+{
+    int32_t i;
+    for (i = 0; i < n; i++)
+        if (v[i] != 0.0 && v[i] < flr)
+            v[i] = (float)flr;
+}
+
+s3a_mgau_model_t *
+s3a_mgau_host_init(const float *mean, const float *var, const float *mixw, int32_t n_mgau,
+                   int32_t n_density, int32_t veclen, double varfloor, double mixwfloor,
+                   int32_t precomp, s3a_logmath_t *lm)
+{
+    s3a_mgau_model_t *g;
+    size_t ng = (size_t)n_mgau * n_density, nv = ng * veclen;
+    float *w;
+    int32_t m, c, i;
+
+    if (n_mgau <= 0 || n_density <= 0 || veclen <= 0 || !lm || !mean || !var || !mixw) {
+        s3a_set_error("s3a_mgau_init: bad arguments");
+        return NULL;
+    }
+    g = (s3a_mgau_model_t *)calloc(1, sizeof *g);
+    g->n_mgau = n_mgau;
+    g->max_comp = n_density;
+    g->veclen = veclen;
+    g->lm = lm;
+    g->n_comp = (int32_t *)calloc(n_mgau, sizeof(int32_t));
+    g->mean = (float *)calloc(nv, sizeof(float));
+    g->prec = (float *)calloc(nv, sizeof(float));
+    g->lrd = (float *)calloc(ng, sizeof(float));
+    g->mixw = (int32_t *)calloc(ng, sizeof(int32_t));
+    w = (float *)malloc(sizeof(float) * n_density);
+    if (!g->n_comp || !g->mean || !g->prec || !g->lrd || !g->mixw || !w) {
+        free(w);
+        s3a_mgau_host_free(g);
+        s3a_set_error("s3a_mgau_init: out of memory");
+        return NULL;
+    }
+
+    for (m = 0; m < n_mgau; m++) {
+        const float *m_in = mean + (size_t)m * n_density * veclen;
+        const float *v_in = var + (size_t)m * n_density * veclen;
+        int32_t *mixw_m = g->mixw + (size_t)m * n_density;
+        int32_t kept = 0;
+
+        /* 1. mixture weights of this senone -> logs3 (before compaction, as
+         *    mgau_mixw_read runs before mgau_uninit_compact) */
+        memcpy(w, mixw + (size_t)m * n_density, sizeof(float) * n_density);
+        if (all_zero(w, n_density)) {
+            for (c = 0; c < n_density; c++)
+                w[c] = 0.0f;
+        }
+        else {
+            floor_nonzero(w, n_density, mixwfloor);
+            normalise(w, n_density);
+        }
+
+        /* 2. keep initialised components only, in order */
+        for (c = 0; c < n_density; c++) {
+            const float *mc = m_in + (size_t)c * veclen, *vc = v_in + (size_t)c * veclen;
+            float *m_out, *p_out;
+            double lrd;
+            if (any_nan(mc, veclen) || any_nan(vc, veclen) || all_zero(vc, veclen))
+                continue;
+            m_out = g->mean + ((size_t)m * n_density + kept) * veclen;
+            p_out = g->prec + ((size_t)m * n_density + kept) * veclen;
+            memcpy(m_out, mc, sizeof(float) * veclen);
+            memcpy(p_out, vc, sizeof(float) * veclen);
+            mixw_m[kept] = (w[c] != 0.0) ? s3a_logs3(lm, w[c]) : S3A_LOGPROB_ZERO;
+
+            /* 3. variance floor, then 4. precompute, per kept component */
+            if (varfloor > 0.0)
+                for (i = 0; i < veclen; i++)
+                    if (p_out[i] < varfloor)
+                        p_out[i] = (float)varfloor;
+            if (precomp) {
+                lrd = 0.0;
+                for (i = 0; i < veclen; i++) {
+                    lrd += log(p_out[i]);
+                    p_out[i] = (float)(1.0 / (p_out[i] * 2.0));
+                }
+                lrd += veclen * log(2.0 * M_PI);
+                g->lrd[(size_t)m * n_density + kept] = (float)(-0.5 * lrd);
+            }
+            kept++;
+        }
+        g->n_comp[m] = kept;
+        for (c = kept; c < n_density; c++)
+            mixw_m[c] = S3A_LOGPROB_ZERO;
+    }
+    free(w);
+
+    g->distfloor = s3a_logmath_log_to_ln(lm, S3A_LOGPROB_ZERO);
+    g->f = 1.0 / log(lm->base);
+    g->precision = S3A_GMM_EXACT;
+    return g;
+}
+
+void
+s3a_mgau_host_free(s3a_mgau_model_t *g)
+{
+    if (!g)
+        return;
+    free(g->n_comp);
+    free(g->mean);
+    free(g->prec);
+    free(g->lrd);
+    free(g->mixw);
+    free(g);
+}
+
+/* parse a means / variances payload; returns pointer into words */
+static int32_t
+parse_gau(const char *path, const uint32_t *w, size_t nw, int32_t *n_mgau, int32_t *n_density,
+          int32_t *veclen, const float **data)
+{
+    int32_t n_feat, n;
+    if (nw < 5) {
+        s3a_set_error("%s: truncated header", path);
+        return S3A_EIO;
+    }
+    *n_mgau = (int32_t)w[0];
+    n_feat = (int32_t)w[1];
+    *n_density = (int32_t)w[2];
+    if (n_feat != 1) {
+        s3a_set_error("%s: #feature streams(%d) != 1 in continuous HMM", path, n_feat);
+        return S3A_EUNSUP;
+    }
+    *veclen = (int32_t)w[3];
+    n = (int32_t)w[4];
+    if (*n_mgau <= 0 || *n_density <= 0 || *veclen <= 0) {
+        s3a_set_error("%s: bad dimensions", path);
+        return S3A_EIO;
+    }
+    if ((int64_t)n == (int64_t)*n_mgau * *n_density * *veclen * *veclen && *veclen > 1) {
+        s3a_set_error("%s: full covariance matrices are not supported", path);
+        return S3A_EUNSUP;
+    }
+    if ((int64_t)n != (int64_t)*n_mgau * *n_density * *veclen) {
+        s3a_set_error("%s: #float32s(%d) doesn't match dimensions: %d x %d x %d", path, n,
+                      *n_mgau, *n_density, *veclen);
+        return S3A_EIO;
+    }
+    if (nw != 5 + (size_t)n) {
+        s3a_set_error("%s: %s data than expected", path, nw > 5 + (size_t)n ? "more" : "less");
+        return S3A_EIO;
+    }
+    *data = (const float *)(w + 5);
+    return S3A_OK;
+}
+
+s3a_mgau_model_t *
+s3a_mgau_init_arrays(const float *mean, const float *var, const float *mixw, int32_t n_mgau,
+                     int32_t n_density, int32_t veclen, double varfloor, double mixwfloor,
+                     int32_t precomp, s3a_logmath_t *logmath)
+{
+    s3a_mgau_model_t *g = s3a_mgau_host_init(mean, var, mixw, n_mgau, n_density, veclen,
+                                             varfloor, mixwfloor, precomp, logmath);
+    if (g && s3a_mgau_dev_create(g) != S3A_OK) {
+        s3a_mgau_host_free(g);
+        return NULL;
+    }
+    return g;
+}
+
+s3a_mgau_model_t *
+s3a_mgau_init(const char *meanfile, const char *varfile, double varfloor, const char *mixwfile,
+              double mixwfloor, int32_t precomp, const char *senmgau, int32_t comp_type,
+              s3a_logmath_t *logmath)
+{
+    uint32_t *wm = NULL, *wv = NULL, *ww = NULL;
+    size_t nm, nv, nw;
+    int32_t S, C, D, S2, C2, D2, S3, n_feat, C3, n;
+    const float *mean, *var;
+    s3a_mgau_model_t *g = NULL;
+
+    if (!meanfile || !varfile || !mixwfile || !logmath || varfloor < 0.0 || mixwfloor < 0.0) {
+        s3a_set_error("s3a_mgau_init: bad arguments");
+        return NULL;
+    }
+    if (!senmgau || strcmp(senmgau, ".cont.") != 0) {
+        s3a_set_error("s3a_mgau_init: only -senmgau .cont. is supported (got %s)",
+                      senmgau ? senmgau : "NULL");
+        return NULL;
+    }
+    if (comp_type != S3A_MIX_INT_FLOAT_COMP) {
+        s3a_set_error("s3a_mgau_init: only MIX_INT_FLOAT_COMP is supported");
+        return NULL;
+    }
+    if (s3a_bio_read(meanfile, "1.0", &wm, &nm) != S3A_OK
+        || s3a_bio_read(varfile, "1.0", &wv, &nv) != S3A_OK
+        || s3a_bio_read(mixwfile, "1.0", &ww, &nw) != S3A_OK)
+        goto done;
+    if (parse_gau(meanfile, wm, nm, &S, &C, &D, &mean) != S3A_OK
+        || parse_gau(varfile, wv, nv, &S2, &C2, &D2, &var) != S3A_OK)
+        goto done;
+    if (S2 != S || C2 != C || D2 != D) {
+        s3a_set_error("%s: dimensions %dx%dx%d don't match those of means %dx%dx%d", varfile,
+                      S2, C2, D2, S, C, D);
+        goto done;
+    }
+    if (nw < 4) {
+        s3a_set_error("%s: truncated header", mixwfile);
+        goto done;
+    }
+    S3 = (int32_t)ww[0]; n_feat = (int32_t)ww[1]; C3 = (int32_t)ww[2]; n = (int32_t)ww[3];
+    if (n_feat != 1) {
+        s3a_set_error("%s: #feature streams(%d) != 1 in continuous HMM", mixwfile, n_feat);
+        goto done;
+    }
+    if (S3 != S || C3 != C || (int64_t)n != (int64_t)S * C || nw != 4 + (size_t)n) {
+        s3a_set_error("%s: %d x %d mixture weights don't match mean/var parameters %d x %d",
+                      mixwfile, S3, C3, S, C);
+        goto done;
+    }
+    g = s3a_mgau_init_arrays(mean, var, (const float *)(ww + 4), S, C, D, varfloor, mixwfloor,
+                             precomp, logmath);
+done:
+    free(wm);
+    free(wv);
+    free(ww);
+    return g;
+}
+
+void
+s3a_mgau_free(s3a_mgau_model_t *g)
+{
+    if (!g)
+        return;
+    s3a_mgau_dev_destroy(g);
+    s3a_mgau_host_free(g);
+}
+
+int32_t s3a_mgau_n_mgau(const s3a_mgau_model_t *g) { return g->n_mgau; }
+int32_t s3a_mgau_max_comp(const s3a_mgau_model_t *g) { return g->max_comp; }
+int32_t s3a_mgau_veclen(const s3a_mgau_model_t *g) { return g->veclen; }
+int32_t s3a_mgau_n_comp(const s3a_mgau_model_t *g, int32_t m)
+{
+    return (m >= 0 && m < g->n_mgau) ? g->n_comp[m] : S3A_EINVAL;
+}
+double s3a_mgau_distfloor(const s3a_mgau_model_t *g) { return g->distfloor; }
+
+int32_t
+s3a_mgau_get_params(const s3a_mgau_model_t *g, float *mean, float *prec, float *lrd,
+                    int32_t *mixw, int32_t *n_comp)
+{
+    size_t ng = (size_t)g->n_mgau * g->max_comp;
+    if (mean) memcpy(mean, g->mean, sizeof(float) * ng * g->veclen);
+    if (prec) memcpy(prec, g->prec, sizeof(float) * ng * g->veclen);
+    if (lrd) memcpy(lrd, g->lrd, sizeof(float) * ng);
+    if (mixw) memcpy(mixw, g->mixw, sizeof(int32_t) * ng);
+    if (n_comp) memcpy(n_comp, g->n_comp, sizeof(int32_t) * g->n_mgau);
+    return S3A_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* transition matrices                                                 */
+/* ------------------------------------------------------------------ */
+s3a_tmat_t *
+s3a_tmat_init_arrays(const float *tp, int32_t n_tmat, int32_t n_state, double tpfloor,
+                     s3a_logmath_t *lm)
+{
+    s3a_tmat_t *t;
+    int32_t n_dst = n_state + 1, i, j, k;
+    float *row;
+
+    if (!tp || n_tmat <= 0 || n_state <= 0 || !lm) {
+        s3a_set_error("s3a_tmat_init: bad arguments");
+        return NULL;
+    }
+    t = (s3a_tmat_t *)calloc(1, sizeof *t);
+    t->n_tmat = n_tmat;
+    t->n_state = n_state;
+    t->tp = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_tmat * n_state * n_dst);
+    row = (float *)malloc(sizeof(float) * n_dst);
+    for (i = 0; i < n_tmat; i++)
+        for (j = 0; j < n_state; j++) {
+            int32_t *out = t->tp + ((size_t)i * n_state + j) * n_dst;
+            memcpy(row, tp + ((size_t)i * n_state + j) * n_dst, sizeof(float) * n_dst);
+            if (normalise(row, n_dst) == 0.0)
+                fprintf(stderr, "WARNING: Normalization failed for tmat %d from state %d\n", i, j);
+            floor_nonzero(row, n_dst, tpfloor);
+            normalise(row, n_dst);
+            for (k = 0; k < n_dst; k++)
+                out[k] = (row[k] == 0.0) ? S3A_LOGPROB_ZERO : s3a_logs3(lm, row[k]);
+        }
+    free(row);
+    /* tmat_chk_uppertri, tmat.c:126-140 */
+    for (i = 0; i < n_tmat; i++)
+        for (j = 1; j < n_state; j++)
+            for (k = 0; k < j; k++)
+                if (t->tp[((size_t)i * n_state + j) * n_dst + k] > S3A_LOGPROB_ZERO) {
+                    s3a_set_error("tmat %d not upper triangular: [%d][%d]", i, j, k);
+                    s3a_tmat_free(t);
+                    return NULL;
+                }
+    return t;
+}
+
+s3a_tmat_t *
+s3a_tmat_init(const char *tmatfile, double tpfloor, int32_t breport, s3a_logmath_t *lm)
+{
+    uint32_t *w = NULL;
+    size_t nw;
+    s3a_tmat_t *t = NULL;
+    int32_t n_tmat, n_src, n_dst, n;
+
+    if (breport)
+        fprintf(stderr, "INFO: Reading HMM transition probability matrices: %s\n", tmatfile);
+    if (s3a_bio_read(tmatfile, "1.0", &w, &nw) != S3A_OK)
+        return NULL;
+    if (nw < 4) {
+        s3a_set_error("%s: truncated header", tmatfile);
+        goto done;
+    }
+    n_tmat = (int32_t)w[0]; n_src = (int32_t)w[1]; n_dst = (int32_t)w[2]; n = (int32_t)w[3];
+    if (n_dst != n_src + 1) {
+        s3a_set_error("%s: #from-states(%d) != #to-states(%d)-1", tmatfile, n_src, n_dst);
+        goto done;
+    }
+    if ((int64_t)n != (int64_t)n_tmat * n_src * n_dst || nw != 4 + (size_t)n) {
+        s3a_set_error("%s: #float32s(%d) doesn't match dimensions: %d x %d x %d", tmatfile, n,
+                      n_tmat, n_src, n_dst);
+        goto done;
+    }
+    t = s3a_tmat_init_arrays((const float *)(w + 4), n_tmat, n_src, tpfloor, lm);
+done:
+    free(w);
+    return t;
+}
+
+void
+s3a_tmat_free(s3a_tmat_t *t)
+{
+    if (t) {
+        free(t->tp);
+        free(t);
+    }
+}
+
+int32_t s3a_tmat_n_tmat(const s3a_tmat_t *t) { return t->n_tmat; }
+int32_t s3a_tmat_n_state(const s3a_tmat_t *t) { return t->n_state; }
+
+int32_t
+s3a_tmat_get_tp(const s3a_tmat_t *t, int32_t *tp)
+{
+    memcpy(tp, t->tp, sizeof(int32_t) * (size_t)t->n_tmat * t->n_state * (t->n_state + 1));
+    return S3A_OK;
+}

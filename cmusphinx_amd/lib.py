@@ -1,0 +1,298 @@
+"""ctypes binding of libcmusphinx_amd.so (the C ABI in include/cmusphinx_amd.h).
+
+Mirrors the reference's interface names for this path (logmath_*, mgau_init,
+mgau_eval, approx_cont_mgau_*_eval, tmat_init, hmm_vit_eval ...) so the parity
+tests read like the reference's own unit tests.  Fails loudly when the library
+is not built: there is deliberately no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcmusphinx_amd.so")
+
+S3A_OK = 0
+LOGPROB_ZERO = -939524096
+GMM_EXACT, GMM_FAST = 0, 1
+MIX_INT_FLOAT_COMP = 2
+
+# every symbol include/cmusphinx_amd.h declares (checked by tests/test_abi.py)
+_SIGS = {
+    "s3a_last_error": (C.c_char_p, []),
+    "s3a_version": (C.c_char_p, []),
+    "s3a_device_count": (C.c_int32, []),
+    "s3a_set_device": (C.c_int32, [C.c_int32]),
+    "s3a_logmath_init": (C.c_void_p, [C.c_double, C.c_int32, C.c_int32]),
+    "s3a_logs3_init": (C.c_void_p, [C.c_double, C.c_int32, C.c_int32]),
+    "s3a_logmath_free": (None, [C.c_void_p]),
+    "s3a_logmath_add": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "s3a_logmath_log": (C.c_int32, [C.c_void_p, C.c_double]),
+    "s3a_logmath_exp": (C.c_double, [C.c_void_p, C.c_int32]),
+    "s3a_logmath_ln_to_log": (C.c_int32, [C.c_void_p, C.c_double]),
+    "s3a_logmath_log_to_ln": (C.c_double, [C.c_void_p, C.c_int32]),
+    "s3a_logmath_log10_to_log": (C.c_int32, [C.c_void_p, C.c_double]),
+    "s3a_logmath_get_base": (C.c_double, [C.c_void_p]),
+    "s3a_logmath_get_zero": (C.c_int32, [C.c_void_p]),
+    "s3a_logmath_get_table_shape": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_uint32)] * 3),
+    "s3a_logmath_copy_table": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "s3a_logs3": (C.c_int32, [C.c_void_p, C.c_double]),
+    "s3a_mgau_init": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_double,
+                                   C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]),
+    "s3a_mgau_init_arrays": (C.c_void_p, [C.c_void_p] * 3 + [C.c_int32] * 3 +
+                             [C.c_double, C.c_double, C.c_int32, C.c_void_p]),
+    "s3a_mgau_free": (None, [C.c_void_p]),
+    "s3a_mgau_n_mgau": (C.c_int32, [C.c_void_p]),
+    "s3a_mgau_max_comp": (C.c_int32, [C.c_void_p]),
+    "s3a_mgau_veclen": (C.c_int32, [C.c_void_p]),
+    "s3a_mgau_n_comp": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "s3a_mgau_distfloor": (C.c_double, [C.c_void_p]),
+    "s3a_mgau_get_params": (C.c_int32, [C.c_void_p] * 6),
+    "s3a_mgau_reset_state": (C.c_int32, [C.c_void_p]),
+    "s3a_mgau_get_state": (C.c_int32, [C.c_void_p] * 4),
+    "s3a_mgau_set_precision": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "s3a_mgau_eval": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "s3a_mgau_score_frames": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "s3a_mgau_score_frames_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
+    "s3a_scorer_init": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_double, C.c_float, C.c_int32]),
+    "s3a_scorer_free": (None, [C.c_void_p]),
+    "s3a_scorer_utt_begin": (C.c_int32, [C.c_void_p]),
+    "s3a_approx_cont_mgau_ci_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(C.c_int32), C.c_int32]),
+    "s3a_approx_cont_mgau_frame_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_int32, C.c_void_p,
+                                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                    C.POINTER(C.c_int32)]),
+    "s3a_comsen_init": (C.c_void_p, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3a_comsen_free": (None, [C.c_void_p]),
+    "s3a_dict2pid_comsenscr": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_tmat_init": (C.c_void_p, [C.c_char_p, C.c_double, C.c_int32, C.c_void_p]),
+    "s3a_tmat_init_arrays": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p]),
+    "s3a_tmat_free": (None, [C.c_void_p]),
+    "s3a_tmat_n_tmat": (C.c_int32, [C.c_void_p]),
+    "s3a_tmat_n_state": (C.c_int32, [C.c_void_p]),
+    "s3a_tmat_get_tp": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "s3a_hmm_batch_init": (C.c_void_p, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "s3a_hmm_batch_free": (None, [C.c_void_p]),
+    "s3a_hmm_batch_setup": (C.c_int32, [C.c_void_p] * 4),
+    "s3a_hmm_batch_clear": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_hmm_batch_enter": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "s3a_hmm_batch_vit_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3a_hmm_batch_get": (C.c_int32, [C.c_void_p] * 8),
+    "s3a_bench_score_frames": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_int32, C.c_int32, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "s3a_dev_malloc": (C.c_void_p, [C.c_size_t]),
+    "s3a_dev_free": (C.c_int32, [C.c_void_p]),
+    "s3a_dev_upload": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "s3a_dev_download": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "s3a_dev_sync": (C.c_int32, []),
+}
+
+_L = None
+MISSING: list = []
+
+
+class S3AError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libcmusphinx_amd.so and type every entry point.  No fallback."""
+    global _L
+    if _L is not None:
+        return _L
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C cmusphinx_amd/csrc`); cmusphinx_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            MISSING.append(name)    # tests/test_abi.py fails on any entry here
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    _L = L
+    return L
+
+
+def _err(L):
+    m = L.s3a_last_error()
+    return m.decode() if m else ""
+
+
+def check(rc, L=None):
+    if rc != S3A_OK:
+        L = L or load()
+        raise S3AError(f"libcmusphinx_amd error {rc}: {_err(L)}")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    return int(load().s3a_device_count())
+
+
+class LogMath:
+    """logmath_t (sphinxbase logmath.h) / logs3_init."""
+
+    def __init__(self, base=1.0003, shift=0, use_table=1):
+        self.L = load()
+        self.h = self.L.s3a_logmath_init(base, shift, use_table)
+        if not self.h:
+            raise S3AError(_err(self.L))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_logmath_free(self.h)
+            self.h = None
+
+    def add(self, x, y): return self.L.s3a_logmath_add(self.h, int(x), int(y))
+    def log(self, p): return self.L.s3a_logmath_log(self.h, float(p))
+    def exp(self, v): return self.L.s3a_logmath_exp(self.h, int(v))
+    def logs3(self, p): return self.L.s3a_logs3(self.h, float(p))
+    def ln_to_log(self, v): return self.L.s3a_logmath_ln_to_log(self.h, float(v))
+    def log_to_ln(self, v): return self.L.s3a_logmath_log_to_ln(self.h, int(v))
+    def log10_to_log(self, v): return self.L.s3a_logmath_log10_to_log(self.h, float(v))
+
+    @property
+    def zero(self): return self.L.s3a_logmath_get_zero(self.h)
+
+    @property
+    def base(self): return self.L.s3a_logmath_get_base(self.h)
+
+    def table_shape(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(self.L.s3a_logmath_get_table_shape(self.h, C.byref(a), C.byref(b), C.byref(c)), self.L)
+        return a.value, b.value, c.value
+
+    @property
+    def table(self):
+        n = self.table_shape()[0]
+        out = np.zeros(n, np.uint32)
+        check(self.L.s3a_logmath_copy_table(self.h, _p(out), n), self.L)
+        return out
+
+
+class DevBuf:
+    """A raw HIP allocation owned by the library's runtime (no torch needed)."""
+
+    def __init__(self, nbytes):
+        self.L = load()
+        self.nbytes = int(nbytes)
+        self.ptr = self.L.s3a_dev_malloc(self.nbytes)
+        if not self.ptr:
+            raise S3AError(_err(self.L))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(self.L.s3a_dev_upload(self.ptr, _p(arr), arr.nbytes), self.L)
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(self.L.s3a_dev_download(_p(out), self.ptr, out.nbytes), self.L)
+        return out
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self.L.s3a_dev_free(self.ptr)
+            self.ptr = None
+
+
+class MgauModel:
+    """mgau_model_t (cont_mgau.h) living on the GPU."""
+
+    def __init__(self, h, lm):
+        self.L = load()
+        self.h = h
+        self.lm = lm            # keep the logmath alive: the model borrows it
+        self.S = self.L.s3a_mgau_n_mgau(h)
+        self.C = self.L.s3a_mgau_max_comp(h)
+        self.D = self.L.s3a_mgau_veclen(h)
+
+    @classmethod
+    def init(cls, meanfile, varfile, mixwfile, lm: LogMath, varfloor=1e-4, mixwfloor=1e-7,
+             precomp=1, senmgau=".cont.", comp_type=MIX_INT_FLOAT_COMP):
+        L = load()
+        h = L.s3a_mgau_init(meanfile.encode(), varfile.encode(), varfloor, mixwfile.encode(),
+                            mixwfloor, precomp, senmgau.encode(), comp_type, lm.h)
+        if not h:
+            raise S3AError(_err(L))
+        return cls(h, lm)
+
+    @classmethod
+    def init_arrays(cls, mean, var, mixw, lm: LogMath, varfloor=1e-4, mixwfloor=1e-7, precomp=1):
+        L = load()
+        mean = np.ascontiguousarray(mean, np.float32)
+        var = np.ascontiguousarray(var, np.float32)
+        S, Cn, D = mean.shape
+        mixw = np.ascontiguousarray(mixw, np.float32).reshape(S, Cn)
+        h = L.s3a_mgau_init_arrays(_p(mean), _p(var), _p(mixw), S, Cn, D, varfloor, mixwfloor,
+                                   precomp, lm.h)
+        if not h:
+            raise S3AError(_err(L))
+        return cls(h, lm)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_mgau_free(self.h)
+            self.h = None
+
+    def params(self):
+        S, Cn, D = self.S, self.C, self.D
+        mean = np.zeros((S, Cn, D), np.float32)
+        prec = np.zeros((S, Cn, D), np.float32)
+        lrd = np.zeros((S, Cn), np.float32)
+        mixw = np.zeros((S, Cn), np.int32)
+        n_comp = np.zeros(S, np.int32)
+        check(self.L.s3a_mgau_get_params(self.h, _p(mean), _p(prec), _p(lrd), _p(mixw), _p(n_comp)))
+        return dict(mean=mean, prec=prec, lrd=lrd, mixw=mixw, n_comp=n_comp,
+                    distfloor=self.L.s3a_mgau_distfloor(self.h))
+
+    def set_precision(self, mode):
+        check(self.L.s3a_mgau_set_precision(self.h, mode))
+
+    def reset_state(self):
+        check(self.L.s3a_mgau_reset_state(self.h))
+
+    def state(self):
+        b = np.zeros(self.S, np.int32); s = np.zeros(self.S, np.int32); u = np.zeros(self.S, np.int32)
+        check(self.L.s3a_mgau_get_state(self.h, _p(b), _p(s), _p(u)))
+        return b, s, u
+
+    def eval(self, m, x, fr=0, update=1, active=None):
+        """mgau_eval(g, m, active, x, fr, update)."""
+        x = np.ascontiguousarray(x, np.float32)
+        act = None
+        if active is not None:
+            act = np.ascontiguousarray(list(active) + [-1], np.int32)
+        return self.L.s3a_mgau_eval(self.h, int(m), _p(act), _p(x), int(fr), int(update))
+
+    def score_frames(self, feat, want_best=True):
+        feat = np.ascontiguousarray(feat, np.float32)
+        T = feat.shape[0]
+        out = np.empty((T, self.S), np.int32)
+        best = np.empty(T, np.int32) if want_best else None
+        check(self.L.s3a_mgau_score_frames(self.h, _p(feat), T, _p(out), _p(best)))
+        return (out, best) if want_best else out
+
+    def bench(self, feat_dev: DevBuf, n_frames, scr_dev: DevBuf, best_dev, frames_per_launch, iters):
+        us, kus, nl = C.c_double(), C.c_double(), C.c_int32()
+        check(self.L.s3a_bench_score_frames(self.h, feat_dev.ptr, n_frames, scr_dev.ptr,
+                                            best_dev.ptr if best_dev else None,
+                                            frames_per_launch, iters, C.byref(us), C.byref(kus),
+                                            C.byref(nl)))
+        return us.value, kus.value, nl.value

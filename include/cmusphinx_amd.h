@@ -1,0 +1,292 @@
+/*
+ * cmusphinx_amd.h -- C ABI of the MI355X-native acoustic-scoring / Viterbi
+ * backend for CMU Sphinx-3 (libcmusphinx_amd.so).
+ *
+ * Plain C: opaque handles, plain pointers and sizes, int status codes.  No
+ * torch / HIP types cross this boundary (streams are passed as void *).
+ * Each entry point names the reference interface it replaces; paths are
+ * relative to the reference root (cjac/cmusphinx).  INTEGRATION.md shows the
+ * srch_funcs_t shim a sphinx3 maintainer adds on top of this header.
+ *
+ * Conventions
+ *   - "host" pointers are ordinary process memory, "dev" pointers are HIP
+ *     device memory of the current device.  Functions without a _dev suffix
+ *     take and return host memory and synchronise before returning.
+ *   - int32 scores are logs3 values (integer log-probabilities in base
+ *     -logbase, default 1.0003), exactly the reference's.
+ *   - status: S3A_OK (0) or a negative S3A_E* code; handle constructors
+ *     return NULL on failure; s3a_last_error() gives the message.  Where the
+ *     reference would E_FATAL (abort) on a malformed model file, this library
+ *     fails the call instead of killing the host process.
+ *   - thread-safety: as the reference (sphinx3/include/srch.h, one kb_t per
+ *     thread): a handle must not be used from two threads at once.
+ *   - there is NO CPU fallback: every scoring / Viterbi entry point runs HIP
+ *     kernels and returns S3A_ENODEV when no gfx950 device is usable.
+ */
+#ifndef CMUSPHINX_AMD_H
+#define CMUSPHINX_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3A_OK        0
+#define S3A_EINVAL   (-1)   /* bad argument */
+#define S3A_EIO      (-2)   /* file missing / malformed / checksum error */
+#define S3A_ENOMEM   (-3)
+#define S3A_ENODEV   (-4)   /* no usable HIP device */
+#define S3A_EHIP     (-5)   /* HIP runtime error (see s3a_last_error) */
+#define S3A_EUNSUP   (-6)   /* model shape outside what the kernels support */
+
+/* sphinx3/include/s3types.h:192 ; sphinxbase prim_type.h:153 */
+#define S3A_LOGPROB_ZERO  ((int32_t)0xc8000000)
+#define S3A_MAX_NEG_INT32 ((int32_t)0x80000000)
+/* sphinx3/include/cont_mgau.h:121-123 */
+#define S3A_NO_BSTIDX   (-1)
+#define S3A_NOT_UPDATED (-100)
+/* sphinx3/include/cont_mgau.h:127-133 */
+#define S3A_FULL_INT_COMP      0
+#define S3A_FULL_FLOAT_COMP    1
+#define S3A_MIX_INT_FLOAT_COMP 2
+
+const char *s3a_last_error(void);
+const char *s3a_version(void);
+/* number of usable gfx950 devices (0 when none / no driver); never fails */
+int32_t s3a_device_count(void);
+/* select the device this thread's subsequent calls use (hipSetDevice) */
+int32_t s3a_set_device(int32_t ordinal);
+
+/* ===================================================================== */
+/* integer log-domain arithmetic                                          */
+/* replaces sphinxbase logmath_t: sphinxbase/include/sphinxbase/logmath.h */
+/*   logmath_init  logmath.c:61-161   logmath_add   logmath.c:391-436     */
+/*   logmath_log   logmath.c:445-452  log_to_ln / ln_to_log  :466-477     */
+/*   logs3_init / logs3  sphinx3/src/libs3decoder/libcommon/logs3.c:101-119 */
+/* ===================================================================== */
+typedef struct s3a_logmath_s s3a_logmath_t;
+
+s3a_logmath_t *s3a_logmath_init(double base, int32_t shift, int32_t use_table);
+s3a_logmath_t *s3a_logs3_init(double base, int32_t breport, int32_t blogtable);
+void    s3a_logmath_free(s3a_logmath_t *lm);
+int32_t s3a_logmath_add(const s3a_logmath_t *lm, int32_t logb_x, int32_t logb_y);
+int32_t s3a_logmath_log(const s3a_logmath_t *lm, double p);
+double  s3a_logmath_exp(const s3a_logmath_t *lm, int32_t logb_p);
+int32_t s3a_logmath_ln_to_log(const s3a_logmath_t *lm, double log_p);
+double  s3a_logmath_log_to_ln(const s3a_logmath_t *lm, int32_t logb_p);
+int32_t s3a_logmath_log10_to_log(const s3a_logmath_t *lm, double log_p);
+double  s3a_logmath_get_base(const s3a_logmath_t *lm);
+int32_t s3a_logmath_get_zero(const s3a_logmath_t *lm);
+/* logmath_get_table_shape, logmath.c:357-369 */
+int32_t s3a_logmath_get_table_shape(const s3a_logmath_t *lm, uint32_t *out_size,
+                                    uint32_t *out_width, uint32_t *out_shift);
+/* copy the add-table, widened to uint32, into out[size] */
+int32_t s3a_logmath_copy_table(const s3a_logmath_t *lm, uint32_t *out, uint32_t size);
+int32_t s3a_logs3(const s3a_logmath_t *lm, double p);
+
+/* ===================================================================== */
+/* continuous-density mixture-Gaussian model                              */
+/* replaces mgau_model_t: sphinx3/include/cont_mgau.h:170-226             */
+/* ===================================================================== */
+typedef struct s3a_mgau_model_s s3a_mgau_model_t;
+
+/*
+ * mgau_init (sphinx3/src/libs3decoder/libam/cont_mgau.c:901-956), same
+ * argument list: reads the S3 means / variances / mixture_weights files,
+ * removes uninitialised components, floors variances, precomputes
+ * 1/(2 sigma^2) and the log-reciprocal-determinant terms, converts mixture
+ * weights to logs3 -- in the reference's order and precision -- then packs the
+ * model into its device layout and uploads it.  Only senmgau ".cont." and
+ * comp_type S3A_MIX_INT_FLOAT_COMP are supported (the hot path of SURVEY.md
+ * section 8); diagonal covariances only.
+ */
+s3a_mgau_model_t *s3a_mgau_init(const char *meanfile, const char *varfile, double varfloor,
+                                const char *mixwfile, double mixwfloor, int32_t precomp,
+                                const char *senmgau, int32_t comp_type,
+                                s3a_logmath_t *logmath);
+/* the same from raw file-domain arrays mean/var [n_mgau][n_density][veclen],
+ * mixw [n_mgau][n_density] (what mgau_file_read / mgau_mixw_read hand on) */
+s3a_mgau_model_t *s3a_mgau_init_arrays(const float *mean, const float *var, const float *mixw,
+                                       int32_t n_mgau, int32_t n_density, int32_t veclen,
+                                       double varfloor, double mixwfloor, int32_t precomp,
+                                       s3a_logmath_t *logmath);
+void    s3a_mgau_free(s3a_mgau_model_t *g);                 /* mgau_free, cont_mgau.c:1210 */
+int32_t s3a_mgau_n_mgau(const s3a_mgau_model_t *g);         /* mgau_n_mgau   cont_mgau.h:229 */
+int32_t s3a_mgau_max_comp(const s3a_mgau_model_t *g);       /* mgau_max_comp cont_mgau.h:230 */
+int32_t s3a_mgau_veclen(const s3a_mgau_model_t *g);         /* mgau_veclen   cont_mgau.h:231 */
+int32_t s3a_mgau_n_comp(const s3a_mgau_model_t *g, int32_t m); /* mgau_n_comp cont_mgau.h:232 */
+double  s3a_mgau_distfloor(const s3a_mgau_model_t *g);
+/* host copies of the precomputed parameters, AoS as in the reference
+ * (mgau_mean/mgau_var/mgau_lrd/mgau_mixw, cont_mgau.h:233-238); any out
+ * pointer may be NULL.  mean/prec: [n_mgau][max_comp][veclen], lrd/mixw:
+ * [n_mgau][max_comp]; entries at c >= n_comp[m] are unspecified. */
+int32_t s3a_mgau_get_params(const s3a_mgau_model_t *g, float *mean, float *prec,
+                            float *lrd, int32_t *mixw, int32_t *n_comp);
+/* per-senone mutable state (mgau_t.bstidx/bstscr/updatetime, cont_mgau.h:174-176):
+ * reset as srch_TST_begin does (srch_time_switch_tree.c:485-490), read back for tests */
+int32_t s3a_mgau_reset_state(s3a_mgau_model_t *g);
+int32_t s3a_mgau_get_state(const s3a_mgau_model_t *g, int32_t *bstidx, int32_t *bstscr,
+                           int32_t *updatetime);
+
+/* arithmetic of the Gaussian kernel */
+#define S3A_GMM_EXACT 0   /* f32 subtract, f64 multiply/accumulate, no FMA: bit-identical to mgau_eval */
+#define S3A_GMM_FAST  1   /* f32 FMA accumulation: within +-S3A_GMM_FAST_TOL logs3 units */
+int32_t s3a_mgau_set_precision(s3a_mgau_model_t *g, int32_t mode);
+
+/*
+ * mgau_eval (cont_mgau.c:1174-1205; declared cont_mgau.h:317-325): score ONE
+ * senone m at ONE vector x (host, veclen floats), optionally restricted to the
+ * -1-terminated component list active_comp, updating the senone's
+ * bstidx/bstscr/updatetime when update_best_id.  Runs on the device; meant for
+ * drop-in completeness and parity tests, not throughput.
+ */
+int32_t s3a_mgau_eval(s3a_mgau_model_t *g, int32_t m, const int32_t *active_comp,
+                      const float *x, int32_t fr, int32_t update_best_id);
+
+/*
+ * Whole-block senone scoring: senscr[t][s] = mgau_eval(g, s, NULL, feat[t], t, 1)
+ * for t < n_frames, s < n_mgau -- the un-normalised all-senones pass that
+ * utt_decode's frame loop performs one frame at a time
+ * (srch.c:746-751 -> gmm_wrap.c:108-167 with every senone active and the CI
+ * beam open).  feat: [n_frames][veclen] float32.  best (optional): per-frame
+ * maximum, i.e. the value approx_cont_mgau_frame_eval returns / srch->senscale.
+ */
+int32_t s3a_mgau_score_frames(s3a_mgau_model_t *g, const float *feat, int32_t n_frames,
+                              int32_t *senscr, int32_t *best);
+/* device-resident variant: nothing leaves HBM; asynchronous on `stream`
+ * (a hipStream_t passed as void *, NULL = default stream) */
+int32_t s3a_mgau_score_frames_dev(s3a_mgau_model_t *g, const float *feat_dev, int32_t n_frames,
+                                  int32_t *senscr_dev, int32_t *best_dev, void *stream);
+
+/* ===================================================================== */
+/* per-frame scoring driver with CI gating                                */
+/* replaces fast_gmm_t (sphinx3/include/fast_algo_struct.h:200-262) +     */
+/* approx_cont_mgau_{ci,frame}_eval (approx_cont_mgau.c:367-616) + the    */
+/* ascr_t buffers they fill (sphinx3/include/ascr.h:99-116)               */
+/* ===================================================================== */
+typedef struct s3a_scorer_s s3a_scorer_t;
+
+/*
+ * Bundles what gmm_wrap.c:108-211 pulls out of srch_t/kbcore_t: the model,
+ * mdef's cd2cisen map (mdef.h:206-208; n_sen entries, the first n_ci_sen are
+ * identity) and the fast_gmm_init parameters
+ * (fast_algo_struct.c:419-461: -ds, -cond_ds, -ci_pbeam (as a probability),
+ * -tighten_factor, -maxcdsenpf).  Gaussian selection / sub-VQ are not
+ * supported: the GPU evaluates every component.
+ */
+s3a_scorer_t *s3a_scorer_init(s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen,
+                              int32_t n_ci_sen, int32_t ds_ratio, int32_t cond_ds,
+                              double ci_pbeam, float tighten_factor, int32_t max_cd);
+void    s3a_scorer_free(s3a_scorer_t *sc);
+/* srch_TST_begin's per-utterance reset of bstidx/updatetime */
+int32_t s3a_scorer_utt_begin(s3a_scorer_t *sc);
+/*
+ * gmm_compute_lv1 slot == approx_ci_gmm_compute (gmm_wrap.c:170-211) ->
+ * approx_cont_mgau_ci_eval: score the CI senones of `feat` for frame `fr`
+ * into ci_senscr[n_ci_sen] (ascr->cache_ci_senscr[cache_idx]) and *best_score
+ * (ascr->cache_best_list[cache_idx]).
+ */
+int32_t s3a_approx_cont_mgau_ci_eval(s3a_scorer_t *sc, const float *feat, int32_t *ci_senscr,
+                                     int32_t *best_score, int32_t fr);
+/*
+ * gmm_compute_lv2 slot == s3_cd_gmm_compute_sen (gmm_wrap.c:108-167) ->
+ * approx_cont_mgau_frame_eval: sen_active[n_sen] in (CI entries are forced
+ * to 1, as the reference does), senscr[n_sen] out (normalised by the frame
+ * best for active senones), rec_sen_active[n_sen] out.  Returns the frame best
+ * through *best (srch->senscale); *n_sen_eval / *n_gau_eval are
+ * mgau_frm_sen_eval / mgau_frm_gau_eval for stat_t (may be NULL).
+ */
+int32_t s3a_approx_cont_mgau_frame_eval(s3a_scorer_t *sc, uint8_t *sen_active,
+                                        uint8_t *rec_sen_active, int32_t *senscr,
+                                        const float *feat, int32_t frame,
+                                        const int32_t *cache_ci_senscr, int32_t *best,
+                                        int32_t *n_sen_eval, int32_t *n_gau_eval);
+
+/*
+ * dict2pid_comsenscr (sphinx3/src/libs3decoder/libsearch/dict2pid.c:1029-1048):
+ * comsenscr[i] = max_{k in comstate[i]} senscr[k] + comwt[i].  The ragged
+ * -1-terminated lists d2p->comstate[i] are passed flattened:
+ * comstate[comstate_off[i] .. comstate_off[i+1]).
+ */
+typedef struct s3a_comsen_s s3a_comsen_t;
+s3a_comsen_t *s3a_comsen_init(int32_t n_comstate, const int32_t *comstate_off,
+                              const int16_t *comstate, const int32_t *comwt);
+void    s3a_comsen_free(s3a_comsen_t *cs);
+int32_t s3a_dict2pid_comsenscr(s3a_comsen_t *cs, const int32_t *senscr, int32_t n_sen,
+                               int32_t *comsenscr);
+
+/* ===================================================================== */
+/* transition matrices + batched HMM Viterbi                              */
+/* replaces tmat_t (sphinx3/include/tmat.h), hmm_context_t / hmm_t        */
+/* (sphinx3/include/hmm.h:156-197) and hmm_vit_eval (libam/hmm.c:855-873) */
+/* ===================================================================== */
+typedef struct s3a_tmat_s s3a_tmat_t;
+/* tmat_init, libam/tmat.c:155-270 (reads, normalises, floors, converts to logs3) */
+s3a_tmat_t *s3a_tmat_init(const char *tmatfile, double tpfloor, int32_t breport,
+                          s3a_logmath_t *logmath);
+s3a_tmat_t *s3a_tmat_init_arrays(const float *tp, int32_t n_tmat, int32_t n_state,
+                                 double tpfloor, s3a_logmath_t *logmath);
+void    s3a_tmat_free(s3a_tmat_t *t);
+int32_t s3a_tmat_n_tmat(const s3a_tmat_t *t);
+int32_t s3a_tmat_n_state(const s3a_tmat_t *t);
+/* copy tp[n_tmat][n_state][n_state+1] logs3 values */
+int32_t s3a_tmat_get_tp(const s3a_tmat_t *t, int32_t *tp);
+
+/*
+ * A batch of N HMMs in structure-of-arrays form (the device-side replacement
+ * of an array of hmm_t).  Scores/histories per state, exit state, ssid (or
+ * per-state ssids for multiplex HMMs), tmatid, bestscore.
+ */
+typedef struct s3a_hmm_batch_s s3a_hmm_batch_t;
+/* hmm_context_init (hmm.c:102-121): n_emit_state 3 or 5 run the hard-wired
+ * left-to-right updates (hmm.c:285-776), other sizes the any-topology one
+ * (hmm.c:779-852).  sseq: [n_sseq][n_emit_state] senone ids (mdef->sseq). */
+s3a_hmm_batch_t *s3a_hmm_batch_init(int32_t n_hmm, int32_t n_emit_state, const s3a_tmat_t *tmat,
+                                    const int16_t *sseq, int32_t n_sseq, int32_t n_sen);
+void    s3a_hmm_batch_free(s3a_hmm_batch_t *b);
+/* hmm_init (hmm.c:130-147) for every HMM i: mpx[i], ssid[i], tmatid[i]; clears all */
+int32_t s3a_hmm_batch_setup(s3a_hmm_batch_t *b, const uint8_t *mpx, const int32_t *ssid,
+                            const int32_t *tmatid);
+/* hmm_clear (hmm.c:225-241) on the listed HMMs (idx NULL = all) */
+int32_t s3a_hmm_batch_clear(s3a_hmm_batch_t *b, const int32_t *idx, int32_t n);
+/* hmm_enter (hmm.c:244-250) on the listed HMMs */
+int32_t s3a_hmm_batch_enter(s3a_hmm_batch_t *b, const int32_t *idx, const int32_t *score,
+                            const int64_t *histid, int32_t n, int32_t frame);
+/* hmm_vit_eval (hmm.c:855-873) on every HMM of the batch against senscr[n_sen]
+ * (host); ret[n_hmm] (optional) receives each HMM's return value (bestscore). */
+int32_t s3a_hmm_batch_vit_eval(s3a_hmm_batch_t *b, const int32_t *senscr, int32_t *ret);
+/* read back: score[n][5] hist[n][5] out_score[n] out_hist[n] bestscore[n]
+ * mpx_ssid[n][5] frame[n]; any pointer may be NULL */
+int32_t s3a_hmm_batch_get(const s3a_hmm_batch_t *b, int32_t *score, int64_t *hist,
+                          int32_t *out_score, int64_t *out_hist, int32_t *bestscore,
+                          int32_t *mpx_ssid, int32_t *frame);
+
+/* ===================================================================== */
+/* measurement hooks used by bench.py (HIP events on the launch stream)   */
+/* ===================================================================== */
+/*
+ * Run s3a_mgau_score_frames_dev `iters` times back to back on an internal
+ * stream and return the average kernel-region time per iteration in
+ * microseconds, measured with hipEvent pairs on that stream (not torch's).
+ * frames_per_launch: 0 = one launch for the whole block (utterance mode),
+ * k > 0 = frame-synchronous mode, ceil(n_frames/k) launches of k frames.
+ */
+int32_t s3a_bench_score_frames(s3a_mgau_model_t *g, const float *feat_dev, int32_t n_frames,
+                               int32_t *senscr_dev, int32_t *best_dev, int32_t frames_per_launch,
+                               int32_t iters, double *avg_us, double *avg_kernel_us,
+                               int32_t *n_launches);
+
+/* raw device-memory helpers so a C host (or ctypes) can stage buffers
+ * without linking the HIP runtime itself */
+void   *s3a_dev_malloc(size_t nbytes);
+int32_t s3a_dev_free(void *p);
+int32_t s3a_dev_upload(void *dst_dev, const void *src_host, size_t nbytes);
+int32_t s3a_dev_download(void *dst_host, const void *src_dev, size_t nbytes);
+int32_t s3a_dev_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMUSPHINX_AMD_H */

@@ -1,0 +1,388 @@
+/*
+ * oracle/ref_dump.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A driver of OUR authorship that links the UNMODIFIED reference
+ * (oracle/_ref/libs3ref.so, built from /root/reference by oracle/Makefile) and
+ * calls the reference's own entry points for the hot path, dumping raw arrays
+ * that tests/golden/make_golden.py packs into committed fixtures and that the
+ * not-gpu tests diff against the oracle restatement (oracle/s3o_*.c).
+ *
+ * Every array goes to  OUTDIR/<name>.<dtype>.<d0>[x<d1>...].bin  (little endian).
+ *
+ * Sub-commands:
+ *   logmath BASE SHIFT OUTDIR
+ *   mgau    MEAN VAR MIXW VARFLOOR MIXWFLOOR LOGBASE FEAT.f32 T OUTDIR
+ *   frame   CD2CISEN.i16 NCISEN MEAN VAR MIXW LOGBASE FEAT.f32 T ACTIVE.u8|all
+ *           CIPBEAM DS TIGHTEN MAXCD OUTDIR
+ *   tmat    TMATFILE TPFLOOR LOGBASE SHIFT OUTDIR
+ *   feat    MFCFILE OUTDIR          (1s_c_d_dd, -cmn current, -agc none, -varnorm no)
+ *   hmm     NEMIT TP.i32 NTMAT SSEQ.i16 NSSEQ SENSCR.i32 NSEN T SPEC.i32 NHMM ENTER.i32 OUTDIR
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <math.h>
+
+#include <sphinxbase/ckd_alloc.h>
+#include <sphinxbase/logmath.h>
+#include <sphinxbase/err.h>
+#include "s3types.h"
+#include "logs3.h"
+#include "cont_mgau.h"
+#include "approx_cont_mgau.h"
+#include "fast_algo_struct.h"
+#include "ascr.h"
+#include "mdef.h"
+#include "tmat.h"
+#include "hmm.h"
+#include <sphinxbase/feat.h>
+#include <sphinxbase/cmn.h>
+#include <sphinxbase/agc.h>
+
+static void
+dump(const char *outdir, const char *name, const char *dtype, const void *p,
+     size_t elsz, int nd, ...)
+{
+    char path[4096], dims[256] = "";
+    size_t n = 1;
+    va_list ap;
+    FILE *fp;
+    int i;
+
+    va_start(ap, nd);
+    for (i = 0; i < nd; i++) {
+        long d = va_arg(ap, long);
+        char t[32];
+        snprintf(t, sizeof t, i ? "x%ld" : "%ld", d);
+        strcat(dims, t);
+        n *= (size_t)d;
+    }
+    va_end(ap);
+    snprintf(path, sizeof path, "%s/%s.%s.%s.bin", outdir, name, dtype, dims);
+    if ((fp = fopen(path, "wb")) == NULL) { perror(path); exit(2); }
+    if (n && fwrite(p, elsz, n, fp) != n) { perror("fwrite"); exit(2); }
+    fclose(fp);
+}
+
+static void *
+slurp(const char *path, size_t *nbytes)
+{
+    FILE *fp = fopen(path, "rb");
+    long sz;
+    void *buf;
+    if (!fp) { perror(path); exit(2); }
+    fseek(fp, 0, SEEK_END);
+    sz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    buf = malloc(sz ? sz : 1);
+    if (sz && fread(buf, 1, sz, fp) != (size_t)sz) { perror("fread"); exit(2); }
+    fclose(fp);
+    if (nbytes) *nbytes = sz;
+    return buf;
+}
+
+static int
+cmd_logmath(int argc, char **argv)
+{
+    double base = atof(argv[0]);
+    int shift = atoi(argv[1]);
+    const char *out = argv[2];
+    logmath_t *lm = logmath_init(base, shift, 1);
+    uint32 size, width, sh, i;
+    int32 *tab, ka[16];
+    double kd[4];
+
+    logmath_get_table_shape(lm, &size, &width, &sh);
+    tab = malloc(sizeof(int32) * size);
+    /* recover the table through the public API: add(0, -d) == table[d] */
+    for (i = 0; i < size; i++)
+        tab[i] = logmath_add(lm, 0, -(int32)i);
+    dump(out, "table", "i32", tab, 4, 1, (long)size);
+    ka[0] = size; ka[1] = width; ka[2] = sh;
+    ka[3] = logmath_get_zero(lm);
+    ka[4] = logmath_log(lm, 1e-150);
+    ka[5] = logmath_log(lm, 42.0);
+    ka[6] = logmath_log(lm, 1e-48);
+    ka[7] = logmath_add(lm, logmath_log(lm, 1e-48), logmath_log(lm, 5e-48));
+    ka[8] = logmath_add(lm, logmath_log(lm, 1e-48), logmath_log(lm, 42.0));
+    ka[9] = logmath_log10_to_log(lm, -7.0);
+    ka[10] = logmath_ln_to_log(lm, -123.456);
+    ka[11] = logs3(lm, 1e-80);
+    ka[12] = logs3(lm, 0.5);
+    ka[13] = logmath_add(lm, S3_LOGPROB_ZERO, -12345);
+    ka[14] = logmath_add(lm, -12345, S3_LOGPROB_ZERO);
+    ka[15] = logmath_add(lm, -100, -100 - (int32)size);
+    dump(out, "known", "i32", ka, 4, 1, 16L);
+    kd[0] = logmath_log_to_ln(lm, S3_LOGPROB_ZERO);
+    kd[1] = logmath_exp(lm, -5000);
+    kd[2] = logmath_log_to_ln(lm, -79150);
+    kd[3] = logmath_get_base(lm);
+    dump(out, "knownf", "f64", kd, 8, 1, 4L);
+    return 0;
+}
+
+static mgau_model_t *
+load_mgau(const char *mean, const char *var, const char *mixw, double varfloor,
+          double mixwfloor, logmath_t *lm)
+{
+    return mgau_init(mean, var, varfloor, mixw, mixwfloor, 1, ".cont.",
+                     MIX_INT_FLOAT_COMP, lm);
+}
+
+static void
+dump_model(const char *out, mgau_model_t *g)
+{
+    int32 S = g->n_mgau, C = g->max_comp, D = g->veclen, m, c;
+    float *mean = calloc((size_t)S * C * D, 4), *var = calloc((size_t)S * C * D, 4);
+    float *lrd = calloc((size_t)S * C, 4);
+    int32 *mixw = calloc((size_t)S * C, 4), *ncomp = calloc(S, 4);
+    for (m = 0; m < S; m++) {
+        ncomp[m] = g->mgau[m].n_comp;
+        for (c = 0; c < g->mgau[m].n_comp; c++) {
+            memcpy(mean + ((size_t)m * C + c) * D, g->mgau[m].mean[c], 4 * D);
+            memcpy(var + ((size_t)m * C + c) * D, g->mgau[m].var[c], 4 * D);
+            lrd[m * C + c] = g->mgau[m].lrd[c];
+            mixw[m * C + c] = g->mgau[m].mixw[c];
+        }
+    }
+    dump(out, "n_comp", "i32", ncomp, 4, 1, (long)S);
+    dump(out, "mean", "f32", mean, 4, 3, (long)S, (long)C, (long)D);
+    dump(out, "prec", "f32", var, 4, 3, (long)S, (long)C, (long)D);
+    dump(out, "lrd", "f32", lrd, 4, 2, (long)S, (long)C);
+    dump(out, "mixw", "i32", mixw, 4, 2, (long)S, (long)C);
+    dump(out, "distfloor", "f64", &g->distfloor, 8, 1, 1L);
+    free(mean); free(var); free(lrd); free(mixw); free(ncomp);
+}
+
+static int
+cmd_mgau(int argc, char **argv)
+{
+    logmath_t *lm = logs3_init(atof(argv[5]), 0, 1);
+    mgau_model_t *g = load_mgau(argv[0], argv[1], argv[2], atof(argv[3]), atof(argv[4]), lm);
+    size_t nb;
+    float *feat = slurp(argv[6], &nb);
+    int32 T = atoi(argv[7]), S = g->n_mgau, D = g->veclen, t, s;
+    const char *out = argv[8];
+    int32 *scr = malloc(sizeof(int32) * (size_t)T * S);
+    int32 *bidx = malloc(sizeof(int32) * (size_t)T * S);
+    int32 *bscr = malloc(sizeof(int32) * (size_t)T * S);
+
+    if (nb != (size_t)T * D * 4) { fprintf(stderr, "feat size mismatch\n"); return 2; }
+    dump_model(out, g);
+    for (t = 0; t < T; t++)
+        for (s = 0; s < S; s++) {
+            scr[(size_t)t * S + s] = mgau_eval(g, s, NULL, feat + (size_t)t * D, t, 1);
+            bidx[(size_t)t * S + s] = g->mgau[s].bstidx;
+            bscr[(size_t)t * S + s] = g->mgau[s].bstscr;
+        }
+    dump(out, "score", "i32", scr, 4, 2, (long)T, (long)S);
+    dump(out, "bstidx", "i32", bidx, 4, 2, (long)T, (long)S);
+    dump(out, "bstscr", "i32", bscr, 4, 2, (long)T, (long)S);
+    return 0;
+}
+
+static int
+cmd_frame(int argc, char **argv)
+{
+    size_t nb;
+    s3senid_t *cd2cisen = slurp(argv[0], &nb);
+    int32 S = (int32)(nb / sizeof(s3senid_t));
+    int32 n_ci_sen = atoi(argv[1]);
+    logmath_t *lm = logs3_init(atof(argv[5]), 0, 1);
+    mgau_model_t *g = load_mgau(argv[2], argv[3], argv[4], 0.0001, 0.0000001, lm);
+    float *feat = slurp(argv[6], &nb);
+    int32 T = atoi(argv[7]), D = g->veclen, t, s;
+    uint8 *active_in = strcmp(argv[8], "all") ? slurp(argv[8], NULL) : NULL;
+    double cipbeam = atof(argv[9]);
+    int32 ds = atoi(argv[10]);
+    float tighten = (float)atof(argv[11]);
+    int32 maxcd = atoi(argv[12]);
+    const char *out = argv[13];
+    fast_gmm_t *fg = fast_gmm_init(ds, 0, 0, 1, 0, 3.2e-5 /* unused */, cipbeam, tighten,
+                                   maxcd, n_ci_sen, lm);
+    ascr_t *a = ascr_init(S, 0, 1, 0, 1, n_ci_sen);
+    mdef_t md;          /* only the fields approx_cont_mgau_* read are filled */
+    ptmr_t tm;
+    int32 *senscr = malloc(sizeof(int32) * (size_t)T * S);
+    int32 *bidx = malloc(sizeof(int32) * (size_t)T * S);
+    int32 *upd = malloc(sizeof(int32) * (size_t)T * S);
+    uint8 *act = malloc((size_t)T * S);
+    int32 *best = malloc(sizeof(int32) * T), *cibest = malloc(sizeof(int32) * T);
+    int32 *cnt = malloc(sizeof(int32) * 4 * T);
+    int32 *ciscr = malloc(sizeof(int32) * (size_t)T * (n_ci_sen > 0 ? n_ci_sen : 1));
+
+    if (S != g->n_mgau) { fprintf(stderr, "cd2cisen size mismatch\n"); return 2; }
+    memset(&md, 0, sizeof md);
+    md.n_sen = S;
+    md.n_ci_sen = n_ci_sen;
+    md.cd2cisen = cd2cisen;
+    ptmr_init(&tm);
+
+    /* as srch_TST_begin does: srch_time_switch_tree.c:485-490 */
+    for (s = 0; s < S; s++) {
+        g->mgau[s].bstidx = NO_BSTIDX;
+        g->mgau[s].updatetime = NOT_UPDATED;
+    }
+    for (t = 0; t < T; t++) {
+        float *fv = feat + (size_t)t * D;
+        /* gmm_compute_lv1: gmm_wrap.c:170-211 */
+        approx_cont_mgau_ci_eval(NULL, NULL, g, fg, &md, fv, a->cache_ci_senscr[0],
+                                 &a->cache_best_list[0], t, lm);
+        memcpy(ciscr + (size_t)t * n_ci_sen, a->cache_ci_senscr[0], 4 * n_ci_sen);
+        cibest[t] = a->cache_best_list[0];
+        cnt[4 * t + 2] = g->frm_ci_sen_eval;
+        cnt[4 * t + 3] = g->frm_ci_gau_eval;
+        /* select_active_gmm stand-in */
+        if (active_in)
+            memcpy(a->sen_active, active_in + (size_t)t * S, S);
+        else
+            memset(a->sen_active, 1, S);
+        /* gmm_compute_lv2: gmm_wrap.c:108-167 */
+        best[t] = approx_cont_mgau_frame_eval(&md, NULL, NULL, g, fg, a, fv, t,
+                                              a->cache_ci_senscr[0], &tm, lm);
+        cnt[4 * t + 0] = g->frm_sen_eval;
+        cnt[4 * t + 1] = g->frm_gau_eval;
+        memcpy(senscr + (size_t)t * S, a->senscr, 4 * S);
+        memcpy(act + (size_t)t * S, a->sen_active, S);
+        for (s = 0; s < S; s++) {
+            bidx[(size_t)t * S + s] = g->mgau[s].bstidx;
+            upd[(size_t)t * S + s] = g->mgau[s].updatetime;
+        }
+    }
+    dump(out, "senscr", "i32", senscr, 4, 2, (long)T, (long)S);
+    dump(out, "sen_active_out", "u8", act, 1, 2, (long)T, (long)S);
+    dump(out, "best", "i32", best, 4, 1, (long)T);
+    dump(out, "ci_best", "i32", cibest, 4, 1, (long)T);
+    dump(out, "ci_senscr", "i32", ciscr, 4, 2, (long)T, (long)n_ci_sen);
+    dump(out, "bstidx", "i32", bidx, 4, 2, (long)T, (long)S);
+    dump(out, "updatetime", "i32", upd, 4, 2, (long)T, (long)S);
+    dump(out, "counts", "i32", cnt, 4, 2, (long)T, 4L);
+    {
+        int32 p[2];
+        p[0] = fg->gmms->ci_pbeam;
+        p[1] = fg->gmms->dyn_ci_pbeam;
+        dump(out, "beams", "i32", p, 4, 1, 2L);
+    }
+    return 0;
+}
+
+static int
+cmd_tmat(int argc, char **argv)
+{
+    logmath_t *lm = logs3_init(atof(argv[2]), 0, 1);
+    tmat_t *t;
+    const char *out = argv[4];
+    int32 ns, i, j, k, *flat;
+    if (atoi(argv[3]) != 0) {
+        logmath_free(lm);
+        lm = logmath_init(atof(argv[2]), atoi(argv[3]), 1);
+    }
+    t = tmat_init(argv[0], atof(argv[1]), 0, lm);
+    ns = t->n_state;
+    flat = malloc(sizeof(int32) * t->n_tmat * ns * (ns + 1));
+    for (i = 0; i < t->n_tmat; i++)
+        for (j = 0; j < ns; j++)
+            for (k = 0; k <= ns; k++)
+                flat[(i * ns + j) * (ns + 1) + k] = t->tp[i][j][k];
+    dump(out, "tp", "i32", flat, 4, 3, (long)t->n_tmat, (long)ns, (long)(ns + 1));
+    return 0;
+}
+
+/*
+ * hmm: run hmm_vit_eval over T frames for NHMM independent HMMs.
+ *   SPEC.i32  [NHMM][3]   = {mpx, ssid, tmatid}
+ *   ENTER.i32 [T][NHMM][2] = {score, histid}; score == INT32_MIN means "no entry this frame"
+ * After every frame dumps score[5], history[5], out, bestscore, mpx ssids.
+ */
+static int
+cmd_hmm(int argc, char **argv)
+{
+    int32 ne = atoi(argv[0]);
+    int32 *tpflat = slurp(argv[1], NULL);
+    int32 ntmat = atoi(argv[2]);
+    s3senid_t *sseqflat = slurp(argv[3], NULL);
+    int32 nsseq = atoi(argv[4]);
+    int32 *senscr = slurp(argv[5], NULL);
+    int32 nsen = atoi(argv[6]), T = atoi(argv[7]);
+    int32 *spec = slurp(argv[8], NULL);
+    int32 nh = atoi(argv[9]);
+    int32 *enter = slurp(argv[10], NULL);
+    const char *out = argv[11];
+    int32 ***tp = (int32 ***)ckd_calloc_3d(ntmat, ne, ne + 1, sizeof(int32));
+    s3senid_t **sseq = (s3senid_t **)ckd_calloc_2d(nsseq, ne, sizeof(s3senid_t));
+    hmm_context_t *ctx;
+    hmm_t *h = calloc(nh, sizeof(hmm_t));
+    int32 i, j, k, t;
+    /* per frame per hmm: 5 scores, out, best, 5 ssid = 12 ; histories 6 (i64) */
+    int32 *o32 = malloc(sizeof(int32) * (size_t)T * nh * 12);
+    long long *o64 = malloc(sizeof(long long) * (size_t)T * nh * 6);
+    int32 *ret = malloc(sizeof(int32) * (size_t)T * nh);
+
+    for (i = 0; i < ntmat; i++)
+        for (j = 0; j < ne; j++)
+            for (k = 0; k <= ne; k++)
+                tp[i][j][k] = tpflat[(i * ne + j) * (ne + 1) + k];
+    for (i = 0; i < nsseq; i++)
+        for (j = 0; j < ne; j++)
+            sseq[i][j] = sseqflat[i * ne + j];
+    ctx = hmm_context_init(ne, tp, senscr, sseq);
+    for (i = 0; i < nh; i++)
+        hmm_init(ctx, &h[i], spec[3 * i], spec[3 * i + 1], (s3tmatid_t)spec[3 * i + 2]);
+
+    for (t = 0; t < T; t++) {
+        hmm_context_set_senscore(ctx, senscr + (size_t)t * nsen);
+        for (i = 0; i < nh; i++) {
+            int32 *e = enter + ((size_t)t * nh + i) * 2;
+            int32 *p = o32 + ((size_t)t * nh + i) * 12;
+            long long *q = o64 + ((size_t)t * nh + i) * 6;
+            if (e[0] != (int32)0x80000000)
+                hmm_enter(&h[i], e[0], e[1], t);
+            ret[(size_t)t * nh + i] = hmm_vit_eval(&h[i]);
+            for (j = 0; j < 5; j++) {
+                p[j] = (j < ne) ? hmm_score(&h[i], j) : 0;
+                q[j] = (j < ne) ? (long long)h[i].state[j].history.id : 0;
+                p[7 + j] = (h[i].mpx && j < ne) ? h[i].s.mpx_ssid[j] : -2;
+            }
+            p[5] = hmm_out_score(&h[i]);
+            p[6] = hmm_bestscore(&h[i]);
+            q[5] = (long long)h[i].out.history.id;
+        }
+    }
+    dump(out, "state", "i32", o32, 4, 3, (long)T, (long)nh, 12L);
+    dump(out, "hist", "i64", o64, 8, 3, (long)T, (long)nh, 6L);
+    dump(out, "ret", "i32", ret, 4, 2, (long)T, (long)nh);
+    return 0;
+}
+
+/* feat_s2mfc2feat exactly as utt_decode calls it (libAPI/utt.c:234) */
+static int
+cmd_feat(int argc, char **argv)
+{
+    feat_t *fcb = feat_init("1s_c_d_dd", CMN_CURRENT, 0, AGC_NONE, 0, 13);
+    mfcc_t ***feat = feat_array_alloc(fcb, S3_MAX_FRAMES);
+    int32 nfr = feat_s2mfc2feat(fcb, argv[0], NULL, "", 0, -1, feat, S3_MAX_FRAMES);
+    int32 D = feat_stream_len(fcb, 0), t;
+    float *flat;
+    if (nfr <= 0) { fprintf(stderr, "feat_s2mfc2feat failed\n"); return 2; }
+    flat = malloc(sizeof(float) * (size_t)nfr * D);
+    for (t = 0; t < nfr; t++)
+        memcpy(flat + (size_t)t * D, feat[t][0], sizeof(float) * D);
+    dump(argv[1], "feat", "f32", flat, 4, 2, (long)nfr, (long)D);
+    return 0;
+}
+
+int
+main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: ref_dump CMD ...\n"); return 1; }
+    err_set_logfp(NULL);        /* silence E_INFO chatter */
+    if (!strcmp(argv[1], "logmath") && argc == 5) return cmd_logmath(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "mgau") && argc == 11) return cmd_mgau(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "frame") && argc == 16) return cmd_frame(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "tmat") && argc == 7) return cmd_tmat(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "feat") && argc == 4) return cmd_feat(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "hmm") && argc == 14) return cmd_hmm(argc - 2, argv + 2);
+    fprintf(stderr, "ref_dump: bad command/arity: %s (%d args)\n", argv[1], argc - 2);
+    return 1;
+}

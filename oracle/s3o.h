@@ -1,0 +1,161 @@
+/*
+ * oracle/s3o.h -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the reference's algorithm for the
+ * GMM-senone-scoring + HMM-Viterbi hot path.  Nothing
+ * in the product (cmusphinx_amd/, include/) may include, link or call this;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do,
+ * and only as the checker.
+ *
+ * Every function cites the reference file:line (relative to /root/reference)
+ * whose behaviour it restates.  The oracle works on plain arrays (the tests
+ * parse the S3 model files with numpy), so it shares no loader code with the
+ * product's host C.
+ *
+ * Parity status: PINNED.  tests/test_oracle_*.py check it (a) against the
+ * reference's own known-answer tests (sphinxbase test_logmath, sphinx3
+ * test_logs3 = 79150, test_hmm/_testhmm_tidigits.res) and (b) against
+ * outputs of the unmodified reference built in this container
+ * (oracle/_ref/ref_dump -> tests/golden/, generator: tests/golden/make_golden.py).
+ */
+#ifndef S3O_H
+#define S3O_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sphinx3/include/s3types.h:192 */
+#define S3O_LOGPROB_ZERO ((int32_t)0xc8000000)
+/* sphinxbase/include/sphinxbase/prim_type.h:153 */
+#define S3O_MAX_NEG_INT32 ((int32_t)0x80000000)
+/* sphinx3/include/cont_mgau.h:121-123 */
+#define S3O_NO_BSTIDX (-1)
+#define S3O_NOT_UPDATED (-100)
+
+/* ------------------------------------------------------------------ */
+/* integer log-domain arithmetic                                       */
+/* sphinxbase/src/libsphinxbase/util/logmath.c:61-161, 391-471         */
+/* ------------------------------------------------------------------ */
+typedef struct s3o_logmath_s {
+    double base, log_of_base, log10_of_base, inv_log_of_base, inv_log10_of_base;
+    int shift;
+    int32_t zero;
+    int width;              /* 1, 2 or 4 bytes per entry in the reference */
+    uint32_t table_size;    /* 0 when built without a table */
+    uint32_t *table;        /* widened to u32; values already truncated to `width` */
+} s3o_logmath_t;
+
+s3o_logmath_t *s3o_logmath_init(double base, int shift, int use_table);
+void s3o_logmath_free(s3o_logmath_t *lm);
+int s3o_logmath_add(const s3o_logmath_t *lm, int x, int y);
+int s3o_logmath_log(const s3o_logmath_t *lm, double p);
+double s3o_logmath_exp(const s3o_logmath_t *lm, int logb_p);
+double s3o_logmath_log_to_ln(const s3o_logmath_t *lm, int logb_p);
+int s3o_logmath_ln_to_log(const s3o_logmath_t *lm, double log_p);
+int s3o_logmath_log10_to_log(const s3o_logmath_t *lm, double log_p);
+/* sphinx3/src/libs3decoder/libcommon/logs3.c:111-119 */
+int32_t s3o_logs3(const s3o_logmath_t *lm, double p);
+
+/* ------------------------------------------------------------------ */
+/* continuous-density mixture Gaussians                                */
+/* sphinx3/include/cont_mgau.h:170-226, libam/cont_mgau.c              */
+/* ------------------------------------------------------------------ */
+typedef struct s3o_mgau_s {
+    int32_t n_mgau, max_comp, veclen;
+    int32_t *n_comp;        /* [n_mgau]  after mgau_uninit_compact */
+    float *mean;            /* [n_mgau][max_comp][veclen] (compacted in place) */
+    float *var;             /* same shape; after precomp holds 1/(2 sigma^2) */
+    float *lrd;             /* [n_mgau][max_comp] */
+    int32_t *mixw;          /* [n_mgau][max_comp] logs3 */
+    int32_t *bstidx, *bstscr, *updatetime;  /* [n_mgau] mutable per-senone state */
+    double distfloor;
+    const s3o_logmath_t *lm;
+    /* per-frame counters, cont_mgau.h:214-218 */
+    int32_t frm_sen_eval, frm_gau_eval, frm_ci_sen_eval, frm_ci_gau_eval;
+} s3o_mgau_t;
+
+/* mgau_init (cont_mgau.c:901-956) minus the file parsing: takes the raw
+ * float arrays of the means / variances / mixture_weights files. */
+s3o_mgau_t *s3o_mgau_init(const float *mean, const float *var, const float *mixw,
+                          int32_t n_mgau, int32_t n_density, int32_t veclen,
+                          double varfloor, double mixwfloor, int precomp,
+                          const s3o_logmath_t *lm);
+void s3o_mgau_free(s3o_mgau_t *g);
+/* mgau_eval (cont_mgau.c:1174-1205) */
+int32_t s3o_mgau_eval(s3o_mgau_t *g, int32_t m, const int32_t *active,
+                      const float *x, int32_t fr, int32_t update_best_id);
+/* reset bstidx/bstscr/updatetime of every senone, as srch_TST_begin does
+ * (srch_time_switch_tree.c:485-490) */
+void s3o_mgau_reset_state(s3o_mgau_t *g);
+
+/* fast_gmm_t subset that matters without GS/SVQ (fast_algo_struct.h) */
+typedef struct s3o_fastgmm_s {
+    int32_t ds_ratio;        /* -ds */
+    int32_t cond_ds;         /* -cond_ds (needs a Gaussian selector: must be 0) */
+    int32_t ci_pbeam;        /* logs3(-ci_pbeam) */
+    int32_t max_cd;          /* -maxcdsenpf */
+    float tighten_factor;    /* -tighten_factor */
+    int32_t dyn_ci_pbeam;    /* out: last beam used */
+    int32_t skip_count;
+} s3o_fastgmm_t;
+
+/* approx_cont_mgau_ci_eval (approx_cont_mgau.c:367-428) */
+void s3o_approx_cont_mgau_ci_eval(s3o_mgau_t *g, const int16_t *cd2cisen, int32_t n_sen,
+                                  const float *feat, int32_t *ci_senscr,
+                                  int32_t *best_score, int32_t fr);
+/* approx_cont_mgau_frame_eval (approx_cont_mgau.c:434-616) */
+int32_t s3o_approx_cont_mgau_frame_eval(s3o_mgau_t *g, s3o_fastgmm_t *fg,
+                                        const int16_t *cd2cisen, int32_t n_ci_sen,
+                                        uint8_t *sen_active, uint8_t *rec_sen_active,
+                                        int32_t *senscr, const float *feat, int32_t frame,
+                                        const int32_t *cache_ci_senscr);
+
+/* dict2pid_comsenscr (libsearch/dict2pid.c:1029-1048); comstate is the
+ * ragged list flattened: comstate_off[i]..comstate_off[i+1] */
+void s3o_dict2pid_comsenscr(int32_t n_comstate, const int32_t *comstate_off,
+                            const int16_t *comstate, const int32_t *comwt,
+                            const int32_t *senscr, int32_t *comsenscr);
+
+/* ------------------------------------------------------------------ */
+/* transition matrices + HMM Viterbi                                   */
+/* libam/tmat.c:155-270, include/hmm.h:156-197, libam/hmm.c            */
+/* ------------------------------------------------------------------ */
+#define S3O_MAX_HMM_NSTATE 5
+typedef struct s3o_hmm_s {
+    int32_t score[S3O_MAX_HMM_NSTATE];
+    int64_t history[S3O_MAX_HMM_NSTATE];    /* union {long id; void *ptr} */
+    int32_t out_score;
+    int64_t out_history;
+    int32_t ssid;                           /* non-mpx */
+    int32_t mpx_ssid[S3O_MAX_HMM_NSTATE];   /* mpx */
+    int32_t bestscore;
+    int32_t tmatid;
+    int32_t frame;
+    uint8_t mpx;
+} s3o_hmm_t;
+
+typedef struct s3o_hmm_ctx_s {
+    int32_t n_emit_state;
+    const int32_t *tp;          /* [n_tmat][n_emit][n_emit+1] logs3 */
+    const int32_t *senscore;    /* [n_sen] */
+    const int16_t *sseq;        /* [n_sseq][n_emit] */
+} s3o_hmm_ctx_t;
+
+/* tmat_init's float->logs3 conversion (tmat.c:232-247): in place on a copy */
+void s3o_tmat_logs3(const float *tp_in, int32_t n_tmat, int32_t n_src,
+                    double tpfloor, const s3o_logmath_t *lm, int32_t *tp_out);
+void s3o_hmm_clear(const s3o_hmm_ctx_t *ctx, s3o_hmm_t *h);                 /* hmm.c:225-241 */
+void s3o_hmm_init(const s3o_hmm_ctx_t *ctx, s3o_hmm_t *h, int mpx,
+                  int32_t ssid, int32_t tmatid);                             /* hmm.c:130-147 */
+void s3o_hmm_enter(s3o_hmm_t *h, int32_t score, int64_t histid, int32_t frame); /* hmm.c:244-250 */
+void s3o_hmm_normalize(const s3o_hmm_ctx_t *ctx, s3o_hmm_t *h, int32_t bestscr); /* hmm.c:260-271 */
+int32_t s3o_hmm_vit_eval(const s3o_hmm_ctx_t *ctx, s3o_hmm_t *h);            /* hmm.c:855-873 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

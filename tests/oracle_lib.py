@@ -1,0 +1,336 @@
+"""ctypes binding of the CPU oracle (oracle/libs3oracle.so).  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+LOGPROB_ZERO = -939524096  # (int32)0xc8000000
+NO_BSTIDX = -1
+NOT_UPDATED = -100
+
+
+class LogMath(C.Structure):
+    _fields_ = [("base", C.c_double), ("log_of_base", C.c_double), ("log10_of_base", C.c_double),
+                ("inv_log_of_base", C.c_double), ("inv_log10_of_base", C.c_double),
+                ("shift", C.c_int), ("zero", C.c_int32), ("width", C.c_int),
+                ("table_size", C.c_uint32), ("table", C.POINTER(C.c_uint32))]
+
+
+class Mgau(C.Structure):
+    _fields_ = [("n_mgau", C.c_int32), ("max_comp", C.c_int32), ("veclen", C.c_int32),
+                ("n_comp", C.POINTER(C.c_int32)), ("mean", C.POINTER(C.c_float)),
+                ("var", C.POINTER(C.c_float)), ("lrd", C.POINTER(C.c_float)),
+                ("mixw", C.POINTER(C.c_int32)), ("bstidx", C.POINTER(C.c_int32)),
+                ("bstscr", C.POINTER(C.c_int32)), ("updatetime", C.POINTER(C.c_int32)),
+                ("distfloor", C.c_double), ("lm", C.POINTER(LogMath)),
+                ("frm_sen_eval", C.c_int32), ("frm_gau_eval", C.c_int32),
+                ("frm_ci_sen_eval", C.c_int32), ("frm_ci_gau_eval", C.c_int32)]
+
+
+class FastGmm(C.Structure):
+    _fields_ = [("ds_ratio", C.c_int32), ("cond_ds", C.c_int32), ("ci_pbeam", C.c_int32),
+                ("max_cd", C.c_int32), ("tighten_factor", C.c_float),
+                ("dyn_ci_pbeam", C.c_int32), ("skip_count", C.c_int32)]
+
+
+class Hmm(C.Structure):
+    _fields_ = [("score", C.c_int32 * 5), ("history", C.c_int64 * 5),
+                ("out_score", C.c_int32), ("out_history", C.c_int64),
+                ("ssid", C.c_int32), ("mpx_ssid", C.c_int32 * 5),
+                ("bestscore", C.c_int32), ("tmatid", C.c_int32), ("frame", C.c_int32),
+                ("mpx", C.c_uint8)]
+
+
+class HmmCtx(C.Structure):
+    _fields_ = [("n_emit_state", C.c_int32), ("tp", C.POINTER(C.c_int32)),
+                ("senscore", C.POINTER(C.c_int32)), ("sseq", C.POINTER(C.c_int16))]
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def build():
+    """(Re)build oracle/libs3oracle.so -- and oracle/_ref when /root/reference exists."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"], check=True,
+                   stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(ORACLE_DIR, "libs3oracle.so")
+    if not os.path.exists(path):
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+    L = C.CDLL(path)
+    L.s3o_logmath_init.restype = C.POINTER(LogMath)
+    L.s3o_logmath_init.argtypes = [C.c_double, C.c_int, C.c_int]
+    L.s3o_logmath_free.argtypes = [C.POINTER(LogMath)]
+    for fn in ("s3o_logmath_add",):
+        getattr(L, fn).restype = C.c_int
+        getattr(L, fn).argtypes = [C.POINTER(LogMath), C.c_int, C.c_int]
+    L.s3o_logmath_log.restype = C.c_int
+    L.s3o_logmath_log.argtypes = [C.POINTER(LogMath), C.c_double]
+    L.s3o_logmath_exp.restype = C.c_double
+    L.s3o_logmath_exp.argtypes = [C.POINTER(LogMath), C.c_int]
+    L.s3o_logmath_log_to_ln.restype = C.c_double
+    L.s3o_logmath_log_to_ln.argtypes = [C.POINTER(LogMath), C.c_int]
+    L.s3o_logmath_ln_to_log.restype = C.c_int
+    L.s3o_logmath_ln_to_log.argtypes = [C.POINTER(LogMath), C.c_double]
+    L.s3o_logmath_log10_to_log.restype = C.c_int
+    L.s3o_logmath_log10_to_log.argtypes = [C.POINTER(LogMath), C.c_double]
+    L.s3o_logs3.restype = C.c_int32
+    L.s3o_logs3.argtypes = [C.POINTER(LogMath), C.c_double]
+    L.s3o_mgau_init.restype = C.POINTER(Mgau)
+    L.s3o_mgau_init.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_int32] * 3 + \
+        [C.c_double, C.c_double, C.c_int, C.POINTER(LogMath)]
+    L.s3o_mgau_free.argtypes = [C.POINTER(Mgau)]
+    L.s3o_mgau_eval.restype = C.c_int32
+    L.s3o_mgau_eval.argtypes = [C.POINTER(Mgau), C.c_int32, C.POINTER(C.c_int32),
+                                C.POINTER(C.c_float), C.c_int32, C.c_int32]
+    L.s3o_mgau_reset_state.argtypes = [C.POINTER(Mgau)]
+    L.s3o_approx_cont_mgau_ci_eval.argtypes = [C.POINTER(Mgau), C.POINTER(C.c_int16), C.c_int32,
+                                               C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_int32), C.c_int32]
+    L.s3o_approx_cont_mgau_frame_eval.restype = C.c_int32
+    L.s3o_approx_cont_mgau_frame_eval.argtypes = [
+        C.POINTER(Mgau), C.POINTER(FastGmm), C.POINTER(C.c_int16), C.c_int32,
+        C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
+        C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]
+    L.s3o_dict2pid_comsenscr.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int16),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32)]
+    L.s3o_tmat_logs3.argtypes = [C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_double,
+                                 C.POINTER(LogMath), C.POINTER(C.c_int32)]
+    L.s3o_hmm_init.argtypes = [C.POINTER(HmmCtx), C.POINTER(Hmm), C.c_int, C.c_int32, C.c_int32]
+    L.s3o_hmm_clear.argtypes = [C.POINTER(HmmCtx), C.POINTER(Hmm)]
+    L.s3o_hmm_enter.argtypes = [C.POINTER(Hmm), C.c_int32, C.c_int64, C.c_int32]
+    L.s3o_hmm_normalize.argtypes = [C.POINTER(HmmCtx), C.POINTER(Hmm), C.c_int32]
+    L.s3o_hmm_vit_eval.restype = C.c_int32
+    L.s3o_hmm_vit_eval.argtypes = [C.POINTER(HmmCtx), C.POINTER(Hmm)]
+    _LIB = L
+    return L
+
+
+class OracleLogMath:
+    def __init__(self, base=1.0003, shift=0, use_table=1):
+        self.L = lib()
+        self.p = self.L.s3o_logmath_init(base, shift, use_table)
+        if not self.p:
+            raise ValueError("bad base")
+
+    def __del__(self):
+        try:
+            self.L.s3o_logmath_free(self.p)
+        except Exception:
+            pass
+
+    @property
+    def table(self):
+        n = self.p.contents.table_size
+        return np.ctypeslib.as_array(self.p.contents.table, shape=(n,)).copy()
+
+    @property
+    def zero(self):
+        return self.p.contents.zero
+
+    @property
+    def width(self):
+        return self.p.contents.width
+
+    def add(self, x, y):
+        return self.L.s3o_logmath_add(self.p, int(x), int(y))
+
+    def log(self, p):
+        return self.L.s3o_logmath_log(self.p, float(p))
+
+    def logs3(self, p):
+        return self.L.s3o_logs3(self.p, float(p))
+
+
+class OracleMgau:
+    """mgau_init on raw arrays + mgau_eval / approx_cont_mgau_frame_eval."""
+
+    def __init__(self, mean, var, mixw, lm: OracleLogMath, varfloor=1e-4, mixwfloor=1e-7):
+        self.L = lib()
+        self.lm = lm
+        mean = np.ascontiguousarray(mean, dtype=np.float32)
+        var = np.ascontiguousarray(var, dtype=np.float32)
+        mixw = np.ascontiguousarray(mixw, dtype=np.float32).reshape(mean.shape[0], mean.shape[1])
+        S, Cn, D = mean.shape
+        self.S, self.C, self.D = S, Cn, D
+        self.p = self.L.s3o_mgau_init(_ptr(mean, C.c_float), _ptr(var, C.c_float),
+                                      _ptr(mixw, C.c_float), S, Cn, D,
+                                      varfloor, mixwfloor, 1, lm.p)
+
+    def __del__(self):
+        try:
+            self.L.s3o_mgau_free(self.p)
+        except Exception:
+            pass
+
+    def arr(self, name, shape, copy=True):
+        a = np.ctypeslib.as_array(getattr(self.p.contents, name), shape=shape)
+        return a.copy() if copy else a
+
+    @property
+    def n_comp(self):
+        return self.arr("n_comp", (self.S,))
+
+    @property
+    def mean(self):
+        return self.arr("mean", (self.S, self.C, self.D))
+
+    @property
+    def prec(self):
+        return self.arr("var", (self.S, self.C, self.D))
+
+    @property
+    def lrd(self):
+        return self.arr("lrd", (self.S, self.C))
+
+    @property
+    def mixw(self):
+        return self.arr("mixw", (self.S, self.C))
+
+    @property
+    def distfloor(self):
+        return self.p.contents.distfloor
+
+    def reset_state(self):
+        self.L.s3o_mgau_reset_state(self.p)
+
+    def eval(self, m, x, fr=0, update=1, active=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        ap = None
+        if active is not None:
+            act = np.ascontiguousarray(list(active) + [-1], dtype=np.int32)
+            ap = _ptr(act, C.c_int32)
+        return self.L.s3o_mgau_eval(self.p, int(m), ap, _ptr(x, C.c_float), int(fr), int(update))
+
+    def score_all(self, feats):
+        """mgau_eval(g, s, NULL, x, t, 1) for every frame and senone -> int32 [T][S]."""
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        T = feats.shape[0]
+        out = np.empty((T, self.S), dtype=np.int32)
+        for t in range(T):
+            xp = _ptr(feats[t], C.c_float)
+            for s in range(self.S):
+                out[t, s] = self.L.s3o_mgau_eval(self.p, s, None, xp, t, 1)
+        return out
+
+    def frame_eval_seq(self, feats, cd2cisen, n_ci_sen, active=None, ci_pbeam=None,
+                       ds=1, tighten=0.5, max_cd=100000):
+        """ci_eval + frame_eval over a frame sequence (srch.c:739-822 with -pl_window 1).
+
+        Returns dict with senscr[T][S], best[T], sen_active_out, bstidx, updatetime, counts.
+        """
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        cd2cisen = np.ascontiguousarray(cd2cisen, dtype=np.int16)
+        T, S = feats.shape[0], self.S
+        if ci_pbeam is None:
+            ci_pbeam = self.lm.logs3(1e-80)
+        fg = FastGmm(ds, 0, int(ci_pbeam), int(max_cd), float(tighten), 0, 0)
+        senscr = np.zeros((T, S), np.int32)
+        act_out = np.zeros((T, S), np.uint8)
+        bidx = np.zeros((T, S), np.int32)
+        upd = np.zeros((T, S), np.int32)
+        best = np.zeros(T, np.int32)
+        cibest = np.zeros(T, np.int32)
+        counts = np.zeros((T, 4), np.int32)
+        ci = np.zeros(max(n_ci_sen, 1), np.int32)
+        cur = np.zeros(S, np.int32)
+        sa = np.zeros(S, np.uint8)
+        rsa = np.zeros(S, np.uint8)
+        b = C.c_int32(0)
+        self.reset_state()
+        for t in range(T):
+            xp = _ptr(feats[t], C.c_float)
+            self.L.s3o_approx_cont_mgau_ci_eval(self.p, _ptr(cd2cisen, C.c_int16), S, xp,
+                                                _ptr(ci, C.c_int32), C.byref(b), t)
+            cibest[t] = b.value
+            counts[t, 2] = self.p.contents.frm_ci_sen_eval
+            counts[t, 3] = self.p.contents.frm_ci_gau_eval
+            sa[:] = 1 if active is None else active[t]
+            best[t] = self.L.s3o_approx_cont_mgau_frame_eval(
+                self.p, C.byref(fg), _ptr(cd2cisen, C.c_int16), n_ci_sen,
+                _ptr(sa, C.c_uint8), _ptr(rsa, C.c_uint8), _ptr(cur, C.c_int32), xp, t,
+                _ptr(ci, C.c_int32))
+            counts[t, 0] = self.p.contents.frm_sen_eval
+            counts[t, 1] = self.p.contents.frm_gau_eval
+            senscr[t] = cur
+            act_out[t] = sa
+            bidx[t] = self.arr("bstidx", (S,))
+            upd[t] = self.arr("updatetime", (S,))
+        return dict(senscr=senscr, best=best, ci_best=cibest, sen_active_out=act_out,
+                    bstidx=bidx, updatetime=upd, counts=counts,
+                    beams=np.array([fg.ci_pbeam, fg.dyn_ci_pbeam], np.int32))
+
+
+def tmat_logs3(tp, lm: OracleLogMath, tpfloor=1e-4):
+    tp = np.ascontiguousarray(tp, dtype=np.float32)
+    out = np.zeros(tp.shape, np.int32)
+    lib().s3o_tmat_logs3(_ptr(tp, C.c_float), tp.shape[0], tp.shape[1], tpfloor, lm.p,
+                         _ptr(out, C.c_int32))
+    return out
+
+
+def comsenscr(comstate_off, comstate, comwt, senscr):
+    comstate_off = np.ascontiguousarray(comstate_off, np.int32)
+    comstate = np.ascontiguousarray(comstate, np.int16)
+    comwt = np.ascontiguousarray(comwt, np.int32)
+    senscr = np.ascontiguousarray(senscr, np.int32)
+    n = len(comwt)
+    out = np.zeros(n, np.int32)
+    lib().s3o_dict2pid_comsenscr(n, _ptr(comstate_off, C.c_int32), _ptr(comstate, C.c_int16),
+                                 _ptr(comwt, C.c_int32), _ptr(senscr, C.c_int32),
+                                 _ptr(out, C.c_int32))
+    return out
+
+
+def hmm_run(n_emit, tp, sseq, senscr, spec, enter):
+    """Run s3o_hmm_vit_eval over T frames for NHMM HMMs (same protocol as ref_dump hmm).
+
+    Returns (state int32 [T][N][12], hist int64 [T][N][6], ret int32 [T][N]).
+    """
+    L = lib()
+    tp = np.ascontiguousarray(tp, np.int32)
+    sseq = np.ascontiguousarray(sseq, np.int16)
+    senscr = np.ascontiguousarray(senscr, np.int32)
+    spec = np.ascontiguousarray(spec, np.int32)
+    enter = np.ascontiguousarray(enter, np.int32)
+    T, nsen = senscr.shape
+    nh = spec.shape[0]
+    ctx = HmmCtx(n_emit, _ptr(tp, C.c_int32), _ptr(senscr, C.c_int32), _ptr(sseq, C.c_int16))
+    hs = (Hmm * nh)()
+    for i in range(nh):
+        L.s3o_hmm_init(C.byref(ctx), C.byref(hs[i]), int(spec[i, 0]), int(spec[i, 1]), int(spec[i, 2]))
+    state = np.zeros((T, nh, 12), np.int32)
+    hist = np.zeros((T, nh, 6), np.int64)
+    ret = np.zeros((T, nh), np.int32)
+    for t in range(T):
+        ctx.senscore = _ptr(senscr[t], C.c_int32)
+        for i in range(nh):
+            if enter[t, i, 0] != -2147483648:
+                L.s3o_hmm_enter(C.byref(hs[i]), int(enter[t, i, 0]), int(enter[t, i, 1]), t)
+            ret[t, i] = L.s3o_hmm_vit_eval(C.byref(ctx), C.byref(hs[i]))
+            h = hs[i]
+            for j in range(5):
+                state[t, i, j] = h.score[j] if j < n_emit else 0
+                hist[t, i, j] = h.history[j] if j < n_emit else 0
+                state[t, i, 7 + j] = h.mpx_ssid[j] if (h.mpx and j < n_emit) else -2
+            state[t, i, 5] = h.out_score
+            state[t, i, 6] = h.bestscore
+            hist[t, i, 5] = h.out_history
+    return state, hist, ret
