@@ -39,20 +39,9 @@
 #include <limits.h>
 #include <vector>
 
-#include "s3a_internal.h"
+#include "s3a_device.h"
 
 #pragma clang fp contract(off)
-
-#define HIPCHK(expr)                                                              \
-    do {                                                                          \
-        hipError_t e_ = (expr);                                                   \
-        if (e_ != hipSuccess) {                                                   \
-            s3a_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
-                          __FILE__, __LINE__);                                    \
-            return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice         \
-                    || e_ == hipErrorInsufficientDriver) ? S3A_ENODEV : S3A_EHIP; \
-        }                                                                         \
-    } while (0)
 
 /* ------------------------------------------------------------------ */
 /* device objects                                                      */
@@ -60,24 +49,6 @@
 #define D4MAIN 10           /* ceil(39/4): the 1s_c_d_dd case gets the unrolled kernel */
 #define FB 8                /* frames per inner group */
 #define GPAD_ALIGN 1024     /* Gaussians padded to a whole number of the largest workgroup */
-
-struct s3a_mgau_dev_s {
-    int32_t S, C, CP, D, D4, G, Gpad;
-    float4 *mean4, *prec4;      /* [D4][Gpad] */
-    float *lrd;                 /* [Gpad] */
-    int32_t *mixw;              /* [Gpad] */
-    uint16_t *tab16;            /* log-add table, width <= 2 */
-    uint32_t *tab32;            /* log-add table, width 4 */
-    uint32_t tab_size;
-    int32_t lm_zero;
-    int32_t *bstidx, *bstscr, *updatetime;  /* [S] */
-    hipStream_t stream;
-    /* scratch for the host-pointer API */
-    float *feat_buf;   size_t feat_cap;     /* padded [T][D4*4] */
-    int32_t *scr_buf;  size_t scr_cap;
-    int32_t *best_buf; size_t best_cap;
-    int32_t n_cu;
-};
 
 static int32_t
 pow2_ceil(int32_t v)
@@ -238,61 +209,6 @@ s3a_mgau_set_precision(s3a_mgau_model_t *g, int32_t mode)
 /* ------------------------------------------------------------------ */
 /* device helpers                                                      */
 /* ------------------------------------------------------------------ */
-struct LogAdd {
-    const uint16_t *tab;        /* LDS or global */
-    uint32_t size;
-    int32_t zero;
-    /* logmath_add, logmath.c:391-436 */
-    __device__ __forceinline__ int32_t operator()(int32_t x, int32_t y) const
-    {
-        if (x <= zero) return y;
-        if (y <= zero) return x;
-        int32_t hi = x > y ? x : y;
-        int32_t lo = x > y ? y : x;
-        uint32_t d = (uint32_t)hi - (uint32_t)lo;
-        if (d >= size) return hi;           /* also covers the wrapped (d < 0) case */
-        return hi + (int32_t)tab[d];
-    }
-};
-
-/* one dimension of cont_mgau.c:1058-1063, bit-exact */
-__device__ __forceinline__ double
-gau_step_exact(double acc, float x, float m, float p)
-{
-    float df = x - m;               /* float32 subtract */
-    double d = (double)df;
-    double d2 = d * d;              /* exact: 24-bit significand squared */
-    double t = d2 * (double)p;      /* rounded once */
-    return acc - t;                 /* rounded once; NOT an fma */
-}
-
-__device__ __forceinline__ float
-gau_step_fast(float acc, float x, float m, float p)
-{
-    float df = x - m;
-    return __builtin_fmaf(-(df * df), p, acc);
-}
-
-template <bool EXACT> struct Acc;
-template <> struct Acc<true> {
-    typedef double T;
-    static __device__ __forceinline__ double step(double a, float x, float m, float p)
-    { return gau_step_exact(a, x, m, p); }
-};
-template <> struct Acc<false> {
-    typedef float T;
-    static __device__ __forceinline__ float step(float a, float x, float m, float p)
-    { return gau_step_fast(a, x, m, p); }
-};
-
-/* gauscr = (int32)(f * max(dval, distfloor)) + mixw : cont_mgau.c:1066-1073 */
-__device__ __forceinline__ int32_t
-gau_to_int(double dval, double f, double distfloor, int32_t mixw)
-{
-    if (dval < distfloor) dval = distfloor;
-    return (int32_t)((uint32_t)(int32_t)(f * dval) + (uint32_t)mixw);
-}
-
 /* ------------------------------------------------------------------ */
 /* k_score_frames: all senones x a chunk of frames                     */
 /* ------------------------------------------------------------------ */
@@ -658,14 +574,18 @@ extern "C" int32_t
 s3a_mgau_score_frames_dev(s3a_mgau_model_t *g, const float *feat_dev, int32_t n_frames,
                           int32_t *senscr_dev, int32_t *best_dev, void *stream)
 {
-    if (!g || !g->dev || !feat_dev || !senscr_dev || n_frames < 0)
+    if (g && !g->dev) {
+        s3a_set_error("host-only model handle: scoring needs a GPU (no CPU fallback)");
+        return S3A_ENODEV;
+    }
+    if (!g || !feat_dev || !senscr_dev || n_frames < 0)
         return S3A_EINVAL;
     return launch_score(g, feat_dev, g->veclen, n_frames, senscr_dev, best_dev,
                         stream ? (hipStream_t)stream : g->dev->stream);
 }
 
-static int32_t
-grow(void **buf, size_t *cap, size_t need)
+int32_t
+s3a_dev_grow(void **buf, size_t *cap, size_t need)
 {
     if (*cap >= need)
         return S3A_OK;
@@ -685,16 +605,20 @@ s3a_mgau_score_frames(s3a_mgau_model_t *g, const float *feat, int32_t n_frames,
     int32_t rc;
     size_t fb, sb;
 
-    if (!g || !g->dev || !feat || !senscr || n_frames < 0)
+    if (g && !g->dev) {
+        s3a_set_error("host-only model handle: scoring needs a GPU (no CPU fallback)");
+        return S3A_ENODEV;
+    }
+    if (!g || !feat || !senscr || n_frames < 0)
         return S3A_EINVAL;
     if (n_frames == 0)
         return S3A_OK;
     d = g->dev;
     fb = (size_t)n_frames * d->D * sizeof(float);
     sb = (size_t)n_frames * d->S * sizeof(int32_t);
-    if ((rc = grow((void **)&d->feat_buf, &d->feat_cap, fb)) != S3A_OK) return rc;
-    if ((rc = grow((void **)&d->scr_buf, &d->scr_cap, sb)) != S3A_OK) return rc;
-    if ((rc = grow((void **)&d->best_buf, &d->best_cap, (size_t)n_frames * 4)) != S3A_OK) return rc;
+    if ((rc = s3a_dev_grow((void **)&d->feat_buf, &d->feat_cap, fb)) != S3A_OK) return rc;
+    if ((rc = s3a_dev_grow((void **)&d->scr_buf, &d->scr_cap, sb)) != S3A_OK) return rc;
+    if ((rc = s3a_dev_grow((void **)&d->best_buf, &d->best_cap, (size_t)n_frames * 4)) != S3A_OK) return rc;
     HIPCHK(hipMemcpyAsync(d->feat_buf, feat, fb, hipMemcpyHostToDevice, d->stream));
     rc = launch_score(g, d->feat_buf, d->D, n_frames, d->scr_buf, best ? d->best_buf : NULL,
                       d->stream);
@@ -847,7 +771,7 @@ s3a_mgau_eval(s3a_mgau_model_t *g, int32_t m, const int32_t *active_comp, const 
         }
     /* scratch: [x: D floats][active: n ints][out: 1 int] in feat_buf */
     need = (size_t)(d->D + n_active + 2) * 4;
-    if ((rc = grow((void **)&d->feat_buf, &d->feat_cap, need)) != S3A_OK)
+    if ((rc = s3a_dev_grow((void **)&d->feat_buf, &d->feat_cap, need)) != S3A_OK)
         return S3A_LOGPROB_ZERO;
     dx = d->feat_buf;
     dout = (int32_t *)(dx + d->D);

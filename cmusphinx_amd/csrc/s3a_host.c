@@ -559,10 +559,9 @@ s3a_mgau_init_arrays(const float *mean, const float *var, const float *mixw, int
     return g;
 }
 
-s3a_mgau_model_t *
-s3a_mgau_init(const char *meanfile, const char *varfile, double varfloor, const char *mixwfile,
-              double mixwfloor, int32_t precomp, const char *senmgau, int32_t comp_type,
-              s3a_logmath_t *logmath)
+static s3a_mgau_model_t *
+mgau_from_files(const char *meanfile, const char *varfile, double varfloor, const char *mixwfile,
+                double mixwfloor, int32_t precomp, s3a_logmath_t *logmath, int upload)
 {
     uint32_t *wm = NULL, *wv = NULL, *ww = NULL;
     size_t nm, nv, nw;
@@ -572,15 +571,6 @@ s3a_mgau_init(const char *meanfile, const char *varfile, double varfloor, const 
 
     if (!meanfile || !varfile || !mixwfile || !logmath || varfloor < 0.0 || mixwfloor < 0.0) {
         s3a_set_error("s3a_mgau_init: bad arguments");
-        return NULL;
-    }
-    if (!senmgau || strcmp(senmgau, ".cont.") != 0) {
-        s3a_set_error("s3a_mgau_init: only -senmgau .cont. is supported (got %s)",
-                      senmgau ? senmgau : "NULL");
-        return NULL;
-    }
-    if (comp_type != S3A_MIX_INT_FLOAT_COMP) {
-        s3a_set_error("s3a_mgau_init: only MIX_INT_FLOAT_COMP is supported");
         return NULL;
     }
     if (s3a_bio_read(meanfile, "1.0", &wm, &nm) != S3A_OK
@@ -609,8 +599,12 @@ s3a_mgau_init(const char *meanfile, const char *varfile, double varfloor, const 
                       mixwfile, S3, C3, S, C);
         goto done;
     }
-    g = s3a_mgau_init_arrays(mean, var, (const float *)(ww + 4), S, C, D, varfloor, mixwfloor,
-                             precomp, logmath);
+    if (upload)
+        g = s3a_mgau_init_arrays(mean, var, (const float *)(ww + 4), S, C, D, varfloor,
+                                 mixwfloor, precomp, logmath);
+    else
+        g = s3a_mgau_host_init(mean, var, (const float *)(ww + 4), S, C, D, varfloor, mixwfloor,
+                               precomp, logmath);
 done:
     free(wm);
     free(wv);
@@ -618,12 +612,38 @@ done:
     return g;
 }
 
+s3a_mgau_model_t *
+s3a_mgau_init(const char *meanfile, const char *varfile, double varfloor, const char *mixwfile,
+              double mixwfloor, int32_t precomp, const char *senmgau, int32_t comp_type,
+              s3a_logmath_t *logmath)
+{
+    if (!senmgau || strcmp(senmgau, ".cont.") != 0) {
+        s3a_set_error("s3a_mgau_init: only -senmgau .cont. is supported (got %s)",
+                      senmgau ? senmgau : "NULL");
+        return NULL;
+    }
+    if (comp_type != S3A_MIX_INT_FLOAT_COMP) {
+        s3a_set_error("s3a_mgau_init: only MIX_INT_FLOAT_COMP is supported");
+        return NULL;
+    }
+    return mgau_from_files(meanfile, varfile, varfloor, mixwfile, mixwfloor, precomp, logmath, 1);
+}
+
+s3a_mgau_model_t *
+s3a_mgau_load_host(const char *meanfile, const char *varfile, double varfloor,
+                   const char *mixwfile, double mixwfloor, int32_t precomp,
+                   s3a_logmath_t *logmath)
+{
+    return mgau_from_files(meanfile, varfile, varfloor, mixwfile, mixwfloor, precomp, logmath, 0);
+}
+
 void
 s3a_mgau_free(s3a_mgau_model_t *g)
 {
     if (!g)
         return;
-    s3a_mgau_dev_destroy(g);
+    if (g->dev)
+        s3a_mgau_dev_destroy(g);
     s3a_mgau_host_free(g);
 }
 
@@ -690,6 +710,24 @@ s3a_tmat_init_arrays(const float *tp, int32_t n_tmat, int32_t n_state, double tp
                     s3a_tmat_free(t);
                     return NULL;
                 }
+    return t;
+}
+
+s3a_tmat_t *
+s3a_tmat_init_logs3(const int32_t *tp, int32_t n_tmat, int32_t n_state)
+{
+    s3a_tmat_t *t;
+    size_t n;
+    if (!tp || n_tmat <= 0 || n_state <= 0) {
+        s3a_set_error("s3a_tmat_init_logs3: bad arguments");
+        return NULL;
+    }
+    n = (size_t)n_tmat * n_state * (n_state + 1);
+    t = (s3a_tmat_t *)calloc(1, sizeof *t);
+    t->n_tmat = n_tmat;
+    t->n_state = n_state;
+    t->tp = (int32_t *)malloc(sizeof(int32_t) * n);
+    memcpy(t->tp, tp, sizeof(int32_t) * n);
     return t;
 }
 

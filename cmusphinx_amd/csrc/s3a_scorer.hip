@@ -1,0 +1,468 @@
+/*
+ * s3a_scorer.hip -- the per-frame scoring driver with CI gating and the
+ * composite-senone pass, on the device.
+ *
+ * Replaces (paths relative to cjac/cmusphinx, sphinx3/src/libs3decoder):
+ *   libam/approx_cont_mgau.c:367-428   approx_cont_mgau_ci_eval
+ *   libam/approx_cont_mgau.c:434-616   approx_cont_mgau_frame_eval
+ *   libam/approx_cont_mgau.c:94-143    approx_isskip        (host, s3a_host side below)
+ *   libam/approx_cont_mgau.c:303-357   approx_compute_dyn_ci_pbeam (host: <= 200 CI senones)
+ *   libsearch/dict2pid.c:1029-1048     dict2pid_comsenscr
+ *
+ * k_gated_frame scores ONE frame.  Lane = Gaussian (as in s3a_device.hip); a
+ * wave owns 64/CP senones.  Per senone the reference's three-way gate is
+ * evaluated once (by every lane of the senone, identically):
+ *   full   : senscr[ci] >= pbest + beam  -> all components, ordered log-add,
+ *            bstidx/bstscr/updatetime updated (update_best_id = 1)
+ *   single : else if scored last frame   -> only component bstidx; state is
+ *            re-written only on a skipped (down-sampled) frame
+ *   ci     : else                        -> copy of the parent CI senone's score
+ * The frame maximum is reduced per wave and merged with one atomicMax; the
+ * normalisation senscr[s] -= best for active senones is a second tiny kernel.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+#include "s3a_device.h"
+
+#pragma clang fp contract(off)
+
+struct s3a_scorer_s {
+    s3a_mgau_model_t *g;
+    int32_t n_sen, n_ci_sen;
+    int16_t *cd2cisen_h;
+    /* fast_gmm_t subset */
+    int32_t ds_ratio, cond_ds, ci_pbeam, max_cd, dyn_ci_pbeam, skip_count;
+    float tighten_factor;
+    /* device */
+    int16_t *cd2cisen_d;
+    uint8_t *ncomp_d;       /* [S] */
+    float *x_d;             /* [D4*4] */
+    uint8_t *act_d;         /* [S] */
+    int32_t *scr_d;         /* [S] */
+    int32_t *ci_d;          /* [n_ci_sen] */
+    int32_t *misc_d;        /* [0]=best [1]=ns [2]=ng */
+    int32_t *misc_h;        /* pinned mirror */
+    int32_t *ci_occ_h, *idx_h;
+};
+
+template <bool EXACT>
+__global__ void __launch_bounds__(256)
+k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4,
+              const float *__restrict__ lrd, const int32_t *__restrict__ mixw_g,
+              const uint16_t *__restrict__ tab_g, uint32_t tab_size, int32_t lm_zero,
+              double f, double distfloor, const float *__restrict__ x, int32_t D4, int32_t CP,
+              int32_t Gpad, int32_t sen_lo, int32_t sen_hi, int32_t ci_phase,
+              const uint8_t *__restrict__ ncomp, const int16_t *__restrict__ cd2cisen,
+              const uint8_t *__restrict__ sen_active, int32_t *__restrict__ senscr,
+              int32_t pbest_plus_beam, int32_t frame, int32_t is_skip,
+              int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc)
+{
+    typedef typename Acc<EXACT>::T acc_t;
+    const int32_t lane = threadIdx.x & 63;
+    const int32_t g = sen_lo * CP + blockIdx.x * 256 + threadIdx.x;
+    const int32_t sen = g / CP, c = g - sen * CP, sl = lane / CP;
+    const bool valid = sen < sen_hi;
+    LogAdd la;
+    la.tab = tab_g; la.size = tab_size; la.zero = lm_zero;
+
+    /* 0 = untouched, 1 = full, 2 = single Gaussian, 3 = CI copy */
+    int32_t mode = 0, ci_scr = 0, bi = S3A_NO_BSTIDX;
+    if (valid) {
+        if (ci_phase)
+            mode = 1;
+        else if (sen_active[sen]) {
+            ci_scr = senscr[cd2cisen[sen]];
+            if (ci_scr >= pbest_plus_beam)
+                mode = 1;
+            else {
+                bi = bstidx[sen];
+                mode = (bi == S3A_NO_BSTIDX || updatetime[sen] != frame - 1) ? 3 : 2;
+            }
+        }
+    }
+    int32_t gs = S3A_LOGPROB_ZERO;
+    if (mode == 1 || (mode == 2 && c == bi)) {
+        acc_t a = (acc_t)lrd[g];
+        for (int32_t k = 0; k < D4; k++) {
+            float4 m = mean4[(size_t)k * Gpad + g], p = prec4[(size_t)k * Gpad + g];
+            const float4 xv = *(const float4 *)(x + 4 * k);
+            a = Acc<EXACT>::step(a, xv.x, m.x, p.x);
+            a = Acc<EXACT>::step(a, xv.y, m.y, p.y);
+            a = Acc<EXACT>::step(a, xv.z, m.z, p.z);
+            a = Acc<EXACT>::step(a, xv.w, m.w, p.w);
+        }
+        gs = gau_to_int((double)a, f, distfloor, mixw_g[g]);
+    }
+    /* ordered chain over the senone's lanes; every lane of the senone runs it */
+    int32_t score = S3A_LOGPROB_ZERO, bs = S3A_LOGPROB_ZERO, bidx = S3A_NO_BSTIDX;
+    const int32_t nc = valid ? (int32_t)ncomp[sen] : 0;
+    for (int32_t cc = 0; cc < CP; cc++) {
+        int32_t v = __shfl(gs, sl * CP + cc, 64);
+        if (mode == 1 && cc < nc) {
+            score = la(score, v);
+            if (v > bs) { bs = v; bidx = cc; }      /* update_best_id = 1: strict >, first max wins */
+        }
+        else if (mode == 2 && cc == bi) {
+            score = la(score, v);
+            if (v > bs) { bs = v; bidx = cc; }
+        }
+    }
+    if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
+    if (mode == 3) score = ci_scr;
+
+    int32_t wbest = INT_MIN, ns = 0, ng = 0;
+    if (mode != 0 && c == 0) {
+        senscr[sen] = score;
+        wbest = score;
+        if (mode == 1) {
+            bstidx[sen] = bidx; bstscr[sen] = bs; updatetime[sen] = frame;
+            ns = 1; ng = nc;
+        }
+        else if (mode == 2) {
+            if (is_skip) { bstidx[sen] = bidx; bstscr[sen] = bs; updatetime[sen] = frame; }
+            ng = 1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        wbest = max(wbest, __shfl_xor(wbest, o, 64));
+        ns += __shfl_xor(ns, o, 64);
+        ng += __shfl_xor(ng, o, 64);
+    }
+    if (lane == 0) {
+        if (wbest != INT_MIN) atomicMax(&misc[0], wbest);
+        if (!ci_phase && ns) atomicAdd(&misc[1], ns);
+        if (!ci_phase && ng) atomicAdd(&misc[2], ng);
+        if (ci_phase && ns) atomicAdd(&misc[3], ns);
+        if (ci_phase && ng) atomicAdd(&misc[4], ng);
+    }
+}
+
+/* approx_cont_mgau.c:597-600 */
+__global__ void
+k_normalise(int32_t *senscr, const uint8_t *sen_active, const int32_t *misc, int32_t S)
+{
+    int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < S && sen_active[s])
+        senscr[s] -= misc[0];
+}
+
+extern "C" s3a_scorer_t *
+s3a_scorer_init(s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen, int32_t n_ci_sen,
+                int32_t ds_ratio, int32_t cond_ds, double ci_pbeam, float tighten_factor,
+                int32_t max_cd)
+{
+    s3a_scorer_t *sc;
+    struct s3a_mgau_dev_s *d;
+    int32_t s;
+
+    if (!g || !g->dev || !cd2cisen || n_sen != g->n_mgau || n_ci_sen < 0 || n_ci_sen > n_sen
+        || ds_ratio < 1) {
+        s3a_set_error("s3a_scorer_init: bad arguments");
+        return NULL;
+    }
+    if (cond_ds) {
+        s3a_set_error("-cond_ds needs a Gaussian selector, which is not supported");
+        return NULL;
+    }
+    /* mdef_is_cisenone(s) == (s == cd2cisen[s]) must hold exactly on [0, n_ci_sen):
+     * the CD gate then sees pbest = max over ALL CI senones, as in the reference
+     * where the CI senones come first (mdef.h:206-208) */
+    for (s = 0; s < n_sen; s++) {
+        int ok = (s < n_ci_sen) ? (cd2cisen[s] == s)
+                                : (cd2cisen[s] >= 0 && cd2cisen[s] < n_ci_sen);
+        if (!ok) {
+            s3a_set_error("cd2cisen: CI senones must be exactly the first %d senones "
+                          "(violated at senone %d -> %d)", n_ci_sen, s, cd2cisen[s]);
+            return NULL;
+        }
+    }
+    d = g->dev;
+    if (d->tab16 == NULL) {
+        s3a_set_error("32-bit log-add tables are not supported by the scoring kernels");
+        return NULL;
+    }
+    sc = (s3a_scorer_t *)calloc(1, sizeof *sc);
+    sc->g = g;
+    sc->n_sen = n_sen;
+    sc->n_ci_sen = n_ci_sen;
+    sc->ds_ratio = ds_ratio;
+    sc->cond_ds = cond_ds;
+    sc->ci_pbeam = s3a_logs3(g->lm, ci_pbeam);      /* fast_algo_struct.c:438 */
+    sc->dyn_ci_pbeam = sc->ci_pbeam;
+    sc->tighten_factor = tighten_factor;
+    sc->max_cd = max_cd;
+    sc->cd2cisen_h = (int16_t *)malloc(sizeof(int16_t) * n_sen);
+    memcpy(sc->cd2cisen_h, cd2cisen, sizeof(int16_t) * n_sen);
+    sc->ci_occ_h = (int32_t *)calloc(n_sen, sizeof(int32_t));
+    sc->idx_h = (int32_t *)calloc(n_ci_sen > 0 ? n_ci_sen : 1, sizeof(int32_t));
+    {
+        uint8_t *nc = (uint8_t *)malloc(n_sen);
+        for (s = 0; s < n_sen; s++) nc[s] = (uint8_t)g->n_comp[s];
+        if (hipMalloc(&sc->cd2cisen_d, sizeof(int16_t) * n_sen) != hipSuccess
+            || hipMalloc(&sc->ncomp_d, n_sen) != hipSuccess
+            || hipMalloc(&sc->x_d, sizeof(float) * d->D4 * 4) != hipSuccess
+            || hipMalloc(&sc->act_d, n_sen) != hipSuccess
+            || hipMalloc(&sc->scr_d, sizeof(int32_t) * n_sen) != hipSuccess
+            || hipMalloc(&sc->ci_d, sizeof(int32_t) * (n_ci_sen > 0 ? n_ci_sen : 1)) != hipSuccess
+            || hipMalloc(&sc->misc_d, sizeof(int32_t) * 8) != hipSuccess
+            || hipHostMalloc(&sc->misc_h, sizeof(int32_t) * 8) != hipSuccess
+            || hipMemcpy(sc->cd2cisen_d, cd2cisen, sizeof(int16_t) * n_sen, hipMemcpyHostToDevice) != hipSuccess
+            || hipMemcpy(sc->ncomp_d, nc, n_sen, hipMemcpyHostToDevice) != hipSuccess
+            || hipMemset(sc->x_d, 0, sizeof(float) * d->D4 * 4) != hipSuccess
+            || hipMemset(sc->scr_d, 0, sizeof(int32_t) * n_sen) != hipSuccess) {
+            free(nc);
+            s3a_set_error("s3a_scorer_init: device allocation failed");
+            s3a_scorer_free(sc);
+            return NULL;
+        }
+        free(nc);
+    }
+    return sc;
+}
+
+extern "C" void
+s3a_scorer_free(s3a_scorer_t *sc)
+{
+    if (!sc) return;
+    (void)hipFree(sc->cd2cisen_d); (void)hipFree(sc->ncomp_d); (void)hipFree(sc->x_d);
+    (void)hipFree(sc->act_d); (void)hipFree(sc->scr_d); (void)hipFree(sc->ci_d);
+    (void)hipFree(sc->misc_d);
+    if (sc->misc_h) (void)hipHostFree(sc->misc_h);
+    free(sc->cd2cisen_h); free(sc->ci_occ_h); free(sc->idx_h);
+    free(sc);
+}
+
+extern "C" int32_t
+s3a_scorer_utt_begin(s3a_scorer_t *sc)
+{
+    if (!sc) return S3A_EINVAL;
+    sc->skip_count = 0;
+    return s3a_mgau_reset_state(sc->g);
+}
+
+static void
+launch_gated(s3a_scorer_t *sc, int32_t lo, int32_t hi, int32_t ci_phase, int32_t thresh,
+             int32_t frame, int32_t is_skip)
+{
+    s3a_mgau_model_t *g = sc->g;
+    struct s3a_mgau_dev_s *d = g->dev;
+    int32_t n_gau = (hi - lo) * d->CP;
+    int32_t grid = (n_gau + 255) / 256;
+    if (grid <= 0) return;
+    if (g->precision == S3A_GMM_EXACT)
+        hipLaunchKernelGGL(k_gated_frame<true>, dim3(grid), dim3(256), 0, d->stream, d->mean4,
+                           d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
+                           g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
+                           sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, frame,
+                           is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d);
+    else
+        hipLaunchKernelGGL(k_gated_frame<false>, dim3(grid), dim3(256), 0, d->stream, d->mean4,
+                           d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
+                           g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
+                           sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, frame,
+                           is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d);
+}
+
+static const int32_t k_misc_init[8] = { INT_MIN, 0, 0, 0, 0, 0, 0, 0 };
+
+extern "C" int32_t
+s3a_approx_cont_mgau_ci_eval(s3a_scorer_t *sc, const float *feat, int32_t *ci_senscr,
+                             int32_t *best_score, int32_t fr)
+{
+    struct s3a_mgau_dev_s *d;
+    if (!sc || !feat || !ci_senscr || !best_score)
+        return S3A_EINVAL;
+    d = sc->g->dev;
+    HIPCHK(hipMemcpyAsync(sc->x_d, feat, sizeof(float) * d->D, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(sc->misc_d, k_misc_init, sizeof k_misc_init, hipMemcpyHostToDevice, d->stream));
+    launch_gated(sc, 0, sc->n_ci_sen, 1, 0, fr, 0);
+    HIPCHK(hipGetLastError());
+    if (sc->n_ci_sen)
+        HIPCHK(hipMemcpyAsync(ci_senscr, sc->scr_d, sizeof(int32_t) * sc->n_ci_sen,
+                              hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(sc->misc_h, sc->misc_d, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    *best_score = sc->misc_h[0];        /* MAX_NEG_INT32 when there are no CI senones */
+    return S3A_OK;
+}
+
+/* approx_compute_dyn_ci_pbeam, approx_cont_mgau.c:303-357 (host: n_ci_sen is ~150) */
+static const int32_t *g_sort_key;
+static int
+cmp_ci_desc(const void *a, const void *b)
+{
+    return g_sort_key[*(const int32_t *)b] - g_sort_key[*(const int32_t *)a];
+}
+
+static int32_t
+dyn_ci_pbeam(s3a_scorer_t *sc, const uint8_t *sen_active, const int32_t *ci)
+{
+    int32_t s, total = 0, pbest;
+    for (s = 0; s < sc->n_sen; s++) {
+        if (s < sc->n_ci_sen)
+            sc->ci_occ_h[s] = 0;
+        else if (sen_active[s])
+            sc->ci_occ_h[sc->cd2cisen_h[s]]++;
+    }
+    for (s = 0; s < sc->n_ci_sen; s++)
+        sc->idx_h[s] = s;
+    g_sort_key = ci;
+    qsort(sc->idx_h, sc->n_ci_sen, sizeof(int32_t), cmp_ci_desc);
+    pbest = ci[sc->idx_h[0]];
+    sc->dyn_ci_pbeam = sc->ci_pbeam;
+    for (s = 0; s < sc->n_ci_sen && ci[sc->idx_h[s]] > pbest + sc->ci_pbeam; s++) {
+        total += sc->ci_occ_h[sc->idx_h[s]];
+        if (total > sc->max_cd) {
+            sc->dyn_ci_pbeam = ci[sc->idx_h[s]] - pbest;
+            break;
+        }
+    }
+    return sc->dyn_ci_pbeam;
+}
+
+extern "C" int32_t
+s3a_approx_cont_mgau_frame_eval(s3a_scorer_t *sc, uint8_t *sen_active, uint8_t *rec_sen_active,
+                                int32_t *senscr, const float *feat, int32_t frame,
+                                const int32_t *cache_ci_senscr, int32_t *best,
+                                int32_t *n_sen_eval, int32_t *n_gau_eval)
+{
+    struct s3a_mgau_dev_s *d;
+    int32_t beam, is_skip, pbest, s, ci_best;
+    int32_t init[8];
+
+    if (!sc || !sen_active || !senscr || !feat || !cache_ci_senscr || !best)
+        return S3A_EINVAL;
+    d = sc->g->dev;
+
+    /* host-side scalar logic of approx_cont_mgau.c:487-511 */
+    if (sc->max_cd < sc->n_sen - sc->n_ci_sen && sc->n_ci_sen > 0)
+        beam = dyn_ci_pbeam(sc, sen_active, cache_ci_senscr);
+    else
+        beam = sc->ci_pbeam;
+    is_skip = (frame % sc->ds_ratio == 0) ? 0 : 1;          /* approx_isskip without a selector */
+    if (is_skip)
+        beam = (int32_t)((float)beam * sc->tighten_factor);
+
+    /* CI senones: copied from the cache, forced active (approx_cont_mgau.c:529-538) */
+    pbest = S3A_MAX_NEG_INT32;
+    for (s = 0; s < sc->n_ci_sen; s++) {
+        if (pbest < cache_ci_senscr[s]) pbest = cache_ci_senscr[s];
+        sen_active[s] = 1;
+    }
+    ci_best = pbest;
+    memcpy(init, k_misc_init, sizeof init);
+    init[0] = ci_best;              /* best starts from the CI maximum */
+
+    HIPCHK(hipMemcpyAsync(sc->x_d, feat, sizeof(float) * d->D, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(sc->act_d, sen_active, sc->n_sen, hipMemcpyHostToDevice, d->stream));
+    if (sc->n_ci_sen)
+        HIPCHK(hipMemcpyAsync(sc->scr_d, cache_ci_senscr, sizeof(int32_t) * sc->n_ci_sen,
+                              hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(sc->misc_d, init, sizeof init, hipMemcpyHostToDevice, d->stream));
+    launch_gated(sc, sc->n_ci_sen, sc->n_sen, 0,
+                 (int32_t)((uint32_t)pbest + (uint32_t)beam), frame, is_skip);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_normalise, dim3((sc->n_sen + 255) / 256), dim3(256), 0, d->stream,
+                       sc->scr_d, sc->act_d, sc->misc_d, sc->n_sen);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(senscr, sc->scr_d, sizeof(int32_t) * sc->n_sen, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipMemcpyAsync(sc->misc_h, sc->misc_d, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (rec_sen_active)
+        memcpy(rec_sen_active, sen_active, sc->n_sen);
+    *best = sc->misc_h[0];
+    if (n_sen_eval) *n_sen_eval = sc->misc_h[1];
+    if (n_gau_eval) *n_gau_eval = sc->misc_h[2];
+    return S3A_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* composite senones                                                   */
+/* ------------------------------------------------------------------ */
+struct s3a_comsen_s {
+    int32_t n_comstate, n_list;
+    int32_t *off_d, *wt_d, *out_d, *scr_d;
+    int16_t *list_d;
+    size_t scr_cap;
+    hipStream_t stream;
+};
+
+__global__ void
+k_comsenscr(int32_t n, const int32_t *__restrict__ off, const int16_t *__restrict__ list,
+            const int32_t *__restrict__ wt, const int32_t *__restrict__ senscr,
+            int32_t *__restrict__ out)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t b = off[i], e = off[i + 1];
+    int32_t best = senscr[list[b]];
+    for (int32_t j = b + 1; j < e; j++)
+        best = max(best, senscr[list[j]]);
+    out[i] = (int32_t)((uint32_t)best + (uint32_t)wt[i]);
+}
+
+extern "C" s3a_comsen_t *
+s3a_comsen_init(int32_t n_comstate, const int32_t *comstate_off, const int16_t *comstate,
+                const int32_t *comwt)
+{
+    s3a_comsen_t *cs;
+    int32_t i, n_list;
+    if (n_comstate <= 0 || !comstate_off || !comstate || !comwt) {
+        s3a_set_error("s3a_comsen_init: bad arguments");
+        return NULL;
+    }
+    n_list = comstate_off[n_comstate];
+    for (i = 0; i < n_comstate; i++)
+        if (comstate_off[i + 1] <= comstate_off[i]) {
+            s3a_set_error("s3a_comsen_init: composite state %d has no member senone", i);
+            return NULL;
+        }
+    cs = (s3a_comsen_t *)calloc(1, sizeof *cs);
+    cs->n_comstate = n_comstate;
+    cs->n_list = n_list;
+    if (hipMalloc(&cs->off_d, 4 * (n_comstate + 1)) != hipSuccess
+        || hipMalloc(&cs->wt_d, 4 * n_comstate) != hipSuccess
+        || hipMalloc(&cs->out_d, 4 * n_comstate) != hipSuccess
+        || hipMalloc(&cs->list_d, 2 * n_list) != hipSuccess
+        || hipMemcpy(cs->off_d, comstate_off, 4 * (n_comstate + 1), hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(cs->wt_d, comwt, 4 * n_comstate, hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(cs->list_d, comstate, 2 * n_list, hipMemcpyHostToDevice) != hipSuccess
+        || hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking) != hipSuccess) {
+        s3a_set_error("s3a_comsen_init: device allocation failed");
+        s3a_comsen_free(cs);
+        return NULL;
+    }
+    return cs;
+}
+
+extern "C" void
+s3a_comsen_free(s3a_comsen_t *cs)
+{
+    if (!cs) return;
+    (void)hipFree(cs->off_d); (void)hipFree(cs->wt_d); (void)hipFree(cs->out_d);
+    (void)hipFree(cs->list_d); (void)hipFree(cs->scr_d);
+    if (cs->stream) (void)hipStreamDestroy(cs->stream);
+    free(cs);
+}
+
+extern "C" int32_t
+s3a_dict2pid_comsenscr(s3a_comsen_t *cs, const int32_t *senscr, int32_t n_sen, int32_t *comsenscr)
+{
+    int32_t rc;
+    if (!cs || !senscr || !comsenscr || n_sen <= 0)
+        return S3A_EINVAL;
+    if ((rc = s3a_dev_grow((void **)&cs->scr_d, &cs->scr_cap, (size_t)n_sen * 4)) != S3A_OK)
+        return rc;
+    HIPCHK(hipMemcpyAsync(cs->scr_d, senscr, (size_t)n_sen * 4, hipMemcpyHostToDevice, cs->stream));
+    hipLaunchKernelGGL(k_comsenscr, dim3((cs->n_comstate + 255) / 256), dim3(256), 0, cs->stream,
+                       cs->n_comstate, cs->off_d, cs->list_d, cs->wt_d, cs->scr_d, cs->out_d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(comsenscr, cs->out_d, (size_t)cs->n_comstate * 4, hipMemcpyDeviceToHost, cs->stream));
+    HIPCHK(hipStreamSynchronize(cs->stream));
+    return S3A_OK;
+}

@@ -44,6 +44,8 @@ _SIGS = {
                                    C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]),
     "s3a_mgau_init_arrays": (C.c_void_p, [C.c_void_p] * 3 + [C.c_int32] * 3 +
                              [C.c_double, C.c_double, C.c_int32, C.c_void_p]),
+    "s3a_mgau_load_host": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_double,
+                                        C.c_int32, C.c_void_p]),
     "s3a_mgau_free": (None, [C.c_void_p]),
     "s3a_mgau_n_mgau": (C.c_int32, [C.c_void_p]),
     "s3a_mgau_max_comp": (C.c_int32, [C.c_void_p]),
@@ -73,6 +75,7 @@ _SIGS = {
     "s3a_dict2pid_comsenscr": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_tmat_init": (C.c_void_p, [C.c_char_p, C.c_double, C.c_int32, C.c_void_p]),
     "s3a_tmat_init_arrays": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p]),
+    "s3a_tmat_init_logs3": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "s3a_tmat_free": (None, [C.c_void_p]),
     "s3a_tmat_n_tmat": (C.c_int32, [C.c_void_p]),
     "s3a_tmat_n_state": (C.c_int32, [C.c_void_p]),
@@ -234,6 +237,17 @@ class MgauModel:
         return cls(h, lm)
 
     @classmethod
+    def load_host(cls, meanfile, varfile, mixwfile, lm: LogMath, varfloor=1e-4, mixwfloor=1e-7,
+                  precomp=1):
+        """Loader only (no upload): parameters can be inspected, scoring fails with ENODEV."""
+        L = load()
+        h = L.s3a_mgau_load_host(meanfile.encode(), varfile.encode(), varfloor, mixwfile.encode(),
+                                 mixwfloor, precomp, lm.h)
+        if not h:
+            raise S3AError(_err(L))
+        return cls(h, lm)
+
+    @classmethod
     def init_arrays(cls, mean, var, mixw, lm: LogMath, varfloor=1e-4, mixwfloor=1e-7, precomp=1):
         L = load()
         mean = np.ascontiguousarray(mean, np.float32)
@@ -296,3 +310,196 @@ class MgauModel:
                                             frames_per_launch, iters, C.byref(us), C.byref(kus),
                                             C.byref(nl)))
         return us.value, kus.value, nl.value
+
+
+class Scorer:
+    """fast_gmm_t + approx_cont_mgau_{ci,frame}_eval + the ascr_t buffers they fill."""
+
+    def __init__(self, g: MgauModel, cd2cisen, n_ci_sen, ds_ratio=1, cond_ds=0, ci_pbeam=1e-80,
+                 tighten_factor=0.5, max_cd=100000):
+        self.L = load()
+        self.g = g
+        self.cd2cisen = np.ascontiguousarray(cd2cisen, np.int16)
+        self.n_sen = len(self.cd2cisen)
+        self.n_ci_sen = int(n_ci_sen)
+        self.h = self.L.s3a_scorer_init(g.h, _p(self.cd2cisen), self.n_sen, self.n_ci_sen,
+                                        ds_ratio, cond_ds, ci_pbeam, tighten_factor, max_cd)
+        if not self.h:
+            raise S3AError(_err(self.L))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_scorer_free(self.h)
+            self.h = None
+
+    def utt_begin(self):
+        check(self.L.s3a_scorer_utt_begin(self.h))
+
+    def ci_eval(self, feat, fr):
+        feat = np.ascontiguousarray(feat, np.float32)
+        ci = np.zeros(max(self.n_ci_sen, 1), np.int32)
+        best = C.c_int32(0)
+        check(self.L.s3a_approx_cont_mgau_ci_eval(self.h, _p(feat), _p(ci), C.byref(best), int(fr)))
+        return ci[:self.n_ci_sen], best.value
+
+    def frame_eval(self, sen_active, senscr, feat, frame, cache_ci_senscr):
+        """In-place on sen_active / senscr like the reference; returns (best, ns, ng, rec_active)."""
+        feat = np.ascontiguousarray(feat, np.float32)
+        ci = np.ascontiguousarray(cache_ci_senscr, np.int32)
+        rec = np.zeros(self.n_sen, np.uint8)
+        best, ns, ng = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(self.L.s3a_approx_cont_mgau_frame_eval(self.h, _p(sen_active), _p(rec), _p(senscr),
+                                                     _p(feat), int(frame), _p(ci), C.byref(best),
+                                                     C.byref(ns), C.byref(ng)))
+        return best.value, ns.value, ng.value, rec
+
+    def frame_eval_seq(self, feats, active=None):
+        """ci_eval + frame_eval over a sequence, as srch_utt_decode_blk with -pl_window 1."""
+        feats = np.ascontiguousarray(feats, np.float32)
+        T, S = feats.shape[0], self.n_sen
+        out = dict(senscr=np.zeros((T, S), np.int32), best=np.zeros(T, np.int32),
+                   ci_best=np.zeros(T, np.int32), sen_active_out=np.zeros((T, S), np.uint8),
+                   bstidx=np.zeros((T, S), np.int32), updatetime=np.zeros((T, S), np.int32),
+                   counts=np.zeros((T, 2), np.int32))
+        cur = np.zeros(S, np.int32)
+        sa = np.zeros(S, np.uint8)
+        self.utt_begin()
+        for t in range(T):
+            ci, cb = self.ci_eval(feats[t], t)
+            out["ci_best"][t] = cb
+            sa[:] = 1 if active is None else active[t]
+            b, ns, ng, _ = self.frame_eval(sa, cur, feats[t], t, ci)
+            out["best"][t] = b
+            out["counts"][t] = (ns, ng)
+            out["senscr"][t] = cur
+            out["sen_active_out"][t] = sa
+            bi, _, ut = self.g.state()
+            out["bstidx"][t] = bi
+            out["updatetime"][t] = ut
+        return out
+
+
+class ComSen:
+    """dict2pid_comsenscr over flattened comstate lists."""
+
+    def __init__(self, comstate_off, comstate, comwt):
+        self.L = load()
+        self.off = np.ascontiguousarray(comstate_off, np.int32)
+        self.lst = np.ascontiguousarray(comstate, np.int16)
+        self.wt = np.ascontiguousarray(comwt, np.int32)
+        self.n = len(self.wt)
+        self.h = self.L.s3a_comsen_init(self.n, _p(self.off), _p(self.lst), _p(self.wt))
+        if not self.h:
+            raise S3AError(_err(self.L))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_comsen_free(self.h)
+            self.h = None
+
+    def comsenscr(self, senscr):
+        senscr = np.ascontiguousarray(senscr, np.int32)
+        out = np.zeros(self.n, np.int32)
+        check(self.L.s3a_dict2pid_comsenscr(self.h, _p(senscr), len(senscr), _p(out)))
+        return out
+
+
+class Tmat:
+    """tmat_t: transition matrices converted to logs3 (host-side object)."""
+
+    def __init__(self, h, lm):
+        self.L = load()
+        self.h = h
+        self.lm = lm
+        self.n_tmat = self.L.s3a_tmat_n_tmat(h)
+        self.n_state = self.L.s3a_tmat_n_state(h)
+
+    @classmethod
+    def init(cls, path, lm: LogMath, tpfloor=1e-4):
+        L = load()
+        h = L.s3a_tmat_init(path.encode(), tpfloor, 0, lm.h)
+        if not h:
+            raise S3AError(_err(L))
+        return cls(h, lm)
+
+    @classmethod
+    def init_arrays(cls, tp, lm: LogMath, tpfloor=1e-4):
+        L = load()
+        tp = np.ascontiguousarray(tp, np.float32)
+        h = L.s3a_tmat_init_arrays(_p(tp), tp.shape[0], tp.shape[1], tpfloor, lm.h)
+        if not h:
+            raise S3AError(_err(L))
+        return cls(h, lm)
+
+    @classmethod
+    def init_logs3(cls, tp_int):
+        L = load()
+        tp_int = np.ascontiguousarray(tp_int, np.int32)
+        h = L.s3a_tmat_init_logs3(_p(tp_int), tp_int.shape[0], tp_int.shape[1])
+        if not h:
+            raise S3AError(_err(L))
+        return cls(h, None)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_tmat_free(self.h)
+            self.h = None
+
+    @property
+    def tp(self):
+        out = np.zeros((self.n_tmat, self.n_state, self.n_state + 1), np.int32)
+        check(self.L.s3a_tmat_get_tp(self.h, _p(out)))
+        return out
+
+
+class HmmBatch:
+    """An array of hmm_t on the GPU (structure of arrays) + hmm_vit_eval on all of them."""
+
+    def __init__(self, n_hmm, tmat: Tmat, sseq, n_sen):
+        self.L = load()
+        self.tmat = tmat
+        self.sseq = np.ascontiguousarray(sseq, np.int16)
+        self.n = int(n_hmm)
+        self.ne = tmat.n_state
+        self.h = self.L.s3a_hmm_batch_init(self.n, self.ne, tmat.h, _p(self.sseq),
+                                           self.sseq.shape[0], int(n_sen))
+        if not self.h:
+            raise S3AError(_err(self.L))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_hmm_batch_free(self.h)
+            self.h = None
+
+    def setup(self, mpx, ssid, tmatid):
+        check(self.L.s3a_hmm_batch_setup(self.h, _p(np.ascontiguousarray(mpx, np.uint8)),
+                                         _p(np.ascontiguousarray(ssid, np.int32)),
+                                         _p(np.ascontiguousarray(tmatid, np.int32))))
+
+    def clear(self, idx=None):
+        if idx is None:
+            check(self.L.s3a_hmm_batch_clear(self.h, None, 0))
+        else:
+            idx = np.ascontiguousarray(idx, np.int32)
+            check(self.L.s3a_hmm_batch_clear(self.h, _p(idx), len(idx)))
+
+    def enter(self, idx, score, histid, frame):
+        idx = np.ascontiguousarray(idx, np.int32)
+        check(self.L.s3a_hmm_batch_enter(self.h, _p(idx), _p(np.ascontiguousarray(score, np.int32)),
+                                         _p(np.ascontiguousarray(histid, np.int64)), len(idx), int(frame)))
+
+    def vit_eval(self, senscr):
+        senscr = np.ascontiguousarray(senscr, np.int32)
+        ret = np.zeros(self.n, np.int32)
+        check(self.L.s3a_hmm_batch_vit_eval(self.h, _p(senscr), _p(ret)))
+        return ret
+
+    def get(self):
+        n = self.n
+        score = np.zeros((n, 5), np.int32); hist = np.zeros((n, 5), np.int64)
+        out_score = np.zeros(n, np.int32); out_hist = np.zeros(n, np.int64)
+        best = np.zeros(n, np.int32); mpx_ssid = np.zeros((n, 5), np.int32); frame = np.zeros(n, np.int32)
+        check(self.L.s3a_hmm_batch_get(self.h, _p(score), _p(hist), _p(out_score), _p(out_hist),
+                                       _p(best), _p(mpx_ssid), _p(frame)))
+        return dict(score=score, hist=hist, out_score=out_score, out_hist=out_hist, bestscore=best,
+                    mpx_ssid=mpx_ssid, frame=frame)

@@ -167,3 +167,67 @@ def read_mfc(path: str) -> np.ndarray:
         if n * 4 + 4 != size:
             raise ValueError(f"{path}: header count does not match file size")
     return np.fromfile(path, dtype=bo + "f4", offset=4, count=n).astype("<f4")
+
+
+def read_mdef(path: str) -> dict:
+    """Sphinx-3 text model-definition file (reference:
+    sphinx3/src/libs3decoder/libam/mdef.c:672-842 mdef_init, :603-656
+    sseq_compress).  Returns the arrays the hot path needs:
+
+    n_ciphone, n_phone, n_emit_state, n_ci_sen, n_sen, n_tmat,
+    ciphone names, per-phone (ci, lc, rc, wpos, tmat, filler),
+    phone_ssid [n_phone], sseq [n_sseq][n_emit] int16 (unique state sequences
+    in first-occurrence order, as sseq_compress numbers them),
+    cd2cisen [n_sen] int16 (mdef.c:819-836).
+    """
+    with open(path, "r") as f:
+        lines = [ln.rstrip("\n") for ln in f if not ln.startswith("#")]
+    it = iter(lines)
+    ver = next(it).strip()
+    if ver != "0.3":
+        raise ValueError(f"{path}: version {ver}, expecting 0.3")
+    hdr = {}
+    for _ in range(6):
+        val, tag = next(it).split()[:2]
+        hdr[tag] = int(val)
+    n_ci, n_tri = hdr["n_base"], hdr["n_tri"]
+    n_phone = n_ci + n_tri
+    n_sen, n_ci_sen, n_tmat = hdr["n_tied_state"], hdr["n_tied_ci_state"], hdr["n_tied_tmat"]
+    if hdr["n_state_map"] % n_phone:
+        raise ValueError(f"{path}: n_state_map not a multiple of #phones")
+    n_emit = hdr["n_state_map"] // n_phone - 1
+    names, name2id = [], {}
+    phones = np.zeros((n_phone, 6), np.int32)        # ci lc rc wpos tmat filler
+    states = np.zeros((n_phone, n_emit), np.int16)
+    wpos_code = {"-": -1, "b": 0, "e": 1, "s": 2, "i": 3}
+    for p in range(n_phone):
+        tok = next(it).split()
+        base, lft, rt, wp, attrib, tmat = tok[:6]
+        st = tok[6:6 + n_emit]
+        if tok[6 + n_emit] != "N":
+            raise ValueError(f"{path}: phone {p}: missing non-emitting state N")
+        if p < n_ci:
+            name2id[base] = p
+            names.append(base)
+            phones[p] = (p, -1, -1, -1, int(tmat), int(attrib == "filler"))
+        else:
+            phones[p] = (name2id[base], name2id[lft], name2id[rt], wpos_code[wp], int(tmat),
+                         int(attrib == "filler"))
+        states[p] = [int(x) for x in st]
+    # sseq_compress: unique sequences numbered by first occurrence over phones
+    seen, sseq, ssid = {}, [], np.zeros(n_phone, np.int32)
+    for p in range(n_phone):
+        key = states[p].tobytes()
+        if key not in seen:
+            seen[key] = len(sseq)
+            sseq.append(states[p].copy())
+        ssid[p] = seen[key]
+    cd2cisen = np.zeros(n_sen, np.int16)
+    cd2cisen[:n_ci_sen] = np.arange(n_ci_sen)
+    for p in range(n_ci, n_phone):
+        ci = phones[p, 0]
+        for s in range(n_emit):
+            cd2cisen[states[p, s]] = states[ci, s]
+    return dict(n_ciphone=n_ci, n_phone=n_phone, n_emit_state=n_emit, n_ci_sen=n_ci_sen,
+                n_sen=n_sen, n_tmat=n_tmat, ciphone=names, phones=phones, states=states,
+                phone_ssid=ssid, sseq=np.array(sseq, np.int16), cd2cisen=cd2cisen)

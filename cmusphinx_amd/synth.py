@@ -5,7 +5,7 @@ means / variances are absent from the reference checkout, SURVEY.md "facts"
 item 1), but its dimensions are fully known: 6144 senones (144 CI first),
 8 Gaussians, 39-dim 1s_c_d_dd features, 48 3-state transition matrices.  This
 module writes models of that SHAPE with seeded synthetic values, in the
-reference's own file formats, so that the reference (oracle/_ref), the oracle
+reference's own file formats, so that the unmodified reference, the CPU oracle
 restatement and the HIP path all load the very same files.
 
 Determinism: everything derives from numpy's PCG64 with an explicit seed and

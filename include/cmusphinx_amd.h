@@ -112,6 +112,14 @@ s3a_mgau_model_t *s3a_mgau_init_arrays(const float *mean, const float *var, cons
                                        int32_t n_mgau, int32_t n_density, int32_t veclen,
                                        double varfloor, double mixwfloor, int32_t precomp,
                                        s3a_logmath_t *logmath);
+/*
+ * Host-only load: everything mgau_init does up to, but excluding, the upload.
+ * For model tools and for checking the loader where no GPU exists; every
+ * scoring entry point fails with S3A_ENODEV on such a handle (no CPU scoring).
+ */
+s3a_mgau_model_t *s3a_mgau_load_host(const char *meanfile, const char *varfile, double varfloor,
+                                     const char *mixwfile, double mixwfloor, int32_t precomp,
+                                     s3a_logmath_t *logmath);
 void    s3a_mgau_free(s3a_mgau_model_t *g);                 /* mgau_free, cont_mgau.c:1210 */
 int32_t s3a_mgau_n_mgau(const s3a_mgau_model_t *g);         /* mgau_n_mgau   cont_mgau.h:229 */
 int32_t s3a_mgau_max_comp(const s3a_mgau_model_t *g);       /* mgau_max_comp cont_mgau.h:230 */
@@ -228,6 +236,9 @@ s3a_tmat_t *s3a_tmat_init(const char *tmatfile, double tpfloor, int32_t breport,
                           s3a_logmath_t *logmath);
 s3a_tmat_t *s3a_tmat_init_arrays(const float *tp, int32_t n_tmat, int32_t n_state,
                                  double tpfloor, s3a_logmath_t *logmath);
+/* adopt an already-converted matrix set: tp[n_tmat][n_state][n_state+1] logs3 values
+ * (what a host that keeps its own tmat_t passes: tmat_t.tp, sphinx3/include/tmat.h) */
+s3a_tmat_t *s3a_tmat_init_logs3(const int32_t *tp, int32_t n_tmat, int32_t n_state);
 void    s3a_tmat_free(s3a_tmat_t *t);
 int32_t s3a_tmat_n_tmat(const s3a_tmat_t *t);
 int32_t s3a_tmat_n_state(const s3a_tmat_t *t);
