@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- senone-scoring throughput of the MI355X-native backend on the
+hub4-shaped CD-GMM model (BASELINE.json configs[1]).
+
+A "step" = one pass of the hot path over one utterance: T = 1000 frames (10 s of
+16 kHz audio at 100 frames/s) scored against all 6144 senones x 8 Gaussians x
+39 dims, i.e. senscr[t][s] = mgau_eval(g, s, NULL, feat[t], t, 1) plus the
+per-frame best (what sphinx3's gmm_compute_lv2 produces frame by frame with
+every senone active and the default -ci_pbeam).  Features are resident in HBM
+before the timed region and the scores stay in HBM.  Arithmetic is the
+bit-exact mode (float32 subtract, float64 accumulate, int32 log-add): the same
+integers as the reference, checked before timing against the CPU oracle.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: utterances shard embarrassingly: each rank scores
+its own utterances (weak scaling, no data-path collective); ONE RCCL all_gather
+of fixed-size per-utterance result records closes the timed region.
+
+Prints ONE JSON line (rank 0).  Extra keys beyond the driver contract:
+  roofline      dominant kernel (k_score_frames) vs HBM peak on ALGORITHMIC bytes
+                (15.73 MB model once per launch + 24.7 KB per frame)
+                plus "valu": its float64 issue-rate fraction -- the bound that
+                actually binds in whole-utterance mode
+  frame_sync    the same kernel launched one frame at a time (the decoder's
+                frame-synchronous regime, B=1): per-launch time and the
+                algorithmic-bytes/s figure the north star's 60% target refers to
+  cpu_baseline  the UNMODIFIED reference (oracle/_ref/ref_dump bench_mgau ->
+                approx_cont_mgau_frame_eval) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VEC_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (FMA counted as 2 flops)
+
+
+def cpu_baseline(model, feats, sample_frames, procs):
+    """Time the reference's own C scoring path on the host (bounded sample)."""
+    from cmusphinx_amd import synth
+    rd = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    d = tempfile.mkdtemp(prefix="s3a_cpu_")
+    synth.write_model(d, model, chksum=False)
+    n = min(sample_frames, len(feats))
+    feats[:n].tofile(os.path.join(d, "x.f32"))
+
+    def run_ref(nproc):
+        cmd = [rd, "bench_mgau", os.path.join(d, "means"), os.path.join(d, "variances"),
+               os.path.join(d, "mixture_weights"), "1.0003", os.path.join(d, "x.f32"), str(n)]
+        t0 = time.time()
+        ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(nproc)]
+        outs = [p.communicate()[0] for p in ps]
+        wall = time.time() - t0
+        secs = [float(o.split()[3]) for o in outs]
+        return n * nproc / max(secs), wall
+
+    if os.path.exists(rd):
+        one, _ = run_ref(1)
+        agg, _ = run_ref(procs) if procs > 1 else (one, 0)
+        kind = "reference"
+        what = "oracle/_ref/ref_dump bench_mgau: unmodified sphinx3 approx_cont_mgau_ci_eval + " \
+               "approx_cont_mgau_frame_eval, gcc -O2, all senones active"
+    else:
+        # CPU port = the oracle restatement (only when the reference build did not travel)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        og = O.OracleMgau(model["mean"], model["var"], model["mixw"], O.OracleLogMath(1.0003))
+        n = min(n, 64)
+        t0 = time.time()
+        og.score_all(feats[:n])
+        one = agg = n / (time.time() - t0)
+        procs = 1
+        kind = "port"
+        what = "oracle/libs3oracle.so s3o_mgau_eval (plain-C restatement), 1 thread"
+    return {"value": round(agg, 1), "unit": "frames/s", "cores": procs, "kind": kind,
+            "single_core": round(one, 1),
+            "sample": f"{n} frames of the same hub4-shaped workload per process; {what}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per utterance (10 s)")
+    ap.add_argument("--cpu-frames", type=int, default=3000, help="CPU-baseline sample per process")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cmusphinx_amd import lib, synth
+    L = lib.load()
+    if lib.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libcmusphinx_amd has no CPU fallback")
+    lib.check(L.s3a_set_device(local_rank))
+
+    T = args.frames
+    model = synth.make_model(**synth.HUB4)
+    lm = lib.LogMath(1.0003)
+    gm = lib.MgauModel.init_arrays(model["mean"], model["var"], model["mixw"], lm)
+    if args.fast:
+        gm.set_precision(lib.GMM_FAST)
+    S, C, D = gm.S, gm.C, gm.D
+    # one distinct synthetic utterance per rank and step slot (seed = utterance index)
+    n_utt = 4
+    feats = [synth.make_features(model, T, seed=7 + rank * n_utt + u) for u in range(n_utt)]
+    fdev = [lib.DevBuf(f.nbytes).upload(f) for f in feats]
+    sdev = lib.DevBuf(T * S * 4)
+    bdev = lib.DevBuf(T * 4)
+
+    # ---- correctness gate before timing: HIP vs CPU oracle on a few frames ----
+    if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        og = O.OracleMgau(model["mean"], model["var"], model["mixw"], O.OracleLogMath(1.0003))
+        pick = [0, T // 2, T - 1]
+        got = gm.score_frames(feats[0][pick], want_best=False)
+        exp = og.score_all(feats[0][pick])
+        if args.fast:
+            assert np.abs(got.astype(np.int64) - exp).max() <= 2, "fast mode outside its tolerance"
+        else:
+            assert np.array_equal(got, exp), "HIP scores differ from the oracle"
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        lib.check(L.s3a_dev_sync())
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+
+    def step(i):
+        # asynchronous: k_score_frames + k_frame_best enqueued on the model's stream
+        gm.score_frames_dev(fdev[i % n_utt], T, sdev, bdev)
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    t0 = time.perf_counter()
+    gm.timer_begin()                    # HIP event on the launch stream
+    for i in range(args.steps):
+        step(i)
+    ev_us = gm.timer_end()              # second event + wait: GPU time of the K steps
+    if dist is not None:
+        # the one exchange of the job: fixed-size per-utterance result records to all ranks
+        import torch
+        best = bdev.download(np.int32, (T,))
+        rec = torch.tensor([rank, T, int(best.astype(np.int64).sum())], dtype=torch.int64,
+                           device=f"cuda:{local_rank}")
+        out = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(out, rec)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        frames_total = world * args.steps * T
+        value = frames_total / dt
+        # ---- roofline of the dominant kernel (k_score_frames), live HIP-event timing ----
+        k_us = ev_us / args.steps                       # one launch of k_score_frames + k_frame_best
+        n_gau = S * C
+        model_bytes = n_gau * (2 * D + 2) * 4           # means + precisions + lrd + mixw, once per launch
+        frame_bytes = D * 4 + S * 4                     # feature vector in, int32 scores out
+        alg_bytes = model_bytes + T * frame_bytes
+        achieved = alg_bytes / (k_us * 1e-6) / 1e9
+        flops = 4.0 * n_gau * D * T                     # sub, mul, mul, sub per Gaussian-dimension
+        tflops = flops / (k_us * 1e-6) / 1e12
+        # ---- frame-synchronous regime: one frame per launch (B = 1) ----
+        gm.bench(fdev[0], T, sdev, None, 1, 1)
+        fs_us, fs_kus, fs_n = gm.bench(fdev[0], T, sdev, None, 1, 3)
+        fs_bytes = model_bytes + frame_bytes
+        fs_gbs = fs_bytes / (fs_kus * 1e-6) / 1e9
+        res = {
+            "metric": "senone_scoring_frames_per_sec (hub4-shaped CD-GMM 6144x8x39, xRT = value/100/n_gpus)",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32-sub/f64-acc/int32-logadd (bit-exact)" if not args.fast else "f32",
+            "data": "synthetic (seeded hub4-shaped model + AR(1) features; real hub4 parameters are not distributable)",
+            "config": {"workload": "configs[1]: hub4_cd_continuous shape, 1 utterance x 1000 frames per step, "
+                                   "senone scoring only (all 6144 senones, 8 Gaussians, 39 dims)",
+                       "frames_per_step": T, "utterances_per_step_per_gpu": 1,
+                       "parallelism": f"utterance-sharded x{world}, one all_gather of result records"},
+            "xRT_per_gpu": round(value / world / 100.0, 1),
+            "roofline": {"kernel": "k_score_frames<8,exact,lds-table,512>", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_us": round(k_us, 2),
+                         "valu": {"bound": "valu-f64", "achieved": round(tflops, 2),
+                                  "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tflops / FP64_VEC_PEAK_TFLOPS, 4),
+                                  "note": "4 non-fusable flops per Gaussian-dim (bit-exactness forbids FMA): "
+                                          "the issue-rate ceiling is peak/2"}},
+            "frame_sync": {"frames_per_launch": 1, "launches": fs_n, "avg_launch_us": round(fs_kus, 3),
+                           "frames_per_sec": round(T / (fs_us * 1e-6), 1),
+                           "algorithmic_bytes_per_launch": fs_bytes,
+                           "achieved_GBs": round(fs_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
+                           "frac": round(fs_gbs / HBM_PEAK_GBS, 4)},
+        }
+        if not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(model, feats[0], args.cpu_frames,
+                                               procs=os.cpu_count() or 1)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,7 @@ struct s3a_mgau_dev_s {
     int32_t *scr_buf;  size_t scr_cap;
     int32_t *best_buf; size_t best_cap;
     int32_t n_cu;
+    hipEvent_t ev0, ev1;        /* s3a_stream_timer_* */
 };
 
 

@@ -193,6 +193,7 @@ s3a_mgau_dev_destroy(s3a_mgau_model_t *g)
     hipFree(d->bstidx); hipFree(d->bstscr); hipFree(d->updatetime);
     hipFree(d->feat_buf); hipFree(d->scr_buf); hipFree(d->best_buf);
     if (d->stream) hipStreamDestroy(d->stream);
+    if (d->ev0) { hipEventDestroy(d->ev0); hipEventDestroy(d->ev1); }
     free(d);
     g->dev = NULL;
 }
@@ -491,25 +492,42 @@ pick_nt(void)
     return nt;
 }
 
+/*
+ * Frames per chunk.  A workgroup of the utterance kernel needs ~100 KB of LDS
+ * (table + transpose tiles + its chunk's features), so ONE workgroup is resident
+ * per CU and the grid executes in rounds of n_cu workgroups.  Time is
+ * proportional to rounds x (frames per chunk + a fixed start-up cost of loading
+ * the table and the Gaussians, worth about 10 frames): pick the chunk count that
+ * minimises it, so that e.g. 96 tiles x 8 chunks = 768 = 3 full rounds of 256.
+ */
 static int32_t
 pick_fpc(const struct s3a_mgau_dev_s *d, int32_t n_frames, int32_t nt)
 {
     static int32_t forced = -1;
     int32_t n_tiles = d->Gpad / nt;
-    int32_t want_blocks = 2 * d->n_cu;
-    int32_t n_chunks = (want_blocks + n_tiles - 1) / n_tiles;
-    int32_t fpc;
+    int32_t best_fpc = FB, nc;
+    int64_t best_cost = -1;
     if (forced < 0) forced = env_int("S3A_SCORE_FPC", 0);
-    if (forced > 0)
-        fpc = forced;
-    else {
-        if (n_chunks < 1) n_chunks = 1;
-        fpc = (n_frames + n_chunks - 1) / n_chunks;
+    if (forced > 0) {
+        int32_t f = ((forced + FB - 1) / FB) * FB;
+        return f > 256 ? 256 : f;
     }
-    fpc = ((fpc + FB - 1) / FB) * FB;
-    if (fpc < FB) fpc = FB;
-    if (fpc > 256) fpc = 256;       /* 40 KB of LDS for features at most */
-    return fpc;
+    for (nc = 1; nc <= 128; nc++) {
+        int32_t fpc = (n_frames + nc - 1) / nc;
+        int32_t chunks, rounds;
+        int64_t cost;
+        fpc = ((fpc + FB - 1) / FB) * FB;
+        if (fpc > 256) continue;            /* 40 KB of LDS for features at most */
+        chunks = (n_frames + fpc - 1) / fpc;
+        rounds = (n_tiles * chunks + d->n_cu - 1) / d->n_cu;
+        cost = (int64_t)rounds * (fpc + 10);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_fpc = fpc;
+        }
+        if (fpc <= FB) break;
+    }
+    return best_fpc;
 }
 
 static int32_t
@@ -848,5 +866,33 @@ s3a_bench_score_frames(s3a_mgau_model_t *g, const float *feat_dev, int32_t n_fra
     if (avg_us) *avg_us = (double)ms * 1000.0 / iters;
     if (avg_kernel_us) *avg_kernel_us = (double)ms * 1000.0 / iters / launches;
     if (n_launches) *n_launches = launches;
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_stream_timer_begin(s3a_mgau_model_t *g)
+{
+    struct s3a_mgau_dev_s *d;
+    if (!g || !g->dev) return S3A_EINVAL;
+    d = g->dev;
+    if (!d->ev0) {
+        HIPCHK(hipEventCreate(&d->ev0));
+        HIPCHK(hipEventCreate(&d->ev1));
+    }
+    HIPCHK(hipEventRecord(d->ev0, d->stream));
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_stream_timer_end(s3a_mgau_model_t *g, double *elapsed_us)
+{
+    struct s3a_mgau_dev_s *d;
+    float ms = 0.0f;
+    if (!g || !g->dev || !g->dev->ev0 || !elapsed_us) return S3A_EINVAL;
+    d = g->dev;
+    HIPCHK(hipEventRecord(d->ev1, d->stream));
+    HIPCHK(hipEventSynchronize(d->ev1));
+    HIPCHK(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+    *elapsed_us = (double)ms * 1000.0;
     return S3A_OK;
 }

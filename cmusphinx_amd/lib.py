@@ -90,6 +90,8 @@ _SIGS = {
     "s3a_bench_score_frames": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_int32, C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "s3a_stream_timer_begin": (C.c_int32, [C.c_void_p]),
+    "s3a_stream_timer_end": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double)]),
     "s3a_dev_malloc": (C.c_void_p, [C.c_size_t]),
     "s3a_dev_free": (C.c_int32, [C.c_void_p]),
     "s3a_dev_upload": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -302,6 +304,19 @@ class MgauModel:
         best = np.empty(T, np.int32) if want_best else None
         check(self.L.s3a_mgau_score_frames(self.h, _p(feat), T, _p(out), _p(best)))
         return (out, best) if want_best else out
+
+    def score_frames_dev(self, feat_dev: DevBuf, n_frames, scr_dev: DevBuf, best_dev=None):
+        """Asynchronous, device-resident: enqueue on the model's stream and return."""
+        check(self.L.s3a_mgau_score_frames_dev(self.h, feat_dev.ptr, n_frames, scr_dev.ptr,
+                                               best_dev.ptr if best_dev else None, None))
+
+    def timer_begin(self):
+        check(self.L.s3a_stream_timer_begin(self.h))
+
+    def timer_end(self):
+        us = C.c_double()
+        check(self.L.s3a_stream_timer_end(self.h, C.byref(us)))
+        return us.value
 
     def bench(self, feat_dev: DevBuf, n_frames, scr_dev: DevBuf, best_dev, frames_per_launch, iters):
         us, kus, nl = C.c_double(), C.c_double(), C.c_int32()

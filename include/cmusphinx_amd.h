@@ -289,6 +289,12 @@ int32_t s3a_bench_score_frames(s3a_mgau_model_t *g, const float *feat_dev, int32
                                int32_t iters, double *avg_us, double *avg_kernel_us,
                                int32_t *n_launches);
 
+/* HIP-event stopwatch on the model's launch stream: begin records an event,
+ * end records a second one, waits for it and returns the elapsed microseconds
+ * of everything enqueued on that stream in between. */
+int32_t s3a_stream_timer_begin(s3a_mgau_model_t *g);
+int32_t s3a_stream_timer_end(s3a_mgau_model_t *g, double *elapsed_us);
+
 /* raw device-memory helpers so a C host (or ctypes) can stage buffers
  * without linking the HIP runtime itself */
 void   *s3a_dev_malloc(size_t nbytes);

@@ -16,6 +16,8 @@
  *           CIPBEAM DS TIGHTEN MAXCD OUTDIR
  *   tmat    TMATFILE TPFLOOR LOGBASE SHIFT OUTDIR
  *   feat    MFCFILE OUTDIR          (1s_c_d_dd, -cmn current, -agc none, -varnorm no)
+ *   bench_mgau MEAN VAR MIXW LOGBASE FEAT.f32 T   (times approx_cont_mgau_frame_eval with every
+ *           senone active; prints "frames T seconds S" -- the CPU baseline of bench.py)
  *   hmm     NEMIT TP.i32 NTMAT SSEQ.i16 NSSEQ SENSCR.i32 NSEN T SPEC.i32 NHMM ENTER.i32 OUTDIR
  */
 #include <stdio.h>
@@ -355,6 +357,49 @@ cmd_hmm(int argc, char **argv)
     return 0;
 }
 
+/*
+ * CPU baseline: the reference's own per-frame scoring path
+ * (approx_cont_mgau_ci_eval + approx_cont_mgau_frame_eval, every senone active,
+ * default -ci_pbeam 1e-80) over T frames; model load excluded from the timing.
+ */
+#include <time.h>
+static int
+cmd_bench_mgau(int argc, char **argv)
+{
+    logmath_t *lm = logs3_init(atof(argv[3]), 0, 1);
+    mgau_model_t *g = load_mgau(argv[0], argv[1], argv[2], 0.0001, 0.0000001, lm);
+    size_t nb;
+    float *feat = slurp(argv[4], &nb);
+    int32 T = atoi(argv[5]), S = g->n_mgau, D = g->veclen, t, s;
+    int32 n_ci = (S >= 144) ? 144 : S / 4;
+    fast_gmm_t *fg = fast_gmm_init(1, 0, 0, 1, 0, 3.2e-5, 1e-80, 0.5f, 100000, n_ci, lm);
+    ascr_t *a = ascr_init(S, 0, 1, 0, 1, n_ci);
+    s3senid_t *c2c = calloc(S, sizeof(s3senid_t));
+    mdef_t md;
+    ptmr_t tm;
+    struct timespec t0, t1;
+    long long chk = 0;
+
+    if (nb < (size_t)T * D * 4) { fprintf(stderr, "feat too short\n"); return 2; }
+    for (s = 0; s < S; s++) c2c[s] = (s < n_ci) ? s : (s % n_ci);
+    memset(&md, 0, sizeof md);
+    md.n_sen = S; md.n_ci_sen = n_ci; md.cd2cisen = c2c;
+    ptmr_init(&tm);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (t = 0; t < T; t++) {
+        float *fv = feat + (size_t)t * D;
+        approx_cont_mgau_ci_eval(NULL, NULL, g, fg, &md, fv, a->cache_ci_senscr[0],
+                                 &a->cache_best_list[0], t, lm);
+        memset(a->sen_active, 1, S);
+        chk += approx_cont_mgau_frame_eval(&md, NULL, NULL, g, fg, a, fv, t,
+                                           a->cache_ci_senscr[0], &tm, lm);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    printf("frames %d seconds %.6f checksum %lld\n", T,
+           (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), chk);
+    return 0;
+}
+
 /* feat_s2mfc2feat exactly as utt_decode calls it (libAPI/utt.c:234) */
 static int
 cmd_feat(int argc, char **argv)
@@ -381,6 +426,7 @@ main(int argc, char **argv)
     if (!strcmp(argv[1], "mgau") && argc == 11) return cmd_mgau(argc - 2, argv + 2);
     if (!strcmp(argv[1], "frame") && argc == 16) return cmd_frame(argc - 2, argv + 2);
     if (!strcmp(argv[1], "tmat") && argc == 7) return cmd_tmat(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "bench_mgau") && argc == 8) return cmd_bench_mgau(argc - 2, argv + 2);
     if (!strcmp(argv[1], "feat") && argc == 4) return cmd_feat(argc - 2, argv + 2);
     if (!strcmp(argv[1], "hmm") && argc == 14) return cmd_hmm(argc - 2, argv + 2);
     fprintf(stderr, "ref_dump: bad command/arity: %s (%d args)\n", argv[1], argc - 2);
