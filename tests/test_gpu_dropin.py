@@ -1,0 +1,71 @@
+"""The drop-in, end to end (MI355X): the UNMODIFIED reference decoder with the three
+scoring slots of its srch_funcs_t table served by libcmusphinx_amd through the C ABI
+(oracle/_ref/ref_s3amd_decode = oracle/ref_s3amd_decode.c + libs3ref.so) must
+reproduce, byte for byte, the hypothesis files (-hyp) AND the per-word acoustic / LM
+score segmentations (-hypseg) of the reference's own CPU scoring on the bundled
+tidigits regression utterances:
+
+  mode 2 (FSG)      vs the reference's own golden tidigits.length.arb.result
+  mode 4 (fwdtree)  lextree + trigram LM, default beams
+  mode 4            narrow -ci_pbeam 1e-5 and -ds 2: the CI gate, the best-Gaussian
+                    back-off and frame down-sampling all fire inside a real search,
+                    with the search's own active-senone masks
+
+Identical -hypseg means identical senone scores along every surviving path and
+identical frame normalisers (ascale), not just identical words.
+"""
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+D = os.path.join(GOLDEN, "tidigits_decode")
+AM = os.path.join(GOLDEN, "tidigits")
+SHIM = os.path.join(ROOT, "oracle", "_ref", "ref_s3amd_decode")
+REFDEC = os.path.join(ROOT, "oracle", "_ref", "sphinx3_decode")
+
+RUNS = {
+    "mode2_fsg": ["-op_mode", "2", "-fsg", os.path.join(D, "test.digits.fsg")],
+    "mode4_trigram": ["-op_mode", "4", "-lm", os.path.join(D, "tidigits.DMP")],
+    "mode4_cibeam_ds2": ["-op_mode", "4", "-lm", os.path.join(D, "tidigits.DMP"),
+                         "-ci_pbeam", "1e-5", "-ds", "2"],
+}
+
+
+def common():
+    return ["-dict", os.path.join(D, "dictionary"), "-fdict", os.path.join(D, "fillerdict"),
+            "-hmm", AM, "-cepdir", os.path.join(D, "cepstra"), "-agc", "none", "-varnorm", "no",
+            "-cmn", "current", "-lw", "9.5", "-ctl", os.path.join(D, "tidigits.length.arb.regression")]
+
+
+def run(binary, extra, tmp_path, tag):
+    hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
+    with open(log, "w") as lf:
+        p = subprocess.run([binary] + common() + extra + ["-hyp", hyp, "-hypseg", seg],
+                           stdout=lf, stderr=subprocess.STDOUT, timeout=600)
+    tail = [l for l in open(log, errors="ignore").read().splitlines() if "s3amd shim" in l or "FATAL" in l]
+    assert p.returncode == 0, "\n".join(tail[-10:])
+    return open(hyp).read(), open(seg).read(), tail
+
+
+@pytest.mark.skipif(not os.path.exists(SHIM), reason="oracle/_ref/ref_s3amd_decode did not travel "
+                    "(built by `make -C oracle ref` where /root/reference exists)")
+@pytest.mark.parametrize("name", list(RUNS))
+def test_reference_decoder_with_gpu_scoring_matches_reference(name, tmp_path):
+    hyp, seg, tail = run(SHIM, RUNS[name], tmp_path, "gpu_" + name)
+    assert any("calls served by the GPU" in l for l in tail)
+    assert hyp == open(os.path.join(D, f"ref_{name}.match")).read()
+    assert seg == open(os.path.join(D, f"ref_{name}.matchseg")).read()
+    if name == "mode2_fsg":     # the reference's own regression golden
+        assert hyp == open(os.path.join(D, "tidigits.length.arb.result")).read()
+
+
+@pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
+def test_live_cpu_reference_agrees_with_committed_golden(tmp_path):
+    """The committed golden is what the reference produces on THIS box too."""
+    hyp, seg, _ = run(REFDEC, RUNS["mode4_trigram"], tmp_path, "cpu_mode4")
+    assert hyp == open(os.path.join(D, "ref_mode4_trigram.match")).read()
+    assert seg == open(os.path.join(D, "ref_mode4_trigram.matchseg")).read()
