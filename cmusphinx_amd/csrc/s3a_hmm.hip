@@ -27,9 +27,10 @@
 #include <limits.h>
 
 #include "s3a_device.h"
+#include "s3a_vit.h"
 
-#define NS 5
-#define WORST S3A_LOGPROB_ZERO
+#define NS S3A_NS
+#define WORST S3A_WORST
 
 struct s3a_hmm_batch_s {
     int32_t n, ne, n_tmat, n_sseq, n_sen;
@@ -42,67 +43,7 @@ struct s3a_hmm_batch_s {
     hipStream_t stream;
 };
 
-__device__ __forceinline__ int32_t
-add32(int32_t a, int32_t b)
-{
-    return (int32_t)((uint32_t)a + (uint32_t)b);
-}
-
-/* per-lane working copy of one HMM */
-struct HmmRegs {
-    int32_t s[NS];
-    int64_t h[NS];
-    int32_t out;
-    int64_t outh;
-    int32_t ssid[NS];
-};
-
-/* hmm_vit_eval_3st_lr, hmm.c:592-674 */
-__device__ __forceinline__ int32_t
-vit3(HmmRegs &r, const int32_t *tp, int32_t e0, int32_t e1, int32_t e2)
-{
-    int32_t s3, s2, s1, s0, t2, t1, t0, best;
-    s2 = add32(r.s[2], e2);
-    s1 = add32(r.s[1], e1);
-    s0 = add32(r.s[0], e0);
-    t0 = t1 = best = WORST;
-    t2 = INT_MIN;
-    if (s2 > WORST) { t1 = add32(s2, tp[2 * 4 + 3]); t0 = add32(s2, tp[2 * 4 + 2]); }
-    if (s1 > WORST && tp[1 * 4 + 3] > WORST) t2 = add32(s1, tp[1 * 4 + 3]);
-    if (t1 > t2) { s3 = t1; r.outh = r.h[2]; }
-    else         { s3 = t2; r.outh = r.h[1]; }
-    if (s3 < WORST) s3 = WORST;
-    r.out = s3;
-    best = s3;
-
-    t1 = t2 = WORST;
-    if (s1 > WORST) t1 = add32(s1, tp[1 * 4 + 2]);
-    if (tp[0 * 4 + 2] > WORST) t2 = add32(s0, tp[0 * 4 + 2]);
-    if (t0 > t1) {
-        if (t2 > t0) { s2 = t2; r.h[2] = r.h[0]; } else s2 = t0;
-    }
-    else {
-        if (t2 > t1) { s2 = t2; r.h[2] = r.h[0]; } else { s2 = t1; r.h[2] = r.h[1]; }
-    }
-    if (s2 < WORST) s2 = WORST;
-    if (s2 > best) best = s2;
-    r.s[2] = s2;
-
-    t0 = t1 = WORST;
-    if (s1 > WORST) t0 = add32(s1, tp[1 * 4 + 1]);
-    if (s0 > WORST) t1 = add32(s0, tp[0 * 4 + 1]);
-    if (t0 > t1) s1 = t0;
-    else { s1 = t1; r.h[1] = r.h[0]; }
-    if (s1 < WORST) s1 = WORST;
-    if (s1 > best) best = s1;
-    r.s[1] = s1;
-
-    s0 = add32(s0, tp[0]);
-    if (s0 < WORST) s0 = WORST;
-    if (s0 > best) best = s0;
-    r.s[0] = s0;
-    return best;
-}
+typedef HmmRegsT<int64_t> HmmRegs;
 
 /* hmm_vit_eval_3st_lr_mpx, hmm.c:677-776; e[st] is only read when ssid[st] != -1 */
 __device__ __forceinline__ int32_t

@@ -144,10 +144,12 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
 
 /* approx_cont_mgau.c:597-600 */
 __global__ void
-k_normalise(int32_t *senscr, const uint8_t *sen_active, const int32_t *misc, int32_t S)
+k_normalise(int32_t *senscr, uint8_t *sen_active, const int32_t *misc, int32_t S, int32_t n_ci)
 {
     int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < S && sen_active[s])
+    if (s >= S) return;
+    if (s < n_ci) sen_active[s] = 1;    /* CI senones are forced active, approx_cont_mgau.c:537 */
+    if (s < n_ci || sen_active[s])
         senscr[s] -= misc[0];
 }
 
@@ -368,7 +370,7 @@ s3a_approx_cont_mgau_frame_eval(s3a_scorer_t *sc, uint8_t *sen_active, uint8_t *
                  (int32_t)((uint32_t)pbest + (uint32_t)beam), frame, is_skip);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_normalise, dim3((sc->n_sen + 255) / 256), dim3(256), 0, d->stream,
-                       sc->scr_d, sc->act_d, sc->misc_d, sc->n_sen);
+                       sc->scr_d, sc->act_d, sc->misc_d, sc->n_sen, sc->n_ci_sen);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(senscr, sc->scr_d, sizeof(int32_t) * sc->n_sen, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipMemcpyAsync(sc->misc_h, sc->misc_d, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, d->stream));
@@ -380,6 +382,10 @@ s3a_approx_cont_mgau_frame_eval(s3a_scorer_t *sc, uint8_t *sen_active, uint8_t *
     if (n_gau_eval) *n_gau_eval = sc->misc_h[2];
     return S3A_OK;
 }
+
+extern "C" uint8_t *s3a_scorer_sen_active_dev(s3a_scorer_t *sc) { return sc ? sc->act_d : NULL; }
+extern "C" int32_t *s3a_scorer_senscr_dev(s3a_scorer_t *sc) { return sc ? sc->scr_d : NULL; }
+extern "C" void *s3a_mgau_stream(s3a_mgau_model_t *g) { return (g && g->dev) ? (void *)g->dev->stream : NULL; }
 
 /* ------------------------------------------------------------------ */
 /* composite senones                                                   */
@@ -464,5 +470,56 @@ s3a_dict2pid_comsenscr(s3a_comsen_t *cs, const int32_t *senscr, int32_t n_sen, i
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(comsenscr, cs->out_d, (size_t)cs->n_comstate * 4, hipMemcpyDeviceToHost, cs->stream));
     HIPCHK(hipStreamSynchronize(cs->stream));
+    return S3A_OK;
+}
+
+extern "C" int32_t *s3a_comsen_dev(s3a_comsen_t *cs) { return cs ? cs->out_d : NULL; }
+
+extern "C" int32_t
+s3a_approx_cont_mgau_frame_eval_dev(s3a_scorer_t *sc, s3a_comsen_t *cs, const float *feat,
+                                    int32_t frame, const int32_t *cache_ci_senscr, int32_t *best,
+                                    int32_t *n_sen_eval, int32_t *n_gau_eval)
+{
+    struct s3a_mgau_dev_s *d;
+    int32_t beam, is_skip, pbest, s;
+    int32_t init[8];
+
+    if (!sc || !feat || !cache_ci_senscr || !best)
+        return S3A_EINVAL;
+    if (sc->max_cd < sc->n_sen - sc->n_ci_sen) {
+        s3a_set_error("-maxcdsenpf (dynamic CI beam) needs the host senone mask: use the host-pointer entry point");
+        return S3A_EUNSUP;
+    }
+    d = sc->g->dev;
+    beam = sc->ci_pbeam;
+    is_skip = (frame % sc->ds_ratio == 0) ? 0 : 1;
+    if (is_skip)
+        beam = (int32_t)((float)beam * sc->tighten_factor);
+    pbest = S3A_MAX_NEG_INT32;
+    for (s = 0; s < sc->n_ci_sen; s++)
+        if (pbest < cache_ci_senscr[s]) pbest = cache_ci_senscr[s];
+    memcpy(init, k_misc_init, sizeof init);
+    init[0] = pbest;
+    HIPCHK(hipMemcpyAsync(sc->x_d, feat, sizeof(float) * d->D, hipMemcpyHostToDevice, d->stream));
+    if (sc->n_ci_sen)
+        HIPCHK(hipMemcpyAsync(sc->scr_d, cache_ci_senscr, sizeof(int32_t) * sc->n_ci_sen,
+                              hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipMemcpyAsync(sc->misc_d, init, sizeof init, hipMemcpyHostToDevice, d->stream));
+    launch_gated(sc, sc->n_ci_sen, sc->n_sen, 0, (int32_t)((uint32_t)pbest + (uint32_t)beam), frame, is_skip);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_normalise, dim3((sc->n_sen + 255) / 256), dim3(256), 0, d->stream,
+                       sc->scr_d, sc->act_d, sc->misc_d, sc->n_sen, sc->n_ci_sen);
+    HIPCHK(hipGetLastError());
+    if (cs) {
+        /* cs has its own stream object but the composite pass must follow the scores: run it here */
+        hipLaunchKernelGGL(k_comsenscr, dim3((cs->n_comstate + 255) / 256), dim3(256), 0, d->stream,
+                           cs->n_comstate, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d, cs->out_d);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(sc->misc_h, sc->misc_d, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    *best = sc->misc_h[0];
+    if (n_sen_eval) *n_sen_eval = sc->misc_h[1];
+    if (n_gau_eval) *n_gau_eval = sc->misc_h[2];
     return S3A_OK;
 }

@@ -87,6 +87,32 @@ _SIGS = {
     "s3a_hmm_batch_enter": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "s3a_hmm_batch_vit_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "s3a_hmm_batch_get": (C.c_int32, [C.c_void_p] * 8),
+    "s3a_lexsearch_init": (C.c_void_p, [C.c_int32] + [C.c_void_p] * 14 + [C.c_void_p, C.c_void_p, C.c_int32,
+                                                                          C.c_void_p, C.c_int32, C.c_int32,
+                                                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3a_lexsearch_free": (None, [C.c_void_p]),
+    "s3a_lexsearch_reset": (C.c_int32, [C.c_void_p]),
+    "s3a_lexsearch_n_node": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "s3a_lexsearch_enter": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.c_int32]),
+    "s3a_lexsearch_active_swap": (C.c_int32, [C.c_void_p]),
+    "s3a_lexsearch_hmm_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
+    "s3a_lexsearch_propagate_non_leaves": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "s3a_lexsearch_propagate_leaves": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_int32]),
+    "s3a_lexsearch_sen_active": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_lexsearch_utt_end": (C.c_int32, [C.c_void_p]),
+    "s3a_lexsearch_get_active": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                             C.c_void_p, C.c_int32]),
+    "s3a_lexsearch_get_hmm": (C.c_int32, [C.c_void_p, C.c_int32] + [C.c_void_p] * 6),
+    "s3a_mgau_stream": (C.c_void_p, [C.c_void_p]),
+    "s3a_scorer_sen_active_dev": (C.c_void_p, [C.c_void_p]),
+    "s3a_scorer_senscr_dev": (C.c_void_p, [C.c_void_p]),
+    "s3a_comsen_dev": (C.c_void_p, [C.c_void_p]),
+    "s3a_approx_cont_mgau_frame_eval_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                        C.POINTER(C.c_int32)]),
     "s3a_bench_score_frames": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_int32, C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

@@ -275,6 +275,93 @@ int32_t s3a_hmm_batch_get(const s3a_hmm_batch_t *b, int32_t *score, int64_t *his
                           int32_t *mpx_ssid, int32_t *frame);
 
 /* ===================================================================== */
+/* lexical-tree search: the per-frame operations of sphinx3 mode 4       */
+/* replaces lextree_t's frame functions, libsearch/lextree.c:910-1663     */
+/* ===================================================================== */
+/*
+ * A "lexsearch" holds ALL lextrees one decoder searches in lock step (mode 4:
+ * -Nlextree unigram trees followed by -Nlextree filler trees,
+ * srch_time_switch_tree.c:260-456), flattened by the host from lextree_t after
+ * lextree_build: per tree t, nodes 0..n_node[t]-1 in any fixed order with
+ *   ssid/tmatid/composite/wid/prob    lextree_node_t fields (lextree.h:187-207); wid < 0 = not a leaf
+ *   child_off/child                   CSR of ln->children in glist order
+ *   n_lc, lc, lcroot_off, lcroot      lextree->lcroot[i].{lc,root} lists in glist order, or
+ *   n_root, root                      lextree->root when n_lc == 0 (filler trees)
+ * plus what the two hmm_context_t need: tmat, mdef->sseq, d2p->comsseq and the
+ * composite-state member lists (d2p->comstate flattened as for s3a_comsen_init).
+ * The trees must be static: composite triphones (dict2pid_is_composite, the only
+ * mode kbcore.c:626 builds), -pheurtype 0, 3-state HMMs.  History ids are the
+ * int32 vithist entry ids.  `stream` (hipStream_t as void*) orders the search
+ * kernels with the scorer's; pass s3a_mgau_stream(g).
+ */
+typedef struct s3a_lexsearch_s s3a_lexsearch_t;
+s3a_lexsearch_t *s3a_lexsearch_init(int32_t n_tree, const int32_t *n_node,
+        const int32_t *const *ssid, const int32_t *const *tmatid, const uint8_t *const *composite,
+        const int32_t *const *wid, const int32_t *const *prob,
+        const int32_t *const *child_off, const int32_t *const *child,
+        const int32_t *n_lc, const int16_t *const *lc,
+        const int32_t *const *lcroot_off, const int32_t *const *lcroot,
+        const int32_t *n_root, const int32_t *const *root,
+        const s3a_tmat_t *tmat, const int16_t *sseq, int32_t n_sseq,
+        const int16_t *comsseq, int32_t n_comsseq, int32_t n_comstate,
+        const int32_t *comstate_off, const int16_t *comstate, void *stream);
+void    s3a_lexsearch_free(s3a_lexsearch_t *ls);
+int32_t s3a_lexsearch_reset(s3a_lexsearch_t *ls);
+int32_t s3a_lexsearch_n_node(const s3a_lexsearch_t *ls, int32_t tree);
+/* lextree_enter (lextree.c:1093-1236) for ALL calls one frame makes into `tree`
+ * (srch_utt_word_trans issues one per word-final CI phone, sequentially): lc[c],
+ * inscore[c], inhist[c]; results equal the sequential calls in this order.
+ * lc is ignored for trees built without left contexts. */
+int32_t s3a_lexsearch_enter(s3a_lexsearch_t *ls, int32_t tree, int32_t n_calls, const int32_t *lc,
+                            const int32_t *inscore, const int32_t *inhist, int32_t cf,
+                            int32_t thresh);
+/* lextree_active_swap (lextree.c:1240-1249) on every tree */
+int32_t s3a_lexsearch_active_swap(s3a_lexsearch_t *ls);
+/* lextree_hmm_eval (lextree.c:1253-1310) on every tree against DEVICE score arrays
+ * (s3a_scorer_senscr_dev / s3a_comsen_dev); per tree: best, wbest (MAX_NEG_INT32 when
+ * nothing is active) and the number of active HMMs */
+int32_t s3a_lexsearch_hmm_eval(s3a_lexsearch_t *ls, const int32_t *senscr_dev,
+                               const int32_t *comsen_dev, int32_t frm, int32_t *best,
+                               int32_t *wbest, int32_t *n_active);
+/* lextree_hmm_propagate_non_leaves (lextree.c:1365-1597) on every tree */
+int32_t s3a_lexsearch_propagate_non_leaves(s3a_lexsearch_t *ls, int32_t cf, int32_t th,
+                                           int32_t pth, int32_t wth);
+/* lextree_hmm_propagate_leaves (lextree.c:1600-1663) minus the vithist_rescore call:
+ * per tree t the word exits in active-list order, n_exit[t] of them at
+ * exit_*[t*max_per_tree ...]: wid, out_score - prob, out_history -- exactly the
+ * arguments the reference passes to vithist_rescore */
+int32_t s3a_lexsearch_propagate_leaves(s3a_lexsearch_t *ls, int32_t wth, int32_t *n_exit,
+                                       int32_t *exit_wid, int32_t *exit_score,
+                                       int32_t *exit_hist, int32_t max_per_tree);
+/* srch_TST_select_active_gmm (srch_time_switch_tree.c:1262-1324): clear, then mark the
+ * senones of every active HMM (composite ones through their member lists) in a DEVICE
+ * flag array of n_sen bytes (s3a_scorer_sen_active_dev) */
+int32_t s3a_lexsearch_sen_active(s3a_lexsearch_t *ls, uint8_t *sen_active_dev, int32_t n_sen);
+/* lextree_utt_end (lextree.c:936-961) on every tree */
+int32_t s3a_lexsearch_utt_end(s3a_lexsearch_t *ls);
+/* read-back for tests: which = 0 active list, 1 next_active list (node ids local to the tree) */
+int32_t s3a_lexsearch_get_active(const s3a_lexsearch_t *ls, int32_t tree, int32_t which,
+                                 int32_t *n_active, int32_t *nodes, int32_t max_nodes);
+/* HMM state of one tree: score/hist [3][n_node], the rest [n_node]; any may be NULL */
+int32_t s3a_lexsearch_get_hmm(const s3a_lexsearch_t *ls, int32_t tree, int32_t *score,
+                              int32_t *hist, int32_t *out_score, int32_t *out_hist,
+                              int32_t *bestscore, int32_t *frame);
+
+/* device-resident scoring for a search that lives on the GPU: the scorer's own
+ * sen_active / senscr buffers and the composite scores never leave HBM */
+void   *s3a_mgau_stream(s3a_mgau_model_t *g);
+uint8_t *s3a_scorer_sen_active_dev(s3a_scorer_t *sc);
+int32_t *s3a_scorer_senscr_dev(s3a_scorer_t *sc);
+int32_t *s3a_comsen_dev(s3a_comsen_t *cs);
+/* approx_cont_mgau_frame_eval with sen_active taken from, and senscr left in, the
+ * scorer's device buffers; cs (optional) then receives dict2pid_comsenscr on device.
+ * -maxcdsenpf's dynamic CI beam needs the host mask and is rejected here. */
+int32_t s3a_approx_cont_mgau_frame_eval_dev(s3a_scorer_t *sc, s3a_comsen_t *cs, const float *feat,
+                                            int32_t frame, const int32_t *cache_ci_senscr,
+                                            int32_t *best, int32_t *n_sen_eval,
+                                            int32_t *n_gau_eval);
+
+/* ===================================================================== */
 /* measurement hooks used by bench.py (HIP events on the launch stream)   */
 /* ===================================================================== */
 /*

@@ -1,0 +1,662 @@
+/*
+ * oracle/ref_tst_shim.c -- TEST INFRASTRUCTURE: sphinx3_decode (mode 4, "fwdtree")
+ * with the WHOLE per-frame hot path re-pointed at a replacement backend through the
+ * reference's own srch_funcs_t table (sphinx3/include/srch.h:528-701).
+ *
+ * Built twice from this one source (oracle/Makefile):
+ *   -DLT_ORACLE  oracle/_ref/ref_s3olt_decode : lextree ops from the CPU oracle
+ *                (oracle/s3o_lextree.c), scoring by the reference.  Runs without a GPU;
+ *                identical -hyp/-hypseg to the unmodified reference PINS the oracle's
+ *                lextree restatement (tests/test_oracle_lextree.py).
+ *   (default)    oracle/_ref/ref_s3amd_tst_decode : senone scoring, composite senones,
+ *                active-senone selection, HMM evaluation and phone-level propagation all
+ *                on the MI355X through include/cmusphinx_amd.h; only the word level
+ *                (vithist + LM) stays the reference's host code, fed by
+ *                the compact word-exit lists.  Senone scores never leave HBM.
+ *
+ * What stays the reference's: kb_init (models, dictionary, LM, lextree_build, dict2pid),
+ * feature computation, the frame loop srch_utt_decode_blk, vithist_*, lm_*, hypothesis
+ * output.  The lextrees the reference built are FLATTENED once (flatten_tree) into the
+ * node/CSR arrays both backends take; the reference's own lextree frame functions are
+ * never called.  The replaced slots restate the control flow of
+ * srch_time_switch_tree.c:457-560 (begin/end), :776-907 (hmm_compute_lv2),
+ * :923-1007 (propagate_graph_ph_lv2), :1010-1210 (rescoring, word transitions),
+ * :1213-1237 (frame_windup), :1262-1324 (select_active_gmm).
+ */
+#define main sphinx3_decode_reference_main
+#include "main_decode.c"        /* the reference's file, in place (for its arg table) */
+#undef main
+
+/* srch_TST_graph_t (the mode's private graph structure) is defined INSIDE the reference's
+ * srch_time_switch_tree.c:233-257, not in a header.  A maintainer would add these slots in
+ * that file; here the file is #included in place (not copied) to obtain the definition. */
+#include "srch_time_switch_tree.c"
+
+#include <string.h>
+#include "srch.h"
+#include "gmm_wrap.h"
+#include "dict2pid.h"
+#include "lextree.h"
+#include "vithist.h"
+
+#ifdef LT_ORACLE
+#include "s3o.h"
+#else
+#include "cmusphinx_amd.h"
+#endif
+
+/* ------------------------------------------------------------------ */
+/* flattening lextree_t                                                */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int32 n_node;
+    lextree_node_t **node;      /* index -> reference node (BFS from lextree->root) */
+    int32 *ssid, *tmatid, *wid, *prob, *child_off, *child;
+    uint8 *composite;
+    int32 n_lc, *lcroot_off, *lcroot, n_root, *root;
+    int16 *lc;
+    int32 type;
+} flat_t;
+
+static int
+cmp_ptr(const void *a, const void *b)
+{
+    const void *x = *(void *const *)a, *y = *(void *const *)b;
+    return (x > y) - (x < y);
+}
+
+typedef struct { lextree_node_t *p; int32 idx; } pmap_t;
+static pmap_t *g_pmap;
+static int32 g_npmap;
+
+static int
+cmp_pmap(const void *a, const void *b)
+{
+    const pmap_t *x = a, *y = b;
+    return (x->p > y->p) - (x->p < y->p);
+}
+
+static int32
+node_index(lextree_node_t *p)
+{
+    int32 lo = 0, hi = g_npmap - 1;
+    while (lo <= hi) {
+        int32 m = (lo + hi) / 2;
+        if (g_pmap[m].p == p) return g_pmap[m].idx;
+        if (g_pmap[m].p < p) lo = m + 1; else hi = m - 1;
+    }
+    E_FATAL("tst shim: lextree node not found while flattening\n");
+    return -1;
+}
+
+static flat_t *
+flatten_tree(lextree_t *lt)
+{
+    flat_t *f = ckd_calloc(1, sizeof(*f));
+    int32 cap = lt->n_node + 16, n = 0, head = 0, i, j, nchild = 0;
+    lextree_node_t **q = ckd_calloc(cap, sizeof(*q));
+    lextree_node_t **seen;
+    gnode_t *gn;
+    (void)cmp_ptr;
+
+    /* BFS over roots (glist order) then children (glist order).  Only the children of ROOT
+     * nodes can have several parents (one per left-context variant of the first phone,
+     * lextree.c:626-660); below that every node has one parent, so no dedupe is needed. */
+    for (gn = lt->root; gn; gn = gnode_next(gn)) {
+        lextree_node_t *ln = gnode_ptr(gn);
+        for (j = 0; j < n && q[j] != ln; j++);
+        if (j == n) { if (n >= cap) E_FATAL("flatten: node count exceeds n_node\n"); q[n++] = ln; }
+    }
+    {
+        int32 n_rootnodes = n, lvl1_start = n;
+        while (head < n) {
+            lextree_node_t *ln = q[head];
+            int is_root = head < n_rootnodes;
+            head++;
+            for (gn = ln->children; gn; gn = gnode_next(gn)) {
+                lextree_node_t *c = gnode_ptr(gn);
+                nchild++;
+                if (is_root) {
+                    for (j = lvl1_start; j < n && q[j] != c; j++);
+                    if (j < n) continue;
+                }
+                if (n >= cap) { cap *= 2; q = ckd_realloc(q, cap * sizeof(*q)); }
+                q[n++] = c;
+            }
+        }
+    }
+    (void)seen;
+    ckd_free(seen);
+    f->n_node = n;
+    f->node = q;
+    g_pmap = ckd_calloc(n, sizeof(pmap_t));
+    g_npmap = n;
+    for (i = 0; i < n; i++) { g_pmap[i].p = q[i]; g_pmap[i].idx = i; }
+    qsort(g_pmap, n, sizeof(pmap_t), cmp_pmap);
+
+    f->ssid = ckd_calloc(n, 4); f->tmatid = ckd_calloc(n, 4); f->wid = ckd_calloc(n, 4);
+    f->prob = ckd_calloc(n, 4); f->composite = ckd_calloc(n, 1);
+    f->child_off = ckd_calloc(n + 1, 4); f->child = ckd_calloc(nchild + 1, 4);
+    for (i = 0, j = 0; i < n; i++) {
+        lextree_node_t *ln = q[i];
+        f->ssid[i] = ln->ssid;
+        f->tmatid[i] = hmm_tmatid(&ln->hmm);
+        f->wid[i] = IS_S3WID(ln->wid) ? ln->wid : -1;
+        f->prob[i] = ln->prob;
+        f->composite[i] = ln->composite ? 1 : 0;
+        f->child_off[i] = j;
+        for (gn = ln->children; gn; gn = gnode_next(gn))
+            f->child[j++] = node_index(gnode_ptr(gn));
+    }
+    f->child_off[n] = j;
+    f->n_lc = lt->n_lc;
+    f->type = lt->type;
+    if (lt->n_lc > 0) {
+        int32 tot = 0;
+        f->lc = ckd_calloc(lt->n_lc, sizeof(int16));
+        f->lcroot_off = ckd_calloc(lt->n_lc + 1, 4);
+        for (i = 0; i < lt->n_lc; i++)
+            tot += glist_count(lt->lcroot[i].root);
+        f->lcroot = ckd_calloc(tot + 1, 4);
+        for (i = 0, j = 0; i < lt->n_lc; i++) {
+            f->lc[i] = lt->lcroot[i].lc;
+            f->lcroot_off[i] = j;
+            for (gn = lt->lcroot[i].root; gn; gn = gnode_next(gn))
+                f->lcroot[j++] = node_index(gnode_ptr(gn));
+        }
+        f->lcroot_off[lt->n_lc] = j;
+    }
+    f->n_root = glist_count(lt->root);
+    f->root = ckd_calloc(f->n_root + 1, 4);
+    for (gn = lt->root, j = 0; gn; gn = gnode_next(gn))
+        f->root[j++] = node_index(gnode_ptr(gn));
+    ckd_free(g_pmap);
+    g_pmap = NULL;
+    return f;
+}
+
+/* ------------------------------------------------------------------ */
+/* backend                                                             */
+/* ------------------------------------------------------------------ */
+static int32 g_ntree;           /* 2 * n_lextree: unigram trees then filler trees */
+static flat_t **g_flat;
+static int32 *g_tp_flat;        /* tmat->tp flattened */
+static int16 *g_sseq_flat, *g_comsseq_flat, *g_comstate;
+static int32 *g_comstate_off, g_n_comstate;
+static int32 g_max_node;
+static int32 *g_best, *g_wbest, *g_nact;
+static int32 *g_exit_n, *g_exit_wid, *g_exit_scr, *g_exit_hist;
+static long g_frames;
+
+#ifdef LT_ORACLE
+static s3o_lextree_t **g_lt;
+#else
+static s3a_logmath_t *g_lm;
+static s3a_mgau_model_t *g_gm;
+static s3a_scorer_t *g_sc;
+static s3a_comsen_t *g_cs;
+static s3a_tmat_t *g_tm;
+static s3a_lexsearch_t *g_ls;
+static void die(const char *w) { E_FATAL("tst shim: %s: %s\n", w, s3a_last_error()); }
+#endif
+
+static void
+backend_init(kb_t *kb, srch_TST_graph_t *tstg)
+{
+    kbcore_t *kbc = kb->kbcore;
+    mdef_t *mdef = kbcore_mdef(kbc);
+    dict2pid_t *d2p = kbcore_dict2pid(kbc);
+    tmat_t *tmat = kbcore_tmat(kbc);
+    int32 ne = mdef_n_emit_state(mdef), i, j, k, n;
+
+    if (!dict2pid_is_composite(d2p))
+        E_FATAL("tst shim: full cross-word triphone expansion grows the lextree during search; "
+                "only composite triphones (the reference's default) are supported\n");
+    if (kb->pl->pheurtype != 0)
+        E_FATAL("tst shim: -pheurtype > 0 is not supported\n");
+    if (kbcore_lmset(kbc)->n_lm != 1)
+        E_FATAL("tst shim: exactly one LM is supported\n");
+
+    g_ntree = 2 * tstg->n_lextree;
+    g_flat = ckd_calloc(g_ntree, sizeof(*g_flat));
+    for (i = 0; i < g_ntree; i++) {
+        lextree_t *lt = (i < tstg->n_lextree) ? tstg->curugtree[i] : tstg->fillertree[i - tstg->n_lextree];
+        g_flat[i] = flatten_tree(lt);
+        if (g_flat[i]->n_node > g_max_node) g_max_node = g_flat[i]->n_node;
+    }
+    g_tp_flat = ckd_calloc(tmat->n_tmat * ne * (ne + 1), 4);
+    for (i = 0; i < tmat->n_tmat; i++)
+        for (j = 0; j < ne; j++)
+            for (k = 0; k <= ne; k++)
+                g_tp_flat[(i * ne + j) * (ne + 1) + k] = tmat->tp[i][j][k];
+    g_sseq_flat = ckd_calloc(mdef_n_sseq(mdef) * ne, 2);
+    for (i = 0; i < mdef_n_sseq(mdef); i++)
+        for (j = 0; j < ne; j++)
+            g_sseq_flat[i * ne + j] = mdef->sseq[i][j];
+    g_comsseq_flat = ckd_calloc(d2p->n_comsseq * ne + 1, 2);
+    for (i = 0; i < d2p->n_comsseq; i++)
+        for (j = 0; j < ne; j++)
+            g_comsseq_flat[i * ne + j] = d2p->comsseq[i][j];
+    for (i = 0, n = 0; i < d2p->n_comstate; i++)
+        for (j = 0; IS_S3SENID(d2p->comstate[i][j]); j++)
+            n++;
+    g_n_comstate = d2p->n_comstate;
+    g_comstate_off = ckd_calloc(g_n_comstate + 1, 4);
+    g_comstate = ckd_calloc(n + 1, 2);
+    for (i = 0, n = 0; i < g_n_comstate; i++) {
+        g_comstate_off[i] = n;
+        for (j = 0; IS_S3SENID(d2p->comstate[i][j]); j++)
+            g_comstate[n++] = d2p->comstate[i][j];
+    }
+    g_comstate_off[g_n_comstate] = n;
+
+    g_best = ckd_calloc(g_ntree, 4); g_wbest = ckd_calloc(g_ntree, 4); g_nact = ckd_calloc(g_ntree, 4);
+    g_exit_n = ckd_calloc(g_ntree, 4);
+    g_exit_wid = ckd_calloc(g_ntree * g_max_node, 4);
+    g_exit_scr = ckd_calloc(g_ntree * g_max_node, 4);
+    g_exit_hist = ckd_calloc(g_ntree * g_max_node, 4);
+
+#ifdef LT_ORACLE
+    g_lt = ckd_calloc(g_ntree, sizeof(*g_lt));
+    for (i = 0; i < g_ntree; i++) {
+        flat_t *f = g_flat[i];
+        g_lt[i] = s3o_lextree_init(f->n_node, f->ssid, f->tmatid, f->composite, f->wid, f->prob,
+                                   f->child_off, f->child, f->n_lc, f->lc, f->lcroot_off, f->lcroot,
+                                   f->n_root, f->root, ne, g_tp_flat, g_sseq_flat, g_comsseq_flat);
+    }
+#else
+    {
+        cmd_ln_t *config = kbcore_config(kbc);
+        const int32 **ssid = ckd_calloc(g_ntree, sizeof(void *)), **tm = ckd_calloc(g_ntree, sizeof(void *));
+        const int32 **wid = ckd_calloc(g_ntree, sizeof(void *)), **prob = ckd_calloc(g_ntree, sizeof(void *));
+        const int32 **coff = ckd_calloc(g_ntree, sizeof(void *)), **ch = ckd_calloc(g_ntree, sizeof(void *));
+        const int32 **lro = ckd_calloc(g_ntree, sizeof(void *)), **lr = ckd_calloc(g_ntree, sizeof(void *));
+        const int32 **root = ckd_calloc(g_ntree, sizeof(void *));
+        const uint8 **comp = ckd_calloc(g_ntree, sizeof(void *));
+        const int16 **lc = ckd_calloc(g_ntree, sizeof(void *));
+        int32 *nn = ckd_calloc(g_ntree, 4), *nlc = ckd_calloc(g_ntree, 4), *nroot = ckd_calloc(g_ntree, 4);
+        if (s3a_device_count() < 1)
+            E_FATAL("tst shim: no GPU; libcmusphinx_amd has no CPU fallback\n");
+        if (kbcore_svq(kbc) || kbcore_gs(kbc) || !kbcore_mgau(kbc))
+            E_FATAL("tst shim: only plain -senmgau .cont. scoring is supported\n");
+        g_lm = s3a_logs3_init(cmd_ln_float64_r(config, "-logbase"), 0, 1);
+        g_gm = s3a_mgau_init(cmd_ln_str_r(config, "-mean"), cmd_ln_str_r(config, "-var"),
+                             cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
+                             cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.",
+                             S3A_MIX_INT_FLOAT_COMP, g_lm);
+        if (!g_gm) die("s3a_mgau_init");
+        g_sc = s3a_scorer_init(g_gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen,
+                               cmd_ln_int32_r(config, "-ds"), cmd_ln_int32_r(config, "-cond_ds"),
+                               cmd_ln_float64_r(config, "-ci_pbeam"),
+                               cmd_ln_float32_r(config, "-tighten_factor"),
+                               cmd_ln_int32_r(config, "-maxcdsenpf"));
+        if (!g_sc) die("s3a_scorer_init");
+        g_cs = s3a_comsen_init(g_n_comstate, g_comstate_off, g_comstate, d2p->comwt);
+        if (!g_cs) die("s3a_comsen_init");
+        g_tm = s3a_tmat_init_logs3(g_tp_flat, tmat->n_tmat, ne);
+        for (i = 0; i < g_ntree; i++) {
+            flat_t *f = g_flat[i];
+            nn[i] = f->n_node; ssid[i] = f->ssid; tm[i] = f->tmatid; comp[i] = f->composite;
+            wid[i] = f->wid; prob[i] = f->prob; coff[i] = f->child_off; ch[i] = f->child;
+            nlc[i] = f->n_lc; lc[i] = f->lc; lro[i] = f->lcroot_off; lr[i] = f->lcroot;
+            nroot[i] = f->n_root; root[i] = f->root;
+        }
+        g_ls = s3a_lexsearch_init(g_ntree, nn, ssid, tm, comp, wid, prob, coff, ch, nlc, lc, lro, lr,
+                                  nroot, root, g_tm, g_sseq_flat, mdef_n_sseq(mdef), g_comsseq_flat,
+                                  d2p->n_comsseq, g_n_comstate, g_comstate_off, g_comstate,
+                                  s3a_mgau_stream(g_gm));
+        if (!g_ls) die("s3a_lexsearch_init");
+    }
+#endif
+    E_INFO("tst shim: %d lextrees flattened (largest %d nodes), backend %s\n", g_ntree, g_max_node,
+#ifdef LT_ORACLE
+           "CPU oracle (oracle/s3o_lextree.c)"
+#else
+           s3a_version()
+#endif
+        );
+}
+
+/* one batch of lextree_enter calls into tree t */
+static void
+be_enter(int32 t, int32 n, int32 *lc, int32 *scr, int32 *hist, int32 cf, int32 thresh)
+{
+#ifdef LT_ORACLE
+    int32 c;
+    for (c = 0; c < n; c++)
+        s3o_lextree_enter(g_lt[t], lc[c], cf, scr[c], hist[c], thresh);
+#else
+    if (s3a_lexsearch_enter(g_ls, t, n, lc, scr, hist, cf, thresh) != S3A_OK) die("enter");
+#endif
+}
+
+static void
+be_swap(void)
+{
+#ifdef LT_ORACLE
+    int32 t;
+    for (t = 0; t < g_ntree; t++) s3o_lextree_active_swap(g_lt[t]);
+#else
+    if (s3a_lexsearch_active_swap(g_ls) != S3A_OK) die("swap");
+#endif
+}
+
+/* ------------------------------------------------------------------ */
+/* replaced srch_funcs_t slots                                         */
+/* ------------------------------------------------------------------ */
+static int
+tst_begin(void *srch)
+{
+    srch_t *s = srch;
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    kbcore_t *kbc = s->kbc;
+    mgau_model_t *g = kbc->mgau;
+    int32 pred, i, lc, zero = 0;
+
+    vithist_utt_reset(tstg->vithist);
+    histprune_zero_histbin(tstg->histprune);
+    pred = vithist_utt_begin(tstg->vithist, kbc);
+    if (g)
+        for (i = 0; i < g->n_mgau; i++) { g->mgau[i].bstidx = NO_BSTIDX; g->mgau[i].updatetime = NOT_UPDATED; }
+#ifndef LT_ORACLE
+    if (s3a_scorer_utt_begin(g_sc) != S3A_OK) die("scorer_utt_begin");
+#endif
+    lc = mdef_silphone(kbc->mdef);
+    be_enter(0, 1, &lc, &zero, &pred, -1, s->beam->hmm);
+    lc = BAD_S3CIPID;
+    be_enter(tstg->n_lextree, 1, &lc, &zero, &pred, -1, s->beam->hmm);
+    tstg->n_lextrans = 1;
+    be_swap();
+    return SRCH_SUCCESS;
+}
+
+static int
+tst_end(void *srch)
+{
+    srch_t *s = srch;
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    int32 t;
+    s->exit_id = vithist_utt_end(tstg->vithist, s->kbc);
+    s->stat->utt_wd_exit = vithist_n_entry(tstg->vithist);
+    histprune_showhistbin(tstg->histprune, s->stat->nfr, s->uttid);
+#ifdef LT_ORACLE
+    for (t = 0; t < g_ntree; t++) s3o_lextree_utt_end(g_lt[t]);
+#else
+    (void)t;
+    if (s3a_lexsearch_utt_end(g_ls) != S3A_OK) die("utt_end");
+#endif
+    lm_cache_stats_dump(kbcore_lm(s->kbc));
+    lm_cache_reset(kbcore_lm(s->kbc));
+    return (s->exit_id >= 0) ? SRCH_SUCCESS : SRCH_FAILURE;
+}
+
+#ifndef LT_ORACLE
+static int
+tst_gmm_lv1(void *srch, float32 *feat, int32 cache_idx, int32 wav_idx)
+{
+    srch_t *s = srch;
+    ascr_t *a = s->ascr;
+    if (s3a_approx_cont_mgau_ci_eval(g_sc, feat, a->cache_ci_senscr[cache_idx],
+                                     &a->cache_best_list[cache_idx], wav_idx) != S3A_OK) die("lv1");
+    return SRCH_SUCCESS;
+}
+
+static int
+tst_select_active(void *srch)
+{
+    srch_t *s = srch;
+    if (s3a_lexsearch_sen_active(g_ls, s3a_scorer_sen_active_dev(g_sc), mdef_n_sen(s->kbc->mdef)) != S3A_OK)
+        die("sen_active");
+    return SRCH_SUCCESS;
+}
+
+static int
+tst_gmm_lv2(void *srch, float32 **feat, int32 wav_idx)
+{
+    srch_t *s = srch;
+    ascr_t *a = s->ascr;
+    int32 best, ns, ng;
+    if (s3a_approx_cont_mgau_frame_eval_dev(g_sc, g_cs, feat[0], wav_idx,
+                                            a->cache_ci_senscr[s->cache_win_strt], &best, &ns, &ng) != S3A_OK)
+        die("lv2");
+    s->senscale = best;
+    s->stat->utt_sen_eval += ns;
+    s->stat->utt_gau_eval += ng;
+    return SRCH_SUCCESS;
+}
+#else
+static int
+tst_select_active(void *srch)
+{
+    srch_t *s = srch;
+    ascr_t *ascr = s->ascr;
+    mdef_t *mdef = kbcore_mdef(s->kbc);
+    dict2pid_t *d2p = kbcore_dict2pid(s->kbc);
+    int32 t;
+    if (!ascr->sen_active) return SRCH_SUCCESS;
+    ascr_clear_ssid_active(ascr);
+    ascr_clear_comssid_active(ascr);
+    for (t = 0; t < g_ntree; t++)
+        s3o_lextree_ssid_active(g_lt[t], ascr->ssid_active, ascr->comssid_active);
+    ascr_clear_sen_active(ascr);
+    s3o_sseq2sen_active(g_sseq_flat, mdef_n_sseq(mdef), mdef_n_emit_state(mdef), ascr->ssid_active,
+                        ascr->sen_active);
+    s3o_comsseq2sen_active(g_comsseq_flat, d2p->n_comsseq, mdef_n_emit_state(mdef), g_comstate_off,
+                           g_comstate, ascr->comssid_active, ascr->sen_active);
+    return SRCH_SUCCESS;
+}
+#endif
+
+static int
+tst_hmm_compute_lv2(void *srch, int32 frmno)
+{
+    srch_t *s = srch;
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    histprune_t *hp = tstg->histprune;
+    beam_t *bm = s->beam;
+    int32 besthmmscr = MAX_NEG_INT32, bestwordscr = MAX_NEG_INT32, frm_nhmm = 0, t, hb, pb, wb;
+
+#ifdef LT_ORACLE
+    for (t = 0; t < g_ntree; t++) {
+        s3o_lextree_hmm_eval(g_lt[t], s->ascr->senscr, s->ascr->comsen, frmno);
+        g_best[t] = g_lt[t]->best; g_wbest[t] = g_lt[t]->wbest; g_nact[t] = g_lt[t]->n_active;
+    }
+#else
+    if (s3a_lexsearch_hmm_eval(g_ls, s3a_scorer_senscr_dev(g_sc), s3a_comsen_dev(g_cs), frmno, g_best,
+                               g_wbest, g_nact) != S3A_OK) die("hmm_eval");
+#endif
+    for (t = 0; t < g_ntree; t++) {
+        if (besthmmscr < g_best[t]) besthmmscr = g_best[t];
+        if (bestwordscr < g_wbest[t]) bestwordscr = g_wbest[t];
+        s->stat->utt_hmm_eval += g_nact[t];
+        frm_nhmm += g_nact[t];
+    }
+    if (besthmmscr > 0)
+        E_ERROR("***ERROR*** Fr %d, best HMM score > 0 (%d); int32 wraparound?\n", frmno, besthmmscr);
+    if (frm_nhmm / hp->hmm_hist_binsize > hp->hmm_hist_bins - 1)
+        hp->hmm_hist[hp->hmm_hist_bins - 1]++;
+    else
+        hp->hmm_hist[frm_nhmm / hp->hmm_hist_binsize]++;
+
+    if (frm_nhmm > (hp->maxhmmpf + (hp->maxhmmpf >> 1))) {
+#ifdef LT_ORACLE
+        int32 nbin = 1000, bw = -(bm->hmm) / nbin, i, j;
+        int32 *bin = ckd_calloc(nbin, sizeof(int32));
+        for (t = 0; t < g_ntree; t++)
+            s3o_lextree_hmm_histbin(g_lt[t], besthmmscr, bin, nbin, bw);
+        for (i = 0, j = 0; (i < nbin) && (j < hp->maxhmmpf); i++, j += bin[i]);
+        ckd_free(bin);
+        hb = -(i * bw);
+        pb = (hb > bm->ptrans) ? hb : bm->ptrans;
+        wb = (hb > bm->word) ? hb : bm->word;
+#else
+        E_FATAL("tst shim: %d active HMMs exceed 1.5 x -maxhmmpf: histogram pruning "
+                "(lextree_hmm_histbin) is not implemented on the device yet\n", frm_nhmm);
+        hb = pb = wb = 0;
+#endif
+    }
+    else {
+        hb = bm->hmm; pb = bm->ptrans; wb = bm->word;
+    }
+    bm->bestscore = besthmmscr;
+    bm->bestwordscore = bestwordscr;
+    bm->thres = bm->bestscore + hb;
+    bm->phone_thres = bm->bestscore + pb;
+    bm->word_thres = bm->bestwordscore + wb;
+    g_frames++;
+    return SRCH_SUCCESS;
+}
+
+static int
+tst_propagate_ph_lv2(void *srch, int32 frmno)
+{
+    srch_t *s = srch;
+    beam_t *bm = s->beam;
+    int32 pth = bm->phone_thres;
+    if (bm->ptranskip != 0 && (frmno % bm->ptranskip) == 0)
+        pth = bm->word_thres;           /* srch_time_switch_tree.c:975-1003 */
+#ifdef LT_ORACLE
+    {
+        int32 t;
+        for (t = 0; t < g_ntree; t++)
+            s3o_lextree_hmm_propagate_non_leaves(g_lt[t], frmno, bm->thres, pth, bm->word_thres);
+    }
+#else
+    if (s3a_lexsearch_propagate_non_leaves(g_ls, frmno, bm->thres, pth, bm->word_thres) != S3A_OK)
+        die("propagate_non_leaves");
+#endif
+    return SRCH_SUCCESS;
+}
+
+/* srch_utt_word_trans, srch_time_switch_tree.c:1087-1179 */
+static void
+tst_word_trans(srch_t *s, int32 cf)
+{
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    vithist_t *vh = tstg->vithist;
+    beam_t *bm = s->beam;
+    dict_t *dict = kbcore_dict(s->kbc);
+    mdef_t *mdef = kbcore_mdef(s->kbc);
+    int32 n_ci = mdef_n_ciphone(mdef), th = bm->bestscore + bm->hmm;
+    int32 *bs = bm->wordbestscores, *bv = bm->wordbestexits;
+    int32 p, vhid, le, k, n, maxpscore = MAX_NEG_INT32;
+    static int32 *c_lc, *c_scr, *c_hist;
+
+    if (vh->bestvh[cf] < 0)
+        return;
+    if (!c_lc) { c_lc = ckd_calloc(n_ci + 1, 4); c_scr = ckd_calloc(n_ci + 1, 4); c_hist = ckd_calloc(n_ci + 1, 4); }
+    for (p = 0; p < n_ci; p++) { bs[p] = MAX_NEG_INT32; bv[p] = -1; }
+    vhid = vithist_first_entry(vh, cf);
+    le = vithist_n_entry(vh) - 1;
+    for (; vhid <= le; vhid++) {
+        vithist_entry_t *ve = vithist_id2entry(vh, vhid);
+        int32 score;
+        if (!vithist_entry_valid(ve))
+            continue;
+        p = dict_last_phone(dict, vithist_entry_wid(ve));
+        if (mdef_is_fillerphone(mdef, p))
+            p = mdef_silphone(mdef);
+        score = vithist_entry_score(ve);
+        if (score > bs[p]) {
+            bs[p] = score;
+            bv[p] = vhid;
+            if (maxpscore < score) maxpscore = score;
+        }
+    }
+    k = tstg->n_lextrans++;
+    k = (k % (tstg->n_lextree * tstg->epl)) / tstg->epl;
+    for (p = 0, n = 0; p < n_ci; p++)
+        if (bv[p] >= 0 && (bm->wordend == 0 || bs[p] > bm->wordend + maxpscore)) {
+            c_lc[n] = p; c_scr[n] = bs[p]; c_hist[n] = bv[p]; n++;
+        }
+    be_enter(k, n, c_lc, c_scr, c_hist, cf, th);
+    c_lc[0] = BAD_S3CIPID; c_scr[0] = vh->bestscore[cf]; c_hist[0] = vh->bestvh[cf];
+    be_enter(tstg->n_lextree + k, 1, c_lc, c_scr, c_hist, cf, th);
+}
+
+static int
+tst_propagate_wd_lv2(void *srch, int32 frmno)
+{
+    srch_t *s = srch;
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    histprune_t *hp = tstg->histprune;
+    vithist_t *vh = tstg->vithist;
+    int32 t, i;
+
+    /* srch_TST_rescoring: word exits of every tree, in tree then active-list order */
+#ifdef LT_ORACLE
+    for (t = 0; t < g_ntree; t++) {
+        g_exit_n[t] = s3o_lextree_hmm_propagate_leaves(g_lt[t], s->beam->word_thres,
+                                                       g_exit_wid + t * g_max_node, g_exit_scr + t * g_max_node,
+                                                       g_exit_hist + t * g_max_node, g_max_node);
+        if (g_exit_n[t] < 0) { E_ERROR("out.history==-1, error\n"); return SRCH_FAILURE; }
+    }
+#else
+    if (s3a_lexsearch_propagate_leaves(g_ls, s->beam->word_thres, g_exit_n, g_exit_wid, g_exit_scr,
+                                       g_exit_hist, g_max_node) != S3A_OK) {
+        E_ERROR("%s\n", s3a_last_error());
+        return SRCH_FAILURE;
+    }
+#endif
+    for (t = 0; t < g_ntree; t++)
+        for (i = 0; i < g_exit_n[t]; i++)
+            vithist_rescore(vh, s->kbc, g_exit_wid[t * g_max_node + i], frmno,
+                            g_exit_scr[t * g_max_node + i], g_exit_hist[t * g_max_node + i],
+                            g_flat[t]->type, -1);
+    vithist_prune(vh, kbcore_dict(s->kbc), frmno, hp->maxwpf, hp->maxhistpf,
+                  s->beam->word_thres - s->beam->bestwordscore);
+    tst_word_trans(s, frmno);
+    return SRCH_SUCCESS;
+}
+
+static int
+tst_frame_windup(void *srch, int32 frmno)
+{
+    srch_t *s = srch;
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    vithist_frame_windup(tstg->vithist, frmno, NULL, s->kbc);
+    be_swap();
+    return SRCH_SUCCESS;
+}
+
+int
+main(int argc, char *argv[])
+{
+    kb_t kb;
+    cmd_ln_t *config;
+    srch_t *s;
+
+    cmd_ln_appl_enter(argc, argv, "default.arg", arg);
+    unlimit();
+    config = cmd_ln_get();
+    kb_init(&kb, config);
+    s = kb.srch;
+    if (s->op_mode != 4)
+        E_FATAL("tst shim: -op_mode 4 (fwdtree) only\n");
+    backend_init(&kb, (srch_TST_graph_t *)s->grh->graph_struct);
+
+    s->funcs->utt_begin = tst_begin;
+    s->funcs->utt_end = tst_end;
+    s->funcs->select_active_gmm = tst_select_active;
+    s->funcs->hmm_compute_lv2 = tst_hmm_compute_lv2;
+    s->funcs->propagate_graph_ph_lv2 = tst_propagate_ph_lv2;
+    s->funcs->propagate_graph_wd_lv2 = tst_propagate_wd_lv2;
+    s->funcs->frame_windup = tst_frame_windup;
+#ifndef LT_ORACLE
+    s->funcs->gmm_compute_lv1 = tst_gmm_lv1;
+    s->funcs->gmm_compute_lv2 = tst_gmm_lv2;
+#endif
+
+    if (!cmd_ln_str_r(config, "-ctl"))
+        E_FATAL("-ctl is required\n");
+    kb.stat->tm = ctl_process(cmd_ln_str_r(config, "-ctl"), cmd_ln_str_r(config, "-ctl_lm"),
+                              cmd_ln_str_r(config, "-ctl_mllr"), cmd_ln_int32_r(config, "-ctloffset"),
+                              cmd_ln_int32_r(config, "-ctlcount"), utt_decode, &kb);
+    if (kb.matchsegfp) fclose(kb.matchsegfp);
+    if (kb.matchfp) fclose(kb.matchfp);
+    stat_report_corpus(kb.stat);
+    E_INFO("tst shim: %ld frames searched by the replacement backend\n", g_frames);
+    if (g_frames == 0)
+        E_FATAL("tst shim: the replaced slots were never called\n");
+    return 0;
+}

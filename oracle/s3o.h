@@ -155,6 +155,55 @@ void s3o_hmm_enter(s3o_hmm_t *h, int32_t score, int64_t histid, int32_t frame); 
 void s3o_hmm_normalize(const s3o_hmm_ctx_t *ctx, s3o_hmm_t *h, int32_t bestscr); /* hmm.c:260-271 */
 int32_t s3o_hmm_vit_eval(const s3o_hmm_ctx_t *ctx, s3o_hmm_t *h);            /* hmm.c:855-873 */
 
+/* ------------------------------------------------------------------ */
+/* lexical-tree search, per-frame operations on a flattened lextree     */
+/* libsearch/lextree.c:910-961, 1093-1663 (see s3o_lextree.c)           */
+/* ------------------------------------------------------------------ */
+typedef struct s3o_lextree_s {
+    int32_t n_node;
+    const int32_t *ssid, *tmatid, *wid, *prob;  /* wid < 0: not a leaf */
+    const uint8_t *composite;
+    const int32_t *child_off, *child;           /* CSR child lists, glist order */
+    int32_t n_lc;                               /* 0: enter through root[] (filler trees) */
+    const int16_t *lc;
+    const int32_t *lcroot_off, *lcroot;         /* per left context: root node list, glist order */
+    int32_t n_root;
+    const int32_t *root;
+    s3o_hmm_ctx_t ctx, comctx;
+    s3o_hmm_t *hmm;                             /* [n_node] */
+    int32_t *active, *next_active;
+    int32_t n_active, n_next_active;
+    int32_t best, wbest;
+} s3o_lextree_t;
+
+s3o_lextree_t *s3o_lextree_init(int32_t n_node, const int32_t *ssid, const int32_t *tmatid,
+                                const uint8_t *composite, const int32_t *wid, const int32_t *prob,
+                                const int32_t *child_off, const int32_t *child,
+                                int32_t n_lc, const int16_t *lc, const int32_t *lcroot_off,
+                                const int32_t *lcroot, int32_t n_root, const int32_t *root,
+                                int32_t n_emit, const int32_t *tp, const int16_t *sseq,
+                                const int16_t *comsseq);
+void s3o_lextree_free(s3o_lextree_t *lt);
+void s3o_lextree_enter(s3o_lextree_t *lt, int32_t lc, int32_t cf, int32_t inscore, int32_t inhist,
+                       int32_t thresh);
+void s3o_lextree_active_swap(s3o_lextree_t *lt);
+int32_t s3o_lextree_hmm_eval(s3o_lextree_t *lt, const int32_t *senscr, const int32_t *comsen,
+                             int32_t frm);
+void s3o_lextree_hmm_histbin(s3o_lextree_t *lt, int32_t bestscr, int32_t *bin, int32_t nbin,
+                             int32_t bw);
+void s3o_lextree_hmm_propagate_non_leaves(s3o_lextree_t *lt, int32_t cf, int32_t th, int32_t pth,
+                                          int32_t wth);
+/* returns #word exits (or -1 on out.history == -1); fills at most max_out */
+int32_t s3o_lextree_hmm_propagate_leaves(const s3o_lextree_t *lt, int32_t wth, int32_t *out_wid,
+                                         int32_t *out_score, int32_t *out_hist, int32_t max_out);
+void s3o_lextree_ssid_active(const s3o_lextree_t *lt, uint8_t *ssid, uint8_t *comssid);
+void s3o_sseq2sen_active(const int16_t *sseq, int32_t n_sseq, int32_t n_emit, const uint8_t *ssid,
+                         uint8_t *sen);
+void s3o_comsseq2sen_active(const int16_t *comsseq, int32_t n_comsseq, int32_t n_emit,
+                            const int32_t *comstate_off, const int16_t *comstate,
+                            const uint8_t *comssid, uint8_t *sen);
+void s3o_lextree_utt_end(s3o_lextree_t *lt);
+
 #ifdef __cplusplus
 }
 #endif

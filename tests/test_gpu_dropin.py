@@ -69,3 +69,25 @@ def test_live_cpu_reference_agrees_with_committed_golden(tmp_path):
     hyp, seg, _ = run(REFDEC, RUNS["mode4_trigram"], tmp_path, "cpu_mode4")
     assert hyp == open(os.path.join(D, "ref_mode4_trigram.match")).read()
     assert seg == open(os.path.join(D, "ref_mode4_trigram.matchseg")).read()
+
+
+# ---------------------------------------------------------------------------
+# the whole per-frame hot path on the GPU: scoring + composite senones +
+# active-senone selection + lextree HMM evaluation + phone-level propagation
+# (oracle/ref_tst_shim.c); only vithist + LM stay the reference's host code
+# ---------------------------------------------------------------------------
+TST = os.path.join(ROOT, "oracle", "_ref", "ref_s3amd_tst_decode")
+
+
+@pytest.mark.skipif(not os.path.exists(TST), reason="oracle/_ref/ref_s3amd_tst_decode did not travel")
+@pytest.mark.parametrize("name", ["mode4_trigram", "mode4_cibeam_ds2"])
+def test_full_device_search_matches_reference(name, tmp_path):
+    hyp, seg, log = (str(tmp_path / f"tst_{name}.{e}") for e in ("match", "matchseg", "log"))
+    with open(log, "w") as lf:
+        p = subprocess.run([TST] + common() + RUNS[name] + ["-hyp", hyp, "-hypseg", seg],
+                           stdout=lf, stderr=subprocess.STDOUT, timeout=900)
+    tail = [l for l in open(log, errors="ignore").read().splitlines() if "tst shim" in l or "FATAL" in l]
+    assert p.returncode == 0, "\n".join(tail[-10:])
+    assert any("frames searched by the replacement backend" in l for l in tail)
+    assert open(hyp).read() == open(os.path.join(D, f"ref_{name}.match")).read()
+    assert open(seg).read() == open(os.path.join(D, f"ref_{name}.matchseg")).read()
