@@ -80,6 +80,11 @@ struct s3a_lexsearch_s {
     int32_t *d_calls, *d_ent, *d_eflag, *d_first;   /* enter scratch */
     unsigned long long *d_key;
     int32_t ent_cap;
+    int32_t *d_thr;                     /* [8] thresholds + frame statistics */
+    int32_t *d_pack, *h_pack;           /* per-frame result record (device / pinned host) */
+    int32_t pack_max_exits;
+    int32_t *h_ring;                    /* pinned staging ring for enter calls */
+    int32_t ring_slot;
     int32_t *h_pin;                     /* pinned host mirror for small read-backs */
     hipStream_t stream;
     int own_stream;
@@ -194,13 +199,14 @@ k_lt_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict__
 /* phase A: every propagating parent nominates its INACTIVE children once */
 __global__ void __launch_bounds__(LT_BLOCK)
 k_lt_prop_mark(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
-               const int32_t *__restrict__ nact, int32_t cf, int32_t th, int32_t pth,
+               const int32_t *__restrict__ nact, int32_t cf, const int32_t *__restrict__ thr,
                const int32_t *__restrict__ wid, const int32_t *__restrict__ prob,
                const int32_t *__restrict__ child_off, const int32_t *__restrict__ child,
                const int32_t *__restrict__ outs, const int32_t *__restrict__ posf,
                int32_t *candf, int32_t *cand, int32_t *ncand)
 {
     const int32_t t = blockIdx.y, i = blockIdx.x * LT_BLOCK + threadIdx.x;
+    const int32_t th = thr[0], pth = thr[1];
     if (i >= nact[t]) return;
     const int32_t u = act[node_base[t] + i];
     if (wid[u] >= 0 || outs[u] < pth) return;
@@ -216,7 +222,8 @@ k_lt_prop_mark(const int32_t *__restrict__ node_base, const int32_t *__restrict_
 __global__ void __launch_bounds__(LT_BLOCK)
 k_lt_prop_resolve(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
                   const int32_t *__restrict__ nact, const int32_t *__restrict__ cand,
-                  const int32_t *__restrict__ ncand, int32_t N, int32_t cf, int32_t th, int32_t pth,
+                  const int32_t *__restrict__ ncand, int32_t N, int32_t cf,
+                  const int32_t *__restrict__ thr,
                   const int32_t *__restrict__ wid, const int32_t *__restrict__ prob,
                   const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
                   const int32_t *__restrict__ pos, const int32_t *__restrict__ posf,
@@ -225,6 +232,7 @@ k_lt_prop_resolve(const int32_t *__restrict__ node_base, const int32_t *__restri
 {
     const int32_t t = blockIdx.y, i = blockIdx.x * LT_BLOCK + threadIdx.x;
     const int32_t na = nact[t], nc = ncand[t];
+    const int32_t th = thr[0], pth = thr[1];
     if (i >= na + nc) return;
     const bool is_active = i < na;
     const int32_t v = is_active ? act[node_base[t] + i] : cand[node_base[t] + (i - na)];
@@ -318,13 +326,14 @@ k_lt_prop_emit(const int32_t *__restrict__ node_base, const int32_t *__restrict_
 /* ------------------------------------------------------------------ */
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_lt_leaves(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
-            const int32_t *__restrict__ nact, int32_t N, int32_t wth,
+            const int32_t *__restrict__ nact, int32_t N, const int32_t *__restrict__ thr,
             const int32_t *__restrict__ wid, const int32_t *__restrict__ prob,
             const int32_t *__restrict__ outs, const int32_t *__restrict__ outh,
             int32_t *flag, int32_t *exits, int32_t *nexit, int32_t n_tree)
 {
     __shared__ int32_t total;
     const int32_t t = blockIdx.x, b = node_base[t], na = nact[t];
+    const int32_t wth = thr[2];
     for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
         const int32_t u = act[b + i];
         flag[b + i] = (wid[u] >= 0 && outs[u] >= wth) ? 1 : 0;
@@ -346,6 +355,69 @@ k_lt_leaves(const int32_t *__restrict__ node_base, const int32_t *__restrict__ a
     for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS)
         flag[b + i] = 0;
     if (threadIdx.x == 0) nexit[t] = total;
+}
+
+/* srch_TST_hmm_compute_lv2's threshold arithmetic (srch_time_switch_tree.c:826-905) on the
+ * device, so that propagation can start without a host round trip:
+ * thr = {thres, phone_thres, word_thres, besthmmscr, bestwordscr, frm_nhmm, need_histprune} */
+__global__ void
+k_lt_thresholds(const int32_t *__restrict__ best, const int32_t *__restrict__ nact, int32_t n_tree,
+                int32_t hmmbeam, int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam,
+                int32_t maxhmmpf, int32_t *thr)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int32_t bh = INT_MIN, bw = INT_MIN, n = 0;
+    for (int32_t t = 0; t < n_tree; t++) {
+        bh = max(bh, best[2 * t]);
+        bw = max(bw, best[2 * t + 1]);
+        n += nact[t];
+    }
+    thr[0] = add32(bh, hmmbeam);
+    thr[2] = add32(bw, wbeam);
+    thr[1] = phone_uses_wbeam ? thr[2] : add32(bh, pbeam);
+    thr[3] = bh; thr[4] = bw; thr[5] = n;
+    thr[6] = (n > maxhmmpf + (maxhmmpf >> 1)) ? 1 : 0;
+}
+
+__global__ void
+k_lt_set_thr(int32_t *thr, int32_t th, int32_t pth, int32_t wth)
+{
+    if (threadIdx.x == 0) { thr[0] = th; thr[1] = pth; thr[2] = wth; }
+}
+
+/* gather everything the host needs from one frame into one contiguous record:
+ * [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | extra[8] | exits (wid,score,hist) */
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_lt_pack(const int32_t *__restrict__ node_base, int32_t n_tree, int32_t N,
+          const int32_t *__restrict__ best, const int32_t *__restrict__ nact,
+          const int32_t *__restrict__ thr, const int32_t *__restrict__ nexit,
+          const int32_t *__restrict__ exits, const int32_t *__restrict__ extra, int32_t *pack,
+          int32_t max_exits)
+{
+    const int32_t T = n_tree, hdr = 5 * T + 16;
+    for (int32_t i = threadIdx.x; i < 2 * T; i += SCAN_THREADS) pack[i] = best[i];
+    for (int32_t i = threadIdx.x; i < T; i += SCAN_THREADS) {
+        pack[2 * T + i] = nact[i];
+        pack[3 * T + 8 + i] = nexit[i];
+        pack[4 * T + 8 + i] = nexit[T + i];
+    }
+    if (threadIdx.x < 8) {
+        pack[3 * T + threadIdx.x] = thr[threadIdx.x];
+        pack[5 * T + 8 + threadIdx.x] = extra ? extra[threadIdx.x] : 0;
+    }
+    int32_t off = 0;
+    for (int32_t t = 0; t < T; t++) {
+        const int32_t n = nexit[t], b = node_base[t];
+        for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
+            const int32_t k = off + i;
+            if (k < max_exits) {
+                pack[hdr + 3 * k] = exits[b + i];
+                pack[hdr + 3 * k + 1] = exits[N + b + i];
+                pack[hdr + 3 * k + 2] = exits[2 * N + b + i];
+            }
+        }
+        off += n;
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -599,6 +671,11 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
     DMALLOC(ls->d_ent, (size_t)2 * ls->ent_cap * 4); DMALLOC(ls->d_eflag, (size_t)ls->ent_cap * 4);
     DMALLOC(ls->d_first, (size_t)N * 4); DMALLOC(ls->d_key, (size_t)N * 8);
     HIPCHK(hipHostMalloc((void **)&ls->h_pin, (size_t)(8 * n_tree + 16) * 4));
+    DMALLOC(ls->d_thr, 8 * 4);
+    ls->pack_max_exits = 2048;
+    DMALLOC(ls->d_pack, (size_t)(5 * n_tree + 16 + 3 * ls->pack_max_exits) * 4);
+    HIPCHK(hipHostMalloc((void **)&ls->h_pack, (size_t)(5 * n_tree + 16 + 3 * ls->pack_max_exits) * 4));
+    HIPCHK(hipHostMalloc((void **)&ls->h_ring, (size_t)8 * (2 * 4096 + 2 * ls->ent_cap) * 4));
     return S3A_OK;
 }
 
@@ -658,11 +735,13 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
         &ls->d_frame, &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
-        &ls->d_first };
+        &ls->d_first, &ls->d_thr, &ls->d_pack };
     for (auto p : ptrs) (void)hipFree(*p);
     (void)hipFree(ls->d_comp); (void)hipFree(ls->d_sseq); (void)hipFree(ls->d_comsseq);
     (void)hipFree(ls->d_comstate); (void)hipFree(ls->d_key);
     if (ls->h_pin) (void)hipHostFree(ls->h_pin);
+    if (ls->h_pack) (void)hipHostFree(ls->h_pack);
+    if (ls->h_ring) (void)hipHostFree(ls->h_ring);
     if (ls->own_stream && ls->stream) (void)hipStreamDestroy(ls->stream);
     delete ls;
 }
@@ -720,35 +799,39 @@ s3a_lexsearch_hmm_eval(s3a_lexsearch_t *ls, const int32_t *senscr_dev, const int
     return S3A_OK;
 }
 
-extern "C" int32_t
-s3a_lexsearch_propagate_non_leaves(s3a_lexsearch_t *ls, int32_t cf, int32_t th, int32_t pth,
-                                   int32_t wth)
+static int32_t
+launch_propagate(s3a_lexsearch_t *ls, int32_t cf)
 {
     int32_t maxn = 0, t, rc;
     const int cur = ls->cur, nxt = cur ^ 1;
-    (void)wth;
-    if (!ls) return S3A_EINVAL;
     for (t = 0; t < ls->n_tree; t++)
         maxn = max(maxn, ls->node_base[t + 1] - ls->node_base[t]);
     if ((rc = fill(ls, ls->d_ncand, 0, ls->n_tree)) != S3A_OK) return rc;
     dim3 grid((maxn + LT_BLOCK - 1) / LT_BLOCK, ls->n_tree);
     hipLaunchKernelGGL(k_lt_prop_mark, grid, dim3(LT_BLOCK), 0, ls->stream, ls->d_node_base,
-                       ls->d_act[cur], ls->d_nact[cur], cf, th, pth, ls->d_wid, ls->d_prob,
+                       ls->d_act[cur], ls->d_nact[cur], cf, ls->d_thr, ls->d_wid, ls->d_prob,
                        ls->d_child_off, ls->d_child, ls->d_outs, ls->d_posf, ls->d_candf, ls->d_cand,
                        ls->d_ncand);
-    HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_lt_prop_resolve, grid, dim3(LT_BLOCK), 0, ls->stream, ls->d_node_base,
-                       ls->d_act[cur], ls->d_nact[cur], ls->d_cand, ls->d_ncand, ls->N, cf, th, pth,
+                       ls->d_act[cur], ls->d_nact[cur], ls->d_cand, ls->d_ncand, ls->N, cf, ls->d_thr,
                        ls->d_wid, ls->d_prob, ls->d_par_off, ls->d_par, ls->d_pos, ls->d_posf,
                        ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame,
                        ls->d_turn, ls->d_selfemit, ls->d_cnt);
-    HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_lt_prop_emit, dim3(ls->n_tree), dim3(SCAN_THREADS), 0, ls->stream,
                        ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], cf, ls->d_child_off,
                        ls->d_child, ls->d_turn, ls->d_selfemit, ls->d_cnt, ls->d_act[nxt],
                        ls->d_nact[nxt], ls->d_pos, ls->d_posf);
     HIPCHK(hipGetLastError());
     return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_lexsearch_propagate_non_leaves(s3a_lexsearch_t *ls, int32_t cf, int32_t th, int32_t pth,
+                                   int32_t wth)
+{
+    if (!ls) return S3A_EINVAL;
+    hipLaunchKernelGGL(k_lt_set_thr, dim3(1), dim3(64), 0, ls->stream, ls->d_thr, th, pth, wth);
+    return launch_propagate(ls, cf);
 }
 
 extern "C" int32_t
@@ -759,8 +842,9 @@ s3a_lexsearch_propagate_leaves(s3a_lexsearch_t *ls, int32_t wth, int32_t *n_exit
     int32_t t;
     const int cur = ls->cur;
     if (!ls || !n_exit || !exit_wid || !exit_score || !exit_hist) return S3A_EINVAL;
+    hipLaunchKernelGGL(k_fill_i32, dim3(1), dim3(64), 0, ls->stream, ls->d_thr + 2, wth, 1);
     hipLaunchKernelGGL(k_lt_leaves, dim3(ls->n_tree), dim3(SCAN_THREADS), 0, ls->stream,
-                       ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->N, wth, ls->d_wid,
+                       ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->N, ls->d_thr, ls->d_wid,
                        ls->d_prob, ls->d_outs, ls->d_outh, ls->d_cnt, ls->d_exit, ls->d_nexit,
                        ls->n_tree);
     HIPCHK(hipGetLastError());
@@ -818,10 +902,8 @@ s3a_lexsearch_enter(s3a_lexsearch_t *ls, int32_t tree, int32_t n_calls, const in
     }
     if (n_ent == 0) return S3A_OK;
     if (n_ent > ls->ent_cap) {
-        (void)hipFree(ls->d_ent); (void)hipFree(ls->d_eflag);
-        ls->ent_cap = n_ent;
-        DMALLOC(ls->d_ent, (size_t)2 * n_ent * 4);
-        DMALLOC(ls->d_eflag, (size_t)n_ent * 4);
+        s3a_set_error("s3a_lexsearch_enter: a left context was entered twice in one batch of calls");
+        return S3A_EINVAL;
     }
     ent.resize((size_t)2 * n_ent);
     for (int32_t c = 0, e = 0; c < n_calls; c++)
@@ -829,8 +911,17 @@ s3a_lexsearch_enter(s3a_lexsearch_t *ls, int32_t tree, int32_t n_calls, const in
             ent[2 * e] = ls->h_rootlist[coff[c] + i];
             ent[2 * e + 1] = c;
         }
-    HIPCHK(hipMemcpyAsync(ls->d_calls, calls.data(), calls.size() * 4, hipMemcpyHostToDevice, ls->stream));
-    HIPCHK(hipMemcpyAsync(ls->d_ent, ent.data(), ent.size() * 4, hipMemcpyHostToDevice, ls->stream));
+    /* stage through a pinned ring (8 slots): a slot is reused only after 4 more frames, and
+     * every frame ends in a stream synchronisation, so the copies below are truly async */
+    {
+        const size_t slot_words = (size_t)2 * 4096 + (size_t)2 * ls->ent_cap;
+        int32_t *slot = ls->h_ring + (size_t)(ls->ring_slot++ & 7) * slot_words;
+        if ((size_t)2 * n_ent > (size_t)2 * ls->ent_cap) { s3a_set_error("enter staging overflow"); return S3A_EINVAL; }
+        memcpy(slot, calls.data(), calls.size() * 4);
+        memcpy(slot + 2 * 4096, ent.data(), ent.size() * 4);
+        HIPCHK(hipMemcpyAsync(ls->d_calls, slot, calls.size() * 4, hipMemcpyHostToDevice, ls->stream));
+        HIPCHK(hipMemcpyAsync(ls->d_ent, slot + 2 * 4096, ent.size() * 4, hipMemcpyHostToDevice, ls->stream));
+    }
     dim3 g((n_ent + 255) / 256), blk(256);
     hipLaunchKernelGGL(k_lt_enter_pass0, g, blk, 0, ls->stream, ls->d_ent, n_ent, ls->d_key, ls->d_first);
     hipLaunchKernelGGL(k_lt_enter_pass1, g, blk, 0, ls->stream, ls->d_ent, n_ent, ls->d_calls,
@@ -843,7 +934,78 @@ s3a_lexsearch_enter(s3a_lexsearch_t *ls, int32_t tree, int32_t n_calls, const in
                        ls->d_prob, thresh, cf + 1, ls->d_key, ls->d_first, ls->d_sc, ls->d_hist,
                        ls->d_frame);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ls->stream));   /* calls / ent are stack vectors */
+    return S3A_OK;
+}
+
+/*
+ * One whole search frame without intermediate host round trips: lextree_hmm_eval on every
+ * tree, the beam thresholds of srch_TST_hmm_compute_lv2, lextree_hmm_propagate_non_leaves,
+ * lextree_hmm_propagate_leaves, then ONE packed read-back + synchronisation.
+ */
+extern "C" int32_t
+s3a_lexsearch_frame_search(s3a_lexsearch_t *ls, const int32_t *senscr_dev,
+                           const int32_t *comsen_dev, int32_t frm, int32_t hmmbeam, int32_t pbeam,
+                           int32_t wbeam, int32_t phone_uses_wbeam, int32_t maxhmmpf,
+                           const int32_t *extra_dev, s3a_frame_result_t *res, int32_t *n_exit,
+                           int32_t *exit_wid, int32_t *exit_score, int32_t *exit_hist,
+                           int32_t max_exits)
+{
+    int32_t maxn = 0, t, rc, total = 0;
+    if (!ls || !senscr_dev || !res || !n_exit || !exit_wid || !exit_score || !exit_hist) return S3A_EINVAL;
+    const int32_t T = ls->n_tree, hdr = 5 * T + 16;
+    for (t = 0; t < T; t++)
+        maxn = max(maxn, ls->node_base[t + 1] - ls->node_base[t]);
+    if ((rc = fill(ls, ls->d_best, INT_MIN, 2 * T)) != S3A_OK) return rc;
+    hipLaunchKernelGGL(k_lt_hmm_eval, dim3((maxn + LT_BLOCK - 1) / LT_BLOCK, T), dim3(LT_BLOCK),
+                       (size_t)ls->n_tmat * 12 * 4, ls->stream, ls->d_node_base, ls->d_act[ls->cur],
+                       ls->d_nact[ls->cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid,
+                       ls->d_comp, ls->d_tp, ls->d_sseq, ls->d_comsseq, senscr_dev,
+                       comsen_dev ? comsen_dev : senscr_dev, ls->d_sc, ls->d_hist, ls->d_outs,
+                       ls->d_outh, ls->d_bests, ls->d_best);
+    hipLaunchKernelGGL(k_lt_thresholds, dim3(1), dim3(64), 0, ls->stream, ls->d_best,
+                       ls->d_nact[ls->cur], T, hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf,
+                       ls->d_thr);
+    if ((rc = launch_propagate(ls, frm)) != S3A_OK) return rc;
+    hipLaunchKernelGGL(k_lt_leaves, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->d_node_base,
+                       ls->d_act[ls->cur], ls->d_nact[ls->cur], ls->N, ls->d_thr, ls->d_wid, ls->d_prob,
+                       ls->d_outs, ls->d_outh, ls->d_cnt, ls->d_exit, ls->d_nexit, T);
+    hipLaunchKernelGGL(k_lt_pack, dim3(1), dim3(SCAN_THREADS), 0, ls->stream, ls->d_node_base, T,
+                       ls->N, ls->d_best, ls->d_nact[ls->cur], ls->d_thr, ls->d_nexit, ls->d_exit,
+                       extra_dev, ls->d_pack, ls->pack_max_exits);
+    HIPCHK(hipGetLastError());
+    /* header + the first 256 exits in one copy; the (rare) rest in a second one */
+    const int32_t first = 256;
+    HIPCHK(hipMemcpyAsync(ls->h_pack, ls->d_pack, (size_t)(hdr + 3 * first) * 4, hipMemcpyDeviceToHost, ls->stream));
+    HIPCHK(hipStreamSynchronize(ls->stream));
+    const int32_t *p = ls->h_pack;
+    res->best_hmm = p[3 * T + 3]; res->best_word = p[3 * T + 4]; res->n_hmm = p[3 * T + 5];
+    res->thres = p[3 * T + 0]; res->phone_thres = p[3 * T + 1]; res->word_thres = p[3 * T + 2];
+    res->need_histprune = p[3 * T + 6];
+    for (int i = 0; i < 8; i++) res->extra[i] = p[5 * T + 8 + i];
+    for (t = 0; t < T; t++) {
+        if (p[4 * T + 8 + t]) {
+            (void)fill(ls, ls->d_nexit, 0, 2 * T);
+            s3a_set_error("out.history==-1 at a word exit of tree %d (LEXTREE_OPERATION_FAILURE)", t);
+            return S3A_EINVAL;
+        }
+        n_exit[t] = p[3 * T + 8 + t];
+        total += n_exit[t];
+    }
+    res->n_exit_total = total;
+    if (total > max_exits || total > ls->pack_max_exits) {
+        s3a_set_error("s3a_lexsearch_frame_search: %d word exits in one frame exceed the buffers", total);
+        return S3A_EINVAL;
+    }
+    if (total > first) {
+        HIPCHK(hipMemcpyAsync(ls->h_pack + hdr + 3 * first, ls->d_pack + hdr + 3 * first,
+                              (size_t)3 * (total - first) * 4, hipMemcpyDeviceToHost, ls->stream));
+        HIPCHK(hipStreamSynchronize(ls->stream));
+    }
+    for (int32_t k = 0; k < total; k++) {
+        exit_wid[k] = p[hdr + 3 * k];
+        exit_score[k] = p[hdr + 3 * k + 1];
+        exit_hist[k] = p[hdr + 3 * k + 2];
+    }
     return S3A_OK;
 }
 

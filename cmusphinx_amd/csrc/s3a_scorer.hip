@@ -58,8 +58,9 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
               int32_t Gpad, int32_t sen_lo, int32_t sen_hi, int32_t ci_phase,
               const uint8_t *__restrict__ ncomp, const int16_t *__restrict__ cd2cisen,
               const uint8_t *__restrict__ sen_active, int32_t *__restrict__ senscr,
-              int32_t pbest_plus_beam, int32_t frame, int32_t is_skip,
-              int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc)
+              int32_t pbest_plus_beam, const int32_t *__restrict__ pbest_ptr, int32_t beam,
+              int32_t frame, int32_t is_skip,
+              int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc, int32_t best_slot)
 {
     typedef typename Acc<EXACT>::T acc_t;
     const int32_t lane = threadIdx.x & 63;
@@ -69,6 +70,9 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
     LogAdd la;
     la.tab = tab_g; la.size = tab_size; la.zero = lm_zero;
 
+    /* device-resident path: the CI maximum was left in memory by the CI phase */
+    if (pbest_ptr)
+        pbest_plus_beam = (int32_t)((uint32_t)*pbest_ptr + (uint32_t)beam);
     /* 0 = untouched, 1 = full, 2 = single Gaussian, 3 = CI copy */
     int32_t mode = 0, ci_scr = 0, bi = S3A_NO_BSTIDX;
     if (valid) {
@@ -134,7 +138,7 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
         ng += __shfl_xor(ng, o, 64);
     }
     if (lane == 0) {
-        if (wbest != INT_MIN) atomicMax(&misc[0], wbest);
+        if (wbest != INT_MIN) atomicMax(&misc[best_slot], wbest);
         if (!ci_phase && ns) atomicAdd(&misc[1], ns);
         if (!ci_phase && ng) atomicAdd(&misc[2], ng);
         if (ci_phase && ns) atomicAdd(&misc[3], ns);
@@ -144,13 +148,23 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
 
 /* approx_cont_mgau.c:597-600 */
 __global__ void
-k_normalise(int32_t *senscr, uint8_t *sen_active, const int32_t *misc, int32_t S, int32_t n_ci)
+k_normalise(int32_t *senscr, uint8_t *sen_active, int32_t *misc, int32_t S, int32_t n_ci,
+            int32_t ci_slot)
 {
     int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
+    int32_t best = misc[0];
+    if (ci_slot >= 0) best = max(best, misc[ci_slot]);   /* CI maximum kept in its own slot */
     if (s < n_ci) sen_active[s] = 1;    /* CI senones are forced active, approx_cont_mgau.c:537 */
     if (s < n_ci || sen_active[s])
-        senscr[s] -= misc[0];
+        senscr[s] -= best;
+    if (s == 0) misc[6] = best;         /* the frame's normaliser (srch->senscale) */
+}
+
+__global__ void
+k_misc_reset(int32_t *misc)
+{
+    if (threadIdx.x < 8) misc[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 5) ? INT_MIN : 0;
 }
 
 extern "C" s3a_scorer_t *
@@ -249,7 +263,8 @@ s3a_scorer_utt_begin(s3a_scorer_t *sc)
 
 static void
 launch_gated(s3a_scorer_t *sc, int32_t lo, int32_t hi, int32_t ci_phase, int32_t thresh,
-             int32_t frame, int32_t is_skip)
+             int32_t frame, int32_t is_skip, const int32_t *pbest_ptr = NULL, int32_t beam = 0,
+             int32_t best_slot = 0)
 {
     s3a_mgau_model_t *g = sc->g;
     struct s3a_mgau_dev_s *d = g->dev;
@@ -260,14 +275,14 @@ launch_gated(s3a_scorer_t *sc, int32_t lo, int32_t hi, int32_t ci_phase, int32_t
         hipLaunchKernelGGL(k_gated_frame<true>, dim3(grid), dim3(256), 0, d->stream, d->mean4,
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
-                           sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, frame,
-                           is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d);
+                           sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
+                           frame, is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d, best_slot);
     else
         hipLaunchKernelGGL(k_gated_frame<false>, dim3(grid), dim3(256), 0, d->stream, d->mean4,
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
-                           sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, frame,
-                           is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d);
+                           sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
+                           frame, is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d, best_slot);
 }
 
 static const int32_t k_misc_init[8] = { INT_MIN, 0, 0, 0, 0, 0, 0, 0 };
@@ -370,7 +385,7 @@ s3a_approx_cont_mgau_frame_eval(s3a_scorer_t *sc, uint8_t *sen_active, uint8_t *
                  (int32_t)((uint32_t)pbest + (uint32_t)beam), frame, is_skip);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_normalise, dim3((sc->n_sen + 255) / 256), dim3(256), 0, d->stream,
-                       sc->scr_d, sc->act_d, sc->misc_d, sc->n_sen, sc->n_ci_sen);
+                       sc->scr_d, sc->act_d, sc->misc_d, sc->n_sen, sc->n_ci_sen, -1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(senscr, sc->scr_d, sizeof(int32_t) * sc->n_sen, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipMemcpyAsync(sc->misc_h, sc->misc_d, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, d->stream));
@@ -508,7 +523,7 @@ s3a_approx_cont_mgau_frame_eval_dev(s3a_scorer_t *sc, s3a_comsen_t *cs, const fl
     launch_gated(sc, sc->n_ci_sen, sc->n_sen, 0, (int32_t)((uint32_t)pbest + (uint32_t)beam), frame, is_skip);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_normalise, dim3((sc->n_sen + 255) / 256), dim3(256), 0, d->stream,
-                       sc->scr_d, sc->act_d, sc->misc_d, sc->n_sen, sc->n_ci_sen);
+                       sc->scr_d, sc->act_d, sc->misc_d, sc->n_sen, sc->n_ci_sen, -1);
     HIPCHK(hipGetLastError());
     if (cs) {
         /* cs has its own stream object but the composite pass must follow the scores: run it here */
@@ -521,5 +536,44 @@ s3a_approx_cont_mgau_frame_eval_dev(s3a_scorer_t *sc, s3a_comsen_t *cs, const fl
     *best = sc->misc_h[0];
     if (n_sen_eval) *n_sen_eval = sc->misc_h[1];
     if (n_gau_eval) *n_gau_eval = sc->misc_h[2];
+    return S3A_OK;
+}
+
+extern "C" int32_t *s3a_scorer_misc_dev(s3a_scorer_t *sc) { return sc ? sc->misc_d : NULL; }
+
+/*
+ * Fully asynchronous frame: CI senones, the CI gate, CD senones, normalisation and the
+ * composite pass are enqueued back to back; nothing is read back.  The frame's results
+ * stay on the device: senscr (s3a_scorer_senscr_dev), comsen (s3a_comsen_dev) and
+ * misc[8] = {.., [1] #CD senones evaluated, [2] #CD Gaussians, [3] #CI senones,
+ * [4] #CI Gaussians, [5] CI best, [6] frame normaliser = srch->senscale}.
+ */
+extern "C" int32_t
+s3a_approx_cont_mgau_frame_eval_async(s3a_scorer_t *sc, s3a_comsen_t *cs, const float *feat,
+                                      int32_t frame)
+{
+    struct s3a_mgau_dev_s *d;
+    int32_t beam, is_skip;
+    if (!sc || !feat) return S3A_EINVAL;
+    if (sc->max_cd < sc->n_sen - sc->n_ci_sen) {
+        s3a_set_error("-maxcdsenpf (dynamic CI beam) needs the host senone mask: use the host-pointer entry point");
+        return S3A_EUNSUP;
+    }
+    d = sc->g->dev;
+    beam = sc->ci_pbeam;
+    is_skip = (frame % sc->ds_ratio == 0) ? 0 : 1;
+    if (is_skip)
+        beam = (int32_t)((float)beam * sc->tighten_factor);
+    HIPCHK(hipMemcpyAsync(sc->x_d, feat, sizeof(float) * d->D, hipMemcpyHostToDevice, d->stream));
+    hipLaunchKernelGGL(k_misc_reset, dim3(1), dim3(64), 0, d->stream, sc->misc_d);
+    launch_gated(sc, 0, sc->n_ci_sen, 1, 0, frame, 0, NULL, 0, 5);                 /* CI -> misc[5] */
+    launch_gated(sc, sc->n_ci_sen, sc->n_sen, 0, 0, frame, is_skip, sc->misc_d + 5, beam, 0);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_normalise, dim3((sc->n_sen + 255) / 256), dim3(256), 0, d->stream,
+                       sc->scr_d, sc->act_d, sc->misc_d, sc->n_sen, sc->n_ci_sen, 5);
+    if (cs)
+        hipLaunchKernelGGL(k_comsenscr, dim3((cs->n_comstate + 255) / 256), dim3(256), 0, d->stream,
+                           cs->n_comstate, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d, cs->out_d);
+    HIPCHK(hipGetLastError());
     return S3A_OK;
 }

@@ -101,6 +101,10 @@ _SIGS = {
     "s3a_lexsearch_propagate_non_leaves": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "s3a_lexsearch_propagate_leaves": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_int32]),
+    "s3a_lexsearch_frame_search": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 6 +
+                                   [C.c_void_p] * 6 + [C.c_int32]),
+    "s3a_approx_cont_mgau_frame_eval_async": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_scorer_misc_dev": (C.c_void_p, [C.c_void_p]),
     "s3a_lexsearch_sen_active": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_lexsearch_utt_end": (C.c_int32, [C.c_void_p]),
     "s3a_lexsearch_get_active": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),

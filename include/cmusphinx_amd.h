@@ -333,6 +333,29 @@ int32_t s3a_lexsearch_propagate_non_leaves(s3a_lexsearch_t *ls, int32_t cf, int3
 int32_t s3a_lexsearch_propagate_leaves(s3a_lexsearch_t *ls, int32_t wth, int32_t *n_exit,
                                        int32_t *exit_wid, int32_t *exit_score,
                                        int32_t *exit_hist, int32_t max_per_tree);
+/*
+ * One whole search frame with a single host synchronisation: lextree_hmm_eval on every
+ * tree, the beam arithmetic of srch_TST_hmm_compute_lv2 (srch_time_switch_tree.c:826-905;
+ * hmmbeam/pbeam/wbeam are beam_t.hmm/ptrans/word, phone_uses_wbeam the -ptranskip frames),
+ * lextree_hmm_propagate_non_leaves, lextree_hmm_propagate_leaves.  Word exits of all trees
+ * come back concatenated in tree order (n_exit[t] each).  extra_dev (optional, 8 int32 in
+ * device memory, e.g. s3a_scorer_misc_dev) is copied into res->extra with the same read-back.
+ * need_histprune != 0 reports that the frame held more than 1.5 x maxhmmpf HMMs, i.e. the
+ * reference would have histogram-pruned (lextree_hmm_histbin): not done on the device yet.
+ */
+typedef struct s3a_frame_result_s {
+    int32_t best_hmm, best_word, n_hmm;         /* beam_t.bestscore / bestwordscore, #active HMMs */
+    int32_t thres, phone_thres, word_thres;     /* beam_t.thres / phone_thres / word_thres */
+    int32_t need_histprune;
+    int32_t n_exit_total;
+    int32_t extra[8];
+} s3a_frame_result_t;
+int32_t s3a_lexsearch_frame_search(s3a_lexsearch_t *ls, const int32_t *senscr_dev,
+                                   const int32_t *comsen_dev, int32_t frm, int32_t hmmbeam,
+                                   int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam,
+                                   int32_t maxhmmpf, const int32_t *extra_dev,
+                                   s3a_frame_result_t *res, int32_t *n_exit, int32_t *exit_wid,
+                                   int32_t *exit_score, int32_t *exit_hist, int32_t max_exits);
 /* srch_TST_select_active_gmm (srch_time_switch_tree.c:1262-1324): clear, then mark the
  * senones of every active HMM (composite ones through their member lists) in a DEVICE
  * flag array of n_sen bytes (s3a_scorer_sen_active_dev) */
@@ -356,6 +379,12 @@ int32_t *s3a_comsen_dev(s3a_comsen_t *cs);
 /* approx_cont_mgau_frame_eval with sen_active taken from, and senscr left in, the
  * scorer's device buffers; cs (optional) then receives dict2pid_comsenscr on device.
  * -maxcdsenpf's dynamic CI beam needs the host mask and is rejected here. */
+/* fully asynchronous variant: also computes the CI senones on the device (no host cache),
+ * reads nothing back; misc (8 int32, device): [1] #CD senones evaluated [2] #CD Gaussians
+ * [3] #CI senones [4] #CI Gaussians [5] CI best [6] frame normaliser (srch->senscale) */
+int32_t s3a_approx_cont_mgau_frame_eval_async(s3a_scorer_t *sc, s3a_comsen_t *cs,
+                                              const float *feat, int32_t frame);
+int32_t *s3a_scorer_misc_dev(s3a_scorer_t *sc);
 int32_t s3a_approx_cont_mgau_frame_eval_dev(s3a_scorer_t *sc, s3a_comsen_t *cs, const float *feat,
                                             int32_t frame, const int32_t *cache_ci_senscr,
                                             int32_t *best, int32_t *n_sen_eval,

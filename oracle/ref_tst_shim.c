@@ -391,13 +391,12 @@ tst_end(void *srch)
 }
 
 #ifndef LT_ORACLE
+static int32 g_ascale_idx;
+
+/* the CI senones are scored on the device inside gmm_compute_lv2 (no host cache needed) */
 static int
 tst_gmm_lv1(void *srch, float32 *feat, int32 cache_idx, int32 wav_idx)
 {
-    srch_t *s = srch;
-    ascr_t *a = s->ascr;
-    if (s3a_approx_cont_mgau_ci_eval(g_sc, feat, a->cache_ci_senscr[cache_idx],
-                                     &a->cache_best_list[cache_idx], wav_idx) != S3A_OK) die("lv1");
     return SRCH_SUCCESS;
 }
 
@@ -410,18 +409,17 @@ tst_select_active(void *srch)
     return SRCH_SUCCESS;
 }
 
+/* enqueue only: CI gate, CD senones, normalisation, composite senones; nothing read back.
+ * srch.c:752 copies s->senscale into ascale[] right after this slot returns; the real
+ * value arrives with the frame's single read-back and is patched in there. */
 static int
 tst_gmm_lv2(void *srch, float32 **feat, int32 wav_idx)
 {
     srch_t *s = srch;
-    ascr_t *a = s->ascr;
-    int32 best, ns, ng;
-    if (s3a_approx_cont_mgau_frame_eval_dev(g_sc, g_cs, feat[0], wav_idx,
-                                            a->cache_ci_senscr[s->cache_win_strt], &best, &ns, &ng) != S3A_OK)
+    if (s3a_approx_cont_mgau_frame_eval_async(g_sc, g_cs, feat[0], wav_idx) != S3A_OK)
         die("lv2");
-    s->senscale = best;
-    s->stat->utt_sen_eval += ns;
-    s->stat->utt_gau_eval += ng;
+    g_ascale_idx = s->num_frm + wav_idx;
+    s->senscale = 0;
     return SRCH_SUCCESS;
 }
 #else
@@ -456,15 +454,18 @@ tst_hmm_compute_lv2(void *srch, int32 frmno)
     beam_t *bm = s->beam;
     int32 besthmmscr = MAX_NEG_INT32, bestwordscr = MAX_NEG_INT32, frm_nhmm = 0, t, hb, pb, wb;
 
-#ifdef LT_ORACLE
+#ifndef LT_ORACLE
+    /* device backend: evaluation, thresholds, propagation and word exits are ONE enqueue
+     * with one read-back, issued from the propagate_graph_wd_lv2 slot */
+    (void)besthmmscr; (void)bestwordscr; (void)frm_nhmm; (void)t; (void)hb; (void)pb; (void)wb;
+    (void)hp; (void)bm;
+    g_frames++;
+    return SRCH_SUCCESS;
+#else
     for (t = 0; t < g_ntree; t++) {
         s3o_lextree_hmm_eval(g_lt[t], s->ascr->senscr, s->ascr->comsen, frmno);
         g_best[t] = g_lt[t]->best; g_wbest[t] = g_lt[t]->wbest; g_nact[t] = g_lt[t]->n_active;
     }
-#else
-    if (s3a_lexsearch_hmm_eval(g_ls, s3a_scorer_senscr_dev(g_sc), s3a_comsen_dev(g_cs), frmno, g_best,
-                               g_wbest, g_nact) != S3A_OK) die("hmm_eval");
-#endif
     for (t = 0; t < g_ntree; t++) {
         if (besthmmscr < g_best[t]) besthmmscr = g_best[t];
         if (bestwordscr < g_wbest[t]) bestwordscr = g_wbest[t];
@@ -479,7 +480,6 @@ tst_hmm_compute_lv2(void *srch, int32 frmno)
         hp->hmm_hist[frm_nhmm / hp->hmm_hist_binsize]++;
 
     if (frm_nhmm > (hp->maxhmmpf + (hp->maxhmmpf >> 1))) {
-#ifdef LT_ORACLE
         int32 nbin = 1000, bw = -(bm->hmm) / nbin, i, j;
         int32 *bin = ckd_calloc(nbin, sizeof(int32));
         for (t = 0; t < g_ntree; t++)
@@ -489,11 +489,6 @@ tst_hmm_compute_lv2(void *srch, int32 frmno)
         hb = -(i * bw);
         pb = (hb > bm->ptrans) ? hb : bm->ptrans;
         wb = (hb > bm->word) ? hb : bm->word;
-#else
-        E_FATAL("tst shim: %d active HMMs exceed 1.5 x -maxhmmpf: histogram pruning "
-                "(lextree_hmm_histbin) is not implemented on the device yet\n", frm_nhmm);
-        hb = pb = wb = 0;
-#endif
     }
     else {
         hb = bm->hmm; pb = bm->ptrans; wb = bm->word;
@@ -505,6 +500,7 @@ tst_hmm_compute_lv2(void *srch, int32 frmno)
     bm->word_thres = bm->bestwordscore + wb;
     g_frames++;
     return SRCH_SUCCESS;
+#endif
 }
 
 static int
@@ -522,8 +518,7 @@ tst_propagate_ph_lv2(void *srch, int32 frmno)
             s3o_lextree_hmm_propagate_non_leaves(g_lt[t], frmno, bm->thres, pth, bm->word_thres);
     }
 #else
-    if (s3a_lexsearch_propagate_non_leaves(g_ls, frmno, bm->thres, pth, bm->word_thres) != S3A_OK)
-        die("propagate_non_leaves");
+    (void)pth;      /* done inside s3a_lexsearch_frame_search (propagate_graph_wd_lv2 slot) */
 #endif
     return SRCH_SUCCESS;
 }
@@ -591,18 +586,46 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
                                                        g_exit_hist + t * g_max_node, g_max_node);
         if (g_exit_n[t] < 0) { E_ERROR("out.history==-1, error\n"); return SRCH_FAILURE; }
     }
-#else
-    if (s3a_lexsearch_propagate_leaves(g_ls, s->beam->word_thres, g_exit_n, g_exit_wid, g_exit_scr,
-                                       g_exit_hist, g_max_node) != S3A_OK) {
-        E_ERROR("%s\n", s3a_last_error());
-        return SRCH_FAILURE;
-    }
-#endif
     for (t = 0; t < g_ntree; t++)
         for (i = 0; i < g_exit_n[t]; i++)
             vithist_rescore(vh, s->kbc, g_exit_wid[t * g_max_node + i], frmno,
                             g_exit_scr[t * g_max_node + i], g_exit_hist[t * g_max_node + i],
                             g_flat[t]->type, -1);
+#else
+    {
+        s3a_frame_result_t r;
+        beam_t *bm = s->beam;
+        int32 k = 0;
+        int32 wbeam_phone = (bm->ptranskip != 0 && (frmno % bm->ptranskip) == 0);
+        if (s3a_lexsearch_frame_search(g_ls, s3a_scorer_senscr_dev(g_sc), s3a_comsen_dev(g_cs), frmno,
+                                       bm->hmm, bm->ptrans, bm->word, wbeam_phone, hp->maxhmmpf,
+                                       s3a_scorer_misc_dev(g_sc), &r, g_exit_n, g_exit_wid, g_exit_scr,
+                                       g_exit_hist, g_ntree * g_max_node) != S3A_OK) {
+            E_ERROR("%s\n", s3a_last_error());
+            return SRCH_FAILURE;
+        }
+        if (r.need_histprune)
+            E_FATAL("tst shim: %d active HMMs exceed 1.5 x -maxhmmpf: histogram pruning "
+                    "(lextree_hmm_histbin) is not implemented on the device yet\n", r.n_hmm);
+        /* what srch_TST_hmm_compute_lv2 leaves in beam_t / stat_t / histprune_t */
+        bm->bestscore = r.best_hmm; bm->bestwordscore = r.best_word;
+        bm->thres = r.thres; bm->phone_thres = r.phone_thres; bm->word_thres = r.word_thres;
+        if (r.best_hmm > 0)
+            E_ERROR("***ERROR*** Fr %d, best HMM score > 0 (%d); int32 wraparound?\n", frmno, r.best_hmm);
+        s->stat->utt_hmm_eval += r.n_hmm;
+        if (r.n_hmm / hp->hmm_hist_binsize > hp->hmm_hist_bins - 1) hp->hmm_hist[hp->hmm_hist_bins - 1]++;
+        else hp->hmm_hist[r.n_hmm / hp->hmm_hist_binsize]++;
+        /* what gmm_compute_lv2 leaves: senscale -> ascale[], evaluation counters */
+        s->senscale = r.extra[6];
+        s->ascale[g_ascale_idx] = r.extra[6];
+        s->stat->utt_sen_eval += r.extra[1]; s->stat->utt_gau_eval += r.extra[2];
+        s->stat->utt_cisen_eval += r.extra[3]; s->stat->utt_cigau_eval += r.extra[4];
+        for (t = 0; t < g_ntree; t++)
+            for (i = 0; i < g_exit_n[t]; i++, k++)
+                vithist_rescore(vh, s->kbc, g_exit_wid[k], frmno, g_exit_scr[k], g_exit_hist[k],
+                                g_flat[t]->type, -1);
+    }
+#endif
     vithist_prune(vh, kbcore_dict(s->kbc), frmno, hp->maxwpf, hp->maxhistpf,
                   s->beam->word_thres - s->beam->bestwordscore);
     tst_word_trans(s, frmno);

@@ -91,3 +91,43 @@ def test_full_device_search_matches_reference(name, tmp_path):
     assert any("frames searched by the replacement backend" in l for l in tail)
     assert open(hyp).read() == open(os.path.join(D, f"ref_{name}.match")).read()
     assert open(seg).read() == open(os.path.join(D, f"ref_{name}.matchseg")).read()
+
+
+# ---------------------------------------------------------------------------
+# RM1 (1935 senones, 6136-node lextrees with multi-parent first-level nodes, 997-word
+# trigram): data is NOT committed (8 MB of third-party model files); tools/
+# fetch_local_data.sh copies it from the reference checkout into tests/_local_data/,
+# which travels with the gpurun snapshot.  Here the expected output is produced LIVE by
+# the unmodified reference on the same box, so no golden file is needed.
+# ---------------------------------------------------------------------------
+RM = os.path.join(ROOT, "tests", "_local_data", "rm1")
+
+
+def rm_args():
+    return ["-mdef", f"{RM}/mdef", "-fdict", f"{RM}/fillerdict", "-dict", f"{RM}/RM.dictionary",
+            "-mean", f"{RM}/means", "-var", f"{RM}/variances", "-mixw", f"{RM}/mixture_weights",
+            "-tmat", f"{RM}/transition_matrices", "-agc", "none", "-varnorm", "no", "-cmn", "current",
+            "-epl", "4", "-fillprob", "0.02", "-maxwpf", "10", "-wip", "0.2",
+            "-lm", f"{RM}/RM.2845.trigram.arpa.DMP", "-lw", "14", "-beam", "1e-140", "-wbeam", "1e-100",
+            "-cepdir", f"{RM}/feat", "-cepext", ".mfc", "-ctl", f"{RM}/rm.ctl", "-op_mode", "4"]
+
+
+@pytest.mark.skipif(not (os.path.exists(TST) and os.path.exists(REFDEC) and os.path.isdir(RM)),
+                    reason="RM1 local data or oracle/_ref binaries absent (tools/fetch_local_data.sh)")
+@pytest.mark.parametrize("binary", ["scoring_only", "full_device"])
+def test_rm1_identical_to_live_reference(binary, tmp_path):
+    exe = SHIM if binary == "scoring_only" else TST
+    out = {}
+    for tag, b in (("ref", REFDEC), ("gpu", exe)):
+        hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
+        with open(log, "w") as lf:
+            p = subprocess.run([b] + rm_args() + ["-hyp", hyp, "-hypseg", seg], stdout=lf,
+                               stderr=subprocess.STDOUT, timeout=1800)
+        tail = [l for l in open(log, errors="ignore").read().splitlines()
+                if l.startswith(("FATAL", "INFO: ref_", "INFO: stat.c")) and ("shim" in l or "SUMMARY" in l or "FATAL" in l)]
+        assert p.returncode == 0, "\n".join(tail[-10:])
+        out[tag] = (open(hyp).read(), open(seg).read())
+        print("\n".join(t[:220] for t in tail[-3:]))
+    assert out["gpu"][0] == out["ref"][0]
+    assert out["gpu"][1] == out["ref"][1]
+    assert out["ref"][0].count("\n") == sum(1 for _ in open(f"{RM}/rm.ctl"))
