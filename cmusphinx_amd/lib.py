@@ -548,3 +548,118 @@ class HmmBatch:
                                        _p(best), _p(mpx_ssid), _p(frame)))
         return dict(score=score, hist=hist, out_score=out_score, out_hist=out_hist, bestscore=best,
                     mpx_ssid=mpx_ssid, frame=frame)
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("best_hmm", C.c_int32), ("best_word", C.c_int32), ("n_hmm", C.c_int32),
+                ("thres", C.c_int32), ("phone_thres", C.c_int32), ("word_thres", C.c_int32),
+                ("need_histprune", C.c_int32), ("n_exit_total", C.c_int32), ("extra", C.c_int32 * 8)]
+
+
+class LexSearch:
+    """All lextrees of one decoder on the GPU (s3a_lexsearch_*): mode 4's per-frame search ops."""
+
+    def __init__(self, trees, tmat: "Tmat", sseq, comsseq, comstate_off, comstate, n_sen, stream=None):
+        self.L = load()
+        self.trees = trees
+        self.T = len(trees)
+        self.n_sen = int(n_sen)
+        self.tmat = tmat
+        keep = self._keep = []
+
+        def col(key, dt):
+            arrs = [np.ascontiguousarray(t[key], dt) for t in trees]
+            keep.append(arrs)
+            ptrs = (C.c_void_p * self.T)(*[a.ctypes.data_as(C.c_void_p).value if a.size else None for a in arrs])
+            keep.append(ptrs)
+            return ptrs
+
+        def ints(key):
+            a = np.array([int(t[key]) for t in trees], np.int32)
+            keep.append(a)
+            return _p(a)
+        self.sseq = np.ascontiguousarray(sseq, np.int16)
+        self.comsseq = np.ascontiguousarray(comsseq, np.int16)
+        self.comstate_off = np.ascontiguousarray(comstate_off, np.int32)
+        self.comstate = np.ascontiguousarray(comstate, np.int16)
+        ne = tmat.n_state
+        self.h = self.L.s3a_lexsearch_init(
+            self.T, ints("n_node"), col("ssid", np.int32), col("tmatid", np.int32), col("composite", np.uint8),
+            col("wid", np.int32), col("prob", np.int32), col("child_off", np.int32), col("child", np.int32),
+            ints("n_lc"), col("lc", np.int16), col("lcroot_off", np.int32), col("lcroot", np.int32),
+            ints("n_root"), col("root", np.int32), tmat.h, _p(self.sseq), len(self.sseq) // ne,
+            _p(self.comsseq), len(self.comsseq) // ne, len(self.comstate_off) - 1, _p(self.comstate_off),
+            _p(self.comstate), stream)
+        if not self.h:
+            raise S3AError(_err(self.L))
+        self.max_node = max(int(t["n_node"]) for t in trees)
+        self.d_sen = DevBuf(4 * self.n_sen)
+        self.d_com = DevBuf(4 * max(len(self.comstate_off) - 1, 1))
+        self.d_act = DevBuf(self.n_sen)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_lexsearch_free(self.h)
+            self.h = None
+
+    def enter(self, t, lc, scr, hist, cf, thresh):
+        lc = np.ascontiguousarray(lc, np.int32); scr = np.ascontiguousarray(scr, np.int32)
+        hist = np.ascontiguousarray(hist, np.int32)
+        check(self.L.s3a_lexsearch_enter(self.h, int(t), len(lc), _p(lc), _p(scr), _p(hist), int(cf), int(thresh)))
+
+    def swap(self):
+        check(self.L.s3a_lexsearch_active_swap(self.h))
+
+    def _upload_scores(self, senscr, comsen):
+        self.d_sen.upload(np.ascontiguousarray(senscr, np.int32))
+        if len(comsen):
+            self.d_com.upload(np.ascontiguousarray(comsen, np.int32))
+
+    def hmm_eval(self, senscr, comsen, frm):
+        self._upload_scores(senscr, comsen)
+        b = np.zeros(self.T, np.int32); w = np.zeros(self.T, np.int32); n = np.zeros(self.T, np.int32)
+        check(self.L.s3a_lexsearch_hmm_eval(self.h, self.d_sen.ptr, self.d_com.ptr, int(frm), _p(b), _p(w), _p(n)))
+        return b, w, n
+
+    def propagate(self, cf, th, pth, wth):
+        check(self.L.s3a_lexsearch_propagate_non_leaves(self.h, int(cf), int(th), int(pth), int(wth)))
+
+    def leaves(self, wth):
+        m = self.max_node
+        n = np.zeros(self.T, np.int32)
+        w = np.zeros(self.T * m, np.int32); s = np.zeros(self.T * m, np.int32); h = np.zeros(self.T * m, np.int32)
+        check(self.L.s3a_lexsearch_propagate_leaves(self.h, int(wth), _p(n), _p(w), _p(s), _p(h), m))
+        return [(w[t * m: t * m + n[t]], s[t * m: t * m + n[t]], h[t * m: t * m + n[t]]) for t in range(self.T)]
+
+    def frame_search(self, senscr, comsen, frm, hmmbeam, pbeam, wbeam, phone_uses_wbeam=0, maxhmmpf=20000):
+        self._upload_scores(senscr, comsen)
+        res = FrameResult()
+        cap = self.T * self.max_node
+        n = np.zeros(self.T, np.int32)
+        w = np.zeros(cap, np.int32); s = np.zeros(cap, np.int32); h = np.zeros(cap, np.int32)
+        check(self.L.s3a_lexsearch_frame_search(self.h, self.d_sen.ptr, self.d_com.ptr, int(frm), int(hmmbeam),
+                                                int(pbeam), int(wbeam), int(phone_uses_wbeam), int(maxhmmpf), None,
+                                                C.byref(res), _p(n), _p(w), _p(s), _p(h), cap))
+        off = np.concatenate([[0], np.cumsum(n)])
+        return res, [(w[off[t]:off[t + 1]], s[off[t]:off[t + 1]], h[off[t]:off[t + 1]]) for t in range(self.T)]
+
+    def active(self, t, which):
+        n = C.c_int32(0)
+        nodes = np.zeros(self.max_node, np.int32)
+        check(self.L.s3a_lexsearch_get_active(self.h, int(t), int(which), C.byref(n), _p(nodes), self.max_node))
+        return nodes[:n.value].copy()
+
+    def state(self, t):
+        nn = int(self.trees[t]["n_node"])
+        sc = np.zeros((3, nn), np.int32); hi = np.zeros((3, nn), np.int32)
+        o = np.zeros(nn, np.int32); oh = np.zeros(nn, np.int32); b = np.zeros(nn, np.int32); f = np.zeros(nn, np.int32)
+        check(self.L.s3a_lexsearch_get_hmm(self.h, int(t), _p(sc), _p(hi), _p(o), _p(oh), _p(b), _p(f)))
+        return np.stack([sc[0], sc[1], sc[2], hi[0], hi[1], hi[2], o, oh, b, f], 1)
+
+    def sen_active(self):
+        check(self.L.s3a_lexsearch_sen_active(self.h, self.d_act.ptr, self.n_sen))
+        check(self.L.s3a_dev_sync())
+        return self.d_act.download(np.uint8, (self.n_sen,))
+
+    def utt_end(self):
+        check(self.L.s3a_lexsearch_utt_end(self.h))

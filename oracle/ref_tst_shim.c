@@ -187,6 +187,9 @@ static int32 g_max_node;
 static int32 *g_best, *g_wbest, *g_nact;
 static int32 *g_exit_n, *g_exit_wid, *g_exit_scr, *g_exit_hist;
 static long g_frames;
+#include <time.h>
+static double g_t_score, g_t_search, g_t_word, g_t_utt;
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
 #ifdef LT_ORACLE
 static s3o_lextree_t **g_lt;
@@ -198,6 +201,63 @@ static s3a_comsen_t *g_cs;
 static s3a_tmat_t *g_tm;
 static s3a_lexsearch_t *g_ls;
 static void die(const char *w) { E_FATAL("tst shim: %s: %s\n", w, s3a_last_error()); }
+#endif
+
+#ifdef LT_ORACLE
+/* Optional trace of the FIRST utterance (env S3O_TRACE=file): the flattened trees and, per
+ * frame, every input the lextree operations consumed and every result they produced.
+ * tests/golden/make_golden.py turns it into the fixture the oracle-vs-HIP lextree parity
+ * tests replay.  Record = {tag, n, n x int32}. */
+static FILE *g_trace;
+static int g_trace_utt;
+static void
+tr(int32 tag, int32 n, const void *data)
+{
+    if (!g_trace) return;
+    fwrite(&tag, 4, 1, g_trace); fwrite(&n, 4, 1, g_trace);
+    if (n) fwrite(data, 4, n, g_trace);
+}
+static void
+tr16(int32 tag, int32 n, const int16 *d)
+{
+    int32 i, *w;
+    if (!g_trace) return;
+    w = ckd_calloc(n + 1, 4);
+    for (i = 0; i < n; i++) w[i] = d[i];
+    tr(tag, n, w);
+    ckd_free(w);
+}
+static void
+tr8(int32 tag, int32 n, const uint8 *d)
+{
+    int32 i, *w;
+    if (!g_trace) return;
+    w = ckd_calloc(n + 1, 4);
+    for (i = 0; i < n; i++) w[i] = d[i];
+    tr(tag, n, w);
+    ckd_free(w);
+}
+static void
+trace_state(int32 tag_base)
+{
+    int32 t;
+    if (!g_trace) return;
+    for (t = 0; t < g_ntree; t++) {
+        s3o_lextree_t *lt = g_lt[t];
+        int32 n = lt->n_node, i, *buf = ckd_calloc(10 * n + 4, 4);
+        tr(tag_base + 0, lt->n_active, lt->active);
+        tr(tag_base + 1, lt->n_next_active, lt->next_active);
+        for (i = 0; i < n; i++) {
+            s3o_hmm_t *h = &lt->hmm[i];
+            buf[10 * i + 0] = h->score[0]; buf[10 * i + 1] = h->score[1]; buf[10 * i + 2] = h->score[2];
+            buf[10 * i + 3] = (int32)h->history[0]; buf[10 * i + 4] = (int32)h->history[1];
+            buf[10 * i + 5] = (int32)h->history[2]; buf[10 * i + 6] = h->out_score;
+            buf[10 * i + 7] = (int32)h->out_history; buf[10 * i + 8] = h->bestscore; buf[10 * i + 9] = h->frame;
+        }
+        tr(tag_base + 2, 10 * n, buf);
+        ckd_free(buf);
+    }
+}
 #endif
 
 static void
@@ -257,6 +317,25 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
     g_exit_hist = ckd_calloc(g_ntree * g_max_node, 4);
 
 #ifdef LT_ORACLE
+    if (getenv("S3O_TRACE") && (g_trace = fopen(getenv("S3O_TRACE"), "wb")) != NULL) {
+        int32 hdr[8] = { g_ntree, ne, tmat->n_tmat, mdef_n_sseq(mdef), d2p->n_comsseq, g_n_comstate,
+                         mdef_n_sen(mdef), d2p->n_comstate };
+        tr(1, 8, hdr);
+        tr(2, tmat->n_tmat * ne * (ne + 1), g_tp_flat);
+        tr16(3, mdef_n_sseq(mdef) * ne, g_sseq_flat);
+        tr16(4, d2p->n_comsseq * ne, g_comsseq_flat);
+        tr(5, g_n_comstate + 1, g_comstate_off);
+        tr16(6, g_comstate_off[g_n_comstate], g_comstate);
+        for (i = 0; i < g_ntree; i++) {
+            flat_t *f = g_flat[i];
+            int32 h2[4] = { f->n_node, f->n_lc, f->n_root, f->type };
+            tr(10, 4, h2); tr(11, f->n_node, f->ssid); tr(12, f->n_node, f->tmatid);
+            tr8(13, f->n_node, f->composite); tr(14, f->n_node, f->wid); tr(15, f->n_node, f->prob);
+            tr(16, f->n_node + 1, f->child_off); tr(17, f->child_off[f->n_node], f->child);
+            if (f->n_lc) { tr16(18, f->n_lc, f->lc); tr(19, f->n_lc + 1, f->lcroot_off); tr(20, f->lcroot_off[f->n_lc], f->lcroot); }
+            tr(21, f->n_root, f->root);
+        }
+    }
     g_lt = ckd_calloc(g_ntree, sizeof(*g_lt));
     for (i = 0; i < g_ntree; i++) {
         flat_t *f = g_flat[i];
@@ -323,6 +402,10 @@ be_enter(int32 t, int32 n, int32 *lc, int32 *scr, int32 *hist, int32 cf, int32 t
 {
 #ifdef LT_ORACLE
     int32 c;
+    if (g_trace) {
+        int32 hdr[4] = { t, n, cf, thresh };
+        tr(30, 4, hdr); tr(31, n, lc); tr(32, n, scr); tr(33, n, hist);
+    }
     for (c = 0; c < n; c++)
         s3o_lextree_enter(g_lt[t], lc[c], cf, scr[c], hist[c], thresh);
 #else
@@ -353,6 +436,7 @@ tst_begin(void *srch)
     mgau_model_t *g = kbc->mgau;
     int32 pred, i, lc, zero = 0;
 
+    g_t_utt -= now_s();
     vithist_utt_reset(tstg->vithist);
     histprune_zero_histbin(tstg->histprune);
     pred = vithist_utt_begin(tstg->vithist, kbc);
@@ -376,11 +460,14 @@ tst_end(void *srch)
     srch_t *s = srch;
     srch_TST_graph_t *tstg = s->grh->graph_struct;
     int32 t;
+    g_t_utt += now_s();
     s->exit_id = vithist_utt_end(tstg->vithist, s->kbc);
     s->stat->utt_wd_exit = vithist_n_entry(tstg->vithist);
     histprune_showhistbin(tstg->histprune, s->stat->nfr, s->uttid);
 #ifdef LT_ORACLE
     for (t = 0; t < g_ntree; t++) s3o_lextree_utt_end(g_lt[t]);
+    if (g_trace) { int32 z = 0; tr(99, 1, &z); fclose(g_trace); g_trace = NULL; }
+    g_trace_utt++;
 #else
     (void)t;
     if (s3a_lexsearch_utt_end(g_ls) != S3A_OK) die("utt_end");
@@ -462,6 +549,13 @@ tst_hmm_compute_lv2(void *srch, int32 frmno)
     g_frames++;
     return SRCH_SUCCESS;
 #else
+    if (g_trace) {
+        int32 fr = frmno;
+        tr(40, 1, &fr);
+        tr(41, mdef_n_sen(kbcore_mdef(s->kbc)), s->ascr->senscr);
+        tr(42, kbcore_dict2pid(s->kbc)->n_comstate, s->ascr->comsen);
+        tr8(43, mdef_n_sen(kbcore_mdef(s->kbc)), s->ascr->sen_active);
+    }
     for (t = 0; t < g_ntree; t++) {
         s3o_lextree_hmm_eval(g_lt[t], s->ascr->senscr, s->ascr->comsen, frmno);
         g_best[t] = g_lt[t]->best; g_wbest[t] = g_lt[t]->wbest; g_nact[t] = g_lt[t]->n_active;
@@ -499,6 +593,12 @@ tst_hmm_compute_lv2(void *srch, int32 frmno)
     bm->phone_thres = bm->bestscore + pb;
     bm->word_thres = bm->bestwordscore + wb;
     g_frames++;
+    if (g_trace) {
+        int32 r[8] = { bm->bestscore, bm->bestwordscore, frm_nhmm, bm->thres, bm->phone_thres, bm->word_thres,
+                       bm->hmm, bm->ptrans };
+        tr(44, 8, r); tr(45, g_ntree, g_best); tr(46, g_ntree, g_wbest); tr(47, g_ntree, g_nact);
+        trace_state(50);
+    }
     return SRCH_SUCCESS;
 #endif
 }
@@ -516,6 +616,7 @@ tst_propagate_ph_lv2(void *srch, int32 frmno)
         int32 t;
         for (t = 0; t < g_ntree; t++)
             s3o_lextree_hmm_propagate_non_leaves(g_lt[t], frmno, bm->thres, pth, bm->word_thres);
+        if (g_trace) { int32 r[3] = { bm->thres, pth, bm->word_thres }; tr(60, 3, r); trace_state(61); }
     }
 #else
     (void)pth;      /* done inside s3a_lexsearch_frame_search (propagate_graph_wd_lv2 slot) */
@@ -585,6 +686,10 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
                                                        g_exit_wid + t * g_max_node, g_exit_scr + t * g_max_node,
                                                        g_exit_hist + t * g_max_node, g_max_node);
         if (g_exit_n[t] < 0) { E_ERROR("out.history==-1, error\n"); return SRCH_FAILURE; }
+        if (g_trace) {
+            tr(70, 1, &g_exit_n[t]); tr(71, g_exit_n[t], g_exit_wid + t * g_max_node);
+            tr(72, g_exit_n[t], g_exit_scr + t * g_max_node); tr(73, g_exit_n[t], g_exit_hist + t * g_max_node);
+        }
     }
     for (t = 0; t < g_ntree; t++)
         for (i = 0; i < g_exit_n[t]; i++)
@@ -597,6 +702,7 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
         beam_t *bm = s->beam;
         int32 k = 0;
         int32 wbeam_phone = (bm->ptranskip != 0 && (frmno % bm->ptranskip) == 0);
+        double t0 = now_s();
         if (s3a_lexsearch_frame_search(g_ls, s3a_scorer_senscr_dev(g_sc), s3a_comsen_dev(g_cs), frmno,
                                        bm->hmm, bm->ptrans, bm->word, wbeam_phone, hp->maxhmmpf,
                                        s3a_scorer_misc_dev(g_sc), &r, g_exit_n, g_exit_wid, g_exit_scr,
@@ -604,6 +710,7 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
             E_ERROR("%s\n", s3a_last_error());
             return SRCH_FAILURE;
         }
+        g_t_search += now_s() - t0;
         if (r.need_histprune)
             E_FATAL("tst shim: %d active HMMs exceed 1.5 x -maxhmmpf: histogram pruning "
                     "(lextree_hmm_histbin) is not implemented on the device yet\n", r.n_hmm);
@@ -626,9 +733,13 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
                                 g_flat[t]->type, -1);
     }
 #endif
-    vithist_prune(vh, kbcore_dict(s->kbc), frmno, hp->maxwpf, hp->maxhistpf,
-                  s->beam->word_thres - s->beam->bestwordscore);
-    tst_word_trans(s, frmno);
+    {
+        double t1 = now_s();
+        vithist_prune(vh, kbcore_dict(s->kbc), frmno, hp->maxwpf, hp->maxhistpf,
+                      s->beam->word_thres - s->beam->bestwordscore);
+        tst_word_trans(s, frmno);
+        g_t_word += now_s() - t1;
+    }
     return SRCH_SUCCESS;
 }
 
@@ -639,6 +750,9 @@ tst_frame_windup(void *srch, int32 frmno)
     srch_TST_graph_t *tstg = s->grh->graph_struct;
     vithist_frame_windup(tstg->vithist, frmno, NULL, s->kbc);
     be_swap();
+#ifdef LT_ORACLE
+    if (g_trace) trace_state(80);
+#endif
     return SRCH_SUCCESS;
 }
 
@@ -679,6 +793,10 @@ main(int argc, char *argv[])
     if (kb.matchfp) fclose(kb.matchfp);
     stat_report_corpus(kb.stat);
     E_INFO("tst shim: %ld frames searched by the replacement backend\n", g_frames);
+    E_INFO("tst shim timing: %.1f us/frame inside utterances (%.0f x real time); of which frame_search "
+           "(enqueue + the one sync) %.1f us, vithist_prune + word transitions %.1f us\n",
+           1e6 * g_t_utt / g_frames, 0.01 * g_frames / g_t_utt, 1e6 * g_t_search / g_frames,
+           1e6 * g_t_word / g_frames);
     if (g_frames == 0)
         E_FATAL("tst shim: the replaced slots were never called\n");
     return 0;

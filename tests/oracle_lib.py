@@ -334,3 +334,142 @@ def hmm_run(n_emit, tp, sseq, senscr, spec, enter):
             state[t, i, 6] = h.bestscore
             hist[t, i, 5] = h.out_history
     return state, hist, ret
+
+
+# ---------------------------------------------------------------------------
+# lextree (oracle/s3o_lextree.c)
+# ---------------------------------------------------------------------------
+class OracleLexSearch:
+    """The trees of one decoder driven through s3o_lextree_* (sequential reference order)."""
+
+    def __init__(self, tr):
+        L = lib()
+        self.L = L
+        self.tr = tr
+        self.keep = []
+        c = lambda a, dt: np.ascontiguousarray(a, dt)
+        self.tp = c(tr["tp"], np.int32); self.sseq = c(tr["sseq"], np.int16)
+        self.comsseq = c(tr["comsseq"], np.int16)
+        self.comstate_off = c(tr["comstate_off"], np.int32); self.comstate = c(tr["comstate"], np.int16)
+        L.s3o_lextree_init.restype = C.c_void_p
+        L.s3o_lextree_init.argtypes = [C.c_int32] + [C.c_void_p] * 7 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                                      C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                                                      C.c_void_p, C.c_void_p]
+        L.s3o_lextree_enter.argtypes = [C.c_void_p] + [C.c_int32] * 5
+        L.s3o_lextree_active_swap.argtypes = [C.c_void_p]
+        L.s3o_lextree_hmm_eval.restype = C.c_int32
+        L.s3o_lextree_hmm_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.s3o_lextree_hmm_propagate_non_leaves.argtypes = [C.c_void_p] + [C.c_int32] * 4
+        L.s3o_lextree_hmm_propagate_leaves.restype = C.c_int32
+        L.s3o_lextree_hmm_propagate_leaves.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.s3o_lextree_ssid_active.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.s3o_sseq2sen_active.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.s3o_comsseq2sen_active.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.s3o_lextree_hmm_histbin.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+        self.lt = []
+        for t in tr["trees"]:
+            arrs = dict(ssid=c(t["ssid"], np.int32), tmatid=c(t["tmatid"], np.int32),
+                        composite=c(t["composite"], np.uint8), wid=c(t["wid"], np.int32),
+                        prob=c(t["prob"], np.int32), child_off=c(t["child_off"], np.int32),
+                        child=c(t["child"], np.int32), lc=c(t["lc"], np.int16),
+                        lcroot_off=c(t["lcroot_off"], np.int32), lcroot=c(t["lcroot"], np.int32),
+                        root=c(t["root"], np.int32))
+            self.keep.append(arrs)
+            p = lambda k: arrs[k].ctypes.data_as(C.c_void_p)
+            self.lt.append(L.s3o_lextree_init(t["n_node"], p("ssid"), p("tmatid"), p("composite"), p("wid"),
+                                              p("prob"), p("child_off"), p("child"), t["n_lc"], p("lc"),
+                                              p("lcroot_off"), p("lcroot"), t["n_root"], p("root"),
+                                              tr["n_emit"], self.tp.ctypes.data_as(C.c_void_p),
+                                              self.sseq.ctypes.data_as(C.c_void_p),
+                                              self.comsseq.ctypes.data_as(C.c_void_p)))
+        self.T = len(self.lt)
+
+    def _lt(self, t):
+        return C.cast(self.lt[t], C.POINTER(LexTree)).contents
+
+    def enter(self, t, lc, scr, hist, cf, thresh):
+        for c in range(len(lc)):
+            self.L.s3o_lextree_enter(self.lt[t], int(lc[c]), cf, int(scr[c]), int(hist[c]), thresh)
+
+    def swap(self):
+        for h in self.lt:
+            self.L.s3o_lextree_active_swap(h)
+
+    def hmm_eval(self, senscr, comsen, frm):
+        s = np.ascontiguousarray(senscr, np.int32); cs = np.ascontiguousarray(comsen, np.int32)
+        best, wbest, nact = [], [], []
+        for t in range(self.T):
+            self.L.s3o_lextree_hmm_eval(self.lt[t], _p2(s), _p2(cs), frm)
+            lt = self._lt(t)
+            best.append(lt.best); wbest.append(lt.wbest); nact.append(lt.n_active)
+        return np.array(best, np.int32), np.array(wbest, np.int32), np.array(nact, np.int32)
+
+    def propagate(self, cf, th, pth, wth):
+        for h in self.lt:
+            self.L.s3o_lextree_hmm_propagate_non_leaves(h, cf, th, pth, wth)
+
+    def leaves(self, wth):
+        out = []
+        for t in range(self.T):
+            n_node = self.tr["trees"][t]["n_node"]
+            w = np.zeros(n_node, np.int32); s = np.zeros(n_node, np.int32); h = np.zeros(n_node, np.int32)
+            n = self.L.s3o_lextree_hmm_propagate_leaves(self.lt[t], wth, _p2(w), _p2(s), _p2(h), n_node)
+            assert n >= 0
+            out.append((w[:n], s[:n], h[:n]))
+        return out
+
+    def active(self, t, which):
+        lt = self._lt(t)
+        n = lt.n_next_active if which else lt.n_active
+        ptr = lt.next_active if which else lt.active
+        if n == 0:
+            return np.zeros(0, np.int32)
+        return np.frombuffer(C.string_at(ptr, 4 * n), dtype=np.int32).copy()
+
+    def state(self, t):
+        """[n_node][10]: score0..2, hist0..2, out_score, out_hist, bestscore, frame (one bulk copy)."""
+        lt = self._lt(t)
+        n = lt.n_node
+        raw = np.frombuffer(C.string_at(lt.hmm, n * C.sizeof(Hmm)), dtype=_HMM_DT)
+        out = np.empty((n, 10), np.int32)
+        out[:, 0:3] = raw["score"][:, :3]
+        out[:, 3:6] = raw["history"][:, :3]
+        out[:, 6] = raw["out_score"]; out[:, 7] = raw["out_history"]
+        out[:, 8] = raw["bestscore"]; out[:, 9] = raw["frame"]
+        return out
+
+    def sen_active(self):
+        tr = self.tr
+        ssid = np.zeros(tr["n_sseq"], np.uint8); com = np.zeros(max(tr["n_comsseq"], 1), np.uint8)
+        sen = np.zeros(tr["n_sen"], np.uint8)
+        for h in self.lt:
+            self.L.s3o_lextree_ssid_active(h, _p2(ssid), _p2(com))
+        self.L.s3o_sseq2sen_active(_p2(self.sseq), tr["n_sseq"], tr["n_emit"], _p2(ssid), _p2(sen))
+        self.L.s3o_comsseq2sen_active(_p2(self.comsseq), tr["n_comsseq"], tr["n_emit"], _p2(self.comstate_off),
+                                      _p2(self.comstate), _p2(com), _p2(sen))
+        return sen
+
+
+class LexTree(C.Structure):
+    _fields_ = [("n_node", C.c_int32),
+                ("ssid", C.c_void_p), ("tmatid", C.c_void_p), ("wid", C.c_void_p), ("prob", C.c_void_p),
+                ("composite", C.c_void_p), ("child_off", C.c_void_p), ("child", C.c_void_p),
+                ("n_lc", C.c_int32), ("lc", C.c_void_p), ("lcroot_off", C.c_void_p), ("lcroot", C.c_void_p),
+                ("n_root", C.c_int32), ("root", C.c_void_p),
+                ("ctx", HmmCtx), ("comctx", HmmCtx),
+                ("hmm", C.POINTER(Hmm)), ("active", C.POINTER(C.c_int32)), ("next_active", C.POINTER(C.c_int32)),
+                ("n_active", C.c_int32), ("n_next_active", C.c_int32), ("best", C.c_int32), ("wbest", C.c_int32)]
+
+
+def _p2(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# numpy view of s3o_hmm_t (must mirror the ctypes Hmm structure, incl. alignment padding)
+_HMM_DT = np.dtype({"names": ["score", "history", "out_score", "out_history", "ssid", "mpx_ssid",
+                              "bestscore", "tmatid", "frame", "mpx"],
+                    "formats": [("<i4", 5), ("<i8", 5), "<i4", "<i8", "<i4", ("<i4", 5), "<i4", "<i4", "<i4", "u1"],
+                    "offsets": [Hmm.score.offset, Hmm.history.offset, Hmm.out_score.offset, Hmm.out_history.offset,
+                                Hmm.ssid.offset, Hmm.mpx_ssid.offset, Hmm.bestscore.offset, Hmm.tmatid.offset,
+                                Hmm.frame.offset, Hmm.mpx.offset],
+                    "itemsize": C.sizeof(Hmm)})
