@@ -150,11 +150,12 @@ def test_fused_frame_search_equals_stepwise(gpu_lib):
         comsen = -rng.integers(0, 30000, tr["n_comstate"]).astype(np.int32)
         best, wbest, nact = a.hmm_eval(senscr, comsen, frm)
         bh, bw = int(best.max()), int(wbest.max())
-        a.propagate(frm, bh + hmmbeam, bh + pbeam, bw + wbeam)
-        ea = a.leaves(bw + wbeam)
+        w32 = lambda v: ((v + 2**31) % 2**32) - 2**31       # int32 wrap-around, as in the reference's C
+        a.propagate(frm, w32(bh + hmmbeam), w32(bh + pbeam), w32(bw + wbeam))
+        ea = a.leaves(w32(bw + wbeam))
         res, eb = b.frame_search(senscr, comsen, frm, hmmbeam, pbeam, wbeam)
         assert (res.best_hmm, res.best_word, res.n_hmm) == (bh, bw, int(nact.sum()))
-        assert (res.thres, res.phone_thres, res.word_thres) == (bh + hmmbeam, bh + pbeam, bw + wbeam)
+        assert (res.thres, res.phone_thres, res.word_thres) == (w32(bh + hmmbeam), w32(bh + pbeam), w32(bw + wbeam))
         for t in range(tr["n_tree"]):
             assert all(np.array_equal(u, v) for u, v in zip(ea[t], eb[t])), (frm, t)
         ls.same(("fused", frm))
