@@ -1,0 +1,596 @@
+/*
+ * s3a_decoder.hip -- the FUSED search frame: the same results as the step-by-step
+ * entry points of s3a_scorer.hip / s3a_lextree.hip with a third of the kernel launches.
+ *
+ * Why: one search frame of sphinx3 mode 4 is ~10 dependent phases on a few thousand
+ * HMMs; each phase is microseconds of work, so the frame costs what its kernel
+ * BOUNDARIES cost (measured: ~1.8 us per enqueued operation, 31 operations per frame
+ * in the step-by-step path, with 4 decoder streams saturating the command processor).
+ * The fused frame needs 11:
+ *
+ *   s3a_decoder_score        H2D feature vector | CI senones | gated CD senones
+ *                            (scores stay RAW; the mask is consumed and cleared)
+ *   s3a_decoder_search       k_dec_hmm_eval   lextree_hmm_eval with the frame normaliser
+ *                                             and the composite-senone max applied on the fly
+ *                                             (approx_cont_mgau.c:597-600, dict2pid.c:1029-1048)
+ *                            k_dec_resolve    lextree_hmm_propagate_non_leaves, phases mark +
+ *                                             resolve in one pass over ALL nodes (no candidate
+ *                                             list), beam thresholds recomputed per workgroup
+ *                            k_dec_finish     per tree: ordered emission of the next list,
+ *                                             ordered word exits; the last workgroup to finish
+ *                                             packs the frame record and resets the per-frame
+ *                                             accumulators
+ *                            D2H record + the frame's ONE synchronisation
+ *   s3a_decoder_transition   H2D calls | k_dec_enter1 | k_dec_enter2 | k_dec_enter3_mark
+ *                            (lextree_enter for the unigram AND the filler tree of the
+ *                            frame, then the active-senone marks of the NEXT frame)
+ *
+ * Parity: tests/test_gpu_lextree.py runs this path in lock step with the step-by-step one
+ * and with the oracle; tests/test_gpu_dropin.py decodes tidigits and RM1 through it and
+ * diffs -hyp/-hypseg against the unmodified reference.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <vector>
+
+#include "s3a_device.h"
+#include "s3a_structs.h"
+#include "s3a_vit.h"
+#include "s3a_scan.h"
+
+#define WORST S3A_WORST
+#define DBLOCK 256
+
+struct FrameBeams {
+    int32_t hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf;
+};
+
+/* thresholds of srch_TST_hmm_compute_lv2 from the per-tree maxima hmm_eval left in best[] */
+__device__ __forceinline__ void
+frame_thresholds(const int32_t *best, const int32_t *nact, int32_t T, const FrameBeams &bm,
+                 int32_t &bh, int32_t &bw, int32_t &n, int32_t &th, int32_t &pth, int32_t &wth)
+{
+    bh = INT_MIN; bw = INT_MIN; n = 0;
+    for (int32_t t = 0; t < T; t++) {
+        bh = max(bh, best[2 * t]);
+        bw = max(bw, best[2 * t + 1]);
+        n += nact[t];
+    }
+    th = add32(bh, bm.hmmbeam);
+    wth = add32(bw, bm.wbeam);
+    pth = bm.phone_uses_wbeam ? wth : add32(bh, bm.pbeam);
+}
+
+/* ------------------------------------------------------------------ */
+__global__ void __launch_bounds__(DBLOCK)
+k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
+               const int32_t *__restrict__ nact, int32_t N, int32_t n_tmat,
+               const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid,
+               const int32_t *__restrict__ wid, const uint8_t *__restrict__ comp,
+               const int32_t *__restrict__ tp_g, const int16_t *__restrict__ sseq,
+               const int16_t *__restrict__ comsseq, const int32_t *__restrict__ cs_off,
+               const int16_t *__restrict__ cs_list, const int32_t *__restrict__ cs_wt,
+               const int32_t *__restrict__ raw, const int32_t *__restrict__ misc,
+               int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
+               int32_t *best_out)
+{
+    extern __shared__ int32_t tp_s[];
+    __shared__ int32_t red[2][DBLOCK / 64];
+    for (int32_t i = threadIdx.x; i < n_tmat * 12; i += DBLOCK)
+        tp_s[i] = tp_g[i];
+    __syncthreads();
+    const int32_t t = blockIdx.y, i = blockIdx.x * DBLOCK + threadIdx.x;
+    const int32_t norm = max(misc[0], misc[5]);         /* the frame's normaliser */
+    int32_t best = INT_MIN, wbest = INT_MIN;
+    if (i < nact[t]) {
+        const int32_t v = act[node_base[t] + i], ss = ssid[v];
+        HmmRegsT<int32_t> r;
+        int32_t e[3];
+        if (comp[v]) {
+#pragma unroll
+            for (int st = 0; st < 3; st++) {
+                const int32_t cs = comsseq[ss * 3 + st];
+                int32_t m = raw[cs_list[cs_off[cs]]];
+                for (int32_t j = cs_off[cs] + 1; j < cs_off[cs + 1]; j++)
+                    m = max(m, raw[cs_list[j]]);
+                e[st] = add32(add32(m, -norm), cs_wt[cs]);
+            }
+        }
+        else {
+#pragma unroll
+            for (int st = 0; st < 3; st++)
+                e[st] = add32(raw[sseq[ss * 3 + st]], -norm);
+        }
+#pragma unroll
+        for (int st = 0; st < 3; st++) { r.s[st] = sc[st * N + v]; r.h[st] = hist[st * N + v]; }
+        r.out = outs[v];
+        r.outh = outh[v];
+        const int32_t k = vit3(r, tp_s + tmatid[v] * 12, e[0], e[1], e[2]);
+#pragma unroll
+        for (int st = 0; st < 3; st++) { sc[st * N + v] = r.s[st]; hist[st * N + v] = r.h[st]; }
+        outs[v] = r.out;
+        outh[v] = r.outh;
+        bests[v] = k;
+        best = k;
+        if (wid[v] >= 0) wbest = k;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        best = max(best, __shfl_xor(best, o, 64));
+        wbest = max(wbest, __shfl_xor(wbest, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = best; red[1][threadIdx.x >> 6] = wbest; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < DBLOCK / 64; w++) { best = max(best, red[0][w]); wbest = max(wbest, red[1][w]); }
+        if (best != INT_MIN) atomicMax(&best_out[2 * t], best);
+        if (wbest != INT_MIN) atomicMax(&best_out[2 * t + 1], wbest);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/*
+ * lextree_hmm_propagate_non_leaves from every node's point of view (see the header of
+ * s3a_lextree.hip for the rule); one thread per node of every tree: inactive nodes
+ * without a propagating parent fall through after two loads.  Also resets the root-entry
+ * scratch (key / first) for this frame's transitions.
+ */
+__global__ void __launch_bounds__(DBLOCK)
+k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
+              const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
+              const int32_t *__restrict__ tree_of, const int32_t *__restrict__ prob,
+              const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
+              const int32_t *__restrict__ pos, const int32_t *__restrict__ posf,
+              int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
+              int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
+              unsigned long long *key, int32_t *first)
+{
+    __shared__ int32_t s_th, s_pth;
+    if (threadIdx.x == 0) {
+        int32_t bh, bw, n, th, pth, wth;
+        frame_thresholds(best, nact, T, bm, bh, bw, n, th, pth, wth);
+        s_th = th; s_pth = pth;
+    }
+    __syncthreads();
+    const int32_t v = blockIdx.x * DBLOCK + threadIdx.x;
+    if (v >= N) return;
+    key[v] = 0ull;
+    first[v] = INT_MAX;
+    const int32_t th = s_th, pth = s_pth, nf = cf + 1;
+    const bool is_active = posf[v] == cf;
+    const int32_t j = is_active ? pos[v] : INT_MAX;
+    const int32_t in0 = sc[v];
+    int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
+    int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
+    for (int32_t k = par_off[v]; k < par_off[v + 1]; k++) {
+        const int32_t p = par[k];
+        if (posf[p] != cf) continue;
+        const int32_t po = outs[p];
+        if (po < pth) continue;
+        const int32_t ns = add32(po, add32(prob[v], -prob[p]));
+        if (ns < th) continue;
+        const int32_t pp = pos[p];
+        if (pp < j) {
+            if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[p]; }
+            if (ns > in0 && pp < firstE) firstE = pp;
+        }
+        else {
+            if (ns > mL || (ns == mL && pp < pL)) { mL = ns; pL = pp; hL = outh[p]; }
+            if (pp < firstL) firstL = pp;
+        }
+    }
+    if (!is_active && mE == INT_MIN)
+        return;                                         /* nothing happens to this node */
+    const int32_t b = node_base[tree_of[v]];
+    int32_t cur = in0, h0 = hist[v], my_turn = -1;
+    bool in_list = false, cleared = false, entered = false;
+    if (mE > in0) {
+        cur = mE; h0 = hE; entered = true; in_list = true; my_turn = firstE;
+    }
+    else if (is_active) {
+        if (bests[v] >= th) { in_list = true; selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); }
+        else { cleared = true; cur = WORST; h0 = -1; }
+    }
+    if (mL > cur) {
+        cur = mL; h0 = hL; entered = true;
+        if (!in_list) { in_list = true; my_turn = firstL; }
+    }
+    if (cleared) {
+        sc[1 * N + v] = WORST; sc[2 * N + v] = WORST;
+        hist[1 * N + v] = -1; hist[2 * N + v] = -1;
+        outs[v] = WORST; outh[v] = -1; bests[v] = WORST;
+    }
+    if (cleared || entered) { sc[v] = cur; hist[v] = h0; }
+    frame[v] = in_list ? nf : (cleared ? -1 : frame[v]);
+    if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[b + my_turn], 1); }
+}
+
+/* ------------------------------------------------------------------ */
+/*
+ * One workgroup per tree: (a) prefix-sum the per-turn counts and write the next active
+ * list in the reference's order, (b) compact the word exits in active-list order; then the
+ * LAST workgroup to arrive (agent-scope release by every workgroup, acquire by the last)
+ * assembles the frame record for the host and resets the per-frame accumulators.
+ * record = [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] | exits
+ */
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_dec_finish(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
+             const int32_t *__restrict__ act, const int32_t *__restrict__ nact,
+             const int32_t *__restrict__ child_off, const int32_t *__restrict__ child,
+             const int32_t *__restrict__ wid, const int32_t *__restrict__ prob,
+             const int32_t *__restrict__ outs, const int32_t *__restrict__ outh,
+             int32_t *turn, int32_t *selfemit, int32_t *cnt, int32_t *nxt, int32_t *nnxt,
+             int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
+             int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits)
+{
+    __shared__ int32_t total, s_wth, s_last;
+    __shared__ int32_t s_thr[8];
+    const int32_t t = blockIdx.x, b = node_base[t], na = nact[t], nf = cf + 1;
+    if (threadIdx.x == 0) {
+        int32_t bh, bw, n, th, pth, wth;
+        frame_thresholds(best, nact, T, bm, bh, bw, n, th, pth, wth);
+        s_wth = wth;
+        s_thr[0] = th; s_thr[1] = pth; s_thr[2] = wth; s_thr[3] = bh; s_thr[4] = bw; s_thr[5] = n;
+        s_thr[6] = (n > bm.maxhmmpf + (bm.maxhmmpf >> 1)) ? 1 : 0;
+        s_thr[7] = (pth < th) ? 1 : 0;      /* see s3a_decoder_search: unsupported beam geometry */
+    }
+    __syncthreads();
+    /* (a) next active list */
+    block_exclusive_scan(cnt + b, na, &total);
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
+        const int32_t u = act[b + i];
+        int32_t k = cnt[b + i];
+        if (selfemit[b + i]) {
+            nxt[b + k] = u; pos[u] = k; posf[u] = nf; k++;
+            selfemit[b + i] = 0;
+        }
+        for (int32_t j = child_off[u]; j < child_off[u + 1]; j++) {
+            const int32_t c = child[j];
+            if (turn[c] == i) {
+                nxt[b + k] = c; pos[c] = k; posf[c] = nf; k++;
+                turn[c] = -1;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) nnxt[t] = total;
+    __syncthreads();
+    /* (b) word exits, in active-list order */
+    const int32_t wth = s_wth;
+    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
+        const int32_t u = act[b + i];
+        cnt[b + i] = (wid[u] >= 0 && outs[u] >= wth) ? 1 : 0;
+    }
+    __syncthreads();
+    block_exclusive_scan(cnt + b, na, &total);
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
+        const int32_t u = act[b + i];
+        if (wid[u] >= 0 && outs[u] >= wth) {
+            const int32_t k = b + cnt[b + i];
+            exits[k] = wid[u];
+            exits[N + k] = add32(outs[u], -prob[u]);
+            exits[2 * N + k] = outh[u];
+            if (outh[u] == -1) atomicExch(&nexit[T + t], 1);
+        }
+    }
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS)
+        cnt[b + i] = 0;
+    if (threadIdx.x == 0) nexit[t] = total;
+    /* publish this tree's results, find out whether we are last */
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                        /* agent-scope release */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = (atomicAdd(done, 1) == T - 1) ? 1 : 0;
+        if (s_last) __threadfence();                            /* agent-scope acquire */
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    const int32_t hdr = 5 * T + 16;
+    volatile const int32_t *vbest = best, *vnexit = nexit, *vex = exits, *vmisc = misc;
+    for (int32_t i = threadIdx.x; i < 2 * T; i += SCAN_THREADS) pack[i] = vbest[i];
+    for (int32_t i = threadIdx.x; i < T; i += SCAN_THREADS) {
+        pack[2 * T + i] = nact[i];
+        pack[3 * T + 8 + i] = vnexit[i];
+        pack[4 * T + 8 + i] = vnexit[T + i];
+    }
+    if (threadIdx.x < 8) {
+        pack[3 * T + threadIdx.x] = s_thr[threadIdx.x];
+        int32_t m = vmisc[threadIdx.x];
+        if (threadIdx.x == 6) m = max(vmisc[0], vmisc[5]);      /* srch->senscale */
+        pack[5 * T + 8 + threadIdx.x] = m;
+    }
+    int32_t off = 0;
+    for (int32_t tt = 0; tt < T; tt++) {
+        const int32_t n = vnexit[tt], bb = node_base[tt];
+        for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
+            const int32_t k = off + i;
+            if (k < max_exits) {
+                pack[hdr + 3 * k] = vex[bb + i];
+                pack[hdr + 3 * k + 1] = vex[N + bb + i];
+                pack[hdr + 3 * k + 2] = vex[2 * N + bb + i];
+            }
+        }
+        off += n;
+    }
+    __syncthreads();
+    /* reset the per-frame accumulators for the next frame */
+    for (int32_t i = threadIdx.x; i < 2 * T; i += SCAN_THREADS) { best[i] = INT_MIN; nexit[i] = 0; }
+    if (threadIdx.x < 8) misc[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 5) ? INT_MIN : 0;
+    if (threadIdx.x == 0) *done = 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* lextree_enter for up to two trees of one frame + next frame's senone marks */
+/* ent[e] = {node (global id), call}; calls[c] = {inscore, inhist}; groups: {tree, ent_lo, ent_hi} */
+__global__ void
+k_dec_enter1(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *__restrict__ calls,
+             const int32_t *__restrict__ prob, const int32_t *__restrict__ sc, int32_t thresh,
+             unsigned long long *key, int32_t *first)
+{
+    const int32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_ent) return;
+    const int32_t v = ent[2 * e], c = ent[2 * e + 1];
+    const int32_t scr = add32(calls[2 * c], prob[v]);
+    if (scr < thresh || !(sc[v] < scr)) return;
+    atomicMax(&key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
+    atomicMin(&first[v], c);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_dec_enter2(const int32_t *__restrict__ groups, const int32_t *__restrict__ ent,
+             const int32_t *__restrict__ calls, const int32_t *__restrict__ prob,
+             const int32_t *__restrict__ sc, const int32_t *__restrict__ frame,
+             const int32_t *__restrict__ first, int32_t thresh, int32_t nf,
+             const int32_t *__restrict__ node_base, int32_t *flag, int32_t *nxt, int32_t *nnxt,
+             int32_t *pos, int32_t *posf)
+{
+    __shared__ int32_t total;
+    const int32_t t = groups[3 * blockIdx.x], lo = groups[3 * blockIdx.x + 1], hi = groups[3 * blockIdx.x + 2];
+    const int32_t n = hi - lo, b = node_base[t];
+    for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const int32_t e = lo + i, v = ent[2 * e], c = ent[2 * e + 1];
+        const int32_t scr = add32(calls[2 * c], prob[v]);
+        flag[e] = (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
+    }
+    __syncthreads();
+    block_exclusive_scan(flag + lo, n, &total);
+    __syncthreads();
+    const int32_t n0 = nnxt[t];
+    for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
+        const int32_t e = lo + i, v = ent[2 * e], c = ent[2 * e + 1];
+        const int32_t scr = add32(calls[2 * c], prob[v]);
+        if (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) {
+            const int32_t k = n0 + flag[e];
+            nxt[b + k] = v; pos[v] = k; posf[v] = nf;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) nnxt[t] = n0 + total;
+}
+
+/* blocks [0, n_ent_blocks): apply the winning entries; the remaining blocks mark the senones
+ * of every node of the NEXT active lists (srch_TST_select_active_gmm for the coming frame) */
+__global__ void __launch_bounds__(DBLOCK)
+k_dec_enter3_mark(int32_t n_ent_blocks, const int32_t *__restrict__ ent, int32_t n_ent,
+                  const int32_t *__restrict__ calls, int32_t nf,
+                  const unsigned long long *__restrict__ key, const int32_t *__restrict__ first,
+                  int32_t *sc, int32_t *hist, int32_t *frame,
+                  int32_t T, int32_t blocks_per_tree, const int32_t *__restrict__ node_base,
+                  const int32_t *__restrict__ nxt, const int32_t *__restrict__ nnxt,
+                  const int32_t *__restrict__ ssid, const uint8_t *__restrict__ comp,
+                  const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
+                  const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
+                  uint8_t *sen_active)
+{
+    if ((int32_t)blockIdx.x < n_ent_blocks) {
+        const int32_t e = blockIdx.x * DBLOCK + threadIdx.x;
+        if (e >= n_ent) return;
+        const int32_t v = ent[2 * e], c = ent[2 * e + 1];
+        const unsigned long long k = key[v];
+        if (k == 0ull) return;
+        const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(k & 0xffffffffu);
+        if (c == win_c) { sc[v] = (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); hist[v] = calls[2 * c + 1]; }
+        if (c == first[v]) frame[v] = nf;
+        return;
+    }
+    const int32_t bb = blockIdx.x - n_ent_blocks;
+    const int32_t t = bb / blocks_per_tree, i = (bb % blocks_per_tree) * DBLOCK + threadIdx.x;
+    if (t >= T || i >= nnxt[t]) return;
+    const int32_t v = nxt[node_base[t] + i], ss = ssid[v];
+    if (comp[v]) {
+        for (int st = 0; st < 3; st++) {
+            const int32_t cs = comsseq[ss * 3 + st];
+            for (int32_t j = cs_off[cs]; j < cs_off[cs + 1]; j++)
+                sen_active[cs_list[j]] = 1;
+        }
+    }
+    else {
+        for (int st = 0; st < 3; st++)
+            sen_active[sseq[ss * 3 + st]] = 1;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* host side                                                           */
+/* ------------------------------------------------------------------ */
+static int32_t
+max_tree_nodes(const s3a_lexsearch_t *ls)
+{
+    int32_t m = 0;
+    for (int32_t t = 0; t < ls->n_tree; t++)
+        m = max(m, ls->node_base[t + 1] - ls->node_base[t]);
+    return m;
+}
+
+extern "C" int32_t
+s3a_decoder_utt_begin(s3a_lexsearch_t *ls, s3a_scorer_t *sc)
+{
+    int32_t rc;
+    if (!ls || !sc) return S3A_EINVAL;
+    if ((rc = s3a_scorer_utt_begin(sc)) != S3A_OK) return rc;
+    if ((rc = s3a_scorer_reset_frame_state(sc)) != S3A_OK) return rc;
+    return S3A_OK;      /* d_best / d_done / key / first are left clean by reset, utt_end and k_dec_finish */
+}
+
+extern "C" int32_t
+s3a_decoder_score(s3a_scorer_t *sc, const float *feat, int32_t frame)
+{
+    if (!sc || !feat) return S3A_EINVAL;
+    return s3a_scorer_enqueue_raw(sc, feat, frame);
+}
+
+extern "C" int32_t
+s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int32_t frm,
+                   int32_t hmmbeam, int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam,
+                   int32_t maxhmmpf, s3a_frame_result_t *res, int32_t *n_exit, int32_t *exit_wid,
+                   int32_t *exit_score, int32_t *exit_hist, int32_t max_exits)
+{
+    if (!ls || !sc || !cs || !res || !n_exit || !exit_wid || !exit_score || !exit_hist) return S3A_EINVAL;
+    const int32_t T = ls->n_tree, hdr = 5 * T + 16, maxn = max_tree_nodes(ls);
+    const int cur = ls->cur, nxt = cur ^ 1;
+    FrameBeams bm = { hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf };
+    int32_t total = 0, t;
+
+    /* A parent that is cleared in this frame (bestscore < thres) must not propagate.  With the
+     * phone threshold at or above the HMM threshold -- true for every sensible beam setting and
+     * enforced by the reference's own histogram branch (pb = max(hb, pbeam)) -- a cleared parent
+     * can never reach it, so the kernels need no cross-node ordering.  Refuse anything else. */
+    if (pbeam < hmmbeam) {
+        s3a_set_error("s3a_decoder_search: -pbeam wider than -beam is not supported");
+        return S3A_EUNSUP;
+    }
+
+    hipLaunchKernelGGL(k_dec_hmm_eval, dim3((maxn + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK),
+                       (size_t)ls->n_tmat * 12 * 4, ls->stream, ls->d_node_base, ls->d_act[cur],
+                       ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
+                       ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
+                       sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best);
+    hipLaunchKernelGGL(k_dec_resolve, dim3((ls->N + DBLOCK - 1) / DBLOCK), dim3(DBLOCK), 0, ls->stream,
+                       ls->N, T, frm, bm, ls->d_best, ls->d_nact[cur], ls->d_node_base, ls->d_tree_of,
+                       ls->d_prob, ls->d_par_off, ls->d_par, ls->d_pos, ls->d_posf, ls->d_sc, ls->d_hist,
+                       ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame, ls->d_turn, ls->d_selfemit,
+                       ls->d_cnt, ls->d_key, ls->d_first);
+    hipLaunchKernelGGL(k_dec_finish, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
+                       ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_child_off, ls->d_child,
+                       ls->d_wid, ls->d_prob, ls->d_outs, ls->d_outh, ls->d_turn, ls->d_selfemit,
+                       ls->d_cnt, ls->d_act[nxt], ls->d_nact[nxt], ls->d_pos, ls->d_posf, ls->d_best,
+                       ls->d_exit, ls->d_nexit, sc->misc_d, ls->d_done, ls->d_pack, ls->pack_max_exits);
+    HIPCHK(hipGetLastError());
+    const int32_t first = 256;
+    HIPCHK(hipMemcpyAsync(ls->h_pack, ls->d_pack, (size_t)(hdr + 3 * first) * 4, hipMemcpyDeviceToHost, ls->stream));
+    HIPCHK(hipStreamSynchronize(ls->stream));
+    const int32_t *p = ls->h_pack;
+    res->best_hmm = p[3 * T + 3]; res->best_word = p[3 * T + 4]; res->n_hmm = p[3 * T + 5];
+    res->thres = p[3 * T + 0]; res->phone_thres = p[3 * T + 1]; res->word_thres = p[3 * T + 2];
+    res->need_histprune = p[3 * T + 6];
+    for (int i = 0; i < 8; i++) res->extra[i] = p[5 * T + 8 + i];
+    if (p[3 * T + 7]) {
+        s3a_set_error("s3a_decoder_search: phone threshold below the HMM threshold in frame %d "
+                      "(-ptranskip with a weak best word): not supported by the fused frame", frm);
+        return S3A_EUNSUP;
+    }
+    for (t = 0; t < T; t++) {
+        if (p[4 * T + 8 + t]) {
+            s3a_set_error("out.history==-1 at a word exit of tree %d (LEXTREE_OPERATION_FAILURE)", t);
+            return S3A_EINVAL;
+        }
+        n_exit[t] = p[3 * T + 8 + t];
+        total += n_exit[t];
+    }
+    res->n_exit_total = total;
+    if (total > max_exits || total > ls->pack_max_exits) {
+        s3a_set_error("s3a_decoder_search: %d word exits in one frame exceed the buffers", total);
+        return S3A_EINVAL;
+    }
+    if (total > first) {
+        HIPCHK(hipMemcpyAsync(ls->h_pack + hdr + 3 * first, ls->d_pack + hdr + 3 * first,
+                              (size_t)3 * (total - first) * 4, hipMemcpyDeviceToHost, ls->stream));
+        HIPCHK(hipStreamSynchronize(ls->stream));
+    }
+    for (int32_t k = 0; k < total; k++) {
+        exit_wid[k] = p[hdr + 3 * k];
+        exit_score[k] = p[hdr + 3 * k + 1];
+        exit_hist[k] = p[hdr + 3 * k + 2];
+    }
+    return S3A_OK;
+}
+
+/*
+ * srch_utt_word_trans's lextree_enter calls (tree_a: n_a calls with left contexts; tree_b:
+ * one call, the filler tree; either count may be 0), the senone marks of the coming frame
+ * and lextree_active_swap.  Also used at utterance begin (cf = -1).
+ */
+extern "C" int32_t
+s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int32_t cf,
+                       int32_t thresh, int32_t tree_a, int32_t n_a, const int32_t *lc_a,
+                       const int32_t *scr_a, const int32_t *hist_a, int32_t tree_b, int32_t n_b,
+                       const int32_t *lc_b, const int32_t *scr_b, const int32_t *hist_b)
+{
+    if (!ls || !sc || !cs || n_a < 0 || n_b < 0 || n_a + n_b > 4096) return S3A_EINVAL;
+    const int32_t T = ls->n_tree, maxn = max_tree_nodes(ls);
+    const int nxt = ls->cur ^ 1;
+    const size_t slot_words = (size_t)2 * 4096 + (size_t)2 * ls->ent_cap;
+    int32_t *slot = ls->h_ring + (size_t)(ls->ring_slot++ & 7) * slot_words;
+    int32_t *groups = slot, *calls = slot + 8, *ent = slot + 2 * 4096;     /* [groups 8][calls ...][entries ...] */
+    int32_t n_ent = 0, n_groups = 0, c = 0;
+
+    for (int g = 0; g < 2; g++) {
+        const int32_t tree = g ? tree_b : tree_a, n = g ? n_b : n_a;
+        const int32_t *lc = g ? lc_b : lc_a, *scr = g ? scr_b : scr_a, *hi = g ? hist_b : hist_a;
+        if (n == 0) continue;
+        if (tree < 0 || tree >= T) return S3A_EINVAL;
+        const int32_t lo = n_ent;
+        for (int32_t i = 0; i < n; i++, c++) {
+            int32_t k = 0;
+            if (ls->n_lc[tree] > 0) {
+                for (k = 0; k < ls->n_lc[tree] && ls->lc[tree][k] != lc[i]; k++);
+                if (k >= ls->n_lc[tree]) {
+                    s3a_set_error("s3a_decoder_transition: left context %d is not a root context of tree %d", lc[i], tree);
+                    return S3A_EINVAL;
+                }
+            }
+            const int32_t off = ls->rootbuf_base[tree] + ls->lcroot_off[tree][k];
+            const int32_t len = ls->lcroot_off[tree][k + 1] - ls->lcroot_off[tree][k];
+            if (n_ent + len > ls->ent_cap) { s3a_set_error("s3a_decoder_transition: entry staging overflow"); return S3A_EINVAL; }
+            calls[2 * c] = scr[i];
+            calls[2 * c + 1] = hi[i];
+            for (int32_t q = 0; q < len; q++, n_ent++) {
+                ent[2 * n_ent] = ls->h_rootlist[off + q];
+                ent[2 * n_ent + 1] = c;
+            }
+        }
+        groups[3 * n_groups] = tree; groups[3 * n_groups + 1] = lo; groups[3 * n_groups + 2] = n_ent;
+        n_groups++;
+    }
+    if (n_ent > 0) {
+        /* one contiguous upload: calls | groups | entries all live in the pinned ring slot */
+        HIPCHK(hipMemcpyAsync(ls->d_calls, slot, (size_t)(8 + 2 * c) * 4, hipMemcpyHostToDevice, ls->stream));
+        HIPCHK(hipMemcpyAsync(ls->d_ent, ent, (size_t)2 * n_ent * 4, hipMemcpyHostToDevice, ls->stream));
+        hipLaunchKernelGGL(k_dec_enter1, dim3((n_ent + 255) / 256), dim3(256), 0, ls->stream, ls->d_ent,
+                           n_ent, ls->d_calls + 8, ls->d_prob, ls->d_sc, thresh, ls->d_key, ls->d_first);
+        hipLaunchKernelGGL(k_dec_enter2, dim3(n_groups), dim3(SCAN_THREADS), 0, ls->stream,
+                           ls->d_calls, ls->d_ent, ls->d_calls + 8, ls->d_prob, ls->d_sc,
+                           ls->d_frame, ls->d_first, thresh, cf + 1, ls->d_node_base, ls->d_eflag,
+                           ls->d_act[nxt], ls->d_nact[nxt], ls->d_pos, ls->d_posf);
+    }
+    {
+        const int32_t n_ent_blocks = (n_ent + DBLOCK - 1) / DBLOCK;
+        const int32_t bpt = (maxn + DBLOCK - 1) / DBLOCK;
+        hipLaunchKernelGGL(k_dec_enter3_mark, dim3(n_ent_blocks + bpt * T), dim3(DBLOCK), 0, ls->stream,
+                           n_ent_blocks, ls->d_ent, n_ent, ls->d_calls + 8, cf + 1, ls->d_key, ls->d_first,
+                           ls->d_sc, ls->d_hist, ls->d_frame, T, bpt, ls->d_node_base, ls->d_act[nxt],
+                           ls->d_nact[nxt], ls->d_ssid, ls->d_comp, ls->d_sseq, ls->d_comsseq, cs->off_d,
+                           cs->list_d, sc->act_d);
+    }
+    HIPCHK(hipGetLastError());
+    ls->cur ^= 1;       /* lextree_active_swap; the new next-list counts are overwritten by k_dec_finish */
+    return S3A_OK;
+}

@@ -40,99 +40,16 @@
 #include <vector>
 
 #include "s3a_device.h"
+#include "s3a_structs.h"
 #include "s3a_vit.h"
+#include "s3a_scan.h"
 
 #define WORST S3A_WORST
 #define LT_BLOCK 256
-#define SCAN_THREADS 1024
-
-struct s3a_lexsearch_s {
-    int32_t n_tree, N;                  /* N = total nodes */
-    int32_t n_emit, n_tmat, n_sen, n_comsen, n_lcmax;
-    std::vector<int32_t> node_base;     /* [n_tree+1] */
-    std::vector<int32_t> n_lc;          /* per tree */
-    std::vector<std::vector<int16_t>> lc;           /* per tree: lc ids */
-    std::vector<std::vector<int32_t>> lcroot_off;   /* per tree: CSR into the tree's root buffer */
-    std::vector<int32_t> rootbuf_base;  /* per tree: offset of its root lists in d_rootlist */
-    std::vector<int32_t> h_rootlist;    /* host copy of the concatenated root lists */
-    /* static (device) */
-    int32_t *d_node_base;
-    int32_t *d_ssid, *d_tmatid, *d_wid, *d_prob;
-    uint8_t *d_comp;
-    int32_t *d_child_off, *d_child, *d_par_off, *d_par;
-    int32_t *d_rootlist;                /* concatenated root lists (global node ids) */
-    int32_t *d_tp;
-    int16_t *d_sseq, *d_comsseq, *d_comstate;
-    int32_t *d_comstate_off;
-    /* state (device) */
-    int32_t *d_sc, *d_hist;             /* [3][N] */
-    int32_t *d_outs, *d_outh, *d_bests, *d_frame;
-    int32_t *d_pos, *d_posf;            /* position in the list of frame posf */
-    int32_t *d_act[2];                  /* [N] each; tree t owns [node_base[t], node_base[t+1]) */
-    int32_t *d_nact[2];                 /* [n_tree] */
-    int cur;                            /* index of the "active" buffer; the other is next_active */
-    /* per-frame scratch */
-    int32_t *d_cand, *d_ncand, *d_candf;    /* candidate inactive children per tree */
-    int32_t *d_turn, *d_selfemit, *d_cnt;   /* [N] */
-    int32_t *d_best;                    /* [n_tree][2] best, wbest */
-    int32_t *d_exit;                    /* [3][N] wid, score, hist of word exits (tree slices) */
-    int32_t *d_nexit;                   /* [n_tree] + [n_tree] error flags */
-    int32_t *d_calls, *d_ent, *d_eflag, *d_first;   /* enter scratch */
-    unsigned long long *d_key;
-    int32_t ent_cap;
-    int32_t *d_thr;                     /* [8] thresholds + frame statistics */
-    int32_t *d_pack, *h_pack;           /* per-frame result record (device / pinned host) */
-    int32_t pack_max_exits;
-    int32_t *h_ring;                    /* pinned staging ring for enter calls */
-    int32_t ring_slot;
-    int32_t *h_pin;                     /* pinned host mirror for small read-backs */
-    hipStream_t stream;
-    int own_stream;
-};
 
 /* ------------------------------------------------------------------ */
 /* helpers                                                             */
 /* ------------------------------------------------------------------ */
-/* exclusive scan of v[0..n) in place by one workgroup; returns the total in *total */
-__device__ void
-block_exclusive_scan(int32_t *v, int32_t n, int32_t *total)
-{
-    __shared__ int32_t wsum[SCAN_THREADS / 64];
-    __shared__ int32_t carry;
-    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int32_t base = 0; base < n; base += SCAN_THREADS) {
-        int32_t i = base + tid;
-        int32_t x = (i < n) ? v[i] : 0;
-        int32_t incl = x;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int32_t y = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += y;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        if (wave == 0) {
-            int32_t w = (lane < SCAN_THREADS / 64) ? wsum[lane] : 0;
-            int32_t wi = w;
-#pragma unroll
-            for (int o = 1; o < SCAN_THREADS / 64; o <<= 1) {
-                int32_t y = __shfl_up(wi, o, 64);
-                if (lane >= o) wi += y;
-            }
-            if (lane < SCAN_THREADS / 64) wsum[lane] = wi - w;  /* exclusive wave offsets */
-        }
-        __syncthreads();
-        int32_t excl = carry + wsum[wave] + incl - x;
-        if (i < n) v[i] = excl;
-        __syncthreads();
-        if (tid == SCAN_THREADS - 1) carry = excl + x;
-        __syncthreads();
-    }
-    if (tid == 0) *total = carry;
-}
-
 /* ------------------------------------------------------------------ */
 /* lextree_hmm_eval                                                    */
 /* ------------------------------------------------------------------ */
@@ -639,6 +556,12 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
     UP(ls->d_ssid, h_ssid); UP(ls->d_tmatid, h_tm); UP(ls->d_wid, h_wid); UP(ls->d_prob, h_prob);
     UP(ls->d_comp, h_comp); UP(ls->d_child_off, h_coff); UP(ls->d_child, h_child);
     UP(ls->d_par_off, h_poff); UP(ls->d_par, h_par); UP(ls->d_rootlist, h_roots);
+    {
+        std::vector<int32_t> h_tree_of(N);
+        for (t = 0; t < n_tree; t++)
+            for (int32_t v = ls->node_base[t]; v < ls->node_base[t + 1]; v++) h_tree_of[v] = t;
+        UP(ls->d_tree_of, h_tree_of);
+    }
     ls->h_rootlist = h_roots;
 #undef UP
     {
@@ -672,6 +595,9 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
     DMALLOC(ls->d_first, (size_t)N * 4); DMALLOC(ls->d_key, (size_t)N * 8);
     HIPCHK(hipHostMalloc((void **)&ls->h_pin, (size_t)(8 * n_tree + 16) * 4));
     DMALLOC(ls->d_thr, 8 * 4);
+    DMALLOC(ls->d_done, 4 * 4);
+    HIPCHK(hipMemset(ls->d_done, 0, 16));
+    HIPCHK(hipMemset(ls->d_key, 0, (size_t)N * 8));
     ls->pack_max_exits = 2048;
     DMALLOC(ls->d_pack, (size_t)(5 * n_tree + 16 + 3 * ls->pack_max_exits) * 4);
     HIPCHK(hipHostMalloc((void **)&ls->h_pack, (size_t)(5 * n_tree + 16 + 3 * ls->pack_max_exits) * 4));
@@ -735,7 +661,7 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
         &ls->d_frame, &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
-        &ls->d_first, &ls->d_thr, &ls->d_pack };
+        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_tree_of, &ls->d_done };
     for (auto p : ptrs) (void)hipFree(*p);
     (void)hipFree(ls->d_comp); (void)hipFree(ls->d_sseq); (void)hipFree(ls->d_comsseq);
     (void)hipFree(ls->d_comstate); (void)hipFree(ls->d_key);
@@ -758,8 +684,11 @@ s3a_lexsearch_reset(s3a_lexsearch_t *ls)
         || (rc = fill(ls, ls->d_candf, INT_MIN, N)) || (rc = fill(ls, ls->d_turn, -1, N))
         || (rc = fill(ls, ls->d_selfemit, 0, N)) || (rc = fill(ls, ls->d_cnt, 0, N))
         || (rc = fill(ls, ls->d_nact[0], 0, ls->n_tree)) || (rc = fill(ls, ls->d_nact[1], 0, ls->n_tree))
-        || (rc = fill(ls, ls->d_nexit, 0, 2 * ls->n_tree)))
+        || (rc = fill(ls, ls->d_nexit, 0, 2 * ls->n_tree))
+        || (rc = fill(ls, ls->d_best, INT_MIN, 2 * ls->n_tree)) || (rc = fill(ls, ls->d_first, INT_MAX, N))
+        || (rc = fill(ls, ls->d_done, 0, 4)))
         return rc;
+    HIPCHK(hipMemsetAsync(ls->d_key, 0, (size_t)N * 8, ls->stream));
     ls->cur = 0;
     return S3A_OK;
 }

@@ -27,27 +27,9 @@
 #include <limits.h>
 
 #include "s3a_device.h"
+#include "s3a_structs.h"
 
 #pragma clang fp contract(off)
-
-struct s3a_scorer_s {
-    s3a_mgau_model_t *g;
-    int32_t n_sen, n_ci_sen;
-    int16_t *cd2cisen_h;
-    /* fast_gmm_t subset */
-    int32_t ds_ratio, cond_ds, ci_pbeam, max_cd, dyn_ci_pbeam, skip_count;
-    float tighten_factor;
-    /* device */
-    int16_t *cd2cisen_d;
-    uint8_t *ncomp_d;       /* [S] */
-    float *x_d;             /* [D4*4] */
-    uint8_t *act_d;         /* [S] */
-    int32_t *scr_d;         /* [S] */
-    int32_t *ci_d;          /* [n_ci_sen] */
-    int32_t *misc_d;        /* [0]=best [1]=ns [2]=ng */
-    int32_t *misc_h;        /* pinned mirror */
-    int32_t *ci_occ_h, *idx_h;
-};
 
 template <bool EXACT>
 __global__ void __launch_bounds__(256)
@@ -60,7 +42,8 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
               const uint8_t *__restrict__ sen_active, int32_t *__restrict__ senscr,
               int32_t pbest_plus_beam, const int32_t *__restrict__ pbest_ptr, int32_t beam,
               int32_t frame, int32_t is_skip,
-              int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc, int32_t best_slot)
+              int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc, int32_t best_slot,
+              uint8_t *clear_active)
 {
     typedef typename Acc<EXACT>::T acc_t;
     const int32_t lane = threadIdx.x & 63;
@@ -118,6 +101,9 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
     if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
     if (mode == 3) score = ci_scr;
 
+    /* fused decoder path: the mask is consumed here, leave it clean for the next frame's marks
+     * (every lane of the senone has read it above; same wave, program order) */
+    if (clear_active && valid && c == 0) clear_active[sen] = 0;
     int32_t wbest = INT_MIN, ns = 0, ng = 0;
     if (mode != 0 && c == 0) {
         senscr[sen] = score;
@@ -264,7 +250,7 @@ s3a_scorer_utt_begin(s3a_scorer_t *sc)
 static void
 launch_gated(s3a_scorer_t *sc, int32_t lo, int32_t hi, int32_t ci_phase, int32_t thresh,
              int32_t frame, int32_t is_skip, const int32_t *pbest_ptr = NULL, int32_t beam = 0,
-             int32_t best_slot = 0)
+             int32_t best_slot = 0, uint8_t *clear_active = NULL)
 {
     s3a_mgau_model_t *g = sc->g;
     struct s3a_mgau_dev_s *d = g->dev;
@@ -276,13 +262,13 @@ launch_gated(s3a_scorer_t *sc, int32_t lo, int32_t hi, int32_t ci_phase, int32_t
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
                            sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
-                           frame, is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d, best_slot);
+                           frame, is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d, best_slot, clear_active);
     else
         hipLaunchKernelGGL(k_gated_frame<false>, dim3(grid), dim3(256), 0, d->stream, d->mean4,
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
                            sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
-                           frame, is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d, best_slot);
+                           frame, is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d, best_slot, clear_active);
 }
 
 static const int32_t k_misc_init[8] = { INT_MIN, 0, 0, 0, 0, 0, 0, 0 };
@@ -405,14 +391,6 @@ extern "C" void *s3a_mgau_stream(s3a_mgau_model_t *g) { return (g && g->dev) ? (
 /* ------------------------------------------------------------------ */
 /* composite senones                                                   */
 /* ------------------------------------------------------------------ */
-struct s3a_comsen_s {
-    int32_t n_comstate, n_list;
-    int32_t *off_d, *wt_d, *out_d, *scr_d;
-    int16_t *list_d;
-    size_t scr_cap;
-    hipStream_t stream;
-};
-
 __global__ void
 k_comsenscr(int32_t n, const int32_t *__restrict__ off, const int16_t *__restrict__ list,
             const int32_t *__restrict__ wt, const int32_t *__restrict__ senscr,
@@ -574,6 +552,42 @@ s3a_approx_cont_mgau_frame_eval_async(s3a_scorer_t *sc, s3a_comsen_t *cs, const 
     if (cs)
         hipLaunchKernelGGL(k_comsenscr, dim3((cs->n_comstate + 255) / 256), dim3(256), 0, d->stream,
                            cs->n_comstate, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d, cs->out_d);
+    HIPCHK(hipGetLastError());
+    return S3A_OK;
+}
+
+/*
+ * Internal (fused decoder frame, s3a_decoder.hip): enqueue the CI phase and the gated CD
+ * phase only.  Scores stay RAW in scr_d (the search kernels subtract the frame best on the
+ * fly, which is what approx_cont_mgau.c:597-600 does for every senone an active HMM can
+ * read); misc[0] = best over evaluated CD senones, misc[5] = CI best; the senone mask is
+ * consumed and cleared.  misc must have been reset (k_misc_reset / the previous frame's
+ * finishing kernel).
+ */
+int32_t
+s3a_scorer_enqueue_raw(s3a_scorer_t *sc, const float *feat, int32_t frame)
+{
+    struct s3a_mgau_dev_s *d = sc->g->dev;
+    int32_t beam = sc->ci_pbeam, is_skip = (frame % sc->ds_ratio == 0) ? 0 : 1;
+    if (sc->max_cd < sc->n_sen - sc->n_ci_sen) {
+        s3a_set_error("-maxcdsenpf (dynamic CI beam) needs the host senone mask: use the host-pointer entry point");
+        return S3A_EUNSUP;
+    }
+    if (is_skip)
+        beam = (int32_t)((float)beam * sc->tighten_factor);
+    HIPCHK(hipMemcpyAsync(sc->x_d, feat, sizeof(float) * d->D, hipMemcpyHostToDevice, d->stream));
+    launch_gated(sc, 0, sc->n_ci_sen, 1, 0, frame, 0, NULL, 0, 5);
+    launch_gated(sc, sc->n_ci_sen, sc->n_sen, 0, 0, frame, is_skip, sc->misc_d + 5, beam, 0, sc->act_d);
+    HIPCHK(hipGetLastError());
+    return S3A_OK;
+}
+
+int32_t
+s3a_scorer_reset_frame_state(s3a_scorer_t *sc)
+{
+    struct s3a_mgau_dev_s *d = sc->g->dev;
+    hipLaunchKernelGGL(k_misc_reset, dim3(1), dim3(64), 0, d->stream, sc->misc_d);
+    HIPCHK(hipMemsetAsync(sc->act_d, 0, sc->n_sen, d->stream));
     HIPCHK(hipGetLastError());
     return S3A_OK;
 }

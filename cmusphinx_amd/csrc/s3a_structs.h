@@ -1,0 +1,92 @@
+/*
+ * s3a_structs.h -- the device-object structures shared by the .hip translation units
+ * (scorer, composite senones, lexical-tree search, fused decoder frame).
+ */
+#ifndef S3A_STRUCTS_H
+#define S3A_STRUCTS_H
+
+#include <vector>
+#include "s3a_device.h"
+
+struct s3a_scorer_s {
+    s3a_mgau_model_t *g;
+    int32_t n_sen, n_ci_sen;
+    int16_t *cd2cisen_h;
+    /* fast_gmm_t subset */
+    int32_t ds_ratio, cond_ds, ci_pbeam, max_cd, dyn_ci_pbeam, skip_count;
+    float tighten_factor;
+    /* device */
+    int16_t *cd2cisen_d;
+    uint8_t *ncomp_d;       /* [S] */
+    float *x_d;             /* [D4*4] */
+    uint8_t *act_d;         /* [S] */
+    int32_t *scr_d;         /* [S] */
+    int32_t *ci_d;          /* [n_ci_sen] */
+    int32_t *misc_d;        /* [0]=best [1]=ns [2]=ng */
+    int32_t *misc_h;        /* pinned mirror */
+    int32_t *ci_occ_h, *idx_h;
+};
+
+
+struct s3a_comsen_s {
+    int32_t n_comstate, n_list;
+    int32_t *off_d, *wt_d, *out_d, *scr_d;
+    int16_t *list_d;
+    size_t scr_cap;
+    hipStream_t stream;
+};
+
+
+struct s3a_lexsearch_s {
+    int32_t n_tree, N;                  /* N = total nodes */
+    int32_t n_emit, n_tmat, n_sen, n_comsen, n_lcmax;
+    std::vector<int32_t> node_base;     /* [n_tree+1] */
+    std::vector<int32_t> n_lc;          /* per tree */
+    std::vector<std::vector<int16_t>> lc;           /* per tree: lc ids */
+    std::vector<std::vector<int32_t>> lcroot_off;   /* per tree: CSR into the tree's root buffer */
+    std::vector<int32_t> rootbuf_base;  /* per tree: offset of its root lists in d_rootlist */
+    std::vector<int32_t> h_rootlist;    /* host copy of the concatenated root lists */
+    /* static (device) */
+    int32_t *d_node_base;
+    int32_t *d_ssid, *d_tmatid, *d_wid, *d_prob;
+    uint8_t *d_comp;
+    int32_t *d_child_off, *d_child, *d_par_off, *d_par;
+    int32_t *d_rootlist;                /* concatenated root lists (global node ids) */
+    int32_t *d_tp;
+    int16_t *d_sseq, *d_comsseq, *d_comstate;
+    int32_t *d_comstate_off;
+    /* state (device) */
+    int32_t *d_sc, *d_hist;             /* [3][N] */
+    int32_t *d_outs, *d_outh, *d_bests, *d_frame;
+    int32_t *d_pos, *d_posf;            /* position in the list of frame posf */
+    int32_t *d_act[2];                  /* [N] each; tree t owns [node_base[t], node_base[t+1]) */
+    int32_t *d_nact[2];                 /* [n_tree] */
+    int cur;                            /* index of the "active" buffer; the other is next_active */
+    /* per-frame scratch */
+    int32_t *d_cand, *d_ncand, *d_candf;    /* candidate inactive children per tree */
+    int32_t *d_turn, *d_selfemit, *d_cnt;   /* [N] */
+    int32_t *d_best;                    /* [n_tree][2] best, wbest */
+    int32_t *d_exit;                    /* [3][N] wid, score, hist of word exits (tree slices) */
+    int32_t *d_nexit;                   /* [n_tree] + [n_tree] error flags */
+    int32_t *d_calls, *d_ent, *d_eflag, *d_first;   /* enter scratch */
+    unsigned long long *d_key;
+    int32_t ent_cap;
+    int32_t *d_thr;                     /* [8] thresholds + frame statistics */
+    int32_t *d_tree_of;                 /* [N] tree index of every node */
+    int32_t *d_done;                    /* workgroup completion counter of the fused finishing kernel */
+    int32_t *d_pack, *h_pack;           /* per-frame result record (device / pinned host) */
+    int32_t pack_max_exits;
+    int32_t *h_ring;                    /* pinned staging ring for enter calls */
+    int32_t ring_slot;
+    int32_t *h_pin;                     /* pinned host mirror for small read-backs */
+    hipStream_t stream;
+    int own_stream;
+};
+
+
+
+/* internal cross-TU entry points */
+int32_t s3a_scorer_enqueue_raw(s3a_scorer_t *sc, const float *feat, int32_t frame);
+int32_t s3a_scorer_reset_frame_state(s3a_scorer_t *sc);
+
+#endif

@@ -105,6 +105,11 @@ _SIGS = {
                                    [C.c_void_p] * 6 + [C.c_int32]),
     "s3a_approx_cont_mgau_frame_eval_async": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_scorer_misc_dev": (C.c_void_p, [C.c_void_p]),
+    "s3a_decoder_utt_begin": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "s3a_decoder_score": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_decoder_search": (C.c_int32, [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p] * 5 + [C.c_int32]),
+    "s3a_decoder_transition": (C.c_int32, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 3 +
+                               [C.c_int32, C.c_int32] + [C.c_void_p] * 3),
     "s3a_lexsearch_sen_active": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_lexsearch_utt_end": (C.c_int32, [C.c_void_p]),
     "s3a_lexsearch_get_active": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),

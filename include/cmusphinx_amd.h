@@ -356,6 +356,34 @@ int32_t s3a_lexsearch_frame_search(s3a_lexsearch_t *ls, const int32_t *senscr_de
                                    int32_t maxhmmpf, const int32_t *extra_dev,
                                    s3a_frame_result_t *res, int32_t *n_exit, int32_t *exit_wid,
                                    int32_t *exit_score, int32_t *exit_hist, int32_t max_exits);
+/*
+ * The FUSED frame (s3a_decoder.hip): the same results as the calls above with a third of
+ * the kernel launches -- a mode-4 frame is bounded by its kernel boundaries, not its work.
+ *   s3a_decoder_utt_begin   srch_TST_begin's device side (state reset)
+ *   s3a_decoder_score       gmm_compute_lv1 + lv2 (CI + gated CD senones; scores stay raw in
+ *                           HBM, the frame normaliser is applied inside the search kernels)
+ *   s3a_decoder_search      hmm_compute_lv2 + propagate_graph_ph_lv2 + the word-exit half of
+ *                           propagate_graph_wd_lv2; ONE synchronisation; results as for
+ *                           s3a_lexsearch_frame_search, res->extra = {-, #CD sen, #CD gau,
+ *                           #CI sen, #CI gau, CI best, senscale, -}
+ *   s3a_decoder_transition  srch_utt_word_trans's lextree_enter calls into one unigram tree
+ *                           (n_a calls) and one filler tree (n_b calls; either may be 0), the
+ *                           active-senone marks for the coming frame (select_active_gmm) and
+ *                           lextree_active_swap.  Must be called once per frame (and once at
+ *                           utterance begin with cf = -1), also when there is nothing to enter.
+ */
+int32_t s3a_decoder_utt_begin(s3a_lexsearch_t *ls, s3a_scorer_t *sc);
+int32_t s3a_decoder_score(s3a_scorer_t *sc, const float *feat, int32_t frame);
+int32_t s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int32_t frm,
+                           int32_t hmmbeam, int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam,
+                           int32_t maxhmmpf, s3a_frame_result_t *res, int32_t *n_exit,
+                           int32_t *exit_wid, int32_t *exit_score, int32_t *exit_hist,
+                           int32_t max_exits);
+int32_t s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int32_t cf,
+                               int32_t thresh, int32_t tree_a, int32_t n_a, const int32_t *lc_a,
+                               const int32_t *scr_a, const int32_t *hist_a, int32_t tree_b,
+                               int32_t n_b, const int32_t *lc_b, const int32_t *scr_b,
+                               const int32_t *hist_b);
 /* srch_TST_select_active_gmm (srch_time_switch_tree.c:1262-1324): clear, then mark the
  * senones of every active HMM (composite ones through their member lists) in a DEVICE
  * flag array of n_sen bytes (s3a_scorer_sen_active_dev) */
