@@ -48,10 +48,15 @@ struct FrameBeams {
     int32_t hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf;
 };
 
-/* thresholds of srch_TST_hmm_compute_lv2 from the per-tree maxima hmm_eval left in best[] */
-__device__ __forceinline__ void
+#define NBIN 1000        /* srch_time_switch_tree.c:858 */
+
+/* thresholds of srch_TST_hmm_compute_lv2 (srch_time_switch_tree.c:849-905) from the per-tree
+ * maxima hmm_eval left in best[]; when the frame holds more than 1.5 x maxhmmpf HMMs the
+ * beam found by the histogram kernels (hbin[NBIN]) replaces -beam and bounds the others */
+__device__ __forceinline__ bool
 frame_thresholds(const int32_t *best, const int32_t *nact, int32_t T, const FrameBeams &bm,
-                 int32_t &bh, int32_t &bw, int32_t &n, int32_t &th, int32_t &pth, int32_t &wth)
+                 const int32_t *hbin, int32_t &bh, int32_t &bw, int32_t &n, int32_t &th,
+                 int32_t &pth, int32_t &wth)
 {
     bh = INT_MIN; bw = INT_MIN; n = 0;
     for (int32_t t = 0; t < T; t++) {
@@ -59,9 +64,17 @@ frame_thresholds(const int32_t *best, const int32_t *nact, int32_t T, const Fram
         bw = max(bw, best[2 * t + 1]);
         n += nact[t];
     }
-    th = add32(bh, bm.hmmbeam);
-    wth = add32(bw, bm.wbeam);
-    pth = bm.phone_uses_wbeam ? wth : add32(bh, bm.pbeam);
+    int32_t hb = bm.hmmbeam, pb = bm.pbeam, wb = bm.wbeam;
+    const bool hist = n > bm.maxhmmpf + (bm.maxhmmpf >> 1);
+    if (hist) {
+        hb = hbin[NBIN];
+        pb = max(hb, pb);
+        wb = max(hb, wb);
+    }
+    th = add32(bh, hb);
+    wth = add32(bw, wb);
+    pth = bm.phone_uses_wbeam ? wth : add32(bh, pb);
+    return hist;
 }
 
 /* ------------------------------------------------------------------ */
@@ -133,6 +146,147 @@ k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
 
 /* ------------------------------------------------------------------ */
 /*
+ * lextree_hmm_histbin (lextree.c:1314-1358) + the bin scan of srch_TST_hmm_compute_lv2
+ * (srch_time_switch_tree.c:870-892).  Two side effects matter: the bins (they fix the
+ * frame's beam) and the ORDER of every tree's active list afterwards -- the reference
+ * rebuilds the list bin by bin, and within a bin in reverse insertion order (glist_add_ptr
+ * prepends), which later decides ties in the propagation.  Kernel 1 bins every active HMM
+ * (LDS-private histogram per workgroup); kernel 2, one workgroup per tree, finds the beam
+ * and performs that stable reordering as a counting sort whose ranks are computed in list
+ * order (wave-level peeling + per-wave bin counts).  Both return at once unless the frame
+ * is over 1.5 x maxhmmpf (or `force`: the stand-alone entry point).
+ */
+__global__ void __launch_bounds__(DBLOCK)
+k_dec_hist_count(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
+                 const int32_t *__restrict__ nact, int32_t T, FrameBeams bm,
+                 const int32_t *__restrict__ best, const int32_t *__restrict__ bests,
+                 int32_t *binof, int32_t *hbin, int32_t force_tree, int32_t fbest, int32_t fbw,
+                 int32_t nbin)
+{
+    __shared__ int32_t s_bin[NBIN];
+    __shared__ int32_t s_go, s_bh, s_bw;
+    const int32_t t = blockIdx.y;
+    if (threadIdx.x == 0) {
+        int32_t bh = INT_MIN, n = 0;
+        for (int32_t k = 0; k < T; k++) { bh = max(bh, best[2 * k]); n += nact[k]; }
+        if (force_tree >= 0) { s_go = (t == force_tree); s_bh = fbest; s_bw = fbw; }
+        else { s_go = n > bm.maxhmmpf + (bm.maxhmmpf >> 1); s_bh = bh; s_bw = -bm.hmmbeam / NBIN; }
+    }
+    __syncthreads();
+    if (!s_go) return;
+    for (int32_t i = threadIdx.x; i < nbin; i += DBLOCK) s_bin[i] = 0;
+    __syncthreads();
+    const int32_t i = blockIdx.x * DBLOCK + threadIdx.x, b = node_base[t];
+    if (i < nact[t]) {
+        int32_t k = (s_bh - bests[act[b + i]]) / s_bw;
+        if (k >= nbin) k = nbin - 1;
+        if (k < 0) k = 0;               /* cannot happen with bestscr = the frame's maximum */
+        binof[b + i] = k;
+        atomicAdd(&s_bin[k], 1);
+    }
+    __syncthreads();
+    for (int32_t k = threadIdx.x; k < nbin; k += DBLOCK)
+        if (s_bin[k]) atomicAdd(&hbin[k], s_bin[k]);
+}
+
+/* inclusive prefix sum over the SCAN_THREADS values of one workgroup */
+__device__ __forceinline__ int32_t
+block_inclusive_sum(int32_t x, int32_t *wsum /* [SCAN_THREADS / 64] shared */)
+{
+    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t y = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += y;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t add = 0;
+    for (int32_t w = 0; w < wave; w++) add += wsum[w];
+    return incl + add;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32_t *__restrict__ nact,
+                int32_t T, FrameBeams bm, const int32_t *__restrict__ binof, int32_t *tmp,
+                int32_t *hbin, int32_t *pos, int32_t force_tree, int32_t nbin)
+{
+    __shared__ int32_t s_cnt[NBIN], s_base[NBIN], s_run[NBIN];
+    __shared__ uint16_t s_cntw[SCAN_THREADS / 64][NBIN];
+    __shared__ int32_t s_wsum[SCAN_THREADS / 64];
+    __shared__ int32_t s_go, s_i;
+    const int32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        int32_t n = 0;
+        for (int32_t k = 0; k < T; k++) n += nact[k];
+        s_go = force_tree >= 0 ? (t == force_tree) : (n > bm.maxhmmpf + (bm.maxhmmpf >> 1));
+        s_i = nbin;
+    }
+    __syncthreads();
+    if (!s_go) return;
+    if (force_tree < 0) {
+        /* for (i = 0, j = 0; i < nbin && j < maxhmmpf; i++, j += bin[i]);  -- bin[0] is never
+         * counted and the read of bin[nbin] after the last increment decides nothing */
+        const int32_t x = (tid >= 1 && tid < nbin) ? hbin[tid] : 0;
+        const int32_t J = block_inclusive_sum(x, s_wsum);       /* j after i reached tid */
+        if (tid < nbin && J >= bm.maxhmmpf) atomicMin(&s_i, bm.maxhmmpf <= 0 ? 0 : tid);
+        __syncthreads();
+        if (t == 0 && tid == 0) hbin[NBIN] = -(s_i * (-bm.hmmbeam / NBIN));
+    }
+    /* this tree's own bin counts and bin bases */
+    const int32_t b = node_base[t], na = nact[t];
+    for (int32_t k = tid; k < nbin; k += SCAN_THREADS) { s_cnt[k] = 0; s_run[k] = 0; }
+    for (int32_t k = tid; k < (SCAN_THREADS / 64) * NBIN; k += SCAN_THREADS) (&s_cntw[0][0])[k] = 0;
+    __syncthreads();
+    for (int32_t i = tid; i < na; i += SCAN_THREADS) atomicAdd(&s_cnt[binof[b + i]], 1);
+    __syncthreads();
+    {
+        const int32_t x = tid < nbin ? s_cnt[tid] : 0;
+        const int32_t incl = block_inclusive_sum(x, s_wsum);
+        if (tid < nbin) s_base[tid] = incl - x;
+    }
+    __syncthreads();
+    for (int32_t c0 = 0; c0 < na; c0 += SCAN_THREADS) {
+        const int32_t i = c0 + tid;
+        const bool valid = i < na;
+        const int32_t k = valid ? binof[b + i] : -1;
+        int32_t rank = 0, tot = 0;
+        bool leader = false;
+        unsigned long long remaining = __ballot(valid);
+        while (remaining) {                                     /* wave-uniform */
+            const int src = __ffsll((long long)remaining) - 1;
+            const int32_t kb = __shfl(k, src, 64);
+            const unsigned long long m = __ballot(valid && k == kb);
+            if (valid && k == kb) {
+                rank = __popcll(m & ((1ull << lane) - 1ull));
+                tot = __popcll(m);
+                leader = (lane == src);
+            }
+            remaining &= ~m;
+        }
+        if (leader) s_cntw[wave][k] = (uint16_t)tot;
+        __syncthreads();
+        if (valid) {
+            int32_t before = s_run[k] + rank;
+            for (int32_t w = 0; w < wave; w++) before += s_cntw[w][k];
+            tmp[b + s_base[k] + s_cnt[k] - 1 - before] = act[b + i];
+        }
+        __syncthreads();
+        if (leader) { atomicAdd(&s_run[k], tot); s_cntw[wave][k] = 0; }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int32_t i = tid; i < na; i += SCAN_THREADS) {
+        const int32_t v = tmp[b + i];
+        act[b + i] = v;
+        pos[v] = i;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/*
  * lextree_hmm_propagate_non_leaves from every node's point of view (see the header of
  * s3a_lextree.hip for the rule); one thread per node of every tree: inactive nodes
  * without a propagating parent fall through after two loads.  Also resets the root-entry
@@ -146,15 +300,17 @@ k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               const int32_t *__restrict__ pos, const int32_t *__restrict__ posf,
               int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
               int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
-              unsigned long long *key, int32_t *first)
+              unsigned long long *key, int32_t *first, int32_t *hbin)
 {
-    __shared__ int32_t s_th, s_pth;
+    __shared__ int32_t s_th, s_pth, s_hist;
     if (threadIdx.x == 0) {
         int32_t bh, bw, n, th, pth, wth;
-        frame_thresholds(best, nact, T, bm, bh, bw, n, th, pth, wth);
+        s_hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth) ? 1 : 0;
         s_th = th; s_pth = pth;
     }
     __syncthreads();
+    if (blockIdx.x == 0 && s_hist)                      /* the bins were consumed by k_dec_hist_sort */
+        for (int32_t i = threadIdx.x; i < NBIN; i += DBLOCK) hbin[i] = 0;
     const int32_t v = blockIdx.x * DBLOCK + threadIdx.x;
     if (v >= N) return;
     key[v] = 0ull;
@@ -214,7 +370,7 @@ k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
  * list in the reference's order, (b) compact the word exits in active-list order; then the
  * LAST workgroup to arrive (agent-scope release by every workgroup, acquire by the last)
  * assembles the frame record for the host and resets the per-frame accumulators.
- * record = [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] | exits
+ * record = [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] | n_next x T | exits
  */
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_dec_finish(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
@@ -224,17 +380,17 @@ k_dec_finish(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__r
              const int32_t *__restrict__ outs, const int32_t *__restrict__ outh,
              int32_t *turn, int32_t *selfemit, int32_t *cnt, int32_t *nxt, int32_t *nnxt,
              int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
-             int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits)
+             int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits, const int32_t *hbin)
 {
     __shared__ int32_t total, s_wth, s_last;
     __shared__ int32_t s_thr[8];
     const int32_t t = blockIdx.x, b = node_base[t], na = nact[t], nf = cf + 1;
     if (threadIdx.x == 0) {
         int32_t bh, bw, n, th, pth, wth;
-        frame_thresholds(best, nact, T, bm, bh, bw, n, th, pth, wth);
+        const bool hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
         s_wth = wth;
         s_thr[0] = th; s_thr[1] = pth; s_thr[2] = wth; s_thr[3] = bh; s_thr[4] = bw; s_thr[5] = n;
-        s_thr[6] = (n > bm.maxhmmpf + (bm.maxhmmpf >> 1)) ? 1 : 0;
+        s_thr[6] = hist ? 1 : 0;
         s_thr[7] = (pth < th) ? 1 : 0;      /* see s3a_decoder_search: unsupported beam geometry */
     }
     __syncthreads();
@@ -293,13 +449,14 @@ k_dec_finish(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__r
     __syncthreads();
     if (!s_last) return;
 
-    const int32_t hdr = 5 * T + 16;
-    volatile const int32_t *vbest = best, *vnexit = nexit, *vex = exits, *vmisc = misc;
+    const int32_t hdr = 6 * T + 16;
+    volatile const int32_t *vbest = best, *vnexit = nexit, *vex = exits, *vmisc = misc, *vnnxt = nnxt;
     for (int32_t i = threadIdx.x; i < 2 * T; i += SCAN_THREADS) pack[i] = vbest[i];
     for (int32_t i = threadIdx.x; i < T; i += SCAN_THREADS) {
         pack[2 * T + i] = nact[i];
         pack[3 * T + 8 + i] = vnexit[i];
         pack[4 * T + 8 + i] = vnexit[T + i];
+        pack[5 * T + 16 + i] = vnnxt[i];
     }
     if (threadIdx.x < 8) {
         pack[3 * T + threadIdx.x] = s_thr[threadIdx.x];
@@ -421,6 +578,16 @@ k_dec_enter3_mark(int32_t n_ent_blocks, const int32_t *__restrict__ ent, int32_t
 /* ------------------------------------------------------------------ */
 /* host side                                                           */
 /* ------------------------------------------------------------------ */
+/* the fused frame orders scorer and search kernels by stream order only */
+static int32_t
+same_stream(const s3a_lexsearch_t *ls, const s3a_scorer_t *sc)
+{
+    if (ls->stream == sc->g->dev->stream) return S3A_OK;
+    s3a_set_error("s3a_decoder_*: the lexsearch and the scorer must share one stream "
+                  "(create the lexsearch with s3a_mgau_stream(g))");
+    return S3A_EINVAL;
+}
+
 static int32_t
 max_tree_nodes(const s3a_lexsearch_t *ls)
 {
@@ -430,13 +597,42 @@ max_tree_nodes(const s3a_lexsearch_t *ls)
     return m;
 }
 
+/* lextree_hmm_histbin (lextree.c:1314-1358) for ONE tree, as a stand-alone operation: adds the
+ * tree's HMMs to bin[0..nbin) and reorders its active list exactly as the reference does.
+ * (The fused frame runs the same kernels for all trees at once, see s3a_decoder_search.) */
+extern "C" int32_t
+s3a_lexsearch_hmm_histbin(s3a_lexsearch_t *ls, int32_t tree, int32_t bestscr, int32_t *bin,
+                          int32_t nbin, int32_t bw)
+{
+    if (!ls || !bin || tree < 0 || tree >= ls->n_tree || nbin <= 0 || nbin > NBIN || bw == 0) return S3A_EINVAL;
+    const int32_t T = ls->n_tree, maxn = max_tree_nodes(ls);
+    FrameBeams bm = { 0, 0, 0, 0, 0 };
+    std::vector<int32_t> h(nbin);
+    HIPCHK(hipMemsetAsync(ls->d_hbin, 0, NBIN * 4, ls->stream));
+    hipLaunchKernelGGL(k_dec_hist_count, dim3((maxn + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK), 0, ls->stream,
+                       ls->d_node_base, ls->d_act[ls->cur], ls->d_nact[ls->cur], T, bm, ls->d_best, ls->d_bests,
+                       ls->d_exit + ls->N, ls->d_hbin, tree, bestscr, bw, nbin);
+    hipLaunchKernelGGL(k_dec_hist_sort, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->d_node_base,
+                       ls->d_act[ls->cur], ls->d_nact[ls->cur], T, bm, ls->d_exit + ls->N, ls->d_exit, ls->d_hbin,
+                       ls->d_pos, tree, nbin);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h.data(), ls->d_hbin, (size_t)nbin * 4, hipMemcpyDeviceToHost, ls->stream));
+    HIPCHK(hipMemsetAsync(ls->d_hbin, 0, NBIN * 4, ls->stream));
+    HIPCHK(hipStreamSynchronize(ls->stream));
+    for (int32_t i = 0; i < nbin; i++) bin[i] += h[i];
+    return S3A_OK;
+}
+
 extern "C" int32_t
 s3a_decoder_utt_begin(s3a_lexsearch_t *ls, s3a_scorer_t *sc)
 {
     int32_t rc;
     if (!ls || !sc) return S3A_EINVAL;
+    if ((rc = same_stream(ls, sc)) != S3A_OK) return rc;
     if ((rc = s3a_scorer_utt_begin(sc)) != S3A_OK) return rc;
     if ((rc = s3a_scorer_reset_frame_state(sc)) != S3A_OK) return rc;
+    ls->last_nnxt = 0;
+    ls->hist_bound = 0;
     return S3A_OK;      /* d_best / d_done / key / first are left clean by reset, utt_end and k_dec_finish */
 }
 
@@ -454,10 +650,19 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                    int32_t *exit_score, int32_t *exit_hist, int32_t max_exits)
 {
     if (!ls || !sc || !cs || !res || !n_exit || !exit_wid || !exit_score || !exit_hist) return S3A_EINVAL;
-    const int32_t T = ls->n_tree, hdr = 5 * T + 16, maxn = max_tree_nodes(ls);
+    if (same_stream(ls, sc) != S3A_OK) return S3A_EINVAL;
+    const int32_t T = ls->n_tree, hdr = 6 * T + 16, maxn = max_tree_nodes(ls);
     const int cur = ls->cur, nxt = cur ^ 1;
     FrameBeams bm = { hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf };
     int32_t total = 0, t;
+    /* histogram pruning can only fire when the frame holds more than 1.5 x maxhmmpf HMMs; the host
+     * knows an upper bound (last frame's next list + the root entries it sent), so the two
+     * histogram kernels are only enqueued when that bound allows it */
+    const bool may_hist = ls->hist_bound > maxhmmpf + (maxhmmpf >> 1);
+    if (may_hist && -hmmbeam / NBIN == 0) {
+        s3a_set_error("s3a_decoder_search: -beam too narrow for histogram pruning (bin width 0)");
+        return S3A_EUNSUP;
+    }
 
     /* A parent that is cleared in this frame (bestscore < thres) must not propagate.  With the
      * phone threshold at or above the HMM threshold -- true for every sensible beam setting and
@@ -473,16 +678,25 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
                        ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
                        sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best);
+    if (may_hist) {
+        hipLaunchKernelGGL(k_dec_hist_count, dim3((maxn + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK), 0, ls->stream,
+                           ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], T, bm, ls->d_best, ls->d_bests,
+                           ls->d_exit + ls->N, ls->d_hbin, -1, 0, 1, NBIN);
+        hipLaunchKernelGGL(k_dec_hist_sort, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->d_node_base,
+                           ls->d_act[cur], ls->d_nact[cur], T, bm, ls->d_exit + ls->N, ls->d_exit, ls->d_hbin,
+                           ls->d_pos, -1, NBIN);
+    }
     hipLaunchKernelGGL(k_dec_resolve, dim3((ls->N + DBLOCK - 1) / DBLOCK), dim3(DBLOCK), 0, ls->stream,
                        ls->N, T, frm, bm, ls->d_best, ls->d_nact[cur], ls->d_node_base, ls->d_tree_of,
                        ls->d_prob, ls->d_par_off, ls->d_par, ls->d_pos, ls->d_posf, ls->d_sc, ls->d_hist,
                        ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame, ls->d_turn, ls->d_selfemit,
-                       ls->d_cnt, ls->d_key, ls->d_first);
+                       ls->d_cnt, ls->d_key, ls->d_first, ls->d_hbin);
     hipLaunchKernelGGL(k_dec_finish, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
                        ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_child_off, ls->d_child,
                        ls->d_wid, ls->d_prob, ls->d_outs, ls->d_outh, ls->d_turn, ls->d_selfemit,
                        ls->d_cnt, ls->d_act[nxt], ls->d_nact[nxt], ls->d_pos, ls->d_posf, ls->d_best,
-                       ls->d_exit, ls->d_nexit, sc->misc_d, ls->d_done, ls->d_pack, ls->pack_max_exits);
+                       ls->d_exit, ls->d_nexit, sc->misc_d, ls->d_done, ls->d_pack, ls->pack_max_exits,
+                       ls->d_hbin);
     HIPCHK(hipGetLastError());
     const int32_t first = 256;
     HIPCHK(hipMemcpyAsync(ls->h_pack, ls->d_pack, (size_t)(hdr + 3 * first) * 4, hipMemcpyDeviceToHost, ls->stream));
@@ -490,8 +704,14 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
     const int32_t *p = ls->h_pack;
     res->best_hmm = p[3 * T + 3]; res->best_word = p[3 * T + 4]; res->n_hmm = p[3 * T + 5];
     res->thres = p[3 * T + 0]; res->phone_thres = p[3 * T + 1]; res->word_thres = p[3 * T + 2];
-    res->need_histprune = p[3 * T + 6];
+    res->need_histprune = p[3 * T + 6];     /* informational: the histogram beam was applied */
     for (int i = 0; i < 8; i++) res->extra[i] = p[5 * T + 8 + i];
+    ls->last_nnxt = 0;
+    for (t = 0; t < T; t++) ls->last_nnxt += p[5 * T + 16 + t];
+    if (res->need_histprune && !may_hist) {
+        s3a_set_error("s3a_decoder_search: internal error, %d active HMMs exceed the host bound %d", res->n_hmm, ls->hist_bound);
+        return S3A_EINVAL;
+    }
     if (p[3 * T + 7]) {
         s3a_set_error("s3a_decoder_search: phone threshold below the HMM threshold in frame %d "
                       "(-ptranskip with a weak best word): not supported by the fused frame", frm);
@@ -535,6 +755,7 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
                        const int32_t *lc_b, const int32_t *scr_b, const int32_t *hist_b)
 {
     if (!ls || !sc || !cs || n_a < 0 || n_b < 0 || n_a + n_b > 4096) return S3A_EINVAL;
+    if (same_stream(ls, sc) != S3A_OK) return S3A_EINVAL;
     const int32_t T = ls->n_tree, maxn = max_tree_nodes(ls);
     const int nxt = ls->cur ^ 1;
     const size_t slot_words = (size_t)2 * 4096 + (size_t)2 * ls->ent_cap;
@@ -591,6 +812,7 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
                            cs->list_d, sc->act_d);
     }
     HIPCHK(hipGetLastError());
+    ls->hist_bound = ls->last_nnxt + n_ent;     /* >= the coming frame's active HMMs */
     ls->cur ^= 1;       /* lextree_active_swap; the new next-list counts are overwritten by k_dec_finish */
     return S3A_OK;
 }

@@ -597,10 +597,13 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
     DMALLOC(ls->d_thr, 8 * 4);
     DMALLOC(ls->d_done, 4 * 4);
     HIPCHK(hipMemset(ls->d_done, 0, 16));
+    DMALLOC(ls->d_hbin, 1024 * 4);
+    HIPCHK(hipMemset(ls->d_hbin, 0, 1024 * 4));
+    ls->hist_bound = ls->last_nnxt = 1 << 30;
     HIPCHK(hipMemset(ls->d_key, 0, (size_t)N * 8));
     ls->pack_max_exits = 2048;
-    DMALLOC(ls->d_pack, (size_t)(5 * n_tree + 16 + 3 * ls->pack_max_exits) * 4);
-    HIPCHK(hipHostMalloc((void **)&ls->h_pack, (size_t)(5 * n_tree + 16 + 3 * ls->pack_max_exits) * 4));
+    DMALLOC(ls->d_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4);
+    HIPCHK(hipHostMalloc((void **)&ls->h_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4));
     HIPCHK(hipHostMalloc((void **)&ls->h_ring, (size_t)8 * (2 * 4096 + 2 * ls->ent_cap) * 4));
     return S3A_OK;
 }
@@ -661,7 +664,7 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
         &ls->d_frame, &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
-        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_tree_of, &ls->d_done };
+        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_tree_of, &ls->d_done, &ls->d_hbin };
     for (auto p : ptrs) (void)hipFree(*p);
     (void)hipFree(ls->d_comp); (void)hipFree(ls->d_sseq); (void)hipFree(ls->d_comsseq);
     (void)hipFree(ls->d_comstate); (void)hipFree(ls->d_key);
@@ -686,8 +689,9 @@ s3a_lexsearch_reset(s3a_lexsearch_t *ls)
         || (rc = fill(ls, ls->d_nact[0], 0, ls->n_tree)) || (rc = fill(ls, ls->d_nact[1], 0, ls->n_tree))
         || (rc = fill(ls, ls->d_nexit, 0, 2 * ls->n_tree))
         || (rc = fill(ls, ls->d_best, INT_MIN, 2 * ls->n_tree)) || (rc = fill(ls, ls->d_first, INT_MAX, N))
-        || (rc = fill(ls, ls->d_done, 0, 4)))
+        || (rc = fill(ls, ls->d_done, 0, 4)) || (rc = fill(ls, ls->d_hbin, 0, 1024)))
         return rc;
+    ls->hist_bound = ls->last_nnxt = 1 << 30;
     HIPCHK(hipMemsetAsync(ls->d_key, 0, (size_t)N * 8, ls->stream));
     ls->cur = 0;
     return S3A_OK;
@@ -807,6 +811,7 @@ s3a_lexsearch_enter(s3a_lexsearch_t *ls, int32_t tree, int32_t n_calls, const in
 {
     if (!ls || tree < 0 || tree >= ls->n_tree || n_calls < 0 || n_calls > 4096) return S3A_EINVAL;
     if (n_calls == 0) return S3A_OK;
+    ls->hist_bound = ls->last_nnxt = 1 << 30;   /* step-by-step use: the fused frame can no longer bound the list */
     const int nxt = ls->cur ^ 1;
     std::vector<int32_t> calls((size_t)2 * n_calls), ent;
     /* host copy of the tree's root lists is implicit: entries are (node, call) pairs

@@ -74,6 +74,8 @@ struct s3a_lexsearch_s {
     int32_t *d_thr;                     /* [8] thresholds + frame statistics */
     int32_t *d_tree_of;                 /* [N] tree index of every node */
     int32_t *d_done;                    /* workgroup completion counter of the fused finishing kernel */
+    int32_t *d_hbin;                    /* [1000] lextree_hmm_histbin bins | [1000] = the histogram beam */
+    int32_t hist_bound, last_nnxt;      /* host upper bound on the coming frame's active HMMs */
     int32_t *d_pack, *h_pack;           /* per-frame result record (device / pinned host) */
     int32_t pack_max_exits;
     int32_t *h_ring;                    /* pinned staging ring for enter calls */

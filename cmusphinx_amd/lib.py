@@ -106,6 +106,7 @@ _SIGS = {
     "s3a_approx_cont_mgau_frame_eval_async": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_scorer_misc_dev": (C.c_void_p, [C.c_void_p]),
     "s3a_decoder_utt_begin": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "s3a_lexsearch_hmm_histbin": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "s3a_decoder_score": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_decoder_search": (C.c_int32, [C.c_void_p] * 3 + [C.c_int32] * 6 + [C.c_void_p] * 5 + [C.c_int32]),
     "s3a_decoder_transition": (C.c_int32, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 3 +
@@ -312,6 +313,10 @@ class MgauModel:
         check(self.L.s3a_mgau_get_params(self.h, _p(mean), _p(prec), _p(lrd), _p(mixw), _p(n_comp)))
         return dict(mean=mean, prec=prec, lrd=lrd, mixw=mixw, n_comp=n_comp,
                     distfloor=self.L.s3a_mgau_distfloor(self.h))
+
+    def stream(self):
+        """The HIP stream this model's kernels run on (hand it to LexSearch for the fused frame)."""
+        return self.L.s3a_mgau_stream(self.h)
 
     def set_precision(self, mode):
         check(self.L.s3a_mgau_set_precision(self.h, mode))
@@ -668,3 +673,40 @@ class LexSearch:
 
     def utt_end(self):
         check(self.L.s3a_lexsearch_utt_end(self.h))
+
+    def histbin(self, t, bestscr, bins, bw):
+        """lextree_hmm_histbin on tree t: adds to bins (int32 array) in place, reorders the active list."""
+        assert bins.dtype == np.int32 and bins.flags.c_contiguous
+        check(self.L.s3a_lexsearch_hmm_histbin(self.h, int(t), int(bestscr), _p(bins), len(bins), int(bw)))
+
+    # ---- the fused frame (s3a_decoder_*): scorer + composite table + lextrees together ----
+    def decoder_utt_begin(self, sc: "Scorer"):
+        check(self.L.s3a_decoder_utt_begin(self.h, sc.h))
+
+    def decoder_score(self, sc: "Scorer", feat, frame):
+        feat = np.ascontiguousarray(feat, np.float32)
+        check(self.L.s3a_decoder_score(sc.h, _p(feat), int(frame)))
+
+    def decoder_search(self, sc: "Scorer", cs: "ComSen", frm, hmmbeam, pbeam, wbeam, phone_uses_wbeam=0,
+                       maxhmmpf=20000):
+        res = FrameResult()
+        cap = self.T * self.max_node
+        n = np.zeros(self.T, np.int32)
+        w = np.zeros(cap, np.int32); s = np.zeros(cap, np.int32); h = np.zeros(cap, np.int32)
+        check(self.L.s3a_decoder_search(self.h, sc.h, cs.h, int(frm), int(hmmbeam), int(pbeam), int(wbeam),
+                                        int(phone_uses_wbeam), int(maxhmmpf), C.byref(res), _p(n), _p(w),
+                                        _p(s), _p(h), cap))
+        off = np.concatenate([[0], np.cumsum(n)])
+        return res, [(w[off[t]:off[t + 1]], s[off[t]:off[t + 1]], h[off[t]:off[t + 1]]) for t in range(self.T)]
+
+    def decoder_transition(self, sc: "Scorer", cs: "ComSen", cf, thresh, a=None, b=None):
+        """a, b = (tree, lc[], scr[], hist[]) or None: this frame's lextree_enter calls; then swap."""
+        def unpack(g):
+            if g is None:
+                z = np.zeros(0, np.int32)
+                return 0, z, z, z
+            return int(g[0]), *(np.ascontiguousarray(x, np.int32) for x in g[1:])
+        ta, la, sa, ha = unpack(a)
+        tb, lb, sb, hb = unpack(b)
+        check(self.L.s3a_decoder_transition(self.h, sc.h, cs.h, int(cf), int(thresh), ta, len(la), _p(la), _p(sa),
+                                            _p(ha), tb, len(lb), _p(lb), _p(sb), _p(hb)))

@@ -373,6 +373,14 @@ int32_t s3a_lexsearch_frame_search(s3a_lexsearch_t *ls, const int32_t *senscr_de
  *                           utterance begin with cf = -1), also when there is nothing to enter.
  */
 int32_t s3a_decoder_utt_begin(s3a_lexsearch_t *ls, s3a_scorer_t *sc);
+/* lextree_hmm_histbin (lextree.c:1314-1358) for one tree: bin[k] += #HMMs with
+ * (bestscr - hmm.bestscore) / bw == k (last bin collects the rest; nbin <= 1000), and the
+ * tree's active list is REORDERED bin by bin, within a bin in reverse list order, exactly as
+ * the reference's glist rebuild does.  s3a_decoder_search applies the same operation to all
+ * trees, followed by the bin scan of srch_time_switch_tree.c:870-892, whenever a frame holds
+ * more than 1.5 x maxhmmpf HMMs; res->need_histprune reports that it did. */
+int32_t s3a_lexsearch_hmm_histbin(s3a_lexsearch_t *ls, int32_t tree, int32_t bestscr, int32_t *bin,
+                                  int32_t nbin, int32_t bw);
 int32_t s3a_decoder_score(s3a_scorer_t *sc, const float *feat, int32_t frame);
 int32_t s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int32_t frm,
                            int32_t hmmbeam, int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam,

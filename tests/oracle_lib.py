@@ -278,6 +278,36 @@ class OracleMgau:
                     beams=np.array([fg.ci_pbeam, fg.dyn_ci_pbeam], np.int32))
 
 
+class OracleFrameScorer:
+    """One frame at a time through s3o_approx_cont_mgau_ci_eval + _frame_eval (what the slots
+    gmm_compute_lv1 / lv2 do with -pl_window 1), keeping ascr_t.senscr between frames."""
+
+    def __init__(self, g: "OracleMgau", cd2cisen, n_ci_sen, ci_pbeam, ds=1, tighten=0.5, max_cd=100000):
+        self.g = g
+        self.cd2cisen = np.ascontiguousarray(cd2cisen, np.int16)
+        self.n_ci = int(n_ci_sen)
+        self.fg = FastGmm(ds, 0, int(ci_pbeam), int(max_cd), float(tighten), 0, 0)
+        self.senscr = np.zeros(g.S, np.int32)
+        self.ci = np.zeros(max(self.n_ci, 1), np.int32)
+        self.rsa = np.zeros(g.S, np.uint8)
+        g.reset_state()
+
+    def step(self, feat, t, sen_active):
+        """sen_active (uint8[S]) is updated in place (CI senones forced on), like the reference.
+        Returns (best, n_cd_sen, n_cd_gau, n_ci_sen, n_ci_gau, ci_best)."""
+        g, L = self.g, self.g.L
+        x = np.ascontiguousarray(feat, np.float32)
+        xp = _ptr(x, C.c_float)
+        b = C.c_int32(0)
+        L.s3o_approx_cont_mgau_ci_eval(g.p, _ptr(self.cd2cisen, C.c_int16), g.S, xp, _ptr(self.ci, C.c_int32),
+                                       C.byref(b), t)
+        cin, cig = g.p.contents.frm_ci_sen_eval, g.p.contents.frm_ci_gau_eval
+        best = L.s3o_approx_cont_mgau_frame_eval(g.p, C.byref(self.fg), _ptr(self.cd2cisen, C.c_int16), self.n_ci,
+                                                 _ptr(sen_active, C.c_uint8), _ptr(self.rsa, C.c_uint8),
+                                                 _ptr(self.senscr, C.c_int32), xp, t, _ptr(self.ci, C.c_int32))
+        return best, g.p.contents.frm_sen_eval, g.p.contents.frm_gau_eval, cin, cig, b.value
+
+
 def tmat_logs3(tp, lm: OracleLogMath, tpfloor=1e-4):
     tp = np.ascontiguousarray(tp, dtype=np.float32)
     out = np.zeros(tp.shape, np.int32)
@@ -437,6 +467,11 @@ class OracleLexSearch:
         out[:, 6] = raw["out_score"]; out[:, 7] = raw["out_history"]
         out[:, 8] = raw["bestscore"]; out[:, 9] = raw["frame"]
         return out
+
+    def histbin(self, t, bestscr, bins, bw):
+        """lextree_hmm_histbin on tree t: bins (int32) updated in place, active list reordered."""
+        assert bins.dtype == np.int32
+        self.L.s3o_lextree_hmm_histbin(self.lt[t], int(bestscr), _p2(bins), len(bins), int(bw))
 
     def sen_active(self):
         tr = self.tr

@@ -93,6 +93,25 @@ def test_full_device_search_matches_reference(name, tmp_path):
     assert open(seg).read() == open(os.path.join(D, f"ref_{name}.matchseg")).read()
 
 
+@pytest.mark.skipif(not (os.path.exists(TST) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
+def test_full_device_search_with_histogram_pruning(tmp_path):
+    """-maxhmmpf 20: most frames exceed 1.5 x the cap, so lextree_hmm_histbin (bins, beam from the
+    bin scan AND the reordering of the active lists) runs on the device; expected output is
+    produced live by the unmodified reference."""
+    extra = RUNS["mode4_trigram"] + ["-maxhmmpf", "20"]
+    ref_hyp, ref_seg, _ = run(REFDEC, extra, tmp_path, "cpu_hist")
+    hyp, seg, log = (str(tmp_path / f"tst_hist.{e}") for e in ("match", "matchseg", "log"))
+    with open(log, "w") as lf:
+        p = subprocess.run([TST] + common() + extra + ["-hyp", hyp, "-hypseg", seg],
+                           stdout=lf, stderr=subprocess.STDOUT, timeout=900)
+    tail = [l for l in open(log, errors="ignore").read().splitlines() if "tst shim" in l or "FATAL" in l]
+    assert p.returncode == 0, "\n".join(tail[-10:])
+    n = [int(l.split("applied in")[1].split()[0]) for l in tail if "histogram pruning" in l]
+    assert n and n[0] > 500, tail
+    assert open(hyp).read() == ref_hyp
+    assert open(seg).read() == ref_seg
+
+
 # ---------------------------------------------------------------------------
 # RM1 (1935 senones, 6136-node lextrees with multi-parent first-level nodes, 997-word
 # trigram): data is NOT committed (8 MB of third-party model files); tools/
@@ -103,8 +122,8 @@ def test_full_device_search_matches_reference(name, tmp_path):
 RM = os.path.join(ROOT, "tests", "_local_data", "rm1")
 
 
-def rm_args():
-    return ["-mdef", f"{RM}/mdef", "-fdict", f"{RM}/fillerdict", "-dict", f"{RM}/RM.dictionary",
+def rm_args(extra=()):
+    return list(extra) + ["-mdef", f"{RM}/mdef", "-fdict", f"{RM}/fillerdict", "-dict", f"{RM}/RM.dictionary",
             "-mean", f"{RM}/means", "-var", f"{RM}/variances", "-mixw", f"{RM}/mixture_weights",
             "-tmat", f"{RM}/transition_matrices", "-agc", "none", "-varnorm", "no", "-cmn", "current",
             "-epl", "4", "-fillprob", "0.02", "-maxwpf", "10", "-wip", "0.2",
@@ -114,19 +133,24 @@ def rm_args():
 
 @pytest.mark.skipif(not (os.path.exists(TST) and os.path.exists(REFDEC) and os.path.isdir(RM)),
                     reason="RM1 local data or oracle/_ref binaries absent (tools/fetch_local_data.sh)")
-@pytest.mark.parametrize("binary", ["scoring_only", "full_device"])
+@pytest.mark.parametrize("binary", ["scoring_only", "full_device", "full_device_histprune"])
 def test_rm1_identical_to_live_reference(binary, tmp_path):
     exe = SHIM if binary == "scoring_only" else TST
+    extra = ["-maxhmmpf", "800"] if binary == "full_device_histprune" else []
     out = {}
     for tag, b in (("ref", REFDEC), ("gpu", exe)):
         hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
         with open(log, "w") as lf:
-            p = subprocess.run([b] + rm_args() + ["-hyp", hyp, "-hypseg", seg], stdout=lf,
+            p = subprocess.run([b] + rm_args(extra) + ["-hyp", hyp, "-hypseg", seg], stdout=lf,
                                stderr=subprocess.STDOUT, timeout=1800)
         tail = [l for l in open(log, errors="ignore").read().splitlines()
                 if l.startswith(("FATAL", "INFO: ref_", "INFO: stat.c")) and ("shim" in l or "SUMMARY" in l or "FATAL" in l)]
         assert p.returncode == 0, "\n".join(tail[-10:])
         out[tag] = (open(hyp).read(), open(seg).read())
+        if tag == "gpu" and extra:
+            n = [int(l.split("applied in")[1].split()[0]) for l in open(log, errors="ignore").read().splitlines()
+                 if l.startswith("INFO: ref_") and "histogram pruning" in l]
+            assert n and n[0] > 1000, n
         print("\n".join(t[:220] for t in tail[-3:]))
     assert out["gpu"][0] == out["ref"][0]
     assert out["gpu"][1] == out["ref"][1]

@@ -19,10 +19,11 @@ def load():
     return lextree_trace.from_npz(np.load(os.path.join(GOLDEN, "lextree_trace_tidigits.npz")))
 
 
-def make_gpu(gpu_lib, tr):
+def make_gpu(gpu_lib, tr, stream=None):
     ne = tr["n_emit"]
     tm = gpu_lib.Tmat.init_logs3(np.asarray(tr["tp"], np.int32).reshape(tr["n_tmat"], ne, ne + 1))
-    return gpu_lib.LexSearch(tr["trees"], tm, tr["sseq"], tr["comsseq"], tr["comstate_off"], tr["comstate"], tr["n_sen"])
+    return gpu_lib.LexSearch(tr["trees"], tm, tr["sseq"], tr["comsseq"], tr["comstate_off"], tr["comstate"],
+                             tr["n_sen"], stream=stream)
 
 
 def test_gpu_replays_the_recorded_trace(gpu_lib):
@@ -38,9 +39,9 @@ class Lockstep:
     def __init__(self, a, b, T):
         self.a, self.b, self.T = a, b, T
 
-    def same(self, label):
+    def same(self, label, lists=(0, 1)):
         for t in range(self.T):
-            for which in (0, 1):
+            for which in lists:
                 assert np.array_equal(self.a.active(t, which), self.b.active(t, which)), (label, t, which)
             assert np.array_equal(self.a.state(t), self.b.state(t)), (label, t)
 
@@ -161,3 +162,132 @@ def test_fused_frame_search_equals_stepwise(gpu_lib):
         ls.same(("fused", frm))
         for x in (a, b):
             x.enter(frm % 4, [frm % 9], [bh - 5000], [frm], frm, bh + hmmbeam); x.swap()
+
+
+def test_histbin_lockstep_with_oracle(gpu_lib):
+    """lextree_hmm_histbin: same bins and the same REORDERED active lists (bins ascending, reverse
+    list order inside a bin), on lists long enough to span several 1024-element passes."""
+    rng = np.random.default_rng(21)
+    tr = synth_forest(rng, n_tree=3, n_node=5000)
+    a, b = O.OracleLexSearch(tr), make_gpu(gpu_lib, tr)
+    ls = Lockstep(a, b, tr["n_tree"])
+    for x in (a, b):
+        for t in range(3):
+            x.enter(t, list(range(9)), [0] * 9, list(range(9)), -1, -10**9)
+        x.swap()
+    for frm in range(16):
+        senscr = (-rng.integers(0, 3000, tr["n_sen"]) * 16).astype(np.int32)      # many equal scores
+        comsen = (-rng.integers(0, 3000, tr["n_comstate"]) * 16).astype(np.int32)
+        ra, rb = a.hmm_eval(senscr, comsen, frm), b.hmm_eval(senscr, comsen, frm)
+        best = int(ra[0].max())
+        for nbin, bw in ((1000, 97), (1000, 5000), (37, 1500)):
+            ba, bb = np.zeros(nbin, np.int32), np.zeros(nbin, np.int32)
+            for t in range(3):
+                a.histbin(t, best, ba, bw); b.histbin(t, best, bb, bw)
+            assert np.array_equal(ba, bb) and ba.sum() == ra[2].sum(), (frm, nbin, bw)
+            ls.same(("histbin", frm, nbin, bw))
+        a.propagate(frm, best - 10**7, best - 10**7, best - 10**7); b.propagate(frm, best - 10**7, best - 10**7, best - 10**7)
+        ls.same(("propagate", frm))
+        a.swap(); b.swap()
+    assert max(len(a.active(t, 0)) for t in range(3)) > 1500     # more than one 1024-element pass
+
+
+class OracleFrame:
+    """The reference's frame (srch_utt_decode_blk's body for mode 4) on the CPU oracle: active
+    senones -> CI + gated CD scoring -> composite senones -> HMM evaluation -> beams (with
+    histogram pruning, srch_time_switch_tree.c:849-905) -> propagation -> word exits."""
+
+    def __init__(self, tr, om, cd2cisen, n_ci, ci_pbeam, comwt):
+        self.tr, self.lex = tr, O.OracleLexSearch(tr)
+        self.fs = O.OracleFrameScorer(om, cd2cisen, n_ci, ci_pbeam)
+        self.comwt = comwt
+
+    def frame(self, feat, frm, hmmbeam, pbeam, wbeam, maxhmmpf):
+        tr, lex = self.tr, self.lex
+        sa = lex.sen_active()
+        best, ns, ng, cin, cig, cib = self.fs.step(feat, frm, sa)
+        comsen = O.comsenscr(tr["comstate_off"], tr["comstate"], self.comwt, self.fs.senscr)
+        b, w, n = lex.hmm_eval(self.fs.senscr, comsen, frm)
+        bh, bw_, nh = int(b.max()), int(w.max()), int(n.sum())
+        hb, pb, wb, hist = hmmbeam, pbeam, wbeam, False
+        if nh > maxhmmpf + (maxhmmpf >> 1):
+            hist = True
+            width = -hmmbeam // 1000
+            bins = np.zeros(1000, np.int32)
+            for t in range(lex.T):
+                lex.histbin(t, bh, bins, width)
+            i = j = 0
+            while i < 1000 and j < maxhmmpf:
+                i += 1
+                if i < 1000:
+                    j += int(bins[i])
+            hb = -(i * width); pb = max(hb, pbeam); wb = max(hb, wbeam)
+        w32 = lambda v: ((v + 2**31) % 2**32) - 2**31       # int32 wrap-around, as in the reference's C
+        th, pth, wth = w32(bh + hb), w32(bh + pb), w32(bw_ + wb)
+        lex.propagate(frm, th, pth, wth)
+        return dict(best=best, counts=(ns, ng, cin, cig, cib), bh=bh, bw=bw_, n=nh, th=th, pth=pth, wth=wth,
+                    hist=hist, exits=lex.leaves(wth))
+
+
+@pytest.mark.parametrize("seed,maxhmmpf,ci_pbeam", [(5, 20000, 1e-80), (6, 150, 1e-80), (7, 400, 1e-12)])
+def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pbeam):
+    """The product path of a mode-4 frame -- s3a_decoder_score / _search / _transition -- against
+    the oracle's step-by-step frame on a synthetic forest WITH a synthetic acoustic model: raw
+    scores normalised inside the search kernels, inline composite senones, histogram pruning,
+    two-tree transitions, next-frame senone marks consumed by the gated scorer."""
+    from cmusphinx_amd import synth
+    rng = np.random.default_rng(seed)
+    tr = synth_forest(rng, n_tree=4, n_node=900, n_sen=600)
+    n_ci = 30
+    m = synth.make_model(600, n_ci, 4, 39, 5, 3, seed=seed + 100)
+    feats = synth.make_features(m, 45, seed=seed + 200)
+    comwt = -rng.integers(0, 3000, tr["n_comstate"]).astype(np.int32)
+    olm = O.OracleLogMath(1.0003)
+    om = O.OracleMgau(m["mean"], m["var"], m["mixw"], olm)
+    of = OracleFrame(tr, om, m["cd2cisen"], n_ci, olm.logs3(ci_pbeam), comwt)
+    glm = gpu_lib.LogMath(1.0003)
+    gm = gpu_lib.MgauModel.init_arrays(m["mean"], m["var"], m["mixw"], glm)
+    sc = gpu_lib.Scorer(gm, m["cd2cisen"], n_ci, ci_pbeam=ci_pbeam)
+    cs = gpu_lib.ComSen(tr["comstate_off"], tr["comstate"], comwt)
+    with pytest.raises(gpu_lib.S3AError, match="must share one stream"):
+        make_gpu(gpu_lib, tr).decoder_utt_begin(sc)
+    ls = make_gpu(gpu_lib, tr, stream=gm.stream())
+    lock = Lockstep(of.lex, ls, tr["n_tree"])
+    hmmbeam, pbeam, wbeam = -2600000, -2000000, -1500000
+
+    ls.decoder_utt_begin(sc)
+    first = (0, [0, 3, 4], [0, 0, -50], [7, 8, 9]), (2, [1], [0], [9])
+    for g in first:
+        of.lex.enter(g[0], g[1], g[2], g[3], -1, -10**9)
+    of.lex.swap()
+    ls.decoder_transition(sc, cs, -1, -10**9, *first)
+    # (the fused transition leaves the emptied next-list counter to be overwritten by the coming
+    # frame's search instead of zeroing it: compare the active lists and every HMM)
+    lock.same("begin", lists=(0,))
+    n_hist = 0
+    for frm in range(len(feats)):
+        o = of.frame(feats[frm], frm, hmmbeam, pbeam, wbeam, maxhmmpf)
+        ls.decoder_score(sc, feats[frm], frm)
+        res, exits = ls.decoder_search(sc, cs, frm, hmmbeam, pbeam, wbeam, 0, maxhmmpf)
+        assert (res.best_hmm, res.best_word, res.n_hmm) == (o["bh"], o["bw"], o["n"]), frm
+        assert (res.thres, res.phone_thres, res.word_thres) == (o["th"], o["pth"], o["wth"]), frm
+        assert bool(res.need_histprune) == o["hist"], frm
+        ns, ng, cin, cig, cib = o["counts"]
+        assert tuple(res.extra[1:7]) == (ns, ng, cin, cig, cib, o["best"]), (frm, list(res.extra), o["counts"], o["best"])
+        for t in range(tr["n_tree"]):
+            assert all(np.array_equal(u, v) for u, v in zip(o["exits"][t], exits[t])), (frm, t)
+        n_hist += o["hist"]
+        # word transitions: a unigram-tree batch (sometimes empty) and a filler-tree call
+        k = frm % 2
+        n = int(rng.integers(0, 5))
+        ga = (k, rng.choice(9, n, replace=False), (o["bh"] - rng.integers(0, 900000, n)).astype(np.int32),
+              rng.integers(0, 10**6, n).astype(np.int32)) if n else None
+        gb = (2 + k, [int(rng.integers(0, 9))], [o["bh"] - 1000], [frm]) if frm % 3 else None
+        for g in (ga, gb):
+            if g is not None:
+                of.lex.enter(g[0], g[1], g[2], g[3], frm, o["bh"] + hmmbeam)
+        of.lex.swap()
+        ls.decoder_transition(sc, cs, frm, o["bh"] + hmmbeam, ga, gb)
+        lock.same(("frame", frm), lists=(0,))
+    assert o["n"] > 50
+    assert (n_hist > 10) == (maxhmmpf < 1000)
