@@ -27,6 +27,8 @@ Prints ONE JSON line (rank 0).  Extra keys beyond the driver contract:
   frame_sync    the same kernel launched one frame at a time (the decoder's
                 frame-synchronous regime, B=1): per-launch time and the
                 algorithmic-bytes/s figure the north star's 60% target refers to
+  full_decode   (N=1) configs[2] shape: whole mode-4 decode of a synthetic hub4 task through the
+                drop-in vs the unmodified CPU reference, outputs byte-identical, xRT of both
   cpu_baseline  the UNMODIFIED reference (oracle/_ref/ref_dump bench_mgau ->
                 approx_cont_mgau_frame_eval) timed on this box's host cores
 """
@@ -89,6 +91,50 @@ def cpu_baseline(model, feats, sample_frames, procs):
             "sample": f"{n} frames of the same hub4-shaped workload per process; {what}"}
 
 
+def full_decode(n_utt=4, n_frames=600, streams=(1, 4)):
+    """configs[2]-shaped extra leg: the whole mode-4 decode (GMM scoring + lextree Viterbi + trigram LM)
+    of a synthetic hub4-shaped task through the drop-in (the reference decoder with its srch_funcs_t
+    slots re-pointed at the C ABI, oracle/_ref/ref_s3amd_tst_decode) next to the unmodified CPU
+    reference on the same files; outputs must be byte-identical.  Skipped when the binaries that
+    bind the reference are absent (they are built where /root/reference exists)."""
+    import re
+    from cmusphinx_amd import synth_task
+    ref = os.path.join(ROOT, "oracle", "_ref", "sphinx3_decode")
+    shim = os.path.join(ROOT, "oracle", "_ref", "ref_s3amd_tst_decode")
+    if not (os.path.exists(ref) and os.path.exists(shim)):
+        return {"skipped": "oracle/_ref binaries absent"}
+    d = tempfile.mkdtemp(prefix="s3a_task_")
+    task = synth_task.make_task(d, n_utt=n_utt, n_frames=n_frames, **synth_task.HUB4_TASK)
+
+    def run(exe, tag, env=None):
+        log = os.path.join(d, tag + ".log")
+        with open(log, "w") as lf:
+            rc = subprocess.run([exe] + task["args"] + ["-hyp", f"{d}/{tag}.match", "-hypseg", f"{d}/{tag}.seg"],
+                                stdout=lf, stderr=subprocess.STDOUT, env=dict(os.environ, **(env or {}))).returncode
+        return rc, open(log, errors="ignore").read()
+
+    rc, log = run(ref, "ref")
+    m = re.search(r"SUMMARY:\s+(\d+) fr;.*?(\d+) hmm/fr.*tot:\s+([0-9.]+) xCPU", log)
+    if rc != 0 or not m:
+        return {"skipped": "reference decoder failed on the synthetic task"}
+    frames, hmm_fr, xcpu = int(m.group(1)), int(m.group(2)), float(m.group(3))
+    out = {"workload": "configs[2] shape: synthetic hub4 task (6144 senones x 8, 20000-word lextrees, ARPA trigram), "
+                       f"{n_utt} utterances, mode 4, reference's hub4 beams (-beam 1e-60 -wbeam 1e-35)",
+           "frames": frames, "active_hmm_per_frame": hmm_fr,
+           "cpu_reference": {"xRT_1core": round(1.0 / max(xcpu, 1e-9), 1), "kind": "reference",
+                             "note": "unmodified sphinx3_decode, stat.c SUMMARY tot xCPU"}}
+    same = True
+    for n in streams:
+        rc, log = run(shim, f"s{n}", {"S3A_STREAMS": str(n)})
+        t = re.search(r"decode-only ([0-9.]+) s = (\d+) x real time aggregate", log)
+        ok = rc == 0 and t and all(open(f"{d}/s{n}.{e}").read() == open(f"{d}/ref.{e}").read() for e in ("match", "seg"))
+        same = same and bool(ok)
+        if t:
+            out[f"gpu_{n}_stream"] = {"decode_s": float(t.group(1)), "xRT": round(frames / 100.0 / float(t.group(1)), 1)}
+    out["identical_to_reference"] = same
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,6 +143,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1000, help="frames per utterance (10 s)")
     ap.add_argument("--cpu-frames", type=int, default=3000, help="CPU-baseline sample per process")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the full-decode extra leg")
     ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
     args = ap.parse_args()
 
@@ -228,6 +275,8 @@ def main():
         if not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(model, feats[0], args.cpu_frames,
                                                procs=os.cpu_count() or 1)
+        if world == 1 and not args.no_decode:
+            res["full_decode"] = full_decode()
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

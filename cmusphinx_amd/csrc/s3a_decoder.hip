@@ -16,10 +16,12 @@
  *                            k_dec_resolve    lextree_hmm_propagate_non_leaves, phases mark +
  *                                             resolve in one pass over ALL nodes (no candidate
  *                                             list), beam thresholds recomputed per workgroup
- *                            k_dec_finish     per tree: ordered emission of the next list,
- *                                             ordered word exits; the last workgroup to finish
- *                                             packs the frame record and resets the per-frame
- *                                             accumulators
+ *                            [k_dec_hist_*    histogram pruning, only when the frame may exceed
+ *                                             1.5 x maxhmmpf HMMs]
+ *                            k_dec_scan       per tree: turn offsets of the next list, ordered
+ *                                             word exits; the last workgroup to finish packs the
+ *                                             frame record and resets the per-frame accumulators
+ *                            k_dec_emit       ordered emission of the next list, wave-parallel
  *                            D2H record + the frame's ONE synchronisation
  *   s3a_decoder_transition   H2D calls | k_dec_enter1 | k_dec_enter2 | k_dec_enter3_mark
  *                            (lextree_enter for the unigram AND the filler tree of the
@@ -366,21 +368,30 @@ k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
 
 /* ------------------------------------------------------------------ */
 /*
- * One workgroup per tree: (a) prefix-sum the per-turn counts and write the next active
- * list in the reference's order, (b) compact the word exits in active-list order; then the
- * LAST workgroup to arrive (agent-scope release by every workgroup, acquire by the last)
- * assembles the frame record for the host and resets the per-frame accumulators.
+ * The ordered emission of the next active list, in two kernels.
+ *
+ * k_dec_scan, one workgroup per tree: prefix-sums the per-turn counts (base[i] = where the
+ * nodes emitted during the turn of active-list position i start in the next list), writes the
+ * self-emitted nodes, and compacts the word exits in active-list order; the LAST workgroup to
+ * finish (agent-scope release by every workgroup, acquire by the last) assembles the frame
+ * record for the host and resets the per-frame accumulators.
+ *
+ * k_dec_emit, a fixed grid of waves sweeping the active list: the children a parent put on the
+ * list during its turn follow in child-list order; a lane per list position finds the few
+ * turns that attributed children, then the whole wave walks such a parent's child list 64
+ * links at a time and ranks the attributed children with a ballot.  (A lextree root has
+ * hundreds of children -- 341 in the 20 k-word task -- and a one-thread walk of such a list,
+ * one dependent HBM access per link, cost 600 us per frame.)
  * record = [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] | n_next x T | exits
  */
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_dec_finish(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
-             const int32_t *__restrict__ act, const int32_t *__restrict__ nact,
-             const int32_t *__restrict__ child_off, const int32_t *__restrict__ child,
-             const int32_t *__restrict__ wid, const int32_t *__restrict__ prob,
-             const int32_t *__restrict__ outs, const int32_t *__restrict__ outh,
-             int32_t *turn, int32_t *selfemit, int32_t *cnt, int32_t *nxt, int32_t *nnxt,
-             int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
-             int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits, const int32_t *hbin)
+k_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
+           const int32_t *__restrict__ act, const int32_t *__restrict__ nact,
+           const int32_t *__restrict__ wid, const int32_t *__restrict__ prob,
+           const int32_t *__restrict__ outs, const int32_t *__restrict__ outh,
+           const int32_t *__restrict__ selfemit, int32_t *cnt, int32_t *base, int32_t *nxt, int32_t *nnxt,
+           int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
+           const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits)
 {
     __shared__ int32_t total, s_wth, s_last;
     __shared__ int32_t s_thr[8];
@@ -394,25 +405,15 @@ k_dec_finish(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__r
         s_thr[7] = (pth < th) ? 1 : 0;      /* see s3a_decoder_search: unsupported beam geometry */
     }
     __syncthreads();
-    /* (a) next active list */
-    block_exclusive_scan(cnt + b, na, &total);
+    /* (a) turn bases + the self-emitted nodes */
+    block_exclusive_scan_to(cnt + b, base + b, na, &total);
     __syncthreads();
     for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
-        const int32_t u = act[b + i];
-        int32_t k = cnt[b + i];
         if (selfemit[b + i]) {
-            nxt[b + k] = u; pos[u] = k; posf[u] = nf; k++;
-            selfemit[b + i] = 0;
-        }
-        for (int32_t j = child_off[u]; j < child_off[u + 1]; j++) {
-            const int32_t c = child[j];
-            if (turn[c] == i) {
-                nxt[b + k] = c; pos[c] = k; posf[c] = nf; k++;
-                turn[c] = -1;
-            }
+            const int32_t u = act[b + i], k = base[b + i];
+            nxt[b + k] = u; pos[u] = k; posf[u] = nf;
         }
     }
-    __syncthreads();
     if (threadIdx.x == 0) nnxt[t] = total;
     __syncthreads();
     /* (b) word exits, in active-list order */
@@ -451,12 +452,12 @@ k_dec_finish(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__r
 
     const int32_t hdr = 6 * T + 16;
     volatile const int32_t *vbest = best, *vnexit = nexit, *vex = exits, *vmisc = misc, *vnnxt = nnxt;
-    for (int32_t i = threadIdx.x; i < 2 * T; i += SCAN_THREADS) pack[i] = vbest[i];
-    for (int32_t i = threadIdx.x; i < T; i += SCAN_THREADS) {
-        pack[2 * T + i] = nact[i];
-        pack[3 * T + 8 + i] = vnexit[i];
-        pack[4 * T + 8 + i] = vnexit[T + i];
-        pack[5 * T + 16 + i] = vnnxt[i];
+    for (int32_t q = threadIdx.x; q < 2 * T; q += SCAN_THREADS) pack[q] = vbest[q];
+    for (int32_t q = threadIdx.x; q < T; q += SCAN_THREADS) {
+        pack[2 * T + q] = nact[q];
+        pack[3 * T + 8 + q] = vnexit[q];
+        pack[4 * T + 8 + q] = vnexit[T + q];
+        pack[5 * T + 16 + q] = vnnxt[q];
     }
     if (threadIdx.x < 8) {
         pack[3 * T + threadIdx.x] = s_thr[threadIdx.x];
@@ -467,42 +468,104 @@ k_dec_finish(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__r
     int32_t off = 0;
     for (int32_t tt = 0; tt < T; tt++) {
         const int32_t n = vnexit[tt], bb = node_base[tt];
-        for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
-            const int32_t k = off + i;
+        for (int32_t q = threadIdx.x; q < n; q += SCAN_THREADS) {
+            const int32_t k = off + q;
             if (k < max_exits) {
-                pack[hdr + 3 * k] = vex[bb + i];
-                pack[hdr + 3 * k + 1] = vex[N + bb + i];
-                pack[hdr + 3 * k + 2] = vex[2 * N + bb + i];
+                pack[hdr + 3 * k] = vex[bb + q];
+                pack[hdr + 3 * k + 1] = vex[N + bb + q];
+                pack[hdr + 3 * k + 2] = vex[2 * N + bb + q];
             }
         }
         off += n;
     }
     __syncthreads();
     /* reset the per-frame accumulators for the next frame */
-    for (int32_t i = threadIdx.x; i < 2 * T; i += SCAN_THREADS) { best[i] = INT_MIN; nexit[i] = 0; }
+    for (int32_t q = threadIdx.x; q < 2 * T; q += SCAN_THREADS) { best[q] = INT_MIN; nexit[q] = 0; }
     if (threadIdx.x < 8) misc[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 5) ? INT_MIN : 0;
     if (threadIdx.x == 0) *done = 0;
 }
 
+#define EMIT_WAVES (DBLOCK / 64)
+#define EMIT_BLOCKS 32          /* workgroups per tree: 128 waves, 8192 list positions per sweep */
+__global__ void __launch_bounds__(DBLOCK)
+k_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
+           const int32_t *__restrict__ nact, const int32_t *__restrict__ child_off,
+           const int32_t *__restrict__ child, int32_t *turn, int32_t *selfemit,
+           const int32_t *__restrict__ base, int32_t *nxt, const int32_t *nnxt, int32_t *pos, int32_t *posf)
+{
+    const int32_t t = blockIdx.y, b = node_base[t], na = nact[t], nf = cf + 1, total = nnxt[t];
+    const int32_t lane = threadIdx.x & 63;
+    /* each wave sweeps 64 list positions at a time: a lane per position finds the (few) turns that
+     * attributed children, then the whole wave walks those parents' child lists */
+    for (int32_t i0 = (blockIdx.x * EMIT_WAVES + (threadIdx.x >> 6)) * 64; i0 < na; i0 += EMIT_BLOCKS * EMIT_WAVES * 64) {
+        const int32_t i = i0 + lane;
+        int32_t lo = 0, hi = 0;
+        if (i < na) {
+            lo = base[b + i];
+            hi = (i + 1 < na) ? base[b + i + 1] : total;
+            if (selfemit[b + i]) { selfemit[b + i] = 0; lo++; }
+        }
+        unsigned long long todo = __ballot(lo < hi);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            int32_t k = __shfl(lo, src, 64);
+            const int32_t kend = __shfl(hi, src, 64), ip = i0 + src, u = act[b + ip];
+            const int32_t c_lo = child_off[u], c_hi = child_off[u + 1];
+            for (int32_t j0 = c_lo; j0 < c_hi && k < kend; j0 += 64) {
+                const int32_t j = j0 + lane;
+                const int32_t c = (j < c_hi) ? child[j] : -1;
+                const bool mine = c >= 0 && turn[c] == ip;
+                const unsigned long long m = __ballot(mine);
+                if (mine) {
+                    const int32_t q = k + __popcll(m & ((1ull << lane) - 1ull));
+                    nxt[b + q] = c; pos[c] = q; posf[c] = nf;
+                    turn[c] = -1;
+                }
+                k += __popcll(m);
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* lextree_enter for up to two trees of one frame + next frame's senone marks */
-/* ent[e] = {node (global id), call}; calls[c] = {inscore, inhist}; groups: {tree, ent_lo, ent_hi} */
+/* calls[c] = {inscore, inhist, offset of the call's root list in rootlist[], first entry index};
+ * entry e of the frame = the (e - first)-th root of its call; groups: {tree, ent_lo, ent_hi}.
+ * (The root lists of a 20 k-word lextree hold ~2000 nodes per left context: expanding ~90 k
+ * entries on the host and copying them every frame cost more than the search itself.) */
+struct Entries {
+    const int32_t *calls, *rootlist;
+    int32_t n_calls;
+    __device__ __forceinline__ void locate(int32_t e, int32_t &v, int32_t &c) const
+    {
+        int32_t lo = 0, hi = n_calls - 1;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (calls[4 * mid + 3] <= e) lo = mid; else hi = mid - 1;
+        }
+        c = lo;
+        v = rootlist[calls[4 * c + 2] + (e - calls[4 * c + 3])];
+    }
+};
+
 __global__ void
-k_dec_enter1(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *__restrict__ calls,
+k_dec_enter1(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
              const int32_t *__restrict__ prob, const int32_t *__restrict__ sc, int32_t thresh,
              unsigned long long *key, int32_t *first)
 {
     const int32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_ent) return;
-    const int32_t v = ent[2 * e], c = ent[2 * e + 1];
-    const int32_t scr = add32(calls[2 * c], prob[v]);
+    int32_t v, c;
+    ent.locate(e, v, c);
+    const int32_t scr = add32(calls[4 * c], prob[v]);
     if (scr < thresh || !(sc[v] < scr)) return;
     atomicMax(&key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
     atomicMin(&first[v], c);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_dec_enter2(const int32_t *__restrict__ groups, const int32_t *__restrict__ ent,
+k_dec_enter2(const int32_t *__restrict__ groups, Entries ent,
              const int32_t *__restrict__ calls, const int32_t *__restrict__ prob,
              const int32_t *__restrict__ sc, const int32_t *__restrict__ frame,
              const int32_t *__restrict__ first, int32_t thresh, int32_t nf,
@@ -513,8 +576,10 @@ k_dec_enter2(const int32_t *__restrict__ groups, const int32_t *__restrict__ ent
     const int32_t t = groups[3 * blockIdx.x], lo = groups[3 * blockIdx.x + 1], hi = groups[3 * blockIdx.x + 2];
     const int32_t n = hi - lo, b = node_base[t];
     for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
-        const int32_t e = lo + i, v = ent[2 * e], c = ent[2 * e + 1];
-        const int32_t scr = add32(calls[2 * c], prob[v]);
+        const int32_t e = lo + i;
+        int32_t v, c;
+        ent.locate(e, v, c);
+        const int32_t scr = add32(calls[4 * c], prob[v]);
         flag[e] = (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
     }
     __syncthreads();
@@ -522,8 +587,10 @@ k_dec_enter2(const int32_t *__restrict__ groups, const int32_t *__restrict__ ent
     __syncthreads();
     const int32_t n0 = nnxt[t];
     for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
-        const int32_t e = lo + i, v = ent[2 * e], c = ent[2 * e + 1];
-        const int32_t scr = add32(calls[2 * c], prob[v]);
+        const int32_t e = lo + i;
+        int32_t v, c;
+        ent.locate(e, v, c);
+        const int32_t scr = add32(calls[4 * c], prob[v]);
         if (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) {
             const int32_t k = n0 + flag[e];
             nxt[b + k] = v; pos[v] = k; posf[v] = nf;
@@ -536,7 +603,7 @@ k_dec_enter2(const int32_t *__restrict__ groups, const int32_t *__restrict__ ent
 /* blocks [0, n_ent_blocks): apply the winning entries; the remaining blocks mark the senones
  * of every node of the NEXT active lists (srch_TST_select_active_gmm for the coming frame) */
 __global__ void __launch_bounds__(DBLOCK)
-k_dec_enter3_mark(int32_t n_ent_blocks, const int32_t *__restrict__ ent, int32_t n_ent,
+k_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
                   const int32_t *__restrict__ calls, int32_t nf,
                   const unsigned long long *__restrict__ key, const int32_t *__restrict__ first,
                   int32_t *sc, int32_t *hist, int32_t *frame,
@@ -550,11 +617,12 @@ k_dec_enter3_mark(int32_t n_ent_blocks, const int32_t *__restrict__ ent, int32_t
     if ((int32_t)blockIdx.x < n_ent_blocks) {
         const int32_t e = blockIdx.x * DBLOCK + threadIdx.x;
         if (e >= n_ent) return;
-        const int32_t v = ent[2 * e], c = ent[2 * e + 1];
+        int32_t v, c;
+        ent.locate(e, v, c);
         const unsigned long long k = key[v];
         if (k == 0ull) return;
         const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(k & 0xffffffffu);
-        if (c == win_c) { sc[v] = (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); hist[v] = calls[2 * c + 1]; }
+        if (c == win_c) { sc[v] = (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); hist[v] = calls[4 * c + 1]; }
         if (c == first[v]) frame[v] = nf;
         return;
     }
@@ -691,12 +759,14 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_prob, ls->d_par_off, ls->d_par, ls->d_pos, ls->d_posf, ls->d_sc, ls->d_hist,
                        ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame, ls->d_turn, ls->d_selfemit,
                        ls->d_cnt, ls->d_key, ls->d_first, ls->d_hbin);
-    hipLaunchKernelGGL(k_dec_finish, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
-                       ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_child_off, ls->d_child,
-                       ls->d_wid, ls->d_prob, ls->d_outs, ls->d_outh, ls->d_turn, ls->d_selfemit,
-                       ls->d_cnt, ls->d_act[nxt], ls->d_nact[nxt], ls->d_pos, ls->d_posf, ls->d_best,
-                       ls->d_exit, ls->d_nexit, sc->misc_d, ls->d_done, ls->d_pack, ls->pack_max_exits,
-                       ls->d_hbin);
+    hipLaunchKernelGGL(k_dec_scan, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
+                       ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_wid, ls->d_prob, ls->d_outs,
+                       ls->d_outh, ls->d_selfemit, ls->d_cnt, ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt],
+                       ls->d_pos, ls->d_posf, ls->d_best, ls->d_exit, ls->d_nexit, ls->d_hbin, sc->misc_d,
+                       ls->d_done, ls->d_pack, ls->pack_max_exits);
+    hipLaunchKernelGGL(k_dec_emit, dim3(EMIT_BLOCKS, T), dim3(DBLOCK), 0, ls->stream, frm, ls->d_node_base,
+                       ls->d_act[cur], ls->d_nact[cur], ls->d_child_off, ls->d_child, ls->d_turn, ls->d_selfemit,
+                       ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt], ls->d_pos, ls->d_posf);
     HIPCHK(hipGetLastError());
     const int32_t first = 256;
     HIPCHK(hipMemcpyAsync(ls->h_pack, ls->d_pack, (size_t)(hdr + 3 * first) * 4, hipMemcpyDeviceToHost, ls->stream));
@@ -758,11 +828,11 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
     if (same_stream(ls, sc) != S3A_OK) return S3A_EINVAL;
     const int32_t T = ls->n_tree, maxn = max_tree_nodes(ls);
     const int nxt = ls->cur ^ 1;
-    const size_t slot_words = (size_t)2 * 4096 + (size_t)2 * ls->ent_cap;
-    int32_t *slot = ls->h_ring + (size_t)(ls->ring_slot++ & 7) * slot_words;
-    int32_t *groups = slot, *calls = slot + 8, *ent = slot + 2 * 4096;     /* [groups 8][calls ...][entries ...] */
+    int32_t *slot = ls->h_ring + (size_t)(ls->ring_slot++ & 7) * ((size_t)2 * 4096 + (size_t)2 * ls->ent_cap);
+    int32_t *groups = slot, *calls = slot + 8;          /* pinned staging: [groups 8][calls 4 each] */
     int32_t n_ent = 0, n_groups = 0, c = 0;
 
+    if (n_a + n_b > 2046) return S3A_EINVAL;
     for (int g = 0; g < 2; g++) {
         const int32_t tree = g ? tree_b : tree_a, n = g ? n_b : n_a;
         const int32_t *lc = g ? lc_b : lc_a, *scr = g ? scr_b : scr_a, *hi = g ? hist_b : hist_a;
@@ -778,27 +848,24 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
                     return S3A_EINVAL;
                 }
             }
-            const int32_t off = ls->rootbuf_base[tree] + ls->lcroot_off[tree][k];
             const int32_t len = ls->lcroot_off[tree][k + 1] - ls->lcroot_off[tree][k];
             if (n_ent + len > ls->ent_cap) { s3a_set_error("s3a_decoder_transition: entry staging overflow"); return S3A_EINVAL; }
-            calls[2 * c] = scr[i];
-            calls[2 * c + 1] = hi[i];
-            for (int32_t q = 0; q < len; q++, n_ent++) {
-                ent[2 * n_ent] = ls->h_rootlist[off + q];
-                ent[2 * n_ent + 1] = c;
-            }
+            calls[4 * c] = scr[i];
+            calls[4 * c + 1] = hi[i];
+            calls[4 * c + 2] = ls->rootbuf_base[tree] + ls->lcroot_off[tree][k];
+            calls[4 * c + 3] = n_ent;
+            n_ent += len;
         }
         groups[3 * n_groups] = tree; groups[3 * n_groups + 1] = lo; groups[3 * n_groups + 2] = n_ent;
         n_groups++;
     }
+    const Entries ent = { ls->d_calls + 8, ls->d_rootlist, c };
     if (n_ent > 0) {
-        /* one contiguous upload: calls | groups | entries all live in the pinned ring slot */
-        HIPCHK(hipMemcpyAsync(ls->d_calls, slot, (size_t)(8 + 2 * c) * 4, hipMemcpyHostToDevice, ls->stream));
-        HIPCHK(hipMemcpyAsync(ls->d_ent, ent, (size_t)2 * n_ent * 4, hipMemcpyHostToDevice, ls->stream));
-        hipLaunchKernelGGL(k_dec_enter1, dim3((n_ent + 255) / 256), dim3(256), 0, ls->stream, ls->d_ent,
+        HIPCHK(hipMemcpyAsync(ls->d_calls, slot, (size_t)(8 + 4 * c) * 4, hipMemcpyHostToDevice, ls->stream));
+        hipLaunchKernelGGL(k_dec_enter1, dim3((n_ent + 255) / 256), dim3(256), 0, ls->stream, ent,
                            n_ent, ls->d_calls + 8, ls->d_prob, ls->d_sc, thresh, ls->d_key, ls->d_first);
         hipLaunchKernelGGL(k_dec_enter2, dim3(n_groups), dim3(SCAN_THREADS), 0, ls->stream,
-                           ls->d_calls, ls->d_ent, ls->d_calls + 8, ls->d_prob, ls->d_sc,
+                           ls->d_calls, ent, ls->d_calls + 8, ls->d_prob, ls->d_sc,
                            ls->d_frame, ls->d_first, thresh, cf + 1, ls->d_node_base, ls->d_eflag,
                            ls->d_act[nxt], ls->d_nact[nxt], ls->d_pos, ls->d_posf);
     }
@@ -806,13 +873,19 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
         const int32_t n_ent_blocks = (n_ent + DBLOCK - 1) / DBLOCK;
         const int32_t bpt = (maxn + DBLOCK - 1) / DBLOCK;
         hipLaunchKernelGGL(k_dec_enter3_mark, dim3(n_ent_blocks + bpt * T), dim3(DBLOCK), 0, ls->stream,
-                           n_ent_blocks, ls->d_ent, n_ent, ls->d_calls + 8, cf + 1, ls->d_key, ls->d_first,
+                           n_ent_blocks, ent, n_ent, ls->d_calls + 8, cf + 1, ls->d_key, ls->d_first,
                            ls->d_sc, ls->d_hist, ls->d_frame, T, bpt, ls->d_node_base, ls->d_act[nxt],
                            ls->d_nact[nxt], ls->d_ssid, ls->d_comp, ls->d_sseq, ls->d_comsseq, cs->off_d,
                            cs->list_d, sc->act_d);
     }
     HIPCHK(hipGetLastError());
-    ls->hist_bound = ls->last_nnxt + n_ent;     /* >= the coming frame's active HMMs */
+    {
+        /* >= the coming frame's active HMMs: what propagation listed + the distinct roots entered */
+        int32_t roots = 0;
+        if (n_a > 0) roots += ls->n_root[tree_a];
+        if (n_b > 0) roots += ls->n_root[tree_b];
+        ls->hist_bound = ls->last_nnxt + min(n_ent, roots);
+    }
     ls->cur ^= 1;       /* lextree_active_swap; the new next-list counts are overwritten by k_dec_finish */
     return S3A_OK;
 }

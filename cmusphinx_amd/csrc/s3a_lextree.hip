@@ -529,6 +529,7 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
             }
         }
         /* root lists: per left context, or the single root list when n_lc == 0 */
+        ls->n_root.push_back(n_root[t]);
         ls->rootbuf_base[t] = (int32_t)h_roots.size();
         if (n_lc[t] > 0) {
             ls->lc[t].assign(lc[t], lc[t] + n_lc[t]);

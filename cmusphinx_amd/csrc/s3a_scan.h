@@ -5,9 +5,9 @@
 #include <stdint.h>
 #define SCAN_THREADS 1024
 
-/* exclusive scan of v[0..n) in place by one workgroup; returns the total in *total */
+/* exclusive scan of src[0..n) into dst[0..n) (may alias) by one workgroup; the total goes to *total */
 __device__ __forceinline__ void
-block_exclusive_scan(int32_t *v, int32_t n, int32_t *total)
+block_exclusive_scan_to(const int32_t *src, int32_t *dst, int32_t n, int32_t *total)
 {
     __shared__ int32_t wsum[SCAN_THREADS / 64];
     __shared__ int32_t carry;
@@ -16,7 +16,7 @@ block_exclusive_scan(int32_t *v, int32_t n, int32_t *total)
     __syncthreads();
     for (int32_t base = 0; base < n; base += SCAN_THREADS) {
         int32_t i = base + tid;
-        int32_t x = (i < n) ? v[i] : 0;
+        int32_t x = (i < n) ? src[i] : 0;
         int32_t incl = x;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -37,7 +37,7 @@ block_exclusive_scan(int32_t *v, int32_t n, int32_t *total)
         }
         __syncthreads();
         int32_t excl = carry + wsum[wave] + incl - x;
-        if (i < n) v[i] = excl;
+        if (i < n) dst[i] = excl;
         __syncthreads();
         if (tid == SCAN_THREADS - 1) carry = excl + x;
         __syncthreads();
@@ -45,5 +45,10 @@ block_exclusive_scan(int32_t *v, int32_t n, int32_t *total)
     if (tid == 0) *total = carry;
 }
 
+__device__ __forceinline__ void
+block_exclusive_scan(int32_t *v, int32_t n, int32_t *total)
+{
+    block_exclusive_scan_to(v, v, n, total);
+}
 
 #endif

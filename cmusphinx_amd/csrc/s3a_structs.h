@@ -42,6 +42,7 @@ struct s3a_lexsearch_s {
     int32_t n_emit, n_tmat, n_sen, n_comsen, n_lcmax;
     std::vector<int32_t> node_base;     /* [n_tree+1] */
     std::vector<int32_t> n_lc;          /* per tree */
+    std::vector<int32_t> n_root;        /* per tree: distinct root nodes */
     std::vector<std::vector<int16_t>> lc;           /* per tree: lc ids */
     std::vector<std::vector<int32_t>> lcroot_off;   /* per tree: CSR into the tree's root buffer */
     std::vector<int32_t> rootbuf_base;  /* per tree: offset of its root lists in d_rootlist */

@@ -149,6 +149,13 @@ flatten_tree(lextree_t *lt)
             f->child[j++] = node_index(gnode_ptr(gn));
     }
     f->child_off[n] = j;
+    {
+        int32 mx = 0;
+        for (i = 0; i < n; i++)
+            if (f->child_off[i + 1] - f->child_off[i] > mx) mx = f->child_off[i + 1] - f->child_off[i];
+        E_INFO("tst shim: lextree type %d: %d nodes, %d links, %d roots, largest fan-out %d\n", lt->type, n, j,
+               glist_count(lt->root), mx);
+    }
     f->n_lc = lt->n_lc;
     f->type = lt->type;
     if (lt->n_lc > 0) {
