@@ -670,6 +670,215 @@ s3a_mgau_get_params(const s3a_mgau_model_t *g, float *mean, float *prec, float *
 }
 
 /* ------------------------------------------------------------------ */
+/* multi-stream scorer: host half of ms_mgau_init                      */
+/* gauden_init + gauden_dist_precompute (ms_gauden.c:330-476),         */
+/* senone_init / senone_mixw_read (ms_senone.c:212-417),               */
+/* ms_mgau_init (ms_mgau.c:149-227)                                    */
+/* ------------------------------------------------------------------ */
+static size_t
+ms_off(const s3a_ms_mgau_t *ms, int32_t m, int32_t f, int32_t d)
+{
+    return (size_t)m * ms->n_density * ms->veclen + (size_t)ms->n_density * ms->featoff[f]
+        + (size_t)d * ms->featlen[f];
+}
+
+s3a_ms_mgau_t *
+s3a_ms_host_init(const float *mean, const float *var, const float *mixw, int32_t n_mgau, int32_t n_feat,
+                 int32_t n_density, const int32_t *featlen, int32_t n_sen, const int32_t *sen2mgau,
+                 double varfloor_d, double mixwfloor, int32_t topn, s3a_logmath_t *lm)
+{
+    s3a_ms_mgau_t *ms;
+    float varfloor = (float)varfloor_d;         /* gauden_init(..., float32 varfloor, ...) */
+    float *row;
+    int32_t m, f, d, i, s, c;
+    size_t n;
+
+    if (!mean || !var || !mixw || !featlen || !lm || n_mgau <= 0 || n_feat <= 0 || n_density <= 0
+        || n_sen <= 1 || !(varfloor_d > 0.0) || !(mixwfloor > 0.0 && mixwfloor < 1.0)) {
+        s3a_set_error("s3a_ms_mgau_init: bad arguments");
+        return NULL;
+    }
+    if ((ms = (s3a_ms_mgau_t *)calloc(1, sizeof *ms)) == NULL) return NULL;
+    ms->n_mgau = n_mgau; ms->n_feat = n_feat; ms->n_density = n_density; ms->n_sen = n_sen; ms->lm = lm;
+    ms->featlen = (int32_t *)malloc(sizeof(int32_t) * n_feat);
+    ms->featoff = (int32_t *)malloc(sizeof(int32_t) * (n_feat + 1));
+    for (f = 0; f < n_feat; f++) {
+        if (featlen[f] <= 0) { s3a_set_error("s3a_ms_mgau_init: bad stream length"); s3a_ms_host_free(ms); return NULL; }
+        ms->featlen[f] = featlen[f];
+        ms->featoff[f] = ms->veclen;
+        ms->veclen += featlen[f];
+    }
+    ms->featoff[n_feat] = ms->veclen;
+    n = (size_t)n_mgau * n_density * ms->veclen;
+    ms->mean = (float *)malloc(sizeof(float) * n);
+    ms->prec = (float *)malloc(sizeof(float) * n);
+    ms->det = (float *)calloc((size_t)n_mgau * n_feat * n_density, sizeof(float));
+    ms->pdf = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_sen * n_feat * n_density);
+    ms->mgau = (int32_t *)malloc(sizeof(int32_t) * n_sen);
+    row = (float *)malloc(sizeof(float) * n_density);
+    if (!ms->mean || !ms->prec || !ms->det || !ms->pdf || !ms->mgau || !row) {
+        free(row); s3a_ms_host_free(ms); s3a_set_error("s3a_ms_mgau_init: out of memory"); return NULL;
+    }
+    memcpy(ms->mean, mean, sizeof(float) * n);
+    memcpy(ms->prec, var, sizeof(float) * n);
+    /* determinant term accumulated in float32, precision = (float32)(1 / (2 var)) */
+    for (m = 0; m < n_mgau; m++)
+        for (f = 0; f < n_feat; f++)
+            for (d = 0; d < n_density; d++) {
+                float *varp = ms->prec + ms_off(ms, m, f, d);
+                float *detp = &ms->det[((size_t)m * n_feat + f) * n_density + d];
+                *detp = (float)0.0;
+                for (i = 0; i < featlen[f]; i++, varp++) {
+                    if (*varp < varfloor)
+                        *varp = varfloor;
+                    *detp += (float)(log(*varp));
+                    *varp = (float)(1.0 / (*varp * 2.0));
+                }
+                *detp += (float)(featlen[f] * log(2.0 * M_PI));
+                *detp *= (float)0.5;
+            }
+    ms->min_density = s3a_logmath_log_to_ln(lm, S3A_LOGPROB_ZERO);
+    /* senone weights: normalise, floor, normalise, -logs3 (TRUNCATE_LOGPDF is not defined) */
+    for (s = 0; s < n_sen; s++)
+        for (f = 0; f < n_feat; f++) {
+            memcpy(row, mixw + ((size_t)s * n_feat + f) * n_density, sizeof(float) * n_density);
+            normalise(row, n_density);
+            for (c = 0; c < n_density; c++)
+                if (row[c] < mixwfloor) row[c] = (float)mixwfloor;
+            normalise(row, n_density);
+            for (c = 0; c < n_density; c++)
+                ms->pdf[((size_t)s * n_feat + f) * n_density + c] = -(s3a_logs3(lm, row[c]));
+        }
+    free(row);
+    ms->one_to_one = (sen2mgau == NULL);
+    for (s = 0; s < n_sen; s++) {
+        ms->mgau[s] = sen2mgau ? sen2mgau[s] : s;
+        if (ms->mgau[s] < 0 || ms->mgau[s] >= n_mgau) {
+            s3a_set_error("s3a_ms_mgau_init: senone %d needs codebook %d of %d", s, ms->mgau[s], n_mgau);
+            s3a_ms_host_free(ms);
+            return NULL;
+        }
+    }
+    ms->topn = (topn <= 0 || topn > n_density) ? n_density : topn;     /* ms_mgau.c:214-219 */
+    return ms;
+}
+
+void
+s3a_ms_host_free(s3a_ms_mgau_t *ms)
+{
+    if (!ms) return;
+    free(ms->featlen); free(ms->featoff); free(ms->mean); free(ms->prec); free(ms->det);
+    free(ms->pdf); free(ms->mgau);
+    free(ms);
+}
+
+s3a_ms_mgau_t *
+s3a_ms_mgau_init_arrays(const float *mean, const float *var, const float *mixw, int32_t n_mgau,
+                        int32_t n_feat, int32_t n_density, const int32_t *featlen, int32_t n_sen,
+                        const int32_t *sen2mgau, double varfloor, double mixwfloor, int32_t topn,
+                        s3a_logmath_t *lm)
+{
+    s3a_ms_mgau_t *ms = s3a_ms_host_init(mean, var, mixw, n_mgau, n_feat, n_density, featlen, n_sen,
+                                         sen2mgau, varfloor, mixwfloor, topn, lm);
+    if (ms && s3a_ms_dev_create(ms) != S3A_OK) {
+        s3a_ms_host_free(ms);
+        return NULL;
+    }
+    return ms;
+}
+
+/* multi-stream means / variances payload (gauden_param_read, ms_gauden.c:205-312) */
+static int32_t
+parse_gau_streams(const char *path, const uint32_t *w, size_t nw, int32_t *n_mgau, int32_t *n_feat,
+                  int32_t *n_density, const int32_t **featlen, const float **data)
+{
+    int64_t tot = 0;
+    int32_t f;
+    if (nw < 4 || (int32_t)w[1] <= 0 || nw < 4 + (size_t)w[1]) { s3a_set_error("%s: truncated header", path); return S3A_EIO; }
+    *n_mgau = (int32_t)w[0]; *n_feat = (int32_t)w[1]; *n_density = (int32_t)w[2];
+    *featlen = (const int32_t *)(w + 3);
+    for (f = 0; f < *n_feat; f++) tot += (*featlen)[f];
+    if (*n_mgau <= 0 || *n_density <= 0 || tot <= 0
+        || (int64_t)(int32_t)w[3 + *n_feat] != (int64_t)*n_mgau * *n_density * tot
+        || nw != 4 + (size_t)*n_feat + (size_t)w[3 + *n_feat]) {
+        s3a_set_error("%s: #float32s doesn't match dimensions", path);
+        return S3A_EIO;
+    }
+    *data = (const float *)(w + 4 + *n_feat);
+    return S3A_OK;
+}
+
+s3a_ms_mgau_t *
+s3a_ms_mgau_init(const char *meanfile, const char *varfile, double varfloor, const char *mixwfile,
+                 double mixwfloor, int32_t precomp, const char *senmgau, const char *lambdafile,
+                 int32_t topn, s3a_logmath_t *lm)
+{
+    uint32_t *wm = NULL, *wv = NULL, *ww = NULL;
+    size_t nm, nv, nw;
+    int32_t M, F, C, M2, F2, C2, S, f, semi;
+    const int32_t *fl, *fl2;
+    const float *mean, *var;
+    int32_t *map = NULL;
+    s3a_ms_mgau_t *ms = NULL;
+
+    if (!meanfile || !varfile || !mixwfile || !senmgau || !lm) { s3a_set_error("s3a_ms_mgau_init: bad arguments"); return NULL; }
+    if (lambdafile) { s3a_set_error("s3a_ms_mgau_init: CD/CI interpolation weights (-lambda) are not supported"); return NULL; }
+    if (!precomp) { s3a_set_error("s3a_ms_mgau_init: precomp must be 1"); return NULL; }
+    semi = strcmp(senmgau, ".semi.") == 0;
+    if (!semi && strcmp(senmgau, ".s3cont.") != 0 && strcmp(senmgau, ".cont.") != 0) {
+        s3a_set_error("s3a_ms_mgau_init: -senmgau %s: senone-codebook mapping FILES are not supported", senmgau);
+        return NULL;
+    }
+    if (s3a_bio_read(meanfile, "1.0", &wm, &nm) != S3A_OK || s3a_bio_read(varfile, "1.0", &wv, &nv) != S3A_OK
+        || s3a_bio_read(mixwfile, "1.0", &ww, &nw) != S3A_OK)
+        goto done;
+    if (parse_gau_streams(meanfile, wm, nm, &M, &F, &C, &fl, &mean) != S3A_OK
+        || parse_gau_streams(varfile, wv, nv, &M2, &F2, &C2, &fl2, &var) != S3A_OK)
+        goto done;
+    if (M2 != M || F2 != F || C2 != C || memcmp(fl, fl2, sizeof(int32_t) * F) != 0) {
+        s3a_set_error("%s: dimensions don't match those of %s", varfile, meanfile);
+        goto done;
+    }
+    if (nw < 4 || (int64_t)(int32_t)ww[3] != (int64_t)(int32_t)ww[0] * (int32_t)ww[1] * (int32_t)ww[2]
+        || nw != 4 + (size_t)ww[3]) {
+        s3a_set_error("%s: #float32s doesn't match dimensions", mixwfile);
+        goto done;
+    }
+    S = (int32_t)ww[0];
+    if ((int32_t)ww[1] != F || (int32_t)ww[2] != C) {
+        s3a_set_error("%s: %d streams x %d codewords don't match the codebooks' %d x %d", mixwfile,
+                      (int32_t)ww[1], (int32_t)ww[2], F, C);
+        goto done;
+    }
+    if (semi) {                             /* all senones share codebook 0 (ms_senone.c:390-397) */
+        map = (int32_t *)calloc(S, sizeof(int32_t));
+    }
+    else if (S > M) {
+        s3a_set_error("Senones need more codebooks (%d) than present (%d)", S, M);
+        goto done;
+    }
+    (void)f;
+    ms = s3a_ms_mgau_init_arrays(mean, var, (const float *)(ww + 4), M, F, C, fl, S, map, varfloor, mixwfloor,
+                                 topn, lm);
+done:
+    free(map); free(wm); free(wv); free(ww);
+    return ms;
+}
+
+void
+s3a_ms_mgau_free(s3a_ms_mgau_t *ms)
+{
+    if (!ms) return;
+    s3a_ms_dev_destroy(ms);
+    s3a_ms_host_free(ms);
+}
+
+int32_t s3a_ms_mgau_n_sen(const s3a_ms_mgau_t *ms) { return ms->n_sen; }
+int32_t s3a_ms_mgau_topn(const s3a_ms_mgau_t *ms) { return ms->topn; }
+int32_t s3a_ms_mgau_veclen(const s3a_ms_mgau_t *ms) { return ms->veclen; }
+
+
+/* ------------------------------------------------------------------ */
 /* transition matrices                                                 */
 /* ------------------------------------------------------------------ */
 s3a_tmat_t *

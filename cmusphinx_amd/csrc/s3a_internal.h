@@ -40,6 +40,20 @@ struct s3a_mgau_model_s {
     struct s3a_mgau_dev_s *dev;
 };
 
+/* multi-stream scorer (-senmgau .s3cont. / .semi.): gauden_t + senone_t of ms_mgau_model_t */
+struct s3a_ms_dev_s;
+struct s3a_ms_mgau_s {
+    int32_t n_mgau, n_feat, n_density, n_sen, topn, veclen;
+    int32_t one_to_one;     /* ".s3cont.": senone s uses codebook s */
+    int32_t *featlen, *featoff;         /* [n_feat], [n_feat + 1] */
+    float *mean, *prec, *det;           /* file order [m][f][d][featlen f]; det [m][f][d] */
+    int32_t *pdf;                       /* [n_sen][n_feat][n_density]  -logs3(weight) */
+    int32_t *mgau;                      /* [n_sen] */
+    double min_density;
+    s3a_logmath_t *lm;                  /* borrowed */
+    struct s3a_ms_dev_s *dev;
+};
+
 struct s3a_tmat_s {
     int32_t n_tmat, n_state;
     int32_t *tp;            /* [n_tmat][n_state][n_state+1] logs3 */
@@ -50,6 +64,15 @@ struct s3a_tmat_s {
  * after verifying the checksum when the header announces one. */
 int32_t s3a_bio_read(const char *path, const char *expect_version, uint32_t **words,
                      size_t *n_words);
+/* host half of ms_mgau_init on raw arrays; leaves msg->dev NULL (s3a_host.c) */
+struct s3a_ms_mgau_s *s3a_ms_host_init(const float *mean, const float *var, const float *mixw,
+                                       int32_t n_mgau, int32_t n_feat, int32_t n_density,
+                                       const int32_t *featlen, int32_t n_sen, const int32_t *sen2mgau,
+                                       double varfloor, double mixwfloor, int32_t topn,
+                                       s3a_logmath_t *lm);
+void s3a_ms_host_free(struct s3a_ms_mgau_s *msg);
+int32_t s3a_ms_dev_create(struct s3a_ms_mgau_s *msg);      /* s3a_ms.hip */
+void s3a_ms_dev_destroy(struct s3a_ms_mgau_s *msg);
 /* host half of mgau_init on raw arrays; leaves g->dev NULL */
 s3a_mgau_model_t *s3a_mgau_host_init(const float *mean, const float *var, const float *mixw,
                                      int32_t n_mgau, int32_t n_density, int32_t veclen,

@@ -105,6 +105,17 @@ _SIGS = {
                                    [C.c_void_p] * 6 + [C.c_int32]),
     "s3a_approx_cont_mgau_frame_eval_async": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_scorer_misc_dev": (C.c_void_p, [C.c_void_p]),
+    "s3a_ms_mgau_init": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_double, C.c_int32,
+                                      C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p]),
+    "s3a_ms_mgau_init_arrays": (C.c_void_p, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p, C.c_int32, C.c_void_p,
+                                                                              C.c_double, C.c_double, C.c_int32,
+                                                                              C.c_void_p]),
+    "s3a_ms_mgau_free": (None, [C.c_void_p]),
+    "s3a_ms_mgau_n_sen": (C.c_int32, [C.c_void_p]),
+    "s3a_ms_mgau_topn": (C.c_int32, [C.c_void_p]),
+    "s3a_ms_mgau_veclen": (C.c_int32, [C.c_void_p]),
+    "s3a_ms_cont_mgau_frame_eval": (C.c_int32, [C.c_void_p] * 4 + [C.c_int32, C.POINTER(C.c_int32)]),
+    "s3a_ms_mgau_get_dist": (C.c_int32, [C.c_void_p] * 3),
     "s3a_decoder_utt_begin": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "s3a_lexsearch_hmm_histbin": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "s3a_decoder_score": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
@@ -432,6 +443,62 @@ class Scorer:
             out["bstidx"][t] = bi
             out["updatetime"][t] = ut
         return out
+
+
+class MsMgau:
+    """ms_mgau_model_t: the multi-stream scorer behind -senmgau .s3cont. / .semi. (s3a_ms_mgau_*)."""
+
+    def __init__(self, h, lm, n_mgau=None, n_feat=None):
+        self.L = load()
+        if not h:
+            raise S3AError(_err(self.L))
+        self.h, self.lm = h, lm
+        self.n_sen = self.L.s3a_ms_mgau_n_sen(h)
+        self.topn = self.L.s3a_ms_mgau_topn(h)
+        self.veclen = self.L.s3a_ms_mgau_veclen(h)
+        self.n_mgau, self.n_feat = n_mgau, n_feat
+
+    @classmethod
+    def init(cls, meanfile, varfile, mixwfile, lm: LogMath, senmgau=".s3cont.", topn=4, varfloor=1e-4,
+             mixwfloor=1e-7, lambdafile=None):
+        L = load()
+        e = lambda p: None if p is None else str(p).encode()
+        return cls(L.s3a_ms_mgau_init(e(meanfile), e(varfile), varfloor, e(mixwfile), mixwfloor, 1, e(senmgau),
+                                      e(lambdafile), int(topn), lm.h), lm)
+
+    @classmethod
+    def init_arrays(cls, mean, var, mixw, n_mgau, n_density, featlen, lm: LogMath, topn, sen2mgau=None,
+                    varfloor=1e-4, mixwfloor=1e-7):
+        L = load()
+        mean = np.ascontiguousarray(mean, np.float32); var = np.ascontiguousarray(var, np.float32)
+        mixw = np.ascontiguousarray(mixw, np.float32)
+        fl = np.ascontiguousarray(featlen, np.int32)
+        n_sen = mixw.size // (len(fl) * n_density)
+        s2m = None if sen2mgau is None else np.ascontiguousarray(sen2mgau, np.int32)
+        return cls(L.s3a_ms_mgau_init_arrays(_p(mean), _p(var), _p(mixw), int(n_mgau), len(fl), int(n_density), _p(fl),
+                                             n_sen, None if s2m is None else _p(s2m), varfloor, mixwfloor, int(topn),
+                                             lm.h), lm, n_mgau, len(fl))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_ms_mgau_free(self.h)
+            self.h = None
+
+    def frame_eval(self, sen_active, senscr, feat, frame=0):
+        """ms_cont_mgau_frame_eval: senscr (int32[S]) updated in place for the active senones; returns best."""
+        sa = np.ascontiguousarray(sen_active, np.uint8)
+        x = np.ascontiguousarray(feat, np.float32)
+        assert senscr.dtype == np.int32 and senscr.flags.c_contiguous and x.size == self.veclen
+        best = C.c_int32(0)
+        check(self.L.s3a_ms_cont_mgau_frame_eval(self.h, _p(sa), _p(senscr), _p(x), int(frame), C.byref(best)))
+        return best.value
+
+    def last_dist(self):
+        n = self.n_mgau * self.n_feat * self.topn
+        d = np.zeros(n, np.int32); di = np.zeros(n, np.int32)
+        check(self.L.s3a_ms_mgau_get_dist(self.h, _p(d), _p(di)))
+        shp = (self.n_mgau, self.n_feat, self.topn)
+        return d.reshape(shp), di.reshape(shp)
 
 
 class ComSen:

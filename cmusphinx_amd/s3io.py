@@ -141,6 +141,15 @@ def write_gau(path: str, arr: np.ndarray, chksum: bool = True):
     _write(path, [n_mgau, 1, n_density, veclen, arr.size], arr, chksum)
 
 
+def write_gau_streams(path: str, flat: np.ndarray, n_mgau: int, n_density: int, featlen, chksum: bool = True):
+    """Multi-stream means/variances file (ms_gauden.c:205-312 gauden_param_read): header
+    n_mgau, n_feat, n_density, veclen[n_feat], total; data in [m][f][d][veclen f] order."""
+    featlen = [int(v) for v in featlen]
+    flat = np.ascontiguousarray(flat, "<f4").ravel()
+    assert flat.size == n_mgau * n_density * sum(featlen)
+    _write(path, [n_mgau, len(featlen), n_density] + featlen + [flat.size], flat, chksum)
+
+
 def write_mixw(path: str, arr: np.ndarray, chksum: bool = True):
     if arr.ndim == 2:
         arr = arr[:, None, :]

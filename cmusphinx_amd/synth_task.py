@@ -16,7 +16,7 @@ models: their mdef / means / variances are absent from the reference checkout (S
                             input -- a clear best path, competitors falling out of the beam
     args                    the decoder arguments shared by the reference and the drop-in
 
-The unmodified reference (oracle/_ref/sphinx3_decode) and the device path decode the same files;
+The unmodified reference decoder (built by the test infrastructure) and the device path decode the same files;
 tests/test_gpu_dropin.py diffs their -hyp/-hypseg outputs.  Deterministic: numpy PCG64, fixed seed.
 """
 from __future__ import annotations

@@ -212,6 +212,46 @@ int32_t s3a_approx_cont_mgau_frame_eval(s3a_scorer_t *sc, uint8_t *sen_active,
                                         const int32_t *cache_ci_senscr, int32_t *best,
                                         int32_t *n_sen_eval, int32_t *n_gau_eval);
 
+/* ------------------------------------------------------------------ */
+/* The multi-stream ("s3.0") senone scorer: -senmgau .s3cont. / .semi. */
+/* Replaces ms_mgau_model_t and its functions:                         */
+/*   ms_mgau_init             libam/ms_mgau.c:149-227                  */
+/*     gauden_init + gauden_dist_precompute  ms_gauden.c:330-476       */
+/*     senone_init / senone_mixw_read        ms_senone.c:212-417       */
+/*   ms_cont_mgau_frame_eval  ms_mgau.c:242-329 (slot gmm_compute_lv2  */
+/*     when kbcore holds an ms_mgau, gmm_wrap.c:136-140)               */
+/*     gauden_dist (top-N codewords)         ms_gauden.c:541-644       */
+/*     senone_eval                           ms_senone.c:442-490       */
+/* Same argument list as ms_mgau_init minus the mdef (only needed for  */
+/* senone->codebook mapping FILES, which are not supported, like the   */
+/* -lambda interpolation file: the call fails).  Scores are the same   */
+/* integers as the reference's (determinant accumulated in float32,    */
+/* float64 distance chain, ordered top-N list, ordered log-add).       */
+/* ------------------------------------------------------------------ */
+typedef struct s3a_ms_mgau_s s3a_ms_mgau_t;
+s3a_ms_mgau_t *s3a_ms_mgau_init(const char *meanfile, const char *varfile, double varfloor,
+                                const char *mixwfile, double mixwfloor, int32_t precomp,
+                                const char *senmgau, const char *lambdafile, int32_t topn,
+                                s3a_logmath_t *logmath);
+/* raw arrays in file order: mean/var [n_mgau][n_feat][n_density][featlen f], mixw
+ * [n_sen][n_feat][n_density]; sen2mgau NULL = one codebook per senone (".s3cont.") */
+s3a_ms_mgau_t *s3a_ms_mgau_init_arrays(const float *mean, const float *var, const float *mixw,
+                                       int32_t n_mgau, int32_t n_feat, int32_t n_density,
+                                       const int32_t *featlen, int32_t n_sen, const int32_t *sen2mgau,
+                                       double varfloor, double mixwfloor, int32_t topn,
+                                       s3a_logmath_t *logmath);
+void    s3a_ms_mgau_free(s3a_ms_mgau_t *msg);
+int32_t s3a_ms_mgau_n_sen(const s3a_ms_mgau_t *msg);
+int32_t s3a_ms_mgau_topn(const s3a_ms_mgau_t *msg);
+int32_t s3a_ms_mgau_veclen(const s3a_ms_mgau_t *msg);
+/* ms_cont_mgau_frame_eval: sen_active / senscr are ascr_t's arrays (host); feat = the frame's
+ * streams concatenated (feat[0] for one stream); senscr[s] is written (normalised) for the active
+ * senones only; *best = the value the reference returns (-> srch->senscale). */
+int32_t s3a_ms_cont_mgau_frame_eval(s3a_ms_mgau_t *msg, const uint8_t *sen_active, int32_t *senscr,
+                                    const float *feat, int32_t frame, int32_t *best);
+/* the top-N lists of the last frame, [n_mgau][n_feat][topn] (test hook; inactive codebooks stale) */
+int32_t s3a_ms_mgau_get_dist(s3a_ms_mgau_t *msg, int32_t *dist, int32_t *dist_id);
+
 /*
  * dict2pid_comsenscr (sphinx3/src/libs3decoder/libsearch/dict2pid.c:1029-1048):
  * comsenscr[i] = max_{k in comstate[i]} senscr[k] + comwt[i].  The ragged

@@ -19,6 +19,8 @@
  *   bench_mgau MEAN VAR MIXW LOGBASE FEAT.f32 T   (times approx_cont_mgau_frame_eval with every
  *           senone active; prints "frames T seconds S" -- the CPU baseline of bench.py)
  *   hmm     NEMIT TP.i32 NTMAT SSEQ.i16 NSSEQ SENSCR.i32 NSEN T SPEC.i32 NHMM ENTER.i32 OUTDIR
+ *   ms      MEAN VAR MIXW SENMGAU(.s3cont.|.semi.) TOPN LOGBASE FEAT.f32 T ACTIVE.u8|all OUTDIR
+ *           (ms_mgau_init + ms_cont_mgau_frame_eval: the -senmgau .s3cont./.semi. scorer)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,6 +40,7 @@
 #include "mdef.h"
 #include "tmat.h"
 #include "hmm.h"
+#include "ms_mgau.h"
 #include <sphinxbase/feat.h>
 #include <sphinxbase/cmn.h>
 #include <sphinxbase/agc.h>
@@ -417,6 +420,81 @@ cmd_feat(int argc, char **argv)
     return 0;
 }
 
+static int
+cmd_ms(int argc, char **argv)
+{
+    logmath_t *lm = logs3_init(atof(argv[5]), 0, 1);
+    int32 topn_arg = atoi(argv[4]);
+    ms_mgau_model_t *msg = ms_mgau_init(argv[0], argv[1], 0.0001, argv[2], 0.0000001, TRUE, argv[3], NULL,
+                                        topn_arg, lm, NULL);
+    gauden_t *g = ms_mgau_gauden(msg);
+    senone_t *sn = ms_mgau_senone(msg);
+    int32 topn = ms_mgau_topn(msg), S = sn->n_sen, T = atoi(argv[7]), D = 0, f, t, s, m, d, c, k;
+    size_t nb;
+    float *feat = slurp(argv[6], &nb);
+    uint8 *active_in = strcmp(argv[8], "all") ? slurp(argv[8], NULL) : NULL;
+    const char *out = argv[9];
+    ascr_t *a = ascr_init(S, 0, 1, 0, 1, 0);
+    mdef_t md;
+    float32 **fv = ckd_calloc(g->n_feat, sizeof(float32 *));
+    int32 *senscr = malloc(sizeof(int32) * (size_t)T * S), *best = malloc(sizeof(int32) * T);
+    size_t nd = (size_t)g->n_mgau * g->n_feat * topn;
+    int32 *dist = malloc(sizeof(int32) * T * nd), *dist_id = malloc(sizeof(int32) * T * nd);
+    uint8 *act = malloc((size_t)T * S);
+    float *det, *prec;
+    int32 *pdf, *flen = malloc(sizeof(int32) * g->n_feat), *mg = malloc(sizeof(int32) * S);
+
+    memset(&md, 0, sizeof md);
+    md.n_sen = S;
+    for (f = 0; f < g->n_feat; f++) { flen[f] = g->featlen[f]; D += g->featlen[f]; }
+    if ((size_t)T * D * 4 > nb) { fprintf(stderr, "feature file too short\n"); return 2; }
+    /* the precomputed model, flattened in file order [m][f][d][featlen] */
+    det = malloc(sizeof(float) * (size_t)g->n_mgau * g->n_feat * g->n_density);
+    prec = malloc(sizeof(float) * (size_t)g->n_mgau * g->n_density * D);
+    for (m = 0, k = 0, c = 0; m < g->n_mgau; m++)
+        for (f = 0; f < g->n_feat; f++)
+            for (d = 0; d < g->n_density; d++) {
+                int32 i;
+                det[k++] = g->det[m][f][d];
+                for (i = 0; i < g->featlen[f]; i++) prec[c++] = g->var[m][f][d][i];
+            }
+    pdf = malloc(sizeof(int32) * (size_t)S * sn->n_feat * sn->n_cw);
+    for (s = 0, k = 0; s < S; s++) {
+        mg[s] = sn->mgau[s];
+        for (f = 0; f < sn->n_feat; f++)
+            for (c = 0; c < sn->n_cw; c++)
+                pdf[k++] = (sn->n_gauden > 1) ? (int32)sn->pdf[s][f][c] : (int32)sn->pdf[f][c][s];
+    }
+    memset(dist, 0, sizeof(int32) * T * nd); memset(dist_id, 0, sizeof(int32) * T * nd);
+    for (t = 0; t < T; t++) {
+        int32 off = 0;
+        for (f = 0; f < g->n_feat; f++) { fv[f] = feat + (size_t)t * D + off; off += g->featlen[f]; }
+        if (active_in) memcpy(a->sen_active, active_in + (size_t)t * S, S);
+        else memset(a->sen_active, 1, S);
+        best[t] = ms_cont_mgau_frame_eval(a, msg, &md, fv, t);
+        memcpy(senscr + (size_t)t * S, a->senscr, 4 * S);
+        memcpy(act + (size_t)t * S, a->sen_active, S);
+        for (m = 0, k = 0; m < g->n_mgau; m++)
+            for (f = 0; f < g->n_feat; f++)
+                for (d = 0; d < topn; d++, k++)
+                    if (msg->mgau_active[m]) {
+                        dist[t * nd + k] = msg->dist[m][f][d].dist;
+                        dist_id[t * nd + k] = msg->dist[m][f][d].id;
+                    }
+    }
+    dump(out, "det", "f32", det, 4, 3, (long)g->n_mgau, (long)g->n_feat, (long)g->n_density);
+    dump(out, "prec", "f32", prec, 4, 1, (long)((size_t)g->n_mgau * g->n_density * D));
+    dump(out, "pdf", "i32", pdf, 4, 3, (long)S, (long)sn->n_feat, (long)sn->n_cw);
+    dump(out, "mgau", "i32", mg, 4, 1, (long)S);
+    dump(out, "featlen", "i32", flen, 4, 1, (long)g->n_feat);
+    dump(out, "senscr", "i32", senscr, 4, 2, (long)T, (long)S);
+    dump(out, "sen_active_out", "u8", act, 1, 2, (long)T, (long)S);
+    dump(out, "best", "i32", best, 4, 1, (long)T);
+    dump(out, "dist", "i32", dist, 4, 4, (long)T, (long)g->n_mgau, (long)g->n_feat, (long)topn);
+    dump(out, "dist_id", "i32", dist_id, 4, 4, (long)T, (long)g->n_mgau, (long)g->n_feat, (long)topn);
+    return 0;
+}
+
 int
 main(int argc, char **argv)
 {
@@ -429,6 +507,7 @@ main(int argc, char **argv)
     if (!strcmp(argv[1], "bench_mgau") && argc == 8) return cmd_bench_mgau(argc - 2, argv + 2);
     if (!strcmp(argv[1], "feat") && argc == 4) return cmd_feat(argc - 2, argv + 2);
     if (!strcmp(argv[1], "hmm") && argc == 14) return cmd_hmm(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "ms") && argc == 12) return cmd_ms(argc - 2, argv + 2);
     fprintf(stderr, "ref_dump: bad command/arity: %s (%d args)\n", argv[1], argc - 2);
     return 1;
 }

@@ -35,6 +35,7 @@ static s3a_logmath_t *g_lm;
 static s3a_mgau_model_t *g_gm;
 static s3a_scorer_t *g_sc;
 static s3a_comsen_t *g_cs;
+static s3a_ms_mgau_t *g_ms;         /* -senmgau .s3cont. / .semi.: the multi-stream scorer instead */
 static int (*g_ref_utt_begin)(void *);
 static int32 g_n_sen, g_n_ci_sen;
 static long g_lv1_calls, g_lv2_calls;
@@ -80,6 +81,31 @@ s3amd_gmm_compute_lv2(void *srch, float32 **feat, int32 wav_idx)
     return SRCH_SUCCESS;
 }
 
+/* slot gmm_compute_lv2 when kbcore holds an ms_mgau (gmm_wrap.c:136-140 -> ms_cont_mgau_frame_eval) */
+static int
+s3amd_ms_gmm_compute_lv2(void *srch, float32 **feat, int32 wav_idx)
+{
+    srch_t *s = (srch_t *)srch;
+    ascr_t *ascr = s->ascr;
+    feat_t *fcb = kbcore_fcb(s->kbc);
+    static float32 *cat;
+    float32 *x = feat[0];
+    int32 best, f, o;
+    if (feat_n_stream(fcb) > 1) {           /* streams are separate rows of feat[][]: concatenate */
+        if (!cat) cat = ckd_calloc(s3a_ms_mgau_veclen(g_ms), sizeof(float32));
+        for (f = 0, o = 0; f < feat_n_stream(fcb); o += feat_stream_len(fcb, f), f++)
+            memcpy(cat + o, feat[f], feat_stream_len(fcb, f) * sizeof(float32));
+        x = cat;
+    }
+    if (s3a_ms_cont_mgau_frame_eval(g_ms, ascr->sen_active, ascr->senscr, x, wav_idx, &best) != S3A_OK)
+        die("ms gmm_compute_lv2");
+    s->senscale = best;
+    if (g_cs && s3a_dict2pid_comsenscr(g_cs, ascr->senscr, g_n_sen, ascr->comsen) != S3A_OK)
+        die("dict2pid_comsenscr");
+    g_lv2_calls++;
+    return SRCH_SUCCESS;
+}
+
 static int
 s3amd_utt_begin(void *srch)
 {
@@ -97,21 +123,31 @@ s3amd_install(kb_t *kb)
     srch_t *s = (srch_t *)kb->srch;
     int composite_pass;
 
-    if (kbcore_mgau(kb->kbcore) == NULL)
-        E_FATAL("s3amd shim: only -senmgau .cont. models are supported\n");
+    if (kbcore_mgau(kb->kbcore) == NULL && kbcore_ms_mgau(kb->kbcore) == NULL)
+        E_FATAL("s3amd shim: only -senmgau .cont. / .s3cont. / .semi. models are supported\n");
     if (kbcore_svq(kb->kbcore) || kbcore_gs(kb->kbcore))
         E_FATAL("s3amd shim: sub-VQ / Gaussian selection are not supported (the GPU scores every component)\n");
     if (s3a_device_count() < 1)
         E_FATAL("s3amd shim: no GPU; libcmusphinx_amd has no CPU fallback\n");
 
     g_lm = s3a_logs3_init(cmd_ln_float64_r(config, "-logbase"), 0, 1);
+    g_n_sen = mdef_n_sen(mdef);
+    g_n_ci_sen = mdef->n_ci_sen;
+    if (kbcore_ms_mgau(kb->kbcore)) {
+        /* the same values ms_mgau_init receives in s3_am_init (kbcore.c:342-364) */
+        g_ms = s3a_ms_mgau_init(cmd_ln_str_r(config, "-mean"), cmd_ln_str_r(config, "-var"),
+                                cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
+                                cmd_ln_float32_r(config, "-mixwfloor"), 1, cmd_ln_str_r(config, "-senmgau"),
+                                cmd_ln_exists_r(config, "-lambda") ? cmd_ln_str_r(config, "-lambda") : NULL,
+                                cmd_ln_int32_r(config, "-topn"), g_lm);
+        if (!g_ms) die("s3a_ms_mgau_init");
+        goto composite;
+    }
     g_gm = s3a_mgau_init(cmd_ln_str_r(config, "-mean"), cmd_ln_str_r(config, "-var"),
                          cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
                          cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.",
                          S3A_MIX_INT_FLOAT_COMP, g_lm);
     if (!g_gm) die("s3a_mgau_init");
-    g_n_sen = mdef_n_sen(mdef);
-    g_n_ci_sen = mdef->n_ci_sen;
     /* the same values fast_gmm_init receives in kb_init (kb.c:218-231) */
     g_sc = s3a_scorer_init(g_gm, mdef->cd2cisen, g_n_sen, g_n_ci_sen,
                            cmd_ln_int32_r(config, "-ds"), cmd_ln_int32_r(config, "-cond_ds"),
@@ -120,6 +156,7 @@ s3amd_install(kb_t *kb)
                            cmd_ln_int32_r(config, "-maxcdsenpf"));
     if (!g_sc) die("s3a_scorer_init");
 
+composite:
     /* composite senones only where the reference's table computes them */
     composite_pass = (s->funcs->gmm_compute_lv2 == s3_cd_gmm_compute_sen_comp);
     if (composite_pass && d2p && d2p->n_comstate > 0) {
@@ -144,10 +181,16 @@ s3amd_install(kb_t *kb)
     }
 
     /* the three slots */
-    g_ref_utt_begin = s->funcs->utt_begin;
-    s->funcs->utt_begin = s3amd_utt_begin;
-    s->funcs->gmm_compute_lv1 = s3amd_gmm_compute_lv1;
-    s->funcs->gmm_compute_lv2 = s3amd_gmm_compute_lv2;
+    if (g_ms) {
+        /* gmm_compute_lv1 stays the reference's: it does nothing for multi-stream models (gmm_wrap.c:193-197) */
+        s->funcs->gmm_compute_lv2 = s3amd_ms_gmm_compute_lv2;
+    }
+    else {
+        g_ref_utt_begin = s->funcs->utt_begin;
+        s->funcs->utt_begin = s3amd_utt_begin;
+        s->funcs->gmm_compute_lv1 = s3amd_gmm_compute_lv1;
+        s->funcs->gmm_compute_lv2 = s3amd_gmm_compute_lv2;
+    }
     E_INFO("s3amd shim installed: %s, %d senones (%d CI), composite pass %s\n", s3a_version(),
            g_n_sen, g_n_ci_sen, g_cs ? "on device" : "none");
 }
@@ -178,6 +221,7 @@ main(int argc, char *argv[])
     if (g_lv2_calls == 0)
         E_FATAL("s3amd shim: the GPU scoring slots were never called\n");
     s3a_comsen_free(g_cs);
+    s3a_ms_mgau_free(g_ms);
     s3a_scorer_free(g_sc);
     s3a_mgau_free(g_gm);
     s3a_logmath_free(g_lm);

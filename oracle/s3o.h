@@ -204,6 +204,32 @@ void s3o_comsseq2sen_active(const int16_t *comsseq, int32_t n_comsseq, int32_t n
                             const uint8_t *comssid, uint8_t *sen);
 void s3o_lextree_utt_end(s3o_lextree_t *lt);
 
+/* ------------------------------------------------------------------ */
+/* multi-stream senone scorer (-senmgau .s3cont. / .semi.)             */
+/* sphinx3 libam/ms_gauden.c, ms_senone.c, ms_mgau.c                   */
+/* ------------------------------------------------------------------ */
+typedef struct s3o_ms_s {
+    int32_t n_mgau, n_feat, n_density, n_sen, topn, veclen;
+    int32_t *featlen, *featoff;     /* [n_feat], [n_feat + 1] */
+    float *mean, *var, *det;        /* file order [m][f][d][featlen f]; var = 1/(2 sigma^2); det [m][f][d] */
+    int32_t *pdf;                   /* [n_sen][n_feat][n_density]  -logs3(mixture weight) */
+    int32_t *mgau;                  /* [n_sen] codebook of each senone */
+    double min_density;
+    int32_t *dist_id, *dist;        /* [n_mgau][n_feat][topn] top-N of the last frame */
+    uint8_t *mgau_active;
+    const s3o_logmath_t *lm;
+} s3o_ms_t;
+
+/* ms_mgau_init (ms_mgau.c:149-227) minus the file parsing; sen2mgau == NULL is ".s3cont." */
+s3o_ms_t *s3o_ms_init(const float *mean, const float *var, const float *mixw, int32_t n_mgau,
+                      int32_t n_feat, int32_t n_density, const int32_t *featlen, int32_t n_sen,
+                      const int32_t *sen2mgau, double varfloor, double mixwfloor, int32_t topn,
+                      const s3o_logmath_t *lm);
+void s3o_ms_free(s3o_ms_t *ms);
+/* ms_cont_mgau_frame_eval (ms_mgau.c:242-329); feat = the streams concatenated */
+int32_t s3o_ms_cont_mgau_frame_eval(s3o_ms_t *ms, const uint8_t *sen_active, int32_t *senscr,
+                                    const float *feat);
+
 #ifdef __cplusplus
 }
 #endif

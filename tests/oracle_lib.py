@@ -508,3 +508,57 @@ _HMM_DT = np.dtype({"names": ["score", "history", "out_score", "out_history", "s
                                 Hmm.ssid.offset, Hmm.mpx_ssid.offset, Hmm.bestscore.offset, Hmm.tmatid.offset,
                                 Hmm.frame.offset, Hmm.mpx.offset],
                     "itemsize": C.sizeof(Hmm)})
+
+
+class Ms(C.Structure):
+    _fields_ = [("n_mgau", C.c_int32), ("n_feat", C.c_int32), ("n_density", C.c_int32), ("n_sen", C.c_int32),
+                ("topn", C.c_int32), ("veclen", C.c_int32), ("featlen", C.POINTER(C.c_int32)),
+                ("featoff", C.POINTER(C.c_int32)), ("mean", C.POINTER(C.c_float)), ("var", C.POINTER(C.c_float)),
+                ("det", C.POINTER(C.c_float)), ("pdf", C.POINTER(C.c_int32)), ("mgau", C.POINTER(C.c_int32)),
+                ("min_density", C.c_double), ("dist_id", C.POINTER(C.c_int32)), ("dist", C.POINTER(C.c_int32)),
+                ("mgau_active", C.POINTER(C.c_uint8)), ("lm", C.c_void_p)]
+
+
+class OracleMs:
+    """ms_mgau_init + ms_cont_mgau_frame_eval (-senmgau .s3cont. / .semi.) on raw arrays."""
+
+    def __init__(self, mean, var, mixw, n_mgau, n_density, featlen, lm: OracleLogMath, topn, sen2mgau=None,
+                 varfloor=1e-4, mixwfloor=1e-7):
+        L = self.L = lib()
+        self.lm = lm
+        L.s3o_ms_init.restype = C.POINTER(Ms)
+        L.s3o_ms_init.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p, C.c_int32, C.c_void_p,
+                                                                       C.c_double, C.c_double, C.c_int32, C.c_void_p]
+        L.s3o_ms_cont_mgau_frame_eval.restype = C.c_int32
+        L.s3o_ms_cont_mgau_frame_eval.argtypes = [C.POINTER(Ms), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.s3o_ms_free.argtypes = [C.POINTER(Ms)]
+        mean = np.ascontiguousarray(mean, np.float32).ravel(); var = np.ascontiguousarray(var, np.float32).ravel()
+        fl = np.ascontiguousarray(featlen, np.int32)
+        mixw = np.ascontiguousarray(mixw, np.float32)
+        self.n_sen = mixw.size // (len(fl) * n_density)
+        s2m = None if sen2mgau is None else np.ascontiguousarray(sen2mgau, np.int32)
+        self.p = L.s3o_ms_init(_p2(mean), _p2(var), _p2(mixw), n_mgau, len(fl), n_density, _p2(fl), self.n_sen,
+                               None if s2m is None else _p2(s2m), varfloor, mixwfloor, topn, lm.p)
+        self.senscr = np.zeros(self.n_sen, np.int32)
+
+    def __del__(self):
+        try:
+            self.L.s3o_ms_free(self.p)
+        except Exception:
+            pass
+
+    def arr(self, name, n, dt):
+        return np.ctypeslib.as_array(getattr(self.p.contents, name), shape=(n,)).astype(dt)
+
+    def frame_eval(self, sen_active, feat):
+        """Returns (best, senscr copy); sen_active uint8[S]."""
+        sa = np.ascontiguousarray(sen_active, np.uint8)
+        x = np.ascontiguousarray(feat, np.float32)
+        best = self.L.s3o_ms_cont_mgau_frame_eval(self.p, _p2(sa), _p2(self.senscr), _p2(x))
+        return best, self.senscr.copy()
+
+    def last_dist(self):
+        c = self.p.contents
+        n = c.n_mgau * c.n_feat * c.topn
+        shp = (c.n_mgau, c.n_feat, c.topn)
+        return self.arr("dist", n, np.int32).reshape(shp), self.arr("dist_id", n, np.int32).reshape(shp)

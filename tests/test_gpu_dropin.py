@@ -64,6 +64,20 @@ def test_reference_decoder_with_gpu_scoring_matches_reference(name, tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
+@pytest.mark.parametrize("topn", [4, 8])
+def test_multistream_scorer_dropin_matches_live_reference(topn, tmp_path):
+    """-senmgau .s3cont.: the reference routes gmm_compute_lv2 to ms_cont_mgau_frame_eval
+    (gauden_dist top-N + senone_eval); the shim serves that slot from s3a_ms_cont_mgau_frame_eval.
+    topn 4 = sorted top-N lists, topn 8 = all 8 densities in codeword order."""
+    extra = RUNS["mode4_trigram"] + ["-senmgau", ".s3cont.", "-topn", str(topn)]
+    ref_hyp, ref_seg, _ = run(REFDEC, extra, tmp_path, f"cpu_ms{topn}")
+    hyp, seg, tail = run(SHIM, extra, tmp_path, f"gpu_ms{topn}")
+    assert any("calls served by the GPU" in l for l in tail)
+    assert hyp == ref_hyp and seg == ref_seg
+    assert seg != open(os.path.join(D, "ref_mode4_trigram.matchseg")).read()       # really a different scorer
+
+
+@pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
 def test_live_cpu_reference_agrees_with_committed_golden(tmp_path):
     """The committed golden is what the reference produces on THIS box too."""
     hyp, seg, _ = run(REFDEC, RUNS["mode4_trigram"], tmp_path, "cpu_mode4")
