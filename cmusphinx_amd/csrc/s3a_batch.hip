@@ -1,0 +1,541 @@
+/*
+ * s3a_batch.hip -- B decoders per kernel launch: the fused frame of s3a_decoder.hip, batched.
+ *
+ * Why: one mode-4 search frame is ~11 dependent, latency-bound launches that leave the chip
+ * almost idle (a few thousand HMMs against 256 CUs); independent decoders on separate HIP
+ * streams overlap only as far as the 4 hardware queues HIP multiplexes them onto (measured:
+ * 4 streams 2.7x one stream, 8 and 16 streams no better).  Utterances are independent, so B
+ * decoders can share EVERY launch instead: the grid gets a z dimension (= the decoders that are
+ * ready), each workgroup reads its decoder's pointers from a descriptor table and its frame
+ * parameters (beams, frame number, this frame's lextree_enter calls, the feature vector) from a
+ * per-step array uploaded with one copy, and runs the very same kernel bodies
+ * (s3a_decoder_kernels.h, s3a_gated.h).  One synchronisation per STEP serves all B decoders.
+ *
+ * Host side: each decoder stays the reference's own single-threaded C (one kb_t, one host
+ * thread: vithist, LM, word transitions).  Per frame a thread records its lextree_enter calls
+ * (s3a_batch_transition: host only) and then calls s3a_batch_step with the frame's features and
+ * beams; the call blocks until every decoder that is inside an utterance has arrived, the last
+ * arrival runs the batch for all of them, and each thread returns with its own frame record.
+ * Decoders between utterances (backtrace, file I/O) are not waited for.  Per-decoder state is
+ * untouched by the batching, so the results are those of the single-decoder path -- which the
+ * tests check (tests/test_gpu_batch.py; the drop-in with S3A_BATCH=1).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <pthread.h>
+#include <vector>
+
+#include "s3a_device.h"
+#include "s3a_structs.h"
+#include "s3a_decoder_kernels.h"
+#include "s3a_gated.h"
+
+#define BMAXC 96            /* lextree_enter calls per decoder per frame (#CI phones + 1) */
+#define BMAXSLOT 256
+#define BFIRST 256          /* word exits copied with the frame record */
+
+struct BSlot {              /* one decoder: static model + its state, all device pointers */
+    int32_t N, T, n_tmat, maxn;
+    const int32_t *node_base, *ssid, *tmatid, *wid, *prob, *child_off, *child, *par_off, *par, *tree_of,
+        *rootlist, *tp;
+    const uint8_t *comp;
+    const int16_t *sseq, *comsseq;
+    int32_t *sc, *hist, *outs, *outh, *bests, *frame, *pos, *posf, *act[2], *nact[2], *turn, *selfemit,
+        *cnt, *base, *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0;
+    unsigned long long *key;
+    const int32_t *cs_off, *cs_wt;
+    const int16_t *cs_list;
+    const float4 *mean4, *prec4;
+    const float *lrd;
+    const int32_t *mixw;
+    const uint16_t *tab16;
+    uint32_t tab_size;
+    int32_t lm_zero;
+    double f, distfloor;
+    int32_t D4, CP, Gpad, n_sen, n_ci_sen;
+    const uint8_t *ncomp;
+    const int16_t *cd2cisen;
+    uint8_t *sen_act;
+    int32_t *scr, *misc, *bstidx, *bstscr, *updatetime;
+};
+
+struct BFrame {             /* one decoder's parameters for one step */
+    float feat[64];         /* first: 16-byte aligned for the kernels' float4 reads */
+    int32_t slot, cur;      /* cur = index of the list searched in this step */
+    int32_t cf, thresh, n_calls, n_ent, n_groups, pad0, groups[8];
+    int32_t frm, may_hist;
+    FrameBeams bm;
+    int32_t sc_frame, sc_beam, sc_is_skip, pad;
+    int32_t calls[4 * BMAXC];
+};
+
+/* ------------------------------------------------------------------ */
+#define SLOT_FRAME const BFrame &f = frames[blockIdx.z]; const BSlot &s = slots[f.slot]
+
+__global__ void
+kb_enter1(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    if ((int32_t)(blockIdx.x * blockDim.x) >= f.n_ent) return;
+    const Entries ent = { f.calls, s.rootlist, f.n_calls };
+    d_dec_enter1(ent, f.n_ent, f.calls, s.prob, s.sc, f.thresh, s.key, s.first, blockIdx.x, 0);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+kb_enter2(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    if ((int32_t)blockIdx.x >= f.n_calls || f.n_ent == 0) return;
+    const Entries ent = { f.calls, s.rootlist, f.n_calls };
+    d_dec_enter2(ent, f.n_ent, f.calls, s.prob, s.sc, s.frame, s.first, f.thresh, f.cf + 1, s.T, s.nact[f.cur],
+                 s.eflag, s.ctot, s.n0, blockIdx.x, 0);
+}
+
+__global__ void __launch_bounds__(DBLOCK)
+kb_enter3_mark(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    const int32_t n_ent_blocks = (f.n_ent + DBLOCK - 1) / DBLOCK, bpt = (s.maxn + DBLOCK - 1) / DBLOCK;
+    if ((int32_t)blockIdx.x >= n_ent_blocks + bpt * s.T) return;
+    const Entries ent = { f.calls, s.rootlist, f.n_calls };
+    d_dec_enter3_mark(n_ent_blocks, ent, f.n_ent, f.calls, f.groups, f.n_groups, f.cf + 1, s.key, s.first, s.eflag,
+                      s.ctot, f.n_ent > 0 ? s.n0 : s.nact[f.cur], s.sc, s.hist, s.frame, s.T, bpt, s.node_base,
+                      s.act[f.cur], s.nact[f.cur], s.pos, s.posf, s.ssid, s.comp, s.sseq, s.comsseq, s.cs_off,
+                      s.cs_list, s.sen_act, blockIdx.x, 0);
+}
+
+template <bool EXACT, bool CI>
+__global__ void __launch_bounds__(256)
+kb_gated(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    const int32_t lo = CI ? 0 : s.n_ci_sen, hi = CI ? s.n_ci_sen : s.n_sen;
+    if ((int32_t)(blockIdx.x * 256) >= (hi - lo) * s.CP) return;
+    d_gated_frame<EXACT>(s.mean4, s.prec4, s.lrd, s.mixw, s.tab16, s.tab_size, s.lm_zero, s.f, s.distfloor,
+                         f.feat, s.D4, s.CP, s.Gpad, lo, hi, CI ? 1 : 0, s.ncomp, s.cd2cisen, s.sen_act, s.scr,
+                         0, CI ? (const int32_t *)NULL : s.misc + 5, CI ? 0 : f.sc_beam, f.sc_frame,
+                         CI ? 0 : f.sc_is_skip, s.bstidx, s.bstscr, s.updatetime, s.misc, CI ? 5 : 0,
+                         CI ? (uint8_t *)NULL : s.sen_act, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(DBLOCK)
+kb_hmm_eval(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    if ((int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * DBLOCK) >= s.maxn) return;
+    d_dec_hmm_eval(s.node_base, s.act[f.cur], s.nact[f.cur], s.N, s.n_tmat, s.ssid, s.tmatid, s.wid, s.comp,
+                   s.tp, s.sseq, s.comsseq, s.cs_off, s.cs_list, s.cs_wt, s.scr, s.misc, s.sc, s.hist, s.outs,
+                   s.outh, s.bests, s.best, blockIdx.x, blockIdx.y);
+}
+
+__global__ void __launch_bounds__(DBLOCK)
+kb_hist_count(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    if (!f.may_hist || (int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * DBLOCK) >= s.maxn) return;
+    d_dec_hist_count(s.node_base, s.act[f.cur], s.nact[f.cur], s.T, f.bm, s.best, s.bests, s.exits + s.N, s.hbin,
+                     -1, 0, 1, NBIN, blockIdx.x, blockIdx.y);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+kb_hist_sort(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    if (!f.may_hist || (int32_t)blockIdx.x >= s.T) return;
+    d_dec_hist_sort(s.node_base, s.act[f.cur], s.nact[f.cur], s.T, f.bm, s.exits + s.N, s.exits, s.hbin, s.pos, -1,
+                    NBIN, blockIdx.x, 0);
+}
+
+__global__ void __launch_bounds__(DBLOCK)
+kb_resolve(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    if ((int32_t)(blockIdx.x * DBLOCK) >= s.N) return;
+    d_dec_resolve(s.N, s.T, f.frm, f.bm, s.best, s.nact[f.cur], s.node_base, s.tree_of, s.prob, s.par_off, s.par,
+                  s.pos, s.posf, s.sc, s.hist, s.outs, s.outh, s.bests, s.frame, s.turn, s.selfemit, s.cnt, s.key,
+                  s.first, s.hbin, blockIdx.x, 0);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+kb_scan(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int32_t *pack_all,
+        int32_t pack_stride, int32_t max_exits)
+{
+    SLOT_FRAME;
+    if ((int32_t)blockIdx.x >= s.T) return;
+    d_dec_scan(s.N, s.T, f.frm, f.bm, s.node_base, s.act[f.cur], s.nact[f.cur], s.wid, s.prob, s.outs, s.outh,
+               s.selfemit, s.cnt, s.base, s.act[f.cur ^ 1], s.nact[f.cur ^ 1], s.pos, s.posf, s.best, s.exits,
+               s.nexit, s.hbin, s.misc, s.done, pack_all + (size_t)blockIdx.z * pack_stride, max_exits,
+               blockIdx.x, 0);
+}
+
+__global__ void __launch_bounds__(DBLOCK)
+kb_emit(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    if ((int32_t)blockIdx.y >= s.T) return;
+    d_dec_emit(f.frm, s.node_base, s.act[f.cur], s.nact[f.cur], s.child_off, s.child, s.turn, s.selfemit, s.base,
+               s.act[f.cur ^ 1], s.nact[f.cur ^ 1], s.pos, s.posf, blockIdx.x, blockIdx.y);
+}
+
+/* ------------------------------------------------------------------ */
+struct BOut {
+    s3a_frame_result_t *res;
+    int32_t *n_exit, *wid, *scr, *hist, max_exits, frm, may_hist, rc;
+    char err[256];
+};
+
+struct s3a_batch_s {
+    int32_t max_slots, n_slots;
+    s3a_lexsearch_t *ls[BMAXSLOT];
+    s3a_scorer_t *sc[BMAXSLOT];
+    s3a_comsen_t *cs[BMAXSLOT];
+    BSlot *d_slots;
+    BFrame *d_frames, *h_frames;        /* device / pinned host, [max_slots] */
+    BFrame stage[BMAXSLOT];             /* per slot: pending transition + this frame's request */
+    BOut out[BMAXSLOT];
+    uint8_t has_trans[BMAXSLOT], active[BMAXSLOT], arrived[BMAXSLOT];
+    int32_t n_active, n_arrived, order[BMAXSLOT];
+    int32_t *d_pack, *h_pack, pack_stride, pack_max_exits, hdr_max;
+    int32_t g_ent, g_ci, g_cd, g_maxn, g_N, g_T, g_mark, g_tmat, exact;
+    unsigned long long gen;
+    long steps, slot_frames;
+    hipStream_t stream;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+};
+
+extern "C" s3a_batch_t *
+s3a_batch_create(int32_t max_slots)
+{
+    if (max_slots <= 0 || max_slots > BMAXSLOT) { s3a_set_error("s3a_batch_create: 1..%d slots", BMAXSLOT); return NULL; }
+    s3a_batch_t *b = new s3a_batch_s();
+    memset((void *)b, 0, sizeof *b);
+    b->max_slots = max_slots;
+    pthread_mutex_init(&b->mu, NULL);
+    pthread_cond_init(&b->cv, NULL);
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess
+        || hipMalloc((void **)&b->d_slots, sizeof(BSlot) * max_slots) != hipSuccess
+        || hipMalloc((void **)&b->d_frames, sizeof(BFrame) * max_slots) != hipSuccess
+        || hipHostMalloc((void **)&b->h_frames, sizeof(BFrame) * max_slots) != hipSuccess) {
+        s3a_set_error("s3a_batch_create: no usable HIP device (libcmusphinx_amd has no CPU fallback)");
+        delete b;
+        return NULL;
+    }
+    return b;
+}
+
+extern "C" void
+s3a_batch_free(s3a_batch_t *b)
+{
+    if (!b) return;
+    (void)hipStreamSynchronize(b->stream);
+    (void)hipFree(b->d_slots); (void)hipFree(b->d_frames); (void)hipHostFree(b->h_frames);
+    if (b->d_pack) (void)hipFree(b->d_pack);
+    if (b->h_pack) (void)hipHostFree(b->h_pack);
+    /* the attached decoders now own a dead stream handle: they must be freed by their owners
+     * WITHOUT further use; their own streams were replaced at attach time */
+    pthread_mutex_destroy(&b->mu);
+    pthread_cond_destroy(&b->cv);
+    delete b;
+}
+
+/* Attach a decoder (its lextrees, scorer and composite table).  All its work from now on is
+ * ordered on the engine's stream. */
+extern "C" int32_t
+s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs)
+{
+    if (!b || !ls || !sc || !cs) return S3A_EINVAL;
+    pthread_mutex_lock(&b->mu);
+    int32_t rc = S3A_OK, slot = b->n_slots;
+    struct s3a_mgau_dev_s *d = sc->g->dev;
+    do {
+        if (slot >= b->max_slots) { s3a_set_error("s3a_batch_attach: all %d slots taken", b->max_slots); rc = S3A_EINVAL; break; }
+        if (d->tab16 == NULL) { s3a_set_error("s3a_batch_attach: 32-bit log-add tables are not supported"); rc = S3A_EUNSUP; break; }
+        if (d->D4 * 4 > 64) { s3a_set_error("s3a_batch_attach: feature vectors longer than 64 are not supported"); rc = S3A_EUNSUP; break; }
+        if (sc->max_cd < sc->n_sen - sc->n_ci_sen) { s3a_set_error("s3a_batch_attach: -maxcdsenpf needs the host-pointer scorer"); rc = S3A_EUNSUP; break; }
+        if (slot > 0 && (sc->g->precision == S3A_GMM_EXACT) != (b->exact != 0)) {
+            s3a_set_error("s3a_batch_attach: all decoders must use the same GMM precision"); rc = S3A_EINVAL; break;
+        }
+        /* whatever the decoder enqueued on its own streams so far (uploads, resets) must be done */
+        if (hipStreamSynchronize(ls->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) { rc = S3A_EHIP; break; }
+        ls->stream = b->stream;         /* (the replaced stream objects stay allocated: harmless) */
+        ls->own_stream = 0;
+        d->stream = b->stream;
+        cs->stream = b->stream;
+        int32_t maxn = 0;
+        for (int32_t t = 0; t < ls->n_tree; t++) maxn = max(maxn, ls->node_base[t + 1] - ls->node_base[t]);
+        BSlot s;
+        memset((void *)&s, 0, sizeof s);
+        s.N = ls->N; s.T = ls->n_tree; s.n_tmat = ls->n_tmat; s.maxn = maxn;
+        s.node_base = ls->d_node_base; s.ssid = ls->d_ssid; s.tmatid = ls->d_tmatid; s.wid = ls->d_wid;
+        s.prob = ls->d_prob; s.child_off = ls->d_child_off; s.child = ls->d_child; s.par_off = ls->d_par_off;
+        s.par = ls->d_par; s.tree_of = ls->d_tree_of; s.rootlist = ls->d_rootlist; s.tp = ls->d_tp;
+        s.comp = ls->d_comp; s.sseq = ls->d_sseq; s.comsseq = ls->d_comsseq;
+        s.sc = ls->d_sc; s.hist = ls->d_hist; s.outs = ls->d_outs; s.outh = ls->d_outh; s.bests = ls->d_bests;
+        s.frame = ls->d_frame; s.pos = ls->d_pos; s.posf = ls->d_posf; s.act[0] = ls->d_act[0]; s.act[1] = ls->d_act[1];
+        s.nact[0] = ls->d_nact[0]; s.nact[1] = ls->d_nact[1]; s.turn = ls->d_turn; s.selfemit = ls->d_selfemit;
+        s.cnt = ls->d_cnt; s.base = ls->d_cand; s.best = ls->d_best; s.exits = ls->d_exit; s.nexit = ls->d_nexit;
+        s.first = ls->d_first; s.eflag = ls->d_eflag; s.hbin = ls->d_hbin; s.done = ls->d_done; s.key = ls->d_key;
+        s.ctot = ls->d_ctot; s.n0 = ls->d_n0;
+        s.cs_off = cs->off_d; s.cs_wt = cs->wt_d; s.cs_list = cs->list_d;
+        s.mean4 = d->mean4; s.prec4 = d->prec4; s.lrd = d->lrd; s.mixw = d->mixw; s.tab16 = d->tab16;
+        s.tab_size = d->tab_size; s.lm_zero = d->lm_zero; s.f = sc->g->f; s.distfloor = sc->g->distfloor;
+        s.D4 = d->D4; s.CP = d->CP; s.Gpad = d->Gpad; s.n_sen = sc->n_sen; s.n_ci_sen = sc->n_ci_sen;
+        s.ncomp = sc->ncomp_d; s.cd2cisen = sc->cd2cisen_d; s.sen_act = sc->act_d; s.scr = sc->scr_d;
+        s.misc = sc->misc_d; s.bstidx = d->bstidx; s.bstscr = d->bstscr; s.updatetime = d->updatetime;
+        if (hipMemcpy(b->d_slots + slot, &s, sizeof s, hipMemcpyHostToDevice) != hipSuccess) { rc = S3A_EHIP; break; }
+        b->ls[slot] = ls; b->sc[slot] = sc; b->cs[slot] = cs;
+        b->exact = sc->g->precision == S3A_GMM_EXACT;
+        /* launch geometry = the maximum over the attached decoders */
+        b->g_ci = max(b->g_ci, (s.n_ci_sen * s.CP + 255) / 256);
+        b->g_cd = max(b->g_cd, ((s.n_sen - s.n_ci_sen) * s.CP + 255) / 256);
+        b->g_maxn = max(b->g_maxn, maxn); b->g_N = max(b->g_N, s.N); b->g_T = max(b->g_T, s.T);
+        b->g_ent = max(b->g_ent, (ls->ent_cap + 255) / 256);
+        b->g_mark = max(b->g_mark, (ls->ent_cap + DBLOCK - 1) / DBLOCK + ((maxn + DBLOCK - 1) / DBLOCK) * s.T);
+        b->g_tmat = max(b->g_tmat, s.n_tmat);
+        const int32_t hdr = 6 * s.T + 16;
+        if (hdr > b->hdr_max || ls->pack_max_exits > b->pack_max_exits) {
+            if (b->d_pack) { (void)hipFree(b->d_pack); (void)hipHostFree(b->h_pack); }
+            b->hdr_max = max(b->hdr_max, hdr);
+            b->pack_max_exits = max(b->pack_max_exits, ls->pack_max_exits);
+            b->pack_stride = b->hdr_max + 3 * b->pack_max_exits;
+            if (hipMalloc((void **)&b->d_pack, (size_t)b->pack_stride * b->max_slots * 4) != hipSuccess
+                || hipHostMalloc((void **)&b->h_pack, (size_t)b->pack_stride * b->max_slots * 4) != hipSuccess) { rc = S3A_EHIP; break; }
+        }
+        b->n_slots++;
+    } while (0);
+    pthread_mutex_unlock(&b->mu);
+    return rc == S3A_OK ? slot : rc;
+}
+
+/* run one step for every arrived decoder; called with the lock held */
+static int32_t
+run_batch(s3a_batch_t *b)
+{
+    const int32_t n = b->n_arrived;
+    int32_t any_hist = 0, g_ent = 0, g_calls = 0, rc = S3A_OK;
+    for (int32_t z = 0; z < n; z++) {
+        const int32_t slot = b->order[z];
+        b->h_frames[z] = b->stage[slot];
+        any_hist |= b->stage[slot].may_hist;
+        g_ent = max(g_ent, (b->stage[slot].n_ent + 255) / 256);
+        g_calls = max(g_calls, b->stage[slot].n_calls);
+    }
+#define CHK(expr) do { if ((expr) != hipSuccess) { s3a_set_error("s3a_batch: %s failed: %s", #expr, hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; goto done; } } while (0)
+    {
+        hipStream_t st = b->stream;
+        const BSlot *S = b->d_slots;
+        const BFrame *F = b->d_frames;
+        CHK(hipMemcpyAsync(b->d_frames, b->h_frames, sizeof(BFrame) * n, hipMemcpyHostToDevice, st));
+        if (g_ent > 0) {
+            hipLaunchKernelGGL(kb_enter1, dim3(g_ent, 1, n), dim3(256), 0, st, S, F);
+            hipLaunchKernelGGL(kb_enter2, dim3(g_calls, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
+        }
+        hipLaunchKernelGGL(kb_enter3_mark, dim3(g_ent * (256 / DBLOCK) + ((b->g_maxn + DBLOCK - 1) / DBLOCK) * b->g_T, 1, n),
+                           dim3(DBLOCK), 0, st, S, F);
+        if (b->exact) {
+            if (b->g_ci) hipLaunchKernelGGL((kb_gated<true, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
+            if (b->g_cd) hipLaunchKernelGGL((kb_gated<true, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
+        }
+        else {
+            if (b->g_ci) hipLaunchKernelGGL((kb_gated<false, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
+            if (b->g_cd) hipLaunchKernelGGL((kb_gated<false, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
+        }
+        hipLaunchKernelGGL(kb_hmm_eval, dim3((b->g_maxn + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK),
+                           (size_t)b->g_tmat * 12 * 4, st, S, F);
+        if (any_hist) {
+            hipLaunchKernelGGL(kb_hist_count, dim3((b->g_maxn + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
+            hipLaunchKernelGGL(kb_hist_sort, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
+        }
+        hipLaunchKernelGGL(kb_resolve, dim3((b->g_N + DBLOCK - 1) / DBLOCK, 1, n), dim3(DBLOCK), 0, st, S, F);
+        hipLaunchKernelGGL(kb_scan, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F, b->d_pack, b->pack_stride,
+                           b->pack_max_exits);
+        hipLaunchKernelGGL(kb_emit, dim3(EMIT_BLOCKS, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
+        CHK(hipGetLastError());
+        /* the records (header + the first exits) of all decoders: one strided copy */
+        CHK(hipMemcpy2DAsync(b->h_pack, (size_t)b->pack_stride * 4, b->d_pack, (size_t)b->pack_stride * 4,
+                             (size_t)(b->hdr_max + 3 * BFIRST) * 4, n, hipMemcpyDeviceToHost, st));
+        CHK(hipStreamSynchronize(st));
+        for (int32_t z = 0; z < n; z++) {
+            const int32_t slot = b->order[z];
+            s3a_lexsearch_t *ls = b->ls[slot];
+            BOut &o = b->out[slot];
+            const int32_t *p = b->h_pack + (size_t)z * b->pack_stride, hdr = 6 * ls->n_tree + 16;
+            int32_t total = 0;
+            o.rc = s3a_dec_unpack(ls, p, o.may_hist != 0, o.frm, o.res, o.n_exit, o.max_exits, &total);
+            if (o.rc != S3A_OK) { strncpy(o.err, s3a_last_error(), sizeof o.err - 1); continue; }
+            if (total > BFIRST) {
+                CHK(hipMemcpyAsync(b->h_pack + (size_t)z * b->pack_stride + hdr + 3 * BFIRST,
+                                   b->d_pack + (size_t)z * b->pack_stride + hdr + 3 * BFIRST,
+                                   (size_t)3 * (total - BFIRST) * 4, hipMemcpyDeviceToHost, st));
+                CHK(hipStreamSynchronize(st));
+            }
+            for (int32_t k = 0; k < total; k++) {
+                o.wid[k] = p[hdr + 3 * k]; o.scr[k] = p[hdr + 3 * k + 1]; o.hist[k] = p[hdr + 3 * k + 2];
+            }
+        }
+    }
+done:
+    if (rc != S3A_OK)
+        for (int32_t z = 0; z < n; z++) { BOut &o = b->out[b->order[z]]; o.rc = rc; strncpy(o.err, s3a_last_error(), sizeof o.err - 1); }
+    b->steps++;
+    b->slot_frames += n;
+    for (int32_t z = 0; z < n; z++) b->arrived[b->order[z]] = 0;
+    b->n_arrived = 0;
+    b->gen++;
+    pthread_cond_broadcast(&b->cv);
+    return rc;
+#undef CHK
+}
+
+/* srch_TST_begin's device side for one decoder; the decoder now takes part in the steps */
+extern "C" int32_t
+s3a_batch_utt_begin(s3a_batch_t *b, int32_t slot)
+{
+    if (!b || slot < 0 || slot >= b->n_slots) return S3A_EINVAL;
+    pthread_mutex_lock(&b->mu);
+    int32_t rc = s3a_decoder_utt_begin(b->ls[slot], b->sc[slot]);
+    if (rc == S3A_OK && !b->active[slot]) { b->active[slot] = 1; b->n_active++; }
+    b->has_trans[slot] = 0;
+    pthread_mutex_unlock(&b->mu);
+    return rc;
+}
+
+/* lextree_utt_end: the decoder leaves the steps (its last recorded transition is dropped: the
+ * reference swaps and then clears those lists anyway) */
+extern "C" int32_t
+s3a_batch_utt_end(s3a_batch_t *b, int32_t slot)
+{
+    if (!b || slot < 0 || slot >= b->n_slots) return S3A_EINVAL;
+    pthread_mutex_lock(&b->mu);
+    int32_t rc = s3a_lexsearch_utt_end(b->ls[slot]);
+    if (b->active[slot]) { b->active[slot] = 0; b->n_active--; }
+    b->has_trans[slot] = 0;
+    if (b->n_arrived > 0 && b->n_arrived == b->n_active)
+        (void)run_batch(b);             /* the others were only waiting for this decoder */
+    pthread_mutex_unlock(&b->mu);
+    return rc;
+}
+
+/* record this frame's lextree_enter calls + the swap (host only; executed by the next step) */
+extern "C" int32_t
+s3a_batch_transition(s3a_batch_t *b, int32_t slot, int32_t cf, int32_t thresh, int32_t tree_a, int32_t n_a,
+                     const int32_t *lc_a, const int32_t *scr_a, const int32_t *hist_a, int32_t tree_b,
+                     int32_t n_b, const int32_t *lc_b, const int32_t *scr_b, const int32_t *hist_b)
+{
+    if (!b || slot < 0 || slot >= b->n_slots) return S3A_EINVAL;
+    BFrame &f = b->stage[slot];
+    if (b->has_trans[slot]) { s3a_set_error("s3a_batch_transition: two transitions without a step"); return S3A_EINVAL; }
+    int32_t rc = s3a_dec_stage_calls(b->ls[slot], tree_a, n_a, lc_a, scr_a, hist_a, tree_b, n_b, lc_b, scr_b,
+                                     hist_b, f.groups, f.calls, BMAXC, &f.n_calls, &f.n_ent, &f.n_groups);
+    if (rc != S3A_OK) return rc;
+    f.cf = cf; f.thresh = thresh;
+    b->ls[slot]->cur ^= 1;              /* lextree_active_swap */
+    b->has_trans[slot] = 1;
+    return S3A_OK;
+}
+
+static int32_t
+submit(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, int32_t frm, int32_t hmmbeam,
+       int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam, int32_t maxhmmpf, s3a_frame_result_t *res,
+       int32_t *n_exit, int32_t *exit_wid, int32_t *exit_score, int32_t *exit_hist, int32_t max_exits)
+{
+    if (!b || slot < 0 || slot >= b->n_slots || !feat || !res || !n_exit || !exit_wid || !exit_score || !exit_hist)
+        return S3A_EINVAL;
+    s3a_lexsearch_t *ls = b->ls[slot];
+    s3a_scorer_t *sc = b->sc[slot];
+    BFrame &f = b->stage[slot];
+    if (!b->active[slot] || !b->has_trans[slot]) {
+        s3a_set_error("s3a_batch_step: slot %d needs utt_begin and a transition before every step", slot);
+        return S3A_EINVAL;
+    }
+    if (pbeam < hmmbeam) { s3a_set_error("s3a_batch_step: -pbeam wider than -beam is not supported"); return S3A_EUNSUP; }
+    f.slot = slot; f.cur = ls->cur; f.frm = frm;
+    f.bm.hmmbeam = hmmbeam; f.bm.pbeam = pbeam; f.bm.wbeam = wbeam; f.bm.phone_uses_wbeam = phone_uses_wbeam;
+    f.bm.maxhmmpf = maxhmmpf;
+    f.may_hist = ls->hist_bound > maxhmmpf + (maxhmmpf >> 1);
+    if (f.may_hist && -hmmbeam / NBIN == 0) { s3a_set_error("s3a_batch_step: -beam too narrow for histogram pruning"); return S3A_EUNSUP; }
+    f.sc_frame = frame;
+    f.sc_is_skip = (frame % sc->ds_ratio == 0) ? 0 : 1;
+    f.sc_beam = f.sc_is_skip ? (int32_t)((float)sc->ci_pbeam * sc->tighten_factor) : sc->ci_pbeam;
+    memset(f.feat, 0, sizeof f.feat);
+    memcpy(f.feat, feat, sizeof(float) * sc->g->veclen);
+    BOut &o = b->out[slot];
+    o.res = res; o.n_exit = n_exit; o.wid = exit_wid; o.scr = exit_score; o.hist = exit_hist;
+    o.max_exits = max_exits; o.frm = frm; o.may_hist = f.may_hist; o.rc = S3A_OK; o.err[0] = 0;
+    b->has_trans[slot] = 0;
+    b->order[b->n_arrived++] = slot;
+    b->arrived[slot] = 1;
+    return S3A_OK;
+}
+
+/* gmm_compute_lv1/lv2 + hmm_compute_lv2 + propagate_graph_ph_lv2 + the word-exit half of
+ * propagate_graph_wd_lv2 for this decoder's frame -- executed together with the same frame step
+ * of every other decoder inside an utterance.  Blocks until the step has run. */
+extern "C" int32_t
+s3a_batch_step(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, int32_t frm, int32_t hmmbeam,
+               int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam, int32_t maxhmmpf,
+               s3a_frame_result_t *res, int32_t *n_exit, int32_t *exit_wid, int32_t *exit_score,
+               int32_t *exit_hist, int32_t max_exits)
+{
+    if (!b) return S3A_EINVAL;
+    pthread_mutex_lock(&b->mu);
+    int32_t rc = submit(b, slot, feat, frame, frm, hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf, res, n_exit,
+                        exit_wid, exit_score, exit_hist, max_exits);
+    if (rc == S3A_OK) {
+        const unsigned long long my_gen = b->gen;
+        if (b->n_arrived == b->n_active)
+            (void)run_batch(b);
+        else
+            while (b->gen == my_gen) pthread_cond_wait(&b->cv, &b->mu);
+        rc = b->out[slot].rc;
+        if (rc != S3A_OK) s3a_set_error("%s", b->out[slot].err);
+    }
+    pthread_mutex_unlock(&b->mu);
+    return rc;
+}
+
+/* single-threaded drivers (tests): submit every active decoder's frame, then run the step */
+extern "C" int32_t
+s3a_batch_submit(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, int32_t frm, int32_t hmmbeam,
+                 int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam, int32_t maxhmmpf,
+                 s3a_frame_result_t *res, int32_t *n_exit, int32_t *exit_wid, int32_t *exit_score,
+                 int32_t *exit_hist, int32_t max_exits)
+{
+    if (!b) return S3A_EINVAL;
+    pthread_mutex_lock(&b->mu);
+    int32_t rc = submit(b, slot, feat, frame, frm, hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf, res, n_exit,
+                        exit_wid, exit_score, exit_hist, max_exits);
+    pthread_mutex_unlock(&b->mu);
+    return rc;
+}
+
+extern "C" int32_t
+s3a_batch_run(s3a_batch_t *b)
+{
+    if (!b) return S3A_EINVAL;
+    pthread_mutex_lock(&b->mu);
+    int32_t rc = S3A_OK;
+    if (b->n_arrived > 0) {
+        rc = run_batch(b);
+        for (int32_t s = 0; rc == S3A_OK && s < b->n_slots; s++)
+            if (b->out[s].rc != S3A_OK) { rc = b->out[s].rc; s3a_set_error("%s", b->out[s].err); }
+    }
+    pthread_mutex_unlock(&b->mu);
+    return rc;
+}
+
+/* steps run so far and decoder-frames they served (mean batch size = frames / steps) */
+extern "C" int32_t
+s3a_batch_stats(s3a_batch_t *b, int64_t *steps, int64_t *slot_frames)
+{
+    if (!b) return S3A_EINVAL;
+    pthread_mutex_lock(&b->mu);
+    if (steps) *steps = b->steps;
+    if (slot_frames) *slot_frames = b->slot_frames;
+    pthread_mutex_unlock(&b->mu);
+    return S3A_OK;
+}

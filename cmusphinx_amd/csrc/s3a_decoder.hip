@@ -42,44 +42,9 @@
 #include "s3a_structs.h"
 #include "s3a_vit.h"
 #include "s3a_scan.h"
+#include "s3a_decoder_kernels.h"
 
-#define WORST S3A_WORST
-#define DBLOCK 256
-
-struct FrameBeams {
-    int32_t hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf;
-};
-
-#define NBIN 1000        /* srch_time_switch_tree.c:858 */
-
-/* thresholds of srch_TST_hmm_compute_lv2 (srch_time_switch_tree.c:849-905) from the per-tree
- * maxima hmm_eval left in best[]; when the frame holds more than 1.5 x maxhmmpf HMMs the
- * beam found by the histogram kernels (hbin[NBIN]) replaces -beam and bounds the others */
-__device__ __forceinline__ bool
-frame_thresholds(const int32_t *best, const int32_t *nact, int32_t T, const FrameBeams &bm,
-                 const int32_t *hbin, int32_t &bh, int32_t &bw, int32_t &n, int32_t &th,
-                 int32_t &pth, int32_t &wth)
-{
-    bh = INT_MIN; bw = INT_MIN; n = 0;
-    for (int32_t t = 0; t < T; t++) {
-        bh = max(bh, best[2 * t]);
-        bw = max(bw, best[2 * t + 1]);
-        n += nact[t];
-    }
-    int32_t hb = bm.hmmbeam, pb = bm.pbeam, wb = bm.wbeam;
-    const bool hist = n > bm.maxhmmpf + (bm.maxhmmpf >> 1);
-    if (hist) {
-        hb = hbin[NBIN];
-        pb = max(hb, pb);
-        wb = max(hb, wb);
-    }
-    th = add32(bh, hb);
-    wth = add32(bw, wb);
-    pth = bm.phone_uses_wbeam ? wth : add32(bh, pb);
-    return hist;
-}
-
-/* ------------------------------------------------------------------ */
+/* thin kernels over the shared bodies (s3a_decoder_kernels.h) */
 __global__ void __launch_bounds__(DBLOCK)
 k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
                const int32_t *__restrict__ nact, int32_t N, int32_t n_tmat,
@@ -92,72 +57,9 @@ k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
                int32_t *best_out)
 {
-    extern __shared__ int32_t tp_s[];
-    __shared__ int32_t red[2][DBLOCK / 64];
-    for (int32_t i = threadIdx.x; i < n_tmat * 12; i += DBLOCK)
-        tp_s[i] = tp_g[i];
-    __syncthreads();
-    const int32_t t = blockIdx.y, i = blockIdx.x * DBLOCK + threadIdx.x;
-    const int32_t norm = max(misc[0], misc[5]);         /* the frame's normaliser */
-    int32_t best = INT_MIN, wbest = INT_MIN;
-    if (i < nact[t]) {
-        const int32_t v = act[node_base[t] + i], ss = ssid[v];
-        HmmRegsT<int32_t> r;
-        int32_t e[3];
-        if (comp[v]) {
-#pragma unroll
-            for (int st = 0; st < 3; st++) {
-                const int32_t cs = comsseq[ss * 3 + st];
-                int32_t m = raw[cs_list[cs_off[cs]]];
-                for (int32_t j = cs_off[cs] + 1; j < cs_off[cs + 1]; j++)
-                    m = max(m, raw[cs_list[j]]);
-                e[st] = add32(add32(m, -norm), cs_wt[cs]);
-            }
-        }
-        else {
-#pragma unroll
-            for (int st = 0; st < 3; st++)
-                e[st] = add32(raw[sseq[ss * 3 + st]], -norm);
-        }
-#pragma unroll
-        for (int st = 0; st < 3; st++) { r.s[st] = sc[st * N + v]; r.h[st] = hist[st * N + v]; }
-        r.out = outs[v];
-        r.outh = outh[v];
-        const int32_t k = vit3(r, tp_s + tmatid[v] * 12, e[0], e[1], e[2]);
-#pragma unroll
-        for (int st = 0; st < 3; st++) { sc[st * N + v] = r.s[st]; hist[st * N + v] = r.h[st]; }
-        outs[v] = r.out;
-        outh[v] = r.outh;
-        bests[v] = k;
-        best = k;
-        if (wid[v] >= 0) wbest = k;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        best = max(best, __shfl_xor(best, o, 64));
-        wbest = max(wbest, __shfl_xor(wbest, o, 64));
-    }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = best; red[1][threadIdx.x >> 6] = wbest; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 0; w < DBLOCK / 64; w++) { best = max(best, red[0][w]); wbest = max(wbest, red[1][w]); }
-        if (best != INT_MIN) atomicMax(&best_out[2 * t], best);
-        if (wbest != INT_MIN) atomicMax(&best_out[2 * t + 1], wbest);
-    }
+    d_dec_hmm_eval(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, blockIdx.x, blockIdx.y);
 }
 
-/* ------------------------------------------------------------------ */
-/*
- * lextree_hmm_histbin (lextree.c:1314-1358) + the bin scan of srch_TST_hmm_compute_lv2
- * (srch_time_switch_tree.c:870-892).  Two side effects matter: the bins (they fix the
- * frame's beam) and the ORDER of every tree's active list afterwards -- the reference
- * rebuilds the list bin by bin, and within a bin in reverse insertion order (glist_add_ptr
- * prepends), which later decides ties in the propagation.  Kernel 1 bins every active HMM
- * (LDS-private histogram per workgroup); kernel 2, one workgroup per tree, finds the beam
- * and performs that stable reordering as a counting sort whose ranks are computed in list
- * order (wave-level peeling + per-wave bin counts).  Both return at once unless the frame
- * is over 1.5 x maxhmmpf (or `force`: the stand-alone entry point).
- */
 __global__ void __launch_bounds__(DBLOCK)
 k_dec_hist_count(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
                  const int32_t *__restrict__ nact, int32_t T, FrameBeams bm,
@@ -165,49 +67,7 @@ k_dec_hist_count(const int32_t *__restrict__ node_base, const int32_t *__restric
                  int32_t *binof, int32_t *hbin, int32_t force_tree, int32_t fbest, int32_t fbw,
                  int32_t nbin)
 {
-    __shared__ int32_t s_bin[NBIN];
-    __shared__ int32_t s_go, s_bh, s_bw;
-    const int32_t t = blockIdx.y;
-    if (threadIdx.x == 0) {
-        int32_t bh = INT_MIN, n = 0;
-        for (int32_t k = 0; k < T; k++) { bh = max(bh, best[2 * k]); n += nact[k]; }
-        if (force_tree >= 0) { s_go = (t == force_tree); s_bh = fbest; s_bw = fbw; }
-        else { s_go = n > bm.maxhmmpf + (bm.maxhmmpf >> 1); s_bh = bh; s_bw = -bm.hmmbeam / NBIN; }
-    }
-    __syncthreads();
-    if (!s_go) return;
-    for (int32_t i = threadIdx.x; i < nbin; i += DBLOCK) s_bin[i] = 0;
-    __syncthreads();
-    const int32_t i = blockIdx.x * DBLOCK + threadIdx.x, b = node_base[t];
-    if (i < nact[t]) {
-        int32_t k = (s_bh - bests[act[b + i]]) / s_bw;
-        if (k >= nbin) k = nbin - 1;
-        if (k < 0) k = 0;               /* cannot happen with bestscr = the frame's maximum */
-        binof[b + i] = k;
-        atomicAdd(&s_bin[k], 1);
-    }
-    __syncthreads();
-    for (int32_t k = threadIdx.x; k < nbin; k += DBLOCK)
-        if (s_bin[k]) atomicAdd(&hbin[k], s_bin[k]);
-}
-
-/* inclusive prefix sum over the SCAN_THREADS values of one workgroup */
-__device__ __forceinline__ int32_t
-block_inclusive_sum(int32_t x, int32_t *wsum /* [SCAN_THREADS / 64] shared */)
-{
-    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t incl = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int32_t y = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += y;
-    }
-    __syncthreads();
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int32_t add = 0;
-    for (int32_t w = 0; w < wave; w++) add += wsum[w];
-    return incl + add;
+    d_dec_hist_count(node_base, act, nact, T, bm, best, bests, binof, hbin, force_tree, fbest, fbw, nbin, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -215,85 +75,9 @@ k_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32
                 int32_t T, FrameBeams bm, const int32_t *__restrict__ binof, int32_t *tmp,
                 int32_t *hbin, int32_t *pos, int32_t force_tree, int32_t nbin)
 {
-    __shared__ int32_t s_cnt[NBIN], s_base[NBIN], s_run[NBIN];
-    __shared__ uint16_t s_cntw[SCAN_THREADS / 64][NBIN];
-    __shared__ int32_t s_wsum[SCAN_THREADS / 64];
-    __shared__ int32_t s_go, s_i;
-    const int32_t t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {
-        int32_t n = 0;
-        for (int32_t k = 0; k < T; k++) n += nact[k];
-        s_go = force_tree >= 0 ? (t == force_tree) : (n > bm.maxhmmpf + (bm.maxhmmpf >> 1));
-        s_i = nbin;
-    }
-    __syncthreads();
-    if (!s_go) return;
-    if (force_tree < 0) {
-        /* for (i = 0, j = 0; i < nbin && j < maxhmmpf; i++, j += bin[i]);  -- bin[0] is never
-         * counted and the read of bin[nbin] after the last increment decides nothing */
-        const int32_t x = (tid >= 1 && tid < nbin) ? hbin[tid] : 0;
-        const int32_t J = block_inclusive_sum(x, s_wsum);       /* j after i reached tid */
-        if (tid < nbin && J >= bm.maxhmmpf) atomicMin(&s_i, bm.maxhmmpf <= 0 ? 0 : tid);
-        __syncthreads();
-        if (t == 0 && tid == 0) hbin[NBIN] = -(s_i * (-bm.hmmbeam / NBIN));
-    }
-    /* this tree's own bin counts and bin bases */
-    const int32_t b = node_base[t], na = nact[t];
-    for (int32_t k = tid; k < nbin; k += SCAN_THREADS) { s_cnt[k] = 0; s_run[k] = 0; }
-    for (int32_t k = tid; k < (SCAN_THREADS / 64) * NBIN; k += SCAN_THREADS) (&s_cntw[0][0])[k] = 0;
-    __syncthreads();
-    for (int32_t i = tid; i < na; i += SCAN_THREADS) atomicAdd(&s_cnt[binof[b + i]], 1);
-    __syncthreads();
-    {
-        const int32_t x = tid < nbin ? s_cnt[tid] : 0;
-        const int32_t incl = block_inclusive_sum(x, s_wsum);
-        if (tid < nbin) s_base[tid] = incl - x;
-    }
-    __syncthreads();
-    for (int32_t c0 = 0; c0 < na; c0 += SCAN_THREADS) {
-        const int32_t i = c0 + tid;
-        const bool valid = i < na;
-        const int32_t k = valid ? binof[b + i] : -1;
-        int32_t rank = 0, tot = 0;
-        bool leader = false;
-        unsigned long long remaining = __ballot(valid);
-        while (remaining) {                                     /* wave-uniform */
-            const int src = __ffsll((long long)remaining) - 1;
-            const int32_t kb = __shfl(k, src, 64);
-            const unsigned long long m = __ballot(valid && k == kb);
-            if (valid && k == kb) {
-                rank = __popcll(m & ((1ull << lane) - 1ull));
-                tot = __popcll(m);
-                leader = (lane == src);
-            }
-            remaining &= ~m;
-        }
-        if (leader) s_cntw[wave][k] = (uint16_t)tot;
-        __syncthreads();
-        if (valid) {
-            int32_t before = s_run[k] + rank;
-            for (int32_t w = 0; w < wave; w++) before += s_cntw[w][k];
-            tmp[b + s_base[k] + s_cnt[k] - 1 - before] = act[b + i];
-        }
-        __syncthreads();
-        if (leader) { atomicAdd(&s_run[k], tot); s_cntw[wave][k] = 0; }
-        __syncthreads();
-    }
-    __syncthreads();
-    for (int32_t i = tid; i < na; i += SCAN_THREADS) {
-        const int32_t v = tmp[b + i];
-        act[b + i] = v;
-        pos[v] = i;
-    }
+    d_dec_hist_sort(node_base, act, nact, T, bm, binof, tmp, hbin, pos, force_tree, nbin, blockIdx.x, blockIdx.y);
 }
 
-/* ------------------------------------------------------------------ */
-/*
- * lextree_hmm_propagate_non_leaves from every node's point of view (see the header of
- * s3a_lextree.hip for the rule); one thread per node of every tree: inactive nodes
- * without a propagating parent fall through after two loads.  Also resets the root-entry
- * scratch (key / first) for this frame's transitions.
- */
 __global__ void __launch_bounds__(DBLOCK)
 k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
               const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
@@ -304,86 +88,9 @@ k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
               unsigned long long *key, int32_t *first, int32_t *hbin)
 {
-    __shared__ int32_t s_th, s_pth, s_hist;
-    if (threadIdx.x == 0) {
-        int32_t bh, bw, n, th, pth, wth;
-        s_hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth) ? 1 : 0;
-        s_th = th; s_pth = pth;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && s_hist)                      /* the bins were consumed by k_dec_hist_sort */
-        for (int32_t i = threadIdx.x; i < NBIN; i += DBLOCK) hbin[i] = 0;
-    const int32_t v = blockIdx.x * DBLOCK + threadIdx.x;
-    if (v >= N) return;
-    key[v] = 0ull;
-    first[v] = INT_MAX;
-    const int32_t th = s_th, pth = s_pth, nf = cf + 1;
-    const bool is_active = posf[v] == cf;
-    const int32_t j = is_active ? pos[v] : INT_MAX;
-    const int32_t in0 = sc[v];
-    int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
-    int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
-    for (int32_t k = par_off[v]; k < par_off[v + 1]; k++) {
-        const int32_t p = par[k];
-        if (posf[p] != cf) continue;
-        const int32_t po = outs[p];
-        if (po < pth) continue;
-        const int32_t ns = add32(po, add32(prob[v], -prob[p]));
-        if (ns < th) continue;
-        const int32_t pp = pos[p];
-        if (pp < j) {
-            if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[p]; }
-            if (ns > in0 && pp < firstE) firstE = pp;
-        }
-        else {
-            if (ns > mL || (ns == mL && pp < pL)) { mL = ns; pL = pp; hL = outh[p]; }
-            if (pp < firstL) firstL = pp;
-        }
-    }
-    if (!is_active && mE == INT_MIN)
-        return;                                         /* nothing happens to this node */
-    const int32_t b = node_base[tree_of[v]];
-    int32_t cur = in0, h0 = hist[v], my_turn = -1;
-    bool in_list = false, cleared = false, entered = false;
-    if (mE > in0) {
-        cur = mE; h0 = hE; entered = true; in_list = true; my_turn = firstE;
-    }
-    else if (is_active) {
-        if (bests[v] >= th) { in_list = true; selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); }
-        else { cleared = true; cur = WORST; h0 = -1; }
-    }
-    if (mL > cur) {
-        cur = mL; h0 = hL; entered = true;
-        if (!in_list) { in_list = true; my_turn = firstL; }
-    }
-    if (cleared) {
-        sc[1 * N + v] = WORST; sc[2 * N + v] = WORST;
-        hist[1 * N + v] = -1; hist[2 * N + v] = -1;
-        outs[v] = WORST; outh[v] = -1; bests[v] = WORST;
-    }
-    if (cleared || entered) { sc[v] = cur; hist[v] = h0; }
-    frame[v] = in_list ? nf : (cleared ? -1 : frame[v]);
-    if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[b + my_turn], 1); }
+    d_dec_resolve(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, blockIdx.x, blockIdx.y);
 }
 
-/* ------------------------------------------------------------------ */
-/*
- * The ordered emission of the next active list, in two kernels.
- *
- * k_dec_scan, one workgroup per tree: prefix-sums the per-turn counts (base[i] = where the
- * nodes emitted during the turn of active-list position i start in the next list), writes the
- * self-emitted nodes, and compacts the word exits in active-list order; the LAST workgroup to
- * finish (agent-scope release by every workgroup, acquire by the last) assembles the frame
- * record for the host and resets the per-frame accumulators.
- *
- * k_dec_emit, a fixed grid of waves sweeping the active list: the children a parent put on the
- * list during its turn follow in child-list order; a lane per list position finds the few
- * turns that attributed children, then the whole wave walks such a parent's child list 64
- * links at a time and ranks the attributed children with a ballot.  (A lextree root has
- * hundreds of children -- 341 in the 20 k-word task -- and a one-thread walk of such a list,
- * one dependent HBM access per link, cost 600 us per frame.)
- * record = [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] | n_next x T | exits
- */
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
            const int32_t *__restrict__ act, const int32_t *__restrict__ nact,
@@ -393,254 +100,51 @@ k_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
            const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits)
 {
-    __shared__ int32_t total, s_wth, s_last;
-    __shared__ int32_t s_thr[8];
-    const int32_t t = blockIdx.x, b = node_base[t], na = nact[t], nf = cf + 1;
-    if (threadIdx.x == 0) {
-        int32_t bh, bw, n, th, pth, wth;
-        const bool hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
-        s_wth = wth;
-        s_thr[0] = th; s_thr[1] = pth; s_thr[2] = wth; s_thr[3] = bh; s_thr[4] = bw; s_thr[5] = n;
-        s_thr[6] = hist ? 1 : 0;
-        s_thr[7] = (pth < th) ? 1 : 0;      /* see s3a_decoder_search: unsupported beam geometry */
-    }
-    __syncthreads();
-    /* (a) turn bases + the self-emitted nodes */
-    block_exclusive_scan_to(cnt + b, base + b, na, &total);
-    __syncthreads();
-    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
-        if (selfemit[b + i]) {
-            const int32_t u = act[b + i], k = base[b + i];
-            nxt[b + k] = u; pos[u] = k; posf[u] = nf;
-        }
-    }
-    if (threadIdx.x == 0) nnxt[t] = total;
-    __syncthreads();
-    /* (b) word exits, in active-list order */
-    const int32_t wth = s_wth;
-    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
-        const int32_t u = act[b + i];
-        cnt[b + i] = (wid[u] >= 0 && outs[u] >= wth) ? 1 : 0;
-    }
-    __syncthreads();
-    block_exclusive_scan(cnt + b, na, &total);
-    __syncthreads();
-    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
-        const int32_t u = act[b + i];
-        if (wid[u] >= 0 && outs[u] >= wth) {
-            const int32_t k = b + cnt[b + i];
-            exits[k] = wid[u];
-            exits[N + k] = add32(outs[u], -prob[u]);
-            exits[2 * N + k] = outh[u];
-            if (outh[u] == -1) atomicExch(&nexit[T + t], 1);
-        }
-    }
-    __syncthreads();
-    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS)
-        cnt[b + i] = 0;
-    if (threadIdx.x == 0) nexit[t] = total;
-    /* publish this tree's results, find out whether we are last */
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();                                        /* agent-scope release */
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = (atomicAdd(done, 1) == T - 1) ? 1 : 0;
-        if (s_last) __threadfence();                            /* agent-scope acquire */
-    }
-    __syncthreads();
-    if (!s_last) return;
-
-    const int32_t hdr = 6 * T + 16;
-    volatile const int32_t *vbest = best, *vnexit = nexit, *vex = exits, *vmisc = misc, *vnnxt = nnxt;
-    for (int32_t q = threadIdx.x; q < 2 * T; q += SCAN_THREADS) pack[q] = vbest[q];
-    for (int32_t q = threadIdx.x; q < T; q += SCAN_THREADS) {
-        pack[2 * T + q] = nact[q];
-        pack[3 * T + 8 + q] = vnexit[q];
-        pack[4 * T + 8 + q] = vnexit[T + q];
-        pack[5 * T + 16 + q] = vnnxt[q];
-    }
-    if (threadIdx.x < 8) {
-        pack[3 * T + threadIdx.x] = s_thr[threadIdx.x];
-        int32_t m = vmisc[threadIdx.x];
-        if (threadIdx.x == 6) m = max(vmisc[0], vmisc[5]);      /* srch->senscale */
-        pack[5 * T + 8 + threadIdx.x] = m;
-    }
-    int32_t off = 0;
-    for (int32_t tt = 0; tt < T; tt++) {
-        const int32_t n = vnexit[tt], bb = node_base[tt];
-        for (int32_t q = threadIdx.x; q < n; q += SCAN_THREADS) {
-            const int32_t k = off + q;
-            if (k < max_exits) {
-                pack[hdr + 3 * k] = vex[bb + q];
-                pack[hdr + 3 * k + 1] = vex[N + bb + q];
-                pack[hdr + 3 * k + 2] = vex[2 * N + bb + q];
-            }
-        }
-        off += n;
-    }
-    __syncthreads();
-    /* reset the per-frame accumulators for the next frame */
-    for (int32_t q = threadIdx.x; q < 2 * T; q += SCAN_THREADS) { best[q] = INT_MIN; nexit[q] = 0; }
-    if (threadIdx.x < 8) misc[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 5) ? INT_MIN : 0;
-    if (threadIdx.x == 0) *done = 0;
+    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, blockIdx.x, blockIdx.y);
 }
 
-#define EMIT_WAVES (DBLOCK / 64)
-#define EMIT_BLOCKS 32          /* workgroups per tree: 128 waves, 8192 list positions per sweep */
 __global__ void __launch_bounds__(DBLOCK)
 k_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
            const int32_t *__restrict__ nact, const int32_t *__restrict__ child_off,
            const int32_t *__restrict__ child, int32_t *turn, int32_t *selfemit,
            const int32_t *__restrict__ base, int32_t *nxt, const int32_t *nnxt, int32_t *pos, int32_t *posf)
 {
-    const int32_t t = blockIdx.y, b = node_base[t], na = nact[t], nf = cf + 1, total = nnxt[t];
-    const int32_t lane = threadIdx.x & 63;
-    /* each wave sweeps 64 list positions at a time: a lane per position finds the (few) turns that
-     * attributed children, then the whole wave walks those parents' child lists */
-    for (int32_t i0 = (blockIdx.x * EMIT_WAVES + (threadIdx.x >> 6)) * 64; i0 < na; i0 += EMIT_BLOCKS * EMIT_WAVES * 64) {
-        const int32_t i = i0 + lane;
-        int32_t lo = 0, hi = 0;
-        if (i < na) {
-            lo = base[b + i];
-            hi = (i + 1 < na) ? base[b + i + 1] : total;
-            if (selfemit[b + i]) { selfemit[b + i] = 0; lo++; }
-        }
-        unsigned long long todo = __ballot(lo < hi);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            int32_t k = __shfl(lo, src, 64);
-            const int32_t kend = __shfl(hi, src, 64), ip = i0 + src, u = act[b + ip];
-            const int32_t c_lo = child_off[u], c_hi = child_off[u + 1];
-            for (int32_t j0 = c_lo; j0 < c_hi && k < kend; j0 += 64) {
-                const int32_t j = j0 + lane;
-                const int32_t c = (j < c_hi) ? child[j] : -1;
-                const bool mine = c >= 0 && turn[c] == ip;
-                const unsigned long long m = __ballot(mine);
-                if (mine) {
-                    const int32_t q = k + __popcll(m & ((1ull << lane) - 1ull));
-                    nxt[b + q] = c; pos[c] = q; posf[c] = nf;
-                    turn[c] = -1;
-                }
-                k += __popcll(m);
-            }
-        }
-    }
+    d_dec_emit(cf, node_base, act, nact, child_off, child, turn, selfemit, base, nxt, nnxt, pos, posf, blockIdx.x, blockIdx.y);
 }
-
-/* ------------------------------------------------------------------ */
-/* lextree_enter for up to two trees of one frame + next frame's senone marks */
-/* calls[c] = {inscore, inhist, offset of the call's root list in rootlist[], first entry index};
- * entry e of the frame = the (e - first)-th root of its call; groups: {tree, ent_lo, ent_hi}.
- * (The root lists of a 20 k-word lextree hold ~2000 nodes per left context: expanding ~90 k
- * entries on the host and copying them every frame cost more than the search itself.) */
-struct Entries {
-    const int32_t *calls, *rootlist;
-    int32_t n_calls;
-    __device__ __forceinline__ void locate(int32_t e, int32_t &v, int32_t &c) const
-    {
-        int32_t lo = 0, hi = n_calls - 1;
-        while (lo < hi) {
-            const int32_t mid = (lo + hi + 1) >> 1;
-            if (calls[4 * mid + 3] <= e) lo = mid; else hi = mid - 1;
-        }
-        c = lo;
-        v = rootlist[calls[4 * c + 2] + (e - calls[4 * c + 3])];
-    }
-};
 
 __global__ void
 k_dec_enter1(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
              const int32_t *__restrict__ prob, const int32_t *__restrict__ sc, int32_t thresh,
              unsigned long long *key, int32_t *first)
 {
-    const int32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_ent) return;
-    int32_t v, c;
-    ent.locate(e, v, c);
-    const int32_t scr = add32(calls[4 * c], prob[v]);
-    if (scr < thresh || !(sc[v] < scr)) return;
-    atomicMax(&key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
-    atomicMin(&first[v], c);
+    d_dec_enter1(ent, n_ent, calls, prob, sc, thresh, key, first, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-k_dec_enter2(const int32_t *__restrict__ groups, Entries ent,
-             const int32_t *__restrict__ calls, const int32_t *__restrict__ prob,
-             const int32_t *__restrict__ sc, const int32_t *__restrict__ frame,
-             const int32_t *__restrict__ first, int32_t thresh, int32_t nf,
-             const int32_t *__restrict__ node_base, int32_t *flag, int32_t *nxt, int32_t *nnxt,
-             int32_t *pos, int32_t *posf)
+k_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
+             const int32_t *__restrict__ prob, const int32_t *__restrict__ sc,
+             const int32_t *__restrict__ frame, const int32_t *__restrict__ first, int32_t thresh,
+             int32_t nf, int32_t T, const int32_t *__restrict__ nnxt, int32_t *flag, int32_t *ctot, int32_t *n0)
 {
-    __shared__ int32_t total;
-    const int32_t t = groups[3 * blockIdx.x], lo = groups[3 * blockIdx.x + 1], hi = groups[3 * blockIdx.x + 2];
-    const int32_t n = hi - lo, b = node_base[t];
-    for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
-        const int32_t e = lo + i;
-        int32_t v, c;
-        ent.locate(e, v, c);
-        const int32_t scr = add32(calls[4 * c], prob[v]);
-        flag[e] = (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
-    }
-    __syncthreads();
-    block_exclusive_scan(flag + lo, n, &total);
-    __syncthreads();
-    const int32_t n0 = nnxt[t];
-    for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
-        const int32_t e = lo + i;
-        int32_t v, c;
-        ent.locate(e, v, c);
-        const int32_t scr = add32(calls[4 * c], prob[v]);
-        if (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) {
-            const int32_t k = n0 + flag[e];
-            nxt[b + k] = v; pos[v] = k; posf[v] = nf;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) nnxt[t] = n0 + total;
+    d_dec_enter2(ent, n_ent, calls, prob, sc, frame, first, thresh, nf, T, nnxt, flag, ctot, n0, blockIdx.x, 0);
 }
 
-/* blocks [0, n_ent_blocks): apply the winning entries; the remaining blocks mark the senones
- * of every node of the NEXT active lists (srch_TST_select_active_gmm for the coming frame) */
 __global__ void __launch_bounds__(DBLOCK)
 k_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
-                  const int32_t *__restrict__ calls, int32_t nf,
-                  const unsigned long long *__restrict__ key, const int32_t *__restrict__ first,
-                  int32_t *sc, int32_t *hist, int32_t *frame,
+                  const int32_t *__restrict__ calls, const int32_t *__restrict__ groups, int32_t n_groups,
+                  int32_t nf, const unsigned long long *__restrict__ key, const int32_t *__restrict__ first,
+                  const int32_t *__restrict__ flag, const int32_t *__restrict__ ctot,
+                  const int32_t *__restrict__ n0, int32_t *sc, int32_t *hist, int32_t *frame,
                   int32_t T, int32_t blocks_per_tree, const int32_t *__restrict__ node_base,
-                  const int32_t *__restrict__ nxt, const int32_t *__restrict__ nnxt,
+                  int32_t *nxt, int32_t *nnxt, int32_t *pos, int32_t *posf,
                   const int32_t *__restrict__ ssid, const uint8_t *__restrict__ comp,
                   const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
                   const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
                   uint8_t *sen_active)
 {
-    if ((int32_t)blockIdx.x < n_ent_blocks) {
-        const int32_t e = blockIdx.x * DBLOCK + threadIdx.x;
-        if (e >= n_ent) return;
-        int32_t v, c;
-        ent.locate(e, v, c);
-        const unsigned long long k = key[v];
-        if (k == 0ull) return;
-        const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(k & 0xffffffffu);
-        if (c == win_c) { sc[v] = (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); hist[v] = calls[4 * c + 1]; }
-        if (c == first[v]) frame[v] = nf;
-        return;
-    }
-    const int32_t bb = blockIdx.x - n_ent_blocks;
-    const int32_t t = bb / blocks_per_tree, i = (bb % blocks_per_tree) * DBLOCK + threadIdx.x;
-    if (t >= T || i >= nnxt[t]) return;
-    const int32_t v = nxt[node_base[t] + i], ss = ssid[v];
-    if (comp[v]) {
-        for (int st = 0; st < 3; st++) {
-            const int32_t cs = comsseq[ss * 3 + st];
-            for (int32_t j = cs_off[cs]; j < cs_off[cs + 1]; j++)
-                sen_active[cs_list[j]] = 1;
-        }
-    }
-    else {
-        for (int st = 0; st < 3; st++)
-            sen_active[sseq[ss * 3 + st]] = 1;
-    }
+    d_dec_enter3_mark(n_ent_blocks, ent, n_ent, calls, groups, n_groups, nf, key, first, flag, ctot, n0, sc, hist,
+                      frame, T, blocks_per_tree, node_base, nxt, nnxt, pos, posf, ssid, comp, sseq, comsseq, cs_off,
+                      cs_list, sen_active, blockIdx.x, 0);
 }
 
 /* ------------------------------------------------------------------ */
@@ -691,6 +195,95 @@ s3a_lexsearch_hmm_histbin(s3a_lexsearch_t *ls, int32_t tree, int32_t bestscr, in
     return S3A_OK;
 }
 
+/* host half of a frame's lextree_enter calls: per call {inscore, inhist, offset of its root list,
+ * first entry index}, per tree a group {tree, first entry, last entry + 1, first call}; also the bound on the
+ * coming frame's active HMMs (ls->hist_bound).  Shared with the batched engine (s3a_batch.hip). */
+int32_t
+s3a_dec_stage_calls(s3a_lexsearch_t *ls, int32_t tree_a, int32_t n_a, const int32_t *lc_a, const int32_t *scr_a,
+                    const int32_t *hist_a, int32_t tree_b, int32_t n_b, const int32_t *lc_b,
+                    const int32_t *scr_b, const int32_t *hist_b, int32_t *groups, int32_t *calls,
+                    int32_t max_calls, int32_t *n_calls, int32_t *n_ent_out, int32_t *n_groups_out)
+{
+    const int32_t T = ls->n_tree;
+    int32_t n_ent = 0, n_groups = 0, c = 0, roots = 0;
+    if (n_a < 0 || n_b < 0 || n_a + n_b > max_calls) {
+        s3a_set_error("lextree_enter: %d calls in one frame exceed the staging buffer (%d)", n_a + n_b, max_calls);
+        return S3A_EINVAL;
+    }
+    for (int g = 0; g < 2; g++) {
+        const int32_t tree = g ? tree_b : tree_a, n = g ? n_b : n_a;
+        const int32_t *lc = g ? lc_b : lc_a, *scr = g ? scr_b : scr_a, *hi = g ? hist_b : hist_a;
+        if (n == 0) continue;
+        if (tree < 0 || tree >= T) return S3A_EINVAL;
+        const int32_t lo = n_ent, c_lo = c;
+        for (int32_t i = 0; i < n; i++, c++) {
+            int32_t k = 0;
+            if (ls->n_lc[tree] > 0) {
+                for (k = 0; k < ls->n_lc[tree] && ls->lc[tree][k] != lc[i]; k++);
+                if (k >= ls->n_lc[tree]) {
+                    s3a_set_error("lextree_enter: left context %d is not a root context of tree %d", lc[i], tree);
+                    return S3A_EINVAL;
+                }
+            }
+            const int32_t len = ls->lcroot_off[tree][k + 1] - ls->lcroot_off[tree][k];
+            if (n_ent + len > ls->ent_cap) { s3a_set_error("lextree_enter: entry staging overflow"); return S3A_EINVAL; }
+            calls[4 * c] = scr[i];
+            calls[4 * c + 1] = hi[i];
+            calls[4 * c + 2] = ls->rootbuf_base[tree] + ls->lcroot_off[tree][k];
+            calls[4 * c + 3] = n_ent;
+            n_ent += len;
+        }
+        groups[4 * n_groups] = tree; groups[4 * n_groups + 1] = lo; groups[4 * n_groups + 2] = n_ent;
+        groups[4 * n_groups + 3] = c_lo;
+        n_groups++;
+        roots += ls->n_root[tree];
+    }
+    /* >= the coming frame's active HMMs: what propagation listed + the distinct roots entered */
+    ls->hist_bound = ls->last_nnxt + min(n_ent, roots);
+    *n_calls = c; *n_ent_out = n_ent; *n_groups_out = n_groups;
+    return S3A_OK;
+}
+
+/* the frame record (see k_dec_scan) -> s3a_frame_result_t + per-tree exit counts; shared with the
+ * batched engine.  Returns the total number of word exits in *total. */
+int32_t
+s3a_dec_unpack(s3a_lexsearch_t *ls, const int32_t *p, bool may_hist, int32_t frm, s3a_frame_result_t *res,
+               int32_t *n_exit, int32_t max_exits, int32_t *total_out)
+{
+    const int32_t T = ls->n_tree;
+    int32_t total = 0, t;
+    res->best_hmm = p[3 * T + 3]; res->best_word = p[3 * T + 4]; res->n_hmm = p[3 * T + 5];
+    res->thres = p[3 * T + 0]; res->phone_thres = p[3 * T + 1]; res->word_thres = p[3 * T + 2];
+    res->need_histprune = p[3 * T + 6];     /* informational: the histogram beam was applied */
+    for (int i = 0; i < 8; i++) res->extra[i] = p[5 * T + 8 + i];
+    ls->last_nnxt = 0;
+    for (t = 0; t < T; t++) ls->last_nnxt += p[5 * T + 16 + t];
+    if (res->need_histprune && !may_hist) {
+        s3a_set_error("fused frame: internal error, %d active HMMs exceed the host bound %d", res->n_hmm, ls->hist_bound);
+        return S3A_EINVAL;
+    }
+    if (p[3 * T + 7]) {
+        s3a_set_error("fused frame: phone threshold below the HMM threshold in frame %d "
+                      "(-ptranskip with a weak best word): not supported", frm);
+        return S3A_EUNSUP;
+    }
+    for (t = 0; t < T; t++) {
+        if (p[4 * T + 8 + t]) {
+            s3a_set_error("out.history==-1 at a word exit of tree %d (LEXTREE_OPERATION_FAILURE)", t);
+            return S3A_EINVAL;
+        }
+        n_exit[t] = p[3 * T + 8 + t];
+        total += n_exit[t];
+    }
+    res->n_exit_total = total;
+    if (total > max_exits || total > ls->pack_max_exits) {
+        s3a_set_error("fused frame: %d word exits in one frame exceed the buffers", total);
+        return S3A_EINVAL;
+    }
+    *total_out = total;
+    return S3A_OK;
+}
+
 extern "C" int32_t
 s3a_decoder_utt_begin(s3a_lexsearch_t *ls, s3a_scorer_t *sc)
 {
@@ -722,7 +315,7 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
     const int32_t T = ls->n_tree, hdr = 6 * T + 16, maxn = max_tree_nodes(ls);
     const int cur = ls->cur, nxt = cur ^ 1;
     FrameBeams bm = { hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf };
-    int32_t total = 0, t;
+    int32_t total = 0;
     /* histogram pruning can only fire when the frame holds more than 1.5 x maxhmmpf HMMs; the host
      * knows an upper bound (last frame's next list + the root entries it sent), so the two
      * histogram kernels are only enqueued when that bound allows it */
@@ -772,33 +365,9 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
     HIPCHK(hipMemcpyAsync(ls->h_pack, ls->d_pack, (size_t)(hdr + 3 * first) * 4, hipMemcpyDeviceToHost, ls->stream));
     HIPCHK(hipStreamSynchronize(ls->stream));
     const int32_t *p = ls->h_pack;
-    res->best_hmm = p[3 * T + 3]; res->best_word = p[3 * T + 4]; res->n_hmm = p[3 * T + 5];
-    res->thres = p[3 * T + 0]; res->phone_thres = p[3 * T + 1]; res->word_thres = p[3 * T + 2];
-    res->need_histprune = p[3 * T + 6];     /* informational: the histogram beam was applied */
-    for (int i = 0; i < 8; i++) res->extra[i] = p[5 * T + 8 + i];
-    ls->last_nnxt = 0;
-    for (t = 0; t < T; t++) ls->last_nnxt += p[5 * T + 16 + t];
-    if (res->need_histprune && !may_hist) {
-        s3a_set_error("s3a_decoder_search: internal error, %d active HMMs exceed the host bound %d", res->n_hmm, ls->hist_bound);
-        return S3A_EINVAL;
-    }
-    if (p[3 * T + 7]) {
-        s3a_set_error("s3a_decoder_search: phone threshold below the HMM threshold in frame %d "
-                      "(-ptranskip with a weak best word): not supported by the fused frame", frm);
-        return S3A_EUNSUP;
-    }
-    for (t = 0; t < T; t++) {
-        if (p[4 * T + 8 + t]) {
-            s3a_set_error("out.history==-1 at a word exit of tree %d (LEXTREE_OPERATION_FAILURE)", t);
-            return S3A_EINVAL;
-        }
-        n_exit[t] = p[3 * T + 8 + t];
-        total += n_exit[t];
-    }
-    res->n_exit_total = total;
-    if (total > max_exits || total > ls->pack_max_exits) {
-        s3a_set_error("s3a_decoder_search: %d word exits in one frame exceed the buffers", total);
-        return S3A_EINVAL;
+    {
+        const int32_t rc = s3a_dec_unpack(ls, p, may_hist, frm, res, n_exit, max_exits, &total);
+        if (rc != S3A_OK) return rc;
     }
     if (total > first) {
         HIPCHK(hipMemcpyAsync(ls->h_pack + hdr + 3 * first, ls->d_pack + hdr + 3 * first,
@@ -824,68 +393,37 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
                        const int32_t *scr_a, const int32_t *hist_a, int32_t tree_b, int32_t n_b,
                        const int32_t *lc_b, const int32_t *scr_b, const int32_t *hist_b)
 {
-    if (!ls || !sc || !cs || n_a < 0 || n_b < 0 || n_a + n_b > 4096) return S3A_EINVAL;
+    if (!ls || !sc || !cs) return S3A_EINVAL;
     if (same_stream(ls, sc) != S3A_OK) return S3A_EINVAL;
     const int32_t T = ls->n_tree, maxn = max_tree_nodes(ls);
     const int nxt = ls->cur ^ 1;
     int32_t *slot = ls->h_ring + (size_t)(ls->ring_slot++ & 7) * ((size_t)2 * 4096 + (size_t)2 * ls->ent_cap);
     int32_t *groups = slot, *calls = slot + 8;          /* pinned staging: [groups 8][calls 4 each] */
-    int32_t n_ent = 0, n_groups = 0, c = 0;
+    int32_t n_ent = 0, n_groups = 0, c = 0, rc;
 
-    if (n_a + n_b > 2046) return S3A_EINVAL;
-    for (int g = 0; g < 2; g++) {
-        const int32_t tree = g ? tree_b : tree_a, n = g ? n_b : n_a;
-        const int32_t *lc = g ? lc_b : lc_a, *scr = g ? scr_b : scr_a, *hi = g ? hist_b : hist_a;
-        if (n == 0) continue;
-        if (tree < 0 || tree >= T) return S3A_EINVAL;
-        const int32_t lo = n_ent;
-        for (int32_t i = 0; i < n; i++, c++) {
-            int32_t k = 0;
-            if (ls->n_lc[tree] > 0) {
-                for (k = 0; k < ls->n_lc[tree] && ls->lc[tree][k] != lc[i]; k++);
-                if (k >= ls->n_lc[tree]) {
-                    s3a_set_error("s3a_decoder_transition: left context %d is not a root context of tree %d", lc[i], tree);
-                    return S3A_EINVAL;
-                }
-            }
-            const int32_t len = ls->lcroot_off[tree][k + 1] - ls->lcroot_off[tree][k];
-            if (n_ent + len > ls->ent_cap) { s3a_set_error("s3a_decoder_transition: entry staging overflow"); return S3A_EINVAL; }
-            calls[4 * c] = scr[i];
-            calls[4 * c + 1] = hi[i];
-            calls[4 * c + 2] = ls->rootbuf_base[tree] + ls->lcroot_off[tree][k];
-            calls[4 * c + 3] = n_ent;
-            n_ent += len;
-        }
-        groups[3 * n_groups] = tree; groups[3 * n_groups + 1] = lo; groups[3 * n_groups + 2] = n_ent;
-        n_groups++;
-    }
+    if ((rc = s3a_dec_stage_calls(ls, tree_a, n_a, lc_a, scr_a, hist_a, tree_b, n_b, lc_b, scr_b, hist_b, groups,
+                                  calls, 2046, &c, &n_ent, &n_groups)) != S3A_OK)
+        return rc;
     const Entries ent = { ls->d_calls + 8, ls->d_rootlist, c };
     if (n_ent > 0) {
         HIPCHK(hipMemcpyAsync(ls->d_calls, slot, (size_t)(8 + 4 * c) * 4, hipMemcpyHostToDevice, ls->stream));
         hipLaunchKernelGGL(k_dec_enter1, dim3((n_ent + 255) / 256), dim3(256), 0, ls->stream, ent,
                            n_ent, ls->d_calls + 8, ls->d_prob, ls->d_sc, thresh, ls->d_key, ls->d_first);
-        hipLaunchKernelGGL(k_dec_enter2, dim3(n_groups), dim3(SCAN_THREADS), 0, ls->stream,
-                           ls->d_calls, ent, ls->d_calls + 8, ls->d_prob, ls->d_sc,
-                           ls->d_frame, ls->d_first, thresh, cf + 1, ls->d_node_base, ls->d_eflag,
-                           ls->d_act[nxt], ls->d_nact[nxt], ls->d_pos, ls->d_posf);
+        hipLaunchKernelGGL(k_dec_enter2, dim3(c), dim3(SCAN_THREADS), 0, ls->stream, ent, n_ent,
+                           ls->d_calls + 8, ls->d_prob, ls->d_sc, ls->d_frame, ls->d_first, thresh, cf + 1, T,
+                           ls->d_nact[nxt], ls->d_eflag, ls->d_ctot, ls->d_n0);
     }
     {
         const int32_t n_ent_blocks = (n_ent + DBLOCK - 1) / DBLOCK;
         const int32_t bpt = (maxn + DBLOCK - 1) / DBLOCK;
         hipLaunchKernelGGL(k_dec_enter3_mark, dim3(n_ent_blocks + bpt * T), dim3(DBLOCK), 0, ls->stream,
-                           n_ent_blocks, ent, n_ent, ls->d_calls + 8, cf + 1, ls->d_key, ls->d_first,
-                           ls->d_sc, ls->d_hist, ls->d_frame, T, bpt, ls->d_node_base, ls->d_act[nxt],
-                           ls->d_nact[nxt], ls->d_ssid, ls->d_comp, ls->d_sseq, ls->d_comsseq, cs->off_d,
+                           n_ent_blocks, ent, n_ent, ls->d_calls + 8, ls->d_calls, n_groups, cf + 1, ls->d_key,
+                           ls->d_first, ls->d_eflag, ls->d_ctot, n_ent > 0 ? ls->d_n0 : ls->d_nact[nxt], ls->d_sc,
+                           ls->d_hist, ls->d_frame, T, bpt, ls->d_node_base, ls->d_act[nxt], ls->d_nact[nxt],
+                           ls->d_pos, ls->d_posf, ls->d_ssid, ls->d_comp, ls->d_sseq, ls->d_comsseq, cs->off_d,
                            cs->list_d, sc->act_d);
     }
     HIPCHK(hipGetLastError());
-    {
-        /* >= the coming frame's active HMMs: what propagation listed + the distinct roots entered */
-        int32_t roots = 0;
-        if (n_a > 0) roots += ls->n_root[tree_a];
-        if (n_b > 0) roots += ls->n_root[tree_b];
-        ls->hist_bound = ls->last_nnxt + min(n_ent, roots);
-    }
     ls->cur ^= 1;       /* lextree_active_swap; the new next-list counts are overwritten by k_dec_finish */
     return S3A_OK;
 }

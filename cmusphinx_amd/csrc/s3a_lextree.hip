@@ -599,6 +599,7 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
     DMALLOC(ls->d_done, 4 * 4);
     HIPCHK(hipMemset(ls->d_done, 0, 16));
     DMALLOC(ls->d_hbin, 1024 * 4);
+    DMALLOC(ls->d_ctot, 4096 * 4); DMALLOC(ls->d_n0, (size_t)n_tree * 4);
     HIPCHK(hipMemset(ls->d_hbin, 0, 1024 * 4));
     ls->hist_bound = ls->last_nnxt = 1 << 30;
     HIPCHK(hipMemset(ls->d_key, 0, (size_t)N * 8));
@@ -665,7 +666,7 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
         &ls->d_frame, &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
-        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_tree_of, &ls->d_done, &ls->d_hbin };
+        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_tree_of, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0 };
     for (auto p : ptrs) (void)hipFree(*p);
     (void)hipFree(ls->d_comp); (void)hipFree(ls->d_sseq); (void)hipFree(ls->d_comsseq);
     (void)hipFree(ls->d_comstate); (void)hipFree(ls->d_key);
@@ -975,10 +976,14 @@ s3a_lexsearch_utt_end(s3a_lexsearch_t *ls)
     if (!ls) return S3A_EINVAL;
     for (t = 0; t < ls->n_tree; t++)
         maxn = max(maxn, ls->node_base[t + 1] - ls->node_base[t]);
-    hipLaunchKernelGGL(k_lt_utt_end, dim3((maxn + LT_BLOCK - 1) / LT_BLOCK, ls->n_tree),
-                       dim3(LT_BLOCK), 0, ls->stream, ls->d_node_base, ls->d_act[ls->cur],
-                       ls->d_nact[ls->cur], ls->N, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh,
-                       ls->d_bests, ls->d_frame);
+    /* both lists: a driver that stops after the last frame's search (the batched engine drops the
+     * final, pointless transition) leaves the survivors in the NEXT list; an already swapped list
+     * only names nodes that are clear or about to be cleared anyway */
+    for (int w = 0; w < 2; w++)
+        hipLaunchKernelGGL(k_lt_utt_end, dim3((maxn + LT_BLOCK - 1) / LT_BLOCK, ls->n_tree),
+                           dim3(LT_BLOCK), 0, ls->stream, ls->d_node_base, ls->d_act[ls->cur ^ w],
+                           ls->d_nact[ls->cur ^ w], ls->N, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh,
+                           ls->d_bests, ls->d_frame);
     HIPCHK(hipGetLastError());
     /* frame-tagged scratch must not leak into the next utterance (frames restart at 0) */
     if ((rc = fill(ls, ls->d_nact[0], 0, ls->n_tree)) || (rc = fill(ls, ls->d_nact[1], 0, ls->n_tree))

@@ -28,6 +28,7 @@
 
 #include "s3a_device.h"
 #include "s3a_structs.h"
+#include "s3a_gated.h"
 
 #pragma clang fp contract(off)
 
@@ -45,91 +46,7 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
               int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc, int32_t best_slot,
               uint8_t *clear_active)
 {
-    typedef typename Acc<EXACT>::T acc_t;
-    const int32_t lane = threadIdx.x & 63;
-    const int32_t g = sen_lo * CP + blockIdx.x * 256 + threadIdx.x;
-    const int32_t sen = g / CP, c = g - sen * CP, sl = lane / CP;
-    const bool valid = sen < sen_hi;
-    LogAdd la;
-    la.tab = tab_g; la.size = tab_size; la.zero = lm_zero;
-
-    /* device-resident path: the CI maximum was left in memory by the CI phase */
-    if (pbest_ptr)
-        pbest_plus_beam = (int32_t)((uint32_t)*pbest_ptr + (uint32_t)beam);
-    /* 0 = untouched, 1 = full, 2 = single Gaussian, 3 = CI copy */
-    int32_t mode = 0, ci_scr = 0, bi = S3A_NO_BSTIDX;
-    if (valid) {
-        if (ci_phase)
-            mode = 1;
-        else if (sen_active[sen]) {
-            ci_scr = senscr[cd2cisen[sen]];
-            if (ci_scr >= pbest_plus_beam)
-                mode = 1;
-            else {
-                bi = bstidx[sen];
-                mode = (bi == S3A_NO_BSTIDX || updatetime[sen] != frame - 1) ? 3 : 2;
-            }
-        }
-    }
-    int32_t gs = S3A_LOGPROB_ZERO;
-    if (mode == 1 || (mode == 2 && c == bi)) {
-        acc_t a = (acc_t)lrd[g];
-        for (int32_t k = 0; k < D4; k++) {
-            float4 m = mean4[(size_t)k * Gpad + g], p = prec4[(size_t)k * Gpad + g];
-            const float4 xv = *(const float4 *)(x + 4 * k);
-            a = Acc<EXACT>::step(a, xv.x, m.x, p.x);
-            a = Acc<EXACT>::step(a, xv.y, m.y, p.y);
-            a = Acc<EXACT>::step(a, xv.z, m.z, p.z);
-            a = Acc<EXACT>::step(a, xv.w, m.w, p.w);
-        }
-        gs = gau_to_int((double)a, f, distfloor, mixw_g[g]);
-    }
-    /* ordered chain over the senone's lanes; every lane of the senone runs it */
-    int32_t score = S3A_LOGPROB_ZERO, bs = S3A_LOGPROB_ZERO, bidx = S3A_NO_BSTIDX;
-    const int32_t nc = valid ? (int32_t)ncomp[sen] : 0;
-    for (int32_t cc = 0; cc < CP; cc++) {
-        int32_t v = __shfl(gs, sl * CP + cc, 64);
-        if (mode == 1 && cc < nc) {
-            score = la(score, v);
-            if (v > bs) { bs = v; bidx = cc; }      /* update_best_id = 1: strict >, first max wins */
-        }
-        else if (mode == 2 && cc == bi) {
-            score = la(score, v);
-            if (v > bs) { bs = v; bidx = cc; }
-        }
-    }
-    if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
-    if (mode == 3) score = ci_scr;
-
-    /* fused decoder path: the mask is consumed here, leave it clean for the next frame's marks
-     * (every lane of the senone has read it above; same wave, program order) */
-    if (clear_active && valid && c == 0) clear_active[sen] = 0;
-    int32_t wbest = INT_MIN, ns = 0, ng = 0;
-    if (mode != 0 && c == 0) {
-        senscr[sen] = score;
-        wbest = score;
-        if (mode == 1) {
-            bstidx[sen] = bidx; bstscr[sen] = bs; updatetime[sen] = frame;
-            ns = 1; ng = nc;
-        }
-        else if (mode == 2) {
-            if (is_skip) { bstidx[sen] = bidx; bstscr[sen] = bs; updatetime[sen] = frame; }
-            ng = 1;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        wbest = max(wbest, __shfl_xor(wbest, o, 64));
-        ns += __shfl_xor(ns, o, 64);
-        ng += __shfl_xor(ng, o, 64);
-    }
-    if (lane == 0) {
-        if (wbest != INT_MIN) atomicMax(&misc[best_slot], wbest);
-        if (!ci_phase && ns) atomicAdd(&misc[1], ns);
-        if (!ci_phase && ng) atomicAdd(&misc[2], ng);
-        if (ci_phase && ns) atomicAdd(&misc[3], ns);
-        if (ci_phase && ng) atomicAdd(&misc[4], ng);
-    }
+    d_gated_frame<EXACT>(mean4, prec4, lrd, mixw_g, tab_g, tab_size, lm_zero, f, distfloor, x, D4, CP, Gpad, sen_lo, sen_hi, ci_phase, ncomp, cd2cisen, sen_active, senscr, pbest_plus_beam, pbest_ptr, beam, frame, is_skip, bstidx, bstscr, updatetime, misc, best_slot, clear_active, blockIdx.x);
 }
 
 /* approx_cont_mgau.c:597-600 */

@@ -76,6 +76,7 @@ struct s3a_lexsearch_s {
     int32_t *d_tree_of;                 /* [N] tree index of every node */
     int32_t *d_done;                    /* workgroup completion counter of the fused finishing kernel */
     int32_t *d_hbin;                    /* [1000] lextree_hmm_histbin bins | [1000] = the histogram beam */
+    int32_t *d_ctot, *d_n0;             /* per-call root counts [4096], list lengths before the entries [n_tree] */
     int32_t hist_bound, last_nnxt;      /* host upper bound on the coming frame's active HMMs */
     int32_t *d_pack, *h_pack;           /* per-frame result record (device / pinned host) */
     int32_t pack_max_exits;
@@ -91,5 +92,12 @@ struct s3a_lexsearch_s {
 /* internal cross-TU entry points */
 int32_t s3a_scorer_enqueue_raw(s3a_scorer_t *sc, const float *feat, int32_t frame);
 int32_t s3a_scorer_reset_frame_state(s3a_scorer_t *sc);
+int32_t s3a_dec_stage_calls(s3a_lexsearch_t *ls, int32_t tree_a, int32_t n_a, const int32_t *lc_a,
+                            const int32_t *scr_a, const int32_t *hist_a, int32_t tree_b, int32_t n_b,
+                            const int32_t *lc_b, const int32_t *scr_b, const int32_t *hist_b,
+                            int32_t *groups, int32_t *calls, int32_t max_calls, int32_t *n_calls,
+                            int32_t *n_ent, int32_t *n_groups);
+int32_t s3a_dec_unpack(s3a_lexsearch_t *ls, const int32_t *p, bool may_hist, int32_t frm,
+                       s3a_frame_result_t *res, int32_t *n_exit, int32_t max_exits, int32_t *total);
 
 #endif

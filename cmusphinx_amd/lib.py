@@ -116,6 +116,17 @@ _SIGS = {
     "s3a_ms_mgau_veclen": (C.c_int32, [C.c_void_p]),
     "s3a_ms_cont_mgau_frame_eval": (C.c_int32, [C.c_void_p] * 4 + [C.c_int32, C.POINTER(C.c_int32)]),
     "s3a_ms_mgau_get_dist": (C.c_int32, [C.c_void_p] * 3),
+    "s3a_batch_create": (C.c_void_p, [C.c_int32]),
+    "s3a_batch_free": (None, [C.c_void_p]),
+    "s3a_batch_attach": (C.c_int32, [C.c_void_p] * 4),
+    "s3a_batch_utt_begin": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "s3a_batch_utt_end": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "s3a_batch_transition": (C.c_int32, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p] * 3 + [C.c_int32, C.c_int32] +
+                             [C.c_void_p] * 3),
+    "s3a_batch_step": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p] * 5 + [C.c_int32]),
+    "s3a_batch_submit": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p] * 5 + [C.c_int32]),
+    "s3a_batch_run": (C.c_int32, [C.c_void_p]),
+    "s3a_batch_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "s3a_decoder_utt_begin": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "s3a_lexsearch_hmm_histbin": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "s3a_decoder_score": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
@@ -499,6 +510,88 @@ class MsMgau:
         check(self.L.s3a_ms_mgau_get_dist(self.h, _p(d), _p(di)))
         shp = (self.n_mgau, self.n_feat, self.topn)
         return d.reshape(shp), di.reshape(shp)
+
+
+class Batch:
+    """B decoders per kernel launch (s3a_batch_*): attach (LexSearch, Scorer, ComSen) triples, then per
+    frame transition() + submit() for every decoder inside an utterance and one run()."""
+
+    def __init__(self, max_slots):
+        self.L = load()
+        self.h = self.L.s3a_batch_create(int(max_slots))
+        if not self.h:
+            raise S3AError(_err(self.L))
+        self.members, self.pending = [], {}
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_batch_free(self.h)
+            self.h = None
+
+    def attach(self, ls: "LexSearch", sc: "Scorer", cs: "ComSen"):
+        slot = self.L.s3a_batch_attach(self.h, ls.h, sc.h, cs.h)
+        check(slot if slot < 0 else 0)
+        self.members.append((ls, sc, cs))
+        return slot
+
+    def utt_begin(self, slot):
+        check(self.L.s3a_batch_utt_begin(self.h, int(slot)))
+
+    def utt_end(self, slot):
+        check(self.L.s3a_batch_utt_end(self.h, int(slot)))
+
+    def transition(self, slot, cf, thresh, a=None, b=None):
+        def unpack(g):
+            if g is None:
+                z = np.zeros(0, np.int32)
+                return 0, z, z, z
+            return int(g[0]), *(np.ascontiguousarray(x, np.int32) for x in g[1:])
+        ta, la, sa, ha = unpack(a)
+        tb, lb, sb, hb = unpack(b)
+        check(self.L.s3a_batch_transition(self.h, int(slot), int(cf), int(thresh), ta, len(la), _p(la), _p(sa), _p(ha),
+                                          tb, len(lb), _p(lb), _p(sb), _p(hb)))
+
+    def _bufs(self, slot):
+        ls = self.members[slot][0]
+        cap = ls.T * ls.max_node
+        return dict(res=FrameResult(), n=np.zeros(ls.T, np.int32), w=np.zeros(cap, np.int32),
+                    s=np.zeros(cap, np.int32), h=np.zeros(cap, np.int32), cap=cap, T=ls.T)
+
+    def _call(self, fn, slot, feat, frame, frm, hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf):
+        o = self._bufs(slot)
+        x = np.ascontiguousarray(feat, np.float32)
+        o["x"] = x
+        check(fn(self.h, int(slot), _p(x), int(frame), int(frm), int(hmmbeam), int(pbeam), int(wbeam),
+                 int(phone_uses_wbeam), int(maxhmmpf), C.byref(o["res"]), _p(o["n"]), _p(o["w"]), _p(o["s"]),
+                 _p(o["h"]), o["cap"]))
+        return o
+
+    @staticmethod
+    def _result(o):
+        off = np.concatenate([[0], np.cumsum(o["n"])])
+        return o["res"], [(o["w"][off[t]:off[t + 1]], o["s"][off[t]:off[t + 1]], o["h"][off[t]:off[t + 1]])
+                          for t in range(o["T"])]
+
+    def submit(self, slot, feat, frame, frm, hmmbeam, pbeam, wbeam, phone_uses_wbeam=0, maxhmmpf=20000):
+        self.pending[slot] = self._call(self.L.s3a_batch_submit, slot, feat, frame, frm, hmmbeam, pbeam, wbeam,
+                                        phone_uses_wbeam, maxhmmpf)
+
+    def run(self):
+        """Execute the step for every submitted slot; returns {slot: (FrameResult, exits per tree)}."""
+        check(self.L.s3a_batch_run(self.h))
+        out = {s: self._result(o) for s, o in self.pending.items()}
+        self.pending = {}
+        return out
+
+    def step(self, slot, feat, frame, frm, hmmbeam, pbeam, wbeam, phone_uses_wbeam=0, maxhmmpf=20000):
+        """Blocking rendezvous (one host thread per decoder)."""
+        return self._result(self._call(self.L.s3a_batch_step, slot, feat, frame, frm, hmmbeam, pbeam, wbeam,
+                                       phone_uses_wbeam, maxhmmpf))
+
+    def stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(self.L.s3a_batch_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
 
 class ComSen:

@@ -432,6 +432,44 @@ int32_t s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen
                                const int32_t *scr_a, const int32_t *hist_a, int32_t tree_b,
                                int32_t n_b, const int32_t *lc_b, const int32_t *scr_b,
                                const int32_t *hist_b);
+/*
+ * The BATCHED fused frame (s3a_batch.hip): B decoders share every kernel launch and the one
+ * synchronisation of a step.  Utterances are independent, a single decoder's
+ * frame is a chain of latency-bound launches that leaves the chip idle, and HIP streams only
+ * overlap as far as the hardware queues go; batching the launches is what scales decoders per
+ * GPU.  Each decoder keeps its own handles (s3a_lexsearch_t / s3a_scorer_t / s3a_comsen_t), its
+ * own host thread and the reference's host code; results are those of s3a_decoder_*.
+ *   s3a_batch_attach      register a decoder (all its work moves to the engine's stream) -> slot
+ *   s3a_batch_utt_begin   srch_TST_begin's device side; the slot now takes part in the steps
+ *   s3a_batch_transition  the frame's lextree_enter calls + lextree_active_swap: RECORDED (host
+ *                         only), executed at the head of the slot's next step; required before
+ *                         every step, also at utterance begin (cf = -1)
+ *   s3a_batch_step        this frame's scoring + search for the slot (arguments as
+ *                         s3a_decoder_score + s3a_decoder_search); BLOCKS until every slot that is
+ *                         inside an utterance has called it; the last arrival runs the step
+ *   s3a_batch_utt_end     lextree_utt_end; the slot leaves the steps (others no longer wait for it)
+ *   s3a_batch_submit/run  the same step for single-threaded drivers: submit every active slot, run
+ */
+typedef struct s3a_batch_s s3a_batch_t;
+s3a_batch_t *s3a_batch_create(int32_t max_slots);
+void    s3a_batch_free(s3a_batch_t *b);
+int32_t s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs);
+int32_t s3a_batch_utt_begin(s3a_batch_t *b, int32_t slot);
+int32_t s3a_batch_utt_end(s3a_batch_t *b, int32_t slot);
+int32_t s3a_batch_transition(s3a_batch_t *b, int32_t slot, int32_t cf, int32_t thresh, int32_t tree_a,
+                             int32_t n_a, const int32_t *lc_a, const int32_t *scr_a, const int32_t *hist_a,
+                             int32_t tree_b, int32_t n_b, const int32_t *lc_b, const int32_t *scr_b,
+                             const int32_t *hist_b);
+int32_t s3a_batch_step(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, int32_t frm,
+                       int32_t hmmbeam, int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam,
+                       int32_t maxhmmpf, s3a_frame_result_t *res, int32_t *n_exit, int32_t *exit_wid,
+                       int32_t *exit_score, int32_t *exit_hist, int32_t max_exits);
+int32_t s3a_batch_submit(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, int32_t frm,
+                         int32_t hmmbeam, int32_t pbeam, int32_t wbeam, int32_t phone_uses_wbeam,
+                         int32_t maxhmmpf, s3a_frame_result_t *res, int32_t *n_exit, int32_t *exit_wid,
+                         int32_t *exit_score, int32_t *exit_hist, int32_t max_exits);
+int32_t s3a_batch_run(s3a_batch_t *b);
+int32_t s3a_batch_stats(s3a_batch_t *b, int64_t *steps, int64_t *slot_frames);
 /* srch_TST_select_active_gmm (srch_time_switch_tree.c:1262-1324): clear, then mark the
  * senones of every active HMM (composite ones through their member lists) in a DEVICE
  * flag array of n_sen bytes (s3a_scorer_sen_active_dev) */

@@ -207,6 +207,11 @@ static __thread s3a_scorer_t *g_sc;
 static __thread s3a_comsen_t *g_cs;
 static __thread s3a_tmat_t *g_tm;
 static __thread s3a_lexsearch_t *g_ls;
+/* S3A_BATCH=1: all decoder threads share every kernel launch through one s3a_batch_t */
+static s3a_batch_t *g_batch;
+static __thread int32 g_slot;
+static __thread float32 g_featbuf[64];
+static __thread int32 g_feat_idx;
 /* lextree_enter calls of the current frame, waiting for the swap (see be_enter) */
 #define PEND_MAX 1024
 static __thread int32 g_pend_tree[2], g_pend_n[2], g_pend_cf, g_pend_thresh;
@@ -439,7 +444,13 @@ be_swap(int32 cf)
     for (t = 0; t < g_ntree; t++) s3o_lextree_active_swap(g_lt[t]);
 #else
     /* the unigram-tree batch may be empty while the filler batch is not: keep them apart by slot */
-    if (s3a_decoder_transition(g_ls, g_sc, g_cs, g_pend_n[0] || g_pend_n[1] ? g_pend_cf : cf,
+    if (g_batch) {
+        if (s3a_batch_transition(g_batch, g_slot, g_pend_n[0] || g_pend_n[1] ? g_pend_cf : cf, g_pend_thresh,
+                                 g_pend_tree[0], g_pend_n[0], g_pend_lc[0], g_pend_scr[0], g_pend_hist[0],
+                                 g_pend_tree[1], g_pend_n[1], g_pend_lc[1], g_pend_scr[1], g_pend_hist[1]) != S3A_OK)
+            die("batch transition");
+    }
+    else if (s3a_decoder_transition(g_ls, g_sc, g_cs, g_pend_n[0] || g_pend_n[1] ? g_pend_cf : cf,
                                g_pend_thresh, g_pend_tree[0], g_pend_n[0], g_pend_lc[0], g_pend_scr[0],
                                g_pend_hist[0], g_pend_tree[1], g_pend_n[1], g_pend_lc[1], g_pend_scr[1],
                                g_pend_hist[1]) != S3A_OK) die("transition");
@@ -466,7 +477,8 @@ tst_begin(void *srch)
     if (g)
         for (i = 0; i < g->n_mgau; i++) { g->mgau[i].bstidx = NO_BSTIDX; g->mgau[i].updatetime = NOT_UPDATED; }
 #ifndef LT_ORACLE
-    if (s3a_decoder_utt_begin(g_ls, g_sc) != S3A_OK) die("decoder_utt_begin");
+    if ((g_batch ? s3a_batch_utt_begin(g_batch, g_slot) : s3a_decoder_utt_begin(g_ls, g_sc)) != S3A_OK)
+        die("decoder_utt_begin");
     g_pend_n[0] = g_pend_n[1] = 0;
 #endif
     lc = mdef_silphone(kbc->mdef);
@@ -494,7 +506,7 @@ tst_end(void *srch)
     g_trace_utt++;
 #else
     (void)t;
-    if (s3a_lexsearch_utt_end(g_ls) != S3A_OK) die("utt_end");
+    if ((g_batch ? s3a_batch_utt_end(g_batch, g_slot) : s3a_lexsearch_utt_end(g_ls)) != S3A_OK) die("utt_end");
 #endif
     lm_cache_stats_dump(kbcore_lm(s->kbc));
     lm_cache_reset(kbcore_lm(s->kbc));
@@ -525,7 +537,11 @@ static int
 tst_gmm_lv2(void *srch, float32 **feat, int32 wav_idx)
 {
     srch_t *s = srch;
-    if (s3a_decoder_score(g_sc, feat[0], wav_idx) != S3A_OK)
+    if (g_batch) {          /* scored inside the batched step (propagate_graph_wd_lv2 slot) */
+        memcpy(g_featbuf, feat[0], sizeof(float32) * s3a_mgau_veclen(g_gm));
+        g_feat_idx = wav_idx;
+    }
+    else if (s3a_decoder_score(g_sc, feat[0], wav_idx) != S3A_OK)
         die("lv2");
     g_ascale_idx = s->num_frm + wav_idx;
     s->senscale = 0;
@@ -726,9 +742,13 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
         int32 k = 0;
         int32 wbeam_phone = (bm->ptranskip != 0 && (frmno % bm->ptranskip) == 0);
         double t0 = now_s();
-        if (s3a_decoder_search(g_ls, g_sc, g_cs, frmno, bm->hmm, bm->ptrans, bm->word, wbeam_phone,
-                               hp->maxhmmpf, &r, g_exit_n, g_exit_wid, g_exit_scr, g_exit_hist,
-                               g_ntree * g_max_node) != S3A_OK) {
+        if ((g_batch
+             ? s3a_batch_step(g_batch, g_slot, g_featbuf, g_feat_idx, frmno, bm->hmm, bm->ptrans, bm->word,
+                              wbeam_phone, hp->maxhmmpf, &r, g_exit_n, g_exit_wid, g_exit_scr, g_exit_hist,
+                              g_ntree * g_max_node)
+             : s3a_decoder_search(g_ls, g_sc, g_cs, frmno, bm->hmm, bm->ptrans, bm->word, wbeam_phone,
+                                  hp->maxhmmpf, &r, g_exit_n, g_exit_wid, g_exit_scr, g_exit_hist,
+                                  g_ntree * g_max_node)) != S3A_OK) {
             E_ERROR("%s\n", s3a_last_error());
             return SRCH_FAILURE;
         }
@@ -846,6 +866,9 @@ worker_main(void *vp)
         E_FATAL("tst shim: -op_mode 4 (fwdtree) only\n");
     backend_init(&kb, (srch_TST_graph_t *)((srch_t *)kb.srch)->grh->graph_struct);
     install_slots(kb.srch);
+#ifndef LT_ORACLE
+    if (g_batch && (g_slot = s3a_batch_attach(g_batch, g_ls, g_sc, g_cs)) < 0) die("batch attach");
+#endif
     pthread_mutex_unlock(&g_init_lock);
     if (pthread_barrier_wait(&g_start) == PTHREAD_BARRIER_SERIAL_THREAD)
         g_t_start = now_s();        /* every decoder is loaded: the decode clock starts here */
@@ -894,6 +917,12 @@ main(int argc, char *argv[])
     cmd_ln_appl_enter(argc, argv, "default.arg", arg);      /* `arg`: the reference's own table */
     unlimit();
     config = cmd_ln_get();
+#ifndef LT_ORACLE
+    if (getenv("S3A_BATCH") && atoi(getenv("S3A_BATCH")) > 0) {
+        if (n_streams < 1) n_streams = 1;
+        if ((g_batch = s3a_batch_create(n_streams)) == NULL) die("batch create");
+    }
+#endif
     if (!cmd_ln_str_r(config, "-ctl"))
         E_FATAL("-ctl is required\n");
     if (n_streams < 1) n_streams = 1;
@@ -935,6 +964,14 @@ main(int argc, char *argv[])
         E_FATAL("tst shim: the replaced slots were never called\n");
     E_INFO("tst shim: %ld frames searched by the replacement backend in %d stream(s)\n", frames, n_streams);
     E_INFO("tst shim: histogram pruning (lextree_hmm_histbin) applied in %ld frames\n", histframes);
+#ifndef LT_ORACLE
+    if (g_batch) {
+        int64_t st = 0, fr = 0;
+        s3a_batch_stats(g_batch, &st, &fr);
+        E_INFO("tst shim: batched engine: %ld steps served %ld decoder-frames (mean batch %.1f)\n", (long)st,
+               (long)fr, st ? (double)fr / st : 0.0);
+    }
+#endif
     E_INFO("tst shim timing: %.1f us/frame inside utterances per stream (%.0f x real time per stream); of which "
            "frame_search (enqueue + the one sync) %.1f us, vithist_prune + word transitions %.1f us\n",
            1e6 * t_utt / frames, 0.01 * frames / (t_utt / n_streams) / n_streams, 1e6 * t_search / frames,

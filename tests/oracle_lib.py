@@ -396,6 +396,7 @@ class OracleLexSearch:
         L.s3o_sseq2sen_active.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.s3o_comsseq2sen_active.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.s3o_lextree_hmm_histbin.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+        L.s3o_lextree_utt_end.argtypes = [C.c_void_p]
         self.lt = []
         for t in tr["trees"]:
             arrs = dict(ssid=c(t["ssid"], np.int32), tmatid=c(t["tmatid"], np.int32),
@@ -467,6 +468,10 @@ class OracleLexSearch:
         out[:, 6] = raw["out_score"]; out[:, 7] = raw["out_history"]
         out[:, 8] = raw["bestscore"]; out[:, 9] = raw["frame"]
         return out
+
+    def utt_end(self):
+        for h in self.lt:
+            self.L.s3o_lextree_utt_end(h)
 
     def histbin(self, t, bestscr, bins, bw):
         """lextree_hmm_histbin on tree t: bins (int32) updated in place, active list reordered."""
