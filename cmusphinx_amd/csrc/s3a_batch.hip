@@ -44,7 +44,9 @@ struct BSlot {              /* one decoder: static model + its state, all device
     const uint8_t *comp;
     const int16_t *sseq, *comsseq;
     int32_t *sc, *hist, *outs, *outh, *bests, *frame, *pos, *posf, *act[2], *nact[2], *turn, *selfemit,
-        *cnt, *base, *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0;
+        *cnt, *base, *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0, *pstamp;
+    const int32_t *rootnodes, *ps, *psof_off, *psof;
+    int32_t n_rootnodes;
     unsigned long long *key;
     const int32_t *cs_off, *cs_wt;
     const int16_t *cs_list;
@@ -128,7 +130,7 @@ kb_hmm_eval(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
     if ((int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * DBLOCK) >= s.maxn) return;
     d_dec_hmm_eval(s.node_base, s.act[f.cur], s.nact[f.cur], s.N, s.n_tmat, s.ssid, s.tmatid, s.wid, s.comp,
                    s.tp, s.sseq, s.comsseq, s.cs_off, s.cs_list, s.cs_wt, s.scr, s.misc, s.sc, s.hist, s.outs,
-                   s.outh, s.bests, s.best, blockIdx.x, blockIdx.y);
+                   s.outh, s.bests, s.best, f.frm, s.psof_off, s.psof, s.pstamp, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -156,8 +158,9 @@ kb_resolve(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
     if ((int32_t)(blockIdx.x * DBLOCK) >= s.N) return;
     d_dec_resolve(s.N, s.T, f.frm, f.bm, s.best, s.nact[f.cur], s.node_base, s.tree_of, s.prob, s.par_off, s.par,
                   s.pos, s.posf, s.sc, s.hist, s.outs, s.outh, s.bests, s.frame, s.turn, s.selfemit, s.cnt, s.key,
-                  s.first, s.hbin, blockIdx.x, 0);
+                  s.first, s.hbin, s.ps, s.pstamp, s.rootnodes, s.n_rootnodes, blockIdx.x, 0);
 }
+
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 kb_scan(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int32_t *pack_all,
@@ -279,7 +282,9 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         s.nact[0] = ls->d_nact[0]; s.nact[1] = ls->d_nact[1]; s.turn = ls->d_turn; s.selfemit = ls->d_selfemit;
         s.cnt = ls->d_cnt; s.base = ls->d_cand; s.best = ls->d_best; s.exits = ls->d_exit; s.nexit = ls->d_nexit;
         s.first = ls->d_first; s.eflag = ls->d_eflag; s.hbin = ls->d_hbin; s.done = ls->d_done; s.key = ls->d_key;
-        s.ctot = ls->d_ctot; s.n0 = ls->d_n0;
+        s.ctot = ls->d_ctot; s.n0 = ls->d_n0; s.pstamp = ls->d_pstamp; s.rootnodes = ls->d_rootnodes;
+        s.ps = ls->d_ps; s.psof_off = ls->d_psof_off; s.psof = ls->d_psof;
+        s.n_rootnodes = ls->n_rootnodes;
         s.cs_off = cs->off_d; s.cs_wt = cs->wt_d; s.cs_list = cs->list_d;
         s.mean4 = d->mean4; s.prec4 = d->prec4; s.lrd = d->lrd; s.mixw = d->mixw; s.tab16 = d->tab16;
         s.tab_size = d->tab_size; s.lm_zero = d->lm_zero; s.f = sc->g->f; s.distfloor = sc->g->distfloor;

@@ -55,9 +55,10 @@ k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                const int16_t *__restrict__ cs_list, const int32_t *__restrict__ cs_wt,
                const int32_t *__restrict__ raw, const int32_t *__restrict__ misc,
                int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
-               int32_t *best_out)
+               int32_t *best_out, int32_t cf, const int32_t *__restrict__ psof_off,
+               const int32_t *__restrict__ psof, int32_t *pstamp)
 {
-    d_dec_hmm_eval(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, blockIdx.x, blockIdx.y);
+    d_dec_hmm_eval(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, cf, psof_off, psof, pstamp, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -86,10 +87,13 @@ k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               const int32_t *__restrict__ pos, const int32_t *__restrict__ posf,
               int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
               int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
-              unsigned long long *key, int32_t *first, int32_t *hbin)
+              unsigned long long *key, int32_t *first, int32_t *hbin,
+              const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
+              const int32_t *__restrict__ rootnodes, int32_t n_rootnodes)
 {
-    d_dec_resolve(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, blockIdx.x, blockIdx.y);
+    d_dec_resolve(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, blockIdx.x, blockIdx.y);
 }
+
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
@@ -338,7 +342,8 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        (size_t)ls->n_tmat * 12 * 4, ls->stream, ls->d_node_base, ls->d_act[cur],
                        ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
                        ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
-                       sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best);
+                       sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best, frm,
+                       ls->d_psof_off, ls->d_psof, ls->d_pstamp);
     if (may_hist) {
         hipLaunchKernelGGL(k_dec_hist_count, dim3((maxn + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK), 0, ls->stream,
                            ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], T, bm, ls->d_best, ls->d_bests,
@@ -351,7 +356,8 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->N, T, frm, bm, ls->d_best, ls->d_nact[cur], ls->d_node_base, ls->d_tree_of,
                        ls->d_prob, ls->d_par_off, ls->d_par, ls->d_pos, ls->d_posf, ls->d_sc, ls->d_hist,
                        ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame, ls->d_turn, ls->d_selfemit,
-                       ls->d_cnt, ls->d_key, ls->d_first, ls->d_hbin);
+                       ls->d_cnt, ls->d_key, ls->d_first, ls->d_hbin, ls->d_ps, ls->d_pstamp, ls->d_rootnodes,
+                       ls->n_rootnodes);
     hipLaunchKernelGGL(k_dec_scan, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
                        ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_wid, ls->d_prob, ls->d_outs,
                        ls->d_outh, ls->d_selfemit, ls->d_cnt, ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt],

@@ -23,6 +23,8 @@ struct FrameBeams {
 };
 
 #define NBIN 1000        /* srch_time_switch_tree.c:858 */
+#define EMIT_WAVES (DBLOCK / 64)
+#define EMIT_BLOCKS 32          /* workgroups per tree in the list sweeps: 128 waves, 8192 positions per pass */
 
 /* thresholds of srch_TST_hmm_compute_lv2 (srch_time_switch_tree.c:849-905) from the per-tree
  * maxima hmm_eval left in best[]; when the frame holds more than 1.5 x maxhmmpf HMMs the
@@ -62,7 +64,8 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                const int16_t *__restrict__ cs_list, const int32_t *__restrict__ cs_wt,
                const int32_t *__restrict__ raw, const int32_t *__restrict__ misc,
                int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
-               int32_t *best_out,
+               int32_t *best_out, int32_t cf, const int32_t *__restrict__ psof_off,
+               const int32_t *__restrict__ psof, int32_t *pstamp,
         const int32_t BX, const int32_t BY)
 {
     extern __shared__ int32_t tp_s[];
@@ -104,6 +107,9 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         bests[v] = k;
         best = k;
         if (wid[v] >= 0) wbest = k;
+        /* this node is active in frame cf: stamp the parent sets its children belong to (k_dec_resolve
+         * skips every node whose parent set carries no stamp of this frame) */
+        for (int32_t q = psof_off[v]; q < psof_off[v + 1]; q++) pstamp[psof[q]] = cf;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -278,6 +284,8 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
               int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
               unsigned long long *key, int32_t *first, int32_t *hbin,
+              const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
+              const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
         const int32_t BX, const int32_t BY)
 {
     __shared__ int32_t s_th, s_pth, s_hist;
@@ -291,10 +299,17 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
         for (int32_t i = threadIdx.x; i < NBIN; i += DBLOCK) hbin[i] = 0;
     const int32_t v = BX * DBLOCK + threadIdx.x;
     if (v >= N) return;
-    key[v] = 0ull;
-    first[v] = INT_MAX;
+    if (v < n_rootnodes) {                              /* lextree_enter only ever touches root nodes */
+        const int32_t r = rootnodes[v];
+        key[r] = 0ull;
+        first[r] = INT_MAX;
+    }
     const int32_t th = s_th, pth = s_pth, nf = cf + 1;
     const bool is_active = posf[v] == cf;
+    if (!is_active) {                                   /* no active parent: nothing can happen to v */
+        const int32_t q = ps[v];
+        if (q < 0 || pstamp[q] != cf) return;
+    }
     const int32_t j = is_active ? pos[v] : INT_MAX;
     const int32_t in0 = sc[v];
     int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
@@ -462,8 +477,6 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     if (threadIdx.x == 0) *done = 0;
 }
 
-#define EMIT_WAVES (DBLOCK / 64)
-#define EMIT_BLOCKS 32          /* workgroups per tree: 128 waves, 8192 list positions per sweep */
 __device__ __forceinline__ void
 d_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
            const int32_t *__restrict__ nact, const int32_t *__restrict__ child_off,

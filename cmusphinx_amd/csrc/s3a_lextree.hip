@@ -38,6 +38,8 @@
 #include <string.h>
 #include <limits.h>
 #include <vector>
+#include <algorithm>
+#include <map>
 
 #include "s3a_device.h"
 #include "s3a_structs.h"
@@ -563,6 +565,32 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
             for (int32_t v = ls->node_base[t]; v < ls->node_base[t + 1]; v++) h_tree_of[v] = t;
         UP(ls->d_tree_of, h_tree_of);
     }
+    {
+        /* parent SETS: nodes with the same parent list share an id (the ~10 k first-level nodes of a
+         * tree all hang under one of a few thousand groups of left-context root variants); an active
+         * node stamps the ids its children carry, so "does v have an active parent" is one look-up */
+        std::map<std::vector<int32_t>, int32_t> ids;
+        std::vector<int32_t> h_ps(N, -1), h_psoff(N + 1, 0), h_psof;
+        for (int32_t v = 0; v < N; v++) {
+            if (h_poff[v + 1] == h_poff[v]) continue;
+            std::vector<int32_t> key(h_par.begin() + h_poff[v], h_par.begin() + h_poff[v + 1]);
+            auto it = ids.find(key);
+            if (it == ids.end()) it = ids.emplace(std::move(key), (int32_t)ids.size()).first;
+            h_ps[v] = it->second;
+        }
+        for (int32_t u = 0; u < N; u++) {
+            std::vector<int32_t> mine;
+            for (int32_t j = h_coff[u]; j < h_coff[u + 1]; j++) mine.push_back(h_ps[h_child[j]]);
+            std::sort(mine.begin(), mine.end());
+            mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
+            h_psoff[u] = (int32_t)h_psof.size();
+            h_psof.insert(h_psof.end(), mine.begin(), mine.end());
+        }
+        h_psoff[N] = (int32_t)h_psof.size();
+        ls->n_pset = (int32_t)ids.size();
+        UP(ls->d_ps, h_ps); UP(ls->d_psof_off, h_psoff); UP(ls->d_psof, h_psof);
+        DMALLOC(ls->d_pstamp, (size_t)(ls->n_pset > 0 ? ls->n_pset : 1) * 4);
+    }
     ls->h_rootlist = h_roots;
 #undef UP
     {
@@ -599,6 +627,14 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
     DMALLOC(ls->d_done, 4 * 4);
     HIPCHK(hipMemset(ls->d_done, 0, 16));
     DMALLOC(ls->d_hbin, 1024 * 4);
+    {
+        std::vector<int32_t> uniq(h_roots);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        ls->n_rootnodes = (int32_t)uniq.size();
+        DMALLOC(ls->d_rootnodes, uniq.size() * 4);
+        if (!uniq.empty()) HIPCHK(hipMemcpy(ls->d_rootnodes, uniq.data(), uniq.size() * 4, hipMemcpyHostToDevice));
+    }
     DMALLOC(ls->d_ctot, 4096 * 4); DMALLOC(ls->d_n0, (size_t)n_tree * 4);
     HIPCHK(hipMemset(ls->d_hbin, 0, 1024 * 4));
     ls->hist_bound = ls->last_nnxt = 1 << 30;
@@ -666,7 +702,8 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
         &ls->d_frame, &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
-        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_tree_of, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0 };
+        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_tree_of, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0, &ls->d_rootnodes, &ls->d_ps, &ls->d_psof_off, &ls->d_psof,
+        &ls->d_pstamp };
     for (auto p : ptrs) (void)hipFree(*p);
     (void)hipFree(ls->d_comp); (void)hipFree(ls->d_sseq); (void)hipFree(ls->d_comsseq);
     (void)hipFree(ls->d_comstate); (void)hipFree(ls->d_key);
@@ -686,7 +723,8 @@ s3a_lexsearch_reset(s3a_lexsearch_t *ls)
         || (rc = fill(ls, ls->d_outs, WORST, N)) || (rc = fill(ls, ls->d_outh, -1, N))
         || (rc = fill(ls, ls->d_bests, WORST, N)) || (rc = fill(ls, ls->d_frame, -1, N))
         || (rc = fill(ls, ls->d_pos, -1, N)) || (rc = fill(ls, ls->d_posf, INT_MIN, N))
-        || (rc = fill(ls, ls->d_candf, INT_MIN, N)) || (rc = fill(ls, ls->d_turn, -1, N))
+        || (rc = fill(ls, ls->d_candf, INT_MIN, N)) || (rc = fill(ls, ls->d_pstamp, INT_MIN, ls->n_pset > 0 ? ls->n_pset : 1))
+        || (rc = fill(ls, ls->d_turn, -1, N))
         || (rc = fill(ls, ls->d_selfemit, 0, N)) || (rc = fill(ls, ls->d_cnt, 0, N))
         || (rc = fill(ls, ls->d_nact[0], 0, ls->n_tree)) || (rc = fill(ls, ls->d_nact[1], 0, ls->n_tree))
         || (rc = fill(ls, ls->d_nexit, 0, 2 * ls->n_tree))
@@ -987,7 +1025,8 @@ s3a_lexsearch_utt_end(s3a_lexsearch_t *ls)
     HIPCHK(hipGetLastError());
     /* frame-tagged scratch must not leak into the next utterance (frames restart at 0) */
     if ((rc = fill(ls, ls->d_nact[0], 0, ls->n_tree)) || (rc = fill(ls, ls->d_nact[1], 0, ls->n_tree))
-        || (rc = fill(ls, ls->d_posf, INT_MIN, ls->N)) || (rc = fill(ls, ls->d_candf, INT_MIN, ls->N)))
+        || (rc = fill(ls, ls->d_posf, INT_MIN, ls->N)) || (rc = fill(ls, ls->d_candf, INT_MIN, ls->N))
+        || (rc = fill(ls, ls->d_pstamp, INT_MIN, ls->n_pset > 0 ? ls->n_pset : 1)))
         return rc;
     HIPCHK(hipStreamSynchronize(ls->stream));
     return S3A_OK;
