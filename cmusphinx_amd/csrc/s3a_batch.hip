@@ -290,7 +290,7 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         s.tab_size = d->tab_size; s.lm_zero = d->lm_zero; s.f = sc->g->f; s.distfloor = sc->g->distfloor;
         s.D4 = d->D4; s.CP = d->CP; s.Gpad = d->Gpad; s.n_sen = sc->n_sen; s.n_ci_sen = sc->n_ci_sen;
         s.ncomp = sc->ncomp_d; s.cd2cisen = sc->cd2cisen_d; s.sen_act = sc->act_d; s.scr = sc->scr_d;
-        s.misc = sc->misc_d; s.bstidx = d->bstidx; s.bstscr = d->bstscr; s.updatetime = d->updatetime;
+        s.misc = sc->misc_d; s.bstidx = sc->bstidx_d; s.bstscr = sc->bstscr_d; s.updatetime = sc->updatetime_d;
         if (hipMemcpy(b->d_slots + slot, &s, sizeof s, hipMemcpyHostToDevice) != hipSuccess) { rc = S3A_EHIP; break; }
         b->ls[slot] = ls; b->sc[slot] = sc; b->cs[slot] = cs;
         b->exact = sc->g->precision == S3A_GMM_EXACT;

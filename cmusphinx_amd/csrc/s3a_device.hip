@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "s3a_device.h"
+#include "s3a_structs.h"
 
 #pragma clang fp contract(off)
 
@@ -662,6 +663,15 @@ k_reset_state(int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t S)
         bstscr[s] = S3A_LOGPROB_ZERO;
         updatetime[s] = S3A_NOT_UPDATED;
     }
+}
+
+/* the same reset on state arrays a scorer owns itself (s3a_scorer_init_private); asynchronous */
+int32_t
+s3a_reset_state_arrays(hipStream_t stream, int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t S)
+{
+    hipLaunchKernelGGL(k_reset_state, dim3((S + 255) / 256), dim3(256), 0, stream, bstidx, bstscr, updatetime, S);
+    HIPCHK(hipGetLastError());
+    return S3A_OK;
 }
 
 extern "C" int32_t

@@ -141,6 +141,31 @@ s3a_scorer_init(s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen, int
         }
         free(nc);
     }
+    sc->bstidx_d = d->bstidx; sc->bstscr_d = d->bstscr; sc->updatetime_d = d->updatetime;
+    return sc;
+}
+
+/* A scorer whose per-utterance Gaussian-selection state (mgau_t.bstidx / bstscr / updatetime,
+ * cont_mgau.h:174-176) is its own: several decoders can then share ONE model on the device
+ * (the batched engine reads the 16 MB of a hub4 model once per step instead of once per decoder). */
+extern "C" s3a_scorer_t *
+s3a_scorer_init_private(s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen, int32_t n_ci_sen,
+                        int32_t ds_ratio, int32_t cond_ds, double ci_pbeam, float tighten_factor,
+                        int32_t max_cd)
+{
+    s3a_scorer_t *sc = s3a_scorer_init(g, cd2cisen, n_sen, n_ci_sen, ds_ratio, cond_ds, ci_pbeam, tighten_factor, max_cd);
+    if (!sc) return NULL;
+    sc->bstidx_d = sc->bstscr_d = sc->updatetime_d = NULL;
+    if (hipMalloc(&sc->bstidx_d, sizeof(int32_t) * n_sen) != hipSuccess
+        || hipMalloc(&sc->bstscr_d, sizeof(int32_t) * n_sen) != hipSuccess
+        || hipMalloc(&sc->updatetime_d, sizeof(int32_t) * n_sen) != hipSuccess) {
+        s3a_set_error("s3a_scorer_init_private: device allocation failed");
+        sc->own_state = 1;
+        s3a_scorer_free(sc);
+        return NULL;
+    }
+    sc->own_state = 1;
+    if (s3a_scorer_utt_begin(sc) != S3A_OK) { s3a_scorer_free(sc); return NULL; }
     return sc;
 }
 
@@ -151,6 +176,7 @@ s3a_scorer_free(s3a_scorer_t *sc)
     (void)hipFree(sc->cd2cisen_d); (void)hipFree(sc->ncomp_d); (void)hipFree(sc->x_d);
     (void)hipFree(sc->act_d); (void)hipFree(sc->scr_d); (void)hipFree(sc->ci_d);
     (void)hipFree(sc->misc_d);
+    if (sc->own_state) { (void)hipFree(sc->bstidx_d); (void)hipFree(sc->bstscr_d); (void)hipFree(sc->updatetime_d); }
     if (sc->misc_h) (void)hipHostFree(sc->misc_h);
     free(sc->cd2cisen_h); free(sc->ci_occ_h); free(sc->idx_h);
     free(sc);
@@ -161,6 +187,8 @@ s3a_scorer_utt_begin(s3a_scorer_t *sc)
 {
     if (!sc) return S3A_EINVAL;
     sc->skip_count = 0;
+    if (sc->own_state)
+        return s3a_reset_state_arrays(sc->g->dev->stream, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->n_sen);
     return s3a_mgau_reset_state(sc->g);
 }
 
@@ -179,13 +207,13 @@ launch_gated(s3a_scorer_t *sc, int32_t lo, int32_t hi, int32_t ci_phase, int32_t
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
                            sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
-                           frame, is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d, best_slot, clear_active);
+                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active);
     else
         hipLaunchKernelGGL(k_gated_frame<false>, dim3(grid), dim3(256), 0, d->stream, d->mean4,
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
                            sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
-                           frame, is_skip, d->bstidx, d->bstscr, d->updatetime, sc->misc_d, best_slot, clear_active);
+                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active);
 }
 
 static const int32_t k_misc_init[8] = { INT_MIN, 0, 0, 0, 0, 0, 0, 0 };

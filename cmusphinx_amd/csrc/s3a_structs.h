@@ -24,6 +24,10 @@ struct s3a_scorer_s {
     int32_t *ci_d;          /* [n_ci_sen] */
     int32_t *misc_d;        /* [0]=best [1]=ns [2]=ng */
     int32_t *misc_h;        /* pinned mirror */
+    /* mgau_t.bstidx/bstscr/updatetime: the model's own arrays, or private ones when several decoders
+     * share one model (s3a_scorer_init_private) */
+    int32_t *bstidx_d, *bstscr_d, *updatetime_d;
+    int own_state;
     int32_t *ci_occ_h, *idx_h;
 };
 
@@ -94,6 +98,7 @@ struct s3a_lexsearch_s {
 /* internal cross-TU entry points */
 int32_t s3a_scorer_enqueue_raw(s3a_scorer_t *sc, const float *feat, int32_t frame);
 int32_t s3a_scorer_reset_frame_state(s3a_scorer_t *sc);
+int32_t s3a_reset_state_arrays(hipStream_t stream, int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t S);
 int32_t s3a_dec_stage_calls(s3a_lexsearch_t *ls, int32_t tree_a, int32_t n_a, const int32_t *lc_a,
                             const int32_t *scr_a, const int32_t *hist_a, int32_t tree_b, int32_t n_b,
                             const int32_t *lc_b, const int32_t *scr_b, const int32_t *hist_b,

@@ -62,6 +62,8 @@ _SIGS = {
                                               C.c_void_p, C.c_void_p]),
     "s3a_scorer_init": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_double, C.c_float, C.c_int32]),
+    "s3a_scorer_init_private": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_double, C.c_float, C.c_int32]),
     "s3a_scorer_free": (None, [C.c_void_p]),
     "s3a_scorer_utt_begin": (C.c_int32, [C.c_void_p]),
     "s3a_approx_cont_mgau_ci_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p,
@@ -393,14 +395,15 @@ class Scorer:
     """fast_gmm_t + approx_cont_mgau_{ci,frame}_eval + the ascr_t buffers they fill."""
 
     def __init__(self, g: MgauModel, cd2cisen, n_ci_sen, ds_ratio=1, cond_ds=0, ci_pbeam=1e-80,
-                 tighten_factor=0.5, max_cd=100000):
+                 tighten_factor=0.5, max_cd=100000, private_state=False):
         self.L = load()
         self.g = g
         self.cd2cisen = np.ascontiguousarray(cd2cisen, np.int16)
         self.n_sen = len(self.cd2cisen)
         self.n_ci_sen = int(n_ci_sen)
-        self.h = self.L.s3a_scorer_init(g.h, _p(self.cd2cisen), self.n_sen, self.n_ci_sen,
-                                        ds_ratio, cond_ds, ci_pbeam, tighten_factor, max_cd)
+        init = self.L.s3a_scorer_init_private if private_state else self.L.s3a_scorer_init
+        self.h = init(g.h, _p(self.cd2cisen), self.n_sen, self.n_ci_sen, ds_ratio, cond_ds, ci_pbeam,
+                      tighten_factor, max_cd)
         if not self.h:
             raise S3AError(_err(self.L))
 

@@ -187,6 +187,11 @@ typedef struct s3a_scorer_s s3a_scorer_t;
 s3a_scorer_t *s3a_scorer_init(s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen,
                               int32_t n_ci_sen, int32_t ds_ratio, int32_t cond_ds,
                               double ci_pbeam, float tighten_factor, int32_t max_cd);
+/* the same, with the scorer's own bstidx/bstscr/updatetime state: lets several decoders share one
+ * s3a_mgau_model_t (all on that model's stream); s3a_mgau_eval / s3a_mgau_state keep using the model's */
+s3a_scorer_t *s3a_scorer_init_private(s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen,
+                              int32_t n_ci_sen, int32_t ds_ratio, int32_t cond_ds,
+                              double ci_pbeam, float tighten_factor, int32_t max_cd);
 void    s3a_scorer_free(s3a_scorer_t *sc);
 /* srch_TST_begin's per-utterance reset of bstidx/updatetime */
 int32_t s3a_scorer_utt_begin(s3a_scorer_t *sc);

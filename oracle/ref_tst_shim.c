@@ -208,7 +208,14 @@ static __thread s3a_comsen_t *g_cs;
 static __thread s3a_tmat_t *g_tm;
 static __thread s3a_lexsearch_t *g_ls;
 /* S3A_BATCH=1: all decoder threads share every kernel launch through one s3a_batch_t */
-static s3a_batch_t *g_batch;
+#define MAX_GROUPS 8
+static s3a_batch_t *g_batches[MAX_GROUPS];       /* S3A_BATCH=G: G engines, decoder i steps with group i % G, so
+                                                 * one group's host phase overlaps the others' device phase */
+static int g_n_groups;
+static __thread s3a_batch_t *g_batch;
+static __thread int g_worker_id;
+static s3a_logmath_t *g_lm_shared[MAX_GROUPS];   /* batch mode: ONE model on the device per group of decoders */
+static s3a_mgau_model_t *g_gm_shared[MAX_GROUPS];
 static __thread int32 g_slot;
 static __thread float32 g_featbuf[64];
 static __thread int32 g_feat_idx;
@@ -374,13 +381,22 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
             E_FATAL("tst shim: no GPU; libcmusphinx_amd has no CPU fallback\n");
         if (kbcore_svq(kbc) || kbcore_gs(kbc) || !kbcore_mgau(kbc))
             E_FATAL("tst shim: only plain -senmgau .cont. scoring is supported\n");
-        g_lm = s3a_logs3_init(cmd_ln_float64_r(config, "-logbase"), 0, 1);
-        g_gm = s3a_mgau_init(cmd_ln_str_r(config, "-mean"), cmd_ln_str_r(config, "-var"),
-                             cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
-                             cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.",
-                             S3A_MIX_INT_FLOAT_COMP, g_lm);
-        if (!g_gm) die("s3a_mgau_init");
-        g_sc = s3a_scorer_init(g_gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen,
+        g_batch = g_n_groups ? g_batches[g_worker_id % g_n_groups] : NULL;
+        if (g_batch && g_gm_shared[g_worker_id % g_n_groups]) {         /* (called under g_init_lock) */
+            g_lm = g_lm_shared[g_worker_id % g_n_groups];
+            g_gm = g_gm_shared[g_worker_id % g_n_groups];
+        }
+        else {
+            g_lm = s3a_logs3_init(cmd_ln_float64_r(config, "-logbase"), 0, 1);
+            g_gm = s3a_mgau_init(cmd_ln_str_r(config, "-mean"), cmd_ln_str_r(config, "-var"),
+                                 cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
+                                 cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.",
+                                 S3A_MIX_INT_FLOAT_COMP, g_lm);
+            if (!g_gm) die("s3a_mgau_init");
+            if (g_batch) { g_lm_shared[g_worker_id % g_n_groups] = g_lm; g_gm_shared[g_worker_id % g_n_groups] = g_gm; }
+        }
+        g_sc = (g_batch ? s3a_scorer_init_private : s3a_scorer_init)(
+                               g_gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen,
                                cmd_ln_int32_r(config, "-ds"), cmd_ln_int32_r(config, "-cond_ds"),
                                cmd_ln_float64_r(config, "-ci_pbeam"),
                                cmd_ln_float32_r(config, "-tighten_factor"),
@@ -860,6 +876,9 @@ worker_main(void *vp)
     av[ac++] = "-ctloffset"; av[ac++] = so; av[ac++] = "-ctlcount"; av[ac++] = sc;
 
     pthread_mutex_lock(&g_init_lock);           /* model / dictionary / LM loading is not re-entrant */
+#ifndef LT_ORACLE
+    g_worker_id = w->id;
+#endif
     config = cmd_ln_parse_r(NULL, arg, ac, av, TRUE);
     kb_init(&kb, config);
     if (((srch_t *)kb.srch)->op_mode != 4)
@@ -920,7 +939,11 @@ main(int argc, char *argv[])
 #ifndef LT_ORACLE
     if (getenv("S3A_BATCH") && atoi(getenv("S3A_BATCH")) > 0) {
         if (n_streams < 1) n_streams = 1;
-        if ((g_batch = s3a_batch_create(n_streams)) == NULL) die("batch create");
+        g_n_groups = atoi(getenv("S3A_BATCH"));
+        if (g_n_groups > MAX_GROUPS) g_n_groups = MAX_GROUPS;
+        if (g_n_groups > n_streams) g_n_groups = n_streams;
+        for (i = 0; i < g_n_groups; i++)
+            if ((g_batches[i] = s3a_batch_create((n_streams + g_n_groups - 1) / g_n_groups)) == NULL) die("batch create");
     }
 #endif
     if (!cmd_ln_str_r(config, "-ctl"))
@@ -965,11 +988,11 @@ main(int argc, char *argv[])
     E_INFO("tst shim: %ld frames searched by the replacement backend in %d stream(s)\n", frames, n_streams);
     E_INFO("tst shim: histogram pruning (lextree_hmm_histbin) applied in %ld frames\n", histframes);
 #ifndef LT_ORACLE
-    if (g_batch) {
-        int64_t st = 0, fr = 0;
-        s3a_batch_stats(g_batch, &st, &fr);
-        E_INFO("tst shim: batched engine: %ld steps served %ld decoder-frames (mean batch %.1f)\n", (long)st,
-               (long)fr, st ? (double)fr / st : 0.0);
+    if (g_n_groups) {
+        int64_t st = 0, fr = 0, a, b;
+        for (i = 0; i < g_n_groups; i++) { s3a_batch_stats(g_batches[i], &a, &b); st += a; fr += b; }
+        E_INFO("tst shim: batched engine: %d group(s), %ld steps served %ld decoder-frames (mean batch %.1f)\n",
+               g_n_groups, (long)st, (long)fr, st ? (double)fr / st : 0.0);
     }
 #endif
     E_INFO("tst shim timing: %.1f us/frame inside utterances per stream (%.0f x real time per stream); of which "

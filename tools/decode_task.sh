@@ -12,6 +12,7 @@ s=$(date +%s%N); oracle/_ref/sphinx3_decode $ARGS -hyp $T/ref.match -hypseg $T/r
 echo "reference rc=$? wall $(( (e - s) / 1000000 )) ms"; grep "^INFO: stat.c.*SUMMARY" $T/ref.log | cut -c1-260
 for N in $STREAMS; do
   B=0; case $N in b*) B=1; N=${N#b};; esac      # "b16" = 16 decoders sharing every launch (s3a_batch_*)
+  case $N in *x*) B=${N#*x}; N=${N%x*};; esac     # "b16x2" = the same in 2 groups that alternate on the GPU
   s=$(date +%s%N); S3A_BATCH=$B S3A_STREAMS=$N oracle/_ref/ref_s3amd_tst_decode $ARGS -hyp $T/s$N.match -hypseg $T/s$N.seg > $T/s$N.log 2>&1; rc=$?; e=$(date +%s%N)
   echo "streams=$N batch=$B rc=$rc wall $(( (e - s) / 1000000 )) ms $(cmp $T/s$N.match $T/ref.match && cmp $T/s$N.seg $T/ref.seg && echo IDENTICAL-to-reference)"
   grep "^INFO.*tst shim t\|^INFO.*histogram\|^INFO.*batched engine\|^FATAL\|^ERROR" $T/s$N.log | cut -c24-300 | head -6
