@@ -70,7 +70,7 @@ struct BFrame {             /* one decoder's parameters for one step */
     int32_t cf, thresh, n_calls, n_ent, n_groups, pad0, groups[8];
     int32_t frm, may_hist;
     FrameBeams bm;
-    int32_t sc_frame, sc_beam, sc_is_skip, pad;
+    int32_t sc_frame, sc_beam, sc_is_skip, mark_rows;   /* mark_rows: bound on the list lengths before the entries */
     int32_t calls[4 * BMAXC];
 };
 
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(DBLOCK)
 kb_enter3_mark(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
 {
     SLOT_FRAME;
-    const int32_t n_ent_blocks = (f.n_ent + DBLOCK - 1) / DBLOCK, bpt = (s.maxn + DBLOCK - 1) / DBLOCK;
+    const int32_t n_ent_blocks = (f.n_ent + DBLOCK - 1) / DBLOCK, bpt = (f.mark_rows + DBLOCK - 1) / DBLOCK;
     if ((int32_t)blockIdx.x >= n_ent_blocks + bpt * s.T) return;
     const Entries ent = { f.calls, s.rootlist, f.n_calls };
     d_dec_enter3_mark(n_ent_blocks, ent, f.n_ent, f.calls, f.groups, f.n_groups, f.cf + 1, s.key, s.first, s.eflag,
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(DBLOCK)
 kb_hmm_eval(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
 {
     SLOT_FRAME;
-    if ((int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * DBLOCK) >= s.maxn) return;
+    if ((int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * DBLOCK) >= s.maxn) return;   /* (grid sized by the host bound) */
     d_dec_hmm_eval(s.node_base, s.act[f.cur], s.nact[f.cur], s.N, s.n_tmat, s.ssid, s.tmatid, s.wid, s.comp,
                    s.tp, s.sseq, s.comsseq, s.cs_off, s.cs_list, s.cs_wt, s.scr, s.misc, s.sc, s.hist, s.outs,
                    s.outh, s.bests, s.best, f.frm, s.psof_off, s.psof, s.pstamp, blockIdx.x, blockIdx.y);
@@ -200,7 +200,7 @@ struct s3a_batch_s {
     BFrame stage[BMAXSLOT];             /* per slot: pending transition + this frame's request */
     BOut out[BMAXSLOT];
     uint8_t has_trans[BMAXSLOT], active[BMAXSLOT], arrived[BMAXSLOT];
-    int32_t n_active, n_arrived, order[BMAXSLOT];
+    int32_t n_active, n_arrived, order[BMAXSLOT], rows[BMAXSLOT];
     int32_t *d_pack, *h_pack, pack_stride, pack_max_exits, hdr_max;
     int32_t g_ent, g_ci, g_cd, g_maxn, g_N, g_T, g_mark, g_tmat, exact;
     unsigned long long gen;
@@ -321,13 +321,15 @@ static int32_t
 run_batch(s3a_batch_t *b)
 {
     const int32_t n = b->n_arrived;
-    int32_t any_hist = 0, g_ent = 0, g_calls = 0, rc = S3A_OK;
+    int32_t any_hist = 0, g_ent = 0, g_calls = 0, g_rows = 1, g_mark = 1, rc = S3A_OK;
     for (int32_t z = 0; z < n; z++) {
         const int32_t slot = b->order[z];
         b->h_frames[z] = b->stage[slot];
         any_hist |= b->stage[slot].may_hist;
         g_ent = max(g_ent, (b->stage[slot].n_ent + 255) / 256);
         g_calls = max(g_calls, b->stage[slot].n_calls);
+        g_rows = max(g_rows, b->rows[slot]);
+        g_mark = max(g_mark, b->stage[slot].mark_rows);
     }
 #define CHK(expr) do { if ((expr) != hipSuccess) { s3a_set_error("s3a_batch: %s failed: %s", #expr, hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; goto done; } } while (0)
     {
@@ -339,7 +341,7 @@ run_batch(s3a_batch_t *b)
             hipLaunchKernelGGL(kb_enter1, dim3(g_ent, 1, n), dim3(256), 0, st, S, F);
             hipLaunchKernelGGL(kb_enter2, dim3(g_calls, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
         }
-        hipLaunchKernelGGL(kb_enter3_mark, dim3(g_ent * (256 / DBLOCK) + ((b->g_maxn + DBLOCK - 1) / DBLOCK) * b->g_T, 1, n),
+        hipLaunchKernelGGL(kb_enter3_mark, dim3(g_ent * (256 / DBLOCK) + ((g_mark + DBLOCK - 1) / DBLOCK) * b->g_T, 1, n),
                            dim3(DBLOCK), 0, st, S, F);
         if (b->exact) {
             if (b->g_ci) hipLaunchKernelGGL((kb_gated<true, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
@@ -349,10 +351,10 @@ run_batch(s3a_batch_t *b)
             if (b->g_ci) hipLaunchKernelGGL((kb_gated<false, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
             if (b->g_cd) hipLaunchKernelGGL((kb_gated<false, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
         }
-        hipLaunchKernelGGL(kb_hmm_eval, dim3((b->g_maxn + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK),
+        hipLaunchKernelGGL(kb_hmm_eval, dim3((g_rows + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK),
                            (size_t)b->g_tmat * 12 * 4, st, S, F);
         if (any_hist) {
-            hipLaunchKernelGGL(kb_hist_count, dim3((b->g_maxn + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
+            hipLaunchKernelGGL(kb_hist_count, dim3((g_rows + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
             hipLaunchKernelGGL(kb_hist_sort, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
         }
         hipLaunchKernelGGL(kb_resolve, dim3((b->g_N + DBLOCK - 1) / DBLOCK, 1, n), dim3(DBLOCK), 0, st, S, F);
@@ -438,6 +440,13 @@ s3a_batch_transition(s3a_batch_t *b, int32_t slot, int32_t cf, int32_t thresh, i
                                      hist_b, f.groups, f.calls, BMAXC, &f.n_calls, &f.n_ent, &f.n_groups);
     if (rc != S3A_OK) return rc;
     f.cf = cf; f.thresh = thresh;
+    {
+        s3a_lexsearch_t *ls = b->ls[slot];
+        int32_t maxn = 0;
+        for (int32_t t = 0; t < ls->n_tree; t++) maxn = max(maxn, ls->node_base[t + 1] - ls->node_base[t]);
+        f.mark_rows = min(maxn, max(ls->last_nnxt, 1));
+        b->rows[slot] = min(maxn, max(ls->hist_bound, 1));      /* bound on the coming frame's list lengths */
+    }
     b->ls[slot]->cur ^= 1;              /* lextree_active_swap */
     b->has_trans[slot] = 1;
     return S3A_OK;

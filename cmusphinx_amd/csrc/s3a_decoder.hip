@@ -338,14 +338,16 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
         return S3A_EUNSUP;
     }
 
-    hipLaunchKernelGGL(k_dec_hmm_eval, dim3((maxn + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK),
+    /* the active lists are at most hist_bound long (host bound): size the per-position grids by it */
+    const int32_t rows = min(maxn, max(ls->hist_bound, 1));
+    hipLaunchKernelGGL(k_dec_hmm_eval, dim3((rows + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK),
                        (size_t)ls->n_tmat * 12 * 4, ls->stream, ls->d_node_base, ls->d_act[cur],
                        ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
                        ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
                        sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best, frm,
                        ls->d_psof_off, ls->d_psof, ls->d_pstamp);
     if (may_hist) {
-        hipLaunchKernelGGL(k_dec_hist_count, dim3((maxn + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK), 0, ls->stream,
+        hipLaunchKernelGGL(k_dec_hist_count, dim3((rows + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK), 0, ls->stream,
                            ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], T, bm, ls->d_best, ls->d_bests,
                            ls->d_exit + ls->N, ls->d_hbin, -1, 0, 1, NBIN);
         hipLaunchKernelGGL(k_dec_hist_sort, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->d_node_base,
@@ -421,7 +423,8 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
     }
     {
         const int32_t n_ent_blocks = (n_ent + DBLOCK - 1) / DBLOCK;
-        const int32_t bpt = (maxn + DBLOCK - 1) / DBLOCK;
+        /* the lists before the entries hold at most last_nnxt nodes (what the search emitted) */
+        const int32_t bpt = (min(maxn, max(ls->last_nnxt, 1)) + DBLOCK - 1) / DBLOCK;
         hipLaunchKernelGGL(k_dec_enter3_mark, dim3(n_ent_blocks + bpt * T), dim3(DBLOCK), 0, ls->stream,
                            n_ent_blocks, ent, n_ent, ls->d_calls + 8, ls->d_calls, n_groups, cf + 1, ls->d_key,
                            ls->d_first, ls->d_eflag, ls->d_ctot, n_ent > 0 ? ls->d_n0 : ls->d_nact[nxt], ls->d_sc,

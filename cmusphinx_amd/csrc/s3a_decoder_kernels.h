@@ -84,9 +84,15 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
 #pragma unroll
             for (int st = 0; st < 3; st++) {
                 const int32_t cs = comsseq[ss * 3 + st];
-                int32_t m = raw[cs_list[cs_off[cs]]];
-                for (int32_t j = cs_off[cs] + 1; j < cs_off[cs + 1]; j++)
-                    m = max(m, raw[cs_list[j]]);
+                /* member senones 8 at a time: ids, then scores, are independent loads */
+                int32_t m = INT_MIN;
+                for (int32_t j0 = cs_off[cs], jend = cs_off[cs + 1]; j0 < jend; j0 += 8) {
+                    int32_t id[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) id[u] = (j0 + u < jend) ? (int32_t)cs_list[j0 + u] : -1;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (id[u] >= 0) m = max(m, raw[id[u]]);
+                }
                 e[st] = add32(add32(m, -norm), cs_wt[cs]);
             }
         }
@@ -288,15 +294,13 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
         const int32_t BX, const int32_t BY)
 {
-    __shared__ int32_t s_th, s_pth, s_hist;
-    if (threadIdx.x == 0) {
-        int32_t bh, bw, n, th, pth, wth;
-        s_hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth) ? 1 : 0;
-        s_th = th; s_pth = pth;
+    /* (the thresholds come from uniform addresses: computed per thread with scalar loads, and only by
+     * the few workgroups that have anything to do -- no LDS, no barrier in front of the early exit) */
+    if (BX == 0) {                              /* the bins were consumed by k_dec_hist_sort */
+        int32_t bh, bw, n, th0, pth0, wth0;
+        if (frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th0, pth0, wth0))
+            for (int32_t i = threadIdx.x; i < NBIN; i += DBLOCK) hbin[i] = 0;
     }
-    __syncthreads();
-    if (BX == 0 && s_hist)                      /* the bins were consumed by k_dec_hist_sort */
-        for (int32_t i = threadIdx.x; i < NBIN; i += DBLOCK) hbin[i] = 0;
     const int32_t v = BX * DBLOCK + threadIdx.x;
     if (v >= N) return;
     if (v < n_rootnodes) {                              /* lextree_enter only ever touches root nodes */
@@ -304,31 +308,47 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
         key[r] = 0ull;
         first[r] = INT_MAX;
     }
-    const int32_t th = s_th, pth = s_pth, nf = cf + 1;
+    const int32_t nf = cf + 1;
     const bool is_active = posf[v] == cf;
     if (!is_active) {                                   /* no active parent: nothing can happen to v */
         const int32_t q = ps[v];
         if (q < 0 || pstamp[q] != cf) return;
     }
+    int32_t th, pth;
+    {
+        int32_t bh, bw, n, wth;
+        (void)frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
+    }
     const int32_t j = is_active ? pos[v] : INT_MAX;
     const int32_t in0 = sc[v];
     int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
     int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
-    for (int32_t k = par_off[v]; k < par_off[v + 1]; k++) {
-        const int32_t p = par[k];
-        if (posf[p] != cf) continue;
-        const int32_t po = outs[p];
-        if (po < pth) continue;
-        const int32_t ns = add32(po, add32(prob[v], -prob[p]));
-        if (ns < th) continue;
-        const int32_t pp = pos[p];
-        if (pp < j) {
-            if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[p]; }
-            if (ns > in0 && pp < firstE) firstE = pp;
-        }
-        else {
-            if (ns > mL || (ns == mL && pp < pL)) { mL = ns; pL = pp; hL = outh[p]; }
-            if (pp < firstL) firstL = pp;
+    /* parents in batches of 8: the ids, then their list stamps, are independent loads (a first-level
+     * node has one parent per left-context variant of its root, ~46: a one-at-a-time walk is 46
+     * dependent round trips); the comparisons below do not depend on the visiting order */
+    for (int32_t k0 = par_off[v], kend = par_off[v + 1]; k0 < kend; k0 += 8) {
+        int32_t pid[8], pf[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) pid[u] = (k0 + u < kend) ? par[k0 + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; u++) pf[u] = (pid[u] >= 0) ? posf[pid[u]] : INT_MIN;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (pf[u] != cf || pid[u] < 0) continue;
+            const int32_t p = pid[u];
+            const int32_t po = outs[p];
+            if (po < pth) continue;
+            const int32_t ns = add32(po, add32(prob[v], -prob[p]));
+            if (ns < th) continue;
+            const int32_t pp = pos[p];
+            if (pp < j) {
+                if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[p]; }
+                if (ns > in0 && pp < firstE) firstE = pp;
+            }
+            else {
+                if (ns > mL || (ns == mL && pp < pL)) { mL = ns; pL = pp; hL = outh[p]; }
+                if (pp < firstL) firstL = pp;
+            }
         }
     }
     if (!is_active && mE == INT_MIN)
