@@ -123,6 +123,111 @@ kb_gated(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
                          CI ? (uint8_t *)NULL : s.sen_act, blockIdx.x);
 }
 
+/*
+ * The gated CD senones of the step's decoders when they share ONE model (the usual case: one
+ * acoustic model, many utterances).  A wave holds the CP Gaussians of one senone for 64/CP
+ * DECODERS side by side: lanes with the same Gaussian read the same parameter address, which the
+ * memory pipeline serves with one request, so the model streams through the caches once per
+ * 64/CP decoders instead of once per decoder, at the same parallelism (a lane per (Gaussian,
+ * decoder) pair).  Gate, distance, ordered log-add: the code of d_gated_frame (s3a_gated.h),
+ * bit-identical results; the per-decoder maxima / counters are reduced per 8-lane group, then
+ * per workgroup in LDS, before they touch the decoders' misc[] words.
+ * (A first version kept the parameters in registers and LOOPED over the decoders: with < 1 wave
+ * per SIMD every decoder's gate -> distance -> log-add chain was exposed latency; 78 us vs 45.)
+ */
+#define GX_THREADS 1024
+template <bool EXACT>
+__global__ void __launch_bounds__(GX_THREADS)
+kb_gated_cd_shared(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int32_t n)
+{
+    typedef typename Acc<EXACT>::T acc_t;
+    __shared__ float xs[64][64 + 4];            /* features of this workgroup's decoders (<= 64 / CP) */
+    __shared__ int32_t red[64][4];              /* per decoder: best, #senones, #Gaussians */
+    const BSlot &s0 = slots[frames[0].slot];
+    const int32_t CP = s0.CP, D4 = s0.D4, Gpad = s0.Gpad, per_wave = 64 / CP;
+    const int32_t z0 = blockIdx.y * per_wave;
+    for (int32_t i = threadIdx.x; i < per_wave * 64; i += GX_THREADS) {
+        const int32_t q = i >> 6, k = i & 63;
+        xs[q][k] = (z0 + q < n && k < D4 * 4) ? frames[z0 + q].feat[k] : 0.0f;
+    }
+    if (threadIdx.x < 64) { red[threadIdx.x][0] = INT_MIN; red[threadIdx.x][1] = 0; red[threadIdx.x][2] = 0; }
+    __syncthreads();
+    const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t q = lane / CP, c = lane - q * CP, z = z0 + q;
+    const int32_t sen = s0.n_ci_sen + blockIdx.x * (GX_THREADS / 64) + wave;
+    const bool valid = sen < s0.n_sen && z < n;
+    const int32_t g = sen * CP + c;
+    int32_t mode = 0, ci_scr = 0, bi = S3A_NO_BSTIDX, frame = 0, is_skip = 0, nc = 0;
+    const BSlot *sp = NULL;
+    LogAdd la;
+    la.tab = s0.tab16; la.size = s0.tab_size; la.zero = s0.lm_zero;
+    if (valid) {
+        const BFrame &f = frames[z];
+        sp = &slots[f.slot];
+        frame = f.sc_frame; is_skip = f.sc_is_skip;
+        nc = (int32_t)s0.ncomp[sen];
+        if (sp->sen_act[sen]) {
+            ci_scr = sp->scr[s0.cd2cisen[sen]];
+            if (ci_scr >= (int32_t)((uint32_t)sp->misc[5] + (uint32_t)f.sc_beam))
+                mode = 1;
+            else {
+                bi = sp->bstidx[sen];
+                mode = (bi == S3A_NO_BSTIDX || sp->updatetime[sen] != frame - 1) ? 3 : 2;
+            }
+        }
+    }
+    int32_t gs = S3A_LOGPROB_ZERO;
+    if (mode == 1 || (mode == 2 && c == bi)) {
+        acc_t a = (acc_t)s0.lrd[g];
+        const float *x = xs[q];
+        for (int32_t k = 0; k < D4; k++) {
+            const float4 m = s0.mean4[(size_t)k * Gpad + g], p = s0.prec4[(size_t)k * Gpad + g];
+            const float4 xv = *(const float4 *)(x + 4 * k);
+            a = Acc<EXACT>::step(a, xv.x, m.x, p.x);
+            a = Acc<EXACT>::step(a, xv.y, m.y, p.y);
+            a = Acc<EXACT>::step(a, xv.z, m.z, p.z);
+            a = Acc<EXACT>::step(a, xv.w, m.w, p.w);
+        }
+        gs = gau_to_int((double)a, s0.f, s0.distfloor, s0.mixw[g]);
+    }
+    int32_t score = S3A_LOGPROB_ZERO, bs = S3A_LOGPROB_ZERO, bidx = S3A_NO_BSTIDX;
+    for (int32_t cc = 0; cc < CP; cc++) {
+        const int32_t v = __shfl(gs, q * CP + cc, 64);
+        if (mode == 1 && cc < nc) {
+            score = la(score, v);
+            if (v > bs) { bs = v; bidx = cc; }
+        }
+        else if (mode == 2 && cc == bi) {
+            score = la(score, v);
+            if (v > bs) { bs = v; bidx = cc; }
+        }
+    }
+    if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
+    if (mode == 3) score = ci_scr;
+    if (valid && c == 0) {
+        sp->sen_act[sen] = 0;                           /* the mask is consumed */
+        if (mode != 0) {
+            sp->scr[sen] = score;
+            atomicMax(&red[q][0], score);
+            if (mode == 1) {
+                sp->bstidx[sen] = bidx; sp->bstscr[sen] = bs; sp->updatetime[sen] = frame;
+                atomicAdd(&red[q][1], 1); atomicAdd(&red[q][2], nc);
+            }
+            else if (mode == 2) {
+                if (is_skip) { sp->bstidx[sen] = bidx; sp->bstscr[sen] = bs; sp->updatetime[sen] = frame; }
+                atomicAdd(&red[q][2], 1);
+            }
+        }
+    }
+    __syncthreads();
+    if ((int32_t)threadIdx.x < per_wave && z0 + (int32_t)threadIdx.x < n) {
+        int32_t *misc = slots[frames[z0 + threadIdx.x].slot].misc;
+        if (red[threadIdx.x][0] != INT_MIN) atomicMax(&misc[0], red[threadIdx.x][0]);
+        if (red[threadIdx.x][1]) atomicAdd(&misc[1], red[threadIdx.x][1]);
+        if (red[threadIdx.x][2]) atomicAdd(&misc[2], red[threadIdx.x][2]);
+    }
+}
+
 __global__ void __launch_bounds__(DBLOCK)
 kb_hmm_eval(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
 {
@@ -343,13 +448,31 @@ run_batch(s3a_batch_t *b)
         }
         hipLaunchKernelGGL(kb_enter3_mark, dim3(g_ent * (256 / DBLOCK) + ((g_mark + DBLOCK - 1) / DBLOCK) * b->g_T, 1, n),
                            dim3(DBLOCK), 0, st, S, F);
+        /* one model for every decoder of the step (and a shape the stationary kernel holds in
+         * registers)?  then the CD senones of all of them are one pass over the model */
+        bool shared = n > 1 && n <= 64 && getenv("S3A_BATCH_NO_SHARED") == NULL;
+        for (int32_t z = 0; z < n && shared; z++) {
+            const s3a_scorer_t *sc = b->sc[b->order[z]], *sc0 = b->sc[b->order[0]];
+            shared = sc->g == sc0->g && sc->n_sen == sc0->n_sen && sc->n_ci_sen == sc0->n_ci_sen
+                && sc->cd2cisen_d != NULL && sc0->g->dev->D4 * 4 <= 64 && sc0->g->dev->CP <= 64;
+        }
+        dim3 gx_grid(1, 1, 1);
+        if (shared) {
+            const s3a_scorer_t *sc0 = b->sc[b->order[0]];
+            const int32_t per_wave = 64 / sc0->g->dev->CP;
+            gx_grid = dim3((sc0->n_sen - sc0->n_ci_sen + GX_THREADS / 64 - 1) / (GX_THREADS / 64), (n + per_wave - 1) / per_wave, 1);
+        }
         if (b->exact) {
             if (b->g_ci) hipLaunchKernelGGL((kb_gated<true, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
-            if (b->g_cd) hipLaunchKernelGGL((kb_gated<true, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
+            if (b->g_cd && shared)
+                hipLaunchKernelGGL((kb_gated_cd_shared<true>), gx_grid, dim3(GX_THREADS), 0, st, S, F, n);
+            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<true, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
         }
         else {
             if (b->g_ci) hipLaunchKernelGGL((kb_gated<false, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
-            if (b->g_cd) hipLaunchKernelGGL((kb_gated<false, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
+            if (b->g_cd && shared)
+                hipLaunchKernelGGL((kb_gated_cd_shared<false>), gx_grid, dim3(GX_THREADS), 0, st, S, F, n);
+            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<false, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
         }
         hipLaunchKernelGGL(kb_hmm_eval, dim3((g_rows + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK),
                            (size_t)b->g_tmat * 12 * 4, st, S, F);

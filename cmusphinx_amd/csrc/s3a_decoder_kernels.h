@@ -81,20 +81,30 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         HmmRegsT<int32_t> r;
         int32_t e[3];
         if (comp[v]) {
+            /* composite senone = max over its member senones (dict2pid.c:1029-1048), up to one member
+             * per context (~46): the three states' lists are walked together, 8 members each per round,
+             * ids first and then scores, so a round is two round trips instead of 48 */
+            int32_t lo[3], hi[3], m[3], wt[3];
 #pragma unroll
             for (int st = 0; st < 3; st++) {
                 const int32_t cs = comsseq[ss * 3 + st];
-                /* member senones 8 at a time: ids, then scores, are independent loads */
-                int32_t m = INT_MIN;
-                for (int32_t j0 = cs_off[cs], jend = cs_off[cs + 1]; j0 < jend; j0 += 8) {
-                    int32_t id[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) id[u] = (j0 + u < jend) ? (int32_t)cs_list[j0 + u] : -1;
-#pragma unroll
-                    for (int u = 0; u < 8; u++) if (id[u] >= 0) m = max(m, raw[id[u]]);
-                }
-                e[st] = add32(add32(m, -norm), cs_wt[cs]);
+                lo[st] = cs_off[cs]; hi[st] = cs_off[cs + 1]; wt[st] = cs_wt[cs]; m[st] = INT_MIN;
             }
+            while (lo[0] < hi[0] || lo[1] < hi[1] || lo[2] < hi[2]) {
+                int32_t id[3][8];
+#pragma unroll
+                for (int st = 0; st < 3; st++)
+#pragma unroll
+                    for (int u = 0; u < 8; u++) id[st][u] = (lo[st] + u < hi[st]) ? (int32_t)cs_list[lo[st] + u] : -1;
+#pragma unroll
+                for (int st = 0; st < 3; st++) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (id[st][u] >= 0) m[st] = max(m[st], raw[id[st][u]]);
+                    lo[st] += 8;
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 3; st++) e[st] = add32(add32(m[st], -norm), wt[st]);
         }
         else {
 #pragma unroll
@@ -586,8 +596,13 @@ mark_node_senones(int32_t v, const int32_t *__restrict__ ssid, const uint8_t *__
     if (comp[v]) {
         for (int st = 0; st < 3; st++) {
             const int32_t cs = comsseq[ss * 3 + st];
-            for (int32_t j = cs_off[cs]; j < cs_off[cs + 1]; j++)
-                sen_active[cs_list[j]] = 1;
+            for (int32_t j0 = cs_off[cs], jend = cs_off[cs + 1]; j0 < jend; j0 += 8) {
+                int32_t id[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) id[u] = (j0 + u < jend) ? (int32_t)cs_list[j0 + u] : -1;
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (id[u] >= 0) sen_active[id[u]] = 1;
+            }
         }
     }
     else {

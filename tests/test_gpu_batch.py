@@ -19,18 +19,21 @@ HMMBEAM, PBEAM, WBEAM = -2600000, -2000000, -1500000
 class Decoder:
     """One decoder = oracle side (OracleFrame) + device side (LexSearch/Scorer/ComSen in a Batch slot)."""
 
-    def __init__(self, gpu_lib, batch, seed, maxhmmpf, ci_pbeam, n_frames):
+    def __init__(self, gpu_lib, batch, seed, maxhmmpf, ci_pbeam, n_frames, shared=None):
+        """shared = (model dict, MgauModel): all decoders score against ONE model on the device (their
+        scorers keep private Gaussian-selection state) -- the engine then runs the model-stationary
+        CD kernel; None: a model of its own."""
         self.rng = np.random.default_rng(seed)
         self.tr = synth_forest(self.rng, n_tree=4, n_node=700, n_sen=500)
         n_ci = 30
-        m = synth.make_model(500, n_ci, 4, 39, 5, 3, seed=seed + 100)
+        m = shared[0] if shared else synth.make_model(500, n_ci, 4, 39, 5, 3, seed=seed + 100)
         self.feats = synth.make_features(m, n_frames, seed=seed + 200)
         comwt = -self.rng.integers(0, 3000, self.tr["n_comstate"]).astype(np.int32)
         olm = O.OracleLogMath(1.0003)
         self.of = OracleFrame(self.tr, O.OracleMgau(m["mean"], m["var"], m["mixw"], olm), m["cd2cisen"], n_ci,
                               olm.logs3(ci_pbeam), comwt)
-        gm = gpu_lib.MgauModel.init_arrays(m["mean"], m["var"], m["mixw"], gpu_lib.LogMath(1.0003))
-        self.sc = gpu_lib.Scorer(gm, m["cd2cisen"], n_ci, ci_pbeam=ci_pbeam)
+        gm = shared[1] if shared else gpu_lib.MgauModel.init_arrays(m["mean"], m["var"], m["mixw"], gpu_lib.LogMath(1.0003))
+        self.sc = gpu_lib.Scorer(gm, m["cd2cisen"], n_ci, ci_pbeam=ci_pbeam, private_state=shared is not None)
         self.cs = gpu_lib.ComSen(self.tr["comstate_off"], self.tr["comstate"], comwt)
         self.ls = make_gpu(gpu_lib, self.tr, stream=gm.stream())
         self.batch, self.slot = batch, batch.attach(self.ls, self.sc, self.cs)
@@ -82,10 +85,15 @@ class Decoder:
         self.frm = None
 
 
-def test_batched_steps_match_one_oracle_per_decoder(gpu_lib):
+@pytest.mark.parametrize("share_model", [False, True])
+def test_batched_steps_match_one_oracle_per_decoder(gpu_lib, share_model):
     batch = gpu_lib.Batch(8)
     cfg = [(11, 20000, 1e-80, 30), (12, 150, 1e-80, 22), (13, 400, 1e-12, 30), (14, 20000, 1e-30, 17), (15, 90, 1e-80, 26)]
-    decs = [Decoder(gpu_lib, batch, *c) for c in cfg]
+    shared = None
+    if share_model:
+        m = synth.make_model(500, 30, 4, 39, 5, 3, seed=999)
+        shared = (m, gpu_lib.MgauModel.init_arrays(m["mean"], m["var"], m["mixw"], gpu_lib.LogMath(1.0003)))
+    decs = [Decoder(gpu_lib, batch, *c, shared=shared) for c in cfg]
     start = [0, 0, 3, 5, 9]             # step at which each decoder begins its first utterance
     utts_done = [0] * len(decs)
     for step in range(75):
