@@ -26,6 +26,7 @@
 #include <string.h>
 #include <limits.h>
 #include <pthread.h>
+#include <time.h>
 #include <vector>
 
 #include "s3a_device.h"
@@ -311,6 +312,7 @@ struct s3a_batch_s {
     unsigned long long gen;
     long steps, slot_frames;
     hipStream_t stream;
+    hipEvent_t ev;
     pthread_mutex_t mu;
     pthread_cond_t cv;
 };
@@ -325,6 +327,7 @@ s3a_batch_create(int32_t max_slots)
     pthread_mutex_init(&b->mu, NULL);
     pthread_cond_init(&b->cv, NULL);
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess
+        || hipEventCreateWithFlags(&b->ev, hipEventDisableTiming) != hipSuccess
         || hipMalloc((void **)&b->d_slots, sizeof(BSlot) * max_slots) != hipSuccess
         || hipMalloc((void **)&b->d_frames, sizeof(BFrame) * max_slots) != hipSuccess
         || hipHostMalloc((void **)&b->h_frames, sizeof(BFrame) * max_slots) != hipSuccess) {
@@ -340,6 +343,7 @@ s3a_batch_free(s3a_batch_t *b)
 {
     if (!b) return;
     (void)hipStreamSynchronize(b->stream);
+    (void)hipEventDestroy(b->ev);
     (void)hipFree(b->d_slots); (void)hipFree(b->d_frames); (void)hipHostFree(b->h_frames);
     if (b->d_pack) (void)hipFree(b->d_pack);
     if (b->h_pack) (void)hipHostFree(b->h_pack);
@@ -483,12 +487,16 @@ run_batch(s3a_batch_t *b)
         hipLaunchKernelGGL(kb_resolve, dim3((b->g_N + DBLOCK - 1) / DBLOCK, 1, n), dim3(DBLOCK), 0, st, S, F);
         hipLaunchKernelGGL(kb_scan, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F, b->d_pack, b->pack_stride,
                            b->pack_max_exits);
-        hipLaunchKernelGGL(kb_emit, dim3(EMIT_BLOCKS, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
         CHK(hipGetLastError());
-        /* the records (header + the first exits) of all decoders: one strided copy */
+        /* the records (header + the first exits) of all decoders: one strided copy, issued BEFORE the
+         * emission kernel: the hosts only need the records, so k_dec_emit overlaps their word-level work
+         * (the next step's kernels follow it in stream order) */
         CHK(hipMemcpy2DAsync(b->h_pack, (size_t)b->pack_stride * 4, b->d_pack, (size_t)b->pack_stride * 4,
                              (size_t)(b->hdr_max + 3 * BFIRST) * 4, n, hipMemcpyDeviceToHost, st));
-        CHK(hipStreamSynchronize(st));
+        CHK(hipEventRecord(b->ev, st));
+        hipLaunchKernelGGL(kb_emit, dim3(EMIT_BLOCKS, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
+        CHK(hipGetLastError());
+        CHK(hipEventSynchronize(b->ev));
         for (int32_t z = 0; z < n; z++) {
             const int32_t slot = b->order[z];
             s3a_lexsearch_t *ls = b->ls[slot];
@@ -515,7 +523,7 @@ done:
     b->slot_frames += n;
     for (int32_t z = 0; z < n; z++) b->arrived[b->order[z]] = 0;
     b->n_arrived = 0;
-    b->gen++;
+    __atomic_store_n(&b->gen, b->gen + 1, __ATOMIC_RELEASE);   /* the waiters spin on this word */
     pthread_cond_broadcast(&b->cv);
     return rc;
 #undef CHK
@@ -624,12 +632,23 @@ s3a_batch_step(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, i
                         exit_wid, exit_score, exit_hist, max_exits);
     if (rc == S3A_OK) {
         const unsigned long long my_gen = b->gen;
-        if (b->n_arrived == b->n_active)
+        if (b->n_arrived == b->n_active) {
             (void)run_batch(b);
-        else
-            while (b->gen == my_gen) pthread_cond_wait(&b->cv, &b->mu);
+            pthread_mutex_unlock(&b->mu);
+        }
+        else {
+            /* wait OUTSIDE the lock, spinning: a step is a few hundred microseconds and there is a
+             * core per decoder thread; a condition variable costs a wake-up plus a convoy on the
+             * mutex for every waiter.  After ~2 ms of spinning (a decoder stuck in file I/O) sleep. */
+            pthread_mutex_unlock(&b->mu);
+            for (long spins = 0; __atomic_load_n(&b->gen, __ATOMIC_ACQUIRE) == my_gen; spins++) {
+                if (spins < 200000) __builtin_ia32_pause();
+                else { struct timespec ts = { 0, 50000 }; nanosleep(&ts, NULL); }
+            }
+        }
         rc = b->out[slot].rc;
         if (rc != S3A_OK) s3a_set_error("%s", b->out[slot].err);
+        return rc;
     }
     pthread_mutex_unlock(&b->mu);
     return rc;

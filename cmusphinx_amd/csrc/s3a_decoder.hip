@@ -365,13 +365,17 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_outh, ls->d_selfemit, ls->d_cnt, ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt],
                        ls->d_pos, ls->d_posf, ls->d_best, ls->d_exit, ls->d_nexit, ls->d_hbin, sc->misc_d,
                        ls->d_done, ls->d_pack, ls->pack_max_exits);
+    HIPCHK(hipGetLastError());
+    /* the host only needs the frame record: copy it and mark the spot BEFORE the emission kernel, which
+     * then overlaps the host's word-level work (the next frame's kernels follow it in stream order) */
+    const int32_t first = 256;
+    HIPCHK(hipMemcpyAsync(ls->h_pack, ls->d_pack, (size_t)(hdr + 3 * first) * 4, hipMemcpyDeviceToHost, ls->stream));
+    HIPCHK(hipEventRecord(ls->ev_pack, ls->stream));
     hipLaunchKernelGGL(k_dec_emit, dim3(EMIT_BLOCKS, T), dim3(DBLOCK), 0, ls->stream, frm, ls->d_node_base,
                        ls->d_act[cur], ls->d_nact[cur], ls->d_child_off, ls->d_child, ls->d_turn, ls->d_selfemit,
                        ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt], ls->d_pos, ls->d_posf);
     HIPCHK(hipGetLastError());
-    const int32_t first = 256;
-    HIPCHK(hipMemcpyAsync(ls->h_pack, ls->d_pack, (size_t)(hdr + 3 * first) * 4, hipMemcpyDeviceToHost, ls->stream));
-    HIPCHK(hipStreamSynchronize(ls->stream));
+    HIPCHK(hipEventSynchronize(ls->ev_pack));
     const int32_t *p = ls->h_pack;
     {
         const int32_t rc = s3a_dec_unpack(ls, p, may_hist, frm, res, n_exit, max_exits, &total);

@@ -639,10 +639,16 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
     HIPCHK(hipMemset(ls->d_hbin, 0, 1024 * 4));
     ls->hist_bound = ls->last_nnxt = 1 << 30;
     HIPCHK(hipMemset(ls->d_key, 0, (size_t)N * 8));
-    ls->pack_max_exits = 2048;
+    {
+        /* every leaf can exit in the same frame (wide beams: thousands do) */
+        int32_t n_leaf = 0;
+        for (int32_t v = 0; v < N; v++) n_leaf += h_wid[v] >= 0 ? 1 : 0;
+        ls->pack_max_exits = n_leaf > 2048 ? n_leaf : 2048;
+    }
     DMALLOC(ls->d_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4);
     HIPCHK(hipHostMalloc((void **)&ls->h_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4));
     HIPCHK(hipHostMalloc((void **)&ls->h_ring, (size_t)8 * (2 * 4096 + 2 * ls->ent_cap) * 4));
+    HIPCHK(hipEventCreateWithFlags(&ls->ev_pack, hipEventDisableTiming));
     return S3A_OK;
 }
 
@@ -710,6 +716,7 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
     if (ls->h_pin) (void)hipHostFree(ls->h_pin);
     if (ls->h_pack) (void)hipHostFree(ls->h_pack);
     if (ls->h_ring) (void)hipHostFree(ls->h_ring);
+    if (ls->ev_pack) (void)hipEventDestroy(ls->ev_pack);
     if (ls->own_stream && ls->stream) (void)hipStreamDestroy(ls->stream);
     delete ls;
 }

@@ -242,4 +242,6 @@ if __name__ == "__main__":
         k, v = a.split("=")
         kw[k] = float(v) if "." in v else int(v)
     t = make_task(out, **kw)
-    print(t["n_tri"], "triphones;", " ".join(t["args"]))
+    # TASK_BEAM / TASK_WBEAM: other beams than the hub4 settings (e.g. the wide-beam stress configuration)
+    args = decoder_args(out, os.environ.get("TASK_BEAM", "1e-60"), os.environ.get("TASK_WBEAM", "1e-35"))
+    print(t["n_tri"], "triphones;", " ".join(args))
