@@ -93,16 +93,29 @@ def test_live_cpu_reference_agrees_with_committed_golden(tmp_path):
 TST = os.path.join(ROOT, "oracle", "_ref", "ref_s3amd_tst_decode")
 
 
+DRIVERS = {
+    "one_decoder": {},                                          # s3a_decoder_*: one decoder, one stream
+    "four_streams": {"S3A_STREAMS": "4"},                       # four decoders on four HIP streams
+    "batched_4x1": {"S3A_STREAMS": "4", "S3A_BATCH": "1"},      # s3a_batch_*: four decoders share every launch
+    "batched_6x2": {"S3A_STREAMS": "6", "S3A_BATCH": "2"},      # two engines of three decoders alternate
+}
+
+
 @pytest.mark.skipif(not os.path.exists(TST), reason="oracle/_ref/ref_s3amd_tst_decode did not travel")
-@pytest.mark.parametrize("name", ["mode4_trigram", "mode4_cibeam_ds2"])
-def test_full_device_search_matches_reference(name, tmp_path):
+@pytest.mark.parametrize("name,driver", [("mode4_trigram", "one_decoder"), ("mode4_cibeam_ds2", "one_decoder"),
+                                         ("mode4_trigram", "four_streams"), ("mode4_trigram", "batched_4x1"),
+                                         ("mode4_cibeam_ds2", "batched_6x2")])
+def test_full_device_search_matches_reference(name, driver, tmp_path):
     hyp, seg, log = (str(tmp_path / f"tst_{name}.{e}") for e in ("match", "matchseg", "log"))
     with open(log, "w") as lf:
         p = subprocess.run([TST] + common() + RUNS[name] + ["-hyp", hyp, "-hypseg", seg],
-                           stdout=lf, stderr=subprocess.STDOUT, timeout=900)
+                           stdout=lf, stderr=subprocess.STDOUT, timeout=900, env=dict(os.environ, **DRIVERS[driver]))
     tail = [l for l in open(log, errors="ignore").read().splitlines() if "tst shim" in l or "FATAL" in l]
     assert p.returncode == 0, "\n".join(tail[-10:])
     assert any("frames searched by the replacement backend" in l for l in tail)
+    if "S3A_BATCH" in DRIVERS[driver]:
+        mb = [float(l.split("mean batch")[1].strip(" )")) for l in tail if "batched engine" in l]
+        assert mb and mb[0] > 1.5, tail                         # the launches really were shared
     assert open(hyp).read() == open(os.path.join(D, f"ref_{name}.match")).read()
     assert open(seg).read() == open(os.path.join(D, f"ref_{name}.matchseg")).read()
 
@@ -147,16 +160,17 @@ def rm_args(extra=()):
 
 @pytest.mark.skipif(not (os.path.exists(TST) and os.path.exists(REFDEC) and os.path.isdir(RM)),
                     reason="RM1 local data or oracle/_ref binaries absent (tools/fetch_local_data.sh)")
-@pytest.mark.parametrize("binary", ["scoring_only", "full_device", "full_device_histprune"])
+@pytest.mark.parametrize("binary", ["scoring_only", "full_device", "full_device_histprune", "full_device_batched"])
 def test_rm1_identical_to_live_reference(binary, tmp_path):
     exe = SHIM if binary == "scoring_only" else TST
-    extra = ["-maxhmmpf", "800"] if binary == "full_device_histprune" else []
+    extra = ["-maxhmmpf", "800"] if binary in ("full_device_histprune", "full_device_batched") else []
+    env = dict(os.environ, S3A_STREAMS="5", S3A_BATCH="2") if binary == "full_device_batched" else None
     out = {}
     for tag, b in (("ref", REFDEC), ("gpu", exe)):
         hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
         with open(log, "w") as lf:
             p = subprocess.run([b] + rm_args(extra) + ["-hyp", hyp, "-hypseg", seg], stdout=lf,
-                               stderr=subprocess.STDOUT, timeout=1800)
+                               stderr=subprocess.STDOUT, timeout=1800, env=env if tag == "gpu" else None)
         tail = [l for l in open(log, errors="ignore").read().splitlines()
                 if l.startswith(("FATAL", "INFO: ref_", "INFO: stat.c")) and ("shim" in l or "SUMMARY" in l or "FATAL" in l)]
         assert p.returncode == 0, "\n".join(tail[-10:])
