@@ -488,6 +488,42 @@ fill(s3a_lexsearch_t *ls, int32_t *p, int32_t v, int32_t n)
     return S3A_OK;
 }
 
+/* the per-decoder half: HMM state, active lists, per-frame scratch, staging buffers */
+static int32_t
+alloc_state(s3a_lexsearch_t *ls)
+{
+    const int32_t N = ls->N, n_tree = ls->n_tree;
+    DMALLOC(ls->d_sc, (size_t)3 * N * 4); DMALLOC(ls->d_hist, (size_t)3 * N * 4);
+    DMALLOC(ls->d_outs, (size_t)N * 4); DMALLOC(ls->d_outh, (size_t)N * 4);
+    DMALLOC(ls->d_bests, (size_t)N * 4); DMALLOC(ls->d_frame, (size_t)N * 4);
+    DMALLOC(ls->d_pos, (size_t)N * 4); DMALLOC(ls->d_posf, (size_t)N * 4);
+    DMALLOC(ls->d_act[0], (size_t)N * 4); DMALLOC(ls->d_act[1], (size_t)N * 4);
+    DMALLOC(ls->d_nact[0], (size_t)n_tree * 4); DMALLOC(ls->d_nact[1], (size_t)n_tree * 4);
+    DMALLOC(ls->d_cand, (size_t)N * 4); DMALLOC(ls->d_ncand, (size_t)n_tree * 4);
+    DMALLOC(ls->d_candf, (size_t)N * 4);
+    DMALLOC(ls->d_turn, (size_t)N * 4); DMALLOC(ls->d_selfemit, (size_t)N * 4); DMALLOC(ls->d_cnt, (size_t)N * 4);
+    DMALLOC(ls->d_best, (size_t)n_tree * 2 * 4);
+    DMALLOC(ls->d_exit, (size_t)3 * N * 4); DMALLOC(ls->d_nexit, (size_t)2 * n_tree * 4);
+    DMALLOC(ls->d_calls, (size_t)2 * 4096 * 4);
+    DMALLOC(ls->d_ent, (size_t)2 * ls->ent_cap * 4); DMALLOC(ls->d_eflag, (size_t)ls->ent_cap * 4);
+    DMALLOC(ls->d_first, (size_t)N * 4); DMALLOC(ls->d_key, (size_t)N * 8);
+    HIPCHK(hipHostMalloc((void **)&ls->h_pin, (size_t)(8 * n_tree + 16) * 4));
+    DMALLOC(ls->d_thr, 8 * 4);
+    DMALLOC(ls->d_done, 4 * 4);
+    HIPCHK(hipMemset(ls->d_done, 0, 16));
+    DMALLOC(ls->d_hbin, 1024 * 4);
+    DMALLOC(ls->d_pstamp, (size_t)(ls->n_pset > 0 ? ls->n_pset : 1) * 4);
+    DMALLOC(ls->d_ctot, 4096 * 4); DMALLOC(ls->d_n0, (size_t)n_tree * 4);
+    HIPCHK(hipMemset(ls->d_hbin, 0, 1024 * 4));
+    ls->hist_bound = ls->last_nnxt = 1 << 30;
+    HIPCHK(hipMemset(ls->d_key, 0, (size_t)N * 8));
+    DMALLOC(ls->d_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4);
+    HIPCHK(hipHostMalloc((void **)&ls->h_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4));
+    HIPCHK(hipHostMalloc((void **)&ls->h_ring, (size_t)8 * (2 * 4096 + 2 * ls->ent_cap) * 4));
+    HIPCHK(hipEventCreateWithFlags(&ls->ev_pack, hipEventDisableTiming));
+    return S3A_OK;
+}
+
 static int32_t
 lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
                 const int32_t *const *ssid, const int32_t *const *tmatid,
@@ -589,7 +625,6 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
         h_psoff[N] = (int32_t)h_psof.size();
         ls->n_pset = (int32_t)ids.size();
         UP(ls->d_ps, h_ps); UP(ls->d_psof_off, h_psoff); UP(ls->d_psof, h_psof);
-        DMALLOC(ls->d_pstamp, (size_t)(ls->n_pset > 0 ? ls->n_pset : 1) * 4);
     }
     ls->h_rootlist = h_roots;
 #undef UP
@@ -607,26 +642,7 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
         if (comstate_off[n_comstate])
             HIPCHK(hipMemcpy(ls->d_comstate, comstate, (size_t)comstate_off[n_comstate] * 2, hipMemcpyHostToDevice));
     }
-    DMALLOC(ls->d_sc, (size_t)3 * N * 4); DMALLOC(ls->d_hist, (size_t)3 * N * 4);
-    DMALLOC(ls->d_outs, (size_t)N * 4); DMALLOC(ls->d_outh, (size_t)N * 4);
-    DMALLOC(ls->d_bests, (size_t)N * 4); DMALLOC(ls->d_frame, (size_t)N * 4);
-    DMALLOC(ls->d_pos, (size_t)N * 4); DMALLOC(ls->d_posf, (size_t)N * 4);
-    DMALLOC(ls->d_act[0], (size_t)N * 4); DMALLOC(ls->d_act[1], (size_t)N * 4);
-    DMALLOC(ls->d_nact[0], (size_t)n_tree * 4); DMALLOC(ls->d_nact[1], (size_t)n_tree * 4);
-    DMALLOC(ls->d_cand, (size_t)N * 4); DMALLOC(ls->d_ncand, (size_t)n_tree * 4);
-    DMALLOC(ls->d_candf, (size_t)N * 4);
-    DMALLOC(ls->d_turn, (size_t)N * 4); DMALLOC(ls->d_selfemit, (size_t)N * 4); DMALLOC(ls->d_cnt, (size_t)N * 4);
-    DMALLOC(ls->d_best, (size_t)n_tree * 2 * 4);
-    DMALLOC(ls->d_exit, (size_t)3 * N * 4); DMALLOC(ls->d_nexit, (size_t)2 * n_tree * 4);
-    DMALLOC(ls->d_calls, (size_t)2 * 4096 * 4);
     ls->ent_cap = (int32_t)h_roots.size() > 0 ? (int32_t)h_roots.size() : 1;   /* every list entered once */
-    DMALLOC(ls->d_ent, (size_t)2 * ls->ent_cap * 4); DMALLOC(ls->d_eflag, (size_t)ls->ent_cap * 4);
-    DMALLOC(ls->d_first, (size_t)N * 4); DMALLOC(ls->d_key, (size_t)N * 8);
-    HIPCHK(hipHostMalloc((void **)&ls->h_pin, (size_t)(8 * n_tree + 16) * 4));
-    DMALLOC(ls->d_thr, 8 * 4);
-    DMALLOC(ls->d_done, 4 * 4);
-    HIPCHK(hipMemset(ls->d_done, 0, 16));
-    DMALLOC(ls->d_hbin, 1024 * 4);
     {
         std::vector<int32_t> uniq(h_roots);
         std::sort(uniq.begin(), uniq.end());
@@ -635,21 +651,13 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
         DMALLOC(ls->d_rootnodes, uniq.size() * 4);
         if (!uniq.empty()) HIPCHK(hipMemcpy(ls->d_rootnodes, uniq.data(), uniq.size() * 4, hipMemcpyHostToDevice));
     }
-    DMALLOC(ls->d_ctot, 4096 * 4); DMALLOC(ls->d_n0, (size_t)n_tree * 4);
-    HIPCHK(hipMemset(ls->d_hbin, 0, 1024 * 4));
-    ls->hist_bound = ls->last_nnxt = 1 << 30;
-    HIPCHK(hipMemset(ls->d_key, 0, (size_t)N * 8));
     {
         /* every leaf can exit in the same frame (wide beams: thousands do) */
         int32_t n_leaf = 0;
         for (int32_t v = 0; v < N; v++) n_leaf += h_wid[v] >= 0 ? 1 : 0;
         ls->pack_max_exits = n_leaf > 2048 ? n_leaf : 2048;
     }
-    DMALLOC(ls->d_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4);
-    HIPCHK(hipHostMalloc((void **)&ls->h_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4));
-    HIPCHK(hipHostMalloc((void **)&ls->h_ring, (size_t)8 * (2 * 4096 + 2 * ls->ent_cap) * 4));
-    HIPCHK(hipEventCreateWithFlags(&ls->ev_pack, hipEventDisableTiming));
-    return S3A_OK;
+    return alloc_state(ls);
 }
 
 extern "C" s3a_lexsearch_t *
@@ -698,21 +706,57 @@ s3a_lexsearch_init(int32_t n_tree, const int32_t *n_node, const int32_t *const *
     return ls;
 }
 
+/* A second decoder over the SAME lextrees: shares proto's static device arrays (topology, ssid/tmat/
+ * word ids, probabilities, parent sets, root lists, senone sequences, transition matrices) and gets
+ * its own state.  proto must outlive its clones.  (20 k-word lextrees are ~25 MB of static arrays:
+ * B decoders reading B copies of them evict each other from the caches; one copy is read B times.) */
+extern "C" s3a_lexsearch_t *
+s3a_lexsearch_clone(const s3a_lexsearch_t *proto, void *stream)
+{
+    if (!proto) return NULL;
+    s3a_lexsearch_t *ls = new s3a_lexsearch_s(*proto);         /* host fields + static device pointers */
+    ls->is_clone = 1;
+    /* everything alloc_state sets must not alias proto's */
+    ls->d_sc = ls->d_hist = ls->d_outs = ls->d_outh = ls->d_bests = ls->d_frame = ls->d_pos = ls->d_posf = NULL;
+    ls->d_act[0] = ls->d_act[1] = ls->d_nact[0] = ls->d_nact[1] = ls->d_cand = ls->d_ncand = ls->d_candf = NULL;
+    ls->d_turn = ls->d_selfemit = ls->d_cnt = ls->d_best = ls->d_exit = ls->d_nexit = ls->d_calls = NULL;
+    ls->d_ent = ls->d_eflag = ls->d_first = ls->d_thr = ls->d_done = ls->d_hbin = ls->d_pstamp = NULL;
+    ls->d_ctot = ls->d_n0 = ls->d_pack = NULL; ls->d_key = NULL;
+    ls->h_pin = ls->h_pack = ls->h_ring = NULL; ls->ev_pack = NULL; ls->ring_slot = 0; ls->cur = 0;
+    if (stream) { ls->stream = (hipStream_t)stream; ls->own_stream = 0; }
+    else if (hipStreamCreateWithFlags(&ls->stream, hipStreamNonBlocking) != hipSuccess) {
+        s3a_set_error("s3a_lexsearch_clone: stream creation failed");
+        ls->own_stream = 0;
+        s3a_lexsearch_free(ls);
+        return NULL;
+    }
+    else ls->own_stream = 1;
+    if (alloc_state(ls) != S3A_OK || s3a_lexsearch_reset(ls) != S3A_OK) {
+        s3a_lexsearch_free(ls);
+        return NULL;
+    }
+    return ls;
+}
+
 extern "C" void
 s3a_lexsearch_free(s3a_lexsearch_t *ls)
 {
     if (!ls) return;
-    int32_t **ptrs[] = { &ls->d_node_base, &ls->d_ssid, &ls->d_tmatid, &ls->d_wid, &ls->d_prob,
+    int32_t **statics[] = { &ls->d_node_base, &ls->d_ssid, &ls->d_tmatid, &ls->d_wid, &ls->d_prob,
         &ls->d_child_off, &ls->d_child, &ls->d_par_off, &ls->d_par, &ls->d_rootlist, &ls->d_tp,
-        &ls->d_comstate_off, &ls->d_sc, &ls->d_hist, &ls->d_outs, &ls->d_outh, &ls->d_bests,
+        &ls->d_comstate_off, &ls->d_tree_of, &ls->d_rootnodes, &ls->d_ps, &ls->d_psof_off, &ls->d_psof };
+    int32_t **state[] = { &ls->d_sc, &ls->d_hist, &ls->d_outs, &ls->d_outh, &ls->d_bests,
         &ls->d_frame, &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
-        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_tree_of, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0, &ls->d_rootnodes, &ls->d_ps, &ls->d_psof_off, &ls->d_psof,
-        &ls->d_pstamp };
-    for (auto p : ptrs) (void)hipFree(*p);
-    (void)hipFree(ls->d_comp); (void)hipFree(ls->d_sseq); (void)hipFree(ls->d_comsseq);
-    (void)hipFree(ls->d_comstate); (void)hipFree(ls->d_key);
+        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0, &ls->d_pstamp };
+    for (auto p : state) (void)hipFree(*p);
+    (void)hipFree(ls->d_key);
+    if (!ls->is_clone) {                /* a clone borrows its prototype's static arrays */
+        for (auto p : statics) (void)hipFree(*p);
+        (void)hipFree(ls->d_comp); (void)hipFree(ls->d_sseq); (void)hipFree(ls->d_comsseq);
+        (void)hipFree(ls->d_comstate);
+    }
     if (ls->h_pin) (void)hipHostFree(ls->h_pin);
     if (ls->h_pack) (void)hipHostFree(ls->h_pack);
     if (ls->h_ring) (void)hipHostFree(ls->h_ring);

@@ -240,7 +240,7 @@ s3a_approx_cont_mgau_ci_eval(s3a_scorer_t *sc, const float *feat, int32_t *ci_se
 }
 
 /* approx_compute_dyn_ci_pbeam, approx_cont_mgau.c:303-357 (host: n_ci_sen is ~150) */
-static const int32_t *g_sort_key;
+static __thread const int32_t *g_sort_key;    /* (qsort has no context argument) */
 static int
 cmp_ci_desc(const void *a, const void *b)
 {

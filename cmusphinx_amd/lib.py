@@ -92,6 +92,7 @@ _SIGS = {
     "s3a_lexsearch_init": (C.c_void_p, [C.c_int32] + [C.c_void_p] * 14 + [C.c_void_p, C.c_void_p, C.c_int32,
                                                                           C.c_void_p, C.c_int32, C.c_int32,
                                                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3a_lexsearch_clone": (C.c_void_p, [C.c_void_p, C.c_void_p]),
     "s3a_lexsearch_free": (None, [C.c_void_p]),
     "s3a_lexsearch_reset": (C.c_int32, [C.c_void_p]),
     "s3a_lexsearch_n_node": (C.c_int32, [C.c_void_p, C.c_int32]),
@@ -774,6 +775,19 @@ class LexSearch:
         if getattr(self, "h", None):
             self.L.s3a_lexsearch_free(self.h)
             self.h = None
+
+    def clone(self, stream=None):
+        """A second decoder over the same trees: static device arrays shared, own state."""
+        c = object.__new__(LexSearch)
+        c.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("h", "d_sen", "d_com", "d_act")})
+        c._proto = self                 # keeps the prototype (owner of the static arrays) alive
+        c.h = self.L.s3a_lexsearch_clone(self.h, stream)
+        if not c.h:
+            raise S3AError(_err(self.L))
+        c.d_sen = DevBuf(4 * self.n_sen)
+        c.d_com = DevBuf(4 * max(len(self.comstate_off) - 1, 1))
+        c.d_act = DevBuf(self.n_sen)
+        return c
 
     def enter(self, t, lc, scr, hist, cf, thresh):
         lc = np.ascontiguousarray(lc, np.int32); scr = np.ascontiguousarray(scr, np.int32)

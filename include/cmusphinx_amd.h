@@ -350,6 +350,9 @@ s3a_lexsearch_t *s3a_lexsearch_init(int32_t n_tree, const int32_t *n_node,
         const s3a_tmat_t *tmat, const int16_t *sseq, int32_t n_sseq,
         const int16_t *comsseq, int32_t n_comsseq, int32_t n_comstate,
         const int32_t *comstate_off, const int16_t *comstate, void *stream);
+/* another decoder over the same lextrees: shares proto's static device arrays, owns its state;
+ * proto must outlive its clones (several decoders per GPU: s3a_batch_*) */
+s3a_lexsearch_t *s3a_lexsearch_clone(const s3a_lexsearch_t *proto, void *stream);
 void    s3a_lexsearch_free(s3a_lexsearch_t *ls);
 int32_t s3a_lexsearch_reset(s3a_lexsearch_t *ls);
 int32_t s3a_lexsearch_n_node(const s3a_lexsearch_t *ls, int32_t tree);

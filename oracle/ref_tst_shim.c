@@ -216,6 +216,7 @@ static __thread s3a_batch_t *g_batch;
 static __thread int g_worker_id;
 static s3a_logmath_t *g_lm_shared[MAX_GROUPS];   /* batch mode: ONE model on the device per group of decoders */
 static s3a_mgau_model_t *g_gm_shared[MAX_GROUPS];
+static s3a_lexsearch_t *g_ls_shared[MAX_GROUPS];  /* ... and one copy of the static lextree arrays */
 static __thread int32 g_slot;
 static __thread float32 g_featbuf[64];
 static __thread int32 g_feat_idx;
@@ -412,10 +413,15 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
             nlc[i] = f->n_lc; lc[i] = f->lc; lro[i] = f->lcroot_off; lr[i] = f->lcroot;
             nroot[i] = f->n_root; root[i] = f->root;
         }
-        g_ls = s3a_lexsearch_init(g_ntree, nn, ssid, tm, comp, wid, prob, coff, ch, nlc, lc, lro, lr,
-                                  nroot, root, g_tm, g_sseq_flat, mdef_n_sseq(mdef), g_comsseq_flat,
-                                  d2p->n_comsseq, g_n_comstate, g_comstate_off, g_comstate,
-                                  s3a_mgau_stream(g_gm));
+        if (g_batch && g_ls_shared[g_worker_id % g_n_groups])
+            g_ls = s3a_lexsearch_clone(g_ls_shared[g_worker_id % g_n_groups], s3a_mgau_stream(g_gm));
+        else {
+            g_ls = s3a_lexsearch_init(g_ntree, nn, ssid, tm, comp, wid, prob, coff, ch, nlc, lc, lro, lr,
+                                      nroot, root, g_tm, g_sseq_flat, mdef_n_sseq(mdef), g_comsseq_flat,
+                                      d2p->n_comsseq, g_n_comstate, g_comstate_off, g_comstate,
+                                      s3a_mgau_stream(g_gm));
+            if (g_batch) g_ls_shared[g_worker_id % g_n_groups] = g_ls;
+        }
         if (!g_ls) die("s3a_lexsearch_init");
     }
 #endif

@@ -19,23 +19,28 @@ HMMBEAM, PBEAM, WBEAM = -2600000, -2000000, -1500000
 class Decoder:
     """One decoder = oracle side (OracleFrame) + device side (LexSearch/Scorer/ComSen in a Batch slot)."""
 
-    def __init__(self, gpu_lib, batch, seed, maxhmmpf, ci_pbeam, n_frames, shared=None):
+    def __init__(self, gpu_lib, batch, seed, maxhmmpf, ci_pbeam, n_frames, shared=None, forest=None):
         """shared = (model dict, MgauModel): all decoders score against ONE model on the device (their
         scorers keep private Gaussian-selection state) -- the engine then runs the model-stationary
         CD kernel; None: a model of its own."""
         self.rng = np.random.default_rng(seed)
-        self.tr = synth_forest(self.rng, n_tree=4, n_node=700, n_sen=500)
+        self.tr = forest["tr"] if forest else synth_forest(self.rng, n_tree=4, n_node=700, n_sen=500)
         n_ci = 30
         m = shared[0] if shared else synth.make_model(500, n_ci, 4, 39, 5, 3, seed=seed + 100)
         self.feats = synth.make_features(m, n_frames, seed=seed + 200)
-        comwt = -self.rng.integers(0, 3000, self.tr["n_comstate"]).astype(np.int32)
+        comwt = forest["comwt"] if forest else -self.rng.integers(0, 3000, self.tr["n_comstate"]).astype(np.int32)
         olm = O.OracleLogMath(1.0003)
         self.of = OracleFrame(self.tr, O.OracleMgau(m["mean"], m["var"], m["mixw"], olm), m["cd2cisen"], n_ci,
                               olm.logs3(ci_pbeam), comwt)
         gm = shared[1] if shared else gpu_lib.MgauModel.init_arrays(m["mean"], m["var"], m["mixw"], gpu_lib.LogMath(1.0003))
         self.sc = gpu_lib.Scorer(gm, m["cd2cisen"], n_ci, ci_pbeam=ci_pbeam, private_state=shared is not None)
         self.cs = gpu_lib.ComSen(self.tr["comstate_off"], self.tr["comstate"], comwt)
-        self.ls = make_gpu(gpu_lib, self.tr, stream=gm.stream())
+        if forest and "proto" in forest:        # the same lextrees as another decoder: share the static arrays
+            self.ls = forest["proto"].clone(stream=gm.stream())
+        else:
+            self.ls = make_gpu(gpu_lib, self.tr, stream=gm.stream())
+            if forest is not None:
+                forest["proto"] = self.ls
         self.batch, self.slot = batch, batch.attach(self.ls, self.sc, self.cs)
         self.lock = Lockstep(self.of.lex, self.ls, self.tr["n_tree"])
         self.maxhmmpf, self.frm, self.n_hist = maxhmmpf, None, 0
@@ -119,6 +124,32 @@ def test_batched_steps_match_one_oracle_per_decoder(gpu_lib, share_model):
     assert decs[1].n_hist > 10 and decs[4].n_hist > 10 and decs[0].n_hist == 0
     steps, frames = batch.stats()
     assert frames == 2 * sum(c[3] for c in cfg) and steps < frames / 2      # really batched
+
+
+def test_cloned_decoders_share_model_and_lextrees(gpu_lib):
+    """The production arrangement: ONE model and ONE set of lextrees on the device, N decoders with their
+    own state (s3a_scorer_init_private + s3a_lexsearch_clone), different utterances."""
+    batch = gpu_lib.Batch(6)
+    rng = np.random.default_rng(77)
+    tr = synth_forest(rng, n_tree=4, n_node=700, n_sen=500)
+    forest = dict(tr=tr, comwt=-rng.integers(0, 3000, tr["n_comstate"]).astype(np.int32))
+    m = synth.make_model(500, 30, 4, 39, 5, 3, seed=998)
+    shared = (m, gpu_lib.MgauModel.init_arrays(m["mean"], m["var"], m["mixw"], gpu_lib.LogMath(1.0003)))
+    decs = [Decoder(gpu_lib, batch, 31 + i, 20000 if i % 2 else 200, 1e-80 if i < 3 else 1e-12, 20 + 3 * i,
+                    shared=shared, forest=forest) for i in range(5)]
+    for d in decs:
+        d.begin()
+    while any(d.frm is not None for d in decs):
+        live = [d for d in decs if d.frm is not None]
+        for d in live:
+            d.oracle_frame()
+            batch.submit(*d.args())
+        out = batch.run()
+        for d in live:
+            d.check_and_advance(*out[d.slot])
+            if d.frm >= len(d.feats):
+                d.end()
+    assert sum(d.n_hist for d in decs) > 10
 
 
 def test_blocking_rendezvous_one_thread_per_decoder(gpu_lib):
