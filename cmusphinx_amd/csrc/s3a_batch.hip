@@ -306,7 +306,7 @@ struct s3a_batch_s {
     BFrame stage[BMAXSLOT];             /* per slot: pending transition + this frame's request */
     BOut out[BMAXSLOT];
     uint8_t has_trans[BMAXSLOT], active[BMAXSLOT], arrived[BMAXSLOT];
-    int32_t n_active, n_arrived, order[BMAXSLOT], rows[BMAXSLOT];
+    int32_t n_active, n_arrived, order[BMAXSLOT], rows[BMAXSLOT], zof[BMAXSLOT], last_order[BMAXSLOT], last_n;
     int32_t *d_pack, *h_pack, pack_stride, pack_max_exits, hdr_max;
     int32_t g_ent, g_ci, g_cd, g_maxn, g_N, g_T, g_mark, g_tmat, exact;
     unsigned long long gen;
@@ -497,24 +497,9 @@ run_batch(s3a_batch_t *b)
         hipLaunchKernelGGL(kb_emit, dim3(EMIT_BLOCKS, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
         CHK(hipGetLastError());
         CHK(hipEventSynchronize(b->ev));
-        for (int32_t z = 0; z < n; z++) {
-            const int32_t slot = b->order[z];
-            s3a_lexsearch_t *ls = b->ls[slot];
-            BOut &o = b->out[slot];
-            const int32_t *p = b->h_pack + (size_t)z * b->pack_stride, hdr = 6 * ls->n_tree + 16;
-            int32_t total = 0;
-            o.rc = s3a_dec_unpack(ls, p, o.may_hist != 0, o.frm, o.res, o.n_exit, o.max_exits, &total);
-            if (o.rc != S3A_OK) { strncpy(o.err, s3a_last_error(), sizeof o.err - 1); continue; }
-            if (total > BFIRST) {
-                CHK(hipMemcpyAsync(b->h_pack + (size_t)z * b->pack_stride + hdr + 3 * BFIRST,
-                                   b->d_pack + (size_t)z * b->pack_stride + hdr + 3 * BFIRST,
-                                   (size_t)3 * (total - BFIRST) * 4, hipMemcpyDeviceToHost, st));
-                CHK(hipStreamSynchronize(st));
-            }
-            for (int32_t k = 0; k < total; k++) {
-                o.wid[k] = p[hdr + 3 * k]; o.scr[k] = p[hdr + 3 * k + 1]; o.hist[k] = p[hdr + 3 * k + 2];
-            }
-        }
+        /* every decoder unpacks its own record (in its own thread, in parallel) after the wake-up */
+        for (int32_t z = 0; z < n; z++) { b->zof[b->order[z]] = z; b->last_order[z] = b->order[z]; }
+        b->last_n = n;
     }
 done:
     if (rc != S3A_OK)
@@ -527,6 +512,33 @@ done:
     pthread_cond_broadcast(&b->cv);
     return rc;
 #undef CHK
+}
+
+/* the calling decoder's frame record of the last step -> its result structures */
+static int32_t
+unpack_own(s3a_batch_t *b, int32_t slot)
+{
+    BOut &o = b->out[slot];
+    if (o.rc != S3A_OK) { s3a_set_error("%s", o.err); return o.rc; }
+    s3a_lexsearch_t *ls = b->ls[slot];
+    const int32_t z = b->zof[slot], hdr = 6 * ls->n_tree + 16;
+    const int32_t *p = b->h_pack + (size_t)z * b->pack_stride;
+    int32_t total = 0;
+    int32_t rc = s3a_dec_unpack(ls, p, o.may_hist != 0, o.frm, o.res, o.n_exit, o.max_exits, &total);
+    if (rc != S3A_OK) return rc;
+    if (total > BFIRST) {               /* rare: more exits than travelled with the record */
+        pthread_mutex_lock(&b->mu);
+        hipError_t e = hipMemcpyAsync(b->h_pack + (size_t)z * b->pack_stride + hdr + 3 * BFIRST,
+                                      b->d_pack + (size_t)z * b->pack_stride + hdr + 3 * BFIRST,
+                                      (size_t)3 * (total - BFIRST) * 4, hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        pthread_mutex_unlock(&b->mu);
+        if (e != hipSuccess) { s3a_set_error("s3a_batch: exit read-back failed: %s", hipGetErrorString(e)); return S3A_EHIP; }
+    }
+    for (int32_t k = 0; k < total; k++) {
+        o.wid[k] = p[hdr + 3 * k]; o.scr[k] = p[hdr + 3 * k + 1]; o.hist[k] = p[hdr + 3 * k + 2];
+    }
+    return S3A_OK;
 }
 
 /* srch_TST_begin's device side for one decoder; the decoder now takes part in the steps */
@@ -646,9 +658,7 @@ s3a_batch_step(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, i
                 else { struct timespec ts = { 0, 50000 }; nanosleep(&ts, NULL); }
             }
         }
-        rc = b->out[slot].rc;
-        if (rc != S3A_OK) s3a_set_error("%s", b->out[slot].err);
-        return rc;
+        return unpack_own(b, slot);
     }
     pthread_mutex_unlock(&b->mu);
     return rc;
@@ -675,12 +685,17 @@ s3a_batch_run(s3a_batch_t *b)
     if (!b) return S3A_EINVAL;
     pthread_mutex_lock(&b->mu);
     int32_t rc = S3A_OK;
+    int32_t n = 0, order[BMAXSLOT];
     if (b->n_arrived > 0) {
         rc = run_batch(b);
-        for (int32_t s = 0; rc == S3A_OK && s < b->n_slots; s++)
-            if (b->out[s].rc != S3A_OK) { rc = b->out[s].rc; s3a_set_error("%s", b->out[s].err); }
+        n = b->last_n;
+        memcpy(order, b->last_order, sizeof(int32_t) * n);
     }
     pthread_mutex_unlock(&b->mu);
+    for (int32_t z = 0; z < n; z++) {
+        const int32_t r = unpack_own(b, order[z]);
+        if (rc == S3A_OK) rc = r;
+    }
     return rc;
 }
 
