@@ -764,13 +764,16 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
         int32 k = 0;
         int32 wbeam_phone = (bm->ptranskip != 0 && (frmno % bm->ptranskip) == 0);
         double t0 = now_s();
-        if ((g_batch
-             ? s3a_batch_step(g_batch, g_slot, g_featbuf, g_feat_idx, frmno, bm->hmm, bm->ptrans, bm->word,
-                              wbeam_phone, hp->maxhmmpf, &r, g_exit_n, g_exit_wid, g_exit_scr, g_exit_hist,
-                              g_ntree * g_max_node)
-             : s3a_decoder_search(g_ls, g_sc, g_cs, frmno, bm->hmm, bm->ptrans, bm->word, wbeam_phone,
-                                  hp->maxhmmpf, &r, g_exit_n, g_exit_wid, g_exit_scr, g_exit_hist,
-                                  g_ntree * g_max_node)) != S3A_OK) {
+        int32 rc = g_batch
+            ? s3a_batch_step(g_batch, g_slot, g_featbuf, g_feat_idx, frmno, bm->hmm, bm->ptrans, bm->word,
+                             wbeam_phone, hp->maxhmmpf, &r, g_exit_n, g_exit_wid, g_exit_scr, g_exit_hist,
+                             g_ntree * g_max_node)
+            : s3a_decoder_search(g_ls, g_sc, g_cs, frmno, bm->hmm, bm->ptrans, bm->word, wbeam_phone,
+                                 hp->maxhmmpf, &r, g_exit_n, g_exit_wid, g_exit_scr, g_exit_hist,
+                                 g_ntree * g_max_node);
+        if (rc == S3A_EUNSUP)           /* a configuration the device path refuses: never a silent difference */
+            E_FATAL("tst shim: %s\n", s3a_last_error());
+        if (rc != S3A_OK) {
             E_ERROR("%s\n", s3a_last_error());
             return SRCH_FAILURE;
         }
