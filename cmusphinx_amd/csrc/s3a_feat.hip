@@ -1,0 +1,140 @@
+/*
+ * s3a_feat.hip -- feature computation on the device for the stream type "1s_c_d_dd": the step
+ * immediately before the scoring path.
+ *
+ * Reference: feat_compute_utt (sphinxbase/src/libsphinxbase/feat/feat.c:1111-1123) over the padded
+ * utterance that feat_s2mfc_read builds (feat.c:396-516: `win` = 3 copies of the first and of the
+ * last frame, which therefore take part in the statistics), cmn() (feat/cmn.c:141-208), agc_max()
+ * (feat/agc.c:109-126), feat_1s_c_d_dd_cep2feat (feat.c:726-769).
+ *
+ * Bit-exact: the cepstral sums are float32 sums IN FRAME ORDER, so k_feat_stats gives every
+ * cepstral dimension one lane that walks the frames sequentially (13 chains of n adds; the frames
+ * are staged through LDS in coalesced tiles); k_feat_apply is elementwise: normalise the seven
+ * frames t-3..t+3 (indices clamped = the reference's padding), then the two difference streams.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "s3a_device.h"
+
+#define FWIN 3
+#define FTILE 64            /* frames per LDS tile in the statistics kernel */
+#define FMAXC 64            /* cepstral dimensions supported */
+
+/* stats[0..cs) = mean, [cs..2cs) = inverse standard deviation (1 if no varnorm), [2cs] = AGC maximum */
+__global__ void __launch_bounds__(256)
+k_feat_stats(const float *__restrict__ cep, int32_t n, int32_t cs, int32_t cmn, int32_t varnorm,
+             int32_t agc_max, float *stats)
+{
+    __shared__ float tile[FTILE][FMAXC + 1];
+    const int32_t nfr = n + 2 * FWIN, i = threadIdx.x;
+    float mean = 0.0f, inv = 1.0f;
+    if (cmn) {
+        float sum = 0.0f;
+        for (int32_t f0 = 0; f0 < nfr; f0 += FTILE) {
+            for (int32_t k = threadIdx.x; k < FTILE * cs; k += 256) {
+                const int32_t f = f0 + k / cs, d = k % cs;
+                if (f < nfr) tile[k / cs][d] = cep[(size_t)min(max(f - FWIN, 0), n - 1) * cs + d];
+            }
+            __syncthreads();
+            if (i < cs)
+                for (int32_t f = 0; f < FTILE && f0 + f < nfr; f++) sum += tile[f][i];
+            __syncthreads();
+        }
+        mean = sum / nfr;
+        if (varnorm) {
+            float var = 0.0f;
+            for (int32_t f0 = 0; f0 < nfr; f0 += FTILE) {
+                for (int32_t k = threadIdx.x; k < FTILE * cs; k += 256) {
+                    const int32_t f = f0 + k / cs, d = k % cs;
+                    if (f < nfr) tile[k / cs][d] = cep[(size_t)min(max(f - FWIN, 0), n - 1) * cs + d];
+                }
+                __syncthreads();
+                if (i < cs)
+                    for (int32_t f = 0; f < FTILE && f0 + f < nfr; f++) { const float t = tile[f][i] - mean; var += t * t; }
+                __syncthreads();
+            }
+            inv = (float)sqrt((double)nfr / (double)var);
+        }
+    }
+    if (i < cs) { stats[i] = mean; stats[cs + i] = inv; }
+    __syncthreads();
+    if (agc_max && i == 0) {
+        /* maximum of the NORMALISED c0 over the padded frames (clamped copies cannot change a maximum) */
+        const bool vn = cmn && varnorm;
+        float mx = -INFINITY;
+        for (int32_t f = 0; f < n; f++) {
+            float v = cep[(size_t)f * cs];
+            if (cmn) v = vn ? (v - mean) * inv : v - mean;
+            mx = fmaxf(mx, v);
+        }
+        stats[2 * cs] = mx;
+    }
+    else if (i == 0) stats[2 * cs] = 0.0f;
+}
+
+__global__ void __launch_bounds__(256)
+k_feat_apply(const float *__restrict__ cep, int32_t n, int32_t cs, int32_t cmn, int32_t varnorm, int32_t agc_max,
+             const float *__restrict__ stats, float *feat, int32_t feat_stride)
+{
+    const int32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n * cs) return;
+    const int32_t t = k / cs, i = k - t * cs;
+    const float mean = stats[i], inv = stats[cs + i], mx = (i == 0) ? stats[2 * cs] : 0.0f;
+    const bool vn = cmn && varnorm;
+    float c[7];
+#pragma unroll
+    for (int o = -3; o <= 3; o++) {
+        float v = cep[(size_t)min(max(t + o, 0), n - 1) * cs + i];
+        if (cmn) v = vn ? (v - mean) * inv : v - mean;
+        if (agc_max && i == 0) v = v - mx;
+        c[o + 3] = v;
+    }
+    float *o = feat + (size_t)t * feat_stride;
+    o[i] = c[3];
+    o[cs + i] = c[5] - c[1];
+    const float d1 = c[6] - c[2], d2 = c[4] - c[0];
+    o[2 * cs + i] = d1 - d2;
+}
+
+/* cep: HOST [n][cepsize]; feat_dev: DEVICE rows of feat_stride floats (>= 3 * cepsize; the columns
+ * beyond are left untouched -- pass the padded stride s3a_mgau_score_frames_dev expects) */
+extern "C" int32_t
+s3a_feat_1s_c_d_dd_dev(const float *cep, int32_t n_frames, int32_t cepsize, int32_t cmn_current,
+                       int32_t varnorm, int32_t agc_max, float *feat_dev, int32_t feat_stride, void *stream)
+{
+    if (!cep || !feat_dev || n_frames <= 0 || cepsize <= 0 || cepsize > FMAXC || feat_stride < 3 * cepsize) {
+        s3a_set_error("s3a_feat_1s_c_d_dd: bad arguments (1..%d cepstral dimensions)", FMAXC);
+        return S3A_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float *cep_d = NULL, *stats = NULL;
+    HIPCHK(hipMalloc((void **)&cep_d, (size_t)n_frames * cepsize * 4));
+    HIPCHK(hipMalloc((void **)&stats, (size_t)(2 * cepsize + 1) * 4));
+    HIPCHK(hipMemcpyAsync(cep_d, cep, (size_t)n_frames * cepsize * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_feat_stats, dim3(1), dim3(256), 0, st, cep_d, n_frames, cepsize, cmn_current, varnorm,
+                       agc_max, stats);
+    hipLaunchKernelGGL(k_feat_apply, dim3((n_frames * cepsize + 255) / 256), dim3(256), 0, st, cep_d, n_frames,
+                       cepsize, cmn_current, varnorm, agc_max, stats, feat_dev, feat_stride);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(cep_d); (void)hipFree(stats);
+    return S3A_OK;
+}
+
+/* the same with the features copied back: feat [n][3 * cepsize] on the host */
+extern "C" int32_t
+s3a_feat_1s_c_d_dd(const float *cep, int32_t n_frames, int32_t cepsize, int32_t cmn_current, int32_t varnorm,
+                   int32_t agc_max, float *feat)
+{
+    if (!feat || n_frames <= 0 || cepsize <= 0) return S3A_EINVAL;
+    float *fd = NULL;
+    HIPCHK(hipMalloc((void **)&fd, (size_t)n_frames * 3 * cepsize * 4));
+    int32_t rc = s3a_feat_1s_c_d_dd_dev(cep, n_frames, cepsize, cmn_current, varnorm, agc_max, fd, 3 * cepsize, NULL);
+    if (rc == S3A_OK && hipMemcpy(feat, fd, (size_t)n_frames * 3 * cepsize * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        s3a_set_error("s3a_feat_1s_c_d_dd: read-back failed");
+        rc = S3A_EHIP;
+    }
+    (void)hipFree(fd);
+    return rc;
+}

@@ -108,6 +108,8 @@ _SIGS = {
                                    [C.c_void_p] * 6 + [C.c_int32]),
     "s3a_approx_cont_mgau_frame_eval_async": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_scorer_misc_dev": (C.c_void_p, [C.c_void_p]),
+    "s3a_feat_1s_c_d_dd": (C.c_int32, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p]),
+    "s3a_feat_1s_c_d_dd_dev": (C.c_int32, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_ms_mgau_init": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_double, C.c_int32,
                                       C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p]),
     "s3a_ms_mgau_init_arrays": (C.c_void_p, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p, C.c_int32, C.c_void_p,
@@ -458,6 +460,16 @@ class Scorer:
             out["bstidx"][t] = bi
             out["updatetime"][t] = ut
         return out
+
+
+def feat_1s_c_d_dd(cep, cmn="current", varnorm=False, agc="none"):
+    """feat_compute_utt for "1s_c_d_dd" on the device: cep [n][cepsize] -> feat [n][3 * cepsize]."""
+    L = load()
+    cep = np.ascontiguousarray(cep, np.float32)
+    n, cs = cep.shape
+    out = np.zeros((n, 3 * cs), np.float32)
+    check(L.s3a_feat_1s_c_d_dd(_p(cep), n, cs, int(cmn == "current"), int(bool(varnorm)), int(agc == "max"), _p(out)))
+    return out
 
 
 class MsMgau:

@@ -218,6 +218,20 @@ int32_t s3a_approx_cont_mgau_frame_eval(s3a_scorer_t *sc, uint8_t *sen_active,
                                         int32_t *n_sen_eval, int32_t *n_gau_eval);
 
 /* ------------------------------------------------------------------ */
+/* Feature computation for the stream type "1s_c_d_dd" (the step before the path).
+ * Replaces feat_compute_utt for that type: sphinxbase/src/libsphinxbase/feat/feat.c:1111-1123 over the
+ * padded utterance of feat_s2mfc_read (:396-516), cmn() feat/cmn.c:141-208 (-cmn current, -varnorm),
+ * agc_max() feat/agc.c:109-126 (-agc max), feat_1s_c_d_dd_cep2feat feat.c:726-769.  Bit-exact float32:
+ * the cepstral sums run in frame order.  cep = [n_frames][cepsize] cepstra as read from an .mfc file.
+ * _dev leaves the features in device memory (rows of feat_stride floats) for s3a_mgau_score_frames_dev. */
+/* ------------------------------------------------------------------ */
+int32_t s3a_feat_1s_c_d_dd(const float *cep, int32_t n_frames, int32_t cepsize, int32_t cmn_current,
+                           int32_t varnorm, int32_t agc_max, float *feat);
+int32_t s3a_feat_1s_c_d_dd_dev(const float *cep, int32_t n_frames, int32_t cepsize, int32_t cmn_current,
+                               int32_t varnorm, int32_t agc_max, float *feat_dev, int32_t feat_stride,
+                               void *stream);
+
+/* ------------------------------------------------------------------ */
 /* The multi-stream ("s3.0") senone scorer: -senmgau .s3cont. / .semi. */
 /* Replaces ms_mgau_model_t and its functions:                         */
 /*   ms_mgau_init             libam/ms_mgau.c:149-227                  */

@@ -15,7 +15,7 @@
  *   frame   CD2CISEN.i16 NCISEN MEAN VAR MIXW LOGBASE FEAT.f32 T ACTIVE.u8|all
  *           CIPBEAM DS TIGHTEN MAXCD OUTDIR
  *   tmat    TMATFILE TPFLOOR LOGBASE SHIFT OUTDIR
- *   feat    MFCFILE OUTDIR          (1s_c_d_dd, -cmn current, -agc none, -varnorm no)
+ *   feat    MFCFILE [CMN VARNORM AGC] OUTDIR   (1s_c_d_dd; default -cmn current, -agc none, -varnorm no)
  *   bench_mgau MEAN VAR MIXW LOGBASE FEAT.f32 T   (times approx_cont_mgau_frame_eval with every
  *           senone active; prints "frames T seconds S" -- the CPU baseline of bench.py)
  *   hmm     NEMIT TP.i32 NTMAT SSEQ.i16 NSSEQ SENSCR.i32 NSEN T SPEC.i32 NHMM ENTER.i32 OUTDIR
@@ -407,7 +407,9 @@ cmd_bench_mgau(int argc, char **argv)
 static int
 cmd_feat(int argc, char **argv)
 {
-    feat_t *fcb = feat_init("1s_c_d_dd", CMN_CURRENT, 0, AGC_NONE, 0, 13);
+    /* optional: CMN(none|current) VARNORM(0|1) AGC(none|max) */
+    feat_t *fcb = feat_init("1s_c_d_dd", argc >= 5 ? cmn_type_from_str(argv[2]) : CMN_CURRENT,
+                            argc >= 5 ? atoi(argv[3]) : 0, argc >= 5 ? agc_type_from_str(argv[4]) : AGC_NONE, 0, 13);
     mfcc_t ***feat = feat_array_alloc(fcb, S3_MAX_FRAMES);
     int32 nfr = feat_s2mfc2feat(fcb, argv[0], NULL, "", 0, -1, feat, S3_MAX_FRAMES);
     int32 D = feat_stream_len(fcb, 0), t;
@@ -506,6 +508,10 @@ main(int argc, char **argv)
     if (!strcmp(argv[1], "tmat") && argc == 7) return cmd_tmat(argc - 2, argv + 2);
     if (!strcmp(argv[1], "bench_mgau") && argc == 8) return cmd_bench_mgau(argc - 2, argv + 2);
     if (!strcmp(argv[1], "feat") && argc == 4) return cmd_feat(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "feat") && argc == 7) {       /* feat MFC CMN VARNORM AGC OUTDIR */
+        char *av[5] = { argv[2], argv[6], argv[3], argv[4], argv[5] };
+        return cmd_feat(5, av);
+    }
     if (!strcmp(argv[1], "hmm") && argc == 14) return cmd_hmm(argc - 2, argv + 2);
     if (!strcmp(argv[1], "ms") && argc == 12) return cmd_ms(argc - 2, argv + 2);
     fprintf(stderr, "ref_dump: bad command/arity: %s (%d args)\n", argv[1], argc - 2);

@@ -230,6 +230,11 @@ void s3o_ms_free(s3o_ms_t *ms);
 int32_t s3o_ms_cont_mgau_frame_eval(s3o_ms_t *ms, const uint8_t *sen_active, int32_t *senscr,
                                     const float *feat);
 
+/* feat_compute_utt for the stream type "1s_c_d_dd" (sphinxbase feat.c:1111-1123, :726-769; cmn.c; agc.c):
+ * cep [n][cepsize] -> feat [n][3 * cepsize] */
+void s3o_feat_1s_c_d_dd(const float *cep, int32_t n_frames, int32_t cepsize, int32_t cmn_current,
+                        int32_t varnorm, int32_t agc_max, float *feat);
+
 #ifdef __cplusplus
 }
 #endif
