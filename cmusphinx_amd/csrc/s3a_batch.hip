@@ -45,7 +45,7 @@ struct BSlot {              /* one decoder: static model + its state, all device
     const uint8_t *comp;
     const int16_t *sseq, *comsseq;
     int32_t *sc, *hist, *outs, *outh, *bests, *frame, *pos, *posf, *act[2], *nact[2], *turn, *selfemit,
-        *cnt, *base, *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0, *pstamp;
+        *cnt, *base, *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0, *pstamp, *propf;
     const int32_t *rootnodes, *ps, *psof_off, *psof;
     int32_t n_rootnodes;
     unsigned long long *key;
@@ -264,9 +264,18 @@ kb_resolve(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
     if ((int32_t)(blockIdx.x * DBLOCK) >= s.N) return;
     d_dec_resolve(s.N, s.T, f.frm, f.bm, s.best, s.nact[f.cur], s.node_base, s.tree_of, s.prob, s.par_off, s.par,
                   s.pos, s.posf, s.sc, s.hist, s.outs, s.outh, s.bests, s.frame, s.turn, s.selfemit, s.cnt, s.key,
-                  s.first, s.hbin, s.ps, s.pstamp, s.rootnodes, s.n_rootnodes, blockIdx.x, 0);
+                  s.first, s.hbin, s.ps, s.pstamp, s.rootnodes, s.n_rootnodes, s.propf, blockIdx.x, 0);
 }
 
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+kb_weak(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+{
+    SLOT_FRAME;
+    if (!(f.bm.phone_uses_wbeam || f.bm.pbeam < f.bm.hmmbeam)) return;
+    d_dec_weak(s.N, s.T, f.frm, f.bm, s.best, s.nact[f.cur], s.node_base, s.act[f.cur], s.prob, s.par_off, s.par, s.pos,
+               s.posf, s.sc, s.outs, s.bests, s.wid, s.hbin, s.propf, s.exits + 2 * (size_t)s.N, 0, 0);
+}
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 kb_scan(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int32_t *pack_all,
@@ -391,7 +400,7 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         s.nact[0] = ls->d_nact[0]; s.nact[1] = ls->d_nact[1]; s.turn = ls->d_turn; s.selfemit = ls->d_selfemit;
         s.cnt = ls->d_cnt; s.base = ls->d_cand; s.best = ls->d_best; s.exits = ls->d_exit; s.nexit = ls->d_nexit;
         s.first = ls->d_first; s.eflag = ls->d_eflag; s.hbin = ls->d_hbin; s.done = ls->d_done; s.key = ls->d_key;
-        s.ctot = ls->d_ctot; s.n0 = ls->d_n0; s.pstamp = ls->d_pstamp; s.rootnodes = ls->d_rootnodes;
+        s.ctot = ls->d_ctot; s.n0 = ls->d_n0; s.pstamp = ls->d_pstamp; s.propf = ls->d_candf; s.rootnodes = ls->d_rootnodes;
         s.ps = ls->d_ps; s.psof_off = ls->d_psof_off; s.psof = ls->d_psof;
         s.n_rootnodes = ls->n_rootnodes;
         s.cs_off = cs->off_d; s.cs_wt = cs->wt_d; s.cs_list = cs->list_d;
@@ -430,11 +439,12 @@ static int32_t
 run_batch(s3a_batch_t *b)
 {
     const int32_t n = b->n_arrived;
-    int32_t any_hist = 0, g_ent = 0, g_calls = 0, g_rows = 1, g_mark = 1, rc = S3A_OK;
+    int32_t any_hist = 0, any_weak = 0, g_ent = 0, g_calls = 0, g_rows = 1, g_mark = 1, rc = S3A_OK;
     for (int32_t z = 0; z < n; z++) {
         const int32_t slot = b->order[z];
         b->h_frames[z] = b->stage[slot];
         any_hist |= b->stage[slot].may_hist;
+        any_weak |= (b->stage[slot].bm.phone_uses_wbeam || b->stage[slot].bm.pbeam < b->stage[slot].bm.hmmbeam) ? 1 : 0;
         g_ent = max(g_ent, (b->stage[slot].n_ent + 255) / 256);
         g_calls = max(g_calls, b->stage[slot].n_calls);
         g_rows = max(g_rows, b->rows[slot]);
@@ -484,6 +494,7 @@ run_batch(s3a_batch_t *b)
             hipLaunchKernelGGL(kb_hist_count, dim3((g_rows + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
             hipLaunchKernelGGL(kb_hist_sort, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
         }
+        if (any_weak) hipLaunchKernelGGL(kb_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
         hipLaunchKernelGGL(kb_resolve, dim3((b->g_N + DBLOCK - 1) / DBLOCK, 1, n), dim3(DBLOCK), 0, st, S, F);
         hipLaunchKernelGGL(kb_scan, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F, b->d_pack, b->pack_stride,
                            b->pack_max_exits);
@@ -609,7 +620,6 @@ submit(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, int32_t f
         s3a_set_error("s3a_batch_step: slot %d needs utt_begin and a transition before every step", slot);
         return S3A_EINVAL;
     }
-    if (pbeam < hmmbeam) { s3a_set_error("s3a_batch_step: -pbeam wider than -beam is not supported"); return S3A_EUNSUP; }
     f.slot = slot; f.cur = ls->cur; f.frm = frm;
     f.bm.hmmbeam = hmmbeam; f.bm.pbeam = pbeam; f.bm.wbeam = wbeam; f.bm.phone_uses_wbeam = phone_uses_wbeam;
     f.bm.maxhmmpf = maxhmmpf;

@@ -89,9 +89,22 @@ k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
               unsigned long long *key, int32_t *first, int32_t *hbin,
               const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
-              const int32_t *__restrict__ rootnodes, int32_t n_rootnodes)
+              const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
+              const int32_t *__restrict__ propf)
 {
-    d_dec_resolve(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, blockIdx.x, blockIdx.y);
+    d_dec_resolve(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, blockIdx.x, blockIdx.y);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
+           const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
+           const int32_t *__restrict__ act, const int32_t *__restrict__ prob,
+           const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
+           const int32_t *__restrict__ pos, const int32_t *__restrict__ posf, const int32_t *__restrict__ sc,
+           const int32_t *__restrict__ outs, const int32_t *__restrict__ bests, const int32_t *__restrict__ wid,
+           const int32_t *__restrict__ hbin, int32_t *propf, int32_t *weaklist)
+{
+    d_dec_weak(N, T, cf, bm, best, nact, node_base, act, prob, par_off, par, pos, posf, sc, outs, bests, wid, hbin, propf, weaklist, 0, 0);
 }
 
 
@@ -266,11 +279,6 @@ s3a_dec_unpack(s3a_lexsearch_t *ls, const int32_t *p, bool may_hist, int32_t frm
         s3a_set_error("fused frame: internal error, %d active HMMs exceed the host bound %d", res->n_hmm, ls->hist_bound);
         return S3A_EINVAL;
     }
-    if (p[3 * T + 7]) {
-        s3a_set_error("fused frame: phone threshold below the HMM threshold in frame %d "
-                      "(-ptranskip with a weak best word): not supported", frm);
-        return S3A_EUNSUP;
-    }
     for (t = 0; t < T; t++) {
         if (p[4 * T + 8 + t]) {
             s3a_set_error("out.history==-1 at a word exit of tree %d (LEXTREE_OPERATION_FAILURE)", t);
@@ -329,15 +337,6 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
         return S3A_EUNSUP;
     }
 
-    /* A parent that is cleared in this frame (bestscore < thres) must not propagate.  With the
-     * phone threshold at or above the HMM threshold -- true for every sensible beam setting and
-     * enforced by the reference's own histogram branch (pb = max(hb, pbeam)) -- a cleared parent
-     * can never reach it, so the kernels need no cross-node ordering.  Refuse anything else. */
-    if (pbeam < hmmbeam) {
-        s3a_set_error("s3a_decoder_search: -pbeam wider than -beam is not supported");
-        return S3A_EUNSUP;
-    }
-
     /* the active lists are at most hist_bound long (host bound): size the per-position grids by it */
     const int32_t rows = min(maxn, max(ls->hist_bound, 1));
     hipLaunchKernelGGL(k_dec_hmm_eval, dim3((rows + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK),
@@ -354,12 +353,17 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                            ls->d_act[cur], ls->d_nact[cur], T, bm, ls->d_exit + ls->N, ls->d_exit, ls->d_hbin,
                            ls->d_pos, -1, NBIN);
     }
+    if (phone_uses_wbeam || pbeam < hmmbeam)     /* the phone threshold may fall below the HMM threshold */
+        hipLaunchKernelGGL(k_dec_weak, dim3(1), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm, ls->d_best,
+                           ls->d_nact[cur], ls->d_node_base, ls->d_act[cur], ls->d_prob, ls->d_par_off, ls->d_par,
+                           ls->d_pos, ls->d_posf, ls->d_sc, ls->d_outs, ls->d_bests, ls->d_wid, ls->d_hbin,
+                           ls->d_candf, ls->d_exit + 2 * (size_t)ls->N);
     hipLaunchKernelGGL(k_dec_resolve, dim3((ls->N + DBLOCK - 1) / DBLOCK), dim3(DBLOCK), 0, ls->stream,
                        ls->N, T, frm, bm, ls->d_best, ls->d_nact[cur], ls->d_node_base, ls->d_tree_of,
                        ls->d_prob, ls->d_par_off, ls->d_par, ls->d_pos, ls->d_posf, ls->d_sc, ls->d_hist,
                        ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame, ls->d_turn, ls->d_selfemit,
                        ls->d_cnt, ls->d_key, ls->d_first, ls->d_hbin, ls->d_ps, ls->d_pstamp, ls->d_rootnodes,
-                       ls->n_rootnodes);
+                       ls->n_rootnodes, ls->d_candf);
     hipLaunchKernelGGL(k_dec_scan, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
                        ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_wid, ls->d_prob, ls->d_outs,
                        ls->d_outh, ls->d_selfemit, ls->d_cnt, ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt],

@@ -286,6 +286,68 @@ d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32
 
 /* ------------------------------------------------------------------ */
 /*
+ * Only when the phone threshold lies BELOW the HMM threshold (-ptranskip frames use the word threshold
+ * for phone transitions, srch_time_switch_tree.c:975-1003; or -pbeam wider than -beam).  Then an
+ * active node under the HMM beam but over the phone threshold ("weak") matters: the reference clears
+ * it at its turn -- and a cleared HMM propagates nothing -- UNLESS a parent earlier in the list
+ * re-entered it first, in which case it survives and does propagate; and that parent may be weak
+ * itself.  The dependency runs along the tree depth, so it is settled here before k_dec_resolve:
+ * one workgroup collects the weak nodes and iterates "entered early by a propagating parent" to
+ * its fixed point (monotone; at most tree-depth rounds), stamping propf[v] = cf.
+ */
+__device__ __forceinline__ void
+d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
+           const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
+           const int32_t *__restrict__ act, const int32_t *__restrict__ prob,
+           const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
+           const int32_t *__restrict__ pos, const int32_t *__restrict__ posf, const int32_t *__restrict__ sc,
+           const int32_t *__restrict__ outs, const int32_t *__restrict__ bests, const int32_t *__restrict__ wid,
+           const int32_t *__restrict__ hbin, int32_t *propf, int32_t *weaklist,
+        const int32_t BX, const int32_t BY)
+{
+    __shared__ int32_t n_weak, changed;
+    int32_t th, pth;
+    {
+        int32_t bh, bw, n, wth;
+        (void)frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
+    }
+    if (pth >= th) return;                              /* the usual geometry: nothing to do (uniform) */
+    if (threadIdx.x == 0) n_weak = 0;
+    __syncthreads();
+    for (int32_t t = 0; t < T; t++)
+        for (int32_t i = threadIdx.x; i < nact[t]; i += SCAN_THREADS) {
+            const int32_t v = act[node_base[t] + i];
+            if (wid[v] < 0 && bests[v] < th && outs[v] >= pth) weaklist[atomicAdd(&n_weak, 1)] = v;
+        }
+    __syncthreads();
+    const int32_t nw = n_weak;
+    for (int32_t round = 0; round < N; round++) {       /* (ends after at most tree-depth rounds) */
+        __syncthreads();
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (int32_t k = threadIdx.x; k < nw; k += SCAN_THREADS) {
+            const int32_t v = weaklist[k];
+            if (((volatile int32_t *)propf)[v] == cf) continue;
+            const int32_t in0 = sc[v], j = pos[v];
+            bool early = false;
+            for (int32_t q = par_off[v]; q < par_off[v + 1] && !early; q++) {
+                const int32_t g = par[q];
+                if (posf[g] != cf || pos[g] >= j) continue;
+                const int32_t po = outs[g];
+                if (po < pth) continue;
+                if (bests[g] < th && ((volatile int32_t *)propf)[g] != cf) continue;
+                const int32_t ns = add32(po, add32(prob[v], -prob[g]));
+                early = ns >= th && ns > in0;
+            }
+            if (early) { ((volatile int32_t *)propf)[v] = cf; changed = 1; }
+        }
+        __syncthreads();
+        if (!changed) break;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/*
  * lextree_hmm_propagate_non_leaves from every node's point of view (see the header of
  * s3a_lextree.hip for the rule); one thread per node of every tree: inactive nodes
  * without a propagating parent fall through after two loads.  Also resets the root-entry
@@ -302,6 +364,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               unsigned long long *key, int32_t *first, int32_t *hbin,
               const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
+              const int32_t *__restrict__ propf,
         const int32_t BX, const int32_t BY)
 {
     /* (the thresholds come from uniform addresses: computed per thread with scalar loads, and only by
@@ -348,6 +411,11 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
             const int32_t p = pid[u];
             const int32_t po = outs[p];
             if (po < pth) continue;
+            /* phone threshold BELOW the HMM threshold (-ptranskip frames, -pbeam wider than -beam): a
+             * parent under the HMM beam is cleared at its turn (hmm_clear resets its exit score) before
+             * it could propagate -- unless one of ITS parents re-entered it earlier in this frame
+             * (k_dec_weak worked that out and stamped it) */
+            if (pth < th && bests[p] < th && propf[p] != cf) continue;
             const int32_t ns = add32(po, add32(prob[v], -prob[p]));
             if (ns < th) continue;
             const int32_t pp = pos[p];
@@ -424,7 +492,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
         s_wth = wth;
         s_thr[0] = th; s_thr[1] = pth; s_thr[2] = wth; s_thr[3] = bh; s_thr[4] = bw; s_thr[5] = n;
         s_thr[6] = hist ? 1 : 0;
-        s_thr[7] = (pth < th) ? 1 : 0;      /* see s3a_decoder_search: unsupported beam geometry */
+        s_thr[7] = 0;
     }
     __syncthreads();
     /* (a) turn bases + the self-emitted nodes */

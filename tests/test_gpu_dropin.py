@@ -121,6 +121,24 @@ def test_full_device_search_matches_reference(name, driver, tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.exists(TST) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
+@pytest.mark.parametrize("driver", ["one_decoder", "batched_4x1"])
+def test_full_device_search_with_phone_threshold_below_hmm_threshold(driver, tmp_path):
+    """-ptranskip 2 (every second frame the WORD threshold gates phone transitions) and a phone beam
+    wider than the HMM beam: HMMs under the beam but over the phone threshold propagate only if a
+    parent re-entered them earlier in the frame (k_dec_weak); expected output live from the reference."""
+    extra = RUNS["mode4_trigram"] + ["-ptranskip", "2", "-beam", "1e-80", "-pbeam", "1e-100", "-wbeam", "1e-40"]
+    ref_hyp, ref_seg, _ = run(REFDEC, extra, tmp_path, "cpu_pt")
+    hyp, seg, log = (str(tmp_path / f"tst_pt.{e}") for e in ("match", "matchseg", "log"))
+    with open(log, "w") as lf:
+        p = subprocess.run([TST] + common() + extra + ["-hyp", hyp, "-hypseg", seg], stdout=lf,
+                           stderr=subprocess.STDOUT, timeout=900, env=dict(os.environ, **DRIVERS[driver]))
+    tail = [l for l in open(log, errors="ignore").read().splitlines() if "tst shim" in l or "FATAL" in l]
+    assert p.returncode == 0, "\n".join(tail[-10:])
+    assert open(hyp).read() == ref_hyp and open(seg).read() == ref_seg
+    assert ref_seg != open(os.path.join(D, "ref_mode4_trigram.matchseg")).read()
+
+
+@pytest.mark.skipif(not (os.path.exists(TST) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
 def test_full_device_search_with_histogram_pruning(tmp_path):
     """-maxhmmpf 20: most frames exceed 1.5 x the cap, so lextree_hmm_histbin (bins, beam from the
     bin scan AND the reordering of the active lists) runs on the device; expected output is

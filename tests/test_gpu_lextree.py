@@ -202,7 +202,7 @@ class OracleFrame:
         self.fs = O.OracleFrameScorer(om, cd2cisen, n_ci, ci_pbeam)
         self.comwt = comwt
 
-    def frame(self, feat, frm, hmmbeam, pbeam, wbeam, maxhmmpf):
+    def frame(self, feat, frm, hmmbeam, pbeam, wbeam, maxhmmpf, phone_uses_wbeam=0):
         tr, lex = self.tr, self.lex
         sa = lex.sen_active()
         best, ns, ng, cin, cig, cib = self.fs.step(feat, frm, sa)
@@ -224,13 +224,19 @@ class OracleFrame:
             hb = -(i * width); pb = max(hb, pbeam); wb = max(hb, wbeam)
         w32 = lambda v: ((v + 2**31) % 2**32) - 2**31       # int32 wrap-around, as in the reference's C
         th, pth, wth = w32(bh + hb), w32(bh + pb), w32(bw_ + wb)
+        if phone_uses_wbeam:            # srch_time_switch_tree.c:975-1003: -ptranskip frames
+            pth = wth
         lex.propagate(frm, th, pth, wth)
         return dict(best=best, counts=(ns, ng, cin, cig, cib), bh=bh, bw=bw_, n=nh, th=th, pth=pth, wth=wth,
                     hist=hist, exits=lex.leaves(wth))
 
 
-@pytest.mark.parametrize("seed,maxhmmpf,ci_pbeam", [(5, 20000, 1e-80), (6, 150, 1e-80), (7, 400, 1e-12)])
-def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pbeam):
+@pytest.mark.parametrize("seed,maxhmmpf,ci_pbeam,pbeam,ptranskip",
+                         [(5, 20000, 1e-80, -2000000, 0), (6, 150, 1e-80, -2000000, 0), (7, 400, 1e-12, -2000000, 0),
+                          (8, 20000, 1e-80, -3400000, 0),       # phone beam WIDER than the HMM beam
+                          (9, 20000, 1e-80, -2000000, 2),       # every 2nd frame: word threshold for phones
+                          (10, 300, 1e-80, -3400000, 3)])
+def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pbeam, pbeam, ptranskip):
     """The product path of a mode-4 frame -- s3a_decoder_score / _search / _transition -- against
     the oracle's step-by-step frame on a synthetic forest WITH a synthetic acoustic model: raw
     scores normalised inside the search kernels, inline composite senones, histogram pruning,
@@ -253,7 +259,7 @@ def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pb
         make_gpu(gpu_lib, tr).decoder_utt_begin(sc)
     ls = make_gpu(gpu_lib, tr, stream=gm.stream())
     lock = Lockstep(of.lex, ls, tr["n_tree"])
-    hmmbeam, pbeam, wbeam = -2600000, -2000000, -1500000
+    hmmbeam, wbeam = -2600000, -1500000
 
     ls.decoder_utt_begin(sc)
     first = (0, [0, 3, 4], [0, 0, -50], [7, 8, 9]), (2, [1], [0], [9])
@@ -266,9 +272,10 @@ def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pb
     lock.same("begin", lists=(0,))
     n_hist = 0
     for frm in range(len(feats)):
-        o = of.frame(feats[frm], frm, hmmbeam, pbeam, wbeam, maxhmmpf)
+        uw = 1 if (ptranskip and frm % ptranskip == 0) else 0
+        o = of.frame(feats[frm], frm, hmmbeam, pbeam, wbeam, maxhmmpf, uw)
         ls.decoder_score(sc, feats[frm], frm)
-        res, exits = ls.decoder_search(sc, cs, frm, hmmbeam, pbeam, wbeam, 0, maxhmmpf)
+        res, exits = ls.decoder_search(sc, cs, frm, hmmbeam, pbeam, wbeam, uw, maxhmmpf)
         assert (res.best_hmm, res.best_word, res.n_hmm) == (o["bh"], o["bw"], o["n"]), frm
         assert (res.thres, res.phone_thres, res.word_thres) == (o["th"], o["pth"], o["wth"]), frm
         assert bool(res.need_histprune) == o["hist"], frm

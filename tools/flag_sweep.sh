@@ -14,9 +14,10 @@ while read -r FLAGS; do
   a=DIFF; cmp -s /tmp/fs_a.match /tmp/fs_ref.match && cmp -s /tmp/fs_a.seg /tmp/fs_ref.seg && a=same
   b=DIFF; cmp -s /tmp/fs_b.match /tmp/fs_ref.match && cmp -s /tmp/fs_b.seg /tmp/fs_ref.seg && b=same
   echo "[$i] rc=$r0/$r1/$r2 one=$a batched=$b :: $FLAGS"
-  [ "$r1" != 0 ] && grep "^FATAL\|^ERROR" /tmp/fs_a.log | head -2 | cut -c1-200
+  [ "$r1" != 0 ] && grep "^FATAL" /tmp/fs_a.log | head -2 | cut -c1-300
 done <<'LIST'
 -ptranskip 1
+-ptranskip 2 -beam 1e-80 -pbeam 1e-100 -wbeam 1e-40
 -ptranskip 3
 -wend_beam 1e-30
 -maxwpf 2 -maxhistpf 5
