@@ -865,6 +865,152 @@ done:
     return ms;
 }
 
+/* ------------------------------------------------------------------ */
+/* pocketsphinx's continuous scorer: host half of ms_mgau_init          */
+/* (pocketsphinx/src/libpocketsphinx/ms_mgau.c:75-138, ms_gauden.c:307-398, ms_senone.c:150-352) */
+/* ------------------------------------------------------------------ */
+#define PS_SENSCR_SHIFT 10
+
+static void
+s3a_ps_host_free(s3a_ps_mgau_t *ps)
+{
+    if (!ps) return;
+    free(ps->featlen); free(ps->featoff); free(ps->mean); free(ps->prec); free(ps->det); free(ps->pdf);
+    free(ps->mgau); free(ps->flags);
+    s3a_logmath_free(ps->lm); s3a_logmath_free(ps->lm8);
+    free(ps);
+}
+
+s3a_ps_mgau_t *
+s3a_ps_ms_mgau_init_arrays(const float *mean, const float *var, const float *mixw, int32_t n_mgau,
+                           int32_t n_feat, int32_t n_density, const int32_t *featlen, int32_t n_sen,
+                           const int32_t *sen2mgau, double varfloor_d, double mixwfloor, int32_t topn,
+                           int32_t aw, double logbase)
+{
+    s3a_ps_mgau_t *ps;
+    float varfloor = (float)varfloor_d, *row;
+    int32_t m, f, d, i, s, c;
+    size_t n;
+    if (!mean || !var || !mixw || !featlen || n_mgau <= 0 || n_feat <= 0 || n_density <= 0 || n_sen <= 1
+        || !(varfloor_d > 0.0) || !(mixwfloor > 0.0 && mixwfloor < 1.0) || aw == 0 || !(logbase > 1.0)) {
+        s3a_set_error("s3a_ps_ms_mgau_init: bad arguments");
+        return NULL;
+    }
+    if ((ps = (s3a_ps_mgau_t *)calloc(1, sizeof *ps)) == NULL) return NULL;
+    ps->n_mgau = n_mgau; ps->n_feat = n_feat; ps->n_density = n_density; ps->n_sen = n_sen; ps->aw = aw;
+    ps->lm = s3a_logmath_init(logbase, 0, 0);                   /* acmod.c: logmath_init(-logbase, 0, FALSE) */
+    ps->lm8 = s3a_logmath_init(logbase, PS_SENSCR_SHIFT, 1);    /* ms_senone.c:293 */
+    ps->featlen = (int32_t *)malloc(sizeof(int32_t) * n_feat);
+    ps->featoff = (int32_t *)malloc(sizeof(int32_t) * (n_feat + 1));
+    for (f = 0; f < n_feat; f++) { ps->featlen[f] = featlen[f]; ps->featoff[f] = ps->veclen; ps->veclen += featlen[f]; }
+    ps->featoff[n_feat] = ps->veclen;
+    n = (size_t)n_mgau * n_density * ps->veclen;
+    ps->mean = (float *)malloc(sizeof(float) * n);
+    ps->prec = (float *)malloc(sizeof(float) * n);
+    ps->det = (float *)calloc((size_t)n_mgau * n_feat * n_density, sizeof(float));
+    ps->pdf = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_sen * n_feat * n_density);
+    ps->mgau = (int32_t *)malloc(sizeof(int32_t) * n_sen);
+    ps->flags = (uint8_t *)calloc(n_sen, 1);
+    row = (float *)malloc(sizeof(float) * n_density);
+    if (!ps->lm || !ps->lm8 || !ps->mean || !ps->prec || !ps->det || !ps->pdf || !ps->mgau || !ps->flags || !row) {
+        free(row); s3a_ps_host_free(ps); s3a_set_error("s3a_ps_ms_mgau_init: out of memory"); return NULL;
+    }
+    memcpy(ps->mean, mean, sizeof(float) * n);
+    memcpy(ps->prec, var, sizeof(float) * n);
+    for (m = 0; m < n_mgau; m++)
+        for (f = 0; f < n_feat; f++)
+            for (d = 0; d < n_density; d++) {
+                float *varp = ps->prec + (size_t)m * n_density * ps->veclen + (size_t)n_density * ps->featoff[f]
+                    + (size_t)d * featlen[f];
+                float *detp = &ps->det[((size_t)m * n_feat + f) * n_density + d];
+                *detp = 0;
+                for (i = 0; i < featlen[f]; i++, varp++) {
+                    if (*varp < varfloor) *varp = varfloor;
+                    *detp += (float)s3a_logmath_log(ps->lm, 1.0 / sqrt(*varp * 2.0 * M_PI));
+                    *varp = (float)s3a_logmath_ln_to_log(ps->lm, (1.0 / (*varp * 2.0)));
+                }
+            }
+    for (s = 0; s < n_sen; s++)
+        for (f = 0; f < n_feat; f++) {
+            memcpy(row, mixw + ((size_t)s * n_feat + f) * n_density, sizeof(float) * n_density);
+            normalise(row, n_density);
+            for (c = 0; c < n_density; c++) if (row[c] < mixwfloor) row[c] = (float)mixwfloor;
+            normalise(row, n_density);
+            for (c = 0; c < n_density; c++) {
+                int32_t p = -(s3a_logmath_log(ps->lm, row[c]));
+                p += (1 << (PS_SENSCR_SHIFT - 1)) - 1;          /* rounding before truncation */
+                ps->pdf[((size_t)s * n_feat + f) * n_density + c] = (p < (255 << PS_SENSCR_SHIFT)) ? (p >> PS_SENSCR_SHIFT) : 255;
+            }
+        }
+    free(row);
+    ps->one_to_one = (sen2mgau == NULL);
+    for (s = 0; s < n_sen; s++) {
+        ps->mgau[s] = sen2mgau ? sen2mgau[s] : s;
+        if (ps->mgau[s] < 0 || ps->mgau[s] >= n_mgau) {
+            s3a_set_error("s3a_ps_ms_mgau_init: senone %d needs codebook %d of %d", s, ps->mgau[s], n_mgau);
+            s3a_ps_host_free(ps);
+            return NULL;
+        }
+    }
+    ps->topn = (topn <= 0 || topn > n_density) ? n_density : topn;
+    if (s3a_ps_dev_create(ps) != S3A_OK) { s3a_ps_host_free(ps); return NULL; }
+    return ps;
+}
+
+s3a_ps_mgau_t *
+s3a_ps_ms_mgau_init(const char *meanfile, const char *varfile, double varfloor, const char *mixwfile,
+                    double mixwfloor, const char *senmgau, int32_t topn, int32_t aw, double logbase)
+{
+    uint32_t *wm = NULL, *wv = NULL, *ww = NULL;
+    size_t nm, nv, nw;
+    int32_t M, F, C, M2, F2, C2, S, semi;
+    const int32_t *fl, *fl2;
+    const float *mean, *var;
+    int32_t *map = NULL;
+    s3a_ps_mgau_t *ps = NULL;
+    if (!meanfile || !varfile || !mixwfile) { s3a_set_error("s3a_ps_ms_mgau_init: bad arguments"); return NULL; }
+    if (s3a_bio_read(meanfile, "1.0", &wm, &nm) != S3A_OK || s3a_bio_read(varfile, "1.0", &wv, &nv) != S3A_OK
+        || s3a_bio_read(mixwfile, "1.0", &ww, &nw) != S3A_OK)
+        goto done;
+    if (parse_gau_streams(meanfile, wm, nm, &M, &F, &C, &fl, &mean) != S3A_OK
+        || parse_gau_streams(varfile, wv, nv, &M2, &F2, &C2, &fl2, &var) != S3A_OK)
+        goto done;
+    if (M2 != M || F2 != F || C2 != C || memcmp(fl, fl2, sizeof(int32_t) * F) != 0) {
+        s3a_set_error("Mixture-gaussians dimensions for means and variances differ");
+        goto done;
+    }
+    if (nw < 4 || (int64_t)(int32_t)ww[3] != (int64_t)(int32_t)ww[0] * (int32_t)ww[1] * (int32_t)ww[2]
+        || nw != 4 + (size_t)ww[3] || (int32_t)ww[1] != F || (int32_t)ww[2] != C) {
+        s3a_set_error("%s: mixture weights don't match the codebooks", mixwfile);
+        goto done;
+    }
+    S = (int32_t)ww[0];
+    /* senone -> codebook mapping as senone_init decides it (ms_senone.c:296-333) */
+    if (senmgau && strcmp(senmgau, ".semi.") && strcmp(senmgau, ".cont.") && strcmp(senmgau, ".s3cont.")) {
+        s3a_set_error("s3a_ps_ms_mgau_init: -senmgau %s: mapping files and .ptm. are not supported", senmgau);
+        goto done;
+    }
+    semi = senmgau ? strcmp(senmgau, ".semi.") == 0 : M == 1;
+    if (semi) map = (int32_t *)calloc(S, sizeof(int32_t));
+    else if (S > M) { s3a_set_error("Senones need more codebooks (%d) than present (%d)", S, M); goto done; }
+    ps = s3a_ps_ms_mgau_init_arrays(mean, var, (const float *)(ww + 4), M, F, C, fl, S, map, varfloor, mixwfloor,
+                                    topn, aw, logbase);
+done:
+    free(map); free(wm); free(wv); free(ww);
+    return ps;
+}
+
+void
+s3a_ps_ms_mgau_free(s3a_ps_mgau_t *ps)
+{
+    if (!ps) return;
+    s3a_ps_dev_destroy(ps);
+    s3a_ps_host_free(ps);
+}
+
+int32_t s3a_ps_ms_mgau_n_sen(const s3a_ps_mgau_t *ps) { return ps->n_sen; }
+int32_t s3a_ps_ms_mgau_veclen(const s3a_ps_mgau_t *ps) { return ps->veclen; }
+
 void
 s3a_ms_mgau_free(s3a_ms_mgau_t *ms)
 {

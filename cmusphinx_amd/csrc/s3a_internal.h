@@ -54,6 +54,20 @@ struct s3a_ms_mgau_s {
     struct s3a_ms_dev_s *dev;
 };
 
+/* pocketsphinx's continuous scorer (ps_mgaufuncs_t "ms"): float32, log-domain precisions, 8-bit weights */
+struct s3a_ps_dev_s;
+struct s3a_ps_mgau_s {
+    int32_t n_mgau, n_feat, n_density, n_sen, topn, veclen, aw;
+    int32_t one_to_one;
+    int32_t *featlen, *featoff;
+    float *mean, *prec, *det;           /* file order; prec = (float) logmath_ln_to_log(1 / (2 var)) */
+    int32_t *pdf;                       /* [n_sen][n_feat][n_density]: the 8-bit weights, widened */
+    int32_t *mgau;
+    s3a_logmath_t *lm, *lm8;            /* owned: unshifted (no table) and shifted by SENSCR_SHIFT (table) */
+    uint8_t *flags;                     /* host scratch [n_sen] */
+    struct s3a_ps_dev_s *dev;
+};
+
 struct s3a_tmat_s {
     int32_t n_tmat, n_state;
     int32_t *tp;            /* [n_tmat][n_state][n_state+1] logs3 */
@@ -71,6 +85,8 @@ struct s3a_ms_mgau_s *s3a_ms_host_init(const float *mean, const float *var, cons
                                        double varfloor, double mixwfloor, int32_t topn,
                                        s3a_logmath_t *lm);
 void s3a_ms_host_free(struct s3a_ms_mgau_s *msg);
+int32_t s3a_ps_dev_create(struct s3a_ps_mgau_s *ps);       /* s3a_psms.hip */
+void s3a_ps_dev_destroy(struct s3a_ps_mgau_s *ps);
 int32_t s3a_ms_dev_create(struct s3a_ms_mgau_s *msg);      /* s3a_ms.hip */
 void s3a_ms_dev_destroy(struct s3a_ms_mgau_s *msg);
 /* host half of mgau_init on raw arrays; leaves g->dev NULL */

@@ -1,0 +1,273 @@
+/*
+ * s3a_psms.hip -- device half of pocketsphinx's continuous scorer (ps_mgaufuncs_t "ms",
+ * pocketsphinx/src/libpocketsphinx/ms_mgau.c:163-252): float32 everywhere, log-domain precisions,
+ * 8-bit mixture weights, int16 negated scores normalised to best = 0.
+ *
+ *   k_ps_dist    lane = (codebook, stream, density): dval = det - sum((x-m)^2 * prec), each product
+ *                and the subtraction rounded to float32 (the reference's single C expression on SSE2,
+ *                no FMA); the top-N list is in DESCENDING order and a tie goes in front of the entry
+ *                it ties with (compute_dist's insertion, ms_gauden.c:497-519), so a density's slot is
+ *                its rank under (value desc, codeword desc); parameters transposed to [dim][P] as in
+ *                s3a_ms.hip
+ *   k_ps_senone  thread = active senone: per stream ((int32)dist + 1023 >> 10) - weight8, log-add on
+ *                the 10-bit-shifted table, negated sum, / aw, int16 clamp; block MIN -> atomicMin
+ *   k_ps_norm    clamp(score - best) into the int16 output
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <vector>
+
+#include "s3a_device.h"
+
+#define PSB 256
+#define PS_SHIFT 10
+
+struct s3a_ps_dev_s {
+    int32_t P;
+    float *meanT, *precT, *det;
+    int32_t *featlen, *featoff, *pdf, *mgau;
+    uint32_t *tab;
+    uint32_t tab_size;
+    int32_t lm_zero;
+    uint8_t *sen_active, *mgau_active;
+    float *feat, *dist;
+    int32_t *dist_id, *scr, *best;
+    int16_t *out, *out_h;
+    hipStream_t stream;
+};
+
+__global__ void
+k_ps_mark(const uint8_t *__restrict__ sen_active, const int32_t *__restrict__ mgau, int32_t n_sen, uint8_t *mgau_active)
+{
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_sen && sen_active[s]) mgau_active[mgau[s]] = 1;
+}
+
+__global__ void __launch_bounds__(PSB)
+k_ps_dist(int32_t n_mgau, int32_t n_feat, int32_t nd, int32_t P, int32_t veclen, int32_t topn,
+          const int32_t *__restrict__ featlen, const int32_t *__restrict__ featoff,
+          const float *__restrict__ meanT, const float *__restrict__ precT, const float *__restrict__ det,
+          const uint8_t *__restrict__ mgau_active, const float *__restrict__ feat, float *dist, int32_t *dist_id)
+{
+    extern __shared__ float x_s[];
+    __shared__ float dv[PSB];
+    for (int32_t i = threadIdx.x; i < veclen; i += PSB) x_s[i] = feat[i];
+    __syncthreads();
+    const int32_t item = blockIdx.x * PSB + threadIdx.x;
+    const int32_t job = item / P, d = item % P, m = job / n_feat, f = job % n_feat;
+    const bool live = job < n_mgau * n_feat && mgau_active[m] != 0;
+    float dval = 0.0f;
+    if (live && d < nd) {
+        const int32_t flen = featlen[f], fo = featoff[f];
+        const size_t base = ((size_t)m * veclen + fo) * P;
+        dval = det[(size_t)job * P + d];
+        for (int32_t i = 0; i < flen; i++) {
+            const float df = x_s[fo + i] - meanT[base + (size_t)i * P + d];
+            const float t = (df * df) * precT[base + (size_t)i * P + d];
+            dval = dval - t;
+        }
+    }
+    dv[threadIdx.x] = dval;
+    __syncthreads();
+    if (!live || d >= nd) return;
+    int32_t rank = d;
+    if (topn < nd) {
+        const float *mine = dv + (threadIdx.x - d);
+        rank = 0;
+        for (int32_t k = 0; k < nd; k++) {
+            const float o = mine[k];
+            rank += (o > dval || (o == dval && k > d)) ? 1 : 0;
+        }
+        if (rank >= topn) return;
+    }
+    const size_t o = (size_t)job * topn + rank;
+    dist[o] = dval;
+    dist_id[o] = d;
+}
+
+struct LogAddShifted {
+    const uint32_t *tab;
+    uint32_t size;
+    int32_t zero;
+    __device__ __forceinline__ int32_t operator()(int32_t x, int32_t y) const
+    {
+        if (x <= zero) return y;
+        if (y <= zero) return x;
+        const int32_t hi = x > y ? x : y, lo = x > y ? y : x;
+        const uint32_t d = (uint32_t)hi - (uint32_t)lo;
+        if (d >= size) return hi;
+        return hi + (int32_t)tab[d];
+    }
+};
+
+__global__ void __launch_bounds__(PSB)
+k_ps_senone(int32_t n_sen, int32_t n_feat, int32_t nd, int32_t topn, int32_t aw,
+            const uint8_t *__restrict__ sen_active, const int32_t *__restrict__ mgau,
+            const int32_t *__restrict__ pdf, const float *__restrict__ dist, const int32_t *__restrict__ dist_id,
+            LogAddShifted la, int32_t *scr, int32_t *best)
+{
+    __shared__ int32_t red[PSB / 64];
+    const int32_t s = blockIdx.x * PSB + threadIdx.x;
+    int32_t v = INT_MAX;
+    if (s < n_sen && sen_active[s]) {
+        const int32_t m = mgau[s];
+        int32_t tot = 0;
+        for (int32_t f = 0; f < n_feat; f++) {
+            const float *fd = dist + ((size_t)m * n_feat + f) * topn;
+            const int32_t *fi = dist_id + ((size_t)m * n_feat + f) * topn;
+            const int32_t *p = pdf + ((size_t)s * n_feat + f) * nd;
+            int32_t fscr = (((int32_t)fd[0] + ((1 << PS_SHIFT) - 1)) >> PS_SHIFT) - p[fi[0]];
+            for (int32_t t = 1; t < topn; t++)
+                fscr = la(fscr, (((int32_t)fd[t] + ((1 << PS_SHIFT) - 1)) >> PS_SHIFT) - p[fi[t]]);
+            tot -= fscr;
+        }
+        tot /= aw;
+        tot = min(max(tot, -32768), 32767);
+        scr[s] = tot;
+        v = tot;
+    }
+    int32_t b = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = min(b, __shfl_xor(b, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < PSB / 64; w++) b = min(b, red[w]);
+        if (b != INT_MAX) atomicMin(best, b);
+    }
+}
+
+__global__ void
+k_ps_norm(int32_t n_sen, const uint8_t *__restrict__ sen_active, const int32_t *__restrict__ best,
+          const int32_t *__restrict__ scr, int16_t *out)
+{
+    const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_sen && sen_active[s]) out[s] = (int16_t)min(max(scr[s] - *best, -32768), 32767);
+}
+
+#define DM(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 4))
+
+extern "C" int32_t
+s3a_ps_dev_create(s3a_ps_mgau_t *ps)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        s3a_set_error("no HIP device: libcmusphinx_amd has no CPU fallback");
+        return S3A_ENODEV;
+    }
+    int32_t P = 1;
+    while (P < ps->n_density) P <<= 1;
+    if (P > PSB) { s3a_set_error("s3a_ps_ms_mgau_init: %d densities per codebook exceed the kernel's %d", ps->n_density, PSB); return S3A_EUNSUP; }
+    if (ps->veclen * 4 > 48 * 1024) { s3a_set_error("s3a_ps_ms_mgau_init: feature vector too long"); return S3A_EUNSUP; }
+    s3a_ps_dev_s *dv = new s3a_ps_dev_s();
+    memset(dv, 0, sizeof *dv);
+    ps->dev = dv;
+    dv->P = P;
+    const int32_t M = ps->n_mgau, F = ps->n_feat, nd = ps->n_density, D = ps->veclen, S = ps->n_sen;
+    const size_t nT = (size_t)M * D * P;
+    std::vector<float> mt(nT, 0.0f), pt(nT, 0.0f), dt((size_t)M * F * P, 0.0f);
+    for (int32_t m = 0; m < M; m++)
+        for (int32_t f = 0; f < F; f++) {
+            const size_t src = (size_t)m * nd * D + (size_t)nd * ps->featoff[f];
+            const size_t dst = ((size_t)m * D + ps->featoff[f]) * P;
+            for (int32_t d = 0; d < nd; d++) {
+                dt[((size_t)m * F + f) * P + d] = ps->det[((size_t)m * F + f) * nd + d];
+                for (int32_t i = 0; i < ps->featlen[f]; i++) {
+                    mt[dst + (size_t)i * P + d] = ps->mean[src + (size_t)d * ps->featlen[f] + i];
+                    pt[dst + (size_t)i * P + d] = ps->prec[src + (size_t)d * ps->featlen[f] + i];
+                }
+            }
+        }
+    HIPCHK(hipStreamCreateWithFlags(&dv->stream, hipStreamNonBlocking));
+    DM(dv->meanT, nT * 4); DM(dv->precT, nT * 4); DM(dv->det, (size_t)M * F * P * 4);
+    DM(dv->featlen, (size_t)F * 4); DM(dv->featoff, (size_t)(F + 1) * 4);
+    DM(dv->pdf, (size_t)S * F * nd * 4); DM(dv->mgau, (size_t)S * 4);
+    DM(dv->sen_active, (size_t)S); DM(dv->mgau_active, (size_t)M); DM(dv->feat, (size_t)D * 4);
+    DM(dv->dist, (size_t)M * F * ps->topn * 4); DM(dv->dist_id, (size_t)M * F * ps->topn * 4);
+    DM(dv->scr, (size_t)S * 4); DM(dv->best, 4); DM(dv->out, (size_t)S * 2);
+    HIPCHK(hipHostMalloc((void **)&dv->out_h, (size_t)S * 2));
+    HIPCHK(hipMemcpy(dv->meanT, mt.data(), nT * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dv->precT, pt.data(), nT * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dv->det, dt.data(), dt.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dv->featlen, ps->featlen, (size_t)F * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dv->featoff, ps->featoff, (size_t)(F + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dv->pdf, ps->pdf, (size_t)S * F * nd * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dv->mgau, ps->mgau, (size_t)S * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dv->dist, 0, (size_t)M * F * ps->topn * 4));
+    HIPCHK(hipMemset(dv->dist_id, 0, (size_t)M * F * ps->topn * 4));
+    HIPCHK(hipMemset(dv->out, 0, (size_t)S * 2));
+    {
+        uint32_t size = 0, width = 0, shift = 0;
+        s3a_logmath_get_table_shape(ps->lm8, &size, &width, &shift);
+        if (size == 0) { s3a_set_error("s3a_ps_ms_mgau_init: no log-add table"); return S3A_EUNSUP; }
+        std::vector<uint32_t> tab(size);
+        s3a_logmath_copy_table(ps->lm8, tab.data(), size);
+        dv->tab_size = size;
+        dv->lm_zero = s3a_logmath_get_zero(ps->lm8);
+        DM(dv->tab, (size_t)size * 4);
+        HIPCHK(hipMemcpy(dv->tab, tab.data(), (size_t)size * 4, hipMemcpyHostToDevice));
+    }
+    return S3A_OK;
+}
+
+extern "C" void
+s3a_ps_dev_destroy(s3a_ps_mgau_t *ps)
+{
+    s3a_ps_dev_s *dv = ps ? ps->dev : NULL;
+    if (!dv) return;
+    void *ptrs[] = { dv->meanT, dv->precT, dv->det, dv->featlen, dv->featoff, dv->pdf, dv->mgau, dv->tab,
+                     dv->sen_active, dv->mgau_active, dv->feat, dv->dist, dv->dist_id, dv->scr, dv->best, dv->out };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (dv->out_h) (void)hipHostFree(dv->out_h);
+    if (dv->stream) (void)hipStreamDestroy(dv->stream);
+    delete dv;
+    ps->dev = NULL;
+}
+
+extern "C" int32_t
+s3a_ps_ms_cont_mgau_frame_eval(s3a_ps_mgau_t *ps, int16_t *senscr, const uint8_t *senone_active,
+                               int32_t n_senone_active, const float *feat, int32_t frame, int32_t compallsen)
+{
+    (void)frame;
+    if (!ps || !ps->dev || !senscr || !feat || (!compallsen && (!senone_active || n_senone_active < 0))) return S3A_EINVAL;
+    s3a_ps_dev_s *dv = ps->dev;
+    const int32_t M = ps->n_mgau, F = ps->n_feat, nd = ps->n_density, S = ps->n_sen, P = dv->P;
+    /* the delta-encoded list (acmod_flags2list) -> flags; out-of-range ids would be a caller bug */
+    if (compallsen) memset(ps->flags, 1, S);
+    else {
+        memset(ps->flags, 0, S);
+        for (int32_t i = 0, n = 0; i < n_senone_active; i++) {
+            const int32_t s = senone_active[i] + n;
+            if (s >= S) { s3a_set_error("s3a_ps_ms_cont_mgau_frame_eval: senone %d out of range", s); return S3A_EINVAL; }
+            ps->flags[s] = 1;
+            n = s;
+        }
+    }
+    const int32_t init = INT_MAX;
+    HIPCHK(hipMemcpyAsync(dv->sen_active, ps->flags, (size_t)S, hipMemcpyHostToDevice, dv->stream));
+    HIPCHK(hipMemcpyAsync(dv->feat, feat, (size_t)ps->veclen * 4, hipMemcpyHostToDevice, dv->stream));
+    HIPCHK(hipMemcpyAsync(dv->best, &init, 4, hipMemcpyHostToDevice, dv->stream));
+    const uint8_t *cb_active = dv->sen_active;
+    if (!ps->one_to_one) {
+        HIPCHK(hipMemsetAsync(dv->mgau_active, 0, (size_t)M, dv->stream));
+        hipLaunchKernelGGL(k_ps_mark, dim3((S + 255) / 256), dim3(256), 0, dv->stream, dv->sen_active, dv->mgau, S, dv->mgau_active);
+        cb_active = dv->mgau_active;
+    }
+    const int64_t items = (int64_t)M * F * P;
+    hipLaunchKernelGGL(k_ps_dist, dim3((uint32_t)((items + PSB - 1) / PSB)), dim3(PSB), (size_t)ps->veclen * 4, dv->stream,
+                       M, F, nd, P, ps->veclen, ps->topn, dv->featlen, dv->featoff, dv->meanT, dv->precT, dv->det,
+                       cb_active, dv->feat, dv->dist, dv->dist_id);
+    LogAddShifted la = { dv->tab, dv->tab_size, dv->lm_zero };
+    hipLaunchKernelGGL(k_ps_senone, dim3((S + PSB - 1) / PSB), dim3(PSB), 0, dv->stream, S, F, nd, ps->topn, ps->aw,
+                       dv->sen_active, dv->mgau, dv->pdf, dv->dist, dv->dist_id, la, dv->scr, dv->best);
+    hipLaunchKernelGGL(k_ps_norm, dim3((S + 255) / 256), dim3(256), 0, dv->stream, S, dv->sen_active, dv->best, dv->scr, dv->out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dv->out_h, dv->out, (size_t)S * 2, hipMemcpyDeviceToHost, dv->stream));
+    HIPCHK(hipStreamSynchronize(dv->stream));
+    for (int32_t s = 0; s < S; s++)
+        if (ps->flags[s]) senscr[s] = dv->out_h[s];
+    return S3A_OK;
+}

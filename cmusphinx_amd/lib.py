@@ -110,6 +110,16 @@ _SIGS = {
     "s3a_scorer_misc_dev": (C.c_void_p, [C.c_void_p]),
     "s3a_feat_1s_c_d_dd": (C.c_int32, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p]),
     "s3a_feat_1s_c_d_dd_dev": (C.c_int32, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_ps_ms_mgau_init": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_double, C.c_char_p, C.c_int32,
+                                         C.c_int32, C.c_double]),
+    "s3a_ps_ms_mgau_init_arrays": (C.c_void_p, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p, C.c_int32, C.c_void_p,
+                                                                                 C.c_double, C.c_double, C.c_int32,
+                                                                                 C.c_int32, C.c_double]),
+    "s3a_ps_ms_mgau_free": (None, [C.c_void_p]),
+    "s3a_ps_ms_mgau_n_sen": (C.c_int32, [C.c_void_p]),
+    "s3a_ps_ms_mgau_veclen": (C.c_int32, [C.c_void_p]),
+    "s3a_ps_ms_cont_mgau_frame_eval": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                                   C.c_int32]),
     "s3a_ms_mgau_init": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_double, C.c_int32,
                                       C.c_char_p, C.c_char_p, C.c_int32, C.c_void_p]),
     "s3a_ms_mgau_init_arrays": (C.c_void_p, [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p, C.c_int32, C.c_void_p,
@@ -470,6 +480,56 @@ def feat_1s_c_d_dd(cep, cmn="current", varnorm=False, agc="none"):
     out = np.zeros((n, 3 * cs), np.float32)
     check(L.s3a_feat_1s_c_d_dd(_p(cep), n, cs, int(cmn == "current"), int(bool(varnorm)), int(agc == "max"), _p(out)))
     return out
+
+
+class PsMsMgau:
+    """pocketsphinx's continuous scorer (the object behind ps_mgaufuncs_t): int16 negated scores, best = 0."""
+
+    def __init__(self, h):
+        self.L = load()
+        if not h:
+            raise S3AError(_err(self.L))
+        self.h = h
+        self.n_sen = self.L.s3a_ps_ms_mgau_n_sen(h)
+        self.veclen = self.L.s3a_ps_ms_mgau_veclen(h)
+
+    @classmethod
+    def init(cls, meanfile, varfile, mixwfile, senmgau=".cont.", topn=4, aw=1, logbase=1.0001, varfloor=1e-4,
+             mixwfloor=1e-7):
+        L = load()
+        e = lambda p: None if p is None else str(p).encode()
+        return cls(L.s3a_ps_ms_mgau_init(e(meanfile), e(varfile), varfloor, e(mixwfile), mixwfloor, e(senmgau), int(topn),
+                                         int(aw), float(logbase)))
+
+    @classmethod
+    def init_arrays(cls, mean, var, mixw, n_mgau, n_density, featlen, topn, aw=1, logbase=1.0001, sen2mgau=None,
+                    varfloor=1e-4, mixwfloor=1e-7):
+        L = load()
+        mean = np.ascontiguousarray(mean, np.float32); var = np.ascontiguousarray(var, np.float32)
+        mixw = np.ascontiguousarray(mixw, np.float32)
+        fl = np.ascontiguousarray(featlen, np.int32)
+        n_sen = mixw.size // (len(fl) * n_density)
+        s2m = None if sen2mgau is None else np.ascontiguousarray(sen2mgau, np.int32)
+        return cls(L.s3a_ps_ms_mgau_init_arrays(_p(mean), _p(var), _p(mixw), int(n_mgau), len(fl), int(n_density), _p(fl),
+                                                n_sen, None if s2m is None else _p(s2m), varfloor, mixwfloor, int(topn),
+                                                int(aw), float(logbase)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_ps_ms_mgau_free(self.h)
+            self.h = None
+
+    def frame_eval(self, senscr, feat, active_list=None, frame=0):
+        """ps_mgau_frame_eval: senscr int16[S] in place; active_list = the delta-encoded uint8 list
+        (acmod_flags2list) or None for compallsen."""
+        x = np.ascontiguousarray(feat, np.float32)
+        assert senscr.dtype == np.int16 and senscr.flags.c_contiguous
+        if active_list is None:
+            check(self.L.s3a_ps_ms_cont_mgau_frame_eval(self.h, _p(senscr), None, 0, _p(x), int(frame), 1))
+        else:
+            lst = np.ascontiguousarray(active_list, np.uint8)
+            check(self.L.s3a_ps_ms_cont_mgau_frame_eval(self.h, _p(senscr), _p(lst) if len(lst) else _p(np.zeros(1, np.uint8)),
+                                                        len(lst), _p(x), int(frame), 0))
 
 
 class MsMgau:

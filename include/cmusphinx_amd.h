@@ -218,6 +218,36 @@ int32_t s3a_approx_cont_mgau_frame_eval(s3a_scorer_t *sc, uint8_t *sen_active,
                                         int32_t *n_sen_eval, int32_t *n_gau_eval);
 
 /* ------------------------------------------------------------------ */
+/* The SECONDARY boundary: pocketsphinx's continuous scorer, the object behind */
+/* the ps_mgaufuncs_t vtable {name, frame_eval, transform, free} (pocketsphinx/src/libpocketsphinx/     */
+/* acmod.h:97-110) that acmod_score calls (acmod.c:1076-1131).  Replaces                                 */
+/*   ms_mgau_init             ms_mgau.c:75-138  (arguments = the -mean -var -varfloor -mixw -mixwfloor   */
+/*                            -senmgau -topn -aw -logbase values it reads from the config)               */
+/*   ms_cont_mgau_frame_eval  ms_mgau.c:163-252 (gauden_dist ms_gauden.c:415-541, senone_eval            */
+/*                            ms_senone.c:367-421)                                                       */
+/* pocketsphinx conventions: float32 arithmetic, scores are int16, NEGATED (smaller = better), scaled by */
+/* >> SENSCR_SHIFT (10) and normalised to best = 0; senone_active is the delta-encoded ascending list of */
+/* acmod_flags2list (acmod.c:1220-1271).  A pocketsphinx maintainer wraps the handle in a struct whose   */
+/* first member is ps_mgau_t {vt, frame_idx} and whose vt->frame_eval forwards here.    */
+/* feat = the frame's streams concatenated.                                                              */
+/* ------------------------------------------------------------------ */
+typedef struct s3a_ps_mgau_s s3a_ps_mgau_t;
+s3a_ps_mgau_t *s3a_ps_ms_mgau_init(const char *meanfile, const char *varfile, double varfloor,
+                                   const char *mixwfile, double mixwfloor, const char *senmgau,
+                                   int32_t topn, int32_t aw, double logbase);
+s3a_ps_mgau_t *s3a_ps_ms_mgau_init_arrays(const float *mean, const float *var, const float *mixw,
+                                          int32_t n_mgau, int32_t n_feat, int32_t n_density,
+                                          const int32_t *featlen, int32_t n_sen, const int32_t *sen2mgau,
+                                          double varfloor, double mixwfloor, int32_t topn, int32_t aw,
+                                          double logbase);
+void    s3a_ps_ms_mgau_free(s3a_ps_mgau_t *ps);
+int32_t s3a_ps_ms_mgau_n_sen(const s3a_ps_mgau_t *ps);
+int32_t s3a_ps_ms_mgau_veclen(const s3a_ps_mgau_t *ps);
+int32_t s3a_ps_ms_cont_mgau_frame_eval(s3a_ps_mgau_t *ps, int16_t *senscr, const uint8_t *senone_active,
+                                       int32_t n_senone_active, const float *feat, int32_t frame,
+                                       int32_t compallsen);
+
+/* ------------------------------------------------------------------ */
 /* Feature computation for the stream type "1s_c_d_dd" (the step before the path).
  * Replaces feat_compute_utt for that type: sphinxbase/src/libsphinxbase/feat/feat.c:1111-1123 over the
  * padded utterance of feat_s2mfc_read (:396-516), cmn() feat/cmn.c:141-208 (-cmn current, -varnorm),

@@ -230,6 +230,27 @@ void s3o_ms_free(s3o_ms_t *ms);
 int32_t s3o_ms_cont_mgau_frame_eval(s3o_ms_t *ms, const uint8_t *sen_active, int32_t *senscr,
                                     const float *feat);
 
+/* ------------------------------------------------------------------ */
+/* pocketsphinx's continuous scorer (ps_mgaufuncs_t "ms"), see s3o_psms.c */
+/* ------------------------------------------------------------------ */
+typedef struct s3o_psms_s {
+    int32_t n_mgau, n_feat, n_density, n_sen, topn, veclen, aw;
+    int32_t *featlen, *featoff;
+    float *mean, *var, *det;        /* var = log-domain precision (float32 of an int), det [m][f][d] */
+    uint8_t *pdf;                   /* [n_sen][n_feat][n_density] 8-bit -log weights */
+    int32_t *mgau;
+    float *dist; int32_t *dist_id;  /* top-N of the last frame [n_mgau][n_feat][topn] */
+    uint8_t *mgau_active;
+    s3o_logmath_t *lm, *lm8;
+} s3o_psms_t;
+s3o_psms_t *s3o_psms_init(const float *mean, const float *var, const float *mixw, int32_t n_mgau,
+                          int32_t n_feat, int32_t n_density, const int32_t *featlen, int32_t n_sen,
+                          const int32_t *sen2mgau, double varfloor, double mixwfloor, int32_t topn,
+                          int32_t aw, double logbase);
+void s3o_psms_free(s3o_psms_t *ms);
+void s3o_psms_frame_eval(s3o_psms_t *ms, int16_t *senscr, const uint8_t *senone_active,
+                         int32_t n_senone_active, const float *feat, int32_t compallsen);
+
 /* feat_compute_utt for the stream type "1s_c_d_dd" (sphinxbase feat.c:1111-1123, :726-769; cmn.c; agc.c):
  * cep [n][cepsize] -> feat [n][3 * cepsize] */
 void s3o_feat_1s_c_d_dd(const float *cep, int32_t n_frames, int32_t cepsize, int32_t cmn_current,

@@ -567,3 +567,50 @@ class OracleMs:
         n = c.n_mgau * c.n_feat * c.topn
         shp = (c.n_mgau, c.n_feat, c.topn)
         return self.arr("dist", n, np.int32).reshape(shp), self.arr("dist_id", n, np.int32).reshape(shp)
+
+
+def delta_encode(mask):
+    """acmod_flags2list (pocketsphinx acmod.c:1220-1271): ascending senone ids as uint8 deltas, gaps over
+    255 bridged by 255-steps (which the scorer treats as active senones too)."""
+    lst, last = [], 0
+    for s in np.nonzero(np.asarray(mask))[0]:
+        d = int(s) - last
+        while d > 255:
+            lst.append(255); d -= 255
+        lst.append(d); last = int(s)
+    return np.array(lst, np.uint8)
+
+
+class OraclePsMs:
+    """pocketsphinx's continuous scorer (ms_mgau_init + ms_cont_mgau_frame_eval) on raw arrays."""
+
+    def __init__(self, mean, var, mixw, n_mgau, n_density, featlen, topn, aw=1, logbase=1.0001, sen2mgau=None,
+                 varfloor=1e-4, mixwfloor=1e-7):
+        L = self.L = lib()
+        L.s3o_psms_init.restype = C.c_void_p
+        L.s3o_psms_init.argtypes = [C.c_void_p] * 3 + [C.c_int32] * 3 + [C.c_void_p, C.c_int32, C.c_void_p, C.c_double,
+                                                                         C.c_double, C.c_int32, C.c_int32, C.c_double]
+        L.s3o_psms_frame_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.s3o_psms_free.argtypes = [C.c_void_p]
+        mean = np.ascontiguousarray(mean, np.float32).ravel(); var = np.ascontiguousarray(var, np.float32).ravel()
+        mixw = np.ascontiguousarray(mixw, np.float32)
+        fl = np.ascontiguousarray(featlen, np.int32)
+        self.n_sen = mixw.size // (len(fl) * n_density)
+        s2m = None if sen2mgau is None else np.ascontiguousarray(sen2mgau, np.int32)
+        self.h = L.s3o_psms_init(_p2(mean), _p2(var), _p2(mixw), n_mgau, len(fl), n_density, _p2(fl), self.n_sen,
+                                 None if s2m is None else _p2(s2m), varfloor, mixwfloor, topn, aw, logbase)
+
+    def __del__(self):
+        try:
+            self.L.s3o_psms_free(self.h)
+        except Exception:
+            pass
+
+    def frame_eval(self, senscr, feat, mask=None):
+        """senscr int16[S] in place; mask None = compallsen."""
+        x = np.ascontiguousarray(feat, np.float32)
+        if mask is None:
+            self.L.s3o_psms_frame_eval(self.h, _p2(senscr), None, 0, _p2(x), 1)
+        else:
+            lst = delta_encode(mask)
+            self.L.s3o_psms_frame_eval(self.h, _p2(senscr), _p2(lst) if len(lst) else None, len(lst), _p2(x), 0)
