@@ -201,3 +201,34 @@ def test_rm1_identical_to_live_reference(binary, tmp_path):
     assert out["gpu"][0] == out["ref"][0]
     assert out["gpu"][1] == out["ref"][1]
     assert out["ref"][0].count("\n") == 20
+
+
+# ---------------------------------------------------------------------------
+# the SECONDARY boundary: pocketsphinx's ps_mgaufuncs_t vtable (acmod.h:97-115).  oracle/ref_ps_shim.c =
+# the unmodified pocketsphinx decoder (fwdtree + fwdflat + bestpath, its own feature computation and
+# senone activation lists) with acmod->mgau swapped for an object that forwards frame_eval to
+# s3a_ps_ms_cont_mgau_frame_eval: hypotheses AND path scores must equal the unmodified run's.
+# ---------------------------------------------------------------------------
+PSSHIM = os.path.join(ROOT, "oracle", "_ref", "ref_ps_shim")
+
+
+@pytest.mark.skipif(not os.path.exists(PSSHIM), reason="oracle/_ref/ref_ps_shim did not travel")
+def test_pocketsphinx_decoder_with_gpu_scorer_matches_pocketsphinx(tmp_path):
+    ctl = tmp_path / "ps.ctl"
+    ctl.write_text("".join(l.split()[0] + "\n" for l in open(os.path.join(D, "tidigits.length.arb.regression"))))
+    out = {}
+    for mode in ("ref", "gpu"):
+        o, log = str(tmp_path / f"ps_{mode}.out"), str(tmp_path / f"ps_{mode}.log")
+        with open(log, "w") as lf:
+            p = subprocess.run([PSSHIM, mode, os.path.join(AM, "mdef"), os.path.join(AM, "means"),
+                                os.path.join(AM, "variances"), os.path.join(AM, "mixture_weights"),
+                                os.path.join(AM, "transition_matrices"), os.path.join(D, "tidigits.ps.dic"),
+                                os.path.join(D, "fillerdict"), os.path.join(D, "tidigits.DMP"), str(ctl),
+                                os.path.join(D, "cepstra"), o], stdout=lf, stderr=subprocess.STDOUT, timeout=600)
+        tail = [l for l in open(log, errors="ignore").read().splitlines() if "ps shim" in l or "FATAL" in l]
+        assert p.returncode == 0, "\n".join(tail[-5:])
+        out[mode] = open(o).read()
+        if mode == "gpu":
+            assert any("frame_eval calls served by" in l for l in tail)
+    assert out["gpu"] == out["ref"]
+    assert out["ref"].count("\n") == 31 and "ONE ONE ONE (man/man.ah.111a" in out["ref"]
