@@ -282,7 +282,7 @@ def main():
                            "achieved_GBs": round(fs_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
                            "frac": round(fs_gbs / HBM_PEAK_GBS, 4)},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # (the CPU baseline and the decode leg: N = 1 runs only)
             res["cpu_baseline"] = cpu_baseline(model, feats[0], args.cpu_frames,
                                                procs=os.cpu_count() or 1)
         if world == 1 and not args.no_decode:
