@@ -63,6 +63,8 @@ struct BSlot {              /* one decoder: static model + its state, all device
     const int16_t *cd2cisen;
     uint8_t *sen_act;
     int32_t *scr, *misc, *bstidx, *bstscr, *updatetime;
+    int32_t *gpart;         /* [3][gp_n]: per-workgroup maxima / counters of kb_gated_cd_multi */
+    int32_t gp_n, pad1;
 };
 
 struct BFrame {             /* one decoder's parameters for one step */
@@ -72,6 +74,7 @@ struct BFrame {             /* one decoder's parameters for one step */
     int32_t frm, may_hist;
     FrameBeams bm;
     int32_t sc_frame, sc_beam, sc_is_skip, mark_rows;   /* mark_rows: bound on the list lengths before the entries */
+    int32_t gpart_n, pad2[3];   /* > 0: this step's CD maxima / counters are in the slot's gpart[] */
     int32_t calls[4 * BMAXC];
 };
 
@@ -110,18 +113,25 @@ kb_enter3_mark(const BSlot *__restrict__ slots, const BFrame *__restrict__ frame
                       s.cs_list, s.sen_act, blockIdx.x, 0);
 }
 
+#define KB_GATED_ARGS s.mean4, s.prec4, s.lrd, s.mixw, s.tab16, s.tab_size, s.lm_zero, s.f, s.distfloor,            \
+                         f.feat, s.D4, s.CP, s.Gpad, lo, hi, CI ? 1 : 0, s.ncomp, s.cd2cisen, s.sen_act, s.scr,     \
+                         0, CI ? (const int32_t *)NULL : s.misc + 5, CI ? 0 : f.sc_beam, f.sc_frame,              \
+                         CI ? 0 : f.sc_is_skip, s.bstidx, s.bstscr, s.updatetime, s.misc, CI ? 5 : 0,             \
+                         CI ? (uint8_t *)NULL : s.sen_act, tab
+/* tab_cap = entries of dynamic LDS the launch provides for the log-add table (0: none) */
 template <bool EXACT, bool CI>
 __global__ void __launch_bounds__(256)
-kb_gated(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
+kb_gated(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, uint32_t tab_cap)
 {
+    extern __shared__ __attribute__((aligned(16))) uint16_t tab_dyn[];
     SLOT_FRAME;
     const int32_t lo = CI ? 0 : s.n_ci_sen, hi = CI ? s.n_ci_sen : s.n_sen;
     if ((int32_t)(blockIdx.x * 256) >= (hi - lo) * s.CP) return;
-    d_gated_frame<EXACT>(s.mean4, s.prec4, s.lrd, s.mixw, s.tab16, s.tab_size, s.lm_zero, s.f, s.distfloor,
-                         f.feat, s.D4, s.CP, s.Gpad, lo, hi, CI ? 1 : 0, s.ncomp, s.cd2cisen, s.sen_act, s.scr,
-                         0, CI ? (const int32_t *)NULL : s.misc + 5, CI ? 0 : f.sc_beam, f.sc_frame,
-                         CI ? 0 : f.sc_is_skip, s.bstidx, s.bstscr, s.updatetime, s.misc, CI ? 5 : 0,
-                         CI ? (uint8_t *)NULL : s.sen_act, blockIdx.x);
+    uint16_t *tab = ((s.tab_size + 7) & ~7u) <= tab_cap ? tab_dyn : (uint16_t *)NULL;
+    if (s.D4 == D4MAIN)
+        d_gated_frame<EXACT, D4MAIN>(KB_GATED_ARGS, blockIdx.x);
+    else
+        d_gated_frame<EXACT, 0>(KB_GATED_ARGS, blockIdx.x);
 }
 
 /*
@@ -136,96 +146,361 @@ kb_gated(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
  * (A first version kept the parameters in registers and LOOPED over the decoders: with < 1 wave
  * per SIMD every decoder's gate -> distance -> log-add chain was exposed latency; 78 us vs 45.)
  */
-#define GX_THREADS 1024
-template <bool EXACT>
+#define GX_THREADS 512      /* 256 VGPRs per lane: the Gaussian (80) stays in registers without spilling */
+#define GX_SEN (GX_THREADS / 64)    /* senones per tile: one per wave */
+struct GxDec {              /* one decoder of the workgroup, staged in LDS */
+    uint8_t *sen_act;
+    int32_t *scr, *misc, *bstidx, *bstscr, *updatetime;
+    int32_t frame, is_skip, thresh, pad;    /* thresh = the CI maximum + the CI beam */
+};
+/*
+ * D4C > 0: the Gaussian is fetched before the gate is known and the gate only selects (see s3a_gated.h).
+ * A workgroup walks several senone tiles (grid.x of them apart): the table is staged once, and the
+ * decoders' maxima / counters leave the workgroup as ONE set of atomics per decoder -- their words share
+ * a cache line per decoder and read-modify-writes of a line are served one after another, which is what
+ * this kernel's time was made of when every tile sent its own.
+ */
+template <bool EXACT, int D4C>
 __global__ void __launch_bounds__(GX_THREADS)
 kb_gated_cd_shared(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int32_t n)
 {
     typedef typename Acc<EXACT>::T acc_t;
-    __shared__ float xs[64][64 + 4];            /* features of this workgroup's decoders (<= 64 / CP) */
+    constexpr int NK = D4C > 0 ? D4C : 1;
     __shared__ int32_t red[64][4];              /* per decoder: best, #senones, #Gaussians */
+    __shared__ GxDec dec[64];
+    /* dynamic: [features of this workgroup's decoders: 64 / CP rows of 64 + 4][the log-add table: the
+     * ordered log-add is a chain of dependent look-ups, from LDS instead of L2] */
+    extern __shared__ __attribute__((aligned(16))) unsigned char gx_smem[];
     const BSlot &s0 = slots[frames[0].slot];
     const int32_t CP = s0.CP, D4 = s0.D4, Gpad = s0.Gpad, per_wave = 64 / CP;
+    float (*xs)[64 + 4] = (float (*)[64 + 4])gx_smem;
+    uint16_t *tab_s = (uint16_t *)(gx_smem + (size_t)per_wave * (64 + 4) * sizeof(float));
     const int32_t z0 = blockIdx.y * per_wave;
-    for (int32_t i = threadIdx.x; i < per_wave * 64; i += GX_THREADS) {
-        const int32_t q = i >> 6, k = i & 63;
-        xs[q][k] = (z0 + q < n && k < D4 * 4) ? frames[z0 + q].feat[k] : 0.0f;
-    }
-    if (threadIdx.x < 64) { red[threadIdx.x][0] = INT_MIN; red[threadIdx.x][1] = 0; red[threadIdx.x][2] = 0; }
-    __syncthreads();
     const int32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int32_t q = lane / CP, c = lane - q * CP, z = z0 + q;
-    const int32_t sen = s0.n_ci_sen + blockIdx.x * (GX_THREADS / 64) + wave;
-    const bool valid = sen < s0.n_sen && z < n;
-    const int32_t g = sen * CP + c;
-    int32_t mode = 0, ci_scr = 0, bi = S3A_NO_BSTIDX, frame = 0, is_skip = 0, nc = 0;
-    const BSlot *sp = NULL;
+    const int32_t n_tiles = (s0.n_sen - s0.n_ci_sen + GX_SEN - 1) / GX_SEN;
+    int32_t tile = blockIdx.x;
+    int32_t sen = s0.n_ci_sen + tile * GX_SEN + wave;
+    bool valid = tile < n_tiles && sen < s0.n_sen && z < n;
+    int32_t g = sen * CP + c;
+
+    /* ---- everything whose address is known now: the lane's Gaussian, the senone's constants ---- */
+    float4 M[NK], P[NK];
+    float lrd_g = 0.0f;
+    int32_t mixw = 0, nc = 0, ci_id = 0;
+#define GX_FETCH                                                                                     \
+    if (valid) {                                                                                     \
+        if (D4C > 0) {                                                                               \
+            _Pragma("unroll")                                                                        \
+            for (int k = 0; k < NK; k++) {                                                           \
+                M[k] = s0.mean4[(size_t)k * Gpad + g];                                               \
+                P[k] = s0.prec4[(size_t)k * Gpad + g];                                               \
+            }                                                                                        \
+            lrd_g = s0.lrd[g];                                                                       \
+            mixw = s0.mixw[g];                                                                       \
+        }                                                                                            \
+        nc = (int32_t)s0.ncomp[sen];                                                                 \
+        ci_id = s0.cd2cisen[sen];                                                                    \
+    }                                                                                                \
+    else if (D4C > 0) {                                                                              \
+        _Pragma("unroll")                                                                            \
+        for (int k = 0; k < NK; k++) M[k] = P[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);             \
+    }
+    GX_FETCH
+    /* ---- while those are in flight: features, the decoders' pointers, the table ---- */
+    for (int32_t i = threadIdx.x; i < per_wave * 64; i += GX_THREADS) {
+        const int32_t qq = i >> 6, k = i & 63;
+        xs[qq][k] = (z0 + qq < n && k < D4 * 4) ? frames[z0 + qq].feat[k] : 0.0f;
+    }
+    if (threadIdx.x < 64) { red[threadIdx.x][0] = INT_MIN; red[threadIdx.x][1] = 0; red[threadIdx.x][2] = 0; }
+    if ((int32_t)threadIdx.x < per_wave && z0 + (int32_t)threadIdx.x < n) {
+        const BFrame &f = frames[z0 + threadIdx.x];
+        const BSlot &sp = slots[f.slot];
+        GxDec d;
+        d.sen_act = sp.sen_act; d.scr = sp.scr; d.misc = sp.misc; d.bstidx = sp.bstidx; d.bstscr = sp.bstscr;
+        d.updatetime = sp.updatetime; d.frame = f.sc_frame; d.is_skip = f.sc_is_skip;
+        d.thresh = (int32_t)((uint32_t)sp.misc[5] + (uint32_t)f.sc_beam); d.pad = 0;
+        dec[threadIdx.x] = d;
+    }
+    {
+        const int32_t n16 = (int32_t)((s0.tab_size * 2 + 15) >> 4);     /* padded to 8 entries by the host */
+        for (int32_t i = threadIdx.x; i < n16; i += GX_THREADS)
+            ((uint4 *)tab_s)[i] = ((const uint4 *)s0.tab16)[i];
+    }
+    __syncthreads();
     LogAdd la;
-    la.tab = s0.tab16; la.size = s0.tab_size; la.zero = s0.lm_zero;
-    if (valid) {
-        const BFrame &f = frames[z];
-        sp = &slots[f.slot];
-        frame = f.sc_frame; is_skip = f.sc_is_skip;
-        nc = (int32_t)s0.ncomp[sen];
-        if (sp->sen_act[sen]) {
-            ci_scr = sp->scr[s0.cd2cisen[sen]];
-            if (ci_scr >= (int32_t)((uint32_t)sp->misc[5] + (uint32_t)f.sc_beam))
-                mode = 1;
-            else {
-                bi = sp->bstidx[sen];
-                mode = (bi == S3A_NO_BSTIDX || sp->updatetime[sen] != frame - 1) ? 3 : 2;
+    la.tab = tab_s; la.size = s0.tab_size; la.zero = s0.lm_zero;
+    GxDec d;
+    if (z < n) d = dec[q];
+    int32_t rbest = INT_MIN, rns = 0, rng = 0;      /* lane c == 0 of each decoder accumulates */
+    for (;;) {
+        /* ---- the gate: one round trip ---- */
+        int32_t mode = 0, ci_scr = 0, bi = S3A_NO_BSTIDX;
+        if (valid) {
+            const int32_t act = d.sen_act[sen], ut = d.updatetime[sen];
+            ci_scr = d.scr[ci_id];
+            bi = d.bstidx[sen];
+            if (act) {
+                if (ci_scr >= d.thresh)
+                    mode = 1;
+                else
+                    mode = (bi == S3A_NO_BSTIDX || ut != d.frame - 1) ? 3 : 2;
             }
         }
-    }
-    int32_t gs = S3A_LOGPROB_ZERO;
-    if (mode == 1 || (mode == 2 && c == bi)) {
-        acc_t a = (acc_t)s0.lrd[g];
-        const float *x = xs[q];
-        for (int32_t k = 0; k < D4; k++) {
-            const float4 m = s0.mean4[(size_t)k * Gpad + g], p = s0.prec4[(size_t)k * Gpad + g];
-            const float4 xv = *(const float4 *)(x + 4 * k);
-            a = Acc<EXACT>::step(a, xv.x, m.x, p.x);
-            a = Acc<EXACT>::step(a, xv.y, m.y, p.y);
-            a = Acc<EXACT>::step(a, xv.z, m.z, p.z);
-            a = Acc<EXACT>::step(a, xv.w, m.w, p.w);
-        }
-        gs = gau_to_int((double)a, s0.f, s0.distfloor, s0.mixw[g]);
-    }
-    int32_t score = S3A_LOGPROB_ZERO, bs = S3A_LOGPROB_ZERO, bidx = S3A_NO_BSTIDX;
-    for (int32_t cc = 0; cc < CP; cc++) {
-        const int32_t v = __shfl(gs, q * CP + cc, 64);
-        if (mode == 1 && cc < nc) {
-            score = la(score, v);
-            if (v > bs) { bs = v; bidx = cc; }
-        }
-        else if (mode == 2 && cc == bi) {
-            score = la(score, v);
-            if (v > bs) { bs = v; bidx = cc; }
-        }
-    }
-    if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
-    if (mode == 3) score = ci_scr;
-    if (valid && c == 0) {
-        sp->sen_act[sen] = 0;                           /* the mask is consumed */
-        if (mode != 0) {
-            sp->scr[sen] = score;
-            atomicMax(&red[q][0], score);
-            if (mode == 1) {
-                sp->bstidx[sen] = bidx; sp->bstscr[sen] = bs; sp->updatetime[sen] = frame;
-                atomicAdd(&red[q][1], 1); atomicAdd(&red[q][2], nc);
+        if (mode != 2) bi = S3A_NO_BSTIDX;
+        const bool wanted = mode == 1 || (mode == 2 && c == bi);
+        int32_t gs = S3A_LOGPROB_ZERO;
+        if (D4C > 0) {
+            acc_t a = (acc_t)lrd_g;
+            const float *x = xs[q];
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                const float4 xv = *(const float4 *)(x + 4 * k);
+                a = Acc<EXACT>::step(a, xv.x, M[k].x, P[k].x);
+                a = Acc<EXACT>::step(a, xv.y, M[k].y, P[k].y);
+                a = Acc<EXACT>::step(a, xv.z, M[k].z, P[k].z);
+                a = Acc<EXACT>::step(a, xv.w, M[k].w, P[k].w);
             }
-            else if (mode == 2) {
-                if (is_skip) { sp->bstidx[sen] = bidx; sp->bstscr[sen] = bs; sp->updatetime[sen] = frame; }
-                atomicAdd(&red[q][2], 1);
+            if (wanted) gs = gau_to_int((double)a, s0.f, s0.distfloor, mixw);
+        }
+        else if (wanted) {
+            acc_t a = (acc_t)s0.lrd[g];
+            const float *x = xs[q];
+            for (int32_t k = 0; k < D4; k++) {
+                const float4 m = s0.mean4[(size_t)k * Gpad + g], p = s0.prec4[(size_t)k * Gpad + g];
+                const float4 xv = *(const float4 *)(x + 4 * k);
+                a = Acc<EXACT>::step(a, xv.x, m.x, p.x);
+                a = Acc<EXACT>::step(a, xv.y, m.y, p.y);
+                a = Acc<EXACT>::step(a, xv.z, m.z, p.z);
+                a = Acc<EXACT>::step(a, xv.w, m.w, p.w);
+            }
+            gs = gau_to_int((double)a, s0.f, s0.distfloor, s0.mixw[g]);
+        }
+        int32_t score = S3A_LOGPROB_ZERO, bs = S3A_LOGPROB_ZERO, bidx = S3A_NO_BSTIDX;
+        for (int32_t cc = 0; cc < CP; cc++) {
+            const int32_t v = __shfl(gs, q * CP + cc, 64);
+            if (mode == 1 && cc < nc) {
+                score = la(score, v);
+                if (v > bs) { bs = v; bidx = cc; }
+            }
+            else if (mode == 2 && cc == bi) {
+                score = la(score, v);
+                if (v > bs) { bs = v; bidx = cc; }
             }
         }
+        if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
+        if (mode == 3) score = ci_scr;
+        if (valid && c == 0) {
+            d.sen_act[sen] = 0;                             /* the mask is consumed */
+            if (mode != 0) {
+                d.scr[sen] = score;
+                rbest = max(rbest, score);
+                if (mode == 1) {
+                    d.bstidx[sen] = bidx; d.bstscr[sen] = bs; d.updatetime[sen] = d.frame;
+                    rns++; rng += nc;
+                }
+                else if (mode == 2) {
+                    if (d.is_skip) { d.bstidx[sen] = bidx; d.bstscr[sen] = bs; d.updatetime[sen] = d.frame; }
+                    rng++;
+                }
+            }
+        }
+        tile += gridDim.x;
+        if (tile >= n_tiles) break;         /* (workgroup-uniform) */
+        sen = s0.n_ci_sen + tile * GX_SEN + wave;
+        valid = sen < s0.n_sen && z < n;
+        g = sen * CP + c;
+        GX_FETCH
+    }
+#undef GX_FETCH
+    if (c == 0 && z < n) {
+        if (rbest != INT_MIN) atomicMax(&red[q][0], rbest);
+        if (rns) atomicAdd(&red[q][1], rns);
+        if (rng) atomicAdd(&red[q][2], rng);
     }
     __syncthreads();
     if ((int32_t)threadIdx.x < per_wave && z0 + (int32_t)threadIdx.x < n) {
-        int32_t *misc = slots[frames[z0 + threadIdx.x].slot].misc;
+        int32_t *misc = dec[threadIdx.x].misc;
         if (red[threadIdx.x][0] != INT_MIN) atomicMax(&misc[0], red[threadIdx.x][0]);
         if (red[threadIdx.x][1]) atomicAdd(&misc[1], red[threadIdx.x][1]);
         if (red[threadIdx.x][2]) atomicAdd(&misc[2], red[threadIdx.x][2]);
+    }
+}
+
+/*
+ * The same, model-stationary: the multi-frame scoring kernel (k_score_frames, s3a_device.hip) with
+ * the decoders of the step in the place of the frames.  A lane keeps ONE Gaussian in registers
+ * and evaluates it for a group of GM_FB decoders (features broadcast from LDS), the values are
+ * transposed through LDS, and lane (senone, c) then runs the gate and the ordered log-add of
+ * decoder c of the group for its senone -- so the model is read once per GM_FB decoders with
+ * fully coalesced loads, at 8 x the arithmetic per byte.  Every Gaussian is computed, the gate
+ * selects (see s3a_gated.h).  The per-decoder maxima / counters leave the workgroup as plain
+ * stores into the decoder's gpart[] (one column per workgroup), merged by the consumers
+ * (d_dec_hmm_eval: the normaliser; d_dec_scan: the frame record): atomics on the decoders'
+ * misc[] words -- one cache line per decoder -- were served one after another and cost more
+ * than the scoring.
+ */
+#define GM_FB 8             /* decoders per group (= accumulators per lane) */
+#define GM_MAXDEC 32        /* decoders per launch (LDS: features + descriptors) */
+template <bool EXACT>
+__global__ void __launch_bounds__(256)
+kb_gated_cd_multi(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int32_t n)
+{
+    typedef typename Acc<EXACT>::T acc_t;
+    __shared__ GxDec dec[GM_MAXDEC];
+    __shared__ int32_t red[4][GM_MAXDEC][3];    /* per wave, per decoder: best, #senones, #Gaussians */
+    __shared__ int32_t tr_s[4][GM_FB * 65];     /* per wave: [decoder of the group][lane] */
+    /* dynamic: [features: GM_MAXDEC rows of D4MAIN float4][the log-add table] */
+    extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
+    float4 *xs4 = (float4 *)gm_smem;
+    uint16_t *tab_s = (uint16_t *)(gm_smem + (size_t)GM_MAXDEC * D4MAIN * sizeof(float4));
+    const BSlot &s0 = slots[frames[0].slot];
+    const int32_t CP = s0.CP, Gpad = s0.Gpad;
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t g = s0.n_ci_sen * CP + blockIdx.x * 256 + tid;
+    const int32_t sen = g / CP, c = g - sen * CP, sl = lane / CP;
+    const bool valid = sen < s0.n_sen;
+
+    /* ---- the lane's Gaussian + the senone's constants ---- */
+    float4 M[D4MAIN], P[D4MAIN];
+    float lrd_g = 0.0f;
+    int32_t mixw = 0, nc = 0, ci_id = 0;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < D4MAIN; k++) {
+            M[k] = s0.mean4[(size_t)k * Gpad + g];
+            P[k] = s0.prec4[(size_t)k * Gpad + g];
+        }
+        lrd_g = s0.lrd[g];
+        mixw = s0.mixw[g];
+        nc = (int32_t)s0.ncomp[sen];
+        ci_id = s0.cd2cisen[sen];
+    }
+    else {
+#pragma unroll
+        for (int k = 0; k < D4MAIN; k++) M[k] = P[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    /* ---- while those are in flight: features, the decoders' descriptors, the table ---- */
+    for (int32_t i = tid; i < GM_MAXDEC * D4MAIN * 4; i += 256) {
+        const int32_t zz = i / (D4MAIN * 4), k = i - zz * (D4MAIN * 4);
+        ((float *)xs4)[i] = zz < n ? frames[zz].feat[k] : 0.0f;
+    }
+    for (int32_t i = tid; i < 4 * GM_MAXDEC; i += 256) {
+        red[i / GM_MAXDEC][i % GM_MAXDEC][0] = INT_MIN; red[i / GM_MAXDEC][i % GM_MAXDEC][1] = 0;
+        red[i / GM_MAXDEC][i % GM_MAXDEC][2] = 0;
+    }
+    if (tid < n) {
+        const BFrame &f = frames[tid];
+        const BSlot &sp = slots[f.slot];
+        GxDec d;
+        d.sen_act = sp.sen_act; d.scr = sp.scr; d.misc = sp.gpart; d.bstidx = sp.bstidx; d.bstscr = sp.bstscr;
+        d.updatetime = sp.updatetime; d.frame = f.sc_frame; d.is_skip = f.sc_is_skip;
+        d.thresh = (int32_t)((uint32_t)sp.misc[5] + (uint32_t)f.sc_beam); d.pad = sp.gp_n;
+        dec[tid] = d;
+    }
+    {
+        const int32_t n16 = (int32_t)((s0.tab_size * 2 + 15) >> 4);     /* padded to 8 entries by the host */
+        for (int32_t i = tid; i < n16; i += 256)
+            ((uint4 *)tab_s)[i] = ((const uint4 *)s0.tab16)[i];
+    }
+    __syncthreads();
+    LogAdd la;
+    la.tab = tab_s; la.size = s0.tab_size; la.zero = s0.lm_zero;
+    int32_t *tr = tr_s[wave];
+    const int32_t n_groups = (n + GM_FB - 1) / GM_FB;
+    for (int32_t grp = blockIdx.y; grp < n_groups; grp += gridDim.y) {
+        const int32_t z0 = grp * GM_FB, nd = min(GM_FB, n - z0);
+        /* ---- the gate of (this senone, decoder c of the group): in flight during the arithmetic ---- */
+        const bool mine = valid && c < nd;
+        int32_t act = 0, ut = 0, ci_scr = 0, bi = S3A_NO_BSTIDX;
+        GxDec d;
+        if (mine) {
+            d = dec[z0 + c];
+            act = d.sen_act[sen]; ut = d.updatetime[sen];
+            ci_scr = d.scr[ci_id];
+            bi = d.bstidx[sen];
+        }
+        /* ---- the lane's Gaussian for every decoder of the group ---- */
+        acc_t a[GM_FB];
+#pragma unroll
+        for (int j = 0; j < GM_FB; j++) a[j] = (acc_t)lrd_g;
+#pragma unroll
+        for (int k = 0; k < D4MAIN; k++) {
+#pragma unroll
+            for (int j = 0; j < GM_FB; j++) {
+                if (j < nd) {
+                    const float4 x = xs4[(z0 + j) * D4MAIN + k];        /* wave-uniform: LDS broadcast */
+                    a[j] = Acc<EXACT>::step(a[j], x.x, M[k].x, P[k].x);
+                    a[j] = Acc<EXACT>::step(a[j], x.y, M[k].y, P[k].y);
+                    a[j] = Acc<EXACT>::step(a[j], x.z, M[k].z, P[k].z);
+                    a[j] = Acc<EXACT>::step(a[j], x.w, M[k].w, P[k].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GM_FB; j++)
+            if (j < nd) tr[j * 65 + lane] = gau_to_int((double)a[j], s0.f, s0.distfloor, mixw);
+        /* same-wave LDS hand-off: no barrier needed, but order the accesses */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        /* ---- gate + ordered log-add: 0 = untouched, 1 = full, 2 = single Gaussian, 3 = CI copy ---- */
+        int32_t mode = 0;
+        if (mine && act) {
+            if (ci_scr >= d.thresh)
+                mode = 1;
+            else
+                mode = (bi == S3A_NO_BSTIDX || ut != d.frame - 1) ? 3 : 2;
+        }
+        int32_t score = S3A_LOGPROB_ZERO, bs = S3A_LOGPROB_ZERO, bidx = S3A_NO_BSTIDX;
+        const int32_t *row = tr + c * 65 + sl * CP;     /* (only read when mine: c < nd <= GM_FB) */
+        if (mode == 1) {
+            for (int32_t cc = 0; cc < nc; cc++) {
+                const int32_t v = row[cc];
+                score = la(score, v);
+                if (v > bs) { bs = v; bidx = cc; }      /* update_best_id = 1: strict >, first max wins */
+            }
+        }
+        else if (mode == 2) {
+            const int32_t v = row[bi];
+            score = la(score, v);
+            if (v > bs) { bs = v; bidx = bi; }
+        }
+        if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
+        if (mode == 3) score = ci_scr;
+        int32_t rbest = INT_MIN, rns = 0, rng = 0;
+        if (mine) {
+            d.sen_act[sen] = 0;                             /* the mask is consumed */
+            if (mode != 0) {
+                d.scr[sen] = score;
+                rbest = score;
+                if (mode == 1) {
+                    d.bstidx[sen] = bidx; d.bstscr[sen] = bs; d.updatetime[sen] = d.frame;
+                    rns = 1; rng = nc;
+                }
+                else if (mode == 2) {
+                    if (d.is_skip) { d.bstidx[sen] = bidx; d.bstscr[sen] = bs; d.updatetime[sen] = d.frame; }
+                    rng = 1;
+                }
+            }
+        }
+        /* over the wave's senones (lanes with the same c) */
+        for (int32_t o = CP; o < 64; o <<= 1) {
+            rbest = max(rbest, __shfl_xor(rbest, o, 64));
+            rns += __shfl_xor(rns, o, 64);
+            rng += __shfl_xor(rng, o, 64);
+        }
+        if (sl == 0 && c < nd) { red[wave][z0 + c][0] = rbest; red[wave][z0 + c][1] = rns; red[wave][z0 + c][2] = rng; }
+        __builtin_amdgcn_wave_barrier();                    /* tr is rewritten by the next group */
+    }
+    __syncthreads();
+    /* this workgroup's column of every decoder it served */
+    if (tid < n && (tid / GM_FB) % (int32_t)gridDim.y == (int32_t)blockIdx.y) {
+        int32_t *gp = dec[tid].misc;
+        const int32_t gp_n = dec[tid].pad;
+        gp[blockIdx.x] = max(max(red[0][tid][0], red[1][tid][0]), max(red[2][tid][0], red[3][tid][0]));
+        gp[gp_n + blockIdx.x] = red[0][tid][1] + red[1][tid][1] + red[2][tid][1] + red[3][tid][1];
+        gp[2 * gp_n + blockIdx.x] = red[0][tid][2] + red[1][tid][2] + red[2][tid][2] + red[3][tid][2];
     }
 }
 
@@ -236,7 +511,7 @@ kb_hmm_eval(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
     if ((int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * DBLOCK) >= s.maxn) return;   /* (grid sized by the host bound) */
     d_dec_hmm_eval(s.node_base, s.act[f.cur], s.nact[f.cur], s.N, s.n_tmat, s.ssid, s.tmatid, s.wid, s.comp,
                    s.tp, s.sseq, s.comsseq, s.cs_off, s.cs_list, s.cs_wt, s.scr, s.misc, s.sc, s.hist, s.outs,
-                   s.outh, s.bests, s.best, f.frm, s.psof_off, s.psof, s.pstamp, blockIdx.x, blockIdx.y);
+                   s.outh, s.bests, s.best, f.frm, s.psof_off, s.psof, s.pstamp, s.gpart, f.gpart_n, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -286,7 +561,7 @@ kb_scan(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int3
     d_dec_scan(s.N, s.T, f.frm, f.bm, s.node_base, s.act[f.cur], s.nact[f.cur], s.wid, s.prob, s.outs, s.outh,
                s.selfemit, s.cnt, s.base, s.act[f.cur ^ 1], s.nact[f.cur ^ 1], s.pos, s.posf, s.best, s.exits,
                s.nexit, s.hbin, s.misc, s.done, pack_all + (size_t)blockIdx.z * pack_stride, max_exits,
-               blockIdx.x, 0);
+               s.gpart, f.gpart_n, blockIdx.x, 0);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -318,6 +593,8 @@ struct s3a_batch_s {
     int32_t n_active, n_arrived, order[BMAXSLOT], rows[BMAXSLOT], zof[BMAXSLOT], last_order[BMAXSLOT], last_n;
     int32_t *d_pack, *h_pack, pack_stride, pack_max_exits, hdr_max;
     int32_t g_ent, g_ci, g_cd, g_maxn, g_N, g_T, g_mark, g_tmat, exact;
+    uint32_t g_tabcap;                  /* entries of the largest log-add table (padded to 8) */
+    int32_t *gpart[BMAXSLOT];           /* per slot: kb_gated_cd_multi's per-workgroup results */
     unsigned long long gen;
     long steps, slot_frames;
     hipStream_t stream;
@@ -356,6 +633,7 @@ s3a_batch_free(s3a_batch_t *b)
     (void)hipFree(b->d_slots); (void)hipFree(b->d_frames); (void)hipHostFree(b->h_frames);
     if (b->d_pack) (void)hipFree(b->d_pack);
     if (b->h_pack) (void)hipHostFree(b->h_pack);
+    for (int32_t i = 0; i < b->n_slots; i++) (void)hipFree(b->gpart[i]);
     /* the attached decoders now own a dead stream handle: they must be freed by their owners
      * WITHOUT further use; their own streams were replaced at attach time */
     pthread_mutex_destroy(&b->mu);
@@ -409,6 +687,9 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         s.D4 = d->D4; s.CP = d->CP; s.Gpad = d->Gpad; s.n_sen = sc->n_sen; s.n_ci_sen = sc->n_ci_sen;
         s.ncomp = sc->ncomp_d; s.cd2cisen = sc->cd2cisen_d; s.sen_act = sc->act_d; s.scr = sc->scr_d;
         s.misc = sc->misc_d; s.bstidx = sc->bstidx_d; s.bstscr = sc->bstscr_d; s.updatetime = sc->updatetime_d;
+        s.gp_n = ((s.n_sen - s.n_ci_sen) * s.CP + 255) / 256;
+        if (hipMalloc((void **)&b->gpart[slot], (size_t)3 * max(1, s.gp_n) * 4) != hipSuccess) { rc = S3A_EHIP; break; }
+        s.gpart = b->gpart[slot];
         if (hipMemcpy(b->d_slots + slot, &s, sizeof s, hipMemcpyHostToDevice) != hipSuccess) { rc = S3A_EHIP; break; }
         b->ls[slot] = ls; b->sc[slot] = sc; b->cs[slot] = cs;
         b->exact = sc->g->precision == S3A_GMM_EXACT;
@@ -419,6 +700,7 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         b->g_ent = max(b->g_ent, (ls->ent_cap + 255) / 256);
         b->g_mark = max(b->g_mark, (ls->ent_cap + DBLOCK - 1) / DBLOCK + ((maxn + DBLOCK - 1) / DBLOCK) * s.T);
         b->g_tmat = max(b->g_tmat, s.n_tmat);
+        b->g_tabcap = max(b->g_tabcap, (s.tab_size + 7) & ~7u);
         const int32_t hdr = 6 * s.T + 16;
         if (hdr > b->hdr_max || ls->pack_max_exits > b->pack_max_exits) {
             if (b->d_pack) { (void)hipFree(b->d_pack); (void)hipHostFree(b->h_pack); }
@@ -455,6 +737,20 @@ run_batch(s3a_batch_t *b)
         hipStream_t st = b->stream;
         const BSlot *S = b->d_slots;
         const BFrame *F = b->d_frames;
+        /* one model for every decoder of the step?  then the CD senones of all of them are one pass
+         * over the model: kb_gated_cd_multi (39/40-dimensional features, >= GM_FB Gaussians per senone
+         * slot), else kb_gated_cd_shared */
+        bool shared = n > 1 && n <= 64 && getenv("S3A_BATCH_NO_SHARED") == NULL;
+        for (int32_t z = 0; z < n && shared; z++) {
+            const s3a_scorer_t *sc = b->sc[b->order[z]], *sc0 = b->sc[b->order[0]];
+            shared = sc->g == sc0->g && sc->n_sen == sc0->n_sen && sc->n_ci_sen == sc0->n_ci_sen
+                && sc->cd2cisen_d != NULL && sc0->g->dev->D4 * 4 <= 64 && sc0->g->dev->CP <= 64;
+        }
+        const struct s3a_mgau_dev_s *d0 = b->sc[b->order[0]]->g->dev;
+        const size_t gm_lds = (size_t)GM_MAXDEC * D4MAIN * sizeof(float4) + (((size_t)d0->tab_size + 7) & ~(size_t)7) * 2;
+        const bool multi = shared && n <= GM_MAXDEC && d0->D4 == D4MAIN && d0->CP >= GM_FB && gm_lds <= 72 * 1024
+            && getenv("S3A_BATCH_NO_MULTI") == NULL;
+        for (int32_t z = 0; z < n; z++) b->h_frames[z].gpart_n = multi ? b->g_cd : 0;
         CHK(hipMemcpyAsync(b->d_frames, b->h_frames, sizeof(BFrame) * n, hipMemcpyHostToDevice, st));
         if (g_ent > 0) {
             hipLaunchKernelGGL(kb_enter1, dim3(g_ent, 1, n), dim3(256), 0, st, S, F);
@@ -462,31 +758,62 @@ run_batch(s3a_batch_t *b)
         }
         hipLaunchKernelGGL(kb_enter3_mark, dim3(g_ent * (256 / DBLOCK) + ((g_mark + DBLOCK - 1) / DBLOCK) * b->g_T, 1, n),
                            dim3(DBLOCK), 0, st, S, F);
-        /* one model for every decoder of the step (and a shape the stationary kernel holds in
-         * registers)?  then the CD senones of all of them are one pass over the model */
-        bool shared = n > 1 && n <= 64 && getenv("S3A_BATCH_NO_SHARED") == NULL;
-        for (int32_t z = 0; z < n && shared; z++) {
-            const s3a_scorer_t *sc = b->sc[b->order[z]], *sc0 = b->sc[b->order[0]];
-            shared = sc->g == sc0->g && sc->n_sen == sc0->n_sen && sc->n_ci_sen == sc0->n_ci_sen
-                && sc->cd2cisen_d != NULL && sc0->g->dev->D4 * 4 <= 64 && sc0->g->dev->CP <= 64;
-        }
+        /* the log-add table goes to LDS when it fits beside nothing else (58 KB for the usual base) */
+        const uint32_t tab_cap = b->g_tabcap * 2 <= 60 * 1024 ? b->g_tabcap : 0;
         dim3 gx_grid(1, 1, 1);
+        size_t gx_lds = 0;
+        const bool d4main = shared && b->sc[b->order[0]]->g->dev->D4 == D4MAIN;
         if (shared) {
+            static bool attr_set = false;
+            if (!attr_set) {        /* static + dynamic LDS exceed the 64 KB default */
+                (void)hipFuncSetAttribute((const void *)kb_gated_cd_shared<true, D4MAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                (void)hipFuncSetAttribute((const void *)kb_gated_cd_shared<false, D4MAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                (void)hipFuncSetAttribute((const void *)kb_gated_cd_shared<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                (void)hipFuncSetAttribute((const void *)kb_gated_cd_shared<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                attr_set = true;
+            }
+            gx_lds = (((size_t)b->sc[b->order[0]]->g->dev->tab_size + 7) & ~(size_t)7) * 2
+                + (size_t)(64 / b->sc[b->order[0]]->g->dev->CP) * (64 + 4) * sizeof(float);
             const s3a_scorer_t *sc0 = b->sc[b->order[0]];
             const int32_t per_wave = 64 / sc0->g->dev->CP;
-            gx_grid = dim3((sc0->n_sen - sc0->n_ci_sen + GX_THREADS / 64 - 1) / (GX_THREADS / 64), (n + per_wave - 1) / per_wave, 1);
+            const int32_t n_tiles = (sc0->n_sen - sc0->n_ci_sen + GX_SEN - 1) / GX_SEN, ny = (n + per_wave - 1) / per_wave;
+            /* two workgroups fit a CU (LDS): one round of them, each walking its share of the tiles */
+            const int32_t per_row = max(1, 2 * sc0->g->dev->n_cu / ny);
+            const int32_t walk = (n_tiles + per_row - 1) / per_row;
+            gx_grid = dim3((n_tiles + walk - 1) / walk, ny, 1);
+        }
+        dim3 gm_grid(1, 1, 1);
+        if (multi) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void *)kb_gated_cd_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                (void)hipFuncSetAttribute((const void *)kb_gated_cd_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                attr_set = true;
+            }
+            /* two workgroups fit a CU (LDS): the groups of GM_FB decoders spread over grid.y as far as that
+             * keeps the launch within one round of workgroups, the rest is walked */
+            const int32_t n_groups = (n + GM_FB - 1) / GM_FB;
+            gm_grid = dim3(b->g_cd, max(1, min(n_groups, 2 * d0->n_cu / max(1, b->g_cd))), 1);
         }
         if (b->exact) {
-            if (b->g_ci) hipLaunchKernelGGL((kb_gated<true, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
-            if (b->g_cd && shared)
-                hipLaunchKernelGGL((kb_gated_cd_shared<true>), gx_grid, dim3(GX_THREADS), 0, st, S, F, n);
-            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<true, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
+            if (b->g_ci) hipLaunchKernelGGL((kb_gated<true, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F, 0u);
+            if (b->g_cd && multi)
+                hipLaunchKernelGGL((kb_gated_cd_multi<true>), gm_grid, dim3(256), gm_lds, st, S, F, n);
+            else if (b->g_cd && shared && d4main)
+                hipLaunchKernelGGL((kb_gated_cd_shared<true, D4MAIN>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
+            else if (b->g_cd && shared)
+                hipLaunchKernelGGL((kb_gated_cd_shared<true, 0>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
+            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<true, false>), dim3(b->g_cd, 1, n), dim3(256), (size_t)tab_cap * 2, st, S, F, tab_cap);
         }
         else {
-            if (b->g_ci) hipLaunchKernelGGL((kb_gated<false, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
-            if (b->g_cd && shared)
-                hipLaunchKernelGGL((kb_gated_cd_shared<false>), gx_grid, dim3(GX_THREADS), 0, st, S, F, n);
-            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<false, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
+            if (b->g_ci) hipLaunchKernelGGL((kb_gated<false, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F, 0u);
+            if (b->g_cd && multi)
+                hipLaunchKernelGGL((kb_gated_cd_multi<false>), gm_grid, dim3(256), gm_lds, st, S, F, n);
+            else if (b->g_cd && shared && d4main)
+                hipLaunchKernelGGL((kb_gated_cd_shared<false, D4MAIN>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
+            else if (b->g_cd && shared)
+                hipLaunchKernelGGL((kb_gated_cd_shared<false, 0>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
+            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<false, false>), dim3(b->g_cd, 1, n), dim3(256), (size_t)tab_cap * 2, st, S, F, tab_cap);
         }
         hipLaunchKernelGGL(kb_hmm_eval, dim3((g_rows + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK),
                            (size_t)b->g_tmat * 12 * 4, st, S, F);

@@ -58,7 +58,7 @@ k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                int32_t *best_out, int32_t cf, const int32_t *__restrict__ psof_off,
                const int32_t *__restrict__ psof, int32_t *pstamp)
 {
-    d_dec_hmm_eval(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, cf, psof_off, psof, pstamp, blockIdx.x, blockIdx.y);
+    d_dec_hmm_eval(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, cf, psof_off, psof, pstamp, NULL, 0, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -117,7 +117,7 @@ k_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
            const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits)
 {
-    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, blockIdx.x, blockIdx.y);
+    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, NULL, 0, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)

@@ -66,15 +66,24 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
                int32_t *best_out, int32_t cf, const int32_t *__restrict__ psof_off,
                const int32_t *__restrict__ psof, int32_t *pstamp,
+               const int32_t *__restrict__ gpart, int32_t gpart_n,
         const int32_t BX, const int32_t BY)
 {
     extern __shared__ int32_t tp_s[];
     __shared__ int32_t red[2][DBLOCK / 64];
+    __shared__ int32_t s_gb[DBLOCK / 64];
     for (int32_t i = threadIdx.x; i < n_tmat * 12; i += DBLOCK)
         tp_s[i] = tp_g[i];
+    /* the batched scorer leaves the CD maximum as one value per workgroup (s3a_batch.hip) */
+    int32_t gb = INT_MIN;
+    for (int32_t i = threadIdx.x; i < gpart_n; i += DBLOCK) gb = max(gb, gpart[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gb = max(gb, __shfl_xor(gb, o, 64));
+    if ((threadIdx.x & 63) == 0) s_gb[threadIdx.x >> 6] = gb;
     __syncthreads();
     const int32_t t = BY, i = BX * DBLOCK + threadIdx.x;
-    const int32_t norm = max(misc[0], misc[5]);         /* the frame's normaliser */
+    int32_t norm = max(misc[0], misc[5]);               /* the frame's normaliser */
+    for (int w = 0; w < DBLOCK / 64; w++) norm = max(norm, s_gb[w]);
     int32_t best = INT_MIN, wbest = INT_MIN;
     if (i < nact[t]) {
         const int32_t v = act[node_base[t] + i], ss = ssid[v];
@@ -481,9 +490,11 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            const int32_t *__restrict__ selfemit, int32_t *cnt, int32_t *base, int32_t *nxt, int32_t *nnxt,
            int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
            const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits,
+           const int32_t *gpart, int32_t gpart_n,
         const int32_t BX, const int32_t BY)
 {
     __shared__ int32_t total, s_wth, s_last;
+    __shared__ int32_t s_gp[3];
     __shared__ int32_t s_thr[8];
     const int32_t t = BX, b = node_base[t], na = nact[t], nf = cf + 1;
     if (threadIdx.x == 0) {
@@ -540,6 +551,22 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     __syncthreads();
     if (!s_last) return;
 
+    /* the batched scorer's per-workgroup maxima / counters (s3a_batch.hip) */
+    if (threadIdx.x == 0) { s_gp[0] = INT_MIN; s_gp[1] = 0; s_gp[2] = 0; }
+    __syncthreads();
+    if (gpart_n > 0) {
+        volatile const int32_t *vg = gpart;
+        int32_t gb = INT_MIN, gs = 0, gg = 0;
+        for (int32_t q = threadIdx.x; q < gpart_n; q += SCAN_THREADS) {
+            gb = max(gb, vg[q]); gs += vg[gpart_n + q]; gg += vg[2 * gpart_n + q];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gb = max(gb, __shfl_xor(gb, o, 64)); gs += __shfl_xor(gs, o, 64); gg += __shfl_xor(gg, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && gb != INT_MIN) { atomicMax(&s_gp[0], gb); atomicAdd(&s_gp[1], gs); atomicAdd(&s_gp[2], gg); }
+    }
+    __syncthreads();
     const int32_t hdr = 6 * T + 16;
     volatile const int32_t *vbest = best, *vnexit = nexit, *vex = exits, *vmisc = misc, *vnnxt = nnxt;
     for (int32_t q = threadIdx.x; q < 2 * T; q += SCAN_THREADS) pack[q] = vbest[q];
@@ -552,7 +579,9 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     if (threadIdx.x < 8) {
         pack[3 * T + threadIdx.x] = s_thr[threadIdx.x];
         int32_t m = vmisc[threadIdx.x];
-        if (threadIdx.x == 6) m = max(vmisc[0], vmisc[5]);      /* srch->senscale */
+        if (threadIdx.x == 0) m = max(m, s_gp[0]);
+        if (threadIdx.x == 1 || threadIdx.x == 2) m += s_gp[threadIdx.x];
+        if (threadIdx.x == 6) m = max(max(vmisc[0], s_gp[0]), vmisc[5]);    /* srch->senscale */
         pack[5 * T + 8 + threadIdx.x] = m;
     }
     int32_t off = 0;

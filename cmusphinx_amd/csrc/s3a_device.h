@@ -96,6 +96,8 @@ gau_to_int(double dval, double f, double distfloor, int32_t mixw)
     return (int32_t)((uint32_t)(int32_t)(f * dval) + (uint32_t)mixw);
 }
 
+#define D4MAIN 10           /* ceil(39/4): the 1s_c_d_dd case gets the unrolled kernels */
+
 int32_t s3a_dev_grow(void **buf, size_t *cap, size_t need);
 
 #endif

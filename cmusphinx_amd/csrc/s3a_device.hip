@@ -47,7 +47,6 @@
 /* ------------------------------------------------------------------ */
 /* device objects                                                      */
 /* ------------------------------------------------------------------ */
-#define D4MAIN 10           /* ceil(39/4): the 1s_c_d_dd case gets the unrolled kernel */
 #define FB 8                /* frames per inner group */
 #define GPAD_ALIGN 1024     /* Gaussians padded to a whole number of the largest workgroup */
 
