@@ -117,7 +117,7 @@ kb_enter3_mark(const BSlot *__restrict__ slots, const BFrame *__restrict__ frame
                          f.feat, s.D4, s.CP, s.Gpad, lo, hi, CI ? 1 : 0, s.ncomp, s.cd2cisen, s.sen_act, s.scr,     \
                          0, CI ? (const int32_t *)NULL : s.misc + 5, CI ? 0 : f.sc_beam, f.sc_frame,              \
                          CI ? 0 : f.sc_is_skip, s.bstidx, s.bstscr, s.updatetime, s.misc, CI ? 5 : 0,             \
-                         CI ? (uint8_t *)NULL : s.sen_act, tab
+                         CI ? (uint8_t *)NULL : s.sen_act, tab, CI ? (int32_t *)NULL : s.gpart, s.gp_n
 /* tab_cap = entries of dynamic LDS the launch provides for the log-add table (0: none) */
 template <bool EXACT, bool CI>
 __global__ void __launch_bounds__(256)
@@ -511,7 +511,7 @@ kb_hmm_eval(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
     if ((int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * DBLOCK) >= s.maxn) return;   /* (grid sized by the host bound) */
     d_dec_hmm_eval(s.node_base, s.act[f.cur], s.nact[f.cur], s.N, s.n_tmat, s.ssid, s.tmatid, s.wid, s.comp,
                    s.tp, s.sseq, s.comsseq, s.cs_off, s.cs_list, s.cs_wt, s.scr, s.misc, s.sc, s.hist, s.outs,
-                   s.outh, s.bests, s.best, f.frm, s.psof_off, s.psof, s.pstamp, s.gpart, f.gpart_n, blockIdx.x, blockIdx.y);
+                   s.outh, s.bests, s.best, f.frm, s.psof_off, s.psof, s.pstamp, s.gpart, f.gpart_n ? s.gp_n : 0, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -561,7 +561,7 @@ kb_scan(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int3
     d_dec_scan(s.N, s.T, f.frm, f.bm, s.node_base, s.act[f.cur], s.nact[f.cur], s.wid, s.prob, s.outs, s.outh,
                s.selfemit, s.cnt, s.base, s.act[f.cur ^ 1], s.nact[f.cur ^ 1], s.pos, s.posf, s.best, s.exits,
                s.nexit, s.hbin, s.misc, s.done, pack_all + (size_t)blockIdx.z * pack_stride, max_exits,
-               s.gpart, f.gpart_n, blockIdx.x, 0);
+               s.gpart, f.gpart_n ? s.gp_n : 0, blockIdx.x, 0);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -594,7 +594,6 @@ struct s3a_batch_s {
     int32_t *d_pack, *h_pack, pack_stride, pack_max_exits, hdr_max;
     int32_t g_ent, g_ci, g_cd, g_maxn, g_N, g_T, g_mark, g_tmat, exact;
     uint32_t g_tabcap;                  /* entries of the largest log-add table (padded to 8) */
-    int32_t *gpart[BMAXSLOT];           /* per slot: kb_gated_cd_multi's per-workgroup results */
     unsigned long long gen;
     long steps, slot_frames;
     hipStream_t stream;
@@ -633,7 +632,7 @@ s3a_batch_free(s3a_batch_t *b)
     (void)hipFree(b->d_slots); (void)hipFree(b->d_frames); (void)hipHostFree(b->h_frames);
     if (b->d_pack) (void)hipFree(b->d_pack);
     if (b->h_pack) (void)hipHostFree(b->h_pack);
-    for (int32_t i = 0; i < b->n_slots; i++) (void)hipFree(b->gpart[i]);
+
     /* the attached decoders now own a dead stream handle: they must be freed by their owners
      * WITHOUT further use; their own streams were replaced at attach time */
     pthread_mutex_destroy(&b->mu);
@@ -687,9 +686,7 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         s.D4 = d->D4; s.CP = d->CP; s.Gpad = d->Gpad; s.n_sen = sc->n_sen; s.n_ci_sen = sc->n_ci_sen;
         s.ncomp = sc->ncomp_d; s.cd2cisen = sc->cd2cisen_d; s.sen_act = sc->act_d; s.scr = sc->scr_d;
         s.misc = sc->misc_d; s.bstidx = sc->bstidx_d; s.bstscr = sc->bstscr_d; s.updatetime = sc->updatetime_d;
-        s.gp_n = ((s.n_sen - s.n_ci_sen) * s.CP + 255) / 256;
-        if (hipMalloc((void **)&b->gpart[slot], (size_t)3 * max(1, s.gp_n) * 4) != hipSuccess) { rc = S3A_EHIP; break; }
-        s.gpart = b->gpart[slot];
+        s.gpart = sc->gpart_d; s.gp_n = sc->gp_n;
         if (hipMemcpy(b->d_slots + slot, &s, sizeof s, hipMemcpyHostToDevice) != hipSuccess) { rc = S3A_EHIP; break; }
         b->ls[slot] = ls; b->sc[slot] = sc; b->cs[slot] = cs;
         b->exact = sc->g->precision == S3A_GMM_EXACT;
@@ -750,7 +747,8 @@ run_batch(s3a_batch_t *b)
         const size_t gm_lds = (size_t)GM_MAXDEC * D4MAIN * sizeof(float4) + (((size_t)d0->tab_size + 7) & ~(size_t)7) * 2;
         const bool multi = shared && n <= GM_MAXDEC && d0->D4 == D4MAIN && d0->CP >= GM_FB && gm_lds <= 72 * 1024
             && getenv("S3A_BATCH_NO_MULTI") == NULL;
-        for (int32_t z = 0; z < n; z++) b->h_frames[z].gpart_n = multi ? b->g_cd : 0;
+        /* (kb_gated_cd_shared, the fallback for other shapes, still merges with atomics) */
+        for (int32_t z = 0; z < n; z++) b->h_frames[z].gpart_n = (multi || !shared) ? 1 : 0;
         CHK(hipMemcpyAsync(b->d_frames, b->h_frames, sizeof(BFrame) * n, hipMemcpyHostToDevice, st));
         if (g_ent > 0) {
             hipLaunchKernelGGL(kb_enter1, dim3(g_ent, 1, n), dim3(256), 0, st, S, F);
@@ -793,11 +791,12 @@ run_batch(s3a_batch_t *b)
             /* two workgroups fit a CU (LDS): the groups of GM_FB decoders spread over grid.y as far as that
              * keeps the launch within one round of workgroups, the rest is walked */
             const int32_t n_groups = (n + GM_FB - 1) / GM_FB;
-            gm_grid = dim3(b->g_cd, max(1, min(n_groups, 2 * d0->n_cu / max(1, b->g_cd))), 1);
+            const int32_t gp_n = b->sc[b->order[0]]->gp_n;
+            gm_grid = dim3(gp_n, max(1, min(n_groups, 2 * d0->n_cu / max(1, gp_n))), 1);
         }
         if (b->exact) {
             if (b->g_ci) hipLaunchKernelGGL((kb_gated<true, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F, 0u);
-            if (b->g_cd && multi)
+            if (multi && gm_grid.x > 0)
                 hipLaunchKernelGGL((kb_gated_cd_multi<true>), gm_grid, dim3(256), gm_lds, st, S, F, n);
             else if (b->g_cd && shared && d4main)
                 hipLaunchKernelGGL((kb_gated_cd_shared<true, D4MAIN>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
@@ -807,7 +806,7 @@ run_batch(s3a_batch_t *b)
         }
         else {
             if (b->g_ci) hipLaunchKernelGGL((kb_gated<false, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F, 0u);
-            if (b->g_cd && multi)
+            if (multi && gm_grid.x > 0)
                 hipLaunchKernelGGL((kb_gated_cd_multi<false>), gm_grid, dim3(256), gm_lds, st, S, F, n);
             else if (b->g_cd && shared && d4main)
                 hipLaunchKernelGGL((kb_gated_cd_shared<false, D4MAIN>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);

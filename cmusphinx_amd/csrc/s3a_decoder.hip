@@ -56,9 +56,10 @@ k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                const int32_t *__restrict__ raw, const int32_t *__restrict__ misc,
                int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
                int32_t *best_out, int32_t cf, const int32_t *__restrict__ psof_off,
-               const int32_t *__restrict__ psof, int32_t *pstamp)
+               const int32_t *__restrict__ psof, int32_t *pstamp,
+               const int32_t *__restrict__ gpart, int32_t gpart_n)
 {
-    d_dec_hmm_eval(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, cf, psof_off, psof, pstamp, NULL, 0, blockIdx.x, blockIdx.y);
+    d_dec_hmm_eval(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, cf, psof_off, psof, pstamp, gpart, gpart_n, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -115,9 +116,10 @@ k_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            const int32_t *__restrict__ outs, const int32_t *__restrict__ outh,
            const int32_t *__restrict__ selfemit, int32_t *cnt, int32_t *base, int32_t *nxt, int32_t *nnxt,
            int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
-           const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits)
+           const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits,
+           const int32_t *gpart, int32_t gpart_n)
 {
-    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, NULL, 0, blockIdx.x, blockIdx.y);
+    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, gpart, gpart_n, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -337,6 +339,9 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
         return S3A_EUNSUP;
     }
 
+    /* the fused CD phase left its maxima / counters per workgroup (s3a_scorer_enqueue_raw) */
+    const int32_t gpart_n = sc->gpart_valid ? sc->gp_n : 0;
+    sc->gpart_valid = 0;
     /* the active lists are at most hist_bound long (host bound): size the per-position grids by it */
     const int32_t rows = min(maxn, max(ls->hist_bound, 1));
     hipLaunchKernelGGL(k_dec_hmm_eval, dim3((rows + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK),
@@ -344,7 +349,7 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
                        ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
                        sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best, frm,
-                       ls->d_psof_off, ls->d_psof, ls->d_pstamp);
+                       ls->d_psof_off, ls->d_psof, ls->d_pstamp, sc->gpart_d, gpart_n);
     if (may_hist) {
         hipLaunchKernelGGL(k_dec_hist_count, dim3((rows + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK), 0, ls->stream,
                            ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], T, bm, ls->d_best, ls->d_bests,
@@ -368,7 +373,7 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_wid, ls->d_prob, ls->d_outs,
                        ls->d_outh, ls->d_selfemit, ls->d_cnt, ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt],
                        ls->d_pos, ls->d_posf, ls->d_best, ls->d_exit, ls->d_nexit, ls->d_hbin, sc->misc_d,
-                       ls->d_done, ls->d_pack, ls->pack_max_exits);
+                       ls->d_done, ls->d_pack, ls->pack_max_exits, sc->gpart_d, gpart_n);
     HIPCHK(hipGetLastError());
     /* the host only needs the frame record: copy it and mark the spot BEFORE the emission kernel, which
      * then overlaps the host's word-level work (the next frame's kernels follow it in stream order) */

@@ -35,7 +35,7 @@ d_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
               int32_t pbest_plus_beam, const int32_t *__restrict__ pbest_ptr, int32_t beam,
               int32_t frame, int32_t is_skip,
               int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc, int32_t best_slot,
-              uint8_t *clear_active, uint16_t *tab_lds,
+              uint8_t *clear_active, uint16_t *tab_lds, int32_t *gpart, int32_t gp_n,
               const int32_t BX)
 {
     typedef typename Acc<EXACT>::T acc_t;
@@ -174,6 +174,10 @@ d_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
         wbest = max(max(red[0][0], red[0][1]), max(red[0][2], red[0][3]));
         ns = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         ng = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        if (gpart) {        /* fused decoder: this workgroup's column, merged by the consumers -- no atomics */
+            gpart[BX] = wbest; gpart[gp_n + BX] = ns; gpart[2 * gp_n + BX] = ng;
+            return;
+        }
         if (wbest != INT_MIN) atomicMax(&misc[best_slot], wbest);
         if (!ci_phase && ns) atomicAdd(&misc[1], ns);
         if (!ci_phase && ng) atomicAdd(&misc[2], ng);

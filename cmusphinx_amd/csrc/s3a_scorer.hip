@@ -44,14 +44,14 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
               int32_t pbest_plus_beam, const int32_t *__restrict__ pbest_ptr, int32_t beam,
               int32_t frame, int32_t is_skip,
               int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc, int32_t best_slot,
-              uint8_t *clear_active, int32_t tab_in_lds)
+              uint8_t *clear_active, int32_t tab_in_lds, int32_t *gpart, int32_t gp_n)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t tab_dyn[];
     uint16_t *tab = tab_in_lds ? tab_dyn : (uint16_t *)NULL;
     if (D4 == D4MAIN)
-        d_gated_frame<EXACT, D4MAIN>(mean4, prec4, lrd, mixw_g, tab_g, tab_size, lm_zero, f, distfloor, x, D4, CP, Gpad, sen_lo, sen_hi, ci_phase, ncomp, cd2cisen, sen_active, senscr, pbest_plus_beam, pbest_ptr, beam, frame, is_skip, bstidx, bstscr, updatetime, misc, best_slot, clear_active, tab, blockIdx.x);
+        d_gated_frame<EXACT, D4MAIN>(mean4, prec4, lrd, mixw_g, tab_g, tab_size, lm_zero, f, distfloor, x, D4, CP, Gpad, sen_lo, sen_hi, ci_phase, ncomp, cd2cisen, sen_active, senscr, pbest_plus_beam, pbest_ptr, beam, frame, is_skip, bstidx, bstscr, updatetime, misc, best_slot, clear_active, tab, gpart, gp_n, blockIdx.x);
     else
-        d_gated_frame<EXACT, 0>(mean4, prec4, lrd, mixw_g, tab_g, tab_size, lm_zero, f, distfloor, x, D4, CP, Gpad, sen_lo, sen_hi, ci_phase, ncomp, cd2cisen, sen_active, senscr, pbest_plus_beam, pbest_ptr, beam, frame, is_skip, bstidx, bstscr, updatetime, misc, best_slot, clear_active, tab, blockIdx.x);
+        d_gated_frame<EXACT, 0>(mean4, prec4, lrd, mixw_g, tab_g, tab_size, lm_zero, f, distfloor, x, D4, CP, Gpad, sen_lo, sen_hi, ci_phase, ncomp, cd2cisen, sen_active, senscr, pbest_plus_beam, pbest_ptr, beam, frame, is_skip, bstidx, bstscr, updatetime, misc, best_slot, clear_active, tab, gpart, gp_n, blockIdx.x);
 }
 
 /* approx_cont_mgau.c:597-600 */
@@ -134,6 +134,7 @@ s3a_scorer_init(s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen, int
             || hipMalloc(&sc->scr_d, sizeof(int32_t) * n_sen) != hipSuccess
             || hipMalloc(&sc->ci_d, sizeof(int32_t) * (n_ci_sen > 0 ? n_ci_sen : 1)) != hipSuccess
             || hipMalloc(&sc->misc_d, sizeof(int32_t) * 8) != hipSuccess
+            || hipMalloc(&sc->gpart_d, sizeof(int32_t) * 3 * (sc->gp_n = ((n_sen - n_ci_sen) * d->CP + 255) / 256, sc->gp_n > 0 ? sc->gp_n : 1)) != hipSuccess
             || hipHostMalloc(&sc->misc_h, sizeof(int32_t) * 8) != hipSuccess
             || hipMemcpy(sc->cd2cisen_d, cd2cisen, sizeof(int16_t) * n_sen, hipMemcpyHostToDevice) != hipSuccess
             || hipMemcpy(sc->ncomp_d, nc, n_sen, hipMemcpyHostToDevice) != hipSuccess
@@ -180,7 +181,7 @@ s3a_scorer_free(s3a_scorer_t *sc)
     if (!sc) return;
     (void)hipFree(sc->cd2cisen_d); (void)hipFree(sc->ncomp_d); (void)hipFree(sc->x_d);
     (void)hipFree(sc->act_d); (void)hipFree(sc->scr_d); (void)hipFree(sc->ci_d);
-    (void)hipFree(sc->misc_d);
+    (void)hipFree(sc->misc_d); (void)hipFree(sc->gpart_d);
     if (sc->own_state) { (void)hipFree(sc->bstidx_d); (void)hipFree(sc->bstscr_d); (void)hipFree(sc->updatetime_d); }
     if (sc->misc_h) (void)hipHostFree(sc->misc_h);
     free(sc->cd2cisen_h); free(sc->ci_occ_h); free(sc->idx_h);
@@ -200,7 +201,7 @@ s3a_scorer_utt_begin(s3a_scorer_t *sc)
 static void
 launch_gated(s3a_scorer_t *sc, int32_t lo, int32_t hi, int32_t ci_phase, int32_t thresh,
              int32_t frame, int32_t is_skip, const int32_t *pbest_ptr = NULL, int32_t beam = 0,
-             int32_t best_slot = 0, uint8_t *clear_active = NULL)
+             int32_t best_slot = 0, uint8_t *clear_active = NULL, int32_t *gpart = NULL)
 {
     s3a_mgau_model_t *g = sc->g;
     struct s3a_mgau_dev_s *d = g->dev;
@@ -216,13 +217,13 @@ launch_gated(s3a_scorer_t *sc, int32_t lo, int32_t hi, int32_t ci_phase, int32_t
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
                            sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
-                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active, tab_in_lds);
+                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active, tab_in_lds, gpart, sc->gp_n);
     else
         hipLaunchKernelGGL(k_gated_frame<false>, dim3(grid), dim3(256), lds, d->stream, d->mean4,
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
                            sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
-                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active, tab_in_lds);
+                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active, tab_in_lds, gpart, sc->gp_n);
 }
 
 static const int32_t k_misc_init[8] = { INT_MIN, 0, 0, 0, 0, 0, 0, 0 };
@@ -531,7 +532,8 @@ s3a_scorer_enqueue_raw(s3a_scorer_t *sc, const float *feat, int32_t frame)
         beam = (int32_t)((float)beam * sc->tighten_factor);
     HIPCHK(hipMemcpyAsync(sc->x_d, feat, sizeof(float) * d->D, hipMemcpyHostToDevice, d->stream));
     launch_gated(sc, 0, sc->n_ci_sen, 1, 0, frame, 0, NULL, 0, 5);
-    launch_gated(sc, sc->n_ci_sen, sc->n_sen, 0, 0, frame, is_skip, sc->misc_d + 5, beam, 0, sc->act_d);
+    launch_gated(sc, sc->n_ci_sen, sc->n_sen, 0, 0, frame, is_skip, sc->misc_d + 5, beam, 0, sc->act_d, sc->gpart_d);
+    sc->gpart_valid = sc->gp_n > 0;
     HIPCHK(hipGetLastError());
     return S3A_OK;
 }

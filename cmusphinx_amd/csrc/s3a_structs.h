@@ -23,6 +23,8 @@ struct s3a_scorer_s {
     int32_t *scr_d;         /* [S] */
     int32_t *ci_d;          /* [n_ci_sen] */
     int32_t *misc_d;        /* [0]=best [1]=ns [2]=ng */
+    int32_t *gpart_d;       /* [3][gp_n]: per-workgroup best / #senones / #Gaussians of the fused CD phase */
+    int32_t gp_n, gpart_valid;
     int32_t *misc_h;        /* pinned mirror */
     /* mgau_t.bstidx/bstscr/updatetime: the model's own arrays, or private ones when several decoders
      * share one model (s3a_scorer_init_private) */
