@@ -143,6 +143,39 @@ def full_decode(n_utt=8, n_frames=600, legs=(("gpu_1_stream", 1, 0), ("gpu_8_bat
     return out
 
 
+def front_end(seconds=100):
+    """Extra leg: the MFCC front end (s3a_fe_process_utt, host buffers: H2D + kernel + D2H)
+    on synthetic 16 kHz audio; its CPU baseline -- the unmodified reference's fe_process_utt on one core
+    (oracle/_ref/ref_dump fe) -- is also the checker of the device output."""
+    import glob
+    from cmusphinx_amd import lib
+    rng = np.random.default_rng(3)
+    n = 16000 * seconds
+    x = (rng.standard_normal(n) * 3000 * (np.sin(np.arange(n) / 9000.0) ** 2)).astype(np.int16)
+    fe = lib.FrontEnd()
+    got = fe.process_utt(x)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fe.process_utt(x)
+    dt = (time.perf_counter() - t0) / reps
+    out = {"workload": f"{seconds} s of synthetic 16 kHz audio, sphinxbase default front end (512-point FFT, 40 mel "
+                       "filters, 13 cepstra)", "frames": int(len(got)), "frames_per_sec": round(len(got) / dt, 1),
+           "xRT": round(len(got) / dt / 100.0, 1), "note": "host buffers: H2D + kernel + D2H per call"}
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    if os.path.exists(ref):
+        with tempfile.TemporaryDirectory() as d:
+            raw = os.path.join(d, "x.raw")
+            x.tofile(raw)
+            o = subprocess.run([ref, "fe", raw, d], env=dict(os.environ, REF_FE_REPS="3"), capture_output=True,
+                               text=True).stdout.split()
+            exp = np.fromfile(glob.glob(os.path.join(d, "cep.f32.*.bin"))[0], "<f4").reshape(-1, got.shape[1])
+        assert exp.shape == got.shape and np.abs(got - exp).max() <= 1e-4, "front end outside its tolerance"
+        out["bit_identical_to_reference"] = round(float((got.view(np.uint32) == exp.view(np.uint32)).mean()), 6)
+        out["cpu_reference"] = {"frames_per_sec": round(float(o[1]) / float(o[3]), 1), "cores": 1, "kind": "reference"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,6 +320,7 @@ def main():
                                                procs=os.cpu_count() or 1)
         if world == 1 and not args.no_decode:
             res["full_decode"] = full_decode()
+            res["front_end"] = front_end()
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -108,6 +108,16 @@ _SIGS = {
                                    [C.c_void_p] * 6 + [C.c_int32]),
     "s3a_approx_cont_mgau_frame_eval_async": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_scorer_misc_dev": (C.c_void_p, [C.c_void_p]),
+    "s3a_fe_default_params": (None, [C.c_void_p]),
+    "s3a_fe_init": (C.c_void_p, [C.c_void_p]),
+    "s3a_fe_free": (None, [C.c_void_p]),
+    "s3a_fe_output_size": (C.c_int32, [C.c_void_p]),
+    "s3a_fe_frame_shift": (C.c_int32, [C.c_void_p]),
+    "s3a_fe_frame_size": (C.c_int32, [C.c_void_p]),
+    "s3a_fe_n_frames": (C.c_int32, [C.c_void_p, C.c_int64]),
+    "s3a_fe_process_utt": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_fe_process_utt_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_void_p]),
     "s3a_feat_1s_c_d_dd": (C.c_int32, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p]),
     "s3a_feat_1s_c_d_dd_dev": (C.c_int32, [C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_ps_ms_mgau_init": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_double, C.c_char_p, C.c_int32,
@@ -480,6 +490,69 @@ def feat_1s_c_d_dd(cep, cmn="current", varnorm=False, agc="none"):
     out = np.zeros((n, 3 * cs), np.float32)
     check(L.s3a_feat_1s_c_d_dd(_p(cep), n, cs, int(cmn == "current"), int(bool(varnorm)), int(agc == "max"), _p(out)))
     return out
+
+
+class FeParams(C.Structure):
+    """s3a_fe_params_t: the front-end options of sphinxbase's fe (fe.h:100-215)."""
+    _fields_ = [("samprate", C.c_float), ("frate", C.c_int32), ("wlen", C.c_float), ("alpha", C.c_float),
+                ("ncep", C.c_int32), ("nfft", C.c_int32), ("nfilt", C.c_int32), ("lowerf", C.c_float),
+                ("upperf", C.c_float), ("transform", C.c_int32), ("lifter", C.c_int32), ("remove_dc", C.c_int32),
+                ("round_filters", C.c_int32), ("unit_area", C.c_int32), ("doublebw", C.c_int32),
+                ("logspec", C.c_int32)]
+
+
+FE_TRANSFORMS = {"legacy": 0, "dct": 1, "htk": 2}
+
+
+class FrontEnd:
+    """The MFCC front end on the device (fe_init_auto_r / fe_process_utt / fe_end_utt); options by the
+    reference's names without the dash, e.g. FrontEnd(samprate=11025, nfilt=36, transform="dct")."""
+
+    def __init__(self, **opts):
+        self.L = load()
+        p = FeParams()
+        self.L.s3a_fe_default_params(C.byref(p))
+        for k, v in opts.items():
+            if k == "transform":
+                v = FE_TRANSFORMS[v] if isinstance(v, str) else v
+            if k == "smoothspec":
+                k, v = "logspec", (2 if v else p.logspec)
+            if not hasattr(p, k):
+                raise TypeError("unknown front-end option " + k)
+            setattr(p, k, v)
+        self.params = p
+        self.h = self.L.s3a_fe_init(C.byref(p))
+        if not self.h:
+            raise RuntimeError("s3a_fe_init: " + self.L.s3a_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_fe_free(self.h)
+            self.h = None
+
+    @property
+    def output_size(self):
+        return self.L.s3a_fe_output_size(self.h)
+
+    @property
+    def frame_shift(self):
+        return self.L.s3a_fe_frame_shift(self.h)
+
+    @property
+    def frame_size(self):
+        return self.L.s3a_fe_frame_size(self.h)
+
+    def n_frames(self, nsamps):
+        return self.L.s3a_fe_n_frames(self.h, nsamps)
+
+    def process_utt(self, spch):
+        """int16 samples -> cepstra [n_frames][output_size] (the final partial frame included)."""
+        spch = np.ascontiguousarray(spch, np.int16)
+        n = self.n_frames(len(spch))
+        out = np.zeros((max(n, 1), self.output_size), np.float32)
+        got = C.c_int32(0)
+        check(self.L.s3a_fe_process_utt(self.h, _p(spch), len(spch), _p(out), n, C.byref(got)))
+        return out[:got.value]
 
 
 class PsMsMgau:

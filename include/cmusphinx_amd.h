@@ -248,6 +248,46 @@ int32_t s3a_ps_ms_cont_mgau_frame_eval(s3a_ps_mgau_t *ps, int16_t *senscr, const
                                        int32_t compallsen);
 
 /* ------------------------------------------------------------------ */
+/* The MFCC front end: 16-bit samples -> cepstra (the step before feat_s2mfc2feat).
+ * Replaces fe_t and its whole-utterance use (sphinxbase/include/sphinxbase/fe.h:300-460):
+ *   s3a_fe_default_params   the defaults of waveform_to_cepstral_command_line_macro (fe.h:100-215)
+ *   s3a_fe_init             fe_init_auto_r (fe_interface.c:212-283) with the options as a struct
+ *   s3a_fe_output_size      fe_get_output_size (:302-306)
+ *   s3a_fe_n_frames         the frame count of fe_process_utt + fe_end_utt (:470-502)
+ *   s3a_fe_process_utt      fe_start_utt + fe_process_utt + fe_end_utt for one utterance: cep
+ *                           [n_frames][output_size] float32, the final partial frame included
+ *   s3a_fe_process_utt_dev  the same with samples and cepstra in device memory, enqueued on a stream
+ * Float64 signal path in the reference's own operation order (its real-FFT schedule included); the one
+ * source of differences from the CPU is log() (device library vs libm, both < 1 ulp): see s3a_fe.hip.
+ * Not supported (S3A_EUNSUP / not expressible): -dither, -warp_params, swapped input. */
+/* ------------------------------------------------------------------ */
+enum { S3A_FE_LEGACY = 0, S3A_FE_DCT = 1, S3A_FE_HTK = 2 };           /* -transform */
+enum { S3A_FE_CEPSTRA = 0, S3A_FE_LOGSPEC = 1, S3A_FE_SMOOTHSPEC = 2 }; /* -logspec / -smoothspec */
+typedef struct {
+    float samprate;         /* -samprate */
+    int32_t frate;          /* -frate */
+    float wlen;             /* -wlen */
+    float alpha;            /* -alpha */
+    int32_t ncep, nfft, nfilt;
+    float lowerf, upperf;
+    int32_t transform;      /* S3A_FE_LEGACY / _DCT / _HTK */
+    int32_t lifter, remove_dc, round_filters, unit_area, doublebw;
+    int32_t logspec;        /* S3A_FE_CEPSTRA / _LOGSPEC / _SMOOTHSPEC */
+} s3a_fe_params_t;
+typedef struct s3a_fe_s s3a_fe_t;
+void s3a_fe_default_params(s3a_fe_params_t *p);
+s3a_fe_t *s3a_fe_init(const s3a_fe_params_t *p);
+void s3a_fe_free(s3a_fe_t *fe);
+int32_t s3a_fe_output_size(const s3a_fe_t *fe);
+int32_t s3a_fe_frame_shift(const s3a_fe_t *fe);
+int32_t s3a_fe_frame_size(const s3a_fe_t *fe);
+int32_t s3a_fe_n_frames(const s3a_fe_t *fe, int64_t nsamps);
+int32_t s3a_fe_process_utt(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, float *cep, int32_t max_frames,
+                           int32_t *n_frames);
+int32_t s3a_fe_process_utt_dev(s3a_fe_t *fe, const int16_t *spch_dev, int64_t nsamps, float *cep_dev,
+                               int32_t max_frames, int32_t *n_frames, void *stream);
+
+/* ------------------------------------------------------------------ */
 /* Feature computation for the stream type "1s_c_d_dd" (the step before the path).
  * Replaces feat_compute_utt for that type: sphinxbase/src/libsphinxbase/feat/feat.c:1111-1123 over the
  * padded utterance of feat_s2mfc_read (:396-516), cmn() feat/cmn.c:141-208 (-cmn current, -varnorm),

@@ -19,6 +19,8 @@
  *   bench_mgau MEAN VAR MIXW LOGBASE FEAT.f32 T   (times approx_cont_mgau_frame_eval with every
  *           senone active; prints "frames T seconds S" -- the CPU baseline of bench.py)
  *   hmm     NEMIT TP.i32 NTMAT SSEQ.i16 NSSEQ SENSCR.i32 NSEN T SPEC.i32 NHMM ENTER.i32 OUTDIR
+ *   fe      RAWFILE(int16 LE) OUTDIR [fe options, e.g. -samprate 11025 -nfilt 36 ...]
+ *           (fe_init_auto_r + fe_process_utt + fe_end_utt: the MFCC front end; also times it)
  *   ms      MEAN VAR MIXW SENMGAU(.s3cont.|.semi.) TOPN LOGBASE FEAT.f32 T ACTIVE.u8|all OUTDIR
  *           (ms_mgau_init + ms_cont_mgau_frame_eval: the -senmgau .s3cont./.semi. scorer)
  */
@@ -44,6 +46,9 @@
 #include <sphinxbase/feat.h>
 #include <sphinxbase/cmn.h>
 #include <sphinxbase/agc.h>
+#include <sphinxbase/fe.h>
+#include <sphinxbase/cmd_ln.h>
+#include <time.h>
 
 static void
 dump(const char *outdir, const char *name, const char *dtype, const void *p,
@@ -497,6 +502,44 @@ cmd_ms(int argc, char **argv)
     return 0;
 }
 
+/* the MFCC front end as sphinx_fe / the live decoders drive it: whole utterance + the final partial frame */
+static int
+cmd_fe(int argc, char **argv)
+{
+    size_t nbytes, nsamps;
+    int16 *raw = (int16 *)slurp(argv[0], &nbytes);
+    cmd_ln_t *config;
+    fe_t *fe;
+    mfcc_t **cep = NULL, *last;
+    int32 nfr = 0, nlast = 0, D, t, rep, reps;
+    float *flat;
+    struct timespec t0, t1;
+    char **av = calloc(argc + 2, sizeof(char *));
+    av[0] = "ref_dump";
+    for (t = 2; t < argc; t++) av[t - 1] = argv[t];
+    av[argc - 1] = "-dither"; av[argc] = "no";      /* (an empty argument list only prints the help) */
+    config = cmd_ln_parse_r(NULL, fe_get_args(), argc + 1, av, TRUE);
+    if (!config || (fe = fe_init_auto_r(config)) == NULL) { fprintf(stderr, "fe_init failed\n"); return 2; }
+    nsamps = nbytes / 2;
+    D = fe_get_output_size(fe);
+    last = calloc(D, sizeof(mfcc_t));
+    reps = getenv("REF_FE_REPS") ? atoi(getenv("REF_FE_REPS")) : 1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (rep = 0; rep < reps; rep++) {
+        if (cep) ckd_free_2d((void **)cep);
+        fe_start_utt(fe);
+        if (fe_process_utt(fe, raw, nsamps, &cep, &nfr) < 0) { fprintf(stderr, "fe_process_utt failed\n"); return 2; }
+        fe_end_utt(fe, last, &nlast);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    printf("frames %d seconds %.6f\n", (nfr + nlast) * reps, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
+    flat = malloc(sizeof(float) * (size_t)(nfr + nlast + 1) * D);
+    for (t = 0; t < nfr; t++) memcpy(flat + (size_t)t * D, cep[t], sizeof(float) * D);
+    if (nlast) memcpy(flat + (size_t)nfr * D, last, sizeof(float) * D);
+    dump(argv[1], "cep", "f32", flat, 4, 2, (long)(nfr + nlast), (long)D);
+    return 0;
+}
+
 int
 main(int argc, char **argv)
 {
@@ -512,6 +555,7 @@ main(int argc, char **argv)
         char *av[5] = { argv[2], argv[6], argv[3], argv[4], argv[5] };
         return cmd_feat(5, av);
     }
+    if (!strcmp(argv[1], "fe") && argc >= 4) return cmd_fe(argc - 2, argv + 2);
     if (!strcmp(argv[1], "hmm") && argc == 14) return cmd_hmm(argc - 2, argv + 2);
     if (!strcmp(argv[1], "ms") && argc == 12) return cmd_ms(argc - 2, argv + 2);
     fprintf(stderr, "ref_dump: bad command/arity: %s (%d args)\n", argv[1], argc - 2);

@@ -256,6 +256,33 @@ void s3o_psms_frame_eval(s3o_psms_t *ms, int16_t *senscr, const uint8_t *senone_
 void s3o_feat_1s_c_d_dd(const float *cep, int32_t n_frames, int32_t cepsize, int32_t cmn_current,
                         int32_t varnorm, int32_t agc_max, float *feat);
 
+/* ---- the MFCC front end (s3o_fe.c; sphinxbase fe_interface.c / fe_sigproc.c) ---- */
+typedef struct {
+    float samprate;         /* -samprate */
+    int32_t frate;          /* -frate */
+    float wlen;             /* -wlen */
+    float alpha;            /* -alpha */
+    int32_t ncep, nfft, nfilt;
+    float lowerf, upperf;
+    int32_t transform;      /* 0 legacy, 1 dct, 2 htk */
+    int32_t lifter, remove_dc, round_filters, unit_area, doublebw;
+    int32_t logspec;        /* 0 cepstra, 1 -logspec, 2 -smoothspec */
+} s3o_fe_params_t;
+
+typedef struct {
+    s3o_fe_params_t p;
+    int32_t fft_order, frame_shift, frame_size, feature_dimension, n_coeffs;
+    double *hamming, *ccc, *sss;
+    int16_t *spec_start, *filt_start, *filt_width;
+    float *filt_coeffs, *mel_cosine, *lifter;
+    float sqrt_inv_n, sqrt_inv_2n;
+} s3o_fe_t;
+
+s3o_fe_t *s3o_fe_init(const s3o_fe_params_t *p);
+void s3o_fe_free(s3o_fe_t *fe);
+int32_t s3o_fe_n_frames(const s3o_fe_t *fe, int64_t nsamps);
+int32_t s3o_fe_process_utt(const s3o_fe_t *fe, const int16_t *spch, int64_t nsamps, float *cep);
+
 #ifdef __cplusplus
 }
 #endif

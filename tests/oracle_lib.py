@@ -614,3 +614,50 @@ class OraclePsMs:
         else:
             lst = delta_encode(mask)
             self.L.s3o_psms_frame_eval(self.h, _p2(senscr), _p2(lst) if len(lst) else None, len(lst), _p2(x), 0)
+
+
+class OracleFeParams(C.Structure):
+    """s3o_fe_params_t"""
+    _fields_ = [("samprate", C.c_float), ("frate", C.c_int32), ("wlen", C.c_float), ("alpha", C.c_float),
+                ("ncep", C.c_int32), ("nfft", C.c_int32), ("nfilt", C.c_int32), ("lowerf", C.c_float),
+                ("upperf", C.c_float), ("transform", C.c_int32), ("lifter", C.c_int32), ("remove_dc", C.c_int32),
+                ("round_filters", C.c_int32), ("unit_area", C.c_int32), ("doublebw", C.c_int32),
+                ("logspec", C.c_int32)]
+
+
+FE_DEFAULTS = dict(samprate=16000.0, frate=100, wlen=0.025625, alpha=0.97, ncep=13, nfft=512, nfilt=40,
+                   lowerf=133.33334, upperf=6855.4976, transform=0, lifter=0, remove_dc=0, round_filters=1,
+                   unit_area=1, doublebw=0, logspec=0)
+
+
+class OracleFe:
+    """The MFCC front end (fe_init_auto_r + fe_process_utt + fe_end_utt), oracle/s3o_fe.c."""
+
+    def __init__(self, **opts):
+        L = self.L = lib()
+        L.s3o_fe_init.restype = C.c_void_p
+        L.s3o_fe_init.argtypes = [C.c_void_p]
+        L.s3o_fe_free.argtypes = [C.c_void_p]
+        L.s3o_fe_n_frames.argtypes = [C.c_void_p, C.c_int64]
+        L.s3o_fe_process_utt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        self.p = OracleFeParams(**dict(FE_DEFAULTS, **opts))
+        self.h = L.s3o_fe_init(C.byref(self.p))
+        if not self.h:
+            raise ValueError("s3o_fe_init rejected the options")
+        self.out_dim = self.p.nfilt if self.p.logspec else self.p.ncep
+
+    def __del__(self):
+        try:
+            self.L.s3o_fe_free(self.h)
+        except Exception:
+            pass
+
+    def n_frames(self, nsamps):
+        return self.L.s3o_fe_n_frames(self.h, nsamps)
+
+    def process_utt(self, spch):
+        spch = np.ascontiguousarray(spch, np.int16)
+        n = self.n_frames(len(spch))
+        out = np.zeros((max(n, 1), self.out_dim), np.float32)
+        self.L.s3o_fe_process_utt(self.h, _p2(spch), len(spch), _p2(out))
+        return out[:n]
