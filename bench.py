@@ -315,6 +315,27 @@ def main():
                            "achieved_GBs": round(fs_gbs, 1), "peak_GBs": HBM_PEAK_GBS,
                            "frac": round(fs_gbs / HBM_PEAK_GBS, 4)},
         }
+        if world == 1 and not args.no_decode:
+            # the same frame-synchronous pass on configs[4]'s model shape (8000 senones x 32 Gaussians: 82 MB per
+            # pass): the launch + latency floor (~3 us) is a fifth of the pass instead of most of it
+            wm = synth.make_model(**synth.WSJ_STRESS)
+            wg = lib.MgauModel.init_arrays(wm["mean"], wm["var"], wm["mixw"], lm)
+            Tw = 200
+            wf = synth.make_features(wm, Tw, seed=99)
+            wfd = lib.DevBuf(wf.nbytes).upload(wf)
+            wsd = lib.DevBuf(Tw * wg.S * 4)
+            gotw = wg.score_frames(wf[[0, Tw - 1]], want_best=False)
+            expw = O.OracleMgau(wm["mean"], wm["var"], wm["mixw"], O.OracleLogMath(1.0003)).score_all(wf[[0, Tw - 1]])
+            assert np.array_equal(gotw, expw), "HIP scores differ from the oracle (WSJ shape)"
+            wg.bench(wfd, Tw, wsd, None, 1, 1)
+            w_us, w_kus, w_n = wg.bench(wfd, Tw, wsd, None, 1, 3)
+            w_bytes = wg.S * wg.C * (2 * wg.D + 2) * 4 + wg.D * 4 + wg.S * 4
+            res["frame_sync_wsj_shape"] = {
+                "workload": "configs[4] model shape: 8000 senones x 32 Gaussians x 39, all senones, 1 frame per launch",
+                "launches": w_n, "avg_launch_us": round(w_kus, 3), "frames_per_sec": round(Tw / (w_us * 1e-6), 1),
+                "algorithmic_bytes_per_launch": w_bytes, "achieved_GBs": round(w_bytes / (w_kus * 1e-6) / 1e9, 1),
+                "peak_GBs": HBM_PEAK_GBS, "frac": round(w_bytes / (w_kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            del wg, wfd, wsd
         if not args.no_cpu and world == 1:      # (the CPU baseline and the decode leg: N = 1 runs only)
             res["cpu_baseline"] = cpu_baseline(model, feats[0], args.cpu_frames,
                                                procs=os.cpu_count() or 1)
