@@ -117,17 +117,14 @@ kb_enter3_mark(const BSlot *__restrict__ slots, const BFrame *__restrict__ frame
                          f.feat, s.D4, s.CP, s.Gpad, lo, hi, CI ? 1 : 0, s.ncomp, s.cd2cisen, s.sen_act, s.scr,     \
                          0, CI ? (const int32_t *)NULL : s.misc + 5, CI ? 0 : f.sc_beam, f.sc_frame,              \
                          CI ? 0 : f.sc_is_skip, s.bstidx, s.bstscr, s.updatetime, s.misc, CI ? 5 : 0,             \
-                         CI ? (uint8_t *)NULL : s.sen_act, tab, CI ? (int32_t *)NULL : s.gpart, s.gp_n
-/* tab_cap = entries of dynamic LDS the launch provides for the log-add table (0: none) */
+                         CI ? (uint8_t *)NULL : s.sen_act, CI ? (int32_t *)NULL : s.gpart, s.gp_n
 template <bool EXACT, bool CI>
 __global__ void __launch_bounds__(256)
-kb_gated(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, uint32_t tab_cap)
+kb_gated(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
 {
-    extern __shared__ __attribute__((aligned(16))) uint16_t tab_dyn[];
     SLOT_FRAME;
     const int32_t lo = CI ? 0 : s.n_ci_sen, hi = CI ? s.n_ci_sen : s.n_sen;
     if ((int32_t)(blockIdx.x * 256) >= (hi - lo) * s.CP) return;
-    uint16_t *tab = ((s.tab_size + 7) & ~7u) <= tab_cap ? tab_dyn : (uint16_t *)NULL;
     if (s.D4 == D4MAIN)
         d_gated_frame<EXACT, D4MAIN>(KB_GATED_ARGS, blockIdx.x);
     else
@@ -350,10 +347,7 @@ kb_gated_cd_multi(const BSlot *__restrict__ slots, const BFrame *__restrict__ fr
     __shared__ GxDec dec[GM_MAXDEC];
     __shared__ int32_t red[4][GM_MAXDEC][3];    /* per wave, per decoder: best, #senones, #Gaussians */
     __shared__ int32_t tr_s[4][GM_FB * 65];     /* per wave: [decoder of the group][lane] */
-    /* dynamic: [features: GM_MAXDEC rows of D4MAIN float4][the log-add table] */
-    extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
-    float4 *xs4 = (float4 *)gm_smem;
-    uint16_t *tab_s = (uint16_t *)(gm_smem + (size_t)GM_MAXDEC * D4MAIN * sizeof(float4));
+    __shared__ float4 xs4[GM_MAXDEC * D4MAIN];  /* the decoders' features */
     const BSlot &s0 = slots[frames[0].slot];
     const int32_t CP = s0.CP, Gpad = s0.Gpad;
     const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -398,14 +392,9 @@ kb_gated_cd_multi(const BSlot *__restrict__ slots, const BFrame *__restrict__ fr
         d.thresh = (int32_t)((uint32_t)sp.misc[5] + (uint32_t)f.sc_beam); d.pad = sp.gp_n;
         dec[tid] = d;
     }
-    {
-        const int32_t n16 = (int32_t)((s0.tab_size * 2 + 15) >> 4);     /* padded to 8 entries by the host */
-        for (int32_t i = tid; i < n16; i += 256)
-            ((uint4 *)tab_s)[i] = ((const uint4 *)s0.tab16)[i];
-    }
     __syncthreads();
-    LogAdd la;
-    la.tab = tab_s; la.size = s0.tab_size; la.zero = s0.lm_zero;
+    LogAdd la;              /* (the table from global memory: see s3a_gated.h) */
+    la.tab = s0.tab16; la.size = s0.tab_size; la.zero = s0.lm_zero;
     int32_t *tr = tr_s[wave];
     const int32_t n_groups = (n + GM_FB - 1) / GM_FB;
     for (int32_t grp = blockIdx.y; grp < n_groups; grp += gridDim.y) {
@@ -593,7 +582,6 @@ struct s3a_batch_s {
     int32_t n_active, n_arrived, order[BMAXSLOT], rows[BMAXSLOT], zof[BMAXSLOT], last_order[BMAXSLOT], last_n;
     int32_t *d_pack, *h_pack, pack_stride, pack_max_exits, hdr_max;
     int32_t g_ent, g_ci, g_cd, g_maxn, g_N, g_T, g_mark, g_tmat, exact;
-    uint32_t g_tabcap;                  /* entries of the largest log-add table (padded to 8) */
     unsigned long long gen;
     long steps, slot_frames;
     hipStream_t stream;
@@ -697,7 +685,6 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         b->g_ent = max(b->g_ent, (ls->ent_cap + 255) / 256);
         b->g_mark = max(b->g_mark, (ls->ent_cap + DBLOCK - 1) / DBLOCK + ((maxn + DBLOCK - 1) / DBLOCK) * s.T);
         b->g_tmat = max(b->g_tmat, s.n_tmat);
-        b->g_tabcap = max(b->g_tabcap, (s.tab_size + 7) & ~7u);
         const int32_t hdr = 6 * s.T + 16;
         if (hdr > b->hdr_max || ls->pack_max_exits > b->pack_max_exits) {
             if (b->d_pack) { (void)hipFree(b->d_pack); (void)hipHostFree(b->h_pack); }
@@ -744,9 +731,11 @@ run_batch(s3a_batch_t *b)
                 && sc->cd2cisen_d != NULL && sc0->g->dev->D4 * 4 <= 64 && sc0->g->dev->CP <= 64;
         }
         const struct s3a_mgau_dev_s *d0 = b->sc[b->order[0]]->g->dev;
-        const size_t gm_lds = (size_t)GM_MAXDEC * D4MAIN * sizeof(float4) + (((size_t)d0->tab_size + 7) & ~(size_t)7) * 2;
-        const bool multi = shared && n <= GM_MAXDEC && d0->D4 == D4MAIN && d0->CP >= GM_FB && gm_lds <= 72 * 1024
+        /* (measured, hub4 shape: one launch per decoder -- kb_gated, grid z -- is as fast up to ~7 decoders:
+         * 10 / 11 / 16 us for 2 / 4 / 7 against 11 / 13 / 17; the shared pass wins from there: 19 us for 13.5) */
+        const bool multi = shared && n >= GM_FB && n <= GM_MAXDEC && d0->D4 == D4MAIN && d0->CP >= GM_FB
             && getenv("S3A_BATCH_NO_MULTI") == NULL;
+        if (!multi && n < GM_FB) shared = false;
         /* (kb_gated_cd_shared, the fallback for other shapes, still merges with atomics) */
         for (int32_t z = 0; z < n; z++) b->h_frames[z].gpart_n = (multi || !shared) ? 1 : 0;
         CHK(hipMemcpyAsync(b->d_frames, b->h_frames, sizeof(BFrame) * n, hipMemcpyHostToDevice, st));
@@ -756,8 +745,6 @@ run_batch(s3a_batch_t *b)
         }
         hipLaunchKernelGGL(kb_enter3_mark, dim3(g_ent * (256 / DBLOCK) + ((g_mark + DBLOCK - 1) / DBLOCK) * b->g_T, 1, n),
                            dim3(DBLOCK), 0, st, S, F);
-        /* the log-add table goes to LDS when it fits beside nothing else (58 KB for the usual base) */
-        const uint32_t tab_cap = b->g_tabcap * 2 <= 60 * 1024 ? b->g_tabcap : 0;
         dim3 gx_grid(1, 1, 1);
         size_t gx_lds = 0;
         const bool d4main = shared && b->sc[b->order[0]]->g->dev->D4 == D4MAIN;
@@ -782,37 +769,31 @@ run_batch(s3a_batch_t *b)
         }
         dim3 gm_grid(1, 1, 1);
         if (multi) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void *)kb_gated_cd_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                (void)hipFuncSetAttribute((const void *)kb_gated_cd_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-                attr_set = true;
-            }
-            /* two workgroups fit a CU (LDS): the groups of GM_FB decoders spread over grid.y as far as that
-             * keeps the launch within one round of workgroups, the rest is walked */
+            /* the groups of GM_FB decoders spread over grid.y as far as that keeps the launch within one round
+             * of workgroups (two per CU), the rest is walked */
             const int32_t n_groups = (n + GM_FB - 1) / GM_FB;
             const int32_t gp_n = b->sc[b->order[0]]->gp_n;
             gm_grid = dim3(gp_n, max(1, min(n_groups, 2 * d0->n_cu / max(1, gp_n))), 1);
         }
         if (b->exact) {
-            if (b->g_ci) hipLaunchKernelGGL((kb_gated<true, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F, 0u);
+            if (b->g_ci) hipLaunchKernelGGL((kb_gated<true, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
             if (multi && gm_grid.x > 0)
-                hipLaunchKernelGGL((kb_gated_cd_multi<true>), gm_grid, dim3(256), gm_lds, st, S, F, n);
+                hipLaunchKernelGGL((kb_gated_cd_multi<true>), gm_grid, dim3(256), 0, st, S, F, n);
             else if (b->g_cd && shared && d4main)
                 hipLaunchKernelGGL((kb_gated_cd_shared<true, D4MAIN>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
             else if (b->g_cd && shared)
                 hipLaunchKernelGGL((kb_gated_cd_shared<true, 0>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
-            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<true, false>), dim3(b->g_cd, 1, n), dim3(256), (size_t)tab_cap * 2, st, S, F, tab_cap);
+            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<true, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
         }
         else {
-            if (b->g_ci) hipLaunchKernelGGL((kb_gated<false, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F, 0u);
+            if (b->g_ci) hipLaunchKernelGGL((kb_gated<false, true>), dim3(b->g_ci, 1, n), dim3(256), 0, st, S, F);
             if (multi && gm_grid.x > 0)
-                hipLaunchKernelGGL((kb_gated_cd_multi<false>), gm_grid, dim3(256), gm_lds, st, S, F, n);
+                hipLaunchKernelGGL((kb_gated_cd_multi<false>), gm_grid, dim3(256), 0, st, S, F, n);
             else if (b->g_cd && shared && d4main)
                 hipLaunchKernelGGL((kb_gated_cd_shared<false, D4MAIN>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
             else if (b->g_cd && shared)
                 hipLaunchKernelGGL((kb_gated_cd_shared<false, 0>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
-            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<false, false>), dim3(b->g_cd, 1, n), dim3(256), (size_t)tab_cap * 2, st, S, F, tab_cap);
+            else if (b->g_cd) hipLaunchKernelGGL((kb_gated<false, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
         }
         hipLaunchKernelGGL(kb_hmm_eval, dim3((g_rows + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK),
                            (size_t)b->g_tmat * 12 * 4, st, S, F);

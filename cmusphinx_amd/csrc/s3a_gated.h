@@ -20,8 +20,10 @@
  * microseconds of work.  A Gaussian's value does not depend on whether it is wanted, so it is computed
  * unconditionally and the gate only SELECTS (same scores, same counters); nearly every active senone
  * is inside the CI beam anyway (41 of 41.5 k Gaussians per frame on the hub4-shaped task).
- * tab_lds != NULL: the workgroup copies the log-add table into LDS while those loads are in flight,
- * so the ordered log-add -- CP dependent look-ups -- does not go to L2.
+ * The log-add table stays in global memory (L2 / vL1D): staging its 58 KB into LDS per workgroup was
+ * measured at twice the kernel's time (13.8 vs 6.8 us for the CD phase of one decoder) -- it halves
+ * the waves a CU can hold and every workgroup waits for the copy -- while most steps of the ordered
+ * log-add skip the table anyway (|difference| beyond its end).
  */
 template <bool EXACT, int D4C>
 __device__ __forceinline__ void
@@ -35,7 +37,7 @@ d_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
               int32_t pbest_plus_beam, const int32_t *__restrict__ pbest_ptr, int32_t beam,
               int32_t frame, int32_t is_skip,
               int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc, int32_t best_slot,
-              uint8_t *clear_active, uint16_t *tab_lds, int32_t *gpart, int32_t gp_n,
+              uint8_t *clear_active, int32_t *gpart, int32_t gp_n,
               const int32_t BX)
 {
     typedef typename Acc<EXACT>::T acc_t;
@@ -45,7 +47,7 @@ d_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
     const int32_t sen = g / CP, c = g - sen * CP, sl = lane / CP;
     const bool valid = sen < sen_hi;
     LogAdd la;
-    la.tab = tab_lds ? tab_lds : tab_g; la.size = tab_size; la.zero = lm_zero;
+    la.tab = tab_g; la.size = tab_size; la.zero = lm_zero;
 
     /* ---- round trip 1: everything whose address is known now ---- */
     float4 M[NK], P[NK];
@@ -78,12 +80,6 @@ d_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
     /* device-resident path: the CI maximum was left in memory by the CI phase */
     if (pbest_ptr)
         pbest_plus_beam = (int32_t)((uint32_t)*pbest_ptr + (uint32_t)beam);
-    if (tab_lds) {
-        /* 16-byte copies; the host pads the table to a multiple of 8 entries */
-        const int32_t n16 = (int32_t)((tab_size * 2 + 15) >> 4);
-        for (int32_t i = threadIdx.x; i < n16; i += 256)
-            ((uint4 *)tab_lds)[i] = ((const uint4 *)tab_g)[i];
-    }
     /* ---- round trip 2: the CI senone's score ---- */
     /* 0 = untouched, 1 = full, 2 = single Gaussian, 3 = CI copy */
     int32_t mode = 0, ci_scr = 0;
@@ -125,7 +121,6 @@ d_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
         }
         gs = gau_to_int((double)a, f, distfloor, mixw_g[g]);
     }
-    if (tab_lds) __syncthreads();
     /* ordered chain over the senone's lanes; every lane of the senone runs it */
     int32_t score = S3A_LOGPROB_ZERO, bs = S3A_LOGPROB_ZERO, bidx = S3A_NO_BSTIDX;
     for (int32_t cc = 0; cc < CP; cc++) {

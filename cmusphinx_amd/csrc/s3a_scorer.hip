@@ -44,14 +44,12 @@ k_gated_frame(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4
               int32_t pbest_plus_beam, const int32_t *__restrict__ pbest_ptr, int32_t beam,
               int32_t frame, int32_t is_skip,
               int32_t *bstidx, int32_t *bstscr, int32_t *updatetime, int32_t *misc, int32_t best_slot,
-              uint8_t *clear_active, int32_t tab_in_lds, int32_t *gpart, int32_t gp_n)
+              uint8_t *clear_active, int32_t *gpart, int32_t gp_n)
 {
-    extern __shared__ __attribute__((aligned(16))) uint16_t tab_dyn[];
-    uint16_t *tab = tab_in_lds ? tab_dyn : (uint16_t *)NULL;
     if (D4 == D4MAIN)
-        d_gated_frame<EXACT, D4MAIN>(mean4, prec4, lrd, mixw_g, tab_g, tab_size, lm_zero, f, distfloor, x, D4, CP, Gpad, sen_lo, sen_hi, ci_phase, ncomp, cd2cisen, sen_active, senscr, pbest_plus_beam, pbest_ptr, beam, frame, is_skip, bstidx, bstscr, updatetime, misc, best_slot, clear_active, tab, gpart, gp_n, blockIdx.x);
+        d_gated_frame<EXACT, D4MAIN>(mean4, prec4, lrd, mixw_g, tab_g, tab_size, lm_zero, f, distfloor, x, D4, CP, Gpad, sen_lo, sen_hi, ci_phase, ncomp, cd2cisen, sen_active, senscr, pbest_plus_beam, pbest_ptr, beam, frame, is_skip, bstidx, bstscr, updatetime, misc, best_slot, clear_active, gpart, gp_n, blockIdx.x);
     else
-        d_gated_frame<EXACT, 0>(mean4, prec4, lrd, mixw_g, tab_g, tab_size, lm_zero, f, distfloor, x, D4, CP, Gpad, sen_lo, sen_hi, ci_phase, ncomp, cd2cisen, sen_active, senscr, pbest_plus_beam, pbest_ptr, beam, frame, is_skip, bstidx, bstscr, updatetime, misc, best_slot, clear_active, tab, gpart, gp_n, blockIdx.x);
+        d_gated_frame<EXACT, 0>(mean4, prec4, lrd, mixw_g, tab_g, tab_size, lm_zero, f, distfloor, x, D4, CP, Gpad, sen_lo, sen_hi, ci_phase, ncomp, cd2cisen, sen_active, senscr, pbest_plus_beam, pbest_ptr, beam, frame, is_skip, bstidx, bstscr, updatetime, misc, best_slot, clear_active, gpart, gp_n, blockIdx.x);
 }
 
 /* approx_cont_mgau.c:597-600 */
@@ -208,22 +206,18 @@ launch_gated(s3a_scorer_t *sc, int32_t lo, int32_t hi, int32_t ci_phase, int32_t
     int32_t n_gau = (hi - lo) * d->CP;
     int32_t grid = (n_gau + 255) / 256;
     if (grid <= 0) return;
-    /* the CD phase (many workgroups, CP dependent table look-ups each) keeps the log-add table in LDS */
-    const size_t tab_bytes = (((size_t)d->tab_size + 7) & ~(size_t)7) * 2;
-    const int32_t tab_in_lds = !ci_phase && tab_bytes <= 60 * 1024;
-    const size_t lds = tab_in_lds ? tab_bytes : 0;
     if (g->precision == S3A_GMM_EXACT)
-        hipLaunchKernelGGL(k_gated_frame<true>, dim3(grid), dim3(256), lds, d->stream, d->mean4,
+        hipLaunchKernelGGL(k_gated_frame<true>, dim3(grid), dim3(256), 0, d->stream, d->mean4,
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
                            sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
-                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active, tab_in_lds, gpart, sc->gp_n);
+                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active, gpart, sc->gp_n);
     else
-        hipLaunchKernelGGL(k_gated_frame<false>, dim3(grid), dim3(256), lds, d->stream, d->mean4,
+        hipLaunchKernelGGL(k_gated_frame<false>, dim3(grid), dim3(256), 0, d->stream, d->mean4,
                            d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero, g->f,
                            g->distfloor, sc->x_d, d->D4, d->CP, d->Gpad, lo, hi, ci_phase,
                            sc->ncomp_d, sc->cd2cisen_d, sc->act_d, sc->scr_d, thresh, pbest_ptr, beam,
-                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active, tab_in_lds, gpart, sc->gp_n);
+                           frame, is_skip, sc->bstidx_d, sc->bstscr_d, sc->updatetime_d, sc->misc_d, best_slot, clear_active, gpart, sc->gp_n);
 }
 
 static const int32_t k_misc_init[8] = { INT_MIN, 0, 0, 0, 0, 0, 0, 0 };

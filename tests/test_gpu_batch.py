@@ -126,17 +126,21 @@ def test_batched_steps_match_one_oracle_per_decoder(gpu_lib, share_model):
     assert frames == 2 * sum(c[3] for c in cfg) and steps < frames / 2      # really batched
 
 
-def test_cloned_decoders_share_model_and_lextrees(gpu_lib):
+@pytest.mark.parametrize("n_dec,n_comp", [(5, 4), (11, 8), (19, 8)])
+def test_cloned_decoders_share_model_and_lextrees(gpu_lib, n_dec, n_comp):
     """The production arrangement: ONE model and ONE set of lextrees on the device, N decoders with their
-    own state (s3a_scorer_init_private + s3a_lexsearch_clone), different utterances."""
-    batch = gpu_lib.Batch(6)
+    own state (s3a_scorer_init_private + s3a_lexsearch_clone), different utterances.  With 8 Gaussians per
+    senone and >= 8 decoders in a step the CD senones of all of them are one model-stationary pass
+    (kb_gated_cd_multi: groups of 8 decoders, the last one partly filled); as the shorter utterances end the
+    steps fall back to one launch per decoder."""
+    batch = gpu_lib.Batch(n_dec + 1)
     rng = np.random.default_rng(77)
     tr = synth_forest(rng, n_tree=4, n_node=700, n_sen=500)
     forest = dict(tr=tr, comwt=-rng.integers(0, 3000, tr["n_comstate"]).astype(np.int32))
-    m = synth.make_model(500, 30, 4, 39, 5, 3, seed=998)
+    m = synth.make_model(500, 30, n_comp, 39, 5, 3, seed=998)
     shared = (m, gpu_lib.MgauModel.init_arrays(m["mean"], m["var"], m["mixw"], gpu_lib.LogMath(1.0003)))
-    decs = [Decoder(gpu_lib, batch, 31 + i, 20000 if i % 2 else 200, 1e-80 if i < 3 else 1e-12, 20 + 3 * i,
-                    shared=shared, forest=forest) for i in range(5)]
+    decs = [Decoder(gpu_lib, batch, 31 + i, 20000 if i % 2 else 200, 1e-80 if i % 5 < 3 else 1e-12, 20 + (3 * i) % 17,
+                    shared=shared, forest=forest) for i in range(n_dec)]
     for d in decs:
         d.begin()
     while any(d.frm is not None for d in decs):
