@@ -493,7 +493,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            const int32_t *gpart, int32_t gpart_n,
         const int32_t BX, const int32_t BY)
 {
-    __shared__ int32_t total, s_wth, s_last;
+    __shared__ int32_t s_wth, s_last;
     __shared__ int32_t s_gp[3];
     __shared__ int32_t s_thr[8];
     const int32_t t = BX, b = node_base[t], na = nact[t], nf = cf + 1;
@@ -506,40 +506,69 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
         s_thr[7] = 0;
     }
     __syncthreads();
-    /* (a) turn bases + the self-emitted nodes */
-    block_exclusive_scan_to(cnt + b, base + b, na, &total);
-    __syncthreads();
-    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
-        if (selfemit[b + i]) {
-            const int32_t u = act[b + i], k = base[b + i];
-            nxt[b + k] = u; pos[u] = k; posf[u] = nf;
-        }
-    }
-    if (threadIdx.x == 0) nnxt[t] = total;
-    __syncthreads();
-    /* (b) word exits, in active-list order */
+    /* ONE sweep over the active list does both ordered compactions: (a) the turn bases (exclusive sum of the
+     * turn counts) with the self-emitted nodes written at theirs, (b) the word exits in list order (exclusive
+     * sum of the exit flags).  The two sums travel as the halves of one 64-bit value through one scan. */
     const int32_t wth = s_wth;
-    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
-        const int32_t u = act[b + i];
-        cnt[b + i] = (wid[u] >= 0 && outs[u] >= wth) ? 1 : 0;
-    }
+    __shared__ unsigned long long s_wsum[SCAN_THREADS / 64], s_carry;
+    __shared__ int32_t s_exit_open;
+    if (threadIdx.x == 0) { s_carry = 0ull; s_exit_open = 0; }
     __syncthreads();
-    block_exclusive_scan(cnt + b, na, &total);
-    __syncthreads();
-    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
-        const int32_t u = act[b + i];
-        if (wid[u] >= 0 && outs[u] >= wth) {
-            const int32_t k = b + cnt[b + i];
-            exits[k] = wid[u];
-            exits[N + k] = add32(outs[u], -prob[u]);
-            exits[2 * N + k] = outh[u];
-            if (outh[u] == -1) atomicExch(&nexit[T + t], 1);
+    {
+        const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        for (int32_t c0 = 0; c0 < na; c0 += SCAN_THREADS) {
+            const int32_t i = c0 + tid;
+            int32_t u = 0, c = 0, se = 0, w = -1, os = 0;
+            if (i < na) {
+                u = act[b + i]; c = cnt[b + i]; se = selfemit[b + i];
+                w = wid[u]; os = outs[u];
+                cnt[b + i] = 0;                                 /* the accumulator of the next frame */
+            }
+            const bool ex = i < na && w >= 0 && os >= wth;
+            const unsigned long long x = (unsigned long long)(uint32_t)c | ((unsigned long long)(ex ? 1u : 0u) << 32);
+            unsigned long long incl = x;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long y = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += y;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            if (wave == 0) {
+                const unsigned long long ws = (lane < SCAN_THREADS / 64) ? s_wsum[lane] : 0ull;
+                unsigned long long wi = ws;
+#pragma unroll
+                for (int o = 1; o < SCAN_THREADS / 64; o <<= 1) {
+                    const unsigned long long y = __shfl_up(wi, o, 64);
+                    if (lane >= o) wi += y;
+                }
+                if (lane < SCAN_THREADS / 64) s_wsum[lane] = wi - ws;   /* exclusive wave offsets */
+            }
+            __syncthreads();
+            const unsigned long long excl = s_carry + s_wsum[wave] + incl - x;
+            if (i < na) {
+                const int32_t k = (int32_t)(uint32_t)excl;
+                base[b + i] = k;
+                if (se) { nxt[b + k] = u; pos[u] = k; posf[u] = nf; }
+                if (ex) {
+                    const int32_t e = b + (int32_t)(excl >> 32);
+                    const int32_t oh = outh[u];
+                    exits[e] = w;
+                    exits[N + e] = add32(os, -prob[u]);
+                    exits[2 * N + e] = oh;
+                    if (oh == -1) s_exit_open = 1;
+                }
+            }
+            __syncthreads();
+            if (tid == SCAN_THREADS - 1) s_carry = excl + x;
+            __syncthreads();
         }
     }
-    __syncthreads();
-    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS)
-        cnt[b + i] = 0;
-    if (threadIdx.x == 0) nexit[t] = total;
+    if (threadIdx.x == 0) {
+        nnxt[t] = (int32_t)(uint32_t)s_carry;
+        nexit[t] = (int32_t)(s_carry >> 32);
+        if (s_exit_open) nexit[T + t] = 1;
+    }
     /* publish this tree's results, find out whether we are last */
     __syncthreads();
     if (threadIdx.x == 0) {
