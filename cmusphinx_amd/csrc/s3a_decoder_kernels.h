@@ -497,6 +497,20 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     __shared__ int32_t s_gp[3];
     __shared__ int32_t s_thr[8];
     const int32_t t = BX, b = node_base[t], na = nact[t], nf = cf + 1;
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    /* the loads of chunk n + 1 (list entry, then its word id / exit score: two dependent round trips) are
+     * issued before the scan of chunk n; the first chunk's before the thresholds are worked out */
+    int32_t u2 = 0, c2 = 0, se2 = 0, w2 = -1, os2 = 0;
+#define SCAN_FETCH(i_)                                                                              \
+    do {                                                                                            \
+        u2 = 0; c2 = 0; se2 = 0; w2 = -1; os2 = 0;                                                  \
+        if ((i_) < na) {                                                                            \
+            u2 = act[b + (i_)]; c2 = cnt[b + (i_)]; se2 = selfemit[b + (i_)];                       \
+            w2 = wid[u2]; os2 = outs[u2];                                                           \
+            cnt[b + (i_)] = 0;                                  /* the accumulator of the next frame */ \
+        }                                                                                           \
+    } while (0)
+    SCAN_FETCH(tid);
     if (threadIdx.x == 0) {
         int32_t bh, bw, n, th, pth, wth;
         const bool hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
@@ -510,20 +524,16 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
      * turn counts) with the self-emitted nodes written at theirs, (b) the word exits in list order (exclusive
      * sum of the exit flags).  The two sums travel as the halves of one 64-bit value through one scan. */
     const int32_t wth = s_wth;
-    __shared__ unsigned long long s_wsum[SCAN_THREADS / 64], s_carry;
+    __shared__ unsigned long long s_wsum[SCAN_THREADS / 64], s_chunk;
     __shared__ int32_t s_exit_open;
-    if (threadIdx.x == 0) { s_carry = 0ull; s_exit_open = 0; }
+    unsigned long long carry = 0ull;            /* every thread keeps the running totals itself */
+    if (threadIdx.x == 0) s_exit_open = 0;
     __syncthreads();
     {
-        const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         for (int32_t c0 = 0; c0 < na; c0 += SCAN_THREADS) {
             const int32_t i = c0 + tid;
-            int32_t u = 0, c = 0, se = 0, w = -1, os = 0;
-            if (i < na) {
-                u = act[b + i]; c = cnt[b + i]; se = selfemit[b + i];
-                w = wid[u]; os = outs[u];
-                cnt[b + i] = 0;                                 /* the accumulator of the next frame */
-            }
+            const int32_t u = u2, c = c2, se = se2, w = w2, os = os2;
+            SCAN_FETCH(i + SCAN_THREADS);
             const bool ex = i < na && w >= 0 && os >= wth;
             const unsigned long long x = (unsigned long long)(uint32_t)c | ((unsigned long long)(ex ? 1u : 0u) << 32);
             unsigned long long incl = x;
@@ -543,9 +553,13 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
                     if (lane >= o) wi += y;
                 }
                 if (lane < SCAN_THREADS / 64) s_wsum[lane] = wi - ws;   /* exclusive wave offsets */
+                if (lane == SCAN_THREADS / 64 - 1) s_chunk = wi;        /* the chunk's totals */
             }
             __syncthreads();
-            const unsigned long long excl = s_carry + s_wsum[wave] + incl - x;
+            /* (a wave only re-reads its own s_wsum entry, and s_chunk is rewritten after the next barrier:
+             * two barriers per chunk are enough) */
+            const unsigned long long excl = carry + s_wsum[wave] + incl - x;
+            carry += s_chunk;
             if (i < na) {
                 const int32_t k = (int32_t)(uint32_t)excl;
                 base[b + i] = k;
@@ -559,14 +573,13 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
                     if (oh == -1) s_exit_open = 1;
                 }
             }
-            __syncthreads();
-            if (tid == SCAN_THREADS - 1) s_carry = excl + x;
-            __syncthreads();
         }
+#undef SCAN_FETCH
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        nnxt[t] = (int32_t)(uint32_t)s_carry;
-        nexit[t] = (int32_t)(s_carry >> 32);
+        nnxt[t] = (int32_t)(uint32_t)carry;
+        nexit[t] = (int32_t)(carry >> 32);
         if (s_exit_open) nexit[T + t] = 1;
     }
     /* publish this tree's results, find out whether we are last */
