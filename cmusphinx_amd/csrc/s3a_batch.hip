@@ -493,12 +493,13 @@ kb_gated_cd_multi(const BSlot *__restrict__ slots, const BFrame *__restrict__ fr
     }
 }
 
-__global__ void __launch_bounds__(DBLOCK)
+template <int EB>
+__global__ void __launch_bounds__(EB)
 kb_hmm_eval(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
 {
     SLOT_FRAME;
-    if ((int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * DBLOCK) >= s.maxn) return;   /* (grid sized by the host bound) */
-    d_dec_hmm_eval(s.node_base, s.act[f.cur], s.nact[f.cur], s.N, s.n_tmat, s.ssid, s.tmatid, s.wid, s.comp,
+    if ((int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * EB) >= s.maxn) return;   /* (grid sized by the host bound) */
+    d_dec_hmm_eval<EB>(s.node_base, s.act[f.cur], s.nact[f.cur], s.N, s.n_tmat, s.ssid, s.tmatid, s.wid, s.comp,
                    s.tp, s.sseq, s.comsseq, s.cs_off, s.cs_list, s.cs_wt, s.scr, s.misc, s.sc, s.hist, s.outs,
                    s.outh, s.bests, s.best, f.frm, s.psof_off, s.psof, s.pstamp, s.gpart, f.gpart_n ? s.gp_n : 0, blockIdx.x, blockIdx.y);
 }
@@ -521,11 +522,11 @@ kb_hist_sort(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
                     NBIN, blockIdx.x, 0);
 }
 
-__global__ void __launch_bounds__(DBLOCK)
+__global__ void __launch_bounds__(RSBLOCK)
 kb_resolve(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
 {
     SLOT_FRAME;
-    if ((int32_t)(blockIdx.x * DBLOCK) >= s.N) return;
+    if ((int32_t)(blockIdx.x * RSBLOCK) >= s.N) return;
     d_dec_resolve(s.N, s.T, f.frm, f.bm, s.best, s.nact[f.cur], s.node_base, s.tree_of, s.prob, s.par_off, s.par,
                   s.pos, s.posf, s.sc, s.hist, s.outs, s.outh, s.bests, s.frame, s.turn, s.selfemit, s.cnt, s.key,
                   s.first, s.hbin, s.ps, s.pstamp, s.rootnodes, s.n_rootnodes, s.propf, blockIdx.x, 0);
@@ -795,14 +796,18 @@ run_batch(s3a_batch_t *b)
                 hipLaunchKernelGGL((kb_gated_cd_shared<false, 0>), gx_grid, dim3(GX_THREADS), gx_lds, st, S, F, n);
             else if (b->g_cd) hipLaunchKernelGGL((kb_gated<false, false>), dim3(b->g_cd, 1, n), dim3(256), 0, st, S, F);
         }
-        hipLaunchKernelGGL(kb_hmm_eval, dim3((g_rows + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK),
-                           (size_t)b->g_tmat * 12 * 4, st, S, F);
+        if (g_rows >= EVBLOCK_LONG_LIST)
+            hipLaunchKernelGGL(kb_hmm_eval<256>, dim3((g_rows + 255) / 256, b->g_T, n), dim3(256),
+                               (size_t)b->g_tmat * 12 * 4, st, S, F);
+        else
+            hipLaunchKernelGGL(kb_hmm_eval<64>, dim3((g_rows + 63) / 64, b->g_T, n), dim3(64),
+                               (size_t)b->g_tmat * 12 * 4, st, S, F);
         if (any_hist) {
             hipLaunchKernelGGL(kb_hist_count, dim3((g_rows + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
             hipLaunchKernelGGL(kb_hist_sort, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
         }
         if (any_weak) hipLaunchKernelGGL(kb_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
-        hipLaunchKernelGGL(kb_resolve, dim3((b->g_N + DBLOCK - 1) / DBLOCK, 1, n), dim3(DBLOCK), 0, st, S, F);
+        hipLaunchKernelGGL(kb_resolve, dim3((b->g_N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, S, F);
         hipLaunchKernelGGL(kb_scan, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F, b->d_pack, b->pack_stride,
                            b->pack_max_exits);
         CHK(hipGetLastError());

@@ -45,7 +45,8 @@
 #include "s3a_decoder_kernels.h"
 
 /* thin kernels over the shared bodies (s3a_decoder_kernels.h) */
-__global__ void __launch_bounds__(DBLOCK)
+template <int EB>
+__global__ void __launch_bounds__(EB)
 k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
                const int32_t *__restrict__ nact, int32_t N, int32_t n_tmat,
                const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid,
@@ -59,7 +60,7 @@ k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                const int32_t *__restrict__ psof, int32_t *pstamp,
                const int32_t *__restrict__ gpart, int32_t gpart_n)
 {
-    d_dec_hmm_eval(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, cf, psof_off, psof, pstamp, gpart, gpart_n, blockIdx.x, blockIdx.y);
+    d_dec_hmm_eval<EB>(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, cf, psof_off, psof, pstamp, gpart, gpart_n, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -80,7 +81,7 @@ k_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32
     d_dec_hist_sort(node_base, act, nact, T, bm, binof, tmp, hbin, pos, force_tree, nbin, blockIdx.x, blockIdx.y);
 }
 
-__global__ void __launch_bounds__(DBLOCK)
+__global__ void __launch_bounds__(RSBLOCK)
 k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
               const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
               const int32_t *__restrict__ tree_of, const int32_t *__restrict__ prob,
@@ -344,7 +345,15 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
     sc->gpart_valid = 0;
     /* the active lists are at most hist_bound long (host bound): size the per-position grids by it */
     const int32_t rows = min(maxn, max(ls->hist_bound, 1));
-    hipLaunchKernelGGL(k_dec_hmm_eval, dim3((rows + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK),
+    if (rows >= EVBLOCK_LONG_LIST)
+        hipLaunchKernelGGL(k_dec_hmm_eval<256>, dim3((rows + 255) / 256, T), dim3(256),
+                       (size_t)ls->n_tmat * 12 * 4, ls->stream, ls->d_node_base, ls->d_act[cur],
+                       ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
+                       ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
+                       sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best, frm,
+                       ls->d_psof_off, ls->d_psof, ls->d_pstamp, sc->gpart_d, gpart_n);
+    else
+        hipLaunchKernelGGL(k_dec_hmm_eval<64>, dim3((rows + 63) / 64, T), dim3(64),
                        (size_t)ls->n_tmat * 12 * 4, ls->stream, ls->d_node_base, ls->d_act[cur],
                        ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
                        ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
@@ -363,7 +372,7 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                            ls->d_nact[cur], ls->d_node_base, ls->d_act[cur], ls->d_prob, ls->d_par_off, ls->d_par,
                            ls->d_pos, ls->d_posf, ls->d_sc, ls->d_outs, ls->d_bests, ls->d_wid, ls->d_hbin,
                            ls->d_candf, ls->d_exit + 2 * (size_t)ls->N);
-    hipLaunchKernelGGL(k_dec_resolve, dim3((ls->N + DBLOCK - 1) / DBLOCK), dim3(DBLOCK), 0, ls->stream,
+    hipLaunchKernelGGL(k_dec_resolve, dim3((ls->N + RSBLOCK - 1) / RSBLOCK), dim3(RSBLOCK), 0, ls->stream,
                        ls->N, T, frm, bm, ls->d_best, ls->d_nact[cur], ls->d_node_base, ls->d_tree_of,
                        ls->d_prob, ls->d_par_off, ls->d_par, ls->d_pos, ls->d_posf, ls->d_sc, ls->d_hist,
                        ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame, ls->d_turn, ls->d_selfemit,

@@ -17,6 +17,11 @@
 
 #define WORST S3A_WORST
 #define DBLOCK 256
+#define RSBLOCK 64          /* k_dec_resolve: the nodes something happens to are neighbours; small workgroups spread them over more CUs */
+/* k_dec_hmm_eval's workgroup size EB (template): 64 while the lists are short -- a few thousand HMMs are a dozen
+ * workgroups of 256, and a CU's memory pipeline serialises their ~50 scattered accesses per HMM; a wave per
+ * workgroup puts them on four times as many CUs (20.6 -> 18.5 us) -- 256 for long lists (56 k HMMs: 34 vs 41 us) */
+#define EVBLOCK_LONG_LIST 4096
 
 struct FrameBeams {
     int32_t hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf;
@@ -54,6 +59,7 @@ frame_thresholds(const int32_t *best, const int32_t *nact, int32_t T, const Fram
 }
 
 /* ------------------------------------------------------------------ */
+template <int EB>
 __device__ __forceinline__ void
 d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
                const int32_t *__restrict__ nact, int32_t N, int32_t n_tmat,
@@ -70,20 +76,20 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         const int32_t BX, const int32_t BY)
 {
     extern __shared__ int32_t tp_s[];
-    __shared__ int32_t red[2][DBLOCK / 64];
-    __shared__ int32_t s_gb[DBLOCK / 64];
-    for (int32_t i = threadIdx.x; i < n_tmat * 12; i += DBLOCK)
+    __shared__ int32_t red[2][EB / 64];
+    __shared__ int32_t s_gb[EB / 64];
+    for (int32_t i = threadIdx.x; i < n_tmat * 12; i += EB)
         tp_s[i] = tp_g[i];
     /* the batched scorer leaves the CD maximum as one value per workgroup (s3a_batch.hip) */
     int32_t gb = INT_MIN;
-    for (int32_t i = threadIdx.x; i < gpart_n; i += DBLOCK) gb = max(gb, gpart[i]);
+    for (int32_t i = threadIdx.x; i < gpart_n; i += EB) gb = max(gb, gpart[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) gb = max(gb, __shfl_xor(gb, o, 64));
     if ((threadIdx.x & 63) == 0) s_gb[threadIdx.x >> 6] = gb;
     __syncthreads();
-    const int32_t t = BY, i = BX * DBLOCK + threadIdx.x;
+    const int32_t t = BY, i = BX * EB + threadIdx.x;
     int32_t norm = max(misc[0], misc[5]);               /* the frame's normaliser */
-    for (int w = 0; w < DBLOCK / 64; w++) norm = max(norm, s_gb[w]);
+    for (int w = 0; w < EB / 64; w++) norm = max(norm, s_gb[w]);
     int32_t best = INT_MIN, wbest = INT_MIN;
     if (i < nact[t]) {
         const int32_t v = act[node_base[t] + i], ss = ssid[v];
@@ -144,7 +150,7 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = best; red[1][threadIdx.x >> 6] = wbest; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 0; w < DBLOCK / 64; w++) { best = max(best, red[0][w]); wbest = max(wbest, red[1][w]); }
+        for (int w = 0; w < EB / 64; w++) { best = max(best, red[0][w]); wbest = max(wbest, red[1][w]); }
         if (best != INT_MIN) atomicMax(&best_out[2 * t], best);
         if (wbest != INT_MIN) atomicMax(&best_out[2 * t + 1], wbest);
     }
@@ -381,9 +387,9 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
     if (BX == 0) {                              /* the bins were consumed by k_dec_hist_sort */
         int32_t bh, bw, n, th0, pth0, wth0;
         if (frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th0, pth0, wth0))
-            for (int32_t i = threadIdx.x; i < NBIN; i += DBLOCK) hbin[i] = 0;
+            for (int32_t i = threadIdx.x; i < NBIN; i += RSBLOCK) hbin[i] = 0;
     }
-    const int32_t v = BX * DBLOCK + threadIdx.x;
+    const int32_t v = BX * RSBLOCK + threadIdx.x;
     if (v >= N) return;
     if (v < n_rootnodes) {                              /* lextree_enter only ever touches root nodes */
         const int32_t r = rootnodes[v];
