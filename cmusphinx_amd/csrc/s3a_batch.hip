@@ -45,7 +45,7 @@ struct BSlot {              /* one decoder: static model + its state, all device
     const uint8_t *comp;
     const int16_t *sseq, *comsseq;
     int32_t *sc, *hist, *outs, *outh, *bests, *frame, *pos, *posf, *act[2], *nact[2], *turn, *selfemit,
-        *cnt, *base, *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0, *pstamp, *propf;
+        *cnt, *base, *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0, *pstamp, *propf, *poswid, *posout;
     const int32_t *rootnodes, *ps, *psof_off, *psof;
     int32_t n_rootnodes;
     unsigned long long *key;
@@ -501,7 +501,7 @@ kb_hmm_eval(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
     if ((int32_t)blockIdx.y >= s.T || (int32_t)(blockIdx.x * EB) >= s.maxn) return;   /* (grid sized by the host bound) */
     d_dec_hmm_eval<EB>(s.node_base, s.act[f.cur], s.nact[f.cur], s.N, s.n_tmat, s.ssid, s.tmatid, s.wid, s.comp,
                    s.tp, s.sseq, s.comsseq, s.cs_off, s.cs_list, s.cs_wt, s.scr, s.misc, s.sc, s.hist, s.outs,
-                   s.outh, s.bests, s.best, f.frm, s.psof_off, s.psof, s.pstamp, s.gpart, f.gpart_n ? s.gp_n : 0, blockIdx.x, blockIdx.y);
+                   s.outh, s.bests, s.best, f.frm, s.psof_off, s.psof, s.pstamp, s.gpart, f.gpart_n ? s.gp_n : 0, s.poswid, s.posout, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -529,7 +529,7 @@ kb_resolve(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
     if ((int32_t)(blockIdx.x * RSBLOCK) >= s.N) return;
     d_dec_resolve(s.N, s.T, f.frm, f.bm, s.best, s.nact[f.cur], s.node_base, s.tree_of, s.prob, s.par_off, s.par,
                   s.pos, s.posf, s.sc, s.hist, s.outs, s.outh, s.bests, s.frame, s.turn, s.selfemit, s.cnt, s.key,
-                  s.first, s.hbin, s.ps, s.pstamp, s.rootnodes, s.n_rootnodes, s.propf, blockIdx.x, 0);
+                  s.first, s.hbin, s.ps, s.pstamp, s.rootnodes, s.n_rootnodes, s.propf, s.posout, blockIdx.x, 0);
 }
 
 
@@ -551,7 +551,7 @@ kb_scan(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int3
     d_dec_scan(s.N, s.T, f.frm, f.bm, s.node_base, s.act[f.cur], s.nact[f.cur], s.wid, s.prob, s.outs, s.outh,
                s.selfemit, s.cnt, s.base, s.act[f.cur ^ 1], s.nact[f.cur ^ 1], s.pos, s.posf, s.best, s.exits,
                s.nexit, s.hbin, s.misc, s.done, pack_all + (size_t)blockIdx.z * pack_stride, max_exits,
-               s.gpart, f.gpart_n ? s.gp_n : 0, blockIdx.x, 0);
+               s.gpart, f.gpart_n ? s.gp_n : 0, s.poswid, s.posout, f.may_hist, blockIdx.x, 0);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -667,6 +667,7 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         s.cnt = ls->d_cnt; s.base = ls->d_cand; s.best = ls->d_best; s.exits = ls->d_exit; s.nexit = ls->d_nexit;
         s.first = ls->d_first; s.eflag = ls->d_eflag; s.hbin = ls->d_hbin; s.done = ls->d_done; s.key = ls->d_key;
         s.ctot = ls->d_ctot; s.n0 = ls->d_n0; s.pstamp = ls->d_pstamp; s.propf = ls->d_candf; s.rootnodes = ls->d_rootnodes;
+        s.poswid = ls->d_poswid; s.posout = ls->d_posout;
         s.ps = ls->d_ps; s.psof_off = ls->d_psof_off; s.psof = ls->d_psof;
         s.n_rootnodes = ls->n_rootnodes;
         s.cs_off = cs->off_d; s.cs_wt = cs->wt_d; s.cs_list = cs->list_d;

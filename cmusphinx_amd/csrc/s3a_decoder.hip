@@ -58,9 +58,9 @@ k_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
                int32_t *best_out, int32_t cf, const int32_t *__restrict__ psof_off,
                const int32_t *__restrict__ psof, int32_t *pstamp,
-               const int32_t *__restrict__ gpart, int32_t gpart_n)
+               const int32_t *__restrict__ gpart, int32_t gpart_n, int32_t *poswid, int32_t *posout)
 {
-    d_dec_hmm_eval<EB>(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, cf, psof_off, psof, pstamp, gpart, gpart_n, blockIdx.x, blockIdx.y);
+    d_dec_hmm_eval<EB>(node_base, act, nact, N, n_tmat, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, misc, sc, hist, outs, outh, bests, best_out, cf, psof_off, psof, pstamp, gpart, gpart_n, poswid, posout, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -92,9 +92,9 @@ k_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               unsigned long long *key, int32_t *first, int32_t *hbin,
               const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
-              const int32_t *__restrict__ propf)
+              const int32_t *__restrict__ propf, int32_t *posout)
 {
-    d_dec_resolve(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, blockIdx.x, blockIdx.y);
+    d_dec_resolve(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -118,9 +118,9 @@ k_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            const int32_t *__restrict__ selfemit, int32_t *cnt, int32_t *base, int32_t *nxt, int32_t *nnxt,
            int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
            const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits,
-           const int32_t *gpart, int32_t gpart_n)
+           const int32_t *gpart, int32_t gpart_n, const int32_t *poswid, const int32_t *posout, int32_t reordered)
 {
-    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, gpart, gpart_n, blockIdx.x, blockIdx.y);
+    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, gpart, gpart_n, poswid, posout, reordered, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -351,14 +351,14 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
                        ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
                        sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best, frm,
-                       ls->d_psof_off, ls->d_psof, ls->d_pstamp, sc->gpart_d, gpart_n);
+                       ls->d_psof_off, ls->d_psof, ls->d_pstamp, sc->gpart_d, gpart_n, ls->d_poswid, ls->d_posout);
     else
         hipLaunchKernelGGL(k_dec_hmm_eval<64>, dim3((rows + 63) / 64, T), dim3(64),
                        (size_t)ls->n_tmat * 12 * 4, ls->stream, ls->d_node_base, ls->d_act[cur],
                        ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
                        ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
                        sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best, frm,
-                       ls->d_psof_off, ls->d_psof, ls->d_pstamp, sc->gpart_d, gpart_n);
+                       ls->d_psof_off, ls->d_psof, ls->d_pstamp, sc->gpart_d, gpart_n, ls->d_poswid, ls->d_posout);
     if (may_hist) {
         hipLaunchKernelGGL(k_dec_hist_count, dim3((rows + DBLOCK - 1) / DBLOCK, T), dim3(DBLOCK), 0, ls->stream,
                            ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], T, bm, ls->d_best, ls->d_bests,
@@ -377,12 +377,13 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_prob, ls->d_par_off, ls->d_par, ls->d_pos, ls->d_posf, ls->d_sc, ls->d_hist,
                        ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame, ls->d_turn, ls->d_selfemit,
                        ls->d_cnt, ls->d_key, ls->d_first, ls->d_hbin, ls->d_ps, ls->d_pstamp, ls->d_rootnodes,
-                       ls->n_rootnodes, ls->d_candf);
+                       ls->n_rootnodes, ls->d_candf, ls->d_posout);
     hipLaunchKernelGGL(k_dec_scan, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
                        ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_wid, ls->d_prob, ls->d_outs,
                        ls->d_outh, ls->d_selfemit, ls->d_cnt, ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt],
                        ls->d_pos, ls->d_posf, ls->d_best, ls->d_exit, ls->d_nexit, ls->d_hbin, sc->misc_d,
-                       ls->d_done, ls->d_pack, ls->pack_max_exits, sc->gpart_d, gpart_n);
+                       ls->d_done, ls->d_pack, ls->pack_max_exits, sc->gpart_d, gpart_n, ls->d_poswid, ls->d_posout,
+                       may_hist ? 1 : 0);
     HIPCHK(hipGetLastError());
     /* the host only needs the frame record: copy it and mark the spot BEFORE the emission kernel, which
      * then overlaps the host's word-level work (the next frame's kernels follow it in stream order) */

@@ -20,8 +20,8 @@
 #define RSBLOCK 64          /* k_dec_resolve: the nodes something happens to are neighbours; small workgroups spread them over more CUs */
 /* k_dec_hmm_eval's workgroup size EB (template): 64 while the lists are short -- a few thousand HMMs are a dozen
  * workgroups of 256, and a CU's memory pipeline serialises their ~50 scattered accesses per HMM; a wave per
- * workgroup puts them on four times as many CUs (20.6 -> 18.5 us) -- 256 for long lists (56 k HMMs: 34 vs 41 us) */
-#define EVBLOCK_LONG_LIST 4096
+ * workgroup puts them on four times as many CUs (20.6 -> 18.5 us) -- 256 for long lists (bound >= 16 k positions; 56 k HMMs: 34 vs 41 us) */
+#define EVBLOCK_LONG_LIST 16384
 
 struct FrameBeams {
     int32_t hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf;
@@ -72,7 +72,7 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
                int32_t *best_out, int32_t cf, const int32_t *__restrict__ psof_off,
                const int32_t *__restrict__ psof, int32_t *pstamp,
-               const int32_t *__restrict__ gpart, int32_t gpart_n,
+               const int32_t *__restrict__ gpart, int32_t gpart_n, int32_t *poswid, int32_t *posout,
         const int32_t BX, const int32_t BY)
 {
     extern __shared__ int32_t tp_s[];
@@ -137,7 +137,11 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         outh[v] = r.outh;
         bests[v] = k;
         best = k;
-        if (wid[v] >= 0) wbest = k;
+        const int32_t w = wid[v];
+        if (w >= 0) wbest = k;
+        /* by list position (coalesced): k_dec_scan finds the word exits without chasing the node ids again */
+        poswid[node_base[t] + i] = w;
+        posout[node_base[t] + i] = r.out;
         /* this node is active in frame cf: stamp the parent sets its children belong to (k_dec_resolve
          * skips every node whose parent set carries no stamp of this frame) */
         for (int32_t q = psof_off[v]; q < psof_off[v + 1]; q++) pstamp[psof[q]] = cf;
@@ -379,7 +383,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               unsigned long long *key, int32_t *first, int32_t *hbin,
               const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
-              const int32_t *__restrict__ propf,
+              const int32_t *__restrict__ propf, int32_t *posout,
         const int32_t BX, const int32_t BY)
 {
     /* (the thresholds come from uniform addresses: computed per thread with scalar loads, and only by
@@ -464,6 +468,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
         sc[1 * N + v] = WORST; sc[2 * N + v] = WORST;
         hist[1 * N + v] = -1; hist[2 * N + v] = -1;
         outs[v] = WORST; outh[v] = -1; bests[v] = WORST;
+        posout[b + j] = WORST;                  /* k_dec_scan reads the exit scores by list position */
     }
     if (cleared || entered) { sc[v] = cur; hist[v] = h0; }
     frame[v] = in_list ? nf : (cleared ? -1 : frame[v]);
@@ -496,23 +501,25 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            const int32_t *__restrict__ selfemit, int32_t *cnt, int32_t *base, int32_t *nxt, int32_t *nnxt,
            int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
            const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits,
-           const int32_t *gpart, int32_t gpart_n,
+           const int32_t *gpart, int32_t gpart_n, const int32_t *poswid, const int32_t *posout, int32_t reordered,
         const int32_t BX, const int32_t BY)
 {
     __shared__ int32_t s_wth, s_last;
     __shared__ int32_t s_gp[3];
     __shared__ int32_t s_thr[8];
-    const int32_t t = BX, b = node_base[t], na = nact[t], nf = cf + 1;
+    const int32_t t = BX, b = node_base[t], na = nact[t];
     const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     /* the loads of chunk n + 1 (list entry, then its word id / exit score: two dependent round trips) are
      * issued before the scan of chunk n; the first chunk's before the thresholds are worked out */
-    int32_t u2 = 0, c2 = 0, se2 = 0, w2 = -1, os2 = 0;
+    int32_t u2 = 0, c2 = 0, w2 = -1, os2 = 0;
 #define SCAN_FETCH(i_)                                                                              \
     do {                                                                                            \
-        u2 = 0; c2 = 0; se2 = 0; w2 = -1; os2 = 0;                                                  \
+        u2 = 0; c2 = 0; w2 = -1; os2 = 0;                                                           \
         if ((i_) < na) {                                                                            \
-            u2 = act[b + (i_)]; c2 = cnt[b + (i_)]; se2 = selfemit[b + (i_)];                       \
-            w2 = wid[u2]; os2 = outs[u2];                                                           \
+            u2 = act[b + (i_)]; c2 = cnt[b + (i_)];                                                 \
+            /* (histogram pruning reorders the list after the evaluation wrote these by position) */   \
+            if (reordered) { w2 = wid[u2]; os2 = outs[u2]; }                                        \
+            else { w2 = poswid[b + (i_)]; os2 = posout[b + (i_)]; }                                 \
             cnt[b + (i_)] = 0;                                  /* the accumulator of the next frame */ \
         }                                                                                           \
     } while (0)
@@ -538,7 +545,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     {
         for (int32_t c0 = 0; c0 < na; c0 += SCAN_THREADS) {
             const int32_t i = c0 + tid;
-            const int32_t u = u2, c = c2, se = se2, w = w2, os = os2;
+            const int32_t u = u2, c = c2, w = w2, os = os2;
             SCAN_FETCH(i + SCAN_THREADS);
             const bool ex = i < na && w >= 0 && os >= wth;
             const unsigned long long x = (unsigned long long)(uint32_t)c | ((unsigned long long)(ex ? 1u : 0u) << 32);
@@ -568,8 +575,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
             carry += s_chunk;
             if (i < na) {
                 const int32_t k = (int32_t)(uint32_t)excl;
-                base[b + i] = k;
-                if (se) { nxt[b + k] = u; pos[u] = k; posf[u] = nf; }
+                base[b + i] = k;        /* (a self-emitted node goes to next[k]: written by k_dec_emit's sweep) */
                 if (ex) {
                     const int32_t e = b + (int32_t)(excl >> 32);
                     const int32_t oh = outh[u];
@@ -669,7 +675,14 @@ d_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__r
         if (i < na) {
             lo = base[b + i];
             hi = (i + 1 < na) ? base[b + i + 1] : total;
-            if (selfemit[b + i]) { selfemit[b + i] = 0; lo++; }
+            if (selfemit[b + i]) {
+                /* the node put itself on the list at its own turn: position = its turn's base (the scattered
+                 * stores happen here, spread over the sweep's workgroups, not in k_dec_scan's one per tree) */
+                const int32_t u = act[b + i];
+                nxt[b + lo] = u; pos[u] = lo; posf[u] = nf;
+                selfemit[b + i] = 0;
+                lo++;
+            }
         }
         unsigned long long todo = __ballot(lo < hi);
         while (todo) {

@@ -504,6 +504,7 @@ alloc_state(s3a_lexsearch_t *ls)
     DMALLOC(ls->d_turn, (size_t)N * 4); DMALLOC(ls->d_selfemit, (size_t)N * 4); DMALLOC(ls->d_cnt, (size_t)N * 4);
     DMALLOC(ls->d_best, (size_t)n_tree * 2 * 4);
     DMALLOC(ls->d_exit, (size_t)3 * N * 4); DMALLOC(ls->d_nexit, (size_t)2 * n_tree * 4);
+    DMALLOC(ls->d_poswid, (size_t)N * 4); DMALLOC(ls->d_posout, (size_t)N * 4);
     DMALLOC(ls->d_calls, (size_t)2 * 4096 * 4);
     DMALLOC(ls->d_ent, (size_t)2 * ls->ent_cap * 4); DMALLOC(ls->d_eflag, (size_t)ls->ent_cap * 4);
     DMALLOC(ls->d_first, (size_t)N * 4); DMALLOC(ls->d_key, (size_t)N * 8);
@@ -721,7 +722,7 @@ s3a_lexsearch_clone(const s3a_lexsearch_t *proto, void *stream)
     ls->d_act[0] = ls->d_act[1] = ls->d_nact[0] = ls->d_nact[1] = ls->d_cand = ls->d_ncand = ls->d_candf = NULL;
     ls->d_turn = ls->d_selfemit = ls->d_cnt = ls->d_best = ls->d_exit = ls->d_nexit = ls->d_calls = NULL;
     ls->d_ent = ls->d_eflag = ls->d_first = ls->d_thr = ls->d_done = ls->d_hbin = ls->d_pstamp = NULL;
-    ls->d_ctot = ls->d_n0 = ls->d_pack = NULL; ls->d_key = NULL;
+    ls->d_ctot = ls->d_n0 = ls->d_pack = NULL; ls->d_key = NULL; ls->d_poswid = ls->d_posout = NULL;
     ls->h_pin = ls->h_pack = ls->h_ring = NULL; ls->ev_pack = NULL; ls->ring_slot = 0; ls->cur = 0;
     if (stream) { ls->stream = (hipStream_t)stream; ls->own_stream = 0; }
     else if (hipStreamCreateWithFlags(&ls->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -749,7 +750,8 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
         &ls->d_frame, &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
-        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0, &ls->d_pstamp };
+        &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0, &ls->d_pstamp,
+        &ls->d_poswid, &ls->d_posout };
     for (auto p : state) (void)hipFree(*p);
     (void)hipFree(ls->d_key);
     if (!ls->is_clone) {                /* a clone borrows its prototype's static arrays */
