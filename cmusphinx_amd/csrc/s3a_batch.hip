@@ -100,11 +100,11 @@ kb_enter2(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
                  s.eflag, s.ctot, s.n0, blockIdx.x, 0);
 }
 
-__global__ void __launch_bounds__(DBLOCK)
+__global__ void __launch_bounds__(M3BLOCK)
 kb_enter3_mark(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
 {
     SLOT_FRAME;
-    const int32_t n_ent_blocks = (f.n_ent + DBLOCK - 1) / DBLOCK, bpt = (f.mark_rows + DBLOCK - 1) / DBLOCK;
+    const int32_t n_ent_blocks = (f.n_ent + M3BLOCK - 1) / M3BLOCK, bpt = (f.mark_rows + M3BLOCK - 1) / M3BLOCK;
     if ((int32_t)blockIdx.x >= n_ent_blocks + bpt * s.T) return;
     const Entries ent = { f.calls, s.rootlist, f.n_calls };
     d_dec_enter3_mark(n_ent_blocks, ent, f.n_ent, f.calls, f.groups, f.n_groups, f.cf + 1, s.key, s.first, s.eflag,
@@ -745,8 +745,8 @@ run_batch(s3a_batch_t *b)
             hipLaunchKernelGGL(kb_enter1, dim3(g_ent, 1, n), dim3(256), 0, st, S, F);
             hipLaunchKernelGGL(kb_enter2, dim3(g_calls, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
         }
-        hipLaunchKernelGGL(kb_enter3_mark, dim3(g_ent * (256 / DBLOCK) + ((g_mark + DBLOCK - 1) / DBLOCK) * b->g_T, 1, n),
-                           dim3(DBLOCK), 0, st, S, F);
+        hipLaunchKernelGGL(kb_enter3_mark, dim3(g_ent * (256 / M3BLOCK) + ((g_mark + M3BLOCK - 1) / M3BLOCK) * b->g_T, 1, n),
+                           dim3(M3BLOCK), 0, st, S, F);
         dim3 gx_grid(1, 1, 1);
         size_t gx_lds = 0;
         const bool d4main = shared && b->sc[b->order[0]]->g->dev->D4 == D4MAIN;

@@ -149,7 +149,7 @@ k_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
     d_dec_enter2(ent, n_ent, calls, prob, sc, frame, first, thresh, nf, T, nnxt, flag, ctot, n0, blockIdx.x, 0);
 }
 
-__global__ void __launch_bounds__(DBLOCK)
+__global__ void __launch_bounds__(M3BLOCK)
 k_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
                   const int32_t *__restrict__ calls, const int32_t *__restrict__ groups, int32_t n_groups,
                   int32_t nf, const unsigned long long *__restrict__ key, const int32_t *__restrict__ first,
@@ -445,10 +445,10 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
                            ls->d_nact[nxt], ls->d_eflag, ls->d_ctot, ls->d_n0);
     }
     {
-        const int32_t n_ent_blocks = (n_ent + DBLOCK - 1) / DBLOCK;
+        const int32_t n_ent_blocks = (n_ent + M3BLOCK - 1) / M3BLOCK;
         /* the lists before the entries hold at most last_nnxt nodes (what the search emitted) */
-        const int32_t bpt = (min(maxn, max(ls->last_nnxt, 1)) + DBLOCK - 1) / DBLOCK;
-        hipLaunchKernelGGL(k_dec_enter3_mark, dim3(n_ent_blocks + bpt * T), dim3(DBLOCK), 0, ls->stream,
+        const int32_t bpt = (min(maxn, max(ls->last_nnxt, 1)) + M3BLOCK - 1) / M3BLOCK;
+        hipLaunchKernelGGL(k_dec_enter3_mark, dim3(n_ent_blocks + bpt * T), dim3(M3BLOCK), 0, ls->stream,
                            n_ent_blocks, ent, n_ent, ls->d_calls + 8, ls->d_calls, n_groups, cf + 1, ls->d_key,
                            ls->d_first, ls->d_eflag, ls->d_ctot, n_ent > 0 ? ls->d_n0 : ls->d_nact[nxt], ls->d_sc,
                            ls->d_hist, ls->d_frame, T, bpt, ls->d_node_base, ls->d_act[nxt], ls->d_nact[nxt],

@@ -17,11 +17,12 @@
 
 #define WORST S3A_WORST
 #define DBLOCK 256
+#define M3BLOCK 64          /* k_dec_enter3_mark: same reason (a composite leaf marks ~140 scattered senones) */
 #define RSBLOCK 64          /* k_dec_resolve: the nodes something happens to are neighbours; small workgroups spread them over more CUs */
 /* k_dec_hmm_eval's workgroup size EB (template): 64 while the lists are short -- a few thousand HMMs are a dozen
  * workgroups of 256, and a CU's memory pipeline serialises their ~50 scattered accesses per HMM; a wave per
- * workgroup puts them on four times as many CUs (20.6 -> 18.5 us) -- 256 for long lists (bound >= 16 k positions; 56 k HMMs: 34 vs 41 us) */
-#define EVBLOCK_LONG_LIST 16384
+ * workgroup puts them on four times as many CUs (20.6 -> 18.5 us) -- 256 for long lists (bound >= 32 k positions; 56 k HMMs: 34 vs 41 us) */
+#define EVBLOCK_LONG_LIST 32768
 
 struct FrameBeams {
     int32_t hmmbeam, pbeam, wbeam, phone_uses_wbeam, maxhmmpf;
@@ -827,7 +828,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
         const int32_t BX, const int32_t BY)
 {
     if ((int32_t)BX < n_ent_blocks) {
-        const int32_t e = BX * DBLOCK + threadIdx.x;
+        const int32_t e = BX * M3BLOCK + threadIdx.x;
         if (e >= n_ent) return;
         int32_t v, c;
         ent.locate(e, v, c);
@@ -853,7 +854,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
         return;
     }
     const int32_t bb = BX - n_ent_blocks;
-    const int32_t t = bb / blocks_per_tree, i = (bb % blocks_per_tree) * DBLOCK + threadIdx.x;
+    const int32_t t = bb / blocks_per_tree, i = (bb % blocks_per_tree) * M3BLOCK + threadIdx.x;
     if (t >= T || i >= n0[t]) return;
     mark_node_senones(nxt[node_base[t] + i], ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active);
 }
