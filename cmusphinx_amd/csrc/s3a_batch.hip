@@ -799,10 +799,10 @@ run_batch(s3a_batch_t *b)
         }
         if (g_rows >= EVBLOCK_LONG_LIST)
             hipLaunchKernelGGL(kb_hmm_eval<256>, dim3((g_rows + 255) / 256, b->g_T, n), dim3(256),
-                               (size_t)b->g_tmat * 12 * 4, st, S, F);
+                               0, st, S, F);
         else
             hipLaunchKernelGGL(kb_hmm_eval<64>, dim3((g_rows + 63) / 64, b->g_T, n), dim3(64),
-                               (size_t)b->g_tmat * 12 * 4, st, S, F);
+                               0, st, S, F);
         if (any_hist) {
             hipLaunchKernelGGL(kb_hist_count, dim3((g_rows + DBLOCK - 1) / DBLOCK, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
             hipLaunchKernelGGL(kb_hist_sort, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F);

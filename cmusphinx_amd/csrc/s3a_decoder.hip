@@ -347,14 +347,14 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
     const int32_t rows = min(maxn, max(ls->hist_bound, 1));
     if (rows >= EVBLOCK_LONG_LIST)
         hipLaunchKernelGGL(k_dec_hmm_eval<256>, dim3((rows + 255) / 256, T), dim3(256),
-                       (size_t)ls->n_tmat * 12 * 4, ls->stream, ls->d_node_base, ls->d_act[cur],
+                       0, ls->stream, ls->d_node_base, ls->d_act[cur],
                        ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
                        ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
                        sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best, frm,
                        ls->d_psof_off, ls->d_psof, ls->d_pstamp, sc->gpart_d, gpart_n, ls->d_poswid, ls->d_posout);
     else
         hipLaunchKernelGGL(k_dec_hmm_eval<64>, dim3((rows + 63) / 64, T), dim3(64),
-                       (size_t)ls->n_tmat * 12 * 4, ls->stream, ls->d_node_base, ls->d_act[cur],
+                       0, ls->stream, ls->d_node_base, ls->d_act[cur],
                        ls->d_nact[cur], ls->N, ls->n_tmat, ls->d_ssid, ls->d_tmatid, ls->d_wid, ls->d_comp,
                        ls->d_tp, ls->d_sseq, ls->d_comsseq, cs->off_d, cs->list_d, cs->wt_d, sc->scr_d,
                        sc->misc_d, ls->d_sc, ls->d_hist, ls->d_outs, ls->d_outh, ls->d_bests, ls->d_best, frm,

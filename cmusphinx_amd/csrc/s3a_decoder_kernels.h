@@ -76,11 +76,10 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                const int32_t *__restrict__ gpart, int32_t gpart_n, int32_t *poswid, int32_t *posout,
         const int32_t BX, const int32_t BY)
 {
-    extern __shared__ int32_t tp_s[];
     __shared__ int32_t red[2][EB / 64];
     __shared__ int32_t s_gb[EB / 64];
-    for (int32_t i = threadIdx.x; i < n_tmat * 12; i += EB)
-        tp_s[i] = tp_g[i];
+    /* (the transition matrices are read from global memory -- 12 cached words per HMM, independent of the senone
+     * chain: staging them in LDS put a copy loop and a barrier in front of every workgroup) */
     /* the batched scorer leaves the CD maximum as one value per workgroup (s3a_batch.hip) */
     int32_t gb = INT_MIN;
     for (int32_t i = threadIdx.x; i < gpart_n; i += EB) gb = max(gb, gpart[i]);
@@ -96,6 +95,20 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         const int32_t v = act[node_base[t] + i], ss = ssid[v];
         HmmRegsT<int32_t> r;
         int32_t e[3];
+        /* the HMM's own state first: these loads do not depend on the senone scores and stay in flight
+         * while the (longer) senone chain below runs */
+#pragma unroll
+        for (int st = 0; st < 3; st++) { r.s[st] = sc[st * N + v]; r.h[st] = hist[st * N + v]; }
+        r.out = outs[v];
+        r.outh = outh[v];
+        int32_t tp[12];
+        {
+            const int4 *tq = (const int4 *)(tp_g + tmatid[v] * 12);    /* 48-byte rows of a 16-byte aligned array */
+            const int4 a = tq[0], bq = tq[1], cq = tq[2];
+            tp[0] = a.x; tp[1] = a.y; tp[2] = a.z; tp[3] = a.w; tp[4] = bq.x; tp[5] = bq.y; tp[6] = bq.z; tp[7] = bq.w;
+            tp[8] = cq.x; tp[9] = cq.y; tp[10] = cq.z; tp[11] = cq.w;
+        }
+        const int32_t w = wid[v], q_lo = psof_off[v], q_hi = psof_off[v + 1];
         if (comp[v]) {
             /* composite senone = max over its member senones (dict2pid.c:1029-1048), up to one member
              * per context (~46): the three states' lists are walked together, 8 members each per round,
@@ -127,25 +140,20 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
             for (int st = 0; st < 3; st++)
                 e[st] = add32(raw[sseq[ss * 3 + st]], -norm);
         }
-#pragma unroll
-        for (int st = 0; st < 3; st++) { r.s[st] = sc[st * N + v]; r.h[st] = hist[st * N + v]; }
-        r.out = outs[v];
-        r.outh = outh[v];
-        const int32_t k = vit3(r, tp_s + tmatid[v] * 12, e[0], e[1], e[2]);
+        const int32_t k = vit3(r, tp, e[0], e[1], e[2]);
 #pragma unroll
         for (int st = 0; st < 3; st++) { sc[st * N + v] = r.s[st]; hist[st * N + v] = r.h[st]; }
         outs[v] = r.out;
         outh[v] = r.outh;
         bests[v] = k;
         best = k;
-        const int32_t w = wid[v];
         if (w >= 0) wbest = k;
         /* by list position (coalesced): k_dec_scan finds the word exits without chasing the node ids again */
         poswid[node_base[t] + i] = w;
         posout[node_base[t] + i] = r.out;
         /* this node is active in frame cf: stamp the parent sets its children belong to (k_dec_resolve
          * skips every node whose parent set carries no stamp of this frame) */
-        for (int32_t q = psof_off[v]; q < psof_off[v + 1]; q++) pstamp[psof[q]] = cf;
+        for (int32_t q = q_lo; q < q_hi; q++) pstamp[psof[q]] = cf;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
