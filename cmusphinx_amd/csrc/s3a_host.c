@@ -1136,3 +1136,161 @@ s3a_tmat_get_tp(const s3a_tmat_t *t, int32_t *tp)
     memcpy(tp, t->tp, sizeof(int32_t) * (size_t)t->n_tmat * t->n_state * (t->n_state + 1));
     return S3A_OK;
 }
+
+/* ------------------------------------------------------------------ */
+/* pocketsphinx's senone score dump (-senlogdir): the cross-decoder    */
+/* score interchange format                         */
+/* ------------------------------------------------------------------ */
+/*
+ * File = an s3 header (bio_writehdr, sphinxbase util/bio.c:154-183: "s3", the pairs version 0.1 /
+ * mdef_file / n_sen / logbase, "endhdr", the 32-bit byte-order word) followed by frames
+ * (acmod_write_scores, pocketsphinx acmod.c:885-923): int16 n_active; then, when every senone is
+ * active, n_active int16 scores; otherwise n_active delta bytes (the list ps_mgau_frame_eval takes)
+ * and the n_active scores of those senones.  Reading (acmod_read_senfh_header :805-836,
+ * acmod_read_scores_internal :928-985) fills the senones that are not listed with SENSCR_DUMMY.
+ */
+#define S3A_SENSCR_DUMMY 0x7fff         /* acmod.h:76 */
+
+struct s3a_senlog_s {
+    FILE *fp;
+    int32_t n_sen, swap, writing;
+    double logbase;
+};
+
+s3a_senlog_t *
+s3a_senlog_open_write(const char *path, const char *mdef_file, int32_t n_sen, double logbase)
+{
+    s3a_senlog_t *s;
+    uint32_t magic = 0x11223344u;
+    if (!path || n_sen <= 0 || n_sen > 32767) {     /* (n_active is an int16 in the file) */
+        s3a_set_error("s3a_senlog_open_write: bad arguments (1..32767 senones)");
+        return NULL;
+    }
+    if ((s = (s3a_senlog_t *)calloc(1, sizeof *s)) == NULL) return NULL;
+    if ((s->fp = fopen(path, "wb")) == NULL) {
+        s3a_set_error("cannot create %s", path);
+        free(s);
+        return NULL;
+    }
+    s->n_sen = n_sen; s->logbase = logbase; s->writing = 1;
+    /* acmod_write_senfh_header (acmod.c:349-361): "%d" and "%f" */
+    fprintf(s->fp, "s3\nversion 0.1\nmdef_file %s\nn_sen %d\nlogbase %f\nendhdr\n", mdef_file ? mdef_file : "(null)",
+            n_sen, logbase);
+    if (fwrite(&magic, 4, 1, s->fp) != 1) {
+        s3a_set_error("%s: write failed", path);
+        s3a_senlog_close(s);
+        return NULL;
+    }
+    return s;
+}
+
+int32_t
+s3a_senlog_write_frame(s3a_senlog_t *s, int32_t n_active, const uint8_t *active, const int16_t *senscr)
+{
+    int16_t n16 = (int16_t)n_active;
+    int32_t i, n;
+    if (!s || !s->writing || !senscr || n_active < 0 || n_active > s->n_sen || (n_active < s->n_sen && n_active > 0 && !active))
+        return S3A_EINVAL;
+    if (fwrite(&n16, 2, 1, s->fp) != 1) goto fail;
+    if (n_active == s->n_sen) {
+        if (fwrite(senscr, 2, (size_t)n_active, s->fp) != (size_t)n_active) goto fail;
+    }
+    else {
+        if (n_active && fwrite(active, 1, (size_t)n_active, s->fp) != (size_t)n_active) goto fail;
+        for (i = n = 0; i < n_active; ++i) {
+            n += active[i];
+            if (n >= s->n_sen) { s3a_set_error("s3a_senlog_write_frame: the active list runs past the last senone"); return S3A_EINVAL; }
+            if (fwrite(senscr + n, 2, 1, s->fp) != 1) goto fail;
+        }
+    }
+    return S3A_OK;
+fail:
+    s3a_set_error("s3a_senlog_write_frame: write failed");
+    return S3A_EIO;
+}
+
+s3a_senlog_t *
+s3a_senlog_open_read(const char *path, int32_t *n_sen, double *logbase)
+{
+    s3a_senlog_t *s;
+    char line[16384], name[256], val[4096];
+    uint32_t magic;
+    if (!path) return NULL;
+    if ((s = (s3a_senlog_t *)calloc(1, sizeof *s)) == NULL) return NULL;
+    if ((s->fp = fopen(path, "rb")) == NULL) {
+        s3a_set_error("cannot open %s", path);
+        free(s);
+        return NULL;
+    }
+    if (fgets(line, sizeof line, s->fp) == NULL || strcmp(line, "s3\n") != 0) goto bad;
+    for (;;) {
+        if (fgets(line, sizeof line, s->fp) == NULL) goto bad;
+        name[0] = val[0] = 0;
+        if (sscanf(line, "%255s %4095s", name, val) < 1) continue;
+        if (strcmp(name, "endhdr") == 0) break;
+        if (strcmp(name, "n_sen") == 0) s->n_sen = atoi(val);
+        else if (strcmp(name, "logbase") == 0) s->logbase = atof(val);
+    }
+    if (fread(&magic, 4, 1, s->fp) != 1) goto bad;
+    if (magic == 0x11223344u) s->swap = 0;
+    else if (bswap32(magic) == 0x11223344u) s->swap = 1;
+    else goto bad;
+    if (s->n_sen <= 0 || s->n_sen > 32767) goto bad;
+    if (n_sen) *n_sen = s->n_sen;
+    if (logbase) *logbase = s->logbase;
+    return s;
+bad:
+    s3a_set_error("%s: not a senone score dump", path);
+    s3a_senlog_close(s);
+    return NULL;
+}
+
+static int16_t
+senlog_swap16(const s3a_senlog_t *s, int16_t v)
+{
+    uint16_t u = (uint16_t)v;
+    return s->swap ? (int16_t)(uint16_t)((u >> 8) | (u << 8)) : v;
+}
+
+/* returns 1 and fills senscr[n_sen] (+ active[n_active], *n_active when given), 0 at the end of the file */
+int32_t
+s3a_senlog_read_frame(s3a_senlog_t *s, int16_t *senscr, uint8_t *active, int32_t *n_active)
+{
+    int16_t n16;
+    int32_t i, n, na;
+    if (!s || s->writing || !senscr) return S3A_EINVAL;
+    if (fread(&n16, 2, 1, s->fp) != 1) return 0;
+    na = senlog_swap16(s, n16);
+    if (na < 0 || na > s->n_sen) { s3a_set_error("senone score dump: %d active of %d senones", na, s->n_sen); return S3A_EIO; }
+    if (n_active) *n_active = na;
+    if (na == s->n_sen) {
+        if (fread(senscr, 2, (size_t)na, s->fp) != (size_t)na) return 0;
+        for (i = 0; i < na; i++) senscr[i] = senlog_swap16(s, senscr[i]);
+        return 1;
+    }
+    {
+        uint8_t *lst = active ? active : (uint8_t *)malloc((size_t)(na ? na : 1));
+        int32_t rc = 1;
+        if (na && fread(lst, 1, (size_t)na, s->fp) != (size_t)na) rc = 0;
+        /* (acmod_read_scores_internal leaves senone 0 untouched unless it is listed; a dummy is what a
+         * reader of a fresh buffer needs, and listed senones overwrite it) */
+        for (i = 0; i < s->n_sen; i++) senscr[i] = (int16_t)S3A_SENSCR_DUMMY;
+        for (i = 0, n = 0; rc == 1 && i < na; ++i) {
+            int16_t v;
+            n += lst[i];
+            if (n >= s->n_sen) { s3a_set_error("senone score dump: active list runs past the last senone"); rc = S3A_EIO; break; }
+            if (fread(&v, 2, 1, s->fp) != 1) { rc = 0; break; }
+            senscr[n] = senlog_swap16(s, v);
+        }
+        if (!active) free(lst);
+        return rc;
+    }
+}
+
+void
+s3a_senlog_close(s3a_senlog_t *s)
+{
+    if (!s) return;
+    if (s->fp) fclose(s->fp);
+    free(s);
+}

@@ -108,6 +108,11 @@ _SIGS = {
                                    [C.c_void_p] * 6 + [C.c_int32]),
     "s3a_approx_cont_mgau_frame_eval_async": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_scorer_misc_dev": (C.c_void_p, [C.c_void_p]),
+    "s3a_senlog_open_write": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_int32, C.c_double]),
+    "s3a_senlog_write_frame": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "s3a_senlog_open_read": (C.c_void_p, [C.c_char_p, C.c_void_p, C.c_void_p]),
+    "s3a_senlog_read_frame": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3a_senlog_close": (None, [C.c_void_p]),
     "s3a_fe_default_params": (None, [C.c_void_p]),
     "s3a_fe_init": (C.c_void_p, [C.c_void_p]),
     "s3a_fe_free": (None, [C.c_void_p]),
@@ -490,6 +495,56 @@ def feat_1s_c_d_dd(cep, cmn="current", varnorm=False, agc="none"):
     out = np.zeros((n, 3 * cs), np.float32)
     check(L.s3a_feat_1s_c_d_dd(_p(cep), n, cs, int(cmn == "current"), int(bool(varnorm)), int(agc == "max"), _p(out)))
     return out
+
+
+class SenLog:
+    """pocketsphinx's senone score dump (-senlogdir): SenLog.create(path, mdef, n_sen, logbase) / SenLog.open(path)."""
+
+    def __init__(self, h, n_sen, logbase):
+        self.L, self.h, self.n_sen, self.logbase = load(), h, n_sen, logbase
+
+    @classmethod
+    def create(cls, path, mdef_file, n_sen, logbase):
+        h = load().s3a_senlog_open_write(path.encode(), mdef_file.encode(), n_sen, logbase)
+        if not h:
+            raise S3AError(_err(load()))
+        return cls(h, n_sen, logbase)
+
+    @classmethod
+    def open(cls, path):
+        n, b = C.c_int32(), C.c_double()
+        h = load().s3a_senlog_open_read(path.encode(), C.byref(n), C.byref(b))
+        if not h:
+            raise S3AError(_err(load()))
+        return cls(h, n.value, b.value)
+
+    def write(self, senscr, active=None):
+        """active: delta-encoded list (uint8) or None = every senone"""
+        senscr = np.ascontiguousarray(senscr, np.int16)
+        if active is None:
+            check(self.L.s3a_senlog_write_frame(self.h, self.n_sen, None, _p(senscr)))
+        else:
+            active = np.ascontiguousarray(active, np.uint8)
+            check(self.L.s3a_senlog_write_frame(self.h, len(active), _p(active) if len(active) else None, _p(senscr)))
+
+    def read(self):
+        """-> (senscr int16[n_sen], active uint8[n_active]) or None at the end of the file"""
+        scr = np.zeros(self.n_sen, np.int16)
+        act = np.zeros(self.n_sen, np.uint8)
+        n = C.c_int32()
+        rc = self.L.s3a_senlog_read_frame(self.h, _p(scr), _p(act), C.byref(n))
+        if rc == 0:
+            return None
+        if rc < 0:
+            check(rc)
+        return scr, act[:n.value].copy()
+
+    def close(self):
+        if self.h:
+            self.L.s3a_senlog_close(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 class FeParams(C.Structure):

@@ -248,6 +248,20 @@ int32_t s3a_ps_ms_cont_mgau_frame_eval(s3a_ps_mgau_t *ps, int16_t *senscr, const
                                        int32_t compallsen);
 
 /* ------------------------------------------------------------------ */
+/* pocketsphinx's senone score dump (-senlogdir): the score interchange format between decoders
+ * (SURVEY.md 8(f).3).  Replaces acmod_write_senfh_header (pocketsphinx/src/libpocketsphinx/acmod.c:349-361),
+ * acmod_write_scores (:885-923), acmod_read_senfh_header (:805-836), acmod_read_scores_internal (:928-985).
+ * Host only (file format); the scores are s3a_ps_ms_cont_mgau_frame_eval's int16 outputs and `active` is the
+ * delta-encoded list it takes.  Senones a frame does not list read back as SENSCR_DUMMY (0x7fff). */
+/* ------------------------------------------------------------------ */
+typedef struct s3a_senlog_s s3a_senlog_t;
+s3a_senlog_t *s3a_senlog_open_write(const char *path, const char *mdef_file, int32_t n_sen, double logbase);
+int32_t s3a_senlog_write_frame(s3a_senlog_t *s, int32_t n_active, const uint8_t *active, const int16_t *senscr);
+s3a_senlog_t *s3a_senlog_open_read(const char *path, int32_t *n_sen, double *logbase);
+int32_t s3a_senlog_read_frame(s3a_senlog_t *s, int16_t *senscr, uint8_t *active, int32_t *n_active);
+void s3a_senlog_close(s3a_senlog_t *s);
+
+/* ------------------------------------------------------------------ */
 /* The MFCC front end: 16-bit samples -> cepstra (the step before feat_s2mfc2feat).
  * Replaces fe_t and its whole-utterance use (sphinxbase/include/sphinxbase/fe.h:300-460):
  *   s3a_fe_default_params   the defaults of waveform_to_cepstral_command_line_macro (fe.h:100-215)

@@ -89,9 +89,10 @@ main(int argc, char **argv)
     int gpu;
     if (argc != 13) { fprintf(stderr, "usage: see the header of oracle/ref_ps_shim.c\n"); return 2; }
     gpu = strcmp(argv[1], "gpu") == 0;
+    /* PS_SENLOGDIR: pocketsphinx's own -senlogdir (acmod_write_scores writes <dir>/<uttid>.sen) */
     config = cmd_ln_init(NULL, ps_args(), TRUE, "-mdef", argv[2], "-mean", argv[3], "-var", argv[4], "-mixw", argv[5],
                          "-tmat", argv[6], "-dict", argv[7], "-fdict", argv[8], "-lm", argv[9], "-senmgau", ".cont.",
-                         "-topn", "4", NULL);
+                         "-topn", "4", getenv("PS_SENLOGDIR") ? "-senlogdir" : NULL, getenv("PS_SENLOGDIR"), NULL);
     if ((ps = ps_init(config)) == NULL) E_FATAL("ps_init failed\n");
     if (strcmp(ps->acmod->mgau->vt->name, "ms") != 0) E_FATAL("ps shim: expected the multi-stream scorer\n");
     if (gpu) {
