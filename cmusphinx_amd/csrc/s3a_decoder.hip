@@ -132,11 +132,18 @@ k_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__r
     d_dec_emit(cf, node_base, act, nact, child_off, child, turn, selfemit, base, nxt, nnxt, pos, posf, blockIdx.x, blockIdx.y);
 }
 
+/* the frame's lextree_enter calls as a kernel argument (groups[8] then 4 ints per call) when there are at most
+ * CALLS_BY_ARG of them -- the usual case: one call per final phone with an exit -- instead of a host-to-device
+ * copy in front of the three kernels */
+#define CALLS_BY_ARG 96
+struct CallsArg { int32_t v[8 + 4 * CALLS_BY_ARG]; };
+
 __global__ void
 k_dec_enter1(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
              const int32_t *__restrict__ prob, const int32_t *__restrict__ sc, int32_t thresh,
-             unsigned long long *key, int32_t *first)
+             unsigned long long *key, int32_t *first, CallsArg ca)
 {
+    if (calls == NULL) { calls = ca.v + 8; ent.calls = calls; }
     d_dec_enter1(ent, n_ent, calls, prob, sc, thresh, key, first, blockIdx.x, blockIdx.y);
 }
 
@@ -144,8 +151,10 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 k_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
              const int32_t *__restrict__ prob, const int32_t *__restrict__ sc,
              const int32_t *__restrict__ frame, const int32_t *__restrict__ first, int32_t thresh,
-             int32_t nf, int32_t T, const int32_t *__restrict__ nnxt, int32_t *flag, int32_t *ctot, int32_t *n0)
+             int32_t nf, int32_t T, const int32_t *__restrict__ nnxt, int32_t *flag, int32_t *ctot, int32_t *n0,
+             CallsArg ca)
 {
+    if (calls == NULL) { calls = ca.v + 8; ent.calls = calls; }
     d_dec_enter2(ent, n_ent, calls, prob, sc, frame, first, thresh, nf, T, nnxt, flag, ctot, n0, blockIdx.x, 0);
 }
 
@@ -160,8 +169,9 @@ k_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
                   const int32_t *__restrict__ ssid, const uint8_t *__restrict__ comp,
                   const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
                   const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
-                  uint8_t *sen_active)
+                  uint8_t *sen_active, CallsArg ca)
 {
+    if (calls == NULL) { calls = ca.v + 8; ent.calls = calls; groups = ca.v; }
     d_dec_enter3_mark(n_ent_blocks, ent, n_ent, calls, groups, n_groups, nf, key, first, flag, ctot, n0, sc, hist,
                       frame, T, blocks_per_tree, node_base, nxt, nnxt, pos, posf, ssid, comp, sseq, comsseq, cs_off,
                       cs_list, sen_active, blockIdx.x, 0);
@@ -435,25 +445,32 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
     if ((rc = s3a_dec_stage_calls(ls, tree_a, n_a, lc_a, scr_a, hist_a, tree_b, n_b, lc_b, scr_b, hist_b, groups,
                                   calls, 2046, &c, &n_ent, &n_groups)) != S3A_OK)
         return rc;
-    const Entries ent = { ls->d_calls + 8, ls->d_rootlist, c };
+    const bool by_arg = c <= CALLS_BY_ARG;
+    CallsArg ca;
+    memset(&ca, 0, sizeof ca);
+    if (by_arg) memcpy(ca.v, slot, (size_t)(8 + 4 * c) * 4);
+    const int32_t *d_calls = by_arg ? (const int32_t *)NULL : ls->d_calls + 8;
+    const int32_t *d_groups = by_arg ? (const int32_t *)NULL : ls->d_calls;
+    const Entries ent = { d_calls, ls->d_rootlist, c };
     if (n_ent > 0) {
-        HIPCHK(hipMemcpyAsync(ls->d_calls, slot, (size_t)(8 + 4 * c) * 4, hipMemcpyHostToDevice, ls->stream));
+        if (!by_arg)
+            HIPCHK(hipMemcpyAsync(ls->d_calls, slot, (size_t)(8 + 4 * c) * 4, hipMemcpyHostToDevice, ls->stream));
         hipLaunchKernelGGL(k_dec_enter1, dim3((n_ent + 255) / 256), dim3(256), 0, ls->stream, ent,
-                           n_ent, ls->d_calls + 8, ls->d_prob, ls->d_sc, thresh, ls->d_key, ls->d_first);
+                           n_ent, d_calls, ls->d_prob, ls->d_sc, thresh, ls->d_key, ls->d_first, ca);
         hipLaunchKernelGGL(k_dec_enter2, dim3(c), dim3(SCAN_THREADS), 0, ls->stream, ent, n_ent,
-                           ls->d_calls + 8, ls->d_prob, ls->d_sc, ls->d_frame, ls->d_first, thresh, cf + 1, T,
-                           ls->d_nact[nxt], ls->d_eflag, ls->d_ctot, ls->d_n0);
+                           d_calls, ls->d_prob, ls->d_sc, ls->d_frame, ls->d_first, thresh, cf + 1, T,
+                           ls->d_nact[nxt], ls->d_eflag, ls->d_ctot, ls->d_n0, ca);
     }
     {
         const int32_t n_ent_blocks = (n_ent + M3BLOCK - 1) / M3BLOCK;
         /* the lists before the entries hold at most last_nnxt nodes (what the search emitted) */
         const int32_t bpt = (min(maxn, max(ls->last_nnxt, 1)) + M3BLOCK - 1) / M3BLOCK;
         hipLaunchKernelGGL(k_dec_enter3_mark, dim3(n_ent_blocks + bpt * T), dim3(M3BLOCK), 0, ls->stream,
-                           n_ent_blocks, ent, n_ent, ls->d_calls + 8, ls->d_calls, n_groups, cf + 1, ls->d_key,
+                           n_ent_blocks, ent, n_ent, d_calls, d_groups, n_groups, cf + 1, ls->d_key,
                            ls->d_first, ls->d_eflag, ls->d_ctot, n_ent > 0 ? ls->d_n0 : ls->d_nact[nxt], ls->d_sc,
                            ls->d_hist, ls->d_frame, T, bpt, ls->d_node_base, ls->d_act[nxt], ls->d_nact[nxt],
                            ls->d_pos, ls->d_posf, ls->d_ssid, ls->d_comp, ls->d_sseq, ls->d_comsseq, cs->off_d,
-                           cs->list_d, sc->act_d);
+                           cs->list_d, sc->act_d, ca);
     }
     HIPCHK(hipGetLastError());
     ls->cur ^= 1;       /* lextree_active_swap; the new next-list counts are overwritten by k_dec_finish */
