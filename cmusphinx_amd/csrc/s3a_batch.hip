@@ -36,7 +36,6 @@
 
 #define BMAXC 96            /* lextree_enter calls per decoder per frame (#CI phones + 1) */
 #define BMAXSLOT 256
-#define BFIRST 256          /* word exits copied with the frame record */
 
 struct BSlot {              /* one decoder: static model + its state, all device pointers */
     int32_t N, T, n_tmat, maxn;
@@ -581,7 +580,7 @@ struct s3a_batch_s {
     BOut out[BMAXSLOT];
     uint8_t has_trans[BMAXSLOT], active[BMAXSLOT], arrived[BMAXSLOT];
     int32_t n_active, n_arrived, order[BMAXSLOT], rows[BMAXSLOT], zof[BMAXSLOT], last_order[BMAXSLOT], last_n;
-    int32_t *d_pack, *h_pack, pack_stride, pack_max_exits, hdr_max;
+    int32_t *h_pack, pack_stride, pack_max_exits, hdr_max;     /* pinned host: the kernels write the frame records there */
     int32_t g_ent, g_ci, g_cd, g_maxn, g_N, g_T, g_mark, g_tmat, exact;
     unsigned long long gen;
     long steps, slot_frames;
@@ -619,7 +618,6 @@ s3a_batch_free(s3a_batch_t *b)
     (void)hipStreamSynchronize(b->stream);
     (void)hipEventDestroy(b->ev);
     (void)hipFree(b->d_slots); (void)hipFree(b->d_frames); (void)hipHostFree(b->h_frames);
-    if (b->d_pack) (void)hipFree(b->d_pack);
     if (b->h_pack) (void)hipHostFree(b->h_pack);
 
     /* the attached decoders now own a dead stream handle: they must be freed by their owners
@@ -689,12 +687,11 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         b->g_tmat = max(b->g_tmat, s.n_tmat);
         const int32_t hdr = 6 * s.T + 16;
         if (hdr > b->hdr_max || ls->pack_max_exits > b->pack_max_exits) {
-            if (b->d_pack) { (void)hipFree(b->d_pack); (void)hipHostFree(b->h_pack); }
+            if (b->h_pack) (void)hipHostFree(b->h_pack);
             b->hdr_max = max(b->hdr_max, hdr);
             b->pack_max_exits = max(b->pack_max_exits, ls->pack_max_exits);
             b->pack_stride = b->hdr_max + 3 * b->pack_max_exits;
-            if (hipMalloc((void **)&b->d_pack, (size_t)b->pack_stride * b->max_slots * 4) != hipSuccess
-                || hipHostMalloc((void **)&b->h_pack, (size_t)b->pack_stride * b->max_slots * 4) != hipSuccess) { rc = S3A_EHIP; break; }
+            if (hipHostMalloc((void **)&b->h_pack, (size_t)b->pack_stride * b->max_slots * 4) != hipSuccess) { rc = S3A_EHIP; break; }
         }
         b->n_slots++;
     } while (0);
@@ -809,14 +806,12 @@ run_batch(s3a_batch_t *b)
         }
         if (any_weak) hipLaunchKernelGGL(kb_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
         hipLaunchKernelGGL(kb_resolve, dim3((b->g_N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, S, F);
-        hipLaunchKernelGGL(kb_scan, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F, b->d_pack, b->pack_stride,
+        hipLaunchKernelGGL(kb_scan, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F, b->h_pack, b->pack_stride,
                            b->pack_max_exits);
         CHK(hipGetLastError());
-        /* the records (header + the first exits) of all decoders: one strided copy, issued BEFORE the
-         * emission kernel: the hosts only need the records, so k_dec_emit overlaps their word-level work
-         * (the next step's kernels follow it in stream order) */
-        CHK(hipMemcpy2DAsync(b->h_pack, (size_t)b->pack_stride * 4, b->d_pack, (size_t)b->pack_stride * 4,
-                             (size_t)(b->hdr_max + 3 * BFIRST) * 4, n, hipMemcpyDeviceToHost, st));
+        /* the records (header + every exit) were written by kb_scan's last workgroups straight into pinned host
+         * memory; the hosts wait for that kernel only, so k_dec_emit overlaps their word-level work (the next
+         * step's kernels follow it in stream order) */
         CHK(hipEventRecord(b->ev, st));
         hipLaunchKernelGGL(kb_emit, dim3(EMIT_BLOCKS, b->g_T, n), dim3(DBLOCK), 0, st, S, F);
         CHK(hipGetLastError());
@@ -850,15 +845,6 @@ unpack_own(s3a_batch_t *b, int32_t slot)
     int32_t total = 0;
     int32_t rc = s3a_dec_unpack(ls, p, o.may_hist != 0, o.frm, o.res, o.n_exit, o.max_exits, &total);
     if (rc != S3A_OK) return rc;
-    if (total > BFIRST) {               /* rare: more exits than travelled with the record */
-        pthread_mutex_lock(&b->mu);
-        hipError_t e = hipMemcpyAsync(b->h_pack + (size_t)z * b->pack_stride + hdr + 3 * BFIRST,
-                                      b->d_pack + (size_t)z * b->pack_stride + hdr + 3 * BFIRST,
-                                      (size_t)3 * (total - BFIRST) * 4, hipMemcpyDeviceToHost, b->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-        pthread_mutex_unlock(&b->mu);
-        if (e != hipSuccess) { s3a_set_error("s3a_batch: exit read-back failed: %s", hipGetErrorString(e)); return S3A_EHIP; }
-    }
     for (int32_t k = 0; k < total; k++) {
         o.wid[k] = p[hdr + 3 * k]; o.scr[k] = p[hdr + 3 * k + 1]; o.hist[k] = p[hdr + 3 * k + 2];
     }

@@ -392,13 +392,12 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_wid, ls->d_prob, ls->d_outs,
                        ls->d_outh, ls->d_selfemit, ls->d_cnt, ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt],
                        ls->d_pos, ls->d_posf, ls->d_best, ls->d_exit, ls->d_nexit, ls->d_hbin, sc->misc_d,
-                       ls->d_done, ls->d_pack, ls->pack_max_exits, sc->gpart_d, gpart_n, ls->d_poswid, ls->d_posout,
+                       ls->d_done, ls->h_pack, ls->pack_max_exits, sc->gpart_d, gpart_n, ls->d_poswid, ls->d_posout,
                        may_hist ? 1 : 0);
     HIPCHK(hipGetLastError());
-    /* the host only needs the frame record: copy it and mark the spot BEFORE the emission kernel, which
-     * then overlaps the host's word-level work (the next frame's kernels follow it in stream order) */
-    const int32_t first = 256;
-    HIPCHK(hipMemcpyAsync(ls->h_pack, ls->d_pack, (size_t)(hdr + 3 * first) * 4, hipMemcpyDeviceToHost, ls->stream));
+    /* the last workgroup of k_dec_scan wrote the frame record (header + every exit) straight into pinned host
+     * memory -- posted writes, no copy engine in the frame; the host waits for that kernel only, and the emission
+     * kernel overlaps its word-level work (the next frame's kernels follow it in stream order) */
     HIPCHK(hipEventRecord(ls->ev_pack, ls->stream));
     hipLaunchKernelGGL(k_dec_emit, dim3(EMIT_BLOCKS, T), dim3(DBLOCK), 0, ls->stream, frm, ls->d_node_base,
                        ls->d_act[cur], ls->d_nact[cur], ls->d_child_off, ls->d_child, ls->d_turn, ls->d_selfemit,
@@ -409,11 +408,6 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
     {
         const int32_t rc = s3a_dec_unpack(ls, p, may_hist, frm, res, n_exit, max_exits, &total);
         if (rc != S3A_OK) return rc;
-    }
-    if (total > first) {
-        HIPCHK(hipMemcpyAsync(ls->h_pack + hdr + 3 * first, ls->d_pack + hdr + 3 * first,
-                              (size_t)3 * (total - first) * 4, hipMemcpyDeviceToHost, ls->stream));
-        HIPCHK(hipStreamSynchronize(ls->stream));
     }
     for (int32_t k = 0; k < total; k++) {
         exit_wid[k] = p[hdr + 3 * k];
