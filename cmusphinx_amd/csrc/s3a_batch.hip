@@ -146,8 +146,9 @@ kb_gated(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
 #define GX_SEN (GX_THREADS / 64)    /* senones per tile: one per wave */
 struct GxDec {              /* one decoder of the workgroup, staged in LDS */
     uint8_t *sen_act;
-    int32_t *scr, *misc, *bstidx, *bstscr, *updatetime;
-    int32_t frame, is_skip, thresh, pad;    /* thresh = the CI maximum + the CI beam */
+    int32_t *scr, *misc, *bstidx, *bstscr, *updatetime;    /* misc: the scorer's counters (kb_gated_cd_shared) or
+                                                            * its per-workgroup columns gpart[] (kb_gated_cd_multi) */
+    int32_t frame, is_skip, thresh, gp_n;   /* thresh = the CI maximum + the CI beam; gp_n = columns of gpart[] */
 };
 /*
  * D4C > 0: the Gaussian is fetched before the gate is known and the gate only selects (see s3a_gated.h).
@@ -215,7 +216,7 @@ kb_gated_cd_shared(const BSlot *__restrict__ slots, const BFrame *__restrict__ f
         GxDec d;
         d.sen_act = sp.sen_act; d.scr = sp.scr; d.misc = sp.misc; d.bstidx = sp.bstidx; d.bstscr = sp.bstscr;
         d.updatetime = sp.updatetime; d.frame = f.sc_frame; d.is_skip = f.sc_is_skip;
-        d.thresh = (int32_t)((uint32_t)sp.misc[5] + (uint32_t)f.sc_beam); d.pad = 0;
+        d.thresh = (int32_t)((uint32_t)sp.misc[5] + (uint32_t)f.sc_beam); d.gp_n = 0;
         dec[threadIdx.x] = d;
     }
     {
@@ -388,7 +389,7 @@ kb_gated_cd_multi(const BSlot *__restrict__ slots, const BFrame *__restrict__ fr
         GxDec d;
         d.sen_act = sp.sen_act; d.scr = sp.scr; d.misc = sp.gpart; d.bstidx = sp.bstidx; d.bstscr = sp.bstscr;
         d.updatetime = sp.updatetime; d.frame = f.sc_frame; d.is_skip = f.sc_is_skip;
-        d.thresh = (int32_t)((uint32_t)sp.misc[5] + (uint32_t)f.sc_beam); d.pad = sp.gp_n;
+        d.thresh = (int32_t)((uint32_t)sp.misc[5] + (uint32_t)f.sc_beam); d.gp_n = sp.gp_n;
         dec[tid] = d;
     }
     __syncthreads();
@@ -485,7 +486,7 @@ kb_gated_cd_multi(const BSlot *__restrict__ slots, const BFrame *__restrict__ fr
     /* this workgroup's column of every decoder it served */
     if (tid < n && (tid / GM_FB) % (int32_t)gridDim.y == (int32_t)blockIdx.y) {
         int32_t *gp = dec[tid].misc;
-        const int32_t gp_n = dec[tid].pad;
+        const int32_t gp_n = dec[tid].gp_n;
         gp[blockIdx.x] = max(max(red[0][tid][0], red[1][tid][0]), max(red[2][tid][0], red[3][tid][0]));
         gp[gp_n + blockIdx.x] = red[0][tid][1] + red[1][tid][1] + red[2][tid][1] + red[3][tid][1];
         gp[2 * gp_n + blockIdx.x] = red[0][tid][2] + red[1][tid][2] + red[2][tid][2] + red[3][tid][2];
