@@ -692,7 +692,7 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
             b->hdr_max = max(b->hdr_max, hdr);
             b->pack_max_exits = max(b->pack_max_exits, ls->pack_max_exits);
             b->pack_stride = b->hdr_max + 3 * b->pack_max_exits;
-            if (hipHostMalloc((void **)&b->h_pack, (size_t)b->pack_stride * b->max_slots * 4) != hipSuccess) { rc = S3A_EHIP; break; }
+            if (hipHostMalloc((void **)&b->h_pack, (size_t)b->pack_stride * b->max_slots * 4, hipHostMallocCoherent) != hipSuccess) { rc = S3A_EHIP; break; }
         }
         b->n_slots++;
     } while (0);

@@ -519,7 +519,8 @@ alloc_state(s3a_lexsearch_t *ls)
     ls->hist_bound = ls->last_nnxt = 1 << 30;
     HIPCHK(hipMemset(ls->d_key, 0, (size_t)N * 8));
     DMALLOC(ls->d_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4);
-    HIPCHK(hipHostMalloc((void **)&ls->h_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4));
+    /* (coherent: k_dec_scan writes the frame record here directly; the host reads it after the event behind that kernel) */
+    HIPCHK(hipHostMalloc((void **)&ls->h_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4, hipHostMallocCoherent));
     HIPCHK(hipHostMalloc((void **)&ls->h_ring, (size_t)8 * (2 * 4096 + 2 * ls->ent_cap) * 4));
     HIPCHK(hipEventCreateWithFlags(&ls->ev_pack, hipEventDisableTiming));
     return S3A_OK;
