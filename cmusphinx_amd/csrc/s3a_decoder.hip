@@ -439,7 +439,7 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
     if ((rc = s3a_dec_stage_calls(ls, tree_a, n_a, lc_a, scr_a, hist_a, tree_b, n_b, lc_b, scr_b, hist_b, groups,
                                   calls, 2046, &c, &n_ent, &n_groups)) != S3A_OK)
         return rc;
-    const bool by_arg = c <= CALLS_BY_ARG;
+    const bool by_arg = c <= CALLS_BY_ARG && getenv("S3A_CALLS_BY_COPY") == NULL;    /* (the variable: tests of the copy path) */
     CallsArg ca;
     memset(&ca, 0, sizeof ca);
     if (by_arg) memcpy(ca.v, slot, (size_t)(8 + 4 * c) * 4);

@@ -236,11 +236,15 @@ class OracleFrame:
                           (8, 20000, 1e-80, -3400000, 0),       # phone beam WIDER than the HMM beam
                           (9, 20000, 1e-80, -2000000, 2),       # every 2nd frame: word threshold for phones
                           (10, 300, 1e-80, -3400000, 3)])
-def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pbeam, pbeam, ptranskip):
+def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pbeam, pbeam, ptranskip, monkeypatch):
     """The product path of a mode-4 frame -- s3a_decoder_score / _search / _transition -- against
     the oracle's step-by-step frame on a synthetic forest WITH a synthetic acoustic model: raw
     scores normalised inside the search kernels, inline composite senones, histogram pruning,
-    two-tree transitions, next-frame senone marks consumed by the gated scorer."""
+    two-tree transitions, next-frame senone marks consumed by the gated scorer.
+    (seed 7 also takes the transition's copy path: the calls through device memory instead of the kernel
+    arguments, which a frame with more than 96 lextree_enter calls would use.)"""
+    if seed == 7:
+        monkeypatch.setenv("S3A_CALLS_BY_COPY", "1")
     from cmusphinx_amd import synth
     rng = np.random.default_rng(seed)
     tr = synth_forest(rng, n_tree=4, n_node=900, n_sen=600)
