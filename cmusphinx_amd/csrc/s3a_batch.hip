@@ -44,7 +44,9 @@ struct BSlot {              /* one decoder: static model + its state, all device
     const uint8_t *comp;
     const int16_t *sseq, *comsseq;
     int32_t *sc, *hist, *outs, *outh, *bests, *frame, *pos, *posf, *act[2], *nact[2], *turn, *selfemit,
-        *cnt, *base, *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0, *pstamp, *propf, *poswid, *posout;
+        *cnt, *base, *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0, *pstamp, *propf, *poswid, *posout, *scan_flag;
+    unsigned long long *scan_agg, *scan_pre;
+    int32_t scan_chunks, pad3;
     const int32_t *rootnodes, *ps, *psof_off, *psof;
     int32_t n_rootnodes;
     unsigned long long *key;
@@ -73,7 +75,7 @@ struct BFrame {             /* one decoder's parameters for one step */
     int32_t frm, may_hist;
     FrameBeams bm;
     int32_t sc_frame, sc_beam, sc_is_skip, mark_rows;   /* mark_rows: bound on the list lengths before the entries */
-    int32_t gpart_n, pad2[3];   /* > 0: this step's CD maxima / counters are in the slot's gpart[] */
+    int32_t gpart_n, scan_epoch, scan_nc, pad2;     /* scan_nc: k_dec_scan workgroups per tree this decoder needs */   /* > 0: this step's CD maxima / counters are in the slot's gpart[] */
     int32_t calls[4 * BMAXC];
 };
 
@@ -544,14 +546,17 @@ kb_weak(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames)
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 kb_scan(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int32_t *pack_all,
-        int32_t pack_stride, int32_t max_exits)
+        int32_t pack_stride, int32_t max_exits, int32_t NC)
 {
     SLOT_FRAME;
-    if ((int32_t)blockIdx.x >= s.T) return;
+    /* the launch has NC workgroups per tree (the largest bound of the step); this decoder needs f.scan_nc of them */
+    const int32_t bt = blockIdx.x / NC, bj = blockIdx.x - bt * NC;
+    if (bt >= s.T || bj >= f.scan_nc) return;
     d_dec_scan(s.N, s.T, f.frm, f.bm, s.node_base, s.act[f.cur], s.nact[f.cur], s.wid, s.prob, s.outs, s.outh,
                s.selfemit, s.cnt, s.base, s.act[f.cur ^ 1], s.nact[f.cur ^ 1], s.pos, s.posf, s.best, s.exits,
                s.nexit, s.hbin, s.misc, s.done, pack_all + (size_t)blockIdx.z * pack_stride, max_exits,
-               s.gpart, f.gpart_n ? s.gp_n : 0, s.poswid, s.posout, f.may_hist, blockIdx.x, 0);
+               s.gpart, f.gpart_n ? s.gp_n : 0, s.poswid, s.posout, f.may_hist, s.scan_agg, s.scan_pre, s.scan_flag,
+               s.scan_chunks, f.scan_epoch, f.scan_nc, bt * f.scan_nc + bj, 0);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -667,6 +672,7 @@ s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_coms
         s.first = ls->d_first; s.eflag = ls->d_eflag; s.hbin = ls->d_hbin; s.done = ls->d_done; s.key = ls->d_key;
         s.ctot = ls->d_ctot; s.n0 = ls->d_n0; s.pstamp = ls->d_pstamp; s.propf = ls->d_candf; s.rootnodes = ls->d_rootnodes;
         s.poswid = ls->d_poswid; s.posout = ls->d_posout;
+        s.scan_agg = ls->d_scan_agg; s.scan_pre = ls->d_scan_pre; s.scan_flag = ls->d_scan_flag; s.scan_chunks = ls->scan_chunks;
         s.ps = ls->d_ps; s.psof_off = ls->d_psof_off; s.psof = ls->d_psof;
         s.n_rootnodes = ls->n_rootnodes;
         s.cs_off = cs->off_d; s.cs_wt = cs->wt_d; s.cs_list = cs->list_d;
@@ -807,8 +813,11 @@ run_batch(s3a_batch_t *b)
         }
         if (any_weak) hipLaunchKernelGGL(kb_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
         hipLaunchKernelGGL(kb_resolve, dim3((b->g_N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, S, F);
-        hipLaunchKernelGGL(kb_scan, dim3(b->g_T, 1, n), dim3(SCAN_THREADS), 0, st, S, F, b->h_pack, b->pack_stride,
-                           b->pack_max_exits);
+        {
+            const int32_t scan_nc = scan_workgroups(g_rows);
+            hipLaunchKernelGGL(kb_scan, dim3(b->g_T * scan_nc, 1, n), dim3(SCAN_THREADS), 0, st, S, F, b->h_pack,
+                               b->pack_stride, b->pack_max_exits, scan_nc);
+        }
         CHK(hipGetLastError());
         /* the records (header + every exit) were written by kb_scan's last workgroups straight into pinned host
          * memory; the hosts wait for that kernel only, so k_dec_emit overlaps their word-level work (the next
@@ -924,6 +933,8 @@ submit(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, int32_t f
     f.bm.hmmbeam = hmmbeam; f.bm.pbeam = pbeam; f.bm.wbeam = wbeam; f.bm.phone_uses_wbeam = phone_uses_wbeam;
     f.bm.maxhmmpf = maxhmmpf;
     f.may_hist = ls->hist_bound > maxhmmpf + (maxhmmpf >> 1);
+    f.scan_epoch = ++ls->scan_epoch;
+    f.scan_nc = scan_workgroups(b->rows[slot]);
     if (f.may_hist && -hmmbeam / NBIN == 0) { s3a_set_error("s3a_batch_step: -beam too narrow for histogram pruning"); return S3A_EUNSUP; }
     f.sc_frame = frame;
     f.sc_is_skip = (frame % sc->ds_ratio == 0) ? 0 : 1;

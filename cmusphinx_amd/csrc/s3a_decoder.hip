@@ -118,9 +118,11 @@ k_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            const int32_t *__restrict__ selfemit, int32_t *cnt, int32_t *base, int32_t *nxt, int32_t *nnxt,
            int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
            const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits,
-           const int32_t *gpart, int32_t gpart_n, const int32_t *poswid, const int32_t *posout, int32_t reordered)
+           const int32_t *gpart, int32_t gpart_n, const int32_t *poswid, const int32_t *posout, int32_t reordered,
+           unsigned long long *st_agg, unsigned long long *st_pre, int32_t *st_flag, int32_t st_stride,
+           int32_t epoch, int32_t NC)
 {
-    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, gpart, gpart_n, poswid, posout, reordered, blockIdx.x, blockIdx.y);
+    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, gpart, gpart_n, poswid, posout, reordered, st_agg, st_pre, st_flag, st_stride, epoch, NC, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)
@@ -293,6 +295,10 @@ s3a_dec_unpack(s3a_lexsearch_t *ls, const int32_t *p, bool may_hist, int32_t frm
         return S3A_EINVAL;
     }
     for (t = 0; t < T; t++) {
+        if (p[4 * T + 8 + t] == 2) {
+            s3a_set_error("fused frame: the chained scan of tree %d timed out (internal error)", t);
+            return S3A_EHIP;
+        }
         if (p[4 * T + 8 + t]) {
             s3a_set_error("out.history==-1 at a word exit of tree %d (LEXTREE_OPERATION_FAILURE)", t);
             return S3A_EINVAL;
@@ -388,12 +394,14 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame, ls->d_turn, ls->d_selfemit,
                        ls->d_cnt, ls->d_key, ls->d_first, ls->d_hbin, ls->d_ps, ls->d_pstamp, ls->d_rootnodes,
                        ls->n_rootnodes, ls->d_candf, ls->d_posout);
-    hipLaunchKernelGGL(k_dec_scan, dim3(T), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
+    const int32_t scan_nc = scan_workgroups(rows);
+    hipLaunchKernelGGL(k_dec_scan, dim3(T * scan_nc), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
                        ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_wid, ls->d_prob, ls->d_outs,
                        ls->d_outh, ls->d_selfemit, ls->d_cnt, ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt],
                        ls->d_pos, ls->d_posf, ls->d_best, ls->d_exit, ls->d_nexit, ls->d_hbin, sc->misc_d,
                        ls->d_done, ls->h_pack, ls->pack_max_exits, sc->gpart_d, gpart_n, ls->d_poswid, ls->d_posout,
-                       may_hist ? 1 : 0);
+                       may_hist ? 1 : 0, ls->d_scan_agg, ls->d_scan_pre, ls->d_scan_flag, ls->scan_chunks,
+                       ++ls->scan_epoch, scan_nc);
     HIPCHK(hipGetLastError());
     /* the last workgroup of k_dec_scan wrote the frame record (header + every exit) straight into pinned host
      * memory -- posted writes, no copy engine in the frame; the host waits for that kernel only, and the emission

@@ -17,6 +17,11 @@
 
 #define WORST S3A_WORST
 #define DBLOCK 256
+/* k_dec_scan: workgroups per tree.  One (walking the list 1024 positions at a time) unless the host's bound on the
+ * list length is long: a chained multi-workgroup scan costs ~3 us per link, which pays from ~16 k positions on
+ * (56 k HMMs per frame: 44 -> 23 us; 3 k HMMs: 14 us either way, and slower when batched) */
+#define SCAN_LONG_LIST 16384
+__host__ __device__ static inline int32_t scan_workgroups(int32_t rows) { return rows >= SCAN_LONG_LIST ? (rows + 1023) / 1024 : 1; }
 #define M3BLOCK 64          /* k_dec_enter3_mark: same reason (a composite leaf marks ~140 scattered senones) */
 #define RSBLOCK 64          /* k_dec_resolve: the nodes something happens to are neighbours; small workgroups spread them over more CUs */
 /* k_dec_hmm_eval's workgroup size EB (template): 64 while the lists are short -- a few thousand HMMs are a dozen
@@ -502,6 +507,14 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
  * one dependent HBM access per link, cost 600 us per frame.)
  * record = [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] | n_next x T | exits
  */
+/*
+ * Several workgroups per tree: workgroup (t, j) owns list positions [j * 1024, (j + 1) * 1024) of tree t and needs
+ * the totals of the chunks in front of it.  Single-pass chained scan: it publishes its own totals (st_agg, flag =
+ * 2 * epoch), then walks back over its predecessors -- adding their totals until one has already published its
+ * inclusive prefix (st_pre, flag = 2 * epoch + 1) -- and publishes its own prefix.  `epoch` grows with every launch
+ * on this decoder, so the flags never need a reset.  Predecessors have smaller workgroup ids (dispatched first) and
+ * the whole grid fits the chip, so the wait always ends; the spin is bounded all the same (error word 2 in the frame record).
+ */
 __device__ __forceinline__ void
 d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
            const int32_t *__restrict__ act, const int32_t *__restrict__ nact,
@@ -511,51 +524,55 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
            const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits,
            const int32_t *gpart, int32_t gpart_n, const int32_t *poswid, const int32_t *posout, int32_t reordered,
+           unsigned long long *st_agg, unsigned long long *st_pre, int32_t *st_flag, int32_t st_stride,
+           int32_t epoch, int32_t NC,
         const int32_t BX, const int32_t BY)
 {
     __shared__ int32_t s_wth, s_last;
     __shared__ int32_t s_gp[3];
     __shared__ int32_t s_thr[8];
-    const int32_t t = BX, b = node_base[t], na = nact[t];
+    __shared__ unsigned long long s_wsum[SCAN_THREADS / 64], s_chunk, s_prefix;
+    __shared__ int32_t s_exit_open;
+    const int32_t t = BX / NC, j = BX - t * NC, b = node_base[t], na = nact[t];
     const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    /* the loads of chunk n + 1 (list entry, then its word id / exit score: two dependent round trips) are
-     * issued before the scan of chunk n; the first chunk's before the thresholds are worked out */
+    const bool live = j * SCAN_THREADS < na || j == 0;      /* (chunk 0 also reports an empty tree's totals) */
+    /* a chunk's list entries: turn count; word id / exit score by list position (after a histogram reordering --
+     * the evaluation wrote them before it -- through the node).  The first chunk's loads are issued before the
+     * thresholds are worked out, the next chunk's before the scan of the current one. */
     int32_t u2 = 0, c2 = 0, w2 = -1, os2 = 0;
 #define SCAN_FETCH(i_)                                                                              \
     do {                                                                                            \
         u2 = 0; c2 = 0; w2 = -1; os2 = 0;                                                           \
         if ((i_) < na) {                                                                            \
             u2 = act[b + (i_)]; c2 = cnt[b + (i_)];                                                 \
-            /* (histogram pruning reorders the list after the evaluation wrote these by position) */   \
             if (reordered) { w2 = wid[u2]; os2 = outs[u2]; }                                        \
             else { w2 = poswid[b + (i_)]; os2 = posout[b + (i_)]; }                                 \
             cnt[b + (i_)] = 0;                                  /* the accumulator of the next frame */ \
         }                                                                                           \
     } while (0)
-    SCAN_FETCH(tid);
-    if (threadIdx.x == 0) {
-        int32_t bh, bw, n, th, pth, wth;
-        const bool hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
-        s_wth = wth;
-        s_thr[0] = th; s_thr[1] = pth; s_thr[2] = wth; s_thr[3] = bh; s_thr[4] = bw; s_thr[5] = n;
-        s_thr[6] = hist ? 1 : 0;
-        s_thr[7] = 0;
-    }
-    __syncthreads();
-    /* ONE sweep over the active list does both ordered compactions: (a) the turn bases (exclusive sum of the
-     * turn counts) with the self-emitted nodes written at theirs, (b) the word exits in list order (exclusive
-     * sum of the exit flags).  The two sums travel as the halves of one 64-bit value through one scan. */
-    const int32_t wth = s_wth;
-    __shared__ unsigned long long s_wsum[SCAN_THREADS / 64], s_chunk;
-    __shared__ int32_t s_exit_open;
-    unsigned long long carry = 0ull;            /* every thread keeps the running totals itself */
-    if (threadIdx.x == 0) s_exit_open = 0;
-    __syncthreads();
-    {
-        for (int32_t c0 = 0; c0 < na; c0 += SCAN_THREADS) {
+    SCAN_FETCH(j * SCAN_THREADS + tid);
+    /* (a workgroup past the end of its tree's list -- the grid is sized by the host's bound -- only reports in) */
+    if (live) {
+        if (tid == 0) {
+            int32_t bh, bw, n, th, pth, wth;
+            const bool hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
+            s_wth = wth;
+            s_thr[0] = th; s_thr[1] = pth; s_thr[2] = wth; s_thr[3] = bh; s_thr[4] = bw; s_thr[5] = n;
+            s_thr[6] = hist ? 1 : 0;
+            s_thr[7] = 0;
+            s_exit_open = 0;
+        }
+        __syncthreads();
+        const int32_t wth = s_wth;
+        unsigned long long carry = 0ull;        /* NC == 1: this workgroup walks all chunks, totals in a register */
+        /* NC > 1: one chunk per workgroup (the host sizes NC by its bound on the list length), chained */
+        for (int32_t c0 = j * SCAN_THREADS; c0 == j * SCAN_THREADS || (NC == 1 && c0 < na); c0 += SCAN_THREADS) {
             const int32_t i = c0 + tid;
             const int32_t u = u2, c = c2, w = w2, os = os2;
-            SCAN_FETCH(i + SCAN_THREADS);
+            if (NC == 1) SCAN_FETCH(i + SCAN_THREADS);
+            /* both ordered compactions in one scan: the turn bases (exclusive sum of the turn counts; the
+             * self-emitted nodes are written at theirs by k_dec_emit) and the word exits in list order (exclusive
+             * sum of the exit flags) travel as the halves of one 64-bit value */
             const bool ex = i < na && w >= 0 && os >= wth;
             const unsigned long long x = (unsigned long long)(uint32_t)c | ((unsigned long long)(ex ? 1u : 0u) << 32);
             unsigned long long incl = x;
@@ -578,13 +595,38 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
                 if (lane == SCAN_THREADS / 64 - 1) s_chunk = wi;        /* the chunk's totals */
             }
             __syncthreads();
-            /* (a wave only re-reads its own s_wsum entry, and s_chunk is rewritten after the next barrier:
-             * two barriers per chunk are enough) */
-            const unsigned long long excl = carry + s_wsum[wave] + incl - x;
-            carry += s_chunk;
+            unsigned long long prefix = carry;
+            if (NC > 1) {
+                if (tid == 0) {
+                    const unsigned long long A = s_chunk;
+                    unsigned long long pre = 0ull;
+                    const int32_t me = t * st_stride + j;    /* (st_stride >= the tree's chunks: the arrays' row length) */
+                    if (j > 0) {
+                        st_agg[me] = A;
+                        __hip_atomic_store(&st_flag[me], 2 * epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int32_t p = j - 1; p >= 0; p--) {
+                            int32_t f, spins = 0;
+                            while ((f = __hip_atomic_load(&st_flag[t * st_stride + p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 2 * epoch) {
+                                if (++spins > (1 << 22)) { nexit[T + t] = 2; break; }   /* (cannot happen: see above) */
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            if (f == 2 * epoch + 1) { pre += ((volatile unsigned long long *)st_pre)[t * st_stride + p]; break; }
+                            pre += ((volatile unsigned long long *)st_agg)[t * st_stride + p];
+                        }
+                    }
+                    st_pre[me] = pre + A;
+                    __hip_atomic_store(&st_flag[me], 2 * epoch + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    s_prefix = pre;
+                }
+                __syncthreads();
+                prefix = s_prefix;
+            }
+            /* (a wave only re-reads its own s_wsum entry, and s_chunk is rewritten after the next chunk's first
+             * barrier: no further barrier is needed before the next chunk) */
+            const unsigned long long excl = prefix + s_wsum[wave] + incl - x;
+            carry = prefix + s_chunk;
             if (i < na) {
-                const int32_t k = (int32_t)(uint32_t)excl;
-                base[b + i] = k;        /* (a self-emitted node goes to next[k]: written by k_dec_emit's sweep) */
+                base[b + i] = (int32_t)(uint32_t)excl;
                 if (ex) {
                     const int32_t e = b + (int32_t)(excl >> 32);
                     const int32_t oh = outh[u];
@@ -594,28 +636,37 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
                     if (oh == -1) s_exit_open = 1;
                 }
             }
+            if (tid == 0 && na <= c0 + SCAN_THREADS) {      /* the tree's last chunk: its totals */
+                nnxt[t] = (int32_t)(uint32_t)carry;
+                nexit[t] = (int32_t)(carry >> 32);
+            }
         }
 #undef SCAN_FETCH
+        __syncthreads();
+        if (tid == 0 && s_exit_open) nexit[T + t] = 1;
     }
+    /* publish this workgroup's results, find out whether it is the last of the launch */
     __syncthreads();
-    if (threadIdx.x == 0) {
-        nnxt[t] = (int32_t)(uint32_t)carry;
-        nexit[t] = (int32_t)(carry >> 32);
-        if (s_exit_open) nexit[T + t] = 1;
-    }
-    /* publish this tree's results, find out whether we are last */
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         __threadfence();                                        /* agent-scope release */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = (atomicAdd(done, 1) == T - 1) ? 1 : 0;
+        s_last = (atomicAdd(done, 1) == T * NC - 1) ? 1 : 0;
         if (s_last) __threadfence();                            /* agent-scope acquire */
     }
     __syncthreads();
     if (!s_last) return;
 
     /* the batched scorer's per-workgroup maxima / counters (s3a_batch.hip) */
-    if (threadIdx.x == 0) { s_gp[0] = INT_MIN; s_gp[1] = 0; s_gp[2] = 0; }
+    if (threadIdx.x == 0) {
+        if (!live) {                            /* (a workgroup that had no chunk has not worked them out yet) */
+            int32_t bh, bw, n, th, pth, wth;
+            const bool hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
+            s_thr[0] = th; s_thr[1] = pth; s_thr[2] = wth; s_thr[3] = bh; s_thr[4] = bw; s_thr[5] = n;
+            s_thr[6] = hist ? 1 : 0;
+            s_thr[7] = 0;
+        }
+        s_gp[0] = INT_MIN; s_gp[1] = 0; s_gp[2] = 0;
+    }
     __syncthreads();
     if (gpart_n > 0) {
         volatile const int32_t *vg = gpart;

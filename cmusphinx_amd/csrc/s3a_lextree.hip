@@ -505,6 +505,15 @@ alloc_state(s3a_lexsearch_t *ls)
     DMALLOC(ls->d_best, (size_t)n_tree * 2 * 4);
     DMALLOC(ls->d_exit, (size_t)3 * N * 4); DMALLOC(ls->d_nexit, (size_t)2 * n_tree * 4);
     DMALLOC(ls->d_poswid, (size_t)N * 4); DMALLOC(ls->d_posout, (size_t)N * 4);
+    {
+        int32_t maxn = 1;
+        for (int32_t t = 0; t < n_tree; t++) maxn = maxn > ls->node_base[t + 1] - ls->node_base[t] ? maxn : ls->node_base[t + 1] - ls->node_base[t];
+        ls->scan_chunks = (maxn + 1023) / 1024;
+        ls->scan_epoch = 0;
+        DMALLOC(ls->d_scan_agg, (size_t)n_tree * ls->scan_chunks * 8); DMALLOC(ls->d_scan_pre, (size_t)n_tree * ls->scan_chunks * 8);
+        DMALLOC(ls->d_scan_flag, (size_t)n_tree * ls->scan_chunks * 4);
+        HIPCHK(hipMemset(ls->d_scan_flag, 0, (size_t)n_tree * ls->scan_chunks * 4));
+    }
     DMALLOC(ls->d_calls, (size_t)2 * 4096 * 4);
     DMALLOC(ls->d_ent, (size_t)2 * ls->ent_cap * 4); DMALLOC(ls->d_eflag, (size_t)ls->ent_cap * 4);
     DMALLOC(ls->d_first, (size_t)N * 4); DMALLOC(ls->d_key, (size_t)N * 8);
@@ -723,7 +732,7 @@ s3a_lexsearch_clone(const s3a_lexsearch_t *proto, void *stream)
     ls->d_act[0] = ls->d_act[1] = ls->d_nact[0] = ls->d_nact[1] = ls->d_cand = ls->d_ncand = ls->d_candf = NULL;
     ls->d_turn = ls->d_selfemit = ls->d_cnt = ls->d_best = ls->d_exit = ls->d_nexit = ls->d_calls = NULL;
     ls->d_ent = ls->d_eflag = ls->d_first = ls->d_thr = ls->d_done = ls->d_hbin = ls->d_pstamp = NULL;
-    ls->d_ctot = ls->d_n0 = ls->d_pack = NULL; ls->d_key = NULL; ls->d_poswid = ls->d_posout = NULL;
+    ls->d_ctot = ls->d_n0 = ls->d_pack = NULL; ls->d_key = NULL; ls->d_poswid = ls->d_posout = NULL; ls->d_scan_agg = ls->d_scan_pre = NULL; ls->d_scan_flag = NULL;
     ls->h_pin = ls->h_pack = ls->h_ring = NULL; ls->ev_pack = NULL; ls->ring_slot = 0; ls->cur = 0;
     if (stream) { ls->stream = (hipStream_t)stream; ls->own_stream = 0; }
     else if (hipStreamCreateWithFlags(&ls->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -752,8 +761,9 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
         &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0, &ls->d_pstamp,
-        &ls->d_poswid, &ls->d_posout };
+        &ls->d_poswid, &ls->d_posout, &ls->d_scan_flag };
     for (auto p : state) (void)hipFree(*p);
+    (void)hipFree(ls->d_scan_agg); (void)hipFree(ls->d_scan_pre);
     (void)hipFree(ls->d_key);
     if (!ls->is_clone) {                /* a clone borrows its prototype's static arrays */
         for (auto p : statics) (void)hipFree(*p);

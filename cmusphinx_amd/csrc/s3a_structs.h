@@ -74,6 +74,8 @@ struct s3a_lexsearch_s {
     int32_t *d_turn, *d_selfemit, *d_cnt;   /* [N] */
     int32_t *d_best;                    /* [n_tree][2] best, wbest */
     int32_t *d_exit;                    /* [3][N] wid, score, hist of word exits (tree slices) */
+    unsigned long long *d_scan_agg, *d_scan_pre;   /* [T][chunks]: k_dec_scan's chained scan (totals / inclusive prefixes) */
+    int32_t *d_scan_flag, scan_epoch, scan_chunks;
     int32_t *d_poswid, *d_posout;       /* [N] by LIST POSITION: word id / exit score of the HMM evaluated there (fused frame) */
     int32_t *d_nexit;                   /* [n_tree] + [n_tree] error flags */
     int32_t *d_calls, *d_ent, *d_eflag, *d_first;   /* enter scratch */
