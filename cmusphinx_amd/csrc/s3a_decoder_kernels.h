@@ -35,6 +35,7 @@ struct FrameBeams {
 
 #define NBIN 1000        /* srch_time_switch_tree.c:858 */
 #define EMIT_WAVES (DBLOCK / 64)
+#define EMIT_NARROW 8           /* children a lane walks by itself in k_dec_emit */
 #define EMIT_BLOCKS 32          /* workgroups per tree in the list sweeps: 128 waves, 8192 positions per pass */
 
 /* thresholds of srch_TST_hmm_compute_lv2 (srch_time_switch_tree.c:849-905) from the per-tree
@@ -744,7 +745,29 @@ d_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__r
                 lo++;
             }
         }
-        unsigned long long todo = __ballot(lo < hi);
+        /* a parent with a handful of children (most nodes) is finished by its own lane: the child ids, then their
+         * turns, are independent loads; only the wide ones (a root has hundreds of children) take the whole wave */
+        bool wide = false;
+        if (lo < hi) {
+            const int32_t u = act[b + i], c_lo = child_off[u], c_hi = child_off[u + 1];
+            if (c_hi - c_lo <= EMIT_NARROW) {
+                int32_t cid[EMIT_NARROW], ct[EMIT_NARROW];
+#pragma unroll
+                for (int q = 0; q < EMIT_NARROW; q++) cid[q] = (c_lo + q < c_hi) ? child[c_lo + q] : -1;
+#pragma unroll
+                for (int q = 0; q < EMIT_NARROW; q++) ct[q] = (cid[q] >= 0) ? turn[cid[q]] : -1;
+                int32_t k = lo;
+#pragma unroll
+                for (int q = 0; q < EMIT_NARROW; q++)
+                    if (cid[q] >= 0 && ct[q] == i && k < hi) {
+                        nxt[b + k] = cid[q]; pos[cid[q]] = k; posf[cid[q]] = nf;
+                        turn[cid[q]] = -1;
+                        k++;
+                    }
+            }
+            else wide = true;
+        }
+        unsigned long long todo = __ballot(wide);
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
