@@ -8,6 +8,7 @@
 #ifndef S3A_DECODER_KERNELS_H
 #define S3A_DECODER_KERNELS_H
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <limits.h>
 #include "s3a_device.h"
@@ -21,7 +22,11 @@
  * list length is long: a chained multi-workgroup scan costs ~3 us per link, which pays from ~16 k positions on
  * (56 k HMMs per frame: 44 -> 23 us; 3 k HMMs: 14 us either way, and slower when batched) */
 #define SCAN_LONG_LIST 16384
-__host__ __device__ static inline int32_t scan_workgroups(int32_t rows) { return rows >= SCAN_LONG_LIST ? (rows + 1023) / 1024 : 1; }
+static inline int32_t scan_workgroups(int32_t rows)
+{
+    /* (S3A_SCAN_CHAINED: the chained scan whatever the length -- for the tests) */
+    return (rows >= SCAN_LONG_LIST || getenv("S3A_SCAN_CHAINED") != NULL) ? (rows + 1023) / 1024 : 1;
+}
 #define M3BLOCK 64          /* k_dec_enter3_mark: same reason (a composite leaf marks ~140 scattered senones) */
 #define RSBLOCK 64          /* k_dec_resolve: the nodes something happens to are neighbours; small workgroups spread them over more CUs */
 /* k_dec_hmm_eval's workgroup size EB (template): 64 while the lists are short -- a few thousand HMMs are a dozen

@@ -235,7 +235,9 @@ class OracleFrame:
                          [(5, 20000, 1e-80, -2000000, 0), (6, 150, 1e-80, -2000000, 0), (7, 400, 1e-12, -2000000, 0),
                           (8, 20000, 1e-80, -3400000, 0),       # phone beam WIDER than the HMM beam
                           (9, 20000, 1e-80, -2000000, 2),       # every 2nd frame: word threshold for phones
-                          (10, 300, 1e-80, -3400000, 3)])
+                          (10, 300, 1e-80, -3400000, 3),
+                          (12, 20000, 1e-80, -2000000, 0),      # 10 000 nodes: lists of several 1024-position chunks
+                          (13, 2500, 1e-80, -2000000, 0)])      # the same with histogram pruning (reordered lists)
 def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pbeam, pbeam, ptranskip, monkeypatch):
     """The product path of a mode-4 frame -- s3a_decoder_score / _search / _transition -- against
     the oracle's step-by-step frame on a synthetic forest WITH a synthetic acoustic model: raw
@@ -245,9 +247,12 @@ def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pb
     arguments, which a frame with more than 96 lextree_enter calls would use.)"""
     if seed == 7:
         monkeypatch.setenv("S3A_CALLS_BY_COPY", "1")
+    big = seed >= 12
+    if big:     # k_dec_scan's chained multi-workgroup path (used from 16 k list positions on) on lists of 2-3 chunks
+        monkeypatch.setenv("S3A_SCAN_CHAINED", "1")
     from cmusphinx_amd import synth
     rng = np.random.default_rng(seed)
-    tr = synth_forest(rng, n_tree=4, n_node=900, n_sen=600)
+    tr = synth_forest(rng, n_tree=4, n_node=10000 if big else 900, n_sen=600)
     n_ci = 30
     m = synth.make_model(600, n_ci, 4, 39, 5, 3, seed=seed + 100)
     feats = synth.make_features(m, 45, seed=seed + 200)
@@ -263,7 +268,8 @@ def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pb
         make_gpu(gpu_lib, tr).decoder_utt_begin(sc)
     ls = make_gpu(gpu_lib, tr, stream=gm.stream())
     lock = Lockstep(of.lex, ls, tr["n_tree"])
-    hmmbeam, wbeam = -2600000, -1500000
+    hmmbeam, wbeam = (-6000000 if big else -2600000), -1500000
+    longest = 0
 
     ls.decoder_utt_begin(sc)
     first = (0, [0, 3, 4], [0, 0, -50], [7, 8, 9]), (2, [1], [0], [9])
@@ -288,6 +294,7 @@ def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pb
         for t in range(tr["n_tree"]):
             assert all(np.array_equal(u, v) for u, v in zip(o["exits"][t], exits[t])), (frm, t)
         n_hist += o["hist"]
+        longest = max(longest, res.n_hmm)
         # word transitions: a unigram-tree batch (sometimes empty) and a filler-tree call
         k = frm % 2
         n = int(rng.integers(0, 5))
@@ -301,4 +308,9 @@ def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pb
         ls.decoder_transition(sc, cs, frm, o["bh"] + hmmbeam, ga, gb)
         lock.same(("frame", frm), lists=(0,))
     assert o["n"] > 50
-    assert (n_hist > 10) == (maxhmmpf < 1000)
+    if seed == 13:
+        assert n_hist >= 3          # (1.5 x 2500 HMMs is reached in the busiest frames only)
+    else:
+        assert (n_hist > 10) == (maxhmmpf < 1000)
+    if seed == 12:
+        assert longest > 4 * 1024 + 500, longest       # four trees: one of them held more than one chunk
