@@ -43,7 +43,7 @@ class Decoder:
                 forest["proto"] = self.ls
         self.batch, self.slot = batch, batch.attach(self.ls, self.sc, self.cs)
         self.lock = Lockstep(self.of.lex, self.ls, self.tr["n_tree"])
-        self.maxhmmpf, self.frm, self.n_hist = maxhmmpf, None, 0
+        self.maxhmmpf, self.frm, self.n_hist, self.most = maxhmmpf, None, 0, 0
 
     def begin(self):
         self.of.fs.g.reset_state()
@@ -71,6 +71,7 @@ class Decoder:
         for t in range(self.tr["n_tree"]):
             assert all(np.array_equal(u, v) for u, v in zip(o["exits"][t], exits[t])), (self.slot, frm, t)
         self.n_hist += o["hist"]
+        self.most = max(self.most, o["n"])
         k = frm % 2
         n = int(rng.integers(0, 5))
         ga = (k, rng.choice(9, n, replace=False), (o["bh"] - rng.integers(0, 900000, n)).astype(np.int32),
@@ -126,16 +127,18 @@ def test_batched_steps_match_one_oracle_per_decoder(gpu_lib, share_model):
     assert frames == 2 * sum(c[3] for c in cfg) and steps < frames / 2      # really batched
 
 
-@pytest.mark.parametrize("n_dec,n_comp", [(5, 4), (11, 8), (19, 8)])
-def test_cloned_decoders_share_model_and_lextrees(gpu_lib, n_dec, n_comp):
+@pytest.mark.parametrize("n_dec,n_comp,n_node", [(5, 4, 700), (11, 8, 700), (19, 8, 700), (3, 8, 10000)])
+def test_cloned_decoders_share_model_and_lextrees(gpu_lib, n_dec, n_comp, n_node, monkeypatch):
     """The production arrangement: ONE model and ONE set of lextrees on the device, N decoders with their
     own state (s3a_scorer_init_private + s3a_lexsearch_clone), different utterances.  With 8 Gaussians per
     senone and >= 8 decoders in a step the CD senones of all of them are one model-stationary pass
     (kb_gated_cd_multi: groups of 8 decoders, the last one partly filled); as the shorter utterances end the
     steps fall back to one launch per decoder."""
+    if n_node > 1024:       # lists of several 1024-position chunks through k_dec_scan's chained multi-workgroup path
+        monkeypatch.setenv("S3A_SCAN_CHAINED", "1")
     batch = gpu_lib.Batch(n_dec + 1)
     rng = np.random.default_rng(77)
-    tr = synth_forest(rng, n_tree=4, n_node=700, n_sen=500)
+    tr = synth_forest(rng, n_tree=4, n_node=n_node, n_sen=500)
     forest = dict(tr=tr, comwt=-rng.integers(0, 3000, tr["n_comstate"]).astype(np.int32))
     m = synth.make_model(500, 30, n_comp, 39, 5, 3, seed=998)
     shared = (m, gpu_lib.MgauModel.init_arrays(m["mean"], m["var"], m["mixw"], gpu_lib.LogMath(1.0003)))
@@ -153,7 +156,9 @@ def test_cloned_decoders_share_model_and_lextrees(gpu_lib, n_dec, n_comp):
             d.check_and_advance(*out[d.slot])
             if d.frm >= len(d.feats):
                 d.end()
-    assert sum(d.n_hist for d in decs) > 10
+    assert sum(d.n_hist for d in decs) > (10 if n_node < 1024 else 0)
+    if n_node > 1024:
+        assert max(d.most for d in decs) > 2 * 1024     # (lists around / over one chunk; the launch has several per tree)
 
 
 def test_blocking_rendezvous_one_thread_per_decoder(gpu_lib):
