@@ -908,7 +908,7 @@ s3a_batch_transition(s3a_batch_t *b, int32_t slot, int32_t cf, int32_t thresh, i
         int32_t maxn = 0;
         for (int32_t t = 0; t < ls->n_tree; t++) maxn = max(maxn, ls->node_base[t + 1] - ls->node_base[t]);
         f.mark_rows = min(maxn, max(ls->last_nnxt, 1));
-        b->rows[slot] = min(maxn, max(ls->hist_bound, 1));      /* bound on the coming frame's list lengths */
+        b->rows[slot] = min(maxn, max(min(ls->hist_bound, ls->row_bound), 1));  /* bound on the coming frame's list lengths */
     }
     b->ls[slot]->cur ^= 1;              /* lextree_active_swap */
     b->has_trans[slot] = 1;

@@ -238,6 +238,7 @@ s3a_dec_stage_calls(s3a_lexsearch_t *ls, int32_t tree_a, int32_t n_a, const int3
 {
     const int32_t T = ls->n_tree;
     int32_t n_ent = 0, n_groups = 0, c = 0, roots = 0;
+    std::vector<int32_t> ent_t(T, 0);
     if (n_a < 0 || n_b < 0 || n_a + n_b > max_calls) {
         s3a_set_error("lextree_enter: %d calls in one frame exceed the staging buffer (%d)", n_a + n_b, max_calls);
         return S3A_EINVAL;
@@ -269,9 +270,14 @@ s3a_dec_stage_calls(s3a_lexsearch_t *ls, int32_t tree_a, int32_t n_a, const int3
         groups[4 * n_groups + 3] = c_lo;
         n_groups++;
         roots += ls->n_root[tree];
+        ent_t[tree] += min(n_ent - lo, ls->n_root[tree]);
     }
     /* >= the coming frame's active HMMs: what propagation listed + the distinct roots entered */
     ls->hist_bound = ls->last_nnxt + min(n_ent, roots);
+    /* per tree: its own share of both (the grids over list positions are per tree) */
+    ls->row_bound = 1;
+    for (int32_t t = 0; t < T; t++)
+        ls->row_bound = max(ls->row_bound, ((size_t)t < ls->nnxt_t.size() ? ls->nnxt_t[t] : 0) + ent_t[t]);
     *n_calls = c; *n_ent_out = n_ent; *n_groups_out = n_groups;
     return S3A_OK;
 }
@@ -289,7 +295,8 @@ s3a_dec_unpack(s3a_lexsearch_t *ls, const int32_t *p, bool may_hist, int32_t frm
     res->need_histprune = p[3 * T + 6];     /* informational: the histogram beam was applied */
     for (int i = 0; i < 8; i++) res->extra[i] = p[5 * T + 8 + i];
     ls->last_nnxt = 0;
-    for (t = 0; t < T; t++) ls->last_nnxt += p[5 * T + 16 + t];
+    ls->nnxt_t.assign(T, 0);
+    for (t = 0; t < T; t++) { ls->nnxt_t[t] = p[5 * T + 16 + t]; ls->last_nnxt += p[5 * T + 16 + t]; }
     if (res->need_histprune && !may_hist) {
         s3a_set_error("fused frame: internal error, %d active HMMs exceed the host bound %d", res->n_hmm, ls->hist_bound);
         return S3A_EINVAL;
@@ -325,6 +332,8 @@ s3a_decoder_utt_begin(s3a_lexsearch_t *ls, s3a_scorer_t *sc)
     if ((rc = s3a_scorer_reset_frame_state(sc)) != S3A_OK) return rc;
     ls->last_nnxt = 0;
     ls->hist_bound = 0;
+    ls->row_bound = 1;
+    ls->nnxt_t.assign(ls->n_tree, 0);
     return S3A_OK;      /* d_best / d_done / key / first are left clean by reset, utt_end and k_dec_finish */
 }
 
@@ -360,7 +369,7 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
     const int32_t gpart_n = sc->gpart_valid ? sc->gp_n : 0;
     sc->gpart_valid = 0;
     /* the active lists are at most hist_bound long (host bound): size the per-position grids by it */
-    const int32_t rows = min(maxn, max(ls->hist_bound, 1));
+    const int32_t rows = min(maxn, max(min(ls->hist_bound, ls->row_bound), 1));
     if (rows >= EVBLOCK_LONG_LIST)
         hipLaunchKernelGGL(k_dec_hmm_eval<256>, dim3((rows + 255) / 256, T), dim3(256),
                        0, ls->stream, ls->d_node_base, ls->d_act[cur],

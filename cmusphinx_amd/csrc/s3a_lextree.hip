@@ -525,7 +525,7 @@ alloc_state(s3a_lexsearch_t *ls)
     DMALLOC(ls->d_pstamp, (size_t)(ls->n_pset > 0 ? ls->n_pset : 1) * 4);
     DMALLOC(ls->d_ctot, 4096 * 4); DMALLOC(ls->d_n0, (size_t)n_tree * 4);
     HIPCHK(hipMemset(ls->d_hbin, 0, 1024 * 4));
-    ls->hist_bound = ls->last_nnxt = 1 << 30;
+    ls->hist_bound = ls->last_nnxt = ls->row_bound = 1 << 30;
     HIPCHK(hipMemset(ls->d_key, 0, (size_t)N * 8));
     DMALLOC(ls->d_pack, (size_t)(6 * n_tree + 16 + 3 * ls->pack_max_exits) * 4);
     /* (coherent: k_dec_scan writes the frame record here directly; the host reads it after the event behind that kernel) */
@@ -795,7 +795,7 @@ s3a_lexsearch_reset(s3a_lexsearch_t *ls)
         || (rc = fill(ls, ls->d_best, INT_MIN, 2 * ls->n_tree)) || (rc = fill(ls, ls->d_first, INT_MAX, N))
         || (rc = fill(ls, ls->d_done, 0, 4)) || (rc = fill(ls, ls->d_hbin, 0, 1024)))
         return rc;
-    ls->hist_bound = ls->last_nnxt = 1 << 30;
+    ls->hist_bound = ls->last_nnxt = ls->row_bound = 1 << 30;
     HIPCHK(hipMemsetAsync(ls->d_key, 0, (size_t)N * 8, ls->stream));
     ls->cur = 0;
     return S3A_OK;
@@ -915,7 +915,7 @@ s3a_lexsearch_enter(s3a_lexsearch_t *ls, int32_t tree, int32_t n_calls, const in
 {
     if (!ls || tree < 0 || tree >= ls->n_tree || n_calls < 0 || n_calls > 4096) return S3A_EINVAL;
     if (n_calls == 0) return S3A_OK;
-    ls->hist_bound = ls->last_nnxt = 1 << 30;   /* step-by-step use: the fused frame can no longer bound the list */
+    ls->hist_bound = ls->last_nnxt = ls->row_bound = 1 << 30;   /* step-by-step use: the fused frame can no longer bound the list */
     const int nxt = ls->cur ^ 1;
     std::vector<int32_t> calls((size_t)2 * n_calls), ent;
     /* host copy of the tree's root lists is implicit: entries are (node, call) pairs

@@ -89,6 +89,8 @@ struct s3a_lexsearch_s {
     int32_t *d_ps, *d_psof_off, *d_psof, *d_pstamp, n_pset;    /* parent-set ids: of a node, of a node's children; frame stamps */
     int32_t *d_ctot, *d_n0;             /* per-call root counts [4096], list lengths before the entries [n_tree] */
     int32_t hist_bound, last_nnxt;      /* host upper bound on the coming frame's active HMMs */
+    int32_t row_bound;                  /* ... on its LONGEST active list (per tree: sizes the per-position grids) */
+    std::vector<int32_t> nnxt_t;        /* per tree: what the last search emitted */
     int32_t *d_pack, *h_pack;           /* per-frame result record (device / pinned host) */
     int32_t pack_max_exits;
     int32_t *h_ring;                    /* pinned staging ring for enter calls */
