@@ -38,6 +38,10 @@ struct s3a_mgau_dev_s {
     int32_t *best_buf; size_t best_cap;
     int32_t n_cu;
     hipEvent_t ev0, ev1;        /* s3a_stream_timer_* */
+    /* the log-add table repacked for the frame-synchronous pass (k_score_frame_sync): 16-bit entries up to
+     * hyb_head, 8-bit entries from there on (the values have dropped below 256): 38 KB instead of 58 */
+    int32_t hyb_ok, hyb_head, hyb_bytes;
+    uint8_t *hyb_tab;           /* device: [hyb_head uint16][tab_size - hyb_head uint8], padded to 16 bytes */
 };
 
 

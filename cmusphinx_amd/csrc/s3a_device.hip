@@ -48,6 +48,7 @@
 /* device objects                                                      */
 /* ------------------------------------------------------------------ */
 #define FB 8                /* frames per inner group */
+#define HYB_MAX_PIECES 10    /* 16-byte pieces of the repacked log-add table per lane of k_score_frame_sync (40 KB) */
 #define GPAD_ALIGN 1024     /* Gaussians padded to a whole number of the largest workgroup */
 
 static int32_t
@@ -175,6 +176,26 @@ s3a_mgau_dev_create(s3a_mgau_model_t *g)
                              hipMemcpyHostToDevice));
         }
     }
+    /* the table repacked for the frame-synchronous pass: 16-bit entries while the values need them, 8-bit ones
+     * from the first multiple-of-1024 index whose value (and, the table being monotone, every later one) fits a byte */
+    d->hyb_ok = 0;
+    if (d->tab16 != NULL) {
+        const s3a_logmath_t *lm = g->lm;
+        uint32_t head = 0;
+        while (head < lm->table_size && lm->table[head] > 255) head += 1024;
+        if (head > lm->table_size) head = (lm->table_size + 7) & ~7u;
+        bool ok = true;
+        for (uint32_t i = head; i < lm->table_size && ok; i++) ok = lm->table[i] <= 255;
+        const size_t bytes = (((size_t)head * 2 + (lm->table_size > head ? lm->table_size - head : 0)) + 15) & ~(size_t)15;
+        if (ok && bytes <= 40 * 1024) {
+            std::vector<uint8_t> pk(bytes, 0);
+            for (uint32_t i = 0; i < head && i < lm->table_size; i++) ((uint16_t *)pk.data())[i] = (uint16_t)lm->table[i];
+            for (uint32_t i = head; i < lm->table_size; i++) pk[(size_t)head * 2 + (i - head)] = (uint8_t)lm->table[i];
+            HIPCHK(hipMalloc(&d->hyb_tab, bytes));
+            HIPCHK(hipMemcpy(d->hyb_tab, pk.data(), bytes, hipMemcpyHostToDevice));
+            d->hyb_ok = 1; d->hyb_head = (int32_t)head; d->hyb_bytes = (int32_t)bytes;
+        }
+    }
     HIPCHK(hipMalloc(&d->bstidx, d->S * sizeof(int32_t)));
     HIPCHK(hipMalloc(&d->bstscr, d->S * sizeof(int32_t)));
     HIPCHK(hipMalloc(&d->updatetime, d->S * sizeof(int32_t)));
@@ -189,7 +210,7 @@ s3a_mgau_dev_destroy(s3a_mgau_model_t *g)
     if (!d)
         return;
     hipFree(d->mean4); hipFree(d->prec4); hipFree(d->lrd); hipFree(d->mixw);
-    hipFree(d->tab16); hipFree(d->tab32);
+    hipFree(d->tab16); hipFree(d->tab32); hipFree(d->hyb_tab);
     hipFree(d->bstidx); hipFree(d->bstscr); hipFree(d->updatetime);
     hipFree(d->feat_buf); hipFree(d->scr_buf); hipFree(d->best_buf);
     if (d->stream) hipStreamDestroy(d->stream);
@@ -345,6 +366,84 @@ k_score_frames(const float4 *__restrict__ mean4, const float4 *__restrict__ prec
         if (c == 0 && sen < S)
             senscr[(size_t)(f0 + fr) * S + sen] = score;
     }
+}
+
+/* ------------------------------------------------------------------ */
+/* k_score_frame_sync: all senones x ONE frame                         */
+/* ------------------------------------------------------------------ */
+/*
+ * The frame-synchronous pass is the read of the model plus, per senone, CP DEPENDENT log-add look-ups that
+ * start when the wave's last parameter has arrived; from global memory each link costs ~0.25 us while
+ * the model streams through the same L2, and the whole 58 KB table in LDS costs half the resident waves.  The
+ * table is monotone and its values drop below 256 after ~9 k entries: 16-bit entries up to there and 8-bit ones
+ * beyond are 38 KB, four workgroups per CU still fit, and every link is an LDS read.
+ */
+template <int CP, bool EXACT>
+__global__ void __launch_bounds__(256)
+k_score_frame_sync(const float4 *__restrict__ mean4, const float4 *__restrict__ prec4,
+                   const float *__restrict__ lrd, const int32_t *__restrict__ mixw_g,
+                   const uint8_t *__restrict__ hyb_g, int32_t hyb_bytes, uint32_t head, uint32_t tab_size,
+                   int32_t lm_zero, double f, double distfloor, const float *__restrict__ feat, int32_t veclen,
+                   int32_t *__restrict__ senscr, int32_t S, int32_t Gpad)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t hyb_s[];
+    __shared__ __attribute__((aligned(16))) float xs[D4MAIN * 4];
+    typedef typename Acc<EXACT>::T acc_t;
+    const int32_t tid = threadIdx.x, lane = tid & 63;
+    const int32_t g = blockIdx.x * 256 + tid;
+    /* the lane's Gaussian first: the copies below run while these loads are in flight */
+    float4 M[D4MAIN], P[D4MAIN];
+#pragma unroll
+    for (int k = 0; k < D4MAIN; k++) {
+        M[k] = mean4[(size_t)k * Gpad + g];
+        P[k] = prec4[(size_t)k * Gpad + g];
+    }
+    const acc_t lrd_g = (acc_t)lrd[g];
+    const int32_t mixw = mixw_g[g];
+    {
+        /* <= HYB_MAX_PIECES 16-byte pieces per lane: all loads in flight, then the LDS writes (a load / wait /
+         * write loop costs a round trip per piece) */
+        const int32_t n16 = hyb_bytes / 16;
+        uint4 piece[HYB_MAX_PIECES];
+#pragma unroll
+        for (int q = 0; q < HYB_MAX_PIECES; q++)
+            piece[q] = (tid + q * 256 < n16) ? ((const uint4 *)hyb_g)[tid + q * 256] : make_uint4(0, 0, 0, 0);
+        const float xv = (tid < D4MAIN * 4 && tid < veclen) ? feat[tid] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < HYB_MAX_PIECES; q++)
+            if (tid + q * 256 < n16) ((uint4 *)hyb_s)[tid + q * 256] = piece[q];
+        if (tid < D4MAIN * 4) xs[tid] = xv;
+    }
+    __syncthreads();
+    acc_t a = lrd_g;
+    const float4 *xs4 = (const float4 *)xs;
+#pragma unroll
+    for (int k = 0; k < D4MAIN; k++) {
+        const float4 x = xs4[k];
+        a = Acc<EXACT>::step(a, x.x, M[k].x, P[k].x);
+        a = Acc<EXACT>::step(a, x.y, M[k].y, P[k].y);
+        a = Acc<EXACT>::step(a, x.z, M[k].z, P[k].z);
+        a = Acc<EXACT>::step(a, x.w, M[k].w, P[k].w);
+    }
+    const int32_t gs = gau_to_int((double)a, f, distfloor, mixw);
+    const int32_t c = lane & (CP - 1), sl = lane / CP, sen = g / CP;
+    const uint16_t *head_s = (const uint16_t *)hyb_s;
+    const uint8_t *tail_s = hyb_s + (size_t)head * 2;
+    int32_t score = S3A_LOGPROB_ZERO;
+#pragma unroll
+    for (int cc = 0; cc < CP; cc++) {
+        const int32_t y = __shfl(gs, sl * CP + cc, 64), x = score;
+        /* logmath_add (logmath.c:391-436) on the repacked table */
+        if (x <= lm_zero) { score = y; continue; }
+        if (y <= lm_zero) continue;
+        const int32_t hi = x > y ? x : y, lo = x > y ? y : x;
+        const uint32_t d = (uint32_t)hi - (uint32_t)lo;
+        if (d >= tab_size) { score = hi; continue; }
+        score = hi + (d < head ? (int32_t)head_s[d] : (int32_t)tail_s[d - head]);
+    }
+    if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
+    if (c == 0 && sen < S)
+        senscr[sen] = score;
 }
 
 /*
@@ -540,7 +639,26 @@ launch_score(const s3a_mgau_model_t *g, const float *feat_dev, int32_t feat_stri
 
     if (n_frames <= 0)
         return S3A_OK;
-    if (d->D4 == D4MAIN && d->tab16 != NULL) {
+    /* one frame, long mixtures: the pass whose tail is the senone's chain of look-ups (16+ links; with 8 the
+     * general kernel is as fast: 4.2 vs 4.4 us on the hub4 shape, 20.1 vs 17.0 us with 32) */
+    if (d->D4 == D4MAIN && d->tab16 != NULL && n_frames == 1 && d->hyb_ok && d->CP >= 16
+        && getenv("S3A_NO_FRAME_SYNC_KERNEL") == NULL) {
+        const dim3 grid(d->Gpad / 256);
+        const size_t lds = (size_t)d->hyb_bytes;
+#define S3A_FS(cp)                                                                                          \
+        case cp:                                                                                            \
+            if (exact) hipLaunchKernelGGL((k_score_frame_sync<cp, true>), grid, dim3(256), lds, st, d->mean4, d->prec4, d->lrd, \
+                           d->mixw, d->hyb_tab, d->hyb_bytes, (uint32_t)d->hyb_head, d->tab_size, d->lm_zero, g->f,       \
+                           g->distfloor, feat_dev, d->D, senscr_dev, d->S, d->Gpad);                        \
+            else hipLaunchKernelGGL((k_score_frame_sync<cp, false>), grid, dim3(256), lds, st, d->mean4, d->prec4, d->lrd, \
+                           d->mixw, d->hyb_tab, d->hyb_bytes, (uint32_t)d->hyb_head, d->tab_size, d->lm_zero, g->f,       \
+                           g->distfloor, feat_dev, d->D, senscr_dev, d->S, d->Gpad);                        \
+            break
+        switch (d->CP) { S3A_FS(1); S3A_FS(2); S3A_FS(4); S3A_FS(8); S3A_FS(16); S3A_FS(32); default: S3A_FS(64); }
+#undef S3A_FS
+        e = hipGetLastError();
+    }
+    else if (d->D4 == D4MAIN && d->tab16 != NULL) {
         int32_t nt = pick_nt();
         int32_t fpc = pick_fpc(d, n_frames, nt);
         /* the table is worth staging in LDS only if a workgroup does enough

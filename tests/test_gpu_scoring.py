@@ -128,6 +128,9 @@ def test_wsj_stress_shape_32_components(gpu_lib, olm):
     sc = gm.score_frames(fx, want_best=False)
     pick = [0, 7, 8, 39]
     assert np.array_equal(sc[pick], og.score_all(fx[pick]))
+    # one frame per call: the frame-synchronous kernel (split log-add table: LDS head + comparisons for the tail)
+    for k in range(40):
+        assert np.array_equal(gm.score_frames(fx[[k]], want_best=False)[0], sc[k]), k
 
 
 def test_fast_mode_within_stated_tolerance(gpu_lib, tid):
