@@ -304,6 +304,9 @@ def main():
                          "traffic_source": "profiles/r1j_prof_summary.txt (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(k_us, 2),
+                         "note": "one launch re-uses the 15.7 MB model for all 1000 frames, so HBM is not what binds "
+                                 "this kernel: the float64 vector pipe is (see valu); the HBM-bound regime of the "
+                                 "same scoring is frame_sync / frame_sync_wsj_shape below",
                          "valu": {"bound": "valu-f64", "achieved": round(tflops, 2),
                                   "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(tflops / FP64_VEC_PEAK_TFLOPS, 4),
