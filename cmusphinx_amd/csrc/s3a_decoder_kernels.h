@@ -872,25 +872,43 @@ d_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
              int32_t *n0,
         const int32_t BX, const int32_t BY)
 {
-    __shared__ int32_t total;
+    __shared__ int32_t s_ws[SCAN_THREADS / 64], s_chunk;
     const int32_t c = BX;
     const int32_t lo = calls[4 * c + 3], hi = (c + 1 < ent.n_calls) ? calls[4 * (c + 1) + 3] : n_ent;
     const int32_t n = hi - lo, roots = calls[4 * c + 2], in = calls[4 * c];
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (c == 0)
-        for (int32_t t = threadIdx.x; t < T; t += SCAN_THREADS) n0[t] = nnxt[t];
-    for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
-        const int32_t v = ent.rootlist[roots + i], scr = add32(in, prob[v]);
-        flag[lo + i] = (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
+        for (int32_t t = tid; t < T; t += SCAN_THREADS) n0[t] = nnxt[t];
+    /* one sweep: the entry's test (four gathers) once, its rank among the call's listed entries by a scan that
+     * never leaves registers / LDS, one store of (rank << 1 | listed) */
+    int32_t carry = 0;
+    for (int32_t c0 = 0; c0 < n; c0 += SCAN_THREADS) {
+        const int32_t i = c0 + tid;
+        int32_t q = 0;
+        if (i < n) {
+            const int32_t v = ent.rootlist[roots + i], scr = add32(in, prob[v]);
+            q = (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
+        }
+        const unsigned long long m = __ballot(q);
+        const int32_t below = __popcll(m & ((1ull << lane) - 1ull));   /* listed entries in front, this wave */
+        if (lane == 0) s_ws[wave] = __popcll(m);
+        __syncthreads();
+        if (wave == 0) {
+            const int32_t w = (lane < SCAN_THREADS / 64) ? s_ws[lane] : 0;
+            int32_t wi = w;
+#pragma unroll
+            for (int o = 1; o < SCAN_THREADS / 64; o <<= 1) {
+                const int32_t y = __shfl_up(wi, o, 64);
+                if (lane >= o) wi += y;
+            }
+            if (lane < SCAN_THREADS / 64) s_ws[lane] = wi - w;
+            if (lane == SCAN_THREADS / 64 - 1) s_chunk = wi;
+        }
+        __syncthreads();
+        if (i < n) flag[lo + i] = ((carry + s_ws[wave] + below) << 1) | q;
+        carry += s_chunk;
     }
-    __syncthreads();
-    block_exclusive_scan(flag + lo, n, &total);
-    __syncthreads();
-    for (int32_t i = threadIdx.x; i < n; i += SCAN_THREADS) {
-        const int32_t v = ent.rootlist[roots + i], scr = add32(in, prob[v]);
-        const int32_t q = (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
-        flag[lo + i] = (flag[lo + i] << 1) | q;
-    }
-    if (threadIdx.x == 0) ctot[c] = total;
+    if (tid == 0) ctot[c] = carry;
 }
 
 /* blocks [0, n_ent_blocks): write the listed roots to the next list (position = list length before
