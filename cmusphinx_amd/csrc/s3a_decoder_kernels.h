@@ -840,14 +840,25 @@ mark_node_senones(int32_t v, const int32_t *__restrict__ ssid, const uint8_t *__
 {
     const int32_t ss = ssid[v];
     if (comp[v]) {
+        /* the three states' member lists together, 8 members each per round (as in d_dec_hmm_eval): a round is
+         * one trip for 24 ids instead of three */
+        int32_t lo[3], hi[3];
+#pragma unroll
         for (int st = 0; st < 3; st++) {
             const int32_t cs = comsseq[ss * 3 + st];
-            for (int32_t j0 = cs_off[cs], jend = cs_off[cs + 1]; j0 < jend; j0 += 8) {
-                int32_t id[8];
+            lo[st] = cs_off[cs]; hi[st] = cs_off[cs + 1];
+        }
+        while (lo[0] < hi[0] || lo[1] < hi[1] || lo[2] < hi[2]) {
+            int32_t id[3][8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) id[u] = (j0 + u < jend) ? (int32_t)cs_list[j0 + u] : -1;
+            for (int st = 0; st < 3; st++)
 #pragma unroll
-                for (int u = 0; u < 8; u++) if (id[u] >= 0) sen_active[id[u]] = 1;
+                for (int u = 0; u < 8; u++) id[st][u] = (lo[st] + u < hi[st]) ? (int32_t)cs_list[lo[st] + u] : -1;
+#pragma unroll
+            for (int st = 0; st < 3; st++) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (id[st][u] >= 0) sen_active[id[st][u]] = 1;
+                lo[st] += 8;
             }
         }
     }
