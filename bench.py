@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 # HBM traffic of one whole-utterance launch of k_score_frames (1000 frames), from the PMC passes committed
-# as profiles/r1j_prof_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of this
+# as profiles/r1k_prof_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of this
 # very command): FETCH_SIZE 8838.3 KB x 2 (the guide's gfx950 correction for 16 B/lane streaming reads)
 # + WRITE_SIZE 24000 KB.  Algorithmic bytes are 40.46 MB: no re-reads to speak of.
 PMC_TRAFFIC_BYTES_PER_LAUNCH = int((2 * 8838.29 + 24000.0) * 1024)
@@ -301,7 +301,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if (T == 1000 and not args.fast) else None,
-                         "traffic_source": "profiles/r1j_prof_summary.txt (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
+                         "traffic_source": "profiles/r1k_prof_summary.txt (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(k_us, 2),
                          "note": "one launch re-uses the 15.7 MB model for all 1000 frames, so HBM is not what binds "
