@@ -1,27 +1,33 @@
 /*
- * oracle/ref_tst_shim.c -- TEST INFRASTRUCTURE: sphinx3_decode (mode 4, "fwdtree")
- * with the WHOLE per-frame hot path re-pointed at a replacement backend through the
- * reference's own srch_funcs_t table (sphinx3/include/srch.h:528-701).
+ * integration/sphinx3/s3amd_tst.c -- the sphinx3 side of the drop-in: sphinx3_decode (mode 4,
+ * "fwdtree") with the WHOLE per-frame hot path served by a replacement backend through the
+ * reference's own srch_funcs_t table (sphinx3/include/srch.h:528-701).  This is the file a
+ * sphinx3 maintainer adds; it is compiled against the unmodified reference
+ * where that lies (oracle/Makefile -> oracle/_ref/, never committed) and run as a test.
  *
- * Built twice from this one source (oracle/Makefile):
- *   -DLT_ORACLE  oracle/_ref/ref_s3olt_decode : lextree ops from the CPU oracle
- *                (oracle/s3o_lextree.c), scoring by the reference.  Runs without a GPU;
- *                identical -hyp/-hypseg to the unmodified reference PINS the oracle's
- *                lextree restatement (tests/test_oracle_lextree.py).
- *   (default)    oracle/_ref/ref_s3amd_tst_decode : senone scoring, composite senones,
- *                active-senone selection, HMM evaluation and phone-level propagation all
- *                on the MI355X through include/cmusphinx_amd.h; only the word level
- *                (vithist + LM) stays the reference's host code, fed by
- *                the compact word-exit lists.  Senone scores never leave HBM.
+ * Built four ways from this one source:
+ *   (default)            oracle/_ref/ref_s3amd_tst_decode : the MI355X backend (include/cmusphinx_amd.h).
+ *        S3A_UTT=L       whole utterances on the device, L at a time: senone scoring, lextree search AND the
+ *                        word level (trigram look-ups, Viterbi history, pruning, word transitions) run as
+ *                        kernels with no host synchronisation inside an utterance (the `decode` slot,
+ *                        srch.h:599-603, srch.c:673-675); the host reads the finished history table back,
+ *                        hands it to the reference's own vithist_utt_end / backtrace / output code.
+ *        (otherwise)     frame-synchronous: scoring + lextree search on the device, the reference's own
+ *                        vithist / LM on the host (one synchronisation per frame); S3A_STREAMS / S3A_BATCH.
+ *   -DLT_ORACLE          oracle/_ref/ref_s3olt_decode : lextree operations from the CPU oracle
+ *                        (oracle/s3o_lextree.c), everything else the reference.  No GPU; identical
+ *                        -hyp/-hypseg to the unmodified reference PINS that restatement.
+ *   -DLT_ORACLE -DWL_ORACLE   oracle/_ref/ref_s3owl_decode : additionally the word level from the CPU oracle
+ *                        (oracle/s3o_wordlevel.c); pins it the same way (tests/test_oracle_wordlevel.py)
+ *                        and records the per-frame word-level trace the device tests replay.
  *
- * What stays the reference's: kb_init (models, dictionary, LM, lextree_build, dict2pid),
- * feature computation, the frame loop srch_utt_decode_blk, vithist_*, lm_*, hypothesis
- * output.  The lextrees the reference built are FLATTENED once (flatten_tree) into the
- * node/CSR arrays both backends take; the reference's own lextree frame functions are
- * never called.  The replaced slots restate the control flow of
- * srch_time_switch_tree.c:457-560 (begin/end), :776-907 (hmm_compute_lv2),
- * :923-1007 (propagate_graph_ph_lv2), :1010-1210 (rescoring, word transitions),
- * :1213-1237 (frame_windup), :1262-1324 (select_active_gmm).
+ * What stays the reference's: kb_init (models, dictionary, LM, lextree_build, dict2pid), feature
+ * computation, the utterance API, hypothesis output (and, frame-synchronous mode, vithist_* / lm_*).
+ * The lextrees the reference built are FLATTENED once (flatten_tree) into the node/CSR arrays the
+ * backends take, its lm_t / dict_t into the plain arrays of s3a_lm3g_init / s3a_wordlevel_init
+ * (flatten_lm).  The replaced slots restate the control flow of srch_time_switch_tree.c:457-560
+ * (begin/end), :776-907 (hmm_compute_lv2), :923-1007 (propagate_graph_ph_lv2), :1010-1210 (rescoring,
+ * word transitions), :1213-1237 (frame_windup), :1262-1324 (select_active_gmm).
  */
 #define main sphinx3_decode_reference_main
 #include "main_decode.c"        /* the reference's file, in place (for its arg table) */
@@ -33,6 +39,7 @@
 #include "srch_time_switch_tree.c"
 
 #include <string.h>
+#include "byteorder.h"
 #include "srch.h"
 #include "gmm_wrap.h"
 #include "dict2pid.h"
@@ -95,7 +102,6 @@ flatten_tree(lextree_t *lt)
     flat_t *f = ckd_calloc(1, sizeof(*f));
     int32 cap = lt->n_node + 16, n = 0, head = 0, i, j, nchild = 0;
     lextree_node_t **q = ckd_calloc(cap, sizeof(*q));
-    lextree_node_t **seen;
     gnode_t *gn;
     (void)cmp_ptr;
 
@@ -125,8 +131,6 @@ flatten_tree(lextree_t *lt)
             }
         }
     }
-    (void)seen;
-    ckd_free(seen);
     f->n_node = n;
     f->node = q;
     g_pmap = ckd_calloc(n, sizeof(pmap_t));
@@ -183,6 +187,138 @@ flatten_tree(lextree_t *lt)
 }
 
 /* ------------------------------------------------------------------ */
+/* flattening lm_t / dict_t for the word level                         */
+/* ------------------------------------------------------------------ */
+/* The trigram as plain sorted arrays (what lm_3g_dmp.c's DMP layout already is, with the prob /
+ * back-off indirections resolved and the segment-relative firsttg made absolute), and the few
+ * per-word facts the word level reads from dict_t / fillpen_t / mdef_t.  "No LM word" = -1. */
+typedef struct {
+    int32 n_ug, n_bg, n_tg;
+    int32 *ug_prob, *ug_bowt, *ug_firstbg, *bg_wid, *bg_prob, *bg_bowt, *bg_firsttg, *tg_wid, *tg_prob;
+    int32 *inclass;
+    int32 n_word, n_ci, *lwid, *fillpen, *last_ci;
+    uint8 *is_filler;
+    int32 startwid, finishwid, silwid, start_lwid, finish_lwid;
+} wl_flat_t;
+
+static wl_flat_t *
+flatten_lm(kbcore_t *kbc)
+{
+    lm_t *lm = kbcore_lm(kbc);
+    dict_t *d = kbcore_dict(kbc);
+    mdef_t *mdef = kbcore_mdef(kbc);
+    wl_flat_t *f = ckd_calloc(1, sizeof(*f));
+    int32 i, w;
+    bg_t *bg = NULL; bg32_t *bg32 = NULL; tg_t *tg = NULL; tg32_t *tg32 = NULL;
+    int own = 0;
+
+    f->n_ug = lm->n_ug;
+    f->n_bg = (lm->ugonly) ? 0 : lm->n_bg;
+    f->n_tg = (lm->ugonly || lm->bgonly) ? 0 : lm->n_tg;
+    f->ug_prob = ckd_calloc(lm->n_ug + 1, 4); f->ug_bowt = ckd_calloc(lm->n_ug + 1, 4);
+    f->ug_firstbg = ckd_calloc(lm->n_ug + 1, 4);
+    for (i = 0; i < lm->n_ug; i++) { f->ug_prob[i] = lm->ug[i].prob.l; f->ug_bowt[i] = lm->ug[i].bowt.l; }
+    for (i = 0; i <= lm->n_ug; i++) f->ug_firstbg[i] = f->n_bg ? lm->ug[i].firstbg : 0;
+    if (f->n_bg) {
+        /* the bigram / trigram records: in memory, or (disk-based DMP, lm.c:1073-1127, 1476-1520) read here */
+        if (lm->is32bits) { bg32 = lm->bg32; tg32 = lm->tg32; } else { bg = lm->bg; tg = lm->tg; }
+        if ((lm->is32bits ? (void *)bg32 : (void *)bg) == NULL) {
+            size_t sz = lm->is32bits ? sizeof(bg32_t) : sizeof(bg_t);
+            void *buf = ckd_calloc(lm->n_bg + 1, sz);
+            own = 1;
+            if (!lm->fp || fseek(lm->fp, lm->bgoff, SEEK_SET) < 0 || fread(buf, sz, lm->n_bg + 1, lm->fp) != (size_t)(lm->n_bg + 1))
+                E_FATAL("tst shim: cannot read the bigrams of a disk-based LM\n");
+            if (lm->is32bits) bg32 = buf; else bg = buf;
+            if (lm->byteswap)
+                for (i = 0; i <= lm->n_bg; i++) {
+                    if (lm->is32bits) { SWAP_INT32(&bg32[i].wid); SWAP_INT32(&bg32[i].probid); SWAP_INT32(&bg32[i].bowtid); SWAP_INT32(&bg32[i].firsttg); }
+                    else { SWAP_INT16(&bg[i].wid); SWAP_INT16(&bg[i].probid); SWAP_INT16(&bg[i].bowtid); SWAP_INT16(&bg[i].firsttg); }
+                }
+            if (f->n_tg) {
+                sz = lm->is32bits ? sizeof(tg32_t) : sizeof(tg_t);
+                buf = ckd_calloc(lm->n_tg + 1, sz);
+                if (fseek(lm->fp, lm->tgoff, SEEK_SET) < 0 || fread(buf, sz, lm->n_tg, lm->fp) != (size_t)lm->n_tg)
+                    E_FATAL("tst shim: cannot read the trigrams of a disk-based LM\n");
+                if (lm->is32bits) tg32 = buf; else tg = buf;
+                if (lm->byteswap)
+                    for (i = 0; i < lm->n_tg; i++) {
+                        if (lm->is32bits) { SWAP_INT32(&tg32[i].wid); SWAP_INT32(&tg32[i].probid); }
+                        else { SWAP_INT16(&tg[i].wid); SWAP_INT16(&tg[i].probid); }
+                    }
+            }
+        }
+        f->bg_wid = ckd_calloc(lm->n_bg + 1, 4); f->bg_prob = ckd_calloc(lm->n_bg + 1, 4);
+        f->bg_bowt = ckd_calloc(lm->n_bg + 1, 4); f->bg_firsttg = ckd_calloc(lm->n_bg + 1, 4);
+        for (i = 0; i < lm->n_bg; i++) {
+            f->bg_wid[i] = lm->is32bits ? (int32)bg32[i].wid : (int32)bg[i].wid;
+            f->bg_prob[i] = lm->bgprob[lm->is32bits ? bg32[i].probid : bg[i].probid].l;
+            if (f->n_tg) f->bg_bowt[i] = lm->tgbowt[lm->is32bits ? bg32[i].bowtid : bg[i].bowtid].l;
+        }
+        if (f->n_tg) {
+            /* load_tg, lm.c:1435-1443: absolute first trigram = tg_segbase[b >> log_bg_seg_sz] + firsttg */
+            for (i = 0; i <= lm->n_bg; i++)
+                f->bg_firsttg[i] = lm->tg_segbase[i >> lm->log_bg_seg_sz]
+                    + (lm->is32bits ? (int32)bg32[i].firsttg : (int32)bg[i].firsttg);
+            f->tg_wid = ckd_calloc(lm->n_tg + 1, 4); f->tg_prob = ckd_calloc(lm->n_tg + 1, 4);
+            for (i = 0; i < lm->n_tg; i++) {
+                f->tg_wid[i] = lm->is32bits ? (int32)tg32[i].wid : (int32)tg[i].wid;
+                f->tg_prob[i] = lm->tgprob[lm->is32bits ? tg32[i].probid : tg[i].probid].l;
+            }
+        }
+        if (own) { ckd_free(lm->is32bits ? (void *)bg32 : (void *)bg); ckd_free(lm->is32bits ? (void *)tg32 : (void *)tg); }
+    }
+    f->n_word = dict_size(d);
+    f->n_ci = mdef_n_ciphone(mdef);
+    f->lwid = ckd_calloc(f->n_word + 1, 4); f->fillpen = ckd_calloc(f->n_word + 1, 4);
+    f->last_ci = ckd_calloc(f->n_word + 1, 4); f->is_filler = ckd_calloc(f->n_word + 1, 1);
+    if (lm->inclass_ugscore) {
+        f->inclass = ckd_calloc(f->n_word + 1, 4);
+        for (w = 0; w < f->n_word; w++) f->inclass[w] = lm->inclass_ugscore[w];
+    }
+    for (w = 0; w < f->n_word; w++) {
+        int32 p = dict_last_phone(d, w);
+        f->lwid[w] = IS_LMWID(lm, lm->dict2lmwid[w]) && lm->dict2lmwid[w] < (s3lmwid32_t)lm->n_ug ? (int32)lm->dict2lmwid[w] : -1;
+        f->is_filler[w] = dict_filler_word(d, w) ? 1 : 0;
+        if (f->is_filler[w]) f->fillpen[w] = fillpen(kbcore_fillpen(kbc), w);
+        f->last_ci[w] = mdef_is_fillerphone(mdef, p) ? mdef_silphone(mdef) : p;
+    }
+    f->startwid = dict_startwid(d); f->finishwid = dict_finishwid(d); f->silwid = dict_silwid(d);
+    f->start_lwid = IS_LMWID(lm, lm_startwid(lm)) ? (int32)lm_startwid(lm) : -1;
+    f->finish_lwid = IS_LMWID(lm, lm_finishwid(lm)) ? (int32)lm_finishwid(lm) : -1;
+    E_INFO("tst shim: LM flattened: %d unigrams, %d bigrams, %d trigrams; %d dictionary words\n",
+           f->n_ug, f->n_bg, f->n_tg, f->n_word);
+    return f;
+}
+
+/* a finished history table -> the reference's vithist_t (which srch_TST_begin left holding the dummy
+ * <s> entry 0), so that the reference's own vithist_utt_end, backtrace, DAG and output code run on it
+ * unchanged.  Blocks are allocated as vithist_entry_alloc (vithist.c:268-294, static there) does. */
+static void
+vithist_fill(vithist_t *vh, int32 n_entry, int32 n_frm, const int32 *score, const int32 *pred, const int32 *lw0,
+             const int32 *lw1, const int32 *wid, const int32 *sf, const int32 *ef, const int32 *ascr,
+             const int32 *lscr, const int32 *type, const int32 *frame_start, const int32 *bestscore,
+             const int32 *bestvh, lm_t *lm)
+{
+    int32 id, f;
+    if (n_entry > VITHIST_MAXBLKS * VITHIST_BLKSIZE)
+        E_FATAL("Viterbi history array exhausted; increase VITHIST_MAXBLKS\n");
+    for (id = 0; id < n_entry; id++) {
+        vithist_entry_t *ve;
+        if (VITHIST_ID2BLKOFFSET(id) == 0 && vh->entry[VITHIST_ID2BLK(id)] == NULL)
+            vh->entry[VITHIST_ID2BLK(id)] = ckd_calloc(VITHIST_BLKSIZE, sizeof(vithist_entry_t));
+        ve = vithist_id2entry(vh, id);
+        ve->wid = wid[id]; ve->sf = sf[id]; ve->ef = ef[id]; ve->ascr = ascr[id]; ve->lscr = lscr[id];
+        ve->path.score = score[id]; ve->path.pred = pred[id]; ve->type = type[id]; ve->valid = 1;
+        ve->lmstate.lm3g.lwid[0] = lw0[id] < 0 ? BAD_LMWID(lm) : (s3lmwid32_t)lw0[id];
+        ve->lmstate.lm3g.lwid[1] = lw1[id] < 0 ? BAD_LMWID(lm) : (s3lmwid32_t)lw1[id];
+        ve->rc = NULL; ve->n_rc = 0;
+    }
+    vh->n_entry = n_entry;
+    vh->n_frm = n_frm;
+    for (f = 0; f <= n_frm; f++) { vh->frame_start[f] = frame_start[f]; vh->bestscore[f] = bestscore[f]; vh->bestvh[f] = bestvh[f]; }
+}
+
+/* ------------------------------------------------------------------ */
 /* backend                                                             */
 /* ------------------------------------------------------------------ */
 static __thread int32 g_ntree;           /* 2 * n_lextree: unigram trees then filler trees */
@@ -234,6 +370,33 @@ static void die(const char *w) { E_FATAL("tst shim: %s: %s\n", w, s3a_last_error
  * tests replay.  Record = {tag, n, n x int32}. */
 static __thread FILE *g_trace;
 static __thread int g_trace_utt;
+#ifdef WL_ORACLE
+/* the word level from oracle/s3o_wordlevel.c, and (env S3O_WLTRACE=file) a record of what it consumed and
+ * produced in every frame of the FIRST utterance: tests/golden/make_golden.py turns it into the fixture the
+ * device word level replays.  Record = {tag, n, n x int32}. */
+static __thread wl_flat_t *g_wl;
+static __thread s3o_lm3g_t g_olm;
+static __thread s3o_wdict_t g_od;
+static __thread s3o_vithist_t *g_ovh;
+static __thread FILE *g_wltrace;
+static void
+wtr(int32 tag, int32 n, const void *data)
+{
+    if (!g_wltrace) return;
+    fwrite(&tag, 4, 1, g_wltrace); fwrite(&n, 4, 1, g_wltrace);
+    if (n) fwrite(data, 4, n, g_wltrace);
+}
+static void
+wtr8(int32 tag, int32 n, const uint8 *d)
+{
+    int32 i, *w;
+    if (!g_wltrace) return;
+    w = ckd_calloc(n + 1, 4);
+    for (i = 0; i < n; i++) w[i] = d[i];
+    wtr(tag, n, w);
+    ckd_free(w);
+}
+#endif
 static void
 tr(int32 tag, int32 n, const void *data)
 {
@@ -367,6 +530,32 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
                                    f->child_off, f->child, f->n_lc, f->lc, f->lcroot_off, f->lcroot,
                                    f->n_root, f->root, ne, g_tp_flat, g_sseq_flat, g_comsseq_flat);
     }
+#ifdef WL_ORACLE
+    {
+        wl_flat_t *w = g_wl = flatten_lm(kbc);
+        vithist_t *vh = tstg->vithist;
+        g_olm.n_ug = w->n_ug; g_olm.n_bg = w->n_bg; g_olm.n_tg = w->n_tg;
+        g_olm.ug_prob = w->ug_prob; g_olm.ug_bowt = w->ug_bowt; g_olm.ug_firstbg = w->ug_firstbg;
+        g_olm.bg_wid = w->bg_wid; g_olm.bg_prob = w->bg_prob; g_olm.bg_bowt = w->bg_bowt; g_olm.bg_firsttg = w->bg_firsttg;
+        g_olm.tg_wid = w->tg_wid; g_olm.tg_prob = w->tg_prob; g_olm.inclass = w->inclass;
+        g_od.n_word = w->n_word; g_od.n_ci = w->n_ci; g_od.lwid = w->lwid; g_od.is_filler = w->is_filler;
+        g_od.fillpen = w->fillpen; g_od.last_ci = w->last_ci; g_od.startwid = w->startwid;
+        g_od.finishwid = w->finishwid; g_od.silwid = w->silwid; g_od.start_lwid = w->start_lwid;
+        g_od.finish_lwid = w->finish_lwid;
+        g_ovh = s3o_vithist_init(1 << 22, S3_MAX_FRAMES, vh->wbeam, vh->bghist);
+        if (getenv("S3O_WLTRACE") && (g_wltrace = fopen(getenv("S3O_WLTRACE"), "wb")) != NULL) {
+            int32 hdr[16] = { w->n_ug, w->n_bg, w->n_tg, w->n_word, w->n_ci, w->startwid, w->finishwid, w->silwid,
+                              w->start_lwid, w->finish_lwid, vh->wbeam, vh->bghist, tstg->histprune->maxwpf,
+                              tstg->histprune->maxhistpf, tstg->n_lextree, tstg->epl };
+            wtr(1, 16, hdr);
+            wtr(2, w->n_ug, w->ug_prob); wtr(3, w->n_ug, w->ug_bowt); wtr(4, w->n_ug + 1, w->ug_firstbg);
+            wtr(5, w->n_bg, w->bg_wid); wtr(6, w->n_bg, w->bg_prob); wtr(7, w->n_bg, w->bg_bowt);
+            wtr(8, w->n_bg ? w->n_bg + 1 : 0, w->bg_firsttg); wtr(9, w->n_tg, w->tg_wid); wtr(10, w->n_tg, w->tg_prob);
+            wtr(11, w->n_word, w->lwid); wtr8(12, w->n_word, w->is_filler); wtr(13, w->n_word, w->fillpen);
+            wtr(14, w->n_word, w->last_ci);
+        }
+    }
+#endif
 #else
     {
         cmd_ln_t *config = kbcore_config(kbc);
@@ -496,6 +685,9 @@ tst_begin(void *srch)
     vithist_utt_reset(tstg->vithist);
     histprune_zero_histbin(tstg->histprune);
     pred = vithist_utt_begin(tstg->vithist, kbc);
+#ifdef WL_ORACLE
+    s3o_vithist_utt_begin(g_ovh, g_od.startwid, g_od.start_lwid);
+#endif
     if (g)
         for (i = 0; i < g->n_mgau; i++) { g->mgau[i].bstidx = NO_BSTIDX; g->mgau[i].updatetime = NOT_UPDATED; }
 #ifndef LT_ORACLE
@@ -519,6 +711,13 @@ tst_end(void *srch)
     srch_TST_graph_t *tstg = s->grh->graph_struct;
     int32 t;
     g_t_utt += now_s();
+#ifdef WL_ORACLE
+    if (g_ovh->overflow) E_FATAL("tst shim: the oracle's history table overflowed\n");
+    vithist_fill(tstg->vithist, g_ovh->n_entry, g_ovh->n_frm, g_ovh->score, g_ovh->pred, g_ovh->lw0, g_ovh->lw1,
+                 g_ovh->wid, g_ovh->sf, g_ovh->ef, g_ovh->ascr, g_ovh->lscr, g_ovh->type, g_ovh->frame_start,
+                 g_ovh->bestscore, g_ovh->bestvh, kbcore_lm(s->kbc));
+    if (g_wltrace) { int32 z = 0; wtr(99, 1, &z); fclose(g_wltrace); g_wltrace = NULL; }
+#endif
     s->exit_id = vithist_utt_end(tstg->vithist, s->kbc);
     s->stat->utt_wd_exit = vithist_n_entry(tstg->vithist);
     histprune_showhistbin(tstg->histprune, s->stat->nfr, s->uttid);
@@ -731,6 +930,33 @@ tst_word_trans(srch_t *s, int32 cf)
     be_enter(tstg->n_lextree + k, 1, c_lc, c_scr, c_hist, cf, th);
 }
 
+#ifdef WL_ORACLE
+static void
+tst_word_trans_oracle(srch_t *s, int32 cf)
+{
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    beam_t *bm = s->beam;
+    int32 th = bm->bestscore + bm->hmm, n, k, fscr, fhist, lcb = BAD_S3CIPID;
+    static __thread int32 *c_lc, *c_scr, *c_hist;
+    const int32 fs = g_ovh->frame_start[cf], ne = g_ovh->n_entry - fs;
+    if (!c_lc) { c_lc = ckd_calloc(g_od.n_ci + 1, 4); c_scr = ckd_calloc(g_od.n_ci + 1, 4); c_hist = ckd_calloc(g_od.n_ci + 1, 4); }
+    n = s3o_word_trans(g_ovh, &g_od, cf, bm->wordend, c_lc, c_scr, c_hist, &fscr, &fhist);
+    {   /* the frame's surviving entries and its lextree_enter calls */
+        int32 hdr[6] = { cf, ne, n, g_ovh->bestscore[cf], g_ovh->bestvh[cf], th };
+        wtr(30, 6, hdr);
+        wtr(31, ne, g_ovh->wid + fs); wtr(32, ne, g_ovh->score + fs); wtr(33, ne, g_ovh->pred + fs);
+        wtr(34, ne, g_ovh->lw0 + fs); wtr(35, ne, g_ovh->lw1 + fs); wtr(36, ne, g_ovh->ascr + fs);
+        wtr(37, ne, g_ovh->lscr + fs); wtr(38, ne, g_ovh->sf + fs); wtr(39, ne, g_ovh->type + fs);
+        if (n > 0) { wtr(40, n, c_lc); wtr(41, n, c_scr); wtr(42, n, c_hist); }
+    }
+    if (n < 0) return;
+    k = tstg->n_lextrans++;
+    k = (k % (tstg->n_lextree * tstg->epl)) / tstg->epl;
+    be_enter(k, n, c_lc, c_scr, c_hist, cf, th);
+    be_enter(tstg->n_lextree + k, 1, &lcb, &fscr, &fhist, cf, th);
+}
+#endif
+
 static int
 tst_propagate_wd_lv2(void *srch, int32 frmno)
 {
@@ -752,11 +978,31 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
             tr(72, g_exit_n[t], g_exit_scr + t * g_max_node); tr(73, g_exit_n[t], g_exit_hist + t * g_max_node);
         }
     }
+#ifdef WL_ORACLE
+    {
+        int32 hdr[4] = { frmno, 0, s->beam->word_thres - s->beam->bestwordscore, s->beam->bestscore + s->beam->hmm };
+        for (t = 0; t < g_ntree; t++) hdr[1] += g_exit_n[t];
+        wtr(20, 4, hdr);
+        for (t = 0; t < g_ntree; t++) {
+            int32 ty = g_flat[t]->type;
+            wtr(21, 1, &ty); wtr(22, g_exit_n[t], g_exit_wid + t * g_max_node);
+            wtr(23, g_exit_n[t], g_exit_scr + t * g_max_node); wtr(24, g_exit_n[t], g_exit_hist + t * g_max_node);
+        }
+    }
+    for (t = 0; t < g_ntree; t++)
+        for (i = 0; i < g_exit_n[t]; i++)
+            if (s3o_vithist_rescore(g_ovh, &g_olm, &g_od, g_exit_wid[t * g_max_node + i], frmno,
+                                    g_exit_scr[t * g_max_node + i], g_exit_hist[t * g_max_node + i],
+                                    g_flat[t]->type) < 0)
+                E_FATAL("Hmm->out.history equals to -1 with score %d, some active phone was not computed?\n",
+                        g_exit_scr[t * g_max_node + i]);
+#else
     for (t = 0; t < g_ntree; t++)
         for (i = 0; i < g_exit_n[t]; i++)
             vithist_rescore(vh, s->kbc, g_exit_wid[t * g_max_node + i], frmno,
                             g_exit_scr[t * g_max_node + i], g_exit_hist[t * g_max_node + i],
                             g_flat[t]->type, -1);
+#endif
 #else
     {
         s3a_frame_result_t r;
@@ -801,9 +1047,16 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
 #endif
     {
         double t1 = now_s();
+#ifdef WL_ORACLE
+        (void)vh;
+        s3o_vithist_prune(g_ovh, &g_od, frmno, hp->maxwpf, hp->maxhistpf,
+                          s->beam->word_thres - s->beam->bestwordscore, NULL);
+        tst_word_trans_oracle(s, frmno);
+#else
         vithist_prune(vh, kbcore_dict(s->kbc), frmno, hp->maxwpf, hp->maxhistpf,
                       s->beam->word_thres - s->beam->bestwordscore);
         tst_word_trans(s, frmno);
+#endif
         g_t_word += now_s() - t1;
     }
     return SRCH_SUCCESS;
@@ -815,6 +1068,9 @@ tst_frame_windup(void *srch, int32 frmno)
     srch_t *s = srch;
     srch_TST_graph_t *tstg = s->grh->graph_struct;
     vithist_frame_windup(tstg->vithist, frmno, NULL, s->kbc);
+#ifdef WL_ORACLE
+    s3o_vithist_frame_windup(g_ovh, frmno);
+#endif
     be_swap(frmno);
 #ifdef LT_ORACLE
     if (g_trace) trace_state(80);

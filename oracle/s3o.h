@@ -205,6 +205,55 @@ void s3o_comsseq2sen_active(const int16_t *comsseq, int32_t n_comsseq, int32_t n
 void s3o_lextree_utt_end(s3o_lextree_t *lt);
 
 /* ------------------------------------------------------------------ */
+/* the word level of mode 4 (s3o_wordlevel.c): trigram look-up,         */
+/* Viterbi history, word transitions                                    */
+/* liblm/lm.c:983-1833, libsearch/vithist.c:300-860,1066-1100,          */
+/* libsearch/srch_time_switch_tree.c:1086-1179, sphinxbase util/heap.c  */
+/* ------------------------------------------------------------------ */
+/* lm_t flattened: probabilities / back-off weights already dereferenced (bgprob[probid] ...)
+ * and language-weighted as lm_set_param left them; bigrams of unigram w = [ug_firstbg[w],
+ * ug_firstbg[w+1]), trigrams of bigram b = [bg_firsttg[b], bg_firsttg[b+1]) (absolute). */
+typedef struct s3o_lm3g_s {
+    int32_t n_ug, n_bg, n_tg;
+    const int32_t *ug_prob, *ug_bowt, *ug_firstbg;              /* [n_ug], [n_ug], [n_ug + 1] */
+    const int32_t *bg_wid, *bg_prob, *bg_bowt, *bg_firsttg;      /* [n_bg] x 3, [n_bg + 1] */
+    const int32_t *tg_wid, *tg_prob;                            /* [n_tg] */
+    const int32_t *inclass;                                     /* per dictionary word, or NULL */
+} s3o_lm3g_t;
+int32_t s3o_lm_bg_score(const s3o_lm3g_t *lm, int32_t lw1, int32_t lw2, int32_t wid);
+int32_t s3o_lm_tg_score(const s3o_lm3g_t *lm, int32_t lw1, int32_t lw2, int32_t lw3, int32_t wid);
+
+/* what the word level reads of dict_t / fillpen_t / mdef_t, per dictionary word id */
+typedef struct s3o_wdict_s {
+    int32_t n_word, n_ci;
+    const int32_t *lwid;        /* lm->dict2lmwid[w] (negative: none) */
+    const uint8_t *is_filler;   /* dict_filler_word */
+    const int32_t *fillpen;     /* fillpen(kbcore_fillpen, w) for filler words */
+    const int32_t *last_ci;     /* dict_last_phone, filler phones mapped to mdef_silphone */
+    int32_t startwid, finishwid, silwid, start_lwid, finish_lwid;
+} s3o_wdict_t;
+
+typedef struct s3o_vithist_s {
+    int32_t cap, max_frames, n_entry, n_frm, wbeam, bghist, overflow;
+    int32_t *score, *pred, *lw0, *lw1, *wid, *sf, *ef, *ascr, *lscr, *type;
+    uint8_t *valid;
+    int32_t *frame_start, *bestscore, *bestvh;
+} s3o_vithist_t;
+
+s3o_vithist_t *s3o_vithist_init(int32_t cap, int32_t max_frames, int32_t wbeam, int32_t bghist);
+void s3o_vithist_free(s3o_vithist_t *vh);
+void s3o_vithist_utt_begin(s3o_vithist_t *vh, int32_t startwid, int32_t start_lwid);
+int32_t s3o_vithist_rescore(s3o_vithist_t *vh, const s3o_lm3g_t *lm, const s3o_wdict_t *d, int32_t wid,
+                            int32_t ef, int32_t score, int32_t pred, int32_t type);
+void s3o_vithist_prune(s3o_vithist_t *vh, const s3o_wdict_t *d, int32_t frm, int32_t maxwpf,
+                       int32_t maxhist, int32_t beam, int32_t *order_out);
+void s3o_vithist_frame_windup(s3o_vithist_t *vh, int32_t frm);
+int32_t s3o_word_trans(const s3o_vithist_t *vh, const s3o_wdict_t *d, int32_t cf, int32_t wordend_beam,
+                       int32_t *lc, int32_t *scr, int32_t *hist, int32_t *fill_scr, int32_t *fill_hist);
+int32_t s3o_vithist_utt_end(s3o_vithist_t *vh, const s3o_lm3g_t *lm, const s3o_wdict_t *d);
+int32_t s3o_vithist_backtrace(const s3o_vithist_t *vh, int32_t id, int32_t *ids, int32_t max_ids);
+
+/* ------------------------------------------------------------------ */
 /* multi-stream senone scorer (-senmgau .s3cont. / .semi.)             */
 /* sphinx3 libam/ms_gauden.c, ms_senone.c, ms_mgau.c                   */
 /* ------------------------------------------------------------------ */
