@@ -1,0 +1,856 @@
+/*
+ * s3a_utt.hip -- WHOLE UTTERANCES on the device: the `decode` slot of srch_funcs_t
+ * (sphinx3/include/srch.h:599-603; srch.c:673-675 hands the whole block to it).
+ *
+ * One engine = one acoustic model, one set of lextrees, one trigram, L decoder LANES.  A lane
+ * decodes one utterance from its first to its last frame without the host: per frame the
+ * lextree_enter calls of the previous frame, the senone marks, CI + gated CD senone scoring,
+ * HMM evaluation, histogram pruning, phone-level propagation, the ordered compaction of the
+ * next active list and of the word exits (the kernel bodies of s3a_decoder_kernels.h /
+ * s3a_gated.h: the very code of the frame-synchronous path) and then the WORD LEVEL
+ * (s3a_wordlevel.h: trigram look-ups, Viterbi history, pruning, word transitions), which
+ * leaves the next frame's lextree_enter calls in device memory.  Everything a frame needs to
+ * know about the previous one lives in HBM (UCtx), so the host only ENQUEUES: L lanes share
+ * every launch (grid z), there is no synchronisation inside an utterance, and the kernels'
+ * grids are fixed (virtual workgroups looped over the list lengths found in memory) so that the
+ * per-frame launch sequence is the same for every frame.  At the end the host reads each lane's
+ * history table back; the reference's own vithist_utt_end / backtrace (or s3a_uttdec_hyp) turn
+ * it into the hypothesis.
+ *
+ * Parity: tests/test_gpu_wordlevel.py (the word level against the oracle, frame by frame, on
+ * recorded RM1 / tidigits traces and on random frames with tied scores) and
+ * tests/test_gpu_dropin.py (S3A_UTT: -hyp / -hypseg byte-identical to the unmodified reference).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <vector>
+
+#include "s3a_device.h"
+#include "s3a_structs.h"
+#include "s3a_decoder_kernels.h"
+#include "s3a_gated.h"
+#include "s3a_wordlevel.h"
+
+/* one lane: the lextree state of a clone, a private scorer state, its history table */
+struct ULane {
+    /* lextree state */
+    int32_t *sc, *hist, *outs, *outh, *bests, *frame, *pos, *posf, *act[2], *nact[2], *turn, *selfemit, *cnt, *base,
+        *best, *exits, *nexit, *first, *eflag, *hbin, *done, *ctot, *n0, *pstamp, *propf, *poswid, *posout, *scan_flag;
+    unsigned long long *scan_agg, *scan_pre, *key;
+    /* scorer state */
+    uint8_t *sen_act;
+    int32_t *scr, *misc, *bstidx, *bstscr, *updatetime, *gpart;
+    /* this utterance */
+    const float *feat;          /* [nfr][D4 * 4] */
+    UCtx *ctx;
+    int32_t *pack;
+    WLane w;
+};
+
+/* what every lane shares */
+struct UShared {
+    int32_t N, T, n_tmat, maxn, n_rootnodes, scan_chunks, pack_max_exits, gp_n;
+    const int32_t *node_base, *ssid, *tmatid, *wid, *prob, *child_off, *child, *par_off, *par, *tree_of, *rootlist, *tp,
+        *rootnodes, *ps, *psof_off, *psof, *cs_off, *cs_wt;
+    const uint8_t *comp;
+    const int16_t *sseq, *comsseq, *cs_list;
+    const float4 *mean4, *prec4;
+    const float *lrd;
+    const int32_t *mixw;
+    const uint16_t *tab16;
+    uint32_t tab_size;
+    int32_t lm_zero;
+    double f, distfloor;
+    int32_t D4, CP, Gpad, n_sen, n_ci_sen;
+    const uint8_t *ncomp;
+    const int16_t *cd2cisen;
+    int32_t ds_ratio, ci_pbeam, ci_pbeam_tight, ptranskip;
+    FrameBeams bm;              /* phone_uses_wbeam is worked out per frame */
+};
+
+#define LANE const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; if (!ctx->active) return
+
+__device__ __forceinline__ FrameBeams
+frame_beams(const UShared &S, int32_t cf)
+{
+    FrameBeams bm = S.bm;
+    bm.phone_uses_wbeam = (S.ptranskip != 0 && (cf % S.ptranskip) == 0) ? 1 : 0;   /* srch_time_switch_tree.c:975-1003 */
+    return bm;
+}
+
+/* ---- lextree_enter calls left by the previous frame's word level (or by utterance begin) ---- */
+__global__ void __launch_bounds__(256)
+ku_enter1(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    const int32_t n_ent = ctx->n_ent;
+    const Entries ent = { ctx->calls, S.rootlist, ctx->n_calls };
+    for (int32_t vb = blockIdx.x; vb * 256 < n_ent; vb += gridDim.x)
+        d_dec_enter1(ent, n_ent, ctx->calls, S.prob, L.sc, ctx->thresh, L.key, L.first, vb, 0);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+ku_enter2(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    if ((int32_t)blockIdx.x >= ctx->n_calls || ctx->n_ent == 0) return;
+    const Entries ent = { ctx->calls, S.rootlist, ctx->n_calls };
+    d_dec_enter2(ent, ctx->n_ent, ctx->calls, S.prob, L.sc, L.frame, L.first, ctx->thresh, ctx->cf, S.T,
+                 L.nact[ctx->cur], L.eflag, L.ctot, L.n0, blockIdx.x, 0);
+}
+
+__global__ void __launch_bounds__(M3BLOCK)
+ku_enter3_mark(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    const int32_t n_ent = ctx->n_ent, cur = ctx->cur;
+    const int32_t *n0 = n_ent > 0 ? L.n0 : L.nact[cur];
+    int32_t rows = 0;
+    for (int32_t t = 0; t < S.T; t++) rows = max(rows, n0[t]);
+    const int32_t n_ent_blocks = (n_ent + M3BLOCK - 1) / M3BLOCK, bpt = (rows + M3BLOCK - 1) / M3BLOCK;
+    const Entries ent = { ctx->calls, S.rootlist, ctx->n_calls };
+    for (int32_t vb = blockIdx.x; vb < n_ent_blocks + bpt * S.T; vb += gridDim.x)
+        d_dec_enter3_mark(n_ent_blocks, ent, n_ent, ctx->calls, ctx->groups, ctx->n_groups, ctx->cf, L.key, L.first, L.eflag,
+                          L.ctot, n0, L.sc, L.hist, L.frame, S.T, bpt, S.node_base, L.act[cur], L.nact[cur], L.pos,
+                          L.posf, S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0);
+}
+
+/* ---- approx_cont_mgau_ci_eval / _frame_eval for the lane's frame (s3a_gated.h) ---- */
+template <bool EXACT, bool CI>
+__global__ void __launch_bounds__(256)
+ku_gated(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    const int32_t lo = CI ? 0 : S.n_ci_sen, hi = CI ? S.n_ci_sen : S.n_sen, cf = ctx->cf;
+    if ((int32_t)(blockIdx.x * 256) >= (hi - lo) * S.CP) return;
+    const float *x = L.feat + (size_t)cf * S.D4 * 4;
+    const int32_t is_skip = (cf % S.ds_ratio == 0) ? 0 : 1;
+    const int32_t beam = is_skip ? S.ci_pbeam_tight : S.ci_pbeam;
+#define KU_GATED_ARGS S.mean4, S.prec4, S.lrd, S.mixw, S.tab16, S.tab_size, S.lm_zero, S.f, S.distfloor, x, S.D4, S.CP,  \
+        S.Gpad, lo, hi, CI ? 1 : 0, S.ncomp, S.cd2cisen, L.sen_act, L.scr, 0, CI ? (const int32_t *)NULL : L.misc + 5,     \
+        CI ? 0 : beam, cf, CI ? 0 : is_skip, L.bstidx, L.bstscr, L.updatetime, L.misc, CI ? 5 : 0,                        \
+        CI ? (uint8_t *)NULL : L.sen_act, CI ? (int32_t *)NULL : L.gpart, S.gp_n
+    if (S.D4 == D4MAIN)
+        d_gated_frame<EXACT, D4MAIN>(KU_GATED_ARGS, blockIdx.x);
+    else
+        d_gated_frame<EXACT, 0>(KU_GATED_ARGS, blockIdx.x);
+}
+
+/* ---- lextree_hmm_eval ---- */
+template <int EB>
+__global__ void __launch_bounds__(EB)
+ku_hmm_eval(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    const int32_t cur = ctx->cur, t = blockIdx.y, na = L.nact[cur][t];
+    for (int32_t vb = blockIdx.x; vb * EB < na; vb += gridDim.x) {
+        d_dec_hmm_eval<EB>(S.node_base, L.act[cur], L.nact[cur], S.N, S.n_tmat, S.ssid, S.tmatid, S.wid, S.comp, S.tp,
+                           S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt, L.scr, L.misc, L.sc, L.hist, L.outs, L.outh,
+                           L.bests, L.best, ctx->cf, S.psof_off, S.psof, L.pstamp, L.gpart, S.gp_n, L.poswid, L.posout,
+                           vb, t);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(DBLOCK)
+ku_hist_count(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    const int32_t cur = ctx->cur, t = blockIdx.y, na = L.nact[cur][t];
+    const FrameBeams bm = frame_beams(S, ctx->cf);
+    for (int32_t vb = blockIdx.x; vb * DBLOCK < na; vb += gridDim.x) {
+        d_dec_hist_count(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.best, L.bests, L.exits + S.N, L.hbin, -1, 0, 1,
+                         NBIN, vb, t);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+ku_hist_sort(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    const int32_t cur = ctx->cur;
+    d_dec_hist_sort(S.node_base, L.act[cur], L.nact[cur], S.T, frame_beams(S, ctx->cf), L.exits + S.N, L.exits, L.hbin,
+                    L.pos, -1, NBIN, blockIdx.x, 0);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+ku_weak(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    const FrameBeams bm = frame_beams(S, ctx->cf);
+    if (!(bm.phone_uses_wbeam || bm.pbeam < bm.hmmbeam)) return;
+    const int32_t cur = ctx->cur;
+    d_dec_weak(S.N, S.T, ctx->cf, bm, L.best, L.nact[cur], S.node_base, L.act[cur], S.prob, S.par_off, S.par, L.pos,
+               L.posf, L.sc, L.outs, L.bests, S.wid, L.hbin, L.propf, L.exits + 2 * (size_t)S.N, 0, 0);
+}
+
+__global__ void __launch_bounds__(RSBLOCK)
+ku_resolve(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    const int32_t cur = ctx->cur;
+    d_dec_resolve(S.N, S.T, ctx->cf, frame_beams(S, ctx->cf), L.best, L.nact[cur], S.node_base, S.tree_of, S.prob,
+                  S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
+                  L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
+                  blockIdx.x, 0);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC)
+{
+    LANE;
+    const int32_t cur = ctx->cur;
+    const FrameBeams bm = frame_beams(S, ctx->cf);
+    /* after a histogram reordering the position-indexed word ids / exit scores are stale */
+    int32_t n = 0;
+    for (int32_t t = 0; t < S.T; t++) n += L.nact[cur][t];
+    const int32_t reordered = n > bm.maxhmmpf + (bm.maxhmmpf >> 1) ? 1 : 0;
+    d_dec_scan(S.N, S.T, ctx->cf, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit,
+               L.cnt, L.base, L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, L.best, L.exits, L.nexit, L.hbin, L.misc,
+               L.done, L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, reordered, L.scan_agg, L.scan_pre,
+               L.scan_flag, S.scan_chunks, ctx->scan_epoch, NC, blockIdx.x, 0);
+}
+
+__global__ void __launch_bounds__(DBLOCK)
+ku_emit(const ULane *__restrict__ lanes, UShared S)
+{
+    LANE;
+    const int32_t cur = ctx->cur;
+    d_dec_emit(ctx->cf, S.node_base, L.act[cur], L.nact[cur], S.child_off, S.child, L.turn, L.selfemit, L.base,
+               L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, blockIdx.x, blockIdx.y);
+}
+
+/* ---- the word level: closes the frame and arms the next one ---- */
+__global__ void __launch_bounds__(WL_THREADS)
+ku_wordlevel(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par)
+{
+    LANE;
+    if (threadIdx.x == 0) ctx->scan_epoch++;        /* (k_dec_scan's flags are stamped per launch) */
+    d_wordlevel_frame(L.w, ctx, L.pack, lm, dict, par);
+}
+
+/* stand-alone word-level frame on a caller-filled record (tests: lock step with the oracle) */
+__global__ void __launch_bounds__(WL_THREADS)
+ku_wordlevel_only(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par)
+{
+    const ULane &L = lanes[blockIdx.z];
+    if (!L.ctx->active) return;
+    d_wordlevel_frame(L.w, L.ctx, L.pack, lm, dict, par);
+}
+
+__global__ void
+ku_fill32(int32_t *p, int32_t v, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+/* ------------------------------------------------------------------ */
+/* host side                                                           */
+/* ------------------------------------------------------------------ */
+struct s3a_lm3g_s {
+    WLm d;                      /* device arrays */
+    int32_t n_dictword;
+    std::vector<int32_t> ug_prob, ug_bowt, ug_firstbg, bg_wid, bg_prob, bg_bowt, bg_firsttg, tg_wid, tg_prob, inclass;
+};
+
+#define DM(ptr, bytes) do { if (hipMalloc((void **)&(ptr), (bytes) > 0 ? (bytes) : 4) != hipSuccess) { \
+        s3a_set_error("s3a_utt: device allocation of %zu bytes failed", (size_t)(bytes)); goto fail; } } while (0)
+#define UPV(dst, vec) do { DM(dst, (vec).size() * 4); \
+        if ((vec).size() && hipMemcpy((void *)(dst), (vec).data(), (vec).size() * 4, hipMemcpyHostToDevice) != hipSuccess) { \
+            s3a_set_error("s3a_utt: upload failed"); goto fail; } } while (0)
+
+extern "C" s3a_lm3g_t *
+s3a_lm3g_init(int32_t n_ug, const int32_t *ug_prob, const int32_t *ug_bowt, const int32_t *ug_firstbg, int32_t n_bg,
+              const int32_t *bg_wid, const int32_t *bg_prob, const int32_t *bg_bowt, const int32_t *bg_firsttg,
+              int32_t n_tg, const int32_t *tg_wid, const int32_t *tg_prob, const int32_t *inclass_ugscore,
+              int32_t n_dictword)
+{
+    if (n_ug <= 0 || !ug_prob || !ug_bowt || n_bg < 0 || n_tg < 0 || (n_bg > 0 && (!ug_firstbg || !bg_wid || !bg_prob))
+        || (n_tg > 0 && (n_bg == 0 || !bg_bowt || !bg_firsttg || !tg_wid || !tg_prob))) {
+        s3a_set_error("s3a_lm3g_init: bad arguments");
+        return NULL;
+    }
+    s3a_lm3g_t *lm = new s3a_lm3g_s();
+    lm->ug_prob.assign(ug_prob, ug_prob + n_ug); lm->ug_bowt.assign(ug_bowt, ug_bowt + n_ug);
+    if (n_bg > 0) lm->ug_firstbg.assign(ug_firstbg, ug_firstbg + n_ug + 1); else lm->ug_firstbg.assign(n_ug + 1, 0);
+    if (n_bg > 0) { lm->bg_wid.assign(bg_wid, bg_wid + n_bg); lm->bg_prob.assign(bg_prob, bg_prob + n_bg); }
+    if (n_tg > 0) {
+        lm->bg_bowt.assign(bg_bowt, bg_bowt + n_bg); lm->bg_firsttg.assign(bg_firsttg, bg_firsttg + n_bg + 1);
+        lm->tg_wid.assign(tg_wid, tg_wid + n_tg); lm->tg_prob.assign(tg_prob, tg_prob + n_tg);
+    }
+    if (inclass_ugscore) lm->inclass.assign(inclass_ugscore, inclass_ugscore + n_dictword);
+    lm->n_dictword = n_dictword;
+    /* the look-ups bisect: every run must be sorted and duplicate-free, as lm_3g_dmp.c writes them
+     * (the reference's find_bg / find_tg, lm.c:1132-1178, assume the same) */
+    for (int32_t w = 0; w < n_ug && n_bg > 0; w++) {
+        const int32_t b0 = lm->ug_firstbg[w], b1 = lm->ug_firstbg[w + 1];
+        if (b0 < 0 || b1 < b0 || b1 > n_bg) { s3a_set_error("s3a_lm3g_init: bigram offsets of unigram %d out of range", w); delete lm; return NULL; }
+        for (int32_t b = b0 + 1; b < b1; b++)
+            if (lm->bg_wid[b] <= lm->bg_wid[b - 1]) { s3a_set_error("s3a_lm3g_init: bigrams of unigram %d are not sorted", w); delete lm; return NULL; }
+    }
+    for (int32_t b = 0; b < n_bg && n_tg > 0; b++) {
+        const int32_t t0 = lm->bg_firsttg[b], t1 = lm->bg_firsttg[b + 1];
+        if (t0 < 0 || t1 < t0 || t1 > n_tg) { s3a_set_error("s3a_lm3g_init: trigram offsets of bigram %d out of range", b); delete lm; return NULL; }
+        for (int32_t t = t0 + 1; t < t1; t++)
+            if (lm->tg_wid[t] <= lm->tg_wid[t - 1]) { s3a_set_error("s3a_lm3g_init: trigrams of bigram %d are not sorted", b); delete lm; return NULL; }
+    }
+    memset(&lm->d, 0, sizeof lm->d);
+    lm->d.n_ug = n_ug; lm->d.n_bg = n_bg; lm->d.n_tg = n_tg;
+    UPV(lm->d.ug_prob, lm->ug_prob); UPV(lm->d.ug_bowt, lm->ug_bowt); UPV(lm->d.ug_firstbg, lm->ug_firstbg);
+    UPV(lm->d.bg_wid, lm->bg_wid); UPV(lm->d.bg_prob, lm->bg_prob); UPV(lm->d.bg_bowt, lm->bg_bowt);
+    UPV(lm->d.bg_firsttg, lm->bg_firsttg); UPV(lm->d.tg_wid, lm->tg_wid); UPV(lm->d.tg_prob, lm->tg_prob);
+    if (inclass_ugscore) UPV(lm->d.inclass, lm->inclass);
+    return lm;
+fail:
+    s3a_lm3g_free(lm);
+    return NULL;
+}
+
+extern "C" void
+s3a_lm3g_free(s3a_lm3g_t *lm)
+{
+    if (!lm) return;
+    const int32_t *p[] = { lm->d.ug_prob, lm->d.ug_bowt, lm->d.ug_firstbg, lm->d.bg_wid, lm->d.bg_prob, lm->d.bg_bowt,
+                           lm->d.bg_firsttg, lm->d.tg_wid, lm->d.tg_prob, lm->d.inclass };
+    for (auto q : p) if (q) (void)hipFree((void *)q);
+    delete lm;
+}
+
+/* lm_tg_score on the host copy (lm.c:1661-1833): the utterance's final </s> transition, tests */
+static int32_t
+h_find(const int32_t *v, int32_t n, int32_t w)
+{
+    int32_t lo = 0, hi = n;
+    while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (v[mid] < w) lo = mid + 1; else hi = mid; }
+    return (lo < n && v[lo] == w) ? lo : -1;
+}
+static int32_t
+h_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static int32_t
+h_bg(const s3a_lm3g_t *lm, int32_t lw1, int32_t lw2, int32_t wid)
+{
+    int32_t s;
+    if (lm->d.n_bg == 0 || lw1 < 0) s = lm->ug_prob[lw2];
+    else {
+        const int32_t b0 = lm->ug_firstbg[lw1], n = lm->ug_firstbg[lw1 + 1] - b0;
+        const int32_t i = n > 0 ? h_find(lm->bg_wid.data() + b0, n, lw2) : -1;
+        s = i >= 0 ? lm->bg_prob[b0 + i] : h_add(lm->ug_bowt[lw1], lm->ug_prob[lw2]);
+    }
+    if (!lm->inclass.empty()) s = h_add(s, lm->inclass[wid]);
+    return s;
+}
+extern "C" int32_t
+s3a_lm3g_tg_score(const s3a_lm3g_t *lm, int32_t lw1, int32_t lw2, int32_t lw3, int32_t wid)
+{
+    if (lm->d.n_tg == 0 || lw1 < 0) return h_bg(lm, lw2, lw3, wid);
+    const int32_t b0 = lm->ug_firstbg[lw1], nb = lm->ug_firstbg[lw1 + 1] - b0;
+    int32_t b = nb > 0 ? h_find(lm->bg_wid.data() + b0, nb, lw2) : -1, bowt = 0;
+    if (b >= 0) {
+        b += b0;
+        bowt = lm->bg_bowt[b];
+        const int32_t t0 = lm->bg_firsttg[b], nt = lm->bg_firsttg[b + 1] - t0;
+        const int32_t i = nt > 0 ? h_find(lm->tg_wid.data() + t0, nt, lw3) : -1;
+        if (i >= 0) return lm->inclass.empty() ? lm->tg_prob[t0 + i] : h_add(lm->tg_prob[t0 + i], lm->inclass[wid]);
+    }
+    return h_add(bowt, h_bg(lm, lw2, lw3, wid));
+}
+
+struct HostLane {
+    s3a_lexsearch_t *ls;
+    s3a_scorer_t *sc;
+    ULane d;
+    UCtx *h_ctx;                /* pinned */
+    float *d_feat;
+    size_t feat_cap;
+    float *h_feat;              /* pinned staging */
+    size_t h_feat_cap;
+    int32_t *h_tab;             /* pinned: the downloaded history table [13 arrays] */
+    size_t h_tab_cap;
+    int32_t *h_st, *h_fstat;    /* pinned */
+    int32_t nfr, n_entry, epoch, dirty;
+};
+
+struct s3a_uttdec_s {
+    s3a_lm3g_t *lm;
+    s3a_comsen_t *cs;
+    s3a_mgau_model_t *g;
+    int32_t n_lanes, max_frames, vh_cap, cand_cap, ex_cap, new_cap, exact, veclen;
+    UShared S;
+    WDict dict;
+    WPar par;
+    s3a_wordlevel_cfg_t cfg;
+    std::vector<int32_t> h_lwid, h_fillpen, h_last_ci, h_tree_type;
+    std::vector<uint8_t> h_is_filler;
+    std::vector<HostLane> lane;
+    ULane *d_lanes;
+    int32_t *d_lcmap;
+    std::vector<int32_t> h_lcmap;
+    int32_t g_eval, eval_block, g_ent, g_mark, scan_nc, hist_possible, weak_possible;
+    hipStream_t stream;
+    int32_t n_utt;              /* lanes in use by the last decode */
+    double last_decode_ms;
+};
+
+static int32_t
+fill32(hipStream_t st, int32_t *p, int32_t v, size_t n)
+{
+    if (n == 0) return S3A_OK;
+    hipLaunchKernelGGL(ku_fill32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, v, n);
+    HIPCHK(hipGetLastError());
+    return S3A_OK;
+}
+
+extern "C" void
+s3a_uttdec_free(s3a_uttdec_t *ud)
+{
+    if (!ud) return;
+    (void)hipStreamSynchronize(ud->stream);
+    for (auto &hl : ud->lane) {
+        WLane &w = hl.d.w;
+        void *p[] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type, w.frame_start, w.bestscore,
+                      w.bestvh, w.st, w.ex_off, w.ex_max, w.ex_pref, w.ex_cnt, w.ex_base, w.cand_score, w.cand_slot, w.hkey,
+                      w.hbest, w.hfirst, w.hlead_e, w.hlead_rank, w.sg, w.srt, w.wfirst, w.heap, w.fstat, hl.d.ctx,
+                      hl.d.pack, hl.d_feat };
+        for (auto q : p) if (q) (void)hipFree(q);
+        if (hl.h_ctx) (void)hipHostFree(hl.h_ctx);
+        if (hl.h_feat) (void)hipHostFree(hl.h_feat);
+        if (hl.h_tab) (void)hipHostFree(hl.h_tab);
+        if (hl.h_st) (void)hipHostFree(hl.h_st);
+        if (hl.h_fstat) (void)hipHostFree(hl.h_fstat);
+        if (hl.sc) s3a_scorer_free(hl.sc);
+        if (hl.ls) s3a_lexsearch_free(hl.ls);
+    }
+    if (ud->d_lanes) (void)hipFree(ud->d_lanes);
+    if (ud->d_lcmap) (void)hipFree(ud->d_lcmap);
+    const void *q[] = { ud->dict.lwid, ud->dict.fillpen, ud->dict.last_ci, ud->dict.is_filler };
+    for (auto p : q) if (p) (void)hipFree((void *)p);
+    delete ud;
+}
+
+extern "C" s3a_uttdec_t *
+s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen,
+                int32_t n_ci_sen, int32_t ds_ratio, int32_t cond_ds, double ci_pbeam, float tighten_factor,
+                int32_t max_cd, s3a_comsen_t *cs, s3a_lm3g_t *lm, const s3a_wordlevel_cfg_t *cfg, int32_t n_lanes,
+                int32_t max_frames, int32_t vh_cap, int32_t cand_cap)
+{
+    if (!proto || !g || !g->dev || !cs || !lm || !cfg || n_lanes <= 0 || n_lanes > 1024 || max_frames <= 0) {
+        s3a_set_error("s3a_uttdec_init: bad arguments");
+        return NULL;
+    }
+    struct s3a_mgau_dev_s *d = g->dev;
+    const int32_t T = proto->n_tree;
+    if (T > WL_MAXT || T != 2 * cfg->n_lextree || cfg->n_ci > 255 || cfg->n_ci <= 0 || cfg->epl <= 0 || cfg->n_lextree <= 0) {
+        s3a_set_error("s3a_uttdec_init: %d lextrees / %d CI phones outside what the word level supports", T, cfg->n_ci);
+        return NULL;
+    }
+    if (cfg->wbeam_vh > 0 || cfg->wbeam > 0 || cfg->hmmbeam > 0 || cfg->pbeam > 0) {
+        s3a_set_error("s3a_uttdec_init: beams must be log probabilities (<= 0)");
+        return NULL;
+    }
+    if (d->tab16 == NULL) { s3a_set_error("s3a_uttdec_init: 32-bit log-add tables are not supported"); return NULL; }
+    if (max_cd < n_sen - n_ci_sen) { s3a_set_error("s3a_uttdec_init: -maxcdsenpf (dynamic CI beam) is not supported on the device-resident path"); return NULL; }
+    if (lm->n_dictword != 0 && lm->n_dictword != cfg->n_word && !lm->inclass.empty()) {
+        s3a_set_error("s3a_uttdec_init: the LM's class table and the dictionary disagree");
+        return NULL;
+    }
+    s3a_uttdec_t *ud = new s3a_uttdec_s();
+    ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
+    ud->cfg = *cfg;
+    ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0;
+    memset(&ud->dict, 0, sizeof ud->dict);
+    ud->stream = d->stream;
+    ud->exact = g->precision == S3A_GMM_EXACT;
+    ud->veclen = g->veclen;
+    int32_t maxn = 0, n_leaf_bound = proto->pack_max_exits;
+    for (int32_t t = 0; t < T; t++) maxn = max(maxn, proto->node_base[t + 1] - proto->node_base[t]);
+    ud->vh_cap = vh_cap > 0 ? vh_cap : (int32_t)min((long long)max_frames * max(cfg->maxhistpf, 1) + 1024, (long long)(4 << 20));
+    ud->cand_cap = cand_cap > 0 ? cand_cap : (1 << 20);
+    ud->ex_cap = n_leaf_bound;
+    ud->new_cap = min(ud->cand_cap, 1 << 18);
+
+    UShared &S = ud->S;
+    memset(&S, 0, sizeof S);
+    S.N = proto->N; S.T = T; S.n_tmat = proto->n_tmat; S.maxn = maxn; S.n_rootnodes = proto->n_rootnodes;
+    S.scan_chunks = proto->scan_chunks; S.pack_max_exits = proto->pack_max_exits;
+    S.node_base = proto->d_node_base; S.ssid = proto->d_ssid; S.tmatid = proto->d_tmatid; S.wid = proto->d_wid;
+    S.prob = proto->d_prob; S.child_off = proto->d_child_off; S.child = proto->d_child; S.par_off = proto->d_par_off;
+    S.par = proto->d_par; S.tree_of = proto->d_tree_of; S.rootlist = proto->d_rootlist; S.tp = proto->d_tp;
+    S.rootnodes = proto->d_rootnodes; S.ps = proto->d_ps; S.psof_off = proto->d_psof_off; S.psof = proto->d_psof;
+    S.cs_off = cs->off_d; S.cs_wt = cs->wt_d; S.cs_list = cs->list_d;
+    S.comp = proto->d_comp; S.sseq = proto->d_sseq; S.comsseq = proto->d_comsseq;
+    S.mean4 = d->mean4; S.prec4 = d->prec4; S.lrd = d->lrd; S.mixw = d->mixw; S.tab16 = d->tab16; S.tab_size = d->tab_size;
+    S.lm_zero = d->lm_zero; S.f = g->f; S.distfloor = g->distfloor; S.D4 = d->D4; S.CP = d->CP; S.Gpad = d->Gpad;
+    S.n_sen = n_sen; S.n_ci_sen = n_ci_sen;
+    S.ds_ratio = ds_ratio > 0 ? ds_ratio : 1; S.ptranskip = cfg->ptranskip;
+    S.bm.hmmbeam = cfg->hmmbeam; S.bm.pbeam = cfg->pbeam; S.bm.wbeam = cfg->wbeam; S.bm.phone_uses_wbeam = 0;
+    S.bm.maxhmmpf = cfg->maxhmmpf;
+
+    /* launch geometry: fixed grids, the kernels loop over the list lengths they find in memory */
+    ud->eval_block = (cfg->maxhmmpf >= EVBLOCK_LONG_LIST && maxn >= EVBLOCK_LONG_LIST) ? 256 : 64;
+    ud->g_eval = max(1, min((maxn + ud->eval_block - 1) / ud->eval_block, 2048 / max(1, min(n_lanes, 8))));
+    ud->g_ent = max(1, min((proto->ent_cap + 255) / 256, 256));
+    ud->g_mark = max(1, min((proto->ent_cap + M3BLOCK - 1) / M3BLOCK + ((maxn + M3BLOCK - 1) / M3BLOCK) * T, 1024));
+    ud->scan_nc = (cfg->maxhmmpf >= SCAN_LONG_LIST && maxn >= SCAN_LONG_LIST) ? (maxn + 1023) / 1024 : 1;
+    /* lextree_hmm_histbin can only fire when more than 1.5 x maxhmmpf HMMs can be active at all */
+    ud->hist_possible = (long long)proto->N > (long long)cfg->maxhmmpf + (cfg->maxhmmpf >> 1);
+    ud->weak_possible = cfg->ptranskip != 0 || cfg->pbeam < cfg->hmmbeam;
+    if (ud->hist_possible && -cfg->hmmbeam / NBIN == 0) {
+        s3a_set_error("s3a_uttdec_init: -beam too narrow for histogram pruning (bin width 0)");
+        delete ud;
+        return NULL;
+    }
+
+    /* dictionary facts + root lists per (tree, left context) */
+    ud->h_lwid.assign(cfg->lwid, cfg->lwid + cfg->n_word); ud->h_fillpen.assign(cfg->fillpen, cfg->fillpen + cfg->n_word);
+    ud->h_last_ci.assign(cfg->last_ci, cfg->last_ci + cfg->n_word);
+    ud->h_is_filler.assign(cfg->is_filler, cfg->is_filler + cfg->n_word);
+    ud->h_tree_type.assign(cfg->tree_type, cfg->tree_type + T);
+    ud->cfg.lwid = ud->h_lwid.data(); ud->cfg.fillpen = ud->h_fillpen.data(); ud->cfg.last_ci = ud->h_last_ci.data();
+    ud->cfg.is_filler = ud->h_is_filler.data(); ud->cfg.tree_type = ud->h_tree_type.data();
+    for (int32_t w = 0; w < cfg->n_word; w++)
+        if (cfg->last_ci[w] < 0 || cfg->last_ci[w] >= cfg->n_ci || (cfg->lwid[w] >= lm->d.n_ug)) {
+            s3a_set_error("s3a_uttdec_init: dictionary word %d has a bad final phone / LM id", w);
+            delete ud;
+            return NULL;
+        }
+    ud->h_lcmap.assign((size_t)T * (cfg->n_ci + 1) * 2, -1);
+    for (int32_t t = 0; t < T; t++) {
+        if (proto->n_lc[t] > 0) {
+            for (int32_t k = 0; k < proto->n_lc[t]; k++) {
+                const int32_t p = proto->lc[t][k];
+                if (p < 0 || p >= cfg->n_ci) continue;
+                ud->h_lcmap[((size_t)t * (cfg->n_ci + 1) + p) * 2] = proto->rootbuf_base[t] + proto->lcroot_off[t][k];
+                ud->h_lcmap[((size_t)t * (cfg->n_ci + 1) + p) * 2 + 1] = proto->lcroot_off[t][k + 1] - proto->lcroot_off[t][k];
+            }
+        }
+        else {
+            /* no left contexts (filler trees): every call enters the one root list, whatever lc says */
+            for (int32_t p = 0; p <= cfg->n_ci; p++) {
+                ud->h_lcmap[((size_t)t * (cfg->n_ci + 1) + p) * 2] = proto->rootbuf_base[t] + proto->lcroot_off[t][0];
+                ud->h_lcmap[((size_t)t * (cfg->n_ci + 1) + p) * 2 + 1] = proto->lcroot_off[t][1] - proto->lcroot_off[t][0];
+            }
+        }
+    }
+    {
+        int32_t *p0 = NULL, *p1 = NULL, *p2 = NULL;
+        uint8_t *p3 = NULL;
+        DM(p0, (size_t)cfg->n_word * 4); DM(p1, (size_t)cfg->n_word * 4); DM(p2, (size_t)cfg->n_word * 4); DM(p3, (size_t)cfg->n_word);
+        ud->dict.lwid = p0; ud->dict.fillpen = p1; ud->dict.last_ci = p2; ud->dict.is_filler = p3;
+        ud->dict.n_word = cfg->n_word; ud->dict.n_ci = cfg->n_ci;
+        if (hipMemcpy(p0, cfg->lwid, (size_t)cfg->n_word * 4, hipMemcpyHostToDevice) != hipSuccess
+            || hipMemcpy(p1, cfg->fillpen, (size_t)cfg->n_word * 4, hipMemcpyHostToDevice) != hipSuccess
+            || hipMemcpy(p2, cfg->last_ci, (size_t)cfg->n_word * 4, hipMemcpyHostToDevice) != hipSuccess
+            || hipMemcpy(p3, cfg->is_filler, (size_t)cfg->n_word, hipMemcpyHostToDevice) != hipSuccess) {
+            s3a_set_error("s3a_uttdec_init: upload failed");
+            goto fail;
+        }
+        UPV(ud->d_lcmap, ud->h_lcmap);
+    }
+    {
+        WPar &P = ud->par;
+        memset(&P, 0, sizeof P);
+        P.wbeam = cfg->wbeam_vh; P.bghist = cfg->bghist; P.maxwpf = cfg->maxwpf; P.maxhist = cfg->maxhistpf;
+        P.wordend = cfg->wordend_beam; P.n_lextree = cfg->n_lextree; P.epl = cfg->epl; P.T = T; P.hmmbeam = cfg->hmmbeam;
+        for (int32_t t = 0; t < T; t++) P.tree_type[t] = cfg->tree_type[t];
+        P.lcmap = ud->d_lcmap;
+    }
+
+    ud->lane.resize(n_lanes);
+    for (auto &hl : ud->lane) memset((void *)&hl, 0, sizeof hl);
+    for (int32_t z = 0; z < n_lanes; z++) {
+        HostLane &hl = ud->lane[z];
+        hl.ls = s3a_lexsearch_clone(proto, (void *)ud->stream);
+        hl.sc = s3a_scorer_init_private(g, cd2cisen, n_sen, n_ci_sen, ds_ratio, cond_ds, ci_pbeam, tighten_factor, max_cd);
+        if (!hl.ls || !hl.sc) goto fail;
+        if (z == 0) {
+            S.gp_n = hl.sc->gp_n;
+            S.ci_pbeam = hl.sc->ci_pbeam;
+            S.ci_pbeam_tight = (int32_t)((float)hl.sc->ci_pbeam * hl.sc->tighten_factor);
+            S.ncomp = hl.sc->ncomp_d;           /* identical in every lane's scorer (model facts) */
+            S.cd2cisen = hl.sc->cd2cisen_d;
+        }
+        s3a_lexsearch_t *ls = hl.ls;
+        ULane &u = hl.d;
+        u.sc = ls->d_sc; u.hist = ls->d_hist; u.outs = ls->d_outs; u.outh = ls->d_outh; u.bests = ls->d_bests;
+        u.frame = ls->d_frame; u.pos = ls->d_pos; u.posf = ls->d_posf; u.act[0] = ls->d_act[0]; u.act[1] = ls->d_act[1];
+        u.nact[0] = ls->d_nact[0]; u.nact[1] = ls->d_nact[1]; u.turn = ls->d_turn; u.selfemit = ls->d_selfemit;
+        u.cnt = ls->d_cnt; u.base = ls->d_cand; u.best = ls->d_best; u.exits = ls->d_exit; u.nexit = ls->d_nexit;
+        u.first = ls->d_first; u.eflag = ls->d_eflag; u.hbin = ls->d_hbin; u.done = ls->d_done; u.ctot = ls->d_ctot;
+        u.n0 = ls->d_n0; u.pstamp = ls->d_pstamp; u.propf = ls->d_candf; u.poswid = ls->d_poswid; u.posout = ls->d_posout;
+        u.scan_flag = ls->d_scan_flag; u.scan_agg = ls->d_scan_agg; u.scan_pre = ls->d_scan_pre; u.key = ls->d_key;
+        u.sen_act = hl.sc->act_d; u.scr = hl.sc->scr_d; u.misc = hl.sc->misc_d; u.bstidx = hl.sc->bstidx_d;
+        u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
+        DM(u.ctx, sizeof(UCtx));
+        DM(u.pack, (size_t)(6 * T + 16 + 3 * proto->pack_max_exits) * 4);
+        WLane &w = u.w;
+        const size_t vc = (size_t)ud->vh_cap * 4, mf = (size_t)(max_frames + 2) * 4;
+        DM(w.score, vc); DM(w.pred, vc); DM(w.lw0, vc); DM(w.lw1, vc); DM(w.wid, vc); DM(w.sf, vc); DM(w.ef, vc);
+        DM(w.ascr, vc); DM(w.lscr, vc); DM(w.type, vc);
+        w.cap = ud->vh_cap;
+        DM(w.frame_start, mf); DM(w.bestscore, mf); DM(w.bestvh, mf); DM(w.st, 16 * 4);
+        const size_t ec = (size_t)(ud->ex_cap + 1) * 4;
+        DM(w.ex_off, ec); DM(w.ex_max, ec); DM(w.ex_pref, ec); DM(w.ex_cnt, ec); DM(w.ex_base, ec);
+        w.ex_cap = ud->ex_cap;
+        DM(w.cand_score, (size_t)ud->cand_cap * 4); DM(w.cand_slot, (size_t)ud->cand_cap * 4);
+        w.cand_cap = ud->cand_cap;
+        size_t hs = 1024;
+        while (hs < (size_t)2 * ud->cand_cap) hs <<= 1;
+        w.hmask = (int32_t)(hs - 1);
+        DM(w.hkey, hs * 8); DM(w.hbest, hs * 8); DM(w.hfirst, hs * 4); DM(w.hlead_e, hs * 4); DM(w.hlead_rank, hs * 4);
+        if (hipMemset(w.hkey, 0, hs * 8) != hipSuccess || hipMemset(w.hbest, 0, hs * 8) != hipSuccess
+            || hipMemset(w.hfirst, 0xff, hs * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_init: memset failed"); goto fail; }
+        w.new_cap = ud->new_cap;
+        DM(w.sg, (size_t)11 * ud->new_cap * 4); DM(w.srt, (size_t)6 * ud->new_cap * 4); DM(w.heap, (size_t)6 * ud->new_cap * 4);
+        DM(w.wfirst, (size_t)cfg->n_word * 4);
+        DM(w.fstat, (size_t)max_frames * 8 * 4);
+        if (hipHostMalloc((void **)&hl.h_ctx, sizeof(UCtx)) != hipSuccess
+            || hipHostMalloc((void **)&hl.h_st, 16 * 4) != hipSuccess
+            || hipHostMalloc((void **)&hl.h_fstat, (size_t)max_frames * 8 * 4) != hipSuccess) {
+            s3a_set_error("s3a_uttdec_init: pinned allocation failed");
+            goto fail;
+        }
+        if (fill32(ud->stream, w.wfirst, INT_MAX, cfg->n_word) != S3A_OK) goto fail;
+    }
+    {
+        std::vector<ULane> tmp(n_lanes);
+        for (int32_t z = 0; z < n_lanes; z++) tmp[z] = ud->lane[z].d;
+        DM(ud->d_lanes, sizeof(ULane) * n_lanes);
+        if (hipMemcpy(ud->d_lanes, tmp.data(), sizeof(ULane) * n_lanes, hipMemcpyHostToDevice) != hipSuccess) goto fail;
+    }
+    if (hipStreamSynchronize(ud->stream) != hipSuccess) goto fail;
+    return ud;
+fail:
+    s3a_uttdec_free(ud);
+    return NULL;
+}
+
+/* srch_TST_begin (srch_time_switch_tree.c:457-512) for one lane: the dummy <s> history entry, the
+ * root entries with silence as left context into unigram tree 0 and filler tree n_lextree */
+static int32_t
+lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t feat_stride)
+{
+    HostLane &hl = ud->lane[z];
+    const s3a_wordlevel_cfg_t &c = ud->cfg;
+    const int32_t D4x4 = ud->S.D4 * 4, T = ud->S.T;
+    int32_t rc;
+    if (nfr <= 0 || nfr > ud->max_frames) { s3a_set_error("s3a_uttdec_decode: %d frames (1..%d)", nfr, ud->max_frames); return S3A_EINVAL; }
+    /* features, rows padded to the scorer's float4 stride */
+    const size_t need = (size_t)nfr * D4x4;
+    if (need > hl.feat_cap) {
+        if (hl.d_feat) (void)hipFree(hl.d_feat);
+        hl.d_feat = NULL; hl.feat_cap = 0;
+        if (hipMalloc((void **)&hl.d_feat, need * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: feature buffer"); return S3A_ENOMEM; }
+        hl.feat_cap = need;
+    }
+    if (need > hl.h_feat_cap) {
+        if (hl.h_feat) (void)hipHostFree(hl.h_feat);
+        hl.h_feat = NULL; hl.h_feat_cap = 0;
+        if (hipHostMalloc((void **)&hl.h_feat, need * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: pinned feature buffer"); return S3A_ENOMEM; }
+        hl.h_feat_cap = need;
+    }
+    for (int32_t t = 0; t < nfr; t++) {
+        float *row = hl.h_feat + (size_t)t * D4x4;
+        memcpy(row, feat + (size_t)t * feat_stride, sizeof(float) * ud->veclen);
+        for (int32_t k = ud->veclen; k < D4x4; k++) row[k] = 0.0f;
+    }
+    HIPCHK(hipMemcpyAsync(hl.d_feat, hl.h_feat, need * 4, hipMemcpyHostToDevice, ud->stream));
+    hl.d.feat = hl.d_feat;
+    hl.nfr = nfr;
+    /* lextree + scorer state as after lextree_utt_end / at srch_TST_begin */
+    if (hl.dirty) {
+        /* the previous utterance of this lane stopped on an error in mid-frame: everything from scratch */
+        const WLane &w = hl.d.w;
+        const size_t hs = (size_t)w.hmask + 1;
+        if ((rc = s3a_lexsearch_reset(hl.ls)) != S3A_OK) return rc;
+        HIPCHK(hipMemsetAsync(w.hkey, 0, hs * 8, ud->stream)); HIPCHK(hipMemsetAsync(w.hbest, 0, hs * 8, ud->stream));
+        HIPCHK(hipMemsetAsync(w.hfirst, 0xff, hs * 4, ud->stream));
+        if ((rc = fill32(ud->stream, w.wfirst, INT_MAX, c.n_word)) != S3A_OK) return rc;
+        hl.dirty = 0;
+    }
+    if ((rc = s3a_lexsearch_utt_end(hl.ls)) != S3A_OK) return rc;
+    hl.ls->cur = 0;
+    if ((rc = s3a_decoder_utt_begin(hl.ls, hl.sc)) != S3A_OK) return rc;
+    /* history: entry 0 (vithist_utt_begin, vithist.c:300-335) */
+    {
+        int32_t e0[10] = { 0 /*score*/, -1 /*pred*/, c.start_lwid, -1 /*lw1*/, c.startwid, -1 /*sf*/, -1 /*ef*/, 0, 0, 0 };
+        int32_t *arr[10] = { hl.d.w.score, hl.d.w.pred, hl.d.w.lw0, hl.d.w.lw1, hl.d.w.wid, hl.d.w.sf, hl.d.w.ef, hl.d.w.ascr,
+                             hl.d.w.lscr, hl.d.w.type };
+        for (int k = 0; k < 10; k++) if ((rc = fill32(ud->stream, arr[k], e0[k], 1)) != S3A_OK) return rc;
+        if ((rc = fill32(ud->stream, hl.d.w.frame_start, 1, 1)) || (rc = fill32(ud->stream, hl.d.w.bestscore, INT_MIN, 1))
+            || (rc = fill32(ud->stream, hl.d.w.bestvh, -1, 1)) || (rc = fill32(ud->stream, hl.d.w.st, 1, 1))
+            || (rc = fill32(ud->stream, hl.d.w.st + 1, 0, 1)))
+            return rc;
+    }
+    UCtx &x = *hl.h_ctx;
+    memset(&x, 0, sizeof x);
+    x.active = 1; x.cf = 0; x.nfr = nfr; x.cur = 0; x.n_lextrans = 1; x.thresh = c.hmmbeam;
+    if (hl.epoch < 1) hl.epoch = 1;
+    x.scan_epoch = hl.epoch;      /* k_dec_scan's flags are never reset: the stamps keep growing */
+    hl.epoch += nfr + 1;
+    {
+        const int32_t nci = c.n_ci;
+        const int32_t *m0 = &ud->h_lcmap[((size_t)0 * (nci + 1) + c.sil_ci) * 2];
+        const int32_t *m1 = &ud->h_lcmap[((size_t)c.n_lextree * (nci + 1) + nci) * 2];
+        if (m0[1] < 0 || m1[1] < 0) { s3a_set_error("s3a_uttdec_decode: silence is not a left context of the unigram lextree"); return S3A_EINVAL; }
+        x.calls[0] = 0; x.calls[1] = 0; x.calls[2] = m0[0]; x.calls[3] = 0;
+        x.calls[4] = 0; x.calls[5] = 0; x.calls[6] = m1[0]; x.calls[7] = m0[1];
+        x.groups[0] = 0; x.groups[1] = 0; x.groups[2] = m0[1]; x.groups[3] = 0;
+        x.groups[4] = c.n_lextree; x.groups[5] = m0[1]; x.groups[6] = m0[1] + m1[1]; x.groups[7] = 1;
+        x.n_calls = 2; x.n_groups = 2; x.n_ent = m0[1] + m1[1];
+        (void)T;
+    }
+    HIPCHK(hipMemcpyAsync(hl.d.ctx, hl.h_ctx, sizeof(UCtx), hipMemcpyHostToDevice, ud->stream));
+    return S3A_OK;
+}
+
+static int32_t
+enqueue_frame(s3a_uttdec_t *ud, int32_t n)
+{
+    hipStream_t st = ud->stream;
+    const ULane *LN = ud->d_lanes;
+    const UShared &S = ud->S;
+    const int32_t T = S.T;
+    hipLaunchKernelGGL(ku_enter1, dim3(ud->g_ent, 1, n), dim3(256), 0, st, LN, S);
+    hipLaunchKernelGGL(ku_enter2, dim3(WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
+    hipLaunchKernelGGL(ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S);
+    const int32_t g_ci = (S.n_ci_sen * S.CP + 255) / 256, g_cd = ((S.n_sen - S.n_ci_sen) * S.CP + 255) / 256;
+    if (ud->exact) {
+        if (g_ci) hipLaunchKernelGGL((ku_gated<true, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
+        if (g_cd) hipLaunchKernelGGL((ku_gated<true, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
+    }
+    else {
+        if (g_ci) hipLaunchKernelGGL((ku_gated<false, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
+        if (g_cd) hipLaunchKernelGGL((ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
+    }
+    if (ud->eval_block == 256)
+        hipLaunchKernelGGL(ku_hmm_eval<256>, dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S);
+    else
+        hipLaunchKernelGGL(ku_hmm_eval<64>, dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S);
+    if (ud->hist_possible) {
+        hipLaunchKernelGGL(ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, 256)), T, n), dim3(DBLOCK), 0, st, LN, S);
+        hipLaunchKernelGGL(ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
+    }
+    if (ud->weak_possible) hipLaunchKernelGGL(ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
+    hipLaunchKernelGGL(ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S);
+    hipLaunchKernelGGL(ku_scan, dim3(T * ud->scan_nc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc);
+    hipLaunchKernelGGL(ku_emit, dim3(EMIT_BLOCKS, T, n), dim3(DBLOCK), 0, st, LN, S);
+    hipLaunchKernelGGL(ku_wordlevel, dim3(1, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par);
+    HIPCHK(hipGetLastError());
+    return S3A_OK;
+}
+
+/* download lane z's history table + frame statistics (after the frames have been enqueued) */
+static int32_t
+lane_fetch_state(s3a_uttdec_t *ud, int32_t z)
+{
+    HostLane &hl = ud->lane[z];
+    HIPCHK(hipMemcpyAsync(hl.h_st, hl.d.w.st, 16 * 4, hipMemcpyDeviceToHost, ud->stream));
+    HIPCHK(hipMemcpyAsync(hl.h_ctx, hl.d.ctx, sizeof(UCtx), hipMemcpyDeviceToHost, ud->stream));
+    HIPCHK(hipMemcpyAsync(hl.h_fstat, hl.d.w.fstat, (size_t)hl.nfr * 8 * 4, hipMemcpyDeviceToHost, ud->stream));
+    return S3A_OK;
+}
+
+static int32_t
+lane_fetch_table(s3a_uttdec_t *ud, int32_t z)
+{
+    HostLane &hl = ud->lane[z];
+    const int32_t n = hl.h_st[0], nf = hl.nfr + 2;
+    hl.n_entry = n;
+    const size_t need = (size_t)10 * (n + 1) + (size_t)3 * nf;
+    if (need > hl.h_tab_cap) {
+        if (hl.h_tab) (void)hipHostFree(hl.h_tab);
+        hl.h_tab = NULL; hl.h_tab_cap = 0;
+        if (hipHostMalloc((void **)&hl.h_tab, need * 4 + 64) != hipSuccess) { s3a_set_error("s3a_uttdec: pinned table buffer"); return S3A_ENOMEM; }
+        hl.h_tab_cap = need;
+    }
+    const WLane &w = hl.d.w;
+    const int32_t *src[10] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type };
+    for (int k = 0; k < 10; k++)
+        HIPCHK(hipMemcpyAsync(hl.h_tab + (size_t)k * (n + 1), src[k], (size_t)n * 4, hipMemcpyDeviceToHost, ud->stream));
+    int32_t *tail = hl.h_tab + (size_t)10 * (n + 1);
+    HIPCHK(hipMemcpyAsync(tail, w.frame_start, (size_t)nf * 4, hipMemcpyDeviceToHost, ud->stream));
+    HIPCHK(hipMemcpyAsync(tail + nf, w.bestscore, (size_t)nf * 4, hipMemcpyDeviceToHost, ud->stream));
+    HIPCHK(hipMemcpyAsync(tail + 2 * nf, w.bestvh, (size_t)nf * 4, hipMemcpyDeviceToHost, ud->stream));
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const int32_t *n_frames,
+                  int32_t feat_stride)
+{
+    if (!ud || n_utt <= 0 || n_utt > ud->n_lanes || !feat || !n_frames || feat_stride < ud->veclen) {
+        s3a_set_error("s3a_uttdec_decode: bad arguments (%d utterances, %d lanes)", n_utt, ud ? ud->n_lanes : 0);
+        return S3A_EINVAL;
+    }
+    int32_t rc, maxT = 0;
+    for (int32_t z = 0; z < n_utt; z++) {
+        if ((rc = lane_begin(ud, z, feat[z], n_frames[z], feat_stride)) != S3A_OK) return rc;
+        maxT = max(maxT, n_frames[z]);
+    }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, ud->stream));
+    for (int32_t f = 0; f < maxT; f++)
+        if ((rc = enqueue_frame(ud, n_utt)) != S3A_OK) return rc;
+    HIPCHK(hipEventRecord(e1, ud->stream));
+    for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_state(ud, z)) != S3A_OK) return rc;
+    HIPCHK(hipStreamSynchronize(ud->stream));
+    {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        ud->last_decode_ms = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_table(ud, z)) != S3A_OK) return rc;
+    HIPCHK(hipStreamSynchronize(ud->stream));
+    ud->n_utt = n_utt;
+    for (int32_t z = 0; z < n_utt; z++) {
+        const int32_t e = ud->lane[z].h_ctx->err;
+        if (e) ud->lane[z].dirty = 1;
+        if (e) {
+            s3a_set_error("s3a_uttdec_decode: utterance %d stopped at frame %d: error bits 0x%x%s%s%s%s%s%s", z,
+                          ud->lane[z].h_ctx->cf, e, (e & WL_E_OPEN_EXIT) ? " (out.history == -1 at a word exit)" : "",
+                          (e & WL_E_EXITS) ? " (too many word exits)" : "", (e & WL_E_CAND) ? " (candidate buffer full)" : "",
+                          (e & WL_E_TABLE) ? " (history table full)" : "", (e & WL_E_LC) ? " (phone is no left context)" : "",
+                          (e & WL_E_NOLM) ? " (word without LM id)" : "");
+            return (e & (WL_E_EXITS | WL_E_CAND | WL_E_TABLE | WL_E_CALLS)) ? S3A_ENOMEM : S3A_EINVAL;
+        }
+    }
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out)
+{
+    if (!ud || !out || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
+    const HostLane &hl = ud->lane[lane];
+    const int32_t n = hl.n_entry, nf = hl.nfr + 2;
+    const int32_t *t = hl.h_tab;
+    memset(out, 0, sizeof *out);
+    out->err = hl.h_ctx->err; out->n_entry = n; out->n_frm = hl.h_st[1]; out->n_frames = hl.nfr;
+    out->score = t; out->pred = t + (size_t)(n + 1); out->lw0 = t + (size_t)2 * (n + 1); out->lw1 = t + (size_t)3 * (n + 1);
+    out->wid = t + (size_t)4 * (n + 1); out->sf = t + (size_t)5 * (n + 1); out->ef = t + (size_t)6 * (n + 1);
+    out->ascr = t + (size_t)7 * (n + 1); out->lscr = t + (size_t)8 * (n + 1); out->type = t + (size_t)9 * (n + 1);
+    const int32_t *tail = t + (size_t)10 * (n + 1);
+    out->frame_start = tail; out->bestscore = tail + nf; out->bestvh = tail + 2 * nf;
+    out->frame_stat = hl.h_fstat;
+    out->max_cand = hl.h_ctx->max_cand; out->max_new = hl.h_ctx->max_new; out->n_tie_frames = hl.h_ctx->n_tie_frames;
+    return S3A_OK;
+}
+
+extern "C" double
+s3a_uttdec_last_decode_ms(const s3a_uttdec_t *ud)
+{
+    return ud ? ud->last_decode_ms : 0.0;
+}
+
+extern "C" int32_t
+s3a_uttdec_n_lanes(const s3a_uttdec_t *ud)
+{
+    return ud ? ud->n_lanes : 0;
+}

@@ -1,0 +1,572 @@
+/*
+ * s3a_wordlevel.h -- the WORD LEVEL of sphinx3's mode-4 search on the device:
+ * what closes a search frame once the lextree kernels have compacted the frame's word exits.
+ *
+ * Replaces, for all word exits of a frame at once,
+ *   vithist_rescore         sphinx3/src/libs3decoder/libsearch/vithist.c:492-574   (-> lm_tg_score, liblm/lm.c:1661-1833)
+ *   vithist_enter           vithist.c:396-489  (comp_rc == -1: composite triphones, kbcore.c:626)
+ *   vithist_prune + _gc     vithist.c:580-718  (heap order: sphinxbase util/heap.c:113-200)
+ *   srch_utt_word_trans     libsearch/srch_time_switch_tree.c:1086-1179
+ *   vithist_frame_windup    vithist.c:748-763
+ *
+ * The reference walks the exits one after another and, per exit, the history entries of the frame
+ * its predecessor ended in; what each (exit, predecessor) CANDIDATE sees depends on the ones before
+ * it in three ways, all reproduced here without walking:
+ *   1. a word candidate enters iff score - wbeam >= the best score entered SO FAR  (vithist.c:560)
+ *      = an exclusive prefix maximum over the candidates in walk order (a rejected candidate lies
+ *      below the running best, so the maximum over ALL earlier candidates is the same number);
+ *   2. candidates with the same LM state (lwid[0], lwid[1]) share ONE entry: it sits where the FIRST
+ *      entered candidate of the state put it and holds the best one, the earliest on ties
+ *      (strict <, vithist.c:449-455) = a hash insert with atomicMin(first) / atomicMax(score, ~seq);
+ *   3. pruning pops the frame's entries from a heap, best first: ranks by score; and when two
+ *      entries above the threshold TIE the pop order is the heap's (not FIFO, not LIFO): then -- and
+ *      only then -- one thread replays the reference's heap on the frame's entries.
+ * History entries of finished frames are immutable and all valid (vithist_frame_gc), so the table
+ * is structure-of-arrays in HBM and a candidate reads three words of its predecessor.
+ *
+ * One workgroup of WL_THREADS per decoder lane runs the phases below with workgroup barriers in
+ * between; all per-frame scratch is global memory (L2-resident).  Phases that scan candidates
+ * assign one exit per wave (64 predecessors per step).
+ */
+#ifndef S3A_WORDLEVEL_H
+#define S3A_WORDLEVEL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <limits.h>
+#include "s3a_vit.h"
+
+#define WL_THREADS 1024
+#define WL_WAVES (WL_THREADS / 64)
+#define WL_MAXCALL 96       /* lextree_enter calls per frame: #CI phones + 1 */
+#define WL_MAXT 16          /* lextrees per decoder (2 x -Nlextree) */
+#define WL_HEAP_LDS 1536    /* frames with at most this many new entries replay the heap in LDS */
+
+/* error bits (UCtx.err / s3a_utt_result_t.err) */
+#define WL_E_OPEN_EXIT 1    /* out.history == -1 at a word exit (LEXTREE_OPERATION_FAILURE / E_FATAL vithist.c:505) */
+#define WL_E_EXITS 2        /* more word exits in a frame than the buffers hold */
+#define WL_E_CAND 4         /* more (exit, predecessor) candidates than cand_cap */
+#define WL_E_TABLE 8        /* history table full */
+#define WL_E_LC 16          /* a word-final phone that is no left context of the unigram tree (assert lextree.c:1111) */
+#define WL_E_NOLM 32        /* a word exit without an LM word id */
+#define WL_E_SCAN 64        /* k_dec_scan's chained scan timed out */
+#define WL_E_CALLS 128      /* more lextree_enter calls than WL_MAXCALL / entries than ent_cap */
+
+struct WLm {                /* lm_t flattened (see include/cmusphinx_amd.h: s3a_lm3g_init) */
+    int32_t n_ug, n_bg, n_tg;
+    const int32_t *ug_prob, *ug_bowt, *ug_firstbg, *bg_wid, *bg_prob, *bg_bowt, *bg_firsttg, *tg_wid, *tg_prob,
+        *inclass;
+};
+
+struct WDict {              /* per dictionary word */
+    int32_t n_word, n_ci;
+    const int32_t *lwid, *fillpen, *last_ci;
+    const uint8_t *is_filler;
+};
+
+struct WPar {
+    int32_t wbeam, bghist, maxwpf, maxhist, wordend, n_lextree, epl, T, hmmbeam;
+    int32_t tree_type[WL_MAXT];
+    const int32_t *lcmap;   /* [T][n_ci + 1][2]: root-list offset / length of (tree, left context); context n_ci = none */
+};
+
+/* the pending lextree_enter calls + where the lane is (device resident, one per lane) */
+struct UCtx {
+    int32_t active, cf, nfr, cur, n_lextrans, err, thresh, n_calls, n_ent, n_groups, scan_epoch, n_tie_frames;
+    int32_t max_cand, max_new, pad0, pad1;
+    int32_t groups[8];
+    int32_t calls[4 * WL_MAXCALL];
+};
+
+struct WLane {              /* one lane's history table + per-frame scratch (device pointers) */
+    int32_t *score, *pred, *lw0, *lw1, *wid, *sf, *ef, *ascr, *lscr, *type;
+    int32_t cap;
+    int32_t *frame_start, *bestscore, *bestvh;      /* [max_frames + 2] */
+    int32_t *st;            /* [0] n_entry  [1] n_frm */
+    int32_t *ex_off, *ex_max, *ex_pref, *ex_cnt, *ex_base;      /* [ex_cap + 1] */
+    int32_t ex_cap;
+    int32_t *cand_score, *cand_slot;                /* [cand_cap] */
+    int32_t cand_cap;
+    unsigned long long *hkey, *hbest;               /* [hmask + 1] */
+    uint32_t *hfirst;
+    int32_t *hlead_e, *hlead_rank;
+    int32_t hmask;
+    int32_t *sg;            /* staging [11][new_cap]: wid sf ascr lscr score pred type lw0 lw1 slot | valid */
+    int32_t new_cap;
+    int32_t *srt;           /* [6][new_cap]: above-threshold list, sorted order, flags, scans */
+    int32_t *wfirst;        /* [n_word]: first sorted position of a word (INT_MAX when idle) */
+    int32_t *heap;          /* [6][new_cap] for the heap replay when it does not fit LDS */
+    int32_t *fstat;         /* [max_frames][8] per-frame statistics for the host */
+};
+
+/* ------------------------------------------------------------------ */
+/* lm_tg_score as a pure function (lm.c:983-995, 1241-1312, 1661-1833) */
+/* ------------------------------------------------------------------ */
+__device__ __forceinline__ int32_t
+wl_find(const int32_t *__restrict__ v, int32_t n, int32_t w)
+{
+    int32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (v[mid] < w) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && v[lo] == w) ? lo : -1;
+}
+
+__device__ __forceinline__ int32_t
+wl_bg_score(const WLm &lm, int32_t lw1, int32_t lw2, int32_t wid)
+{
+    int32_t s;
+    if (lm.n_bg == 0 || lw1 < 0)
+        s = lm.ug_prob[lw2];
+    else {
+        const int32_t b0 = lm.ug_firstbg[lw1], n = lm.ug_firstbg[lw1 + 1] - b0;
+        const int32_t i = n > 0 ? wl_find(lm.bg_wid + b0, n, lw2) : -1;
+        s = i >= 0 ? lm.bg_prob[b0 + i] : add32(lm.ug_bowt[lw1], lm.ug_prob[lw2]);
+    }
+    if (lm.inclass) s = add32(s, lm.inclass[wid]);
+    return s;
+}
+
+__device__ __forceinline__ int32_t
+wl_tg_score(const WLm &lm, int32_t lw1, int32_t lw2, int32_t lw3, int32_t wid)
+{
+    if (lm.n_tg == 0 || lw1 < 0)
+        return wl_bg_score(lm, lw2, lw3, wid);
+    const int32_t b0 = lm.ug_firstbg[lw1], nb = lm.ug_firstbg[lw1 + 1] - b0;
+    int32_t b = nb > 0 ? wl_find(lm.bg_wid + b0, nb, lw2) : -1;
+    int32_t bowt = 0;
+    if (b >= 0) {
+        b += b0;
+        bowt = lm.bg_bowt[b];
+        const int32_t t0 = lm.bg_firsttg[b], nt = lm.bg_firsttg[b + 1] - t0;
+        const int32_t i = nt > 0 ? wl_find(lm.tg_wid + t0, nt, lw3) : -1;
+        if (i >= 0) {
+            int32_t s = lm.tg_prob[t0 + i];
+            if (lm.inclass) s = add32(s, lm.inclass[wid]);
+            return s;
+        }
+    }
+    return add32(bowt, wl_bg_score(lm, lw2, lw3, wid));
+}
+
+/* ------------------------------------------------------------------ */
+/* workgroup primitives                                                */
+/* ------------------------------------------------------------------ */
+/* exclusive prefix (sum or max) of src[0..n) into dst[0..n), WL_THREADS wide; returns the total to all */
+template <bool MAXOP>
+__device__ __forceinline__ int32_t
+wl_scan(const int32_t *src, int32_t *dst, int32_t n, int32_t init)
+{
+    __shared__ int32_t ws[WL_WAVES];
+    __shared__ int32_t carry_s;
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    if (tid == 0) carry_s = init;
+    __syncthreads();
+    for (int32_t base = 0; base < n; base += WL_THREADS) {
+        const int32_t i = base + tid;
+        const int32_t x = i < n ? src[i] : (MAXOP ? INT_MIN : 0);
+        int32_t incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t y = __shfl_up(incl, o, 64);
+            if (lane >= o) incl = MAXOP ? max(incl, y) : incl + y;
+        }
+        if (lane == 63) ws[wave] = incl;
+        __syncthreads();
+        int32_t pre = carry_s;          /* everything before this wave */
+        for (int32_t w = 0; w < wave; w++) pre = MAXOP ? max(pre, ws[w]) : pre + ws[w];
+        int32_t excl = __shfl_up(incl, 1, 64);
+        excl = lane == 0 ? pre : (MAXOP ? max(pre, excl) : pre + excl);
+        if (i < n) dst[i] = excl;
+        __syncthreads();
+        if (tid == WL_THREADS - 1) carry_s = MAXOP ? max(excl, x) : excl + x;
+        __syncthreads();
+    }
+    return carry_s;
+}
+
+__device__ __forceinline__ unsigned long long
+wl_key(int32_t lw0, int32_t lw1)
+{
+    return (1ull << 62) | ((unsigned long long)(uint32_t)(lw0 + 1) << 31) | (unsigned long long)(uint32_t)(lw1 + 1);
+}
+
+__device__ __forceinline__ unsigned long long
+wl_pack(int32_t score, uint32_t seq)
+{
+    return ((unsigned long long)((uint32_t)score ^ 0x80000000u) << 32) | (unsigned long long)(0xffffffffu - seq);
+}
+
+#define WL_ALOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+/* the reference's heap (sphinxbase util/heap.c) on index arrays; val = -score.  One thread. */
+struct WlHeap {
+    int32_t *val, *data, *nl, *nr, *l, *r;
+    int32_t n_alloc, top;
+    __device__ void insert(int32_t data_, int32_t val_)
+    {
+        /* subheap_insert, heap.c:113-148, unrolled into a descent */
+        int32_t cur = top, parent = -1, side = 0;
+        int32_t d = data_, v = val_;
+        while (cur >= 0) {
+            if (val[cur] > v) { const int32_t td = data[cur], tv = val[cur]; data[cur] = d; val[cur] = v; d = td; v = tv; }
+            parent = cur;
+            if (nl[cur] > nr[cur]) { nr[cur]++; side = 1; cur = r[cur]; }
+            else { nl[cur]++; side = 0; cur = l[cur]; }
+        }
+        const int32_t k = n_alloc++;
+        data[k] = d; val[k] = v; l[k] = r[k] = -1; nl[k] = nr[k] = 0;
+        if (parent < 0) top = k;
+        else if (side) r[parent] = k; else l[parent] = k;
+    }
+    __device__ int32_t pop()            /* heap_pop + subheap_pop, heap.c:159-213; -1 when empty */
+    {
+        if (top < 0) return -1;
+        const int32_t out = data[top];
+        int32_t cur = top, parent = -1, side = 0;
+        for (;;) {
+            const int32_t lc = l[cur], rc = r[cur];
+            if (lc < 0 && rc < 0) {             /* the node disappears */
+                if (parent < 0) top = -1;
+                else if (side) r[parent] = -1; else l[parent] = -1;
+                break;
+            }
+            int32_t nx;
+            if (lc < 0) { nx = rc; nr[cur]--; side = 1; }
+            else if (rc < 0 || val[lc] < val[rc]) { nx = lc; nl[cur]--; side = 0; }
+            else { nx = rc; nr[cur]--; side = 1; }
+            data[cur] = data[nx]; val[cur] = val[nx];
+            parent = cur;
+            cur = nx;
+        }
+        return out;
+    }
+};
+
+/*
+ * One frame of the word level for one lane.  `pack` = the frame record k_dec_scan's last
+ * workgroup assembled: [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] |
+ * n_next x T | exits (wid, score, history) in tree then list order.
+ */
+__device__ __forceinline__ void
+d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par)
+{
+    __shared__ int32_t s_tb[WL_MAXT + 1];
+    __shared__ int32_t s_i[16];
+    __shared__ unsigned long long s_ci[256];
+    __shared__ unsigned long long s_u64[2];
+    __shared__ int32_t s_heap[6 * WL_HEAP_LDS];
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t T = par.T, hdr = 6 * T + 16, cf = ctx->cf;
+    const int32_t fs = L.st[0];                 /* == frame_start[cf] */
+    const int32_t *fstart = L.frame_start;
+    const int32_t *ex = pack + hdr;
+
+    /* ---- P1: the exits, their candidate counts ---- */
+    if (tid == 0) {
+        int32_t n = 0, e = 0;
+        for (int32_t t = 0; t < T; t++) {
+            s_tb[t] = n; n += pack[3 * T + 8 + t];
+            if (pack[4 * T + 8 + t] == 1) e |= WL_E_OPEN_EXIT;
+            if (pack[4 * T + 8 + t] == 2) e |= WL_E_SCAN;
+        }
+        s_tb[T] = n;
+        if (n > L.ex_cap) e |= WL_E_EXITS;
+        s_i[0] = e;
+    }
+    __syncthreads();
+    const int32_t nx = s_tb[T];
+    int32_t err = s_i[0];
+    if (err) {                                  /* (uniform) the utterance ends here, as in the reference */
+        if (tid == 0) { ctx->err |= err; ctx->active = 0; }
+        return;
+    }
+    for (int32_t e = tid; e < nx; e += WL_THREADS) {
+        const int32_t w = ex[3 * e], h = ex[3 * e + 2];
+        int32_t c = 1;
+        if (!dict.is_filler[w] && h != 0) { const int32_t f = L.ef[h]; c = fstart[f + 1] - fstart[f]; }
+        L.ex_off[e] = c;
+    }
+    const int32_t n_cand = wl_scan<false>(L.ex_off, L.ex_off, nx, 0);
+    if (tid == 0) {
+        L.ex_off[nx] = n_cand;
+        if (n_cand > L.cand_cap || 2 * (long long)n_cand > (long long)L.hmask + 1) ctx->err |= WL_E_CAND;
+        if (n_cand > ctx->max_cand) ctx->max_cand = n_cand;
+    }
+    __syncthreads();
+    if (n_cand > L.cand_cap || 2 * (long long)n_cand > (long long)L.hmask + 1) {
+        if (tid == 0) ctx->active = 0;
+        return;
+    }
+
+    /* ---- P2: every candidate's path score; per exit the maximum ---- */
+    for (int32_t e = wave; e < nx; e += WL_WAVES) {
+        const int32_t w = ex[3 * e], scr = ex[3 * e + 1], h = ex[3 * e + 2], off = L.ex_off[e];
+        const int32_t ascr = add32(scr, -L.score[h]);
+        int32_t m = INT_MIN;
+        if (dict.is_filler[w]) {
+            m = add32(scr, dict.fillpen[w]);
+            if (lane == 0) L.cand_score[off] = m;
+        }
+        else {
+            const int32_t lwid = dict.lwid[w];
+            const int32_t cnt = L.ex_off[e + 1] - off, se = h == 0 ? 0 : fstart[L.ef[h]];
+            if (lwid < 0) { if (lane == 0) atomicOr(&ctx->err, WL_E_NOLM); }
+            else
+                for (int32_t j = lane; j < cnt; j += 64) {
+                    const int32_t i = se + j;
+                    const int32_t sc = add32(add32(L.score[i], ascr), wl_tg_score(lm, L.lw1[i], L.lw0[i], lwid, w));
+                    L.cand_score[off + j] = sc;
+                    m = max(m, sc);
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        }
+        if (lane == 0) L.ex_max[e] = m;
+    }
+    __syncthreads();
+    if (ctx->err & WL_E_NOLM) { if (tid == 0) ctx->active = 0; return; }
+    /* the best score entered before each exit's first candidate; the frame's best */
+    const int32_t M = wl_scan<true>(L.ex_max, L.ex_pref, nx, INT_MIN);
+
+    /* ---- P3: which candidates enter (vithist.c:560), into which LM state ---- */
+    for (int32_t e = wave; e < nx; e += WL_WAVES) {
+        const int32_t w = ex[3 * e], h = ex[3 * e + 2], off = L.ex_off[e], cnt = L.ex_off[e + 1] - off;
+        const bool filler = dict.is_filler[w] != 0;
+        const int32_t lwid = filler ? 0 : dict.lwid[w], se = h == 0 ? 0 : fstart[L.ef[h]];
+        int32_t running = L.ex_pref[e];
+        for (int32_t j0 = 0; j0 < cnt; j0 += 64) {
+            const int32_t j = j0 + lane;
+            const int32_t sc = j < cnt ? L.cand_score[off + j] : INT_MIN;
+            int32_t incl = sc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int32_t y = __shfl_up(incl, o, 64);
+                if (lane >= o) incl = max(incl, y);
+            }
+            int32_t before = __shfl_up(incl, 1, 64);
+            before = lane == 0 ? running : max(running, before);
+            const bool in = j < cnt && (filler || add32(sc, -par.wbeam) >= before);
+            int32_t slot = -1;
+            if (in) {
+                const unsigned long long key = filler ? wl_key(L.lw0[h], L.lw1[h]) : wl_key(lwid, L.lw0[se + j]);
+                uint32_t hh = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)L.hmask;
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&L.hkey[hh], 0ull, key);
+                    if (old == 0ull || old == key) break;
+                    hh = (hh + 1) & (uint32_t)L.hmask;
+                }
+                slot = (int32_t)hh;
+                atomicMin(&L.hfirst[hh], (uint32_t)(off + j));
+                atomicMax(&L.hbest[hh], wl_pack(sc, (uint32_t)(off + j)));
+            }
+            if (j < cnt) L.cand_slot[off + j] = slot;
+            running = max(running, __shfl(incl, 63, 64));
+        }
+    }
+    __syncthreads();
+
+    /* ---- P4: the first entered candidate of each LM state founds the entry: rank within its exit ---- */
+    for (int32_t e = wave; e < nx; e += WL_WAVES) {
+        const int32_t off = L.ex_off[e], cnt = L.ex_off[e + 1] - off;
+        int32_t carry = 0;
+        for (int32_t j0 = 0; j0 < cnt; j0 += 64) {
+            const int32_t j = j0 + lane;
+            const int32_t slot = j < cnt ? L.cand_slot[off + j] : -1;
+            const bool lead = slot >= 0 && WL_ALOAD(&L.hfirst[slot]) == (uint32_t)(off + j);
+            const unsigned long long mk = __ballot(lead);
+            if (lead) { L.hlead_e[slot] = e; L.hlead_rank[slot] = carry + __popcll(mk & ((1ull << lane) - 1ull)); }
+            carry += __popcll(mk);
+        }
+        if (lane == 0) L.ex_cnt[e] = carry;
+    }
+    __syncthreads();
+    const int32_t n_new = wl_scan<false>(L.ex_cnt, L.ex_base, nx, 0);
+    if (tid == 0) {
+        if (n_new > L.new_cap || (long long)fs + n_new > L.cap) ctx->err |= WL_E_TABLE;
+        if (n_new > ctx->max_new) ctx->max_new = n_new;
+    }
+    __syncthreads();
+    if (n_new > L.new_cap || (long long)fs + n_new > L.cap) { if (tid == 0) ctx->active = 0; return; }
+    int32_t *sg_wid = L.sg, *sg_sf = L.sg + L.new_cap, *sg_ascr = L.sg + 2 * L.new_cap, *sg_lscr = L.sg + 3 * L.new_cap,
+        *sg_score = L.sg + 4 * L.new_cap, *sg_pred = L.sg + 5 * L.new_cap, *sg_type = L.sg + 6 * L.new_cap,
+        *sg_lw0 = L.sg + 7 * L.new_cap, *sg_lw1 = L.sg + 8 * L.new_cap, *sg_slot = L.sg + 9 * L.new_cap,
+        *sg_valid = L.sg + 10 * L.new_cap;
+
+    /* ---- P5: the best candidate of each LM state writes the entry (staged in founding order) ---- */
+    for (int32_t e = wave; e < nx; e += WL_WAVES) {
+        const int32_t w = ex[3 * e], scr = ex[3 * e + 1], h = ex[3 * e + 2], off = L.ex_off[e], cnt = L.ex_off[e + 1] - off;
+        const bool filler = dict.is_filler[w] != 0;
+        const int32_t se = h == 0 ? 0 : fstart[L.ef[h]], ascr = add32(scr, -L.score[h]);
+        int32_t ty = 0;
+        for (int32_t t = 0; t < T; t++) if (e >= s_tb[t]) ty = par.tree_type[t];
+        for (int32_t j = lane; j < cnt; j += 64) {
+            const int32_t slot = L.cand_slot[off + j];
+            if (slot < 0) continue;
+            const int32_t sc = L.cand_score[off + j];
+            if (WL_ALOAD(&L.hbest[slot]) != wl_pack(sc, (uint32_t)(off + j))) continue;
+            const int32_t k = L.ex_base[L.hlead_e[slot]] + L.hlead_rank[slot];
+            sg_wid[k] = w; sg_sf[k] = L.ef[h] + 1; sg_ascr[k] = ascr; sg_score[k] = sc; sg_type[k] = ty; sg_slot[k] = slot;
+            if (filler) { sg_lscr[k] = dict.fillpen[w]; sg_pred[k] = h; sg_lw0[k] = L.lw0[h]; sg_lw1[k] = L.lw1[h]; }
+            else {
+                const int32_t i = se + j;
+                sg_lscr[k] = add32(sc, -add32(L.score[i], ascr)); sg_pred[k] = i; sg_lw0[k] = dict.lwid[w]; sg_lw1[k] = L.lw0[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    /* ---- P6: vithist_prune: the entries at or above the threshold, best first ---- */
+    const int32_t prune_beam = add32(pack[3 * T + 2], -pack[3 * T + 4]);    /* word_thres - bestwordscore */
+    const int32_t th = add32(M, prune_beam);
+    int32_t *a_list = L.srt, *a_sorted = L.srt + L.new_cap, *a_c = L.srt + 2 * L.new_cap, *a_scan = L.srt + 3 * L.new_cap,
+        *a_first = L.srt + 4 * L.new_cap;
+    if (tid == 0) { s_i[1] = 0; s_i[2] = 0; s_i[3] = INT_MAX; }
+    for (int32_t k = tid; k < n_new; k += WL_THREADS) sg_valid[k] = 0;
+    __syncthreads();
+    for (int32_t k = tid; k < n_new; k += WL_THREADS)
+        if (sg_score[k] >= th) a_list[atomicAdd(&s_i[1], 1)] = k;
+    __syncthreads();
+    const int32_t n_th = s_i[1];
+    for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+        const int32_t k = a_list[q], s = sg_score[k];
+        int32_t r = 0, tie = 0;
+        for (int32_t p = 0; p < n_th; p++) {
+            const int32_t k2 = a_list[p], s2 = sg_score[k2];
+            r += (s2 > s || (s2 == s && k2 < k)) ? 1 : 0;
+            tie |= (s2 == s && k2 != k) ? 1 : 0;
+        }
+        a_sorted[r] = k;
+        if (tie) s_i[2] = 1;
+    }
+    __syncthreads();
+    if (s_i[2] && par.maxhist > 0) {
+        /* two entries above the threshold tie: their pop order is the heap's.  Replay it (one thread):
+         * every entry of the frame inserted in table order, then popped until the threshold */
+        if (tid == 0) {
+            WlHeap hp;
+            int32_t *base = n_new <= WL_HEAP_LDS ? s_heap : L.heap;
+            const int32_t stride = n_new <= WL_HEAP_LDS ? WL_HEAP_LDS : L.new_cap;
+            hp.val = base; hp.data = base + stride; hp.nl = base + 2 * stride; hp.nr = base + 3 * stride;
+            hp.l = base + 4 * stride; hp.r = base + 5 * stride; hp.n_alloc = 0; hp.top = -1;
+            for (int32_t k = 0; k < n_new; k++) hp.insert(k, (int32_t)(0u - (uint32_t)sg_score[k]));
+            for (int32_t r = 0; r < n_th; r++) a_sorted[r] = hp.pop();
+            ctx->n_tie_frames++;
+        }
+        __syncthreads();
+    }
+    /* the walk of vithist.c:683-713 over the sorted entries, in closed form:
+     *  - only the first filler entry counts ("keep only one best filler word entry per frame");
+     *  - the distinct words in order of first appearance: the first maxwpf of them are kept;
+     *  - of a kept word, its first entry, and (unless -bghist) its others;
+     *  - the first maxhist such entries are valid. */
+    for (int32_t r = tid; r < n_th; r += WL_THREADS)
+        if (dict.is_filler[sg_wid[a_sorted[r]]]) atomicMin(&s_i[3], r);
+    __syncthreads();
+    const int32_t first_filler = s_i[3];
+    for (int32_t r = tid; r < n_th; r += WL_THREADS) {
+        const int32_t w = sg_wid[a_sorted[r]];
+        if (!(dict.is_filler[w] && r > first_filler)) atomicMin(&L.wfirst[w], r);
+    }
+    __syncthreads();
+    for (int32_t r = tid; r < n_th; r += WL_THREADS) {
+        const int32_t w = sg_wid[a_sorted[r]];
+        const bool elig = !(dict.is_filler[w] && r > first_filler);
+        const int32_t f = elig ? WL_ALOAD(&L.wfirst[w]) : -1;
+        a_first[r] = f;
+        a_c[r] = (elig && f == r) ? 1 : 0;
+    }
+    __syncthreads();
+    (void)wl_scan<false>(a_c, a_scan, n_th, 0);         /* a_scan[r] = index of the word first seen at r */
+    __syncthreads();
+    for (int32_t r = tid; r < n_th; r += WL_THREADS) {
+        const int32_t f = a_first[r];
+        int32_t c = 0;
+        if (f >= 0 && a_scan[f] < par.maxwpf && (f == r || !par.bghist)) c = 1;
+        a_c[r] = c;
+    }
+    __syncthreads();
+    for (int32_t r = tid; r < n_th; r += WL_THREADS) L.wfirst[sg_wid[a_sorted[r]]] = INT_MAX;
+    (void)wl_scan<false>(a_c, a_first, n_th, 0);        /* entries kept before r */
+    __syncthreads();
+    for (int32_t r = tid; r < n_th; r += WL_THREADS)
+        if (a_c[r] && a_first[r] < par.maxhist) sg_valid[a_sorted[r]] = 1;
+    __syncthreads();
+    /* vithist_frame_gc: the valid entries, in table order, become the frame's entries */
+    const int32_t n_valid = wl_scan<false>(sg_valid, a_scan, n_new, 0);
+    if (tid == 0) { s_u64[0] = 0ull; }
+    if (tid < 256) s_ci[tid] = 0ull;
+    __syncthreads();
+    for (int32_t k = tid; k < n_new; k += WL_THREADS) {
+        const int32_t slot = sg_slot[k];
+        L.hkey[slot] = 0ull; L.hfirst[slot] = 0xffffffffu; L.hbest[slot] = 0ull;   /* the table is clean again */
+        if (!sg_valid[k]) continue;
+        const int32_t id = fs + a_scan[k];
+        L.wid[id] = sg_wid[k]; L.sf[id] = sg_sf[k]; L.ef[id] = cf; L.ascr[id] = sg_ascr[k]; L.lscr[id] = sg_lscr[k];
+        L.score[id] = sg_score[k]; L.pred[id] = sg_pred[k]; L.type[id] = sg_type[k]; L.lw0[id] = sg_lw0[k]; L.lw1[id] = sg_lw1[k];
+        const unsigned long long key = wl_pack(sg_score[k], (uint32_t)id);
+        atomicMax(&s_u64[0], key);                                      /* best valid entry, the first on ties */
+        atomicMax(&s_ci[dict.last_ci[sg_wid[k]]], key);                 /* ... per word-final CI phone */
+    }
+    __syncthreads();
+
+    /* ---- P7: srch_utt_word_trans, vithist_frame_windup, the lane's next frame ---- */
+    if (tid == 0) {
+        const int32_t n_entry = fs + n_valid;
+        const int32_t bestvh = s_u64[0] ? (int32_t)(0xffffffffu - (uint32_t)(s_u64[0] & 0xffffffffull)) : -1;
+        const int32_t bh = pack[3 * T + 3];
+        int32_t n_calls = 0, n_ent = 0, n_groups = 0, e2 = 0;
+        L.bestscore[cf] = nx > 0 ? M : INT_MIN;
+        L.bestvh[cf] = bestvh;
+        if (bestvh >= 0) {
+            int32_t maxp = INT_MIN;
+            int32_t k = ctx->n_lextrans++;
+            k = (k % (par.n_lextree * par.epl)) / par.epl;
+            for (int32_t p = 0; p < dict.n_ci; p++)
+                if (s_ci[p]) maxp = max(maxp, (int32_t)((uint32_t)(s_ci[p] >> 32) ^ 0x80000000u));
+            const int32_t lo = n_ent;
+            for (int32_t p = 0; p < dict.n_ci; p++) {
+                if (!s_ci[p]) continue;
+                const int32_t bs = (int32_t)((uint32_t)(s_ci[p] >> 32) ^ 0x80000000u);
+                const int32_t bv = (int32_t)(0xffffffffu - (uint32_t)(s_ci[p] & 0xffffffffull));
+                if (!(par.wordend == 0 || bs > add32(par.wordend, maxp))) continue;
+                const int32_t *m = par.lcmap + ((size_t)k * (dict.n_ci + 1) + p) * 2;
+                if (m[1] < 0) { e2 |= WL_E_LC; continue; }
+                if (n_calls >= WL_MAXCALL - 1) { e2 |= WL_E_CALLS; break; }
+                ctx->calls[4 * n_calls] = bs; ctx->calls[4 * n_calls + 1] = bv; ctx->calls[4 * n_calls + 2] = m[0];
+                ctx->calls[4 * n_calls + 3] = n_ent;
+                n_ent += m[1]; n_calls++;
+            }
+            if (n_calls > 0) {
+                ctx->groups[0] = k; ctx->groups[1] = lo; ctx->groups[2] = n_ent; ctx->groups[3] = 0;
+                n_groups = 1;
+            }
+            {   /* the filler lextree of this transition: the frame's best exit, no left context */
+                const int32_t tf = par.n_lextree + k;
+                const int32_t *m = par.lcmap + ((size_t)tf * (dict.n_ci + 1) + dict.n_ci) * 2;
+                ctx->calls[4 * n_calls] = L.bestscore[cf]; ctx->calls[4 * n_calls + 1] = bestvh;
+                ctx->calls[4 * n_calls + 2] = m[0]; ctx->calls[4 * n_calls + 3] = n_ent;
+                ctx->groups[4 * n_groups] = tf; ctx->groups[4 * n_groups + 1] = n_ent; ctx->groups[4 * n_groups + 3] = n_calls;
+                n_ent += m[1]; n_calls++;
+                ctx->groups[4 * n_groups + 2] = n_ent;
+                n_groups++;
+            }
+        }
+        ctx->n_calls = n_calls; ctx->n_ent = n_ent; ctx->n_groups = n_groups;
+        ctx->thresh = add32(bh, par.hmmbeam);           /* bm->bestscore + bm->hmm */
+        L.st[0] = n_entry; L.st[1] = cf + 1;
+        L.frame_start[cf + 1] = n_entry;
+        L.bestscore[cf + 1] = INT_MIN; L.bestvh[cf + 1] = -1;
+        /* what the host keeps of the frame: srch->ascale[], stat_t counters */
+        int32_t *fsr = L.fstat + (size_t)cf * 8;
+        fsr[0] = pack[5 * T + 8 + 6]; fsr[1] = pack[3 * T + 5]; fsr[2] = pack[5 * T + 8 + 1]; fsr[3] = pack[5 * T + 8 + 2];
+        fsr[4] = pack[5 * T + 8 + 3]; fsr[5] = pack[5 * T + 8 + 4]; fsr[6] = pack[3 * T + 6]; fsr[7] = nx;
+        if (e2) ctx->err |= e2;
+        ctx->cf = cf + 1;
+        ctx->cur ^= 1;                                  /* lextree_active_swap */
+        if (cf + 1 >= ctx->nfr || e2) ctx->active = 0;
+    }
+}
+
+#endif

@@ -611,6 +611,90 @@ int32_t s3a_approx_cont_mgau_frame_eval_dev(s3a_scorer_t *sc, s3a_comsen_t *cs, 
                                             int32_t *n_gau_eval);
 
 /* ===================================================================== */
+/* the word level + whole utterances on the device (s3a_utt.hip)          */
+/* ===================================================================== */
+/*
+ * with the word level on the device an utterance needs no host between its
+ * first and its last frame -- the `decode` slot of srch_funcs_t (sphinx3/include/srch.h:599-603;
+ * srch_utt_decode_blk hands the whole block to it, libsearch/srch.c:673-675).
+ *
+ * s3a_lm3g_t = lm_t (sphinx3/include/lm.h:559-660) flattened by the caller: unigram w has prob
+ * ug_prob[w], back-off ug_bowt[w] and the bigrams [ug_firstbg[w], ug_firstbg[w+1]); bigram b has
+ * second word bg_wid[b], prob bg_prob[b] (= lm->bgprob[bg.probid].l), back-off bg_bowt[b]
+ * (= lm->tgbowt[bg.bowtid].l) and the trigrams [bg_firsttg[b], bg_firsttg[b+1]) (absolute:
+ * tg_segbase[b >> log_bg_seg_sz] + bg.firsttg, lm.c:1435-1443); trigram t has third word tg_wid[t]
+ * and prob tg_prob[t].  All values as lm_set_param left them (language weight, insertion penalty
+ * applied; lm.c:355-388).  Runs must be sorted and duplicate-free (checked).  n_bg = 0 / n_tg = 0
+ * select lm->ugonly / lm->bgonly behaviour.  inclass_ugscore (per DICTIONARY word, or NULL) =
+ * lm->inclass_ugscore of class-based LMs.  "No LM word" (BAD_LMWID) is any negative id.
+ * s3a_lm3g_tg_score is lm_tg_score (lm.c:1661-1833) on the host copy.
+ */
+typedef struct s3a_lm3g_s s3a_lm3g_t;
+s3a_lm3g_t *s3a_lm3g_init(int32_t n_ug, const int32_t *ug_prob, const int32_t *ug_bowt,
+                          const int32_t *ug_firstbg, int32_t n_bg, const int32_t *bg_wid,
+                          const int32_t *bg_prob, const int32_t *bg_bowt, const int32_t *bg_firsttg,
+                          int32_t n_tg, const int32_t *tg_wid, const int32_t *tg_prob,
+                          const int32_t *inclass_ugscore, int32_t n_dictword);
+void s3a_lm3g_free(s3a_lm3g_t *lm);
+int32_t s3a_lm3g_tg_score(const s3a_lm3g_t *lm, int32_t lw1, int32_t lw2, int32_t lw3, int32_t wid);
+
+/* What the word level reads of dict_t / fillpen_t / mdef_t / vithist_t / histprune_t / beam_t /
+ * srch_TST_graph_t (the caller's arrays are copied). */
+typedef struct {
+    int32_t n_word, n_ci;           /* dict_size, mdef_n_ciphone */
+    const int32_t *lwid;            /* [n_word] lm->dict2lmwid[w], negative = none */
+    const uint8_t *is_filler;       /* [n_word] dict_filler_word */
+    const int32_t *fillpen;         /* [n_word] fillpen(kbcore_fillpen, w) of filler words */
+    const int32_t *last_ci;         /* [n_word] dict_last_phone, filler phones mapped to mdef_silphone */
+    int32_t startwid, finishwid, silwid;    /* dict_startwid / _finishwid / _silwid */
+    int32_t start_lwid, finish_lwid;        /* lm_startwid / lm_finishwid */
+    int32_t sil_ci;                 /* mdef_silphone */
+    int32_t wbeam_vh, bghist;       /* vithist_t.wbeam, .bghist (vithist.c:160-190) */
+    int32_t maxwpf, maxhistpf;      /* histprune_t */
+    int32_t wordend_beam;           /* beam_t.wordend */
+    int32_t n_lextree, epl;         /* srch_TST_graph_t.n_lextree, .epl */
+    int32_t hmmbeam, pbeam, wbeam;  /* beam_t.hmm, .ptrans, .word */
+    int32_t ptranskip, maxhmmpf;    /* beam_t.ptranskip, histprune_t.maxhmmpf */
+    const int32_t *tree_type;       /* [2 * n_lextree] lextree_t.type of the lexsearch's trees */
+} s3a_wordlevel_cfg_t;
+
+/*
+ * s3a_uttdec_t: n_lanes decoder lanes over ONE model (proto's lextrees are shared, every lane gets
+ * its own search state, senone state and history table; scorer arguments as s3a_scorer_init).
+ * max_frames bounds an utterance; vh_cap (history entries per utterance, 0 = max_frames x
+ * maxhistpf) and cand_cap ((word exit, predecessor) pairs per frame, 0 = 1 M) size the buffers --
+ * exceeding them ends the utterance with an error, never silently.
+ *   s3a_uttdec_decode   n_utt <= n_lanes utterances, feat[z] = n_frames[z] rows of feat_stride
+ *                       floats (host): uploads, runs every frame of every utterance on the
+ *                       device (srch_TST_begin .. the last frame_windup) and reads the history
+ *                       tables back.  Blocks.
+ *   s3a_uttdec_result   the finished table of lane z as read-only arrays (valid until the next
+ *                       decode): vithist_entry_t fields by entry id, frame_start / bestscore /
+ *                       bestvh by frame (n_frm + 1 values), frame_stat[f] = {senscale (->
+ *                       srch->ascale[f]), #HMMs, #CD senones, #CD Gaussians, #CI senones, #CI
+ *                       Gaussians, histogram pruning applied, #word exits}.
+ */
+typedef struct s3a_uttdec_s s3a_uttdec_t;
+typedef struct {
+    int32_t err, n_entry, n_frm, n_frames;
+    const int32_t *score, *pred, *lw0, *lw1, *wid, *sf, *ef, *ascr, *lscr, *type;
+    const int32_t *frame_start, *bestscore, *bestvh;
+    const int32_t *frame_stat;
+    int32_t max_cand, max_new, n_tie_frames;
+} s3a_utt_result_t;
+s3a_uttdec_t *s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t *cd2cisen,
+                              int32_t n_sen, int32_t n_ci_sen, int32_t ds_ratio, int32_t cond_ds,
+                              double ci_pbeam, float tighten_factor, int32_t max_cd, s3a_comsen_t *cs,
+                              s3a_lm3g_t *lm, const s3a_wordlevel_cfg_t *cfg, int32_t n_lanes,
+                              int32_t max_frames, int32_t vh_cap, int32_t cand_cap);
+void s3a_uttdec_free(s3a_uttdec_t *ud);
+int32_t s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat,
+                          const int32_t *n_frames, int32_t feat_stride);
+int32_t s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out);
+int32_t s3a_uttdec_n_lanes(const s3a_uttdec_t *ud);
+double s3a_uttdec_last_decode_ms(const s3a_uttdec_t *ud);    /* HIP-event time of the last decode's frames */
+
+/* ===================================================================== */
 /* measurement hooks used by bench.py (HIP events on the launch stream)   */
 /* ===================================================================== */
 /*

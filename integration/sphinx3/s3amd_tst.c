@@ -1185,6 +1185,217 @@ concat_parts(const char *dst, int n)
     fclose(out);
 }
 
+#ifndef LT_ORACLE
+/* ------------------------------------------------------------------ */
+/* S3A_UTT=L: whole utterances on the device, L at a time              */
+/* ------------------------------------------------------------------ */
+/*
+ * One kb_t (the models, dictionary and LM are loaded ONCE), one s3a_uttdec_t with L lanes.  The
+ * control file is walked by the reference's own ctl_process; its per-utterance callback computes the
+ * features exactly as utt_decode does (libAPI/utt.c:185-258) and QUEUES the utterance; every L
+ * utterances the queue is decoded in one s3a_uttdec_decode call -- srch_TST_begin to the last
+ * frame_windup of every utterance on the device, no host work per frame -- and each utterance is then
+ * finished in control-file order by the reference's own code: srch_utt_begin, the history table
+ * read back into its vithist_t (vithist_fill), srch_utt_end (vithist_utt_end, backtrace, -hyp /
+ * -hypseg / lattices / statistics).
+ */
+typedef struct { char *uttid, *uttfile; float32 *feat; int32 nfr; } uq_t;
+static s3a_uttdec_t *g_ud;
+static s3a_lm3g_t *g_lm3g;
+static uq_t *g_uq;
+static int32 g_uq_n, g_uq_cap;
+static kb_t *g_ukb;
+static double g_t_dev, g_t_fin, g_t_feat;
+static long g_utt_frames, g_max_cand, g_max_new, g_tie_frames;
+
+static int
+utt_begin_slot(void *srch)              /* srch_TST_begin without the device work (the lanes did it) */
+{
+    srch_t *s = srch;
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    vithist_utt_reset(tstg->vithist);
+    histprune_zero_histbin(tstg->histprune);
+    vithist_utt_begin(tstg->vithist, s->kbc);
+    tstg->n_lextrans = 1;
+    return SRCH_SUCCESS;
+}
+
+static int
+utt_end_slot(void *srch)                /* srch_TST_end, :514-560 */
+{
+    srch_t *s = srch;
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    s->exit_id = vithist_utt_end(tstg->vithist, s->kbc);
+    s->stat->utt_wd_exit = vithist_n_entry(tstg->vithist);
+    histprune_showhistbin(tstg->histprune, s->stat->nfr, s->uttid);
+    lm_cache_stats_dump(kbcore_lm(s->kbc));
+    lm_cache_reset(kbcore_lm(s->kbc));
+    return (s->exit_id >= 0) ? SRCH_SUCCESS : SRCH_FAILURE;
+}
+
+static void
+utt_finish(kb_t *kb, int32 z)
+{
+    srch_t *s = kb->srch;
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    histprune_t *hp = tstg->histprune;
+    stat_t *st = kb->stat;
+    uq_t *q = &g_uq[z];
+    s3a_utt_result_t r;
+    int32 f;
+
+    if (s3a_uttdec_result(g_ud, z, &r) != S3A_OK) die("uttdec result");
+    kb_set_uttid(q->uttid, q->uttfile, kb);
+    s->uttid = kb->uttid;
+    s->uttfile = kb->uttfile;
+    E_INFO("Processing: %s\n", q->uttid);
+    utt_begin(kb);                              /* srch_utt_begin -> utt_begin_slot */
+    while (r.n_frames >= s->ascale_sz) {        /* srch.c:697-704 */
+        s->ascale = (int32 *)ckd_realloc(s->ascale, (s->ascale_sz + DFLT_UTT_SIZE) * sizeof(int32));
+        s->ascale_sz += DFLT_UTT_SIZE;
+    }
+    for (f = 0; f < r.n_frames; f++) {
+        const int32 *fs = r.frame_stat + 8 * f;
+        s->ascale[f] = fs[0];                   /* srch.c:752 */
+        st->utt_hmm_eval += fs[1]; st->utt_sen_eval += fs[2]; st->utt_gau_eval += fs[3];
+        st->utt_cisen_eval += fs[4]; st->utt_cigau_eval += fs[5];
+        if (fs[1] / hp->hmm_hist_binsize > hp->hmm_hist_bins - 1) hp->hmm_hist[hp->hmm_hist_bins - 1]++;
+        else hp->hmm_hist[fs[1] / hp->hmm_hist_binsize]++;
+        if (fs[6]) g_histframes++;
+    }
+    st->nfr += r.n_frames;                      /* srch.c:839 */
+    g_frames += r.n_frames;
+    if (r.max_cand > g_max_cand) g_max_cand = r.max_cand;
+    if (r.max_new > g_max_new) g_max_new = r.max_new;
+    g_tie_frames += r.n_tie_frames;
+    vithist_fill(tstg->vithist, r.n_entry, r.n_frm, r.score, r.pred, r.lw0, r.lw1, r.wid, r.sf, r.ef, r.ascr, r.lscr,
+                 r.type, r.frame_start, r.bestscore, r.bestvh, kbcore_lm(kb->kbcore));
+    utt_end(kb);                                /* srch_utt_end -> utt_end_slot, gen_hyp, match_write ... */
+    st->tot_fr += st->nfr;
+    ckd_free(q->uttid); ckd_free(q->uttfile); ckd_free(q->feat);
+}
+
+static void
+utt_flush(kb_t *kb)
+{
+    const float **feat;
+    int32 *nfr, z;
+    double t0;
+    if (g_uq_n == 0) return;
+    feat = ckd_calloc(g_uq_n, sizeof(*feat));
+    nfr = ckd_calloc(g_uq_n, sizeof(*nfr));
+    for (z = 0; z < g_uq_n; z++) { feat[z] = g_uq[z].feat; nfr[z] = g_uq[z].nfr; g_utt_frames += g_uq[z].nfr; }
+    t0 = now_s();
+    if (s3a_uttdec_decode(g_ud, g_uq_n, feat, nfr, kbcore_fcb(kb->kbcore)->stream_len[0]) != S3A_OK) die("uttdec decode");
+    g_t_dev += now_s() - t0;
+    t0 = now_s();
+    for (z = 0; z < g_uq_n; z++) utt_finish(kb, z);
+    g_t_fin += now_s() - t0;
+    g_uq_n = 0;
+    ckd_free(feat); ckd_free(nfr);
+}
+
+/* ctl_process callback: utt_decode's feature half (libAPI/utt.c:185-245), then queue */
+static void
+utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
+{
+    kb_t *kb = data;
+    kbcore_t *kbcore = kb->kbcore;
+    cmd_ln_t *config = kbcore_config(kbcore);
+    int32 total_frame, veclen = kbcore_fcb(kbcore)->stream_len[0], t;
+    uq_t *q;
+    double t0 = now_s();
+
+    if (cmd_ln_boolean_r(config, "-adcin"))
+        E_FATAL("tst shim: -adcin is not supported with S3A_UTT (utt.c's wavfile_read is static)\n");
+    if (ur->lmname != NULL || ur->regmatname != NULL)
+        E_FATAL("tst shim: per-utterance LM / MLLR switching is not supported with S3A_UTT\n");
+    if ((total_frame = feat_s2mfc2feat(kbcore_fcb(kbcore), ur->uttfile, cmd_ln_str_r(config, "-cepdir"),
+                                       cmd_ln_str_r(config, "-cepext"), sf, ef, kb->feat, S3_MAX_FRAMES)) < 0)
+        E_FATAL("Cannot read file %s. Forced exit\n", ur->uttfile);
+    q = &g_uq[g_uq_n++];
+    q->uttid = ckd_salloc(uttid);
+    q->uttfile = ckd_salloc(ur->uttfile);
+    q->nfr = total_frame;
+    q->feat = ckd_calloc((size_t)total_frame * veclen + 1, sizeof(float32));
+    for (t = 0; t < total_frame; t++)
+        memcpy(q->feat + (size_t)t * veclen, kb->feat[t][0], veclen * sizeof(float32));
+    g_t_feat += now_s() - t0;
+    if (g_uq_n == g_uq_cap) utt_flush(kb);
+}
+
+static int
+utt_mode_main(int argc, char *argv[], int n_lanes)
+{
+    static kb_t kb;
+    cmd_ln_t *config = cmd_ln_get();
+    srch_t *s;
+    srch_TST_graph_t *tstg;
+    kbcore_t *kbc;
+    mdef_t *mdef;
+    wl_flat_t *w;
+    s3a_wordlevel_cfg_t cfg;
+    int32 *tree_type, t;
+    double t_load = now_s(), t_dec;
+    (void)argc; (void)argv;
+
+    kb_init(&kb, config);
+    s = kb.srch;
+    if (s->op_mode != 4) E_FATAL("tst shim: -op_mode 4 (fwdtree) only\n");
+    tstg = s->grh->graph_struct;
+    kbc = kb.kbcore;
+    mdef = kbcore_mdef(kbc);
+    backend_init(&kb, tstg);
+    w = flatten_lm(kbc);
+    g_lm3g = s3a_lm3g_init(w->n_ug, w->ug_prob, w->ug_bowt, w->ug_firstbg, w->n_bg, w->bg_wid, w->bg_prob, w->bg_bowt,
+                           w->bg_firsttg, w->n_tg, w->tg_wid, w->tg_prob, w->inclass, w->n_word);
+    if (!g_lm3g) die("s3a_lm3g_init");
+    tree_type = ckd_calloc(g_ntree, 4);
+    for (t = 0; t < g_ntree; t++) tree_type[t] = g_flat[t]->type;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.n_word = w->n_word; cfg.n_ci = w->n_ci; cfg.lwid = w->lwid; cfg.is_filler = w->is_filler; cfg.fillpen = w->fillpen;
+    cfg.last_ci = w->last_ci; cfg.startwid = w->startwid; cfg.finishwid = w->finishwid; cfg.silwid = w->silwid;
+    cfg.start_lwid = w->start_lwid; cfg.finish_lwid = w->finish_lwid; cfg.sil_ci = mdef_silphone(mdef);
+    cfg.wbeam_vh = tstg->vithist->wbeam; cfg.bghist = tstg->vithist->bghist;
+    cfg.maxwpf = tstg->histprune->maxwpf; cfg.maxhistpf = tstg->histprune->maxhistpf;
+    cfg.wordend_beam = s->beam->wordend; cfg.n_lextree = tstg->n_lextree; cfg.epl = tstg->epl;
+    cfg.hmmbeam = s->beam->hmm; cfg.pbeam = s->beam->ptrans; cfg.wbeam = s->beam->word;
+    cfg.ptranskip = s->beam->ptranskip; cfg.maxhmmpf = tstg->histprune->maxhmmpf; cfg.tree_type = tree_type;
+    g_ud = s3a_uttdec_init(g_ls, g_gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen, cmd_ln_int32_r(config, "-ds"),
+                           cmd_ln_int32_r(config, "-cond_ds"), cmd_ln_float64_r(config, "-ci_pbeam"),
+                           cmd_ln_float32_r(config, "-tighten_factor"), cmd_ln_int32_r(config, "-maxcdsenpf"), g_cs,
+                           g_lm3g, &cfg, n_lanes, S3_MAX_FRAMES, getenv("S3A_UTT_VHCAP") ? atoi(getenv("S3A_UTT_VHCAP")) : 0,
+                           getenv("S3A_UTT_CANDCAP") ? atoi(getenv("S3A_UTT_CANDCAP")) : 0);
+    if (!g_ud) die("s3a_uttdec_init");
+    s->funcs->utt_begin = utt_begin_slot;
+    s->funcs->utt_end = utt_end_slot;
+    g_uq_cap = n_lanes;
+    g_uq = ckd_calloc(n_lanes, sizeof(*g_uq));
+    g_ukb = &kb;
+    t_load = now_s() - t_load;
+    t_dec = now_s();
+    kb.stat->tm = ctl_process(cmd_ln_str_r(config, "-ctl"), cmd_ln_str_r(config, "-ctl_lm"), cmd_ln_str_r(config, "-ctl_mllr"),
+                              cmd_ln_int32_r(config, "-ctloffset"), cmd_ln_int32_r(config, "-ctlcount"), utt_collect, &kb);
+    utt_flush(&kb);
+    t_dec = now_s() - t_dec;
+    if (kb.matchsegfp) fclose(kb.matchsegfp);
+    if (kb.matchfp) fclose(kb.matchfp);
+    if (g_frames == 0) E_FATAL("tst shim: nothing was decoded\n");
+    E_INFO("tst shim: %ld frames searched by the replacement backend in %d lane(s), whole utterances on the device\n",
+           g_frames, n_lanes);
+    E_INFO("tst shim: histogram pruning (lextree_hmm_histbin) applied in %ld frames\n", g_histframes);
+    E_INFO("tst shim utt mode: word level: at most %ld candidates and %ld new history entries in a frame; "
+           "%ld frames replayed the reference's heap (tied scores)\n", g_max_cand, g_max_new, g_tie_frames);
+    E_INFO("tst shim utt mode timing: device decode %.3f s (%.1f us/frame-lane, %.0f x real time aggregate), "
+           "features %.3f s, hypotheses + output %.3f s\n", g_t_dev, 1e6 * g_t_dev / g_frames,
+           0.01 * g_frames / g_t_dev, g_t_feat, g_t_fin);
+    E_INFO("tst shim throughput: %ld frames, decode-only %.3f s = %.0f x real time aggregate "
+           "(%.3f s incl. loading %d decoders one after another)\n",
+           g_frames, t_dec, 0.01 * g_frames / t_dec, t_dec + t_load, 1);
+    return 0;
+}
+#endif
+
 int
 main(int argc, char *argv[])
 {
@@ -1202,6 +1413,8 @@ main(int argc, char *argv[])
     unlimit();
     config = cmd_ln_get();
 #ifndef LT_ORACLE
+    if (getenv("S3A_UTT") && atoi(getenv("S3A_UTT")) > 0)
+        return utt_mode_main(argc, argv, atoi(getenv("S3A_UTT")));
     if (getenv("S3A_BATCH") && atoi(getenv("S3A_BATCH")) > 0) {
         if (n_streams < 1) n_streams = 1;
         g_n_groups = atoi(getenv("S3A_BATCH"));
