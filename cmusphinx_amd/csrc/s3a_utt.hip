@@ -44,7 +44,6 @@ struct ULane {
     uint8_t *sen_act;
     int32_t *scr, *misc, *bstidx, *bstscr, *updatetime, *gpart;
     /* this utterance */
-    const float *feat;          /* [nfr][D4 * 4] */
     UCtx *ctx;
     int32_t *pack;
     WLane w;
@@ -126,7 +125,7 @@ ku_gated(const ULane *__restrict__ lanes, UShared S)
     LANE;
     const int32_t lo = CI ? 0 : S.n_ci_sen, hi = CI ? S.n_ci_sen : S.n_sen, cf = ctx->cf;
     if ((int32_t)(blockIdx.x * 256) >= (hi - lo) * S.CP) return;
-    const float *x = L.feat + (size_t)cf * S.D4 * 4;
+    const float *x = ctx->feat + (size_t)cf * S.D4 * 4;
     const int32_t is_skip = (cf % S.ds_ratio == 0) ? 0 : 1;
     const int32_t beam = is_skip ? S.ci_pbeam_tight : S.ci_pbeam;
 #define KU_GATED_ARGS S.mean4, S.prec4, S.lrd, S.mixw, S.tab16, S.tab_size, S.lm_zero, S.f, S.distfloor, x, S.D4, S.CP,  \
@@ -659,7 +658,6 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
         for (int32_t k = ud->veclen; k < D4x4; k++) row[k] = 0.0f;
     }
     HIPCHK(hipMemcpyAsync(hl.d_feat, hl.h_feat, need * 4, hipMemcpyHostToDevice, ud->stream));
-    hl.d.feat = hl.d_feat;
     hl.nfr = nfr;
     /* lextree + scorer state as after lextree_utt_end / at srch_TST_begin */
     if (hl.dirty) {
@@ -688,6 +686,7 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     }
     UCtx &x = *hl.h_ctx;
     memset(&x, 0, sizeof x);
+    x.feat = hl.d_feat;
     x.active = 1; x.cf = 0; x.nfr = nfr; x.cur = 0; x.n_lextrans = 1; x.thresh = c.hmmbeam;
     if (hl.epoch < 1) hl.epoch = 1;
     x.scan_epoch = hl.epoch;      /* k_dec_scan's flags are never reset: the stamps keep growing */

@@ -71,6 +71,7 @@ struct WPar {
 
 /* the pending lextree_enter calls + where the lane is (device resident, one per lane) */
 struct UCtx {
+    const float *feat;      /* this utterance's features [nfr][D4 * 4] */
     int32_t active, cf, nfr, cur, n_lextrans, err, thresh, n_calls, n_ent, n_groups, scan_epoch, n_tie_frames;
     int32_t max_cand, max_new, pad0, pad1;
     int32_t groups[8];
