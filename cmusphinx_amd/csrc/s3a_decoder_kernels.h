@@ -651,6 +651,9 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
         __syncthreads();
         if (tid == 0 && s_exit_open) nexit[T + t] = 1;
     }
+    /* (whole-utterance engine, s3a_utt.hip: the word-level kernel that follows assembles the frame record itself
+     * -- d_dec_pack_frame -- so no workgroup needs to know that it is the last one: no fences, no counter) */
+    if (done == NULL) return;
     /* publish this workgroup's results, find out whether it is the last of the launch */
     __syncthreads();
     if (tid == 0) {
@@ -722,6 +725,70 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     for (int32_t q = threadIdx.x; q < 2 * T; q += SCAN_THREADS) { best[q] = INT_MIN; nexit[q] = 0; }
     if (threadIdx.x < 8) misc[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 5) ? INT_MIN : 0;
     if (threadIdx.x == 0) *done = 0;
+}
+
+/* The frame record of d_dec_scan's last workgroup, assembled instead by ONE workgroup of a LATER kernel
+ * (blockDim.x threads; everything the scan kernels wrote is visible across the kernel boundary), followed by
+ * the same reset of the per-frame accumulators. */
+__device__ __forceinline__ void
+d_dec_pack_frame(int32_t N, int32_t T, FrameBeams bm, const int32_t *__restrict__ node_base,
+                 const int32_t *__restrict__ nact, int32_t *best, const int32_t *exits, int32_t *nexit,
+                 const int32_t *hbin, int32_t *misc, int32_t *pack, int32_t max_exits, const int32_t *gpart,
+                 int32_t gpart_n, const int32_t *nnxt)
+{
+    __shared__ int32_t sp_gp[3], sp_thr[8];
+    const int32_t nt = blockDim.x;
+    if (threadIdx.x == 0) {
+        int32_t bh, bw, n, th, pth, wth;
+        const bool hist = frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
+        sp_thr[0] = th; sp_thr[1] = pth; sp_thr[2] = wth; sp_thr[3] = bh; sp_thr[4] = bw; sp_thr[5] = n;
+        sp_thr[6] = hist ? 1 : 0; sp_thr[7] = 0;
+        sp_gp[0] = INT_MIN; sp_gp[1] = 0; sp_gp[2] = 0;
+    }
+    __syncthreads();
+    if (gpart_n > 0) {
+        int32_t gb = INT_MIN, gs = 0, gg = 0;
+        for (int32_t q = threadIdx.x; q < gpart_n; q += nt) { gb = max(gb, gpart[q]); gs += gpart[gpart_n + q]; gg += gpart[2 * gpart_n + q]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gb = max(gb, __shfl_xor(gb, o, 64)); gs += __shfl_xor(gs, o, 64); gg += __shfl_xor(gg, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && gb != INT_MIN) { atomicMax(&sp_gp[0], gb); atomicAdd(&sp_gp[1], gs); atomicAdd(&sp_gp[2], gg); }
+    }
+    __syncthreads();
+    const int32_t hdr = 6 * T + 16;
+    for (int32_t q = threadIdx.x; q < 2 * T; q += nt) pack[q] = best[q];
+    for (int32_t q = threadIdx.x; q < T; q += nt) {
+        pack[2 * T + q] = nact[q];
+        pack[3 * T + 8 + q] = nexit[q];
+        pack[4 * T + 8 + q] = nexit[T + q];
+        pack[5 * T + 16 + q] = nnxt[q];
+    }
+    if (threadIdx.x < 8) {
+        pack[3 * T + threadIdx.x] = sp_thr[threadIdx.x];
+        int32_t m = misc[threadIdx.x];
+        if (threadIdx.x == 0) m = max(m, sp_gp[0]);
+        if (threadIdx.x == 1 || threadIdx.x == 2) m += sp_gp[threadIdx.x];
+        if (threadIdx.x == 6) m = max(max(misc[0], sp_gp[0]), misc[5]);     /* srch->senscale */
+        pack[5 * T + 8 + threadIdx.x] = m;
+    }
+    int32_t off = 0;
+    for (int32_t tt = 0; tt < T; tt++) {
+        const int32_t n = nexit[tt], bb = node_base[tt];
+        for (int32_t q = threadIdx.x; q < n; q += nt) {
+            const int32_t k = off + q;
+            if (k < max_exits) {
+                pack[hdr + 3 * k] = exits[bb + q];
+                pack[hdr + 3 * k + 1] = exits[N + bb + q];
+                pack[hdr + 3 * k + 2] = exits[2 * N + bb + q];
+            }
+        }
+        off += n;
+    }
+    __syncthreads();
+    for (int32_t q = threadIdx.x; q < 2 * T; q += nt) { best[q] = INT_MIN; nexit[q] = 0; }
+    if (threadIdx.x < 8) misc[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 5) ? INT_MIN : 0;
+    __syncthreads();
 }
 
 __device__ __forceinline__ void

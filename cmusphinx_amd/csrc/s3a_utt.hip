@@ -210,7 +210,7 @@ ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC)
     const int32_t reordered = n > bm.maxhmmpf + (bm.maxhmmpf >> 1) ? 1 : 0;
     d_dec_scan(S.N, S.T, ctx->cf, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit,
                L.cnt, L.base, L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, L.best, L.exits, L.nexit, L.hbin, L.misc,
-               L.done, L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, reordered, L.scan_agg, L.scan_pre,
+               (int32_t *)NULL /* no tail: ku_wordlevel assembles the frame record */, L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, reordered, L.scan_agg, L.scan_pre,
                L.scan_flag, S.scan_chunks, ctx->scan_epoch, NC, blockIdx.x, 0);
 }
 
@@ -229,6 +229,9 @@ ku_wordlevel(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPa
 {
     LANE;
     if (threadIdx.x == 0) ctx->scan_epoch++;        /* (k_dec_scan's flags are stamped per launch) */
+    const int32_t cur = ctx->cur;
+    d_dec_pack_frame(S.N, S.T, frame_beams(S, ctx->cf), S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc,
+                     L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1]);
     d_wordlevel_frame(L.w, ctx, L.pack, lm, dict, par);
 }
 
@@ -412,8 +415,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     for (auto &hl : ud->lane) {
         WLane &w = hl.d.w;
         void *p[] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type, w.frame_start, w.bestscore,
-                      w.bestvh, w.st, w.ex_off, w.ex_max, w.ex_pref, w.ex_cnt, w.ex_base, w.cand_score, w.cand_slot, w.hkey,
-                      w.hbest, w.hfirst, w.hlead_e, w.hlead_rank, w.sg, w.srt, w.wfirst, w.heap, w.fstat, hl.d.ctx,
+                      w.bestvh, w.st, w.ex_off, w.lmc, w.cand_pref, w.cand_e, w.cand_score, w.cand_slot, w.hkey,
+                      w.hbest, w.hfirst, w.hlead_rank, w.sg, w.srt, w.wfirst, w.heap, w.fstat, hl.d.ctx,
                       hl.d.pack, hl.d_feat };
         for (auto q : p) if (q) (void)hipFree(q);
         if (hl.h_ctx) (void)hipHostFree(hl.h_ctx);
@@ -589,18 +592,19 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         WLane &w = u.w;
         const size_t vc = (size_t)ud->vh_cap * 4, mf = (size_t)(max_frames + 2) * 4;
         DM(w.score, vc); DM(w.pred, vc); DM(w.lw0, vc); DM(w.lw1, vc); DM(w.wid, vc); DM(w.sf, vc); DM(w.ef, vc);
-        DM(w.ascr, vc); DM(w.lscr, vc); DM(w.type, vc);
+        DM(w.ascr, vc); DM(w.lscr, vc); DM(w.type, vc); DM(w.lmc, 5 * vc);
         w.cap = ud->vh_cap;
         DM(w.frame_start, mf); DM(w.bestscore, mf); DM(w.bestvh, mf); DM(w.st, 16 * 4);
         const size_t ec = (size_t)(ud->ex_cap + 1) * 4;
-        DM(w.ex_off, ec); DM(w.ex_max, ec); DM(w.ex_pref, ec); DM(w.ex_cnt, ec); DM(w.ex_base, ec);
+        DM(w.ex_off, ec);
         w.ex_cap = ud->ex_cap;
         DM(w.cand_score, (size_t)ud->cand_cap * 4); DM(w.cand_slot, (size_t)ud->cand_cap * 4);
+        DM(w.cand_pref, (size_t)ud->cand_cap * 4); DM(w.cand_e, (size_t)ud->cand_cap * 4);
         w.cand_cap = ud->cand_cap;
         size_t hs = 1024;
         while (hs < (size_t)2 * ud->cand_cap) hs <<= 1;
         w.hmask = (int32_t)(hs - 1);
-        DM(w.hkey, hs * 8); DM(w.hbest, hs * 8); DM(w.hfirst, hs * 4); DM(w.hlead_e, hs * 4); DM(w.hlead_rank, hs * 4);
+        DM(w.hkey, hs * 8); DM(w.hbest, hs * 8); DM(w.hfirst, hs * 4); DM(w.hlead_rank, hs * 4);
         if (hipMemset(w.hkey, 0, hs * 8) != hipSuccess || hipMemset(w.hbest, 0, hs * 8) != hipSuccess
             || hipMemset(w.hfirst, 0xff, hs * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_init: memset failed"); goto fail; }
         w.new_cap = ud->new_cap;
@@ -679,6 +683,12 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
         int32_t *arr[10] = { hl.d.w.score, hl.d.w.pred, hl.d.w.lw0, hl.d.w.lw1, hl.d.w.wid, hl.d.w.sf, hl.d.w.ef, hl.d.w.ascr,
                              hl.d.w.lscr, hl.d.w.type };
         for (int k = 0; k < 10; k++) if ((rc = fill32(ud->stream, arr[k], e0[k], 1)) != S3A_OK) return rc;
+        {   /* wl_lm_context of entry 0: state (<s>, none): no trigram run, the bigrams of <s> */
+            const s3a_lm3g_t *lm = ud->lm;
+            int32_t c5[5] = { 0, 0, 0, 0, -1 };
+            if (lm->d.n_bg > 0 && c.start_lwid >= 0) { c5[3] = lm->ug_firstbg[c.start_lwid]; c5[4] = lm->ug_firstbg[c.start_lwid + 1] - c5[3]; }
+            for (int k = 0; k < 5; k++) if ((rc = fill32(ud->stream, hl.d.w.lmc + (size_t)k * hl.d.w.cap, c5[k], 1)) != S3A_OK) return rc;
+        }
         if ((rc = fill32(ud->stream, hl.d.w.frame_start, 1, 1)) || (rc = fill32(ud->stream, hl.d.w.bestscore, INT_MIN, 1))
             || (rc = fill32(ud->stream, hl.d.w.bestvh, -1, 1)) || (rc = fill32(ud->stream, hl.d.w.st, 1, 1))
             || (rc = fill32(ud->stream, hl.d.w.st + 1, 0, 1)))

@@ -80,16 +80,17 @@ struct UCtx {
 
 struct WLane {              /* one lane's history table + per-frame scratch (device pointers) */
     int32_t *score, *pred, *lw0, *lw1, *wid, *sf, *ef, *ascr, *lscr, *type;
+    int32_t *lmc;           /* [5][cap] LM context of every entry (wl_lm_context) */
     int32_t cap;
     int32_t *frame_start, *bestscore, *bestvh;      /* [max_frames + 2] */
     int32_t *st;            /* [0] n_entry  [1] n_frm */
-    int32_t *ex_off, *ex_max, *ex_pref, *ex_cnt, *ex_base;      /* [ex_cap + 1] */
+    int32_t *ex_off;        /* [ex_cap + 1] first candidate of every exit */
     int32_t ex_cap;
-    int32_t *cand_score, *cand_slot;                /* [cand_cap] */
+    int32_t *cand_score, *cand_slot, *cand_pref, *cand_e;      /* [cand_cap] */
     int32_t cand_cap;
     unsigned long long *hkey, *hbest;               /* [hmask + 1] */
     uint32_t *hfirst;
-    int32_t *hlead_e, *hlead_rank;
+    int32_t *hlead_rank;
     int32_t hmask;
     int32_t *sg;            /* staging [11][new_cap]: wid sf ascr lscr score pred type lw0 lw1 slot | valid */
     int32_t new_cap;
@@ -245,10 +246,49 @@ struct WlHeap {
     }
 };
 
+/* the LM context of a history entry with LM state (lw0, lw1), worked out ONCE when the entry is made:
+ * the trigram run and back-off weight of the bigram (lw1, lw0) (load_tg, lm.c:1363-1525: a missing bigram
+ * or no lw1 = an empty run, weight 0) and the bigram run of lw0 (lm_bg_score's search, lm.c:1262-1280).
+ * A candidate then costs two short bisections instead of four. */
+__device__ __forceinline__ void
+wl_lm_context(const WLm &lm, int32_t lw0, int32_t lw1, int32_t *c5)
+{
+    int32_t t0 = 0, nt = 0, bowt = 0, b0 = 0, nb = -1;      /* nb < 0: unigram only, no back-off weight */
+    if (lm.n_tg > 0 && lw1 >= 0) {
+        const int32_t q0 = lm.ug_firstbg[lw1], qn = lm.ug_firstbg[lw1 + 1] - q0;
+        const int32_t b = qn > 0 ? wl_find(lm.bg_wid + q0, qn, lw0) : -1;
+        if (b >= 0) { bowt = lm.bg_bowt[q0 + b]; t0 = lm.bg_firsttg[q0 + b]; nt = lm.bg_firsttg[q0 + b + 1] - t0; }
+    }
+    if (lm.n_bg > 0 && lw0 >= 0) { b0 = lm.ug_firstbg[lw0]; nb = lm.ug_firstbg[lw0 + 1] - b0; }
+    c5[0] = t0; c5[1] = nt; c5[2] = bowt; c5[3] = b0; c5[4] = nb;
+}
+
+/* lm_tg_score(lw1, lw0, lw3) for the predecessor entry i with precomputed context */
+__device__ __forceinline__ int32_t
+wl_tg_score_ctx(const WLm &lm, const WLane &L, int32_t i, int32_t lw0, int32_t lw3, int32_t wid)
+{
+    const int32_t t0 = L.lmc[i], nt = L.lmc[L.cap + i];
+    int32_t s;
+    const int32_t k = nt > 0 ? wl_find(lm.tg_wid + t0, nt, lw3) : -1;
+    if (k >= 0) s = lm.tg_prob[t0 + k];
+    else {
+        const int32_t bowt = L.lmc[2 * (size_t)L.cap + i], b0 = L.lmc[3 * (size_t)L.cap + i], nb = L.lmc[4 * (size_t)L.cap + i];
+        if (nb < 0) s = lm.ug_prob[lw3];
+        else {
+            const int32_t j = nb > 0 ? wl_find(lm.bg_wid + b0, nb, lw3) : -1;
+            s = j >= 0 ? lm.bg_prob[b0 + j] : add32(lm.ug_bowt[lw0], lm.ug_prob[lw3]);
+        }
+        s = add32(bowt, s);
+    }
+    if (lm.inclass) s = add32(s, lm.inclass[wid]);
+    return s;
+}
+
 /*
- * One frame of the word level for one lane.  `pack` = the frame record k_dec_scan's last
- * workgroup assembled: [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] |
- * n_next x T | exits (wid, score, history) in tree then list order.
+ * One frame of the word level for one lane.  `pack` = the frame record (d_dec_pack_frame):
+ * [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] | n_next x T | exits (wid, score,
+ * history) in tree then list order.  Candidates are numbered in the reference's walk order: exit by exit,
+ * within a word exit the history entries of the predecessor's frame in table order.
  */
 __device__ __forceinline__ void
 d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par)
@@ -258,7 +298,7 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
     __shared__ unsigned long long s_ci[256];
     __shared__ unsigned long long s_u64[2];
     __shared__ int32_t s_heap[6 * WL_HEAP_LDS];
-    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t tid = threadIdx.x;
     const int32_t T = par.T, hdr = 6 * T + 16, cf = ctx->cf;
     const int32_t fs = L.st[0];                 /* == frame_start[cf] */
     const int32_t *fstart = L.frame_start;
@@ -278,9 +318,8 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
     }
     __syncthreads();
     const int32_t nx = s_tb[T];
-    int32_t err = s_i[0];
-    if (err) {                                  /* (uniform) the utterance ends here, as in the reference */
-        if (tid == 0) { ctx->err |= err; ctx->active = 0; }
+    if (s_i[0]) {                               /* (uniform) the utterance ends here, as in the reference */
+        if (tid == 0) { ctx->err |= s_i[0]; ctx->active = 0; }
         return;
     }
     for (int32_t e = tid; e < nx; e += WL_THREADS) {
@@ -294,6 +333,7 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         L.ex_off[nx] = n_cand;
         if (n_cand > L.cand_cap || 2 * (long long)n_cand > (long long)L.hmask + 1) ctx->err |= WL_E_CAND;
         if (n_cand > ctx->max_cand) ctx->max_cand = n_cand;
+        s_i[4] = 0;
     }
     __syncthreads();
     if (n_cand > L.cand_cap || 2 * (long long)n_cand > (long long)L.hmask + 1) {
@@ -301,119 +341,89 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         return;
     }
 
-    /* ---- P2: every candidate's path score; per exit the maximum ---- */
-    for (int32_t e = wave; e < nx; e += WL_WAVES) {
-        const int32_t w = ex[3 * e], scr = ex[3 * e + 1], h = ex[3 * e + 2], off = L.ex_off[e];
-        const int32_t ascr = add32(scr, -L.score[h]);
-        int32_t m = INT_MIN;
-        if (dict.is_filler[w]) {
-            m = add32(scr, dict.fillpen[w]);
-            if (lane == 0) L.cand_score[off] = m;
-        }
+    /* ---- P2: every candidate's path score (a thread per candidate) ---- */
+    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
+        int32_t lo = 0, hi = nx;                /* the exit of candidate c: last e with ex_off[e] <= c */
+        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (L.ex_off[mid] <= c) lo = mid; else hi = mid; }
+        const int32_t e = lo, w = ex[3 * e], scr = ex[3 * e + 1], h = ex[3 * e + 2];
+        L.cand_e[c] = e;
+        int32_t sc;
+        if (dict.is_filler[w]) sc = add32(scr, dict.fillpen[w]);
         else {
             const int32_t lwid = dict.lwid[w];
-            const int32_t cnt = L.ex_off[e + 1] - off, se = h == 0 ? 0 : fstart[L.ef[h]];
-            if (lwid < 0) { if (lane == 0) atomicOr(&ctx->err, WL_E_NOLM); }
-            else
-                for (int32_t j = lane; j < cnt; j += 64) {
-                    const int32_t i = se + j;
-                    const int32_t sc = add32(add32(L.score[i], ascr), wl_tg_score(lm, L.lw1[i], L.lw0[i], lwid, w));
-                    L.cand_score[off + j] = sc;
-                    m = max(m, sc);
-                }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+            if (lwid < 0) { s_i[4] = 1; sc = INT_MIN; }
+            else {
+                const int32_t i = (h == 0 ? 0 : fstart[L.ef[h]]) + (c - L.ex_off[e]);
+                sc = add32(add32(L.score[i], add32(scr, -L.score[h])), wl_tg_score_ctx(lm, L, i, L.lw0[i], lwid, w));
+            }
         }
-        if (lane == 0) L.ex_max[e] = m;
+        L.cand_score[c] = sc;
     }
     __syncthreads();
-    if (ctx->err & WL_E_NOLM) { if (tid == 0) ctx->active = 0; return; }
-    /* the best score entered before each exit's first candidate; the frame's best */
-    const int32_t M = wl_scan<true>(L.ex_max, L.ex_pref, nx, INT_MIN);
+    if (s_i[4]) { if (tid == 0) { ctx->err |= WL_E_NOLM; ctx->active = 0; } return; }
+    /* the best score entered before each candidate; the frame's best */
+    const int32_t M = wl_scan<true>(L.cand_score, L.cand_pref, n_cand, INT_MIN);
 
     /* ---- P3: which candidates enter (vithist.c:560), into which LM state ---- */
-    for (int32_t e = wave; e < nx; e += WL_WAVES) {
-        const int32_t w = ex[3 * e], h = ex[3 * e + 2], off = L.ex_off[e], cnt = L.ex_off[e + 1] - off;
+    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
+        const int32_t e = L.cand_e[c], w = ex[3 * e], h = ex[3 * e + 2], sc = L.cand_score[c];
         const bool filler = dict.is_filler[w] != 0;
-        const int32_t lwid = filler ? 0 : dict.lwid[w], se = h == 0 ? 0 : fstart[L.ef[h]];
-        int32_t running = L.ex_pref[e];
-        for (int32_t j0 = 0; j0 < cnt; j0 += 64) {
-            const int32_t j = j0 + lane;
-            const int32_t sc = j < cnt ? L.cand_score[off + j] : INT_MIN;
-            int32_t incl = sc;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int32_t y = __shfl_up(incl, o, 64);
-                if (lane >= o) incl = max(incl, y);
+        int32_t slot = -1;
+        if (filler || add32(sc, -par.wbeam) >= L.cand_pref[c]) {
+            unsigned long long key;
+            if (filler) key = wl_key(L.lw0[h], L.lw1[h]);
+            else key = wl_key(dict.lwid[w], L.lw0[(h == 0 ? 0 : fstart[L.ef[h]]) + (c - L.ex_off[e])]);
+            uint32_t hh = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)L.hmask;
+            for (;;) {
+                const unsigned long long old = atomicCAS(&L.hkey[hh], 0ull, key);
+                if (old == 0ull || old == key) break;
+                hh = (hh + 1) & (uint32_t)L.hmask;
             }
-            int32_t before = __shfl_up(incl, 1, 64);
-            before = lane == 0 ? running : max(running, before);
-            const bool in = j < cnt && (filler || add32(sc, -par.wbeam) >= before);
-            int32_t slot = -1;
-            if (in) {
-                const unsigned long long key = filler ? wl_key(L.lw0[h], L.lw1[h]) : wl_key(lwid, L.lw0[se + j]);
-                uint32_t hh = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)L.hmask;
-                for (;;) {
-                    const unsigned long long old = atomicCAS(&L.hkey[hh], 0ull, key);
-                    if (old == 0ull || old == key) break;
-                    hh = (hh + 1) & (uint32_t)L.hmask;
-                }
-                slot = (int32_t)hh;
-                atomicMin(&L.hfirst[hh], (uint32_t)(off + j));
-                atomicMax(&L.hbest[hh], wl_pack(sc, (uint32_t)(off + j)));
-            }
-            if (j < cnt) L.cand_slot[off + j] = slot;
-            running = max(running, __shfl(incl, 63, 64));
+            slot = (int32_t)hh;
+            atomicMin(&L.hfirst[hh], (uint32_t)c);
+            atomicMax(&L.hbest[hh], wl_pack(sc, (uint32_t)c));
         }
+        L.cand_slot[c] = slot;
     }
     __syncthreads();
 
-    /* ---- P4: the first entered candidate of each LM state founds the entry: rank within its exit ---- */
-    for (int32_t e = wave; e < nx; e += WL_WAVES) {
-        const int32_t off = L.ex_off[e], cnt = L.ex_off[e + 1] - off;
-        int32_t carry = 0;
-        for (int32_t j0 = 0; j0 < cnt; j0 += 64) {
-            const int32_t j = j0 + lane;
-            const int32_t slot = j < cnt ? L.cand_slot[off + j] : -1;
-            const bool lead = slot >= 0 && WL_ALOAD(&L.hfirst[slot]) == (uint32_t)(off + j);
-            const unsigned long long mk = __ballot(lead);
-            if (lead) { L.hlead_e[slot] = e; L.hlead_rank[slot] = carry + __popcll(mk & ((1ull << lane) - 1ull)); }
-            carry += __popcll(mk);
-        }
-        if (lane == 0) L.ex_cnt[e] = carry;
+    /* ---- P4: the first entered candidate of each LM state founds the entry, in walk order ---- */
+    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
+        const int32_t slot = L.cand_slot[c];
+        L.cand_pref[c] = (slot >= 0 && WL_ALOAD(&L.hfirst[slot]) == (uint32_t)c) ? 1 : 0;
     }
-    __syncthreads();
-    const int32_t n_new = wl_scan<false>(L.ex_cnt, L.ex_base, nx, 0);
+    const int32_t n_new = wl_scan<false>(L.cand_pref, L.cand_pref, n_cand, 0);
     if (tid == 0) {
         if (n_new > L.new_cap || (long long)fs + n_new > L.cap) ctx->err |= WL_E_TABLE;
         if (n_new > ctx->max_new) ctx->max_new = n_new;
     }
     __syncthreads();
     if (n_new > L.new_cap || (long long)fs + n_new > L.cap) { if (tid == 0) ctx->active = 0; return; }
+    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
+        const int32_t slot = L.cand_slot[c];
+        if (slot >= 0 && WL_ALOAD(&L.hfirst[slot]) == (uint32_t)c) L.hlead_rank[slot] = L.cand_pref[c];
+    }
+    __syncthreads();
     int32_t *sg_wid = L.sg, *sg_sf = L.sg + L.new_cap, *sg_ascr = L.sg + 2 * L.new_cap, *sg_lscr = L.sg + 3 * L.new_cap,
         *sg_score = L.sg + 4 * L.new_cap, *sg_pred = L.sg + 5 * L.new_cap, *sg_type = L.sg + 6 * L.new_cap,
         *sg_lw0 = L.sg + 7 * L.new_cap, *sg_lw1 = L.sg + 8 * L.new_cap, *sg_slot = L.sg + 9 * L.new_cap,
         *sg_valid = L.sg + 10 * L.new_cap;
 
     /* ---- P5: the best candidate of each LM state writes the entry (staged in founding order) ---- */
-    for (int32_t e = wave; e < nx; e += WL_WAVES) {
-        const int32_t w = ex[3 * e], scr = ex[3 * e + 1], h = ex[3 * e + 2], off = L.ex_off[e], cnt = L.ex_off[e + 1] - off;
-        const bool filler = dict.is_filler[w] != 0;
-        const int32_t se = h == 0 ? 0 : fstart[L.ef[h]], ascr = add32(scr, -L.score[h]);
+    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
+        const int32_t slot = L.cand_slot[c];
+        if (slot < 0) continue;
+        const int32_t sc = L.cand_score[c];
+        if (WL_ALOAD(&L.hbest[slot]) != wl_pack(sc, (uint32_t)c)) continue;
+        const int32_t e = L.cand_e[c], w = ex[3 * e], scr = ex[3 * e + 1], h = ex[3 * e + 2];
+        const int32_t k = WL_ALOAD(&L.hlead_rank[slot]), ascr = add32(scr, -L.score[h]);
         int32_t ty = 0;
         for (int32_t t = 0; t < T; t++) if (e >= s_tb[t]) ty = par.tree_type[t];
-        for (int32_t j = lane; j < cnt; j += 64) {
-            const int32_t slot = L.cand_slot[off + j];
-            if (slot < 0) continue;
-            const int32_t sc = L.cand_score[off + j];
-            if (WL_ALOAD(&L.hbest[slot]) != wl_pack(sc, (uint32_t)(off + j))) continue;
-            const int32_t k = L.ex_base[L.hlead_e[slot]] + L.hlead_rank[slot];
-            sg_wid[k] = w; sg_sf[k] = L.ef[h] + 1; sg_ascr[k] = ascr; sg_score[k] = sc; sg_type[k] = ty; sg_slot[k] = slot;
-            if (filler) { sg_lscr[k] = dict.fillpen[w]; sg_pred[k] = h; sg_lw0[k] = L.lw0[h]; sg_lw1[k] = L.lw1[h]; }
-            else {
-                const int32_t i = se + j;
-                sg_lscr[k] = add32(sc, -add32(L.score[i], ascr)); sg_pred[k] = i; sg_lw0[k] = dict.lwid[w]; sg_lw1[k] = L.lw0[i];
-            }
+        sg_wid[k] = w; sg_sf[k] = L.ef[h] + 1; sg_ascr[k] = ascr; sg_score[k] = sc; sg_type[k] = ty; sg_slot[k] = slot;
+        if (dict.is_filler[w]) { sg_lscr[k] = dict.fillpen[w]; sg_pred[k] = h; sg_lw0[k] = L.lw0[h]; sg_lw1[k] = L.lw1[h]; }
+        else {
+            const int32_t i = (h == 0 ? 0 : fstart[L.ef[h]]) + (c - L.ex_off[e]);
+            sg_lscr[k] = add32(sc, -add32(L.score[i], ascr)); sg_pred[k] = i; sg_lw0[k] = dict.lwid[w]; sg_lw1[k] = L.lw0[i];
         }
     }
     __syncthreads();
@@ -478,9 +488,7 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         a_first[r] = f;
         a_c[r] = (elig && f == r) ? 1 : 0;
     }
-    __syncthreads();
     (void)wl_scan<false>(a_c, a_scan, n_th, 0);         /* a_scan[r] = index of the word first seen at r */
-    __syncthreads();
     for (int32_t r = tid; r < n_th; r += WL_THREADS) {
         const int32_t f = a_first[r];
         int32_t c = 0;
@@ -490,7 +498,6 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
     __syncthreads();
     for (int32_t r = tid; r < n_th; r += WL_THREADS) L.wfirst[sg_wid[a_sorted[r]]] = INT_MAX;
     (void)wl_scan<false>(a_c, a_first, n_th, 0);        /* entries kept before r */
-    __syncthreads();
     for (int32_t r = tid; r < n_th; r += WL_THREADS)
         if (a_c[r] && a_first[r] < par.maxhist) sg_valid[a_sorted[r]] = 1;
     __syncthreads();
@@ -506,6 +513,12 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         const int32_t id = fs + a_scan[k];
         L.wid[id] = sg_wid[k]; L.sf[id] = sg_sf[k]; L.ef[id] = cf; L.ascr[id] = sg_ascr[k]; L.lscr[id] = sg_lscr[k];
         L.score[id] = sg_score[k]; L.pred[id] = sg_pred[k]; L.type[id] = sg_type[k]; L.lw0[id] = sg_lw0[k]; L.lw1[id] = sg_lw1[k];
+        {
+            int32_t c5[5];
+            wl_lm_context(lm, sg_lw0[k], sg_lw1[k], c5);
+#pragma unroll
+            for (int q = 0; q < 5; q++) L.lmc[(size_t)q * L.cap + id] = c5[q];
+        }
         const unsigned long long key = wl_pack(sg_score[k], (uint32_t)id);
         atomicMax(&s_u64[0], key);                                      /* best valid entry, the first on ties */
         atomicMax(&s_ci[dict.last_ci[sg_wid[k]]], key);                 /* ... per word-final CI phone */
