@@ -407,18 +407,59 @@ fill32(hipStream_t st, int32_t *p, int32_t v, size_t n)
     return S3A_OK;
 }
 
+static void
+wlane_free(WLane &w)
+{
+    void *p[] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type, w.lmc, w.frame_start, w.bestscore,
+                  w.bestvh, w.st, w.ex_off, w.cand_pref, w.cand_e, w.cand_score, w.cand_slot, w.hkey, w.hbest, w.hfirst,
+                  w.hlead_rank, w.sg, w.srt, w.wfirst, w.heap, w.fstat };
+    for (auto q : p) if (q) (void)hipFree(q);
+    memset((void *)&w, 0, sizeof w);
+}
+
+/* one lane's history table and per-frame scratch */
+static int32_t
+wlane_alloc(WLane &w, int32_t vh_cap, int32_t max_frames, int32_t ex_cap, int32_t cand_cap, int32_t new_cap, int32_t n_word,
+            hipStream_t st)
+{
+    const size_t vc = (size_t)vh_cap * 4, mf = (size_t)(max_frames + 2) * 4;
+    size_t hs = 1024;
+    memset((void *)&w, 0, sizeof w);
+    DM(w.score, vc); DM(w.pred, vc); DM(w.lw0, vc); DM(w.lw1, vc); DM(w.wid, vc); DM(w.sf, vc); DM(w.ef, vc);
+    DM(w.ascr, vc); DM(w.lscr, vc); DM(w.type, vc); DM(w.lmc, 5 * vc);
+    w.cap = vh_cap;
+    DM(w.frame_start, mf); DM(w.bestscore, mf); DM(w.bestvh, mf); DM(w.st, 16 * 4);
+    DM(w.ex_off, (size_t)(ex_cap + 1) * 4);
+    w.ex_cap = ex_cap;
+    DM(w.cand_score, (size_t)cand_cap * 4); DM(w.cand_slot, (size_t)cand_cap * 4);
+    DM(w.cand_pref, (size_t)cand_cap * 4); DM(w.cand_e, (size_t)cand_cap * 4);
+    w.cand_cap = cand_cap;
+    while (hs < (size_t)2 * cand_cap) hs <<= 1;
+    w.hmask = (int32_t)(hs - 1);
+    DM(w.hkey, hs * 8); DM(w.hbest, hs * 8); DM(w.hfirst, hs * 4); DM(w.hlead_rank, hs * 4);
+    if (hipMemset(w.hkey, 0, hs * 8) != hipSuccess || hipMemset(w.hbest, 0, hs * 8) != hipSuccess
+        || hipMemset(w.hfirst, 0xff, hs * 4) != hipSuccess) { s3a_set_error("s3a_utt: memset failed"); goto fail; }
+    w.new_cap = new_cap;
+    DM(w.sg, (size_t)11 * new_cap * 4); DM(w.srt, (size_t)6 * new_cap * 4); DM(w.heap, (size_t)6 * new_cap * 4);
+    DM(w.wfirst, (size_t)n_word * 4);
+    DM(w.fstat, (size_t)max_frames * 8 * 4);
+    if (fill32(st, w.wfirst, INT_MAX, n_word) != S3A_OK) goto fail;
+    return S3A_OK;
+fail:
+    wlane_free(w);
+    return S3A_ENOMEM;
+}
+
 extern "C" void
 s3a_uttdec_free(s3a_uttdec_t *ud)
 {
     if (!ud) return;
     (void)hipStreamSynchronize(ud->stream);
     for (auto &hl : ud->lane) {
-        WLane &w = hl.d.w;
-        void *p[] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type, w.frame_start, w.bestscore,
-                      w.bestvh, w.st, w.ex_off, w.lmc, w.cand_pref, w.cand_e, w.cand_score, w.cand_slot, w.hkey,
-                      w.hbest, w.hfirst, w.hlead_rank, w.sg, w.srt, w.wfirst, w.heap, w.fstat, hl.d.ctx,
-                      hl.d.pack, hl.d_feat };
-        for (auto q : p) if (q) (void)hipFree(q);
+        wlane_free(hl.d.w);
+        if (hl.d.ctx) (void)hipFree(hl.d.ctx);
+        if (hl.d.pack) (void)hipFree(hl.d.pack);
+        if (hl.d_feat) (void)hipFree(hl.d_feat);
         if (hl.h_ctx) (void)hipHostFree(hl.h_ctx);
         if (hl.h_feat) (void)hipHostFree(hl.h_feat);
         if (hl.h_tab) (void)hipHostFree(hl.h_tab);
@@ -589,35 +630,13 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
         DM(u.ctx, sizeof(UCtx));
         DM(u.pack, (size_t)(6 * T + 16 + 3 * proto->pack_max_exits) * 4);
-        WLane &w = u.w;
-        const size_t vc = (size_t)ud->vh_cap * 4, mf = (size_t)(max_frames + 2) * 4;
-        DM(w.score, vc); DM(w.pred, vc); DM(w.lw0, vc); DM(w.lw1, vc); DM(w.wid, vc); DM(w.sf, vc); DM(w.ef, vc);
-        DM(w.ascr, vc); DM(w.lscr, vc); DM(w.type, vc); DM(w.lmc, 5 * vc);
-        w.cap = ud->vh_cap;
-        DM(w.frame_start, mf); DM(w.bestscore, mf); DM(w.bestvh, mf); DM(w.st, 16 * 4);
-        const size_t ec = (size_t)(ud->ex_cap + 1) * 4;
-        DM(w.ex_off, ec);
-        w.ex_cap = ud->ex_cap;
-        DM(w.cand_score, (size_t)ud->cand_cap * 4); DM(w.cand_slot, (size_t)ud->cand_cap * 4);
-        DM(w.cand_pref, (size_t)ud->cand_cap * 4); DM(w.cand_e, (size_t)ud->cand_cap * 4);
-        w.cand_cap = ud->cand_cap;
-        size_t hs = 1024;
-        while (hs < (size_t)2 * ud->cand_cap) hs <<= 1;
-        w.hmask = (int32_t)(hs - 1);
-        DM(w.hkey, hs * 8); DM(w.hbest, hs * 8); DM(w.hfirst, hs * 4); DM(w.hlead_rank, hs * 4);
-        if (hipMemset(w.hkey, 0, hs * 8) != hipSuccess || hipMemset(w.hbest, 0, hs * 8) != hipSuccess
-            || hipMemset(w.hfirst, 0xff, hs * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_init: memset failed"); goto fail; }
-        w.new_cap = ud->new_cap;
-        DM(w.sg, (size_t)11 * ud->new_cap * 4); DM(w.srt, (size_t)6 * ud->new_cap * 4); DM(w.heap, (size_t)6 * ud->new_cap * 4);
-        DM(w.wfirst, (size_t)cfg->n_word * 4);
-        DM(w.fstat, (size_t)max_frames * 8 * 4);
+        if (wlane_alloc(u.w, ud->vh_cap, max_frames, ud->ex_cap, ud->cand_cap, ud->new_cap, cfg->n_word, ud->stream) != S3A_OK) goto fail;
         if (hipHostMalloc((void **)&hl.h_ctx, sizeof(UCtx)) != hipSuccess
             || hipHostMalloc((void **)&hl.h_st, 16 * 4) != hipSuccess
             || hipHostMalloc((void **)&hl.h_fstat, (size_t)max_frames * 8 * 4) != hipSuccess) {
             s3a_set_error("s3a_uttdec_init: pinned allocation failed");
             goto fail;
         }
-        if (fill32(ud->stream, w.wfirst, INT_MAX, cfg->n_word) != S3A_OK) goto fail;
     }
     {
         std::vector<ULane> tmp(n_lanes);
@@ -862,4 +881,159 @@ extern "C" int32_t
 s3a_uttdec_n_lanes(const s3a_uttdec_t *ud)
 {
     return ud ? ud->n_lanes : 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* the word level on its own (parity tests: frame by frame against the oracle) */
+/* ------------------------------------------------------------------ */
+struct s3a_wltest_s {
+    s3a_lm3g_t *lm;
+    WDict dict;
+    WPar par;
+    ULane lane, *d_lane;
+    UCtx *h_ctx;
+    int32_t *d_lcmap, *h_pack, *h_tab;
+    int32_t T, n_ci, n_word, start_lwid, max_exits, cap, max_frames;
+    size_t h_tab_cap;
+    hipStream_t stream;
+};
+
+extern "C" void
+s3a_wltest_free(s3a_wltest_t *wt)
+{
+    if (!wt) return;
+    wlane_free(wt->lane.w);
+    const void *q[] = { wt->dict.lwid, wt->dict.fillpen, wt->dict.last_ci, wt->dict.is_filler, wt->d_lcmap, wt->lane.ctx,
+                        wt->lane.pack, wt->d_lane };
+    for (auto p : q) if (p) (void)hipFree((void *)p);
+    if (wt->h_ctx) (void)hipHostFree(wt->h_ctx);
+    if (wt->h_pack) (void)hipHostFree(wt->h_pack);
+    if (wt->h_tab) (void)hipHostFree(wt->h_tab);
+    if (wt->stream) (void)hipStreamDestroy(wt->stream);
+    delete wt;
+}
+
+/* cfg: the dictionary / pruning fields of s3a_wordlevel_cfg_t; lcmap_len[t * (n_ci + 1) + p] = length of the root list
+ * lextree_enter(tree t, left context p) walks (p == n_ci: none), negative = not a context of that tree */
+extern "C" s3a_wltest_t *
+s3a_wltest_init(s3a_lm3g_t *lm, const s3a_wordlevel_cfg_t *cfg, const int32_t *lcmap_len, int32_t vh_cap,
+                int32_t cand_cap, int32_t max_exits, int32_t max_frames)
+{
+    if (!lm || !cfg || !lcmap_len || cfg->n_ci <= 0 || cfg->n_ci > 255 || 2 * cfg->n_lextree > WL_MAXT) {
+        s3a_set_error("s3a_wltest_init: bad arguments");
+        return NULL;
+    }
+    s3a_wltest_t *wt = new s3a_wltest_s();
+    memset((void *)wt, 0, sizeof *wt);
+    wt->lm = lm; wt->T = 2 * cfg->n_lextree; wt->n_ci = cfg->n_ci; wt->n_word = cfg->n_word; wt->start_lwid = cfg->start_lwid;
+    wt->max_exits = max_exits; wt->cap = vh_cap; wt->max_frames = max_frames;
+    const int32_t T = wt->T, hdr = 6 * T + 16;
+    std::vector<int32_t> lcmap((size_t)T * (cfg->n_ci + 1) * 2);
+    {
+        int32_t off = 0;
+        for (size_t i = 0; i < (size_t)T * (cfg->n_ci + 1); i++) { lcmap[2 * i] = off; lcmap[2 * i + 1] = lcmap_len[i]; if (lcmap_len[i] > 0) off += lcmap_len[i]; }
+    }
+    int32_t *p0 = NULL, *p1 = NULL, *p2 = NULL;
+    uint8_t *p3 = NULL;
+    if (hipStreamCreateWithFlags(&wt->stream, hipStreamNonBlocking) != hipSuccess) { s3a_set_error("s3a_wltest_init: no HIP device"); delete wt; return NULL; }
+    DM(p0, (size_t)cfg->n_word * 4); DM(p1, (size_t)cfg->n_word * 4); DM(p2, (size_t)cfg->n_word * 4); DM(p3, (size_t)cfg->n_word);
+    wt->dict.lwid = p0; wt->dict.fillpen = p1; wt->dict.last_ci = p2; wt->dict.is_filler = p3;
+    wt->dict.n_word = cfg->n_word; wt->dict.n_ci = cfg->n_ci;
+    if (hipMemcpy(p0, cfg->lwid, (size_t)cfg->n_word * 4, hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(p1, cfg->fillpen, (size_t)cfg->n_word * 4, hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(p2, cfg->last_ci, (size_t)cfg->n_word * 4, hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(p3, cfg->is_filler, (size_t)cfg->n_word, hipMemcpyHostToDevice) != hipSuccess) goto fail;
+    UPV(wt->d_lcmap, lcmap);
+    wt->par.wbeam = cfg->wbeam_vh; wt->par.bghist = cfg->bghist; wt->par.maxwpf = cfg->maxwpf; wt->par.maxhist = cfg->maxhistpf;
+    wt->par.wordend = cfg->wordend_beam; wt->par.n_lextree = cfg->n_lextree; wt->par.epl = cfg->epl; wt->par.T = T;
+    wt->par.hmmbeam = cfg->hmmbeam; wt->par.lcmap = wt->d_lcmap;
+    for (int32_t t = 0; t < T; t++) wt->par.tree_type[t] = cfg->tree_type[t];
+    if (wlane_alloc(wt->lane.w, vh_cap, max_frames, max_exits, cand_cap, cand_cap < (1 << 18) ? cand_cap : (1 << 18), cfg->n_word, wt->stream) != S3A_OK) goto fail;
+    DM(wt->lane.ctx, sizeof(UCtx));
+    DM(wt->lane.pack, (size_t)(hdr + 3 * max_exits) * 4);
+    DM(wt->d_lane, sizeof(ULane));
+    if (hipMemcpy(wt->d_lane, &wt->lane, sizeof(ULane), hipMemcpyHostToDevice) != hipSuccess
+        || hipHostMalloc((void **)&wt->h_ctx, sizeof(UCtx)) != hipSuccess
+        || hipHostMalloc((void **)&wt->h_pack, (size_t)(hdr + 3 * max_exits) * 4) != hipSuccess) goto fail;
+    return wt;
+fail:
+    s3a_wltest_free(wt);
+    return NULL;
+}
+
+/* vithist_utt_begin: entry 0 */
+extern "C" int32_t
+s3a_wltest_begin(s3a_wltest_t *wt, int32_t startwid, int32_t n_frames)
+{
+    if (!wt || n_frames <= 0 || n_frames > wt->max_frames) return S3A_EINVAL;
+    WLane &w = wt->lane.w;
+    int32_t rc;
+    const int32_t e0[10] = { 0, -1, wt->start_lwid, -1, startwid, -1, -1, 0, 0, 0 };
+    int32_t *arr[10] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type };
+    for (int k = 0; k < 10; k++) if ((rc = fill32(wt->stream, arr[k], e0[k], 1)) != S3A_OK) return rc;
+    int32_t c5[5] = { 0, 0, 0, 0, -1 };
+    if (wt->lm->d.n_bg > 0 && wt->start_lwid >= 0) { c5[3] = wt->lm->ug_firstbg[wt->start_lwid]; c5[4] = wt->lm->ug_firstbg[wt->start_lwid + 1] - c5[3]; }
+    for (int k = 0; k < 5; k++) if ((rc = fill32(wt->stream, w.lmc + (size_t)k * w.cap, c5[k], 1)) != S3A_OK) return rc;
+    if ((rc = fill32(wt->stream, w.frame_start, 1, 1)) || (rc = fill32(wt->stream, w.bestscore, INT_MIN, 1))
+        || (rc = fill32(wt->stream, w.bestvh, -1, 1)) || (rc = fill32(wt->stream, w.st, 1, 1)) || (rc = fill32(wt->stream, w.st + 1, 0, 1)))
+        return rc;
+    memset(wt->h_ctx, 0, sizeof(UCtx));
+    wt->h_ctx->active = 1; wt->h_ctx->nfr = n_frames; wt->h_ctx->n_lextrans = 1;
+    HIPCHK(hipMemcpyAsync(wt->lane.ctx, wt->h_ctx, sizeof(UCtx), hipMemcpyHostToDevice, wt->stream));
+    HIPCHK(hipStreamSynchronize(wt->stream));
+    return S3A_OK;
+}
+
+/* One frame: n_exit[T] word exits per tree, exits = (wid, score, history) x total in tree-then-list order;
+ * best_hmm / best_word / word_thres = beam_t.bestscore / .bestwordscore / .word_thres of the frame.
+ * Out: the lextree_enter calls it leaves: calls[4c] = {score, history, root-list offset, first entry}. */
+extern "C" int32_t
+s3a_wltest_frame(s3a_wltest_t *wt, const int32_t *n_exit, const int32_t *exits, int32_t best_hmm, int32_t best_word,
+                 int32_t word_thres, int32_t *n_calls, int32_t *calls, int32_t *thresh, int32_t *n_ent)
+{
+    if (!wt || !n_exit || !n_calls || !calls) return S3A_EINVAL;
+    const int32_t T = wt->T, hdr = 6 * T + 16;
+    int32_t total = 0;
+    memset(wt->h_pack, 0, (size_t)hdr * 4);
+    for (int32_t t = 0; t < T; t++) { wt->h_pack[3 * T + 8 + t] = n_exit[t]; total += n_exit[t]; }
+    if (total > wt->max_exits) return S3A_EINVAL;
+    wt->h_pack[3 * T + 2] = word_thres; wt->h_pack[3 * T + 3] = best_hmm; wt->h_pack[3 * T + 4] = best_word;
+    if (total) memcpy(wt->h_pack + hdr, exits, (size_t)3 * total * 4);
+    HIPCHK(hipMemcpyAsync(wt->lane.pack, wt->h_pack, (size_t)(hdr + 3 * total) * 4, hipMemcpyHostToDevice, wt->stream));
+    hipLaunchKernelGGL(ku_wordlevel_only, dim3(1, 1, 1), dim3(WL_THREADS), 0, wt->stream, wt->d_lane, wt->lm->d, wt->dict, wt->par);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(wt->h_ctx, wt->lane.ctx, sizeof(UCtx), hipMemcpyDeviceToHost, wt->stream));
+    HIPCHK(hipStreamSynchronize(wt->stream));
+    if (wt->h_ctx->err) { s3a_set_error("s3a_wltest_frame: error bits 0x%x", wt->h_ctx->err); return S3A_EINVAL; }
+    *n_calls = wt->h_ctx->n_calls;
+    memcpy(calls, wt->h_ctx->calls, (size_t)4 * wt->h_ctx->n_calls * 4);
+    if (thresh) *thresh = wt->h_ctx->thresh;
+    if (n_ent) *n_ent = wt->h_ctx->n_ent;
+    return S3A_OK;
+}
+
+/* the table so far: out[k * n_entry + id], k = score pred lw0 lw1 wid sf ef ascr lscr type; frames[f] for
+ * f <= n_frm: frame_start | bestscore | bestvh (each max_out_frames long) */
+extern "C" int32_t
+s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int32_t *out, int32_t max_entries,
+                 int32_t *frames, int32_t max_out_frames, int32_t *n_tie_frames)
+{
+    if (!wt || !n_entry || !n_frm) return S3A_EINVAL;
+    int32_t st[2];
+    const WLane &w = wt->lane.w;
+    HIPCHK(hipMemcpy(st, w.st, 8, hipMemcpyDeviceToHost));
+    *n_entry = st[0]; *n_frm = st[1];
+    if (n_tie_frames) *n_tie_frames = wt->h_ctx->n_tie_frames;
+    if (out) {
+        if (st[0] > max_entries) return S3A_EINVAL;
+        const int32_t *src[10] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type };
+        for (int k = 0; k < 10; k++) HIPCHK(hipMemcpy(out + (size_t)k * st[0], src[k], (size_t)st[0] * 4, hipMemcpyDeviceToHost));
+    }
+    if (frames) {
+        if (st[1] + 1 > max_out_frames) return S3A_EINVAL;
+        HIPCHK(hipMemcpy(frames, w.frame_start, (size_t)(st[1] + 1) * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(frames + max_out_frames, w.bestscore, (size_t)(st[1] + 1) * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(frames + 2 * (size_t)max_out_frames, w.bestvh, (size_t)(st[1] + 1) * 4, hipMemcpyDeviceToHost));
+    }
+    return S3A_OK;
 }

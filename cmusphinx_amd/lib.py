@@ -175,6 +175,25 @@ _SIGS = {
     "s3a_approx_cont_mgau_frame_eval_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                         C.POINTER(C.c_int32)]),
+    "s3a_lm3g_init": (C.c_void_p, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_lm3g_free": (None, [C.c_void_p]),
+    "s3a_lm3g_tg_score": (C.c_int32, [C.c_void_p] + [C.c_int32] * 4),
+    "s3a_uttdec_init": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_double, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int32]),
+    "s3a_uttdec_free": (None, [C.c_void_p]),
+    "s3a_uttdec_decode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_uttdec_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
+    "s3a_uttdec_last_decode_ms": (C.c_double, [C.c_void_p]),
+    "s3a_wltest_init": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "s3a_wltest_free": (None, [C.c_void_p]),
+    "s3a_wltest_begin": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "s3a_wltest_frame": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "s3a_wltest_fetch": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "s3a_bench_score_frames": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_int32, C.c_int32, C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
@@ -1087,3 +1106,101 @@ class LexSearch:
         tb, lb, sb, hb = unpack(b)
         check(self.L.s3a_decoder_transition(self.h, sc.h, cs.h, int(cf), int(thresh), ta, len(la), _p(la), _p(sa),
                                             _p(ha), tb, len(lb), _p(lb), _p(sb), _p(hb)))
+
+
+class WordLevelCfg(C.Structure):
+    """s3a_wordlevel_cfg_t"""
+    _fields_ = [("n_word", C.c_int32), ("n_ci", C.c_int32), ("lwid", C.c_void_p), ("is_filler", C.c_void_p),
+                ("fillpen", C.c_void_p), ("last_ci", C.c_void_p)] + \
+               [(k, C.c_int32) for k in ("startwid", "finishwid", "silwid", "start_lwid", "finish_lwid", "sil_ci", "wbeam_vh",
+                                         "bghist", "maxwpf", "maxhistpf", "wordend_beam", "n_lextree", "epl", "hmmbeam",
+                                         "pbeam", "wbeam", "ptranskip", "maxhmmpf")] + [("tree_type", C.c_void_p)]
+
+
+class Lm3g:
+    """lm_t flattened (s3a_lm3g_init); t = dict with the arrays of a word-level trace"""
+
+    def __init__(self, t):
+        self.L = load()
+        g = lambda k: np.ascontiguousarray(t[k], dtype=np.int32) if k in t and len(np.atleast_1d(t[k])) else None
+        self.keep = [g(k) for k in ("ug_prob", "ug_bowt", "ug_firstbg", "bg_wid", "bg_prob", "bg_bowt", "bg_firsttg",
+                                    "tg_wid", "tg_prob")]
+        a = self.keep
+        self.h = self.L.s3a_lm3g_init(int(t["n_ug"]), _p(a[0]), _p(a[1]), _p(a[2]), int(t["n_bg"]), _p(a[3]), _p(a[4]),
+                                      _p(a[5]), _p(a[6]), int(t["n_tg"]), _p(a[7]), _p(a[8]), None, int(t["n_word"]))
+        if not self.h:
+            raise S3AError(_err(self.L))
+
+    def tg_score(self, lw1, lw2, lw3, wid=0):
+        return int(self.L.s3a_lm3g_tg_score(self.h, lw1, lw2, lw3, wid))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_lm3g_free(self.h)
+            self.h = None
+
+
+def wordlevel_cfg(t, tree_type, keep, wordend=None, maxwpf=None, maxhist=None, hmmbeam=-1000000):
+    g = lambda k, dt=np.int32: np.ascontiguousarray(t[k], dtype=dt)
+    keep += [g("lwid"), g("is_filler", np.uint8), g("fillpen"), g("last_ci"), np.ascontiguousarray(tree_type, dtype=np.int32)]
+    a = keep[-5:]
+    c = WordLevelCfg()
+    c.n_word, c.n_ci = int(t["n_word"]), int(t["n_ci"])
+    c.lwid, c.is_filler, c.fillpen, c.last_ci, c.tree_type = (x.ctypes.data for x in a)
+    for k in ("startwid", "finishwid", "silwid", "start_lwid", "finish_lwid", "bghist", "n_lextree", "epl"):
+        setattr(c, k, int(t[k]))
+    c.sil_ci = int(t["n_ci"]) - 1
+    c.wbeam_vh = int(t["wbeam"])
+    c.maxwpf = int(t["maxwpf"] if maxwpf is None else maxwpf)
+    c.maxhistpf = int(t["maxhistpf"] if maxhist is None else maxhist)
+    c.wordend_beam = int(t.get("wordend", 0) if wordend is None else wordend)
+    c.hmmbeam = hmmbeam
+    c.pbeam = c.wbeam = hmmbeam
+    c.maxhmmpf = 100000
+    return c
+
+
+class WlTest:
+    """The device word level on its own (s3a_wltest_*): one frame per call, next to the oracle."""
+
+    def __init__(self, t, tree_type, cap=1 << 16, cand_cap=1 << 16, max_exits=4096, max_frames=1024, **kw):
+        self.L = load()
+        self.lm = Lm3g(t)
+        self.keep = []
+        self.cfg = wordlevel_cfg(t, tree_type, self.keep, **kw)
+        self.T, self.n_ci = len(tree_type), int(t["n_ci"])
+        self.lcmap_len = np.full((self.T, self.n_ci + 1), 3, np.int32)      # every (tree, context) has a 3-node root list
+        self.h = self.L.s3a_wltest_init(self.lm.h, C.byref(self.cfg), _p(self.lcmap_len), cap, cand_cap, max_exits, max_frames)
+        if not self.h:
+            raise S3AError(_err(self.L))
+        self.cap, self.max_frames, self.startwid = cap, max_frames, int(t["startwid"])
+        check(self.L.s3a_wltest_begin(self.h, self.startwid, max_frames), self.L)
+
+    def frame(self, trees, best_hmm, best_word, word_thres):
+        n_exit = np.array([len(t[1]) for t in trees], np.int32)
+        ex = np.zeros((int(n_exit.sum()), 3), np.int32)
+        k = 0
+        for _, wid, scr, hist in trees:
+            n = len(wid)
+            ex[k:k + n, 0], ex[k:k + n, 1], ex[k:k + n, 2] = wid, scr, hist
+            k += n
+        calls = np.zeros(4 * 128, np.int32)
+        nc, th, ne = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(self.L.s3a_wltest_frame(self.h, _p(n_exit), _p(ex), int(best_hmm), int(best_word), int(word_thres),
+                                      C.byref(nc), _p(calls), C.byref(th), C.byref(ne)), self.L)
+        return calls[: 4 * nc.value].reshape(-1, 4).copy(), th.value, ne.value
+
+    def table(self):
+        n, nf, nt = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(self.L.s3a_wltest_fetch(self.h, C.byref(n), C.byref(nf), None, 0, None, 0, C.byref(nt)), self.L)
+        out = np.zeros((10, max(n.value, 1)), np.int32)[:, : n.value].copy()
+        fr = np.zeros((3, nf.value + 1), np.int32)
+        check(self.L.s3a_wltest_fetch(self.h, C.byref(n), C.byref(nf), _p(out), n.value, _p(fr), nf.value + 1, C.byref(nt)), self.L)
+        d = {k: out[i] for i, k in enumerate(("score", "pred", "lw0", "lw1", "wid", "sf", "ef", "ascr", "lscr", "type"))}
+        d.update(frame_start=fr[0], bestscore=fr[1], bestvh=fr[2], n_tie_frames=nt.value)
+        return d
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_wltest_free(self.h)
+            self.h = None

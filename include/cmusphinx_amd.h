@@ -692,6 +692,23 @@ int32_t s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *f
                           const int32_t *n_frames, int32_t feat_stride);
 int32_t s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out);
 int32_t s3a_uttdec_n_lanes(const s3a_uttdec_t *ud);
+/* The word level on its own (one lane, no lextrees): what closes a frame -- vithist_rescore for
+ * every word exit, vithist_prune, srch_utt_word_trans, vithist_frame_windup -- on caller-supplied
+ * exits; the parity tests drive it frame by frame next to the oracle.  cfg: dictionary / pruning
+ * fields of s3a_wordlevel_cfg_t; lcmap_len[t * (n_ci + 1) + p] = length of the root list
+ * lextree_enter(tree t, left context p) walks (p == n_ci: no context), negative: not a context. */
+typedef struct s3a_wltest_s s3a_wltest_t;
+s3a_wltest_t *s3a_wltest_init(s3a_lm3g_t *lm, const s3a_wordlevel_cfg_t *cfg, const int32_t *lcmap_len,
+                              int32_t vh_cap, int32_t cand_cap, int32_t max_exits, int32_t max_frames);
+void s3a_wltest_free(s3a_wltest_t *wt);
+int32_t s3a_wltest_begin(s3a_wltest_t *wt, int32_t startwid, int32_t n_frames);
+int32_t s3a_wltest_frame(s3a_wltest_t *wt, const int32_t *n_exit, const int32_t *exits, int32_t best_hmm,
+                         int32_t best_word, int32_t word_thres, int32_t *n_calls, int32_t *calls,
+                         int32_t *thresh, int32_t *n_ent);
+int32_t s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int32_t *out,
+                         int32_t max_entries, int32_t *frames, int32_t max_out_frames,
+                         int32_t *n_tie_frames);
+
 double s3a_uttdec_last_decode_ms(const s3a_uttdec_t *ud);    /* HIP-event time of the last decode's frames */
 
 /* ===================================================================== */

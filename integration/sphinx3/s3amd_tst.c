@@ -544,10 +544,10 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
         g_od.finish_lwid = w->finish_lwid;
         g_ovh = s3o_vithist_init(1 << 22, S3_MAX_FRAMES, vh->wbeam, vh->bghist);
         if (getenv("S3O_WLTRACE") && (g_wltrace = fopen(getenv("S3O_WLTRACE"), "wb")) != NULL) {
-            int32 hdr[16] = { w->n_ug, w->n_bg, w->n_tg, w->n_word, w->n_ci, w->startwid, w->finishwid, w->silwid,
+            int32 hdr[17] = { w->n_ug, w->n_bg, w->n_tg, w->n_word, w->n_ci, w->startwid, w->finishwid, w->silwid,
                               w->start_lwid, w->finish_lwid, vh->wbeam, vh->bghist, tstg->histprune->maxwpf,
-                              tstg->histprune->maxhistpf, tstg->n_lextree, tstg->epl };
-            wtr(1, 16, hdr);
+                              tstg->histprune->maxhistpf, tstg->n_lextree, tstg->epl, kb->beam->wordend };
+            wtr(1, 17, hdr);
             wtr(2, w->n_ug, w->ug_prob); wtr(3, w->n_ug, w->ug_bowt); wtr(4, w->n_ug + 1, w->ug_firstbg);
             wtr(5, w->n_bg, w->bg_wid); wtr(6, w->n_bg, w->bg_prob); wtr(7, w->n_bg, w->bg_bowt);
             wtr(8, w->n_bg ? w->n_bg + 1 : 0, w->bg_firsttg); wtr(9, w->n_tg, w->tg_wid); wtr(10, w->n_tg, w->tg_prob);

@@ -540,6 +540,28 @@ cmd_fe(int argc, char **argv)
     return 0;
 }
 
+/* heap VALUES.i32 OUTDIR: the reference's own heap (sphinxbase util/heap.c): insert data = index with the
+ * given values in order, pop everything; dumps the pop order (vithist_prune pops its entries this way) */
+#include "sphinxbase/heap.h"
+static int
+cmd_heap(int argc, char **argv)
+{
+    size_t nb;
+    long n, i;
+    int32 *v = (int32 *)slurp(argv[0], &nb), *order;
+    heap_t *h = heap_new();
+    void *data;
+    int32 val;
+    n = (long)(nb / 4);
+    order = calloc(n + 1, sizeof(int32));
+    for (i = 0; i < n; i++) heap_insert(h, (void *)(long)(i + 1), v[i]);
+    for (i = 0; heap_pop(h, &data, &val) > 0; i++) order[i] = (int32)((long)data - 1);
+    if (i != n) { fprintf(stderr, "heap: popped %ld of %ld\n", i, n); return 2; }
+    dump(argv[1], "order", "i32", order, 4, 1, n);
+    heap_destroy(h);
+    return 0;
+}
+
 int
 main(int argc, char **argv)
 {
@@ -558,6 +580,7 @@ main(int argc, char **argv)
     if (!strcmp(argv[1], "fe") && argc >= 4) return cmd_fe(argc - 2, argv + 2);
     if (!strcmp(argv[1], "hmm") && argc == 14) return cmd_hmm(argc - 2, argv + 2);
     if (!strcmp(argv[1], "ms") && argc == 12) return cmd_ms(argc - 2, argv + 2);
+    if (!strcmp(argv[1], "heap") && argc == 4) return cmd_heap(argc - 2, argv + 2);
     fprintf(stderr, "ref_dump: bad command/arity: %s (%d args)\n", argv[1], argc - 2);
     return 1;
 }

@@ -16,12 +16,23 @@ identical frame normalisers (ascale), not just identical words.
 """
 import os
 import subprocess
+import sys
 
 import pytest
 
 from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
+
+
+def need(*paths):
+    """oracle/_ref (the reference build) and tests/_local_data travel to the GPU box with the snapshot; a gpu-marked
+    test that cannot find them must FAIL, not vanish (they are git-ignored: a clean checkout has neither)."""
+    missing = [p for p in paths if not os.path.exists(p)]
+    if missing:
+        pytest.fail("missing on the GPU box: " + ", ".join(missing) +
+                    " (make -C oracle ref; tools/fetch_local_data.sh -- both need /root/reference)")
+
 D = os.path.join(GOLDEN, "tidigits_decode")
 AM = os.path.join(GOLDEN, "tidigits")
 SHIM = os.path.join(ROOT, "oracle", "_ref", "ref_s3amd_decode")
@@ -41,6 +52,11 @@ def common():
             "-cmn", "current", "-lw", "9.5", "-ctl", os.path.join(D, "tidigits.length.arb.regression")]
 
 
+@pytest.fixture(autouse=True)
+def _artefacts():
+    need(SHIM, REFDEC, TST, PSSHIM, RM)
+
+
 def run(binary, extra, tmp_path, tag):
     hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
     with open(log, "w") as lf:
@@ -51,8 +67,6 @@ def run(binary, extra, tmp_path, tag):
     return open(hyp).read(), open(seg).read(), tail
 
 
-@pytest.mark.skipif(not os.path.exists(SHIM), reason="oracle/_ref/ref_s3amd_decode did not travel "
-                    "(built by `make -C oracle ref` where /root/reference exists)")
 @pytest.mark.parametrize("name", list(RUNS))
 def test_reference_decoder_with_gpu_scoring_matches_reference(name, tmp_path):
     hyp, seg, tail = run(SHIM, RUNS[name], tmp_path, "gpu_" + name)
@@ -63,7 +77,6 @@ def test_reference_decoder_with_gpu_scoring_matches_reference(name, tmp_path):
         assert hyp == open(os.path.join(D, "tidigits.length.arb.result")).read()
 
 
-@pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
 @pytest.mark.parametrize("topn", [4, 8])
 def test_multistream_scorer_dropin_matches_live_reference(topn, tmp_path):
     """-senmgau .s3cont.: the reference routes gmm_compute_lv2 to ms_cont_mgau_frame_eval
@@ -77,7 +90,6 @@ def test_multistream_scorer_dropin_matches_live_reference(topn, tmp_path):
     assert seg != open(os.path.join(D, "ref_mode4_trigram.matchseg")).read()       # really a different scorer
 
 
-@pytest.mark.skipif(not (os.path.exists(SHIM) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
 def test_live_cpu_reference_agrees_with_committed_golden(tmp_path):
     """The committed golden is what the reference produces on THIS box too."""
     hyp, seg, _ = run(REFDEC, RUNS["mode4_trigram"], tmp_path, "cpu_mode4")
@@ -98,13 +110,16 @@ DRIVERS = {
     "four_streams": {"S3A_STREAMS": "4"},                       # four decoders on four HIP streams
     "batched_4x1": {"S3A_STREAMS": "4", "S3A_BATCH": "1"},      # s3a_batch_*: four decoders share every launch
     "batched_6x2": {"S3A_STREAMS": "6", "S3A_BATCH": "2"},      # two engines of three decoders alternate
+    # s3a_uttdec_*: WHOLE utterances on the device (word level, history table, trigram included), one kb_t
+    "utt_1": {"S3A_UTT": "1"},
+    "utt_4": {"S3A_UTT": "4"},
 }
 
 
-@pytest.mark.skipif(not os.path.exists(TST), reason="oracle/_ref/ref_s3amd_tst_decode did not travel")
 @pytest.mark.parametrize("name,driver", [("mode4_trigram", "one_decoder"), ("mode4_cibeam_ds2", "one_decoder"),
                                          ("mode4_trigram", "four_streams"), ("mode4_trigram", "batched_4x1"),
-                                         ("mode4_cibeam_ds2", "batched_6x2")])
+                                         ("mode4_cibeam_ds2", "batched_6x2"), ("mode4_trigram", "utt_1"),
+                                         ("mode4_trigram", "utt_4"), ("mode4_cibeam_ds2", "utt_4")])
 def test_full_device_search_matches_reference(name, driver, tmp_path):
     hyp, seg, log = (str(tmp_path / f"tst_{name}.{e}") for e in ("match", "matchseg", "log"))
     with open(log, "w") as lf:
@@ -120,8 +135,7 @@ def test_full_device_search_matches_reference(name, driver, tmp_path):
     assert open(seg).read() == open(os.path.join(D, f"ref_{name}.matchseg")).read()
 
 
-@pytest.mark.skipif(not (os.path.exists(TST) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
-@pytest.mark.parametrize("driver", ["one_decoder", "batched_4x1"])
+@pytest.mark.parametrize("driver", ["one_decoder", "batched_4x1", "utt_4"])
 def test_full_device_search_with_phone_threshold_below_hmm_threshold(driver, tmp_path):
     """-ptranskip 2 (every second frame the WORD threshold gates phone transitions) and a phone beam
     wider than the HMM beam: HMMs under the beam but over the phone threshold propagate only if a
@@ -138,8 +152,8 @@ def test_full_device_search_with_phone_threshold_below_hmm_threshold(driver, tmp
     assert ref_seg != open(os.path.join(D, "ref_mode4_trigram.matchseg")).read()
 
 
-@pytest.mark.skipif(not (os.path.exists(TST) and os.path.exists(REFDEC)), reason="oracle/_ref missing")
-def test_full_device_search_with_histogram_pruning(tmp_path):
+@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4"])
+def test_full_device_search_with_histogram_pruning(driver, tmp_path):
     """-maxhmmpf 20: most frames exceed 1.5 x the cap, so lextree_hmm_histbin (bins, beam from the
     bin scan AND the reordering of the active lists) runs on the device; expected output is
     produced live by the unmodified reference."""
@@ -148,7 +162,7 @@ def test_full_device_search_with_histogram_pruning(tmp_path):
     hyp, seg, log = (str(tmp_path / f"tst_hist.{e}") for e in ("match", "matchseg", "log"))
     with open(log, "w") as lf:
         p = subprocess.run([TST] + common() + extra + ["-hyp", hyp, "-hypseg", seg],
-                           stdout=lf, stderr=subprocess.STDOUT, timeout=900)
+                           stdout=lf, stderr=subprocess.STDOUT, timeout=900, env=dict(os.environ, **DRIVERS[driver]))
     tail = [l for l in open(log, errors="ignore").read().splitlines() if "tst shim" in l or "FATAL" in l]
     assert p.returncode == 0, "\n".join(tail[-10:])
     n = [int(l.split("applied in")[1].split()[0]) for l in tail if "histogram pruning" in l]
@@ -176,24 +190,30 @@ def rm_args(extra=()):
             "-cepdir", f"{RM}/feat", "-cepext", ".mfc", "-ctl", f"{RM}/rm.ctl", "-ctlcount", "20", "-op_mode", "4"]
 
 
-@pytest.mark.skipif(not (os.path.exists(TST) and os.path.exists(REFDEC) and os.path.isdir(RM)),
-                    reason="RM1 local data or oracle/_ref binaries absent (tools/fetch_local_data.sh)")
-@pytest.mark.parametrize("binary", ["scoring_only", "full_device", "full_device_histprune", "full_device_batched"])
+@pytest.mark.parametrize("binary", ["scoring_only", "full_device", "full_device_histprune", "full_device_batched",
+                                    "utt_1", "utt_7_histprune", "utt_3_tight_word_limits"])
 def test_rm1_identical_to_live_reference(binary, tmp_path):
     exe = SHIM if binary == "scoring_only" else TST
-    extra = ["-maxhmmpf", "800"] if binary in ("full_device_histprune", "full_device_batched") else []
+    extra = ["-maxhmmpf", "800"] if binary in ("full_device_histprune", "full_device_batched", "utt_7_histprune") else []
     env = dict(os.environ, S3A_STREAMS="5", S3A_BATCH="2") if binary == "full_device_batched" else None
+    if binary.startswith("utt_"):
+        env = dict(os.environ, S3A_UTT=binary.split("_")[1])
+    if binary == "utt_3_tight_word_limits":     # the word level's own pruning: few words / histories per frame, bigram history
+        extra = ["-maxwpf", "3", "-maxhistpf", "8", "-bghist", "1"]
     out = {}
     for tag, b in (("ref", REFDEC), ("gpu", exe)):
         hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
         with open(log, "w") as lf:
-            p = subprocess.run([b] + rm_args(extra) + ["-hyp", hyp, "-hypseg", seg], stdout=lf,
+            args = rm_args(extra)
+            if "-maxwpf" in extra:
+                i = args.index("-maxwpf", len(extra)); del args[i:i + 2]
+            p = subprocess.run([b] + args + ["-hyp", hyp, "-hypseg", seg], stdout=lf,
                                stderr=subprocess.STDOUT, timeout=1800, env=env if tag == "gpu" else None)
         tail = [l for l in open(log, errors="ignore").read().splitlines()
                 if l.startswith(("FATAL", "INFO: ref_", "INFO: stat.c")) and ("shim" in l or "SUMMARY" in l or "FATAL" in l)]
         assert p.returncode == 0, "\n".join(tail[-10:])
         out[tag] = (open(hyp).read(), open(seg).read())
-        if tag == "gpu" and extra:
+        if tag == "gpu" and "-maxhmmpf" in extra:
             n = [int(l.split("applied in")[1].split()[0]) for l in open(log, errors="ignore").read().splitlines()
                  if l.startswith("INFO: ref_") and "histogram pruning" in l]
             assert n and n[0] > 1000, n
@@ -212,7 +232,6 @@ def test_rm1_identical_to_live_reference(binary, tmp_path):
 PSSHIM = os.path.join(ROOT, "oracle", "_ref", "ref_ps_shim")
 
 
-@pytest.mark.skipif(not os.path.exists(PSSHIM), reason="oracle/_ref/ref_ps_shim did not travel")
 def test_pocketsphinx_decoder_with_gpu_scorer_matches_pocketsphinx(tmp_path):
     ctl = tmp_path / "ps.ctl"
     ctl.write_text("".join(l.split()[0] + "\n" for l in open(os.path.join(D, "tidigits.length.arb.regression"))))
@@ -232,3 +251,51 @@ def test_pocketsphinx_decoder_with_gpu_scorer_matches_pocketsphinx(tmp_path):
             assert any("frame_eval calls served by" in l for l in tail)
     assert out["gpu"] == out["ref"]
     assert out["ref"].count("\n") == 31 and "ONE ONE ONE (man/man.ah.111a" in out["ref"]
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configs[2] / configs[4] as tests: the synthetic hub4-shaped task (6144 senones x 8, 20 000 words,
+# ARPA trigram, hub4 beams) and the WSJ-shaped one (8000 x 32) decoded with a wide beam -- thousands of word exits
+# and hundreds of thousands of (exit, predecessor) candidates per frame, tied scores in half of the frames --
+# through the frame-synchronous drop-in and through whole utterances on the device; expected output live from the
+# unmodified reference on the same files.
+# ---------------------------------------------------------------------------
+def synth_task(kind, tmp_path, n_utt, n_frames, env=None):
+    out = subprocess.run([sys.executable, "-m", "cmusphinx_amd.synth_task", kind, str(tmp_path / "task"), f"n_utt={n_utt}",
+                          f"n_frames={n_frames}"], check=True, capture_output=True, text=True, cwd=ROOT,
+                         env=dict(os.environ, **(env or {}))).stdout
+    return out.split(";")[1].split()
+
+
+def decode_task(exe, args, tmp_path, tag, env=None):
+    hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
+    with open(log, "w") as lf:
+        p = subprocess.run([exe] + args + ["-hyp", hyp, "-hypseg", seg], stdout=lf, stderr=subprocess.STDOUT, timeout=1800,
+                           env=dict(os.environ, **(env or {})))
+    tail = [l for l in open(log, errors="ignore").read().splitlines() if "tst shim" in l or "FATAL" in l or "SUMMARY" in l]
+    assert p.returncode == 0, "\n".join(tail[-10:])
+    return open(hyp).read(), open(seg).read(), tail
+
+
+@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4"])
+def test_hub4_shaped_full_decode_matches_reference(driver, tmp_path):
+    args = synth_task("hub4", tmp_path, 4, 250)
+    ref = decode_task(REFDEC, args, tmp_path, "ref")
+    got = decode_task(TST, args, tmp_path, driver, DRIVERS[driver])
+    assert got[0] == ref[0] and got[1] == ref[1]
+    assert ref[0].count("\n") == 4
+    cd = [l for l in ref[2] if "SUMMARY" in l]
+    assert cd and int(cd[0].split("cdsen/fr")[0].split()[-1]) > 3000       # most of the 6144 senones scored per frame
+
+
+def test_wsj_shaped_wide_beam_decode_matches_reference(tmp_path):
+    """configs[4]: 8000 senones x 32 Gaussians, -beam 1e-120 -pbeam 1e-100 -wbeam 1e-80 -maxhmmpf 100000."""
+    args = synth_task("wsj", tmp_path, 2, 60, env=dict(TASK_BEAM="1e-120", TASK_WBEAM="1e-80")) + \
+        ["-pbeam", "1e-100", "-maxhmmpf", "100000"]
+    ref = decode_task(REFDEC, args, tmp_path, "ref")
+    got = decode_task(TST, args, tmp_path, "utt_2", {"S3A_UTT": "2"})
+    assert got[0] == ref[0] and got[1] == ref[1]
+    wl = [l for l in got[2] if "word level: at most" in l]
+    assert wl and int(wl[0].split("at most")[1].split()[0]) > 20000, wl     # a real word-level load
+    one = decode_task(TST, args, tmp_path, "one", {})
+    assert one[0] == ref[0] and one[1] == ref[1]

@@ -1,0 +1,84 @@
+"""The WORD LEVEL on the MI355X (s3a_wordlevel.h through s3a_wltest_*) against the oracle and the recorded
+reference-grade traces, frame by frame: trigram look-ups, the history entries a frame leaves (ids, order, every
+field), the frame's best exit and the lextree_enter calls of srch_utt_word_trans.  Bit-exact.
+
+  * replay of the tidigits / RM1 traces (real dictionary, real trigram read from the DMP file);
+  * random frames on a coarse score grid -- tied scores everywhere, so the heap's pop order decides what
+    survives -- under tight -maxwpf / -maxhistpf, -bghist and a word-end beam.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_wordlevel as OW
+import wordlevel_trace as WT
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+FIELDS = ("score", "pred", "lw0", "lw1", "wid", "sf", "ef", "ascr", "lscr", "type")
+HMMBEAM = -1000000
+
+
+def run_lockstep(gpu_lib, t, frames, tree_type, **kw):
+    """frames: iterable of (trees, prune_beam, thresh) -> drives the device and the oracle side by side"""
+    ow = OW.OracleWordLevel(t, max_frames=4096, wordend=kw.get("wordend"))
+    wl = gpu_lib.WlTest(t, tree_type, **kw)
+    n_calls = 0
+    for frm, (trees, prune_beam, thresh) in enumerate(frames):
+        if callable(trees):
+            trees = trees(ow, frm)
+        r = ow.frame(frm, trees, prune_beam, maxwpf=kw.get("maxwpf"), maxhist=kw.get("maxhist"))
+        calls, th, n_ent = wl.frame(trees, thresh - HMMBEAM, 0, prune_beam)
+        assert th == thresh
+        if r["calls"] is None:
+            assert len(calls) == 0, frm
+        else:
+            lc, cs, ch = r["calls"]
+            assert len(calls) == len(lc) + 1, frm
+            assert np.array_equal(calls[:-1, 0], cs) and np.array_equal(calls[:-1, 1], ch), frm
+            assert (calls[-1, 0], calls[-1, 1]) == r["fill"], frm
+            assert n_ent == 3 * len(calls)
+            n_calls += len(lc)
+    a, b = ow.table(), wl.table()
+    assert len(a["score"]) == len(b["score"])
+    for k in FIELDS + ("frame_start", "bestscore", "bestvh"):
+        assert np.array_equal(a[k], b[k]), k
+    return a, b, n_calls
+
+
+@pytest.mark.parametrize("name", ["tidigits", "rm1"])
+def test_device_word_level_replays_the_recorded_trace(gpu_lib, name):
+    tr = WT.from_npz(np.load(os.path.join(GOLDEN, f"wordlevel_{name}.npz")))
+    fr = [([(t["type"], t["wid"], t["scr"], t["hist"]) for t in f["trees"]], f["prune_beam"], f["thresh"]) for f in tr["frames"]]
+    a, b, n_calls = run_lockstep(gpu_lib, tr, fr, tr["tree_type"], cap=1 << 18, cand_cap=1 << 17)
+    # ... and the recorded results themselves (the reference's, not just the oracle's)
+    rec = {k: np.concatenate([f["res"][k] for f in tr["frames"]]) for k in ("wid", "score", "pred", "lw0", "lw1", "ascr", "lscr", "sf", "type")}
+    for k, v in rec.items():
+        assert np.array_equal(b[k][1:], v), k
+    assert n_calls > 50 and len(b["score"]) > 100
+
+
+def test_device_trigram_matches_the_oracle_on_the_rm1_lm(gpu_lib):
+    tr = WT.from_npz(np.load(os.path.join(GOLDEN, "wordlevel_rm1.npz")))
+    ow = OW.OracleWordLevel(tr)
+    lm = gpu_lib.Lm3g(tr)               # (the host copy; the device copy is what the replay above exercises)
+    rng = np.random.default_rng(3)
+    for _ in range(20000):
+        l1, l2, l3 = (int(x) for x in rng.integers(0, tr["n_ug"], 3))
+        if rng.random() < 0.05:
+            l1 = -1
+        assert lm.tg_score(l1, l2, l3) == ow.tg_score(l1, l2, l3)
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(maxwpf=2, maxhist=5)), (3, dict(maxwpf=3, maxhist=40, wordend=-2500)),
+                                     (4, dict(maxwpf=50, maxhist=3)), (5, dict(maxwpf=6, maxhist=9))])
+def test_random_frames_with_tied_scores_lockstep(gpu_lib, seed, kw):
+    rng = np.random.default_rng(seed)
+    t = OW.random_task(rng)
+    if seed == 5:
+        t["bghist"] = 1
+    tree_type = [0, 0, 0, -1, -1, -1]
+    fr = [((lambda ow, frm, r=rng: OW.random_frame(r, ow, frm)), int(rng.integers(-6, -1)) * 1000, -123456 - 7 * i) for i in range(160)]
+    a, b, n_calls = run_lockstep(gpu_lib, t, fr, tree_type, **kw)
+    assert b["n_tie_frames"] > 20 and len(b["score"]) > 150 and n_calls > 100
