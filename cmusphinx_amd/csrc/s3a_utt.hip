@@ -1037,3 +1037,113 @@ s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int32_t *ou
     }
     return S3A_OK;
 }
+
+/* ------------------------------------------------------------------ */
+/* the hypothesis of a finished lane (host): vithist_utt_end + vithist_backtrace */
+/* ------------------------------------------------------------------ */
+/* vithist_utt_end (vithist.c:766-860): the last frame's entries rescored into </s>; when the last frame has no
+ * entry the reference first adds a silence entry spanning the rest (vithist_rescore with the silence word) and
+ * retries.  Then vithist_backtrace (vithist.c:1066-1100).  Nothing is written to the lane's table: the added
+ * entries exist in the record only. */
+extern "C" int32_t
+s3a_uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index, s3a_hyp_record_t *rec)
+{
+    if (!ud || !rec || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
+    s3a_utt_result_t r;
+    int32_t rc = s3a_uttdec_result(ud, lane, &r);
+    if (rc != S3A_OK) return rc;
+    const s3a_wordlevel_cfg_t &c = ud->cfg;
+    memset(rec, 0, sizeof *rec);
+    if (uttid) strncpy(rec->uttid, uttid, sizeof rec->uttid - 1);
+    rec->utt_index = utt_index; rec->n_frames = r.n_frames; rec->n_entry = r.n_entry; rec->status = r.err ? -1 : 0;
+    for (int32_t f = 0; f < r.n_frames; f++) rec->total_scale = h_add(rec->total_scale, r.frame_stat[8 * f]);
+    if (r.err) return S3A_OK;
+    int32_t f, sv = 0, nsv = 0;
+    for (f = r.n_frm - 1; f >= 0; --f) {
+        sv = r.frame_start[f]; nsv = r.frame_start[f + 1];
+        if (sv < nsv) break;
+    }
+    if (f < 0) { rec->status = -2; return S3A_OK; }     /* no word exit at all: vithist_utt_end returns -1 */
+    int32_t best = INT_MIN, bestvh = -1;
+    for (int32_t i = sv; i < nsv; i++) {
+        const int32_t s = h_add(r.score[i], s3a_lm3g_tg_score(ud->lm, r.lw1[i], r.lw0[i], c.finish_lwid, c.finishwid));
+        if (best < s) { best = s; bestvh = i; }
+    }
+    /* optional silence entry (frame n_frm - 1) when the search died early */
+    bool have_sil = false;
+    s3a_hyp_word_t silw = { 0, 0, 0, 0, 0, 0 };
+    int32_t sil_score = 0, last_ef = r.ef[bestvh], last_score = r.score[bestvh];
+    if (f != r.n_frm - 1) {
+        have_sil = true;
+        silw.wid = c.silwid; silw.sf = r.ef[bestvh] + 1; silw.ef = r.n_frm - 1;
+        silw.ascr = h_add(r.score[bestvh], -r.score[bestvh]);       /* score - pve->path.score with score = pve's */
+        silw.lscr = c.fillpen[c.silwid];
+        sil_score = h_add(r.score[bestvh], silw.lscr);
+        best = h_add(sil_score, s3a_lm3g_tg_score(ud->lm, r.lw1[bestvh], r.lw0[bestvh], c.finish_lwid, c.finishwid));
+        last_ef = silw.ef; last_score = sil_score;
+    }
+    /* backtrace */
+    int32_t n = 0;
+    for (int32_t i = bestvh; i > 0; i = r.pred[i]) n++;
+    const int32_t total = n + (have_sil ? 1 : 0) + 1;
+    rec->n_words = total; rec->score = best; rec->exit_id = r.n_entry + (have_sil ? 1 : 0);
+    if (total > S3A_HYP_MAXW) { rec->status = -3; rec->n_words = 0; return S3A_OK; }
+    int32_t k = n - 1;
+    for (int32_t i = bestvh; i > 0; i = r.pred[i], k--) {
+        s3a_hyp_word_t &w = rec->word[k];
+        w.wid = r.wid[i]; w.sf = r.sf[i]; w.ef = r.ef[i]; w.ascr = r.ascr[i]; w.lscr = r.lscr[i];
+    }
+    k = n;
+    if (have_sil) rec->word[k++] = silw;
+    {
+        s3a_hyp_word_t &w = rec->word[k];
+        w.wid = c.finishwid; w.sf = last_ef + 1; w.ef = r.n_frm; w.ascr = 0; w.lscr = h_add(best, -last_score);
+    }
+    for (int32_t q = 0; q < total; q++) {               /* compute_scale, srch_output.c:52-60 */
+        s3a_hyp_word_t &w = rec->word[q];
+        int32_t sc = 0;
+        for (int32_t i = w.sf; i < w.ef && i < r.n_frames; i++) if (i >= 0) sc = h_add(sc, r.frame_stat[8 * i]);
+        w.scale = sc;
+    }
+    return S3A_OK;
+}
+
+/* match_write / matchseg_write (libsearch/srch_output.c:74-161) for one record: the -hyp and -hypseg lines.
+ * wordstr / basewid / is_filler by dictionary word id; lw, wip = lm_t.lw, lm_t.wip (lm_rawscore, lm.c:2171-2178). */
+extern "C" int32_t
+s3a_hyp_format(const s3a_hyp_record_t *rec, const char *const *wordstr, const int32_t *basewid, const uint8_t *is_filler,
+               int32_t startwid, int32_t finishwid, float lw, int32_t wip, int32_t unscale, char *match_line,
+               size_t match_cap, char *seg_line, size_t seg_cap)
+{
+    if (!rec || !wordstr || !basewid || !is_filler || !match_line || !seg_line) return S3A_EINVAL;
+    size_t mp = 0, sp = 0;
+#define APP(buf, pos, cap, ...) do { int w_ = snprintf((buf) + (pos), (pos) < (cap) ? (cap) - (pos) : 0, __VA_ARGS__); \
+        if (w_ < 0 || (pos) + (size_t)w_ >= (cap)) return S3A_EINVAL; (pos) += (size_t)w_; } while (0)
+    int counter = 0;
+    if (rec->n_words == 0) APP(match_line, mp, match_cap, "(null)");
+    for (int32_t q = 0; q < rec->n_words; q++) {
+        const s3a_hyp_word_t &w = rec->word[q];
+        if (w.sf == w.ef) continue;
+        if (!is_filler[w.wid] && w.wid != finishwid && w.wid != startwid) APP(match_line, mp, match_cap, "%s ", wordstr[basewid[w.wid]]);
+        counter++;
+    }
+    if (counter == 0) APP(match_line, mp, match_cap, " ");
+    APP(match_line, mp, match_cap, "(%s)\n", rec->uttid);
+    int32_t ascr = 0, lscr = 0, gscale = 0;
+    auto raw = [&](int32_t s) { s -= wip; float fs = (float)s; fs /= lw; return (int32_t)fs; };
+    for (int32_t q = 0; q < rec->n_words; q++) {
+        const s3a_hyp_word_t &w = rec->word[q];
+        if (w.sf == w.ef) continue;
+        ascr += w.ascr; lscr += raw(w.lscr);
+        if (unscale) gscale += w.scale;
+    }
+    APP(seg_line, sp, seg_cap, "%s S %d T %d A %d L %d", rec->uttid, rec->total_scale, ascr + lscr + gscale, ascr + gscale, lscr);
+    for (int32_t q = 0; q < rec->n_words; q++) {
+        const s3a_hyp_word_t &w = rec->word[q];
+        if (w.sf == w.ef) continue;
+        APP(seg_line, sp, seg_cap, " %d %d %d %s", w.sf, w.ascr + (unscale ? w.scale : 0), raw(w.lscr), wordstr[w.wid]);
+    }
+    APP(seg_line, sp, seg_cap, " %d\n", rec->n_frames);
+#undef APP
+    return S3A_OK;
+}

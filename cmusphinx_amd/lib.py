@@ -186,6 +186,9 @@ _SIGS = {
     "s3a_uttdec_decode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
+    "s3a_uttdec_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]),
+    "s3a_hyp_format": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                   C.c_int32, C.c_int32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "s3a_uttdec_last_decode_ms": (C.c_double, [C.c_void_p]),
     "s3a_wltest_init": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "s3a_wltest_free": (None, [C.c_void_p]),
@@ -1203,4 +1206,70 @@ class WlTest:
     def __del__(self):
         if getattr(self, "h", None):
             self.L.s3a_wltest_free(self.h)
+            self.h = None
+
+
+HYP_MAXW = 250
+
+
+class HypWord(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("wid", "sf", "ef", "ascr", "lscr", "scale")]
+
+
+class HypRecord(C.Structure):
+    """s3a_hyp_record_t: one utterance's hypothesis, fixed size (the unit of the end-of-batch gather)"""
+    _fields_ = [("uttid", C.c_char * 96)] + \
+               [(k, C.c_int32) for k in ("utt_index", "n_words", "n_frames", "score", "total_scale", "n_entry", "status", "exit_id")] + \
+               [("word", HypWord * HYP_MAXW)]
+
+
+class UttResult(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("err", "n_entry", "n_frm", "n_frames")] + \
+               [(k, C.POINTER(C.c_int32)) for k in ("score", "pred", "lw0", "lw1", "wid", "sf", "ef", "ascr", "lscr", "type",
+                                                    "frame_start", "bestscore", "bestvh", "frame_stat")] + \
+               [(k, C.c_int32) for k in ("max_cand", "max_new", "n_tie_frames")]
+
+
+class UttDec:
+    """s3a_uttdec_t: whole utterances on the device, n_lanes at a time (the `decode` slot of srch_funcs_t)"""
+
+    def __init__(self, proto: "LexSearch", g: "MgauModel", cd2cisen, n_ci_sen, comsen: "ComSen", lm: "Lm3g", cfg, n_lanes,
+                 ds=1, cond_ds=0, ci_pbeam=1e-80, tighten_factor=0.5, max_cd=100000, max_frames=15000, vh_cap=0, cand_cap=0):
+        self.L = load()
+        self._keep = (proto, g, comsen, lm, cfg, np.ascontiguousarray(cd2cisen, np.int16))
+        self.h = self.L.s3a_uttdec_init(proto.h, g.h, _p(self._keep[5]), len(self._keep[5]), int(n_ci_sen), int(ds), int(cond_ds),
+                                        float(ci_pbeam), float(tighten_factor), int(max_cd), comsen.h, lm.h, C.byref(cfg),
+                                        int(n_lanes), int(max_frames), int(vh_cap), int(cand_cap))
+        if not self.h:
+            raise S3AError(_err(self.L))
+        self.n_lanes = int(n_lanes)
+
+    def decode(self, feats):
+        """feats: list of float32 [nfr, veclen] arrays (at most n_lanes)"""
+        feats = [np.ascontiguousarray(f, np.float32) for f in feats]
+        ptrs = (C.c_void_p * len(feats))(*[f.ctypes.data for f in feats])
+        nfr = np.array([len(f) for f in feats], np.int32)
+        check(self.L.s3a_uttdec_decode(self.h, len(feats), ptrs, _p(nfr), feats[0].shape[1]), self.L)
+        return float(self.L.s3a_uttdec_last_decode_ms(self.h))
+
+    def result(self, lane):
+        r = UttResult()
+        check(self.L.s3a_uttdec_result(self.h, lane, C.byref(r)), self.L)
+        n, nf = r.n_entry, r.n_frm
+        out = {k: np.ctypeslib.as_array(getattr(r, k), (n,)).copy() for k in
+               ("score", "pred", "lw0", "lw1", "wid", "sf", "ef", "ascr", "lscr", "type")}
+        for k in ("frame_start", "bestscore", "bestvh"):
+            out[k] = np.ctypeslib.as_array(getattr(r, k), (nf + 1,)).copy()
+        out["frame_stat"] = np.ctypeslib.as_array(r.frame_stat, (r.n_frames * 8,)).reshape(-1, 8).copy()
+        out.update(err=r.err, n_frm=nf, max_cand=r.max_cand, max_new=r.max_new, n_tie_frames=r.n_tie_frames)
+        return out
+
+    def hyp(self, lane, uttid="", utt_index=0):
+        rec = HypRecord()
+        check(self.L.s3a_uttdec_hyp(self.h, lane, uttid.encode(), int(utt_index), C.byref(rec)), self.L)
+        return rec
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_uttdec_free(self.h)
             self.h = None

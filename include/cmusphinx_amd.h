@@ -692,6 +692,30 @@ int32_t s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *f
                           const int32_t *n_frames, int32_t feat_stride);
 int32_t s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out);
 int32_t s3a_uttdec_n_lanes(const s3a_uttdec_t *ud);
+/*
+ * The hypothesis of a finished lane as a fixed-size record -- what one utterance contributes to the end-of-batch
+ * gather when the control file is sharded over GPUs ({uttid, words, sf/ef, ascr, lscr, score,
+ * n_frames}; one all-gather of these records, no per-frame collective).  s3a_uttdec_hyp = vithist_utt_end
+ * (vithist.c:766-860: the final </s> transition, the silence patch when the last frames have no exit) +
+ * vithist_backtrace (:1066-1100) on the lane's table; word[].scale = the frame normalisers over [sf, ef)
+ * (compute_scale, srch_output.c:52-60).  status: 0 ok, -1 decode error, -2 no word exit, -3 more than
+ * S3A_HYP_MAXW words.  s3a_hyp_format = match_write / matchseg_write (srch_output.c:74-161): the utterance's
+ * -hyp and -hypseg lines (wordstr / basewid / is_filler by dictionary word id; lw, wip = lm_t.lw / .wip for
+ * lm_rawscore, lm.c:2171-2178; unscale = -hypsegscore_unscale).
+ */
+#define S3A_HYP_MAXW 250
+typedef struct { int32_t wid, sf, ef, ascr, lscr, scale; } s3a_hyp_word_t;
+typedef struct {
+    char uttid[96];
+    int32_t utt_index, n_words, n_frames, score, total_scale, n_entry, status, exit_id;
+    s3a_hyp_word_t word[S3A_HYP_MAXW];
+} s3a_hyp_record_t;
+int32_t s3a_uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index,
+                       s3a_hyp_record_t *rec);
+int32_t s3a_hyp_format(const s3a_hyp_record_t *rec, const char *const *wordstr, const int32_t *basewid,
+                       const uint8_t *is_filler, int32_t startwid, int32_t finishwid, float lw, int32_t wip,
+                       int32_t unscale, char *match_line, size_t match_cap, char *seg_line, size_t seg_cap);
+
 /* The word level on its own (one lane, no lextrees): what closes a frame -- vithist_rescore for
  * every word exit, vithist_prune, srch_utt_word_trans, vithist_frame_windup -- on caller-supplied
  * exits; the parity tests drive it frame by frame next to the oracle.  cfg: dictionary / pruning

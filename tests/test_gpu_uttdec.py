@@ -1,0 +1,78 @@
+"""Whole utterances through the C ABI alone (MI355X): cepstra -> s3a_feat_1s_c_d_dd -> s3a_uttdec_decode ->
+s3a_uttdec_hyp -> s3a_hyp_format, against the unmodified reference's -hyp / -hypseg files.
+
+The decoder is rebuilt from a BUNDLE (cmusphinx_amd/bundle.py) that the sphinx3 side of the drop-in wrote once
+(S3A_EXPORT: the reference's own kb_init loads the models, the dictionary, the LM and builds the lextrees); from
+there on no reference code runs: features, scoring, search, word level, history table, final </s> transition,
+backtrace and output formatting are all libcmusphinx_amd's.  tidigits: the committed reference goldens.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cmusphinx_amd import bundle, s3io
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+D = os.path.join(GOLDEN, "tidigits_decode")
+AM = os.path.join(GOLDEN, "tidigits")
+TST = os.path.join(ROOT, "oracle", "_ref", "ref_s3amd_tst_decode")
+
+
+@pytest.fixture(scope="module")
+def tidigits_bundle(tmp_path_factory):
+    if not os.path.exists(TST):
+        pytest.fail(f"{TST} is missing on the GPU box (make -C oracle ref)")
+    out = str(tmp_path_factory.mktemp("bundle") / "tidigits.bundle")
+    args = [TST, "-dict", f"{D}/dictionary", "-fdict", f"{D}/fillerdict", "-hmm", AM, "-cepdir", f"{D}/cepstra",
+            "-agc", "none", "-varnorm", "no", "-cmn", "current", "-lw", "9.5",
+            "-ctl", f"{D}/tidigits.length.arb.regression", "-op_mode", "4", "-lm", f"{D}/tidigits.DMP"]
+    p = subprocess.run(args, env=dict(os.environ, S3A_UTT="1", S3A_EXPORT=out), stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=600)
+    assert p.returncode == 0 and os.path.getsize(out) > 1000
+    return out
+
+
+def ctl_entries():
+    for line in open(f"{D}/tidigits.length.arb.regression"):
+        f = line.split()
+        if f:
+            yield f[0], (f[3] if len(f) > 3 else os.path.basename(f[0]))
+
+
+@pytest.mark.parametrize("n_lanes", [1, 5])
+def test_tidigits_through_the_c_abi_alone(gpu_lib, tidigits_bundle, n_lanes):
+    dec = bundle.Decoder(tidigits_bundle, n_lanes)
+    utts = list(ctl_entries())
+    assert len(utts) == 31
+    match, seg = [], []
+    for k in range(0, len(utts), n_lanes):
+        chunk = utts[k:k + n_lanes]
+        feats = [gpu_lib.feat_1s_c_d_dd(s3io.read_mfc(f"{D}/cepstra/{u}.mfc"), cmn="current") for u, _ in chunk]
+        dec.decode(feats)
+        for z, (u, uid) in enumerate(chunk):
+            rec = dec.hyp(z, uid, k + z)
+            assert rec.status == 0 and rec.n_frames == len(feats[z])
+            m, s = dec.format(rec)
+            match.append(m); seg.append(s)
+    assert "".join(match) == open(f"{D}/ref_mode4_trigram.match").read()
+    assert "".join(seg) == open(f"{D}/ref_mode4_trigram.matchseg").read()
+
+
+def test_hypothesis_records_are_fixed_size_and_self_contained(gpu_lib, tidigits_bundle):
+    """what the end-of-batch gather ships: sizeof(s3a_hyp_record_t) bytes per utterance, formatted on another 'rank'"""
+    import ctypes as C
+    dec = bundle.Decoder(tidigits_bundle, 2)
+    utts = list(ctl_entries())[:2]
+    feats = [gpu_lib.feat_1s_c_d_dd(s3io.read_mfc(f"{D}/cepstra/{u}.mfc"), cmn="current") for u, _ in utts]
+    dec.decode(feats)
+    recs = [dec.hyp(z, uid, z) for z, (_, uid) in enumerate(utts)]
+    assert C.sizeof(gpu_lib.HypRecord) == 96 + 8 * 4 + 250 * 24
+    raw = b"".join(bytes(r) for r in recs)                    # "the wire"
+    back = [gpu_lib.HypRecord.from_buffer_copy(raw[i * C.sizeof(gpu_lib.HypRecord):]) for i in range(2)]
+    lines = [dec.format(r) for r in back]
+    ref = open(f"{D}/ref_mode4_trigram.match").read().splitlines(keepends=True)
+    assert [l[0] for l in lines] == ref[:2]
+    assert back[1].utt_index == 1 and back[0].word[0].sf == 0
