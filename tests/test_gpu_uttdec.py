@@ -50,7 +50,7 @@ def test_tidigits_through_the_c_abi_alone(gpu_lib, tidigits_bundle, n_lanes):
     match, seg = [], []
     for k in range(0, len(utts), n_lanes):
         chunk = utts[k:k + n_lanes]
-        feats = [gpu_lib.feat_1s_c_d_dd(s3io.read_mfc(f"{D}/cepstra/{u}.mfc"), cmn="current") for u, _ in chunk]
+        feats = [gpu_lib.feat_1s_c_d_dd(s3io.read_mfc(f"{D}/cepstra/{u}.mfc").reshape(-1, 13), cmn="current") for u, _ in chunk]
         dec.decode(feats)
         for z, (u, uid) in enumerate(chunk):
             rec = dec.hyp(z, uid, k + z)
@@ -66,7 +66,7 @@ def test_hypothesis_records_are_fixed_size_and_self_contained(gpu_lib, tidigits_
     import ctypes as C
     dec = bundle.Decoder(tidigits_bundle, 2)
     utts = list(ctl_entries())[:2]
-    feats = [gpu_lib.feat_1s_c_d_dd(s3io.read_mfc(f"{D}/cepstra/{u}.mfc"), cmn="current") for u, _ in utts]
+    feats = [gpu_lib.feat_1s_c_d_dd(s3io.read_mfc(f"{D}/cepstra/{u}.mfc").reshape(-1, 13), cmn="current") for u, _ in utts]
     dec.decode(feats)
     recs = [dec.hyp(z, uid, z) for z, (_, uid) in enumerate(utts)]
     assert C.sizeof(gpu_lib.HypRecord) == 96 + 8 * 4 + 250 * 24
