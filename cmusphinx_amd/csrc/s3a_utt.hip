@@ -396,6 +396,11 @@ struct s3a_uttdec_s {
     hipStream_t stream;
     int32_t n_utt;              /* lanes in use by the last decode */
     double last_decode_ms;
+    int32_t prof_every;         /* > 0: every prof_every-th frame is bracketed by events */
+    struct ProfEv { int32_t cls; hipEvent_t a, b; };
+    std::vector<ProfEv> prof_ev;
+    double prof_us[16];
+    int64_t prof_n[16];
 };
 
 static int32_t
@@ -504,7 +509,8 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     s3a_uttdec_t *ud = new s3a_uttdec_s();
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
-    ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0;
+    ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
+    memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
     ud->stream = d->stream;
     ud->exact = g->precision == S3A_GMM_EXACT;
@@ -654,7 +660,7 @@ fail:
 /* srch_TST_begin (srch_time_switch_tree.c:457-512) for one lane: the dummy <s> history entry, the
  * root entries with silence as left context into unigram tree 0 and filler tree n_lextree */
 static int32_t
-lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t feat_stride)
+lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t feat_stride, bool feat_on_device)
 {
     HostLane &hl = ud->lane[z];
     const s3a_wordlevel_cfg_t &c = ud->cfg;
@@ -662,25 +668,33 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     int32_t rc;
     if (nfr <= 0 || nfr > ud->max_frames) { s3a_set_error("s3a_uttdec_decode: %d frames (1..%d)", nfr, ud->max_frames); return S3A_EINVAL; }
     /* features, rows padded to the scorer's float4 stride */
-    const size_t need = (size_t)nfr * D4x4;
-    if (need > hl.feat_cap) {
-        if (hl.d_feat) (void)hipFree(hl.d_feat);
-        hl.d_feat = NULL; hl.feat_cap = 0;
-        if (hipMalloc((void **)&hl.d_feat, need * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: feature buffer"); return S3A_ENOMEM; }
-        hl.feat_cap = need;
+    const float *d_feat_use = feat;
+    if (!feat_on_device) {
+        const size_t need = (size_t)nfr * D4x4;
+        if (need > hl.feat_cap) {
+            if (hl.d_feat) (void)hipFree(hl.d_feat);
+            hl.d_feat = NULL; hl.feat_cap = 0;
+            if (hipMalloc((void **)&hl.d_feat, need * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: feature buffer"); return S3A_ENOMEM; }
+            hl.feat_cap = need;
+        }
+        if (need > hl.h_feat_cap) {
+            if (hl.h_feat) (void)hipHostFree(hl.h_feat);
+            hl.h_feat = NULL; hl.h_feat_cap = 0;
+            if (hipHostMalloc((void **)&hl.h_feat, need * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: pinned feature buffer"); return S3A_ENOMEM; }
+            hl.h_feat_cap = need;
+        }
+        for (int32_t t = 0; t < nfr; t++) {
+            float *row = hl.h_feat + (size_t)t * D4x4;
+            memcpy(row, feat + (size_t)t * feat_stride, sizeof(float) * ud->veclen);
+            for (int32_t k = ud->veclen; k < D4x4; k++) row[k] = 0.0f;
+        }
+        HIPCHK(hipMemcpyAsync(hl.d_feat, hl.h_feat, need * 4, hipMemcpyHostToDevice, ud->stream));
+        d_feat_use = hl.d_feat;
     }
-    if (need > hl.h_feat_cap) {
-        if (hl.h_feat) (void)hipHostFree(hl.h_feat);
-        hl.h_feat = NULL; hl.h_feat_cap = 0;
-        if (hipHostMalloc((void **)&hl.h_feat, need * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: pinned feature buffer"); return S3A_ENOMEM; }
-        hl.h_feat_cap = need;
+    else if (feat_stride != D4x4) {
+        s3a_set_error("s3a_uttdec_decode_dev: device features must have rows of %d floats (zero padded)", D4x4);
+        return S3A_EINVAL;
     }
-    for (int32_t t = 0; t < nfr; t++) {
-        float *row = hl.h_feat + (size_t)t * D4x4;
-        memcpy(row, feat + (size_t)t * feat_stride, sizeof(float) * ud->veclen);
-        for (int32_t k = ud->veclen; k < D4x4; k++) row[k] = 0.0f;
-    }
-    HIPCHK(hipMemcpyAsync(hl.d_feat, hl.h_feat, need * 4, hipMemcpyHostToDevice, ud->stream));
     hl.nfr = nfr;
     /* lextree + scorer state as after lextree_utt_end / at srch_TST_begin */
     if (hl.dirty) {
@@ -715,7 +729,7 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     }
     UCtx &x = *hl.h_ctx;
     memset(&x, 0, sizeof x);
-    x.feat = hl.d_feat;
+    x.feat = d_feat_use;
     x.active = 1; x.cf = 0; x.nfr = nfr; x.cur = 0; x.n_lextrans = 1; x.thresh = c.hmmbeam;
     if (hl.epoch < 1) hl.epoch = 1;
     x.scan_epoch = hl.epoch;      /* k_dec_scan's flags are never reset: the stamps keep growing */
@@ -736,38 +750,50 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     return S3A_OK;
 }
 
+/* kernel classes of a frame (s3a_uttdec_profile) */
+enum { UK_ENTER1, UK_ENTER2, UK_ENTER3, UK_GATED_CI, UK_GATED_CD, UK_HMM_EVAL, UK_HIST_COUNT, UK_HIST_SORT, UK_WEAK,
+       UK_RESOLVE, UK_SCAN, UK_EMIT, UK_WORD, UK_N };
+static const char *const uk_names[UK_N] = { "ku_enter1", "ku_enter2", "ku_enter3_mark", "ku_gated_ci", "ku_gated_cd",
+    "ku_hmm_eval", "ku_hist_count", "ku_hist_sort", "ku_weak", "ku_resolve", "ku_scan", "ku_emit", "ku_wordlevel" };
+
 static int32_t
-enqueue_frame(s3a_uttdec_t *ud, int32_t n)
+enqueue_frame(s3a_uttdec_t *ud, int32_t n, bool prof)
 {
     hipStream_t st = ud->stream;
     const ULane *LN = ud->d_lanes;
     const UShared &S = ud->S;
     const int32_t T = S.T;
-    hipLaunchKernelGGL(ku_enter1, dim3(ud->g_ent, 1, n), dim3(256), 0, st, LN, S);
-    hipLaunchKernelGGL(ku_enter2, dim3(WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
-    hipLaunchKernelGGL(ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S);
+    /* profiled frames bracket every launch with HIP events on the launch stream */
+#define UKL(cls, ...) do { hipEvent_t a_ = NULL, b_ = NULL;                                                   \
+        if (prof) { (void)hipEventCreate(&a_); (void)hipEventCreate(&b_); (void)hipEventRecord(a_, st); }        \
+        hipLaunchKernelGGL(__VA_ARGS__);                                                                         \
+        if (prof) { (void)hipEventRecord(b_, st); ud->prof_ev.push_back({ cls, a_, b_ }); } } while (0)
+    UKL(UK_ENTER1, ku_enter1, dim3(ud->g_ent, 1, n), dim3(256), 0, st, LN, S);
+    UKL(UK_ENTER2, ku_enter2, dim3(WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
+    UKL(UK_ENTER3, ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S);
     const int32_t g_ci = (S.n_ci_sen * S.CP + 255) / 256, g_cd = ((S.n_sen - S.n_ci_sen) * S.CP + 255) / 256;
     if (ud->exact) {
-        if (g_ci) hipLaunchKernelGGL((ku_gated<true, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
-        if (g_cd) hipLaunchKernelGGL((ku_gated<true, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
+        if (g_ci) UKL(UK_GATED_CI, (ku_gated<true, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
+        if (g_cd) UKL(UK_GATED_CD, (ku_gated<true, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
     }
     else {
-        if (g_ci) hipLaunchKernelGGL((ku_gated<false, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
-        if (g_cd) hipLaunchKernelGGL((ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
+        if (g_ci) UKL(UK_GATED_CI, (ku_gated<false, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
+        if (g_cd) UKL(UK_GATED_CD, (ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
     }
     if (ud->eval_block == 256)
-        hipLaunchKernelGGL(ku_hmm_eval<256>, dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S);
+        UKL(UK_HMM_EVAL, ku_hmm_eval<256>, dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S);
     else
-        hipLaunchKernelGGL(ku_hmm_eval<64>, dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S);
+        UKL(UK_HMM_EVAL, ku_hmm_eval<64>, dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S);
     if (ud->hist_possible) {
-        hipLaunchKernelGGL(ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, 256)), T, n), dim3(DBLOCK), 0, st, LN, S);
-        hipLaunchKernelGGL(ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
+        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, 64)), T, n), dim3(DBLOCK), 0, st, LN, S);
+        UKL(UK_HIST_SORT, ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
     }
-    if (ud->weak_possible) hipLaunchKernelGGL(ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
-    hipLaunchKernelGGL(ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S);
-    hipLaunchKernelGGL(ku_scan, dim3(T * ud->scan_nc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc);
-    hipLaunchKernelGGL(ku_emit, dim3(EMIT_BLOCKS, T, n), dim3(DBLOCK), 0, st, LN, S);
-    hipLaunchKernelGGL(ku_wordlevel, dim3(1, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par);
+    if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
+    UKL(UK_RESOLVE, ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S);
+    UKL(UK_SCAN, ku_scan, dim3(T * ud->scan_nc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc);
+    UKL(UK_EMIT, ku_emit, dim3(EMIT_BLOCKS, T, n), dim3(DBLOCK), 0, st, LN, S);
+    UKL(UK_WORD, ku_wordlevel, dim3(1, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par);
+#undef UKL
     HIPCHK(hipGetLastError());
     return S3A_OK;
 }
@@ -807,9 +833,9 @@ lane_fetch_table(s3a_uttdec_t *ud, int32_t z)
     return S3A_OK;
 }
 
-extern "C" int32_t
-s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const int32_t *n_frames,
-                  int32_t feat_stride)
+static int32_t
+uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const int32_t *n_frames,
+              int32_t feat_stride, bool feat_on_device)
 {
     if (!ud || n_utt <= 0 || n_utt > ud->n_lanes || !feat || !n_frames || feat_stride < ud->veclen) {
         s3a_set_error("s3a_uttdec_decode: bad arguments (%d utterances, %d lanes)", n_utt, ud ? ud->n_lanes : 0);
@@ -817,14 +843,14 @@ s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, con
     }
     int32_t rc, maxT = 0;
     for (int32_t z = 0; z < n_utt; z++) {
-        if ((rc = lane_begin(ud, z, feat[z], n_frames[z], feat_stride)) != S3A_OK) return rc;
+        if ((rc = lane_begin(ud, z, feat[z], n_frames[z], feat_stride, feat_on_device)) != S3A_OK) return rc;
         maxT = max(maxT, n_frames[z]);
     }
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, ud->stream));
     for (int32_t f = 0; f < maxT; f++)
-        if ((rc = enqueue_frame(ud, n_utt)) != S3A_OK) return rc;
+        if ((rc = enqueue_frame(ud, n_utt, ud->prof_every > 0 && f % ud->prof_every == 0)) != S3A_OK) return rc;
     HIPCHK(hipEventRecord(e1, ud->stream));
     for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_state(ud, z)) != S3A_OK) return rc;
     HIPCHK(hipStreamSynchronize(ud->stream));
@@ -834,6 +860,12 @@ s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, con
         ud->last_decode_ms = ms;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
+    for (auto &e : ud->prof_ev) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ud->prof_us[e.cls] += 1e3 * ms; ud->prof_n[e.cls]++; }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    ud->prof_ev.clear();
     for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_table(ud, z)) != S3A_OK) return rc;
     HIPCHK(hipStreamSynchronize(ud->stream));
     ud->n_utt = n_utt;
@@ -850,6 +882,20 @@ s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, con
         }
     }
     return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const int32_t *n_frames, int32_t feat_stride)
+{
+    return uttdec_decode(ud, n_utt, feat, n_frames, feat_stride, false);
+}
+
+/* the same with the features already in HBM: feat_dev[z] = n_frames[z] rows of feat_stride floats on the device,
+ * feat_stride = the scorer's row length (feature length rounded up to a multiple of 4, padding zero) */
+extern "C" int32_t
+s3a_uttdec_decode_dev(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev, const int32_t *n_frames, int32_t feat_stride)
+{
+    return uttdec_decode(ud, n_utt, feat_dev, n_frames, feat_stride, true);
 }
 
 extern "C" int32_t
@@ -1145,5 +1191,42 @@ s3a_hyp_format(const s3a_hyp_record_t *rec, const char *const *wordstr, const in
     }
     APP(seg_line, sp, seg_cap, " %d\n", rec->n_frames);
 #undef APP
+    return S3A_OK;
+}
+
+/* per-kernel timing: from now on every `every`-th frame of a decode is bracketed, launch by launch, by HIP events
+ * on the launch stream (0 = off; totals are reset).  s3a_uttdec_profile returns, per kernel class, the summed
+ * microseconds and the number of timed launches since; *names (optional) = the class names. */
+extern "C" int32_t
+s3a_uttdec_set_profile(s3a_uttdec_t *ud, int32_t every)
+{
+    if (!ud || every < 0) return S3A_EINVAL;
+    ud->prof_every = every;
+    memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_uttdec_profile(const s3a_uttdec_t *ud, double *us, int64_t *launches, const char **names, int32_t max_classes)
+{
+    if (!ud || !us || !launches) return S3A_EINVAL;
+    const int32_t n = max_classes < UK_N ? max_classes : UK_N;
+    for (int32_t k = 0; k < n; k++) { us[k] = ud->prof_us[k]; launches[k] = ud->prof_n[k]; if (names) names[k] = uk_names[k]; }
+    return n;
+}
+
+/* what one launch of the scoring kernels moves, for roofline arithmetic: Gaussians of the model (padded lanes
+ * excluded), feature dimension, senones, CI senones */
+extern "C" int32_t
+s3a_uttdec_shape(const s3a_uttdec_t *ud, int32_t *n_sen, int32_t *n_ci_sen, int32_t *n_comp_padded, int32_t *veclen,
+                 int32_t *n_node, int32_t *n_tree)
+{
+    if (!ud) return S3A_EINVAL;
+    if (n_sen) *n_sen = ud->S.n_sen;
+    if (n_ci_sen) *n_ci_sen = ud->S.n_ci_sen;
+    if (n_comp_padded) *n_comp_padded = ud->S.CP;
+    if (veclen) *veclen = ud->veclen;
+    if (n_node) *n_node = ud->S.N;
+    if (n_tree) *n_tree = ud->S.T;
     return S3A_OK;
 }

@@ -184,8 +184,12 @@ _SIGS = {
                                      C.c_int32, C.c_int32, C.c_int32]),
     "s3a_uttdec_free": (None, [C.c_void_p]),
     "s3a_uttdec_decode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_uttdec_decode_dev": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
+    "s3a_uttdec_set_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "s3a_uttdec_profile": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_uttdec_shape": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_int32)] * 6),
     "s3a_uttdec_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]),
     "s3a_hyp_format": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                    C.c_int32, C.c_int32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
@@ -1252,6 +1256,13 @@ class UttDec:
         check(self.L.s3a_uttdec_decode(self.h, len(feats), ptrs, _p(nfr), feats[0].shape[1]), self.L)
         return float(self.L.s3a_uttdec_last_decode_ms(self.h))
 
+    def decode_dev(self, bufs, nfr, stride):
+        """bufs: DevBuf objects holding [nfr, stride] float32 (stride = 4 * ceil(veclen / 4), zero padded)"""
+        ptrs = (C.c_void_p * len(bufs))(*[b.ptr for b in bufs])
+        n = np.ascontiguousarray(nfr, np.int32)
+        check(self.L.s3a_uttdec_decode_dev(self.h, len(bufs), ptrs, _p(n), int(stride)), self.L)
+        return float(self.L.s3a_uttdec_last_decode_ms(self.h))
+
     def result(self, lane):
         r = UttResult()
         check(self.L.s3a_uttdec_result(self.h, lane, C.byref(r)), self.L)
@@ -1263,6 +1274,15 @@ class UttDec:
         out["frame_stat"] = np.ctypeslib.as_array(r.frame_stat, (r.n_frames * 8,)).reshape(-1, 8).copy()
         out.update(err=r.err, n_frm=nf, max_cand=r.max_cand, max_new=r.max_new, n_tie_frames=r.n_tie_frames)
         return out
+
+    def set_profile(self, every):
+        check(self.L.s3a_uttdec_set_profile(self.h, int(every)), self.L)
+
+    def profile(self):
+        """{kernel class: (summed microseconds, timed launches)} since set_profile"""
+        us = (C.c_double * 16)(); n = (C.c_int64 * 16)(); names = (C.c_char_p * 16)()
+        k = self.L.s3a_uttdec_profile(self.h, us, n, names, 16)
+        return {names[i].decode(): (us[i], n[i]) for i in range(k) if n[i]}
 
     def hyp(self, lane, uttid="", utt_index=0):
         rec = HypRecord()

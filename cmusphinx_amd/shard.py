@@ -5,16 +5,24 @@ The reference has no distributed mode; its only batch-partitioning device is
 libcommon/corpus.c:538 ctl_process).  Utterances are independent (all
 per-utterance state is reset in srch_utt_begin, srch.c:453-479), so the path
 shards embarrassingly: rank r of W decodes its slice of the control list with a
-replicated model and NO per-frame collective; one all_gather of fixed-size
-result records closes the batch, and rank 0 re-assembles them in control-file
-order so the output diffs cleanly against a single-process run.
+replicated model and NO per-frame collective; ONE all_gather of fixed-size
+hypothesis records (s3a_hyp_record_t, include/cmusphinx_amd.h: uttid, words with
+sf/ef/ascr/lscr/scale, score, n_frames -- what -hyp and -hypseg are written from)
+closes the batch, and rank 0 writes both files in control-file order so they diff
+cleanly against a single-process run.  The collective is
+torch.distributed's all_gather: backend "nccl" is RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests; the records themselves are packed, read and formatted by
+the C ABI (s3a_uttdec_hyp / s3a_hyp_format).
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
-REC_WORDS = 64          # hypothesis words kept per record
-REC_LEN = 4 + REC_WORDS  # [utt_index, n_frames, total_score, n_words, word ids...]
+from . import lib
+
+REC_BYTES = C.sizeof(lib.HypRecord)
 
 
 def shard_contiguous(n_utt: int, rank: int, world: int):
@@ -38,45 +46,50 @@ def shard_by_frames(n_frames, rank: int, world: int):
     return sorted(mine)
 
 
-def pack_record(utt_index: int, n_frames: int, total_score: int, word_ids) -> np.ndarray:
-    rec = np.full(REC_LEN, -1, np.int64)
-    w = list(word_ids)[:REC_WORDS]
-    rec[0], rec[1], rec[2], rec[3] = utt_index, n_frames, total_score, len(w)
-    rec[4:4 + len(w)] = w
-    return rec
-
-
-def unpack_record(rec):
-    n = int(rec[3])
-    return dict(utt=int(rec[0]), n_frames=int(rec[1]), score=int(rec[2]),
-                words=[int(v) for v in rec[4:4 + n]])
-
-
 def gather_records(local_records, n_utt_total: int, dist=None, device="cpu"):
-    """all_gather fixed-size records; returns the list in utterance order (every rank).
+    """ONE all_gather of the ranks' hypothesis records; returns them in utterance order (every rank).
 
-    `dist` is torch.distributed (backend nccl == RCCL on the GPU box, gloo in the
-    CPU tests); None means single process.  Ranks may hold different counts:
-    each pads to the maximum, padding rows carry utt = -1.
+    local_records: list of lib.HypRecord with utt_index set.  Ranks may hold different counts: each pads to
+    the maximum with records whose utt_index is -1 (one extra all_gather of a single int64 finds the maximum).
+    Raises when an utterance is missing or duplicated, or a record reports a word-list overflow.
     """
-    local = np.stack(local_records) if len(local_records) else np.zeros((0, REC_LEN), np.int64)
+    n_local = len(local_records)
+    local = np.frombuffer(b"".join(bytes(r) for r in local_records), np.uint8).reshape(n_local, REC_BYTES) \
+        if n_local else np.zeros((0, REC_BYTES), np.uint8)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         allrec = local
     else:
         import torch
         world = dist.get_world_size()
-        cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+        cnt = torch.tensor([n_local], dtype=torch.int64, device=device)
         cnts = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(cnts, cnt)
         m = max(int(c.item()) for c in cnts)
-        buf = torch.full((max(m, 1), REC_LEN), -1, dtype=torch.int64, device=device)
-        if local.shape[0]:
-            buf[:local.shape[0]] = torch.from_numpy(local).to(device)
+        pad = lib.HypRecord()
+        pad.utt_index = -1
+        buf = torch.from_numpy(np.frombuffer(bytes(pad) * max(m, 1), np.uint8).reshape(max(m, 1), REC_BYTES).copy()).to(device)
+        if n_local:
+            buf[:n_local] = torch.from_numpy(local.copy()).to(device)
         out = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(out, buf)
+        dist.all_gather(out, buf)                       # the batch's one exchange (RCCL over xGMI on the GPU box)
         allrec = torch.cat(out).cpu().numpy()
-    allrec = allrec[allrec[:, 0] >= 0]
-    got = sorted((unpack_record(r) for r in allrec), key=lambda d: d["utt"])
-    if [d["utt"] for d in got] != list(range(n_utt_total)):
+    recs = [lib.HypRecord.from_buffer_copy(allrec[i].tobytes()) for i in range(allrec.shape[0])]
+    recs = sorted((r for r in recs if r.utt_index >= 0), key=lambda r: r.utt_index)
+    if [r.utt_index for r in recs] != list(range(n_utt_total)):
         raise RuntimeError("gather: utterances missing or duplicated across ranks")
-    return got
+    over = [r.utt_index for r in recs if r.status == -3]
+    if over:
+        raise RuntimeError(f"gather: hypotheses of utterances {over} exceed S3A_HYP_MAXW words")
+    return recs
+
+
+def write_outputs(recs, fmt, hyp_path=None, hypseg_path=None):
+    """-hyp / -hypseg files from gathered records (fmt: record -> (match line, matchseg line), e.g. bundle.Decoder.format)"""
+    lines = [fmt(r) for r in recs]
+    if hyp_path:
+        with open(hyp_path, "w") as f:
+            f.writelines(l[0] for l in lines)
+    if hypseg_path:
+        with open(hypseg_path, "w") as f:
+            f.writelines(l[1] for l in lines)
+    return lines

@@ -690,6 +690,9 @@ s3a_uttdec_t *s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g,
 void s3a_uttdec_free(s3a_uttdec_t *ud);
 int32_t s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat,
                           const int32_t *n_frames, int32_t feat_stride);
+/* the same with the features already resident in HBM: rows of feat_stride = 4 * ceil(veclen / 4) floats, zero padded */
+int32_t s3a_uttdec_decode_dev(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev,
+                              const int32_t *n_frames, int32_t feat_stride);
 int32_t s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out);
 int32_t s3a_uttdec_n_lanes(const s3a_uttdec_t *ud);
 /*
@@ -734,6 +737,14 @@ int32_t s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int
                          int32_t *n_tie_frames);
 
 double s3a_uttdec_last_decode_ms(const s3a_uttdec_t *ud);    /* HIP-event time of the last decode's frames */
+/* per-kernel timing for roofline arithmetic: every `every`-th frame of the following decodes is bracketed,
+ * launch by launch, by HIP events on the launch stream (0 = off, resets the totals); s3a_uttdec_profile
+ * returns per kernel class the summed microseconds / launches (and the class names); returns #classes. */
+int32_t s3a_uttdec_set_profile(s3a_uttdec_t *ud, int32_t every);
+int32_t s3a_uttdec_profile(const s3a_uttdec_t *ud, double *us, int64_t *launches, const char **names,
+                           int32_t max_classes);
+int32_t s3a_uttdec_shape(const s3a_uttdec_t *ud, int32_t *n_sen, int32_t *n_ci_sen, int32_t *n_comp_padded,
+                         int32_t *veclen, int32_t *n_node, int32_t *n_tree);
 
 /* ===================================================================== */
 /* measurement hooks used by bench.py (HIP events on the launch stream)   */
