@@ -110,7 +110,7 @@ def cpu_baseline(task, d, n_procs):
            "active_hmm_per_frame": hmm,
            "sample": f"unmodified oracle/_ref/sphinx3_decode (gcc -O2), full mode-4 decode of the same task files: 2 utterances "
                      f"({frames} frames) in one process for single_core (stat.c SUMMARY tot xCPU); value = {n_procs} processes "
-                     f"at once over disjoint -ctloffset/-ctlcount shards, 1 utterance (1000 frames) each, summed 100/xClk; "
+                     f"at once over disjoint -ctloffset/-ctlcount shards, 1 utterance (~10 s) each, summed 100/xClk; "
                      f"model loading excluded (SUMMARY counts decoding only)"}
     return out, (open(hyp).read(), open(seg).read())
 
@@ -216,13 +216,15 @@ def main():
         dist.barrier()
     targs = synth_task.decoder_args(d)
     utts = [l.split()[0] for l in open(os.path.join(d, "ctl")) if l.strip()]
+    hfeat = [s3io.read_mfc(os.path.join(d, "feat", u + ".mfc")) for u in utts]
     t_load = time.perf_counter()
-    dec = bundle.Decoder(bpath, NL, precision=lib.GMM_FAST if args.fast else lib.GMM_EXACT, max_frames=max(T, 16))
+    dec = bundle.Decoder(bpath, NL, precision=lib.GMM_FAST if args.fast else lib.GMM_EXACT,
+                         max_frames=max(len(f) for f in hfeat) // 39 + 8)
     t_load = time.perf_counter() - t_load
     D4x4 = 4 * ((dec.veclen + 3) // 4)
     fdev, nfr = [], []
-    for u in utts:
-        f = s3io.read_mfc(os.path.join(d, "feat", u + ".mfc")).reshape(-1, dec.veclen)
+    for f in hfeat:
+        f = f.reshape(-1, dec.veclen)
         pad = np.zeros((len(f), D4x4), np.float32)
         pad[:, :dec.veclen] = f
         fdev.append(lib.DevBuf(pad.nbytes).upload(pad))
