@@ -138,6 +138,173 @@ ku_gated(const ULane *__restrict__ lanes, UShared S)
         d_gated_frame<EXACT, 0>(KU_GATED_ARGS, blockIdx.x);
 }
 
+/*
+ * The gated CD senones of ALL lanes in one pass over the model (approx_cont_mgau_frame_eval x lanes): the
+ * model-stationary scoring kernel (k_score_frames, s3a_device.hip) with the lanes' frames in the place of an
+ * utterance's frames.  A lane of the wave keeps ONE Gaussian in registers and evaluates it for a group of UG_FB
+ * decoder lanes (their feature vectors broadcast from LDS), the values are transposed through a per-wave LDS tile,
+ * and wave lane (senone, c) then runs the gate and the ordered log-add of decoder lane c of the group for its
+ * senone.  The model is read once per launch-row instead of once per decoder lane (per-lane launches moved
+ * lanes x 15.7 MB per frame: 32 lanes = 0.5 GB), with coalesced 16-byte loads; every Gaussian is computed and the
+ * gate only selects (s3a_gated.h).  Maxima / counters leave the workgroup as plain stores into the decoder lane's
+ * gpart[] column (merged by d_dec_hmm_eval / d_dec_pack_frame): no atomics.  Same results as ku_gated, bit for bit.
+ */
+#define UG_FB 8
+#define UG_MAX 32
+struct UgDec {
+    uint8_t *sen_act;
+    int32_t *scr, *gpart, *bstidx, *bstscr, *updatetime;
+    int32_t frame, is_skip, thresh, active;
+};
+
+template <bool EXACT>
+__global__ void __launch_bounds__(256)
+ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes)
+{
+    typedef typename Acc<EXACT>::T acc_t;
+    __shared__ UgDec dec[UG_MAX];
+    __shared__ int32_t red[4][UG_MAX][3];
+    __shared__ int32_t tr_s[4][UG_FB * 65];
+    __shared__ float4 xs4[UG_MAX * D4MAIN];
+    const int32_t zb = blockIdx.z * UG_MAX, n = min(UG_MAX, n_lanes - zb);
+    const int32_t CP = S.CP, Gpad = S.Gpad;
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t g = S.n_ci_sen * CP + blockIdx.x * 256 + tid;
+    const int32_t sen = g / CP, c = g - sen * CP, sl = lane / CP;
+    const bool valid = sen < S.n_sen;
+    float4 M[D4MAIN], P[D4MAIN];
+    float lrd_g = 0.0f;
+    int32_t mixw = 0, nc = 0, ci_id = 0;
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < D4MAIN; k++) { M[k] = S.mean4[(size_t)k * Gpad + g]; P[k] = S.prec4[(size_t)k * Gpad + g]; }
+        lrd_g = S.lrd[g];
+        mixw = S.mixw[g];
+        nc = (int32_t)S.ncomp[sen];
+        ci_id = S.cd2cisen[sen];
+    }
+    else {
+#pragma unroll
+        for (int k = 0; k < D4MAIN; k++) M[k] = P[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (tid < UG_MAX) {
+        UgDec d;
+        memset(&d, 0, sizeof d);
+        if (tid < n) {
+            const ULane &Lz = lanes[zb + tid];
+            const UCtx *cx = Lz.ctx;
+            d.active = cx->active;
+            if (d.active) {
+                const int32_t cf = cx->cf;
+                d.sen_act = Lz.sen_act; d.scr = Lz.scr; d.gpart = Lz.gpart; d.bstidx = Lz.bstidx; d.bstscr = Lz.bstscr;
+                d.updatetime = Lz.updatetime; d.frame = cf; d.is_skip = (cf % S.ds_ratio == 0) ? 0 : 1;
+                d.thresh = add32(Lz.misc[5], d.is_skip ? S.ci_pbeam_tight : S.ci_pbeam);
+            }
+        }
+        dec[tid] = d;
+    }
+    for (int32_t i = tid; i < 4 * UG_MAX; i += 256) {
+        red[i / UG_MAX][i % UG_MAX][0] = INT_MIN; red[i / UG_MAX][i % UG_MAX][1] = 0; red[i / UG_MAX][i % UG_MAX][2] = 0;
+    }
+    __syncthreads();
+    for (int32_t i = tid; i < UG_MAX * D4MAIN * 4; i += 256) {
+        const int32_t zz = i / (D4MAIN * 4), k = i - zz * (D4MAIN * 4);
+        float v = 0.0f;
+        if (zz < n && dec[zz].active) { const UCtx *cx = lanes[zb + zz].ctx; v = cx->feat[(size_t)cx->cf * (D4MAIN * 4) + k]; }
+        ((float *)xs4)[i] = v;
+    }
+    __syncthreads();
+    LogAdd la;
+    la.tab = S.tab16; la.size = S.tab_size; la.zero = S.lm_zero;
+    int32_t *tr = tr_s[wave];
+    const int32_t n_groups = (n + UG_FB - 1) / UG_FB;
+    for (int32_t grp = blockIdx.y; grp < n_groups; grp += gridDim.y) {
+        const int32_t z0 = grp * UG_FB, nd = min(UG_FB, n - z0);
+        bool mine = valid && c < nd;
+        int32_t act = 0, ut = 0, ci_scr = 0, bi = S3A_NO_BSTIDX;
+        UgDec d;
+        if (mine) {
+            d = dec[z0 + c];
+            mine = d.active != 0;
+        }
+        if (mine) {
+            act = d.sen_act[sen]; ut = d.updatetime[sen];
+            ci_scr = d.scr[ci_id];
+            bi = d.bstidx[sen];
+        }
+        acc_t a[UG_FB];
+#pragma unroll
+        for (int j = 0; j < UG_FB; j++) a[j] = (acc_t)lrd_g;
+#pragma unroll
+        for (int k = 0; k < D4MAIN; k++) {
+#pragma unroll
+            for (int j = 0; j < UG_FB; j++) {
+                if (j < nd) {
+                    const float4 x = xs4[(z0 + j) * D4MAIN + k];
+                    a[j] = Acc<EXACT>::step(a[j], x.x, M[k].x, P[k].x);
+                    a[j] = Acc<EXACT>::step(a[j], x.y, M[k].y, P[k].y);
+                    a[j] = Acc<EXACT>::step(a[j], x.z, M[k].z, P[k].z);
+                    a[j] = Acc<EXACT>::step(a[j], x.w, M[k].w, P[k].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UG_FB; j++)
+            if (j < nd) tr[j * 65 + lane] = gau_to_int((double)a[j], S.f, S.distfloor, mixw);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int32_t mode = 0;
+        if (mine && act) {
+            if (ci_scr >= d.thresh) mode = 1;
+            else mode = (bi == S3A_NO_BSTIDX || ut != d.frame - 1) ? 3 : 2;
+        }
+        int32_t score = S3A_LOGPROB_ZERO, bs = S3A_LOGPROB_ZERO, bidx = S3A_NO_BSTIDX;
+        const int32_t *row = tr + c * 65 + sl * CP;
+        if (mode == 1) {
+            for (int32_t cc = 0; cc < nc; cc++) {
+                const int32_t v = row[cc];
+                score = la(score, v);
+                if (v > bs) { bs = v; bidx = cc; }
+            }
+        }
+        else if (mode == 2) {
+            const int32_t v = row[bi];
+            score = la(score, v);
+            if (v > bs) { bs = v; bidx = bi; }
+        }
+        if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
+        if (mode == 3) score = ci_scr;
+        int32_t rbest = INT_MIN, rns = 0, rng = 0;
+        if (mine) {
+            d.sen_act[sen] = 0;
+            if (mode != 0) {
+                d.scr[sen] = score;
+                rbest = score;
+                if (mode == 1) { d.bstidx[sen] = bidx; d.bstscr[sen] = bs; d.updatetime[sen] = d.frame; rns = 1; rng = nc; }
+                else if (mode == 2) {
+                    if (d.is_skip) { d.bstidx[sen] = bidx; d.bstscr[sen] = bs; d.updatetime[sen] = d.frame; }
+                    rng = 1;
+                }
+            }
+        }
+        for (int32_t o = CP; o < 64; o <<= 1) {
+            rbest = max(rbest, __shfl_xor(rbest, o, 64));
+            rns += __shfl_xor(rns, o, 64);
+            rng += __shfl_xor(rng, o, 64);
+        }
+        if (sl == 0 && c < nd) { red[wave][z0 + c][0] = rbest; red[wave][z0 + c][1] = rns; red[wave][z0 + c][2] = rng; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (tid < n && dec[tid].active && (tid / UG_FB) % (int32_t)gridDim.y == (int32_t)blockIdx.y) {
+        int32_t *gp = dec[tid].gpart;
+        gp[blockIdx.x] = max(max(red[0][tid][0], red[1][tid][0]), max(red[2][tid][0], red[3][tid][0]));
+        gp[S.gp_n + blockIdx.x] = red[0][tid][1] + red[1][tid][1] + red[2][tid][1] + red[3][tid][1];
+        gp[2 * S.gp_n + blockIdx.x] = red[0][tid][2] + red[1][tid][2] + red[2][tid][2] + red[3][tid][2];
+    }
+}
+
 /* ---- lextree_hmm_eval ---- */
 template <int EB>
 __global__ void __launch_bounds__(EB)
@@ -772,13 +939,21 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, bool prof)
     UKL(UK_ENTER2, ku_enter2, dim3(WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
     UKL(UK_ENTER3, ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S);
     const int32_t g_ci = (S.n_ci_sen * S.CP + 255) / 256, g_cd = ((S.n_sen - S.n_ci_sen) * S.CP + 255) / 256;
+    /* from UG_FB lanes on the CD senones of all lanes are ONE pass over the model (39/40-dimensional features,
+     * >= UG_FB Gaussian slots per senone); (S3A_UTT_NO_MULTI: the per-lane kernel whatever the lane count -- tests) */
+    const bool multi = n >= UG_FB && S.D4 == D4MAIN && S.CP >= UG_FB && S.CP <= 64 && g_cd > 0 && S.gp_n == g_cd
+        && getenv("S3A_UTT_NO_MULTI") == NULL;
+    const int32_t gz = (n + UG_MAX - 1) / UG_MAX, groups = (min(n, UG_MAX) + UG_FB - 1) / UG_FB;
+    const dim3 gm(g_cd, max(1, min(groups, 2 * ud->g->dev->n_cu / max(1, g_cd * gz))), gz);
     if (ud->exact) {
         if (g_ci) UKL(UK_GATED_CI, (ku_gated<true, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
-        if (g_cd) UKL(UK_GATED_CD, (ku_gated<true, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
+        if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<true>), gm, dim3(256), 0, st, LN, S, n);
+        else if (g_cd) UKL(UK_GATED_CD, (ku_gated<true, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
     }
     else {
         if (g_ci) UKL(UK_GATED_CI, (ku_gated<false, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
-        if (g_cd) UKL(UK_GATED_CD, (ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
+        if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<false>), gm, dim3(256), 0, st, LN, S, n);
+        else if (g_cd) UKL(UK_GATED_CD, (ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
     }
     if (ud->eval_block == 256)
         UKL(UK_HMM_EVAL, ku_hmm_eval<256>, dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S);

@@ -40,6 +40,7 @@
 #define WL_MAXCALL 96       /* lextree_enter calls per frame: #CI phones + 1 */
 #define WL_MAXT 16          /* lextrees per decoder (2 x -Nlextree) */
 #define WL_HEAP_LDS 1536    /* frames with at most this many new entries replay the heap in LDS */
+#define WL_LDS_EX 1024      /* frames with at most this many word exits keep them (and their candidate offsets) in LDS */
 
 /* error bits (UCtx.err / s3a_utt_result_t.err) */
 #define WL_E_OPEN_EXIT 1    /* out.history == -1 at a word exit (LEXTREE_OPERATION_FAILURE / E_FATAL vithist.c:505) */
@@ -298,11 +299,13 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
     __shared__ unsigned long long s_ci[256];
     __shared__ unsigned long long s_u64[2];
     __shared__ int32_t s_heap[6 * WL_HEAP_LDS];
+    __shared__ int32_t s_ex[3 * WL_LDS_EX], s_off[WL_LDS_EX + 1];    /* the usual frame: exits + candidate offsets in LDS */
     const int32_t tid = threadIdx.x;
     const int32_t T = par.T, hdr = 6 * T + 16, cf = ctx->cf;
     const int32_t fs = L.st[0];                 /* == frame_start[cf] */
     const int32_t *fstart = L.frame_start;
     const int32_t *ex = pack + hdr;
+    int32_t *off = L.ex_off;
 
     /* ---- P1: the exits, their candidate counts ---- */
     if (tid == 0) {
@@ -322,15 +325,21 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         if (tid == 0) { ctx->err |= s_i[0]; ctx->active = 0; }
         return;
     }
+    if (nx <= WL_LDS_EX) {
+        for (int32_t i = tid; i < 3 * nx; i += WL_THREADS) s_ex[i] = ex[i];
+        __syncthreads();
+        ex = s_ex;
+        off = s_off;
+    }
     for (int32_t e = tid; e < nx; e += WL_THREADS) {
         const int32_t w = ex[3 * e], h = ex[3 * e + 2];
         int32_t c = 1;
         if (!dict.is_filler[w] && h != 0) { const int32_t f = L.ef[h]; c = fstart[f + 1] - fstart[f]; }
-        L.ex_off[e] = c;
+        off[e] = c;
     }
-    const int32_t n_cand = wl_scan<false>(L.ex_off, L.ex_off, nx, 0);
+    const int32_t n_cand = wl_scan<false>(off, off, nx, 0);
     if (tid == 0) {
-        L.ex_off[nx] = n_cand;
+        off[nx] = n_cand;
         if (n_cand > L.cand_cap || 2 * (long long)n_cand > (long long)L.hmask + 1) ctx->err |= WL_E_CAND;
         if (n_cand > ctx->max_cand) ctx->max_cand = n_cand;
         s_i[4] = 0;
@@ -344,7 +353,7 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
     /* ---- P2: every candidate's path score (a thread per candidate) ---- */
     for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
         int32_t lo = 0, hi = nx;                /* the exit of candidate c: last e with ex_off[e] <= c */
-        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (L.ex_off[mid] <= c) lo = mid; else hi = mid; }
+        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (off[mid] <= c) lo = mid; else hi = mid; }
         const int32_t e = lo, w = ex[3 * e], scr = ex[3 * e + 1], h = ex[3 * e + 2];
         L.cand_e[c] = e;
         int32_t sc;
@@ -353,7 +362,7 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
             const int32_t lwid = dict.lwid[w];
             if (lwid < 0) { s_i[4] = 1; sc = INT_MIN; }
             else {
-                const int32_t i = (h == 0 ? 0 : fstart[L.ef[h]]) + (c - L.ex_off[e]);
+                const int32_t i = (h == 0 ? 0 : fstart[L.ef[h]]) + (c - off[e]);
                 sc = add32(add32(L.score[i], add32(scr, -L.score[h])), wl_tg_score_ctx(lm, L, i, L.lw0[i], lwid, w));
             }
         }
@@ -372,7 +381,7 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         if (filler || add32(sc, -par.wbeam) >= L.cand_pref[c]) {
             unsigned long long key;
             if (filler) key = wl_key(L.lw0[h], L.lw1[h]);
-            else key = wl_key(dict.lwid[w], L.lw0[(h == 0 ? 0 : fstart[L.ef[h]]) + (c - L.ex_off[e])]);
+            else key = wl_key(dict.lwid[w], L.lw0[(h == 0 ? 0 : fstart[L.ef[h]]) + (c - off[e])]);
             uint32_t hh = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)L.hmask;
             for (;;) {
                 const unsigned long long old = atomicCAS(&L.hkey[hh], 0ull, key);
@@ -422,7 +431,7 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         sg_wid[k] = w; sg_sf[k] = L.ef[h] + 1; sg_ascr[k] = ascr; sg_score[k] = sc; sg_type[k] = ty; sg_slot[k] = slot;
         if (dict.is_filler[w]) { sg_lscr[k] = dict.fillpen[w]; sg_pred[k] = h; sg_lw0[k] = L.lw0[h]; sg_lw1[k] = L.lw1[h]; }
         else {
-            const int32_t i = (h == 0 ? 0 : fstart[L.ef[h]]) + (c - L.ex_off[e]);
+            const int32_t i = (h == 0 ? 0 : fstart[L.ef[h]]) + (c - off[e]);
             sg_lscr[k] = add32(sc, -add32(L.score[i], ascr)); sg_pred[k] = i; sg_lw0[k] = dict.lwid[w]; sg_lw1[k] = L.lw0[i];
         }
     }
