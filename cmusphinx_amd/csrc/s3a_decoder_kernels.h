@@ -791,18 +791,19 @@ d_dec_pack_frame(int32_t N, int32_t T, FrameBeams bm, const int32_t *__restrict_
     __syncthreads();
 }
 
+/* (wave_id of n_waves waves sweep tree t's list: the kernels map their workgroups onto that) */
 __device__ __forceinline__ void
-d_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
-           const int32_t *__restrict__ nact, const int32_t *__restrict__ child_off,
-           const int32_t *__restrict__ child, int32_t *turn, int32_t *selfemit,
-           const int32_t *__restrict__ base, int32_t *nxt, const int32_t *nnxt, int32_t *pos, int32_t *posf,
-        const int32_t BX, const int32_t BY)
+d_dec_emit_w(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
+             const int32_t *__restrict__ nact, const int32_t *__restrict__ child_off,
+             const int32_t *__restrict__ child, int32_t *turn, int32_t *selfemit,
+             const int32_t *__restrict__ base, int32_t *nxt, const int32_t *nnxt, int32_t *pos, int32_t *posf,
+        const int32_t t, const int32_t wave_id, const int32_t n_waves)
 {
-    const int32_t t = BY, b = node_base[t], na = nact[t], nf = cf + 1, total = nnxt[t];
+    const int32_t b = node_base[t], na = nact[t], nf = cf + 1, total = nnxt[t];
     const int32_t lane = threadIdx.x & 63;
     /* each wave sweeps 64 list positions at a time: a lane per position finds the (few) turns that
      * attributed children, then the whole wave walks those parents' child lists */
-    for (int32_t i0 = (BX * EMIT_WAVES + (threadIdx.x >> 6)) * 64; i0 < na; i0 += EMIT_BLOCKS * EMIT_WAVES * 64) {
+    for (int32_t i0 = wave_id * 64; i0 < na; i0 += n_waves * 64) {
         const int32_t i = i0 + lane;
         int32_t lo = 0, hi = 0;
         if (i < na) {
@@ -860,6 +861,17 @@ d_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__r
             }
         }
     }
+}
+
+__device__ __forceinline__ void
+d_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
+           const int32_t *__restrict__ nact, const int32_t *__restrict__ child_off,
+           const int32_t *__restrict__ child, int32_t *turn, int32_t *selfemit,
+           const int32_t *__restrict__ base, int32_t *nxt, const int32_t *nnxt, int32_t *pos, int32_t *posf,
+        const int32_t BX, const int32_t BY)
+{
+    d_dec_emit_w(cf, node_base, act, nact, child_off, child, turn, selfemit, base, nxt, nnxt, pos, posf, BY,
+                 BX * EMIT_WAVES + (threadIdx.x >> 6), EMIT_BLOCKS * EMIT_WAVES);
 }
 
 /* ------------------------------------------------------------------ */

@@ -70,7 +70,10 @@ struct UShared {
     FrameBeams bm;              /* phone_uses_wbeam is worked out per frame */
 };
 
-#define LANE const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; if (!ctx->active) return
+/* lanes run in lock step from frame 0: the frame index f is a kernel argument, the list searched in frame f is
+ * list f & 1 (lextree_active_swap flips it every frame) -- no kernel has to read what the word level of the previous
+ * frame wrote last, so the word level can share a launch with the emission sweep */
+#define LANE const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; if (f >= ctx->nfr || !ctx->active) return; const int32_t cur = f & 1; (void)cur
 
 __device__ __forceinline__ FrameBeams
 frame_beams(const UShared &S, int32_t cf)
@@ -82,7 +85,7 @@ frame_beams(const UShared &S, int32_t cf)
 
 /* ---- lextree_enter calls left by the previous frame's word level (or by utterance begin) ---- */
 __global__ void __launch_bounds__(256)
-ku_enter1(const ULane *__restrict__ lanes, UShared S)
+ku_enter1(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
     const int32_t n_ent = ctx->n_ent;
@@ -92,27 +95,27 @@ ku_enter1(const ULane *__restrict__ lanes, UShared S)
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-ku_enter2(const ULane *__restrict__ lanes, UShared S)
+ku_enter2(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
     if ((int32_t)blockIdx.x >= ctx->n_calls || ctx->n_ent == 0) return;
     const Entries ent = { ctx->calls, S.rootlist, ctx->n_calls };
-    d_dec_enter2(ent, ctx->n_ent, ctx->calls, S.prob, L.sc, L.frame, L.first, ctx->thresh, ctx->cf, S.T,
-                 L.nact[ctx->cur], L.eflag, L.ctot, L.n0, blockIdx.x, 0);
+    d_dec_enter2(ent, ctx->n_ent, ctx->calls, S.prob, L.sc, L.frame, L.first, ctx->thresh, f, S.T,
+                 L.nact[cur], L.eflag, L.ctot, L.n0, blockIdx.x, 0);
 }
 
 __global__ void __launch_bounds__(M3BLOCK)
-ku_enter3_mark(const ULane *__restrict__ lanes, UShared S)
+ku_enter3_mark(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const int32_t n_ent = ctx->n_ent, cur = ctx->cur;
+    const int32_t n_ent = ctx->n_ent;
     const int32_t *n0 = n_ent > 0 ? L.n0 : L.nact[cur];
     int32_t rows = 0;
     for (int32_t t = 0; t < S.T; t++) rows = max(rows, n0[t]);
     const int32_t n_ent_blocks = (n_ent + M3BLOCK - 1) / M3BLOCK, bpt = (rows + M3BLOCK - 1) / M3BLOCK;
     const Entries ent = { ctx->calls, S.rootlist, ctx->n_calls };
     for (int32_t vb = blockIdx.x; vb < n_ent_blocks + bpt * S.T; vb += gridDim.x)
-        d_dec_enter3_mark(n_ent_blocks, ent, n_ent, ctx->calls, ctx->groups, ctx->n_groups, ctx->cf, L.key, L.first, L.eflag,
+        d_dec_enter3_mark(n_ent_blocks, ent, n_ent, ctx->calls, ctx->groups, ctx->n_groups, f, L.key, L.first, L.eflag,
                           L.ctot, n0, L.sc, L.hist, L.frame, S.T, bpt, S.node_base, L.act[cur], L.nact[cur], L.pos,
                           L.posf, S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0);
 }
@@ -120,10 +123,10 @@ ku_enter3_mark(const ULane *__restrict__ lanes, UShared S)
 /* ---- approx_cont_mgau_ci_eval / _frame_eval for the lane's frame (s3a_gated.h) ---- */
 template <bool EXACT, bool CI>
 __global__ void __launch_bounds__(256)
-ku_gated(const ULane *__restrict__ lanes, UShared S)
+ku_gated(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const int32_t lo = CI ? 0 : S.n_ci_sen, hi = CI ? S.n_ci_sen : S.n_sen, cf = ctx->cf;
+    const int32_t lo = CI ? 0 : S.n_ci_sen, hi = CI ? S.n_ci_sen : S.n_sen, cf = f;
     if ((int32_t)(blockIdx.x * 256) >= (hi - lo) * S.CP) return;
     const float *x = ctx->feat + (size_t)cf * S.D4 * 4;
     const int32_t is_skip = (cf % S.ds_ratio == 0) ? 0 : 1;
@@ -159,7 +162,7 @@ struct UgDec {
 
 template <bool EXACT>
 __global__ void __launch_bounds__(256)
-ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes)
+ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, int32_t f)
 {
     typedef typename Acc<EXACT>::T acc_t;
     __shared__ UgDec dec[UG_MAX];
@@ -193,9 +196,9 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes)
         if (tid < n) {
             const ULane &Lz = lanes[zb + tid];
             const UCtx *cx = Lz.ctx;
-            d.active = cx->active;
+            d.active = (cx->active && f < cx->nfr) ? 1 : 0;
             if (d.active) {
-                const int32_t cf = cx->cf;
+                const int32_t cf = f;
                 d.sen_act = Lz.sen_act; d.scr = Lz.scr; d.gpart = Lz.gpart; d.bstidx = Lz.bstidx; d.bstscr = Lz.bstscr;
                 d.updatetime = Lz.updatetime; d.frame = cf; d.is_skip = (cf % S.ds_ratio == 0) ? 0 : 1;
                 d.thresh = add32(Lz.misc[5], d.is_skip ? S.ci_pbeam_tight : S.ci_pbeam);
@@ -210,7 +213,7 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes)
     for (int32_t i = tid; i < UG_MAX * D4MAIN * 4; i += 256) {
         const int32_t zz = i / (D4MAIN * 4), k = i - zz * (D4MAIN * 4);
         float v = 0.0f;
-        if (zz < n && dec[zz].active) { const UCtx *cx = lanes[zb + zz].ctx; v = cx->feat[(size_t)cx->cf * (D4MAIN * 4) + k]; }
+        if (zz < n && dec[zz].active) { const UCtx *cx = lanes[zb + zz].ctx; v = cx->feat[(size_t)f * (D4MAIN * 4) + k]; }
         ((float *)xs4)[i] = v;
     }
     __syncthreads();
@@ -308,25 +311,25 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes)
 /* ---- lextree_hmm_eval ---- */
 template <int EB>
 __global__ void __launch_bounds__(EB)
-ku_hmm_eval(const ULane *__restrict__ lanes, UShared S)
+ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const int32_t cur = ctx->cur, t = blockIdx.y, na = L.nact[cur][t];
+    const int32_t t = blockIdx.y, na = L.nact[cur][t];
     for (int32_t vb = blockIdx.x; vb * EB < na; vb += gridDim.x) {
         d_dec_hmm_eval<EB>(S.node_base, L.act[cur], L.nact[cur], S.N, S.n_tmat, S.ssid, S.tmatid, S.wid, S.comp, S.tp,
                            S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt, L.scr, L.misc, L.sc, L.hist, L.outs, L.outh,
-                           L.bests, L.best, ctx->cf, S.psof_off, S.psof, L.pstamp, L.gpart, S.gp_n, L.poswid, L.posout,
+                           L.bests, L.best, f, S.psof_off, S.psof, L.pstamp, L.gpart, S.gp_n, L.poswid, L.posout,
                            vb, t);
         __syncthreads();
     }
 }
 
 __global__ void __launch_bounds__(DBLOCK)
-ku_hist_count(const ULane *__restrict__ lanes, UShared S)
+ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const int32_t cur = ctx->cur, t = blockIdx.y, na = L.nact[cur][t];
-    const FrameBeams bm = frame_beams(S, ctx->cf);
+    const int32_t t = blockIdx.y, na = L.nact[cur][t];
+    const FrameBeams bm = frame_beams(S, f);
     for (int32_t vb = blockIdx.x; vb * DBLOCK < na; vb += gridDim.x) {
         d_dec_hist_count(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.best, L.bests, L.exits + S.N, L.hbin, -1, 0, 1,
                          NBIN, vb, t);
@@ -335,71 +338,68 @@ ku_hist_count(const ULane *__restrict__ lanes, UShared S)
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-ku_hist_sort(const ULane *__restrict__ lanes, UShared S)
+ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const int32_t cur = ctx->cur;
-    d_dec_hist_sort(S.node_base, L.act[cur], L.nact[cur], S.T, frame_beams(S, ctx->cf), L.exits + S.N, L.exits, L.hbin,
+    d_dec_hist_sort(S.node_base, L.act[cur], L.nact[cur], S.T, frame_beams(S, f), L.exits + S.N, L.exits, L.hbin,
                     L.pos, -1, NBIN, blockIdx.x, 0);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-ku_weak(const ULane *__restrict__ lanes, UShared S)
+ku_weak(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const FrameBeams bm = frame_beams(S, ctx->cf);
+    const FrameBeams bm = frame_beams(S, f);
     if (!(bm.phone_uses_wbeam || bm.pbeam < bm.hmmbeam)) return;
-    const int32_t cur = ctx->cur;
-    d_dec_weak(S.N, S.T, ctx->cf, bm, L.best, L.nact[cur], S.node_base, L.act[cur], S.prob, S.par_off, S.par, L.pos,
+    d_dec_weak(S.N, S.T, f, bm, L.best, L.nact[cur], S.node_base, L.act[cur], S.prob, S.par_off, S.par, L.pos,
                L.posf, L.sc, L.outs, L.bests, S.wid, L.hbin, L.propf, L.exits + 2 * (size_t)S.N, 0, 0);
 }
 
 __global__ void __launch_bounds__(RSBLOCK)
-ku_resolve(const ULane *__restrict__ lanes, UShared S)
+ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const int32_t cur = ctx->cur;
-    d_dec_resolve(S.N, S.T, ctx->cf, frame_beams(S, ctx->cf), L.best, L.nact[cur], S.node_base, S.tree_of, S.prob,
+    d_dec_resolve(S.N, S.T, f, frame_beams(S, f), L.best, L.nact[cur], S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
                   L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
                   blockIdx.x, 0);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC)
+ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t f)
 {
     LANE;
-    const int32_t cur = ctx->cur;
-    const FrameBeams bm = frame_beams(S, ctx->cf);
+    const FrameBeams bm = frame_beams(S, f);
     /* after a histogram reordering the position-indexed word ids / exit scores are stale */
     int32_t n = 0;
     for (int32_t t = 0; t < S.T; t++) n += L.nact[cur][t];
     const int32_t reordered = n > bm.maxhmmpf + (bm.maxhmmpf >> 1) ? 1 : 0;
-    d_dec_scan(S.N, S.T, ctx->cf, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit,
+    d_dec_scan(S.N, S.T, f, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit,
                L.cnt, L.base, L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, L.best, L.exits, L.nexit, L.hbin, L.misc,
                (int32_t *)NULL /* no tail: ku_wordlevel assembles the frame record */, L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, reordered, L.scan_agg, L.scan_pre,
                L.scan_flag, S.scan_chunks, ctx->scan_epoch, NC, blockIdx.x, 0);
 }
 
-__global__ void __launch_bounds__(DBLOCK)
-ku_emit(const ULane *__restrict__ lanes, UShared S)
-{
-    LANE;
-    const int32_t cur = ctx->cur;
-    d_dec_emit(ctx->cf, S.node_base, L.act[cur], L.nact[cur], S.child_off, S.child, L.turn, L.selfemit, L.base,
-               L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, blockIdx.x, blockIdx.y);
-}
-
-/* ---- the word level: closes the frame and arms the next one ---- */
+/* ---- the ordered emission of the next list AND the word level, one launch ----
+ * workgroup 0 of a lane: the frame record (d_dec_pack_frame) + the word level, which closes the frame and leaves the
+ * next frame's lextree_enter calls; workgroups 1 .. 8 T: the emission sweep (16 waves each, 8 workgroups per tree).
+ * The two read nothing the other writes. */
+#define UE_WG_PER_TREE 8
 __global__ void __launch_bounds__(WL_THREADS)
-ku_wordlevel(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par)
+ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, int32_t f)
 {
     LANE;
+    if (blockIdx.x > 0) {
+        const int32_t t = (blockIdx.x - 1) / UE_WG_PER_TREE, bx = (blockIdx.x - 1) % UE_WG_PER_TREE;
+        d_dec_emit_w(f, S.node_base, L.act[cur], L.nact[cur], S.child_off, S.child, L.turn, L.selfemit, L.base,
+                     L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, t, bx * WL_WAVES + (threadIdx.x >> 6),
+                     UE_WG_PER_TREE * WL_WAVES);
+        return;
+    }
     if (threadIdx.x == 0) ctx->scan_epoch++;        /* (k_dec_scan's flags are stamped per launch) */
-    const int32_t cur = ctx->cur;
-    d_dec_pack_frame(S.N, S.T, frame_beams(S, ctx->cf), S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc,
+    d_dec_pack_frame(S.N, S.T, frame_beams(S, f), S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc,
                      L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1]);
-    d_wordlevel_frame(L.w, ctx, L.pack, lm, dict, par);
+    d_wordlevel_frame(L.w, ctx, L.pack, lm, dict, par, f);
 }
 
 /* stand-alone word-level frame on a caller-filled record (tests: lock step with the oracle) */
@@ -408,7 +408,7 @@ ku_wordlevel_only(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par)
 {
     const ULane &L = lanes[blockIdx.z];
     if (!L.ctx->active) return;
-    d_wordlevel_frame(L.w, L.ctx, L.pack, lm, dict, par);
+    d_wordlevel_frame(L.w, L.ctx, L.pack, lm, dict, par, L.ctx->cf);
 }
 
 __global__ void
@@ -921,10 +921,10 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
 enum { UK_ENTER1, UK_ENTER2, UK_ENTER3, UK_GATED_CI, UK_GATED_CD, UK_HMM_EVAL, UK_HIST_COUNT, UK_HIST_SORT, UK_WEAK,
        UK_RESOLVE, UK_SCAN, UK_EMIT, UK_WORD, UK_N };
 static const char *const uk_names[UK_N] = { "ku_enter1", "ku_enter2", "ku_enter3_mark", "ku_gated_ci", "ku_gated_cd",
-    "ku_hmm_eval", "ku_hist_count", "ku_hist_sort", "ku_weak", "ku_resolve", "ku_scan", "ku_emit", "ku_wordlevel" };
+    "ku_hmm_eval", "ku_hist_count", "ku_hist_sort", "ku_weak", "ku_resolve", "ku_scan", "ku_emit", "ku_emit_word" };
 
 static int32_t
-enqueue_frame(s3a_uttdec_t *ud, int32_t n, bool prof)
+enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
 {
     hipStream_t st = ud->stream;
     const ULane *LN = ud->d_lanes;
@@ -935,9 +935,9 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, bool prof)
         if (prof) { (void)hipEventCreate(&a_); (void)hipEventCreate(&b_); (void)hipEventRecord(a_, st); }        \
         hipLaunchKernelGGL(__VA_ARGS__);                                                                         \
         if (prof) { (void)hipEventRecord(b_, st); ud->prof_ev.push_back({ cls, a_, b_ }); } } while (0)
-    UKL(UK_ENTER1, ku_enter1, dim3(ud->g_ent, 1, n), dim3(256), 0, st, LN, S);
-    UKL(UK_ENTER2, ku_enter2, dim3(WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
-    UKL(UK_ENTER3, ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S);
+    UKL(UK_ENTER1, ku_enter1, dim3(ud->g_ent, 1, n), dim3(256), 0, st, LN, S, f);
+    UKL(UK_ENTER2, ku_enter2, dim3(WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+    UKL(UK_ENTER3, ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S, f);
     const int32_t g_ci = (S.n_ci_sen * S.CP + 255) / 256, g_cd = ((S.n_sen - S.n_ci_sen) * S.CP + 255) / 256;
     /* from UG_FB lanes on the CD senones of all lanes are ONE pass over the model (39/40-dimensional features,
      * >= UG_FB Gaussian slots per senone); (S3A_UTT_NO_MULTI: the per-lane kernel whatever the lane count -- tests) */
@@ -946,28 +946,27 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, bool prof)
     const int32_t gz = (n + UG_MAX - 1) / UG_MAX, groups = (min(n, UG_MAX) + UG_FB - 1) / UG_FB;
     const dim3 gm(g_cd, max(1, min(groups, 2 * ud->g->dev->n_cu / max(1, g_cd * gz))), gz);
     if (ud->exact) {
-        if (g_ci) UKL(UK_GATED_CI, (ku_gated<true, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
-        if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<true>), gm, dim3(256), 0, st, LN, S, n);
-        else if (g_cd) UKL(UK_GATED_CD, (ku_gated<true, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
+        if (g_ci) UKL(UK_GATED_CI, (ku_gated<true, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S, f);
+        if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<true>), gm, dim3(256), 0, st, LN, S, n, f);
+        else if (g_cd) UKL(UK_GATED_CD, (ku_gated<true, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S, f);
     }
     else {
-        if (g_ci) UKL(UK_GATED_CI, (ku_gated<false, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S);
-        if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<false>), gm, dim3(256), 0, st, LN, S, n);
-        else if (g_cd) UKL(UK_GATED_CD, (ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S);
+        if (g_ci) UKL(UK_GATED_CI, (ku_gated<false, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S, f);
+        if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<false>), gm, dim3(256), 0, st, LN, S, n, f);
+        else if (g_cd) UKL(UK_GATED_CD, (ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S, f);
     }
     if (ud->eval_block == 256)
-        UKL(UK_HMM_EVAL, ku_hmm_eval<256>, dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S);
+        UKL(UK_HMM_EVAL, ku_hmm_eval<256>, dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S, f);
     else
-        UKL(UK_HMM_EVAL, ku_hmm_eval<64>, dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S);
+        UKL(UK_HMM_EVAL, ku_hmm_eval<64>, dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
     if (ud->hist_possible) {
-        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, 64)), T, n), dim3(DBLOCK), 0, st, LN, S);
-        UKL(UK_HIST_SORT, ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
+        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
+        UKL(UK_HIST_SORT, ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     }
-    if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S);
-    UKL(UK_RESOLVE, ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S);
-    UKL(UK_SCAN, ku_scan, dim3(T * ud->scan_nc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc);
-    UKL(UK_EMIT, ku_emit, dim3(EMIT_BLOCKS, T, n), dim3(DBLOCK), 0, st, LN, S);
-    UKL(UK_WORD, ku_wordlevel, dim3(1, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par);
+    if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+    UKL(UK_RESOLVE, ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+    UKL(UK_SCAN, ku_scan, dim3(T * ud->scan_nc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc, f);
+    UKL(UK_WORD, ku_emit_word, dim3(1 + UE_WG_PER_TREE * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f);
 #undef UKL
     HIPCHK(hipGetLastError());
     return S3A_OK;
@@ -1025,7 +1024,7 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, ud->stream));
     for (int32_t f = 0; f < maxT; f++)
-        if ((rc = enqueue_frame(ud, n_utt, ud->prof_every > 0 && f % ud->prof_every == 0)) != S3A_OK) return rc;
+        if ((rc = enqueue_frame(ud, n_utt, f, ud->prof_every > 0 && f % ud->prof_every == 0)) != S3A_OK) return rc;
     HIPCHK(hipEventRecord(e1, ud->stream));
     for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_state(ud, z)) != S3A_OK) return rc;
     HIPCHK(hipStreamSynchronize(ud->stream));

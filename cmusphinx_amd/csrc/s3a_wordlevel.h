@@ -292,7 +292,7 @@ wl_tg_score_ctx(const WLm &lm, const WLane &L, int32_t i, int32_t lw0, int32_t l
  * within a word exit the history entries of the predecessor's frame in table order.
  */
 __device__ __forceinline__ void
-d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par)
+d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, const int32_t cf)
 {
     __shared__ int32_t s_tb[WL_MAXT + 1];
     __shared__ int32_t s_i[16];
@@ -301,7 +301,7 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
     __shared__ int32_t s_heap[6 * WL_HEAP_LDS];
     __shared__ int32_t s_ex[3 * WL_LDS_EX], s_off[WL_LDS_EX + 1];    /* the usual frame: exits + candidate offsets in LDS */
     const int32_t tid = threadIdx.x;
-    const int32_t T = par.T, hdr = 6 * T + 16, cf = ctx->cf;
+    const int32_t T = par.T, hdr = 6 * T + 16;
     const int32_t fs = L.st[0];                 /* == frame_start[cf] */
     const int32_t *fstart = L.frame_start;
     const int32_t *ex = pack + hdr;
