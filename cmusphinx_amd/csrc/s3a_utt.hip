@@ -386,7 +386,7 @@ ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t f)
  * The two read nothing the other writes. */
 #define UE_WG_PER_TREE 8
 __global__ void __launch_bounds__(WL_THREADS)
-ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, int32_t f)
+ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, int32_t f, int32_t big)
 {
     LANE;
     if (blockIdx.x > 0) {
@@ -399,7 +399,46 @@ ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPa
     if (threadIdx.x == 0) ctx->scan_epoch++;        /* (k_dec_scan's flags are stamped per launch) */
     d_dec_pack_frame(S.N, S.T, frame_beams(S, f), S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc,
                      L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1]);
-    d_wordlevel_frame(L.w, ctx, L.pack, lm, dict, par, f);
+    if (big) d_wl_big_begin(L.w, ctx, L.pack, dict, par);   /* wide beams: the candidate phases follow as their own launches */
+    else d_wordlevel_frame(L.w, ctx, L.pack, lm, dict, par, f);
+}
+
+/* the wide-beam word level: WL_BIG_G workgroups per lane and phase (s3a_wordlevel.h) */
+__global__ void __launch_bounds__(WL_THREADS)
+ku_wl_p2(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par, int32_t f)
+{
+    LANE;
+    d_wl_big_p2(L.w, ctx, L.pack, lm, dict, par, f, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(WL_THREADS)
+ku_wl_p3(const ULane *__restrict__ lanes, WDict dict, WPar par, int32_t f)
+{
+    LANE;
+    d_wl_big_p3(L.w, ctx, L.pack, dict, par, f, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(WL_THREADS)
+ku_wl_p4a(const ULane *__restrict__ lanes, WPar par, int32_t f)
+{
+    LANE;
+    d_wl_big_p4a(L.w, ctx, L.pack, par, f, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(WL_THREADS)
+ku_wl_p4b(const ULane *__restrict__ lanes, WPar par, int32_t f)
+{
+    LANE;
+    d_wl_big_p4b(L.w, ctx, L.pack, par, f, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(WL_THREADS)
+ku_wl_p5(const ULane *__restrict__ lanes, WDict dict, WPar par, int32_t f)
+{
+    LANE;
+    d_wl_big_p5(L.w, ctx, L.pack, dict, par, f, blockIdx.x, gridDim.x);
+}
+__global__ void __launch_bounds__(WL_THREADS)
+ku_wl_finish(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par, int32_t f)
+{
+    LANE;
+    d_wl_big_finish(L.w, ctx, L.pack, lm, dict, par, f);
 }
 
 /* stand-alone word-level frame on a caller-filled record (tests: lock step with the oracle) */
@@ -566,8 +605,9 @@ struct s3a_uttdec_s {
     int32_t prof_every;         /* > 0: every prof_every-th frame is bracketed by events */
     struct ProfEv { int32_t cls; hipEvent_t a, b; };
     std::vector<ProfEv> prof_ev;
-    double prof_us[16];
-    int64_t prof_n[16];
+    double prof_us[24];
+    int64_t prof_n[24];
+    int32_t big_wl;             /* the word level's candidate phases as their own launches (wide beams) */
 };
 
 static int32_t
@@ -584,7 +624,7 @@ wlane_free(WLane &w)
 {
     void *p[] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type, w.lmc, w.frame_start, w.bestscore,
                   w.bestvh, w.st, w.ex_off, w.cand_pref, w.cand_e, w.cand_score, w.cand_slot, w.hkey, w.hbest, w.hfirst,
-                  w.hlead_rank, w.sg, w.srt, w.wfirst, w.heap, w.fstat };
+                  w.hlead_rank, w.sg, w.srt, w.wfirst, w.wbest, w.part, w.part2, w.tb, w.heap, w.fstat };
     for (auto q : p) if (q) (void)hipFree(q);
     memset((void *)&w, 0, sizeof w);
 }
@@ -613,9 +653,10 @@ wlane_alloc(WLane &w, int32_t vh_cap, int32_t max_frames, int32_t ex_cap, int32_
         || hipMemset(w.hfirst, 0xff, hs * 4) != hipSuccess) { s3a_set_error("s3a_utt: memset failed"); goto fail; }
     w.new_cap = new_cap;
     DM(w.sg, (size_t)11 * new_cap * 4); DM(w.srt, (size_t)6 * new_cap * 4); DM(w.heap, (size_t)6 * new_cap * 4);
-    DM(w.wfirst, (size_t)n_word * 4);
+    DM(w.wfirst, (size_t)n_word * 4); DM(w.wbest, (size_t)n_word * 4);
+    DM(w.part, WL_BIG_G * 4); DM(w.part2, WL_BIG_G * 4); DM(w.tb, (WL_MAXT + 1) * 4);
     DM(w.fstat, (size_t)max_frames * 8 * 4);
-    if (fill32(st, w.wfirst, INT_MAX, n_word) != S3A_OK) goto fail;
+    if (fill32(st, w.wfirst, INT_MAX, n_word) != S3A_OK || fill32(st, w.wbest, INT_MIN, n_word) != S3A_OK) goto fail;
     return S3A_OK;
 fail:
     wlane_free(w);
@@ -715,6 +756,9 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     /* lextree_hmm_histbin can only fire when more than 1.5 x maxhmmpf HMMs can be active at all */
     ud->hist_possible = (long long)proto->N > (long long)cfg->maxhmmpf + (cfg->maxhmmpf >> 1);
     ud->weak_possible = cfg->ptranskip != 0 || cfg->pbeam < cfg->hmmbeam;
+    /* wide beams (thousands of word exits, 10^5..10^6 (exit, predecessor) candidates per frame): the word level's
+     * candidate phases run chip-wide as their own launches; S3A_UTT_BIGWL=0/1 overrides */
+    ud->big_wl = getenv("S3A_UTT_BIGWL") ? atoi(getenv("S3A_UTT_BIGWL")) != 0 : (cfg->maxhmmpf >= 50000 && maxn >= 50000);
     if (ud->hist_possible && -cfg->hmmbeam / NBIN == 0) {
         s3a_set_error("s3a_uttdec_init: -beam too narrow for histogram pruning (bin width 0)");
         delete ud;
@@ -871,7 +915,7 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
         if ((rc = s3a_lexsearch_reset(hl.ls)) != S3A_OK) return rc;
         HIPCHK(hipMemsetAsync(w.hkey, 0, hs * 8, ud->stream)); HIPCHK(hipMemsetAsync(w.hbest, 0, hs * 8, ud->stream));
         HIPCHK(hipMemsetAsync(w.hfirst, 0xff, hs * 4, ud->stream));
-        if ((rc = fill32(ud->stream, w.wfirst, INT_MAX, c.n_word)) != S3A_OK) return rc;
+        if ((rc = fill32(ud->stream, w.wfirst, INT_MAX, c.n_word)) != S3A_OK || (rc = fill32(ud->stream, w.wbest, INT_MIN, c.n_word)) != S3A_OK) return rc;
         hl.dirty = 0;
     }
     if ((rc = s3a_lexsearch_utt_end(hl.ls)) != S3A_OK) return rc;
@@ -919,9 +963,9 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
 
 /* kernel classes of a frame (s3a_uttdec_profile) */
 enum { UK_ENTER1, UK_ENTER2, UK_ENTER3, UK_GATED_CI, UK_GATED_CD, UK_HMM_EVAL, UK_HIST_COUNT, UK_HIST_SORT, UK_WEAK,
-       UK_RESOLVE, UK_SCAN, UK_EMIT, UK_WORD, UK_N };
+       UK_RESOLVE, UK_SCAN, UK_EMIT, UK_WORD, UK_WL_P2, UK_WL_P3, UK_WL_P4, UK_WL_P5, UK_WL_FIN, UK_N };
 static const char *const uk_names[UK_N] = { "ku_enter1", "ku_enter2", "ku_enter3_mark", "ku_gated_ci", "ku_gated_cd",
-    "ku_hmm_eval", "ku_hist_count", "ku_hist_sort", "ku_weak", "ku_resolve", "ku_scan", "ku_emit", "ku_emit_word" };
+    "ku_hmm_eval", "ku_hist_count", "ku_hist_sort", "ku_weak", "ku_resolve", "ku_scan", "ku_emit", "ku_emit_word", "ku_wl_p2", "ku_wl_p3", "ku_wl_p4ab", "ku_wl_p5", "ku_wl_finish" };
 
 static int32_t
 enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
@@ -966,7 +1010,16 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     UKL(UK_RESOLVE, ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
     UKL(UK_SCAN, ku_scan, dim3(T * ud->scan_nc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc, f);
-    UKL(UK_WORD, ku_emit_word, dim3(1 + UE_WG_PER_TREE * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f);
+    UKL(UK_WORD, ku_emit_word, dim3(1 + UE_WG_PER_TREE * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
+    if (ud->big_wl) {
+        const dim3 gb(WL_BIG_G, 1, n), one(1, 1, n), tb(WL_THREADS);
+        UKL(UK_WL_P2, ku_wl_p2, gb, tb, 0, st, LN, ud->lm->d, ud->dict, ud->par, f);
+        UKL(UK_WL_P3, ku_wl_p3, gb, tb, 0, st, LN, ud->dict, ud->par, f);
+        UKL(UK_WL_P4, ku_wl_p4a, gb, tb, 0, st, LN, ud->par, f);
+        UKL(UK_WL_P4, ku_wl_p4b, gb, tb, 0, st, LN, ud->par, f);
+        UKL(UK_WL_P5, ku_wl_p5, gb, tb, 0, st, LN, ud->dict, ud->par, f);
+        UKL(UK_WL_FIN, ku_wl_finish, one, tb, 0, st, LN, ud->lm->d, ud->dict, ud->par, f);
+    }
 #undef UKL
     HIPCHK(hipGetLastError());
     return S3A_OK;

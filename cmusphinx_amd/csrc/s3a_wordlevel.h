@@ -41,6 +41,8 @@
 #define WL_MAXT 16          /* lextrees per decoder (2 x -Nlextree) */
 #define WL_HEAP_LDS 1536    /* frames with at most this many new entries replay the heap in LDS */
 #define WL_LDS_EX 1024      /* frames with at most this many word exits keep them (and their candidate offsets) in LDS */
+#define WL_RANK_MAX 384     /* entries above the pruning threshold ranked all against all; beyond: selection */
+#define WL_BIG_G 256        /* workgroups per lane of the wide-beam launches */
 
 /* error bits (UCtx.err / s3a_utt_result_t.err) */
 #define WL_E_OPEN_EXIT 1    /* out.history == -1 at a word exit (LEXTREE_OPERATION_FAILURE / E_FATAL vithist.c:505) */
@@ -97,6 +99,8 @@ struct WLane {              /* one lane's history table + per-frame scratch (dev
     int32_t new_cap;
     int32_t *srt;           /* [6][new_cap]: above-threshold list, sorted order, flags, scans */
     int32_t *wfirst;        /* [n_word]: first sorted position of a word (INT_MAX when idle) */
+    int32_t *wbest;         /* [n_word]: best score of a word's entries in the frame (INT_MIN when idle) */
+    int32_t *part, *part2, *tb;     /* [WL_BIG_G] per-chunk partials of the wide-beam launches; [WL_MAXT + 1] */
     int32_t *heap;          /* [6][new_cap] for the heap replay when it does not fit LDS */
     int32_t *fstat;         /* [max_frames][8] per-frame statistics for the host */
 };
@@ -286,51 +290,47 @@ wl_tg_score_ctx(const WLm &lm, const WLane &L, int32_t i, int32_t lw0, int32_t l
 }
 
 /*
- * One frame of the word level for one lane.  `pack` = the frame record (d_dec_pack_frame):
+ * One frame of the word level for one lane, in phases.  `pack` = the frame record (d_dec_pack_frame):
  * [best,wbest] x T | nact x T | thr[8] | n_exit x T | err x T | misc[8] | n_next x T | exits (wid, score,
  * history) in tree then list order.  Candidates are numbered in the reference's walk order: exit by exit,
  * within a word exit the history entries of the predecessor's frame in table order.
+ *
+ * The candidate phases take a candidate RANGE [c_lo, c_hi): the usual frame (a few hundred to a few thousand
+ * candidates) is ONE workgroup running every phase over [0, n_cand) with workgroup barriers in between
+ * (d_wordlevel_frame); a wide-beam frame (10^5 .. 10^6 candidates) is a sequence of launches in which
+ * workgroup g of G owns chunk g and the two order-dependent quantities travel as per-chunk partials
+ * (L.part): the running best before a candidate = max(best of the chunks in front, prefix inside the chunk),
+ * an entry's place in the table = entries founded in the chunks in front + rank inside the chunk.
+ * L.st: [0] n_entry [1] n_frm | per frame: [4] nx [5] n_cand [6] the frame's best [7] n_new [8] stop.
  */
-__device__ __forceinline__ void
-d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, const int32_t cf)
-{
-    __shared__ int32_t s_tb[WL_MAXT + 1];
-    __shared__ int32_t s_i[16];
-    __shared__ unsigned long long s_ci[256];
-    __shared__ unsigned long long s_u64[2];
-    __shared__ int32_t s_heap[6 * WL_HEAP_LDS];
-    __shared__ int32_t s_ex[3 * WL_LDS_EX], s_off[WL_LDS_EX + 1];    /* the usual frame: exits + candidate offsets in LDS */
-    const int32_t tid = threadIdx.x;
-    const int32_t T = par.T, hdr = 6 * T + 16;
-    const int32_t fs = L.st[0];                 /* == frame_start[cf] */
-    const int32_t *fstart = L.frame_start;
-    const int32_t *ex = pack + hdr;
-    int32_t *off = L.ex_off;
+struct WlFr {               /* what every phase needs of the frame */
+    const int32_t *ex;      /* exits: (wid, score, history) x nx */
+    const int32_t *off;     /* [nx + 1] first candidate of every exit */
+    const int32_t *tb;      /* [T + 1] first exit of every tree */
+    int32_t nx, n_cand, cf;
+};
 
-    /* ---- P1: the exits, their candidate counts ---- */
+/* P1: the exits' candidate counts -> off[], n_cand.  tb / err_out are shared-memory words of the caller. */
+__device__ __forceinline__ int32_t
+wl_p1(const WLane &L, const int32_t *pack, const WDict &dict, int32_t T, int32_t *tb, int32_t *off, const int32_t *ex,
+      int32_t *err_out)
+{
+    const int32_t tid = threadIdx.x;
+    const int32_t *fstart = L.frame_start;
     if (tid == 0) {
         int32_t n = 0, e = 0;
         for (int32_t t = 0; t < T; t++) {
-            s_tb[t] = n; n += pack[3 * T + 8 + t];
+            tb[t] = n; n += pack[3 * T + 8 + t];
             if (pack[4 * T + 8 + t] == 1) e |= WL_E_OPEN_EXIT;
             if (pack[4 * T + 8 + t] == 2) e |= WL_E_SCAN;
         }
-        s_tb[T] = n;
+        tb[T] = n;
         if (n > L.ex_cap) e |= WL_E_EXITS;
-        s_i[0] = e;
+        *err_out = e;
     }
     __syncthreads();
-    const int32_t nx = s_tb[T];
-    if (s_i[0]) {                               /* (uniform) the utterance ends here, as in the reference */
-        if (tid == 0) { ctx->err |= s_i[0]; ctx->active = 0; }
-        return;
-    }
-    if (nx <= WL_LDS_EX) {
-        for (int32_t i = tid; i < 3 * nx; i += WL_THREADS) s_ex[i] = ex[i];
-        __syncthreads();
-        ex = s_ex;
-        off = s_off;
-    }
+    const int32_t nx = tb[T];
+    if (*err_out) return -1;
     for (int32_t e = tid; e < nx; e += WL_THREADS) {
         const int32_t w = ex[3 * e], h = ex[3 * e + 2];
         int32_t c = 1;
@@ -338,50 +338,57 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         off[e] = c;
     }
     const int32_t n_cand = wl_scan<false>(off, off, nx, 0);
-    if (tid == 0) {
-        off[nx] = n_cand;
-        if (n_cand > L.cand_cap || 2 * (long long)n_cand > (long long)L.hmask + 1) ctx->err |= WL_E_CAND;
-        if (n_cand > ctx->max_cand) ctx->max_cand = n_cand;
-        s_i[4] = 0;
-    }
+    if (tid == 0) off[nx] = n_cand;
     __syncthreads();
-    if (n_cand > L.cand_cap || 2 * (long long)n_cand > (long long)L.hmask + 1) {
-        if (tid == 0) ctx->active = 0;
-        return;
-    }
+    return n_cand;
+}
 
-    /* ---- P2: every candidate's path score (a thread per candidate) ---- */
-    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
-        int32_t lo = 0, hi = nx;                /* the exit of candidate c: last e with ex_off[e] <= c */
-        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (off[mid] <= c) lo = mid; else hi = mid; }
-        const int32_t e = lo, w = ex[3 * e], scr = ex[3 * e + 1], h = ex[3 * e + 2];
+/* the predecessor entry of candidate c of exit e */
+__device__ __forceinline__ int32_t
+wl_pred_of(const WLane &L, const WlFr &fr, int32_t e, int32_t c, int32_t h)
+{
+    return (h == 0 ? 0 : L.frame_start[L.ef[h]]) + (c - fr.off[e]);
+}
+
+/* P2: the candidates' path scores, their exits; the exclusive prefix maximum INSIDE the range -> cand_pref;
+ * returns the range's maximum.  *bad (shared) is set when a word exit has no LM word. */
+__device__ __forceinline__ int32_t
+wl_p2(const WLane &L, const WLm &lm, const WDict &dict, const WlFr &fr, int32_t c_lo, int32_t c_hi, int32_t *bad)
+{
+    for (int32_t c = c_lo + (int32_t)threadIdx.x; c < c_hi; c += WL_THREADS) {
+        int32_t lo = 0, hi = fr.nx;             /* the exit of candidate c: last e with off[e] <= c */
+        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (fr.off[mid] <= c) lo = mid; else hi = mid; }
+        const int32_t e = lo, w = fr.ex[3 * e], scr = fr.ex[3 * e + 1], h = fr.ex[3 * e + 2];
         L.cand_e[c] = e;
         int32_t sc;
         if (dict.is_filler[w]) sc = add32(scr, dict.fillpen[w]);
         else {
             const int32_t lwid = dict.lwid[w];
-            if (lwid < 0) { s_i[4] = 1; sc = INT_MIN; }
+            if (lwid < 0) { *bad = 1; sc = INT_MIN; }
             else {
-                const int32_t i = (h == 0 ? 0 : fstart[L.ef[h]]) + (c - off[e]);
+                const int32_t i = wl_pred_of(L, fr, e, c, h);
                 sc = add32(add32(L.score[i], add32(scr, -L.score[h])), wl_tg_score_ctx(lm, L, i, L.lw0[i], lwid, w));
             }
         }
         L.cand_score[c] = sc;
     }
     __syncthreads();
-    if (s_i[4]) { if (tid == 0) { ctx->err |= WL_E_NOLM; ctx->active = 0; } return; }
-    /* the best score entered before each candidate; the frame's best */
-    const int32_t M = wl_scan<true>(L.cand_score, L.cand_pref, n_cand, INT_MIN);
+    return wl_scan<true>(L.cand_score + c_lo, L.cand_pref + c_lo, c_hi - c_lo, INT_MIN);
+}
 
-    /* ---- P3: which candidates enter (vithist.c:560), into which LM state ---- */
-    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
-        const int32_t e = L.cand_e[c], w = ex[3 * e], h = ex[3 * e + 2], sc = L.cand_score[c];
+/* P3: which candidates enter (vithist.c:560; `before` = the best score of everything in front of the range), into
+ * which LM state */
+__device__ __forceinline__ void
+wl_p3(const WLane &L, const WDict &dict, const WPar &par, const WlFr &fr, int32_t c_lo, int32_t c_hi, int32_t before)
+{
+    for (int32_t c = c_lo + (int32_t)threadIdx.x; c < c_hi; c += WL_THREADS) {
+        const int32_t e = L.cand_e[c], w = fr.ex[3 * e], h = fr.ex[3 * e + 2], sc = L.cand_score[c];
         const bool filler = dict.is_filler[w] != 0;
         int32_t slot = -1;
-        if (filler || add32(sc, -par.wbeam) >= L.cand_pref[c]) {
+        if (filler || add32(sc, -par.wbeam) >= max(before, L.cand_pref[c])) {
             unsigned long long key;
             if (filler) key = wl_key(L.lw0[h], L.lw1[h]);
-            else key = wl_key(dict.lwid[w], L.lw0[(h == 0 ? 0 : fstart[L.ef[h]]) + (c - off[e])]);
+            else key = wl_key(dict.lwid[w], L.lw0[wl_pred_of(L, fr, e, c, h)]);
             uint32_t hh = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)L.hmask;
             for (;;) {
                 const unsigned long long old = atomicCAS(&L.hkey[hh], 0ull, key);
@@ -394,122 +401,259 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         }
         L.cand_slot[c] = slot;
     }
-    __syncthreads();
+}
 
-    /* ---- P4: the first entered candidate of each LM state founds the entry, in walk order ---- */
-    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
+/* P4a: the first entered candidate of each LM state founds the entry: its rank INSIDE the range -> cand_pref;
+ * returns the number of entries founded in the range */
+__device__ __forceinline__ int32_t
+wl_p4a(const WLane &L, int32_t c_lo, int32_t c_hi)
+{
+    for (int32_t c = c_lo + (int32_t)threadIdx.x; c < c_hi; c += WL_THREADS) {
         const int32_t slot = L.cand_slot[c];
         L.cand_pref[c] = (slot >= 0 && WL_ALOAD(&L.hfirst[slot]) == (uint32_t)c) ? 1 : 0;
     }
-    const int32_t n_new = wl_scan<false>(L.cand_pref, L.cand_pref, n_cand, 0);
-    if (tid == 0) {
-        if (n_new > L.new_cap || (long long)fs + n_new > L.cap) ctx->err |= WL_E_TABLE;
-        if (n_new > ctx->max_new) ctx->max_new = n_new;
-    }
-    __syncthreads();
-    if (n_new > L.new_cap || (long long)fs + n_new > L.cap) { if (tid == 0) ctx->active = 0; return; }
-    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
+    return wl_scan<false>(L.cand_pref + c_lo, L.cand_pref + c_lo, c_hi - c_lo, 0);
+}
+
+/* P4b: the founders publish the entry's place (base = entries founded in front of the range) */
+__device__ __forceinline__ void
+wl_p4b(const WLane &L, int32_t c_lo, int32_t c_hi, int32_t base)
+{
+    for (int32_t c = c_lo + (int32_t)threadIdx.x; c < c_hi; c += WL_THREADS) {
         const int32_t slot = L.cand_slot[c];
-        if (slot >= 0 && WL_ALOAD(&L.hfirst[slot]) == (uint32_t)c) L.hlead_rank[slot] = L.cand_pref[c];
+        if (slot >= 0 && WL_ALOAD(&L.hfirst[slot]) == (uint32_t)c) L.hlead_rank[slot] = base + L.cand_pref[c];
     }
-    __syncthreads();
+}
+
+/* P5: the best candidate of each LM state writes the entry (staged in founding order) */
+__device__ __forceinline__ void
+wl_p5(const WLane &L, const WDict &dict, const WPar &par, const WlFr &fr, int32_t c_lo, int32_t c_hi)
+{
     int32_t *sg_wid = L.sg, *sg_sf = L.sg + L.new_cap, *sg_ascr = L.sg + 2 * L.new_cap, *sg_lscr = L.sg + 3 * L.new_cap,
         *sg_score = L.sg + 4 * L.new_cap, *sg_pred = L.sg + 5 * L.new_cap, *sg_type = L.sg + 6 * L.new_cap,
-        *sg_lw0 = L.sg + 7 * L.new_cap, *sg_lw1 = L.sg + 8 * L.new_cap, *sg_slot = L.sg + 9 * L.new_cap,
-        *sg_valid = L.sg + 10 * L.new_cap;
-
-    /* ---- P5: the best candidate of each LM state writes the entry (staged in founding order) ---- */
-    for (int32_t c = tid; c < n_cand; c += WL_THREADS) {
+        *sg_lw0 = L.sg + 7 * L.new_cap, *sg_lw1 = L.sg + 8 * L.new_cap, *sg_slot = L.sg + 9 * L.new_cap;
+    for (int32_t c = c_lo + (int32_t)threadIdx.x; c < c_hi; c += WL_THREADS) {
         const int32_t slot = L.cand_slot[c];
         if (slot < 0) continue;
         const int32_t sc = L.cand_score[c];
         if (WL_ALOAD(&L.hbest[slot]) != wl_pack(sc, (uint32_t)c)) continue;
-        const int32_t e = L.cand_e[c], w = ex[3 * e], scr = ex[3 * e + 1], h = ex[3 * e + 2];
+        const int32_t e = L.cand_e[c], w = fr.ex[3 * e], scr = fr.ex[3 * e + 1], h = fr.ex[3 * e + 2];
         const int32_t k = WL_ALOAD(&L.hlead_rank[slot]), ascr = add32(scr, -L.score[h]);
         int32_t ty = 0;
-        for (int32_t t = 0; t < T; t++) if (e >= s_tb[t]) ty = par.tree_type[t];
+        for (int32_t t = 0; t < par.T; t++) if (e >= fr.tb[t]) ty = par.tree_type[t];
         sg_wid[k] = w; sg_sf[k] = L.ef[h] + 1; sg_ascr[k] = ascr; sg_score[k] = sc; sg_type[k] = ty; sg_slot[k] = slot;
         if (dict.is_filler[w]) { sg_lscr[k] = dict.fillpen[w]; sg_pred[k] = h; sg_lw0[k] = L.lw0[h]; sg_lw1[k] = L.lw1[h]; }
         else {
-            const int32_t i = (h == 0 ? 0 : fstart[L.ef[h]]) + (c - off[e]);
+            const int32_t i = wl_pred_of(L, fr, e, c, h);
             sg_lscr[k] = add32(sc, -add32(L.score[i], ascr)); sg_pred[k] = i; sg_lw0[k] = dict.lwid[w]; sg_lw1[k] = L.lw0[i];
         }
     }
-    __syncthreads();
+}
 
-    /* ---- P6: vithist_prune: the entries at or above the threshold, best first ---- */
+/* the K-th largest (K >= 1) of vals[0..n): radix select, 4 passes of 8 bits; also how many are greater / equal */
+__device__ __forceinline__ void
+wl_select(const int32_t *vals, int32_t n, int32_t K, int32_t &V, int32_t &n_gt, int32_t &n_eq)
+{
+    __shared__ int32_t sh_hist[256];
+    __shared__ uint32_t sh_prefix;
+    __shared__ int32_t sh_k, sh_cnt[2];
+    const int32_t tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) { sh_prefix = 0u; sh_k = K; sh_cnt[0] = 0; sh_cnt[1] = 0; }
+    uint32_t mask = 0u;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) sh_hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = sh_prefix;
+        for (int32_t i = tid; i < n; i += WL_THREADS) {
+            const uint32_t u = (uint32_t)vals[i] ^ 0x80000000u;
+            if ((u & mask) == prefix) atomicAdd(&sh_hist[(u >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int32_t acc = 0, k = sh_k, b;
+            for (b = 255; b > 0; b--) { if (acc + sh_hist[b] >= k) break; acc += sh_hist[b]; }
+            sh_k = k - acc;
+            sh_prefix = prefix | ((uint32_t)b << shift);
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const uint32_t vu = sh_prefix;
+    int32_t g = 0, e = 0;
+    for (int32_t i = tid; i < n; i += WL_THREADS) {
+        const uint32_t u = (uint32_t)vals[i] ^ 0x80000000u;
+        g += u > vu ? 1 : 0; e += u == vu ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); e += __shfl_xor(e, o, 64); }
+    if ((tid & 63) == 0) { atomicAdd(&sh_cnt[0], g); atomicAdd(&sh_cnt[1], e); }
+    __syncthreads();
+    V = (int32_t)(vu ^ 0x80000000u); n_gt = sh_cnt[0]; n_eq = sh_cnt[1];
+    __syncthreads();
+}
+
+/* P6 + P7: vithist_prune, vithist_frame_gc, srch_utt_word_trans, vithist_frame_windup; arms the lane's next frame.
+ * One workgroup.  M = the frame's best score, n_new = entries staged. */
+__device__ __forceinline__ void
+wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, int32_t cf,
+          int32_t nx, int32_t n_new, int32_t M)
+{
+    __shared__ int32_t s_i[16];
+    __shared__ unsigned long long s_ci[256];
+    __shared__ unsigned long long s_u64[2];
+    __shared__ int32_t s_heap[6 * WL_HEAP_LDS];
+    const int32_t tid = threadIdx.x, T = par.T;
+    const int32_t fs = L.st[0];
+    int32_t *sg_wid = L.sg, *sg_sf = L.sg + L.new_cap, *sg_ascr = L.sg + 2 * L.new_cap, *sg_lscr = L.sg + 3 * L.new_cap,
+        *sg_score = L.sg + 4 * L.new_cap, *sg_pred = L.sg + 5 * L.new_cap, *sg_type = L.sg + 6 * L.new_cap,
+        *sg_lw0 = L.sg + 7 * L.new_cap, *sg_lw1 = L.sg + 8 * L.new_cap, *sg_slot = L.sg + 9 * L.new_cap,
+        *sg_valid = L.sg + 10 * L.new_cap;
     const int32_t prune_beam = add32(pack[3 * T + 2], -pack[3 * T + 4]);    /* word_thres - bestwordscore */
     const int32_t th = add32(M, prune_beam);
     int32_t *a_list = L.srt, *a_sorted = L.srt + L.new_cap, *a_c = L.srt + 2 * L.new_cap, *a_scan = L.srt + 3 * L.new_cap,
-        *a_first = L.srt + 4 * L.new_cap;
-    if (tid == 0) { s_i[1] = 0; s_i[2] = 0; s_i[3] = INT_MAX; }
+        *a_first = L.srt + 4 * L.new_cap, *a_val = L.srt + 5 * L.new_cap;
+    __syncthreads();
+    if (tid == 0) { s_i[1] = 0; s_i[2] = 0; s_i[3] = INT_MAX; s_i[5] = 0; s_i[6] = 0; s_i[7] = INT_MIN; s_i[8] = 0; s_i[9] = 0; s_i[10] = 0; }
     for (int32_t k = tid; k < n_new; k += WL_THREADS) sg_valid[k] = 0;
     __syncthreads();
     for (int32_t k = tid; k < n_new; k += WL_THREADS)
         if (sg_score[k] >= th) a_list[atomicAdd(&s_i[1], 1)] = k;
     __syncthreads();
     const int32_t n_th = s_i[1];
-    for (int32_t q = tid; q < n_th; q += WL_THREADS) {
-        const int32_t k = a_list[q], s = sg_score[k];
-        int32_t r = 0, tie = 0;
-        for (int32_t p = 0; p < n_th; p++) {
-            const int32_t k2 = a_list[p], s2 = sg_score[k2];
-            r += (s2 > s || (s2 == s && k2 < k)) ? 1 : 0;
-            tie |= (s2 == s && k2 != k) ? 1 : 0;
-        }
-        a_sorted[r] = k;
-        if (tie) s_i[2] = 1;
-    }
-    __syncthreads();
-    if (s_i[2] && par.maxhist > 0) {
-        /* two entries above the threshold tie: their pop order is the heap's.  Replay it (one thread):
-         * every entry of the frame inserted in table order, then popped until the threshold */
-        if (tid == 0) {
-            WlHeap hp;
-            int32_t *base = n_new <= WL_HEAP_LDS ? s_heap : L.heap;
-            const int32_t stride = n_new <= WL_HEAP_LDS ? WL_HEAP_LDS : L.new_cap;
-            hp.val = base; hp.data = base + stride; hp.nl = base + 2 * stride; hp.nr = base + 3 * stride;
-            hp.l = base + 4 * stride; hp.r = base + 5 * stride; hp.n_alloc = 0; hp.top = -1;
-            for (int32_t k = 0; k < n_new; k++) hp.insert(k, (int32_t)(0u - (uint32_t)sg_score[k]));
-            for (int32_t r = 0; r < n_th; r++) a_sorted[r] = hp.pop();
-            ctx->n_tie_frames++;
+    bool done = false;
+    if (n_th > WL_RANK_MAX && par.maxhist > 0 && par.maxwpf > 0) {
+        /* ---- many entries above the threshold: vithist_prune by SELECTION instead of sorting.  The walk of
+         * vithist.c:683-713 keeps (a) the best filler entry, (b) the maxwpf distinct words whose best entries score
+         * highest, (c) of those words every entry (only the best with -bghist), (d) of all these the maxhist best.
+         * Each is a maximum or a K-th largest value -- unless two candidates TIE exactly at one of the four cuts: then
+         * the heap's pop order decides, and the frame falls through to the replay below. ---- */
+        int32_t sens = 0;
+        /* (a) */
+        for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+            const int32_t k = a_list[q];
+            if (dict.is_filler[sg_wid[k]]) atomicMax(&s_i[7], sg_score[k]);
         }
         __syncthreads();
+        const int32_t fmax = s_i[7];
+        for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+            const int32_t k = a_list[q];
+            if (dict.is_filler[sg_wid[k]] && sg_score[k] == fmax) { atomicAdd(&s_i[8], 1); s_i[9] = k; }
+        }
+        __syncthreads();
+        if (s_i[8] > 1) sens = 1;
+        const int32_t ff = s_i[8] == 1 ? s_i[9] : -1;
+        /* (b) the words' best scores */
+        for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+            const int32_t k = a_list[q], w = sg_wid[k];
+            if (dict.is_filler[w] && k != ff) continue;
+            if (atomicMax(&L.wbest[w], sg_score[k]) == INT_MIN) a_sorted[atomicAdd(&s_i[5], 1)] = w;     /* first touch: a distinct word */
+        }
+        __syncthreads();
+        const int32_t n_words = s_i[5];
+        for (int32_t i = tid; i < n_words; i += WL_THREADS) a_val[i] = WL_ALOAD(&L.wbest[a_sorted[i]]);
+        __syncthreads();
+        int32_t wcut = INT_MIN;                         /* words with a best score >= wcut are kept */
+        if (n_words > par.maxwpf) {
+            int32_t g, e;
+            wl_select(a_val, n_words, par.maxwpf, wcut, g, e);
+            if (g + e != par.maxwpf) sens = 1;
+        }
+        /* (c) the candidates of the final cut */
+        for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+            const int32_t k = a_list[q], w = sg_wid[k];
+            int32_t c = 0;
+            if (!(dict.is_filler[w] && k != ff)) {
+                const int32_t wb = WL_ALOAD(&L.wbest[w]);
+                if (wb >= wcut) {
+                    if (!par.bghist) c = 1;
+                    else if (sg_score[k] == wb) { c = 1; if (atomicAdd(&L.wfirst[w], 1) != INT_MAX) s_i[10] = 1; }   /* two best entries of a word */
+                }
+            }
+            if (c) a_first[atomicAdd(&s_i[6], 1)] = k;
+        }
+        __syncthreads();
+        if (s_i[10]) sens = 1;
+        const int32_t n_c = s_i[6];
+        for (int32_t i = tid; i < n_words; i += WL_THREADS) { L.wbest[a_sorted[i]] = INT_MIN; L.wfirst[a_sorted[i]] = INT_MAX; }
+        for (int32_t i = tid; i < n_c; i += WL_THREADS) a_val[i] = sg_score[a_first[i]];
+        __syncthreads();
+        /* (d) */
+        int32_t hcut = INT_MIN;
+        if (n_c > par.maxhist) {
+            int32_t g, e;
+            wl_select(a_val, n_c, par.maxhist, hcut, g, e);
+            if (g + e != par.maxhist) sens = 1;
+        }
+        if (!sens) {
+            for (int32_t i = tid; i < n_c; i += WL_THREADS) if (a_val[i] >= hcut) sg_valid[a_first[i]] = 1;
+            done = true;
+        }
+        else if (tid == 0) ctx->n_tie_frames++;
+        __syncthreads();
     }
-    /* the walk of vithist.c:683-713 over the sorted entries, in closed form:
-     *  - only the first filler entry counts ("keep only one best filler word entry per frame");
-     *  - the distinct words in order of first appearance: the first maxwpf of them are kept;
-     *  - of a kept word, its first entry, and (unless -bghist) its others;
-     *  - the first maxhist such entries are valid. */
-    for (int32_t r = tid; r < n_th; r += WL_THREADS)
-        if (dict.is_filler[sg_wid[a_sorted[r]]]) atomicMin(&s_i[3], r);
-    __syncthreads();
-    const int32_t first_filler = s_i[3];
-    for (int32_t r = tid; r < n_th; r += WL_THREADS) {
-        const int32_t w = sg_wid[a_sorted[r]];
-        if (!(dict.is_filler[w] && r > first_filler)) atomicMin(&L.wfirst[w], r);
+    if (!done) {
+        /* ---- rank by score; two entries above the threshold that tie pop in the heap's order: replay it ---- */
+        if (n_th <= WL_RANK_MAX) {
+            for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+                const int32_t k = a_list[q], sc = sg_score[k];
+                int32_t r = 0, tie = 0;
+                for (int32_t p = 0; p < n_th; p++) {
+                    const int32_t k2 = a_list[p], s2 = sg_score[k2];
+                    r += (s2 > sc || (s2 == sc && k2 < k)) ? 1 : 0;
+                    tie |= (s2 == sc && k2 != k) ? 1 : 0;
+                }
+                a_sorted[r] = k;
+                if (tie) s_i[2] = 1;
+            }
+            __syncthreads();
+        }
+        else if (tid == 0) s_i[2] = 1;
+        __syncthreads();
+        if (s_i[2] && par.maxhist > 0) {
+            if (tid == 0) {
+                WlHeap hp;
+                int32_t *base = n_new <= WL_HEAP_LDS ? s_heap : L.heap;
+                const int32_t stride = n_new <= WL_HEAP_LDS ? WL_HEAP_LDS : L.new_cap;
+                hp.val = base; hp.data = base + stride; hp.nl = base + 2 * stride; hp.nr = base + 3 * stride;
+                hp.l = base + 4 * stride; hp.r = base + 5 * stride; hp.n_alloc = 0; hp.top = -1;
+                for (int32_t k = 0; k < n_new; k++) hp.insert(k, (int32_t)(0u - (uint32_t)sg_score[k]));
+                for (int32_t r = 0; r < n_th; r++) a_sorted[r] = hp.pop();
+                if (n_th <= WL_RANK_MAX) ctx->n_tie_frames++;
+            }
+            __syncthreads();
+        }
+        /* the walk of vithist.c:683-713 over the sorted entries, in closed form */
+        for (int32_t r = tid; r < n_th; r += WL_THREADS)
+            if (dict.is_filler[sg_wid[a_sorted[r]]]) atomicMin(&s_i[3], r);
+        __syncthreads();
+        const int32_t first_filler = s_i[3];
+        for (int32_t r = tid; r < n_th; r += WL_THREADS) {
+            const int32_t w = sg_wid[a_sorted[r]];
+            if (!(dict.is_filler[w] && r > first_filler)) atomicMin(&L.wfirst[w], r);
+        }
+        __syncthreads();
+        for (int32_t r = tid; r < n_th; r += WL_THREADS) {
+            const int32_t w = sg_wid[a_sorted[r]];
+            const bool elig = !(dict.is_filler[w] && r > first_filler);
+            const int32_t f = elig ? WL_ALOAD(&L.wfirst[w]) : -1;
+            a_first[r] = f;
+            a_c[r] = (elig && f == r) ? 1 : 0;
+        }
+        (void)wl_scan<false>(a_c, a_scan, n_th, 0);         /* a_scan[r] = index of the word first seen at r */
+        for (int32_t r = tid; r < n_th; r += WL_THREADS) {
+            const int32_t f = a_first[r];
+            int32_t c = 0;
+            if (f >= 0 && a_scan[f] < par.maxwpf && (f == r || !par.bghist)) c = 1;
+            a_c[r] = c;
+        }
+        __syncthreads();
+        for (int32_t r = tid; r < n_th; r += WL_THREADS) L.wfirst[sg_wid[a_sorted[r]]] = INT_MAX;
+        (void)wl_scan<false>(a_c, a_first, n_th, 0);        /* entries kept before r */
+        for (int32_t r = tid; r < n_th; r += WL_THREADS)
+            if (a_c[r] && a_first[r] < par.maxhist) sg_valid[a_sorted[r]] = 1;
+        __syncthreads();
     }
-    __syncthreads();
-    for (int32_t r = tid; r < n_th; r += WL_THREADS) {
-        const int32_t w = sg_wid[a_sorted[r]];
-        const bool elig = !(dict.is_filler[w] && r > first_filler);
-        const int32_t f = elig ? WL_ALOAD(&L.wfirst[w]) : -1;
-        a_first[r] = f;
-        a_c[r] = (elig && f == r) ? 1 : 0;
-    }
-    (void)wl_scan<false>(a_c, a_scan, n_th, 0);         /* a_scan[r] = index of the word first seen at r */
-    for (int32_t r = tid; r < n_th; r += WL_THREADS) {
-        const int32_t f = a_first[r];
-        int32_t c = 0;
-        if (f >= 0 && a_scan[f] < par.maxwpf && (f == r || !par.bghist)) c = 1;
-        a_c[r] = c;
-    }
-    __syncthreads();
-    for (int32_t r = tid; r < n_th; r += WL_THREADS) L.wfirst[sg_wid[a_sorted[r]]] = INT_MAX;
-    (void)wl_scan<false>(a_c, a_first, n_th, 0);        /* entries kept before r */
-    for (int32_t r = tid; r < n_th; r += WL_THREADS)
-        if (a_c[r] && a_first[r] < par.maxhist) sg_valid[a_sorted[r]] = 1;
-    __syncthreads();
     /* vithist_frame_gc: the valid entries, in table order, become the frame's entries */
     const int32_t n_valid = wl_scan<false>(sg_valid, a_scan, n_new, 0);
     if (tid == 0) { s_u64[0] = 0ull; }
@@ -590,6 +734,181 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         ctx->cur ^= 1;                                  /* lextree_active_swap */
         if (cf + 1 >= ctx->nfr || e2) ctx->active = 0;
     }
+}
+
+/* errors that end the utterance (as the reference's E_FATAL / SRCH_FAILURE do) */
+__device__ __forceinline__ void
+wl_stop(UCtx *ctx, int32_t err)
+{
+    if (threadIdx.x == 0) { ctx->err |= err; ctx->active = 0; }
+}
+
+__device__ __forceinline__ bool
+wl_check_caps(const WLane &L, UCtx *ctx, int32_t n_cand)
+{
+    const bool over = n_cand > L.cand_cap || 2 * (long long)n_cand > (long long)L.hmask + 1;
+    if (threadIdx.x == 0 && n_cand > ctx->max_cand) ctx->max_cand = n_cand;
+    if (over) wl_stop(ctx, WL_E_CAND);
+    return !over;
+}
+
+__device__ __forceinline__ bool
+wl_check_new(const WLane &L, UCtx *ctx, int32_t n_new)
+{
+    const bool over = n_new > L.new_cap || (long long)L.st[0] + n_new > L.cap;
+    if (threadIdx.x == 0 && n_new > ctx->max_new) ctx->max_new = n_new;
+    if (over) wl_stop(ctx, WL_E_TABLE);
+    return !over;
+}
+
+/* the whole frame by ONE workgroup */
+__device__ __forceinline__ void
+d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, const int32_t cf)
+{
+    __shared__ int32_t s_tb[WL_MAXT + 1];
+    __shared__ int32_t s_flag[2];
+    __shared__ int32_t s_ex[3 * WL_LDS_EX], s_off[WL_LDS_EX + 1];    /* the usual frame: exits + candidate offsets in LDS */
+    const int32_t T = par.T, hdr = 6 * T + 16;
+    const int32_t *ex = pack + hdr;
+    int32_t *off = L.ex_off;
+    int32_t nx0 = 0;
+    for (int32_t t = 0; t < T; t++) nx0 += pack[3 * T + 8 + t];
+    if (threadIdx.x == 0) s_flag[1] = 0;
+    if (nx0 <= WL_LDS_EX) {
+        for (int32_t i = threadIdx.x; i < 3 * nx0; i += WL_THREADS) s_ex[i] = ex[i];
+        __syncthreads();
+        ex = s_ex;
+        off = s_off;
+    }
+    const int32_t n_cand = wl_p1(L, pack, dict, T, s_tb, off, ex, &s_flag[0]);
+    if (n_cand < 0) { wl_stop(ctx, s_flag[0]); return; }
+    if (!wl_check_caps(L, ctx, n_cand)) return;
+    WlFr fr;
+    fr.ex = ex; fr.off = off; fr.tb = s_tb; fr.nx = s_tb[T]; fr.n_cand = n_cand; fr.cf = cf;
+    const int32_t M = wl_p2(L, lm, dict, fr, 0, n_cand, &s_flag[1]);
+    if (s_flag[1]) { wl_stop(ctx, WL_E_NOLM); return; }
+    wl_p3(L, dict, par, fr, 0, n_cand, INT_MIN);
+    __syncthreads();
+    const int32_t n_new = wl_p4a(L, 0, n_cand);
+    if (!wl_check_new(L, ctx, n_new)) return;
+    wl_p4b(L, 0, n_cand, 0);
+    __syncthreads();
+    wl_p5(L, dict, par, fr, 0, n_cand);
+    __syncthreads();
+    wl_finish(L, ctx, pack, lm, dict, par, cf, fr.nx, n_new, M);
+}
+
+/* ---- the same frame as a sequence of launches, G workgroups per lane (wide-beam frames) ---- */
+__device__ __forceinline__ void
+wl_chunk(int32_t n_cand, int32_t g, int32_t G, int32_t &c_lo, int32_t &c_hi)
+{
+    const int32_t per = ((n_cand + G - 1) / G + 63) & ~63;
+    c_lo = min(n_cand, g * per); c_hi = min(n_cand, c_lo + per);
+}
+
+/* launch A (one workgroup per lane; after d_dec_pack_frame): P1 */
+__device__ __forceinline__ void
+d_wl_big_begin(const WLane &L, UCtx *ctx, const int32_t *pack, const WDict &dict, const WPar &par)
+{
+    __shared__ int32_t s_tb[WL_MAXT + 1];
+    __shared__ int32_t s_flag[2];
+    const int32_t T = par.T, hdr = 6 * T + 16;
+    if (threadIdx.x == 0) L.st[8] = 1;                  /* stop, until this launch got through */
+    const int32_t n_cand = wl_p1(L, pack, dict, T, s_tb, L.ex_off, pack + hdr, &s_flag[0]);
+    if (n_cand < 0) { wl_stop(ctx, s_flag[0]); return; }
+    if (!wl_check_caps(L, ctx, n_cand)) return;
+    if (threadIdx.x <= T) L.tb[threadIdx.x] = s_tb[threadIdx.x];
+    if (threadIdx.x == 0) { L.st[4] = s_tb[T]; L.st[5] = n_cand; L.st[8] = 0; }
+}
+
+#define WL_BIG_FRAME                                                                                       \
+    if (L.st[8]) return;                                                                                   \
+    WlFr fr;                                                                                               \
+    fr.ex = pack + 6 * par.T + 16; fr.off = L.ex_off; fr.tb = L.tb; fr.nx = L.st[4]; fr.n_cand = L.st[5]; fr.cf = cf; \
+    int32_t c_lo, c_hi;                                                                                    \
+    wl_chunk(fr.n_cand, g, G, c_lo, c_hi)
+
+/* launch B: P2 for chunk g; part[g] = the chunk's best score */
+__device__ __forceinline__ void
+d_wl_big_p2(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, int32_t cf,
+            int32_t g, int32_t G)
+{
+    __shared__ int32_t s_bad;
+    WL_BIG_FRAME;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    const int32_t m = wl_p2(L, lm, dict, fr, c_lo, c_hi, &s_bad);
+    if (threadIdx.x == 0) { L.part[g] = m; if (s_bad) atomicOr(&ctx->err, WL_E_NOLM); }
+}
+
+/* launch C: P3 for chunk g (the best score in front of the chunk = max of the earlier chunks' bests) */
+__device__ __forceinline__ void
+d_wl_big_p3(const WLane &L, UCtx *ctx, const int32_t *pack, const WDict &dict, const WPar &par, int32_t cf, int32_t g, int32_t G)
+{
+    __shared__ int32_t s_m[2];
+    WL_BIG_FRAME;
+    if (ctx->err & WL_E_NOLM) return;
+    if (threadIdx.x == 0) { s_m[0] = INT_MIN; s_m[1] = INT_MIN; }
+    __syncthreads();
+    int32_t before = INT_MIN, all = INT_MIN;
+    for (int32_t q = threadIdx.x; q < G; q += WL_THREADS) { const int32_t v = L.part[q]; all = max(all, v); if (q < g) before = max(before, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before = max(before, __shfl_xor(before, o, 64)); all = max(all, __shfl_xor(all, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&s_m[0], before); atomicMax(&s_m[1], all); }
+    __syncthreads();
+    if (g == 0 && threadIdx.x == 0) L.st[6] = s_m[1];
+    wl_p3(L, dict, par, fr, c_lo, c_hi, s_m[0]);
+}
+
+/* launch D: P4a for chunk g; part2[g] = entries founded in the chunk */
+__device__ __forceinline__ void
+d_wl_big_p4a(const WLane &L, UCtx *ctx, const int32_t *pack, const WPar &par, int32_t cf, int32_t g, int32_t G)
+{
+    WL_BIG_FRAME;
+    if (ctx->err & WL_E_NOLM) return;
+    const int32_t n = wl_p4a(L, c_lo, c_hi);
+    if (threadIdx.x == 0) L.part2[g] = n;
+}
+
+/* launch E: P4b for chunk g */
+__device__ __forceinline__ void
+d_wl_big_p4b(const WLane &L, UCtx *ctx, const int32_t *pack, const WPar &par, int32_t cf, int32_t g, int32_t G)
+{
+    __shared__ int32_t s_n[2];
+    WL_BIG_FRAME;
+    if (ctx->err & WL_E_NOLM) return;
+    if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; }
+    __syncthreads();
+    int32_t before = 0, all = 0;
+    for (int32_t q = threadIdx.x; q < G; q += WL_THREADS) { const int32_t v = L.part2[q]; all += v; if (q < g) before += v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); all += __shfl_xor(all, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_n[0], before); atomicAdd(&s_n[1], all); }
+    __syncthreads();
+    if (g == 0 && threadIdx.x == 0) L.st[7] = s_n[1];
+    if (s_n[1] > L.new_cap || (long long)L.st[0] + s_n[1] > L.cap) return;       /* (the last launch reports it) */
+    wl_p4b(L, c_lo, c_hi, s_n[0]);
+}
+
+/* launch F: P5 for chunk g */
+__device__ __forceinline__ void
+d_wl_big_p5(const WLane &L, UCtx *ctx, const int32_t *pack, const WDict &dict, const WPar &par, int32_t cf, int32_t g, int32_t G)
+{
+    WL_BIG_FRAME;
+    if (ctx->err & WL_E_NOLM) return;
+    if (L.st[7] > L.new_cap || (long long)L.st[0] + L.st[7] > L.cap) return;
+    wl_p5(L, dict, par, fr, c_lo, c_hi);
+}
+
+/* launch G (one workgroup per lane): P6 + P7 */
+__device__ __forceinline__ void
+d_wl_big_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, int32_t cf)
+{
+    if (L.st[8]) return;
+    if (ctx->err & WL_E_NOLM) { wl_stop(ctx, WL_E_NOLM); return; }
+    const int32_t n_new = L.st[7];
+    if (!wl_check_new(L, ctx, n_new)) return;
+    wl_finish(L, ctx, pack, lm, dict, par, cf, L.st[4], n_new, L.st[6]);
 }
 
 #endif

@@ -1280,8 +1280,8 @@ class UttDec:
 
     def profile(self):
         """{kernel class: (summed microseconds, timed launches)} since set_profile"""
-        us = (C.c_double * 16)(); n = (C.c_int64 * 16)(); names = (C.c_char_p * 16)()
-        k = self.L.s3a_uttdec_profile(self.h, us, n, names, 16)
+        us = (C.c_double * 24)(); n = (C.c_int64 * 24)(); names = (C.c_char_p * 24)()
+        k = self.L.s3a_uttdec_profile(self.h, us, n, names, 24)
         return {names[i].decode(): (us[i], n[i]) for i in range(k) if n[i]}
 
     def hyp(self, lane, uttid="", utt_index=0):

@@ -120,10 +120,10 @@ class OracleWordLevel:
         return out
 
 
-def random_task(rng, n_word=40, n_ci=8, n_filler=3, density=0.3):
+def random_task(rng, n_word=40, n_ci=8, n_filler=3, density=0.3, grid=100):
     """A small random trigram + dictionary in the trace's layout (scores on a coarse grid, so that ties are common)."""
     n_ug = n_word - n_filler + 2                    # words + <s> </s>
-    ug_prob = (rng.integers(-60, -5, n_ug) * 100).astype(np.int32)
+    ug_prob = (rng.integers(-60, -5, n_ug) * 100 + rng.integers(0, 100, n_ug) // grid * grid).astype(np.int32)
     ug_bowt = (rng.integers(-20, 0, n_ug) * 100).astype(np.int32)
     bg_w, bg_p, bg_b, firstbg, tg_w, tg_p, firsttg = [], [], [], [0], [], [], []
     for w1 in range(n_ug):
@@ -151,7 +151,7 @@ def random_task(rng, n_word=40, n_ci=8, n_filler=3, density=0.3):
                 last_ci=last_ci)
 
 
-def random_frame(rng, ow, frm, n_tree=6, max_exits=14):
+def random_frame(rng, ow, frm, n_tree=6, max_exits=14, grid=100):
     """Random word exits whose predecessors are existing history entries; scores on a coarse grid."""
     vh = ow.vh.contents
     n_hist = vh.n_entry
@@ -166,6 +166,6 @@ def random_frame(rng, ow, frm, n_tree=6, max_exits=14):
         else:
             wid = rng.integers(0, n_word - n_filler, n)
         hist = rng.integers(0, n_hist, len(wid))
-        scr = (rng.integers(-90, -40, len(wid)) * 100 - 3000 * frm).astype(np.int32)
+        scr = (rng.integers(-9000, -4000, len(wid)) // grid * grid - 3000 * frm).astype(np.int32)
         trees.append((-1 if filler_tree else 0, wid.astype(np.int32), scr, hist.astype(np.int32)))
     return trees

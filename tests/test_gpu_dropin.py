@@ -113,13 +113,15 @@ DRIVERS = {
     # s3a_uttdec_*: WHOLE utterances on the device (word level, history table, trigram included), one kb_t
     "utt_1": {"S3A_UTT": "1"},
     "utt_4": {"S3A_UTT": "4"},
+    "utt_3_bigwl": {"S3A_UTT": "3", "S3A_UTT_BIGWL": "1"},      # the word level's candidate phases as chip-wide launches
 }
 
 
 @pytest.mark.parametrize("name,driver", [("mode4_trigram", "one_decoder"), ("mode4_cibeam_ds2", "one_decoder"),
                                          ("mode4_trigram", "four_streams"), ("mode4_trigram", "batched_4x1"),
                                          ("mode4_cibeam_ds2", "batched_6x2"), ("mode4_trigram", "utt_1"),
-                                         ("mode4_trigram", "utt_4"), ("mode4_cibeam_ds2", "utt_4")])
+                                         ("mode4_trigram", "utt_4"), ("mode4_cibeam_ds2", "utt_4"),
+                                         ("mode4_trigram", "utt_3_bigwl")])
 def test_full_device_search_matches_reference(name, driver, tmp_path):
     hyp, seg, log = (str(tmp_path / f"tst_{name}.{e}") for e in ("match", "matchseg", "log"))
     with open(log, "w") as lf:
@@ -277,7 +279,7 @@ def decode_task(exe, args, tmp_path, tag, env=None):
     return open(hyp).read(), open(seg).read(), tail
 
 
-@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4"])
+@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4", "utt_3_bigwl"])
 def test_hub4_shaped_full_decode_matches_reference(driver, tmp_path):
     args = synth_task("hub4", tmp_path, 4, 250)
     ref = decode_task(REFDEC, args, tmp_path, "ref")

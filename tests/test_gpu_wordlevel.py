@@ -82,3 +82,21 @@ def test_random_frames_with_tied_scores_lockstep(gpu_lib, seed, kw):
     fr = [((lambda ow, frm, r=rng: OW.random_frame(r, ow, frm)), int(rng.integers(-6, -1)) * 1000, -123456 - 7 * i) for i in range(160)]
     a, b, n_calls = run_lockstep(gpu_lib, t, fr, tree_type, **kw)
     assert b["n_tie_frames"] > 20 and len(b["score"]) > 150 and n_calls > 100
+
+
+@pytest.mark.parametrize("seed,grid,kw", [(11, 1, dict(maxwpf=5, maxhist=12)), (12, 1, dict(maxwpf=40, maxhist=30)),
+                                          (13, 10, dict(maxwpf=7, maxhist=100)), (14, 1, dict(maxwpf=6, maxhist=9))])
+def test_large_frames_prune_by_selection_lockstep(gpu_lib, seed, grid, kw):
+    """hundreds of entries above the pruning threshold: the device prunes by selection (best filler, the maxwpf best
+    words, the maxhist best of their entries) and replays the heap only when a cut falls on a tie (grid 10: often)."""
+    rng = np.random.default_rng(seed)
+    t = OW.random_task(rng, n_word=500, n_ci=12, density=0.04, grid=grid)
+    t["wbeam"] = -60000
+    if seed == 14:
+        t["bghist"] = 1
+    tree_type = [0, 0, 0, -1, -1, -1]
+    fr = [((lambda ow, frm, r=rng: OW.random_frame(r, ow, frm, max_exits=260, grid=grid)), -50000, -123456 - 7 * i) for i in range(40)]
+    a, b, n_calls = run_lockstep(gpu_lib, t, fr, tree_type, cap=1 << 18, cand_cap=1 << 19, **kw)
+    assert len(b["score"]) > 300
+    if grid == 10:
+        assert b["n_tie_frames"] > 0
