@@ -450,46 +450,75 @@ wl_p5(const WLane &L, const WDict &dict, const WPar &par, const WlFr &fr, int32_
     }
 }
 
-/* the K-th largest (K >= 1) of vals[0..n): radix select, 4 passes of 8 bits; also how many are greater / equal */
+/* ordered append to a list whose length lives in shared memory: one atomic per wave.  Every lane of the wave calls. */
+__device__ __forceinline__ int32_t
+wl_append(int32_t *counter, bool pred)
+{
+    const unsigned long long m = __ballot(pred);
+    if (!m) return -1;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader, 64);
+    return pred ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
+/* the K-th largest (K >= 1) of vals[0..n), and how many are greater / equal: radix select on (max - value), eight
+ * bits at a time from the highest bit the values differ in (scores of one frame share their high bits: a fixed
+ * 32-bit radix would send every key to one histogram bin for two passes) */
 __device__ __forceinline__ void
 wl_select(const int32_t *vals, int32_t n, int32_t K, int32_t &V, int32_t &n_gt, int32_t &n_eq)
 {
     __shared__ int32_t sh_hist[256];
     __shared__ uint32_t sh_prefix;
-    __shared__ int32_t sh_k, sh_cnt[2];
+    __shared__ int32_t sh_k, sh_cnt[2], sh_mm[2];
     const int32_t tid = threadIdx.x;
     __syncthreads();
-    if (tid == 0) { sh_prefix = 0u; sh_k = K; sh_cnt[0] = 0; sh_cnt[1] = 0; }
+    if (tid == 0) { sh_prefix = 0u; sh_k = K; sh_cnt[0] = 0; sh_cnt[1] = 0; sh_mm[0] = INT_MIN; sh_mm[1] = INT_MAX; }
+    __syncthreads();
+    {
+        int32_t mx = INT_MIN, mn = INT_MAX;
+        for (int32_t i = tid; i < n; i += WL_THREADS) { const int32_t v = vals[i]; mx = max(mx, v); mn = min(mn, v); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o, 64)); mn = min(mn, __shfl_xor(mn, o, 64)); }
+        if ((tid & 63) == 0) { atomicMax(&sh_mm[0], mx); atomicMin(&sh_mm[1], mn); }
+    }
+    __syncthreads();
+    const int32_t vmax = sh_mm[0];
+    const uint32_t range = (uint32_t)vmax - (uint32_t)sh_mm[1];
+    int bits = 32 - __clz((int)(range | 1u));               /* keys u = vmax - v lie in [0, 2^bits) */
+    bits = (bits + 7) & ~7;
     uint32_t mask = 0u;
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    /* the K-th SMALLEST key */
+    for (int shift = bits - 8; shift >= 0; shift -= 8) {
         if (tid < 256) sh_hist[tid] = 0;
         __syncthreads();
         const uint32_t prefix = sh_prefix;
         for (int32_t i = tid; i < n; i += WL_THREADS) {
-            const uint32_t u = (uint32_t)vals[i] ^ 0x80000000u;
+            const uint32_t u = (uint32_t)vmax - (uint32_t)vals[i];
             if ((u & mask) == prefix) atomicAdd(&sh_hist[(u >> shift) & 255u], 1);
         }
         __syncthreads();
         if (tid == 0) {
             int32_t acc = 0, k = sh_k, b;
-            for (b = 255; b > 0; b--) { if (acc + sh_hist[b] >= k) break; acc += sh_hist[b]; }
+            for (b = 0; b < 255; b++) { if (acc + sh_hist[b] >= k) break; acc += sh_hist[b]; }
             sh_k = k - acc;
             sh_prefix = prefix | ((uint32_t)b << shift);
         }
         mask |= 255u << shift;
         __syncthreads();
     }
-    const uint32_t vu = sh_prefix;
+    const uint32_t ku = sh_prefix;
     int32_t g = 0, e = 0;
     for (int32_t i = tid; i < n; i += WL_THREADS) {
-        const uint32_t u = (uint32_t)vals[i] ^ 0x80000000u;
-        g += u > vu ? 1 : 0; e += u == vu ? 1 : 0;
+        const uint32_t u = (uint32_t)vmax - (uint32_t)vals[i];
+        g += u < ku ? 1 : 0; e += u == ku ? 1 : 0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); e += __shfl_xor(e, o, 64); }
     if ((tid & 63) == 0) { atomicAdd(&sh_cnt[0], g); atomicAdd(&sh_cnt[1], e); }
     __syncthreads();
-    V = (int32_t)(vu ^ 0x80000000u); n_gt = sh_cnt[0]; n_eq = sh_cnt[1];
+    V = (int32_t)((uint32_t)vmax - ku); n_gt = sh_cnt[0]; n_eq = sh_cnt[1];
     __syncthreads();
 }
 
@@ -517,8 +546,11 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
     if (tid == 0) { s_i[1] = 0; s_i[2] = 0; s_i[3] = INT_MAX; s_i[5] = 0; s_i[6] = 0; s_i[7] = INT_MIN; s_i[8] = 0; s_i[9] = 0; s_i[10] = 0; }
     for (int32_t k = tid; k < n_new; k += WL_THREADS) sg_valid[k] = 0;
     __syncthreads();
-    for (int32_t k = tid; k < n_new; k += WL_THREADS)
-        if (sg_score[k] >= th) a_list[atomicAdd(&s_i[1], 1)] = k;
+    for (int32_t k0 = 0; k0 < n_new; k0 += WL_THREADS) {
+        const int32_t k = k0 + tid;
+        const int32_t at = wl_append(&s_i[1], k < n_new && sg_score[k] >= th);
+        if (at >= 0) a_list[at] = k;
+    }
     __syncthreads();
     const int32_t n_th = s_i[1];
     bool done = false;
@@ -544,10 +576,17 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
         if (s_i[8] > 1) sens = 1;
         const int32_t ff = s_i[8] == 1 ? s_i[9] : -1;
         /* (b) the words' best scores */
-        for (int32_t q = tid; q < n_th; q += WL_THREADS) {
-            const int32_t k = a_list[q], w = sg_wid[k];
-            if (dict.is_filler[w] && k != ff) continue;
-            if (atomicMax(&L.wbest[w], sg_score[k]) == INT_MIN) a_sorted[atomicAdd(&s_i[5], 1)] = w;     /* first touch: a distinct word */
+        for (int32_t q0 = 0; q0 < n_th; q0 += WL_THREADS) {
+            const int32_t q = q0 + tid;
+            bool first = false;
+            int32_t w = 0;
+            if (q < n_th) {
+                const int32_t k = a_list[q];
+                w = sg_wid[k];
+                if (!(dict.is_filler[w] && k != ff)) first = atomicMax(&L.wbest[w], sg_score[k]) == INT_MIN;   /* first touch: a distinct word */
+            }
+            const int32_t at = wl_append(&s_i[5], first);
+            if (at >= 0) a_sorted[at] = w;
         }
         __syncthreads();
         const int32_t n_words = s_i[5];
@@ -560,17 +599,22 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
             if (g + e != par.maxwpf) sens = 1;
         }
         /* (c) the candidates of the final cut */
-        for (int32_t q = tid; q < n_th; q += WL_THREADS) {
-            const int32_t k = a_list[q], w = sg_wid[k];
-            int32_t c = 0;
-            if (!(dict.is_filler[w] && k != ff)) {
-                const int32_t wb = WL_ALOAD(&L.wbest[w]);
-                if (wb >= wcut) {
-                    if (!par.bghist) c = 1;
-                    else if (sg_score[k] == wb) { c = 1; if (atomicAdd(&L.wfirst[w], 1) != INT_MAX) s_i[10] = 1; }   /* two best entries of a word */
+        for (int32_t q0 = 0; q0 < n_th; q0 += WL_THREADS) {
+            const int32_t q = q0 + tid;
+            int32_t c = 0, k = 0;
+            if (q < n_th) {
+                k = a_list[q];
+                const int32_t w = sg_wid[k];
+                if (!(dict.is_filler[w] && k != ff)) {
+                    const int32_t wb = WL_ALOAD(&L.wbest[w]);
+                    if (wb >= wcut) {
+                        if (!par.bghist) c = 1;
+                        else if (sg_score[k] == wb) { c = 1; if (atomicAdd(&L.wfirst[w], 1) != INT_MAX) s_i[10] = 1; }   /* two best entries of a word */
+                    }
                 }
             }
-            if (c) a_first[atomicAdd(&s_i[6], 1)] = k;
+            const int32_t at = wl_append(&s_i[6], c != 0);
+            if (at >= 0) a_first[at] = k;
         }
         __syncthreads();
         if (s_i[10]) sens = 1;
