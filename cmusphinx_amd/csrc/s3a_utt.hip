@@ -624,7 +624,7 @@ wlane_free(WLane &w)
 {
     void *p[] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type, w.lmc, w.frame_start, w.bestscore,
                   w.bestvh, w.st, w.ex_off, w.cand_pref, w.cand_e, w.cand_score, w.cand_slot, w.hkey, w.hbest, w.hfirst,
-                  w.hlead_rank, w.sg, w.srt, w.wfirst, w.wbest, w.part, w.part2, w.tb, w.heap, w.fstat };
+                  w.hlead_rank, w.sg, w.srt, w.wfirst, w.wbest, w.part, w.part2, w.tb, w.heap, w.nrl, w.fstat };
     for (auto q : p) if (q) (void)hipFree(q);
     memset((void *)&w, 0, sizeof w);
 }
@@ -652,7 +652,7 @@ wlane_alloc(WLane &w, int32_t vh_cap, int32_t max_frames, int32_t ex_cap, int32_
     if (hipMemset(w.hkey, 0, hs * 8) != hipSuccess || hipMemset(w.hbest, 0, hs * 8) != hipSuccess
         || hipMemset(w.hfirst, 0xff, hs * 4) != hipSuccess) { s3a_set_error("s3a_utt: memset failed"); goto fail; }
     w.new_cap = new_cap;
-    DM(w.sg, (size_t)11 * new_cap * 4); DM(w.srt, (size_t)6 * new_cap * 4); DM(w.heap, (size_t)6 * new_cap * 4);
+    DM(w.sg, (size_t)11 * new_cap * 4); DM(w.srt, (size_t)6 * new_cap * 4); DM(w.heap, (size_t)18 * new_cap * 4); DM(w.nrl, (size_t)new_cap * 4);
     DM(w.wfirst, (size_t)n_word * 4); DM(w.wbest, (size_t)n_word * 4);
     DM(w.part, WL_BIG_G * 4); DM(w.part2, WL_BIG_G * 4); DM(w.tb, (WL_MAXT + 1) * 4);
     DM(w.fstat, (size_t)max_frames * 8 * 4);

@@ -101,7 +101,8 @@ struct WLane {              /* one lane's history table + per-frame scratch (dev
     int32_t *wfirst;        /* [n_word]: first sorted position of a word (INT_MAX when idle) */
     int32_t *wbest;         /* [n_word]: best score of a word's entries in the frame (INT_MIN when idle) */
     int32_t *part, *part2, *tb;     /* [WL_BIG_G] per-chunk partials of the wide-beam launches; [WL_MAXT + 1] */
-    int32_t *heap;          /* [6][new_cap] for the heap replay when it does not fit LDS */
+    int32_t *heap;          /* [18][new_cap] scratch of wl_heap_nrl */
+    int32_t *nrl;           /* [new_cap] pop order of a frame's staged entries among equal scores */
     int32_t *fstat;         /* [max_frames][8] per-frame statistics for the host */
 };
 
@@ -522,6 +523,100 @@ wl_select(const int32_t *vals, int32_t n, int32_t K, int32_t &V, int32_t &n_gt, 
     __syncthreads();
 }
 
+/*
+ * The pop order of the reference's heap among EQUAL values, in parallel.  sphinxbase's heap (util/heap.c) is a
+ * binary tree balanced by subtree counts, so its SHAPE depends on the number of inserts only: insert #i walks a
+ * fixed root-to-leaf path (arrival j >= 1 at a node goes left when j is odd, right when even, as arrival (j-1)/2
+ * there), pushing the larger of (node's value, carried value) down (strict >: on a tie the newcomer moves on).
+ * A node therefore keeps the minimum of its arrival stream (the earliest on ties) and sends, at arrival j, the
+ * loser of (minimum so far, arrival j) to a child: an exclusive prefix minimum per node -- one segmented scan per
+ * tree level builds the heap.  Popping merges the children's pop sequences, the right child's element first on a
+ * tie (subheap_pop, heap.c:159-200: `l->val < r->val` picks left): among equal values the pop order is the
+ * pre-order (node, right subtree, left subtree) of the BUILT heap.  nrl[k] = that pre-order number of the node
+ * that holds staged entry k after all inserts (subtree sizes = arrival counts).  One workgroup.
+ * Scratch hs: [18][stride] int32.  The heap's values are -score (vithist.c:669).
+ */
+__device__ __forceinline__ void
+wl_heap_nrl(const int32_t *sg_score, int32_t n, int32_t *hs, int32_t stride, int32_t *nrl)
+{
+    __shared__ unsigned long long sh_wk[WL_WAVES];
+    __shared__ int32_t sh_wf[WL_WAVES];
+    __shared__ unsigned long long sh_carry;
+    __shared__ int32_t sh_cnt;
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t *e_val[2] = { hs, hs + 3 * stride }, *e_id[2] = { hs + stride, hs + 4 * stride },
+        *e_node[2] = { hs + 2 * stride, hs + 5 * stride };
+    int32_t *len = hs + 6 * stride, *off = hs + 10 * stride, *nrlp = hs + 14 * stride;    /* [4 * stride] each, by node */
+    const unsigned long long NONE = ~0ull;
+    __syncthreads();
+    for (int32_t i = tid; i < n; i += WL_THREADS) {
+        e_val[0][i] = (int32_t)(0u - (uint32_t)sg_score[i]); e_id[0][i] = i; e_node[0][i] = 1;
+    }
+    if (tid == 0) { len[1] = n; off[1] = 0; nrlp[1] = 0; }
+    __syncthreads();
+    int32_t m = n, cur = 0;
+    for (int32_t d = 0; m > 0; d++, cur ^= 1) {
+        const int32_t P0 = 1 << d, P1 = 2 << d;
+        /* the children's arrival counts and pre-order numbers */
+        for (int32_t p = P0 + tid; p < P1; p += WL_THREADS) {
+            const int32_t Lp = len[p];
+            const int32_t ll = Lp > 0 ? Lp / 2 : 0, lr = Lp > 0 ? (Lp - 1) / 2 : 0;
+            len[2 * p] = ll; len[2 * p + 1] = lr;
+            nrlp[2 * p + 1] = nrlp[p] + 1; nrlp[2 * p] = nrlp[p] + 1 + lr;
+        }
+        __syncthreads();
+        const int32_t m_next = wl_scan<false>(len + P1, off + P1, P1, 0);      /* the next level's stream offsets */
+        /* exclusive segmented prefix minimum over this level's streams */
+        if (tid == 0) sh_carry = NONE;
+        __syncthreads();
+        for (int32_t base = 0; base < m; base += WL_THREADS) {
+            const int32_t i = base + tid;
+            const bool valid = i < m;
+            int32_t p = 0, j = 0, v = 0;
+            if (valid) { p = e_node[cur][i]; j = i - off[p]; v = e_val[cur][i]; }
+            const unsigned long long own = valid ? (((unsigned long long)((uint32_t)v ^ 0x80000000u) << 32) | (uint32_t)i) : NONE;
+            unsigned long long k = own;
+            int32_t f = (!valid || j == 0) ? 1 : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long k2 = __shfl_up(k, o, 64);
+                const int32_t f2 = __shfl_up(f, o, 64);
+                if (lane >= o) { if (!f) k = k2 < k ? k2 : k; f |= f2; }
+            }
+            if (lane == 63) { sh_wk[wave] = k; sh_wf[wave] = f; }
+            __syncthreads();
+            unsigned long long acc = sh_carry;              /* the running minimum entering this wave */
+            for (int32_t w = 0; w < wave; w++) acc = sh_wf[w] ? sh_wk[w] : (sh_wk[w] < acc ? sh_wk[w] : acc);
+            const unsigned long long incl = f ? k : (acc < k ? acc : k);
+            unsigned long long prev = __shfl_up(incl, 1, 64);
+            if (lane == 0) prev = acc;
+            __syncthreads();
+            if (tid == WL_THREADS - 1) sh_carry = incl;
+            if (valid) {
+                const unsigned long long excl = j == 0 ? NONE : prev;
+                const int32_t Lp = len[p];
+                if (j == Lp - 1) {                          /* the node's final element */
+                    const unsigned long long fin = excl < own ? excl : own;
+                    nrl[e_id[cur][(int32_t)(uint32_t)(fin & 0xffffffffull)]] = nrlp[p];
+                }
+                if (j > 0) {
+                    const int32_t ei = (int32_t)(uint32_t)(excl & 0xffffffffull);
+                    const int32_t ev = e_val[cur][ei];
+                    const bool push_old = ev > v;           /* root->val > val: the old minimum moves down */
+                    const int32_t c = (j & 1) ? 2 * p : 2 * p + 1, q = off[c] + (j - 1) / 2;
+                    e_val[cur ^ 1][q] = push_old ? ev : v;
+                    e_id[cur ^ 1][q] = push_old ? e_id[cur][ei] : e_id[cur][i];
+                    e_node[cur ^ 1][q] = c;
+                }
+            }
+            __syncthreads();
+        }
+        m = m_next;
+    }
+    __syncthreads();
+    (void)sh_cnt;
+}
+
 /* P6 + P7: vithist_prune, vithist_frame_gc, srch_utt_word_trans, vithist_frame_windup; arms the lane's next frame.
  * One workgroup.  M = the frame's best score, n_new = entries staged. */
 __device__ __forceinline__ void
@@ -554,14 +649,24 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
     __syncthreads();
     const int32_t n_th = s_i[1];
     bool done = false;
-    if (n_th > WL_RANK_MAX && par.maxhist > 0 && par.maxwpf > 0) {
+    int32_t *nrl = L.nrl;
+    for (int attempt = 0; attempt < 2 && !done && n_th > WL_RANK_MAX && par.maxhist > 0 && par.maxwpf > 0; attempt++) {
         /* ---- many entries above the threshold: vithist_prune by SELECTION instead of sorting.  The walk of
          * vithist.c:683-713 keeps (a) the best filler entry, (b) the maxwpf distinct words whose best entries score
          * highest, (c) of those words every entry (only the best with -bghist), (d) of all these the maxhist best.
-         * Each is a maximum or a K-th largest value -- unless two candidates TIE exactly at one of the four cuts: then
-         * the heap's pop order decides, and the frame falls through to the replay below. ---- */
+         * Each is a maximum or a K-th largest value -- unless candidates TIE exactly at one of the cuts: then the
+         * heap's pop order among the tied decides, and a second attempt breaks every tie by it (wl_heap_nrl). ---- */
+        const bool use_nrl = attempt == 1;
         int32_t sens = 0;
-        /* (a) */
+        __syncthreads();
+        if (tid == 0) { s_i[5] = 0; s_i[6] = 0; s_i[7] = INT_MIN; s_i[8] = 0; s_i[9] = -1; s_i[10] = 0; s_i[11] = INT_MAX; s_i[12] = 0; }
+        __syncthreads();
+        if (use_nrl) {
+            wl_heap_nrl(sg_score, n_new, L.heap, L.new_cap, nrl);
+            if (tid == 0) ctx->n_tie_frames++;
+            __syncthreads();
+        }
+        /* (a) the first filler */
         for (int32_t q = tid; q < n_th; q += WL_THREADS) {
             const int32_t k = a_list[q];
             if (dict.is_filler[sg_wid[k]]) atomicMax(&s_i[7], sg_score[k]);
@@ -570,12 +675,18 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
         const int32_t fmax = s_i[7];
         for (int32_t q = tid; q < n_th; q += WL_THREADS) {
             const int32_t k = a_list[q];
-            if (dict.is_filler[sg_wid[k]] && sg_score[k] == fmax) { atomicAdd(&s_i[8], 1); s_i[9] = k; }
+            if (dict.is_filler[sg_wid[k]] && sg_score[k] == fmax) { atomicAdd(&s_i[8], 1); if (use_nrl) atomicMin(&s_i[11], nrl[k]); else s_i[9] = k; }
         }
         __syncthreads();
-        if (s_i[8] > 1) sens = 1;
-        const int32_t ff = s_i[8] == 1 ? s_i[9] : -1;
-        /* (b) the words' best scores */
+        if (use_nrl && s_i[8] > 0)
+            for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+                const int32_t k = a_list[q];
+                if (dict.is_filler[sg_wid[k]] && sg_score[k] == fmax && nrl[k] == s_i[11]) s_i[9] = k;
+            }
+        __syncthreads();
+        if (!use_nrl && s_i[8] > 1) sens = 1;
+        const int32_t ff = s_i[8] >= 1 ? s_i[9] : -1;
+        /* (b) the words' best scores (and, second attempt, where their first entries pop among equals) */
         for (int32_t q0 = 0; q0 < n_th; q0 += WL_THREADS) {
             const int32_t q = q0 + tid;
             bool first = false;
@@ -590,13 +701,34 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
         }
         __syncthreads();
         const int32_t n_words = s_i[5];
+        if (use_nrl) {
+            for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+                const int32_t k = a_list[q], w = sg_wid[k];
+                if (!(dict.is_filler[w] && k != ff) && sg_score[k] == WL_ALOAD(&L.wbest[w])) atomicMin(&L.wfirst[w], nrl[k]);
+            }
+            __syncthreads();
+        }
         for (int32_t i = tid; i < n_words; i += WL_THREADS) a_val[i] = WL_ALOAD(&L.wbest[a_sorted[i]]);
         __syncthreads();
-        int32_t wcut = INT_MIN;                         /* words with a best score >= wcut are kept */
+        int32_t wcut = INT_MIN, wncut = INT_MAX;        /* kept: best score > wcut, or == wcut and first entry's order <= wncut */
         if (n_words > par.maxwpf) {
             int32_t g, e;
             wl_select(a_val, n_words, par.maxwpf, wcut, g, e);
-            if (g + e != par.maxwpf) sens = 1;
+            if (g + e != par.maxwpf) {
+                if (!use_nrl) sens = 1;
+                else {
+                    for (int32_t i0 = 0; i0 < n_words; i0 += WL_THREADS) {
+                        const int32_t i = i0 + tid;
+                        const bool tied = i < n_words && a_val[i] == wcut;
+                        const int32_t at = wl_append(&s_i[12], tied);
+                        if (at >= 0) a_c[at] = -WL_ALOAD(&L.wfirst[a_sorted[i]]);
+                    }
+                    __syncthreads();
+                    int32_t v, g2, e2;
+                    wl_select(a_c, s_i[12], par.maxwpf - g, v, g2, e2);
+                    wncut = -v;
+                }
+            }
         }
         /* (c) the candidates of the final cut */
         for (int32_t q0 = 0; q0 < n_th; q0 += WL_THREADS) {
@@ -607,9 +739,13 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
                 const int32_t w = sg_wid[k];
                 if (!(dict.is_filler[w] && k != ff)) {
                     const int32_t wb = WL_ALOAD(&L.wbest[w]);
-                    if (wb >= wcut) {
+                    const bool kept = wb > wcut || (wb == wcut && (!use_nrl || wncut == INT_MAX || WL_ALOAD(&L.wfirst[w]) <= wncut));
+                    if (kept) {
                         if (!par.bghist) c = 1;
-                        else if (sg_score[k] == wb) { c = 1; if (atomicAdd(&L.wfirst[w], 1) != INT_MAX) s_i[10] = 1; }   /* two best entries of a word */
+                        else if (sg_score[k] == wb) {
+                            if (use_nrl) c = nrl[k] == WL_ALOAD(&L.wfirst[w]) ? 1 : 0;
+                            else { c = 1; if (atomicAdd(&L.wfirst[w], 1) != INT_MAX) s_i[10] = 1; }     /* two best entries of a word */
+                        }
                     }
                 }
             }
@@ -622,20 +758,37 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
         for (int32_t i = tid; i < n_words; i += WL_THREADS) { L.wbest[a_sorted[i]] = INT_MIN; L.wfirst[a_sorted[i]] = INT_MAX; }
         for (int32_t i = tid; i < n_c; i += WL_THREADS) a_val[i] = sg_score[a_first[i]];
         __syncthreads();
-        /* (d) */
-        int32_t hcut = INT_MIN;
+        /* (d) the maxhist best of them */
+        int32_t hcut = INT_MIN, hncut = INT_MAX;
         if (n_c > par.maxhist) {
             int32_t g, e;
             wl_select(a_val, n_c, par.maxhist, hcut, g, e);
-            if (g + e != par.maxhist) sens = 1;
+            if (g + e != par.maxhist) {
+                if (!use_nrl) sens = 1;
+                else {
+                    if (tid == 0) s_i[12] = 0;
+                    __syncthreads();
+                    for (int32_t i0 = 0; i0 < n_c; i0 += WL_THREADS) {
+                        const int32_t i = i0 + tid;
+                        const bool tied = i < n_c && a_val[i] == hcut;
+                        const int32_t at = wl_append(&s_i[12], tied);
+                        if (at >= 0) a_c[at] = -nrl[a_first[i]];
+                    }
+                    __syncthreads();
+                    int32_t v, g2, e2;
+                    wl_select(a_c, s_i[12], par.maxhist - g, v, g2, e2);
+                    hncut = -v;
+                }
+            }
         }
         if (!sens) {
-            for (int32_t i = tid; i < n_c; i += WL_THREADS) if (a_val[i] >= hcut) sg_valid[a_first[i]] = 1;
+            for (int32_t i = tid; i < n_c; i += WL_THREADS)
+                if (a_val[i] > hcut || (a_val[i] == hcut && (hncut == INT_MAX || nrl[a_first[i]] <= hncut))) sg_valid[a_first[i]] = 1;
             done = true;
         }
-        else if (tid == 0) ctx->n_tie_frames++;
         __syncthreads();
     }
+    if (!done && n_th > WL_RANK_MAX) done = true;      /* (-maxwpf 0 / -maxhistpf 0: nothing survives) */
     if (!done) {
         /* ---- rank by score; two entries above the threshold that tie pop in the heap's order: replay it ---- */
         if (n_th <= WL_RANK_MAX) {
@@ -652,18 +805,33 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
             }
             __syncthreads();
         }
-        else if (tid == 0) s_i[2] = 1;
         __syncthreads();
         if (s_i[2] && par.maxhist > 0) {
-            if (tid == 0) {
-                WlHeap hp;
-                int32_t *base = n_new <= WL_HEAP_LDS ? s_heap : L.heap;
-                const int32_t stride = n_new <= WL_HEAP_LDS ? WL_HEAP_LDS : L.new_cap;
-                hp.val = base; hp.data = base + stride; hp.nl = base + 2 * stride; hp.nr = base + 3 * stride;
-                hp.l = base + 4 * stride; hp.r = base + 5 * stride; hp.n_alloc = 0; hp.top = -1;
-                for (int32_t k = 0; k < n_new; k++) hp.insert(k, (int32_t)(0u - (uint32_t)sg_score[k]));
-                for (int32_t r = 0; r < n_th; r++) a_sorted[r] = hp.pop();
-                if (n_th <= WL_RANK_MAX) ctx->n_tie_frames++;
+            /* two entries above the threshold tie: they pop in the heap's order.  Few entries: one thread replays the
+             * reference's heap in LDS; more: the pop order among equals in parallel (wl_heap_nrl), ranks again */
+            if (n_new <= WL_HEAP_LDS) {
+                if (tid == 0) {
+                    WlHeap hp;
+                    hp.val = s_heap; hp.data = s_heap + WL_HEAP_LDS; hp.nl = s_heap + 2 * WL_HEAP_LDS; hp.nr = s_heap + 3 * WL_HEAP_LDS;
+                    hp.l = s_heap + 4 * WL_HEAP_LDS; hp.r = s_heap + 5 * WL_HEAP_LDS; hp.n_alloc = 0; hp.top = -1;
+                    for (int32_t k = 0; k < n_new; k++) hp.insert(k, (int32_t)(0u - (uint32_t)sg_score[k]));
+                    for (int32_t r = 0; r < n_th; r++) a_sorted[r] = hp.pop();
+                    ctx->n_tie_frames++;
+                }
+            }
+            else {
+                wl_heap_nrl(sg_score, n_new, L.heap, L.new_cap, nrl);
+                if (tid == 0) ctx->n_tie_frames++;
+                __syncthreads();
+                for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+                    const int32_t k = a_list[q], sc = sg_score[k], nk = nrl[k];
+                    int32_t r = 0;
+                    for (int32_t p = 0; p < n_th; p++) {
+                        const int32_t k2 = a_list[p], s2 = sg_score[k2];
+                        r += (s2 > sc || (s2 == sc && nrl[k2] < nk)) ? 1 : 0;
+                    }
+                    a_sorted[r] = k;
+                }
             }
             __syncthreads();
         }
