@@ -553,7 +553,7 @@ s3a_mgau_init_arrays(const float *mean, const float *var, const float *mixw, int
     s3a_mgau_model_t *g = s3a_mgau_host_init(mean, var, mixw, n_mgau, n_density, veclen,
                                              varfloor, mixwfloor, precomp, logmath);
     if (g && s3a_mgau_dev_create(g) != S3A_OK) {
-        s3a_mgau_host_free(g);
+        s3a_mgau_free(g);           /* device half (whatever dev_create got to) + host half */
         return NULL;
     }
     return g;
@@ -797,7 +797,10 @@ parse_gau_streams(const char *path, const uint32_t *w, size_t nw, int32_t *n_mga
     if (nw < 4 || (int32_t)w[1] <= 0 || nw < 4 + (size_t)w[1]) { s3a_set_error("%s: truncated header", path); return S3A_EIO; }
     *n_mgau = (int32_t)w[0]; *n_feat = (int32_t)w[1]; *n_density = (int32_t)w[2];
     *featlen = (const int32_t *)(w + 3);
-    for (f = 0; f < *n_feat; f++) tot += (*featlen)[f];
+    for (f = 0; f < *n_feat; f++) {
+        if ((*featlen)[f] <= 0) { s3a_set_error("%s: stream %d has length %d", path, f, (*featlen)[f]); return S3A_EIO; }
+        tot += (*featlen)[f];
+    }
     if (*n_mgau <= 0 || *n_density <= 0 || tot <= 0
         || (int64_t)(int32_t)w[3 + *n_feat] != (int64_t)*n_mgau * *n_density * tot
         || nw != 4 + (size_t)*n_feat + (size_t)w[3 + *n_feat]) {
@@ -896,6 +899,8 @@ s3a_ps_ms_mgau_init_arrays(const float *mean, const float *var, const float *mix
         s3a_set_error("s3a_ps_ms_mgau_init: bad arguments");
         return NULL;
     }
+    for (f = 0; f < n_feat; f++)
+        if (featlen[f] <= 0) { s3a_set_error("s3a_ps_ms_mgau_init: stream %d has length %d", f, featlen[f]); return NULL; }
     if ((ps = (s3a_ps_mgau_t *)calloc(1, sizeof *ps)) == NULL) return NULL;
     ps->n_mgau = n_mgau; ps->n_feat = n_feat; ps->n_density = n_density; ps->n_sen = n_sen; ps->aw = aw;
     ps->lm = s3a_logmath_init(logbase, 0, 0);                   /* acmod.c: logmath_init(-logbase, 0, FALSE) */

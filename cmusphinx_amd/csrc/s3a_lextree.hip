@@ -694,8 +694,7 @@ s3a_lexsearch_init(int32_t n_tree, const int32_t *n_node, const int32_t *const *
         return NULL;
     }
     if (n_comstate <= 0 || !comstate_off) { n_comstate = 0; comstate_off = zero_off; }
-    ls = new s3a_lexsearch_s();
-    memset((void *)&ls->d_node_base, 0, (char *)&ls->own_stream - (char *)&ls->d_node_base);
+    ls = new s3a_lexsearch_s();        /* value-initialised: every pointer / counter starts at zero */
     ls->n_emit = 3;
     ls->cur = 0;
     if (stream) { ls->stream = (hipStream_t)stream; ls->own_stream = 0; }
