@@ -556,7 +556,7 @@ kb_scan(const BSlot *__restrict__ slots, const BFrame *__restrict__ frames, int3
                s.selfemit, s.cnt, s.base, s.act[f.cur ^ 1], s.nact[f.cur ^ 1], s.pos, s.posf, s.best, s.exits,
                s.nexit, s.hbin, s.misc, s.done, pack_all + (size_t)blockIdx.z * pack_stride, max_exits,
                s.gpart, f.gpart_n ? s.gp_n : 0, s.poswid, s.posout, f.may_hist, s.scan_agg, s.scan_pre, s.scan_flag,
-               s.scan_chunks, f.scan_epoch, f.scan_nc, bt * f.scan_nc + bj, 0);
+               s.scan_chunks, f.scan_epoch, f.scan_nc, f.scan_nc, bt * f.scan_nc + bj, 0);
 }
 
 __global__ void __launch_bounds__(DBLOCK)

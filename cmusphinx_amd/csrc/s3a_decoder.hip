@@ -122,7 +122,7 @@ k_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            unsigned long long *st_agg, unsigned long long *st_pre, int32_t *st_flag, int32_t st_stride,
            int32_t epoch, int32_t NC)
 {
-    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, gpart, gpart_n, poswid, posout, reordered, st_agg, st_pre, st_flag, st_stride, epoch, NC, blockIdx.x, blockIdx.y);
+    d_dec_scan(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, gpart, gpart_n, poswid, posout, reordered, st_agg, st_pre, st_flag, st_stride, epoch, NC, NC, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(DBLOCK)

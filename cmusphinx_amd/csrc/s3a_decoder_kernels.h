@@ -119,7 +119,7 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
             tp[0] = a.x; tp[1] = a.y; tp[2] = a.z; tp[3] = a.w; tp[4] = bq.x; tp[5] = bq.y; tp[6] = bq.z; tp[7] = bq.w;
             tp[8] = cq.x; tp[9] = cq.y; tp[10] = cq.z; tp[11] = cq.w;
         }
-        const int32_t w = wid[v], q_lo = psof_off[v], q_hi = psof_off[v + 1];
+        const int32_t w = wid[v], q_lo = psof_off ? psof_off[v] : 0, q_hi = psof_off ? psof_off[v + 1] : 0;
         if (comp[v]) {
             /* composite senone = max over its member senones (dict2pid.c:1029-1048), up to one member
              * per context (~46): the three states' lists are walked together, 8 members each per round,
@@ -163,7 +163,8 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         poswid[node_base[t] + i] = w;
         posout[node_base[t] + i] = r.out;
         /* this node is active in frame cf: stamp the parent sets its children belong to (k_dec_resolve
-         * skips every node whose parent set carries no stamp of this frame) */
+         * skips every node whose parent set carries no stamp of this frame).  (psof_off == NULL: the caller stamps
+         * after the thresholds are known, and only for the nodes that propagate: d_dec_stamp) */
         for (int32_t q = q_lo; q < q_hi; q++) pstamp[psof[q]] = cf;
     }
 #pragma unroll
@@ -178,6 +179,35 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         if (best != INT_MIN) atomicMax(&best_out[2 * t], best);
         if (wbest != INT_MIN) atomicMax(&best_out[2 * t + 1], wbest);
     }
+}
+
+/* the frame's thresholds when the histogram beam is known to the caller (hb_hist <= 0) or not in force (> 0) */
+__device__ __forceinline__ void
+frame_thresholds_hb(const int32_t *best, int32_t T, const FrameBeams &bm, int32_t hb_hist, int32_t &th, int32_t &pth)
+{
+    int32_t bh = INT_MIN, bw = INT_MIN;
+    for (int32_t t = 0; t < T; t++) { bh = max(bh, best[2 * t]); bw = max(bw, best[2 * t + 1]); }
+    int32_t hb = bm.hmmbeam, pb = bm.pbeam, wb = bm.wbeam;
+    if (hb_hist <= 0) { hb = hb_hist; pb = max(hb, pb); wb = max(hb, wb); }
+    th = add32(bh, hb);
+    pth = bm.phone_uses_wbeam ? add32(bw, wb) : add32(bh, pb);
+}
+
+/*
+ * Which nodes can be entered in this frame: an active HMM whose exit score reaches the phone threshold stamps the
+ * parent sets its children belong to (a superset of the HMMs that propagate: lextree.c:1445-1452; one that is
+ * cleared first -- phone threshold below the HMM threshold -- is sorted out by d_dec_resolve_node).  Run once the
+ * thresholds are final: k_dec_resolve then walks the parent lists of those nodes only (a few hundred instead of
+ * every child of every active HMM, each with up to ~46 parents).  A lane per list position i of tree t.
+ */
+__device__ __forceinline__ void
+d_dec_stamp(const int32_t *__restrict__ act, const int32_t *__restrict__ outs, const int32_t *__restrict__ psof_off,
+            const int32_t *__restrict__ psof, int32_t *pstamp, int32_t b, int32_t na, int32_t i, int32_t pth, int32_t cf)
+{
+    if (i >= na) return;
+    const int32_t u = act[b + i];
+    if (outs[u] < pth) return;
+    for (int32_t q = psof_off[u], q_hi = psof_off[u + 1]; q < q_hi; q++) pstamp[psof[q]] = cf;
 }
 
 /* ------------------------------------------------------------------ */
@@ -245,7 +275,7 @@ block_inclusive_sum(int32_t x, int32_t *wsum /* [SCAN_THREADS / 64] shared */)
     return incl + add;
 }
 
-__device__ __forceinline__ void
+__device__ __forceinline__ int32_t
 d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32_t *__restrict__ nact,
                 int32_t T, FrameBeams bm, const int32_t *__restrict__ binof, int32_t *tmp,
                 int32_t *hbin, int32_t *pos, int32_t force_tree, int32_t nbin,
@@ -263,7 +293,7 @@ d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32
         s_i = nbin;
     }
     __syncthreads();
-    if (!s_go) return;
+    if (!s_go) return 1;                        /* (no histogram beam in force: beams are <= 0) */
     if (force_tree < 0) {
         /* for (i = 0, j = 0; i < nbin && j < maxhmmpf; i++, j += bin[i]);  -- bin[0] is never
          * counted and the read of bin[nbin] after the last increment decides nothing */
@@ -321,6 +351,8 @@ d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32
         act[b + i] = v;
         pos[v] = i;
     }
+    __syncthreads();
+    return force_tree < 0 ? -(s_i * (-bm.hmmbeam / NBIN)) : 1;      /* the histogram beam (hbin[NBIN]) */
 }
 
 /* ------------------------------------------------------------------ */
@@ -392,8 +424,9 @@ d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
  * without a propagating parent fall through after two loads.  Also resets the root-entry
  * scratch (key / first) for this frame's transitions.
  */
+/* what happens to node v (active, or with an active parent) in this frame: the rule of s3a_lextree.hip */
 __device__ __forceinline__ void
-d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
+d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
               const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
               const int32_t *__restrict__ tree_of, const int32_t *__restrict__ prob,
               const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
@@ -404,28 +437,9 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout,
-        const int32_t BX, const int32_t BY)
+        const int32_t v, const bool is_active, const bool has_par)
 {
-    /* (the thresholds come from uniform addresses: computed per thread with scalar loads, and only by
-     * the few workgroups that have anything to do -- no LDS, no barrier in front of the early exit) */
-    if (BX == 0) {                              /* the bins were consumed by k_dec_hist_sort */
-        int32_t bh, bw, n, th0, pth0, wth0;
-        if (frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th0, pth0, wth0))
-            for (int32_t i = threadIdx.x; i < NBIN; i += RSBLOCK) hbin[i] = 0;
-    }
-    const int32_t v = BX * RSBLOCK + threadIdx.x;
-    if (v >= N) return;
-    if (v < n_rootnodes) {                              /* lextree_enter only ever touches root nodes */
-        const int32_t r = rootnodes[v];
-        key[r] = 0ull;
-        first[r] = INT_MAX;
-    }
     const int32_t nf = cf + 1;
-    const bool is_active = posf[v] == cf;
-    if (!is_active) {                                   /* no active parent: nothing can happen to v */
-        const int32_t q = ps[v];
-        if (q < 0 || pstamp[q] != cf) return;
-    }
     int32_t th, pth;
     {
         int32_t bh, bw, n, wth;
@@ -438,7 +452,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
     /* parents in batches of 8: the ids, then their list stamps, are independent loads (a first-level
      * node has one parent per left-context variant of its root, ~46: a one-at-a-time walk is 46
      * dependent round trips); the comparisons below do not depend on the visiting order */
-    for (int32_t k0 = par_off[v], kend = par_off[v + 1]; k0 < kend; k0 += 8) {
+    for (int32_t k0 = has_par ? par_off[v] : 0, kend = has_par ? par_off[v + 1] : 0; k0 < kend; k0 += 8) {
         int32_t pid[8], pf[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) pid[u] = (k0 + u < kend) ? par[k0 + u] : -1;
@@ -495,6 +509,41 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
     if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[b + my_turn], 1); }
 }
 
+__device__ __forceinline__ void
+d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
+              const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
+              const int32_t *__restrict__ tree_of, const int32_t *__restrict__ prob,
+              const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
+              const int32_t *__restrict__ pos, const int32_t *__restrict__ posf,
+              int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
+              int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
+              unsigned long long *key, int32_t *first, int32_t *hbin,
+              const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
+              const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
+              const int32_t *__restrict__ propf, int32_t *posout,
+        const int32_t BX, const int32_t BY)
+{
+    /* (the thresholds come from uniform addresses: computed per thread with scalar loads, and only by
+     * the few workgroups that have anything to do -- no LDS, no barrier in front of the early exit) */
+    if (BX == 0) {                              /* the bins were consumed by k_dec_hist_sort */
+        int32_t bh, bw, n, th0, pth0, wth0;
+        if (frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th0, pth0, wth0))
+            for (int32_t i = threadIdx.x; i < NBIN; i += RSBLOCK) hbin[i] = 0;
+    }
+    const int32_t v = BX * RSBLOCK + threadIdx.x;
+    if (v >= N) return;
+    if (v < n_rootnodes) {                              /* lextree_enter only ever touches root nodes */
+        const int32_t r = rootnodes[v];
+        key[r] = 0ull;
+        first[r] = INT_MAX;
+    }
+    const bool is_active = posf[v] == cf;
+    const int32_t q = ps[v];
+    const bool has_par = q >= 0 && pstamp[q] == cf;     /* some parent may enter v (its parent set is stamped) */
+    if (!is_active && !has_par) return;                 /* nothing can happen to v */
+    d_dec_resolve_node(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout, v, is_active, has_par);
+}
+
 /* ------------------------------------------------------------------ */
 /*
  * The ordered emission of the next active list, in two kernels.
@@ -520,6 +569,10 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
  * inclusive prefix (st_pre, flag = 2 * epoch + 1) -- and publishes its own prefix.  `epoch` grows with every launch
  * on this decoder, so the flags never need a reset.  Predecessors have smaller workgroup ids (dispatched first) and
  * the whole grid fits the chip, so the wait always ends; the spin is bounded all the same (error word 2 in the frame record).
+ * With GC < NC workgroups per tree a workgroup takes every GC-th chunk in turn (the whole-utterance engine: the host
+ * does not know the list lengths, and a workgroup per possible chunk is thousands of workgroups that only find out
+ * that they have nothing to do).  A chunk still only waits for chunks with smaller numbers, which belong to workgroups
+ * of the same tree that are dispatched together with it (GC is small), so the wait ends as before.
  */
 __device__ __forceinline__ void
 d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
@@ -531,7 +584,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
            const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits,
            const int32_t *gpart, int32_t gpart_n, const int32_t *poswid, const int32_t *posout, int32_t reordered,
            unsigned long long *st_agg, unsigned long long *st_pre, int32_t *st_flag, int32_t st_stride,
-           int32_t epoch, int32_t NC,
+           int32_t epoch, int32_t NC, int32_t GC,
         const int32_t BX, const int32_t BY)
 {
     __shared__ int32_t s_wth, s_last;
@@ -539,8 +592,10 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     __shared__ int32_t s_thr[8];
     __shared__ unsigned long long s_wsum[SCAN_THREADS / 64], s_chunk, s_prefix;
     __shared__ int32_t s_exit_open;
-    const int32_t t = BX / NC, j = BX - t * NC, b = node_base[t], na = nact[t];
+    /* GC <= NC workgroups per tree are launched; workgroup j owns chunks j, j + GC, ... (GC == NC: one each) */
+    const int32_t t = BX / GC, j = BX - t * GC, b = node_base[t], na = nact[t];
     const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t c_step = (NC == 1 ? 1 : GC) * SCAN_THREADS;
     const bool live = j * SCAN_THREADS < na || j == 0;      /* (chunk 0 also reports an empty tree's totals) */
     /* a chunk's list entries: turn count; word id / exit score by list position (after a histogram reordering --
      * the evaluation wrote them before it -- through the node).  The first chunk's loads are issued before the
@@ -572,10 +627,10 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
         const int32_t wth = s_wth;
         unsigned long long carry = 0ull;        /* NC == 1: this workgroup walks all chunks, totals in a register */
         /* NC > 1: one chunk per workgroup (the host sizes NC by its bound on the list length), chained */
-        for (int32_t c0 = j * SCAN_THREADS; c0 == j * SCAN_THREADS || (NC == 1 && c0 < na); c0 += SCAN_THREADS) {
-            const int32_t i = c0 + tid;
+        for (int32_t c0 = j * SCAN_THREADS; c0 == j * SCAN_THREADS || c0 < na; c0 += c_step) {
+            const int32_t i = c0 + tid, jc = c0 / SCAN_THREADS;
             const int32_t u = u2, c = c2, w = w2, os = os2;
-            if (NC == 1) SCAN_FETCH(i + SCAN_THREADS);
+            SCAN_FETCH(i + c_step);
             /* both ordered compactions in one scan: the turn bases (exclusive sum of the turn counts; the
              * self-emitted nodes are written at theirs by k_dec_emit) and the word exits in list order (exclusive
              * sum of the exit flags) travel as the halves of one 64-bit value */
@@ -606,11 +661,11 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
                 if (tid == 0) {
                     const unsigned long long A = s_chunk;
                     unsigned long long pre = 0ull;
-                    const int32_t me = t * st_stride + j;    /* (st_stride >= the tree's chunks: the arrays' row length) */
-                    if (j > 0) {
+                    const int32_t me = t * st_stride + jc;   /* (st_stride >= the tree's chunks: the arrays' row length) */
+                    if (jc > 0) {
                         st_agg[me] = A;
                         __hip_atomic_store(&st_flag[me], 2 * epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        for (int32_t p = j - 1; p >= 0; p--) {
+                        for (int32_t p = jc - 1; p >= 0; p--) {
                             int32_t f, spins = 0;
                             while ((f = __hip_atomic_load(&st_flag[t * st_stride + p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 2 * epoch) {
                                 if (++spins > (1 << 22)) { nexit[T + t] = 2; break; }   /* (cannot happen: see above) */
@@ -659,7 +714,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     if (tid == 0) {
         __threadfence();                                        /* agent-scope release */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = (atomicAdd(done, 1) == T * NC - 1) ? 1 : 0;
+        s_last = (atomicAdd(done, 1) == T * GC - 1) ? 1 : 0;
         if (s_last) __threadfence();                            /* agent-scope acquire */
     }
     __syncthreads();

@@ -68,12 +68,20 @@ struct UShared {
     const int16_t *cd2cisen;
     int32_t ds_ratio, ci_pbeam, ci_pbeam_tight, ptranskip;
     FrameBeams bm;              /* phone_uses_wbeam is worked out per frame */
+    /* what decides whether a workgroup has anything to do sits at addresses known from the kernel arguments alone: the
+     * lanes' contexts and active-list lengths are two arrays (ONE round trip to the early exit instead of lane struct ->
+     * pointer -> value: with 64 lanes most workgroups of a fixed grid only find out that they are not needed, and
+     * that chain times the number of such waves over the chip's resident waves WAS the launch) */
+    UCtx *ctx_all;              /* [n_lanes] */
+    int32_t *nact_all;          /* [n_lanes][2][WL_MAXT] */
 };
 
 /* lanes run in lock step from frame 0: the frame index f is a kernel argument, the list searched in frame f is
  * list f & 1 (lextree_active_swap flips it every frame) -- no kernel has to read what the word level of the previous
  * frame wrote last, so the word level can share a launch with the emission sweep */
-#define LANE const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; if (f >= ctx->nfr || !ctx->active) return; const int32_t cur = f & 1; (void)cur
+#define LANE UCtx *ctx = S.ctx_all + blockIdx.z; if (f >= ctx->nfr || !ctx->active) return;                      \
+    const int32_t cur = f & 1; const int32_t *nact_cur = S.nact_all + ((size_t)blockIdx.z * 2 + cur) * WL_MAXT;       \
+    const ULane &L = lanes[blockIdx.z]; (void)cur; (void)nact_cur
 
 __device__ __forceinline__ FrameBeams
 frame_beams(const UShared &S, int32_t cf)
@@ -314,35 +322,56 @@ __global__ void __launch_bounds__(EB)
 ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const int32_t t = blockIdx.y, na = L.nact[cur][t];
+    const int32_t t = blockIdx.y, na = nact_cur[t];
     for (int32_t vb = blockIdx.x; vb * EB < na; vb += gridDim.x) {
         d_dec_hmm_eval<EB>(S.node_base, L.act[cur], L.nact[cur], S.N, S.n_tmat, S.ssid, S.tmatid, S.wid, S.comp, S.tp,
                            S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt, L.scr, L.misc, L.sc, L.hist, L.outs, L.outh,
-                           L.bests, L.best, f, S.psof_off, S.psof, L.pstamp, L.gpart, S.gp_n, L.poswid, L.posout,
+                           L.bests, L.best, f, (const int32_t *)NULL /* ku_hist_count stamps */, S.psof, L.pstamp, L.gpart, S.gp_n, L.poswid, L.posout,
                            vb, t);
         __syncthreads();
     }
 }
 
+/* after the evaluation: the histogram bins when the frame holds more than 1.5 x -maxhmmpf HMMs (lextree_hmm_histbin);
+ * otherwise the thresholds are final and the HMMs that can propagate stamp their children's parent sets (d_dec_stamp) */
 __global__ void __launch_bounds__(DBLOCK)
 ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const int32_t t = blockIdx.y, na = L.nact[cur][t];
+    const int32_t t = blockIdx.y, na = nact_cur[t];
+    if ((int32_t)blockIdx.x * DBLOCK >= na) return;
     const FrameBeams bm = frame_beams(S, f);
-    for (int32_t vb = blockIdx.x; vb * DBLOCK < na; vb += gridDim.x) {
-        d_dec_hist_count(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.best, L.bests, L.exits + S.N, L.hbin, -1, 0, 1,
-                         NBIN, vb, t);
-        __syncthreads();
+    int32_t n = 0;
+    for (int32_t k = 0; k < S.T; k++) n += nact_cur[k];
+    if (n > bm.maxhmmpf + (bm.maxhmmpf >> 1)) {
+        for (int32_t vb = blockIdx.x; vb * DBLOCK < na; vb += gridDim.x) {
+            d_dec_hist_count(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.best, L.bests, L.exits + S.N, L.hbin, -1, 0, 1,
+                             NBIN, vb, t);
+            __syncthreads();
+        }
+        return;
     }
+    int32_t th, pth;
+    frame_thresholds_hb(L.best, S.T, bm, 1, th, pth);
+    const int32_t b = S.node_base[t];
+    for (int32_t i = blockIdx.x * DBLOCK + threadIdx.x; i < na; i += gridDim.x * DBLOCK)
+        d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp, b, na, i, pth, f);
 }
 
+/* the histogram beam + the reordering of the lists (frames over 1.5 x -maxhmmpf only), then the stamps of such a frame */
 __global__ void __launch_bounds__(SCAN_THREADS)
 ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    d_dec_hist_sort(S.node_base, L.act[cur], L.nact[cur], S.T, frame_beams(S, f), L.exits + S.N, L.exits, L.hbin,
-                    L.pos, -1, NBIN, blockIdx.x, 0);
+    const FrameBeams bm = frame_beams(S, f);
+    const int32_t hb = d_dec_hist_sort(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.exits + S.N, L.exits, L.hbin,
+                                       L.pos, -1, NBIN, blockIdx.x, 0);
+    if (hb > 0) return;
+    int32_t th, pth;
+    frame_thresholds_hb(L.best, S.T, bm, hb, th, pth);
+    const int32_t t = blockIdx.x, na = nact_cur[t], b = S.node_base[t];
+    for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS)
+        d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp, b, na, i, pth, f);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -366,18 +395,18 @@ ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t f)
+ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t GC, int32_t f)
 {
     LANE;
     const FrameBeams bm = frame_beams(S, f);
     /* after a histogram reordering the position-indexed word ids / exit scores are stale */
     int32_t n = 0;
-    for (int32_t t = 0; t < S.T; t++) n += L.nact[cur][t];
+    for (int32_t t = 0; t < S.T; t++) n += nact_cur[t];
     const int32_t reordered = n > bm.maxhmmpf + (bm.maxhmmpf >> 1) ? 1 : 0;
     d_dec_scan(S.N, S.T, f, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit,
                L.cnt, L.base, L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, L.best, L.exits, L.nexit, L.hbin, L.misc,
                (int32_t *)NULL /* no tail: ku_wordlevel assembles the frame record */, L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, reordered, L.scan_agg, L.scan_pre,
-               L.scan_flag, S.scan_chunks, ctx->scan_epoch, NC, blockIdx.x, 0);
+               L.scan_flag, S.scan_chunks, ctx->scan_epoch, NC, GC, blockIdx.x, 0);
 }
 
 /* ---- the ordered emission of the next list AND the word level, one launch ----
@@ -390,54 +419,57 @@ ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPa
 {
     LANE;
     if (blockIdx.x > 0) {
-        const int32_t t = (blockIdx.x - 1) / UE_WG_PER_TREE, bx = (blockIdx.x - 1) % UE_WG_PER_TREE;
+        const int32_t wgpt = ((int32_t)gridDim.x - 1) / S.T;        /* emission workgroups per tree */
+        const int32_t t = (blockIdx.x - 1) / wgpt, bx = (blockIdx.x - 1) % wgpt;
         d_dec_emit_w(f, S.node_base, L.act[cur], L.nact[cur], S.child_off, S.child, L.turn, L.selfemit, L.base,
                      L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, t, bx * WL_WAVES + (threadIdx.x >> 6),
-                     UE_WG_PER_TREE * WL_WAVES);
+                     wgpt * WL_WAVES);
         return;
     }
+    const long long t_in = (long long)wall_clock64();
     if (threadIdx.x == 0) ctx->scan_epoch++;        /* (k_dec_scan's flags are stamped per launch) */
     d_dec_pack_frame(S.N, S.T, frame_beams(S, f), S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc,
                      L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1]);
     if (big) d_wl_big_begin(L.w, ctx, L.pack, dict, par);   /* wide beams: the candidate phases follow as their own launches */
-    else d_wordlevel_frame(L.w, ctx, L.pack, lm, dict, par, f);
+    else d_wordlevel_frame(L.w, ctx, L.pack, lm, dict, par, f, t_in);
 }
 
+#define LANE_W const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; if (f >= ctx->nfr || !ctx->active) return
 /* the wide-beam word level: WL_BIG_G workgroups per lane and phase (s3a_wordlevel.h) */
 __global__ void __launch_bounds__(WL_THREADS)
 ku_wl_p2(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par, int32_t f)
 {
-    LANE;
+    LANE_W;
     d_wl_big_p2(L.w, ctx, L.pack, lm, dict, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
 ku_wl_p3(const ULane *__restrict__ lanes, WDict dict, WPar par, int32_t f)
 {
-    LANE;
+    LANE_W;
     d_wl_big_p3(L.w, ctx, L.pack, dict, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
 ku_wl_p4a(const ULane *__restrict__ lanes, WPar par, int32_t f)
 {
-    LANE;
+    LANE_W;
     d_wl_big_p4a(L.w, ctx, L.pack, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
 ku_wl_p4b(const ULane *__restrict__ lanes, WPar par, int32_t f)
 {
-    LANE;
+    LANE_W;
     d_wl_big_p4b(L.w, ctx, L.pack, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
 ku_wl_p5(const ULane *__restrict__ lanes, WDict dict, WPar par, int32_t f)
 {
-    LANE;
+    LANE_W;
     d_wl_big_p5(L.w, ctx, L.pack, dict, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
 ku_wl_finish(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par, int32_t f)
 {
-    LANE;
+    LANE_W;
     d_wl_big_finish(L.w, ctx, L.pack, lm, dict, par, f);
 }
 
@@ -447,7 +479,7 @@ ku_wordlevel_only(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par)
 {
     const ULane &L = lanes[blockIdx.z];
     if (!L.ctx->active) return;
-    d_wordlevel_frame(L.w, L.ctx, L.pack, lm, dict, par, L.ctx->cf);
+    d_wordlevel_frame(L.w, L.ctx, L.pack, lm, dict, par, L.ctx->cf, (long long)wall_clock64());
 }
 
 __global__ void
@@ -598,7 +630,7 @@ struct s3a_uttdec_s {
     ULane *d_lanes;
     int32_t *d_lcmap;
     std::vector<int32_t> h_lcmap;
-    int32_t g_eval, eval_block, g_ent, g_mark, scan_nc, hist_possible, weak_possible;
+    int32_t g_eval, eval_block, g_ent, g_mark, scan_nc, scan_gc, hist_possible, weak_possible;
     hipStream_t stream;
     int32_t n_utt;              /* lanes in use by the last decode */
     double last_decode_ms;
@@ -623,7 +655,7 @@ static void
 wlane_free(WLane &w)
 {
     void *p[] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type, w.lmc, w.frame_start, w.bestscore,
-                  w.bestvh, w.st, w.ex_off, w.cand_pref, w.cand_e, w.cand_score, w.cand_slot, w.hkey, w.hbest, w.hfirst,
+                  w.bestvh, w.st, w.ex_off, w.ex_info, w.cand_i, w.cand_pref, w.cand_e, w.cand_score, w.cand_slot, w.hkey, w.hbest, w.hfirst,
                   w.hlead_rank, w.sg, w.srt, w.wfirst, w.wbest, w.part, w.part2, w.tb, w.heap, w.nrl, w.fstat };
     for (auto q : p) if (q) (void)hipFree(q);
     memset((void *)&w, 0, sizeof w);
@@ -641,10 +673,10 @@ wlane_alloc(WLane &w, int32_t vh_cap, int32_t max_frames, int32_t ex_cap, int32_
     DM(w.ascr, vc); DM(w.lscr, vc); DM(w.type, vc); DM(w.lmc, 5 * vc);
     w.cap = vh_cap;
     DM(w.frame_start, mf); DM(w.bestscore, mf); DM(w.bestvh, mf); DM(w.st, 16 * 4);
-    DM(w.ex_off, (size_t)(ex_cap + 1) * 4);
+    DM(w.ex_off, (size_t)(ex_cap + 1) * 4); DM(w.ex_info, (size_t)3 * ex_cap * 4);
     w.ex_cap = ex_cap;
     DM(w.cand_score, (size_t)cand_cap * 4); DM(w.cand_slot, (size_t)cand_cap * 4);
-    DM(w.cand_pref, (size_t)cand_cap * 4); DM(w.cand_e, (size_t)cand_cap * 4);
+    DM(w.cand_pref, (size_t)cand_cap * 4); DM(w.cand_e, (size_t)cand_cap * 4); DM(w.cand_i, (size_t)cand_cap * 4);
     w.cand_cap = cand_cap;
     while (hs < (size_t)2 * cand_cap) hs <<= 1;
     w.hmask = (int32_t)(hs - 1);
@@ -670,8 +702,10 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     (void)hipStreamSynchronize(ud->stream);
     for (auto &hl : ud->lane) {
         wlane_free(hl.d.w);
-        if (hl.d.ctx) (void)hipFree(hl.d.ctx);
         if (hl.d.pack) (void)hipFree(hl.d.pack);
+        if (hl.ls && ud->S.nact_all && hl.ls->d_nact[0] >= ud->S.nact_all
+            && hl.ls->d_nact[0] < ud->S.nact_all + (size_t)ud->n_lanes * 2 * WL_MAXT)
+            hl.ls->d_nact[0] = hl.ls->d_nact[1] = NULL;     /* borrowed from nact_all */
         if (hl.d_feat) (void)hipFree(hl.d_feat);
         if (hl.h_ctx) (void)hipHostFree(hl.h_ctx);
         if (hl.h_feat) (void)hipHostFree(hl.h_feat);
@@ -682,6 +716,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
     if (ud->d_lanes) (void)hipFree(ud->d_lanes);
+    if (ud->S.ctx_all) (void)hipFree(ud->S.ctx_all);
+    if (ud->S.nact_all) (void)hipFree(ud->S.nact_all);
     if (ud->d_lcmap) (void)hipFree(ud->d_lcmap);
     const void *q[] = { ud->dict.lwid, ud->dict.fillpen, ud->dict.last_ci, ud->dict.is_filler };
     for (auto p : q) if (p) (void)hipFree((void *)p);
@@ -749,10 +785,14 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
 
     /* launch geometry: fixed grids, the kernels loop over the list lengths they find in memory */
     ud->eval_block = (cfg->maxhmmpf >= EVBLOCK_LONG_LIST && maxn >= EVBLOCK_LONG_LIST) ? 256 : 64;
-    ud->g_eval = max(1, min((maxn + ud->eval_block - 1) / ud->eval_block, 2048 / max(1, min(n_lanes, 8))));
+    /* fixed grids, sized for the usual frame: a workgroup loops when a list is longer (virtual workgroups); with many
+     * lanes the idle workgroups of a generous grid cost more than the loop */
+    ud->g_eval = max(1, min((maxn + ud->eval_block - 1) / ud->eval_block, n_lanes >= 32 ? 64 : 2048 / max(1, min(n_lanes, 8))));
+    if (getenv("S3A_UTT_GEVAL")) ud->g_eval = max(1, atoi(getenv("S3A_UTT_GEVAL")));
     ud->g_ent = max(1, min((proto->ent_cap + 255) / 256, 256));
     ud->g_mark = max(1, min((proto->ent_cap + M3BLOCK - 1) / M3BLOCK + ((maxn + M3BLOCK - 1) / M3BLOCK) * T, 1024));
     ud->scan_nc = (cfg->maxhmmpf >= SCAN_LONG_LIST && maxn >= SCAN_LONG_LIST) ? (maxn + 1023) / 1024 : 1;
+    ud->scan_gc = getenv("S3A_UTT_SCAN_G") ? atoi(getenv("S3A_UTT_SCAN_G")) : 0;
     /* lextree_hmm_histbin can only fire when more than 1.5 x maxhmmpf HMMs can be active at all */
     ud->hist_possible = (long long)proto->N > (long long)cfg->maxhmmpf + (cfg->maxhmmpf >> 1);
     ud->weak_possible = cfg->ptranskip != 0 || cfg->pbeam < cfg->hmmbeam;
@@ -822,6 +862,11 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
 
     ud->lane.resize(n_lanes);
     for (auto &hl : ud->lane) memset((void *)&hl, 0, sizeof hl);
+    if (T > WL_MAXT) { s3a_set_error("s3a_uttdec_init: more than %d lextrees", WL_MAXT); goto fail; }
+    DM(ud->S.ctx_all, sizeof(UCtx) * n_lanes);
+    DM(ud->S.nact_all, (size_t)n_lanes * 2 * WL_MAXT * 4);
+    if (hipMemset(ud->S.nact_all, 0, (size_t)n_lanes * 2 * WL_MAXT * 4) != hipSuccess
+        || hipMemset(ud->S.ctx_all, 0, sizeof(UCtx) * n_lanes) != hipSuccess) goto fail;
     for (int32_t z = 0; z < n_lanes; z++) {
         HostLane &hl = ud->lane[z];
         hl.ls = s3a_lexsearch_clone(proto, (void *)ud->stream);
@@ -838,6 +883,9 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         ULane &u = hl.d;
         u.sc = ls->d_sc; u.hist = ls->d_hist; u.outs = ls->d_outs; u.outh = ls->d_outh; u.bests = ls->d_bests;
         u.frame = ls->d_frame; u.pos = ls->d_pos; u.posf = ls->d_posf; u.act[0] = ls->d_act[0]; u.act[1] = ls->d_act[1];
+        /* the clone's list lengths move into the engine's array (borrowed: s3a_uttdec_free takes them back) */
+        (void)hipFree(ls->d_nact[0]); (void)hipFree(ls->d_nact[1]);
+        ls->d_nact[0] = ud->S.nact_all + ((size_t)z * 2) * WL_MAXT; ls->d_nact[1] = ud->S.nact_all + ((size_t)z * 2 + 1) * WL_MAXT;
         u.nact[0] = ls->d_nact[0]; u.nact[1] = ls->d_nact[1]; u.turn = ls->d_turn; u.selfemit = ls->d_selfemit;
         u.cnt = ls->d_cnt; u.base = ls->d_cand; u.best = ls->d_best; u.exits = ls->d_exit; u.nexit = ls->d_nexit;
         u.first = ls->d_first; u.eflag = ls->d_eflag; u.hbin = ls->d_hbin; u.done = ls->d_done; u.ctot = ls->d_ctot;
@@ -845,7 +893,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         u.scan_flag = ls->d_scan_flag; u.scan_agg = ls->d_scan_agg; u.scan_pre = ls->d_scan_pre; u.key = ls->d_key;
         u.sen_act = hl.sc->act_d; u.scr = hl.sc->scr_d; u.misc = hl.sc->misc_d; u.bstidx = hl.sc->bstidx_d;
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
-        DM(u.ctx, sizeof(UCtx));
+        u.ctx = ud->S.ctx_all + z;
         DM(u.pack, (size_t)(6 * T + 16 + 3 * proto->pack_max_exits) * 4);
         if (wlane_alloc(u.w, ud->vh_cap, max_frames, ud->ex_cap, ud->cand_cap, ud->new_cap, cfg->n_word, ud->stream) != S3A_OK) goto fail;
         if (hipHostMalloc((void **)&hl.h_ctx, sizeof(UCtx)) != hipSuccess
@@ -1003,14 +1051,17 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
         UKL(UK_HMM_EVAL, ku_hmm_eval<256>, dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S, f);
     else
         UKL(UK_HMM_EVAL, ku_hmm_eval<64>, dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
-    if (ud->hist_possible) {
-        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
-        UKL(UK_HIST_SORT, ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+    {
+        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= 32 ? 16 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
+        if (ud->hist_possible) UKL(UK_HIST_SORT, ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     }
     if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     UKL(UK_RESOLVE, ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
-    UKL(UK_SCAN, ku_scan, dim3(T * ud->scan_nc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc, f);
-    UKL(UK_WORD, ku_emit_word, dim3(1 + UE_WG_PER_TREE * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
+    /* chained scan: a few workgroups per tree take the chunks in turn (about as many workgroups as the chip holds) */
+    const int32_t scan_gc = ud->scan_gc > 0 ? min(ud->scan_gc, ud->scan_nc) : max(1, min(ud->scan_nc, max(2, 768 / max(1, T * n))));
+    UKL(UK_SCAN, ku_scan, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc, scan_gc, f);
+    /* (many lanes: fewer emission workgroups per tree -- each sweeps further -- instead of thousands of idle ones) */
+    UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= 32 && !ud->big_wl ? 2 : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
     if (ud->big_wl) {
         const dim3 gb(WL_BIG_G, 1, n), one(1, 1, n), tb(WL_THREADS);
         UKL(UK_WL_P2, ku_wl_p2, gb, tb, 0, st, LN, ud->lm->d, ud->dict, ud->par, f);
@@ -1141,6 +1192,14 @@ s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out)
     out->frame_start = tail; out->bestscore = tail + nf; out->bestvh = tail + 2 * nf;
     out->frame_stat = hl.h_fstat;
     out->max_cand = hl.h_ctx->max_cand; out->max_new = hl.h_ctx->max_new; out->n_tie_frames = hl.h_ctx->n_tie_frames;
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16)
+{
+    if (!ud || !out16 || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
+    for (int i = 0; i < 16; i++) out16[i] = ud->lane[lane].h_ctx->tacc[i];
     return S3A_OK;
 }
 

@@ -39,7 +39,6 @@
 #define WL_WAVES (WL_THREADS / 64)
 #define WL_MAXCALL 96       /* lextree_enter calls per frame: #CI phones + 1 */
 #define WL_MAXT 16          /* lextrees per decoder (2 x -Nlextree) */
-#define WL_HEAP_LDS 1536    /* frames with at most this many new entries replay the heap in LDS */
 #define WL_LDS_EX 1024      /* frames with at most this many word exits keep them (and their candidate offsets) in LDS */
 #define WL_RANK_MAX 384     /* entries above the pruning threshold ranked all against all; beyond: selection */
 #define WL_BIG_G 256        /* workgroups per lane of the wide-beam launches */
@@ -79,6 +78,7 @@ struct UCtx {
     int32_t max_cand, max_new, pad0, pad1;
     int32_t groups[8];
     int32_t calls[4 * WL_MAXCALL];
+    long long tacc[16];     /* time spent per word-level phase (100 MHz ticks; tools/wl_phases) */
 };
 
 struct WLane {              /* one lane's history table + per-frame scratch (device pointers) */
@@ -88,8 +88,9 @@ struct WLane {              /* one lane's history table + per-frame scratch (dev
     int32_t *frame_start, *bestscore, *bestvh;      /* [max_frames + 2] */
     int32_t *st;            /* [0] n_entry  [1] n_frm */
     int32_t *ex_off;        /* [ex_cap + 1] first candidate of every exit */
+    int32_t *ex_info;       /* [3][ex_cap] per exit: first predecessor (-1: filler) | LM word id (filler: its penalty) | score[history] */
     int32_t ex_cap;
-    int32_t *cand_score, *cand_slot, *cand_pref, *cand_e;      /* [cand_cap] */
+    int32_t *cand_score, *cand_slot, *cand_pref, *cand_e, *cand_i;     /* [cand_cap] (cand_i: the predecessor entry) */
     int32_t cand_cap;
     unsigned long long *hkey, *hbest;               /* [hmask + 1] */
     uint32_t *hfirst;
@@ -118,6 +119,52 @@ wl_find(const int32_t *__restrict__ v, int32_t n, int32_t w)
         if (v[mid] < w) lo = mid + 1; else hi = mid;
     }
     return (lo < n && v[lo] == w) ? lo : -1;
+}
+
+/* Two searches at once, 8-ary: a round is 7 + 7 INDEPENDENT loads, so a look-up in a run of 1000 words is four
+ * dependent round trips instead of ten -- what matters when ONE workgroup per lane walks the word level and the
+ * frame waits for it (the wide-beam launches keep the bisection: they are bound by traffic, not by the chain).
+ * a[0..na) / b[0..nb) ascending without duplicates (the successor lists of lm_3g_dmp.c); na, nb <= 0: empty.
+ * ra / rb = the position of wa / wb, or -1. */
+__device__ __forceinline__ void
+wl_find2(const int32_t *__restrict__ a, int32_t na, int32_t wa, const int32_t *__restrict__ b, int32_t nb, int32_t wb,
+         int32_t &ra, int32_t &rb)
+{
+    int32_t alo = 0, ahi = max(na, 0), blo = 0, bhi = max(nb, 0);     /* the first element >= w lies in [lo, hi] */
+    while (ahi - alo > 8 || bhi - blo > 8) {
+        const int32_t sa = ahi - alo > 8 ? (ahi - alo) >> 3 : 0, sb = bhi - blo > 8 ? (bhi - blo) >> 3 : 0;
+        int32_t xa[7], xb[7];
+#pragma unroll
+        for (int u = 0; u < 7; u++) { xa[u] = sa ? a[alo + (u + 1) * sa] : INT_MAX; xb[u] = sb ? b[blo + (u + 1) * sb] : INT_MAX; }
+        int32_t ca = 0, cb = 0;
+#pragma unroll
+        for (int u = 0; u < 7; u++) { ca += xa[u] < wa ? 1 : 0; cb += xb[u] < wb ? 1 : 0; }
+        if (sa) { const int32_t o = alo; if (ca < 7) ahi = o + (ca + 1) * sa; if (ca > 0) alo = o + ca * sa + 1; }
+        if (sb) { const int32_t o = blo; if (cb < 7) bhi = o + (cb + 1) * sb; if (cb > 0) blo = o + cb * sb + 1; }
+    }
+    int32_t ya[9], yb[9];
+#pragma unroll
+    for (int u = 0; u < 9; u++) {
+        ya[u] = (alo + u <= ahi && alo + u < na) ? a[alo + u] : INT_MAX;
+        yb[u] = (blo + u <= bhi && blo + u < nb) ? b[blo + u] : INT_MAX;
+    }
+    int32_t ca = 0, cb = 0;
+    bool fa = false, fb = false;
+#pragma unroll
+    for (int u = 0; u < 9; u++) {
+        ca += ya[u] < wa ? 1 : 0; cb += yb[u] < wb ? 1 : 0;
+        fa |= ya[u] == wa && wa != INT_MAX; fb |= yb[u] == wb && wb != INT_MAX;
+    }
+    ra = fa ? alo + ca : -1;
+    rb = fb ? blo + cb : -1;
+}
+
+__device__ __forceinline__ int32_t
+wl_find8(const int32_t *__restrict__ v, int32_t n, int32_t w)
+{
+    int32_t r, r2;
+    wl_find2(v, n, w, v, 0, 0, r, r2);
+    return r;
 }
 
 __device__ __forceinline__ int32_t
@@ -208,50 +255,6 @@ wl_pack(int32_t score, uint32_t seq)
 
 #define WL_ALOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-/* the reference's heap (sphinxbase util/heap.c) on index arrays; val = -score.  One thread. */
-struct WlHeap {
-    int32_t *val, *data, *nl, *nr, *l, *r;
-    int32_t n_alloc, top;
-    __device__ void insert(int32_t data_, int32_t val_)
-    {
-        /* subheap_insert, heap.c:113-148, unrolled into a descent */
-        int32_t cur = top, parent = -1, side = 0;
-        int32_t d = data_, v = val_;
-        while (cur >= 0) {
-            if (val[cur] > v) { const int32_t td = data[cur], tv = val[cur]; data[cur] = d; val[cur] = v; d = td; v = tv; }
-            parent = cur;
-            if (nl[cur] > nr[cur]) { nr[cur]++; side = 1; cur = r[cur]; }
-            else { nl[cur]++; side = 0; cur = l[cur]; }
-        }
-        const int32_t k = n_alloc++;
-        data[k] = d; val[k] = v; l[k] = r[k] = -1; nl[k] = nr[k] = 0;
-        if (parent < 0) top = k;
-        else if (side) r[parent] = k; else l[parent] = k;
-    }
-    __device__ int32_t pop()            /* heap_pop + subheap_pop, heap.c:159-213; -1 when empty */
-    {
-        if (top < 0) return -1;
-        const int32_t out = data[top];
-        int32_t cur = top, parent = -1, side = 0;
-        for (;;) {
-            const int32_t lc = l[cur], rc = r[cur];
-            if (lc < 0 && rc < 0) {             /* the node disappears */
-                if (parent < 0) top = -1;
-                else if (side) r[parent] = -1; else l[parent] = -1;
-                break;
-            }
-            int32_t nx;
-            if (lc < 0) { nx = rc; nr[cur]--; side = 1; }
-            else if (rc < 0 || val[lc] < val[rc]) { nx = lc; nl[cur]--; side = 0; }
-            else { nx = rc; nr[cur]--; side = 1; }
-            data[cur] = data[nx]; val[cur] = val[nx];
-            parent = cur;
-            cur = nx;
-        }
-        return out;
-    }
-};
-
 /* the LM context of a history entry with LM state (lw0, lw1), worked out ONCE when the entry is made:
  * the trigram run and back-off weight of the bigram (lw1, lw0) (load_tg, lm.c:1363-1525: a missing bigram
  * or no lw1 = an empty run, weight 0) and the bigram run of lw0 (lm_bg_score's search, lm.c:1262-1280).
@@ -262,29 +265,45 @@ wl_lm_context(const WLm &lm, int32_t lw0, int32_t lw1, int32_t *c5)
     int32_t t0 = 0, nt = 0, bowt = 0, b0 = 0, nb = -1;      /* nb < 0: unigram only, no back-off weight */
     if (lm.n_tg > 0 && lw1 >= 0) {
         const int32_t q0 = lm.ug_firstbg[lw1], qn = lm.ug_firstbg[lw1 + 1] - q0;
-        const int32_t b = qn > 0 ? wl_find(lm.bg_wid + q0, qn, lw0) : -1;
+        const int32_t b = qn > 0 ? wl_find8(lm.bg_wid + q0, qn, lw0) : -1;
         if (b >= 0) { bowt = lm.bg_bowt[q0 + b]; t0 = lm.bg_firsttg[q0 + b]; nt = lm.bg_firsttg[q0 + b + 1] - t0; }
     }
     if (lm.n_bg > 0 && lw0 >= 0) { b0 = lm.ug_firstbg[lw0]; nb = lm.ug_firstbg[lw0 + 1] - b0; }
     c5[0] = t0; c5[1] = nt; c5[2] = bowt; c5[3] = b0; c5[4] = nb;
 }
 
-/* lm_tg_score(lw1, lw0, lw3) for the predecessor entry i with precomputed context */
+/* lm_tg_score(lw1, lw0, lw3) for the predecessor entry i with precomputed context.  KARY: the trigram look-up and the
+ * bigram look-up it falls back to run side by side (wl_find2), everything else is loaded up front. */
+template <bool KARY>
 __device__ __forceinline__ int32_t
 wl_tg_score_ctx(const WLm &lm, const WLane &L, int32_t i, int32_t lw0, int32_t lw3, int32_t wid)
 {
     const int32_t t0 = L.lmc[i], nt = L.lmc[L.cap + i];
     int32_t s;
-    const int32_t k = nt > 0 ? wl_find(lm.tg_wid + t0, nt, lw3) : -1;
-    if (k >= 0) s = lm.tg_prob[t0 + k];
-    else {
+    if (KARY) {
         const int32_t bowt = L.lmc[2 * (size_t)L.cap + i], b0 = L.lmc[3 * (size_t)L.cap + i], nb = L.lmc[4 * (size_t)L.cap + i];
-        if (nb < 0) s = lm.ug_prob[lw3];
+        const int32_t ug = lm.ug_prob[lw3], ubo = lw0 >= 0 ? lm.ug_bowt[lw0] : 0;
+        int32_t k, j;
+        wl_find2(lm.tg_wid + t0, nt, lw3, lm.bg_wid + b0, nb, lw3, k, j);
+        if (k >= 0) s = lm.tg_prob[t0 + k];
         else {
-            const int32_t j = nb > 0 ? wl_find(lm.bg_wid + b0, nb, lw3) : -1;
-            s = j >= 0 ? lm.bg_prob[b0 + j] : add32(lm.ug_bowt[lw0], lm.ug_prob[lw3]);
+            if (nb < 0) s = ug;
+            else s = j >= 0 ? lm.bg_prob[b0 + j] : add32(ubo, ug);
+            s = add32(bowt, s);
         }
-        s = add32(bowt, s);
+    }
+    else {
+        const int32_t k = nt > 0 ? wl_find(lm.tg_wid + t0, nt, lw3) : -1;
+        if (k >= 0) s = lm.tg_prob[t0 + k];
+        else {
+            const int32_t bowt = L.lmc[2 * (size_t)L.cap + i], b0 = L.lmc[3 * (size_t)L.cap + i], nb = L.lmc[4 * (size_t)L.cap + i];
+            if (nb < 0) s = lm.ug_prob[lw3];
+            else {
+                const int32_t j = nb > 0 ? wl_find(lm.bg_wid + b0, nb, lw3) : -1;
+                s = j >= 0 ? lm.bg_prob[b0 + j] : add32(lm.ug_bowt[lw0], lm.ug_prob[lw3]);
+            }
+            s = add32(bowt, s);
+        }
     }
     if (lm.inclass) s = add32(s, lm.inclass[wid]);
     return s;
@@ -308,13 +327,16 @@ struct WlFr {               /* what every phase needs of the frame */
     const int32_t *ex;      /* exits: (wid, score, history) x nx */
     const int32_t *off;     /* [nx + 1] first candidate of every exit */
     const int32_t *tb;      /* [T + 1] first exit of every tree */
+    const int32_t *xa, *xb, *xc;    /* per exit (P1): first predecessor entry (-1: a filler word) | LM word id (filler: its
+                             * penalty) | path score of the exit's history entry */
     int32_t nx, n_cand, cf;
 };
 
-/* P1: the exits' candidate counts -> off[], n_cand.  tb / err_out are shared-memory words of the caller. */
+/* P1: the exits' candidate counts -> off[], n_cand; what every candidate of an exit shares -> xa / xb / xc.
+ * tb / err_out are shared-memory words of the caller. */
 __device__ __forceinline__ int32_t
 wl_p1(const WLane &L, const int32_t *pack, const WDict &dict, int32_t T, int32_t *tb, int32_t *off, const int32_t *ex,
-      int32_t *err_out)
+      int32_t *xa, int32_t *xb, int32_t *xc, int32_t *err_out)
 {
     const int32_t tid = threadIdx.x;
     const int32_t *fstart = L.frame_start;
@@ -334,9 +356,12 @@ wl_p1(const WLane &L, const int32_t *pack, const WDict &dict, int32_t T, int32_t
     if (*err_out) return -1;
     for (int32_t e = tid; e < nx; e += WL_THREADS) {
         const int32_t w = ex[3 * e], h = ex[3 * e + 2];
-        int32_t c = 1;
-        if (!dict.is_filler[w] && h != 0) { const int32_t f = L.ef[h]; c = fstart[f + 1] - fstart[f]; }
+        const bool filler = dict.is_filler[w] != 0;
+        const int32_t aux = filler ? dict.fillpen[w] : dict.lwid[w], sh = L.score[h];
+        int32_t c = 1, pb = 0;
+        if (!filler && h != 0) { const int32_t f = L.ef[h]; pb = fstart[f]; c = fstart[f + 1] - pb; }
         off[e] = c;
+        xa[e] = filler ? -1 : pb; xb[e] = aux; xc[e] = sh;
     }
     const int32_t n_cand = wl_scan<false>(off, off, nx, 0);
     if (tid == 0) off[nx] = n_cand;
@@ -344,34 +369,26 @@ wl_p1(const WLane &L, const int32_t *pack, const WDict &dict, int32_t T, int32_t
     return n_cand;
 }
 
-/* the predecessor entry of candidate c of exit e */
-__device__ __forceinline__ int32_t
-wl_pred_of(const WLane &L, const WlFr &fr, int32_t e, int32_t c, int32_t h)
-{
-    return (h == 0 ? 0 : L.frame_start[L.ef[h]]) + (c - fr.off[e]);
-}
-
-/* P2: the candidates' path scores, their exits; the exclusive prefix maximum INSIDE the range -> cand_pref;
- * returns the range's maximum.  *bad (shared) is set when a word exit has no LM word. */
+/* P2: the candidates' path scores, their exits and predecessors; the exclusive prefix maximum INSIDE the range ->
+ * cand_pref; returns the range's maximum.  *bad (shared) is set when a word exit has no LM word. */
+template <bool KARY>
 __device__ __forceinline__ int32_t
 wl_p2(const WLane &L, const WLm &lm, const WDict &dict, const WlFr &fr, int32_t c_lo, int32_t c_hi, int32_t *bad)
 {
     for (int32_t c = c_lo + (int32_t)threadIdx.x; c < c_hi; c += WL_THREADS) {
         int32_t lo = 0, hi = fr.nx;             /* the exit of candidate c: last e with off[e] <= c */
         while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (fr.off[mid] <= c) lo = mid; else hi = mid; }
-        const int32_t e = lo, w = fr.ex[3 * e], scr = fr.ex[3 * e + 1], h = fr.ex[3 * e + 2];
+        const int32_t e = lo, w = fr.ex[3 * e], scr = fr.ex[3 * e + 1], pb = fr.xa[e], aux = fr.xb[e];
         L.cand_e[c] = e;
-        int32_t sc;
-        if (dict.is_filler[w]) sc = add32(scr, dict.fillpen[w]);
+        int32_t sc, i;
+        if (pb < 0) { sc = add32(scr, aux); i = fr.ex[3 * e + 2]; }         /* a filler word: its penalty, no LM state change */
+        else if (aux < 0) { *bad = 1; sc = INT_MIN; i = 0; }
         else {
-            const int32_t lwid = dict.lwid[w];
-            if (lwid < 0) { *bad = 1; sc = INT_MIN; }
-            else {
-                const int32_t i = wl_pred_of(L, fr, e, c, h);
-                sc = add32(add32(L.score[i], add32(scr, -L.score[h])), wl_tg_score_ctx(lm, L, i, L.lw0[i], lwid, w));
-            }
+            i = pb + (c - fr.off[e]);
+            sc = add32(add32(L.score[i], add32(scr, -fr.xc[e])), wl_tg_score_ctx<KARY>(lm, L, i, L.lw0[i], aux, w));
         }
         L.cand_score[c] = sc;
+        L.cand_i[c] = i;
     }
     __syncthreads();
     return wl_scan<true>(L.cand_score + c_lo, L.cand_pref + c_lo, c_hi - c_lo, INT_MIN);
@@ -383,13 +400,13 @@ __device__ __forceinline__ void
 wl_p3(const WLane &L, const WDict &dict, const WPar &par, const WlFr &fr, int32_t c_lo, int32_t c_hi, int32_t before)
 {
     for (int32_t c = c_lo + (int32_t)threadIdx.x; c < c_hi; c += WL_THREADS) {
-        const int32_t e = L.cand_e[c], w = fr.ex[3 * e], h = fr.ex[3 * e + 2], sc = L.cand_score[c];
-        const bool filler = dict.is_filler[w] != 0;
+        const int32_t e = L.cand_e[c], i = L.cand_i[c], sc = L.cand_score[c];
+        const bool filler = fr.xa[e] < 0;
         int32_t slot = -1;
         if (filler || add32(sc, -par.wbeam) >= max(before, L.cand_pref[c])) {
             unsigned long long key;
-            if (filler) key = wl_key(L.lw0[h], L.lw1[h]);
-            else key = wl_key(dict.lwid[w], L.lw0[wl_pred_of(L, fr, e, c, h)]);
+            if (filler) key = wl_key(L.lw0[i], L.lw1[i]);
+            else key = wl_key(fr.xb[e], L.lw0[i]);
             uint32_t hh = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)L.hmask;
             for (;;) {
                 const unsigned long long old = atomicCAS(&L.hkey[hh], 0ull, key);
@@ -438,16 +455,13 @@ wl_p5(const WLane &L, const WDict &dict, const WPar &par, const WlFr &fr, int32_
         if (slot < 0) continue;
         const int32_t sc = L.cand_score[c];
         if (WL_ALOAD(&L.hbest[slot]) != wl_pack(sc, (uint32_t)c)) continue;
-        const int32_t e = L.cand_e[c], w = fr.ex[3 * e], scr = fr.ex[3 * e + 1], h = fr.ex[3 * e + 2];
-        const int32_t k = WL_ALOAD(&L.hlead_rank[slot]), ascr = add32(scr, -L.score[h]);
+        const int32_t e = L.cand_e[c], w = fr.ex[3 * e], scr = fr.ex[3 * e + 1], h = fr.ex[3 * e + 2], i = L.cand_i[c];
+        const int32_t k = WL_ALOAD(&L.hlead_rank[slot]), ascr = add32(scr, -fr.xc[e]);
         int32_t ty = 0;
         for (int32_t t = 0; t < par.T; t++) if (e >= fr.tb[t]) ty = par.tree_type[t];
         sg_wid[k] = w; sg_sf[k] = L.ef[h] + 1; sg_ascr[k] = ascr; sg_score[k] = sc; sg_type[k] = ty; sg_slot[k] = slot;
-        if (dict.is_filler[w]) { sg_lscr[k] = dict.fillpen[w]; sg_pred[k] = h; sg_lw0[k] = L.lw0[h]; sg_lw1[k] = L.lw1[h]; }
-        else {
-            const int32_t i = wl_pred_of(L, fr, e, c, h);
-            sg_lscr[k] = add32(sc, -add32(L.score[i], ascr)); sg_pred[k] = i; sg_lw0[k] = dict.lwid[w]; sg_lw1[k] = L.lw0[i];
-        }
+        if (fr.xa[e] < 0) { sg_lscr[k] = fr.xb[e]; sg_pred[k] = h; sg_lw0[k] = L.lw0[h]; sg_lw1[k] = L.lw1[h]; }
+        else { sg_lscr[k] = add32(sc, -add32(L.score[i], ascr)); sg_pred[k] = i; sg_lw0[k] = fr.xb[e]; sg_lw1[k] = L.lw0[i]; }
     }
 }
 
@@ -617,16 +631,20 @@ wl_heap_nrl(const int32_t *sg_score, int32_t n, int32_t *hs, int32_t stride, int
     (void)sh_cnt;
 }
 
+/* phase timing (thread 0; constant 100 MHz clock): ctx->tacc[i] += time since the previous stamp */
+#define WL_STAMP(tp, i) do { if (threadIdx.x == 0 && (tp)) { const long long t_ = (long long)wall_clock64(); ctx->tacc[i] += t_ - *(tp); *(tp) = t_; } } while (0)
+
 /* P6 + P7: vithist_prune, vithist_frame_gc, srch_utt_word_trans, vithist_frame_windup; arms the lane's next frame.
  * One workgroup.  M = the frame's best score, n_new = entries staged. */
 __device__ __forceinline__ void
 wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, int32_t cf,
-          int32_t nx, int32_t n_new, int32_t M)
+          int32_t nx, int32_t n_new, int32_t M, long long *tp)
 {
     __shared__ int32_t s_i[16];
     __shared__ unsigned long long s_ci[256];
     __shared__ unsigned long long s_u64[2];
-    __shared__ int32_t s_heap[6 * WL_HEAP_LDS];
+    __shared__ int32_t s_rk[12][WL_RANK_MAX];
+    __shared__ int32_t s_cnt[2][256];
     const int32_t tid = threadIdx.x, T = par.T;
     const int32_t fs = L.st[0];
     int32_t *sg_wid = L.sg, *sg_sf = L.sg + L.new_cap, *sg_ascr = L.sg + 2 * L.new_cap, *sg_lscr = L.sg + 3 * L.new_cap,
@@ -638,7 +656,7 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
     int32_t *a_list = L.srt, *a_sorted = L.srt + L.new_cap, *a_c = L.srt + 2 * L.new_cap, *a_scan = L.srt + 3 * L.new_cap,
         *a_first = L.srt + 4 * L.new_cap, *a_val = L.srt + 5 * L.new_cap;
     __syncthreads();
-    if (tid == 0) { s_i[1] = 0; s_i[2] = 0; s_i[3] = INT_MAX; s_i[5] = 0; s_i[6] = 0; s_i[7] = INT_MIN; s_i[8] = 0; s_i[9] = 0; s_i[10] = 0; }
+    if (tid == 0) { s_i[1] = 0; s_i[2] = 0; s_i[3] = INT_MAX; s_i[5] = 0; s_i[6] = 0; s_i[7] = INT_MIN; s_i[8] = 0; s_i[9] = 0; s_i[10] = 0; s_i[13] = ctx->n_lextrans; }
     for (int32_t k = tid; k < n_new; k += WL_THREADS) sg_valid[k] = 0;
     __syncthreads();
     for (int32_t k0 = 0; k0 < n_new; k0 += WL_THREADS) {
@@ -790,82 +808,67 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
     }
     if (!done && n_th > WL_RANK_MAX) done = true;      /* (-maxwpf 0 / -maxhistpf 0: nothing survives) */
     if (!done) {
-        /* ---- rank by score; two entries above the threshold that tie pop in the heap's order: replay it ---- */
-        if (n_th <= WL_RANK_MAX) {
-            for (int32_t q = tid; q < n_th; q += WL_THREADS) {
-                const int32_t k = a_list[q], sc = sg_score[k];
-                int32_t r = 0, tie = 0;
-                for (int32_t p = 0; p < n_th; p++) {
-                    const int32_t k2 = a_list[p], s2 = sg_score[k2];
-                    r += (s2 > sc || (s2 == sc && k2 < k)) ? 1 : 0;
-                    tie |= (s2 == sc && k2 != k) ? 1 : 0;
+        /* ---- at most WL_RANK_MAX entries above the threshold: rank them by score, all against all, in LDS (s_rk: the
+         * entry, its score, its word, filler?).  Two of them that TIE pop in the heap's order: wl_heap_nrl, ranks again ---- */
+        for (int32_t q = tid; q < n_th; q += WL_THREADS) {
+            const int32_t k = a_list[q], w = sg_wid[k];
+            s_rk[0][q] = k; s_rk[1][q] = sg_score[k]; s_rk[2][q] = w; s_rk[3][q] = dict.is_filler[w] ? 1 : 0;
+        }
+        __syncthreads();
+        for (int pass = 0; pass < 2; pass++) {
+            int32_t k = 0, w = 0, fl = 0, r = 0, tie = 0;
+            if (tid < n_th) {
+                k = s_rk[0][tid]; w = s_rk[2][tid]; fl = s_rk[3][tid];
+                const int32_t sc = s_rk[1][tid], nk = pass ? s_rk[4][tid] : k;
+                for (int32_t p2 = 0; p2 < n_th; p2++) {
+                    const int32_t s2 = s_rk[1][p2], n2 = pass ? s_rk[4][p2] : s_rk[0][p2];
+                    r += (s2 > sc || (s2 == sc && n2 < nk)) ? 1 : 0;
+                    tie |= (s2 == sc && p2 != tid) ? 1 : 0;
                 }
-                a_sorted[r] = k;
                 if (tie) s_i[2] = 1;
             }
             __syncthreads();
-        }
-        __syncthreads();
-        if (s_i[2] && par.maxhist > 0) {
-            /* two entries above the threshold tie: they pop in the heap's order.  Few entries: one thread replays the
-             * reference's heap in LDS; more: the pop order among equals in parallel (wl_heap_nrl), ranks again */
-            if (n_new <= WL_HEAP_LDS) {
-                if (tid == 0) {
-                    WlHeap hp;
-                    hp.val = s_heap; hp.data = s_heap + WL_HEAP_LDS; hp.nl = s_heap + 2 * WL_HEAP_LDS; hp.nr = s_heap + 3 * WL_HEAP_LDS;
-                    hp.l = s_heap + 4 * WL_HEAP_LDS; hp.r = s_heap + 5 * WL_HEAP_LDS; hp.n_alloc = 0; hp.top = -1;
-                    for (int32_t k = 0; k < n_new; k++) hp.insert(k, (int32_t)(0u - (uint32_t)sg_score[k]));
-                    for (int32_t r = 0; r < n_th; r++) a_sorted[r] = hp.pop();
-                    ctx->n_tie_frames++;
-                }
-            }
-            else {
+            if (pass == 0 && s_i[2] && par.maxhist > 0) {
                 wl_heap_nrl(sg_score, n_new, L.heap, L.new_cap, nrl);
                 if (tid == 0) ctx->n_tie_frames++;
                 __syncthreads();
-                for (int32_t q = tid; q < n_th; q += WL_THREADS) {
-                    const int32_t k = a_list[q], sc = sg_score[k], nk = nrl[k];
-                    int32_t r = 0;
-                    for (int32_t p = 0; p < n_th; p++) {
-                        const int32_t k2 = a_list[p], s2 = sg_score[k2];
-                        r += (s2 > sc || (s2 == sc && nrl[k2] < nk)) ? 1 : 0;
-                    }
-                    a_sorted[r] = k;
-                }
+                if (tid < n_th) s_rk[4][tid] = nrl[k];
+                __syncthreads();
+                continue;
             }
+            if (tid < n_th) { s_rk[5][r] = k; s_rk[6][r] = w; s_rk[7][r] = fl; }       /* the pop order */
             __syncthreads();
+            break;
         }
         /* the walk of vithist.c:683-713 over the sorted entries, in closed form */
-        for (int32_t r = tid; r < n_th; r += WL_THREADS)
-            if (dict.is_filler[sg_wid[a_sorted[r]]]) atomicMin(&s_i[3], r);
+        if (tid < n_th && s_rk[7][tid]) atomicMin(&s_i[3], tid);
         __syncthreads();
         const int32_t first_filler = s_i[3];
-        for (int32_t r = tid; r < n_th; r += WL_THREADS) {
-            const int32_t w = sg_wid[a_sorted[r]];
-            if (!(dict.is_filler[w] && r > first_filler)) atomicMin(&L.wfirst[w], r);
+        {
+            const int32_t r = tid;
+            int32_t f = -1, c = 0, w = 0;
+            bool elig = false;
+            if (r < n_th) {
+                w = s_rk[6][r];
+                elig = !(s_rk[7][r] && r > first_filler);
+                if (elig) {                         /* where the word was first seen */
+                    f = r;
+                    for (int32_t p2 = 0; p2 < r; p2++)
+                        if (s_rk[6][p2] == w && !(s_rk[7][p2] && p2 > first_filler)) { f = p2; break; }
+                }
+                s_rk[8][r] = (elig && f == r) ? 1 : 0;
+            }
+            (void)wl_scan<false>(s_rk[8], s_rk[9], n_th, 0);        /* s_rk[9][r] = index of the word first seen at r */
+            if (r < n_th) {
+                c = (f >= 0 && s_rk[9][f] < par.maxwpf && (f == r || !par.bghist)) ? 1 : 0;
+                s_rk[10][r] = c;
+            }
+            (void)wl_scan<false>(s_rk[10], s_rk[11], n_th, 0);      /* entries kept before r */
+            if (r < n_th && c && s_rk[11][r] < par.maxhist) sg_valid[s_rk[5][r]] = 1;
         }
-        __syncthreads();
-        for (int32_t r = tid; r < n_th; r += WL_THREADS) {
-            const int32_t w = sg_wid[a_sorted[r]];
-            const bool elig = !(dict.is_filler[w] && r > first_filler);
-            const int32_t f = elig ? WL_ALOAD(&L.wfirst[w]) : -1;
-            a_first[r] = f;
-            a_c[r] = (elig && f == r) ? 1 : 0;
-        }
-        (void)wl_scan<false>(a_c, a_scan, n_th, 0);         /* a_scan[r] = index of the word first seen at r */
-        for (int32_t r = tid; r < n_th; r += WL_THREADS) {
-            const int32_t f = a_first[r];
-            int32_t c = 0;
-            if (f >= 0 && a_scan[f] < par.maxwpf && (f == r || !par.bghist)) c = 1;
-            a_c[r] = c;
-        }
-        __syncthreads();
-        for (int32_t r = tid; r < n_th; r += WL_THREADS) L.wfirst[sg_wid[a_sorted[r]]] = INT_MAX;
-        (void)wl_scan<false>(a_c, a_first, n_th, 0);        /* entries kept before r */
-        for (int32_t r = tid; r < n_th; r += WL_THREADS)
-            if (a_c[r] && a_first[r] < par.maxhist) sg_valid[a_sorted[r]] = 1;
         __syncthreads();
     }
+    WL_STAMP(tp, 6);
     /* vithist_frame_gc: the valid entries, in table order, become the frame's entries */
     const int32_t n_valid = wl_scan<false>(sg_valid, a_scan, n_new, 0);
     if (tid == 0) { s_u64[0] = 0ull; }
@@ -890,41 +893,55 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
     }
     __syncthreads();
 
-    /* ---- P7: srch_utt_word_trans, vithist_frame_windup, the lane's next frame ---- */
+    WL_STAMP(tp, 7);
+    /* ---- P7: srch_utt_word_trans, vithist_frame_windup, the lane's next frame ----
+     * One lextree_enter call per word-final CI phone whose best entry is within -wend_beam of the best of them, in
+     * phone order; a lane per phone reads its root list (lcmap), the calls' places follow from counting. */
+    const int32_t bestvh = s_u64[0] ? (int32_t)(0xffffffffu - (uint32_t)(s_u64[0] & 0xffffffffull)) : -1;
+    const int32_t ktree = (s_i[13] % (par.n_lextree * par.epl)) / par.epl;       /* the unigram tree of this transition */
+    if (tid == 0) { s_i[14] = INT_MIN; s_i[15] = 0; }
+    __syncthreads();
+    int32_t p_bs = 0, p_bv = 0, p_m0 = 0, p_m1 = 0;
+    bool p_on = false;
+    if (bestvh >= 0 && tid < dict.n_ci && s_ci[tid]) {
+        p_on = true;
+        p_bs = (int32_t)((uint32_t)(s_ci[tid] >> 32) ^ 0x80000000u);
+        p_bv = (int32_t)(0xffffffffu - (uint32_t)(s_ci[tid] & 0xffffffffull));
+        const int32_t *m = par.lcmap + ((size_t)ktree * (dict.n_ci + 1) + tid) * 2;
+        p_m0 = m[0]; p_m1 = m[1];
+        atomicMax(&s_i[14], p_bs);
+    }
+    __syncthreads();
+    if (p_on) p_on = par.wordend == 0 || p_bs > add32(par.wordend, s_i[14]);
+    if (p_on && p_m1 < 0) { atomicOr(&s_i[15], WL_E_LC); p_on = false; }
+    if (tid < 256) { s_cnt[0][tid] = p_on ? 1 : 0; s_cnt[1][tid] = p_on ? p_m1 : 0; }
+    __syncthreads();
+    if (p_on) {
+        int32_t idx = 0, ent = 0;
+        for (int32_t q = 0; q < tid; q++) { idx += s_cnt[0][q]; ent += s_cnt[1][q]; }
+        if (idx >= WL_MAXCALL - 1) atomicOr(&s_i[15], WL_E_CALLS);
+        else { ctx->calls[4 * idx] = p_bs; ctx->calls[4 * idx + 1] = p_bv; ctx->calls[4 * idx + 2] = p_m0; ctx->calls[4 * idx + 3] = ent; }
+    }
+    __syncthreads();
     if (tid == 0) {
         const int32_t n_entry = fs + n_valid;
-        const int32_t bestvh = s_u64[0] ? (int32_t)(0xffffffffu - (uint32_t)(s_u64[0] & 0xffffffffull)) : -1;
         const int32_t bh = pack[3 * T + 3];
-        int32_t n_calls = 0, n_ent = 0, n_groups = 0, e2 = 0;
+        int32_t n_calls = 0, n_ent = 0, n_groups = 0;
+        const int32_t e2 = s_i[15];
         L.bestscore[cf] = nx > 0 ? M : INT_MIN;
         L.bestvh[cf] = bestvh;
         if (bestvh >= 0) {
-            int32_t maxp = INT_MIN;
-            int32_t k = ctx->n_lextrans++;
-            k = (k % (par.n_lextree * par.epl)) / par.epl;
-            for (int32_t p = 0; p < dict.n_ci; p++)
-                if (s_ci[p]) maxp = max(maxp, (int32_t)((uint32_t)(s_ci[p] >> 32) ^ 0x80000000u));
-            const int32_t lo = n_ent;
-            for (int32_t p = 0; p < dict.n_ci; p++) {
-                if (!s_ci[p]) continue;
-                const int32_t bs = (int32_t)((uint32_t)(s_ci[p] >> 32) ^ 0x80000000u);
-                const int32_t bv = (int32_t)(0xffffffffu - (uint32_t)(s_ci[p] & 0xffffffffull));
-                if (!(par.wordend == 0 || bs > add32(par.wordend, maxp))) continue;
-                const int32_t *m = par.lcmap + ((size_t)k * (dict.n_ci + 1) + p) * 2;
-                if (m[1] < 0) { e2 |= WL_E_LC; continue; }
-                if (n_calls >= WL_MAXCALL - 1) { e2 |= WL_E_CALLS; break; }
-                ctx->calls[4 * n_calls] = bs; ctx->calls[4 * n_calls + 1] = bv; ctx->calls[4 * n_calls + 2] = m[0];
-                ctx->calls[4 * n_calls + 3] = n_ent;
-                n_ent += m[1]; n_calls++;
-            }
+            for (int32_t q = 0; q < dict.n_ci && q < 256; q++) { n_calls += s_cnt[0][q]; n_ent += s_cnt[1][q]; }
+            if (n_calls > WL_MAXCALL - 1) n_calls = WL_MAXCALL - 1;     /* (WL_E_CALLS is set: the utterance stops) */
+            ctx->n_lextrans = s_i[13] + 1;
             if (n_calls > 0) {
-                ctx->groups[0] = k; ctx->groups[1] = lo; ctx->groups[2] = n_ent; ctx->groups[3] = 0;
+                ctx->groups[0] = ktree; ctx->groups[1] = 0; ctx->groups[2] = n_ent; ctx->groups[3] = 0;
                 n_groups = 1;
             }
             {   /* the filler lextree of this transition: the frame's best exit, no left context */
-                const int32_t tf = par.n_lextree + k;
+                const int32_t tf = par.n_lextree + ktree;
                 const int32_t *m = par.lcmap + ((size_t)tf * (dict.n_ci + 1) + dict.n_ci) * 2;
-                ctx->calls[4 * n_calls] = L.bestscore[cf]; ctx->calls[4 * n_calls + 1] = bestvh;
+                ctx->calls[4 * n_calls] = nx > 0 ? M : INT_MIN; ctx->calls[4 * n_calls + 1] = bestvh;
                 ctx->calls[4 * n_calls + 2] = m[0]; ctx->calls[4 * n_calls + 3] = n_ent;
                 ctx->groups[4 * n_groups] = tf; ctx->groups[4 * n_groups + 1] = n_ent; ctx->groups[4 * n_groups + 3] = n_calls;
                 n_ent += m[1]; n_calls++;
@@ -946,6 +963,7 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
         ctx->cur ^= 1;                                  /* lextree_active_swap */
         if (cf + 1 >= ctx->nfr || e2) ctx->active = 0;
     }
+    WL_STAMP(tp, 8);
 }
 
 /* errors that end the utterance (as the reference's E_FATAL / SRCH_FAILURE do) */
@@ -975,14 +993,17 @@ wl_check_new(const WLane &L, UCtx *ctx, int32_t n_new)
 
 /* the whole frame by ONE workgroup */
 __device__ __forceinline__ void
-d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, const int32_t cf)
+d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, const int32_t cf,
+                  long long t_in)
 {
     __shared__ int32_t s_tb[WL_MAXT + 1];
     __shared__ int32_t s_flag[2];
     __shared__ int32_t s_ex[3 * WL_LDS_EX], s_off[WL_LDS_EX + 1];    /* the usual frame: exits + candidate offsets in LDS */
+    __shared__ int32_t s_xi[3][WL_LDS_EX];
     const int32_t T = par.T, hdr = 6 * T + 16;
     const int32_t *ex = pack + hdr;
-    int32_t *off = L.ex_off;
+    int32_t *off = L.ex_off, *xa = L.ex_info, *xb = L.ex_info + L.ex_cap, *xc = L.ex_info + 2 * (size_t)L.ex_cap;
+    long long tprev = t_in, *tp = &tprev;
     int32_t nx0 = 0;
     for (int32_t t = 0; t < T; t++) nx0 += pack[3 * T + 8 + t];
     if (threadIdx.x == 0) s_flag[1] = 0;
@@ -990,24 +1011,30 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
         for (int32_t i = threadIdx.x; i < 3 * nx0; i += WL_THREADS) s_ex[i] = ex[i];
         __syncthreads();
         ex = s_ex;
-        off = s_off;
+        off = s_off; xa = s_xi[0]; xb = s_xi[1]; xc = s_xi[2];
     }
-    const int32_t n_cand = wl_p1(L, pack, dict, T, s_tb, off, ex, &s_flag[0]);
+    WL_STAMP(tp, 0);
+    const int32_t n_cand = wl_p1(L, pack, dict, T, s_tb, off, ex, xa, xb, xc, &s_flag[0]);
     if (n_cand < 0) { wl_stop(ctx, s_flag[0]); return; }
     if (!wl_check_caps(L, ctx, n_cand)) return;
     WlFr fr;
-    fr.ex = ex; fr.off = off; fr.tb = s_tb; fr.nx = s_tb[T]; fr.n_cand = n_cand; fr.cf = cf;
-    const int32_t M = wl_p2(L, lm, dict, fr, 0, n_cand, &s_flag[1]);
+    fr.ex = ex; fr.off = off; fr.tb = s_tb; fr.xa = xa; fr.xb = xb; fr.xc = xc; fr.nx = s_tb[T]; fr.n_cand = n_cand; fr.cf = cf;
+    WL_STAMP(tp, 1);
+    const int32_t M = wl_p2<true>(L, lm, dict, fr, 0, n_cand, &s_flag[1]);
     if (s_flag[1]) { wl_stop(ctx, WL_E_NOLM); return; }
+    WL_STAMP(tp, 2);
     wl_p3(L, dict, par, fr, 0, n_cand, INT_MIN);
     __syncthreads();
+    WL_STAMP(tp, 3);
     const int32_t n_new = wl_p4a(L, 0, n_cand);
     if (!wl_check_new(L, ctx, n_new)) return;
     wl_p4b(L, 0, n_cand, 0);
     __syncthreads();
+    WL_STAMP(tp, 4);
     wl_p5(L, dict, par, fr, 0, n_cand);
     __syncthreads();
-    wl_finish(L, ctx, pack, lm, dict, par, cf, fr.nx, n_new, M);
+    WL_STAMP(tp, 5);
+    wl_finish(L, ctx, pack, lm, dict, par, cf, fr.nx, n_new, M, tp);
 }
 
 /* ---- the same frame as a sequence of launches, G workgroups per lane (wide-beam frames) ---- */
@@ -1026,7 +1053,8 @@ d_wl_big_begin(const WLane &L, UCtx *ctx, const int32_t *pack, const WDict &dict
     __shared__ int32_t s_flag[2];
     const int32_t T = par.T, hdr = 6 * T + 16;
     if (threadIdx.x == 0) L.st[8] = 1;                  /* stop, until this launch got through */
-    const int32_t n_cand = wl_p1(L, pack, dict, T, s_tb, L.ex_off, pack + hdr, &s_flag[0]);
+    const int32_t n_cand = wl_p1(L, pack, dict, T, s_tb, L.ex_off, pack + hdr, L.ex_info, L.ex_info + L.ex_cap,
+                                 L.ex_info + 2 * (size_t)L.ex_cap, &s_flag[0]);
     if (n_cand < 0) { wl_stop(ctx, s_flag[0]); return; }
     if (!wl_check_caps(L, ctx, n_cand)) return;
     if (threadIdx.x <= T) L.tb[threadIdx.x] = s_tb[threadIdx.x];
@@ -1037,6 +1065,7 @@ d_wl_big_begin(const WLane &L, UCtx *ctx, const int32_t *pack, const WDict &dict
     if (L.st[8]) return;                                                                                   \
     WlFr fr;                                                                                               \
     fr.ex = pack + 6 * par.T + 16; fr.off = L.ex_off; fr.tb = L.tb; fr.nx = L.st[4]; fr.n_cand = L.st[5]; fr.cf = cf; \
+    fr.xa = L.ex_info; fr.xb = L.ex_info + L.ex_cap; fr.xc = L.ex_info + 2 * (size_t)L.ex_cap;             \
     int32_t c_lo, c_hi;                                                                                    \
     wl_chunk(fr.n_cand, g, G, c_lo, c_hi)
 
@@ -1049,7 +1078,7 @@ d_wl_big_p2(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const
     WL_BIG_FRAME;
     if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
-    const int32_t m = wl_p2(L, lm, dict, fr, c_lo, c_hi, &s_bad);
+    const int32_t m = wl_p2<false>(L, lm, dict, fr, c_lo, c_hi, &s_bad);
     if (threadIdx.x == 0) { L.part[g] = m; if (s_bad) atomicOr(&ctx->err, WL_E_NOLM); }
 }
 
@@ -1120,7 +1149,7 @@ d_wl_big_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, c
     if (ctx->err & WL_E_NOLM) { wl_stop(ctx, WL_E_NOLM); return; }
     const int32_t n_new = L.st[7];
     if (!wl_check_new(L, ctx, n_new)) return;
-    wl_finish(L, ctx, pack, lm, dict, par, cf, L.st[4], n_new, L.st[6]);
+    wl_finish(L, ctx, pack, lm, dict, par, cf, L.st[4], n_new, L.st[6], (long long *)NULL);
 }
 
 #endif

@@ -186,6 +186,7 @@ _SIGS = {
     "s3a_uttdec_decode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_decode_dev": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_uttdec_wl_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_set_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
     "s3a_uttdec_profile": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),

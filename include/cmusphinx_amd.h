@@ -694,6 +694,10 @@ int32_t s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *f
 int32_t s3a_uttdec_decode_dev(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev,
                               const int32_t *n_frames, int32_t feat_stride);
 int32_t s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out);
+/* diagnostics: time lane z's last utterance spent in each phase of the one-workgroup word level, in 100 MHz ticks
+ * ([0] frame record + exits, [1] P1, [2] P2 trigram scores, [3] P3 hash insert, [4] P4 entry places, [5] P5 staging,
+ * [6] pruning, [7] table + LM contexts, [8] word transitions) */
+int32_t s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16);
 int32_t s3a_uttdec_n_lanes(const s3a_uttdec_t *ud);
 /*
  * The hypothesis of a finished lane as a fixed-size record -- what one utterance contributes to the end-of-batch

@@ -1206,7 +1206,8 @@ static uq_t *g_uq;
 static int32 g_uq_n, g_uq_cap;
 static kb_t *g_ukb;
 static double g_t_dev, g_t_fin, g_t_feat;
-static long g_utt_frames, g_max_cand, g_max_new, g_tie_frames;
+static long g_utt_frames, g_max_cand, g_max_new, g_tie_frames, g_frames_lane0;
+static long long g_wl_ticks[16];
 
 static int
 utt_begin_slot(void *srch)              /* srch_TST_begin without the device work (the lanes did it) */
@@ -1245,6 +1246,13 @@ utt_finish(kb_t *kb, int32 z)
     int32 f;
 
     if (s3a_uttdec_result(g_ud, z, &r) != S3A_OK) die("uttdec result");
+    if (z == 0 && getenv("S3A_UTT_TICKS")) {
+        long long tk[16];
+        int i;
+        if (s3a_uttdec_wl_ticks(g_ud, 0, tk) == S3A_OK)
+            for (i = 0; i < 9; i++) g_wl_ticks[i] += tk[i];
+        g_frames_lane0 += r.n_frames;
+    }
     kb_set_uttid(q->uttid, q->uttfile, kb);
     s->uttid = kb->uttid;
     s->uttfile = kb->uttfile;
@@ -1497,6 +1505,11 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     E_INFO("tst shim: histogram pruning (lextree_hmm_histbin) applied in %ld frames\n", g_histframes);
     E_INFO("tst shim utt mode: word level: at most %ld candidates and %ld new history entries in a frame; "
            "%ld frames replayed the reference's heap (tied scores)\n", g_max_cand, g_max_new, g_tie_frames);
+    if (getenv("S3A_UTT_TICKS")) {
+        int i;
+        for (i = 0; i < 9; i++)
+            E_INFO("tst shim utt mode: word-level phase %d of lane 0: %.2f us per frame\n", i, 0.01 * g_wl_ticks[i] / (g_frames_lane0 ? g_frames_lane0 : 1));
+    }
     E_INFO("tst shim utt mode timing: device decode %.3f s (%.1f us/frame-lane, %.0f x real time aggregate), "
            "features %.3f s, hypotheses + output %.3f s\n", g_t_dev, 1e6 * g_t_dev / g_frames,
            0.01 * g_frames / g_t_dev, g_t_feat, g_t_fin);
