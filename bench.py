@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--lanes", type=int, default=32, help="utterances decoded together per step and GPU")
+    ap.add_argument("--engines", type=int, default=1, help="decoder engines per GPU (own stream each) the lanes are split over")
     ap.add_argument("--frames", type=int, default=1000, help="frames per utterance (10 s)")
     ap.add_argument("--utts", type=int, default=64, help="distinct synthetic utterances (cycled)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline's aggregate leg (0 = physical cores, at most 16)")
@@ -218,9 +219,17 @@ def main():
     utts = [l.split()[0] for l in open(os.path.join(d, "ctl")) if l.strip()]
     hfeat = [s3io.read_mfc(os.path.join(d, "feat", u + ".mfc")) for u in utts]
     t_load = time.perf_counter()
-    dec = bundle.Decoder(bpath, NL, precision=lib.GMM_FAST if args.fast else lib.GMM_EXACT,
-                         max_frames=max(len(f) for f in hfeat) // 39 + 8)
+    NE = max(1, args.engines)
+    assert NL % NE == 0, "--lanes must be a multiple of --engines"
+    NLE = NL // NE                                  # lanes per engine
+    decs = [bundle.Decoder(bpath, NLE, precision=lib.GMM_FAST if args.fast else lib.GMM_EXACT,
+                           max_frames=max(len(f) for f in hfeat) // 39 + 8) for _ in range(NE)]
+    dec = decs[0]
     t_load = time.perf_counter() - t_load
+    pool = None
+    if NE > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(NE)
     D4x4 = 4 * ((dec.veclen + 3) // 4)
     fdev, nfr = [], []
     for f in hfeat:
@@ -234,13 +243,22 @@ def main():
         g0 = (rank * 1000003 + i * NL) % U
         return [(g0 + z) % U for z in range(NL)]
 
-    def run_step(i, recs=None):
+    def run_step(i, recs=None, engines=None):
         ids = batch(i)
-        ms = dec.ud.decode_dev([fdev[k] for k in ids], [nfr[k] for k in ids], D4x4)
+
+        def one(e):         # engine e decodes its share of the step's utterances (the C calls release the GIL)
+            sub = ids[e * NLE:(e + 1) * NLE]
+            ms = decs[e].ud.decode_dev([fdev[k] for k in sub], [nfr[k] for k in sub], D4x4)
+            out = []
+            if recs is not None:
+                out = [decs[e].hyp(z, utts[k], (rank * args.steps + i) * NL + e * NLE + z) for z, k in enumerate(sub)]
+            return ms, out
+        es = range(NE) if engines is None else engines
+        done = list(pool.map(one, es)) if (pool is not None and len(es) > 1) else [one(e) for e in es]
         if recs is not None:
-            for z, k in enumerate(ids):
-                recs.append(dec.hyp(z, utts[k], (rank * args.steps + i) * NL + z))
-        return ms
+            for _, out in done:
+                recs.extend(out)
+        return max(ms for ms, _ in done)
 
     # ---------------- correctness gate + CPU baseline (rank 0, untimed) ----------------
     cpu, ref_out = None, None
@@ -254,10 +272,10 @@ def main():
             cpu, ref_out = cpu_baseline({"args": targs, "ctl": os.path.join(d, "ctl")}, d, min(n_procs, max(1, U - 2)))
         assert ref_out, "the reference decoder failed on the task"
         got = []
-        for first in range(0, 2, min(NL, 2)):           # the reference's two utterances (one lane: one after the other)
-            ids = list(range(first, first + min(NL, 2))) + [(2 + z) % U for z in range(NL - 2)]
+        for first in range(0, 2, min(NLE, 2)):           # the reference's two utterances (one lane: one after the other)
+            ids = list(range(first, first + min(NLE, 2))) + [(2 + z) % U for z in range(NLE - 2)]
             dec.ud.decode_dev([fdev[k] for k in ids], [nfr[k] for k in ids], D4x4)
-            got += [dec.format(dec.hyp(z, utts[ids[z]], first + z)) for z in range(min(NL, 2))]
+            got += [dec.format(dec.hyp(z, utts[ids[z]], first + z)) for z in range(min(NLE, 2))]
         assert "".join(g[0] for g in got) == ref_out[0] and ("".join(g[1] for g in got) == ref_out[1] or args.fast), \
             "device hypotheses differ from the unmodified reference decoder's"
 
@@ -296,14 +314,14 @@ def main():
         value = frames_total / dt
         # ---- per-kernel timing of one profiled batch (HIP events on the launch stream, every 4th frame) ----
         dec.ud.set_profile(4)
-        run_step(0)
+        run_step(0, engines=[0])
         prof = dec.ud.profile()
         dec.ud.set_profile(0)
         res0 = dec.ud.result(0)
-        lanes_hmm = float(np.mean([dec.ud.result(z)["frame_stat"][:, 1].mean() for z in range(NL)]))
-        lanes_sen = float(np.mean([dec.ud.result(z)["frame_stat"][:, 2].mean() for z in range(NL)]))
-        lanes_gau = float(np.mean([dec.ud.result(z)["frame_stat"][:, 3].mean() for z in range(NL)]))
-        lanes_exit = float(np.mean([dec.ud.result(z)["frame_stat"][:, 7].mean() for z in range(NL)]))
+        lanes_hmm = float(np.mean([dec.ud.result(z)["frame_stat"][:, 1].mean() for z in range(NLE)]))
+        lanes_sen = float(np.mean([dec.ud.result(z)["frame_stat"][:, 2].mean() for z in range(NLE)]))
+        lanes_gau = float(np.mean([dec.ud.result(z)["frame_stat"][:, 3].mean() for z in range(NLE)]))
+        lanes_exit = float(np.mean([dec.ud.result(z)["frame_stat"][:, 7].mean() for z in range(NLE)]))
         tot = sum(us for us, _ in prof.values())
         kern = {k: {"avg_launch_us": round(us / n, 2), "share": round(us / tot, 4)} for k, (us, n) in prof.items()}
         dom = max(prof, key=lambda k: prof[k][0])
@@ -315,14 +333,14 @@ def main():
         # per model pass + per lane the feature vector in and the scored senones out; search kernels: ~84 B of HMM state
         # read + written per active HMM; the word level: 40 B per history entry made + 16 B per (exit, predecessor) pair
         alg = {
-            "ku_gated_cd": (S - Sci) * Cc * (2 * D + 2) * 4 + NL * (D * 4 + lanes_sen * 4),
-            "ku_gated_ci": Sci * Cc * (2 * D + 2) * 4 + NL * (D * 4 + Sci * 4),
+            "ku_gated_cd": (S - Sci) * Cc * (2 * D + 2) * 4 + NLE * (D * 4 + lanes_sen * 4),
+            "ku_gated_ci": Sci * Cc * (2 * D + 2) * 4 + NLE * (D * 4 + Sci * 4),
         }
         for k in ("ku_hmm_eval", "ku_resolve", "ku_scan", "ku_emit", "ku_enter1", "ku_enter2", "ku_enter3_mark", "ku_hist_count", "ku_hist_sort", "ku_weak"):
-            alg[k] = NL * lanes_hmm * 84.0
-        alg["ku_wordlevel"] = NL * (res0["max_cand"] * 16.0 + res0["max_new"] * 40.0)
+            alg[k] = NLE * lanes_hmm * 84.0
+        alg["ku_wordlevel"] = NLE * (res0["max_cand"] * 16.0 + res0["max_new"] * 40.0)
         alg["ku_emit_word"] = alg["ku_emit"] + alg["ku_wordlevel"]      # the emission sweep and the word level share a launch
-        alg.setdefault(dom, NL * lanes_hmm * 84.0)
+        alg.setdefault(dom, NLE * lanes_hmm * 84.0)
         ach = alg[dom] / (dom_us * 1e-6) / 1e9
         res = {
             "metric": "decoded_frames_per_sec (full mode-4 decode, hub4-shaped CD-GMM 6144x8x39 + 20k-word lextrees + trigram; xRT = value/100/n_gpus)",
@@ -334,7 +352,7 @@ def main():
             "config": {"workload": f"configs[3]: batch of synthetic 10 s utterances, hub4_cd_continuous shape, full decode (senone scoring + "
                                    f"lextree Viterbi + trigram word level on the device), {args.steps * NL} utterances per GPU "
                                    f"({NL} lanes x {args.steps} steps)",
-                       "frames_per_utterance": T, "utterances_per_step_per_gpu": NL, "lanes": NL,
+                       "frames_per_utterance": T, "utterances_per_step_per_gpu": NL, "lanes": NL, "engines": NE,
                        "beams": "-beam 1e-60 -wbeam 1e-35 -maxhmmpf 20000 -maxwpf 10 -lw 9.5 (the reference's hub4 settings)",
                        "parallelism": f"utterance-sharded x{world}, one all_gather of s3a_hyp_record_t ({shard.REC_BYTES} B per utterance)"},
             "xRT_per_gpu": round(value / world / 100.0, 1),

@@ -85,7 +85,7 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                int32_t *best_out, int32_t cf, const int32_t *__restrict__ psof_off,
                const int32_t *__restrict__ psof, int32_t *pstamp,
                const int32_t *__restrict__ gpart, int32_t gpart_n, int32_t *poswid, int32_t *posout,
-        const int32_t BX, const int32_t BY)
+        const int32_t BX, const int32_t BY, const int32_t *__restrict__ cs_val = NULL)
 {
     __shared__ int32_t red[2][EB / 64];
     __shared__ int32_t s_gb[EB / 64];
@@ -120,7 +120,14 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
             tp[8] = cq.x; tp[9] = cq.y; tp[10] = cq.z; tp[11] = cq.w;
         }
         const int32_t w = wid[v], q_lo = psof_off ? psof_off[v] : 0, q_hi = psof_off ? psof_off[v + 1] : 0;
-        if (comp[v]) {
+        if (comp[v] && cs_val) {                /* (the maxima were worked out once per composite senone: d_comsen_max) */
+#pragma unroll
+            for (int st = 0; st < 3; st++) {
+                const int32_t cs = comsseq[ss * 3 + st];
+                e[st] = add32(add32(cs_val[cs], -norm), cs_wt[cs]);
+            }
+        }
+        else if (comp[v]) {
             /* composite senone = max over its member senones (dict2pid.c:1029-1048), up to one member
              * per context (~46): the three states' lists are walked together, 8 members each per round,
              * ids first and then scores, so a round is two round trips instead of 48 */
@@ -966,14 +973,57 @@ d_dec_enter1(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
     atomicMin(&first[v], c);
 }
 
+/* The composite senones wanted in this frame (cs_need[cs] == stamp): their member senones are marked for scoring
+ * (d_comsen_mark, before the scoring kernels) and, after scoring, their score -- the maximum over the members,
+ * dict2pid.c:1029-1048 -- is left in cs_val[] for d_dec_hmm_eval (d_comsen_max): once per composite senone and frame
+ * instead of once per HMM that carries it (a word-final HMM has three, of ~46 members each).  A wave looks at 64
+ * composite senones with one load (few are wanted: a wave per senone would be thousands of waves that only find that
+ * out), then its four 16-lane groups take the wanted ones in turn.  cs0 = the wave's first composite senone. */
+template <bool MAXOP>
+__device__ __forceinline__ void
+d_comsen_wave(int32_t n_cs, const int32_t *__restrict__ cs_need, int32_t stamp, const int32_t *__restrict__ cs_off,
+              const int16_t *__restrict__ cs_list, uint8_t *sen_active, const int32_t *__restrict__ raw, int32_t *cs_val,
+              int32_t cs0)
+{
+    const int32_t lane = threadIdx.x & 63, sub = lane >> 4, l16 = lane & 15;
+    const int32_t mine = cs0 + lane;
+    const unsigned long long mask = __ballot(mine < n_cs && cs_need[mine] == stamp);
+    const int32_t n = __popcll(mask);
+    for (int32_t k0 = 0; k0 < n; k0 += 4) {            /* wave-uniform trip count: the shuffles below see all lanes */
+        const int32_t k = k0 + sub;
+        unsigned long long m = mask;
+        for (int32_t i = 0; i < k && m; i++) m &= m - 1ull;
+        const bool on = k < n;
+        const int32_t cs = on ? cs0 + (__ffsll((long long)m) - 1) : 0;
+        int32_t mx = INT_MIN;
+        if (on)
+            for (int32_t q = cs_off[cs] + l16, hi = cs_off[cs + 1]; q < hi; q += 16) {
+                const int32_t id = cs_list[q];
+                if (MAXOP) mx = max(mx, raw[id]); else sen_active[id] = 1;
+            }
+        if (MAXOP) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+            if (on && l16 == 0) cs_val[cs] = mx;
+        }
+    }
+}
+
 /* senones of one node (srch_TST_select_active_gmm's per-node step) */
 __device__ __forceinline__ void
 mark_node_senones(int32_t v, const int32_t *__restrict__ ssid, const uint8_t *__restrict__ comp,
                   const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
-                  const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list, uint8_t *sen_active)
+                  const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list, uint8_t *sen_active,
+                  int32_t *cs_need = NULL, int32_t stamp = 0)
 {
     const int32_t ss = ssid[v];
-    if (comp[v]) {
+    if (comp[v] && cs_need) {
+        /* the whole-utterance engine: a composite senone is WANTED (stamp); its members are marked once per frame by
+         * d_comsen_mark however many HMMs share it */
+#pragma unroll
+        for (int st = 0; st < 3; st++) cs_need[comsseq[ss * 3 + st]] = stamp;
+    }
+    else if (comp[v]) {
         /* the three states' member lists together, 8 members each per round (as in d_dec_hmm_eval): a round is
          * one trip for 24 ids instead of three */
         int32_t lo[3], hi[3];
@@ -1075,7 +1125,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
                   const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
                   const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
                   uint8_t *sen_active,
-        const int32_t BX, const int32_t BY)
+        const int32_t BX, const int32_t BY, int32_t *cs_need = NULL)
 {
     if ((int32_t)BX < n_ent_blocks) {
         const int32_t e = BX * M3BLOCK + threadIdx.x;
@@ -1094,7 +1144,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
             int32_t k = n0[t] + (fl >> 1);
             for (int32_t cc = c_lo; cc < c; cc++) k += ctot[cc];
             nxt[node_base[t] + k] = v; pos[v] = k; posf[v] = nf;
-            mark_node_senones(v, ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active);
+            mark_node_senones(v, ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf);
         }
         const unsigned long long k = key[v];
         if (k == 0ull) return;
@@ -1106,7 +1156,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
     const int32_t bb = BX - n_ent_blocks;
     const int32_t t = bb / blocks_per_tree, i = (bb % blocks_per_tree) * M3BLOCK + threadIdx.x;
     if (t >= T || i >= n0[t]) return;
-    mark_node_senones(nxt[node_base[t] + i], ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active);
+    mark_node_senones(nxt[node_base[t] + i], ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf);
 }
 
 

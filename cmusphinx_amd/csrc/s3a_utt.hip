@@ -43,6 +43,7 @@ struct ULane {
     /* scorer state */
     uint8_t *sen_act;
     int32_t *scr, *misc, *bstidx, *bstscr, *updatetime, *gpart;
+    int32_t *cs_need, *cs_val;  /* [n_cs] composite senones: wanted in frame (stamp) | score of the frame */
     /* this utterance */
     UCtx *ctx;
     int32_t *pack;
@@ -51,7 +52,7 @@ struct ULane {
 
 /* what every lane shares */
 struct UShared {
-    int32_t N, T, n_tmat, maxn, n_rootnodes, scan_chunks, pack_max_exits, gp_n;
+    int32_t N, T, n_tmat, maxn, n_rootnodes, scan_chunks, pack_max_exits, gp_n, n_cs;
     const int32_t *node_base, *ssid, *tmatid, *wid, *prob, *child_off, *child, *par_off, *par, *tree_of, *rootlist, *tp,
         *rootnodes, *ps, *psof_off, *psof, *cs_off, *cs_wt;
     const uint8_t *comp;
@@ -125,7 +126,7 @@ ku_enter3_mark(const ULane *__restrict__ lanes, UShared S, int32_t f)
     for (int32_t vb = blockIdx.x; vb < n_ent_blocks + bpt * S.T; vb += gridDim.x)
         d_dec_enter3_mark(n_ent_blocks, ent, n_ent, ctx->calls, ctx->groups, ctx->n_groups, f, L.key, L.first, L.eflag,
                           L.ctot, n0, L.sc, L.hist, L.frame, S.T, bpt, S.node_base, L.act[cur], L.nact[cur], L.pos,
-                          L.posf, S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0);
+                          L.posf, S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0, L.cs_need);
 }
 
 /* ---- approx_cont_mgau_ci_eval / _frame_eval for the lane's frame (s3a_gated.h) ---- */
@@ -135,6 +136,14 @@ ku_gated(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
     const int32_t lo = CI ? 0 : S.n_ci_sen, hi = CI ? S.n_ci_sen : S.n_sen, cf = f;
+    if (CI) {               /* the CI launch's extra workgroups: the members of the composite senones wanted in this frame */
+        const int32_t g_ci = (S.n_ci_sen * S.CP + 255) / 256;
+        if ((int32_t)blockIdx.x >= g_ci) {
+            d_comsen_wave<false>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, L.sen_act, (const int32_t *)NULL, (int32_t *)NULL,
+                                 ((int32_t)blockIdx.x - g_ci) * 256 + (int32_t)(threadIdx.x & ~63));
+            return;
+        }
+    }
     if ((int32_t)(blockIdx.x * 256) >= (hi - lo) * S.CP) return;
     const float *x = ctx->feat + (size_t)cf * S.D4 * 4;
     const int32_t is_skip = (cf % S.ds_ratio == 0) ? 0 : 1;
@@ -316,6 +325,15 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, i
     }
 }
 
+/* ---- the scores of the composite senones wanted in this frame (after the scoring kernels) ---- */
+__global__ void __launch_bounds__(256)
+ku_comsen_max(const ULane *__restrict__ lanes, UShared S, int32_t f)
+{
+    LANE;
+    d_comsen_wave<true>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, (uint8_t *)NULL, L.scr, L.cs_val,
+                        (int32_t)blockIdx.x * 256 + (int32_t)(threadIdx.x & ~63));
+}
+
 /* ---- lextree_hmm_eval ---- */
 template <int EB>
 __global__ void __launch_bounds__(EB)
@@ -327,7 +345,7 @@ ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t f)
         d_dec_hmm_eval<EB>(S.node_base, L.act[cur], L.nact[cur], S.N, S.n_tmat, S.ssid, S.tmatid, S.wid, S.comp, S.tp,
                            S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt, L.scr, L.misc, L.sc, L.hist, L.outs, L.outh,
                            L.bests, L.best, f, (const int32_t *)NULL /* ku_hist_count stamps */, S.psof, L.pstamp, L.gpart, S.gp_n, L.poswid, L.posout,
-                           vb, t);
+                           vb, t, L.cs_val);
         __syncthreads();
     }
 }
@@ -703,6 +721,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     for (auto &hl : ud->lane) {
         wlane_free(hl.d.w);
         if (hl.d.pack) (void)hipFree(hl.d.pack);
+        if (hl.d.cs_need) (void)hipFree(hl.d.cs_need);
+        if (hl.d.cs_val) (void)hipFree(hl.d.cs_val);
         if (hl.ls && ud->S.nact_all && hl.ls->d_nact[0] >= ud->S.nact_all
             && hl.ls->d_nact[0] < ud->S.nact_all + (size_t)ud->n_lanes * 2 * WL_MAXT)
             hl.ls->d_nact[0] = hl.ls->d_nact[1] = NULL;     /* borrowed from nact_all */
@@ -774,7 +794,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     S.prob = proto->d_prob; S.child_off = proto->d_child_off; S.child = proto->d_child; S.par_off = proto->d_par_off;
     S.par = proto->d_par; S.tree_of = proto->d_tree_of; S.rootlist = proto->d_rootlist; S.tp = proto->d_tp;
     S.rootnodes = proto->d_rootnodes; S.ps = proto->d_ps; S.psof_off = proto->d_psof_off; S.psof = proto->d_psof;
-    S.cs_off = cs->off_d; S.cs_wt = cs->wt_d; S.cs_list = cs->list_d;
+    S.cs_off = cs->off_d; S.cs_wt = cs->wt_d; S.cs_list = cs->list_d; S.n_cs = cs->n_comstate;
     S.comp = proto->d_comp; S.sseq = proto->d_sseq; S.comsseq = proto->d_comsseq;
     S.mean4 = d->mean4; S.prec4 = d->prec4; S.lrd = d->lrd; S.mixw = d->mixw; S.tab16 = d->tab16; S.tab_size = d->tab_size;
     S.lm_zero = d->lm_zero; S.f = g->f; S.distfloor = g->distfloor; S.D4 = d->D4; S.CP = d->CP; S.Gpad = d->Gpad;
@@ -893,6 +913,8 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         u.scan_flag = ls->d_scan_flag; u.scan_agg = ls->d_scan_agg; u.scan_pre = ls->d_scan_pre; u.key = ls->d_key;
         u.sen_act = hl.sc->act_d; u.scr = hl.sc->scr_d; u.misc = hl.sc->misc_d; u.bstidx = hl.sc->bstidx_d;
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
+        DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4);
+        if (fill32(ud->stream, u.cs_need, -1, (size_t)cs->n_comstate + 1) != S3A_OK) goto fail;
         u.ctx = ud->S.ctx_all + z;
         DM(u.pack, (size_t)(6 * T + 16 + 3 * proto->pack_max_exits) * 4);
         if (wlane_alloc(u.w, ud->vh_cap, max_frames, ud->ex_cap, ud->cand_cap, ud->new_cap, cfg->n_word, ud->stream) != S3A_OK) goto fail;
@@ -969,6 +991,7 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     if ((rc = s3a_lexsearch_utt_end(hl.ls)) != S3A_OK) return rc;
     hl.ls->cur = 0;
     if ((rc = s3a_decoder_utt_begin(hl.ls, hl.sc)) != S3A_OK) return rc;
+    if ((rc = fill32(ud->stream, hl.d.cs_need, -1, (size_t)ud->S.n_cs + 1)) != S3A_OK) return rc;   /* (frame stamps restart) */
     /* history: entry 0 (vithist_utt_begin, vithist.c:300-335) */
     {
         int32_t e0[10] = { 0 /*score*/, -1 /*pred*/, c.start_lwid, -1 /*lw1*/, c.startwid, -1 /*sf*/, -1 /*ef*/, 0, 0, 0 };
@@ -985,6 +1008,7 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
             || (rc = fill32(ud->stream, hl.d.w.bestvh, -1, 1)) || (rc = fill32(ud->stream, hl.d.w.st, 1, 1))
             || (rc = fill32(ud->stream, hl.d.w.st + 1, 0, 1)))
             return rc;
+
     }
     UCtx &x = *hl.h_ctx;
     memset(&x, 0, sizeof x);
@@ -1010,10 +1034,10 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
 }
 
 /* kernel classes of a frame (s3a_uttdec_profile) */
-enum { UK_ENTER1, UK_ENTER2, UK_ENTER3, UK_GATED_CI, UK_GATED_CD, UK_HMM_EVAL, UK_HIST_COUNT, UK_HIST_SORT, UK_WEAK,
+enum { UK_ENTER1, UK_ENTER2, UK_ENTER3, UK_GATED_CI, UK_GATED_CD, UK_COMSEN, UK_HMM_EVAL, UK_HIST_COUNT, UK_HIST_SORT, UK_WEAK,
        UK_RESOLVE, UK_SCAN, UK_EMIT, UK_WORD, UK_WL_P2, UK_WL_P3, UK_WL_P4, UK_WL_P5, UK_WL_FIN, UK_N };
 static const char *const uk_names[UK_N] = { "ku_enter1", "ku_enter2", "ku_enter3_mark", "ku_gated_ci", "ku_gated_cd",
-    "ku_hmm_eval", "ku_hist_count", "ku_hist_sort", "ku_weak", "ku_resolve", "ku_scan", "ku_emit", "ku_emit_word", "ku_wl_p2", "ku_wl_p3", "ku_wl_p4ab", "ku_wl_p5", "ku_wl_finish" };
+    "ku_comsen_max", "ku_hmm_eval", "ku_hist_count", "ku_hist_sort", "ku_weak", "ku_resolve", "ku_scan", "ku_emit", "ku_emit_word", "ku_wl_p2", "ku_wl_p3", "ku_wl_p4ab", "ku_wl_p5", "ku_wl_finish" };
 
 static int32_t
 enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
@@ -1031,6 +1055,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     UKL(UK_ENTER2, ku_enter2, dim3(WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     UKL(UK_ENTER3, ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S, f);
     const int32_t g_ci = (S.n_ci_sen * S.CP + 255) / 256, g_cd = ((S.n_sen - S.n_ci_sen) * S.CP + 255) / 256;
+    const int32_t g_cs = (S.n_cs + 255) / 256;         /* composite senones: a wave looks at 64 */
     /* from UG_FB lanes on the CD senones of all lanes are ONE pass over the model (39/40-dimensional features,
      * >= UG_FB Gaussian slots per senone); (S3A_UTT_NO_MULTI: the per-lane kernel whatever the lane count -- tests) */
     const bool multi = n >= UG_FB && S.D4 == D4MAIN && S.CP >= UG_FB && S.CP <= 64 && g_cd > 0 && S.gp_n == g_cd
@@ -1038,15 +1063,16 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     const int32_t gz = (n + UG_MAX - 1) / UG_MAX, groups = (min(n, UG_MAX) + UG_FB - 1) / UG_FB;
     const dim3 gm(g_cd, max(1, min(groups, 2 * ud->g->dev->n_cu / max(1, g_cd * gz))), gz);
     if (ud->exact) {
-        if (g_ci) UKL(UK_GATED_CI, (ku_gated<true, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S, f);
+        if (g_ci) UKL(UK_GATED_CI, (ku_gated<true, true>), dim3(g_ci + g_cs, 1, n), dim3(256), 0, st, LN, S, f);
         if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<true>), gm, dim3(256), 0, st, LN, S, n, f);
         else if (g_cd) UKL(UK_GATED_CD, (ku_gated<true, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S, f);
     }
     else {
-        if (g_ci) UKL(UK_GATED_CI, (ku_gated<false, true>), dim3(g_ci, 1, n), dim3(256), 0, st, LN, S, f);
+        if (g_ci) UKL(UK_GATED_CI, (ku_gated<false, true>), dim3(g_ci + g_cs, 1, n), dim3(256), 0, st, LN, S, f);
         if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<false>), gm, dim3(256), 0, st, LN, S, n, f);
         else if (g_cd) UKL(UK_GATED_CD, (ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S, f);
     }
+    if (g_cs) UKL(UK_COMSEN, ku_comsen_max, dim3(g_cs, 1, n), dim3(256), 0, st, LN, S, f);
     if (ud->eval_block == 256)
         UKL(UK_HMM_EVAL, ku_hmm_eval<256>, dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S, f);
     else
@@ -1058,7 +1084,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     UKL(UK_RESOLVE, ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
     /* chained scan: a few workgroups per tree take the chunks in turn (about as many workgroups as the chip holds) */
-    const int32_t scan_gc = ud->scan_gc > 0 ? min(ud->scan_gc, ud->scan_nc) : max(1, min(ud->scan_nc, max(2, 768 / max(1, T * n))));
+    const int32_t scan_gc = ud->scan_gc > 0 ? min(ud->scan_gc, ud->scan_nc) : max(1, min(ud->scan_nc, max(1, 768 / max(1, T * n))));
     UKL(UK_SCAN, ku_scan, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc, scan_gc, f);
     /* (many lanes: fewer emission workgroups per tree -- each sweeps further -- instead of thousands of idle ones) */
     UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= 32 && !ud->big_wl ? 2 : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
