@@ -162,6 +162,18 @@ def scoring_legs(lib, fast):
                              "frames_per_sec": round(T / (fs_us * 1e-6), 1), "algorithmic_bytes_per_launch": fs_bytes,
                              "achieved_GBs": round(fs_bytes / (fs_kus * 1e-6) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                              "frac": round(fs_bytes / (fs_kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        # B decoders' frames folded into ONE pass over the model (what the whole-utterance engine does from 8 lanes on:
+        # ku_gated_cd_multi; here the model-stationary scoring kernel with B frames per launch).  SURVEY 8(d)'s per-unit
+        # figure is per FRAME (a pass over the model + the frame's vector and scores), so `achieved` = B x that / time; the
+        # bytes that actually cross the HBM pins per launch are the model ONCE + B frames: hbm_GBs.
+        for B in (2, 8):
+            gm.bench(fd, T, sd, None, B, 1)
+            b_us, b_kus, b_n = gm.bench(fd, T, sd, None, B, 3)
+            leg[f"frame_sync_b{B}"] = {"frames_per_launch": B, "launches": b_n, "avg_launch_us": round(b_kus, 3),
+                                        "frames_per_sec": round(T / (b_us * 1e-6), 1), "algorithmic_bytes_per_launch": B * fs_bytes,
+                                        "achieved_GBs": round(B * fs_bytes / (b_kus * 1e-6) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+                                        "frac": round(B * fs_bytes / (b_kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "hbm_GBs": round((model_bytes + B * frame_bytes) / (b_kus * 1e-6) / 1e9, 1)}
         out[name] = leg
         del gm, fd, sd, bd
     return out
@@ -170,15 +182,16 @@ def scoring_legs(lib, fast):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--lanes", type=int, default=32, help="utterances decoded together per step and GPU")
-    ap.add_argument("--engines", type=int, default=1, help="decoder engines per GPU (own stream each) the lanes are split over")
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--lanes", type=int, default=256, help="utterances decoded together per step and GPU")
+    ap.add_argument("--engines", type=int, default=4, help="decoder engines per GPU (own stream each) the lanes are split over")
     ap.add_argument("--frames", type=int, default=1000, help="frames per utterance (10 s)")
     ap.add_argument("--utts", type=int, default=64, help="distinct synthetic utterances (cycled)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline's aggregate leg (0 = physical cores, at most 16)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-scoring", action="store_true", help="skip the scoring-only extra legs")
+    ap.add_argument("--only-scoring", action="store_true", help="only the scoring legs (PMC passes over the scoring kernels)")
     ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
     args = ap.parse_args()
 
@@ -198,6 +211,9 @@ def main():
     if lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libcmusphinx_amd has no CPU fallback")
     lib.check(L.s3a_set_device(local_rank))
+    if args.only_scoring:
+        print(json.dumps({"scoring": scoring_legs(lib, args.fast)}))
+        return
     if not (os.path.exists(SHIM) and os.path.exists(REFDEC)):
         raise SystemExit("bench.py needs oracle/_ref (the reference build: kb_init loads the models); make -C oracle ref")
 

@@ -551,6 +551,86 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
     d_dec_resolve_node(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout, v, is_active, has_par);
 }
 
+/*
+ * k_dec_resolve for many lanes per launch (the whole-utterance engine).  With dozens of lanes the one-node-per-thread
+ * sweep is hundreds of thousands of waves that live for the chain list stamp -> parent set -> its stamp and find
+ * nothing to do: the launch lasts [waves / resident waves] x that chain.  Here
+ *   - workgroups [0, GA) take the ACTIVE HMMs by list position, 64 per work item (dense waves: every lane has work);
+ *   - workgroups [GA, GA + GB) sweep all nodes for the NOT active ones a propagating parent may enter, K nodes per
+ *     thread, N/K apart (static parent-set id -> the set's stamp: two trips to the early exit, K times fewer waves);
+ *     the wave's candidates -- siblings, so they come in runs -- are compacted through LDS and handled 64 at a time.
+ */
+template <int K>
+__device__ __forceinline__ void
+d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
+              const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
+              const int32_t *__restrict__ tree_of, const int32_t *__restrict__ prob,
+              const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
+              const int32_t *__restrict__ pos, const int32_t *__restrict__ posf,
+              int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
+              int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
+              unsigned long long *key, int32_t *first, int32_t *hbin,
+              const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
+              const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
+              const int32_t *__restrict__ propf, int32_t *posout, const int32_t *__restrict__ act,
+        const int32_t BX, const int32_t GA, const int32_t GB)
+{
+#define RS_ARGS N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn,  \
+        selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout
+    static_assert(RSBLOCK == 64, "d_dec_resolve_utt: one wave per workgroup");
+    if (BX == 0) {                              /* the bins were consumed by k_dec_hist_sort */
+        int32_t bh, bw, n, th0, pth0, wth0;
+        if (frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th0, pth0, wth0))
+            for (int32_t i = threadIdx.x; i < NBIN; i += RSBLOCK) hbin[i] = 0;
+    }
+    if (BX < GA) {
+        for (int32_t v = BX * RSBLOCK + threadIdx.x; v < n_rootnodes; v += GA * RSBLOCK) {     /* lextree_enter only ever touches root nodes */
+            const int32_t r = rootnodes[v];
+            key[r] = 0ull;
+            first[r] = INT_MAX;
+        }
+        int32_t w0 = 0;                         /* first work item of tree t */
+        for (int32_t t = 0; t < T; t++) {
+            const int32_t na = nact[t], nw = (na + RSBLOCK - 1) / RSBLOCK, b = node_base[t];
+            /* this workgroup's items of tree t: w = BX, BX + GA, ... within [w0, w0 + nw) */
+            int32_t w = BX >= w0 % GA ? w0 - w0 % GA + BX : w0 - w0 % GA + GA + BX;
+            for (; w < w0 + nw; w += GA) {
+                const int32_t i = (w - w0) * RSBLOCK + threadIdx.x;
+                if (i < na) {
+                    const int32_t v = act[b + i], q = ps[v];
+                    d_dec_resolve_node(RS_ARGS, v, true, q >= 0 && pstamp[q] == cf);
+                }
+            }
+            w0 += nw;
+        }
+        return;
+    }
+    const int32_t stride = GB * RSBLOCK, v0 = (BX - GA) * RSBLOCK + threadIdx.x;
+    int32_t q[K], st[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { const int32_t v = v0 + k * stride; q[k] = v < N ? ps[v] : -1; }
+#pragma unroll
+    for (int k = 0; k < K; k++) st[k] = q[k] >= 0 ? pstamp[q[k]] : cf - 1;
+    __shared__ int32_t s_cand[64 * K];
+    int32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const bool c = st[k] == cf;
+        const unsigned long long m = __ballot(c);
+        if (c) s_cand[total + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = v0 + k * stride;
+        total += __popcll(m);
+    }
+    if (total == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int32_t i = threadIdx.x; i < total; i += 64) {
+        const int32_t v = s_cand[i];
+        if (posf[v] != cf) d_dec_resolve_node(RS_ARGS, v, false, true);     /* (the active ones: by list position) */
+    }
+#undef RS_ARGS
+}
+
 /* ------------------------------------------------------------------ */
 /*
  * The ordered emission of the next active list, in two kernels.

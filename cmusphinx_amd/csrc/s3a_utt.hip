@@ -402,14 +402,28 @@ ku_weak(const ULane *__restrict__ lanes, UShared S, int32_t f)
                L.posf, L.sc, L.outs, L.bests, S.wid, L.hbin, L.propf, L.exits + 2 * (size_t)S.N, 0, 0);
 }
 
+/* few lanes: one node per thread over all nodes (the chain is what counts) */
 __global__ void __launch_bounds__(RSBLOCK)
 ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    d_dec_resolve(S.N, S.T, f, frame_beams(S, f), L.best, L.nact[cur], S.node_base, S.tree_of, S.prob,
+    d_dec_resolve(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
                   L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
                   blockIdx.x, 0);
+}
+
+/* many lanes: the active HMMs by list position + a K-nodes-per-thread sweep for the rest (the number of waves counts) */
+#define UR_K 8
+__global__ void __launch_bounds__(RSBLOCK)
+ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t f)
+{
+    LANE;
+    const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
+    d_dec_resolve_utt<UR_K>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
+                  S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
+                  L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
+                  L.act[cur], blockIdx.x, (int32_t)gridDim.x - GB, GB);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -648,7 +662,8 @@ struct s3a_uttdec_s {
     ULane *d_lanes;
     int32_t *d_lcmap;
     std::vector<int32_t> h_lcmap;
-    int32_t g_eval, eval_block, g_ent, g_mark, scan_nc, scan_gc, hist_possible, weak_possible;
+    int32_t many;               /* from this many lanes on: the grids / kernels for many lanes per launch (S3A_UTT_MANY; tests) */
+    int32_t g_eval, eval_block, g_ent, g_mark, g_res, scan_nc, scan_gc, hist_possible, weak_possible;
     hipStream_t stream;
     int32_t n_utt;              /* lanes in use by the last decode */
     double last_decode_ms;
@@ -805,10 +820,12 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
 
     /* launch geometry: fixed grids, the kernels loop over the list lengths they find in memory */
     ud->eval_block = (cfg->maxhmmpf >= EVBLOCK_LONG_LIST && maxn >= EVBLOCK_LONG_LIST) ? 256 : 64;
+    ud->many = getenv("S3A_UTT_MANY") ? max(1, atoi(getenv("S3A_UTT_MANY"))) : 32;
     /* fixed grids, sized for the usual frame: a workgroup loops when a list is longer (virtual workgroups); with many
      * lanes the idle workgroups of a generous grid cost more than the loop */
-    ud->g_eval = max(1, min((maxn + ud->eval_block - 1) / ud->eval_block, n_lanes >= 32 ? 64 : 2048 / max(1, min(n_lanes, 8))));
+    ud->g_eval = max(1, min((maxn + ud->eval_block - 1) / ud->eval_block, n_lanes >= ud->many ? 64 : 2048 / max(1, min(n_lanes, 8))));
     if (getenv("S3A_UTT_GEVAL")) ud->g_eval = max(1, atoi(getenv("S3A_UTT_GEVAL")));
+    ud->g_res = max(1, min((proto->N + RSBLOCK - 1) / RSBLOCK, n_lanes >= ud->many ? 128 : 1024));
     ud->g_ent = max(1, min((proto->ent_cap + 255) / 256, 256));
     ud->g_mark = max(1, min((proto->ent_cap + M3BLOCK - 1) / M3BLOCK + ((maxn + M3BLOCK - 1) / M3BLOCK) * T, 1024));
     ud->scan_nc = (cfg->maxhmmpf >= SCAN_LONG_LIST && maxn >= SCAN_LONG_LIST) ? (maxn + 1023) / 1024 : 1;
@@ -1078,16 +1095,20 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     else
         UKL(UK_HMM_EVAL, ku_hmm_eval<64>, dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
     {
-        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= 32 ? 16 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
+        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 16 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
         if (ud->hist_possible) UKL(UK_HIST_SORT, ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     }
     if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
-    UKL(UK_RESOLVE, ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+    {   /* (the active HMMs by list position: ud->g_res workgroups that loop; the rest: a sweep, UR_K nodes per thread) */
+        const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
+        if (n >= ud->many) UKL(UK_RESOLVE, ku_resolve_lists, dim3(ud->g_res + GB, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+        else UKL(UK_RESOLVE, ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+    }
     /* chained scan: a few workgroups per tree take the chunks in turn (about as many workgroups as the chip holds) */
     const int32_t scan_gc = ud->scan_gc > 0 ? min(ud->scan_gc, ud->scan_nc) : max(1, min(ud->scan_nc, max(1, 768 / max(1, T * n))));
     UKL(UK_SCAN, ku_scan, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc, scan_gc, f);
     /* (many lanes: fewer emission workgroups per tree -- each sweeps further -- instead of thousands of idle ones) */
-    UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= 32 && !ud->big_wl ? 2 : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
+    UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= ud->many && !ud->big_wl ? 2 : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
     if (ud->big_wl) {
         const dim3 gb(WL_BIG_G, 1, n), one(1, 1, n), tb(WL_THREADS);
         UKL(UK_WL_P2, ku_wl_p2, gb, tb, 0, st, LN, ud->lm->d, ud->dict, ud->par, f);

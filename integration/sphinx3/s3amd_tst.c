@@ -40,6 +40,7 @@
 
 #include <string.h>
 #include "byteorder.h"
+#include "s3_decode.h"
 #include "srch.h"
 #include "gmm_wrap.h"
 #include "dict2pid.h"
@@ -1520,6 +1521,100 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
 }
 #endif
 
+/* ------------------------------------------------------------------ */
+/* S3A_LIVE=gpu|cpu: the reference's LIVE API (libAPI/s3_decode.c)     */
+/* ------------------------------------------------------------------ */
+/*
+ * s3_decode_init / _begin_utt / _process (cepstra in blocks) / _end_utt / _hypothesis, as an application embedding
+ * the decoder calls them.  s3_decode_init runs kb_init; an integrator installs the replacement slots right after it
+ * (two calls), everything else is the reference's: feat_s2mfc2feat_live, utt_decode_block -> srch_utt_decode_blk ->
+ * the per-frame slots.  S3A_LIVE=cpu leaves the table alone (the expected output of the test).
+ */
+static float32 **
+read_cep(const char *path, int32 ceplen, int32 *n_out)
+{
+    FILE *fp = fopen(path, "rb");
+    int32 n, i, swap = 0;
+    long sz;
+    float32 **c;
+    if (!fp) E_FATAL("cannot read %s\n", path);
+    fseek(fp, 0, SEEK_END); sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+    if (fread(&n, 4, 1, fp) != 1) E_FATAL("%s: empty\n", path);
+    if ((long)n * 4 + 4 != sz) { SWAP_INT32(&n); swap = 1; }
+    if ((long)n * 4 + 4 != sz || n % ceplen) E_FATAL("%s: not a cepstrum file\n", path);
+    c = (float32 **)ckd_calloc_2d(n / ceplen + 1, ceplen, sizeof(float32));
+    if (fread(c[0], 4, n, fp) != (size_t)n) E_FATAL("%s: short read\n", path);
+    if (swap) for (i = 0; i < n; i++) SWAP_FLOAT32(&c[0][i]);
+    fclose(fp);
+    *n_out = n / ceplen;
+    return c;
+}
+
+static int
+live_mode_main(int argc, char *argv[], int use_gpu)
+{
+    s3_decode_t d;
+    cmd_ln_t *config;
+    const char *cepdir, *cepext;
+    arg_t *defs;
+    int n_live = 0, n_dec = 0, a, b2, n = 0;
+    char line[4096], uttid[4096], path[8192];
+    FILE *ctl;
+    int32 ceplen, block = getenv("S3A_LIVE_BLOCK") ? atoi(getenv("S3A_LIVE_BLOCK")) : 37, n_utt = 0;
+
+    /* the live decoder's own argument table + what sphinx3_decode's table has on top of it (-cepdir, -cepext, ...) */
+    while (S3_DECODE_ARG_DEFS[n_live].name) n_live++;
+    while (arg[n_dec].name) n_dec++;
+    defs = (arg_t *)ckd_calloc(n_live + n_dec + 1, sizeof(arg_t));
+    for (a = 0; a < n_live; a++) defs[n++] = S3_DECODE_ARG_DEFS[a];
+    for (a = 0; a < n_dec; a++) {
+        for (b2 = 0; b2 < n_live && strcmp(arg[a].name, S3_DECODE_ARG_DEFS[b2].name); b2++) ;
+        if (b2 == n_live) defs[n++] = arg[a];
+    }
+    cmd_ln_appl_enter(argc, argv, "default.arg", defs);     /* (parts of the reference read the global table) */
+    config = cmd_ln_get();
+    if (!config) E_FATAL("bad arguments\n");
+    memset(&d, 0, sizeof d);
+    if (s3_decode_init(&d, config) != S3_DECODE_SUCCESS) E_FATAL("s3_decode_init failed\n");
+    if (use_gpu) {
+        srch_t *s = (srch_t *)d.kb.srch;
+        if (s->op_mode != 4) E_FATAL("tst shim: -op_mode 4 (fwdtree) only\n");
+        backend_init(&d.kb, (srch_TST_graph_t *)s->grh->graph_struct);
+        install_slots(s);
+    }
+    cepdir = cmd_ln_str_r(config, "-cepdir"); cepext = cmd_ln_str_r(config, "-cepext");
+    ceplen = feat_cepsize(kbcore_fcb(d.kbcore));
+    if ((ctl = fopen(cmd_ln_str_r(config, "-ctl"), "r")) == NULL) E_FATAL("cannot read the control file\n");
+    while (fgets(line, sizeof line, ctl)) {
+        float32 **cep;
+        int32 nfr, f;
+        char *hyp = NULL, *id = NULL;
+        hyp_t **segs = NULL;
+        if (sscanf(line, "%4095s", uttid) != 1 || uttid[0] == '#') continue;
+        snprintf(path, sizeof path, "%s/%s%s", cepdir ? cepdir : ".", uttid, cepext ? cepext : ".mfc");
+        cep = read_cep(path, ceplen, &nfr);
+        if (s3_decode_begin_utt(&d, uttid) != S3_DECODE_SUCCESS) E_FATAL("s3_decode_begin_utt failed\n");
+        for (f = 0; f < nfr; f += block)
+            if (s3_decode_process(&d, cep + f, nfr - f < block ? nfr - f : block) != S3_DECODE_SUCCESS)
+                E_FATAL("s3_decode_process failed\n");
+        s3_decode_end_utt(&d);
+        if (s3_decode_hypothesis(&d, &id, &hyp, &segs) != S3_DECODE_SUCCESS) E_FATAL("s3_decode_hypothesis failed\n");
+        printf("LIVE %s:", id ? id : uttid);
+        for (; segs && *segs; segs++)
+            printf(" %s(%d,%d,%d,%d)", dict_wordstr(kbcore_dict(d.kbcore), (*segs)->id), (*segs)->sf, (*segs)->ef, (*segs)->ascr, (*segs)->lscr);
+        printf(" | %s\n", hyp ? hyp : "");
+        ckd_free_2d((void **)cep);
+        n_utt++;
+    }
+    fclose(ctl);
+    E_INFO("tst shim live mode: %d utterances through s3_decode_process in blocks of %d frames, %s slots, %ld frames searched by the replacement backend\n",
+           n_utt, block, use_gpu ? "replacement" : "reference", g_frames);
+    if (d.kb.matchsegfp) { fclose(d.kb.matchsegfp); d.kb.matchsegfp = NULL; }
+    if (d.kb.matchfp) { fclose(d.kb.matchfp); d.kb.matchfp = NULL; }
+    fflush(stdout);
+    return 0;
+}
+
 int
 main(int argc, char *argv[])
 {
@@ -1533,6 +1628,8 @@ main(int argc, char *argv[])
     char line[16384];
     FILE *fp;
 
+    if (getenv("S3A_LIVE"))
+        return live_mode_main(argc, argv, strcmp(getenv("S3A_LIVE"), "cpu") != 0);
     cmd_ln_appl_enter(argc, argv, "default.arg", arg);      /* `arg`: the reference's own table */
     unlimit();
     config = cmd_ln_get();

@@ -114,6 +114,8 @@ DRIVERS = {
     "utt_1": {"S3A_UTT": "1"},
     "utt_4": {"S3A_UTT": "4"},
     "utt_3_bigwl": {"S3A_UTT": "3", "S3A_UTT_BIGWL": "1"},      # the word level's candidate phases as chip-wide launches
+    "utt_40": {"S3A_UTT": "40", "S3A_UTT_MANY": "2"},           # the kernels / grids chosen from 32 utterances per launch on
+                                                                # (list-driven resolve, fewer workgroups that loop), forced from 2
 }
 
 
@@ -121,7 +123,7 @@ DRIVERS = {
                                          ("mode4_trigram", "four_streams"), ("mode4_trigram", "batched_4x1"),
                                          ("mode4_cibeam_ds2", "batched_6x2"), ("mode4_trigram", "utt_1"),
                                          ("mode4_trigram", "utt_4"), ("mode4_cibeam_ds2", "utt_4"),
-                                         ("mode4_trigram", "utt_3_bigwl")])
+                                         ("mode4_trigram", "utt_3_bigwl"), ("mode4_trigram", "utt_40")])
 def test_full_device_search_matches_reference(name, driver, tmp_path):
     hyp, seg, log = (str(tmp_path / f"tst_{name}.{e}") for e in ("match", "matchseg", "log"))
     with open(log, "w") as lf:
@@ -137,7 +139,7 @@ def test_full_device_search_matches_reference(name, driver, tmp_path):
     assert open(seg).read() == open(os.path.join(D, f"ref_{name}.matchseg")).read()
 
 
-@pytest.mark.parametrize("driver", ["one_decoder", "batched_4x1", "utt_4"])
+@pytest.mark.parametrize("driver", ["one_decoder", "batched_4x1", "utt_4", "utt_40"])
 def test_full_device_search_with_phone_threshold_below_hmm_threshold(driver, tmp_path):
     """-ptranskip 2 (every second frame the WORD threshold gates phone transitions) and a phone beam
     wider than the HMM beam: HMMs under the beam but over the phone threshold propagate only if a
@@ -154,7 +156,7 @@ def test_full_device_search_with_phone_threshold_below_hmm_threshold(driver, tmp
     assert ref_seg != open(os.path.join(D, "ref_mode4_trigram.matchseg")).read()
 
 
-@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4"])
+@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4", "utt_40"])
 def test_full_device_search_with_histogram_pruning(driver, tmp_path):
     """-maxhmmpf 20: most frames exceed 1.5 x the cap, so lextree_hmm_histbin (bins, beam from the
     bin scan AND the reordering of the active lists) runs on the device; expected output is
@@ -193,13 +195,13 @@ def rm_args(extra=()):
 
 
 @pytest.mark.parametrize("binary", ["scoring_only", "full_device", "full_device_histprune", "full_device_batched",
-                                    "utt_1", "utt_7_histprune", "utt_3_tight_word_limits"])
+                                    "utt_1", "utt_7_histprune", "utt_3_tight_word_limits", "utt_33"])
 def test_rm1_identical_to_live_reference(binary, tmp_path):
     exe = SHIM if binary == "scoring_only" else TST
     extra = ["-maxhmmpf", "800"] if binary in ("full_device_histprune", "full_device_batched", "utt_7_histprune") else []
     env = dict(os.environ, S3A_STREAMS="5", S3A_BATCH="2") if binary == "full_device_batched" else None
     if binary.startswith("utt_"):
-        env = dict(os.environ, S3A_UTT=binary.split("_")[1])
+        env = dict(os.environ, S3A_UTT=binary.split("_")[1], **({"S3A_UTT_MANY": "2"} if binary == "utt_33" else {}))
     if binary == "utt_3_tight_word_limits":     # the word level's own pruning: few words / histories per frame, bigram history
         extra = ["-maxwpf", "3", "-maxhistpf", "8", "-bghist", "1"]
     out = {}
@@ -279,7 +281,7 @@ def decode_task(exe, args, tmp_path, tag, env=None):
     return open(hyp).read(), open(seg).read(), tail
 
 
-@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4", "utt_3_bigwl"])
+@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4", "utt_3_bigwl", "utt_40"])
 def test_hub4_shaped_full_decode_matches_reference(driver, tmp_path):
     args = synth_task("hub4", tmp_path, 4, 250)
     ref = decode_task(REFDEC, args, tmp_path, "ref")
@@ -301,3 +303,22 @@ def test_wsj_shaped_wide_beam_decode_matches_reference(tmp_path):
     assert wl and int(wl[0].split("at most")[1].split()[0]) > 20000, wl     # a real word-level load
     one = decode_task(TST, args, tmp_path, "one", {})
     assert one[0] == ref[0] and one[1] == ref[1]
+
+
+def test_live_api_s3_decode_process_with_replacement_slots(tmp_path):
+    """The reference's LIVE API (libAPI/s3_decode.c): s3_decode_init, then per utterance s3_decode_begin_utt,
+    s3_decode_process on blocks of 37 cepstral frames (feat_s2mfc2feat_live -> utt_decode_block), s3_decode_end_utt,
+    s3_decode_hypothesis -- once with the reference's own slots, once with the replacement slots installed right after
+    s3_decode_init.  Same word segments (ids, frames, scores), same strings, same -hyp / -hypseg files."""
+    out = {}
+    for mode in ("cpu", "gpu"):
+        hyp, seg = str(tmp_path / f"live_{mode}.match"), str(tmp_path / f"live_{mode}.matchseg")
+        p = subprocess.run([TST] + common() + RUNS["mode4_trigram"] + ["-hyp", hyp, "-hypseg", seg], capture_output=True,
+                           text=True, errors="ignore", timeout=900, env=dict(os.environ, S3A_LIVE=mode))
+        info = [l for l in p.stderr.splitlines() if "tst shim live mode" in l or "FATAL" in l]
+        assert p.returncode == 0 and info, p.stderr[-2000:]
+        searched = int(info[-1].split("slots,")[1].split()[0])
+        assert (searched > 3000) if mode == "gpu" else (searched == 0), info[-1]
+        out[mode] = ([l for l in p.stdout.splitlines() if l.startswith("LIVE ")], open(hyp).read(), open(seg).read())
+    assert len(out["cpu"][0]) == 31 and out["cpu"][1].count("\n") == 31
+    assert out["gpu"] == out["cpu"]

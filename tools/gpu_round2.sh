@@ -14,9 +14,13 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/bench.err
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python $R/bench.py --steps 4 --warmup 1 --no-cpu > $OUT/prof_stats.log 2>&1
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/prof_pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-scoring --frames 200 --utts 32 > $OUT/prof_pmc_fetch.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/prof_pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-scoring --frames 200 --utts 32 > $OUT/prof_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-scoring > $OUT/prof_stats.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/prof_pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-scoring --frames 100 --utts 32 --lanes 64 --engines 1 > $OUT/prof_pmc_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/prof_pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-scoring --frames 100 --utts 32 --lanes 64 --engines 1 > $OUT/prof_pmc_write.log 2>&1
+# the scoring kernels alone (whole-utterance + frame-synchronous, hub4 and WSJ shapes): kernel trace and the two PMC passes
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scoring_stats -o scoring -- python $R/bench.py --only-scoring > $OUT/scoring.json 2> $OUT/prof_scoring_stats.log
+timeout 600 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/prof_scoring_pmc_fetch -o scoring -- python $R/bench.py --only-scoring > $OUT/prof_scoring_pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/prof_scoring_pmc_write -o scoring -- python $R/bench.py --only-scoring > $OUT/prof_scoring_pmc_write.log 2>&1
 cd $R
 python tools/prof_summarise.py $OUT > $OUT/prof_summary.txt 2>&1
 f=$(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/bench_kernel_stats.csv
@@ -25,6 +29,6 @@ find $OUT/prof_* -type f \( -name "*.db" -o -name "*.json" -o -name "*_kernel_tr
 TASK_BEAM=1e-120 TASK_WBEAM=1e-80 tools/utt_task.sh wsj 16 400 "1 16" -pbeam 1e-100 -maxhmmpf 100000 > $OUT/wsj_task.txt 2>&1
 TASK_BEAM=1e-120 TASK_WBEAM=1e-80 S3A_UTT=16 tools/prof_task.sh ${1:-r2}_wsj_utt16 wsj 16 400 -pbeam 1e-100 -maxhmmpf 100000 > $OUT/wsj_prof.txt 2>&1
 # the hub4 task: one lane, and the frame-synchronous drop-in for comparison
-tools/utt_task.sh hub4 16 600 "1 4 16" > $OUT/hub4_task.txt 2>&1
+tools/utt_task.sh hub4 64 600 "1 4 16 64" > $OUT/hub4_task.txt 2>&1
 S3A_UTT=1 tools/prof_task.sh ${1:-r2}_hub4_utt1 hub4 4 600 > $OUT/hub4_utt1_prof.txt 2>&1
 du -sh $OUT; tail -3 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; tail -2 $OUT/bench.err; cat $OUT/wsj_task.txt | grep -v histogram; grep -v histogram $OUT/hub4_task.txt; cat $OUT/prof_summary.txt | head -60
