@@ -869,6 +869,71 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     if (threadIdx.x == 0) *done = 0;
 }
 
+/*
+ * The frame record for the whole-utterance engine's word level, which runs in the SAME workgroup right after: every
+ * input is loaded up front (one round trip: per-tree maxima, list lengths, exit counts, the scorer's per-workgroup
+ * columns), the record is assembled in LDS (hdr_s: the header, 6 T + 16 words; ex_s: the exits when there are at most
+ * ex_cap of them) and written to `pack` on the side (the wide-beam launches and the host read it there).  Returns the
+ * number of exits.  blockDim.x threads; hdr_s / ex_s are the caller's shared arrays.
+ */
+__device__ __forceinline__ int32_t
+d_dec_pack_frame_lds(int32_t N, int32_t T, FrameBeams bm, const int32_t *__restrict__ node_base,
+                     const int32_t *__restrict__ nact, int32_t *best, const int32_t *exits, int32_t *nexit,
+                     const int32_t *hbin, int32_t *misc, int32_t *pack, int32_t max_exits, const int32_t *gpart,
+                     int32_t gpart_n, const int32_t *nnxt, int32_t *hdr_s, int32_t *ex_s, int32_t ex_cap)
+{
+    __shared__ int32_t sp_gp[3];
+    const int32_t nt = blockDim.x, tid = threadIdx.x, hdr = 6 * T + 16;
+    int32_t gb = INT_MIN, gs = 0, gg = 0;
+    for (int32_t q = tid; q < gpart_n; q += nt) { gb = max(gb, gpart[q]); gs += gpart[gpart_n + q]; gg += gpart[2 * gpart_n + q]; }
+    for (int32_t q = tid; q < hdr; q += nt) hdr_s[q] = 0;
+    if (tid < 3) sp_gp[tid] = tid == 0 ? INT_MIN : 0;
+    __syncthreads();
+    if (tid < 2 * T) hdr_s[tid] = best[tid];
+    if (tid < T) {
+        hdr_s[2 * T + tid] = nact[tid];
+        hdr_s[3 * T + 8 + tid] = nexit[tid];
+        hdr_s[4 * T + 8 + tid] = nexit[T + tid];
+        hdr_s[5 * T + 16 + tid] = nnxt[tid];
+    }
+    if (tid >= 64 && tid < 72) hdr_s[5 * T + 8 + (tid - 64)] = misc[tid - 64];      /* raw: merged with the columns below */
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        gb = max(gb, __shfl_xor(gb, o, 64)); gs += __shfl_xor(gs, o, 64); gg += __shfl_xor(gg, o, 64);
+    }
+    if ((tid & 63) == 0 && gb != INT_MIN) { atomicMax(&sp_gp[0], gb); atomicAdd(&sp_gp[1], gs); atomicAdd(&sp_gp[2], gg); }
+    __syncthreads();
+    if (tid == 0) {
+        int32_t bh, bw, n, th, pth, wth;
+        const bool hist = frame_thresholds(hdr_s, hdr_s + 2 * T, T, bm, hbin, bh, bw, n, th, pth, wth);
+        hdr_s[3 * T + 0] = th; hdr_s[3 * T + 1] = pth; hdr_s[3 * T + 2] = wth; hdr_s[3 * T + 3] = bh; hdr_s[3 * T + 4] = bw;
+        hdr_s[3 * T + 5] = n; hdr_s[3 * T + 6] = hist ? 1 : 0; hdr_s[3 * T + 7] = 0;
+        const int32_t m0 = hdr_s[5 * T + 8 + 0], m5 = hdr_s[5 * T + 8 + 5];
+        hdr_s[5 * T + 8 + 0] = max(m0, sp_gp[0]);
+        hdr_s[5 * T + 8 + 1] += sp_gp[1];
+        hdr_s[5 * T + 8 + 2] += sp_gp[2];
+        hdr_s[5 * T + 8 + 6] = max(max(m0, sp_gp[0]), m5);      /* srch->senscale */
+    }
+    int32_t off = 0, total = 0;
+    for (int32_t tt = 0; tt < T; tt++) total += hdr_s[3 * T + 8 + tt];
+    for (int32_t tt = 0; tt < T; tt++) {
+        const int32_t n = hdr_s[3 * T + 8 + tt], bb = node_base[tt];
+        for (int32_t q = tid; q < n; q += nt) {
+            const int32_t k = off + q;
+            const int32_t w = exits[bb + q], sc = exits[N + bb + q], h = exits[2 * N + bb + q];
+            if (k < max_exits) { pack[hdr + 3 * k] = w; pack[hdr + 3 * k + 1] = sc; pack[hdr + 3 * k + 2] = h; }
+            if (total <= ex_cap) { ex_s[3 * k] = w; ex_s[3 * k + 1] = sc; ex_s[3 * k + 2] = h; }
+        }
+        off += n;
+    }
+    __syncthreads();
+    for (int32_t q = tid; q < hdr; q += nt) pack[q] = hdr_s[q];
+    for (int32_t q = tid; q < 2 * T; q += nt) { best[q] = INT_MIN; nexit[q] = 0; }
+    if (tid < 8) misc[tid] = (tid == 0 || tid == 5) ? INT_MIN : 0;
+    __syncthreads();
+    return total;
+}
+
 /* The frame record of d_dec_scan's last workgroup, assembled instead by ONE workgroup of a LATER kernel
  * (blockDim.x threads; everything the scan kernels wrote is visible across the kernel boundary), followed by
  * the same reset of the per-frame accumulators. */

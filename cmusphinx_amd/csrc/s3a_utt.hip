@@ -458,12 +458,13 @@ ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPa
                      wgpt * WL_WAVES);
         return;
     }
+    __shared__ int32_t s_hdr[6 * WL_MAXT + 16], s_ex[3 * WL_LDS_EX];
     const long long t_in = (long long)wall_clock64();
     if (threadIdx.x == 0) ctx->scan_epoch++;        /* (k_dec_scan's flags are stamped per launch) */
-    d_dec_pack_frame(S.N, S.T, frame_beams(S, f), S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc,
-                     L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1]);
+    const int32_t nx = d_dec_pack_frame_lds(S.N, S.T, frame_beams(S, f), S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin,
+                                            L.misc, L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1], s_hdr, s_ex, WL_LDS_EX);
     if (big) d_wl_big_begin(L.w, ctx, L.pack, dict, par);   /* wide beams: the candidate phases follow as their own launches */
-    else d_wordlevel_frame(L.w, ctx, L.pack, lm, dict, par, f, t_in);
+    else d_wordlevel_frame(L.w, ctx, L.pack, s_hdr, nx <= WL_LDS_EX ? s_ex : (const int32_t *)NULL, lm, dict, par, f, t_in);
 }
 
 #define LANE_W const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; if (f >= ctx->nfr || !ctx->active) return
@@ -509,9 +510,17 @@ ku_wl_finish(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par, int3
 __global__ void __launch_bounds__(WL_THREADS)
 ku_wordlevel_only(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par)
 {
+    __shared__ int32_t s_hdr[6 * WL_MAXT + 16], s_ex[3 * WL_LDS_EX];
     const ULane &L = lanes[blockIdx.z];
     if (!L.ctx->active) return;
-    d_wordlevel_frame(L.w, L.ctx, L.pack, lm, dict, par, L.ctx->cf, (long long)wall_clock64());
+    const int32_t hdr = 6 * par.T + 16;
+    int32_t nx = 0;
+    for (int32_t t = 0; t < par.T; t++) nx += L.pack[3 * par.T + 8 + t];
+    for (int32_t i = threadIdx.x; i < hdr; i += WL_THREADS) s_hdr[i] = L.pack[i];
+    if (nx <= WL_LDS_EX) for (int32_t i = threadIdx.x; i < 3 * nx; i += WL_THREADS) s_ex[i] = L.pack[hdr + i];
+    __syncthreads();
+    d_wordlevel_frame(L.w, L.ctx, L.pack, s_hdr, nx <= WL_LDS_EX ? s_ex : (const int32_t *)NULL, lm, dict, par, L.ctx->cf,
+                      (long long)wall_clock64());
 }
 
 __global__ void
@@ -1106,7 +1115,8 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     }
     /* chained scan: a few workgroups per tree take the chunks in turn (about as many workgroups as the chip holds) */
     const int32_t scan_gc = ud->scan_gc > 0 ? min(ud->scan_gc, ud->scan_nc) : max(1, min(ud->scan_nc, max(1, 768 / max(1, T * n))));
-    UKL(UK_SCAN, ku_scan, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, ud->scan_nc, scan_gc, f);
+    /* (one workgroup per tree: it walks the chunks with the totals in a register -- no flags, no look-back) */
+    UKL(UK_SCAN, ku_scan, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, scan_gc == 1 ? 1 : ud->scan_nc, scan_gc, f);
     /* (many lanes: fewer emission workgroups per tree -- each sweeps further -- instead of thousands of idle ones) */
     UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= ud->many && !ud->big_wl ? 2 : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
     if (ud->big_wl) {

@@ -661,8 +661,12 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
     __syncthreads();
     for (int32_t k0 = 0; k0 < n_new; k0 += WL_THREADS) {
         const int32_t k = k0 + tid;
-        const int32_t at = wl_append(&s_i[1], k < n_new && sg_score[k] >= th);
-        if (at >= 0) a_list[at] = k;
+        const int32_t sck = k < n_new ? sg_score[k] : INT_MIN, wk = k < n_new ? sg_wid[k] : 0;
+        const int32_t at = wl_append(&s_i[1], k < n_new && sck >= th);
+        if (at >= 0) {
+            a_list[at] = k;
+            if (at < WL_RANK_MAX) { s_rk[0][at] = k; s_rk[1][at] = sck; s_rk[2][at] = wk; s_rk[3][at] = dict.is_filler[wk] ? 1 : 0; }
+        }
     }
     __syncthreads();
     const int32_t n_th = s_i[1];
@@ -810,11 +814,7 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
     if (!done) {
         /* ---- at most WL_RANK_MAX entries above the threshold: rank them by score, all against all, in LDS (s_rk: the
          * entry, its score, its word, filler?).  Two of them that TIE pop in the heap's order: wl_heap_nrl, ranks again ---- */
-        for (int32_t q = tid; q < n_th; q += WL_THREADS) {
-            const int32_t k = a_list[q], w = sg_wid[k];
-            s_rk[0][q] = k; s_rk[1][q] = sg_score[k]; s_rk[2][q] = w; s_rk[3][q] = dict.is_filler[w] ? 1 : 0;
-        }
-        __syncthreads();
+        /* (s_rk[0..3] were filled when the list above the threshold was made) */
         for (int pass = 0; pass < 2; pass++) {
             int32_t k = 0, w = 0, fl = 0, r = 0, tie = 0;
             if (tid < n_th) {
@@ -991,30 +991,24 @@ wl_check_new(const WLane &L, UCtx *ctx, int32_t n_new)
     return !over;
 }
 
-/* the whole frame by ONE workgroup */
+/* the whole frame by ONE workgroup.  hdr = the frame record's header (the caller's LDS copy), ex_lds = the exits in LDS
+ * (NULL when there are more than WL_LDS_EX: then they are read from the record in global memory, `pack`) */
 __device__ __forceinline__ void
-d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const WDict &dict, const WPar &par, const int32_t cf,
-                  long long t_in)
+d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const int32_t *hdr, const int32_t *ex_lds, const WLm &lm,
+                  const WDict &dict, const WPar &par, const int32_t cf, long long t_in)
 {
     __shared__ int32_t s_tb[WL_MAXT + 1];
     __shared__ int32_t s_flag[2];
-    __shared__ int32_t s_ex[3 * WL_LDS_EX], s_off[WL_LDS_EX + 1];    /* the usual frame: exits + candidate offsets in LDS */
+    __shared__ int32_t s_off[WL_LDS_EX + 1];                        /* the usual frame: candidate offsets in LDS */
     __shared__ int32_t s_xi[3][WL_LDS_EX];
-    const int32_t T = par.T, hdr = 6 * T + 16;
-    const int32_t *ex = pack + hdr;
+    const int32_t T = par.T;
+    const int32_t *ex = pack + (6 * T + 16);
     int32_t *off = L.ex_off, *xa = L.ex_info, *xb = L.ex_info + L.ex_cap, *xc = L.ex_info + 2 * (size_t)L.ex_cap;
     long long tprev = t_in, *tp = &tprev;
-    int32_t nx0 = 0;
-    for (int32_t t = 0; t < T; t++) nx0 += pack[3 * T + 8 + t];
     if (threadIdx.x == 0) s_flag[1] = 0;
-    if (nx0 <= WL_LDS_EX) {
-        for (int32_t i = threadIdx.x; i < 3 * nx0; i += WL_THREADS) s_ex[i] = ex[i];
-        __syncthreads();
-        ex = s_ex;
-        off = s_off; xa = s_xi[0]; xb = s_xi[1]; xc = s_xi[2];
-    }
+    if (ex_lds) { ex = ex_lds; off = s_off; xa = s_xi[0]; xb = s_xi[1]; xc = s_xi[2]; }
     WL_STAMP(tp, 0);
-    const int32_t n_cand = wl_p1(L, pack, dict, T, s_tb, off, ex, xa, xb, xc, &s_flag[0]);
+    const int32_t n_cand = wl_p1(L, hdr, dict, T, s_tb, off, ex, xa, xb, xc, &s_flag[0]);
     if (n_cand < 0) { wl_stop(ctx, s_flag[0]); return; }
     if (!wl_check_caps(L, ctx, n_cand)) return;
     WlFr fr;
@@ -1034,7 +1028,7 @@ d_wordlevel_frame(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm,
     wl_p5(L, dict, par, fr, 0, n_cand);
     __syncthreads();
     WL_STAMP(tp, 5);
-    wl_finish(L, ctx, pack, lm, dict, par, cf, fr.nx, n_new, M, tp);
+    wl_finish(L, ctx, hdr, lm, dict, par, cf, fr.nx, n_new, M, tp);
 }
 
 /* ---- the same frame as a sequence of launches, G workgroups per lane (wide-beam frames) ---- */
