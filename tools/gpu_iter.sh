@@ -12,7 +12,7 @@ grep "word-level phase" gpurun_out/utt/task_hub4.u1.log | cut -c24-200 > $OUT/ti
 grep "word-level phase" gpurun_out/utt/task_hub4.u16.log | cut -c24-200 > $OUT/ticks_u16.txt
 S3A_UTT=1 SKIP_REF=1 tools/prof_task.sh ${NAME}_hub4_utt1 hub4 4 600 > $OUT/hub4_utt1_prof.txt 2>&1
 for L in ${@:-32}; do
-  python bench.py --steps 4 --warmup 1 --no-cpu --no-scoring --lanes $L > $OUT/bench_l$L.json 2> $OUT/bench_l$L.err; echo "bench lanes=$L rc=$?"
+  python bench.py --steps 4 --warmup 1 --no-cpu --no-scoring --lanes $L --engines 1 > $OUT/bench_l$L.json 2> $OUT/bench_l$L.err; echo "bench lanes=$L rc=$?"
   python - <<PY
 import json
 d = json.load(open("$OUT/bench_l$L.json"))
