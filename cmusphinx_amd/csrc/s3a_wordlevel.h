@@ -20,13 +20,15 @@
  *      (strict <, vithist.c:449-455) = a hash insert with atomicMin(first) / atomicMax(score, ~seq);
  *   3. pruning pops the frame's entries from a heap, best first: ranks by score; and when two
  *      entries above the threshold TIE the pop order is the heap's (not FIFO, not LIFO): then -- and
- *      only then -- one thread replays the reference's heap on the frame's entries.
+ *      only then -- the heap's order among equal values is worked out in parallel (wl_heap_nrl).
  * History entries of finished frames are immutable and all valid (vithist_frame_gc), so the table
  * is structure-of-arrays in HBM and a candidate reads three words of its predecessor.
  *
  * One workgroup of WL_THREADS per decoder lane runs the phases below with workgroup barriers in
- * between; all per-frame scratch is global memory (L2-resident).  Phases that scan candidates
- * assign one exit per wave (64 predecessors per step).
+ * between (the frame waits for this one workgroup, so the phases are arranged for few DEPENDENT
+ * round trips: the frame record, the exits and what the candidates of an exit share sit in LDS, the
+ * two LM look-ups of a candidate run side by side 8-ary, the pruning ranks in LDS); a wide-beam
+ * frame (10^5..10^6 candidates) runs the candidate phases chip-wide as separate launches instead.
  */
 #ifndef S3A_WORDLEVEL_H
 #define S3A_WORDLEVEL_H
