@@ -444,7 +444,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
               const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout,
-        const int32_t v, const bool is_active, const bool has_par)
+        const int32_t v, const bool is_active, const bool has_par, const int32_t j_known = -1, const int32_t b_known = -1)
 {
     const int32_t nf = cf + 1;
     int32_t th, pth;
@@ -452,7 +452,20 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
         int32_t bh, bw, n, wth;
         (void)frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
     }
-    const int32_t j = is_active ? pos[v] : INT_MAX;
+    if (is_active && !has_par) {
+        /* no parent can enter v (the usual active HMM): it survives or is cleared at its own turn -- one gather */
+        const int32_t j = j_known >= 0 ? j_known : pos[v], b = b_known >= 0 ? b_known : node_base[tree_of[v]];
+        if (bests[v] >= th) { selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); frame[v] = nf; }
+        else {
+            sc[v] = WORST; sc[1 * N + v] = WORST; sc[2 * N + v] = WORST;
+            hist[v] = -1; hist[1 * N + v] = -1; hist[2 * N + v] = -1;
+            outs[v] = WORST; outh[v] = -1; bests[v] = WORST;
+            posout[b + j] = WORST;
+            frame[v] = -1;
+        }
+        return;
+    }
+    const int32_t j = is_active ? (j_known >= 0 ? j_known : pos[v]) : INT_MAX;     /* (known when v was taken from the list) */
     const int32_t in0 = sc[v];
     int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
     int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
@@ -491,7 +504,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
     }
     if (!is_active && mE == INT_MIN)
         return;                                         /* nothing happens to this node */
-    const int32_t b = node_base[tree_of[v]];
+    const int32_t b = b_known >= 0 ? b_known : node_base[tree_of[v]];
     int32_t cur = in0, h0 = hist[v], my_turn = -1;
     bool in_list = false, cleared = false, entered = false;
     if (mE > in0) {
@@ -598,7 +611,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
                 const int32_t i = (w - w0) * RSBLOCK + threadIdx.x;
                 if (i < na) {
                     const int32_t v = act[b + i], q = ps[v];
-                    d_dec_resolve_node(RS_ARGS, v, true, q >= 0 && pstamp[q] == cf);
+                    d_dec_resolve_node(RS_ARGS, v, true, q >= 0 && pstamp[q] == cf, i, b);
                 }
             }
             w0 += nw;
@@ -1090,6 +1103,41 @@ d_dec_emit(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *__r
 struct Entries {
     const int32_t *calls, *rootlist;
     int32_t n_calls;
+    const int32_t *rootprob = nullptr;      /* prob[] of the roots IN LIST ORDER (optional): the entry test of the many
+                                             * entries that fail it is then two coalesced loads and no gather */
+    /* entry e: its call and its place in the root lists */
+    __device__ __forceinline__ void locate_idx(int32_t e, int32_t &idx, int32_t &c) const
+    {
+        int32_t lo = 0, hi = n_calls - 1;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (calls[4 * mid + 3] <= e) lo = mid; else hi = mid - 1;
+        }
+        c = lo;
+        idx = calls[4 * c + 2] + (e - calls[4 * c + 3]);
+    }
+    /* the same for a whole wave at once (EVERY lane of the wave must call): the calls' first entries are loaded once,
+     * 64 per lane-register, and each lane counts the calls that start at or before its entry -- one round trip instead
+     * of the bisection's five dependent ones (the entry kernels are that chain times tens of thousands of waves) */
+    __device__ __forceinline__ void locate_idx_wave(int32_t e, int32_t &idx, int32_t &c) const
+    {
+        if (n_calls > 128) { locate_idx(e, idx, c); return; }
+        const int32_t lane = threadIdx.x & 63;
+        const int32_t o0 = lane < n_calls ? calls[4 * lane + 3] : INT_MAX, r0 = lane < n_calls ? calls[4 * lane + 2] : 0;
+        const int32_t o1 = lane + 64 < n_calls ? calls[4 * (lane + 64) + 3] : INT_MAX, r1 = lane + 64 < n_calls ? calls[4 * (lane + 64) + 2] : 0;
+        int32_t cnt = 0;
+        const int32_t n0 = min(n_calls, 64);
+        for (int32_t k = 0; k < n0; k++) cnt += __shfl(o0, k, 64) <= e ? 1 : 0;
+        for (int32_t k = 64; k < n_calls; k++) cnt += __shfl(o1, k - 64, 64) <= e ? 1 : 0;
+        c = max(cnt - 1, 0);
+        const int32_t oc = c < 64 ? __shfl(o0, c, 64) : __shfl(o1, c - 64, 64), rc = c < 64 ? __shfl(r0, c, 64) : __shfl(r1, c - 64, 64);
+        idx = rc + (e - oc);
+    }
+    /* the look-ahead probability of the root at place idx (node v when it has been loaded already, else -1) */
+    __device__ __forceinline__ int32_t root_prob(int32_t idx, const int32_t *__restrict__ prob) const
+    {
+        return rootprob ? rootprob[idx] : prob[rootlist[idx]];
+    }
     __device__ __forceinline__ void locate(int32_t e, int32_t &v, int32_t &c) const
     {
         int32_t lo = 0, hi = n_calls - 1;
@@ -1109,11 +1157,13 @@ d_dec_enter1(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
         const int32_t BX, const int32_t BY)
 {
     const int32_t e = BX * blockDim.x + threadIdx.x;
+    int32_t idx, c;
+    ent.locate_idx_wave(e < n_ent ? e : 0, idx, c);
     if (e >= n_ent) return;
-    int32_t v, c;
-    ent.locate(e, v, c);
-    const int32_t scr = add32(calls[4 * c], prob[v]);
-    if (scr < thresh || !(sc[v] < scr)) return;
+    const int32_t scr = add32(calls[4 * c], ent.root_prob(idx, prob));
+    if (scr < thresh) return;
+    const int32_t v = ent.rootlist[idx];
+    if (!(sc[v] < scr)) return;
     atomicMax(&key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
     atomicMin(&first[v], c);
 }
@@ -1226,8 +1276,11 @@ d_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
         const int32_t i = c0 + tid;
         int32_t q = 0;
         if (i < n) {
-            const int32_t v = ent.rootlist[roots + i], scr = add32(in, prob[v]);
-            q = (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
+            const int32_t scr = add32(in, ent.root_prob(roots + i, prob));
+            if (scr >= thresh) {
+                const int32_t v = ent.rootlist[roots + i];
+                q = (sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
+            }
         }
         const unsigned long long m = __ballot(q);
         const int32_t below = __popcll(m & ((1ull << lane) - 1ull));   /* listed entries in front, this wave */
@@ -1270,13 +1323,13 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
                   const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
                   const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
                   uint8_t *sen_active,
-        const int32_t BX, const int32_t BY, int32_t *cs_need = NULL)
+        const int32_t BX, const int32_t BY, int32_t *cs_need = NULL, int32_t thresh = INT_MIN)
 {
     if ((int32_t)BX < n_ent_blocks) {
         const int32_t e = BX * M3BLOCK + threadIdx.x;
+        int32_t idx, c;
+        ent.locate_idx_wave(e < n_ent ? e : 0, idx, c);
         if (e >= n_ent) return;
-        int32_t v, c;
-        ent.locate(e, v, c);
         const int32_t g = (n_groups > 1 && e >= groups[4 + 1]) ? 1 : 0;
         const int32_t t = groups[4 * g], c_lo = groups[4 * g + 3];
         if (e == groups[4 * g + 1]) {                    /* first entry of the group: new list length */
@@ -1284,6 +1337,9 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
             for (int32_t cc = c_lo; cc < ent.n_calls && calls[4 * cc + 3] < groups[4 * g + 2]; cc++) tot += ctot[cc];
             nnxt[t] = n0[t] + tot;
         }
+        /* an entry under the threshold entered nothing (with the roots' probabilities in list order: no gather) */
+        if (ent.rootprob && add32(calls[4 * c], ent.rootprob[idx]) < thresh) return;
+        const int32_t v = ent.rootlist[idx];
         const int32_t fl = flag[e];
         if (fl & 1) {
             int32_t k = n0[t] + (fl >> 1);

@@ -54,7 +54,7 @@ struct ULane {
 struct UShared {
     int32_t N, T, n_tmat, maxn, n_rootnodes, scan_chunks, pack_max_exits, gp_n, n_cs;
     const int32_t *node_base, *ssid, *tmatid, *wid, *prob, *child_off, *child, *par_off, *par, *tree_of, *rootlist, *tp,
-        *rootnodes, *ps, *psof_off, *psof, *cs_off, *cs_wt;
+        *rootnodes, *ps, *psof_off, *psof, *cs_off, *cs_wt, *rootprob;
     const uint8_t *comp;
     const int16_t *sseq, *comsseq, *cs_list;
     const float4 *mean4, *prec4;
@@ -93,24 +93,46 @@ frame_beams(const UShared &S, int32_t cf)
 }
 
 /* ---- lextree_enter calls left by the previous frame's word level (or by utterance begin) ---- */
+/* the entry test (d_dec_enter1) with the calls' table in LDS: an entry finds its call by a bisection in LDS and fails the
+ * test -- almost all do -- after ONE global round trip (its root's look-ahead probability, in list order) */
 __global__ void __launch_bounds__(256)
 ku_enter1(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
+    __shared__ int32_t s_off[WL_MAXCALL], s_root[WL_MAXCALL], s_in[WL_MAXCALL];
     LANE;
-    const int32_t n_ent = ctx->n_ent;
-    const Entries ent = { ctx->calls, S.rootlist, ctx->n_calls };
-    for (int32_t vb = blockIdx.x; vb * 256 < n_ent; vb += gridDim.x)
-        d_dec_enter1(ent, n_ent, ctx->calls, S.prob, L.sc, ctx->thresh, L.key, L.first, vb, 0);
+    const int32_t n_ent = ctx->n_ent, n_calls = min(ctx->n_calls, WL_MAXCALL), thresh = ctx->thresh;
+    if ((int32_t)blockIdx.x * 256 >= n_ent) return;
+    if ((int32_t)threadIdx.x < n_calls) {
+        s_in[threadIdx.x] = ctx->calls[4 * threadIdx.x]; s_root[threadIdx.x] = ctx->calls[4 * threadIdx.x + 2];
+        s_off[threadIdx.x] = ctx->calls[4 * threadIdx.x + 3];
+    }
+    __syncthreads();
+    for (int32_t e = blockIdx.x * 256 + threadIdx.x; e < n_ent; e += gridDim.x * 256) {
+        int32_t lo = 0, hi = n_calls - 1;
+        while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (s_off[mid] <= e) lo = mid; else hi = mid - 1; }
+        const int32_t c = lo, idx = s_root[c] + (e - s_off[c]);
+        const int32_t scr = add32(s_in[c], S.rootprob[idx]);
+        if (scr < thresh) continue;
+        const int32_t v = S.rootlist[idx];
+        if (!(L.sc[v] < scr)) continue;
+        atomicMax(&L.key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
+        atomicMin(&L.first[v], c);
+    }
 }
 
+/* (a workgroup per lextree_enter call; with many lanes fewer workgroups that take the calls in turn) */
 __global__ void __launch_bounds__(SCAN_THREADS)
 ku_enter2(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    if ((int32_t)blockIdx.x >= ctx->n_calls || ctx->n_ent == 0) return;
-    const Entries ent = { ctx->calls, S.rootlist, ctx->n_calls };
-    d_dec_enter2(ent, ctx->n_ent, ctx->calls, S.prob, L.sc, L.frame, L.first, ctx->thresh, f, S.T,
-                 L.nact[cur], L.eflag, L.ctot, L.n0, blockIdx.x, 0);
+    const int32_t n_calls = ctx->n_calls;
+    if ((int32_t)blockIdx.x >= n_calls || ctx->n_ent == 0) return;
+    const Entries ent = { ctx->calls, S.rootlist, n_calls, S.rootprob };
+    for (int32_t c = blockIdx.x; c < n_calls; c += gridDim.x) {
+        d_dec_enter2(ent, ctx->n_ent, ctx->calls, S.prob, L.sc, L.frame, L.first, ctx->thresh, f, S.T,
+                     L.nact[cur], L.eflag, L.ctot, L.n0, c, 0);
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(M3BLOCK)
@@ -122,11 +144,11 @@ ku_enter3_mark(const ULane *__restrict__ lanes, UShared S, int32_t f)
     int32_t rows = 0;
     for (int32_t t = 0; t < S.T; t++) rows = max(rows, n0[t]);
     const int32_t n_ent_blocks = (n_ent + M3BLOCK - 1) / M3BLOCK, bpt = (rows + M3BLOCK - 1) / M3BLOCK;
-    const Entries ent = { ctx->calls, S.rootlist, ctx->n_calls };
+    const Entries ent = { ctx->calls, S.rootlist, ctx->n_calls, S.rootprob };
     for (int32_t vb = blockIdx.x; vb < n_ent_blocks + bpt * S.T; vb += gridDim.x)
         d_dec_enter3_mark(n_ent_blocks, ent, n_ent, ctx->calls, ctx->groups, ctx->n_groups, f, L.key, L.first, L.eflag,
                           L.ctot, n0, L.sc, L.hist, L.frame, S.T, bpt, S.node_base, L.act[cur], L.nact[cur], L.pos,
-                          L.posf, S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0, L.cs_need);
+                          L.posf, S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0, L.cs_need, ctx->thresh);
 }
 
 /* ---- approx_cont_mgau_ci_eval / _frame_eval for the lane's frame (s3a_gated.h) ---- */
@@ -524,6 +546,13 @@ ku_wordlevel_only(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par)
 }
 
 __global__ void
+ku_gather32(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t *dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+__global__ void
 ku_fill32(int32_t *p, int32_t v, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -760,6 +789,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
     if (ud->d_lanes) (void)hipFree(ud->d_lanes);
+    if (ud->S.rootprob) (void)hipFree((void *)ud->S.rootprob);
     if (ud->S.ctx_all) (void)hipFree(ud->S.ctx_all);
     if (ud->S.nact_all) (void)hipFree(ud->S.nact_all);
     if (ud->d_lcmap) (void)hipFree(ud->d_lcmap);
@@ -817,6 +847,15 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     S.node_base = proto->d_node_base; S.ssid = proto->d_ssid; S.tmatid = proto->d_tmatid; S.wid = proto->d_wid;
     S.prob = proto->d_prob; S.child_off = proto->d_child_off; S.child = proto->d_child; S.par_off = proto->d_par_off;
     S.par = proto->d_par; S.tree_of = proto->d_tree_of; S.rootlist = proto->d_rootlist; S.tp = proto->d_tp;
+    {   /* the roots' look-ahead probabilities in root-list order (Entries::rootprob) */
+        const size_t nr = proto->h_rootlist.size();
+        int32_t *rp = NULL;
+        if (nr > 0) {
+            if (hipMalloc((void **)&rp, nr * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_init: out of device memory"); goto fail; }
+            hipLaunchKernelGGL(ku_gather32, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ud->stream, proto->d_prob, proto->d_rootlist, rp, nr);
+        }
+        S.rootprob = rp;
+    }
     S.rootnodes = proto->d_rootnodes; S.ps = proto->d_ps; S.psof_off = proto->d_psof_off; S.psof = proto->d_psof;
     S.cs_off = cs->off_d; S.cs_wt = cs->wt_d; S.cs_list = cs->list_d; S.n_cs = cs->n_comstate;
     S.comp = proto->d_comp; S.sseq = proto->d_sseq; S.comsseq = proto->d_comsseq;
@@ -1078,7 +1117,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
         hipLaunchKernelGGL(__VA_ARGS__);                                                                         \
         if (prof) { (void)hipEventRecord(b_, st); ud->prof_ev.push_back({ cls, a_, b_ }); } } while (0)
     UKL(UK_ENTER1, ku_enter1, dim3(ud->g_ent, 1, n), dim3(256), 0, st, LN, S, f);
-    UKL(UK_ENTER2, ku_enter2, dim3(WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+    UKL(UK_ENTER2, ku_enter2, dim3(n >= ud->many ? 24 : WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     UKL(UK_ENTER3, ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S, f);
     const int32_t g_ci = (S.n_ci_sen * S.CP + 255) / 256, g_cd = ((S.n_sen - S.n_ci_sen) * S.CP + 255) / 256;
     const int32_t g_cs = (S.n_cs + 255) / 256;         /* composite senones: a wave looks at 64 */
