@@ -182,9 +182,9 @@ def scoring_legs(lib, fast):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--lanes", type=int, default=256, help="utterances decoded together per step and GPU")
+    ap.add_argument("--lanes", type=int, default=512, help="utterances decoded together per step and GPU")
     ap.add_argument("--engines", type=int, default=4, help="decoder engines per GPU (own stream each) the lanes are split over")
     ap.add_argument("--frames", type=int, default=1000, help="frames per utterance (10 s)")
     ap.add_argument("--utts", type=int, default=64, help="distinct synthetic utterances (cycled)")
@@ -263,6 +263,7 @@ def main():
         ids = batch(i)
 
         def one(e):         # engine e decodes its share of the step's utterances (the C calls release the GIL)
+            lib.check(L.s3a_set_device(local_rank))     # (HIP's current device is per host thread)
             sub = ids[e * NLE:(e + 1) * NLE]
             ms = decs[e].ud.decode_dev([fdev[k] for k in sub], [nfr[k] for k in sub], D4x4)
             out = []

@@ -532,11 +532,13 @@ launch_score_t(const s3a_mgau_model_t *g, const float *feat_dev, int32_t feat_st
     int32_t grid = ((n_tiles + 7) / 8) * n_chunks * 8;
     size_t lds = score_lds_bytes(d, fpc, TAB_LDS, NT);
     auto kern = k_score_frames<CP, EXACT, TAB_LDS, NT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64];           /* per device: the opt-in belongs to the device that is current */
+    int dev_now = 0;
+    (void)hipGetDevice(&dev_now);
+    if (dev_now < 0 || dev_now >= 64 || !attr_set[dev_now]) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024);
-        attr_set = true;
+        if (dev_now >= 0 && dev_now < 64) attr_set[dev_now] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st,
                        d->mean4, d->prec4, d->lrd, d->mixw, d->tab16, d->tab_size, d->lm_zero,

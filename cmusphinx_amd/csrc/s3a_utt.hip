@@ -700,6 +700,8 @@ struct s3a_uttdec_s {
     ULane *d_lanes;
     int32_t *d_lcmap;
     std::vector<int32_t> h_lcmap;
+    int device;                 /* the device the engine lives on: made current at every entry point (HIP's current
+                                 * device is per host thread, and engines are driven from several) */
     int32_t many;               /* from this many lanes on: the grids / kernels for many lanes per launch (S3A_UTT_MANY; tests) */
     int32_t g_eval, eval_block, g_ent, g_mark, g_res, scan_nc, scan_gc, hist_possible, weak_possible;
     hipStream_t stream;
@@ -770,6 +772,7 @@ extern "C" void
 s3a_uttdec_free(s3a_uttdec_t *ud)
 {
     if (!ud) return;
+    (void)hipSetDevice(ud->device);
     (void)hipStreamSynchronize(ud->stream);
     for (auto &hl : ud->lane) {
         wlane_free(hl.d.w);
@@ -828,6 +831,8 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
     ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
+    ud->device = 0;
+    (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
     ud->stream = d->stream;
@@ -1215,6 +1220,7 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
         s3a_set_error("s3a_uttdec_decode: bad arguments (%d utterances, %d lanes)", n_utt, ud ? ud->n_lanes : 0);
         return S3A_EINVAL;
     }
+    HIPCHK(hipSetDevice(ud->device));
     int32_t rc, maxT = 0;
     for (int32_t z = 0; z < n_utt; z++) {
         if ((rc = lane_begin(ud, z, feat[z], n_frames[z], feat_stride, feat_on_device)) != S3A_OK) return rc;

@@ -14,7 +14,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/bench.err
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-scoring > $OUT/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu --no-scoring --lanes 256 > $OUT/prof_stats.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/prof_pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-scoring --frames 100 --utts 32 --lanes 64 --engines 1 > $OUT/prof_pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/prof_pmc_write -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu --no-scoring --frames 100 --utts 32 --lanes 64 --engines 1 > $OUT/prof_pmc_write.log 2>&1
 # the scoring kernels alone (whole-utterance + frame-synchronous, hub4 and WSJ shapes): kernel trace and the two PMC passes
