@@ -2,18 +2,18 @@
 """bench.py -- full mode-4 DECODING throughput of the MI355X-native backend on the hub4-shaped CD-GMM task
 (BASELINE.json configs[3]: a batch of synthetic 10 s utterances, hub4 model, sharded over the GPUs).
 
-A "step" = one batch of L utterances (L decoder lanes, default 32; 1000 frames = 10 s of 16 kHz audio each)
-decoded from the first to the last frame on the device: CI + gated CD senone scoring (6144 senones x 8 Gaussians
+A "step" = one batch of L utterances (L decoder lanes, default 512, split over E = 4 engines with a stream and a host
+thread each; 1000 frames = 10 s of 16 kHz audio per utterance) decoded from the first to the last frame on the device: CI + gated CD senone scoring (6144 senones x 8 Gaussians
 x 39), lextree HMM evaluation over three unigram + three filler lextrees of a 20 000-word dictionary, histogram
 and beam pruning, phone-level propagation, the word level (trigram look-ups, Viterbi history, word pruning, word
 transitions) -- s3a_uttdec_decode_dev, no host work inside an utterance -- then the hypothesis records
-(s3a_uttdec_hyp: final </s> transition + backtrace).  With the defaults (--steps 32, 32 lanes) the timed region
+(s3a_uttdec_hyp: final </s> transition + backtrace).  With the defaults (--steps 2, 512 lanes) the timed region
 decodes 1024 utterances per GPU.  Features are resident in HBM before the timed region; the history tables and
 hypotheses come back to the host inside it.  Arithmetic is the bit-exact mode (float32 subtract, float64
 accumulate, int32 log-add): the decoder's -hyp / -hypseg lines are checked against the unmodified reference
 decoder (CPU, same files) before timing.
 
-    python bench.py --gpus 1 --steps 32 --warmup 2
+    python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -26,13 +26,14 @@ The decoder is rebuilt from a bundle (cmusphinx_amd/bundle.py) through the C ABI
 once, UNTIMED, to load the models / dictionary / LM, build the lextrees and write that bundle.
 
 Prints ONE JSON line (rank 0).  Extra keys beyond the driver contract:
-  roofline      the dominant kernel of the timed pipeline (per-kernel HIP-event timing of a profiled batch):
+  roofline      the dominant kernel of the timed pipeline (per-kernel HIP-event timing of a profiled batch of ONE engine):
                 achieved = algorithmic bytes per launch / average launch time vs the 8 TB/s HBM peak
   kernels       every kernel class of a frame: average microseconds per launch, share of the frame
   cpu_baseline  the UNMODIFIED reference decoder (oracle/_ref/sphinx3_decode) on the same task and host: one
                 process, and P processes over disjoint control-file shards (P = physical cores, capped)
   scoring       configs[1]: whole-utterance senone scoring (k_score_frames) and the frame-synchronous pass
-                (one model pass per frame) on the hub4 and the configs[4] (8000 x 32) model shapes
+                (one model pass per frame; and 2 / 8 frames folded into one pass) on the hub4 and the configs[4]
+                (8000 x 32) model shapes
 """
 import argparse
 import json
