@@ -1131,7 +1131,8 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     const bool multi = n >= UG_FB && S.D4 == D4MAIN && S.CP >= UG_FB && S.CP <= 64 && g_cd > 0 && S.gp_n == g_cd
         && getenv("S3A_UTT_NO_MULTI") == NULL;
     const int32_t gz = (n + UG_MAX - 1) / UG_MAX, groups = (min(n, UG_MAX) + UG_FB - 1) / UG_FB;
-    const dim3 gm(g_cd, max(1, min(groups, 2 * ud->g->dev->n_cu / max(1, g_cd * gz))), gz);
+    const int32_t gy_env = getenv("S3A_UTT_GY") ? atoi(getenv("S3A_UTT_GY")) : 0;
+    const dim3 gm(g_cd, gy_env > 0 ? min(groups, gy_env) : max(1, min(groups, 2 * ud->g->dev->n_cu / max(1, g_cd * gz))), gz);
     if (ud->exact) {
         if (g_ci) UKL(UK_GATED_CI, (ku_gated<true, true>), dim3(g_ci + g_cs, 1, n), dim3(256), 0, st, LN, S, f);
         if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<true>), gm, dim3(256), 0, st, LN, S, n, f);
