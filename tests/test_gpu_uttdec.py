@@ -76,3 +76,39 @@ def test_hypothesis_records_are_fixed_size_and_self_contained(gpu_lib, tidigits_
     ref = open(f"{D}/ref_mode4_trigram.match").read().splitlines(keepends=True)
     assert [l[0] for l in lines] == ref[:2]
     assert back[1].utt_index == 1 and back[0].word[0].sf == 0
+
+
+def test_very_short_and_ragged_utterances(gpu_lib, tidigits_bundle, tmp_path):
+    """Utterances of 1, 2, 5, 12 and 40 frames in ONE batch (more lanes than utterances).  The reference cannot end an
+    utterance of 1 or 2 frames (`s->funcs->utt_end failed`: no word exit reached a history entry) and writes no line
+    for it; from 5 frames on it writes <sil> / a word.  Same files through S3A_UTT, and through the C ABI alone the
+    hypothesis records of the two unendable utterances carry a failure status while the others format identically."""
+    import struct
+    REF = os.path.join(ROOT, "oracle", "_ref", "sphinx3_decode")
+    cep = s3io.read_mfc(f"{D}/cepstra/man/man.ah.2934za.mfc").reshape(-1, 13)
+    lens = [1, 2, 5, 12, 40]
+    os.makedirs(tmp_path / "cep")
+    for n in lens:
+        with open(tmp_path / "cep" / f"t{n}.mfc", "wb") as f:
+            f.write(struct.pack("<i", 13 * n))
+            f.write(cep[:n].astype("<f4").tobytes())
+    (tmp_path / "ctl").write_text("".join(f"t{n}\n" for n in lens))
+    args = ["-dict", f"{D}/dictionary", "-fdict", f"{D}/fillerdict", "-hmm", AM, "-cepdir", str(tmp_path / "cep"),
+            "-agc", "none", "-varnorm", "no", "-cmn", "current", "-lw", "9.5", "-ctl", str(tmp_path / "ctl"),
+            "-op_mode", "4", "-lm", f"{D}/tidigits.DMP"]
+    out = {}
+    for tag, exe, env in (("ref", REF, None), ("utt", TST, dict(os.environ, S3A_UTT="8"))):
+        hyp, seg = str(tmp_path / f"{tag}.match"), str(tmp_path / f"{tag}.matchseg")
+        p = subprocess.run([exe] + args + ["-hyp", hyp, "-hypseg", seg], capture_output=True, text=True, errors="ignore",
+                           timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-1500:]
+        out[tag] = (open(hyp).read(), open(seg).read(), p.stderr.count("utt_end failed"))
+    assert out["ref"][0].count("\n") == 3 and out["ref"][2] == 2          # t1, t2: no line, two failures reported
+    assert out["utt"] == out["ref"]
+    dec = bundle.Decoder(tidigits_bundle, 8)
+    feats = [gpu_lib.feat_1s_c_d_dd(cep[:n].copy(), cmn="current") for n in lens]
+    dec.decode(feats)
+    recs = [dec.hyp(z, f"t{n}", z) for z, n in enumerate(lens)]
+    assert [r.status != 0 for r in recs] == [True, True, False, False, False]
+    assert "".join(dec.format(r)[0] for r in recs[2:]) == out["ref"][0]
+    assert "".join(dec.format(r)[1] for r in recs[2:]) == out["ref"][1]
