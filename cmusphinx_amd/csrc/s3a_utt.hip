@@ -44,6 +44,7 @@ struct ULane {
     uint8_t *sen_act;
     int32_t *scr, *misc, *bstidx, *bstscr, *updatetime, *gpart;
     int32_t *cs_need, *cs_val;  /* [n_cs] composite senones: wanted in frame (stamp) | score of the frame */
+    int32_t *dynbeam;           /* [1] the frame's CI beam when -maxcdsenpf is in force (ku_dyn_ci_beam) */
     /* this utterance */
     UCtx *ctx;
     int32_t *pack;
@@ -68,6 +69,8 @@ struct UShared {
     const uint8_t *ncomp;
     const int16_t *cd2cisen;
     int32_t ds_ratio, ci_pbeam, ci_pbeam_tight, ptranskip;
+    int32_t max_cd;             /* -maxcdsenpf; >= the number of CD senones: no dynamic beam */
+    float tighten;
     FrameBeams bm;              /* phone_uses_wbeam is worked out per frame */
     /* what decides whether a workgroup has anything to do sits at addresses known from the kernel arguments alone: the
      * lanes' contexts and active-list lengths are two arrays (ONE round trip to the early exit instead of lane struct ->
@@ -169,7 +172,7 @@ ku_gated(const ULane *__restrict__ lanes, UShared S, int32_t f)
     if ((int32_t)(blockIdx.x * 256) >= (hi - lo) * S.CP) return;
     const float *x = ctx->feat + (size_t)cf * S.D4 * 4;
     const int32_t is_skip = (cf % S.ds_ratio == 0) ? 0 : 1;
-    const int32_t beam = is_skip ? S.ci_pbeam_tight : S.ci_pbeam;
+    const int32_t beam = (!CI && S.max_cd < S.n_sen - S.n_ci_sen) ? L.dynbeam[0] : (is_skip ? S.ci_pbeam_tight : S.ci_pbeam);
 #define KU_GATED_ARGS S.mean4, S.prec4, S.lrd, S.mixw, S.tab16, S.tab_size, S.lm_zero, S.f, S.distfloor, x, S.D4, S.CP,  \
         S.Gpad, lo, hi, CI ? 1 : 0, S.ncomp, S.cd2cisen, L.sen_act, L.scr, 0, CI ? (const int32_t *)NULL : L.misc + 5,     \
         CI ? 0 : beam, cf, CI ? 0 : is_skip, L.bstidx, L.bstscr, L.updatetime, L.misc, CI ? 5 : 0,                        \
@@ -240,7 +243,8 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, i
                 const int32_t cf = f;
                 d.sen_act = Lz.sen_act; d.scr = Lz.scr; d.gpart = Lz.gpart; d.bstidx = Lz.bstidx; d.bstscr = Lz.bstscr;
                 d.updatetime = Lz.updatetime; d.frame = cf; d.is_skip = (cf % S.ds_ratio == 0) ? 0 : 1;
-                d.thresh = add32(Lz.misc[5], d.is_skip ? S.ci_pbeam_tight : S.ci_pbeam);
+                d.thresh = add32(Lz.misc[5], S.max_cd < S.n_sen - S.n_ci_sen ? Lz.dynbeam[0]
+                                                                                  : (d.is_skip ? S.ci_pbeam_tight : S.ci_pbeam));
             }
         }
         dec[tid] = d;
@@ -344,6 +348,50 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, i
         gp[blockIdx.x] = max(max(red[0][tid][0], red[1][tid][0]), max(red[2][tid][0], red[3][tid][0]));
         gp[S.gp_n + blockIdx.x] = red[0][tid][1] + red[1][tid][1] + red[2][tid][1] + red[3][tid][1];
         gp[2 * S.gp_n + blockIdx.x] = red[0][tid][2] + red[1][tid][2] + red[2][tid][2] + red[3][tid][2];
+    }
+}
+
+/* ---- approx_compute_dyn_ci_pbeam (approx_cont_mgau.c:303-357, -maxcdsenpf): the CI senones in descending score order,
+ * the active CD senones each of them stands for counted along the way; the beam is cut where the count passes the cap.
+ * (Ties need no order: the cut is a score.)  One workgroup per lane, between the CI and the CD scoring launches. ---- */
+#define UDB_MAXCI 1024
+__global__ void __launch_bounds__(1024)
+ku_dyn_ci_beam(const ULane *__restrict__ lanes, UShared S, int32_t f)
+{
+    __shared__ int32_t s_occ[UDB_MAXCI], s_scr[UDB_MAXCI], s_ord[UDB_MAXCI], s_cut;
+    LANE;
+    const int32_t n_ci = S.n_ci_sen, tid = threadIdx.x;
+    for (int32_t c = tid; c < n_ci; c += 1024) { s_occ[c] = 0; s_scr[c] = L.scr[c]; }
+    if (tid == 0) s_cut = INT_MAX;
+    __syncthreads();
+    for (int32_t s = n_ci + tid; s < S.n_sen; s += 1024)
+        if (L.sen_act[s]) atomicAdd(&s_occ[S.cd2cisen[s]], 1);
+    __syncthreads();
+    for (int32_t c = tid; c < n_ci; c += 1024) {
+        const int32_t v = s_scr[c];
+        int32_t r = 0;
+        for (int32_t c2 = 0; c2 < n_ci; c2++) { const int32_t v2 = s_scr[c2]; r += (v2 > v || (v2 == v && c2 < c)) ? 1 : 0; }
+        s_ord[r] = c;
+    }
+    __syncthreads();
+    const int32_t pbest = s_scr[s_ord[0]];
+    for (int32_t r = tid; r < n_ci; r += 1024) {
+        int32_t total = 0;
+        for (int32_t r2 = 0; r2 <= r; r2++) total += s_occ[s_ord[r2]];
+        if (total > S.max_cd) atomicMin(&s_cut, r);          /* the first rank at which the count passes the cap */
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int32_t beam = S.ci_pbeam;
+        if (s_cut != INT_MAX) {
+            /* (the reference's loop runs while the score is above pbest + ci_pbeam: a cut beyond that is none) */
+            const int32_t v = s_scr[s_ord[s_cut]];
+            bool in_beam = true;
+            for (int32_t r = 0; r <= s_cut && in_beam; r++) in_beam = s_scr[s_ord[r]] > add32(pbest, S.ci_pbeam);
+            if (in_beam) beam = v - pbest;
+        }
+        if (f % S.ds_ratio != 0) beam = (int32_t)((float)beam * S.tighten);
+        L.dynbeam[0] = beam;
     }
 }
 
@@ -779,6 +827,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.d.pack) (void)hipFree(hl.d.pack);
         if (hl.d.cs_need) (void)hipFree(hl.d.cs_need);
         if (hl.d.cs_val) (void)hipFree(hl.d.cs_val);
+        if (hl.d.dynbeam) (void)hipFree(hl.d.dynbeam);
         if (hl.ls && ud->S.nact_all && hl.ls->d_nact[0] >= ud->S.nact_all
             && hl.ls->d_nact[0] < ud->S.nact_all + (size_t)ud->n_lanes * 2 * WL_MAXT)
             hl.ls->d_nact[0] = hl.ls->d_nact[1] = NULL;     /* borrowed from nact_all */
@@ -822,7 +871,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         return NULL;
     }
     if (d->tab16 == NULL) { s3a_set_error("s3a_uttdec_init: 32-bit log-add tables are not supported"); return NULL; }
-    if (max_cd < n_sen - n_ci_sen) { s3a_set_error("s3a_uttdec_init: -maxcdsenpf (dynamic CI beam) is not supported on the device-resident path"); return NULL; }
+    if (max_cd < n_sen - n_ci_sen && n_ci_sen > UDB_MAXCI) { s3a_set_error("s3a_uttdec_init: -maxcdsenpf with more than %d CI senones", UDB_MAXCI); return NULL; }
     if (lm->n_dictword != 0 && lm->n_dictword != cfg->n_word && !lm->inclass.empty()) {
         s3a_set_error("s3a_uttdec_init: the LM's class table and the dictionary disagree");
         return NULL;
@@ -966,6 +1015,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
             S.gp_n = hl.sc->gp_n;
             S.ci_pbeam = hl.sc->ci_pbeam;
             S.ci_pbeam_tight = (int32_t)((float)hl.sc->ci_pbeam * hl.sc->tighten_factor);
+            S.max_cd = max_cd; S.tighten = hl.sc->tighten_factor;
             S.ncomp = hl.sc->ncomp_d;           /* identical in every lane's scorer (model facts) */
             S.cd2cisen = hl.sc->cd2cisen_d;
         }
@@ -983,7 +1033,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         u.scan_flag = ls->d_scan_flag; u.scan_agg = ls->d_scan_agg; u.scan_pre = ls->d_scan_pre; u.key = ls->d_key;
         u.sen_act = hl.sc->act_d; u.scr = hl.sc->scr_d; u.misc = hl.sc->misc_d; u.bstidx = hl.sc->bstidx_d;
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
-        DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4);
+        DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4); DM(u.dynbeam, 16);
         if (fill32(ud->stream, u.cs_need, -1, (size_t)cs->n_comstate + 1) != S3A_OK) goto fail;
         u.ctx = ud->S.ctx_all + z;
         DM(u.pack, (size_t)(6 * T + 16 + 3 * proto->pack_max_exits) * 4);
@@ -1135,11 +1185,13 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     const dim3 gm(g_cd, gy_env > 0 ? min(groups, gy_env) : max(1, min(groups, 2 * ud->g->dev->n_cu / max(1, g_cd * gz))), gz);
     if (ud->exact) {
         if (g_ci) UKL(UK_GATED_CI, (ku_gated<true, true>), dim3(g_ci + g_cs, 1, n), dim3(256), 0, st, LN, S, f);
+        if (S.max_cd < S.n_sen - S.n_ci_sen) UKL(UK_GATED_CI, ku_dyn_ci_beam, dim3(1, 1, n), dim3(1024), 0, st, LN, S, f);
         if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<true>), gm, dim3(256), 0, st, LN, S, n, f);
         else if (g_cd) UKL(UK_GATED_CD, (ku_gated<true, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S, f);
     }
     else {
         if (g_ci) UKL(UK_GATED_CI, (ku_gated<false, true>), dim3(g_ci + g_cs, 1, n), dim3(256), 0, st, LN, S, f);
+        if (S.max_cd < S.n_sen - S.n_ci_sen) UKL(UK_GATED_CI, ku_dyn_ci_beam, dim3(1, 1, n), dim3(1024), 0, st, LN, S, f);
         if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<false>), gm, dim3(256), 0, st, LN, S, n, f);
         else if (g_cd) UKL(UK_GATED_CD, (ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S, f);
     }

@@ -195,13 +195,15 @@ def rm_args(extra=()):
 
 
 @pytest.mark.parametrize("binary", ["scoring_only", "full_device", "full_device_histprune", "full_device_batched",
-                                    "utt_1", "utt_7_histprune", "utt_3_tight_word_limits", "utt_33", "utt_5_bestpath"])
+                                    "utt_1", "utt_7_histprune", "utt_3_tight_word_limits", "utt_33", "utt_5_bestpath", "utt_4_maxcdsenpf", "utt_34_maxcdsenpf"])
 def test_rm1_identical_to_live_reference(binary, tmp_path):
     exe = SHIM if binary == "scoring_only" else TST
     extra = ["-maxhmmpf", "800"] if binary in ("full_device_histprune", "full_device_batched", "utt_7_histprune") else []
     env = dict(os.environ, S3A_STREAMS="5", S3A_BATCH="2") if binary == "full_device_batched" else None
     if binary.startswith("utt_"):
-        env = dict(os.environ, S3A_UTT=binary.split("_")[1], **({"S3A_UTT_MANY": "2"} if binary == "utt_33" else {}))
+        env = dict(os.environ, S3A_UTT=binary.split("_")[1], **({"S3A_UTT_MANY": "2"} if binary.split("_")[1] in ("33", "34") else {}))
+    if binary.endswith("_maxcdsenpf"):          # the dynamic CI beam (approx_compute_dyn_ci_pbeam): 145 instead of 572 CD
+        extra = ["-ci_pbeam", "1e-10", "-maxcdsenpf", "150"]    # senones per frame survive the gate; worked out on the device
     if binary == "utt_5_bestpath":              # the reference's SECOND pass (DAG from the history table, dag_bestpath)
         extra = ["-bestpath", "1"]              # runs unchanged on the table the device produced (srch_utt_end)
     if binary == "utt_3_tight_word_limits":     # the word level's own pruning: few words / histories per frame, bigram history
