@@ -105,6 +105,10 @@ def cpu_baseline(task, d, n_procs):
         s = parse_summary(lg)
         if q.returncode == 0 and s:
             agg += 100.0 / max(s[3], 1e-9)            # xClk = seconds of wall clock per second of audio
+    more = {}                                        # utterance index -> its (-hyp, -hypseg) line: extra checks of the gate
+    for i, (q, h2, s2, _) in enumerate(ps):
+        if q.returncode == 0 and os.path.exists(h2) and os.path.exists(s2):
+            more[2 + i] = (open(h2).read(), open(s2).read())
     out = {"value": round(agg, 1), "unit": "frames/s", "cores": n_procs, "kind": "reference",
            "single_core": round(100.0 / max(xcpu, 1e-9), 1), "single_core_xRT": round(1.0 / max(xcpu, 1e-9), 2),
            "aggregate_xRT": round(agg / 100.0, 1), "physical_cores_on_host": physical_cores(),
@@ -113,7 +117,7 @@ def cpu_baseline(task, d, n_procs):
                      f"({frames} frames) in one process for single_core (stat.c SUMMARY tot xCPU); value = {n_procs} processes "
                      f"at once over disjoint -ctloffset/-ctlcount shards, 1 utterance (~10 s) each, summed 100/xClk; "
                      f"model loading excluded (SUMMARY counts decoding only)"}
-    return out, (open(hyp).read(), open(seg).read())
+    return out, (open(hyp).read(), open(seg).read(), more)
 
 
 def scoring_legs(lib, fast):
@@ -285,7 +289,7 @@ def main():
         if args.no_cpu:
             p, hyp, seg, log = run_reference(targs, os.path.join(d, "ctl"), 0, 2, d, "gate")
             p.wait()
-            ref_out = (open(hyp).read(), open(seg).read())
+            ref_out = (open(hyp).read(), open(seg).read(), {})
         else:
             cpu, ref_out = cpu_baseline({"args": targs, "ctl": os.path.join(d, "ctl")}, d, min(n_procs, max(1, U - 2)))
         assert ref_out, "the reference decoder failed on the task"
@@ -296,6 +300,17 @@ def main():
             got += [dec.format(dec.hyp(z, utts[ids[z]], first + z)) for z in range(min(NLE, 2))]
         assert "".join(g[0] for g in got) == ref_out[0] and ("".join(g[1] for g in got) == ref_out[1] or args.fast), \
             "device hypotheses differ from the unmodified reference decoder's"
+        # ... and every utterance the CPU baseline's shard processes decoded (all of the task's distinct utterances)
+        n_checked = 2
+        todo = sorted(ref_out[2])
+        for k0 in range(0, len(todo), NLE):
+            ids = todo[k0:k0 + NLE]
+            dec.ud.decode_dev([fdev[k] for k in ids], [nfr[k] for k in ids], D4x4)
+            for z, k in enumerate(ids):
+                m_, s_ = dec.format(dec.hyp(z, utts[k], k))
+                assert m_ == ref_out[2][k][0] and (s_ == ref_out[2][k][1] or args.fast), \
+                    f"device hypothesis of utterance {k} differs from the unmodified reference decoder's"
+            n_checked += len(ids)
 
     def sync_all():
         if dist is not None:
@@ -375,7 +390,7 @@ def main():
                        "parallelism": f"utterance-sharded x{world}, one all_gather of s3a_hyp_record_t ({shard.REC_BYTES} B per utterance)"},
             "xRT_per_gpu": round(value / world / 100.0, 1),
             "device_ms_per_step": round(dev_ms / args.steps, 3),
-            "identical_to_reference": True,
+            "identical_to_reference": True, "utterances_checked_against_reference": n_checked,
             "load_s": round(t_load, 2),
             "per_frame": {"active_hmm": round(lanes_hmm, 1), "cd_senones_scored": round(lanes_sen, 1), "cd_gaussians": round(lanes_gau, 1),
                           "word_exits": round(lanes_exit, 2), "max_candidates": int(res0["max_cand"]), "tie_frames_lane0": int(res0["n_tie_frames"])},
