@@ -884,7 +884,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
-    ud->stream = d->stream;
+    ud->stream = d->stream;             /* (the model's stream: engines that are to overlap each need a model of their own) */
     ud->exact = g->precision == S3A_GMM_EXACT;
     ud->veclen = g->veclen;
     int32_t maxn = 0, n_leaf_bound = proto->pack_max_exits;
@@ -1072,17 +1072,20 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     const float *d_feat_use = feat;
     if (!feat_on_device) {
         const size_t need = (size_t)nfr * D4x4;
+        /* (buffers grow with slack: every hipMalloc / hipHostMalloc / free stalls ALL streams of the device, the other
+         * engines' too -- a lane must not pay that each time its utterance is a little longer than the last) */
+        const size_t grow = (size_t)min(ud->max_frames, max(nfr + nfr / 2, 1024)) * D4x4;
         if (need > hl.feat_cap) {
             if (hl.d_feat) (void)hipFree(hl.d_feat);
             hl.d_feat = NULL; hl.feat_cap = 0;
-            if (hipMalloc((void **)&hl.d_feat, need * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: feature buffer"); return S3A_ENOMEM; }
-            hl.feat_cap = need;
+            if (hipMalloc((void **)&hl.d_feat, grow * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: feature buffer"); return S3A_ENOMEM; }
+            hl.feat_cap = grow;
         }
         if (need > hl.h_feat_cap) {
             if (hl.h_feat) (void)hipHostFree(hl.h_feat);
             hl.h_feat = NULL; hl.h_feat_cap = 0;
-            if (hipHostMalloc((void **)&hl.h_feat, need * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: pinned feature buffer"); return S3A_ENOMEM; }
-            hl.h_feat_cap = need;
+            if (hipHostMalloc((void **)&hl.h_feat, grow * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: pinned feature buffer"); return S3A_ENOMEM; }
+            hl.h_feat_cap = grow;
         }
         for (int32_t t = 0; t < nfr; t++) {
             float *row = hl.h_feat + (size_t)t * D4x4;
@@ -1249,10 +1252,11 @@ lane_fetch_table(s3a_uttdec_t *ud, int32_t z)
     hl.n_entry = n;
     const size_t need = (size_t)10 * (n + 1) + (size_t)3 * nf;
     if (need > hl.h_tab_cap) {
+        const size_t grow = max(need * 2, (size_t)1 << 18);        /* (with slack: see lane_begin) */
         if (hl.h_tab) (void)hipHostFree(hl.h_tab);
         hl.h_tab = NULL; hl.h_tab_cap = 0;
-        if (hipHostMalloc((void **)&hl.h_tab, need * 4 + 64) != hipSuccess) { s3a_set_error("s3a_uttdec: pinned table buffer"); return S3A_ENOMEM; }
-        hl.h_tab_cap = need;
+        if (hipHostMalloc((void **)&hl.h_tab, grow * 4 + 64) != hipSuccess) { s3a_set_error("s3a_uttdec: pinned table buffer"); return S3A_ENOMEM; }
+        hl.h_tab_cap = grow;
     }
     const WLane &w = hl.d.w;
     const int32_t *src[10] = { w.score, w.pred, w.lw0, w.lw1, w.wid, w.sf, w.ef, w.ascr, w.lscr, w.type };

@@ -1201,7 +1201,9 @@ concat_parts(const char *dst, int n)
  * -hypseg / lattices / statistics).
  */
 typedef struct { char *uttid, *uttfile; float32 *feat; int32 nfr; } uq_t;
-static s3a_uttdec_t *g_ud;
+#define UTT_MAX_ENGINES 8
+static s3a_uttdec_t *g_ud, *g_uds[UTT_MAX_ENGINES];    /* g_ud = g_uds[0]; S3A_UTT_ENGINES engines of g_lpe lanes each */
+static int32 g_n_eng = 1, g_lpe;
 static s3a_lm3g_t *g_lm3g;
 static uq_t *g_uq;
 static int32 g_uq_n, g_uq_cap;
@@ -1246,7 +1248,7 @@ utt_finish(kb_t *kb, int32 z)
     s3a_utt_result_t r;
     int32 f;
 
-    if (s3a_uttdec_result(g_ud, z, &r) != S3A_OK) die("uttdec result");
+    if (s3a_uttdec_result(g_uds[z / g_lpe], z % g_lpe, &r) != S3A_OK) die("uttdec result");
     if (z == 0 && getenv("S3A_UTT_TICKS")) {
         long long tk[16];
         int i;
@@ -1284,18 +1286,65 @@ utt_finish(kb_t *kb, int32 z)
     ckd_free(q->uttid); ckd_free(q->uttfile); ckd_free(q->feat);
 }
 
+typedef struct { int32 e, n, veclen, rc, state; const float **feat; const int32 *nfr; pthread_t th; } eng_job_t;
+static eng_job_t g_job[UTT_MAX_ENGINES];        /* state: 0 idle, 1 posted, 2 done */
+static pthread_mutex_t g_eng_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_eng_cv = PTHREAD_COND_INITIALIZER;
+static int g_eng_started;
+
+/* one persistent host thread per engine (a thread's first HIP call is expensive: not one per batch) */
+static void *
+eng_main(void *vp)
+{
+    eng_job_t *j = vp;
+    (void)s3a_dev_sync();               /* (the thread's HIP state, before the decode clock starts) */
+    pthread_mutex_lock(&g_eng_lock);
+    j->state = 0;
+    pthread_cond_broadcast(&g_eng_cv);
+    pthread_mutex_unlock(&g_eng_lock);
+    for (;;) {
+        pthread_mutex_lock(&g_eng_lock);
+        while (j->state != 1) pthread_cond_wait(&g_eng_cv, &g_eng_lock);
+        pthread_mutex_unlock(&g_eng_lock);
+        j->rc = s3a_uttdec_decode(g_uds[j->e], j->n, j->feat, j->nfr, j->veclen);
+        pthread_mutex_lock(&g_eng_lock);
+        j->state = 2;
+        pthread_cond_broadcast(&g_eng_cv);
+        pthread_mutex_unlock(&g_eng_lock);
+    }
+    return NULL;
+}
+
+/* the queue, g_lpe utterances per engine; the engines (own stream each) decode side by side, a host thread each --
+ * the tails of one engine's launches are another's work */
 static void
 utt_flush(kb_t *kb)
 {
     const float **feat;
-    int32 *nfr, z;
+    int32 *nfr, z, e, n_used;
     double t0;
+    eng_job_t *job = g_job;
     if (g_uq_n == 0) return;
     feat = ckd_calloc(g_uq_n, sizeof(*feat));
     nfr = ckd_calloc(g_uq_n, sizeof(*nfr));
     for (z = 0; z < g_uq_n; z++) { feat[z] = g_uq[z].feat; nfr[z] = g_uq[z].nfr; g_utt_frames += g_uq[z].nfr; }
     t0 = now_s();
-    if (s3a_uttdec_decode(g_ud, g_uq_n, feat, nfr, kbcore_fcb(kb->kbcore)->stream_len[0]) != S3A_OK) die("uttdec decode");
+    n_used = (g_uq_n + g_lpe - 1) / g_lpe;
+    for (e = 0; e < n_used; e++) {
+        job[e].e = e; job[e].n = (e + 1) * g_lpe <= g_uq_n ? g_lpe : g_uq_n - e * g_lpe;
+        job[e].feat = feat + e * g_lpe; job[e].nfr = nfr + e * g_lpe;
+        job[e].veclen = kbcore_fcb(kb->kbcore)->stream_len[0]; job[e].rc = S3A_OK;
+    }
+    if (g_n_eng == 1) job[0].rc = s3a_uttdec_decode(g_uds[0], job[0].n, job[0].feat, job[0].nfr, job[0].veclen);
+    else {
+        pthread_mutex_lock(&g_eng_lock);
+        for (e = 0; e < n_used; e++) job[e].state = 1;
+        pthread_cond_broadcast(&g_eng_cv);
+        for (e = 0; e < n_used; e++) while (job[e].state != 2) pthread_cond_wait(&g_eng_cv, &g_eng_lock);
+        for (e = 0; e < n_used; e++) job[e].state = 0;
+        pthread_mutex_unlock(&g_eng_lock);
+    }
+    for (e = 0; e < n_used; e++) if (job[e].rc != S3A_OK) die("uttdec decode");
     g_t_dev += now_s() - t0;
     t0 = now_s();
     for (z = 0; z < g_uq_n; z++) utt_finish(kb, z);
@@ -1476,12 +1525,43 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     cfg.wordend_beam = s->beam->wordend; cfg.n_lextree = tstg->n_lextree; cfg.epl = tstg->epl;
     cfg.hmmbeam = s->beam->hmm; cfg.pbeam = s->beam->ptrans; cfg.wbeam = s->beam->word;
     cfg.ptranskip = s->beam->ptranskip; cfg.maxhmmpf = tstg->histprune->maxhmmpf; cfg.tree_type = tree_type;
-    if (!getenv("S3A_EXPORT"))
-    g_ud = s3a_uttdec_init(g_ls, g_gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen, cmd_ln_int32_r(config, "-ds"),
+    g_n_eng = getenv("S3A_UTT_ENGINES") ? atoi(getenv("S3A_UTT_ENGINES")) : 1;     /* the lanes are split over the engines */
+    if (g_n_eng < 1) g_n_eng = 1;
+    if (g_n_eng > UTT_MAX_ENGINES) g_n_eng = UTT_MAX_ENGINES;
+    if (g_n_eng > n_lanes) g_n_eng = n_lanes;
+    g_lpe = (n_lanes + g_n_eng - 1) / g_n_eng;
+    n_lanes = g_lpe * g_n_eng;
+    if (!getenv("S3A_EXPORT")) {
+        int32 e;
+        for (e = 0; e < g_n_eng; e++) {
+            /* every further engine gets a model of its own: an engine runs on its model's stream, and engines are
+             * to overlap (the lextrees, the trigram and the composite-senone table are shared) */
+            s3a_mgau_model_t *gm = g_gm;
+            if (e > 0) {
+                gm = s3a_mgau_init(cmd_ln_str_r(config, "-mean"), cmd_ln_str_r(config, "-var"),
+                                   cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
+                                   cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.", S3A_MIX_INT_FLOAT_COMP, g_lm);
+                if (!gm) die("s3a_mgau_init");
+            }
+            g_uds[e] = s3a_uttdec_init(g_ls, gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen, cmd_ln_int32_r(config, "-ds"),
                            cmd_ln_int32_r(config, "-cond_ds"), cmd_ln_float64_r(config, "-ci_pbeam"),
                            cmd_ln_float32_r(config, "-tighten_factor"), cmd_ln_int32_r(config, "-maxcdsenpf"), g_cs,
-                           g_lm3g, &cfg, n_lanes, S3_MAX_FRAMES, getenv("S3A_UTT_VHCAP") ? atoi(getenv("S3A_UTT_VHCAP")) : 0,
+                           g_lm3g, &cfg, g_lpe, S3_MAX_FRAMES, getenv("S3A_UTT_VHCAP") ? atoi(getenv("S3A_UTT_VHCAP")) : 0,
                            getenv("S3A_UTT_CANDCAP") ? atoi(getenv("S3A_UTT_CANDCAP")) : 0);
+            if (!g_uds[e]) die("s3a_uttdec_init");
+        }
+        g_ud = g_uds[0];
+        if (g_n_eng > 1) {              /* the engines' host threads */
+            for (e = 0; e < g_n_eng; e++) {
+                g_job[e].e = e; g_job[e].state = 3;
+                if (pthread_create(&g_job[e].th, NULL, eng_main, &g_job[e]) != 0) die("pthread_create");
+            }
+            pthread_mutex_lock(&g_eng_lock);
+            for (e = 0; e < g_n_eng; e++) while (g_job[e].state != 0) pthread_cond_wait(&g_eng_cv, &g_eng_lock);
+            pthread_mutex_unlock(&g_eng_lock);
+            g_eng_started = 1;
+        }
+    }
     if (getenv("S3A_EXPORT")) {
         export_bundle(getenv("S3A_EXPORT"), &kb, tstg, w, &cfg);
         return 0;

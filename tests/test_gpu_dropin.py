@@ -114,6 +114,7 @@ DRIVERS = {
     "utt_1": {"S3A_UTT": "1"},
     "utt_4": {"S3A_UTT": "4"},
     "utt_3_bigwl": {"S3A_UTT": "3", "S3A_UTT_BIGWL": "1"},      # the word level's candidate phases as chip-wide launches
+    "utt_8_engines2": {"S3A_UTT": "8", "S3A_UTT_ENGINES": "2"},    # two engines of four lanes, a host thread each
     "utt_40": {"S3A_UTT": "40", "S3A_UTT_MANY": "2"},           # the kernels / grids chosen from 32 utterances per launch on
                                                                 # (list-driven resolve, fewer workgroups that loop), forced from 2
 }
@@ -123,7 +124,8 @@ DRIVERS = {
                                          ("mode4_trigram", "four_streams"), ("mode4_trigram", "batched_4x1"),
                                          ("mode4_cibeam_ds2", "batched_6x2"), ("mode4_trigram", "utt_1"),
                                          ("mode4_trigram", "utt_4"), ("mode4_cibeam_ds2", "utt_4"),
-                                         ("mode4_trigram", "utt_3_bigwl"), ("mode4_trigram", "utt_40")])
+                                         ("mode4_trigram", "utt_3_bigwl"), ("mode4_trigram", "utt_40"),
+                                         ("mode4_cibeam_ds2", "utt_8_engines2")])
 def test_full_device_search_matches_reference(name, driver, tmp_path):
     hyp, seg, log = (str(tmp_path / f"tst_{name}.{e}") for e in ("match", "matchseg", "log"))
     with open(log, "w") as lf:
@@ -285,7 +287,7 @@ def decode_task(exe, args, tmp_path, tag, env=None):
     return open(hyp).read(), open(seg).read(), tail
 
 
-@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4", "utt_3_bigwl", "utt_40"])
+@pytest.mark.parametrize("driver", ["one_decoder", "utt_1", "utt_4", "utt_3_bigwl", "utt_40", "utt_8_engines2"])
 def test_hub4_shaped_full_decode_matches_reference(driver, tmp_path):
     args = synth_task("hub4", tmp_path, 4, 250)
     ref = decode_task(REFDEC, args, tmp_path, "ref")
