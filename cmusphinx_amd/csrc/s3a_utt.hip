@@ -1,6 +1,6 @@
 /*
  * s3a_utt.hip -- WHOLE UTTERANCES on the device: the `decode` slot of srch_funcs_t
- * (sphinx3/include/srch.h:599-603; srch.c:673-675 hands the whole block to it).
+ * (sphinx3/include/srch.h:552-555; srch.c:673-675 hands the whole block to it).
  *
  * One engine = one acoustic model, one set of lextrees, one trigram, L decoder LANES.  A lane
  * decodes one utterance from its first to its last frame without the host: per frame the

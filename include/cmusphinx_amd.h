@@ -615,7 +615,7 @@ int32_t s3a_approx_cont_mgau_frame_eval_dev(s3a_scorer_t *sc, s3a_comsen_t *cs, 
 /* ===================================================================== */
 /*
  * with the word level on the device an utterance needs no host between its
- * first and its last frame -- the `decode` slot of srch_funcs_t (sphinx3/include/srch.h:599-603;
+ * first and its last frame -- the `decode` slot of srch_funcs_t (sphinx3/include/srch.h:552-555;
  * srch_utt_decode_blk hands the whole block to it, libsearch/srch.c:673-675).
  *
  * s3a_lm3g_t = lm_t (sphinx3/include/lm.h:559-660) flattened by the caller: unigram w has prob

@@ -10,7 +10,7 @@
  *        S3A_UTT=L       whole utterances on the device, L at a time: senone scoring, lextree search AND the
  *                        word level (trigram look-ups, Viterbi history, pruning, word transitions) run as
  *                        kernels with no host synchronisation inside an utterance (the `decode` slot,
- *                        srch.h:599-603, srch.c:673-675); the host reads the finished history table back,
+ *                        srch.h:552-555, srch.c:673-675); the host reads the finished history table back,
  *                        hands it to the reference's own vithist_utt_end / backtrace / output code.
  *        (otherwise)     frame-synchronous: scoring + lextree search on the device, the reference's own
  *                        vithist / LM on the host (one synchronisation per frame); S3A_STREAMS / S3A_BATCH.
