@@ -204,12 +204,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # S3A_BENCH_ONE_GPU=1: every rank on GPU 0, the gather over gloo -- a rehearsal of the multi-rank flow (sharding,
+    # barriers, max over ranks, the gather, rank 0's files) on a one-GPU box; RCCL cannot put two ranks on one GPU
+    rehearsal = world > 1 and os.environ.get("S3A_BENCH_ONE_GPU") == "1"
+    tdev = "cpu" if rehearsal else f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from cmusphinx_amd import bundle, lib, s3io, shard, synth_task
     L = lib.load()
@@ -316,7 +324,7 @@ def main():
         if dist is not None:
             dist.barrier()
         lib.check(L.s3a_dev_sync())
-        if dist is not None:
+        if dist is not None and not rehearsal:
             import torch
             torch.cuda.synchronize()
 
@@ -329,14 +337,14 @@ def main():
     for i in range(args.steps):
         dev_ms += run_step(i, recs)
     if dist is not None:
-        allrec = shard.gather_records(recs, world * args.steps * NL, dist, device=f"cuda:{local_rank}")
+        allrec = shard.gather_records(recs, world * args.steps * NL, dist, device=tdev)
     else:
         allrec = recs
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
