@@ -1710,6 +1710,44 @@ main(int argc, char *argv[])
 
     if (getenv("S3A_LIVE"))
         return live_mode_main(argc, argv, strcmp(getenv("S3A_LIVE"), "cpu") != 0);
+#ifndef LT_ORACLE
+    /* One process per GPU (torchrun / mpirun set RANK, WORLD_SIZE, LOCAL_RANK): rank r decodes the r-th contiguous
+     * share of the control file (inside the caller's -ctloffset / -ctlcount) on GPU LOCAL_RANK and writes
+     * <hyp>.part<r> / <hypseg>.part<r>; the parts, concatenated in rank order, are the one-process files. */
+    if (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 && getenv("RANK")) {
+        const int W = atoi(getenv("WORLD_SIZE")), r = atoi(getenv("RANK"));
+        const int lr = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : r;
+        static char so[32], sc[32], part[2][4300];
+        char **av = ckd_calloc(argc + 8, sizeof(char *));
+        const char *ctl = NULL;
+        int ac = 0, a, uoff = 0, ucnt = -1, n_lines = 0, base, extra, off, cnt;
+        if (s3a_set_device(lr) != S3A_OK) E_FATAL("tst shim: rank %d cannot use GPU %d\n", r, lr);
+        for (a = 0; a < argc; a++) {
+            if (a > 0 && a + 1 < argc && !strcmp(argv[a], "-ctloffset")) { uoff = atoi(argv[++a]); continue; }
+            if (a > 0 && a + 1 < argc && !strcmp(argv[a], "-ctlcount")) { ucnt = atoi(argv[++a]); continue; }
+            if (a > 0 && a + 1 < argc && !strcmp(argv[a], "-ctl")) ctl = argv[a + 1];
+            if (a > 0 && a + 1 < argc && (!strcmp(argv[a], "-hyp") || !strcmp(argv[a], "-hypseg"))) {
+                const int k = !strcmp(argv[a], "-hyp") ? 0 : 1;
+                snprintf(part[k], sizeof part[k], "%s.part%03d", argv[a + 1], r);
+                av[ac++] = argv[a]; av[ac++] = part[k]; a++;
+                continue;
+            }
+            av[ac++] = argv[a];
+        }
+        if (!ctl || (fp = fopen(ctl, "r")) == NULL) E_FATAL("tst shim: -ctl is required\n");
+        while (fgets(line, sizeof line, fp)) if (line[0] != '\n' && line[0] != '#') n_lines++;
+        fclose(fp);
+        n_lines = n_lines > uoff ? n_lines - uoff : 0;
+        if (ucnt >= 0 && ucnt < n_lines) n_lines = ucnt;
+        base = n_lines / W; extra = n_lines % W;
+        off = uoff + r * base + (r < extra ? r : extra); cnt = base + (r < extra ? 1 : 0);
+        snprintf(so, sizeof so, "%d", off); snprintf(sc, sizeof sc, "%d", cnt);
+        av[ac++] = "-ctloffset"; av[ac++] = so; av[ac++] = "-ctlcount"; av[ac++] = sc;
+        argc = ac; argv = av;
+        E_INFO("tst shim: rank %d of %d on GPU %d: control-file entries %d .. %d\n", r, W, lr, off, off + cnt - 1);
+        if (cnt == 0) return 0;
+    }
+#endif
     cmd_ln_appl_enter(argc, argv, "default.arg", arg);      /* `arg`: the reference's own table */
     unlimit();
     config = cmd_ln_get();

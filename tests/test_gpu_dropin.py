@@ -328,3 +328,21 @@ def test_live_api_s3_decode_process_with_replacement_slots(tmp_path):
         out[mode] = ([l for l in p.stdout.splitlines() if l.startswith("LIVE ")], open(hyp).read(), open(seg).read())
     assert len(out["cpu"][0]) == 31 and out["cpu"][1].count("\n") == 31
     assert out["gpu"] == out["cpu"]
+
+
+def test_one_process_per_gpu_shards_the_control_file(tmp_path):
+    """RANK / WORLD_SIZE / LOCAL_RANK (as torchrun or mpirun set them): rank r decodes the r-th contiguous share of the
+    control file on GPU LOCAL_RANK and writes <hyp>.part<r>; the parts in rank order are the one-process files.  Three
+    ranks here, all on GPU 0 (the box has one), 31 utterances -> shares of 11, 10, 10."""
+    hyp, seg = str(tmp_path / "w.match"), str(tmp_path / "w.matchseg")
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, S3A_UTT="4", WORLD_SIZE="3", RANK=str(r), LOCAL_RANK="0")
+        procs.append(subprocess.Popen([TST] + common() + RUNS["mode4_trigram"] + ["-hyp", hyp, "-hypseg", seg],
+                                      stdout=subprocess.DEVNULL, stderr=open(tmp_path / f"r{r}.log", "w"), env=env))
+    for r, p in enumerate(procs):
+        assert p.wait(timeout=900) == 0, open(tmp_path / f"r{r}.log", errors="ignore").read()[-2000:]
+    parts = [open(f"{hyp}.part{r:03d}").read() for r in range(3)]
+    assert [p.count("\n") for p in parts] == [11, 10, 10]
+    assert "".join(parts) == open(os.path.join(D, "ref_mode4_trigram.match")).read()
+    assert "".join(open(f"{seg}.part{r:03d}").read() for r in range(3)) == open(os.path.join(D, "ref_mode4_trigram.matchseg")).read()
