@@ -109,9 +109,9 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         /* the HMM's own state first: these loads do not depend on the senone scores and stay in flight
          * while the (longer) senone chain below runs */
 #pragma unroll
-        for (int st = 0; st < 3; st++) { r.s[st] = sc[st * N + v]; r.h[st] = hist[st * N + v]; }
-        r.out = outs[v];
-        r.outh = outh[v];
+        for (int st = 0; st < 3; st++) { r.s[st] = sc[NSI(st, N, v)]; r.h[st] = hist[NSI(st, N, v)]; }
+        r.out = outs[NSV(v)];
+        r.outh = outh[NSV(v)];
         int32_t tp[12];
         {
             const int4 *tq = (const int4 *)(tp_g + tmatid[v] * 12);    /* 48-byte rows of a 16-byte aligned array */
@@ -160,10 +160,10 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         }
         const int32_t k = vit3(r, tp, e[0], e[1], e[2]);
 #pragma unroll
-        for (int st = 0; st < 3; st++) { sc[st * N + v] = r.s[st]; hist[st * N + v] = r.h[st]; }
-        outs[v] = r.out;
-        outh[v] = r.outh;
-        bests[v] = k;
+        for (int st = 0; st < 3; st++) { sc[NSI(st, N, v)] = r.s[st]; hist[NSI(st, N, v)] = r.h[st]; }
+        outs[NSV(v)] = r.out;
+        outh[NSV(v)] = r.outh;
+        bests[NSV(v)] = k;
         best = k;
         if (w >= 0) wbest = k;
         /* by list position (coalesced): k_dec_scan finds the word exits without chasing the node ids again */
@@ -213,7 +213,7 @@ d_dec_stamp(const int32_t *__restrict__ act, const int32_t *__restrict__ outs, c
 {
     if (i >= na) return;
     const int32_t u = act[b + i];
-    if (outs[u] < pth) return;
+    if (outs[NSV(u)] < pth) return;
     for (int32_t q = psof_off[u], q_hi = psof_off[u + 1]; q < q_hi; q++) pstamp[psof[q]] = cf;
 }
 
@@ -252,7 +252,7 @@ d_dec_hist_count(const int32_t *__restrict__ node_base, const int32_t *__restric
     __syncthreads();
     const int32_t i = BX * DBLOCK + threadIdx.x, b = node_base[t];
     if (i < nact[t]) {
-        int32_t k = (s_bh - bests[act[b + i]]) / s_bw;
+        int32_t k = (s_bh - bests[NSV(act[b + i])]) / s_bw;
         if (k >= nbin) k = nbin - 1;
         if (k < 0) k = 0;               /* cannot happen with bestscr = the frame's maximum */
         binof[b + i] = k;
@@ -395,7 +395,7 @@ d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     for (int32_t t = 0; t < T; t++)
         for (int32_t i = threadIdx.x; i < nact[t]; i += SCAN_THREADS) {
             const int32_t v = act[node_base[t] + i];
-            if (wid[v] < 0 && bests[v] < th && outs[v] >= pth) weaklist[atomicAdd(&n_weak, 1)] = v;
+            if (wid[v] < 0 && bests[NSV(v)] < th && outs[NSV(v)] >= pth) weaklist[atomicAdd(&n_weak, 1)] = v;
         }
     __syncthreads();
     const int32_t nw = n_weak;
@@ -406,14 +406,14 @@ d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
         for (int32_t k = threadIdx.x; k < nw; k += SCAN_THREADS) {
             const int32_t v = weaklist[k];
             if (((volatile int32_t *)propf)[v] == cf) continue;
-            const int32_t in0 = sc[v], j = pos[v];
+            const int32_t in0 = sc[NSV(v)], j = pos[v];
             bool early = false;
             for (int32_t q = par_off[v]; q < par_off[v + 1] && !early; q++) {
                 const int32_t g = par[q];
                 if (posf[g] != cf || pos[g] >= j) continue;
-                const int32_t po = outs[g];
+                const int32_t po = outs[NSV(g)];
                 if (po < pth) continue;
-                if (bests[g] < th && ((volatile int32_t *)propf)[g] != cf) continue;
+                if (bests[NSV(g)] < th && ((volatile int32_t *)propf)[g] != cf) continue;
                 const int32_t ns = add32(po, add32(prob[v], -prob[g]));
                 early = ns >= th && ns > in0;
             }
@@ -455,18 +455,18 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
     if (is_active && !has_par) {
         /* no parent can enter v (the usual active HMM): it survives or is cleared at its own turn -- one gather */
         const int32_t j = j_known >= 0 ? j_known : pos[v], b = b_known >= 0 ? b_known : node_base[tree_of[v]];
-        if (bests[v] >= th) { selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); frame[v] = nf; }
+        if (bests[NSV(v)] >= th) { selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); frame[v] = nf; }
         else {
-            sc[v] = WORST; sc[1 * N + v] = WORST; sc[2 * N + v] = WORST;
-            hist[v] = -1; hist[1 * N + v] = -1; hist[2 * N + v] = -1;
-            outs[v] = WORST; outh[v] = -1; bests[v] = WORST;
+            sc[NSV(v)] = WORST; sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
+            hist[NSV(v)] = -1; hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
+            outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
             posout[b + j] = WORST;
             frame[v] = -1;
         }
         return;
     }
     const int32_t j = is_active ? (j_known >= 0 ? j_known : pos[v]) : INT_MAX;     /* (known when v was taken from the list) */
-    const int32_t in0 = sc[v];
+    const int32_t in0 = sc[NSV(v)];
     int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
     int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
     /* parents in batches of 8: the ids, then their list stamps, are independent loads (a first-level
@@ -482,22 +482,22 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
         for (int u = 0; u < 8; u++) {
             if (pf[u] != cf || pid[u] < 0) continue;
             const int32_t p = pid[u];
-            const int32_t po = outs[p];
+            const int32_t po = outs[NSV(p)];
             if (po < pth) continue;
             /* phone threshold BELOW the HMM threshold (-ptranskip frames, -pbeam wider than -beam): a
              * parent under the HMM beam is cleared at its turn (hmm_clear resets its exit score) before
              * it could propagate -- unless one of ITS parents re-entered it earlier in this frame
              * (k_dec_weak worked that out and stamped it) */
-            if (pth < th && bests[p] < th && propf[p] != cf) continue;
+            if (pth < th && bests[NSV(p)] < th && propf[p] != cf) continue;
             const int32_t ns = add32(po, add32(prob[v], -prob[p]));
             if (ns < th) continue;
             const int32_t pp = pos[p];
             if (pp < j) {
-                if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[p]; }
+                if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[NSV(p)]; }
                 if (ns > in0 && pp < firstE) firstE = pp;
             }
             else {
-                if (ns > mL || (ns == mL && pp < pL)) { mL = ns; pL = pp; hL = outh[p]; }
+                if (ns > mL || (ns == mL && pp < pL)) { mL = ns; pL = pp; hL = outh[NSV(p)]; }
                 if (pp < firstL) firstL = pp;
             }
         }
@@ -505,13 +505,13 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
     if (!is_active && mE == INT_MIN)
         return;                                         /* nothing happens to this node */
     const int32_t b = b_known >= 0 ? b_known : node_base[tree_of[v]];
-    int32_t cur = in0, h0 = hist[v], my_turn = -1;
+    int32_t cur = in0, h0 = hist[NSV(v)], my_turn = -1;
     bool in_list = false, cleared = false, entered = false;
     if (mE > in0) {
         cur = mE; h0 = hE; entered = true; in_list = true; my_turn = firstE;
     }
     else if (is_active) {
-        if (bests[v] >= th) { in_list = true; selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); }
+        if (bests[NSV(v)] >= th) { in_list = true; selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); }
         else { cleared = true; cur = WORST; h0 = -1; }
     }
     if (mL > cur) {
@@ -519,12 +519,12 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
         if (!in_list) { in_list = true; my_turn = firstL; }
     }
     if (cleared) {
-        sc[1 * N + v] = WORST; sc[2 * N + v] = WORST;
-        hist[1 * N + v] = -1; hist[2 * N + v] = -1;
-        outs[v] = WORST; outh[v] = -1; bests[v] = WORST;
+        sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
+        hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
+        outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
         posout[b + j] = WORST;                  /* k_dec_scan reads the exit scores by list position */
     }
-    if (cleared || entered) { sc[v] = cur; hist[v] = h0; }
+    if (cleared || entered) { sc[NSV(v)] = cur; hist[NSV(v)] = h0; }
     frame[v] = in_list ? nf : (cleared ? -1 : frame[v]);
     if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[b + my_turn], 1); }
 }
@@ -706,7 +706,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
         u2 = 0; c2 = 0; w2 = -1; os2 = 0;                                                           \
         if ((i_) < na) {                                                                            \
             u2 = act[b + (i_)]; c2 = cnt[b + (i_)];                                                 \
-            if (reordered) { w2 = wid[u2]; os2 = outs[u2]; }                                        \
+            if (reordered) { w2 = wid[u2]; os2 = outs[NSV(u2)]; }                                        \
             else { w2 = poswid[b + (i_)]; os2 = posout[b + (i_)]; }                                 \
             cnt[b + (i_)] = 0;                                  /* the accumulator of the next frame */ \
         }                                                                                           \
@@ -790,7 +790,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
                 base[b + i] = (int32_t)(uint32_t)excl;
                 if (ex) {
                     const int32_t e = b + (int32_t)(excl >> 32);
-                    const int32_t oh = outh[u];
+                    const int32_t oh = outh[NSV(u)];
                     exits[e] = w;
                     exits[N + e] = add32(os, -prob[u]);
                     exits[2 * N + e] = oh;
@@ -1163,7 +1163,7 @@ d_dec_enter1(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
     const int32_t scr = add32(calls[4 * c], ent.root_prob(idx, prob));
     if (scr < thresh) return;
     const int32_t v = ent.rootlist[idx];
-    if (!(sc[v] < scr)) return;
+    if (!(sc[NSV(v)] < scr)) return;
     atomicMax(&key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
     atomicMin(&first[v], c);
 }
@@ -1279,7 +1279,7 @@ d_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
             const int32_t scr = add32(in, ent.root_prob(roots + i, prob));
             if (scr >= thresh) {
                 const int32_t v = ent.rootlist[roots + i];
-                q = (sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
+                q = (sc[NSV(v)] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
             }
         }
         const unsigned long long m = __ballot(q);
@@ -1350,7 +1350,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
         const unsigned long long k = key[v];
         if (k == 0ull) return;
         const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(k & 0xffffffffu);
-        if (c == win_c) { sc[v] = (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); hist[v] = calls[4 * c + 1]; }
+        if (c == win_c) { sc[NSV(v)] = (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); hist[NSV(v)] = calls[4 * c + 1]; }
         if (c == first[v]) frame[v] = nf;
         return;
     }

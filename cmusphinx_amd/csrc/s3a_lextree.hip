@@ -85,15 +85,15 @@ k_lt_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict__
             e0 = senscr[sseq[ss * 3 + 0]]; e1 = senscr[sseq[ss * 3 + 1]]; e2 = senscr[sseq[ss * 3 + 2]];
         }
 #pragma unroll
-        for (int st = 0; st < 3; st++) { r.s[st] = sc[st * N + v]; r.h[st] = hist[st * N + v]; }
-        r.out = outs[v];
-        r.outh = outh[v];
+        for (int st = 0; st < 3; st++) { r.s[st] = sc[NSI(st, N, v)]; r.h[st] = hist[NSI(st, N, v)]; }
+        r.out = outs[NSV(v)];
+        r.outh = outh[NSV(v)];
         int32_t k = vit3(r, tp_s + tmatid[v] * 12, e0, e1, e2);
 #pragma unroll
-        for (int st = 0; st < 3; st++) { sc[st * N + v] = r.s[st]; hist[st * N + v] = r.h[st]; }
-        outs[v] = r.out;
-        outh[v] = r.outh;
-        bests[v] = k;
+        for (int st = 0; st < 3; st++) { sc[NSI(st, N, v)] = r.s[st]; hist[NSI(st, N, v)] = r.h[st]; }
+        outs[NSV(v)] = r.out;
+        outh[NSV(v)] = r.outh;
+        bests[NSV(v)] = k;
         best = k;
         if (wid[v] >= 0) wbest = k;
     }
@@ -128,10 +128,10 @@ k_lt_prop_mark(const int32_t *__restrict__ node_base, const int32_t *__restrict_
     const int32_t th = thr[0], pth = thr[1];
     if (i >= nact[t]) return;
     const int32_t u = act[node_base[t] + i];
-    if (wid[u] >= 0 || outs[u] < pth) return;
+    if (wid[u] >= 0 || outs[NSV(u)] < pth) return;
     for (int32_t j = child_off[u]; j < child_off[u + 1]; j++) {
         const int32_t c = child[j];
-        const int32_t ns = add32(outs[u], add32(prob[c], -prob[u]));
+        const int32_t ns = add32(outs[NSV(u)], add32(prob[c], -prob[u]));
         if (ns >= th && posf[c] != cf && atomicExch(&candf[c], cf) != cf)
             cand[node_base[t] + atomicAdd(&ncand[t], 1)] = c;
     }
@@ -157,7 +157,7 @@ k_lt_prop_resolve(const int32_t *__restrict__ node_base, const int32_t *__restri
     const int32_t v = is_active ? act[node_base[t] + i] : cand[node_base[t] + (i - na)];
     const int32_t j = is_active ? i : INT_MAX;      /* own turn; candidates have none */
     const int32_t nf = cf + 1;
-    const int32_t in0 = sc[v];                      /* state 0 score */
+    const int32_t in0 = sc[NSV(v)];                      /* state 0 score */
 
     /* scan the parents once: maxima and earliest positions for the early and late sets */
     int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
@@ -165,27 +165,27 @@ k_lt_prop_resolve(const int32_t *__restrict__ node_base, const int32_t *__restri
     for (int32_t k = par_off[v]; k < par_off[v + 1]; k++) {
         const int32_t p = par[k];
         if (posf[p] != cf) continue;                /* parent not in this frame's list */
-        const int32_t po = outs[p];
+        const int32_t po = outs[NSV(p)];
         if (po < pth) continue;
         const int32_t ns = add32(po, add32(prob[v], -prob[p]));
         if (ns < th) continue;
         const int32_t pp = pos[p];
         if (pp < j) {
-            if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[p]; }
+            if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[NSV(p)]; }
             if (ns > in0 && pp < firstE) firstE = pp;
         }
         else {
-            if (ns > mL || (ns == mL && pp < pL)) { mL = ns; pL = pp; hL = outh[p]; }
+            if (ns > mL || (ns == mL && pp < pL)) { mL = ns; pL = pp; hL = outh[NSV(p)]; }
             if (pp < firstL) firstL = pp;
         }
     }
-    int32_t cur = in0, h0 = hist[v], my_turn = -1;
+    int32_t cur = in0, h0 = hist[NSV(v)], my_turn = -1;
     bool in_list = false, cleared = false, entered = false;
     if (mE > in0) {                                 /* entered before its own turn */
         cur = mE; h0 = hE; entered = true; in_list = true; my_turn = firstE;
     }
     else if (is_active) {
-        if (bests[v] >= th) { in_list = true; selfemit[node_base[t] + i] = 1; atomicAdd(&cnt[node_base[t] + i], 1); }
+        if (bests[NSV(v)] >= th) { in_list = true; selfemit[node_base[t] + i] = 1; atomicAdd(&cnt[node_base[t] + i], 1); }
         else { cleared = true; cur = WORST; h0 = -1; }
     }
     if (mL > cur) {                                 /* (re-)entered after its own turn */
@@ -197,11 +197,11 @@ k_lt_prop_resolve(const int32_t *__restrict__ node_base, const int32_t *__restri
         }
     }
     if (cleared) {
-        sc[1 * N + v] = WORST; sc[2 * N + v] = WORST;
-        hist[1 * N + v] = -1; hist[2 * N + v] = -1;
-        outs[v] = WORST; outh[v] = -1; bests[v] = WORST;
+        sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
+        hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
+        outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
     }
-    if (cleared || entered) { sc[v] = cur; hist[v] = h0; }
+    if (cleared || entered) { sc[NSV(v)] = cur; hist[NSV(v)] = h0; }
     frame[v] = in_list ? nf : (cleared ? -1 : frame[v]);
     if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[node_base[t] + my_turn], 1); }
 }
@@ -255,19 +255,19 @@ k_lt_leaves(const int32_t *__restrict__ node_base, const int32_t *__restrict__ a
     const int32_t wth = thr[2];
     for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
         const int32_t u = act[b + i];
-        flag[b + i] = (wid[u] >= 0 && outs[u] >= wth) ? 1 : 0;
+        flag[b + i] = (wid[u] >= 0 && outs[NSV(u)] >= wth) ? 1 : 0;
     }
     __syncthreads();
     block_exclusive_scan(flag + b, na, &total);
     __syncthreads();
     for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS) {
         const int32_t u = act[b + i];
-        if (wid[u] >= 0 && outs[u] >= wth) {
+        if (wid[u] >= 0 && outs[NSV(u)] >= wth) {
             const int32_t k = b + flag[b + i];
             exits[k] = wid[u];
-            exits[N + k] = add32(outs[u], -prob[u]);
-            exits[2 * N + k] = outh[u];
-            if (outh[u] == -1) atomicExch(&nexit[n_tree + t], 1);   /* "out.history==-1, error" */
+            exits[N + k] = add32(outs[NSV(u)], -prob[u]);
+            exits[2 * N + k] = outh[NSV(u)];
+            if (outh[NSV(u)] == -1) atomicExch(&nexit[n_tree + t], 1);   /* "out.history==-1, error" */
         }
     }
     __syncthreads();
@@ -373,7 +373,7 @@ k_lt_enter_pass1(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *
     if (e >= n_ent) return;
     const int32_t v = ent[2 * e], c = ent[2 * e + 1];
     const int32_t scr = add32(calls[2 * c], prob[v]);
-    if (scr < thresh || !(sc[v] < scr)) return;
+    if (scr < thresh || !(sc[NSV(v)] < scr)) return;
     /* larger score wins; among equal scores the earlier call wins (strict '<' in the reference) */
     atomicMax(&key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
     atomicMin(&first[v], c);
@@ -390,7 +390,7 @@ k_lt_enter_pass2(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *
     for (int32_t e = threadIdx.x; e < n_ent; e += SCAN_THREADS) {
         const int32_t v = ent[2 * e], c = ent[2 * e + 1];
         const int32_t scr = add32(calls[2 * c], prob[v]);
-        flag[e] = (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
+        flag[e] = (scr >= thresh && sc[NSV(v)] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
     }
     __syncthreads();
     block_exclusive_scan(flag, n_ent, &total);
@@ -399,7 +399,7 @@ k_lt_enter_pass2(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *
     for (int32_t e = threadIdx.x; e < n_ent; e += SCAN_THREADS) {
         const int32_t v = ent[2 * e], c = ent[2 * e + 1];
         const int32_t scr = add32(calls[2 * c], prob[v]);
-        if (scr >= thresh && sc[v] < scr && first[v] == c && frame[v] != nf) {
+        if (scr >= thresh && sc[NSV(v)] < scr && first[v] == c && frame[v] != nf) {
             const int32_t k = n0 + flag[e];
             nxt[b + k] = v; pos[v] = k; posf[v] = nf;
         }
@@ -423,7 +423,7 @@ k_lt_enter_pass3(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *
     const int32_t win_s = (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u);
     /* every entry of v sees the same key; only the winner's thread writes.  The
      * in-score read in passes 1-2 is the ORIGINAL one, so writing here is safe */
-    if (c == win_c) { sc[v] = win_s; hist[v] = calls[2 * c + 1]; }
+    if (c == win_c) { sc[NSV(v)] = win_s; hist[NSV(v)] = calls[2 * c + 1]; }
     if (c == first[v]) frame[v] = nf;
     (void)prob; (void)thresh;
 }
@@ -463,8 +463,19 @@ k_lt_utt_end(const int32_t *__restrict__ node_base, const int32_t *__restrict__ 
     const int32_t t = blockIdx.y, i = blockIdx.x * LT_BLOCK + threadIdx.x;
     if (i >= nact[t]) return;
     const int32_t v = act[node_base[t] + i];
-    for (int st = 0; st < 3; st++) { sc[st * N + v] = WORST; hist[st * N + v] = -1; }
-    outs[v] = WORST; outh[v] = -1; bests[v] = WORST; frame[v] = -1;
+    for (int st = 0; st < 3; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
+    outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST; frame[v] = -1;
+}
+
+/* every node record: inactive HMM (hmm_clear) */
+__global__ void __launch_bounds__(LT_BLOCK)
+k_lt_reset_nodes(int32_t *sc, int32_t N)
+{
+    const int32_t v = blockIdx.x * LT_BLOCK + threadIdx.x;
+    if (v >= N) return;
+    int32_t *r = sc + NSV(v);
+    r[0] = WORST; r[1] = WORST; r[2] = WORST; r[3] = -1; r[4] = -1; r[5] = -1;
+    r[NS_OFF_OUTS] = WORST; r[NS_OFF_OUTH] = -1; r[NS_OFF_BESTS] = WORST;
 }
 
 __global__ void
@@ -493,9 +504,10 @@ static int32_t
 alloc_state(s3a_lexsearch_t *ls)
 {
     const int32_t N = ls->N, n_tree = ls->n_tree;
-    DMALLOC(ls->d_sc, (size_t)3 * N * 4); DMALLOC(ls->d_hist, (size_t)3 * N * 4);
-    DMALLOC(ls->d_outs, (size_t)N * 4); DMALLOC(ls->d_outh, (size_t)N * 4);
-    DMALLOC(ls->d_bests, (size_t)N * 4); DMALLOC(ls->d_frame, (size_t)N * 4);
+    DMALLOC(ls->d_sc, (size_t)NST * (N > 0 ? N : 1) * 4);      /* the node records (s3a_structs.h); the rest point into them */
+    ls->d_hist = ls->d_sc + NS_OFF_HIST; ls->d_outs = ls->d_sc + NS_OFF_OUTS; ls->d_outh = ls->d_sc + NS_OFF_OUTH;
+    ls->d_bests = ls->d_sc + NS_OFF_BESTS;
+    DMALLOC(ls->d_frame, (size_t)N * 4);
     DMALLOC(ls->d_pos, (size_t)N * 4); DMALLOC(ls->d_posf, (size_t)N * 4);
     DMALLOC(ls->d_act[0], (size_t)N * 4); DMALLOC(ls->d_act[1], (size_t)N * 4);
     DMALLOC(ls->d_nact[0], (size_t)n_tree * 4); DMALLOC(ls->d_nact[1], (size_t)n_tree * 4);
@@ -755,7 +767,7 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
     int32_t **statics[] = { &ls->d_node_base, &ls->d_ssid, &ls->d_tmatid, &ls->d_wid, &ls->d_prob,
         &ls->d_child_off, &ls->d_child, &ls->d_par_off, &ls->d_par, &ls->d_rootlist, &ls->d_tp,
         &ls->d_comstate_off, &ls->d_tree_of, &ls->d_rootnodes, &ls->d_ps, &ls->d_psof_off, &ls->d_psof };
-    int32_t **state[] = { &ls->d_sc, &ls->d_hist, &ls->d_outs, &ls->d_outh, &ls->d_bests,
+    int32_t **state[] = { &ls->d_sc,            /* (d_hist, d_outs, d_outh, d_bests point into d_sc's records) */
         &ls->d_frame, &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
@@ -782,9 +794,8 @@ extern "C" int32_t
 s3a_lexsearch_reset(s3a_lexsearch_t *ls)
 {
     int32_t rc, N = ls->N;
-    if ((rc = fill(ls, ls->d_sc, WORST, 3 * N)) || (rc = fill(ls, ls->d_hist, -1, 3 * N))
-        || (rc = fill(ls, ls->d_outs, WORST, N)) || (rc = fill(ls, ls->d_outh, -1, N))
-        || (rc = fill(ls, ls->d_bests, WORST, N)) || (rc = fill(ls, ls->d_frame, -1, N))
+    hipLaunchKernelGGL(k_lt_reset_nodes, dim3((unsigned)((N + LT_BLOCK - 1) / LT_BLOCK)), dim3(LT_BLOCK), 0, ls->stream, ls->d_sc, N);
+    if ((rc = fill(ls, ls->d_frame, -1, N))
         || (rc = fill(ls, ls->d_pos, -1, N)) || (rc = fill(ls, ls->d_posf, INT_MIN, N))
         || (rc = fill(ls, ls->d_candf, INT_MIN, N)) || (rc = fill(ls, ls->d_pstamp, INT_MIN, ls->n_pset > 0 ? ls->n_pset : 1))
         || (rc = fill(ls, ls->d_turn, -1, N))
@@ -1122,13 +1133,21 @@ s3a_lexsearch_get_hmm(const s3a_lexsearch_t *ls, int32_t tree, int32_t *score, i
     if (!ls || tree < 0 || tree >= ls->n_tree) return S3A_EINVAL;
     const int32_t b = ls->node_base[tree], n = ls->node_base[tree + 1] - b, N = ls->N;
     HIPCHK(hipStreamSynchronize(ls->stream));
-    for (int st = 0; st < 3; st++) {
-        if (score) HIPCHK(hipMemcpy(score + (size_t)st * n, ls->d_sc + (size_t)st * N + b, (size_t)n * 4, hipMemcpyDeviceToHost));
-        if (hist) HIPCHK(hipMemcpy(hist + (size_t)st * n, ls->d_hist + (size_t)st * N + b, (size_t)n * 4, hipMemcpyDeviceToHost));
+    {   /* the tree's node records, taken apart on the host */
+        std::vector<int32_t> rec((size_t)NST * (n > 0 ? n : 1));
+        (void)N;
+        HIPCHK(hipMemcpy(rec.data(), ls->d_sc + NSV(b), (size_t)NST * n * 4, hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < n; i++) {
+            const int32_t *r = rec.data() + (size_t)i * NST;
+            for (int st = 0; st < 3; st++) {
+                if (score) score[(size_t)st * n + i] = r[st];
+                if (hist) hist[(size_t)st * n + i] = r[NS_OFF_HIST + st];
+            }
+            if (out_score) out_score[i] = r[NS_OFF_OUTS];
+            if (out_hist) out_hist[i] = r[NS_OFF_OUTH];
+            if (bestscore) bestscore[i] = r[NS_OFF_BESTS];
+        }
     }
-    if (out_score) HIPCHK(hipMemcpy(out_score, ls->d_outs + b, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (out_hist) HIPCHK(hipMemcpy(out_hist, ls->d_outh + b, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (bestscore) HIPCHK(hipMemcpy(bestscore, ls->d_bests + b, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (frame) HIPCHK(hipMemcpy(frame, ls->d_frame + b, (size_t)n * 4, hipMemcpyDeviceToHost));
     return S3A_OK;
 }

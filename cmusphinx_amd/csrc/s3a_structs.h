@@ -34,6 +34,21 @@ struct s3a_scorer_s {
 };
 
 
+/*
+ * The search state of a lextree node is ONE 64-byte record: the three state scores, their histories, the exit score and
+ * history, the HMM's best score (an HMM evaluation touched 17 cache lines of nine node-indexed arrays for it; now one
+ * or two).  The kernels keep their five pointers -- sc, hist, outs, outh, bests = the record's fields at node 0 -- and
+ * index them with NSI (state st of node v) / NSV (a per-node field of v).  The list stamp (posf) and the other per-node
+ * words that sweeps read for ALL nodes stay arrays of their own.
+ */
+#define NST 16                                  /* int32 words per node record */
+#define NSI(st, N, v) ((size_t)(v) * NST + (st))
+#define NSV(v) ((size_t)(v) * NST)
+#define NS_OFF_HIST 3
+#define NS_OFF_OUTS 6
+#define NS_OFF_OUTH 7
+#define NS_OFF_BESTS 8
+
 struct s3a_comsen_s {
     int32_t n_comstate, n_list;
     int32_t *off_d, *wt_d, *out_d, *scr_d;

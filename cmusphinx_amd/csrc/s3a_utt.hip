@@ -117,7 +117,7 @@ ku_enter1(const ULane *__restrict__ lanes, UShared S, int32_t f)
         const int32_t scr = add32(s_in[c], S.rootprob[idx]);
         if (scr < thresh) continue;
         const int32_t v = S.rootlist[idx];
-        if (!(L.sc[v] < scr)) continue;
+        if (!(L.sc[NSV(v)] < scr)) continue;
         atomicMax(&L.key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
         atomicMin(&L.first[v], c);
     }
