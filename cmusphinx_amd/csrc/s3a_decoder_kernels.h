@@ -455,13 +455,13 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
     if (is_active && !has_par) {
         /* no parent can enter v (the usual active HMM): it survives or is cleared at its own turn -- one gather */
         const int32_t j = j_known >= 0 ? j_known : pos[v], b = b_known >= 0 ? b_known : node_base[tree_of[v]];
-        if (bests[NSV(v)] >= th) { selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); frame[v] = nf; }
+        if (bests[NSV(v)] >= th) { selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); frame[NSV(v)] = nf; }
         else {
             sc[NSV(v)] = WORST; sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
             hist[NSV(v)] = -1; hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
             outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
             posout[b + j] = WORST;
-            frame[v] = -1;
+            frame[NSV(v)] = -1;
         }
         return;
     }
@@ -525,7 +525,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
         posout[b + j] = WORST;                  /* k_dec_scan reads the exit scores by list position */
     }
     if (cleared || entered) { sc[NSV(v)] = cur; hist[NSV(v)] = h0; }
-    frame[v] = in_list ? nf : (cleared ? -1 : frame[v]);
+    frame[NSV(v)] = in_list ? nf : (cleared ? -1 : frame[NSV(v)]);
     if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[b + my_turn], 1); }
 }
 
@@ -1279,7 +1279,7 @@ d_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
             const int32_t scr = add32(in, ent.root_prob(roots + i, prob));
             if (scr >= thresh) {
                 const int32_t v = ent.rootlist[roots + i];
-                q = (sc[NSV(v)] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
+                q = (sc[NSV(v)] < scr && first[v] == c && frame[NSV(v)] != nf) ? 1 : 0;
             }
         }
         const unsigned long long m = __ballot(q);
@@ -1351,7 +1351,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
         if (k == 0ull) return;
         const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(k & 0xffffffffu);
         if (c == win_c) { sc[NSV(v)] = (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); hist[NSV(v)] = calls[4 * c + 1]; }
-        if (c == first[v]) frame[v] = nf;
+        if (c == first[v]) frame[NSV(v)] = nf;
         return;
     }
     const int32_t bb = BX - n_ent_blocks;

@@ -202,7 +202,7 @@ k_lt_prop_resolve(const int32_t *__restrict__ node_base, const int32_t *__restri
         outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
     }
     if (cleared || entered) { sc[NSV(v)] = cur; hist[NSV(v)] = h0; }
-    frame[v] = in_list ? nf : (cleared ? -1 : frame[v]);
+    frame[NSV(v)] = in_list ? nf : (cleared ? -1 : frame[NSV(v)]);
     if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[node_base[t] + my_turn], 1); }
 }
 
@@ -390,7 +390,7 @@ k_lt_enter_pass2(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *
     for (int32_t e = threadIdx.x; e < n_ent; e += SCAN_THREADS) {
         const int32_t v = ent[2 * e], c = ent[2 * e + 1];
         const int32_t scr = add32(calls[2 * c], prob[v]);
-        flag[e] = (scr >= thresh && sc[NSV(v)] < scr && first[v] == c && frame[v] != nf) ? 1 : 0;
+        flag[e] = (scr >= thresh && sc[NSV(v)] < scr && first[v] == c && frame[NSV(v)] != nf) ? 1 : 0;
     }
     __syncthreads();
     block_exclusive_scan(flag, n_ent, &total);
@@ -399,7 +399,7 @@ k_lt_enter_pass2(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *
     for (int32_t e = threadIdx.x; e < n_ent; e += SCAN_THREADS) {
         const int32_t v = ent[2 * e], c = ent[2 * e + 1];
         const int32_t scr = add32(calls[2 * c], prob[v]);
-        if (scr >= thresh && sc[NSV(v)] < scr && first[v] == c && frame[v] != nf) {
+        if (scr >= thresh && sc[NSV(v)] < scr && first[v] == c && frame[NSV(v)] != nf) {
             const int32_t k = n0 + flag[e];
             nxt[b + k] = v; pos[v] = k; posf[v] = nf;
         }
@@ -424,7 +424,7 @@ k_lt_enter_pass3(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *
     /* every entry of v sees the same key; only the winner's thread writes.  The
      * in-score read in passes 1-2 is the ORIGINAL one, so writing here is safe */
     if (c == win_c) { sc[NSV(v)] = win_s; hist[NSV(v)] = calls[2 * c + 1]; }
-    if (c == first[v]) frame[v] = nf;
+    if (c == first[v]) frame[NSV(v)] = nf;
     (void)prob; (void)thresh;
 }
 
@@ -464,7 +464,7 @@ k_lt_utt_end(const int32_t *__restrict__ node_base, const int32_t *__restrict__ 
     if (i >= nact[t]) return;
     const int32_t v = act[node_base[t] + i];
     for (int st = 0; st < 3; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
-    outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST; frame[v] = -1;
+    outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST; frame[NSV(v)] = -1;
 }
 
 /* every node record: inactive HMM (hmm_clear) */
@@ -475,7 +475,7 @@ k_lt_reset_nodes(int32_t *sc, int32_t N)
     if (v >= N) return;
     int32_t *r = sc + NSV(v);
     r[0] = WORST; r[1] = WORST; r[2] = WORST; r[3] = -1; r[4] = -1; r[5] = -1;
-    r[NS_OFF_OUTS] = WORST; r[NS_OFF_OUTH] = -1; r[NS_OFF_BESTS] = WORST;
+    r[NS_OFF_OUTS] = WORST; r[NS_OFF_OUTH] = -1; r[NS_OFF_BESTS] = WORST; r[NS_OFF_FRAME] = -1;
 }
 
 __global__ void
@@ -506,8 +506,7 @@ alloc_state(s3a_lexsearch_t *ls)
     const int32_t N = ls->N, n_tree = ls->n_tree;
     DMALLOC(ls->d_sc, (size_t)NST * (N > 0 ? N : 1) * 4);      /* the node records (s3a_structs.h); the rest point into them */
     ls->d_hist = ls->d_sc + NS_OFF_HIST; ls->d_outs = ls->d_sc + NS_OFF_OUTS; ls->d_outh = ls->d_sc + NS_OFF_OUTH;
-    ls->d_bests = ls->d_sc + NS_OFF_BESTS;
-    DMALLOC(ls->d_frame, (size_t)N * 4);
+    ls->d_bests = ls->d_sc + NS_OFF_BESTS; ls->d_frame = ls->d_sc + NS_OFF_FRAME;
     DMALLOC(ls->d_pos, (size_t)N * 4); DMALLOC(ls->d_posf, (size_t)N * 4);
     DMALLOC(ls->d_act[0], (size_t)N * 4); DMALLOC(ls->d_act[1], (size_t)N * 4);
     DMALLOC(ls->d_nact[0], (size_t)n_tree * 4); DMALLOC(ls->d_nact[1], (size_t)n_tree * 4);
@@ -767,8 +766,8 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
     int32_t **statics[] = { &ls->d_node_base, &ls->d_ssid, &ls->d_tmatid, &ls->d_wid, &ls->d_prob,
         &ls->d_child_off, &ls->d_child, &ls->d_par_off, &ls->d_par, &ls->d_rootlist, &ls->d_tp,
         &ls->d_comstate_off, &ls->d_tree_of, &ls->d_rootnodes, &ls->d_ps, &ls->d_psof_off, &ls->d_psof };
-    int32_t **state[] = { &ls->d_sc,            /* (d_hist, d_outs, d_outh, d_bests point into d_sc's records) */
-        &ls->d_frame, &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
+    int32_t **state[] = { &ls->d_sc,            /* (d_hist, d_outs, d_outh, d_bests, d_frame point into d_sc's records) */
+        &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
         &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0, &ls->d_pstamp,
@@ -795,8 +794,7 @@ s3a_lexsearch_reset(s3a_lexsearch_t *ls)
 {
     int32_t rc, N = ls->N;
     hipLaunchKernelGGL(k_lt_reset_nodes, dim3((unsigned)((N + LT_BLOCK - 1) / LT_BLOCK)), dim3(LT_BLOCK), 0, ls->stream, ls->d_sc, N);
-    if ((rc = fill(ls, ls->d_frame, -1, N))
-        || (rc = fill(ls, ls->d_pos, -1, N)) || (rc = fill(ls, ls->d_posf, INT_MIN, N))
+    if ( (rc = fill(ls, ls->d_pos, -1, N)) || (rc = fill(ls, ls->d_posf, INT_MIN, N))
         || (rc = fill(ls, ls->d_candf, INT_MIN, N)) || (rc = fill(ls, ls->d_pstamp, INT_MIN, ls->n_pset > 0 ? ls->n_pset : 1))
         || (rc = fill(ls, ls->d_turn, -1, N))
         || (rc = fill(ls, ls->d_selfemit, 0, N)) || (rc = fill(ls, ls->d_cnt, 0, N))
@@ -1146,8 +1144,8 @@ s3a_lexsearch_get_hmm(const s3a_lexsearch_t *ls, int32_t tree, int32_t *score, i
             if (out_score) out_score[i] = r[NS_OFF_OUTS];
             if (out_hist) out_hist[i] = r[NS_OFF_OUTH];
             if (bestscore) bestscore[i] = r[NS_OFF_BESTS];
+            if (frame) frame[i] = r[NS_OFF_FRAME];
         }
     }
-    if (frame) HIPCHK(hipMemcpy(frame, ls->d_frame + b, (size_t)n * 4, hipMemcpyDeviceToHost));
     return S3A_OK;
 }

@@ -36,8 +36,8 @@ struct s3a_scorer_s {
 
 /*
  * The search state of a lextree node is ONE 64-byte record: the three state scores, their histories, the exit score and
- * history, the HMM's best score (an HMM evaluation touched 17 cache lines of nine node-indexed arrays for it; now one
- * or two).  The kernels keep their five pointers -- sc, hist, outs, outh, bests = the record's fields at node 0 -- and
+ * history, the HMM's best score, the frame it is listed for (an HMM evaluation touched 17 cache lines of nine node-indexed arrays for it; now one
+ * or two).  The kernels keep their pointers -- sc, hist, outs, outh, bests, frame = the record's fields at node 0 -- and
  * index them with NSI (state st of node v) / NSV (a per-node field of v).  The list stamp (posf) and the other per-node
  * words that sweeps read for ALL nodes stay arrays of their own.
  */
@@ -48,6 +48,7 @@ struct s3a_scorer_s {
 #define NS_OFF_OUTS 6
 #define NS_OFF_OUTH 7
 #define NS_OFF_BESTS 8
+#define NS_OFF_FRAME 9          /* the frame the HMM is listed for (hmm_frame) */
 
 struct s3a_comsen_s {
     int32_t n_comstate, n_list;
