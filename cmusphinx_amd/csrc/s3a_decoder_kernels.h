@@ -85,7 +85,7 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
                int32_t *best_out, int32_t cf, const int32_t *__restrict__ psof_off,
                const int32_t *__restrict__ psof, int32_t *pstamp,
                const int32_t *__restrict__ gpart, int32_t gpart_n, int32_t *poswid, int32_t *posout,
-        const int32_t BX, const int32_t BY, const int32_t *__restrict__ cs_val = NULL)
+        const int32_t BX, const int32_t BY, const int32_t *__restrict__ cs_val = NULL, const int4 *__restrict__ node4 = NULL)
 {
     __shared__ int32_t red[2][EB / 64];
     __shared__ int32_t s_gb[EB / 64];
@@ -103,7 +103,12 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
     for (int w = 0; w < EB / 64; w++) norm = max(norm, s_gb[w]);
     int32_t best = INT_MIN, wbest = INT_MIN;
     if (i < nact[t]) {
-        const int32_t v = act[node_base[t] + i], ss = ssid[v];
+        const int32_t v = act[node_base[t] + i];
+        /* the node's static words (senone-sequence id, transition matrix, word id, composite?): one 16-byte load when
+         * the caller keeps them packed (node4), else four arrays */
+        int4 nd;
+        if (node4) nd = node4[v]; else { nd.x = ssid[v]; nd.y = tmatid[v]; nd.z = wid[v]; nd.w = comp[v]; }
+        const int32_t ss = nd.x;
         HmmRegsT<int32_t> r;
         int32_t e[3];
         /* the HMM's own state first: these loads do not depend on the senone scores and stay in flight
@@ -114,20 +119,20 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         r.outh = outh[NSV(v)];
         int32_t tp[12];
         {
-            const int4 *tq = (const int4 *)(tp_g + tmatid[v] * 12);    /* 48-byte rows of a 16-byte aligned array */
+            const int4 *tq = (const int4 *)(tp_g + nd.y * 12);         /* 48-byte rows of a 16-byte aligned array */
             const int4 a = tq[0], bq = tq[1], cq = tq[2];
             tp[0] = a.x; tp[1] = a.y; tp[2] = a.z; tp[3] = a.w; tp[4] = bq.x; tp[5] = bq.y; tp[6] = bq.z; tp[7] = bq.w;
             tp[8] = cq.x; tp[9] = cq.y; tp[10] = cq.z; tp[11] = cq.w;
         }
-        const int32_t w = wid[v], q_lo = psof_off ? psof_off[v] : 0, q_hi = psof_off ? psof_off[v + 1] : 0;
-        if (comp[v] && cs_val) {                /* (the maxima were worked out once per composite senone: d_comsen_max) */
+        const int32_t w = nd.z, q_lo = psof_off ? psof_off[v] : 0, q_hi = psof_off ? psof_off[v + 1] : 0;
+        if (nd.w && cs_val) {                /* (the maxima were worked out once per composite senone: d_comsen_max) */
 #pragma unroll
             for (int st = 0; st < 3; st++) {
                 const int32_t cs = comsseq[ss * 3 + st];
                 e[st] = add32(add32(cs_val[cs], -norm), cs_wt[cs]);
             }
         }
-        else if (comp[v]) {
+        else if (nd.w) {
             /* composite senone = max over its member senones (dict2pid.c:1029-1048), up to one member
              * per context (~46): the three states' lists are walked together, 8 members each per round,
              * ids first and then scores, so a round is two round trips instead of 48 */

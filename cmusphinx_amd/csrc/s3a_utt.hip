@@ -58,6 +58,7 @@ struct UShared {
         *rootnodes, *ps, *psof_off, *psof, *cs_off, *cs_wt, *rootprob;
     const uint8_t *comp;
     const int16_t *sseq, *comsseq, *cs_list;
+    const int4 *node4;          /* per node: {ssid, tmatid, wid, composite}: ku_hmm_eval's static words as one load */
     const float4 *mean4, *prec4;
     const float *lrd;
     const int32_t *mixw;
@@ -415,7 +416,7 @@ ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t f)
         d_dec_hmm_eval<EB>(S.node_base, L.act[cur], L.nact[cur], S.N, S.n_tmat, S.ssid, S.tmatid, S.wid, S.comp, S.tp,
                            S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt, L.scr, L.misc, L.sc, L.hist, L.outs, L.outh,
                            L.bests, L.best, f, (const int32_t *)NULL /* ku_hist_count stamps */, S.psof, L.pstamp, L.gpart, S.gp_n, L.poswid, L.posout,
-                           vb, t, L.cs_val);
+                           vb, t, L.cs_val, S.node4);
         __syncthreads();
     }
 }
@@ -591,6 +592,14 @@ ku_wordlevel_only(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par)
     __syncthreads();
     d_wordlevel_frame(L.w, L.ctx, L.pack, s_hdr, nx <= WL_LDS_EX ? s_ex : (const int32_t *)NULL, lm, dict, par, L.ctx->cf,
                       (long long)wall_clock64());
+}
+
+__global__ void
+ku_pack_node4(const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid, const int32_t *__restrict__ wid,
+              const uint8_t *__restrict__ comp, int4 *out, int32_t N)
+{
+    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < N) out[v] = make_int4(ssid[v], tmatid[v], wid[v], (int32_t)comp[v]);
 }
 
 __global__ void
@@ -842,6 +851,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     }
     if (ud->d_lanes) (void)hipFree(ud->d_lanes);
     if (ud->S.rootprob) (void)hipFree((void *)ud->S.rootprob);
+    if (ud->S.node4) (void)hipFree((void *)ud->S.node4);
     if (ud->S.ctx_all) (void)hipFree(ud->S.ctx_all);
     if (ud->S.nact_all) (void)hipFree(ud->S.nact_all);
     if (ud->d_lcmap) (void)hipFree(ud->d_lcmap);
@@ -901,6 +911,13 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     S.node_base = proto->d_node_base; S.ssid = proto->d_ssid; S.tmatid = proto->d_tmatid; S.wid = proto->d_wid;
     S.prob = proto->d_prob; S.child_off = proto->d_child_off; S.child = proto->d_child; S.par_off = proto->d_par_off;
     S.par = proto->d_par; S.tree_of = proto->d_tree_of; S.rootlist = proto->d_rootlist; S.tp = proto->d_tp;
+    {   /* the nodes' static words, packed */
+        int4 *n4 = NULL;
+        if (hipMalloc((void **)&n4, (size_t)(proto->N > 0 ? proto->N : 1) * sizeof(int4)) != hipSuccess) { s3a_set_error("s3a_uttdec_init: out of device memory"); goto fail; }
+        hipLaunchKernelGGL(ku_pack_node4, dim3((unsigned)((proto->N + 255) / 256)), dim3(256), 0, ud->stream, proto->d_ssid, proto->d_tmatid,
+                           proto->d_wid, proto->d_comp, n4, proto->N);
+        S.node4 = n4;
+    }
     {   /* the roots' look-ahead probabilities in root-list order (Entries::rootprob) */
         const size_t nr = proto->h_rootlist.size();
         int32_t *rp = NULL;
