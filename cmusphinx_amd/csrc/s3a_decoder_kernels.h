@@ -212,14 +212,20 @@ frame_thresholds_hb(const int32_t *best, int32_t T, const FrameBeams &bm, int32_
  * thresholds are final: k_dec_resolve then walks the parent lists of those nodes only (a few hundred instead of
  * every child of every active HMM, each with up to ~46 parents).  A lane per list position i of tree t.
  */
+/* the stamp of frame cf in a stamp array of type PS: the frame number itself, or (8-bit stamps) cf mod 255 -- 255 is
+ * "never stamped" */
+template <typename PS> __device__ __forceinline__ PS ps_val(int32_t cf) { return (PS)cf; }
+template <> __device__ __forceinline__ uint8_t ps_val<uint8_t>(int32_t cf) { return (uint8_t)(cf % 255); }
+
+template <typename PS>
 __device__ __forceinline__ void
 d_dec_stamp(const int32_t *__restrict__ act, const int32_t *__restrict__ outs, const int32_t *__restrict__ psof_off,
-            const int32_t *__restrict__ psof, int32_t *pstamp, int32_t b, int32_t na, int32_t i, int32_t pth, int32_t cf)
+            const int32_t *__restrict__ psof, PS *pstamp, int32_t b, int32_t na, int32_t i, int32_t pth, int32_t cf)
 {
     if (i >= na) return;
     const int32_t u = act[b + i];
     if (outs[NSV(u)] < pth) return;
-    for (int32_t q = psof_off[u], q_hi = psof_off[u + 1]; q < q_hi; q++) pstamp[psof[q]] = cf;
+    for (int32_t q = psof_off[u], q_hi = psof_off[u + 1]; q < q_hi; q++) pstamp[psof[q]] = ps_val<PS>(cf);
 }
 
 /* ------------------------------------------------------------------ */
@@ -436,7 +442,10 @@ d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
  * without a propagating parent fall through after two loads.  Also resets the root-entry
  * scratch (key / first) for this frame's transitions.
  */
-/* what happens to node v (active, or with an active parent) in this frame: the rule of s3a_lextree.hip */
+/* what happens to node v (active, or with an active parent) in this frame: the rule of s3a_lextree.hip.
+ * (PS = the type of the parent sets' stamps: int32 frame numbers, or their low 8 bits in the whole-utterance engine --
+ * a stale stamp that happens to match only costs a parent walk that finds nothing) */
+template <typename PS>
 __device__ __forceinline__ void
 d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
               const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
@@ -446,7 +455,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
               int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
               int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
               unsigned long long *key, int32_t *first, int32_t *hbin,
-              const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
+              const int32_t *__restrict__ ps, const PS *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout,
         const int32_t v, const bool is_active, const bool has_par, const int32_t j_known = -1, const int32_t b_known = -1)
@@ -534,6 +543,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
     if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[b + my_turn], 1); }
 }
 
+template <typename PS>
 __device__ __forceinline__ void
 d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
               const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
@@ -543,7 +553,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
               int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
               unsigned long long *key, int32_t *first, int32_t *hbin,
-              const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
+              const int32_t *__restrict__ ps, const PS *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout,
         const int32_t BX, const int32_t BY)
@@ -564,7 +574,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
     }
     const bool is_active = posf[v] == cf;
     const int32_t q = ps[v];
-    const bool has_par = q >= 0 && pstamp[q] == cf;     /* some parent may enter v (its parent set is stamped) */
+    const bool has_par = q >= 0 && pstamp[q] == ps_val<PS>(cf); /* some parent may enter v (its parent set is stamped) */
     if (!is_active && !has_par) return;                 /* nothing can happen to v */
     d_dec_resolve_node(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout, v, is_active, has_par);
 }
@@ -578,7 +588,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
  *     thread, N/K apart (static parent-set id -> the set's stamp: two trips to the early exit, K times fewer waves);
  *     the wave's candidates -- siblings, so they come in runs -- are compacted through LDS and handled 64 at a time.
  */
-template <int K>
+template <int K, typename PS>
 __device__ __forceinline__ void
 d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
               const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
@@ -588,7 +598,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
               int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
               int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
               unsigned long long *key, int32_t *first, int32_t *hbin,
-              const int32_t *__restrict__ ps, const int32_t *__restrict__ pstamp,
+              const int32_t *__restrict__ ps, const PS *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout, const int32_t *__restrict__ act,
         const int32_t BX, const int32_t GA, const int32_t GB)
@@ -616,7 +626,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
                 const int32_t i = (w - w0) * RSBLOCK + threadIdx.x;
                 if (i < na) {
                     const int32_t v = act[b + i], q = ps[v];
-                    d_dec_resolve_node(RS_ARGS, v, true, q >= 0 && pstamp[q] == cf, i, b);
+                    d_dec_resolve_node(RS_ARGS, v, true, q >= 0 && pstamp[q] == ps_val<PS>(cf), i, b);
                 }
             }
             w0 += nw;
@@ -624,16 +634,17 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
         return;
     }
     const int32_t stride = GB * RSBLOCK, v0 = (BX - GA) * RSBLOCK + threadIdx.x;
-    int32_t q[K], st[K];
+    int32_t q[K];
+    PS st[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { const int32_t v = v0 + k * stride; q[k] = v < N ? ps[v] : -1; }
 #pragma unroll
-    for (int k = 0; k < K; k++) st[k] = q[k] >= 0 ? pstamp[q[k]] : cf - 1;
+    for (int k = 0; k < K; k++) st[k] = q[k] >= 0 ? pstamp[q[k]] : (PS)(ps_val<PS>(cf) + 1);
     __shared__ int32_t s_cand[64 * K];
     int32_t total = 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const bool c = st[k] == cf;
+        const bool c = st[k] == ps_val<PS>(cf);
         const unsigned long long m = __ballot(c);
         if (c) s_cand[total + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = v0 + k * stride;
         total += __popcll(m);

@@ -44,6 +44,8 @@ struct ULane {
     uint8_t *sen_act;
     int32_t *scr, *misc, *bstidx, *bstscr, *updatetime, *gpart;
     int32_t *cs_need, *cs_val;  /* [n_cs] composite senones: wanted in frame (stamp) | score of the frame */
+    uint8_t *pstamp8;           /* [n_pset] the parent sets' stamps, the frame number's low 8 bits (a quarter of the
+                                 * sweep's gathers' footprint; a stale match costs a walk that finds nothing) */
     int32_t *dynbeam;           /* [1] the frame's CI beam when -maxcdsenpf is in force (ku_dyn_ci_beam) */
     /* this utterance */
     UCtx *ctx;
@@ -53,7 +55,7 @@ struct ULane {
 
 /* what every lane shares */
 struct UShared {
-    int32_t N, T, n_tmat, maxn, n_rootnodes, scan_chunks, pack_max_exits, gp_n, n_cs;
+    int32_t N, T, n_tmat, maxn, n_rootnodes, scan_chunks, pack_max_exits, gp_n, n_cs, n_pset_bytes;
     const int32_t *node_base, *ssid, *tmatid, *wid, *prob, *child_off, *child, *par_off, *par, *tree_of, *rootlist, *tp,
         *rootnodes, *ps, *psof_off, *psof, *cs_off, *cs_wt, *rootprob;
     const uint8_t *comp;
@@ -444,7 +446,7 @@ ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t f)
     frame_thresholds_hb(L.best, S.T, bm, 1, th, pth);
     const int32_t b = S.node_base[t];
     for (int32_t i = blockIdx.x * DBLOCK + threadIdx.x; i < na; i += gridDim.x * DBLOCK)
-        d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp, b, na, i, pth, f);
+        d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp8, b, na, i, pth, f);
 }
 
 /* the histogram beam + the reordering of the lists (frames over 1.5 x -maxhmmpf only), then the stamps of such a frame */
@@ -460,7 +462,7 @@ ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t f)
     frame_thresholds_hb(L.best, S.T, bm, hb, th, pth);
     const int32_t t = blockIdx.x, na = nact_cur[t], b = S.node_base[t];
     for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS)
-        d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp, b, na, i, pth, f);
+        d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp8, b, na, i, pth, f);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -480,7 +482,7 @@ ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
     LANE;
     d_dec_resolve(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
-                  L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
+                  L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
                   blockIdx.x, 0);
 }
 
@@ -493,7 +495,7 @@ ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t f)
     const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
     d_dec_resolve_utt<UR_K>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
-                  L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
+                  L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
                   L.act[cur], blockIdx.x, (int32_t)gridDim.x - GB, GB);
 }
 
@@ -837,6 +839,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.d.cs_need) (void)hipFree(hl.d.cs_need);
         if (hl.d.cs_val) (void)hipFree(hl.d.cs_val);
         if (hl.d.dynbeam) (void)hipFree(hl.d.dynbeam);
+        if (hl.d.pstamp8) (void)hipFree(hl.d.pstamp8);
         if (hl.ls && ud->S.nact_all && hl.ls->d_nact[0] >= ud->S.nact_all
             && hl.ls->d_nact[0] < ud->S.nact_all + (size_t)ud->n_lanes * 2 * WL_MAXT)
             hl.ls->d_nact[0] = hl.ls->d_nact[1] = NULL;     /* borrowed from nact_all */
@@ -1050,7 +1053,8 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         u.scan_flag = ls->d_scan_flag; u.scan_agg = ls->d_scan_agg; u.scan_pre = ls->d_scan_pre; u.key = ls->d_key;
         u.sen_act = hl.sc->act_d; u.scr = hl.sc->scr_d; u.misc = hl.sc->misc_d; u.bstidx = hl.sc->bstidx_d;
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
-        DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4); DM(u.dynbeam, 16);
+        DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4); DM(u.dynbeam, 16); DM(u.pstamp8, (size_t)proto->n_pset + 64); S.n_pset_bytes = proto->n_pset + 64;
+        if (hipMemset(u.pstamp8, 0xff, (size_t)proto->n_pset + 64) != hipSuccess) goto fail;
         if (fill32(ud->stream, u.cs_need, -1, (size_t)cs->n_comstate + 1) != S3A_OK) goto fail;
         u.ctx = ud->S.ctx_all + z;
         DM(u.pack, (size_t)(6 * T + 16 + 3 * proto->pack_max_exits) * 4);
@@ -1132,6 +1136,7 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     hl.ls->cur = 0;
     if ((rc = s3a_decoder_utt_begin(hl.ls, hl.sc)) != S3A_OK) return rc;
     if ((rc = fill32(ud->stream, hl.d.cs_need, -1, (size_t)ud->S.n_cs + 1)) != S3A_OK) return rc;   /* (frame stamps restart) */
+    HIPCHK(hipMemsetAsync(hl.d.pstamp8, 0xff, (size_t)ud->S.n_pset_bytes, ud->stream));
     /* history: entry 0 (vithist_utt_begin, vithist.c:300-335) */
     {
         int32_t e0[10] = { 0 /*score*/, -1 /*pred*/, c.start_lwid, -1 /*lw1*/, c.startwid, -1 /*sf*/, -1 /*ef*/, 0, 0, 0 };
