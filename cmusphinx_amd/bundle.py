@@ -33,7 +33,11 @@ def read(path):
     raw = np.fromfile(path, dtype="<i4")
     pos, b, trees = 0, {}, []
     while pos < len(raw):
+        if pos + 2 > len(raw):
+            raise ValueError(f"{path}: truncated bundle (record header at word {pos})")
         tag, n = int(raw[pos]), int(raw[pos + 1])
+        if n < 0 or pos + 2 + n > len(raw):
+            raise ValueError(f"{path}: truncated bundle (record {tag} wants {n} words at word {pos})")
         d = raw[pos + 2: pos + 2 + n].copy()
         pos += 2 + n
         if tag == 1:
