@@ -133,6 +133,21 @@ def test_wsj_stress_shape_32_components(gpu_lib, olm):
         assert np.array_equal(gm.score_frames(fx[[k]], want_best=False)[0], sc[k]), k
 
 
+def test_wsj_stress_shape_at_full_size(gpu_lib, olm):
+    """configs[4] at its full size: 8000 senones x 32 Gaussians x 39 (82 MB of parameters): ten frames against the oracle,
+    through the many-frames kernel and one frame per launch (k_score_frame_sync)."""
+    m = synth.make_model(**synth.WSJ_STRESS)
+    assert m["mean"].shape[0] == 8000 and m["mean"].shape[1] == 32
+    fx = synth.make_features(m, 10, seed=5)
+    gm = gpu_lib.MgauModel.init_arrays(m["mean"], m["var"], m["mixw"], gpu_lib.LogMath(1.0003))
+    og = O.OracleMgau(m["mean"], m["var"], m["mixw"], olm)
+    exp = og.score_all(fx)
+    sc = gm.score_frames(fx, want_best=False)
+    assert sc.shape == (10, 8000) and np.array_equal(sc, exp)
+    for k in (0, 4, 9):
+        assert np.array_equal(gm.score_frames(fx[[k]], want_best=False)[0], exp[k]), k
+
+
 def test_fast_mode_within_stated_tolerance(gpu_lib, tid):
     g = golden("tidigits_mgau.npz")
     tid.set_precision(gpu_lib.GMM_FAST)
