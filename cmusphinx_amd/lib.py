@@ -1285,6 +1285,13 @@ class UttDec:
         k = self.L.s3a_uttdec_profile(self.h, us, n, names, 24)
         return {names[i].decode(): (us[i], n[i]) for i in range(k) if n[i]}
 
+    def wl_ticks(self, lane=0):
+        """time lane's last utterance spent in the phases of the one-workgroup word level, in microseconds:
+        [record + exits, P1, P2, P3, P4, P5, pruning, table + LM contexts, word transitions]"""
+        t = (C.c_longlong * 16)()
+        check(self.L.s3a_uttdec_wl_ticks(self.h, int(lane), t), self.L)
+        return [0.01 * t[i] for i in range(9)]
+
     def hyp(self, lane, uttid="", utt_index=0):
         rec = HypRecord()
         check(self.L.s3a_uttdec_hyp(self.h, lane, uttid.encode(), int(utt_index), C.byref(rec)), self.L)
