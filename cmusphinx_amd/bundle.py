@@ -106,6 +106,20 @@ class Decoder:
     def hyp(self, lane, uttid="", utt_index=0):
         return self.ud.hyp(lane, uttid, utt_index)
 
+    def hyp_var(self, lane, uttid="", utt_index=0):
+        return self.ud.hyp_var(lane, uttid, utt_index)
+
+    def format_var(self, hdr, words):
+        """the same from a header + words pair (no word limit)"""
+        L = lib.load()
+        words = np.ascontiguousarray(words, np.int32)
+        cap = (1 << 16) + 64 * len(words)
+        m, s = C.create_string_buffer(cap), C.create_string_buffer(cap)
+        lib.check(L.s3a_hyp_format_var(C.byref(hdr), lib._p(words), self._wordstr, lib._p(self._basewid), lib._p(self._isfill),
+                                       self.b["startwid"], self.b["finishwid"], np.float32(self.b["lw"]), int(self.b["wip"]),
+                                       self.b["hypsegscore_unscale"], m, len(m), s, len(s)), L)
+        return m.value.decode(), s.value.decode()
+
     def format(self, rec):
         """-> (the utterance's -hyp line, its -hypseg line)"""
         L = lib.load()

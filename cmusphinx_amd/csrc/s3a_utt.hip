@@ -772,6 +772,7 @@ struct s3a_uttdec_s {
     double prof_us[24];
     int64_t prof_n[24];
     int32_t big_wl;             /* the word level's candidate phases as their own launches (wide beams) */
+    hipEvent_t ev0, ev1;        /* around the frames of a decode (last_decode_ms) */
 };
 
 static int32_t
@@ -852,6 +853,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.sc) s3a_scorer_free(hl.sc);
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
+    if (ud->ev0) (void)hipEventDestroy(ud->ev0);
+    if (ud->ev1) (void)hipEventDestroy(ud->ev1);
     if (ud->d_lanes) (void)hipFree(ud->d_lanes);
     if (ud->S.rootprob) (void)hipFree((void *)ud->S.rootprob);
     if (ud->S.node4) (void)hipFree((void *)ud->S.node4);
@@ -893,7 +896,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
     ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
-    ud->device = 0;
+    ud->device = 0; ud->ev0 = ud->ev1 = NULL;
     (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
@@ -960,8 +963,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     ud->big_wl = getenv("S3A_UTT_BIGWL") ? atoi(getenv("S3A_UTT_BIGWL")) != 0 : (cfg->maxhmmpf >= 50000 && maxn >= 50000);
     if (ud->hist_possible && -cfg->hmmbeam / NBIN == 0) {
         s3a_set_error("s3a_uttdec_init: -beam too narrow for histogram pruning (bin width 0)");
-        delete ud;
-        return NULL;
+        goto fail;
     }
 
     /* dictionary facts + root lists per (tree, left context) */
@@ -974,8 +976,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     for (int32_t w = 0; w < cfg->n_word; w++)
         if (cfg->last_ci[w] < 0 || cfg->last_ci[w] >= cfg->n_ci || (cfg->lwid[w] >= lm->d.n_ug)) {
             s3a_set_error("s3a_uttdec_init: dictionary word %d has a bad final phone / LM id", w);
-            delete ud;
-            return NULL;
+            goto fail;
         }
     ud->h_lcmap.assign((size_t)T * (cfg->n_ci + 1) * 2, -1);
     for (int32_t t = 0; t < T; t++) {
@@ -1305,32 +1306,43 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
         if ((rc = lane_begin(ud, z, feat[z], n_frames[z], feat_stride, feat_on_device)) != S3A_OK) return rc;
         maxT = max(maxT, n_frames[z]);
     }
-    hipEvent_t e0, e1;
-    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventRecord(e0, ud->stream));
-    for (int32_t f = 0; f < maxT; f++)
-        if ((rc = enqueue_frame(ud, n_utt, f, ud->prof_every > 0 && f % ud->prof_every == 0)) != S3A_OK) return rc;
-    HIPCHK(hipEventRecord(e1, ud->stream));
-    for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_state(ud, z)) != S3A_OK) return rc;
-    HIPCHK(hipStreamSynchronize(ud->stream));
-    {
+    /* (the engine's two timing events live as long as the engine; the per-launch events of profiled frames are destroyed
+     * on every way out) */
+    if (!ud->ev0 && (hipEventCreate(&ud->ev0) != hipSuccess || hipEventCreate(&ud->ev1) != hipSuccess)) {
+        s3a_set_error("s3a_uttdec_decode: hipEventCreate failed");
+        return S3A_EHIP;
+    }
+    rc = S3A_OK;
+    if (hipEventRecord(ud->ev0, ud->stream) != hipSuccess) rc = S3A_EHIP;
+    for (int32_t f = 0; f < maxT && rc == S3A_OK; f++)
+        rc = enqueue_frame(ud, n_utt, f, ud->prof_every > 0 && f % ud->prof_every == 0);
+    if (rc == S3A_OK && hipEventRecord(ud->ev1, ud->stream) != hipSuccess) rc = S3A_EHIP;
+    for (int32_t z = 0; z < n_utt && rc == S3A_OK; z++) rc = lane_fetch_state(ud, z);
+    if (hipStreamSynchronize(ud->stream) != hipSuccess && rc == S3A_OK) { s3a_set_error("s3a_uttdec_decode: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
+    if (rc == S3A_OK) {
         float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, ud->ev0, ud->ev1);
         ud->last_decode_ms = ms;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     for (auto &e : ud->prof_ev) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ud->prof_us[e.cls] += 1e3 * ms; ud->prof_n[e.cls]++; }
+        if (rc == S3A_OK && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ud->prof_us[e.cls] += 1e3 * ms; ud->prof_n[e.cls]++; }
         (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
     }
     ud->prof_ev.clear();
+    if (rc != S3A_OK) {
+        for (int32_t z = 0; z < n_utt; z++) ud->lane[z].dirty = 1;      /* nothing is known about the lanes' state */
+        return rc;
+    }
     for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_table(ud, z)) != S3A_OK) return rc;
     HIPCHK(hipStreamSynchronize(ud->stream));
     ud->n_utt = n_utt;
+    /* EVERY lane that stopped in mid-frame starts its next utterance from scratch (a capacity overflow usually hits several
+     * lanes of a batch); then the first one is reported */
+    for (int32_t z = 0; z < n_utt; z++)
+        if (ud->lane[z].h_ctx->err) ud->lane[z].dirty = 1;
     for (int32_t z = 0; z < n_utt; z++) {
         const int32_t e = ud->lane[z].h_ctx->err;
-        if (e) ud->lane[z].dirty = 1;
         if (e) {
             s3a_set_error("s3a_uttdec_decode: utterance %d stopped at frame %d: error bits 0x%x%s%s%s%s%s%s", z,
                           ud->lane[z].h_ctx->cf, e, (e & WL_E_OPEN_EXIT) ? " (out.history == -1 at a word exit)" : "",
@@ -1558,10 +1570,11 @@ s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int32_t *ou
  * entry the reference first adds a silence entry spanning the rest (vithist_rescore with the silence word) and
  * retries.  Then vithist_backtrace (vithist.c:1066-1100).  Nothing is written to the lane's table: the added
  * entries exist in the record only. */
-extern "C" int32_t
-s3a_uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index, s3a_hyp_record_t *rec)
+static int32_t
+uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index, s3a_hyp_header_t *rec,
+           s3a_hyp_word_t *words, int32_t max_words)
 {
-    if (!ud || !rec || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
+    if (!ud || !rec || lane < 0 || lane >= ud->n_utt || max_words < 0 || (max_words > 0 && !words)) return S3A_EINVAL;
     s3a_utt_result_t r;
     int32_t rc = s3a_uttdec_result(ud, lane, &r);
     if (rc != S3A_OK) return rc;
@@ -1600,20 +1613,21 @@ s3a_uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_in
     for (int32_t i = bestvh; i > 0; i = r.pred[i]) n++;
     const int32_t total = n + (have_sil ? 1 : 0) + 1;
     rec->n_words = total; rec->score = best; rec->exit_id = r.n_entry + (have_sil ? 1 : 0);
-    if (total > S3A_HYP_MAXW) { rec->status = -3; rec->n_words = 0; return S3A_OK; }
+    /* (more words than the caller has room for: status -3, n_words = what it takes) */
+    if (total > max_words) { rec->status = -3; return S3A_OK; }
     int32_t k = n - 1;
     for (int32_t i = bestvh; i > 0; i = r.pred[i], k--) {
-        s3a_hyp_word_t &w = rec->word[k];
+        s3a_hyp_word_t &w = words[k];
         w.wid = r.wid[i]; w.sf = r.sf[i]; w.ef = r.ef[i]; w.ascr = r.ascr[i]; w.lscr = r.lscr[i];
     }
     k = n;
-    if (have_sil) rec->word[k++] = silw;
+    if (have_sil) words[k++] = silw;
     {
-        s3a_hyp_word_t &w = rec->word[k];
+        s3a_hyp_word_t &w = words[k];
         w.wid = c.finishwid; w.sf = last_ef + 1; w.ef = r.n_frm; w.ascr = 0; w.lscr = h_add(best, -last_score);
     }
     for (int32_t q = 0; q < total; q++) {               /* compute_scale, srch_output.c:52-60 */
-        s3a_hyp_word_t &w = rec->word[q];
+        s3a_hyp_word_t &w = words[q];
         int32_t sc = 0;
         for (int32_t i = w.sf; i < w.ef && i < r.n_frames; i++) if (i >= 0) sc = h_add(sc, r.frame_stat[8 * i]);
         w.scale = sc;
@@ -1621,21 +1635,40 @@ s3a_uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_in
     return S3A_OK;
 }
 
+extern "C" int32_t
+s3a_uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index, s3a_hyp_record_t *rec)
+{
+    if (!rec) return S3A_EINVAL;
+    memset(rec, 0, sizeof *rec);
+    const int32_t rc = uttdec_hyp(ud, lane, uttid, utt_index, (s3a_hyp_header_t *)rec, rec->word, S3A_HYP_MAXW);
+    if (rc == S3A_OK && rec->status == -3) rec->n_words = 0;
+    return rc;
+}
+
+/* the same without the word limit: the header (what s3a_hyp_record_t begins with) + as many words as the hypothesis has.
+ * max_words too small (0 to ask): status -3, hdr->n_words = the number it takes, nothing written to words[] */
+extern "C" int32_t
+s3a_uttdec_hyp_var(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index, s3a_hyp_header_t *hdr,
+                   s3a_hyp_word_t *words, int32_t max_words)
+{
+    return uttdec_hyp(ud, lane, uttid, utt_index, hdr, words, max_words);
+}
+
 /* match_write / matchseg_write (libsearch/srch_output.c:74-161) for one record: the -hyp and -hypseg lines.
  * wordstr / basewid / is_filler by dictionary word id; lw, wip = lm_t.lw, lm_t.wip (lm_rawscore, lm.c:2171-2178). */
 extern "C" int32_t
-s3a_hyp_format(const s3a_hyp_record_t *rec, const char *const *wordstr, const int32_t *basewid, const uint8_t *is_filler,
-               int32_t startwid, int32_t finishwid, float lw, int32_t wip, int32_t unscale, char *match_line,
-               size_t match_cap, char *seg_line, size_t seg_cap)
+s3a_hyp_format_var(const s3a_hyp_header_t *rec, const s3a_hyp_word_t *words, const char *const *wordstr, const int32_t *basewid,
+                   const uint8_t *is_filler, int32_t startwid, int32_t finishwid, float lw, int32_t wip, int32_t unscale,
+                   char *match_line, size_t match_cap, char *seg_line, size_t seg_cap)
 {
-    if (!rec || !wordstr || !basewid || !is_filler || !match_line || !seg_line) return S3A_EINVAL;
+    if (!rec || !wordstr || !basewid || !is_filler || !match_line || !seg_line || (rec->n_words > 0 && !words)) return S3A_EINVAL;
     size_t mp = 0, sp = 0;
 #define APP(buf, pos, cap, ...) do { int w_ = snprintf((buf) + (pos), (pos) < (cap) ? (cap) - (pos) : 0, __VA_ARGS__); \
         if (w_ < 0 || (pos) + (size_t)w_ >= (cap)) return S3A_EINVAL; (pos) += (size_t)w_; } while (0)
     int counter = 0;
     if (rec->n_words == 0) APP(match_line, mp, match_cap, "(null)");
     for (int32_t q = 0; q < rec->n_words; q++) {
-        const s3a_hyp_word_t &w = rec->word[q];
+        const s3a_hyp_word_t &w = words[q];
         if (w.sf == w.ef) continue;
         if (!is_filler[w.wid] && w.wid != finishwid && w.wid != startwid) APP(match_line, mp, match_cap, "%s ", wordstr[basewid[w.wid]]);
         counter++;
@@ -1645,20 +1678,30 @@ s3a_hyp_format(const s3a_hyp_record_t *rec, const char *const *wordstr, const in
     int32_t ascr = 0, lscr = 0, gscale = 0;
     auto raw = [&](int32_t s) { s -= wip; float fs = (float)s; fs /= lw; return (int32_t)fs; };
     for (int32_t q = 0; q < rec->n_words; q++) {
-        const s3a_hyp_word_t &w = rec->word[q];
+        const s3a_hyp_word_t &w = words[q];
         if (w.sf == w.ef) continue;
         ascr += w.ascr; lscr += raw(w.lscr);
         if (unscale) gscale += w.scale;
     }
     APP(seg_line, sp, seg_cap, "%s S %d T %d A %d L %d", rec->uttid, rec->total_scale, ascr + lscr + gscale, ascr + gscale, lscr);
     for (int32_t q = 0; q < rec->n_words; q++) {
-        const s3a_hyp_word_t &w = rec->word[q];
+        const s3a_hyp_word_t &w = words[q];
         if (w.sf == w.ef) continue;
         APP(seg_line, sp, seg_cap, " %d %d %d %s", w.sf, w.ascr + (unscale ? w.scale : 0), raw(w.lscr), wordstr[w.wid]);
     }
     APP(seg_line, sp, seg_cap, " %d\n", rec->n_frames);
 #undef APP
     return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_hyp_format(const s3a_hyp_record_t *rec, const char *const *wordstr, const int32_t *basewid, const uint8_t *is_filler,
+               int32_t startwid, int32_t finishwid, float lw, int32_t wip, int32_t unscale, char *match_line,
+               size_t match_cap, char *seg_line, size_t seg_cap)
+{
+    if (!rec) return S3A_EINVAL;
+    return s3a_hyp_format_var((const s3a_hyp_header_t *)rec, rec->word, wordstr, basewid, is_filler, startwid, finishwid, lw,
+                              wip, unscale, match_line, match_cap, seg_line, seg_cap);
 }
 
 /* per-kernel timing: from now on every `every`-th frame of a decode is bracketed, launch by launch, by HIP events

@@ -192,6 +192,9 @@ _SIGS = {
     "s3a_uttdec_profile": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_shape": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_int32)] * 6),
     "s3a_uttdec_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]),
+    "s3a_uttdec_hyp_var": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_hyp_format_var": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                       C.c_int32, C.c_int32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "s3a_hyp_format": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                    C.c_int32, C.c_int32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "s3a_uttdec_last_decode_ms": (C.c_double, [C.c_void_p]),
@@ -1228,6 +1231,12 @@ class HypRecord(C.Structure):
                [("word", HypWord * HYP_MAXW)]
 
 
+class HypHeader(C.Structure):
+    """s3a_hyp_header_t: what s3a_hyp_record_t begins with; the words travel beside it (no word limit)"""
+    _fields_ = [("uttid", C.c_char * 96)] + \
+               [(k, C.c_int32) for k in ("utt_index", "n_words", "n_frames", "score", "total_scale", "n_entry", "status", "exit_id")]
+
+
 class UttResult(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("err", "n_entry", "n_frm", "n_frames")] + \
                [(k, C.POINTER(C.c_int32)) for k in ("score", "pred", "lw0", "lw1", "wid", "sf", "ef", "ascr", "lscr", "type",
@@ -1296,6 +1305,16 @@ class UttDec:
         rec = HypRecord()
         check(self.L.s3a_uttdec_hyp(self.h, lane, uttid.encode(), int(utt_index), C.byref(rec)), self.L)
         return rec
+
+    def hyp_var(self, lane, uttid="", utt_index=0):
+        """-> (HypHeader, words int32 [n_words, 6]: wid sf ef ascr lscr scale), however long the hypothesis is"""
+        hdr = HypHeader()
+        words = np.zeros((HYP_MAXW, 6), np.int32)
+        check(self.L.s3a_uttdec_hyp_var(self.h, lane, uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
+        if hdr.status == -3:
+            words = np.zeros((hdr.n_words, 6), np.int32)
+            check(self.L.s3a_uttdec_hyp_var(self.h, lane, uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
+        return hdr, words[:hdr.n_words if hdr.status == 0 else 0].copy()
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -83,9 +83,64 @@ def gather_records(local_records, n_utt_total: int, dist=None, device="cpu"):
     return recs
 
 
-def write_outputs(recs, fmt, hyp_path=None, hypseg_path=None):
-    """-hyp / -hypseg files from gathered records (fmt: record -> (match line, matchseg line), e.g. bundle.Decoder.format)"""
-    lines = [fmt(r) for r in recs]
+def gather_var(local, n_utt_total: int, dist=None, device="cpu"):
+    """The exchange without a word limit: local = list of (lib.HypHeader, words int32 [n_words, 6]).  Two collectives:
+    the fixed-size headers (every rank learns every hypothesis' length), then the ranks' words, each rank's block padded
+    to the largest rank's total.  Returns [(header, words)] in utterance order (every rank)."""
+    HB = C.sizeof(lib.HypHeader)
+    n_local = len(local)
+    hdr = np.frombuffer(b"".join(bytes(h) for h, _ in local), np.uint8).reshape(n_local, HB) if n_local else np.zeros((0, HB), np.uint8)
+    words = np.concatenate([np.asarray(w, np.int32).reshape(-1, 6) for _, w in local]) if n_local else np.zeros((0, 6), np.int32)
+    assert [int(h.n_words) if h.status == 0 else 0 for h, _ in local] == [len(w) for _, w in local]
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        blocks = [(hdr, words)]
+    else:
+        import torch
+        world = dist.get_world_size()
+        cnt = torch.tensor([n_local, len(words)], dtype=torch.int64, device=device)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        mh, mw = (max(int(c[k].item()) for c in cnts) for k in (0, 1))
+        pad = lib.HypHeader()
+        pad.utt_index = -1
+        hb = np.frombuffer(bytes(pad) * max(mh, 1), np.uint8).reshape(max(mh, 1), HB).copy()
+        hb[:n_local] = hdr
+        wb = np.zeros((max(mw, 1), 6), np.int32)
+        wb[:len(words)] = words
+        th, tw = torch.from_numpy(hb).to(device), torch.from_numpy(wb).to(device)
+        oh, ow = [torch.empty_like(th) for _ in range(world)], [torch.empty_like(tw) for _ in range(world)]
+        dist.all_gather(oh, th)                         # lengths (and everything else that is fixed-size)
+        dist.all_gather(ow, tw)                         # the padded payload
+        blocks = [(h.cpu().numpy(), w.cpu().numpy()) for h, w in zip(oh, ow)]
+    out = []
+    for hb, wb in blocks:
+        pos = 0
+        for i in range(hb.shape[0]):
+            h = lib.HypHeader.from_buffer_copy(hb[i].tobytes())
+            if h.utt_index < 0:
+                continue
+            n = int(h.n_words) if h.status == 0 else 0
+            out.append((h, wb[pos:pos + n].copy()))
+            pos += n
+    out.sort(key=lambda t: t[0].utt_index)
+    if [h.utt_index for h, _ in out] != list(range(n_utt_total)):
+        raise RuntimeError("gather: utterances missing or duplicated across ranks")
+    return out
+
+
+def write_outputs(recs, fmt, hyp_path=None, hypseg_path=None, log=None):
+    """-hyp / -hypseg files from gathered records (fmt: record -> (match line, matchseg line), e.g. bundle.Decoder.format;
+    records may be (header, words) pairs, then fmt takes both).  An utterance that could not be ended (status != 0:
+    decode error, no word exit) gets NO line in either file -- the reference logs `utt_end failed` and writes
+    nothing for it (srch.c:495-498) -- so the files stay byte-identical to a single-process reference run."""
+    lines = []
+    for r in recs:
+        h = r[0] if isinstance(r, tuple) else r
+        if h.status != 0:
+            if log is not None:
+                log.append((h.utt_index, h.uttid.decode(errors="replace"), h.status))
+            continue
+        lines.append(fmt(*r) if isinstance(r, tuple) else fmt(r))
     if hyp_path:
         with open(hyp_path, "w") as f:
             f.writelines(l[0] for l in lines)

@@ -722,6 +722,20 @@ int32_t s3a_uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_
 int32_t s3a_hyp_format(const s3a_hyp_record_t *rec, const char *const *wordstr, const int32_t *basewid,
                        const uint8_t *is_filler, int32_t startwid, int32_t finishwid, float lw, int32_t wip,
                        int32_t unscale, char *match_line, size_t match_cap, char *seg_line, size_t seg_cap);
+/* The same without a word limit (a ten-minute utterance has thousands of words): a fixed-size header -- what
+ * s3a_hyp_record_t begins with -- and as many s3a_hyp_word_t as the hypothesis has.  The end-of-batch exchange is
+ * then two collectives: the headers (every rank learns every n_words), then the words, padded per rank to the
+ * largest rank's total.  max_words too small (0 to ask): status -3 and hdr->n_words = the count it takes. */
+typedef struct {
+    char uttid[96];
+    int32_t utt_index, n_words, n_frames, score, total_scale, n_entry, status, exit_id;
+} s3a_hyp_header_t;
+int32_t s3a_uttdec_hyp_var(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index,
+                           s3a_hyp_header_t *hdr, s3a_hyp_word_t *words, int32_t max_words);
+int32_t s3a_hyp_format_var(const s3a_hyp_header_t *hdr, const s3a_hyp_word_t *words, const char *const *wordstr,
+                           const int32_t *basewid, const uint8_t *is_filler, int32_t startwid, int32_t finishwid,
+                           float lw, int32_t wip, int32_t unscale, char *match_line, size_t match_cap,
+                           char *seg_line, size_t seg_cap);
 
 /* The word level on its own (one lane, no lextrees): what closes a frame -- vithist_rescore for
  * every word exit, vithist_prune, srch_utt_word_trans, vithist_frame_windup -- on caller-supplied

@@ -112,3 +112,33 @@ def test_very_short_and_ragged_utterances(gpu_lib, tidigits_bundle, tmp_path):
     assert [r.status != 0 for r in recs] == [True, True, False, False, False]
     assert "".join(dec.format(r)[0] for r in recs[2:]) == out["ref"][0]
     assert "".join(dec.format(r)[1] for r in recs[2:]) == out["ref"][1]
+
+
+def test_every_lane_that_overflowed_restarts_clean(gpu_lib, tidigits_bundle):
+    """A history table far too small stops SEVERAL lanes of a batch in mid-frame (WL_E_TABLE is raised after the hash
+    inserts).  The decode reports the first; every one of them must start its next utterance from scratch -- stale
+    hash slots / lextree state in a lane that was not the first would give silently wrong history entries.  Then the
+    var-length hypothesis API on the same lanes."""
+    utts = list(ctl_entries())[:4]
+    feats = [gpu_lib.feat_1s_c_d_dd(s3io.read_mfc(f"{D}/cepstra/{u}.mfc").reshape(-1, 13), cmn="current") for u, _ in utts]
+    ref_m = open(f"{D}/ref_mode4_trigram.match").read().splitlines(keepends=True)
+    ref_s = open(f"{D}/ref_mode4_trigram.matchseg").read().splitlines(keepends=True)
+    small = bundle.Decoder(tidigits_bundle, 4, vh_cap=64)
+    with pytest.raises(gpu_lib.S3AError, match="history table full"):
+        small.decode(feats)
+    errs = [small.ud.result(z)["err"] for z in range(4)]
+    assert sum(1 for e in errs if e) >= 2, errs              # the point of the test: more than one lane stopped
+    # the same engine, the same lanes, short utterances that fit the tiny table: frames cut so that few entries are made
+    short = [f[:12].copy() for f in feats]
+    small.decode(short)
+    good = bundle.Decoder(tidigits_bundle, 4)
+    good.decode(short)
+    for z in range(4):
+        a, b = small.ud.result(z), good.ud.result(z)
+        assert a["err"] == 0 and all(np.array_equal(a[k], b[k]) for k in ("score", "pred", "wid", "lw0", "lw1", "sf", "ef", "ascr", "lscr"))
+    # ... and full utterances after an overflow in a roomy engine whose lanes are then reused
+    good.decode(feats)
+    for z, (_, uid) in enumerate(utts):
+        h, w = good.hyp_var(z, uid, z)
+        assert h.status == 0 and len(w) == h.n_words
+        assert good.format_var(h, w) == (ref_m[z], ref_s[z]) == good.format(good.hyp(z, uid, z))

@@ -125,3 +125,76 @@ def test_gather_refuses_missing_and_overflowing_records():
     r.status = -3
     with pytest.raises(RuntimeError, match="exceed S3A_HYP_MAXW"):
         shard.gather_records([r], 1)
+
+
+def test_failed_utterances_get_no_line_as_in_the_reference():
+    """srch.c:495-498: when utt_end fails (no word exit, a decode error) the reference writes neither a -hyp nor a
+    -hypseg line for the utterance; the gathered files must do the same"""
+    recs = [make_record(u) for u in range(4)]
+    recs[1].status, recs[1].n_words = -2, 0
+    recs[3].status, recs[3].n_words = -1, 0
+    got = shard.gather_records(recs, 4)
+    log = []
+    lines = shard.write_outputs(got, fmt, log=log)
+    assert [l[0] for l in lines] == [fmt(make_record(0))[0], fmt(make_record(2))[0]]
+    assert [(i, s) for i, _, s in log] == [(1, -2), (3, -1)]
+
+
+def _hdr_words(u, n_words=None):
+    r = make_record(u)
+    h = lib.HypHeader.from_buffer_copy(bytes(r)[:C.sizeof(lib.HypHeader)])
+    w = np.frombuffer(bytes(r)[C.sizeof(lib.HypHeader):], np.int32).reshape(-1, 6)[:r.n_words].copy()
+    if n_words is not None:                 # a long hypothesis: repeat the middle words
+        mid = np.tile(w[1:-1], (n_words // max(len(w) - 2, 1) + 1, 1))[:n_words - 2]
+        w = np.concatenate([w[:1], mid, w[-1:]])
+        h.n_words = len(w)
+    return h, w
+
+
+def fmt_var(h, w):
+    L = lib.load()
+    ws = (C.c_char_p * len(WORDS))(*[x.encode() for x in WORDS])
+    m, s = C.create_string_buffer(1 << 20), C.create_string_buffer(1 << 20)
+    w = np.ascontiguousarray(w, np.int32)
+    lib.check(L.s3a_hyp_format_var(C.byref(h), lib._p(w), ws, lib._p(BASE), lib._p(FILL), 0, 1, np.float32(9.5), -3567, 0, m, len(m), s, len(s)), L)
+    return m.value.decode(), s.value.decode()
+
+
+def _worker_var(rank, world, port, lens, outdir, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.shard_contiguous(len(lens), rank, world)
+    got = shard.gather_var([_hdr_words(u, lens[u]) for u in mine], len(lens), dist)
+    if rank == 0:
+        shard.write_outputs(got, fmt_var, os.path.join(outdir, "v2.match"), os.path.join(outdir, "v2.matchseg"))
+        q.put([int(h.n_words) for h, _ in got])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_variable_length_gather_has_no_word_limit(tmp_path):
+    """lengths gather + padded payload: hypotheses far beyond S3A_HYP_MAXW words cross the ranks intact, and what fits
+    the fixed record formats to the same lines either way"""
+    import torch.multiprocessing as mp
+    lens = [None, 1200, None, 3, 4000]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_var, args=(r, 2, port, lens, str(tmp_path), q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[1] == 1200 and got[4] == 4000 and got[3] == 3
+    one = shard.gather_var([_hdr_words(u, lens[u]) for u in range(len(lens))], len(lens))
+    shard.write_outputs(one, fmt_var, str(tmp_path / "v1.match"), str(tmp_path / "v1.matchseg"))
+    for e in ("match", "matchseg"):
+        assert open(tmp_path / f"v1.{e}").read() == open(tmp_path / f"v2.{e}").read()
+    assert fmt_var(*_hdr_words(0)) == fmt(make_record(0)) and fmt_var(*_hdr_words(2)) == fmt(make_record(2))
