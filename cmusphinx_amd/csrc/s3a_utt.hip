@@ -47,6 +47,8 @@ struct ULane {
     uint8_t *pstamp8;           /* [n_pset] the parent sets' stamps, the frame number's low 8 bits (a quarter of the
                                  * sweep's gathers' footprint; a stale match costs a walk that finds nothing) */
     int32_t *dynbeam;           /* [1] the frame's CI beam when -maxcdsenpf is in force (ku_dyn_ci_beam) */
+    int32_t *win;               /* [K][n_sen] look-ahead window: every senone's score for the frames f0 .. f0 + K - 1 */
+    uint8_t *winb;              /* [K][n_sen] ... and the best component of its mixture (255: none) */
     /* this utterance */
     UCtx *ctx;
     int32_t *pack;
@@ -79,6 +81,7 @@ struct UShared {
      * lanes' contexts and active-list lengths are two arrays (ONE round trip to the early exit instead of lane struct ->
      * pointer -> value: with 64 lanes most workgroups of a fixed grid only find out that they are not needed, and
      * that chain times the number of such waves over the chip's resident waves WAS the launch) */
+    int32_t win_K;              /* > 0: look-ahead scoring, K frames per window (ku_score_window / ku_select); 0: per-frame scoring */
     UCtx *ctx_all;              /* [n_lanes] */
     int32_t *nact_all;          /* [n_lanes][2][WL_MAXT] */
 };
@@ -89,6 +92,8 @@ struct UShared {
 #define LANE UCtx *ctx = S.ctx_all + blockIdx.z; if (f >= ctx->nfr || !ctx->active) return;                      \
     const int32_t cur = f & 1; const int32_t *nact_cur = S.nact_all + ((size_t)blockIdx.z * 2 + cur) * WL_MAXT;       \
     const ULane &L = lanes[blockIdx.z]; (void)cur; (void)nact_cur
+/* the frame's senone scores: the lane's row of the look-ahead window, or the per-frame scorer's array */
+#define SCR_ROW (S.win_K > 0 ? L.win + (size_t)(f % S.win_K) * S.n_sen : L.scr)
 
 __device__ __forceinline__ FrameBeams
 frame_beams(const UShared &S, int32_t cf)
@@ -354,6 +359,259 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, i
     }
 }
 
+/*
+ * LOOK-AHEAD SCORING: every senone of the coming K frames of every lane in ONE pass over the model.
+ *
+ * A Gaussian's value does not depend on the search (only WHICH scores are used does: the active-senone mask and the
+ * CI gate of approx_cont_mgau_frame_eval select among them), and the lanes' features are resident in HBM, so the
+ * Gaussians are taken out of the frame's chain of launches altogether: every K frames ONE launch of the
+ * model-stationary kernel (k_score_frames, s3a_device.hip: a lane of the wave keeps its Gaussian in VGPRs, the frames
+ * stream past from LDS, eight at a time, and the senone's ordered log-add runs on transposed values with the log-add
+ * table in LDS) scores n_lanes x K (lane, frame) slots for ALL senones -- a batch of 128 lanes x 8 frames is the
+ * same 1024 frames per model pass as a 10 s utterance -- into the lanes' window buffers (win: score per senone, winb:
+ * the best component, mgau_eval's update_best_id).  Per frame ku_select then applies the gate to the ACTIVE senones
+ * (the very decisions of d_gated_frame, s3a_gated.h) and patches the few back-off scores in place; ku_hmm_eval reads
+ * the window row.  The model is read once per K frames of all lanes (per-frame passes: once per frame and 32 lanes).
+ * Bit for bit the scores of ku_gated / ku_gated_cd_multi (tests/test_gpu_uttdec.py, test_gpu_dropin.py).
+ */
+#define UW_FB 8
+struct UwGroup {
+    const float *feat;      /* the lane's features at the group's first frame */
+    int32_t *win;           /* the lane's window rows from the group's first row */
+    uint8_t *winb;
+    int32_t nv, pad;        /* valid frames of the group (0: lane finished / idle) */
+};
+
+template <int CP, bool EXACT, bool TAB_LDS, int NT>
+__global__ void __launch_bounds__(NT)
+ku_score_window(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, int32_t f0, int32_t K, int32_t fpc,
+                int32_t n_chunks, int32_t n_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int DP = D4MAIN * 4;
+    typedef typename Acc<EXACT>::T acc_t;
+    /* XCD-aware decode of blockIdx.x (as k_score_frames): all chunks of a Gaussian tile run on XCD tile % 8 */
+    const int32_t b = blockIdx.x, xcd = b & 7, r = b >> 3;
+    const int32_t chunk = r % n_chunks, tile = (r / n_chunks) * 8 + xcd;
+    if (tile >= n_tiles) return;
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t g = tile * NT + tid;
+    const int32_t q0 = chunk * fpc, total = n_lanes * K;
+    const int32_t nslot = min(fpc, total - q0), ngrp = (nslot + UW_FB - 1) / UW_FB;
+
+    float *xs = (float *)smem;
+    size_t off = (size_t)fpc * DP * sizeof(float);
+    int32_t *tr = (int32_t *)(smem + off) + wave * (UW_FB * 65);
+    off += (size_t)(NT / 64) * UW_FB * 65 * sizeof(int32_t);
+    off = (off + 15) & ~(size_t)15;
+    UwGroup *grp = (UwGroup *)(smem + off);
+    off += (size_t)(fpc / UW_FB) * sizeof(UwGroup);
+    off = (off + 15) & ~(size_t)15;
+    uint16_t *tab_s = (uint16_t *)(smem + off);
+
+    /* the chunk's groups: 8 consecutive frames of one lane each (K is a multiple of 8) */
+    int32_t *s_any = (int32_t *)xs;             /* (the feature area is filled after the early exit) */
+    if (tid == 0) *s_any = 0;
+    __syncthreads();
+    if (tid < ngrp) {
+        const int32_t q = q0 + tid * UW_FB, z = q / K, j0 = q - z * K;
+        UwGroup gr;
+        gr.feat = NULL; gr.win = NULL; gr.winb = NULL; gr.nv = 0; gr.pad = 0;
+        const UCtx *cx = S.ctx_all + z;
+        if (cx->active) {
+            const int32_t left = cx->nfr - (f0 + j0);
+            if (left > 0) {
+                gr.nv = min(left, UW_FB);
+                gr.feat = cx->feat + (size_t)(f0 + j0) * DP;
+                gr.win = lanes[z].win + (size_t)j0 * S.n_sen;
+                gr.winb = lanes[z].winb + (size_t)j0 * S.n_sen;
+            }
+        }
+        grp[tid] = gr;
+        if (gr.nv) *s_any = 1;
+    }
+    __syncthreads();
+    if (!*s_any) return;                        /* every lane of the chunk has finished its utterance */
+    __syncthreads();
+
+    if (TAB_LDS) {
+        const uint4 *src = (const uint4 *)S.tab16;
+        uint4 *dst = (uint4 *)tab_s;
+        const int32_t n16 = (int32_t)((S.tab_size * 2 + 15) >> 4);
+        for (int32_t i = tid; i < n16; i += NT) dst[i] = src[i];
+    }
+    for (int32_t i = tid; i < ngrp * UW_FB * (DP / 4); i += NT) {      /* 16-byte pieces: rows are DP floats, zero padded */
+        const int32_t slot = i / (DP / 4), k = i - slot * (DP / 4), gi = slot / UW_FB, j = slot - gi * UW_FB;
+        const UwGroup &gr = grp[gi];
+        ((float4 *)xs)[i] = j < gr.nv ? ((const float4 *)(gr.feat + (size_t)j * DP))[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    float4 M[D4MAIN], P[D4MAIN];
+#pragma unroll
+    for (int k = 0; k < D4MAIN; k++) { M[k] = S.mean4[(size_t)k * S.Gpad + g]; P[k] = S.prec4[(size_t)k * S.Gpad + g]; }
+    const acc_t lrd_g = (acc_t)S.lrd[g];
+    const int32_t mixw = S.mixw[g];
+    const int32_t c = lane & (CP - 1), sl = lane / CP, sen = g / CP;
+    const int32_t nc = sen < S.n_sen ? (int32_t)S.ncomp[sen] : 0;
+    LogAdd la;
+    la.tab = TAB_LDS ? tab_s : S.tab16; la.size = S.tab_size; la.zero = S.lm_zero;
+    __syncthreads();
+    const float4 *xs4 = (const float4 *)xs;
+    for (int32_t gi = 0; gi < ngrp; gi++) {
+        const int32_t nv = grp[gi].nv;
+        if (nv == 0) continue;
+        const int32_t fr = gi * UW_FB;
+        acc_t a[UW_FB];
+#pragma unroll
+        for (int j = 0; j < UW_FB; j++) a[j] = lrd_g;
+#pragma unroll
+        for (int k = 0; k < D4MAIN; k++) {
+#pragma unroll
+            for (int j = 0; j < UW_FB; j++) {
+                const float4 x = xs4[(fr + j) * D4MAIN + k];       /* wave-uniform: LDS broadcast */
+                a[j] = Acc<EXACT>::step(a[j], x.x, M[k].x, P[k].x);
+                a[j] = Acc<EXACT>::step(a[j], x.y, M[k].y, P[k].y);
+                a[j] = Acc<EXACT>::step(a[j], x.z, M[k].z, P[k].z);
+                a[j] = Acc<EXACT>::step(a[j], x.w, M[k].w, P[k].w);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UW_FB; j++) tr[j * 65 + lane] = gau_to_int((double)a[j], S.f, S.distfloor, mixw);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int32_t *win = grp[gi].win;
+        uint8_t *winb = grp[gi].winb;
+        for (int j = c; j < UW_FB; j += CP) {
+            int32_t score = S3A_LOGPROB_ZERO, bs = S3A_LOGPROB_ZERO, bidx = 255;
+            const int32_t *row = tr + j * 65 + sl * CP;
+#pragma unroll
+            for (int cc = 0; cc < CP; cc++) {
+                const int32_t v = row[cc];
+                if (cc < nc) {                      /* (padded slots: not components of the senone) */
+                    score = la(score, v);
+                    if (v > bs) { bs = v; bidx = cc; }      /* update_best_id: strict >, the first maximum */
+                }
+            }
+            if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
+            if (sen < S.n_sen && j < nv) {
+                win[(size_t)j * S.n_sen + sen] = score;
+                winb[(size_t)j * S.n_sen + sen] = (uint8_t)bidx;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* one Gaussian for one frame (the gate's best-Gaussian back-off; a few senones per frame when the gate fires at all) */
+template <bool EXACT>
+__device__ __forceinline__ int32_t
+uw_one_gaussian(const UShared &S, int32_t g, const float *__restrict__ x)
+{
+    typedef typename Acc<EXACT>::T acc_t;
+    acc_t a = (acc_t)S.lrd[g];
+    for (int32_t k = 0; k < S.D4; k++) {
+        const float4 m = S.mean4[(size_t)k * S.Gpad + g], p = S.prec4[(size_t)k * S.Gpad + g];
+        const float4 xv = *(const float4 *)(x + 4 * k);
+        a = Acc<EXACT>::step(a, xv.x, m.x, p.x);
+        a = Acc<EXACT>::step(a, xv.y, m.y, p.y);
+        a = Acc<EXACT>::step(a, xv.z, m.z, p.z);
+        a = Acc<EXACT>::step(a, xv.w, m.w, p.w);
+    }
+    return gau_to_int((double)a, S.f, S.distfloor, S.mixw[g]);
+}
+
+/*
+ * approx_cont_mgau_ci_eval + approx_cont_mgau_frame_eval on the window row of the lane's frame: the CI senones (always
+ * evaluated; their maximum is the gate's reference), then per ACTIVE CD senone the three-way gate of
+ * approx_cont_mgau.c:188-284 -- inside the CI beam: the full mixture (already in the row) and its best component;
+ * outside: the best Gaussian of the previous frame alone if the senone was evaluated then, else the CI senone's score
+ * -- with bstidx / updatetime kept as the reference keeps them (-ds skip frames included), the frame's best score and
+ * the evaluation counters as columns of gpart[] (merged by ku_hmm_eval and the frame record), the mask consumed.
+ * USEL_G workgroups per lane; every one works out the CI maximum for itself (n_ci_sen loads from one row).
+ */
+#define USEL_G 8
+template <bool EXACT>
+__global__ void __launch_bounds__(256)
+ku_select(const ULane *__restrict__ lanes, UShared S, int32_t f, int32_t K)
+{
+    __shared__ int32_t red[3][4];
+    __shared__ int32_t s_pb;
+    LANE;
+    const int32_t tid = threadIdx.x, ln = tid & 63, bx = blockIdx.x;
+    int32_t *row = L.win + (size_t)(f % K) * S.n_sen;
+    const uint8_t *brow = L.winb + (size_t)(f % K) * S.n_sen;
+    int32_t pb = INT_MIN, cig = 0;
+    for (int32_t ci = tid; ci < S.n_ci_sen; ci += 256) { pb = max(pb, row[ci]); cig += (int32_t)S.ncomp[ci]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pb = max(pb, __shfl_xor(pb, o, 64)); cig += __shfl_xor(cig, o, 64); }
+    if (ln == 0) { red[0][tid >> 6] = pb; red[1][tid >> 6] = cig; }
+    __syncthreads();
+    if (tid == 0) {
+        pb = max(max(red[0][0], red[0][1]), max(red[0][2], red[0][3]));
+        s_pb = pb;
+        if (bx == 0) {          /* the CI phase's outputs: best CI score, senones / Gaussians evaluated */
+            L.misc[5] = pb; L.misc[3] = S.n_ci_sen; L.misc[4] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        }
+    }
+    __syncthreads();
+    pb = s_pb;
+    const int32_t is_skip = (f % S.ds_ratio == 0) ? 0 : 1;
+    const int32_t beam = (S.max_cd < S.n_sen - S.n_ci_sen) ? L.dynbeam[0] : (is_skip ? S.ci_pbeam_tight : S.ci_pbeam);
+    const int32_t thresh = add32(pb, beam);
+    LogAdd la;
+    la.tab = S.tab16; la.size = S.tab_size; la.zero = S.lm_zero;
+    int32_t rbest = INT_MIN, rns = 0, rng = 0;
+    for (int32_t s0 = S.n_ci_sen + bx * 256; s0 < S.n_sen; s0 += (int32_t)gridDim.x * 256) {
+        const int32_t sen = s0 + tid;
+        if (sen >= S.n_sen) continue;
+        if (!L.sen_act[sen]) continue;
+        L.sen_act[sen] = 0;                         /* the mask is consumed: clean for the next frame's marks */
+        const int32_t ci_scr = row[S.cd2cisen[sen]];
+        if (ci_scr >= thresh) {                     /* full evaluation */
+            const int32_t bi = (int32_t)brow[sen];
+            L.bstidx[sen] = bi == 255 ? S3A_NO_BSTIDX : bi;
+            L.updatetime[sen] = f;
+            rbest = max(rbest, row[sen]); rns++; rng += (int32_t)S.ncomp[sen];
+            continue;
+        }
+        const int32_t bi = L.bstidx[sen], ut = L.updatetime[sen];
+        if (bi == S3A_NO_BSTIDX || ut != f - 1) {   /* the CI senone stands in */
+            row[sen] = ci_scr;
+            rbest = max(rbest, ci_scr);
+            continue;
+        }
+        /* the best Gaussian of the previous frame alone */
+        const int32_t v = uw_one_gaussian<EXACT>(S, sen * S.CP + bi, ctx->feat + (size_t)f * S.D4 * 4);
+        int32_t score = la(S3A_LOGPROB_ZERO, v);
+        if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
+        row[sen] = score;
+        rbest = max(rbest, score); rng++;
+        if (is_skip) { L.bstidx[sen] = v > S3A_LOGPROB_ZERO ? bi : S3A_NO_BSTIDX; L.updatetime[sen] = f; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        rbest = max(rbest, __shfl_xor(rbest, o, 64)); rns += __shfl_xor(rns, o, 64); rng += __shfl_xor(rng, o, 64);
+    }
+    __syncthreads();
+    if (ln == 0) { red[0][tid >> 6] = rbest; red[1][tid >> 6] = rns; red[2][tid >> 6] = rng; }
+    __syncthreads();
+    if (tid == 0 && bx < S.gp_n) {
+        L.gpart[bx] = max(max(red[0][0], red[0][1]), max(red[0][2], red[0][3]));
+        L.gpart[S.gp_n + bx] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        L.gpart[2 * S.gp_n + bx] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    }
+    /* (the columns beyond this grid stay neutral: written once at init) */
+}
+
+/* the members of the composite senones wanted in this frame join the mask (before ku_select) */
+__global__ void __launch_bounds__(256)
+ku_comsen_mark(const ULane *__restrict__ lanes, UShared S, int32_t f)
+{
+    LANE;
+    d_comsen_wave<false>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, L.sen_act, (const int32_t *)NULL, (int32_t *)NULL,
+                         (int32_t)blockIdx.x * 256 + (int32_t)(threadIdx.x & ~63));
+}
+
 /* ---- approx_compute_dyn_ci_pbeam (approx_cont_mgau.c:303-357, -maxcdsenpf): the CI senones in descending score order,
  * the active CD senones each of them stands for counted along the way; the beam is cut where the count passes the cap.
  * (Ties need no order: the cut is a score.)  One workgroup per lane, between the CI and the CD scoring launches. ---- */
@@ -364,7 +622,7 @@ ku_dyn_ci_beam(const ULane *__restrict__ lanes, UShared S, int32_t f)
     __shared__ int32_t s_occ[UDB_MAXCI], s_scr[UDB_MAXCI], s_ord[UDB_MAXCI], s_cut;
     LANE;
     const int32_t n_ci = S.n_ci_sen, tid = threadIdx.x;
-    for (int32_t c = tid; c < n_ci; c += 1024) { s_occ[c] = 0; s_scr[c] = L.scr[c]; }
+    for (int32_t c = tid; c < n_ci; c += 1024) { s_occ[c] = 0; s_scr[c] = SCR_ROW[c]; }
     if (tid == 0) s_cut = INT_MAX;
     __syncthreads();
     for (int32_t s = n_ci + tid; s < S.n_sen; s += 1024)
@@ -403,7 +661,7 @@ __global__ void __launch_bounds__(256)
 ku_comsen_max(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    d_comsen_wave<true>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, (uint8_t *)NULL, L.scr, L.cs_val,
+    d_comsen_wave<true>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, (uint8_t *)NULL, SCR_ROW, L.cs_val,
                         (int32_t)blockIdx.x * 256 + (int32_t)(threadIdx.x & ~63));
 }
 
@@ -416,7 +674,7 @@ ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t f)
     const int32_t t = blockIdx.y, na = nact_cur[t];
     for (int32_t vb = blockIdx.x; vb * EB < na; vb += gridDim.x) {
         d_dec_hmm_eval<EB>(S.node_base, L.act[cur], L.nact[cur], S.N, S.n_tmat, S.ssid, S.tmatid, S.wid, S.comp, S.tp,
-                           S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt, L.scr, L.misc, L.sc, L.hist, L.outs, L.outh,
+                           S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt, SCR_ROW, L.misc, L.sc, L.hist, L.outs, L.outh,
                            L.bests, L.best, f, (const int32_t *)NULL /* ku_hist_count stamps */, S.psof, L.pstamp, L.gpart, S.gp_n, L.poswid, L.posout,
                            vb, t, L.cs_val, S.node4);
         __syncthreads();
@@ -773,6 +1031,8 @@ struct s3a_uttdec_s {
     int64_t prof_n[24];
     int32_t big_wl;             /* the word level's candidate phases as their own launches (wide beams) */
     hipEvent_t ev0, ev1;        /* around the frames of a decode (last_decode_ms) */
+    int32_t no_multi, gy;       /* tuning switches, read ONCE at init (S3A_UTT_NO_MULTI, S3A_UTT_GY; tests) */
+    int32_t win_fpc;            /* S3A_UTT_WIN_FPC: slots per chunk of the look-ahead scoring (0: the cost model's) */
 };
 
 static int32_t
@@ -841,6 +1101,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.d.cs_val) (void)hipFree(hl.d.cs_val);
         if (hl.d.dynbeam) (void)hipFree(hl.d.dynbeam);
         if (hl.d.pstamp8) (void)hipFree(hl.d.pstamp8);
+        if (hl.d.win) (void)hipFree(hl.d.win);
+        if (hl.d.winb) (void)hipFree(hl.d.winb);
         if (hl.ls && ud->S.nact_all && hl.ls->d_nact[0] >= ud->S.nact_all
             && hl.ls->d_nact[0] < ud->S.nact_all + (size_t)ud->n_lanes * 2 * WL_MAXT)
             hl.ls->d_nact[0] = hl.ls->d_nact[1] = NULL;     /* borrowed from nact_all */
@@ -945,6 +1207,8 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
 
     /* launch geometry: fixed grids, the kernels loop over the list lengths they find in memory */
     ud->eval_block = (cfg->maxhmmpf >= EVBLOCK_LONG_LIST && maxn >= EVBLOCK_LONG_LIST) ? 256 : 64;
+    ud->no_multi = getenv("S3A_UTT_NO_MULTI") != NULL;
+    ud->gy = getenv("S3A_UTT_GY") ? atoi(getenv("S3A_UTT_GY")) : 0;
     ud->many = getenv("S3A_UTT_MANY") ? max(1, atoi(getenv("S3A_UTT_MANY"))) : 32;
     /* fixed grids, sized for the usual frame: a workgroup loops when a list is longer (virtual workgroups); with many
      * lanes the idle workgroups of a generous grid cost more than the loop */
@@ -1020,6 +1284,19 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         P.lcmap = ud->d_lcmap;
     }
 
+    /* look-ahead scoring (ku_score_window): the 39/40-dimensional case with a 16-bit log-add table and at most 64
+     * Gaussian slots per senone; K frames per window so that a window of all lanes is ~1024 (lane, frame) slots -- what
+     * a model pass amortises over -- within 8 .. 64 frames.  S3A_UTT_WIN=0: the per-frame scoring kernels (tests). */
+    {
+        int32_t K = 0;
+        if (d->D4 == D4MAIN && d->CP <= 64 && d->Gpad % 512 == 0) {
+            K = (1024 + n_lanes - 1) / n_lanes;
+            K = min(64, max(8, ((K + 7) / 8) * 8));
+            if (getenv("S3A_UTT_WIN")) K = max(0, (atoi(getenv("S3A_UTT_WIN")) + 7) / 8 * 8);
+        }
+        S.win_K = K;
+        ud->win_fpc = getenv("S3A_UTT_WIN_FPC") ? atoi(getenv("S3A_UTT_WIN_FPC")) : 0;
+    }
     ud->lane.resize(n_lanes);
     for (auto &hl : ud->lane) memset((void *)&hl, 0, sizeof hl);
     if (T > WL_MAXT) { s3a_set_error("s3a_uttdec_init: more than %d lextrees", WL_MAXT); goto fail; }
@@ -1056,6 +1333,12 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
         DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4); DM(u.dynbeam, 16); DM(u.pstamp8, (size_t)proto->n_pset + 64); S.n_pset_bytes = proto->n_pset + 64;
         if (hipMemset(u.pstamp8, 0xff, (size_t)proto->n_pset + 64) != hipSuccess) goto fail;
+        if (S.win_K > 0) {
+            DM(u.win, (size_t)S.win_K * n_sen * 4); DM(u.winb, (size_t)S.win_K * n_sen);
+            /* ku_select fills the first USEL_G columns of gpart[]; the others stay neutral */
+            if (fill32(ud->stream, u.gpart, INT_MIN, (size_t)max(S.gp_n, 0)) != S3A_OK
+                || fill32(ud->stream, u.gpart + max(S.gp_n, 0), 0, (size_t)2 * max(S.gp_n, 0)) != S3A_OK) goto fail;
+        }
         if (fill32(ud->stream, u.cs_need, -1, (size_t)cs->n_comstate + 1) != S3A_OK) goto fail;
         u.ctx = ud->S.ctx_all + z;
         DM(u.pack, (size_t)(6 * T + 16 + 3 * proto->pack_max_exits) * 4);
@@ -1179,11 +1462,88 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     return S3A_OK;
 }
 
+/* ---- look-ahead scoring: geometry + launch of ku_score_window ---- */
+struct UwGeom { int32_t nt, fpc, n_chunks, n_tiles, grid, tab_lds; size_t lds; };
+
+static size_t
+uw_lds_bytes(int32_t fpc, int32_t nt, bool tab_lds, uint32_t tab_size)
+{
+    size_t b = (size_t)fpc * D4MAIN * 4 * sizeof(float);
+    b += (size_t)(nt / 64) * UW_FB * 65 * sizeof(int32_t);
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)(fpc / UW_FB) * sizeof(UwGroup);
+    b = (b + 15) & ~(size_t)15;
+    if (tab_lds) b += ((size_t)tab_size * 2 + 15) & ~(size_t)15;
+    return b;
+}
+
+/* (lane, frame) slots per chunk: a workgroup needs ~100 KB of LDS, so one is resident per CU and the grid runs in rounds
+ * of n_cu workgroups; time ~ rounds x (slots per chunk + a start-up worth ~10 slots): s3a_device.hip, pick_fpc */
+static UwGeom
+uw_geometry(const s3a_uttdec_t *ud, int32_t n_lanes)
+{
+    const UShared &S = ud->S;
+    const int32_t total = n_lanes * S.win_K, n_cu = max(1, ud->g->dev->n_cu);
+    UwGeom q;
+    q.tab_lds = total >= 2 * UW_FB ? 1 : 0;
+    q.nt = q.tab_lds ? 512 : 256;
+    q.n_tiles = S.Gpad / q.nt;
+    int32_t best_fpc = UW_FB;
+    int64_t best_cost = -1;
+    for (int32_t nc = 1; nc <= 512; nc++) {
+        int32_t fpc = (total + nc - 1) / nc;
+        fpc = ((fpc + UW_FB - 1) / UW_FB) * UW_FB;
+        if (fpc > 256) continue;
+        const int32_t chunks = (total + fpc - 1) / fpc;
+        const int64_t rounds = ((int64_t)q.n_tiles * chunks + n_cu - 1) / n_cu;
+        const int64_t cost = rounds * (fpc + 10);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_fpc = fpc; }
+        if (fpc <= UW_FB) break;
+    }
+    if (ud->win_fpc > 0) best_fpc = min(256, ((ud->win_fpc + UW_FB - 1) / UW_FB) * UW_FB);
+    q.fpc = best_fpc;
+    q.n_chunks = (total + q.fpc - 1) / q.fpc;
+    q.grid = ((q.n_tiles + 7) / 8) * q.n_chunks * 8;
+    q.lds = uw_lds_bytes(q.fpc, q.nt, q.tab_lds != 0, S.tab_size);
+    if (q.lds > 160 * 1024) { q.tab_lds = 0; q.lds = uw_lds_bytes(q.fpc, q.nt, false, S.tab_size); }
+    return q;
+}
+
+template <int CP, bool EXACT>
+static hipError_t
+uw_launch_cp(const s3a_uttdec_t *ud, const UwGeom &q, int32_t n, int32_t f0, hipStream_t st)
+{
+#define UW_GO(TAB, NT) do { auto kern = ku_score_window<CP, EXACT, TAB, NT>;                                            \
+        if (q.lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                                       160 * 1024) != hipSuccess) return hipGetLastError();             \
+        hipLaunchKernelGGL(kern, dim3(q.grid), dim3(NT), q.lds, st, ud->d_lanes, ud->S, n, f0, ud->S.win_K, q.fpc,        \
+                           q.n_chunks, q.n_tiles); } while (0)
+    if (q.nt == 512) { if (q.tab_lds) UW_GO(true, 512); else UW_GO(false, 512); }
+    else UW_GO(false, 256);
+#undef UW_GO
+    return hipGetLastError();
+}
+
+static int32_t
+uw_launch(const s3a_uttdec_t *ud, int32_t n, int32_t f0)
+{
+    const UwGeom q = uw_geometry(ud, n);
+    hipError_t e;
+#define UW_CASE(cp) case cp: e = ud->exact ? uw_launch_cp<cp, true>(ud, q, n, f0, ud->stream) : uw_launch_cp<cp, false>(ud, q, n, f0, ud->stream); break
+    switch (ud->S.CP) {
+    UW_CASE(1); UW_CASE(2); UW_CASE(4); UW_CASE(8); UW_CASE(16); UW_CASE(32);
+    default: e = ud->exact ? uw_launch_cp<64, true>(ud, q, n, f0, ud->stream) : uw_launch_cp<64, false>(ud, q, n, f0, ud->stream); break;
+    }
+#undef UW_CASE
+    if (e != hipSuccess) { s3a_set_error("ku_score_window launch failed: %s", hipGetErrorString(e)); return S3A_EHIP; }
+    return S3A_OK;
+}
+
 /* kernel classes of a frame (s3a_uttdec_profile) */
 enum { UK_ENTER1, UK_ENTER2, UK_ENTER3, UK_GATED_CI, UK_GATED_CD, UK_COMSEN, UK_HMM_EVAL, UK_HIST_COUNT, UK_HIST_SORT, UK_WEAK,
-       UK_RESOLVE, UK_SCAN, UK_EMIT, UK_WORD, UK_WL_P2, UK_WL_P3, UK_WL_P4, UK_WL_P5, UK_WL_FIN, UK_N };
+       UK_RESOLVE, UK_SCAN, UK_EMIT, UK_WORD, UK_WL_P2, UK_WL_P3, UK_WL_P4, UK_WL_P5, UK_WL_FIN, UK_WINDOW, UK_N };
 static const char *const uk_names[UK_N] = { "ku_enter1", "ku_enter2", "ku_enter3_mark", "ku_gated_ci", "ku_gated_cd",
-    "ku_comsen_max", "ku_hmm_eval", "ku_hist_count", "ku_hist_sort", "ku_weak", "ku_resolve", "ku_scan", "ku_emit", "ku_emit_word", "ku_wl_p2", "ku_wl_p3", "ku_wl_p4ab", "ku_wl_p5", "ku_wl_finish" };
+    "ku_comsen_max", "ku_hmm_eval", "ku_hist_count", "ku_hist_sort", "ku_weak", "ku_resolve", "ku_scan", "ku_emit", "ku_emit_word", "ku_wl_p2", "ku_wl_p3", "ku_wl_p4ab", "ku_wl_p5", "ku_wl_finish", "ku_score_window" };
 
 static int32_t
 enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
@@ -1202,12 +1562,29 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     UKL(UK_ENTER3, ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S, f);
     const int32_t g_ci = (S.n_ci_sen * S.CP + 255) / 256, g_cd = ((S.n_sen - S.n_ci_sen) * S.CP + 255) / 256;
     const int32_t g_cs = (S.n_cs + 255) / 256;         /* composite senones: a wave looks at 64 */
+    if (S.win_K > 0) {
+        /* look-ahead scoring: every K frames one pass over the model for all lanes' coming K frames; per frame the
+         * composite senones' members join the mask and the gate selects (ku_select) */
+        if (f % S.win_K == 0) {
+            hipEvent_t a_ = NULL, b_ = NULL;
+            if (prof) { (void)hipEventCreate(&a_); (void)hipEventCreate(&b_); (void)hipEventRecord(a_, st); }
+            const int32_t rc = uw_launch(ud, n, f);
+            if (rc != S3A_OK) return rc;
+            if (prof) { (void)hipEventRecord(b_, st); ud->prof_ev.push_back({ UK_WINDOW, a_, b_ }); }
+        }
+        if (g_cs) UKL(UK_GATED_CI, ku_comsen_mark, dim3(g_cs, 1, n), dim3(256), 0, st, LN, S, f);
+        if (S.max_cd < S.n_sen - S.n_ci_sen) UKL(UK_GATED_CI, ku_dyn_ci_beam, dim3(1, 1, n), dim3(1024), 0, st, LN, S, f);
+        const int32_t g_sel = max(1, min(USEL_G, min(S.gp_n, (S.n_sen - S.n_ci_sen + 255) / 256)));
+        if (ud->exact) UKL(UK_GATED_CD, ku_select<true>, dim3(g_sel, 1, n), dim3(256), 0, st, LN, S, f, S.win_K);
+        else UKL(UK_GATED_CD, ku_select<false>, dim3(g_sel, 1, n), dim3(256), 0, st, LN, S, f, S.win_K);
+    }
+    else {
     /* from UG_FB lanes on the CD senones of all lanes are ONE pass over the model (39/40-dimensional features,
      * >= UG_FB Gaussian slots per senone); (S3A_UTT_NO_MULTI: the per-lane kernel whatever the lane count -- tests) */
     const bool multi = n >= UG_FB && S.D4 == D4MAIN && S.CP >= UG_FB && S.CP <= 64 && g_cd > 0 && S.gp_n == g_cd
-        && getenv("S3A_UTT_NO_MULTI") == NULL;
+        && !ud->no_multi;
     const int32_t gz = (n + UG_MAX - 1) / UG_MAX, groups = (min(n, UG_MAX) + UG_FB - 1) / UG_FB;
-    const int32_t gy_env = getenv("S3A_UTT_GY") ? atoi(getenv("S3A_UTT_GY")) : 0;
+    const int32_t gy_env = ud->gy;
     const dim3 gm(g_cd, gy_env > 0 ? min(groups, gy_env) : max(1, min(groups, 2 * ud->g->dev->n_cu / max(1, g_cd * gz))), gz);
     if (ud->exact) {
         if (g_ci) UKL(UK_GATED_CI, (ku_gated<true, true>), dim3(g_ci + g_cs, 1, n), dim3(256), 0, st, LN, S, f);
@@ -1220,6 +1597,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
         if (S.max_cd < S.n_sen - S.n_ci_sen) UKL(UK_GATED_CI, ku_dyn_ci_beam, dim3(1, 1, n), dim3(1024), 0, st, LN, S, f);
         if (multi) UKL(UK_GATED_CD, (ku_gated_cd_multi<false>), gm, dim3(256), 0, st, LN, S, n, f);
         else if (g_cd) UKL(UK_GATED_CD, (ku_gated<false, false>), dim3(g_cd, 1, n), dim3(256), 0, st, LN, S, f);
+    }
     }
     if (g_cs) UKL(UK_COMSEN, ku_comsen_max, dim3(g_cs, 1, n), dim3(256), 0, st, LN, S, f);
     if (ud->eval_block == 256)

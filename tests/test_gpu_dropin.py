@@ -117,6 +117,10 @@ DRIVERS = {
     "utt_8_engines2": {"S3A_UTT": "8", "S3A_UTT_ENGINES": "2"},    # two engines of four lanes, a host thread each
     "utt_40": {"S3A_UTT": "40", "S3A_UTT_MANY": "2"},           # the kernels / grids chosen from 32 utterances per launch on
                                                                 # (list-driven resolve, fewer workgroups that loop), forced from 2
+    # the per-frame scoring kernels (ku_gated / ku_gated_cd_multi) instead of the look-ahead window + ku_select
+    "utt_4_perframe": {"S3A_UTT": "4", "S3A_UTT_WIN": "0"},
+    "utt_40_perframe": {"S3A_UTT": "40", "S3A_UTT_MANY": "2", "S3A_UTT_WIN": "0"},
+    "utt_5_win16": {"S3A_UTT": "5", "S3A_UTT_WIN": "16"},       # another window length than the lane count picks
 }
 
 
@@ -125,7 +129,9 @@ DRIVERS = {
                                          ("mode4_cibeam_ds2", "batched_6x2"), ("mode4_trigram", "utt_1"),
                                          ("mode4_trigram", "utt_4"), ("mode4_cibeam_ds2", "utt_4"),
                                          ("mode4_trigram", "utt_3_bigwl"), ("mode4_trigram", "utt_40"),
-                                         ("mode4_cibeam_ds2", "utt_8_engines2")])
+                                         ("mode4_cibeam_ds2", "utt_8_engines2"), ("mode4_cibeam_ds2", "utt_4_perframe"),
+                                         ("mode4_trigram", "utt_40_perframe"), ("mode4_cibeam_ds2", "utt_40_perframe"),
+                                         ("mode4_cibeam_ds2", "utt_5_win16"), ("mode4_cibeam_ds2", "utt_40")])
 def test_full_device_search_matches_reference(name, driver, tmp_path):
     hyp, seg, log = (str(tmp_path / f"tst_{name}.{e}") for e in ("match", "matchseg", "log"))
     with open(log, "w") as lf:
