@@ -1,39 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- full mode-4 DECODING throughput of the MI355X-native backend on the hub4-shaped CD-GMM task
-(BASELINE.json configs[3]: a batch of synthetic 10 s utterances, hub4 model, sharded over the GPUs).
+"""bench.py -- BASELINE.json configs[3] as written: a FIXED batch of 1024 distinct synthetic 10 s utterances, hub4-shaped
+CD-GMM model, full mode-4 decode, sharded over the GPUs of one node.
 
-A "step" = one batch of L utterances (L decoder lanes, default 512, split over E = 4 engines with a stream and a host
-thread each; 1000 frames = 10 s of 16 kHz audio per utterance) decoded from the first to the last frame on the device: CI + gated CD senone scoring (6144 senones x 8 Gaussians
-x 39), lextree HMM evaluation over three unigram + three filler lextrees of a 20 000-word dictionary, histogram
-and beam pruning, phone-level propagation, the word level (trigram look-ups, Viterbi history, word pruning, word
-transitions) -- s3a_uttdec_decode_dev, no host work inside an utterance -- then the hypothesis records
-(s3a_uttdec_hyp: final </s> transition + backtrace).  With the defaults (--steps 2, 512 lanes) the timed region
-decodes 1024 utterances per GPU.  Features are resident in HBM before the timed region; the history tables and
-hypotheses come back to the host inside it.  Arithmetic is the bit-exact mode (float32 subtract, float64
-accumulate, int32 log-add): the decoder's -hyp / -hypseg lines are checked against the unmodified reference
-decoder (CPU, same files) before timing.
+A "step" = one pass of the hot path over the batch: every utterance of the rank's share of the 1024-utterance control
+list (contiguous -ctloffset/-ctlcount style shards: shard.shard_contiguous; --scaling weak: every rank decodes a whole
+batch) is decoded from its first to its last frame on the device -- look-ahead senone scoring of all 6144 senones x 8
+Gaussians x 39 (one model pass per 8 frames of all lanes), the CI gate, lextree HMM evaluation over three unigram + three
+filler lextrees of a 20 000-word dictionary, histogram and beam pruning, phone-level propagation, the word level (trigram
+look-ups, Viterbi history, word pruning, word transitions): s3a_uttdec_decode_dev, no host work inside an utterance --
+then the hypotheses (s3a_uttdec_hyp_var: final </s> transition + backtrace) and ONE exchange of them across the ranks.
+Inside a rank the share is sorted by length and cut into groups of similar length (lanes run in lock step: a group lasts
+as long as its longest utterance), the groups are dealt to E engines (own stream + host thread each) whose launch tails
+overlap.  Features are resident in HBM before the timed region; history tables and hypotheses come back inside it.
+Arithmetic is the bit-exact mode (float32 subtract, float64 accumulate, int32 log-add).  After the timed region rank 0
+formats the LAST step's gathered hypotheses and compares every -hyp / -hypseg line with the unmodified reference
+decoder's (CPU, same files); a difference is an error, not a number.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: utterances shard embarrassingly: every rank decodes its own batches with a replicated
-model (weak scaling, no data-path collective); ONE all_gather (RCCL) of the fixed-size hypothesis records
-(s3a_hyp_record_t) closes the timed region, and rank 0 formats -hyp / -hypseg in utterance order.
-
 The decoder is rebuilt from a bundle (cmusphinx_amd/bundle.py) through the C ABI; the sphinx3 side of the drop-in
-(oracle/_ref/ref_s3amd_tst_decode = integration/sphinx3/s3amd_tst.c + the unmodified reference's kb_init) runs
-once, UNTIMED, to load the models / dictionary / LM, build the lextrees and write that bundle.
+(oracle/_ref/ref_s3amd_tst_decode = integration/sphinx3 + the unmodified reference's kb_init) runs once, UNTIMED, to load
+the models / dictionary / LM, build the lextrees and write that bundle.
 
 Prints ONE JSON line (rank 0).  Extra keys beyond the driver contract:
-  roofline      the dominant kernel of the timed pipeline (per-kernel HIP-event timing of a profiled batch of ONE engine):
-                achieved = algorithmic bytes per launch / average launch time vs the 8 TB/s HBM peak
+  roofline      the dominant kernel of a frame (per-kernel HIP-event timing of one profiled group of ONE engine; the
+                look-ahead scoring launch counted per frame it serves): achieved = algorithmic bytes (or flops) per launch
+                / average launch time; traffic = HBM bytes per launch from the committed PMC pass (profiles/)
   kernels       every kernel class of a frame: average microseconds per launch, share of the frame
-  cpu_baseline  the UNMODIFIED reference decoder (oracle/_ref/sphinx3_decode) on the same task and host: one
-                process, and P processes over disjoint control-file shards (P = physical cores, capped)
-  scoring       configs[1]: whole-utterance senone scoring (k_score_frames) and the frame-synchronous pass
-                (one model pass per frame; and 2 / 8 frames folded into one pass) on the hub4 and the configs[4]
-                (8000 x 32) model shapes
+  cpu_baseline  the UNMODIFIED reference decoder (oracle/_ref/sphinx3_decode) on the same task files: 16 processes (where
+                the host's aggregate peaks) over contiguous control-file shards of the batch's first 128 utterances, and
+                one process alone with stat.c's sen / search / tot split
+  strong_scaling_projection   what one GPU does with the 128 utterances an 8-GPU run gives it
+  scoring       configs[1]: whole-utterance senone scoring and the frame-synchronous pass (1 / 2 / 8 frames per model
+                pass) on the hub4 and the configs[4] (8000 x 32) model shapes, SURVEY 8(d) accounting
 """
 import argparse
 import json
@@ -53,6 +54,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VEC_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (FMA counted as 2 flops)
 REFDEC = os.path.join(ROOT, "oracle", "_ref", "sphinx3_decode")
 SHIM = os.path.join(ROOT, "oracle", "_ref", "ref_s3amd_tst_decode")
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # tools/pmc_traffic.py: HBM bytes per launch and kernel
 
 
 def physical_cores():
@@ -74,7 +76,7 @@ def physical_cores():
 
 
 def run_reference(task_args, ctl, offset, count, d, tag):
-    """the unmodified reference decoder on `count` utterances from `offset`; returns (hyp, hypseg, frames, xCPU, xClk)"""
+    """the unmodified reference decoder on `count` utterances from `offset` (a process, not waited for)"""
     args = list(task_args)
     args[args.index("-ctl") + 1] = ctl
     hyp, seg, log = (os.path.join(d, f"{tag}.{e}") for e in ("match", "seg", "log"))
@@ -84,44 +86,101 @@ def run_reference(task_args, ctl, offset, count, d, tag):
     return p, hyp, seg, log
 
 
+SUMMARY = re.compile(r"SUMMARY:\s+(\d+) fr;.*?([0-9.]+) xCPU\s+([0-9.]+) xClk \[Ovhrd.*?\];\s+(\d+) hmm/fr, \d+ wd/fr, ([0-9.]+) xCPU\s+([0-9.]+) xClk;"
+                     r"\s+tot:\s+([0-9.]+) xCPU,\s+([0-9.]+) xClk")
+
+
 def parse_summary(log):
-    m = re.search(r"SUMMARY:\s+(\d+) fr;.*?(\d+) hmm/fr.*tot:\s+([0-9.]+) xCPU,\s+([0-9.]+) xClk", open(log, errors="ignore").read())
-    return (int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))) if m else None
+    """stat.c:201-228 -> dict(frames, hmm, sen/search/tot xCPU and xClk)"""
+    m = SUMMARY.search(open(log, errors="ignore").read())
+    if not m:
+        return None
+    return dict(frames=int(m.group(1)), sen_xcpu=float(m.group(2)), sen_xclk=float(m.group(3)), hmm=int(m.group(4)),
+                srch_xcpu=float(m.group(5)), srch_xclk=float(m.group(6)), tot_xcpu=float(m.group(7)), tot_xclk=float(m.group(8)))
 
 
-def cpu_baseline(task, d, n_procs):
-    """sphinx3_decode on the identical files; 1 process (2 utterances), then n_procs processes over
-    disjoint control-file shards (1 utterance each), all at once."""
-    p, hyp, seg, log = run_reference(task["args"], task["ctl"], 0, 2, d, "cpu1")
-    p.wait()
-    one = parse_summary(log)
-    if p.returncode != 0 or not one:
-        return None, None
-    frames, hmm, xcpu, xclk = one
-    ps = [run_reference(task["args"], task["ctl"], 2 + i, 1, d, f"cpuN{i}") for i in range(n_procs)]
-    agg = 0.0
-    for q, _, _, lg in ps:
+def shards(n, parts):
+    base, extra = divmod(n, parts)
+    out, lo = [], 0
+    for r in range(parts):
+        c = base + (1 if r < extra else 0)
+        if c:
+            out.append((lo, c))
+        lo += c
+    return out
+
+
+def cpu_batch(targs, ctl, d, n_utt, n_procs, tag):
+    """the reference over utterances [0, n_utt) as n_procs concurrent processes on contiguous shards -> (aggregate
+    frames/s over the decoding time of the slowest process, summaries, hyp text, hypseg text)"""
+    ps = [run_reference(targs, ctl, lo, c, d, f"{tag}{i}") for i, (lo, c) in enumerate(shards(n_utt, n_procs))]
+    sums, hyp, seg = [], [], []
+    for q, h, s, lg in ps:
         q.wait()
-        s = parse_summary(lg)
-        if q.returncode == 0 and s:
-            agg += 100.0 / max(s[3], 1e-9)            # xClk = seconds of wall clock per second of audio
-    more = {}                                        # utterance index -> its (-hyp, -hypseg) line: extra checks of the gate
-    for i, (q, h2, s2, _) in enumerate(ps):
-        if q.returncode == 0 and os.path.exists(h2) and os.path.exists(s2):
-            more[2 + i] = (open(h2).read(), open(s2).read())
-    out = {"value": round(agg, 1), "unit": "frames/s", "cores": n_procs, "kind": "reference",
-           "single_core": round(100.0 / max(xcpu, 1e-9), 1), "single_core_xRT": round(1.0 / max(xcpu, 1e-9), 2),
-           "aggregate_xRT": round(agg / 100.0, 1), "physical_cores_on_host": physical_cores(),
-           "active_hmm_per_frame": hmm,
-           "sample": f"unmodified oracle/_ref/sphinx3_decode (gcc -O2), full mode-4 decode of the same task files: 2 utterances "
-                     f"({frames} frames) in one process for single_core (stat.c SUMMARY tot xCPU); value = {n_procs} processes "
-                     f"at once over disjoint -ctloffset/-ctlcount shards, 1 utterance (~10 s) each, summed 100/xClk; "
-                     f"model loading excluded (SUMMARY counts decoding only)"}
-    return out, (open(hyp).read(), open(seg).read(), more)
+        sm = parse_summary(lg)
+        if q.returncode != 0 or not sm:
+            return None
+        sums.append(sm)
+        hyp.append(open(h).read())
+        seg.append(open(s).read())
+    frames = sum(s["frames"] for s in sums)
+    wall = max(s["frames"] * s["tot_xclk"] / 100.0 for s in sums)          # seconds of decoding of the slowest shard
+    return frames / max(wall, 1e-9), sums, "".join(hyp), "".join(seg)
+
+
+def cpu_baseline(targs, ctl, d, n_utt, n_procs, check_all, physical_leg):
+    """sphinx3_decode on the identical files.  The reference is single-threaded, so N processes decode
+    contiguous control-file shards; this host does not scale to its core count (tools/cpu_scaling.py, profiles/: 16
+    processes 6.6 k frames/s, 32: 6.2 k, 64: 5.4 k, 128: 3.6 k -- every process streams the 15.7 MB model per frame), so
+    `value` is the best-N leg: n_procs (default 16) processes x 8 utterances of the batch, a bounded sample (~30 s).
+    single_core = one process alone.  --cpu-physical adds the N = physical-cores leg (one utterance each, ~2 min);
+    --check-all lets the reference decode the REST of the batch too (unmeasured, ~3 min) so that every utterance of the
+    device's output is compared."""
+    one = cpu_batch(targs, ctl, d, min(2, n_utt), 1, "cpu1_")
+    if not one:
+        return None, None
+    s1 = one[1][0]
+    n_smp = min(n_utt, 8 * n_procs)
+    big = cpu_batch(targs, ctl, d, n_smp, n_procs, "cpuN_")
+    if not big:
+        return None, None
+    hyp, seg, n_chk = big[2], big[3], n_smp
+    if check_all and n_smp < n_utt:
+        args2 = list(targs)
+        rest = [run_reference(targs, ctl, n_smp + lo, c, d, f"cpuR{i}_") for i, (lo, c) in enumerate(shards(n_utt - n_smp, n_procs))]
+        for q, h, sg, _ in rest:
+            q.wait()
+            if q.returncode != 0:
+                return None, None
+            hyp += open(h).read()
+            seg += open(sg).read()
+        n_chk = n_utt
+    out = {"value": round(big[0], 1), "unit": "frames/s", "cores": len(big[1]), "kind": "reference",
+           "physical_cores_on_host": physical_cores(), "aggregate_xRT": round(big[0] / 100.0, 1),
+           "per_core_in_batch": round(big[0] / len(big[1]), 1),
+           "single_core": round(100.0 / max(s1["tot_xcpu"], 1e-9), 1), "single_core_xRT": round(1.0 / max(s1["tot_xcpu"], 1e-9), 2),
+           "single_core_split_xCPU": {"sen": s1["sen_xcpu"], "search": s1["srch_xcpu"], "tot": s1["tot_xcpu"]},
+           "single_core_split_xClk": {"sen": s1["sen_xclk"], "search": s1["srch_xclk"], "tot": s1["tot_xclk"]},
+           "batch_split_xClk_mean": {k: round(float(np.mean([s[k + "_xclk"] for s in big[1]])), 3) for k in ("sen", "srch", "tot")},
+           "active_hmm_per_frame": s1["hmm"], "utterances": n_smp, "frames": sum(s["frames"] for s in big[1]),
+           "sample": f"unmodified oracle/_ref/sphinx3_decode (gcc -O2), full mode-4 decode of the same task files: value = the first "
+                     f"{n_smp} utterances of the batch as {len(big[1])} concurrent processes over contiguous -ctloffset/-ctlcount shards, "
+                     f"frames / decoding time of the slowest shard (stat.c SUMMARY xClk; model loading excluded); {len(big[1])} processes "
+                     f"is where this host's aggregate peaks (profiles/r3_cpu_scaling.txt: more processes decode FEWER frames/s); "
+                     f"single_core = one process alone on 2 utterances ({s1['frames']} frames), with stat.c's sen / search / tot split"}
+    if physical_leg:
+        pc = physical_cores()
+        phys = cpu_batch(targs, ctl, d, min(n_utt, pc), pc, "cpuP_")
+        if phys:
+            out["procs_physical_cores"] = {"procs": len(phys[1]), "value": round(phys[0], 1), "xRT": round(phys[0] / 100.0, 1),
+                                           "per_core": round(phys[0] / len(phys[1]), 1)}
+    return out, (hyp, seg, n_chk)
 
 
 def scoring_legs(lib, fast):
-    """configs[1] (+ the configs[4] model shape): senone scoring only, features and scores resident in HBM"""
+    """configs[1] (+ the configs[4] model shape): senone scoring only, features and scores resident in HBM.
+    SURVEY 8(d): algorithmic bytes of a launch = the Gaussians' parameters ONCE per model pass + per frame the vector in
+    and the scores out; 4 non-fusable flops per Gaussian-dimension."""
     from cmusphinx_amd import synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -143,7 +202,21 @@ def scoring_legs(lib, fast):
         assert (np.abs(got.astype(np.int64) - exp).max() <= 2) if fast else np.array_equal(got, exp), "HIP scores differ from the oracle"
         model_bytes = S * Cc * (2 * D + 2) * 4
         frame_bytes = D * 4 + S * 4
-        leg = {"shape": f"{S} senones x {Cc} Gaussians x {D}"}
+        flops_frame = 4.0 * S * Cc * D
+        leg = {"shape": f"{S} senones x {Cc} Gaussians x {D}", "model_bytes_per_pass": model_bytes, "bytes_per_frame": frame_bytes}
+
+        def entry(B, us, extra=None):
+            alg = model_bytes + B * frame_bytes
+            gbs = alg / (us * 1e-6) / 1e9
+            tfl = B * flops_frame / (us * 1e-6) / 1e12
+            e = {"frames_per_launch": B, "avg_launch_us": round(us, 3), "algorithmic_bytes_per_launch": alg,
+                 "hbm": {"achieved_GBs": round(gbs, 1), "peak_GBs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)},
+                 "valu": {"achieved_TFLOPs": round(tfl, 2), "peak_TFLOPs": FP64_VEC_PEAK_TFLOPS, "frac": round(tfl / FP64_VEC_PEAK_TFLOPS, 4)}}
+            e["bound"] = "hbm" if e["hbm"]["frac"] >= e["valu"]["frac"] else "valu-f64"
+            e["frac"] = max(e["hbm"]["frac"], e["valu"]["frac"])
+            if extra:
+                e.update(extra)
+            return e
         if name == "hub4":
             for _ in range(3):
                 gm.score_frames_dev(fd, T, sd, bd)
@@ -153,32 +226,11 @@ def scoring_legs(lib, fast):
             for _ in range(K):
                 gm.score_frames_dev(fd, T, sd, bd)
             k_us = gm.timer_end() / K
-            alg = model_bytes + T * frame_bytes
-            tfl = 4.0 * S * Cc * D * T / (k_us * 1e-6) / 1e12
-            leg["whole_utterance"] = {"kernel": "k_score_frames<8,exact,lds-table,512>", "frames_per_sec": round(T / (k_us * 1e-6), 1),
-                                      "avg_launch_us": round(k_us, 2), "algorithmic_bytes_per_launch": alg,
-                                      "achieved_GBs": round(alg / (k_us * 1e-6) / 1e9, 1),
-                                      "valu": {"bound": "valu-f64", "achieved": round(tfl, 2), "peak": FP64_VEC_PEAK_TFLOPS,
-                                               "unit": "TFLOP/s", "frac": round(tfl / FP64_VEC_PEAK_TFLOPS, 4)}}
-        gm.bench(fd, T, sd, None, 1, 1)
-        fs_us, fs_kus, fs_n = gm.bench(fd, T, sd, None, 1, 3)
-        fs_bytes = model_bytes + frame_bytes
-        leg["frame_sync"] = {"frames_per_launch": 1, "launches": fs_n, "avg_launch_us": round(fs_kus, 3),
-                             "frames_per_sec": round(T / (fs_us * 1e-6), 1), "algorithmic_bytes_per_launch": fs_bytes,
-                             "achieved_GBs": round(fs_bytes / (fs_kus * 1e-6) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
-                             "frac": round(fs_bytes / (fs_kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-        # B decoders' frames folded into ONE pass over the model (what the whole-utterance engine does from 8 lanes on:
-        # ku_gated_cd_multi; here the model-stationary scoring kernel with B frames per launch).  SURVEY 8(d)'s per-unit
-        # figure is per FRAME (a pass over the model + the frame's vector and scores), so `achieved` = B x that / time; the
-        # bytes that actually cross the HBM pins per launch are the model ONCE + B frames: hbm_GBs.
-        for B in (2, 8):
+            leg["whole_utterance"] = entry(T, k_us, {"kernel": "k_score_frames<8,exact,lds-table,512>", "frames_per_sec": round(T / (k_us * 1e-6), 1)})
+        for B in (1, 2, 8):
             gm.bench(fd, T, sd, None, B, 1)
             b_us, b_kus, b_n = gm.bench(fd, T, sd, None, B, 3)
-            leg[f"frame_sync_b{B}"] = {"frames_per_launch": B, "launches": b_n, "avg_launch_us": round(b_kus, 3),
-                                        "frames_per_sec": round(T / (b_us * 1e-6), 1), "algorithmic_bytes_per_launch": B * fs_bytes,
-                                        "achieved_GBs": round(B * fs_bytes / (b_kus * 1e-6) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
-                                        "frac": round(B * fs_bytes / (b_kus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                        "hbm_GBs": round((model_bytes + B * frame_bytes) / (b_kus * 1e-6) / 1e9, 1)}
+            leg["frame_sync" if B == 1 else f"frame_sync_b{B}"] = entry(B, b_kus, {"launches": b_n, "frames_per_sec": round(T / (b_us * 1e-6), 1)})
         out[name] = leg
         del gm, fd, sd, bd
     return out
@@ -189,12 +241,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--lanes", type=int, default=512, help="utterances decoded together per step and GPU")
+    ap.add_argument("--utts", type=int, default=1024, help="distinct synthetic utterances of the batch (configs[3]: 1024)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: the fixed batch is split over the ranks (configs[3] as written); weak: every rank decodes a whole batch")
+    ap.add_argument("--lanes", type=int, default=512, help="decoder lanes per GPU (utterances in flight)")
     ap.add_argument("--engines", type=int, default=4, help="decoder engines per GPU (own stream each) the lanes are split over")
-    ap.add_argument("--frames", type=int, default=1000, help="frames per utterance (10 s)")
-    ap.add_argument("--utts", type=int, default=64, help="distinct synthetic utterances (cycled)")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline aggregate leg (0 = physical cores, at most one per utterance of the task)")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--min-group", type=int, default=32, help="a rank's share is cut into groups of at least this many utterances")
+    ap.add_argument("--frames", type=int, default=1000, help="nominal frames per utterance (10 s)")
+    ap.add_argument("--cpu-procs", type=int, default=16, help="processes of the CPU baseline's batch leg (16: where this host's aggregate peaks)")
+    ap.add_argument("--no-cpu", action="store_true", help="no CPU baseline: the reference decodes (and checks) 2 utterances only")
+    ap.add_argument("--check-all", action="store_true", help="the reference decodes the WHOLE batch (~3 more minutes of CPU): every utterance is compared")
+    ap.add_argument("--cpu-physical", action="store_true", help="add the CPU leg with one process per physical core (~2 minutes)")
     ap.add_argument("--no-scoring", action="store_true", help="skip the scoring-only extra legs")
     ap.add_argument("--only-scoring", action="store_true", help="only the scoring legs (PMC passes over the scoring kernels)")
     ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
@@ -235,17 +292,18 @@ def main():
     tag = os.environ.get("MASTER_PORT", str(os.getpid()))
     d = os.path.join(tempfile.gettempdir(), f"s3a_bench_{tag}")
     bpath = os.path.join(d, "decoder.bundle")
+    t_setup = time.perf_counter()
     if rank == 0:
         os.makedirs(d, exist_ok=True)
-        task = synth_task.make_task(d, n_utt=U, n_frames=T, **synth_task.HUB4_TASK)
-        targs = synth_task.decoder_args(d)
-        r = subprocess.run([SHIM] + targs, env=dict(os.environ, S3A_UTT="1", S3A_EXPORT=bpath),
+        synth_task.make_task(d, n_utt=U, n_frames=T, **synth_task.HUB4_TASK)
+        r = subprocess.run([SHIM] + synth_task.decoder_args(d), env=dict(os.environ, S3A_UTT="1", S3A_EXPORT=bpath),
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         assert r.returncode == 0 and os.path.exists(bpath), "bundle export failed"
     if dist is not None:
         dist.barrier()
     targs = synth_task.decoder_args(d)
-    utts = [l.split()[0] for l in open(os.path.join(d, "ctl")) if l.strip()]
+    ctl = os.path.join(d, "ctl")
+    utts = [l.split()[0] for l in open(ctl) if l.strip()]
     hfeat = [s3io.read_mfc(os.path.join(d, "feat", u + ".mfc")) for u in utts]
     t_load = time.perf_counter()
     NE = max(1, args.engines)
@@ -255,10 +313,8 @@ def main():
                            max_frames=max(len(f) for f in hfeat) // 39 + 8) for _ in range(NE)]
     dec = decs[0]
     t_load = time.perf_counter() - t_load
-    pool = None
-    if NE > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(NE)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(NE)
     D4x4 = 4 * ((dec.veclen + 3) // 4)
     fdev, nfr = [], []
     for f in hfeat:
@@ -268,57 +324,55 @@ def main():
         fdev.append(lib.DevBuf(pad.nbytes).upload(pad))
         nfr.append(len(f))
 
-    def batch(i):           # utterance indices of step i of this rank
-        g0 = (rank * 1000003 + i * NL) % U
-        return [(g0 + z) % U for z in range(NL)]
+    # ---------------- the schedule: this rank's share, sorted by length, in groups of similar length ----------------
+    def schedule(ids):
+        """-> per engine the list of groups (utterance ids) it decodes one after the other.  Lanes run in lock step, so a
+        group lasts as long as its longest utterance: groups hold utterances of similar length; groups are dealt to the
+        engines longest first, to the engine with the least frames so far."""
+        order = sorted(ids, key=lambda k: (-nfr[k], k))
+        gsz = min(NLE, max(args.min_group, -(-len(order) // NE)))
+        groups = [order[i:i + gsz] for i in range(0, len(order), gsz)]
+        per, load = [[] for _ in range(NE)], [0] * NE
+        for g in groups:
+            e = min(range(NE), key=lambda k: (load[k], k))
+            per[e].append(g)
+            load[e] += nfr[g[0]]
+        return per
 
-    def run_step(i, recs=None, engines=None):
-        ids = batch(i)
+    def my_share(step):
+        if args.scaling == "strong":
+            return shard.shard_contiguous(U, rank, world), 0
+        return list(range(U)), rank * U              # weak: a whole batch per rank (record ids offset by the rank)
 
-        def one(e):         # engine e decodes its share of the step's utterances (the C calls release the GIL)
+    def run_step(step, recs=None, sched=None):
+        ids, base = my_share(step)
+        per = sched if sched is not None else schedule(ids)
+
+        def one(e):         # engine e decodes its groups one after the other (the C calls release the GIL)
             lib.check(L.s3a_set_device(local_rank))     # (HIP's current device is per host thread)
-            sub = ids[e * NLE:(e + 1) * NLE]
-            ms = decs[e].ud.decode_dev([fdev[k] for k in sub], [nfr[k] for k in sub], D4x4)
-            out = []
-            if recs is not None:
-                out = [decs[e].hyp(z, utts[k], (rank * args.steps + i) * NL + e * NLE + z) for z, k in enumerate(sub)]
+            ms, out = 0.0, []
+            for g in per[e]:
+                ms += decs[e].ud.decode_dev([fdev[k] for k in g], [nfr[k] for k in g], D4x4)
+                if recs is not None:
+                    out += [decs[e].hyp_var(z, utts[k], base + k) for z, k in enumerate(g)]
             return ms, out
-        es = range(NE) if engines is None else engines
-        done = list(pool.map(one, es)) if (pool is not None and len(es) > 1) else [one(e) for e in es]
+        done = list(pool.map(one, range(NE)))
         if recs is not None:
             for _, out in done:
                 recs.extend(out)
         return max(ms for ms, _ in done)
 
-    # ---------------- correctness gate + CPU baseline (rank 0, untimed) ----------------
-    cpu, ref_out = None, None
+    # ---------------- the reference (rank 0, untimed): CPU baseline + what the device's output is compared with ----------------
+    cpu, ref = None, None
     if rank == 0:
-        n_procs = args.cpu_procs or physical_cores()           # (capped below by the utterances the task has)
+        n_procs = max(1, args.cpu_procs)
         if args.no_cpu:
-            p, hyp, seg, log = run_reference(targs, os.path.join(d, "ctl"), 0, 2, d, "gate")
-            p.wait()
-            ref_out = (open(hyp).read(), open(seg).read(), {})
+            one = cpu_batch(targs, ctl, d, min(2, U), 1, "gate_")
+            ref = (one[2], one[3], min(2, U)) if one else None
         else:
-            cpu, ref_out = cpu_baseline({"args": targs, "ctl": os.path.join(d, "ctl")}, d, min(n_procs, max(1, U - 2)))
-        assert ref_out, "the reference decoder failed on the task"
-        got = []
-        for first in range(0, 2, min(NLE, 2)):           # the reference's two utterances (one lane: one after the other)
-            ids = list(range(first, first + min(NLE, 2))) + [(2 + z) % U for z in range(NLE - 2)]
-            dec.ud.decode_dev([fdev[k] for k in ids], [nfr[k] for k in ids], D4x4)
-            got += [dec.format(dec.hyp(z, utts[ids[z]], first + z)) for z in range(min(NLE, 2))]
-        assert "".join(g[0] for g in got) == ref_out[0] and ("".join(g[1] for g in got) == ref_out[1] or args.fast), \
-            "device hypotheses differ from the unmodified reference decoder's"
-        # ... and every utterance the CPU baseline's shard processes decoded (all of the task's distinct utterances)
-        n_checked = 2
-        todo = sorted(ref_out[2])
-        for k0 in range(0, len(todo), NLE):
-            ids = todo[k0:k0 + NLE]
-            dec.ud.decode_dev([fdev[k] for k in ids], [nfr[k] for k in ids], D4x4)
-            for z, k in enumerate(ids):
-                m_, s_ = dec.format(dec.hyp(z, utts[k], k))
-                assert m_ == ref_out[2][k][0] and (s_ == ref_out[2][k][1] or args.fast), \
-                    f"device hypothesis of utterance {k} differs from the unmodified reference decoder's"
-            n_checked += len(ids)
+            cpu, ref = cpu_baseline(targs, ctl, d, U, n_procs, args.check_all, args.cpu_physical)
+        assert ref, "the reference decoder failed on the task"
+    t_setup = time.perf_counter() - t_setup
 
     def sync_all():
         if dist is not None:
@@ -329,17 +383,16 @@ def main():
             torch.cuda.synchronize()
 
     # ---------------- the timed region ----------------
+    n_total = U if args.scaling == "strong" else U * world
     for i in range(args.warmup):
         run_step(i)
     sync_all()
-    recs, dev_ms = [], 0.0
+    dev_ms, allrec = 0.0, None
     t0 = time.perf_counter()
     for i in range(args.steps):
+        recs = []
         dev_ms += run_step(i, recs)
-    if dist is not None:
-        allrec = shard.gather_records(recs, world * args.steps * NL, dist, device=tdev)
-    else:
-        allrec = recs
+        allrec = shard.gather_var(recs, n_total, dist, device=tdev) if dist is not None else sorted(recs, key=lambda t: t[0].utt_index)
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -348,69 +401,133 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    weak = None
+    if world > 1 and args.scaling == "strong":
+        # the second figure: weak scaling, every rank a whole batch (one step)
+        args.scaling = "weak"
+        sync_all()
+        t1 = time.perf_counter()
+        wrecs = []
+        run_step(0, wrecs)
+        wall = shard.gather_var(wrecs, U * world, dist, device=tdev)
+        sync_all()
+        wdt = time.perf_counter() - t1
+        tw = torch.tensor([wdt], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        weak = {"value": round(sum(h.n_frames for h, _ in wall) / float(tw.item()), 1), "unit": "frames/s", "utterances": U * world,
+                "note": "every rank decodes the whole 1024-utterance batch (one step)"}
+        args.scaling = "strong"
+
     if rank == 0:
-        frames_total = sum(r.n_frames for r in allrec)
-        assert len(allrec) == world * args.steps * NL and all(r.status == 0 for r in allrec)
-        lines = shard.write_outputs(allrec, dec.format, os.path.join(d, "bench.match"), os.path.join(d, "bench.matchseg"))
-        value = frames_total / dt
-        # ---- per-kernel timing of one profiled batch (HIP events on the launch stream, every 4th frame) ----
+        assert len(allrec) == n_total and all(h.status == 0 for h, _ in allrec)
+        frames_step = sum(h.n_frames for h, _ in allrec)
+        value = frames_step * args.steps / dt
+        # ---- the gate: the LAST timed step's hypotheses, every line against the unmodified reference decoder's ----
+        lines = shard.write_outputs(allrec[:U], dec.format_var, os.path.join(d, "bench.match"), os.path.join(d, "bench.matchseg"))
+        n_chk = ref[2]
+        got_h, got_s = "".join(l[0] for l in lines[:n_chk]), "".join(l[1] for l in lines[:n_chk])
+        hyp_ok, seg_ok = got_h == ref[0], got_s == ref[1]
+        assert hyp_ok and (seg_ok or args.fast), "device hypotheses differ from the unmodified reference decoder's"
+
+        # ---- per-kernel timing of one profiled group (HIP events on the launch stream, every 4th frame) ----
+        sched = schedule(my_share(0)[0])
+        g0 = sched[0][0]
         dec.ud.set_profile(4)
-        run_step(0, engines=[0])
+        dec.ud.decode_dev([fdev[k] for k in g0], [nfr[k] for k in g0], D4x4)
         prof = dec.ud.profile()
         dec.ud.set_profile(0)
+        nl0 = len(g0)
+        stat = [dec.ud.result(z)["frame_stat"] for z in range(nl0)]
         res0 = dec.ud.result(0)
-        lanes_hmm = float(np.mean([dec.ud.result(z)["frame_stat"][:, 1].mean() for z in range(NLE)]))
-        lanes_sen = float(np.mean([dec.ud.result(z)["frame_stat"][:, 2].mean() for z in range(NLE)]))
-        lanes_gau = float(np.mean([dec.ud.result(z)["frame_stat"][:, 3].mean() for z in range(NLE)]))
-        lanes_exit = float(np.mean([dec.ud.result(z)["frame_stat"][:, 7].mean() for z in range(NLE)]))
-        tot = sum(us for us, _ in prof.values())
-        kern = {k: {"avg_launch_us": round(us / n, 2), "share": round(us / tot, 4)} for k, (us, n) in prof.items()}
-        dom = max(prof, key=lambda k: prof[k][0])
-        dom_us = prof[dom][0] / prof[dom][1]
+        lanes_hmm, lanes_sen, lanes_gau, lanes_exit = (float(np.mean([s[:, c].mean() for s in stat])) for c in (1, 2, 3, 7))
         b = dec.b
-        S, Sci, D = b["n_sen"], b["n_ci_sen"], dec.veclen
-        Cc = dec.g.C
-        # ALGORITHMIC bytes of one launch (all NL lanes' frame): SURVEY.md 8(d).  Scoring: the Gaussians' parameters once
-        # per model pass + per lane the feature vector in and the scored senones out; search kernels: ~84 B of HMM state
-        # read + written per active HMM; the word level: 40 B per history entry made + 16 B per (exit, predecessor) pair
-        alg = {
-            "ku_gated_cd": (S - Sci) * Cc * (2 * D + 2) * 4 + NLE * (D * 4 + lanes_sen * 4),
-            "ku_gated_ci": Sci * Cc * (2 * D + 2) * 4 + NLE * (D * 4 + Sci * 4),
-        }
-        for k in ("ku_hmm_eval", "ku_resolve", "ku_scan", "ku_emit", "ku_enter1", "ku_enter2", "ku_enter3_mark", "ku_hist_count", "ku_hist_sort", "ku_weak"):
-            alg[k] = NLE * lanes_hmm * 84.0
-        alg["ku_wordlevel"] = NLE * (res0["max_cand"] * 16.0 + res0["max_new"] * 40.0)
-        alg["ku_emit_word"] = alg["ku_emit"] + alg["ku_wordlevel"]      # the emission sweep and the word level share a launch
-        alg.setdefault(dom, NLE * lanes_hmm * 84.0)
-        ach = alg[dom] / (dom_us * 1e-6) / 1e9
+        S, Sci, D, Cc = b["n_sen"], b["n_ci_sen"], dec.veclen, dec.g.C
+        K = max(1, dec.ud.window())
+        per_frame = {k: (us / n / (K if k == "ku_score_window" else 1)) for k, (us, n) in prof.items()}
+        tot = sum(per_frame.values())
+        kern = {k: {"avg_launch_us": round(prof[k][0] / prof[k][1], 2), "us_per_frame": round(v, 2), "share": round(v / tot, 4)}
+                for k, v in per_frame.items()}
+        dom = max(per_frame, key=lambda k: per_frame[k])
+        dom_us = prof[dom][0] / prof[dom][1]
+        # ALGORITHMIC bytes of one launch (all lanes of the engine): SURVEY.md 8(d).  Look-ahead scoring: the Gaussians'
+        # parameters once per model pass + per (lane, frame) the vector in and every senone's score (+ 1 byte: its best
+        # component) out; search kernels: ~84 B of HMM state read + written per active HMM; the word level: 40 B per
+        # history entry made + 16 B per (exit, predecessor) pair
+        win_slots = nl0 * K
+        alg = {"ku_score_window": S * Cc * (2 * D + 2) * 4 + win_slots * (D * 4 + S * 5),
+               "ku_gated_cd": nl0 * (S * 1 + lanes_sen * 13.0), "ku_gated_ci": nl0 * 4.0 * b["n_comstate"],
+               "ku_comsen_max": nl0 * 4.0 * b["n_comstate"]}
+        for k in ("ku_hmm_eval", "ku_resolve", "ku_scan", "ku_emit", "ku_enter1", "ku_enter2", "ku_enter3_mark", "ku_hist_count",
+                  "ku_hist_sort", "ku_weak"):
+            alg[k] = nl0 * lanes_hmm * 84.0
+        alg["ku_emit_word"] = alg["ku_emit"] + nl0 * (res0["max_cand"] * 16.0 + res0["max_new"] * 40.0)
+        alg.setdefault(dom, nl0 * lanes_hmm * 84.0)
+        pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else {}
+        traffic = pmc.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+        if dom == "ku_score_window":
+            flops = 4.0 * S * Cc * D * win_slots
+            ach = flops / (dom_us * 1e-6) / 1e12
+            roof = {"kernel": dom, "bound": "valu-f64", "achieved": round(ach, 2), "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP64_VEC_PEAK_TFLOPS, 4),
+                    "hbm_GBs": round(alg[dom] / (dom_us * 1e-6) / 1e9, 1), "hbm_frac": round(alg[dom] / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        else:
+            ach = alg[dom] / (dom_us * 1e-6) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5)}
+        roof.update({"traffic": traffic, "traffic_source": pmc.get("source") if traffic is not None else None,
+                     "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_us": round(dom_us, 2), "launches_timed": int(prof[dom][1]),
+                     "lanes_in_launch": nl0,
+                     "note": "per-launch HIP-event timing of every 4th frame of one group of one engine running alone; one launch "
+                             "serves all lanes' frame (ku_score_window: all lanes' next K frames).  The search kernels are chains of "
+                             "scattered 4-byte accesses over a few thousand HMMs per lane: latency-bound, nowhere near a bandwidth "
+                             "roof (DESIGN.md 4); the scoring is float64-VALU-bound (bit-exact mode: no FMA)"})
+
+        # ---- what N = 8 gives a GPU: 128 of the 1024 utterances ----
+        proj = None
+        if world == 1 and U >= 8:
+            ids8 = shard.shard_contiguous(U, 0, 8)
+            sch8 = schedule(ids8)
+            run_step(0, sched=sch8)
+            lib.check(L.s3a_dev_sync())
+            t8 = time.perf_counter()
+            run_step(0, recs=[], sched=sch8)
+            lib.check(L.s3a_dev_sync())
+            t8 = time.perf_counter() - t8
+            f8 = sum(nfr[k] for k in ids8)
+            proj = {"gpus": 8, "utterances_per_gpu": len(ids8), "groups": [len(g) for e in sch8 for g in e],
+                    "frames_per_sec_per_gpu": round(f8 / t8, 1), "implied_strong_scaling_efficiency": round(f8 / t8 / value, 3),
+                    "note": "one GPU decoding rank 0's share of an 8-rank run of the same batch (hypotheses included, no gather): "
+                            "fewer lanes in flight per GPU fill the chip less"}
+
         res = {
             "metric": "decoded_frames_per_sec (full mode-4 decode, hub4-shaped CD-GMM 6144x8x39 + 20k-word lextrees + trigram; xRT = value/100/n_gpus)",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32-sub/f64-acc/int32-logadd (bit-exact), int32 Viterbi + word level" if not args.fast else "f32 scoring (+-2 logs3), int32 search",
-            "data": f"synthetic (seeded hub4-shaped model, dictionary, ARPA trigram; {U} distinct 10 s utterances sampled from the model "
-                    "along LM sentences, cycled; real hub4 parameters are not in the reference checkout)",
-            "config": {"workload": f"configs[3]: batch of synthetic 10 s utterances, hub4_cd_continuous shape, full decode (senone scoring + "
-                                   f"lextree Viterbi + trigram word level on the device), {args.steps * NL} utterances per GPU "
-                                   f"({NL} lanes x {args.steps} steps)",
-                       "frames_per_utterance": T, "utterances_per_step_per_gpu": NL, "lanes": NL, "engines": NE,
+            "data": f"synthetic (seeded hub4-shaped model, dictionary, ARPA trigram; {U} DISTINCT ~10 s utterances sampled from the model "
+                    "along LM sentences; real hub4 parameters are not in the reference checkout); features resident in HBM before the "
+                    "timed region (the CPU baseline reads its feature files)",
+            "config": {"workload": f"configs[3]: batch of {U} synthetic 10 s utterances, hub4_cd_continuous shape, full decode (senone "
+                                   f"scoring + lextree Viterbi + trigram word level on the device), sharded over {world} GPU(s); a step = "
+                                   f"the whole batch once" + (" per rank" if args.scaling == "weak" else ""),
+                       "utterances_per_step": n_total, "frames_per_step": frames_step, "lanes_per_gpu": NL, "engines_per_gpu": NE,
+                       "groups_rank0": [len(g) for e in sched for g in e],
                        "beams": "-beam 1e-60 -wbeam 1e-35 -maxhmmpf 20000 -maxwpf 10 -lw 9.5 (the reference's hub4 settings)",
-                       "parallelism": f"utterance-sharded x{world}, one all_gather of s3a_hyp_record_t ({shard.REC_BYTES} B per utterance)"},
+                       "parallelism": f"utterance-sharded x{world} ({args.scaling}), two collectives per batch: headers, then the words "
+                                      f"padded per rank (no word limit)"},
             "xRT_per_gpu": round(value / world / 100.0, 1),
             "device_ms_per_step": round(dev_ms / args.steps, 3),
-            "identical_to_reference": True, "utterances_checked_against_reference": n_checked,
-            "load_s": round(t_load, 2),
+            "identical_to_reference": {"hyp": hyp_ok, "hypseg": seg_ok}, "utterances_checked_against_reference": n_chk,
+            "load_s": round(t_load, 2), "setup_s": round(t_setup, 1),
             "per_frame": {"active_hmm": round(lanes_hmm, 1), "cd_senones_scored": round(lanes_sen, 1), "cd_gaussians": round(lanes_gau, 1),
                           "word_exits": round(lanes_exit, 2), "max_candidates": int(res0["max_cand"]), "tie_frames_lane0": int(res0["n_tie_frames"])},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(alg[dom]),
-                         "avg_launch_us": round(dom_us, 2), "launches_timed": int(prof[dom][1]),
-                         "note": "per-launch HIP-event timing of every 4th frame of one batch; one launch serves all lanes' frame. "
-                                 "The frame is a chain of ~13 latency-bound launches over a few thousand HMMs per lane: no kernel "
-                                 "of it is near a bandwidth roof (see kernels and DESIGN.md 4); the HBM-bound regime of the "
-                                 "scoring is scoring.*.frame_sync"},
+            "roofline": roof,
             "kernels": kern,
         }
+        if weak:
+            res["weak_scaling"] = weak
+        if proj:
+            res["strong_scaling_projection"] = proj
         if cpu:
             res["cpu_baseline"] = cpu
         if world == 1 and not args.no_scoring:

@@ -1786,6 +1786,12 @@ s3a_uttdec_n_lanes(const s3a_uttdec_t *ud)
     return ud ? ud->n_lanes : 0;
 }
 
+extern "C" int32_t
+s3a_uttdec_window(const s3a_uttdec_t *ud)
+{
+    return ud ? ud->S.win_K : 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* the word level on its own (parity tests: frame by frame against the oracle) */
 /* ------------------------------------------------------------------ */

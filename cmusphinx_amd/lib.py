@@ -188,6 +188,7 @@ _SIGS = {
     "s3a_uttdec_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_wl_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
+    "s3a_uttdec_window": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_set_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
     "s3a_uttdec_profile": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_shape": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_int32)] * 6),
@@ -1305,6 +1306,9 @@ class UttDec:
         rec = HypRecord()
         check(self.L.s3a_uttdec_hyp(self.h, lane, uttid.encode(), int(utt_index), C.byref(rec)), self.L)
         return rec
+
+    def window(self):
+        return int(self.L.s3a_uttdec_window(self.h))
 
     def hyp_var(self, lane, uttid="", utt_index=0):
         """-> (HypHeader, words int32 [n_words, 6]: wid sf ef ascr lscr scale), however long the hypothesis is"""

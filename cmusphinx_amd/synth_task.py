@@ -176,13 +176,15 @@ def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frame
         rc = sil if rc >= n_reg else rc
         return tri_states.get((ph, lc, rc, wp), [3 * ph, 3 * ph + 1, 3 * ph + 2])
 
+    cum_mixw = np.cumsum(mixw / mixw.sum(axis=1, keepdims=True), axis=1)
+    sd = np.sqrt(var) * noise
+
     def emit(sen, tm, out):
+        """one pass through the phone's emitting states: geometric durations, a mixture component per frame"""
         for s in range(N_EMIT):
             dur = int(rng.geometric(1.0 - tmat[tm, s, s]))
-            for _ in range(dur):
-                k = int(rng.choice(n_comp, p=mixw[sen[s]] / mixw[sen[s]].sum()))
-                out.append(mean[sen[s], k] + rng.standard_normal(VECLEN).astype(np.float32)
-                           * np.sqrt(var[sen[s], k]) * noise)
+            k = np.minimum((rng.random(dur)[:, None] >= cum_mixw[sen[s]][None, :]).sum(axis=1), n_comp - 1)
+            out.append(mean[sen[s], k] + rng.standard_normal((dur, VECLEN)).astype(np.float32) * sd[sen[s], k])
 
     truth, ctl = [], []
     for u in range(n_utt):
@@ -209,7 +211,7 @@ def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frame
             lc = phones[j - 1][0] if j > 0 else sil
             rc = phones[j + 1][0] if j + 1 < len(phones) else sil
             emit(states_of(ph, lc, rc, wp), ph, frames)
-        x = np.asarray(frames, np.float32)
+        x = np.concatenate(frames).astype(np.float32)
         name = f"utt{u:04d}"
         with open(os.path.join(dirpath, "feat", name + ".mfc"), "wb") as f:
             np.array([x.size], "<i4").tofile(f)

@@ -699,6 +699,9 @@ int32_t s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out)
  * [6] pruning, [7] table + LM contexts, [8] word transitions) */
 int32_t s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16);
 int32_t s3a_uttdec_n_lanes(const s3a_uttdec_t *ud);
+/* frames per look-ahead scoring window (one pass over the acoustic model scores every senone of the next K frames of
+ * all lanes; approx_cont_mgau_frame_eval's gate is then applied per frame); 0: per-frame scoring kernels */
+int32_t s3a_uttdec_window(const s3a_uttdec_t *ud);
 /*
  * The hypothesis of a finished lane as a fixed-size record -- what one utterance contributes to the end-of-batch
  * gather when the control file is sharded over GPUs ({uttid, words, sf/ef, ascr, lscr, score,

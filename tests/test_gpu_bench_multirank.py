@@ -15,20 +15,38 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_share_the_gpu_and_gather_their_hypotheses(tmp_path):
+def run_bench(tmp_path, port, extra):
     env = dict(os.environ, S3A_BENCH_ONE_GPU="1", TMPDIR=str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--lanes", "6", "--engines", "2", "--frames", "150", "--utts", "10", "--no-cpu", "--no-scoring"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--lanes", "6", "--engines", "2", "--min-group", "2", "--frames", "150", "--utts", "10", "--no-scoring"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, errors="ignore", timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]                # rank 0 only
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["identical_to_reference"] is True
-    assert d["config"]["lanes"] == 6 and d["config"]["engines"] == 2
-    # 2 ranks x 2 steps x 6 lanes utterances (the task's sentences run a little past the nominal 150 frames), all of
-    # them gathered on rank 0: value x time = the frames of BOTH ranks
+    return json.loads(lines[0])
+
+
+def test_two_ranks_split_the_fixed_batch_and_gather_their_hypotheses(tmp_path):
+    """strong scaling (configs[3] as written): ONE 10-utterance control list, rank r decodes its contiguous shard
+    (shard.shard_contiguous = -ctloffset/-ctlcount) inside the timed region, the hypotheses cross the ranks in two
+    collectives (headers, then the padded words), and rank 0 compares EVERY utterance of the batch -- both ranks' --
+    with the unmodified reference decoder run over the whole list (the CPU baseline's batch leg, 3 processes)."""
+    d = run_bench(tmp_path, 29541, ["--cpu-procs", "3"])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
+    assert d["identical_to_reference"] == {"hyp": True, "hypseg": True} and d["utterances_checked_against_reference"] == 10
+    assert d["config"]["utterances_per_step"] == 10 and d["config"]["lanes_per_gpu"] == 6 and d["config"]["engines_per_gpu"] == 2
+    assert sum(d["config"]["groups_rank0"]) == 5             # rank 0's share of the 10
+    # value x time = the frames of the whole batch, once per step
     frames = d["value"] * d["ms_per_step"] * 1e-3 * d["steps"]
-    assert 2 * 2 * 6 * 100 < frames < 2 * 2 * 6 * 400
-    assert "roofline" in d and "kernels" in d
+    assert abs(frames - 2 * d["config"]["frames_per_step"]) < 1e-3 * frames and 10 * 100 < d["config"]["frames_per_step"] < 10 * 400
+    assert d["cpu_baseline"]["cores"] == 3 and d["cpu_baseline"]["utterances"] == 10        # (3 processes x 8 >= the batch)
+    assert set(d["cpu_baseline"]["single_core_split_xCPU"]) == {"sen", "search", "tot"}
+    assert d["weak_scaling"]["utterances"] == 20 and d["weak_scaling"]["value"] > 0
+    assert d["roofline"]["frac"] <= 1.0 and "kernels" in d
+
+
+def test_two_ranks_weak_scaling(tmp_path):
+    d = run_bench(tmp_path, 29543, ["--scaling", "weak", "--no-cpu"])
+    assert d["scaling"] == "weak" and d["config"]["utterances_per_step"] == 20
+    assert d["identical_to_reference"]["hyp"] is True and d["utterances_checked_against_reference"] == 2
