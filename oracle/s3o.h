@@ -254,6 +254,31 @@ int32_t s3o_vithist_utt_end(s3o_vithist_t *vh, const s3o_lm3g_t *lm, const s3o_w
 int32_t s3o_vithist_backtrace(const s3o_vithist_t *vh, int32_t id, int32_t *ids, int32_t max_ids);
 
 /* ------------------------------------------------------------------ */
+/* the second pass (s3o_dag.c): word lattice from the history table,    */
+/* filler bypass, best path under the trigram                           */
+/* libsearch/vithist.c:1100-1311, dag.c:186-300, 397-484, 590-671,      */
+/* 893-965, 1037-1075, srch_time_switch_tree.c:1391-1440                */
+/* ------------------------------------------------------------------ */
+typedef struct s3o_dagcfg_s {
+    int32_t n_word;
+    const int32_t *basewid;     /* dict_basewid */
+    const uint8_t *is_filler;   /* dict_filler_word (0 for <s> / </s>) */
+    const int32_t *lwid;        /* lm->dict2lmwid[w] */
+    const int32_t *fillpen;     /* fillpen(fpen, w) of the filler words */
+    int32_t startwid, finishwid, start_lwid, finish_lwid;
+    int32_t wip;                /* logs3(fpen->wip) */
+    double lwf;                 /* -bestpathlw / -lw (1.0 when -bestpathlw is 0) */
+    int32_t min_endfr, maxedge, maxlmop, maxlpf;
+} s3o_dagcfg_t;
+/* history table incl. the final </s> entry (endid); hyp_* = the first pass's words (kept whatever their duration);
+ * out = [5][max_out]: wid sf ef ascr lscr; returns the number of words, -1: no path / limits, -2: out too small;
+ * stats[5] (optional): nodes kept, links built, links after the bypass, bypass links, LM operations */
+int32_t s3o_dag_bestpath(const s3o_dagcfg_t *c, const s3o_lm3g_t *lm, int32_t n_entry, const int32_t *wid,
+                         const int32_t *sf, const int32_t *ef, const int32_t *ascr, const int32_t *lscr,
+                         const int32_t *score, const uint8_t *valid, int32_t n_frm, int32_t endid, int32_t n_hyp,
+                         const int32_t *hyp_wid, const int32_t *hyp_sf, int32_t *out, int32_t max_out, int32_t *stats);
+
+/* ------------------------------------------------------------------ */
 /* multi-stream senone scorer (-senmgau .s3cont. / .semi.)             */
 /* sphinx3 libam/ms_gauden.c, ms_senone.c, ms_mgau.c                   */
 /* ------------------------------------------------------------------ */
