@@ -17,7 +17,8 @@ from . import lib
 
 CFG_INTS = ["wbeam_vh", "bghist", "maxwpf", "maxhistpf", "wordend_beam", "n_lextree", "epl", "hmmbeam", "pbeam", "wbeam",
             "ptranskip", "maxhmmpf", "ds", "cond_ds", "maxcdsenpf", "hypsegscore_unscale"]
-CFG_DBL = ["logbase", "varfloor", "mixwfloor", "ci_pbeam", "tighten_factor", "lw", "wip"]
+CFG_DBL = ["logbase", "varfloor", "mixwfloor", "ci_pbeam", "tighten_factor", "lw", "wip", "bestpathlw"]
+CFG_DAG = ["min_endfr", "maxedge", "maxlmop", "maxlpf", "wip_logs3", "bestpath"]
 TREE = {11: "ssid", 12: "tmatid", 13: "composite", 14: "wid", 15: "prob", 16: "child_off", 17: "child", 18: "lc",
         19: "lcroot_off", 20: "lcroot", 21: "root"}
 STATIC = {2: "tp", 3: "sseq", 4: "comsseq", 5: "comstate_off", 6: "comstate", 7: "comwt", 8: "cd2cisen",
@@ -63,6 +64,9 @@ def read(path):
         elif tag == 51:
             for k, v in zip(CFG_DBL, d.view("<f8")):
                 b[k] = float(v)
+        elif tag == 55:
+            for k, v in zip(CFG_DAG, d):
+                b[k] = int(v)
         elif tag in (52, 53, 54):
             b[{52: "mean", 53: "var", 54: "mixw"}[tag]] = _cstr(d)
     b["trees"] = trees
@@ -72,7 +76,8 @@ def read(path):
 class Decoder:
     """bundle -> s3a_uttdec_t with n_lanes lanes (and what formatting a hypothesis needs)"""
 
-    def __init__(self, bundle, n_lanes, precision=lib.GMM_EXACT, vh_cap=0, cand_cap=0, max_frames=15000):
+    def __init__(self, bundle, n_lanes, precision=lib.GMM_EXACT, vh_cap=0, cand_cap=0, max_frames=15000, bestpath=False,
+                 keep_tables=True, link_cap=0, pair_cap=0, bestpathlw=None):
         b = self.b = read(bundle) if isinstance(bundle, str) else bundle
         ne = b["n_emit"]
         self.logmath = lib.LogMath(b["logbase"])
@@ -93,6 +98,11 @@ class Decoder:
                              cond_ds=b["cond_ds"], ci_pbeam=b["ci_pbeam"], tighten_factor=b["tighten_factor"],
                              max_cd=b["maxcdsenpf"], max_frames=max_frames, vh_cap=vh_cap, cand_cap=cand_cap)
         self.n_lanes = n_lanes
+        self.dag_cfg = None
+        if bestpath:
+            # the second pass behind every decode: lattice + best path on the device
+            self.dag_cfg = lib.dag_cfg(b, self._keep, bestpathlw=bestpathlw)
+            self.ud.enable_bestpath(self.dag_cfg, link_cap, pair_cap, keep_tables)
         self.veclen = b["veclen"]
         ws = [w.encode() for w in b["words"]]
         self._wordstr = (C.c_char_p * len(ws))(*ws)
@@ -108,6 +118,10 @@ class Decoder:
 
     def hyp_var(self, lane, uttid="", utt_index=0):
         return self.ud.hyp_var(lane, uttid, utt_index)
+
+    def bestpath_hyp(self, lane, uttid="", utt_index=0):
+        """the second pass's hypothesis: (HypHeader, words)"""
+        return self.ud.bestpath_hyp(lane, uttid, utt_index)
 
     def format_var(self, hdr, words):
         """the same from a header + words pair (no word limit)"""

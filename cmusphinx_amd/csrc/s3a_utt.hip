@@ -33,6 +33,8 @@
 #include "s3a_decoder_kernels.h"
 #include "s3a_gated.h"
 #include "s3a_wordlevel.h"
+#include "s3a_lm3g.h"
+#include "s3a_dag.h"
 
 /* one lane: the lextree state of a clone, a private scorer state, its history table */
 struct ULane {
@@ -879,11 +881,6 @@ ku_fill32(int32_t *p, int32_t v, size_t n)
 /* ------------------------------------------------------------------ */
 /* host side                                                           */
 /* ------------------------------------------------------------------ */
-struct s3a_lm3g_s {
-    WLm d;                      /* device arrays */
-    int32_t n_dictword;
-    std::vector<int32_t> ug_prob, ug_bowt, ug_firstbg, bg_wid, bg_prob, bg_bowt, bg_firsttg, tg_wid, tg_prob, inclass;
-};
 
 #define DM(ptr, bytes) do { if (hipMalloc((void **)&(ptr), (bytes) > 0 ? (bytes) : 4) != hipSuccess) { \
         s3a_set_error("s3a_utt: device allocation of %zu bytes failed", (size_t)(bytes)); goto fail; } } while (0)
@@ -1033,6 +1030,9 @@ struct s3a_uttdec_s {
     hipEvent_t ev0, ev1;        /* around the frames of a decode (last_decode_ms) */
     int32_t no_multi, gy;       /* tuning switches, read ONCE at init (S3A_UTT_NO_MULTI, S3A_UTT_GY; tests) */
     int32_t win_fpc;            /* S3A_UTT_WIN_FPC: slots per chunk of the look-ahead scoring (0: the cost model's) */
+    s3a_dagpass_t *dag;         /* the second pass after every decode (s3a_uttdec_enable_bestpath), or NULL */
+    int32_t keep_tables;        /* 0: with the second pass enabled the history tables stay on the device */
+    int32_t tables_fetched;
 };
 
 static int32_t
@@ -1115,6 +1115,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.sc) s3a_scorer_free(hl.sc);
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
+    if (ud->dag) s3a_dagpass_free(ud->dag);
     if (ud->ev0) (void)hipEventDestroy(ud->ev0);
     if (ud->ev1) (void)hipEventDestroy(ud->ev1);
     if (ud->d_lanes) (void)hipFree(ud->d_lanes);
@@ -1158,7 +1159,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
     ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
-    ud->device = 0; ud->ev0 = ud->ev1 = NULL;
+    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0;
     (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
@@ -1695,6 +1696,8 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
     for (int32_t f = 0; f < maxT && rc == S3A_OK; f++)
         rc = enqueue_frame(ud, n_utt, f, ud->prof_every > 0 && f % ud->prof_every == 0);
     if (rc == S3A_OK && hipEventRecord(ud->ev1, ud->stream) != hipSuccess) rc = S3A_EHIP;
+    /* the second pass: vithist_utt_end + lattice + best path for every lane, behind the last frame on the same stream */
+    if (rc == S3A_OK && ud->dag) rc = s3a_dagpass_enqueue(ud->dag, n_utt, ud->stream, 1);
     for (int32_t z = 0; z < n_utt && rc == S3A_OK; z++) rc = lane_fetch_state(ud, z);
     if (hipStreamSynchronize(ud->stream) != hipSuccess && rc == S3A_OK) { s3a_set_error("s3a_uttdec_decode: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
     if (rc == S3A_OK) {
@@ -1712,7 +1715,10 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
         for (int32_t z = 0; z < n_utt; z++) ud->lane[z].dirty = 1;      /* nothing is known about the lanes' state */
         return rc;
     }
-    for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_table(ud, z)) != S3A_OK) return rc;
+    ud->tables_fetched = (!ud->dag || ud->keep_tables) ? 1 : 0;
+    if (ud->tables_fetched)
+        for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_table(ud, z)) != S3A_OK) return rc;
+    if (ud->dag && (rc = s3a_dagpass_finish(ud->dag, n_utt, ud->stream)) != S3A_OK) return rc;
     HIPCHK(hipStreamSynchronize(ud->stream));
     ud->n_utt = n_utt;
     /* EVERY lane that stopped in mid-frame starts its next utterance from scratch (a capacity overflow usually hits several
@@ -1751,6 +1757,7 @@ extern "C" int32_t
 s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out)
 {
     if (!ud || !out || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
+    if (!ud->tables_fetched) { s3a_set_error("s3a_uttdec_result: the history tables were left on the device (s3a_uttdec_enable_bestpath, keep_tables = 0)"); return S3A_EUNSUP; }
     const HostLane &hl = ud->lane[lane];
     const int32_t n = hl.n_entry, nf = hl.nfr + 2;
     const int32_t *t = hl.h_tab;
@@ -1771,6 +1778,66 @@ s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16)
 {
     if (!ud || !out16 || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
     for (int i = 0; i < 16; i++) out16[i] = ud->lane[lane].h_ctx->tacc[i];
+    return S3A_OK;
+}
+
+/* ---- the second pass behind every decode ---- */
+extern "C" int32_t
+s3a_uttdec_enable_bestpath(s3a_uttdec_t *ud, const s3a_dag_cfg_t *cfg, int32_t link_cap, int32_t pair_cap, int32_t keep_tables)
+{
+    if (!ud || !cfg) return S3A_EINVAL;
+    HIPCHK(hipSetDevice(ud->device));
+    if (ud->dag) { s3a_dagpass_free(ud->dag); ud->dag = NULL; }
+    ud->dag = s3a_dagpass_init(ud->lm, cfg, ud->n_lanes, ud->vh_cap, ud->max_frames, link_cap, pair_cap);
+    if (!ud->dag) return S3A_ENOMEM;
+    for (int32_t z = 0; z < ud->n_lanes; z++) {
+        const WLane &w = ud->lane[z].d.w;
+        DagTab t;
+        t.score = w.score; t.pred = w.pred; t.lw0 = w.lw0; t.lw1 = w.lw1; t.wid = w.wid; t.sf = w.sf; t.ef = w.ef; t.ascr = w.ascr;
+        t.lscr = w.lscr; t.type = w.type; t.frame_start = w.frame_start; t.st = w.st; t.cap = w.cap;
+        s3a_dagpass_bind(ud->dag, z, t);
+    }
+    ud->keep_tables = keep_tables ? 1 : 0;
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_uttdec_bestpath_result(s3a_uttdec_t *ud, int32_t lane, s3a_dag_result_t *out)
+{
+    if (!ud || !ud->dag || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
+    return s3a_dagpass_result(ud->dag, lane, out);
+}
+
+extern "C" int32_t
+s3a_uttdec_bestpath_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index, s3a_hyp_header_t *hdr,
+                        s3a_hyp_word_t *words, int32_t max_words)
+{
+    if (!ud || !ud->dag || !hdr || lane < 0 || lane >= ud->n_utt || max_words < 0 || (max_words > 0 && !words)) return S3A_EINVAL;
+    const HostLane &hl = ud->lane[lane];
+    s3a_dag_result_t r;
+    int32_t rc = s3a_dagpass_result(ud->dag, lane, &r);
+    if (rc != S3A_OK) return rc;
+    memset(hdr, 0, sizeof *hdr);
+    if (uttid) strncpy(hdr->uttid, uttid, sizeof hdr->uttid - 1);
+    hdr->utt_index = utt_index; hdr->n_frames = hl.nfr; hdr->n_entry = r.n_entry; hdr->exit_id = r.endid; hdr->score = r.score;
+    for (int32_t f = 0; f < hl.nfr; f++) hdr->total_scale = h_add(hdr->total_scale, hl.h_fstat[8 * f]);
+    if (hl.h_ctx->err) { hdr->status = -1; return S3A_OK; }
+    if (r.status == DG_E_NOEXIT) { hdr->status = -2; return S3A_OK; }
+    if (r.status == DG_E_NOPATH) { hdr->status = -4; return S3A_OK; }     /* "Bestpath search failed": the reference writes no line */
+    if (r.status != 0) {
+        s3a_set_error("s3a_uttdec_bestpath_hyp: the second pass of lane %d stopped with status %d (3: a capacity of the pass or "
+                      "-maxedge, 4: inconsistent table, 5: positive bypass edge)", lane, r.status);
+        return r.status == DG_E_CAP ? S3A_ENOMEM : S3A_EUNSUP;
+    }
+    hdr->n_words = r.n_words;
+    if (r.n_words > max_words) { hdr->status = -3; return S3A_OK; }
+    for (int32_t q = 0; q < r.n_words; q++) {
+        s3a_hyp_word_t &w = words[q];
+        w.wid = r.wid[q]; w.sf = r.sf[q]; w.ef = r.ef[q]; w.ascr = r.ascr[q]; w.lscr = r.lscr[q];
+        int32_t sc = 0;
+        for (int32_t i = w.sf; i < w.ef && i < hl.nfr; i++) if (i >= 0) sc = h_add(sc, hl.h_fstat[8 * i]);
+        w.scale = sc;
+    }
     return S3A_OK;
 }
 

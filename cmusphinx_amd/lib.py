@@ -189,6 +189,13 @@ _SIGS = {
     "s3a_uttdec_wl_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_window": (C.c_int32, [C.c_void_p]),
+    "s3a_dagpass_init": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "s3a_dagpass_free": (None, [C.c_void_p]),
+    "s3a_dagpass_run_tables": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_dagpass_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_uttdec_enable_bestpath": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "s3a_uttdec_bestpath_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_uttdec_bestpath_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_set_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
     "s3a_uttdec_profile": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_shape": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_int32)] * 6),
@@ -1238,6 +1245,85 @@ class HypHeader(C.Structure):
                [(k, C.c_int32) for k in ("utt_index", "n_words", "n_frames", "score", "total_scale", "n_entry", "status", "exit_id")]
 
 
+class DagCfg(C.Structure):
+    """s3a_dag_cfg_t"""
+    _fields_ = [("n_word", C.c_int32), ("basewid", C.c_void_p), ("is_filler", C.c_void_p), ("lwid", C.c_void_p), ("fillpen", C.c_void_p)] + \
+               [(k, C.c_int32) for k in ("startwid", "finishwid", "silwid", "start_lwid", "finish_lwid", "wip")] + [("lwf", C.c_double)] + \
+               [(k, C.c_int32) for k in ("min_endfr", "maxedge", "maxlmop", "maxlpf")]
+
+
+class DagResult(C.Structure):
+    """s3a_dag_result_t"""
+    _fields_ = [(k, C.c_int32) for k in ("status", "n_words", "n_node", "n_link", "n_bypass", "lmop", "score", "first_pass_score", "n_entry", "endid")] + \
+               [(k, C.POINTER(C.c_int32)) for k in ("wid", "sf", "ef", "ascr", "lscr")]
+
+    def words(self):
+        n = self.n_words
+        return np.stack([np.ctypeslib.as_array(getattr(self, k), (n,)).copy() if n else np.zeros(0, np.int32)
+                         for k in ("wid", "sf", "ef", "ascr", "lscr")], axis=1) if n else np.zeros((0, 5), np.int32)
+
+
+class DagTable(C.Structure):
+    """s3a_dag_table_t"""
+    _fields_ = [(k, C.c_int32) for k in ("n_entry", "n_frm", "endid", "n_hyp")] + \
+               [(k, C.c_void_p) for k in ("wid", "sf", "ef", "ascr", "lscr", "score", "hyp_wid", "hyp_sf")]
+
+
+def dag_cfg(b, keep, bestpathlw=None, min_endfr=None, maxedge=None, maxlmop=None, maxlpf=None):
+    """s3a_dag_cfg_t from a bundle dict (cmusphinx_amd/bundle.py); `keep` collects the arrays the struct points into"""
+    c = DagCfg()
+    arrs = [np.ascontiguousarray(b["basewid"], np.int32), np.ascontiguousarray(b["is_filler"], np.uint8),
+            np.ascontiguousarray(b["lwid"], np.int32), np.ascontiguousarray(b["fillpen"], np.int32)]
+    keep.extend(arrs)
+    c.n_word = b["n_word"]
+    c.basewid, c.is_filler, c.lwid, c.fillpen = (a.ctypes.data for a in arrs)
+    for k in ("startwid", "finishwid", "silwid", "start_lwid", "finish_lwid"):
+        setattr(c, k, b[k])
+    c.wip = b.get("wip_logs3", 0)
+    lw = bestpathlw if bestpathlw is not None else b.get("bestpathlw", 0.0)
+    c.lwf = float(np.float32(lw) / np.float32(b["lw"])) if lw else 1.0
+    c.min_endfr = b.get("min_endfr", 3) if min_endfr is None else min_endfr
+    c.maxedge = b.get("maxedge", 2000000) if maxedge is None else maxedge
+    c.maxlmop = b.get("maxlmop", 100000000) if maxlmop is None else maxlmop
+    c.maxlpf = b.get("maxlpf", 40000) if maxlpf is None else maxlpf
+    return c
+
+
+class DagPass:
+    """s3a_dagpass_t on host-provided history tables (parity tests)"""
+
+    def __init__(self, lm: "Lm3g", cfg: DagCfg, n_lanes, max_entries, max_frames, link_cap=0, pair_cap=0):
+        self.L = load()
+        self._keep = (lm, cfg)
+        self.h = self.L.s3a_dagpass_init(lm.h, C.byref(cfg), int(n_lanes), int(max_entries), int(max_frames), int(link_cap), int(pair_cap))
+        if not self.h:
+            raise S3AError(_err(self.L))
+
+    def run(self, tables):
+        """tables: list of dicts with wid sf ef ascr lscr score (int32 arrays incl. the final </s> entry), n_frm, endid,
+        hyp_wid, hyp_sf -> list of DagResult"""
+        arr = (DagTable * len(tables))()
+        keep = []
+        for t, d in zip(arr, tables):
+            a = {k: np.ascontiguousarray(d[k], np.int32) for k in ("wid", "sf", "ef", "ascr", "lscr", "score", "hyp_wid", "hyp_sf")}
+            keep.append(a)
+            t.n_entry, t.n_frm, t.endid, t.n_hyp = len(a["wid"]), int(d["n_frm"]), int(d["endid"]), len(a["hyp_wid"])
+            for k, v in a.items():
+                setattr(t, k, v.ctypes.data)
+        check(self.L.s3a_dagpass_run_tables(self.h, len(tables), arr), self.L)
+        out = []
+        for z in range(len(tables)):
+            r = DagResult()
+            check(self.L.s3a_dagpass_result(self.h, z, C.byref(r)), self.L)
+            out.append(r)
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_dagpass_free(self.h)
+            self.h = None
+
+
 class UttResult(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("err", "n_entry", "n_frm", "n_frames")] + \
                [(k, C.POINTER(C.c_int32)) for k in ("score", "pred", "lw0", "lw1", "wid", "sf", "ef", "ascr", "lscr", "type",
@@ -1309,6 +1395,25 @@ class UttDec:
 
     def window(self):
         return int(self.L.s3a_uttdec_window(self.h))
+
+    def enable_bestpath(self, cfg, link_cap=0, pair_cap=0, keep_tables=True):
+        self._dag_cfg = cfg
+        check(self.L.s3a_uttdec_enable_bestpath(self.h, C.byref(cfg), int(link_cap), int(pair_cap), 1 if keep_tables else 0), self.L)
+
+    def bestpath_result(self, lane):
+        r = DagResult()
+        check(self.L.s3a_uttdec_bestpath_result(self.h, int(lane), C.byref(r)), self.L)
+        return r
+
+    def bestpath_hyp(self, lane, uttid="", utt_index=0):
+        """the second pass's hypothesis: (HypHeader, words int32 [n_words, 6])"""
+        hdr = HypHeader()
+        words = np.zeros((HYP_MAXW, 6), np.int32)
+        check(self.L.s3a_uttdec_bestpath_hyp(self.h, lane, uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
+        if hdr.status == -3:
+            words = np.zeros((hdr.n_words, 6), np.int32)
+            check(self.L.s3a_uttdec_bestpath_hyp(self.h, lane, uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
+        return hdr, words[:hdr.n_words if hdr.status == 0 else 0].copy()
 
     def hyp_var(self, lane, uttid="", utt_index=0):
         """-> (HypHeader, words int32 [n_words, 6]: wid sf ef ascr lscr scale), however long the hypothesis is"""

@@ -757,6 +757,57 @@ int32_t s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int
                          int32_t max_entries, int32_t *frames, int32_t max_out_frames,
                          int32_t *n_tie_frames);
 
+/* ===================================================================== */
+/* the second pass: lattice from the Viterbi history, best path under the trigram          */
+/* ===================================================================== */
+/*
+ * vithist_dag_build (libsearch/vithist.c:1100-1311), dag_bypass_filler_nodes (dag.c:1037-1075), dag_search /
+ * dag_bestpath (dag.c:893-965, 397-484), dag_backtrace (dag.c:590-671) as srch_TST_bestpath_impl drives them
+ * (srch_time_switch_tree.c:1391-1440), one workgroup per utterance, all lanes at once.  cfg: per dictionary word
+ * basewid (dict_basewid), is_filler (dict_filler_word), lwid (lm->dict2lmwid), fillpen (fillpen() of the filler words);
+ * wip = logs3(fillpen_t.wip); lwf = -bestpathlw / -lw (1.0 when -bestpathlw is 0); min_endfr / maxedge / maxlmop /
+ * maxlpf = the reference's arguments of those names.  Capacities: max_entries history entries per utterance (the
+ * final </s> / silence entries included), link_cap lattice links, pair_cap filler-bypass links.
+ */
+typedef struct s3a_dagpass_s s3a_dagpass_t;
+typedef struct {
+    int32_t n_word;
+    const int32_t *basewid;
+    const uint8_t *is_filler;
+    const int32_t *lwid, *fillpen;
+    int32_t startwid, finishwid, silwid, start_lwid, finish_lwid, wip;
+    double lwf;
+    int32_t min_endfr, maxedge, maxlmop, maxlpf;
+} s3a_dag_cfg_t;
+/* status: 0 ok; 1 no word exit; 2 "Bestpath search failed" (no path / LM operation limit: the reference writes no line);
+ * 3 a capacity or -maxedge exceeded; 4 inconsistent table; 5 positive bypass edge (unsupported) */
+typedef struct {
+    int32_t status, n_words, n_node, n_link, n_bypass, lmop, score, first_pass_score, n_entry, endid;
+    const int32_t *wid, *sf, *ef, *ascr, *lscr;     /* [n_words], utterance order; owned by the pass until its next run */
+} s3a_dag_result_t;
+/* a finished history table handed over from the host (parity tests; the engine binds its device tables itself):
+ * n_entry entries INCLUDING vithist_utt_end's final </s> entry (endid), n_frm frames, the first pass's hypothesis */
+typedef struct {
+    int32_t n_entry, n_frm, endid, n_hyp;
+    const int32_t *wid, *sf, *ef, *ascr, *lscr, *score, *hyp_wid, *hyp_sf;
+} s3a_dag_table_t;
+s3a_dagpass_t *s3a_dagpass_init(s3a_lm3g_t *lm, const s3a_dag_cfg_t *cfg, int32_t n_lanes, int32_t max_entries,
+                                int32_t max_frames, int32_t link_cap, int32_t pair_cap);
+void s3a_dagpass_free(s3a_dagpass_t *dp);
+int32_t s3a_dagpass_run_tables(s3a_dagpass_t *dp, int32_t n_utt, const s3a_dag_table_t *tabs);
+int32_t s3a_dagpass_result(const s3a_dagpass_t *dp, int32_t lane, s3a_dag_result_t *out);
+/* the whole-utterance engine with the second pass: after the frames of every s3a_uttdec_decode* the lanes' tables go
+ * through vithist_utt_end and the pass ON THE DEVICE; keep_tables = 0: the history tables are not read back at all
+ * (s3a_uttdec_result / s3a_uttdec_hyp then fail; the hypotheses come from s3a_uttdec_bestpath_hyp).
+ * s3a_uttdec_bestpath_hyp: the second pass's hypothesis of a lane as header + words (scale = the frame normalisers
+ * over [sf, ef), as in s3a_uttdec_hyp); status 0 ok, -1 decode error, -2 no word exit, -4 bestpath failed (the
+ * reference writes no line then), -3 max_words too small. */
+int32_t s3a_uttdec_enable_bestpath(s3a_uttdec_t *ud, const s3a_dag_cfg_t *cfg, int32_t link_cap, int32_t pair_cap,
+                                   int32_t keep_tables);
+int32_t s3a_uttdec_bestpath_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index,
+                                s3a_hyp_header_t *hdr, s3a_hyp_word_t *words, int32_t max_words);
+int32_t s3a_uttdec_bestpath_result(s3a_uttdec_t *ud, int32_t lane, s3a_dag_result_t *out);
+
 double s3a_uttdec_last_decode_ms(const s3a_uttdec_t *ud);    /* HIP-event time of the last decode's frames */
 /* per-kernel timing for roofline arithmetic: every `every`-th frame of the following decodes is bracketed,
  * launch by launch, by HIP events on the launch stream (0 = off, resets the totals); s3a_uttdec_profile

@@ -46,6 +46,7 @@
 #include "dict2pid.h"
 #include "lextree.h"
 #include "vithist.h"
+#include "dag.h"
 
 #ifdef LT_ORACLE
 #include "s3o.h"
@@ -973,6 +974,45 @@ utt_end_slot(void *srch)                /* srch_TST_end, :514-560 */
     return (s->exit_id >= 0) ? SRCH_SUCCESS : SRCH_FAILURE;
 }
 
+/* -bestpath 1 in utt mode: the SECOND PASS ran on the device behind the utterance's last frame (s3a_uttdec_enable_bestpath:
+ * vithist_utt_end, lattice, filler bypass, best path, backtrace); the two slots srch_utt_end calls for it
+ * (srch.c:519-530 gen_dag, :609-640 bestpath_impl) hand the result over.  S3A_UTT_HOSTDAG=1: the reference's own
+ * vithist_dag_build / dag_search on the table the device produced (the comparison run). */
+static int g_dev_dag;
+static long g_dag_utts;
+static __thread int32 g_cur_lane;
+static dag_t *
+utt_gen_dag_slot(void *srch, glist_t hyp)
+{
+    srch_t *s = srch;
+    dag_t *dag = ckd_calloc(1, sizeof(*dag));           /* an empty lattice: srch_utt_end only tests the pointer */
+    (void)hyp;
+    dag_init(dag, kbcore_config(s->kbc), kbcore_logmath(s->kbc));
+    return dag;
+}
+static glist_t
+utt_bestpath_slot(void *srch, dag_t *dag)
+{
+    srch_t *s = srch;
+    dict_t *dict = kbcore_dict(s->kbc);
+    s3a_dag_result_t r;
+    glist_t rhyp = NULL;
+    int32 i;
+    (void)dag;
+    if (s3a_uttdec_bestpath_result(g_uds[g_cur_lane / g_lpe], g_cur_lane % g_lpe, &r) != S3A_OK) die("bestpath result");
+    if (r.status == 2) { E_ERROR("Bestpath search failed for %s\n", s->uttid); return NULL; }
+    if (r.status != 0) E_FATAL("tst shim: the device's second pass stopped with status %d: %s\n", r.status, s3a_last_error());
+    E_INFO("tst shim: second pass on the device: %s: %d entries -> %d nodes, %d links (+%d bypass), %d LM operations, %d words\n",
+           s->uttid, r.n_entry, r.n_node, r.n_link, r.n_bypass, r.lmop, r.n_words);
+    for (i = 0; i < r.n_words; i++) {
+        srch_hyp_t *h = (srch_hyp_t *)ckd_calloc(1, sizeof(srch_hyp_t));
+        h->id = r.wid[i]; h->word = dict_wordstr(dict, h->id); h->sf = r.sf[i]; h->ef = r.ef[i]; h->ascr = r.ascr[i]; h->lscr = r.lscr[i];
+        rhyp = glist_add_ptr(rhyp, (void *)h);
+    }
+    g_dag_utts++;
+    return glist_reverse(rhyp);
+}
+
 static void
 utt_finish(kb_t *kb, int32 z)
 {
@@ -1017,6 +1057,7 @@ utt_finish(kb_t *kb, int32 z)
     g_tie_frames += r.n_tie_frames;
     vithist_fill(tstg->vithist, r.n_entry, r.n_frm, r.score, r.pred, r.lw0, r.lw1, r.wid, r.sf, r.ef, r.ascr, r.lscr,
                  r.type, r.frame_start, r.bestscore, r.bestvh, kbcore_lm(kb->kbcore));
+    g_cur_lane = z;
     utt_end(kb);                                /* srch_utt_end -> utt_end_slot, gen_hyp, match_write ... */
     st->tot_fr += st->nfr;
     ckd_free(q->uttid); ckd_free(q->uttfile); ckd_free(q->feat);
@@ -1216,8 +1257,11 @@ export_bundle(const char *path, kb_t *kb, srch_TST_graph_t *tstg, wl_flat_t *w, 
         double dd[8] = { cmd_ln_float64_r(config, "-logbase"), cmd_ln_float32_r(config, "-varfloor"),
                          cmd_ln_float32_r(config, "-mixwfloor"), cmd_ln_float64_r(config, "-ci_pbeam"),
                          cmd_ln_float32_r(config, "-tighten_factor"), (double)kbcore_lm(kbc)->lw,
-                         (double)kbcore_lm(kbc)->wip, 0.0 };
-        xw(50, 16, c); xw(51, 16, dd);
+                         (double)kbcore_lm(kbc)->wip, (double)cmd_ln_float32_r(config, "-bestpathlw") };
+        int32 dg[6] = { cmd_ln_int32_r(config, "-min_endfr"), cmd_ln_int32_r(config, "-maxedge"), cmd_ln_int32_r(config, "-maxlmop"),
+                        cmd_ln_int32_r(config, "-maxlpf"), logs3(kbcore_logmath(kbc), kbcore_fillpen(kbc)->wip),
+                        cmd_ln_boolean_r(config, "-bestpath") ? 1 : 0 };
+        xw(50, 16, c); xw(51, 16, dd); xw(55, 6, dg);
         xwstr(52, cmd_ln_str_r(config, "-mean")); xwstr(53, cmd_ln_str_r(config, "-var")); xwstr(54, cmd_ln_str_r(config, "-mixw"));
     }
     fclose(g_xfp);
@@ -1285,6 +1329,23 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
                            g_lm3g, &cfg, g_lpe, S3_MAX_FRAMES, getenv("S3A_UTT_VHCAP") ? atoi(getenv("S3A_UTT_VHCAP")) : 0,
                            getenv("S3A_UTT_CANDCAP") ? atoi(getenv("S3A_UTT_CANDCAP")) : 0);
             if (!g_uds[e]) die("s3a_uttdec_init");
+            if (cmd_ln_boolean_r(config, "-bestpath") && !getenv("S3A_UTT_HOSTDAG")) {
+                s3a_dag_cfg_t dc;
+                float32 bplw = cmd_ln_float32_r(config, "-bestpathlw");
+                int32 *base = ckd_calloc(w->n_word + 1, 4), i;
+                for (i = 0; i < w->n_word; i++) base[i] = dict_basewid(kbcore_dict(kbc), i);
+                memset(&dc, 0, sizeof dc);
+                dc.n_word = w->n_word; dc.basewid = base; dc.is_filler = w->is_filler; dc.lwid = w->lwid; dc.fillpen = w->fillpen;
+                dc.startwid = w->startwid; dc.finishwid = w->finishwid; dc.silwid = w->silwid; dc.start_lwid = w->start_lwid;
+                dc.finish_lwid = w->finish_lwid; dc.wip = logs3(kbcore_logmath(kbc), kbcore_fillpen(kbc)->wip);
+                dc.lwf = bplw ? (bplw / cmd_ln_float32_r(config, "-lw")) : 1.0;
+                dc.min_endfr = cmd_ln_int32_r(config, "-min_endfr"); dc.maxedge = cmd_ln_int32_r(config, "-maxedge");
+                dc.maxlmop = cmd_ln_int32_r(config, "-maxlmop"); dc.maxlpf = cmd_ln_int32_r(config, "-maxlpf");
+                if (s3a_uttdec_enable_bestpath(g_uds[e], &dc, getenv("S3A_DAG_LINKS") ? atoi(getenv("S3A_DAG_LINKS")) : 0,
+                                               getenv("S3A_DAG_PAIRS") ? atoi(getenv("S3A_DAG_PAIRS")) : 0, 1) != S3A_OK) die("s3a_uttdec_enable_bestpath");
+                ckd_free(base);
+                g_dev_dag = 1;
+            }
         }
         g_ud = g_uds[0];
         if (g_n_eng > 1) {              /* the engines' host threads */
@@ -1305,6 +1366,7 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     if (!g_ud) die("s3a_uttdec_init");
     s->funcs->utt_begin = utt_begin_slot;
     s->funcs->utt_end = utt_end_slot;
+    if (g_dev_dag) { s->funcs->gen_dag = utt_gen_dag_slot; s->funcs->bestpath_impl = utt_bestpath_slot; }
     g_uq_cap = n_lanes;
     g_uq = ckd_calloc(n_lanes, sizeof(*g_uq));
     g_ukb = &kb;
@@ -1320,6 +1382,7 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     E_INFO("tst shim: %ld frames searched by the replacement backend in %d lane(s), whole utterances on the device\n",
            g_frames, n_lanes);
     E_INFO("tst shim: histogram pruning (lextree_hmm_histbin) applied in %ld frames\n", g_histframes);
+    if (g_dev_dag) E_INFO("tst shim: second pass (lattice + best path) of %ld utterances served by the device\n", g_dag_utts);
     E_INFO("tst shim utt mode: word level: at most %ld candidates and %ld new history entries in a frame; "
            "%ld frames replayed the reference's heap (tied scores)\n", g_max_cand, g_max_new, g_tie_frames);
     if (getenv("S3A_UTT_TICKS")) {

@@ -85,6 +85,18 @@ odag_bestpath_impl(void *srch, dag_t *dag)
     out = ckd_calloc(5 * (n + 8), 4);
     nw = s3o_dag_bestpath(&c, &olm, n, wid, sf, ef, ascr, lscr, score, valid, vh->n_frm, s->exit_id, nh, hw, hs, out, n + 8, stats);
     for (d = dag->list; d; d = d->alloc_next) nnode++;
+    if (getenv("S3O_DAGDUMP")) {
+        /* fixture for the device tests: {tag, n, n x int32} records: the table the second pass read, what it produced */
+        FILE *fp = fopen(getenv("S3O_DAGDUMP"), "ab");
+        int32 hdr[8] = { n, vh->n_frm, s->exit_id, nh, nw, stats[0], stats[1], stats[3] }, tag, cnt;
+        const int32 *arrs[8] = { wid, sf, ef, ascr, lscr, score, hw, hs };
+        if (!fp) E_FATAL("cannot append to %s\n", getenv("S3O_DAGDUMP"));
+        tag = 1; cnt = 8; fwrite(&tag, 4, 1, fp); fwrite(&cnt, 4, 1, fp); fwrite(hdr, 4, 8, fp);
+        for (i = 0; i < 8; i++) { tag = 10 + i; cnt = i < 6 ? n : nh; fwrite(&tag, 4, 1, fp); fwrite(&cnt, 4, 1, fp); fwrite(arrs[i], 4, cnt, fp); }
+        tag = 20; cnt = 1; fwrite(&tag, 4, 1, fp); fwrite(&cnt, 4, 1, fp); fwrite(&stats[4], 4, 1, fp);
+        for (i = 0; i < 5; i++) { tag = 30 + i; cnt = nw > 0 ? nw : 0; fwrite(&tag, 4, 1, fp); fwrite(&cnt, 4, 1, fp); if (cnt) fwrite(out + (size_t)i * (n + 8), 4, cnt, fp); }
+        fclose(fp);
+    }
     if (stats[0] != nnode || stats[1] != dag->nlink)
         E_FATAL("dag oracle: lattice of %d nodes / %d links, the reference's dag_t has %d / %d\n", stats[0], stats[1], nnode, dag->nlink);
     E_INFO("dag oracle: %s: %d entries -> %d nodes, %d links (+%d bypass), %d LM operations, %d words\n", s->uttid, n, stats[0],

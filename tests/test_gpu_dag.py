@@ -1,0 +1,143 @@
+"""The second pass on the device (MI355X): lattice from the Viterbi history, filler bypass, best path
+under the trigram, backtrace -- s3a_dagpass_* / s3a_uttdec_enable_bestpath.
+
+(a) recorded history tables of the REFERENCE (tests/golden/dag_tables.npz, written by tests/golden/make_dag_golden.py
+    from oracle/_ref/ref_s3odag_decode): the device's words (wid, sf, ef, ascr, lscr), lattice sizes and LM-operation
+    counts against the pinned restatement's, tidigits (31 utterances, two option sets) and RM1 (real 997-word trigram;
+    -min_endfr 0; a tight -maxlpf under which some searches must FAIL exactly where the reference's do);
+(b) whole decodes: the drop-in with -bestpath 1 (utt mode: first pass, vithist_utt_end and second pass all on the device)
+    writes the unmodified reference's -hyp / -hypseg; the same through the C ABI alone with the history tables never
+    read back (keep_tables = 0).
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cmusphinx_amd import bundle, lib, s3io
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+D = os.path.join(GOLDEN, "tidigits_decode")
+AM = os.path.join(GOLDEN, "tidigits")
+RM = os.path.join(ROOT, "tests", "_local_data", "rm1")
+TST = os.path.join(ROOT, "oracle", "_ref", "ref_s3amd_tst_decode")
+REFDEC = os.path.join(ROOT, "oracle", "_ref", "sphinx3_decode")
+OVERRIDES = {"tidigits": {}, "tidigits_lw14_minendfr1": {"bestpathlw": 14.0, "min_endfr": 1}, "rm1": {}, "rm1_minendfr0": {"min_endfr": 0},
+             "rm1_maxlpf5": {"maxlpf": 5}}
+
+
+def tidigits_args():
+    return ["-dict", f"{D}/dictionary", "-fdict", f"{D}/fillerdict", "-hmm", AM, "-cepdir", f"{D}/cepstra", "-agc", "none",
+            "-varnorm", "no", "-cmn", "current", "-lw", "9.5", "-ctl", f"{D}/tidigits.length.arb.regression", "-op_mode", "4",
+            "-lm", f"{D}/tidigits.DMP"]
+
+
+def rm_args(n=20):
+    return ["-mdef", f"{RM}/mdef", "-fdict", f"{RM}/fillerdict", "-dict", f"{RM}/RM.dictionary", "-mean", f"{RM}/means",
+            "-var", f"{RM}/variances", "-mixw", f"{RM}/mixture_weights", "-tmat", f"{RM}/transition_matrices",
+            "-agc", "none", "-varnorm", "no", "-cmn", "current", "-epl", "4", "-fillprob", "0.02", "-maxwpf", "10",
+            "-wip", "0.2", "-lm", f"{RM}/RM.2845.trigram.arpa.DMP", "-lw", "14", "-beam", "1e-140", "-wbeam", "1e-100",
+            "-cepdir", f"{RM}/feat", "-cepext", ".mfc", "-ctl", f"{RM}/rm.ctl", "-ctlcount", str(n), "-op_mode", "4"]
+
+
+def export(args, path):
+    for p in (TST,):
+        if not os.path.exists(p):
+            pytest.fail(f"{p} is missing on the GPU box (make -C oracle ref)")
+    r = subprocess.run([TST] + args, env=dict(os.environ, S3A_UTT="1", S3A_EXPORT=path), stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=600)
+    assert r.returncode == 0 and os.path.getsize(path) > 1000
+    return bundle.read(path)
+
+
+@pytest.fixture(scope="module")
+def bundles(tmp_path_factory):
+    d = tmp_path_factory.mktemp("dagb")
+    out = {"tidigits": export(tidigits_args(), str(d / "t.bundle"))}
+    if not os.path.isdir(RM):
+        pytest.fail(f"{RM} is missing on the GPU box (tools/fetch_local_data.sh)")
+    out["rm1"] = export(rm_args(), str(d / "r.bundle"))
+    return out
+
+
+@pytest.mark.parametrize("case", list(OVERRIDES))
+def test_device_second_pass_on_recorded_reference_tables(gpu_lib, bundles, case):
+    G = np.load(os.path.join(GOLDEN, "dag_tables.npz"))
+    b = bundles["tidigits" if case.startswith("tidigits") else "rm1"]
+    n_utt = int(G[f"{case}.n"][0])
+    tabs = []
+    for k in range(n_utt):
+        hdr = G[f"{case}.{k}.hdr"]
+        tabs.append({key: G[f"{case}.{k}.{key}"] for key in ("wid", "sf", "ef", "ascr", "lscr", "score", "hyp_wid", "hyp_sf")}
+                    | {"n_frm": int(hdr[1]), "endid": int(hdr[2])})
+    keep = []
+    cfg = gpu_lib.dag_cfg(b, keep, **OVERRIDES[case])
+    lm = gpu_lib.Lm3g(dict(b, wbeam=b["wbeam_vh"]))
+    dp = gpu_lib.DagPass(lm, cfg, n_utt, max(len(t["wid"]) for t in tabs), max(t["n_frm"] for t in tabs) + 2, link_cap=1 << 17, pair_cap=1 << 14)
+    res = dp.run(tabs)
+    n_fail = 0
+    for k, r in enumerate(res):
+        hdr = G[f"{case}.{k}.hdr"]
+        nw = int(hdr[4])
+        assert (r.n_node, r.n_link, r.n_bypass) == (int(hdr[5]), int(hdr[6]), int(hdr[7])), (case, k, r.status)
+        if nw < 0:                      # the reference's search gave up (LM operation limit): so must the device's
+            assert r.status == 2 and r.n_words == 0, (case, k, r.status)
+            n_fail += 1
+            continue
+        assert r.status == 0, (case, k, r.status)
+        assert r.lmop == int(G[f"{case}.{k}.lmop"][0]), (case, k)
+        exp = np.stack([G[f"{case}.{k}.o_{key}"] for key in ("wid", "sf", "ef", "ascr", "lscr")], axis=1)
+        assert np.array_equal(r.words(), exp), (case, k)
+    assert (n_fail > 0) == (case == "rm1_maxlpf5")
+
+
+def run(exe, args, tmp_path, tag, env=None):
+    hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
+    with open(log, "w") as lf:
+        p = subprocess.run([exe] + args + ["-hyp", hyp, "-hypseg", seg], stdout=lf, stderr=subprocess.STDOUT, timeout=1200, env=env)
+    txt = open(log, errors="ignore").read()
+    assert p.returncode == 0, "\n".join(l for l in txt.splitlines() if "FATAL" in l or "tst shim" in l)[-2000:]
+    return open(hyp).read(), open(seg).read(), txt
+
+
+@pytest.mark.parametrize("task,lanes,extra", [("tidigits", "5", []), ("tidigits", "1", ["-bestpathlw", "14", "-min_endfr", "1"]),
+                                               ("rm1", "7", []), ("rm1", "33", ["-maxlpf", "5"])])
+def test_dropin_with_both_passes_on_the_device(task, lanes, extra, tmp_path):
+    args = (tidigits_args() if task == "tidigits" else rm_args()) + ["-bestpath", "1"] + extra
+    ref = run(REFDEC, args, tmp_path, "ref")
+    gpu = run(TST, args, tmp_path, "gpu", env=dict(os.environ, S3A_UTT=lanes))
+    assert "second pass (lattice + best path) of" in gpu[2] and "served by the device" in gpu[2]
+    assert gpu[0] == ref[0] and gpu[1] == ref[1]
+    if "-maxlpf" in extra:
+        assert 0 < ref[0].count("\n") < 20
+    # the second pass is no bystander on RM1: its output differs from the first pass's
+    if task == "rm1" and not extra:
+        fp = run(REFDEC, rm_args(), tmp_path, "fp")
+        assert fp[1] != ref[1]
+
+
+def test_second_pass_through_the_c_abi_alone_tables_stay_on_the_device(gpu_lib, tmp_path):
+    """bundle -> s3a_uttdec_init + s3a_uttdec_enable_bestpath(keep_tables = 0): cepstra in, the second pass's hypotheses
+    out; the history tables are never read back (s3a_uttdec_result refuses)"""
+    args = tidigits_args() + ["-bestpath", "1"]
+    ref = run(REFDEC, args, tmp_path, "ref")
+    bpath = str(tmp_path / "t.bundle")
+    export(args, bpath)
+    dec = bundle.Decoder(bpath, 4, bestpath=True, keep_tables=False)
+    utts = [l.split() for l in open(f"{D}/tidigits.length.arb.regression") if l.strip()]
+    utts = [(f[0], f[3] if len(f) > 3 else os.path.basename(f[0])) for f in utts]
+    match, seg = [], []
+    for k in range(0, len(utts), 4):
+        chunk = utts[k:k + 4]
+        feats = [gpu_lib.feat_1s_c_d_dd(s3io.read_mfc(f"{D}/cepstra/{u}.mfc").reshape(-1, 13), cmn="current") for u, _ in chunk]
+        dec.decode(feats)
+        with pytest.raises(gpu_lib.S3AError, match="left on the device"):
+            dec.ud.result(0)
+        for z, (_, uid) in enumerate(chunk):
+            h, w = dec.bestpath_hyp(z, uid, k + z)
+            assert h.status == 0 and h.n_frames == len(feats[z])
+            m, s = dec.format_var(h, w)
+            match.append(m); seg.append(s)
+    assert "".join(match) == ref[0] and "".join(seg) == ref[1]
