@@ -344,23 +344,31 @@ def main():
             return shard.shard_contiguous(U, rank, world), 0
         return list(range(U)), rank * U              # weak: a whole batch per rank (record ids offset by the rank)
 
+    host_t = {}
+
     def run_step(step, recs=None, sched=None):
         ids, base = my_share(step)
         per = sched if sched is not None else schedule(ids)
 
         def one(e):         # engine e decodes its groups one after the other (the C calls release the GIL)
             lib.check(L.s3a_set_device(local_rank))     # (HIP's current device is per host thread)
-            ms, out = 0.0, []
+            ms, out, t_dec, t_hyp = 0.0, [], 0.0, 0.0
             for g in per[e]:
+                t0 = time.perf_counter()
                 ms += decs[e].ud.decode_dev([fdev[k] for k in g], [nfr[k] for k in g], D4x4)
+                t1 = time.perf_counter()
                 if recs is not None:
                     out += [decs[e].hyp_var(z, utts[k], base + k) for z, k in enumerate(g)]
-            return ms, out
+                t_dec += t1 - t0
+                t_hyp += time.perf_counter() - t1
+            return ms, out, t_dec, t_hyp
         done = list(pool.map(one, range(NE)))
         if recs is not None:
-            for _, out in done:
-                recs.extend(out)
-        return max(ms for ms, _ in done)
+            for d_ in done:
+                recs.extend(d_[1])
+        host_t["decode_call_s"] = max(d_[2] for d_ in done)
+        host_t["hyp_s"] = max(d_[3] for d_ in done)
+        return max(d_[0] for d_ in done)
 
     # ---------------- the reference (rank 0, untimed): CPU baseline + what the device's output is compared with ----------------
     cpu, ref = None, None
@@ -517,6 +525,7 @@ def main():
                                       f"padded per rank (no word limit)"},
             "xRT_per_gpu": round(value / world / 100.0, 1),
             "device_ms_per_step": round(dev_ms / args.steps, 3),
+            "host_side_last_step": {k: round(v, 3) for k, v in host_t.items()},
             "identical_to_reference": {"hyp": hyp_ok, "hypseg": seg_ok}, "utterances_checked_against_reference": n_chk,
             "load_s": round(t_load, 2), "setup_s": round(t_setup, 1),
             "per_frame": {"active_hmm": round(lanes_hmm, 1), "cd_senones_scored": round(lanes_sen, 1), "cd_gaussians": round(lanes_gau, 1),

@@ -105,6 +105,53 @@ frame_beams(const UShared &S, int32_t cf)
     return bm;
 }
 
+/* ---- utterance boundaries of ALL lanes in two launches ----
+ * (lextree_utt_end + srch_TST_begin per lane were ~25 small launches, a copy and a stream synchronisation EACH: with
+ * 128 lanes per engine several percent of a batch)
+ * ku_lanes_end: hmm_clear on whatever the last utterance left active (lextree_utt_end, lextree.c:1666-1700), both lists;
+ * ku_lanes_begin: the frame-tagged scratch, the scorer's per-senone state (cont_mgau.c:1183-1190 as srch_TST_begin
+ * :485-490 resets it), the masks, and the history table's entry 0 (vithist_utt_begin, vithist.c:300-335). */
+struct UBegin { int32_t e0[10], lmc[5], n_pset; };
+
+__global__ void __launch_bounds__(256)
+ku_lanes_end(const ULane *__restrict__ lanes, UShared S)
+{
+    const ULane &L = lanes[blockIdx.z];
+    const int32_t t = blockIdx.y % S.T, w = blockIdx.y / S.T;
+    const int32_t na = S.nact_all[((size_t)blockIdx.z * 2 + w) * WL_MAXT + t], b = S.node_base[t];
+    for (int32_t i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) {
+        const int32_t v = L.act[w][b + i];
+        int32_t *r = L.sc + NSV(v);
+        r[0] = WORST; r[1] = WORST; r[2] = WORST; r[3] = -1; r[4] = -1; r[5] = -1;
+        r[NS_OFF_OUTS] = WORST; r[NS_OFF_OUTH] = -1; r[NS_OFF_BESTS] = WORST; r[NS_OFF_FRAME] = -1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ku_lanes_begin(const ULane *__restrict__ lanes, UShared S, UBegin B)
+{
+    const ULane &L = lanes[blockIdx.z];
+    const int32_t i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int32_t i = i0; i < S.N; i += stride) { L.posf[i] = INT_MIN; L.propf[i] = INT_MIN; }
+    for (int32_t i = i0; i < B.n_pset; i += stride) L.pstamp[i] = INT_MIN;
+    for (int32_t i = i0; i < S.n_pset_bytes; i += stride) L.pstamp8[i] = 0xff;
+    for (int32_t i = i0; i < S.n_sen; i += stride) {
+        L.bstidx[i] = S3A_NO_BSTIDX; L.bstscr[i] = S3A_LOGPROB_ZERO; L.updatetime[i] = S3A_NOT_UPDATED; L.sen_act[i] = 0;
+    }
+    for (int32_t i = i0; i <= S.n_cs; i += stride) L.cs_need[i] = -1;
+    if (blockIdx.x == 0) {
+        const int32_t tid = threadIdx.x;
+        if (tid < 2 * WL_MAXT) S.nact_all[(size_t)blockIdx.z * 2 * WL_MAXT + tid] = 0;
+        if (tid < 8) L.misc[tid] = (tid == 0 || tid == 5) ? INT_MIN : 0;
+        if (tid == 32) {
+            int32_t *arr[10] = { L.w.score, L.w.pred, L.w.lw0, L.w.lw1, L.w.wid, L.w.sf, L.w.ef, L.w.ascr, L.w.lscr, L.w.type };
+            for (int k = 0; k < 10; k++) arr[k][0] = B.e0[k];
+            for (int k = 0; k < 5; k++) L.w.lmc[(size_t)k * L.w.cap] = B.lmc[k];
+            L.w.frame_start[0] = 1; L.w.bestscore[0] = INT_MIN; L.w.bestvh[0] = -1; L.w.st[0] = 1; L.w.st[1] = 0;
+        }
+    }
+}
+
 /* ---- lextree_enter calls left by the previous frame's word level (or by utterance begin) ---- */
 /* the entry test (d_dec_enter1) with the calls' table in LDS: an entry finds its call by a bisection in LDS and fails the
  * test -- almost all do -- after ONE global round trip (its root's look-ahead probability, in list order) */
@@ -1030,6 +1077,8 @@ struct s3a_uttdec_s {
     hipEvent_t ev0, ev1;        /* around the frames of a decode (last_decode_ms) */
     int32_t no_multi, gy;       /* tuning switches, read ONCE at init (S3A_UTT_NO_MULTI, S3A_UTT_GY; tests) */
     int32_t win_fpc;            /* S3A_UTT_WIN_FPC: slots per chunk of the look-ahead scoring (0: the cost model's) */
+    UCtx *h_ctx_up;             /* pinned [n_lanes]: the lanes' contexts of the coming decode, uploaded with ONE copy */
+    int32_t n_pset;
     s3a_dagpass_t *dag;         /* the second pass after every decode (s3a_uttdec_enable_bestpath), or NULL */
     int32_t keep_tables;        /* 0: with the second pass enabled the history tables stay on the device */
     int32_t tables_fetched;
@@ -1116,6 +1165,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
     if (ud->dag) s3a_dagpass_free(ud->dag);
+    if (ud->h_ctx_up) (void)hipHostFree(ud->h_ctx_up);
     if (ud->ev0) (void)hipEventDestroy(ud->ev0);
     if (ud->ev1) (void)hipEventDestroy(ud->ev1);
     if (ud->d_lanes) (void)hipFree(ud->d_lanes);
@@ -1159,7 +1209,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
     ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
-    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0;
+    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->h_ctx_up = NULL; ud->n_pset = proto->n_pset;
     (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
@@ -1302,6 +1352,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     for (auto &hl : ud->lane) memset((void *)&hl, 0, sizeof hl);
     if (T > WL_MAXT) { s3a_set_error("s3a_uttdec_init: more than %d lextrees", WL_MAXT); goto fail; }
     DM(ud->S.ctx_all, sizeof(UCtx) * n_lanes);
+    if (hipHostMalloc((void **)&ud->h_ctx_up, sizeof(UCtx) * n_lanes) != hipSuccess) { s3a_set_error("s3a_uttdec_init: pinned allocation failed"); goto fail; }
     DM(ud->S.nact_all, (size_t)n_lanes * 2 * WL_MAXT * 4);
     if (hipMemset(ud->S.nact_all, 0, (size_t)n_lanes * 2 * WL_MAXT * 4) != hipSuccess
         || hipMemset(ud->S.ctx_all, 0, sizeof(UCtx) * n_lanes) != hipSuccess) goto fail;
@@ -1417,29 +1468,12 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
         if ((rc = fill32(ud->stream, w.wfirst, INT_MAX, c.n_word)) != S3A_OK || (rc = fill32(ud->stream, w.wbest, INT_MIN, c.n_word)) != S3A_OK) return rc;
         hl.dirty = 0;
     }
-    if ((rc = s3a_lexsearch_utt_end(hl.ls)) != S3A_OK) return rc;
+    /* (lextree_utt_end, srch_TST_begin's resets and the history table's entry 0: ku_lanes_end / ku_lanes_begin, all
+     * lanes in two launches -- uttdec_decode; here only the host-side bookkeeping of the lane's objects) */
     hl.ls->cur = 0;
-    if ((rc = s3a_decoder_utt_begin(hl.ls, hl.sc)) != S3A_OK) return rc;
-    if ((rc = fill32(ud->stream, hl.d.cs_need, -1, (size_t)ud->S.n_cs + 1)) != S3A_OK) return rc;   /* (frame stamps restart) */
-    HIPCHK(hipMemsetAsync(hl.d.pstamp8, 0xff, (size_t)ud->S.n_pset_bytes, ud->stream));
-    /* history: entry 0 (vithist_utt_begin, vithist.c:300-335) */
-    {
-        int32_t e0[10] = { 0 /*score*/, -1 /*pred*/, c.start_lwid, -1 /*lw1*/, c.startwid, -1 /*sf*/, -1 /*ef*/, 0, 0, 0 };
-        int32_t *arr[10] = { hl.d.w.score, hl.d.w.pred, hl.d.w.lw0, hl.d.w.lw1, hl.d.w.wid, hl.d.w.sf, hl.d.w.ef, hl.d.w.ascr,
-                             hl.d.w.lscr, hl.d.w.type };
-        for (int k = 0; k < 10; k++) if ((rc = fill32(ud->stream, arr[k], e0[k], 1)) != S3A_OK) return rc;
-        {   /* wl_lm_context of entry 0: state (<s>, none): no trigram run, the bigrams of <s> */
-            const s3a_lm3g_t *lm = ud->lm;
-            int32_t c5[5] = { 0, 0, 0, 0, -1 };
-            if (lm->d.n_bg > 0 && c.start_lwid >= 0) { c5[3] = lm->ug_firstbg[c.start_lwid]; c5[4] = lm->ug_firstbg[c.start_lwid + 1] - c5[3]; }
-            for (int k = 0; k < 5; k++) if ((rc = fill32(ud->stream, hl.d.w.lmc + (size_t)k * hl.d.w.cap, c5[k], 1)) != S3A_OK) return rc;
-        }
-        if ((rc = fill32(ud->stream, hl.d.w.frame_start, 1, 1)) || (rc = fill32(ud->stream, hl.d.w.bestscore, INT_MIN, 1))
-            || (rc = fill32(ud->stream, hl.d.w.bestvh, -1, 1)) || (rc = fill32(ud->stream, hl.d.w.st, 1, 1))
-            || (rc = fill32(ud->stream, hl.d.w.st + 1, 0, 1)))
-            return rc;
-
-    }
+    hl.ls->last_nnxt = 0; hl.ls->hist_bound = 0; hl.ls->row_bound = 1;
+    hl.ls->nnxt_t.assign(hl.ls->n_tree, 0);
+    hl.sc->skip_count = 0;
     UCtx &x = *hl.h_ctx;
     memset(&x, 0, sizeof x);
     x.feat = d_feat_use;
@@ -1459,7 +1493,7 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
         x.n_calls = 2; x.n_groups = 2; x.n_ent = m0[1] + m1[1];
         (void)T;
     }
-    HIPCHK(hipMemcpyAsync(hl.d.ctx, hl.h_ctx, sizeof(UCtx), hipMemcpyHostToDevice, ud->stream));
+    ud->h_ctx_up[z] = x;            /* (uploaded with the other lanes': uttdec_decode) */
     return S3A_OK;
 }
 
@@ -1684,6 +1718,20 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
     for (int32_t z = 0; z < n_utt; z++) {
         if ((rc = lane_begin(ud, z, feat[z], n_frames[z], feat_stride, feat_on_device)) != S3A_OK) return rc;
         maxT = max(maxT, n_frames[z]);
+    }
+    {
+        const s3a_wordlevel_cfg_t &c = ud->cfg;
+        UBegin B;
+        const int32_t e0[10] = { 0 /*score*/, -1 /*pred*/, c.start_lwid, -1 /*lw1*/, c.startwid, -1 /*sf*/, -1 /*ef*/, 0, 0, 0 };
+        memcpy(B.e0, e0, sizeof e0);
+        /* wl_lm_context of entry 0: state (<s>, none): no trigram run, the bigrams of <s> */
+        B.lmc[0] = B.lmc[1] = B.lmc[2] = B.lmc[3] = 0; B.lmc[4] = -1;
+        if (ud->lm->d.n_bg > 0 && c.start_lwid >= 0) { B.lmc[3] = ud->lm->ug_firstbg[c.start_lwid]; B.lmc[4] = ud->lm->ug_firstbg[c.start_lwid + 1] - B.lmc[3]; }
+        B.n_pset = ud->n_pset > 0 ? ud->n_pset : 1;
+        hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * ud->S.T, n_utt), dim3(256), 0, ud->stream, ud->d_lanes, ud->S);
+        hipLaunchKernelGGL(ku_lanes_begin, dim3(32, 1, n_utt), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, B);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(ud->S.ctx_all, ud->h_ctx_up, sizeof(UCtx) * n_utt, hipMemcpyHostToDevice, ud->stream));
     }
     /* (the engine's two timing events live as long as the engine; the per-launch events of profiled frames are destroyed
      * on every way out) */

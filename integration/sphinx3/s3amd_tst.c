@@ -1329,7 +1329,10 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
                            g_lm3g, &cfg, g_lpe, S3_MAX_FRAMES, getenv("S3A_UTT_VHCAP") ? atoi(getenv("S3A_UTT_VHCAP")) : 0,
                            getenv("S3A_UTT_CANDCAP") ? atoi(getenv("S3A_UTT_CANDCAP")) : 0);
             if (!g_uds[e]) die("s3a_uttdec_init");
-            if (cmd_ln_boolean_r(config, "-bestpath") && !getenv("S3A_UTT_HOSTDAG")) {
+            /* (lattice files and N-best lists are written from the reference's dag_t: those runs keep its own
+             * vithist_dag_build on the table the device produced) */
+            if (cmd_ln_boolean_r(config, "-bestpath") && !getenv("S3A_UTT_HOSTDAG") && !cmd_ln_str_r(config, "-outlatdir")
+                && !cmd_ln_str_r(config, "-nbestdir")) {
                 s3a_dag_cfg_t dc;
                 float32 bplw = cmd_ln_float32_r(config, "-bestpathlw");
                 int32 *base = ckd_calloc(w->n_word + 1, 4), i;
