@@ -391,6 +391,12 @@ def main():
             torch.cuda.synchronize()
 
     # ---------------- the timed region ----------------
+    cgather = None
+    if dist is None:
+        try:
+            cgather = lib.Gather(0, 1)      # (the drop-in's own C exchange; RCCL loaded at run time)
+        except lib.S3AError:
+            cgather = None
     n_total = U if args.scaling == "strong" else U * world
     for i in range(args.warmup):
         run_step(i)
@@ -400,7 +406,12 @@ def main():
     for i in range(args.steps):
         recs = []
         dev_ms += run_step(i, recs)
-        allrec = shard.gather_var(recs, n_total, dist, device=tdev) if dist is not None else sorted(recs, key=lambda t: t[0].utt_index)
+        if dist is not None:
+            allrec = shard.gather_var(recs, n_total, dist, device=tdev)          # two collectives of torch.distributed (RCCL)
+        elif cgather is not None:
+            allrec = cgather.gather(recs, n_total)       # the C side's exchange (s3a_gather_hyps over RCCL), one rank
+        else:
+            allrec = sorted(recs, key=lambda t: t[0].utt_index)
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -527,6 +538,8 @@ def main():
             "device_ms_per_step": round(dev_ms / args.steps, 3),
             "host_side_last_step": {k: round(v, 3) for k, v in host_t.items()},
             "identical_to_reference": {"hyp": hyp_ok, "hypseg": seg_ok}, "utterances_checked_against_reference": n_chk,
+            "exchange": ("torch.distributed all_gather x2 (RCCL)" if world > 1 else
+                         "s3a_gather_hyps (C, RCCL, 1 rank)" if cgather is not None else "none (RCCL not loadable)"),
             "load_s": round(t_load, 2), "setup_s": round(t_setup, 1),
             "per_frame": {"active_hmm": round(lanes_hmm, 1), "cd_senones_scored": round(lanes_sen, 1), "cd_gaussians": round(lanes_gau, 1),
                           "word_exits": round(lanes_exit, 2), "max_candidates": int(res0["max_cand"]), "tie_frames_lane0": int(res0["n_tie_frames"])},

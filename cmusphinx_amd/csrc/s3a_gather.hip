@@ -1,0 +1,177 @@
+/*
+ * s3a_gather.hip -- the end-of-batch exchange of hypotheses in C, over RCCL: when the control file is
+ * sharded over the GPUs of a node (-ctloffset / -ctlcount per rank, main_decode.c:164-169) every rank ends with the
+ * hypotheses of its own utterances; ONE exchange brings them to every rank in control-file order, so that rank 0 writes
+ * -hyp / -hypseg as a single process would.  No per-frame collective exists anywhere in the path.
+ *
+ * Variable-length records (a header + n_words words per utterance), three all-gathers on device buffers: the ranks'
+ * counts, the headers (padded to the largest rank's count), the words (padded to the largest rank's total).  RCCL is
+ * loaded at run time (dlopen librccl.so: the library itself does not link it; a host program without RCCL still loads
+ * libcmusphinx_amd.so) and the communicator is bootstrapped through a file: rank 0 writes ncclGetUniqueId's 128 bytes to
+ * `rendezvous` (write + rename), the other ranks wait for it -- the ranks of one node share a file system.
+ */
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <algorithm>
+#include <vector>
+
+#include "s3a_device.h"
+
+typedef struct { char internal[128]; } rcclUniqueId;
+typedef void *rcclComm_t;
+typedef int (*fn_get_id)(rcclUniqueId *);
+typedef int (*fn_init_rank)(rcclComm_t *, int, rcclUniqueId, int);
+typedef int (*fn_all_gather)(const void *, void *, size_t, int, rcclComm_t, hipStream_t);
+typedef int (*fn_destroy)(rcclComm_t);
+typedef const char *(*fn_errstr)(int);
+
+struct s3a_gather_s {
+    void *lib;
+    fn_get_id get_id; fn_init_rank init_rank; fn_all_gather all_gather; fn_destroy destroy; fn_errstr errstr;
+    rcclComm_t comm;
+    int32_t rank, world;
+    hipStream_t stream;
+    std::vector<s3a_hyp_header_t> hdr;
+    std::vector<s3a_hyp_word_t> words;
+    std::vector<int64_t> word_off;
+};
+
+#define RCHK(g, expr) do { int r_ = (expr); if (r_ != 0) { s3a_set_error("%s failed: %s", #expr, (g)->errstr ? (g)->errstr(r_) : "?"); return S3A_EHIP; } } while (0)
+
+extern "C" void
+s3a_gather_free(s3a_gather_t *g)
+{
+    if (!g) return;
+    if (g->comm && g->destroy) (void)g->destroy(g->comm);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    if (g->lib) dlclose(g->lib);
+    delete g;
+}
+
+extern "C" s3a_gather_t *
+s3a_gather_init(int32_t rank, int32_t world, const char *rendezvous)
+{
+    if (rank < 0 || world <= 0 || rank >= world || (world > 1 && (!rendezvous || !*rendezvous))) { s3a_set_error("s3a_gather_init: bad arguments"); return NULL; }
+    s3a_gather_t *g = new s3a_gather_s();
+    g->lib = NULL; g->comm = NULL; g->stream = NULL; g->rank = rank; g->world = world;
+    const char *names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
+    for (auto n : names) if (!g->lib) g->lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!g->lib) { s3a_set_error("s3a_gather_init: librccl.so not found (%s)", dlerror()); delete g; return NULL; }
+    g->get_id = (fn_get_id)dlsym(g->lib, "ncclGetUniqueId"); g->init_rank = (fn_init_rank)dlsym(g->lib, "ncclCommInitRank");
+    g->all_gather = (fn_all_gather)dlsym(g->lib, "ncclAllGather"); g->destroy = (fn_destroy)dlsym(g->lib, "ncclCommDestroy");
+    g->errstr = (fn_errstr)dlsym(g->lib, "ncclGetErrorString");
+    if (!g->get_id || !g->init_rank || !g->all_gather || !g->destroy) { s3a_set_error("s3a_gather_init: librccl.so lacks the nccl* entry points"); s3a_gather_free(g); return NULL; }
+    rcclUniqueId id;
+    memset(&id, 0, sizeof id);
+    if (rank == 0) {
+        int r = g->get_id(&id);
+        if (r != 0) { s3a_set_error("ncclGetUniqueId failed: %s", g->errstr ? g->errstr(r) : "?"); s3a_gather_free(g); return NULL; }
+        if (world > 1) {
+            char tmp[4096];
+            snprintf(tmp, sizeof tmp, "%s.tmp", rendezvous);
+            FILE *fp = fopen(tmp, "wb");
+            if (!fp || fwrite(&id, sizeof id, 1, fp) != 1 || fclose(fp) != 0 || rename(tmp, rendezvous) != 0) {
+                s3a_set_error("s3a_gather_init: cannot write the rendezvous file %s", rendezvous); s3a_gather_free(g); return NULL;
+            }
+        }
+    }
+    else {
+        int tries = 0;
+        for (;; tries++) {
+            FILE *fp = fopen(rendezvous, "rb");
+            if (fp) { const size_t k = fread(&id, sizeof id, 1, fp); fclose(fp); if (k == 1) break; }
+            if (tries > 6000) { s3a_set_error("s3a_gather_init: rank %d waited 10 minutes for %s", rank, rendezvous); s3a_gather_free(g); return NULL; }
+            usleep(100000);
+        }
+    }
+    if (hipStreamCreate(&g->stream) != hipSuccess) { s3a_set_error("s3a_gather_init: hipStreamCreate failed"); s3a_gather_free(g); return NULL; }
+    int r = g->init_rank(&g->comm, world, id, rank);
+    if (r != 0) { s3a_set_error("ncclCommInitRank failed: %s", g->errstr ? g->errstr(r) : "?"); g->comm = NULL; s3a_gather_free(g); return NULL; }
+    return g;
+}
+
+/* this rank's hypotheses in, everybody's out (utterance order; every utterance index 0 .. n_total - 1 exactly once) */
+extern "C" int32_t
+s3a_gather_hyps(s3a_gather_t *g, int32_t n_local, const s3a_hyp_header_t *hdr, const s3a_hyp_word_t *words, int32_t n_total)
+{
+    if (!g || n_local < 0 || (n_local > 0 && !hdr) || n_total < 0) return S3A_EINVAL;
+    long long nw_local = 0;
+    for (int32_t i = 0; i < n_local; i++) nw_local += hdr[i].status == 0 ? hdr[i].n_words : 0;
+    if (nw_local > 0 && !words) return S3A_EINVAL;
+    const int W = g->world;
+    long long cnt[2] = { n_local, nw_local }, *d_cnt = NULL, *d_all = NULL;
+    std::vector<long long> all((size_t)2 * W);
+    HIPCHK(hipMalloc((void **)&d_cnt, sizeof cnt)); HIPCHK(hipMalloc((void **)&d_all, sizeof(long long) * 2 * W));
+    HIPCHK(hipMemcpyAsync(d_cnt, cnt, sizeof cnt, hipMemcpyHostToDevice, g->stream));
+    RCHK(g, g->all_gather(d_cnt, d_all, sizeof cnt, 0 /* ncclInt8: bytes */, g->comm, g->stream));
+    HIPCHK(hipMemcpyAsync(all.data(), d_all, sizeof(long long) * 2 * W, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    (void)hipFree(d_cnt); (void)hipFree(d_all);
+    long long mh = 1, mw = 1;
+    for (int r = 0; r < W; r++) { mh = std::max(mh, all[2 * r]); mw = std::max(mw, all[2 * r + 1]); }
+    const size_t hb = (size_t)mh * sizeof(s3a_hyp_header_t), wb = (size_t)mw * sizeof(s3a_hyp_word_t);
+    char *d_h = NULL, *d_w = NULL, *d_ah = NULL, *d_aw = NULL;
+    HIPCHK(hipMalloc((void **)&d_h, hb)); HIPCHK(hipMalloc((void **)&d_w, wb));
+    HIPCHK(hipMalloc((void **)&d_ah, hb * W)); HIPCHK(hipMalloc((void **)&d_aw, wb * W));
+    HIPCHK(hipMemsetAsync(d_h, 0xff, hb, g->stream));           /* padding headers: utt_index -1 */
+    HIPCHK(hipMemsetAsync(d_w, 0, wb, g->stream));
+    if (n_local) HIPCHK(hipMemcpyAsync(d_h, hdr, (size_t)n_local * sizeof(s3a_hyp_header_t), hipMemcpyHostToDevice, g->stream));
+    {
+        /* the words of the utterances that have any, back to back */
+        std::vector<s3a_hyp_word_t> flat((size_t)nw_local);
+        size_t pos = 0, src = 0;
+        for (int32_t i = 0; i < n_local; i++) {
+            const int32_t n = hdr[i].status == 0 ? hdr[i].n_words : 0;
+            if (n) memcpy(&flat[pos], words + src, (size_t)n * sizeof(s3a_hyp_word_t));
+            pos += n; src += n;
+        }
+        if (nw_local) HIPCHK(hipMemcpy(d_w, flat.data(), (size_t)nw_local * sizeof(s3a_hyp_word_t), hipMemcpyHostToDevice));
+    }
+    RCHK(g, g->all_gather(d_h, d_ah, hb, 0, g->comm, g->stream));          /* the lengths (and all that is fixed-size) */
+    RCHK(g, g->all_gather(d_w, d_aw, wb, 0, g->comm, g->stream));          /* the padded payload */
+    std::vector<char> ah(hb * W), aw(wb * W);
+    HIPCHK(hipMemcpyAsync(ah.data(), d_ah, hb * W, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipMemcpyAsync(aw.data(), d_aw, wb * W, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    (void)hipFree(d_h); (void)hipFree(d_w); (void)hipFree(d_ah); (void)hipFree(d_aw);
+    struct Rec { int32_t idx; const s3a_hyp_header_t *h; const s3a_hyp_word_t *w; };
+    std::vector<Rec> recs;
+    for (int r = 0; r < W; r++) {
+        const s3a_hyp_header_t *hh = (const s3a_hyp_header_t *)(ah.data() + hb * r);
+        const s3a_hyp_word_t *ww = (const s3a_hyp_word_t *)(aw.data() + wb * r);
+        size_t pos = 0;
+        for (long long i = 0; i < all[2 * r]; i++) {
+            if (hh[i].utt_index < 0) continue;
+            recs.push_back({ hh[i].utt_index, &hh[i], ww + pos });
+            pos += hh[i].status == 0 ? hh[i].n_words : 0;
+        }
+    }
+    std::sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) { return a.idx < b.idx; });
+    if ((int32_t)recs.size() != n_total) { s3a_set_error("s3a_gather_hyps: %zu utterances arrived, %d expected", recs.size(), n_total); return S3A_EINVAL; }
+    for (int32_t i = 0; i < n_total; i++)
+        if (recs[i].idx != i) { s3a_set_error("s3a_gather_hyps: utterance %d missing or duplicated across ranks", i); return S3A_EINVAL; }
+    g->hdr.resize(n_total); g->word_off.assign((size_t)n_total + 1, 0);
+    size_t tot = 0;
+    for (int32_t i = 0; i < n_total; i++) { g->hdr[i] = *recs[i].h; g->word_off[i] = (int64_t)tot; tot += recs[i].h->status == 0 ? recs[i].h->n_words : 0; }
+    g->word_off[n_total] = (int64_t)tot;
+    g->words.resize(tot ? tot : 1);
+    for (int32_t i = 0; i < n_total; i++) {
+        const int32_t n = recs[i].h->status == 0 ? recs[i].h->n_words : 0;
+        if (n) memcpy(&g->words[(size_t)g->word_off[i]], recs[i].w, (size_t)n * sizeof(s3a_hyp_word_t));
+    }
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_gather_result(const s3a_gather_t *g, int32_t utt_index, const s3a_hyp_header_t **hdr, const s3a_hyp_word_t **words)
+{
+    if (!g || !hdr || !words || utt_index < 0 || utt_index >= (int32_t)g->hdr.size()) return S3A_EINVAL;
+    *hdr = &g->hdr[utt_index];
+    *words = &g->words[(size_t)g->word_off[utt_index]];
+    return S3A_OK;
+}

@@ -189,6 +189,10 @@ _SIGS = {
     "s3a_uttdec_wl_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_window": (C.c_int32, [C.c_void_p]),
+    "s3a_gather_init": (C.c_void_p, [C.c_int32, C.c_int32, C.c_char_p]),
+    "s3a_gather_free": (None, [C.c_void_p]),
+    "s3a_gather_hyps": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_gather_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "s3a_dagpass_init": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "s3a_dagpass_free": (None, [C.c_void_p]),
     "s3a_dagpass_run_tables": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -1287,6 +1291,36 @@ def dag_cfg(b, keep, bestpathlw=None, min_endfr=None, maxedge=None, maxlmop=None
     c.maxlmop = b.get("maxlmop", 100000000) if maxlmop is None else maxlmop
     c.maxlpf = b.get("maxlpf", 40000) if maxlpf is None else maxlpf
     return c
+
+
+class Gather:
+    """s3a_gather_t: the end-of-batch exchange of (header, words) hypotheses over RCCL, in C"""
+
+    def __init__(self, rank, world, rendezvous=""):
+        self.L = load()
+        self.h = self.L.s3a_gather_init(int(rank), int(world), rendezvous.encode())
+        if not self.h:
+            raise S3AError(_err(self.L))
+
+    def gather(self, local, n_total):
+        """local: [(HypHeader, words int32 [n, 6])] -> the whole batch's, in utterance order"""
+        hdr = (HypHeader * max(len(local), 1))(*[h for h, _ in local])
+        words = np.ascontiguousarray(np.concatenate([np.asarray(w, np.int32).reshape(-1, 6) for _, w in local])
+                                     if local else np.zeros((0, 6), np.int32))
+        check(self.L.s3a_gather_hyps(self.h, len(local), hdr, _p(words) if len(words) else None, int(n_total)), self.L)
+        out = []
+        for i in range(n_total):
+            ph, pw = C.POINTER(HypHeader)(), C.POINTER(C.c_int32)()
+            check(self.L.s3a_gather_result(self.h, i, C.byref(ph), C.byref(pw)), self.L)
+            h = HypHeader.from_buffer_copy(bytes(ph.contents))
+            n = h.n_words if h.status == 0 else 0
+            out.append((h, np.ctypeslib.as_array(pw, (n * 6,)).reshape(n, 6).copy() if n else np.zeros((0, 6), np.int32)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.s3a_gather_free(self.h)
+            self.h = None
 
 
 class DagPass:

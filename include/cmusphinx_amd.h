@@ -758,6 +758,26 @@ int32_t s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int
                          int32_t *n_tie_frames);
 
 /* ===================================================================== */
+/* the end-of-batch exchange of hypotheses in C over RCCL  */
+/* ===================================================================== */
+/*
+ * The control file sharded over the ranks (-ctloffset / -ctlcount, main_decode.c:164-169; ctl_process, corpus.c:538): every
+ * rank holds the hypotheses of its own utterances (s3a_uttdec_hyp_var / s3a_uttdec_bestpath_hyp: header + words),
+ * s3a_gather_hyps brings ALL of them to every rank in utterance order -- three all-gathers over RCCL on device buffers
+ * (counts; headers; words, each padded to the largest rank's) -- and s3a_gather_result hands them out (owned by the
+ * gather until its next call).  RCCL is loaded at run time; the communicator is bootstrapped through the file
+ * `rendezvous` (rank 0 writes ncclGetUniqueId's bytes; one node, one file system).  words = the local utterances' words
+ * back to back (status != 0: none).  n_total = utterances of the whole batch: each index exactly once, else an error.
+ */
+typedef struct s3a_gather_s s3a_gather_t;
+s3a_gather_t *s3a_gather_init(int32_t rank, int32_t world, const char *rendezvous);
+void s3a_gather_free(s3a_gather_t *g);
+int32_t s3a_gather_hyps(s3a_gather_t *g, int32_t n_local, const s3a_hyp_header_t *hdr, const s3a_hyp_word_t *words,
+                        int32_t n_total);
+int32_t s3a_gather_result(const s3a_gather_t *g, int32_t utt_index, const s3a_hyp_header_t **hdr,
+                          const s3a_hyp_word_t **words);
+
+/* ===================================================================== */
 /* the second pass: lattice from the Viterbi history, best path under the trigram          */
 /* ===================================================================== */
 /*

@@ -980,6 +980,30 @@ utt_end_slot(void *srch)                /* srch_TST_end, :514-560 */
  * vithist_dag_build / dag_search on the table the device produced (the comparison run). */
 static int g_dev_dag;
 static long g_dag_utts;
+/* one process per GPU: the rank's hypotheses as (header, words) records for the end-of-batch exchange (s3a_gather_hyps) */
+static int g_rank = 0, g_world = 1, g_rank_first = 0, g_rank_total = 0, g_gather = 0;
+static char g_final[2][4300];
+static s3a_hyp_header_t *g_rec_hdr;
+static s3a_hyp_word_t *g_rec_words;
+static int32 g_rec_n, g_rec_cap, g_rec_nw, g_rec_wcap;
+static void
+rec_add(int32 z)
+{
+    s3a_uttdec_t *ud = g_uds[z / g_lpe];
+    s3a_hyp_header_t h;
+    int32 need = 0, rc;
+    if (g_rec_n == g_rec_cap) { g_rec_cap = g_rec_cap ? 2 * g_rec_cap : 1024; g_rec_hdr = ckd_realloc(g_rec_hdr, (size_t)g_rec_cap * sizeof(*g_rec_hdr)); }
+    for (;;) {
+        if (g_rec_nw + need > g_rec_wcap) { g_rec_wcap = 2 * (g_rec_nw + need) + 4096; g_rec_words = ckd_realloc(g_rec_words, (size_t)g_rec_wcap * sizeof(*g_rec_words)); }
+        rc = g_dev_dag ? s3a_uttdec_bestpath_hyp(ud, z % g_lpe, g_uq[z].uttid, g_rank_first + g_rec_n, &h, g_rec_words + g_rec_nw, g_rec_wcap - g_rec_nw)
+                       : s3a_uttdec_hyp_var(ud, z % g_lpe, g_uq[z].uttid, g_rank_first + g_rec_n, &h, g_rec_words + g_rec_nw, g_rec_wcap - g_rec_nw);
+        if (rc != S3A_OK) die("hypothesis record");
+        if (h.status != -3) break;
+        need = h.n_words;
+    }
+    g_rec_hdr[g_rec_n++] = h;
+    if (h.status == 0) g_rec_nw += h.n_words;
+}
 static __thread int32 g_cur_lane;
 static dag_t *
 utt_gen_dag_slot(void *srch, glist_t hyp)
@@ -1058,6 +1082,7 @@ utt_finish(kb_t *kb, int32 z)
     vithist_fill(tstg->vithist, r.n_entry, r.n_frm, r.score, r.pred, r.lw0, r.lw1, r.wid, r.sf, r.ef, r.ascr, r.lscr,
                  r.type, r.frame_start, r.bestscore, r.bestvh, kbcore_lm(kb->kbcore));
     g_cur_lane = z;
+    if (g_gather) rec_add(z);
     utt_end(kb);                                /* srch_utt_end -> utt_end_slot, gen_hyp, match_write ... */
     st->tot_fr += st->nfr;
     ckd_free(q->uttid); ckd_free(q->uttfile); ckd_free(q->feat);
@@ -1367,6 +1392,23 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
         return 0;
     }
     if (!g_ud) die("s3a_uttdec_init");
+    /* the exchange over RCCL: between the ranks of a multi-GPU run (S3A_NO_RCCL=1: not, e.g. ranks that share one GPU);
+     * S3A_GATHER=1 in a single process: the same code with one rank, the files written to <hyp>.gathered (tests) */
+    g_gather = (g_world > 1 && !getenv("S3A_NO_RCCL")) || (g_world == 1 && getenv("S3A_GATHER") != NULL);
+    if (g_world == 1 && g_gather) {
+        FILE *cf = fopen(cmd_ln_str_r(config, "-ctl"), "r");
+        char ln[16384];
+        int32 nl = 0, k;
+        while (cf && fgets(ln, sizeof ln, cf)) if (ln[0] != '\n' && ln[0] != '#') nl++;
+        if (cf) fclose(cf);
+        nl = nl > cmd_ln_int32_r(config, "-ctloffset") ? nl - cmd_ln_int32_r(config, "-ctloffset") : 0;
+        if (cmd_ln_int32_r(config, "-ctlcount") >= 0 && cmd_ln_int32_r(config, "-ctlcount") < nl) nl = cmd_ln_int32_r(config, "-ctlcount");
+        g_rank_total = nl;
+        for (k = 0; k < 2; k++) {
+            const char *nm = cmd_ln_str_r(config, k == 0 ? "-hyp" : "-hypseg");
+            if (nm) snprintf(g_final[k], sizeof g_final[k], "%s.gathered", nm);
+        }
+    }
     s->funcs->utt_begin = utt_begin_slot;
     s->funcs->utt_end = utt_end_slot;
     if (g_dev_dag) { s->funcs->gen_dag = utt_gen_dag_slot; s->funcs->bestpath_impl = utt_bestpath_slot; }
@@ -1381,6 +1423,44 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     t_dec = now_s() - t_dec;
     if (kb.matchsegfp) fclose(kb.matchsegfp);
     if (kb.matchfp) fclose(kb.matchfp);
+    if (g_gather && (g_final[0][0] || g_final[1][0])) {
+        /* the end-of-batch exchange: every rank's hypothesis records to every rank over RCCL, in C; rank 0
+         * writes the files of the whole control list (match_write / matchseg_write: s3a_hyp_format_var) */
+        char rdv[4400];
+        s3a_gather_t *gt;
+        snprintf(rdv, sizeof rdv, "%s.rccl-id", g_final[0][0] ? g_final[0] : g_final[1]);
+        if (g_rank == 0) remove(rdv);
+        if ((gt = s3a_gather_init(g_rank, g_world, rdv)) == NULL) die("s3a_gather_init");
+        if (s3a_gather_hyps(gt, g_rec_n, g_rec_hdr, g_rec_words, g_rank_total) != S3A_OK) die("s3a_gather_hyps");
+        if (g_rank == 0) {
+            dict_t *dict = kbcore_dict(kbc);
+            const int32 nw = dict_size(dict);
+            const char **wstr = ckd_calloc(nw + 1, sizeof(char *));
+            int32 *base = ckd_calloc(nw + 1, 4), i;
+            FILE *fh = g_final[0][0] ? fopen(g_final[0], "w") : NULL, *fs = g_final[1][0] ? fopen(g_final[1], "w") : NULL;
+            for (i = 0; i < nw; i++) { wstr[i] = dict_wordstr(dict, i); base[i] = dict_basewid(dict, i); }
+            for (i = 0; i < g_rank_total; i++) {
+                const s3a_hyp_header_t *h;
+                const s3a_hyp_word_t *ww;
+                size_t cap;
+                char *m, *sg;
+                if (s3a_gather_result(gt, i, &h, &ww) != S3A_OK) die("s3a_gather_result");
+                if (h->status != 0) continue;               /* the reference writes no line for it (srch.c:495-498) */
+                cap = 65536 + 64 * (size_t)h->n_words;
+                m = ckd_calloc(cap, 1); sg = ckd_calloc(cap, 1);
+                if (s3a_hyp_format_var(h, ww, wstr, base, w->is_filler, w->startwid, w->finishwid, (float)kbcore_lm(kbc)->lw,
+                                       kbcore_lm(kbc)->wip, cmd_ln_int32_r(config, "-hypsegscore_unscale"), m, cap, sg, cap) != S3A_OK) die("s3a_hyp_format_var");
+                if (fh) fputs(m, fh);
+                if (fs) fputs(sg, fs);
+                ckd_free(m); ckd_free(sg);
+            }
+            if (fh) fclose(fh);
+            if (fs) fclose(fs);
+            E_INFO("tst shim: rank 0 gathered %d utterances from %d ranks over RCCL and wrote the output files\n", g_rank_total, g_world);
+            remove(rdv);
+        }
+        s3a_gather_free(gt);
+    }
     if (g_frames == 0) E_FATAL("tst shim: nothing was decoded\n");
     E_INFO("tst shim: %ld frames searched by the replacement backend in %d lane(s), whole utterances on the device\n",
            g_frames, n_lanes);
@@ -1515,7 +1595,8 @@ main(int argc, char *argv[])
 #ifndef LT_ORACLE
     /* One process per GPU (torchrun / mpirun set RANK, WORLD_SIZE, LOCAL_RANK): rank r decodes the r-th contiguous
      * share of the control file (inside the caller's -ctloffset / -ctlcount) on GPU LOCAL_RANK and writes
-     * <hyp>.part<r> / <hypseg>.part<r>; the parts, concatenated in rank order, are the one-process files. */
+     * <hyp>.part<r> / <hypseg>.part<r>; the parts, concatenated in rank order, are the one-process files.  With S3A_UTT the
+     * ranks also exchange their hypothesis records over RCCL (s3a_gather_hyps) and rank 0 writes <hyp> / <hypseg>. */
     if (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 && getenv("RANK")) {
         const int W = atoi(getenv("WORLD_SIZE")), r = atoi(getenv("RANK"));
         const int lr = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : r;
@@ -1531,6 +1612,7 @@ main(int argc, char *argv[])
             if (a > 0 && a + 1 < argc && (!strcmp(argv[a], "-hyp") || !strcmp(argv[a], "-hypseg"))) {
                 const int k = !strcmp(argv[a], "-hyp") ? 0 : 1;
                 snprintf(part[k], sizeof part[k], "%s.part%03d", argv[a + 1], r);
+                snprintf(g_final[k], sizeof g_final[k], "%s", argv[a + 1]);
                 av[ac++] = argv[a]; av[ac++] = part[k]; a++;
                 continue;
             }
@@ -1543,11 +1625,12 @@ main(int argc, char *argv[])
         if (ucnt >= 0 && ucnt < n_lines) n_lines = ucnt;
         base = n_lines / W; extra = n_lines % W;
         off = uoff + r * base + (r < extra ? r : extra); cnt = base + (r < extra ? 1 : 0);
+        g_rank = r; g_world = W; g_rank_first = off - uoff; g_rank_total = n_lines;
         snprintf(so, sizeof so, "%d", off); snprintf(sc, sizeof sc, "%d", cnt);
         av[ac++] = "-ctloffset"; av[ac++] = so; av[ac++] = "-ctlcount"; av[ac++] = sc;
         argc = ac; argv = av;
         E_INFO("tst shim: rank %d of %d on GPU %d: control-file entries %d .. %d\n", r, W, lr, off, off + cnt - 1);
-        if (cnt == 0) return 0;
+        if (cnt == 0 && !(getenv("S3A_UTT") && atoi(getenv("S3A_UTT")) > 0)) return 0;
     }
 #endif
     cmd_ln_appl_enter(argc, argv, "default.arg", arg);      /* `arg`: the reference's own table */

@@ -343,7 +343,7 @@ def test_one_process_per_gpu_shards_the_control_file(tmp_path):
     hyp, seg = str(tmp_path / "w.match"), str(tmp_path / "w.matchseg")
     procs = []
     for r in range(3):
-        env = dict(os.environ, S3A_UTT="4", WORLD_SIZE="3", RANK=str(r), LOCAL_RANK="0")
+        env = dict(os.environ, S3A_UTT="4", WORLD_SIZE="3", RANK=str(r), LOCAL_RANK="0", S3A_NO_RCCL="1")   # (RCCL: one rank per GPU)
         procs.append(subprocess.Popen([TST] + common() + RUNS["mode4_trigram"] + ["-hyp", hyp, "-hypseg", seg],
                                       stdout=subprocess.DEVNULL, stderr=open(tmp_path / f"r{r}.log", "w"), env=env))
     for r, p in enumerate(procs):
@@ -352,3 +352,20 @@ def test_one_process_per_gpu_shards_the_control_file(tmp_path):
     assert [p.count("\n") for p in parts] == [11, 10, 10]
     assert "".join(parts) == open(os.path.join(D, "ref_mode4_trigram.match")).read()
     assert "".join(open(f"{seg}.part{r:03d}").read() for r in range(3)) == open(os.path.join(D, "ref_mode4_trigram.matchseg")).read()
+
+
+def test_end_of_batch_exchange_in_c_over_rccl_one_rank(tmp_path):
+    """The C side of the multi-GPU flow (s3a_gather_init / s3a_gather_hyps: RCCL loaded at run time, three all-gathers of
+    (header, words) records on device buffers, rank 0 writing -hyp / -hypseg through s3a_hyp_format_var) with the one rank
+    a one-GPU box allows: S3A_GATHER=1 makes the drop-in write <hyp>.gathered from the gathered records; with -bestpath 1
+    the records are the SECOND pass's.  Utterances that cannot be ended get no line either way."""
+    for tag, extra in (("fp", []), ("bp", ["-bestpath", "1"])):
+        hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
+        with open(log, "w") as lf:
+            p = subprocess.run([TST] + common() + RUNS["mode4_trigram"] + extra + ["-hyp", hyp, "-hypseg", seg], stdout=lf,
+                               stderr=subprocess.STDOUT, timeout=900, env=dict(os.environ, S3A_UTT="6", S3A_GATHER="1"))
+        txt = open(log, errors="ignore").read()
+        assert p.returncode == 0, "\n".join(l for l in txt.splitlines() if "FATAL" in l or "tst shim" in l)[-2000:]
+        assert "gathered 31 utterances from 1 ranks over RCCL" in txt
+        assert open(hyp + ".gathered").read() == open(hyp).read() and open(seg + ".gathered").read() == open(seg).read()
+        assert open(hyp).read().count("\n") == 31
