@@ -248,6 +248,7 @@ def main():
     ap.add_argument("--engines", type=int, default=4, help="decoder engines per GPU (own stream each) the lanes are split over")
     ap.add_argument("--min-group", type=int, default=32, help="a rank's share is cut into groups of at least this many utterances")
     ap.add_argument("--frames", type=int, default=1000, help="nominal frames per utterance (10 s)")
+    ap.add_argument("--cand-cap", type=int, default=0, help="word-level candidate capacity per lane (0: the library's default, 1 << 20)")
     ap.add_argument("--cpu-procs", type=int, default=16, help="processes of the CPU baseline's batch leg (16: where this host's aggregate peaks)")
     ap.add_argument("--no-cpu", action="store_true", help="no CPU baseline: the reference decodes (and checks) 2 utterances only")
     ap.add_argument("--check-all", action="store_true", help="the reference decodes the WHOLE batch (~3 more minutes of CPU): every utterance is compared")
@@ -309,7 +310,7 @@ def main():
     NE = max(1, args.engines)
     assert NL % NE == 0, "--lanes must be a multiple of --engines"
     NLE = NL // NE                                  # lanes per engine
-    decs = [bundle.Decoder(bpath, NLE, precision=lib.GMM_FAST if args.fast else lib.GMM_EXACT,
+    decs = [bundle.Decoder(bpath, NLE, precision=lib.GMM_FAST if args.fast else lib.GMM_EXACT, cand_cap=args.cand_cap,
                            max_frames=max(len(f) for f in hfeat) // 39 + 8) for _ in range(NE)]
     dec = decs[0]
     t_load = time.perf_counter() - t_load
@@ -393,10 +394,18 @@ def main():
     # ---------------- the timed region ----------------
     cgather = None
     if dist is None:
+        import ctypes
+        saved = os.dup(1)
         try:
+            sys.stdout.flush()
+            os.dup2(2, 1)                   # (RCCL prints a version banner to C stdout: keep stdout to the ONE JSON line)
             cgather = lib.Gather(0, 1)      # (the drop-in's own C exchange; RCCL loaded at run time)
         except lib.S3AError:
             cgather = None
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
     n_total = U if args.scaling == "strong" else U * world
     for i in range(args.warmup):
         run_step(i)
@@ -446,6 +455,14 @@ def main():
         n_chk = ref[2]
         got_h, got_s = "".join(l[0] for l in lines[:n_chk]), "".join(l[1] for l in lines[:n_chk])
         hyp_ok, seg_ok = got_h == ref[0], got_s == ref[1]
+        if not (hyp_ok and seg_ok):
+            rl, rs = ref[0].splitlines(keepends=True), ref[1].splitlines(keepends=True)
+            bad = [k for k in range(min(n_chk, len(rl), len(lines))) if lines[k][0] != rl[k] or lines[k][1] != rs[k]]
+            where = {k: (e, gi, z) for e, gs in enumerate(schedule(my_share(0)[0])) for gi, g in enumerate(gs) for z, k in enumerate(g)}
+            print(f"bench: {len(bad)} of {n_chk} checked utterances differ from the reference: "
+                  + ", ".join(f"utt {k} (engine, group, lane) = {where.get(k)}" for k in bad[:12]), file=sys.stderr)
+            for k in bad[:2]:
+                print("  device:", lines[k][1].strip()[:600], "\n  refrnc:", rs[k].strip()[:600], file=sys.stderr)
         assert hyp_ok and (seg_ok or args.fast), "device hypotheses differ from the unmodified reference decoder's"
 
         # ---- per-kernel timing of one profiled group (HIP events on the launch stream, every 4th frame) ----

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <limits.h>
 #include <vector>
@@ -149,6 +150,62 @@ ku_lanes_begin(const ULane *__restrict__ lanes, UShared S, UBegin B)
             for (int k = 0; k < 5; k++) L.w.lmc[(size_t)k * L.w.cap] = B.lmc[k];
             L.w.frame_start[0] = 1; L.w.bestscore[0] = INT_MIN; L.w.bestvh[0] = -1; L.w.st[0] = 1; L.w.st[1] = 0;
         }
+    }
+}
+
+/* debugging (S3A_UTT_FRAMECHECK=1): after every frame, every node record that is not an inactive HMM must be on the NEXT
+ * list at the place its record names; the first violation of a lane is kept: dbg[0] = frame + 1 (0: none), [1] node,
+ * [2..7] sc0 sc1 outs bests frame-tag posf, [8] pos, [9] turn, [10] list length of its tree, [11] what sits at pos */
+__global__ void __launch_bounds__(256)
+ku_framecheck(const ULane *__restrict__ lanes, UShared S, int32_t f, int32_t *dbg_all)
+{
+    LANE;
+    int32_t *dbg = dbg_all + 16 * blockIdx.z;
+    const int32_t nf = f + 1, nxt = cur ^ 1;
+    for (int32_t v = blockIdx.x * 256 + threadIdx.x; v < S.N; v += gridDim.x * 256) {
+        const int32_t *r = L.sc + NSV(v);
+        const bool clean = r[0] == WORST && r[1] == WORST && r[2] == WORST && r[NS_OFF_OUTS] == WORST && r[NS_OFF_BESTS] == WORST;
+        const int32_t t = S.tree_of[v], b = S.node_base[t], p = L.pos[v];
+        const int32_t nn = S.nact_all[((size_t)blockIdx.z * 2 + nxt) * WL_MAXT + t];
+        const bool listed = L.posf[v] == nf && p >= 0 && p < nn && L.act[nxt][b + p] == v;
+        /* the propagation scratch must be consumed by the end of the frame: turn by node; selfemit / cnt by list position */
+        if (L.turn[v] != -1 || L.selfemit[v] != 0 || L.cnt[v] != 0) {
+            if (atomicCAS(&dbg[15], 0, f + 1) == 0) {
+                /* (reported through the same record when the node check finds nothing) */
+                if (atomicCAS(&dbg[0], 0, -(f + 1)) == 0) {
+                    dbg[1] = v; dbg[2] = L.turn[v]; dbg[3] = L.selfemit[v]; dbg[4] = L.cnt[v]; dbg[5] = ctx->nfr; dbg[6] = S.nact_all[((size_t)blockIdx.z * 2 + cur) * WL_MAXT + S.tree_of[v]];
+                    dbg[7] = v - S.node_base[S.tree_of[v]]; dbg[14] = S.tree_of[v];
+                }
+            }
+        }
+        if ((!clean && !listed) || (listed && r[NS_OFF_FRAME] != nf)) {
+            if (atomicCAS(&dbg[0], 0, f + 1) == 0) {
+                dbg[1] = v; dbg[2] = r[0]; dbg[3] = r[1]; dbg[4] = r[NS_OFF_OUTS]; dbg[5] = r[NS_OFF_BESTS]; dbg[6] = r[NS_OFF_FRAME];
+                dbg[7] = L.posf[v]; dbg[8] = p; dbg[9] = L.turn[v]; dbg[10] = nn; dbg[11] = (p >= 0 && p < nn) ? L.act[nxt][b + p] : -7;
+                dbg[12] = clean ? 1 : 0; dbg[13] = listed ? 1 : 0; dbg[14] = t;
+            }
+        }
+    }
+}
+
+/* self-check (tests / debugging): after ku_lanes_end every node record of a lane must be an inactive HMM (hmm_clear);
+ * out[0..5] = nodes whose state-0 / -1 / -2 score, exit score, best score is not WORST, whose frame tag is not -1;
+ * out[6] = the first such node; out[7] = nodes with turn != -1 | selfemit / cnt left set (by position) */
+__global__ void __launch_bounds__(256)
+ku_selfcheck(const ULane *__restrict__ lanes, UShared S, int32_t lane, int32_t *out)
+{
+    const ULane &L = lanes[lane];
+    for (int32_t v = blockIdx.x * 256 + threadIdx.x; v < S.N; v += gridDim.x * 256) {
+        const int32_t *r = L.sc + NSV(v);
+        bool bad = false;
+        if (r[0] != WORST) { atomicAdd(&out[0], 1); bad = true; }
+        if (r[1] != WORST) { atomicAdd(&out[1], 1); bad = true; }
+        if (r[2] != WORST) { atomicAdd(&out[2], 1); bad = true; }
+        if (r[NS_OFF_OUTS] != WORST) { atomicAdd(&out[3], 1); bad = true; }
+        if (r[NS_OFF_BESTS] != WORST) { atomicAdd(&out[4], 1); bad = true; }
+        if (r[NS_OFF_FRAME] != -1) { atomicAdd(&out[5], 1); bad = true; }
+        if (bad) atomicMin(&out[6], v);
+        if (L.turn[v] != -1 || L.selfemit[v] != 0 || L.cnt[v] != 0) atomicAdd(&out[7], 1);
     }
 }
 
@@ -1076,6 +1133,7 @@ struct s3a_uttdec_s {
     int32_t big_wl;             /* the word level's candidate phases as their own launches (wide beams) */
     hipEvent_t ev0, ev1;        /* around the frames of a decode (last_decode_ms) */
     int32_t no_multi, gy;       /* tuning switches, read ONCE at init (S3A_UTT_NO_MULTI, S3A_UTT_GY; tests) */
+    int32_t *d_dbg;             /* S3A_UTT_FRAMECHECK: [n_lanes][16] first broken invariant per lane */
     int32_t win_fpc;            /* S3A_UTT_WIN_FPC: slots per chunk of the look-ahead scoring (0: the cost model's) */
     UCtx *h_ctx_up;             /* pinned [n_lanes]: the lanes' contexts of the coming decode, uploaded with ONE copy */
     int32_t n_pset;
@@ -1259,6 +1317,8 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     /* launch geometry: fixed grids, the kernels loop over the list lengths they find in memory */
     ud->eval_block = (cfg->maxhmmpf >= EVBLOCK_LONG_LIST && maxn >= EVBLOCK_LONG_LIST) ? 256 : 64;
     ud->no_multi = getenv("S3A_UTT_NO_MULTI") != NULL;
+    ud->d_dbg = NULL;
+    if (getenv("S3A_UTT_FRAMECHECK")) { if (hipMalloc((void **)&ud->d_dbg, (size_t)n_lanes * 64) != hipSuccess || hipMemset(ud->d_dbg, 0, (size_t)n_lanes * 64) != hipSuccess) ud->d_dbg = NULL; }
     ud->gy = getenv("S3A_UTT_GY") ? atoi(getenv("S3A_UTT_GY")) : 0;
     ud->many = getenv("S3A_UTT_MANY") ? max(1, atoi(getenv("S3A_UTT_MANY"))) : 32;
     /* fixed grids, sized for the usual frame: a workgroup loops when a list is longer (virtual workgroups); with many
@@ -1352,8 +1412,8 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     for (auto &hl : ud->lane) memset((void *)&hl, 0, sizeof hl);
     if (T > WL_MAXT) { s3a_set_error("s3a_uttdec_init: more than %d lextrees", WL_MAXT); goto fail; }
     DM(ud->S.ctx_all, sizeof(UCtx) * n_lanes);
-    if (hipHostMalloc((void **)&ud->h_ctx_up, sizeof(UCtx) * n_lanes) != hipSuccess) { s3a_set_error("s3a_uttdec_init: pinned allocation failed"); goto fail; }
     DM(ud->S.nact_all, (size_t)n_lanes * 2 * WL_MAXT * 4);
+    if (hipHostMalloc((void **)&ud->h_ctx_up, sizeof(UCtx) * n_lanes) != hipSuccess) { s3a_set_error("s3a_uttdec_init: pinned allocation failed"); goto fail; }
     if (hipMemset(ud->S.nact_all, 0, (size_t)n_lanes * 2 * WL_MAXT * 4) != hipSuccess
         || hipMemset(ud->S.ctx_all, 0, sizeof(UCtx) * n_lanes) != hipSuccess) goto fail;
     for (int32_t z = 0; z < n_lanes; z++) {
@@ -1664,6 +1724,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
         UKL(UK_WL_P5, ku_wl_p5, gb, tb, 0, st, LN, ud->dict, ud->par, f);
         UKL(UK_WL_FIN, ku_wl_finish, one, tb, 0, st, LN, ud->lm->d, ud->dict, ud->par, f);
     }
+    if (ud->d_dbg) hipLaunchKernelGGL(ku_framecheck, dim3(64, 1, n), dim3(256), 0, st, LN, S, f, ud->d_dbg);
 #undef UKL
     HIPCHK(hipGetLastError());
     return S3A_OK;
@@ -1893,6 +1954,32 @@ extern "C" double
 s3a_uttdec_last_decode_ms(const s3a_uttdec_t *ud)
 {
     return ud ? ud->last_decode_ms : 0.0;
+}
+
+/* diagnostics: lextree_utt_end on every lane, then the node records of `lane` that are not an inactive HMM
+ * (see ku_selfcheck); all zeros (out[6] = INT_MAX) on a healthy lane */
+extern "C" int32_t
+s3a_uttdec_selfcheck(s3a_uttdec_t *ud, int32_t lane, int32_t *out8)
+{
+    if (!ud || !out8 || lane < 0 || lane >= ud->n_lanes) return S3A_EINVAL;
+    HIPCHK(hipSetDevice(ud->device));
+    int32_t *d = NULL, init[8] = { 0, 0, 0, 0, 0, 0, INT_MAX, 0 };
+    HIPCHK(hipMalloc((void **)&d, sizeof init));
+    HIPCHK(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ud->stream));
+    hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * ud->S.T, ud->n_lanes), dim3(256), 0, ud->stream, ud->d_lanes, ud->S);
+    hipLaunchKernelGGL(ku_selfcheck, dim3(64), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, lane, d);
+    HIPCHK(hipMemcpyAsync(out8, d, sizeof init, hipMemcpyDeviceToHost, ud->stream));
+    HIPCHK(hipStreamSynchronize(ud->stream));
+    (void)hipFree(d);
+    if (ud->d_dbg) {
+        int32_t g[16];
+        HIPCHK(hipMemcpy(g, ud->d_dbg + 16 * lane, sizeof g, hipMemcpyDeviceToHost));
+        if (g[0] < 0) fprintf(stderr, "framecheck lane %d: scratch left set first at frame %d (utterance of %d frames): index %d (tree %d, offset %d; current list length %d): turn %d selfemit %d cnt %d\n",
+                              lane, -g[0] - 1, g[5], g[1], g[14], g[7], g[6], g[2], g[3], g[4]);
+        else if (g[0]) fprintf(stderr, "framecheck lane %d: first violation at frame %d node %d (tree %d): sc0 %d sc1 %d outs %d bests %d frame-tag %d posf %d pos %d turn %d | next list length %d, act[pos] %d | clean %d listed %d\n",
+                          lane, g[0] - 1, g[1], g[14], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13]);
+    }
+    return S3A_OK;
 }
 
 extern "C" int32_t

@@ -963,7 +963,10 @@ wl_finish(const WLane &L, UCtx *ctx, const int32_t *pack, const WLm &lm, const W
         if (e2) ctx->err |= e2;
         ctx->cf = cf + 1;
         ctx->cur ^= 1;                                  /* lextree_active_swap */
-        if (cf + 1 >= ctx->nfr || e2) ctx->active = 0;
+        /* (NOT at the utterance's last frame: the emission workgroups of this very launch test ctx->active, and one that
+         * starts after this workgroup has finished -- another queue's kernels on the chip -- would skip its sweep and leave
+         * the propagation scratch set for the lane's NEXT utterance; frames >= nfr are skipped by the frame test anyway) */
+        if (e2) ctx->active = 0;
     }
     WL_STAMP(tp, 8);
 }

@@ -189,6 +189,7 @@ _SIGS = {
     "s3a_uttdec_wl_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_window": (C.c_int32, [C.c_void_p]),
+    "s3a_uttdec_selfcheck": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_gather_init": (C.c_void_p, [C.c_int32, C.c_int32, C.c_char_p]),
     "s3a_gather_free": (None, [C.c_void_p]),
     "s3a_gather_hyps": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -1429,6 +1430,11 @@ class UttDec:
 
     def window(self):
         return int(self.L.s3a_uttdec_window(self.h))
+
+    def selfcheck(self, lane):
+        out = np.zeros(8, np.int32)
+        check(self.L.s3a_uttdec_selfcheck(self.h, int(lane), _p(out)), self.L)
+        return out
 
     def enable_bestpath(self, cfg, link_cap=0, pair_cap=0, keep_tables=True):
         self._dag_cfg = cfg

@@ -699,6 +699,10 @@ int32_t s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out)
  * [6] pruning, [7] table + LM contexts, [8] word transitions) */
 int32_t s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16);
 int32_t s3a_uttdec_n_lanes(const s3a_uttdec_t *ud);
+/* diagnostics: lextree_utt_end on every lane, then how many node records of `lane` are NOT an inactive HMM
+ * (out[0..5]: state scores 0/1/2, exit score, best score, frame tag; out[6] the first such node, INT_MAX: none;
+ * out[7] propagation scratch left set) -- all clean on a healthy lane between utterances */
+int32_t s3a_uttdec_selfcheck(s3a_uttdec_t *ud, int32_t lane, int32_t *out8);
 /* frames per look-ahead scoring window (one pass over the acoustic model scores every senone of the next K frames of
  * all lanes; approx_cont_mgau_frame_eval's gate is then applied per frame); 0: per-frame scoring kernels */
 int32_t s3a_uttdec_window(const s3a_uttdec_t *ud);
