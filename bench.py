@@ -363,7 +363,7 @@ def main():
                 t_dec += t1 - t0
                 t_hyp += time.perf_counter() - t1
             return ms, out, t_dec, t_hyp
-        done = list(pool.map(one, range(NE)))
+        done = list(pool.map(one, range(NE))) if NE > 1 else [one(0)]     # (one engine: on the calling thread)
         if recs is not None:
             for d_ in done:
                 recs.extend(d_[1])
@@ -393,7 +393,7 @@ def main():
 
     # ---------------- the timed region ----------------
     cgather = None
-    if dist is None:
+    if dist is None and not os.environ.get("S3A_BENCH_NO_RCCL"):
         import ctypes
         saved = os.dup(1)
         try:
@@ -500,6 +500,10 @@ def main():
         alg.setdefault(dom, nl0 * lanes_hmm * 84.0)
         pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else {}
         traffic = pmc.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+        if traffic is not None and pmc.get("lanes") and dom != "ku_score_window":
+            # the PMC passes ran a smaller engine: the search kernels' traffic is per lane (the look-ahead scoring launch has
+            # the same (lane, frame) slots whatever the lane count: K adapts)
+            traffic = int(traffic * nl0 / pmc["lanes"])
         if dom == "ku_score_window":
             flops = 4.0 * S * Cc * D * win_slots
             ach = flops / (dom_us * 1e-6) / 1e12
