@@ -563,7 +563,8 @@ def main():
                          "s3a_gather_hyps (C, RCCL, 1 rank)" if cgather is not None else "none (RCCL not loadable)"),
             "load_s": round(t_load, 2), "setup_s": round(t_setup, 1),
             "per_frame": {"active_hmm": round(lanes_hmm, 1), "cd_senones_scored": round(lanes_sen, 1), "cd_gaussians": round(lanes_gau, 1),
-                          "word_exits": round(lanes_exit, 2), "max_candidates": int(res0["max_cand"]), "tie_frames_lane0": int(res0["n_tie_frames"])},
+                          "word_exits": round(lanes_exit, 2), "max_active_hmm": int(max(s_[:, 1].max() for s_ in stat)),
+                          "frames_with_histogram_pruning": int(sum(int(s_[:, 6].sum()) for s_ in stat)), "max_candidates": int(res0["max_cand"]), "tie_frames_lane0": int(res0["n_tie_frames"])},
             "roofline": roof,
             "kernels": kern,
         }
