@@ -1088,6 +1088,116 @@ s3a_lm3g_tg_score(const s3a_lm3g_t *lm, int32_t lw1, int32_t lw2, int32_t lw3, i
     return h_add(bowt, h_bg(lm, lw2, lw3, wid));
 }
 
+/* ------------------------------------------------------------------ */
+/* the hypothesis of a finished lane, on the device                    */
+/* ------------------------------------------------------------------ */
+/*
+ * vithist_utt_end (vithist.c:766-860) + vithist_backtrace (vithist.c:1066-1100) + compute_scale (srch_output.c:52-60)
+ * for every lane behind its last frame: the best transition into </s> from the last frame that has entries (the
+ * earliest of equals), a silence entry over the rest when the search died early, the backtrace, every word's sum of
+ * frame normalisers.  Nothing is added to the lane's table: the final entries exist in the record only.  What the
+ * host reads back per utterance is UH_N words + 24 bytes per hypothesis word, not the history table: the lanes' words
+ * are packed one behind the other (a lane reserves its place with one atomicAdd on the word counter behind the headers),
+ * so that ONE linear copy brings them over.
+ */
+enum { UH_STATUS, UH_NENTRY, UH_NFRM, UH_TSCALE, UH_NWORDS, UH_SCORE, UH_EXIT, UH_WOFF, UH_N };
+#define UH_FIRST 96          /* words per lane that travel with the headers (more: a second copy) */
+struct UHypPar { int32_t finish_lwid, finishwid, silwid, wcap; };
+#define UH_T 256
+#define UH_IDS 2048
+
+__global__ void __launch_bounds__(UH_T)
+ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *__restrict__ hdr_all, int32_t *__restrict__ words_all)
+{
+    const ULane &L = lanes[blockIdx.x];
+    const WLane &w = L.w;
+    const UCtx *ctx = L.ctx;
+    int32_t *hdr = hdr_all + (size_t)blockIdx.x * UH_N;
+    const int32_t tid = threadIdx.x, nfr = ctx->nfr, n_entry = w.st[0], n_frm = w.st[1];
+    __shared__ uint32_t s_scale;
+    __shared__ int32_t s_woff;
+    __shared__ unsigned long long s_best;
+    __shared__ int32_t s_f, s_n, s_ids[UH_IDS];
+    if (tid == 0) { s_scale = 0u; s_best = 0ull; s_n = 0; }
+    __syncthreads();
+    uint32_t part = 0u;
+    for (int32_t f = tid; f < nfr; f += UH_T) part += (uint32_t)w.fstat[(size_t)f * 8];
+    atomicAdd(&s_scale, part);
+    if (tid == 0) {
+        int32_t f;
+        for (f = n_frm - 1; f >= 0; --f)
+            if (w.frame_start[f] < w.frame_start[f + 1]) break;
+        s_f = f;
+    }
+    __syncthreads();
+    const int32_t f = s_f, err = ctx->err;
+    if (tid == 0) {
+        hdr[UH_STATUS] = err ? -1 : (f < 0 ? -2 : 0); hdr[UH_NENTRY] = n_entry; hdr[UH_NFRM] = n_frm; hdr[UH_TSCALE] = (int32_t)s_scale;
+        hdr[UH_NWORDS] = 0; hdr[UH_SCORE] = 0; hdr[UH_EXIT] = -1; hdr[UH_WOFF] = 0;
+    }
+    if (err || f < 0) return;               /* (f < 0: no word exit at all -- vithist_utt_end returns -1) */
+    const int32_t sv = w.frame_start[f], nsv = w.frame_start[f + 1];
+    for (int32_t i = sv + tid; i < nsv; i += UH_T) {
+        const int32_t sc = add32(w.score[i], wl_tg_score(lm, w.lw1[i], w.lw0[i], P.finish_lwid, P.finishwid));
+        atomicMax(&s_best, wl_pack(sc, (uint32_t)i));            /* best < s: the earliest of equals */
+    }
+    __syncthreads();
+    const int32_t bestvh = (int32_t)(0xffffffffu - (uint32_t)(s_best & 0xffffffffull));
+    int32_t best = (int32_t)((uint32_t)(s_best >> 32) ^ 0x80000000u);
+    const bool have_sil = f != n_frm - 1;   /* the search died early: a silence entry over the rest (vithist.c:817-826) */
+    if (tid == 0) {
+        int32_t n = 0;
+        for (int32_t i = bestvh; i > 0; i = w.pred[i], n++) if (n < UH_IDS) s_ids[n] = i;
+        s_n = n;
+        const int32_t tot = n + (have_sil ? 1 : 0) + 1;
+        s_woff = tot <= P.wcap ? atomicAdd(hdr_all + (size_t)gridDim.x * UH_N, tot) : 0;
+    }
+    __syncthreads();
+    const int32_t n = s_n, total = n + (have_sil ? 1 : 0) + 1;
+    int32_t *words = words_all + (size_t)s_woff * 6;
+    int32_t last_ef = w.ef[bestvh], last_score = w.score[bestvh];
+    int32_t sil_lscr = 0;
+    if (have_sil) {
+        sil_lscr = dict.fillpen[P.silwid];
+        const int32_t sil_score = add32(w.score[bestvh], sil_lscr);
+        best = add32(sil_score, wl_tg_score(lm, w.lw1[bestvh], w.lw0[bestvh], P.finish_lwid, P.finishwid));
+        last_ef = n_frm - 1; last_score = sil_score;
+    }
+    if (tid == 0) { hdr[UH_NWORDS] = total; hdr[UH_SCORE] = best; hdr[UH_EXIT] = n_entry + (have_sil ? 1 : 0); hdr[UH_WOFF] = s_woff; }
+    if (total > P.wcap) { if (tid == 0) hdr[UH_STATUS] = -3; return; }
+    if (n <= UH_IDS) {
+        for (int32_t q = tid; q < n; q += UH_T) {
+            const int32_t i = s_ids[n - 1 - q];
+            int32_t *o = words + (size_t)q * 6;
+            o[0] = w.wid[i]; o[1] = w.sf[i]; o[2] = w.ef[i]; o[3] = w.ascr[i]; o[4] = w.lscr[i];
+        }
+    }
+    else if (tid == 0) {
+        int32_t k = n - 1;
+        for (int32_t i = bestvh; i > 0; i = w.pred[i], k--) {
+            int32_t *o = words + (size_t)k * 6;
+            o[0] = w.wid[i]; o[1] = w.sf[i]; o[2] = w.ef[i]; o[3] = w.ascr[i]; o[4] = w.lscr[i];
+        }
+    }
+    if (tid == 0) {
+        int32_t k = n;
+        if (have_sil) {
+            int32_t *o = words + (size_t)k * 6;
+            o[0] = P.silwid; o[1] = w.ef[bestvh] + 1; o[2] = n_frm - 1; o[3] = add32(w.score[bestvh], -w.score[bestvh]); o[4] = sil_lscr;
+            k++;
+        }
+        int32_t *o = words + (size_t)k * 6;
+        o[0] = P.finishwid; o[1] = last_ef + 1; o[2] = n_frm; o[3] = 0; o[4] = add32(best, -last_score);
+    }
+    __syncthreads();
+    for (int32_t q = tid; q < total; q += UH_T) {           /* compute_scale */
+        int32_t *o = words + (size_t)q * 6;
+        uint32_t sc = 0u;
+        for (int32_t i = max(o[1], 0); i < o[2] && i < nfr; i++) sc += (uint32_t)w.fstat[(size_t)i * 8];
+        o[5] = (int32_t)sc;
+    }
+}
+
 struct HostLane {
     s3a_lexsearch_t *ls;
     s3a_scorer_t *sc;
@@ -1134,12 +1244,17 @@ struct s3a_uttdec_s {
     hipEvent_t ev0, ev1;        /* around the frames of a decode (last_decode_ms) */
     int32_t no_multi, gy;       /* tuning switches, read ONCE at init (S3A_UTT_NO_MULTI, S3A_UTT_GY; tests) */
     int32_t *d_dbg;             /* S3A_UTT_FRAMECHECK: [n_lanes][16] first broken invariant per lane */
+    int32_t times;              /* S3A_UTT_TIMES: print the host-side phases of every decode call to stderr */
     int32_t win_fpc;            /* S3A_UTT_WIN_FPC: slots per chunk of the look-ahead scoring (0: the cost model's) */
+    UCtx *h_ctx_dn;             /* pinned [n_lanes]: the lanes' contexts after a decode (HostLane.h_ctx points into it) */
+    int32_t *d_hyp_hdr, *h_hyp_hdr;     /* [n_lanes][UH_N]: ku_hyp's header per lane (device / pinned) */
+    int32_t *d_hyp_words, *h_hyp_words; /* [n_lanes][hyp_wcap][6]: its words */
+    int32_t hyp_wcap;
     UCtx *h_ctx_up;             /* pinned [n_lanes]: the lanes' contexts of the coming decode, uploaded with ONE copy */
     int32_t n_pset;
     s3a_dagpass_t *dag;         /* the second pass after every decode (s3a_uttdec_enable_bestpath), or NULL */
     int32_t keep_tables;        /* 0: with the second pass enabled the history tables stay on the device */
-    int32_t tables_fetched;
+    int32_t tables_fetched, fstat_fetched;
 };
 
 static int32_t
@@ -1214,7 +1329,6 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
             && hl.ls->d_nact[0] < ud->S.nact_all + (size_t)ud->n_lanes * 2 * WL_MAXT)
             hl.ls->d_nact[0] = hl.ls->d_nact[1] = NULL;     /* borrowed from nact_all */
         if (hl.d_feat) (void)hipFree(hl.d_feat);
-        if (hl.h_ctx) (void)hipHostFree(hl.h_ctx);
         if (hl.h_feat) (void)hipHostFree(hl.h_feat);
         if (hl.h_tab) (void)hipHostFree(hl.h_tab);
         if (hl.h_st) (void)hipHostFree(hl.h_st);
@@ -1224,6 +1338,11 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     }
     if (ud->dag) s3a_dagpass_free(ud->dag);
     if (ud->h_ctx_up) (void)hipHostFree(ud->h_ctx_up);
+    if (ud->h_ctx_dn) (void)hipHostFree(ud->h_ctx_dn);
+    if (ud->h_hyp_hdr) (void)hipHostFree(ud->h_hyp_hdr);
+    if (ud->h_hyp_words) (void)hipHostFree(ud->h_hyp_words);
+    if (ud->d_hyp_hdr) (void)hipFree(ud->d_hyp_hdr);
+    if (ud->d_hyp_words) (void)hipFree(ud->d_hyp_words);
     if (ud->ev0) (void)hipEventDestroy(ud->ev0);
     if (ud->ev1) (void)hipEventDestroy(ud->ev1);
     if (ud->d_lanes) (void)hipFree(ud->d_lanes);
@@ -1267,7 +1386,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
     ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
-    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->h_ctx_up = NULL; ud->n_pset = proto->n_pset;
+    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->h_ctx_up = NULL; ud->h_ctx_dn = NULL; ud->d_hyp_hdr = ud->h_hyp_hdr = ud->d_hyp_words = ud->h_hyp_words = NULL; ud->hyp_wcap = 0; ud->n_pset = proto->n_pset;
     (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
@@ -1406,6 +1525,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
             if (getenv("S3A_UTT_WIN")) K = max(0, (atoi(getenv("S3A_UTT_WIN")) + 7) / 8 * 8);
         }
         S.win_K = K;
+        ud->times = getenv("S3A_UTT_TIMES") ? atoi(getenv("S3A_UTT_TIMES")) : 0;
         ud->win_fpc = getenv("S3A_UTT_WIN_FPC") ? atoi(getenv("S3A_UTT_WIN_FPC")) : 0;
     }
     ud->lane.resize(n_lanes);
@@ -1413,7 +1533,14 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     if (T > WL_MAXT) { s3a_set_error("s3a_uttdec_init: more than %d lextrees", WL_MAXT); goto fail; }
     DM(ud->S.ctx_all, sizeof(UCtx) * n_lanes);
     DM(ud->S.nact_all, (size_t)n_lanes * 2 * WL_MAXT * 4);
-    if (hipHostMalloc((void **)&ud->h_ctx_up, sizeof(UCtx) * n_lanes) != hipSuccess) { s3a_set_error("s3a_uttdec_init: pinned allocation failed"); goto fail; }
+    ud->hyp_wcap = max_frames + 4;
+    if (hipHostMalloc((void **)&ud->h_ctx_up, sizeof(UCtx) * n_lanes) != hipSuccess
+        || hipHostMalloc((void **)&ud->h_ctx_dn, sizeof(UCtx) * n_lanes) != hipSuccess
+        || hipHostMalloc((void **)&ud->h_hyp_hdr, ((size_t)n_lanes * UH_N + 1) * 4) != hipSuccess
+        || hipHostMalloc((void **)&ud->h_hyp_words, (size_t)n_lanes * ud->hyp_wcap * 6 * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_init: pinned allocation failed"); goto fail; }
+    memset(ud->h_ctx_dn, 0, sizeof(UCtx) * n_lanes);
+    DM(ud->d_hyp_hdr, ((size_t)n_lanes * UH_N + 1) * 4);
+    DM(ud->d_hyp_words, (size_t)n_lanes * ud->hyp_wcap * 6 * 4);
     if (hipMemset(ud->S.nact_all, 0, (size_t)n_lanes * 2 * WL_MAXT * 4) != hipSuccess
         || hipMemset(ud->S.ctx_all, 0, sizeof(UCtx) * n_lanes) != hipSuccess) goto fail;
     for (int32_t z = 0; z < n_lanes; z++) {
@@ -1455,8 +1582,8 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
         u.ctx = ud->S.ctx_all + z;
         DM(u.pack, (size_t)(6 * T + 16 + 3 * proto->pack_max_exits) * 4);
         if (wlane_alloc(u.w, ud->vh_cap, max_frames, ud->ex_cap, ud->cand_cap, ud->new_cap, cfg->n_word, ud->stream) != S3A_OK) goto fail;
-        if (hipHostMalloc((void **)&hl.h_ctx, sizeof(UCtx)) != hipSuccess
-            || hipHostMalloc((void **)&hl.h_st, 16 * 4) != hipSuccess
+        hl.h_ctx = ud->h_ctx_dn + z;
+        if (hipHostMalloc((void **)&hl.h_st, 16 * 4) != hipSuccess
             || hipHostMalloc((void **)&hl.h_fstat, (size_t)max_frames * 8 * 4) != hipSuccess) {
             s3a_set_error("s3a_uttdec_init: pinned allocation failed");
             goto fail;
@@ -1732,11 +1859,9 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
 
 /* download lane z's history table + frame statistics (after the frames have been enqueued) */
 static int32_t
-lane_fetch_state(s3a_uttdec_t *ud, int32_t z)
+lane_fetch_fstat(s3a_uttdec_t *ud, int32_t z)
 {
     HostLane &hl = ud->lane[z];
-    HIPCHK(hipMemcpyAsync(hl.h_st, hl.d.w.st, 16 * 4, hipMemcpyDeviceToHost, ud->stream));
-    HIPCHK(hipMemcpyAsync(hl.h_ctx, hl.d.ctx, sizeof(UCtx), hipMemcpyDeviceToHost, ud->stream));
     HIPCHK(hipMemcpyAsync(hl.h_fstat, hl.d.w.fstat, (size_t)hl.nfr * 8 * 4, hipMemcpyDeviceToHost, ud->stream));
     return S3A_OK;
 }
@@ -1776,6 +1901,9 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
     }
     HIPCHK(hipSetDevice(ud->device));
     int32_t rc, maxT = 0;
+    double tm[6] = { 0, 0, 0, 0, 0, 0 };
+    auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    tm[0] = now();
     for (int32_t z = 0; z < n_utt; z++) {
         if ((rc = lane_begin(ud, z, feat[z], n_frames[z], feat_stride, feat_on_device)) != S3A_OK) return rc;
         maxT = max(maxT, n_frames[z]);
@@ -1801,13 +1929,27 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
         return S3A_EHIP;
     }
     rc = S3A_OK;
+    tm[1] = now();
     if (hipEventRecord(ud->ev0, ud->stream) != hipSuccess) rc = S3A_EHIP;
     for (int32_t f = 0; f < maxT && rc == S3A_OK; f++)
         rc = enqueue_frame(ud, n_utt, f, ud->prof_every > 0 && f % ud->prof_every == 0);
     if (rc == S3A_OK && hipEventRecord(ud->ev1, ud->stream) != hipSuccess) rc = S3A_EHIP;
-    /* the second pass: vithist_utt_end + lattice + best path for every lane, behind the last frame on the same stream */
+    /* (the second pass -- vithist_utt_end + lattice + best path for every lane -- follows the first pass's hypotheses below) */
+    tm[2] = now();
+    /* every lane's hypothesis on the device (before the second pass appends its final entries to the tables); what
+     * comes back: the lanes' contexts (error bits, counters), the hypothesis headers, then the words */
+    if (rc == S3A_OK) {
+        const s3a_wordlevel_cfg_t &c = ud->cfg;
+        const UHypPar P = { c.finish_lwid, c.finishwid, c.silwid, ud->hyp_wcap };
+        if (hipMemsetAsync(ud->d_hyp_hdr + (size_t)n_utt * UH_N, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
+        hipLaunchKernelGGL(ku_hyp, dim3(n_utt), dim3(UH_T), 0, ud->stream, ud->d_lanes, ud->lm->d, ud->dict, P, ud->d_hyp_hdr, ud->d_hyp_words);
+        if (hipGetLastError() != hipSuccess) { s3a_set_error("s3a_uttdec_decode: ku_hyp launch failed"); rc = S3A_EHIP; }
+    }
     if (rc == S3A_OK && ud->dag) rc = s3a_dagpass_enqueue(ud->dag, n_utt, ud->stream, 1);
-    for (int32_t z = 0; z < n_utt && rc == S3A_OK; z++) rc = lane_fetch_state(ud, z);
+    const size_t first_words = min((size_t)n_utt * UH_FIRST, (size_t)ud->n_lanes * ud->hyp_wcap);
+    if (rc == S3A_OK && (hipMemcpyAsync(ud->h_ctx_dn, ud->S.ctx_all, sizeof(UCtx) * n_utt, hipMemcpyDeviceToHost, ud->stream) != hipSuccess
+                         || hipMemcpyAsync(ud->h_hyp_hdr, ud->d_hyp_hdr, ((size_t)n_utt * UH_N + 1) * 4, hipMemcpyDeviceToHost, ud->stream) != hipSuccess
+                         || hipMemcpyAsync(ud->h_hyp_words, ud->d_hyp_words, first_words * 24, hipMemcpyDeviceToHost, ud->stream) != hipSuccess)) rc = S3A_EHIP;
     if (hipStreamSynchronize(ud->stream) != hipSuccess && rc == S3A_OK) { s3a_set_error("s3a_uttdec_decode: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
     if (rc == S3A_OK) {
         float ms = 0.0f;
@@ -1824,11 +1966,26 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
         for (int32_t z = 0; z < n_utt; z++) ud->lane[z].dirty = 1;      /* nothing is known about the lanes' state */
         return rc;
     }
-    ud->tables_fetched = (!ud->dag || ud->keep_tables) ? 1 : 0;
-    if (ud->tables_fetched)
-        for (int32_t z = 0; z < n_utt; z++) if ((rc = lane_fetch_table(ud, z)) != S3A_OK) return rc;
+    tm[3] = now();
+    /* the history tables and the per-frame statistics stay on the device until someone asks (s3a_uttdec_result) */
+    ud->tables_fetched = 0; ud->fstat_fetched = 0;
+    for (int32_t z = 0; z < n_utt; z++) {
+        const int32_t *h = ud->h_hyp_hdr + (size_t)z * UH_N;
+        ud->lane[z].h_st[0] = h[UH_NENTRY]; ud->lane[z].h_st[1] = h[UH_NFRM];
+    }
+    {
+        const size_t total_words = (size_t)ud->h_hyp_hdr[(size_t)n_utt * UH_N];
+        if (total_words > first_words)
+            HIPCHK(hipMemcpyAsync(ud->h_hyp_words + first_words * 6, ud->d_hyp_words + first_words * 6, (total_words - first_words) * 24,
+                                  hipMemcpyDeviceToHost, ud->stream));
+    }
     if (ud->dag && (rc = s3a_dagpass_finish(ud->dag, n_utt, ud->stream)) != S3A_OK) return rc;
+    tm[4] = now();
     HIPCHK(hipStreamSynchronize(ud->stream));
+    tm[5] = now();
+    if (ud->times)
+        fprintf(stderr, "s3a_uttdec_decode: %d lanes x %d frames: begin %.1f ms, enqueue %.1f, wait %.1f (device %.1f), hypothesis copies issued %.1f, done %.1f\n",
+                n_utt, maxT, 1e3 * (tm[1] - tm[0]), 1e3 * (tm[2] - tm[1]), 1e3 * (tm[3] - tm[2]), ud->last_decode_ms, 1e3 * (tm[4] - tm[3]), 1e3 * (tm[5] - tm[4]));
     ud->n_utt = n_utt;
     /* EVERY lane that stopped in mid-frame starts its next utterance from scratch (a capacity overflow usually hits several
      * lanes of a batch); then the first one is reported */
@@ -1862,11 +2019,35 @@ s3a_uttdec_decode_dev(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_
     return uttdec_decode(ud, n_utt, feat_dev, n_frames, feat_stride, true);
 }
 
+/* the first s3a_uttdec_result (or second-pass hypothesis) after a decode brings the per-frame statistics -- and the
+ * history tables -- of ALL lanes of that decode to the host; decodes whose caller only wants hypotheses never move them */
+static int32_t
+uttdec_fetch(s3a_uttdec_t *ud, bool tables)
+{
+    HIPCHK(hipSetDevice(ud->device));
+    int32_t rc;
+    bool any = false;
+    if (!ud->fstat_fetched) {
+        for (int32_t z = 0; z < ud->n_utt; z++) if ((rc = lane_fetch_fstat(ud, z)) != S3A_OK) return rc;
+        any = true;
+    }
+    if (tables && !ud->tables_fetched) {
+        for (int32_t z = 0; z < ud->n_utt; z++) if ((rc = lane_fetch_table(ud, z)) != S3A_OK) return rc;
+        any = true;
+    }
+    if (any) HIPCHK(hipStreamSynchronize(ud->stream));
+    ud->fstat_fetched = 1;
+    if (tables) ud->tables_fetched = 1;
+    return S3A_OK;
+}
+
 extern "C" int32_t
 s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out)
 {
     if (!ud || !out || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
-    if (!ud->tables_fetched) { s3a_set_error("s3a_uttdec_result: the history tables were left on the device (s3a_uttdec_enable_bestpath, keep_tables = 0)"); return S3A_EUNSUP; }
+    if (ud->dag && !ud->keep_tables) { s3a_set_error("s3a_uttdec_result: the history tables were left on the device (s3a_uttdec_enable_bestpath, keep_tables = 0)"); return S3A_EUNSUP; }
+    int32_t rc;
+    if ((rc = uttdec_fetch(ud, true)) != S3A_OK) return rc;
     const HostLane &hl = ud->lane[lane];
     const int32_t n = hl.n_entry, nf = hl.nfr + 2;
     const int32_t *t = hl.h_tab;
@@ -1926,6 +2107,7 @@ s3a_uttdec_bestpath_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32
     s3a_dag_result_t r;
     int32_t rc = s3a_dagpass_result(ud->dag, lane, &r);
     if (rc != S3A_OK) return rc;
+    if ((rc = uttdec_fetch(ud, false)) != S3A_OK) return rc;       /* (the frame normalisers of this decode's lanes) */
     memset(hdr, 0, sizeof *hdr);
     if (uttid) strncpy(hdr->uttid, uttid, sizeof hdr->uttid - 1);
     hdr->utt_index = utt_index; hdr->n_frames = hl.nfr; hdr->n_entry = r.n_entry; hdr->exit_id = r.endid; hdr->score = r.score;
@@ -2152,72 +2334,29 @@ s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int32_t *ou
 /* ------------------------------------------------------------------ */
 /* the hypothesis of a finished lane (host): vithist_utt_end + vithist_backtrace */
 /* ------------------------------------------------------------------ */
-/* vithist_utt_end (vithist.c:766-860): the last frame's entries rescored into </s>; when the last frame has no
- * entry the reference first adds a silence entry spanning the rest (vithist_rescore with the silence word) and
- * retries.  Then vithist_backtrace (vithist.c:1066-1100).  Nothing is written to the lane's table: the added
- * entries exist in the record only. */
+/* what ku_hyp left for the lane (vithist_utt_end + vithist_backtrace + compute_scale on the device): header + words.
+ * Status 0 ok, -1 the decode stopped with an error, -2 no word exit at all (vithist_utt_end returns -1), -3 more words
+ * than the caller has room for (n_words = what it takes). */
 static int32_t
 uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index, s3a_hyp_header_t *rec,
            s3a_hyp_word_t *words, int32_t max_words)
 {
     if (!ud || !rec || lane < 0 || lane >= ud->n_utt || max_words < 0 || (max_words > 0 && !words)) return S3A_EINVAL;
-    s3a_utt_result_t r;
-    int32_t rc = s3a_uttdec_result(ud, lane, &r);
-    if (rc != S3A_OK) return rc;
-    const s3a_wordlevel_cfg_t &c = ud->cfg;
+    const HostLane &hl = ud->lane[lane];
+    const int32_t *h = ud->h_hyp_hdr + (size_t)lane * UH_N;
     memset(rec, 0, sizeof *rec);
     if (uttid) strncpy(rec->uttid, uttid, sizeof rec->uttid - 1);
-    rec->utt_index = utt_index; rec->n_frames = r.n_frames; rec->n_entry = r.n_entry; rec->status = r.err ? -1 : 0;
-    for (int32_t f = 0; f < r.n_frames; f++) rec->total_scale = h_add(rec->total_scale, r.frame_stat[8 * f]);
-    if (r.err) return S3A_OK;
-    int32_t f, sv = 0, nsv = 0;
-    for (f = r.n_frm - 1; f >= 0; --f) {
-        sv = r.frame_start[f]; nsv = r.frame_start[f + 1];
-        if (sv < nsv) break;
+    rec->utt_index = utt_index; rec->n_frames = hl.nfr; rec->n_entry = h[UH_NENTRY]; rec->status = h[UH_STATUS];
+    rec->total_scale = h[UH_TSCALE];
+    if (h[UH_STATUS] == -3) {
+        s3a_set_error("s3a_uttdec_hyp: lane %d: a hypothesis of %d words in an utterance of %d frames", lane, h[UH_NWORDS], hl.nfr);
+        return S3A_EINVAL;
     }
-    if (f < 0) { rec->status = -2; return S3A_OK; }     /* no word exit at all: vithist_utt_end returns -1 */
-    int32_t best = INT_MIN, bestvh = -1;
-    for (int32_t i = sv; i < nsv; i++) {
-        const int32_t s = h_add(r.score[i], s3a_lm3g_tg_score(ud->lm, r.lw1[i], r.lw0[i], c.finish_lwid, c.finishwid));
-        if (best < s) { best = s; bestvh = i; }
-    }
-    /* optional silence entry (frame n_frm - 1) when the search died early */
-    bool have_sil = false;
-    s3a_hyp_word_t silw = { 0, 0, 0, 0, 0, 0 };
-    int32_t sil_score = 0, last_ef = r.ef[bestvh], last_score = r.score[bestvh];
-    if (f != r.n_frm - 1) {
-        have_sil = true;
-        silw.wid = c.silwid; silw.sf = r.ef[bestvh] + 1; silw.ef = r.n_frm - 1;
-        silw.ascr = h_add(r.score[bestvh], -r.score[bestvh]);       /* score - pve->path.score with score = pve's */
-        silw.lscr = c.fillpen[c.silwid];
-        sil_score = h_add(r.score[bestvh], silw.lscr);
-        best = h_add(sil_score, s3a_lm3g_tg_score(ud->lm, r.lw1[bestvh], r.lw0[bestvh], c.finish_lwid, c.finishwid));
-        last_ef = silw.ef; last_score = sil_score;
-    }
-    /* backtrace */
-    int32_t n = 0;
-    for (int32_t i = bestvh; i > 0; i = r.pred[i]) n++;
-    const int32_t total = n + (have_sil ? 1 : 0) + 1;
-    rec->n_words = total; rec->score = best; rec->exit_id = r.n_entry + (have_sil ? 1 : 0);
-    /* (more words than the caller has room for: status -3, n_words = what it takes) */
-    if (total > max_words) { rec->status = -3; return S3A_OK; }
-    int32_t k = n - 1;
-    for (int32_t i = bestvh; i > 0; i = r.pred[i], k--) {
-        s3a_hyp_word_t &w = words[k];
-        w.wid = r.wid[i]; w.sf = r.sf[i]; w.ef = r.ef[i]; w.ascr = r.ascr[i]; w.lscr = r.lscr[i];
-    }
-    k = n;
-    if (have_sil) words[k++] = silw;
-    {
-        s3a_hyp_word_t &w = words[k];
-        w.wid = c.finishwid; w.sf = last_ef + 1; w.ef = r.n_frm; w.ascr = 0; w.lscr = h_add(best, -last_score);
-    }
-    for (int32_t q = 0; q < total; q++) {               /* compute_scale, srch_output.c:52-60 */
-        s3a_hyp_word_t &w = words[q];
-        int32_t sc = 0;
-        for (int32_t i = w.sf; i < w.ef && i < r.n_frames; i++) if (i >= 0) sc = h_add(sc, r.frame_stat[8 * i]);
-        w.scale = sc;
-    }
+    if (rec->status != 0) return S3A_OK;
+    rec->n_words = h[UH_NWORDS]; rec->score = h[UH_SCORE]; rec->exit_id = h[UH_EXIT];
+    if (rec->n_words > max_words) { rec->status = -3; return S3A_OK; }
+    static_assert(sizeof(s3a_hyp_word_t) == 24, "s3a_hyp_word_t is six int32");
+    memcpy(words, ud->h_hyp_words + (size_t)h[UH_WOFF] * 6, (size_t)rec->n_words * sizeof(s3a_hyp_word_t));
     return S3A_OK;
 }
 

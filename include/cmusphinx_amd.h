@@ -712,7 +712,9 @@ int32_t s3a_uttdec_window(const s3a_uttdec_t *ud);
  * n_frames}; one all-gather of these records, no per-frame collective).  s3a_uttdec_hyp = vithist_utt_end
  * (vithist.c:766-860: the final </s> transition, the silence patch when the last frames have no exit) +
  * vithist_backtrace (:1066-1100) on the lane's table; word[].scale = the frame normalisers over [sf, ef)
- * (compute_scale, srch_output.c:52-60).  status: 0 ok, -1 decode error, -2 no word exit, -3 more than
+ * (compute_scale, srch_output.c:52-60) -- computed ON THE DEVICE behind the utterance's last frame, for all lanes in one
+ * launch: a decode brings back 32 bytes + 24 bytes per word per utterance; the history tables and per-frame statistics
+ * cross to the host only when s3a_uttdec_result asks for them (the first call after a decode fetches all its lanes').  status: 0 ok, -1 decode error, -2 no word exit, -3 more than
  * S3A_HYP_MAXW words.  s3a_hyp_format = match_write / matchseg_write (srch_output.c:74-161): the utterance's
  * -hyp and -hypseg lines (wordstr / basewid / is_filler by dictionary word id; lw, wip = lm_t.lw / .wip for
  * lm_rawscore, lm.c:2171-2178; unscale = -hypsegscore_unscale).
