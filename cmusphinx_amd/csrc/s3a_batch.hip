@@ -638,6 +638,7 @@ s3a_batch_free(s3a_batch_t *b)
 extern "C" int32_t
 s3a_batch_attach(s3a_batch_t *b, s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs)
 {
+    LS_NEED_3ST(ls, "s3a_batch_attach");
     if (!b || !ls || !sc || !cs) return S3A_EINVAL;
     pthread_mutex_lock(&b->mu);
     int32_t rc = S3A_OK, slot = b->n_slots;

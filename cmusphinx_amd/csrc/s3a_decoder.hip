@@ -325,6 +325,7 @@ s3a_dec_unpack(s3a_lexsearch_t *ls, const int32_t *p, bool may_hist, int32_t frm
 extern "C" int32_t
 s3a_decoder_utt_begin(s3a_lexsearch_t *ls, s3a_scorer_t *sc)
 {
+    LS_NEED_3ST(ls, "s3a_decoder_utt_begin");
     int32_t rc;
     if (!ls || !sc) return S3A_EINVAL;
     if ((rc = same_stream(ls, sc)) != S3A_OK) return rc;
@@ -350,6 +351,7 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                    int32_t maxhmmpf, s3a_frame_result_t *res, int32_t *n_exit, int32_t *exit_wid,
                    int32_t *exit_score, int32_t *exit_hist, int32_t max_exits)
 {
+    LS_NEED_3ST(ls, "s3a_decoder_search");
     if (!ls || !sc || !cs || !res || !n_exit || !exit_wid || !exit_score || !exit_hist) return S3A_EINVAL;
     if (same_stream(ls, sc) != S3A_OK) return S3A_EINVAL;
     const int32_t T = ls->n_tree, hdr = 6 * T + 16, maxn = max_tree_nodes(ls);
@@ -445,6 +447,7 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
                        const int32_t *scr_a, const int32_t *hist_a, int32_t tree_b, int32_t n_b,
                        const int32_t *lc_b, const int32_t *scr_b, const int32_t *hist_b)
 {
+    LS_NEED_3ST(ls, "s3a_decoder_transition");
     if (!ls || !sc || !cs) return S3A_EINVAL;
     if (same_stream(ls, sc) != S3A_OK) return S3A_EINVAL;
     const int32_t T = ls->n_tree, maxn = max_tree_nodes(ls);

@@ -71,7 +71,7 @@ frame_thresholds(const int32_t *best, const int32_t *nact, int32_t T, const Fram
 }
 
 /* ------------------------------------------------------------------ */
-template <int EB>
+template <int EB, int NE = 3>
 __device__ __forceinline__ void
 d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
                const int32_t *__restrict__ nact, int32_t N, int32_t n_tmat,
@@ -110,25 +110,24 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         if (node4) nd = node4[v]; else { nd.x = ssid[v]; nd.y = tmatid[v]; nd.z = wid[v]; nd.w = comp[v]; }
         const int32_t ss = nd.x;
         HmmRegsT<int32_t> r;
-        int32_t e[3];
+        int32_t e[NE];
         /* the HMM's own state first: these loads do not depend on the senone scores and stay in flight
          * while the (longer) senone chain below runs */
 #pragma unroll
-        for (int st = 0; st < 3; st++) { r.s[st] = sc[NSI(st, N, v)]; r.h[st] = hist[NSI(st, N, v)]; }
+        for (int st = 0; st < NE; st++) { r.s[st] = sc[NSI(st, N, v)]; r.h[st] = hist[NSI(st, N, v)]; }
         r.out = outs[NSV(v)];
         r.outh = outh[NSV(v)];
-        int32_t tp[12];
+        int32_t tp[NS_TPW(NE)];
         {
-            const int4 *tq = (const int4 *)(tp_g + nd.y * 12);         /* 48-byte rows of a 16-byte aligned array */
-            const int4 a = tq[0], bq = tq[1], cq = tq[2];
-            tp[0] = a.x; tp[1] = a.y; tp[2] = a.z; tp[3] = a.w; tp[4] = bq.x; tp[5] = bq.y; tp[6] = bq.z; tp[7] = bq.w;
-            tp[8] = cq.x; tp[9] = cq.y; tp[10] = cq.z; tp[11] = cq.w;
+            const int4 *tq = (const int4 *)(tp_g + nd.y * NS_TPW(NE));       /* 48- / 128-byte rows of a 16-byte aligned array */
+#pragma unroll
+            for (int q = 0; q < NS_TPW(NE) / 4; q++) { const int4 a = tq[q]; tp[4 * q] = a.x; tp[4 * q + 1] = a.y; tp[4 * q + 2] = a.z; tp[4 * q + 3] = a.w; }
         }
         const int32_t w = nd.z, q_lo = psof_off ? psof_off[v] : 0, q_hi = psof_off ? psof_off[v + 1] : 0;
         if (nd.w && cs_val) {                /* (the maxima were worked out once per composite senone: d_comsen_max) */
 #pragma unroll
-            for (int st = 0; st < 3; st++) {
-                const int32_t cs = comsseq[ss * 3 + st];
+            for (int st = 0; st < NE; st++) {
+                const int32_t cs = comsseq[ss * NE + st];
                 e[st] = add32(add32(cs_val[cs], -norm), cs_wt[cs]);
             }
         }
@@ -136,36 +135,42 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
             /* composite senone = max over its member senones (dict2pid.c:1029-1048), up to one member
              * per context (~46): the three states' lists are walked together, 8 members each per round,
              * ids first and then scores, so a round is two round trips instead of 48 */
-            int32_t lo[3], hi[3], m[3], wt[3];
+            int32_t lo[NE], hi[NE], m[NE], wt[NE];
 #pragma unroll
-            for (int st = 0; st < 3; st++) {
-                const int32_t cs = comsseq[ss * 3 + st];
+            for (int st = 0; st < NE; st++) {
+                const int32_t cs = comsseq[ss * NE + st];
                 lo[st] = cs_off[cs]; hi[st] = cs_off[cs + 1]; wt[st] = cs_wt[cs]; m[st] = INT_MIN;
             }
-            while (lo[0] < hi[0] || lo[1] < hi[1] || lo[2] < hi[2]) {
-                int32_t id[3][8];
+            for (;;) {
+                bool more = false;
 #pragma unroll
-                for (int st = 0; st < 3; st++)
+                for (int st = 0; st < NE; st++) more = more || lo[st] < hi[st];
+                if (!more) break;
+                int32_t id[NE][8];
+#pragma unroll
+                for (int st = 0; st < NE; st++)
 #pragma unroll
                     for (int u = 0; u < 8; u++) id[st][u] = (lo[st] + u < hi[st]) ? (int32_t)cs_list[lo[st] + u] : -1;
 #pragma unroll
-                for (int st = 0; st < 3; st++) {
+                for (int st = 0; st < NE; st++) {
 #pragma unroll
                     for (int u = 0; u < 8; u++) if (id[st][u] >= 0) m[st] = max(m[st], raw[id[st][u]]);
                     lo[st] += 8;
                 }
             }
 #pragma unroll
-            for (int st = 0; st < 3; st++) e[st] = add32(add32(m[st], -norm), wt[st]);
+            for (int st = 0; st < NE; st++) e[st] = add32(add32(m[st], -norm), wt[st]);
         }
         else {
 #pragma unroll
-            for (int st = 0; st < 3; st++)
-                e[st] = add32(raw[sseq[ss * 3 + st]], -norm);
+            for (int st = 0; st < NE; st++)
+                e[st] = add32(raw[sseq[ss * NE + st]], -norm);
         }
-        const int32_t k = vit3(r, tp, e[0], e[1], e[2]);
+        int32_t k;
+        if (NE == 5) { int32_t out_written = 0; k = vit5(r, tp, e, out_written); (void)out_written; }
+        else k = vit3(r, tp, e[0], e[1], e[2]);
 #pragma unroll
-        for (int st = 0; st < 3; st++) { sc[NSI(st, N, v)] = r.s[st]; hist[NSI(st, N, v)] = r.h[st]; }
+        for (int st = 0; st < NE; st++) { sc[NSI(st, N, v)] = r.s[st]; hist[NSI(st, N, v)] = r.h[st]; }
         outs[NSV(v)] = r.out;
         outh[NSV(v)] = r.outh;
         bests[NSV(v)] = k;
@@ -471,8 +476,8 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
         const int32_t j = j_known >= 0 ? j_known : pos[v], b = b_known >= 0 ? b_known : node_base[tree_of[v]];
         if (bests[NSV(v)] >= th) { selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); frame[NSV(v)] = nf; }
         else {
-            sc[NSV(v)] = WORST; sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
-            hist[NSV(v)] = -1; hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
+            const int32_t ne = (int32_t)(hist - sc);        /* (the record's layout: s3a_structs.h) */
+            for (int32_t st = 0; st < ne; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
             outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
             posout[b + j] = WORST;
             frame[NSV(v)] = -1;
@@ -533,8 +538,8 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
         if (!in_list) { in_list = true; my_turn = firstL; }
     }
     if (cleared) {
-        sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
-        hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
+        const int32_t ne = (int32_t)(hist - sc);
+        for (int32_t st = 1; st < ne; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
         outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
         posout[b + j] = WORST;                  /* k_dec_scan reads the exit scores by list position */
     }
@@ -1225,14 +1230,19 @@ __device__ __forceinline__ void
 mark_node_senones(int32_t v, const int32_t *__restrict__ ssid, const uint8_t *__restrict__ comp,
                   const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
                   const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list, uint8_t *sen_active,
-                  int32_t *cs_need = NULL, int32_t stamp = 0)
+                  int32_t *cs_need = NULL, int32_t stamp = 0, int32_t ne = 3)
 {
     const int32_t ss = ssid[v];
     if (comp[v] && cs_need) {
         /* the whole-utterance engine: a composite senone is WANTED (stamp); its members are marked once per frame by
          * d_comsen_mark however many HMMs share it */
-#pragma unroll
-        for (int st = 0; st < 3; st++) cs_need[comsseq[ss * 3 + st]] = stamp;
+        for (int st = 0; st < ne; st++) cs_need[comsseq[ss * ne + st]] = stamp;
+    }
+    else if (comp[v] && ne != 3) {
+        for (int st = 0; st < ne; st++) {
+            const int32_t cs = comsseq[ss * ne + st];
+            for (int32_t q = cs_off[cs]; q < cs_off[cs + 1]; q++) sen_active[cs_list[q]] = 1;
+        }
     }
     else if (comp[v]) {
         /* the three states' member lists together, 8 members each per round (as in d_dec_hmm_eval): a round is
@@ -1258,8 +1268,8 @@ mark_node_senones(int32_t v, const int32_t *__restrict__ ssid, const uint8_t *__
         }
     }
     else {
-        for (int st = 0; st < 3; st++)
-            sen_active[sseq[ss * 3 + st]] = 1;
+        for (int st = 0; st < ne; st++)
+            sen_active[sseq[ss * ne + st]] = 1;
     }
 }
 
@@ -1361,7 +1371,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
             int32_t k = n0[t] + (fl >> 1);
             for (int32_t cc = c_lo; cc < c; cc++) k += ctot[cc];
             nxt[node_base[t] + k] = v; pos[v] = k; posf[v] = nf;
-            mark_node_senones(v, ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf);
+            mark_node_senones(v, ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf, (int32_t)(hist - sc));
         }
         const unsigned long long k = key[v];
         if (k == 0ull) return;
@@ -1373,7 +1383,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
     const int32_t bb = BX - n_ent_blocks;
     const int32_t t = bb / blocks_per_tree, i = (bb % blocks_per_tree) * M3BLOCK + threadIdx.x;
     if (t >= T || i >= n0[t]) return;
-    mark_node_senones(nxt[node_base[t] + i], ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf);
+    mark_node_senones(nxt[node_base[t] + i], ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf, (int32_t)(hist - sc));
 }
 
 

@@ -469,13 +469,13 @@ k_lt_utt_end(const int32_t *__restrict__ node_base, const int32_t *__restrict__ 
 
 /* every node record: inactive HMM (hmm_clear) */
 __global__ void __launch_bounds__(LT_BLOCK)
-k_lt_reset_nodes(int32_t *sc, int32_t N)
+k_lt_reset_nodes(int32_t *sc, int32_t N, int32_t ne)
 {
     const int32_t v = blockIdx.x * LT_BLOCK + threadIdx.x;
     if (v >= N) return;
     int32_t *r = sc + NSV(v);
-    r[0] = WORST; r[1] = WORST; r[2] = WORST; r[3] = -1; r[4] = -1; r[5] = -1;
-    r[NS_OFF_OUTS] = WORST; r[NS_OFF_OUTH] = -1; r[NS_OFF_BESTS] = WORST; r[NS_OFF_FRAME] = -1;
+    for (int32_t st = 0; st < ne; st++) { r[st] = WORST; r[NS_HIST(ne) + st] = -1; }
+    r[NS_OUTS(ne)] = WORST; r[NS_OUTH(ne)] = -1; r[NS_BESTS(ne)] = WORST; r[NS_FRAME(ne)] = -1;
 }
 
 __global__ void
@@ -505,8 +505,9 @@ alloc_state(s3a_lexsearch_t *ls)
 {
     const int32_t N = ls->N, n_tree = ls->n_tree;
     DMALLOC(ls->d_sc, (size_t)NST * (N > 0 ? N : 1) * 4);      /* the node records (s3a_structs.h); the rest point into them */
-    ls->d_hist = ls->d_sc + NS_OFF_HIST; ls->d_outs = ls->d_sc + NS_OFF_OUTS; ls->d_outh = ls->d_sc + NS_OFF_OUTH;
-    ls->d_bests = ls->d_sc + NS_OFF_BESTS; ls->d_frame = ls->d_sc + NS_OFF_FRAME;
+    const int32_t ne = ls->n_emit;
+    ls->d_hist = ls->d_sc + NS_HIST(ne); ls->d_outs = ls->d_sc + NS_OUTS(ne); ls->d_outh = ls->d_sc + NS_OUTH(ne);
+    ls->d_bests = ls->d_sc + NS_BESTS(ne); ls->d_frame = ls->d_sc + NS_FRAME(ne);
     DMALLOC(ls->d_pos, (size_t)N * 4); DMALLOC(ls->d_posf, (size_t)N * 4);
     DMALLOC(ls->d_act[0], (size_t)N * 4); DMALLOC(ls->d_act[1], (size_t)N * 4);
     DMALLOC(ls->d_nact[0], (size_t)n_tree * 4); DMALLOC(ls->d_nact[1], (size_t)n_tree * 4);
@@ -651,13 +652,17 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
     ls->h_rootlist = h_roots;
 #undef UP
     {
-        size_t tpn = (size_t)tmat->n_tmat * 12;
-        DMALLOC(ls->d_tp, tpn * 4);
-        HIPCHK(hipMemcpy(ls->d_tp, tmat->tp, tpn * 4, hipMemcpyHostToDevice));
-        DMALLOC(ls->d_sseq, (size_t)n_sseq * 3 * 2);
-        HIPCHK(hipMemcpy(ls->d_sseq, sseq, (size_t)n_sseq * 3 * 2, hipMemcpyHostToDevice));
-        DMALLOC(ls->d_comsseq, (size_t)n_comsseq * 3 * 2);
-        if (n_comsseq) HIPCHK(hipMemcpy(ls->d_comsseq, comsseq, (size_t)n_comsseq * 3 * 2, hipMemcpyHostToDevice));
+        /* transition matrices: rows of ne x (ne + 1) words at a 16-byte aligned stride (int4 loads in the HMM kernel) */
+        const int32_t ne = ls->n_emit, tpw = NS_TPW(ne), tpr = ne * (ne + 1);
+        std::vector<int32_t> h_tp((size_t)tmat->n_tmat * tpw, 0);
+        for (int32_t m = 0; m < tmat->n_tmat; m++)
+            for (int32_t k = 0; k < tpr; k++) h_tp[(size_t)m * tpw + k] = tmat->tp[(size_t)m * tpr + k];
+        DMALLOC(ls->d_tp, h_tp.size() * 4);
+        HIPCHK(hipMemcpy(ls->d_tp, h_tp.data(), h_tp.size() * 4, hipMemcpyHostToDevice));
+        DMALLOC(ls->d_sseq, (size_t)n_sseq * ne * 2);
+        HIPCHK(hipMemcpy(ls->d_sseq, sseq, (size_t)n_sseq * ne * 2, hipMemcpyHostToDevice));
+        DMALLOC(ls->d_comsseq, (size_t)n_comsseq * ne * 2);
+        if (n_comsseq) HIPCHK(hipMemcpy(ls->d_comsseq, comsseq, (size_t)n_comsseq * ne * 2, hipMemcpyHostToDevice));
         DMALLOC(ls->d_comstate_off, (size_t)(n_comstate + 1) * 4);
         HIPCHK(hipMemcpy(ls->d_comstate_off, comstate_off, (size_t)(n_comstate + 1) * 4, hipMemcpyHostToDevice));
         DMALLOC(ls->d_comstate, (size_t)comstate_off[n_comstate] * 2);
@@ -700,13 +705,13 @@ s3a_lexsearch_init(int32_t n_tree, const int32_t *n_node, const int32_t *const *
         s3a_set_error("s3a_lexsearch_init: bad arguments");
         return NULL;
     }
-    if (tmat->n_state != 3) {
-        s3a_set_error("s3a_lexsearch: only 3-state HMM topologies are supported by the lextree kernels");
+    if (tmat->n_state != 3 && tmat->n_state != 5) {
+        s3a_set_error("s3a_lexsearch: %d-state HMM topologies are not supported (3 or 5 emitting states: hmm_vit_eval_3st_lr / _5st_lr)", tmat->n_state);
         return NULL;
     }
     if (n_comstate <= 0 || !comstate_off) { n_comstate = 0; comstate_off = zero_off; }
     ls = new s3a_lexsearch_s();        /* value-initialised: every pointer / counter starts at zero */
-    ls->n_emit = 3;
+    ls->n_emit = tmat->n_state;
     ls->cur = 0;
     if (stream) { ls->stream = (hipStream_t)stream; ls->own_stream = 0; }
     else {
@@ -793,7 +798,7 @@ extern "C" int32_t
 s3a_lexsearch_reset(s3a_lexsearch_t *ls)
 {
     int32_t rc, N = ls->N;
-    hipLaunchKernelGGL(k_lt_reset_nodes, dim3((unsigned)((N + LT_BLOCK - 1) / LT_BLOCK)), dim3(LT_BLOCK), 0, ls->stream, ls->d_sc, N);
+    hipLaunchKernelGGL(k_lt_reset_nodes, dim3((unsigned)((N + LT_BLOCK - 1) / LT_BLOCK)), dim3(LT_BLOCK), 0, ls->stream, ls->d_sc, N, ls->n_emit);
     if ( (rc = fill(ls, ls->d_pos, -1, N)) || (rc = fill(ls, ls->d_posf, INT_MIN, N))
         || (rc = fill(ls, ls->d_candf, INT_MIN, N)) || (rc = fill(ls, ls->d_pstamp, INT_MIN, ls->n_pset > 0 ? ls->n_pset : 1))
         || (rc = fill(ls, ls->d_turn, -1, N))
@@ -819,6 +824,7 @@ extern "C" int32_t
 s3a_lexsearch_hmm_eval(s3a_lexsearch_t *ls, const int32_t *senscr_dev, const int32_t *comsen_dev,
                        int32_t frm, int32_t *best, int32_t *wbest, int32_t *n_active)
 {
+    LS_NEED_3ST(ls, "s3a_lexsearch_hmm_eval");
     int32_t maxn = 0, t, rc;
     (void)frm;
     if (!ls || !senscr_dev || !best || !wbest || !n_active) return S3A_EINVAL;
@@ -874,6 +880,7 @@ extern "C" int32_t
 s3a_lexsearch_propagate_non_leaves(s3a_lexsearch_t *ls, int32_t cf, int32_t th, int32_t pth,
                                    int32_t wth)
 {
+    LS_NEED_3ST(ls, "s3a_lexsearch_propagate_non_leaves");
     if (!ls) return S3A_EINVAL;
     hipLaunchKernelGGL(k_lt_set_thr, dim3(1), dim3(64), 0, ls->stream, ls->d_thr, th, pth, wth);
     return launch_propagate(ls, cf);
@@ -884,6 +891,7 @@ s3a_lexsearch_propagate_leaves(s3a_lexsearch_t *ls, int32_t wth, int32_t *n_exit
                                int32_t *exit_wid, int32_t *exit_score, int32_t *exit_hist,
                                int32_t max_per_tree)
 {
+    LS_NEED_3ST(ls, "s3a_lexsearch_propagate_leaves");
     int32_t t;
     const int cur = ls->cur;
     if (!ls || !n_exit || !exit_wid || !exit_score || !exit_hist) return S3A_EINVAL;
@@ -921,6 +929,7 @@ extern "C" int32_t
 s3a_lexsearch_enter(s3a_lexsearch_t *ls, int32_t tree, int32_t n_calls, const int32_t *lc,
                     const int32_t *inscore, const int32_t *inhist, int32_t cf, int32_t thresh)
 {
+    LS_NEED_3ST(ls, "s3a_lexsearch_enter");
     if (!ls || tree < 0 || tree >= ls->n_tree || n_calls < 0 || n_calls > 4096) return S3A_EINVAL;
     if (n_calls == 0) return S3A_OK;
     ls->hist_bound = ls->last_nnxt = ls->row_bound = 1 << 30;   /* step-by-step use: the fused frame can no longer bound the list */
@@ -996,6 +1005,7 @@ s3a_lexsearch_frame_search(s3a_lexsearch_t *ls, const int32_t *senscr_dev,
                            int32_t *exit_wid, int32_t *exit_score, int32_t *exit_hist,
                            int32_t max_exits)
 {
+    LS_NEED_3ST(ls, "s3a_lexsearch_frame_search");
     int32_t maxn = 0, t, rc, total = 0;
     if (!ls || !senscr_dev || !res || !n_exit || !exit_wid || !exit_score || !exit_hist) return S3A_EINVAL;
     const int32_t T = ls->n_tree, hdr = 5 * T + 16;
@@ -1066,6 +1076,7 @@ s3a_lexsearch_active_swap(s3a_lexsearch_t *ls)
 extern "C" int32_t
 s3a_lexsearch_sen_active(s3a_lexsearch_t *ls, uint8_t *sen_active_dev, int32_t n_sen)
 {
+    LS_NEED_3ST(ls, "s3a_lexsearch_sen_active");
     int32_t maxn = 0, t;
     if (!ls || !sen_active_dev || n_sen <= 0) return S3A_EINVAL;
     for (t = 0; t < ls->n_tree; t++)
@@ -1137,14 +1148,15 @@ s3a_lexsearch_get_hmm(const s3a_lexsearch_t *ls, int32_t tree, int32_t *score, i
         HIPCHK(hipMemcpy(rec.data(), ls->d_sc + NSV(b), (size_t)NST * n * 4, hipMemcpyDeviceToHost));
         for (int32_t i = 0; i < n; i++) {
             const int32_t *r = rec.data() + (size_t)i * NST;
-            for (int st = 0; st < 3; st++) {
+            const int32_t ne = ls->n_emit;
+            for (int st = 0; st < ne; st++) {
                 if (score) score[(size_t)st * n + i] = r[st];
-                if (hist) hist[(size_t)st * n + i] = r[NS_OFF_HIST + st];
+                if (hist) hist[(size_t)st * n + i] = r[NS_HIST(ne) + st];
             }
-            if (out_score) out_score[i] = r[NS_OFF_OUTS];
-            if (out_hist) out_hist[i] = r[NS_OFF_OUTH];
-            if (bestscore) bestscore[i] = r[NS_OFF_BESTS];
-            if (frame) frame[i] = r[NS_OFF_FRAME];
+            if (out_score) out_score[i] = r[NS_OUTS(ne)];
+            if (out_hist) out_hist[i] = r[NS_OUTH(ne)];
+            if (bestscore) bestscore[i] = r[NS_BESTS(ne)];
+            if (frame) frame[i] = r[NS_FRAME(ne)];
         }
     }
     return S3A_OK;

@@ -35,7 +35,7 @@ struct s3a_scorer_s {
 
 
 /*
- * The search state of a lextree node is ONE 64-byte record: the three state scores, their histories, the exit score and
+ * The search state of a lextree node is ONE 64-byte record: the three (or five) state scores, their histories, the exit score and
  * history, the HMM's best score, the frame it is listed for (an HMM evaluation touched 17 cache lines of nine node-indexed arrays for it; now one
  * or two).  The kernels keep their pointers -- sc, hist, outs, outh, bests, frame = the record's fields at node 0 -- and
  * index them with NSI (state st of node v) / NSV (a per-node field of v).  The list stamp (posf) and the other per-node
@@ -44,11 +44,15 @@ struct s3a_scorer_s {
 #define NST 16                                  /* int32 words per node record */
 #define NSI(st, N, v) ((size_t)(v) * NST + (st))
 #define NSV(v) ((size_t)(v) * NST)
-#define NS_OFF_HIST 3
-#define NS_OFF_OUTS 6
-#define NS_OFF_OUTH 7
-#define NS_OFF_BESTS 8
-#define NS_OFF_FRAME 9          /* the frame the HMM is listed for (hmm_frame) */
+/* field offsets for an HMM of ne emitting states (3 or 5): ne scores, ne histories, exit score, exit history, best score,
+ * frame tag = 2 ne + 4 <= NST words.  A kernel that holds the derived pointers knows ne as hist - sc. */
+#define NS_HIST(ne) (ne)
+#define NS_OUTS(ne) (2 * (ne))
+#define NS_OUTH(ne) (2 * (ne) + 1)
+#define NS_BESTS(ne) (2 * (ne) + 2)
+#define NS_FRAME(ne) (2 * (ne) + 3)    /* the frame the HMM is listed for (hmm_frame) */
+/* transition-matrix row stride on the device: ne x (ne + 1) words padded to 16-byte multiples (12 / 32) */
+#define NS_TPW(ne) ((((ne) * ((ne) + 1)) + 3) & ~3)
 
 struct s3a_comsen_s {
     int32_t n_comstate, n_list;
@@ -119,6 +123,12 @@ struct s3a_lexsearch_s {
 };
 
 
+
+/* the frame-synchronous entry points (single calls of the lextree API, the fused frame, the batch of decoders) run 3-state
+ * HMMs; 5-state topologies are served by the whole-utterance engine (s3a_uttdec_*) */
+#define LS_NEED_3ST(ls, fn) do { if ((ls) && (ls)->n_emit != 3) { \
+        s3a_set_error(fn ": %d-state HMMs are decoded by the whole-utterance engine (s3a_uttdec_*) only", (ls)->n_emit); \
+        return S3A_EUNSUP; } } while (0)
 
 /* internal cross-TU entry points */
 int32_t s3a_scorer_enqueue_raw(s3a_scorer_t *sc, const float *feat, int32_t frame);

@@ -61,6 +61,7 @@ struct ULane {
 /* what every lane shares */
 struct UShared {
     int32_t N, T, n_tmat, maxn, n_rootnodes, scan_chunks, pack_max_exits, gp_n, n_cs, n_pset_bytes;
+    int32_t ne;                 /* emitting states per HMM (3 or 5): the node record's layout, s3a_structs.h */
     const int32_t *node_base, *ssid, *tmatid, *wid, *prob, *child_off, *child, *par_off, *par, *tree_of, *rootlist, *tp,
         *rootnodes, *ps, *psof_off, *psof, *cs_off, *cs_wt, *rootprob;
     const uint8_t *comp;
@@ -123,8 +124,9 @@ ku_lanes_end(const ULane *__restrict__ lanes, UShared S)
     for (int32_t i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) {
         const int32_t v = L.act[w][b + i];
         int32_t *r = L.sc + NSV(v);
-        r[0] = WORST; r[1] = WORST; r[2] = WORST; r[3] = -1; r[4] = -1; r[5] = -1;
-        r[NS_OFF_OUTS] = WORST; r[NS_OFF_OUTH] = -1; r[NS_OFF_BESTS] = WORST; r[NS_OFF_FRAME] = -1;
+        const int32_t ne = S.ne;
+        for (int32_t st = 0; st < ne; st++) { r[st] = WORST; r[NS_HIST(ne) + st] = -1; }
+        r[NS_OUTS(ne)] = WORST; r[NS_OUTH(ne)] = -1; r[NS_BESTS(ne)] = WORST; r[NS_FRAME(ne)] = -1;
     }
 }
 
@@ -164,7 +166,9 @@ ku_framecheck(const ULane *__restrict__ lanes, UShared S, int32_t f, int32_t *db
     const int32_t nf = f + 1, nxt = cur ^ 1;
     for (int32_t v = blockIdx.x * 256 + threadIdx.x; v < S.N; v += gridDim.x * 256) {
         const int32_t *r = L.sc + NSV(v);
-        const bool clean = r[0] == WORST && r[1] == WORST && r[2] == WORST && r[NS_OFF_OUTS] == WORST && r[NS_OFF_BESTS] == WORST;
+        const int32_t ne = S.ne;
+        bool clean = r[NS_OUTS(ne)] == WORST && r[NS_BESTS(ne)] == WORST;
+        for (int32_t st = 0; st < ne; st++) clean = clean && r[st] == WORST;
         const int32_t t = S.tree_of[v], b = S.node_base[t], p = L.pos[v];
         const int32_t nn = S.nact_all[((size_t)blockIdx.z * 2 + nxt) * WL_MAXT + t];
         const bool listed = L.posf[v] == nf && p >= 0 && p < nn && L.act[nxt][b + p] == v;
@@ -178,9 +182,9 @@ ku_framecheck(const ULane *__restrict__ lanes, UShared S, int32_t f, int32_t *db
                 }
             }
         }
-        if ((!clean && !listed) || (listed && r[NS_OFF_FRAME] != nf)) {
+        if ((!clean && !listed) || (listed && r[NS_FRAME(ne)] != nf)) {
             if (atomicCAS(&dbg[0], 0, f + 1) == 0) {
-                dbg[1] = v; dbg[2] = r[0]; dbg[3] = r[1]; dbg[4] = r[NS_OFF_OUTS]; dbg[5] = r[NS_OFF_BESTS]; dbg[6] = r[NS_OFF_FRAME];
+                dbg[1] = v; dbg[2] = r[0]; dbg[3] = r[1]; dbg[4] = r[NS_OUTS(ne)]; dbg[5] = r[NS_BESTS(ne)]; dbg[6] = r[NS_FRAME(ne)];
                 dbg[7] = L.posf[v]; dbg[8] = p; dbg[9] = L.turn[v]; dbg[10] = nn; dbg[11] = (p >= 0 && p < nn) ? L.act[nxt][b + p] : -7;
                 dbg[12] = clean ? 1 : 0; dbg[13] = listed ? 1 : 0; dbg[14] = t;
             }
@@ -198,12 +202,12 @@ ku_selfcheck(const ULane *__restrict__ lanes, UShared S, int32_t lane, int32_t *
     for (int32_t v = blockIdx.x * 256 + threadIdx.x; v < S.N; v += gridDim.x * 256) {
         const int32_t *r = L.sc + NSV(v);
         bool bad = false;
-        if (r[0] != WORST) { atomicAdd(&out[0], 1); bad = true; }
-        if (r[1] != WORST) { atomicAdd(&out[1], 1); bad = true; }
-        if (r[2] != WORST) { atomicAdd(&out[2], 1); bad = true; }
-        if (r[NS_OFF_OUTS] != WORST) { atomicAdd(&out[3], 1); bad = true; }
-        if (r[NS_OFF_BESTS] != WORST) { atomicAdd(&out[4], 1); bad = true; }
-        if (r[NS_OFF_FRAME] != -1) { atomicAdd(&out[5], 1); bad = true; }
+        const int32_t ne = S.ne;
+        for (int32_t st = 0; st < ne; st++)         /* (states 2 .. ne - 1 are counted together) */
+            if (r[st] != WORST) { atomicAdd(&out[st < 2 ? st : 2], 1); bad = true; }
+        if (r[NS_OUTS(ne)] != WORST) { atomicAdd(&out[3], 1); bad = true; }
+        if (r[NS_BESTS(ne)] != WORST) { atomicAdd(&out[4], 1); bad = true; }
+        if (r[NS_FRAME(ne)] != -1) { atomicAdd(&out[5], 1); bad = true; }
         if (bad) atomicMin(&out[6], v);
         if (L.turn[v] != -1 || L.selfemit[v] != 0 || L.cnt[v] != 0) atomicAdd(&out[7], 1);
     }
@@ -772,14 +776,14 @@ ku_comsen_max(const ULane *__restrict__ lanes, UShared S, int32_t f)
 }
 
 /* ---- lextree_hmm_eval ---- */
-template <int EB>
+template <int EB, int NE>
 __global__ void __launch_bounds__(EB)
 ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
     const int32_t t = blockIdx.y, na = nact_cur[t];
     for (int32_t vb = blockIdx.x; vb * EB < na; vb += gridDim.x) {
-        d_dec_hmm_eval<EB>(S.node_base, L.act[cur], L.nact[cur], S.N, S.n_tmat, S.ssid, S.tmatid, S.wid, S.comp, S.tp,
+        d_dec_hmm_eval<EB, NE>(S.node_base, L.act[cur], L.nact[cur], S.N, S.n_tmat, S.ssid, S.tmatid, S.wid, S.comp, S.tp,
                            S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt, SCR_ROW, L.misc, L.sc, L.hist, L.outs, L.outh,
                            L.bests, L.best, f, (const int32_t *)NULL /* ku_hist_count stamps */, S.psof, L.pstamp, L.gpart, S.gp_n, L.poswid, L.posout,
                            vb, t, L.cs_val, S.node4);
@@ -1406,7 +1410,7 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     S.scan_chunks = proto->scan_chunks; S.pack_max_exits = proto->pack_max_exits;
     S.node_base = proto->d_node_base; S.ssid = proto->d_ssid; S.tmatid = proto->d_tmatid; S.wid = proto->d_wid;
     S.prob = proto->d_prob; S.child_off = proto->d_child_off; S.child = proto->d_child; S.par_off = proto->d_par_off;
-    S.par = proto->d_par; S.tree_of = proto->d_tree_of; S.rootlist = proto->d_rootlist; S.tp = proto->d_tp;
+    S.par = proto->d_par; S.tree_of = proto->d_tree_of; S.rootlist = proto->d_rootlist; S.tp = proto->d_tp; S.ne = proto->n_emit;
     {   /* the nodes' static words, packed */
         int4 *n4 = NULL;
         if (hipMalloc((void **)&n4, (size_t)(proto->N > 0 ? proto->N : 1) * sizeof(int4)) != hipSuccess) { s3a_set_error("s3a_uttdec_init: out of device memory"); goto fail; }
@@ -1822,10 +1826,14 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     }
     }
     if (g_cs) UKL(UK_COMSEN, ku_comsen_max, dim3(g_cs, 1, n), dim3(256), 0, st, LN, S, f);
-    if (ud->eval_block == 256)
-        UKL(UK_HMM_EVAL, ku_hmm_eval<256>, dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S, f);
+    if (S.ne == 5) {
+        if (ud->eval_block == 256) UKL(UK_HMM_EVAL, (ku_hmm_eval<256, 5>), dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S, f);
+        else UKL(UK_HMM_EVAL, (ku_hmm_eval<64, 5>), dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
+    }
+    else if (ud->eval_block == 256)
+        UKL(UK_HMM_EVAL, (ku_hmm_eval<256, 3>), dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S, f);
     else
-        UKL(UK_HMM_EVAL, ku_hmm_eval<64>, dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
+        UKL(UK_HMM_EVAL, (ku_hmm_eval<64, 3>), dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
     {
         UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 16 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
         if (ud->hist_possible) UKL(UK_HIST_SORT, ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);

@@ -44,8 +44,10 @@ def _phone_names(n_ciphone):
 
 
 def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frames=1000,
-              sep=1.0, noise=1.0, ctx_keep=0.5):
-    """Write the task under dirpath; returns a dict describing it (paths, args, truth)."""
+              sep=1.0, noise=1.0, ctx_keep=0.5, n_emit=3):
+    """Write the task under dirpath; returns a dict describing it (paths, args, truth).  n_emit = emitting states per
+    HMM: 3 (hub4 / WSJ / RM1 / tidigits) or 5 (Bakis topology with skip transitions: hmm_vit_eval_5st_lr)."""
+    N_EMIT = n_emit
     rng = np.random.Generator(np.random.PCG64(seed))
     os.makedirs(os.path.join(dirpath, "feat"), exist_ok=True)
     names = _phone_names(n_ciphone)
@@ -103,11 +105,11 @@ def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frame
         f.write("#\n# Columns definitions\n#base lft  rt p attrib tmat      ... state id's ...\n")
         for c in range(n_ciphone):
             att = "filler" if c >= n_reg else "n/a"
-            f.write("%9s   -   - - %6s %4d %6d %6d %6d N\n" % (names[c], att, c, 3 * c, 3 * c + 1, 3 * c + 2))
+            f.write("%9s   -   - - %6s %4d %s N\n" % (names[c], att, c, " ".join("%6d" % (N_EMIT * c + k) for k in range(N_EMIT))))
         for (b, lc, rc, wp) in tri:
             st = tri_states[(b, lc, rc, wp)]
-            f.write("%9s %9s %9s %s    n/a %4d %6d %6d %6d N\n"
-                    % (names[b], names[lc], names[rc], WPOS[wp], b, st[0], st[1], st[2]))
+            f.write("%9s %9s %9s %s    n/a %4d %s N\n"
+                    % (names[b], names[lc], names[rc], WPOS[wp], b, " ".join("%6d" % x for x in st)))
 
     # ---------------- acoustic model ----------------
     scale = synth._DIM_SCALE
@@ -138,6 +140,11 @@ def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frame
     for i in range(N_EMIT):
         tmat[sil, i, i] = 0.85
         tmat[sil, i, i + 1] = 0.15
+    if N_EMIT == 5:                     # the 5-state topology's skips (i -> i + 2, the exit included)
+        for i in range(N_EMIT - 1):
+            skip = 0.2 * tmat[:, i, i + 1]
+            tmat[:, i, i + 2] = skip
+            tmat[:, i, i + 1] -= skip
     s3io.write_gau(os.path.join(dirpath, "means"), mean, False)
     s3io.write_gau(os.path.join(dirpath, "variances"), var, False)
     s3io.write_mixw(os.path.join(dirpath, "mixture_weights"), mixw, False)
@@ -174,7 +181,7 @@ def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frame
     def states_of(ph, lc, rc, wp):
         lc = sil if lc >= n_reg else lc
         rc = sil if rc >= n_reg else rc
-        return tri_states.get((ph, lc, rc, wp), [3 * ph, 3 * ph + 1, 3 * ph + 2])
+        return tri_states.get((ph, lc, rc, wp), [N_EMIT * ph + k for k in range(N_EMIT)])
 
     cum_mixw = np.cumsum(mixw / mixw.sum(axis=1, keepdims=True), axis=1)
     sd = np.sqrt(var) * noise
@@ -196,7 +203,7 @@ def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frame
             m = len(prons[w])
             for j, ph in enumerate(prons[w]):
                 phones.append((ph, 2 if m == 1 else 0 if j == 0 else 1 if j == m - 1 else 3, w))
-            est = 8.6 * len(phones)
+            est = 8.6 * len(phones) * (N_EMIT / 3)
             if est >= n_frames - 30:
                 break
             if rng.random() < 0.08:
@@ -206,7 +213,7 @@ def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frame
         for j, (ph, wp, _) in enumerate(phones):
             if ph == sil:
                 for _ in range(int(rng.integers(2, 5))):
-                    emit([3 * sil, 3 * sil + 1, 3 * sil + 2], sil, frames)
+                    emit([N_EMIT * sil + k for k in range(N_EMIT)], sil, frames)
                 continue
             lc = phones[j - 1][0] if j > 0 else sil
             rc = phones[j + 1][0] if j + 1 < len(phones) else sil
