@@ -20,10 +20,10 @@ CFG_INTS = ["wbeam_vh", "bghist", "maxwpf", "maxhistpf", "wordend_beam", "n_lext
 CFG_DBL = ["logbase", "varfloor", "mixwfloor", "ci_pbeam", "tighten_factor", "lw", "wip", "bestpathlw"]
 CFG_DAG = ["min_endfr", "maxedge", "maxlmop", "maxlpf", "wip_logs3", "bestpath"]
 TREE = {11: "ssid", 12: "tmatid", 13: "composite", 14: "wid", 15: "prob", 16: "child_off", 17: "child", 18: "lc",
-        19: "lcroot_off", 20: "lcroot", 21: "root"}
+        19: "lcroot_off", 20: "lcroot", 21: "root", 22: "ci"}
 STATIC = {2: "tp", 3: "sseq", 4: "comsseq", 5: "comstate_off", 6: "comstate", 7: "comwt", 8: "cd2cisen",
           31: "ug_prob", 32: "ug_bowt", 33: "ug_firstbg", 34: "bg_wid", 35: "bg_prob", 36: "bg_bowt", 37: "bg_firsttg",
-          38: "tg_wid", 39: "tg_prob", 41: "lwid", 42: "is_filler", 43: "fillpen", 44: "last_ci", 46: "basewid"}
+          38: "tg_wid", 39: "tg_prob", 41: "lwid", 42: "is_filler", 43: "fillpen", 44: "last_ci", 46: "basewid", 57: "sen2cimap"}
 
 
 def _cstr(cells):
@@ -67,6 +67,8 @@ def read(path):
         elif tag == 55:
             for k, v in zip(CFG_DAG, d):
                 b[k] = int(v)
+        elif tag == 56:
+            b["pheurtype"], b["pl_beam"], b["pl_window"] = (int(x) for x in d)
         elif tag in (52, 53, 54):
             b[{52: "mean", 53: "var", 54: "mixw"}[tag]] = _cstr(d)
     b["trees"] = trees
@@ -98,6 +100,12 @@ class Decoder:
                              cond_ds=b["cond_ds"], ci_pbeam=b["ci_pbeam"], tighten_factor=b["tighten_factor"],
                              max_cd=b["maxcdsenpf"], max_frames=max_frames, vh_cap=vh_cap, cand_cap=cand_cap)
         self.n_lanes = n_lanes
+        if b.get("pheurtype", 0) > 0:
+            # -pheurtype 1..3: the phoneme look-ahead inside the engine
+            n = b["n_ci_sen"] + 1
+            self.ud.enable_pheur(b["pheurtype"], b["pl_beam"], b["pl_window"],
+                                 [np.asarray(t["ci"], np.int32).astype(np.uint8) for t in b["trees"]],
+                                 np.asarray(b["sen2cimap"], np.int32)[:n].astype(np.int16), b["n_ci"])
         self.dag_cfg = None
         if bestpath:
             # the second pass behind every decode: lattice + best path on the device

@@ -198,6 +198,15 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
     }
 }
 
+/* -pheurtype > 0 (lextree.c:1443-1486): a transition parent -> child must also satisfy
+ * out(parent) + (prob(child) - prob(parent)) + phn_heur[ci(child)] >= hth(parent), hth = the running maximum of that
+ * expression over the propagating HMMs up to the parent in active-list order (kbc->maxNewHeurScore, reset per tree)
+ * + pl_beam; hth_pos is indexed by list position (tree slices), heur by CI phone.  All NULL: -pheurtype 0. */
+struct HeurArgs {
+    const uint8_t *node_ci;
+    const int32_t *heur, *hth_pos;
+};
+
 /* the frame's thresholds when the histogram beam is known to the caller (hb_hist <= 0) or not in force (> 0) */
 __device__ __forceinline__ void
 frame_thresholds_hb(const int32_t *best, int32_t T, const FrameBeams &bm, int32_t hb_hist, int32_t &th, int32_t &pth)
@@ -463,7 +472,8 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
               const int32_t *__restrict__ ps, const PS *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout,
-        const int32_t v, const bool is_active, const bool has_par, const int32_t j_known = -1, const int32_t b_known = -1)
+        const int32_t v, const bool is_active, const bool has_par, const int32_t j_known = -1, const int32_t b_known = -1,
+        const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
 {
     const int32_t nf = cf + 1;
     int32_t th, pth;
@@ -511,6 +521,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
             const int32_t ns = add32(po, add32(prob[v], -prob[p]));
             if (ns < th) continue;
             const int32_t pp = pos[p];
+            if (hx.hth_pos && add32(ns, hx.heur[hx.node_ci[v]]) < hx.hth_pos[(b_known >= 0 ? b_known : node_base[tree_of[v]]) + pp]) continue;
             if (pp < j) {
                 if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[NSV(p)]; }
                 if (ns > in0 && pp < firstE) firstE = pp;
@@ -561,7 +572,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
               const int32_t *__restrict__ ps, const PS *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout,
-        const int32_t BX, const int32_t BY)
+        const int32_t BX, const int32_t BY, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
 {
     /* (the thresholds come from uniform addresses: computed per thread with scalar loads, and only by
      * the few workgroups that have anything to do -- no LDS, no barrier in front of the early exit) */
@@ -581,7 +592,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
     const int32_t q = ps[v];
     const bool has_par = q >= 0 && pstamp[q] == ps_val<PS>(cf); /* some parent may enter v (its parent set is stamped) */
     if (!is_active && !has_par) return;                 /* nothing can happen to v */
-    d_dec_resolve_node(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout, v, is_active, has_par);
+    d_dec_resolve_node(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout, v, is_active, has_par, -1, -1, hx);
 }
 
 /*
@@ -606,7 +617,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
               const int32_t *__restrict__ ps, const PS *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout, const int32_t *__restrict__ act,
-        const int32_t BX, const int32_t GA, const int32_t GB)
+        const int32_t BX, const int32_t GA, const int32_t GB, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
 {
 #define RS_ARGS N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn,  \
         selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout
@@ -631,7 +642,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
                 const int32_t i = (w - w0) * RSBLOCK + threadIdx.x;
                 if (i < na) {
                     const int32_t v = act[b + i], q = ps[v];
-                    d_dec_resolve_node(RS_ARGS, v, true, q >= 0 && pstamp[q] == ps_val<PS>(cf), i, b);
+                    d_dec_resolve_node(RS_ARGS, v, true, q >= 0 && pstamp[q] == ps_val<PS>(cf), i, b, hx);
                 }
             }
             w0 += nw;
@@ -660,7 +671,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int32_t i = threadIdx.x; i < total; i += 64) {
         const int32_t v = s_cand[i];
-        if (posf[v] != cf) d_dec_resolve_node(RS_ARGS, v, false, true);     /* (the active ones: by list position) */
+        if (posf[v] != cf) d_dec_resolve_node(RS_ARGS, v, false, true, -1, -1, hx);     /* (the active ones: by list position) */
     }
 #undef RS_ARGS
 }

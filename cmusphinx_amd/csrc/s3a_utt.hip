@@ -52,6 +52,11 @@ struct ULane {
     int32_t *dynbeam;           /* [1] the frame's CI beam when -maxcdsenpf is in force (ku_dyn_ci_beam) */
     int32_t *win;               /* [K][n_sen] look-ahead window: every senone's score for the frames f0 .. f0 + K - 1 */
     uint8_t *winb;              /* [K][n_sen] ... and the best component of its mixture (255: none) */
+    /* -pheurtype > 0 (s3a_uttdec_enable_pheur) */
+    int32_t *ci_all;            /* [max_frames][n_ci_sen] the utterance's raw CI senone scores (gmm_compute_lv1 for every frame) */
+    int32_t *heur_all;          /* [max_frames][n_ci] phn_heur_list of every frame (pl_computePhnHeur) */
+    int32_t *hth_pos;           /* [N] by list position (tree slices): the heuristic threshold of the HMM listed there */
+    int32_t *ph_scratch;        /* [3 n_ci_sen + 8] the look-ahead pass's throw-away best-Gaussian state and counters */
     /* this utterance */
     UCtx *ctx;
     int32_t *pack;
@@ -85,6 +90,9 @@ struct UShared {
      * lanes' contexts and active-list lengths are two arrays (ONE round trip to the early exit instead of lane struct ->
      * pointer -> value: with 64 lanes most workgroups of a fixed grid only find out that they are not needed, and
      * that chain times the number of such waves over the chip's resident waves WAS the launch) */
+    int32_t pheurtype, pl_beam, pl_window, n_ci;        /* -pheurtype (0: off), logs3(-pl_beam), -pl_window, #CI phones */
+    const uint8_t *node_ci;     /* [N] CI phone of every lextree node (lextree_node_t.ci) */
+    const int16_t *sen2cimap;   /* [n_ci_sen + 1] mdef_t.sen2cimap of the CI senones and the first CD senone */
     int32_t win_K;              /* > 0: look-ahead scoring, K frames per window (ku_score_window / ku_select); 0: per-frame scoring */
     UCtx *ctx_all;              /* [n_lanes] */
     int32_t *nact_all;          /* [n_lanes][2][WL_MAXT] */
@@ -775,6 +783,140 @@ ku_comsen_max(const ULane *__restrict__ lanes, UShared S, int32_t f)
                         (int32_t)blockIdx.x * 256 + (int32_t)(threadIdx.x & ~63));
 }
 
+/* ---- phoneme look-ahead (-pheurtype 1..3, -pl_window, -pl_beam) ----
+ * The reference scores the CI senones -pl_window frames ahead (gmm_compute_lv1 into ascr->cache_ci_senscr, srch.c:738-741,
+ * :813-817), sums a per-phone figure over the window into pl->phn_heur_list before every frame's search
+ * (srch_TST_compute_heuristic, srch_time_switch_tree.c:755-775 -> pl_computePhnHeur, fast_algo_struct.c:219-300) and lets
+ * lextree_hmm_propagate_non_leaves (lextree.c:1443-1486) drop transitions whose score + heuristic of the child's phone
+ * falls below the running maximum + pl_beam.  A lane's features are resident, so here BOTH tables are made for the whole
+ * utterance in two launches at its beginning: ku_ci_ahead = approx_cont_mgau_ci_eval for every frame (raw scores, as the
+ * cache holds them); ku_phn_heur = pl_computePhnHeur for every frame t over the frames [t, min(t + window, n_frames)).
+ */
+template <bool EXACT>
+__global__ void __launch_bounds__(256)
+ku_ci_ahead(const ULane *__restrict__ lanes, UShared S)
+{
+    const ULane &L = lanes[blockIdx.z];
+    const UCtx *ctx = L.ctx;
+    const int32_t cf = blockIdx.y;
+    if (cf >= ctx->nfr) return;
+    if ((int32_t)(blockIdx.x * 256) >= S.n_ci_sen * S.CP) return;
+    const float *x = ctx->feat + (size_t)cf * S.D4 * 4;
+    int32_t *tmp = L.ph_scratch;
+#define KU_AHEAD_ARGS S.mean4, S.prec4, S.lrd, S.mixw, S.tab16, S.tab_size, S.lm_zero, S.f, S.distfloor, x, S.D4, S.CP, S.Gpad, 0,   \
+        S.n_ci_sen, 1, S.ncomp, S.cd2cisen, (const uint8_t *)NULL, L.ci_all + (size_t)cf * S.n_ci_sen, 0, (const int32_t *)NULL, 0, cf, 0,  \
+        tmp, tmp + S.n_ci_sen, tmp + 2 * S.n_ci_sen, tmp + 3 * S.n_ci_sen, 5, (uint8_t *)NULL, (int32_t *)NULL, 0
+    if (S.D4 == D4MAIN) d_gated_frame<EXACT, D4MAIN>(KU_AHEAD_ARGS, blockIdx.x);
+    else d_gated_frame<EXACT, 0>(KU_AHEAD_ARGS, blockIdx.x);
+}
+
+/* NO_UFLOW_ADD, fast_algo_struct.c:206-216 (int32 wrap-around, then the underflow patch) */
+__device__ __forceinline__ int32_t
+ph_add(int32_t a, int32_t b)
+{
+    const int32_t c = add32(a, b);
+    return (c > 0 && a < 0 && b < 0) ? INT_MIN : c;
+}
+
+#define PH_T 64
+#define PH_MAXCI 96
+__global__ void __launch_bounds__(PH_T)
+ku_phn_heur(const ULane *__restrict__ lanes, UShared S)
+{
+    const ULane &L = lanes[blockIdx.z];
+    const int32_t nfr = L.ctx->nfr, t = blockIdx.x * PH_T + threadIdx.x, n_cis = S.n_ci_sen, nci = S.n_ci;
+    __shared__ int32_t s_ph[PH_MAXCI][PH_T + 1];
+    if (t >= nfr) return;
+    const int16_t *s2c = S.sen2cimap;
+    for (int32_t p = 0; p < nci; p++) s_ph[p][threadIdx.x] = 0;         /* (every CI senone's phone: all CI phones) */
+    const int32_t t_end = min(t + S.pl_window, nfr);
+#define PH(p) s_ph[p][threadIdx.x]
+    for (int32_t i = t; i < t_end; i++) {
+        const int32_t *row = L.ci_all + (size_t)i * n_cis;
+        int32_t cur = 0, var = INT_MIN;
+        if (S.pheurtype == 1) {                 /* sum over the window of the phone's best senone */
+            for (int32_t j = 0; j < n_cis; j++) {
+                const int32_t v = row[j];
+                if (var < v) var = v;
+                cur = s2c[j];
+                if (cur != s2c[j + 1]) { PH(cur) = ph_add(PH(cur), var); var = INT_MIN; }
+            }
+        }
+        else if (S.pheurtype == 2) {
+            /* "sum of averages" as the reference computes it: the phone's running sum starts from MAX_NEG_INT32, so its
+             * first addition overflows -- undefined in C; the pinned build (gcc -O2, oracle/Makefile) drops NO_UFLOW_ADD's
+             * patch where an operand is that constant and keeps the wrapped sum: that is what is restated here */
+            for (int32_t j = 0; j < n_cis; j++) {
+                var = var == INT_MIN && (j == 0 || s2c[j - 1] != s2c[j]) ? add32(row[j], INT_MIN) : ph_add(row[j], var);
+                cur = s2c[j];
+                if (cur != s2c[j + 1]) { var /= S.ne; PH(cur) = ph_add(PH(cur), var); var = INT_MIN; }
+            }
+        }
+        else {                                  /* type 3, with its "dangerous hack" as written */
+            for (int32_t j = 0; j < n_cis; j++) {
+                const int32_t v = row[j];
+                if (cur == 0 || cur != s2c[j - 1]) PH(cur) = ph_add(PH(cur), v);
+                cur = s2c[j];
+                if (var < v) var = v;
+                if (s2c[j] != s2c[j + 1]) { PH(cur) = ph_add(PH(cur), var); var = INT_MIN; }
+            }
+        }
+    }
+    for (int32_t p = 0; p < nci; p++) L.heur_all[(size_t)t * nci + p] = PH(p);
+#undef PH
+}
+
+/* per frame, behind the thresholds: the heuristic threshold of every propagating HMM by list position -- the running maximum
+ * over the active list (per tree: kbc->maxNewHeurScore is reset by every lextree_hmm_propagate_non_leaves call) of
+ * max over children (out + (prob(child) - prob) + phn_heur[ci(child)]), plus pl_beam (lextree.c:1443-1462).  One workgroup
+ * per (tree, lane); an HMM propagates when it is no leaf and its exit score reaches the phone threshold (with the phone
+ * beam no wider than the HMM beam -- checked when the look-ahead is enabled -- such an HMM is never cleared first). */
+__global__ void __launch_bounds__(1024)
+ku_heur_thresh(const ULane *__restrict__ lanes, UShared S, int32_t f)
+{
+    LANE;
+    const int32_t t = blockIdx.x, na = nact_cur[t], b = S.node_base[t], tid = threadIdx.x;
+    if (na == 0) return;
+    int32_t th, pth;
+    {
+        int32_t bh, bw, n, wth;
+        (void)frame_thresholds(L.best, nact_cur, S.T, frame_beams(S, f), L.hbin, bh, bw, n, th, pth, wth);
+    }
+    const int32_t *heur = L.heur_all + (size_t)f * S.n_ci;
+    const int32_t *act = L.act[cur];
+    __shared__ int32_t s_w[16], s_carry;
+    if (tid == 0) s_carry = INT_MIN;
+    __syncthreads();
+    for (int32_t i0 = 0; i0 < na; i0 += 1024) {
+        const int32_t i = i0 + tid;
+        int32_t m = INT_MIN;
+        if (i < na) {
+            const int32_t p = act[b + i];
+            const int32_t po = L.outs[NSV(p)];
+            if (S.wid[p] < 0 && po >= pth) {
+                const int32_t pp = S.prob[p];
+                for (int32_t q = S.child_off[p]; q < S.child_off[p + 1]; q++) {
+                    const int32_t c = S.child[q];
+                    m = max(m, add32(add32(po, add32(S.prob[c], -pp)), heur[S.node_ci[c]]));
+                }
+            }
+        }
+        /* inclusive running maximum over the chunk: wave scan, then the waves' totals */
+        int32_t x = m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(x, o, 64); if ((tid & 63) >= o) x = max(x, y); }
+        if ((tid & 63) == 63) s_w[tid >> 6] = x;
+        __syncthreads();
+        int32_t pre = s_carry;
+        for (int32_t w = 0; w < (tid >> 6); w++) pre = max(pre, s_w[w]);
+        x = max(x, pre);
+        if (i < na) L.hth_pos[b + i] = add32(x, S.pl_beam);
+        __syncthreads();
+        if (tid == 1023) s_carry = x;
+        __syncthreads();
+    }
+}
+
 /* ---- lextree_hmm_eval ---- */
 template <int EB, int NE>
 __global__ void __launch_bounds__(EB)
@@ -843,6 +985,9 @@ ku_weak(const ULane *__restrict__ lanes, UShared S, int32_t f)
                L.posf, L.sc, L.outs, L.bests, S.wid, L.hbin, L.propf, L.exits + 2 * (size_t)S.N, 0, 0);
 }
 
+/* the phoneme look-ahead's inputs of the frame (all NULL with -pheurtype 0) */
+#define UHX (S.pheurtype > 0 ? HeurArgs{ S.node_ci, L.heur_all + (size_t)f * S.n_ci, L.hth_pos } : HeurArgs{ NULL, NULL, NULL })
+
 /* few lanes: one node per thread over all nodes (the chain is what counts) */
 __global__ void __launch_bounds__(RSBLOCK)
 ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
@@ -851,7 +996,7 @@ ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
     d_dec_resolve(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
                   L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
-                  blockIdx.x, 0);
+                  blockIdx.x, 0, UHX);
 }
 
 /* many lanes: the active HMMs by list position + a K-nodes-per-thread sweep for the rest (the number of waves counts) */
@@ -864,7 +1009,7 @@ ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t f)
     d_dec_resolve_utt<UR_K>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
                   L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
-                  L.act[cur], blockIdx.x, (int32_t)gridDim.x - GB, GB);
+                  L.act[cur], blockIdx.x, (int32_t)gridDim.x - GB, GB, UHX);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -1327,6 +1472,10 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.d.cs_val) (void)hipFree(hl.d.cs_val);
         if (hl.d.dynbeam) (void)hipFree(hl.d.dynbeam);
         if (hl.d.pstamp8) (void)hipFree(hl.d.pstamp8);
+        if (hl.d.ci_all) (void)hipFree(hl.d.ci_all);
+        if (hl.d.heur_all) (void)hipFree(hl.d.heur_all);
+        if (hl.d.hth_pos) (void)hipFree(hl.d.hth_pos);
+        if (hl.d.ph_scratch) (void)hipFree(hl.d.ph_scratch);
         if (hl.d.win) (void)hipFree(hl.d.win);
         if (hl.d.winb) (void)hipFree(hl.d.winb);
         if (hl.ls && ud->S.nact_all && hl.ls->d_nact[0] >= ud->S.nact_all
@@ -1350,6 +1499,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     if (ud->ev0) (void)hipEventDestroy(ud->ev0);
     if (ud->ev1) (void)hipEventDestroy(ud->ev1);
     if (ud->d_lanes) (void)hipFree(ud->d_lanes);
+    if (ud->S.node_ci) (void)hipFree((void *)ud->S.node_ci);
+    if (ud->S.sen2cimap) (void)hipFree((void *)ud->S.sen2cimap);
     if (ud->S.rootprob) (void)hipFree((void *)ud->S.rootprob);
     if (ud->S.node4) (void)hipFree((void *)ud->S.node4);
     if (ud->S.ctx_all) (void)hipFree(ud->S.ctx_all);
@@ -1839,6 +1990,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
         if (ud->hist_possible) UKL(UK_HIST_SORT, ku_hist_sort, dim3(T, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     }
     if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+    if (S.pheurtype > 0) UKL(UK_RESOLVE, ku_heur_thresh, dim3(T, 1, n), dim3(1024), 0, st, LN, S, f);
     {   /* (the active HMMs by list position: ud->g_res workgroups that loop; the rest: a sweep, UR_K nodes per thread) */
         const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
         if (n >= ud->many) UKL(UK_RESOLVE, ku_resolve_lists, dim3(ud->g_res + GB, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
@@ -1929,6 +2081,14 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
         hipLaunchKernelGGL(ku_lanes_begin, dim3(32, 1, n_utt), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, B);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ud->S.ctx_all, ud->h_ctx_up, sizeof(UCtx) * n_utt, hipMemcpyHostToDevice, ud->stream));
+        if (ud->S.pheurtype > 0) {
+            /* the phoneme look-ahead's tables for the whole utterance: every frame's CI senone scores, every frame's phn_heur_list */
+            const dim3 g((ud->S.n_ci_sen * ud->S.CP + 255) / 256, maxT, n_utt);
+            if (ud->exact) hipLaunchKernelGGL(ku_ci_ahead<true>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S);
+            else hipLaunchKernelGGL(ku_ci_ahead<false>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S);
+            hipLaunchKernelGGL(ku_phn_heur, dim3((maxT + PH_T - 1) / PH_T, 1, n_utt), dim3(PH_T), 0, ud->stream, ud->d_lanes, ud->S);
+            HIPCHK(hipGetLastError());
+        }
     }
     /* (the engine's two timing events live as long as the engine; the per-launch events of profiled frames are destroyed
      * on every way out) */
@@ -2076,6 +2236,64 @@ s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16)
 {
     if (!ud || !out16 || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
     for (int i = 0; i < 16; i++) out16[i] = ud->lane[lane].h_ctx->tacc[i];
+    return S3A_OK;
+}
+
+/* ---- phoneme look-ahead (-pheurtype 1..3) ---- */
+extern "C" int32_t
+s3a_uttdec_enable_pheur(s3a_uttdec_t *ud, int32_t pheurtype, int32_t pl_beam, int32_t pl_window, const uint8_t *const *node_ci,
+                        const int16_t *sen2cimap, int32_t n_ci)
+{
+    if (!ud || pheurtype < 0 || pheurtype > 3) return S3A_EINVAL;
+    HIPCHK(hipSetDevice(ud->device));
+    if (pheurtype == 0) { ud->S.pheurtype = 0; return S3A_OK; }
+    if (!node_ci || !sen2cimap || n_ci <= 0 || n_ci > PH_MAXCI || pl_window < 1) {
+        s3a_set_error("s3a_uttdec_enable_pheur: bad arguments (%d CI phones, 1..%d; -pl_window %d >= 1)", n_ci, PH_MAXCI, pl_window);
+        return S3A_EINVAL;
+    }
+    if (ud->weak_possible) {
+        s3a_set_error("s3a_uttdec_enable_pheur: -pheurtype with a phone beam wider than the HMM beam (-pbeam < -beam) or with -ptranskip is not supported");
+        return S3A_EUNSUP;
+    }
+    if (ud->S.n_sen <= ud->S.n_ci_sen) { s3a_set_error("s3a_uttdec_enable_pheur: the model has no CD senones"); return S3A_EUNSUP; }
+    UShared &S = ud->S;
+    if (!S.node_ci) {
+        std::vector<uint8_t> h((size_t)S.N);
+        for (int32_t t = 0; t < S.T; t++) {
+            const int32_t b = ud->lane[0].ls->node_base[t], n = ud->lane[0].ls->node_base[t + 1] - b;
+            if (!node_ci[t]) { s3a_set_error("s3a_uttdec_enable_pheur: no CI phones for tree %d", t); return S3A_EINVAL; }
+            for (int32_t i = 0; i < n; i++) {
+                if (node_ci[t][i] >= n_ci) { s3a_set_error("s3a_uttdec_enable_pheur: tree %d node %d: CI phone %d of %d", t, i, node_ci[t][i], n_ci); return S3A_EINVAL; }
+                h[(size_t)b + i] = node_ci[t][i];
+            }
+        }
+        for (int32_t j = 0; j < S.n_ci_sen; j++)         /* (entry n_ci_sen is only compared with) */
+            if (sen2cimap[j] < 0 || sen2cimap[j] >= n_ci) { s3a_set_error("s3a_uttdec_enable_pheur: sen2cimap[%d] = %d", j, sen2cimap[j]); return S3A_EINVAL; }
+        uint8_t *d_ci = NULL; int16_t *d_s2c = NULL;
+        if (hipMalloc((void **)&d_ci, (size_t)S.N) != hipSuccess || hipMalloc((void **)&d_s2c, (size_t)(S.n_ci_sen + 1) * 2) != hipSuccess
+            || hipMemcpy(d_ci, h.data(), (size_t)S.N, hipMemcpyHostToDevice) != hipSuccess
+            || hipMemcpy(d_s2c, sen2cimap, (size_t)(S.n_ci_sen + 1) * 2, hipMemcpyHostToDevice) != hipSuccess) {
+            if (d_ci) (void)hipFree(d_ci);
+            if (d_s2c) (void)hipFree(d_s2c);
+            s3a_set_error("s3a_uttdec_enable_pheur: device allocation failed");
+            return S3A_ENOMEM;
+        }
+        S.node_ci = d_ci; S.sen2cimap = d_s2c;
+        std::vector<ULane> tmp((size_t)ud->n_lanes);
+        for (int32_t z = 0; z < ud->n_lanes; z++) {
+            ULane &u = ud->lane[z].d;
+            if (hipMalloc((void **)&u.ci_all, (size_t)ud->max_frames * S.n_ci_sen * 4) != hipSuccess
+                || hipMalloc((void **)&u.heur_all, (size_t)ud->max_frames * n_ci * 4) != hipSuccess
+                || hipMalloc((void **)&u.hth_pos, (size_t)S.N * 4) != hipSuccess
+                || hipMalloc((void **)&u.ph_scratch, ((size_t)3 * S.n_ci_sen + 8) * 4) != hipSuccess) {
+                s3a_set_error("s3a_uttdec_enable_pheur: device allocation failed");
+                return S3A_ENOMEM;
+            }
+            tmp[z] = u;
+        }
+        HIPCHK(hipMemcpy(ud->d_lanes, tmp.data(), sizeof(ULane) * ud->n_lanes, hipMemcpyHostToDevice));
+    }
+    S.pheurtype = pheurtype; S.pl_beam = pl_beam; S.pl_window = pl_window; S.n_ci = n_ci;
     return S3A_OK;
 }
 

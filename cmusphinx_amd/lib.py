@@ -189,6 +189,7 @@ _SIGS = {
     "s3a_uttdec_wl_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_window": (C.c_int32, [C.c_void_p]),
+    "s3a_uttdec_enable_pheur": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_selfcheck": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_gather_init": (C.c_void_p, [C.c_int32, C.c_int32, C.c_char_p]),
     "s3a_gather_free": (None, [C.c_void_p]),
@@ -1430,6 +1431,13 @@ class UttDec:
 
     def window(self):
         return int(self.L.s3a_uttdec_window(self.h))
+
+    def enable_pheur(self, pheurtype, pl_beam, pl_window, node_ci, sen2cimap, n_ci):
+        """-pheurtype 1..3: node_ci = per tree the nodes' CI phones (uint8), sen2cimap = int16 [n_ci_sen + 1]"""
+        arrs = [np.ascontiguousarray(a, np.uint8) for a in node_ci]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        s2c = np.ascontiguousarray(sen2cimap, np.int16)
+        check(self.L.s3a_uttdec_enable_pheur(self.h, int(pheurtype), int(pl_beam), int(pl_window), ptrs, _p(s2c), int(n_ci)), self.L)
 
     def selfcheck(self, lane):
         out = np.zeros(8, np.int32)

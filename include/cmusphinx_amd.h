@@ -707,6 +707,18 @@ int32_t s3a_uttdec_selfcheck(s3a_uttdec_t *ud, int32_t lane, int32_t *out8);
  * all lanes; approx_cont_mgau_frame_eval's gate is then applied per frame); 0: per-frame scoring kernels */
 int32_t s3a_uttdec_window(const s3a_uttdec_t *ud);
 /*
+ * Phoneme look-ahead (-pheurtype 1..3, -pl_window, -pl_beam; sphinx3/include/cmdln_macro.h:255-267): the CI senones of
+ * the next pl_window frames give every CI phone a heuristic score (pl_computePhnHeur, libam/fast_algo_struct.c:219-300:
+ * 1 = sum of the phone's best senone, 2 = "sum of averages", 3 = type 1 plus the reference's first-senone terms), and
+ * lextree_hmm_propagate_non_leaves (libsearch/lextree.c:1443-1486) enters a child only if score + heuristic of the child's
+ * phone reaches the running maximum of that figure over the active list + pl_beam.  pl_beam = logs3(-pl_beam);
+ * node_ci[t][i] = lextree_node_t.ci of node i of tree t (the trees of s3a_lexsearch_init, in its order);
+ * sen2cimap = mdef_t.sen2cimap[0 .. n_ci_sen] (one entry past the CI senones, as the reference reads it).
+ * Not supported together with a phone beam wider than the HMM beam or -ptranskip (S3A_EUNSUP).  pheurtype 0: off.
+ */
+int32_t s3a_uttdec_enable_pheur(s3a_uttdec_t *ud, int32_t pheurtype, int32_t pl_beam, int32_t pl_window,
+                                const uint8_t *const *node_ci, const int16_t *sen2cimap, int32_t n_ci);
+/*
  * The hypothesis of a finished lane as a fixed-size record -- what one utterance contributes to the end-of-batch
  * gather when the control file is sharded over GPUs ({uttid, words, sf/ef, ascr, lscr, score,
  * n_frames}; one all-gather of these records, no per-frame collective).  s3a_uttdec_hyp = vithist_utt_end

@@ -23,7 +23,7 @@ typedef struct {
     int32 n_node;
     lextree_node_t **node;      /* index -> reference node (BFS from lextree->root) */
     int32 *ssid, *tmatid, *wid, *prob, *child_off, *child;
-    uint8 *composite;
+    uint8 *composite, *ci;      /* ci: lextree_node_t.ci, the node's CI phone (phoneme look-ahead) */
     int32 n_lc, *lcroot_off, *lcroot, n_root, *root;
     int16 *lc;
     int32 type;
@@ -103,7 +103,7 @@ flatten_tree(lextree_t *lt)
     qsort(g_pmap, n, sizeof(pmap_t), cmp_pmap);
 
     f->ssid = ckd_calloc(n, 4); f->tmatid = ckd_calloc(n, 4); f->wid = ckd_calloc(n, 4);
-    f->prob = ckd_calloc(n, 4); f->composite = ckd_calloc(n, 1);
+    f->prob = ckd_calloc(n, 4); f->composite = ckd_calloc(n, 1); f->ci = ckd_calloc(n, 1);
     f->child_off = ckd_calloc(n + 1, 4); f->child = ckd_calloc(nchild + 1, 4);
     for (i = 0, j = 0; i < n; i++) {
         lextree_node_t *ln = q[i];
@@ -112,6 +112,7 @@ flatten_tree(lextree_t *lt)
         f->wid[i] = IS_S3WID(ln->wid) ? ln->wid : -1;
         f->prob[i] = ln->prob;
         f->composite[i] = ln->composite ? 1 : 0;
+        f->ci[i] = (uint8)ln->ci;
         f->child_off[i] = j;
         for (gn = ln->children; gn; gn = gnode_next(gn))
             f->child[j++] = node_index(gnode_ptr(gn));

@@ -197,8 +197,8 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
     if (!dict2pid_is_composite(d2p))
         E_FATAL("tst shim: full cross-word triphone expansion grows the lextree during search; "
                 "only composite triphones (the reference's default) are supported\n");
-    if (kb->pl->pheurtype != 0)
-        E_FATAL("tst shim: -pheurtype > 0 is not supported\n");
+    if (kb->pl->pheurtype != 0 && !getenv("S3A_UTT"))
+        E_FATAL("tst shim: -pheurtype > 0 is served by the whole-utterance engine only (S3A_UTT=lanes)\n");
     if (kbcore_lmset(kbc)->n_lm != 1)
         E_FATAL("tst shim: exactly one LM is supported\n");
 
@@ -1251,7 +1251,7 @@ export_bundle(const char *path, kb_t *kb, srch_TST_graph_t *tstg, wl_flat_t *w, 
         xw(14, f->n_node, f->wid); xw(15, f->n_node, f->prob); xw(16, f->n_node + 1, f->child_off);
         xw(17, f->child_off[f->n_node], f->child);
         if (f->n_lc) { xw16(18, f->n_lc, f->lc); xw(19, f->n_lc + 1, f->lcroot_off); xw(20, f->lcroot_off[f->n_lc], f->lcroot); }
-        xw(21, f->n_root, f->root);
+        xw(21, f->n_root, f->root); xw8(22, f->n_node, f->ci);
     }
     {
         int32 h[3] = { w->n_ug, w->n_bg, w->n_tg };
@@ -1287,6 +1287,10 @@ export_bundle(const char *path, kb_t *kb, srch_TST_graph_t *tstg, wl_flat_t *w, 
                         cmd_ln_int32_r(config, "-maxlpf"), logs3(kbcore_logmath(kbc), kbcore_fillpen(kbc)->wip),
                         cmd_ln_boolean_r(config, "-bestpath") ? 1 : 0 };
         xw(50, 16, c); xw(51, 16, dd); xw(55, 6, dg);
+        {
+            int32 ph[3] = { kb->pl->pheurtype, kb->pl->pl_beam, cmd_ln_int32_r(config, "-pl_window") };
+            xw(56, 3, ph); xw16(57, mdef->n_ci_sen + 1, mdef->sen2cimap);
+        }
         xwstr(52, cmd_ln_str_r(config, "-mean")); xwstr(53, cmd_ln_str_r(config, "-var")); xwstr(54, cmd_ln_str_r(config, "-mixw"));
     }
     fclose(g_xfp);
@@ -1354,6 +1358,14 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
                            g_lm3g, &cfg, g_lpe, S3_MAX_FRAMES, getenv("S3A_UTT_VHCAP") ? atoi(getenv("S3A_UTT_VHCAP")) : 0,
                            getenv("S3A_UTT_CANDCAP") ? atoi(getenv("S3A_UTT_CANDCAP")) : 0);
             if (!g_uds[e]) die("s3a_uttdec_init");
+            if (kb.pl->pheurtype != 0) {        /* -pheurtype 1..3: phoneme look-ahead inside the engine */
+                const uint8_t **nci = ckd_calloc(g_ntree, sizeof(*nci));
+                int32 t;
+                for (t = 0; t < g_ntree; t++) nci[t] = g_flat[t]->ci;
+                if (s3a_uttdec_enable_pheur(g_uds[e], kb.pl->pheurtype, kb.pl->pl_beam, cmd_ln_int32_r(config, "-pl_window"), nci,
+                                            mdef->sen2cimap, mdef_n_ciphone(mdef)) != S3A_OK) die("s3a_uttdec_enable_pheur");
+                ckd_free(nci);
+            }
             /* (lattice files and N-best lists are written from the reference's dag_t: those runs keep its own
              * vithist_dag_build on the table the device produced) */
             if (cmd_ln_boolean_r(config, "-bestpath") && !getenv("S3A_UTT_HOSTDAG") && !cmd_ln_str_r(config, "-outlatdir")
