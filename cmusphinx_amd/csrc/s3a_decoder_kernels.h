@@ -459,7 +459,7 @@ d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
 /* what happens to node v (active, or with an active parent) in this frame: the rule of s3a_lextree.hip.
  * (PS = the type of the parent sets' stamps: int32 frame numbers, or their low 8 bits in the whole-utterance engine --
  * a stale stamp that happens to match only costs a parent walk that finds nothing) */
-template <typename PS>
+template <typename PS, bool HEUR = false>
 __device__ __forceinline__ void
 d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
               const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
@@ -487,7 +487,11 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
         if (bests[NSV(v)] >= th) { selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); frame[NSV(v)] = nf; }
         else {
             const int32_t ne = (int32_t)(hist - sc);        /* (the record's layout: s3a_structs.h) */
-            for (int32_t st = 0; st < ne; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
+            if (ne == 3) {
+                sc[NSV(v)] = WORST; sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
+                hist[NSV(v)] = -1; hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
+            }
+            else for (int32_t st = 0; st < ne; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
             outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
             posout[b + j] = WORST;
             frame[NSV(v)] = -1;
@@ -521,7 +525,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
             const int32_t ns = add32(po, add32(prob[v], -prob[p]));
             if (ns < th) continue;
             const int32_t pp = pos[p];
-            if (hx.hth_pos && add32(ns, hx.heur[hx.node_ci[v]]) < hx.hth_pos[(b_known >= 0 ? b_known : node_base[tree_of[v]]) + pp]) continue;
+            if (HEUR && add32(ns, hx.heur[hx.node_ci[v]]) < hx.hth_pos[(b_known >= 0 ? b_known : node_base[tree_of[v]]) + pp]) continue;
             if (pp < j) {
                 if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[NSV(p)]; }
                 if (ns > in0 && pp < firstE) firstE = pp;
@@ -550,7 +554,11 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
     }
     if (cleared) {
         const int32_t ne = (int32_t)(hist - sc);
-        for (int32_t st = 1; st < ne; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
+        if (ne == 3) {
+            sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
+            hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
+        }
+        else for (int32_t st = 1; st < ne; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
         outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
         posout[b + j] = WORST;                  /* k_dec_scan reads the exit scores by list position */
     }
@@ -559,7 +567,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
     if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[b + my_turn], 1); }
 }
 
-template <typename PS>
+template <typename PS, bool HEUR = false>
 __device__ __forceinline__ void
 d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
               const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
@@ -592,7 +600,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
     const int32_t q = ps[v];
     const bool has_par = q >= 0 && pstamp[q] == ps_val<PS>(cf); /* some parent may enter v (its parent set is stamped) */
     if (!is_active && !has_par) return;                 /* nothing can happen to v */
-    d_dec_resolve_node(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout, v, is_active, has_par, -1, -1, hx);
+    d_dec_resolve_node<PS, HEUR>(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout, v, is_active, has_par, -1, -1, hx);
 }
 
 /*
@@ -604,7 +612,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
  *     thread, N/K apart (static parent-set id -> the set's stamp: two trips to the early exit, K times fewer waves);
  *     the wave's candidates -- siblings, so they come in runs -- are compacted through LDS and handled 64 at a time.
  */
-template <int K, typename PS>
+template <int K, typename PS, bool HEUR = false>
 __device__ __forceinline__ void
 d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
               const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
@@ -642,7 +650,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
                 const int32_t i = (w - w0) * RSBLOCK + threadIdx.x;
                 if (i < na) {
                     const int32_t v = act[b + i], q = ps[v];
-                    d_dec_resolve_node(RS_ARGS, v, true, q >= 0 && pstamp[q] == ps_val<PS>(cf), i, b, hx);
+                    d_dec_resolve_node<PS, HEUR>(RS_ARGS, v, true, q >= 0 && pstamp[q] == ps_val<PS>(cf), i, b, hx);
                 }
             }
             w0 += nw;
@@ -671,7 +679,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int32_t i = threadIdx.x; i < total; i += 64) {
         const int32_t v = s_cand[i];
-        if (posf[v] != cf) d_dec_resolve_node(RS_ARGS, v, false, true, -1, -1, hx);     /* (the active ones: by list position) */
+        if (posf[v] != cf) d_dec_resolve_node<PS, HEUR>(RS_ARGS, v, false, true, -1, -1, hx);     /* (the active ones: by list position) */
     }
 #undef RS_ARGS
 }
@@ -1247,7 +1255,11 @@ mark_node_senones(int32_t v, const int32_t *__restrict__ ssid, const uint8_t *__
     if (comp[v] && cs_need) {
         /* the whole-utterance engine: a composite senone is WANTED (stamp); its members are marked once per frame by
          * d_comsen_mark however many HMMs share it */
-        for (int st = 0; st < ne; st++) cs_need[comsseq[ss * ne + st]] = stamp;
+        if (ne == 3) {
+#pragma unroll
+            for (int st = 0; st < 3; st++) cs_need[comsseq[ss * 3 + st]] = stamp;
+        }
+        else for (int st = 0; st < ne; st++) cs_need[comsseq[ss * ne + st]] = stamp;
     }
     else if (comp[v] && ne != 3) {
         for (int st = 0; st < ne; st++) {
@@ -1277,6 +1289,10 @@ mark_node_senones(int32_t v, const int32_t *__restrict__ ssid, const uint8_t *__
                 lo[st] += 8;
             }
         }
+    }
+    else if (ne == 3) {
+        for (int st = 0; st < 3; st++)
+            sen_active[sseq[ss * 3 + st]] = 1;
     }
     else {
         for (int st = 0; st < ne; st++)

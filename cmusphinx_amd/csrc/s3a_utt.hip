@@ -986,14 +986,15 @@ ku_weak(const ULane *__restrict__ lanes, UShared S, int32_t f)
 }
 
 /* the phoneme look-ahead's inputs of the frame (all NULL with -pheurtype 0) */
-#define UHX (S.pheurtype > 0 ? HeurArgs{ S.node_ci, L.heur_all + (size_t)f * S.n_ci, L.hth_pos } : HeurArgs{ NULL, NULL, NULL })
+#define UHX (HEUR ? HeurArgs{ S.node_ci, L.heur_all + (size_t)f * S.n_ci, L.hth_pos } : HeurArgs{ NULL, NULL, NULL })
 
 /* few lanes: one node per thread over all nodes (the chain is what counts) */
+template <bool HEUR>
 __global__ void __launch_bounds__(RSBLOCK)
 ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    d_dec_resolve(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
+    d_dec_resolve<uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
                   L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
                   blockIdx.x, 0, UHX);
@@ -1001,12 +1002,13 @@ ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
 
 /* many lanes: the active HMMs by list position + a K-nodes-per-thread sweep for the rest (the number of waves counts) */
 #define UR_K 8
+template <bool HEUR>
 __global__ void __launch_bounds__(RSBLOCK)
 ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
     const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
-    d_dec_resolve_utt<UR_K>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
+    d_dec_resolve_utt<UR_K, uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
                   L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
                   L.act[cur], blockIdx.x, (int32_t)gridDim.x - GB, GB, UHX);
@@ -1993,8 +1995,12 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     if (S.pheurtype > 0) UKL(UK_RESOLVE, ku_heur_thresh, dim3(T, 1, n), dim3(1024), 0, st, LN, S, f);
     {   /* (the active HMMs by list position: ud->g_res workgroups that loop; the rest: a sweep, UR_K nodes per thread) */
         const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
-        if (n >= ud->many) UKL(UK_RESOLVE, ku_resolve_lists, dim3(ud->g_res + GB, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
-        else UKL(UK_RESOLVE, ku_resolve, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+        if (S.pheurtype > 0) {
+            if (n >= ud->many) UKL(UK_RESOLVE, ku_resolve_lists<true>, dim3(ud->g_res + GB, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+            else UKL(UK_RESOLVE, ku_resolve<true>, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+        }
+        else if (n >= ud->many) UKL(UK_RESOLVE, ku_resolve_lists<false>, dim3(ud->g_res + GB, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+        else UKL(UK_RESOLVE, ku_resolve<false>, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
     }
     /* chained scan: a few workgroups per tree take the chunks in turn (about as many workgroups as the chip holds) */
     const int32_t scan_gc = ud->scan_gc > 0 ? min(ud->scan_gc, ud->scan_nc) : max(1, min(ud->scan_nc, max(1, 768 / max(1, T * n))));
