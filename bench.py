@@ -247,6 +247,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=512, help="decoder lanes per GPU (utterances in flight)")
     ap.add_argument("--engines", type=int, default=4, help="decoder engines per GPU (own stream each) the lanes are split over")
     ap.add_argument("--min-group", type=int, default=32, help="a rank's share is cut into groups of at least this many utterances")
+    ap.add_argument("--group-fixed", type=int, default=16, help="small shares: the per-frame cost of a group in lane equivalents (sizes the groups so that the engines finish together)")
     ap.add_argument("--frames", type=int, default=1000, help="nominal frames per utterance (10 s)")
     ap.add_argument("--cand-cap", type=int, default=0, help="word-level candidate capacity per lane (0: the library's default, 1 << 20)")
     ap.add_argument("--cpu-procs", type=int, default=16, help="processes of the CPU baseline's batch leg (16: where this host's aggregate peaks)")
@@ -331,8 +332,30 @@ def main():
         group lasts as long as its longest utterance: groups hold utterances of similar length; groups are dealt to the
         engines longest first, to the engine with the least frames so far."""
         order = sorted(ids, key=lambda k: (-nfr[k], k))
-        gsz = min(NLE, max(args.min_group, -(-len(order) // NE)))
-        groups = [order[i:i + gsz] for i in range(0, len(order), gsz)]
+        if args.min_group <= len(order) <= NE * NLE and NE > 1:
+            # a small share (one group per engine, e.g. 128 utterances on one of 8 GPUs): the engines run side by side, so
+            # what counts is when the LAST one finishes.  A group costs its longest utterance x (lanes + a fixed part per
+            # frame): the group of the longest utterances gets fewer lanes, so that all engines finish together.
+            fixed = args.group_fixed
+
+            def cut(limit):
+                out, i = [], 0
+                while i < len(order):
+                    n = max(1, min(NLE, len(order) - i, limit // nfr[order[i]] - fixed))
+                    out.append(order[i:i + n])
+                    i += n
+                return out
+            lo, hi = 1, nfr[order[0]] * (NLE + fixed)
+            while lo < hi:
+                mid = (lo + hi) // 2
+                if len(cut(mid)) <= NE:
+                    hi = mid
+                else:
+                    lo = mid + 1
+            groups = cut(lo)
+        else:
+            gsz = min(NLE, max(args.min_group, -(-len(order) // NE)))
+            groups = [order[i:i + gsz] for i in range(0, len(order), gsz)]
         per, load = [[] for _ in range(NE)], [0] * NE
         for g in groups:
             e = min(range(NE), key=lambda k: (load[k], k))

@@ -577,6 +577,7 @@ struct BOut {
 
 struct s3a_batch_s {
     int32_t max_slots, n_slots;
+    int opt_scan_chained;               /* S3A_SCAN_CHAINED when the batch was created (tests) */
     s3a_lexsearch_t *ls[BMAXSLOT];
     s3a_scorer_t *sc[BMAXSLOT];
     s3a_comsen_t *cs[BMAXSLOT];
@@ -603,6 +604,7 @@ s3a_batch_create(int32_t max_slots)
     s3a_batch_t *b = new s3a_batch_s();
     memset((void *)b, 0, sizeof *b);
     b->max_slots = max_slots;
+    b->opt_scan_chained = getenv("S3A_SCAN_CHAINED") != NULL;
     pthread_mutex_init(&b->mu, NULL);
     pthread_cond_init(&b->cv, NULL);
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess
@@ -731,7 +733,9 @@ run_batch(s3a_batch_t *b)
         /* one model for every decoder of the step?  then the CD senones of all of them are one pass
          * over the model: kb_gated_cd_multi (39/40-dimensional features, >= GM_FB Gaussians per senone
          * slot), else kb_gated_cd_shared */
-        bool shared = n > 1 && n <= 64 && getenv("S3A_BATCH_NO_SHARED") == NULL;
+        /* (tuning switches of the tests, read ONCE per process) */
+        static const bool no_shared = getenv("S3A_BATCH_NO_SHARED") != NULL, no_multi = getenv("S3A_BATCH_NO_MULTI") != NULL;
+        bool shared = n > 1 && n <= 64 && !no_shared;
         for (int32_t z = 0; z < n && shared; z++) {
             const s3a_scorer_t *sc = b->sc[b->order[z]], *sc0 = b->sc[b->order[0]];
             shared = sc->g == sc0->g && sc->n_sen == sc0->n_sen && sc->n_ci_sen == sc0->n_ci_sen
@@ -741,7 +745,7 @@ run_batch(s3a_batch_t *b)
         /* (measured, hub4 shape: one launch per decoder -- kb_gated, grid z -- is as fast up to ~7 decoders:
          * 10 / 11 / 16 us for 2 / 4 / 7 against 11 / 13 / 17; the shared pass wins from there: 19 us for 13.5) */
         const bool multi = shared && n >= GM_FB && n <= GM_MAXDEC && d0->D4 == D4MAIN && d0->CP >= GM_FB
-            && getenv("S3A_BATCH_NO_MULTI") == NULL;
+            && !no_multi;
         if (!multi && n < GM_FB) shared = false;
         /* (kb_gated_cd_shared, the fallback for other shapes, still merges with atomics) */
         for (int32_t z = 0; z < n; z++) b->h_frames[z].gpart_n = (multi || !shared) ? 1 : 0;
@@ -815,7 +819,7 @@ run_batch(s3a_batch_t *b)
         if (any_weak) hipLaunchKernelGGL(kb_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, S, F);
         hipLaunchKernelGGL(kb_resolve, dim3((b->g_N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, S, F);
         {
-            const int32_t scan_nc = scan_workgroups(g_rows);
+            const int32_t scan_nc = scan_workgroups(g_rows, b->opt_scan_chained);
             hipLaunchKernelGGL(kb_scan, dim3(b->g_T * scan_nc, 1, n), dim3(SCAN_THREADS), 0, st, S, F, b->h_pack,
                                b->pack_stride, b->pack_max_exits, scan_nc);
         }
@@ -935,7 +939,7 @@ submit(s3a_batch_t *b, int32_t slot, const float *feat, int32_t frame, int32_t f
     f.bm.maxhmmpf = maxhmmpf;
     f.may_hist = ls->hist_bound > maxhmmpf + (maxhmmpf >> 1);
     f.scan_epoch = ++ls->scan_epoch;
-    f.scan_nc = scan_workgroups(b->rows[slot]);
+    f.scan_nc = scan_workgroups(b->rows[slot], b->opt_scan_chained);
     if (f.may_hist && -hmmbeam / NBIN == 0) { s3a_set_error("s3a_batch_step: -beam too narrow for histogram pruning"); return S3A_EUNSUP; }
     f.sc_frame = frame;
     f.sc_is_skip = (frame % sc->ds_ratio == 0) ? 0 : 1;

@@ -405,7 +405,7 @@ s3a_decoder_search(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, int3
                        ls->d_outs, ls->d_outh, ls->d_bests, ls->d_frame, ls->d_turn, ls->d_selfemit,
                        ls->d_cnt, ls->d_key, ls->d_first, ls->d_hbin, ls->d_ps, ls->d_pstamp, ls->d_rootnodes,
                        ls->n_rootnodes, ls->d_candf, ls->d_posout);
-    const int32_t scan_nc = scan_workgroups(rows);
+    const int32_t scan_nc = scan_workgroups(rows, ls->opt_scan_chained);
     hipLaunchKernelGGL(k_dec_scan, dim3(T * scan_nc), dim3(SCAN_THREADS), 0, ls->stream, ls->N, T, frm, bm,
                        ls->d_node_base, ls->d_act[cur], ls->d_nact[cur], ls->d_wid, ls->d_prob, ls->d_outs,
                        ls->d_outh, ls->d_selfemit, ls->d_cnt, ls->d_cand, ls->d_act[nxt], ls->d_nact[nxt],
@@ -459,7 +459,7 @@ s3a_decoder_transition(s3a_lexsearch_t *ls, s3a_scorer_t *sc, s3a_comsen_t *cs, 
     if ((rc = s3a_dec_stage_calls(ls, tree_a, n_a, lc_a, scr_a, hist_a, tree_b, n_b, lc_b, scr_b, hist_b, groups,
                                   calls, 2046, &c, &n_ent, &n_groups)) != S3A_OK)
         return rc;
-    const bool by_arg = c <= CALLS_BY_ARG && getenv("S3A_CALLS_BY_COPY") == NULL;    /* (the variable: tests of the copy path) */
+    const bool by_arg = c <= CALLS_BY_ARG && !ls->opt_calls_by_copy;          /* (the option: tests of the copy path) */
     CallsArg ca;
     memset(&ca, 0, sizeof ca);
     if (by_arg) memcpy(ca.v, slot, (size_t)(8 + 4 * c) * 4);

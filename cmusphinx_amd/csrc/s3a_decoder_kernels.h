@@ -22,10 +22,10 @@
  * list length is long: a chained multi-workgroup scan costs ~3 us per link, which pays from ~16 k positions on
  * (56 k HMMs per frame: 44 -> 23 us; 3 k HMMs: 14 us either way, and slower when batched) */
 #define SCAN_LONG_LIST 16384
-static inline int32_t scan_workgroups(int32_t rows)
+static inline int32_t scan_workgroups(int32_t rows, int chained)
 {
-    /* (S3A_SCAN_CHAINED: the chained scan whatever the length -- for the tests) */
-    return (rows >= SCAN_LONG_LIST || getenv("S3A_SCAN_CHAINED") != NULL) ? (rows + 1023) / 1024 : 1;
+    /* (chained = S3A_SCAN_CHAINED when the search object was made: the chained scan whatever the length -- for the tests) */
+    return (rows >= SCAN_LONG_LIST || chained) ? (rows + 1023) / 1024 : 1;
 }
 #define M3BLOCK 64          /* k_dec_enter3_mark: same reason (a composite leaf marks ~140 scattered senones) */
 #define RSBLOCK 64          /* k_dec_resolve: the nodes something happens to are neighbours; small workgroups spread them over more CUs */

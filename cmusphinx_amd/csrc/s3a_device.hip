@@ -643,8 +643,8 @@ launch_score(const s3a_mgau_model_t *g, const float *feat_dev, int32_t feat_stri
         return S3A_OK;
     /* one frame, long mixtures: the pass whose tail is the senone's chain of look-ups (16+ links; with 8 the
      * general kernel is as fast: 4.2 vs 4.4 us on the hub4 shape, 20.1 vs 17.0 us with 32) */
-    if (d->D4 == D4MAIN && d->tab16 != NULL && n_frames == 1 && d->hyb_ok && d->CP >= 16
-        && getenv("S3A_NO_FRAME_SYNC_KERNEL") == NULL) {
+    static const bool no_frame_sync = getenv("S3A_NO_FRAME_SYNC_KERNEL") != NULL;      /* (tests; read once per process) */
+    if (d->D4 == D4MAIN && d->tab16 != NULL && n_frames == 1 && d->hyb_ok && d->CP >= 16 && !no_frame_sync) {
         const dim3 grid(d->Gpad / 256);
         const size_t lds = (size_t)d->hyb_bytes;
 #define S3A_FS(cp)                                                                                          \

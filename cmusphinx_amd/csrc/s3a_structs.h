@@ -118,6 +118,7 @@ struct s3a_lexsearch_s {
     int32_t *h_pin;                     /* pinned host mirror for small read-backs */
     hipStream_t stream;
     int own_stream;
+    int opt_calls_by_copy, opt_scan_chained;    /* S3A_CALLS_BY_COPY / S3A_SCAN_CHAINED as read when the object was made (tests) */
     int is_clone;                       /* static device arrays borrowed from a prototype (s3a_lexsearch_clone) */
     hipEvent_t ev_pack;                 /* recorded after the frame record's copy (the emission kernel follows it) */
 };
