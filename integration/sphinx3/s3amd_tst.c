@@ -924,575 +924,7 @@ concat_parts(const char *dst, int n)
 }
 
 #ifndef LT_ORACLE
-/* ------------------------------------------------------------------ */
-/* S3A_UTT=L: whole utterances on the device, L at a time              */
-/* ------------------------------------------------------------------ */
-/*
- * One kb_t (the models, dictionary and LM are loaded ONCE), one s3a_uttdec_t with L lanes.  The
- * control file is walked by the reference's own ctl_process; its per-utterance callback computes the
- * features exactly as utt_decode does (libAPI/utt.c:185-258) and QUEUES the utterance; every L
- * utterances the queue is decoded in one s3a_uttdec_decode call -- srch_TST_begin to the last
- * frame_windup of every utterance on the device, no host work per frame -- and each utterance is then
- * finished in control-file order by the reference's own code: srch_utt_begin, the history table
- * read back into its vithist_t (vithist_fill), srch_utt_end (vithist_utt_end, backtrace, -hyp /
- * -hypseg / lattices / statistics).
- */
-typedef struct { char *uttid, *uttfile; float32 *feat; int32 nfr; } uq_t;
-#define UTT_MAX_ENGINES 8
-static s3a_uttdec_t *g_ud, *g_uds[UTT_MAX_ENGINES];    /* g_ud = g_uds[0]; S3A_UTT_ENGINES engines of g_lpe lanes each */
-static int32 g_n_eng = 1, g_lpe;
-static s3a_lm3g_t *g_lm3g;
-static uq_t *g_uq;
-static int32 g_uq_n, g_uq_cap;
-static kb_t *g_ukb;
-static double g_t_dev, g_t_fin, g_t_feat;
-static long g_utt_frames, g_max_cand, g_max_new, g_tie_frames, g_frames_lane0;
-static long long g_wl_ticks[16];
-
-static int
-utt_begin_slot(void *srch)              /* srch_TST_begin without the device work (the lanes did it) */
-{
-    srch_t *s = srch;
-    srch_TST_graph_t *tstg = s->grh->graph_struct;
-    vithist_utt_reset(tstg->vithist);
-    histprune_zero_histbin(tstg->histprune);
-    vithist_utt_begin(tstg->vithist, s->kbc);
-    tstg->n_lextrans = 1;
-    return SRCH_SUCCESS;
-}
-
-static int
-utt_end_slot(void *srch)                /* srch_TST_end, :514-560 */
-{
-    srch_t *s = srch;
-    srch_TST_graph_t *tstg = s->grh->graph_struct;
-    s->exit_id = vithist_utt_end(tstg->vithist, s->kbc);
-    s->stat->utt_wd_exit = vithist_n_entry(tstg->vithist);
-    histprune_showhistbin(tstg->histprune, s->stat->nfr, s->uttid);
-    lm_cache_stats_dump(kbcore_lm(s->kbc));
-    lm_cache_reset(kbcore_lm(s->kbc));
-    return (s->exit_id >= 0) ? SRCH_SUCCESS : SRCH_FAILURE;
-}
-
-/* -bestpath 1 in utt mode: the SECOND PASS ran on the device behind the utterance's last frame (s3a_uttdec_enable_bestpath:
- * vithist_utt_end, lattice, filler bypass, best path, backtrace); the two slots srch_utt_end calls for it
- * (srch.c:519-530 gen_dag, :609-640 bestpath_impl) hand the result over.  S3A_UTT_HOSTDAG=1: the reference's own
- * vithist_dag_build / dag_search on the table the device produced (the comparison run). */
-static int g_dev_dag;
-static long g_dag_utts;
-/* one process per GPU: the rank's hypotheses as (header, words) records for the end-of-batch exchange (s3a_gather_hyps) */
-static int g_rank = 0, g_world = 1, g_rank_first = 0, g_rank_total = 0, g_gather = 0;
-static char g_final[2][4300];
-static s3a_hyp_header_t *g_rec_hdr;
-static s3a_hyp_word_t *g_rec_words;
-static int32 g_rec_n, g_rec_cap, g_rec_nw, g_rec_wcap;
-static void
-rec_add(int32 z)
-{
-    s3a_uttdec_t *ud = g_uds[z / g_lpe];
-    s3a_hyp_header_t h;
-    int32 need = 0, rc;
-    if (g_rec_n == g_rec_cap) { g_rec_cap = g_rec_cap ? 2 * g_rec_cap : 1024; g_rec_hdr = ckd_realloc(g_rec_hdr, (size_t)g_rec_cap * sizeof(*g_rec_hdr)); }
-    for (;;) {
-        if (g_rec_nw + need > g_rec_wcap) { g_rec_wcap = 2 * (g_rec_nw + need) + 4096; g_rec_words = ckd_realloc(g_rec_words, (size_t)g_rec_wcap * sizeof(*g_rec_words)); }
-        rc = g_dev_dag ? s3a_uttdec_bestpath_hyp(ud, z % g_lpe, g_uq[z].uttid, g_rank_first + g_rec_n, &h, g_rec_words + g_rec_nw, g_rec_wcap - g_rec_nw)
-                       : s3a_uttdec_hyp_var(ud, z % g_lpe, g_uq[z].uttid, g_rank_first + g_rec_n, &h, g_rec_words + g_rec_nw, g_rec_wcap - g_rec_nw);
-        if (rc != S3A_OK) die("hypothesis record");
-        if (h.status != -3) break;
-        need = h.n_words;
-    }
-    g_rec_hdr[g_rec_n++] = h;
-    if (h.status == 0) g_rec_nw += h.n_words;
-}
-static __thread int32 g_cur_lane;
-static dag_t *
-utt_gen_dag_slot(void *srch, glist_t hyp)
-{
-    srch_t *s = srch;
-    dag_t *dag = ckd_calloc(1, sizeof(*dag));           /* an empty lattice: srch_utt_end only tests the pointer */
-    (void)hyp;
-    dag_init(dag, kbcore_config(s->kbc), kbcore_logmath(s->kbc));
-    return dag;
-}
-static glist_t
-utt_bestpath_slot(void *srch, dag_t *dag)
-{
-    srch_t *s = srch;
-    dict_t *dict = kbcore_dict(s->kbc);
-    s3a_dag_result_t r;
-    glist_t rhyp = NULL;
-    int32 i;
-    (void)dag;
-    if (s3a_uttdec_bestpath_result(g_uds[g_cur_lane / g_lpe], g_cur_lane % g_lpe, &r) != S3A_OK) die("bestpath result");
-    if (r.status == 2) { E_ERROR("Bestpath search failed for %s\n", s->uttid); return NULL; }
-    if (r.status != 0) E_FATAL("tst shim: the device's second pass stopped with status %d: %s\n", r.status, s3a_last_error());
-    E_INFO("tst shim: second pass on the device: %s: %d entries -> %d nodes, %d links (+%d bypass), %d LM operations, %d words\n",
-           s->uttid, r.n_entry, r.n_node, r.n_link, r.n_bypass, r.lmop, r.n_words);
-    for (i = 0; i < r.n_words; i++) {
-        srch_hyp_t *h = (srch_hyp_t *)ckd_calloc(1, sizeof(srch_hyp_t));
-        h->id = r.wid[i]; h->word = dict_wordstr(dict, h->id); h->sf = r.sf[i]; h->ef = r.ef[i]; h->ascr = r.ascr[i]; h->lscr = r.lscr[i];
-        rhyp = glist_add_ptr(rhyp, (void *)h);
-    }
-    g_dag_utts++;
-    return glist_reverse(rhyp);
-}
-
-static void
-utt_finish(kb_t *kb, int32 z)
-{
-    srch_t *s = kb->srch;
-    srch_TST_graph_t *tstg = s->grh->graph_struct;
-    histprune_t *hp = tstg->histprune;
-    stat_t *st = kb->stat;
-    uq_t *q = &g_uq[z];
-    s3a_utt_result_t r;
-    int32 f;
-
-    if (s3a_uttdec_result(g_uds[z / g_lpe], z % g_lpe, &r) != S3A_OK) die("uttdec result");
-    if (z == 0 && getenv("S3A_UTT_TICKS")) {
-        long long tk[16];
-        int i;
-        if (s3a_uttdec_wl_ticks(g_ud, 0, tk) == S3A_OK)
-            for (i = 0; i < 9; i++) g_wl_ticks[i] += tk[i];
-        g_frames_lane0 += r.n_frames;
-    }
-    kb_set_uttid(q->uttid, q->uttfile, kb);
-    s->uttid = kb->uttid;
-    s->uttfile = kb->uttfile;
-    E_INFO("Processing: %s\n", q->uttid);
-    utt_begin(kb);                              /* srch_utt_begin -> utt_begin_slot */
-    while (r.n_frames >= s->ascale_sz) {        /* srch.c:697-704 */
-        s->ascale = (int32 *)ckd_realloc(s->ascale, (s->ascale_sz + DFLT_UTT_SIZE) * sizeof(int32));
-        s->ascale_sz += DFLT_UTT_SIZE;
-    }
-    for (f = 0; f < r.n_frames; f++) {
-        const int32 *fs = r.frame_stat + 8 * f;
-        s->ascale[f] = fs[0];                   /* srch.c:752 */
-        st->utt_hmm_eval += fs[1]; st->utt_sen_eval += fs[2]; st->utt_gau_eval += fs[3];
-        st->utt_cisen_eval += fs[4]; st->utt_cigau_eval += fs[5];
-        if (fs[1] / hp->hmm_hist_binsize > hp->hmm_hist_bins - 1) hp->hmm_hist[hp->hmm_hist_bins - 1]++;
-        else hp->hmm_hist[fs[1] / hp->hmm_hist_binsize]++;
-        if (fs[6]) g_histframes++;
-    }
-    st->nfr += r.n_frames;                      /* srch.c:839 */
-    g_frames += r.n_frames;
-    if (r.max_cand > g_max_cand) g_max_cand = r.max_cand;
-    if (r.max_new > g_max_new) g_max_new = r.max_new;
-    g_tie_frames += r.n_tie_frames;
-    vithist_fill(tstg->vithist, r.n_entry, r.n_frm, r.score, r.pred, r.lw0, r.lw1, r.wid, r.sf, r.ef, r.ascr, r.lscr,
-                 r.type, r.frame_start, r.bestscore, r.bestvh, kbcore_lm(kb->kbcore));
-    g_cur_lane = z;
-    if (g_gather) rec_add(z);
-    utt_end(kb);                                /* srch_utt_end -> utt_end_slot, gen_hyp, match_write ... */
-    st->tot_fr += st->nfr;
-    ckd_free(q->uttid); ckd_free(q->uttfile); ckd_free(q->feat);
-}
-
-typedef struct { int32 e, n, veclen, rc, state; const float **feat; const int32 *nfr; pthread_t th; } eng_job_t;
-static eng_job_t g_job[UTT_MAX_ENGINES];        /* state: 0 idle, 1 posted, 2 done */
-static pthread_mutex_t g_eng_lock = PTHREAD_MUTEX_INITIALIZER;
-static pthread_cond_t g_eng_cv = PTHREAD_COND_INITIALIZER;
-static int g_eng_started;
-
-/* one persistent host thread per engine (a thread's first HIP call is expensive: not one per batch) */
-static void *
-eng_main(void *vp)
-{
-    eng_job_t *j = vp;
-    (void)s3a_dev_sync();               /* (the thread's HIP state, before the decode clock starts) */
-    pthread_mutex_lock(&g_eng_lock);
-    j->state = 0;
-    pthread_cond_broadcast(&g_eng_cv);
-    pthread_mutex_unlock(&g_eng_lock);
-    for (;;) {
-        pthread_mutex_lock(&g_eng_lock);
-        while (j->state != 1) pthread_cond_wait(&g_eng_cv, &g_eng_lock);
-        pthread_mutex_unlock(&g_eng_lock);
-        j->rc = s3a_uttdec_decode(g_uds[j->e], j->n, j->feat, j->nfr, j->veclen);
-        pthread_mutex_lock(&g_eng_lock);
-        j->state = 2;
-        pthread_cond_broadcast(&g_eng_cv);
-        pthread_mutex_unlock(&g_eng_lock);
-    }
-    return NULL;
-}
-
-/* the queue, g_lpe utterances per engine; the engines (own stream each) decode side by side, a host thread each --
- * the tails of one engine's launches are another's work */
-static void
-utt_flush(kb_t *kb)
-{
-    const float **feat;
-    int32 *nfr, z, e, n_used;
-    double t0;
-    eng_job_t *job = g_job;
-    if (g_uq_n == 0) return;
-    feat = ckd_calloc(g_uq_n, sizeof(*feat));
-    nfr = ckd_calloc(g_uq_n, sizeof(*nfr));
-    for (z = 0; z < g_uq_n; z++) { feat[z] = g_uq[z].feat; nfr[z] = g_uq[z].nfr; g_utt_frames += g_uq[z].nfr; }
-    t0 = now_s();
-    n_used = (g_uq_n + g_lpe - 1) / g_lpe;
-    for (e = 0; e < n_used; e++) {
-        job[e].e = e; job[e].n = (e + 1) * g_lpe <= g_uq_n ? g_lpe : g_uq_n - e * g_lpe;
-        job[e].feat = feat + e * g_lpe; job[e].nfr = nfr + e * g_lpe;
-        job[e].veclen = kbcore_fcb(kb->kbcore)->stream_len[0]; job[e].rc = S3A_OK;
-    }
-    if (g_n_eng == 1) job[0].rc = s3a_uttdec_decode(g_uds[0], job[0].n, job[0].feat, job[0].nfr, job[0].veclen);
-    else {
-        pthread_mutex_lock(&g_eng_lock);
-        for (e = 0; e < n_used; e++) job[e].state = 1;
-        pthread_cond_broadcast(&g_eng_cv);
-        for (e = 0; e < n_used; e++) while (job[e].state != 2) pthread_cond_wait(&g_eng_cv, &g_eng_lock);
-        for (e = 0; e < n_used; e++) job[e].state = 0;
-        pthread_mutex_unlock(&g_eng_lock);
-    }
-    for (e = 0; e < n_used; e++) if (job[e].rc != S3A_OK) die("uttdec decode");
-    g_t_dev += now_s() - t0;
-    t0 = now_s();
-    for (z = 0; z < g_uq_n; z++) utt_finish(kb, z);
-    g_t_fin += now_s() - t0;
-    g_uq_n = 0;
-    ckd_free(feat); ckd_free(nfr);
-}
-
-/* ctl_process callback: utt_decode's feature half (libAPI/utt.c:185-245), then queue */
-static void
-utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
-{
-    kb_t *kb = data;
-    kbcore_t *kbcore = kb->kbcore;
-    cmd_ln_t *config = kbcore_config(kbcore);
-    int32 total_frame, veclen = kbcore_fcb(kbcore)->stream_len[0], t;
-    uq_t *q;
-    double t0 = now_s();
-
-    if (cmd_ln_boolean_r(config, "-adcin"))
-        E_FATAL("tst shim: -adcin is not supported with S3A_UTT (utt.c's wavfile_read is static)\n");
-    if (ur->lmname != NULL || ur->regmatname != NULL)
-        E_FATAL("tst shim: per-utterance LM / MLLR switching is not supported with S3A_UTT\n");
-    if ((total_frame = feat_s2mfc2feat(kbcore_fcb(kbcore), ur->uttfile, cmd_ln_str_r(config, "-cepdir"),
-                                       cmd_ln_str_r(config, "-cepext"), sf, ef, kb->feat, S3_MAX_FRAMES)) < 0)
-        E_FATAL("Cannot read file %s. Forced exit\n", ur->uttfile);
-    q = &g_uq[g_uq_n++];
-    q->uttid = ckd_salloc(uttid);
-    q->uttfile = ckd_salloc(ur->uttfile);
-    q->nfr = total_frame;
-    q->feat = ckd_calloc((size_t)total_frame * veclen + 1, sizeof(float32));
-    for (t = 0; t < total_frame; t++)
-        memcpy(q->feat + (size_t)t * veclen, kb->feat[t][0], veclen * sizeof(float32));
-    g_t_feat += now_s() - t0;
-    if (g_uq_n == g_uq_cap) utt_flush(kb);
-}
-
-/*
- * S3A_EXPORT=file: everything s3a_uttdec_init takes -- the flattened lextrees, senone sequences, composite
- * senones, transition matrices, the flattened trigram, the dictionary facts, beams and pruning limits, the model
- * file names -- written as tagged records {tag, n, n x int32} (int16 / uint8 arrays widened; strings as bytes in
- * int32 cells).  cmusphinx_amd/bundle.py rebuilds the decoder from it through the C ABI alone, so a measurement
- * or a multi-GPU driver needs this program only ONCE, for loading (kb_init) -- never inside a timed region.
- */
-static FILE *g_xfp;
-static void
-xw(int32 tag, int32 n, const void *d)
-{
-    fwrite(&tag, 4, 1, g_xfp); fwrite(&n, 4, 1, g_xfp);
-    if (n) fwrite(d, 4, n, g_xfp);
-}
-static void
-xw16(int32 tag, int32 n, const int16 *d)
-{
-    int32 i, *w = ckd_calloc(n + 1, 4);
-    for (i = 0; i < n; i++) w[i] = d[i];
-    xw(tag, n, w);
-    ckd_free(w);
-}
-static void
-xw8(int32 tag, int32 n, const uint8 *d)
-{
-    int32 i, *w = ckd_calloc(n + 1, 4);
-    for (i = 0; i < n; i++) w[i] = d[i];
-    xw(tag, n, w);
-    ckd_free(w);
-}
-static void
-xwstr(int32 tag, const char *str)
-{
-    int32 n = (int32)strlen(str) + 1, cells = (n + 3) / 4;
-    char *b = ckd_calloc(cells + 1, 4);
-    memcpy(b, str, n);
-    xw(tag, cells, b);
-    ckd_free(b);
-}
-
-static void
-export_bundle(const char *path, kb_t *kb, srch_TST_graph_t *tstg, wl_flat_t *w, const s3a_wordlevel_cfg_t *cfg)
-{
-    kbcore_t *kbc = kb->kbcore;
-    cmd_ln_t *config = kbcore_config(kbc);
-    mdef_t *mdef = kbcore_mdef(kbc);
-    dict_t *d = kbcore_dict(kbc);
-    dict2pid_t *d2p = kbcore_dict2pid(kbc);
-    tmat_t *tmat = kbcore_tmat(kbc);
-    int32 ne = mdef_n_emit_state(mdef), t, i;
-    if ((g_xfp = fopen(path, "wb")) == NULL) E_FATAL("cannot write %s\n", path);
-    {
-        int32 h[10] = { g_ntree, ne, tmat->n_tmat, mdef_n_sseq(mdef), d2p->n_comsseq, g_n_comstate, mdef_n_sen(mdef),
-                        mdef->n_ci_sen, mdef_n_ciphone(mdef), kbcore_fcb(kbc)->stream_len[0] };
-        xw(1, 10, h);
-    }
-    xw(2, tmat->n_tmat * ne * (ne + 1), g_tp_flat); xw16(3, mdef_n_sseq(mdef) * ne, g_sseq_flat);
-    xw16(4, d2p->n_comsseq * ne, g_comsseq_flat); xw(5, g_n_comstate + 1, g_comstate_off);
-    xw16(6, g_comstate_off[g_n_comstate], g_comstate); xw(7, g_n_comstate, d2p->comwt);
-    xw16(8, mdef_n_sen(mdef), mdef->cd2cisen);
-    for (t = 0; t < g_ntree; t++) {
-        flat_t *f = g_flat[t];
-        int32 h2[4] = { f->n_node, f->n_lc, f->n_root, f->type };
-        xw(10, 4, h2); xw(11, f->n_node, f->ssid); xw(12, f->n_node, f->tmatid); xw8(13, f->n_node, f->composite);
-        xw(14, f->n_node, f->wid); xw(15, f->n_node, f->prob); xw(16, f->n_node + 1, f->child_off);
-        xw(17, f->child_off[f->n_node], f->child);
-        if (f->n_lc) { xw16(18, f->n_lc, f->lc); xw(19, f->n_lc + 1, f->lcroot_off); xw(20, f->lcroot_off[f->n_lc], f->lcroot); }
-        xw(21, f->n_root, f->root); xw8(22, f->n_node, f->ci);
-    }
-    {
-        int32 h[3] = { w->n_ug, w->n_bg, w->n_tg };
-        xw(30, 3, h);
-        xw(31, w->n_ug, w->ug_prob); xw(32, w->n_ug, w->ug_bowt); xw(33, w->n_ug + 1, w->ug_firstbg);
-        xw(34, w->n_bg, w->bg_wid); xw(35, w->n_bg, w->bg_prob); xw(36, w->n_tg ? w->n_bg : 0, w->bg_bowt);
-        xw(37, w->n_tg ? w->n_bg + 1 : 0, w->bg_firsttg); xw(38, w->n_tg, w->tg_wid); xw(39, w->n_tg, w->tg_prob);
-    }
-    {
-        int32 h[7] = { w->n_word, w->startwid, w->finishwid, w->silwid, w->start_lwid, w->finish_lwid, cfg->sil_ci };
-        int32 *base = ckd_calloc(w->n_word + 1, 4), *lmraw = ckd_calloc(2, 4);
-        size_t tot = 0;
-        char *strs, *q;
-        xw(40, 7, h); xw(41, w->n_word, w->lwid); xw8(42, w->n_word, w->is_filler); xw(43, w->n_word, w->fillpen);
-        xw(44, w->n_word, w->last_ci);
-        for (i = 0; i < w->n_word; i++) { base[i] = dict_basewid(d, i); tot += strlen(dict_wordstr(d, i)) + 1; }
-        xw(46, w->n_word, base);
-        q = strs = ckd_calloc(tot + 8, 1);
-        for (i = 0; i < w->n_word; i++) { strcpy(q, dict_wordstr(d, i)); q += strlen(q) + 1; }
-        xw(45, (int32)((tot + 3) / 4), strs);
-        ckd_free(strs); ckd_free(base); ckd_free(lmraw);
-    }
-    {
-        int32 c[16] = { cfg->wbeam_vh, cfg->bghist, cfg->maxwpf, cfg->maxhistpf, cfg->wordend_beam, cfg->n_lextree, cfg->epl,
-                        cfg->hmmbeam, cfg->pbeam, cfg->wbeam, cfg->ptranskip, cfg->maxhmmpf, cmd_ln_int32_r(config, "-ds"),
-                        cmd_ln_int32_r(config, "-cond_ds"), cmd_ln_int32_r(config, "-maxcdsenpf"),
-                        cmd_ln_int32_r(config, "-hypsegscore_unscale") };
-        double dd[8] = { cmd_ln_float64_r(config, "-logbase"), cmd_ln_float32_r(config, "-varfloor"),
-                         cmd_ln_float32_r(config, "-mixwfloor"), cmd_ln_float64_r(config, "-ci_pbeam"),
-                         cmd_ln_float32_r(config, "-tighten_factor"), (double)kbcore_lm(kbc)->lw,
-                         (double)kbcore_lm(kbc)->wip, (double)cmd_ln_float32_r(config, "-bestpathlw") };
-        int32 dg[6] = { cmd_ln_int32_r(config, "-min_endfr"), cmd_ln_int32_r(config, "-maxedge"), cmd_ln_int32_r(config, "-maxlmop"),
-                        cmd_ln_int32_r(config, "-maxlpf"), logs3(kbcore_logmath(kbc), kbcore_fillpen(kbc)->wip),
-                        cmd_ln_boolean_r(config, "-bestpath") ? 1 : 0 };
-        xw(50, 16, c); xw(51, 16, dd); xw(55, 6, dg);
-        {
-            int32 ph[3] = { kb->pl->pheurtype, kb->pl->pl_beam, cmd_ln_int32_r(config, "-pl_window") };
-            xw(56, 3, ph); xw16(57, mdef->n_ci_sen + 1, mdef->sen2cimap);
-        }
-        xwstr(52, cmd_ln_str_r(config, "-mean")); xwstr(53, cmd_ln_str_r(config, "-var")); xwstr(54, cmd_ln_str_r(config, "-mixw"));
-    }
-    fclose(g_xfp);
-    E_INFO("tst shim: decoder bundle written to %s\n", path);
-}
-
-static int
-utt_mode_main(int argc, char *argv[], int n_lanes)
-{
-    static kb_t kb;
-    cmd_ln_t *config = cmd_ln_get();
-    srch_t *s;
-    srch_TST_graph_t *tstg;
-    kbcore_t *kbc;
-    mdef_t *mdef;
-    wl_flat_t *w;
-    s3a_wordlevel_cfg_t cfg;
-    int32 *tree_type, t;
-    double t_load = now_s(), t_dec;
-    (void)argc; (void)argv;
-
-    kb_init(&kb, config);
-    s = kb.srch;
-    if (s->op_mode != 4) E_FATAL("tst shim: -op_mode 4 (fwdtree) only\n");
-    tstg = s->grh->graph_struct;
-    kbc = kb.kbcore;
-    mdef = kbcore_mdef(kbc);
-    backend_init(&kb, tstg);
-    w = flatten_lm(kbc);
-    g_lm3g = s3a_lm3g_init(w->n_ug, w->ug_prob, w->ug_bowt, w->ug_firstbg, w->n_bg, w->bg_wid, w->bg_prob, w->bg_bowt,
-                           w->bg_firsttg, w->n_tg, w->tg_wid, w->tg_prob, w->inclass, w->n_word);
-    if (!g_lm3g) die("s3a_lm3g_init");
-    tree_type = ckd_calloc(g_ntree, 4);
-    for (t = 0; t < g_ntree; t++) tree_type[t] = g_flat[t]->type;
-    memset(&cfg, 0, sizeof cfg);
-    cfg.n_word = w->n_word; cfg.n_ci = w->n_ci; cfg.lwid = w->lwid; cfg.is_filler = w->is_filler; cfg.fillpen = w->fillpen;
-    cfg.last_ci = w->last_ci; cfg.startwid = w->startwid; cfg.finishwid = w->finishwid; cfg.silwid = w->silwid;
-    cfg.start_lwid = w->start_lwid; cfg.finish_lwid = w->finish_lwid; cfg.sil_ci = mdef_silphone(mdef);
-    cfg.wbeam_vh = tstg->vithist->wbeam; cfg.bghist = tstg->vithist->bghist;
-    cfg.maxwpf = tstg->histprune->maxwpf; cfg.maxhistpf = tstg->histprune->maxhistpf;
-    cfg.wordend_beam = s->beam->wordend; cfg.n_lextree = tstg->n_lextree; cfg.epl = tstg->epl;
-    cfg.hmmbeam = s->beam->hmm; cfg.pbeam = s->beam->ptrans; cfg.wbeam = s->beam->word;
-    cfg.ptranskip = s->beam->ptranskip; cfg.maxhmmpf = tstg->histprune->maxhmmpf; cfg.tree_type = tree_type;
-    g_n_eng = getenv("S3A_UTT_ENGINES") ? atoi(getenv("S3A_UTT_ENGINES")) : 1;     /* the lanes are split over the engines */
-    if (g_n_eng < 1) g_n_eng = 1;
-    if (g_n_eng > UTT_MAX_ENGINES) g_n_eng = UTT_MAX_ENGINES;
-    if (g_n_eng > n_lanes) g_n_eng = n_lanes;
-    g_lpe = (n_lanes + g_n_eng - 1) / g_n_eng;
-    n_lanes = g_lpe * g_n_eng;
-    if (!getenv("S3A_EXPORT")) {
-        int32 e;
-        for (e = 0; e < g_n_eng; e++) {
-            /* every further engine gets a model of its own: an engine runs on its model's stream, and engines are
-             * to overlap (the lextrees, the trigram and the composite-senone table are shared) */
-            s3a_mgau_model_t *gm = g_gm;
-            if (e > 0) {
-                gm = s3a_mgau_init(cmd_ln_str_r(config, "-mean"), cmd_ln_str_r(config, "-var"),
-                                   cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
-                                   cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.", S3A_MIX_INT_FLOAT_COMP, g_lm);
-                if (!gm) die("s3a_mgau_init");
-            }
-            g_uds[e] = s3a_uttdec_init(g_ls, gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen, cmd_ln_int32_r(config, "-ds"),
-                           cmd_ln_int32_r(config, "-cond_ds"), cmd_ln_float64_r(config, "-ci_pbeam"),
-                           cmd_ln_float32_r(config, "-tighten_factor"), cmd_ln_int32_r(config, "-maxcdsenpf"), g_cs,
-                           g_lm3g, &cfg, g_lpe, S3_MAX_FRAMES, getenv("S3A_UTT_VHCAP") ? atoi(getenv("S3A_UTT_VHCAP")) : 0,
-                           getenv("S3A_UTT_CANDCAP") ? atoi(getenv("S3A_UTT_CANDCAP")) : 0);
-            if (!g_uds[e]) die("s3a_uttdec_init");
-            if (kb.pl->pheurtype != 0) {        /* -pheurtype 1..3: phoneme look-ahead inside the engine */
-                const uint8_t **nci = ckd_calloc(g_ntree, sizeof(*nci));
-                int32 t;
-                for (t = 0; t < g_ntree; t++) nci[t] = g_flat[t]->ci;
-                if (s3a_uttdec_enable_pheur(g_uds[e], kb.pl->pheurtype, kb.pl->pl_beam, cmd_ln_int32_r(config, "-pl_window"), nci,
-                                            mdef->sen2cimap, mdef_n_ciphone(mdef)) != S3A_OK) die("s3a_uttdec_enable_pheur");
-                ckd_free(nci);
-            }
-            /* (lattice files and N-best lists are written from the reference's dag_t: those runs keep its own
-             * vithist_dag_build on the table the device produced) */
-            if (cmd_ln_boolean_r(config, "-bestpath") && !getenv("S3A_UTT_HOSTDAG") && !cmd_ln_str_r(config, "-outlatdir")
-                && !cmd_ln_str_r(config, "-nbestdir")) {
-                s3a_dag_cfg_t dc;
-                float32 bplw = cmd_ln_float32_r(config, "-bestpathlw");
-                int32 *base = ckd_calloc(w->n_word + 1, 4), i;
-                for (i = 0; i < w->n_word; i++) base[i] = dict_basewid(kbcore_dict(kbc), i);
-                memset(&dc, 0, sizeof dc);
-                dc.n_word = w->n_word; dc.basewid = base; dc.is_filler = w->is_filler; dc.lwid = w->lwid; dc.fillpen = w->fillpen;
-                dc.startwid = w->startwid; dc.finishwid = w->finishwid; dc.silwid = w->silwid; dc.start_lwid = w->start_lwid;
-                dc.finish_lwid = w->finish_lwid; dc.wip = logs3(kbcore_logmath(kbc), kbcore_fillpen(kbc)->wip);
-                dc.lwf = bplw ? (bplw / cmd_ln_float32_r(config, "-lw")) : 1.0;
-                dc.min_endfr = cmd_ln_int32_r(config, "-min_endfr"); dc.maxedge = cmd_ln_int32_r(config, "-maxedge");
-                dc.maxlmop = cmd_ln_int32_r(config, "-maxlmop"); dc.maxlpf = cmd_ln_int32_r(config, "-maxlpf");
-                if (s3a_uttdec_enable_bestpath(g_uds[e], &dc, getenv("S3A_DAG_LINKS") ? atoi(getenv("S3A_DAG_LINKS")) : 0,
-                                               getenv("S3A_DAG_PAIRS") ? atoi(getenv("S3A_DAG_PAIRS")) : 0, 1) != S3A_OK) die("s3a_uttdec_enable_bestpath");
-                ckd_free(base);
-                g_dev_dag = 1;
-            }
-        }
-        g_ud = g_uds[0];
-        if (g_n_eng > 1) {              /* the engines' host threads */
-            for (e = 0; e < g_n_eng; e++) {
-                g_job[e].e = e; g_job[e].state = 3;
-                if (pthread_create(&g_job[e].th, NULL, eng_main, &g_job[e]) != 0) die("pthread_create");
-            }
-            pthread_mutex_lock(&g_eng_lock);
-            for (e = 0; e < g_n_eng; e++) while (g_job[e].state != 0) pthread_cond_wait(&g_eng_cv, &g_eng_lock);
-            pthread_mutex_unlock(&g_eng_lock);
-            g_eng_started = 1;
-        }
-    }
-    if (getenv("S3A_EXPORT")) {
-        export_bundle(getenv("S3A_EXPORT"), &kb, tstg, w, &cfg);
-        return 0;
-    }
-    if (!g_ud) die("s3a_uttdec_init");
-    /* the exchange over RCCL: between the ranks of a multi-GPU run (S3A_NO_RCCL=1: not, e.g. ranks that share one GPU);
-     * S3A_GATHER=1 in a single process: the same code with one rank, the files written to <hyp>.gathered (tests) */
-    g_gather = (g_world > 1 && !getenv("S3A_NO_RCCL")) || (g_world == 1 && getenv("S3A_GATHER") != NULL);
-    if (g_world == 1 && g_gather) {
-        FILE *cf = fopen(cmd_ln_str_r(config, "-ctl"), "r");
-        char ln[16384];
-        int32 nl = 0, k;
-        while (cf && fgets(ln, sizeof ln, cf)) if (ln[0] != '\n' && ln[0] != '#') nl++;
-        if (cf) fclose(cf);
-        nl = nl > cmd_ln_int32_r(config, "-ctloffset") ? nl - cmd_ln_int32_r(config, "-ctloffset") : 0;
-        if (cmd_ln_int32_r(config, "-ctlcount") >= 0 && cmd_ln_int32_r(config, "-ctlcount") < nl) nl = cmd_ln_int32_r(config, "-ctlcount");
-        g_rank_total = nl;
-        for (k = 0; k < 2; k++) {
-            const char *nm = cmd_ln_str_r(config, k == 0 ? "-hyp" : "-hypseg");
-            if (nm) snprintf(g_final[k], sizeof g_final[k], "%s.gathered", nm);
-        }
-    }
-    s->funcs->utt_begin = utt_begin_slot;
-    s->funcs->utt_end = utt_end_slot;
-    if (g_dev_dag) { s->funcs->gen_dag = utt_gen_dag_slot; s->funcs->bestpath_impl = utt_bestpath_slot; }
-    g_uq_cap = n_lanes;
-    g_uq = ckd_calloc(n_lanes, sizeof(*g_uq));
-    g_ukb = &kb;
-    t_load = now_s() - t_load;
-    t_dec = now_s();
-    kb.stat->tm = ctl_process(cmd_ln_str_r(config, "-ctl"), cmd_ln_str_r(config, "-ctl_lm"), cmd_ln_str_r(config, "-ctl_mllr"),
-                              cmd_ln_int32_r(config, "-ctloffset"), cmd_ln_int32_r(config, "-ctlcount"), utt_collect, &kb);
-    utt_flush(&kb);
-    t_dec = now_s() - t_dec;
-    if (kb.matchsegfp) fclose(kb.matchsegfp);
-    if (kb.matchfp) fclose(kb.matchfp);
-    if (g_gather && (g_final[0][0] || g_final[1][0])) {
-        /* the end-of-batch exchange: every rank's hypothesis records to every rank over RCCL, in C; rank 0
-         * writes the files of the whole control list (match_write / matchseg_write: s3a_hyp_format_var) */
-        char rdv[4400];
-        s3a_gather_t *gt;
-        snprintf(rdv, sizeof rdv, "%s.rccl-id", g_final[0][0] ? g_final[0] : g_final[1]);
-        if (g_rank == 0) remove(rdv);
-        if ((gt = s3a_gather_init(g_rank, g_world, rdv)) == NULL) die("s3a_gather_init");
-        if (s3a_gather_hyps(gt, g_rec_n, g_rec_hdr, g_rec_words, g_rank_total) != S3A_OK) die("s3a_gather_hyps");
-        if (g_rank == 0) {
-            dict_t *dict = kbcore_dict(kbc);
-            const int32 nw = dict_size(dict);
-            const char **wstr = ckd_calloc(nw + 1, sizeof(char *));
-            int32 *base = ckd_calloc(nw + 1, 4), i;
-            FILE *fh = g_final[0][0] ? fopen(g_final[0], "w") : NULL, *fs = g_final[1][0] ? fopen(g_final[1], "w") : NULL;
-            for (i = 0; i < nw; i++) { wstr[i] = dict_wordstr(dict, i); base[i] = dict_basewid(dict, i); }
-            for (i = 0; i < g_rank_total; i++) {
-                const s3a_hyp_header_t *h;
-                const s3a_hyp_word_t *ww;
-                size_t cap;
-                char *m, *sg;
-                if (s3a_gather_result(gt, i, &h, &ww) != S3A_OK) die("s3a_gather_result");
-                if (h->status != 0) continue;               /* the reference writes no line for it (srch.c:495-498) */
-                cap = 65536 + 64 * (size_t)h->n_words;
-                m = ckd_calloc(cap, 1); sg = ckd_calloc(cap, 1);
-                if (s3a_hyp_format_var(h, ww, wstr, base, w->is_filler, w->startwid, w->finishwid, (float)kbcore_lm(kbc)->lw,
-                                       kbcore_lm(kbc)->wip, cmd_ln_int32_r(config, "-hypsegscore_unscale"), m, cap, sg, cap) != S3A_OK) die("s3a_hyp_format_var");
-                if (fh) fputs(m, fh);
-                if (fs) fputs(sg, fs);
-                ckd_free(m); ckd_free(sg);
-            }
-            if (fh) fclose(fh);
-            if (fs) fclose(fs);
-            E_INFO("tst shim: rank 0 gathered %d utterances from %d ranks over RCCL and wrote the output files\n", g_rank_total, g_world);
-            remove(rdv);
-        }
-        s3a_gather_free(gt);
-    }
-    if (g_frames == 0) E_FATAL("tst shim: nothing was decoded\n");
-    E_INFO("tst shim: %ld frames searched by the replacement backend in %d lane(s), whole utterances on the device\n",
-           g_frames, n_lanes);
-    E_INFO("tst shim: histogram pruning (lextree_hmm_histbin) applied in %ld frames\n", g_histframes);
-    if (g_dev_dag) E_INFO("tst shim: second pass (lattice + best path) of %ld utterances served by the device\n", g_dag_utts);
-    E_INFO("tst shim utt mode: word level: at most %ld candidates and %ld new history entries in a frame; "
-           "%ld frames replayed the reference's heap (tied scores)\n", g_max_cand, g_max_new, g_tie_frames);
-    if (getenv("S3A_UTT_TICKS")) {
-        int i;
-        for (i = 0; i < 9; i++)
-            E_INFO("tst shim utt mode: word-level phase %d of lane 0: %.2f us per frame\n", i, 0.01 * g_wl_ticks[i] / (g_frames_lane0 ? g_frames_lane0 : 1));
-    }
-    E_INFO("tst shim utt mode timing: device decode %.3f s (%.1f us/frame-lane, %.0f x real time aggregate), "
-           "features %.3f s, hypotheses + output %.3f s\n", g_t_dev, 1e6 * g_t_dev / g_frames,
-           0.01 * g_frames / g_t_dev, g_t_feat, g_t_fin);
-    E_INFO("tst shim throughput: %ld frames, decode-only %.3f s = %.0f x real time aggregate "
-           "(%.3f s incl. loading %d decoders one after another)\n",
-           g_frames, t_dec, 0.01 * g_frames / t_dec, t_dec + t_load, 1);
-    return 0;
-}
+#include "s3amd_uttmode.h"
 #endif
 
 /* ------------------------------------------------------------------ */
