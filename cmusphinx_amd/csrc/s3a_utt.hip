@@ -1002,13 +1002,13 @@ ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
 
 /* many lanes: the active HMMs by list position + a K-nodes-per-thread sweep for the rest (the number of waves counts) */
 #define UR_K 8
-template <bool HEUR>
+template <bool HEUR, int URK = UR_K>
 __global__ void __launch_bounds__(RSBLOCK)
 ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t f)
 {
     LANE;
-    const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
-    d_dec_resolve_utt<UR_K, uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
+    const int32_t GB = ((S.N + URK - 1) / URK + RSBLOCK - 1) / RSBLOCK;
+    d_dec_resolve_utt<URK, uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
                   L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
                   L.act[cur], blockIdx.x, (int32_t)gridDim.x - GB, GB, UHX);
@@ -1393,6 +1393,7 @@ struct s3a_uttdec_s {
     int64_t prof_n[24];
     int32_t big_wl;             /* the word level's candidate phases as their own launches (wide beams) */
     hipEvent_t ev0, ev1;        /* around the frames of a decode (last_decode_ms) */
+    int32_t urk;                /* S3A_UTT_URK: nodes per thread of the resolve sweep (experiments) */
     int32_t no_multi, gy;       /* tuning switches, read ONCE at init (S3A_UTT_NO_MULTI, S3A_UTT_GY; tests) */
     int32_t *d_dbg;             /* S3A_UTT_FRAMECHECK: [n_lanes][16] first broken invariant per lane */
     int32_t times;              /* S3A_UTT_TIMES: print the host-side phases of every decode call to stderr */
@@ -1602,6 +1603,8 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
     ud->g_eval = max(1, min((maxn + ud->eval_block - 1) / ud->eval_block, n_lanes >= ud->many ? 64 : 2048 / max(1, min(n_lanes, 8))));
     if (getenv("S3A_UTT_GEVAL")) ud->g_eval = max(1, atoi(getenv("S3A_UTT_GEVAL")));
     ud->g_res = max(1, min((proto->N + RSBLOCK - 1) / RSBLOCK, n_lanes >= ud->many ? 128 : 1024));
+    if (getenv("S3A_UTT_GRES")) ud->g_res = max(1, atoi(getenv("S3A_UTT_GRES")));
+    ud->urk = getenv("S3A_UTT_URK") ? atoi(getenv("S3A_UTT_URK")) : UR_K;
     ud->g_ent = max(1, min((proto->ent_cap + 255) / 256, 256));
     ud->g_mark = max(1, min((proto->ent_cap + M3BLOCK - 1) / M3BLOCK + ((maxn + M3BLOCK - 1) / M3BLOCK) * T, 1024));
     ud->scan_nc = (cfg->maxhmmpf >= SCAN_LONG_LIST && maxn >= SCAN_LONG_LIST) ? (maxn + 1023) / 1024 : 1;
@@ -1999,6 +2002,8 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
             if (n >= ud->many) UKL(UK_RESOLVE, ku_resolve_lists<true>, dim3(ud->g_res + GB, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
             else UKL(UK_RESOLVE, ku_resolve<true>, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
         }
+        else if (n >= ud->many && ud->urk == 16) { const int32_t GB16 = ((S.N + 15) / 16 + RSBLOCK - 1) / RSBLOCK; UKL(UK_RESOLVE, (ku_resolve_lists<false, 16>), dim3(ud->g_res + GB16, 1, n), dim3(RSBLOCK), 0, st, LN, S, f); }
+        else if (n >= ud->many && ud->urk == 4) { const int32_t GB4 = ((S.N + 3) / 4 + RSBLOCK - 1) / RSBLOCK; UKL(UK_RESOLVE, (ku_resolve_lists<false, 4>), dim3(ud->g_res + GB4, 1, n), dim3(RSBLOCK), 0, st, LN, S, f); }
         else if (n >= ud->many) UKL(UK_RESOLVE, ku_resolve_lists<false>, dim3(ud->g_res + GB, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
         else UKL(UK_RESOLVE, ku_resolve<false>, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
     }
