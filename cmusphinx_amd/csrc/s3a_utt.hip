@@ -844,7 +844,7 @@ ku_phn_heur(const ULane *__restrict__ lanes, UShared S)
         }
         else if (S.pheurtype == 2) {
             /* "sum of averages" as the reference computes it: the phone's running sum starts from MAX_NEG_INT32, so its
-             * first addition overflows -- undefined in C; the pinned build (gcc -O2, oracle/Makefile) drops NO_UFLOW_ADD's
+             * first addition overflows -- undefined in C; the pinned reference build (gcc -O2) drops NO_UFLOW_ADD's
              * patch where an operand is that constant and keeps the wrapped sum: that is what is restated here */
             for (int32_t j = 0; j < n_cis; j++) {
                 var = var == INT_MIN && (j == 0 || s2c[j - 1] != s2c[j]) ? add32(row[j], INT_MIN) : ph_add(row[j], var);
@@ -1514,12 +1514,48 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     delete ud;
 }
 
+/* the tuning options as the environment names them (S3A_UTT_*): what the drop-in program and the tests pass to
+ * s3a_uttdec_init_opts; the library itself never reads the environment for an engine's configuration */
+extern "C" void
+s3a_uttdec_opts_default(s3a_uttdec_opts_t *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->big_wl = -1; o->window = -1;
+}
+
+extern "C" void
+s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o)
+{
+    if (!o) return;
+    s3a_uttdec_opts_default(o);
+    auto num = [](const char *name, int32_t dflt) { const char *v = getenv(name); return v ? (int32_t)atoi(v) : dflt; };
+    o->many = num("S3A_UTT_MANY", 0); o->big_wl = num("S3A_UTT_BIGWL", -1); o->window = num("S3A_UTT_WIN", -1);
+    o->window_fpc = num("S3A_UTT_WIN_FPC", 0); o->g_eval = num("S3A_UTT_GEVAL", 0); o->g_res = num("S3A_UTT_GRES", 0);
+    o->scan_g = num("S3A_UTT_SCAN_G", 0); o->gy = num("S3A_UTT_GY", 0); o->sweep_k = num("S3A_UTT_URK", 0);
+    o->no_multi = getenv("S3A_UTT_NO_MULTI") != NULL; o->framecheck = getenv("S3A_UTT_FRAMECHECK") != NULL;
+    o->times = num("S3A_UTT_TIMES", 0);
+}
+
 extern "C" s3a_uttdec_t *
 s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen,
                 int32_t n_ci_sen, int32_t ds_ratio, int32_t cond_ds, double ci_pbeam, float tighten_factor,
                 int32_t max_cd, s3a_comsen_t *cs, s3a_lm3g_t *lm, const s3a_wordlevel_cfg_t *cfg, int32_t n_lanes,
                 int32_t max_frames, int32_t vh_cap, int32_t cand_cap)
 {
+    return s3a_uttdec_init_opts(proto, g, cd2cisen, n_sen, n_ci_sen, ds_ratio, cond_ds, ci_pbeam, tighten_factor, max_cd, cs, lm, cfg,
+                                n_lanes, max_frames, vh_cap, cand_cap, NULL);
+}
+
+extern "C" s3a_uttdec_t *
+s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t *cd2cisen, int32_t n_sen,
+                int32_t n_ci_sen, int32_t ds_ratio, int32_t cond_ds, double ci_pbeam, float tighten_factor,
+                int32_t max_cd, s3a_comsen_t *cs, s3a_lm3g_t *lm, const s3a_wordlevel_cfg_t *cfg, int32_t n_lanes,
+                int32_t max_frames, int32_t vh_cap, int32_t cand_cap, const s3a_uttdec_opts_t *opts)
+{
+    s3a_uttdec_opts_t o_;
+    if (opts) o_ = *opts; else s3a_uttdec_opts_default(&o_);
+    const s3a_uttdec_opts_t &O = o_;
     if (!proto || !g || !g->dev || !cs || !lm || !cfg || n_lanes <= 0 || n_lanes > 1024 || max_frames <= 0) {
         s3a_set_error("s3a_uttdec_init: bad arguments");
         return NULL;
@@ -1593,28 +1629,28 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
 
     /* launch geometry: fixed grids, the kernels loop over the list lengths they find in memory */
     ud->eval_block = (cfg->maxhmmpf >= EVBLOCK_LONG_LIST && maxn >= EVBLOCK_LONG_LIST) ? 256 : 64;
-    ud->no_multi = getenv("S3A_UTT_NO_MULTI") != NULL;
+    ud->no_multi = O.no_multi != 0;
     ud->d_dbg = NULL;
-    if (getenv("S3A_UTT_FRAMECHECK")) { if (hipMalloc((void **)&ud->d_dbg, (size_t)n_lanes * 64) != hipSuccess || hipMemset(ud->d_dbg, 0, (size_t)n_lanes * 64) != hipSuccess) ud->d_dbg = NULL; }
-    ud->gy = getenv("S3A_UTT_GY") ? atoi(getenv("S3A_UTT_GY")) : 0;
-    ud->many = getenv("S3A_UTT_MANY") ? max(1, atoi(getenv("S3A_UTT_MANY"))) : 32;
+    if (O.framecheck) { if (hipMalloc((void **)&ud->d_dbg, (size_t)n_lanes * 64) != hipSuccess || hipMemset(ud->d_dbg, 0, (size_t)n_lanes * 64) != hipSuccess) ud->d_dbg = NULL; }
+    ud->gy = O.gy;
+    ud->many = O.many > 0 ? O.many : 32;
     /* fixed grids, sized for the usual frame: a workgroup loops when a list is longer (virtual workgroups); with many
      * lanes the idle workgroups of a generous grid cost more than the loop */
     ud->g_eval = max(1, min((maxn + ud->eval_block - 1) / ud->eval_block, n_lanes >= ud->many ? 64 : 2048 / max(1, min(n_lanes, 8))));
-    if (getenv("S3A_UTT_GEVAL")) ud->g_eval = max(1, atoi(getenv("S3A_UTT_GEVAL")));
+    if (O.g_eval > 0) ud->g_eval = O.g_eval;
     ud->g_res = max(1, min((proto->N + RSBLOCK - 1) / RSBLOCK, n_lanes >= ud->many ? 128 : 1024));
-    if (getenv("S3A_UTT_GRES")) ud->g_res = max(1, atoi(getenv("S3A_UTT_GRES")));
-    ud->urk = getenv("S3A_UTT_URK") ? atoi(getenv("S3A_UTT_URK")) : UR_K;
+    if (O.g_res > 0) ud->g_res = O.g_res;
+    ud->urk = O.sweep_k > 0 ? O.sweep_k : UR_K;
     ud->g_ent = max(1, min((proto->ent_cap + 255) / 256, 256));
     ud->g_mark = max(1, min((proto->ent_cap + M3BLOCK - 1) / M3BLOCK + ((maxn + M3BLOCK - 1) / M3BLOCK) * T, 1024));
     ud->scan_nc = (cfg->maxhmmpf >= SCAN_LONG_LIST && maxn >= SCAN_LONG_LIST) ? (maxn + 1023) / 1024 : 1;
-    ud->scan_gc = getenv("S3A_UTT_SCAN_G") ? atoi(getenv("S3A_UTT_SCAN_G")) : 0;
+    ud->scan_gc = O.scan_g;
     /* lextree_hmm_histbin can only fire when more than 1.5 x maxhmmpf HMMs can be active at all */
     ud->hist_possible = (long long)proto->N > (long long)cfg->maxhmmpf + (cfg->maxhmmpf >> 1);
     ud->weak_possible = cfg->ptranskip != 0 || cfg->pbeam < cfg->hmmbeam;
     /* wide beams (thousands of word exits, 10^5..10^6 (exit, predecessor) candidates per frame): the word level's
-     * candidate phases run chip-wide as their own launches; S3A_UTT_BIGWL=0/1 overrides */
-    ud->big_wl = getenv("S3A_UTT_BIGWL") ? atoi(getenv("S3A_UTT_BIGWL")) != 0 : (cfg->maxhmmpf >= 50000 && maxn >= 50000);
+     * candidate phases run chip-wide as their own launches; opts->big_wl = 0 / 1 overrides */
+    ud->big_wl = O.big_wl >= 0 ? (O.big_wl != 0) : (cfg->maxhmmpf >= 50000 && maxn >= 50000);
     if (ud->hist_possible && -cfg->hmmbeam / NBIN == 0) {
         s3a_set_error("s3a_uttdec_init: -beam too narrow for histogram pruning (bin width 0)");
         goto fail;
@@ -1676,17 +1712,17 @@ s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t
 
     /* look-ahead scoring (ku_score_window): the 39/40-dimensional case with a 16-bit log-add table and at most 64
      * Gaussian slots per senone; K frames per window so that a window of all lanes is ~1024 (lane, frame) slots -- what
-     * a model pass amortises over -- within 8 .. 64 frames.  S3A_UTT_WIN=0: the per-frame scoring kernels (tests). */
+     * a model pass amortises over -- within 8 .. 64 frames.  opts->window = 0: the per-frame scoring kernels (tests). */
     {
         int32_t K = 0;
         if (d->D4 == D4MAIN && d->CP <= 64 && d->Gpad % 512 == 0) {
             K = (1024 + n_lanes - 1) / n_lanes;
             K = min(64, max(8, ((K + 7) / 8) * 8));
-            if (getenv("S3A_UTT_WIN")) K = max(0, (atoi(getenv("S3A_UTT_WIN")) + 7) / 8 * 8);
+            if (O.window >= 0) K = (O.window + 7) / 8 * 8;
         }
         S.win_K = K;
-        ud->times = getenv("S3A_UTT_TIMES") ? atoi(getenv("S3A_UTT_TIMES")) : 0;
-        ud->win_fpc = getenv("S3A_UTT_WIN_FPC") ? atoi(getenv("S3A_UTT_WIN_FPC")) : 0;
+        ud->times = O.times;
+        ud->win_fpc = O.window_fpc;
     }
     ud->lane.resize(n_lanes);
     for (auto &hl : ud->lane) memset((void *)&hl, 0, sizeof hl);

@@ -182,6 +182,11 @@ _SIGS = {
     "s3a_uttdec_init": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_double, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32]),
+    "s3a_uttdec_init_opts": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_double, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "s3a_uttdec_opts_default": (None, [C.c_void_p]),
+    "s3a_uttdec_opts_from_env": (None, [C.c_void_p]),
     "s3a_uttdec_free": (None, [C.c_void_p]),
     "s3a_uttdec_decode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_decode_dev": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -1367,16 +1372,29 @@ class UttResult(C.Structure):
                [(k, C.c_int32) for k in ("max_cand", "max_new", "n_tie_frames")]
 
 
+class UttDecOpts(C.Structure):
+    """s3a_uttdec_opts_t: the engine's tuning options (every variant gives the same bits)"""
+    _fields_ = [(k, C.c_int32) for k in ("many", "big_wl", "window", "window_fpc", "g_eval", "g_res", "scan_g", "gy", "sweep_k",
+                                         "no_multi", "framecheck", "times")] + [("reserved", C.c_int32 * 4)]
+
+
 class UttDec:
     """s3a_uttdec_t: whole utterances on the device, n_lanes at a time (the `decode` slot of srch_funcs_t)"""
 
     def __init__(self, proto: "LexSearch", g: "MgauModel", cd2cisen, n_ci_sen, comsen: "ComSen", lm: "Lm3g", cfg, n_lanes,
-                 ds=1, cond_ds=0, ci_pbeam=1e-80, tighten_factor=0.5, max_cd=100000, max_frames=15000, vh_cap=0, cand_cap=0):
+                 ds=1, cond_ds=0, ci_pbeam=1e-80, tighten_factor=0.5, max_cd=100000, max_frames=15000, vh_cap=0, cand_cap=0,
+                 opts=None):
+        """opts: dict of s3a_uttdec_opts_t fields; what it leaves out comes from the S3A_UTT_* environment variables (this
+        harness reads them -- s3a_uttdec_opts_from_env -- the library does not)"""
         self.L = load()
         self._keep = (proto, g, comsen, lm, cfg, np.ascontiguousarray(cd2cisen, np.int16))
-        self.h = self.L.s3a_uttdec_init(proto.h, g.h, _p(self._keep[5]), len(self._keep[5]), int(n_ci_sen), int(ds), int(cond_ds),
-                                        float(ci_pbeam), float(tighten_factor), int(max_cd), comsen.h, lm.h, C.byref(cfg),
-                                        int(n_lanes), int(max_frames), int(vh_cap), int(cand_cap))
+        o = UttDecOpts()
+        self.L.s3a_uttdec_opts_from_env(C.byref(o))
+        for k, v in (opts or {}).items():
+            setattr(o, k, int(v))
+        self.h = self.L.s3a_uttdec_init_opts(proto.h, g.h, _p(self._keep[5]), len(self._keep[5]), int(n_ci_sen), int(ds), int(cond_ds),
+                                             float(ci_pbeam), float(tighten_factor), int(max_cd), comsen.h, lm.h, C.byref(cfg),
+                                             int(n_lanes), int(max_frames), int(vh_cap), int(cand_cap), C.byref(o))
         if not self.h:
             raise S3AError(_err(self.L))
         self.n_lanes = int(n_lanes)

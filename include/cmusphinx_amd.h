@@ -687,6 +687,27 @@ s3a_uttdec_t *s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g,
                               double ci_pbeam, float tighten_factor, int32_t max_cd, s3a_comsen_t *cs,
                               s3a_lm3g_t *lm, const s3a_wordlevel_cfg_t *cfg, int32_t n_lanes,
                               int32_t max_frames, int32_t vh_cap, int32_t cand_cap);
+/* The same with the engine's tuning options as arguments (all zero / -1 = the library's choice; every variant gives the
+ * same bits): many = lanes from which the grids / kernels for many lanes per launch are used (default 32); big_wl = the word
+ * level's candidate phases as launches of their own (-1: by the beams' width); window = frames per look-ahead scoring pass
+ * (-1: ~1024 (lane, frame) slots per pass; 0: per-frame scoring kernels), window_fpc = slots per workgroup chunk of that pass;
+ * g_eval / g_res / scan_g / gy / sweep_k = grid sizes of the HMM evaluation, the resolve kernels, the scan, the gated scorer and
+ * the nodes per thread of the resolve sweep; no_multi = no shared CD pass of the per-frame scorer; framecheck = run the
+ * per-frame invariant kernel; times = print the host-side phases of every decode to stderr.  s3a_uttdec_init is
+ * s3a_uttdec_init_opts with opts = NULL (defaults); the library never reads the environment for these:
+ * s3a_uttdec_opts_from_env fills the struct from the S3A_UTT_* variables for hosts that want that (the drop-in program,
+ * the test harness). */
+typedef struct {
+    int32_t many, big_wl, window, window_fpc, g_eval, g_res, scan_g, gy, sweep_k, no_multi, framecheck, times;
+    int32_t reserved[4];
+} s3a_uttdec_opts_t;
+void s3a_uttdec_opts_default(s3a_uttdec_opts_t *o);
+void s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o);
+s3a_uttdec_t *s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const int16_t *cd2cisen,
+                                   int32_t n_sen, int32_t n_ci_sen, int32_t ds_ratio, int32_t cond_ds, double ci_pbeam,
+                                   float tighten_factor, int32_t max_cd, s3a_comsen_t *cs, s3a_lm3g_t *lm,
+                                   const s3a_wordlevel_cfg_t *cfg, int32_t n_lanes, int32_t max_frames, int32_t vh_cap,
+                                   int32_t cand_cap, const s3a_uttdec_opts_t *opts);
 void s3a_uttdec_free(s3a_uttdec_t *ud);
 int32_t s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat,
                           const int32_t *n_frames, int32_t feat_stride);

@@ -322,11 +322,13 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
                                    cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.", S3A_MIX_INT_FLOAT_COMP, g_lm);
                 if (!gm) die("s3a_mgau_init");
             }
-            g_uds[e] = s3a_uttdec_init(g_ls, gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen, cmd_ln_int32_r(config, "-ds"),
+            s3a_uttdec_opts_t uo;
+            s3a_uttdec_opts_from_env(&uo);          /* (this program's tuning switches are environment variables; the library takes arguments) */
+            g_uds[e] = s3a_uttdec_init_opts(g_ls, gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen, cmd_ln_int32_r(config, "-ds"),
                            cmd_ln_int32_r(config, "-cond_ds"), cmd_ln_float64_r(config, "-ci_pbeam"),
                            cmd_ln_float32_r(config, "-tighten_factor"), cmd_ln_int32_r(config, "-maxcdsenpf"), g_cs,
                            g_lm3g, &cfg, g_lpe, S3_MAX_FRAMES, getenv("S3A_UTT_VHCAP") ? atoi(getenv("S3A_UTT_VHCAP")) : 0,
-                           getenv("S3A_UTT_CANDCAP") ? atoi(getenv("S3A_UTT_CANDCAP")) : 0);
+                           getenv("S3A_UTT_CANDCAP") ? atoi(getenv("S3A_UTT_CANDCAP")) : 0, &uo);
             if (!g_uds[e]) die("s3a_uttdec_init");
             if (kb.pl->pheurtype != 0) {        /* -pheurtype 1..3: phoneme look-ahead inside the engine */
                 const uint8_t **nci = ckd_calloc(g_ntree, sizeof(*nci));
