@@ -59,7 +59,7 @@ utt_end_slot(void *srch)                /* srch_TST_end, :514-560 */
  * (srch.c:519-530 gen_dag, :609-640 bestpath_impl) hand the result over.  S3A_UTT_HOSTDAG=1: the reference's own
  * vithist_dag_build / dag_search on the table the device produced (the comparison run). */
 static int g_dev_dag;
-static long g_dag_utts;
+static long g_dag_utts, g_failed_utts;
 /* one process per GPU: the rank's hypotheses as (header, words) records for the end-of-batch exchange (s3a_gather_hyps) */
 static int g_rank = 0, g_world = 1, g_rank_first = 0, g_rank_total = 0, g_gather = 0;
 static char g_final[2][4300];
@@ -129,6 +129,14 @@ utt_finish(kb_t *kb, int32 z)
     int32 f;
 
     if (s3a_uttdec_result(g_uds[z / g_lpe], z % g_lpe, &r) != S3A_OK) die("uttdec result");
+    if (r.err) {
+        E_ERROR("tst shim: utterance %s stopped on the device (error bits 0x%x: a capacity of its lane -- S3A_UTT_VHCAP / S3A_UTT_CANDCAP); no hypothesis written\n",
+                q->uttid, r.err);
+        g_failed_utts++;
+        if (g_gather) rec_add(z);               /* (status -1: the exchange carries it, rank 0 writes no line) */
+        ckd_free(q->uttid); ckd_free(q->uttfile); ckd_free(q->feat);
+        return;
+    }
     if (z == 0 && getenv("S3A_UTT_TICKS")) {
         long long tk[16];
         int i;
@@ -226,7 +234,18 @@ utt_flush(kb_t *kb)
         for (e = 0; e < n_used; e++) job[e].state = 0;
         pthread_mutex_unlock(&g_eng_lock);
     }
-    for (e = 0; e < n_used; e++) if (job[e].rc != S3A_OK) die("uttdec decode");
+    /* a decode call fails when ONE of its utterances could not be decoded (a capacity of that lane: history table,
+     * candidate buffers): the other lanes' results are complete -- they are finished as usual, the failed utterance is
+     * reported and gets no -hyp / -hypseg line (as an utterance the reference fails on), and the run ends with status 1.
+     * Anything else (no lane names an error: the device, the arguments) ends the run here. */
+    for (e = 0; e < n_used; e++)
+        if (job[e].rc != S3A_OK) {
+            s3a_utt_result_t r;
+            int32 bad = 0;
+            for (z = 0; z < job[e].n; z++) if (s3a_uttdec_result(g_uds[e], z, &r) == S3A_OK && r.err) bad++;
+            if (!bad) die("uttdec decode");
+            E_ERROR("tst shim: %d utterance(s) of this batch were not decoded: %s\n", bad, s3a_last_error());
+        }
     g_t_dev += now_s() - t0;
     t0 = now_s();
     for (z = 0; z < g_uq_n; z++) utt_finish(kb, z);
@@ -463,5 +482,9 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     E_INFO("tst shim throughput: %ld frames, decode-only %.3f s = %.0f x real time aggregate "
            "(%.3f s incl. loading %d decoders one after another)\n",
            g_frames, t_dec, 0.01 * g_frames / t_dec, t_dec + t_load, 1);
+    if (g_failed_utts) {
+        E_ERROR("tst shim: %ld utterance(s) were not decoded (see above); every other utterance is in the output\n", g_failed_utts);
+        return 1;
+    }
     return 0;
 }

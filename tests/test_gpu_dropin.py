@@ -369,3 +369,26 @@ def test_end_of_batch_exchange_in_c_over_rccl_one_rank(tmp_path):
         assert "gathered 31 utterances from 1 ranks over RCCL" in txt
         assert open(hyp + ".gathered").read() == open(hyp).read() and open(seg + ".gathered").read() == open(seg).read()
         assert open(hyp).read().count("\n") == 31
+
+
+def test_an_utterance_that_overflows_its_lane_does_not_take_the_batch_down(tmp_path):
+    """A history table far too small for the long utterances (S3A_UTT_VHCAP): the lanes that overflow stop loudly, the other
+    utterances of the same batches are decoded, finished and written as always (their lines are the reference's, in order),
+    the failed ones get no line -- as an utterance the reference itself fails on -- and the run ends with status 1."""
+    hyp, seg, log = (str(tmp_path / f"o.{e}") for e in ("match", "matchseg", "log"))
+    with open(log, "w") as lf:
+        p = subprocess.run([TST] + common() + RUNS["mode4_trigram"] + ["-hyp", hyp, "-hypseg", seg], stdout=lf,
+                           stderr=subprocess.STDOUT, timeout=900, env=dict(os.environ, S3A_UTT="4", S3A_UTT_VHCAP="300", S3A_GATHER="1"))
+    txt = open(log, errors="ignore").read()
+    assert p.returncode == 1, txt[-3000:]
+    assert "history table full" in txt and "no hypothesis written" in txt
+    ref_h = open(os.path.join(D, "ref_mode4_trigram.match")).read().splitlines()
+    ref_s = open(os.path.join(D, "ref_mode4_trigram.matchseg")).read().splitlines()
+    got_h, got_s = open(hyp).read().splitlines(), open(seg).read().splitlines()
+    assert 0 < len(got_h) < len(ref_h) and len(got_s) == len(got_h)
+    it = iter(ref_h)
+    assert all(any(l == r for r in it) for l in got_h)              # a subsequence of the reference's lines, in order
+    assert set(got_s) <= set(ref_s)
+    # the lanes that overflowed were reset: the utterances decoded AFTER a failure on the same lanes are right (above), and
+    # the exchange's records carry the failures as status -1 (rank 0 writes no line for them)
+    assert open(hyp + ".gathered").read() == open(hyp).read()
