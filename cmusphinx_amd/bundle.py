@@ -121,6 +121,13 @@ class Decoder:
         """feats: list (<= n_lanes) of [nfr, veclen] float32 -> device milliseconds"""
         return self.ud.decode(feats)
 
+    def decode_queue(self, feats):
+        """any number of utterances, lanes refilled as they finish -> device milliseconds"""
+        return self.ud.decode_queue(feats)
+
+    def queue_hyp(self, utt, uttid="", utt_index=0):
+        return self.ud.queue_hyp(utt, uttid, utt_index)
+
     def hyp(self, lane, uttid="", utt_index=0):
         return self.ud.hyp(lane, uttid, utt_index)
 

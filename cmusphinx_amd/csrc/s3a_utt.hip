@@ -98,10 +98,13 @@ struct UShared {
     int32_t *nact_all;          /* [n_lanes][2][WL_MAXT] */
 };
 
-/* lanes run in lock step from frame 0: the frame index f is a kernel argument, the list searched in frame f is
- * list f & 1 (lextree_active_swap flips it every frame) -- no kernel has to read what the word level of the previous
- * frame wrote last, so the word level can share a launch with the emission sweep */
-#define LANE UCtx *ctx = S.ctx_all + blockIdx.z; if (f >= ctx->nfr || !ctx->active) return;                      \
+/* the lanes share every launch: the kernels' argument fg is the ENGINE's frame counter, a lane's own frame is
+ * f = fg - ctx->f0 (f0 = 0 when all lanes start together; a lane that took its next utterance from the queue when the
+ * last one ended -- s3a_uttdec_decode_queue -- started later), the list searched in frame f is list f & 1
+ * (lextree_active_swap flips it every frame) -- no kernel has to read what the word level of the previous frame wrote
+ * last, so the word level can share a launch with the emission sweep */
+#define LANE UCtx *ctx = S.ctx_all + blockIdx.z; const int32_t f = fg - ctx->f0;                                    \
+    if (f < 0 || f >= ctx->nfr || !ctx->active) return;                                                           \
     const int32_t cur = f & 1; const int32_t *nact_cur = S.nact_all + ((size_t)blockIdx.z * 2 + cur) * WL_MAXT;       \
     const ULane &L = lanes[blockIdx.z]; (void)cur; (void)nact_cur
 /* the frame's senone scores: the lane's row of the look-ahead window, or the per-frame scorer's array */
@@ -123,25 +126,50 @@ frame_beams(const UShared &S, int32_t cf)
  * :485-490 resets it), the masks, and the history table's entry 0 (vithist_utt_begin, vithist.c:300-335). */
 struct UBegin { int32_t e0[10], lmc[5], n_pset; };
 
+/* (sub: the lanes of a refill event, s3a_uttdec_decode_queue -- NULL: lanes 0 .. gridDim.z - 1) */
 __global__ void __launch_bounds__(256)
-ku_lanes_end(const ULane *__restrict__ lanes, UShared S)
+ku_lanes_end(const ULane *__restrict__ lanes, UShared S, const int32_t *__restrict__ sub, int32_t n_word)
 {
-    const ULane &L = lanes[blockIdx.z];
+    const int32_t z = sub ? sub[blockIdx.z] : (int32_t)blockIdx.z;
+    const ULane &L = lanes[z];
     const int32_t t = blockIdx.y % S.T, w = blockIdx.y / S.T;
-    const int32_t na = S.nact_all[((size_t)blockIdx.z * 2 + w) * WL_MAXT + t], b = S.node_base[t];
+    const int32_t ne = S.ne;
+    if (sub && S.ctx_all[z].err) {
+        /* the utterance this lane just finished stopped on an error in mid-frame: everything from scratch, as the host
+         * does for a dirty lane (lane_begin: s3a_lexsearch_reset + the word level's hash / per-word scratch) */
+        const int32_t nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x, stride = nb * 256;
+        for (int32_t v = b * 256 + threadIdx.x; v < S.N; v += stride) {
+            int32_t *r = L.sc + NSV(v);
+            for (int32_t st = 0; st < ne; st++) { r[st] = WORST; r[NS_HIST(ne) + st] = -1; }
+            r[NS_OUTS(ne)] = WORST; r[NS_OUTH(ne)] = -1; r[NS_BESTS(ne)] = WORST; r[NS_FRAME(ne)] = -1;
+            L.pos[v] = -1; L.turn[v] = -1; L.selfemit[v] = 0; L.cnt[v] = 0; L.first[v] = INT_MAX; L.key[v] = 0ull;
+        }
+        for (int32_t i = b * 256 + threadIdx.x; i <= L.w.hmask; i += stride) { L.w.hkey[i] = 0ull; L.w.hbest[i] = 0ull; L.w.hfirst[i] = 0xffffffffu; }
+        for (int32_t i = b * 256 + threadIdx.x; i < n_word; i += stride) { L.w.wfirst[i] = INT_MAX; L.w.wbest[i] = INT_MIN; }
+        if (b == 0) {
+            for (int32_t i = threadIdx.x; i < 2 * S.T; i += 256) { L.nexit[i] = 0; L.best[i] = INT_MIN; }
+            for (int32_t i = threadIdx.x; i < 1024; i += 256) L.hbin[i] = 0;
+            if (threadIdx.x < 4) L.done[threadIdx.x] = 0;
+        }
+        return;
+    }
+    const int32_t na = S.nact_all[((size_t)z * 2 + w) * WL_MAXT + t], b = S.node_base[t];
     for (int32_t i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) {
         const int32_t v = L.act[w][b + i];
         int32_t *r = L.sc + NSV(v);
-        const int32_t ne = S.ne;
         for (int32_t st = 0; st < ne; st++) { r[st] = WORST; r[NS_HIST(ne) + st] = -1; }
         r[NS_OUTS(ne)] = WORST; r[NS_OUTH(ne)] = -1; r[NS_BESTS(ne)] = WORST; r[NS_FRAME(ne)] = -1;
     }
 }
 
+/* (sub / utt / stage: a refill event -- lane sub[z] takes utterance utt[z] of the queue, whose context was staged on the
+ * device before the first frame) */
 __global__ void __launch_bounds__(256)
-ku_lanes_begin(const ULane *__restrict__ lanes, UShared S, UBegin B)
+ku_lanes_begin(const ULane *__restrict__ lanes, UShared S, UBegin B, const int32_t *__restrict__ sub,
+               const int32_t *__restrict__ utt, const UCtx *__restrict__ stage)
 {
-    const ULane &L = lanes[blockIdx.z];
+    const int32_t z = sub ? sub[blockIdx.z] : (int32_t)blockIdx.z;
+    const ULane &L = lanes[z];
     const int32_t i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
     for (int32_t i = i0; i < S.N; i += stride) { L.posf[i] = INT_MIN; L.propf[i] = INT_MIN; }
     for (int32_t i = i0; i < B.n_pset; i += stride) L.pstamp[i] = INT_MIN;
@@ -152,13 +180,19 @@ ku_lanes_begin(const ULane *__restrict__ lanes, UShared S, UBegin B)
     for (int32_t i = i0; i <= S.n_cs; i += stride) L.cs_need[i] = -1;
     if (blockIdx.x == 0) {
         const int32_t tid = threadIdx.x;
-        if (tid < 2 * WL_MAXT) S.nact_all[(size_t)blockIdx.z * 2 * WL_MAXT + tid] = 0;
+        if (tid < 2 * WL_MAXT) S.nact_all[(size_t)z * 2 * WL_MAXT + tid] = 0;
         if (tid < 8) L.misc[tid] = (tid == 0 || tid == 5) ? INT_MIN : 0;
         if (tid == 32) {
             int32_t *arr[10] = { L.w.score, L.w.pred, L.w.lw0, L.w.lw1, L.w.wid, L.w.sf, L.w.ef, L.w.ascr, L.w.lscr, L.w.type };
             for (int k = 0; k < 10; k++) arr[k][0] = B.e0[k];
             for (int k = 0; k < 5; k++) L.w.lmc[(size_t)k * L.w.cap] = B.lmc[k];
             L.w.frame_start[0] = 1; L.w.bestscore[0] = INT_MIN; L.w.bestvh[0] = -1; L.w.st[0] = 1; L.w.st[1] = 0;
+        }
+        if (stage) {
+            static_assert(sizeof(UCtx) % 4 == 0, "UCtx is copied word by word");
+            const int32_t *src = (const int32_t *)(stage + utt[blockIdx.z]);
+            int32_t *dst = (int32_t *)(S.ctx_all + z);
+            for (int32_t i = tid; i < (int32_t)(sizeof(UCtx) / 4); i += 256) dst[i] = src[i];
         }
     }
 }
@@ -167,7 +201,7 @@ ku_lanes_begin(const ULane *__restrict__ lanes, UShared S, UBegin B)
  * list at the place its record names; the first violation of a lane is kept: dbg[0] = frame + 1 (0: none), [1] node,
  * [2..7] sc0 sc1 outs bests frame-tag posf, [8] pos, [9] turn, [10] list length of its tree, [11] what sits at pos */
 __global__ void __launch_bounds__(256)
-ku_framecheck(const ULane *__restrict__ lanes, UShared S, int32_t f, int32_t *dbg_all)
+ku_framecheck(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t *dbg_all)
 {
     LANE;
     int32_t *dbg = dbg_all + 16 * blockIdx.z;
@@ -225,7 +259,7 @@ ku_selfcheck(const ULane *__restrict__ lanes, UShared S, int32_t lane, int32_t *
 /* the entry test (d_dec_enter1) with the calls' table in LDS: an entry finds its call by a bisection in LDS and fails the
  * test -- almost all do -- after ONE global round trip (its root's look-ahead probability, in list order) */
 __global__ void __launch_bounds__(256)
-ku_enter1(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_enter1(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     __shared__ int32_t s_off[WL_MAXCALL], s_root[WL_MAXCALL], s_in[WL_MAXCALL];
     LANE;
@@ -251,7 +285,7 @@ ku_enter1(const ULane *__restrict__ lanes, UShared S, int32_t f)
 
 /* (a workgroup per lextree_enter call; with many lanes fewer workgroups that take the calls in turn) */
 __global__ void __launch_bounds__(SCAN_THREADS)
-ku_enter2(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_enter2(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     const int32_t n_calls = ctx->n_calls;
@@ -265,7 +299,7 @@ ku_enter2(const ULane *__restrict__ lanes, UShared S, int32_t f)
 }
 
 __global__ void __launch_bounds__(M3BLOCK)
-ku_enter3_mark(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_enter3_mark(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     const int32_t n_ent = ctx->n_ent;
@@ -283,7 +317,7 @@ ku_enter3_mark(const ULane *__restrict__ lanes, UShared S, int32_t f)
 /* ---- approx_cont_mgau_ci_eval / _frame_eval for the lane's frame (s3a_gated.h) ---- */
 template <bool EXACT, bool CI>
 __global__ void __launch_bounds__(256)
-ku_gated(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_gated(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     const int32_t lo = CI ? 0 : S.n_ci_sen, hi = CI ? S.n_ci_sen : S.n_sen, cf = f;
@@ -330,7 +364,7 @@ struct UgDec {
 
 template <bool EXACT>
 __global__ void __launch_bounds__(256)
-ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, int32_t f)
+ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, int32_t fg)
 {
     typedef typename Acc<EXACT>::T acc_t;
     __shared__ UgDec dec[UG_MAX];
@@ -364,9 +398,9 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, i
         if (tid < n) {
             const ULane &Lz = lanes[zb + tid];
             const UCtx *cx = Lz.ctx;
-            d.active = (cx->active && f < cx->nfr) ? 1 : 0;
+            const int32_t cf = fg - cx->f0;            /* the lane's own frame */
+            d.active = (cx->active && cf >= 0 && cf < cx->nfr) ? 1 : 0;
             if (d.active) {
-                const int32_t cf = f;
                 d.sen_act = Lz.sen_act; d.scr = Lz.scr; d.gpart = Lz.gpart; d.bstidx = Lz.bstidx; d.bstscr = Lz.bstscr;
                 d.updatetime = Lz.updatetime; d.frame = cf; d.is_skip = (cf % S.ds_ratio == 0) ? 0 : 1;
                 d.thresh = add32(Lz.misc[5], S.max_cd < S.n_sen - S.n_ci_sen ? Lz.dynbeam[0]
@@ -382,7 +416,7 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, i
     for (int32_t i = tid; i < UG_MAX * D4MAIN * 4; i += 256) {
         const int32_t zz = i / (D4MAIN * 4), k = i - zz * (D4MAIN * 4);
         float v = 0.0f;
-        if (zz < n && dec[zz].active) { const UCtx *cx = lanes[zb + zz].ctx; v = cx->feat[(size_t)f * (D4MAIN * 4) + k]; }
+        if (zz < n && dec[zz].active) { const UCtx *cx = lanes[zb + zz].ctx; v = cx->feat[(size_t)dec[zz].frame * (D4MAIN * 4) + k]; }
         ((float *)xs4)[i] = v;
     }
     __syncthreads();
@@ -536,11 +570,12 @@ ku_score_window(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, int
         UwGroup gr;
         gr.feat = NULL; gr.win = NULL; gr.winb = NULL; gr.nv = 0; gr.pad = 0;
         const UCtx *cx = S.ctx_all + z;
-        if (cx->active) {
-            const int32_t left = cx->nfr - (f0 + j0);
+        const int32_t fl = f0 - cx->f0 + j0;            /* the lane's own frame (its utterance began at a window's first frame) */
+        if (cx->active && fl >= 0) {
+            const int32_t left = cx->nfr - fl;
             if (left > 0) {
                 gr.nv = min(left, UW_FB);
-                gr.feat = cx->feat + (size_t)(f0 + j0) * DP;
+                gr.feat = cx->feat + (size_t)fl * DP;
                 gr.win = lanes[z].win + (size_t)j0 * S.n_sen;
                 gr.winb = lanes[z].winb + (size_t)j0 * S.n_sen;
             }
@@ -650,7 +685,7 @@ uw_one_gaussian(const UShared &S, int32_t g, const float *__restrict__ x)
 #define USEL_G 8
 template <bool EXACT>
 __global__ void __launch_bounds__(256)
-ku_select(const ULane *__restrict__ lanes, UShared S, int32_t f, int32_t K)
+ku_select(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t K)
 {
     __shared__ int32_t red[3][4];
     __shared__ int32_t s_pb;
@@ -723,7 +758,7 @@ ku_select(const ULane *__restrict__ lanes, UShared S, int32_t f, int32_t K)
 
 /* the members of the composite senones wanted in this frame join the mask (before ku_select) */
 __global__ void __launch_bounds__(256)
-ku_comsen_mark(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_comsen_mark(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     d_comsen_wave<false>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, L.sen_act, (const int32_t *)NULL, (int32_t *)NULL,
@@ -735,7 +770,7 @@ ku_comsen_mark(const ULane *__restrict__ lanes, UShared S, int32_t f)
  * (Ties need no order: the cut is a score.)  One workgroup per lane, between the CI and the CD scoring launches. ---- */
 #define UDB_MAXCI 1024
 __global__ void __launch_bounds__(1024)
-ku_dyn_ci_beam(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_dyn_ci_beam(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     __shared__ int32_t s_occ[UDB_MAXCI], s_scr[UDB_MAXCI], s_ord[UDB_MAXCI], s_cut;
     LANE;
@@ -776,7 +811,7 @@ ku_dyn_ci_beam(const ULane *__restrict__ lanes, UShared S, int32_t f)
 
 /* ---- the scores of the composite senones wanted in this frame (after the scoring kernels) ---- */
 __global__ void __launch_bounds__(256)
-ku_comsen_max(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_comsen_max(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     d_comsen_wave<true>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, (uint8_t *)NULL, SCR_ROW, L.cs_val,
@@ -794,9 +829,9 @@ ku_comsen_max(const ULane *__restrict__ lanes, UShared S, int32_t f)
  */
 template <bool EXACT>
 __global__ void __launch_bounds__(256)
-ku_ci_ahead(const ULane *__restrict__ lanes, UShared S)
+ku_ci_ahead(const ULane *__restrict__ lanes, UShared S, const int32_t *__restrict__ sub)
 {
-    const ULane &L = lanes[blockIdx.z];
+    const ULane &L = lanes[sub ? sub[blockIdx.z] : (int32_t)blockIdx.z];
     const UCtx *ctx = L.ctx;
     const int32_t cf = blockIdx.y;
     if (cf >= ctx->nfr) return;
@@ -821,9 +856,9 @@ ph_add(int32_t a, int32_t b)
 #define PH_T 64
 #define PH_MAXCI 96
 __global__ void __launch_bounds__(PH_T)
-ku_phn_heur(const ULane *__restrict__ lanes, UShared S)
+ku_phn_heur(const ULane *__restrict__ lanes, UShared S, const int32_t *__restrict__ sub)
 {
-    const ULane &L = lanes[blockIdx.z];
+    const ULane &L = lanes[sub ? sub[blockIdx.z] : (int32_t)blockIdx.z];
     const int32_t nfr = L.ctx->nfr, t = blockIdx.x * PH_T + threadIdx.x, n_cis = S.n_ci_sen, nci = S.n_ci;
     __shared__ int32_t s_ph[PH_MAXCI][PH_T + 1];
     if (t >= nfr) return;
@@ -872,7 +907,7 @@ ku_phn_heur(const ULane *__restrict__ lanes, UShared S)
  * per (tree, lane); an HMM propagates when it is no leaf and its exit score reaches the phone threshold (with the phone
  * beam no wider than the HMM beam -- checked when the look-ahead is enabled -- such an HMM is never cleared first). */
 __global__ void __launch_bounds__(1024)
-ku_heur_thresh(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_heur_thresh(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     const int32_t t = blockIdx.x, na = nact_cur[t], b = S.node_base[t], tid = threadIdx.x;
@@ -920,7 +955,7 @@ ku_heur_thresh(const ULane *__restrict__ lanes, UShared S, int32_t f)
 /* ---- lextree_hmm_eval ---- */
 template <int EB, int NE>
 __global__ void __launch_bounds__(EB)
-ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     const int32_t t = blockIdx.y, na = nact_cur[t];
@@ -936,7 +971,7 @@ ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t f)
 /* after the evaluation: the histogram bins when the frame holds more than 1.5 x -maxhmmpf HMMs (lextree_hmm_histbin);
  * otherwise the thresholds are final and the HMMs that can propagate stamp their children's parent sets (d_dec_stamp) */
 __global__ void __launch_bounds__(DBLOCK)
-ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     const int32_t t = blockIdx.y, na = nact_cur[t];
@@ -961,7 +996,7 @@ ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t f)
 
 /* the histogram beam + the reordering of the lists (frames over 1.5 x -maxhmmpf only), then the stamps of such a frame */
 __global__ void __launch_bounds__(SCAN_THREADS)
-ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     const FrameBeams bm = frame_beams(S, f);
@@ -976,7 +1011,7 @@ ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t f)
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-ku_weak(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_weak(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     const FrameBeams bm = frame_beams(S, f);
@@ -991,7 +1026,7 @@ ku_weak(const ULane *__restrict__ lanes, UShared S, int32_t f)
 /* few lanes: one node per thread over all nodes (the chain is what counts) */
 template <bool HEUR>
 __global__ void __launch_bounds__(RSBLOCK)
-ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     d_dec_resolve<uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
@@ -1004,7 +1039,7 @@ ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t f)
 #define UR_K 8
 template <bool HEUR, int URK = UR_K>
 __global__ void __launch_bounds__(RSBLOCK)
-ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t f)
+ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     LANE;
     const int32_t GB = ((S.N + URK - 1) / URK + RSBLOCK - 1) / RSBLOCK;
@@ -1015,7 +1050,7 @@ ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t f)
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t GC, int32_t f)
+ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t GC, int32_t fg)
 {
     LANE;
     const FrameBeams bm = frame_beams(S, f);
@@ -1035,7 +1070,7 @@ ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t GC, int3
  * The two read nothing the other writes. */
 #define UE_WG_PER_TREE 8
 __global__ void __launch_bounds__(WL_THREADS)
-ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, int32_t f, int32_t big)
+ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, int32_t fg, int32_t big)
 {
     LANE;
     if (blockIdx.x > 0) {
@@ -1055,40 +1090,41 @@ ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPa
     else d_wordlevel_frame(L.w, ctx, L.pack, s_hdr, nx <= WL_LDS_EX ? s_ex : (const int32_t *)NULL, lm, dict, par, f, t_in);
 }
 
-#define LANE_W const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; if (f >= ctx->nfr || !ctx->active) return
+#define LANE_W const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; const int32_t f = fg - ctx->f0;               \
+    if (f < 0 || f >= ctx->nfr || !ctx->active) return
 /* the wide-beam word level: WL_BIG_G workgroups per lane and phase (s3a_wordlevel.h) */
 __global__ void __launch_bounds__(WL_THREADS)
-ku_wl_p2(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par, int32_t f)
+ku_wl_p2(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par, int32_t fg)
 {
     LANE_W;
     d_wl_big_p2(L.w, ctx, L.pack, lm, dict, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
-ku_wl_p3(const ULane *__restrict__ lanes, WDict dict, WPar par, int32_t f)
+ku_wl_p3(const ULane *__restrict__ lanes, WDict dict, WPar par, int32_t fg)
 {
     LANE_W;
     d_wl_big_p3(L.w, ctx, L.pack, dict, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
-ku_wl_p4a(const ULane *__restrict__ lanes, WPar par, int32_t f)
+ku_wl_p4a(const ULane *__restrict__ lanes, WPar par, int32_t fg)
 {
     LANE_W;
     d_wl_big_p4a(L.w, ctx, L.pack, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
-ku_wl_p4b(const ULane *__restrict__ lanes, WPar par, int32_t f)
+ku_wl_p4b(const ULane *__restrict__ lanes, WPar par, int32_t fg)
 {
     LANE_W;
     d_wl_big_p4b(L.w, ctx, L.pack, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
-ku_wl_p5(const ULane *__restrict__ lanes, WDict dict, WPar par, int32_t f)
+ku_wl_p5(const ULane *__restrict__ lanes, WDict dict, WPar par, int32_t fg)
 {
     LANE_W;
     d_wl_big_p5(L.w, ctx, L.pack, dict, par, f, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(WL_THREADS)
-ku_wl_finish(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par, int32_t f)
+ku_wl_finish(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par, int32_t fg)
 {
     LANE_W;
     d_wl_big_finish(L.w, ctx, L.pack, lm, dict, par, f);
@@ -1251,19 +1287,22 @@ s3a_lm3g_tg_score(const s3a_lm3g_t *lm, int32_t lw1, int32_t lw2, int32_t lw3, i
  * are packed one behind the other (a lane reserves its place with one atomicAdd on the word counter behind the headers),
  * so that ONE linear copy brings them over.
  */
-enum { UH_STATUS, UH_NENTRY, UH_NFRM, UH_TSCALE, UH_NWORDS, UH_SCORE, UH_EXIT, UH_WOFF, UH_N };
+enum { UH_STATUS, UH_NENTRY, UH_NFRM, UH_TSCALE, UH_NWORDS, UH_SCORE, UH_EXIT, UH_WOFF,
+       UH_ERR, UH_CF, UH_MAXCAND, UH_MAXNEW, UH_NTIE, UH_NFR, UH_PAD0, UH_PAD1, UH_N };   /* (from UH_ERR on: the lane's context when it ended) */
 #define UH_FIRST 96          /* words per lane that travel with the headers (more: a second copy) */
-struct UHypPar { int32_t finish_lwid, finishwid, silwid, wcap; };
+struct UHypPar { int32_t finish_lwid, finishwid, silwid, wcap, wtotal; };     /* wcap: words per hypothesis; wtotal: of the packed buffer */
 #define UH_T 256
 #define UH_IDS 2048
 
 __global__ void __launch_bounds__(UH_T)
-ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *__restrict__ hdr_all, int32_t *__restrict__ words_all)
+ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *__restrict__ hdr_all, int32_t *__restrict__ words_all,
+       int32_t *__restrict__ wcount, const int32_t *__restrict__ sub, const int32_t *__restrict__ slot)
 {
-    const ULane &L = lanes[blockIdx.x];
+    /* (sub / slot: a refill event -- lane sub[x] has finished the utterance whose header goes to slot[x]; NULL: lane x, header x) */
+    const ULane &L = lanes[sub ? sub[blockIdx.x] : (int32_t)blockIdx.x];
     const WLane &w = L.w;
     const UCtx *ctx = L.ctx;
-    int32_t *hdr = hdr_all + (size_t)blockIdx.x * UH_N;
+    int32_t *hdr = hdr_all + (size_t)(slot ? slot[blockIdx.x] : (int32_t)blockIdx.x) * UH_N;
     const int32_t tid = threadIdx.x, nfr = ctx->nfr, n_entry = w.st[0], n_frm = w.st[1];
     __shared__ uint32_t s_scale;
     __shared__ int32_t s_woff;
@@ -1285,6 +1324,8 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
     if (tid == 0) {
         hdr[UH_STATUS] = err ? -1 : (f < 0 ? -2 : 0); hdr[UH_NENTRY] = n_entry; hdr[UH_NFRM] = n_frm; hdr[UH_TSCALE] = (int32_t)s_scale;
         hdr[UH_NWORDS] = 0; hdr[UH_SCORE] = 0; hdr[UH_EXIT] = -1; hdr[UH_WOFF] = 0;
+        hdr[UH_ERR] = err; hdr[UH_CF] = ctx->cf; hdr[UH_MAXCAND] = ctx->max_cand; hdr[UH_MAXNEW] = ctx->max_new;
+        hdr[UH_NTIE] = ctx->n_tie_frames; hdr[UH_NFR] = nfr; hdr[UH_PAD0] = 0; hdr[UH_PAD1] = 0;
     }
     if (err || f < 0) return;               /* (f < 0: no word exit at all -- vithist_utt_end returns -1) */
     const int32_t sv = w.frame_start[f], nsv = w.frame_start[f + 1];
@@ -1301,11 +1342,12 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
         for (int32_t i = bestvh; i > 0; i = w.pred[i], n++) if (n < UH_IDS) s_ids[n] = i;
         s_n = n;
         const int32_t tot = n + (have_sil ? 1 : 0) + 1;
-        s_woff = tot <= P.wcap ? atomicAdd(hdr_all + (size_t)gridDim.x * UH_N, tot) : 0;
+        s_woff = tot <= P.wcap ? atomicAdd(wcount, tot) : -1;
+        if (s_woff >= 0 && (long long)s_woff + tot > (long long)P.wtotal) s_woff = -1;
     }
     __syncthreads();
     const int32_t n = s_n, total = n + (have_sil ? 1 : 0) + 1;
-    int32_t *words = words_all + (size_t)s_woff * 6;
+    int32_t *words = words_all + (size_t)max(s_woff, 0) * 6;
     int32_t last_ef = w.ef[bestvh], last_score = w.score[bestvh];
     int32_t sil_lscr = 0;
     if (have_sil) {
@@ -1314,8 +1356,8 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
         best = add32(sil_score, wl_tg_score(lm, w.lw1[bestvh], w.lw0[bestvh], P.finish_lwid, P.finishwid));
         last_ef = n_frm - 1; last_score = sil_score;
     }
-    if (tid == 0) { hdr[UH_NWORDS] = total; hdr[UH_SCORE] = best; hdr[UH_EXIT] = n_entry + (have_sil ? 1 : 0); hdr[UH_WOFF] = s_woff; }
-    if (total > P.wcap) { if (tid == 0) hdr[UH_STATUS] = -3; return; }
+    if (tid == 0) { hdr[UH_NWORDS] = total; hdr[UH_SCORE] = best; hdr[UH_EXIT] = n_entry + (have_sil ? 1 : 0); hdr[UH_WOFF] = max(s_woff, 0); }
+    if (s_woff < 0) { if (tid == 0) hdr[UH_STATUS] = -3; return; }
     if (n <= UH_IDS) {
         for (int32_t q = tid; q < n; q += UH_T) {
             const int32_t i = s_ids[n - 1 - q];
@@ -1407,6 +1449,14 @@ struct s3a_uttdec_s {
     s3a_dagpass_t *dag;         /* the second pass after every decode (s3a_uttdec_enable_bestpath), or NULL */
     int32_t keep_tables;        /* 0: with the second pass enabled the history tables stay on the device */
     int32_t tables_fetched, fstat_fetched;
+    /* s3a_uttdec_decode_queue (lane refill): everything of a queue lives in buffers that only grow */
+    int32_t q_n;                /* utterances of the last decode when it was a queue (0: a plain decode) */
+    std::vector<int32_t> q_nfr; /* their frame counts */
+    float *q_feat_d, *q_feat_h; size_t q_feat_cap;      /* the queue's features, rows padded to the scorer's stride */
+    UCtx *q_ctx_d, *q_ctx_h; size_t q_ctx_cap;          /* the utterances' staged contexts */
+    int32_t *q_sched_d, *q_sched_h; size_t q_sched_cap; /* the refill events' lane / utterance lists */
+    int32_t *q_hdr_d, *q_hdr_h; size_t q_hdr_cap;       /* [n_utt][UH_N] + the word counter */
+    int32_t *q_words_d, *q_words_h; size_t q_words_cap, q_words_hcap;   /* hypothesis words, packed (6 int32 each) */
 };
 
 static int32_t
@@ -1493,6 +1543,12 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
     if (ud->dag) s3a_dagpass_free(ud->dag);
+    {
+        void *qd[] = { ud->q_feat_d, ud->q_ctx_d, ud->q_sched_d, ud->q_hdr_d, ud->q_words_d };
+        void *qh[] = { ud->q_feat_h, ud->q_ctx_h, ud->q_sched_h, ud->q_hdr_h, ud->q_words_h };
+        for (auto q : qd) if (q) (void)hipFree(q);
+        for (auto q : qh) if (q) (void)hipHostFree(q);
+    }
     if (ud->h_ctx_up) (void)hipHostFree(ud->h_ctx_up);
     if (ud->h_ctx_dn) (void)hipHostFree(ud->h_ctx_dn);
     if (ud->h_hyp_hdr) (void)hipHostFree(ud->h_hyp_hdr);
@@ -1580,7 +1636,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
     ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
-    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->h_ctx_up = NULL; ud->h_ctx_dn = NULL; ud->d_hyp_hdr = ud->h_hyp_hdr = ud->d_hyp_words = ud->h_hyp_words = NULL; ud->hyp_wcap = 0; ud->n_pset = proto->n_pset;
+    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->q_n = 0; ud->q_feat_d = ud->q_feat_h = NULL; ud->q_ctx_d = ud->q_ctx_h = NULL; ud->q_sched_d = ud->q_sched_h = NULL; ud->q_hdr_d = ud->q_hdr_h = NULL; ud->q_words_d = ud->q_words_h = NULL; ud->q_feat_cap = ud->q_ctx_cap = ud->q_sched_cap = ud->q_hdr_cap = ud->q_words_cap = ud->q_words_hcap = 0; ud->h_ctx_up = NULL; ud->h_ctx_dn = NULL; ud->d_hyp_hdr = ud->h_hyp_hdr = ud->d_hyp_words = ud->h_hyp_words = NULL; ud->hyp_wcap = 0; ud->n_pset = proto->n_pset;
     (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
@@ -1798,14 +1854,53 @@ fail:
     return NULL;
 }
 
+/* a lane whose previous utterance stopped on an error in mid-frame: everything from scratch */
+static int32_t
+lane_scrub(s3a_uttdec_t *ud, int32_t z)
+{
+    HostLane &hl = ud->lane[z];
+    int32_t rc;
+    if (!hl.dirty) return S3A_OK;
+    const WLane &w = hl.d.w;
+    const size_t hs = (size_t)w.hmask + 1;
+    if ((rc = s3a_lexsearch_reset(hl.ls)) != S3A_OK) return rc;
+    HIPCHK(hipMemsetAsync(w.hkey, 0, hs * 8, ud->stream)); HIPCHK(hipMemsetAsync(w.hbest, 0, hs * 8, ud->stream));
+    HIPCHK(hipMemsetAsync(w.hfirst, 0xff, hs * 4, ud->stream));
+    if ((rc = fill32(ud->stream, w.wfirst, INT_MAX, ud->cfg.n_word)) != S3A_OK || (rc = fill32(ud->stream, w.wbest, INT_MIN, ud->cfg.n_word)) != S3A_OK) return rc;
+    hl.dirty = 0;
+    return S3A_OK;
+}
+
+/* the context an utterance starts from: srch_TST_begin's lextree_enter calls (silence as left context into unigram tree 0
+ * and filler tree n_lextree), frame 0, the first beam */
+static int32_t
+utt_context(const s3a_uttdec_t *ud, UCtx &x, const float *d_feat, int32_t nfr, int32_t scan_epoch, int32_t f0, int32_t utt)
+{
+    const s3a_wordlevel_cfg_t &c = ud->cfg;
+    memset(&x, 0, sizeof x);
+    x.feat = d_feat;
+    x.active = 1; x.cf = 0; x.nfr = nfr; x.cur = 0; x.n_lextrans = 1; x.thresh = c.hmmbeam;
+    x.scan_epoch = scan_epoch;      /* k_dec_scan's flags are never reset: the stamps keep growing */
+    x.f0 = f0; x.utt = utt;
+    const int32_t nci = c.n_ci;
+    const int32_t *m0 = &ud->h_lcmap[((size_t)0 * (nci + 1) + c.sil_ci) * 2];
+    const int32_t *m1 = &ud->h_lcmap[((size_t)c.n_lextree * (nci + 1) + nci) * 2];
+    if (m0[1] < 0 || m1[1] < 0) { s3a_set_error("s3a_uttdec_decode: silence is not a left context of the unigram lextree"); return S3A_EINVAL; }
+    x.calls[0] = 0; x.calls[1] = 0; x.calls[2] = m0[0]; x.calls[3] = 0;
+    x.calls[4] = 0; x.calls[5] = 0; x.calls[6] = m1[0]; x.calls[7] = m0[1];
+    x.groups[0] = 0; x.groups[1] = 0; x.groups[2] = m0[1]; x.groups[3] = 0;
+    x.groups[4] = c.n_lextree; x.groups[5] = m0[1]; x.groups[6] = m0[1] + m1[1]; x.groups[7] = 1;
+    x.n_calls = 2; x.n_groups = 2; x.n_ent = m0[1] + m1[1];
+    return S3A_OK;
+}
+
 /* srch_TST_begin (srch_time_switch_tree.c:457-512) for one lane: the dummy <s> history entry, the
  * root entries with silence as left context into unigram tree 0 and filler tree n_lextree */
 static int32_t
 lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t feat_stride, bool feat_on_device)
 {
     HostLane &hl = ud->lane[z];
-    const s3a_wordlevel_cfg_t &c = ud->cfg;
-    const int32_t D4x4 = ud->S.D4 * 4, T = ud->S.T;
+    const int32_t D4x4 = ud->S.D4 * 4;
     int32_t rc;
     if (nfr <= 0 || nfr > ud->max_frames) { s3a_set_error("s3a_uttdec_decode: %d frames (1..%d)", nfr, ud->max_frames); return S3A_EINVAL; }
     /* features, rows padded to the scorer's float4 stride */
@@ -1841,16 +1936,7 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     }
     hl.nfr = nfr;
     /* lextree + scorer state as after lextree_utt_end / at srch_TST_begin */
-    if (hl.dirty) {
-        /* the previous utterance of this lane stopped on an error in mid-frame: everything from scratch */
-        const WLane &w = hl.d.w;
-        const size_t hs = (size_t)w.hmask + 1;
-        if ((rc = s3a_lexsearch_reset(hl.ls)) != S3A_OK) return rc;
-        HIPCHK(hipMemsetAsync(w.hkey, 0, hs * 8, ud->stream)); HIPCHK(hipMemsetAsync(w.hbest, 0, hs * 8, ud->stream));
-        HIPCHK(hipMemsetAsync(w.hfirst, 0xff, hs * 4, ud->stream));
-        if ((rc = fill32(ud->stream, w.wfirst, INT_MAX, c.n_word)) != S3A_OK || (rc = fill32(ud->stream, w.wbest, INT_MIN, c.n_word)) != S3A_OK) return rc;
-        hl.dirty = 0;
-    }
+    if ((rc = lane_scrub(ud, z)) != S3A_OK) return rc;
     /* (lextree_utt_end, srch_TST_begin's resets and the history table's entry 0: ku_lanes_end / ku_lanes_begin, all
      * lanes in two launches -- uttdec_decode; here only the host-side bookkeeping of the lane's objects) */
     hl.ls->cur = 0;
@@ -1858,24 +1944,9 @@ lane_begin(s3a_uttdec_t *ud, int32_t z, const float *feat, int32_t nfr, int32_t 
     hl.ls->nnxt_t.assign(hl.ls->n_tree, 0);
     hl.sc->skip_count = 0;
     UCtx &x = *hl.h_ctx;
-    memset(&x, 0, sizeof x);
-    x.feat = d_feat_use;
-    x.active = 1; x.cf = 0; x.nfr = nfr; x.cur = 0; x.n_lextrans = 1; x.thresh = c.hmmbeam;
     if (hl.epoch < 1) hl.epoch = 1;
-    x.scan_epoch = hl.epoch;      /* k_dec_scan's flags are never reset: the stamps keep growing */
+    if ((rc = utt_context(ud, x, d_feat_use, nfr, hl.epoch, 0, -1)) != S3A_OK) return rc;
     hl.epoch += nfr + 1;
-    {
-        const int32_t nci = c.n_ci;
-        const int32_t *m0 = &ud->h_lcmap[((size_t)0 * (nci + 1) + c.sil_ci) * 2];
-        const int32_t *m1 = &ud->h_lcmap[((size_t)c.n_lextree * (nci + 1) + nci) * 2];
-        if (m0[1] < 0 || m1[1] < 0) { s3a_set_error("s3a_uttdec_decode: silence is not a left context of the unigram lextree"); return S3A_EINVAL; }
-        x.calls[0] = 0; x.calls[1] = 0; x.calls[2] = m0[0]; x.calls[3] = 0;
-        x.calls[4] = 0; x.calls[5] = 0; x.calls[6] = m1[0]; x.calls[7] = m0[1];
-        x.groups[0] = 0; x.groups[1] = 0; x.groups[2] = m0[1]; x.groups[3] = 0;
-        x.groups[4] = c.n_lextree; x.groups[5] = m0[1]; x.groups[6] = m0[1] + m1[1]; x.groups[7] = 1;
-        x.n_calls = 2; x.n_groups = 2; x.n_ent = m0[1] + m1[1];
-        (void)T;
-    }
     ud->h_ctx_up[z] = x;            /* (uploaded with the other lanes': uttdec_decode) */
     return S3A_OK;
 }
@@ -2108,6 +2179,7 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
     }
     HIPCHK(hipSetDevice(ud->device));
     int32_t rc, maxT = 0;
+    ud->q_n = 0;
     double tm[6] = { 0, 0, 0, 0, 0, 0 };
     auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
     tm[0] = now();
@@ -2124,16 +2196,16 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
         B.lmc[0] = B.lmc[1] = B.lmc[2] = B.lmc[3] = 0; B.lmc[4] = -1;
         if (ud->lm->d.n_bg > 0 && c.start_lwid >= 0) { B.lmc[3] = ud->lm->ug_firstbg[c.start_lwid]; B.lmc[4] = ud->lm->ug_firstbg[c.start_lwid + 1] - B.lmc[3]; }
         B.n_pset = ud->n_pset > 0 ? ud->n_pset : 1;
-        hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * ud->S.T, n_utt), dim3(256), 0, ud->stream, ud->d_lanes, ud->S);
-        hipLaunchKernelGGL(ku_lanes_begin, dim3(32, 1, n_utt), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, B);
+        hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * ud->S.T, n_utt), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, (const int32_t *)NULL, 0);
+        hipLaunchKernelGGL(ku_lanes_begin, dim3(32, 1, n_utt), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, B, (const int32_t *)NULL, (const int32_t *)NULL, (const UCtx *)NULL);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(ud->S.ctx_all, ud->h_ctx_up, sizeof(UCtx) * n_utt, hipMemcpyHostToDevice, ud->stream));
         if (ud->S.pheurtype > 0) {
             /* the phoneme look-ahead's tables for the whole utterance: every frame's CI senone scores, every frame's phn_heur_list */
             const dim3 g((ud->S.n_ci_sen * ud->S.CP + 255) / 256, maxT, n_utt);
-            if (ud->exact) hipLaunchKernelGGL(ku_ci_ahead<true>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S);
-            else hipLaunchKernelGGL(ku_ci_ahead<false>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S);
-            hipLaunchKernelGGL(ku_phn_heur, dim3((maxT + PH_T - 1) / PH_T, 1, n_utt), dim3(PH_T), 0, ud->stream, ud->d_lanes, ud->S);
+            if (ud->exact) hipLaunchKernelGGL(ku_ci_ahead<true>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S, (const int32_t *)NULL);
+            else hipLaunchKernelGGL(ku_ci_ahead<false>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S, (const int32_t *)NULL);
+            hipLaunchKernelGGL(ku_phn_heur, dim3((maxT + PH_T - 1) / PH_T, 1, n_utt), dim3(PH_T), 0, ud->stream, ud->d_lanes, ud->S, (const int32_t *)NULL);
             HIPCHK(hipGetLastError());
         }
     }
@@ -2155,9 +2227,10 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
      * comes back: the lanes' contexts (error bits, counters), the hypothesis headers, then the words */
     if (rc == S3A_OK) {
         const s3a_wordlevel_cfg_t &c = ud->cfg;
-        const UHypPar P = { c.finish_lwid, c.finishwid, c.silwid, ud->hyp_wcap };
+        const UHypPar P = { c.finish_lwid, c.finishwid, c.silwid, ud->hyp_wcap, (int32_t)min((long long)ud->n_lanes * ud->hyp_wcap, (long long)INT_MAX) };
         if (hipMemsetAsync(ud->d_hyp_hdr + (size_t)n_utt * UH_N, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
-        hipLaunchKernelGGL(ku_hyp, dim3(n_utt), dim3(UH_T), 0, ud->stream, ud->d_lanes, ud->lm->d, ud->dict, P, ud->d_hyp_hdr, ud->d_hyp_words);
+        hipLaunchKernelGGL(ku_hyp, dim3(n_utt), dim3(UH_T), 0, ud->stream, ud->d_lanes, ud->lm->d, ud->dict, P, ud->d_hyp_hdr, ud->d_hyp_words,
+                           ud->d_hyp_hdr + (size_t)n_utt * UH_N, (const int32_t *)NULL, (const int32_t *)NULL);
         if (hipGetLastError() != hipSuccess) { s3a_set_error("s3a_uttdec_decode: ku_hyp launch failed"); rc = S3A_EHIP; }
     }
     if (rc == S3A_OK && ud->dag) rc = s3a_dagpass_enqueue(ud->dag, n_utt, ud->stream, 1);
@@ -2232,6 +2305,234 @@ extern "C" int32_t
 s3a_uttdec_decode_dev(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev, const int32_t *n_frames, int32_t feat_stride)
 {
     return uttdec_decode(ud, n_utt, feat_dev, n_frames, feat_stride, true);
+}
+
+/* ------------------------------------------------------------------ */
+/* a QUEUE of utterances: lanes are refilled                           */
+/* ------------------------------------------------------------------ */
+/*
+ * s3a_uttdec_decode decodes at most n_lanes utterances and the lanes of a call finish with the longest of them.  Here
+ * the engine takes ANY number of utterances (ctl_process, libcommon/corpus.c:538, knows no coupling between them either):
+ * the first n_lanes start at frame 0, and a lane whose utterance has ended takes the next one of the queue at the next
+ * window boundary (with look-ahead scoring a lane's frames are scored K at a time, so utterances begin at multiples of K;
+ * without it: at the next frame) -- every utterance's length is known before the first launch, so the whole schedule is
+ * made on the host up front and, as in a plain decode, the host only enqueues: per frame the usual launches (a lane's own
+ * frame is fg - ctx->f0), per refill event the finished lanes' hypotheses (ku_hyp into the UTTERANCE's header slot),
+ * lextree_utt_end (ku_lanes_end; a lane whose utterance stopped on an error is scrubbed on the device), and
+ * srch_TST_begin + the staged context of the utterance the lane takes (ku_lanes_begin).  What comes back: a header +
+ * words per utterance (s3a_uttdec_queue_hyp); the history tables are reused by the lanes' next utterances and are not
+ * available (no s3a_uttdec_result, no second pass).
+ */
+template <typename TP>
+static int32_t
+q_grow(TP **d, TP **h, size_t *cap, size_t need, const char *what)
+{
+    if (need <= *cap) return S3A_OK;
+    const size_t grow = need + need / 4 + 64;
+    if (*d) (void)hipFree(*d);
+    if (h && *h) (void)hipHostFree(*h);
+    *d = NULL; if (h) *h = NULL; *cap = 0;
+    if (hipMalloc((void **)d, grow * sizeof(TP)) != hipSuccess || (h && hipHostMalloc((void **)h, grow * sizeof(TP)) != hipSuccess)) {
+        s3a_set_error("s3a_uttdec_decode_queue: out of memory (%s, %zu bytes)", what, grow * sizeof(TP));
+        return S3A_ENOMEM;
+    }
+    *cap = grow;
+    return S3A_OK;
+}
+
+static int32_t
+uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const int32_t *n_frames, int32_t feat_stride,
+                    bool feat_on_device)
+{
+    if (!ud || n_utt <= 0 || !feat || !n_frames || feat_stride < ud->veclen) {
+        s3a_set_error("s3a_uttdec_decode_queue: bad arguments (%d utterances)", n_utt);
+        return S3A_EINVAL;
+    }
+    if (ud->dag) { s3a_set_error("s3a_uttdec_decode_queue: the second pass needs a lane's history table after its utterance; decode without lane refill"); return S3A_EUNSUP; }
+    HIPCHK(hipSetDevice(ud->device));
+    const UShared &S = ud->S;
+    const int32_t n = min(ud->n_lanes, n_utt), E = S.win_K > 0 ? S.win_K : 1, D4x4 = S.D4 * 4, T = S.T;
+    int32_t rc;
+    ud->n_utt = 0; ud->q_n = 0;
+    std::vector<size_t> row0((size_t)n_utt + 1, 0);
+    for (int32_t u = 0; u < n_utt; u++) {
+        if (n_frames[u] <= 0 || n_frames[u] > ud->max_frames) { s3a_set_error("s3a_uttdec_decode_queue: utterance %d has %d frames (1..%d)", u, n_frames[u], ud->max_frames); return S3A_EINVAL; }
+        if (!feat[u]) { s3a_set_error("s3a_uttdec_decode_queue: utterance %d has no features", u); return S3A_EINVAL; }
+        row0[u + 1] = row0[u] + (size_t)n_frames[u];
+    }
+    /* features: one buffer, rows padded to the scorer's float4 stride, one copy */
+    std::vector<const float *> fd((size_t)n_utt);
+    if (!feat_on_device) {
+        if ((rc = q_grow(&ud->q_feat_d, &ud->q_feat_h, &ud->q_feat_cap, row0[n_utt] * D4x4, "features")) != S3A_OK) return rc;
+        for (int32_t u = 0; u < n_utt; u++) {
+            for (int32_t t = 0; t < n_frames[u]; t++) {
+                float *row = ud->q_feat_h + (row0[u] + t) * D4x4;
+                memcpy(row, feat[u] + (size_t)t * feat_stride, sizeof(float) * ud->veclen);
+                for (int32_t k = ud->veclen; k < D4x4; k++) row[k] = 0.0f;
+            }
+            fd[u] = ud->q_feat_d + row0[u] * D4x4;
+        }
+        HIPCHK(hipMemcpyAsync(ud->q_feat_d, ud->q_feat_h, row0[n_utt] * D4x4 * 4, hipMemcpyHostToDevice, ud->stream));
+    }
+    else {
+        if (feat_stride != D4x4) { s3a_set_error("s3a_uttdec_decode_queue_dev: device features must have rows of %d floats (zero padded)", D4x4); return S3A_EINVAL; }
+        for (int32_t u = 0; u < n_utt; u++) fd[u] = feat[u];
+    }
+    for (int32_t z = 0; z < n; z++) {
+        if ((rc = lane_scrub(ud, z)) != S3A_OK) return rc;
+        HostLane &hl = ud->lane[z];
+        hl.ls->cur = 0; hl.ls->last_nnxt = 0; hl.ls->hist_bound = 0; hl.ls->row_bound = 1;
+        hl.ls->nnxt_t.assign(hl.ls->n_tree, 0);
+        hl.sc->skip_count = 0;
+        if (hl.epoch < 1) hl.epoch = 1;
+    }
+    /* the schedule: who ends and who begins at which boundary */
+    struct Ev { int32_t f, o_el, o_bl, n_end, n_beg, max_nfr; };
+    std::vector<Ev> evs;
+    std::vector<int32_t> sched, lane_utt((size_t)n, -1), lane_end((size_t)n, 0), last_utt((size_t)n, -1);
+    if ((rc = q_grow(&ud->q_ctx_d, &ud->q_ctx_h, &ud->q_ctx_cap, (size_t)n_utt, "contexts")) != S3A_OK) return rc;
+    int32_t next = 0;
+    for (int32_t F = 0;; F += E) {
+        std::vector<int32_t> el, eu, bl, bu;
+        int32_t mx = 0;
+        for (int32_t z = 0; z < n; z++)
+            if (lane_utt[z] >= 0 && lane_end[z] <= F) { el.push_back(z); eu.push_back(lane_utt[z]); lane_utt[z] = -1; }
+        for (int32_t z = 0; z < n && next < n_utt; z++)
+            if (lane_utt[z] < 0) {
+                const int32_t u = next++;
+                HostLane &hl = ud->lane[z];
+                if ((rc = utt_context(ud, ud->q_ctx_h[u], fd[u], n_frames[u], hl.epoch, F, u)) != S3A_OK) return rc;
+                hl.epoch += n_frames[u] + 1;
+                hl.nfr = n_frames[u];
+                bl.push_back(z); bu.push_back(u); lane_utt[z] = u; lane_end[z] = F + n_frames[u]; last_utt[z] = u;
+                mx = max(mx, n_frames[u]);
+            }
+        if (!el.empty() || !bl.empty()) {
+            Ev e = { F, (int32_t)sched.size(), 0, (int32_t)el.size(), (int32_t)bl.size(), mx };
+            sched.insert(sched.end(), el.begin(), el.end()); sched.insert(sched.end(), eu.begin(), eu.end());
+            e.o_bl = (int32_t)sched.size();
+            sched.insert(sched.end(), bl.begin(), bl.end()); sched.insert(sched.end(), bu.begin(), bu.end());
+            evs.push_back(e);
+        }
+        bool busy = false;
+        for (int32_t z = 0; z < n; z++) busy = busy || lane_utt[z] >= 0;
+        if (!busy) break;
+    }
+    const int32_t F_end = evs.back().f;           /* (the last event only ends lanes) */
+    if ((rc = q_grow(&ud->q_sched_d, &ud->q_sched_h, &ud->q_sched_cap, sched.size(), "schedule")) != S3A_OK) return rc;
+    memcpy(ud->q_sched_h, sched.data(), sched.size() * 4);
+    HIPCHK(hipMemcpyAsync(ud->q_sched_d, ud->q_sched_h, sched.size() * 4, hipMemcpyHostToDevice, ud->stream));
+    HIPCHK(hipMemcpyAsync(ud->q_ctx_d, ud->q_ctx_h, sizeof(UCtx) * n_utt, hipMemcpyHostToDevice, ud->stream));
+    /* results: a header per utterance + the word counter; the words packed (an utterance's hypothesis has at most one word
+     * per frame + silence + </s>) */
+    const size_t wtotal = min(row0[n_utt] + (size_t)4 * n_utt, (size_t)INT_MAX / 8);
+    if ((rc = q_grow(&ud->q_hdr_d, &ud->q_hdr_h, &ud->q_hdr_cap, (size_t)n_utt * UH_N + 1, "hypothesis headers")) != S3A_OK) return rc;
+    if ((rc = q_grow(&ud->q_words_d, (int32_t **)NULL, &ud->q_words_cap, wtotal * 6, "hypothesis words")) != S3A_OK) return rc;
+    HIPCHK(hipMemsetAsync(ud->q_hdr_d, 0, ((size_t)n_utt * UH_N + 1) * 4, ud->stream));
+    int32_t *wcount = ud->q_hdr_d + (size_t)n_utt * UH_N;
+    const s3a_wordlevel_cfg_t &c = ud->cfg;
+    UBegin B;
+    {
+        const int32_t e0[10] = { 0 /*score*/, -1 /*pred*/, c.start_lwid, -1 /*lw1*/, c.startwid, -1 /*sf*/, -1 /*ef*/, 0, 0, 0 };
+        memcpy(B.e0, e0, sizeof e0);
+        B.lmc[0] = B.lmc[1] = B.lmc[2] = B.lmc[3] = 0; B.lmc[4] = -1;
+        if (ud->lm->d.n_bg > 0 && c.start_lwid >= 0) { B.lmc[3] = ud->lm->ug_firstbg[c.start_lwid]; B.lmc[4] = ud->lm->ug_firstbg[c.start_lwid + 1] - B.lmc[3]; }
+        B.n_pset = ud->n_pset > 0 ? ud->n_pset : 1;
+    }
+    const UHypPar P = { c.finish_lwid, c.finishwid, c.silwid, ud->hyp_wcap, (int32_t)wtotal };
+    /* whatever the engine's last decode left active (it ends its lanes at the NEXT decode's beginning) */
+    hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * T, n), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, (const int32_t *)NULL, 0);
+    HIPCHK(hipGetLastError());
+    auto run_event = [&](const Ev &e) -> int32_t {
+        const int32_t *el = ud->q_sched_d + e.o_el, *eu = el + e.n_end, *bl = ud->q_sched_d + e.o_bl, *bu = bl + e.n_beg;
+        if (e.n_end > 0) {
+            hipLaunchKernelGGL(ku_hyp, dim3(e.n_end), dim3(UH_T), 0, ud->stream, ud->d_lanes, ud->lm->d, ud->dict, P, ud->q_hdr_d, ud->q_words_d, wcount, el, eu);
+            hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * T, e.n_end), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, el, c.n_word);
+        }
+        if (e.n_beg > 0) {
+            hipLaunchKernelGGL(ku_lanes_begin, dim3(32, 1, e.n_beg), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, B, bl, bu, (const UCtx *)ud->q_ctx_d);
+            if (S.pheurtype > 0) {
+                const dim3 g((S.n_ci_sen * S.CP + 255) / 256, e.max_nfr, e.n_beg);
+                if (ud->exact) hipLaunchKernelGGL(ku_ci_ahead<true>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S, bl);
+                else hipLaunchKernelGGL(ku_ci_ahead<false>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S, bl);
+                hipLaunchKernelGGL(ku_phn_heur, dim3((e.max_nfr + PH_T - 1) / PH_T, 1, e.n_beg), dim3(PH_T), 0, ud->stream, ud->d_lanes, ud->S, bl);
+            }
+        }
+        HIPCHK(hipGetLastError());
+        return S3A_OK;
+    };
+    if (!ud->ev0 && (hipEventCreate(&ud->ev0) != hipSuccess || hipEventCreate(&ud->ev1) != hipSuccess)) {
+        s3a_set_error("s3a_uttdec_decode_queue: hipEventCreate failed");
+        return S3A_EHIP;
+    }
+    rc = S3A_OK;
+    if (hipEventRecord(ud->ev0, ud->stream) != hipSuccess) rc = S3A_EHIP;
+    size_t ei = 0;
+    for (int32_t fg = 0; fg < F_end && rc == S3A_OK; fg++) {
+        if (ei < evs.size() && evs[ei].f == fg) rc = run_event(evs[ei++]);
+        if (rc == S3A_OK) rc = enqueue_frame(ud, n, fg, ud->prof_every > 0 && fg % ud->prof_every == 0);
+    }
+    while (rc == S3A_OK && ei < evs.size()) rc = run_event(evs[ei++]);
+    if (rc == S3A_OK && hipEventRecord(ud->ev1, ud->stream) != hipSuccess) rc = S3A_EHIP;
+    if (rc == S3A_OK && hipMemcpyAsync(ud->q_hdr_h, ud->q_hdr_d, ((size_t)n_utt * UH_N + 1) * 4, hipMemcpyDeviceToHost, ud->stream) != hipSuccess) rc = S3A_EHIP;
+    if (hipStreamSynchronize(ud->stream) != hipSuccess && rc == S3A_OK) { s3a_set_error("s3a_uttdec_decode_queue: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
+    if (rc == S3A_OK) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, ud->ev0, ud->ev1);
+        ud->last_decode_ms = ms;
+    }
+    for (auto &e : ud->prof_ev) {
+        float ms = 0.0f;
+        if (rc == S3A_OK && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ud->prof_us[e.cls] += 1e3 * ms; ud->prof_n[e.cls]++; }
+        (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    }
+    ud->prof_ev.clear();
+    if (rc != S3A_OK) {
+        for (int32_t z = 0; z < n; z++) ud->lane[z].dirty = 1;      /* nothing is known about the lanes' state */
+        return rc;
+    }
+    {
+        const size_t total_words = (size_t)ud->q_hdr_h[(size_t)n_utt * UH_N];
+        if (total_words * 6 > ud->q_words_hcap) {
+            if (ud->q_words_h) (void)hipHostFree(ud->q_words_h);
+            ud->q_words_h = NULL; ud->q_words_hcap = 0;
+            const size_t grow = total_words * 6 + total_words + 1024;
+            if (hipHostMalloc((void **)&ud->q_words_h, grow * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode_queue: pinned word buffer"); return S3A_ENOMEM; }
+            ud->q_words_hcap = grow;
+        }
+        if (total_words > 0) HIPCHK(hipMemcpy(ud->q_words_h, ud->q_words_d, total_words * 24, hipMemcpyDeviceToHost));
+    }
+    ud->q_n = n_utt;
+    ud->q_nfr.assign(n_frames, n_frames + n_utt);
+    /* a lane whose LAST utterance stopped in mid-frame starts the next decode from scratch (the others of its utterances
+     * that stopped were scrubbed on the device when the lane took its next one) */
+    for (int32_t z = 0; z < n; z++)
+        if (last_utt[z] >= 0 && ud->q_hdr_h[(size_t)last_utt[z] * UH_N + UH_ERR]) ud->lane[z].dirty = 1;
+    for (int32_t u = 0; u < n_utt; u++) {
+        const int32_t *h = ud->q_hdr_h + (size_t)u * UH_N;
+        const int32_t e = h[UH_ERR];
+        if (e) {
+            s3a_set_error("s3a_uttdec_decode_queue: utterance %d stopped at frame %d: error bits 0x%x%s%s%s%s%s%s", u, h[UH_CF], e,
+                          (e & WL_E_OPEN_EXIT) ? " (out.history == -1 at a word exit)" : "",
+                          (e & WL_E_EXITS) ? " (too many word exits)" : "", (e & WL_E_CAND) ? " (candidate buffer full)" : "",
+                          (e & WL_E_TABLE) ? " (history table full)" : "", (e & WL_E_LC) ? " (phone is no left context)" : "",
+                          (e & WL_E_NOLM) ? " (word without LM id)" : "");
+            return (e & (WL_E_EXITS | WL_E_CAND | WL_E_TABLE | WL_E_CALLS)) ? S3A_ENOMEM : S3A_EINVAL;
+        }
+    }
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const int32_t *n_frames, int32_t feat_stride)
+{
+    return uttdec_decode_queue(ud, n_utt, feat, n_frames, feat_stride, false);
+}
+
+extern "C" int32_t
+s3a_uttdec_decode_queue_dev(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev, const int32_t *n_frames, int32_t feat_stride)
+{
+    return uttdec_decode_queue(ud, n_utt, feat_dev, n_frames, feat_stride, true);
 }
 
 /* the first s3a_uttdec_result (or second-pass hypothesis) after a decode brings the per-frame statistics -- and the
@@ -2421,7 +2722,7 @@ s3a_uttdec_selfcheck(s3a_uttdec_t *ud, int32_t lane, int32_t *out8)
     int32_t *d = NULL, init[8] = { 0, 0, 0, 0, 0, 0, INT_MAX, 0 };
     HIPCHK(hipMalloc((void **)&d, sizeof init));
     HIPCHK(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, ud->stream));
-    hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * ud->S.T, ud->n_lanes), dim3(256), 0, ud->stream, ud->d_lanes, ud->S);
+    hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * ud->S.T, ud->n_lanes), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, (const int32_t *)NULL, 0);
     hipLaunchKernelGGL(ku_selfcheck, dim3(64), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, lane, d);
     HIPCHK(hipMemcpyAsync(out8, d, sizeof init, hipMemcpyDeviceToHost, ud->stream));
     HIPCHK(hipStreamSynchronize(ud->stream));
@@ -2611,25 +2912,53 @@ s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int32_t *ou
  * Status 0 ok, -1 the decode stopped with an error, -2 no word exit at all (vithist_utt_end returns -1), -3 more words
  * than the caller has room for (n_words = what it takes). */
 static int32_t
-uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index, s3a_hyp_header_t *rec,
-           s3a_hyp_word_t *words, int32_t max_words)
+hyp_from_header(const int32_t *h, const int32_t *words_base, int32_t nfr, int32_t which, const char *uttid, int32_t utt_index,
+                s3a_hyp_header_t *rec, s3a_hyp_word_t *words, int32_t max_words)
 {
-    if (!ud || !rec || lane < 0 || lane >= ud->n_utt || max_words < 0 || (max_words > 0 && !words)) return S3A_EINVAL;
-    const HostLane &hl = ud->lane[lane];
-    const int32_t *h = ud->h_hyp_hdr + (size_t)lane * UH_N;
     memset(rec, 0, sizeof *rec);
     if (uttid) strncpy(rec->uttid, uttid, sizeof rec->uttid - 1);
-    rec->utt_index = utt_index; rec->n_frames = hl.nfr; rec->n_entry = h[UH_NENTRY]; rec->status = h[UH_STATUS];
+    rec->utt_index = utt_index; rec->n_frames = nfr; rec->n_entry = h[UH_NENTRY]; rec->status = h[UH_STATUS];
     rec->total_scale = h[UH_TSCALE];
     if (h[UH_STATUS] == -3) {
-        s3a_set_error("s3a_uttdec_hyp: lane %d: a hypothesis of %d words in an utterance of %d frames", lane, h[UH_NWORDS], hl.nfr);
+        s3a_set_error("s3a_uttdec_hyp: utterance %d: a hypothesis of %d words in an utterance of %d frames", which, h[UH_NWORDS], nfr);
         return S3A_EINVAL;
     }
     if (rec->status != 0) return S3A_OK;
     rec->n_words = h[UH_NWORDS]; rec->score = h[UH_SCORE]; rec->exit_id = h[UH_EXIT];
     if (rec->n_words > max_words) { rec->status = -3; return S3A_OK; }
     static_assert(sizeof(s3a_hyp_word_t) == 24, "s3a_hyp_word_t is six int32");
-    memcpy(words, ud->h_hyp_words + (size_t)h[UH_WOFF] * 6, (size_t)rec->n_words * sizeof(s3a_hyp_word_t));
+    memcpy(words, words_base + (size_t)h[UH_WOFF] * 6, (size_t)rec->n_words * sizeof(s3a_hyp_word_t));
+    return S3A_OK;
+}
+
+static int32_t
+uttdec_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index, s3a_hyp_header_t *rec,
+           s3a_hyp_word_t *words, int32_t max_words)
+{
+    if (!ud || !rec || lane < 0 || lane >= ud->n_utt || max_words < 0 || (max_words > 0 && !words)) return S3A_EINVAL;
+    return hyp_from_header(ud->h_hyp_hdr + (size_t)lane * UH_N, ud->h_hyp_words, ud->lane[lane].nfr, lane, uttid, utt_index, rec, words, max_words);
+}
+
+/* after s3a_uttdec_decode_queue: the hypothesis of utterance `utt` of the queue (as s3a_uttdec_hyp_var for a lane) */
+extern "C" int32_t
+s3a_uttdec_queue_hyp(s3a_uttdec_t *ud, int32_t utt, const char *uttid, int32_t utt_index, s3a_hyp_header_t *hdr,
+                     s3a_hyp_word_t *words, int32_t max_words)
+{
+    if (!ud || !hdr || utt < 0 || utt >= ud->q_n || max_words < 0 || (max_words > 0 && !words)) return S3A_EINVAL;
+    return hyp_from_header(ud->q_hdr_h + (size_t)utt * UH_N, ud->q_words_h, ud->q_nfr[utt], utt, uttid, utt_index, hdr, words, max_words);
+}
+
+/* ... and what stopped it, if anything: the word level's error bits (0: decoded), the frame it stopped at, the largest
+ * candidate / new-entry counts of a frame (capacity planning) */
+extern "C" int32_t
+s3a_uttdec_queue_status(s3a_uttdec_t *ud, int32_t utt, int32_t *err, int32_t *stopped_at, int32_t *max_cand, int32_t *max_new)
+{
+    if (!ud || utt < 0 || utt >= ud->q_n) return S3A_EINVAL;
+    const int32_t *h = ud->q_hdr_h + (size_t)utt * UH_N;
+    if (err) *err = h[UH_ERR];
+    if (stopped_at) *stopped_at = h[UH_CF];
+    if (max_cand) *max_cand = h[UH_MAXCAND];
+    if (max_new) *max_new = h[UH_MAXNEW];
     return S3A_OK;
 }
 

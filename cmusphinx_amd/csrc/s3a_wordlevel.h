@@ -77,7 +77,9 @@ struct WPar {
 struct UCtx {
     const float *feat;      /* this utterance's features [nfr][D4 * 4] */
     int32_t active, cf, nfr, cur, n_lextrans, err, thresh, n_calls, n_ent, n_groups, scan_epoch, n_tie_frames;
-    int32_t max_cand, max_new, pad0, pad1;
+    int32_t max_cand, max_new;
+    int32_t f0;             /* the engine's frame counter at this utterance's first frame (lane refill: s3a_uttdec_decode_queue) */
+    int32_t utt;            /* the utterance's place in the queue (-1: a plain decode) */
     int32_t groups[8];
     int32_t calls[4 * WL_MAXCALL];
     long long tacc[16];     /* time spent per word-level phase (100 MHz ticks; tools/wl_phases) */

@@ -190,6 +190,10 @@ _SIGS = {
     "s3a_uttdec_free": (None, [C.c_void_p]),
     "s3a_uttdec_decode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_decode_dev": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_uttdec_decode_queue": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_uttdec_decode_queue_dev": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_uttdec_queue_status": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3a_uttdec_queue_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_wl_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
@@ -1413,6 +1417,38 @@ class UttDec:
         n = np.ascontiguousarray(nfr, np.int32)
         check(self.L.s3a_uttdec_decode_dev(self.h, len(bufs), ptrs, _p(n), int(stride)), self.L)
         return float(self.L.s3a_uttdec_last_decode_ms(self.h))
+
+    def decode_queue(self, feats):
+        """feats: ANY number of float32 [nfr, veclen] arrays; a lane takes the queue's next utterance when its own has
+        ended (s3a_uttdec_decode_queue).  Raises for the first utterance that stopped; the others' results stand."""
+        feats = [np.ascontiguousarray(f, np.float32) for f in feats]
+        ptrs = (C.c_void_p * len(feats))(*[f.ctypes.data for f in feats])
+        nfr = np.array([len(f) for f in feats], np.int32)
+        check(self.L.s3a_uttdec_decode_queue(self.h, len(feats), ptrs, _p(nfr), feats[0].shape[1]), self.L)
+        return float(self.L.s3a_uttdec_last_decode_ms(self.h))
+
+    def decode_queue_dev(self, bufs, nfr, stride):
+        """the same with the features resident in HBM (bufs: DevBuf objects or raw device addresses)"""
+        ptrs = (C.c_void_p * len(bufs))(*[getattr(b, "ptr", b) for b in bufs])
+        n = np.ascontiguousarray(nfr, np.int32)
+        check(self.L.s3a_uttdec_decode_queue_dev(self.h, len(bufs), ptrs, _p(n), int(stride)), self.L)
+        return float(self.L.s3a_uttdec_last_decode_ms(self.h))
+
+    def queue_status(self, utt):
+        """-> dict(err, stopped_at, max_cand, max_new) of utterance `utt` of the last queue"""
+        v = [C.c_int32() for _ in range(4)]
+        check(self.L.s3a_uttdec_queue_status(self.h, int(utt), *[C.byref(x) for x in v]), self.L)
+        return dict(zip(("err", "stopped_at", "max_cand", "max_new"), (x.value for x in v)))
+
+    def queue_hyp(self, utt, uttid="", utt_index=0):
+        """-> (HypHeader, words int32 [n_words, 6]) of utterance `utt` of the last queue"""
+        hdr = HypHeader()
+        words = np.zeros((HYP_MAXW, 6), np.int32)
+        check(self.L.s3a_uttdec_queue_hyp(self.h, int(utt), uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
+        if hdr.status == -3:
+            words = np.zeros((hdr.n_words, 6), np.int32)
+            check(self.L.s3a_uttdec_queue_hyp(self.h, int(utt), uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
+        return hdr, words[:hdr.n_words if hdr.status == 0 else 0].copy()
 
     def result(self, lane):
         r = UttResult()

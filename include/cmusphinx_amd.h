@@ -715,6 +715,22 @@ int32_t s3a_uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *f
 int32_t s3a_uttdec_decode_dev(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev,
                               const int32_t *n_frames, int32_t feat_stride);
 int32_t s3a_uttdec_result(s3a_uttdec_t *ud, int32_t lane, s3a_utt_result_t *out);
+/* A QUEUE of utterances with lane refill -- what ctl_process (libcommon/corpus.c:538-640) is to the reference: any
+ * number of utterances, no coupling between them.  The first n_lanes start together; a lane whose utterance has ended
+ * (srch_utt_end, srch.c:482-560) takes the queue's next one (srch_utt_begin, srch.c:453-479: every per-utterance state
+ * reset) at the next boundary of the look-ahead scoring window (at the next frame without it) while the other lanes go
+ * on.  The lengths are known up front, so the host makes the whole schedule before the first launch and only enqueues;
+ * an utterance that stops on an error (a capacity of its lane) is reported, its lane is scrubbed on the device and takes
+ * the next utterance.  Results per UTTERANCE of the queue (its index in feat[]): s3a_uttdec_queue_hyp (header + words, as
+ * s3a_uttdec_hyp_var), s3a_uttdec_queue_status.  The history tables are reused by the lanes' next utterances:
+ * s3a_uttdec_result and the second pass (s3a_uttdec_enable_bestpath: refused) need s3a_uttdec_decode.  Returns the first
+ * stopped utterance's error (the others' results are complete). */
+int32_t s3a_uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat,
+                                const int32_t *n_frames, int32_t feat_stride);
+int32_t s3a_uttdec_decode_queue_dev(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev,
+                                    const int32_t *n_frames, int32_t feat_stride);
+int32_t s3a_uttdec_queue_status(s3a_uttdec_t *ud, int32_t utt, int32_t *err, int32_t *stopped_at,
+                                int32_t *max_cand, int32_t *max_new);
 /* diagnostics: time lane z's last utterance spent in each phase of the one-workgroup word level, in 100 MHz ticks
  * ([0] frame record + exits, [1] P1, [2] P2 trigram scores, [3] P3 hash insert, [4] P4 entry places, [5] P5 staging,
  * [6] pruning, [7] table + LM contexts, [8] word transitions) */
@@ -774,6 +790,8 @@ typedef struct {
 } s3a_hyp_header_t;
 int32_t s3a_uttdec_hyp_var(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index,
                            s3a_hyp_header_t *hdr, s3a_hyp_word_t *words, int32_t max_words);
+int32_t s3a_uttdec_queue_hyp(s3a_uttdec_t *ud, int32_t utt, const char *uttid, int32_t utt_index,
+                             s3a_hyp_header_t *hdr, s3a_hyp_word_t *words, int32_t max_words);
 int32_t s3a_hyp_format_var(const s3a_hyp_header_t *hdr, const s3a_hyp_word_t *words, const char *const *wordstr,
                            const int32_t *basewid, const uint8_t *is_filler, int32_t startwid, int32_t finishwid,
                            float lw, int32_t wip, int32_t unscale, char *match_line, size_t match_cap,

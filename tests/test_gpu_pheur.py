@@ -94,6 +94,12 @@ def test_phoneme_lookahead_from_a_bundle(task3, gpu_lib):
             hyp += h
             seg += s
     assert hyp == open(d + "/refb.hyp").read() and seg == open(d + "/refb.hypseg").read()
+    # the same through a queue with lane refill: 8 utterances in 3 lanes (the look-ahead tables are made when a lane
+    # takes its utterance)
+    dec3 = bundle.Decoder(bp, 3)
+    dec3.decode_queue(feats)
+    out = [dec3.format_var(*dec3.queue_hyp(k, utts[k], k)) for k in range(8)]
+    assert "".join(o[0] for o in out) == hyp and "".join(o[1] for o in out) == seg
 
 
 def test_lookahead_with_a_wide_phone_beam_is_refused(task3):

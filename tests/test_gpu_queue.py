@@ -1,0 +1,113 @@
+"""Lane refill (s3a_uttdec_decode_queue) on the MI355X: a queue of ANY number of utterances, a lane takes the next one when
+its own has ended -- ctl_process (libcommon/corpus.c:538) knows no coupling between utterances either.  The ragged tidigits
+set (31 utterances, 105 .. 476 frames) through engines of 1 .. 40 lanes: every utterance's -hyp / -hypseg line is the
+unmodified reference's, whichever lane decoded it, whenever it started, whatever ran in that lane before (including an
+utterance that stopped on a capacity error: the lane is scrubbed on the device)."""
+import os
+
+import numpy as np
+import pytest
+
+from cmusphinx_amd import s3io
+from conftest import GOLDEN
+from test_gpu_uttdec import D, ctl_entries, tidigits_bundle  # noqa: F401  (fixture)
+from cmusphinx_amd import bundle
+
+pytestmark = pytest.mark.gpu
+
+
+def tidigits_feats(gpu_lib):
+    utts = list(ctl_entries())
+    feats = [gpu_lib.feat_1s_c_d_dd(s3io.read_mfc(f"{D}/cepstra/{u}.mfc").reshape(-1, 13), cmn="current") for u, _ in utts]
+    return utts, feats
+
+
+def ref_lines():
+    return (open(f"{D}/ref_mode4_trigram.match").read().splitlines(keepends=True),
+            open(f"{D}/ref_mode4_trigram.matchseg").read().splitlines(keepends=True))
+
+
+def queue_lines(dec, utts, order=None):
+    order = list(range(len(utts))) if order is None else order
+    m, s = {}, {}
+    for q, k in enumerate(order):
+        hdr, words = dec.queue_hyp(q, utts[k][1], k)
+        assert hdr.status == 0, (k, hdr.status)
+        m[k], s[k] = dec.format_var(hdr, words)
+    return [m[k] for k in range(len(utts))], [s[k] for k in range(len(utts))]
+
+
+@pytest.mark.parametrize("n_lanes,window", [(1, None), (3, None), (8, None), (40, None), (3, 0), (5, 16)])
+def test_ragged_queue_matches_the_reference(gpu_lib, tidigits_bundle, monkeypatch, n_lanes, window):
+    """more utterances than lanes (and, at 40, fewer); look-ahead windows of 8 .. 64 frames and per-frame scoring"""
+    if window is not None:
+        monkeypatch.setenv("S3A_UTT_WIN", str(window))
+    dec = bundle.Decoder(tidigits_bundle, n_lanes)
+    utts, feats = tidigits_feats(gpu_lib)
+    assert len(utts) == 31 and len({len(f) for f in feats}) > 20          # ragged
+    dec.decode_queue(feats)
+    m, s = queue_lines(dec, utts)
+    rm, rs = ref_lines()
+    assert m == rm
+    assert s == rs
+    assert dec.queue_hyp(0, "x", 0)[0].n_frames == len(feats[0])
+
+
+def test_queue_order_and_reuse_of_an_engine(gpu_lib, tidigits_bundle):
+    """longest first (what a caller does to keep the lanes busy to the end), then a plain decode, then the queue again:
+    the engine goes from one mode to the other without a trace"""
+    dec = bundle.Decoder(tidigits_bundle, 4)
+    utts, feats = tidigits_feats(gpu_lib)
+    rm, rs = ref_lines()
+    order = sorted(range(len(feats)), key=lambda k: -len(feats[k]))
+    dec.decode_queue([feats[k] for k in order])
+    m, s = queue_lines(dec, utts, order)
+    assert m == rm and s == rs
+    dec.decode(feats[:4])
+    for z in range(4):
+        assert dec.format_var(*dec.hyp_var(z, utts[z][1], z)) == (rm[z], rs[z])
+    with pytest.raises(gpu_lib.S3AError):
+        dec.queue_hyp(0)                          # the last decode was no queue
+    dec.decode_queue(feats[::-1])
+    m, s = queue_lines(dec, utts, list(range(len(feats)))[::-1])
+    assert m == rm and s == rs
+    with pytest.raises(gpu_lib.S3AError):
+        dec.hyp_var(0)                            # ... and now it was one: no lane results
+
+
+def test_a_lane_whose_utterance_overflowed_is_scrubbed_on_the_device(gpu_lib, tidigits_bundle):
+    """A history table far too small: the long utterances stop in mid-frame (WL_E_TABLE), the 12-frame ones between them
+    fit.  Every lane alternates between the two; the short ones must come out as from an engine that never failed."""
+    utts, feats = tidigits_feats(gpu_lib)
+    short = [f[:12].copy() for f in feats[:6]]
+    queue = []
+    for k in range(6):
+        queue += [feats[k], short[k]]
+    small = bundle.Decoder(tidigits_bundle, 2, vh_cap=64)
+    with pytest.raises(gpu_lib.S3AError, match="history table full"):
+        small.decode_queue(queue)
+    st = [small.ud.queue_status(q) for q in range(len(queue))]
+    assert all(st[2 * k]["err"] != 0 for k in range(6)), st         # every long one stopped
+    assert all(st[2 * k + 1]["err"] == 0 for k in range(6)), st
+    good = bundle.Decoder(tidigits_bundle, 2)
+    good.decode_queue(short)
+    for k in range(6):
+        a = small.queue_hyp(2 * k + 1, f"s{k}", k)
+        b = good.queue_hyp(k, f"s{k}", k)
+        assert bytes(a[0]) == bytes(b[0]) and np.array_equal(a[1], b[1])
+        assert small.queue_hyp(2 * k)[0].status == -1
+    # the engine's lanes were left dirty or clean as their LAST utterance left them: the next queue is decoded right
+    small.decode_queue(short)
+    for k in range(6):
+        a, b = small.queue_hyp(k, f"s{k}", k), good.queue_hyp(k, f"s{k}", k)
+        assert bytes(a[0]) == bytes(b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_queue_refuses_what_it_cannot_serve(gpu_lib, tidigits_bundle):
+    dec = bundle.Decoder(tidigits_bundle, 2, bestpath=True)
+    utts, feats = tidigits_feats(gpu_lib)
+    with pytest.raises(gpu_lib.S3AError, match="second pass"):
+        dec.decode_queue(feats[:3])
+    dec = bundle.Decoder(tidigits_bundle, 2)
+    with pytest.raises(gpu_lib.S3AError):
+        dec.decode_queue([feats[0], feats[1][:0]])                  # an utterance without frames
