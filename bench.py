@@ -9,9 +9,10 @@ Gaussians x 39 (one model pass per 8 frames of all lanes), the CI gate, lextree 
 filler lextrees of a 20 000-word dictionary, histogram and beam pruning, phone-level propagation, the word level (trigram
 look-ups, Viterbi history, word pruning, word transitions): s3a_uttdec_decode_dev, no host work inside an utterance --
 then the hypotheses (s3a_uttdec_hyp_var: final </s> transition + backtrace) and ONE exchange of them across the ranks.
-Inside a rank the share is sorted by length and cut into groups of similar length (lanes run in lock step: a group lasts
-as long as its longest utterance), the groups are dealt to E engines (own stream + host thread each) whose launch tails
-overlap.  Features are resident in HBM before the timed region; history tables and hypotheses come back inside it.
+Inside a rank the share is dealt, longest first, to E engines (own stream + host thread each, their launch tails overlap);
+an engine decodes its share as ONE queue with lane refill (s3a_uttdec_decode_queue_dev: a lane takes the next utterance
+when its own has ended); a share of no more utterances than lanes (--refill 0: any share) runs as groups of similar
+length in lock step.  Features are resident in HBM before the timed region; history tables and hypotheses come back inside it.
 Arithmetic is the bit-exact mode (float32 subtract, float64 accumulate, int32 log-add).  After the timed region rank 0
 formats the LAST step's gathered hypotheses and compares every -hyp / -hypseg line with the unmodified reference
 decoder's (CPU, same files); a difference is an error, not a number.
@@ -248,6 +249,7 @@ def main():
     ap.add_argument("--engines", type=int, default=4, help="decoder engines per GPU (own stream each) the lanes are split over")
     ap.add_argument("--min-group", type=int, default=32, help="a rank's share is cut into groups of at least this many utterances")
     ap.add_argument("--group-fixed", type=int, default=16, help="small shares: the per-frame cost of a group in lane equivalents (sizes the groups so that the engines finish together)")
+    ap.add_argument("--refill", type=int, default=1, help="1: a share of more utterances than lanes is ONE queue per engine, a lane takes the next utterance when its own has ended (s3a_uttdec_decode_queue_dev); 0: groups of similar length, lanes in lock step")
     ap.add_argument("--frames", type=int, default=1000, help="nominal frames per utterance (10 s)")
     ap.add_argument("--cand-cap", type=int, default=0, help="word-level candidate capacity per lane (0: the library's default, 1 << 20)")
     ap.add_argument("--cpu-procs", type=int, default=16, help="processes of the CPU baseline's batch leg (16: where this host's aggregate peaks)")
@@ -332,6 +334,10 @@ def main():
         group lasts as long as its longest utterance: groups hold utterances of similar length; groups are dealt to the
         engines longest first, to the engine with the least frames so far."""
         order = sorted(ids, key=lambda k: (-nfr[k], k))
+        if args.refill and len(order) > NE * NLE:
+            # lane refill: every engine one queue, longest first (the lanes stay busy to the end); dealt like cards so that
+            # the engines' queues hold the same mix of lengths
+            return [[order[e::NE]] if order[e::NE] else [] for e in range(NE)]
         if args.min_group <= len(order) <= NE * NLE and NE > 1:
             # a small share (one group per engine, e.g. 128 utterances on one of 8 GPUs): the engines run side by side, so
             # what counts is when the LAST one finishes.  A group costs its longest utterance x (lanes + a fixed part per
@@ -379,10 +385,15 @@ def main():
             ms, out, t_dec, t_hyp = 0.0, [], 0.0, 0.0
             for g in per[e]:
                 t0 = time.perf_counter()
-                ms += decs[e].ud.decode_dev([fdev[k] for k in g], [nfr[k] for k in g], D4x4)
+                refill = args.refill and len(g) > NLE
+                if refill:
+                    ms += decs[e].ud.decode_queue_dev([fdev[k] for k in g], [nfr[k] for k in g], D4x4)
+                else:
+                    ms += decs[e].ud.decode_dev([fdev[k] for k in g], [nfr[k] for k in g], D4x4)
                 t1 = time.perf_counter()
                 if recs is not None:
-                    out += [decs[e].hyp_var(z, utts[k], base + k) for z, k in enumerate(g)]
+                    get = decs[e].queue_hyp if refill else decs[e].hyp_var
+                    out += [get(z, utts[k], base + k) for z, k in enumerate(g)]
                 t_dec += t1 - t0
                 t_hyp += time.perf_counter() - t1
             return ms, out, t_dec, t_hyp
@@ -490,7 +501,7 @@ def main():
 
         # ---- per-kernel timing of one profiled group (HIP events on the launch stream, every 4th frame) ----
         sched = schedule(my_share(0)[0])
-        g0 = sched[0][0]
+        g0 = sched[0][0][:NLE]
         dec.ud.set_profile(4)
         dec.ud.decode_dev([fdev[k] for k in g0], [nfr[k] for k in g0], D4x4)
         prof = dec.ud.profile()
@@ -573,7 +584,7 @@ def main():
             "config": {"workload": f"configs[3]: batch of {U} synthetic 10 s utterances, hub4_cd_continuous shape, full decode (senone "
                                    f"scoring + lextree Viterbi + trigram word level on the device), sharded over {world} GPU(s); a step = "
                                    f"the whole batch once" + (" per rank" if args.scaling == "weak" else ""),
-                       "utterances_per_step": n_total, "frames_per_step": frames_step, "lanes_per_gpu": NL, "engines_per_gpu": NE,
+                       "utterances_per_step": n_total, "frames_per_step": frames_step, "lanes_per_gpu": NL, "engines_per_gpu": NE, "lane_refill": bool(args.refill and len(my_share(0)[0]) > NL),
                        "groups_rank0": [len(g) for e in sched for g in e],
                        "beams": "-beam 1e-60 -wbeam 1e-35 -maxhmmpf 20000 -maxwpf 10 -lw 9.5 (the reference's hub4 settings)",
                        "parallelism": f"utterance-sharded x{world} ({args.scaling}), two collectives per batch: headers, then the words "

@@ -176,7 +176,7 @@ utt_finish(kb_t *kb, int32 z)
     ckd_free(q->uttid); ckd_free(q->uttfile); ckd_free(q->feat);
 }
 
-typedef struct { int32 e, n, veclen, rc, state; const float **feat; const int32 *nfr; pthread_t th; } eng_job_t;
+typedef struct { int32 e, n, veclen, rc, state, queue; const float **feat; const int32 *nfr; pthread_t th; } eng_job_t;
 static eng_job_t g_job[UTT_MAX_ENGINES];        /* state: 0 idle, 1 posted, 2 done */
 static pthread_mutex_t g_eng_lock = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_eng_cv = PTHREAD_COND_INITIALIZER;
@@ -196,7 +196,8 @@ eng_main(void *vp)
         pthread_mutex_lock(&g_eng_lock);
         while (j->state != 1) pthread_cond_wait(&g_eng_cv, &g_eng_lock);
         pthread_mutex_unlock(&g_eng_lock);
-        j->rc = s3a_uttdec_decode(g_uds[j->e], j->n, j->feat, j->nfr, j->veclen);
+        j->rc = j->queue ? s3a_uttdec_decode_queue(g_uds[j->e], j->n, j->feat, j->nfr, j->veclen)
+                         : s3a_uttdec_decode(g_uds[j->e], j->n, j->feat, j->nfr, j->veclen);
         pthread_mutex_lock(&g_eng_lock);
         j->state = 2;
         pthread_cond_broadcast(&g_eng_cv);
@@ -205,11 +206,135 @@ eng_main(void *vp)
     return NULL;
 }
 
+/* S3A_UTT_QUEUE=n: lane refill.  n (>= the lanes) control-file entries are collected, dealt to the engines longest first,
+ * and every engine decodes its share as ONE queue (s3a_uttdec_decode_queue): a lane takes the next utterance when its own
+ * has ended, so a ragged corpus keeps every lane busy (in lock step a batch lasts as long as its longest utterance).
+ * The lanes' history tables are reused by their next utterances, so the reference's srch_utt_end cannot finish these
+ * utterances: the -hyp / -hypseg lines are written here, in control-file order, from the device's hypothesis records
+ * (s3a_uttdec_queue_hyp = vithist_utt_end + backtrace on the device; s3a_hyp_format_var = match_write / matchseg_write);
+ * no per-utterance statistics, lattices or second pass in this mode. */
+static int g_queue;
+static wl_flat_t *g_wflat;
+static const int32 *g_sort_nfr;
+static int
+cmp_longest_first(const void *a, const void *b)
+{
+    const int32 x = *(const int32 *)a, y = *(const int32 *)b;
+    if (g_sort_nfr[x] != g_sort_nfr[y]) return g_sort_nfr[y] - g_sort_nfr[x];
+    return x - y;
+}
+
+static void
+utt_flush_queue(kb_t *kb)
+{
+    static const char **wstr;
+    static int32 *base;
+    kbcore_t *kbc = kb->kbcore;
+    dict_t *dict = kbcore_dict(kbc);
+    cmd_ln_t *config = kbcore_config(kbc);
+    const int32 n = g_uq_n, veclen = kbcore_fcb(kbc)->stream_len[0];
+    int32 *order, *nfr_all, *slot_e, *slot_q, *nfr2, cnt[UTT_MAX_ENGINES], off[UTT_MAX_ENGINES + 1], z, e, n_used = 0;
+    const float **feat2;
+    eng_job_t *job = g_job;
+    double t0;
+    if (n == 0) return;
+    if (!wstr) {
+        const int32 nw = dict_size(dict);
+        int32 i;
+        wstr = ckd_calloc(nw + 1, sizeof(char *));
+        base = ckd_calloc(nw + 1, 4);
+        for (i = 0; i < nw; i++) { wstr[i] = dict_wordstr(dict, i); base[i] = dict_basewid(dict, i); }
+    }
+    order = ckd_calloc(n, 4); nfr_all = ckd_calloc(n, 4); slot_e = ckd_calloc(n, 4); slot_q = ckd_calloc(n, 4);
+    nfr2 = ckd_calloc(n, 4); feat2 = ckd_calloc(n, sizeof(*feat2));
+    for (z = 0; z < n; z++) { order[z] = z; nfr_all[z] = g_uq[z].nfr; g_utt_frames += g_uq[z].nfr; }
+    g_sort_nfr = nfr_all;
+    qsort(order, n, sizeof(int32), cmp_longest_first);
+    for (e = 0; e < g_n_eng; e++) cnt[e] = 0;
+    for (z = 0; z < n; z++) cnt[z % g_n_eng]++;
+    off[0] = 0;
+    for (e = 0; e < g_n_eng; e++) { off[e + 1] = off[e] + cnt[e]; if (cnt[e] > 0) n_used = e + 1; }
+    for (z = 0; z < n; z++) {
+        const int32 u = order[z], q = z / g_n_eng;
+        e = z % g_n_eng;
+        slot_e[u] = e; slot_q[u] = q;
+        feat2[off[e] + q] = g_uq[u].feat; nfr2[off[e] + q] = g_uq[u].nfr;
+    }
+    t0 = now_s();
+    for (e = 0; e < n_used; e++) {
+        job[e].e = e; job[e].n = cnt[e]; job[e].feat = feat2 + off[e]; job[e].nfr = nfr2 + off[e];
+        job[e].veclen = veclen; job[e].rc = S3A_OK; job[e].queue = 1;
+    }
+    if (g_n_eng == 1) job[0].rc = s3a_uttdec_decode_queue(g_uds[0], job[0].n, job[0].feat, job[0].nfr, job[0].veclen);
+    else {
+        pthread_mutex_lock(&g_eng_lock);
+        for (e = 0; e < n_used; e++) job[e].state = 1;
+        pthread_cond_broadcast(&g_eng_cv);
+        for (e = 0; e < n_used; e++) while (job[e].state != 2) pthread_cond_wait(&g_eng_cv, &g_eng_lock);
+        for (e = 0; e < n_used; e++) job[e].state = 0;
+        pthread_mutex_unlock(&g_eng_lock);
+    }
+    for (e = 0; e < n_used; e++)
+        if (job[e].rc != S3A_OK) {
+            int32 bad = 0, q, err;
+            for (q = 0; q < job[e].n; q++) if (s3a_uttdec_queue_status(g_uds[e], q, &err, NULL, NULL, NULL) == S3A_OK && err) bad++;
+            if (!bad) die("uttdec decode_queue");
+            E_ERROR("tst shim: %d utterance(s) of this queue were not decoded: %s\n", bad, s3a_last_error());
+        }
+    g_t_dev += now_s() - t0;
+    t0 = now_s();
+    for (z = 0; z < n; z++) {           /* control-file order */
+        s3a_uttdec_t *ud = g_uds[slot_e[z]];
+        s3a_hyp_header_t h;
+        s3a_hyp_word_t *words = NULL;
+        int32 need = 0, cap = 0, err = 0, mc = 0, mn = 0;
+        for (;;) {
+            if (need > cap) { cap = need + 64; words = ckd_realloc(words, (size_t)cap * sizeof(*words)); }
+            if (s3a_uttdec_queue_hyp(ud, slot_q[z], g_uq[z].uttid, g_rank_first + g_rec_n, &h, words, cap) != S3A_OK) die("hypothesis record");
+            if (h.status != -3) break;
+            need = h.n_words;
+        }
+        (void)s3a_uttdec_queue_status(ud, slot_q[z], &err, NULL, &mc, &mn);
+        if (mc > g_max_cand) g_max_cand = mc;
+        if (mn > g_max_new) g_max_new = mn;
+        g_frames += g_uq[z].nfr;
+        if (g_gather) {
+            if (g_rec_n == g_rec_cap) { g_rec_cap = g_rec_cap ? 2 * g_rec_cap : 1024; g_rec_hdr = ckd_realloc(g_rec_hdr, (size_t)g_rec_cap * sizeof(*g_rec_hdr)); }
+            if (g_rec_nw + h.n_words > g_rec_wcap) { g_rec_wcap = 2 * (g_rec_nw + h.n_words) + 4096; g_rec_words = ckd_realloc(g_rec_words, (size_t)g_rec_wcap * sizeof(*g_rec_words)); }
+            if (h.status == 0 && h.n_words > 0) memcpy(g_rec_words + g_rec_nw, words, (size_t)h.n_words * sizeof(*words));
+            g_rec_hdr[g_rec_n++] = h;
+            if (h.status == 0) g_rec_nw += h.n_words;
+        }
+        if (h.status == -1) {
+            E_ERROR("tst shim: utterance %s stopped on the device (error bits 0x%x: a capacity of its lane -- S3A_UTT_VHCAP / S3A_UTT_CANDCAP); no hypothesis written\n",
+                    g_uq[z].uttid, err);
+            g_failed_utts++;
+        }
+        else if (h.status != 0)
+            E_ERROR("s->funcs->utt_end failed\n");     /* (srch.c:495-498: no word exit reached a history entry; no line) */
+        else {
+            const size_t lcap = 65536 + 64 * (size_t)h.n_words;
+            char *m = ckd_calloc(lcap, 1), *sg = ckd_calloc(lcap, 1);
+            if (s3a_hyp_format_var(&h, words, wstr, base, g_wflat->is_filler, g_wflat->startwid, g_wflat->finishwid, (float)kbcore_lm(kbc)->lw,
+                                   kbcore_lm(kbc)->wip, cmd_ln_int32_r(config, "-hypsegscore_unscale"), m, lcap, sg, lcap) != S3A_OK) die("s3a_hyp_format_var");
+            if (kb->matchfp) fputs(m, kb->matchfp);
+            if (kb->matchsegfp) fputs(sg, kb->matchsegfp);
+            ckd_free(m); ckd_free(sg);
+        }
+        ckd_free(words);
+        ckd_free(g_uq[z].uttid); ckd_free(g_uq[z].uttfile); ckd_free(g_uq[z].feat);
+    }
+    g_t_fin += now_s() - t0;
+    g_uq_n = 0;
+    ckd_free(order); ckd_free(nfr_all); ckd_free(slot_e); ckd_free(slot_q); ckd_free(nfr2); ckd_free(feat2);
+}
+
 /* the queue, g_lpe utterances per engine; the engines (own stream each) decode side by side, a host thread each --
  * the tails of one engine's launches are another's work */
 static void
 utt_flush(kb_t *kb)
 {
+    if (g_queue) { utt_flush_queue(kb); return; }
     const float **feat;
     int32 *nfr, z, e, n_used;
     double t0;
@@ -223,7 +348,7 @@ utt_flush(kb_t *kb)
     for (e = 0; e < n_used; e++) {
         job[e].e = e; job[e].n = (e + 1) * g_lpe <= g_uq_n ? g_lpe : g_uq_n - e * g_lpe;
         job[e].feat = feat + e * g_lpe; job[e].nfr = nfr + e * g_lpe;
-        job[e].veclen = kbcore_fcb(kb->kbcore)->stream_len[0]; job[e].rc = S3A_OK;
+        job[e].veclen = kbcore_fcb(kb->kbcore)->stream_len[0]; job[e].rc = S3A_OK; job[e].queue = 0;
     }
     if (g_n_eng == 1) job[0].rc = s3a_uttdec_decode(g_uds[0], job[0].n, job[0].feat, job[0].nfr, job[0].veclen);
     else {
@@ -416,7 +541,14 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     s->funcs->utt_end = utt_end_slot;
     if (g_dev_dag) { s->funcs->gen_dag = utt_gen_dag_slot; s->funcs->bestpath_impl = utt_bestpath_slot; }
     g_uq_cap = n_lanes;
-    g_uq = ckd_calloc(n_lanes, sizeof(*g_uq));
+    g_wflat = w;
+    if (getenv("S3A_UTT_QUEUE")) {      /* lane refill: this many control-file entries per queue (at least the lanes) */
+        if (g_dev_dag || cmd_ln_str_r(config, "-outlatdir") || cmd_ln_str_r(config, "-nbestdir") || cmd_ln_boolean_r(config, "-bestpath"))
+            E_FATAL("tst shim: S3A_UTT_QUEUE (lane refill) keeps no history tables: no second pass / lattices / N-best in this mode\n");
+        g_queue = 1;
+        if (atoi(getenv("S3A_UTT_QUEUE")) > g_uq_cap) g_uq_cap = atoi(getenv("S3A_UTT_QUEUE"));
+    }
+    g_uq = ckd_calloc(g_uq_cap, sizeof(*g_uq));
     g_ukb = &kb;
     t_load = now_s() - t_load;
     t_dec = now_s();

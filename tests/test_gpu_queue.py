@@ -111,3 +111,20 @@ def test_queue_refuses_what_it_cannot_serve(gpu_lib, tidigits_bundle):
     dec = bundle.Decoder(tidigits_bundle, 2)
     with pytest.raises(gpu_lib.S3AError):
         dec.decode_queue([feats[0], feats[1][:0]])                  # an utterance without frames
+
+
+@pytest.mark.parametrize("env", [{"S3A_UTT": "4", "S3A_UTT_QUEUE": "31"}, {"S3A_UTT": "6", "S3A_UTT_ENGINES": "2", "S3A_UTT_QUEUE": "12"},
+                                 {"S3A_UTT": "2", "S3A_UTT_QUEUE": "1", "S3A_UTT_WIN": "0"}])
+def test_drop_in_program_with_lane_refill(tmp_path, env):
+    """sphinx3_decode's command line, S3A_UTT_QUEUE: the control file in queues of 31 / 12 / 2 entries, lanes refilled,
+    the -hyp / -hypseg files written in control-file order from the device's hypothesis records"""
+    import subprocess
+    from test_gpu_uttdec import AM, TST
+    hyp, seg = str(tmp_path / "q.match"), str(tmp_path / "q.matchseg")
+    args = [TST, "-dict", f"{D}/dictionary", "-fdict", f"{D}/fillerdict", "-hmm", AM, "-cepdir", f"{D}/cepstra",
+            "-agc", "none", "-varnorm", "no", "-cmn", "current", "-lw", "9.5", "-ctl", f"{D}/tidigits.length.arb.regression",
+            "-op_mode", "4", "-lm", f"{D}/tidigits.DMP", "-hyp", hyp, "-hypseg", seg]
+    p = subprocess.run(args, env=dict(os.environ, **env), capture_output=True, text=True, errors="ignore", timeout=900)
+    assert p.returncode == 0, p.stderr[-2500:]
+    assert open(hyp).read() == open(f"{D}/ref_mode4_trigram.match").read()
+    assert open(seg).read() == open(f"{D}/ref_mode4_trigram.matchseg").read()
