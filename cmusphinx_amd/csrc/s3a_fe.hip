@@ -372,6 +372,13 @@ s3a_fe_n_frames(const s3a_fe_t *fe, int64_t nsamps)
     return (int32_t)(full + (nsamps - full * fe->frame_shift > 0 ? 1 : 0));
 }
 
+/* the stream the front end's launches go to by default */
+extern "C" void *
+s3a_fe_stream(const s3a_fe_t *fe)
+{
+    return fe ? (void *)fe->stream : NULL;
+}
+
 /* samples and cepstra in DEVICE memory; enqueued on `stream` (NULL: the front end's own), not synchronised */
 extern "C" int32_t
 s3a_fe_process_utt_dev(s3a_fe_t *fe, const int16_t *spch_dev, int64_t nsamps, float *cep_dev, int32_t max_frames,

@@ -138,3 +138,51 @@ s3a_feat_1s_c_d_dd(const float *cep, int32_t n_frames, int32_t cepsize, int32_t 
     (void)hipFree(fd);
     return rc;
 }
+
+/*
+ * 16-bit samples (host) -> the utterance's 1s_c_d_dd features RESIDENT IN HBM, ready for s3a_uttdec_decode_dev /
+ * s3a_uttdec_decode_queue_dev: what utt_decode does with -adcin (sphinx3/src/libs3decoder/libAPI/utt.c:208-233) --
+ * fe_start_utt + fe_process_utt (NO fe_end_utt when drop_partial_frame: the samples behind the last whole frame are
+ * dropped, as that function drops them) + feat_s2mfc2feat_live(beginutt, endutt) = feat_s2mfc2feat_block_utt
+ * (feat.c:1241-1265: first and last frame replicated `win` times, then feat_compute_utt) -- with the cepstra never
+ * leaving the device: k_fe_frames -> k_feat_stats -> k_feat_apply on the front end's stream.  *feat_dev_out: rows of
+ * *feat_stride = 4 * ceil(3 * cepsize / 4) floats, zero padded; the caller releases it with s3a_dev_free.
+ */
+extern "C" int32_t
+s3a_audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t drop_partial_frame, int32_t cmn_current,
+                      int32_t varnorm, int32_t agc_max, float **feat_dev_out, int32_t *n_frames, int32_t *feat_stride)
+{
+    if (!fe || !spch || !feat_dev_out || !n_frames || !feat_stride || nsamps <= 0) return S3A_EINVAL;
+    const int32_t cs = s3a_fe_output_size(fe), fsize = s3a_fe_frame_size(fe), fshift = s3a_fe_frame_shift(fe);
+    const int32_t n_all = s3a_fe_n_frames(fe, nsamps);
+    const int32_t n = drop_partial_frame ? (nsamps < fsize ? 0 : (int32_t)(1 + (nsamps - fsize) / fshift)) : n_all;
+    *feat_dev_out = NULL; *n_frames = n; *feat_stride = 4 * ((3 * cs + 3) / 4);
+    if (cs <= 0 || cs > FMAXC) { s3a_set_error("s3a_audio_to_feat_dev: %d cepstral dimensions (1..%d)", cs, FMAXC); return S3A_EINVAL; }
+    if (n <= 0) { s3a_set_error("s3a_audio_to_feat_dev: %lld samples are less than one frame of %d", (long long)nsamps, fsize); return S3A_EINVAL; }
+    hipStream_t st = (hipStream_t)s3a_fe_stream(fe);
+    int16_t *spch_d = NULL;
+    float *cep_d = NULL, *out = NULL;
+    const size_t row = (size_t)*feat_stride, out_floats = (size_t)n * row + 2 * FMAXC + 8;     /* (+ the statistics behind the rows) */
+    int32_t rc = S3A_OK, k = 0;
+    if (hipMalloc((void **)&spch_d, (size_t)nsamps * 2) != hipSuccess || hipMalloc((void **)&cep_d, (size_t)n_all * cs * 4) != hipSuccess
+        || hipMalloc((void **)&out, out_floats * 4) != hipSuccess) {
+        s3a_set_error("s3a_audio_to_feat_dev: out of device memory");
+        rc = S3A_ENOMEM;
+    }
+    if (rc == S3A_OK && (hipMemsetAsync(out, 0, out_floats * 4, st) != hipSuccess
+                         || hipMemcpyAsync(spch_d, spch, (size_t)nsamps * 2, hipMemcpyHostToDevice, st) != hipSuccess)) rc = S3A_EHIP;
+    if (rc == S3A_OK) rc = s3a_fe_process_utt_dev(fe, spch_d, nsamps, cep_d, n_all, &k, (void *)st);
+    if (rc == S3A_OK) {
+        float *stats = out + (size_t)n * row;
+        hipLaunchKernelGGL(k_feat_stats, dim3(1), dim3(256), 0, st, cep_d, n, cs, cmn_current, varnorm, agc_max, stats);
+        hipLaunchKernelGGL(k_feat_apply, dim3((n * cs + 255) / 256), dim3(256), 0, st, cep_d, n, cs, cmn_current, varnorm, agc_max,
+                           stats, out, *feat_stride);
+        if (hipGetLastError() != hipSuccess) rc = S3A_EHIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == S3A_OK) rc = S3A_EHIP;
+    if (spch_d) (void)hipFree(spch_d);
+    if (cep_d) (void)hipFree(cep_d);
+    if (rc != S3A_OK) { if (out) (void)hipFree(out); return rc; }
+    *feat_dev_out = out;
+    return S3A_OK;
+}

@@ -300,6 +300,7 @@ int32_t s3a_fe_process_utt(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, fl
                            int32_t *n_frames);
 int32_t s3a_fe_process_utt_dev(s3a_fe_t *fe, const int16_t *spch_dev, int64_t nsamps, float *cep_dev,
                                int32_t max_frames, int32_t *n_frames, void *stream);
+void   *s3a_fe_stream(const s3a_fe_t *fe);      /* the HIP stream the front end enqueues on when none is given */
 
 /* ------------------------------------------------------------------ */
 /* Feature computation for the stream type "1s_c_d_dd" (the step before the path).
@@ -314,6 +315,16 @@ int32_t s3a_feat_1s_c_d_dd(const float *cep, int32_t n_frames, int32_t cepsize, 
 int32_t s3a_feat_1s_c_d_dd_dev(const float *cep, int32_t n_frames, int32_t cepsize, int32_t cmn_current,
                                int32_t varnorm, int32_t agc_max, float *feat_dev, int32_t feat_stride,
                                void *stream);
+
+/* Raw audio to features resident in HBM, one call: what utt_decode does with -adcin
+ * (sphinx3/src/libs3decoder/libAPI/utt.c:208-233: fe_start_utt + fe_process_utt -- no fe_end_utt, so with
+ * drop_partial_frame the samples behind the last whole frame are dropped as there -- then
+ * feat_s2mfc2feat_live(beginutt, endutt) = feat_s2mfc2feat_block_utt, feat.c:1241-1265), the cepstra never leaving the
+ * device.  *feat_dev_out: *n_frames rows of *feat_stride floats (zero padded: what s3a_uttdec_decode_dev /
+ * s3a_uttdec_decode_queue_dev take); release with s3a_dev_free. */
+int32_t s3a_audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t drop_partial_frame,
+                              int32_t cmn_current, int32_t varnorm, int32_t agc_max, float **feat_dev_out,
+                              int32_t *n_frames, int32_t *feat_stride);
 
 /* ------------------------------------------------------------------ */
 /* The multi-stream ("s3.0") senone scorer: -senmgau .s3cont. / .semi. */

@@ -17,13 +17,16 @@
  * read back into its vithist_t (vithist_fill), srch_utt_end (vithist_utt_end, backtrace, -hyp /
  * -hypseg / lattices / statistics).
  */
-typedef struct { char *uttid, *uttfile; float32 *feat; int32 nfr; } uq_t;
+typedef struct { char *uttid, *uttfile; float32 *feat; int32 nfr; int32 on_dev; } uq_t;   /* on_dev: feat is device memory (-adcin) */
 #define UTT_MAX_ENGINES 8
 static s3a_uttdec_t *g_ud, *g_uds[UTT_MAX_ENGINES];    /* g_ud = g_uds[0]; S3A_UTT_ENGINES engines of g_lpe lanes each */
 static int32 g_n_eng = 1, g_lpe;
 static s3a_lm3g_t *g_lm3g;
 static uq_t *g_uq;
 static int32 g_uq_n, g_uq_cap;
+static int g_adcin, g_cmn_current, g_varnorm, g_agc_max;     /* -adcin: features made on the device from the samples */
+static s3a_fe_t *g_fe;
+static void uq_free(uq_t *q) { ckd_free(q->uttid); ckd_free(q->uttfile); if (q->on_dev) (void)s3a_dev_free(q->feat); else ckd_free(q->feat); }
 static kb_t *g_ukb;
 static double g_t_dev, g_t_fin, g_t_feat;
 static long g_utt_frames, g_max_cand, g_max_new, g_tie_frames, g_frames_lane0;
@@ -134,7 +137,7 @@ utt_finish(kb_t *kb, int32 z)
                 q->uttid, r.err);
         g_failed_utts++;
         if (g_gather) rec_add(z);               /* (status -1: the exchange carries it, rank 0 writes no line) */
-        ckd_free(q->uttid); ckd_free(q->uttfile); ckd_free(q->feat);
+        uq_free(q);
         return;
     }
     if (z == 0 && getenv("S3A_UTT_TICKS")) {
@@ -173,14 +176,24 @@ utt_finish(kb_t *kb, int32 z)
     if (g_gather) rec_add(z);
     utt_end(kb);                                /* srch_utt_end -> utt_end_slot, gen_hyp, match_write ... */
     st->tot_fr += st->nfr;
-    ckd_free(q->uttid); ckd_free(q->uttfile); ckd_free(q->feat);
+    uq_free(q);
 }
 
-typedef struct { int32 e, n, veclen, rc, state, queue; const float **feat; const int32 *nfr; pthread_t th; } eng_job_t;
+typedef struct { int32 e, n, veclen, rc, state, queue, dev; const float **feat; const int32 *nfr; pthread_t th; } eng_job_t;
 static eng_job_t g_job[UTT_MAX_ENGINES];        /* state: 0 idle, 1 posted, 2 done */
 static pthread_mutex_t g_eng_lock = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_eng_cv = PTHREAD_COND_INITIALIZER;
 static int g_eng_started;
+
+/* (features in host memory: rows of veclen floats; -adcin: made on the device, rows of the scorer's padded stride) */
+static int32
+eng_decode(const eng_job_t *j)
+{
+    s3a_uttdec_t *ud = g_uds[j->e];
+    const int32 stride = j->dev ? 4 * ((j->veclen + 3) / 4) : j->veclen;
+    if (j->queue) return j->dev ? s3a_uttdec_decode_queue_dev(ud, j->n, j->feat, j->nfr, stride) : s3a_uttdec_decode_queue(ud, j->n, j->feat, j->nfr, stride);
+    return j->dev ? s3a_uttdec_decode_dev(ud, j->n, j->feat, j->nfr, stride) : s3a_uttdec_decode(ud, j->n, j->feat, j->nfr, stride);
+}
 
 /* one persistent host thread per engine (a thread's first HIP call is expensive: not one per batch) */
 static void *
@@ -196,8 +209,7 @@ eng_main(void *vp)
         pthread_mutex_lock(&g_eng_lock);
         while (j->state != 1) pthread_cond_wait(&g_eng_cv, &g_eng_lock);
         pthread_mutex_unlock(&g_eng_lock);
-        j->rc = j->queue ? s3a_uttdec_decode_queue(g_uds[j->e], j->n, j->feat, j->nfr, j->veclen)
-                         : s3a_uttdec_decode(g_uds[j->e], j->n, j->feat, j->nfr, j->veclen);
+        j->rc = eng_decode(j);
         pthread_mutex_lock(&g_eng_lock);
         j->state = 2;
         pthread_cond_broadcast(&g_eng_cv);
@@ -263,9 +275,9 @@ utt_flush_queue(kb_t *kb)
     t0 = now_s();
     for (e = 0; e < n_used; e++) {
         job[e].e = e; job[e].n = cnt[e]; job[e].feat = feat2 + off[e]; job[e].nfr = nfr2 + off[e];
-        job[e].veclen = veclen; job[e].rc = S3A_OK; job[e].queue = 1;
+        job[e].veclen = veclen; job[e].rc = S3A_OK; job[e].queue = 1; job[e].dev = g_adcin;
     }
-    if (g_n_eng == 1) job[0].rc = s3a_uttdec_decode_queue(g_uds[0], job[0].n, job[0].feat, job[0].nfr, job[0].veclen);
+    if (g_n_eng == 1) job[0].rc = eng_decode(&job[0]);
     else {
         pthread_mutex_lock(&g_eng_lock);
         for (e = 0; e < n_used; e++) job[e].state = 1;
@@ -322,7 +334,7 @@ utt_flush_queue(kb_t *kb)
             ckd_free(m); ckd_free(sg);
         }
         ckd_free(words);
-        ckd_free(g_uq[z].uttid); ckd_free(g_uq[z].uttfile); ckd_free(g_uq[z].feat);
+        uq_free(&g_uq[z]);
     }
     g_t_fin += now_s() - t0;
     g_uq_n = 0;
@@ -348,9 +360,9 @@ utt_flush(kb_t *kb)
     for (e = 0; e < n_used; e++) {
         job[e].e = e; job[e].n = (e + 1) * g_lpe <= g_uq_n ? g_lpe : g_uq_n - e * g_lpe;
         job[e].feat = feat + e * g_lpe; job[e].nfr = nfr + e * g_lpe;
-        job[e].veclen = kbcore_fcb(kb->kbcore)->stream_len[0]; job[e].rc = S3A_OK; job[e].queue = 0;
+        job[e].veclen = kbcore_fcb(kb->kbcore)->stream_len[0]; job[e].rc = S3A_OK; job[e].queue = 0; job[e].dev = g_adcin;
     }
-    if (g_n_eng == 1) job[0].rc = s3a_uttdec_decode(g_uds[0], job[0].n, job[0].feat, job[0].nfr, job[0].veclen);
+    if (g_n_eng == 1) job[0].rc = eng_decode(&job[0]);
     else {
         pthread_mutex_lock(&g_eng_lock);
         for (e = 0; e < n_used; e++) job[e].state = 1;
@@ -379,6 +391,62 @@ utt_flush(kb_t *kb)
     ckd_free(feat); ckd_free(nfr);
 }
 
+/* -adcin: the utterance's samples (what utt.c's static wavfile_read hands utt_decode: <-cepdir>/<file><-cepext>, -adchdr
+ * bytes of header skipped, the rest 16-bit samples in the machine's byte order) */
+static int16 *
+adc_read(const char *uttfile, int32 *nsamps, cmd_ln_t *config)
+{
+    const char *ext = cmd_ln_str_r(config, "-cepext"), *dir = cmd_ln_str_r(config, "-cepdir");
+    const int32 hdr = cmd_ln_int32_r(config, "-adchdr");
+    const size_t le = strlen(ext), lf = strlen(uttfile);
+    char *path = ckd_calloc((dir ? strlen(dir) : 0) + lf + le + 2, 1);
+    FILE *fp;
+    long bytes;
+    int16 *data = NULL;
+    if (le <= lf && strcmp(uttfile + lf - le, ext) == 0) ext = "";
+    if (dir) sprintf(path, "%s/%s%s", dir, uttfile, ext); else sprintf(path, "%s%s", uttfile, ext);
+    if ((fp = fopen(path, "rb")) == NULL) E_FATAL("fopen(%s,rb) failed\n", path);
+    fseek(fp, 0, SEEK_END);
+    bytes = ftell(fp) - (hdr > 0 ? hdr : 0);
+    if (bytes >= 0 && fseek(fp, hdr > 0 ? hdr : 0, SEEK_SET) == 0) {
+        const long n = bytes / (long)sizeof(int16);
+        data = ckd_calloc(n > 0 ? n : 1, sizeof(int16));
+        if ((long)fread(data, sizeof(int16), n, fp) < n) { E_ERROR("Failed to read %ld samples from %s\n", n, path); ckd_free(data); data = NULL; }
+        else *nsamps = (int32)n;
+    }
+    fclose(fp);
+    ckd_free(path);
+    return data;
+}
+
+/* the front end fe_init_auto_r (fe_interface.c:212-283) builds from the same options */
+static void
+adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
+{
+    s3a_fe_params_t p;
+    const char *tr = cmd_ln_str_r(config, "-transform"), *cmn = cmd_ln_str_r(config, "-cmn"), *agc = cmd_ln_str_r(config, "-agc");
+    if (strcmp(kbcore_fcb(kbc)->name, "1s_c_d_dd") != 0) E_FATAL("tst shim: -adcin with S3A_UTT: feature type 1s_c_d_dd only (is %s)\n", kbcore_fcb(kbc)->name);
+    if (cmd_ln_boolean_r(config, "-dither")) E_FATAL("tst shim: -adcin with S3A_UTT: -dither is not supported\n");
+    if (strcmp(cmd_ln_str_r(config, "-input_endian"), "little") != 0) E_FATAL("tst shim: -adcin with S3A_UTT: little-endian samples only\n");
+    if (cmd_ln_str_r(config, "-warp_params") != NULL) E_FATAL("tst shim: -adcin with S3A_UTT: frequency warping is not supported\n");
+    if (kbcore_fcb(kbc)->lda != NULL) E_FATAL("tst shim: -adcin with S3A_UTT: LDA is not supported\n");
+    s3a_fe_default_params(&p);
+    p.samprate = cmd_ln_float32_r(config, "-samprate"); p.frate = cmd_ln_int32_r(config, "-frate"); p.wlen = cmd_ln_float32_r(config, "-wlen");
+    p.alpha = cmd_ln_float32_r(config, "-alpha"); p.ncep = cmd_ln_int32_r(config, "-ncep"); p.nfft = cmd_ln_int32_r(config, "-nfft");
+    p.nfilt = cmd_ln_int32_r(config, "-nfilt"); p.lowerf = cmd_ln_float32_r(config, "-lowerf"); p.upperf = cmd_ln_float32_r(config, "-upperf");
+    p.transform = strcmp(tr, "dct") == 0 ? S3A_FE_DCT : strcmp(tr, "htk") == 0 ? S3A_FE_HTK : S3A_FE_LEGACY;
+    p.lifter = cmd_ln_int32_r(config, "-lifter"); p.remove_dc = cmd_ln_boolean_r(config, "-remove_dc");
+    p.round_filters = cmd_ln_boolean_r(config, "-round_filters"); p.unit_area = cmd_ln_boolean_r(config, "-unit_area");
+    p.doublebw = cmd_ln_boolean_r(config, "-doublebw");
+    p.logspec = cmd_ln_boolean_r(config, "-smoothspec") ? S3A_FE_SMOOTHSPEC : cmd_ln_boolean_r(config, "-logspec") ? S3A_FE_LOGSPEC : S3A_FE_CEPSTRA;
+    if ((g_fe = s3a_fe_init(&p)) == NULL) E_FATAL("tst shim: s3a_fe_init: %s\n", s3a_last_error());
+    if (strcmp(cmn, "current") != 0 && strcmp(cmn, "none") != 0) E_FATAL("tst shim: -adcin with S3A_UTT: -cmn current / none only\n");
+    if (strcmp(agc, "max") != 0 && strcmp(agc, "none") != 0) E_FATAL("tst shim: -adcin with S3A_UTT: -agc max / none only\n");
+    g_cmn_current = strcmp(cmn, "current") == 0; g_agc_max = strcmp(agc, "max") == 0;
+    g_varnorm = cmd_ln_boolean_r(config, "-varnorm");
+    g_adcin = 1;
+}
+
 /* ctl_process callback: utt_decode's feature half (libAPI/utt.c:185-245), then queue */
 static void
 utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
@@ -390,20 +458,35 @@ utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
     uq_t *q;
     double t0 = now_s();
 
-    if (cmd_ln_boolean_r(config, "-adcin"))
-        E_FATAL("tst shim: -adcin is not supported with S3A_UTT (utt.c's wavfile_read is static)\n");
     if (ur->lmname != NULL || ur->regmatname != NULL)
         E_FATAL("tst shim: per-utterance LM / MLLR switching is not supported with S3A_UTT\n");
-    if ((total_frame = feat_s2mfc2feat(kbcore_fcb(kbcore), ur->uttfile, cmd_ln_str_r(config, "-cepdir"),
-                                       cmd_ln_str_r(config, "-cepext"), sf, ef, kb->feat, S3_MAX_FRAMES)) < 0)
-        E_FATAL("Cannot read file %s. Forced exit\n", ur->uttfile);
     q = &g_uq[g_uq_n++];
     q->uttid = ckd_salloc(uttid);
     q->uttfile = ckd_salloc(ur->uttfile);
-    q->nfr = total_frame;
-    q->feat = ckd_calloc((size_t)total_frame * veclen + 1, sizeof(float32));
-    for (t = 0; t < total_frame; t++)
-        memcpy(q->feat + (size_t)t * veclen, kb->feat[t][0], veclen * sizeof(float32));
+    if (g_adcin) {
+        /* -adcin: raw audio -> MFCC -> features on the device (utt.c:208-233 does it with fe_process_utt and
+         * feat_s2mfc2feat_live on the host); the features stay in HBM and the engines read them there */
+        int32 nsamps = 0, stride = 0;
+        int16 *adc = adc_read(ur->uttfile, &nsamps, config);
+        float *dfeat = NULL;
+        (void)sf; (void)ef; (void)t;
+        if (adc == NULL) E_FATAL("Cannot read file %s. Forced exit\n", ur->uttfile);
+        if (s3a_audio_to_feat_dev(g_fe, adc, nsamps, 1, g_cmn_current, g_varnorm, g_agc_max, &dfeat, &total_frame, &stride) != S3A_OK)
+            E_FATAL("tst shim: MFCC / feature computation failed for %s: %s\n", ur->uttfile, s3a_last_error());
+        ckd_free(adc);
+        if (total_frame > S3_MAX_FRAMES) E_FATAL("Maximum number of frames (%d) exceeded\n", S3_MAX_FRAMES);
+        if (stride != 4 * ((veclen + 3) / 4)) E_FATAL("tst shim: -adcin: the front end's features (%d floats per row) do not fit the model's %d-dimensional stream\n", stride, veclen);
+        q->nfr = total_frame; q->feat = dfeat; q->on_dev = 1;
+    }
+    else {
+        if ((total_frame = feat_s2mfc2feat(kbcore_fcb(kbcore), ur->uttfile, cmd_ln_str_r(config, "-cepdir"),
+                                           cmd_ln_str_r(config, "-cepext"), sf, ef, kb->feat, S3_MAX_FRAMES)) < 0)
+            E_FATAL("Cannot read file %s. Forced exit\n", ur->uttfile);
+        q->nfr = total_frame; q->on_dev = 0;
+        q->feat = ckd_calloc((size_t)total_frame * veclen + 1, sizeof(float32));
+        for (t = 0; t < total_frame; t++)
+            memcpy(q->feat + (size_t)t * veclen, kb->feat[t][0], veclen * sizeof(float32));
+    }
     g_t_feat += now_s() - t0;
     if (g_uq_n == g_uq_cap) utt_flush(kb);
 }
@@ -542,6 +625,7 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     if (g_dev_dag) { s->funcs->gen_dag = utt_gen_dag_slot; s->funcs->bestpath_impl = utt_bestpath_slot; }
     g_uq_cap = n_lanes;
     g_wflat = w;
+    if (cmd_ln_exists_r(config, "-adcin") && cmd_ln_boolean_r(config, "-adcin")) adc_frontend_init(config, kbc);
     if (getenv("S3A_UTT_QUEUE")) {      /* lane refill: this many control-file entries per queue (at least the lanes) */
         if (g_dev_dag || cmd_ln_str_r(config, "-outlatdir") || cmd_ln_str_r(config, "-nbestdir") || cmd_ln_boolean_r(config, "-bestpath"))
             E_FATAL("tst shim: S3A_UTT_QUEUE (lane refill) keeps no history tables: no second pass / lattices / N-best in this mode\n");

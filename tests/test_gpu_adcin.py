@@ -1,0 +1,78 @@
+"""-adcin through the whole-utterance engine (MI355X): raw 16-bit audio -> MFCC (s3a_fe) -> 1s_c_d_dd features (s3a_feat)
+-> decode, everything after the file read on the device (s3a_audio_to_feat_dev: the cepstra and the features never leave
+HBM) -- what utt_decode does with -adcin on the host (libAPI/utt.c:208-233: fe_process_utt WITHOUT fe_end_utt, then
+feat_s2mfc2feat_live over the whole utterance).  The unmodified reference with the same command line is the judge.
+Audio: the reference's own test files (pocketsphinx goforward.raw, sphinxbase chan3.raw: tests/golden/fe.npz; the
+tidigits utterance dhd.2934z.raw of pocketsphinx/test/data/tidigits)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from test_gpu_uttdec import AM, D, TST
+
+pytestmark = pytest.mark.gpu
+REF = os.path.join(ROOT, "oracle", "_ref", "sphinx3_decode")
+
+
+@pytest.fixture(scope="module")
+def audio_task(tmp_path_factory):
+    for b in (REF, TST):
+        if not os.path.exists(b):
+            pytest.fail(f"{b} is missing on the GPU box (make -C oracle ref)")
+    d = tmp_path_factory.mktemp("adcin")
+    g = np.load(os.path.join(GOLDEN, "fe.npz"))
+    g["goforward_raw"].astype("<i2").tofile(d / "goforward.raw")
+    g["chan3_raw"].astype("<i2").tofile(d / "chan3.raw")
+    g["goforward_raw"][3000:3000 + 9000].astype("<i2").tofile(d / "short.raw")
+    raw = open(os.path.join(D, "raw", "dhd.2934z.raw"), "rb").read()
+    (d / "dhd.raw").write_bytes(raw)
+    (d / "hdr.raw").write_bytes(b"H" * 44 + raw)             # the same behind a 44-byte header: its own run with -adchdr 44
+    (d / "ctl").write_text("dhd\ngoforward\nchan3\nshort\n")
+    (d / "ctlh").write_text("hdr\n")
+    args = ["-dict", f"{D}/dictionary", "-fdict", f"{D}/fillerdict", "-hmm", AM, "-cepdir", str(d), "-cepext", ".raw", "-adcin", "yes",
+            "-agc", "none", "-varnorm", "no", "-cmn", "current", "-lw", "9.5", "-op_mode", "4", "-lm", f"{D}/tidigits.DMP"]
+    return d, args
+
+
+def run(exe, args, d, tag, env=None, ctl="ctl", extra=()):
+    hyp, seg = str(d / f"{tag}.match"), str(d / f"{tag}.matchseg")
+    p = subprocess.run([exe] + args + ["-ctl", str(d / ctl), "-hyp", hyp, "-hypseg", seg] + list(extra), capture_output=True, text=True,
+                       errors="ignore", timeout=900, env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr[-2500:]
+    return open(hyp).read(), open(seg).read()
+
+
+@pytest.mark.parametrize("env", [{"S3A_UTT": "1"}, {"S3A_UTT": "4"}, {"S3A_UTT": "2", "S3A_UTT_QUEUE": "4"},
+                                 {"S3A_UTT": "4", "S3A_UTT_ENGINES": "2"}])
+def test_raw_audio_decodes_as_the_reference(audio_task, env):
+    d, args = audio_task
+    ref = run(REF, args, d, "ref")
+    assert ref[0].count("\n") == 4 and "(dhd)" in ref[0]
+    got = run(TST, args, d, "utt" + "_".join(env.values()), env)
+    assert got[0] == ref[0]                 # the words
+    assert got[1] == ref[1]                 # ... and every score: the device front end's cepstra are the host's, bit for bit
+
+
+def test_header_skip_and_other_front_end_options(audio_task):
+    d, args = audio_task
+    ref = run(REF, args, d, "refh", ctl="ctlh", extra=["-adchdr", "44"])
+    got = run(TST, args, d, "utth", {"S3A_UTT": "2"}, ctl="ctlh", extra=["-adchdr", "44"])
+    assert got == ref and "(hdr)" in ref[0]
+    opt = ["-transform", "dct", "-remove_dc", "yes", "-lifter", "22", "-varnorm", "yes", "-agc", "max"]
+    a2 = [a for a in args]
+    for k in ("-varnorm", "-agc"):
+        i = a2.index(k)
+        del a2[i:i + 2]
+    ref = run(REF, a2 + opt, d, "refo")
+    got = run(TST, a2 + opt, d, "utto", {"S3A_UTT": "3"})
+    assert got == ref
+
+
+def test_unsupported_front_end_options_are_refused(audio_task):
+    d, args = audio_task
+    p = subprocess.run([TST] + args + ["-ctl", str(d / "ctl"), "-dither", "yes"], capture_output=True, text=True, errors="ignore",
+                       timeout=600, env=dict(os.environ, S3A_UTT="2"))
+    assert p.returncode != 0 and "-dither is not supported" in p.stderr
