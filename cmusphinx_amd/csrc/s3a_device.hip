@@ -203,6 +203,44 @@ s3a_mgau_dev_create(s3a_mgau_model_t *g)
     return s3a_mgau_reset_state(g);
 }
 
+/*
+ * An adapted model: the Gaussians' means, precisions (1 / (2 sigma^2)) and log determinant terms replaced in place,
+ * host AoS [n_mgau][max_comp][veclen] / [n_mgau][max_comp] as mgau_model_t holds them after adapt_set_mllr
+ * (libam/adaptor.c:106-170: means + variances reloaded, mllr_norm_mgau, variance floor, mgau_precomp -- all of it the
+ * reference's own host code; the replacement backend takes the result).  The mixture weights and the senones' component
+ * counts do not change (checked by the caller against s3a_mgau_n_comp).  Every scorer / engine built on this model sees
+ * the new parameters from its next launch on (they read the model's device arrays); not to be called while one runs.
+ */
+extern "C" int32_t
+s3a_mgau_set_params(s3a_mgau_model_t *g, const float *mean, const float *prec, const float *lrd)
+{
+    if (!g || !g->dev || !mean || !prec || !lrd) return S3A_EINVAL;
+    struct s3a_mgau_dev_s *d = g->dev;
+    const size_t nv = (size_t)d->D4 * d->Gpad;
+    std::vector<float4> hm(nv), hp(nv);
+    std::vector<float> hl(d->Gpad, 0.0f);
+    memset(hm.data(), 0, nv * sizeof(float4));
+    memset(hp.data(), 0, nv * sizeof(float4));
+    memcpy(g->mean, mean, (size_t)d->S * d->C * d->D * sizeof(float));
+    memcpy(g->prec, prec, (size_t)d->S * d->C * d->D * sizeof(float));
+    memcpy(g->lrd, lrd, (size_t)d->S * d->C * sizeof(float));
+    for (int32_t s = 0; s < d->S; s++)
+        for (int32_t c = 0; c < g->n_comp[s]; c++) {
+            const size_t gi = (size_t)s * d->CP + c;
+            const float *m = g->mean + ((size_t)s * d->C + c) * d->D, *p = g->prec + ((size_t)s * d->C + c) * d->D;
+            for (int32_t i = 0; i < d->D; i++) {
+                ((float *)&hm[(size_t)(i >> 2) * d->Gpad + gi])[i & 3] = m[i];
+                ((float *)&hp[(size_t)(i >> 2) * d->Gpad + gi])[i & 3] = p[i];
+            }
+            hl[gi] = g->lrd[(size_t)s * d->C + c];
+        }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(d->mean4, hm.data(), nv * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d->prec4, hp.data(), nv * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d->lrd, hl.data(), d->Gpad * sizeof(float), hipMemcpyHostToDevice));
+    return S3A_OK;
+}
+
 extern "C" void
 s3a_mgau_dev_destroy(s3a_mgau_model_t *g)
 {

@@ -47,6 +47,10 @@ _SIGS = {
     "s3a_mgau_load_host": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_double,
                                         C.c_int32, C.c_void_p]),
     "s3a_mgau_free": (None, [C.c_void_p]),
+    "s3a_mgau_set_params": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3a_fe_stream": (C.c_void_p, [C.c_void_p]),
+    "s3a_audio_to_feat_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "s3a_mgau_n_mgau": (C.c_int32, [C.c_void_p]),
     "s3a_mgau_max_comp": (C.c_int32, [C.c_void_p]),
     "s3a_mgau_veclen": (C.c_int32, [C.c_void_p]),

@@ -121,6 +121,11 @@ s3a_mgau_model_t *s3a_mgau_load_host(const char *meanfile, const char *varfile, 
                                      const char *mixwfile, double mixwfloor, int32_t precomp,
                                      s3a_logmath_t *logmath);
 void    s3a_mgau_free(s3a_mgau_model_t *g);                 /* mgau_free, cont_mgau.c:1210 */
+/* An ADAPTED model (-mllr / -ctl_mllr): the parameters mgau_model_t holds after adapt_set_mllr (libam/adaptor.c:106-170:
+ * reload, mllr_norm_mgau mllr.c:210-256, variance floor, mgau_precomp cont_mgau.c:857-894 -- the reference's host code,
+ * run by kb_setmllr kb.c:335-365) replace the model's in place: mean / prec [n_mgau][max_comp][veclen] (prec = the
+ * precomputed 1 / (2 sigma^2)), lrd [n_mgau][max_comp], rows of senone m valid up to s3a_mgau_n_comp(g, m). */
+int32_t s3a_mgau_set_params(s3a_mgau_model_t *g, const float *mean, const float *prec, const float *lrd);
 int32_t s3a_mgau_n_mgau(const s3a_mgau_model_t *g);         /* mgau_n_mgau   cont_mgau.h:229 */
 int32_t s3a_mgau_max_comp(const s3a_mgau_model_t *g);       /* mgau_max_comp cont_mgau.h:230 */
 int32_t s3a_mgau_veclen(const s3a_mgau_model_t *g);         /* mgau_veclen   cont_mgau.h:231 */

@@ -185,6 +185,65 @@ trace_state(int32 tag_base)
 }
 #endif
 
+#ifndef LT_ORACLE
+/* -mllr / -ctl_mllr: kb_setmllr (kb.c:335-365 -> adapt_set_mllr, libam/adaptor.c:106-170) has rewritten the host model
+ * -- means and variances reloaded, mllr_norm_mgau, variance floor, mgau_precomp --; the device model takes the result
+ * (s3a_mgau_set_params).  g_mllr_cur: the regression matrix file the device models hold ("": none). */
+static char g_mllr_cur[4096];
+static void
+adapt_upload(kb_t *kb, s3a_mgau_model_t *gm)
+{
+    mgau_model_t *g = kbcore_mgau(kb->kbcore);
+    const int32 S = mgau_n_mgau(g), C = mgau_max_comp(g), D = mgau_veclen(g);
+    float *mean, *prec, *lrd;
+    int32 m, c;
+    if (S != s3a_mgau_n_mgau(gm) || C != s3a_mgau_max_comp(gm) || D != s3a_mgau_veclen(gm))
+        E_FATAL("tst shim: the adapted model's shape differs from the device model's\n");
+    mean = ckd_calloc((size_t)S * C * D, sizeof(float)); prec = ckd_calloc((size_t)S * C * D, sizeof(float));
+    lrd = ckd_calloc((size_t)S * C, sizeof(float));
+    for (m = 0; m < S; m++) {
+        if (mgau_n_comp(g, m) != s3a_mgau_n_comp(gm, m))
+            E_FATAL("tst shim: senone %d has %d components after adaptation, the device model %d\n", m, mgau_n_comp(g, m), s3a_mgau_n_comp(gm, m));
+        for (c = 0; c < mgau_n_comp(g, m); c++) {
+            memcpy(mean + ((size_t)m * C + c) * D, mgau_mean(g, m, c), D * sizeof(float));
+            memcpy(prec + ((size_t)m * C + c) * D, mgau_var(g, m, c), D * sizeof(float));
+            lrd[(size_t)m * C + c] = mgau_lrd(g, m, c);
+        }
+    }
+    if (s3a_mgau_set_params(gm, mean, prec, lrd) != S3A_OK) die("s3a_mgau_set_params");
+    ckd_free(mean); ckd_free(prec); ckd_free(lrd);
+}
+
+/* the device model(s) follow the host model: gms[0 .. n) all take it when the regression matrix file has changed */
+static void
+adapt_sync(kb_t *kb, s3a_mgau_model_t **gms, int32 n)
+{
+    const char *now = (kb->adapt_am && kb->adapt_am->prevmllrfn) ? kb->adapt_am->prevmllrfn : "";
+    int32 e;
+    if (strcmp(now, g_mllr_cur) == 0) return;
+    if (strlen(now) >= sizeof g_mllr_cur) E_FATAL("tst shim: MLLR file name too long\n");
+    for (e = 0; e < n; e++) adapt_upload(kb, gms[e]);
+    strcpy(g_mllr_cur, now);
+    E_INFO("tst shim: the device model%s now hold%s the model adapted with %s\n", n > 1 ? "s" : "", n > 1 ? "" : "s", now);
+}
+
+/* ctl_process callback of the frame-synchronous drivers: utt_decode (libAPI/utt.c:185) behind the model switch it would
+ * make itself (:245-246), so that the device model has switched too before the first frame is scored */
+static void
+utt_decode_adapt(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
+{
+    kb_t *kb = data;
+    if (ur->regmatname != NULL) {
+        if (g_n_groups) E_FATAL("tst shim: -ctl_mllr with S3A_BATCH (decoders share one device model) is not supported\n");
+        kb_setmllr(ur->regmatname, ur->cb2mllrname, kb);
+        adapt_sync(kb, &g_gm, 1);
+    }
+    utt_decode(data, ur, sf, ef, uttid);
+}
+#else
+#define utt_decode_adapt utt_decode
+#endif
+
 static void
 backend_init(kb_t *kb, srch_TST_graph_t *tstg)
 {
@@ -350,6 +409,10 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
             if (g_batch) g_ls_shared[g_worker_id % g_n_groups] = g_ls;
         }
         if (!g_ls) die("s3a_lexsearch_init");
+        if (kb->adapt_am && kb->adapt_am->prevmllrfn && kb->adapt_am->prevmllrfn[0]) {     /* -mllr: kb_init adapted the host model */
+            if (g_n_groups) E_FATAL("tst shim: -mllr with S3A_BATCH is not supported\n");
+            adapt_sync(kb, &g_gm, 1);
+        }
     }
 #endif
     E_INFO("tst shim: %d lextrees flattened (largest %d nodes), backend %s\n", g_ntree, g_max_node,
@@ -897,7 +960,7 @@ worker_main(void *vp)
 
     if (w->cnt > 0)
         kb.stat->tm = ctl_process(cmd_ln_str_r(config, "-ctl"), cmd_ln_str_r(config, "-ctl_lm"),
-                                  cmd_ln_str_r(config, "-ctl_mllr"), w->off, w->cnt, utt_decode, &kb);
+                                  cmd_ln_str_r(config, "-ctl_mllr"), w->off, w->cnt, utt_decode_adapt, &kb);
     if (kb.matchsegfp) fclose(kb.matchsegfp);
     if (kb.matchfp) fclose(kb.matchfp);
     w->frames = g_frames; w->histframes = g_histframes; w->t_utt = g_t_utt; w->t_search = g_t_search; w->t_word = g_t_word;

@@ -19,6 +19,7 @@
  */
 typedef struct { char *uttid, *uttfile; float32 *feat; int32 nfr; int32 on_dev; } uq_t;   /* on_dev: feat is device memory (-adcin) */
 #define UTT_MAX_ENGINES 8
+static s3a_mgau_model_t *g_gms[UTT_MAX_ENGINES];       /* the engines' device models (MLLR: all follow the host model) */
 static s3a_uttdec_t *g_ud, *g_uds[UTT_MAX_ENGINES];    /* g_ud = g_uds[0]; S3A_UTT_ENGINES engines of g_lpe lanes each */
 static int32 g_n_eng = 1, g_lpe;
 static s3a_lm3g_t *g_lm3g;
@@ -458,8 +459,15 @@ utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
     uq_t *q;
     double t0 = now_s();
 
-    if (ur->lmname != NULL || ur->regmatname != NULL)
-        E_FATAL("tst shim: per-utterance LM / MLLR switching is not supported with S3A_UTT\n");
+    if (ur->lmname != NULL)
+        E_FATAL("tst shim: per-utterance LM switching is not supported with S3A_UTT\n");
+    if (ur->regmatname != NULL && strcmp(ur->regmatname, kb->adapt_am->prevmllrfn) != 0) {
+        /* -ctl_mllr names another regression matrix: what is queued is decoded with the model it was queued for, then the
+         * host model is adapted (kb_setmllr, as utt_decode would: utt.c:245-246) and every engine's device model follows */
+        utt_flush(kb);
+        kb_setmllr(ur->regmatname, ur->cb2mllrname, kb);
+        adapt_sync(kb, g_gms, g_n_eng);
+    }
     q = &g_uq[g_uq_n++];
     q->uttid = ckd_salloc(uttid);
     q->uttfile = ckd_salloc(ur->uttfile);
@@ -548,7 +556,9 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
                                    cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
                                    cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.", S3A_MIX_INT_FLOAT_COMP, g_lm);
                 if (!gm) die("s3a_mgau_init");
+                if (g_mllr_cur[0]) adapt_upload(&kb, gm);       /* -mllr: this engine's model too */
             }
+            g_gms[e] = gm;
             s3a_uttdec_opts_t uo;
             s3a_uttdec_opts_from_env(&uo);          /* (this program's tuning switches are environment variables; the library takes arguments) */
             g_uds[e] = s3a_uttdec_init_opts(g_ls, gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen, cmd_ln_int32_r(config, "-ds"),
