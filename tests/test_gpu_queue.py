@@ -1,6 +1,6 @@
 """Lane refill (s3a_uttdec_decode_queue) on the MI355X: a queue of ANY number of utterances, a lane takes the next one when
 its own has ended -- ctl_process (libcommon/corpus.c:538) knows no coupling between utterances either.  The ragged tidigits
-set (31 utterances, 105 .. 476 frames) through engines of 1 .. 40 lanes: every utterance's -hyp / -hypseg line is the
+set (31 utterances, 82 .. 339 frames) through engines of 1 .. 40 lanes: every utterance's -hyp / -hypseg line is the
 unmodified reference's, whichever lane decoded it, whenever it started, whatever ran in that lane before (including an
 utterance that stopped on a capacity error: the lane is scrubbed on the device)."""
 import os
