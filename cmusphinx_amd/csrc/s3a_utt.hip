@@ -96,6 +96,9 @@ struct UShared {
     int32_t win_K;              /* > 0: look-ahead scoring, K frames per window (ku_score_window / ku_select); 0: per-frame scoring */
     UCtx *ctx_all;              /* [n_lanes] */
     int32_t *nact_all;          /* [n_lanes][2][WL_MAXT] */
+    const int32_t *fgbase;      /* [1] what the kernels add to their frame argument: 0 in stream mode (the argument is the engine's
+                                 * frame counter); in graph mode a block of frames is captured ONCE with the arguments 0 .. G - 1 and
+                                 * replayed, the block's last node (ku_advance) moves this counter on by G */
 };
 
 /* the lanes share every launch: the kernels' argument fg is the ENGINE's frame counter, a lane's own frame is
@@ -103,7 +106,7 @@ struct UShared {
  * last one ended -- s3a_uttdec_decode_queue -- started later), the list searched in frame f is list f & 1
  * (lextree_active_swap flips it every frame) -- no kernel has to read what the word level of the previous frame wrote
  * last, so the word level can share a launch with the emission sweep */
-#define LANE UCtx *ctx = S.ctx_all + blockIdx.z; const int32_t f = fg - ctx->f0;                                    \
+#define LANE UCtx *ctx = S.ctx_all + blockIdx.z; const int32_t f = fg + *S.fgbase - ctx->f0;                         \
     if (f < 0 || f >= ctx->nfr || !ctx->active) return;                                                           \
     const int32_t cur = f & 1; const int32_t *nact_cur = S.nact_all + ((size_t)blockIdx.z * 2 + cur) * WL_MAXT;       \
     const ULane &L = lanes[blockIdx.z]; (void)cur; (void)nact_cur
@@ -398,7 +401,7 @@ ku_gated_cd_multi(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, i
         if (tid < n) {
             const ULane &Lz = lanes[zb + tid];
             const UCtx *cx = Lz.ctx;
-            const int32_t cf = fg - cx->f0;            /* the lane's own frame */
+            const int32_t cf = fg + *S.fgbase - cx->f0;        /* the lane's own frame */
             d.active = (cx->active && cf >= 0 && cf < cx->nfr) ? 1 : 0;
             if (d.active) {
                 d.sen_act = Lz.sen_act; d.scr = Lz.scr; d.gpart = Lz.gpart; d.bstidx = Lz.bstidx; d.bstscr = Lz.bstscr;
@@ -570,7 +573,7 @@ ku_score_window(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, int
         UwGroup gr;
         gr.feat = NULL; gr.win = NULL; gr.winb = NULL; gr.nv = 0; gr.pad = 0;
         const UCtx *cx = S.ctx_all + z;
-        const int32_t fl = f0 - cx->f0 + j0;            /* the lane's own frame (its utterance began at a window's first frame) */
+        const int32_t fl = f0 + *S.fgbase - cx->f0 + j0;        /* the lane's own frame (its utterance began at a window's first frame) */
         if (cx->active && fl >= 0) {
             const int32_t left = cx->nfr - fl;
             if (left > 0) {
@@ -1147,6 +1150,13 @@ ku_wordlevel_only(const ULane *__restrict__ lanes, WLm lm, WDict dict, WPar par)
                       (long long)wall_clock64());
 }
 
+/* the last node of a captured block of frames: the engine's frame counter moves on */
+__global__ void
+ku_advance(int32_t *fgbase, int32_t by)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *fgbase += by;
+}
+
 __global__ void
 ku_pack_node4(const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid, const int32_t *__restrict__ wid,
               const uint8_t *__restrict__ comp, int4 *out, int32_t N)
@@ -1449,6 +1459,11 @@ struct s3a_uttdec_s {
     s3a_dagpass_t *dag;         /* the second pass after every decode (s3a_uttdec_enable_bestpath), or NULL */
     int32_t keep_tables;        /* 0: with the second pass enabled the history tables stay on the device */
     int32_t tables_fetched, fstat_fetched;
+    /* graph mode (s3a_uttdec_opts_t.graph): a block of frames captured once per lane count, replayed block after block */
+    int32_t use_graph;
+    int32_t *d_fgbase;
+    struct FrameGraph { int32_t n, frames; hipGraphExec_t exec; UShared S; };
+    std::vector<FrameGraph> graphs;
     /* s3a_uttdec_decode_queue (lane refill): everything of a queue lives in buffers that only grow */
     int32_t q_n;                /* utterances of the last decode when it was a queue (0: a plain decode) */
     std::vector<int32_t> q_nfr; /* their frame counts */
@@ -1549,6 +1564,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         for (auto q : qd) if (q) (void)hipFree(q);
         for (auto q : qh) if (q) (void)hipHostFree(q);
     }
+    for (auto &fg_ : ud->graphs) if (fg_.exec) (void)hipGraphExecDestroy(fg_.exec);
+    if (ud->d_fgbase) (void)hipFree(ud->d_fgbase);
     if (ud->h_ctx_up) (void)hipHostFree(ud->h_ctx_up);
     if (ud->h_ctx_dn) (void)hipHostFree(ud->h_ctx_dn);
     if (ud->h_hyp_hdr) (void)hipHostFree(ud->h_hyp_hdr);
@@ -1590,7 +1607,7 @@ s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o)
     o->window_fpc = num("S3A_UTT_WIN_FPC", 0); o->g_eval = num("S3A_UTT_GEVAL", 0); o->g_res = num("S3A_UTT_GRES", 0);
     o->scan_g = num("S3A_UTT_SCAN_G", 0); o->gy = num("S3A_UTT_GY", 0); o->sweep_k = num("S3A_UTT_URK", 0);
     o->no_multi = getenv("S3A_UTT_NO_MULTI") != NULL; o->framecheck = getenv("S3A_UTT_FRAMECHECK") != NULL;
-    o->times = num("S3A_UTT_TIMES", 0);
+    o->times = num("S3A_UTT_TIMES", 0); o->graph = num("S3A_UTT_GRAPH", 0);
 }
 
 extern "C" s3a_uttdec_t *
@@ -1636,7 +1653,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
     ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
-    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->q_n = 0; ud->q_feat_d = ud->q_feat_h = NULL; ud->q_ctx_d = ud->q_ctx_h = NULL; ud->q_sched_d = ud->q_sched_h = NULL; ud->q_hdr_d = ud->q_hdr_h = NULL; ud->q_words_d = ud->q_words_h = NULL; ud->q_feat_cap = ud->q_ctx_cap = ud->q_sched_cap = ud->q_hdr_cap = ud->q_words_cap = ud->q_words_hcap = 0; ud->h_ctx_up = NULL; ud->h_ctx_dn = NULL; ud->d_hyp_hdr = ud->h_hyp_hdr = ud->d_hyp_words = ud->h_hyp_words = NULL; ud->hyp_wcap = 0; ud->n_pset = proto->n_pset;
+    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->use_graph = 0; ud->d_fgbase = NULL; ud->q_n = 0; ud->q_feat_d = ud->q_feat_h = NULL; ud->q_ctx_d = ud->q_ctx_h = NULL; ud->q_sched_d = ud->q_sched_h = NULL; ud->q_hdr_d = ud->q_hdr_h = NULL; ud->q_words_d = ud->q_words_h = NULL; ud->q_feat_cap = ud->q_ctx_cap = ud->q_sched_cap = ud->q_hdr_cap = ud->q_words_cap = ud->q_words_hcap = 0; ud->h_ctx_up = NULL; ud->h_ctx_dn = NULL; ud->d_hyp_hdr = ud->h_hyp_hdr = ud->d_hyp_words = ud->h_hyp_words = NULL; ud->hyp_wcap = 0; ud->n_pset = proto->n_pset;
     (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
@@ -1785,6 +1802,10 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     if (T > WL_MAXT) { s3a_set_error("s3a_uttdec_init: more than %d lextrees", WL_MAXT); goto fail; }
     DM(ud->S.ctx_all, sizeof(UCtx) * n_lanes);
     DM(ud->S.nact_all, (size_t)n_lanes * 2 * WL_MAXT * 4);
+    DM(ud->d_fgbase, 64);
+    if (hipMemset(ud->d_fgbase, 0, 64) != hipSuccess) goto fail;
+    ud->S.fgbase = ud->d_fgbase;
+    ud->use_graph = O.graph != 0 && !ud->big_wl && !O.framecheck;
     ud->hyp_wcap = max_frames + 4;
     if (hipHostMalloc((void **)&ud->h_ctx_up, sizeof(UCtx) * n_lanes) != hipSuccess
         || hipHostMalloc((void **)&ud->h_ctx_dn, sizeof(UCtx) * n_lanes) != hipSuccess
@@ -2000,12 +2021,13 @@ uw_geometry(const s3a_uttdec_t *ud, int32_t n_lanes)
 
 template <int CP, bool EXACT>
 static hipError_t
-uw_launch_cp(const s3a_uttdec_t *ud, const UwGeom &q, int32_t n, int32_t f0, hipStream_t st)
+uw_launch_cp(const s3a_uttdec_t *ud, const UwGeom &q, int32_t n, int32_t f0, hipStream_t st, bool attr_only)
 {
+    /* (attr_only: the function attribute alone -- before a stream capture, where it may not be set) */
 #define UW_GO(TAB, NT) do { auto kern = ku_score_window<CP, EXACT, TAB, NT>;                                            \
         if (q.lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                                        160 * 1024) != hipSuccess) return hipGetLastError();             \
-        hipLaunchKernelGGL(kern, dim3(q.grid), dim3(NT), q.lds, st, ud->d_lanes, ud->S, n, f0, ud->S.win_K, q.fpc,        \
+        if (!attr_only) hipLaunchKernelGGL(kern, dim3(q.grid), dim3(NT), q.lds, st, ud->d_lanes, ud->S, n, f0, ud->S.win_K, q.fpc,        \
                            q.n_chunks, q.n_tiles); } while (0)
     if (q.nt == 512) { if (q.tab_lds) UW_GO(true, 512); else UW_GO(false, 512); }
     else UW_GO(false, 256);
@@ -2014,14 +2036,14 @@ uw_launch_cp(const s3a_uttdec_t *ud, const UwGeom &q, int32_t n, int32_t f0, hip
 }
 
 static int32_t
-uw_launch(const s3a_uttdec_t *ud, int32_t n, int32_t f0)
+uw_launch(const s3a_uttdec_t *ud, int32_t n, int32_t f0, bool attr_only = false)
 {
     const UwGeom q = uw_geometry(ud, n);
     hipError_t e;
-#define UW_CASE(cp) case cp: e = ud->exact ? uw_launch_cp<cp, true>(ud, q, n, f0, ud->stream) : uw_launch_cp<cp, false>(ud, q, n, f0, ud->stream); break
+#define UW_CASE(cp) case cp: e = ud->exact ? uw_launch_cp<cp, true>(ud, q, n, f0, ud->stream, attr_only) : uw_launch_cp<cp, false>(ud, q, n, f0, ud->stream, attr_only); break
     switch (ud->S.CP) {
     UW_CASE(1); UW_CASE(2); UW_CASE(4); UW_CASE(8); UW_CASE(16); UW_CASE(32);
-    default: e = ud->exact ? uw_launch_cp<64, true>(ud, q, n, f0, ud->stream) : uw_launch_cp<64, false>(ud, q, n, f0, ud->stream); break;
+    default: e = ud->exact ? uw_launch_cp<64, true>(ud, q, n, f0, ud->stream, attr_only) : uw_launch_cp<64, false>(ud, q, n, f0, ud->stream, attr_only); break;
     }
 #undef UW_CASE
     if (e != hipSuccess) { s3a_set_error("ku_score_window launch failed: %s", hipGetErrorString(e)); return S3A_EHIP; }
@@ -2135,6 +2157,46 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     return S3A_OK;
 }
 
+/* ---- graph mode: the launches of a BLOCK of frames as one HIP graph ----
+ * The launch sequence of a frame is the same for every frame (fixed grids; what a kernel has to do it finds in memory), and
+ * the frame number reaches the kernels as argument + *S.fgbase: a block of G frames (G = the look-ahead window, so that the
+ * block holds exactly one scoring pass) is captured once per lane count with the arguments 0 .. G - 1, its last node moves
+ * the counter on by G, and a decode is ceil(frames / G) graph launches (the frames behind an utterance's end find nothing to
+ * do).  The host's part of a frame drops from ~13 launches to 1 / G of a graph launch. */
+static int32_t
+graph_block_frames(const s3a_uttdec_t *ud)
+{
+    return ud->S.win_K > 0 ? ud->S.win_K : 8;
+}
+
+static int32_t
+graph_for(s3a_uttdec_t *ud, int32_t n, hipGraphExec_t *out)
+{
+    const int32_t G = graph_block_frames(ud);
+    for (auto &g : ud->graphs)
+        if (g.n == n && g.frames == G && memcmp(&g.S, &ud->S, sizeof(UShared)) == 0) { *out = g.exec; return S3A_OK; }
+    /* (function attributes must not be set while the stream captures: the scoring pass's dynamic LDS, once, up front) */
+    if (ud->S.win_K > 0) {
+        const int32_t rc0 = uw_launch(ud, n, 0, true);
+        if (rc0 != S3A_OK) return rc0;
+    }
+    hipGraph_t graph = NULL;
+    hipGraphExec_t exec = NULL;
+    if (hipStreamBeginCapture(ud->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { s3a_set_error("s3a_uttdec: hipStreamBeginCapture failed: %s", hipGetErrorString(hipGetLastError())); return S3A_EHIP; }
+    int32_t rc = S3A_OK;
+    for (int32_t j = 0; j < G && rc == S3A_OK; j++) rc = enqueue_frame(ud, n, j, false);
+    if (rc == S3A_OK) hipLaunchKernelGGL(ku_advance, dim3(1), dim3(64), 0, ud->stream, ud->d_fgbase, G);
+    if (hipStreamEndCapture(ud->stream, &graph) != hipSuccess || !graph) { s3a_set_error("s3a_uttdec: hipStreamEndCapture failed: %s", hipGetErrorString(hipGetLastError())); return S3A_EHIP; }
+    if (rc != S3A_OK) { (void)hipGraphDestroy(graph); return rc; }
+    if (hipGraphInstantiate(&exec, graph, NULL, NULL, 0) != hipSuccess || !exec) { (void)hipGraphDestroy(graph); s3a_set_error("s3a_uttdec: hipGraphInstantiate failed: %s", hipGetErrorString(hipGetLastError())); return S3A_EHIP; }
+    (void)hipGraphDestroy(graph);
+    s3a_uttdec_s::FrameGraph fgr;
+    fgr.n = n; fgr.frames = G; fgr.exec = exec; fgr.S = ud->S;
+    ud->graphs.push_back(fgr);
+    *out = exec;
+    return S3A_OK;
+}
+
 /* download lane z's history table + frame statistics (after the frames have been enqueued) */
 static int32_t
 lane_fetch_fstat(s3a_uttdec_t *ud, int32_t z)
@@ -2218,6 +2280,16 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
     rc = S3A_OK;
     tm[1] = now();
     if (hipEventRecord(ud->ev0, ud->stream) != hipSuccess) rc = S3A_EHIP;
+    if (ud->use_graph && ud->prof_every == 0) {
+        hipGraphExec_t ge = NULL;
+        const int32_t G = graph_block_frames(ud);
+        rc = graph_for(ud, n_utt, &ge);
+        if (rc == S3A_OK && hipMemsetAsync(ud->d_fgbase, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
+        for (int32_t f = 0; f < maxT && rc == S3A_OK; f += G)
+            if (hipGraphLaunch(ge, ud->stream) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
+        if (rc == S3A_OK && hipMemsetAsync(ud->d_fgbase, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
+    }
+    else
     for (int32_t f = 0; f < maxT && rc == S3A_OK; f++)
         rc = enqueue_frame(ud, n_utt, f, ud->prof_every > 0 && f % ud->prof_every == 0);
     if (rc == S3A_OK && hipEventRecord(ud->ev1, ud->stream) != hipSuccess) rc = S3A_EHIP;
@@ -2351,7 +2423,9 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     if (ud->dag) { s3a_set_error("s3a_uttdec_decode_queue: the second pass needs a lane's history table after its utterance; decode without lane refill"); return S3A_EUNSUP; }
     HIPCHK(hipSetDevice(ud->device));
     const UShared &S = ud->S;
-    const int32_t n = min(ud->n_lanes, n_utt), E = S.win_K > 0 ? S.win_K : 1, D4x4 = S.D4 * 4, T = S.T;
+    const bool graph_mode = ud->use_graph && ud->prof_every == 0;
+    /* utterances begin at window boundaries (the look-ahead pass scores K frames of all lanes); in graph mode at the blocks' */
+    const int32_t n = min(ud->n_lanes, n_utt), E = graph_mode ? graph_block_frames(ud) : (S.win_K > 0 ? S.win_K : 1), D4x4 = S.D4 * 4, T = S.T;
     int32_t rc;
     ud->n_utt = 0; ud->q_n = 0;
     std::vector<size_t> row0((size_t)n_utt + 1, 0);
@@ -2468,11 +2542,22 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     rc = S3A_OK;
     if (hipEventRecord(ud->ev0, ud->stream) != hipSuccess) rc = S3A_EHIP;
     size_t ei = 0;
+    if (graph_mode) {
+        hipGraphExec_t ge = NULL;
+        rc = graph_for(ud, n, &ge);
+        if (rc == S3A_OK && hipMemsetAsync(ud->d_fgbase, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
+        for (int32_t fg = 0; fg < F_end && rc == S3A_OK; fg += E) {        /* (E = the graph's block: refill events fall between blocks) */
+            if (ei < evs.size() && evs[ei].f == fg) rc = run_event(evs[ei++]);
+            if (rc == S3A_OK && hipGraphLaunch(ge, ud->stream) != hipSuccess) { s3a_set_error("s3a_uttdec_decode_queue: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
+        }
+    }
+    else
     for (int32_t fg = 0; fg < F_end && rc == S3A_OK; fg++) {
         if (ei < evs.size() && evs[ei].f == fg) rc = run_event(evs[ei++]);
         if (rc == S3A_OK) rc = enqueue_frame(ud, n, fg, ud->prof_every > 0 && fg % ud->prof_every == 0);
     }
     while (rc == S3A_OK && ei < evs.size()) rc = run_event(evs[ei++]);
+    if (graph_mode && rc == S3A_OK && hipMemsetAsync(ud->d_fgbase, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
     if (rc == S3A_OK && hipEventRecord(ud->ev1, ud->stream) != hipSuccess) rc = S3A_EHIP;
     if (rc == S3A_OK && hipMemcpyAsync(ud->q_hdr_h, ud->q_hdr_d, ((size_t)n_utt * UH_N + 1) * 4, hipMemcpyDeviceToHost, ud->stream) != hipSuccess) rc = S3A_EHIP;
     if (hipStreamSynchronize(ud->stream) != hipSuccess && rc == S3A_OK) { s3a_set_error("s3a_uttdec_decode_queue: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }

@@ -709,13 +709,16 @@ s3a_uttdec_t *s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g,
  * (-1: ~1024 (lane, frame) slots per pass; 0: per-frame scoring kernels), window_fpc = slots per workgroup chunk of that pass;
  * g_eval / g_res / scan_g / gy / sweep_k = grid sizes of the HMM evaluation, the resolve kernels, the scan, the gated scorer and
  * the nodes per thread of the resolve sweep; no_multi = no shared CD pass of the per-frame scorer; framecheck = run the
- * per-frame invariant kernel; times = print the host-side phases of every decode to stderr.  s3a_uttdec_init is
+ * per-frame invariant kernel; times = print the host-side phases of every decode to stderr; graph = HIP-graph replay of the
+ * frames' launches (below).  s3a_uttdec_init is
  * s3a_uttdec_init_opts with opts = NULL (defaults); the library never reads the environment for these:
  * s3a_uttdec_opts_from_env fills the struct from the S3A_UTT_* variables for hosts that want that (the drop-in program,
  * the test harness). */
 typedef struct {
     int32_t many, big_wl, window, window_fpc, g_eval, g_res, scan_g, gy, sweep_k, no_multi, framecheck, times;
-    int32_t reserved[4];
+    int32_t graph;          /* 1: the frames' launches are captured ONCE as a HIP graph (a block of `window` frames per lane count)
+                             * and replayed block after block: one graph launch per block instead of ~13 kernel launches per frame */
+    int32_t reserved[3];
 } s3a_uttdec_opts_t;
 void s3a_uttdec_opts_default(s3a_uttdec_opts_t *o);
 void s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o);

@@ -128,3 +128,25 @@ def test_drop_in_program_with_lane_refill(tmp_path, env):
     assert p.returncode == 0, p.stderr[-2500:]
     assert open(hyp).read() == open(f"{D}/ref_mode4_trigram.match").read()
     assert open(seg).read() == open(f"{D}/ref_mode4_trigram.matchseg").read()
+
+
+@pytest.mark.parametrize("n_lanes,window", [(1, None), (5, None), (3, 0), (8, 16)])
+def test_graph_mode_replays_a_block_of_frames(gpu_lib, tidigits_bundle, monkeypatch, n_lanes, window):
+    """s3a_uttdec_opts_t.graph: the launches of a block of frames captured once as a HIP graph and replayed (the frame number
+    reaches the kernels through a device counter); plain decodes and queues, the same bytes as stream mode = the reference"""
+    monkeypatch.setenv("S3A_UTT_GRAPH", "1")
+    if window is not None:
+        monkeypatch.setenv("S3A_UTT_WIN", str(window))
+    dec = bundle.Decoder(tidigits_bundle, n_lanes)
+    utts, feats = tidigits_feats(gpu_lib)
+    rm, rs = ref_lines()
+    for k in range(0, 2 * n_lanes, n_lanes):                # two plain decodes (the second replays the first's graph)
+        chunk = feats[k:k + n_lanes]
+        dec.decode(chunk)
+        for z in range(len(chunk)):
+            assert dec.format_var(*dec.hyp_var(z, utts[k + z][1], k + z)) == (rm[k + z], rs[k + z])
+    dec.decode_queue(feats)
+    m, s = queue_lines(dec, utts)
+    assert m == rm and s == rs
+    dec.decode(feats[:1])                                   # fewer lanes: another graph
+    assert dec.format_var(*dec.hyp_var(0, utts[0][1], 0)) == (rm[0], rs[0])
