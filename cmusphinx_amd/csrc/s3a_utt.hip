@@ -1607,7 +1607,7 @@ s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o)
     o->window_fpc = num("S3A_UTT_WIN_FPC", 0); o->g_eval = num("S3A_UTT_GEVAL", 0); o->g_res = num("S3A_UTT_GRES", 0);
     o->scan_g = num("S3A_UTT_SCAN_G", 0); o->gy = num("S3A_UTT_GY", 0); o->sweep_k = num("S3A_UTT_URK", 0);
     o->no_multi = getenv("S3A_UTT_NO_MULTI") != NULL; o->framecheck = getenv("S3A_UTT_FRAMECHECK") != NULL;
-    o->times = num("S3A_UTT_TIMES", 0); o->graph = num("S3A_UTT_GRAPH", 0);
+    o->times = num("S3A_UTT_TIMES", 0); o->graph = num("S3A_UTT_GRAPH", 0); o->window_max = num("S3A_UTT_WIN_MAX", 0);
 }
 
 extern "C" s3a_uttdec_t *
@@ -1784,13 +1784,15 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     }
 
     /* look-ahead scoring (ku_score_window): the 39/40-dimensional case with a 16-bit log-add table and at most 64
-     * Gaussian slots per senone; K frames per window so that a window of all lanes is ~1024 (lane, frame) slots -- what
-     * a model pass amortises over -- within 8 .. 64 frames.  opts->window = 0: the per-frame scoring kernels (tests). */
+     * Gaussian slots per senone; K = 8 frames per window: from 128 lanes on that is the ~1024 (lane, frame) slots a model pass
+     * amortises over, and with fewer lanes a longer window buys < 1 % (measured: one lane 94.6 x real time with K = 64, 93.5
+     * with 8; 8 and 32 lanes: no difference) while a refilled lane has to wait for a window boundary.  opts->window_max > 0:
+     * up to that many frames so that a pass has ~1024 slots; opts->window: exactly that (0: the per-frame scoring kernels). */
     {
         int32_t K = 0;
         if (d->D4 == D4MAIN && d->CP <= 64 && d->Gpad % 512 == 0) {
-            K = (1024 + n_lanes - 1) / n_lanes;
-            K = min(64, max(8, ((K + 7) / 8) * 8));
+            K = 8;
+            if (O.window_max > 8) K = min(((O.window_max + 7) / 8) * 8, max(8, (((1024 + n_lanes - 1) / n_lanes + 7) / 8) * 8));
             if (O.window >= 0) K = (O.window + 7) / 8 * 8;
         }
         S.win_K = K;

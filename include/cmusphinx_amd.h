@@ -706,7 +706,7 @@ s3a_uttdec_t *s3a_uttdec_init(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g,
 /* The same with the engine's tuning options as arguments (all zero / -1 = the library's choice; every variant gives the
  * same bits): many = lanes from which the grids / kernels for many lanes per launch are used (default 32); big_wl = the word
  * level's candidate phases as launches of their own (-1: by the beams' width); window = frames per look-ahead scoring pass
- * (-1: ~1024 (lane, frame) slots per pass; 0: per-frame scoring kernels), window_fpc = slots per workgroup chunk of that pass;
+ * (-1: 8, or up to window_max for ~1024 (lane, frame) slots per pass; 0: per-frame scoring kernels), window_fpc = slots per workgroup chunk of that pass;
  * g_eval / g_res / scan_g / gy / sweep_k = grid sizes of the HMM evaluation, the resolve kernels, the scan, the gated scorer and
  * the nodes per thread of the resolve sweep; no_multi = no shared CD pass of the per-frame scorer; framecheck = run the
  * per-frame invariant kernel; times = print the host-side phases of every decode to stderr; graph = HIP-graph replay of the
@@ -718,7 +718,8 @@ typedef struct {
     int32_t many, big_wl, window, window_fpc, g_eval, g_res, scan_g, gy, sweep_k, no_multi, framecheck, times;
     int32_t graph;          /* 1: the frames' launches are captured ONCE as a HIP graph (a block of `window` frames per lane count)
                              * and replayed block after block: one graph launch per block instead of ~13 kernel launches per frame */
-    int32_t reserved[3];
+    int32_t window_max;     /* > 0: the longest look-ahead window the library may choose (lane refill happens at window boundaries) */
+    int32_t reserved[2];
 } s3a_uttdec_opts_t;
 void s3a_uttdec_opts_default(s3a_uttdec_opts_t *o);
 void s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o);
