@@ -28,6 +28,7 @@
 #include <string.h>
 #include <limits.h>
 #include <vector>
+#include <map>
 
 #include "s3a_device.h"
 #include "s3a_structs.h"
@@ -2397,6 +2398,35 @@ s3a_uttdec_decode_dev(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_
  * words per utterance (s3a_uttdec_queue_hyp); the history tables are reused by the lanes' next utterances and are not
  * available (no s3a_uttdec_result, no second pass).
  */
+/* The refill schedule, host arithmetic alone (no device): utterance u of the queue runs in lane[u] from engine frame f0[u]
+ * on.  The first n_lanes utterances start at frame 0; from then on, at every multiple of `boundary` frames, every lane whose
+ * utterance has ended takes the queue's next one (lanes in index order).  Returns the engine frame at which the last lane is
+ * done (a multiple of `boundary`), or S3A_EINVAL. */
+extern "C" int32_t
+s3a_queue_schedule(int32_t n_lanes, int32_t boundary, int32_t n_utt, const int32_t *n_frames, int32_t *lane, int32_t *f0)
+{
+    if (n_lanes <= 0 || boundary <= 0 || n_utt <= 0 || !n_frames || !lane || !f0) return S3A_EINVAL;
+    const int32_t n = min(n_lanes, n_utt);
+    std::vector<int32_t> busy_until((size_t)n, 0);
+    std::vector<char> busy((size_t)n, 0);
+    int32_t next = 0;
+    for (int32_t u = 0; u < n_utt; u++) if (n_frames[u] <= 0) return S3A_EINVAL;
+    for (long long F = 0;; F += boundary) {
+        if (F > INT_MAX - boundary) return S3A_EINVAL;
+        bool any = false;
+        for (int32_t z = 0; z < n; z++) {
+            if (busy[z] && busy_until[z] <= F) busy[z] = 0;
+            if (!busy[z] && next < n_utt) {
+                lane[next] = z; f0[next] = (int32_t)F;
+                busy_until[z] = (int32_t)F + n_frames[next]; busy[z] = 1;
+                next++;
+            }
+            any = any || busy[z];
+        }
+        if (!any) return (int32_t)F;
+    }
+}
+
 template <typename TP>
 static int32_t
 q_grow(TP **d, TP **h, size_t *cap, size_t need, const char *what)
@@ -2462,37 +2492,36 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
         hl.sc->skip_count = 0;
         if (hl.epoch < 1) hl.epoch = 1;
     }
-    /* the schedule: who ends and who begins at which boundary */
+    /* the schedule (s3a_queue_schedule: host arithmetic on the lengths), then who ends and who begins at which boundary */
     struct Ev { int32_t f, o_el, o_bl, n_end, n_beg, max_nfr; };
     std::vector<Ev> evs;
-    std::vector<int32_t> sched, lane_utt((size_t)n, -1), lane_end((size_t)n, 0), last_utt((size_t)n, -1);
+    std::vector<int32_t> sched, u_lane((size_t)n_utt), u_f0((size_t)n_utt), last_utt((size_t)n, -1);
     if ((rc = q_grow(&ud->q_ctx_d, &ud->q_ctx_h, &ud->q_ctx_cap, (size_t)n_utt, "contexts")) != S3A_OK) return rc;
-    int32_t next = 0;
-    for (int32_t F = 0;; F += E) {
-        std::vector<int32_t> el, eu, bl, bu;
-        int32_t mx = 0;
-        for (int32_t z = 0; z < n; z++)
-            if (lane_utt[z] >= 0 && lane_end[z] <= F) { el.push_back(z); eu.push_back(lane_utt[z]); lane_utt[z] = -1; }
-        for (int32_t z = 0; z < n && next < n_utt; z++)
-            if (lane_utt[z] < 0) {
-                const int32_t u = next++;
-                HostLane &hl = ud->lane[z];
-                if ((rc = utt_context(ud, ud->q_ctx_h[u], fd[u], n_frames[u], hl.epoch, F, u)) != S3A_OK) return rc;
-                hl.epoch += n_frames[u] + 1;
-                hl.nfr = n_frames[u];
-                bl.push_back(z); bu.push_back(u); lane_utt[z] = u; lane_end[z] = F + n_frames[u]; last_utt[z] = u;
-                mx = max(mx, n_frames[u]);
-            }
-        if (!el.empty() || !bl.empty()) {
-            Ev e = { F, (int32_t)sched.size(), 0, (int32_t)el.size(), (int32_t)bl.size(), mx };
-            sched.insert(sched.end(), el.begin(), el.end()); sched.insert(sched.end(), eu.begin(), eu.end());
+    {
+        const int32_t fe = s3a_queue_schedule(n, E, n_utt, n_frames, u_lane.data(), u_f0.data());
+        if (fe < 0) return fe;
+        struct Lists { std::vector<int32_t> el, eu, bl, bu; int32_t mx = 0; };
+        std::map<int32_t, Lists> at;
+        for (int32_t u = 0; u < n_utt; u++) {           /* (queue order = the order of a lane's utterances) */
+            const int32_t z = u_lane[u], F = u_f0[u], Fe = ((F + n_frames[u] + E - 1) / E) * E;
+            HostLane &hl = ud->lane[z];
+            if ((rc = utt_context(ud, ud->q_ctx_h[u], fd[u], n_frames[u], hl.epoch, F, u)) != S3A_OK) return rc;
+            hl.epoch += n_frames[u] + 1;
+            hl.nfr = n_frames[u];
+            last_utt[z] = u;
+            Lists &b = at[F];
+            b.bl.push_back(z); b.bu.push_back(u); b.mx = max(b.mx, n_frames[u]);
+            Lists &e = at[Fe];
+            e.el.push_back(z); e.eu.push_back(u);
+        }
+        for (auto &kv : at) {
+            const Lists &l = kv.second;
+            Ev e = { kv.first, (int32_t)sched.size(), 0, (int32_t)l.el.size(), (int32_t)l.bl.size(), l.mx };
+            sched.insert(sched.end(), l.el.begin(), l.el.end()); sched.insert(sched.end(), l.eu.begin(), l.eu.end());
             e.o_bl = (int32_t)sched.size();
-            sched.insert(sched.end(), bl.begin(), bl.end()); sched.insert(sched.end(), bu.begin(), bu.end());
+            sched.insert(sched.end(), l.bl.begin(), l.bl.end()); sched.insert(sched.end(), l.bu.begin(), l.bu.end());
             evs.push_back(e);
         }
-        bool busy = false;
-        for (int32_t z = 0; z < n; z++) busy = busy || lane_utt[z] >= 0;
-        if (!busy) break;
     }
     const int32_t F_end = evs.back().f;           /* (the last event only ends lanes) */
     if ((rc = q_grow(&ud->q_sched_d, &ud->q_sched_h, &ud->q_sched_cap, sched.size(), "schedule")) != S3A_OK) return rc;

@@ -196,6 +196,7 @@ _SIGS = {
     "s3a_uttdec_decode_dev": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_decode_queue": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_decode_queue_dev": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_queue_schedule": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "s3a_uttdec_queue_status": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "s3a_uttdec_queue_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
@@ -287,6 +288,16 @@ def check(rc, L=None):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def queue_schedule(n_lanes, boundary, n_frames):
+    """the lane-refill schedule of s3a_uttdec_decode_queue (host arithmetic): -> (lane[u], f0[u], engine frames in all)"""
+    nf = np.ascontiguousarray(n_frames, np.int32)
+    lane, f0 = np.zeros(len(nf), np.int32), np.zeros(len(nf), np.int32)
+    total = load().s3a_queue_schedule(int(n_lanes), int(boundary), len(nf), _p(nf), _p(lane), _p(f0))
+    if total < 0:
+        raise S3AError(f"s3a_queue_schedule: error {total}")
+    return lane, f0, int(total)
 
 
 def device_count() -> int:

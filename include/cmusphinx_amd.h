@@ -751,6 +751,11 @@ int32_t s3a_uttdec_decode_queue_dev(s3a_uttdec_t *ud, int32_t n_utt, const float
                                     const int32_t *n_frames, int32_t feat_stride);
 int32_t s3a_uttdec_queue_status(s3a_uttdec_t *ud, int32_t utt, int32_t *err, int32_t *stopped_at,
                                 int32_t *max_cand, int32_t *max_new);
+/* the schedule s3a_uttdec_decode_queue follows, host arithmetic on the lengths alone (no device): utterance u runs in
+ * lane[u] from engine frame f0[u] on; lanes are refilled at multiples of `boundary` frames (the engine's: its look-ahead
+ * window, s3a_uttdec_window; 1 without look-ahead scoring).  Returns the engine frames the whole queue takes. */
+int32_t s3a_queue_schedule(int32_t n_lanes, int32_t boundary, int32_t n_utt, const int32_t *n_frames,
+                           int32_t *lane, int32_t *f0);
 /* diagnostics: time lane z's last utterance spent in each phase of the one-workgroup word level, in 100 MHz ticks
  * ([0] frame record + exits, [1] P1, [2] P2 trigram scores, [3] P3 hash insert, [4] P4 entry places, [5] P5 staging,
  * [6] pruning, [7] table + LM contexts, [8] word transitions) */
