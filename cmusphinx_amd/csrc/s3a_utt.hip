@@ -2139,8 +2139,14 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
         else if (n >= ud->many) UKL(UK_RESOLVE, ku_resolve_lists<false>, dim3(ud->g_res + GB, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
         else UKL(UK_RESOLVE, ku_resolve<false>, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
     }
-    /* chained scan: a few workgroups per tree take the chunks in turn (about as many workgroups as the chip holds) */
-    const int32_t scan_gc = ud->scan_gc > 0 ? min(ud->scan_gc, ud->scan_nc) : max(1, min(ud->scan_nc, max(1, 768 / max(1, T * n))));
+    /* the scan over long lists: either one workgroup per possible chunk, chained (a chunk waits for chunks with SMALLER
+     * numbers only = workgroups dispatched before it: the wait ends whatever else runs on the chip), when that is no more
+     * workgroups than the chip holds -- a single lane, wide beams --, or one workgroup per tree that walks the chunks itself.
+     * (Round 2 had a few workgroups per tree taking the chunks in turn: workgroup 0's second chunk then waits for the LAST
+     * workgroup's first, a workgroup dispatched after it -- with several engines on the chip every slot can end up held by
+     * such a waiter whose partner is not dispatched yet: observed as WL_E_SCAN time-outs with 8 engines of 64 lanes;
+     * opts->scan_g still asks for that variant.) */
+    const int32_t scan_gc = ud->scan_gc > 0 ? min(ud->scan_gc, ud->scan_nc) : ((long long)T * n * ud->scan_nc <= 768 ? ud->scan_nc : 1);
     /* (one workgroup per tree: it walks the chunks with the totals in a register -- no flags, no look-back) */
     UKL(UK_SCAN, ku_scan, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, scan_gc == 1 ? 1 : ud->scan_nc, scan_gc, f);
     /* (many lanes: fewer emission workgroups per tree -- each sweeps further -- instead of thousands of idle ones) */
