@@ -25,7 +25,7 @@
 static inline int32_t scan_workgroups(int32_t rows, int chained)
 {
     /* (chained = S3A_SCAN_CHAINED when the search object was made: the chained scan whatever the length -- for the tests) */
-    return (rows >= SCAN_LONG_LIST || chained) ? (rows + 1023) / 1024 : 1;
+    return (rows >= SCAN_LONG_LIST || chained) ? (rows + SCAN_THREADS - 1) / SCAN_THREADS : 1;
 }
 #define M3BLOCK 64          /* k_dec_enter3_mark: same reason (a composite leaf marks ~140 scattered senones) */
 #define RSBLOCK 64          /* k_dec_resolve: the nodes something happens to are neighbours; small workgroups spread them over more CUs */

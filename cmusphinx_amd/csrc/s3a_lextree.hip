@@ -520,7 +520,7 @@ alloc_state(s3a_lexsearch_t *ls)
     {
         int32_t maxn = 1;
         for (int32_t t = 0; t < n_tree; t++) maxn = maxn > ls->node_base[t + 1] - ls->node_base[t] ? maxn : ls->node_base[t + 1] - ls->node_base[t];
-        ls->scan_chunks = (maxn + 1023) / 1024;
+        ls->scan_chunks = (maxn + SCAN_THREADS - 1) / SCAN_THREADS;
         ls->scan_epoch = 0;
         DMALLOC(ls->d_scan_agg, (size_t)n_tree * ls->scan_chunks * 8); DMALLOC(ls->d_scan_pre, (size_t)n_tree * ls->scan_chunks * 8);
         DMALLOC(ls->d_scan_flag, (size_t)n_tree * ls->scan_chunks * 4);

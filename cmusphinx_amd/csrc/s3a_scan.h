@@ -3,7 +3,9 @@
 #define S3A_SCAN_H
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifndef SCAN_THREADS
 #define SCAN_THREADS 1024
+#endif
 
 /* exclusive scan of src[0..n) into dst[0..n) (may alias) by one workgroup; the total goes to *total */
 __device__ __forceinline__ void
