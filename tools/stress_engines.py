@@ -45,6 +45,25 @@ for g in groups:
 print("truth:", len(truth), "utterances by one engine alone", flush=True)
 pool = ThreadPoolExecutor(E)
 bad_total = 0
+if os.environ.get("STRESS_QUEUE"):
+    # lane refill under concurrency: every round every engine decodes a different random share of the utterances as ONE
+    # queue in a different random order (utterances land in different lanes, begin at different engine frames, after
+    # different predecessors), E engines side by side
+    rng = np.random.default_rng(12345)
+    for r in range(R):
+        perm = rng.permutation(U)
+        shares = [list(map(int, perm[e::E])) for e in range(E)]
+
+        def one_q(e):
+            lib.check(L.s3a_set_device(0))
+            g = shares[e]
+            decs[e].ud.decode_queue_dev([fdev[k] for k in g], [nfr[k] for k in g], 40)
+            return [(k, e, q) for q, k in enumerate(g) if decs[e].format_var(*decs[e].queue_hyp(q, utts[k], k)) != truth[k]]
+        bad = [b for o in pool.map(one_q, range(E)) for b in o]
+        bad_total += len(bad)
+        print(f"queue round {r}: {len(bad)} mismatches (utterance, engine, place in the queue)", bad[:10], flush=True)
+    print("TOTAL mismatches:", bad_total)
+    sys.exit(1 if bad_total else 0)
 for r in range(R):
     per = [[] for _ in range(E)]
     for i, g in enumerate(groups * max(1, (2 * E) // max(1, len(groups)))):
