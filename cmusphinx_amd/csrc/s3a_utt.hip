@@ -2083,7 +2083,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
         hipLaunchKernelGGL(__VA_ARGS__);                                                                         \
         if (prof) { (void)hipEventRecord(b_, st); ud->prof_ev.push_back({ cls, a_, b_ }); } } while (0)
     UKL(UK_ENTER1, ku_enter1, dim3(ud->g_ent, 1, n), dim3(256), 0, st, LN, S, f);
-    UKL(UK_ENTER2, ku_enter2, dim3(n >= ud->many ? 24 : WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+    UKL(UK_ENTER2, ku_enter2, dim3(n >= ud->many ? 12 : WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     UKL(UK_ENTER3, ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S, f);
     const int32_t g_ci = (S.n_ci_sen * S.CP + 255) / 256, g_cd = ((S.n_sen - S.n_ci_sen) * S.CP + 255) / 256;
     const int32_t g_cs = (S.n_cs + 255) / 256;         /* composite senones: a wave looks at 64 */
