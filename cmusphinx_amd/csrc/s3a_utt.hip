@@ -1728,6 +1728,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->urk = O.sweep_k > 0 ? O.sweep_k : UR_K;
     ud->g_ent = max(1, min((proto->ent_cap + 255) / 256, 256));
     ud->g_mark = max(1, min((proto->ent_cap + M3BLOCK - 1) / M3BLOCK + ((maxn + M3BLOCK - 1) / M3BLOCK) * T, 1024));
+    if (n_lanes >= ud->many) ud->g_mark = min(ud->g_mark, 128);     /* (many lanes: 1024 workgroups per lane were 131 k per launch, most of them idle: 50 -> 30 us per 128-lane launch, 331 -> 349 k frames/s) */
     ud->scan_nc = (cfg->maxhmmpf >= SCAN_LONG_LIST && maxn >= SCAN_LONG_LIST) ? (maxn + SCAN_THREADS - 1) / SCAN_THREADS : 1;
     ud->scan_gc = O.scan_g;
     /* lextree_hmm_histbin can only fire when more than 1.5 x maxhmmpf HMMs can be active at all */
@@ -2134,7 +2135,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     else
         UKL(UK_HMM_EVAL, (ku_hmm_eval<64, 3>), dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
     {
-        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 16 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
+        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 8 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
         if (ud->hist_possible) UKL(UK_HIST_SORT, ku_hist_sort, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     }
     if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
@@ -2161,7 +2162,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     /* (one workgroup per tree: it walks the chunks with the totals in a register -- no flags, no look-back) */
     UKL(UK_SCAN, ku_scan, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, scan_gc == 1 ? 1 : ud->scan_nc, scan_gc, f);
     /* (many lanes: fewer emission workgroups per tree -- each sweeps further -- instead of thousands of idle ones) */
-    UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= ud->many && !ud->big_wl ? 2 : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
+    UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= ud->many && !ud->big_wl ? 1 : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
     if (ud->big_wl) {
         const dim3 gb(WL_BIG_G, 1, n), one(1, 1, n), tb(WL_THREADS);
         UKL(UK_WL_P2, ku_wl_p2, gb, tb, 0, st, LN, ud->lm->d, ud->dict, ud->par, f);
