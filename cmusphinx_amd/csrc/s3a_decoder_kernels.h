@@ -714,8 +714,9 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
  * that they have nothing to do).  A chunk still only waits for chunks with smaller numbers, which belong to workgroups
  * of the same tree that are dispatched together with it (GC is small), so the wait ends as before.
  */
+template <int NT>
 __device__ __forceinline__ void
-d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
+d_dec_scan_t(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
            const int32_t *__restrict__ act, const int32_t *__restrict__ nact,
            const int32_t *__restrict__ wid, const int32_t *__restrict__ prob,
            const int32_t *__restrict__ outs, const int32_t *__restrict__ outh,
@@ -730,13 +731,13 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     __shared__ int32_t s_wth, s_last;
     __shared__ int32_t s_gp[3];
     __shared__ int32_t s_thr[8];
-    __shared__ unsigned long long s_wsum[SCAN_THREADS / 64], s_chunk, s_prefix;
+    __shared__ unsigned long long s_wsum[NT / 64], s_chunk, s_prefix;
     __shared__ int32_t s_exit_open;
     /* GC <= NC workgroups per tree are launched; workgroup j owns chunks j, j + GC, ... (GC == NC: one each) */
     const int32_t t = BX / GC, j = BX - t * GC, b = node_base[t], na = nact[t];
     const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t c_step = (NC == 1 ? 1 : GC) * SCAN_THREADS;
-    const bool live = j * SCAN_THREADS < na || j == 0;      /* (chunk 0 also reports an empty tree's totals) */
+    const int32_t c_step = (NC == 1 ? 1 : GC) * NT;
+    const bool live = j * NT < na || j == 0;      /* (chunk 0 also reports an empty tree's totals) */
     /* a chunk's list entries: turn count; word id / exit score by list position (after a histogram reordering --
      * the evaluation wrote them before it -- through the node).  The first chunk's loads are issued before the
      * thresholds are worked out, the next chunk's before the scan of the current one. */
@@ -751,7 +752,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
             cnt[b + (i_)] = 0;                                  /* the accumulator of the next frame */ \
         }                                                                                           \
     } while (0)
-    SCAN_FETCH(j * SCAN_THREADS + tid);
+    SCAN_FETCH(j * NT + tid);
     /* (a workgroup past the end of its tree's list -- the grid is sized by the host's bound -- only reports in) */
     if (live) {
         if (tid == 0) {
@@ -767,8 +768,8 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
         const int32_t wth = s_wth;
         unsigned long long carry = 0ull;        /* NC == 1: this workgroup walks all chunks, totals in a register */
         /* NC > 1: one chunk per workgroup (the host sizes NC by its bound on the list length), chained */
-        for (int32_t c0 = j * SCAN_THREADS; c0 == j * SCAN_THREADS || c0 < na; c0 += c_step) {
-            const int32_t i = c0 + tid, jc = c0 / SCAN_THREADS;
+        for (int32_t c0 = j * NT; c0 == j * NT || c0 < na; c0 += c_step) {
+            const int32_t i = c0 + tid, jc = c0 / NT;
             const int32_t u = u2, c = c2, w = w2, os = os2;
             SCAN_FETCH(i + c_step);
             /* both ordered compactions in one scan: the turn bases (exclusive sum of the turn counts; the
@@ -785,15 +786,15 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
             if (lane == 63) s_wsum[wave] = incl;
             __syncthreads();
             if (wave == 0) {
-                const unsigned long long ws = (lane < SCAN_THREADS / 64) ? s_wsum[lane] : 0ull;
+                const unsigned long long ws = (lane < NT / 64) ? s_wsum[lane] : 0ull;
                 unsigned long long wi = ws;
 #pragma unroll
-                for (int o = 1; o < SCAN_THREADS / 64; o <<= 1) {
+                for (int o = 1; o < NT / 64; o <<= 1) {
                     const unsigned long long y = __shfl_up(wi, o, 64);
                     if (lane >= o) wi += y;
                 }
-                if (lane < SCAN_THREADS / 64) s_wsum[lane] = wi - ws;   /* exclusive wave offsets */
-                if (lane == SCAN_THREADS / 64 - 1) s_chunk = wi;        /* the chunk's totals */
+                if (lane < NT / 64) s_wsum[lane] = wi - ws;   /* exclusive wave offsets */
+                if (lane == NT / 64 - 1) s_chunk = wi;        /* the chunk's totals */
             }
             __syncthreads();
             unsigned long long prefix = carry;
@@ -837,7 +838,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
                     if (oh == -1) s_exit_open = 1;
                 }
             }
-            if (tid == 0 && na <= c0 + SCAN_THREADS) {      /* the tree's last chunk: its totals */
+            if (tid == 0 && na <= c0 + NT) {      /* the tree's last chunk: its totals */
                 nnxt[t] = (int32_t)(uint32_t)carry;
                 nexit[t] = (int32_t)(carry >> 32);
             }
@@ -875,7 +876,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     if (gpart_n > 0) {
         volatile const int32_t *vg = gpart;
         int32_t gb = INT_MIN, gs = 0, gg = 0;
-        for (int32_t q = threadIdx.x; q < gpart_n; q += SCAN_THREADS) {
+        for (int32_t q = threadIdx.x; q < gpart_n; q += NT) {
             gb = max(gb, vg[q]); gs += vg[gpart_n + q]; gg += vg[2 * gpart_n + q];
         }
 #pragma unroll
@@ -887,8 +888,8 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     __syncthreads();
     const int32_t hdr = 6 * T + 16;
     volatile const int32_t *vbest = best, *vnexit = nexit, *vex = exits, *vmisc = misc, *vnnxt = nnxt;
-    for (int32_t q = threadIdx.x; q < 2 * T; q += SCAN_THREADS) pack[q] = vbest[q];
-    for (int32_t q = threadIdx.x; q < T; q += SCAN_THREADS) {
+    for (int32_t q = threadIdx.x; q < 2 * T; q += NT) pack[q] = vbest[q];
+    for (int32_t q = threadIdx.x; q < T; q += NT) {
         pack[2 * T + q] = nact[q];
         pack[3 * T + 8 + q] = vnexit[q];
         pack[4 * T + 8 + q] = vnexit[T + q];
@@ -905,7 +906,7 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     int32_t off = 0;
     for (int32_t tt = 0; tt < T; tt++) {
         const int32_t n = vnexit[tt], bb = node_base[tt];
-        for (int32_t q = threadIdx.x; q < n; q += SCAN_THREADS) {
+        for (int32_t q = threadIdx.x; q < n; q += NT) {
             const int32_t k = off + q;
             if (k < max_exits) {
                 pack[hdr + 3 * k] = vex[bb + q];
@@ -917,9 +918,25 @@ d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     }
     __syncthreads();
     /* reset the per-frame accumulators for the next frame */
-    for (int32_t q = threadIdx.x; q < 2 * T; q += SCAN_THREADS) { best[q] = INT_MIN; nexit[q] = 0; }
+    for (int32_t q = threadIdx.x; q < 2 * T; q += NT) { best[q] = INT_MIN; nexit[q] = 0; }
     if (threadIdx.x < 8) misc[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 5) ? INT_MIN : 0;
     if (threadIdx.x == 0) *done = 0;
+}
+
+__device__ __forceinline__ void
+d_dec_scan(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ node_base,
+           const int32_t *__restrict__ act, const int32_t *__restrict__ nact,
+           const int32_t *__restrict__ wid, const int32_t *__restrict__ prob,
+           const int32_t *__restrict__ outs, const int32_t *__restrict__ outh,
+           const int32_t *__restrict__ selfemit, int32_t *cnt, int32_t *base, int32_t *nxt, int32_t *nnxt,
+           int32_t *pos, int32_t *posf, int32_t *best, int32_t *exits, int32_t *nexit,
+           const int32_t *hbin, int32_t *misc, int32_t *done, int32_t *pack, int32_t max_exits,
+           const int32_t *gpart, int32_t gpart_n, const int32_t *poswid, const int32_t *posout, int32_t reordered,
+           unsigned long long *st_agg, unsigned long long *st_pre, int32_t *st_flag, int32_t st_stride,
+           int32_t epoch, int32_t NC, int32_t GC,
+        const int32_t BX, const int32_t BY)
+{
+    d_dec_scan_t<SCAN_THREADS>(N, T, cf, bm, node_base, act, nact, wid, prob, outs, outh, selfemit, cnt, base, nxt, nnxt, pos, posf, best, exits, nexit, hbin, misc, done, pack, max_exits, gpart, gpart_n, poswid, posout, reordered, st_agg, st_pre, st_flag, st_stride, epoch, NC, GC, BX, BY);
 }
 
 /*

@@ -1064,7 +1064,8 @@ ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t fg)
                   L.act[cur], blockIdx.x, (int32_t)gridDim.x - GB, GB, UHX);
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t GC, int32_t fg)
 {
     LANE;
@@ -1073,7 +1074,7 @@ ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t GC, int3
     int32_t n = 0;
     for (int32_t t = 0; t < S.T; t++) n += nact_cur[t];
     const int32_t reordered = n > bm.maxhmmpf + (bm.maxhmmpf >> 1) ? 1 : 0;
-    d_dec_scan(S.N, S.T, f, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit,
+    d_dec_scan_t<NT>(S.N, S.T, f, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit,
                L.cnt, L.base, L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, L.best, L.exits, L.nexit, L.hbin, L.misc,
                (int32_t *)NULL /* no tail: ku_wordlevel assembles the frame record */, L.pack, S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, reordered, L.scan_agg, L.scan_pre,
                L.scan_flag, S.scan_chunks, ctx->scan_epoch, NC, GC, blockIdx.x, 0);
@@ -1473,6 +1474,7 @@ struct s3a_uttdec_s {
     int32_t tables_fetched, fstat_fetched;
     /* graph mode (s3a_uttdec_opts_t.graph): a block of frames captured once per lane count, replayed block after block */
     int32_t use_graph;
+    int32_t scan_small_from;    /* lanes per launch from which ku_scan runs with 256-thread workgroups */
     int32_t *d_fgbase;
     struct FrameGraph { int32_t n, frames; hipGraphExec_t exec; UShared S; };
     std::vector<FrameGraph> graphs;
@@ -1619,7 +1621,7 @@ s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o)
     o->window_fpc = num("S3A_UTT_WIN_FPC", 0); o->g_eval = num("S3A_UTT_GEVAL", 0); o->g_res = num("S3A_UTT_GRES", 0);
     o->scan_g = num("S3A_UTT_SCAN_G", 0); o->gy = num("S3A_UTT_GY", 0); o->sweep_k = num("S3A_UTT_URK", 0);
     o->no_multi = getenv("S3A_UTT_NO_MULTI") != NULL; o->framecheck = getenv("S3A_UTT_FRAMECHECK") != NULL;
-    o->times = num("S3A_UTT_TIMES", 0); o->graph = num("S3A_UTT_GRAPH", 0); o->window_max = num("S3A_UTT_WIN_MAX", 0);
+    o->times = num("S3A_UTT_TIMES", 0); o->graph = num("S3A_UTT_GRAPH", 0); o->window_max = num("S3A_UTT_WIN_MAX", 0); o->scan_small_from = num("S3A_UTT_SCAN_SMALL", 0);
 }
 
 extern "C" s3a_uttdec_t *
@@ -1821,6 +1823,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     if (hipMemset(ud->d_fgbase, 0, 64) != hipSuccess) goto fail;
     ud->S.fgbase = ud->d_fgbase;
     ud->use_graph = O.graph != 0 && !ud->big_wl && !O.framecheck;
+    ud->scan_small_from = O.scan_small_from > 0 ? O.scan_small_from : 64;
     ud->hyp_wcap = max_frames + 4;
     if (hipHostMalloc((void **)&ud->h_ctx_up, sizeof(UCtx) * n_lanes) != hipSuccess
         || hipHostMalloc((void **)&ud->h_ctx_dn, sizeof(UCtx) * n_lanes) != hipSuccess
@@ -2160,7 +2163,13 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
      * opts->scan_g still asks for that variant.) */
     const int32_t scan_gc = ud->scan_gc > 0 ? min(ud->scan_gc, ud->scan_nc) : ((long long)T * n * ud->scan_nc <= 768 ? ud->scan_nc : 1);
     /* (one workgroup per tree: it walks the chunks with the totals in a register -- no flags, no look-back) */
-    UKL(UK_SCAN, ku_scan, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, scan_gc == 1 ? 1 : ud->scan_nc, scan_gc, f);
+    /* (from 64 lanes on, one workgroup per tree: 256 threads -- four times the chunks to walk, 53 instead of 29 us per 128-lane
+     * launch alone, but with four engines on the chip a 256-thread workgroup finds a slot where a 1024-thread one waits for half
+     * a CU: 355 -> 362 k frames/s; with 32-lane engines the other way round: 268 -> 259 k) */
+    if (scan_gc == 1 && n >= ud->scan_small_from)
+        UKL(UK_SCAN, ku_scan<256>, dim3(T, 1, n), dim3(256), 0, st, LN, S, 1, 1, f);
+    else
+        UKL(UK_SCAN, ku_scan<SCAN_THREADS>, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, scan_gc == 1 ? 1 : ud->scan_nc, scan_gc, f);
     /* (many lanes: fewer emission workgroups per tree -- each sweeps further -- instead of thousands of idle ones) */
     UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= ud->many && !ud->big_wl ? 1 : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
     if (ud->big_wl) {

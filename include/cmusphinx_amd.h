@@ -719,7 +719,8 @@ typedef struct {
     int32_t graph;          /* 1: the frames' launches are captured ONCE as a HIP graph (a block of `window` frames per lane count)
                              * and replayed block after block: one graph launch per block instead of ~13 kernel launches per frame */
     int32_t window_max;     /* > 0: the longest look-ahead window the library may choose (lane refill happens at window boundaries) */
-    int32_t reserved[2];
+    int32_t scan_small_from; /* lanes per launch from which the scan uses 256-thread workgroups (0: 64) */
+    int32_t reserved[1];
 } s3a_uttdec_opts_t;
 void s3a_uttdec_opts_default(s3a_uttdec_opts_t *o);
 void s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o);

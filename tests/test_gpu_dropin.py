@@ -115,7 +115,8 @@ DRIVERS = {
     "utt_4": {"S3A_UTT": "4"},
     "utt_3_bigwl": {"S3A_UTT": "3", "S3A_UTT_BIGWL": "1"},      # the word level's candidate phases as chip-wide launches
     "utt_8_engines2": {"S3A_UTT": "8", "S3A_UTT_ENGINES": "2"},    # two engines of four lanes, a host thread each
-    "utt_40": {"S3A_UTT": "40", "S3A_UTT_MANY": "2"},           # the kernels / grids chosen from 32 utterances per launch on
+    "utt_40": {"S3A_UTT": "40", "S3A_UTT_MANY": "2", "S3A_UTT_SCAN_SMALL": "2"},   # the kernels / grids chosen from 32 (the scan's
+                                                                # 256-thread workgroups: from 64) utterances per launch on
                                                                 # (list-driven resolve, fewer workgroups that loop), forced from 2
     # the per-frame scoring kernels (ku_gated / ku_gated_cd_multi) instead of the look-ahead window + ku_select
     "utt_4_perframe": {"S3A_UTT": "4", "S3A_UTT_WIN": "0"},

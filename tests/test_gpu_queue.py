@@ -150,3 +150,18 @@ def test_graph_mode_replays_a_block_of_frames(gpu_lib, tidigits_bundle, monkeypa
     assert m == rm and s == rs
     dec.decode(feats[:1])                                   # fewer lanes: another graph
     assert dec.format_var(*dec.hyp_var(0, utts[0][1], 0)) == (rm[0], rs[0])
+
+
+def test_scan_with_small_workgroups(gpu_lib, tidigits_bundle, monkeypatch):
+    """the scan as 256-thread workgroups (what engines of 64 lanes and more use: four times the chunks per list) forced onto a
+    3-lane engine: plain decodes and a queue, the reference's lines"""
+    monkeypatch.setenv("S3A_UTT_SCAN_SMALL", "1")
+    dec = bundle.Decoder(tidigits_bundle, 3)
+    utts, feats = tidigits_feats(gpu_lib)
+    rm, rs = ref_lines()
+    dec.decode(feats[:3])
+    for z in range(3):
+        assert dec.format_var(*dec.hyp_var(z, utts[z][1], z)) == (rm[z], rs[z])
+    dec.decode_queue(feats)
+    m, s = queue_lines(dec, utts)
+    assert m == rm and s == rs
