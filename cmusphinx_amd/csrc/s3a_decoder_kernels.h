@@ -1324,25 +1324,26 @@ mark_node_senones(int32_t v, const int32_t *__restrict__ ssid, const uint8_t *__
  * Workgroup 0 also snapshots the list lengths before the entries (n0[t]).  (One workgroup
  * scanning all ~90 k entries of a 20 k-word frame took 30 us; the calls are independent.)
  */
+template <int NT>
 __device__ __forceinline__ void
-d_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
+d_dec_enter2_t(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
              const int32_t *__restrict__ prob, const int32_t *__restrict__ sc,
              const int32_t *__restrict__ frame, const int32_t *__restrict__ first, int32_t thresh,
              int32_t nf, int32_t T, const int32_t *__restrict__ nnxt, int32_t *flag, int32_t *ctot,
              int32_t *n0,
         const int32_t BX, const int32_t BY)
 {
-    __shared__ int32_t s_ws[SCAN_THREADS / 64], s_chunk;
+    __shared__ int32_t s_ws[NT / 64], s_chunk;
     const int32_t c = BX;
     const int32_t lo = calls[4 * c + 3], hi = (c + 1 < ent.n_calls) ? calls[4 * (c + 1) + 3] : n_ent;
     const int32_t n = hi - lo, roots = calls[4 * c + 2], in = calls[4 * c];
     const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (c == 0)
-        for (int32_t t = tid; t < T; t += SCAN_THREADS) n0[t] = nnxt[t];
+        for (int32_t t = tid; t < T; t += NT) n0[t] = nnxt[t];
     /* one sweep: the entry's test (four gathers) once, its rank among the call's listed entries by a scan that
      * never leaves registers / LDS, one store of (rank << 1 | listed) */
     int32_t carry = 0;
-    for (int32_t c0 = 0; c0 < n; c0 += SCAN_THREADS) {
+    for (int32_t c0 = 0; c0 < n; c0 += NT) {
         const int32_t i = c0 + tid;
         int32_t q = 0;
         if (i < n) {
@@ -1357,21 +1358,32 @@ d_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
         if (lane == 0) s_ws[wave] = __popcll(m);
         __syncthreads();
         if (wave == 0) {
-            const int32_t w = (lane < SCAN_THREADS / 64) ? s_ws[lane] : 0;
+            const int32_t w = (lane < NT / 64) ? s_ws[lane] : 0;
             int32_t wi = w;
 #pragma unroll
-            for (int o = 1; o < SCAN_THREADS / 64; o <<= 1) {
+            for (int o = 1; o < NT / 64; o <<= 1) {
                 const int32_t y = __shfl_up(wi, o, 64);
                 if (lane >= o) wi += y;
             }
-            if (lane < SCAN_THREADS / 64) s_ws[lane] = wi - w;
-            if (lane == SCAN_THREADS / 64 - 1) s_chunk = wi;
+            if (lane < NT / 64) s_ws[lane] = wi - w;
+            if (lane == NT / 64 - 1) s_chunk = wi;
         }
         __syncthreads();
         if (i < n) flag[lo + i] = ((carry + s_ws[wave] + below) << 1) | q;
         carry += s_chunk;
     }
     if (tid == 0) ctot[c] = carry;
+}
+
+__device__ __forceinline__ void
+d_dec_enter2(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
+             const int32_t *__restrict__ prob, const int32_t *__restrict__ sc,
+             const int32_t *__restrict__ frame, const int32_t *__restrict__ first, int32_t thresh,
+             int32_t nf, int32_t T, const int32_t *__restrict__ nnxt, int32_t *flag, int32_t *ctot,
+             int32_t *n0,
+        const int32_t BX, const int32_t BY)
+{
+    d_dec_enter2_t<SCAN_THREADS>(ent, n_ent, calls, prob, sc, frame, first, thresh, nf, T, nnxt, flag, ctot, n0, BX, BY);
 }
 
 /* blocks [0, n_ent_blocks): write the listed roots to the next list (position = list length before
