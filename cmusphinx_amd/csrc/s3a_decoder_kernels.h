@@ -307,16 +307,17 @@ block_inclusive_sum(int32_t x, int32_t *wsum /* [SCAN_THREADS / 64] shared */)
     return incl + add;
 }
 
+template <int NT>
 __device__ __forceinline__ int32_t
-d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32_t *__restrict__ nact,
+d_dec_hist_sort_t(const int32_t *__restrict__ node_base, int32_t *act, const int32_t *__restrict__ nact,
                 int32_t T, FrameBeams bm, const int32_t *__restrict__ binof, int32_t *tmp,
                 int32_t *hbin, int32_t *pos, int32_t force_tree, int32_t nbin,
         const int32_t BX, const int32_t BY)
 {
     __shared__ int32_t s_cnt[NBIN], s_base[NBIN], s_run[NBIN];
-    __shared__ uint16_t s_cntw[SCAN_THREADS / 64][NBIN];
-    __shared__ int32_t s_wsum[SCAN_THREADS / 64];
-    __shared__ int32_t s_go, s_i;
+    __shared__ uint16_t s_cntw[NT / 64][NBIN];
+    __shared__ int32_t s_wsum[NT / 64];
+    __shared__ int32_t s_go, s_i, s_tot;
     const int32_t t = BX, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         int32_t n = 0;
@@ -329,26 +330,42 @@ d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32
     if (force_tree < 0) {
         /* for (i = 0, j = 0; i < nbin && j < maxhmmpf; i++, j += bin[i]);  -- bin[0] is never
          * counted and the read of bin[nbin] after the last increment decides nothing */
-        const int32_t x = (tid >= 1 && tid < nbin) ? hbin[tid] : 0;
-        const int32_t J = block_inclusive_sum(x, s_wsum);       /* j after i reached tid */
-        if (tid < nbin && J >= bm.maxhmmpf) atomicMin(&s_i, bm.maxhmmpf <= 0 ? 0 : tid);
-        __syncthreads();
+        /* (the bins in chunks of NT with a running total: the workgroup may be smaller than the histogram) */
+        int32_t carry = 0;
+        for (int32_t k0 = 0; k0 < nbin; k0 += NT) {
+            const int32_t k = k0 + tid;
+            const int32_t x = (k >= 1 && k < nbin) ? hbin[k] : 0;
+            const int32_t J = carry + block_inclusive_sum(x, s_wsum);       /* j after i reached k */
+            if (k < nbin && J >= bm.maxhmmpf) atomicMin(&s_i, bm.maxhmmpf <= 0 ? 0 : k);
+            if (tid == NT - 1) s_tot = J;
+            __syncthreads();
+            carry = s_tot;
+            __syncthreads();
+        }
         if (t == 0 && tid == 0) hbin[NBIN] = -(s_i * (-bm.hmmbeam / NBIN));
     }
     /* this tree's own bin counts and bin bases */
     const int32_t b = node_base[t], na = nact[t];
-    for (int32_t k = tid; k < nbin; k += SCAN_THREADS) { s_cnt[k] = 0; s_run[k] = 0; }
-    for (int32_t k = tid; k < (SCAN_THREADS / 64) * NBIN; k += SCAN_THREADS) (&s_cntw[0][0])[k] = 0;
+    for (int32_t k = tid; k < nbin; k += NT) { s_cnt[k] = 0; s_run[k] = 0; }
+    for (int32_t k = tid; k < (NT / 64) * NBIN; k += NT) (&s_cntw[0][0])[k] = 0;
     __syncthreads();
-    for (int32_t i = tid; i < na; i += SCAN_THREADS) atomicAdd(&s_cnt[binof[b + i]], 1);
+    for (int32_t i = tid; i < na; i += NT) atomicAdd(&s_cnt[binof[b + i]], 1);
     __syncthreads();
     {
-        const int32_t x = tid < nbin ? s_cnt[tid] : 0;
-        const int32_t incl = block_inclusive_sum(x, s_wsum);
-        if (tid < nbin) s_base[tid] = incl - x;
+        int32_t carry = 0;
+        for (int32_t k0 = 0; k0 < nbin; k0 += NT) {
+            const int32_t k = k0 + tid;
+            const int32_t x = k < nbin ? s_cnt[k] : 0;
+            const int32_t incl = carry + block_inclusive_sum(x, s_wsum);
+            if (k < nbin) s_base[k] = incl - x;
+            if (tid == NT - 1) s_tot = incl;
+            __syncthreads();
+            carry = s_tot;
+            __syncthreads();
+        }
     }
     __syncthreads();
-    for (int32_t c0 = 0; c0 < na; c0 += SCAN_THREADS) {
+    for (int32_t c0 = 0; c0 < na; c0 += NT) {
         const int32_t i = c0 + tid;
         const bool valid = i < na;
         const int32_t k = valid ? binof[b + i] : -1;
@@ -378,13 +395,22 @@ d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32
         __syncthreads();
     }
     __syncthreads();
-    for (int32_t i = tid; i < na; i += SCAN_THREADS) {
+    for (int32_t i = tid; i < na; i += NT) {
         const int32_t v = tmp[b + i];
         act[b + i] = v;
         pos[v] = i;
     }
     __syncthreads();
     return force_tree < 0 ? -(s_i * (-bm.hmmbeam / NBIN)) : 1;      /* the histogram beam (hbin[NBIN]) */
+}
+
+__device__ __forceinline__ int32_t
+d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32_t *__restrict__ nact,
+                int32_t T, FrameBeams bm, const int32_t *__restrict__ binof, int32_t *tmp,
+                int32_t *hbin, int32_t *pos, int32_t force_tree, int32_t nbin,
+        const int32_t BX, const int32_t BY)
+{
+    return d_dec_hist_sort_t<SCAN_THREADS>(node_base, act, nact, T, bm, binof, tmp, hbin, pos, force_tree, nbin, BX, BY);
 }
 
 /* ------------------------------------------------------------------ */

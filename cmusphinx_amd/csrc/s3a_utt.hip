@@ -1000,7 +1000,8 @@ ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 }
 
 /* the histogram beam + the reordering of the lists (frames over 1.5 x -maxhmmpf only), then the stamps of such a frame */
-__global__ void __launch_bounds__(SCAN_THREADS)
+template <int NT>
+__global__ void __launch_bounds__(NT)
 ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
     /* ONE workgroup per lane that takes the trees in turn: the usual frame has nothing to sort, and a workgroup per (tree,
@@ -1012,14 +1013,14 @@ ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t fg)
     for (int32_t k = 0; k < S.T; k++) n += nact_cur[k];
     if (n <= bm.maxhmmpf + (bm.maxhmmpf >> 1)) return;          /* (uniform: no histogram beam in this frame) */
     for (int32_t t = 0; t < S.T; t++) {
-        const int32_t hb = d_dec_hist_sort(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.exits + S.N, L.exits, L.hbin,
+        const int32_t hb = d_dec_hist_sort_t<NT>(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.exits + S.N, L.exits, L.hbin,
                                            L.pos, -1, NBIN, t, 0);
         __syncthreads();
         if (hb <= 0) {
             int32_t th, pth;
             frame_thresholds_hb(L.best, S.T, bm, hb, th, pth);
             const int32_t na = nact_cur[t], b = S.node_base[t];
-            for (int32_t i = threadIdx.x; i < na; i += SCAN_THREADS)
+            for (int32_t i = threadIdx.x; i < na; i += NT)
                 d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp8, b, na, i, pth, f);
         }
         __syncthreads();
@@ -2144,7 +2145,11 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
         UKL(UK_HMM_EVAL, (ku_hmm_eval<64, 3>), dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
     {
         UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 8 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
-        if (ud->hist_possible) UKL(UK_HIST_SORT, ku_hist_sort, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+        if (ud->hist_possible) {
+            /* (from 64 lanes on 256 threads: the launch's 128 workgroups mostly only leave, and small ones find a slot sooner) */
+            if (n >= ud->scan_small_from) UKL(UK_HIST_SORT, ku_hist_sort<256>, dim3(1, 1, n), dim3(256), 0, st, LN, S, f);
+            else UKL(UK_HIST_SORT, ku_hist_sort<SCAN_THREADS>, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+        }
     }
     if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     if (S.pheurtype > 0) UKL(UK_RESOLVE, ku_heur_thresh, dim3(T, 1, n), dim3(1024), 0, st, LN, S, f);
