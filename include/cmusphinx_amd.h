@@ -922,6 +922,119 @@ int32_t s3a_uttdec_shape(const s3a_uttdec_t *ud, int32_t *n_sen, int32_t *n_ci_s
                          int32_t *veclen, int32_t *n_node, int32_t *n_tree);
 
 /* ===================================================================== */
+/* pocketsphinx's first pass on the device (the search half)                                    */
+/* replaces, behind ps_searchfuncs_t {start, step, finish, ...} (pocketsphinx/src/libpocketsphinx/                */
+/* pocketsphinx_internal.h:68-81), the lexicon-tree Viterbi search of ngram_search_fwdtree.c:                     */
+/*   ngram_fwdtree_start :464   ngram_fwdtree_search :1446-1488   ngram_fwdtree_finish :1490                      */
+/*   compute_sen_active :513  renormalize_scores :555  evaluate_channels :694 (eval_root_chan :595,               */
+/*   eval_nonroot_chan :613, eval_word_chan :634)  prune_channels :1125 (prune_root_chan :714,                    */
+/*   prune_nonroot_chan :794, last_phone_transition :877, prune_word_chan :1037)  bptable_maxwpf :1183            */
+/*   word_transition :1236  deactivate_channels :1421                                                             */
+/* with hmm_vit_eval in pocketsphinx's conventions (hmm.c:532-609 3-state, :249-528 5-state, multiplexed and      */
+/* not: int32 path scores, int16 NEGATED senone scores, uint8 negated transition scores), ngram_search_save_bp    */
+/* (ngram_search.c:360), ngram_search_exit_score (:601), ngram_search_find_exit (:444) + the backtrace of         */
+/* ngram_search_bp_hyp (:486) / ngram_search_bp2itor (:777), and ngram_tg_score >> SENSCR_SHIFT on the            */
+/* language model (sphinxbase lm3g_templates.c:73-195 behind ngram_model_set_score, ngram_model_set.c:709).       */
+/*                                                                                                                */
+/* One LANE = one ps_decoder_t utterance; one workgroup runs a lane's whole frame (no launch per phase, no        */
+/* cross-workgroup ordering), lanes run side by side.  The backpointer table that comes back is the               */
+/* reference's, entry for entry (order included), so that everything downstream of the first pass -- fwdflat,     */
+/* the lattice, bestpath, the segment iterator -- runs unchanged on it (integration/pocketsphinx/ps_search_amd.c).*/
+/*                                                                                                                */
+/* s3a_psfwd_desc_t is what the search reads of bin_mdef_t / tmat_t / dict_t / dict2pid_t / ngram_search_t /      */
+/* ngram_model_t, flattened by the caller (copied at init):                                                       */
+/*   channels are numbered roots first: [0, n_root) = ngs->root_chan[], [n_root, n_root + n_nonroot) = the        */
+/*   interior channels; ch_child_off/ch_child = a channel's children in sibling (->next, ->alt) order;            */
+/*   ch_pen_off/ch_pen_wid = its penult_phn_wid list in homophone_set order; a word's last-phone channels are     */
+/*   its right contexts rc_ssid[w_rc_off[w] .. w_rc_off[w+1]) (dict2pid_rssid(last, last2)->ssid[]) with          */
+/*   rc_cimap[w_rc_row[w]][ci] = ->cimap[ci]; sp_* = ngs->single_phone_wid[] (the first n_1ph_lm are in the LM)   */
+/*   with their permanently allocated root channels; root_lc_ssid[r][lc] / sp_lc_ssid[i][lc] =                    */
+/*   dict2pid_ldiph_lc(ciphone, ci2phone, lc).  w_lmwid[w] = the LM's id of dictionary word w                     */
+/*   (ngram_model_set_current_wid), negative = NGRAM_INVALID_WID.  LM arrays as s3a_lm3g_init's, values as        */
+/*   ngram_model_apply_weights left them (ngram_iter_get).  Beams etc. are ngram_search_calc_beams' values.        */
+/* ===================================================================== */
+#define S3A_PSW_SINGLE 1    /* dict_is_single_phone */
+#define S3A_PSW_FILLER 2    /* dict_filler_word */
+#define S3A_PSW_REAL   4    /* dict_real_word */
+typedef struct s3a_psfwd_desc_s {
+    int32_t n_ci, sil_ci, n_emit, n_sen, n_sseq, n_tmat;
+    const uint16_t *sseq;           /* [n_sseq][n_emit]  bin_mdef_t.sseq */
+    const uint8_t *tp;              /* [n_tmat][n_emit][n_emit + 1]  tmat_t.tp */
+    int32_t n_words, start_wid, finish_wid, silence_wid;
+    const int32_t *w_basewid, *w_lmwid;
+    const int16_t *w_first_ci, *w_last_ci, *w_last2_ci;     /* last2 = -1 for single-phone words */
+    const uint8_t *w_flags;         /* S3A_PSW_* */
+    const int32_t *w_rc_off;        /* [n_words + 1] */
+    const uint16_t *rc_ssid;
+    const int32_t *w_rc_row;        /* [n_words] row of rc_cimap, -1 for single-phone words */
+    int32_t n_rc_rows;
+    const int16_t *rc_cimap;        /* [n_rc_rows][n_ci] */
+    const int16_t *w_rc_tmat;       /* [n_words] bin_mdef_pid2tmatid(last phone) */
+    int32_t n_root, n_nonroot;
+    const int16_t *root_ci, *root_ci2, *root_tmat;
+    const uint16_t *root_ssid0;     /* [n_root] hmm_mpx_ssid(&rhmm->hmm, 0) after create_search_tree */
+    const uint16_t *root_lc_ssid;   /* [n_root][n_ci] */
+    const int32_t *ch_child_off, *ch_child;     /* [n_root + n_nonroot + 1], channel numbers */
+    const int32_t *ch_pen_off, *ch_pen_wid;     /* [n_root + n_nonroot + 1], word ids */
+    const uint16_t *nr_ssid;        /* [n_nonroot] */
+    const int16_t *nr_tmat, *nr_ci;
+    int32_t n_1ph, n_1ph_lm;
+    const int32_t *sp_wid;
+    const uint16_t *sp_ssid0, *sp_lc_ssid;      /* [n_1ph], [n_1ph][n_ci] */
+    const int16_t *sp_tmat, *sp_ci;
+    int32_t n_fill;                 /* word_transition's filler loop (:1380-1402): the words it enters, in its order */
+    const int32_t *fill_sp;         /* [n_fill] index into sp_* */
+    int32_t lm_order, lm_n_ug, lm_n_bg, lm_n_tg, lm_zero;
+    const int32_t *ug_prob, *ug_bowt, *ug_firstbg;          /* ug_firstbg [n_ug + 1] */
+    const int32_t *bg_wid, *bg_prob, *bg_bowt, *bg_firsttg; /* bg_firsttg [n_bg + 1] */
+    const int32_t *tg_wid, *tg_prob;
+    int32_t beam, pbeam, wbeam, lpbeam, lponlybeam, fillpen, silpen, nwpen, pip, maxwpf, maxhmmpf;
+} s3a_psfwd_desc_t;
+
+/* the finished (or running) backpointer table of a lane: bptbl_t by field, ngs->bscore_stack, ngs->bp_table_idx
+ * [0 .. n_mark), the search's scalars; pointers are host copies owned by the engine until the lane's next call */
+typedef struct {
+    int32_t status;                 /* 0 ok; S3A_ENOMEM = a table overflowed (the lane stopped, loudly) */
+    int32_t n_frame, n_mark, bpidx, bss_head, best_score, last_phone_best_score, renormalized;
+    int32_t st[8];                  /* ngram_search_stats_t: n_phone_eval, n_root_chan_eval, n_nonroot_chan_eval,
+                                       n_last_chan_eval, n_word_lastchan_eval, n_lastphn_cand_utt, n_senone_active_utt, 0 */
+    const int32_t *frame, *wid, *bp, *score, *s_idx, *real_wid;
+    const uint8_t *valid;
+    const int32_t *bscore_stack, *bp_table_idx;
+} s3a_psfwd_table_t;
+typedef struct { int32_t wid, sf, ef, ascr, lscr, bp; } s3a_psfwd_seg_t;
+
+typedef struct s3a_psfwd_s s3a_psfwd_t;
+/* max_frames bounds an utterance (int16 frame numbers in the reference: <= 32767); bp_cap / bss_cap = entries of
+ * the backpointer table / right-context score stack per lane (0: 64 and 64 * n_ci per frame) -- the reference grows
+ * them, exceeding them here stops the lane with status S3A_ENOMEM */
+s3a_psfwd_t *s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames,
+                            int32_t bp_cap, int32_t bss_cap);
+void    s3a_psfwd_free(s3a_psfwd_t *e);
+int32_t s3a_psfwd_n_lanes(const s3a_psfwd_t *e);
+/* frame-synchronous use (the three slots; senone scores come from whatever ps_mgau_t the decoder has):
+ *   start       ngram_fwdtree_start
+ *   sen_active  compute_sen_active for frame_idx: flags[n_sen] (host) = acmod->senone_active_vec as bytes
+ *   step        ngram_fwdtree_search for frame_idx given acmod_score's senscr[n_sen] (host; only the flagged
+ *               senones are read); returns 1, or 0 where the reference returns 0 (recognition failed), < 0 on error
+ *   finish      ngram_fwdtree_finish (n_frames = acmod->output_frame) */
+int32_t s3a_psfwd_start(s3a_psfwd_t *e, int32_t lane);
+int32_t s3a_psfwd_sen_active(s3a_psfwd_t *e, int32_t lane, int32_t frame_idx, uint8_t *flags);
+int32_t s3a_psfwd_step(s3a_psfwd_t *e, int32_t lane, const int16_t *senscr, int32_t frame_idx);
+int32_t s3a_psfwd_finish(s3a_psfwd_t *e, int32_t lane, int32_t n_frames);
+/* whole utterances: n_utt <= n_lanes utterances, feat[z] = n_frames[z] rows of the scorer's veclen floats (host);
+ * scoring (s3a_ps_ms_cont_mgau_frame_eval's arithmetic, active senones only unless compallsen) and the search of
+ * every frame of every lane run on the device between one upload and one download of scalars. */
+int32_t s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const float *const *feat,
+                         const int32_t *n_frames, int32_t compallsen);
+int32_t s3a_psfwd_table(s3a_psfwd_t *e, int32_t lane, s3a_psfwd_table_t *out);
+/* ngram_search_find_exit(-1) + the backtrace with ngram_search_bp2itor's scores (lwf = 1), made on the device:
+ * returns the number of segments (utterance order; 0 = no exit), -3 if max_seg is too small; *out_score = the
+ * exit's path score */
+int32_t s3a_psfwd_hyp(s3a_psfwd_t *e, int32_t lane, int32_t *out_score, s3a_psfwd_seg_t *seg, int32_t max_seg);
+double  s3a_psfwd_last_decode_ms(const s3a_psfwd_t *e);
+
+/* ===================================================================== */
 /* measurement hooks used by bench.py (HIP events on the launch stream)   */
 /* ===================================================================== */
 /*
