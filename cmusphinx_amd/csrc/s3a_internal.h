@@ -87,6 +87,9 @@ struct s3a_ms_mgau_s *s3a_ms_host_init(const float *mean, const float *var, cons
 void s3a_ms_host_free(struct s3a_ms_mgau_s *msg);
 int32_t s3a_ps_dev_create(struct s3a_ps_mgau_s *ps);       /* s3a_psms.hip */
 void s3a_ps_dev_destroy(struct s3a_ps_mgau_s *ps);
+/* all senones of many frames, before normalisation (s3a_psms.hip; used by s3a_psfwd.hip) */
+int32_t s3a_ps_score_slots_dev(struct s3a_ps_mgau_s *ps, const float *feat_dev, const int32_t *slot_row_dev,
+                               int32_t n_slots, int16_t *raw_dev, void *stream);
 int32_t s3a_ms_dev_create(struct s3a_ms_mgau_s *msg);      /* s3a_ms.hip */
 void s3a_ms_dev_destroy(struct s3a_ms_mgau_s *msg);
 /* host half of mgau_init on raw arrays; leaves g->dev NULL */

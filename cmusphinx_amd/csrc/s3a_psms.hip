@@ -37,6 +37,7 @@ struct s3a_ps_dev_s {
     int32_t *dist_id, *scr, *best;
     int16_t *out, *out_h;
     hipStream_t stream;
+    float *bdist; int32_t *bdist_id; size_t bdist_cap;     /* s3a_ps_score_slots_dev's top-N lists */
 };
 
 __global__ void
@@ -148,6 +149,137 @@ k_ps_norm(int32_t n_sen, const uint8_t *__restrict__ sen_active, const int32_t *
     if (s < n_sen && sen_active[s]) out[s] = (int16_t)min(max(scr[s] - *best, -32768), 32767);
 }
 
+
+/* ------------------------------------------------------------------ */
+/* many frames at once for the whole-utterance search (s3a_psfwd.hip): slot q scores feature row slot_row[q]  */
+/* (negative: empty slot) for EVERY senone; out[q][n_sen] = the int16-clamped score BEFORE normalisation      */
+/* (ms_mgau.c:185-189 / :228-233 normalise by the best of the senones the frame's active list names; the      */
+/* search does that per frame from these).  A senone's score does not depend on which others are computed.    */
+/* ------------------------------------------------------------------ */
+#define PS_FT 8     /* frames per tile: a thread keeps its density's partial sums of PS_FT frames */
+__global__ void __launch_bounds__(PSB)
+k_ps_dist_slots(int32_t n_mgau, int32_t n_feat, int32_t nd, int32_t P, int32_t veclen, int32_t topn,
+                const int32_t *__restrict__ featlen, const int32_t *__restrict__ featoff,
+                const float *__restrict__ meanT, const float *__restrict__ precT, const float *__restrict__ det,
+                const float *__restrict__ feat, const int32_t *__restrict__ slot_row, int32_t slot0, int32_t n_slots,
+                float *dist, int32_t *dist_id)
+{
+    extern __shared__ float x_s[];          /* [PS_FT][veclen] */
+    __shared__ float dv[PS_FT][PSB];
+    const int32_t q0 = slot0 + blockIdx.y * PS_FT;
+    for (int32_t i = threadIdx.x; i < PS_FT * veclen; i += PSB) {
+        const int32_t t = i / veclen, q = q0 + t;
+        const int32_t row = (q < slot0 + n_slots) ? slot_row[q] : -1;
+        x_s[i] = row >= 0 ? feat[(size_t)row * veclen + (i - t * veclen)] : 0.0f;
+    }
+    __syncthreads();
+    const int32_t item = blockIdx.x * PSB + threadIdx.x;
+    const int32_t job = item / P, d = item % P, m = job / n_feat, f = job % n_feat;
+    const bool live = job < n_mgau * n_feat && d < nd;
+    float acc[PS_FT];
+#pragma unroll
+    for (int t = 0; t < PS_FT; t++) acc[t] = 0.0f;
+    if (live) {
+        const int32_t flen = featlen[f], fo = featoff[f];
+        const size_t base = ((size_t)m * veclen + fo) * P;
+        const float dt = det[(size_t)job * P + d];
+#pragma unroll
+        for (int t = 0; t < PS_FT; t++) acc[t] = dt;
+        for (int32_t i = 0; i < flen; i++) {
+            const float mu = meanT[base + (size_t)i * P + d], pr = precT[base + (size_t)i * P + d];
+#pragma unroll
+            for (int t = 0; t < PS_FT; t++) {
+                const float df = x_s[t * veclen + fo + i] - mu;
+                const float tt = (df * df) * pr;
+                acc[t] = acc[t] - tt;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PS_FT; t++) dv[t][threadIdx.x] = acc[t];
+    __syncthreads();
+    if (!live) return;
+    for (int t = 0; t < PS_FT; t++) {
+        const int32_t q = q0 + t;
+        if (q >= slot0 + n_slots) break;
+        const float dval = acc[t];
+        int32_t rank = d;
+        if (topn < nd) {
+            const float *mine = &dv[t][threadIdx.x - d];
+            rank = 0;
+            for (int32_t k = 0; k < nd; k++) {
+                const float o = mine[k];
+                rank += (o > dval || (o == dval && k > d)) ? 1 : 0;
+            }
+            if (rank >= topn) continue;
+        }
+        const size_t o = ((size_t)(q - slot0) * n_mgau * n_feat + job) * topn + rank;
+        dist[o] = dval;
+        dist_id[o] = d;
+    }
+}
+
+__global__ void __launch_bounds__(PSB)
+k_ps_senone_slots(int32_t n_sen, int32_t n_mgau, int32_t n_feat, int32_t nd, int32_t topn, int32_t aw,
+                  const int32_t *__restrict__ mgau, const int32_t *__restrict__ pdf, const float *__restrict__ dist,
+                  const int32_t *__restrict__ dist_id, LogAddShifted la, const int32_t *__restrict__ slot_row,
+                  int32_t slot0, int16_t *out)
+{
+    const int32_t s = blockIdx.x * PSB + threadIdx.x, q = slot0 + blockIdx.y;
+    if (s >= n_sen || slot_row[q] < 0) return;
+    const int32_t m = mgau[s];
+    int32_t tot = 0;
+    for (int32_t f = 0; f < n_feat; f++) {
+        const size_t o = ((size_t)blockIdx.y * n_mgau * n_feat + (size_t)m * n_feat + f) * topn;
+        const float *fd = dist + o;
+        const int32_t *fi = dist_id + o;
+        const int32_t *p = pdf + ((size_t)s * n_feat + f) * nd;
+        int32_t fscr = (((int32_t)fd[0] + ((1 << PS_SHIFT) - 1)) >> PS_SHIFT) - p[fi[0]];
+        for (int32_t t = 1; t < topn; t++)
+            fscr = la(fscr, (((int32_t)fd[t] + ((1 << PS_SHIFT) - 1)) >> PS_SHIFT) - p[fi[t]]);
+        tot -= fscr;
+    }
+    tot /= aw;
+    out[(size_t)q * n_sen + s] = (int16_t)min(max(tot, -32768), 32767);
+}
+
+/* internal (s3a_internal.h): feat_dev [rows][veclen], slot_row_dev [n_slots], raw_dev [n_slots][n_sen], on `stream` */
+extern "C" int32_t
+s3a_ps_score_slots_dev(s3a_ps_mgau_t *ps, const float *feat_dev, const int32_t *slot_row_dev, int32_t n_slots,
+                       int16_t *raw_dev, void *stream)
+{
+    if (!ps || !ps->dev || n_slots < 0) return S3A_EINVAL;
+    s3a_ps_dev_s *dv = ps->dev;
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t M = ps->n_mgau, F = ps->n_feat, nd = ps->n_density, S = ps->n_sen, P = dv->P;
+    const size_t per_slot = (size_t)M * F * ps->topn;
+    /* the top-N lists of a tile of slots: at most 256 MB at a time */
+    int32_t tile = (int32_t)(((size_t)256 << 20) / (per_slot * 8));
+    tile = tile < PS_FT ? PS_FT : (tile / PS_FT) * PS_FT;
+    if (tile > n_slots) tile = ((n_slots + PS_FT - 1) / PS_FT) * PS_FT;
+    if (tile < PS_FT) tile = PS_FT;
+    if (dv->bdist_cap < (size_t)tile * per_slot) {
+        if (dv->bdist) (void)hipFree(dv->bdist);
+        if (dv->bdist_id) (void)hipFree(dv->bdist_id);
+        dv->bdist = NULL; dv->bdist_id = NULL; dv->bdist_cap = 0;
+        HIPCHK(hipMalloc((void **)&dv->bdist, (size_t)tile * per_slot * 4));
+        HIPCHK(hipMalloc((void **)&dv->bdist_id, (size_t)tile * per_slot * 4));
+        dv->bdist_cap = (size_t)tile * per_slot;
+    }
+    LogAddShifted la = { dv->tab, dv->tab_size, dv->lm_zero };
+    const int64_t items = (int64_t)M * F * P;
+    for (int32_t s0 = 0; s0 < n_slots; s0 += tile) {
+        const int32_t n = n_slots - s0 < tile ? n_slots - s0 : tile;
+        hipLaunchKernelGGL(k_ps_dist_slots, dim3((uint32_t)((items + PSB - 1) / PSB), (n + PS_FT - 1) / PS_FT), dim3(PSB),
+                           (size_t)PS_FT * ps->veclen * 4, st, M, F, nd, P, ps->veclen, ps->topn, dv->featlen, dv->featoff,
+                           dv->meanT, dv->precT, dv->det, feat_dev, slot_row_dev, s0, n, dv->bdist, dv->bdist_id);
+        hipLaunchKernelGGL(k_ps_senone_slots, dim3((S + PSB - 1) / PSB, n), dim3(PSB), 0, st, S, M, F, nd, ps->topn, ps->aw,
+                           dv->mgau, dv->pdf, dv->bdist, dv->bdist_id, la, slot_row_dev, s0, raw_dev);
+    }
+    HIPCHK(hipGetLastError());
+    return S3A_OK;
+}
+
 #define DM(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 4))
 
 extern "C" int32_t
@@ -221,6 +353,8 @@ s3a_ps_dev_destroy(s3a_ps_mgau_t *ps)
     void *ptrs[] = { dv->meanT, dv->precT, dv->det, dv->featlen, dv->featoff, dv->pdf, dv->mgau, dv->tab,
                      dv->sen_active, dv->mgau_active, dv->feat, dv->dist, dv->dist_id, dv->scr, dv->best, dv->out };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (dv->bdist) (void)hipFree(dv->bdist);
+    if (dv->bdist_id) (void)hipFree(dv->bdist_id);
     if (dv->out_h) (void)hipHostFree(dv->out_h);
     if (dv->stream) (void)hipStreamDestroy(dv->stream);
     delete dv;

@@ -218,6 +218,20 @@ _SIGS = {
     "s3a_uttdec_bestpath_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_set_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
     "s3a_uttdec_profile": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_psfwd_init": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "s3a_psfwd_free": (None, [C.c_void_p]),
+    "s3a_psfwd_n_lanes": (C.c_int32, [C.c_void_p]),
+    "s3a_psfwd_start": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "s3a_psfwd_reset": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "s3a_psfwd_sen_active": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "s3a_psfwd_step": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
+    "s3a_psfwd_finish": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "s3a_psfwd_decode": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "s3a_psfwd_table": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_psfwd_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_int32]),
+    "s3a_psfwd_get_sp_ssid": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_psfwd_set_sp_ssid": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_psfwd_last_decode_ms": (C.c_double, [C.c_void_p]),
     "s3a_uttdec_shape": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_int32)] * 6),
     "s3a_uttdec_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_hyp_var": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),

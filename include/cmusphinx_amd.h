@@ -1016,17 +1016,28 @@ int32_t s3a_psfwd_n_lanes(const s3a_psfwd_t *e);
  *   start       ngram_fwdtree_start
  *   sen_active  compute_sen_active for frame_idx: flags[n_sen] (host) = acmod->senone_active_vec as bytes
  *   step        ngram_fwdtree_search for frame_idx given acmod_score's senscr[n_sen] (host; only the flagged
- *               senones are read); returns 1, or 0 where the reference returns 0 (recognition failed), < 0 on error
+ *               senones are read) and acmod->n_senone_active (a statistic); returns 1, or 0 where the reference
+ *               returns 0 (recognition failed), < 0 on error
  *   finish      ngram_fwdtree_finish (n_frames = acmod->output_frame) */
 int32_t s3a_psfwd_start(s3a_psfwd_t *e, int32_t lane);
 int32_t s3a_psfwd_sen_active(s3a_psfwd_t *e, int32_t lane, int32_t frame_idx, uint8_t *flags);
-int32_t s3a_psfwd_step(s3a_psfwd_t *e, int32_t lane, const int16_t *senscr, int32_t frame_idx);
+int32_t s3a_psfwd_step(s3a_psfwd_t *e, int32_t lane, const int16_t *senscr, int32_t frame_idx, int32_t n_senone_active);
 int32_t s3a_psfwd_finish(s3a_psfwd_t *e, int32_t lane, int32_t n_frames);
 /* whole utterances: n_utt <= n_lanes utterances, feat[z] = n_frames[z] rows of the scorer's veclen floats (host);
  * scoring (s3a_ps_ms_cont_mgau_frame_eval's arithmetic, active senones only unless compallsen) and the search of
  * every frame of every lane run on the device between one upload and one download of scalars. */
 int32_t s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const float *const *feat,
-                         const int32_t *n_frames, int32_t compallsen);
+                         const int32_t *n_frames, int32_t compallsen, int32_t fresh);
+/* A lane is a ps_decoder_t: as in the reference, start does NOT restore a new decoder's channels -- frame numbers,
+ * histories and multiplexed senone-sequence ids of pruned channels survive into the next utterance (hmm_clear_scores,
+ * hmm.c:176, leaves them), which is observable: a stale frame number equal to f + 1 loses an entry in
+ * prune_nonroot_chan (:833-837), stale multiplexed ids activate senones and move the frame's normaliser.  reset (and
+ * fresh != 0 in decode) makes the lane a NEW decoder: results then do not depend on what the lane decoded before.
+ * get/set_sp_ssid: the multiplexed ids [n_1ph][n_emit] of the single-phone words' channels, which the reference's
+ * fwdflat pass shares with the first pass (ngram_search_fwdflat.c:381-387) and leaves changed. */
+int32_t s3a_psfwd_reset(s3a_psfwd_t *e, int32_t lane);
+int32_t s3a_psfwd_get_sp_ssid(s3a_psfwd_t *e, int32_t lane, uint16_t *ssid);
+int32_t s3a_psfwd_set_sp_ssid(s3a_psfwd_t *e, int32_t lane, const uint16_t *ssid);
 int32_t s3a_psfwd_table(s3a_psfwd_t *e, int32_t lane, s3a_psfwd_table_t *out);
 /* ngram_search_find_exit(-1) + the backtrace with ngram_search_bp2itor's scores (lwf = 1), made on the device:
  * returns the number of segments (utterance order; 0 = no exit), -3 if max_seg is too small; *out_score = the
