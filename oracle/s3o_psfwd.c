@@ -889,3 +889,22 @@ s3o_psfwd_backtrace(const s3o_psfwd_t *s, int32_t bpidx, int32_t *wid, int32_t *
     }
     return n;
 }
+
+/* accessors for the ctypes harness (tests/psfwd_synth.py) */
+void
+s3o_psfwd_scalars(const s3o_psfwd_t *s, int32_t *out)
+{
+    out[0] = s->n_frame; out[1] = s->bpidx; out[2] = s->bss_head; out[3] = s->best_score; out[4] = s->last_phone_best_score;
+    out[5] = s->renormalized; out[6] = s->st_n_root_chan_eval; out[7] = s->st_n_nonroot_chan_eval; out[8] = s->st_n_last_chan_eval;
+    out[9] = s->st_n_word_lastchan_eval; out[10] = s->st_n_lastphn_cand_utt; out[11] = s->st_n_senone_active_utt;
+}
+const int32_t *
+s3o_psfwd_array(const s3o_psfwd_t *s, int32_t which)
+{
+    switch (which) {
+    case 0: return s->bp_frame; case 1: return s->bp_wid; case 2: return s->bp_bp; case 3: return s->bp_score;
+    case 4: return s->bp_sidx; case 5: return s->bp_realwid; case 6: return s->bss; case 7: return s->bp_table_idx + 1;
+    }
+    return 0;
+}
+const uint8_t *s3o_psfwd_valid(const s3o_psfwd_t *s) { return s->bp_valid; }

@@ -107,6 +107,9 @@ int32_t s3o_psfwd_tg_score(const s3o_psfwd_t *s, int32_t w3, int32_t w2, int32_t
 /* ngram_search_bp2itor for every entry of the backtrace from bp (utterance order); returns the count */
 int32_t s3o_psfwd_backtrace(const s3o_psfwd_t *s, int32_t bp, int32_t *wid, int32_t *sf, int32_t *ef,
                             int32_t *ascr, int32_t *lscr, int32_t *bps, int32_t max);
+void s3o_psfwd_scalars(const s3o_psfwd_t *s, int32_t *out);
+const int32_t *s3o_psfwd_array(const s3o_psfwd_t *s, int32_t which);
+const uint8_t *s3o_psfwd_valid(const s3o_psfwd_t *s);
 /* hmm_vit_eval on one HMM given plain arrays (unit tests of the device's evaluation) */
 int32_t s3o_ps_hmm_vit_eval(s3o_pshmm_t *h, int32_t n_emit, const uint8_t *tp, const uint16_t *sseq,
                             const int16_t *senscr);

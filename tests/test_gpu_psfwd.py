@@ -1,0 +1,70 @@
+"""Parity (MI355X): pocketsphinx's first pass on the device (cmusphinx_amd/csrc/s3a_psfwd.hip behind
+ps_searchfuncs_t, integration/pocketsphinx/ps_search_amd.c) against the unmodified pocketsphinx decoder run live on the
+same box (oracle/_ref/ref_ps_fwd): hypothesis strings AND path scores, the segmentations, and -- first pass only --
+the whole backpointer table, entry for entry in the reference's order, the right-context score stack, the search
+statistics.  Frame-synchronous (start / step / finish with the decoder's own scorer: semi-continuous or continuous),
+with the reference's fwdflat + bestpath on top of the device's table, and as whole utterances in 1 .. 31 lanes
+(scoring + search on the device, hypotheses made on the device).  Bit-exact: integer work."""
+import pytest
+
+import psfwd_cases as P
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(args, tmp_path, amd_extra=()):
+    r = P.run("ref_ps_fwd", args, tmp_path, "ref")
+    a = P.run("ref_ps_amdfwd", args + list(amd_extra), tmp_path, "amd")
+    assert "first pass served by libcmusphinx_amd" in a[3] or "first pass served by" in a[3]
+    return r, a
+
+
+def test_pocketsphinx_regression_default_passes(tmp_path):
+    """test-tidigits-simple.sh as pocketsphinx runs it: 31 utterances through one decoder, fwdflat + bestpath"""
+    r, a = pair(P.sc_args(tmp_path), tmp_path)
+    P.assert_same(r, a, tables=False)
+
+
+def test_pocketsphinx_regression_tables(tmp_path):
+    r, a = pair(P.sc_args(tmp_path) + P.FIRST_PASS_ONLY, tmp_path)
+    P.assert_same(r, a)
+
+
+def test_continuous_model_frame_synchronous(tmp_path):
+    r, a = pair(P.cont_args(tmp_path) + P.FIRST_PASS_ONLY, tmp_path)
+    P.assert_same(r, a)
+
+
+@pytest.mark.parametrize("lanes", [1, 8, 31])
+def test_whole_utterances_on_the_device(tmp_path, lanes):
+    r, a = pair(P.cont_args(tmp_path) + P.FIRST_PASS_ONLY + ["-fresh", "yes"], tmp_path, ["-batch", str(lanes)])
+    P.assert_same(r, a)
+
+
+def test_whole_utterances_all_senones(tmp_path):
+    r, a = pair(P.cont_args(tmp_path) + P.FIRST_PASS_ONLY + ["-fresh", "yes", "-compallsen", "yes"], tmp_path, ["-batch", "16"])
+    P.assert_same(r, a)
+
+
+def test_whole_utterances_keep_decoder_state(tmp_path):
+    """one lane, utterance after utterance WITHOUT resets = one reference decoder used the same way"""
+    r, a = pair(P.cont_args(tmp_path) + P.FIRST_PASS_ONLY, tmp_path, ["-batch", "1"])
+    P.assert_same(r, a)
+
+
+def test_goforward_raw(tmp_path):
+    r, a = pair(P.turtle_args(tmp_path, ("goforward", "numbers", "something")) + P.FIRST_PASS_ONLY, tmp_path)
+    P.assert_same(r, a)
+    assert r[0].startswith("go forward ten meters (goforward")
+
+
+@pytest.mark.parametrize("extra", [[], ["-maxhmmpf", "800", "-maxwpf", "5", "-beam", "1e-60", "-wbeam", "1e-30"]],
+                         ids=["default", "pruned"])
+def test_mandarin_trigram_tables(tmp_path, extra):
+    r, a = pair(P.zh_args(tmp_path) + P.FIRST_PASS_ONLY + extra, tmp_path)
+    P.assert_same(r, a)
+
+
+def test_mandarin_default_passes(tmp_path):
+    r, a = pair(P.zh_args(tmp_path, ("goforward",)), tmp_path)
+    P.assert_same(r, a, tables=False)
