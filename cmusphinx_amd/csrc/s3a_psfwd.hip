@@ -26,6 +26,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
@@ -33,7 +34,7 @@
 
 #include "s3a_device.h"
 
-#define NT 256
+#define NT 512
 #define PS_WORST ((int32_t)0xE0000000)      /* hmm.h:74 */
 #define PS_TMAT_WORST (-255)                /* hmm.h:80 */
 #define PS_BAD_SSID 0xffff
@@ -46,6 +47,9 @@ struct PsfScalars {
     int32_t st_root, st_nonroot, st_last, st_wlast, st_cand, st_sen;
     int32_t n_total;            /* frames of the utterance (whole-utterance mode) */
     int32_t exit_bp, exit_score, n_seg, finished;
+#ifdef PSF_TIMING
+    unsigned long long t_phase[16], t_last;     /* wall_clock64 ticks (100 MHz) per phase of the frame; diagnostics build */
+#endif
 };
 
 struct PsfLane {
@@ -61,7 +65,8 @@ struct PsfLane {
     int32_t *bp_frame, *bp_wid, *bp_bp, *bp_score, *bp_sidx, *bp_realwid;
     uint8_t *bp_valid;
     int32_t *bss, *bp_idx;                      /* bp_idx[1 + frame]; [0] is the reference's bp_table_idx[-1] */
-    uint8_t *flags;                             /* [n_sen] acmod->senone_active_vec */
+    uint8_t *flags;                             /* [n_sen] acmod->senone_active_vec as bytes (frame-synchronous mode's output) */
+    int32_t *rl;                                /* [n_root] the roots active in the current frame, in index order */
     int16_t *senscr;                            /* [n_sen] frame-synchronous mode: acmod_score's output */
     const int16_t *raw;                         /* whole-utterance mode: [window][n_sen] scores before normalisation */
     PsfScalars *sc;
@@ -322,41 +327,64 @@ hmm_vit_eval(const PsfModel &M, PsfLane &L, int32_t c, int32_t m, const SenScr &
 #undef TPV
 }
 
-/* acmod_activate_hmm, acmod.c:1173-1214 */
+/* acmod_activate_hmm, acmod.c:1173-1214: acmod->senone_active_vec is a bit vector in LDS */
+#define SENBITS_WORDS 2048      /* 65536 senones (s3senid_t is 16 bits) */
+#define ROOTBITS_WORDS 1024     /* 32768 root channels */
+__device__ __forceinline__ void
+setbit(uint32_t *bits, uint32_t i) { atomicOr(&bits[i >> 5], 1u << (i & 31)); }
+
 template <int NE, bool MPX> __device__ __forceinline__ void
-activate(const PsfModel &M, const PsfLane &L, int32_t c, int32_t m, uint8_t *flags)
+activate(const PsfModel &M, const PsfLane &L, int32_t c, int32_t m, uint32_t *bits)
 {
     if (MPX) {
 #pragma unroll
         for (int k = 0; k < NE; k++) {
             const uint16_t id = L.mpxid[k * M.n_mpx + m];
-            if (id != PS_BAD_SSID) flags[M.sseq[(uint32_t)id * NE + k]] = 1;
+            if (id != PS_BAD_SSID) setbit(bits, M.sseq[(uint32_t)id * NE + k]);
         }
     }
     else {
         const uint32_t ssid = M.ch_ssid[c];
 #pragma unroll
-        for (int k = 0; k < NE; k++) flags[M.sseq[ssid * NE + k]] = 1;
+        for (int k = 0; k < NE; k++) setbit(bits, M.sseq[ssid * NE + k]);
     }
 }
 
-/* compute_sen_active :513-552 into L.flags */
+/* the roots active in frame f, in index order, from their bit vector: L.rl[0 .. return) */
+__device__ int32_t
+d_root_list(const PsfModel &M, PsfLane &L, Wg &wg, const uint32_t *rootbits)
+{
+    const int32_t nw = (M.n_root + 31) >> 5;
+    int32_t base = 0;
+    for (int32_t w0 = 0; w0 < nw; w0 += NT) {
+        const int32_t w = w0 + threadIdx.x;
+        uint32_t v = w < nw ? rootbits[w] : 0u;
+        int32_t off, o2, tot, t2;
+        wg_scan2(wg, __popc(v), 0, off, o2, tot, t2);
+        off += base;
+        while (v) { const int b = __ffs(v) - 1; v &= v - 1; L.rl[off++] = (w << 5) + b; }
+        base += tot;
+    }
+    __syncthreads();
+    return base;
+}
+
+/* compute_sen_active :513-552 into the bit vector */
 template <int NE> __device__ void
-d_sen_active(const PsfModel &M, PsfLane &L, const PsfScalars &S, int32_t f)
+d_sen_active(const PsfModel &M, PsfLane &L, const PsfScalars &S, int32_t f, uint32_t *senbits, int32_t n_rl)
 {
     const int tid = threadIdx.x, cur = f & 1;
-    for (int32_t i = tid; i < M.n_sen; i += NT) L.flags[i] = 0;
+    for (int32_t i = tid; i < ((M.n_sen + 31) >> 5); i += NT) senbits[i] = 0;
     __syncthreads();
-    for (int32_t i = tid; i < M.n_root; i += NT)
-        if (L.frame[i] == f) activate<NE, true>(M, L, i, i, L.flags);
-    for (int32_t j = tid; j < S.n_acl[cur]; j += NT) activate<NE, false>(M, L, L.acl[cur][j], 0, L.flags);
+    for (int32_t j = tid; j < n_rl; j += NT) { const int32_t i = L.rl[j]; activate<NE, true>(M, L, i, i, senbits); }
+    for (int32_t j = tid; j < S.n_acl[cur]; j += NT) activate<NE, false>(M, L, L.acl[cur][j], 0, senbits);
     for (int32_t j = tid; j < S.n_awl[cur]; j += NT) {
         const int32_t w = L.awl[cur][j], c0 = M.rc_base + M.w_rc_base[w];
         for (int32_t r = 0; r < M.w_rcsize[w]; r++)
-            if (L.frame[c0 + r] == f) activate<NE, false>(M, L, c0 + r, 0, L.flags);
+            if (L.frame[c0 + r] == f) activate<NE, false>(M, L, c0 + r, 0, senbits);
     }
     for (int32_t i = tid; i < M.n_1ph; i += NT)
-        if (L.frame[M.sp_base + i] == f) activate<NE, true>(M, L, M.sp_base + i, M.n_root + i, L.flags);
+        if (L.frame[M.sp_base + i] == f) activate<NE, true>(M, L, M.sp_base + i, M.n_root + i, senbits);
     __syncthreads();
 }
 
@@ -365,43 +393,59 @@ d_sen_active(const PsfModel &M, PsfLane &L, const PsfScalars &S, int32_t f)
  * flags into a delta list in which a gap over 255 is bridged by extra entries -- senones that are then scored and
  * take part in the normalisation like any other (ms_mgau.c:219-233); the best (smallest) score over all listed
  * senones is the frame's normaliser.  Returns it through *best, the list length through *count.
+ * One thread per 32-senone word of the bit vector; the previous active senone of a word's first one comes from a
+ * workgroup max-scan of the words' highest set bits (the list starts its deltas at senone 0).
  */
 __device__ void
-d_normaliser(const PsfModel &M, const PsfLane &L, Wg &wg, int32_t *sh, const int16_t *raw, int compallsen,
+d_normaliser(const PsfModel &M, Wg &wg, int32_t *sh, const uint32_t *senbits, const int16_t *raw, int compallsen,
              int32_t *best, int32_t *count)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t mn = INT_MAX, cnt = 0;
     if (compallsen) {
         for (int32_t s = tid; s < M.n_sen; s += NT) mn = min(mn, (int32_t)raw[s]);
         cnt = tid == 0 ? M.n_sen : 0;
     }
     else {
-        const int32_t K = (M.n_sen + NT - 1) / NT, s0 = tid * K, s1 = min(M.n_sen, s0 + K);
-        int32_t first = -1, prev = -1;
-        for (int32_t s = s0; s < s1; s++) {
-            if (!L.flags[s]) continue;
-            if (prev < 0) first = s;
-            else for (int32_t x = prev + 255; x < s; x += 255) { mn = min(mn, (int32_t)raw[x]); cnt++; }
-            mn = min(mn, (int32_t)raw[s]); cnt++;
-            prev = s;
-        }
-        sh[tid] = first; sh[NT + tid] = prev;
-        __syncthreads();
-        if (tid == 0) {
-            int32_t last = 0;       /* acmod_flags2list starts its deltas at senone 0 */
-            for (int t = 0; t < NT; t++) {
-                if (sh[t] < 0) continue;
-                for (int32_t x = last + 255; x < sh[t]; x += 255) { mn = min(mn, (int32_t)raw[x]); cnt++; }
-                last = sh[NT + t];
+        const int32_t nw = (M.n_sen + 31) >> 5;
+        int32_t carry = 0;          /* the last active senone before this chunk of words (0: the list's origin) */
+        for (int32_t w0 = 0; w0 < nw; w0 += NT) {
+            const int32_t w = w0 + tid;
+            uint32_t v = w < nw ? senbits[w] : 0u;
+            /* inclusive max-scan of the highest active senone per word */
+            int32_t hi = v ? (w << 5) + 31 - __clz(v) : -1, x = hi;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(x, o, 64); if (lane >= o) x = max(x, y); }
+            if (lane == 63) sh[wv] = x;
+            __syncthreads();
+            int32_t before = -1, all = -1;
+#pragma unroll
+            for (int i = 0; i < NT / 64; i++) { if (i < wv) before = max(before, sh[i]); all = max(all, sh[i]); }
+            int32_t prevx = __shfl_up(x, 1, 64);
+            if (lane == 0) prevx = -1;
+            int32_t prev = max(before, prevx);
+            if (prev < 0) prev = carry;
+            __syncthreads();
+            while (v) {
+                const int32_t s = (w << 5) + __ffs(v) - 1;
+                v &= v - 1;
+                for (int32_t b = prev + 255; b < s; b += 255) { mn = min(mn, (int32_t)raw[b]); cnt++; }
+                mn = min(mn, (int32_t)raw[s]); cnt++;
+                prev = s;
             }
+            if (all >= 0) carry = all;
         }
-        __syncthreads();
     }
     int32_t a = -mn, b = INT_MIN, z = 0;
     wg_reduce4(wg, a, b, cnt, z);
     *best = -a; *count = cnt;
 }
+
+#ifdef PSF_TIMING
+#define TPHASE(S, k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); (S).t_phase[k] += t_ - (S).t_last; (S).t_last = t_; } } while (0)
+#else
+#define TPHASE(S, k) do { } while (0)
+#endif
 
 /* ------------------------------------------------------------------ */
 /* one frame of one lane: ngram_fwdtree_search :1446-1488             */
@@ -414,7 +458,29 @@ struct FrameShared {
     int32_t bins[256];
     int32_t brc_score[256], brc_path[256], brc_lc[256];
     int32_t carryA, carryB, carryC, misc[8];
+    int32_t n_rl;
+    uint32_t senbits[SENBITS_WORDS];            /* acmod->senone_active_vec */
+    uint32_t rootbits[ROOTBITS_WORDS];          /* roots active in the NEXT frame (set while the frame runs) */
 };
+
+/* at a kernel's start: the bit vector of the roots active in frame f, from the channels' frame numbers */
+__device__ void
+d_root_bits_from_frames(const PsfModel &M, const PsfLane &L, uint32_t *rootbits, int32_t f)
+{
+    for (int32_t i = threadIdx.x; i < ((M.n_root + 31) >> 5); i += NT) rootbits[i] = 0;
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < M.n_root; i += NT) if (L.frame[i] == f) setbit(rootbits, i);
+    __syncthreads();
+}
+/* at a frame's start: rootbits -> L.rl, then cleared to collect the next frame's */
+__device__ void
+d_frame_roots(const PsfModel &M, PsfLane &L, FrameShared &F)
+{
+    const int32_t n = d_root_list(M, L, F.wg, F.rootbits);
+    if (threadIdx.x == 0) F.n_rl = n;
+    for (int32_t i = threadIdx.x; i < ((M.n_root + 31) >> 5); i += NT) F.rootbits[i] = 0;
+    __syncthreads();
+}
 
 template <int NE> __device__ void
 d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &sen, int32_t n_senone_active)
@@ -441,7 +507,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
             const int32_t o = L.out_score[c];
             if (o > PS_WORST) L.out_score[c] = sub32(o, norm);
         };
-        for (int32_t i = tid; i < M.n_root; i += NT) if (L.frame[i] == f) normalize(i);
+        for (int32_t j = tid; j < F.n_rl; j += NT) normalize(L.rl[j]);
         for (int32_t j = tid; j < S.n_acl[cur]; j += NT) normalize(L.acl[cur][j]);
         for (int32_t j = tid; j < S.n_awl[cur]; j += NT) {
             const int32_t w = L.awl[cur][j], c0 = M.rc_base + M.w_rc_base[w];
@@ -452,11 +518,11 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         __syncthreads();
     }
 
+    TPHASE(S, 2);
     /* ---- evaluate_channels :694-706 ---- */
     {
         int32_t mx = PS_WORST, lp = PS_WORST, n_rt = 0, kj = 0;
-        for (int32_t i = tid; i < M.n_root; i += NT)
-            if (L.frame[i] == f) { mx = max(mx, hmm_vit_eval<NE, true>(M, L, i, i, sen)); n_rt++; }
+        for (int32_t j = tid; j < F.n_rl; j += NT) { const int32_t i = L.rl[j]; mx = max(mx, hmm_vit_eval<NE, true>(M, L, i, i, sen)); n_rt++; }
         for (int32_t j = tid; j < S.n_acl[cur]; j += NT) mx = max(mx, hmm_vit_eval<NE, false>(M, L, L.acl[cur][j], 0, sen));
         for (int32_t j = tid; j < S.n_awl[cur]; j += NT) {
             const int32_t w = L.awl[cur][j], c0 = M.rc_base + M.w_rc_base[w];
@@ -487,15 +553,21 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         __syncthreads();
     }
 
+    TPHASE(S, 3);
     /* ---- prune_channels :1125-1177: the dynamic beam ---- */
     if (tid == 0) { S.n_cand = 0; S.dyn_beam = M.beam; }
     const int32_t bw = -M.beam / 256;
     if (M.maxhmmpf != -1 && S.st_root + S.st_nonroot > M.maxhmmpf && bw != 0) {     /* block-uniform */
         for (int i = tid; i < 256; i += NT) F.bins[i] = 0;
         __syncthreads();
-        for (int32_t i = tid; i < M.n_root; i += NT) {
-            int32_t b = sub32(S.best_score, L.best[i]) / bw;
+        /* every root channel is binned (:1143-1151); one that is not active has bestscore WORST_SCORE */
+        for (int32_t j = tid; j < F.n_rl; j += NT) {
+            int32_t b = sub32(S.best_score, L.best[L.rl[j]]) / bw;
             atomicAdd(&F.bins[b >= 256 ? 255 : b], 1);
+        }
+        if (tid == 0) {
+            int32_t b = sub32(S.best_score, PS_WORST) / bw;
+            atomicAdd(&F.bins[b >= 256 ? 255 : b], M.n_root - F.n_rl);
         }
         for (int32_t j = tid; j < S.n_acl[cur]; j += NT) {
             int32_t b = sub32(S.best_score, L.best[L.acl[cur][j]]) / bw;
@@ -530,14 +602,15 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     };
     if (tid == 0) { F.carryA = 0; F.carryC = 0; }
     __syncthreads();
-    const int32_t n_par = M.n_root + n_acl;
+    const int32_t n_rl = F.n_rl, n_par = n_rl + n_acl;
     for (int32_t base = 0; base < n_par; base += NT) {
         const int32_t p = base + tid;
         int32_t cntA = 0, cntC = 0, c = -1, pos = -1;
         bool alive = false, surv = false, selfapp = false;
         if (p < n_par) {
-            if (p < M.n_root) { c = p; alive = !(L.frame[c] < f); }
-            else { pos = p - M.n_root; c = acl[pos]; alive = true; }
+            if (p < n_rl) c = L.rl[p];
+            else { pos = p - n_rl; c = acl[pos]; }
+            alive = true;
         }
         if (alive) {
             surv = L.best[c] > thresh;
@@ -571,7 +644,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         wg_scan2(F.wg, cntA, cntC, oa, oc, ta, tc);
         oa += F.carryA; oc += F.carryC;
         if (alive && surv) {
-            if (pos < 0) L.frame[c] = nf;                                               /* :733 */
+            if (pos < 0) { L.frame[c] = nf; setbit(F.rootbits, c); }                    /* :733 */
             if (selfapp) { nacl[oa] = c; napos[c - M.n_root] = oa; oa++; }
             const int32_t ns0 = add32(L.out_score[c], M.pip);
             if (ns0 > newphone_thresh)
@@ -622,6 +695,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     }
     if (tid == 0) { S.n_acl[nxt] = n_nacl; S.n_cand = n_cand; S.st_cand += n_cand; }
     __syncthreads();
+    TPHASE(S, 4);
 
     /* ---- last_phone_transition :877-1030 ---- */
     {
@@ -699,6 +773,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         }
     }
 
+    TPHASE(S, 5);
     /* ---- prune_word_chan :1037-1122 with ngram_search_save_bp (ngram_search.c:360-441) ---- */
     {
         const int32_t newword_thresh = add32(S.lp_best, M.wbeam), lpo_thresh = add32(S.lp_best, M.lponlybeam);
@@ -765,6 +840,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         __syncthreads();
     }
     const int32_t bp0 = F.misc[0], bp1 = S.bpidx, n_ent = bp1 - bp0;
+    TPHASE(S, 6);
 
     /* ---- bptable_maxwpf :1183-1233 ---- */
     if (M.maxwpf != -1 && M.maxwpf != M.n_words && n_ent > 0) {
@@ -808,6 +884,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         __syncthreads();
     }
 
+    TPHASE(S, 7);
     /* ---- word_transition :1236-1405 ---- */
     {
         /* the best exit per right-context phone over ALL entries of the frame (valid or not) except </s> */
@@ -835,6 +912,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                 if (ns > wthresh && (L.frame[i] < f || ns > L.score[i])) {
                     L.score[i] = ns; L.hist[i] = F.brc_path[ci]; L.frame[i] = nf;
                     L.mpxid[i] = M.root_lc_ssid[i * M.n_ci + F.brc_lc[ci]];
+                    setbit(F.rootbits, i);
                 }
             }
             /* single-phone words of the LM: the best predecessor with its trigram score (:1323-1349) */
@@ -879,11 +957,13 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         __syncthreads();
     }
 
+    TPHASE(S, 8);
     /* ---- deactivate_channels :1421-1443 ---- */
-    for (int32_t i = tid; i < M.n_root; i += NT) if (L.frame[i] == f) hmm_clear_scores<NE>(M, L, i);
+    for (int32_t j = tid; j < F.n_rl; j += NT) { const int32_t i = L.rl[j]; if (L.frame[i] == f) hmm_clear_scores<NE>(M, L, i); }
     for (int32_t i = tid; i < M.n_1ph; i += NT) if (L.frame[M.sp_base + i] == f) hmm_clear_scores<NE>(M, L, M.sp_base + i);
     if (tid == 0) S.n_frame++;
     __syncthreads();
+    TPHASE(S, 9);
 }
 
 /* ngram_fwdtree_start :464-507; fresh: what a new decoder's channels look like (init_search_tree :66-148) */
@@ -989,9 +1069,14 @@ k_psf_sen_active(PsfModel M, PsfLane *lanes, int32_t lane, int32_t f)
 {
     PsfLane L = lanes[lane];
     __shared__ PsfScalars S;
+    __shared__ Wg wg;
+    __shared__ uint32_t senbits[SENBITS_WORDS], rootbits[ROOTBITS_WORDS];
     if (threadIdx.x == 0) S = *L.sc;
     __syncthreads();
-    d_sen_active<NE>(M, L, S, f);
+    d_root_bits_from_frames(M, L, rootbits, f);
+    const int32_t n_rl = d_root_list(M, L, wg, rootbits);
+    d_sen_active<NE>(M, L, S, f, senbits, n_rl);
+    for (int32_t s = threadIdx.x; s < M.n_sen; s += NT) L.flags[s] = (senbits[s >> 5] >> (s & 31)) & 1;
 }
 
 /* frame-synchronous: one frame of one lane with the caller's (normalised) senone scores in L.senscr */
@@ -1002,6 +1087,8 @@ k_psf_step(PsfModel M, PsfLane *lanes, int32_t lane, int32_t f, int32_t n_senone
     __shared__ FrameShared F;
     if (threadIdx.x == 0) F.S = *L.sc;
     __syncthreads();
+    d_root_bits_from_frames(M, L, F.rootbits, f);
+    d_frame_roots(M, L, F);
     SenScr sen = { L.senscr, 0, 0 };
     d_frame<NE>(M, L, F, f, sen, n_senone_active);
     __syncthreads();
@@ -1032,11 +1119,18 @@ k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, in
     __syncthreads();
     const int32_t n_total = F.S.n_total;
     if (F.S.finished) return;
+    d_root_bits_from_frames(M, L, F.rootbits, f0);
     for (int32_t f = f0; f < f0 + n_win && f < n_total; f++) {
         const int16_t *raw = L.raw + (size_t)(f - f0) * M.n_sen;
         int32_t best = 0, count = 0;
-        if (!compallsen) d_sen_active<NE>(M, L, F.S, f);
-        d_normaliser(M, L, F.wg, F.sh, raw, compallsen, &best, &count);
+#ifdef PSF_TIMING
+        if (threadIdx.x == 0) F.S.t_last = wall_clock64();
+#endif
+        d_frame_roots(M, L, F);
+        if (!compallsen) d_sen_active<NE>(M, L, F.S, f, F.senbits, F.n_rl);
+        TPHASE(F.S, 0);
+        d_normaliser(M, F.wg, F.sh, F.senbits, raw, compallsen, &best, &count);
+        TPHASE(F.S, 1);
         SenScr sen = { raw, best, 1 };
         d_frame<NE>(M, L, F, f, sen, count);
         __syncthreads();
@@ -1116,11 +1210,12 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     }
     if (d->n_emit != 3 && d->n_emit != 5) { s3a_set_error("s3a_psfwd_init: %d emitting states (3 or 5 served)", d->n_emit); return NULL; }
     if (d->n_ci > 256) { s3a_set_error("s3a_psfwd_init: %d CI phones exceed the kernel's 256", d->n_ci); return NULL; }
+    if (d->n_root > 32 * ROOTBITS_WORDS || d->n_sen > 32 * SENBITS_WORDS) { s3a_set_error("s3a_psfwd_init: %d roots / %d senones exceed the kernel's bit vectors", d->n_root, d->n_sen); return NULL; }
     if (d->n_1ph > NT) { s3a_set_error("s3a_psfwd_init: %d single-phone words exceed the kernel's %d", d->n_1ph, NT); return NULL; }
     if (max_frames > 32767) { s3a_set_error("s3a_psfwd_init: max_frames %d (the reference's frame numbers are int16)", max_frames); return NULL; }
     s3a_psfwd_t *e = new s3a_psfwd_t();
     e->lanes_d = NULL; e->lane_ids_d = NULL; e->stream = NULL; e->ev0 = e->ev1 = NULL; e->last_ms = 0;
-    e->feat_d = NULL; e->feat_cap = 0; e->slot_row_d = NULL; e->slot_cap = 0; e->raw_d = NULL; e->raw_cap = 0; e->win = 8;
+    e->feat_d = NULL; e->feat_cap = 0; e->slot_row_d = NULL; e->slot_cap = 0; e->raw_d = NULL; e->raw_cap = 0; e->win = 32;
     PsfModel &M = e->M;
     memset(&M, 0, sizeof(M));
     e->n_lanes = n_lanes;
@@ -1208,7 +1303,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
         LANE(L.bp_frame, int32_t, M.bp_cap); LANE(L.bp_wid, int32_t, M.bp_cap); LANE(L.bp_bp, int32_t, M.bp_cap); LANE(L.bp_score, int32_t, M.bp_cap);
         LANE(L.bp_sidx, int32_t, M.bp_cap); LANE(L.bp_realwid, int32_t, M.bp_cap); LANE(L.bp_valid, uint8_t, M.bp_cap);
         LANE(L.bss, int32_t, M.bss_cap); LANE(L.bp_idx, int32_t, max_frames + 3);
-        LANE(L.flags, uint8_t, d->n_sen); LANE(L.senscr, int16_t, d->n_sen);
+        LANE(L.flags, uint8_t, d->n_sen); LANE(L.senscr, int16_t, d->n_sen); LANE(L.rl, int32_t, d->n_root + 1);
         LANE(L.sc, PsfScalars, 1); LANE(L.seg, s3a_psfwd_seg_t, MAX_SEG);
         L.raw = NULL;
     }
@@ -1447,6 +1542,14 @@ s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const flo
     for (int32_t z = 0; z < n_utt; z++) {
         PsfScalars sc;
         HIPCHK(hipMemcpy(&sc, e->lanes_h[z].sc, sizeof(sc), hipMemcpyDeviceToHost));
+#ifdef PSF_TIMING
+        if (z == 0) {
+            static const char *nm[10] = { "sen_active", "normaliser", "renorm", "eval", "beam+prune_tree", "last_phone", "prune_word", "maxwpf", "word_trans", "deactivate" };
+            fprintf(stderr, "PSF_TIMING lane 0, %d frames, us per frame:", sc.n_frame);
+            for (int k = 0; k < 10; k++) fprintf(stderr, " %s %.1f", nm[k], sc.t_phase[k] * 0.01 / (sc.n_frame ? sc.n_frame : 1));
+            fprintf(stderr, "\n");
+        }
+#endif
         if (sc.status != 0) { s3a_set_error("s3a_psfwd_decode: utterance %d: the backpointer table (%d entries) or score stack (%d) is full", z, M.bp_cap, M.bss_cap); return sc.status; }
     }
     return S3A_OK;

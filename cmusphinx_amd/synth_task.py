@@ -38,19 +38,21 @@ VECLEN = 39
 WPOS = "besi"                # mdef word-position codes: begin, end, single, internal
 
 
-def _phone_names(n_ciphone):
+def _phone_names(n_ciphone, sorted_names=False):
+    """sorted_names: filler phones named so that the CI phone list is in strcmp order, which pocketsphinx's
+    mdef reader insists on (bin_mdef.c:126); the values of the task do not depend on the names"""
     reg = [f"P{i:02d}" for i in range(n_ciphone - N_FILLER_PHONES)]
-    return reg + ["SIL", "+NOISE+", "+BREATH+"]
+    return reg + (["SIL", "TNOISE", "UBREATH"] if sorted_names else ["SIL", "+NOISE+", "+BREATH+"])
 
 
 def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frames=1000,
-              sep=1.0, noise=1.0, ctx_keep=0.5, n_emit=3):
+              sep=1.0, noise=1.0, ctx_keep=0.5, n_emit=3, sorted_names=False):
     """Write the task under dirpath; returns a dict describing it (paths, args, truth).  n_emit = emitting states per
     HMM: 3 (hub4 / WSJ / RM1 / tidigits) or 5 (Bakis topology with skip transitions: hmm_vit_eval_5st_lr)."""
     N_EMIT = n_emit
     rng = np.random.Generator(np.random.PCG64(seed))
     os.makedirs(os.path.join(dirpath, "feat"), exist_ok=True)
-    names = _phone_names(n_ciphone)
+    names = _phone_names(n_ciphone, sorted_names)
     n_reg = n_ciphone - N_FILLER_PHONES
     sil = n_reg
     n_ci_sen = n_ciphone * N_EMIT
@@ -72,7 +74,7 @@ def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frame
         for w, p in zip(words, prons):
             f.write(f"{w}\t{' '.join(names[x] for x in p)}\n")
     with open(os.path.join(dirpath, "fillerdict"), "w") as f:
-        f.write("<s>\tSIL\n</s>\tSIL\n<sil>\tSIL\n++NOISE++\t+NOISE+\n++BREATH++\t+BREATH+\n")
+        f.write(f"<s>\tSIL\n</s>\tSIL\n<sil>\tSIL\n++NOISE++\t{names[-2]}\n++BREATH++\t{names[-1]}\n")
 
     # ---------------- triphones + tying ----------------
     tri = set()
@@ -230,6 +232,15 @@ def make_task(dirpath, n_sen, n_ciphone, n_comp, n_words, seed, n_utt=4, n_frame
     with open(os.path.join(dirpath, "truth"), "w") as f:
         f.write("\n".join(f"{t} ({n})" for t, n in zip(truth, ctl)) + "\n")
     return dict(dir=dirpath, n_tri=len(tri), utts=ctl, truth=truth, args=decoder_args(dirpath))
+
+
+def ps_decoder_args(d):
+    """the same task files through pocketsphinx (make_task(..., sorted_names=True)): its continuous scorer, its own
+    default beams, first pass only"""
+    return ["-mdef", f"{d}/mdef", "-mean", f"{d}/means", "-var", f"{d}/variances", "-mixw", f"{d}/mixture_weights",
+            "-tmat", f"{d}/transition_matrices", "-senmgau", ".cont.", "-dict", f"{d}/dict", "-fdict", f"{d}/fillerdict",
+            "-lm", f"{d}/lm.arpa", "-feat", "1s_c", "-ceplen", str(VECLEN), "-cmn", "none", "-agc", "none", "-varnorm", "no",
+            "-cepdir", f"{d}/feat", "-cepext", ".mfc", "-ctl", f"{d}/ctl", "-fwdflat", "no", "-bestpath", "no"]
 
 
 def decoder_args(d, beam="1e-60", wbeam="1e-35"):

@@ -271,6 +271,13 @@ ps_amd_decode_cep_batch(ps_decoder_t *ps, int n_utt, mfcc_t ***cep, const int *n
         E_ERROR("s3a_psfwd_decode: %s\n", s3a_last_error());
         goto done;
     }
+    {
+        int32 tot = 0;
+        double ms = s3a_psfwd_last_decode_ms(b->e);
+        for (z = 0; z < n_utt; z++) tot += nfr[z];
+        E_INFO("batch of %d utterances, %d frames: %.2f ms on the device (scoring + search; %.0f frames/s)\n", n_utt, tot, ms,
+               ms > 0 ? tot / (ms * 1e-3) : 0.0);
+    }
     for (z = 0; z < n_utt; z++) {
         static s3a_psfwd_seg_t seg[4096];
         int32 score = 0, n, i;
