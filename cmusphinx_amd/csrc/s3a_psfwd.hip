@@ -67,6 +67,7 @@ struct PsfLane {
     int32_t *bss, *bp_idx;                      /* bp_idx[1 + frame]; [0] is the reference's bp_table_idx[-1] */
     uint8_t *flags;                             /* [n_sen] acmod->senone_active_vec as bytes (frame-synchronous mode's output) */
     int32_t *rl;                                /* [n_root] the roots active in the current frame, in index order */
+    int32_t *arc;                               /* the allocated last-phone channels of the active words, in (word list, right context) order */
     int16_t *senscr;                            /* [n_sen] frame-synchronous mode: acmod_score's output */
     const int16_t *raw;                         /* whole-utterance mode: [window][n_sen] scores before normalisation */
     PsfScalars *sc;
@@ -371,18 +372,21 @@ d_root_list(const PsfModel &M, PsfLane &L, Wg &wg, const uint32_t *rootbits)
 
 /* compute_sen_active :513-552 into the bit vector */
 template <int NE> __device__ void
-d_sen_active(const PsfModel &M, PsfLane &L, const PsfScalars &S, int32_t f, uint32_t *senbits, int32_t n_rl)
+d_sen_active(const PsfModel &M, PsfLane &L, const PsfScalars &S, int32_t f, uint32_t *senbits, int32_t n_rl, int32_t n_arc)
 {
     const int tid = threadIdx.x, cur = f & 1;
     for (int32_t i = tid; i < ((M.n_sen + 31) >> 5); i += NT) senbits[i] = 0;
     __syncthreads();
     for (int32_t j = tid; j < n_rl; j += NT) { const int32_t i = L.rl[j]; activate<NE, true>(M, L, i, i, senbits); }
     for (int32_t j = tid; j < S.n_acl[cur]; j += NT) activate<NE, false>(M, L, L.acl[cur][j], 0, senbits);
-    for (int32_t j = tid; j < S.n_awl[cur]; j += NT) {
-        const int32_t w = L.awl[cur][j], c0 = M.rc_base + M.w_rc_base[w];
-        for (int32_t r = 0; r < M.w_rcsize[w]; r++)
-            if (L.frame[c0 + r] == f) activate<NE, false>(M, L, c0 + r, 0, senbits);
-    }
+    if (n_arc >= 0)
+        for (int32_t j = tid; j < n_arc; j += NT) activate<NE, false>(M, L, L.arc[j], 0, senbits);
+    else
+        for (int32_t j = tid; j < S.n_awl[cur]; j += NT) {
+            const int32_t w = L.awl[cur][j], c0 = M.rc_base + M.w_rc_base[w];
+            for (int32_t r = 0; r < M.w_rcsize[w]; r++)
+                if (L.frame[c0 + r] == f) activate<NE, false>(M, L, c0 + r, 0, senbits);
+        }
     for (int32_t i = tid; i < M.n_1ph; i += NT)
         if (L.frame[M.sp_base + i] == f) activate<NE, true>(M, L, M.sp_base + i, M.n_root + i, senbits);
     __syncthreads();
@@ -458,7 +462,8 @@ struct FrameShared {
     int32_t bins[256];
     int32_t brc_score[256], brc_path[256], brc_lc[256];
     int32_t carryA, carryB, carryC, misc[8];
-    int32_t n_rl;
+    int32_t n_rl, n_arc;
+    int32_t pa[4][NT];                          /* a chunk of parents in prune: first item, channel, list position, appends itself */
     uint32_t senbits[SENBITS_WORDS];            /* acmod->senone_active_vec */
     uint32_t rootbits[ROOTBITS_WORDS];          /* roots active in the NEXT frame (set while the frame runs) */
 };
@@ -479,6 +484,29 @@ d_frame_roots(const PsfModel &M, PsfLane &L, FrameShared &F)
     const int32_t n = d_root_list(M, L, F.wg, F.rootbits);
     if (threadIdx.x == 0) F.n_rl = n;
     for (int32_t i = threadIdx.x; i < ((M.n_root + 31) >> 5); i += NT) F.rootbits[i] = 0;
+    __syncthreads();
+}
+/* at a frame's start: the word_chan lists of the active words (eval_word_chan's walk, :645-662) as one flat list */
+__device__ void
+d_frame_word_chans(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f)
+{
+    const int32_t n_awl = F.S.n_awl[f & 1];
+    int32_t base = 0;
+    for (int32_t j0 = 0; j0 < n_awl; j0 += NT) {
+        const int32_t j = j0 + threadIdx.x;
+        int32_t cnt = 0, c0 = 0, rcs = 0;
+        if (j < n_awl) {
+            const int32_t w = L.awl[f & 1][j];
+            c0 = M.rc_base + M.w_rc_base[w]; rcs = M.w_rcsize[w];
+            for (int32_t r = 0; r < rcs; r++) cnt += L.frame[c0 + r] == f ? 1 : 0;
+        }
+        int32_t off, o2, tot, t2;
+        wg_scan2(F.wg, cnt, 0, off, o2, tot, t2);
+        off += base;
+        for (int32_t r = 0; r < rcs; r++) if (L.frame[c0 + r] == f) L.arc[off++] = c0 + r;
+        base += tot;
+    }
+    if (threadIdx.x == 0) F.n_arc = base;
     __syncthreads();
 }
 
@@ -509,10 +537,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         };
         for (int32_t j = tid; j < F.n_rl; j += NT) normalize(L.rl[j]);
         for (int32_t j = tid; j < S.n_acl[cur]; j += NT) normalize(L.acl[cur][j]);
-        for (int32_t j = tid; j < S.n_awl[cur]; j += NT) {
-            const int32_t w = L.awl[cur][j], c0 = M.rc_base + M.w_rc_base[w];
-            for (int32_t r = 0; r < M.w_rcsize[w]; r++) if (L.frame[c0 + r] == f) normalize(c0 + r);
-        }
+        for (int32_t j = tid; j < F.n_arc; j += NT) normalize(L.arc[j]);
         for (int32_t i = tid; i < M.n_1ph; i += NT) if (L.frame[M.sp_base + i] == f) normalize(M.sp_base + i);
         if (tid == 0) S.renorm = 1;
         __syncthreads();
@@ -524,11 +549,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         int32_t mx = PS_WORST, lp = PS_WORST, n_rt = 0, kj = 0;
         for (int32_t j = tid; j < F.n_rl; j += NT) { const int32_t i = L.rl[j]; mx = max(mx, hmm_vit_eval<NE, true>(M, L, i, i, sen)); n_rt++; }
         for (int32_t j = tid; j < S.n_acl[cur]; j += NT) mx = max(mx, hmm_vit_eval<NE, false>(M, L, L.acl[cur][j], 0, sen));
-        for (int32_t j = tid; j < S.n_awl[cur]; j += NT) {
-            const int32_t w = L.awl[cur][j], c0 = M.rc_base + M.w_rc_base[w];
-            for (int32_t r = 0; r < M.w_rcsize[w]; r++)
-                if (L.frame[c0 + r] == f) { lp = max(lp, hmm_vit_eval<NE, false>(M, L, c0 + r, 0, sen)); kj++; }
-        }
+        for (int32_t j = tid; j < F.n_arc; j += NT) { lp = max(lp, hmm_vit_eval<NE, false>(M, L, L.arc[j], 0, sen)); kj++; }
         int32_t j1 = 0;
         for (int32_t i = tid; i < M.n_1ph; i += NT) {
             const int32_t c = M.sp_base + i;
@@ -603,16 +624,17 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     if (tid == 0) { F.carryA = 0; F.carryC = 0; }
     __syncthreads();
     const int32_t n_rl = F.n_rl, n_par = n_rl + n_acl;
+    /* the next list's entries come in the order (parent in list order: itself, then its entered children in sibling
+     * order).  Per chunk of NT parents: every parent's item count (1 + children if it propagates), then the items
+     * FLAT over the threads -- a root with dozens of children does not hold a thread for dozens of turns. */
     for (int32_t base = 0; base < n_par; base += NT) {
         const int32_t p = base + tid;
-        int32_t cntA = 0, cntC = 0, c = -1, pos = -1;
-        bool alive = false, surv = false, selfapp = false;
+        int32_t items = 0, cntC = 0, c = -1, pos = -1;
+        bool surv = false, selfapp = false;
         if (p < n_par) {
             if (p < n_rl) c = L.rl[p];
             else { pos = p - n_rl; c = acl[pos]; }
-            alive = true;
-        }
-        if (alive) {
+            items = 1;
             surv = L.best[c] > thresh;
             if (pos >= 0 && surv) {
                 /* :822-826 `if (hmm_frame != nf)`: unless the parent's turn came first and entered this channel */
@@ -622,56 +644,60 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                 if (par < M.n_root) par_first_entered = !(L.frame[par] < f) && enters(par, -1, c, &ns);
                 else if (in_acl(par) && apos[par - M.n_root] < pos) par_first_entered = enters(par, apos[par - M.n_root], c, &ns);
                 selfapp = !par_first_entered;
-                cntA += selfapp ? 1 : 0;
             }
             if (surv) {
                 const int32_t ns0 = add32(L.out_score[c], M.pip);
-                if (ns0 > newphone_thresh)
-                    for (int32_t e = M.ch_child_off[c]; e < M.ch_child_off[c + 1]; e++) {
-                        const int32_t x = M.ch_child[e];
-                        int32_t ns;
-                        if (!enters(c, pos, x, &ns)) continue;
-                        bool app;
-                        if (pos < 0) app = true;                                        /* :750-752 */
-                        else if (in_acl(x)) app = !(L.best[x] > thresh && apos[x - M.n_root] < pos);
-                        else app = L.frame[x] != nf;                                    /* :833-836 */
-                        cntA += app ? 1 : 0;
-                    }
+                if (ns0 > newphone_thresh) items += M.ch_child_off[c + 1] - M.ch_child_off[c];
                 if (ns0 > lastphn_thresh) cntC = M.ch_pen_off[c + 1] - M.ch_pen_off[c];
             }
         }
-        int32_t oa, oc, ta, tc;
-        wg_scan2(F.wg, cntA, cntC, oa, oc, ta, tc);
-        oa += F.carryA; oc += F.carryC;
-        if (alive && surv) {
+        int32_t io, oc, ti, tc;
+        wg_scan2(F.wg, items, cntC, io, oc, ti, tc);
+        F.pa[0][tid] = io; F.pa[1][tid] = c; F.pa[2][tid] = pos; F.pa[3][tid] = selfapp ? 1 : 0;
+        oc += F.carryC;
+        if (surv) {
             if (pos < 0) { L.frame[c] = nf; setbit(F.rootbits, c); }                    /* :733 */
-            if (selfapp) { nacl[oa] = c; napos[c - M.n_root] = oa; oa++; }
-            const int32_t ns0 = add32(L.out_score[c], M.pip);
-            if (ns0 > newphone_thresh)
-                for (int32_t e = M.ch_child_off[c]; e < M.ch_child_off[c + 1]; e++) {
-                    const int32_t x = M.ch_child[e];
-                    int32_t ns;
-                    if (!enters(c, pos, x, &ns)) continue;
-                    const bool xin = in_acl(x);
-                    bool app;
-                    if (pos < 0) app = true;
-                    else if (xin) app = !(L.best[x] > thresh && apos[x - M.n_root] < pos);
-                    else app = L.frame[x] != nf;
-                    if (app) { nacl[oa] = x; napos[x - M.n_root] = oa; oa++; }
-                    if (xin) {      /* parked: x's own state is still being read by others */
-                        L.ent_score[x - M.n_root] = ns; L.ent_hist[x - M.n_root] = L.out_hist[c]; L.ent_stamp[x - M.n_root] = tick;
-                    }
-                    else { L.score[x] = ns; L.hist[x] = L.out_hist[c]; L.frame[x] = nf; }  /* hmm_enter; only its parent touches an inactive channel */
-                }
             if (cntC > 0) {
-                const int32_t cs = sub32(ns0, M.nwpen), ch = L.out_hist[c];
+                const int32_t cs = sub32(add32(L.out_score[c], M.pip), M.nwpen), ch = L.out_hist[c];
                 for (int32_t e = M.ch_pen_off[c]; e < M.ch_pen_off[c + 1]; e++, oc++) {
                     L.cand_wid[oc] = M.ch_pen_wid[e]; L.cand_score[oc] = cs; L.cand_bp[oc] = ch;
                 }
             }
         }
         __syncthreads();
-        if (tid == 0) { F.carryA += ta; F.carryC += tc; }
+        for (int32_t qb = 0; qb < ti; qb += NT) {
+            const int32_t q = qb + tid;
+            int32_t flag = 0, item = -1;
+            if (q < ti) {
+                int lo = 0, hi = NT - 1;            /* the last parent whose first item is <= q */
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (F.pa[0][mid] <= q) lo = mid; else hi = mid - 1; }
+                const int32_t k = q - F.pa[0][lo], pc = F.pa[1][lo], ppos = F.pa[2][lo];
+                if (k == 0) { flag = F.pa[3][lo]; item = pc; }
+                else {
+                    const int32_t x = M.ch_child[M.ch_child_off[pc] + k - 1];
+                    int32_t ns;
+                    if (enters(pc, ppos, x, &ns)) {
+                        const bool xin = in_acl(x);
+                        bool app;
+                        if (ppos < 0) app = true;                                       /* :750-752 */
+                        else if (xin) app = !(L.best[x] > thresh && apos[x - M.n_root] < ppos);
+                        else app = L.frame[x] != nf;                                    /* :833-836 */
+                        flag = app ? 1 : 0; item = x;
+                        if (xin) {      /* parked: x's own state is still being read by others */
+                            L.ent_score[x - M.n_root] = ns; L.ent_hist[x - M.n_root] = L.out_hist[pc]; L.ent_stamp[x - M.n_root] = tick;
+                        }
+                        else { L.score[x] = ns; L.hist[x] = L.out_hist[pc]; L.frame[x] = nf; }  /* hmm_enter; only its parent touches an inactive channel */
+                    }
+                }
+            }
+            int32_t oa, oz, ta, tz;
+            wg_scan2(F.wg, flag, 0, oa, oz, ta, tz);
+            if (flag) { nacl[F.carryA + oa] = item; napos[item - M.n_root] = F.carryA + oa; }
+            __syncthreads();
+            if (tid == 0) F.carryA += ta;
+            __syncthreads();
+        }
+        if (tid == 0) F.carryC += tc;
         __syncthreads();
     }
     const int32_t n_nacl = F.carryA, n_cand = F.carryC;
@@ -1075,7 +1101,7 @@ k_psf_sen_active(PsfModel M, PsfLane *lanes, int32_t lane, int32_t f)
     __syncthreads();
     d_root_bits_from_frames(M, L, rootbits, f);
     const int32_t n_rl = d_root_list(M, L, wg, rootbits);
-    d_sen_active<NE>(M, L, S, f, senbits, n_rl);
+    d_sen_active<NE>(M, L, S, f, senbits, n_rl, -1);
     for (int32_t s = threadIdx.x; s < M.n_sen; s += NT) L.flags[s] = (senbits[s >> 5] >> (s & 31)) & 1;
 }
 
@@ -1089,6 +1115,7 @@ k_psf_step(PsfModel M, PsfLane *lanes, int32_t lane, int32_t f, int32_t n_senone
     __syncthreads();
     d_root_bits_from_frames(M, L, F.rootbits, f);
     d_frame_roots(M, L, F);
+    d_frame_word_chans(M, L, F, f);
     SenScr sen = { L.senscr, 0, 0 };
     d_frame<NE>(M, L, F, f, sen, n_senone_active);
     __syncthreads();
@@ -1127,7 +1154,8 @@ k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, in
         if (threadIdx.x == 0) F.S.t_last = wall_clock64();
 #endif
         d_frame_roots(M, L, F);
-        if (!compallsen) d_sen_active<NE>(M, L, F.S, f, F.senbits, F.n_rl);
+        d_frame_word_chans(M, L, F, f);
+        if (!compallsen) d_sen_active<NE>(M, L, F.S, f, F.senbits, F.n_rl, F.n_arc);
         TPHASE(F.S, 0);
         d_normaliser(M, F.wg, F.sh, F.senbits, raw, compallsen, &best, &count);
         TPHASE(F.S, 1);
@@ -1303,7 +1331,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
         LANE(L.bp_frame, int32_t, M.bp_cap); LANE(L.bp_wid, int32_t, M.bp_cap); LANE(L.bp_bp, int32_t, M.bp_cap); LANE(L.bp_score, int32_t, M.bp_cap);
         LANE(L.bp_sidx, int32_t, M.bp_cap); LANE(L.bp_realwid, int32_t, M.bp_cap); LANE(L.bp_valid, uint8_t, M.bp_cap);
         LANE(L.bss, int32_t, M.bss_cap); LANE(L.bp_idx, int32_t, max_frames + 3);
-        LANE(L.flags, uint8_t, d->n_sen); LANE(L.senscr, int16_t, d->n_sen); LANE(L.rl, int32_t, d->n_root + 1);
+        LANE(L.flags, uint8_t, d->n_sen); LANE(L.senscr, int16_t, d->n_sen); LANE(L.rl, int32_t, d->n_root + 1); LANE(L.arc, int32_t, n_rc + 1);
         LANE(L.sc, PsfScalars, 1); LANE(L.seg, s3a_psfwd_seg_t, MAX_SEG);
         L.raw = NULL;
     }
