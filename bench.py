@@ -26,10 +26,15 @@ The decoder is rebuilt from a bundle (cmusphinx_amd/bundle.py) through the C ABI
 the models / dictionary / LM, build the lextrees and write that bundle.
 
 Prints ONE JSON line (rank 0).  Extra keys beyond the driver contract:
-  roofline      the dominant kernel of a frame (per-kernel HIP-event timing of one profiled group of ONE engine; the
-                look-ahead scoring launch counted per frame it serves): achieved = algorithmic bytes (or flops) per launch
-                / average launch time; traffic = HBM bytes per launch from the committed PMC pass (profiles/)
-  kernels       every kernel class of a frame: average microseconds per launch, share of the frame
+  roofline      the dominant kernel of a frame IN THE BENCH (HIP events around every launch of every 8th frame of every engine
+                while all engines run; the look-ahead scoring launch counted per frame it serves): achieved = algorithmic
+                bytes (or flops) per launch / average launch time; `alone` = the same with one engine on the chip; traffic =
+                HBM bytes per launch from the committed PMC pass (profiles/)
+  roofline_scoring  the engine's scoring kernel (north_star's second metric is about scoring): VALU and HBM fractions
+  search        SURVEY 8(d)'s 84 B per active HMM credited ONCE per frame to the search kernels together; HMM updates/s
+  kernels       every kernel class of a frame: microseconds per launch in the bench and alone, stretch, share of the frame
+  ps_fwdtree    SURVEY 8(f).3: pocketsphinx's first pass on the device (s3a_psfwd_decode: scoring + search, one workgroup per
+                utterance) on the same model shape, with the unmodified pocketsphinx on the host beside it
   cpu_baseline  the UNMODIFIED reference decoder (oracle/_ref/sphinx3_decode) on the same task files: 16 processes (where
                 the host's aggregate peaks) over contiguous control-file shards of the batch's first 128 utterances, and
                 one process alone with stat.c's sen / search / tot split
@@ -237,6 +242,60 @@ def scoring_legs(lib, fast):
     return out
 
 
+PSREF = os.path.join(ROOT, "oracle", "_ref", "ref_ps_fwd")
+PSAMD = os.path.join(ROOT, "oracle", "_ref", "ref_ps_amdfwd")
+
+
+def ps_fwdtree_leg(d, lanes, n_frames, n_cpu=4):
+    """pocketsphinx's first pass on the device, measured: the hub4-SHAPED task (same generator, phone names
+    in the order pocketsphinx's mdef reader insists on) decoded by ref_ps_amdfwd -batch <lanes> (integration/pocketsphinx/
+    ps_search_amd.c: features by the decoder's feat_t, then s3a_psfwd_decode = scoring + search of every frame of every
+    lane on the device, hypotheses made on the device), `lanes` utterances as ONE batch; the unmodified pocketsphinx
+    (ref_ps_fwd, one host core) decodes the first n_cpu of them for the comparison and the CPU rate."""
+    from cmusphinx_amd import synth_task
+    if not (os.path.exists(PSREF) and os.path.exists(PSAMD)):
+        return None
+    t = os.path.join(d, "pstask")
+    synth_task.make_task(t, n_utt=lanes, n_frames=n_frames, sorted_names=True, **synth_task.HUB4_TASK)
+    args = synth_task.ps_decoder_args(t)
+    out = {}
+
+    def run(exe, extra, tag, ctl=None):
+        a = list(args)
+        if ctl:
+            a[a.index("-ctl") + 1] = ctl
+        m, sg, lg = (os.path.join(d, f"ps_{tag}.{e}") for e in ("match", "seg", "log"))
+        with open(lg, "w") as lf:
+            r = subprocess.run([exe] + a + extra + ["-hyp", m, "-hypseg", sg], stdout=lf, stderr=subprocess.STDOUT)
+        return r.returncode, open(m).read() if os.path.exists(m) else "", open(sg).read() if os.path.exists(sg) else "", open(lg, errors="ignore").read()
+    ctl4 = os.path.join(d, "ps_ctl_cpu")
+    with open(ctl4, "w") as f:
+        f.writelines(open(os.path.join(t, "ctl")).readlines()[:n_cpu])
+    rc, rm, rs, rlog = run(PSREF, ["-fresh", "yes"], "ref", ctl4)
+    if rc != 0:
+        return {"error": "the unmodified pocketsphinx failed on the task"}
+    cpu = re.search(r"decoded (\d+) frames in ([0-9.]+) s", rlog)
+    rc, am, asg, alog = run(PSAMD, ["-fresh", "yes", "-batch", str(lanes)], "amd")
+    if rc != 0:
+        return {"error": "ref_ps_amdfwd failed: " + " | ".join(l for l in alog.splitlines() if "ERROR" in l or "FATAL" in l)[-300:]}
+    dev = re.search(r"batch of (\d+) utterances, (\d+) frames: ([0-9.]+) ms on the device", alog)
+    same_h = "".join(am.splitlines(keepends=True)[:n_cpu]) == rm
+    same_s = "".join(asg.splitlines(keepends=True)[:n_cpu]) == rs
+    tree = re.search(r"(\d+) roots, (\d+) interior channels, (\d+) single-phone words", alog)
+    out = {"workload": f"hub4-shaped CD-GMM 6144 x 8 x 39, 20 k-word dictionary, ARPA trigram, pocketsphinx's default beams; {lanes} "
+                       f"utterances of ~{n_frames} frames as ONE batch of lanes (one workgroup per utterance), first pass only",
+           "lanes": int(dev.group(1)), "frames": int(dev.group(2)), "device_ms": float(dev.group(3)),
+           "frames_per_sec": round(int(dev.group(2)) / (float(dev.group(3)) * 1e-3), 1),
+           "xRT": round(int(dev.group(2)) / (float(dev.group(3)) * 1e-3) / 100.0, 1),
+           "identical_to_pocketsphinx": {"hyp_and_score": same_h, "segmentation": same_s, "utterances_checked": n_cpu},
+           "search_space": {"roots": int(tree.group(1)), "interior_channels": int(tree.group(2)), "single_phone_words": int(tree.group(3))} if tree else None,
+           "cpu_pocketsphinx": {"frames": int(cpu.group(1)), "seconds": float(cpu.group(2)), "frames_per_sec": round(int(cpu.group(1)) / max(float(cpu.group(2)), 1e-9), 1),
+                                "cores": 1, "kind": "reference"} if cpu else None,
+           "timed": "HIP events on the engine's stream around the windows' scoring + search launches of the whole batch (features resident)"}
+    assert same_h and same_s, "pocketsphinx first pass on the device differs from the unmodified pocketsphinx"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +316,8 @@ def main():
     ap.add_argument("--check-all", action="store_true", help="the reference decodes the WHOLE batch (~3 more minutes of CPU): every utterance is compared")
     ap.add_argument("--cpu-physical", action="store_true", help="add the CPU leg with one process per physical core (~2 minutes)")
     ap.add_argument("--no-scoring", action="store_true", help="skip the scoring-only extra legs")
+    ap.add_argument("--no-ps", action="store_true", help="skip the pocketsphinx first-pass leg")
+    ap.add_argument("--ps-lanes", type=int, default=256, help="utterances (= lanes) of the pocketsphinx leg's batch")
     ap.add_argument("--only-scoring", action="store_true", help="only the scoring legs (PMC passes over the scoring kernels)")
     ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
     args = ap.parse_args()
@@ -499,62 +560,124 @@ def main():
                 print("  device:", lines[k][1].strip()[:600], "\n  refrnc:", rs[k].strip()[:600], file=sys.stderr)
         assert hyp_ok and (seg_ok or args.fast), "device hypotheses differ from the unmodified reference decoder's"
 
-        # ---- per-kernel timing of one profiled group (HIP events on the launch stream, every 4th frame) ----
+        # ---- per-kernel timing (HIP events on the engines' launch streams around every launch of the profiled frames) ----
+        # ALONE: one group of one engine with the chip to itself (every 4th frame).  IN THE BENCH: one more whole step with
+        # ALL engines running as they do in the timed region, every engine bracketing every 8th frame's launches -- the
+        # kernels stretch when four engines share the chip, and the line's `roofline` describes the run it times.
         sched = schedule(my_share(0)[0])
         g0 = sched[0][0][:NLE]
         dec.ud.set_profile(4)
         dec.ud.decode_dev([fdev[k] for k in g0], [nfr[k] for k in g0], D4x4)
-        prof = dec.ud.profile()
+        prof_alone = dec.ud.profile()
         dec.ud.set_profile(0)
         nl0 = len(g0)
         stat = [dec.ud.result(z)["frame_stat"] for z in range(nl0)]
         res0 = dec.ud.result(0)
+        for dd in decs:
+            dd.ud.set_profile(8)
+        run_step(0, sched=sched)
+        lib.check(L.s3a_dev_sync())
+        prof = {}
+        for dd in decs:
+            for k, (us, n) in dd.ud.profile().items():
+                a0, n0 = prof.get(k, (0.0, 0))
+                prof[k] = (a0 + us, n0 + n)
+            dd.ud.set_profile(0)
+        prof = {k: v for k, v in prof.items() if v[1] > 0}
+        lanes_bench = float(np.mean([min(NLE, sum(len(g) for g in e_)) for e_ in sched if e_])) if any(sched) else float(nl0)
         lanes_hmm, lanes_sen, lanes_gau, lanes_exit = (float(np.mean([s[:, c].mean() for s in stat])) for c in (1, 2, 3, 7))
         b = dec.b
         S, Sci, D, Cc = b["n_sen"], b["n_ci_sen"], dec.veclen, dec.g.C
         K = max(1, dec.ud.window())
-        per_frame = {k: (us / n / (K if k == "ku_score_window" else 1)) for k, (us, n) in prof.items()}
-        tot = sum(per_frame.values())
-        kern = {k: {"avg_launch_us": round(prof[k][0] / prof[k][1], 2), "us_per_frame": round(v, 2), "share": round(v / tot, 4)}
-                for k, v in per_frame.items()}
-        dom = max(per_frame, key=lambda k: per_frame[k])
+        SCORING = ("ku_score_window", "ku_gated_cd", "ku_gated_ci", "ku_comsen_max")
+
+        def per_frame_of(pr):
+            return {k: (us / n / (K if k == "ku_score_window" else 1)) for k, (us, n) in pr.items() if n > 0}
+        pf_b, pf_a = per_frame_of(prof), per_frame_of(prof_alone)
+        tot = sum(pf_b.values())
+        kern = {k: {"avg_launch_us": round(prof[k][0] / prof[k][1], 2),
+                    "avg_launch_us_alone": round(prof_alone[k][0] / prof_alone[k][1], 2) if prof_alone.get(k, (0, 0))[1] else None,
+                    "stretch": round((prof[k][0] / prof[k][1]) / (prof_alone[k][0] / prof_alone[k][1]), 2) if prof_alone.get(k, (0, 0))[1] else None,
+                    "us_per_frame": round(v, 2), "share": round(v / tot, 4), "launches_timed": int(prof[k][1])}
+                for k, v in pf_b.items()}
+        dom = max(pf_b, key=lambda k: pf_b[k])
         dom_us = prof[dom][0] / prof[dom][1]
-        # ALGORITHMIC bytes of one launch (all lanes of the engine): SURVEY.md 8(d).  Look-ahead scoring: the Gaussians'
+        dom_us_alone = prof_alone[dom][0] / prof_alone[dom][1] if prof_alone.get(dom, (0, 0))[1] else None
+        # ALGORITHMIC bytes of one launch (all lanes of an engine): SURVEY.md 8(d).  Look-ahead scoring: the Gaussians'
         # parameters once per model pass + per (lane, frame) the vector in and every senone's score (+ 1 byte: its best
-        # component) out; search kernels: ~84 B of HMM state read + written per active HMM; the word level: 40 B per
-        # history entry made + 16 B per (exit, predecessor) pair
-        win_slots = nl0 * K
-        alg = {"ku_score_window": S * Cc * (2 * D + 2) * 4 + win_slots * (D * 4 + S * 5),
-               "ku_gated_cd": nl0 * (S * 1 + lanes_sen * 13.0), "ku_gated_ci": nl0 * 4.0 * b["n_comstate"],
-               "ku_comsen_max": nl0 * 4.0 * b["n_comstate"]}
-        for k in ("ku_hmm_eval", "ku_resolve", "ku_scan", "ku_emit", "ku_enter1", "ku_enter2", "ku_enter3_mark", "ku_hist_count",
-                  "ku_hist_sort", "ku_weak"):
-            alg[k] = nl0 * lanes_hmm * 84.0
-        alg["ku_emit_word"] = alg["ku_emit"] + nl0 * (res0["max_cand"] * 16.0 + res0["max_new"] * 40.0)
-        alg.setdefault(dom, nl0 * lanes_hmm * 84.0)
+        # component) out.  The search: SURVEY's ~84 B of HMM state read + written per active HMM per frame is the budget of
+        # K5-K7 TOGETHER and is credited ONCE per frame to the search as a whole (`search` below); a single search kernel
+        # gets the part of it that kernel has to move: the Viterbi update reads and writes the whole state
+        # (84 B), a propagation / entry / marking kernel reads an exit score + history and writes an entry score + history
+        # + list slot (28 B), the scan and the histogram passes touch one word per HMM (8 B).  The word level: 40 B per
+        # history entry made + 16 B per (exit, predecessor) pair.
+        HMM_BYTES = {"ku_hmm_eval": 84.0, "ku_resolve": 28.0, "ku_emit": 28.0, "ku_enter1": 28.0, "ku_enter2": 28.0, "ku_enter3_mark": 28.0,
+                     "ku_scan": 8.0, "ku_hist_count": 8.0, "ku_hist_sort": 8.0, "ku_weak": 8.0}
+
+        def alg_bytes(k, nl):
+            if k == "ku_score_window":
+                return S * Cc * (2 * D + 2) * 4 + nl * K * (D * 4 + S * 5)
+            if k == "ku_gated_cd":
+                return nl * (S * 1 + lanes_sen * 13.0)
+            if k in ("ku_gated_ci", "ku_comsen_max"):
+                return nl * 4.0 * b["n_comstate"]
+            if k == "ku_emit_word" or k.startswith("ku_wl_"):
+                return nl * (lanes_hmm * 28.0 * (k == "ku_emit_word") + res0["max_cand"] * 16.0 + res0["max_new"] * 40.0)
+            return nl * lanes_hmm * HMM_BYTES.get(k, 28.0)
         pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else {}
         traffic = pmc.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
         if traffic is not None and pmc.get("lanes") and dom != "ku_score_window":
             # the PMC passes ran a smaller engine: the search kernels' traffic is per lane (the look-ahead scoring launch has
             # the same (lane, frame) slots whatever the lane count: K adapts)
-            traffic = int(traffic * nl0 / pmc["lanes"])
+            traffic = int(traffic * lanes_bench / pmc["lanes"])
+
+        def scoring_roof(us, nl):
+            flops = 4.0 * S * Cc * D * nl * K
+            ach = flops / (us * 1e-6) / 1e12
+            gbs = alg_bytes("ku_score_window", nl) / (us * 1e-6) / 1e9
+            return {"bound": "valu-f64", "achieved": round(ach, 2), "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP64_VEC_PEAK_TFLOPS, 4), "hbm_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "avg_launch_us": round(us, 2), "lane_frame_slots_per_launch": int(nl * K)}
         if dom == "ku_score_window":
-            flops = 4.0 * S * Cc * D * win_slots
-            ach = flops / (dom_us * 1e-6) / 1e12
-            roof = {"kernel": dom, "bound": "valu-f64", "achieved": round(ach, 2), "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP64_VEC_PEAK_TFLOPS, 4),
-                    "hbm_GBs": round(alg[dom] / (dom_us * 1e-6) / 1e9, 1), "hbm_frac": round(alg[dom] / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            roof = dict(scoring_roof(dom_us, lanes_bench), kernel=dom)
+            if dom_us_alone:
+                roof["alone"] = scoring_roof(dom_us_alone, nl0)
         else:
-            ach = alg[dom] / (dom_us * 1e-6) / 1e9
+            ab = alg_bytes(dom, lanes_bench)
+            ach = ab / (dom_us * 1e-6) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5)}
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "avg_launch_us": round(dom_us, 2)}
+            if dom_us_alone:
+                aa = alg_bytes(dom, nl0) / (dom_us_alone * 1e-6) / 1e9
+                roof["alone"] = {"achieved": round(aa, 1), "frac": round(aa / HBM_PEAK_GBS, 5), "avg_launch_us": round(dom_us_alone, 2), "lanes_in_launch": nl0}
         roof.update({"traffic": traffic, "traffic_source": pmc.get("source") if traffic is not None else None,
-                     "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_us": round(dom_us, 2), "launches_timed": int(prof[dom][1]),
-                     "lanes_in_launch": nl0,
-                     "note": "per-launch HIP-event timing of every 4th frame of one group of one engine running alone; one launch "
-                             "serves all lanes' frame (ku_score_window: all lanes' next K frames).  The search kernels are chains of "
-                             "scattered 4-byte accesses over a few thousand HMMs per lane: latency-bound, nowhere near a bandwidth "
-                             "roof (DESIGN.md 4); the scoring is float64-VALU-bound (bit-exact mode: no FMA)"})
+                     "algorithmic_bytes_per_launch": int(alg_bytes(dom, lanes_bench)), "launches_timed": int(prof[dom][1]),
+                     "lanes_in_launch": round(lanes_bench, 1), "measured": f"in the bench: all {NE} engines running, HIP events around every launch of every 8th frame",
+                     "note": "the dominant kernel = the largest share of a frame IN THE BENCH (the `kernels` table; `alone` = the same kernel "
+                             "with one engine on the chip).  One launch serves all lanes' frame (ku_score_window: all lanes' next K frames).  "
+                             "The search kernels are chains of scattered 4-byte accesses over a few thousand HMMs per lane: latency-bound, "
+                             "nowhere near a bandwidth roof (DESIGN.md 4); the scoring is float64-VALU-bound (bit-exact mode: no FMA)"})
+        # north_star's second metric is about SCORING: the engine's scoring kernel as a second roofline entry
+        roof_scoring = None
+        if "ku_score_window" in prof:
+            roof_scoring = dict(scoring_roof(prof["ku_score_window"][0] / prof["ku_score_window"][1], lanes_bench), kernel="ku_score_window",
+                                share_of_frame=kern["ku_score_window"]["share"])
+            if prof_alone.get("ku_score_window", (0, 0))[1]:
+                roof_scoring["alone"] = scoring_roof(prof_alone["ku_score_window"][0] / prof_alone["ku_score_window"][1], nl0)
+            roof_scoring["note"] = ("hub4 single-frame scoring (one frame per model pass, HBM-bound) is in `scoring.hub4.frame_sync`: north_star's "
+                                    ">= 0.60 of HBM peak is NOT met there at B = 1; the engine scores K frames of all lanes per model pass instead")
+        # the search as a whole: SURVEY 8(d)'s 84 B per active HMM credited once per frame
+        srch_us = sum(v for k, v in pf_b.items() if k not in SCORING)
+        srch_us_alone = sum(v for k, v in pf_a.items() if k not in SCORING)
+        srch_bytes = lanes_bench * lanes_hmm * 84.0
+        search = {"us_per_frame": round(srch_us, 2), "us_per_frame_alone": round(srch_us_alone, 2),
+                  "share_of_frame": round(srch_us / tot, 4), "kernels": sorted(k for k in pf_b if k not in SCORING),
+                  "algorithmic_bytes_per_frame": int(srch_bytes), "achieved_GBs": round(srch_bytes / (srch_us * 1e-6) / 1e9, 1),
+                  "frac": round(srch_bytes / (srch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "bound": "latency (scattered 4-byte accesses)",
+                  "active_hmm_updates_per_s": round(lanes_hmm * value, 0),
+                  "active_hmm_updates_per_s_cpu_single_core": round(cpu["active_hmm_per_frame"] * cpu["single_core"], 0) if cpu else None,
+                  "note": "84 B x active HMMs x lanes of an engine / the summed duration of the engine's search kernels of one frame, all "
+                          "engines running; active_hmm_updates_per_s = active HMMs per frame x whole-job frames/s"}
 
         # ---- what N = 8 gives a GPU: 128 of the 1024 utterances ----
         proj = None
@@ -600,6 +723,8 @@ def main():
                           "word_exits": round(lanes_exit, 2), "max_active_hmm": int(max(s_[:, 1].max() for s_ in stat)),
                           "frames_with_histogram_pruning": int(sum(int(s_[:, 6].sum()) for s_ in stat)), "max_candidates": int(res0["max_cand"]), "tie_frames_lane0": int(res0["n_tie_frames"])},
             "roofline": roof,
+            "roofline_scoring": roof_scoring,
+            "search": search,
             "kernels": kern,
         }
         if weak:
@@ -610,6 +735,8 @@ def main():
             res["cpu_baseline"] = cpu
         if world == 1 and not args.no_scoring:
             res["scoring"] = scoring_legs(lib, args.fast)
+        if world == 1 and not args.no_ps:
+            res["ps_fwdtree"] = ps_fwdtree_leg(d, args.ps_lanes, T)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <sphinxbase/ckd_alloc.h>
 #include <sphinxbase/cmd_ln.h>
 #include <sphinxbase/err.h>
@@ -211,6 +212,10 @@ main(int argc, char **argv)
         return 0;
     }
 #endif
+    {
+    struct timespec ts0, ts1;
+    long tot_frames = 0;
+    double t_decode = 0.0;
     while (fgets(line, sizeof line, ctl)) {
         char uttid[1024];
         const char *hyp, *id;
@@ -226,21 +231,30 @@ main(int argc, char **argv)
         if (adcin) {
             FILE *fh = fopen(path, "rb");
             if (!fh) E_FATAL("cannot open %s\n", path);
+            clock_gettime(CLOCK_MONOTONIC, &ts0);
             ps_decode_raw(ps, fh, uttid, -1);
+            clock_gettime(CLOCK_MONOTONIC, &ts1);
             fclose(fh);
         }
         else {
             int32 nfr;
             mfcc_t **cep = read_mfc(path, &nfr, feat_cepsize(ps->acmod->fcb));
+            clock_gettime(CLOCK_MONOTONIC, &ts0);
             ps_start_utt(ps, uttid);
             ps_process_cep(ps, cep, nfr, FALSE, TRUE);
             ps_end_utt(ps);
+            clock_gettime(CLOCK_MONOTONIC, &ts1);
             ckd_free_2d((void **)cep);
         }
+        t_decode += (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
+        tot_frames += ps->acmod->output_frame;
         if (bpfh) dump_bptable(bpfh, ps, uttid);       /* before ps_get_hyp: a bestpath pass does not touch it either */
         hyp = ps_get_hyp(ps, &score, &id);
         fprintf(out, "%s (%s %d)\n", hyp ? hyp : "", uttid, score);
         if (segfh) write_seg(segfh, ps, uttid);
+    }
+    E_INFO("decoded %ld frames in %.3f s (%.1f frames/s; features, scoring and search of one utterance at a time, model loading excluded)\n",
+           tot_frames, t_decode, t_decode > 0 ? tot_frames / t_decode : 0.0);
     }
     fclose(out);
     if (segfh) fclose(segfh);
