@@ -360,6 +360,8 @@ def main():
     t_setup = time.perf_counter()
     if rank == 0:
         os.makedirs(d, exist_ok=True)
+        if os.path.exists(os.path.join(d, "rccl-id")):
+            os.remove(os.path.join(d, "rccl-id"))
         synth_task.make_task(d, n_utt=U, n_frames=T, **synth_task.HUB4_TASK)
         r = subprocess.run([SHIM] + synth_task.decoder_args(d), env=dict(os.environ, S3A_UTT="1", S3A_EXPORT=bpath),
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -487,15 +489,20 @@ def main():
             torch.cuda.synchronize()
 
     # ---------------- the timed region ----------------
+    # ONE exchange, in C, for every N: s3a_gather_init (RCCL loaded at run time, ncclUniqueId through a file under the
+    # run's own temporary directory) + s3a_gather_hyps (three ncclAllGathers).  torch.distributed only supplies the barrier
+    # and the max over ranks.  S3A_BENCH_ONE_GPU=1 (several ranks on one GPU, where RCCL cannot run) keeps shard.gather_var.
     cgather = None
-    if dist is None and not os.environ.get("S3A_BENCH_NO_RCCL"):
+    if not rehearsal and not os.environ.get("S3A_BENCH_NO_RCCL"):
         import ctypes
         saved = os.dup(1)
         try:
             sys.stdout.flush()
             os.dup2(2, 1)                   # (RCCL prints a version banner to C stdout: keep stdout to the ONE JSON line)
-            cgather = lib.Gather(0, 1)      # (the drop-in's own C exchange; RCCL loaded at run time)
-        except lib.S3AError:
+            cgather = lib.Gather(rank, world, os.path.join(d, "rccl-id"))
+        except lib.S3AError as e:
+            if world > 1:
+                raise SystemExit(f"bench.py: the C exchange could not start on rank {rank}: {e}")
             cgather = None
         finally:
             ctypes.CDLL(None).fflush(None)
@@ -510,10 +517,10 @@ def main():
     for i in range(args.steps):
         recs = []
         dev_ms += run_step(i, recs)
-        if dist is not None:
-            allrec = shard.gather_var(recs, n_total, dist, device=tdev)          # two collectives of torch.distributed (RCCL)
-        elif cgather is not None:
-            allrec = cgather.gather(recs, n_total)       # the C side's exchange (s3a_gather_hyps over RCCL), one rank
+        if cgather is not None:
+            allrec = cgather.gather(recs, n_total)       # the C side's exchange (s3a_gather_hyps over RCCL), every N
+        elif dist is not None:
+            allrec = shard.gather_var(recs, n_total, dist, device=tdev)          # rehearsal on one GPU: torch.distributed (gloo)
         else:
             allrec = sorted(recs, key=lambda t: t[0].utt_index)
     sync_all()
@@ -532,7 +539,7 @@ def main():
         t1 = time.perf_counter()
         wrecs = []
         run_step(0, wrecs)
-        wall = shard.gather_var(wrecs, U * world, dist, device=tdev)
+        wall = cgather.gather(wrecs, U * world) if cgather is not None else shard.gather_var(wrecs, U * world, dist, device=tdev)
         sync_all()
         wdt = time.perf_counter() - t1
         tw = torch.tensor([wdt], dtype=torch.float64, device=tdev)
@@ -710,14 +717,14 @@ def main():
                        "utterances_per_step": n_total, "frames_per_step": frames_step, "lanes_per_gpu": NL, "engines_per_gpu": NE, "lane_refill": bool(args.refill and len(my_share(0)[0]) > NL),
                        "groups_rank0": [len(g) for e in sched for g in e],
                        "beams": "-beam 1e-60 -wbeam 1e-35 -maxhmmpf 20000 -maxwpf 10 -lw 9.5 (the reference's hub4 settings)",
-                       "parallelism": f"utterance-sharded x{world} ({args.scaling}), two collectives per batch: headers, then the words "
-                                      f"padded per rank (no word limit)"},
+                       "parallelism": f"utterance-sharded x{world} ({args.scaling}), ONE exchange per batch in C (three ncclAllGathers: counts, "
+                                      f"headers, words padded per rank; no word limit), no per-frame collective"},
             "xRT_per_gpu": round(value / world / 100.0, 1),
             "device_ms_per_step": round(dev_ms / args.steps, 3),
             "host_side_last_step": {k: round(v, 3) for k, v in host_t.items()},
             "identical_to_reference": {"hyp": hyp_ok, "hypseg": seg_ok}, "utterances_checked_against_reference": n_chk,
-            "exchange": ("torch.distributed all_gather x2 (RCCL)" if world > 1 else
-                         "s3a_gather_hyps (C, RCCL, 1 rank)" if cgather is not None else "none (RCCL not loadable)"),
+            "exchange": (f"s3a_gather_hyps (C, RCCL, {world} rank{'s' if world > 1 else ''})" if cgather is not None else
+                         "torch.distributed all_gather x2 over gloo (S3A_BENCH_ONE_GPU rehearsal)" if world > 1 else "none (RCCL not loadable)"),
             "load_s": round(t_load, 2), "setup_s": round(t_setup, 1),
             "per_frame": {"active_hmm": round(lanes_hmm, 1), "cd_senones_scored": round(lanes_sen, 1), "cd_gaussians": round(lanes_gau, 1),
                           "word_exits": round(lanes_exit, 2), "max_active_hmm": int(max(s_[:, 1].max() for s_ in stat)),

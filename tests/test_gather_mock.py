@@ -1,0 +1,93 @@
+"""The C exchange with world > 1, on CPU: s3a_gather_init (file rendezvous) + s3a_gather_hyps (three all-gathers: counts,
+headers padded to the largest rank, words padded to the largest rank; ordering by utterance index) run in 2 and 3 processes
+against tests/mock_rccl.c, a stand-in librccl.so whose collectives go through files and take host pointers.  What the real
+RCCL run on N GPUs does with device buffers is this arithmetic; on a one-GPU box only world = 1 can be exercised."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+WORKER = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from cmusphinx_amd import lib
+rank, world, rdv, n_total, drop = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
+g = lib.Gather(rank, world, rdv)
+for rnd in range(2):                       # twice: the staging buffers are reused (and must grow in round 2)
+    recs = []
+    for u in range(n_total):
+        if u % world != (rank + rnd) % world:
+            continue
+        if drop and rank == world - 1:
+            continue                       # a rank that sends nothing although it was given a share
+        n = (u * 7 + rnd * 13) % 11 * (1 + 5 * rnd)
+        h = lib.HypHeader()
+        h.utt_index, h.status, h.n_frames, h.score, h.n_words = u, (1 if u % 5 == 4 else 0), 100 + u, -1000 * u - rnd, n
+        w = (np.arange(n * 6, dtype=np.int32).reshape(n, 6) + 1000 * u + rnd) if h.status == 0 else np.zeros((0, 6), np.int32)
+        recs.append((h, w))
+    try:
+        out = g.gather(recs, n_total)
+        res = [[h.utt_index, h.status, h.n_frames, h.score, h.n_words, w.ravel().tolist()] for h, w in out]
+        err = None
+    except lib.S3AError as e:
+        res, err = None, str(e)
+    if rank == 0:
+        print(json.dumps({"round": rnd, "res": res, "err": err}))
+'''
+
+
+@pytest.fixture(scope="module")
+def mock_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("mockrccl")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", str(d / "librccl.so"), os.path.join(ROOT, "tests", "mock_rccl.c")], check=True)
+    return d
+
+
+def run_world(mock_dir, tmp_path, world, n_total, drop=0):
+    rdv = str(tmp_path / "rccl-id")
+    env = dict(os.environ, LD_LIBRARY_PATH=f"{mock_dir}:" + os.environ.get("LD_LIBRARY_PATH", ""), MOCK_RCCL_DIR=str(tmp_path))
+    ps = [subprocess.Popen([sys.executable, "-c", WORKER, ROOT, str(r), str(world), rdv, str(n_total), str(drop)], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=120) for p in ps]
+    assert all(p.returncode == 0 for p in ps), "\n".join(o[1][-800:] for o in outs)
+    return [json.loads(l) for l in outs[0][0].splitlines() if l.startswith("{")]
+
+
+def expected(n_total, rnd):
+    out = []
+    for u in range(n_total):
+        n = (u * 7 + rnd * 13) % 11 * (1 + 5 * rnd)
+        st = 1 if u % 5 == 4 else 0
+        w = (np.arange(n * 6, dtype=np.int32) + 1000 * u + rnd).tolist() if st == 0 else []
+        out.append([u, st, 100 + u, -1000 * u - rnd, n, w])
+    return out
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 23), (3, 31), (4, 5)])
+def test_ranks_exchange_ragged_records(mock_dir, tmp_path, world, n_total):
+    got = run_world(mock_dir, tmp_path, world, n_total)
+    assert [g["round"] for g in got] == [0, 1]
+    for g in got:
+        assert g["err"] is None
+        assert g["res"] == expected(n_total, g["round"])
+
+
+def test_missing_utterances_are_reported_not_invented(mock_dir, tmp_path):
+    """three ranks, one sends nothing although the control file gave it a share: the count check must fail loudly"""
+    got = run_world(mock_dir, tmp_path, 3, 12, drop=1)
+    for g in got:
+        assert g["res"] is None and ("missing or duplicated" in g["err"] or "expected" in g["err"])
+
+
+def test_stale_rendezvous_file_is_ignored(mock_dir, tmp_path):
+    rdv = tmp_path / "rccl-id"
+    rdv.write_bytes(b"x" * 128)
+    os.utime(rdv, (1000000000, 1000000000))           # left behind by a run long ago
+    got = run_world(mock_dir, tmp_path, 2, 9)
+    assert got[0]["err"] is None and got[0]["res"] == expected(9, 0)
