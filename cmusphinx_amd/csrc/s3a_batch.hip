@@ -604,7 +604,7 @@ s3a_batch_create(int32_t max_slots)
     s3a_batch_t *b = new s3a_batch_s();
     memset((void *)b, 0, sizeof *b);
     b->max_slots = max_slots;
-    b->opt_scan_chained = getenv("S3A_SCAN_CHAINED") != NULL;
+    b->opt_scan_chained = s3a_variants()->scan_chained != 0;
     pthread_mutex_init(&b->mu, NULL);
     pthread_cond_init(&b->cv, NULL);
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess
@@ -733,8 +733,7 @@ run_batch(s3a_batch_t *b)
         /* one model for every decoder of the step?  then the CD senones of all of them are one pass
          * over the model: kb_gated_cd_multi (39/40-dimensional features, >= GM_FB Gaussians per senone
          * slot), else kb_gated_cd_shared */
-        /* (tuning switches of the tests, read ONCE per process) */
-        static const bool no_shared = getenv("S3A_BATCH_NO_SHARED") != NULL, no_multi = getenv("S3A_BATCH_NO_MULTI") != NULL;
+        const bool no_shared = s3a_variants()->batch_no_shared != 0, no_multi = s3a_variants()->batch_no_multi != 0;
         bool shared = n > 1 && n <= 64 && !no_shared;
         for (int32_t z = 0; z < n && shared; z++) {
             const s3a_scorer_t *sc = b->sc[b->order[z]], *sc0 = b->sc[b->order[0]];

@@ -157,7 +157,9 @@ d_dag_utt_end(const DagShared &G, const DagLane &L, const WLm &lm)
             L.io[DG_IO_NENT] = n + 1;
             /* vithist_backtrace, vithist.c:1066-1100: id > 0 */
             int32_t k = 0;
-            for (int32_t id = n; id > 0 && k < G.hyp_cap; id = L.tab.pred[id], k++) { L.hyp_wid[k] = L.tab.wid[id]; L.hyp_sf[k] = L.tab.sf[id]; }
+            int32_t id = n;
+            for (; id > 0 && k < G.hyp_cap; id = L.tab.pred[id], k++) { L.hyp_wid[k] = L.tab.wid[id]; L.hyp_sf[k] = L.tab.sf[id]; }
+            if (id > 0) L.io[DG_IO_STATUS] = DG_E_CAP;         /* (cannot happen: hyp_cap >= the frames + 4, a word takes a frame) */
             L.io[DG_IO_NHYP] = k;
             L.io[DG_IO_FIRSTSCORE] = best;
         }
@@ -301,7 +303,8 @@ k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_ut
     const int32_t LR = wl_scan<false>(L.lcnt, L.loff, F1, 0);
     if (tid == 0) { L.loff[F1] = LR; L.io[DG_IO_NNODE] = NK; L.io[DG_IO_NLINK] = LR; }
     DG_BAR();
-    if (LR > G.link_cap || LR > G.maxedge) { if (tid == 0) L.io[DG_IO_STATUS] = DG_E_CAP; return; }
+    /* -maxedge is NOT enforced here: vithist_dag_build ignores dag_link's return (vithist.c:1161-1170); link_cap is this pass's memory */
+    if (LR > G.link_cap) { if (tid == 0) L.io[DG_IO_STATUS] = DG_E_CAP; return; }
     /* real link (exit i of node x, node y of frame efp[i] + 1): id = loff[e] + eapos[i] * kcnt[e + 1] + nkpos[y] */
 #define DG_RLINK(i_, y_) (L.loff[L.efp[i_]] + L.eapos[i_] * L.kcnt[L.efp[i_] + 1] + L.nkpos[y_])
 
@@ -368,6 +371,9 @@ k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_ut
     }
     if (tid == 0) { int32_t nb = 0; for (int32_t s = 0; s < NN; s++) nb += L.bpcnt[s]; L.io[DG_IO_NBYPASS] = nb; }
     DG_BAR();
+    /* dag_bypass_filler_nodes gives up when the links exceed -maxedge (dag.c:1034, :1382) and the reference then searches a
+     * PARTLY bypassed lattice (srch_time_switch_tree.c:1408-1412) whose shape depends on where it stopped: not reproduced --
+     * the utterance is reported as failed by this pass (status DG_E_CAP), never the batch */
     if (LR + L.io[DG_IO_NBYPASS] > G.maxedge) { if (tid == 0) L.io[DG_IO_STATUS] = DG_E_CAP; return; }
 
     /* ---- which links the recursion of dag_search evaluates: those that lead to the end node over non-filler nodes ---- */
@@ -488,7 +494,9 @@ k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_ut
     {
         int32_t maxlmop = G.maxlmop;
         if (G.maxlpf > 0 && (long long)G.maxlpf * n_frm < (long long)maxlmop) maxlmop = G.maxlpf * n_frm;
-        if (!s_any || s_lmop > maxlmop) { L.io[DG_IO_STATUS] = DG_E_NOPATH; return; }      /* "Bestpath search failed" */
+        /* dag_search takes a link only on `l->pscr > bestscore` from (int32)0x80000000 (dag.c:918-928): links without a path do not count */
+        const int32_t top = s_any ? (int32_t)((uint32_t)(s_max >> 32) ^ 0x80000000u) : INT_MIN;
+        if (!s_any || top == INT_MIN || s_lmop > maxlmop) { L.io[DG_IO_STATUS] = DG_E_NOPATH; return; }      /* "Bestpath search failed" */
     }
     /* ---- dag_backtrace (one thread): from the end node back to the root, bypassed fillers restored ---- */
     {
@@ -628,9 +636,10 @@ s3a_dagpass_init(s3a_lm3g_t *lm, const s3a_dag_cfg_t *cfg, int32_t n_lanes, int3
     G.h1mask = h - 1;
     h = 1024; while (h < 2 * (pair_cap > 0 ? pair_cap : (1 << 16))) h <<= 1;
     G.bmask = h - 1;
-    G.link_cap = link_cap > 0 ? link_cap : (1 << 19);
+    /* the default follows -maxedge (the reference's 2 000 000) up to a memory budget of 2 M links (36 B each) per lane */
+    G.link_cap = link_cap > 0 ? link_cap : (cfg->maxedge > 0 && cfg->maxedge < (1 << 21) ? cfg->maxedge : (1 << 21));
     G.task_cap = G.link_cap / 2 + (G.bmask + 1) / 2;
-    G.hyp_cap = 4096;
+    G.hyp_cap = max_frames + 4 > 4096 ? max_frames + 4 : 4096;
     G.min_endfr = cfg->min_endfr; G.maxedge = cfg->maxedge; G.maxlmop = cfg->maxlmop; G.maxlpf = cfg->maxlpf;
     G.startwid = cfg->startwid; G.finishwid = cfg->finishwid; G.silwid = cfg->silwid; G.start_lwid = cfg->start_lwid;
     G.finish_lwid = cfg->finish_lwid; G.wip = cfg->wip; G.lwf = cfg->lwf;

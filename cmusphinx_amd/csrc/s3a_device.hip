@@ -612,23 +612,12 @@ launch_score_nt(const s3a_mgau_model_t *g, const float *feat_dev, int32_t feat_s
 
 /* choose the frames-per-chunk so that the grid fills the chip (>= ~2 workgroups
  * of 8 waves per CU) without shrinking chunks below one FB group */
-/* tuning knobs (environment, read once): workgroup size and frames per chunk */
-static int32_t
-env_int(const char *name, int32_t dflt)
-{
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-
+/* tuning knobs (s3a_set_variants): workgroup size and frames per chunk */
 static int32_t
 pick_nt(void)
 {
-    static int32_t nt = 0;
-    if (nt == 0) {
-        nt = env_int("S3A_SCORE_NT", 512);
-        if (nt != 256 && nt != 512 && nt != 1024) nt = 512;
-    }
-    return nt;
+    const int32_t nt = s3a_variants()->score_nt;
+    return (nt == 256 || nt == 512 || nt == 1024) ? nt : 512;
 }
 
 /*
@@ -642,11 +631,10 @@ pick_nt(void)
 static int32_t
 pick_fpc(const struct s3a_mgau_dev_s *d, int32_t n_frames, int32_t nt)
 {
-    static int32_t forced = -1;
+    const int32_t forced = s3a_variants()->score_fpc;
     int32_t n_tiles = d->Gpad / nt;
     int32_t best_fpc = FB, nc;
     int64_t best_cost = -1;
-    if (forced < 0) forced = env_int("S3A_SCORE_FPC", 0);
     if (forced > 0) {
         int32_t f = ((forced + FB - 1) / FB) * FB;
         return f > 256 ? 256 : f;
@@ -681,7 +669,7 @@ launch_score(const s3a_mgau_model_t *g, const float *feat_dev, int32_t feat_stri
         return S3A_OK;
     /* one frame, long mixtures: the pass whose tail is the senone's chain of look-ups (16+ links; with 8 the
      * general kernel is as fast: 4.2 vs 4.4 us on the hub4 shape, 20.1 vs 17.0 us with 32) */
-    static const bool no_frame_sync = getenv("S3A_NO_FRAME_SYNC_KERNEL") != NULL;      /* (tests; read once per process) */
+    const bool no_frame_sync = s3a_variants()->no_frame_sync_kernel != 0;
     if (d->D4 == D4MAIN && d->tab16 != NULL && n_frames == 1 && d->hyb_ok && d->CP >= 16 && !no_frame_sync) {
         const dim3 grid(d->Gpad / 256);
         const size_t lds = (size_t)d->hyb_bytes;

@@ -38,6 +38,19 @@ s3a_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+/* kernel variants (include/cmusphinx_amd.h): process-wide, set by the host program, never read from the environment */
+static s3a_variants_t g_variants;
+void s3a_variants_default(s3a_variants_t *v) { if (v) memset(v, 0, sizeof *v); }
+int32_t
+s3a_set_variants(const s3a_variants_t *v)
+{
+    if (!v) return S3A_EINVAL;
+    if (v->score_nt != 0 && v->score_nt != 256 && v->score_nt != 512 && v->score_nt != 1024) { s3a_set_error("s3a_set_variants: score_nt 0 / 256 / 512 / 1024"); return S3A_EINVAL; }
+    g_variants = *v;
+    return S3A_OK;
+}
+const s3a_variants_t *s3a_variants(void) { return &g_variants; }
+
 const char *
 s3a_last_error(void)
 {

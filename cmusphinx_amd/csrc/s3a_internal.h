@@ -13,6 +13,7 @@ extern "C" {
 #endif
 
 void s3a_set_error(const char *fmt, ...);
+const s3a_variants_t *s3a_variants(void);      /* s3a_host.c: what s3a_set_variants stored */
 
 struct s3a_logmath_s {
     double base, log_of_base, log10_of_base, inv_log_of_base, inv_log10_of_base;

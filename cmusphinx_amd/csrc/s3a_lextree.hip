@@ -712,7 +712,7 @@ s3a_lexsearch_init(int32_t n_tree, const int32_t *n_node, const int32_t *const *
     if (n_comstate <= 0 || !comstate_off) { n_comstate = 0; comstate_off = zero_off; }
     ls = new s3a_lexsearch_s();        /* value-initialised: every pointer / counter starts at zero */
     ls->n_emit = tmat->n_state;
-    ls->opt_calls_by_copy = getenv("S3A_CALLS_BY_COPY") != NULL; ls->opt_scan_chained = getenv("S3A_SCAN_CHAINED") != NULL;
+    ls->opt_calls_by_copy = s3a_variants()->calls_by_copy != 0; ls->opt_scan_chained = s3a_variants()->scan_chained != 0;
     ls->cur = 0;
     if (stream) { ls->stream = (hipStream_t)stream; ls->own_stream = 0; }
     else {
@@ -743,7 +743,7 @@ s3a_lexsearch_clone(const s3a_lexsearch_t *proto, void *stream)
     if (!proto) return NULL;
     s3a_lexsearch_t *ls = new s3a_lexsearch_s(*proto);         /* host fields + static device pointers */
     ls->is_clone = 1;
-    ls->opt_calls_by_copy = getenv("S3A_CALLS_BY_COPY") != NULL; ls->opt_scan_chained = getenv("S3A_SCAN_CHAINED") != NULL;
+    ls->opt_calls_by_copy = s3a_variants()->calls_by_copy != 0; ls->opt_scan_chained = s3a_variants()->scan_chained != 0;
     /* everything alloc_state sets must not alias proto's */
     ls->d_sc = ls->d_hist = ls->d_outs = ls->d_outh = ls->d_bests = ls->d_frame = ls->d_pos = ls->d_posf = NULL;
     ls->d_act[0] = ls->d_act[1] = ls->d_nact[0] = ls->d_nact[1] = ls->d_cand = ls->d_ncand = ls->d_candf = NULL;

@@ -2842,10 +2842,17 @@ s3a_uttdec_bestpath_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32
     if (hl.h_ctx->err) { hdr->status = -1; return S3A_OK; }
     if (r.status == DG_E_NOEXIT) { hdr->status = -2; return S3A_OK; }
     if (r.status == DG_E_NOPATH) { hdr->status = -4; return S3A_OK; }     /* "Bestpath search failed": the reference writes no line */
+    if (r.status == DG_E_CAP || r.status == DG_E_POSEDGE) {
+        /* THIS utterance's second pass gave up (a capacity of the pass, -maxedge during the filler bypass, a positive bypass
+         * edge): a failed utterance, as "Bestpath search failed" is in the reference -- never a failed batch */
+        s3a_set_error("s3a_uttdec_bestpath_hyp: the second pass of lane %d gave up with status %d (3: a capacity of the pass or "
+                      "-maxedge in the filler bypass, 5: positive bypass edge): no hypothesis from it", lane, r.status);
+        hdr->status = -5;
+        return S3A_OK;
+    }
     if (r.status != 0) {
-        s3a_set_error("s3a_uttdec_bestpath_hyp: the second pass of lane %d stopped with status %d (3: a capacity of the pass or "
-                      "-maxedge, 4: inconsistent table, 5: positive bypass edge)", lane, r.status);
-        return r.status == DG_E_CAP ? S3A_ENOMEM : S3A_EUNSUP;
+        s3a_set_error("s3a_uttdec_bestpath_hyp: the second pass of lane %d stopped with status %d (4: inconsistent table)", lane, r.status);
+        return S3A_EUNSUP;
     }
     hdr->n_words = r.n_words;
     if (r.n_words > max_words) { hdr->status = -3; return S3A_OK; }

@@ -218,6 +218,8 @@ _SIGS = {
     "s3a_uttdec_bestpath_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_set_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
     "s3a_uttdec_profile": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_variants_default": (None, [C.c_void_p]),
+    "s3a_set_variants": (C.c_int32, [C.c_void_p]),
     "s3a_psfwd_init": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "s3a_psfwd_free": (None, [C.c_void_p]),
     "s3a_psfwd_n_lanes": (C.c_int32, [C.c_void_p]),
@@ -1331,6 +1333,19 @@ def dag_cfg(b, keep, bestpathlw=None, min_endfr=None, maxedge=None, maxlmop=None
     c.maxlmop = b.get("maxlmop", 100000000) if maxlmop is None else maxlmop
     c.maxlpf = b.get("maxlpf", 40000) if maxlpf is None else maxlpf
     return c
+
+
+class Variants(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("scan_chained", "calls_by_copy", "batch_no_shared", "batch_no_multi",
+                                         "no_frame_sync_kernel", "score_nt", "score_fpc")]
+
+
+def set_variants(**kw):
+    """s3a_set_variants: force kernel variants (process-wide; objects created afterwards); no arguments = the defaults"""
+    v = Variants()
+    for k, x in kw.items():
+        setattr(v, k, int(x))
+    check(load().s3a_set_variants(C.byref(v)), load())
 
 
 class Gather:

@@ -904,7 +904,9 @@ int32_t s3a_dagpass_result(const s3a_dagpass_t *dp, int32_t lane, s3a_dag_result
  * (s3a_uttdec_result / s3a_uttdec_hyp then fail; the hypotheses come from s3a_uttdec_bestpath_hyp).
  * s3a_uttdec_bestpath_hyp: the second pass's hypothesis of a lane as header + words (scale = the frame normalisers
  * over [sf, ef), as in s3a_uttdec_hyp); status 0 ok, -1 decode error, -2 no word exit, -4 bestpath failed (the
- * reference writes no line then), -3 max_words too small. */
+ * reference writes no line then), -5 the pass gave up on THIS utterance (its link capacity, -maxedge during the filler bypass -- where the
+ * reference goes on with a partly bypassed lattice --, or a positive bypass edge): a failed utterance, not a failed batch; -3 max_words too
+ * small. */
 int32_t s3a_uttdec_enable_bestpath(s3a_uttdec_t *ud, const s3a_dag_cfg_t *cfg, int32_t link_cap, int32_t pair_cap,
                                    int32_t keep_tables);
 int32_t s3a_uttdec_bestpath_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index,
@@ -1044,6 +1046,22 @@ int32_t s3a_psfwd_table(s3a_psfwd_t *e, int32_t lane, s3a_psfwd_table_t *out);
  * exit's path score */
 int32_t s3a_psfwd_hyp(s3a_psfwd_t *e, int32_t lane, int32_t *out_score, s3a_psfwd_seg_t *seg, int32_t max_seg);
 double  s3a_psfwd_last_decode_ms(const s3a_psfwd_t *e);
+
+/* ===================================================================== */
+/* Kernel variants that are otherwise chosen from the model shape / list sizes.  Every variant gives the same bits;  */
+/* the tests force the rarely taken ones, tuning runs sweep the sizes.  The library reads NO environment variable:  */
+/* a host that wants environment control reads it itself (as it does for s3a_uttdec_opts_t).  Process-wide; applies */
+/* to objects created and calls made after s3a_set_variants.                                                        */
+/* ===================================================================== */
+typedef struct {
+    int32_t scan_chained;           /* the chained multi-workgroup prefix scan for lists of any size (default: from 16 k positions) */
+    int32_t calls_by_copy;          /* lextree_enter calls through device memory, not kernel arguments (default: above 96 calls) */
+    int32_t batch_no_shared, batch_no_multi;    /* s3a_batch: one scoring launch per decoder instead of the shared-model passes */
+    int32_t no_frame_sync_kernel;   /* single-frame scoring through the general kernel */
+    int32_t score_nt, score_fpc;    /* whole-utterance scoring: workgroup size (256 / 512 / 1024; 0 = 512), frames per chunk (0 = chosen) */
+} s3a_variants_t;
+void    s3a_variants_default(s3a_variants_t *v);
+int32_t s3a_set_variants(const s3a_variants_t *v);
 
 /* ===================================================================== */
 /* measurement hooks used by bench.py (HIP events on the launch stream)   */

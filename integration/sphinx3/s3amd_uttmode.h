@@ -109,6 +109,11 @@ utt_bestpath_slot(void *srch, dag_t *dag)
     (void)dag;
     if (s3a_uttdec_bestpath_result(g_uds[g_cur_lane / g_lpe], g_cur_lane % g_lpe, &r) != S3A_OK) die("bestpath result");
     if (r.status == 2) { E_ERROR("Bestpath search failed for %s\n", s->uttid); return NULL; }
+    if (r.status == 3 || r.status == 5) {       /* this utterance only: srch_utt_end logs "Bestpath search failed." and goes on */
+        E_ERROR("the device's second pass gave up on %s (status %d: link capacity / -maxedge in the filler bypass / positive bypass edge)\n", s->uttid, r.status);
+        g_failed_utts++;
+        return NULL;
+    }
     if (r.status != 0) E_FATAL("tst shim: the device's second pass stopped with status %d: %s\n", r.status, s3a_last_error());
     E_INFO("tst shim: second pass on the device: %s: %d entries -> %d nodes, %d links (+%d bypass), %d LM operations, %d words\n",
            s->uttid, r.n_entry, r.n_node, r.n_link, r.n_bypass, r.lmop, r.n_words);

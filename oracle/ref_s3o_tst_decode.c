@@ -1,19 +1,13 @@
 /*
- * integration/sphinx3/s3amd_tst.c -- the sphinx3 side of the drop-in: sphinx3_decode (mode 4,
- * "fwdtree") with the WHOLE per-frame hot path served by a replacement backend through the
- * reference's own srch_funcs_t table (sphinx3/include/srch.h:528-701).  This is the file a
- * sphinx3 maintainer adds; it is compiled against the unmodified reference
- * where that lies (oracle/Makefile -> oracle/_ref/, never committed) and run as a test.
- *
- * Built by oracle/Makefile into oracle/_ref/ref_s3amd_tst_decode: the MI355X backend (include/cmusphinx_amd.h).
- *        S3A_UTT=L       whole utterances on the device, L at a time: senone scoring, lextree search AND the
- *                        word level (trigram look-ups, Viterbi history, pruning, word transitions) run as
- *                        kernels with no host synchronisation inside an utterance (the `decode` slot,
- *                        srch.h:552-555, srch.c:673-675); the host reads the finished history table back,
- *                        hands it to the reference's own vithist_utt_end / backtrace / output code.
- *        (otherwise)     frame-synchronous: scoring + lextree search on the device, the reference's own
- *                        vithist / LM on the host (one synchronisation per frame); S3A_STREAMS / S3A_BATCH.
- * (The programs that serve the same slots from the CPU restatement, and so pin it, are oracle/ref_s3o_tst_decode.c.)
+ * oracle/ref_s3o_tst_decode.c -- TEST INFRASTRUCTURE: sphinx3_decode (mode 4, "fwdtree") with the per-frame lextree
+ * operations -- and, with -DWL_ORACLE, the word level -- served by the CPU restatement (oracle/s3o_lextree.c,
+ * oracle/s3o_wordlevel.c) through the reference's own srch_funcs_t table (sphinx3/include/srch.h:528-701).  Same slots
+ * and the same flattening (integration/sphinx3/s3amd_flatten.h) as the product binding integration/sphinx3/s3amd_tst.c,
+ * without any of the product: no GPU, no libcmusphinx_amd.
+ *   (default)            oracle/_ref/ref_s3olt_decode : identical -hyp / -hypseg to the unmodified reference PINS the
+ *                        lextree restatement (tests/test_oracle_lextree.py)
+ *   -DWL_ORACLE          oracle/_ref/ref_s3owl_decode : pins the word level the same way
+ *                        (tests/test_oracle_wordlevel.py) and records the per-frame word-level trace the device tests replay.
  *
  * What stays the reference's: kb_init (models, dictionary, LM, lextree_build, dict2pid), feature
  * computation, the utterance API, hypothesis output (and, frame-synchronous mode, vithist_* / lm_*).
@@ -42,7 +36,7 @@
 #include "vithist.h"
 #include "dag.h"
 
-#include "cmusphinx_amd.h"
+#include "s3o.h"
 
 #include "s3amd_flatten.h"
 
@@ -62,86 +56,91 @@ static __thread long g_frames, g_histframes;
 static __thread double g_t_score, g_t_search, g_t_word, g_t_utt;
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 
-static __thread s3a_logmath_t *g_lm;
-static __thread s3a_mgau_model_t *g_gm;
-static __thread s3a_scorer_t *g_sc;
-static __thread s3a_comsen_t *g_cs;
-static __thread s3a_tmat_t *g_tm;
-static __thread s3a_lexsearch_t *g_ls;
-/* S3A_BATCH=1: all decoder threads share every kernel launch through one s3a_batch_t */
-#define MAX_GROUPS 8
-static s3a_batch_t *g_batches[MAX_GROUPS];       /* S3A_BATCH=G: G engines, decoder i steps with group i % G, so
-                                                 * one group's host phase overlaps the others' device phase */
-static int g_n_groups;
-static __thread s3a_batch_t *g_batch;
-static __thread int g_worker_id;
-static s3a_logmath_t *g_lm_shared[MAX_GROUPS];   /* batch mode: ONE model on the device per group of decoders */
-static s3a_mgau_model_t *g_gm_shared[MAX_GROUPS];
-static s3a_lexsearch_t *g_ls_shared[MAX_GROUPS];  /* ... and one copy of the static lextree arrays */
-static __thread int32 g_slot;
-static __thread float32 g_featbuf[64];
-static __thread int32 g_feat_idx;
-/* lextree_enter calls of the current frame, waiting for the swap (see be_enter) */
-#define PEND_MAX 1024
-static __thread int32 g_pend_tree[2], g_pend_n[2], g_pend_cf, g_pend_thresh;
-static __thread int32 g_pend_lc[2][PEND_MAX], g_pend_scr[2][PEND_MAX], g_pend_hist[2][PEND_MAX];
-static void die(const char *w) { E_FATAL("tst shim: %s: %s\n", w, s3a_last_error()); }
+static __thread s3o_lextree_t **g_lt;
 
-
-/* -mllr / -ctl_mllr: kb_setmllr (kb.c:335-365 -> adapt_set_mllr, libam/adaptor.c:106-170) has rewritten the host model
- * -- means and variances reloaded, mllr_norm_mgau, variance floor, mgau_precomp --; the device model takes the result
- * (s3a_mgau_set_params).  g_mllr_cur: the regression matrix file the device models hold ("": none). */
-static char g_mllr_cur[4096];
+/* Optional trace of the FIRST utterance (env S3O_TRACE=file): the flattened trees and, per
+ * frame, every input the lextree operations consumed and every result they produced.
+ * tests/golden/make_golden.py turns it into the fixture the oracle-vs-HIP lextree parity
+ * tests replay.  Record = {tag, n, n x int32}. */
+static __thread FILE *g_trace;
+static __thread int g_trace_utt;
+#ifdef WL_ORACLE
+/* the word level from oracle/s3o_wordlevel.c, and (env S3O_WLTRACE=file) a record of what it consumed and
+ * produced in every frame of the FIRST utterance: tests/golden/make_golden.py turns it into the fixture the
+ * device word level replays.  Record = {tag, n, n x int32}. */
+static __thread wl_flat_t *g_wl;
+static __thread s3o_lm3g_t g_olm;
+static __thread s3o_wdict_t g_od;
+static __thread s3o_vithist_t *g_ovh;
+static __thread FILE *g_wltrace;
 static void
-adapt_upload(kb_t *kb, s3a_mgau_model_t *gm)
+wtr(int32 tag, int32 n, const void *data)
 {
-    mgau_model_t *g = kbcore_mgau(kb->kbcore);
-    const int32 S = mgau_n_mgau(g), C = mgau_max_comp(g), D = mgau_veclen(g);
-    float *mean, *prec, *lrd;
-    int32 m, c;
-    if (S != s3a_mgau_n_mgau(gm) || C != s3a_mgau_max_comp(gm) || D != s3a_mgau_veclen(gm))
-        E_FATAL("tst shim: the adapted model's shape differs from the device model's\n");
-    mean = ckd_calloc((size_t)S * C * D, sizeof(float)); prec = ckd_calloc((size_t)S * C * D, sizeof(float));
-    lrd = ckd_calloc((size_t)S * C, sizeof(float));
-    for (m = 0; m < S; m++) {
-        if (mgau_n_comp(g, m) != s3a_mgau_n_comp(gm, m))
-            E_FATAL("tst shim: senone %d has %d components after adaptation, the device model %d\n", m, mgau_n_comp(g, m), s3a_mgau_n_comp(gm, m));
-        for (c = 0; c < mgau_n_comp(g, m); c++) {
-            memcpy(mean + ((size_t)m * C + c) * D, mgau_mean(g, m, c), D * sizeof(float));
-            memcpy(prec + ((size_t)m * C + c) * D, mgau_var(g, m, c), D * sizeof(float));
-            lrd[(size_t)m * C + c] = mgau_lrd(g, m, c);
+    if (!g_wltrace) return;
+    fwrite(&tag, 4, 1, g_wltrace); fwrite(&n, 4, 1, g_wltrace);
+    if (n) fwrite(data, 4, n, g_wltrace);
+}
+static void
+wtr8(int32 tag, int32 n, const uint8 *d)
+{
+    int32 i, *w;
+    if (!g_wltrace) return;
+    w = ckd_calloc(n + 1, 4);
+    for (i = 0; i < n; i++) w[i] = d[i];
+    wtr(tag, n, w);
+    ckd_free(w);
+}
+#endif
+static void
+tr(int32 tag, int32 n, const void *data)
+{
+    if (!g_trace) return;
+    fwrite(&tag, 4, 1, g_trace); fwrite(&n, 4, 1, g_trace);
+    if (n) fwrite(data, 4, n, g_trace);
+}
+static void
+tr16(int32 tag, int32 n, const int16 *d)
+{
+    int32 i, *w;
+    if (!g_trace) return;
+    w = ckd_calloc(n + 1, 4);
+    for (i = 0; i < n; i++) w[i] = d[i];
+    tr(tag, n, w);
+    ckd_free(w);
+}
+static void
+tr8(int32 tag, int32 n, const uint8 *d)
+{
+    int32 i, *w;
+    if (!g_trace) return;
+    w = ckd_calloc(n + 1, 4);
+    for (i = 0; i < n; i++) w[i] = d[i];
+    tr(tag, n, w);
+    ckd_free(w);
+}
+static void
+trace_state(int32 tag_base)
+{
+    int32 t;
+    if (!g_trace) return;
+    for (t = 0; t < g_ntree; t++) {
+        s3o_lextree_t *lt = g_lt[t];
+        int32 n = lt->n_node, i, *buf = ckd_calloc(10 * n + 4, 4);
+        tr(tag_base + 0, lt->n_active, lt->active);
+        tr(tag_base + 1, lt->n_next_active, lt->next_active);
+        for (i = 0; i < n; i++) {
+            s3o_hmm_t *h = &lt->hmm[i];
+            buf[10 * i + 0] = h->score[0]; buf[10 * i + 1] = h->score[1]; buf[10 * i + 2] = h->score[2];
+            buf[10 * i + 3] = (int32)h->history[0]; buf[10 * i + 4] = (int32)h->history[1];
+            buf[10 * i + 5] = (int32)h->history[2]; buf[10 * i + 6] = h->out_score;
+            buf[10 * i + 7] = (int32)h->out_history; buf[10 * i + 8] = h->bestscore; buf[10 * i + 9] = h->frame;
         }
+        tr(tag_base + 2, 10 * n, buf);
+        ckd_free(buf);
     }
-    if (s3a_mgau_set_params(gm, mean, prec, lrd) != S3A_OK) die("s3a_mgau_set_params");
-    ckd_free(mean); ckd_free(prec); ckd_free(lrd);
 }
 
-/* the device model(s) follow the host model: gms[0 .. n) all take it when the regression matrix file has changed */
-static void
-adapt_sync(kb_t *kb, s3a_mgau_model_t **gms, int32 n)
-{
-    const char *now = (kb->adapt_am && kb->adapt_am->prevmllrfn) ? kb->adapt_am->prevmllrfn : "";
-    int32 e;
-    if (strcmp(now, g_mllr_cur) == 0) return;
-    if (strlen(now) >= sizeof g_mllr_cur) E_FATAL("tst shim: MLLR file name too long\n");
-    for (e = 0; e < n; e++) adapt_upload(kb, gms[e]);
-    strcpy(g_mllr_cur, now);
-    E_INFO("tst shim: the device model%s now hold%s the model adapted with %s\n", n > 1 ? "s" : "", n > 1 ? "" : "s", now);
-}
-
-/* ctl_process callback of the frame-synchronous drivers: utt_decode (libAPI/utt.c:185) behind the model switch it would
- * make itself (:245-246), so that the device model has switched too before the first frame is scored */
-static void
-utt_decode_adapt(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
-{
-    kb_t *kb = data;
-    if (ur->regmatname != NULL) {
-        if (g_n_groups) E_FATAL("tst shim: -ctl_mllr with S3A_BATCH (decoders share one device model) is not supported\n");
-        kb_setmllr(ur->regmatname, ur->cb2mllrname, kb);
-        adapt_sync(kb, &g_gm, 1);
-    }
-    utt_decode(data, ur, sf, ef, uttid);
-}
+#define utt_decode_adapt utt_decode
 
 static void
 backend_init(kb_t *kb, srch_TST_graph_t *tstg)
@@ -199,68 +198,60 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
     g_exit_scr = ckd_calloc(g_ntree * g_max_node, 4);
     g_exit_hist = ckd_calloc(g_ntree * g_max_node, 4);
 
-    {
-        cmd_ln_t *config = kbcore_config(kbc);
-        const int32 **ssid = ckd_calloc(g_ntree, sizeof(void *)), **tm = ckd_calloc(g_ntree, sizeof(void *));
-        const int32 **wid = ckd_calloc(g_ntree, sizeof(void *)), **prob = ckd_calloc(g_ntree, sizeof(void *));
-        const int32 **coff = ckd_calloc(g_ntree, sizeof(void *)), **ch = ckd_calloc(g_ntree, sizeof(void *));
-        const int32 **lro = ckd_calloc(g_ntree, sizeof(void *)), **lr = ckd_calloc(g_ntree, sizeof(void *));
-        const int32 **root = ckd_calloc(g_ntree, sizeof(void *));
-        const uint8 **comp = ckd_calloc(g_ntree, sizeof(void *));
-        const int16 **lc = ckd_calloc(g_ntree, sizeof(void *));
-        int32 *nn = ckd_calloc(g_ntree, 4), *nlc = ckd_calloc(g_ntree, 4), *nroot = ckd_calloc(g_ntree, 4);
-        if (s3a_device_count() < 1)
-            E_FATAL("tst shim: no GPU; libcmusphinx_amd has no CPU fallback\n");
-        if (kbcore_svq(kbc) || kbcore_gs(kbc) || !kbcore_mgau(kbc))
-            E_FATAL("tst shim: only plain -senmgau .cont. scoring is supported\n");
-        g_batch = g_n_groups ? g_batches[g_worker_id % g_n_groups] : NULL;
-        if (g_batch && g_gm_shared[g_worker_id % g_n_groups]) {         /* (called under g_init_lock) */
-            g_lm = g_lm_shared[g_worker_id % g_n_groups];
-            g_gm = g_gm_shared[g_worker_id % g_n_groups];
-        }
-        else {
-            g_lm = s3a_logs3_init(cmd_ln_float64_r(config, "-logbase"), 0, 1);
-            g_gm = s3a_mgau_init(cmd_ln_str_r(config, "-mean"), cmd_ln_str_r(config, "-var"),
-                                 cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
-                                 cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.",
-                                 S3A_MIX_INT_FLOAT_COMP, g_lm);
-            if (!g_gm) die("s3a_mgau_init");
-            if (g_batch) { g_lm_shared[g_worker_id % g_n_groups] = g_lm; g_gm_shared[g_worker_id % g_n_groups] = g_gm; }
-        }
-        g_sc = (g_batch ? s3a_scorer_init_private : s3a_scorer_init)(
-                               g_gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen,
-                               cmd_ln_int32_r(config, "-ds"), cmd_ln_int32_r(config, "-cond_ds"),
-                               cmd_ln_float64_r(config, "-ci_pbeam"),
-                               cmd_ln_float32_r(config, "-tighten_factor"),
-                               cmd_ln_int32_r(config, "-maxcdsenpf"));
-        if (!g_sc) die("s3a_scorer_init");
-        g_cs = s3a_comsen_init(g_n_comstate, g_comstate_off, g_comstate, d2p->comwt);
-        if (!g_cs) die("s3a_comsen_init");
-        g_tm = s3a_tmat_init_logs3(g_tp_flat, tmat->n_tmat, ne);
+    if (getenv("S3O_TRACE") && (g_trace = fopen(getenv("S3O_TRACE"), "wb")) != NULL) {
+        int32 hdr[8] = { g_ntree, ne, tmat->n_tmat, mdef_n_sseq(mdef), d2p->n_comsseq, g_n_comstate,
+                         mdef_n_sen(mdef), d2p->n_comstate };
+        tr(1, 8, hdr);
+        tr(2, tmat->n_tmat * ne * (ne + 1), g_tp_flat);
+        tr16(3, mdef_n_sseq(mdef) * ne, g_sseq_flat);
+        tr16(4, d2p->n_comsseq * ne, g_comsseq_flat);
+        tr(5, g_n_comstate + 1, g_comstate_off);
+        tr16(6, g_comstate_off[g_n_comstate], g_comstate);
         for (i = 0; i < g_ntree; i++) {
             flat_t *f = g_flat[i];
-            nn[i] = f->n_node; ssid[i] = f->ssid; tm[i] = f->tmatid; comp[i] = f->composite;
-            wid[i] = f->wid; prob[i] = f->prob; coff[i] = f->child_off; ch[i] = f->child;
-            nlc[i] = f->n_lc; lc[i] = f->lc; lro[i] = f->lcroot_off; lr[i] = f->lcroot;
-            nroot[i] = f->n_root; root[i] = f->root;
-        }
-        if (g_batch && g_ls_shared[g_worker_id % g_n_groups])
-            g_ls = s3a_lexsearch_clone(g_ls_shared[g_worker_id % g_n_groups], s3a_mgau_stream(g_gm));
-        else {
-            g_ls = s3a_lexsearch_init(g_ntree, nn, ssid, tm, comp, wid, prob, coff, ch, nlc, lc, lro, lr,
-                                      nroot, root, g_tm, g_sseq_flat, mdef_n_sseq(mdef), g_comsseq_flat,
-                                      d2p->n_comsseq, g_n_comstate, g_comstate_off, g_comstate,
-                                      s3a_mgau_stream(g_gm));
-            if (g_batch) g_ls_shared[g_worker_id % g_n_groups] = g_ls;
-        }
-        if (!g_ls) die("s3a_lexsearch_init");
-        if (kb->adapt_am && kb->adapt_am->prevmllrfn && kb->adapt_am->prevmllrfn[0]) {     /* -mllr: kb_init adapted the host model */
-            if (g_n_groups) E_FATAL("tst shim: -mllr with S3A_BATCH is not supported\n");
-            adapt_sync(kb, &g_gm, 1);
+            int32 h2[4] = { f->n_node, f->n_lc, f->n_root, f->type };
+            tr(10, 4, h2); tr(11, f->n_node, f->ssid); tr(12, f->n_node, f->tmatid);
+            tr8(13, f->n_node, f->composite); tr(14, f->n_node, f->wid); tr(15, f->n_node, f->prob);
+            tr(16, f->n_node + 1, f->child_off); tr(17, f->child_off[f->n_node], f->child);
+            if (f->n_lc) { tr16(18, f->n_lc, f->lc); tr(19, f->n_lc + 1, f->lcroot_off); tr(20, f->lcroot_off[f->n_lc], f->lcroot); }
+            tr(21, f->n_root, f->root);
         }
     }
+    g_lt = ckd_calloc(g_ntree, sizeof(*g_lt));
+    for (i = 0; i < g_ntree; i++) {
+        flat_t *f = g_flat[i];
+        g_lt[i] = s3o_lextree_init(f->n_node, f->ssid, f->tmatid, f->composite, f->wid, f->prob,
+                                   f->child_off, f->child, f->n_lc, f->lc, f->lcroot_off, f->lcroot,
+                                   f->n_root, f->root, ne, g_tp_flat, g_sseq_flat, g_comsseq_flat);
+    }
+#ifdef WL_ORACLE
+    {
+        wl_flat_t *w = g_wl = flatten_lm(kbc);
+        vithist_t *vh = tstg->vithist;
+        g_olm.n_ug = w->n_ug; g_olm.n_bg = w->n_bg; g_olm.n_tg = w->n_tg;
+        g_olm.ug_prob = w->ug_prob; g_olm.ug_bowt = w->ug_bowt; g_olm.ug_firstbg = w->ug_firstbg;
+        g_olm.bg_wid = w->bg_wid; g_olm.bg_prob = w->bg_prob; g_olm.bg_bowt = w->bg_bowt; g_olm.bg_firsttg = w->bg_firsttg;
+        g_olm.tg_wid = w->tg_wid; g_olm.tg_prob = w->tg_prob; g_olm.inclass = w->inclass;
+        g_od.n_word = w->n_word; g_od.n_ci = w->n_ci; g_od.lwid = w->lwid; g_od.is_filler = w->is_filler;
+        g_od.fillpen = w->fillpen; g_od.last_ci = w->last_ci; g_od.startwid = w->startwid;
+        g_od.finishwid = w->finishwid; g_od.silwid = w->silwid; g_od.start_lwid = w->start_lwid;
+        g_od.finish_lwid = w->finish_lwid;
+        g_ovh = s3o_vithist_init(1 << 22, S3_MAX_FRAMES, vh->wbeam, vh->bghist);
+        if (getenv("S3O_WLTRACE") && (g_wltrace = fopen(getenv("S3O_WLTRACE"), "wb")) != NULL) {
+            int32 hdr[17] = { w->n_ug, w->n_bg, w->n_tg, w->n_word, w->n_ci, w->startwid, w->finishwid, w->silwid,
+                              w->start_lwid, w->finish_lwid, vh->wbeam, vh->bghist, tstg->histprune->maxwpf,
+                              tstg->histprune->maxhistpf, tstg->n_lextree, tstg->epl, kb->beam->wordend };
+            wtr(1, 17, hdr);
+            wtr(2, w->n_ug, w->ug_prob); wtr(3, w->n_ug, w->ug_bowt); wtr(4, w->n_ug + 1, w->ug_firstbg);
+            wtr(5, w->n_bg, w->bg_wid); wtr(6, w->n_bg, w->bg_prob); wtr(7, w->n_bg, w->bg_bowt);
+            wtr(8, w->n_bg ? w->n_bg + 1 : 0, w->bg_firsttg); wtr(9, w->n_tg, w->tg_wid); wtr(10, w->n_tg, w->tg_prob);
+            wtr(11, w->n_word, w->lwid); wtr8(12, w->n_word, w->is_filler); wtr(13, w->n_word, w->fillpen);
+            wtr(14, w->n_word, w->last_ci);
+        }
+    }
+#endif
     E_INFO("tst shim: %d lextrees flattened (largest %d nodes), backend %s\n", g_ntree, g_max_node,
-           s3a_version()
+           "CPU oracle (oracle/s3o_lextree.c)"
         );
 }
 
@@ -268,30 +259,21 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
 static void
 be_enter(int32 t, int32 n, int32 *lc, int32 *scr, int32 *hist, int32 cf, int32 thresh)
 {
-    /* fused device frame: the calls of a frame (one unigram tree, then one filler tree) are
-     * collected and issued together with the swap by be_swap -> s3a_decoder_transition */
-    int32 g = (t >= g_ntree / 2), c;
-    if (n == 0) return;
-    if (g_pend_n[g] || n > PEND_MAX) E_FATAL("tst shim: unexpected lextree_enter pattern\n");
-    g_pend_tree[g] = t; g_pend_n[g] = n; g_pend_cf = cf; g_pend_thresh = thresh;
-    for (c = 0; c < n; c++) { g_pend_lc[g][c] = lc[c]; g_pend_scr[g][c] = scr[c]; g_pend_hist[g][c] = hist[c]; }
+    int32 c;
+    if (g_trace) {
+        int32 hdr[4] = { t, n, cf, thresh };
+        tr(30, 4, hdr); tr(31, n, lc); tr(32, n, scr); tr(33, n, hist);
+    }
+    for (c = 0; c < n; c++)
+        s3o_lextree_enter(g_lt[t], lc[c], cf, scr[c], hist[c], thresh);
 }
 
 static void
 be_swap(int32 cf)
 {
-    /* the unigram-tree batch may be empty while the filler batch is not: keep them apart by slot */
-    if (g_batch) {
-        if (s3a_batch_transition(g_batch, g_slot, g_pend_n[0] || g_pend_n[1] ? g_pend_cf : cf, g_pend_thresh,
-                                 g_pend_tree[0], g_pend_n[0], g_pend_lc[0], g_pend_scr[0], g_pend_hist[0],
-                                 g_pend_tree[1], g_pend_n[1], g_pend_lc[1], g_pend_scr[1], g_pend_hist[1]) != S3A_OK)
-            die("batch transition");
-    }
-    else if (s3a_decoder_transition(g_ls, g_sc, g_cs, g_pend_n[0] || g_pend_n[1] ? g_pend_cf : cf,
-                               g_pend_thresh, g_pend_tree[0], g_pend_n[0], g_pend_lc[0], g_pend_scr[0],
-                               g_pend_hist[0], g_pend_tree[1], g_pend_n[1], g_pend_lc[1], g_pend_scr[1],
-                               g_pend_hist[1]) != S3A_OK) die("transition");
-    g_pend_n[0] = g_pend_n[1] = 0;
+    int32 t;
+    (void)cf;
+    for (t = 0; t < g_ntree; t++) s3o_lextree_active_swap(g_lt[t]);
 }
 
 /* ------------------------------------------------------------------ */
@@ -310,11 +292,11 @@ tst_begin(void *srch)
     vithist_utt_reset(tstg->vithist);
     histprune_zero_histbin(tstg->histprune);
     pred = vithist_utt_begin(tstg->vithist, kbc);
+#ifdef WL_ORACLE
+    s3o_vithist_utt_begin(g_ovh, g_od.startwid, g_od.start_lwid);
+#endif
     if (g)
         for (i = 0; i < g->n_mgau; i++) { g->mgau[i].bstidx = NO_BSTIDX; g->mgau[i].updatetime = NOT_UPDATED; }
-    if ((g_batch ? s3a_batch_utt_begin(g_batch, g_slot) : s3a_decoder_utt_begin(g_ls, g_sc)) != S3A_OK)
-        die("decoder_utt_begin");
-    g_pend_n[0] = g_pend_n[1] = 0;
     lc = mdef_silphone(kbc->mdef);
     be_enter(0, 1, &lc, &zero, &pred, -1, s->beam->hmm);
     lc = BAD_S3CIPID;
@@ -331,47 +313,42 @@ tst_end(void *srch)
     srch_TST_graph_t *tstg = s->grh->graph_struct;
     int32 t;
     g_t_utt += now_s();
+#ifdef WL_ORACLE
+    if (g_ovh->overflow) E_FATAL("tst shim: the oracle's history table overflowed\n");
+    vithist_fill(tstg->vithist, g_ovh->n_entry, g_ovh->n_frm, g_ovh->score, g_ovh->pred, g_ovh->lw0, g_ovh->lw1,
+                 g_ovh->wid, g_ovh->sf, g_ovh->ef, g_ovh->ascr, g_ovh->lscr, g_ovh->type, g_ovh->frame_start,
+                 g_ovh->bestscore, g_ovh->bestvh, kbcore_lm(s->kbc));
+    if (g_wltrace) { int32 z = 0; wtr(99, 1, &z); fclose(g_wltrace); g_wltrace = NULL; }
+#endif
     s->exit_id = vithist_utt_end(tstg->vithist, s->kbc);
     s->stat->utt_wd_exit = vithist_n_entry(tstg->vithist);
     histprune_showhistbin(tstg->histprune, s->stat->nfr, s->uttid);
-    (void)t;
-    if ((g_batch ? s3a_batch_utt_end(g_batch, g_slot) : s3a_lexsearch_utt_end(g_ls)) != S3A_OK) die("utt_end");
+    for (t = 0; t < g_ntree; t++) s3o_lextree_utt_end(g_lt[t]);
+    if (g_trace) { int32 z = 0; tr(99, 1, &z); fclose(g_trace); g_trace = NULL; }
+    g_trace_utt++;
     lm_cache_stats_dump(kbcore_lm(s->kbc));
     lm_cache_reset(kbcore_lm(s->kbc));
     return (s->exit_id >= 0) ? SRCH_SUCCESS : SRCH_FAILURE;
 }
 
-static __thread int32 g_ascale_idx;
-
-/* the CI senones are scored on the device inside gmm_compute_lv2 (no host cache needed) */
-static int
-tst_gmm_lv1(void *srch, float32 *feat, int32 cache_idx, int32 wav_idx)
-{
-    return SRCH_SUCCESS;
-}
-
 static int
 tst_select_active(void *srch)
 {
-    /* the senones of the coming frame were marked by the previous s3a_decoder_transition */
-    return SRCH_SUCCESS;
-}
-
-/* enqueue only: CI gate + CD senones (raw scores; the search kernels subtract the frame's
- * best); nothing read back.  srch.c:752 copies s->senscale into ascale[] right after this
- * slot returns; the real value arrives with the frame's single read-back and is patched in. */
-static int
-tst_gmm_lv2(void *srch, float32 **feat, int32 wav_idx)
-{
     srch_t *s = srch;
-    if (g_batch) {          /* scored inside the batched step (propagate_graph_wd_lv2 slot) */
-        memcpy(g_featbuf, feat[0], sizeof(float32) * s3a_mgau_veclen(g_gm));
-        g_feat_idx = wav_idx;
-    }
-    else if (s3a_decoder_score(g_sc, feat[0], wav_idx) != S3A_OK)
-        die("lv2");
-    g_ascale_idx = s->num_frm + wav_idx;
-    s->senscale = 0;
+    ascr_t *ascr = s->ascr;
+    mdef_t *mdef = kbcore_mdef(s->kbc);
+    dict2pid_t *d2p = kbcore_dict2pid(s->kbc);
+    int32 t;
+    if (!ascr->sen_active) return SRCH_SUCCESS;
+    ascr_clear_ssid_active(ascr);
+    ascr_clear_comssid_active(ascr);
+    for (t = 0; t < g_ntree; t++)
+        s3o_lextree_ssid_active(g_lt[t], ascr->ssid_active, ascr->comssid_active);
+    ascr_clear_sen_active(ascr);
+    s3o_sseq2sen_active(g_sseq_flat, mdef_n_sseq(mdef), mdef_n_emit_state(mdef), ascr->ssid_active,
+                        ascr->sen_active);
+    s3o_comsseq2sen_active(g_comsseq_flat, d2p->n_comsseq, mdef_n_emit_state(mdef), g_comstate_off,
+                           g_comstate, ascr->comssid_active, ascr->sen_active);
     return SRCH_SUCCESS;
 }
 
@@ -384,11 +361,57 @@ tst_hmm_compute_lv2(void *srch, int32 frmno)
     beam_t *bm = s->beam;
     int32 besthmmscr = MAX_NEG_INT32, bestwordscr = MAX_NEG_INT32, frm_nhmm = 0, t, hb, pb, wb;
 
-    /* device backend: evaluation, thresholds, propagation and word exits are ONE enqueue
-     * with one read-back, issued from the propagate_graph_wd_lv2 slot */
-    (void)besthmmscr; (void)bestwordscr; (void)frm_nhmm; (void)t; (void)hb; (void)pb; (void)wb;
-    (void)hp; (void)bm;
+    if (g_trace) {
+        int32 fr = frmno;
+        tr(40, 1, &fr);
+        tr(41, mdef_n_sen(kbcore_mdef(s->kbc)), s->ascr->senscr);
+        tr(42, kbcore_dict2pid(s->kbc)->n_comstate, s->ascr->comsen);
+        tr8(43, mdef_n_sen(kbcore_mdef(s->kbc)), s->ascr->sen_active);
+    }
+    for (t = 0; t < g_ntree; t++) {
+        s3o_lextree_hmm_eval(g_lt[t], s->ascr->senscr, s->ascr->comsen, frmno);
+        g_best[t] = g_lt[t]->best; g_wbest[t] = g_lt[t]->wbest; g_nact[t] = g_lt[t]->n_active;
+    }
+    for (t = 0; t < g_ntree; t++) {
+        if (besthmmscr < g_best[t]) besthmmscr = g_best[t];
+        if (bestwordscr < g_wbest[t]) bestwordscr = g_wbest[t];
+        s->stat->utt_hmm_eval += g_nact[t];
+        frm_nhmm += g_nact[t];
+    }
+    if (besthmmscr > 0)
+        E_ERROR("***ERROR*** Fr %d, best HMM score > 0 (%d); int32 wraparound?\n", frmno, besthmmscr);
+    if (frm_nhmm / hp->hmm_hist_binsize > hp->hmm_hist_bins - 1)
+        hp->hmm_hist[hp->hmm_hist_bins - 1]++;
+    else
+        hp->hmm_hist[frm_nhmm / hp->hmm_hist_binsize]++;
+
+    if (frm_nhmm > (hp->maxhmmpf + (hp->maxhmmpf >> 1))) {
+        int32 nbin = 1000, bw = -(bm->hmm) / nbin, i, j;
+        int32 *bin = ckd_calloc(nbin, sizeof(int32));
+        for (t = 0; t < g_ntree; t++)
+            s3o_lextree_hmm_histbin(g_lt[t], besthmmscr, bin, nbin, bw);
+        for (i = 0, j = 0; (i < nbin) && (j < hp->maxhmmpf); i++, j += bin[i]);
+        ckd_free(bin);
+        g_histframes++;
+        hb = -(i * bw);
+        pb = (hb > bm->ptrans) ? hb : bm->ptrans;
+        wb = (hb > bm->word) ? hb : bm->word;
+    }
+    else {
+        hb = bm->hmm; pb = bm->ptrans; wb = bm->word;
+    }
+    bm->bestscore = besthmmscr;
+    bm->bestwordscore = bestwordscr;
+    bm->thres = bm->bestscore + hb;
+    bm->phone_thres = bm->bestscore + pb;
+    bm->word_thres = bm->bestwordscore + wb;
     g_frames++;
+    if (g_trace) {
+        int32 r[8] = { bm->bestscore, bm->bestwordscore, frm_nhmm, bm->thres, bm->phone_thres, bm->word_thres,
+                       bm->hmm, bm->ptrans };
+        tr(44, 8, r); tr(45, g_ntree, g_best); tr(46, g_ntree, g_wbest); tr(47, g_ntree, g_nact);
+        trace_state(50);
+    }
     return SRCH_SUCCESS;
 }
 
@@ -400,7 +423,12 @@ tst_propagate_ph_lv2(void *srch, int32 frmno)
     int32 pth = bm->phone_thres;
     if (bm->ptranskip != 0 && (frmno % bm->ptranskip) == 0)
         pth = bm->word_thres;           /* srch_time_switch_tree.c:975-1003 */
-    (void)pth;      /* done inside s3a_lexsearch_frame_search (propagate_graph_wd_lv2 slot) */
+    {
+        int32 t;
+        for (t = 0; t < g_ntree; t++)
+            s3o_lextree_hmm_propagate_non_leaves(g_lt[t], frmno, bm->thres, pth, bm->word_thres);
+        if (g_trace) { int32 r[3] = { bm->thres, pth, bm->word_thres }; tr(60, 3, r); trace_state(61); }
+    }
     return SRCH_SUCCESS;
 }
 
@@ -450,6 +478,32 @@ tst_word_trans(srch_t *s, int32 cf)
     be_enter(tstg->n_lextree + k, 1, c_lc, c_scr, c_hist, cf, th);
 }
 
+#ifdef WL_ORACLE
+static void
+tst_word_trans_oracle(srch_t *s, int32 cf)
+{
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    beam_t *bm = s->beam;
+    int32 th = bm->bestscore + bm->hmm, n, k, fscr, fhist, lcb = BAD_S3CIPID;
+    static __thread int32 *c_lc, *c_scr, *c_hist;
+    const int32 fs = g_ovh->frame_start[cf], ne = g_ovh->n_entry - fs;
+    if (!c_lc) { c_lc = ckd_calloc(g_od.n_ci + 1, 4); c_scr = ckd_calloc(g_od.n_ci + 1, 4); c_hist = ckd_calloc(g_od.n_ci + 1, 4); }
+    n = s3o_word_trans(g_ovh, &g_od, cf, bm->wordend, c_lc, c_scr, c_hist, &fscr, &fhist);
+    {   /* the frame's surviving entries and its lextree_enter calls */
+        int32 hdr[6] = { cf, ne, n, g_ovh->bestscore[cf], g_ovh->bestvh[cf], th };
+        wtr(30, 6, hdr);
+        wtr(31, ne, g_ovh->wid + fs); wtr(32, ne, g_ovh->score + fs); wtr(33, ne, g_ovh->pred + fs);
+        wtr(34, ne, g_ovh->lw0 + fs); wtr(35, ne, g_ovh->lw1 + fs); wtr(36, ne, g_ovh->ascr + fs);
+        wtr(37, ne, g_ovh->lscr + fs); wtr(38, ne, g_ovh->sf + fs); wtr(39, ne, g_ovh->type + fs);
+        if (n > 0) { wtr(40, n, c_lc); wtr(41, n, c_scr); wtr(42, n, c_hist); }
+    }
+    if (n < 0) return;
+    k = tstg->n_lextrans++;
+    k = (k % (tstg->n_lextree * tstg->epl)) / tstg->epl;
+    be_enter(k, n, c_lc, c_scr, c_hist, cf, th);
+    be_enter(tstg->n_lextree + k, 1, &lcb, &fscr, &fhist, cf, th);
+}
+#endif
 
 static int
 tst_propagate_wd_lv2(void *srch, int32 frmno)
@@ -461,51 +515,53 @@ tst_propagate_wd_lv2(void *srch, int32 frmno)
     int32 t, i;
 
     /* srch_TST_rescoring: word exits of every tree, in tree then active-list order */
-    {
-        s3a_frame_result_t r;
-        beam_t *bm = s->beam;
-        int32 k = 0;
-        int32 wbeam_phone = (bm->ptranskip != 0 && (frmno % bm->ptranskip) == 0);
-        double t0 = now_s();
-        int32 rc = g_batch
-            ? s3a_batch_step(g_batch, g_slot, g_featbuf, g_feat_idx, frmno, bm->hmm, bm->ptrans, bm->word,
-                             wbeam_phone, hp->maxhmmpf, &r, g_exit_n, g_exit_wid, g_exit_scr, g_exit_hist,
-                             g_ntree * g_max_node)
-            : s3a_decoder_search(g_ls, g_sc, g_cs, frmno, bm->hmm, bm->ptrans, bm->word, wbeam_phone,
-                                 hp->maxhmmpf, &r, g_exit_n, g_exit_wid, g_exit_scr, g_exit_hist,
-                                 g_ntree * g_max_node);
-        if (rc == S3A_EUNSUP)           /* a configuration the device path refuses: never a silent difference */
-            E_FATAL("tst shim: %s\n", s3a_last_error());
-        if (rc != S3A_OK) {
-            E_ERROR("%s\n", s3a_last_error());
-            return SRCH_FAILURE;
+    for (t = 0; t < g_ntree; t++) {
+        g_exit_n[t] = s3o_lextree_hmm_propagate_leaves(g_lt[t], s->beam->word_thres,
+                                                       g_exit_wid + t * g_max_node, g_exit_scr + t * g_max_node,
+                                                       g_exit_hist + t * g_max_node, g_max_node);
+        if (g_exit_n[t] < 0) { E_ERROR("out.history==-1, error\n"); return SRCH_FAILURE; }
+        if (g_trace) {
+            tr(70, 1, &g_exit_n[t]); tr(71, g_exit_n[t], g_exit_wid + t * g_max_node);
+            tr(72, g_exit_n[t], g_exit_scr + t * g_max_node); tr(73, g_exit_n[t], g_exit_hist + t * g_max_node);
         }
-        g_t_search += now_s() - t0;
-        if (r.need_histprune)
-            g_histframes++;     /* lextree_hmm_histbin + the bin scan ran on the device */
-        /* what srch_TST_hmm_compute_lv2 leaves in beam_t / stat_t / histprune_t */
-        bm->bestscore = r.best_hmm; bm->bestwordscore = r.best_word;
-        bm->thres = r.thres; bm->phone_thres = r.phone_thres; bm->word_thres = r.word_thres;
-        if (r.best_hmm > 0)
-            E_ERROR("***ERROR*** Fr %d, best HMM score > 0 (%d); int32 wraparound?\n", frmno, r.best_hmm);
-        s->stat->utt_hmm_eval += r.n_hmm;
-        if (r.n_hmm / hp->hmm_hist_binsize > hp->hmm_hist_bins - 1) hp->hmm_hist[hp->hmm_hist_bins - 1]++;
-        else hp->hmm_hist[r.n_hmm / hp->hmm_hist_binsize]++;
-        /* what gmm_compute_lv2 leaves: senscale -> ascale[], evaluation counters */
-        s->senscale = r.extra[6];
-        s->ascale[g_ascale_idx] = r.extra[6];
-        s->stat->utt_sen_eval += r.extra[1]; s->stat->utt_gau_eval += r.extra[2];
-        s->stat->utt_cisen_eval += r.extra[3]; s->stat->utt_cigau_eval += r.extra[4];
-        for (t = 0; t < g_ntree; t++)
-            for (i = 0; i < g_exit_n[t]; i++, k++)
-                vithist_rescore(vh, s->kbc, g_exit_wid[k], frmno, g_exit_scr[k], g_exit_hist[k],
-                                g_flat[t]->type, -1);
     }
+#ifdef WL_ORACLE
+    {
+        int32 hdr[4] = { frmno, 0, s->beam->word_thres - s->beam->bestwordscore, s->beam->bestscore + s->beam->hmm };
+        for (t = 0; t < g_ntree; t++) hdr[1] += g_exit_n[t];
+        wtr(20, 4, hdr);
+        for (t = 0; t < g_ntree; t++) {
+            int32 ty = g_flat[t]->type;
+            wtr(21, 1, &ty); wtr(22, g_exit_n[t], g_exit_wid + t * g_max_node);
+            wtr(23, g_exit_n[t], g_exit_scr + t * g_max_node); wtr(24, g_exit_n[t], g_exit_hist + t * g_max_node);
+        }
+    }
+    for (t = 0; t < g_ntree; t++)
+        for (i = 0; i < g_exit_n[t]; i++)
+            if (s3o_vithist_rescore(g_ovh, &g_olm, &g_od, g_exit_wid[t * g_max_node + i], frmno,
+                                    g_exit_scr[t * g_max_node + i], g_exit_hist[t * g_max_node + i],
+                                    g_flat[t]->type) < 0)
+                E_FATAL("Hmm->out.history equals to -1 with score %d, some active phone was not computed?\n",
+                        g_exit_scr[t * g_max_node + i]);
+#else
+    for (t = 0; t < g_ntree; t++)
+        for (i = 0; i < g_exit_n[t]; i++)
+            vithist_rescore(vh, s->kbc, g_exit_wid[t * g_max_node + i], frmno,
+                            g_exit_scr[t * g_max_node + i], g_exit_hist[t * g_max_node + i],
+                            g_flat[t]->type, -1);
+#endif
     {
         double t1 = now_s();
+#ifdef WL_ORACLE
+        (void)vh;
+        s3o_vithist_prune(g_ovh, &g_od, frmno, hp->maxwpf, hp->maxhistpf,
+                          s->beam->word_thres - s->beam->bestwordscore, NULL);
+        tst_word_trans_oracle(s, frmno);
+#else
         vithist_prune(vh, kbcore_dict(s->kbc), frmno, hp->maxwpf, hp->maxhistpf,
                       s->beam->word_thres - s->beam->bestwordscore);
         tst_word_trans(s, frmno);
+#endif
         g_t_word += now_s() - t1;
     }
     return SRCH_SUCCESS;
@@ -517,7 +573,11 @@ tst_frame_windup(void *srch, int32 frmno)
     srch_t *s = srch;
     srch_TST_graph_t *tstg = s->grh->graph_struct;
     vithist_frame_windup(tstg->vithist, frmno, NULL, s->kbc);
+#ifdef WL_ORACLE
+    s3o_vithist_frame_windup(g_ovh, frmno);
+#endif
     be_swap(frmno);
+    if (g_trace) trace_state(80);
     return SRCH_SUCCESS;
 }
 
@@ -536,8 +596,6 @@ install_slots(srch_t *s)
     s->funcs->propagate_graph_ph_lv2 = tst_propagate_ph_lv2;
     s->funcs->propagate_graph_wd_lv2 = tst_propagate_wd_lv2;
     s->funcs->frame_windup = tst_frame_windup;
-    s->funcs->gmm_compute_lv1 = tst_gmm_lv1;
-    s->funcs->gmm_compute_lv2 = tst_gmm_lv2;
 }
 
 /*
@@ -582,14 +640,12 @@ worker_main(void *vp)
     av[ac++] = "-ctloffset"; av[ac++] = so; av[ac++] = "-ctlcount"; av[ac++] = sc;
 
     pthread_mutex_lock(&g_init_lock);           /* model / dictionary / LM loading is not re-entrant */
-    g_worker_id = w->id;
     config = cmd_ln_parse_r(NULL, arg, ac, av, TRUE);
     kb_init(&kb, config);
     if (((srch_t *)kb.srch)->op_mode != 4)
         E_FATAL("tst shim: -op_mode 4 (fwdtree) only\n");
     backend_init(&kb, (srch_TST_graph_t *)((srch_t *)kb.srch)->grh->graph_struct);
     install_slots(kb.srch);
-    if (g_batch && (g_slot = s3a_batch_attach(g_batch, g_ls, g_sc, g_cs)) < 0) die("batch attach");
     pthread_mutex_unlock(&g_init_lock);
     if (pthread_barrier_wait(&g_start) == PTHREAD_BARRIER_SERIAL_THREAD)
         g_t_start = now_s();        /* every decoder is loaded: the decode clock starts here */
@@ -622,7 +678,6 @@ concat_parts(const char *dst, int n)
     fclose(out);
 }
 
-#include "s3amd_uttmode.h"
 
 /* ------------------------------------------------------------------ */
 /* S3A_LIVE=gpu|cpu: the reference's LIVE API (libAPI/s3_decode.c)     */
@@ -733,58 +788,9 @@ main(int argc, char *argv[])
 
     if (getenv("S3A_LIVE"))
         return live_mode_main(argc, argv, strcmp(getenv("S3A_LIVE"), "cpu") != 0);
-    /* One process per GPU (torchrun / mpirun set RANK, WORLD_SIZE, LOCAL_RANK): rank r decodes the r-th contiguous
-     * share of the control file (inside the caller's -ctloffset / -ctlcount) on GPU LOCAL_RANK and writes
-     * <hyp>.part<r> / <hypseg>.part<r>; the parts, concatenated in rank order, are the one-process files.  With S3A_UTT the
-     * ranks also exchange their hypothesis records over RCCL (s3a_gather_hyps) and rank 0 writes <hyp> / <hypseg>. */
-    if (getenv("WORLD_SIZE") && atoi(getenv("WORLD_SIZE")) > 1 && getenv("RANK")) {
-        const int W = atoi(getenv("WORLD_SIZE")), r = atoi(getenv("RANK"));
-        const int lr = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : r;
-        static char so[32], sc[32], part[2][4300];
-        char **av = ckd_calloc(argc + 8, sizeof(char *));
-        const char *ctl = NULL;
-        int ac = 0, a, uoff = 0, ucnt = -1, n_lines = 0, base, extra, off, cnt;
-        if (s3a_set_device(lr) != S3A_OK) E_FATAL("tst shim: rank %d cannot use GPU %d\n", r, lr);
-        for (a = 0; a < argc; a++) {
-            if (a > 0 && a + 1 < argc && !strcmp(argv[a], "-ctloffset")) { uoff = atoi(argv[++a]); continue; }
-            if (a > 0 && a + 1 < argc && !strcmp(argv[a], "-ctlcount")) { ucnt = atoi(argv[++a]); continue; }
-            if (a > 0 && a + 1 < argc && !strcmp(argv[a], "-ctl")) ctl = argv[a + 1];
-            if (a > 0 && a + 1 < argc && (!strcmp(argv[a], "-hyp") || !strcmp(argv[a], "-hypseg"))) {
-                const int k = !strcmp(argv[a], "-hyp") ? 0 : 1;
-                snprintf(part[k], sizeof part[k], "%s.part%03d", argv[a + 1], r);
-                snprintf(g_final[k], sizeof g_final[k], "%s", argv[a + 1]);
-                av[ac++] = argv[a]; av[ac++] = part[k]; a++;
-                continue;
-            }
-            av[ac++] = argv[a];
-        }
-        if (!ctl || (fp = fopen(ctl, "r")) == NULL) E_FATAL("tst shim: -ctl is required\n");
-        while (fgets(line, sizeof line, fp)) if (line[0] != '\n' && line[0] != '#') n_lines++;
-        fclose(fp);
-        n_lines = n_lines > uoff ? n_lines - uoff : 0;
-        if (ucnt >= 0 && ucnt < n_lines) n_lines = ucnt;
-        base = n_lines / W; extra = n_lines % W;
-        off = uoff + r * base + (r < extra ? r : extra); cnt = base + (r < extra ? 1 : 0);
-        g_rank = r; g_world = W; g_rank_first = off - uoff; g_rank_total = n_lines;
-        snprintf(so, sizeof so, "%d", off); snprintf(sc, sizeof sc, "%d", cnt);
-        av[ac++] = "-ctloffset"; av[ac++] = so; av[ac++] = "-ctlcount"; av[ac++] = sc;
-        argc = ac; argv = av;
-        E_INFO("tst shim: rank %d of %d on GPU %d: control-file entries %d .. %d\n", r, W, lr, off, off + cnt - 1);
-        if (cnt == 0 && !(getenv("S3A_UTT") && atoi(getenv("S3A_UTT")) > 0)) return 0;
-    }
     cmd_ln_appl_enter(argc, argv, "default.arg", arg);      /* `arg`: the reference's own table */
     unlimit();
     config = cmd_ln_get();
-    if (getenv("S3A_UTT") && atoi(getenv("S3A_UTT")) > 0)
-        return utt_mode_main(argc, argv, atoi(getenv("S3A_UTT")));
-    if (getenv("S3A_BATCH") && atoi(getenv("S3A_BATCH")) > 0) {
-        if (n_streams < 1) n_streams = 1;
-        g_n_groups = atoi(getenv("S3A_BATCH"));
-        if (g_n_groups > MAX_GROUPS) g_n_groups = MAX_GROUPS;
-        if (g_n_groups > n_streams) g_n_groups = n_streams;
-        for (i = 0; i < g_n_groups; i++)
-            if ((g_batches[i] = s3a_batch_create((n_streams + g_n_groups - 1) / g_n_groups)) == NULL) die("batch create");
-    }
     if (!cmd_ln_str_r(config, "-ctl"))
         E_FATAL("-ctl is required\n");
     if (n_streams < 1) n_streams = 1;
@@ -826,12 +832,6 @@ main(int argc, char *argv[])
         E_FATAL("tst shim: the replaced slots were never called\n");
     E_INFO("tst shim: %ld frames searched by the replacement backend in %d stream(s)\n", frames, n_streams);
     E_INFO("tst shim: histogram pruning (lextree_hmm_histbin) applied in %ld frames\n", histframes);
-    if (g_n_groups) {
-        int64_t st = 0, fr = 0, a, b;
-        for (i = 0; i < g_n_groups; i++) { s3a_batch_stats(g_batches[i], &a, &b); st += a; fr += b; }
-        E_INFO("tst shim: batched engine: %d group(s), %ld steps served %ld decoder-frames (mean batch %.1f)\n",
-               g_n_groups, (long)st, (long)fr, st ? (double)fr / st : 0.0);
-    }
     E_INFO("tst shim timing: %.1f us/frame inside utterances per stream (%.0f x real time per stream); of which "
            "frame_search (enqueue + the one sync) %.1f us, vithist_prune + word transitions %.1f us\n",
            1e6 * t_utt / frames, 0.01 * frames / (t_utt / n_streams) / n_streams, 1e6 * t_search / frames,

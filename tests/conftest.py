@@ -38,6 +38,13 @@ def olm():
     return O.OracleLogMath(1.0003, 0, 1)
 
 
+@pytest.fixture
+def variants(gpu_lib):
+    """force kernel variants for one test (s3a_set_variants is process-wide): restored to the defaults afterwards"""
+    yield gpu_lib.set_variants
+    gpu_lib.set_variants()
+
+
 @pytest.fixture(scope="session")
 def gpu_lib():
     """The product library on a box with a GPU.  Never falls back."""

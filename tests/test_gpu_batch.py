@@ -128,14 +128,14 @@ def test_batched_steps_match_one_oracle_per_decoder(gpu_lib, share_model):
 
 
 @pytest.mark.parametrize("n_dec,n_comp,n_node", [(5, 4, 700), (11, 8, 700), (19, 8, 700), (3, 8, 10000)])
-def test_cloned_decoders_share_model_and_lextrees(gpu_lib, n_dec, n_comp, n_node, monkeypatch):
+def test_cloned_decoders_share_model_and_lextrees(gpu_lib, n_dec, n_comp, n_node, variants):
     """The production arrangement: ONE model and ONE set of lextrees on the device, N decoders with their
     own state (s3a_scorer_init_private + s3a_lexsearch_clone), different utterances.  With 8 Gaussians per
     senone and >= 8 decoders in a step the CD senones of all of them are one model-stationary pass
     (kb_gated_cd_multi: groups of 8 decoders, the last one partly filled); as the shorter utterances end the
     steps fall back to one launch per decoder."""
     if n_node > 1024:       # lists of several 1024-position chunks through k_dec_scan's chained multi-workgroup path
-        monkeypatch.setenv("S3A_SCAN_CHAINED", "1")
+        variants(scan_chained=1)
     batch = gpu_lib.Batch(n_dec + 1)
     rng = np.random.default_rng(77)
     tr = synth_forest(rng, n_tree=4, n_node=n_node, n_sen=500)

@@ -93,6 +93,40 @@ def test_device_second_pass_on_recorded_reference_tables(gpu_lib, bundles, case)
     assert (n_fail > 0) == (case == "rm1_maxlpf5")
 
 
+def test_a_lattice_beyond_the_link_capacity_fails_its_utterance_only(gpu_lib, bundles):
+    """a dense lattice must not kill the batch.  With a link capacity smaller than some of the RM1 lattices the
+    pass reports status 3 for THOSE utterances (the drop-in then writes no second-pass line for them, as after the
+    reference's "Bestpath search failed") and decodes the others exactly as before; -maxedge is not enforced while the
+    lattice is built (vithist_dag_build ignores dag_link's return): a tiny -maxedge only stops utterances in the bypass."""
+    G = np.load(os.path.join(GOLDEN, "dag_tables.npz"))
+    case, b = "rm1", bundles["rm1"]
+    n_utt = int(G[f"{case}.n"][0])
+    tabs, nlink = [], []
+    for k in range(n_utt):
+        hdr = G[f"{case}.{k}.hdr"]
+        tabs.append({key: G[f"{case}.{k}.{key}"] for key in ("wid", "sf", "ef", "ascr", "lscr", "score", "hyp_wid", "hyp_sf")}
+                    | {"n_frm": int(hdr[1]), "endid": int(hdr[2])})
+        nlink.append(int(hdr[6]))
+    cap = int(np.median(nlink))
+    keep = []
+    lm = gpu_lib.Lm3g(dict(b, wbeam=b["wbeam_vh"]))
+    dp = gpu_lib.DagPass(lm, gpu_lib.dag_cfg(b, keep, **OVERRIDES[case]), n_utt, max(len(t["wid"]) for t in tabs),
+                         max(t["n_frm"] for t in tabs) + 2, link_cap=cap, pair_cap=1 << 14)
+    res = dp.run(tabs)
+    st = [r.status for r in res]
+    assert [s == 3 for s in st] == [n > cap for n in nlink] and 0 < sum(s == 3 for s in st) < n_utt
+    for k, r in enumerate(res):
+        if r.status == 0:
+            exp = np.stack([G[f"{case}.{k}.o_{key}"] for key in ("wid", "sf", "ef", "ascr", "lscr")], axis=1)
+            assert np.array_equal(r.words(), exp), k
+    # -maxedge below every lattice's link count: the BUILD still goes through (node / link counts as recorded)
+    keep2 = []
+    cfg2 = gpu_lib.dag_cfg(b, keep2, **dict(OVERRIDES[case], maxedge=min(nlink) - 1))
+    dp2 = gpu_lib.DagPass(lm, cfg2, n_utt, max(len(t["wid"]) for t in tabs), max(t["n_frm"] for t in tabs) + 2, link_cap=1 << 17, pair_cap=1 << 14)
+    for k, r in enumerate(dp2.run(tabs)):
+        assert r.n_link == nlink[k] and r.status == 3, (k, r.status)
+
+
 def run(exe, args, tmp_path, tag, env=None):
     hyp, seg, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "matchseg", "log"))
     with open(log, "w") as lf:

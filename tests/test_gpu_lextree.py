@@ -238,18 +238,20 @@ class OracleFrame:
                           (10, 300, 1e-80, -3400000, 3),
                           (12, 20000, 1e-80, -2000000, 0),      # 10 000 nodes: lists of several 1024-position chunks
                           (13, 2500, 1e-80, -2000000, 0)])      # the same with histogram pruning (reordered lists)
-def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pbeam, pbeam, ptranskip, monkeypatch):
+def test_fused_decoder_frame_lockstep_with_oracle(gpu_lib, seed, maxhmmpf, ci_pbeam, pbeam, ptranskip, variants):
     """The product path of a mode-4 frame -- s3a_decoder_score / _search / _transition -- against
     the oracle's step-by-step frame on a synthetic forest WITH a synthetic acoustic model: raw
     scores normalised inside the search kernels, inline composite senones, histogram pruning,
     two-tree transitions, next-frame senone marks consumed by the gated scorer.
     (seed 7 also takes the transition's copy path: the calls through device memory instead of the kernel
     arguments, which a frame with more than 96 lextree_enter calls would use.)"""
+    force = {}
     if seed == 7:
-        monkeypatch.setenv("S3A_CALLS_BY_COPY", "1")
+        force["calls_by_copy"] = 1
     big = seed >= 12
     if big:     # k_dec_scan's chained multi-workgroup path (used from 16 k list positions on) on lists of 2-3 chunks
-        monkeypatch.setenv("S3A_SCAN_CHAINED", "1")
+        force["scan_chained"] = 1
+    variants(**force)
     from cmusphinx_amd import synth
     rng = np.random.default_rng(seed)
     tr = synth_forest(rng, n_tree=4, n_node=10000 if big else 900, n_sen=600)
