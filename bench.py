@@ -33,6 +33,9 @@ Prints ONE JSON line (rank 0).  Extra keys beyond the driver contract:
   roofline_scoring  the engine's scoring kernel (north_star's second metric is about scoring): VALU and HBM fractions
   search        SURVEY 8(d)'s 84 B per active HMM credited ONCE per frame to the search kernels together; HMM updates/s
   kernels       every kernel class of a frame: microseconds per launch in the bench and alone, stretch, share of the frame
+  wide_beam     configs[4]: the WSJ-shaped 8000 x 32 model with the wide beam in a 64-lane engine: frames/s, active HMMs and
+                candidates per frame, per-kernel microseconds, the LDS / VGPR occupancy of the word-level kernels, the
+                first 8 utterances compared with the unmodified reference
   ps_fwdtree    SURVEY 8(f).3: pocketsphinx's first pass on the device (s3a_psfwd_decode: scoring + search, one workgroup per
                 utterance) on the same model shape, with the unmodified pocketsphinx on the host beside it
   cpu_baseline  the UNMODIFIED reference decoder (oracle/_ref/sphinx3_decode) on the same task files: 16 processes (where
@@ -242,6 +245,82 @@ def scoring_legs(lib, fast):
     return out
 
 
+def wide_beam_leg(lib, d, lanes, n_frames, fast, n_check=8):
+    """BASELINE configs[4]: the WSJ-shaped model (8000 senones x 32 Gaussians, 20 k-word trigram) decoded with the wide
+    beam -beam 1e-120 -pbeam 1e-100 -wbeam 1e-80 -maxhmmpf 100000 ("stress active-HMM count and LDS occupancy"):
+    `lanes` utterances in ONE engine, whole utterances on the device; the first n_check utterances compared, -hyp and
+    -hypseg line by line, with the unmodified reference (n_check single-utterance processes side by side)."""
+    from cmusphinx_amd import bundle, s3io, synth_task
+    t = os.path.join(d, "wsjtask")
+    synth_task.make_task(t, n_utt=lanes, n_frames=n_frames, **synth_task.WSJ_TASK)
+    targs = synth_task.decoder_args(t, beam="1e-120", wbeam="1e-80") + ["-pbeam", "1e-100", "-maxhmmpf", "100000"]
+    bpath = os.path.join(t, "decoder.bundle")
+    r = subprocess.run([SHIM] + targs, env=dict(os.environ, S3A_UTT="1", S3A_EXPORT=bpath), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if r.returncode != 0 or not os.path.exists(bpath):
+        return {"error": "bundle export failed"}
+    ctl = os.path.join(t, "ctl")
+    utts = [l.split()[0] for l in open(ctl) if l.strip()]
+    refs = [run_reference(targs, ctl, i, 1, t, f"wref{i}_") for i in range(min(n_check, len(utts)))]     # (runs beside the device legs)
+    hfeat = [s3io.read_mfc(os.path.join(t, "feat", u + ".mfc")) for u in utts]
+    dec = bundle.Decoder(bpath, lanes, precision=lib.GMM_FAST if fast else lib.GMM_EXACT, max_frames=max(len(f) for f in hfeat) // 39 + 8)
+    D4x4 = 4 * ((dec.veclen + 3) // 4)
+    fdev, nfr = [], []
+    for f in hfeat:
+        f = f.reshape(-1, dec.veclen)
+        pad = np.zeros((len(f), D4x4), np.float32)
+        pad[:, :dec.veclen] = f
+        fdev.append(lib.DevBuf(pad.nbytes).upload(pad))
+        nfr.append(len(f))
+    dec.ud.decode_dev(fdev, nfr, D4x4)                      # warm-up
+    ms = dec.ud.decode_dev(fdev, nfr, D4x4)
+    recs = [dec.hyp_var(z, utts[z], z) for z in range(len(utts))]
+    stat = [dec.ud.result(z)["frame_stat"] for z in range(len(utts))]
+    res0 = [dec.ud.result(z) for z in range(min(4, len(utts)))]
+    dec.ud.set_profile(4)
+    dec.ud.decode_dev(fdev, nfr, D4x4)
+    prof = dec.ud.profile()
+    dec.ud.set_profile(0)
+    K = max(1, dec.ud.window())
+    pf = {k: (us / n / (K if k == "ku_score_window" else 1)) for k, (us, n) in prof.items() if n > 0}
+    tot = sum(pf.values())
+    frames = sum(nfr)
+    n_ok = n_cmp = 0
+    cpu_fps = None
+    cpu_frames, cpu_wall = 0, 0.0
+    for i, (q, h, sg, lg) in enumerate(refs):
+        q.wait()
+        sm = parse_summary(lg)
+        if q.returncode != 0 or not sm:
+            continue
+        m_, s_ = dec.format_var(*recs[i])
+        n_cmp += 1
+        n_ok += int(open(h).read() == m_ and open(sg).read() == s_)
+        cpu_frames += sm["frames"]
+        cpu_wall = max(cpu_wall, sm["frames"] * sm["tot_xclk"] / 100.0)
+    if n_cmp:
+        cpu_fps = cpu_frames / max(cpu_wall, 1e-9)
+    resrc = json.load(open(os.path.join(ROOT, "profiles", "r4_kernel_resources.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "r4_kernel_resources.json")) else {}
+    hmm = np.concatenate([s_[:, 1] for s_ in stat])
+    out = {"workload": f"configs[4]: WSJ-shaped 8000 senones x 32 Gaussians x 39, 20 k-word dictionary, ARPA trigram, -beam 1e-120 -pbeam 1e-100 "
+                       f"-wbeam 1e-80 -maxhmmpf 100000; {len(utts)} utterances in one {lanes}-lane engine, whole utterances on the device",
+           "lanes": lanes, "frames": int(frames), "device_ms": round(ms, 2), "frames_per_sec": round(frames / (ms * 1e-3), 1),
+           "xRT": round(frames / (ms * 1e-3) / 100.0, 1),
+           "per_frame": {"active_hmm_mean": round(float(hmm.mean()), 1), "active_hmm_max": int(hmm.max()),
+                         "word_exits_mean": round(float(np.mean([s_[:, 7].mean() for s_ in stat])), 1),
+                         "max_candidates_per_frame": int(max(r_["max_cand"] for r_ in res0)), "max_new_history_entries_per_frame": int(max(r_["max_new"] for r_ in res0)),
+                         "frames_with_histogram_pruning": int(sum(int(s_[:, 6].sum()) for s_ in stat))},
+           "kernels_us_per_frame": {k: round(v, 2) for k, v in sorted(pf.items(), key=lambda kv: -kv[1])}, "us_per_frame_all_lanes": round(tot, 1),
+           "occupancy": {k: resrc.get(k) for k in ("ku_emit_word", "ku_hist_sort<256>", "ku_hist_sort<1024>") if k in resrc},
+           "occupancy_note": "from the code objects (profiles/r4_kernel_resources.json): ku_emit_word = 1024 threads x 88 VGPRs + 53 280 B LDS per workgroup "
+                             "(LDS admits 3 workgroups per CU, the VGPRs 5 waves per SIMD = 1 workgroup of 16 waves + part of a second: ONE resident workgroup per CU); "
+                             "ku_hist_sort<1024> 44 076 B LDS, <256> 20 028 B",
+           "identical_to_reference": {"utterances_checked": n_cmp, "identical": n_ok},
+           "cpu_reference": {"frames_per_sec": round(cpu_fps, 1) if cpu_fps else None, "processes": n_cmp, "frames": cpu_frames, "kind": "reference",
+                             "note": "the unmodified sphinx3_decode, one single-utterance process per checked utterance side by side (stat.c xClk of the slowest)"}}
+    assert n_cmp == 0 or n_ok == n_cmp, "wide-beam decode on the device differs from the unmodified reference"
+    return out
+
+
 PSREF = os.path.join(ROOT, "oracle", "_ref", "ref_ps_fwd")
 PSAMD = os.path.join(ROOT, "oracle", "_ref", "ref_ps_amdfwd")
 
@@ -317,6 +396,9 @@ def main():
     ap.add_argument("--cpu-physical", action="store_true", help="add the CPU leg with one process per physical core (~2 minutes)")
     ap.add_argument("--no-scoring", action="store_true", help="skip the scoring-only extra legs")
     ap.add_argument("--no-ps", action="store_true", help="skip the pocketsphinx first-pass leg")
+    ap.add_argument("--no-wide-beam", action="store_true", help="skip the configs[4] wide-beam leg")
+    ap.add_argument("--wide-lanes", type=int, default=64, help="lanes of the wide-beam leg's engine")
+    ap.add_argument("--wide-frames", type=int, default=40, help="nominal frames per utterance of the wide-beam leg (utterances follow LM sentences: about twice that)")
     ap.add_argument("--ps-lanes", type=int, default=256, help="utterances (= lanes) of the pocketsphinx leg's batch")
     ap.add_argument("--only-scoring", action="store_true", help="only the scoring legs (PMC passes over the scoring kernels)")
     ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
@@ -744,6 +826,8 @@ def main():
             res["scoring"] = scoring_legs(lib, args.fast)
         if world == 1 and not args.no_ps:
             res["ps_fwdtree"] = ps_fwdtree_leg(d, args.ps_lanes, T)
+        if world == 1 and not args.no_wide_beam:
+            res["wide_beam"] = wide_beam_leg(lib, d, args.wide_lanes, args.wide_frames, args.fast)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

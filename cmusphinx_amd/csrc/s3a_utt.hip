@@ -1086,7 +1086,7 @@ ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t GC, int3
  * workgroup 0 of a lane: the frame record (d_dec_pack_frame) + the word level, which closes the frame and leaves the
  * next frame's lextree_enter calls; workgroups 1 .. 8 T: the emission sweep (16 waves each, 8 workgroups per tree).
  * The two read nothing the other writes. */
-#define UE_WG_PER_TREE 8
+#define UE_WG_PER_TREE (8 * 1024 / WL_THREADS)      /* the emission sweep keeps its 128 waves per tree */
 __global__ void __launch_bounds__(WL_THREADS)
 ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, int32_t fg, int32_t big)
 {
@@ -2181,7 +2181,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     else
         UKL(UK_SCAN, ku_scan<SCAN_THREADS>, dim3(T * scan_gc, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, scan_gc == 1 ? 1 : ud->scan_nc, scan_gc, f);
     /* (many lanes: fewer emission workgroups per tree -- each sweeps further -- instead of thousands of idle ones) */
-    UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= ud->many && !ud->big_wl ? 1 : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
+    UKL(UK_WORD, ku_emit_word, dim3(1 + (n >= ud->many && !ud->big_wl ? 1024 / WL_THREADS : UE_WG_PER_TREE) * T, 1, n), dim3(WL_THREADS), 0, st, LN, S, ud->lm->d, ud->dict, ud->par, f, ud->big_wl);
     if (ud->big_wl) {
         const dim3 gb(WL_BIG_G, 1, n), one(1, 1, n), tb(WL_THREADS);
         UKL(UK_WL_P2, ku_wl_p2, gb, tb, 0, st, LN, ud->lm->d, ud->dict, ud->par, f);

@@ -37,11 +37,16 @@
 #include <limits.h>
 #include "s3a_vit.h"
 
+#ifndef WL_THREADS
 #define WL_THREADS 1024
+#endif
 #define WL_WAVES (WL_THREADS / 64)
 #define WL_MAXCALL 96       /* lextree_enter calls per frame: #CI phones + 1 */
 #define WL_MAXT 16          /* lextrees per decoder (2 x -Nlextree) */
-#define WL_LDS_EX 1024      /* frames with at most this many word exits keep them (and their candidate offsets) in LDS */
+#ifndef WL_LDS_EX
+#define WL_LDS_EX 1024
+#endif
+/* WL_LDS_EX:  frames with at most this many word exits keep them (and their candidate offsets) in LDS */
 #define WL_RANK_MAX 384     /* entries above the pruning threshold ranked all against all; beyond: selection */
 #define WL_BIG_G 256        /* workgroups per lane of the wide-beam launches */
 
