@@ -47,14 +47,15 @@ struct PsfScalars {
     int32_t st_root, st_nonroot, st_last, st_wlast, st_cand, st_sen;
     int32_t n_total;            /* frames of the utterance (whole-utterance mode) */
     int32_t exit_bp, exit_score, n_seg, finished;
+    int32_t clean;              /* the last utterance was finished without failure: a new decoder's state is a light reset away */
 #ifdef PSF_TIMING
     unsigned long long t_phase[16], t_last;     /* wall_clock64 ticks (100 MHz) per phase of the frame; diagnostics build */
 #endif
 };
 
 struct PsfLane {
-    int32_t *score, *hist;                      /* [n_emit][n_hmm] */
-    int32_t *out_score, *out_hist, *best, *frame;
+    int32_t *st;                                /* [n_hmm][CH_STRIDE]: a channel's hmm_t state in ONE 64-byte record (channels are
+                                                   visited at random: one cache line per visit, not one per field) */
     uint16_t *mpxid;                            /* [n_emit][n_mpx]: roots, then single-phone words */
     int32_t *acl[2], *apos[2];                  /* active_chan_list; position of an interior channel in it */
     int32_t *awl[2];                            /* active_word_list */
@@ -97,6 +98,15 @@ struct PsfModel {
     int32_t beam, pbeam, wbeam, lpbeam, lponlybeam, fillpen, silpen, nwpen, pip, maxwpf, maxhmmpf;
     int32_t bp_cap, bss_cap, max_frames, cand_cap;
 };
+
+/* a channel's record: score[5], history[5], out_score, out_history, bestscore, frame */
+#define CH_STRIDE 16
+#define CH_SC(L, c, k) (L).st[(size_t)(c) * CH_STRIDE + (k)]
+#define CH_HI(L, c, k) (L).st[(size_t)(c) * CH_STRIDE + 5 + (k)]
+#define CH_OS(L, c) (L).st[(size_t)(c) * CH_STRIDE + 10]
+#define CH_OH(L, c) (L).st[(size_t)(c) * CH_STRIDE + 11]
+#define CH_BE(L, c) (L).st[(size_t)(c) * CH_STRIDE + 12]
+#define CH_FR(L, c) (L).st[(size_t)(c) * CH_STRIDE + 13]
 
 __device__ __forceinline__ int32_t add32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t sub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
@@ -228,15 +238,15 @@ template <int NE> __device__ __forceinline__ void
 hmm_clear_scores(const PsfModel &M, PsfLane &L, int32_t c)
 {
 #pragma unroll
-    for (int k = 0; k < NE; k++) L.score[k * M.n_hmm + c] = PS_WORST;
-    L.out_score[c] = PS_WORST; L.best[c] = PS_WORST;
+    for (int k = 0; k < NE; k++) CH_SC(L, c, k) = PS_WORST;
+    CH_OS(L, c) = PS_WORST; CH_BE(L, c) = PS_WORST;
 }
 template <int NE> __device__ __forceinline__ void
 hmm_clear(const PsfModel &M, PsfLane &L, int32_t c)
 {
 #pragma unroll
-    for (int k = 0; k < NE; k++) { L.score[k * M.n_hmm + c] = PS_WORST; L.hist[k * M.n_hmm + c] = -1; }
-    L.out_score[c] = PS_WORST; L.out_hist[c] = -1; L.best[c] = PS_WORST; L.frame[c] = -1;
+    for (int k = 0; k < NE; k++) { CH_SC(L, c, k) = PS_WORST; CH_HI(L, c, k) = -1; }
+    CH_OS(L, c) = PS_WORST; CH_OH(L, c) = -1; CH_BE(L, c) = PS_WORST; CH_FR(L, c) = -1;
 }
 
 /*
@@ -251,7 +261,6 @@ hmm_clear(const PsfModel &M, PsfLane &L, int32_t c)
 template <int NE, bool MPX> __device__ int32_t
 hmm_vit_eval(const PsfModel &M, PsfLane &L, int32_t c, int32_t m, const SenScr &sen)
 {
-    const int32_t H = M.n_hmm;
     const uint8_t *tp = M.tp + (size_t)M.ch_tmat[c] * NE * (NE + 1);
     int32_t sc[NE], hi[NE], V[NE];
     uint16_t id[NE];
@@ -260,7 +269,7 @@ hmm_vit_eval(const PsfModel &M, PsfLane &L, int32_t c, int32_t m, const SenScr &
     const uint32_t ssid = MPX ? 0u : M.ch_ssid[c];
 #pragma unroll
     for (int k = 0; k < NE; k++) {
-        sc[k] = L.score[k * H + c]; hi[k] = L.hist[k * H + c];
+        sc[k] = CH_SC(L, c, k); hi[k] = CH_HI(L, c, k);
         if (MPX) {
             id[k] = L.mpxid[k * M.n_mpx + m];
             bad[k] = k > 0 && id[k] == PS_BAD_SSID;
@@ -278,7 +287,7 @@ hmm_vit_eval(const PsfModel &M, PsfLane &L, int32_t c, int32_t m, const SenScr &
         int32_t oh;
         if (t1 > t2) { v = t1; oh = hi[NE - 1]; } else { v = t2; oh = hi[NE - 2]; }
         if (v < PS_WORST) v = PS_WORST;
-        L.out_score[c] = v; L.out_hist[c] = oh;
+        CH_OS(L, c) = v; CH_OH(L, c) = oh;
         best = v;
     }
     /* states NE-1 .. 2: sources j, j-1, j-2 */
@@ -303,7 +312,7 @@ hmm_vit_eval(const PsfModel &M, PsfLane &L, int32_t c, int32_t m, const SenScr &
         if (v < PS_WORST) v = PS_WORST;
         if (v > best) best = v;
         /* sources of the lower states are V[] and the OLD hi[] / id[] of lower indices: safe to store now */
-        L.score[j * H + c] = v; L.hist[j * H + c] = nh;
+        CH_SC(L, c, j) = v; CH_HI(L, c, j) = nh;
         if (MPX) L.mpxid[j * M.n_mpx + m] = nid;
     }
     /* state 1 */
@@ -312,18 +321,18 @@ hmm_vit_eval(const PsfModel &M, PsfLane &L, int32_t c, int32_t m, const SenScr &
     if (t0 > t1) v = t0;
     else {
         v = t1;
-        L.hist[1 * H + c] = hi[0];
+        CH_HI(L, c, 1) = hi[0];
         if (MPX) L.mpxid[1 * M.n_mpx + m] = id[0];
     }
     if (v < PS_WORST) v = PS_WORST;
     if (v > best) best = v;
-    L.score[1 * H + c] = v;
+    CH_SC(L, c, 1) = v;
     /* state 0 */
     v = add32(V[0], TPV(0, 0));
     if (v < PS_WORST) v = PS_WORST;
     if (v > best) best = v;
-    L.score[c] = v;
-    L.best[c] = best;
+    CH_SC(L, c, 0) = v;
+    CH_BE(L, c) = best;
     return best;
 #undef TPV
 }
@@ -385,10 +394,10 @@ d_sen_active(const PsfModel &M, PsfLane &L, const PsfScalars &S, int32_t f, uint
         for (int32_t j = tid; j < S.n_awl[cur]; j += NT) {
             const int32_t w = L.awl[cur][j], c0 = M.rc_base + M.w_rc_base[w];
             for (int32_t r = 0; r < M.w_rcsize[w]; r++)
-                if (L.frame[c0 + r] == f) activate<NE, false>(M, L, c0 + r, 0, senbits);
+                if (CH_FR(L, c0 + r) == f) activate<NE, false>(M, L, c0 + r, 0, senbits);
         }
     for (int32_t i = tid; i < M.n_1ph; i += NT)
-        if (L.frame[M.sp_base + i] == f) activate<NE, true>(M, L, M.sp_base + i, M.n_root + i, senbits);
+        if (CH_FR(L, M.sp_base + i) == f) activate<NE, true>(M, L, M.sp_base + i, M.n_root + i, senbits);
     __syncthreads();
 }
 
@@ -474,7 +483,7 @@ d_root_bits_from_frames(const PsfModel &M, const PsfLane &L, uint32_t *rootbits,
 {
     for (int32_t i = threadIdx.x; i < ((M.n_root + 31) >> 5); i += NT) rootbits[i] = 0;
     __syncthreads();
-    for (int32_t i = threadIdx.x; i < M.n_root; i += NT) if (L.frame[i] == f) setbit(rootbits, i);
+    for (int32_t i = threadIdx.x; i < M.n_root; i += NT) if (CH_FR(L, i) == f) setbit(rootbits, i);
     __syncthreads();
 }
 /* at a frame's start: rootbits -> L.rl, then cleared to collect the next frame's */
@@ -498,12 +507,12 @@ d_frame_word_chans(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f)
         if (j < n_awl) {
             const int32_t w = L.awl[f & 1][j];
             c0 = M.rc_base + M.w_rc_base[w]; rcs = M.w_rcsize[w];
-            for (int32_t r = 0; r < rcs; r++) cnt += L.frame[c0 + r] == f ? 1 : 0;
+            for (int32_t r = 0; r < rcs; r++) cnt += CH_FR(L, c0 + r) == f ? 1 : 0;
         }
         int32_t off, o2, tot, t2;
         wg_scan2(F.wg, cnt, 0, off, o2, tot, t2);
         off += base;
-        for (int32_t r = 0; r < rcs; r++) if (L.frame[c0 + r] == f) L.arc[off++] = c0 + r;
+        for (int32_t r = 0; r < rcs; r++) if (CH_FR(L, c0 + r) == f) L.arc[off++] = c0 + r;
         base += tot;
     }
     if (threadIdx.x == 0) F.n_arc = base;
@@ -515,7 +524,6 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
 {
     PsfScalars &S = F.S;
     const int tid = threadIdx.x, cur = f & 1, nxt = cur ^ 1, nf = f + 1;
-    const int32_t H = M.n_hmm;
 
     if (tid == 0) {
         S.st_sen += n_senone_active;
@@ -531,14 +539,14 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         const int32_t norm = S.best_score;
         auto normalize = [&](int32_t c) {
 #pragma unroll
-            for (int k = 0; k < NE; k++) { const int32_t v = L.score[k * H + c]; if (v > PS_WORST) L.score[k * H + c] = sub32(v, norm); }
-            const int32_t o = L.out_score[c];
-            if (o > PS_WORST) L.out_score[c] = sub32(o, norm);
+            for (int k = 0; k < NE; k++) { const int32_t v = CH_SC(L, c, k); if (v > PS_WORST) CH_SC(L, c, k) = sub32(v, norm); }
+            const int32_t o = CH_OS(L, c);
+            if (o > PS_WORST) CH_OS(L, c) = sub32(o, norm);
         };
         for (int32_t j = tid; j < F.n_rl; j += NT) normalize(L.rl[j]);
         for (int32_t j = tid; j < S.n_acl[cur]; j += NT) normalize(L.acl[cur][j]);
         for (int32_t j = tid; j < F.n_arc; j += NT) normalize(L.arc[j]);
-        for (int32_t i = tid; i < M.n_1ph; i += NT) if (L.frame[M.sp_base + i] == f) normalize(M.sp_base + i);
+        for (int32_t i = tid; i < M.n_1ph; i += NT) if (CH_FR(L, M.sp_base + i) == f) normalize(M.sp_base + i);
         if (tid == 0) S.renorm = 1;
         __syncthreads();
     }
@@ -553,7 +561,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         int32_t j1 = 0;
         for (int32_t i = tid; i < M.n_1ph; i += NT) {
             const int32_t c = M.sp_base + i;
-            if (L.frame[c] < f) continue;
+            if (CH_FR(L, c) < f) continue;
             const int32_t b = hmm_vit_eval<NE, true>(M, L, c, M.n_root + i, sen);
             if (M.sp_wid[i] != M.finish_wid) lp = max(lp, b);
             j1++;
@@ -583,7 +591,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         __syncthreads();
         /* every root channel is binned (:1143-1151); one that is not active has bestscore WORST_SCORE */
         for (int32_t j = tid; j < F.n_rl; j += NT) {
-            int32_t b = sub32(S.best_score, L.best[L.rl[j]]) / bw;
+            int32_t b = sub32(S.best_score, CH_BE(L, L.rl[j])) / bw;
             atomicAdd(&F.bins[b >= 256 ? 255 : b], 1);
         }
         if (tid == 0) {
@@ -591,7 +599,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
             atomicAdd(&F.bins[b >= 256 ? 255 : b], M.n_root - F.n_rl);
         }
         for (int32_t j = tid; j < S.n_acl[cur]; j += NT) {
-            int32_t b = sub32(S.best_score, L.best[L.acl[cur][j]]) / bw;
+            int32_t b = sub32(S.best_score, CH_BE(L, L.acl[cur][j])) / bw;
             atomicAdd(&F.bins[b >= 256 ? 255 : b], 1);
         }
         __syncthreads();
@@ -612,13 +620,13 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     auto in_acl = [&](int32_t c) -> bool { const int32_t p = apos[c - M.n_root]; return p >= 0 && p < n_acl && acl[p] == c; };
     /* does parent p (position ppos in the list, -1 = root) enter child x?  everything read is immutable in this phase */
     auto enters = [&](int32_t p, int32_t ppos, int32_t x, int32_t *ns_out) -> bool {
-        if (!(L.best[p] > thresh)) return false;
-        const int32_t ns = add32(L.out_score[p], M.pip);
+        if (!(CH_BE(L, p) > thresh)) return false;
+        const int32_t ns = add32(CH_OS(L, p), M.pip);
         *ns_out = ns;
         if (!(ns > newphone_thresh)) return false;
-        if (!in_acl(x)) return (L.frame[x] < f) || (ns > L.score[x]);
+        if (!in_acl(x)) return (CH_FR(L, x) < f) || (ns > CH_SC(L, x, 0));
         const bool pfirst = ppos < 0 || ppos < apos[x - M.n_root];
-        if (pfirst || L.best[x] > thresh) return ns > L.score[x];
+        if (pfirst || CH_BE(L, x) > thresh) return ns > CH_SC(L, x, 0);
         return ns > PS_WORST;       /* x's turn came first and cleared it (:866-867) */
     };
     if (tid == 0) { F.carryA = 0; F.carryC = 0; }
@@ -635,18 +643,18 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
             if (p < n_rl) c = L.rl[p];
             else { pos = p - n_rl; c = acl[pos]; }
             items = 1;
-            surv = L.best[c] > thresh;
+            surv = CH_BE(L, c) > thresh;
             if (pos >= 0 && surv) {
                 /* :822-826 `if (hmm_frame != nf)`: unless the parent's turn came first and entered this channel */
                 const int32_t par = M.ch_par[c];
                 int32_t ns;
                 bool par_first_entered = false;
-                if (par < M.n_root) par_first_entered = !(L.frame[par] < f) && enters(par, -1, c, &ns);
+                if (par < M.n_root) par_first_entered = !(CH_FR(L, par) < f) && enters(par, -1, c, &ns);
                 else if (in_acl(par) && apos[par - M.n_root] < pos) par_first_entered = enters(par, apos[par - M.n_root], c, &ns);
                 selfapp = !par_first_entered;
             }
             if (surv) {
-                const int32_t ns0 = add32(L.out_score[c], M.pip);
+                const int32_t ns0 = add32(CH_OS(L, c), M.pip);
                 if (ns0 > newphone_thresh) items += M.ch_child_off[c + 1] - M.ch_child_off[c];
                 if (ns0 > lastphn_thresh) cntC = M.ch_pen_off[c + 1] - M.ch_pen_off[c];
             }
@@ -656,9 +664,9 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         F.pa[0][tid] = io; F.pa[1][tid] = c; F.pa[2][tid] = pos; F.pa[3][tid] = selfapp ? 1 : 0;
         oc += F.carryC;
         if (surv) {
-            if (pos < 0) { L.frame[c] = nf; setbit(F.rootbits, c); }                    /* :733 */
+            if (pos < 0) { CH_FR(L, c) = nf; setbit(F.rootbits, c); }                    /* :733 */
             if (cntC > 0) {
-                const int32_t cs = sub32(add32(L.out_score[c], M.pip), M.nwpen), ch = L.out_hist[c];
+                const int32_t cs = sub32(add32(CH_OS(L, c), M.pip), M.nwpen), ch = CH_OH(L, c);
                 for (int32_t e = M.ch_pen_off[c]; e < M.ch_pen_off[c + 1]; e++, oc++) {
                     L.cand_wid[oc] = M.ch_pen_wid[e]; L.cand_score[oc] = cs; L.cand_bp[oc] = ch;
                 }
@@ -680,13 +688,13 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                         const bool xin = in_acl(x);
                         bool app;
                         if (ppos < 0) app = true;                                       /* :750-752 */
-                        else if (xin) app = !(L.best[x] > thresh && apos[x - M.n_root] < ppos);
-                        else app = L.frame[x] != nf;                                    /* :833-836 */
+                        else if (xin) app = !(CH_BE(L, x) > thresh && apos[x - M.n_root] < ppos);
+                        else app = CH_FR(L, x) != nf;                                    /* :833-836 */
                         flag = app ? 1 : 0; item = x;
                         if (xin) {      /* parked: x's own state is still being read by others */
-                            L.ent_score[x - M.n_root] = ns; L.ent_hist[x - M.n_root] = L.out_hist[pc]; L.ent_stamp[x - M.n_root] = tick;
+                            L.ent_score[x - M.n_root] = ns; L.ent_hist[x - M.n_root] = CH_OH(L, pc); L.ent_stamp[x - M.n_root] = tick;
                         }
-                        else { L.score[x] = ns; L.hist[x] = L.out_hist[pc]; L.frame[x] = nf; }  /* hmm_enter; only its parent touches an inactive channel */
+                        else { CH_SC(L, x, 0) = ns; CH_HI(L, x, 0) = CH_OH(L, pc); CH_FR(L, x) = nf; }  /* hmm_enter; only its parent touches an inactive channel */
                     }
                 }
             }
@@ -704,7 +712,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     /* channels of this frame that did not survive: cleared unless the parent came first and entered them (:866-867) */
     for (int32_t j = tid; j < n_acl; j += NT) {
         const int32_t c = acl[j];
-        if (L.best[c] > thresh) continue;
+        if (CH_BE(L, c) > thresh) continue;
         bool keep = false;
         if (L.ent_stamp[c - M.n_root] == tick) {
             const int32_t par = M.ch_par[c];
@@ -716,8 +724,8 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     /* the parked entries; every channel of the next list is active in f + 1 */
     for (int32_t j = tid; j < n_nacl; j += NT) {
         const int32_t x = nacl[j];
-        if (L.ent_stamp[x - M.n_root] == tick) { L.score[x] = L.ent_score[x - M.n_root]; L.hist[x] = L.ent_hist[x - M.n_root]; }
-        L.frame[x] = nf;
+        if (L.ent_stamp[x - M.n_root] == tick) { CH_SC(L, x, 0) = L.ent_score[x - M.n_root]; CH_HI(L, x, 0) = L.ent_hist[x - M.n_root]; }
+        CH_FR(L, x) = nf;
     }
     if (tid == 0) { S.n_acl[nxt] = n_nacl; S.n_cand = n_cand; S.st_cand += n_cand; }
     __syncthreads();
@@ -787,7 +795,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                 const int32_t sc = L.cand_score[i], bp = L.cand_bp[i], c0 = M.rc_base + M.w_rc_base[w];
                 for (int32_t r = 0; r < M.w_rcsize[w]; r++) {
                     const int32_t c = c0 + r;
-                    if (L.frame[c] < f || sc > L.score[c]) { L.score[c] = sc; L.hist[c] = bp; L.frame[c] = nf; k++; }
+                    if (CH_FR(L, c) < f || sc > CH_SC(L, c, 0)) { CH_SC(L, c, 0) = sc; CH_HI(L, c, 0) = bp; CH_FR(L, c) = nf; k++; }
                 }
             }
             int32_t off, o2, tot, t2;
@@ -812,22 +820,22 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
             if (q < n_awl) {
                 w = L.awl[cur][q]; c0 = M.rc_base + M.w_rc_base[w]; rcs = M.w_rcsize[w];
                 for (int32_t r = 0; r < rcs; r++) {
-                    const int32_t c = c0 + r, fr = L.frame[c];
+                    const int32_t c = c0 + r, fr = CH_FR(L, c);
                     if (fr < f) continue;                                   /* not allocated */
-                    if (L.best[c] > lpo_thresh) {
-                        L.frame[c] = nf; k++;
-                        const int32_t o = L.out_score[c];
-                        if (o > newword_thresh) { if (n_ex == 0 || ex_score < o) { ex_score = o; ex_hist = L.out_hist[c]; } n_ex++; }
+                    if (CH_BE(L, c) > lpo_thresh) {
+                        CH_FR(L, c) = nf; k++;
+                        const int32_t o = CH_OS(L, c);
+                        if (o > newword_thresh) { if (n_ex == 0 || ex_score < o) { ex_score = o; ex_hist = CH_OH(L, c); } n_ex++; }
                     }
                     else if (fr != nf) hmm_clear<NE>(M, L, c);              /* listelem_free */
                 }
             }
             else if (q < n_items) {
                 const int32_t i = q - n_awl, c = M.sp_base + i;
-                if (!(L.frame[c] < f) && L.best[c] > lpo_thresh) {
-                    L.frame[c] = nf;
-                    const int32_t o = L.out_score[c];
-                    if (o > newword_thresh) { w = M.sp_wid[i]; ex_score = o; ex_hist = L.out_hist[c]; n_ex = 1; rcs = 1; }
+                if (!(CH_FR(L, c) < f) && CH_BE(L, c) > lpo_thresh) {
+                    CH_FR(L, c) = nf;
+                    const int32_t o = CH_OS(L, c);
+                    if (o > newword_thresh) { w = M.sp_wid[i]; ex_score = o; ex_hist = CH_OH(L, c); n_ex = 1; rcs = 1; }
                 }
             }
             const int32_t has = n_ex > 0 ? 1 : 0;
@@ -843,8 +851,8 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                     L.bp_sidx[bp] = si; L.bp_valid[bp] = 1;
                     if (q < n_awl) {
                         for (int32_t r = 0; r < rcs; r++) {
-                            const int32_t c = c0 + r, o = L.out_score[c];
-                            L.bss[si + r] = (L.best[c] > lpo_thresh && o > newword_thresh) ? o : PS_WORST;
+                            const int32_t c = c0 + r, o = CH_OS(L, c);
+                            L.bss[si + r] = (CH_BE(L, c) > lpo_thresh && o > newword_thresh) ? o : PS_WORST;
                         }
                     }
                     else L.bss[si] = ex_score;
@@ -935,8 +943,8 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
             /* into the roots (:1301-1317) */
             for (int32_t i = tid; i < M.n_root; i += NT) {
                 const int32_t ci = M.root_ci[i], ns = add32(add32(F.brc_score[ci], M.nwpen), M.pip);
-                if (ns > wthresh && (L.frame[i] < f || ns > L.score[i])) {
-                    L.score[i] = ns; L.hist[i] = F.brc_path[ci]; L.frame[i] = nf;
+                if (ns > wthresh && (CH_FR(L, i) < f || ns > CH_SC(L, i, 0))) {
+                    CH_SC(L, i, 0) = ns; CH_HI(L, i, 0) = F.brc_path[ci]; CH_FR(L, i) = nf;
                     L.mpxid[i] = M.root_lc_ssid[i * M.n_ci + F.brc_lc[ci]];
                     setbit(F.rootbits, i);
                 }
@@ -967,16 +975,16 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                     L.lt_dscr[w] = dscr;
                     if (kind & 1) {
                         const int32_t ns = add32(dscr, M.pip);
-                        if (ns > wthresh && (L.frame[c] < f || ns > L.score[c])) {
+                        if (ns > wthresh && (CH_FR(L, c) < f || ns > CH_SC(L, c, 0))) {
                             const int32_t pb = L.lt_bp[w];
-                            L.score[c] = ns; L.hist[c] = pb; L.frame[c] = nf;
+                            CH_SC(L, c, 0) = ns; CH_HI(L, c, 0) = pb; CH_FR(L, c) = nf;
                             L.mpxid[M.n_root + i] = M.sp_lc_ssid[i * M.n_ci + M.w_last_ci[L.bp_wid[pb]]];
                         }
                     }
                 }
                 if (kind & 6) {
                     const int32_t ns = add32(add32(F.brc_score[M.sil_ci], (kind & 2) ? M.silpen : M.fillpen), M.pip);
-                    if (ns > wthresh && (L.frame[c] < f || ns > L.score[c])) { L.score[c] = ns; L.hist[c] = F.brc_path[M.sil_ci]; L.frame[c] = nf; }
+                    if (ns > wthresh && (CH_FR(L, c) < f || ns > CH_SC(L, c, 0))) { CH_SC(L, c, 0) = ns; CH_HI(L, c, 0) = F.brc_path[M.sil_ci]; CH_FR(L, c) = nf; }
                 }
             }
         }
@@ -985,8 +993,8 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
 
     TPHASE(S, 8);
     /* ---- deactivate_channels :1421-1443 ---- */
-    for (int32_t j = tid; j < F.n_rl; j += NT) { const int32_t i = L.rl[j]; if (L.frame[i] == f) hmm_clear_scores<NE>(M, L, i); }
-    for (int32_t i = tid; i < M.n_1ph; i += NT) if (L.frame[M.sp_base + i] == f) hmm_clear_scores<NE>(M, L, M.sp_base + i);
+    for (int32_t j = tid; j < F.n_rl; j += NT) { const int32_t i = L.rl[j]; if (CH_FR(L, i) == f) hmm_clear_scores<NE>(M, L, i); }
+    for (int32_t i = tid; i < M.n_1ph; i += NT) if (CH_FR(L, M.sp_base + i) == f) hmm_clear_scores<NE>(M, L, M.sp_base + i);
     if (tid == 0) S.n_frame++;
     __syncthreads();
     TPHASE(S, 9);
@@ -997,7 +1005,23 @@ template <int NE> __device__ void
 d_start(const PsfModel &M, PsfLane &L, PsfScalars &S, int fresh)
 {
     const int tid = threadIdx.x;
-    if (fresh) {
+    /* after an utterance that was finished (ngram_fwdtree_finish cleared the roots, the last active lists and every
+     * word's last-phone channels; pruning cleared the scores of everything else) the state differs from a new decoder's
+     * only in the interior channels' stale frame numbers and histories, the multiplexed ids, the last-transition cache and
+     * the real-word ids of the old table: reset those, not 20+ MB of channel records */
+    const bool light = fresh && S.clean, full = fresh && !light;
+    const int32_t old_bpidx = S.bpidx;
+    __syncthreads();
+    if (light) {
+        for (int32_t c = M.n_root + tid; c < M.n_ch; c += NT) hmm_clear<NE>(M, L, c);
+        for (int32_t i = tid; i < M.n_mpx; i += NT) {
+            L.mpxid[i] = i < M.n_root ? M.root_ssid0[i] : M.sp_ssid0[i - M.n_root];
+            for (int k = 1; k < NE; k++) L.mpxid[k * M.n_mpx + i] = PS_BAD_SSID;
+        }
+        for (int32_t w = tid; w < M.n_words; w += NT) { L.lt_dscr[w] = 0; L.lt_bp[w] = 0; }
+        for (int32_t i = tid; i < old_bpidx && i < M.bp_cap; i += NT) L.bp_realwid[i] = 0;
+    }
+    if (full) {
         for (int32_t c = tid; c < M.n_hmm; c += NT) hmm_clear<NE>(M, L, c);
         for (int32_t i = tid; i < M.n_mpx; i += NT) {
             L.mpxid[i] = i < M.n_root ? M.root_ssid0[i] : M.sp_ssid0[i - M.n_root];
@@ -1012,11 +1036,11 @@ d_start(const PsfModel &M, PsfLane &L, PsfScalars &S, int fresh)
     __syncthreads();
     if (tid == 0) {
         const int32_t keep_tick = S.tick, n_total = S.n_total;
-        memset(&S, 0, sizeof(S));
+        memset(&S, 0, sizeof(S));           /* (clean = 0 until this utterance is finished) */
         S.tick = keep_tick + 1; S.n_total = n_total;
         S.exit_bp = NO_BP;
         const int32_t c = M.sp_base + M.start_sp;
-        L.score[c] = 0; L.hist[c] = NO_BP; L.frame[c] = 0;                 /* hmm_enter(<s>, 0, NO_BP, 0) */
+        CH_SC(L, c, 0) = 0; CH_HI(L, c, 0) = NO_BP; CH_FR(L, c) = 0;                 /* hmm_enter(<s>, 0, NO_BP, 0) */
     }
     __syncthreads();
 }
@@ -1034,7 +1058,7 @@ d_finish(const PsfModel &M, PsfLane &L, PsfScalars &S, int32_t cf)
         for (int32_t r = 0; r < M.w_rcsize[w]; r++) hmm_clear<NE>(M, L, c0 + r);     /* ngram_search_free_all_rc */
     }
     __syncthreads();
-    if (tid == 0) S.finished = 1;
+    if (tid == 0) { S.finished = 1; S.clean = (S.status == 0 && S.best_score > PS_WORST) ? 1 : 0; }
 }
 
 /* ngram_search_find_exit (ngram_search.c:444-484) + ngram_search_bp_iter / _bp2itor (:862-903, :777-818), lwf = 1 */
@@ -1172,6 +1196,66 @@ k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, in
     if (threadIdx.x == 0) *L.sc = F.S;
 }
 
+/* whole utterances from a QUEUE: the lanes are persistent workgroups, a lane takes the next utterance of the batch when its
+ * own has ended (ps_decode_raw's loop over a control file, batch.c:720-760, one decoder per lane; every utterance starts
+ * from a new decoder's state).  Hypotheses are made on the device and kept per utterance. */
+#define PSF_QRES 8
+struct PsfQueue {
+    int32_t n_utt, seg_cap;
+    int32_t *next;                  /* the queue's head */
+    const int32_t *nfr;             /* [n_utt] */
+    const long long *row0;          /* [n_utt] first row of the utterance in the score matrix */
+    const int16_t *raw;             /* [rows][n_sen] */
+    int32_t *res;                   /* [n_utt][PSF_QRES]: status, exit score, #segments, frames searched, #backpointers, lane */
+    s3a_psfwd_seg_t *seg;           /* [n_utt][seg_cap] */
+};
+
+template <int NE> __global__ void __launch_bounds__(NT)
+k_psf_queue(PsfModel M, PsfLane *lanes, PsfQueue Q, int compallsen)
+{
+    PsfLane L = lanes[blockIdx.x];
+    __shared__ FrameShared F;
+    __shared__ int32_t s_u;
+    if (threadIdx.x == 0) F.S = *L.sc;
+    __syncthreads();
+    for (;;) {
+        if (threadIdx.x == 0) s_u = atomicAdd(Q.next, 1);
+        __syncthreads();
+        const int32_t u = s_u;
+        __syncthreads();
+        if (u >= Q.n_utt) break;
+        const int32_t n_total = Q.nfr[u];
+        const int16_t *raw0 = Q.raw + (size_t)Q.row0[u] * M.n_sen;
+        if (threadIdx.x == 0) F.S.n_total = n_total;
+        __syncthreads();
+        d_start<NE>(M, L, F.S, 1);
+        d_root_bits_from_frames(M, L, F.rootbits, 0);
+        for (int32_t f = 0; f < n_total; f++) {
+            const int16_t *raw = raw0 + (size_t)f * M.n_sen;
+            int32_t best = 0, count = 0;
+            d_frame_roots(M, L, F);
+            d_frame_word_chans(M, L, F, f);
+            if (!compallsen) d_sen_active<NE>(M, L, F.S, f, F.senbits, F.n_rl, F.n_arc);
+            d_normaliser(M, F.wg, F.sh, F.senbits, raw, compallsen, &best, &count);
+            SenScr sen = { raw, best, 1 };
+            d_frame<NE>(M, L, F, f, sen, count);
+            __syncthreads();
+        }
+        d_finish<NE>(M, L, F.S, n_total);
+        __syncthreads();
+        d_hyp(M, L, F.S);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t *r = Q.res + (size_t)u * PSF_QRES;
+            r[0] = F.S.status; r[1] = F.S.exit_score; r[2] = F.S.exit_bp == NO_BP ? 0 : F.S.n_seg; r[3] = F.S.n_frame; r[4] = F.S.bpidx; r[5] = blockIdx.x;
+        }
+        const int32_t ns = F.S.exit_bp == NO_BP ? 0 : (F.S.n_seg < Q.seg_cap ? F.S.n_seg : Q.seg_cap);
+        for (int32_t i = threadIdx.x; i < ns && i < MAX_SEG; i += NT) Q.seg[(size_t)u * Q.seg_cap + i] = L.seg[i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *L.sc = F.S;
+}
+
 /* ------------------------------------------------------------------ */
 /* host side                                                          */
 /* ------------------------------------------------------------------ */
@@ -1194,6 +1278,12 @@ struct s3a_psfwd_s {
     int32_t *slot_row_d; size_t slot_cap;
     int16_t *raw_d; size_t raw_cap;
     int32_t win;
+    /* the queue's per-utterance results */
+    int32_t *q_next_d, *q_nfr_d, *q_res_d; long long *q_row0_d; s3a_psfwd_seg_t *q_seg_d;
+    size_t q_cap;
+    int32_t q_n, q_seg_cap;
+    std::vector<int32_t> q_res_h;
+    std::vector<s3a_psfwd_seg_t> q_seg_h;
 };
 
 template <typename T> static T *
@@ -1221,6 +1311,7 @@ s3a_psfwd_free(s3a_psfwd_t *e)
     if (e->feat_d) (void)hipFree(e->feat_d);
     if (e->slot_row_d) (void)hipFree(e->slot_row_d);
     if (e->raw_d) (void)hipFree(e->raw_d);
+    { void *qp[] = { e->q_next_d, e->q_nfr_d, e->q_res_d, e->q_row0_d, e->q_seg_d }; for (void *q : qp) if (q) (void)hipFree(q); }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1243,7 +1334,8 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     if (max_frames > 32767) { s3a_set_error("s3a_psfwd_init: max_frames %d (the reference's frame numbers are int16)", max_frames); return NULL; }
     s3a_psfwd_t *e = new s3a_psfwd_t();
     e->lanes_d = NULL; e->lane_ids_d = NULL; e->stream = NULL; e->ev0 = e->ev1 = NULL; e->last_ms = 0;
-    e->feat_d = NULL; e->feat_cap = 0; e->slot_row_d = NULL; e->slot_cap = 0; e->raw_d = NULL; e->raw_cap = 0; e->win = 32;
+    e->feat_d = NULL; e->feat_cap = 0; e->slot_row_d = NULL; e->slot_cap = 0; e->raw_d = NULL; e->raw_cap = 0; e->win = 0;
+    e->q_next_d = e->q_nfr_d = e->q_res_d = NULL; e->q_row0_d = NULL; e->q_seg_d = NULL; e->q_cap = 0; e->q_n = 0; e->q_seg_cap = 256;
     PsfModel &M = e->M;
     memset(&M, 0, sizeof(M));
     e->n_lanes = n_lanes;
@@ -1321,8 +1413,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     for (int32_t z = 0; z < n_lanes; z++) {
         PsfLane &L = e->lanes_h[z];
         const size_t H = M.n_hmm;
-        LANE(L.score, int32_t, NE * H); LANE(L.hist, int32_t, NE * H);
-        LANE(L.out_score, int32_t, H); LANE(L.out_hist, int32_t, H); LANE(L.best, int32_t, H); LANE(L.frame, int32_t, H);
+        LANE(L.st, int32_t, CH_STRIDE * H);
         LANE(L.mpxid, uint16_t, (size_t)NE * M.n_mpx);
         for (int k = 0; k < 2; k++) { LANE(L.acl[k], int32_t, d->n_nonroot + 1); LANE(L.apos[k], int32_t, d->n_nonroot + 1); LANE(L.awl[k], int32_t, M.cand_cap + 1); }
         LANE(L.wstamp, int32_t, W); LANE(L.lt_sf, int32_t, W); LANE(L.lt_dscr, int32_t, W); LANE(L.lt_bp, int32_t, W);
@@ -1506,7 +1597,8 @@ s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const flo
 {
     if (!e || !scorer || !feat || !n_frames || n_utt < 1 || n_utt > e->n_lanes) { s3a_set_error("s3a_psfwd_decode: bad argument"); return S3A_EINVAL; }
     const PsfModel &M = e->M;
-    const int32_t D = s3a_ps_ms_mgau_veclen(scorer), W = e->win;
+    const int32_t D = s3a_ps_ms_mgau_veclen(scorer);
+    int32_t W = e->win;
     if (s3a_ps_ms_mgau_n_sen(scorer) != M.n_sen) { s3a_set_error("s3a_psfwd_decode: the scorer has %d senones, the search %d", s3a_ps_ms_mgau_n_sen(scorer), M.n_sen); return S3A_EINVAL; }
     size_t total = 0;
     int32_t longest = 0;
@@ -1522,6 +1614,10 @@ s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const flo
         HIPCHK(hipMalloc((void **)&e->feat_d, (total * D + 1) * 4));
         e->feat_cap = total * D;
     }
+    /* every lane's senone scores of the WHOLE utterance before its search starts (int16 per senone and frame: 12 MB per
+     * 10 s of a 6144-senone model): the lanes then run their utterances from the first frame to the last in ONE launch,
+     * none waiting for another at window boundaries (a frame's cost varies several-fold along an utterance) */
+    if (e->win <= 0) W = longest > 0 ? longest : 1;
     const size_t n_slots = (size_t)n_utt * W, n_windows = (size_t)(longest + W - 1) / W + 1;
     if (e->slot_cap < n_slots * n_windows) {
         if (e->slot_row_d) (void)hipFree(e->slot_row_d);
@@ -1581,4 +1677,95 @@ s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const flo
         if (sc.status != 0) { s3a_set_error("s3a_psfwd_decode: utterance %d: the backpointer table (%d entries) or score stack (%d) is full", z, M.bp_cap, M.bss_cap); return sc.status; }
     }
     return S3A_OK;
+}
+
+/* n_utt utterances (any number) through the engine's lanes as a queue: all senone scores first (one model-stationary pass
+ * over the batch's frames), then ONE launch in which every lane decodes utterance after utterance.  Every utterance starts
+ * from a new decoder's state.  Results: s3a_psfwd_queue_hyp. */
+extern "C" int32_t
+s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const float *const *feat, const int32_t *n_frames,
+                       int32_t compallsen)
+{
+    if (!e || !scorer || !feat || !n_frames || n_utt < 1) { s3a_set_error("s3a_psfwd_decode_queue: bad argument"); return S3A_EINVAL; }
+    const PsfModel &M = e->M;
+    const int32_t D = s3a_ps_ms_mgau_veclen(scorer);
+    if (s3a_ps_ms_mgau_n_sen(scorer) != M.n_sen) { s3a_set_error("s3a_psfwd_decode_queue: the scorer has %d senones, the search %d", s3a_ps_ms_mgau_n_sen(scorer), M.n_sen); return S3A_EINVAL; }
+    size_t total = 0;
+    std::vector<long long> row0(n_utt);
+    for (int32_t z = 0; z < n_utt; z++) {
+        if (n_frames[z] < 0 || n_frames[z] > M.max_frames) { s3a_set_error("s3a_psfwd_decode_queue: utterance %d has %d frames (max_frames %d)", z, n_frames[z], M.max_frames); return S3A_EINVAL; }
+        row0[z] = (long long)total; total += n_frames[z];
+    }
+    if (e->feat_cap < total * D) {
+        if (e->feat_d) (void)hipFree(e->feat_d);
+        e->feat_d = NULL; e->feat_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->feat_d, (total * D + 1) * 4));
+        e->feat_cap = total * D;
+    }
+    if (e->slot_cap < total + 1) {
+        if (e->slot_row_d) (void)hipFree(e->slot_row_d);
+        e->slot_row_d = NULL; e->slot_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->slot_row_d, (total + 1) * 4));
+        e->slot_cap = total + 1;
+    }
+    if (e->raw_cap < (total + 1) * M.n_sen) {
+        if (e->raw_d) (void)hipFree(e->raw_d);
+        e->raw_d = NULL; e->raw_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->raw_d, (total + 1) * M.n_sen * 2));
+        e->raw_cap = (total + 1) * M.n_sen;
+    }
+    if (e->q_cap < (size_t)n_utt) {
+        void *qp[] = { e->q_next_d, e->q_nfr_d, e->q_res_d, e->q_row0_d, e->q_seg_d };
+        for (void *q : qp) if (q) (void)hipFree(q);
+        e->q_next_d = e->q_nfr_d = e->q_res_d = NULL; e->q_row0_d = NULL; e->q_seg_d = NULL; e->q_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->q_next_d, 4)); HIPCHK(hipMalloc((void **)&e->q_nfr_d, (size_t)n_utt * 4));
+        HIPCHK(hipMalloc((void **)&e->q_res_d, (size_t)n_utt * PSF_QRES * 4)); HIPCHK(hipMalloc((void **)&e->q_row0_d, (size_t)n_utt * 8));
+        HIPCHK(hipMalloc((void **)&e->q_seg_d, (size_t)n_utt * e->q_seg_cap * sizeof(s3a_psfwd_seg_t)));
+        e->q_cap = n_utt;
+    }
+    for (int32_t z = 0; z < n_utt; z++)
+        if (n_frames[z]) HIPCHK(hipMemcpyAsync(e->feat_d + (size_t)row0[z] * D, feat[z], (size_t)n_frames[z] * D * 4, hipMemcpyHostToDevice, e->stream));
+    std::vector<int32_t> rows(total + 1);
+    for (size_t i = 0; i < total; i++) rows[i] = (int32_t)i;
+    HIPCHK(hipMemcpyAsync(e->slot_row_d, rows.data(), total * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->q_nfr_d, n_frames, (size_t)n_utt * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->q_row0_d, row0.data(), (size_t)n_utt * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->q_next_d, 0, 4, e->stream));
+    HIPCHK(hipMemsetAsync(e->q_res_d, 0xff, (size_t)n_utt * PSF_QRES * 4, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));            /* (rows is a local) */
+    HIPCHK(hipEventRecord(e->ev0, e->stream));
+    int32_t rc = s3a_ps_score_slots_dev(scorer, e->feat_d, e->slot_row_d, (int32_t)total, e->raw_d, e->stream);
+    if (rc != S3A_OK) return rc;
+    PsfQueue Q;
+    Q.n_utt = n_utt; Q.seg_cap = e->q_seg_cap; Q.next = e->q_next_d; Q.nfr = e->q_nfr_d; Q.row0 = e->q_row0_d; Q.raw = e->raw_d;
+    Q.res = e->q_res_d; Q.seg = e->q_seg_d;
+    const int32_t n_wg = n_utt < e->n_lanes ? n_utt : e->n_lanes;
+    NE_LAUNCH(k_psf_queue, dim3(n_wg), M, e->lanes_d, Q, compallsen);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev1, e->stream));
+    e->q_res_h.resize((size_t)n_utt * PSF_QRES); e->q_seg_h.resize((size_t)n_utt * e->q_seg_cap);
+    HIPCHK(hipMemcpyAsync(e->q_res_h.data(), e->q_res_d, (size_t)n_utt * PSF_QRES * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->q_seg_h.data(), e->q_seg_d, (size_t)n_utt * e->q_seg_cap * sizeof(s3a_psfwd_seg_t), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->last_ms = ms;
+    e->q_n = n_utt;
+    for (int32_t z = 0; z < n_utt; z++) {
+        const int32_t *r = &e->q_res_h[(size_t)z * PSF_QRES];
+        if (r[0] != 0) { s3a_set_error("s3a_psfwd_decode_queue: utterance %d: %s", z, r[0] == -1 ? "not decoded" : "the backpointer table or score stack is full"); return r[0] == -1 ? S3A_EHIP : r[0]; }
+    }
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_psfwd_queue_hyp(s3a_psfwd_t *e, int32_t utt, int32_t *out_score, s3a_psfwd_seg_t *seg, int32_t max_seg)
+{
+    if (!e || utt < 0 || utt >= e->q_n) { s3a_set_error("s3a_psfwd_queue_hyp: bad utterance index"); return S3A_EINVAL; }
+    const int32_t *r = &e->q_res_h[(size_t)utt * PSF_QRES];
+    if (r[0] != 0) { s3a_set_error("s3a_psfwd_queue_hyp: utterance %d failed (status %d)", utt, r[0]); return S3A_EINVAL; }
+    if (out_score) *out_score = r[1];
+    if (r[2] > e->q_seg_cap || r[2] > max_seg) { s3a_set_error("s3a_psfwd_queue_hyp: %d segments, room for %d", r[2], max_seg < e->q_seg_cap ? max_seg : e->q_seg_cap); return -3; }
+    if (seg && r[2] > 0) memcpy(seg, &e->q_seg_h[(size_t)utt * e->q_seg_cap], sizeof(s3a_psfwd_seg_t) * r[2]);
+    return r[2];
 }

@@ -157,6 +157,12 @@ k_ps_norm(int32_t n_sen, const uint8_t *__restrict__ sen_active, const int32_t *
 /* search does that per frame from these).  A senone's score does not depend on which others are computed.    */
 /* ------------------------------------------------------------------ */
 #define PS_FT 8     /* frames per tile: a thread keeps its density's partial sums of PS_FT frames */
+typedef float ps_f2 __attribute__((ext_vector_type(2)));
+typedef float ps_f4 __attribute__((ext_vector_type(4)));
+/* thread = (codebook, stream, density), PS_FT frames at once: the density's mean / precision are read ONCE per tile, the
+ * frames' components come as two 16-byte LDS broadcasts per dimension, and the four operations of a dimension
+ * (x - m, squared, times the precision, subtracted from the sum: each rounded to float32 as the reference's scalar SSE2
+ * code rounds them, never fused) run two frames wide (packed float32 VALU) */
 __global__ void __launch_bounds__(PSB)
 k_ps_dist_slots(int32_t n_mgau, int32_t n_feat, int32_t nd, int32_t P, int32_t veclen, int32_t topn,
                 const int32_t *__restrict__ featlen, const int32_t *__restrict__ featoff,
@@ -164,45 +170,50 @@ k_ps_dist_slots(int32_t n_mgau, int32_t n_feat, int32_t nd, int32_t P, int32_t v
                 const float *__restrict__ feat, const int32_t *__restrict__ slot_row, int32_t slot0, int32_t n_slots,
                 float *dist, int32_t *dist_id)
 {
-    extern __shared__ float x_s[];          /* [PS_FT][veclen] */
+    extern __shared__ ps_f4 x_s4[];         /* [veclen][PS_FT] floats: a dimension's PS_FT frames are contiguous */
+    float *x_s = (float *)x_s4;
     __shared__ float dv[PS_FT][PSB];
     const int32_t q0 = slot0 + blockIdx.y * PS_FT;
     for (int32_t i = threadIdx.x; i < PS_FT * veclen; i += PSB) {
-        const int32_t t = i / veclen, q = q0 + t;
+        const int32_t t = i / veclen, k = i - t * veclen, q = q0 + t;
         const int32_t row = (q < slot0 + n_slots) ? slot_row[q] : -1;
-        x_s[i] = row >= 0 ? feat[(size_t)row * veclen + (i - t * veclen)] : 0.0f;
+        x_s[k * PS_FT + t] = row >= 0 ? feat[(size_t)row * veclen + k] : 0.0f;
     }
     __syncthreads();
     const int32_t item = blockIdx.x * PSB + threadIdx.x;
     const int32_t job = item / P, d = item % P, m = job / n_feat, f = job % n_feat;
     const bool live = job < n_mgau * n_feat && d < nd;
-    float acc[PS_FT];
+    ps_f2 acc[PS_FT / 2];
 #pragma unroll
-    for (int t = 0; t < PS_FT; t++) acc[t] = 0.0f;
+    for (int t = 0; t < PS_FT / 2; t++) acc[t] = (ps_f2)(0.0f, 0.0f);
     if (live) {
         const int32_t flen = featlen[f], fo = featoff[f];
         const size_t base = ((size_t)m * veclen + fo) * P;
         const float dt = det[(size_t)job * P + d];
 #pragma unroll
-        for (int t = 0; t < PS_FT; t++) acc[t] = dt;
+        for (int t = 0; t < PS_FT / 2; t++) acc[t] = (ps_f2)(dt, dt);
         for (int32_t i = 0; i < flen; i++) {
             const float mu = meanT[base + (size_t)i * P + d], pr = precT[base + (size_t)i * P + d];
+            const ps_f2 mu2 = (ps_f2)(mu, mu), pr2 = (ps_f2)(pr, pr);
+            const ps_f4 xa = x_s4[(fo + i) * (PS_FT / 4)], xb = x_s4[(fo + i) * (PS_FT / 4) + 1];
+            const ps_f2 x[PS_FT / 2] = { xa.xy, xa.zw, xb.xy, xb.zw };
 #pragma unroll
-            for (int t = 0; t < PS_FT; t++) {
-                const float df = x_s[t * veclen + fo + i] - mu;
-                const float tt = (df * df) * pr;
+            for (int t = 0; t < PS_FT / 2; t++) {
+                const ps_f2 df = x[t] - mu2;
+                const ps_f2 sq = df * df;
+                const ps_f2 tt = sq * pr2;
                 acc[t] = acc[t] - tt;
             }
         }
     }
 #pragma unroll
-    for (int t = 0; t < PS_FT; t++) dv[t][threadIdx.x] = acc[t];
+    for (int t = 0; t < PS_FT / 2; t++) { dv[2 * t][threadIdx.x] = acc[t].x; dv[2 * t + 1][threadIdx.x] = acc[t].y; }
     __syncthreads();
     if (!live) return;
     for (int t = 0; t < PS_FT; t++) {
         const int32_t q = q0 + t;
         if (q >= slot0 + n_slots) break;
-        const float dval = acc[t];
+        const float dval = dv[t][threadIdx.x];
         int32_t rank = d;
         if (topn < nd) {
             const float *mine = &dv[t][threadIdx.x - d];
@@ -271,7 +282,7 @@ s3a_ps_score_slots_dev(s3a_ps_mgau_t *ps, const float *feat_dev, const int32_t *
     for (int32_t s0 = 0; s0 < n_slots; s0 += tile) {
         const int32_t n = n_slots - s0 < tile ? n_slots - s0 : tile;
         hipLaunchKernelGGL(k_ps_dist_slots, dim3((uint32_t)((items + PSB - 1) / PSB), (n + PS_FT - 1) / PS_FT), dim3(PSB),
-                           (size_t)PS_FT * ps->veclen * 4, st, M, F, nd, P, ps->veclen, ps->topn, dv->featlen, dv->featoff,
+                           (size_t)PS_FT * ps->veclen * 4 + 16, st, M, F, nd, P, ps->veclen, ps->topn, dv->featlen, dv->featoff,
                            dv->meanT, dv->precT, dv->det, feat_dev, slot_row_dev, s0, n, dv->bdist, dv->bdist_id);
         hipLaunchKernelGGL(k_ps_senone_slots, dim3((S + PSB - 1) / PSB, n), dim3(PSB), 0, st, S, M, F, nd, ps->topn, ps->aw,
                            dv->mgau, dv->pdf, dv->bdist, dv->bdist_id, la, slot_row_dev, s0, raw_dev);

@@ -1040,6 +1040,14 @@ int32_t s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, c
 int32_t s3a_psfwd_reset(s3a_psfwd_t *e, int32_t lane);
 int32_t s3a_psfwd_get_sp_ssid(s3a_psfwd_t *e, int32_t lane, uint16_t *ssid);
 int32_t s3a_psfwd_set_sp_ssid(s3a_psfwd_t *e, int32_t lane, const uint16_t *ssid);
+/* ANY number of utterances through the engine's lanes as a queue (pocketsphinx_batch's loop over a control file, one
+ * decoder per lane): every senone score of the batch first (one model-stationary pass over all frames), then ONE launch in
+ * which a lane takes the next utterance when its own has ended -- no lane waits for another.  Every utterance starts from
+ * a NEW decoder's state (results do not depend on which lane decoded what).  s3a_psfwd_queue_hyp: utterance utt's
+ * hypothesis as s3a_psfwd_hyp gives it (at most 256 segments are kept per utterance). */
+int32_t s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const float *const *feat,
+                               const int32_t *n_frames, int32_t compallsen);
+int32_t s3a_psfwd_queue_hyp(s3a_psfwd_t *e, int32_t utt, int32_t *out_score, s3a_psfwd_seg_t *seg, int32_t max_seg);
 int32_t s3a_psfwd_table(s3a_psfwd_t *e, int32_t lane, s3a_psfwd_table_t *out);
 /* ngram_search_find_exit(-1) + the backtrace with ngram_search_bp2itor's scores (lwf = 1), made on the device:
  * returns the number of segments (utterance order; 0 = no exit), -3 if max_seg is too small; *out_score = the

@@ -242,7 +242,10 @@ ps_amd_decode_cep_batch(ps_decoder_t *ps, int n_utt, mfcc_t ***cep, const int *n
     int z, rv = -1;
     if (ps->search == NULL || ps->search->vt->start != amd_start) { E_ERROR("ps_amd_decode_cep_batch: ps_amd_search_install first\n"); return -1; }
     b = BINDING(ps->search);
-    if (n_utt > b->n_lanes) { E_ERROR("ps_amd_decode_cep_batch: %d utterances, %d lanes\n", n_utt, b->n_lanes); return -1; }
+    /* more utterances than lanes: the lanes take them from a queue (s3a_psfwd_decode_queue; every utterance from a new
+     * decoder's state; no backpointer-table dump) */
+    const int queue = n_utt > b->n_lanes;
+    if (queue && (bpfh || !fresh)) { E_ERROR("ps_amd_decode_cep_batch: %d utterances on %d lanes go through the queue: -fresh yes, no -bpdump\n", n_utt, b->n_lanes); return -1; }
     if (feat_dimension1(fcb) != 1) { E_ERROR("ps_amd_decode_cep_batch: one feature stream served\n"); return -1; }
     if (b->scorer == NULL) {
         if (strcmp(ps->acmod->mgau->vt->name, "ms") != 0) {
@@ -267,23 +270,24 @@ ps_amd_decode_cep_batch(ps_decoder_t *ps, int n_utt, mfcc_t ***cep, const int *n
         nfr[z] = n > 0 ? feat_s2mfc2feat_live(fcb, cep[z], &n, TRUE, TRUE, feats[z]) : 0;
         rows[z] = (const float *)feats[z][0][0];
     }
-    if (s3a_psfwd_decode(b->e, b->scorer, n_utt, rows, nfr, cmd_ln_boolean_r(config, "-compallsen"), fresh) != S3A_OK) {
-        E_ERROR("s3a_psfwd_decode: %s\n", s3a_last_error());
+    if ((queue ? s3a_psfwd_decode_queue(b->e, b->scorer, n_utt, rows, nfr, cmd_ln_boolean_r(config, "-compallsen"))
+               : s3a_psfwd_decode(b->e, b->scorer, n_utt, rows, nfr, cmd_ln_boolean_r(config, "-compallsen"), fresh)) != S3A_OK) {
+        E_ERROR("s3a_psfwd_decode%s: %s\n", queue ? "_queue" : "", s3a_last_error());
         goto done;
     }
     {
         int32 tot = 0;
         double ms = s3a_psfwd_last_decode_ms(b->e);
         for (z = 0; z < n_utt; z++) tot += nfr[z];
-        E_INFO("batch of %d utterances, %d frames: %.2f ms on the device (scoring + search; %.0f frames/s)\n", n_utt, tot, ms,
-               ms > 0 ? tot / (ms * 1e-3) : 0.0);
+        E_INFO("batch of %d utterances, %d frames: %.2f ms on the device (scoring + search; %.0f frames/s)%s\n", n_utt, tot, ms,
+               ms > 0 ? tot / (ms * 1e-3) : 0.0, queue ? " [queue]" : "");
     }
     for (z = 0; z < n_utt; z++) {
         static s3a_psfwd_seg_t seg[4096];
         int32 score = 0, n, i;
         size_t len = 0;
         char *c;
-        if ((n = s3a_psfwd_hyp(b->e, z, &score, seg, 4096)) < 0) { E_ERROR("s3a_psfwd_hyp: %s\n", s3a_last_error()); goto done; }
+        if ((n = queue ? s3a_psfwd_queue_hyp(b->e, z, &score, seg, 4096) : s3a_psfwd_hyp(b->e, z, &score, seg, 4096)) < 0) { E_ERROR("s3a_psfwd_hyp: %s\n", s3a_last_error()); goto done; }
         out_score[z] = score;
         /* ngram_search_bp_hyp (ngram_search.c:486-539): the real words' base strings */
         for (i = 0; i < n; i++)

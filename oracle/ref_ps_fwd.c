@@ -91,6 +91,7 @@ static const arg_t defn[] = {
     { "-fresh", ARG_BOOLEAN, "no", "A new decoder for every utterance" },
     { "-batch", ARG_INT32, "0", "Utterances per device batch (AMD backend)" },
     { "-trace", ARG_STRING, NULL, "Per-frame trace of the first pass" },
+    { "-queue", ARG_BOOLEAN, "no", "AMD backend: the whole control file as ONE queue over the -batch lanes" },
     CMDLN_EMPTY_OPTION
 };
 static int g_batch;
@@ -179,11 +180,17 @@ main(int argc, char **argv)
 #if defined(PS_BACKEND_AMD)
     if (g_batch > 0) {
         /* whole utterances on the device, g_batch lanes at a time */
-        int ceplen = feat_cepsize(ps->acmod->fcb), n = 0, i;
-        mfcc_t ***cep = ckd_calloc(g_batch, sizeof(*cep));
-        int *nfr = ckd_calloc(g_batch, sizeof(int));
-        char **ids = ckd_calloc(g_batch, sizeof(char *)), **hyps = ckd_calloc(g_batch, sizeof(char *));
-        int32 *scores = ckd_calloc(g_batch, sizeof(int32));
+        int ceplen = feat_cepsize(ps->acmod->fcb), n = 0, i, per_call = g_batch;
+        if (cmd_ln_boolean_r(config, "-queue")) {       /* every utterance of the control file in one call */
+            per_call = 0;
+            while (fgets(line, sizeof line, ctl)) per_call++;
+            rewind(ctl);
+            if (per_call < 1) per_call = 1;
+        }
+        mfcc_t ***cep = ckd_calloc(per_call, sizeof(*cep));
+        int *nfr = ckd_calloc(per_call, sizeof(int));
+        char **ids = ckd_calloc(per_call, sizeof(char *)), **hyps = ckd_calloc(per_call, sizeof(char *));
+        int32 *scores = ckd_calloc(per_call, sizeof(int32));
         int more = 1;
         if (adcin) E_FATAL("-batch takes cepstrum files\n");
         while (more) {
@@ -196,7 +203,7 @@ main(int argc, char **argv)
                 nfr[n] = k;
                 ids[n++] = ckd_salloc(uttid);
             }
-            if (n == g_batch || (!more && n > 0)) {
+            if (n == per_call || (!more && n > 0)) {
                 if (ps_amd_decode_cep_batch(ps, n, cep, nfr, fresh, hyps, scores, segfh, ids, bpfh) < 0) E_FATAL("batch decode failed\n");
                 for (i = 0; i < n; i++) {
                     fprintf(out, "%s (%s %d)\n", hyps[i] ? hyps[i] : "", ids[i], scores[i]);

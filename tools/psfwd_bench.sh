@@ -16,3 +16,10 @@ for L in "$@"; do
   head -4 $O/amd$L.match | cmp -s - $O/ref4.match && echo "lanes $L: first 4 hypotheses identical to the reference's" || echo "lanes $L: HYP DIFF"
   head -4 $O/amd$L.seg | cmp -s - $O/ref4.seg || echo "lanes $L: SEG DIFF"
 done
+# the whole control file as one queue over Q lanes: QUEUE="256 512" bash tools/psfwd_bench.sh ...
+for L in $QUEUE; do
+  oracle/_ref/ref_ps_amdfwd $PSA -fresh yes -batch $L -queue yes -hyp $O/q$L.match -hypseg $O/q$L.seg > $O/q$L.log 2>&1 || { echo "queue lanes $L FAILED"; grep -E "ERROR|FATAL" $O/q$L.log | tail -3; continue; }
+  grep "ms on the device" $O/q$L.log | sed "s/^.*batch of/queue lanes $L: batch of/" | head -3
+  head -4 $O/q$L.match | cmp -s - $O/ref4.match && echo "queue lanes $L: first 4 hypotheses identical to the reference's" || echo "queue lanes $L: HYP DIFF"
+  head -4 $O/q$L.seg | cmp -s - $O/ref4.seg || echo "queue lanes $L: SEG DIFF"
+done
