@@ -68,12 +68,13 @@ def run(exe, args, tmp_path, tag, env=None, timeout=900):
     """-> (match text, seg text, bpdump dict, log text)"""
     need(os.path.join(REF, exe))
     m, s, b, log = (str(tmp_path / f"{tag}.{e}") for e in ("match", "seg", "bp", "log"))
+    dump = [] if "-queue" in args else ["-bpdump", b]       # (the queue keeps hypotheses, not tables)
     with open(log, "w") as lf:
-        p = subprocess.run([os.path.join(REF, exe)] + args + ["-hyp", m, "-hypseg", s, "-bpdump", b], stdout=lf,
+        p = subprocess.run([os.path.join(REF, exe)] + args + ["-hyp", m, "-hypseg", s] + dump, stdout=lf,
                            stderr=subprocess.STDOUT, timeout=timeout, env=dict(os.environ, **(env or {})))
     txt = open(log, errors="ignore").read()
     assert p.returncode == 0, f"{exe} failed:\n" + "\n".join(l for l in txt.splitlines() if "FATAL" in l or "ERROR" in l)[-2000:]
-    return open(m).read(), open(s).read(), psfwd_dump.read_bpdump(b), txt
+    return open(m).read(), open(s).read(), psfwd_dump.read_bpdump(b) if dump else None, txt
 
 
 def assert_same(a, b, tables=True):

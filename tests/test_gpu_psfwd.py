@@ -52,6 +52,17 @@ def test_whole_utterances_keep_decoder_state(tmp_path):
     P.assert_same(r, a)
 
 
+@pytest.mark.parametrize("lanes", [1, 4, 31])
+def test_whole_utterances_from_a_queue(tmp_path, lanes):
+    """s3a_psfwd_decode_queue: 31 utterances through 1 / 4 / 31 persistent lanes, a lane taking the next utterance when
+    its own has ended (light reset in between): every result is a new decoder's, whatever lane decoded it"""
+    args = P.cont_args(tmp_path) + P.FIRST_PASS_ONLY + ["-fresh", "yes"]
+    r = P.run("ref_ps_fwd", args, tmp_path, "ref")
+    a = P.run("ref_ps_amdfwd", args + ["-batch", str(lanes), "-queue", "yes"], tmp_path, "amd")
+    assert "[queue]" in a[3] or lanes == 31
+    assert a[0] == r[0] and a[1] == r[1]
+
+
 def test_goforward_raw(tmp_path):
     r, a = pair(P.turtle_args(tmp_path, ("goforward", "numbers", "something")) + P.FIRST_PASS_ONLY, tmp_path)
     P.assert_same(r, a)
