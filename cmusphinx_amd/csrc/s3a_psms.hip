@@ -254,6 +254,96 @@ k_ps_senone_slots(int32_t n_sen, int32_t n_mgau, int32_t n_feat, int32_t nd, int
     out[(size_t)q * n_sen + s] = (int16_t)min(max(tot, -32768), 32767);
 }
 
+/*
+ * Continuous models (-senmgau .cont.: senone s has codebook s, one stream): distances, top-N and the senone's score in
+ * ONE kernel -- the top-N lists never leave the workgroup (the two-kernel path writes and re-reads 8 bytes per
+ * (slot, codebook, rank): 196 KB per frame of a 6144 x 8 model, more than the model itself).  A tile is PS_CT frames: the
+ * Gaussians' parameters are read once per PS_CT frames (PS_CT = 32: the 15.7 MB model once per 0.32 s of audio).
+ * Arithmetic as k_ps_dist_slots + k_ps_senone_slots, value for value.  (Measured round 4: feeding the frames' components
+ * through scalar loads instead of LDS broadcasts is slower, 109 vs 96 ms per 290 k frames.)
+ */
+#define PS_CT 32
+#define PS_CH 8         /* frames ranked and scored at a time */
+__global__ void __launch_bounds__(PSB)
+k_ps_cont_slots(int32_t n_sen, int32_t nd, int32_t P, int32_t veclen, int32_t topn, int32_t aw,
+                const float *__restrict__ meanT, const float *__restrict__ precT, const float *__restrict__ det,
+                const int32_t *__restrict__ pdf, LogAddShifted la, const float *__restrict__ feat,
+                const int32_t *__restrict__ slot_row, int32_t n_slots, int16_t *out)
+{
+    extern __shared__ ps_f4 x_s4[];         /* [veclen][PS_CT] */
+    float *x_s = (float *)x_s4;
+    __shared__ float dv[PS_CH][PSB];
+    __shared__ float topv[PS_CH][PSB / 2][4];       /* (P >= 2: at most PSB / 2 codebooks per block; top-N <= 4) */
+    __shared__ int32_t topi[PS_CH][PSB / 2][4];
+    __shared__ int32_t s_row[PS_CT];
+    const int32_t q0 = blockIdx.y * PS_CT;
+    if (threadIdx.x < PS_CT) s_row[threadIdx.x] = (q0 + (int32_t)threadIdx.x < n_slots) ? slot_row[q0 + threadIdx.x] : -1;
+    __syncthreads();
+    for (int32_t i = threadIdx.x; i < PS_CT * veclen; i += PSB) {
+        const int32_t t = i / veclen, k = i - t * veclen, row = s_row[t];
+        x_s[k * PS_CT + t] = row >= 0 ? feat[(size_t)row * veclen + k] : 0.0f;
+    }
+    __syncthreads();
+    const int32_t CB = PSB / P, item = blockIdx.x * PSB + threadIdx.x, m = item / P, d = item % P, cbl = threadIdx.x / P;
+    const bool live = m < n_sen && d < nd;
+    ps_f2 acc[PS_CT / 2];
+    {
+        const float dt = live ? det[(size_t)m * P + d] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < PS_CT / 2; t++) acc[t] = (ps_f2)(dt, dt);
+    }
+    if (live) {
+        const size_t base = (size_t)m * veclen * P;
+        for (int32_t i = 0; i < veclen; i++) {
+            const float mu = meanT[base + (size_t)i * P + d], pr = precT[base + (size_t)i * P + d];
+            const ps_f2 mu2 = (ps_f2)(mu, mu), pr2 = (ps_f2)(pr, pr);
+#pragma unroll
+            for (int g = 0; g < PS_CT / 4; g++) {
+                const ps_f4 xv = x_s4[i * (PS_CT / 4) + g];
+                ps_f2 df = xv.xy - mu2, sq = df * df, tt = sq * pr2;
+                acc[2 * g] = acc[2 * g] - tt;
+                df = xv.zw - mu2; sq = df * df; tt = sq * pr2;
+                acc[2 * g + 1] = acc[2 * g + 1] - tt;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < PS_CT / PS_CH; c++) {
+#pragma unroll
+        for (int t = 0; t < PS_CH / 2; t++) { dv[2 * t][threadIdx.x] = acc[c * (PS_CH / 2) + t].x; dv[2 * t + 1][threadIdx.x] = acc[c * (PS_CH / 2) + t].y; }
+        __syncthreads();
+        if (live) {
+            for (int t = 0; t < PS_CH; t++) {
+                const float dval = dv[t][threadIdx.x];
+                int32_t rank = d;
+                if (topn < nd) {
+                    const float *mine = &dv[t][threadIdx.x - d];
+                    rank = 0;
+                    for (int32_t k = 0; k < nd; k++) {
+                        const float o = mine[k];
+                        rank += (o > dval || (o == dval && k > d)) ? 1 : 0;
+                    }
+                }
+                if (rank < topn) { topv[t][cbl][rank] = dval; topi[t][cbl][rank] = d; }
+            }
+        }
+        __syncthreads();
+        /* the senone's score: one (codebook, frame) per thread */
+        for (int32_t pr_ = threadIdx.x; pr_ < CB * PS_CH; pr_ += PSB) {
+            const int32_t t = pr_ / CB, cb = pr_ - t * CB, sm = blockIdx.x * CB + cb, row = s_row[c * PS_CH + t];
+            if (sm >= n_sen || row < 0) continue;
+            const int32_t *pw = pdf + (size_t)sm * nd;
+            int32_t fscr = (((int32_t)topv[t][cb][0] + ((1 << PS_SHIFT) - 1)) >> PS_SHIFT) - pw[topi[t][cb][0]];
+            for (int32_t r = 1; r < topn; r++)
+                fscr = la(fscr, (((int32_t)topv[t][cb][r] + ((1 << PS_SHIFT) - 1)) >> PS_SHIFT) - pw[topi[t][cb][r]]);
+            int32_t tot = -fscr;
+            tot /= aw;
+            out[(size_t)(q0 + c * PS_CH + t) * n_sen + sm] = (int16_t)min(max(tot, -32768), 32767);
+        }
+        __syncthreads();
+    }
+}
+
 /* internal (s3a_internal.h): feat_dev [rows][veclen], slot_row_dev [n_slots], raw_dev [n_slots][n_sen], on `stream` */
 extern "C" int32_t
 s3a_ps_score_slots_dev(s3a_ps_mgau_t *ps, const float *feat_dev, const int32_t *slot_row_dev, int32_t n_slots,
@@ -279,6 +369,13 @@ s3a_ps_score_slots_dev(s3a_ps_mgau_t *ps, const float *feat_dev, const int32_t *
     }
     LogAddShifted la = { dv->tab, dv->tab_size, dv->lm_zero };
     const int64_t items = (int64_t)M * F * P;
+    if (ps->one_to_one && F == 1 && P >= 2 && ps->topn <= 4 && ps->topn <= nd && M == S && (size_t)PS_CT * ps->veclen * 4 <= 32 * 1024) {
+        hipLaunchKernelGGL(k_ps_cont_slots, dim3((uint32_t)((items + PSB - 1) / PSB), (n_slots + PS_CT - 1) / PS_CT), dim3(PSB),
+                           (size_t)PS_CT * ps->veclen * 4 + 16, st, S, nd, P, ps->veclen, ps->topn, ps->aw, dv->meanT, dv->precT, dv->det,
+                           dv->pdf, la, feat_dev, slot_row_dev, n_slots, raw_dev);
+        HIPCHK(hipGetLastError());
+        return S3A_OK;
+    }
     for (int32_t s0 = 0; s0 < n_slots; s0 += tile) {
         const int32_t n = n_slots - s0 < tile ? n_slots - s0 : tile;
         hipLaunchKernelGGL(k_ps_dist_slots, dim3((uint32_t)((items + PSB - 1) / PSB), (n + PS_FT - 1) / PS_FT), dim3(PSB),
