@@ -325,17 +325,17 @@ PSREF = os.path.join(ROOT, "oracle", "_ref", "ref_ps_fwd")
 PSAMD = os.path.join(ROOT, "oracle", "_ref", "ref_ps_amdfwd")
 
 
-def ps_fwdtree_leg(d, lanes, n_frames, n_cpu=4):
-    """pocketsphinx's first pass on the device, measured: the hub4-SHAPED task (same generator, phone names
-    in the order pocketsphinx's mdef reader insists on) decoded by ref_ps_amdfwd -batch <lanes> (integration/pocketsphinx/
-    ps_search_amd.c: features by the decoder's feat_t, then s3a_psfwd_decode = scoring + search of every frame of every
-    lane on the device, hypotheses made on the device), `lanes` utterances as ONE batch; the unmodified pocketsphinx
-    (ref_ps_fwd, one host core) decodes the first n_cpu of them for the comparison and the CPU rate."""
+def ps_fwdtree_leg(t, lanes, n_cpu=4):
+    """pocketsphinx's first pass on the device, measured on configs[3]'s OWN batch: the task directory t (the
+    1024 utterances the main line decodes; its phone names are in the order pocketsphinx's mdef reader insists on) decoded by
+    ref_ps_amdfwd -batch <lanes> -queue yes (integration/pocketsphinx/ps_search_amd.c: features by the decoder's feat_t, then
+    s3a_psfwd_decode_queue = every senone score of the batch, then ONE launch in which `lanes` persistent workgroups take
+    utterance after utterance; hypotheses made on the device); the unmodified pocketsphinx (ref_ps_fwd, one host core)
+    decodes the first n_cpu of them for the comparison and the CPU rate."""
     from cmusphinx_amd import synth_task
     if not (os.path.exists(PSREF) and os.path.exists(PSAMD)):
         return None
-    t = os.path.join(d, "pstask")
-    synth_task.make_task(t, n_utt=lanes, n_frames=n_frames, sorted_names=True, **synth_task.HUB4_TASK)
+    d = t
     args = synth_task.ps_decoder_args(t)
     out = {}
 
@@ -354,23 +354,24 @@ def ps_fwdtree_leg(d, lanes, n_frames, n_cpu=4):
     if rc != 0:
         return {"error": "the unmodified pocketsphinx failed on the task"}
     cpu = re.search(r"decoded (\d+) frames in ([0-9.]+) s", rlog)
-    rc, am, asg, alog = run(PSAMD, ["-fresh", "yes", "-batch", str(lanes)], "amd")
+    rc, am, asg, alog = run(PSAMD, ["-fresh", "yes", "-batch", str(lanes), "-queue", "yes"], "amd")
     if rc != 0:
         return {"error": "ref_ps_amdfwd failed: " + " | ".join(l for l in alog.splitlines() if "ERROR" in l or "FATAL" in l)[-300:]}
     dev = re.search(r"batch of (\d+) utterances, (\d+) frames: ([0-9.]+) ms on the device", alog)
     same_h = "".join(am.splitlines(keepends=True)[:n_cpu]) == rm
     same_s = "".join(asg.splitlines(keepends=True)[:n_cpu]) == rs
     tree = re.search(r"(\d+) roots, (\d+) interior channels, (\d+) single-phone words", alog)
-    out = {"workload": f"hub4-shaped CD-GMM 6144 x 8 x 39, 20 k-word dictionary, ARPA trigram, pocketsphinx's default beams; {lanes} "
-                       f"utterances of ~{n_frames} frames as ONE batch of lanes (one workgroup per utterance), first pass only",
-           "lanes": int(dev.group(1)), "frames": int(dev.group(2)), "device_ms": float(dev.group(3)),
+    out = {"workload": f"configs[3]'s batch through pocketsphinx: hub4-shaped CD-GMM 6144 x 8 x 39, 20 k-word dictionary, ARPA trigram, "
+                       f"pocketsphinx's default beams, first pass only; {dev.group(1)} utterances as ONE queue over {lanes} lanes "
+                       f"(one persistent workgroup per lane)",
+           "lanes": lanes, "utterances": int(dev.group(1)), "frames": int(dev.group(2)), "device_ms": float(dev.group(3)),
            "frames_per_sec": round(int(dev.group(2)) / (float(dev.group(3)) * 1e-3), 1),
            "xRT": round(int(dev.group(2)) / (float(dev.group(3)) * 1e-3) / 100.0, 1),
            "identical_to_pocketsphinx": {"hyp_and_score": same_h, "segmentation": same_s, "utterances_checked": n_cpu},
            "search_space": {"roots": int(tree.group(1)), "interior_channels": int(tree.group(2)), "single_phone_words": int(tree.group(3))} if tree else None,
            "cpu_pocketsphinx": {"frames": int(cpu.group(1)), "seconds": float(cpu.group(2)), "frames_per_sec": round(int(cpu.group(1)) / max(float(cpu.group(2)), 1e-9), 1),
                                 "cores": 1, "kind": "reference"} if cpu else None,
-           "timed": "HIP events on the engine's stream around the windows' scoring + search launches of the whole batch (features resident)"}
+           "timed": "HIP events on the engine's stream around the batch's scoring launch + the search launch (features resident in HBM)"}
     assert same_h and same_s, "pocketsphinx first pass on the device differs from the unmodified pocketsphinx"
     return out
 
@@ -395,6 +396,7 @@ def main():
     ap.add_argument("--check-all", action="store_true", help="the reference decodes the WHOLE batch (~3 more minutes of CPU): every utterance is compared")
     ap.add_argument("--cpu-physical", action="store_true", help="add the CPU leg with one process per physical core (~2 minutes)")
     ap.add_argument("--no-scoring", action="store_true", help="skip the scoring-only extra legs")
+    ap.add_argument("--plain", action="store_true", help="the timed steps and the in-bench kernel timing only (no single-engine profile, no 8-GPU projection, no extra legs): the command rocprofv3 wraps for profiles/, so that its per-kernel averages are those of the bench's own regime")
     ap.add_argument("--no-ps", action="store_true", help="skip the pocketsphinx first-pass leg")
     ap.add_argument("--no-wide-beam", action="store_true", help="skip the configs[4] wide-beam leg")
     ap.add_argument("--wide-lanes", type=int, default=64, help="lanes of the wide-beam leg's engine")
@@ -403,6 +405,8 @@ def main():
     ap.add_argument("--only-scoring", action="store_true", help="only the scoring legs (PMC passes over the scoring kernels)")
     ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
     args = ap.parse_args()
+    if args.plain:
+        args.no_cpu = args.no_scoring = args.no_ps = args.no_wide_beam = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -444,7 +448,7 @@ def main():
         os.makedirs(d, exist_ok=True)
         if os.path.exists(os.path.join(d, "rccl-id")):
             os.remove(os.path.join(d, "rccl-id"))
-        synth_task.make_task(d, n_utt=U, n_frames=T, **synth_task.HUB4_TASK)
+        synth_task.make_task(d, n_utt=U, n_frames=T, sorted_names=True, **synth_task.HUB4_TASK)
         r = subprocess.run([SHIM] + synth_task.decoder_args(d), env=dict(os.environ, S3A_UTT="1", S3A_EXPORT=bpath),
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         assert r.returncode == 0 and os.path.exists(bpath), "bundle export failed"
@@ -655,10 +659,12 @@ def main():
         # kernels stretch when four engines share the chip, and the line's `roofline` describes the run it times.
         sched = schedule(my_share(0)[0])
         g0 = sched[0][0][:NLE]
-        dec.ud.set_profile(4)
-        dec.ud.decode_dev([fdev[k] for k in g0], [nfr[k] for k in g0], D4x4)
-        prof_alone = dec.ud.profile()
-        dec.ud.set_profile(0)
+        prof_alone = {}
+        if not args.plain:
+            dec.ud.set_profile(4)
+            dec.ud.decode_dev([fdev[k] for k in g0], [nfr[k] for k in g0], D4x4)
+            prof_alone = dec.ud.profile()
+            dec.ud.set_profile(0)
         nl0 = len(g0)
         stat = [dec.ud.result(z)["frame_stat"] for z in range(nl0)]
         res0 = dec.ud.result(0)
@@ -770,7 +776,7 @@ def main():
 
         # ---- what N = 8 gives a GPU: 128 of the 1024 utterances ----
         proj = None
-        if world == 1 and U >= 8:
+        if world == 1 and U >= 8 and not args.plain:
             ids8 = shard.shard_contiguous(U, 0, 8)
             sch8 = schedule(ids8)
             run_step(0, sched=sch8)
@@ -825,7 +831,7 @@ def main():
         if world == 1 and not args.no_scoring:
             res["scoring"] = scoring_legs(lib, args.fast)
         if world == 1 and not args.no_ps:
-            res["ps_fwdtree"] = ps_fwdtree_leg(d, args.ps_lanes, T)
+            res["ps_fwdtree"] = ps_fwdtree_leg(d, args.ps_lanes)
         if world == 1 and not args.no_wide_beam:
             res["wide_beam"] = wide_beam_leg(lib, d, args.wide_lanes, args.wide_frames, args.fast)
         print(json.dumps(res))
