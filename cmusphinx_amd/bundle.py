@@ -128,6 +128,9 @@ class Decoder:
     def queue_hyp(self, utt, uttid="", utt_index=0):
         return self.ud.queue_hyp(utt, uttid, utt_index)
 
+    def queue_bestpath_hyp(self, utt, uttid="", utt_index=0):
+        return self.ud.queue_bestpath_hyp(utt, uttid, utt_index)
+
     def hyp(self, lane, uttid="", utt_index=0):
         return self.ud.hyp(lane, uttid, utt_index)
 

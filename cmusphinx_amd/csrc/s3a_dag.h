@@ -58,6 +58,11 @@ int32_t s3a_dagpass_bind(s3a_dagpass_t *dp, int32_t lane, const DagTab &tab);
 int32_t s3a_dagpass_enqueue(s3a_dagpass_t *dp, int32_t n, hipStream_t stream, int32_t do_utt_end);
 int32_t s3a_dagpass_fetch(s3a_dagpass_t *dp, int32_t n, hipStream_t stream);
 int32_t s3a_dagpass_finish(s3a_dagpass_t *dp, int32_t n, hipStream_t stream);     /* fetch + utterance order */
+/* inside a queue with lane refill: descriptors up once, then the pass for the lanes of a refill event (ids on the device) */
+int32_t s3a_dagpass_prepare(s3a_dagpass_t *dp, hipStream_t stream);
+int32_t s3a_dagpass_enqueue_lanes(s3a_dagpass_t *dp, const int32_t *lane_ids_dev, int32_t n, hipStream_t stream);
+const DagLane *s3a_dagpass_dev_lanes(const s3a_dagpass_t *dp);
+int32_t s3a_dagpass_hyp_cap(const s3a_dagpass_t *dp);
 
 
 #endif

@@ -168,15 +168,16 @@ d_dag_utt_end(const DagShared &G, const DagLane &L, const WLm &lm)
 }
 
 __global__ void __launch_bounds__(DG_T)
-k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_utt_end, int32_t use_active)
+k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_utt_end, int32_t use_active, const int32_t *__restrict__ lane_ids)
 {
-    const DagLane &L = lanes[blockIdx.x];
+    /* (lane_ids: the lanes that have ended at a refill event of a queue; NULL: lane = workgroup) */
+    const DagLane &L = lanes[lane_ids ? lane_ids[blockIdx.x] : (int32_t)blockIdx.x];
     const int32_t tid = threadIdx.x;
     __shared__ int32_t s_err, s_cnt, s_any, s_lmop;
     __shared__ unsigned long long s_max;
     if (use_active && !L.io[DG_IO_ACTIVE]) return;
     if (tid == 0) { s_err = 0; s_lmop = 0; }
-    if (tid == 0) { L.io[DG_IO_STATUS] = 0; L.io[DG_IO_NWORDS] = 0; }
+    if (tid == 0) { L.io[DG_IO_STATUS] = 0; L.io[DG_IO_NWORDS] = 0; L.io[DG_IO_NNODE] = 0; L.io[DG_IO_NLINK] = 0; }
     __syncthreads();
     if (do_utt_end) d_dag_utt_end(G, L, lm);
     const int32_t E = L.io[DG_IO_NENT], endid = L.io[DG_IO_ENDID], n_frm = L.tab.st[1], n_hyp = L.io[DG_IO_NHYP];
@@ -574,9 +575,9 @@ k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_ut
 /* host side                                                           */
 /* ------------------------------------------------------------------ */
 __global__ void
-k_dag_reset(DagShared G, const DagLane *__restrict__ lanes, int32_t use_active)
+k_dag_reset(DagShared G, const DagLane *__restrict__ lanes, int32_t use_active, const int32_t *__restrict__ lane_ids)
 {
-    const DagLane &L = lanes[blockIdx.y];
+    const DagLane &L = lanes[lane_ids ? lane_ids[blockIdx.y] : (int32_t)blockIdx.y];
     if (use_active && !L.io[DG_IO_ACTIVE]) return;
     const int32_t stride = gridDim.x * blockDim.x;
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= G.h1mask; i += stride) {
@@ -717,12 +718,41 @@ s3a_dagpass_enqueue(s3a_dagpass_t *dp, int32_t n, hipStream_t st, int32_t do_utt
         HIPCHK(hipStreamSynchronize(st));       /* (the source vector may change after this call) */
         dp->lanes_dirty = false;
     }
-    hipLaunchKernelGGL(k_dag_reset, dim3(64, n), dim3(256), 0, st, dp->G, dp->d_lanes, do_utt_end ? 0 : 1);
-    hipLaunchKernelGGL(k_dag_pass, dim3(n), dim3(DG_T), 0, st, dp->G, dp->d_lanes, dp->lm->d, do_utt_end, do_utt_end ? 0 : 1);
+    hipLaunchKernelGGL(k_dag_reset, dim3(64, n), dim3(256), 0, st, dp->G, dp->d_lanes, do_utt_end ? 0 : 1, (const int32_t *)NULL);
+    hipLaunchKernelGGL(k_dag_pass, dim3(n), dim3(DG_T), 0, st, dp->G, dp->d_lanes, dp->lm->d, do_utt_end, do_utt_end ? 0 : 1, (const int32_t *)NULL);
     HIPCHK(hipGetLastError());
     dp->n_run = n;
     return S3A_OK;
 }
+
+/* a queue with lane refill (s3a_uttdec_decode_queue): the lane descriptors go up once before the first frame ... */
+int32_t
+s3a_dagpass_prepare(s3a_dagpass_t *dp, hipStream_t st)
+{
+    if (!dp) return S3A_EINVAL;
+    if (dp->lanes_dirty) {
+        HIPCHK(hipMemcpyAsync(dp->d_lanes, dp->lane.data(), sizeof(DagLane) * dp->n_lanes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        dp->lanes_dirty = false;
+    }
+    dp->n_run = 0;
+    return S3A_OK;
+}
+
+/* ... and at a refill event the pass (vithist_utt_end included) runs for the n lanes listed in lane_ids_dev, behind their last
+ * frame and before their tables are reused; nothing is fetched: the caller's kernel copies what it wants out of the lanes */
+int32_t
+s3a_dagpass_enqueue_lanes(s3a_dagpass_t *dp, const int32_t *lane_ids_dev, int32_t n, hipStream_t st)
+{
+    if (!dp || !lane_ids_dev || n <= 0 || n > dp->n_lanes || dp->lanes_dirty) return S3A_EINVAL;
+    hipLaunchKernelGGL(k_dag_reset, dim3(64, n), dim3(256), 0, st, dp->G, dp->d_lanes, 0, lane_ids_dev);
+    hipLaunchKernelGGL(k_dag_pass, dim3(n), dim3(DG_T), 0, st, dp->G, dp->d_lanes, dp->lm->d, 1, 0, lane_ids_dev);
+    HIPCHK(hipGetLastError());
+    return S3A_OK;
+}
+
+const DagLane *s3a_dagpass_dev_lanes(const s3a_dagpass_t *dp) { return dp ? dp->d_lanes : NULL; }
+int32_t s3a_dagpass_hyp_cap(const s3a_dagpass_t *dp) { return dp ? dp->G.hyp_cap : 0; }
 
 int32_t
 s3a_dagpass_fetch(s3a_dagpass_t *dp, int32_t n, hipStream_t st)
@@ -771,6 +801,89 @@ s3a_dagpass_finish(s3a_dagpass_t *dp, int32_t n, hipStream_t st)
     const int32_t rc = s3a_dagpass_fetch(dp, n, st);
     if (rc != S3A_OK) return rc;
     dag_reverse_out(dp, n);
+    return S3A_OK;
+}
+
+/*
+ * The lattice the pass built for `lane` as vithist_dag_build (vithist.c:1100-1311) leaves it, in the orders of the
+ * reference's lists -- what dag_write / dag_write_htk (dag.c:731-897) print and what a dag_t can be rebuilt from:
+ *   nodes  in dag->list order (the LAST node made comes first: alloc_next is a head insertion, :1249-1251) = NODEID order
+ *          of the Sphinx-3 file;
+ *   links  grouped by source node in that order and, per source, in succlist order: dag_link (dag.c:186-238) prepends, the
+ *          links of a node are made exit by exit (the hook list: latest end frame first) and per exit over the kept nodes
+ *          of the next frame in sfwid order, so the list reads end frames ascending and, per end frame, the frame's nodes in
+ *          reverse list order.  An exit with a positive acoustic score makes no link (dag_link refuses, :193-195).
+ * The predecessor list of a node is its incoming links by source id ASCENDING in this numbering (all made in source order).
+ * Available after any pass that got as far as the link count (status 0, DG_E_NOPATH, DG_E_POSEDGE, DG_E_CAP from links /
+ * bypass); host side: three small copies + loops.  nodes == NULL or links == NULL: sizes only.
+ */
+extern "C" int32_t
+s3a_dagpass_lattice(s3a_dagpass_t *dp, int32_t lane, s3a_lat_info_t *info, s3a_lat_node_t *nodes, int32_t node_cap,
+                    s3a_lat_link_t *links, int32_t link_cap)
+{
+    if (!dp || !info || lane < 0 || lane >= dp->n_run) return S3A_EINVAL;
+    HIPCHK(hipSetDevice(dp->device));
+    const DagLane &L = dp->lane[lane];
+    int32_t io[DG_IO_N], st2[2];
+    HIPCHK(hipMemcpy(io, L.io, sizeof io, hipMemcpyDeviceToHost));
+    memset(info, 0, sizeof *info);
+    info->status = io[DG_IO_STATUS];
+    const int32_t NK = io[DG_IO_NNODE], E = io[DG_IO_NENT], endid = io[DG_IO_ENDID];
+    if (NK <= 0 || E <= 0 || endid < 0) { s3a_set_error("s3a_dagpass_lattice: lane %d has no lattice (pass status %d)", lane, io[DG_IO_STATUS]); return S3A_EUNSUP; }
+    HIPCHK(hipMemcpy(st2, L.tab.st, 8, hipMemcpyDeviceToHost));
+    const int32_t n_frm = st2[1], F1 = n_frm + 1;
+    std::vector<int32_t> kcnt(F1 + 1), kbase(F1 + 1), nbase(F1 + 1), knode(NK);
+    HIPCHK(hipMemcpy(kcnt.data(), L.kcnt, (size_t)F1 * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(kbase.data(), L.kbase, (size_t)(F1 + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nbase.data(), L.nbase, (size_t)(F1 + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(knode.data(), L.knode, (size_t)NK * 4, hipMemcpyDeviceToHost));
+    const int32_t NN = nbase[F1];
+    if (NN <= 0 || NN > dp->G.E_cap || kbase[F1] != NK) { s3a_set_error("s3a_dagpass_lattice: inconsistent node counts"); return S3A_EUNSUP; }
+    std::vector<int32_t> nfirst(NN), nsf(NN), nfef(NN), nlef(NN), nhk(NN), hkbase(NN), nkpos(NN), hkent(E), efp(E), eapos(E), enode(E),
+        wid(E), ascr(E), lscr(E);
+#define GET(v, src, n) HIPCHK(hipMemcpy((v).data(), (src), (size_t)(n) * 4, hipMemcpyDeviceToHost))
+    GET(nfirst, L.nfirst, NN); GET(nsf, L.nsf, NN); GET(nfef, L.nfef, NN); GET(nlef, L.nlef, NN); GET(nhk, L.nhk, NN); GET(hkbase, L.hkbase, NN);
+    GET(nkpos, L.nkpos, NN); GET(hkent, L.hkent, E); GET(efp, L.efp, E); GET(eapos, L.eapos, E); GET(enode, L.enode, E);
+    GET(wid, L.tab.wid, E); GET(ascr, L.tab.ascr, E); GET(lscr, L.tab.lscr, E);
+#undef GET
+    auto file_id = [&](int32_t k) { return NK - 1 - k; };            /* k = rank among the kept nodes in (start frame, list) order */
+    auto rank_of = [&](int32_t p) { return kbase[nsf[p]] + nkpos[p]; };
+    /* the links, counted first */
+    long long n_links = 0;
+    for (int32_t k = NK - 1; k >= 0; k--) {
+        const int32_t p = knode[k];
+        for (int32_t h = 0; h < nhk[p]; h++) { const int32_t ie = hkent[hkbase[p] + h]; if (eapos[ie] >= 0) n_links += kcnt[efp[ie] + 1]; }
+    }
+    const int32_t endn = enode[endid], rootn = knode[0];
+    info->n_frames = n_frm; info->n_nodes = NK; info->n_links = (int32_t)n_links;
+    info->initial = file_id(rank_of(rootn)); info->final = file_id(rank_of(endn)); info->final_ascr = 0;
+    for (int32_t h = 0; h < nhk[endn]; h++) { const int32_t ie = hkent[hkbase[endn] + h]; if (efp[ie] == n_frm) info->final_ascr = ascr[ie]; }
+    if (!nodes || !links) return S3A_OK;
+    if (node_cap < NK || link_cap < n_links) { s3a_set_error("s3a_dagpass_lattice: %d nodes / %lld links exceed the caller's arrays", NK, n_links); return S3A_ENOMEM; }
+    for (int32_t k = NK - 1; k >= 0; k--) {
+        const int32_t p = knode[k], i0 = nfirst[p];
+        s3a_lat_node_t &n = nodes[file_id(k)];
+        n.wid = wid[i0]; n.sf = nsf[p]; n.fef = nfef[p]; n.lef = nlef[p]; n.ascr = ascr[i0]; n.lscr = lscr[i0];
+    }
+    int32_t q = 0;
+    std::vector<int32_t> ex;
+    for (int32_t k = NK - 1; k >= 0; k--) {
+        const int32_t p = knode[k];
+        ex.clear();
+        for (int32_t h = 0; h < nhk[p]; h++) { const int32_t ie = hkent[hkbase[p] + h]; if (eapos[ie] >= 0) ex.push_back(ie); }
+        for (size_t a = 1; a < ex.size(); a++) {                   /* by end frame, ascending (a node has one exit per end frame) */
+            const int32_t x = ex[a]; size_t b = a;
+            while (b > 0 && efp[ex[b - 1]] > efp[x]) { ex[b] = ex[b - 1]; b--; }
+            ex[b] = x;
+        }
+        for (int32_t ie : ex) {
+            const int32_t f2 = efp[ie] + 1;
+            for (int32_t yy = kcnt[f2] - 1; yy >= 0; yy--) {
+                s3a_lat_link_t &l = links[q++];
+                l.from = file_id(k); l.to = file_id(kbase[f2] + yy); l.ascr = ascr[ie]; l.lscr = lscr[ie]; l.ef = f2 - 1;
+            }
+        }
+    }
     return S3A_OK;
 }
 

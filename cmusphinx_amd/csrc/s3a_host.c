@@ -1312,3 +1312,85 @@ s3a_senlog_close(s3a_senlog_t *s)
     if (s->fp) fclose(s->fp);
     free(s);
 }
+
+/* ------------------------------------------------------------------ */
+/* lattice files from the device's lattice (dag_write, dag_write_htk: sphinx3 libsearch/dag.c:731-897) */
+/* ------------------------------------------------------------------ */
+typedef struct { char *buf; int64_t cap, len; } lat_out_t;
+static void
+lat_put(lat_out_t *o, const char *fmt, ...)
+{
+    va_list ap;
+    int n;
+    char tmp[1];
+    const int64_t room = o->cap > o->len ? o->cap - o->len : 0;
+    va_start(ap, fmt);
+    n = vsnprintf(room > 0 ? o->buf + o->len : tmp, room > 0 ? (size_t)room : 0, fmt, ap);
+    va_end(ap);
+    if (n > 0) o->len += n;
+}
+
+int64_t
+s3a_lattice_format_s3(const char *header, const s3a_lat_info_t *info, const s3a_lat_node_t *nodes,
+                      const s3a_lat_link_t *links, const char *const *wordstr, char *buf, int64_t cap)
+{
+    lat_out_t o;
+    int32_t i;
+    if (!info || !nodes || (!links && info->n_links > 0) || !wordstr || cap < 0 || (cap > 0 && !buf)) { s3a_set_error("s3a_lattice_format_s3: bad arguments"); return S3A_EINVAL; }
+    o.buf = buf; o.cap = cap; o.len = 0;
+    if (header) lat_put(&o, "%s", header);
+    lat_put(&o, "Frames %d\n#\n", info->n_frames);
+    lat_put(&o, "Nodes %d (NODEID WORD STARTFRAME FIRST-ENDFRAME LAST-ENDFRAME)\n", info->n_nodes);
+    for (i = 0; i < info->n_nodes; i++)
+        lat_put(&o, "%d %s %d %d %d\n", i, wordstr[nodes[i].wid], nodes[i].sf, nodes[i].fef, nodes[i].lef);
+    lat_put(&o, "#\nInitial %d\nFinal %d\n", info->initial, info->final);
+    lat_put(&o, "BestSegAscr 0 (NODEID ENDFRAME ASCORE)\n#\n");
+    lat_put(&o, "Edges (FROM-NODEID TO-NODEID ASCORE)\n");
+    for (i = 0; i < info->n_links; i++) lat_put(&o, "%d %d %d\n", links[i].from, links[i].to, links[i].ascr);
+    lat_put(&o, "End\n");
+    return o.len;
+}
+
+int64_t
+s3a_lattice_format_htk(const char *header, const s3a_htk_opts_t *h, const s3a_lat_info_t *info, const s3a_lat_node_t *nodes,
+                       const s3a_lat_link_t *links, const char *const *wordstr, char *buf, int64_t cap)
+{
+    lat_out_t o;
+    int32_t i, j, *first = NULL, *order = NULL;
+    float fps;
+    if (!h || !info || !nodes || (!links && info->n_links > 0) || !wordstr || !h->basewid || !h->n_alt || cap < 0 || (cap > 0 && !buf)) {
+        s3a_set_error("s3a_lattice_format_htk: bad arguments");
+        return S3A_EINVAL;
+    }
+    o.buf = buf; o.cap = cap; o.len = 0;
+    lat_put(&o, "# Lattice generated by Sphinx-III\n");
+    if (header) lat_put(&o, "%s", header);
+    lat_put(&o, "VERSION=1.0\nUTTERANCE=%s\n", h->uttid ? h->uttid : "");
+    if (h->have_lm) {
+        if (h->lmname) lat_put(&o, "lmname=%s\n", h->lmname);
+        lat_put(&o, "lmscale=%f\n", h->opt_lw);
+        lat_put(&o, "wdpenalty=%f\n", h->opt_wip);
+    }
+    lat_put(&o, "N=%d\tL=%d\n", info->n_nodes + 1, info->n_links + 1);
+    fps = h->frate > 0 ? (float)h->frate : 100.0f;
+    lat_put(&o, "I=%-5d t=%-10.2f\n", 0, (float)info->n_frames / fps);
+    for (i = 0; i < info->n_nodes; i++) lat_put(&o, "I=%-5d t=%-10.2f\n", i + 1, (float)nodes[i].sf / fps);
+    lat_put(&o, "J=%-10d S=%-5d E=%-5d W=%-20s a=%-10.2f v=%-5d l=%-10.2f\n", 0, info->final + 1, 0, wordstr[nodes[info->final].wid], 0.0, 1, 0.0);
+    /* a node's predlist = its incoming links by source id ascending: a stable counting sort of the links by destination */
+    first = (int32_t *)calloc((size_t)info->n_nodes + 2, sizeof(int32_t));
+    order = (int32_t *)malloc(((size_t)info->n_links + 1) * sizeof(int32_t));
+    if (!first || !order) { free(first); free(order); s3a_set_error("s3a_lattice_format_htk: out of memory"); return S3A_ENOMEM; }
+    for (i = 0; i < info->n_links; i++) first[links[i].to + 1]++;
+    for (i = 0; i < info->n_nodes; i++) first[i + 1] += first[i];
+    for (i = 0; i < info->n_links; i++) order[first[links[i].to]++] = i;
+    for (j = 0; j < info->n_links; j++) {
+        const s3a_lat_link_t *l = &links[order[j]];
+        const int32_t b = h->basewid[nodes[l->from].wid];
+        int32_t ls = l->lscr;
+        if (h->have_lm) { ls -= h->lm_wip; ls = (int32_t)((float)ls / h->lm_lw); }      /* lm_rawscore, lm.c:2172-2178 */
+        lat_put(&o, "J=%-10d S=%-5d E=%-5d W=%-20s a=%-10.2f v=%-5d l=%-10.2f\n", j + 1, l->from + 1, l->to + 1, wordstr[b],
+                (double)(l->ascr << h->log_shift) * h->log_of_base, h->n_alt[b], (double)(ls << h->log_shift) * h->log_of_base);
+    }
+    free(first); free(order);
+    return o.len;
+}

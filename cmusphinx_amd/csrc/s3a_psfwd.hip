@@ -34,7 +34,12 @@
 
 #include "s3a_device.h"
 
-#define NT 512
+#ifndef NT
+#define NT 512          /* threads of a lane's workgroup (build parameter: tools/psfwd_variants.sh) */
+#endif
+#ifndef PSF_WPE
+#define PSF_WPE 4       /* minimum waves per SIMD the search kernels are compiled for (caps the VGPRs: 2 lanes per CU need 4 with NT 512) */
+#endif
 #define PS_WORST ((int32_t)0xE0000000)      /* hmm.h:74 */
 #define PS_TMAT_WORST (-255)                /* hmm.h:80 */
 #define PS_BAD_SSID 0xffff
@@ -1161,7 +1166,7 @@ k_psf_finish(PsfModel M, PsfLane *lanes, int32_t lane, int32_t cf)
 }
 
 /* whole utterances: frames [f0, f0 + n_win) of every lane of the batch; a lane's utterance may end inside */
-template <int NE> __global__ void __launch_bounds__(NT)
+template <int NE> __global__ void __launch_bounds__(NT, PSF_WPE)
 k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, int32_t n_win, int compallsen)
 {
     PsfLane L = lanes[lane_ids[blockIdx.x]];
@@ -1203,6 +1208,7 @@ k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, in
 struct PsfQueue {
     int32_t n_utt, seg_cap;
     int32_t *next;                  /* the queue's head */
+    const int32_t *ready;           /* utterances whose scores are complete (the scoring runs beside the search); NULL: all */
     const int32_t *nfr;             /* [n_utt] */
     const long long *row0;          /* [n_utt] first row of the utterance in the score matrix */
     const int16_t *raw;             /* [rows][n_sen] */
@@ -1210,12 +1216,13 @@ struct PsfQueue {
     s3a_psfwd_seg_t *seg;           /* [n_utt][seg_cap] */
 };
 
-template <int NE> __global__ void __launch_bounds__(NT)
+template <int NE> __global__ void __launch_bounds__(NT, PSF_WPE)
 k_psf_queue(PsfModel M, PsfLane *lanes, PsfQueue Q, int compallsen)
 {
     PsfLane L = lanes[blockIdx.x];
     __shared__ FrameShared F;
     __shared__ int32_t s_u;
+    if (Q.ready) __builtin_amdgcn_s_setprio(3);     /* the scoring shares the CU: this lane's few waves go first at instruction issue */
     if (threadIdx.x == 0) F.S = *L.sc;
     __syncthreads();
     for (;;) {
@@ -1224,6 +1231,14 @@ k_psf_queue(PsfModel M, PsfLane *lanes, PsfQueue Q, int compallsen)
         const int32_t u = s_u;
         __syncthreads();
         if (u >= Q.n_utt) break;
+        if (Q.ready) {
+            /* the utterance's scores come from a kernel on another stream: wait for its completion mark (a store behind that
+             * kernel, so everything it wrote is in memory), then drop what this CU may hold of those lines */
+            if (threadIdx.x == 0)
+                while (__hip_atomic_load(Q.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= u) __builtin_amdgcn_s_sleep(32);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
         const int32_t n_total = Q.nfr[u];
         const int16_t *raw0 = Q.raw + (size_t)Q.row0[u] * M.n_sen;
         if (threadIdx.x == 0) F.S.n_total = n_total;
@@ -1256,6 +1271,12 @@ k_psf_queue(PsfModel M, PsfLane *lanes, PsfQueue Q, int compallsen)
     if (threadIdx.x == 0) *L.sc = F.S;
 }
 
+__global__ void
+k_psf_mark_ready(int32_t *ready, int32_t n)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ready, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* ------------------------------------------------------------------ */
 /* host side                                                          */
 /* ------------------------------------------------------------------ */
@@ -1267,8 +1288,9 @@ struct s3a_psfwd_s {
     std::vector<PsfLane> lanes_h;
     PsfLane *lanes_d;
     int32_t *lane_ids_d;
-    hipStream_t stream;
-    hipEvent_t ev0, ev1;
+    hipStream_t stream, stream_sc;          /* the search's stream; the scoring's when it runs beside the search (queue) */
+    hipEvent_t ev0, ev1, ev_sc;
+    int32_t *q_ready_d;
     double last_ms;
     /* host mirrors for s3a_psfwd_table */
     std::vector<int32_t> t_frame, t_wid, t_bp, t_score, t_sidx, t_realwid, t_bss, t_idx;
@@ -1314,6 +1336,9 @@ s3a_psfwd_free(s3a_psfwd_t *e)
     { void *qp[] = { e->q_next_d, e->q_nfr_d, e->q_res_d, e->q_row0_d, e->q_seg_d }; for (void *q : qp) if (q) (void)hipFree(q); }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev_sc) (void)hipEventDestroy(e->ev_sc);
+    if (e->stream_sc) (void)hipStreamDestroy(e->stream_sc);
+    if (e->q_ready_d) (void)hipFree(e->q_ready_d);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1333,7 +1358,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     if (d->n_1ph > NT) { s3a_set_error("s3a_psfwd_init: %d single-phone words exceed the kernel's %d", d->n_1ph, NT); return NULL; }
     if (max_frames > 32767) { s3a_set_error("s3a_psfwd_init: max_frames %d (the reference's frame numbers are int16)", max_frames); return NULL; }
     s3a_psfwd_t *e = new s3a_psfwd_t();
-    e->lanes_d = NULL; e->lane_ids_d = NULL; e->stream = NULL; e->ev0 = e->ev1 = NULL; e->last_ms = 0;
+    e->lanes_d = NULL; e->lane_ids_d = NULL; e->stream = NULL; e->stream_sc = NULL; e->ev0 = e->ev1 = e->ev_sc = NULL; e->q_ready_d = NULL; e->last_ms = 0;
     e->feat_d = NULL; e->feat_cap = 0; e->slot_row_d = NULL; e->slot_cap = 0; e->raw_d = NULL; e->raw_cap = 0; e->win = 0;
     e->q_next_d = e->q_nfr_d = e->q_res_d = NULL; e->q_row0_d = NULL; e->q_seg_d = NULL; e->q_cap = 0; e->q_n = 0; e->q_seg_cap = 256;
     PsfModel &M = e->M;
@@ -1388,6 +1413,8 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     if (M.sil_sp < 0 || M.start_sp < 0) { s3a_set_error("s3a_psfwd_init: <sil> or <s> is not a listed single-phone word"); delete e; return NULL; }
 
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess
+        || hipStreamCreateWithFlags(&e->stream_sc, hipStreamNonBlocking) != hipSuccess
+        || hipEventCreateWithFlags(&e->ev_sc, hipEventDisableTiming) != hipSuccess || hipMalloc((void **)&e->q_ready_d, 4) != hipSuccess
         || hipEventCreate(&e->ev1) != hipSuccess) { s3a_set_error("s3a_psfwd_init: stream / event creation failed"); s3a_psfwd_free(e); return NULL; }
     UP(M.sseq, d->sseq, (size_t)d->n_sseq * NE);
     UP(M.tp, d->tp, (size_t)d->n_tmat * NE * (NE + 1));
@@ -1734,14 +1761,46 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
     HIPCHK(hipMemsetAsync(e->q_res_d, 0xff, (size_t)n_utt * PSF_QRES * 4, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));            /* (rows is a local) */
     HIPCHK(hipEventRecord(e->ev0, e->stream));
-    int32_t rc = s3a_ps_score_slots_dev(scorer, e->feat_d, e->slot_row_d, (int32_t)total, e->raw_d, e->stream);
-    if (rc != S3A_OK) return rc;
+    const int32_t n_wg = n_utt < e->n_lanes ? n_utt : e->n_lanes;
     PsfQueue Q;
     Q.n_utt = n_utt; Q.seg_cap = e->q_seg_cap; Q.next = e->q_next_d; Q.nfr = e->q_nfr_d; Q.row0 = e->q_row0_d; Q.raw = e->raw_d;
-    Q.res = e->q_res_d; Q.seg = e->q_seg_d;
-    const int32_t n_wg = n_utt < e->n_lanes ? n_utt : e->n_lanes;
+    Q.res = e->q_res_d; Q.seg = e->q_seg_d; Q.ready = NULL;
+    int32_t rc;
+    if (n_utt <= n_wg || !s3a_variants()->ps_overlap) {
+        rc = s3a_ps_score_slots_dev(scorer, e->feat_d, e->slot_row_d, (int32_t)total, e->raw_d, e->stream);
+        if (rc != S3A_OK) return rc;
+    }
+    else {
+        /* The scoring is float32 arithmetic that fills the vector units; the search is one workgroup per lane waiting on
+         * dependent memory accesses.  They share the chip: the first utterance of every lane is scored, then the search
+         * starts, and the rest of the queue is scored on a second stream beside it, a group of utterances per launch with a
+         * completion mark behind each (k_psf_mark_ready) that a lane checks before it takes an utterance. */
+        Q.ready = e->q_ready_d;
+        HIPCHK(hipMemsetAsync(e->q_ready_d, 0, 4, e->stream));
+        HIPCHK(hipEventRecord(e->ev_sc, e->stream));
+        HIPCHK(hipStreamWaitEvent(e->stream_sc, e->ev_sc, 0));
+        const int32_t group = n_wg / 4 > 0 ? n_wg / 4 : 1;
+        for (int32_t u0 = 0; u0 < n_utt; ) {
+            const int32_t u1 = u0 == 0 ? n_wg : (u0 + group < n_utt ? u0 + group : n_utt);
+            const long long r0 = row0[u0], r1 = u1 < n_utt ? row0[u1] : (long long)total;
+            if (r1 > r0) {
+                rc = s3a_ps_score_slots_dev(scorer, e->feat_d, e->slot_row_d + r0, (int32_t)(r1 - r0), e->raw_d + (size_t)r0 * M.n_sen, e->stream_sc);
+                if (rc != S3A_OK) { (void)hipStreamSynchronize(e->stream_sc); return rc; }
+            }
+            hipLaunchKernelGGL(k_psf_mark_ready, dim3(1), dim3(64), 0, e->stream_sc, e->q_ready_d, u1);
+            if (u0 == 0) {
+                HIPCHK(hipEventRecord(e->ev_sc, e->stream_sc));
+                HIPCHK(hipStreamWaitEvent(e->stream, e->ev_sc, 0));
+            }
+            u0 = u1;
+        }
+    }
     NE_LAUNCH(k_psf_queue, dim3(n_wg), M, e->lanes_d, Q, compallsen);
     HIPCHK(hipGetLastError());
+    if (Q.ready) {                  /* the scoring stream ends before the search can, but the timed region closes on both */
+        HIPCHK(hipEventRecord(e->ev_sc, e->stream_sc));
+        HIPCHK(hipStreamWaitEvent(e->stream, e->ev_sc, 0));
+    }
     HIPCHK(hipEventRecord(e->ev1, e->stream));
     e->q_res_h.resize((size_t)n_utt * PSF_QRES); e->q_seg_h.resize((size_t)n_utt * e->q_seg_cap);
     HIPCHK(hipMemcpyAsync(e->q_res_h.data(), e->q_res_d, (size_t)n_utt * PSF_QRES * 4, hipMemcpyDeviceToHost, e->stream));

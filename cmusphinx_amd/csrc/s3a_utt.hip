@@ -1416,6 +1416,44 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
     }
 }
 
+/*
+ * A queue with the second pass (s3a_uttdec_enable_bestpath + s3a_uttdec_decode_queue): the pass has just run for the lanes that
+ * ended at this refill event; what it left in the lane's arena -- status words, the best path end first -- goes to the
+ * UTTERANCE's slot before the lane's next utterance overwrites it: 16 status words per utterance, the words packed behind one
+ * counter like ku_hyp's, in utterance order, each with its sum of frame normalisers (compute_scale).
+ */
+#define UD_WOFF 15          /* (a free io word: where the utterance's words start in the packed buffer; -1: no room) */
+__global__ void __launch_bounds__(UH_T)
+ku_dag_store(const ULane *__restrict__ lanes, const DagLane *__restrict__ dl, int32_t hyp_cap, int32_t *__restrict__ io_all,
+             int32_t *__restrict__ words_all, int32_t *__restrict__ wcount, int32_t wtotal, const int32_t *__restrict__ sub,
+             const int32_t *__restrict__ slot)
+{
+    const int32_t z = sub[blockIdx.x], u = slot[blockIdx.x], tid = threadIdx.x;
+    const ULane &L = lanes[z];
+    const DagLane &D = dl[z];
+    const int32_t nfr = L.ctx->nfr;
+    int32_t *io = io_all + (size_t)u * DG_IO_N;
+    __shared__ int32_t s_woff;
+    const int32_t status = D.io[DG_IO_STATUS], n = status == 0 ? D.io[DG_IO_NWORDS] : 0;
+    if (tid < DG_IO_N && tid != UD_WOFF) io[tid] = D.io[tid];
+    if (tid == 0) {
+        s_woff = n > 0 ? atomicAdd(wcount, n) : 0;
+        if (n > 0 && (long long)s_woff + n > (long long)wtotal) s_woff = -1;
+        io[UD_WOFF] = s_woff;
+    }
+    __syncthreads();
+    if (s_woff < 0 || n <= 0) return;
+    int32_t *words = words_all + (size_t)s_woff * 6;
+    for (int32_t q = tid; q < n; q += UH_T) {
+        const int32_t r = n - 1 - q;            /* (dag_backtrace prepends: the pass leaves the words end first) */
+        int32_t *o = words + (size_t)q * 6;
+        for (int k = 0; k < 5; k++) o[k] = D.out[(size_t)k * hyp_cap + r];
+        uint32_t sc = 0u;
+        for (int32_t i = max(o[1], 0); i < o[2] && i < nfr; i++) sc += (uint32_t)L.w.fstat[(size_t)i * 8];
+        o[5] = (int32_t)sc;
+    }
+}
+
 struct HostLane {
     s3a_lexsearch_t *ls;
     s3a_scorer_t *sc;
@@ -1488,6 +1526,9 @@ struct s3a_uttdec_s {
     int32_t *q_sched_d, *q_sched_h; size_t q_sched_cap; /* the refill events' lane / utterance lists */
     int32_t *q_hdr_d, *q_hdr_h; size_t q_hdr_cap;       /* [n_utt][UH_N] + the word counter */
     int32_t *q_words_d, *q_words_h; size_t q_words_cap, q_words_hcap;   /* hypothesis words, packed (6 int32 each) */
+    int32_t *q_dio_d, *q_dio_h; size_t q_dio_cap;       /* the second pass inside a queue: [n_utt][DG_IO_N] + the word counter */
+    int32_t *q_dw_d, *q_dw_h; size_t q_dw_cap, q_dw_hcap;   /* its words, packed */
+    int32_t q_dag;              /* the last queue ran the second pass */
 };
 
 static int32_t
@@ -1573,6 +1614,10 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.sc) s3a_scorer_free(hl.sc);
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
+    if (ud->q_dio_d) (void)hipFree(ud->q_dio_d);
+    if (ud->q_dio_h) (void)hipHostFree(ud->q_dio_h);
+    if (ud->q_dw_d) (void)hipFree(ud->q_dw_d);
+    if (ud->q_dw_h) (void)hipHostFree(ud->q_dw_h);
     if (ud->dag) s3a_dagpass_free(ud->dag);
     {
         void *qd[] = { ud->q_feat_d, ud->q_ctx_d, ud->q_sched_d, ud->q_hdr_d, ud->q_words_d };
@@ -1669,7 +1714,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
     ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
-    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->use_graph = 0; ud->d_fgbase = NULL; ud->q_n = 0; ud->q_feat_d = ud->q_feat_h = NULL; ud->q_ctx_d = ud->q_ctx_h = NULL; ud->q_sched_d = ud->q_sched_h = NULL; ud->q_hdr_d = ud->q_hdr_h = NULL; ud->q_words_d = ud->q_words_h = NULL; ud->q_feat_cap = ud->q_ctx_cap = ud->q_sched_cap = ud->q_hdr_cap = ud->q_words_cap = ud->q_words_hcap = 0; ud->h_ctx_up = NULL; ud->h_ctx_dn = NULL; ud->d_hyp_hdr = ud->h_hyp_hdr = ud->d_hyp_words = ud->h_hyp_words = NULL; ud->hyp_wcap = 0; ud->n_pset = proto->n_pset;
+    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->use_graph = 0; ud->d_fgbase = NULL; ud->q_n = 0; ud->q_feat_d = ud->q_feat_h = NULL; ud->q_ctx_d = ud->q_ctx_h = NULL; ud->q_sched_d = ud->q_sched_h = NULL; ud->q_hdr_d = ud->q_hdr_h = NULL; ud->q_words_d = ud->q_words_h = NULL; ud->q_dio_d = ud->q_dio_h = NULL; ud->q_dw_d = ud->q_dw_h = NULL; ud->q_dio_cap = ud->q_dw_cap = ud->q_dw_hcap = 0; ud->q_dag = 0; ud->q_feat_cap = ud->q_ctx_cap = ud->q_sched_cap = ud->q_hdr_cap = ud->q_words_cap = ud->q_words_hcap = 0; ud->h_ctx_up = NULL; ud->h_ctx_dn = NULL; ud->d_hyp_hdr = ud->h_hyp_hdr = ud->d_hyp_words = ud->h_hyp_words = NULL; ud->hyp_wcap = 0; ud->n_pset = proto->n_pset;
     (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
@@ -2489,7 +2534,6 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
         s3a_set_error("s3a_uttdec_decode_queue: bad arguments (%d utterances)", n_utt);
         return S3A_EINVAL;
     }
-    if (ud->dag) { s3a_set_error("s3a_uttdec_decode_queue: the second pass needs a lane's history table after its utterance; decode without lane refill"); return S3A_EUNSUP; }
     HIPCHK(hipSetDevice(ud->device));
     const UShared &S = ud->S;
     const bool graph_mode = ud->use_graph && ud->prof_every == 0;
@@ -2572,6 +2616,15 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     if ((rc = q_grow(&ud->q_words_d, (int32_t **)NULL, &ud->q_words_cap, wtotal * 6, "hypothesis words")) != S3A_OK) return rc;
     HIPCHK(hipMemsetAsync(ud->q_hdr_d, 0, ((size_t)n_utt * UH_N + 1) * 4, ud->stream));
     int32_t *wcount = ud->q_hdr_d + (size_t)n_utt * UH_N;
+    ud->q_dag = 0;
+    if (ud->dag) {
+        /* the second pass of the lanes that end at a refill event runs right there, before the lane's table is reused */
+        if ((rc = q_grow(&ud->q_dio_d, &ud->q_dio_h, &ud->q_dio_cap, (size_t)n_utt * DG_IO_N + 1, "second-pass status")) != S3A_OK) return rc;
+        if ((rc = q_grow(&ud->q_dw_d, (int32_t **)NULL, &ud->q_dw_cap, wtotal * 6, "second-pass words")) != S3A_OK) return rc;
+        HIPCHK(hipMemsetAsync(ud->q_dio_d, 0xff, ((size_t)n_utt * DG_IO_N) * 4, ud->stream));
+        HIPCHK(hipMemsetAsync(ud->q_dio_d + (size_t)n_utt * DG_IO_N, 0, 4, ud->stream));
+        if ((rc = s3a_dagpass_prepare(ud->dag, ud->stream)) != S3A_OK) return rc;
+    }
     const s3a_wordlevel_cfg_t &c = ud->cfg;
     UBegin B;
     {
@@ -2589,6 +2642,12 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
         const int32_t *el = ud->q_sched_d + e.o_el, *eu = el + e.n_end, *bl = ud->q_sched_d + e.o_bl, *bu = bl + e.n_beg;
         if (e.n_end > 0) {
             hipLaunchKernelGGL(ku_hyp, dim3(e.n_end), dim3(UH_T), 0, ud->stream, ud->d_lanes, ud->lm->d, ud->dict, P, ud->q_hdr_d, ud->q_words_d, wcount, el, eu);
+            if (ud->dag) {
+                const int32_t drc = s3a_dagpass_enqueue_lanes(ud->dag, el, e.n_end, ud->stream);
+                if (drc != S3A_OK) return drc;
+                hipLaunchKernelGGL(ku_dag_store, dim3(e.n_end), dim3(UH_T), 0, ud->stream, ud->d_lanes, s3a_dagpass_dev_lanes(ud->dag), s3a_dagpass_hyp_cap(ud->dag),
+                                   ud->q_dio_d, ud->q_dw_d, ud->q_dio_d + (size_t)n_utt * DG_IO_N, (int32_t)wtotal, el, eu);
+            }
             hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * T, e.n_end), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, el, c.n_word);
         }
         if (e.n_beg > 0) {
@@ -2628,6 +2687,7 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     if (graph_mode && rc == S3A_OK && hipMemsetAsync(ud->d_fgbase, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
     if (rc == S3A_OK && hipEventRecord(ud->ev1, ud->stream) != hipSuccess) rc = S3A_EHIP;
     if (rc == S3A_OK && hipMemcpyAsync(ud->q_hdr_h, ud->q_hdr_d, ((size_t)n_utt * UH_N + 1) * 4, hipMemcpyDeviceToHost, ud->stream) != hipSuccess) rc = S3A_EHIP;
+    if (rc == S3A_OK && ud->dag && hipMemcpyAsync(ud->q_dio_h, ud->q_dio_d, ((size_t)n_utt * DG_IO_N + 1) * 4, hipMemcpyDeviceToHost, ud->stream) != hipSuccess) rc = S3A_EHIP;
     if (hipStreamSynchronize(ud->stream) != hipSuccess && rc == S3A_OK) { s3a_set_error("s3a_uttdec_decode_queue: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
     if (rc == S3A_OK) {
         float ms = 0.0f;
@@ -2654,6 +2714,18 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
             ud->q_words_hcap = grow;
         }
         if (total_words > 0) HIPCHK(hipMemcpy(ud->q_words_h, ud->q_words_d, total_words * 24, hipMemcpyDeviceToHost));
+    }
+    if (ud->dag) {
+        const size_t total_words = (size_t)ud->q_dio_h[(size_t)n_utt * DG_IO_N];
+        if (total_words * 6 > ud->q_dw_hcap) {
+            if (ud->q_dw_h) (void)hipHostFree(ud->q_dw_h);
+            ud->q_dw_h = NULL; ud->q_dw_hcap = 0;
+            const size_t grow = total_words * 6 + total_words + 1024;
+            if (hipHostMalloc((void **)&ud->q_dw_h, grow * 4) != hipSuccess) { s3a_set_error("s3a_uttdec_decode_queue: pinned word buffer (second pass)"); return S3A_ENOMEM; }
+            ud->q_dw_hcap = grow;
+        }
+        if (total_words > 0) HIPCHK(hipMemcpy(ud->q_dw_h, ud->q_dw_d, min(total_words, wtotal) * 24, hipMemcpyDeviceToHost));
+        ud->q_dag = 1;
     }
     ud->q_n = n_utt;
     ud->q_nfr.assign(n_frames, n_frames + n_utt);
@@ -2823,6 +2895,49 @@ s3a_uttdec_bestpath_result(s3a_uttdec_t *ud, int32_t lane, s3a_dag_result_t *out
 {
     if (!ud || !ud->dag || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
     return s3a_dagpass_result(ud->dag, lane, out);
+}
+
+/* the second pass's hypothesis of utterance `utt` of the last queue (s3a_uttdec_bestpath_hyp's record and status codes) */
+extern "C" int32_t
+s3a_uttdec_queue_bestpath_hyp(s3a_uttdec_t *ud, int32_t utt, const char *uttid, int32_t utt_index, s3a_hyp_header_t *hdr,
+                              s3a_hyp_word_t *words, int32_t max_words)
+{
+    if (!ud || !hdr || utt < 0 || utt >= ud->q_n || max_words < 0 || (max_words > 0 && !words)) return S3A_EINVAL;
+    if (!ud->q_dag) { s3a_set_error("s3a_uttdec_queue_bestpath_hyp: the last queue ran without the second pass (s3a_uttdec_enable_bestpath)"); return S3A_EINVAL; }
+    const int32_t *h = ud->q_hdr_h + (size_t)utt * UH_N, *io = ud->q_dio_h + (size_t)utt * DG_IO_N;
+    memset(hdr, 0, sizeof *hdr);
+    if (uttid) strncpy(hdr->uttid, uttid, sizeof hdr->uttid - 1);
+    hdr->utt_index = utt_index; hdr->n_frames = ud->q_nfr[utt]; hdr->n_entry = io[DG_IO_NENT]; hdr->exit_id = io[DG_IO_ENDID];
+    hdr->score = io[DG_IO_SCORE]; hdr->total_scale = h[UH_TSCALE];
+    if (h[UH_ERR]) { hdr->status = -1; return S3A_OK; }
+    const int32_t st = io[DG_IO_STATUS];
+    if (st == DG_E_NOEXIT) { hdr->status = -2; return S3A_OK; }
+    if (st == DG_E_NOPATH) { hdr->status = -4; return S3A_OK; }
+    if (st == DG_E_CAP || st == DG_E_POSEDGE) {
+        s3a_set_error("s3a_uttdec_queue_bestpath_hyp: the second pass of utterance %d gave up with status %d (3: a capacity of the pass or "
+                      "-maxedge in the filler bypass, 5: positive bypass edge): no hypothesis from it", utt, st);
+        hdr->status = -5;
+        return S3A_OK;
+    }
+    if (st != 0) { s3a_set_error("s3a_uttdec_queue_bestpath_hyp: the second pass of utterance %d stopped with status %d", utt, st); return S3A_EUNSUP; }
+    hdr->n_words = io[DG_IO_NWORDS];
+    if (io[UD_WOFF] < 0) { s3a_set_error("s3a_uttdec_queue_bestpath_hyp: the packed word buffer was too small"); return S3A_ENOMEM; }
+    if (hdr->n_words > max_words) { hdr->status = -3; return S3A_OK; }
+    const int32_t *w = ud->q_dw_h + (size_t)io[UD_WOFF] * 6;
+    for (int32_t q = 0; q < hdr->n_words; q++) {
+        s3a_hyp_word_t &o = words[q];
+        o.wid = w[6 * q]; o.sf = w[6 * q + 1]; o.ef = w[6 * q + 2]; o.ascr = w[6 * q + 3]; o.lscr = w[6 * q + 4]; o.scale = w[6 * q + 5];
+    }
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_uttdec_lattice(s3a_uttdec_t *ud, int32_t lane, s3a_lat_info_t *info, s3a_lat_node_t *nodes, int32_t node_cap,
+                   s3a_lat_link_t *links, int32_t link_cap)
+{
+    if (!ud || !ud->dag || lane < 0 || lane >= ud->n_utt) { s3a_set_error("s3a_uttdec_lattice: no second pass on this engine (s3a_uttdec_enable_bestpath) or bad lane"); return S3A_EINVAL; }
+    if (ud->q_n) { s3a_set_error("s3a_uttdec_lattice: a queue keeps no lattices (decode in lock-step batches)"); return S3A_EUNSUP; }
+    return s3a_dagpass_lattice(ud->dag, lane, info, nodes, node_cap, links, link_cap);
 }
 
 extern "C" int32_t

@@ -213,9 +213,14 @@ _SIGS = {
     "s3a_dagpass_free": (None, [C.c_void_p]),
     "s3a_dagpass_run_tables": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_dagpass_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_dagpass_lattice": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "s3a_uttdec_lattice": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "s3a_lattice_format_s3": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "s3a_lattice_format_htk": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "s3a_uttdec_enable_bestpath": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "s3a_uttdec_bestpath_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_bestpath_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_uttdec_queue_bestpath_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_set_profile": (C.c_int32, [C.c_void_p, C.c_int32]),
     "s3a_uttdec_profile": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_variants_default": (None, [C.c_void_p]),
@@ -1339,7 +1344,7 @@ def dag_cfg(b, keep, bestpathlw=None, min_endfr=None, maxedge=None, maxlmop=None
 
 class Variants(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("scan_chained", "calls_by_copy", "batch_no_shared", "batch_no_multi",
-                                         "no_frame_sync_kernel", "score_nt", "score_fpc")]
+                                         "no_frame_sync_kernel", "score_nt", "score_fpc", "ps_overlap")]
 
 
 def set_variants(**kw):
@@ -1561,6 +1566,16 @@ class UttDec:
         if hdr.status == -3:
             words = np.zeros((hdr.n_words, 6), np.int32)
             check(self.L.s3a_uttdec_bestpath_hyp(self.h, lane, uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
+        return hdr, words[:hdr.n_words if hdr.status == 0 else 0].copy()
+
+    def queue_bestpath_hyp(self, utt, uttid="", utt_index=0):
+        """the second pass's hypothesis of utterance `utt` of the last queue: (HypHeader, words int32 [n_words, 6])"""
+        hdr = HypHeader()
+        words = np.zeros((HYP_MAXW, 6), np.int32)
+        check(self.L.s3a_uttdec_queue_bestpath_hyp(self.h, int(utt), uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
+        if hdr.status == -3:
+            words = np.zeros((hdr.n_words, 6), np.int32)
+            check(self.L.s3a_uttdec_queue_bestpath_hyp(self.h, int(utt), uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
         return hdr, words[:hdr.n_words if hdr.status == 0 else 0].copy()
 
     def hyp_var(self, lane, uttid="", utt_index=0):

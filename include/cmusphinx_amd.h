@@ -899,6 +899,44 @@ s3a_dagpass_t *s3a_dagpass_init(s3a_lm3g_t *lm, const s3a_dag_cfg_t *cfg, int32_
 void s3a_dagpass_free(s3a_dagpass_t *dp);
 int32_t s3a_dagpass_run_tables(s3a_dagpass_t *dp, int32_t n_utt, const s3a_dag_table_t *tabs);
 int32_t s3a_dagpass_result(const s3a_dagpass_t *dp, int32_t lane, s3a_dag_result_t *out);
+/*
+ * The lattice itself, for lattice files and for code that wants the reference's dag_t (N-best): the nodes and links
+ * vithist_dag_build (vithist.c:1100-1311) makes, in the reference's list orders.  nodes[]: dag->list order = the NODEID
+ * order of dag_write (dag.c:731-790); wid / sf / fef / lef / node_ascr / node_lscr of dagnode_t.  links[]: grouped by
+ * source node in that order, per source in succlist order (= the order of dag_write's Edges section); ascr / lscr / ef of
+ * daglink_t; a node's predlist is its incoming links by source id ascending.  info: dag->nfrm, counts, dag->root and
+ * dag->end as node ids, dag->final.ascr, the pass's status.  Call with nodes = links = NULL for the sizes.  Valid until the
+ * lane's next pass; available whenever the pass got as far as counting the links (also when the best path then failed).
+ */
+typedef struct { int32_t wid, sf, fef, lef, ascr, lscr; } s3a_lat_node_t;
+typedef struct { int32_t from, to, ascr, lscr, ef; } s3a_lat_link_t;
+typedef struct { int32_t status, n_frames, n_nodes, n_links, initial, final, final_ascr; } s3a_lat_info_t;
+int32_t s3a_dagpass_lattice(s3a_dagpass_t *dp, int32_t lane, s3a_lat_info_t *info, s3a_lat_node_t *nodes, int32_t node_cap,
+                            s3a_lat_link_t *links, int32_t link_cap);
+int32_t s3a_uttdec_lattice(s3a_uttdec_t *ud, int32_t lane, s3a_lat_info_t *info, s3a_lat_node_t *nodes, int32_t node_cap,
+                           s3a_lat_link_t *links, int32_t link_cap);
+/*
+ * dag_write (dag.c:731-790: "Frames", "Nodes", "Initial"/"Final", "BestSegAscr 0", "Edges", "End") and dag_write_htk
+ * (dag.c:793-897) on such a lattice, into a caller buffer; host code, no device.  `header` = the comment block
+ * dag_write_header (dag.c:694-728) prints from the decoder's configuration (the caller has the configuration; may be "").
+ * wordstr[wid] = dict_wordstr.  HTK: basewid[wid] = dict_basewid, n_alt[basewid] = pronunciations of the base word
+ * (the dict_nextalt chain), logbase / log_shift of the decoder's logmath (a = ascr * ln(base)), lm_lw / lm_wip = lm_t.lw /
+ * lm_t.wip for lm_rawscore (lm.c:2172-2178; have_lm = 0: no LM, l = lscr as it is), lmname or NULL, opt_lw / opt_wip = the
+ * -lw / -wip arguments as float32, frate = -frate.  Return: the bytes the text needs (more than cap: nothing usable was
+ * written), < 0 on bad arguments.
+ */
+int64_t s3a_lattice_format_s3(const char *header, const s3a_lat_info_t *info, const s3a_lat_node_t *nodes,
+                              const s3a_lat_link_t *links, const char *const *wordstr, char *buf, int64_t cap);
+typedef struct {
+    const char *uttid, *lmname;
+    int32_t have_lm, lm_wip, frate, log_shift;
+    float lm_lw, opt_lw, opt_wip;
+    double log_of_base;
+    const int32_t *basewid, *n_alt;
+} s3a_htk_opts_t;
+int64_t s3a_lattice_format_htk(const char *header, const s3a_htk_opts_t *o, const s3a_lat_info_t *info,
+                               const s3a_lat_node_t *nodes, const s3a_lat_link_t *links, const char *const *wordstr,
+                               char *buf, int64_t cap);
 /* the whole-utterance engine with the second pass: after the frames of every s3a_uttdec_decode* the lanes' tables go
  * through vithist_utt_end and the pass ON THE DEVICE; keep_tables = 0: the history tables are not read back at all
  * (s3a_uttdec_result / s3a_uttdec_hyp then fail; the hypotheses come from s3a_uttdec_bestpath_hyp).
@@ -911,6 +949,11 @@ int32_t s3a_uttdec_enable_bestpath(s3a_uttdec_t *ud, const s3a_dag_cfg_t *cfg, i
                                    int32_t keep_tables);
 int32_t s3a_uttdec_bestpath_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index,
                                 s3a_hyp_header_t *hdr, s3a_hyp_word_t *words, int32_t max_words);
+/* With the second pass enabled, s3a_uttdec_decode_queue* (lane refill) runs it at every refill event for the lanes that have
+ * ended, before their history tables are reused; the result is kept per UTTERANCE of the queue (no lattices: s3a_uttdec_lattice
+ * needs a lock-step decode).  Same record and status codes as s3a_uttdec_bestpath_hyp. */
+int32_t s3a_uttdec_queue_bestpath_hyp(s3a_uttdec_t *ud, int32_t utt, const char *uttid, int32_t utt_index,
+                                      s3a_hyp_header_t *hdr, s3a_hyp_word_t *words, int32_t max_words);
 int32_t s3a_uttdec_bestpath_result(s3a_uttdec_t *ud, int32_t lane, s3a_dag_result_t *out);
 
 double s3a_uttdec_last_decode_ms(const s3a_uttdec_t *ud);    /* HIP-event time of the last decode's frames */
@@ -1067,6 +1110,7 @@ typedef struct {
     int32_t batch_no_shared, batch_no_multi;    /* s3a_batch: one scoring launch per decoder instead of the shared-model passes */
     int32_t no_frame_sync_kernel;   /* single-frame scoring through the general kernel */
     int32_t score_nt, score_fpc;    /* whole-utterance scoring: workgroup size (256 / 512 / 1024; 0 = 512), frames per chunk (0 = chosen) */
+    int32_t ps_overlap;             /* s3a_psfwd_decode_queue: score the queue's later utterances BESIDE the search (second stream) instead of before it */
 } s3a_variants_t;
 void    s3a_variants_default(s3a_variants_t *v);
 int32_t s3a_set_variants(const s3a_variants_t *v);

@@ -22,6 +22,7 @@
  * emitting states.  -lmname switching and ps_load_dict go through reinit, which re-exports.
  */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sphinxbase/ckd_alloc.h>
 #include <sphinxbase/err.h>
@@ -194,6 +195,12 @@ ps_amd_search_install(ps_decoder_t *ps, int n_lanes)
     b = ckd_calloc(1, sizeof(*b));
     b->ps = ps;
     b->n_lanes = n_lanes > 0 ? n_lanes : 1;
+    if (getenv("PSAMD_OVERLAP")) {     /* (this program's switch; the library takes it as a field of s3a_variants_t) */
+        s3a_variants_t v;
+        s3a_variants_default(&v);
+        v.ps_overlap = 1;
+        s3a_set_variants(&v);
+    }
     if (amd_build(b, (ngram_search_t *)ps->search) < 0) { ckd_free(b); return -1; }
     b->orig = ps->search->vt;
     b->vt = *b->orig;

@@ -33,6 +33,10 @@
 #include "srch_time_switch_tree.c"
 
 #include <string.h>
+#include <math.h>
+#include "pio.h"
+#include "genrand.h"
+#include "logs3.h"
 #include "byteorder.h"
 #include "s3_decode.h"
 #include "srch.h"

@@ -89,14 +89,125 @@ rec_add(int32 z)
     if (h.status == 0) g_rec_nw += h.n_words;
 }
 static __thread int32 g_cur_lane;
+static int g_want_lattice;      /* -outlatdir / -nbestdir: the reference's writers and its N-best search get a dag_t made from the device's lattice */
+static char **g_wordstr;
+/* gen_dag (srch.c:519-530; srch_TST_gen_dag = vithist_dag_build, srch_time_switch_tree.c:1381-1389): the lattice was built on
+ * the device behind the utterance's last frame.  Without -outlatdir / -nbestdir srch_utt_end only tests the pointer (an empty
+ * dag_t will do); with them the device's lattice is poured into a dag_t -- nodes and links made in the order vithist_dag_build
+ * makes them (vithist.c:1243-1281), so that every list reads as the reference's -- and dag_write_htk, nbest_search and their
+ * like run on it as they are. */
 static dag_t *
 utt_gen_dag_slot(void *srch, glist_t hyp)
 {
     srch_t *s = srch;
-    dag_t *dag = ckd_calloc(1, sizeof(*dag));           /* an empty lattice: srch_utt_end only tests the pointer */
+    cmd_ln_t *config = kbcore_config(s->kbc);
+    dag_t *dag = ckd_calloc(1, sizeof(*dag));
+    s3a_uttdec_t *ud = g_uds[g_cur_lane / g_lpe];
+    s3a_lat_info_t info;
+    s3a_lat_node_t *nodes;
+    s3a_lat_link_t *links;
+    dagnode_t **dn;
+    int32 i, j, k, *first;
     (void)hyp;
-    dag_init(dag, kbcore_config(s->kbc), kbcore_logmath(s->kbc));
+    dag_init(dag, config, kbcore_logmath(s->kbc));
+    if (!g_want_lattice) return dag;
+    if (s3a_uttdec_lattice(ud, g_cur_lane % g_lpe, &info, NULL, 0, NULL, 0) != S3A_OK) {
+        E_ERROR("tst shim: no lattice from the device for %s: %s\n", s->uttid, s3a_last_error());
+        dag_destroy(dag);
+        return NULL;
+    }
+    nodes = ckd_calloc(info.n_nodes + 1, sizeof(*nodes));
+    links = ckd_calloc(info.n_links + 1, sizeof(*links));
+    if (s3a_uttdec_lattice(ud, g_cur_lane % g_lpe, &info, nodes, info.n_nodes, links, info.n_links) != S3A_OK) die("s3a_uttdec_lattice");
+    dn = ckd_calloc(info.n_nodes + 1, sizeof(*dn));
+    for (k = info.n_nodes - 1; k >= 0; k--) {           /* dag->list is built by head insertion: its first node is made last */
+        dagnode_t *d = listelem_malloc(dag->node_alloc);
+        d->wid = nodes[k].wid; d->node_ascr = nodes[k].ascr; d->node_lscr = nodes[k].lscr;
+        d->sf = nodes[k].sf; d->fef = nodes[k].fef; d->lef = nodes[k].lef;
+        d->seqid = info.n_nodes - 1 - k; d->hook = NULL; d->predlist = NULL; d->succlist = NULL; d->reachable = 0;
+        d->alloc_next = dag->list; dag->list = d;
+        dn[k] = d;
+    }
+    first = ckd_calloc(info.n_nodes + 2, sizeof(*first));
+    for (i = 0; i < info.n_links; i++) first[links[i].from + 1]++;
+    for (k = 0; k < info.n_nodes; k++) first[k + 1] += first[k];
+    for (k = info.n_nodes - 1; k >= 0; k--)             /* sources in the order they were made; dag_link prepends: a list's last link first */
+        for (j = first[k + 1] - 1; j >= first[k]; j--)
+            dag_link(dag, dn[k], dn[links[j].to], links[j].ascr, links[j].lscr, links[j].ef, NULL);
+    dag->root = dn[info.initial]; dag->end = dn[info.final];
+    dag->entry.node = dag->root; dag->entry.ascr = 0; dag->entry.next = NULL; dag->entry.pscr_valid = 0; dag->entry.bypass = NULL;
+    dag->final.node = dag->end; dag->final.ascr = info.final_ascr; dag->final.next = NULL; dag->final.pscr_valid = 0; dag->final.bypass = NULL;
+    dag->filler_removed = 0; dag->fudged = 0; dag->nfrm = info.n_frames;
+    dag->maxedge = cmd_ln_int32_r(config, "-maxedge");
+    dag->maxlmop = cmd_ln_int32_r(config, "-maxlmop");
+    k = cmd_ln_int32_r(config, "-maxlpf") * dag->nfrm;
+    if (k > 0 && dag->maxlmop > k) dag->maxlmop = k;
+    dag->lmop = 0;
+    if (getenv("S3A_LAT_LIBHTK") && cmd_ln_str_r(config, "-outlatdir")) {
+        /* (test hook) dag_write_htk by the library's own formatter beside the reference's file: <file>.libhtk */
+        dict_t *dict = kbcore_dict(s->kbc);
+        lm_t *lm = kbcore_lm(s->kbc);
+        logmath_t *lmath = kbcore_logmath(s->kbc);
+        s3a_htk_opts_t ho;
+        char str[2048], *hdr = NULL, *buf;
+        size_t hl = 0;
+        int64_t need;
+        int32 nw = dict_size(dict), *base = ckd_calloc(nw + 1, 4), *nalt = ckd_calloc(nw + 1, 4);
+        FILE *hf = open_memstream(&hdr, &hl), *fp;
+        dag_write_header(hf, config);
+        fclose(hf);
+        for (i = 0; i < nw; i++) { base[i] = dict_basewid(dict, i); nalt[base[i]]++; }
+        memset(&ho, 0, sizeof ho);
+        ho.uttid = s->uttid; ho.lmname = lm ? lm->name : NULL; ho.have_lm = lm != NULL; ho.lm_wip = lm ? lm->wip : 0; ho.lm_lw = lm ? lm->lw : 1.0f;
+        ho.frate = cmd_ln_exists_r(config, "-frate") ? cmd_ln_int32_r(config, "-frate") : 0;
+        ho.log_shift = logmath_get_shift(lmath); ho.log_of_base = log(logmath_get_base(lmath));
+        ho.opt_lw = cmd_ln_float32_r(config, "-lw"); ho.opt_wip = cmd_ln_float32_r(config, "-wip");
+        ho.basewid = base; ho.n_alt = nalt;
+        need = s3a_lattice_format_htk(hdr, &ho, &info, nodes, links, (const char *const *)g_wordstr, NULL, 0);
+        buf = ckd_calloc(need + 1, 1);
+        s3a_lattice_format_htk(hdr, &ho, &info, nodes, links, (const char *const *)g_wordstr, buf, need + 1);
+        ctl_outfile(str, cmd_ln_str_r(config, "-outlatdir"), "libhtk", (s->uttfile ? s->uttfile : s->uttid), s->uttid, cmd_ln_boolean_r(config, "-build_outdirs"));
+        if ((fp = fopen(str, "w")) != NULL) { fwrite(buf, 1, need, fp); fclose(fp); }
+        ckd_free(buf); ckd_free(base); ckd_free(nalt); free(hdr);
+    }
+    ckd_free(first); ckd_free(dn); ckd_free(nodes); ckd_free(links);
     return dag;
+}
+/* dag_dump (srch.c:586-590: the Sphinx-3 format's "custom implementation" slot; NULL in srch_TST_funcs, so that srch_utt_end
+ * calls dag_write, dag.c:731-790): the same file by the library's formatter, straight from the device's lattice */
+static int
+utt_dag_dump_slot(void *srch, dag_t *dag)
+{
+    srch_t *s = srch;
+    cmd_ln_t *config = kbcore_config(s->kbc);
+    s3a_uttdec_t *ud = g_uds[g_cur_lane / g_lpe];
+    s3a_lat_info_t info;
+    s3a_lat_node_t *nodes;
+    s3a_lat_link_t *links;
+    char str[2048], *hdr = NULL, *buf;
+    size_t hl = 0;
+    int64_t need;
+    int32 ispipe;
+    FILE *hf, *fp;
+    (void)dag;
+    if (s3a_uttdec_lattice(ud, g_cur_lane % g_lpe, &info, NULL, 0, NULL, 0) != S3A_OK) return SRCH_FAILURE;
+    nodes = ckd_calloc(info.n_nodes + 1, sizeof(*nodes));
+    links = ckd_calloc(info.n_links + 1, sizeof(*links));
+    if (s3a_uttdec_lattice(ud, g_cur_lane % g_lpe, &info, nodes, info.n_nodes, links, info.n_links) != S3A_OK) die("s3a_uttdec_lattice");
+    hf = open_memstream(&hdr, &hl);
+    dag_write_header(hf, config);
+    fclose(hf);
+    need = s3a_lattice_format_s3(hdr, &info, nodes, links, (const char *const *)g_wordstr, NULL, 0);
+    buf = ckd_calloc(need + 1, 1);
+    s3a_lattice_format_s3(hdr, &info, nodes, links, (const char *const *)g_wordstr, buf, need + 1);
+    ctl_outfile(str, cmd_ln_str_r(config, "-outlatdir"), cmd_ln_str_r(config, "-latext"), (s->uttfile ? s->uttfile : s->uttid), s->uttid,
+                cmd_ln_boolean_r(config, "-build_outdirs"));
+    E_INFO("Writing lattice file in Sphinx III format: %s\n", str);
+    if ((fp = fopen_comp(str, "w", &ispipe)) == NULL) { E_ERROR("fopen_comp (%s,w) failed\n", str); ckd_free(buf); ckd_free(nodes); ckd_free(links); free(hdr); return SRCH_FAILURE; }
+    fwrite(buf, 1, need, fp);
+    fclose_comp(fp, ispipe);
+    ckd_free(buf); ckd_free(nodes); ckd_free(links); free(hdr);
+    return SRCH_SUCCESS;
 }
 static glist_t
 utt_bestpath_slot(void *srch, dag_t *dag)
@@ -308,7 +419,9 @@ utt_flush_queue(kb_t *kb)
         int32 need = 0, cap = 0, err = 0, mc = 0, mn = 0;
         for (;;) {
             if (need > cap) { cap = need + 64; words = ckd_realloc(words, (size_t)cap * sizeof(*words)); }
-            if (s3a_uttdec_queue_hyp(ud, slot_q[z], g_uq[z].uttid, g_rank_first + g_rec_n, &h, words, cap) != S3A_OK) die("hypothesis record");
+            /* -bestpath 1: the second pass ran on the device at the lane's refill event; its hypothesis is the utterance's */
+            if ((g_dev_dag ? s3a_uttdec_queue_bestpath_hyp(ud, slot_q[z], g_uq[z].uttid, g_rank_first + g_rec_n, &h, words, cap)
+                           : s3a_uttdec_queue_hyp(ud, slot_q[z], g_uq[z].uttid, g_rank_first + g_rec_n, &h, words, cap)) != S3A_OK) die("hypothesis record");
             if (h.status != -3) break;
             need = h.n_words;
         }
@@ -328,9 +441,15 @@ utt_flush_queue(kb_t *kb)
                     g_uq[z].uttid, err);
             g_failed_utts++;
         }
+        else if (h.status == -4) E_ERROR("Bestpath search failed for %s\n", g_uq[z].uttid);      /* (dag.c:945: no line) */
+        else if (h.status == -5) {
+            E_ERROR("the device's second pass gave up on %s: %s\n", g_uq[z].uttid, s3a_last_error());
+            g_failed_utts++;
+        }
         else if (h.status != 0)
             E_ERROR("s->funcs->utt_end failed\n");     /* (srch.c:495-498: no word exit reached a history entry; no line) */
-        else {
+        else if (g_dev_dag) g_dag_utts++;
+        if (h.status == 0) {
             const size_t lcap = 65536 + 64 * (size_t)h.n_words;
             char *m = ckd_calloc(lcap, 1), *sg = ckd_calloc(lcap, 1);
             if (s3a_hyp_format_var(&h, words, wstr, base, g_wflat->is_filler, g_wflat->startwid, g_wflat->finishwid, (float)kbcore_lm(kbc)->lw,
@@ -425,6 +544,7 @@ adc_read(const char *uttfile, int32 *nsamps, cmd_ln_t *config)
     return data;
 }
 
+static int g_dither, g_swap;
 /* the front end fe_init_auto_r (fe_interface.c:212-283) builds from the same options */
 static void
 adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
@@ -432,8 +552,10 @@ adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
     s3a_fe_params_t p;
     const char *tr = cmd_ln_str_r(config, "-transform"), *cmn = cmd_ln_str_r(config, "-cmn"), *agc = cmd_ln_str_r(config, "-agc");
     if (strcmp(kbcore_fcb(kbc)->name, "1s_c_d_dd") != 0) E_FATAL("tst shim: -adcin with S3A_UTT: feature type 1s_c_d_dd only (is %s)\n", kbcore_fcb(kbc)->name);
-    if (cmd_ln_boolean_r(config, "-dither")) E_FATAL("tst shim: -adcin with S3A_UTT: -dither is not supported\n");
-    if (strcmp(cmd_ln_str_r(config, "-input_endian"), "little") != 0) E_FATAL("tst shim: -adcin with S3A_UTT: little-endian samples only\n");
+    /* -dither / -input_endian act on the samples as they enter the front end's frame buffer (fe_read_frame / fe_shift_frame,
+     * fe_sigproc.c:596-640), once per sample and in sample order: done on the samples before they go to the device (utt_collect) */
+    g_dither = cmd_ln_boolean_r(config, "-dither") ? 1 : 0;
+    g_swap = strcmp(cmd_ln_str_r(config, "-input_endian"), "little") != 0;      /* (this host is little-endian: fe_interface.c:80-84) */
     if (cmd_ln_str_r(config, "-warp_params") != NULL) E_FATAL("tst shim: -adcin with S3A_UTT: frequency warping is not supported\n");
     if (kbcore_fcb(kbc)->lda != NULL) E_FATAL("tst shim: -adcin with S3A_UTT: LDA is not supported\n");
     s3a_fe_default_params(&p);
@@ -484,6 +606,18 @@ utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
         float *dfeat = NULL;
         (void)sf; (void)ef; (void)t;
         if (adc == NULL) E_FATAL("Cannot read file %s. Forced exit\n", ur->uttfile);
+        if (g_swap) { int32 k; for (k = 0; k < nsamps; k++) SWAP_INT16(&adc[k]); }
+        if (g_dither) {
+            /* every sample that enters a frame gets one draw of the generator kb_init's fe_init_auto_r seeded (-seed), in
+             * sample order; the samples behind the last whole frame enter none (utt_decode calls no fe_end_utt).  The
+             * generator's state runs on from utterance to utterance, so the control file is walked in order here. */
+            const int32 fs = s3a_fe_frame_size(g_fe), sh = s3a_fe_frame_shift(g_fe);
+            if (nsamps >= fs) {
+                const int32 used = fs + ((nsamps - fs) / sh) * sh;
+                int32 k;
+                for (k = 0; k < used; k++) adc[k] += (int16)((!(s3_rand_int31() % 4)) ? 1 : 0);
+            }
+        }
         if (s3a_audio_to_feat_dev(g_fe, adc, nsamps, 1, g_cmn_current, g_varnorm, g_agc_max, &dfeat, &total_frame, &stride) != S3A_OK)
             E_FATAL("tst shim: MFCC / feature computation failed for %s: %s\n", ur->uttfile, s3a_last_error());
         ckd_free(adc);
@@ -580,10 +714,10 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
                                             mdef->sen2cimap, mdef_n_ciphone(mdef)) != S3A_OK) die("s3a_uttdec_enable_pheur");
                 ckd_free(nci);
             }
-            /* (lattice files and N-best lists are written from the reference's dag_t: those runs keep its own
-             * vithist_dag_build on the table the device produced) */
-            if (cmd_ln_boolean_r(config, "-bestpath") && !getenv("S3A_UTT_HOSTDAG") && !cmd_ln_str_r(config, "-outlatdir")
-                && !cmd_ln_str_r(config, "-nbestdir")) {
+            /* the second pass on the device; lattice files (-outlatdir) are written from the device's lattice, N-best lists
+             * (-nbestdir) by the reference's own A* search on a dag_t poured from it (utt_gen_dag_slot) */
+            if ((cmd_ln_boolean_r(config, "-bestpath") || cmd_ln_str_r(config, "-outlatdir") || cmd_ln_str_r(config, "-nbestdir"))
+                && !getenv("S3A_UTT_HOSTDAG")) {
                 s3a_dag_cfg_t dc;
                 float32 bplw = cmd_ln_float32_r(config, "-bestpathlw");
                 int32 *base = ckd_calloc(w->n_word + 1, 4), i;
@@ -637,13 +771,23 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     }
     s->funcs->utt_begin = utt_begin_slot;
     s->funcs->utt_end = utt_end_slot;
-    if (g_dev_dag) { s->funcs->gen_dag = utt_gen_dag_slot; s->funcs->bestpath_impl = utt_bestpath_slot; }
+    if (g_dev_dag) {
+        s->funcs->gen_dag = utt_gen_dag_slot; s->funcs->bestpath_impl = utt_bestpath_slot;
+        if (cmd_ln_str_r(config, "-outlatdir") || cmd_ln_str_r(config, "-nbestdir")) {
+            dict_t *dict = kbcore_dict(kbc);
+            int32 i;
+            g_want_lattice = 1;
+            g_wordstr = ckd_calloc(dict_size(dict) + 1, sizeof(*g_wordstr));
+            for (i = 0; i < dict_size(dict); i++) g_wordstr[i] = (char *)dict_wordstr(dict, i);
+            if (cmd_ln_str_r(config, "-outlatdir") && strcmp(cmd_ln_str_r(config, "-outlatfmt"), "htk") != 0) s->funcs->dag_dump = utt_dag_dump_slot;
+        }
+    }
     g_uq_cap = n_lanes;
     g_wflat = w;
     if (cmd_ln_exists_r(config, "-adcin") && cmd_ln_boolean_r(config, "-adcin")) adc_frontend_init(config, kbc);
     if (getenv("S3A_UTT_QUEUE")) {      /* lane refill: this many control-file entries per queue (at least the lanes) */
-        if (g_dev_dag || cmd_ln_str_r(config, "-outlatdir") || cmd_ln_str_r(config, "-nbestdir") || cmd_ln_boolean_r(config, "-bestpath"))
-            E_FATAL("tst shim: S3A_UTT_QUEUE (lane refill) keeps no history tables: no second pass / lattices / N-best in this mode\n");
+        if (cmd_ln_str_r(config, "-outlatdir") || cmd_ln_str_r(config, "-nbestdir") || (cmd_ln_boolean_r(config, "-bestpath") && !g_dev_dag))
+            E_FATAL("tst shim: S3A_UTT_QUEUE (lane refill) keeps no history tables: no lattices / N-best / host second pass in this mode (-bestpath 1 runs on the device)\n");
         g_queue = 1;
         if (atoi(getenv("S3A_UTT_QUEUE")) > g_uq_cap) g_uq_cap = atoi(getenv("S3A_UTT_QUEUE"));
     }
@@ -696,8 +840,8 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
         s3a_gather_free(gt);
     }
     if (g_frames == 0) E_FATAL("tst shim: nothing was decoded\n");
-    E_INFO("tst shim: %ld frames searched by the replacement backend in %d lane(s), whole utterances on the device\n",
-           g_frames, n_lanes);
+    E_INFO("tst shim: %ld frames searched by the replacement backend in %d lane(s), whole utterances on the device%s\n",
+           g_frames, n_lanes, g_queue ? " (queues with lane refill)" : "");
     E_INFO("tst shim: histogram pruning (lextree_hmm_histbin) applied in %ld frames\n", g_histframes);
     if (g_dev_dag) E_INFO("tst shim: second pass (lattice + best path) of %ld utterances served by the device\n", g_dag_utts);
     E_INFO("tst shim utt mode: word level: at most %ld candidates and %ld new history entries in a frame; "

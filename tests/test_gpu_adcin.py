@@ -71,8 +71,29 @@ def test_header_skip_and_other_front_end_options(audio_task):
     assert got == ref
 
 
+def test_dither_and_big_endian_samples(audio_task):
+    """-dither yes -seed N: every sample that enters a frame gets one draw of the generator the reference's fe_init seeded, in
+    sample order, the generator running on from utterance to utterance (fe_sigproc.c:606-613, 630-638) -- applied to the samples
+    before they go to the device; -input_endian big: the samples swapped (fe->swap).  Every score as the reference's."""
+    d, args = audio_task
+    ref = run(REF, args, d, "refd", extra=["-dither", "yes", "-seed", "1234"])
+    plain = run(REF, args, d, "refp")
+    assert ref[1] != plain[1]                                           # (the dither is no bystander)
+    for env in ({"S3A_UTT": "1"}, {"S3A_UTT": "3"}, {"S3A_UTT": "2", "S3A_UTT_QUEUE": "4"}):
+        got = run(TST, args, d, "uttd" + "_".join(env.values()), env, extra=["-dither", "yes", "-seed", "1234"])
+        assert got == ref
+    be = d / "be"
+    be.mkdir(exist_ok=True)
+    for n in ("dhd", "goforward", "chan3", "short"):
+        np.fromfile(d / f"{n}.raw", "<i2").astype(">i2").tofile(be / f"{n}.raw")
+    a2 = [a if a != str(d) else str(be) for a in args]
+    refb = run(REF, a2, d, "refb", extra=["-input_endian", "big"])
+    assert refb == plain
+    assert run(TST, a2, d, "uttb", {"S3A_UTT": "2"}, extra=["-input_endian", "big", "-dither", "yes", "-seed", "1234"]) == ref
+
+
 def test_unsupported_front_end_options_are_refused(audio_task):
     d, args = audio_task
-    p = subprocess.run([TST] + args + ["-ctl", str(d / "ctl"), "-dither", "yes"], capture_output=True, text=True, errors="ignore",
+    p = subprocess.run([TST] + args + ["-ctl", str(d / "ctl"), "-warp_params", "1.1"], capture_output=True, text=True, errors="ignore",
                        timeout=600, env=dict(os.environ, S3A_UTT="2"))
-    assert p.returncode != 0 and "-dither is not supported" in p.stderr
+    assert p.returncode != 0 and "frequency warping is not supported" in p.stderr

@@ -103,11 +103,28 @@ def test_a_lane_whose_utterance_overflowed_is_scrubbed_on_the_device(gpu_lib, ti
         assert bytes(a[0]) == bytes(b[0]) and np.array_equal(a[1], b[1])
 
 
-def test_queue_refuses_what_it_cannot_serve(gpu_lib, tidigits_bundle):
-    dec = bundle.Decoder(tidigits_bundle, 2, bestpath=True)
+def test_second_pass_inside_the_queue_through_the_c_abi(gpu_lib, tidigits_bundle):
+    """s3a_uttdec_enable_bestpath + s3a_uttdec_decode_queue: the second pass of a lane runs at its refill event; per utterance
+    the record of a lock-step decode's s3a_uttdec_bestpath_hyp, words, scores and frame normalisers"""
     utts, feats = tidigits_feats(gpu_lib)
-    with pytest.raises(gpu_lib.S3AError, match="second pass"):
-        dec.decode_queue(feats[:3])
+    lock = bundle.Decoder(tidigits_bundle, 4, bestpath=True)
+    want = []
+    for i in range(0, 12, 4):
+        lock.decode(feats[i:i + 4])
+        want += [lock.bestpath_hyp(z, utts[i + z][1], i + z) for z in range(4)]
+    dec = bundle.Decoder(tidigits_bundle, 3, bestpath=True)
+    dec.decode_queue(feats[:12])
+    for u in range(12):
+        h, w = dec.queue_bestpath_hyp(u, utts[u][1], u)
+        assert h.status == 0 and h.status == want[u][0].status
+        assert (h.n_frames, h.n_words, h.score, h.total_scale, h.exit_id) == (want[u][0].n_frames, want[u][0].n_words, want[u][0].score,
+                                                                            want[u][0].total_scale, want[u][0].exit_id), u
+        assert np.array_equal(w, want[u][1]), u
+        assert dec.format_var(h, w) == lock.format_var(*want[u])
+
+
+def test_queue_refuses_what_it_cannot_serve(gpu_lib, tidigits_bundle):
+    utts, feats = tidigits_feats(gpu_lib)
     dec = bundle.Decoder(tidigits_bundle, 2)
     with pytest.raises(gpu_lib.S3AError):
         dec.decode_queue([feats[0], feats[1][:0]])                  # an utterance without frames
