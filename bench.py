@@ -372,6 +372,31 @@ def ps_fwdtree_leg(t, lanes, n_cpu=4):
            "cpu_pocketsphinx": {"frames": int(cpu.group(1)), "seconds": float(cpu.group(2)), "frames_per_sec": round(int(cpu.group(1)) / max(float(cpu.group(2)), 1e-9), 1),
                                 "cores": 1, "kind": "reference"} if cpu else None,
            "timed": "HIP events on the engine's stream around the batch's scoring launch + the search launch (features resident in HBM)"}
+    sc = re.search(r"of which scoring ([0-9.]+) ms", alog)
+    if sc and float(sc.group(1)) > 0:
+        # the two kernels of the leg: k_ps_cont_tr (float32 without FMA, two frames per packed operation: the packed non-FMA rate is
+        # half of MI355X_MICROARCH.md's 157.3 TFLOP/s, which counts an FMA as two) and k_psf_queue (the search: one workgroup per lane)
+        fr, sms, tms = int(dev.group(2)), float(sc.group(1)), float(dev.group(3))
+        flop = fr * 6144 * 8 * 39 * 4.0
+        pmc = os.path.join(ROOT, "profiles", "r4_pmc_ps.json")
+        traffic = None
+        if os.path.exists(pmc):
+            k = json.load(open(pmc))["kernels"].get("k_psf_queue<3>")
+            traffic = k["bytes_per_frame"] if k else None
+        srch_ms = tms - sms
+        alg = 1700 * 64 * 2 + 2 * 1500
+        out["roofline_scoring"] = {"kernel": "k_ps_cont_tr<8,39>", "bound": "valu-f32 (packed, no FMA)", "avg_launch_us": round(sms * 1e3, 1),
+                                   "achieved": round(flop / (sms * 1e-3) / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s",
+                                   "frac": round(flop / (sms * 1e-3) / 1e12 / 78.6, 4),
+                                   "algorithmic_flop_per_frame": 6144 * 8 * 39 * 4}
+        out["roofline_search"] = {"kernel": "k_psf_queue<3>", "bound": "hbm (64-byte channel records visited at random) / latency of a lane's phases",
+                                  "avg_launch_us": round(srch_ms * 1e3, 1), "us_per_lane_frame": round(srch_ms * 1e3 * lanes / fr, 1),
+                                  "algorithmic_bytes_per_frame": alg, "achieved": round(fr * alg / (srch_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
+                                  "unit": "GB/s", "frac": round(fr * alg / (srch_ms * 1e-3) / 1e9 / 8000.0, 4),
+                                  "traffic_bytes_per_frame": traffic,
+                                  "traffic_source": "profiles/r4_pmc_ps.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 256 utterances over 128 lanes)" if traffic else None,
+                                  "note": "algorithmic = ~1 700 active channels per frame (pocketsphinx's own count: 1 191 - 2 270 per frame) x a 64-byte "
+                                          "record read and written + the active senones' int16 scores"}
     assert same_h and same_s, "pocketsphinx first pass on the device differs from the unmodified pocketsphinx"
     return out
 
@@ -401,7 +426,7 @@ def main():
     ap.add_argument("--no-wide-beam", action="store_true", help="skip the configs[4] wide-beam leg")
     ap.add_argument("--wide-lanes", type=int, default=64, help="lanes of the wide-beam leg's engine")
     ap.add_argument("--wide-frames", type=int, default=40, help="nominal frames per utterance of the wide-beam leg (utterances follow LM sentences: about twice that)")
-    ap.add_argument("--ps-lanes", type=int, default=256, help="utterances (= lanes) of the pocketsphinx leg's batch")
+    ap.add_argument("--ps-lanes", type=int, default=512, help="lanes (persistent one-workgroup decoders, two per CU) the pocketsphinx leg runs the batch through as one queue")
     ap.add_argument("--only-scoring", action="store_true", help="only the scoring legs (PMC passes over the scoring kernels)")
     ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
     args = ap.parse_args()

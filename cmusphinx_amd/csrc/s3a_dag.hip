@@ -80,6 +80,16 @@ dg_find(const unsigned long long *keys, int32_t mask, unsigned long long key)
     return -1;
 }
 
+/* the entry / exit hashes are allocated for the engine's largest possible table (millions of entries); an utterance uses -- and
+ * k_dag_reset clears -- the power of two that its own entries need (monotone in n, so a bound on n bounds the slots) */
+__device__ __forceinline__ int32_t
+dg_eff_mask(int32_t h1mask, int32_t n_entry)
+{
+    int32_t m = 1024;
+    while (m < 2 * (n_entry + 4) && m - 1 < h1mask) m <<= 1;
+    return m - 1 < h1mask ? m - 1 : h1mask;
+}
+
 /* phases of one workgroup exchange data through global memory, much of it written by atomics (which live in L2):
  * release, barrier, acquire (the agent-scope fences write back / invalidate the CU's vector L1) */
 #define DG_BAR() do { __threadfence(); __syncthreads(); __threadfence(); } while (0)
@@ -186,6 +196,7 @@ k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_ut
         return;
     }
     const int32_t F1 = n_frm + 1;           /* start frames 0 .. n_frm */
+    const int32_t hmask = dg_eff_mask(G.h1mask, E);
     const int32_t *wid = L.tab.wid, *sf = L.tab.sf, *ef = L.tab.ef, *ascr = L.tab.ascr, *score = L.tab.score;
 
     /* ---- P1: nodes = distinct (start frame', word) ---- */
@@ -196,7 +207,7 @@ k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_ut
         L.sfp[i] = s; L.efp[i] = e;
         if (s > n_frm || e > n_frm || e < 0) { s_err = DG_E_TABLE; continue; }
         bool fresh;
-        const int32_t slot = dg_insert(L.h1key, G.h1mask, (unsigned long long)s * (unsigned long long)G.n_word + (unsigned long long)wid[i] + 1ull, &fresh);
+        const int32_t slot = dg_insert(L.h1key, hmask, (unsigned long long)s * (unsigned long long)G.n_word + (unsigned long long)wid[i] + 1ull, &fresh);
         if (slot < 0) { s_err = DG_E_CAP; continue; }
         L.eslot[i] = slot;
         atomicMin(&L.h1first[slot], i);
@@ -227,7 +238,7 @@ k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_ut
     for (int32_t k = tid; k < n_hyp; k += DG_T) {
         const int32_t hs = L.hyp_sf[k] == 0 ? 1 : L.hyp_sf[k];
         if (hs < 0 || hs > n_frm) continue;
-        const int32_t slot = dg_find(L.h1key, G.h1mask, (unsigned long long)hs * (unsigned long long)G.n_word + (unsigned long long)L.hyp_wid[k] + 1ull);
+        const int32_t slot = dg_find(L.h1key, hmask, (unsigned long long)hs * (unsigned long long)G.n_word + (unsigned long long)L.hyp_wid[k] + 1ull);
         if (slot >= 0) L.nkeep[L.h1node[slot]] = 1;
     }
     __shared__ int32_t s_root, s_end, s_fin;
@@ -263,7 +274,7 @@ k_dag_pass(DagShared G, const DagLane *__restrict__ lanes, WLm lm, int32_t do_ut
     for (int32_t i = tid; i < E; i += DG_T) {
         const int32_t p = L.h1node[L.eslot[i]];
         L.enode[i] = p;
-        const int32_t slot = dg_insert(L.h2key, G.h1mask, (unsigned long long)p * (unsigned long long)(G.F + 1) + (unsigned long long)L.efp[i] + 1ull, (bool *)NULL);
+        const int32_t slot = dg_insert(L.h2key, hmask, (unsigned long long)p * (unsigned long long)(G.F + 1) + (unsigned long long)L.efp[i] + 1ull, (bool *)NULL);
         if (slot < 0) { s_err = DG_E_CAP; continue; }
         L.eslot[i] = slot;                               /* (now the exit's slot) */
         atomicMax(&L.h2best[slot], wl_pack(score[i], (uint32_t)i));
@@ -580,7 +591,9 @@ k_dag_reset(DagShared G, const DagLane *__restrict__ lanes, int32_t use_active, 
     const DagLane &L = lanes[lane_ids ? lane_ids[blockIdx.y] : (int32_t)blockIdx.y];
     if (use_active && !L.io[DG_IO_ACTIVE]) return;
     const int32_t stride = gridDim.x * blockDim.x;
-    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= G.h1mask; i += stride) {
+    /* (use_active: the caller filled io[NENT]; else vithist_utt_end runs first in the pass and appends at most two entries) */
+    const int32_t hmask = dg_eff_mask(G.h1mask, use_active ? L.io[DG_IO_NENT] : L.tab.st[0] + 2);
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= hmask; i += stride) {
         L.h1key[i] = 0ull; L.h2key[i] = 0ull; L.h2best[i] = 0ull; L.h1first[i] = INT_MAX; L.h1last[i] = -1; L.h1node[i] = -1;
     }
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= G.bmask; i += stride) { L.bkey[i] = 0ull; L.bbest[i] = 0ull; L.bdstar[i] = -1; }

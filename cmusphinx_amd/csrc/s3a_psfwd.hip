@@ -1291,7 +1291,8 @@ struct s3a_psfwd_s {
     hipStream_t stream, stream_sc;          /* the search's stream; the scoring's when it runs beside the search (queue) */
     hipEvent_t ev0, ev1, ev_sc;
     int32_t *q_ready_d;
-    double last_ms;
+    double last_ms, last_score_ms;          /* the last decode: whole region; its scoring launches (0 when they ran beside the search) */
+    hipEvent_t ev_mid;
     /* host mirrors for s3a_psfwd_table */
     std::vector<int32_t> t_frame, t_wid, t_bp, t_score, t_sidx, t_realwid, t_bss, t_idx;
     std::vector<uint8_t> t_valid;
@@ -1336,6 +1337,7 @@ s3a_psfwd_free(s3a_psfwd_t *e)
     { void *qp[] = { e->q_next_d, e->q_nfr_d, e->q_res_d, e->q_row0_d, e->q_seg_d }; for (void *q : qp) if (q) (void)hipFree(q); }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
     if (e->ev_sc) (void)hipEventDestroy(e->ev_sc);
     if (e->stream_sc) (void)hipStreamDestroy(e->stream_sc);
     if (e->q_ready_d) (void)hipFree(e->q_ready_d);
@@ -1358,7 +1360,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     if (d->n_1ph > NT) { s3a_set_error("s3a_psfwd_init: %d single-phone words exceed the kernel's %d", d->n_1ph, NT); return NULL; }
     if (max_frames > 32767) { s3a_set_error("s3a_psfwd_init: max_frames %d (the reference's frame numbers are int16)", max_frames); return NULL; }
     s3a_psfwd_t *e = new s3a_psfwd_t();
-    e->lanes_d = NULL; e->lane_ids_d = NULL; e->stream = NULL; e->stream_sc = NULL; e->ev0 = e->ev1 = e->ev_sc = NULL; e->q_ready_d = NULL; e->last_ms = 0;
+    e->lanes_d = NULL; e->lane_ids_d = NULL; e->stream = NULL; e->stream_sc = NULL; e->ev0 = e->ev1 = e->ev_sc = NULL; e->q_ready_d = NULL; e->last_ms = 0; e->last_score_ms = 0; e->ev_mid = NULL;
     e->feat_d = NULL; e->feat_cap = 0; e->slot_row_d = NULL; e->slot_cap = 0; e->raw_d = NULL; e->raw_cap = 0; e->win = 0;
     e->q_next_d = e->q_nfr_d = e->q_res_d = NULL; e->q_row0_d = NULL; e->q_seg_d = NULL; e->q_cap = 0; e->q_n = 0; e->q_seg_cap = 256;
     PsfModel &M = e->M;
@@ -1415,7 +1417,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess
         || hipStreamCreateWithFlags(&e->stream_sc, hipStreamNonBlocking) != hipSuccess
         || hipEventCreateWithFlags(&e->ev_sc, hipEventDisableTiming) != hipSuccess || hipMalloc((void **)&e->q_ready_d, 4) != hipSuccess
-        || hipEventCreate(&e->ev1) != hipSuccess) { s3a_set_error("s3a_psfwd_init: stream / event creation failed"); s3a_psfwd_free(e); return NULL; }
+        || hipEventCreate(&e->ev1) != hipSuccess || hipEventCreate(&e->ev_mid) != hipSuccess) { s3a_set_error("s3a_psfwd_init: stream / event creation failed"); s3a_psfwd_free(e); return NULL; }
     UP(M.sseq, d->sseq, (size_t)d->n_sseq * NE);
     UP(M.tp, d->tp, (size_t)d->n_tmat * NE * (NE + 1));
     UP(M.w_basewid, d->w_basewid, W); UP(M.w_lmwid, d->w_lmwid, W);
@@ -1473,6 +1475,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
 
 extern "C" int32_t s3a_psfwd_n_lanes(const s3a_psfwd_t *e) { return e ? e->n_lanes : 0; }
 extern "C" double s3a_psfwd_last_decode_ms(const s3a_psfwd_t *e) { return e ? e->last_ms : 0.0; }
+extern "C" double s3a_psfwd_last_score_ms(const s3a_psfwd_t *e) { return e ? e->last_score_ms : 0.0; }
 
 #define LANECHK(fn) do { if (!e || lane < 0 || lane >= e->n_lanes) { s3a_set_error(fn ": bad lane"); return S3A_EINVAL; } } while (0)
 #define NE_LAUNCH(kern, grid, ...) do { if (e->M.n_emit == 3) hipLaunchKernelGGL(kern<3>, grid, dim3(NT), 0, e->stream, __VA_ARGS__); \
@@ -1769,6 +1772,7 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
     if (n_utt <= n_wg || !s3a_variants()->ps_overlap) {
         rc = s3a_ps_score_slots_dev(scorer, e->feat_d, e->slot_row_d, (int32_t)total, e->raw_d, e->stream);
         if (rc != S3A_OK) return rc;
+        HIPCHK(hipEventRecord(e->ev_mid, e->stream));
     }
     else {
         /* The scoring is float32 arithmetic that fills the vector units; the search is one workgroup per lane waiting on
@@ -1809,6 +1813,8 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev1));
     e->last_ms = ms;
+    e->last_score_ms = 0;
+    if (!Q.ready) { HIPCHK(hipEventElapsedTime(&ms, e->ev0, e->ev_mid)); e->last_score_ms = ms; }
     e->q_n = n_utt;
     for (int32_t z = 0; z < n_utt; z++) {
         const int32_t *r = &e->q_res_h[(size_t)z * PSF_QRES];

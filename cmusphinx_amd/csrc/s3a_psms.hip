@@ -28,6 +28,7 @@
 struct s3a_ps_dev_s {
     int32_t P;
     float *meanT, *precT, *det;
+    float *meanS, *precS; int32_t VP;       /* [codebook][density][veclen padded to 4]: k_ps_cont_tr (one feature stream) */
     int32_t *featlen, *featoff, *pdf, *mgau;
     uint32_t *tab;
     uint32_t tab_size;
@@ -185,16 +186,16 @@ k_ps_dist_slots(int32_t n_mgau, int32_t n_feat, int32_t nd, int32_t P, int32_t v
     const bool live = job < n_mgau * n_feat && d < nd;
     ps_f2 acc[PS_FT / 2];
 #pragma unroll
-    for (int t = 0; t < PS_FT / 2; t++) acc[t] = (ps_f2)(0.0f, 0.0f);
+    for (int t = 0; t < PS_FT / 2; t++) acc[t] = ps_f2{ 0.0f, 0.0f };
     if (live) {
         const int32_t flen = featlen[f], fo = featoff[f];
         const size_t base = ((size_t)m * veclen + fo) * P;
         const float dt = det[(size_t)job * P + d];
 #pragma unroll
-        for (int t = 0; t < PS_FT / 2; t++) acc[t] = (ps_f2)(dt, dt);
+        for (int t = 0; t < PS_FT / 2; t++) acc[t] = ps_f2{ dt, dt };
         for (int32_t i = 0; i < flen; i++) {
             const float mu = meanT[base + (size_t)i * P + d], pr = precT[base + (size_t)i * P + d];
-            const ps_f2 mu2 = (ps_f2)(mu, mu), pr2 = (ps_f2)(pr, pr);
+            const ps_f2 mu2 = ps_f2{ mu, mu }, pr2 = ps_f2{ pr, pr };
             const ps_f4 xa = x_s4[(fo + i) * (PS_FT / 4)], xb = x_s4[(fo + i) * (PS_FT / 4) + 1];
             const ps_f2 x[PS_FT / 2] = { xa.xy, xa.zw, xb.xy, xb.zw };
 #pragma unroll
@@ -290,13 +291,13 @@ k_ps_cont_slots(int32_t n_sen, int32_t nd, int32_t P, int32_t veclen, int32_t to
     {
         const float dt = live ? det[(size_t)m * P + d] : 0.0f;
 #pragma unroll
-        for (int t = 0; t < PS_CT / 2; t++) acc[t] = (ps_f2)(dt, dt);
+        for (int t = 0; t < PS_CT / 2; t++) acc[t] = ps_f2{ dt, dt };
     }
     if (live) {
         const size_t base = (size_t)m * veclen * P;
         for (int32_t i = 0; i < veclen; i++) {
             const float mu = meanT[base + (size_t)i * P + d], pr = precT[base + (size_t)i * P + d];
-            const ps_f2 mu2 = (ps_f2)(mu, mu), pr2 = (ps_f2)(pr, pr);
+            const ps_f2 mu2 = ps_f2{ mu, mu }, pr2 = ps_f2{ pr, pr };
 #pragma unroll
             for (int g = 0; g < PS_CT / 4; g++) {
                 const ps_f4 xv = x_s4[i * (PS_CT / 4) + g];
@@ -344,6 +345,153 @@ k_ps_cont_slots(int32_t n_sen, int32_t nd, int32_t P, int32_t veclen, int32_t to
     }
 }
 
+/*
+ * The same scores with the roles turned round: a LANE IS A FRAME (PT_FL frames per lane, two per packed float32 operation), the
+ * Gaussian is uniform over the wave.  k_ps_cont_slots gives every lane a Gaussian and broadcasts the frames' components from LDS:
+ * one 16-byte LDS read per eight packed operations on each of four SIMDs is all the LDS delivers, and the kernel stops at 0.29 of
+ * the packed-float32 rate.  Here a lane keeps its frames' vectors in VGPRs for the whole launch (PT_FL x veclen registers), the
+ * means and precisions come through the scalar cache (a Gaussian's parameters are contiguous: meanS / precS = [codebook][density]
+ * [veclen padded to 4]) and the inner loop touches no memory: per dimension and frame pair subtract, square, scale, accumulate.
+ * A lane then holds all densities of the codebook for its frames: the rank of a density (value descending, a tie in front of the
+ * entry it ties with: codeword descending) is counted in registers, the top-N mixture is summed in that order, and the int16
+ * scores leave through an LDS tile [frame][senone] so that a frame's row is written 128 bytes at a time.
+ * Arithmetic: k_ps_cont_slots's, value for value (same operations on the same operands in the same order).
+ */
+#ifndef PT_FL
+#define PT_FL 2         /* frames per lane: one packed pair (78 registers of features: four waves per SIMD hide the latency of the dependent operations) */
+#endif
+#define PT_SG 64        /* senones per workgroup (the tile's row: 128 bytes of int16) */
+template <int ND, int VL>
+__global__ void __launch_bounds__(PSB)
+k_ps_cont_tr(int32_t n_sen, int32_t P, int32_t VP, int32_t topn, int32_t aw,
+             const float *__restrict__ meanS, const float *__restrict__ precS, const float *__restrict__ det,
+             const int32_t *__restrict__ pdf, LogAddShifted la, const float *__restrict__ feat,
+             const int32_t *__restrict__ slot_row, int32_t n_slots, int16_t *out)
+{
+    constexpr int TF = 64 * PT_FL;                  /* frames of a workgroup: all four waves take the same frames, other senones */
+    __shared__ int16_t tile[TF][PT_SG + 2];
+    __shared__ float dvs[ND][PT_FL][PSB];          /* a thread's densities of the senone in hand (private slots) */
+    __shared__ int32_t s_row[TF];
+    const int32_t q0 = blockIdx.y * TF, s0 = blockIdx.x * PT_SG, lane = threadIdx.x & 63,
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     /* (uniform: the parameter addresses below are scalar) */
+    for (int32_t i = threadIdx.x; i < TF; i += PSB) s_row[i] = (q0 + i < n_slots) ? slot_row[q0 + i] : -1;
+    __syncthreads();
+    /* this lane's frames: lane + 64 j, j < PT_FL */
+    ps_f2 x[PT_FL / 2][VL];                         /* frames (lane + 128 j, lane + 128 j + 64) side by side */
+#pragma unroll
+    for (int j = 0; j < PT_FL / 2; j++) {
+        const int32_t r0 = s_row[lane + 128 * j], r1 = s_row[lane + 128 * j + 64];
+#pragma unroll
+        for (int i = 0; i < VL; i++) x[j][i] = ps_f2{ r0 >= 0 ? feat[(size_t)r0 * VL + i] : 0.0f, r1 >= 0 ? feat[(size_t)r1 * VL + i] : 0.0f };      /* (a cast of (a, b) would splat b) */
+    }
+    for (int32_t sl = wave; sl < PT_SG; sl += PSB / 64) {
+        const int32_t m = s0 + sl;                  /* (uniform over the wave) */
+        if (m >= n_sen) break;
+        /* one Gaussian at a time (the loop over the densities stays a loop: eight Gaussians' parameters unrolled side by side
+         * want 640 scalar registers), its parameters eight dimensions ahead of the arithmetic: the scalar loads of chunk c + 1
+         * are issued before chunk c is computed (the scheduling barriers keep them there) */
+#pragma unroll 1
+        for (int d = 0; d < ND; d++) {
+            const float *mu = meanS + ((size_t)m * ND + d) * VP, *pr = precS + ((size_t)m * ND + d) * VP;
+            const float dt = det[(size_t)m * P + d];
+            ps_f2 acc[PT_FL / 2];
+#pragma unroll
+            for (int j = 0; j < PT_FL / 2; j++) acc[j] = ps_f2{ dt, dt };
+            constexpr int NC = (VL + 7) / 8;
+            float pm[2][8], pp[2][8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { pm[0][k] = mu[k]; pp[0][k] = pr[k]; }       /* (VP >= 8) */
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c + 1 < NC) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) if ((c + 1) * 8 + k < ((VL + 3) & ~3)) { pm[(c + 1) & 1][k] = mu[(c + 1) * 8 + k]; pp[(c + 1) & 1][k] = pr[(c + 1) * 8 + k]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                /* the chunk in phases over independent values (a dependent chain of four operations per value would wait for
+                 * the pipeline at every step); only the accumulation keeps its order: dimension by dimension */
+                ps_f2 t[8][PT_FL / 2];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (c * 8 + k < VL) {
+                        const float mi = pm[c & 1][k];
+                        const ps_f2 mu2 = ps_f2{ mi, mi };
+#pragma unroll
+                        for (int j = 0; j < PT_FL / 2; j++) t[k][j] = x[j][c * 8 + k] - mu2;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (c * 8 + k < VL) {
+#pragma unroll
+                        for (int j = 0; j < PT_FL / 2; j++) t[k][j] = t[k][j] * t[k][j];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (c * 8 + k < VL) {
+                        const float pi = pp[c & 1][k];
+                        const ps_f2 pr2 = ps_f2{ pi, pi };
+#pragma unroll
+                        for (int j = 0; j < PT_FL / 2; j++) t[k][j] = t[k][j] * pr2;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (c * 8 + k < VL) {
+#pragma unroll
+                        for (int j = 0; j < PT_FL / 2; j++) acc[j] = acc[j] - t[k][j];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < PT_FL / 2; j++) { dvs[d][2 * j][threadIdx.x] = acc[j].x; dvs[d][2 * j + 1][threadIdx.x] = acc[j].y; }
+        }
+        float dval[ND][PT_FL];                      /* (a thread reads back what it wrote: no barrier) */
+#pragma unroll
+        for (int d = 0; d < ND; d++)
+#pragma unroll
+            for (int j = 0; j < PT_FL; j++) dval[d][j] = dvs[d][j][threadIdx.x];
+        int32_t pw[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) pw[d] = pdf[(size_t)m * ND + d];
+#pragma unroll
+        for (int j = 0; j < PT_FL; j++) {
+            /* ranks, then the mixture over the ranks 0 .. topn - 1 in that order */
+            int32_t rank[ND];
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                int32_t r = 0;
+#pragma unroll
+                for (int k = 0; k < ND; k++) r += (dval[k][j] > dval[d][j] || (dval[k][j] == dval[d][j] && k > d)) ? 1 : 0;
+                rank[d] = topn < ND ? r : d;
+            }
+            int32_t fscr = 0;
+            for (int32_t r = 0; r < topn; r++) {
+                float v = 0.0f;
+                int32_t w = 0;
+#pragma unroll
+                for (int d = 0; d < ND; d++) if (rank[d] == r) { v = dval[d][j]; w = pw[d]; }
+                const int32_t term = (((int32_t)v + ((1 << PS_SHIFT) - 1)) >> PS_SHIFT) - w;
+                fscr = r == 0 ? term : la(fscr, term);
+            }
+            int32_t tot = -fscr;
+            tot /= aw;
+            tile[lane + 64 * j][sl] = (int16_t)min(max(tot, -32768), 32767);
+        }
+    }
+    __syncthreads();
+    /* a frame's row of the tile: PT_SG int16 = 128 bytes, four bytes per thread, 32 threads per row */
+    const int32_t ns = n_sen - s0 < PT_SG ? n_sen - s0 : PT_SG;
+    for (int32_t e = threadIdx.x; e < TF * (PT_SG / 2); e += PSB) {
+        const int32_t fr = e / (PT_SG / 2), c = (e - fr * (PT_SG / 2)) * 2;
+        if (s_row[fr] < 0) continue;
+        int16_t *o = out + (size_t)(q0 + fr) * n_sen + s0 + c;
+        if (c + 1 < ns && (((size_t)(q0 + fr) * n_sen + s0 + c) & 1) == 0) *(int32_t *)o = (int32_t)(uint16_t)tile[fr][c] | ((int32_t)tile[fr][c + 1] << 16);
+        else { if (c < ns) o[0] = tile[fr][c]; if (c + 1 < ns) o[1] = tile[fr][c + 1]; }
+    }
+}
+
 /* internal (s3a_internal.h): feat_dev [rows][veclen], slot_row_dev [n_slots], raw_dev [n_slots][n_sen], on `stream` */
 extern "C" int32_t
 s3a_ps_score_slots_dev(s3a_ps_mgau_t *ps, const float *feat_dev, const int32_t *slot_row_dev, int32_t n_slots,
@@ -369,6 +517,12 @@ s3a_ps_score_slots_dev(s3a_ps_mgau_t *ps, const float *feat_dev, const int32_t *
     }
     LogAddShifted la = { dv->tab, dv->tab_size, dv->lm_zero };
     const int64_t items = (int64_t)M * F * P;
+    if (ps->one_to_one && F == 1 && nd == 8 && ps->veclen == 39 && ps->topn <= nd && M == S && dv->meanS && !s3a_variants()->ps_score_by_gaussian) {
+        hipLaunchKernelGGL((k_ps_cont_tr<8, 39>), dim3((S + PT_SG - 1) / PT_SG, (n_slots + 64 * PT_FL - 1) / (64 * PT_FL)), dim3(PSB), 0, st, S, P,
+                           dv->VP, ps->topn, ps->aw, dv->meanS, dv->precS, dv->det, dv->pdf, la, feat_dev, slot_row_dev, n_slots, raw_dev);
+        HIPCHK(hipGetLastError());
+        return S3A_OK;
+    }
     if (ps->one_to_one && F == 1 && P >= 2 && ps->topn <= 4 && ps->topn <= nd && M == S && (size_t)PS_CT * ps->veclen * 4 <= 32 * 1024) {
         hipLaunchKernelGGL(k_ps_cont_slots, dim3((uint32_t)((items + PSB - 1) / PSB), (n_slots + PS_CT - 1) / PS_CT), dim3(PSB),
                            (size_t)PS_CT * ps->veclen * 4 + 16, st, S, nd, P, ps->veclen, ps->topn, ps->aw, dv->meanT, dv->precT, dv->det,
@@ -432,6 +586,20 @@ s3a_ps_dev_create(s3a_ps_mgau_t *ps)
     HIPCHK(hipMemcpy(dv->meanT, mt.data(), nT * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dv->precT, pt.data(), nT * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dv->det, dt.data(), dt.size() * 4, hipMemcpyHostToDevice));
+    if (F == 1) {           /* a Gaussian's parameters contiguous, for the kernel that reads them through the scalar cache */
+        const int32_t VP = (D + 3) & ~3;
+        std::vector<float> ms((size_t)M * nd * VP + 64, 0.0f), pss((size_t)M * nd * VP + 64, 0.0f);
+        for (int32_t m = 0; m < M; m++)
+            for (int32_t d = 0; d < nd; d++)
+                for (int32_t i = 0; i < D; i++) {
+                    ms[((size_t)m * nd + d) * VP + i] = ps->mean[((size_t)m * nd + d) * D + i];
+                    pss[((size_t)m * nd + d) * VP + i] = ps->prec[((size_t)m * nd + d) * D + i];
+                }
+        dv->VP = VP;
+        DM(dv->meanS, ms.size() * 4); DM(dv->precS, pss.size() * 4);
+        HIPCHK(hipMemcpy(dv->meanS, ms.data(), ms.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dv->precS, pss.data(), pss.size() * 4, hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemcpy(dv->featlen, ps->featlen, (size_t)F * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dv->featoff, ps->featoff, (size_t)(F + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dv->pdf, ps->pdf, (size_t)S * F * nd * 4, hipMemcpyHostToDevice));
@@ -458,7 +626,7 @@ s3a_ps_dev_destroy(s3a_ps_mgau_t *ps)
 {
     s3a_ps_dev_s *dv = ps ? ps->dev : NULL;
     if (!dv) return;
-    void *ptrs[] = { dv->meanT, dv->precT, dv->det, dv->featlen, dv->featoff, dv->pdf, dv->mgau, dv->tab,
+    void *ptrs[] = { dv->meanS, dv->precS, dv->meanT, dv->precT, dv->det, dv->featlen, dv->featoff, dv->pdf, dv->mgau, dv->tab,
                      dv->sen_active, dv->mgau_active, dv->feat, dv->dist, dv->dist_id, dv->scr, dv->best, dv->out };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (dv->bdist) (void)hipFree(dv->bdist);

@@ -241,6 +241,7 @@ _SIGS = {
     "s3a_psfwd_get_sp_ssid": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_psfwd_set_sp_ssid": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_psfwd_last_decode_ms": (C.c_double, [C.c_void_p]),
+    "s3a_psfwd_last_score_ms": (C.c_double, [C.c_void_p]),
     "s3a_uttdec_shape": (C.c_int32, [C.c_void_p] + [C.POINTER(C.c_int32)] * 6),
     "s3a_uttdec_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_hyp_var": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -1344,7 +1345,7 @@ def dag_cfg(b, keep, bestpathlw=None, min_endfr=None, maxedge=None, maxlmop=None
 
 class Variants(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("scan_chained", "calls_by_copy", "batch_no_shared", "batch_no_multi",
-                                         "no_frame_sync_kernel", "score_nt", "score_fpc", "ps_overlap")]
+                                         "no_frame_sync_kernel", "score_nt", "score_fpc", "ps_overlap", "ps_score_by_gaussian")]
 
 
 def set_variants(**kw):

@@ -1097,6 +1097,7 @@ int32_t s3a_psfwd_table(s3a_psfwd_t *e, int32_t lane, s3a_psfwd_table_t *out);
  * exit's path score */
 int32_t s3a_psfwd_hyp(s3a_psfwd_t *e, int32_t lane, int32_t *out_score, s3a_psfwd_seg_t *seg, int32_t max_seg);
 double  s3a_psfwd_last_decode_ms(const s3a_psfwd_t *e);
+double  s3a_psfwd_last_score_ms(const s3a_psfwd_t *e);     /* of it, the scoring launches (s3a_psfwd_decode_queue; 0 when they ran beside the search) */
 
 /* ===================================================================== */
 /* Kernel variants that are otherwise chosen from the model shape / list sizes.  Every variant gives the same bits;  */
@@ -1111,6 +1112,7 @@ typedef struct {
     int32_t no_frame_sync_kernel;   /* single-frame scoring through the general kernel */
     int32_t score_nt, score_fpc;    /* whole-utterance scoring: workgroup size (256 / 512 / 1024; 0 = 512), frames per chunk (0 = chosen) */
     int32_t ps_overlap;             /* s3a_psfwd_decode_queue: score the queue's later utterances BESIDE the search (second stream) instead of before it */
+    int32_t ps_score_by_gaussian;   /* pocketsphinx batch scoring: the lane-per-Gaussian kernel (k_ps_cont_slots) instead of lane-per-frame */
 } s3a_variants_t;
 void    s3a_variants_default(s3a_variants_t *v);
 int32_t s3a_set_variants(const s3a_variants_t *v);

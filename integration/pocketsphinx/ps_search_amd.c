@@ -288,6 +288,7 @@ ps_amd_decode_cep_batch(ps_decoder_t *ps, int n_utt, mfcc_t ***cep, const int *n
         for (z = 0; z < n_utt; z++) tot += nfr[z];
         E_INFO("batch of %d utterances, %d frames: %.2f ms on the device (scoring + search; %.0f frames/s)%s\n", n_utt, tot, ms,
                ms > 0 ? tot / (ms * 1e-3) : 0.0, queue ? " [queue]" : "");
+        if (queue) E_INFO("of which scoring %.2f ms\n", s3a_psfwd_last_score_ms(b->e));
     }
     for (z = 0; z < n_utt; z++) {
         static s3a_psfwd_seg_t seg[4096];

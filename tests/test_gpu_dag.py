@@ -191,11 +191,24 @@ def test_lattice_files_from_the_device_lattice(task, lanes, fmt, extra, tmp_path
             assert lib_htk[k] == lat_ref[k], k
 
 
-# N-best lists (-nbestdir): the reference's own nbest_search (astar.c:656-716) crashes in every build for a 64-bit machine --
-# it calls fopen_comp without a prototype (no pio.h in astar.c), the FILE * comes back truncated to an int and the first
-# fprintf faults (sphinx3_decode -nbestdir ... on tidigits and on RM1: SIGSEGV in nbest_search) -- so there is no reference
-# output to compare with.  The drop-in hands the reference's nbest_impl the dag_t poured from the device's lattice, the one the
-# lattice tests above check link for link.
+@pytest.mark.parametrize("task,lanes,extra", [("tidigits", "8", []), ("rm1", "20", ["-bestpath", "1"])])
+def test_nbest_lists_on_the_device_lattice(task, lanes, extra, tmp_path):
+    """-nbestdir: the reference's own A* (astar.c nbest_search through srch_TST_nbest_impl: remove unreachable nodes, bypass
+    fillers, heuristic scores, search) on a dag_t poured from the device's lattice: the N-best files are the unmodified
+    reference's, line for line.  (The reference's astar.c needs its own pio.h on the compiler's command line to run on a
+    64-bit machine at all: oracle/Makefile.)"""
+    base = tidigits_args() if task == "tidigits" else rm_args()
+    outs = {}
+    for tag, exe, env in (("ref", REFDEC, None), ("gpu", TST, dict(os.environ, S3A_UTT=lanes))):
+        d = tmp_path / f"nb_{tag}"
+        d.mkdir()
+        outs[tag] = run(exe, base + extra + ["-nbestdir", str(d), "-nbest", "20", "-nbestext", "nbest"], tmp_path, tag, env=env) + (_files(str(d)),)
+    ref, gpu = outs["ref"], outs["gpu"]
+    assert gpu[0] == ref[0] and gpu[1] == ref[1]
+    assert len(ref[3]) == (31 if task == "tidigits" else 20) and sorted(ref[3]) == sorted(gpu[3])
+    assert any(v.count(b"\nT ") > 3 for v in ref[3].values())          # (lists with several hypotheses)
+    for k in sorted(ref[3]):
+        assert gpu[3][k] == ref[3][k], k
 
 
 @pytest.mark.parametrize("task,lanes,queue,extra", [("tidigits", "4", "31", []), ("tidigits", "7", "16", ["-bestpathlw", "14", "-min_endfr", "1"]),
