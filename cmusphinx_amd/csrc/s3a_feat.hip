@@ -21,7 +21,9 @@
 #define FTILE 64            /* frames per LDS tile in the statistics kernel */
 #define FMAXC 64            /* cepstral dimensions supported */
 
-/* stats[0..cs) = mean, [cs..2cs) = inverse standard deviation (1 if no varnorm), [2cs] = AGC maximum */
+/* stats[0..cs) = mean, [cs..2cs) = inverse standard deviation (1 if no varnorm), [2cs] = AGC maximum.
+ * cmn == 2 (-cmn prior, cmn_prior.c:143-170): every frame loses the PRIOR mean stats[3 FMAXC ..) and the running sums
+ * stats[4 FMAXC ..) (cmn_t.sum, filled by the caller) take the padded frames in frame order; they are left there for the caller */
 __global__ void __launch_bounds__(256)
 k_feat_stats(const float *__restrict__ cep, int32_t n, int32_t cs, int32_t cmn, int32_t varnorm,
              int32_t agc_max, float *stats)
@@ -30,7 +32,7 @@ k_feat_stats(const float *__restrict__ cep, int32_t n, int32_t cs, int32_t cmn, 
     const int32_t nfr = n + 2 * FWIN, i = threadIdx.x;
     float mean = 0.0f, inv = 1.0f;
     if (cmn) {
-        float sum = 0.0f;
+        float sum = (cmn == 2 && i < cs) ? stats[4 * FMAXC + i] : 0.0f;
         for (int32_t f0 = 0; f0 < nfr; f0 += FTILE) {
             for (int32_t k = threadIdx.x; k < FTILE * cs; k += 256) {
                 const int32_t f = f0 + k / cs, d = k % cs;
@@ -42,7 +44,8 @@ k_feat_stats(const float *__restrict__ cep, int32_t n, int32_t cs, int32_t cmn, 
             __syncthreads();
         }
         mean = sum / nfr;
-        if (varnorm) {
+        if (cmn == 2 && i < cs) { stats[4 * FMAXC + i] = sum; mean = stats[3 * FMAXC + i]; }
+        if (varnorm && cmn != 2) {
             float var = 0.0f;
             for (int32_t f0 = 0; f0 < nfr; f0 += FTILE) {
                 for (int32_t k = threadIdx.x; k < FTILE * cs; k += 256) {
@@ -61,7 +64,7 @@ k_feat_stats(const float *__restrict__ cep, int32_t n, int32_t cs, int32_t cmn, 
     __syncthreads();
     if (agc_max && i == 0) {
         /* maximum of the NORMALISED c0 over the padded frames (clamped copies cannot change a maximum) */
-        const bool vn = cmn && varnorm;
+        const bool vn = cmn == 1 && varnorm;
         float mx = -INFINITY;
         for (int32_t f = 0; f < n; f++) {
             float v = cep[(size_t)f * cs];
@@ -81,7 +84,7 @@ k_feat_apply(const float *__restrict__ cep, int32_t n, int32_t cs, int32_t cmn, 
     if (k >= n * cs) return;
     const int32_t t = k / cs, i = k - t * cs;
     const float mean = stats[i], inv = stats[cs + i], mx = (i == 0) ? stats[2 * cs] : 0.0f;
-    const bool vn = cmn && varnorm;
+    const bool vn = cmn == 1 && varnorm;
     float c[7];
 #pragma unroll
     for (int o = -3; o <= 3; o++) {
@@ -148,9 +151,10 @@ s3a_feat_1s_c_d_dd(const float *cep, int32_t n_frames, int32_t cepsize, int32_t 
  * leaving the device: k_fe_frames -> k_feat_stats -> k_feat_apply on the front end's stream.  *feat_dev_out: rows of
  * *feat_stride = 4 * ceil(3 * cepsize / 4) floats, zero padded; the caller releases it with s3a_dev_free.
  */
-extern "C" int32_t
-s3a_audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t drop_partial_frame, int32_t cmn_current,
-                      int32_t varnorm, int32_t agc_max, float **feat_dev_out, int32_t *n_frames, int32_t *feat_stride)
+static int32_t
+audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t drop_partial_frame, int32_t cmn_current,
+                  int32_t varnorm, int32_t agc_max, float **feat_dev_out, int32_t *n_frames, int32_t *feat_stride,
+                  const float *prior_mean, float *prior_sum)
 {
     if (!fe || !spch || !feat_dev_out || !n_frames || !feat_stride || nsamps <= 0) return S3A_EINVAL;
     const int32_t cs = s3a_fe_output_size(fe), fsize = s3a_fe_frame_size(fe), fshift = s3a_fe_frame_shift(fe);
@@ -162,7 +166,7 @@ s3a_audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t
     hipStream_t st = (hipStream_t)s3a_fe_stream(fe);
     int16_t *spch_d = NULL;
     float *cep_d = NULL, *out = NULL;
-    const size_t row = (size_t)*feat_stride, out_floats = (size_t)n * row + 2 * FMAXC + 8;     /* (+ the statistics behind the rows) */
+    const size_t row = (size_t)*feat_stride, out_floats = (size_t)n * row + 5 * FMAXC + 8;     /* (+ the statistics behind the rows) */
     int32_t rc = S3A_OK, k = 0;
     if (hipMalloc((void **)&spch_d, (size_t)nsamps * 2) != hipSuccess || hipMalloc((void **)&cep_d, (size_t)n_all * cs * 4) != hipSuccess
         || hipMalloc((void **)&out, out_floats * 4) != hipSuccess) {
@@ -172,6 +176,9 @@ s3a_audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t
     if (rc == S3A_OK && (hipMemsetAsync(out, 0, out_floats * 4, st) != hipSuccess
                          || hipMemcpyAsync(spch_d, spch, (size_t)nsamps * 2, hipMemcpyHostToDevice, st) != hipSuccess)) rc = S3A_EHIP;
     if (rc == S3A_OK) rc = s3a_fe_process_utt_dev(fe, spch_d, nsamps, cep_d, n_all, &k, (void *)st);
+    if (rc == S3A_OK && prior_mean
+        && (hipMemcpyAsync(out + (size_t)n * row + 3 * FMAXC, prior_mean, (size_t)cs * 4, hipMemcpyHostToDevice, st) != hipSuccess
+            || hipMemcpyAsync(out + (size_t)n * row + 4 * FMAXC, prior_sum, (size_t)cs * 4, hipMemcpyHostToDevice, st) != hipSuccess)) rc = S3A_EHIP;
     if (rc == S3A_OK) {
         float *stats = out + (size_t)n * row;
         hipLaunchKernelGGL(k_feat_stats, dim3(1), dim3(256), 0, st, cep_d, n, cs, cmn_current, varnorm, agc_max, stats);
@@ -179,10 +186,31 @@ s3a_audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t
                            stats, out, *feat_stride);
         if (hipGetLastError() != hipSuccess) rc = S3A_EHIP;
     }
+    if (rc == S3A_OK && prior_sum && hipMemcpyAsync(prior_sum, out + (size_t)n * row + 4 * FMAXC, (size_t)cs * 4, hipMemcpyDeviceToHost, st) != hipSuccess) rc = S3A_EHIP;
     if (hipStreamSynchronize(st) != hipSuccess && rc == S3A_OK) rc = S3A_EHIP;
     if (spch_d) (void)hipFree(spch_d);
     if (cep_d) (void)hipFree(cep_d);
     if (rc != S3A_OK) { if (out) (void)hipFree(out); return rc; }
     *feat_dev_out = out;
     return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t drop_partial_frame, int32_t cmn_current,
+                      int32_t varnorm, int32_t agc_max, float **feat_dev_out, int32_t *n_frames, int32_t *feat_stride)
+{
+    return audio_to_feat_dev(fe, spch, nsamps, drop_partial_frame, cmn_current ? 1 : 0, varnorm, agc_max, feat_dev_out, n_frames, feat_stride,
+                             (const float *)NULL, (float *)NULL);
+}
+
+/* -cmn prior on whole utterances (feat_s2mfc2feat_block_utt -> feat_cmn -> cmn_prior, cmn_prior.c:143-170): every frame of the
+ * padded utterance loses cmn_mean[] (the mean the decoder has learnt from EARLIER utterances), and cmn_sum[] (cmn_t.sum) takes
+ * the padded frames in frame order, float32, starting from the value handed in.  The caller owns the state between utterances:
+ * nframe += n_frames + 6, then cmn_prior's window shift and cmn_prior_update (cmn_prior.c:95-141). */
+extern "C" int32_t
+s3a_audio_to_feat_dev_prior(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t drop_partial_frame, const float *cmn_mean,
+                            float *cmn_sum, int32_t agc_max, float **feat_dev_out, int32_t *n_frames, int32_t *feat_stride)
+{
+    if (!cmn_mean || !cmn_sum) return S3A_EINVAL;
+    return audio_to_feat_dev(fe, spch, nsamps, drop_partial_frame, 2, 0, agc_max, feat_dev_out, n_frames, feat_stride, cmn_mean, cmn_sum);
 }

@@ -330,6 +330,13 @@ int32_t s3a_feat_1s_c_d_dd_dev(const float *cep, int32_t n_frames, int32_t cepsi
 int32_t s3a_audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t drop_partial_frame,
                               int32_t cmn_current, int32_t varnorm, int32_t agc_max, float **feat_dev_out,
                               int32_t *n_frames, int32_t *feat_stride);
+/* the same with -cmn prior (cmn_prior.c:143-170 on the whole padded utterance): every frame loses cmn_mean[cepsize] (cmn_t.cmn_mean:
+ * what the decoder learnt from earlier utterances); cmn_sum[cepsize] (cmn_t.sum) comes in, takes the padded frames in frame
+ * order (float32) and goes out.  The state between utterances stays the caller's (cmn_t.nframe += n_frames + 6, the window
+ * shift, cmn_prior_update: cmn_prior.c:95-141). */
+int32_t s3a_audio_to_feat_dev_prior(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t drop_partial_frame,
+                                    const float *cmn_mean, float *cmn_sum, int32_t agc_max, float **feat_dev_out,
+                                    int32_t *n_frames, int32_t *feat_stride);
 
 /* ------------------------------------------------------------------ */
 /* The multi-stream ("s3.0") senone scorer: -senmgau .s3cont. / .semi. */

@@ -36,6 +36,8 @@
 #include <math.h>
 #include "pio.h"
 #include "genrand.h"
+#include "cmn.h"
+#include "fixpoint.h"
 #include "logs3.h"
 #include "byteorder.h"
 #include "s3_decode.h"
@@ -147,6 +149,49 @@ utt_decode_adapt(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
     utt_decode(data, ur, sf, ef, uttid);
 }
 
+/* the lextrees the search walks now (the CURRENT LM's unigram trees + the filler trees), flattened */
+static void
+flatten_current_trees(srch_TST_graph_t *tstg)
+{
+    int32 i;
+    g_ntree = 2 * tstg->n_lextree;
+    g_flat = ckd_calloc(g_ntree, sizeof(*g_flat));
+    for (i = 0; i < g_ntree; i++) {
+        lextree_t *lt = (i < tstg->n_lextree) ? tstg->curugtree[i] : tstg->fillertree[i - tstg->n_lextree];
+        g_flat[i] = flatten_tree(lt);
+        if (g_flat[i]->n_node > g_max_node) g_max_node = g_flat[i]->n_node;
+    }
+}
+
+/* ... and the device search space made of them (g_tm, the senone-sequence tables and the model's stream exist) */
+static s3a_lexsearch_t *
+make_lexsearch(mdef_t *mdef, dict2pid_t *d2p)
+{
+    const int32 **ssid = ckd_calloc(g_ntree, sizeof(void *)), **tm = ckd_calloc(g_ntree, sizeof(void *));
+    const int32 **wid = ckd_calloc(g_ntree, sizeof(void *)), **prob = ckd_calloc(g_ntree, sizeof(void *));
+    const int32 **coff = ckd_calloc(g_ntree, sizeof(void *)), **ch = ckd_calloc(g_ntree, sizeof(void *));
+    const int32 **lro = ckd_calloc(g_ntree, sizeof(void *)), **lr = ckd_calloc(g_ntree, sizeof(void *));
+    const int32 **root = ckd_calloc(g_ntree, sizeof(void *));
+    const uint8 **comp = ckd_calloc(g_ntree, sizeof(void *));
+    const int16 **lc = ckd_calloc(g_ntree, sizeof(void *));
+    int32 *nn = ckd_calloc(g_ntree, 4), *nlc = ckd_calloc(g_ntree, 4), *nroot = ckd_calloc(g_ntree, 4), i;
+    s3a_lexsearch_t *ls;
+    for (i = 0; i < g_ntree; i++) {
+        flat_t *f = g_flat[i];
+        nn[i] = f->n_node; ssid[i] = f->ssid; tm[i] = f->tmatid; comp[i] = f->composite;
+        wid[i] = f->wid; prob[i] = f->prob; coff[i] = f->child_off; ch[i] = f->child;
+        nlc[i] = f->n_lc; lc[i] = f->lc; lro[i] = f->lcroot_off; lr[i] = f->lcroot;
+        nroot[i] = f->n_root; root[i] = f->root;
+    }
+    ls = s3a_lexsearch_init(g_ntree, nn, ssid, tm, comp, wid, prob, coff, ch, nlc, lc, lro, lr,
+                            nroot, root, g_tm, g_sseq_flat, mdef_n_sseq(mdef), g_comsseq_flat,
+                            d2p->n_comsseq, g_n_comstate, g_comstate_off, g_comstate,
+                            s3a_mgau_stream(g_gm));
+    ckd_free(ssid); ckd_free(tm); ckd_free(wid); ckd_free(prob); ckd_free(coff); ckd_free(ch); ckd_free(lro); ckd_free(lr);
+    ckd_free(root); ckd_free(comp); ckd_free(lc); ckd_free(nn); ckd_free(nlc); ckd_free(nroot);
+    return ls;
+}
+
 static void
 backend_init(kb_t *kb, srch_TST_graph_t *tstg)
 {
@@ -161,16 +206,12 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
                 "only composite triphones (the reference's default) are supported\n");
     if (kb->pl->pheurtype != 0 && !getenv("S3A_UTT"))
         E_FATAL("tst shim: -pheurtype > 0 is served by the whole-utterance engine only (S3A_UTT=lanes)\n");
-    if (kbcore_lmset(kbc)->n_lm != 1)
-        E_FATAL("tst shim: exactly one LM is supported\n");
+    /* several LMs (-lmctlfn; every LM has unigram lextrees of its own, srch_time_switch_tree.c:260-330): the whole-utterance
+     * mode keeps a search space and engines per LM and switches between utterances (s3amd_uttmode.h) */
+    if (kbcore_lmset(kbc)->n_lm != 1 && !getenv("S3A_UTT"))
+        E_FATAL("tst shim: several LMs (-lmctlfn) are served by the whole-utterance engine only (S3A_UTT=lanes)\n");
 
-    g_ntree = 2 * tstg->n_lextree;
-    g_flat = ckd_calloc(g_ntree, sizeof(*g_flat));
-    for (i = 0; i < g_ntree; i++) {
-        lextree_t *lt = (i < tstg->n_lextree) ? tstg->curugtree[i] : tstg->fillertree[i - tstg->n_lextree];
-        g_flat[i] = flatten_tree(lt);
-        if (g_flat[i]->n_node > g_max_node) g_max_node = g_flat[i]->n_node;
-    }
+    flatten_current_trees(tstg);
     g_tp_flat = ckd_calloc(tmat->n_tmat * ne * (ne + 1), 4);
     for (i = 0; i < tmat->n_tmat; i++)
         for (j = 0; j < ne; j++)
@@ -205,14 +246,6 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
 
     {
         cmd_ln_t *config = kbcore_config(kbc);
-        const int32 **ssid = ckd_calloc(g_ntree, sizeof(void *)), **tm = ckd_calloc(g_ntree, sizeof(void *));
-        const int32 **wid = ckd_calloc(g_ntree, sizeof(void *)), **prob = ckd_calloc(g_ntree, sizeof(void *));
-        const int32 **coff = ckd_calloc(g_ntree, sizeof(void *)), **ch = ckd_calloc(g_ntree, sizeof(void *));
-        const int32 **lro = ckd_calloc(g_ntree, sizeof(void *)), **lr = ckd_calloc(g_ntree, sizeof(void *));
-        const int32 **root = ckd_calloc(g_ntree, sizeof(void *));
-        const uint8 **comp = ckd_calloc(g_ntree, sizeof(void *));
-        const int16 **lc = ckd_calloc(g_ntree, sizeof(void *));
-        int32 *nn = ckd_calloc(g_ntree, 4), *nlc = ckd_calloc(g_ntree, 4), *nroot = ckd_calloc(g_ntree, 4);
         if (s3a_device_count() < 1)
             E_FATAL("tst shim: no GPU; libcmusphinx_amd has no CPU fallback\n");
         if (kbcore_svq(kbc) || kbcore_gs(kbc) || !kbcore_mgau(kbc))
@@ -241,20 +274,10 @@ backend_init(kb_t *kb, srch_TST_graph_t *tstg)
         g_cs = s3a_comsen_init(g_n_comstate, g_comstate_off, g_comstate, d2p->comwt);
         if (!g_cs) die("s3a_comsen_init");
         g_tm = s3a_tmat_init_logs3(g_tp_flat, tmat->n_tmat, ne);
-        for (i = 0; i < g_ntree; i++) {
-            flat_t *f = g_flat[i];
-            nn[i] = f->n_node; ssid[i] = f->ssid; tm[i] = f->tmatid; comp[i] = f->composite;
-            wid[i] = f->wid; prob[i] = f->prob; coff[i] = f->child_off; ch[i] = f->child;
-            nlc[i] = f->n_lc; lc[i] = f->lc; lro[i] = f->lcroot_off; lr[i] = f->lcroot;
-            nroot[i] = f->n_root; root[i] = f->root;
-        }
         if (g_batch && g_ls_shared[g_worker_id % g_n_groups])
             g_ls = s3a_lexsearch_clone(g_ls_shared[g_worker_id % g_n_groups], s3a_mgau_stream(g_gm));
         else {
-            g_ls = s3a_lexsearch_init(g_ntree, nn, ssid, tm, comp, wid, prob, coff, ch, nlc, lc, lro, lr,
-                                      nroot, root, g_tm, g_sseq_flat, mdef_n_sseq(mdef), g_comsseq_flat,
-                                      d2p->n_comsseq, g_n_comstate, g_comstate_off, g_comstate,
-                                      s3a_mgau_stream(g_gm));
+            g_ls = make_lexsearch(mdef, d2p);
             if (g_batch) g_ls_shared[g_worker_id % g_n_groups] = g_ls;
         }
         if (!g_ls) die("s3a_lexsearch_init");

@@ -544,7 +544,7 @@ adc_read(const char *uttfile, int32 *nsamps, cmd_ln_t *config)
     return data;
 }
 
-static int g_dither, g_swap;
+static int g_dither, g_swap, g_cmn_prior;
 /* the front end fe_init_auto_r (fe_interface.c:212-283) builds from the same options */
 static void
 adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
@@ -568,12 +568,22 @@ adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
     p.doublebw = cmd_ln_boolean_r(config, "-doublebw");
     p.logspec = cmd_ln_boolean_r(config, "-smoothspec") ? S3A_FE_SMOOTHSPEC : cmd_ln_boolean_r(config, "-logspec") ? S3A_FE_LOGSPEC : S3A_FE_CEPSTRA;
     if ((g_fe = s3a_fe_init(&p)) == NULL) E_FATAL("tst shim: s3a_fe_init: %s\n", s3a_last_error());
-    if (strcmp(cmn, "current") != 0 && strcmp(cmn, "none") != 0) E_FATAL("tst shim: -adcin with S3A_UTT: -cmn current / none only\n");
+    /* -cmn prior: the mean learnt from the utterances before (cmn_t of the decoder's feat_t, -cmninit) is subtracted on the device
+     * and the running sums take the utterance there; the state between utterances stays in the reference's cmn_t (utt_collect) */
+    g_cmn_prior = strcmp(cmn, "prior") == 0;
+    if (g_cmn_prior && cmd_ln_boolean_r(config, "-varnorm")) E_FATAL("Variance normalization not implemented in live mode decode\n");   /* (cmn_prior.c:150-152) */
+    if (strcmp(cmn, "current") != 0 && strcmp(cmn, "none") != 0 && !g_cmn_prior) E_FATAL("tst shim: -adcin with S3A_UTT: -cmn current / prior / none only\n");
     if (strcmp(agc, "max") != 0 && strcmp(agc, "none") != 0) E_FATAL("tst shim: -adcin with S3A_UTT: -agc max / none only\n");
     g_cmn_current = strcmp(cmn, "current") == 0; g_agc_max = strcmp(agc, "max") == 0;
     g_varnorm = cmd_ln_boolean_r(config, "-varnorm");
     g_adcin = 1;
 }
+
+/* (the LM contexts: below, with utt_mode_main) */
+typedef struct { const char *name; flat_t **flat; s3a_lexsearch_t *ls; s3a_lm3g_t *lm3g; wl_flat_t *w; s3a_uttdec_t *uds[UTT_MAX_ENGINES]; } lmctx_t;
+static lmctx_t *g_ctx;
+static int32 g_n_ctx, g_cur_ctx;
+static void ctx_switch(kb_t *kb, int32 k);
 
 /* ctl_process callback: utt_decode's feature half (libAPI/utt.c:185-245), then queue */
 static void
@@ -586,8 +596,12 @@ utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
     uq_t *q;
     double t0 = now_s();
 
-    if (ur->lmname != NULL)
-        E_FATAL("tst shim: per-utterance LM switching is not supported with S3A_UTT\n");
+    if (ur->lmname != NULL) {                   /* -ctl_lm (utt.c:240-241) */
+        int32 k;
+        for (k = 0; k < g_n_ctx; k++) if (strcmp(g_ctx[k].name, ur->lmname) == 0) break;
+        if (k == g_n_ctx) E_FATAL("tst shim: -ctl_lm names %s, which is not in the LM set\n", ur->lmname);
+        if (k != g_cur_ctx) { utt_flush(kb); ctx_switch(kb, k); }
+    }
     if (ur->regmatname != NULL && strcmp(ur->regmatname, kb->adapt_am->prevmllrfn) != 0) {
         /* -ctl_mllr names another regression matrix: what is queued is decoded with the model it was queued for, then the
          * host model is adapted (kb_setmllr, as utt_decode would: utt.c:245-246) and every engine's device model follows */
@@ -618,7 +632,26 @@ utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
                 for (k = 0; k < used; k++) adc[k] += (int16)((!(s3_rand_int31() % 4)) ? 1 : 0);
             }
         }
-        if (s3a_audio_to_feat_dev(g_fe, adc, nsamps, 1, g_cmn_current, g_varnorm, g_agc_max, &dfeat, &total_frame, &stride) != S3A_OK)
+        if (g_cmn_prior) {
+            /* feat_s2mfc2feat_live(beginutt, endutt) = feat_s2mfc2feat_block_utt -> feat_cmn: cmn_prior over the padded utterance,
+             * then cmn_prior_update (feat.c:1066-1080, cmn_prior.c:95-170) */
+            cmn_t *cm = kbcore_fcb(kbcore)->cmn_struct;
+            if (s3a_audio_to_feat_dev_prior(g_fe, adc, nsamps, 1, cm->cmn_mean, cm->sum, g_agc_max, &dfeat, &total_frame, &stride) != S3A_OK)
+                E_FATAL("tst shim: MFCC / feature computation failed for %s: %s\n", ur->uttfile, s3a_last_error());
+            cm->nframe += total_frame + 2 * feat_window_size(kbcore_fcb(kbcore));
+            if (cm->nframe > CMN_WIN_HWM) {            /* cmn_prior_shiftwin (static in cmn_prior.c:95-112), restated */
+                mfcc_t sf = FLOAT2MFCC(1.0) / cm->nframe;
+                int32 i;
+                for (i = 0; i < cm->veclen; i++) cm->cmn_mean[i] = cm->sum[i] / cm->nframe;
+                if (cm->nframe >= CMN_WIN_HWM) {
+                    sf = CMN_WIN * sf;
+                    for (i = 0; i < cm->veclen; i++) cm->sum[i] = MFCCMUL(cm->sum[i], sf);
+                    cm->nframe = CMN_WIN;
+                }
+            }
+            cmn_prior_update(cm);
+        }
+        else if (s3a_audio_to_feat_dev(g_fe, adc, nsamps, 1, g_cmn_current, g_varnorm, g_agc_max, &dfeat, &total_frame, &stride) != S3A_OK)
             E_FATAL("tst shim: MFCC / feature computation failed for %s: %s\n", ur->uttfile, s3a_last_error());
         ckd_free(adc);
         if (total_frame > S3_MAX_FRAMES) E_FATAL("Maximum number of frames (%d) exceeded\n", S3_MAX_FRAMES);
@@ -641,28 +674,23 @@ utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
 
 #include "s3amd_export.h"
 
-static int
-utt_mode_main(int argc, char *argv[], int n_lanes)
+/* Everything that depends on the LANGUAGE MODEL: the flattened trigram, the word level's per-word tables and the engines on the
+ * current lextrees (g_ls).  One LM: once.  Several (-lmctlfn): once per LM, each after srch_set_lm has made it the current one
+ * (every LM has unigram lextrees of its own: srch_time_switch_tree.c:260-330). */
+static wl_flat_t *g_w;
+static s3a_wordlevel_cfg_t g_cfg;
+static void
+lm_context_init(kb_t *kbp, int with_engines)
 {
-    static kb_t kb;
+#define kb (*kbp)
     cmd_ln_t *config = cmd_ln_get();
-    srch_t *s;
-    srch_TST_graph_t *tstg;
-    kbcore_t *kbc;
-    mdef_t *mdef;
+    srch_t *s = kb.srch;
+    srch_TST_graph_t *tstg = s->grh->graph_struct;
+    kbcore_t *kbc = kb.kbcore;
+    mdef_t *mdef = kbcore_mdef(kbc);
     wl_flat_t *w;
     s3a_wordlevel_cfg_t cfg;
-    int32 *tree_type, t;
-    double t_load = now_s(), t_dec;
-    (void)argc; (void)argv;
-
-    kb_init(&kb, config);
-    s = kb.srch;
-    if (s->op_mode != 4) E_FATAL("tst shim: -op_mode 4 (fwdtree) only\n");
-    tstg = s->grh->graph_struct;
-    kbc = kb.kbcore;
-    mdef = kbcore_mdef(kbc);
-    backend_init(&kb, tstg);
+    int32 *tree_type, t, e;
     w = flatten_lm(kbc);
     g_lm3g = s3a_lm3g_init(w->n_ug, w->ug_prob, w->ug_bowt, w->ug_firstbg, w->n_bg, w->bg_wid, w->bg_prob, w->bg_bowt,
                            w->bg_firsttg, w->n_tg, w->tg_wid, w->tg_prob, w->inclass, w->n_word);
@@ -678,19 +706,14 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     cfg.wordend_beam = s->beam->wordend; cfg.n_lextree = tstg->n_lextree; cfg.epl = tstg->epl;
     cfg.hmmbeam = s->beam->hmm; cfg.pbeam = s->beam->ptrans; cfg.wbeam = s->beam->word;
     cfg.ptranskip = s->beam->ptranskip; cfg.maxhmmpf = tstg->histprune->maxhmmpf; cfg.tree_type = tree_type;
-    g_n_eng = getenv("S3A_UTT_ENGINES") ? atoi(getenv("S3A_UTT_ENGINES")) : 1;     /* the lanes are split over the engines */
-    if (g_n_eng < 1) g_n_eng = 1;
-    if (g_n_eng > UTT_MAX_ENGINES) g_n_eng = UTT_MAX_ENGINES;
-    if (g_n_eng > n_lanes) g_n_eng = n_lanes;
-    g_lpe = (n_lanes + g_n_eng - 1) / g_n_eng;
-    n_lanes = g_lpe * g_n_eng;
-    if (!getenv("S3A_EXPORT")) {
-        int32 e;
+    g_w = w; g_cfg = cfg;
+    if (!with_engines) return;
         for (e = 0; e < g_n_eng; e++) {
             /* every further engine gets a model of its own: an engine runs on its model's stream, and engines are
              * to overlap (the lextrees, the trigram and the composite-senone table are shared) */
             s3a_mgau_model_t *gm = g_gm;
-            if (e > 0) {
+            if (e > 0 && g_gms[e]) gm = g_gms[e];          /* (another LM's context: the engines of one index share their model) */
+            else if (e > 0) {
                 gm = s3a_mgau_init(cmd_ln_str_r(config, "-mean"), cmd_ln_str_r(config, "-var"),
                                    cmd_ln_float32_r(config, "-varfloor"), cmd_ln_str_r(config, "-mixw"),
                                    cmd_ln_float32_r(config, "-mixwfloor"), 1, ".cont.", S3A_MIX_INT_FLOAT_COMP, g_lm);
@@ -735,6 +758,90 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
                 g_dev_dag = 1;
             }
         }
+#undef kb
+}
+
+/* -lmctlfn / -ctl_lm / -lmname: a context per LM of the set -- its lextrees flattened, its search space, its trigram, its engines
+ * (the acoustic models and their streams are shared by the engines of the same index: contexts never run side by side).
+ * utt.c:240-241 switches with srch_set_lm before an utterance; here what is queued is decoded with the LM it was queued for,
+ * then the LM's context becomes the current one. */
+static void
+ctx_save(int32 k, const char *name)
+{
+    int32 e;
+    g_ctx[k].name = name; g_ctx[k].flat = g_flat; g_ctx[k].ls = g_ls; g_ctx[k].lm3g = g_lm3g; g_ctx[k].w = g_w;
+    for (e = 0; e < g_n_eng; e++) g_ctx[k].uds[e] = g_uds[e];
+}
+static void
+ctx_switch(kb_t *kb, int32 k)
+{
+    int32 e;
+    if (k == g_cur_ctx) return;
+    srch_set_lm((srch_t *)kb->srch, g_ctx[k].name);
+    g_flat = g_ctx[k].flat; g_ls = g_ctx[k].ls; g_lm3g = g_ctx[k].lm3g; g_w = g_ctx[k].w; g_wflat = g_ctx[k].w;
+    for (e = 0; e < g_n_eng; e++) g_uds[e] = g_ctx[k].uds[e];
+    g_ud = g_uds[0];
+    g_cur_ctx = k;
+}
+
+static int
+utt_mode_main(int argc, char *argv[], int n_lanes)
+{
+    static kb_t kb;
+    cmd_ln_t *config = cmd_ln_get();
+    srch_t *s;
+    srch_TST_graph_t *tstg;
+    kbcore_t *kbc;
+    mdef_t *mdef;
+    wl_flat_t *w;
+    s3a_wordlevel_cfg_t cfg;
+    int32 *tree_type, t;
+    double t_load = now_s(), t_dec;
+    (void)argc; (void)argv;
+
+    kb_init(&kb, config);
+    s = kb.srch;
+    if (s->op_mode != 4) E_FATAL("tst shim: -op_mode 4 (fwdtree) only\n");
+    tstg = s->grh->graph_struct;
+    kbc = kb.kbcore;
+    mdef = kbcore_mdef(kbc);
+    /* with -ctl_lm the reference names no current LM until the first utterance does (lmset_init, lmset.c:143-158; the lextrees
+     * in use are the first LM's: srch_time_switch_tree.c:357-360): make that LM the current one, as its trees already are */
+    if (kbcore_lmset(kbc)->cur_lm == NULL) srch_set_lm(s, kbcore_lmset(kbc)->lmarray[0]->name);
+    backend_init(&kb, tstg);
+    g_n_eng = getenv("S3A_UTT_ENGINES") ? atoi(getenv("S3A_UTT_ENGINES")) : 1;     /* the lanes are split over the engines */
+    if (g_n_eng < 1) g_n_eng = 1;
+    if (g_n_eng > UTT_MAX_ENGINES) g_n_eng = UTT_MAX_ENGINES;
+    if (g_n_eng > n_lanes) g_n_eng = n_lanes;
+    g_lpe = (n_lanes + g_n_eng - 1) / g_n_eng;
+    n_lanes = g_lpe * g_n_eng;
+    lm_context_init(&kb, getenv("S3A_EXPORT") == NULL);
+    w = g_w; cfg = g_cfg;
+    {
+        lmset_t *ls = kbcore_lmset(kbc);
+        g_n_ctx = ls->n_lm;
+        g_ctx = ckd_calloc(g_n_ctx > 0 ? g_n_ctx : 1, sizeof(*g_ctx));
+        g_cur_ctx = 0;
+        for (t = 0; t < g_n_ctx; t++) if (ls->lmarray[t] == ls->cur_lm) g_cur_ctx = t;
+        ctx_save(g_cur_ctx, ls->lmarray[g_cur_ctx]->name);
+        if (g_n_ctx > 1 && !getenv("S3A_EXPORT")) {
+            const int32 first = g_cur_ctx;
+            for (t = 0; t < g_n_ctx; t++) {
+                if (t == first) continue;
+                srch_set_lm(s, ls->lmarray[t]->name);
+                flatten_current_trees(tstg);
+                if ((g_ls = make_lexsearch(mdef, kbcore_dict2pid(kbc))) == NULL) die("s3a_lexsearch_init");
+                lm_context_init(&kb, 1);
+                ctx_save(t, ls->lmarray[t]->name);
+                E_INFO("tst shim: LM %s: search space and %d engine(s) of its own\n", ls->lmarray[t]->name, g_n_eng);
+            }
+            g_cur_ctx = -1;
+            ctx_switch(&kb, first);
+            w = g_w;
+        }
+    }
+    if (!getenv("S3A_EXPORT")) {
+        int32 e;
         g_ud = g_uds[0];
         if (g_n_eng > 1) {              /* the engines' host threads */
             for (e = 0; e < g_n_eng; e++) {

@@ -92,6 +92,25 @@ def test_dither_and_big_endian_samples(audio_task):
     assert run(TST, a2, d, "uttb", {"S3A_UTT": "2"}, extra=["-input_endian", "big", "-dither", "yes", "-seed", "1234"]) == ref
 
 
+def test_cmn_prior(audio_task):
+    """-cmn prior (the live-mode normalisation: every frame loses the mean learnt from the utterances BEFORE, cmn_prior.c): the
+    subtraction and the running sums on the device, the decoder's cmn_t carried between utterances by the drop-in (window shift
+    beyond 800 frames included: the control file is long enough)"""
+    d, args = audio_task
+    a2 = [a for a in args]
+    k = a2.index("-cmn")
+    a2[k + 1] = "prior"
+    (d / "ctlp").write_text("dhd\ngoforward\nchan3\nshort\nchan3\ndhd\ngoforward\n")
+    ref = run(REF, a2, d, "refcp", ctl="ctlp", extra=["-cmninit", "10.0"])
+    cur = run(REF, args, d, "refcc", ctl="ctlp")
+    assert ref[1] != cur[1] and ref[0].count("\n") == 7
+    first = [l for l in ref[1].splitlines() if l.startswith("dhd ")]
+    assert len(first) == 2 and first[0] != first[1]                     # (the same audio, another prior: the state moves)
+    for env in ({"S3A_UTT": "1"}, {"S3A_UTT": "3"}, {"S3A_UTT": "2", "S3A_UTT_QUEUE": "5"}):
+        got = run(TST, a2, d, "uttcp" + "_".join(env.values()), env, ctl="ctlp", extra=["-cmninit", "10.0"])
+        assert got == ref
+
+
 def test_unsupported_front_end_options_are_refused(audio_task):
     d, args = audio_task
     p = subprocess.run([TST] + args + ["-ctl", str(d / "ctl"), "-warp_params", "1.1"], capture_output=True, text=True, errors="ignore",

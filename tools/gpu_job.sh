@@ -1,4 +1,6 @@
-export S3A_ON_GPU_BOX=1
-python -m pytest tests/test_gpu_psms.py tests/test_gpu_psfwd.py tests/test_gpu_psfwd_synth.py tests/test_gpu_dag.py -q 2>&1 | tail -8
-bash tools/psfwd_variants.sh "base:512" 2>&1 | tail -2
-grep -h "scor\|ms on" gpurun_out/psvar/base/q512.log | tail -5
+gcc -shared -fPIC -o /tmp/segv.so tools/segv_trace.c
+R=$(pwd); D=$R/tests/golden/tidigits_decode; AM=$R/tests/golden/tidigits; C=$R/tests/golden/tidigits_clm
+mkdir -p /tmp/clm && cd /tmp/clm
+printf "{ $C/digits.probdef }\n$C/digits.cls.lm digitclass {\n[low]\n[high]\n}\n$D/tidigits.DMP plain\n" > lmctl
+awk '{print (NR%3==0) ? "plain" : "digitclass"}' $D/tidigits.length.arb.regression > ctl_lm
+S3A_UTT=4 LD_PRELOAD=/tmp/segv.so $R/oracle/_ref/ref_s3amd_tst_decode -dict $D/dictionary -fdict $D/fillerdict -hmm $AM -cepdir $D/cepstra -agc none -varnorm no -cmn current -lw 9.5 -ctl $D/tidigits.length.arb.regression -op_mode 4 -lmctlfn /tmp/clm/lmctl -ctl_lm /tmp/clm/ctl_lm -lmname plain -hyp /tmp/clm/g.match -hypseg /tmp/clm/g.seg 2>&1 | tail -25
