@@ -429,6 +429,7 @@ def main():
     ap.add_argument("--ps-lanes", type=int, default=512, help="lanes (persistent one-workgroup decoders, two per CU) the pocketsphinx leg runs the batch through as one queue")
     ap.add_argument("--only-scoring", action="store_true", help="only the scoring legs (PMC passes over the scoring kernels)")
     ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
+    ap.add_argument("--variant", action="append", default=[], metavar="FIELD=INT", help="a field of s3a_variants_t (s3a_set_variants), e.g. hist_sort_launch=1: A/B runs of kernel variants")
     args = ap.parse_args()
     if args.plain:
         args.no_cpu = args.no_scoring = args.no_ps = args.no_wide_beam = True
@@ -454,6 +455,8 @@ def main():
 
     from cmusphinx_amd import bundle, lib, s3io, shard, synth_task
     L = lib.load()
+    if args.variant:
+        lib.set_variants(**{kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.variant})
     if lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libcmusphinx_amd has no CPU fallback")
     lib.check(L.s3a_set_device(local_rank))
@@ -677,6 +680,12 @@ def main():
             for k in bad[:2]:
                 print("  device:", lines[k][1].strip()[:600], "\n  refrnc:", rs[k].strip()[:600], file=sys.stderr)
         assert hyp_ok and (seg_ok or args.fast), "device hypotheses differ from the unmodified reference decoder's"
+        if args.plain:
+            # the rocprofv3-wrapped command: the timed regime and nothing else (no lock-step decode for statistics, no profiled step)
+            print(json.dumps({"metric": "decoded_frames_per_sec", "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "plain": True,
+                              "identical_to_reference": {"hyp": bool(hyp_ok), "hypseg": bool(seg_ok)}}))
+            return
 
         # ---- per-kernel timing (HIP events on the engines' launch streams around every launch of the profiled frames) ----
         # ALONE: one group of one engine with the chip to itself (every 4th frame).  IN THE BENCH: one more whole step with

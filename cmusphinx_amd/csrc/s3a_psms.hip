@@ -487,7 +487,7 @@ k_ps_cont_tr(int32_t n_sen, int32_t P, int32_t VP, int32_t topn, int32_t aw,
         const int32_t fr = e / (PT_SG / 2), c = (e - fr * (PT_SG / 2)) * 2;
         if (s_row[fr] < 0) continue;
         int16_t *o = out + (size_t)(q0 + fr) * n_sen + s0 + c;
-        if (c + 1 < ns && (((size_t)(q0 + fr) * n_sen + s0 + c) & 1) == 0) *(int32_t *)o = (int32_t)(uint16_t)tile[fr][c] | ((int32_t)tile[fr][c + 1] << 16);
+        if (c + 1 < ns && ((uintptr_t)o & 3) == 0) *(int32_t *)o = (int32_t)(uint16_t)tile[fr][c] | ((int32_t)tile[fr][c + 1] << 16);
         else { if (c < ns) o[0] = tile[fr][c]; if (c + 1 < ns) o[1] = tile[fr][c + 1]; }
     }
 }
@@ -518,15 +518,25 @@ s3a_ps_score_slots_dev(s3a_ps_mgau_t *ps, const float *feat_dev, const int32_t *
     LogAddShifted la = { dv->tab, dv->tab_size, dv->lm_zero };
     const int64_t items = (int64_t)M * F * P;
     if (ps->one_to_one && F == 1 && nd == 8 && ps->veclen == 39 && ps->topn <= nd && M == S && dv->meanS && !s3a_variants()->ps_score_by_gaussian) {
-        hipLaunchKernelGGL((k_ps_cont_tr<8, 39>), dim3((S + PT_SG - 1) / PT_SG, (n_slots + 64 * PT_FL - 1) / (64 * PT_FL)), dim3(PSB), 0, st, S, P,
-                           dv->VP, ps->topn, ps->aw, dv->meanS, dv->precS, dv->det, dv->pdf, la, feat_dev, slot_row_dev, n_slots, raw_dev);
+        /* (a grid's y dimension ends at 65 535: batches beyond 8.4 M frames go in several launches) */
+        const int32_t per_launch = 65535 * 64 * PT_FL;
+        for (int32_t s0 = 0; s0 < n_slots; s0 += per_launch) {
+            const int32_t n = n_slots - s0 < per_launch ? n_slots - s0 : per_launch;
+            hipLaunchKernelGGL((k_ps_cont_tr<8, 39>), dim3((S + PT_SG - 1) / PT_SG, (n + 64 * PT_FL - 1) / (64 * PT_FL)), dim3(PSB), 0, st, S, P,
+                               dv->VP, ps->topn, ps->aw, dv->meanS, dv->precS, dv->det, dv->pdf, la, feat_dev, slot_row_dev + s0, n,
+                               raw_dev + (size_t)s0 * S);
+        }
         HIPCHK(hipGetLastError());
         return S3A_OK;
     }
     if (ps->one_to_one && F == 1 && P >= 2 && ps->topn <= 4 && ps->topn <= nd && M == S && (size_t)PS_CT * ps->veclen * 4 <= 32 * 1024) {
-        hipLaunchKernelGGL(k_ps_cont_slots, dim3((uint32_t)((items + PSB - 1) / PSB), (n_slots + PS_CT - 1) / PS_CT), dim3(PSB),
-                           (size_t)PS_CT * ps->veclen * 4 + 16, st, S, nd, P, ps->veclen, ps->topn, ps->aw, dv->meanT, dv->precT, dv->det,
-                           dv->pdf, la, feat_dev, slot_row_dev, n_slots, raw_dev);
+        const int32_t per_launch = 65535 * PS_CT;
+        for (int32_t s0 = 0; s0 < n_slots; s0 += per_launch) {
+            const int32_t n = n_slots - s0 < per_launch ? n_slots - s0 : per_launch;
+            hipLaunchKernelGGL(k_ps_cont_slots, dim3((uint32_t)((items + PSB - 1) / PSB), (n + PS_CT - 1) / PS_CT), dim3(PSB),
+                               (size_t)PS_CT * ps->veclen * 4 + 16, st, S, nd, P, ps->veclen, ps->topn, ps->aw, dv->meanT, dv->precT, dv->det,
+                               dv->pdf, la, feat_dev, slot_row_dev + s0, n, raw_dev + (size_t)s0 * S);
+        }
         HIPCHK(hipGetLastError());
         return S3A_OK;
     }

@@ -975,23 +975,59 @@ ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 
 /* after the evaluation: the histogram bins when the frame holds more than 1.5 x -maxhmmpf HMMs (lextree_hmm_histbin);
  * otherwise the thresholds are final and the HMMs that can propagate stamp their children's parent sets (d_dec_stamp) */
+/* what ku_hist_sort does for a lane (below): the histogram beam, the lists reordered, the stamps of such a frame */
+template <int NT>
+__device__ __forceinline__ void
+d_hist_sort_lane(const ULane &L, const UShared &S, const FrameBeams &bm, const int32_t *nact_cur, int32_t cur, int32_t f)
+{
+    for (int32_t t = 0; t < S.T; t++) {
+        const int32_t hb = d_dec_hist_sort_t<NT>(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.exits + S.N, L.exits, L.hbin,
+                                           L.pos, -1, NBIN, t, 0);
+        __syncthreads();
+        if (hb <= 0) {
+            int32_t th, pth;
+            frame_thresholds_hb(L.best, S.T, bm, hb, th, pth);
+            const int32_t na = nact_cur[t], b = S.node_base[t];
+            for (int32_t i = threadIdx.x; i < na; i += NT)
+                d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp8, b, na, i, pth, f);
+        }
+        __syncthreads();
+    }
+}
+
+/* own_sort: the frame's histogram sort has no launch of its own -- almost no frame needs it (37 of 1.15 M in the bench), and with
+ * several engines on the chip a launch that only finds that out still waits its turn (57 us on average in the four-engine bench) --:
+ * in a frame under the histogram beam the LAST workgroup of the lane to finish its bins (a counter in the lane's context, release
+ * / acquire around it) runs the sort; in every other frame nothing is counted at all */
 __global__ void __launch_bounds__(DBLOCK)
-ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t fg)
+ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t own_sort)
 {
     LANE;
+    __shared__ int32_t s_last;
     const int32_t t = blockIdx.y, na = nact_cur[t];
-    if ((int32_t)blockIdx.x * DBLOCK >= na) return;
+    const bool has_work = (int32_t)blockIdx.x * DBLOCK < na;
     const FrameBeams bm = frame_beams(S, f);
     int32_t n = 0;
     for (int32_t k = 0; k < S.T; k++) n += nact_cur[k];
     if (n > bm.maxhmmpf + (bm.maxhmmpf >> 1)) {
-        for (int32_t vb = blockIdx.x; vb * DBLOCK < na; vb += gridDim.x) {
-            d_dec_hist_count(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.best, L.bests, L.exits + S.N, L.hbin, -1, 0, 1,
-                             NBIN, vb, t);
-            __syncthreads();
-        }
+        if (has_work)
+            for (int32_t vb = blockIdx.x; vb * DBLOCK < na; vb += gridDim.x) {
+                d_dec_hist_count(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.best, L.bests, L.exits + S.N, L.hbin, -1, 0, 1,
+                                 NBIN, vb, t);
+                __syncthreads();
+            }
+        if (!own_sort) return;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&ctx->hist_wg, 1) == (int32_t)(gridDim.x * gridDim.y) - 1;
+        __syncthreads();
+        if (!s_last) return;
+        if (threadIdx.x == 0) ctx->hist_wg = 0;
+        __threadfence();
+        d_hist_sort_lane<DBLOCK>(L, S, bm, nact_cur, cur, f);
         return;
     }
+    if (!has_work) return;
     int32_t th, pth;
     frame_thresholds_hb(L.best, S.T, bm, 1, th, pth);
     const int32_t b = S.node_base[t];
@@ -1012,19 +1048,7 @@ ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t fg)
     int32_t n = 0;
     for (int32_t k = 0; k < S.T; k++) n += nact_cur[k];
     if (n <= bm.maxhmmpf + (bm.maxhmmpf >> 1)) return;          /* (uniform: no histogram beam in this frame) */
-    for (int32_t t = 0; t < S.T; t++) {
-        const int32_t hb = d_dec_hist_sort_t<NT>(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.exits + S.N, L.exits, L.hbin,
-                                           L.pos, -1, NBIN, t, 0);
-        __syncthreads();
-        if (hb <= 0) {
-            int32_t th, pth;
-            frame_thresholds_hb(L.best, S.T, bm, hb, th, pth);
-            const int32_t na = nact_cur[t], b = S.node_base[t];
-            for (int32_t i = threadIdx.x; i < na; i += NT)
-                d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp8, b, na, i, pth, f);
-        }
-        __syncthreads();
-    }
+    d_hist_sort_lane<NT>(L, S, bm, nact_cur, cur, f);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -2189,8 +2213,10 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     else
         UKL(UK_HMM_EVAL, (ku_hmm_eval<64, 3>), dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
     {
-        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 8 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f);
-        if (ud->hist_possible) {
+        /* many lanes: the (rare) histogram sort rides on the count's launch (its 256-thread form is the one used there anyway) */
+        const int32_t own_sort = ud->hist_possible && n >= ud->scan_small_from && !s3a_variants()->hist_sort_launch ? 1 : 0;
+        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 8 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f, own_sort);
+        if (ud->hist_possible && !own_sort) {
             /* (from 64 lanes on 256 threads: the launch's 128 workgroups mostly only leave, and small ones find a slot sooner) */
             if (n >= ud->scan_small_from) UKL(UK_HIST_SORT, ku_hist_sort<256>, dim3(1, 1, n), dim3(256), 0, st, LN, S, f);
             else UKL(UK_HIST_SORT, ku_hist_sort<SCAN_THREADS>, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);

@@ -87,6 +87,7 @@ struct UCtx {
     int32_t max_cand, max_new;
     int32_t f0;             /* the engine's frame counter at this utterance's first frame (lane refill: s3a_uttdec_decode_queue) */
     int32_t utt;            /* the utterance's place in the queue (-1: a plain decode) */
+    int32_t hist_wg;        /* workgroups of ku_hist_count that have finished a frame under the histogram beam (the last one sorts) */
     int32_t groups[8];
     int32_t calls[4 * WL_MAXCALL];
     long long tacc[16];     /* time spent per word-level phase (100 MHz ticks; tools/wl_phases) */

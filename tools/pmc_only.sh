@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; NAME=${1:-pmc}; OUT=$R/gpurun_out/$NAME; mkdir -p 
 make -s -C oracle oracle
 export TMPDIR=/tmp S3A_BENCH_NO_RCCL=1 ${PMC_ENV:-}
 cd /tmp
-PMC_ARGS="--steps 1 --warmup 0 --no-cpu --no-scoring --frames 100 --utts 64 --lanes 64 --engines 1"
+PMC_ARGS="--steps 1 --warmup 0 --plain --frames 100 --utts 64 --lanes 64 --engines 1"
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/prof_pmc_fetch -o bench -- python $R/bench.py $PMC_ARGS > $OUT/prof_pmc_fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/prof_pmc_write -o bench -- python $R/bench.py $PMC_ARGS > $OUT/prof_pmc_write.log 2>&1; echo "write rc=$?"
 timeout 600 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/prof_scoring_pmc_fetch -o scoring -- python $R/bench.py --only-scoring > $OUT/prof_scoring_pmc_fetch.log 2>&1
