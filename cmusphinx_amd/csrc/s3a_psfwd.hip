@@ -61,8 +61,8 @@ struct PsfScalars {
 struct PsfLane {
     int32_t *st;                                /* [n_hmm][CH_STRIDE]: a channel's hmm_t state in ONE 64-byte record (channels are
                                                    visited at random: one cache line per visit, not one per field) */
-    uint16_t *mpxid;                            /* [n_emit][n_mpx]: roots, then single-phone words */
-    int32_t *acl[2], *apos[2];                  /* active_chan_list; position of an interior channel in it */
+    uint16_t *mpxid;                            /* [n_mpx][MPX_STRIDE]: roots, then single-phone words; a channel's ids side by side (one line per visit) */
+    int32_t *acl[2];                            /* active_chan_list (a channel's position in it: CH_AP, in its record) */
     int32_t *awl[2];                            /* active_word_list */
     int32_t *wstamp;                            /* word entered by last_phone_transition in tick .. */
     int32_t *lt_sf, *lt_dscr, *lt_bp;           /* last_ltrans_t */
@@ -106,12 +106,23 @@ struct PsfModel {
 
 /* a channel's record: score[5], history[5], out_score, out_history, bestscore, frame */
 #define CH_STRIDE 16
+#define MPX_STRIDE 8        /* senone-sequence ids of a multiplexed channel's states (<= 5), 16 bytes per channel */
+#define MPX_ID(L, k, m) (L).mpxid[(size_t)(m) * MPX_STRIDE + (k)]
 #define CH_SC(L, c, k) (L).st[(size_t)(c) * CH_STRIDE + (k)]
 #define CH_HI(L, c, k) (L).st[(size_t)(c) * CH_STRIDE + 5 + (k)]
 #define CH_OS(L, c) (L).st[(size_t)(c) * CH_STRIDE + 10]
 #define CH_OH(L, c) (L).st[(size_t)(c) * CH_STRIDE + 11]
 #define CH_BE(L, c) (L).st[(size_t)(c) * CH_STRIDE + 12]
 #define CH_FR(L, c) (L).st[(size_t)(c) * CH_STRIDE + 13]
+/* the two spare words: an interior channel's position in active list 0 / 1.  What is looked at together lives together: a channel is
+ * visited through "is it on the list, where, and what are its scores", and a position in an array of its own was one more 64-byte
+ * line fetched -- and, written, one more line written back -- per visit (PMC: 792 KB of traffic per lane-frame for 220 KB of records) */
+#define CH_AP(L, par, c) (L).st[(size_t)(c) * CH_STRIDE + 14 + (par)]
+/* a parked entry (score, history, the tick it was parked in): with three emitting states the record's unused words 3, 8, 4;
+ * with five, arrays of their own */
+template <int NE> __device__ __forceinline__ int32_t &ent_score_ref(PsfLane &L, int32_t c, int32_t n_root) { return NE == 3 ? CH_SC(L, c, 3) : L.ent_score[c - n_root]; }
+template <int NE> __device__ __forceinline__ int32_t &ent_hist_ref(PsfLane &L, int32_t c, int32_t n_root) { return NE == 3 ? CH_HI(L, c, 3) : L.ent_hist[c - n_root]; }
+template <int NE> __device__ __forceinline__ int32_t &ent_stamp_ref(PsfLane &L, int32_t c, int32_t n_root) { return NE == 3 ? CH_SC(L, c, 4) : L.ent_stamp[c - n_root]; }
 
 __device__ __forceinline__ int32_t add32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 __device__ __forceinline__ int32_t sub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
@@ -276,7 +287,7 @@ hmm_vit_eval(const PsfModel &M, PsfLane &L, int32_t c, int32_t m, const SenScr &
     for (int k = 0; k < NE; k++) {
         sc[k] = CH_SC(L, c, k); hi[k] = CH_HI(L, c, k);
         if (MPX) {
-            id[k] = L.mpxid[k * M.n_mpx + m];
+            id[k] = MPX_ID(L, k, m);
             bad[k] = k > 0 && id[k] == PS_BAD_SSID;
             V[k] = bad[k] ? PS_WORST : add32(sc[k], sen(M.sseq[(uint32_t)id[k] * NE + k]));
         }
@@ -318,7 +329,7 @@ hmm_vit_eval(const PsfModel &M, PsfLane &L, int32_t c, int32_t m, const SenScr &
         if (v > best) best = v;
         /* sources of the lower states are V[] and the OLD hi[] / id[] of lower indices: safe to store now */
         CH_SC(L, c, j) = v; CH_HI(L, c, j) = nh;
-        if (MPX) L.mpxid[j * M.n_mpx + m] = nid;
+        if (MPX) MPX_ID(L, j, m) = nid;
     }
     /* state 1 */
     t0 = MPX ? (V[1] != PS_WORST ? add32(V[1], TPV(1, 1)) : PS_WORST) : add32(V[1], TPV(1, 1));
@@ -327,7 +338,7 @@ hmm_vit_eval(const PsfModel &M, PsfLane &L, int32_t c, int32_t m, const SenScr &
     else {
         v = t1;
         CH_HI(L, c, 1) = hi[0];
-        if (MPX) L.mpxid[1 * M.n_mpx + m] = id[0];
+        if (MPX) MPX_ID(L, 1, m) = id[0];
     }
     if (v < PS_WORST) v = PS_WORST;
     if (v > best) best = v;
@@ -354,7 +365,7 @@ activate(const PsfModel &M, const PsfLane &L, int32_t c, int32_t m, uint32_t *bi
     if (MPX) {
 #pragma unroll
         for (int k = 0; k < NE; k++) {
-            const uint16_t id = L.mpxid[k * M.n_mpx + m];
+            const uint16_t id = MPX_ID(L, k, m);
             if (id != PS_BAD_SSID) setbit(bits, M.sseq[(uint32_t)id * NE + k]);
         }
     }
@@ -619,10 +630,11 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     const int32_t thresh = add32(S.best_score, S.dyn_beam);
     const int32_t newphone_thresh = add32(S.best_score, M.pbeam), lastphn_thresh = add32(S.best_score, M.lpbeam);
     const int32_t n_acl = S.n_acl[cur];
-    int32_t *acl = L.acl[cur], *apos = L.apos[cur], *nacl = L.acl[nxt], *napos = L.apos[nxt];
+    int32_t *acl = L.acl[cur], *nacl = L.acl[nxt];
+#define APOS(c) CH_AP(L, cur, c)
 
     /* ---- prune_root_chan :714-788 + prune_nonroot_chan :794-870, outputs in the reference's order ---- */
-    auto in_acl = [&](int32_t c) -> bool { const int32_t p = apos[c - M.n_root]; return p >= 0 && p < n_acl && acl[p] == c; };
+    auto in_acl = [&](int32_t c) -> bool { const int32_t p = APOS(c); return p >= 0 && p < n_acl && acl[p] == c; };
     /* does parent p (position ppos in the list, -1 = root) enter child x?  everything read is immutable in this phase */
     auto enters = [&](int32_t p, int32_t ppos, int32_t x, int32_t *ns_out) -> bool {
         if (!(CH_BE(L, p) > thresh)) return false;
@@ -630,7 +642,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         *ns_out = ns;
         if (!(ns > newphone_thresh)) return false;
         if (!in_acl(x)) return (CH_FR(L, x) < f) || (ns > CH_SC(L, x, 0));
-        const bool pfirst = ppos < 0 || ppos < apos[x - M.n_root];
+        const bool pfirst = ppos < 0 || ppos < APOS(x);
         if (pfirst || CH_BE(L, x) > thresh) return ns > CH_SC(L, x, 0);
         return ns > PS_WORST;       /* x's turn came first and cleared it (:866-867) */
     };
@@ -655,7 +667,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                 int32_t ns;
                 bool par_first_entered = false;
                 if (par < M.n_root) par_first_entered = !(CH_FR(L, par) < f) && enters(par, -1, c, &ns);
-                else if (in_acl(par) && apos[par - M.n_root] < pos) par_first_entered = enters(par, apos[par - M.n_root], c, &ns);
+                else if (in_acl(par) && APOS(par) < pos) par_first_entered = enters(par, APOS(par), c, &ns);
                 selfapp = !par_first_entered;
             }
             if (surv) {
@@ -693,11 +705,11 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                         const bool xin = in_acl(x);
                         bool app;
                         if (ppos < 0) app = true;                                       /* :750-752 */
-                        else if (xin) app = !(CH_BE(L, x) > thresh && apos[x - M.n_root] < ppos);
+                        else if (xin) app = !(CH_BE(L, x) > thresh && APOS(x) < ppos);
                         else app = CH_FR(L, x) != nf;                                    /* :833-836 */
                         flag = app ? 1 : 0; item = x;
                         if (xin) {      /* parked: x's own state is still being read by others */
-                            L.ent_score[x - M.n_root] = ns; L.ent_hist[x - M.n_root] = CH_OH(L, pc); L.ent_stamp[x - M.n_root] = tick;
+                            ent_score_ref<NE>(L, x, M.n_root) = ns; ent_hist_ref<NE>(L, x, M.n_root) = CH_OH(L, pc); ent_stamp_ref<NE>(L, x, M.n_root) = tick;
                         }
                         else { CH_SC(L, x, 0) = ns; CH_HI(L, x, 0) = CH_OH(L, pc); CH_FR(L, x) = nf; }  /* hmm_enter; only its parent touches an inactive channel */
                     }
@@ -705,7 +717,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
             }
             int32_t oa, oz, ta, tz;
             wg_scan2(F.wg, flag, 0, oa, oz, ta, tz);
-            if (flag) { nacl[F.carryA + oa] = item; napos[item - M.n_root] = F.carryA + oa; }
+            if (flag) { nacl[F.carryA + oa] = item; CH_AP(L, nxt, item) = F.carryA + oa; }
             __syncthreads();
             if (tid == 0) F.carryA += ta;
             __syncthreads();
@@ -719,9 +731,9 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         const int32_t c = acl[j];
         if (CH_BE(L, c) > thresh) continue;
         bool keep = false;
-        if (L.ent_stamp[c - M.n_root] == tick) {
+        if (ent_stamp_ref<NE>(L, c, M.n_root) == tick) {
             const int32_t par = M.ch_par[c];
-            keep = par < M.n_root || apos[par - M.n_root] < j;
+            keep = par < M.n_root || APOS(par) < j;
         }
         if (!keep) hmm_clear_scores<NE>(M, L, c);
     }
@@ -729,7 +741,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     /* the parked entries; every channel of the next list is active in f + 1 */
     for (int32_t j = tid; j < n_nacl; j += NT) {
         const int32_t x = nacl[j];
-        if (L.ent_stamp[x - M.n_root] == tick) { CH_SC(L, x, 0) = L.ent_score[x - M.n_root]; CH_HI(L, x, 0) = L.ent_hist[x - M.n_root]; }
+        if (ent_stamp_ref<NE>(L, x, M.n_root) == tick) { CH_SC(L, x, 0) = ent_score_ref<NE>(L, x, M.n_root); CH_HI(L, x, 0) = ent_hist_ref<NE>(L, x, M.n_root); }
         CH_FR(L, x) = nf;
     }
     if (tid == 0) { S.n_acl[nxt] = n_nacl; S.n_cand = n_cand; S.st_cand += n_cand; }
@@ -950,7 +962,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                 const int32_t ci = M.root_ci[i], ns = add32(add32(F.brc_score[ci], M.nwpen), M.pip);
                 if (ns > wthresh && (CH_FR(L, i) < f || ns > CH_SC(L, i, 0))) {
                     CH_SC(L, i, 0) = ns; CH_HI(L, i, 0) = F.brc_path[ci]; CH_FR(L, i) = nf;
-                    L.mpxid[i] = M.root_lc_ssid[i * M.n_ci + F.brc_lc[ci]];
+                    MPX_ID(L, 0, i) = M.root_lc_ssid[i * M.n_ci + F.brc_lc[ci]];
                     setbit(F.rootbits, i);
                 }
             }
@@ -983,7 +995,7 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                         if (ns > wthresh && (CH_FR(L, c) < f || ns > CH_SC(L, c, 0))) {
                             const int32_t pb = L.lt_bp[w];
                             CH_SC(L, c, 0) = ns; CH_HI(L, c, 0) = pb; CH_FR(L, c) = nf;
-                            L.mpxid[M.n_root + i] = M.sp_lc_ssid[i * M.n_ci + M.w_last_ci[L.bp_wid[pb]]];
+                            MPX_ID(L, 0, M.n_root + i) = M.sp_lc_ssid[i * M.n_ci + M.w_last_ci[L.bp_wid[pb]]];
                         }
                     }
                 }
@@ -1020,8 +1032,8 @@ d_start(const PsfModel &M, PsfLane &L, PsfScalars &S, int fresh)
     if (light) {
         for (int32_t c = M.n_root + tid; c < M.n_ch; c += NT) hmm_clear<NE>(M, L, c);
         for (int32_t i = tid; i < M.n_mpx; i += NT) {
-            L.mpxid[i] = i < M.n_root ? M.root_ssid0[i] : M.sp_ssid0[i - M.n_root];
-            for (int k = 1; k < NE; k++) L.mpxid[k * M.n_mpx + i] = PS_BAD_SSID;
+            MPX_ID(L, 0, i) = i < M.n_root ? M.root_ssid0[i] : M.sp_ssid0[i - M.n_root];
+            for (int k = 1; k < NE; k++) MPX_ID(L, k, i) = PS_BAD_SSID;
         }
         for (int32_t w = tid; w < M.n_words; w += NT) { L.lt_dscr[w] = 0; L.lt_bp[w] = 0; }
         for (int32_t i = tid; i < old_bpidx && i < M.bp_cap; i += NT) L.bp_realwid[i] = 0;
@@ -1029,11 +1041,11 @@ d_start(const PsfModel &M, PsfLane &L, PsfScalars &S, int fresh)
     if (full) {
         for (int32_t c = tid; c < M.n_hmm; c += NT) hmm_clear<NE>(M, L, c);
         for (int32_t i = tid; i < M.n_mpx; i += NT) {
-            L.mpxid[i] = i < M.n_root ? M.root_ssid0[i] : M.sp_ssid0[i - M.n_root];
-            for (int k = 1; k < NE; k++) L.mpxid[k * M.n_mpx + i] = PS_BAD_SSID;
+            MPX_ID(L, 0, i) = i < M.n_root ? M.root_ssid0[i] : M.sp_ssid0[i - M.n_root];
+            for (int k = 1; k < NE; k++) MPX_ID(L, k, i) = PS_BAD_SSID;
         }
         for (int32_t w = tid; w < M.n_words; w += NT) { L.lt_dscr[w] = 0; L.lt_bp[w] = 0; L.wstamp[w] = 0; }
-        for (int32_t i = tid; i < M.n_nonroot; i += NT) { L.apos[0][i] = -1; L.apos[1][i] = -1; L.ent_stamp[i] = 0; }
+        for (int32_t i = tid; i < M.n_nonroot; i += NT) { CH_AP(L, 0, M.n_root + i) = -1; CH_AP(L, 1, M.n_root + i) = -1; ent_stamp_ref<NE>(L, M.n_root + i, M.n_root) = 0; }
         for (int32_t i = tid; i < M.bp_cap; i += NT) L.bp_realwid[i] = 0;
     }
     for (int32_t w = tid; w < M.n_words; w += NT) L.lt_sf[w] = -1;
@@ -1443,8 +1455,8 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
         PsfLane &L = e->lanes_h[z];
         const size_t H = M.n_hmm;
         LANE(L.st, int32_t, CH_STRIDE * H);
-        LANE(L.mpxid, uint16_t, (size_t)NE * M.n_mpx);
-        for (int k = 0; k < 2; k++) { LANE(L.acl[k], int32_t, d->n_nonroot + 1); LANE(L.apos[k], int32_t, d->n_nonroot + 1); LANE(L.awl[k], int32_t, M.cand_cap + 1); }
+        LANE(L.mpxid, uint16_t, (size_t)MPX_STRIDE * M.n_mpx);
+        for (int k = 0; k < 2; k++) { LANE(L.acl[k], int32_t, d->n_nonroot + 1); LANE(L.awl[k], int32_t, M.cand_cap + 1); }
         LANE(L.wstamp, int32_t, W); LANE(L.lt_sf, int32_t, W); LANE(L.lt_dscr, int32_t, W); LANE(L.lt_bp, int32_t, W);
         LANE(L.ent_score, int32_t, d->n_nonroot + 1); LANE(L.ent_hist, int32_t, d->n_nonroot + 1); LANE(L.ent_stamp, int32_t, d->n_nonroot + 1);
         LANE(L.cand_wid, int32_t, M.cand_cap); LANE(L.cand_score, int32_t, M.cand_cap); LANE(L.cand_bp, int32_t, M.cand_cap); LANE(L.cand_ef, int32_t, M.cand_cap);
@@ -1553,10 +1565,10 @@ s3a_psfwd_get_sp_ssid(s3a_psfwd_t *e, int32_t lane, uint16_t *ssid)
 {
     LANECHK("s3a_psfwd_get_sp_ssid");
     const PsfModel &M = e->M;
-    std::vector<uint16_t> all((size_t)M.n_emit * M.n_mpx);
+    std::vector<uint16_t> all((size_t)MPX_STRIDE * M.n_mpx);
     HIPCHK(hipMemcpy(all.data(), e->lanes_h[lane].mpxid, all.size() * 2, hipMemcpyDeviceToHost));
     for (int32_t i = 0; i < M.n_1ph; i++)
-        for (int32_t k = 0; k < M.n_emit; k++) ssid[i * M.n_emit + k] = all[(size_t)k * M.n_mpx + M.n_root + i];
+        for (int32_t k = 0; k < M.n_emit; k++) ssid[i * M.n_emit + k] = all[(size_t)(M.n_root + i) * MPX_STRIDE + k];
     return S3A_OK;
 }
 
@@ -1565,10 +1577,10 @@ s3a_psfwd_set_sp_ssid(s3a_psfwd_t *e, int32_t lane, const uint16_t *ssid)
 {
     LANECHK("s3a_psfwd_set_sp_ssid");
     const PsfModel &M = e->M;
-    std::vector<uint16_t> all((size_t)M.n_emit * M.n_mpx);
+    std::vector<uint16_t> all((size_t)MPX_STRIDE * M.n_mpx);
     HIPCHK(hipMemcpy(all.data(), e->lanes_h[lane].mpxid, all.size() * 2, hipMemcpyDeviceToHost));
     for (int32_t i = 0; i < M.n_1ph; i++)
-        for (int32_t k = 0; k < M.n_emit; k++) all[(size_t)k * M.n_mpx + M.n_root + i] = ssid[i * M.n_emit + k];
+        for (int32_t k = 0; k < M.n_emit; k++) all[(size_t)(M.n_root + i) * MPX_STRIDE + k] = ssid[i * M.n_emit + k];
     HIPCHK(hipMemcpy(e->lanes_h[lane].mpxid, all.data(), all.size() * 2, hipMemcpyHostToDevice));
     return S3A_OK;
 }

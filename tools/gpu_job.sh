@@ -1,4 +1,4 @@
-for v in "" "--variant hist_sort_launch=1" ""; do
-python bench.py --plain $v > gpurun_out/plain_ab.json 2> gpurun_out/plain_ab.err; python -c "
-import json; r=json.load(open('gpurun_out/plain_ab.json')); print('$v', r['value'], r['identical_to_reference'])"
-done
+export S3A_ON_GPU_BOX=1
+python -m pytest tests/test_gpu_psfwd.py tests/test_gpu_psfwd_synth.py -q -x 2>&1 | tail -4
+bash tools/psfwd_variants.sh "base:256 512" 2>&1 | tail -4
+grep -h "of which" gpurun_out/psvar/base/q512.log | tail -1
