@@ -214,3 +214,53 @@ s3a_audio_to_feat_dev_prior(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, i
     if (!cmn_mean || !cmn_sum) return S3A_EINVAL;
     return audio_to_feat_dev(fe, spch, nsamps, drop_partial_frame, 2, 0, agc_max, feat_dev_out, n_frames, feat_stride, cmn_mean, cmn_sum);
 }
+
+/* feat_lda_transform (sphinxbase feat/lda.c:137-160): every row of the feature matrix times the transposed LDA matrix --
+ * out[j] = sum over k, IN ORDER, of feat[k] * lda[j][k] (a float32 product and a float32 sum per term, no FMA) -- into rows of
+ * the output dimension rounded up to four floats (zero padded: the stride the engines take for a model of that dimension) */
+__global__ void __launch_bounds__(256)
+k_feat_lda(const float *__restrict__ feat, int32_t n, int32_t stride, const float *__restrict__ lda, int32_t in_dim, int32_t out_dim,
+           float *out, int32_t out_stride)
+{
+    __shared__ float row[4][FMAXC * 3 + 4];
+    const int32_t sub = threadIdx.x >> 6, lane = threadIdx.x & 63, t = blockIdx.x * 4 + sub;
+    if (t < n) for (int32_t k = lane; k < in_dim; k += 64) row[sub][k] = feat[(size_t)t * stride + k];
+    __syncthreads();
+    if (t >= n) return;
+    for (int32_t j = lane; j < out_stride; j += 64) {
+        float acc = 0.0f;
+        if (j < out_dim)
+            for (int32_t k = 0; k < in_dim; k++) { const float p = row[sub][k] * lda[(size_t)j * in_dim + k]; acc = acc + p; }
+        out[(size_t)t * out_stride + j] = acc;
+    }
+}
+
+extern "C" int32_t
+s3a_feat_lda_dev(float **feat_dev, int32_t n_frames, int32_t *feat_stride, const float *lda, int32_t in_dim, int32_t out_dim, void *stream)
+{
+    if (!feat_dev || !*feat_dev || !feat_stride || !lda || n_frames < 1 || in_dim < 1 || in_dim > 3 * FMAXC || out_dim < 1 || out_dim > in_dim
+        || *feat_stride < in_dim) {
+        s3a_set_error("s3a_feat_lda_dev: bad arguments (%d x %d matrix)", out_dim, in_dim);
+        return S3A_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t os = 4 * ((out_dim + 3) / 4);
+    float *lda_d = NULL, *out = NULL;
+    if (hipMalloc((void **)&lda_d, (size_t)out_dim * in_dim * 4) != hipSuccess || hipMalloc((void **)&out, ((size_t)n_frames * os + 8) * 4) != hipSuccess) {
+        if (lda_d) (void)hipFree(lda_d);
+        s3a_set_error("s3a_feat_lda_dev: out of device memory");
+        return S3A_ENOMEM;
+    }
+    int32_t rc = S3A_OK;
+    if (hipMemcpyAsync(lda_d, lda, (size_t)out_dim * in_dim * 4, hipMemcpyHostToDevice, st) != hipSuccess) rc = S3A_EHIP;
+    if (rc == S3A_OK) {
+        hipLaunchKernelGGL(k_feat_lda, dim3((n_frames + 3) / 4), dim3(256), 0, st, *feat_dev, n_frames, *feat_stride, lda_d, in_dim, out_dim, out, os);
+        if (hipGetLastError() != hipSuccess) rc = S3A_EHIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == S3A_OK) rc = S3A_EHIP;
+    (void)hipFree(lda_d);
+    if (rc != S3A_OK) { (void)hipFree(out); return rc; }
+    (void)hipFree(*feat_dev);
+    *feat_dev = out; *feat_stride = os;
+    return S3A_OK;
+}

@@ -51,6 +51,7 @@ _SIGS = {
     "s3a_fe_stream": (C.c_void_p, [C.c_void_p]),
     "s3a_audio_to_feat_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3a_feat_lda_dev": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "s3a_audio_to_feat_dev_prior": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "s3a_mgau_n_mgau": (C.c_int32, [C.c_void_p]),
     "s3a_mgau_max_comp": (C.c_int32, [C.c_void_p]),

@@ -157,6 +157,14 @@ def write_mixw(path: str, arr: np.ndarray, chksum: bool = True):
     _write(path, [n_mgau, n_feat, n_comp, arr.size], arr, chksum)
 
 
+def write_lda(path: str, arr: np.ndarray, chksum: bool = True):
+    """feature transform file (sphinxbase feat/lda.c:60-133 feat_read_lda: bio_fread_3d): [n_lda][rows = output dims][cols = stream length]"""
+    if arr.ndim == 2:
+        arr = arr[None]
+    n, m, k = arr.shape
+    _write(path, [n, m, k, arr.size], arr, chksum)
+
+
 def write_tmat(path: str, arr: np.ndarray, chksum: bool = True):
     n_tmat, n_src, n_dst = arr.shape
     assert n_dst == n_src + 1

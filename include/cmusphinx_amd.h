@@ -337,6 +337,12 @@ int32_t s3a_audio_to_feat_dev(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps,
 int32_t s3a_audio_to_feat_dev_prior(s3a_fe_t *fe, const int16_t *spch, int64_t nsamps, int32_t drop_partial_frame,
                                     const float *cmn_mean, float *cmn_sum, int32_t agc_max, float **feat_dev_out,
                                     int32_t *n_frames, int32_t *feat_stride);
+/* feat_lda_transform (sphinxbase feat/lda.c:137-160; -lda / -ldadim) on feature rows resident in HBM (s3a_audio_to_feat_dev's
+ * buffer): row <- the first out_dim entries of LDA x row (float32, terms in order, no FMA) in a NEW buffer whose rows are out_dim
+ * rounded up to four floats (zero padded: what the engines take for a model of that dimension); the old buffer is freed, *feat_dev
+ * and *feat_stride are updated.  lda = feat_t.lda[0]: [out_dim][in_dim] (the file's eigenvectors as rows), host memory. */
+int32_t s3a_feat_lda_dev(float **feat_dev, int32_t n_frames, int32_t *feat_stride, const float *lda, int32_t in_dim, int32_t out_dim,
+                         void *stream);
 
 /* ------------------------------------------------------------------ */
 /* The multi-stream ("s3.0") senone scorer: -senmgau .s3cont. / .semi. */

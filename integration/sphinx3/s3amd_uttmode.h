@@ -303,11 +303,13 @@ static pthread_cond_t g_eng_cv = PTHREAD_COND_INITIALIZER;
 static int g_eng_started;
 
 /* (features in host memory: rows of veclen floats; -adcin: made on the device, rows of the scorer's padded stride) */
+static int32 g_feat_dim;
 static int32
 eng_decode(const eng_job_t *j)
 {
     s3a_uttdec_t *ud = g_uds[j->e];
-    const int32 stride = j->dev ? 4 * ((j->veclen + 3) / 4) : j->veclen;
+    /* (device features: rows of the OUTPUT dimension -- -ldadim may have cut it -- rounded up to four floats) */
+    const int32 stride = j->dev ? 4 * ((g_feat_dim + 3) / 4) : j->veclen;
     if (j->queue) return j->dev ? s3a_uttdec_decode_queue_dev(ud, j->n, j->feat, j->nfr, stride) : s3a_uttdec_decode_queue(ud, j->n, j->feat, j->nfr, stride);
     return j->dev ? s3a_uttdec_decode_dev(ud, j->n, j->feat, j->nfr, stride) : s3a_uttdec_decode(ud, j->n, j->feat, j->nfr, stride);
 }
@@ -557,7 +559,6 @@ adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
     g_dither = cmd_ln_boolean_r(config, "-dither") ? 1 : 0;
     g_swap = strcmp(cmd_ln_str_r(config, "-input_endian"), "little") != 0;      /* (this host is little-endian: fe_interface.c:80-84) */
     if (cmd_ln_str_r(config, "-warp_params") != NULL) E_FATAL("tst shim: -adcin with S3A_UTT: frequency warping is not supported\n");
-    if (kbcore_fcb(kbc)->lda != NULL) E_FATAL("tst shim: -adcin with S3A_UTT: LDA is not supported\n");
     s3a_fe_default_params(&p);
     p.samprate = cmd_ln_float32_r(config, "-samprate"); p.frate = cmd_ln_int32_r(config, "-frate"); p.wlen = cmd_ln_float32_r(config, "-wlen");
     p.alpha = cmd_ln_float32_r(config, "-alpha"); p.ncep = cmd_ln_int32_r(config, "-ncep"); p.nfft = cmd_ln_int32_r(config, "-nfft");
@@ -577,6 +578,7 @@ adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
     g_cmn_current = strcmp(cmn, "current") == 0; g_agc_max = strcmp(agc, "max") == 0;
     g_varnorm = cmd_ln_boolean_r(config, "-varnorm");
     g_adcin = 1;
+    g_feat_dim = feat_dimension(kbcore_fcb(kbc));
 }
 
 /* (the LM contexts: below, with utt_mode_main) */
@@ -654,8 +656,13 @@ utt_collect(void *data, utt_res_t *ur, int32 sf, int32 ef, char *uttid)
         else if (s3a_audio_to_feat_dev(g_fe, adc, nsamps, 1, g_cmn_current, g_varnorm, g_agc_max, &dfeat, &total_frame, &stride) != S3A_OK)
             E_FATAL("tst shim: MFCC / feature computation failed for %s: %s\n", ur->uttfile, s3a_last_error());
         ckd_free(adc);
+        if (kbcore_fcb(kbcore)->lda) {         /* -lda / -ldadim: feat_lda_transform behind the feature computation (feat.c:1215-1216) */
+            feat_t *fcb = kbcore_fcb(kbcore);
+            if (s3a_feat_lda_dev(&dfeat, total_frame, &stride, &fcb->lda[0][0][0], fcb->stream_len[0], feat_dimension(fcb), s3a_fe_stream(g_fe)) != S3A_OK)
+                E_FATAL("tst shim: LDA transform failed for %s: %s\n", ur->uttfile, s3a_last_error());
+        }
         if (total_frame > S3_MAX_FRAMES) E_FATAL("Maximum number of frames (%d) exceeded\n", S3_MAX_FRAMES);
-        if (stride != 4 * ((veclen + 3) / 4)) E_FATAL("tst shim: -adcin: the front end's features (%d floats per row) do not fit the model's %d-dimensional stream\n", stride, veclen);
+        if (stride != 4 * ((feat_dimension(kbcore_fcb(kbcore)) + 3) / 4)) E_FATAL("tst shim: -adcin: the front end's features (%d floats per row) do not fit the model's %d-dimensional stream\n", stride, feat_dimension(kbcore_fcb(kbcore)));
         q->nfr = total_frame; q->feat = dfeat; q->on_dev = 1;
     }
     else {

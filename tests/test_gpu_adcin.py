@@ -111,6 +111,37 @@ def test_cmn_prior(audio_task):
         assert got == ref
 
 
+def test_lda_feature_transform(audio_task, tmp_path):
+    """-lda / -ldadim (feat_lda_transform behind the feature computation): the rows transformed on the device, float32 terms in the
+    reference's order.  A full 39 x 39 rotation with the tidigits model, and a reduction to 32 dimensions with the model's
+    Gaussians cut to 32 (data made here: what counts is that the reference and the device see the same numbers)."""
+    from cmusphinx_amd import s3io
+    d, args = audio_task
+    rng = np.random.default_rng(5)
+    q, _ = np.linalg.qr(rng.standard_normal((39, 39)))
+    lda = (np.eye(39) * 0.9 + 0.1 * q).astype(np.float32)
+    s3io.write_lda(str(tmp_path / "lda39"), lda)
+    plain = run(REF, args, d, "refl0")
+    ref = run(REF, args, d, "refl1", extra=["-lda", str(tmp_path / "lda39")])
+    assert ref[1] != plain[1]
+    assert run(TST, args, d, "uttl1", {"S3A_UTT": "3"}, extra=["-lda", str(tmp_path / "lda39")]) == ref
+    # 32 dimensions: the model's means / variances cut to the first 32, the other model files as they are
+    m32 = tmp_path / "m32"
+    m32.mkdir()
+    for f in ("mdef", "mixture_weights", "transition_matrices", "feat.params"):
+        if os.path.exists(os.path.join(AM, f)):
+            (m32 / f).write_bytes(open(os.path.join(AM, f), "rb").read())
+    for f in ("means", "variances"):
+        g = s3io.read_gau(os.path.join(AM, f))
+        s3io.write_gau(str(m32 / f), np.ascontiguousarray(g[:, :, :32]))
+    a2 = [str(m32) if a == AM else a for a in args]
+    ex = ["-lda", str(tmp_path / "lda39"), "-ldadim", "32"]
+    ref32 = run(REF, a2, d, "refl2", extra=ex)
+    assert ref32[0].count("\n") == 4 and ref32[1] != ref[1]
+    for env in ({"S3A_UTT": "1"}, {"S3A_UTT": "2", "S3A_UTT_QUEUE": "4"}):
+        assert run(TST, a2, d, "uttl2" + "_".join(env.values()), env, extra=ex) == ref32
+
+
 def test_unsupported_front_end_options_are_refused(audio_task):
     d, args = audio_task
     p = subprocess.run([TST] + args + ["-ctl", str(d / "ctl"), "-warp_params", "1.1"], capture_output=True, text=True, errors="ignore",
