@@ -224,9 +224,50 @@ s3a_fe_default_params(s3a_fe_params_t *p)
     p->transform = S3A_FE_LEGACY; p->round_filters = 1; p->unit_area = 1;
 }
 
-/* Hz <-> mel, neutral warping (fe_sigproc.c:288-301): float32 in and out, float64 inside */
-static float hz2mel(float hz) { return (float)(2595.0 * log10(1.0 + hz / 700.0)); }
-static float mel2hz(float mel) { return (float)(700.0 * (pow(10.0, mel / 2595.0) - 1.0)); }
+/* -warp_type / -warp_params (fe_warp.c; the three shapes: fe_warp_inverse_linear.c:138-170, fe_warp_affine.c:139-170,
+ * fe_warp_piecewise_linear.c:127-215): float32 arithmetic as there */
+struct FeWarp { int32_t type; float a, b, f0, f1; };
+static FeWarp
+make_warp(const s3a_fe_params_t *p)
+{
+    FeWarp w = { 0, 0.0f, 0.0f, 0.0f, 0.0f };
+    if (p->warp_type == S3A_FE_WARP_NONE || p->warp_params[0] == 0.0f) return w;          /* (slope zero: "warping not applied") */
+    w.type = p->warp_type; w.a = p->warp_params[0]; w.b = p->warp_params[1];
+    if (w.type == S3A_FE_WARP_PIECEWISE) {
+        const float nyq = p->samprate / 2;
+        if (w.b < p->samprate) {
+            if (w.b == 0) w.b = p->samprate * 0.85f;
+            w.f0 = (nyq - w.a * w.b) / (nyq - w.b);
+            w.f1 = nyq * w.b * (w.a - 1.0f) / (nyq - w.b);
+        }
+    }
+    return w;
+}
+static float
+unwarped_to_warped(const FeWarp &w, float x)
+{
+    float t;
+    switch (w.type) {
+    case S3A_FE_WARP_INVERSE: return x / w.a;
+    case S3A_FE_WARP_AFFINE: t = x * w.a; t += w.b; return t;
+    case S3A_FE_WARP_PIECEWISE: return x < w.b ? x * w.a : w.f0 * x + w.f1;
+    default: return x;
+    }
+}
+static float
+warped_to_unwarped(const FeWarp &w, float x)
+{
+    float t;
+    switch (w.type) {
+    case S3A_FE_WARP_INVERSE: return x * w.a;
+    case S3A_FE_WARP_AFFINE: t = x - w.b; t /= w.a; return t;
+    case S3A_FE_WARP_PIECEWISE: if (x < w.a * w.b) return x / w.a; t = x - w.f1; t /= w.f0; return t;
+    default: return x;
+    }
+}
+/* Hz <-> mel (fe_mel / fe_melinv, fe_sigproc.c:288-301): float32 in and out, float64 inside, the warping on the Hz side */
+static float hz2mel(const FeWarp &w, float hz) { const float wd = unwarped_to_warped(w, hz); return (float)(2595.0 * log10(1.0 + wd / 700.0)); }
+static float mel2hz(const FeWarp &w, float mel) { const float wd = (float)(700.0 * (pow(10.0, mel / 2595.0) - 1.0)); return warped_to_unwarped(w, wd); }
 
 template <typename T>
 static int32_t
@@ -278,12 +319,13 @@ s3a_fe_init(const s3a_fe_params_t *p)
         cc[i] = cos(a); ss[i] = sin(a);
     }
     /* mel filters: the three corner frequencies of every filter, then its bins and weights */
-    float melmin = hz2mel(p->lowerf), melmax = hz2mel(p->upperf);
+    const FeWarp warp = make_warp(p);
+    float melmin = hz2mel(warp, p->lowerf), melmax = hz2mel(warp, p->upperf);
     const float melbw = (melmax - melmin) / (nf + 1);
     if (p->doublebw) {
         melmin -= melbw; melmax += melbw;
-        if (mel2hz(melmin) < 0 || mel2hz(melmax) > p->samprate / 2) {
-            s3a_set_error("s3a_fe_init: -doublebw filter edges out of range (%f .. %f)", mel2hz(melmin), mel2hz(melmax));
+        if (mel2hz(warp, melmin) < 0 || mel2hz(warp, melmax) > p->samprate / 2) {
+            s3a_set_error("s3a_fe_init: -doublebw filter edges out of range (%f .. %f)", mel2hz(warp, melmin), mel2hz(warp, melmax));
             free(fe);
             return NULL;
         }
@@ -292,7 +334,7 @@ s3a_fe_init(const s3a_fe_params_t *p)
     std::vector<float> corner((size_t)nf * 3);
     for (int32_t i = 0; i < nf; i++)
         for (int32_t j = 0; j < 3; j++) {
-            float hz = mel2hz((i + (p->doublebw ? 2 * j : j)) * melbw + melmin);
+            float hz = mel2hz(warp, (i + (p->doublebw ? 2 * j : j)) * melbw + melmin);
             if (p->round_filters) hz = ((int)(hz / fftfreq + 0.5)) * fftfreq;
             corner[i * 3 + j] = hz;
         }

@@ -647,7 +647,7 @@ class FeParams(C.Structure):
                 ("ncep", C.c_int32), ("nfft", C.c_int32), ("nfilt", C.c_int32), ("lowerf", C.c_float),
                 ("upperf", C.c_float), ("transform", C.c_int32), ("lifter", C.c_int32), ("remove_dc", C.c_int32),
                 ("round_filters", C.c_int32), ("unit_area", C.c_int32), ("doublebw", C.c_int32),
-                ("logspec", C.c_int32)]
+                ("logspec", C.c_int32), ("warp_type", C.c_int32), ("warp_params", C.c_float * 2)]
 
 
 FE_TRANSFORMS = {"legacy": 0, "dct": 1, "htk": 2}

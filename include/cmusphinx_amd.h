@@ -292,7 +292,10 @@ typedef struct {
     int32_t transform;      /* S3A_FE_LEGACY / _DCT / _HTK */
     int32_t lifter, remove_dc, round_filters, unit_area, doublebw;
     int32_t logspec;        /* S3A_FE_CEPSTRA / _LOGSPEC / _SMOOTHSPEC */
+    int32_t warp_type;      /* -warp_type: S3A_FE_WARP_NONE / _INVERSE (inverse_linear, the default type) / _AFFINE / _PIECEWISE */
+    float warp_params[2];   /* -warp_params: a | a b | a F (fe_warp_*.c); a = 0: no warping */
 } s3a_fe_params_t;
+enum { S3A_FE_WARP_NONE = 0, S3A_FE_WARP_INVERSE = 1, S3A_FE_WARP_AFFINE = 2, S3A_FE_WARP_PIECEWISE = 3 };
 typedef struct s3a_fe_s s3a_fe_t;
 void s3a_fe_default_params(s3a_fe_params_t *p);
 s3a_fe_t *s3a_fe_init(const s3a_fe_params_t *p);

@@ -558,7 +558,6 @@ adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
      * fe_sigproc.c:596-640), once per sample and in sample order: done on the samples before they go to the device (utt_collect) */
     g_dither = cmd_ln_boolean_r(config, "-dither") ? 1 : 0;
     g_swap = strcmp(cmd_ln_str_r(config, "-input_endian"), "little") != 0;      /* (this host is little-endian: fe_interface.c:80-84) */
-    if (cmd_ln_str_r(config, "-warp_params") != NULL) E_FATAL("tst shim: -adcin with S3A_UTT: frequency warping is not supported\n");
     s3a_fe_default_params(&p);
     p.samprate = cmd_ln_float32_r(config, "-samprate"); p.frate = cmd_ln_int32_r(config, "-frate"); p.wlen = cmd_ln_float32_r(config, "-wlen");
     p.alpha = cmd_ln_float32_r(config, "-alpha"); p.ncep = cmd_ln_int32_r(config, "-ncep"); p.nfft = cmd_ln_int32_r(config, "-nfft");
@@ -568,6 +567,16 @@ adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
     p.round_filters = cmd_ln_boolean_r(config, "-round_filters"); p.unit_area = cmd_ln_boolean_r(config, "-unit_area");
     p.doublebw = cmd_ln_boolean_r(config, "-doublebw");
     p.logspec = cmd_ln_boolean_r(config, "-smoothspec") ? S3A_FE_SMOOTHSPEC : cmd_ln_boolean_r(config, "-logspec") ? S3A_FE_LOGSPEC : S3A_FE_CEPSTRA;
+    if (cmd_ln_str_r(config, "-warp_params") != NULL) {        /* fe_warp_set / fe_warp_set_parameters (fe_warp.c:108-178) */
+        const char *wt = cmd_ln_str_r(config, "-warp_type");
+        float a = 0.0f, b = 0.0f;
+        (void)sscanf(cmd_ln_str_r(config, "-warp_params"), "%f %f", &a, &b);
+        p.warp_type = (strcmp(wt, "inverse_linear") == 0 || strcmp(wt, "inverse") == 0) ? S3A_FE_WARP_INVERSE
+            : (strcmp(wt, "affine") == 0 || strcmp(wt, "linear") == 0) ? S3A_FE_WARP_AFFINE
+            : (strcmp(wt, "piecewise_linear") == 0 || strcmp(wt, "piecewise") == 0) ? S3A_FE_WARP_PIECEWISE : -1;
+        if (p.warp_type < 0) E_FATAL("tst shim: -warp_type %s is unknown\n", wt);
+        p.warp_params[0] = a; p.warp_params[1] = b;
+    }
     if ((g_fe = s3a_fe_init(&p)) == NULL) E_FATAL("tst shim: s3a_fe_init: %s\n", s3a_last_error());
     /* -cmn prior: the mean learnt from the utterances before (cmn_t of the decoder's feat_t, -cmninit) is subtracted on the device
      * and the running sums take the utterance there; the state between utterances stays in the reference's cmn_t (utt_collect) */

@@ -142,8 +142,21 @@ def test_lda_feature_transform(audio_task, tmp_path):
         assert run(TST, a2, d, "uttl2" + "_".join(env.values()), env, extra=ex) == ref32
 
 
+@pytest.mark.parametrize("wtype,wpar", [("inverse_linear", "0.94"), ("affine", "1.05 12.0"), ("piecewise_linear", "0.92 6000")])
+def test_frequency_warping(audio_task, wtype, wpar):
+    """-warp_type / -warp_params (VTLN; fe_warp_*.c): the mel filters' corner frequencies through the warping function, float32 as
+    the reference computes them; the decodes' scores equal the reference's to the last digit"""
+    d, args = audio_task
+    plain = run(REF, args, d, "refw0")
+    ref = run(REF, args, d, "refw_" + wtype, extra=["-warp_type", wtype, "-warp_params", wpar])
+    assert ref[1] != plain[1]
+    assert run(TST, args, d, "uttw_" + wtype, {"S3A_UTT": "2"}, extra=["-warp_type", wtype, "-warp_params", wpar]) == ref
+
+
 def test_unsupported_front_end_options_are_refused(audio_task):
     d, args = audio_task
-    p = subprocess.run([TST] + args + ["-ctl", str(d / "ctl"), "-warp_params", "1.1"], capture_output=True, text=True, errors="ignore",
+    a2 = [a if a != "current" else "prior" for a in args]
+    a2[a2.index("-varnorm") + 1] = "yes"
+    p = subprocess.run([TST] + a2 + ["-ctl", str(d / "ctl")], capture_output=True, text=True, errors="ignore",
                        timeout=600, env=dict(os.environ, S3A_UTT="2"))
-    assert p.returncode != 0 and "frequency warping is not supported" in p.stderr
+    assert p.returncode != 0 and "Variance normalization not implemented in live mode" in p.stderr
