@@ -31,6 +31,7 @@
 #include <string.h>
 #include <limits.h>
 #include <vector>
+#include <algorithm>
 
 #include "s3a_device.h"
 
@@ -1220,6 +1221,7 @@ k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, in
 struct PsfQueue {
     int32_t n_utt, seg_cap;
     int32_t *next;                  /* the queue's head */
+    const int32_t *order;           /* the k-th utterance the lanes take (longest first: the queue's tail is short ones); NULL: k */
     const int32_t *ready;           /* utterances whose scores are complete (the scoring runs beside the search); NULL: all */
     const int32_t *nfr;             /* [n_utt] */
     const long long *row0;          /* [n_utt] first row of the utterance in the score matrix */
@@ -1240,14 +1242,15 @@ k_psf_queue(PsfModel M, PsfLane *lanes, PsfQueue Q, int compallsen)
     for (;;) {
         if (threadIdx.x == 0) s_u = atomicAdd(Q.next, 1);
         __syncthreads();
-        const int32_t u = s_u;
+        const int32_t k_ = s_u;
         __syncthreads();
-        if (u >= Q.n_utt) break;
+        if (k_ >= Q.n_utt) break;
+        const int32_t u = Q.order ? Q.order[k_] : k_;
         if (Q.ready) {
             /* the utterance's scores come from a kernel on another stream: wait for its completion mark (a store behind that
              * kernel, so everything it wrote is in memory), then drop what this CU may hold of those lines */
             if (threadIdx.x == 0)
-                while (__hip_atomic_load(Q.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= u) __builtin_amdgcn_s_sleep(32);
+                while (__hip_atomic_load(Q.ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) <= k_) __builtin_amdgcn_s_sleep(32);
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -1314,7 +1317,7 @@ struct s3a_psfwd_s {
     int16_t *raw_d; size_t raw_cap;
     int32_t win;
     /* the queue's per-utterance results */
-    int32_t *q_next_d, *q_nfr_d, *q_res_d; long long *q_row0_d; s3a_psfwd_seg_t *q_seg_d;
+    int32_t *q_next_d, *q_nfr_d, *q_res_d, *q_order_d; long long *q_row0_d; s3a_psfwd_seg_t *q_seg_d;
     size_t q_cap;
     int32_t q_n, q_seg_cap;
     std::vector<int32_t> q_res_h;
@@ -1346,7 +1349,7 @@ s3a_psfwd_free(s3a_psfwd_t *e)
     if (e->feat_d) (void)hipFree(e->feat_d);
     if (e->slot_row_d) (void)hipFree(e->slot_row_d);
     if (e->raw_d) (void)hipFree(e->raw_d);
-    { void *qp[] = { e->q_next_d, e->q_nfr_d, e->q_res_d, e->q_row0_d, e->q_seg_d }; for (void *q : qp) if (q) (void)hipFree(q); }
+    { void *qp[] = { e->q_next_d, e->q_nfr_d, e->q_res_d, e->q_row0_d, e->q_seg_d, e->q_order_d }; for (void *q : qp) if (q) (void)hipFree(q); }
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev_mid) (void)hipEventDestroy(e->ev_mid);
@@ -1374,7 +1377,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     s3a_psfwd_t *e = new s3a_psfwd_t();
     e->lanes_d = NULL; e->lane_ids_d = NULL; e->stream = NULL; e->stream_sc = NULL; e->ev0 = e->ev1 = e->ev_sc = NULL; e->q_ready_d = NULL; e->last_ms = 0; e->last_score_ms = 0; e->ev_mid = NULL;
     e->feat_d = NULL; e->feat_cap = 0; e->slot_row_d = NULL; e->slot_cap = 0; e->raw_d = NULL; e->raw_cap = 0; e->win = 0;
-    e->q_next_d = e->q_nfr_d = e->q_res_d = NULL; e->q_row0_d = NULL; e->q_seg_d = NULL; e->q_cap = 0; e->q_n = 0; e->q_seg_cap = 256;
+    e->q_next_d = e->q_nfr_d = e->q_res_d = e->q_order_d = NULL; e->q_row0_d = NULL; e->q_seg_d = NULL; e->q_cap = 0; e->q_n = 0; e->q_seg_cap = 256;
     PsfModel &M = e->M;
     memset(&M, 0, sizeof(M));
     e->n_lanes = n_lanes;
@@ -1757,10 +1760,10 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
         e->raw_cap = (total + 1) * M.n_sen;
     }
     if (e->q_cap < (size_t)n_utt) {
-        void *qp[] = { e->q_next_d, e->q_nfr_d, e->q_res_d, e->q_row0_d, e->q_seg_d };
+        void *qp[] = { e->q_next_d, e->q_nfr_d, e->q_res_d, e->q_row0_d, e->q_seg_d, e->q_order_d };
         for (void *q : qp) if (q) (void)hipFree(q);
-        e->q_next_d = e->q_nfr_d = e->q_res_d = NULL; e->q_row0_d = NULL; e->q_seg_d = NULL; e->q_cap = 0;
-        HIPCHK(hipMalloc((void **)&e->q_next_d, 4)); HIPCHK(hipMalloc((void **)&e->q_nfr_d, (size_t)n_utt * 4));
+        e->q_next_d = e->q_nfr_d = e->q_res_d = e->q_order_d = NULL; e->q_row0_d = NULL; e->q_seg_d = NULL; e->q_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->q_next_d, 4)); HIPCHK(hipMalloc((void **)&e->q_nfr_d, (size_t)n_utt * 4)); HIPCHK(hipMalloc((void **)&e->q_order_d, (size_t)n_utt * 4));
         HIPCHK(hipMalloc((void **)&e->q_res_d, (size_t)n_utt * PSF_QRES * 4)); HIPCHK(hipMalloc((void **)&e->q_row0_d, (size_t)n_utt * 8));
         HIPCHK(hipMalloc((void **)&e->q_seg_d, (size_t)n_utt * e->q_seg_cap * sizeof(s3a_psfwd_seg_t)));
         e->q_cap = n_utt;
@@ -1772,6 +1775,13 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
     HIPCHK(hipMemcpyAsync(e->slot_row_d, rows.data(), total * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->q_nfr_d, n_frames, (size_t)n_utt * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->q_row0_d, row0.data(), (size_t)n_utt * 8, hipMemcpyHostToDevice, e->stream));
+    /* the lanes take the utterances longest first: whatever is taken last, when the other lanes run dry, is short (pocketsphinx_batch
+     * walks the control file in order; an utterance's result does not depend on when it is decoded -- every one starts from a new
+     * decoder's state -- and the results are kept by utterance index) */
+    std::vector<int32_t> order(n_utt);
+    for (int32_t z = 0; z < n_utt; z++) order[z] = z;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return n_frames[a] > n_frames[b]; });
+    HIPCHK(hipMemcpyAsync(e->q_order_d, order.data(), (size_t)n_utt * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemsetAsync(e->q_next_d, 0, 4, e->stream));
     HIPCHK(hipMemsetAsync(e->q_res_d, 0xff, (size_t)n_utt * PSF_QRES * 4, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));            /* (rows is a local) */
@@ -1779,7 +1789,7 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
     const int32_t n_wg = n_utt < e->n_lanes ? n_utt : e->n_lanes;
     PsfQueue Q;
     Q.n_utt = n_utt; Q.seg_cap = e->q_seg_cap; Q.next = e->q_next_d; Q.nfr = e->q_nfr_d; Q.row0 = e->q_row0_d; Q.raw = e->raw_d;
-    Q.res = e->q_res_d; Q.seg = e->q_seg_d; Q.ready = NULL;
+    Q.res = e->q_res_d; Q.seg = e->q_seg_d; Q.ready = NULL; Q.order = NULL;
     int32_t rc;
     if (n_utt <= n_wg || !s3a_variants()->ps_overlap) {
         rc = s3a_ps_score_slots_dev(scorer, e->feat_d, e->slot_row_d, (int32_t)total, e->raw_d, e->stream);
@@ -1791,7 +1801,7 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
          * dependent memory accesses.  They share the chip: the first utterance of every lane is scored, then the search
          * starts, and the rest of the queue is scored on a second stream beside it, a group of utterances per launch with a
          * completion mark behind each (k_psf_mark_ready) that a lane checks before it takes an utterance. */
-        Q.ready = e->q_ready_d;
+        Q.ready = e->q_ready_d;        /* (the marks count utterances in index order: no reordering here) */
         HIPCHK(hipMemsetAsync(e->q_ready_d, 0, 4, e->stream));
         HIPCHK(hipEventRecord(e->ev_sc, e->stream));
         HIPCHK(hipStreamWaitEvent(e->stream_sc, e->ev_sc, 0));
@@ -1811,6 +1821,7 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
             u0 = u1;
         }
     }
+    if (!Q.ready) Q.order = e->q_order_d;
     NE_LAUNCH(k_psf_queue, dim3(n_wg), M, e->lanes_d, Q, compallsen);
     HIPCHK(hipGetLastError());
     if (Q.ready) {                  /* the scoring stream ends before the search can, but the timed region closes on both */
