@@ -311,8 +311,9 @@ def wide_beam_leg(lib, d, lanes, n_frames, fast, n_check=8):
                          "frames_with_histogram_pruning": int(sum(int(s_[:, 6].sum()) for s_ in stat))},
            "kernels_us_per_frame": {k: round(v, 2) for k, v in sorted(pf.items(), key=lambda kv: -kv[1])}, "us_per_frame_all_lanes": round(tot, 1),
            "occupancy": {k: resrc.get(k) for k in ("ku_emit_word", "ku_hist_sort<256>", "ku_hist_sort<1024>") if k in resrc},
-           "occupancy_note": "from the code objects (profiles/r4_kernel_resources.json): ku_emit_word = 1024 threads x 88 VGPRs + 53 280 B LDS per workgroup "
-                             "(LDS admits 3 workgroups per CU, the VGPRs 5 waves per SIMD = 1 workgroup of 16 waves + part of a second: ONE resident workgroup per CU); "
+           "occupancy_note": "from the code objects (profiles/r4_kernel_resources.json): ku_emit_word = 512 threads x 88 VGPRs + 53 280 B LDS per workgroup "
+                             "(LDS admits 3 workgroups per CU, the VGPRs 5 waves per SIMD = 20 waves = 2 workgroups of 8: TWO resident workgroups per CU; "
+                             "with 1024 threads, until round 4, it was one); "
                              "ku_hist_sort<1024> 44 076 B LDS, <256> 20 028 B",
            "identical_to_reference": {"utterances_checked": n_cmp, "identical": n_ok},
            "cpu_reference": {"frames_per_sec": round(cpu_fps, 1) if cpu_fps else None, "processes": n_cmp, "frames": cpu_frames, "kind": "reference",

@@ -37,10 +37,12 @@
 #include <limits.h>
 #include "s3a_vit.h"
 
-/* (overridable for experiments only: measured round 4, 512 / 256 threads shorten ku_emit_word under four engines by 14 / 25 %
- * for +2 % throughput, but an RM1 decode differs at 256 -- the phases are validated at 1024) */
+/* 512 threads (round 4; 1024 before): with four engines on the chip a 1024-thread workgroup of 53 KB LDS waits for half a CU to
+ * be free at once -- ku_emit_word 262 -> 231 us per launch in the bench, +1.9 % frames/s -- and the whole GPU suite is green at
+ * 512 (profiles/r4_wl_threads_experiment.txt).  256 shortens the launch further (+2.5 %) but an RM1 decode differs: not a
+ * supported value. */
 #ifndef WL_THREADS
-#define WL_THREADS 1024
+#define WL_THREADS 512
 #endif
 #define WL_WAVES (WL_THREADS / 64)
 #define WL_MAXCALL 96       /* lextree_enter calls per frame: #CI phones + 1 */
