@@ -521,15 +521,20 @@ d_frame_word_chans(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f)
     for (int32_t j0 = 0; j0 < n_awl; j0 += NT) {
         const int32_t j = j0 + threadIdx.x;
         int32_t cnt = 0, c0 = 0, rcs = 0;
+        unsigned long long live = 0ull;             /* (the first 64 right contexts' frame tests, kept: a record is visited once) */
         if (j < n_awl) {
             const int32_t w = L.awl[f & 1][j];
             c0 = M.rc_base + M.w_rc_base[w]; rcs = M.w_rcsize[w];
-            for (int32_t r = 0; r < rcs; r++) cnt += CH_FR(L, c0 + r) == f ? 1 : 0;
+            for (int32_t r = 0; r < rcs; r++) {
+                const bool on = CH_FR(L, c0 + r) == f;
+                cnt += on ? 1 : 0;
+                if (on && r < 64) live |= 1ull << r;
+            }
         }
         int32_t off, o2, tot, t2;
         wg_scan2(F.wg, cnt, 0, off, o2, tot, t2);
         off += base;
-        for (int32_t r = 0; r < rcs; r++) if (CH_FR(L, c0 + r) == f) L.arc[off++] = c0 + r;
+        for (int32_t r = 0; r < rcs; r++) if (r < 64 ? (live >> r) & 1ull : CH_FR(L, c0 + r) == f) L.arc[off++] = c0 + r;
         base += tot;
     }
     if (threadIdx.x == 0) F.n_arc = base;

@@ -1,4 +1,4 @@
-for cfg in "512 4" "640 4" "768 4" "768 6" "1024 4"; do set -- $cfg
-python bench.py --plain --lanes $1 --engines $2 > gpurun_out/plain_l.json 2> gpurun_out/plain_l.err; python -c "
-import json; r=json.load(open('gpurun_out/plain_l.json')); print('lanes $1 engines $2', r['value'], r['identical_to_reference'])" 2>&1 | tail -1
-done
+export S3A_ON_GPU_BOX=1
+python -m pytest tests/test_gpu_psfwd.py tests/test_gpu_psfwd_synth.py -q -x 2>&1 | tail -2
+bash tools/psfwd_variants.sh "base:512" 2>&1 | tail -2
+bash tools/psfwd_pmc.sh gpurun_out/pspmc2 256 128 2>&1 | grep -A8 "k_psf_queue"
