@@ -39,8 +39,8 @@
 
 /* 512 threads (round 4; 1024 before): with four engines on the chip a 1024-thread workgroup of 53 KB LDS waits for half a CU to
  * be free at once -- ku_emit_word 262 -> 231 us per launch in the bench, +1.9 % frames/s -- and the whole GPU suite is green at
- * 512 (profiles/r4_wl_threads_experiment.txt).  256 shortens the launch further (+2.5 %) but an RM1 decode differs: not a
- * supported value. */
+ * 512 (profiles/r4_wl_threads_experiment.txt).  256 would shorten the launch further (+2.5 %) but the all-against-all ranking
+ * below takes a thread per entry, up to WL_RANK_MAX = 384 (static_assert). */
 #ifndef WL_THREADS
 #define WL_THREADS 512
 #endif
@@ -52,6 +52,9 @@
 #endif
 /* WL_LDS_EX:  frames with at most this many word exits keep them (and their candidate offsets) in LDS */
 #define WL_RANK_MAX 384     /* entries above the pruning threshold ranked all against all; beyond: selection */
+static_assert(WL_THREADS >= WL_RANK_MAX && WL_THREADS >= 256 && WL_THREADS % 64 == 0 && WL_THREADS <= 1024,
+              "the word level ranks up to WL_RANK_MAX entries with a thread each and keeps 256-entry tables a thread per entry "
+              "(this is what a 256-thread build got wrong on RM1)");
 #define WL_BIG_G 256        /* workgroups per lane of the wide-beam launches */
 
 /* error bits (UCtx.err / s3a_utt_result_t.err) */
