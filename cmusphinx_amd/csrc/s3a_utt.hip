@@ -1111,7 +1111,10 @@ ku_scan(const ULane *__restrict__ lanes, UShared S, int32_t NC, int32_t GC, int3
  * next frame's lextree_enter calls; workgroups 1 .. 8 T: the emission sweep (16 waves each, 8 workgroups per tree).
  * The two read nothing the other writes. */
 #define UE_WG_PER_TREE (8 * 1024 / WL_THREADS)      /* the emission sweep keeps its 128 waves per tree */
-__global__ void __launch_bounds__(WL_THREADS)
+#ifndef WL_EMIT_WPE
+#define WL_EMIT_WPE 1
+#endif
+__global__ void __launch_bounds__(WL_THREADS, WL_EMIT_WPE)
 ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, int32_t fg, int32_t big)
 {
     LANE;

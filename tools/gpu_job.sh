@@ -1,4 +1,7 @@
-export S3A_ON_GPU_BOX=1
-python -m pytest tests/test_gpu_psfwd.py tests/test_gpu_psfwd_synth.py -q -x 2>&1 | tail -2
-bash tools/psfwd_variants.sh "base:512" 2>&1 | tail -2
-bash tools/psfwd_pmc.sh gpurun_out/pspmc2 256 128 2>&1 | grep -A8 "k_psf_queue"
+cp cmusphinx_amd/libcmusphinx_amd.so /tmp/lib_base.so
+for v in base wpe6 base wpe6; do
+if [ $v = base ]; then cp /tmp/lib_base.so cmusphinx_amd/libcmusphinx_amd.so; else cp cmusphinx_amd/variants/lib_$v.so cmusphinx_amd/libcmusphinx_amd.so; fi
+python bench.py --plain > gpurun_out/plain_v.json 2> gpurun_out/plain_v.err; python -c "
+import json; r=json.load(open('gpurun_out/plain_v.json')); print('$v', r['value'], r['identical_to_reference'])" 2>&1 | tail -1
+done
+cp /tmp/lib_base.so cmusphinx_amd/libcmusphinx_amd.so
