@@ -710,6 +710,45 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
 #undef RS_ARGS
 }
 
+/*
+ * The nodes a propagating parent may ENTER while they are not on the list, found from the parents' side (round 4): the stamping
+ * pass has listed the frame's HMMs whose exit score reaches the phone threshold (plist, any order); a wave takes such an HMM and
+ * its lanes take the HMM's children (the static child lists of the emission sweep).  A child that is on the list is the other
+ * half's (by list position); one with several parents -- a first-level node has one per left-context variant of its root -- is
+ * taken by whichever listed parent claims it first (claim[]: the frame number, one atomic per such visit; the node rule walks all
+ * parents anyway and does not depend on who called).  Replaces the sweep over ALL nodes for stamped parent sets (216 k nodes per
+ * lane and frame for a few hundred propagating HMMs); the stamps stay for the active nodes' "can a parent enter me".
+ */
+template <typename PS, bool HEUR = false>
+__device__ __forceinline__ void
+d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
+              const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
+              const int32_t *__restrict__ tree_of, const int32_t *__restrict__ prob,
+              const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
+              const int32_t *__restrict__ pos, const int32_t *__restrict__ posf,
+              int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
+              int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt,
+              unsigned long long *key, int32_t *first, int32_t *hbin,
+              const int32_t *__restrict__ ps, const PS *__restrict__ pstamp,
+              const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
+              const int32_t *__restrict__ propf, int32_t *posout,
+              const int32_t *__restrict__ plist, int32_t n_plist, const int32_t *__restrict__ child_off,
+              const int32_t *__restrict__ child, int32_t *claim, int32_t W, int32_t NW, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
+{
+    const int32_t lane = threadIdx.x & 63;
+    for (int32_t k = W; k < n_plist; k += NW) {
+        const int32_t u = plist[k];
+        for (int32_t c = child_off[u] + lane, c_hi = child_off[u + 1]; c < c_hi; c += 64) {
+            const int32_t x = child[c];
+            if (posf[x] == cf) continue;                                    /* on the list: resolved by list position */
+            if (par_off[x + 1] - par_off[x] > 1 && atomicExch(&claim[x], cf) == cf) continue;  /* another parent took it */
+            d_dec_resolve_node<PS, HEUR>(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh,
+                                         bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf,
+                                         posout, x, false, true, -1, -1, hx);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /*
  * The ordered emission of the next active list, in two kernels.

@@ -51,6 +51,9 @@ struct ULane {
     uint8_t *pstamp8;           /* [n_pset] the parent sets' stamps, the frame number's low 8 bits (a quarter of the
                                  * sweep's gathers' footprint; a stale match costs a walk that finds nothing) */
     int32_t *dynbeam;           /* [1] the frame's CI beam when -maxcdsenpf is in force (ku_dyn_ci_beam) */
+    int32_t *claim;             /* [N] a several-parent node taken in frame .. by one of its propagating parents (ku_resolve_lists) */
+    int32_t *plist, *pcnt;      /* [N], [2]: the HMMs of the frame that can propagate (exit score over the phone threshold), any order;
+                                 * their number by frame parity (the stamping pass appends, a wave at a time; resolve walks their children) */
     int32_t *win;               /* [K][n_sen] look-ahead window: every senone's score for the frames f0 .. f0 + K - 1 */
     uint8_t *winb;              /* [K][n_sen] ... and the best component of its mixture (255: none) */
     /* -pheurtype > 0 (s3a_uttdec_enable_pheur) */
@@ -175,9 +178,10 @@ ku_lanes_begin(const ULane *__restrict__ lanes, UShared S, UBegin B, const int32
     const int32_t z = sub ? sub[blockIdx.z] : (int32_t)blockIdx.z;
     const ULane &L = lanes[z];
     const int32_t i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
-    for (int32_t i = i0; i < S.N; i += stride) { L.posf[i] = INT_MIN; L.propf[i] = INT_MIN; }
+    for (int32_t i = i0; i < S.N; i += stride) { L.posf[i] = INT_MIN; L.propf[i] = INT_MIN; L.claim[i] = INT_MIN; }
     for (int32_t i = i0; i < B.n_pset; i += stride) L.pstamp[i] = INT_MIN;
     for (int32_t i = i0; i < S.n_pset_bytes; i += stride) L.pstamp8[i] = 0xff;
+    if (i0 == 0) { L.pcnt[0] = 0; L.pcnt[1] = 0; }
     for (int32_t i = i0; i < S.n_sen; i += stride) {
         L.bstidx[i] = S3A_NO_BSTIDX; L.bstscr[i] = S3A_LOGPROB_ZERO; L.updatetime[i] = S3A_NOT_UPDATED; L.sen_act[i] = 0;
     }
@@ -975,6 +979,31 @@ ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 
 /* after the evaluation: the histogram bins when the frame holds more than 1.5 x -maxhmmpf HMMs (lextree_hmm_histbin);
  * otherwise the thresholds are final and the HMMs that can propagate stamp their children's parent sets (d_dec_stamp) */
+/* The stamps of tree t's HMMs that can propagate (d_dec_stamp) AND their ids appended to the lane's list of the frame, a wave at
+ * a time (one atomic per 64 HMMs; the order does not matter: ku_resolve_lists visits the children of every listed HMM).  i0 / stride:
+ * this workgroup's first list position and the step to its next, uniform over the workgroup. */
+__device__ __forceinline__ void
+d_stamp_and_list(const ULane &L, const UShared &S, int32_t cur, int32_t t, int32_t na, int32_t pth, int32_t f, int32_t i0, int32_t stride)
+{
+    const int32_t b = S.node_base[t];
+    int32_t *cnt = &L.pcnt[f & 1];
+    for (int32_t ib = i0; ib < na; ib += stride) {
+        const int32_t i = ib + (int32_t)threadIdx.x;
+        int32_t u = -1;
+        bool prop = false;
+        if (i < na) { u = L.act[cur][b + i]; prop = L.outs[NSV(u)] >= pth; }
+        if (prop) for (int32_t q = S.psof_off[u], q_hi = S.psof_off[u + 1]; q < q_hi; q++) L.pstamp8[S.psof[q]] = ps_val<uint8_t>(f);
+        const unsigned long long m = __ballot(prop);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            int32_t base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(cnt, __popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (prop) L.plist[base + __popcll(m & ((1ull << lane) - 1ull))] = u;
+        }
+    }
+}
+
 /* what ku_hist_sort does for a lane (below): the histogram beam, the lists reordered, the stamps of such a frame */
 template <int NT>
 __device__ __forceinline__ void
@@ -987,9 +1016,7 @@ d_hist_sort_lane(const ULane &L, const UShared &S, const FrameBeams &bm, const i
         if (hb <= 0) {
             int32_t th, pth;
             frame_thresholds_hb(L.best, S.T, bm, hb, th, pth);
-            const int32_t na = nact_cur[t], b = S.node_base[t];
-            for (int32_t i = threadIdx.x; i < na; i += NT)
-                d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp8, b, na, i, pth, f);
+            d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, 0, NT);
         }
         __syncthreads();
     }
@@ -1006,6 +1033,7 @@ ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t ow
     __shared__ int32_t s_last;
     const int32_t t = blockIdx.y, na = nact_cur[t];
     const bool has_work = (int32_t)blockIdx.x * DBLOCK < na;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) L.pcnt[(f + 1) & 1] = 0;       /* (the coming frame's list) */
     const FrameBeams bm = frame_beams(S, f);
     int32_t n = 0;
     for (int32_t k = 0; k < S.T; k++) n += nact_cur[k];
@@ -1030,9 +1058,7 @@ ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t ow
     if (!has_work) return;
     int32_t th, pth;
     frame_thresholds_hb(L.best, S.T, bm, 1, th, pth);
-    const int32_t b = S.node_base[t];
-    for (int32_t i = blockIdx.x * DBLOCK + threadIdx.x; i < na; i += gridDim.x * DBLOCK)
-        d_dec_stamp(L.act[cur], L.outs, S.psof_off, S.psof, L.pstamp8, b, na, i, pth, f);
+    d_stamp_and_list(L, S, cur, t, na, pth, f, blockIdx.x * DBLOCK, gridDim.x * DBLOCK);
 }
 
 /* the histogram beam + the reordering of the lists (frames over 1.5 x -maxhmmpf only), then the stamps of such a frame */
@@ -1078,6 +1104,30 @@ ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 
 /* many lanes: the active HMMs by list position + a K-nodes-per-thread sweep for the rest (the number of waves counts) */
 #define UR_K 8
+/* ... and the not active ones from their propagating parents' child lists instead of the sweep (GL one-wave workgroups per lane behind
+ * the GA of the active HMMs) */
+#ifndef UR_GL
+#define UR_GL 512     /* one-wave workgroups per lane that walk the propagating HMMs (32: 333 k, 128: 369 k, 512: 375 k, 1024: 370 k, 2048: 358 k frames/s; the sweep: 368 k) */
+#endif
+template <bool HEUR>
+__global__ void __launch_bounds__(RSBLOCK)
+ku_resolve_plist(const ULane *__restrict__ lanes, UShared S, int32_t fg)
+{
+    LANE;
+    const int32_t GA = (int32_t)gridDim.x - UR_GL;
+    if ((int32_t)blockIdx.x < GA) {
+        d_dec_resolve_utt<UR_K, uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
+                      S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
+                      L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
+                      L.act[cur], blockIdx.x, GA, 0, UHX);
+        return;
+    }
+    d_dec_resolve_children<uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
+                  S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
+                  L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
+                  L.plist, L.pcnt[f & 1], S.child_off, S.child, L.claim, (int32_t)blockIdx.x - GA, UR_GL, UHX);
+}
+
 template <bool HEUR, int URK = UR_K>
 __global__ void __launch_bounds__(RSBLOCK)
 ku_resolve_lists(const ULane *__restrict__ lanes, UShared S, int32_t fg)
@@ -1624,6 +1674,9 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.d.cs_val) (void)hipFree(hl.d.cs_val);
         if (hl.d.dynbeam) (void)hipFree(hl.d.dynbeam);
         if (hl.d.pstamp8) (void)hipFree(hl.d.pstamp8);
+        if (hl.d.plist) (void)hipFree(hl.d.plist);
+        if (hl.d.claim) (void)hipFree(hl.d.claim);
+        if (hl.d.pcnt) (void)hipFree(hl.d.pcnt);
         if (hl.d.ci_all) (void)hipFree(hl.d.ci_all);
         if (hl.d.heur_all) (void)hipFree(hl.d.heur_all);
         if (hl.d.hth_pos) (void)hipFree(hl.d.hth_pos);
@@ -1936,6 +1989,8 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         u.sen_act = hl.sc->act_d; u.scr = hl.sc->scr_d; u.misc = hl.sc->misc_d; u.bstidx = hl.sc->bstidx_d;
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
         DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4); DM(u.dynbeam, 16); DM(u.pstamp8, (size_t)proto->n_pset + 64); S.n_pset_bytes = proto->n_pset + 64;
+        DM(u.plist, (size_t)(proto->N + 64) * 4); DM(u.pcnt, 16); DM(u.claim, (size_t)(proto->N + 64) * 4);
+        if (hipMemset(u.pcnt, 0, 16) != hipSuccess) goto fail;
         if (hipMemset(u.pstamp8, 0xff, (size_t)proto->n_pset + 64) != hipSuccess) goto fail;
         if (S.win_K > 0) {
             DM(u.win, (size_t)S.win_K * n_sen * 4); DM(u.winb, (size_t)S.win_K * n_sen);
@@ -2229,7 +2284,12 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     if (S.pheurtype > 0) UKL(UK_RESOLVE, ku_heur_thresh, dim3(T, 1, n), dim3(1024), 0, st, LN, S, f);
     {   /* (the active HMMs by list position: ud->g_res workgroups that loop; the rest: a sweep, UR_K nodes per thread) */
         const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
-        if (S.pheurtype > 0) {
+        const bool by_parents = n >= ud->many && !s3a_variants()->resolve_sweep;   /* the not active nodes from their propagating parents' side */
+        if (by_parents) {
+            if (S.pheurtype > 0) UKL(UK_RESOLVE, ku_resolve_plist<true>, dim3(ud->g_res + UR_GL, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+            else UKL(UK_RESOLVE, ku_resolve_plist<false>, dim3(ud->g_res + UR_GL, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
+        }
+        else if (S.pheurtype > 0) {
             if (n >= ud->many) UKL(UK_RESOLVE, ku_resolve_lists<true>, dim3(ud->g_res + GB, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
             else UKL(UK_RESOLVE, ku_resolve<true>, dim3((S.N + RSBLOCK - 1) / RSBLOCK, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
         }

@@ -1347,7 +1347,7 @@ def dag_cfg(b, keep, bestpathlw=None, min_endfr=None, maxedge=None, maxlmop=None
 
 class Variants(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("scan_chained", "calls_by_copy", "batch_no_shared", "batch_no_multi",
-                                         "no_frame_sync_kernel", "score_nt", "score_fpc", "hist_sort_launch", "ps_overlap", "ps_score_by_gaussian")]
+                                         "no_frame_sync_kernel", "score_nt", "score_fpc", "resolve_sweep", "hist_sort_launch", "ps_overlap", "ps_score_by_gaussian")]
 
 
 def set_variants(**kw):

@@ -1127,6 +1127,7 @@ typedef struct {
     int32_t batch_no_shared, batch_no_multi;    /* s3a_batch: one scoring launch per decoder instead of the shared-model passes */
     int32_t no_frame_sync_kernel;   /* single-frame scoring through the general kernel */
     int32_t score_nt, score_fpc;    /* whole-utterance scoring: workgroup size (256 / 512 / 1024; 0 = 512), frames per chunk (0 = chosen) */
+    int32_t resolve_sweep;          /* whole-utterance engine, many lanes: find the nodes a parent may enter by the sweep over all nodes (round 2/3) instead of from the propagating HMMs' child lists */
     int32_t hist_sort_launch;       /* whole-utterance engine: the histogram sort as a launch of its own in every frame (default: on the count's launch, when a frame needs it) */
     int32_t ps_overlap;             /* s3a_psfwd_decode_queue: score the queue's later utterances BESIDE the search (second stream) instead of before it */
     int32_t ps_score_by_gaussian;   /* pocketsphinx batch scoring: the lane-per-Gaussian kernel (k_ps_cont_slots) instead of lane-per-frame */
