@@ -1,6 +1,9 @@
+export S3A_ON_GPU_BOX=1
+python -m pytest tests/test_gpu_dropin.py tests/test_gpu_uttdec.py tests/test_gpu_pheur.py -q -x > gpurun_out/plist_tests.txt 2>&1; tail -2 gpurun_out/plist_tests.txt | cut -c1-200
 cp cmusphinx_amd/libcmusphinx_amd.so /tmp/lib_base.so
-for v in gl512 gl1024 gl2048 sweep gl512; do
-if [ $v = sweep ]; then cp /tmp/lib_base.so cmusphinx_amd/libcmusphinx_amd.so; X="--variant resolve_sweep=1"; else cp cmusphinx_amd/variants/lib_$v.so cmusphinx_amd/libcmusphinx_amd.so; X=""; fi
+for v in base gl8 gl16 gl64 sweep base; do
+X=""
+if [ $v = base ]; then cp /tmp/lib_base.so cmusphinx_amd/libcmusphinx_amd.so; elif [ $v = sweep ]; then cp /tmp/lib_base.so cmusphinx_amd/libcmusphinx_amd.so; X="--variant resolve_sweep=1"; else cp cmusphinx_amd/variants/lib_$v.so cmusphinx_amd/libcmusphinx_amd.so; fi
 python bench.py --plain $X > gpurun_out/plain_v.json 2> gpurun_out/plain_v.err; python -c "
 import json; r=json.load(open('gpurun_out/plain_v.json')); print('$v', r['value'], r['identical_to_reference'])" 2>&1 | tail -1
 done
