@@ -712,12 +712,12 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
 
 /*
  * The nodes a propagating parent may ENTER while they are not on the list, found from the parents' side (round 4): the stamping
- * pass has listed the frame's HMMs whose exit score reaches the phone threshold (plist, any order); a wave takes such an HMM and
- * its lanes take the HMM's children (the static child lists of the emission sweep).  A child that is on the list is the other
- * half's (by list position); one with several parents -- a first-level node has one per left-context variant of its root -- is
- * taken by whichever listed parent claims it first (claim[]: the frame number, one atomic per such visit; the node rule walks all
- * parents anyway and does not depend on who called).  Replaces the sweep over ALL nodes for stamped parent sets (216 k nodes per
- * lane and frame for a few hundred propagating HMMs); the stamps stay for the active nodes' "can a parent enter me".
+ * pass has listed the frame's stamped PARENT SETS (plist, any order, each once); a wave takes a set and its lanes take the set's
+ * members (psmem: the nodes that share that parent list -- the children of one interior node, or the ~340 first-level nodes under
+ * the ~46 left-context variants of one root).  A member that is on the list is the other half's (by list position).  Replaces
+ * the sweep over ALL nodes for stamped parent sets (216 k nodes per lane and frame for a few hundred propagating HMMs); the
+ * byte stamps stay for the active nodes' "can a parent enter me".  (Listing the propagating HMMs and walking their child
+ * lists visited a first-level node once per variant, with an atomic claim each time: 375 k frames/s in the bench.)
  */
 template <typename PS, bool HEUR = false>
 __device__ __forceinline__ void
@@ -732,16 +732,15 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
               const int32_t *__restrict__ ps, const PS *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout,
-              const int32_t *__restrict__ plist, int32_t n_plist, const int32_t *__restrict__ child_off,
-              const int32_t *__restrict__ child, int32_t *claim, int32_t W, int32_t NW, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
+              const int32_t *__restrict__ plist, int32_t n_plist, const int32_t *__restrict__ psmem_off,
+              const int32_t *__restrict__ psmem, int32_t W, int32_t NW, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
 {
     const int32_t lane = threadIdx.x & 63;
     for (int32_t k = W; k < n_plist; k += NW) {
-        const int32_t u = plist[k];
-        for (int32_t c = child_off[u] + lane, c_hi = child_off[u + 1]; c < c_hi; c += 64) {
-            const int32_t x = child[c];
+        const int32_t q = plist[k];
+        for (int32_t c = psmem_off[q] + lane, c_hi = psmem_off[q + 1]; c < c_hi; c += 64) {
+            const int32_t x = psmem[c];
             if (posf[x] == cf) continue;                                    /* on the list: resolved by list position */
-            if (par_off[x + 1] - par_off[x] > 1 && atomicExch(&claim[x], cf) == cf) continue;  /* another parent took it */
             d_dec_resolve_node<PS, HEUR>(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh,
                                          bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf,
                                          posout, x, false, true, -1, -1, hx);

@@ -648,6 +648,16 @@ lexsearch_build(s3a_lexsearch_t *ls, int32_t n_tree, const int32_t *n_node,
         h_psoff[N] = (int32_t)h_psof.size();
         ls->n_pset = (int32_t)ids.size();
         UP(ls->d_ps, h_ps); UP(ls->d_psof_off, h_psoff); UP(ls->d_psof, h_psof);
+        /* ... and the members of every set, ascending (the whole-utterance engine resolves the not active nodes set by set) */
+        std::vector<int32_t> h_pmoff(ids.size() + 1, 0), h_pmem(N);
+        for (int32_t v = 0; v < N; v++) if (h_ps[v] >= 0) h_pmoff[h_ps[v] + 1]++;
+        for (size_t q = 0; q < ids.size(); q++) h_pmoff[q + 1] += h_pmoff[q];
+        {
+            std::vector<int32_t> fillm(h_pmoff.begin(), h_pmoff.end() - 1);
+            for (int32_t v = 0; v < N; v++) if (h_ps[v] >= 0) h_pmem[fillm[h_ps[v]]++] = v;
+        }
+        h_pmem.resize(h_pmoff[ids.size()] > 0 ? h_pmoff[ids.size()] : 1);
+        UP(ls->d_psmem_off, h_pmoff); UP(ls->d_psmem, h_pmem);
     }
     ls->h_rootlist = h_roots;
 #undef UP
@@ -772,7 +782,7 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
     if (!ls) return;
     int32_t **statics[] = { &ls->d_node_base, &ls->d_ssid, &ls->d_tmatid, &ls->d_wid, &ls->d_prob,
         &ls->d_child_off, &ls->d_child, &ls->d_par_off, &ls->d_par, &ls->d_rootlist, &ls->d_tp,
-        &ls->d_comstate_off, &ls->d_tree_of, &ls->d_rootnodes, &ls->d_ps, &ls->d_psof_off, &ls->d_psof };
+        &ls->d_comstate_off, &ls->d_tree_of, &ls->d_rootnodes, &ls->d_ps, &ls->d_psof_off, &ls->d_psof, &ls->d_psmem_off, &ls->d_psmem };
     int32_t **state[] = { &ls->d_sc,            /* (d_hist, d_outs, d_outh, d_bests, d_frame point into d_sc's records) */
         &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,

@@ -106,7 +106,7 @@ struct s3a_lexsearch_s {
     int32_t *d_done;                    /* workgroup completion counter of the fused finishing kernel */
     int32_t *d_hbin;                    /* [1000] lextree_hmm_histbin bins | [1000] = the histogram beam */
     int32_t *d_rootnodes, n_rootnodes;  /* the distinct root nodes of all trees */
-    int32_t *d_ps, *d_psof_off, *d_psof, *d_pstamp, n_pset;    /* parent-set ids: of a node, of a node's children; frame stamps */
+    int32_t *d_ps, *d_psof_off, *d_psof, *d_psmem_off, *d_psmem, *d_pstamp, n_pset;    /* parent-set ids: of a node, of a node's children; frame stamps */
     int32_t *d_ctot, *d_n0;             /* per-call root counts [4096], list lengths before the entries [n_tree] */
     int32_t hist_bound, last_nnxt;      /* host upper bound on the coming frame's active HMMs */
     int32_t row_bound;                  /* ... on its LONGEST active list (per tree: sizes the per-position grids) */

@@ -51,9 +51,9 @@ struct ULane {
     uint8_t *pstamp8;           /* [n_pset] the parent sets' stamps, the frame number's low 8 bits (a quarter of the
                                  * sweep's gathers' footprint; a stale match costs a walk that finds nothing) */
     int32_t *dynbeam;           /* [1] the frame's CI beam when -maxcdsenpf is in force (ku_dyn_ci_beam) */
-    int32_t *claim;             /* [N] a several-parent node taken in frame .. by one of its propagating parents (ku_resolve_lists) */
-    int32_t *plist, *pcnt;      /* [N], [2]: the HMMs of the frame that can propagate (exit score over the phone threshold), any order;
-                                 * their number by frame parity (the stamping pass appends, a wave at a time; resolve walks their children) */
+    int32_t *claim;             /* [N >= n_pset] the frame in which a parent set was last listed (d_stamp_and_list) */
+    int32_t *plist, *pcnt;      /* [N], [2]: the parent sets stamped in the frame (by an HMM whose exit score reaches the phone threshold), any order;
+                                 * their number by frame parity (the stamping pass appends; ku_resolve_plist walks their members) */
     int32_t *win;               /* [K][n_sen] look-ahead window: every senone's score for the frames f0 .. f0 + K - 1 */
     uint8_t *winb;              /* [K][n_sen] ... and the best component of its mixture (255: none) */
     /* -pheurtype > 0 (s3a_uttdec_enable_pheur) */
@@ -72,7 +72,7 @@ struct UShared {
     int32_t N, T, n_tmat, maxn, n_rootnodes, scan_chunks, pack_max_exits, gp_n, n_cs, n_pset_bytes;
     int32_t ne;                 /* emitting states per HMM (3 or 5): the node record's layout, s3a_structs.h */
     const int32_t *node_base, *ssid, *tmatid, *wid, *prob, *child_off, *child, *par_off, *par, *tree_of, *rootlist, *tp,
-        *rootnodes, *ps, *psof_off, *psof, *cs_off, *cs_wt, *rootprob;
+        *rootnodes, *ps, *psof_off, *psof, *psmem_off, *psmem, *cs_off, *cs_wt, *rootprob;
     const uint8_t *comp;
     const int16_t *sseq, *comsseq, *cs_list;
     const int4 *node4;          /* per node: {ssid, tmatid, wid, composite}: ku_hmm_eval's static words as one load */
@@ -979,9 +979,10 @@ ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 
 /* after the evaluation: the histogram bins when the frame holds more than 1.5 x -maxhmmpf HMMs (lextree_hmm_histbin);
  * otherwise the thresholds are final and the HMMs that can propagate stamp their children's parent sets (d_dec_stamp) */
-/* The stamps of tree t's HMMs that can propagate (d_dec_stamp) AND their ids appended to the lane's list of the frame, a wave at
- * a time (one atomic per 64 HMMs; the order does not matter: ku_resolve_lists visits the children of every listed HMM).  i0 / stride:
- * this workgroup's first list position and the step to its next, uniform over the workgroup. */
+/* The stamps of tree t's HMMs that can propagate (d_dec_stamp) AND the stamped sets appended to the lane's list of the frame, each
+ * once (claim[set] = the frame number, exchanged: whoever finds an older frame there lists the set; the order does not matter,
+ * ku_resolve_plist visits the members of every listed set).  i0 / stride: this workgroup's first list position and the step to
+ * its next, uniform over the workgroup. */
 __device__ __forceinline__ void
 d_stamp_and_list(const ULane &L, const UShared &S, int32_t cur, int32_t t, int32_t na, int32_t pth, int32_t f, int32_t i0, int32_t stride)
 {
@@ -992,15 +993,12 @@ d_stamp_and_list(const ULane &L, const UShared &S, int32_t cur, int32_t t, int32
         int32_t u = -1;
         bool prop = false;
         if (i < na) { u = L.act[cur][b + i]; prop = L.outs[NSV(u)] >= pth; }
-        if (prop) for (int32_t q = S.psof_off[u], q_hi = S.psof_off[u + 1]; q < q_hi; q++) L.pstamp8[S.psof[q]] = ps_val<uint8_t>(f);
-        const unsigned long long m = __ballot(prop);
-        if (m) {
-            const int lane = threadIdx.x & 63;
-            int32_t base = 0;
-            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(cnt, __popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1);
-            if (prop) L.plist[base + __popcll(m & ((1ull << lane) - 1ull))] = u;
-        }
+        if (prop)
+            for (int32_t q = S.psof_off[u], q_hi = S.psof_off[u + 1]; q < q_hi; q++) {
+                const int32_t ps = S.psof[q];
+                L.pstamp8[ps] = ps_val<uint8_t>(f);
+                if (atomicExch(&L.claim[ps], f) != f) L.plist[atomicAdd(cnt, 1)] = ps;     /* the first HMM to stamp the set lists it */
+            }
     }
 }
 
@@ -1104,10 +1102,10 @@ ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 
 /* many lanes: the active HMMs by list position + a K-nodes-per-thread sweep for the rest (the number of waves counts) */
 #define UR_K 8
-/* ... and the not active ones from their propagating parents' child lists instead of the sweep (GL one-wave workgroups per lane behind
- * the GA of the active HMMs) */
+/* ... and the not active ones from the frame's list of stamped parent sets instead of the sweep (GL one-wave workgroups per lane
+ * behind the GA of the active HMMs) */
 #ifndef UR_GL
-#define UR_GL 512     /* one-wave workgroups per lane that walk the propagating HMMs (32: 333 k, 128: 369 k, 512: 375 k, 1024: 370 k, 2048: 358 k frames/s; the sweep: 368 k) */
+#define UR_GL 512     /* one-wave workgroups per lane that walk the listed sets (one box: 128: 353.5 k, 256: 362.2 k, 512: 363.9 k frames/s; the sweep: 355.9 k) */
 #endif
 template <bool HEUR>
 __global__ void __launch_bounds__(RSBLOCK)
@@ -1125,7 +1123,7 @@ ku_resolve_plist(const ULane *__restrict__ lanes, UShared S, int32_t fg)
     d_dec_resolve_children<uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                   S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
                   L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
-                  L.plist, L.pcnt[f & 1], S.child_off, S.child, L.claim, (int32_t)blockIdx.x - GA, UR_GL, UHX);
+                  L.plist, L.pcnt[f & 1], S.psmem_off, S.psmem, (int32_t)blockIdx.x - GA, UR_GL, UHX);
 }
 
 template <bool HEUR, int URK = UR_K>
@@ -1831,7 +1829,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         }
         S.rootprob = rp;
     }
-    S.rootnodes = proto->d_rootnodes; S.ps = proto->d_ps; S.psof_off = proto->d_psof_off; S.psof = proto->d_psof;
+    S.rootnodes = proto->d_rootnodes; S.ps = proto->d_ps; S.psof_off = proto->d_psof_off; S.psof = proto->d_psof; S.psmem_off = proto->d_psmem_off; S.psmem = proto->d_psmem;
     S.cs_off = cs->off_d; S.cs_wt = cs->wt_d; S.cs_list = cs->list_d; S.n_cs = cs->n_comstate;
     S.comp = proto->d_comp; S.sseq = proto->d_sseq; S.comsseq = proto->d_comsseq;
     S.mean4 = d->mean4; S.prec4 = d->prec4; S.lrd = d->lrd; S.mixw = d->mixw; S.tab16 = d->tab16; S.tab_size = d->tab_size;
