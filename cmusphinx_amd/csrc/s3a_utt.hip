@@ -59,7 +59,7 @@ struct ULane {
     /* -pheurtype > 0 (s3a_uttdec_enable_pheur) */
     int32_t *ci_all;            /* [max_frames][n_ci_sen] the utterance's raw CI senone scores (gmm_compute_lv1 for every frame) */
     int32_t *heur_all;          /* [max_frames][n_ci] phn_heur_list of every frame (pl_computePhnHeur) */
-    int32_t *hth_pos;           /* [N] by list position (tree slices): the heuristic threshold of the HMM listed there */
+    int32_t *hth_pos;           /* [3][N] by list position (tree slices): the heuristic threshold of the HMM listed there; ku_weak_heur's survivors */
     int32_t *ph_scratch;        /* [3 n_ci_sen + 8] the look-ahead pass's throw-away best-Gaussian state and counters */
     /* this utterance */
     UCtx *ctx;
@@ -913,8 +913,8 @@ ku_phn_heur(const ULane *__restrict__ lanes, UShared S, const int32_t *__restric
 /* per frame, behind the thresholds: the heuristic threshold of every propagating HMM by list position -- the running maximum
  * over the active list (per tree: kbc->maxNewHeurScore is reset by every lextree_hmm_propagate_non_leaves call) of
  * max over children (out + (prob(child) - prob) + phn_heur[ci(child)]), plus pl_beam (lextree.c:1443-1462).  One workgroup
- * per (tree, lane); an HMM propagates when it is no leaf and its exit score reaches the phone threshold (with the phone
- * beam no wider than the HMM beam -- checked when the look-ahead is enabled -- such an HMM is never cleared first). */
+ * per (tree, lane); an HMM propagates when it is no leaf and its exit score reaches the phone threshold (this kernel: the phone
+ * threshold never below the HMM threshold, so such an HMM is never cleared first; otherwise ku_weak_heur). */
 __global__ void __launch_bounds__(1024)
 ku_heur_thresh(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 {
@@ -958,6 +958,142 @@ ku_heur_thresh(const ULane *__restrict__ lanes, UShared S, int32_t fg)
         __syncthreads();
         if (tid == 1023) s_carry = x;
         __syncthreads();
+    }
+}
+
+/*
+ * -pheurtype together with a phone threshold BELOW the HMM threshold (-ptranskip frames: bestwordscore + -wbeam; -pbeam wider
+ * than -beam): the two dependencies meet.  A "weak" HMM (under the HMM beam, exit score over the phone threshold) propagates only
+ * when a parent EARLIER in the list entered it first (d_dec_weak) -- and with the look-ahead that entry must also pass the
+ * heuristic threshold at the parent's list position, which is the running maximum over the HMMs that propagate up to there,
+ * surviving weak ones included (lextree.c:1424-1458: the clear at the HMM's turn, then maxNewHeurScore).  Every dependency
+ * points to a smaller list position of the same tree, so one workgroup per (tree, lane):
+ *   1. the running maximum over the HMMs that propagate whatever happens (not weak) -> hth_pos (raw), and the weak HMMs
+ *      compacted in list order with their own contribution (position, max over children);
+ *   2. ONE wave walks the weak HMMs in list order, its lanes over the HMM's parents: entered early by a propagating parent
+ *      whose threshold (hth_pos at the parent's position, or the best surviving weak HMM at or before it) the entry passes
+ *      -> propf stamp, and the survivor joins the list of (position, running maximum);
+ *   3. hth_pos = max(raw, survivors at or before the position) + pl_beam.
+ * Replaces ku_weak + ku_heur_thresh when both options are on (in a frame with the usual geometry no HMM is weak and 2. is empty).
+ */
+__global__ void __launch_bounds__(1024)
+ku_weak_heur(const ULane *__restrict__ lanes, UShared S, int32_t fg)
+{
+    LANE;
+    const int32_t t = blockIdx.x, na = nact_cur[t], b = S.node_base[t], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (na == 0) return;
+    int32_t th, pth;
+    {
+        int32_t bh, bw, n, wth;
+        (void)frame_thresholds(L.best, nact_cur, S.T, frame_beams(S, f), L.hbin, bh, bw, n, th, pth, wth);
+    }
+    const bool weak_frame = pth < th;
+    const int32_t *heur = L.heur_all + (size_t)f * S.n_ci;
+    const int32_t *act = L.act[cur];
+    int32_t *wl_v = L.exits + b, *wl_pos = L.exits + (size_t)S.N + b, *wl_H = L.exits + 2 * (size_t)S.N + b;   /* (free between the histogram and the scan) */
+    int32_t *sv_pos = L.hth_pos + (size_t)S.N + b, *sv_max = L.hth_pos + 2 * (size_t)S.N + b;
+    __shared__ int32_t s_w[16], s_c[16], s_carry, s_nw, s_ns;
+    if (tid == 0) { s_carry = INT_MIN; s_nw = 0; s_ns = 0; }
+    __syncthreads();
+    for (int32_t i0 = 0; i0 < na; i0 += 1024) {
+        const int32_t i = i0 + tid;
+        int32_t m = INT_MIN, p = -1;
+        bool wk = false;
+        if (i < na) {
+            p = act[b + i];
+            const int32_t po = L.outs[NSV(p)];
+            if (S.wid[p] < 0 && po >= pth) {
+                const int32_t pp = S.prob[p];
+                for (int32_t q = S.child_off[p]; q < S.child_off[p + 1]; q++) {
+                    const int32_t c = S.child[q];
+                    m = max(m, add32(add32(po, add32(S.prob[c], -pp)), heur[S.node_ci[c]]));
+                }
+                wk = weak_frame && L.bests[NSV(p)] < th;
+            }
+        }
+        const unsigned long long wm = __ballot(wk);
+        int32_t x = wk ? INT_MIN : m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(x, o, 64); if (lane >= o) x = max(x, y); }
+        if (lane == 63) s_w[wv] = x;
+        if (lane == 0) s_c[wv] = __popcll(wm);
+        __syncthreads();
+        int32_t pre = s_carry, at = s_nw;
+        for (int32_t w = 0; w < wv; w++) { pre = max(pre, s_w[w]); at += s_c[w]; }
+        x = max(x, pre);
+        if (i < na) L.hth_pos[b + i] = x;
+        if (wk) {
+            const int32_t k = at + __popcll(wm & ((1ull << lane) - 1ull));
+            wl_v[k] = p; wl_pos[k] = i; wl_H[k] = m;
+        }
+        __syncthreads();
+        if (tid == 1023) { s_carry = x; s_nw = at + s_c[15]; }
+        __syncthreads();
+    }
+    const int32_t nw = s_nw;
+    if (nw == 0) {
+        for (int32_t i = tid; i < na; i += 1024) L.hth_pos[b + i] = add32(L.hth_pos[b + i], S.pl_beam);
+        return;
+    }
+    __threadfence_block();
+    if (wv == 0) {
+        int32_t ns = 0, smax = INT_MIN;
+        for (int32_t k = 0; k < nw; k++) {
+            const int32_t v = wl_v[k], j = wl_pos[k];
+            const int32_t in0 = L.sc[NSV(v)], hv = heur[S.node_ci[v]];
+            bool early = false;
+            for (int32_t q0 = S.par_off[v], q_hi = S.par_off[v + 1]; q0 < q_hi && !early; q0 += 64) {
+                bool pass = false;
+                const int32_t q = q0 + lane;
+                if (q < q_hi) {
+                    const int32_t g = S.par[q];
+                    const int32_t pp = L.pos[g];
+                    if (L.posf[g] == f && pp < j) {
+                        const int32_t po = L.outs[NSV(g)];
+                        if (po >= pth && (L.bests[NSV(g)] >= th || ((volatile int32_t *)L.propf)[g] == f)) {
+                            const int32_t nsc = add32(po, add32(S.prob[v], -S.prob[g]));
+                            if (nsc >= th && nsc > in0) {
+                                int32_t hm = L.hth_pos[b + pp];
+                                if (ns > 0 && ((volatile int32_t *)sv_pos)[0] <= pp) {       /* the last survivor at or before pp */
+                                    int32_t lo = 0, hi = ns - 1;
+                                    while (lo < hi) {
+                                        const int32_t mid = (lo + hi + 1) >> 1;
+                                        if (((volatile int32_t *)sv_pos)[mid] <= pp) lo = mid; else hi = mid - 1;
+                                    }
+                                    hm = max(hm, ((volatile int32_t *)sv_max)[lo]);
+                                }
+                                pass = add32(nsc, hv) >= add32(hm, S.pl_beam);
+                            }
+                        }
+                    }
+                }
+                early = __any(pass);
+            }
+            if (early) {
+                smax = max(smax, wl_H[k]);
+                if (lane == 0) {
+                    ((volatile int32_t *)L.propf)[v] = f;
+                    ((volatile int32_t *)sv_pos)[ns] = j; ((volatile int32_t *)sv_max)[ns] = smax;
+                }
+                ns++;
+                __threadfence_block();
+            }
+        }
+        if (lane == 0) s_ns = ns;
+    }
+    __syncthreads();
+    const int32_t ns = s_ns;
+    for (int32_t i = tid; i < na; i += 1024) {
+        int32_t hm = L.hth_pos[b + i];
+        if (ns > 0 && sv_pos[0] <= i) {
+            int32_t lo = 0, hi = ns - 1;
+            while (lo < hi) {
+                const int32_t mid = (lo + hi + 1) >> 1;
+                if (sv_pos[mid] <= i) lo = mid; else hi = mid - 1;
+            }
+            hm = max(hm, sv_max[lo]);
+        }
+        L.hth_pos[b + i] = add32(hm, S.pl_beam);
     }
 }
 
@@ -2278,8 +2414,11 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
             else UKL(UK_HIST_SORT, ku_hist_sort<SCAN_THREADS>, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
         }
     }
-    if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
-    if (S.pheurtype > 0) UKL(UK_RESOLVE, ku_heur_thresh, dim3(T, 1, n), dim3(1024), 0, st, LN, S, f);
+    if (ud->weak_possible && S.pheurtype > 0) UKL(UK_WEAK, ku_weak_heur, dim3(T, 1, n), dim3(1024), 0, st, LN, S, f);
+    else {
+        if (ud->weak_possible) UKL(UK_WEAK, ku_weak, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+        if (S.pheurtype > 0) UKL(UK_RESOLVE, ku_heur_thresh, dim3(T, 1, n), dim3(1024), 0, st, LN, S, f);
+    }
     {   /* (the active HMMs by list position: ud->g_res workgroups that loop; the rest: a sweep, UR_K nodes per thread) */
         const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
         const bool by_parents = n >= ud->many && !s3a_variants()->resolve_sweep;   /* the not active nodes from their propagating parents' side */
@@ -2911,10 +3050,6 @@ s3a_uttdec_enable_pheur(s3a_uttdec_t *ud, int32_t pheurtype, int32_t pl_beam, in
         s3a_set_error("s3a_uttdec_enable_pheur: bad arguments (%d CI phones, 1..%d; -pl_window %d >= 1)", n_ci, PH_MAXCI, pl_window);
         return S3A_EINVAL;
     }
-    if (ud->weak_possible) {
-        s3a_set_error("s3a_uttdec_enable_pheur: -pheurtype with a phone beam wider than the HMM beam (-pbeam < -beam) or with -ptranskip is not supported");
-        return S3A_EUNSUP;
-    }
     if (ud->S.n_sen <= ud->S.n_ci_sen) { s3a_set_error("s3a_uttdec_enable_pheur: the model has no CD senones"); return S3A_EUNSUP; }
     UShared &S = ud->S;
     if (!S.node_ci) {
@@ -2944,7 +3079,7 @@ s3a_uttdec_enable_pheur(s3a_uttdec_t *ud, int32_t pheurtype, int32_t pl_beam, in
             ULane &u = ud->lane[z].d;
             if (hipMalloc((void **)&u.ci_all, (size_t)ud->max_frames * S.n_ci_sen * 4) != hipSuccess
                 || hipMalloc((void **)&u.heur_all, (size_t)ud->max_frames * n_ci * 4) != hipSuccess
-                || hipMalloc((void **)&u.hth_pos, (size_t)S.N * 4) != hipSuccess
+                || hipMalloc((void **)&u.hth_pos, (size_t)3 * S.N * 4) != hipSuccess      /* (+ ku_weak_heur's survivors) */
                 || hipMalloc((void **)&u.ph_scratch, ((size_t)3 * S.n_ci_sen + 8) * 4) != hipSuccess) {
                 s3a_set_error("s3a_uttdec_enable_pheur: device allocation failed");
                 return S3A_ENOMEM;

@@ -793,7 +793,8 @@ int32_t s3a_uttdec_window(const s3a_uttdec_t *ud);
  * phone reaches the running maximum of that figure over the active list + pl_beam.  pl_beam = logs3(-pl_beam);
  * node_ci[t][i] = lextree_node_t.ci of node i of tree t (the trees of s3a_lexsearch_init, in its order);
  * sen2cimap = mdef_t.sen2cimap[0 .. n_ci_sen] (one entry past the CI senones, as the reference reads it).
- * Not supported together with a phone beam wider than the HMM beam or -ptranskip (S3A_EUNSUP).  pheurtype 0: off.
+ * Together with a phone threshold below the HMM threshold (-ptranskip frames, -pbeam wider than -beam) the engine settles the
+ * two dependencies along the list in one kernel (ku_weak_heur; lextree.c:1424-1458).  pheurtype 0: off.
  */
 int32_t s3a_uttdec_enable_pheur(s3a_uttdec_t *ud, int32_t pheurtype, int32_t pl_beam, int32_t pl_window,
                                 const uint8_t *const *node_ci, const int16_t *sen2cimap, int32_t n_ci);

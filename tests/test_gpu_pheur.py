@@ -20,6 +20,11 @@ OPTS = {
     "t1_w5": ["-pheurtype", "1", "-pl_window", "5", "-pl_beam", "1e-30"],
     "t2_w3": ["-pheurtype", "2", "-pl_window", "3", "-pl_beam", "1e-5"],
     "t3_w4": ["-pheurtype", "3", "-pl_window", "4", "-pl_beam", "1e-20"],
+    # ... with -ptranskip: in those frames the phone threshold is bestwordscore + -wbeam, BELOW the HMM threshold -- HMMs under the
+    # HMM beam propagate when an earlier parent re-entered them, and that entry must pass the look-ahead too (ku_weak_heur)
+    "t1_w5_skip3": ["-pheurtype", "1", "-pl_window", "5", "-pl_beam", "1e-30", "-ptranskip", "3"],
+    "t3_w4_skip2": ["-pheurtype", "3", "-pl_window", "4", "-pl_beam", "1e-20", "-ptranskip", "2"],
+    "t2_w3_skip1": ["-pheurtype", "2", "-pl_window", "3", "-pl_beam", "1e-5", "-ptranskip", "1"],
     "t1_w10_hist": ["-pheurtype", "1", "-pl_window", "10", "-pl_beam", "1e-25", "-maxhmmpf", "400", "-ci_pbeam", "1e-8"],
 }
 
@@ -102,10 +107,12 @@ def test_phoneme_lookahead_from_a_bundle(task3, gpu_lib):
     assert "".join(o[0] for o in out) == hyp and "".join(o[1] for o in out) == seg
 
 
-def test_lookahead_with_a_wide_phone_beam_is_refused(task3):
+def test_lookahead_with_a_wide_phone_beam(task3):
+    """-pbeam wider than -beam: every frame has HMMs under the HMM beam that may still propagate (refused until round 4)"""
     d, args = task3
     wide = [a for a in args]
     wide[wide.index("-pbeam") + 1] = "1e-90"               # wider than -beam 1e-70
-    r = subprocess.run([TST] + wide + OPTS["t1_w1"] + ["-hyp", d + "/w.hyp"], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, S3A_UTT="2"))
-    assert r.returncode != 0 and "not supported" in r.stderr
+    for key, opt in (("wide_t1", "t1_w5"), ("wide_t3_skip", "t3_w4_skip2")):
+        OPTS[key] = OPTS[opt]
+        both(d, wide, key, "u4_" + key, {"S3A_UTT": "4"})
+        both(d, wide, key, "u1_" + key, {"S3A_UTT": "1"})
