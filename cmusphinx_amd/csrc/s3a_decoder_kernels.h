@@ -736,9 +736,65 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
               const int32_t *__restrict__ psmem, int32_t W, int32_t NW, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
 {
     const int32_t lane = threadIdx.x & 63;
+    /* (one wave per workgroup) the qualifying parents of a several-parent set, loaded once for all of its members */
+    __shared__ int32_t s_po[64], s_pp[64], s_ph[64], s_pr[64], s_ht[64];
+    int32_t th, pth;
+    {
+        int32_t bh, bw, n, wth;
+        (void)frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
+    }
     for (int32_t k = W; k < n_plist; k += NW) {
         const int32_t q = plist[k];
-        for (int32_t c = psmem_off[q] + lane, c_hi = psmem_off[q + 1]; c < c_hi; c += 64) {
+        const int32_t m_lo = psmem_off[q], m_hi = psmem_off[q + 1];
+        const int32_t x0 = psmem[m_lo], kp0 = par_off[x0], np = par_off[x0 + 1] - kp0;
+        if (np > 1 && np <= 64) {
+            /* a first-level set: ~340 members under the ~46 left-context variants of one root.  Every member walking the
+             * same 46 parents was 46 x (id + list stamp) gathers per member; the few variants that do propagate are found
+             * once, and a member only combines their exit scores with its own probability (the rule of d_dec_resolve_node
+             * for a node that is not on the list: every parent is "earlier") */
+            bool qual = false;
+            int32_t po = 0, pp = 0, ph = 0, pr = 0, ht = INT_MIN, g = -1;
+            if (lane < np) {
+                g = par[kp0 + lane];
+                if (posf[g] == cf) {
+                    po = outs[NSV(g)];
+                    qual = po >= pth && !(pth < th && bests[NSV(g)] < th && propf[g] != cf);
+                }
+            }
+            const unsigned long long qm = __ballot(qual);
+            if (!qm) continue;
+            const int32_t b = node_base[tree_of[x0]];
+            if (qual) {
+                pp = pos[g]; ph = outh[NSV(g)]; pr = prob[g];
+                if (HEUR) ht = hx.hth_pos[b + pp];
+                const int32_t at = __popcll(qm & ((1ull << lane) - 1ull));
+                s_po[at] = po; s_pp[at] = pp; s_ph[at] = ph; s_pr[at] = pr; s_ht[at] = ht;
+            }
+            __syncthreads();
+            const int32_t nq = __popcll(qm), nf = cf + 1;
+            for (int32_t c = m_lo + lane; c < m_hi; c += 64) {
+                const int32_t x = psmem[c];
+                if (posf[x] == cf) continue;                                /* on the list: resolved by list position */
+                const int32_t in0 = sc[NSV(x)], px = prob[x];
+                const int32_t hv = HEUR ? hx.heur[hx.node_ci[x]] : 0;
+                int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
+                for (int32_t u = 0; u < nq; u++) {
+                    const int32_t ns = add32(s_po[u], add32(px, -s_pr[u]));
+                    if (ns < th) continue;
+                    if (HEUR && add32(ns, hv) < s_ht[u]) continue;
+                    const int32_t up = s_pp[u];
+                    if (ns > mE || (ns == mE && up < pE)) { mE = ns; pE = up; hE = s_ph[u]; }
+                    if (ns > in0 && up < firstE) firstE = up;
+                }
+                if (mE > in0) {
+                    sc[NSV(x)] = mE; hist[NSV(x)] = hE; frame[NSV(x)] = nf;
+                    turn[x] = firstE; atomicAdd(&cnt[b + firstE], 1);
+                }
+            }
+            __syncthreads();
+            continue;
+        }
+        for (int32_t c = m_lo + lane; c < m_hi; c += 64) {
             const int32_t x = psmem[c];
             if (posf[x] == cf) continue;                                    /* on the list: resolved by list position */
             d_dec_resolve_node<PS, HEUR>(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh,
