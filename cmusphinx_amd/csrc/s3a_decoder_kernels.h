@@ -482,6 +482,46 @@ d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
  * without a propagating parent fall through after two loads.  Also resets the root-entry
  * scratch (key / first) for this frame's transitions.
  */
+/* what the parents found mean for node v (the second half of the rule): the best entry by a parent earlier in the list (mE from
+ * list position pE with history hE; firstE = the first earlier parent that improves on v's own entry score), the same for the
+ * later parents, v's own survival at its turn j, the clear, and the turn at which v joins the next list */
+__device__ __forceinline__ void
+d_dec_resolve_finish(int32_t N, int32_t cf, int32_t th, int32_t b, int32_t v, bool is_active, int32_t j, int32_t in0,
+                     int32_t mE, int32_t hE, int32_t firstE, int32_t mL, int32_t hL, int32_t firstL,
+                     int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests,
+                     int32_t *frame, int32_t *turn, int32_t *selfemit, int32_t *cnt, int32_t *posout)
+{
+    const int32_t nf = cf + 1;
+    if (!is_active && mE == INT_MIN)
+        return;                                         /* nothing happens to this node */
+    int32_t cur = in0, h0 = hist[NSV(v)], my_turn = -1;
+    bool in_list = false, cleared = false, entered = false;
+    if (mE > in0) {
+        cur = mE; h0 = hE; entered = true; in_list = true; my_turn = firstE;
+    }
+    else if (is_active) {
+        if (bests[NSV(v)] >= th) { in_list = true; selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); }
+        else { cleared = true; cur = WORST; h0 = -1; }
+    }
+    if (mL > cur) {
+        cur = mL; h0 = hL; entered = true;
+        if (!in_list) { in_list = true; my_turn = firstL; }
+    }
+    if (cleared) {
+        const int32_t ne = (int32_t)(hist - sc);
+        if (ne == 3) {
+            sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
+            hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
+        }
+        else for (int32_t st = 1; st < ne; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
+        outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
+        posout[b + j] = WORST;                  /* k_dec_scan reads the exit scores by list position */
+    }
+    if (cleared || entered) { sc[NSV(v)] = cur; hist[NSV(v)] = h0; }
+    frame[NSV(v)] = in_list ? nf : (cleared ? -1 : frame[NSV(v)]);
+    if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[b + my_turn], 1); }
+}
+
 /* what happens to node v (active, or with an active parent) in this frame: the rule of s3a_lextree.hip.
  * (PS = the type of the parent sets' stamps: int32 frame numbers, or their low 8 bits in the whole-utterance engine --
  * a stale stamp that happens to match only costs a parent walk that finds nothing) */
@@ -562,35 +602,8 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
             }
         }
     }
-    if (!is_active && mE == INT_MIN)
-        return;                                         /* nothing happens to this node */
-    const int32_t b = b_known >= 0 ? b_known : node_base[tree_of[v]];
-    int32_t cur = in0, h0 = hist[NSV(v)], my_turn = -1;
-    bool in_list = false, cleared = false, entered = false;
-    if (mE > in0) {
-        cur = mE; h0 = hE; entered = true; in_list = true; my_turn = firstE;
-    }
-    else if (is_active) {
-        if (bests[NSV(v)] >= th) { in_list = true; selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); }
-        else { cleared = true; cur = WORST; h0 = -1; }
-    }
-    if (mL > cur) {
-        cur = mL; h0 = hL; entered = true;
-        if (!in_list) { in_list = true; my_turn = firstL; }
-    }
-    if (cleared) {
-        const int32_t ne = (int32_t)(hist - sc);
-        if (ne == 3) {
-            sc[NSI(1, N, v)] = WORST; sc[NSI(2, N, v)] = WORST;
-            hist[NSI(1, N, v)] = -1; hist[NSI(2, N, v)] = -1;
-        }
-        else for (int32_t st = 1; st < ne; st++) { sc[NSI(st, N, v)] = WORST; hist[NSI(st, N, v)] = -1; }
-        outs[NSV(v)] = WORST; outh[NSV(v)] = -1; bests[NSV(v)] = WORST;
-        posout[b + j] = WORST;                  /* k_dec_scan reads the exit scores by list position */
-    }
-    if (cleared || entered) { sc[NSV(v)] = cur; hist[NSV(v)] = h0; }
-    frame[NSV(v)] = in_list ? nf : (cleared ? -1 : frame[NSV(v)]);
-    if (my_turn >= 0) { turn[v] = my_turn; atomicAdd(&cnt[b + my_turn], 1); }
+    d_dec_resolve_finish(N, cf, th, b_known >= 0 ? b_known : node_base[tree_of[v]], v, is_active, j, in0, mE, hE, firstE, mL, hL, firstL,
+                         sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, posout);
 }
 
 template <typename PS, bool HEUR = false>
@@ -651,7 +664,8 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
               const int32_t *__restrict__ ps, const PS *__restrict__ pstamp,
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout, const int32_t *__restrict__ act,
-        const int32_t BX, const int32_t GA, const int32_t GB, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
+        const int32_t BX, const int32_t GA, const int32_t GB, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL },
+        const int32_t *__restrict__ claim = NULL)
 {
 #define RS_ARGS N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh, bests, frame, turn,  \
         selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf, posout
@@ -676,7 +690,13 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
                 const int32_t i = (w - w0) * RSBLOCK + threadIdx.x;
                 if (i < na) {
                     const int32_t v = act[b + i], q = ps[v];
-                    d_dec_resolve_node<PS, HEUR>(RS_ARGS, v, true, q >= 0 && pstamp[q] == ps_val<PS>(cf), i, b, hx);
+                    const bool has_par = q >= 0 && pstamp[q] == ps_val<PS>(cf);
+                    /* (claim: the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
+                    if (has_par && claim && claim[q] == cf) {
+                        const int32_t np = par_off[v + 1] - par_off[v];
+                        if (np > 1 && np <= 64) continue;
+                    }
+                    d_dec_resolve_node<PS, HEUR>(RS_ARGS, v, true, has_par, i, b, hx);
                 }
             }
             w0 += nw;
@@ -750,8 +770,8 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
         if (np > 1 && np <= 64) {
             /* a first-level set: ~340 members under the ~46 left-context variants of one root.  Every member walking the
              * same 46 parents was 46 x (id + list stamp) gathers per member; the few variants that do propagate are found
-             * once, and a member only combines their exit scores with its own probability (the rule of d_dec_resolve_node
-             * for a node that is not on the list: every parent is "earlier") */
+             * once, and a member only combines their exit scores with its own probability (the parent loop of
+             * d_dec_resolve_node from LDS; the members that are ON the list included: d_dec_resolve_utt skips them) */
             bool qual = false;
             int32_t po = 0, pp = 0, ph = 0, pr = 0, ht = INT_MIN, g = -1;
             if (lane < np) {
@@ -762,7 +782,6 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
                 }
             }
             const unsigned long long qm = __ballot(qual);
-            if (!qm) continue;
             const int32_t b = node_base[tree_of[x0]];
             if (qual) {
                 pp = pos[g]; ph = outh[NSV(g)]; pr = prob[g];
@@ -771,25 +790,32 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
                 s_po[at] = po; s_pp[at] = pp; s_ph[at] = ph; s_pr[at] = pr; s_ht[at] = ht;
             }
             __syncthreads();
-            const int32_t nq = __popcll(qm), nf = cf + 1;
+            const int32_t nq = __popcll(qm);
             for (int32_t c = m_lo + lane; c < m_hi; c += 64) {
                 const int32_t x = psmem[c];
-                if (posf[x] == cf) continue;                                /* on the list: resolved by list position */
+                const bool on_list = posf[x] == cf;                         /* (the list position pass leaves these members to us) */
+                if (!on_list && nq == 0) continue;
+                const int32_t j = on_list ? pos[x] : INT_MAX;
                 const int32_t in0 = sc[NSV(x)], px = prob[x];
                 const int32_t hv = HEUR ? hx.heur[hx.node_ci[x]] : 0;
                 int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
+                int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
                 for (int32_t u = 0; u < nq; u++) {
                     const int32_t ns = add32(s_po[u], add32(px, -s_pr[u]));
                     if (ns < th) continue;
                     if (HEUR && add32(ns, hv) < s_ht[u]) continue;
                     const int32_t up = s_pp[u];
-                    if (ns > mE || (ns == mE && up < pE)) { mE = ns; pE = up; hE = s_ph[u]; }
-                    if (ns > in0 && up < firstE) firstE = up;
+                    if (up < j) {
+                        if (ns > mE || (ns == mE && up < pE)) { mE = ns; pE = up; hE = s_ph[u]; }
+                        if (ns > in0 && up < firstE) firstE = up;
+                    }
+                    else {
+                        if (ns > mL || (ns == mL && up < pL)) { mL = ns; pL = up; hL = s_ph[u]; }
+                        if (up < firstL) firstL = up;
+                    }
                 }
-                if (mE > in0) {
-                    sc[NSV(x)] = mE; hist[NSV(x)] = hE; frame[NSV(x)] = nf;
-                    turn[x] = firstE; atomicAdd(&cnt[b + firstE], 1);
-                }
+                d_dec_resolve_finish(N, cf, th, b, x, on_list, j, in0, mE, hE, firstE, mL, hL, firstL,
+                                     sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, posout);
             }
             __syncthreads();
             continue;

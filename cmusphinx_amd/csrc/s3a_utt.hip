@@ -1253,7 +1253,7 @@ ku_resolve_plist(const ULane *__restrict__ lanes, UShared S, int32_t fg)
         d_dec_resolve_utt<UR_K, uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,
                       S.par_off, S.par, L.pos, L.posf, L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit,
                       L.cnt, L.key, L.first, L.hbin, S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout,
-                      L.act[cur], blockIdx.x, GA, 0, UHX);
+                      L.act[cur], blockIdx.x, GA, 0, UHX, L.claim);
         return;
     }
     d_dec_resolve_children<uint8_t, HEUR>(S.N, S.T, f, frame_beams(S, f), L.best, nact_cur, S.node_base, S.tree_of, S.prob,

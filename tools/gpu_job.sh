@@ -1,5 +1,5 @@
 export S3A_ON_GPU_BOX=1
-python -m pytest tests/test_gpu_dropin.py tests/test_gpu_uttdec.py tests/test_gpu_pheur.py tests/test_gpu_queue.py -q -x > gpurun_out/shared_tests.txt 2>&1; tail -2 gpurun_out/shared_tests.txt | cut -c1-200
+python -m pytest tests/test_gpu_dropin.py tests/test_gpu_uttdec.py tests/test_gpu_pheur.py tests/test_gpu_queue.py -q -x > gpurun_out/shared2_tests.txt 2>&1; tail -2 gpurun_out/shared2_tests.txt | cut -c1-200
 cp cmusphinx_amd/libcmusphinx_amd.so /tmp/lib_base.so
 for v in base prev base prev; do
 X=""
