@@ -202,6 +202,11 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
  * out(parent) + (prob(child) - prob(parent)) + phn_heur[ci(child)] >= hth(parent), hth = the running maximum of that
  * expression over the propagating HMMs up to the parent in active-list order (kbc->maxNewHeurScore, reset per tree)
  * + pl_beam; hth_pos is indexed by list position (tree slices), heur by CI phone.  All NULL: -pheurtype 0. */
+/* listed parent sets with this many parents or more (up to 64) are resolved set-wise (d_dec_resolve_children) */
+#ifndef SET_NP_MIN
+#define SET_NP_MIN 2
+#endif
+
 struct HeurArgs {
     const uint8_t *node_ci;
     const int32_t *heur, *hth_pos;
@@ -694,7 +699,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
                     /* (claim: the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
                     if (has_par && claim && claim[q] == cf) {
                         const int32_t np = par_off[v + 1] - par_off[v];
-                        if (np > 1 && np <= 64) continue;
+                        if (np >= SET_NP_MIN && np <= 64) continue;
                     }
                     d_dec_resolve_node<PS, HEUR>(RS_ARGS, v, true, has_par, i, b, hx);
                 }
@@ -767,7 +772,7 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
         const int32_t q = plist[k];
         const int32_t m_lo = psmem_off[q], m_hi = psmem_off[q + 1];
         const int32_t x0 = psmem[m_lo], kp0 = par_off[x0], np = par_off[x0 + 1] - kp0;
-        if (np > 1 && np <= 64) {
+        if (np >= SET_NP_MIN && np <= 64) {
             /* a first-level set: ~340 members under the ~46 left-context variants of one root.  Every member walking the
              * same 46 parents was 46 x (id + list stamp) gathers per member; the few variants that do propagate are found
              * once, and a member only combines their exit scores with its own probability (the parent loop of

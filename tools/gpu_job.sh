@@ -1,10 +1,6 @@
 export S3A_ON_GPU_BOX=1
-python -m pytest tests/test_gpu_dropin.py tests/test_gpu_uttdec.py tests/test_gpu_pheur.py tests/test_gpu_queue.py -q -x > gpurun_out/shared2_tests.txt 2>&1; tail -2 gpurun_out/shared2_tests.txt | cut -c1-200
-cp cmusphinx_amd/libcmusphinx_amd.so /tmp/lib_base.so
-for v in base prev base prev; do
-X=""
-if [ $v = base ]; then cp /tmp/lib_base.so cmusphinx_amd/libcmusphinx_amd.so; else cp cmusphinx_amd/variants/lib_$v.so cmusphinx_amd/libcmusphinx_amd.so; fi
-python bench.py --plain $X > gpurun_out/plain_v.json 2> gpurun_out/plain_v.err; python -c "
-import json; r=json.load(open('gpurun_out/plain_v.json')); print('$v', r['value'], r['identical_to_reference'])" 2>&1 | tail -1
-done
-cp /tmp/lib_base.so cmusphinx_amd/libcmusphinx_amd.so
+bash tools/pmc_only.sh r4pmc2 > gpurun_out/r4pmc2.log 2>&1; tail -3 gpurun_out/r4pmc2.log | cut -c1-200
+[ -s gpurun_out/r4pmc2/pmc_traffic.json ] && cp gpurun_out/r4pmc2/pmc_traffic.json profiles/pmc_traffic.json
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/r4g_pytest_gpu.txt 2>&1; tail -3 gpurun_out/r4g_pytest_gpu.txt | cut -c1-200
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -2
+bash tools/gpu_round4.sh g 2>&1 | tail -30

@@ -11,7 +11,7 @@ d, out, source = sys.argv[1], sys.argv[2], sys.argv[3]
 lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 CLASS = {"ku_enter1": "ku_enter1", "ku_enter2": "ku_enter2", "ku_enter3_mark": "ku_enter3_mark", "ku_comsen_mark": "ku_gated_ci",
          "ku_dyn_ci_beam": "ku_gated_ci", "ku_select": "ku_gated_cd", "ku_comsen_max": "ku_comsen_max", "ku_hmm_eval": "ku_hmm_eval",
-         "ku_hist_count": "ku_hist_count", "ku_hist_sort": "ku_hist_sort", "ku_weak": "ku_weak", "ku_resolve_lists": "ku_resolve",
+         "ku_hist_count": "ku_hist_count", "ku_hist_sort": "ku_hist_sort", "ku_weak": "ku_weak", "ku_resolve_lists": "ku_resolve", "ku_resolve_plist": "ku_resolve", "ku_weak_heur": "ku_weak",
          "ku_resolve": "ku_resolve", "ku_scan": "ku_scan", "ku_emit_word": "ku_emit_word", "ku_score_window": "ku_score_window",
          "ku_gated_cd_multi": "ku_gated_cd", "ku_gated": "ku_gated_ci", "k_score_frames": "k_score_frames", "k_score_frame_sync": "k_score_frame_sync",
          "ku_lanes_begin": "ku_lanes_begin", "ku_lanes_end": "ku_lanes_end", "k_dag_pass": "k_dag_pass"}
