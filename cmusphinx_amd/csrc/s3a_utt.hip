@@ -1120,7 +1120,7 @@ ku_hmm_eval(const ULane *__restrict__ lanes, UShared S, int32_t fg)
  * ku_resolve_plist visits the members of every listed set).  i0 / stride: this workgroup's first list position and the step to
  * its next, uniform over the workgroup. */
 __device__ __forceinline__ void
-d_stamp_and_list(const ULane &L, const UShared &S, int32_t cur, int32_t t, int32_t na, int32_t pth, int32_t f, int32_t i0, int32_t stride)
+d_stamp_and_list(const ULane &L, const UShared &S, int32_t cur, int32_t t, int32_t na, int32_t pth, int32_t f, int32_t i0, int32_t stride, int32_t list_sets)
 {
     const int32_t b = S.node_base[t];
     int32_t *cnt = &L.pcnt[f & 1];
@@ -1133,7 +1133,7 @@ d_stamp_and_list(const ULane &L, const UShared &S, int32_t cur, int32_t t, int32
             for (int32_t q = S.psof_off[u], q_hi = S.psof_off[u + 1]; q < q_hi; q++) {
                 const int32_t ps = S.psof[q];
                 L.pstamp8[ps] = ps_val<uint8_t>(f);
-                if (atomicExch(&L.claim[ps], f) != f) L.plist[atomicAdd(cnt, 1)] = ps;     /* the first HMM to stamp the set lists it */
+                if (list_sets && atomicExch(&L.claim[ps], f) != f) L.plist[atomicAdd(cnt, 1)] = ps;     /* the first HMM to stamp the set lists it (only when ku_resolve_plist follows) */
             }
     }
 }
@@ -1141,7 +1141,7 @@ d_stamp_and_list(const ULane &L, const UShared &S, int32_t cur, int32_t t, int32
 /* what ku_hist_sort does for a lane (below): the histogram beam, the lists reordered, the stamps of such a frame */
 template <int NT>
 __device__ __forceinline__ void
-d_hist_sort_lane(const ULane &L, const UShared &S, const FrameBeams &bm, const int32_t *nact_cur, int32_t cur, int32_t f)
+d_hist_sort_lane(const ULane &L, const UShared &S, const FrameBeams &bm, const int32_t *nact_cur, int32_t cur, int32_t f, int32_t list_sets)
 {
     for (int32_t t = 0; t < S.T; t++) {
         const int32_t hb = d_dec_hist_sort_t<NT>(S.node_base, L.act[cur], L.nact[cur], S.T, bm, L.exits + S.N, L.exits, L.hbin,
@@ -1150,7 +1150,7 @@ d_hist_sort_lane(const ULane &L, const UShared &S, const FrameBeams &bm, const i
         if (hb <= 0) {
             int32_t th, pth;
             frame_thresholds_hb(L.best, S.T, bm, hb, th, pth);
-            d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, 0, NT);
+            d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, 0, NT, list_sets);
         }
         __syncthreads();
     }
@@ -1161,7 +1161,7 @@ d_hist_sort_lane(const ULane &L, const UShared &S, const FrameBeams &bm, const i
  * in a frame under the histogram beam the LAST workgroup of the lane to finish its bins (a counter in the lane's context, release
  * / acquire around it) runs the sort; in every other frame nothing is counted at all */
 __global__ void __launch_bounds__(DBLOCK)
-ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t own_sort)
+ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t own_sort, int32_t list_sets)
 {
     LANE;
     __shared__ int32_t s_last;
@@ -1186,19 +1186,19 @@ ku_hist_count(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t ow
         if (!s_last) return;
         if (threadIdx.x == 0) ctx->hist_wg = 0;
         __threadfence();
-        d_hist_sort_lane<DBLOCK>(L, S, bm, nact_cur, cur, f);
+        d_hist_sort_lane<DBLOCK>(L, S, bm, nact_cur, cur, f, list_sets);
         return;
     }
     if (!has_work) return;
     int32_t th, pth;
     frame_thresholds_hb(L.best, S.T, bm, 1, th, pth);
-    d_stamp_and_list(L, S, cur, t, na, pth, f, blockIdx.x * DBLOCK, gridDim.x * DBLOCK);
+    d_stamp_and_list(L, S, cur, t, na, pth, f, blockIdx.x * DBLOCK, gridDim.x * DBLOCK, list_sets);
 }
 
 /* the histogram beam + the reordering of the lists (frames over 1.5 x -maxhmmpf only), then the stamps of such a frame */
 template <int NT>
 __global__ void __launch_bounds__(NT)
-ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t fg)
+ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t list_sets)
 {
     /* ONE workgroup per lane that takes the trees in turn: the usual frame has nothing to sort, and a workgroup per (tree,
      * lane) was 768 workgroups of 1024 threads per launch whose only act is to leave -- cheap alone (7 us), 43 us on average
@@ -1208,7 +1208,7 @@ ku_hist_sort(const ULane *__restrict__ lanes, UShared S, int32_t fg)
     int32_t n = 0;
     for (int32_t k = 0; k < S.T; k++) n += nact_cur[k];
     if (n <= bm.maxhmmpf + (bm.maxhmmpf >> 1)) return;          /* (uniform: no histogram beam in this frame) */
-    d_hist_sort_lane<NT>(L, S, bm, nact_cur, cur, f);
+    d_hist_sort_lane<NT>(L, S, bm, nact_cur, cur, f, list_sets);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -2404,14 +2404,17 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
         UKL(UK_HMM_EVAL, (ku_hmm_eval<256, 3>), dim3(ud->g_eval, T, n), dim3(256), 0, st, LN, S, f);
     else
         UKL(UK_HMM_EVAL, (ku_hmm_eval<64, 3>), dim3(ud->g_eval, T, n), dim3(64), 0, st, LN, S, f);
+    /* the not active nodes from the list of stamped parent sets (the stamping pass then also lists the sets) -- not with wide
+     * beams (tens of thousands of active HMMs, thousands of listed sets per frame: configs[4] is faster with the sweep) */
+    const int32_t by_parents = n >= ud->many && !ud->big_wl && !s3a_variants()->resolve_sweep ? 1 : 0;
     {
         /* many lanes: the (rare) histogram sort rides on the count's launch (its 256-thread form is the one used there anyway) */
         const int32_t own_sort = ud->hist_possible && n >= ud->scan_small_from && !s3a_variants()->hist_sort_launch ? 1 : 0;
-        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 8 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f, own_sort);
+        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 8 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f, own_sort, by_parents);
         if (ud->hist_possible && !own_sort) {
             /* (from 64 lanes on 256 threads: the launch's 128 workgroups mostly only leave, and small ones find a slot sooner) */
-            if (n >= ud->scan_small_from) UKL(UK_HIST_SORT, ku_hist_sort<256>, dim3(1, 1, n), dim3(256), 0, st, LN, S, f);
-            else UKL(UK_HIST_SORT, ku_hist_sort<SCAN_THREADS>, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
+            if (n >= ud->scan_small_from) UKL(UK_HIST_SORT, ku_hist_sort<256>, dim3(1, 1, n), dim3(256), 0, st, LN, S, f, by_parents);
+            else UKL(UK_HIST_SORT, ku_hist_sort<SCAN_THREADS>, dim3(1, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f, by_parents);
         }
     }
     if (ud->weak_possible && S.pheurtype > 0) UKL(UK_WEAK, ku_weak_heur, dim3(T, 1, n), dim3(1024), 0, st, LN, S, f);
@@ -2421,7 +2424,6 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     }
     {   /* (the active HMMs by list position: ud->g_res workgroups that loop; the rest: a sweep, UR_K nodes per thread) */
         const int32_t GB = ((S.N + UR_K - 1) / UR_K + RSBLOCK - 1) / RSBLOCK;
-        const bool by_parents = n >= ud->many && !s3a_variants()->resolve_sweep;   /* the not active nodes from their propagating parents' side */
         if (by_parents) {
             if (S.pheurtype > 0) UKL(UK_RESOLVE, ku_resolve_plist<true>, dim3(ud->g_res + UR_GL, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
             else UKL(UK_RESOLVE, ku_resolve_plist<false>, dim3(ud->g_res + UR_GL, 1, n), dim3(RSBLOCK), 0, st, LN, S, f);
