@@ -692,6 +692,9 @@ uw_one_gaussian(const UShared &S, int32_t g, const float *__restrict__ x)
  * USEL_G workgroups per lane; every one works out the CI maximum for itself (n_ci_sen loads from one row).
  */
 #define USEL_G 8
+#ifndef G_HIST_MANY
+#define G_HIST_MANY 9      /* ku_hist_count's workgroups per (tree, lane) with many lanes (5: 440.1, 7: 445.1, 8: 440.4, 9: 447.5 k frames/s) */
+#endif
 template <bool EXACT>
 __global__ void __launch_bounds__(256)
 ku_select(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t K)
@@ -1241,7 +1244,7 @@ ku_resolve(const ULane *__restrict__ lanes, UShared S, int32_t fg)
 /* ... and the not active ones from the frame's list of stamped parent sets instead of the sweep (GL one-wave workgroups per lane
  * behind the GA of the active HMMs) */
 #ifndef UR_GL
-#define UR_GL 512     /* one-wave workgroups per lane that walk the listed sets (one box: 128: 353.5 k, 256: 362.2 k, 512: 363.9 k frames/s; the sweep: 355.9 k) */
+#define UR_GL 192     /* one-wave workgroups per lane that walk the listed sets (one box: 128: 353.5 k, 256: 362.2 k, 512: 363.9 k frames/s; the sweep: 355.9 k) */
 #endif
 template <bool HEUR>
 __global__ void __launch_bounds__(RSBLOCK)
@@ -1984,14 +1987,29 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->many = O.many > 0 ? O.many : 32;
     /* fixed grids, sized for the usual frame: a workgroup loops when a list is longer (virtual workgroups); with many
      * lanes the idle workgroups of a generous grid cost more than the loop */
-    ud->g_eval = max(1, min((maxn + ud->eval_block - 1) / ud->eval_block, n_lanes >= ud->many ? 64 : 2048 / max(1, min(n_lanes, 8))));
+    /* (many lanes: NOT a multiple of 16 -- measured with four 128-lane engines: 32 / 48 / 64 / 96 workgroups per (tree, lane) 406 /
+     * 424 / 411 / 409 k frames/s, 24 ... 72 otherwise 428 ... 438 k, odd counts best: consecutive (tree, lane) groups then start on
+     * rotating XCDs instead of piling every group's first, always busy, workgroup onto the same one) */
+#ifndef G_EVAL_MANY
+#define G_EVAL_MANY 57
+#endif
+    ud->g_eval = max(1, min((maxn + ud->eval_block - 1) / ud->eval_block, n_lanes >= ud->many ? G_EVAL_MANY : 2048 / max(1, min(n_lanes, 8))));
     if (O.g_eval > 0) ud->g_eval = O.g_eval;
-    ud->g_res = max(1, min((proto->N + RSBLOCK - 1) / RSBLOCK, n_lanes >= ud->many ? 128 : 1024));
+#ifndef G_RES_MANY
+#define G_RES_MANY 49         /* (128: 401 k, 96: 403 k, 64: 405 k / 408.5 k, 48: 411 k, 32: 410 k frames/s; + UR_GL an odd total) */
+#endif
+    ud->g_res = max(1, min((proto->N + RSBLOCK - 1) / RSBLOCK, n_lanes >= ud->many ? G_RES_MANY : 1024));
     if (O.g_res > 0) ud->g_res = O.g_res;
     ud->urk = O.sweep_k > 0 ? O.sweep_k : UR_K;
-    ud->g_ent = max(1, min((proto->ent_cap + 255) / 256, 256));
+#ifndef G_ENT
+#define G_ENT 256
+#endif
+    ud->g_ent = max(1, min((proto->ent_cap + 255) / 256, G_ENT));
     ud->g_mark = max(1, min((proto->ent_cap + M3BLOCK - 1) / M3BLOCK + ((maxn + M3BLOCK - 1) / M3BLOCK) * T, 1024));
-    if (n_lanes >= ud->many) ud->g_mark = min(ud->g_mark, 128);     /* (many lanes: 1024 workgroups per lane were 131 k per launch, most of them idle: 50 -> 30 us per 128-lane launch, 331 -> 349 k frames/s) */
+#ifndef G_MARK_MANY
+#define G_MARK_MANY 128
+#endif
+    if (n_lanes >= ud->many) ud->g_mark = min(ud->g_mark, G_MARK_MANY);     /* (many lanes: 1024 workgroups per lane were 131 k per launch, most of them idle: 50 -> 30 us per 128-lane launch, 331 -> 349 k frames/s) */
     ud->scan_nc = (cfg->maxhmmpf >= SCAN_LONG_LIST && maxn >= SCAN_LONG_LIST) ? (maxn + SCAN_THREADS - 1) / SCAN_THREADS : 1;
     ud->scan_gc = O.scan_g;
     /* lextree_hmm_histbin can only fire when more than 1.5 x maxhmmpf HMMs can be active at all */
@@ -2410,7 +2428,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     {
         /* many lanes: the (rare) histogram sort rides on the count's launch (its 256-thread form is the one used there anyway) */
         const int32_t own_sort = ud->hist_possible && n >= ud->scan_small_from && !s3a_variants()->hist_sort_launch ? 1 : 0;
-        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? 8 : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f, own_sort, by_parents);
+        UKL(UK_HIST_COUNT, ku_hist_count, dim3(max(1, min((S.maxn + DBLOCK - 1) / DBLOCK, n >= ud->many ? G_HIST_MANY : 64)), T, n), dim3(DBLOCK), 0, st, LN, S, f, own_sort, by_parents);
         if (ud->hist_possible && !own_sort) {
             /* (from 64 lanes on 256 threads: the launch's 128 workgroups mostly only leave, and small ones find a slot sooner) */
             if (n >= ud->scan_small_from) UKL(UK_HIST_SORT, ku_hist_sort<256>, dim3(1, 1, n), dim3(256), 0, st, LN, S, f, by_parents);
