@@ -692,6 +692,9 @@ uw_one_gaussian(const UShared &S, int32_t g, const float *__restrict__ x)
  * USEL_G workgroups per lane; every one works out the CI maximum for itself (n_ci_sen loads from one row).
  */
 #define USEL_G 8
+#ifndef G_ENTER2_MANY
+#define G_ENTER2_MANY 12   /* ku_enter2's workgroups per lane from 64 lanes on (they take the calls in turn) */
+#endif
 #ifndef G_HIST_MANY
 #define G_HIST_MANY 9      /* ku_hist_count's workgroups per (tree, lane) with many lanes (5: 440.1, 7: 445.1, 8: 440.4, 9: 447.5 k frames/s) */
 #endif
@@ -2370,7 +2373,7 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     UKL(UK_ENTER1, ku_enter1, dim3(ud->g_ent, 1, n), dim3(256), 0, st, LN, S, f);
     /* (from 64 lanes on: 256-thread workgroups, as the scan below: 365 -> 371 k frames/s with four engines on the chip) */
     if (n >= ud->scan_small_from)
-        UKL(UK_ENTER2, ku_enter2<256>, dim3(12, 1, n), dim3(256), 0, st, LN, S, f);
+        UKL(UK_ENTER2, ku_enter2<256>, dim3(G_ENTER2_MANY, 1, n), dim3(256), 0, st, LN, S, f);
     else
         UKL(UK_ENTER2, ku_enter2<SCAN_THREADS>, dim3(n >= ud->many ? 12 : WL_MAXCALL, 1, n), dim3(SCAN_THREADS), 0, st, LN, S, f);
     UKL(UK_ENTER3, ku_enter3_mark, dim3(ud->g_mark, 1, n), dim3(M3BLOCK), 0, st, LN, S, f);
