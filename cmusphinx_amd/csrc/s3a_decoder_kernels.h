@@ -18,6 +18,10 @@
 
 #define WORST S3A_WORST
 #define DBLOCK 256
+/* a word that ATOMICS of an earlier phase of the SAME launch may have changed (they execute in L2; this CU's vector L1 can still
+ * hold the line from an earlier plain load): read past the L1 (sc1).  Across a kernel boundary a plain load does; the bodies below
+ * also run as phases of one persistent launch (ku_frames, s3a_utt.hip), so they read such words this way. */
+#define S3A_ALD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 /* k_dec_scan: workgroups per tree.  One (walking the list 1024 positions at a time) unless the host's bound on the
  * list length is long: a chained multi-workgroup scan costs ~3 us per link, which pays from ~16 k positions on
  * (56 k HMMs per frame: 44 -> 23 us; 3 k HMMs: 14 us either way, and slower when batched) */
@@ -71,6 +75,99 @@ frame_thresholds(const int32_t *best, const int32_t *nact, int32_t T, const Fram
 }
 
 /* ------------------------------------------------------------------ */
+/* one HMM: node v of the active list, evaluated against the frame's senone scores (raw: the scorer's row; norm: the frame's
+ * normaliser); returns the HMM's best score, w = its word id (< 0: not a word-final node) and out = its exit score */
+template <int NE>
+__device__ __forceinline__ int32_t
+d_dec_hmm_eval_node(int32_t v, int32_t N, const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid,
+                    const int32_t *__restrict__ wid, const uint8_t *__restrict__ comp,
+                    const int32_t *__restrict__ tp_g, const int16_t *__restrict__ sseq,
+                    const int16_t *__restrict__ comsseq, const int32_t *__restrict__ cs_off,
+                    const int16_t *__restrict__ cs_list, const int32_t *__restrict__ cs_wt,
+                    const int32_t *__restrict__ raw, int32_t norm,
+                    int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests, int32_t cf,
+                    const int32_t *__restrict__ psof_off, const int32_t *__restrict__ psof, int32_t *pstamp,
+                    const int32_t *__restrict__ cs_val, const int4 *__restrict__ node4, int32_t &w, int32_t &out)
+{
+    /* the node's static words (senone-sequence id, transition matrix, word id, composite?): one 16-byte load when
+     * the caller keeps them packed (node4), else four arrays */
+    int4 nd;
+    if (node4) nd = node4[v]; else { nd.x = ssid[v]; nd.y = tmatid[v]; nd.z = wid[v]; nd.w = comp[v]; }
+    const int32_t ss = nd.x;
+    HmmRegsT<int32_t> r;
+    int32_t e[NE];
+    /* the HMM's own state first: these loads do not depend on the senone scores and stay in flight
+     * while the (longer) senone chain below runs */
+#pragma unroll
+    for (int st = 0; st < NE; st++) { r.s[st] = sc[NSI(st, N, v)]; r.h[st] = hist[NSI(st, N, v)]; }
+    r.out = outs[NSV(v)];
+    r.outh = outh[NSV(v)];
+    int32_t tp[NS_TPW(NE)];
+    {
+        const int4 *tq = (const int4 *)(tp_g + nd.y * NS_TPW(NE));       /* 48- / 128-byte rows of a 16-byte aligned array */
+#pragma unroll
+        for (int q = 0; q < NS_TPW(NE) / 4; q++) { const int4 a = tq[q]; tp[4 * q] = a.x; tp[4 * q + 1] = a.y; tp[4 * q + 2] = a.z; tp[4 * q + 3] = a.w; }
+    }
+    const int32_t q_lo = psof_off ? psof_off[v] : 0, q_hi = psof_off ? psof_off[v + 1] : 0;
+    w = nd.z;
+    if (nd.w && cs_val) {                /* (the maxima were worked out once per composite senone: d_comsen_max) */
+#pragma unroll
+        for (int st = 0; st < NE; st++) {
+            const int32_t cs = comsseq[ss * NE + st];
+            e[st] = add32(add32(cs_val[cs], -norm), cs_wt[cs]);
+        }
+    }
+    else if (nd.w) {
+        /* composite senone = max over its member senones (dict2pid.c:1029-1048), up to one member
+         * per context (~46): the three states' lists are walked together, 8 members each per round,
+         * ids first and then scores, so a round is two round trips instead of 48 */
+        int32_t lo[NE], hi[NE], m[NE], wt[NE];
+#pragma unroll
+        for (int st = 0; st < NE; st++) {
+            const int32_t cs = comsseq[ss * NE + st];
+            lo[st] = cs_off[cs]; hi[st] = cs_off[cs + 1]; wt[st] = cs_wt[cs]; m[st] = INT_MIN;
+        }
+        for (;;) {
+            bool more = false;
+#pragma unroll
+            for (int st = 0; st < NE; st++) more = more || lo[st] < hi[st];
+            if (!more) break;
+            int32_t id[NE][8];
+#pragma unroll
+            for (int st = 0; st < NE; st++)
+#pragma unroll
+                for (int u = 0; u < 8; u++) id[st][u] = (lo[st] + u < hi[st]) ? (int32_t)cs_list[lo[st] + u] : -1;
+#pragma unroll
+            for (int st = 0; st < NE; st++) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (id[st][u] >= 0) m[st] = max(m[st], raw[id[st][u]]);
+                lo[st] += 8;
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < NE; st++) e[st] = add32(add32(m[st], -norm), wt[st]);
+    }
+    else {
+#pragma unroll
+        for (int st = 0; st < NE; st++)
+            e[st] = add32(raw[sseq[ss * NE + st]], -norm);
+    }
+    int32_t k;
+    if (NE == 5) { int32_t out_written = 0; k = vit5(r, tp, e, out_written); (void)out_written; }
+    else k = vit3(r, tp, e[0], e[1], e[2]);
+#pragma unroll
+    for (int st = 0; st < NE; st++) { sc[NSI(st, N, v)] = r.s[st]; hist[NSI(st, N, v)] = r.h[st]; }
+    outs[NSV(v)] = r.out;
+    outh[NSV(v)] = r.outh;
+    bests[NSV(v)] = k;
+    out = r.out;
+    /* this node is active in frame cf: stamp the parent sets its children belong to (k_dec_resolve
+     * skips every node whose parent set carries no stamp of this frame).  (psof_off == NULL: the caller stamps
+     * after the thresholds are known, and only for the nodes that propagate: d_dec_stamp) */
+    for (int32_t q = q_lo; q < q_hi; q++) pstamp[psof[q]] = cf;
+    return k;
+}
+
 template <int EB, int NE = 3>
 __device__ __forceinline__ void
 d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
@@ -104,85 +201,14 @@ d_dec_hmm_eval(const int32_t *__restrict__ node_base, const int32_t *__restrict_
     int32_t best = INT_MIN, wbest = INT_MIN;
     if (i < nact[t]) {
         const int32_t v = act[node_base[t] + i];
-        /* the node's static words (senone-sequence id, transition matrix, word id, composite?): one 16-byte load when
-         * the caller keeps them packed (node4), else four arrays */
-        int4 nd;
-        if (node4) nd = node4[v]; else { nd.x = ssid[v]; nd.y = tmatid[v]; nd.z = wid[v]; nd.w = comp[v]; }
-        const int32_t ss = nd.x;
-        HmmRegsT<int32_t> r;
-        int32_t e[NE];
-        /* the HMM's own state first: these loads do not depend on the senone scores and stay in flight
-         * while the (longer) senone chain below runs */
-#pragma unroll
-        for (int st = 0; st < NE; st++) { r.s[st] = sc[NSI(st, N, v)]; r.h[st] = hist[NSI(st, N, v)]; }
-        r.out = outs[NSV(v)];
-        r.outh = outh[NSV(v)];
-        int32_t tp[NS_TPW(NE)];
-        {
-            const int4 *tq = (const int4 *)(tp_g + nd.y * NS_TPW(NE));       /* 48- / 128-byte rows of a 16-byte aligned array */
-#pragma unroll
-            for (int q = 0; q < NS_TPW(NE) / 4; q++) { const int4 a = tq[q]; tp[4 * q] = a.x; tp[4 * q + 1] = a.y; tp[4 * q + 2] = a.z; tp[4 * q + 3] = a.w; }
-        }
-        const int32_t w = nd.z, q_lo = psof_off ? psof_off[v] : 0, q_hi = psof_off ? psof_off[v + 1] : 0;
-        if (nd.w && cs_val) {                /* (the maxima were worked out once per composite senone: d_comsen_max) */
-#pragma unroll
-            for (int st = 0; st < NE; st++) {
-                const int32_t cs = comsseq[ss * NE + st];
-                e[st] = add32(add32(cs_val[cs], -norm), cs_wt[cs]);
-            }
-        }
-        else if (nd.w) {
-            /* composite senone = max over its member senones (dict2pid.c:1029-1048), up to one member
-             * per context (~46): the three states' lists are walked together, 8 members each per round,
-             * ids first and then scores, so a round is two round trips instead of 48 */
-            int32_t lo[NE], hi[NE], m[NE], wt[NE];
-#pragma unroll
-            for (int st = 0; st < NE; st++) {
-                const int32_t cs = comsseq[ss * NE + st];
-                lo[st] = cs_off[cs]; hi[st] = cs_off[cs + 1]; wt[st] = cs_wt[cs]; m[st] = INT_MIN;
-            }
-            for (;;) {
-                bool more = false;
-#pragma unroll
-                for (int st = 0; st < NE; st++) more = more || lo[st] < hi[st];
-                if (!more) break;
-                int32_t id[NE][8];
-#pragma unroll
-                for (int st = 0; st < NE; st++)
-#pragma unroll
-                    for (int u = 0; u < 8; u++) id[st][u] = (lo[st] + u < hi[st]) ? (int32_t)cs_list[lo[st] + u] : -1;
-#pragma unroll
-                for (int st = 0; st < NE; st++) {
-#pragma unroll
-                    for (int u = 0; u < 8; u++) if (id[st][u] >= 0) m[st] = max(m[st], raw[id[st][u]]);
-                    lo[st] += 8;
-                }
-            }
-#pragma unroll
-            for (int st = 0; st < NE; st++) e[st] = add32(add32(m[st], -norm), wt[st]);
-        }
-        else {
-#pragma unroll
-            for (int st = 0; st < NE; st++)
-                e[st] = add32(raw[sseq[ss * NE + st]], -norm);
-        }
-        int32_t k;
-        if (NE == 5) { int32_t out_written = 0; k = vit5(r, tp, e, out_written); (void)out_written; }
-        else k = vit3(r, tp, e[0], e[1], e[2]);
-#pragma unroll
-        for (int st = 0; st < NE; st++) { sc[NSI(st, N, v)] = r.s[st]; hist[NSI(st, N, v)] = r.h[st]; }
-        outs[NSV(v)] = r.out;
-        outh[NSV(v)] = r.outh;
-        bests[NSV(v)] = k;
+        int32_t w, out;
+        const int32_t k = d_dec_hmm_eval_node<NE>(v, N, ssid, tmatid, wid, comp, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, norm,
+                                                  sc, hist, outs, outh, bests, cf, psof_off, psof, pstamp, cs_val, node4, w, out);
         best = k;
         if (w >= 0) wbest = k;
         /* by list position (coalesced): k_dec_scan finds the word exits without chasing the node ids again */
         poswid[node_base[t] + i] = w;
-        posout[node_base[t] + i] = r.out;
-        /* this node is active in frame cf: stamp the parent sets its children belong to (k_dec_resolve
-         * skips every node whose parent set carries no stamp of this frame).  (psof_off == NULL: the caller stamps
-         * after the thresholds are known, and only for the nodes that propagate: d_dec_stamp) */
-        for (int32_t q = q_lo; q < q_hi; q++) pstamp[psof[q]] = cf;
+        posout[node_base[t] + i] = out;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -259,15 +285,16 @@ d_dec_stamp(const int32_t *__restrict__ act, const int32_t *__restrict__ outs, c
  * order (wave-level peeling + per-wave bin counts).  Both return at once unless the frame
  * is over 1.5 x maxhmmpf (or `force`: the stand-alone entry point).
  */
+/* (NT threads; s_bin: NBIN words of the workgroup's LDS) */
+template <int NT>
 __device__ __forceinline__ void
-d_dec_hist_count(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
+d_dec_hist_count_t(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
                  const int32_t *__restrict__ nact, int32_t T, FrameBeams bm,
                  const int32_t *__restrict__ best, const int32_t *__restrict__ bests,
                  int32_t *binof, int32_t *hbin, int32_t force_tree, int32_t fbest, int32_t fbw,
                  int32_t nbin,
-        const int32_t BX, const int32_t BY)
+        const int32_t BX, const int32_t BY, int32_t *s_bin)
 {
-    __shared__ int32_t s_bin[NBIN];
     __shared__ int32_t s_go, s_bh, s_bw;
     const int32_t t = BY;
     if (threadIdx.x == 0) {
@@ -278,9 +305,9 @@ d_dec_hist_count(const int32_t *__restrict__ node_base, const int32_t *__restric
     }
     __syncthreads();
     if (!s_go) return;
-    for (int32_t i = threadIdx.x; i < nbin; i += DBLOCK) s_bin[i] = 0;
+    for (int32_t i = threadIdx.x; i < nbin; i += NT) s_bin[i] = 0;
     __syncthreads();
-    const int32_t i = BX * DBLOCK + threadIdx.x, b = node_base[t];
+    const int32_t i = BX * NT + threadIdx.x, b = node_base[t];
     if (i < nact[t]) {
         int32_t k = (s_bh - bests[NSV(act[b + i])]) / s_bw;
         if (k >= nbin) k = nbin - 1;
@@ -289,8 +316,20 @@ d_dec_hist_count(const int32_t *__restrict__ node_base, const int32_t *__restric
         atomicAdd(&s_bin[k], 1);
     }
     __syncthreads();
-    for (int32_t k = threadIdx.x; k < nbin; k += DBLOCK)
+    for (int32_t k = threadIdx.x; k < nbin; k += NT)
         if (s_bin[k]) atomicAdd(&hbin[k], s_bin[k]);
+}
+
+__device__ __forceinline__ void
+d_dec_hist_count(const int32_t *__restrict__ node_base, const int32_t *__restrict__ act,
+                 const int32_t *__restrict__ nact, int32_t T, FrameBeams bm,
+                 const int32_t *__restrict__ best, const int32_t *__restrict__ bests,
+                 int32_t *binof, int32_t *hbin, int32_t force_tree, int32_t fbest, int32_t fbw,
+                 int32_t nbin,
+        const int32_t BX, const int32_t BY)
+{
+    __shared__ int32_t s_bin[NBIN];
+    d_dec_hist_count_t<DBLOCK>(node_base, act, nact, T, bm, best, bests, binof, hbin, force_tree, fbest, fbw, nbin, BX, BY, s_bin);
 }
 
 /* inclusive prefix sum over the SCAN_THREADS values of one workgroup */
@@ -312,17 +351,26 @@ block_inclusive_sum(int32_t x, int32_t *wsum /* [SCAN_THREADS / 64] shared */)
     return incl + add;
 }
 
+/* the sort's LDS: the caller's (the persistent frame kernel lends an area other phases use too) */
+template <int NT>
+struct HistSortWs {
+    int32_t s_cnt[NBIN], s_base[NBIN], s_run[NBIN];
+    uint16_t s_cntw[NT / 64][NBIN];
+    int32_t s_wsum[NT / 64];
+    int32_t s_go, s_i, s_tot;
+};
+
 template <int NT>
 __device__ __forceinline__ int32_t
-d_dec_hist_sort_t(const int32_t *__restrict__ node_base, int32_t *act, const int32_t *__restrict__ nact,
+d_dec_hist_sort_ws(const int32_t *__restrict__ node_base, int32_t *act, const int32_t *__restrict__ nact,
                 int32_t T, FrameBeams bm, const int32_t *__restrict__ binof, int32_t *tmp,
                 int32_t *hbin, int32_t *pos, int32_t force_tree, int32_t nbin,
-        const int32_t BX, const int32_t BY)
+        const int32_t BX, const int32_t BY, HistSortWs<NT> &ws)
 {
-    __shared__ int32_t s_cnt[NBIN], s_base[NBIN], s_run[NBIN];
-    __shared__ uint16_t s_cntw[NT / 64][NBIN];
-    __shared__ int32_t s_wsum[NT / 64];
-    __shared__ int32_t s_go, s_i, s_tot;
+    int32_t (&s_cnt)[NBIN] = ws.s_cnt, (&s_base)[NBIN] = ws.s_base, (&s_run)[NBIN] = ws.s_run;
+    uint16_t (&s_cntw)[NT / 64][NBIN] = ws.s_cntw;
+    int32_t (&s_wsum)[NT / 64] = ws.s_wsum;
+    int32_t &s_go = ws.s_go, &s_i = ws.s_i, &s_tot = ws.s_tot;
     const int32_t t = BX, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         int32_t n = 0;
@@ -339,7 +387,7 @@ d_dec_hist_sort_t(const int32_t *__restrict__ node_base, int32_t *act, const int
         int32_t carry = 0;
         for (int32_t k0 = 0; k0 < nbin; k0 += NT) {
             const int32_t k = k0 + tid;
-            const int32_t x = (k >= 1 && k < nbin) ? hbin[k] : 0;
+            const int32_t x = (k >= 1 && k < nbin) ? S3A_ALD(&hbin[k]) : 0;    /* (the counting pass's atomics) */
             const int32_t J = carry + block_inclusive_sum(x, s_wsum);       /* j after i reached k */
             if (k < nbin && J >= bm.maxhmmpf) atomicMin(&s_i, bm.maxhmmpf <= 0 ? 0 : k);
             if (tid == NT - 1) s_tot = J;
@@ -409,6 +457,17 @@ d_dec_hist_sort_t(const int32_t *__restrict__ node_base, int32_t *act, const int
     return force_tree < 0 ? -(s_i * (-bm.hmmbeam / NBIN)) : 1;      /* the histogram beam (hbin[NBIN]) */
 }
 
+template <int NT>
+__device__ __forceinline__ int32_t
+d_dec_hist_sort_t(const int32_t *__restrict__ node_base, int32_t *act, const int32_t *__restrict__ nact,
+                int32_t T, FrameBeams bm, const int32_t *__restrict__ binof, int32_t *tmp,
+                int32_t *hbin, int32_t *pos, int32_t force_tree, int32_t nbin,
+        const int32_t BX, const int32_t BY)
+{
+    __shared__ HistSortWs<NT> ws;
+    return d_dec_hist_sort_ws<NT>(node_base, act, nact, T, bm, binof, tmp, hbin, pos, force_tree, nbin, BX, BY, ws);
+}
+
 __device__ __forceinline__ int32_t
 d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32_t *__restrict__ nact,
                 int32_t T, FrameBeams bm, const int32_t *__restrict__ binof, int32_t *tmp,
@@ -429,8 +488,9 @@ d_dec_hist_sort(const int32_t *__restrict__ node_base, int32_t *act, const int32
  * one workgroup collects the weak nodes and iterates "entered early by a propagating parent" to
  * its fixed point (monotone; at most tree-depth rounds), stamping propf[v] = cf.
  */
+template <int NT>
 __device__ __forceinline__ void
-d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
+d_dec_weak_t(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
            const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
            const int32_t *__restrict__ act, const int32_t *__restrict__ prob,
            const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
@@ -449,7 +509,7 @@ d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
     if (threadIdx.x == 0) n_weak = 0;
     __syncthreads();
     for (int32_t t = 0; t < T; t++)
-        for (int32_t i = threadIdx.x; i < nact[t]; i += SCAN_THREADS) {
+        for (int32_t i = threadIdx.x; i < nact[t]; i += NT) {
             const int32_t v = act[node_base[t] + i];
             if (wid[v] < 0 && bests[NSV(v)] < th && outs[NSV(v)] >= pth) weaklist[atomicAdd(&n_weak, 1)] = v;
         }
@@ -459,7 +519,7 @@ d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
         __syncthreads();
         if (threadIdx.x == 0) changed = 0;
         __syncthreads();
-        for (int32_t k = threadIdx.x; k < nw; k += SCAN_THREADS) {
+        for (int32_t k = threadIdx.x; k < nw; k += NT) {
             const int32_t v = weaklist[k];
             if (((volatile int32_t *)propf)[v] == cf) continue;
             const int32_t in0 = sc[NSV(v)], j = pos[v];
@@ -478,6 +538,19 @@ d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__res
         __syncthreads();
         if (!changed) break;
     }
+}
+
+__device__ __forceinline__ void
+d_dec_weak(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
+           const int32_t *__restrict__ nact, const int32_t *__restrict__ node_base,
+           const int32_t *__restrict__ act, const int32_t *__restrict__ prob,
+           const int32_t *__restrict__ par_off, const int32_t *__restrict__ par,
+           const int32_t *__restrict__ pos, const int32_t *__restrict__ posf, const int32_t *__restrict__ sc,
+           const int32_t *__restrict__ outs, const int32_t *__restrict__ bests, const int32_t *__restrict__ wid,
+           const int32_t *__restrict__ hbin, int32_t *propf, int32_t *weaklist,
+        const int32_t BX, const int32_t BY)
+{
+    d_dec_weak_t<SCAN_THREADS>(N, T, cf, bm, best, nact, node_base, act, prob, par_off, par, pos, posf, sc, outs, bests, wid, hbin, propf, weaklist, BX, BY);
 }
 
 /* ------------------------------------------------------------------ */
@@ -744,6 +817,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
  * byte stamps stay for the active nodes' "can a parent enter me".  (Listing the propagating HMMs and walking their child
  * lists visited a first-level node once per variant, with an atomic claim each time: 375 k frames/s in the bench.)
  */
+/* (WS: the wave's own 5 x 64 words of LDS when the workgroup holds several waves -- ku_frames --, else NULL: one wave per workgroup) */
 template <typename PS, bool HEUR = false>
 __device__ __forceinline__ void
 d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__restrict__ best,
@@ -758,11 +832,16 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout,
               const int32_t *__restrict__ plist, int32_t n_plist, const int32_t *__restrict__ psmem_off,
-              const int32_t *__restrict__ psmem, int32_t W, int32_t NW, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
+              const int32_t *__restrict__ psmem, int32_t W, int32_t NW, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL },
+              int32_t *WS = NULL)
 {
     const int32_t lane = threadIdx.x & 63;
-    /* (one wave per workgroup) the qualifying parents of a several-parent set, loaded once for all of its members */
-    __shared__ int32_t s_po[64], s_pp[64], s_ph[64], s_pr[64], s_ht[64];
+    /* the qualifying parents of a several-parent set, loaded once for all of its members */
+    __shared__ int32_t s_own[5][64];
+    int32_t *s_po = WS ? WS : s_own[0], *s_pp = s_po + 64, *s_ph = s_po + 128, *s_pr = s_po + 192, *s_ht = s_po + 256;
+    /* (a wave's stores to its LDS area seen by its other lanes) */
+#define RC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
     int32_t th, pth;
     {
         int32_t bh, bw, n, wth;
@@ -794,7 +873,7 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
                 const int32_t at = __popcll(qm & ((1ull << lane) - 1ull));
                 s_po[at] = po; s_pp[at] = pp; s_ph[at] = ph; s_pr[at] = pr; s_ht[at] = ht;
             }
-            __syncthreads();
+            RC_WAVE_SYNC();
             const int32_t nq = __popcll(qm);
             for (int32_t c = m_lo + lane; c < m_hi; c += 64) {
                 const int32_t x = psmem[c];
@@ -822,7 +901,7 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
                 d_dec_resolve_finish(N, cf, th, b, x, on_list, j, in0, mE, hE, firstE, mL, hL, firstL,
                                      sc, hist, outs, outh, bests, frame, turn, selfemit, cnt, posout);
             }
-            __syncthreads();
+            RC_WAVE_SYNC();
             continue;
         }
         for (int32_t c = m_lo + lane; c < m_hi; c += 64) {
@@ -833,6 +912,7 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
                                          posout, x, false, true, -1, -1, hx);
         }
     }
+#undef RC_WAVE_SYNC
 }
 
 /* ------------------------------------------------------------------ */
@@ -897,7 +977,7 @@ d_dec_scan_t(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__r
     do {                                                                                            \
         u2 = 0; c2 = 0; w2 = -1; os2 = 0;                                                           \
         if ((i_) < na) {                                                                            \
-            u2 = act[b + (i_)]; c2 = cnt[b + (i_)];                                                 \
+            u2 = act[b + (i_)]; c2 = S3A_ALD(&cnt[b + (i_)]);  /* (d_dec_resolve_finish's atomicAdd) */ \
             if (reordered) { w2 = wid[u2]; os2 = outs[NSV(u2)]; }                                        \
             else { w2 = poswid[b + (i_)]; os2 = posout[b + (i_)]; }                                 \
             cnt[b + (i_)] = 0;                                  /* the accumulator of the next frame */ \
@@ -1110,7 +1190,7 @@ d_dec_pack_frame_lds(int32_t N, int32_t T, FrameBeams bm, const int32_t *__restr
     for (int32_t q = tid; q < hdr; q += nt) hdr_s[q] = 0;
     if (tid < 3) sp_gp[tid] = tid == 0 ? INT_MIN : 0;
     __syncthreads();
-    if (tid < 2 * T) hdr_s[tid] = best[tid];
+    if (tid < 2 * T) hdr_s[tid] = S3A_ALD(&best[tid]);               /* (d_dec_hmm_eval's atomicMax) */
     if (tid < T) {
         hdr_s[2 * T + tid] = nact[tid];
         hdr_s[3 * T + 8 + tid] = nexit[tid];
@@ -1501,7 +1581,7 @@ d_dec_enter2_t(Entries ent, int32_t n_ent, const int32_t *__restrict__ calls,
             const int32_t scr = add32(in, ent.root_prob(roots + i, prob));
             if (scr >= thresh) {
                 const int32_t v = ent.rootlist[roots + i];
-                q = (sc[NSV(v)] < scr && first[v] == c && frame[NSV(v)] != nf) ? 1 : 0;
+                q = (sc[NSV(v)] < scr && S3A_ALD(&first[v]) == c && frame[NSV(v)] != nf) ? 1 : 0;   /* (d_dec_enter1's atomicMin) */
             }
         }
         const unsigned long long m = __ballot(q);
@@ -1556,10 +1636,12 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
                   const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
                   const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
                   uint8_t *sen_active,
-        const int32_t BX, const int32_t BY, int32_t *cs_need = NULL, int32_t thresh = INT_MIN)
+        const int32_t BX, const int32_t BY, int32_t *cs_need = NULL, int32_t thresh = INT_MIN, int32_t TX = -1)
 {
+    /* (TX: the thread's place in its M3BLOCK-wide virtual workgroup when that is not the real one: ku_frames) */
+    const int32_t tx = TX >= 0 ? TX : (int32_t)threadIdx.x;
     if ((int32_t)BX < n_ent_blocks) {
-        const int32_t e = BX * M3BLOCK + threadIdx.x;
+        const int32_t e = BX * M3BLOCK + tx;
         int32_t idx, c;
         ent.locate_idx_wave(e < n_ent ? e : 0, idx, c);
         if (e >= n_ent) return;
@@ -1580,15 +1662,15 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
             nxt[node_base[t] + k] = v; pos[v] = k; posf[v] = nf;
             mark_node_senones(v, ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf, (int32_t)(hist - sc));
         }
-        const unsigned long long k = key[v];
+        const unsigned long long k = S3A_ALD(&key[v]);                  /* (d_dec_enter1's atomicMax / atomicMin) */
         if (k == 0ull) return;
         const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(k & 0xffffffffu);
         if (c == win_c) { sc[NSV(v)] = (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); hist[NSV(v)] = calls[4 * c + 1]; }
-        if (c == first[v]) frame[NSV(v)] = nf;
+        if (c == S3A_ALD(&first[v])) frame[NSV(v)] = nf;
         return;
     }
     const int32_t bb = BX - n_ent_blocks;
-    const int32_t t = bb / blocks_per_tree, i = (bb % blocks_per_tree) * M3BLOCK + threadIdx.x;
+    const int32_t t = bb / blocks_per_tree, i = (bb % blocks_per_tree) * M3BLOCK + tx;
     if (t >= T || i >= n0[t]) return;
     mark_node_senones(nxt[node_base[t] + i], ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf, (int32_t)(hist - sc));
 }

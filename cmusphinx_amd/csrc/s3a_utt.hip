@@ -29,6 +29,7 @@
 #include <limits.h>
 #include <vector>
 #include <map>
+#include <atomic>
 
 #include "s3a_device.h"
 #include "s3a_structs.h"
@@ -698,27 +699,27 @@ uw_one_gaussian(const UShared &S, int32_t g, const float *__restrict__ x)
 #ifndef G_HIST_MANY
 #define G_HIST_MANY 9      /* ku_hist_count's workgroups per (tree, lane) with many lanes (5: 440.1, 7: 445.1, 8: 440.4, 9: 447.5 k frames/s) */
 #endif
-template <bool EXACT>
-__global__ void __launch_bounds__(256)
-ku_select(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t K)
+/* (NT threads; workgroup bx of G takes every G-th run of NT CD senones and leaves its maxima / counters in column bx of gpart[]) */
+template <bool EXACT, int NT>
+__device__ __forceinline__ void
+d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t K, int32_t bx, int32_t G)
 {
-    __shared__ int32_t red[3][4];
+    __shared__ int32_t red[3][NT / 64];
     __shared__ int32_t s_pb;
-    LANE;
-    const int32_t tid = threadIdx.x, ln = tid & 63, bx = blockIdx.x;
+    const int32_t tid = threadIdx.x, ln = tid & 63;
     int32_t *row = L.win + (size_t)(f % K) * S.n_sen;
     const uint8_t *brow = L.winb + (size_t)(f % K) * S.n_sen;
     int32_t pb = INT_MIN, cig = 0;
-    for (int32_t ci = tid; ci < S.n_ci_sen; ci += 256) { pb = max(pb, row[ci]); cig += (int32_t)S.ncomp[ci]; }
+    for (int32_t ci = tid; ci < S.n_ci_sen; ci += NT) { pb = max(pb, row[ci]); cig += (int32_t)S.ncomp[ci]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { pb = max(pb, __shfl_xor(pb, o, 64)); cig += __shfl_xor(cig, o, 64); }
     if (ln == 0) { red[0][tid >> 6] = pb; red[1][tid >> 6] = cig; }
     __syncthreads();
     if (tid == 0) {
-        pb = max(max(red[0][0], red[0][1]), max(red[0][2], red[0][3]));
+        for (int w = 1; w < NT / 64; w++) { pb = max(pb, red[0][w]); cig += red[1][w]; }
         s_pb = pb;
         if (bx == 0) {          /* the CI phase's outputs: best CI score, senones / Gaussians evaluated */
-            L.misc[5] = pb; L.misc[3] = S.n_ci_sen; L.misc[4] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            L.misc[5] = pb; L.misc[3] = S.n_ci_sen; L.misc[4] = cig;
         }
     }
     __syncthreads();
@@ -729,7 +730,7 @@ ku_select(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t K)
     LogAdd la;
     la.tab = S.tab16; la.size = S.tab_size; la.zero = S.lm_zero;
     int32_t rbest = INT_MIN, rns = 0, rng = 0;
-    for (int32_t s0 = S.n_ci_sen + bx * 256; s0 < S.n_sen; s0 += (int32_t)gridDim.x * 256) {
+    for (int32_t s0 = S.n_ci_sen + bx * NT; s0 < S.n_sen; s0 += G * NT) {
         const int32_t sen = s0 + tid;
         if (sen >= S.n_sen) continue;
         if (!L.sen_act[sen]) continue;
@@ -764,11 +765,20 @@ ku_select(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t K)
     if (ln == 0) { red[0][tid >> 6] = rbest; red[1][tid >> 6] = rns; red[2][tid >> 6] = rng; }
     __syncthreads();
     if (tid == 0 && bx < S.gp_n) {
-        L.gpart[bx] = max(max(red[0][0], red[0][1]), max(red[0][2], red[0][3]));
-        L.gpart[S.gp_n + bx] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        L.gpart[2 * S.gp_n + bx] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        for (int w = 1; w < NT / 64; w++) { rbest = max(rbest, red[0][w]); rns += red[1][w]; rng += red[2][w]; }
+        L.gpart[bx] = rbest;
+        L.gpart[S.gp_n + bx] = rns;
+        L.gpart[2 * S.gp_n + bx] = rng;
     }
     /* (the columns beyond this grid stay neutral: written once at init) */
+}
+
+template <bool EXACT>
+__global__ void __launch_bounds__(256)
+ku_select(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t K)
+{
+    LANE;
+    d_select<EXACT, 256>(L, S, ctx, f, K, blockIdx.x, gridDim.x);
 }
 
 /* the members of the composite senones wanted in this frame join the mask (before ku_select) */
@@ -1325,6 +1335,308 @@ ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPa
     else d_wordlevel_frame(L.w, ctx, L.pack, s_hdr, nx <= WL_LDS_EX ? s_ex : (const int32_t *)NULL, lm, dict, par, f, t_in);
 }
 
+/* ====================================================================================================================
+ * ku_frames: A BLOCK OF FRAMES IN ONE LAUNCH -- the lane's frame as the phases of a persistent workgroup (round 5).
+ *
+ * The reference's frame loop (srch.c:746-835; lextree.c:1253-1597) has no boundary between its steps; the launches above
+ * have twelve per frame, each a grid over all lanes whose workgroups mostly find out that they are not needed, and several
+ * engines take turns on the chip.  Here a lane is ONE 512-thread workgroup (or a cluster of C of them) that stays on its CU
+ * for the whole block of K frames -- the look-ahead window ku_score_window has just scored -- and walks the same steps with a
+ * workgroup barrier between them: lextree_enter (test / rank / apply + senone marks), the composite senones' members, the CI
+ * gate (d_select), the composite maxima, lextree_hmm_eval, the stamps of the HMMs that propagate + the list of stamped parent
+ * sets (or the histogram beam and the reordering), -ptranskip's weak HMMs, lextree_hmm_propagate_non_leaves from the node's
+ * point of view (by list position + a wave per listed parent set), the ordered scan, the emission of the next list and the
+ * word level.  The bodies are the launch path's (s3a_decoder_kernels.h, s3a_wordlevel.h): same rule, same bits.
+ *
+ * A lane's data is its own, so C = 1 needs nothing but __syncthreads() (two lanes per CU: 512 lanes fill the chip and never
+ * wait for one another inside a block).  With fewer lanes than workgroup slots a lane is a CLUSTER of C workgroups on one XCD
+ * (block b runs on XCD b % 8: observed, used for speed only) with a counter barrier between the phases: every workgroup
+ * arrives behind an agent-scope release and leaves through an agent-scope acquire (a CU's L1 is not refreshed by other CUs'
+ * stores, the XCDs' L2s are not coherent with each other).  Words that ATOMICS of an earlier phase changed are read past the L1
+ * (S3A_ALD); the per-tree maxima are copied to LDS once per frame and every later phase reads the copy.
+ * LDS: the word level's arrays + one pool the other phases share (two workgroups per CU).
+ * Not served here (the engine then keeps the launch path): the wide-beam word level (big_wl), -pheurtype, -maxcdsenpf,
+ * per-frame scoring (window = 0), the invariant checker, per-launch profiling.
+ * ==================================================================================================================== */
+#define KF_NT WL_THREADS
+#define KF_WAVES (KF_NT / 64)
+#define KF_SPIN_MAX (1 << 21)
+static_assert(KF_NT == 512, "ku_frames: the word level's workgroup is the frame's workgroup");
+
+union KfPool {                  /* phases that never overlap share this LDS */
+    struct { int32_t off[WL_MAXCALL], root[WL_MAXCALL], in[WL_MAXCALL]; } e1;
+    int32_t bin[NBIN];
+    HistSortWs<KF_NT> hs;
+    int32_t rc[KF_WAVES][5 * 64];
+    struct { int32_t hdr[6 * WL_MAXT + 16], ex[3 * WL_LDS_EX]; } wl;
+};
+
+struct KfBar { int32_t *cnt; int32_t C, target; int32_t *dead; };
+
+/* all workgroups of the lane's cluster have finished the phase and see what the others wrote */
+__device__ __forceinline__ void
+kf_barrier(KfBar &B)
+{
+    __syncthreads();
+    if (B.C == 1) return;
+    B.target += B.C;
+    if (threadIdx.x == 0 && !*B.dead) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        (void)__hip_atomic_fetch_add(B.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int32_t spins = 0;
+        while (__hip_atomic_load(B.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B.target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > KF_SPIN_MAX) { *B.dead = 1; break; }        /* (cannot happen while the cluster is resident: the host sizes the grid) */
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+/* list position g of the lane's trees laid end to end -> (tree, position in its list); pre[t] = positions in front of tree t */
+__device__ __forceinline__ void
+kf_locate(const int32_t *pre, int32_t T, int32_t g, int32_t &t, int32_t &i)
+{
+    t = 0;
+    while (t + 1 < T && g >= pre[t + 1]) t++;
+    i = g - pre[t];
+}
+
+template <int NE, bool EXACT>
+__global__ void __launch_bounds__(KF_NT, 4)
+ku_frames(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, int32_t fg0, int32_t n_fr, int32_t n_lanes,
+          int32_t C, int32_t *bar, int32_t weak_possible)
+{
+    __shared__ KfPool pool;
+    __shared__ int32_t s_best[2 * WL_MAXT], s_acc[2 * WL_MAXT], s_pre[WL_MAXT + 1], s_red[KF_WAVES], s_dead;
+    /* the lane and this workgroup's place in its cluster: a cluster's workgroups share an XCD */
+    int32_t z, r;
+    if (C == 1) { z = blockIdx.x; r = 0; }
+    else { const int32_t b = blockIdx.x, xcd = b & 7, j = b >> 3; z = (j / C) * 8 + xcd; r = j % C; }
+    if (z >= n_lanes) return;
+    const ULane &L = lanes[z];
+    UCtx *ctx = S.ctx_all + z;
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = S.T;
+    const int32_t gtid = r * KF_NT + tid, gstride = C * KF_NT, gwave = r * KF_WAVES + wave, gwaves = C * KF_WAVES;
+    if (tid == 0) s_dead = 0;
+    KfBar B = { bar + z, C, 0, &s_dead };
+    __syncthreads();
+    const int32_t f0 = ctx->f0, nfr = ctx->nfr;
+    for (int32_t fg = fg0; fg < fg0 + n_fr; fg++) {
+        const int32_t f = fg - f0;
+        if (f < 0 || f >= nfr) continue;
+        /* (the word level ends an utterance that ran into an error: uniform over the cluster behind the frame's last barrier) */
+        if (!((volatile UCtx *)ctx)->active || s_dead) break;
+        const int32_t cur = f & 1;
+        const int32_t *nact_cur = S.nact_all + ((size_t)z * 2 + cur) * WL_MAXT;
+        const FrameBeams bm = frame_beams(S, f);
+        const int32_t n_ent = ctx->n_ent, n_calls_all = ctx->n_calls, thresh = ctx->thresh;
+
+        /* ---- lextree_enter, step 1: the entry test (ku_enter1) ---- */
+        if (n_ent > 0) {
+            const int32_t n_calls = min(n_calls_all, WL_MAXCALL);
+            if (tid < n_calls) { pool.e1.in[tid] = ctx->calls[4 * tid]; pool.e1.root[tid] = ctx->calls[4 * tid + 2]; pool.e1.off[tid] = ctx->calls[4 * tid + 3]; }
+            __syncthreads();
+            for (int32_t e = gtid; e < n_ent; e += gstride) {
+                int32_t lo = 0, hi = n_calls - 1;
+                while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (pool.e1.off[mid] <= e) lo = mid; else hi = mid - 1; }
+                const int32_t c = lo, idx = pool.e1.root[c] + (e - pool.e1.off[c]);
+                const int32_t scr = add32(pool.e1.in[c], S.rootprob[idx]);
+                if (scr < thresh) continue;
+                const int32_t v = S.rootlist[idx];
+                if (!(L.sc[NSV(v)] < scr)) continue;
+                atomicMax(&L.key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
+                atomicMin(&L.first[v], c);
+            }
+            kf_barrier(B);
+            /* ---- step 2: which roots a call lists, ranked in root-list order (ku_enter2) ---- */
+            const Entries ent = { ctx->calls, S.rootlist, n_calls_all, S.rootprob };
+            for (int32_t c = r; c < n_calls_all; c += C) {
+                d_dec_enter2_t<KF_NT>(ent, n_ent, ctx->calls, S.prob, L.sc, L.frame, L.first, thresh, f, T, L.nact[cur], L.eflag, L.ctot, L.n0, c, 0);
+                __syncthreads();
+            }
+            kf_barrier(B);
+        }
+        /* ---- step 3: the listed roots, the winning entries, the senone marks of the frame's list (ku_enter3_mark) ---- */
+        {
+            const int32_t *n0 = n_ent > 0 ? L.n0 : L.nact[cur];
+            int32_t rows = 0;
+            for (int32_t t = 0; t < T; t++) rows = max(rows, n0[t]);
+            const int32_t neb = (n_ent + M3BLOCK - 1) / M3BLOCK, bpt = (rows + M3BLOCK - 1) / M3BLOCK;
+            const Entries ent = { ctx->calls, S.rootlist, n_calls_all, S.rootprob };
+            for (int32_t vb = gwave; vb < neb + bpt * T; vb += gwaves)
+                d_dec_enter3_mark(neb, ent, n_ent, ctx->calls, ctx->groups, ctx->n_groups, f, L.key, L.first, L.eflag, L.ctot, n0, L.sc,
+                                  L.hist, L.frame, T, bpt, S.node_base, L.act[cur], L.nact[cur], L.pos, L.posf, S.ssid, S.comp, S.sseq,
+                                  S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0, L.cs_need, thresh, lane);
+        }
+        kf_barrier(B);
+        /* the frame's lists are final: their lengths end to end */
+        if (tid == 0) {
+            int32_t a = 0;
+            for (int32_t t = 0; t < T; t++) { s_pre[t] = a; a += nact_cur[t]; }
+            s_pre[T] = a;
+        }
+        /* ---- the composite senones' members join the mask (ku_comsen_mark) ---- */
+        for (int32_t w = gwave; w * 64 < S.n_cs; w += gwaves)
+            d_comsen_wave<false>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, L.sen_act, (const int32_t *)NULL, (int32_t *)NULL, w * 64);
+        kf_barrier(B);
+        const int32_t n_tot = s_pre[T];
+        const bool hist_frame = n_tot > bm.maxhmmpf + (bm.maxhmmpf >> 1);
+        const int32_t *row = L.win + (size_t)(f % S.win_K) * S.n_sen;
+        /* ---- approx_cont_mgau_ci_eval / _frame_eval on the window row (ku_select); the launch path's columns of gpart[] that this
+         * cluster does not write are made neutral, so that an engine may take either path from frame to frame ---- */
+        {
+            const int32_t g_all = max(1, min(USEL_G, min(S.gp_n, (S.n_sen - S.n_ci_sen + 255) / 256))), G = min(C, g_all);
+            if (r < G) d_select<EXACT, KF_NT>(L, S, ctx, f, S.win_K, r, G);
+            if (r == 0 && tid >= G && tid < g_all) { L.gpart[tid] = INT_MIN; L.gpart[S.gp_n + tid] = 0; L.gpart[2 * S.gp_n + tid] = 0; }
+        }
+        kf_barrier(B);
+        /* ---- the scores of the composite senones wanted in this frame (ku_comsen_max) ---- */
+        for (int32_t w = gwave; w * 64 < S.n_cs; w += gwaves)
+            d_comsen_wave<true>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, w * 64);
+        kf_barrier(B);
+        /* ---- lextree_hmm_eval (ku_hmm_eval): a thread per list position of the trees laid end to end; the per-tree maxima are
+         * gathered in LDS and leave the workgroup as one atomic per tree ---- */
+        {
+            int32_t gb = INT_MIN;
+            for (int32_t i = tid; i < S.gp_n; i += KF_NT) gb = max(gb, L.gpart[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) gb = max(gb, __shfl_xor(gb, o, 64));
+            if (lane == 0) s_red[wave] = gb;
+            if (tid < 2 * T) s_acc[tid] = INT_MIN;
+            __syncthreads();
+            int32_t norm = max(L.misc[0], L.misc[5]);               /* the frame's normaliser */
+            for (int w = 0; w < KF_WAVES; w++) norm = max(norm, s_red[w]);
+            const int32_t *act = L.act[cur];
+            for (int32_t g0 = r * KF_NT; g0 < n_tot; g0 += gstride) {
+                const int32_t g = g0 + tid;
+                int32_t t = -1, k = INT_MIN, w = -1;
+                if (g < n_tot) {
+                    int32_t i, out;
+                    kf_locate(s_pre, T, g, t, i);
+                    const int32_t b = S.node_base[t], v = act[b + i];
+                    k = d_dec_hmm_eval_node<NE>(v, S.N, S.ssid, S.tmatid, S.wid, S.comp, S.tp, S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt,
+                                                row, norm, L.sc, L.hist, L.outs, L.outh, L.bests, f, (const int32_t *)NULL, S.psof, L.pstamp,
+                                                L.cs_val, S.node4, w, out);
+                    L.poswid[b + i] = w;
+                    L.posout[b + i] = out;
+                }
+                /* a wave's 64 positions belong to one tree, or to two or three at the seams */
+                unsigned long long todo = __ballot(t >= 0);
+                while (todo) {
+                    const int32_t tt = __shfl(t, __ffsll((long long)todo) - 1, 64);
+                    const bool mine = t == tt;
+                    int32_t x = mine ? k : INT_MIN, y = (mine && w >= 0) ? k : INT_MIN;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { x = max(x, __shfl_xor(x, o, 64)); y = max(y, __shfl_xor(y, o, 64)); }
+                    if (lane == 0) { atomicMax(&s_acc[2 * tt], x); if (y != INT_MIN) atomicMax(&s_acc[2 * tt + 1], y); }
+                    todo &= ~__ballot(mine);
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * T && s_acc[tid] != INT_MIN) atomicMax(&L.best[tid], s_acc[tid]);
+        }
+        kf_barrier(B);
+        /* the frame's per-tree maxima: final; every later phase reads this copy */
+        if (tid < 2 * T) s_best[tid] = S3A_ALD(&L.best[tid]);
+        if (r == 0 && tid == 0) L.pcnt[(f + 1) & 1] = 0;           /* (the coming frame's list of stamped parent sets) */
+        __syncthreads();
+        /* ---- lextree_hmm_histbin + the histogram beam (frames over 1.5 x -maxhmmpf), else the stamps of the HMMs that can
+         * propagate and the list of stamped parent sets (ku_hist_count / ku_hist_sort) ---- */
+        if (hist_frame) {
+            for (int32_t t = 0; t < T; t++)
+                for (int32_t vb = r; vb * KF_NT < nact_cur[t]; vb += C) {
+                    d_dec_hist_count_t<KF_NT>(S.node_base, L.act[cur], L.nact[cur], T, bm, s_best, L.bests, L.exits + S.N, L.hbin, -1, 0, 1, NBIN, vb, t, pool.bin);
+                    __syncthreads();
+                }
+            kf_barrier(B);
+            if (r == 0)
+                for (int32_t t = 0; t < T; t++) {
+                    const int32_t hb = d_dec_hist_sort_ws<KF_NT>(S.node_base, L.act[cur], L.nact[cur], T, bm, L.exits + S.N, L.exits, L.hbin, L.pos, -1, NBIN, t, 0, pool.hs);
+                    __syncthreads();
+                    if (hb <= 0) {
+                        int32_t th, pth;
+                        frame_thresholds_hb(s_best, T, bm, hb, th, pth);
+                        d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, 0, KF_NT, 1);
+                    }
+                    __syncthreads();
+                }
+        }
+        else {
+            int32_t th, pth;
+            frame_thresholds_hb(s_best, T, bm, 1, th, pth);
+            for (int32_t t = 0; t < T; t++) d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, r * KF_NT, gstride, 1);
+        }
+        kf_barrier(B);
+        /* ---- -ptranskip frames / -pbeam wider than -beam: the weak HMMs that a parent earlier in the list re-entered (ku_weak) ---- */
+        if (weak_possible && (bm.phone_uses_wbeam || bm.pbeam < bm.hmmbeam)) {
+            if (r == 0)
+                d_dec_weak_t<KF_NT>(S.N, T, f, bm, s_best, L.nact[cur], S.node_base, L.act[cur], S.prob, S.par_off, S.par, L.pos, L.posf, L.sc, L.outs,
+                                    L.bests, S.wid, L.hbin, L.propf, L.exits + 2 * (size_t)S.N, 0, 0);
+            kf_barrier(B);
+        }
+        /* ---- lextree_hmm_propagate_non_leaves from the node's point of view (ku_resolve_plist) ---- */
+        {
+            if (r == 0 && hist_frame)
+                for (int32_t i = tid; i < NBIN; i += KF_NT) L.hbin[i] = 0;         /* (the bins were consumed by the sort; hbin[NBIN] stays) */
+            for (int32_t v = gtid; v < S.n_rootnodes; v += gstride) {              /* lextree_enter only ever touches root nodes */
+                const int32_t rn = S.rootnodes[v];
+                L.key[rn] = 0ull;
+                L.first[rn] = INT_MAX;
+            }
+            const int32_t *act = L.act[cur];
+            /* the active HMMs by list position */
+            for (int32_t g = gtid; g < n_tot; g += gstride) {
+                int32_t t, i;
+                kf_locate(s_pre, T, g, t, i);
+                const int32_t b = S.node_base[t], v = act[b + i], q = S.ps[v];
+                const bool has_par = q >= 0 && L.pstamp8[q] == ps_val<uint8_t>(f);
+                /* (the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
+                if (has_par && S3A_ALD(&L.claim[q]) == f) {
+                    const int32_t np = S.par_off[v + 1] - S.par_off[v];
+                    if (np >= SET_NP_MIN && np <= 64) continue;
+                }
+                d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, s_best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                   L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                   S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b);
+            }
+            /* the members of the listed parent sets: a wave per set */
+            d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, s_best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                   L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                   S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, L.plist, S3A_ALD(&L.pcnt[f & 1]),
+                                                   S.psmem_off, S.psmem, gwave, gwaves, HeurArgs{ NULL, NULL, NULL }, pool.rc[wave]);
+        }
+        kf_barrier(B);
+        /* ---- the ordered compaction of the next list and of the word exits (ku_scan): a tree per workgroup in turn ---- */
+        for (int32_t t = r; t < T; t += C) {
+            d_dec_scan_t<KF_NT>(S.N, T, f, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit, L.cnt, L.base,
+                                L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, s_best, L.exits, L.nexit, L.hbin, L.misc, (int32_t *)NULL, L.pack,
+                                S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, hist_frame ? 1 : 0, L.scan_agg, L.scan_pre, L.scan_flag,
+                                S.scan_chunks, 0, 1, 1, t, 0);
+            __syncthreads();
+        }
+        kf_barrier(B);
+        /* ---- the emission of the next list (every workgroup but the first when there are several) and the word level (the
+         * first), which closes the frame and leaves the next frame's lextree_enter calls (ku_emit_word) ---- */
+        if (C == 1 || r > 0) {
+            const int32_t ew = C == 1 ? wave : gwave - KF_WAVES, enw = C == 1 ? KF_WAVES : gwaves - KF_WAVES;
+            for (int32_t t = 0; t < T; t++)
+                d_dec_emit_w(f, S.node_base, L.act[cur], L.nact[cur], S.child_off, S.child, L.turn, L.selfemit, L.base, L.act[cur ^ 1], L.nact[cur ^ 1],
+                             L.pos, L.posf, t, ew, enw);
+        }
+        if (r == 0) {
+            __syncthreads();
+            const long long t_in = (long long)wall_clock64();
+            const int32_t nx = d_dec_pack_frame_lds(S.N, T, bm, S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc, L.pack,
+                                                    S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1], pool.wl.hdr, pool.wl.ex, WL_LDS_EX);
+            d_wordlevel_frame(L.w, ctx, L.pack, pool.wl.hdr, nx <= WL_LDS_EX ? pool.wl.ex : (const int32_t *)NULL, lm, dict, par, f, t_in);
+        }
+        kf_barrier(B);
+    }
+    if (s_dead && tid == 0) { ctx->err |= WL_E_SCAN; ctx->active = 0; }
+}
+
 #define LANE_W const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; const int32_t f = fg - ctx->f0;               \
     if (f < 0 || f >= ctx->nfr || !ctx->active) return
 /* the wide-beam word level: WL_BIG_G workgroups per lane and phase (s3a_wordlevel.h) */
@@ -1746,7 +2058,17 @@ struct s3a_uttdec_s {
     int32_t *q_dio_d, *q_dio_h; size_t q_dio_cap;       /* the second pass inside a queue: [n_utt][DG_IO_N] + the word counter */
     int32_t *q_dw_d, *q_dw_h; size_t q_dw_cap, q_dw_hcap;   /* its words, packed */
     int32_t q_dag;              /* the last queue ran the second pass */
+    /* ku_frames: the frames of a window as one launch */
+    int32_t persist;            /* the engine's configuration is served and the option allows it */
+    int32_t kf_cluster_opt;     /* s3a_uttdec_opts_t.cluster */
+    int32_t kf_slots;           /* workgroups of ku_frames the device holds at once */
+    int32_t *d_kfbar;           /* [n_lanes] the clusters' barrier counters */
+    int32_t kf_last_c;          /* workgroups per lane of the last launch (diagnostics) */
+    int32_t kf_counted;         /* this engine is counted in g_kf_live */
 };
+
+/* engines with ku_frames alive per device: an engine that is alone on its device may give a lane a cluster of workgroups */
+static std::atomic<int> g_kf_live[64];
 
 static int32_t
 fill32(hipStream_t st, int32_t *p, int32_t v, size_t n)
@@ -1834,6 +2156,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.sc) s3a_scorer_free(hl.sc);
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
+    if (ud->kf_counted) { g_kf_live[ud->device]--; ud->kf_counted = 0; }
+    if (ud->d_kfbar) (void)hipFree(ud->d_kfbar);
     if (ud->q_dio_d) (void)hipFree(ud->q_dio_d);
     if (ud->q_dio_h) (void)hipHostFree(ud->q_dio_h);
     if (ud->q_dw_d) (void)hipFree(ud->q_dw_d);
@@ -1889,6 +2213,7 @@ s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o)
     o->scan_g = num("S3A_UTT_SCAN_G", 0); o->gy = num("S3A_UTT_GY", 0); o->sweep_k = num("S3A_UTT_URK", 0);
     o->no_multi = getenv("S3A_UTT_NO_MULTI") != NULL; o->framecheck = getenv("S3A_UTT_FRAMECHECK") != NULL;
     o->times = num("S3A_UTT_TIMES", 0); o->graph = num("S3A_UTT_GRAPH", 0); o->window_max = num("S3A_UTT_WIN_MAX", 0); o->scan_small_from = num("S3A_UTT_SCAN_SMALL", 0);
+    o->persist = num("S3A_UTT_PERSIST", 0); o->cluster = num("S3A_UTT_CLUSTER", 0);
 }
 
 extern "C" s3a_uttdec_t *
@@ -2105,6 +2430,13 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     if (hipMemset(ud->d_fgbase, 0, 64) != hipSuccess) goto fail;
     ud->S.fgbase = ud->d_fgbase;
     ud->use_graph = O.graph != 0 && !ud->big_wl && !O.framecheck;
+    ud->persist = O.persist >= 0 && !ud->use_graph && !O.framecheck ? 1 : 0;
+    ud->kf_cluster_opt = O.cluster; ud->kf_last_c = 0; ud->kf_slots = 0; ud->d_kfbar = NULL; ud->kf_counted = 0;
+    if (ud->persist) {
+        DM(ud->d_kfbar, (size_t)n_lanes * 4);
+        if (hipMemset(ud->d_kfbar, 0, (size_t)n_lanes * 4) != hipSuccess) goto fail;
+        if (ud->device >= 0 && ud->device < 64) { g_kf_live[ud->device]++; ud->kf_counted = 1; }
+    }
     ud->scan_small_from = O.scan_small_from > 0 ? O.scan_small_from : 64;
     ud->hyp_wcap = max_frames + 4;
     if (hipHostMalloc((void **)&ud->h_ctx_up, sizeof(UCtx) * n_lanes) != hipSuccess
@@ -2491,6 +2823,53 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     return S3A_OK;
 }
 
+/* ---- ku_frames: the frames [fg0, fg0 + nf) of all lanes as ONE launch (behind the look-ahead pass that scores them) ---- */
+/* does this engine, as it is configured now, run its frames through ku_frames? */
+static bool
+kf_served(const s3a_uttdec_t *ud)
+{
+    const UShared &S = ud->S;
+    return ud->persist && S.win_K > 0 && !ud->big_wl && S.pheurtype == 0 && S.max_cd >= S.n_sen - S.n_ci_sen && !ud->d_dbg
+        && ud->prof_every == 0 && (S.ne == 3 || S.ne == 5) && S.T <= WL_MAXT;
+}
+
+template <int NE, bool EXACT>
+static int32_t
+kf_launch_t(s3a_uttdec_t *ud, int32_t n, int32_t fg0, int32_t nf)
+{
+    auto kern = ku_frames<NE, EXACT>;
+    if (ud->kf_slots == 0) {
+        /* how many of its workgroups the device holds at once: a cluster's workgroups wait for one another */
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, KF_NT, 0) != hipSuccess || nb < 1) nb = 1;
+        ud->kf_slots = nb * ud->g->dev->n_cu;
+    }
+    /* workgroups per lane: the lanes' clusters share the XCDs evenly (lane z on XCD z % 8) and must all be resident */
+    const int32_t per_xcd = max(1, ud->kf_slots / 8), lanes_per_xcd = (n + 7) / 8;
+    int32_t C = 1;
+    if (ud->kf_cluster_opt > 0) C = ud->kf_cluster_opt;
+    else if (ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1) C = min(per_xcd / lanes_per_xcd, 32);
+    /* (one margin slot per XCD: the occupancy query can be one workgroup per CU high, MI355X_MICROARCH "Residency") */
+    C = max(1, min(C, (per_xcd - (per_xcd > 8 ? 4 : 0)) / lanes_per_xcd));
+    ud->kf_last_c = C;
+    const int32_t grid = C == 1 ? n : 8 * C * lanes_per_xcd;
+    if (C > 1) HIPCHK(hipMemsetAsync(ud->d_kfbar, 0, (size_t)n * 4, ud->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(KF_NT), 0, ud->stream, ud->d_lanes, ud->S, ud->lm->d, ud->dict, ud->par, fg0, nf, n, C,
+                       ud->d_kfbar, ud->weak_possible);
+    HIPCHK(hipGetLastError());
+    return S3A_OK;
+}
+
+/* the frames [fg0, fg0 + nf) of lanes 0 .. n - 1: fg0 is a window boundary, nf at most the window */
+static int32_t
+enqueue_block(s3a_uttdec_t *ud, int32_t n, int32_t fg0, int32_t nf)
+{
+    int32_t rc = uw_launch(ud, n, fg0, false);
+    if (rc != S3A_OK) return rc;
+    if (ud->S.ne == 5) return ud->exact ? kf_launch_t<5, true>(ud, n, fg0, nf) : kf_launch_t<5, false>(ud, n, fg0, nf);
+    return ud->exact ? kf_launch_t<3, true>(ud, n, fg0, nf) : kf_launch_t<3, false>(ud, n, fg0, nf);
+}
+
 /* ---- graph mode: the launches of a BLOCK of frames as one HIP graph ----
  * The launch sequence of a frame is the same for every frame (fixed grids; what a kernel has to do it finds in memory), and
  * the frame number reaches the kernels as argument + *S.fgbase: a block of G frames (G = the look-ahead window, so that the
@@ -2623,6 +3002,9 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
             if (hipGraphLaunch(ge, ud->stream) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
         if (rc == S3A_OK && hipMemsetAsync(ud->d_fgbase, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
     }
+    else if (kf_served(ud))
+        for (int32_t f = 0; f < maxT && rc == S3A_OK; f += ud->S.win_K)
+            rc = enqueue_block(ud, n_utt, f, min(ud->S.win_K, maxT - f));
     else
     for (int32_t f = 0; f < maxT && rc == S3A_OK; f++)
         rc = enqueue_frame(ud, n_utt, f, ud->prof_every > 0 && f % ud->prof_every == 0);
@@ -2927,6 +3309,11 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
             if (rc == S3A_OK && hipGraphLaunch(ge, ud->stream) != hipSuccess) { s3a_set_error("s3a_uttdec_decode_queue: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
         }
     }
+    else if (kf_served(ud))
+        for (int32_t fg = 0; fg < F_end && rc == S3A_OK; fg += E) {        /* (E = the window: refill events fall on its boundaries) */
+            if (ei < evs.size() && evs[ei].f == fg) rc = run_event(evs[ei++]);
+            if (rc == S3A_OK) rc = enqueue_block(ud, n, fg, min(E, F_end - fg));
+        }
     else
     for (int32_t fg = 0; fg < F_end && rc == S3A_OK; fg++) {
         if (ei < evs.size() && evs[ei].f == fg) rc = run_event(evs[ei++]);

@@ -1433,7 +1433,7 @@ class UttResult(C.Structure):
 class UttDecOpts(C.Structure):
     """s3a_uttdec_opts_t: the engine's tuning options (every variant gives the same bits)"""
     _fields_ = [(k, C.c_int32) for k in ("many", "big_wl", "window", "window_fpc", "g_eval", "g_res", "scan_g", "gy", "sweep_k",
-                                         "no_multi", "framecheck", "times", "graph", "window_max", "scan_small_from")] + [("reserved", C.c_int32 * 1)]
+                                         "no_multi", "framecheck", "times", "graph", "window_max", "scan_small_from", "persist", "cluster")] + [("reserved", C.c_int32 * 2)]
 
 
 class UttDec:

@@ -736,7 +736,16 @@ typedef struct {
                              * and replayed block after block: one graph launch per block instead of ~13 kernel launches per frame */
     int32_t window_max;     /* > 0: the longest look-ahead window the library may choose (lane refill happens at window boundaries) */
     int32_t scan_small_from; /* lanes per launch from which the scan uses 256-thread workgroups (0: 64) */
-    int32_t reserved[1];
+    int32_t persist;        /* the frames of a look-ahead window as ONE launch (ku_frames: a lane = a persistent 512-thread workgroup, or
+                             * a cluster of them, that walks the frame's steps with barriers instead of launch boundaries -- the
+                             * reference's srch.c:746-835 loop has none): 0 = whenever the engine's configuration is served
+                             * (look-ahead scoring on, no wide-beam word level, no -pheurtype, no -maxcdsenpf), -1 = never (the twelve
+                             * launches per frame of rounds 2-4), 1 = as 0.  Same bits either way. */
+    int32_t cluster;        /* workgroups per lane of that launch: 0 = the library's choice (1 when the lanes fill the chip, more
+                             * -- on one XCD, with a counter barrier between the steps -- when they do not; only an engine that is
+                             * alone on its device chooses more than 1: the clusters of one launch must be resident together);
+                             * > 0 = exactly that many where they fit (the caller then answers for co-residency) */
+    int32_t reserved[2];
 } s3a_uttdec_opts_t;
 void s3a_uttdec_opts_default(s3a_uttdec_opts_t *o);
 void s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o);
