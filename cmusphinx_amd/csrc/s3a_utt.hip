@@ -134,39 +134,77 @@ frame_beams(const UShared &S, int32_t cf)
  * :485-490 resets it), the masks, and the history table's entry 0 (vithist_utt_begin, vithist.c:300-335). */
 struct UBegin { int32_t e0[10], lmc[5], n_pset; };
 
-/* (sub: the lanes of a refill event, s3a_uttdec_decode_queue -- NULL: lanes 0 .. gridDim.z - 1) */
-__global__ void __launch_bounds__(256)
-ku_lanes_end(const ULane *__restrict__ lanes, UShared S, const int32_t *__restrict__ sub, int32_t n_word)
+/* lextree_utt_end for lane z by the threads (vt, vt + vstride, ...) of whatever grid the caller has; scrub: the lane's utterance
+ * stopped on an error in mid-frame -- everything from scratch, as the host does for a dirty lane (lane_scrub: s3a_lexsearch_reset +
+ * the word level's hash / per-word scratch) */
+__device__ __forceinline__ void
+d_lane_end(const ULane &L, const UShared &S, int32_t z, bool scrub, int32_t n_word, int32_t vt, int32_t vstride)
 {
-    const int32_t z = sub ? sub[blockIdx.z] : (int32_t)blockIdx.z;
-    const ULane &L = lanes[z];
-    const int32_t t = blockIdx.y % S.T, w = blockIdx.y / S.T;
     const int32_t ne = S.ne;
-    if (sub && S.ctx_all[z].err) {
-        /* the utterance this lane just finished stopped on an error in mid-frame: everything from scratch, as the host
-         * does for a dirty lane (lane_begin: s3a_lexsearch_reset + the word level's hash / per-word scratch) */
-        const int32_t nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x, stride = nb * 256;
-        for (int32_t v = b * 256 + threadIdx.x; v < S.N; v += stride) {
+    if (scrub) {
+        for (int32_t v = vt; v < S.N; v += vstride) {
             int32_t *r = L.sc + NSV(v);
             for (int32_t st = 0; st < ne; st++) { r[st] = WORST; r[NS_HIST(ne) + st] = -1; }
             r[NS_OUTS(ne)] = WORST; r[NS_OUTH(ne)] = -1; r[NS_BESTS(ne)] = WORST; r[NS_FRAME(ne)] = -1;
             L.pos[v] = -1; L.turn[v] = -1; L.selfemit[v] = 0; L.cnt[v] = 0; L.first[v] = INT_MAX; L.key[v] = 0ull;
         }
-        for (int32_t i = b * 256 + threadIdx.x; i <= L.w.hmask; i += stride) { L.w.hkey[i] = 0ull; L.w.hbest[i] = 0ull; L.w.hfirst[i] = 0xffffffffu; }
-        for (int32_t i = b * 256 + threadIdx.x; i < n_word; i += stride) { L.w.wfirst[i] = INT_MAX; L.w.wbest[i] = INT_MIN; }
-        if (b == 0) {
-            for (int32_t i = threadIdx.x; i < 2 * S.T; i += 256) { L.nexit[i] = 0; L.best[i] = INT_MIN; }
-            for (int32_t i = threadIdx.x; i < 1024; i += 256) L.hbin[i] = 0;
-            if (threadIdx.x < 4) L.done[threadIdx.x] = 0;
-        }
+        for (int32_t i = vt; i <= L.w.hmask; i += vstride) { L.w.hkey[i] = 0ull; L.w.hbest[i] = 0ull; L.w.hfirst[i] = 0xffffffffu; }
+        for (int32_t i = vt; i < n_word; i += vstride) { L.w.wfirst[i] = INT_MAX; L.w.wbest[i] = INT_MIN; }
+        for (int32_t i = vt; i < 2 * S.T; i += vstride) { L.nexit[i] = 0; L.best[i] = INT_MIN; }
+        for (int32_t i = vt; i < 1024; i += vstride) L.hbin[i] = 0;
+        if (vt < 4) L.done[vt] = 0;
         return;
     }
-    const int32_t na = S.nact_all[((size_t)z * 2 + w) * WL_MAXT + t], b = S.node_base[t];
-    for (int32_t i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) {
-        const int32_t v = L.act[w][b + i];
-        int32_t *r = L.sc + NSV(v);
-        for (int32_t st = 0; st < ne; st++) { r[st] = WORST; r[NS_HIST(ne) + st] = -1; }
-        r[NS_OUTS(ne)] = WORST; r[NS_OUTH(ne)] = -1; r[NS_BESTS(ne)] = WORST; r[NS_FRAME(ne)] = -1;
+    for (int32_t w = 0; w < 2; w++)
+        for (int32_t t = 0; t < S.T; t++) {
+            const int32_t na = S.nact_all[((size_t)z * 2 + w) * WL_MAXT + t], b = S.node_base[t];
+            for (int32_t i = vt; i < na; i += vstride) {
+                const int32_t v = L.act[w][b + i];
+                int32_t *r = L.sc + NSV(v);
+                for (int32_t st = 0; st < ne; st++) { r[st] = WORST; r[NS_HIST(ne) + st] = -1; }
+                r[NS_OUTS(ne)] = WORST; r[NS_OUTH(ne)] = -1; r[NS_BESTS(ne)] = WORST; r[NS_FRAME(ne)] = -1;
+            }
+        }
+}
+
+/* (sub: the lanes of a refill event, s3a_uttdec_decode_queue -- NULL: lanes 0 .. gridDim.z - 1) */
+__global__ void __launch_bounds__(256)
+ku_lanes_end(const ULane *__restrict__ lanes, UShared S, const int32_t *__restrict__ sub, int32_t n_word)
+{
+    const int32_t z = sub ? sub[blockIdx.z] : (int32_t)blockIdx.z;
+    const int32_t nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+    d_lane_end(lanes[z], S, z, sub && S.ctx_all[z].err, n_word, b * 256 + (int32_t)threadIdx.x, nb * 256);
+}
+
+/* srch_TST_begin's resets for lane z (threads vt, vt + vstride, ...; lead: the one workgroup -- threads tid of it -- that also writes
+ * the small things): the frame-tagged scratch, the scorer's per-senone state, the masks, the history table's entry 0; src: the
+ * utterance's staged context (a queue), copied word by word into the lane's */
+__device__ __forceinline__ void
+d_lane_begin(const ULane &L, const UShared &S, const UBegin &B, int32_t z, const UCtx *src, int32_t vt, int32_t vstride, bool lead, int32_t tid, int32_t lead_nt)
+{
+    for (int32_t i = vt; i < S.N; i += vstride) { L.posf[i] = INT_MIN; L.propf[i] = INT_MIN; L.claim[i] = INT_MIN; }
+    for (int32_t i = vt; i < B.n_pset; i += vstride) L.pstamp[i] = INT_MIN;
+    for (int32_t i = vt; i < S.n_pset_bytes; i += vstride) L.pstamp8[i] = 0xff;
+    if (vt == 0) { L.pcnt[0] = 0; L.pcnt[1] = 0; }
+    for (int32_t i = vt; i < S.n_sen; i += vstride) {
+        L.bstidx[i] = S3A_NO_BSTIDX; L.bstscr[i] = S3A_LOGPROB_ZERO; L.updatetime[i] = S3A_NOT_UPDATED; L.sen_act[i] = 0;
+    }
+    for (int32_t i = vt; i <= S.n_cs; i += vstride) L.cs_need[i] = -1;
+    if (lead) {
+        if (tid < 2 * WL_MAXT) S.nact_all[(size_t)z * 2 * WL_MAXT + tid] = 0;
+        if (tid < 8) L.misc[tid] = (tid == 0 || tid == 5) ? INT_MIN : 0;
+        if (tid == 32) {
+            int32_t *arr[10] = { L.w.score, L.w.pred, L.w.lw0, L.w.lw1, L.w.wid, L.w.sf, L.w.ef, L.w.ascr, L.w.lscr, L.w.type };
+            for (int k = 0; k < 10; k++) arr[k][0] = B.e0[k];
+            for (int k = 0; k < 5; k++) L.w.lmc[(size_t)k * L.w.cap] = B.lmc[k];
+            L.w.frame_start[0] = 1; L.w.bestscore[0] = INT_MIN; L.w.bestvh[0] = -1; L.w.st[0] = 1; L.w.st[1] = 0;
+        }
+        if (src) {
+            static_assert(sizeof(UCtx) % 4 == 0, "UCtx is copied word by word");
+            const int32_t *s4 = (const int32_t *)src;
+            int32_t *dst = (int32_t *)(S.ctx_all + z);
+            for (int32_t i = tid; i < (int32_t)(sizeof(UCtx) / 4); i += lead_nt) dst[i] = s4[i];
+        }
     }
 }
 
@@ -177,33 +215,8 @@ ku_lanes_begin(const ULane *__restrict__ lanes, UShared S, UBegin B, const int32
                const int32_t *__restrict__ utt, const UCtx *__restrict__ stage)
 {
     const int32_t z = sub ? sub[blockIdx.z] : (int32_t)blockIdx.z;
-    const ULane &L = lanes[z];
-    const int32_t i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
-    for (int32_t i = i0; i < S.N; i += stride) { L.posf[i] = INT_MIN; L.propf[i] = INT_MIN; L.claim[i] = INT_MIN; }
-    for (int32_t i = i0; i < B.n_pset; i += stride) L.pstamp[i] = INT_MIN;
-    for (int32_t i = i0; i < S.n_pset_bytes; i += stride) L.pstamp8[i] = 0xff;
-    if (i0 == 0) { L.pcnt[0] = 0; L.pcnt[1] = 0; }
-    for (int32_t i = i0; i < S.n_sen; i += stride) {
-        L.bstidx[i] = S3A_NO_BSTIDX; L.bstscr[i] = S3A_LOGPROB_ZERO; L.updatetime[i] = S3A_NOT_UPDATED; L.sen_act[i] = 0;
-    }
-    for (int32_t i = i0; i <= S.n_cs; i += stride) L.cs_need[i] = -1;
-    if (blockIdx.x == 0) {
-        const int32_t tid = threadIdx.x;
-        if (tid < 2 * WL_MAXT) S.nact_all[(size_t)z * 2 * WL_MAXT + tid] = 0;
-        if (tid < 8) L.misc[tid] = (tid == 0 || tid == 5) ? INT_MIN : 0;
-        if (tid == 32) {
-            int32_t *arr[10] = { L.w.score, L.w.pred, L.w.lw0, L.w.lw1, L.w.wid, L.w.sf, L.w.ef, L.w.ascr, L.w.lscr, L.w.type };
-            for (int k = 0; k < 10; k++) arr[k][0] = B.e0[k];
-            for (int k = 0; k < 5; k++) L.w.lmc[(size_t)k * L.w.cap] = B.lmc[k];
-            L.w.frame_start[0] = 1; L.w.bestscore[0] = INT_MIN; L.w.bestvh[0] = -1; L.w.st[0] = 1; L.w.st[1] = 0;
-        }
-        if (stage) {
-            static_assert(sizeof(UCtx) % 4 == 0, "UCtx is copied word by word");
-            const int32_t *src = (const int32_t *)(stage + utt[blockIdx.z]);
-            int32_t *dst = (int32_t *)(S.ctx_all + z);
-            for (int32_t i = tid; i < (int32_t)(sizeof(UCtx) / 4); i += 256) dst[i] = src[i];
-        }
-    }
+    d_lane_begin(lanes[z], S, B, z, stage ? stage + utt[blockIdx.z] : (const UCtx *)NULL, blockIdx.x * 256 + (int32_t)threadIdx.x, gridDim.x * 256,
+                 blockIdx.x == 0, threadIdx.x, 256);
 }
 
 /* debugging (S3A_UTT_FRAMECHECK=1): after every frame, every node record that is not an inactive HMM must be on the NEXT
@@ -547,8 +560,10 @@ struct UwGroup {
 template <int CP, bool EXACT, bool TAB_LDS, int NT>
 __global__ void __launch_bounds__(NT)
 ku_score_window(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, int32_t f0, int32_t K, int32_t fpc,
-                int32_t n_chunks, int32_t n_tiles)
+                int32_t n_chunks, int32_t n_tiles, const UwGroup *__restrict__ gdesc, int32_t n_g)
 {
+    /* (gdesc: n_g groups of up to 8 consecutive frames of ANY utterances, written by the host -- the whole call's frames scored before
+     * the search starts, rows in one buffer (ku_frames, SCORES FIRST); NULL: the lanes' coming K frames into their window rows) */
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int DP = D4MAIN * 4;
     typedef typename Acc<EXACT>::T acc_t;
@@ -558,7 +573,7 @@ ku_score_window(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, int
     if (tile >= n_tiles) return;
     const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int32_t g = tile * NT + tid;
-    const int32_t q0 = chunk * fpc, total = n_lanes * K;
+    const int32_t q0 = chunk * fpc, total = gdesc ? n_g * UW_FB : n_lanes * K;
     const int32_t nslot = min(fpc, total - q0), ngrp = (nslot + UW_FB - 1) / UW_FB;
 
     float *xs = (float *)smem;
@@ -575,7 +590,12 @@ ku_score_window(const ULane *__restrict__ lanes, UShared S, int32_t n_lanes, int
     int32_t *s_any = (int32_t *)xs;             /* (the feature area is filled after the early exit) */
     if (tid == 0) *s_any = 0;
     __syncthreads();
-    if (tid < ngrp) {
+    if (tid < ngrp && gdesc) {
+        const UwGroup gr = gdesc[q0 / UW_FB + tid];
+        grp[tid] = gr;
+        if (gr.nv) *s_any = 1;
+    }
+    else if (tid < ngrp) {
         const int32_t q = q0 + tid * UW_FB, z = q / K, j0 = q - z * K;
         UwGroup gr;
         gr.feat = NULL; gr.win = NULL; gr.winb = NULL; gr.nv = 0; gr.pad = 0;
@@ -702,13 +722,11 @@ uw_one_gaussian(const UShared &S, int32_t g, const float *__restrict__ x)
 /* (NT threads; workgroup bx of G takes every G-th run of NT CD senones and leaves its maxima / counters in column bx of gpart[]) */
 template <bool EXACT, int NT>
 __device__ __forceinline__ void
-d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t K, int32_t bx, int32_t G)
+d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *row, const uint8_t *brow, int32_t bx, int32_t G)
 {
     __shared__ int32_t red[3][NT / 64];
     __shared__ int32_t s_pb;
     const int32_t tid = threadIdx.x, ln = tid & 63;
-    int32_t *row = L.win + (size_t)(f % K) * S.n_sen;
-    const uint8_t *brow = L.winb + (size_t)(f % K) * S.n_sen;
     int32_t pb = INT_MIN, cig = 0;
     for (int32_t ci = tid; ci < S.n_ci_sen; ci += NT) { pb = max(pb, row[ci]); cig += (int32_t)S.ncomp[ci]; }
 #pragma unroll
@@ -778,7 +796,7 @@ __global__ void __launch_bounds__(256)
 ku_select(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t K)
 {
     LANE;
-    d_select<EXACT, 256>(L, S, ctx, f, K, blockIdx.x, gridDim.x);
+    d_select<EXACT, 256>(L, S, ctx, f, L.win + (size_t)(f % K) * S.n_sen, L.winb + (size_t)(f % K) * S.n_sen, blockIdx.x, gridDim.x);
 }
 
 /* the members of the composite senones wanted in this frame join the mask (before ku_select) */
@@ -1335,33 +1353,171 @@ ku_emit_word(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPa
     else d_wordlevel_frame(L.w, ctx, L.pack, s_hdr, nx <= WL_LDS_EX ? s_ex : (const int32_t *)NULL, lm, dict, par, f, t_in);
 }
 
+/* ------------------------------------------------------------------ */
+/* the hypothesis of a finished lane, on the device                    */
+/* ------------------------------------------------------------------ */
+/*
+ * vithist_utt_end (vithist.c:766-860) + vithist_backtrace (vithist.c:1066-1100) + compute_scale (srch_output.c:52-60)
+ * for every lane behind its last frame: the best transition into </s> from the last frame that has entries (the
+ * earliest of equals), a silence entry over the rest when the search died early, the backtrace, every word's sum of
+ * frame normalisers.  Nothing is added to the lane's table: the final entries exist in the record only.  What the
+ * host reads back per utterance is UH_N words + 24 bytes per hypothesis word, not the history table: the lanes' words
+ * are packed one behind the other (a lane reserves its place with one atomicAdd on the word counter behind the headers),
+ * so that ONE linear copy brings them over.
+ */
+enum { UH_STATUS, UH_NENTRY, UH_NFRM, UH_TSCALE, UH_NWORDS, UH_SCORE, UH_EXIT, UH_WOFF,
+       UH_ERR, UH_CF, UH_MAXCAND, UH_MAXNEW, UH_NTIE, UH_NFR, UH_PAD0, UH_PAD1, UH_N };   /* (from UH_ERR on: the lane's context when it ended) */
+#define UH_FIRST 96          /* words per lane that travel with the headers (more: a second copy) */
+struct UHypPar { int32_t finish_lwid, finishwid, silwid, wcap, wtotal; };     /* wcap: words per hypothesis; wtotal: of the packed buffer */
+#define UH_T 256
+#define UH_IDS 2048
+
+/* (NT threads of one workgroup; hdr: the utterance's header slot) */
+template <int NT>
+__device__ __forceinline__ void
+d_hyp(const ULane &L, const UCtx *ctx, const WLm &lm, const WDict &dict, const UHypPar &P, int32_t *__restrict__ hdr, int32_t *__restrict__ words_all,
+      int32_t *__restrict__ wcount)
+{
+    const WLane &w = L.w;
+    const int32_t tid = threadIdx.x, nfr = ctx->nfr, n_entry = w.st[0], n_frm = w.st[1];
+    __shared__ uint32_t s_scale;
+    __shared__ int32_t s_woff;
+    __shared__ unsigned long long s_best;
+    __shared__ int32_t s_f, s_n, s_ids[UH_IDS];
+    if (tid == 0) { s_scale = 0u; s_best = 0ull; s_n = 0; }
+    __syncthreads();
+    uint32_t part = 0u;
+    for (int32_t f = tid; f < nfr; f += NT) part += (uint32_t)w.fstat[(size_t)f * 8];
+    atomicAdd(&s_scale, part);
+    if (tid == 0) {
+        int32_t f;
+        for (f = n_frm - 1; f >= 0; --f)
+            if (w.frame_start[f] < w.frame_start[f + 1]) break;
+        s_f = f;
+    }
+    __syncthreads();
+    const int32_t f = s_f, err = ctx->err;
+    if (tid == 0) {
+        hdr[UH_STATUS] = err ? -1 : (f < 0 ? -2 : 0); hdr[UH_NENTRY] = n_entry; hdr[UH_NFRM] = n_frm; hdr[UH_TSCALE] = (int32_t)s_scale;
+        hdr[UH_NWORDS] = 0; hdr[UH_SCORE] = 0; hdr[UH_EXIT] = -1; hdr[UH_WOFF] = 0;
+        hdr[UH_ERR] = err; hdr[UH_CF] = ctx->cf; hdr[UH_MAXCAND] = ctx->max_cand; hdr[UH_MAXNEW] = ctx->max_new;
+        hdr[UH_NTIE] = ctx->n_tie_frames; hdr[UH_NFR] = nfr; hdr[UH_PAD0] = 0; hdr[UH_PAD1] = 0;
+    }
+    if (err || f < 0) return;               /* (f < 0: no word exit at all -- vithist_utt_end returns -1) */
+    const int32_t sv = w.frame_start[f], nsv = w.frame_start[f + 1];
+    for (int32_t i = sv + tid; i < nsv; i += NT) {
+        const int32_t sc = add32(w.score[i], wl_tg_score(lm, w.lw1[i], w.lw0[i], P.finish_lwid, P.finishwid));
+        atomicMax(&s_best, wl_pack(sc, (uint32_t)i));            /* best < s: the earliest of equals */
+    }
+    __syncthreads();
+    const int32_t bestvh = (int32_t)(0xffffffffu - (uint32_t)(s_best & 0xffffffffull));
+    int32_t best = (int32_t)((uint32_t)(s_best >> 32) ^ 0x80000000u);
+    const bool have_sil = f != n_frm - 1;   /* the search died early: a silence entry over the rest (vithist.c:817-826) */
+    if (tid == 0) {
+        int32_t n = 0;
+        for (int32_t i = bestvh; i > 0; i = w.pred[i], n++) if (n < UH_IDS) s_ids[n] = i;
+        s_n = n;
+        const int32_t tot = n + (have_sil ? 1 : 0) + 1;
+        s_woff = tot <= P.wcap ? atomicAdd(wcount, tot) : -1;
+        if (s_woff >= 0 && (long long)s_woff + tot > (long long)P.wtotal) s_woff = -1;
+    }
+    __syncthreads();
+    const int32_t n = s_n, total = n + (have_sil ? 1 : 0) + 1;
+    int32_t *words = words_all + (size_t)max(s_woff, 0) * 6;
+    int32_t last_ef = w.ef[bestvh], last_score = w.score[bestvh];
+    int32_t sil_lscr = 0;
+    if (have_sil) {
+        sil_lscr = dict.fillpen[P.silwid];
+        const int32_t sil_score = add32(w.score[bestvh], sil_lscr);
+        best = add32(sil_score, wl_tg_score(lm, w.lw1[bestvh], w.lw0[bestvh], P.finish_lwid, P.finishwid));
+        last_ef = n_frm - 1; last_score = sil_score;
+    }
+    if (tid == 0) { hdr[UH_NWORDS] = total; hdr[UH_SCORE] = best; hdr[UH_EXIT] = n_entry + (have_sil ? 1 : 0); hdr[UH_WOFF] = max(s_woff, 0); }
+    if (s_woff < 0) { if (tid == 0) hdr[UH_STATUS] = -3; return; }
+    if (n <= UH_IDS) {
+        for (int32_t q = tid; q < n; q += NT) {
+            const int32_t i = s_ids[n - 1 - q];
+            int32_t *o = words + (size_t)q * 6;
+            o[0] = w.wid[i]; o[1] = w.sf[i]; o[2] = w.ef[i]; o[3] = w.ascr[i]; o[4] = w.lscr[i];
+        }
+    }
+    else if (tid == 0) {
+        int32_t k = n - 1;
+        for (int32_t i = bestvh; i > 0; i = w.pred[i], k--) {
+            int32_t *o = words + (size_t)k * 6;
+            o[0] = w.wid[i]; o[1] = w.sf[i]; o[2] = w.ef[i]; o[3] = w.ascr[i]; o[4] = w.lscr[i];
+        }
+    }
+    if (tid == 0) {
+        int32_t k = n;
+        if (have_sil) {
+            int32_t *o = words + (size_t)k * 6;
+            o[0] = P.silwid; o[1] = w.ef[bestvh] + 1; o[2] = n_frm - 1; o[3] = add32(w.score[bestvh], -w.score[bestvh]); o[4] = sil_lscr;
+            k++;
+        }
+        int32_t *o = words + (size_t)k * 6;
+        o[0] = P.finishwid; o[1] = last_ef + 1; o[2] = n_frm; o[3] = 0; o[4] = add32(best, -last_score);
+    }
+    __syncthreads();
+    for (int32_t q = tid; q < total; q += NT) {           /* compute_scale */
+        int32_t *o = words + (size_t)q * 6;
+        uint32_t sc = 0u;
+        for (int32_t i = max(o[1], 0); i < o[2] && i < nfr; i++) sc += (uint32_t)w.fstat[(size_t)i * 8];
+        o[5] = (int32_t)sc;
+    }
+}
+
+
+__global__ void __launch_bounds__(UH_T)
+ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *__restrict__ hdr_all, int32_t *__restrict__ words_all,
+       int32_t *__restrict__ wcount, const int32_t *__restrict__ sub, const int32_t *__restrict__ slot)
+{
+    /* (sub / slot: a refill event -- lane sub[x] has finished the utterance whose header goes to slot[x]; NULL: lane x, header x) */
+    const ULane &L = lanes[sub ? sub[blockIdx.x] : (int32_t)blockIdx.x];
+    d_hyp<UH_T>(L, L.ctx, lm, dict, P, hdr_all + (size_t)(slot ? slot[blockIdx.x] : (int32_t)blockIdx.x) * UH_N, words_all, wcount);
+}
+
 /* ====================================================================================================================
- * ku_frames: A BLOCK OF FRAMES IN ONE LAUNCH -- the lane's frame as the phases of a persistent workgroup (round 5).
+ * ku_frames: THE LANE'S FRAMES IN ONE LAUNCH -- the frame as the phases of a persistent workgroup (round 5).
  *
  * The reference's frame loop (srch.c:746-835; lextree.c:1253-1597) has no boundary between its steps; the launches above
  * have twelve per frame, each a grid over all lanes whose workgroups mostly find out that they are not needed, and several
  * engines take turns on the chip.  Here a lane is ONE 512-thread workgroup (or a cluster of C of them) that stays on its CU
- * for the whole block of K frames -- the look-ahead window ku_score_window has just scored -- and walks the same steps with a
- * workgroup barrier between them: lextree_enter (test / rank / apply + senone marks), the composite senones' members, the CI
- * gate (d_select), the composite maxima, lextree_hmm_eval, the stamps of the HMMs that propagate + the list of stamped parent
- * sets (or the histogram beam and the reordering), -ptranskip's weak HMMs, lextree_hmm_propagate_non_leaves from the node's
- * point of view (by list position + a wave per listed parent set), the ordered scan, the emission of the next list and the
- * word level.  The bodies are the launch path's (s3a_decoder_kernels.h, s3a_wordlevel.h): same rule, same bits.
+ * and walks the same steps with a workgroup barrier between them: lextree_enter (test / rank / apply + senone marks), the
+ * composite senones' members, the CI gate (d_select), the composite maxima, lextree_hmm_eval, the stamps of the HMMs that
+ * propagate + the list of stamped parent sets (or the histogram beam and the reordering), -ptranskip's weak HMMs,
+ * lextree_hmm_propagate_non_leaves from the node's point of view (by list position + a wave per listed parent set), the
+ * ordered scan, the emission of the next list and the word level.  The bodies are the launch path's
+ * (s3a_decoder_kernels.h, s3a_wordlevel.h): same rule, same bits.
  *
- * A lane's data is its own, so C = 1 needs nothing but __syncthreads() (two lanes per CU: 512 lanes fill the chip and never
- * wait for one another inside a block).  With fewer lanes than workgroup slots a lane is a CLUSTER of C workgroups on one XCD
- * (block b runs on XCD b % 8: observed, used for speed only) with a counter barrier between the phases: every workgroup
- * arrives behind an agent-scope release and leaves through an agent-scope acquire (a CU's L1 is not refreshed by other CUs'
- * stores, the XCDs' L2s are not coherent with each other).  Words that ATOMICS of an earlier phase changed are read past the L1
- * (S3A_ALD); the per-tree maxima are copied to LDS once per frame and every later phase reads the copy.
- * LDS: the word level's arrays + one pool the other phases share (two workgroups per CU).
+ * SCORES FIRST.  A senone's score does not depend on the search, so the look-ahead pass (ku_score_window) scores EVERY frame
+ * of every utterance of the call before the search starts (rows [frame][senone] in HBM, 5 bytes per senone and frame: what a
+ * 288 GB device is for), and the lanes never meet again: measured on the hub4-shaped batch, the time lanes take for the same
+ * eight frames spreads 1 : 4.7 : 16 (fastest : median : slowest), so every boundary all lanes must reach together costs
+ * the median lane more than its own work.  Three modes:
+ *   KF_WINDOW  frames [fg0, fg0 + n_fr) of every lane from its K-frame window rows (the launch path's buffers): what is left
+ *              when the scores of the whole call do not fit the device;
+ *   KF_STATIC  lane z decodes utterance z from its first to its last frame (s3a_uttdec_decode: at most n_lanes utterances,
+ *              the tables stay in the lanes);
+ *   KF_QUEUE   a lane TAKES the queue's next utterance (one atomic), begins it (srch_TST_begin's resets, d_lane_begin),
+ *              decodes it, leaves its hypothesis in the utterance's slot (d_hyp) and ends it (lextree_utt_end, d_lane_end)
+ *              -- s3a_uttdec_decode_queue without a schedule: no lane waits for a boundary, the chip drains only once.
+ *
+ * A lane's data is its own, so C = 1 needs nothing but __syncthreads() (two lanes per CU: 512 lanes fill the chip).  With
+ * fewer lanes than workgroup slots a lane is a CLUSTER of C workgroups on one XCD (block b runs on XCD b % 8: observed, used
+ * for speed only) with a counter barrier between the phases: every workgroup arrives behind an agent-scope release and leaves
+ * through an agent-scope acquire (a CU's L1 is not refreshed by other CUs' stores, the XCDs' L2s are not coherent with each
+ * other).  Words that ATOMICS of an earlier phase changed are read past the L1 (S3A_ALD); the per-tree maxima are copied to
+ * LDS once per frame and every later phase reads the copy.  LDS: the word level's arrays + one pool the other phases share
+ * (two workgroups per CU).
  * Not served here (the engine then keeps the launch path): the wide-beam word level (big_wl), -pheurtype, -maxcdsenpf,
- * per-frame scoring (window = 0), the invariant checker, per-launch profiling.
+ * per-frame scoring (window = 0), the invariant checker, per-launch profiling; a queue with the second pass.
  * ==================================================================================================================== */
 #define KF_NT WL_THREADS
 #define KF_WAVES (KF_NT / 64)
 #define KF_SPIN_MAX (1 << 21)
 static_assert(KF_NT == 512, "ku_frames: the word level's workgroup is the frame's workgroup");
+enum { KF_WINDOW, KF_STATIC, KF_QUEUE };
 
 union KfPool {                  /* phases that never overlap share this LDS */
     struct { int32_t off[WL_MAXCALL], root[WL_MAXCALL], in[WL_MAXCALL]; } e1;
@@ -1371,7 +1527,29 @@ union KfPool {                  /* phases that never overlap share this LDS */
     struct { int32_t hdr[6 * WL_MAXT + 16], ex[3 * WL_LDS_EX]; } wl;
 };
 
+struct KfSh {                   /* the workgroup's LDS outside the word level's own arrays */
+    KfPool pool;
+    int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
+};
+
 struct KfBar { int32_t *cnt; int32_t C, target; int32_t *dead; };
+
+/* what a call's launch works on besides the lanes (by value) */
+struct KfJob {
+    int32_t mode, fg0, n_fr;    /* KF_WINDOW: the engine frames of this launch */
+    int32_t n_utt;              /* KF_QUEUE: utterances of this launch (the queue's, or a part of it that fits the score buffer) */
+    int32_t u0;                 /* ... the first one's place in the queue */
+    int32_t *next;              /* ... [1] the counter the lanes take their utterances from */
+    int32_t *lane_u;            /* ... [n_lanes] what a lane's first workgroup took (read by the rest of its cluster) */
+    const UCtx *stage;          /* ... [queue] the utterances' staged contexts */
+    const long long *row0;      /* KF_STATIC: [n_lanes], KF_QUEUE: [queue]: the utterance's first row in the score buffer */
+    int32_t *scores;            /* [rows][n_sen] every frame's senone scores (ku_score_window); d_select patches the back-offs in place */
+    const uint8_t *bests;       /* [rows][n_sen] ... and the best component of every mixture */
+    int32_t *hdr, *words, *wcount;  /* KF_QUEUE: the hypotheses (ku_hyp's buffers) */
+    UHypPar P;
+    UBegin B;
+    int32_t n_word;
+};
 
 /* all workgroups of the lane's cluster have finished the phase and see what the others wrote */
 __device__ __forceinline__ void
@@ -1403,13 +1581,244 @@ kf_locate(const int32_t *pre, int32_t T, int32_t g, int32_t &t, int32_t &i)
     i = g - pre[t];
 }
 
+/* frame f of lane z (workgroup r of its C): row / brow = the frame's senone scores and best components */
+template <int NE, bool EXACT>
+__device__ __forceinline__ void
+kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict &dict, const WPar &par, KfSh &sh, KfBar &B, int32_t z,
+         int32_t r, int32_t C, int32_t f, int32_t *row, const uint8_t *brow, int32_t weak_possible)
+{
+    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = S.T;
+    const int32_t gtid = r * KF_NT + tid, gstride = C * KF_NT, gwave = r * KF_WAVES + wave, gwaves = C * KF_WAVES;
+    /* where the frame's time goes (thread 0 of the cluster's first workgroup: one clock read per step) */
+    long long t_prev = 0;
+#define KF_STAMP(i) do { if (r == 0 && tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kacc[i] += t_ - t_prev; t_prev = t_; } } while (0)
+    const int32_t cur = f & 1;
+    const int32_t *nact_cur = S.nact_all + ((size_t)z * 2 + cur) * WL_MAXT;
+    const FrameBeams bm = frame_beams(S, f);
+    const int32_t n_ent = ctx->n_ent, n_calls_all = ctx->n_calls, thresh = ctx->thresh;
+    if (r == 0 && tid == 0) { t_prev = (long long)wall_clock64(); ctx->kacc[13]++; }
+
+    /* ---- lextree_enter, step 1: the entry test (ku_enter1) ---- */
+    if (n_ent > 0) {
+        const int32_t n_calls = min(n_calls_all, WL_MAXCALL);
+        if (tid < n_calls) { sh.pool.e1.in[tid] = ctx->calls[4 * tid]; sh.pool.e1.root[tid] = ctx->calls[4 * tid + 2]; sh.pool.e1.off[tid] = ctx->calls[4 * tid + 3]; }
+        __syncthreads();
+        for (int32_t e = gtid; e < n_ent; e += gstride) {
+            int32_t lo = 0, hi = n_calls - 1;
+            while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.pool.e1.off[mid] <= e) lo = mid; else hi = mid - 1; }
+            const int32_t c = lo, idx = sh.pool.e1.root[c] + (e - sh.pool.e1.off[c]);
+            const int32_t scr = add32(sh.pool.e1.in[c], S.rootprob[idx]);
+            if (scr < thresh) continue;
+            const int32_t v = S.rootlist[idx];
+            if (!(L.sc[NSV(v)] < scr)) continue;
+            atomicMax(&L.key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
+            atomicMin(&L.first[v], c);
+        }
+        kf_barrier(B);
+        KF_STAMP(0);
+        /* ---- step 2: which roots a call lists, ranked in root-list order (ku_enter2) ---- */
+        const Entries ent = { ctx->calls, S.rootlist, n_calls_all, S.rootprob };
+        for (int32_t c = r; c < n_calls_all; c += C) {
+            d_dec_enter2_t<KF_NT>(ent, n_ent, ctx->calls, S.prob, L.sc, L.frame, L.first, thresh, f, T, L.nact[cur], L.eflag, L.ctot, L.n0, c, 0);
+            __syncthreads();
+        }
+        kf_barrier(B);
+        KF_STAMP(1);
+    }
+    /* ---- step 3: the listed roots, the winning entries, the senone marks of the frame's list (ku_enter3_mark) ---- */
+    {
+        const int32_t *n0 = n_ent > 0 ? L.n0 : L.nact[cur];
+        int32_t rows = 0;
+        for (int32_t t = 0; t < T; t++) rows = max(rows, n0[t]);
+        const int32_t neb = (n_ent + M3BLOCK - 1) / M3BLOCK, bpt = (rows + M3BLOCK - 1) / M3BLOCK;
+        const Entries ent = { ctx->calls, S.rootlist, n_calls_all, S.rootprob };
+        for (int32_t vb = gwave; vb < neb + bpt * T; vb += gwaves)
+            d_dec_enter3_mark(neb, ent, n_ent, ctx->calls, ctx->groups, ctx->n_groups, f, L.key, L.first, L.eflag, L.ctot, n0, L.sc,
+                              L.hist, L.frame, T, bpt, S.node_base, L.act[cur], L.nact[cur], L.pos, L.posf, S.ssid, S.comp, S.sseq,
+                              S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0, L.cs_need, thresh, lane);
+    }
+    kf_barrier(B);
+    KF_STAMP(2);
+    /* the frame's lists are final: their lengths end to end */
+    if (tid == 0) {
+        int32_t a = 0;
+        for (int32_t t = 0; t < T; t++) { sh.pre[t] = a; a += nact_cur[t]; }
+        sh.pre[T] = a;
+    }
+    /* ---- the composite senones' members join the mask (ku_comsen_mark) ---- */
+    for (int32_t w = gwave; w * 64 < S.n_cs; w += gwaves)
+        d_comsen_wave<false>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, L.sen_act, (const int32_t *)NULL, (int32_t *)NULL, w * 64);
+    kf_barrier(B);
+    KF_STAMP(3);
+    const int32_t n_tot = sh.pre[T];
+    const bool hist_frame = n_tot > bm.maxhmmpf + (bm.maxhmmpf >> 1);
+    /* ---- approx_cont_mgau_ci_eval / _frame_eval on the window row (ku_select); the launch path's columns of gpart[] that this
+     * cluster does not write are made neutral, so that an engine may take either path from frame to frame ---- */
+    {
+        const int32_t g_all = max(1, min(USEL_G, min(S.gp_n, (S.n_sen - S.n_ci_sen + 255) / 256))), G = min(C, g_all);
+        if (r < G) d_select<EXACT, KF_NT>(L, S, ctx, f, row, brow, r, G);
+        if (r == 0 && tid >= G && tid < g_all) { L.gpart[tid] = INT_MIN; L.gpart[S.gp_n + tid] = 0; L.gpart[2 * S.gp_n + tid] = 0; }
+    }
+    kf_barrier(B);
+    KF_STAMP(4);
+    /* ---- the scores of the composite senones wanted in this frame (ku_comsen_max) ---- */
+    for (int32_t w = gwave; w * 64 < S.n_cs; w += gwaves)
+        d_comsen_wave<true>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, w * 64);
+    kf_barrier(B);
+    KF_STAMP(5);
+    /* ---- lextree_hmm_eval (ku_hmm_eval): a thread per list position of the trees laid end to end; the per-tree maxima are
+     * gathered in LDS and leave the workgroup as one atomic per tree ---- */
+    {
+        int32_t gb = INT_MIN;
+        for (int32_t i = tid; i < S.gp_n; i += KF_NT) gb = max(gb, L.gpart[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gb = max(gb, __shfl_xor(gb, o, 64));
+        if (lane == 0) sh.red[wave] = gb;
+        if (tid < 2 * T) sh.acc[tid] = INT_MIN;
+        __syncthreads();
+        int32_t norm = max(L.misc[0], L.misc[5]);               /* the frame's normaliser */
+        for (int w = 0; w < KF_WAVES; w++) norm = max(norm, sh.red[w]);
+        const int32_t *act = L.act[cur];
+        for (int32_t g0 = r * KF_NT; g0 < n_tot; g0 += gstride) {
+            const int32_t g = g0 + tid;
+            int32_t t = -1, k = INT_MIN, w = -1;
+            if (g < n_tot) {
+                int32_t i, out;
+                kf_locate(sh.pre, T, g, t, i);
+                const int32_t b = S.node_base[t], v = act[b + i];
+                k = d_dec_hmm_eval_node<NE>(v, S.N, S.ssid, S.tmatid, S.wid, S.comp, S.tp, S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt,
+                                            row, norm, L.sc, L.hist, L.outs, L.outh, L.bests, f, (const int32_t *)NULL, S.psof, L.pstamp,
+                                            L.cs_val, S.node4, w, out);
+                L.poswid[b + i] = w;
+                L.posout[b + i] = out;
+            }
+            /* a wave's 64 positions belong to one tree, or to two or three at the seams */
+            unsigned long long todo = __ballot(t >= 0);
+            while (todo) {
+                const int32_t tt = __shfl(t, __ffsll((long long)todo) - 1, 64);
+                const bool mine = t == tt;
+                int32_t x = mine ? k : INT_MIN, y = (mine && w >= 0) ? k : INT_MIN;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { x = max(x, __shfl_xor(x, o, 64)); y = max(y, __shfl_xor(y, o, 64)); }
+                if (lane == 0) { atomicMax(&sh.acc[2 * tt], x); if (y != INT_MIN) atomicMax(&sh.acc[2 * tt + 1], y); }
+                todo &= ~__ballot(mine);
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * T && sh.acc[tid] != INT_MIN) atomicMax(&L.best[tid], sh.acc[tid]);
+    }
+    kf_barrier(B);
+    KF_STAMP(6);
+    /* the frame's per-tree maxima: final; every later phase reads this copy */
+    if (tid < 2 * T) sh.best[tid] = S3A_ALD(&L.best[tid]);
+    if (r == 0 && tid == 0) L.pcnt[(f + 1) & 1] = 0;           /* (the coming frame's list of stamped parent sets) */
+    __syncthreads();
+    /* ---- lextree_hmm_histbin + the histogram beam (frames over 1.5 x -maxhmmpf), else the stamps of the HMMs that can
+     * propagate and the list of stamped parent sets (ku_hist_count / ku_hist_sort) ---- */
+    if (hist_frame) {
+        for (int32_t t = 0; t < T; t++)
+            for (int32_t vb = r; vb * KF_NT < nact_cur[t]; vb += C) {
+                d_dec_hist_count_t<KF_NT>(S.node_base, L.act[cur], L.nact[cur], T, bm, sh.best, L.bests, L.exits + S.N, L.hbin, -1, 0, 1, NBIN, vb, t, sh.pool.bin);
+                __syncthreads();
+            }
+        kf_barrier(B);
+        if (r == 0)
+            for (int32_t t = 0; t < T; t++) {
+                const int32_t hb = d_dec_hist_sort_ws<KF_NT>(S.node_base, L.act[cur], L.nact[cur], T, bm, L.exits + S.N, L.exits, L.hbin, L.pos, -1, NBIN, t, 0, sh.pool.hs);
+                __syncthreads();
+                if (hb <= 0) {
+                    int32_t th, pth;
+                    frame_thresholds_hb(sh.best, T, bm, hb, th, pth);
+                    d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, 0, KF_NT, 1);
+                }
+                __syncthreads();
+            }
+    }
+    else {
+        int32_t th, pth;
+        frame_thresholds_hb(sh.best, T, bm, 1, th, pth);
+        for (int32_t t = 0; t < T; t++) d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, r * KF_NT, gstride, 1);
+    }
+    kf_barrier(B);
+    KF_STAMP(7);
+    /* ---- -ptranskip frames / -pbeam wider than -beam: the weak HMMs that a parent earlier in the list re-entered (ku_weak) ---- */
+    if (weak_possible && (bm.phone_uses_wbeam || bm.pbeam < bm.hmmbeam)) {
+        if (r == 0)
+            d_dec_weak_t<KF_NT>(S.N, T, f, bm, sh.best, L.nact[cur], S.node_base, L.act[cur], S.prob, S.par_off, S.par, L.pos, L.posf, L.sc, L.outs,
+                                L.bests, S.wid, L.hbin, L.propf, L.exits + 2 * (size_t)S.N, 0, 0);
+        kf_barrier(B);
+        KF_STAMP(8);
+    }
+    /* ---- lextree_hmm_propagate_non_leaves from the node's point of view (ku_resolve_plist) ---- */
+    {
+        if (r == 0 && hist_frame)
+            for (int32_t i = tid; i < NBIN; i += KF_NT) L.hbin[i] = 0;         /* (the bins were consumed by the sort; hbin[NBIN] stays) */
+        for (int32_t v = gtid; v < S.n_rootnodes; v += gstride) {              /* lextree_enter only ever touches root nodes */
+            const int32_t rn = S.rootnodes[v];
+            L.key[rn] = 0ull;
+            L.first[rn] = INT_MAX;
+        }
+        const int32_t *act = L.act[cur];
+        /* the active HMMs by list position */
+        for (int32_t g = gtid; g < n_tot; g += gstride) {
+            int32_t t, i;
+            kf_locate(sh.pre, T, g, t, i);
+            const int32_t b = S.node_base[t], v = act[b + i], q = S.ps[v];
+            const bool has_par = q >= 0 && L.pstamp8[q] == ps_val<uint8_t>(f);
+            /* (the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
+            if (has_par && S3A_ALD(&L.claim[q]) == f) {
+                const int32_t np = S.par_off[v + 1] - S.par_off[v];
+                if (np >= SET_NP_MIN && np <= 64) continue;
+            }
+            d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                               L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                               S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b);
+        }
+        /* the members of the listed parent sets: a wave per set */
+        d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                               L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                               S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, L.plist, S3A_ALD(&L.pcnt[f & 1]),
+                                               S.psmem_off, S.psmem, gwave, gwaves, HeurArgs{ NULL, NULL, NULL }, sh.pool.rc[wave]);
+    }
+    kf_barrier(B);
+    KF_STAMP(9);
+    /* ---- the ordered compaction of the next list and of the word exits (ku_scan): a tree per workgroup in turn ---- */
+    for (int32_t t = r; t < T; t += C) {
+        d_dec_scan_t<KF_NT>(S.N, T, f, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit, L.cnt, L.base,
+                            L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, sh.best, L.exits, L.nexit, L.hbin, L.misc, (int32_t *)NULL, L.pack,
+                            S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, hist_frame ? 1 : 0, L.scan_agg, L.scan_pre, L.scan_flag,
+                            S.scan_chunks, 0, 1, 1, t, 0);
+        __syncthreads();
+    }
+    kf_barrier(B);
+    KF_STAMP(10);
+    /* ---- the emission of the next list (every workgroup but the first when there are several) and the word level (the
+     * first), which closes the frame and leaves the next frame's lextree_enter calls (ku_emit_word) ---- */
+    if (C == 1 || r > 0) {
+        const int32_t ew = C == 1 ? wave : gwave - KF_WAVES, enw = C == 1 ? KF_WAVES : gwaves - KF_WAVES;
+        for (int32_t t = 0; t < T; t++)
+            d_dec_emit_w(f, S.node_base, L.act[cur], L.nact[cur], S.child_off, S.child, L.turn, L.selfemit, L.base, L.act[cur ^ 1], L.nact[cur ^ 1],
+                         L.pos, L.posf, t, ew, enw);
+    }
+    if (r == 0) {
+        __syncthreads();
+        if (C == 1) KF_STAMP(15);
+        const long long t_in = (long long)wall_clock64();
+        const int32_t nx = d_dec_pack_frame_lds(S.N, T, bm, S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc, L.pack,
+                                                S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1], sh.pool.wl.hdr, sh.pool.wl.ex, WL_LDS_EX);
+        d_wordlevel_frame(L.w, ctx, L.pack, sh.pool.wl.hdr, nx <= WL_LDS_EX ? sh.pool.wl.ex : (const int32_t *)NULL, lm, dict, par, f, t_in);
+    }
+    kf_barrier(B);
+    KF_STAMP(11);
+#undef KF_STAMP
+}
+
 template <int NE, bool EXACT>
 __global__ void __launch_bounds__(KF_NT, 4)
-ku_frames(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, int32_t fg0, int32_t n_fr, int32_t n_lanes,
-          int32_t C, int32_t *bar, int32_t weak_possible)
+ku_frames(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, KfJob J, int32_t n_lanes, int32_t C, int32_t *bar,
+          int32_t weak_possible)
 {
-    __shared__ KfPool pool;
-    __shared__ int32_t s_best[2 * WL_MAXT], s_acc[2 * WL_MAXT], s_pre[WL_MAXT + 1], s_red[KF_WAVES], s_dead;
+    __shared__ KfSh sh;
     /* the lane and this workgroup's place in its cluster: a cluster's workgroups share an XCD */
     int32_t z, r;
     if (C == 1) { z = blockIdx.x; r = 0; }
@@ -1417,224 +1826,66 @@ ku_frames(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar p
     if (z >= n_lanes) return;
     const ULane &L = lanes[z];
     UCtx *ctx = S.ctx_all + z;
-    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = S.T;
-    const int32_t gtid = r * KF_NT + tid, gstride = C * KF_NT, gwave = r * KF_WAVES + wave, gwaves = C * KF_WAVES;
-    if (tid == 0) s_dead = 0;
-    KfBar B = { bar + z, C, 0, &s_dead };
+    const int32_t tid = threadIdx.x;
+    if (tid == 0) sh.dead = 0;
+    KfBar B = { bar + z, C, 0, &sh.dead };
     __syncthreads();
-    const int32_t f0 = ctx->f0, nfr = ctx->nfr;
-    for (int32_t fg = fg0; fg < fg0 + n_fr; fg++) {
-        const int32_t f = fg - f0;
-        if (f < 0 || f >= nfr) continue;
-        /* (the word level ends an utterance that ran into an error: uniform over the cluster behind the frame's last barrier) */
-        if (!((volatile UCtx *)ctx)->active || s_dead) break;
-        const int32_t cur = f & 1;
-        const int32_t *nact_cur = S.nact_all + ((size_t)z * 2 + cur) * WL_MAXT;
-        const FrameBeams bm = frame_beams(S, f);
-        const int32_t n_ent = ctx->n_ent, n_calls_all = ctx->n_calls, thresh = ctx->thresh;
-
-        /* ---- lextree_enter, step 1: the entry test (ku_enter1) ---- */
-        if (n_ent > 0) {
-            const int32_t n_calls = min(n_calls_all, WL_MAXCALL);
-            if (tid < n_calls) { pool.e1.in[tid] = ctx->calls[4 * tid]; pool.e1.root[tid] = ctx->calls[4 * tid + 2]; pool.e1.off[tid] = ctx->calls[4 * tid + 3]; }
-            __syncthreads();
-            for (int32_t e = gtid; e < n_ent; e += gstride) {
-                int32_t lo = 0, hi = n_calls - 1;
-                while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (pool.e1.off[mid] <= e) lo = mid; else hi = mid - 1; }
-                const int32_t c = lo, idx = pool.e1.root[c] + (e - pool.e1.off[c]);
-                const int32_t scr = add32(pool.e1.in[c], S.rootprob[idx]);
-                if (scr < thresh) continue;
-                const int32_t v = S.rootlist[idx];
-                if (!(L.sc[NSV(v)] < scr)) continue;
-                atomicMax(&L.key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
-                atomicMin(&L.first[v], c);
-            }
-            kf_barrier(B);
-            /* ---- step 2: which roots a call lists, ranked in root-list order (ku_enter2) ---- */
-            const Entries ent = { ctx->calls, S.rootlist, n_calls_all, S.rootprob };
-            for (int32_t c = r; c < n_calls_all; c += C) {
-                d_dec_enter2_t<KF_NT>(ent, n_ent, ctx->calls, S.prob, L.sc, L.frame, L.first, thresh, f, T, L.nact[cur], L.eflag, L.ctot, L.n0, c, 0);
-                __syncthreads();
-            }
-            kf_barrier(B);
+    const long long t_launch = (long long)wall_clock64();
+    if (J.mode == KF_WINDOW) {
+        const int32_t f0 = ctx->f0, nfr = ctx->nfr;
+        for (int32_t fg = J.fg0; fg < J.fg0 + J.n_fr; fg++) {
+            const int32_t f = fg - f0;
+            if (f < 0 || f >= nfr) continue;
+            /* (the word level ends an utterance that ran into an error: uniform over the cluster behind the frame's last barrier) */
+            if (!((volatile UCtx *)ctx)->active || sh.dead) break;
+            kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, L.win + (size_t)(f % S.win_K) * S.n_sen,
+                                L.winb + (size_t)(f % S.win_K) * S.n_sen, weak_possible);
         }
-        /* ---- step 3: the listed roots, the winning entries, the senone marks of the frame's list (ku_enter3_mark) ---- */
-        {
-            const int32_t *n0 = n_ent > 0 ? L.n0 : L.nact[cur];
-            int32_t rows = 0;
-            for (int32_t t = 0; t < T; t++) rows = max(rows, n0[t]);
-            const int32_t neb = (n_ent + M3BLOCK - 1) / M3BLOCK, bpt = (rows + M3BLOCK - 1) / M3BLOCK;
-            const Entries ent = { ctx->calls, S.rootlist, n_calls_all, S.rootprob };
-            for (int32_t vb = gwave; vb < neb + bpt * T; vb += gwaves)
-                d_dec_enter3_mark(neb, ent, n_ent, ctx->calls, ctx->groups, ctx->n_groups, f, L.key, L.first, L.eflag, L.ctot, n0, L.sc,
-                                  L.hist, L.frame, T, bpt, S.node_base, L.act[cur], L.nact[cur], L.pos, L.posf, S.ssid, S.comp, S.sseq,
-                                  S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0, L.cs_need, thresh, lane);
-        }
-        kf_barrier(B);
-        /* the frame's lists are final: their lengths end to end */
-        if (tid == 0) {
-            int32_t a = 0;
-            for (int32_t t = 0; t < T; t++) { s_pre[t] = a; a += nact_cur[t]; }
-            s_pre[T] = a;
-        }
-        /* ---- the composite senones' members join the mask (ku_comsen_mark) ---- */
-        for (int32_t w = gwave; w * 64 < S.n_cs; w += gwaves)
-            d_comsen_wave<false>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, L.sen_act, (const int32_t *)NULL, (int32_t *)NULL, w * 64);
-        kf_barrier(B);
-        const int32_t n_tot = s_pre[T];
-        const bool hist_frame = n_tot > bm.maxhmmpf + (bm.maxhmmpf >> 1);
-        const int32_t *row = L.win + (size_t)(f % S.win_K) * S.n_sen;
-        /* ---- approx_cont_mgau_ci_eval / _frame_eval on the window row (ku_select); the launch path's columns of gpart[] that this
-         * cluster does not write are made neutral, so that an engine may take either path from frame to frame ---- */
-        {
-            const int32_t g_all = max(1, min(USEL_G, min(S.gp_n, (S.n_sen - S.n_ci_sen + 255) / 256))), G = min(C, g_all);
-            if (r < G) d_select<EXACT, KF_NT>(L, S, ctx, f, S.win_K, r, G);
-            if (r == 0 && tid >= G && tid < g_all) { L.gpart[tid] = INT_MIN; L.gpart[S.gp_n + tid] = 0; L.gpart[2 * S.gp_n + tid] = 0; }
-        }
-        kf_barrier(B);
-        /* ---- the scores of the composite senones wanted in this frame (ku_comsen_max) ---- */
-        for (int32_t w = gwave; w * 64 < S.n_cs; w += gwaves)
-            d_comsen_wave<true>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, w * 64);
-        kf_barrier(B);
-        /* ---- lextree_hmm_eval (ku_hmm_eval): a thread per list position of the trees laid end to end; the per-tree maxima are
-         * gathered in LDS and leave the workgroup as one atomic per tree ---- */
-        {
-            int32_t gb = INT_MIN;
-            for (int32_t i = tid; i < S.gp_n; i += KF_NT) gb = max(gb, L.gpart[i]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) gb = max(gb, __shfl_xor(gb, o, 64));
-            if (lane == 0) s_red[wave] = gb;
-            if (tid < 2 * T) s_acc[tid] = INT_MIN;
-            __syncthreads();
-            int32_t norm = max(L.misc[0], L.misc[5]);               /* the frame's normaliser */
-            for (int w = 0; w < KF_WAVES; w++) norm = max(norm, s_red[w]);
-            const int32_t *act = L.act[cur];
-            for (int32_t g0 = r * KF_NT; g0 < n_tot; g0 += gstride) {
-                const int32_t g = g0 + tid;
-                int32_t t = -1, k = INT_MIN, w = -1;
-                if (g < n_tot) {
-                    int32_t i, out;
-                    kf_locate(s_pre, T, g, t, i);
-                    const int32_t b = S.node_base[t], v = act[b + i];
-                    k = d_dec_hmm_eval_node<NE>(v, S.N, S.ssid, S.tmatid, S.wid, S.comp, S.tp, S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt,
-                                                row, norm, L.sc, L.hist, L.outs, L.outh, L.bests, f, (const int32_t *)NULL, S.psof, L.pstamp,
-                                                L.cs_val, S.node4, w, out);
-                    L.poswid[b + i] = w;
-                    L.posout[b + i] = out;
-                }
-                /* a wave's 64 positions belong to one tree, or to two or three at the seams */
-                unsigned long long todo = __ballot(t >= 0);
-                while (todo) {
-                    const int32_t tt = __shfl(t, __ffsll((long long)todo) - 1, 64);
-                    const bool mine = t == tt;
-                    int32_t x = mine ? k : INT_MIN, y = (mine && w >= 0) ? k : INT_MIN;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) { x = max(x, __shfl_xor(x, o, 64)); y = max(y, __shfl_xor(y, o, 64)); }
-                    if (lane == 0) { atomicMax(&s_acc[2 * tt], x); if (y != INT_MIN) atomicMax(&s_acc[2 * tt + 1], y); }
-                    todo &= ~__ballot(mine);
-                }
-            }
-            __syncthreads();
-            if (tid < 2 * T && s_acc[tid] != INT_MIN) atomicMax(&L.best[tid], s_acc[tid]);
-        }
-        kf_barrier(B);
-        /* the frame's per-tree maxima: final; every later phase reads this copy */
-        if (tid < 2 * T) s_best[tid] = S3A_ALD(&L.best[tid]);
-        if (r == 0 && tid == 0) L.pcnt[(f + 1) & 1] = 0;           /* (the coming frame's list of stamped parent sets) */
-        __syncthreads();
-        /* ---- lextree_hmm_histbin + the histogram beam (frames over 1.5 x -maxhmmpf), else the stamps of the HMMs that can
-         * propagate and the list of stamped parent sets (ku_hist_count / ku_hist_sort) ---- */
-        if (hist_frame) {
-            for (int32_t t = 0; t < T; t++)
-                for (int32_t vb = r; vb * KF_NT < nact_cur[t]; vb += C) {
-                    d_dec_hist_count_t<KF_NT>(S.node_base, L.act[cur], L.nact[cur], T, bm, s_best, L.bests, L.exits + S.N, L.hbin, -1, 0, 1, NBIN, vb, t, pool.bin);
-                    __syncthreads();
-                }
-            kf_barrier(B);
-            if (r == 0)
-                for (int32_t t = 0; t < T; t++) {
-                    const int32_t hb = d_dec_hist_sort_ws<KF_NT>(S.node_base, L.act[cur], L.nact[cur], T, bm, L.exits + S.N, L.exits, L.hbin, L.pos, -1, NBIN, t, 0, pool.hs);
-                    __syncthreads();
-                    if (hb <= 0) {
-                        int32_t th, pth;
-                        frame_thresholds_hb(s_best, T, bm, hb, th, pth);
-                        d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, 0, KF_NT, 1);
-                    }
-                    __syncthreads();
-                }
-        }
-        else {
-            int32_t th, pth;
-            frame_thresholds_hb(s_best, T, bm, 1, th, pth);
-            for (int32_t t = 0; t < T; t++) d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, r * KF_NT, gstride, 1);
-        }
-        kf_barrier(B);
-        /* ---- -ptranskip frames / -pbeam wider than -beam: the weak HMMs that a parent earlier in the list re-entered (ku_weak) ---- */
-        if (weak_possible && (bm.phone_uses_wbeam || bm.pbeam < bm.hmmbeam)) {
-            if (r == 0)
-                d_dec_weak_t<KF_NT>(S.N, T, f, bm, s_best, L.nact[cur], S.node_base, L.act[cur], S.prob, S.par_off, S.par, L.pos, L.posf, L.sc, L.outs,
-                                    L.bests, S.wid, L.hbin, L.propf, L.exits + 2 * (size_t)S.N, 0, 0);
-            kf_barrier(B);
-        }
-        /* ---- lextree_hmm_propagate_non_leaves from the node's point of view (ku_resolve_plist) ---- */
-        {
-            if (r == 0 && hist_frame)
-                for (int32_t i = tid; i < NBIN; i += KF_NT) L.hbin[i] = 0;         /* (the bins were consumed by the sort; hbin[NBIN] stays) */
-            for (int32_t v = gtid; v < S.n_rootnodes; v += gstride) {              /* lextree_enter only ever touches root nodes */
-                const int32_t rn = S.rootnodes[v];
-                L.key[rn] = 0ull;
-                L.first[rn] = INT_MAX;
-            }
-            const int32_t *act = L.act[cur];
-            /* the active HMMs by list position */
-            for (int32_t g = gtid; g < n_tot; g += gstride) {
-                int32_t t, i;
-                kf_locate(s_pre, T, g, t, i);
-                const int32_t b = S.node_base[t], v = act[b + i], q = S.ps[v];
-                const bool has_par = q >= 0 && L.pstamp8[q] == ps_val<uint8_t>(f);
-                /* (the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
-                if (has_par && S3A_ALD(&L.claim[q]) == f) {
-                    const int32_t np = S.par_off[v + 1] - S.par_off[v];
-                    if (np >= SET_NP_MIN && np <= 64) continue;
-                }
-                d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, s_best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                                   L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                                   S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b);
-            }
-            /* the members of the listed parent sets: a wave per set */
-            d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, s_best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                                   L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                                   S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, L.plist, S3A_ALD(&L.pcnt[f & 1]),
-                                                   S.psmem_off, S.psmem, gwave, gwaves, HeurArgs{ NULL, NULL, NULL }, pool.rc[wave]);
-        }
-        kf_barrier(B);
-        /* ---- the ordered compaction of the next list and of the word exits (ku_scan): a tree per workgroup in turn ---- */
-        for (int32_t t = r; t < T; t += C) {
-            d_dec_scan_t<KF_NT>(S.N, T, f, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit, L.cnt, L.base,
-                                L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, s_best, L.exits, L.nexit, L.hbin, L.misc, (int32_t *)NULL, L.pack,
-                                S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, hist_frame ? 1 : 0, L.scan_agg, L.scan_pre, L.scan_flag,
-                                S.scan_chunks, 0, 1, 1, t, 0);
-            __syncthreads();
-        }
-        kf_barrier(B);
-        /* ---- the emission of the next list (every workgroup but the first when there are several) and the word level (the
-         * first), which closes the frame and leaves the next frame's lextree_enter calls (ku_emit_word) ---- */
-        if (C == 1 || r > 0) {
-            const int32_t ew = C == 1 ? wave : gwave - KF_WAVES, enw = C == 1 ? KF_WAVES : gwaves - KF_WAVES;
-            for (int32_t t = 0; t < T; t++)
-                d_dec_emit_w(f, S.node_base, L.act[cur], L.nact[cur], S.child_off, S.child, L.turn, L.selfemit, L.base, L.act[cur ^ 1], L.nact[cur ^ 1],
-                             L.pos, L.posf, t, ew, enw);
-        }
-        if (r == 0) {
-            __syncthreads();
-            const long long t_in = (long long)wall_clock64();
-            const int32_t nx = d_dec_pack_frame_lds(S.N, T, bm, S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc, L.pack,
-                                                    S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1], pool.wl.hdr, pool.wl.ex, WL_LDS_EX);
-            d_wordlevel_frame(L.w, ctx, L.pack, pool.wl.hdr, nx <= WL_LDS_EX ? pool.wl.ex : (const int32_t *)NULL, lm, dict, par, f, t_in);
-        }
-        kf_barrier(B);
     }
-    if (s_dead && tid == 0) { ctx->err |= WL_E_SCAN; ctx->active = 0; }
+    else if (J.mode == KF_STATIC) {
+        const int32_t nfr = ctx->nfr;
+        const size_t r0 = (size_t)J.row0[z];
+        for (int32_t f = 0; f < nfr; f++) {
+            if (!((volatile UCtx *)ctx)->active || sh.dead) break;
+            kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, J.scores + (r0 + f) * S.n_sen, J.bests + (r0 + f) * S.n_sen, weak_possible);
+        }
+    }
+    else {
+        const int32_t gtid = r * KF_NT + tid, gstride = C * KF_NT;
+        for (;;) {
+            /* the queue's next utterance: taken by the lane's first workgroup */
+            if (r == 0 && tid == 0) {
+                const int32_t u = atomicAdd(J.next, 1);
+                sh.u = u;
+                if (C > 1) __hip_atomic_store(&J.lane_u[z], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            kf_barrier(B);
+            if (r > 0 && tid == 0) sh.u = __hip_atomic_load(&J.lane_u[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int32_t u = sh.u;
+            if (u >= J.n_utt || sh.dead) break;
+            /* srch_utt_begin (srch.c:453-479): every per-utterance state reset, the utterance's context */
+            d_lane_begin(L, S, J.B, z, J.stage + J.u0 + u, gtid, gstride, r == 0, tid, KF_NT);
+            kf_barrier(B);
+            const int32_t nfr = ctx->nfr;
+            const size_t r0 = (size_t)J.row0[J.u0 + u];
+            for (int32_t f = 0; f < nfr; f++) {
+                if (!((volatile UCtx *)ctx)->active || sh.dead) break;
+                kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, J.scores + (r0 + f) * S.n_sen, J.bests + (r0 + f) * S.n_sen, weak_possible);
+            }
+            /* srch_utt_end (srch.c:482-560): the hypothesis goes to the utterance's slot, the lane's lists are cleared */
+            if (r == 0) d_hyp<KF_NT>(L, ctx, lm, dict, J.P, J.hdr + (size_t)(J.u0 + u) * UH_N, J.words, J.wcount);
+            kf_barrier(B);
+            d_lane_end(L, S, z, ctx->err != 0, J.n_word, gtid, gstride);
+            kf_barrier(B);
+        }
+    }
+    if (r == 0 && tid == 0) { ctx->kacc[12] += (long long)wall_clock64() - t_launch; ctx->kacc[14]++; }
+    if (r == 0 && tid == 0 && J.mode == KF_WINDOW && J.fg0 == 512) {
+        ctx->kdbg[0] = t_launch; ctx->kdbg[1] = (long long)wall_clock64();
+        ctx->kdbg[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); ctx->kdbg[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+    if (sh.dead && tid == 0) { ctx->err |= WL_E_SCAN; ctx->active = 0; }
 }
 
 #define LANE_W const ULane &L = lanes[blockIdx.z]; UCtx *ctx = L.ctx; const int32_t f = fg - ctx->f0;               \
@@ -1829,122 +2080,6 @@ s3a_lm3g_tg_score(const s3a_lm3g_t *lm, int32_t lw1, int32_t lw2, int32_t lw3, i
     return h_add(bowt, h_bg(lm, lw2, lw3, wid));
 }
 
-/* ------------------------------------------------------------------ */
-/* the hypothesis of a finished lane, on the device                    */
-/* ------------------------------------------------------------------ */
-/*
- * vithist_utt_end (vithist.c:766-860) + vithist_backtrace (vithist.c:1066-1100) + compute_scale (srch_output.c:52-60)
- * for every lane behind its last frame: the best transition into </s> from the last frame that has entries (the
- * earliest of equals), a silence entry over the rest when the search died early, the backtrace, every word's sum of
- * frame normalisers.  Nothing is added to the lane's table: the final entries exist in the record only.  What the
- * host reads back per utterance is UH_N words + 24 bytes per hypothesis word, not the history table: the lanes' words
- * are packed one behind the other (a lane reserves its place with one atomicAdd on the word counter behind the headers),
- * so that ONE linear copy brings them over.
- */
-enum { UH_STATUS, UH_NENTRY, UH_NFRM, UH_TSCALE, UH_NWORDS, UH_SCORE, UH_EXIT, UH_WOFF,
-       UH_ERR, UH_CF, UH_MAXCAND, UH_MAXNEW, UH_NTIE, UH_NFR, UH_PAD0, UH_PAD1, UH_N };   /* (from UH_ERR on: the lane's context when it ended) */
-#define UH_FIRST 96          /* words per lane that travel with the headers (more: a second copy) */
-struct UHypPar { int32_t finish_lwid, finishwid, silwid, wcap, wtotal; };     /* wcap: words per hypothesis; wtotal: of the packed buffer */
-#define UH_T 256
-#define UH_IDS 2048
-
-__global__ void __launch_bounds__(UH_T)
-ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *__restrict__ hdr_all, int32_t *__restrict__ words_all,
-       int32_t *__restrict__ wcount, const int32_t *__restrict__ sub, const int32_t *__restrict__ slot)
-{
-    /* (sub / slot: a refill event -- lane sub[x] has finished the utterance whose header goes to slot[x]; NULL: lane x, header x) */
-    const ULane &L = lanes[sub ? sub[blockIdx.x] : (int32_t)blockIdx.x];
-    const WLane &w = L.w;
-    const UCtx *ctx = L.ctx;
-    int32_t *hdr = hdr_all + (size_t)(slot ? slot[blockIdx.x] : (int32_t)blockIdx.x) * UH_N;
-    const int32_t tid = threadIdx.x, nfr = ctx->nfr, n_entry = w.st[0], n_frm = w.st[1];
-    __shared__ uint32_t s_scale;
-    __shared__ int32_t s_woff;
-    __shared__ unsigned long long s_best;
-    __shared__ int32_t s_f, s_n, s_ids[UH_IDS];
-    if (tid == 0) { s_scale = 0u; s_best = 0ull; s_n = 0; }
-    __syncthreads();
-    uint32_t part = 0u;
-    for (int32_t f = tid; f < nfr; f += UH_T) part += (uint32_t)w.fstat[(size_t)f * 8];
-    atomicAdd(&s_scale, part);
-    if (tid == 0) {
-        int32_t f;
-        for (f = n_frm - 1; f >= 0; --f)
-            if (w.frame_start[f] < w.frame_start[f + 1]) break;
-        s_f = f;
-    }
-    __syncthreads();
-    const int32_t f = s_f, err = ctx->err;
-    if (tid == 0) {
-        hdr[UH_STATUS] = err ? -1 : (f < 0 ? -2 : 0); hdr[UH_NENTRY] = n_entry; hdr[UH_NFRM] = n_frm; hdr[UH_TSCALE] = (int32_t)s_scale;
-        hdr[UH_NWORDS] = 0; hdr[UH_SCORE] = 0; hdr[UH_EXIT] = -1; hdr[UH_WOFF] = 0;
-        hdr[UH_ERR] = err; hdr[UH_CF] = ctx->cf; hdr[UH_MAXCAND] = ctx->max_cand; hdr[UH_MAXNEW] = ctx->max_new;
-        hdr[UH_NTIE] = ctx->n_tie_frames; hdr[UH_NFR] = nfr; hdr[UH_PAD0] = 0; hdr[UH_PAD1] = 0;
-    }
-    if (err || f < 0) return;               /* (f < 0: no word exit at all -- vithist_utt_end returns -1) */
-    const int32_t sv = w.frame_start[f], nsv = w.frame_start[f + 1];
-    for (int32_t i = sv + tid; i < nsv; i += UH_T) {
-        const int32_t sc = add32(w.score[i], wl_tg_score(lm, w.lw1[i], w.lw0[i], P.finish_lwid, P.finishwid));
-        atomicMax(&s_best, wl_pack(sc, (uint32_t)i));            /* best < s: the earliest of equals */
-    }
-    __syncthreads();
-    const int32_t bestvh = (int32_t)(0xffffffffu - (uint32_t)(s_best & 0xffffffffull));
-    int32_t best = (int32_t)((uint32_t)(s_best >> 32) ^ 0x80000000u);
-    const bool have_sil = f != n_frm - 1;   /* the search died early: a silence entry over the rest (vithist.c:817-826) */
-    if (tid == 0) {
-        int32_t n = 0;
-        for (int32_t i = bestvh; i > 0; i = w.pred[i], n++) if (n < UH_IDS) s_ids[n] = i;
-        s_n = n;
-        const int32_t tot = n + (have_sil ? 1 : 0) + 1;
-        s_woff = tot <= P.wcap ? atomicAdd(wcount, tot) : -1;
-        if (s_woff >= 0 && (long long)s_woff + tot > (long long)P.wtotal) s_woff = -1;
-    }
-    __syncthreads();
-    const int32_t n = s_n, total = n + (have_sil ? 1 : 0) + 1;
-    int32_t *words = words_all + (size_t)max(s_woff, 0) * 6;
-    int32_t last_ef = w.ef[bestvh], last_score = w.score[bestvh];
-    int32_t sil_lscr = 0;
-    if (have_sil) {
-        sil_lscr = dict.fillpen[P.silwid];
-        const int32_t sil_score = add32(w.score[bestvh], sil_lscr);
-        best = add32(sil_score, wl_tg_score(lm, w.lw1[bestvh], w.lw0[bestvh], P.finish_lwid, P.finishwid));
-        last_ef = n_frm - 1; last_score = sil_score;
-    }
-    if (tid == 0) { hdr[UH_NWORDS] = total; hdr[UH_SCORE] = best; hdr[UH_EXIT] = n_entry + (have_sil ? 1 : 0); hdr[UH_WOFF] = max(s_woff, 0); }
-    if (s_woff < 0) { if (tid == 0) hdr[UH_STATUS] = -3; return; }
-    if (n <= UH_IDS) {
-        for (int32_t q = tid; q < n; q += UH_T) {
-            const int32_t i = s_ids[n - 1 - q];
-            int32_t *o = words + (size_t)q * 6;
-            o[0] = w.wid[i]; o[1] = w.sf[i]; o[2] = w.ef[i]; o[3] = w.ascr[i]; o[4] = w.lscr[i];
-        }
-    }
-    else if (tid == 0) {
-        int32_t k = n - 1;
-        for (int32_t i = bestvh; i > 0; i = w.pred[i], k--) {
-            int32_t *o = words + (size_t)k * 6;
-            o[0] = w.wid[i]; o[1] = w.sf[i]; o[2] = w.ef[i]; o[3] = w.ascr[i]; o[4] = w.lscr[i];
-        }
-    }
-    if (tid == 0) {
-        int32_t k = n;
-        if (have_sil) {
-            int32_t *o = words + (size_t)k * 6;
-            o[0] = P.silwid; o[1] = w.ef[bestvh] + 1; o[2] = n_frm - 1; o[3] = add32(w.score[bestvh], -w.score[bestvh]); o[4] = sil_lscr;
-            k++;
-        }
-        int32_t *o = words + (size_t)k * 6;
-        o[0] = P.finishwid; o[1] = last_ef + 1; o[2] = n_frm; o[3] = 0; o[4] = add32(best, -last_score);
-    }
-    __syncthreads();
-    for (int32_t q = tid; q < total; q += UH_T) {           /* compute_scale */
-        int32_t *o = words + (size_t)q * 6;
-        uint32_t sc = 0u;
-        for (int32_t i = max(o[1], 0); i < o[2] && i < nfr; i++) sc += (uint32_t)w.fstat[(size_t)i * 8];
-        o[5] = (int32_t)sc;
-    }
-}
-
 /*
  * A queue with the second pass (s3a_uttdec_enable_bestpath + s3a_uttdec_decode_queue): the pass has just run for the lanes that
  * ended at this refill event; what it left in the lane's arena -- status words, the best path end first -- goes to the
@@ -2065,6 +2200,11 @@ struct s3a_uttdec_s {
     int32_t *d_kfbar;           /* [n_lanes] the clusters' barrier counters */
     int32_t kf_last_c;          /* workgroups per lane of the last launch (diagnostics) */
     int32_t kf_counted;         /* this engine is counted in g_kf_live */
+    int32_t *d_kfnext;          /* [16 + n_lanes] the queue's counter | what a lane's first workgroup took */
+    /* SCORES FIRST: every frame's senone scores of a call (ku_frames, KF_STATIC / KF_QUEUE) */
+    int32_t *sb_scores; uint8_t *sb_bests; size_t sb_rows_cap;
+    UwGroup *sb_gdesc_d, *sb_gdesc_h; size_t sb_g_cap;
+    long long *sb_row0_d, *sb_row0_h; size_t sb_row0_cap;
 };
 
 /* engines with ku_frames alive per device: an engine that is alone on its device may give a lane a cluster of workgroups */
@@ -2158,6 +2298,13 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     }
     if (ud->kf_counted) { g_kf_live[ud->device]--; ud->kf_counted = 0; }
     if (ud->d_kfbar) (void)hipFree(ud->d_kfbar);
+    if (ud->d_kfnext) (void)hipFree(ud->d_kfnext);
+    if (ud->sb_scores) (void)hipFree(ud->sb_scores);
+    if (ud->sb_bests) (void)hipFree(ud->sb_bests);
+    if (ud->sb_gdesc_d) (void)hipFree(ud->sb_gdesc_d);
+    if (ud->sb_gdesc_h) (void)hipHostFree(ud->sb_gdesc_h);
+    if (ud->sb_row0_d) (void)hipFree(ud->sb_row0_d);
+    if (ud->sb_row0_h) (void)hipHostFree(ud->sb_row0_h);
     if (ud->q_dio_d) (void)hipFree(ud->q_dio_d);
     if (ud->q_dio_h) (void)hipHostFree(ud->q_dio_h);
     if (ud->q_dw_d) (void)hipFree(ud->q_dw_d);
@@ -2431,8 +2578,11 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->S.fgbase = ud->d_fgbase;
     ud->use_graph = O.graph != 0 && !ud->big_wl && !O.framecheck;
     ud->persist = O.persist >= 0 && !ud->use_graph && !O.framecheck ? 1 : 0;
-    ud->kf_cluster_opt = O.cluster; ud->kf_last_c = 0; ud->kf_slots = 0; ud->d_kfbar = NULL; ud->kf_counted = 0;
+    ud->kf_cluster_opt = O.cluster; ud->kf_last_c = 0; ud->kf_slots = 0; ud->d_kfbar = NULL; ud->kf_counted = 0; ud->d_kfnext = NULL;
+    ud->sb_scores = NULL; ud->sb_bests = NULL; ud->sb_rows_cap = 0; ud->sb_gdesc_d = ud->sb_gdesc_h = NULL; ud->sb_g_cap = 0;
+    ud->sb_row0_d = ud->sb_row0_h = NULL; ud->sb_row0_cap = 0;
     if (ud->persist) {
+        DM(ud->d_kfnext, (size_t)(16 + n_lanes) * 4);
         DM(ud->d_kfbar, (size_t)n_lanes * 4);
         if (hipMemset(ud->d_kfbar, 0, (size_t)n_lanes * 4) != hipSuccess) goto fail;
         if (ud->device >= 0 && ud->device < 64) { g_kf_live[ud->device]++; ud->kf_counted = 1; }
@@ -2624,10 +2774,10 @@ uw_lds_bytes(int32_t fpc, int32_t nt, bool tab_lds, uint32_t tab_size)
 /* (lane, frame) slots per chunk: a workgroup needs ~100 KB of LDS, so one is resident per CU and the grid runs in rounds
  * of n_cu workgroups; time ~ rounds x (slots per chunk + a start-up worth ~10 slots): s3a_device.hip, pick_fpc */
 static UwGeom
-uw_geometry(const s3a_uttdec_t *ud, int32_t n_lanes)
+uw_geometry(const s3a_uttdec_t *ud, int32_t n_lanes, int32_t total_slots = 0)
 {
     const UShared &S = ud->S;
-    const int32_t total = n_lanes * S.win_K, n_cu = max(1, ud->g->dev->n_cu);
+    const int32_t total = total_slots > 0 ? total_slots : n_lanes * S.win_K, n_cu = max(1, ud->g->dev->n_cu);
     UwGeom q;
     q.tab_lds = total >= 2 * UW_FB ? 1 : 0;
     q.nt = q.tab_lds ? 512 : 256;
@@ -2655,14 +2805,14 @@ uw_geometry(const s3a_uttdec_t *ud, int32_t n_lanes)
 
 template <int CP, bool EXACT>
 static hipError_t
-uw_launch_cp(const s3a_uttdec_t *ud, const UwGeom &q, int32_t n, int32_t f0, hipStream_t st, bool attr_only)
+uw_launch_cp(const s3a_uttdec_t *ud, const UwGeom &q, int32_t n, int32_t f0, hipStream_t st, bool attr_only, const UwGroup *gdesc = NULL, int32_t n_g = 0)
 {
     /* (attr_only: the function attribute alone -- before a stream capture, where it may not be set) */
 #define UW_GO(TAB, NT) do { auto kern = ku_score_window<CP, EXACT, TAB, NT>;                                            \
         if (q.lds > 64 * 1024 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                                        160 * 1024) != hipSuccess) return hipGetLastError();             \
         if (!attr_only) hipLaunchKernelGGL(kern, dim3(q.grid), dim3(NT), q.lds, st, ud->d_lanes, ud->S, n, f0, ud->S.win_K, q.fpc,        \
-                           q.n_chunks, q.n_tiles); } while (0)
+                           q.n_chunks, q.n_tiles, gdesc, n_g); } while (0)
     if (q.nt == 512) { if (q.tab_lds) UW_GO(true, 512); else UW_GO(false, 512); }
     else UW_GO(false, 256);
 #undef UW_GO
@@ -2670,14 +2820,15 @@ uw_launch_cp(const s3a_uttdec_t *ud, const UwGeom &q, int32_t n, int32_t f0, hip
 }
 
 static int32_t
-uw_launch(const s3a_uttdec_t *ud, int32_t n, int32_t f0, bool attr_only = false)
+uw_launch(const s3a_uttdec_t *ud, int32_t n, int32_t f0, bool attr_only = false, const UwGroup *gdesc = NULL, int32_t n_g = 0)
 {
-    const UwGeom q = uw_geometry(ud, n);
+    /* (gdesc: n_g groups of 8 frames from the host's table instead of the lanes' windows) */
+    const UwGeom q = uw_geometry(ud, n, gdesc ? n_g * UW_FB : 0);
     hipError_t e;
-#define UW_CASE(cp) case cp: e = ud->exact ? uw_launch_cp<cp, true>(ud, q, n, f0, ud->stream, attr_only) : uw_launch_cp<cp, false>(ud, q, n, f0, ud->stream, attr_only); break
+#define UW_CASE(cp) case cp: e = ud->exact ? uw_launch_cp<cp, true>(ud, q, n, f0, ud->stream, attr_only, gdesc, n_g) : uw_launch_cp<cp, false>(ud, q, n, f0, ud->stream, attr_only, gdesc, n_g); break
     switch (ud->S.CP) {
     UW_CASE(1); UW_CASE(2); UW_CASE(4); UW_CASE(8); UW_CASE(16); UW_CASE(32);
-    default: e = ud->exact ? uw_launch_cp<64, true>(ud, q, n, f0, ud->stream, attr_only) : uw_launch_cp<64, false>(ud, q, n, f0, ud->stream, attr_only); break;
+    default: e = ud->exact ? uw_launch_cp<64, true>(ud, q, n, f0, ud->stream, attr_only, gdesc, n_g) : uw_launch_cp<64, false>(ud, q, n, f0, ud->stream, attr_only, gdesc, n_g); break;
     }
 #undef UW_CASE
     if (e != hipSuccess) { s3a_set_error("ku_score_window launch failed: %s", hipGetErrorString(e)); return S3A_EHIP; }
@@ -2823,6 +2974,23 @@ enqueue_frame(s3a_uttdec_t *ud, int32_t n, int32_t f, bool prof)
     return S3A_OK;
 }
 
+template <typename TP>
+static int32_t
+q_grow(TP **d, TP **h, size_t *cap, size_t need, const char *what)
+{
+    if (need <= *cap) return S3A_OK;
+    const size_t grow = need + need / 4 + 64;
+    if (*d) (void)hipFree(*d);
+    if (h && *h) (void)hipHostFree(*h);
+    *d = NULL; if (h) *h = NULL; *cap = 0;
+    if (hipMalloc((void **)d, grow * sizeof(TP)) != hipSuccess || (h && hipHostMalloc((void **)h, grow * sizeof(TP)) != hipSuccess)) {
+        s3a_set_error("s3a_uttdec_decode_queue: out of memory (%s, %zu bytes)", what, grow * sizeof(TP));
+        return S3A_ENOMEM;
+    }
+    *cap = grow;
+    return S3A_OK;
+}
+
 /* ---- ku_frames: the frames [fg0, fg0 + nf) of all lanes as ONE launch (behind the look-ahead pass that scores them) ---- */
 /* does this engine, as it is configured now, run its frames through ku_frames? */
 static bool
@@ -2835,7 +3003,7 @@ kf_served(const s3a_uttdec_t *ud)
 
 template <int NE, bool EXACT>
 static int32_t
-kf_launch_t(s3a_uttdec_t *ud, int32_t n, int32_t fg0, int32_t nf)
+kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
 {
     auto kern = ku_frames<NE, EXACT>;
     if (ud->kf_slots == 0) {
@@ -2849,25 +3017,160 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, int32_t fg0, int32_t nf)
     int32_t C = 1;
     if (ud->kf_cluster_opt > 0) C = ud->kf_cluster_opt;
     else if (ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1) C = min(per_xcd / lanes_per_xcd, 32);
-    /* (one margin slot per XCD: the occupancy query can be one workgroup per CU high, MI355X_MICROARCH "Residency") */
+    /* (a margin per XCD: the occupancy query can be one workgroup per CU high, MI355X_MICROARCH "Residency") */
     C = max(1, min(C, (per_xcd - (per_xcd > 8 ? 4 : 0)) / lanes_per_xcd));
     ud->kf_last_c = C;
     const int32_t grid = C == 1 ? n : 8 * C * lanes_per_xcd;
     if (C > 1) HIPCHK(hipMemsetAsync(ud->d_kfbar, 0, (size_t)n * 4, ud->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(KF_NT), 0, ud->stream, ud->d_lanes, ud->S, ud->lm->d, ud->dict, ud->par, fg0, nf, n, C,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(KF_NT), 0, ud->stream, ud->d_lanes, ud->S, ud->lm->d, ud->dict, ud->par, J, n, C,
                        ud->d_kfbar, ud->weak_possible);
     HIPCHK(hipGetLastError());
     return S3A_OK;
 }
 
-/* the frames [fg0, fg0 + nf) of lanes 0 .. n - 1: fg0 is a window boundary, nf at most the window */
+static int32_t
+kf_launch(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
+{
+    if (ud->S.ne == 5) return ud->exact ? kf_launch_t<5, true>(ud, n, J) : kf_launch_t<5, false>(ud, n, J);
+    return ud->exact ? kf_launch_t<3, true>(ud, n, J) : kf_launch_t<3, false>(ud, n, J);
+}
+
+/* the frames [fg0, fg0 + nf) of lanes 0 .. n - 1 from their window rows: fg0 is a window boundary, nf at most the window */
 static int32_t
 enqueue_block(s3a_uttdec_t *ud, int32_t n, int32_t fg0, int32_t nf)
 {
     int32_t rc = uw_launch(ud, n, fg0, false);
     if (rc != S3A_OK) return rc;
-    if (ud->S.ne == 5) return ud->exact ? kf_launch_t<5, true>(ud, n, fg0, nf) : kf_launch_t<5, false>(ud, n, fg0, nf);
-    return ud->exact ? kf_launch_t<3, true>(ud, n, fg0, nf) : kf_launch_t<3, false>(ud, n, fg0, nf);
+    KfJob J;
+    memset(&J, 0, sizeof J);
+    J.mode = KF_WINDOW; J.fg0 = fg0; J.n_fr = nf;
+    return kf_launch(ud, n, J);
+}
+
+/* ---- SCORES FIRST: every frame of the call's utterances scored into one buffer before the search starts ---- */
+/* rows of senone scores the device can hold beside everything else (5 bytes per senone and frame; half of what is free now) */
+static size_t
+sb_budget_rows(const s3a_uttdec_t *ud)
+{
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+    const size_t per_row = (size_t)ud->S.n_sen * 5;
+    return (fr / 2 + ud->sb_rows_cap * per_row) / per_row;
+}
+
+static int32_t
+sb_reserve(s3a_uttdec_t *ud, size_t rows, size_t groups, size_t n_utt)
+{
+    const size_t S_ = (size_t)ud->S.n_sen;
+    if (rows > ud->sb_rows_cap) {
+        if (ud->sb_scores) (void)hipFree(ud->sb_scores);
+        if (ud->sb_bests) (void)hipFree(ud->sb_bests);
+        ud->sb_scores = NULL; ud->sb_bests = NULL; ud->sb_rows_cap = 0;
+        const size_t grow = rows + rows / 16 + 64;
+        if (hipMalloc((void **)&ud->sb_scores, grow * S_ * 4) != hipSuccess || hipMalloc((void **)&ud->sb_bests, grow * S_) != hipSuccess) {
+            if (ud->sb_scores) (void)hipFree(ud->sb_scores);
+            ud->sb_scores = NULL; ud->sb_bests = NULL;
+            s3a_set_error("s3a_uttdec: the score buffer (%zu rows of %zu senones) does not fit the device", grow, S_);
+            return S3A_ENOMEM;
+        }
+        ud->sb_rows_cap = grow;
+    }
+    int32_t rc;
+    if ((rc = q_grow(&ud->sb_gdesc_d, &ud->sb_gdesc_h, &ud->sb_g_cap, groups, "score groups")) != S3A_OK) return rc;
+    if ((rc = q_grow(&ud->sb_row0_d, &ud->sb_row0_h, &ud->sb_row0_cap, n_utt + 1, "score rows")) != S3A_OK) return rc;
+    return S3A_OK;
+}
+
+/* the groups of utterances [u0, u1): 8 consecutive frames each, rows from `row` on; returns the groups written */
+static size_t
+sb_describe(s3a_uttdec_t *ud, const float *const *feat_dev, const int32_t *n_frames, int32_t u0, int32_t u1, size_t g_at)
+{
+    const size_t S_ = (size_t)ud->S.n_sen;
+    const int32_t DP = ud->S.D4 * 4;
+    size_t row = 0, g = g_at;
+    for (int32_t u = u0; u < u1; u++) {
+        ud->sb_row0_h[u] = (long long)row;
+        for (int32_t j0 = 0; j0 < n_frames[u]; j0 += UW_FB, g++) {
+            UwGroup &gr = ud->sb_gdesc_h[g];
+            gr.feat = feat_dev[u] + (size_t)j0 * DP;
+            gr.win = ud->sb_scores + (row + j0) * S_;
+            gr.winb = ud->sb_bests + (row + j0) * S_;
+            gr.nv = min(UW_FB, n_frames[u] - j0); gr.pad = 0;
+        }
+        row += (size_t)n_frames[u];
+    }
+    return g - g_at;
+}
+
+/* score the groups [g0, g0 + n_g) of the uploaded table: launches of up to SB_PIECE groups */
+#define SB_PIECE 1024
+static int32_t
+sb_score(s3a_uttdec_t *ud, size_t g0, size_t n_g)
+{
+    for (size_t g = 0; g < n_g; g += SB_PIECE) {
+        const int32_t rc = uw_launch(ud, 0, 0, false, ud->sb_gdesc_d + g0 + g, (int32_t)min((size_t)SB_PIECE, n_g - g));
+        if (rc != S3A_OK) return rc;
+    }
+    return S3A_OK;
+}
+
+/* s3a_uttdec_decode through ku_frames: lane z decodes utterance z, all of its frames in one launch.  feat_dev[z]: the lane's
+ * features on the device.  Returns S3A_EUNSUP when the scores do not fit (the caller then decodes in window blocks). */
+static int32_t
+kf_decode_static(s3a_uttdec_t *ud, int32_t n_utt, const int32_t *n_frames)
+{
+    size_t rows = 0, groups = 0;
+    std::vector<const float *> fd((size_t)n_utt);
+    for (int32_t z = 0; z < n_utt; z++) { rows += (size_t)n_frames[z]; groups += (size_t)(n_frames[z] + UW_FB - 1) / UW_FB; fd[z] = ud->h_ctx_up[z].feat; }
+    if (rows > sb_budget_rows(ud)) return S3A_EUNSUP;
+    int32_t rc;
+    if ((rc = sb_reserve(ud, rows, groups, (size_t)n_utt)) != S3A_OK) return rc;
+    const size_t ng = sb_describe(ud, fd.data(), n_frames, 0, n_utt, 0);
+    HIPCHK(hipMemcpyAsync(ud->sb_gdesc_d, ud->sb_gdesc_h, ng * sizeof(UwGroup), hipMemcpyHostToDevice, ud->stream));
+    HIPCHK(hipMemcpyAsync(ud->sb_row0_d, ud->sb_row0_h, (size_t)n_utt * 8, hipMemcpyHostToDevice, ud->stream));
+    if ((rc = sb_score(ud, 0, ng)) != S3A_OK) return rc;
+    KfJob J;
+    memset(&J, 0, sizeof J);
+    J.mode = KF_STATIC; J.row0 = ud->sb_row0_d; J.scores = ud->sb_scores; J.bests = ud->sb_bests;
+    return kf_launch(ud, n_utt, J);
+}
+
+/* s3a_uttdec_decode_queue through ku_frames: the lanes take the utterances themselves.  The queue goes through in as many parts as
+ * the score buffer needs (one, unless the queue's frames outgrow half the free device memory). */
+static int32_t
+kf_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev, const int32_t *n_frames, const UBegin &B, const UHypPar &P,
+                int32_t *wcount)
+{
+    const size_t budget = sb_budget_rows(ud);
+    /* the parts: consecutive utterances whose rows fit */
+    std::vector<int32_t> cut(1, 0);
+    size_t rows = 0, max_rows = 0, groups = 0;
+    for (int32_t u = 0; u < n_utt; u++) {
+        if (rows > 0 && rows + (size_t)n_frames[u] > budget) { cut.push_back(u); rows = 0; }
+        rows += (size_t)n_frames[u];
+        max_rows = max(max_rows, rows);
+        groups += (size_t)(n_frames[u] + UW_FB - 1) / UW_FB;
+    }
+    cut.push_back(n_utt);
+    if (max_rows > budget) { s3a_set_error("s3a_uttdec_decode_queue: an utterance's scores (%zu rows) do not fit the device", max_rows); return S3A_ENOMEM; }
+    int32_t rc;
+    if ((rc = sb_reserve(ud, max_rows, groups, (size_t)n_utt)) != S3A_OK) return rc;
+    std::vector<size_t> g_at(cut.size(), 0);
+    for (size_t k = 0; k + 1 < cut.size(); k++) g_at[k + 1] = g_at[k] + sb_describe(ud, feat_dev, n_frames, cut[k], cut[k + 1], g_at[k]);
+    HIPCHK(hipMemcpyAsync(ud->sb_gdesc_d, ud->sb_gdesc_h, g_at.back() * sizeof(UwGroup), hipMemcpyHostToDevice, ud->stream));
+    HIPCHK(hipMemcpyAsync(ud->sb_row0_d, ud->sb_row0_h, (size_t)n_utt * 8, hipMemcpyHostToDevice, ud->stream));
+    for (size_t k = 0; k + 1 < cut.size(); k++) {
+        const int32_t u0 = cut[k], nu = cut[k + 1] - cut[k];
+        if ((rc = sb_score(ud, g_at[k], g_at[k + 1] - g_at[k])) != S3A_OK) return rc;
+        HIPCHK(hipMemsetAsync(ud->d_kfnext, 0, 4, ud->stream));
+        KfJob J;
+        memset(&J, 0, sizeof J);
+        J.mode = KF_QUEUE; J.n_utt = nu; J.u0 = u0; J.next = ud->d_kfnext; J.lane_u = ud->d_kfnext + 16; J.stage = ud->q_ctx_d;
+        J.row0 = ud->sb_row0_d; J.scores = ud->sb_scores; J.bests = ud->sb_bests;
+        J.hdr = ud->q_hdr_d; J.words = ud->q_words_d; J.wcount = wcount; J.P = P; J.B = B; J.n_word = ud->cfg.n_word;
+        if ((rc = kf_launch(ud, min(ud->n_lanes, nu), J)) != S3A_OK) return rc;
+    }
+    return S3A_OK;
 }
 
 /* ---- graph mode: the launches of a BLOCK of frames as one HIP graph ----
@@ -3002,9 +3305,15 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
             if (hipGraphLaunch(ge, ud->stream) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
         if (rc == S3A_OK && hipMemsetAsync(ud->d_fgbase, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
     }
-    else if (kf_served(ud))
-        for (int32_t f = 0; f < maxT && rc == S3A_OK; f += ud->S.win_K)
-            rc = enqueue_block(ud, n_utt, f, min(ud->S.win_K, maxT - f));
+    else if (kf_served(ud)) {
+        /* every frame scored first, then each lane's utterance as one launch; in window blocks when the scores do not fit */
+        rc = kf_decode_static(ud, n_utt, n_frames);
+        if (rc == S3A_EUNSUP) {
+            rc = S3A_OK;
+            for (int32_t f = 0; f < maxT && rc == S3A_OK; f += ud->S.win_K)
+                rc = enqueue_block(ud, n_utt, f, min(ud->S.win_K, maxT - f));
+        }
+    }
     else
     for (int32_t f = 0; f < maxT && rc == S3A_OK; f++)
         rc = enqueue_frame(ud, n_utt, f, ud->prof_every > 0 && f % ud->prof_every == 0);
@@ -3140,23 +3449,6 @@ s3a_queue_schedule(int32_t n_lanes, int32_t boundary, int32_t n_utt, const int32
     }
 }
 
-template <typename TP>
-static int32_t
-q_grow(TP **d, TP **h, size_t *cap, size_t need, const char *what)
-{
-    if (need <= *cap) return S3A_OK;
-    const size_t grow = need + need / 4 + 64;
-    if (*d) (void)hipFree(*d);
-    if (h && *h) (void)hipHostFree(*h);
-    *d = NULL; if (h) *h = NULL; *cap = 0;
-    if (hipMalloc((void **)d, grow * sizeof(TP)) != hipSuccess || (h && hipHostMalloc((void **)h, grow * sizeof(TP)) != hipSuccess)) {
-        s3a_set_error("s3a_uttdec_decode_queue: out of memory (%s, %zu bytes)", what, grow * sizeof(TP));
-        return S3A_ENOMEM;
-    }
-    *cap = grow;
-    return S3A_OK;
-}
-
 static int32_t
 uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const int32_t *n_frames, int32_t feat_stride,
                     bool feat_on_device)
@@ -3168,6 +3460,8 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     HIPCHK(hipSetDevice(ud->device));
     const UShared &S = ud->S;
     const bool graph_mode = ud->use_graph && ud->prof_every == 0;
+    /* ku_frames (KF_QUEUE): the lanes take the utterances themselves -- no schedule, no refill events, no window boundaries */
+    const bool kfq = !graph_mode && kf_served(ud) && !ud->dag;
     /* utterances begin at window boundaries (the look-ahead pass scores K frames of all lanes); in graph mode at the blocks' */
     const int32_t n = min(ud->n_lanes, n_utt), E = graph_mode ? graph_block_frames(ud) : (S.win_K > 0 ? S.win_K : 1), D4x4 = S.D4 * 4, T = S.T;
     int32_t rc;
@@ -3209,7 +3503,12 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     std::vector<Ev> evs;
     std::vector<int32_t> sched, u_lane((size_t)n_utt), u_f0((size_t)n_utt), last_utt((size_t)n, -1);
     if ((rc = q_grow(&ud->q_ctx_d, &ud->q_ctx_h, &ud->q_ctx_cap, (size_t)n_utt, "contexts")) != S3A_OK) return rc;
-    {
+    if (kfq) {
+        for (int32_t u = 0; u < n_utt; u++)
+            if ((rc = utt_context(ud, ud->q_ctx_h[u], fd[u], n_frames[u], 1, 0, u)) != S3A_OK) return rc;
+        for (int32_t z = 0; z < n; z++) ud->lane[z].nfr = 0;
+    }
+    else {
         const int32_t fe = s3a_queue_schedule(n, E, n_utt, n_frames, u_lane.data(), u_f0.data());
         if (fe < 0) return fe;
         struct Lists { std::vector<int32_t> el, eu, bl, bu; int32_t mx = 0; };
@@ -3235,10 +3534,12 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
             evs.push_back(e);
         }
     }
-    const int32_t F_end = evs.back().f;           /* (the last event only ends lanes) */
+    const int32_t F_end = evs.empty() ? 0 : evs.back().f;           /* (the last event only ends lanes) */
     if ((rc = q_grow(&ud->q_sched_d, &ud->q_sched_h, &ud->q_sched_cap, sched.size(), "schedule")) != S3A_OK) return rc;
-    memcpy(ud->q_sched_h, sched.data(), sched.size() * 4);
-    HIPCHK(hipMemcpyAsync(ud->q_sched_d, ud->q_sched_h, sched.size() * 4, hipMemcpyHostToDevice, ud->stream));
+    if (!sched.empty()) {
+        memcpy(ud->q_sched_h, sched.data(), sched.size() * 4);
+        HIPCHK(hipMemcpyAsync(ud->q_sched_d, ud->q_sched_h, sched.size() * 4, hipMemcpyHostToDevice, ud->stream));
+    }
     HIPCHK(hipMemcpyAsync(ud->q_ctx_d, ud->q_ctx_h, sizeof(UCtx) * n_utt, hipMemcpyHostToDevice, ud->stream));
     /* results: a header per utterance + the word counter; the words packed (an utterance's hypothesis has at most one word
      * per frame + silence + </s>) */
@@ -3300,7 +3601,10 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     rc = S3A_OK;
     if (hipEventRecord(ud->ev0, ud->stream) != hipSuccess) rc = S3A_EHIP;
     size_t ei = 0;
-    if (graph_mode) {
+    if (kfq) {
+        if (rc == S3A_OK) rc = kf_decode_queue(ud, n_utt, fd.data(), n_frames, B, P, wcount);
+    }
+    else if (graph_mode) {
         hipGraphExec_t ge = NULL;
         rc = graph_for(ud, n, &ge);
         if (rc == S3A_OK && hipMemsetAsync(ud->d_fgbase, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
@@ -3445,6 +3749,34 @@ s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16)
 {
     if (!ud || !out16 || lane < 0 || lane >= ud->n_utt) return S3A_EINVAL;
     for (int i = 0; i < 16; i++) out16[i] = ud->lane[lane].h_ctx->tacc[i];
+    return S3A_OK;
+}
+
+/* ku_frames' clock: [0..11] lextree_enter test / rank / apply + marks, composite members, CI gate, composite maxima, HMM evaluation,
+ * stamps (or histogram), weak HMMs, propagation, scan, emission + word level; [15] the emission alone when the lane is one
+ * workgroup; [12] inside the launches, [13] frames, [14] launches -- of the utterance lane `lane` decoded last (read from the
+ * device); out16[15] < 0 when the engine does not run ku_frames */
+extern "C" int32_t
+s3a_uttdec_frame_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16, int32_t *cluster)
+{
+    if (!ud || !out16 || lane < 0 || lane >= ud->n_lanes) return S3A_EINVAL;
+    HIPCHK(hipSetDevice(ud->device));
+    UCtx x;
+    HIPCHK(hipMemcpy(&x, ud->S.ctx_all + lane, sizeof x, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 16; i++) out16[i] = x.kacc[i];
+    if (cluster) *cluster = kf_served(ud) ? ud->kf_last_c : 0;
+    return S3A_OK;
+}
+
+/* diagnostics: lane's ku_frames launch that began at engine frame 512: clock (100 MHz) at entry and exit, HW_ID, XCC_ID */
+extern "C" int32_t
+s3a_uttdec_frame_dbg(s3a_uttdec_t *ud, int32_t lane, long long *out4)
+{
+    if (!ud || !out4 || lane < 0 || lane >= ud->n_lanes) return S3A_EINVAL;
+    HIPCHK(hipSetDevice(ud->device));
+    UCtx x;
+    HIPCHK(hipMemcpy(&x, ud->S.ctx_all + lane, sizeof x, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) out4[i] = x.kdbg[i];
     return S3A_OK;
 }
 

@@ -96,6 +96,8 @@ struct UCtx {
     int32_t groups[8];
     int32_t calls[4 * WL_MAXCALL];
     long long tacc[16];     /* time spent per word-level phase (100 MHz ticks; tools/wl_phases) */
+    long long kdbg[4];      /* ku_frames, the launch that began at engine frame 512: clock at entry / exit, hardware id, XCC id (diagnostics) */
+    long long kacc[16];     /* ku_frames: time per step of the frame (100 MHz ticks, workgroup 0 of the lane's cluster; s3a_uttdec_frame_ticks) */
 };
 
 struct WLane {              /* one lane's history table + per-frame scratch (device pointers) */

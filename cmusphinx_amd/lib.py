@@ -203,6 +203,8 @@ _SIGS = {
     "s3a_uttdec_queue_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_wl_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_uttdec_frame_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "s3a_uttdec_frame_dbg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_window": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_enable_pheur": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -1531,6 +1533,22 @@ class UttDec:
         t = (C.c_longlong * 16)()
         check(self.L.s3a_uttdec_wl_ticks(self.h, int(lane), t), self.L)
         return [0.01 * t[i] for i in range(9)]
+
+    def frame_ticks(self, lane=0):
+        """ku_frames' clock for the utterance `lane` decoded last -> (dict step -> microseconds, frames, launches, cluster);
+        cluster 0: the engine runs the frame as separate launches"""
+        t = (C.c_longlong * 16)(); c = C.c_int32()
+        check(self.L.s3a_uttdec_frame_ticks(self.h, int(lane), t, C.byref(c)), self.L)
+        names = ("enter_test", "enter_rank", "enter_apply_mark", "comsen_mark", "select", "comsen_max", "hmm_eval", "stamp_hist", "weak",
+                 "resolve", "scan", "emit_word")
+        d = {names[i]: 0.01 * t[i] for i in range(12)}
+        d["emit_only"] = 0.01 * t[15]; d["in_launch"] = 0.01 * t[12]
+        return d, int(t[13]), int(t[14]), int(c.value)
+
+    def frame_dbg(self, lane=0):
+        t = (C.c_longlong * 4)()
+        check(self.L.s3a_uttdec_frame_dbg(self.h, int(lane), t), self.L)
+        return [int(x) for x in t]
 
     def hyp(self, lane, uttid="", utt_index=0):
         rec = HypRecord()

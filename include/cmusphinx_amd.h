@@ -786,6 +786,17 @@ int32_t s3a_queue_schedule(int32_t n_lanes, int32_t boundary, int32_t n_utt, con
  * ([0] frame record + exits, [1] P1, [2] P2 trigram scores, [3] P3 hash insert, [4] P4 entry places, [5] P5 staging,
  * [6] pruning, [7] table + LM contexts, [8] word transitions) */
 int32_t s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16);
+/* diagnostics: the same for the steps of a frame inside ku_frames (s3a_uttdec_opts_t.persist), of the utterance the lane decoded last:
+ * [0] lextree_enter's entry test (lextree.c:1093-1236), [1] its ranking, [2] the entries applied + the senone marks
+ * (srch_time_switch_tree.c:1101-1153), [3] composite senones' members, [4] the CI gate (approx_cont_mgau.c:188-284), [5] composite
+ * maxima, [6] lextree_hmm_eval, [7] stamps of the propagating HMMs / histogram (lextree.c:1314-1358), [8] -ptranskip's weak HMMs,
+ * [9] lextree_hmm_propagate_non_leaves, [10] the ordered scan, [11] emission + word level ([15]: the emission alone when the lane is
+ * one workgroup), [12] ticks inside the launches, [13] frames, [14] launches.  *cluster = workgroups per lane of the last launch
+ * (0: the engine runs the frame as separate launches). */
+int32_t s3a_uttdec_frame_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16, int32_t *cluster);
+/* diagnostics: where and when the lane's workgroup ran the launch that began at engine frame 512: clock at entry and exit (100 MHz),
+ * the hardware's HW_ID and XCC_ID registers (tools/kf_phases.py --placement) */
+int32_t s3a_uttdec_frame_dbg(s3a_uttdec_t *ud, int32_t lane, long long *out4);
 int32_t s3a_uttdec_n_lanes(const s3a_uttdec_t *ud);
 /* diagnostics: lextree_utt_end on every lane, then how many node records of `lane` are NOT an inactive HMM
  * (out[0..5]: state scores 0/1/2, exit score, best score, frame tag; out[6] the first such node, INT_MAX: none;
