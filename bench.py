@@ -402,6 +402,37 @@ def ps_fwdtree_leg(t, lanes, n_cpu=4):
     return out
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: N ranks of this very command, one per GPU, the way the reference shards a
+    control file over processes (-ctloffset / -ctlcount, main_decode.c:164-169).  The children find RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT in their environment exactly as under torch.distributed.run; rank 0's stdout (the ONE JSON line) is this
+    process's.  S3A_BENCH_ONE_GPU=1: every rank on GPU 0 (the rehearsal on a one-GPU box)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while any(p_.poll() is None for p_ in procs):
+            time.sleep(0.2)
+            bad = [p_.returncode for p_ in procs if p_.poll() not in (None, 0)]
+            if bad:                 # (a rank that failed must not leave the others waiting at a barrier for ever)
+                rc = bad[0]
+                break
+        rc = rc or next((p_.returncode for p_ in procs if p_.returncode), 0)
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -434,6 +465,10 @@ def main():
     args = ap.parse_args()
     if args.plain:
         args.no_cpu = args.no_scoring = args.no_ps = args.no_wide_beam = True
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: start as many ranks as --gpus says")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -77,7 +77,9 @@ frame_thresholds(const int32_t *best, const int32_t *nact, int32_t T, const Fram
 /* ------------------------------------------------------------------ */
 /* one HMM: node v of the active list, evaluated against the frame's senone scores (raw: the scorer's row; norm: the frame's
  * normaliser); returns the HMM's best score, w = its word id (< 0: not a word-final node) and out = its exit score */
-template <int NE>
+/* (TAG: the record's frame tag is written along, as if the HMM survived the frame -- ku_frames: its propagation pass then only has to
+ * touch the records of the HMMs it clears or enters, not of every survivor) */
+template <int NE, bool TAG = false>
 __device__ __forceinline__ int32_t
 d_dec_hmm_eval_node(int32_t v, int32_t N, const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid,
                     const int32_t *__restrict__ wid, const uint8_t *__restrict__ comp,
@@ -160,6 +162,7 @@ d_dec_hmm_eval_node(int32_t v, int32_t N, const int32_t *__restrict__ ssid, cons
     outs[NSV(v)] = r.out;
     outh[NSV(v)] = r.outh;
     bests[NSV(v)] = k;
+    if (TAG) sc[NSV(v) + NS_FRAME(NE)] = cf + 1;
     out = r.out;
     /* this node is active in frame cf: stamp the parent sets its children belong to (k_dec_resolve
      * skips every node whose parent set carries no stamp of this frame).  (psof_off == NULL: the caller stamps
@@ -617,11 +620,13 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
               const int32_t *__restrict__ rootnodes, int32_t n_rootnodes,
               const int32_t *__restrict__ propf, int32_t *posout,
         const int32_t v, const bool is_active, const bool has_par, const int32_t j_known = -1, const int32_t b_known = -1,
-        const HeurArgs hx = HeurArgs{ NULL, NULL, NULL })
+        const HeurArgs hx = HeurArgs{ NULL, NULL, NULL }, const int32_t *thp = NULL)
 {
+    /* (thp: the frame's {HMM threshold, phone threshold} when the caller has worked them out once -- ku_frames) */
     const int32_t nf = cf + 1;
     int32_t th, pth;
-    {
+    if (thp) { th = thp[0]; pth = thp[1]; }
+    else {
         int32_t bh, bw, n, wth;
         (void)frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
     }
@@ -833,7 +838,7 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
               const int32_t *__restrict__ propf, int32_t *posout,
               const int32_t *__restrict__ plist, int32_t n_plist, const int32_t *__restrict__ psmem_off,
               const int32_t *__restrict__ psmem, int32_t W, int32_t NW, const HeurArgs hx = HeurArgs{ NULL, NULL, NULL },
-              int32_t *WS = NULL)
+              int32_t *WS = NULL, const int32_t *thp = NULL)
 {
     const int32_t lane = threadIdx.x & 63;
     /* the qualifying parents of a several-parent set, loaded once for all of its members */
@@ -843,7 +848,8 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
 #define RC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   \
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
     int32_t th, pth;
-    {
+    if (thp) { th = thp[0]; pth = thp[1]; }
+    else {
         int32_t bh, bw, n, wth;
         (void)frame_thresholds(best, nact, T, bm, hbin, bh, bw, n, th, pth, wth);
     }
@@ -909,7 +915,7 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
             if (posf[x] == cf) continue;                                    /* on the list: resolved by list position */
             d_dec_resolve_node<PS, HEUR>(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh,
                                          bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf,
-                                         posout, x, false, true, -1, -1, hx);
+                                         posout, x, false, true, -1, -1, hx, thp);
         }
     }
 #undef RC_WAVE_SYNC
@@ -1492,15 +1498,48 @@ d_comsen_wave(int32_t n_cs, const int32_t *__restrict__ cs_need, int32_t stamp, 
     }
 }
 
+/* the same for a LIST of wanted composite senones (ku_frames): 16-lane group `grp` of `n_grp` takes every n_grp-th entry */
+template <bool MAXOP>
+__device__ __forceinline__ void
+d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
+              uint8_t *sen_active, const int32_t *__restrict__ raw, int32_t *cs_val, int32_t grp, int32_t n_grp)
+{
+    const int32_t l16 = threadIdx.x & 15;
+    for (int32_t j0 = 0; j0 < n_w; j0 += n_grp) {           /* (trip count uniform over the wave: the shuffles below see all lanes) */
+        const int32_t j = j0 + grp;
+        const bool on = j < n_w;
+        const int32_t cs = on ? wl[j] : 0;
+        int32_t mx = INT_MIN;
+        if (on)
+            for (int32_t q = cs_off[cs] + l16, hi = cs_off[cs + 1]; q < hi; q += 16) {
+                const int32_t id = cs_list[q];
+                if (MAXOP) mx = max(mx, raw[id]); else sen_active[id] = 1;
+            }
+        if (MAXOP) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+            if (on && l16 == 0) cs_val[cs] = mx;
+        }
+    }
+}
+
 /* senones of one node (srch_TST_select_active_gmm's per-node step) */
 __device__ __forceinline__ void
 mark_node_senones(int32_t v, const int32_t *__restrict__ ssid, const uint8_t *__restrict__ comp,
                   const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
                   const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list, uint8_t *sen_active,
-                  int32_t *cs_need = NULL, int32_t stamp = 0, int32_t ne = 3)
+                  int32_t *cs_need = NULL, int32_t stamp = 0, int32_t ne = 3, int32_t *cs_wl = NULL, int32_t *cs_wn = NULL)
 {
     const int32_t ss = ssid[v];
-    if (comp[v] && cs_need) {
+    if (comp[v] && cs_need && cs_wl) {
+        /* ... and LISTED once per frame by whoever stamps it first (ku_frames: the list is what the member marks and the maxima walk,
+         * instead of a sweep over all composite senones for the few that are wanted) */
+        for (int st = 0; st < ne; st++) {
+            const int32_t cs = comsseq[ss * ne + st];
+            if (atomicExch(&cs_need[cs], stamp) != stamp) cs_wl[atomicAdd(cs_wn, 1)] = cs;
+        }
+    }
+    else if (comp[v] && cs_need) {
         /* the whole-utterance engine: a composite senone is WANTED (stamp); its members are marked once per frame by
          * d_comsen_mark however many HMMs share it */
         if (ne == 3) {
@@ -1636,7 +1675,8 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
                   const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
                   const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
                   uint8_t *sen_active,
-        const int32_t BX, const int32_t BY, int32_t *cs_need = NULL, int32_t thresh = INT_MIN, int32_t TX = -1)
+        const int32_t BX, const int32_t BY, int32_t *cs_need = NULL, int32_t thresh = INT_MIN, int32_t TX = -1,
+        int32_t *cs_wl = NULL, int32_t *cs_wn = NULL)
 {
     /* (TX: the thread's place in its M3BLOCK-wide virtual workgroup when that is not the real one: ku_frames) */
     const int32_t tx = TX >= 0 ? TX : (int32_t)threadIdx.x;
@@ -1660,7 +1700,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
             int32_t k = n0[t] + (fl >> 1);
             for (int32_t cc = c_lo; cc < c; cc++) k += ctot[cc];
             nxt[node_base[t] + k] = v; pos[v] = k; posf[v] = nf;
-            mark_node_senones(v, ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf, (int32_t)(hist - sc));
+            mark_node_senones(v, ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf, (int32_t)(hist - sc), cs_wl, cs_wn);
         }
         const unsigned long long k = S3A_ALD(&key[v]);                  /* (d_dec_enter1's atomicMax / atomicMin) */
         if (k == 0ull) return;
@@ -1672,7 +1712,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
     const int32_t bb = BX - n_ent_blocks;
     const int32_t t = bb / blocks_per_tree, i = (bb % blocks_per_tree) * M3BLOCK + tx;
     if (t >= T || i >= n0[t]) return;
-    mark_node_senones(nxt[node_base[t] + i], ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf, (int32_t)(hist - sc));
+    mark_node_senones(nxt[node_base[t] + i], ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf, (int32_t)(hist - sc), cs_wl, cs_wn);
 }
 
 

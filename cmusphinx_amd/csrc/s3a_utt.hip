@@ -49,6 +49,9 @@ struct ULane {
     uint8_t *sen_act;
     int32_t *scr, *misc, *bstidx, *bstscr, *updatetime, *gpart;
     int32_t *cs_need, *cs_val;  /* [n_cs] composite senones: wanted in frame (stamp) | score of the frame */
+    int32_t *cs_wl, *cs_wn;     /* [n_cs + 1], [1] ku_frames: the composite senones wanted in the frame, each once, any order | their number */
+    int32_t *posbest;           /* [N] ku_frames: by list position, the HMM's best score of the frame (as poswid / posout) */
+    int32_t *ent;               /* [2 ent_cap] ku_frames: lextree_enter's scratch (the entries that pass the threshold test) */
     uint8_t *pstamp8;           /* [n_pset] the parent sets' stamps, the frame number's low 8 bits (a quarter of the
                                  * sweep's gathers' footprint; a stale match costs a walk that finds nothing) */
     int32_t *dynbeam;           /* [1] the frame's CI beam when -maxcdsenpf is in force (ku_dyn_ci_beam) */
@@ -185,7 +188,7 @@ d_lane_begin(const ULane &L, const UShared &S, const UBegin &B, int32_t z, const
     for (int32_t i = vt; i < S.N; i += vstride) { L.posf[i] = INT_MIN; L.propf[i] = INT_MIN; L.claim[i] = INT_MIN; }
     for (int32_t i = vt; i < B.n_pset; i += vstride) L.pstamp[i] = INT_MIN;
     for (int32_t i = vt; i < S.n_pset_bytes; i += vstride) L.pstamp8[i] = 0xff;
-    if (vt == 0) { L.pcnt[0] = 0; L.pcnt[1] = 0; }
+    if (vt == 0) { L.pcnt[0] = 0; L.pcnt[1] = 0; L.cs_wn[0] = 0; }
     for (int32_t i = vt; i < S.n_sen; i += vstride) {
         L.bstidx[i] = S3A_NO_BSTIDX; L.bstscr[i] = S3A_LOGPROB_ZERO; L.updatetime[i] = S3A_NOT_UPDATED; L.sen_act[i] = 0;
     }
@@ -1516,20 +1519,28 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_NT WL_THREADS
 #define KF_WAVES (KF_NT / 64)
 #define KF_SPIN_MAX (1 << 21)
+#define KF_MAXC 32
+#define KF_MAXSEG (KF_MAXC * KF_WAVES)
+#define KF_SETS 1024            /* listed parent sets a workgroup takes per pass of the propagation step */
 static_assert(KF_NT == 512, "ku_frames: the word level's workgroup is the frame's workgroup");
 enum { KF_WINDOW, KF_STATIC, KF_QUEUE };
 
 union KfPool {                  /* phases that never overlap share this LDS */
-    struct { int32_t off[WL_MAXCALL], root[WL_MAXCALL], in[WL_MAXCALL]; } e1;
+    struct { int32_t off[WL_MAXCALL], root[WL_MAXCALL], in[WL_MAXCALL], hist[WL_MAXCALL]; } e1;
     int32_t bin[NBIN];
     HistSortWs<KF_NT> hs;
-    int32_t rc[KF_WAVES][5 * 64];
+    struct {                    /* the propagation pass: the big sets' per-wave parent tables; the listed sets of a pass */
+        int32_t rc[KF_WAVES][5 * 64];
+        int32_t mlo[KF_SETS], pre[KF_SETS + 1], big[KF_SETS], nbig, m_all;
+    } rs;
     struct { int32_t hdr[6 * WL_MAXT + 16], ex[3 * WL_LDS_EX]; } wl;
 };
 
 struct KfSh {                   /* the workgroup's LDS outside the word level's own arrays */
     KfPool pool;
     int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
+    int32_t seg[KF_MAXSEG + 1], ws[KF_WAVES + 1], gq[4];    /* lextree_enter: the waves' segments of passing entries, scan scratch */
+    int32_t thr[4];             /* the frame's thresholds: HMM, phone, word (final once the histogram beam is known) */
 };
 
 struct KfBar { int32_t *cnt; int32_t C, target; int32_t *dead; };
@@ -1598,44 +1609,131 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     const int32_t n_ent = ctx->n_ent, n_calls_all = ctx->n_calls, thresh = ctx->thresh;
     if (r == 0 && tid == 0) { t_prev = (long long)wall_clock64(); ctx->kacc[13]++; }
 
-    /* ---- lextree_enter, step 1: the entry test (ku_enter1) ---- */
+    /* ---- lextree_enter (lextree.c:1093-1236; ku_enter1 / 2 / 3 of the launch path): of the frame's ~60 k (call, root) entries a few
+     * hundred pass the threshold test, so ONE sweep tests them all (a coalesced load each) and keeps the ones that pass, in entry
+     * order -- every wave compacts its own stretch --; ranking and applying then only see those.  Key / first: as d_dec_enter1. ---- */
     if (n_ent > 0) {
-        const int32_t n_calls = min(n_calls_all, WL_MAXCALL);
-        if (tid < n_calls) { sh.pool.e1.in[tid] = ctx->calls[4 * tid]; sh.pool.e1.root[tid] = ctx->calls[4 * tid + 2]; sh.pool.e1.off[tid] = ctx->calls[4 * tid + 3]; }
-        __syncthreads();
-        for (int32_t e = gtid; e < n_ent; e += gstride) {
-            int32_t lo = 0, hi = n_calls - 1;
-            while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.pool.e1.off[mid] <= e) lo = mid; else hi = mid - 1; }
-            const int32_t c = lo, idx = sh.pool.e1.root[c] + (e - sh.pool.e1.off[c]);
-            const int32_t scr = add32(sh.pool.e1.in[c], S.rootprob[idx]);
-            if (scr < thresh) continue;
-            const int32_t v = S.rootlist[idx];
-            if (!(L.sc[NSV(v)] < scr)) continue;
-            atomicMax(&L.key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
-            atomicMin(&L.first[v], c);
+        const int32_t n_calls = min(n_calls_all, WL_MAXCALL), nf = f;
+        if (tid < n_calls) {
+            sh.pool.e1.in[tid] = ctx->calls[4 * tid]; sh.pool.e1.hist[tid] = ctx->calls[4 * tid + 1];
+            sh.pool.e1.root[tid] = ctx->calls[4 * tid + 2]; sh.pool.e1.off[tid] = ctx->calls[4 * tid + 3];
         }
+        if (r == 0 && tid < T) L.n0[tid] = L.nact[cur][tid];            /* the list lengths before the entries */
+        __syncthreads();
+        const int32_t R = (((n_ent + gwaves - 1) / gwaves) + 63) & ~63, e_lo = gwave * R, e_hi = min(e_lo + R, n_ent);
+        int32_t cntw = 0, c = 0;
+        if (e_lo < e_hi) {          /* the call of the stretch's first entry; the lanes then only step forward */
+            int32_t lo = 0, hi = n_calls - 1;
+            while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.pool.e1.off[mid] <= e_lo) lo = mid; else hi = mid - 1; }
+            c = lo;
+        }
+        for (int32_t e0 = e_lo; e0 < e_hi; e0 += 64) {
+            const int32_t e = e0 + lane;
+            /* an entry counts when it passes the threshold AND improves on its root's entry score: only such an entry can list the
+             * root, win it, or tag it (the others pass through lextree_enter without a trace) */
+            bool keep = false;
+            int32_t scr = 0, v = 0;
+            if (e < e_hi) {
+                while (c + 1 < n_calls && sh.pool.e1.off[c + 1] <= e) c++;
+                const int32_t idx = sh.pool.e1.root[c] + (e - sh.pool.e1.off[c]);
+                scr = add32(sh.pool.e1.in[c], S.rootprob[idx]);
+                if (scr >= thresh) { v = S.rootlist[idx]; keep = L.sc[NSV(v)] < scr; }
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                /* (what the later steps need of the entry, side by side: its root, its score, its call) */
+                const int32_t p_ = e_lo + cntw + __popcll(m & ((1ull << lane) - 1ull));
+                L.eflag[p_] = v; L.ent[2 * p_] = scr; L.ent[2 * p_ + 1] = c;
+                atomicMax(&L.key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
+                atomicMin(&L.first[v], c);
+            }
+            cntw += __popcll(m);
+        }
+        if (lane == 0) L.ctot[gwave] = cntw;
         kf_barrier(B);
         KF_STAMP(0);
-        /* ---- step 2: which roots a call lists, ranked in root-list order (ku_enter2) ---- */
-        const Entries ent = { ctx->calls, S.rootlist, n_calls_all, S.rootprob };
-        for (int32_t c = r; c < n_calls_all; c += C) {
-            d_dec_enter2_t<KF_NT>(ent, n_ent, ctx->calls, S.prob, L.sc, L.frame, L.first, thresh, f, T, L.nact[cur], L.eflag, L.ctot, L.n0, c, 0);
+        /* the entries that passed, by the lane's first workgroup: which of them list their root (the first qualifying call of a node
+         * that is not listed yet), ranked in entry order by a scan; then the listed roots, the winning entries, the frame tags */
+        if (r == 0) {
+            {
+                const int32_t x = tid < gwaves ? L.ctot[tid] : 0;
+                int32_t incl = x;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+                if (lane == 63) sh.ws[wave] = incl;
+                __syncthreads();
+                int32_t add = 0;
+                for (int32_t w = 0; w < wave; w++) add += sh.ws[w];
+                if (tid < gwaves) sh.seg[tid] = add + incl - x;
+                if (tid == gwaves - 1) sh.seg[gwaves] = add + incl;
+                if (tid < 4) sh.gq[tid] = 0;
+                __syncthreads();
+            }
+            const int32_t P = sh.seg[gwaves], c1 = ctx->n_groups > 1 ? ctx->groups[4 + 3] : INT_MAX;      /* (group 1's first call) */
+            int32_t carry = 0;
+            for (int32_t i0 = 0; i0 < P; i0 += KF_NT) {
+                const int32_t i = i0 + tid;
+                int32_t q = 0, c = 0, p_ = 0;
+                if (i < P) {
+                    int32_t lo = 0, hi = gwaves - 1;
+                    while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
+                    p_ = lo * R + (i - sh.seg[lo]);
+                    const int32_t v = L.eflag[p_];
+                    c = L.ent[2 * p_ + 1];
+                    q = (S3A_ALD(&L.first[v]) == c && L.frame[NSV(v)] != nf) ? 1 : 0;       /* (sc < scr: true of every kept entry) */
+                }
+                const unsigned long long m = __ballot(q), m0 = __ballot(q && c < c1);
+                if (lane == 0) { sh.ws[wave] = __popcll(m); if (m0) atomicAdd(&sh.gq[0], __popcll(m0)); }
+                __syncthreads();
+                int32_t before = carry;
+                for (int32_t w = 0; w < wave; w++) before += sh.ws[w];
+                if (i < P) L.ent[2 * p_ + 1] = ((before + __popcll(m & ((1ull << lane) - 1ull))) << 8) | (q << 7) | c;
+                for (int32_t w = 0; w < KF_WAVES; w++) carry += sh.ws[w];
+                __syncthreads();
+            }
+            /* the groups' new list lengths (group 0 = the unigram tree's calls, group 1 = the filler tree's: consecutive entries) */
+            if (tid == 0) { sh.gq[1] = carry - sh.gq[0]; }
             __syncthreads();
+            if (tid < ctx->n_groups) { const int32_t t = ctx->groups[4 * tid]; L.nact[cur][t] = L.n0[t] + sh.gq[tid]; }
+            for (int32_t i = tid; i < P; i += KF_NT) {
+                int32_t lo = 0, hi = gwaves - 1;
+                while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
+                const int32_t p_ = lo * R + (i - sh.seg[lo]);
+                const int32_t v = L.eflag[p_], scr = L.ent[2 * p_], fl = L.ent[2 * p_ + 1], c = fl & 127;
+                const int32_t g = c >= c1 ? 1 : 0, t = ctx->groups[4 * g];
+                if (fl & 128) {
+                    const int32_t k = L.n0[t] + (fl >> 8) - (g ? sh.gq[0] : 0);
+                    L.act[cur][S.node_base[t] + k] = v; L.pos[v] = k; L.posf[v] = nf;
+                    mark_node_senones(v, S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, L.cs_need, nf, NE, L.cs_wl, L.cs_wn);
+                }
+                const unsigned long long key = S3A_ALD(&L.key[v]);
+                const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(key & 0xffffffffu);
+                (void)scr;
+                if (c == win_c) { L.sc[NSV(v)] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); L.hist[NSV(v)] = sh.pool.e1.hist[c]; }
+                if (c == S3A_ALD(&L.first[v])) L.frame[NSV(v)] = nf;
+            }
+            /* lextree_enter's scratch of the roots it touched is clean again (the launch path sweeps all root nodes in its resolve) */
+            __syncthreads();
+            for (int32_t i = tid; i < P; i += KF_NT) {
+                int32_t lo = 0, hi = gwaves - 1;
+                while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
+                const int32_t v = L.eflag[lo * R + (i - sh.seg[lo])];
+                L.key[v] = 0ull; L.first[v] = INT_MAX;
+            }
         }
-        kf_barrier(B);
         KF_STAMP(1);
     }
-    /* ---- step 3: the listed roots, the winning entries, the senone marks of the frame's list (ku_enter3_mark) ---- */
+    /* ---- the senone marks of the nodes that were on the frame's list before the entries (srch_TST_select_active_gmm) ---- */
     {
         const int32_t *n0 = n_ent > 0 ? L.n0 : L.nact[cur];
-        int32_t rows = 0;
-        for (int32_t t = 0; t < T; t++) rows = max(rows, n0[t]);
-        const int32_t neb = (n_ent + M3BLOCK - 1) / M3BLOCK, bpt = (rows + M3BLOCK - 1) / M3BLOCK;
-        const Entries ent = { ctx->calls, S.rootlist, n_calls_all, S.rootprob };
-        for (int32_t vb = gwave; vb < neb + bpt * T; vb += gwaves)
-            d_dec_enter3_mark(neb, ent, n_ent, ctx->calls, ctx->groups, ctx->n_groups, f, L.key, L.first, L.eflag, L.ctot, n0, L.sc,
-                              L.hist, L.frame, T, bpt, S.node_base, L.act[cur], L.nact[cur], L.pos, L.posf, S.ssid, S.comp, S.sseq,
-                              S.comsseq, S.cs_off, S.cs_list, L.sen_act, vb, 0, L.cs_need, thresh, lane);
+        int32_t a = 0;
+        for (int32_t t = 0; t < T; t++) {
+            const int32_t na = n0[t], b = S.node_base[t];
+            /* (the trees laid end to end: thread gtid's positions are gtid, gtid + gstride, ... of the concatenation) */
+            for (int32_t i = gtid - a % gstride + (gtid < a % gstride ? gstride : 0); i < na; i += gstride)
+                mark_node_senones(L.act[cur][b + i], S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, L.cs_need, f, NE, L.cs_wl, L.cs_wn);
+            a += na;
+        }
     }
     kf_barrier(B);
     KF_STAMP(2);
@@ -1645,9 +1743,9 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         for (int32_t t = 0; t < T; t++) { sh.pre[t] = a; a += nact_cur[t]; }
         sh.pre[T] = a;
     }
-    /* ---- the composite senones' members join the mask (ku_comsen_mark) ---- */
-    for (int32_t w = gwave; w * 64 < S.n_cs; w += gwaves)
-        d_comsen_wave<false>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, L.sen_act, (const int32_t *)NULL, (int32_t *)NULL, w * 64);
+    /* ---- the members of the composite senones wanted in the frame join the mask (ku_comsen_mark): from the frame's list ---- */
+    const int32_t n_csw = S3A_ALD(&L.cs_wn[0]);
+    d_comsen_list<false>(L.cs_wl, n_csw, S.cs_off, S.cs_list, L.sen_act, (const int32_t *)NULL, (int32_t *)NULL, gtid >> 4, gstride >> 4);
     kf_barrier(B);
     KF_STAMP(3);
     const int32_t n_tot = sh.pre[T];
@@ -1662,8 +1760,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     kf_barrier(B);
     KF_STAMP(4);
     /* ---- the scores of the composite senones wanted in this frame (ku_comsen_max) ---- */
-    for (int32_t w = gwave; w * 64 < S.n_cs; w += gwaves)
-        d_comsen_wave<true>(S.n_cs, L.cs_need, f, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, w * 64);
+    d_comsen_list<true>(L.cs_wl, n_csw, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, gtid >> 4, gstride >> 4);
     kf_barrier(B);
     KF_STAMP(5);
     /* ---- lextree_hmm_eval (ku_hmm_eval): a thread per list position of the trees laid end to end; the per-tree maxima are
@@ -1675,6 +1772,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         for (int o = 32; o > 0; o >>= 1) gb = max(gb, __shfl_xor(gb, o, 64));
         if (lane == 0) sh.red[wave] = gb;
         if (tid < 2 * T) sh.acc[tid] = INT_MIN;
+        if (r == 0 && tid == 0) L.cs_wn[0] = 0;                 /* (the frame's list of composite senones is consumed) */
         __syncthreads();
         int32_t norm = max(L.misc[0], L.misc[5]);               /* the frame's normaliser */
         for (int w = 0; w < KF_WAVES; w++) norm = max(norm, sh.red[w]);
@@ -1686,11 +1784,12 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 int32_t i, out;
                 kf_locate(sh.pre, T, g, t, i);
                 const int32_t b = S.node_base[t], v = act[b + i];
-                k = d_dec_hmm_eval_node<NE>(v, S.N, S.ssid, S.tmatid, S.wid, S.comp, S.tp, S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt,
-                                            row, norm, L.sc, L.hist, L.outs, L.outh, L.bests, f, (const int32_t *)NULL, S.psof, L.pstamp,
-                                            L.cs_val, S.node4, w, out);
+                k = d_dec_hmm_eval_node<NE, true>(v, S.N, S.ssid, S.tmatid, S.wid, S.comp, S.tp, S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt,
+                                                  row, norm, L.sc, L.hist, L.outs, L.outh, L.bests, f, (const int32_t *)NULL, S.psof, L.pstamp,
+                                                  L.cs_val, S.node4, w, out);
                 L.poswid[b + i] = w;
                 L.posout[b + i] = out;
+                L.posbest[b + i] = k;
             }
             /* a wave's 64 positions belong to one tree, or to two or three at the seams */
             unsigned long long todo = __ballot(t >= 0);
@@ -1735,9 +1834,22 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             }
     }
     else {
+        /* (d_stamp_and_list with the exit scores by list position: coalesced, and the few HMMs that propagate then chase their node) */
         int32_t th, pth;
         frame_thresholds_hb(sh.best, T, bm, 1, th, pth);
-        for (int32_t t = 0; t < T; t++) d_stamp_and_list(L, S, cur, t, nact_cur[t], pth, f, r * KF_NT, gstride, 1);
+        int32_t *pc = &L.pcnt[f & 1];
+        for (int32_t g = gtid; g < n_tot; g += gstride) {
+            int32_t t, i;
+            kf_locate(sh.pre, T, g, t, i);
+            const int32_t b = S.node_base[t];
+            if (L.posout[b + i] < pth) continue;
+            const int32_t u = L.act[cur][b + i];
+            for (int32_t q = S.psof_off[u], q_hi = S.psof_off[u + 1]; q < q_hi; q++) {
+                const int32_t ps = S.psof[q];
+                L.pstamp8[ps] = ps_val<uint8_t>(f);
+                if (atomicExch(&L.claim[ps], f) != f) L.plist[atomicAdd(pc, 1)] = ps;
+            }
+        }
     }
     kf_barrier(B);
     KF_STAMP(7);
@@ -1751,34 +1863,102 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     }
     /* ---- lextree_hmm_propagate_non_leaves from the node's point of view (ku_resolve_plist) ---- */
     {
+        if (tid == 0) {
+            int32_t bh, bw, n, th, pth, wth;
+            (void)frame_thresholds(sh.best, nact_cur, T, bm, L.hbin, bh, bw, n, th, pth, wth);
+            sh.thr[0] = th; sh.thr[1] = pth; sh.thr[2] = wth;
+        }
+        __syncthreads();
         if (r == 0 && hist_frame)
             for (int32_t i = tid; i < NBIN; i += KF_NT) L.hbin[i] = 0;         /* (the bins were consumed by the sort; hbin[NBIN] stays) */
-        for (int32_t v = gtid; v < S.n_rootnodes; v += gstride) {              /* lextree_enter only ever touches root nodes */
-            const int32_t rn = S.rootnodes[v];
-            L.key[rn] = 0ull;
-            L.first[rn] = INT_MAX;
-        }
         const int32_t *act = L.act[cur];
-        /* the active HMMs by list position */
-        for (int32_t g = gtid; g < n_tot; g += gstride) {
-            int32_t t, i;
-            kf_locate(sh.pre, T, g, t, i);
-            const int32_t b = S.node_base[t], v = act[b + i], q = S.ps[v];
-            const bool has_par = q >= 0 && L.pstamp8[q] == ps_val<uint8_t>(f);
-            /* (the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
-            if (has_par && S3A_ALD(&L.claim[q]) == f) {
-                const int32_t np = S.par_off[v + 1] - S.par_off[v];
-                if (np >= SET_NP_MIN && np <= 64) continue;
+        /* the active HMMs by list position, two per thread and turn (their chains of gathers run side by side) */
+        for (int32_t g0 = r * 2 * KF_NT; g0 < n_tot; g0 += 2 * gstride) {
+            int32_t gg[2] = { g0 + tid, g0 + KF_NT + tid }, tt[2], ii[2], bb[2], vv[2], qq[2], pbv[2];
+            uint8_t stv[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                tt[u] = 0; ii[u] = 0; bb[u] = 0; vv[u] = -1;
+                if (gg[u] < n_tot) { kf_locate(sh.pre, T, gg[u], tt[u], ii[u]); bb[u] = S.node_base[tt[u]]; vv[u] = act[bb[u] + ii[u]]; }
             }
-            d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                               L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                               S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b);
+#pragma unroll
+            for (int u = 0; u < 2; u++) { qq[u] = vv[u] >= 0 ? S.ps[vv[u]] : -1; pbv[u] = vv[u] >= 0 ? L.posbest[bb[u] + ii[u]] : 0; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) stv[u] = qq[u] >= 0 ? L.pstamp8[qq[u]] : (uint8_t)(ps_val<uint8_t>(f) + 1);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (vv[u] < 0) continue;
+                const int32_t v = vv[u], q = qq[u], i = ii[u], b = bb[u];
+                const bool has_par = q >= 0 && stv[u] == ps_val<uint8_t>(f);
+                /* (the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
+                if (has_par && S3A_ALD(&L.claim[q]) == f) {
+                    const int32_t np = S.par_off[v + 1] - S.par_off[v];
+                    if (np >= SET_NP_MIN && np <= 64) continue;
+                }
+                /* the usual active HMM -- no parent can enter it, and it survives: it joins the next list at its own turn; its record
+                 * carries the frame tag since the evaluation (a histogram frame has reordered the positions: through the node) */
+                if (!has_par && !hist_frame && pbv[u] >= sh.thr[0]) { L.selfemit[b + i] = 1; atomicAdd(&L.cnt[b + i], 1); continue; }
+                d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                   L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                   S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b,
+                                                   HeurArgs{ NULL, NULL, NULL }, sh.thr);
+            }
         }
-        /* the members of the listed parent sets: a wave per set */
-        d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                               L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                               S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, L.plist, S3A_ALD(&L.pcnt[f & 1]),
-                                               S.psmem_off, S.psmem, gwave, gwaves, HeurArgs{ NULL, NULL, NULL }, sh.pool.rc[wave]);
+        if (C == 1) { __syncthreads(); if (tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kdbg[0] += t_ - t_prev; ctx->kdbg[1] += S3A_ALD(&L.pcnt[f & 1]); } }
+        /* the frame's listed parent sets (d_stamp_and_list): this workgroup's share, up to KF_SETS per pass.  Their headers are
+         * fetched for all sets at once; the members of the one-parent sets (an interior node's children: most sets, a handful of
+         * members each) become ONE flat run of work items, a thread each; a several-parent set (the ~340 first-level nodes under the
+         * ~46 left-context variants of a root) takes a wave that finds the propagating variants once (d_dec_resolve_children) */
+        {
+            auto &rs = sh.pool.rs;
+            const int32_t n_pl = S3A_ALD(&L.pcnt[f & 1]), per = (n_pl + C - 1) / C, k_lo = min(n_pl, r * per), k_hi = min(n_pl, k_lo + per);
+            for (int32_t k0 = k_lo; k0 < k_hi; k0 += KF_SETS) {
+                const int32_t nk = min(KF_SETS, k_hi - k0);
+                if (tid == 0) rs.nbig = 0;
+                __syncthreads();
+                for (int32_t j = tid; j < KF_SETS; j += KF_NT) {
+                    int32_t cm = 0, m_lo = 0;
+                    if (j < nk) {
+                        const int32_t q = L.plist[k0 + j];
+                        m_lo = S.psmem_off[q];
+                        const int32_t m_hi = S.psmem_off[q + 1], x0 = S.psmem[m_lo], np = S.par_off[x0 + 1] - S.par_off[x0];
+                        if (np >= SET_NP_MIN && np <= 64) rs.big[atomicAdd(&rs.nbig, 1)] = q;
+                        else cm = m_hi - m_lo;
+                    }
+                    rs.mlo[j] = m_lo; rs.pre[j] = cm;
+                }
+                __syncthreads();
+                {   /* exclusive sums of the sets' member counts: two sets per thread */
+                    const int32_t a0 = rs.pre[2 * tid], a1 = rs.pre[2 * tid + 1];
+                    int32_t incl = a0 + a1;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+                    if (lane == 63) sh.ws[wave] = incl;
+                    __syncthreads();
+                    int32_t add = 0;
+                    for (int32_t w = 0; w < wave; w++) add += sh.ws[w];
+                    rs.pre[2 * tid] = add + incl - a0 - a1; rs.pre[2 * tid + 1] = add + incl - a1;
+                    if (tid == KF_NT - 1) rs.m_all = add + incl;
+                    __syncthreads();
+                }
+                const int32_t M = rs.m_all;
+                for (int32_t m = tid; m < M; m += KF_NT) {
+                    int32_t lo = 0, hi = nk - 1;
+                    while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.pre[mid] <= m) lo = mid; else hi = mid - 1; }
+                    const int32_t x = S.psmem[rs.mlo[lo] + (m - rs.pre[lo])];
+                    if (L.posf[x] == f) continue;                               /* on the list: resolved by list position */
+                    d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                       L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                       S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, x, false, true, -1, -1,
+                                                       HeurArgs{ NULL, NULL, NULL }, sh.thr);
+                }
+                d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                       L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                       S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, rs.big, rs.nbig,
+                                                       S.psmem_off, S.psmem, wave, KF_WAVES, HeurArgs{ NULL, NULL, NULL }, rs.rc[wave], sh.thr);
+                __syncthreads();
+            }
+        }
     }
     kf_barrier(B);
     KF_STAMP(9);
@@ -2274,6 +2454,9 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.d.pack) (void)hipFree(hl.d.pack);
         if (hl.d.cs_need) (void)hipFree(hl.d.cs_need);
         if (hl.d.cs_val) (void)hipFree(hl.d.cs_val);
+        if (hl.d.cs_wl) (void)hipFree(hl.d.cs_wl);
+        if (hl.d.cs_wn) (void)hipFree(hl.d.cs_wn);
+        if (hl.d.posbest) (void)hipFree(hl.d.posbest);
         if (hl.d.dynbeam) (void)hipFree(hl.d.dynbeam);
         if (hl.d.pstamp8) (void)hipFree(hl.d.pstamp8);
         if (hl.d.plist) (void)hipFree(hl.d.plist);
@@ -2625,7 +2808,9 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         u.scan_flag = ls->d_scan_flag; u.scan_agg = ls->d_scan_agg; u.scan_pre = ls->d_scan_pre; u.key = ls->d_key;
         u.sen_act = hl.sc->act_d; u.scr = hl.sc->scr_d; u.misc = hl.sc->misc_d; u.bstidx = hl.sc->bstidx_d;
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
-        DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4); DM(u.dynbeam, 16); DM(u.pstamp8, (size_t)proto->n_pset + 64); S.n_pset_bytes = proto->n_pset + 64;
+        DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4); DM(u.dynbeam, 16);
+        DM(u.cs_wl, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_wn, 16); u.ent = ls->d_ent; DM(u.posbest, (size_t)(proto->N + 64) * 4);
+        if (hipMemset(u.cs_wn, 0, 16) != hipSuccess) goto fail; DM(u.pstamp8, (size_t)proto->n_pset + 64); S.n_pset_bytes = proto->n_pset + 64;
         DM(u.plist, (size_t)(proto->N + 64) * 4); DM(u.pcnt, 16); DM(u.claim, (size_t)(proto->N + 64) * 4);
         if (hipMemset(u.pcnt, 0, 16) != hipSuccess) goto fail;
         if (hipMemset(u.pstamp8, 0xff, (size_t)proto->n_pset + 64) != hipSuccess) goto fail;

@@ -97,11 +97,14 @@ def main():
             acc[k] = acc.get(k, 0.0) + v
         nf += f
         nl += l
+        dbg = decs[0].ud.frame_dbg(z)
+        for k in range(4):
+            acc["dbg%d" % k] = acc.get("dbg%d" % k, 0.0) + dbg[k]
     out = {"lanes": args.lanes, "engines": NE, "utts": len(nfr), "frames": total, "frames_per_s": round(total / best, 1), "s_per_step": round(best, 4),
            "device_ms": [round(m, 1) for m in ms], "window": decs[0].ud.window(), "cluster": C,
            "us_per_frame": {k: round(v / max(nf, 1), 2) for k, v in acc.items()}, "frames_sampled": nf, "launches_sampled": nl}
     if nf:
-        out["us_per_frame"]["sum_steps"] = round(sum(v for k, v in acc.items() if k not in ("in_launch", "emit_only")) / nf, 2)
+        out["us_per_frame"]["sum_steps"] = round(sum(v for k, v in acc.items() if k not in ("in_launch", "emit_only") and not k.startswith("dbg")) / nf, 2)
     print(json.dumps(out))
 
 
