@@ -81,20 +81,17 @@ frame_thresholds(const int32_t *best, const int32_t *nact, int32_t T, const Fram
  * touch the records of the HMMs it clears or enters, not of every survivor) */
 template <int NE, bool TAG = false>
 __device__ __forceinline__ int32_t
-d_dec_hmm_eval_node(int32_t v, int32_t N, const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid,
-                    const int32_t *__restrict__ wid, const uint8_t *__restrict__ comp,
+d_dec_hmm_eval_nd(int32_t v, const int4 nd, int32_t N,
                     const int32_t *__restrict__ tp_g, const int16_t *__restrict__ sseq,
                     const int16_t *__restrict__ comsseq, const int32_t *__restrict__ cs_off,
                     const int16_t *__restrict__ cs_list, const int32_t *__restrict__ cs_wt,
                     const int32_t *__restrict__ raw, int32_t norm,
                     int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests, int32_t cf,
                     const int32_t *__restrict__ psof_off, const int32_t *__restrict__ psof, int32_t *pstamp,
-                    const int32_t *__restrict__ cs_val, const int4 *__restrict__ node4, int32_t &w, int32_t &out)
+                    const int32_t *__restrict__ cs_val, int32_t &w, int32_t &out)
 {
-    /* the node's static words (senone-sequence id, transition matrix, word id, composite?): one 16-byte load when
-     * the caller keeps them packed (node4), else four arrays */
-    int4 nd;
-    if (node4) nd = node4[v]; else { nd.x = ssid[v]; nd.y = tmatid[v]; nd.z = wid[v]; nd.w = comp[v]; }
+    /* (nd: the node's static words -- senone-sequence id, transition matrix, word id, composite? -- loaded by the caller, who may
+     * have asked for them a turn ahead: ku_frames) */
     const int32_t ss = nd.x;
     HmmRegsT<int32_t> r;
     int32_t e[NE];
@@ -169,6 +166,25 @@ d_dec_hmm_eval_node(int32_t v, int32_t N, const int32_t *__restrict__ ssid, cons
      * after the thresholds are known, and only for the nodes that propagate: d_dec_stamp) */
     for (int32_t q = q_lo; q < q_hi; q++) pstamp[psof[q]] = cf;
     return k;
+}
+
+template <int NE, bool TAG = false>
+__device__ __forceinline__ int32_t
+d_dec_hmm_eval_node(int32_t v, int32_t N, const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid,
+                    const int32_t *__restrict__ wid, const uint8_t *__restrict__ comp,
+                    const int32_t *__restrict__ tp_g, const int16_t *__restrict__ sseq,
+                    const int16_t *__restrict__ comsseq, const int32_t *__restrict__ cs_off,
+                    const int16_t *__restrict__ cs_list, const int32_t *__restrict__ cs_wt,
+                    const int32_t *__restrict__ raw, int32_t norm,
+                    int32_t *sc, int32_t *hist, int32_t *outs, int32_t *outh, int32_t *bests, int32_t cf,
+                    const int32_t *__restrict__ psof_off, const int32_t *__restrict__ psof, int32_t *pstamp,
+                    const int32_t *__restrict__ cs_val, const int4 *__restrict__ node4, int32_t &w, int32_t &out)
+{
+    /* the node's static words: one 16-byte load when the caller keeps them packed (node4), else four arrays */
+    int4 nd;
+    if (node4) nd = node4[v]; else { nd.x = ssid[v]; nd.y = tmatid[v]; nd.z = wid[v]; nd.w = comp[v]; }
+    return d_dec_hmm_eval_nd<NE, TAG>(v, nd, N, tp_g, sseq, comsseq, cs_off, cs_list, cs_wt, raw, norm, sc, hist, outs, outh, bests, cf, psof_off, psof,
+                                     pstamp, cs_val, w, out);
 }
 
 template <int EB, int NE = 3>
@@ -1498,27 +1514,41 @@ d_comsen_wave(int32_t n_cs, const int32_t *__restrict__ cs_need, int32_t stamp, 
     }
 }
 
-/* the same for a LIST of wanted composite senones (ku_frames): 16-lane group `grp` of `n_grp` takes every n_grp-th entry */
+/* the same for a LIST of wanted composite senones (ku_frames): 16-lane group `grp` of `n_grp` takes every n_grp-th entry, two entries
+ * per turn (their chains list entry -> member range -> member ids -> scores run side by side) */
 template <bool MAXOP>
 __device__ __forceinline__ void
 d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
-              uint8_t *sen_active, const int32_t *__restrict__ raw, int32_t *cs_val, int32_t grp, int32_t n_grp)
+              uint8_t *sen_active, const int32_t *__restrict__ raw, int32_t *cs_val, int32_t grp, int32_t n_grp,
+              const int32_t *__restrict__ cs_wt = NULL)
 {
+    /* (cs_wt: the composite senone's weight is added to the maximum -- add32 wraps, so the evaluation's
+     * (score - normaliser) + weight comes out the same whichever is added first) */
     const int32_t l16 = threadIdx.x & 15;
-    for (int32_t j0 = 0; j0 < n_w; j0 += n_grp) {           /* (trip count uniform over the wave: the shuffles below see all lanes) */
-        const int32_t j = j0 + grp;
-        const bool on = j < n_w;
-        const int32_t cs = on ? wl[j] : 0;
-        int32_t mx = INT_MIN;
-        if (on)
-            for (int32_t q = cs_off[cs] + l16, hi = cs_off[cs + 1]; q < hi; q += 16) {
-                const int32_t id = cs_list[q];
-                if (MAXOP) mx = max(mx, raw[id]); else sen_active[id] = 1;
-            }
+    for (int32_t j0 = 0; j0 < n_w; j0 += 2 * n_grp) {       /* (trip count uniform over the wave: the shuffles below see all lanes) */
+        int32_t cs[2], lo[2], hi[2], mx[2];
+        bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int32_t j = j0 + u * n_grp + grp; on[u] = j < n_w; cs[u] = on[u] ? wl[j] : 0; }
+#pragma unroll
+        for (int u = 0; u < 2; u++) { lo[u] = on[u] ? cs_off[cs[u]] : 0; hi[u] = on[u] ? cs_off[cs[u] + 1] : 0; mx[u] = INT_MIN; }
+        for (int32_t q0 = 0; ; q0 += 16) {
+            int32_t id[2];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const int32_t q = lo[u] + q0 + l16; id[u] = q < hi[u] ? (int32_t)cs_list[q] : -1; any = any || lo[u] + q0 < hi[u]; }
+            if (!any) break;
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (id[u] >= 0) { if (MAXOP) mx[u] = max(mx[u], raw[id[u]]); else sen_active[id[u]] = 1; }
+        }
         if (MAXOP) {
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-            if (on && l16 == 0) cs_val[cs] = mx;
+            for (int u = 0; u < 2; u++) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) mx[u] = max(mx[u], __shfl_xor(mx[u], o, 64));
+                if (on[u] && l16 == 0) cs_val[cs[u]] = cs_wt ? add32(mx[u], cs_wt[cs[u]]) : mx[u];
+            }
         }
     }
 }

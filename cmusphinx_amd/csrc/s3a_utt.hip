@@ -80,6 +80,8 @@ struct UShared {
     const uint8_t *comp;
     const int16_t *sseq, *comsseq, *cs_list;
     const int4 *node4;          /* per node: {ssid, tmatid, wid, composite}: ku_hmm_eval's static words as one load */
+    const int32_t *nodesen;     /* per node, 2 (3 states) or 4 (5 states) words: its senone ids -- of a composite node its composite-senone ids --
+                                 * as 16-bit halves (ku_frames: one load instead of the chain node -> sequence id -> three 2-byte gathers) */
     const float4 *mean4, *prec4;
     const float *lrd;
     const int32_t *mixw;
@@ -1379,14 +1381,14 @@ struct UHypPar { int32_t finish_lwid, finishwid, silwid, wcap, wtotal; };     /*
 template <int NT>
 __device__ __forceinline__ void
 d_hyp(const ULane &L, const UCtx *ctx, const WLm &lm, const WDict &dict, const UHypPar &P, int32_t *__restrict__ hdr, int32_t *__restrict__ words_all,
-      int32_t *__restrict__ wcount)
+      int32_t *__restrict__ wcount, int32_t *s_ids /* [UH_IDS] of the workgroup's LDS */)
 {
     const WLane &w = L.w;
     const int32_t tid = threadIdx.x, nfr = ctx->nfr, n_entry = w.st[0], n_frm = w.st[1];
     __shared__ uint32_t s_scale;
     __shared__ int32_t s_woff;
     __shared__ unsigned long long s_best;
-    __shared__ int32_t s_f, s_n, s_ids[UH_IDS];
+    __shared__ int32_t s_f, s_n;
     if (tid == 0) { s_scale = 0u; s_best = 0ull; s_n = 0; }
     __syncthreads();
     uint32_t part = 0u;
@@ -1477,7 +1479,8 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 {
     /* (sub / slot: a refill event -- lane sub[x] has finished the utterance whose header goes to slot[x]; NULL: lane x, header x) */
     const ULane &L = lanes[sub ? sub[blockIdx.x] : (int32_t)blockIdx.x];
-    d_hyp<UH_T>(L, L.ctx, lm, dict, P, hdr_all + (size_t)(slot ? slot[blockIdx.x] : (int32_t)blockIdx.x) * UH_N, words_all, wcount);
+    __shared__ int32_t s_ids[UH_IDS];
+    d_hyp<UH_T>(L, L.ctx, lm, dict, P, hdr_all + (size_t)(slot ? slot[blockIdx.x] : (int32_t)blockIdx.x) * UH_N, words_all, wcount, s_ids);
 }
 
 /* ====================================================================================================================
@@ -1522,6 +1525,8 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_MAXC 32
 #define KF_MAXSEG (KF_MAXC * KF_WAVES)
 #define KF_SETS 1024            /* listed parent sets a workgroup takes per pass of the propagation step */
+#define KF_TP_LDS 1024          /* words of transition matrices kept in LDS */
+#define KF_BIG 256              /* ... of which several-parent sets whose headers stay in LDS (the others: d_dec_resolve_children) */
 static_assert(KF_NT == 512, "ku_frames: the word level's workgroup is the frame's workgroup");
 enum { KF_WINDOW, KF_STATIC, KF_QUEUE };
 
@@ -1532,6 +1537,7 @@ union KfPool {                  /* phases that never overlap share this LDS */
     struct {                    /* the propagation pass: the big sets' per-wave parent tables; the listed sets of a pass */
         int32_t rc[KF_WAVES][5 * 64];
         int32_t mlo[KF_SETS], pre[KF_SETS + 1], big[KF_SETS], nbig, m_all;
+        int32_t bmlo[KF_BIG], bmhi[KF_BIG], bkp0[KF_BIG], bnp[KF_BIG];     /* the several-parent sets' headers */
     } rs;
     struct { int32_t hdr[6 * WL_MAXT + 16], ex[3 * WL_LDS_EX]; } wl;
 };
@@ -1541,6 +1547,7 @@ struct KfSh {                   /* the workgroup's LDS outside the word level's 
     int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
     int32_t seg[KF_MAXSEG + 1], ws[KF_WAVES + 1], gq[4];    /* lextree_enter: the waves' segments of passing entries, scan scratch */
     int32_t thr[4];             /* the frame's thresholds: HMM, phone, word (final once the histogram beam is known) */
+    int32_t tp[KF_TP_LDS];      /* the transition matrices (when they fit: 48 of hub4's 3-state topology are 2.3 KB) */
 };
 
 struct KfBar { int32_t *cnt; int32_t C, target; int32_t *dead; };
@@ -1590,6 +1597,67 @@ kf_locate(const int32_t *pre, int32_t T, int32_t g, int32_t &t, int32_t &i)
     t = 0;
     while (t + 1 < T && g >= pre[t + 1]) t++;
     i = g - pre[t];
+}
+
+/*
+ * lextree_hmm_eval's step for one HMM, as ku_frames runs it.  What bounds the frame's steps on this chip is the NUMBER of scattered
+ * accesses -- a gather or scatter instruction costs a cycle per lane in the CU's address path whatever it moves (measured: asking for
+ * the chain's loads turns ahead changes nothing) --, so the HMM's 64-byte record travels as 16-byte pieces (2 + 3 accesses for a
+ * 3-state HMM instead of 8 loads + 10 stores), its senone ids come packed with the node (nodesen: one access instead of the sequence
+ * id and three 2-byte gathers), a composite senone's score arrives with its weight added (cs_val: d_comsen_list), and the transition
+ * matrices are read from LDS when they fit.  Same arithmetic as d_dec_hmm_eval_nd (vit3 / vit5); the frame tag is written along.
+ */
+template <int NE>
+__device__ __forceinline__ int32_t
+kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const int32_t *__restrict__ tp_g, const int32_t *tp_lds, const bool tp_in_lds,
+            const int32_t *__restrict__ raw, int32_t norm,
+            const int32_t *__restrict__ cs_valw, int32_t *rec_all, int32_t cf, int32_t &w, int32_t &out)
+{
+    constexpr int NV = NE == 3 ? 2 : 3;             /* 16-byte pieces that hold scores, histories, exit score, exit history */
+    int4 *rec = (int4 *)(rec_all + NSV(v));
+    int32_t wd[4 * NV];
+#pragma unroll
+    for (int q = 0; q < NV; q++) { const int4 a = rec[q]; wd[4 * q] = a.x; wd[4 * q + 1] = a.y; wd[4 * q + 2] = a.z; wd[4 * q + 3] = a.w; }
+    int32_t id[NE];
+    if (NE == 3) {
+        const int2 a = *(const int2 *)(nodesen + (size_t)v * 2);
+        id[0] = a.x & 0xffff; id[1] = (int32_t)((uint32_t)a.x >> 16); id[2] = a.y & 0xffff;
+    }
+    else {
+        const int4 a = *(const int4 *)(nodesen + (size_t)v * 4);
+        id[0] = a.x & 0xffff; id[1] = (int32_t)((uint32_t)a.x >> 16); id[2] = a.y & 0xffff; id[3] = (int32_t)((uint32_t)a.y >> 16); id[NE - 1] = a.z & 0xffff;
+    }
+    int32_t tp[NS_TPW(NE)];
+    if (tp_in_lds) {
+#pragma unroll
+        for (int q = 0; q < NS_TPW(NE); q++) tp[q] = tp_lds[nd.y * NS_TPW(NE) + q];
+    }
+    else {
+        const int4 *tq = (const int4 *)(tp_g + nd.y * NS_TPW(NE));
+#pragma unroll
+        for (int q = 0; q < NS_TPW(NE) / 4; q++) { const int4 a = tq[q]; tp[4 * q] = a.x; tp[4 * q + 1] = a.y; tp[4 * q + 2] = a.z; tp[4 * q + 3] = a.w; }
+    }
+    HmmRegsT<int32_t> r;
+#pragma unroll
+    for (int st = 0; st < NE; st++) { r.s[st] = wd[st]; r.h[st] = wd[NE + st]; }
+    r.out = wd[2 * NE]; r.outh = wd[2 * NE + 1];
+    int32_t e[NE];
+    const int32_t *src = nd.w ? cs_valw : raw;
+#pragma unroll
+    for (int st = 0; st < NE; st++) e[st] = add32(src[id[st]], -norm);
+    int32_t k;
+    if (NE == 5) { int32_t out_written = 0; k = vit5(r, tp, e, out_written); (void)out_written; }
+    else k = vit3(r, tp, e[0], e[1], e[2]);
+#pragma unroll
+    for (int st = 0; st < NE; st++) { wd[st] = r.s[st]; wd[NE + st] = r.h[st]; }
+    wd[2 * NE] = r.out; wd[2 * NE + 1] = r.outh;
+#pragma unroll
+    for (int q = 0; q < NV; q++) rec[q] = make_int4(wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]);
+    /* the best score and the frame tag (as if the HMM survived the frame: kf_frame's propagation pass corrects the ones it clears) */
+    static_assert(2 * 3 + 2 == 8 && 2 * 5 + 2 == 12, "the record's layout: s3a_structs.h");
+    rec[NV] = make_int4(k, cf + 1, 0, 0);
+    w = nd.z; out = r.out;
+    return k;
 }
 
 /* frame f of lane z (workgroup r of its C): row / brow = the frame's senone scores and best components */
@@ -1760,7 +1828,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     kf_barrier(B);
     KF_STAMP(4);
     /* ---- the scores of the composite senones wanted in this frame (ku_comsen_max) ---- */
-    d_comsen_list<true>(L.cs_wl, n_csw, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, gtid >> 4, gstride >> 4);
+    d_comsen_list<true>(L.cs_wl, n_csw, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, gtid >> 4, gstride >> 4, S.cs_wt);
     kf_barrier(B);
     KF_STAMP(5);
     /* ---- lextree_hmm_eval (ku_hmm_eval): a thread per list position of the trees laid end to end; the per-tree maxima are
@@ -1777,19 +1845,33 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         int32_t norm = max(L.misc[0], L.misc[5]);               /* the frame's normaliser */
         for (int w = 0; w < KF_WAVES; w++) norm = max(norm, sh.red[w]);
         const int32_t *act = L.act[cur];
+        const bool tp_in_lds = S.n_tmat * NS_TPW(NE) <= KF_TP_LDS;
+        /* (the chain list position -> node -> its static words -> senone ids -> scores: the node is asked for two turns ahead, its
+         * static words one turn ahead, so that a turn only waits for the ids and the scores) */
+        int32_t t0 = -1, i0 = 0, b0 = 0, v0 = -1, t1 = -1, i1 = 0, b1 = 0, v1 = -1;
+        int4 nd0 = make_int4(0, 0, 0, 0);
+        {
+            const int32_t ga = r * KF_NT + tid, gb_ = ga + gstride;
+            if (ga < n_tot) { kf_locate(sh.pre, T, ga, t0, i0); b0 = S.node_base[t0]; v0 = act[b0 + i0]; }
+            if (gb_ < n_tot) { kf_locate(sh.pre, T, gb_, t1, i1); b1 = S.node_base[t1]; v1 = act[b1 + i1]; }
+            if (v0 >= 0) nd0 = S.node4[v0];
+        }
         for (int32_t g0 = r * KF_NT; g0 < n_tot; g0 += gstride) {
-            const int32_t g = g0 + tid;
-            int32_t t = -1, k = INT_MIN, w = -1;
-            if (g < n_tot) {
-                int32_t i, out;
-                kf_locate(sh.pre, T, g, t, i);
-                const int32_t b = S.node_base[t], v = act[b + i];
-                k = d_dec_hmm_eval_node<NE, true>(v, S.N, S.ssid, S.tmatid, S.wid, S.comp, S.tp, S.sseq, S.comsseq, S.cs_off, S.cs_list, S.cs_wt,
-                                                  row, norm, L.sc, L.hist, L.outs, L.outh, L.bests, f, (const int32_t *)NULL, S.psof, L.pstamp,
-                                                  L.cs_val, S.node4, w, out);
-                L.poswid[b + i] = w;
-                L.posout[b + i] = out;
-                L.posbest[b + i] = k;
+            int4 nd1 = make_int4(0, 0, 0, 0);
+            if (v1 >= 0) nd1 = S.node4[v1];
+            int32_t t2 = -1, i2 = 0, b2 = 0, v2 = -1;
+            {
+                const int32_t gc = g0 + 2 * gstride + tid;
+                if (gc < n_tot) { kf_locate(sh.pre, T, gc, t2, i2); b2 = S.node_base[t2]; v2 = act[b2 + i2]; }
+            }
+            const int32_t t = t0;
+            int32_t k = INT_MIN, w = -1;
+            if (v0 >= 0) {
+                int32_t out;
+                k = kf_hmm_eval<NE>(v0, nd0, S.nodesen, S.tp, sh.tp, tp_in_lds, row, norm, L.cs_val, L.sc, f, w, out);
+                L.poswid[b0 + i0] = w;
+                L.posout[b0 + i0] = out;
+                L.posbest[b0 + i0] = k;
             }
             /* a wave's 64 positions belong to one tree, or to two or three at the seams */
             unsigned long long todo = __ballot(t >= 0);
@@ -1802,6 +1884,8 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 if (lane == 0) { atomicMax(&sh.acc[2 * tt], x); if (y != INT_MIN) atomicMax(&sh.acc[2 * tt + 1], y); }
                 todo &= ~__ballot(mine);
             }
+            t0 = t1; i0 = i1; b0 = b1; v0 = v1; nd0 = nd1;
+            t1 = t2; i1 = i2; b1 = b2; v1 = v2;
         }
         __syncthreads();
         if (tid < 2 * T && sh.acc[tid] != INT_MIN) atomicMax(&L.best[tid], sh.acc[tid]);
@@ -1904,7 +1988,9 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                                                    HeurArgs{ NULL, NULL, NULL }, sh.thr);
             }
         }
-        if (C == 1) { __syncthreads(); if (tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kdbg[0] += t_ - t_prev; ctx->kdbg[1] += S3A_ALD(&L.pcnt[f & 1]); } }
+        if (C == 1) { __syncthreads(); if (tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kdbg[0] += t_ - t_prev; } }
+        long long t_sub = (long long)wall_clock64();
+#define KF_SUB(i) do { if (C == 1) { __syncthreads(); if (tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kdbg[i] += t_ - t_sub; t_sub = t_; } } } while (0)
         /* the frame's listed parent sets (d_stamp_and_list): this workgroup's share, up to KF_SETS per pass.  Their headers are
          * fetched for all sets at once; the members of the one-parent sets (an interior node's children: most sets, a handful of
          * members each) become ONE flat run of work items, a thread each; a several-parent set (the ~340 first-level nodes under the
@@ -1922,7 +2008,11 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                         const int32_t q = L.plist[k0 + j];
                         m_lo = S.psmem_off[q];
                         const int32_t m_hi = S.psmem_off[q + 1], x0 = S.psmem[m_lo], np = S.par_off[x0 + 1] - S.par_off[x0];
-                        if (np >= SET_NP_MIN && np <= 64) rs.big[atomicAdd(&rs.nbig, 1)] = q;
+                        if (np >= SET_NP_MIN && np <= 64) {
+                            const int32_t at = atomicAdd(&rs.nbig, 1);
+                            rs.big[at] = q;
+                            if (at < KF_BIG) { rs.bmlo[at] = m_lo; rs.bmhi[at] = m_hi; rs.bkp0[at] = S.par_off[x0]; rs.bnp[at] = np; }
+                        }
                         else cm = m_hi - m_lo;
                     }
                     rs.mlo[j] = m_lo; rs.pre[j] = cm;
@@ -1941,6 +2031,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     if (tid == KF_NT - 1) rs.m_all = add + incl;
                     __syncthreads();
                 }
+                KF_SUB(1);
                 const int32_t M = rs.m_all;
                 for (int32_t m = tid; m < M; m += KF_NT) {
                     int32_t lo = 0, hi = nk - 1;
@@ -1952,10 +2043,77 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                                                        S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, x, false, true, -1, -1,
                                                        HeurArgs{ NULL, NULL, NULL }, sh.thr);
                 }
-                d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                                       L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                                       S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, rs.big, rs.nbig,
-                                                       S.psmem_off, S.psmem, wave, KF_WAVES, HeurArgs{ NULL, NULL, NULL }, rs.rc[wave], sh.thr);
+                KF_SUB(2);
+                /* the several-parent sets, a wave each (d_dec_resolve_children's rule; the set's header comes from LDS, two runs of 64
+                 * members are in flight at a time) */
+                {
+                    const int32_t nb = min(rs.nbig, KF_BIG), th = sh.thr[0], pth = sh.thr[1];
+                    int32_t *s_po = rs.rc[wave], *s_pp = s_po + 64, *s_ph = s_po + 128, *s_pr = s_po + 192;
+                    for (int32_t k = wave; k < nb; k += KF_WAVES) {
+                        const int32_t m_lo = rs.bmlo[k], m_hi = rs.bmhi[k], kp0 = rs.bkp0[k], np = rs.bnp[k];
+                        bool qual = false;
+                        int32_t po = 0, g = -1;
+                        if (lane < np) {
+                            g = S.par[kp0 + lane];
+                            if (L.posf[g] == f) {
+                                po = L.outs[NSV(g)];
+                                qual = po >= pth && !(pth < th && L.bests[NSV(g)] < th && L.propf[g] != f);
+                            }
+                        }
+                        const unsigned long long qm = __ballot(qual);
+                        const int32_t x0 = S.psmem[m_lo], b = S.node_base[S.tree_of[x0]];
+                        if (qual) {
+                            const int32_t at = __popcll(qm & ((1ull << lane) - 1ull));
+                            s_po[at] = po; s_pp[at] = L.pos[g]; s_ph[at] = L.outh[NSV(g)]; s_pr[at] = S.prob[g];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const int32_t nq = __popcll(qm);
+                        for (int32_t c0 = m_lo; c0 < m_hi; c0 += 128) {
+                            int32_t xx[2], pf[2], i0v[2], pxv[2], jv[2];
+#pragma unroll
+                            for (int u = 0; u < 2; u++) { const int32_t c = c0 + 64 * u + lane; xx[u] = c < m_hi ? S.psmem[c] : -1; }
+#pragma unroll
+                            for (int u = 0; u < 2; u++) {
+                                pf[u] = xx[u] >= 0 ? L.posf[xx[u]] : INT_MIN;
+                                i0v[u] = xx[u] >= 0 ? L.sc[NSV(xx[u])] : 0; pxv[u] = xx[u] >= 0 ? S.prob[xx[u]] : 0;
+                                jv[u] = xx[u] >= 0 ? L.pos[xx[u]] : 0;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 2; u++) {
+                                if (xx[u] < 0) continue;
+                                const int32_t x = xx[u];
+                                const bool on_list = pf[u] == f;                    /* (the list position pass leaves these members to us) */
+                                if (!on_list && nq == 0) continue;
+                                const int32_t j = on_list ? jv[u] : INT_MAX, in0 = i0v[u], px = pxv[u];
+                                int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
+                                int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
+                                for (int32_t q = 0; q < nq; q++) {
+                                    const int32_t ns = add32(s_po[q], add32(px, -s_pr[q]));
+                                    if (ns < th) continue;
+                                    const int32_t up = s_pp[q];
+                                    if (up < j) {
+                                        if (ns > mE || (ns == mE && up < pE)) { mE = ns; pE = up; hE = s_ph[q]; }
+                                        if (ns > in0 && up < firstE) firstE = up;
+                                    }
+                                    else {
+                                        if (ns > mL || (ns == mL && up < pL)) { mL = ns; pL = up; hL = s_ph[q]; }
+                                        if (up < firstL) firstL = up;
+                                    }
+                                }
+                                d_dec_resolve_finish(S.N, f, th, b, x, on_list, j, in0, mE, hE, firstE, mL, hL, firstL,
+                                                     L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.posout);
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                    /* (more several-parent sets than headers fit: the rest through the general routine) */
+                    if (rs.nbig > KF_BIG)
+                        d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                               L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                               S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, rs.big + KF_BIG, rs.nbig - KF_BIG,
+                                                               S.psmem_off, S.psmem, wave, KF_WAVES, HeurArgs{ NULL, NULL, NULL }, rs.rc[wave], sh.thr);
+                }
+                KF_SUB(3);
                 __syncthreads();
             }
         }
@@ -2008,6 +2166,8 @@ ku_frames(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar p
     UCtx *ctx = S.ctx_all + z;
     const int32_t tid = threadIdx.x;
     if (tid == 0) sh.dead = 0;
+    if (S.n_tmat * NS_TPW(NE) <= KF_TP_LDS)
+        for (int32_t i = tid; i < S.n_tmat * NS_TPW(NE); i += KF_NT) sh.tp[i] = S.tp[i];
     KfBar B = { bar + z, C, 0, &sh.dead };
     __syncthreads();
     const long long t_launch = (long long)wall_clock64();
@@ -2054,7 +2214,8 @@ ku_frames(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar p
                 kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, J.scores + (r0 + f) * S.n_sen, J.bests + (r0 + f) * S.n_sen, weak_possible);
             }
             /* srch_utt_end (srch.c:482-560): the hypothesis goes to the utterance's slot, the lane's lists are cleared */
-            if (r == 0) d_hyp<KF_NT>(L, ctx, lm, dict, J.P, J.hdr + (size_t)(J.u0 + u) * UH_N, J.words, J.wcount);
+            static_assert(3 * WL_LDS_EX >= UH_IDS, "d_hyp's backtrace ids borrow the word level's exit area");
+            if (r == 0) d_hyp<KF_NT>(L, ctx, lm, dict, J.P, J.hdr + (size_t)(J.u0 + u) * UH_N, J.words, J.wcount, sh.pool.wl.ex);
             kf_barrier(B);
             d_lane_end(L, S, z, ctx->err != 0, J.n_word, gtid, gstride);
             kf_barrier(B);
@@ -2138,6 +2299,21 @@ ku_pack_node4(const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmat
 {
     const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < N) out[v] = make_int4(ssid[v], tmatid[v], wid[v], (int32_t)comp[v]);
+}
+
+/* (ne = 3: 2 words per node, ne = 5: 4) */
+__global__ void
+ku_pack_nodesen(const int32_t *__restrict__ ssid, const uint8_t *__restrict__ comp, const int16_t *__restrict__ sseq,
+                const int16_t *__restrict__ comsseq, int32_t *out, int32_t N, int32_t ne)
+{
+    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const int16_t *row = (comp[v] ? comsseq : sseq) + (size_t)ssid[v] * ne;
+    const int32_t sv = ne == 3 ? 2 : 4;
+    for (int32_t k = 0; k < sv; k++) {
+        const uint32_t lo = 2 * k < ne ? (uint32_t)(uint16_t)row[2 * k] : 0u, hi = 2 * k + 1 < ne ? (uint32_t)(uint16_t)row[2 * k + 1] : 0u;
+        out[(size_t)v * sv + k] = (int32_t)(lo | (hi << 16));
+    }
 }
 
 __global__ void
@@ -2514,6 +2690,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     if (ud->S.sen2cimap) (void)hipFree((void *)ud->S.sen2cimap);
     if (ud->S.rootprob) (void)hipFree((void *)ud->S.rootprob);
     if (ud->S.node4) (void)hipFree((void *)ud->S.node4);
+    if (ud->S.nodesen) (void)hipFree((void *)ud->S.nodesen);
     if (ud->S.ctx_all) (void)hipFree(ud->S.ctx_all);
     if (ud->S.nact_all) (void)hipFree(ud->S.nact_all);
     if (ud->d_lcmap) (void)hipFree(ud->d_lcmap);
@@ -2616,6 +2793,12 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         hipLaunchKernelGGL(ku_pack_node4, dim3((unsigned)((proto->N + 255) / 256)), dim3(256), 0, ud->stream, proto->d_ssid, proto->d_tmatid,
                            proto->d_wid, proto->d_comp, n4, proto->N);
         S.node4 = n4;
+        int32_t *ns = NULL;
+        const int32_t ne = proto->n_emit;
+        DM(ns, (size_t)proto->N * (ne == 3 ? 2 : 4) * 4);
+        S.nodesen = ns;
+        hipLaunchKernelGGL(ku_pack_nodesen, dim3((unsigned)((proto->N + 255) / 256)), dim3(256), 0, ud->stream, proto->d_ssid, proto->d_comp, proto->d_sseq,
+                           proto->d_comsseq, ns, proto->N, ne);
     }
     {   /* the roots' look-ahead probabilities in root-list order (Entries::rootprob) */
         const size_t nr = proto->h_rootlist.size();
