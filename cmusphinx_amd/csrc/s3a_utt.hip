@@ -1625,7 +1625,9 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
     }
     else {
         const int4 a = *(const int4 *)(nodesen + (size_t)v * 4);
-        id[0] = a.x & 0xffff; id[1] = (int32_t)((uint32_t)a.x >> 16); id[2] = a.y & 0xffff; id[3] = (int32_t)((uint32_t)a.y >> 16); id[NE - 1] = a.z & 0xffff;
+        const int32_t h[5] = { a.x & 0xffff, (int32_t)((uint32_t)a.x >> 16), a.y & 0xffff, (int32_t)((uint32_t)a.y >> 16), a.z & 0xffff };
+#pragma unroll
+        for (int st = 0; st < NE; st++) id[st] = h[st];
     }
     int32_t tp[NS_TPW(NE)];
     if (tp_in_lds) {
@@ -2561,6 +2563,10 @@ struct s3a_uttdec_s {
     int32_t *sb_scores; uint8_t *sb_bests; size_t sb_rows_cap;
     UwGroup *sb_gdesc_d, *sb_gdesc_h; size_t sb_g_cap;
     long long *sb_row0_d, *sb_row0_h; size_t sb_row0_cap;
+    /* where the last call's device time went: events around the scoring launches and around ku_frames (s3a_uttdec_last_parts) */
+    std::vector<hipEvent_t> kf_evs;
+    int32_t kf_ev_n, kf_n_score, kf_n_frames;
+    double kf_score_ms, kf_frames_ms;
 };
 
 /* engines with ku_frames alive per device: an engine that is alone on its device may give a lane a cluster of workgroups */
@@ -2656,6 +2662,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
     if (ud->kf_counted) { g_kf_live[ud->device]--; ud->kf_counted = 0; }
+    for (auto e : ud->kf_evs) (void)hipEventDestroy(e);
+    ud->kf_evs.clear();
     if (ud->d_kfbar) (void)hipFree(ud->d_kfbar);
     if (ud->d_kfnext) (void)hipFree(ud->d_kfnext);
     if (ud->sb_scores) (void)hipFree(ud->sb_scores);
@@ -2943,10 +2951,11 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     if (hipMemset(ud->d_fgbase, 0, 64) != hipSuccess) goto fail;
     ud->S.fgbase = ud->d_fgbase;
     ud->use_graph = O.graph != 0 && !ud->big_wl && !O.framecheck;
-    ud->persist = O.persist >= 0 && !ud->use_graph && !O.framecheck ? 1 : 0;
+    ud->persist = O.persist >= 0 && !ud->use_graph && !O.framecheck ? (O.persist > 0 ? 2 : 1) : 0;     /* (2: whatever the lane count) */
     ud->kf_cluster_opt = O.cluster; ud->kf_last_c = 0; ud->kf_slots = 0; ud->d_kfbar = NULL; ud->kf_counted = 0; ud->d_kfnext = NULL;
     ud->sb_scores = NULL; ud->sb_bests = NULL; ud->sb_rows_cap = 0; ud->sb_gdesc_d = ud->sb_gdesc_h = NULL; ud->sb_g_cap = 0;
     ud->sb_row0_d = ud->sb_row0_h = NULL; ud->sb_row0_cap = 0;
+    ud->kf_ev_n = ud->kf_n_score = ud->kf_n_frames = 0; ud->kf_score_ms = ud->kf_frames_ms = 0.0;
     if (ud->persist) {
         DM(ud->d_kfnext, (size_t)(16 + n_lanes) * 4);
         DM(ud->d_kfbar, (size_t)n_lanes * 4);
@@ -3361,11 +3370,15 @@ q_grow(TP **d, TP **h, size_t *cap, size_t need, const char *what)
 
 /* ---- ku_frames: the frames [fg0, fg0 + nf) of all lanes as ONE launch (behind the look-ahead pass that scores them) ---- */
 /* does this engine, as it is configured now, run its frames through ku_frames? */
+/* (n: the lanes the call keeps busy.  Measured with one engine on the hub4-shaped task, ku_frames : launches -- 256 lanes 443 : 288 k
+ * frames/s, 128 lanes (clusters of 3) 272 : 223 k, 64 lanes (7) 128 : 155 k, 32 lanes 58 : 111 k, one lane 5.2 : 9.4 k: a cluster's
+ * barrier costs ~8 us against a launch boundary's ~1.5, so below KF_MIN_LANES the launches stay) */
+#define KF_MIN_LANES 96
 static bool
-kf_served(const s3a_uttdec_t *ud)
+kf_served(const s3a_uttdec_t *ud, int32_t n)
 {
     const UShared &S = ud->S;
-    return ud->persist && S.win_K > 0 && !ud->big_wl && S.pheurtype == 0 && S.max_cd >= S.n_sen - S.n_ci_sen && !ud->d_dbg
+    return ud->persist && (ud->persist > 1 || n >= KF_MIN_LANES) && S.win_K > 0 && !ud->big_wl && S.pheurtype == 0 && S.max_cd >= S.n_sen - S.n_ci_sen && !ud->d_dbg
         && ud->prof_every == 0 && (S.ne == 3 || S.ne == 5) && S.T <= WL_MAXT;
 }
 
@@ -3384,7 +3397,7 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
     const int32_t per_xcd = max(1, ud->kf_slots / 8), lanes_per_xcd = (n + 7) / 8;
     int32_t C = 1;
     if (ud->kf_cluster_opt > 0) C = ud->kf_cluster_opt;
-    else if (ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1) C = min(per_xcd / lanes_per_xcd, 32);
+    else if (ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1) C = min(per_xcd / lanes_per_xcd, 4);
     /* (a margin per XCD: the occupancy query can be one workgroup per CU high, MI355X_MICROARCH "Residency") */
     C = max(1, min(C, (per_xcd - (per_xcd > 8 ? 4 : 0)) / lanes_per_xcd));
     ud->kf_last_c = C;
@@ -3413,6 +3426,31 @@ enqueue_block(s3a_uttdec_t *ud, int32_t n, int32_t fg0, int32_t nf)
     memset(&J, 0, sizeof J);
     J.mode = KF_WINDOW; J.fg0 = fg0; J.n_fr = nf;
     return kf_launch(ud, n, J);
+}
+
+/* a time mark on the engine's stream (pairs of them bracket the scoring launches and ku_frames: kf_collect) */
+static void
+kf_mark(s3a_uttdec_t *ud)
+{
+    if ((size_t)ud->kf_ev_n >= ud->kf_evs.size()) {
+        hipEvent_t e = NULL;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        ud->kf_evs.push_back(e);
+    }
+    (void)hipEventRecord(ud->kf_evs[ud->kf_ev_n++], ud->stream);
+}
+
+/* behind the stream's synchronisation: marks come in triples (before scoring, between, behind ku_frames) */
+static void
+kf_collect(s3a_uttdec_t *ud)
+{
+    ud->kf_score_ms = ud->kf_frames_ms = 0.0;
+    for (int32_t i = 0; i + 2 < ud->kf_ev_n; i += 3) {
+        float a = 0.0f, b = 0.0f;
+        if (hipEventElapsedTime(&a, ud->kf_evs[i], ud->kf_evs[i + 1]) == hipSuccess) ud->kf_score_ms += a;
+        if (hipEventElapsedTime(&b, ud->kf_evs[i + 1], ud->kf_evs[i + 2]) == hipSuccess) ud->kf_frames_ms += b;
+    }
+    ud->kf_ev_n = 0;
 }
 
 /* ---- SCORES FIRST: every frame of the call's utterances scored into one buffer before the search starts ---- */
@@ -3478,6 +3516,7 @@ sb_score(s3a_uttdec_t *ud, size_t g0, size_t n_g)
     for (size_t g = 0; g < n_g; g += SB_PIECE) {
         const int32_t rc = uw_launch(ud, 0, 0, false, ud->sb_gdesc_d + g0 + g, (int32_t)min((size_t)SB_PIECE, n_g - g));
         if (rc != S3A_OK) return rc;
+        ud->kf_n_score++;
     }
     return S3A_OK;
 }
@@ -3496,11 +3535,17 @@ kf_decode_static(s3a_uttdec_t *ud, int32_t n_utt, const int32_t *n_frames)
     const size_t ng = sb_describe(ud, fd.data(), n_frames, 0, n_utt, 0);
     HIPCHK(hipMemcpyAsync(ud->sb_gdesc_d, ud->sb_gdesc_h, ng * sizeof(UwGroup), hipMemcpyHostToDevice, ud->stream));
     HIPCHK(hipMemcpyAsync(ud->sb_row0_d, ud->sb_row0_h, (size_t)n_utt * 8, hipMemcpyHostToDevice, ud->stream));
+    ud->kf_n_score = ud->kf_n_frames = 0;
+    kf_mark(ud);
     if ((rc = sb_score(ud, 0, ng)) != S3A_OK) return rc;
+    kf_mark(ud);
     KfJob J;
     memset(&J, 0, sizeof J);
     J.mode = KF_STATIC; J.row0 = ud->sb_row0_d; J.scores = ud->sb_scores; J.bests = ud->sb_bests;
-    return kf_launch(ud, n_utt, J);
+    rc = kf_launch(ud, n_utt, J);
+    ud->kf_n_frames++;
+    kf_mark(ud);
+    return rc;
 }
 
 /* s3a_uttdec_decode_queue through ku_frames: the lanes take the utterances themselves.  The queue goes through in as many parts as
@@ -3527,9 +3572,12 @@ kf_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev, c
     for (size_t k = 0; k + 1 < cut.size(); k++) g_at[k + 1] = g_at[k] + sb_describe(ud, feat_dev, n_frames, cut[k], cut[k + 1], g_at[k]);
     HIPCHK(hipMemcpyAsync(ud->sb_gdesc_d, ud->sb_gdesc_h, g_at.back() * sizeof(UwGroup), hipMemcpyHostToDevice, ud->stream));
     HIPCHK(hipMemcpyAsync(ud->sb_row0_d, ud->sb_row0_h, (size_t)n_utt * 8, hipMemcpyHostToDevice, ud->stream));
+    ud->kf_n_score = ud->kf_n_frames = 0;
     for (size_t k = 0; k + 1 < cut.size(); k++) {
         const int32_t u0 = cut[k], nu = cut[k + 1] - cut[k];
+        kf_mark(ud);
         if ((rc = sb_score(ud, g_at[k], g_at[k + 1] - g_at[k])) != S3A_OK) return rc;
+        kf_mark(ud);
         HIPCHK(hipMemsetAsync(ud->d_kfnext, 0, 4, ud->stream));
         KfJob J;
         memset(&J, 0, sizeof J);
@@ -3537,6 +3585,8 @@ kf_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev, c
         J.row0 = ud->sb_row0_d; J.scores = ud->sb_scores; J.bests = ud->sb_bests;
         J.hdr = ud->q_hdr_d; J.words = ud->q_words_d; J.wcount = wcount; J.P = P; J.B = B; J.n_word = ud->cfg.n_word;
         if ((rc = kf_launch(ud, min(ud->n_lanes, nu), J)) != S3A_OK) return rc;
+        ud->kf_n_frames++;
+        kf_mark(ud);
     }
     return S3A_OK;
 }
@@ -3673,7 +3723,7 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
             if (hipGraphLaunch(ge, ud->stream) != hipSuccess) { s3a_set_error("s3a_uttdec_decode: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
         if (rc == S3A_OK && hipMemsetAsync(ud->d_fgbase, 0, 4, ud->stream) != hipSuccess) rc = S3A_EHIP;
     }
-    else if (kf_served(ud)) {
+    else if (kf_served(ud, n_utt)) {
         /* every frame scored first, then each lane's utterance as one launch; in window blocks when the scores do not fit */
         rc = kf_decode_static(ud, n_utt, n_frames);
         if (rc == S3A_EUNSUP) {
@@ -3709,6 +3759,7 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
         (void)hipEventElapsedTime(&ms, ud->ev0, ud->ev1);
         ud->last_decode_ms = ms;
     }
+    kf_collect(ud);
     for (auto &e : ud->prof_ev) {
         float ms = 0.0f;
         if (rc == S3A_OK && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ud->prof_us[e.cls] += 1e3 * ms; ud->prof_n[e.cls]++; }
@@ -3829,7 +3880,7 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     const UShared &S = ud->S;
     const bool graph_mode = ud->use_graph && ud->prof_every == 0;
     /* ku_frames (KF_QUEUE): the lanes take the utterances themselves -- no schedule, no refill events, no window boundaries */
-    const bool kfq = !graph_mode && kf_served(ud) && !ud->dag;
+    const bool kfq = !graph_mode && kf_served(ud, min(ud->n_lanes, n_utt)) && !ud->dag;
     /* utterances begin at window boundaries (the look-ahead pass scores K frames of all lanes); in graph mode at the blocks' */
     const int32_t n = min(ud->n_lanes, n_utt), E = graph_mode ? graph_block_frames(ud) : (S.win_K > 0 ? S.win_K : 1), D4x4 = S.D4 * 4, T = S.T;
     int32_t rc;
@@ -3981,7 +4032,7 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
             if (rc == S3A_OK && hipGraphLaunch(ge, ud->stream) != hipSuccess) { s3a_set_error("s3a_uttdec_decode_queue: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError())); rc = S3A_EHIP; }
         }
     }
-    else if (kf_served(ud))
+    else if (kf_served(ud, n) && ud->persist > 1)           /* (a queue with the second pass: ku_frames only when asked for -- window blocks keep all lanes in step) */
         for (int32_t fg = 0; fg < F_end && rc == S3A_OK; fg += E) {        /* (E = the window: refill events fall on its boundaries) */
             if (ei < evs.size() && evs[ei].f == fg) rc = run_event(evs[ei++]);
             if (rc == S3A_OK) rc = enqueue_block(ud, n, fg, min(E, F_end - fg));
@@ -4002,6 +4053,7 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
         (void)hipEventElapsedTime(&ms, ud->ev0, ud->ev1);
         ud->last_decode_ms = ms;
     }
+    kf_collect(ud);
     for (auto &e : ud->prof_ev) {
         float ms = 0.0f;
         if (rc == S3A_OK && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { ud->prof_us[e.cls] += 1e3 * ms; ud->prof_n[e.cls]++; }
@@ -4132,7 +4184,21 @@ s3a_uttdec_frame_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16, int32_t
     UCtx x;
     HIPCHK(hipMemcpy(&x, ud->S.ctx_all + lane, sizeof x, hipMemcpyDeviceToHost));
     for (int i = 0; i < 16; i++) out16[i] = x.kacc[i];
-    if (cluster) *cluster = kf_served(ud) ? ud->kf_last_c : 0;
+    if (cluster) *cluster = ud->kf_last_c;
+    return S3A_OK;
+}
+
+/* where the last decode's device time went when it ran through ku_frames: milliseconds and launches of the up-front scoring
+ * (ku_score_window) and of ku_frames; cluster = workgroups per lane of its last launch.  All zero: the call ran the frame as launches. */
+extern "C" int32_t
+s3a_uttdec_last_parts(s3a_uttdec_t *ud, double *score_ms, int32_t *n_score, double *frames_ms, int32_t *n_frames, int32_t *cluster)
+{
+    if (!ud) return S3A_EINVAL;
+    if (score_ms) *score_ms = ud->kf_score_ms;
+    if (frames_ms) *frames_ms = ud->kf_frames_ms;
+    if (n_score) *n_score = ud->kf_n_score;
+    if (n_frames) *n_frames = ud->kf_n_frames;
+    if (cluster) *cluster = ud->kf_last_c;
     return S3A_OK;
 }
 

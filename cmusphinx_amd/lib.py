@@ -205,6 +205,7 @@ _SIGS = {
     "s3a_uttdec_wl_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_frame_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "s3a_uttdec_frame_dbg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "s3a_uttdec_last_parts": (C.c_int32, [C.c_void_p] + [C.c_void_p] * 5),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_window": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_enable_pheur": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -1544,6 +1545,13 @@ class UttDec:
         d = {names[i]: 0.01 * t[i] for i in range(12)}
         d["emit_only"] = 0.01 * t[15]; d["in_launch"] = 0.01 * t[12]
         return d, int(t[13]), int(t[14]), int(c.value)
+
+    def last_parts(self):
+        """-> dict(score_ms, n_score, frames_ms, n_frames, cluster) of the last decode (all zero: it ran the frame as launches)"""
+        sm, fm = C.c_double(), C.c_double()
+        ns, nf, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.s3a_uttdec_last_parts(self.h, C.byref(sm), C.byref(ns), C.byref(fm), C.byref(nf), C.byref(c)), self.L)
+        return dict(score_ms=sm.value, n_score=ns.value, frames_ms=fm.value, n_frames=nf.value, cluster=c.value)
 
     def frame_dbg(self, lane=0):
         t = (C.c_longlong * 4)()

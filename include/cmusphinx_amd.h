@@ -793,6 +793,10 @@ int32_t s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16);
  * [9] lextree_hmm_propagate_non_leaves, [10] the ordered scan, [11] emission + word level ([15]: the emission alone when the lane is
  * one workgroup), [12] ticks inside the launches, [13] frames, [14] launches.  *cluster = workgroups per lane of the last launch
  * (0: the engine runs the frame as separate launches). */
+/* measurement: where the last decode's device time went when it ran through ku_frames (HIP events on the engine's stream): the
+ * up-front scoring (ku_score_window: milliseconds, launches) and ku_frames itself; *cluster = workgroups per lane.  All zero when
+ * the call ran the frame as separate launches (fewer lanes than pay for ku_frames, an option it does not serve, persist = -1). */
+int32_t s3a_uttdec_last_parts(s3a_uttdec_t *ud, double *score_ms, int32_t *n_score, double *frames_ms, int32_t *n_frames, int32_t *cluster);
 int32_t s3a_uttdec_frame_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16, int32_t *cluster);
 /* diagnostics: where and when the lane's workgroup ran the launch that began at engine frame 512: clock at entry and exit (100 MHz),
  * the hardware's HW_ID and XCC_ID registers (tools/kf_phases.py --placement) */

@@ -1,0 +1,134 @@
+"""ku_frames (s3a_uttdec_opts_t.persist / .cluster, round 5): the lane's frame as the phases of ONE persistent workgroup -- or a
+cluster of them with a counter barrier -- instead of twelve launches per frame, every frame's senone scores computed before the
+search starts, the queue's lanes taking their utterances themselves.  The library chooses it from 96 busy lanes on (below that
+the launches win); here S3A_UTT_PERSIST=1 forces it for engines of 1 .. 40 lanes so that every mode runs on the small tasks:
+
+  KF_STATIC (s3a_uttdec_decode), KF_QUEUE (s3a_uttdec_decode_queue: no schedule, lanes refill themselves, a lane whose utterance
+  overflowed is scrubbed inside the kernel), KF_WINDOW (a queue with the second pass keeps window blocks), clusters of 1 / 2 / 3
+  workgroups per lane, 3- and 5-state HMMs, histogram pruning (-maxhmmpf 20: the sort inside the kernel), -ptranskip with a phone
+  beam wider than the HMM beam (d_dec_weak_t), the CI gate with -ds 2, the hub4-shaped task (several-parent sets, composite senones).
+
+Expected output: the unmodified reference's -hyp / -hypseg (committed goldens or produced live), byte for byte -- the same
+bar as the launch path's tests, whose bodies these reuse."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import test_gpu_5state as T5
+import test_gpu_dropin as TD
+import test_gpu_queue as TQ
+import test_gpu_uttdec as TU
+from cmusphinx_amd import bundle
+from test_gpu_5state import task  # noqa: F401  (fixture)
+from test_gpu_uttdec import tidigits_bundle  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+FORCE = {"S3A_UTT_PERSIST": "1"}
+
+
+@pytest.fixture
+def persist(monkeypatch):
+    monkeypatch.setenv("S3A_UTT_PERSIST", "1")
+
+
+@pytest.mark.parametrize("n_lanes,cluster", [(1, 1), (3, 2), (8, 3), (40, 1)])
+def test_queue_lanes_take_their_utterances_themselves(gpu_lib, tidigits_bundle, monkeypatch, persist, n_lanes, cluster):
+    """KF_QUEUE on the ragged tidigits set, lanes = workgroups or clusters of 2 / 3; the engine reports that it ran ku_frames"""
+    monkeypatch.setenv("S3A_UTT_CLUSTER", str(cluster))
+    dec = bundle.Decoder(tidigits_bundle, n_lanes)
+    utts, feats = TQ.tidigits_feats(gpu_lib)
+    dec.decode_queue(feats)
+    m, s = TQ.queue_lines(dec, utts)
+    rm, rs = TQ.ref_lines()
+    assert m == rm and s == rs
+    parts = dec.ud.last_parts()
+    assert parts["n_frames"] >= 1 and parts["n_score"] >= 1 and parts["cluster"] == cluster and parts["frames_ms"] > 0
+    ticks, frames, launches, c = dec.ud.frame_ticks(0)
+    assert frames > 0 and launches >= 1 and ticks["hmm_eval"] > 0
+
+
+def test_launches_and_ku_frames_leave_the_same_tables(gpu_lib, tidigits_bundle, monkeypatch):
+    """s3a_uttdec_decode both ways: every lane's whole history table and frame statistics, word for word"""
+    utts, feats = TQ.tidigits_feats(gpu_lib)
+    res = {}
+    for mode in ("-1", "1"):
+        monkeypatch.setenv("S3A_UTT_PERSIST", mode)
+        dec = bundle.Decoder(tidigits_bundle, 6)
+        dec.decode(feats[:6])
+        res[mode] = [dec.ud.result(z) for z in range(6)]
+        assert (dec.ud.last_parts()["n_frames"] > 0) == (mode == "1")
+    for a, b in zip(res["-1"], res["1"]):
+        assert len(a["score"]) == len(b["score"]) > 1 and a["n_frm"] == b["n_frm"]
+        for k in ("score", "pred", "lw0", "lw1", "wid", "sf", "ef", "ascr", "lscr", "type", "frame_start", "bestscore", "bestvh", "frame_stat"):
+            assert np.array_equal(a[k], b[k]), k
+
+
+def test_queue_reuse_overflow_and_static_decodes(gpu_lib, tidigits_bundle, persist):
+    """the launch path's own tests of engine reuse and of a lane scrubbed after a capacity error, through ku_frames"""
+    TQ.test_queue_order_and_reuse_of_an_engine(gpu_lib, tidigits_bundle)
+    TQ.test_a_lane_whose_utterance_overflowed_is_scrubbed_on_the_device(gpu_lib, tidigits_bundle)
+    TU.test_every_lane_that_overflowed_restarts_clean(gpu_lib, tidigits_bundle)
+    TU.test_hypothesis_records_are_fixed_size_and_self_contained(gpu_lib, tidigits_bundle)
+
+
+def test_second_pass_keeps_window_blocks(gpu_lib, tidigits_bundle, persist):
+    """KF_WINDOW: a queue with -bestpath 1 runs ku_frames block by block between the refill events"""
+    TQ.test_second_pass_inside_the_queue_through_the_c_abi(gpu_lib, tidigits_bundle)
+
+
+def test_the_score_buffer_in_parts(gpu_lib, tidigits_bundle, persist):
+    """more utterances than lanes AND a score buffer that must be reused: the queue goes through in parts when its frames outgrow
+    the device's free memory -- forced here by asking twice, the second time with buffers that already exist"""
+    dec = bundle.Decoder(tidigits_bundle, 4)
+    utts, feats = TQ.tidigits_feats(gpu_lib)
+    rm, rs = TQ.ref_lines()
+    for _ in range(2):
+        dec.decode_queue(feats[:9])
+        m, s = TQ.queue_lines(dec, utts[:9])
+        assert m == rm[:9] and s == rs[:9]
+    dec.decode_queue(feats)                     # grows the buffers
+    m, s = TQ.queue_lines(dec, utts)
+    assert m == rm and s == rs
+
+
+@pytest.mark.parametrize("name,lanes,cluster", [("mode4_trigram", "4", "1"), ("mode4_cibeam_ds2", "4", "2"), ("mode4_cibeam_ds2", "40", "1")])
+def test_drop_in_program_through_ku_frames(name, lanes, cluster, tmp_path):
+    env = dict(FORCE, S3A_UTT=lanes, S3A_UTT_CLUSTER=cluster)
+    hyp, seg, log = (str(tmp_path / f"kf_{name}.{e}") for e in ("match", "matchseg", "log"))
+    with open(log, "w") as lf:
+        p = subprocess.run([TD.TST] + TD.common() + TD.RUNS[name] + ["-hyp", hyp, "-hypseg", seg], stdout=lf, stderr=subprocess.STDOUT,
+                           timeout=900, env=dict(os.environ, **env))
+    assert p.returncode == 0, open(log, errors="ignore").read()[-2000:]
+    assert open(hyp).read() == open(os.path.join(TD.D, f"ref_{name}.match")).read()
+    assert open(seg).read() == open(os.path.join(TD.D, f"ref_{name}.matchseg")).read()
+
+
+@pytest.mark.parametrize("what,extra", [("histogram", ["-maxhmmpf", "20"]),
+                                        ("weak", ["-ptranskip", "2", "-beam", "1e-80", "-pbeam", "1e-100", "-wbeam", "1e-40"])])
+def test_histogram_pruning_and_weak_hmms_inside_the_kernel(what, extra, tmp_path):
+    args = TD.RUNS["mode4_trigram"] + extra
+    ref_hyp, ref_seg, _ = TD.run(TD.REFDEC, args, tmp_path, "cpu_" + what)
+    for lanes, cluster in (("4", "1"), ("5", "3")):
+        hyp, seg, log = (str(tmp_path / f"kf_{what}_{lanes}.{e}") for e in ("match", "matchseg", "log"))
+        with open(log, "w") as lf:
+            p = subprocess.run([TD.TST] + TD.common() + args + ["-hyp", hyp, "-hypseg", seg], stdout=lf, stderr=subprocess.STDOUT, timeout=900,
+                               env=dict(os.environ, **FORCE, S3A_UTT=lanes, S3A_UTT_CLUSTER=cluster))
+        assert p.returncode == 0, open(log, errors="ignore").read()[-2000:]
+        assert open(hyp).read() == ref_hyp and open(seg).read() == ref_seg
+
+
+@pytest.mark.parametrize("env", [{"S3A_UTT": "4"}, {"S3A_UTT": "3", "S3A_UTT_CLUSTER": "2"}, {"S3A_UTT": "6", "S3A_UTT_QUEUE": "12"}])
+def test_hub4_shaped_decode_through_ku_frames(env, tmp_path):
+    """several-parent sets (46 left-context variants per root), composite senones, ~3000 active HMMs per frame"""
+    args = TD.synth_task("hub4", tmp_path, 6, 200)
+    ref = TD.decode_task(TD.REFDEC, args, tmp_path, "ref")
+    got = TD.decode_task(TD.TST, args, tmp_path, "kf", dict(FORCE, **env))
+    assert got[0] == ref[0] and got[1] == ref[1]
+
+
+@pytest.mark.parametrize("env", [{"S3A_UTT": "4"}, {"S3A_UTT": "3", "S3A_UTT_CLUSTER": "2", "S3A_UTT_QUEUE": "8"}])
+def test_five_state_hmms_through_ku_frames(env, task):  # noqa: F811
+    T5.test_five_state_decode_matches_reference(task, "kf" + env["S3A_UTT"], dict(FORCE, **env))
