@@ -245,7 +245,7 @@ def scoring_legs(lib, fast):
     return out
 
 
-def wide_beam_leg(lib, d, lanes, n_frames, fast, n_check=8):
+def wide_beam_leg(lib, d, lanes, n_frames, fast, n_check=64):
     """BASELINE configs[4]: the WSJ-shaped model (8000 senones x 32 Gaussians, 20 k-word trigram) decoded with the wide
     beam -beam 1e-120 -pbeam 1e-100 -wbeam 1e-80 -maxhmmpf 100000 ("stress active-HMM count and LDS occupancy"):
     `lanes` utterances in ONE engine, whole utterances on the device; the first n_check utterances compared, -hyp and
@@ -326,7 +326,7 @@ PSREF = os.path.join(ROOT, "oracle", "_ref", "ref_ps_fwd")
 PSAMD = os.path.join(ROOT, "oracle", "_ref", "ref_ps_amdfwd")
 
 
-def ps_fwdtree_leg(t, lanes, n_cpu=4):
+def ps_fwdtree_leg(t, lanes, n_cpu=128, n_proc=16):
     """pocketsphinx's first pass on the device, measured on configs[3]'s OWN batch: the task directory t (the
     1024 utterances the main line decodes; its phone names are in the order pocketsphinx's mdef reader insists on) decoded by
     ref_ps_amdfwd -batch <lanes> -queue yes (integration/pocketsphinx/ps_search_amd.c: features by the decoder's feat_t, then
@@ -348,13 +348,25 @@ def ps_fwdtree_leg(t, lanes, n_cpu=4):
         with open(lg, "w") as lf:
             r = subprocess.run([exe] + a + extra + ["-hyp", m, "-hypseg", sg], stdout=lf, stderr=subprocess.STDOUT)
         return r.returncode, open(m).read() if os.path.exists(m) else "", open(sg).read() if os.path.exists(sg) else "", open(lg, errors="ignore").read()
-    ctl4 = os.path.join(d, "ps_ctl_cpu")
-    with open(ctl4, "w") as f:
-        f.writelines(open(os.path.join(t, "ctl")).readlines()[:n_cpu])
-    rc, rm, rs, rlog = run(PSREF, ["-fresh", "yes"], "ref", ctl4)
-    if rc != 0:
+    # the unmodified pocketsphinx on the first n_cpu utterances: n_proc single-core processes side by side, a slice of the list each
+    lines = open(os.path.join(t, "ctl")).readlines()[:n_cpu]
+    n_cpu = len(lines)
+    from concurrent.futures import ThreadPoolExecutor
+    cuts = [(i * n_cpu // n_proc, (i + 1) * n_cpu // n_proc) for i in range(n_proc)]
+    cuts = [c_ for c_ in cuts if c_[1] > c_[0]]
+
+    def ref_slice(i):
+        cf = os.path.join(d, f"ps_ctl_cpu{i}")
+        with open(cf, "w") as f:
+            f.writelines(lines[cuts[i][0]:cuts[i][1]])
+        return run(PSREF, ["-fresh", "yes"], f"ref{i}", cf)
+    with ThreadPoolExecutor(len(cuts)) as ex:
+        refs_ = list(ex.map(ref_slice, range(len(cuts))))
+    if any(r_[0] != 0 for r_ in refs_):
         return {"error": "the unmodified pocketsphinx failed on the task"}
-    cpu = re.search(r"decoded (\d+) frames in ([0-9.]+) s", rlog)
+    rm, rs = "".join(r_[1] for r_ in refs_), "".join(r_[2] for r_ in refs_)
+    cpus = [re.search(r"decoded (\d+) frames in ([0-9.]+) s", r_[3]) for r_ in refs_]
+    cpu = cpus[0]
     rc, am, asg, alog = run(PSAMD, ["-fresh", "yes", "-batch", str(lanes), "-queue", "yes"], "amd")
     if rc != 0:
         return {"error": "ref_ps_amdfwd failed: " + " | ".join(l for l in alog.splitlines() if "ERROR" in l or "FATAL" in l)[-300:]}
@@ -371,7 +383,8 @@ def ps_fwdtree_leg(t, lanes, n_cpu=4):
            "identical_to_pocketsphinx": {"hyp_and_score": same_h, "segmentation": same_s, "utterances_checked": n_cpu},
            "search_space": {"roots": int(tree.group(1)), "interior_channels": int(tree.group(2)), "single_phone_words": int(tree.group(3))} if tree else None,
            "cpu_pocketsphinx": {"frames": int(cpu.group(1)), "seconds": float(cpu.group(2)), "frames_per_sec": round(int(cpu.group(1)) / max(float(cpu.group(2)), 1e-9), 1),
-                                "cores": 1, "kind": "reference"} if cpu else None,
+                                "cores": 1, "kind": "reference", "processes_side_by_side": len(cuts),
+                                "aggregate_frames_per_sec": round(sum(int(c_.group(1)) for c_ in cpus if c_) / max(max(float(c_.group(2)) for c_ in cpus if c_), 1e-9), 1)} if cpu else None,
            "timed": "HIP events on the engine's stream around the batch's scoring launch + the search launch (features resident in HBM)"}
     sc = re.search(r"of which scoring ([0-9.]+) ms", alog)
     if sc and float(sc.group(1)) > 0:
@@ -442,7 +455,7 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong: the fixed batch is split over the ranks (configs[3] as written); weak: every rank decodes a whole batch")
     ap.add_argument("--lanes", type=int, default=512, help="decoder lanes per GPU (utterances in flight)")
-    ap.add_argument("--engines", type=int, default=4, help="decoder engines per GPU (own stream each) the lanes are split over")
+    ap.add_argument("--engines", type=int, default=1, help="decoder engines per GPU (own stream each) the lanes are split over (1 since round 5: ku_frames keeps every lane on its own workgroup, so one engine fills the chip; the launch path of rounds 2-4 wanted 4)")
     ap.add_argument("--min-group", type=int, default=32, help="a rank's share is cut into groups of at least this many utterances")
     ap.add_argument("--group-fixed", type=int, default=16, help="small shares: the per-frame cost of a group in lane equivalents (sizes the groups so that the engines finish together)")
     ap.add_argument("--refill", type=int, default=1, help="1: a share of more utterances than lanes is ONE queue per engine, a lane takes the next utterance when its own has ended (s3a_uttdec_decode_queue_dev); 0: groups of similar length, lanes in lock step")
@@ -723,128 +736,115 @@ def main():
                               "identical_to_reference": {"hyp": bool(hyp_ok), "hypseg": bool(seg_ok)}}))
             return
 
-        # ---- per-kernel timing (HIP events on the engines' launch streams around every launch of the profiled frames) ----
-        # ALONE: one group of one engine with the chip to itself (every 4th frame).  IN THE BENCH: one more whole step with
-        # ALL engines running as they do in the timed region, every engine bracketing every 8th frame's launches -- the
-        # kernels stretch when four engines share the chip, and the line's `roofline` describes the run it times.
+        # ---- where the step's device time went (round 5: the engine runs ku_frames) ----
+        # The timed region is TWO kinds of launches per engine and queue part: ku_score_window (every frame of the part scored first)
+        # and ku_frames (the lanes decode the part's utterances from their first to their last frame, taking them from the queue
+        # themselves).  HIP events on the engine's own stream bracket both (s3a_uttdec_last_parts: of the LAST timed step); inside
+        # ku_frames the steps of a frame are clocked by the kernel itself (s3a_uttdec_frame_ticks, workgroup 0 of a lane, summed over
+        # the lane's last utterance).  An engine that kept the launch path (fewer than 96 busy lanes, --variant, S3A_UTT_PERSIST=-1)
+        # reports no parts: the per-launch profile of rounds 2-4 is then taken instead.
         sched = schedule(my_share(0)[0])
+        parts = [dd.ud.last_parts() for dd in decs]
+        persistent = all(p_["n_frames"] > 0 for p_ in parts)
+        phases, ph_frames = {}, 0
+        if persistent:
+            for dd in decs:
+                for z in range(0, NLE, max(1, NLE // 16)):
+                    t_, f_, _, _ = dd.ud.frame_ticks(z)
+                    for k, v in t_.items():
+                        phases[k] = phases.get(k, 0.0) + v
+                    ph_frames += f_
+        # frame statistics (active HMMs, senones scored, word exits per frame): one lock-step decode of the first lanes' utterances
         g0 = sched[0][0][:NLE]
-        prof_alone = {}
-        if not args.plain:
-            dec.ud.set_profile(4)
-            dec.ud.decode_dev([fdev[k] for k in g0], [nfr[k] for k in g0], D4x4)
-            prof_alone = dec.ud.profile()
-            dec.ud.set_profile(0)
+        dec.ud.decode_dev([fdev[k] for k in g0], [nfr[k] for k in g0], D4x4)
         nl0 = len(g0)
         stat = [dec.ud.result(z)["frame_stat"] for z in range(nl0)]
         res0 = dec.ud.result(0)
-        for dd in decs:
-            dd.ud.set_profile(8)
-        run_step(0, sched=sched)
-        lib.check(L.s3a_dev_sync())
-        prof = {}
-        for dd in decs:
-            for k, (us, n) in dd.ud.profile().items():
-                a0, n0 = prof.get(k, (0.0, 0))
-                prof[k] = (a0 + us, n0 + n)
-            dd.ud.set_profile(0)
-        prof = {k: v for k, v in prof.items() if v[1] > 0}
         lanes_bench = float(np.mean([min(NLE, sum(len(g) for g in e_)) for e_ in sched if e_])) if any(sched) else float(nl0)
         lanes_hmm, lanes_sen, lanes_gau, lanes_exit = (float(np.mean([s[:, c].mean() for s in stat])) for c in (1, 2, 3, 7))
         b = dec.b
         S, Sci, D, Cc = b["n_sen"], b["n_ci_sen"], dec.veclen, dec.g.C
         K = max(1, dec.ud.window())
-        SCORING = ("ku_score_window", "ku_gated_cd", "ku_gated_ci", "ku_comsen_max")
-
-        def per_frame_of(pr):
-            return {k: (us / n / (K if k == "ku_score_window" else 1)) for k, (us, n) in pr.items() if n > 0}
-        pf_b, pf_a = per_frame_of(prof), per_frame_of(prof_alone)
-        tot = sum(pf_b.values())
-        kern = {k: {"avg_launch_us": round(prof[k][0] / prof[k][1], 2),
-                    "avg_launch_us_alone": round(prof_alone[k][0] / prof_alone[k][1], 2) if prof_alone.get(k, (0, 0))[1] else None,
-                    "stretch": round((prof[k][0] / prof[k][1]) / (prof_alone[k][0] / prof_alone[k][1]), 2) if prof_alone.get(k, (0, 0))[1] else None,
-                    "us_per_frame": round(v, 2), "share": round(v / tot, 4), "launches_timed": int(prof[k][1])}
-                for k, v in pf_b.items()}
-        dom = max(pf_b, key=lambda k: pf_b[k])
-        dom_us = prof[dom][0] / prof[dom][1]
-        dom_us_alone = prof_alone[dom][0] / prof_alone[dom][1] if prof_alone.get(dom, (0, 0))[1] else None
-        # ALGORITHMIC bytes of one launch (all lanes of an engine): SURVEY.md 8(d).  Look-ahead scoring: the Gaussians'
-        # parameters once per model pass + per (lane, frame) the vector in and every senone's score (+ 1 byte: its best
-        # component) out.  The search: SURVEY's ~84 B of HMM state read + written per active HMM per frame is the budget of
-        # K5-K7 TOGETHER and is credited ONCE per frame to the search as a whole (`search` below); a single search kernel
-        # gets the part of it that kernel has to move: the Viterbi update reads and writes the whole state
-        # (84 B), a propagation / entry / marking kernel reads an exit score + history and writes an entry score + history
-        # + list slot (28 B), the scan and the histogram passes touch one word per HMM (8 B).  The word level: 40 B per
-        # history entry made + 16 B per (exit, predecessor) pair.
-        HMM_BYTES = {"ku_hmm_eval": 84.0, "ku_resolve": 28.0, "ku_emit": 28.0, "ku_enter1": 28.0, "ku_enter2": 28.0, "ku_enter3_mark": 28.0,
-                     "ku_scan": 8.0, "ku_hist_count": 8.0, "ku_hist_sort": 8.0, "ku_weak": 8.0}
-
-        def alg_bytes(k, nl):
-            if k == "ku_score_window":
-                return S * Cc * (2 * D + 2) * 4 + nl * K * (D * 4 + S * 5)
-            if k == "ku_gated_cd":
-                return nl * (S * 1 + lanes_sen * 13.0)
-            if k in ("ku_gated_ci", "ku_comsen_max"):
-                return nl * 4.0 * b["n_comstate"]
-            if k == "ku_emit_word" or k.startswith("ku_wl_"):
-                return nl * (lanes_hmm * 28.0 * (k == "ku_emit_word") + res0["max_cand"] * 16.0 + res0["max_new"] * 40.0)
-            return nl * lanes_hmm * HMM_BYTES.get(k, 28.0)
         pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else {}
-        traffic = pmc.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
-        if traffic is not None and pmc.get("lanes") and dom != "ku_score_window":
-            # the PMC passes ran a smaller engine: the search kernels' traffic is per lane (the look-ahead scoring launch has
-            # the same (lane, frame) slots whatever the lane count: K adapts)
-            traffic = int(traffic * lanes_bench / pmc["lanes"])
-
-        def scoring_roof(us, nl):
-            flops = 4.0 * S * Cc * D * nl * K
-            ach = flops / (us * 1e-6) / 1e12
-            gbs = alg_bytes("ku_score_window", nl) / (us * 1e-6) / 1e9
-            return {"bound": "valu-f64", "achieved": round(ach, 2), "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP64_VEC_PEAK_TFLOPS, 4), "hbm_GBs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "avg_launch_us": round(us, 2), "lane_frame_slots_per_launch": int(nl * K)}
-        if dom == "ku_score_window":
-            roof = dict(scoring_roof(dom_us, lanes_bench), kernel=dom)
-            if dom_us_alone:
-                roof["alone"] = scoring_roof(dom_us_alone, nl0)
+        prof, prof_alone, kern, search, roof, roof_scoring = {}, {}, {}, None, None, None
+        fr_rank = sum(nfr[k] for k in my_share(0)[0])           # (this rank's frames of a step: the parts are this rank's engines')
+        if persistent:
+            score_ms = max(p_["score_ms"] for p_ in parts)
+            frames_ms = max(p_["frames_ms"] for p_ in parts)
+            n_score = sum(p_["n_score"] for p_ in parts)
+            n_kf = sum(p_["n_frames"] for p_ in parts)
+            tot_ms = score_ms + frames_ms
+            # ALGORITHMIC bytes.  Scoring: the Gaussians' parameters once per model pass (a launch scores up to 8192
+            # frames against them) + per frame the vector in and every senone's score and best component out.  The search: ~84 B of
+            # HMM state read + written per active HMM and frame (4 scores + 4 history ids + 3 senone gathers), the frame's selected
+            # senone scores (4 B each), 40 B per history entry made and 16 B per (exit, predecessor) pair at the word level.
+            alg_score = n_score * S * Cc * (2 * D + 2) * 4 + fr_rank * (D * 4 + S * 5)
+            per_lane_frame = 84.0 * lanes_hmm + 4.0 * (lanes_sen + Sci) + 28.0 * lanes_exit
+            alg_frames = fr_rank * per_lane_frame
+            kf_gbs = alg_frames / (frames_ms * 1e-3) / 1e9
+            tr = pmc.get("kernels", {}).get("ku_frames", {})
+            traffic = int(tr["hbm_bytes_per_lane_frame"] * fr_rank / max(n_kf, 1)) if tr.get("hbm_bytes_per_lane_frame") else None
+            flops = 4.0 * S * Cc * D * fr_rank
+            sc_tfl = flops / (score_ms * 1e-3) / 1e12
+            roof = {"kernel": "ku_frames", "bound": "hbm", "achieved": round(kf_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(kf_gbs / HBM_PEAK_GBS, 5), "avg_launch_us": round(1e3 * frames_ms / max(n_kf / len(decs), 1), 1),
+                    "launches_timed": int(n_kf), "traffic": traffic, "traffic_source": pmc.get("source") if traffic is not None else None,
+                    "algorithmic_bytes_per_launch": int(alg_frames / max(n_kf, 1)), "algorithmic_bytes_per_lane_frame": round(per_lane_frame, 1),
+                    "lanes_in_launch": round(lanes_bench, 1), "workgroups_per_lane": parts[0]["cluster"],
+                    "measured": "HIP events on the engine's stream around ku_frames, last timed step",
+                    "note": "the dominant kernel by device time (`kernels`): ONE launch decodes a queue part -- every lane its utterances, frame "
+                            "after frame, the twelve steps of a frame as phases of a persistent 512-thread workgroup (`phases_us_per_lane_frame`). "
+                            "Its steps are bound by the NUMBER of scattered accesses (a gather / scatter costs a cycle per lane in the CU's "
+                            "address path whatever it moves: DESIGN.md 4.1), not by bytes: nowhere near the bandwidth roof; the scoring is "
+                            "float64-VALU-bound (bit-exact mode: no FMA)"}
+            roof_scoring = {"kernel": "ku_score_window", "bound": "valu-f64", "achieved": round(sc_tfl, 2), "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(sc_tfl / FP64_VEC_PEAK_TFLOPS, 4), "hbm_GBs": round(alg_score / (score_ms * 1e-3) / 1e9, 1),
+                            "hbm_frac": round(alg_score / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * score_ms / max(n_score / len(decs), 1), 2),
+                            "launches_timed": int(n_score), "frames_per_launch": round(fr_rank / max(n_score, 1), 1), "share_of_step": round(score_ms / tot_ms, 4),
+                            "note": "every frame of the step scored BEFORE the search (rows [frame][senone] in HBM, 5 B per senone and frame); hub4 "
+                                    "single-frame scoring (one frame per model pass, HBM-bound) is in `scoring.hub4.frame_sync`: north_star's >= 0.60 "
+                                    "of HBM peak is NOT met there at B = 1"}
+            kern = {"ku_frames": {"avg_launch_us": roof["avg_launch_us"], "launches_timed": int(n_kf), "ms_per_step": round(frames_ms, 2), "share": round(frames_ms / tot_ms, 4)},
+                    "ku_score_window": {"avg_launch_us": roof_scoring["avg_launch_us"], "launches_timed": int(n_score), "ms_per_step": round(score_ms, 2),
+                                        "share": round(score_ms / tot_ms, 4)}}
+            search = {"ms_per_step": round(frames_ms, 2), "us_per_lane_frame": round(1e3 * frames_ms * lanes_bench * len(decs) / fr_rank, 2) if fr_rank else None,
+                      "share_of_step": round(frames_ms / tot_ms, 4), "algorithmic_bytes_per_step": int(fr_rank * lanes_hmm * 84.0),
+                      "achieved_GBs": round(fr_rank * lanes_hmm * 84.0 / (frames_ms * 1e-3) / 1e9, 1),
+                      "frac": round(fr_rank * lanes_hmm * 84.0 / (frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": "scattered-access rate (address path of the CUs)",
+                      "active_hmm_updates_per_s": round(lanes_hmm * value, 0),
+                      "active_hmm_updates_per_s_cpu_single_core": round(cpu["active_hmm_per_frame"] * cpu["single_core"], 0) if cpu else None,
+                      "phases_us_per_lane_frame": {k: round(v / max(ph_frames, 1), 2) for k, v in sorted(phases.items()) if k != "in_launch"},
+                      "lane_frames_clocked": int(ph_frames),
+                      "note": "84 B x active HMMs x frames of the step / ku_frames' device time; the phases are what one lane's workgroup spends per frame "
+                              "(two lanes share a CU, so the chip's rate is lanes / that)"}
         else:
-            ab = alg_bytes(dom, lanes_bench)
-            ach = ab / (dom_us * 1e-6) / 1e9
-            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "avg_launch_us": round(dom_us, 2)}
-            if dom_us_alone:
-                aa = alg_bytes(dom, nl0) / (dom_us_alone * 1e-6) / 1e9
-                roof["alone"] = {"achieved": round(aa, 1), "frac": round(aa / HBM_PEAK_GBS, 5), "avg_launch_us": round(dom_us_alone, 2), "lanes_in_launch": nl0}
-        roof.update({"traffic": traffic, "traffic_source": pmc.get("source") if traffic is not None else None,
-                     "algorithmic_bytes_per_launch": int(alg_bytes(dom, lanes_bench)), "launches_timed": int(prof[dom][1]),
-                     "lanes_in_launch": round(lanes_bench, 1), "measured": f"in the bench: all {NE} engines running, HIP events around every launch of every 8th frame",
-                     "note": "the dominant kernel = the largest share of a frame IN THE BENCH (the `kernels` table; `alone` = the same kernel "
-                             "with one engine on the chip).  One launch serves all lanes' frame (ku_score_window: all lanes' next K frames).  "
-                             "The search kernels are chains of scattered 4-byte accesses over a few thousand HMMs per lane: latency-bound, "
-                             "nowhere near a bandwidth roof (DESIGN.md 4); the scoring is float64-VALU-bound (bit-exact mode: no FMA)"})
-        # north_star's second metric is about SCORING: the engine's scoring kernel as a second roofline entry
-        roof_scoring = None
-        if "ku_score_window" in prof:
-            roof_scoring = dict(scoring_roof(prof["ku_score_window"][0] / prof["ku_score_window"][1], lanes_bench), kernel="ku_score_window",
-                                share_of_frame=kern["ku_score_window"]["share"])
-            if prof_alone.get("ku_score_window", (0, 0))[1]:
-                roof_scoring["alone"] = scoring_roof(prof_alone["ku_score_window"][0] / prof_alone["ku_score_window"][1], nl0)
-            roof_scoring["note"] = ("hub4 single-frame scoring (one frame per model pass, HBM-bound) is in `scoring.hub4.frame_sync`: north_star's "
-                                    ">= 0.60 of HBM peak is NOT met there at B = 1; the engine scores K frames of all lanes per model pass instead")
-        # the search as a whole: SURVEY 8(d)'s 84 B per active HMM credited once per frame
-        srch_us = sum(v for k, v in pf_b.items() if k not in SCORING)
-        srch_us_alone = sum(v for k, v in pf_a.items() if k not in SCORING)
-        srch_bytes = lanes_bench * lanes_hmm * 84.0
-        search = {"us_per_frame": round(srch_us, 2), "us_per_frame_alone": round(srch_us_alone, 2),
-                  "share_of_frame": round(srch_us / tot, 4), "kernels": sorted(k for k in pf_b if k not in SCORING),
-                  "algorithmic_bytes_per_frame": int(srch_bytes), "achieved_GBs": round(srch_bytes / (srch_us * 1e-6) / 1e9, 1),
-                  "frac": round(srch_bytes / (srch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "bound": "latency (scattered 4-byte accesses)",
-                  "active_hmm_updates_per_s": round(lanes_hmm * value, 0),
-                  "active_hmm_updates_per_s_cpu_single_core": round(cpu["active_hmm_per_frame"] * cpu["single_core"], 0) if cpu else None,
-                  "note": "84 B x active HMMs x lanes of an engine / the summed duration of the engine's search kernels of one frame, all "
-                          "engines running; active_hmm_updates_per_s = active HMMs per frame x whole-job frames/s"}
+            # the launch path (rounds 2-4): HIP events around every launch of every 8th frame, all engines running
+            for dd in decs:
+                dd.ud.set_profile(8)
+            run_step(0, sched=sched)
+            lib.check(L.s3a_dev_sync())
+            for dd in decs:
+                for k, (us, n) in dd.ud.profile().items():
+                    a0, n0 = prof.get(k, (0.0, 0))
+                    prof[k] = (a0 + us, n0 + n)
+                dd.ud.set_profile(0)
+            prof = {k: v for k, v in prof.items() if v[1] > 0}
+            pf_b = {k: (us / n / (K if k == "ku_score_window" else 1)) for k, (us, n) in prof.items() if n > 0}
+            tot = sum(pf_b.values())
+            kern = {k: {"avg_launch_us": round(prof[k][0] / prof[k][1], 2), "us_per_frame": round(v, 2), "share": round(v / tot, 4), "launches_timed": int(prof[k][1])}
+                    for k, v in pf_b.items()}
+            dom = max(pf_b, key=lambda k: pf_b[k])
+            dom_us = prof[dom][0] / prof[dom][1]
+            ab = lanes_bench * lanes_hmm * 84.0 if dom != "ku_score_window" else S * Cc * (2 * D + 2) * 4 + lanes_bench * K * (D * 4 + S * 5)
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ab / (dom_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ab / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "avg_launch_us": round(dom_us, 2), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(ab), "launches_timed": int(prof[dom][1]), "lanes_in_launch": round(lanes_bench, 1),
+                    "measured": f"the launch path: all {NE} engines running, HIP events around every launch of every 8th frame"}
+            srch_us = sum(v for k, v in pf_b.items() if k not in ("ku_score_window", "ku_gated_cd", "ku_gated_ci", "ku_comsen_max"))
+            search = {"us_per_frame": round(srch_us, 2), "achieved_GBs": round(lanes_bench * lanes_hmm * 84.0 / (srch_us * 1e-6) / 1e9, 1),
+                      "frac": round(lanes_bench * lanes_hmm * 84.0 / (srch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "active_hmm_updates_per_s": round(lanes_hmm * value, 0)}
 
-        # ---- what N = 8 gives a GPU: 128 of the 1024 utterances ----
+        # ---- what N = 8 gives a GPU: 128 of the 1024 utterances (the engine gives a lane a cluster of workgroups then) ----
         proj = None
         if world == 1 and U >= 8 and not args.plain:
             ids8 = shard.shard_contiguous(U, 0, 8)
@@ -858,8 +858,27 @@ def main():
             f8 = sum(nfr[k] for k in ids8)
             proj = {"gpus": 8, "utterances_per_gpu": len(ids8), "groups": [len(g) for e in sch8 for g in e],
                     "frames_per_sec_per_gpu": round(f8 / t8, 1), "implied_strong_scaling_efficiency": round(f8 / t8 / value, 3),
+                    "workgroups_per_lane": decs[0].ud.last_parts()["cluster"],
                     "note": "one GPU decoding rank 0's share of an 8-rank run of the same batch (hypotheses included, no gather): "
-                            "fewer lanes in flight per GPU fill the chip less"}
+                            "fewer utterances than workgroup slots, so a lane is a cluster of workgroups with a counter barrier between the frame's steps"}
+
+        # ---- configs[2]: ONE utterance alone (an engine of one lane: the frame as launches -- below 96 lanes they beat ku_frames) ----
+        single = None
+        if world == 1 and not args.plain:
+            one = bundle.Decoder(bpath, 1, precision=lib.GMM_FAST if args.fast else lib.GMM_EXACT, cand_cap=args.cand_cap, max_frames=max(nfr) + 8)
+            k1 = max(range(U), key=lambda k: nfr[k])
+            one.ud.decode_dev([fdev[k1]], [nfr[k1]], D4x4)
+            t1 = time.perf_counter()
+            ms1 = one.ud.decode_dev([fdev[k1]], [nfr[k1]], D4x4)
+            t1 = time.perf_counter() - t1
+            h1 = one.hyp_var(0, utts[k1], k1)
+            same = None
+            if k1 < n_chk:
+                same = one.format_var(*h1)[0] == ref[0].splitlines(keepends=True)[k1]
+            single = {"frames": nfr[k1], "frames_per_sec": round(nfr[k1] / t1, 1), "xRT": round(nfr[k1] / t1 / 100.0, 1), "us_per_frame_device": round(1e3 * ms1 / nfr[k1], 2),
+                      "path": "launches" if one.ud.last_parts()["n_frames"] == 0 else "ku_frames", "identical_to_reference": same,
+                      "note": "configs[2]: the batch's longest utterance decoded alone by a one-lane engine, host call to hypothesis (wall clock)"}
+            del one
 
         res = {
             "metric": "decoded_frames_per_sec (full mode-4 decode, hub4-shaped CD-GMM 6144x8x39 + 20k-word lextrees + trigram; xRT = value/100/n_gpus)",
@@ -891,6 +910,8 @@ def main():
             "roofline_scoring": roof_scoring,
             "search": search,
             "kernels": kern,
+            "single_utterance": single,
+            "rank_devices": [0 if rehearsal else r_ for r_ in range(world)],
         }
         if weak:
             res["weak_scaling"] = weak

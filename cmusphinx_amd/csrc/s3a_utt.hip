@@ -2867,6 +2867,9 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     /* wide beams (thousands of word exits, 10^5..10^6 (exit, predecessor) candidates per frame): the word level's
      * candidate phases run chip-wide as their own launches; opts->big_wl = 0 / 1 overrides */
     ud->big_wl = O.big_wl >= 0 ? (O.big_wl != 0) : (cfg->maxhmmpf >= 50000 && maxn >= 50000);
+    /* (wide beams keep the round-3 SWEEP in the resolve launch, whose workgroups G_RES_MANY was never meant to size: 128 there, as
+     * before the list-position grids were retuned -- configs[4]: 363 us per launch against 659) */
+    if (ud->big_wl && O.g_res <= 0 && n_lanes >= ud->many) ud->g_res = max(1, min((proto->N + RSBLOCK - 1) / RSBLOCK, 128));
     if (ud->hist_possible && -cfg->hmmbeam / NBIN == 0) {
         s3a_set_error("s3a_uttdec_init: -beam too narrow for histogram pruning (bin width 0)");
         goto fail;
