@@ -2153,11 +2153,17 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
 #undef KF_STAMP
 }
 
+struct KfArgs { UShared S; WLm lm; WDict dict; WPar par; KfJob J; };
+#define KF_ARG_SLOTS 8
+
 template <int NE, bool EXACT>
 __global__ void __launch_bounds__(KF_NT, 4)
-ku_frames(const ULane *__restrict__ lanes, UShared S, WLm lm, WDict dict, WPar par, KfJob J, int32_t n_lanes, int32_t C, int32_t *bar,
+ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t n_lanes, int32_t C, int32_t *bar,
           int32_t weak_possible)
 {
+    /* (what every lane shares arrives through memory, not as ~300 words of kernel arguments the compiler then tries to keep in
+     * registers for the whole frame loop: SGPR spills 1 493 -> 647, VGPR spills 342 -> 248, scratch 524 -> 308 B per lane) */
+    const UShared &S = A->S; const WLm &lm = A->lm; const WDict &dict = A->dict; const WPar &par = A->par; const KfJob &J = A->J;
     __shared__ KfSh sh;
     /* the lane and this workgroup's place in its cluster: a cluster's workgroups share an XCD */
     int32_t z, r;
@@ -2559,6 +2565,8 @@ struct s3a_uttdec_s {
     int32_t kf_last_c;          /* workgroups per lane of the last launch (diagnostics) */
     int32_t kf_counted;         /* this engine is counted in g_kf_live */
     int32_t *d_kfnext;          /* [16 + n_lanes] the queue's counter | what a lane's first workgroup took */
+    void *d_kfargs, *h_kfargs;  /* [KF_ARG_SLOTS] KfArgs: ku_frames' shared arguments (device / pinned) */
+    int32_t kf_arg_at;
     /* SCORES FIRST: every frame's senone scores of a call (ku_frames, KF_STATIC / KF_QUEUE) */
     int32_t *sb_scores; uint8_t *sb_bests; size_t sb_rows_cap;
     UwGroup *sb_gdesc_d, *sb_gdesc_h; size_t sb_g_cap;
@@ -2666,6 +2674,8 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     ud->kf_evs.clear();
     if (ud->d_kfbar) (void)hipFree(ud->d_kfbar);
     if (ud->d_kfnext) (void)hipFree(ud->d_kfnext);
+    if (ud->d_kfargs) (void)hipFree(ud->d_kfargs);
+    if (ud->h_kfargs) (void)hipHostFree(ud->h_kfargs);
     if (ud->sb_scores) (void)hipFree(ud->sb_scores);
     if (ud->sb_bests) (void)hipFree(ud->sb_bests);
     if (ud->sb_gdesc_d) (void)hipFree(ud->sb_gdesc_d);
@@ -2955,12 +2965,14 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->S.fgbase = ud->d_fgbase;
     ud->use_graph = O.graph != 0 && !ud->big_wl && !O.framecheck;
     ud->persist = O.persist >= 0 && !ud->use_graph && !O.framecheck ? (O.persist > 0 ? 2 : 1) : 0;     /* (2: whatever the lane count) */
-    ud->kf_cluster_opt = O.cluster; ud->kf_last_c = 0; ud->kf_slots = 0; ud->d_kfbar = NULL; ud->kf_counted = 0; ud->d_kfnext = NULL;
+    ud->kf_cluster_opt = O.cluster; ud->kf_last_c = 0; ud->kf_slots = 0; ud->d_kfbar = NULL; ud->kf_counted = 0; ud->d_kfnext = NULL; ud->d_kfargs = ud->h_kfargs = NULL; ud->kf_arg_at = 0;
     ud->sb_scores = NULL; ud->sb_bests = NULL; ud->sb_rows_cap = 0; ud->sb_gdesc_d = ud->sb_gdesc_h = NULL; ud->sb_g_cap = 0;
     ud->sb_row0_d = ud->sb_row0_h = NULL; ud->sb_row0_cap = 0;
     ud->kf_ev_n = ud->kf_n_score = ud->kf_n_frames = 0; ud->kf_score_ms = ud->kf_frames_ms = 0.0;
     if (ud->persist) {
         DM(ud->d_kfnext, (size_t)(16 + n_lanes) * 4);
+        DM(ud->d_kfargs, sizeof(KfArgs) * KF_ARG_SLOTS);
+        if (hipHostMalloc(&ud->h_kfargs, sizeof(KfArgs) * KF_ARG_SLOTS) != hipSuccess) { s3a_set_error("s3a_uttdec_init: pinned allocation failed"); goto fail; }
         DM(ud->d_kfbar, (size_t)n_lanes * 4);
         if (hipMemset(ud->d_kfbar, 0, (size_t)n_lanes * 4) != hipSuccess) goto fail;
         if (ud->device >= 0 && ud->device < 64) { g_kf_live[ud->device]++; ud->kf_counted = 1; }
@@ -3406,7 +3418,13 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
     ud->kf_last_c = C;
     const int32_t grid = C == 1 ? n : 8 * C * lanes_per_xcd;
     if (C > 1) HIPCHK(hipMemsetAsync(ud->d_kfbar, 0, (size_t)n * 4, ud->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(KF_NT), 0, ud->stream, ud->d_lanes, ud->S, ud->lm->d, ud->dict, ud->par, J, n, C,
+    /* the launch's shared arguments: a slot of a small ring (pinned + device) so that launches may queue up behind one another */
+    if (ud->kf_arg_at > 0 && ud->kf_arg_at % KF_ARG_SLOTS == 0) HIPCHK(hipStreamSynchronize(ud->stream));
+    KfArgs *ha = (KfArgs *)ud->h_kfargs + ud->kf_arg_at % KF_ARG_SLOTS, *da = (KfArgs *)ud->d_kfargs + ud->kf_arg_at % KF_ARG_SLOTS;
+    ud->kf_arg_at++;
+    ha->S = ud->S; ha->lm = ud->lm->d; ha->dict = ud->dict; ha->par = ud->par; ha->J = J;
+    HIPCHK(hipMemcpyAsync(da, ha, sizeof(KfArgs), hipMemcpyHostToDevice, ud->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(KF_NT), 0, ud->stream, ud->d_lanes, (const KfArgs *)da, n, C,
                        ud->d_kfbar, ud->weak_possible);
     HIPCHK(hipGetLastError());
     return S3A_OK;
