@@ -662,7 +662,7 @@ def main():
         try:
             sys.stdout.flush()
             os.dup2(2, 1)                   # (RCCL prints a version banner to C stdout: keep stdout to the ONE JSON line)
-            cgather = lib.Gather(rank, world, os.path.join(d, "rccl-id"))
+            cgather = lib.Gather(rank, world, os.path.join(d, "rccl-id"), run_id=int(os.environ.get("MASTER_PORT", "0")) or os.getpid())
         except lib.S3AError as e:
             if world > 1:
                 raise SystemExit(f"bench.py: the C exchange could not start on rank {rank}: {e}")

@@ -132,9 +132,35 @@ process_start_epoch(void)
     return btime && hz > 0 ? (double)btime + (double)ticks / (double)hz : 0.0;
 }
 
+/* how old (against this process's start) a rendezvous file WITHOUT a run id may be and still count as this run's */
+#define S3A_GATHER_FRESH_S 120.0
+
+static s3a_gather_t *gather_init(int32_t rank, int32_t world, const char *rendezvous, unsigned long long run_id);
+
 extern "C" s3a_gather_t *
 s3a_gather_init(int32_t rank, int32_t world, const char *rendezvous)
 {
+    return gather_init(rank, world, rendezvous, 0ull);
+}
+
+extern "C" s3a_gather_t *
+s3a_gather_init_run(int32_t rank, int32_t world, const char *rendezvous, unsigned long long run_id)
+{
+    if (run_id == 0ull) { s3a_set_error("s3a_gather_init_run: the run id must not be 0"); return NULL; }
+    return gather_init(rank, world, rendezvous, run_id);
+}
+
+static s3a_gather_t *
+gather_init(int32_t rank, int32_t world, const char *rendezvous_arg, unsigned long long run_id)
+{
+    /* with a run id the file is <rendezvous>.<run id>: another run's file has another name, and what the file holds is checked
+     * against the id; no clock is compared (ranks may be born at any time, on hosts whose clocks differ) */
+    char rdv_run[4200];
+    const char *rendezvous = rendezvous_arg;
+    if (run_id != 0ull && rendezvous_arg && *rendezvous_arg) {
+        snprintf(rdv_run, sizeof rdv_run, "%s.%016llx", rendezvous_arg, run_id);
+        rendezvous = rdv_run;
+    }
     if (rank < 0 || world <= 0 || rank >= world || (world > 1 && (!rendezvous || !*rendezvous))) { s3a_set_error("s3a_gather_init: bad arguments"); return NULL; }
     s3a_gather_t *g = new s3a_gather_s();
     g->lib = NULL; g->comm = NULL; g->stream = NULL; g->rank = rank; g->world = world; g->host_staging = 0;
@@ -154,24 +180,34 @@ s3a_gather_init(int32_t rank, int32_t world, const char *rendezvous)
         int r = g->get_id(&id);
         if (r != 0) { s3a_set_error("ncclGetUniqueId failed: %s", g->errstr ? g->errstr(r) : "?"); s3a_gather_free(g); return NULL; }
         if (world > 1) {
-            char tmp[4096];
+            char tmp[4300];
             snprintf(tmp, sizeof tmp, "%s.tmp", rendezvous);
+            (void)unlink(rendezvous);           /* (whatever an earlier run of the same name left) */
             FILE *fp = fopen(tmp, "wb");
-            if (!fp || fwrite(&id, sizeof id, 1, fp) != 1 || fclose(fp) != 0 || rename(tmp, rendezvous) != 0) {
+            if (!fp || (run_id != 0ull && fwrite(&run_id, sizeof run_id, 1, fp) != 1) || fwrite(&id, sizeof id, 1, fp) != 1 || fclose(fp) != 0
+                || rename(tmp, rendezvous) != 0) {
                 s3a_set_error("s3a_gather_init: cannot write the rendezvous file %s", rendezvous); s3a_gather_free(g); return NULL;
             }
         }
     }
     else {
-        /* a file left by a crashed earlier run would hold a dead communicator's id: only a file written after this
-         * process (and therefore this run: the launcher starts the ranks together) started is taken */
-        const double born = process_start_epoch();
+        /* a file left by a crashed earlier run would hold a dead communicator's id.  With a run id: the file's name and first
+         * word carry it (the launcher hands every rank of a run the same id -- MASTER_PORT, a job id -- and a new one to the next
+         * run).  Without: only a file not older than S3A_GATHER_FRESH_S before this process started is taken -- the ranks of a
+         * run must then start within that window of one another, on one host clock (s3a_gather_init's contract) */
+        const double born = run_id != 0ull ? 0.0 : process_start_epoch();
         int tries = 0;
         for (;; tries++) {
             struct stat sb;
-            if (stat(rendezvous, &sb) == 0 && (double)sb.st_mtime + 1.0 >= born) {
+            if (stat(rendezvous, &sb) == 0 && (run_id != 0ull || born == 0.0 || (double)sb.st_mtime + S3A_GATHER_FRESH_S >= born)) {
                 FILE *fp = fopen(rendezvous, "rb");
-                if (fp) { const size_t k = fread(&id, sizeof id, 1, fp); fclose(fp); if (k == 1) break; }
+                if (fp) {
+                    unsigned long long got = 0ull;
+                    const bool head = run_id == 0ull || (fread(&got, sizeof got, 1, fp) == 1 && got == run_id);
+                    const size_t k = head ? fread(&id, sizeof id, 1, fp) : 0;
+                    fclose(fp);
+                    if (k == 1) break;
+                }
             }
             if (tries > 6000) { s3a_set_error("s3a_gather_init: rank %d waited 10 minutes for a fresh %s", rank, rendezvous); s3a_gather_free(g); return NULL; }
             usleep(100000);

@@ -50,6 +50,7 @@ s3a_set_variants(const s3a_variants_t *v)
     return S3A_OK;
 }
 const s3a_variants_t *s3a_variants(void) { return &g_variants; }
+void s3a_get_variants(s3a_variants_t *v) { if (v) *v = g_variants; }
 
 const char *
 s3a_last_error(void)
@@ -1330,6 +1331,26 @@ lat_put(lat_out_t *o, const char *fmt, ...)
     if (n > 0) o->len += n;
 }
 
+/* a lattice's indices before they are used: initial / final node, every link's ends, word ids not negative (the caller's wordstr /
+ * basewid arrays are as long as its dictionary: that bound is the caller's) */
+static int32_t
+lat_check(const s3a_lat_info_t *info, const s3a_lat_node_t *nodes, const s3a_lat_link_t *links, const char *who)
+{
+    int32_t i;
+    if (info->n_nodes < 0 || info->n_links < 0 || (info->n_nodes > 0 && (info->initial < 0 || info->initial >= info->n_nodes || info->final < 0 || info->final >= info->n_nodes))) {
+        s3a_set_error("%s: initial / final node outside the lattice's %d nodes", who, info->n_nodes);
+        return S3A_EINVAL;
+    }
+    for (i = 0; i < info->n_nodes; i++)
+        if (nodes[i].wid < 0) { s3a_set_error("%s: node %d has word id %d", who, i, nodes[i].wid); return S3A_EINVAL; }
+    for (i = 0; i < info->n_links; i++)
+        if (links[i].from < 0 || links[i].from >= info->n_nodes || links[i].to < 0 || links[i].to >= info->n_nodes) {
+            s3a_set_error("%s: link %d joins nodes %d -> %d of %d", who, i, links[i].from, links[i].to, info->n_nodes);
+            return S3A_EINVAL;
+        }
+    return S3A_OK;
+}
+
 int64_t
 s3a_lattice_format_s3(const char *header, const s3a_lat_info_t *info, const s3a_lat_node_t *nodes,
                       const s3a_lat_link_t *links, const char *const *wordstr, char *buf, int64_t cap)
@@ -1337,6 +1358,7 @@ s3a_lattice_format_s3(const char *header, const s3a_lat_info_t *info, const s3a_
     lat_out_t o;
     int32_t i;
     if (!info || !nodes || (!links && info->n_links > 0) || !wordstr || cap < 0 || (cap > 0 && !buf)) { s3a_set_error("s3a_lattice_format_s3: bad arguments"); return S3A_EINVAL; }
+    if (lat_check(info, nodes, links, "s3a_lattice_format_s3") != S3A_OK) return S3A_EINVAL;
     o.buf = buf; o.cap = cap; o.len = 0;
     if (header) lat_put(&o, "%s", header);
     lat_put(&o, "Frames %d\n#\n", info->n_frames);
@@ -1362,6 +1384,7 @@ s3a_lattice_format_htk(const char *header, const s3a_htk_opts_t *h, const s3a_la
         s3a_set_error("s3a_lattice_format_htk: bad arguments");
         return S3A_EINVAL;
     }
+    if (lat_check(info, nodes, links, "s3a_lattice_format_htk") != S3A_OK) return S3A_EINVAL;
     o.buf = buf; o.cap = cap; o.len = 0;
     lat_put(&o, "# Lattice generated by Sphinx-III\n");
     if (header) lat_put(&o, "%s", header);

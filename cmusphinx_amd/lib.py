@@ -211,6 +211,8 @@ _SIGS = {
     "s3a_uttdec_enable_pheur": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_uttdec_selfcheck": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_gather_init": (C.c_void_p, [C.c_int32, C.c_int32, C.c_char_p]),
+    "s3a_get_variants": (None, [C.c_void_p]),
+    "s3a_gather_init_run": (C.c_void_p, [C.c_int32, C.c_int32, C.c_char_p, C.c_uint64]),
     "s3a_gather_free": (None, [C.c_void_p]),
     "s3a_gather_hyps": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_gather_result": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -1364,9 +1366,13 @@ def set_variants(**kw):
 class Gather:
     """s3a_gather_t: the end-of-batch exchange of (header, words) hypotheses over RCCL, in C"""
 
-    def __init__(self, rank, world, rendezvous=""):
+    def __init__(self, rank, world, rendezvous="", run_id=0):
+        """run_id != 0: s3a_gather_init_run (the rendezvous file carries the launcher's run id; no clocks compared)"""
         self.L = load()
-        self.h = self.L.s3a_gather_init(int(rank), int(world), rendezvous.encode())
+        if run_id:
+            self.h = self.L.s3a_gather_init_run(int(rank), int(world), rendezvous.encode(), int(run_id))
+        else:
+            self.h = self.L.s3a_gather_init(int(rank), int(world), rendezvous.encode())
         if not self.h:
             raise S3AError(_err(self.L))
 

@@ -893,8 +893,18 @@ int32_t s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int
  * `rendezvous` (rank 0 writes ncclGetUniqueId's bytes; one node, one file system).  words = the local utterances' words
  * back to back (status != 0: none).  n_total = utterances of the whole batch: each index exactly once, else an error.
  */
+/* (A test double: when the loaded librccl.so exports the symbol `s3a_comm_takes_host_pointers` -- tests/mock_rccl.c does, RCCL does not --
+ * the staging buffers handed to ncclAllGather are host memory, so that the exchange's arithmetic with world > 1 can run on a box
+ * without GPUs: tests/test_gather_mock.py.  No product path sets it.) */
 typedef struct s3a_gather_s s3a_gather_t;
 s3a_gather_t *s3a_gather_init(int32_t rank, int32_t world, const char *rendezvous);
+/* The same with a RUN ID (any non-zero number the launcher gives every rank of one run and not to the next: MASTER_PORT, a job id):
+ * the file is `rendezvous`.<run id>, its first word is the id, rank 0 removes what an earlier run of the same name left, and no
+ * clock is compared -- ranks may start at any time after one another (staggered or containerised launches, a restarted worker,
+ * a shared file system whose server keeps another time).  s3a_gather_init without an id recognises a stale file by its age: it
+ * takes a file written no longer than 120 s before the calling process started, so the ranks of a run must start within that
+ * window of one another and see one clock; prefer s3a_gather_init_run. */
+s3a_gather_t *s3a_gather_init_run(int32_t rank, int32_t world, const char *rendezvous, unsigned long long run_id);
 void s3a_gather_free(s3a_gather_t *g);
 int32_t s3a_gather_hyps(s3a_gather_t *g, int32_t n_local, const s3a_hyp_header_t *hdr, const s3a_hyp_word_t *words,
                         int32_t n_total);
@@ -963,8 +973,9 @@ int32_t s3a_uttdec_lattice(s3a_uttdec_t *ud, int32_t lane, s3a_lat_info_t *info,
  * wordstr[wid] = dict_wordstr.  HTK: basewid[wid] = dict_basewid, n_alt[basewid] = pronunciations of the base word
  * (the dict_nextalt chain), logbase / log_shift of the decoder's logmath (a = ascr * ln(base)), lm_lw / lm_wip = lm_t.lw /
  * lm_t.wip for lm_rawscore (lm.c:2172-2178; have_lm = 0: no LM, l = lscr as it is), lmname or NULL, opt_lw / opt_wip = the
- * -lw / -wip arguments as float32, frate = -frate.  Return: the bytes the text needs (more than cap: nothing usable was
- * written), < 0 on bad arguments.
+ * -lw / -wip arguments as float32, frate = -frate.  Return: the bytes the text needs WITHOUT the terminating NUL; the buffer holds the
+ * whole text only when cap > that (a return >= cap: truncated -- call again with a larger buffer); < 0 on bad arguments (a lattice
+ * whose initial / final node or link ends lie outside its nodes, negative word ids).
  */
 int64_t s3a_lattice_format_s3(const char *header, const s3a_lat_info_t *info, const s3a_lat_node_t *nodes,
                               const s3a_lat_link_t *links, const char *const *wordstr, char *buf, int64_t cap);
@@ -1158,6 +1169,7 @@ typedef struct {
     int32_t ps_score_by_gaussian;   /* pocketsphinx batch scoring: the lane-per-Gaussian kernel (k_ps_cont_slots) instead of lane-per-frame */
 } s3a_variants_t;
 void    s3a_variants_default(s3a_variants_t *v);
+void    s3a_get_variants(s3a_variants_t *v);            /* the variants in force (read-modify-write with s3a_set_variants) */
 int32_t s3a_set_variants(const s3a_variants_t *v);
 
 /* ===================================================================== */

@@ -34,7 +34,9 @@
 #define PSAMD_DESC_T s3a_psfwd_desc_t
 #include "psamd_export.h"
 
-#define PSAMD_MAX_FRAMES 8192       /* frames per utterance the lanes are sized for */
+#define PSAMD_MAX_FRAMES 8192       /* frames per utterance the lanes are sized for unless PSAMD_MAX_FRAMES says otherwise (the reference grows
+                                     * its tables up to 32 767 frames: an utterance beyond the lanes' size ends with an error from step, never
+                                     * silently) */
 
 typedef struct {
     ps_searchfuncs_t vt;            /* the decoder's table with the slots re-pointed; MUST be first */
@@ -45,6 +47,7 @@ typedef struct {
     psamd_pool_t pool;
     s3a_ps_mgau_t *scorer;          /* whole-utterance mode, made on first use */
     int n_lanes;
+    int32 max_frames;
     uint8 *flags;
     uint16 *sp_ssid;
 } amd_search_t;
@@ -59,7 +62,16 @@ amd_build(amd_search_t *b, ngram_search_t *ngs)
     ckd_free(b->flags); ckd_free(b->sp_ssid);
     b->flags = NULL; b->sp_ssid = NULL;
     if (psamd_export(b->ps, ngs, &b->desc, &b->pool) < 0) return -1;
-    if ((b->e = s3a_psfwd_init(&b->desc, b->n_lanes, PSAMD_MAX_FRAMES, 0, 0)) == NULL) {
+    {
+        /* the lanes' capacities from the configuration: frames per utterance (this program's PSAMD_MAX_FRAMES variable, up to the
+         * reference's own limit), backpointer entries per frame from -maxwpf (0: the library's default) */
+        const char *mf = getenv("PSAMD_MAX_FRAMES");
+        int32 max_frames = mf ? atoi(mf) : PSAMD_MAX_FRAMES;
+        if (max_frames < 16) max_frames = 16;
+        if (max_frames > 32767) max_frames = 32767;
+        b->max_frames = max_frames;
+    }
+    if ((b->e = s3a_psfwd_init(&b->desc, b->n_lanes, b->max_frames, 0, 0)) == NULL) {
         E_ERROR("s3a_psfwd_init: %s\n", s3a_last_error());
         return -1;
     }
@@ -73,11 +85,19 @@ amd_start(ps_search_t *search)
 {
     ngram_search_t *ngs = (ngram_search_t *)search;
     amd_search_t *b = BINDING(search);
-    int32 i, k;
+    int32 i, k, n_words = ps_search_n_words(ngs);
     ngs->done = FALSE;
     ngram_model_flush(ngs->lmset);
     ckd_free(search->hyp_str);
     search->hyp_str = NULL;
+    /* what ngram_fwdtree_start resets of the decoder's own structures (ngram_search_fwdtree.c:472-494): a partial result asked for
+     * before this utterance's table has come back must not see the last utterance's */
+    memset(&ngs->st, 0, sizeof(ngs->st));
+    ngs->bpidx = 0; ngs->bss_head = 0;
+    for (i = 0; i < n_words; ++i) ngs->word_lat_idx[i] = NO_BP;
+    ngs->n_active_chan[0] = ngs->n_active_chan[1] = 0;
+    ngs->n_active_word[0] = ngs->n_active_word[1] = 0;
+    ngs->best_score = 0; ngs->renormalized = 0; ngs->n_frame = 0;
     /* the single-phone words' channels are shared with the host's fwdflat pass, which leaves its ids in them */
     for (i = 0; i < b->desc.n_1ph; i++) {
         root_chan_t *r = (root_chan_t *)ngs->word_chan[b->desc.sp_wid[i]];
@@ -161,6 +181,39 @@ amd_finish(ps_search_t *search)
     return b->orig->finish(search);
 }
 
+/* partial results (ps_get_hyp / ps_seg_iter / ps_get_prob between ps_start_utt and ps_end_utt: normal live use): the device's table
+ * as it stands comes into the decoder's structures first, then the reference's own code reads it (ngram_search.c:770-) */
+static int
+amd_pull_partial(ps_search_t *search)
+{
+    ngram_search_t *ngs = (ngram_search_t *)search;
+    amd_search_t *b = BINDING(search);
+    const int32 cf = ps_search_acmod(search)->output_frame;
+    if (ngs->done || cf <= 0) return 0;
+    return amd_table_to_ngs(b, ngs, 0, cf);
+}
+
+static char const *
+amd_hyp(ps_search_t *search, int32 *out_score)
+{
+    if (amd_pull_partial(search) < 0) return NULL;
+    return BINDING(search)->orig->hyp(search, out_score);
+}
+
+static int32
+amd_prob(ps_search_t *search)
+{
+    if (amd_pull_partial(search) < 0) return 0;
+    return BINDING(search)->orig->prob(search);
+}
+
+static ps_seg_t *
+amd_seg_iter(ps_search_t *search, int32 *out_score)
+{
+    if (amd_pull_partial(search) < 0) return NULL;
+    return BINDING(search)->orig->seg_iter(search, out_score);
+}
+
 static int
 amd_reinit(ps_search_t *search, dict_t *dict, dict2pid_t *d2p)
 {
@@ -197,7 +250,7 @@ ps_amd_search_install(ps_decoder_t *ps, int n_lanes)
     b->n_lanes = n_lanes > 0 ? n_lanes : 1;
     if (getenv("PSAMD_OVERLAP")) {     /* (this program's switch; the library takes it as a field of s3a_variants_t) */
         s3a_variants_t v;
-        s3a_variants_default(&v);
+        s3a_get_variants(&v);           /* (the other variants stay as the host set them) */
         v.ps_overlap = 1;
         s3a_set_variants(&v);
     }
@@ -205,6 +258,7 @@ ps_amd_search_install(ps_decoder_t *ps, int n_lanes)
     b->orig = ps->search->vt;
     b->vt = *b->orig;
     b->vt.start = amd_start; b->vt.step = amd_step; b->vt.finish = amd_finish; b->vt.reinit = amd_reinit; b->vt.free = amd_free;
+    b->vt.hyp = amd_hyp; b->vt.prob = amd_prob; b->vt.seg_iter = amd_seg_iter;
     ps->search->vt = &b->vt;
     E_INFO("first pass served by %s: %d lanes, %d roots, %d interior channels, %d single-phone words\n", s3a_version(), b->n_lanes,
            b->desc.n_root, b->desc.n_nonroot, b->desc.n_1ph);

@@ -931,7 +931,13 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
         s3a_gather_t *gt;
         snprintf(rdv, sizeof rdv, "%s.rccl-id", g_final[0][0] ? g_final[0] : g_final[1]);
         if (g_rank == 0) remove(rdv);
-        if ((gt = s3a_gather_init(g_rank, g_world, rdv)) == NULL) die("s3a_gather_init");
+        /* (a launcher that hands its ranks a run id -- MASTER_PORT, S3A_RUN_ID -- gets the rendezvous that compares no clocks) */
+        {
+            const char *rid = getenv("S3A_RUN_ID") ? getenv("S3A_RUN_ID") : getenv("MASTER_PORT");
+            const unsigned long long run_id = rid ? strtoull(rid, NULL, 10) : 0ull;
+            gt = run_id ? s3a_gather_init_run(g_rank, g_world, rdv, run_id) : s3a_gather_init(g_rank, g_world, rdv);
+        }
+        if (gt == NULL) die("s3a_gather_init");
         if (s3a_gather_hyps(gt, g_rec_n, g_rec_hdr, g_rec_words, g_rank_total) != S3A_OK) die("s3a_gather_hyps");
         if (g_rank == 0) {
             dict_t *dict = kbcore_dict(kbc);

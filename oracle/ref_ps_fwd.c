@@ -92,6 +92,7 @@ static const arg_t defn[] = {
     { "-batch", ARG_INT32, "0", "Utterances per device batch (AMD backend)" },
     { "-trace", ARG_STRING, NULL, "Per-frame trace of the first pass" },
     { "-queue", ARG_BOOLEAN, "no", "AMD backend: the whole control file as ONE queue over the -batch lanes" },
+    { "-partial", ARG_INT32, "0", "Ask for a partial hypothesis every N frames (written to <-hyp>.partial)" },
     CMDLN_EMPTY_OPTION
 };
 static int g_batch;
@@ -163,7 +164,8 @@ main(int argc, char **argv)
 {
     cmd_ln_t *config;
     ps_decoder_t *ps;
-    FILE *ctl, *out, *segfh = NULL, *bpfh = NULL;
+    FILE *ctl, *out, *segfh = NULL, *bpfh = NULL, *partfh = NULL;
+    int32 partial = 0;
     char line[4096], path[4096];
     int fresh, adcin;
     if ((config = cmd_ln_parse_r(NULL, defn, argc, argv, TRUE)) == NULL) return 2;
@@ -177,6 +179,8 @@ main(int argc, char **argv)
         E_FATAL("ctl/hyp\n");
     if (cmd_ln_str_r(config, "-hypseg")) segfh = fopen(cmd_ln_str_r(config, "-hypseg"), "w");
     if (cmd_ln_str_r(config, "-bpdump")) bpfh = fopen(cmd_ln_str_r(config, "-bpdump"), "wb");
+    partial = cmd_ln_int32_r(config, "-partial");
+    if (partial > 0) { char pp[4200]; snprintf(pp, sizeof pp, "%s.partial", cmd_ln_str_r(config, "-hyp")); partfh = fopen(pp, "w"); }
 #if defined(PS_BACKEND_AMD)
     if (g_batch > 0) {
         /* whole utterances on the device, g_batch lanes at a time */
@@ -248,6 +252,18 @@ main(int argc, char **argv)
             mfcc_t **cep = read_mfc(path, &nfr, feat_cepsize(ps->acmod->fcb));
             clock_gettime(CLOCK_MONOTONIC, &ts0);
             ps_start_utt(ps, uttid);
+            if (partial > 0 && partfh) {
+                /* live use: the cepstra in blocks, a partial result between them (ps_get_hyp while the utterance is open) */
+                int32 at;
+                for (at = 0; at < nfr; at += partial) {
+                    int32 sc;
+                    const char *ph, *pid;
+                    ps_process_cep(ps, cep + at, nfr - at < partial ? nfr - at : partial, FALSE, FALSE);
+                    ph = ps_get_hyp(ps, &sc, &pid);
+                    fprintf(partfh, "%s %d: %s (%d)\n", uttid, ps->acmod->output_frame, ph ? ph : "", sc);
+                }
+            }
+            else
             ps_process_cep(ps, cep, nfr, FALSE, TRUE);
             ps_end_utt(ps);
             clock_gettime(CLOCK_MONOTONIC, &ts1);
@@ -266,6 +282,7 @@ main(int argc, char **argv)
     fclose(out);
     if (segfh) fclose(segfh);
     if (bpfh) fclose(bpfh);
+    if (partfh) fclose(partfh);
     ps_free(ps);
     return 0;
 }

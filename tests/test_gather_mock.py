@@ -18,7 +18,10 @@ import numpy as np
 sys.path.insert(0, sys.argv[1])
 from cmusphinx_amd import lib
 rank, world, rdv, n_total, drop = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
-g = lib.Gather(rank, world, rdv)
+run_id = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+if len(sys.argv) > 8 and rank > 0:
+    import time; time.sleep(float(sys.argv[8]))           # a rank born late
+g = lib.Gather(rank, world, rdv, run_id=run_id)
 for rnd in range(2):                       # twice: the staging buffers are reused (and must grow in round 2)
     recs = []
     for u in range(n_total):
@@ -49,10 +52,11 @@ def mock_dir(tmp_path_factory):
     return d
 
 
-def run_world(mock_dir, tmp_path, world, n_total, drop=0):
+def run_world(mock_dir, tmp_path, world, n_total, drop=0, run_id=0, late=0.0):
     rdv = str(tmp_path / "rccl-id")
     env = dict(os.environ, LD_LIBRARY_PATH=f"{mock_dir}:" + os.environ.get("LD_LIBRARY_PATH", ""), MOCK_RCCL_DIR=str(tmp_path))
-    ps = [subprocess.Popen([sys.executable, "-c", WORKER, ROOT, str(r), str(world), rdv, str(n_total), str(drop)], env=env,
+    extra = [str(run_id)] + ([str(late)] if late else [])
+    ps = [subprocess.Popen([sys.executable, "-c", WORKER, ROOT, str(r), str(world), rdv, str(n_total), str(drop)] + extra, env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = [p.communicate(timeout=120) for p in ps]
     assert all(p.returncode == 0 for p in ps), "\n".join(o[1][-800:] for o in outs)
@@ -91,3 +95,15 @@ def test_stale_rendezvous_file_is_ignored(mock_dir, tmp_path):
     os.utime(rdv, (1000000000, 1000000000))           # left behind by a run long ago
     got = run_world(mock_dir, tmp_path, 2, 9)
     assert got[0]["err"] is None and got[0]["res"] == expected(9, 0)
+
+
+def test_run_id_rendezvous_compares_no_clocks(mock_dir, tmp_path):
+    """s3a_gather_init_run: a rank born seconds after rank 0 wrote the file still takes it (the age test of the id-less form would
+    have been at its limit with the 1 s window of round 4); a file of ANOTHER run id next to it, and an old file under the run's own
+    name (rank 0 removes it before it writes), are not mistaken for it"""
+    (tmp_path / "rccl-id.00000000000004d2").write_bytes(b"y" * 136)          # run 1234's, left behind
+    (tmp_path / ("rccl-id.%016x" % 777)).write_bytes(b"z" * 136)             # this run's name, a crashed earlier attempt
+    os.utime(tmp_path / ("rccl-id.%016x" % 777), (1000000000, 1000000000))
+    got = run_world(mock_dir, tmp_path, 2, 11, run_id=777, late=2.5)
+    assert got[0]["err"] is None and got[0]["res"] == expected(11, 0)
+    assert got[1]["err"] is None and got[1]["res"] == expected(11, 1)

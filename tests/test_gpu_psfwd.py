@@ -79,3 +79,15 @@ def test_mandarin_trigram_tables(tmp_path, extra):
 def test_mandarin_default_passes(tmp_path):
     r, a = pair(P.zh_args(tmp_path, ("goforward",)), tmp_path)
     P.assert_same(r, a, tables=False)
+
+
+def test_partial_results_while_the_utterance_is_open(tmp_path):
+    """live use: ps_get_hyp between ps_start_utt and ps_end_utt (the cepstra in blocks of 25 frames).  The binding resets the
+    decoder's own table at start and brings the device's table over before the reference's ngram_search_hyp reads it: every
+    partial string and score, and the final results, are the unmodified decoder's -- also for the SECOND utterance of a
+    decoder, which must not see the first one's table."""
+    args = P.cont_args(tmp_path) + P.FIRST_PASS_ONLY + ["-partial", "25"]
+    r, a = pair(args, tmp_path)
+    P.assert_same(r, a)
+    rp, ap = open(str(tmp_path / "ref.match.partial")).read(), open(str(tmp_path / "amd.match.partial")).read()
+    assert rp.count("\n") > 100 and rp == ap
