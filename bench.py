@@ -415,7 +415,7 @@ def ps_fwdtree_leg(t, lanes, n_cpu=128, n_proc=16):
     return out
 
 
-def launch_ranks(n):
+def launch_ranks(n, cmd=None):
     """`python bench.py --gpus N` without a launcher around it: N ranks of this very command, one per GPU, the way the reference shards a
     control file over processes (-ctloffset / -ctlcount, main_decode.c:164-169).  The children find RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT in their environment exactly as under torch.distributed.run; rank 0's stdout (the ONE JSON line) is this
@@ -428,7 +428,7 @@ def launch_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen(cmd if cmd is not None else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     try:

@@ -50,3 +50,20 @@ def test_two_ranks_weak_scaling(tmp_path):
     d = run_bench(tmp_path, 29543, ["--scaling", "weak", "--no-cpu"])
     assert d["scaling"] == "weak" and d["config"]["utterances_per_step"] == 20
     assert d["identical_to_reference"]["hyp"] is True and d["utterances_checked_against_reference"] == 2
+
+
+def test_bench_starts_its_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (round 5): the command re-executes itself as two ranks (here both on
+    GPU 0: S3A_BENCH_ONE_GPU=1) and rank 0 prints the ONE line with n_gpus = 2"""
+    env = dict(os.environ, S3A_BENCH_ONE_GPU="1", TMPDIR=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lanes", "6", "--engines", "2",
+           "--min-group", "2", "--frames", "150", "--utts", "10", "--no-scoring", "--no-cpu", "--no-ps", "--no-wide-beam"]
+    p = subprocess.run(cmd, capture_output=True, text=True, errors="ignore", timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rank_devices"] == [0, 0] and d["identical_to_reference"]["hyp"] is True
+    assert d["config"]["utterances_per_step"] == 10
