@@ -1524,8 +1524,9 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_SPIN_MAX (1 << 21)
 #define KF_MAXC 32
 #define KF_MAXSEG (KF_MAXC * KF_WAVES)
-#define KF_SETS 1024            /* listed parent sets a workgroup takes per pass of the propagation step */
+#define KF_SETS 512            /* listed parent sets a workgroup takes per pass of the propagation step */
 #define KF_TP_LDS 1024          /* words of transition matrices kept in LDS */
+#define KF_ENT 640              /* propagating parents of a pass's several-parent sets kept in LDS (a set whose parents find no room goes the wave-per-set way) */
 #define KF_BIG 256              /* ... of which several-parent sets whose headers stay in LDS (the others: d_dec_resolve_children) */
 static_assert(KF_NT == 512, "ku_frames: the word level's workgroup is the frame's workgroup");
 enum { KF_WINDOW, KF_STATIC, KF_QUEUE };
@@ -1535,9 +1536,15 @@ union KfPool {                  /* phases that never overlap share this LDS */
     int32_t bin[NBIN];
     HistSortWs<KF_NT> hs;
     struct {                    /* the propagation pass: the big sets' per-wave parent tables; the listed sets of a pass */
-        int32_t rc[KF_WAVES][5 * 64];
+        union {                     /* (the tables are read before the wave-per-set routine borrows the area) */
+            int32_t rc[KF_WAVES][5 * 64];
+            int32_t ent[KF_ENT][5];         /* the several-parent sets' propagating parents, chained per set: exit score, list position, exit
+                                             * history, probability, next entry of the set (-1: none) */
+        };
         int32_t mlo[KF_SETS], pre[KF_SETS + 1], big[KF_SETS], nbig, m_all;
-        int32_t bmlo[KF_BIG], bmhi[KF_BIG], bkp0[KF_BIG], bnp[KF_BIG];     /* the several-parent sets' headers */
+        int32_t bmlo[KF_BIG], bnm[KF_BIG], bkp0[KF_BIG], bnp[KF_BIG];      /* the several-parent sets' headers: members, parents */
+        int32_t bnq[KF_BIG], bpre[KF_BIG + 1], bmpre[KF_BIG + 1], leg[KF_BIG], nleg;       /* first entry of the set's chain (-1: none; -2: no room), work-item prefixes */
+        int32_t n_ent;
     } rs;
     struct { int32_t hdr[6 * WL_MAXT + 16], ex[3 * WL_LDS_EX]; } wl;
 };
@@ -1993,47 +2000,59 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         if (C == 1) { __syncthreads(); if (tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kdbg[0] += t_ - t_prev; } }
         long long t_sub = (long long)wall_clock64();
 #define KF_SUB(i) do { if (C == 1) { __syncthreads(); if (tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kdbg[i] += t_ - t_sub; t_sub = t_; } } } while (0)
-        /* the frame's listed parent sets (d_stamp_and_list): this workgroup's share, up to KF_SETS per pass.  Their headers are
-         * fetched for all sets at once; the members of the one-parent sets (an interior node's children: most sets, a handful of
-         * members each) become ONE flat run of work items, a thread each; a several-parent set (the ~340 first-level nodes under the
-         * ~46 left-context variants of a root) takes a wave that finds the propagating variants once (d_dec_resolve_children) */
+        /* the frame's listed parent sets (d_stamp_and_list): this workgroup's share, up to KF_SETS per pass -- everything as flat work
+         * items (measured: ~130 listed sets per frame, 87 of them several-parent sets of ~10 members and one or two propagating
+         * parents each; a wave per such set was 11 sets in a row per wave, each a chain of five round trips: 98 us of the frame):
+         *   1. the sets' headers, all at once;
+         *   2. the one-parent sets' members (an interior node's children), a thread each;
+         *   3. a thread per (several-parent set, parent): the PROPAGATING parents go to the set's table in LDS (exit score, list
+         *      position, exit history, probability: up to KF_TQ; a set with more goes the wave-per-set way);
+         *   4. a thread per (several-parent set, member), on the list or not: d_dec_resolve_children's rule with the table. */
         {
             auto &rs = sh.pool.rs;
+            const int32_t th = sh.thr[0], pth = sh.thr[1];
             const int32_t n_pl = S3A_ALD(&L.pcnt[f & 1]), per = (n_pl + C - 1) / C, k_lo = min(n_pl, r * per), k_hi = min(n_pl, k_lo + per);
             for (int32_t k0 = k_lo; k0 < k_hi; k0 += KF_SETS) {
                 const int32_t nk = min(KF_SETS, k_hi - k0);
-                if (tid == 0) rs.nbig = 0;
+                if (tid == 0) { rs.nbig = 0; rs.nleg = 0; rs.n_ent = 0; }
                 __syncthreads();
-                for (int32_t j = tid; j < KF_SETS; j += KF_NT) {
+                {
+                    static_assert(KF_SETS == KF_NT, "a set per thread");
                     int32_t cm = 0, m_lo = 0;
-                    if (j < nk) {
-                        const int32_t q = L.plist[k0 + j];
+                    if (tid < nk) {
+                        const int32_t q = L.plist[k0 + tid];
                         m_lo = S.psmem_off[q];
-                        const int32_t m_hi = S.psmem_off[q + 1], x0 = S.psmem[m_lo], np = S.par_off[x0 + 1] - S.par_off[x0];
+                        const int32_t m_hi = S.psmem_off[q + 1], x0 = S.psmem[m_lo], kp0 = S.par_off[x0], np = S.par_off[x0 + 1] - kp0;
                         if (np >= SET_NP_MIN && np <= 64) {
                             const int32_t at = atomicAdd(&rs.nbig, 1);
                             rs.big[at] = q;
-                            if (at < KF_BIG) { rs.bmlo[at] = m_lo; rs.bmhi[at] = m_hi; rs.bkp0[at] = S.par_off[x0]; rs.bnp[at] = np; }
+                            if (at < KF_BIG) { rs.bmlo[at] = m_lo; rs.bnm[at] = m_hi - m_lo; rs.bkp0[at] = kp0; rs.bnp[at] = np; rs.bnq[at] = -1; }
                         }
                         else cm = m_hi - m_lo;
                     }
-                    rs.mlo[j] = m_lo; rs.pre[j] = cm;
+                    rs.mlo[tid] = m_lo; rs.pre[tid] = cm;
                 }
                 __syncthreads();
-                {   /* exclusive sums of the sets' member counts: two sets per thread */
-                    const int32_t a0 = rs.pre[2 * tid], a1 = rs.pre[2 * tid + 1];
-                    int32_t incl = a0 + a1;
+                const int32_t nb = min(rs.nbig, KF_BIG);
+                {   /* exclusive sums: the one-parent sets' members | the several-parent sets' parents | their members */
+                    const int32_t a0 = rs.pre[tid], pn = tid < nb ? rs.bnp[tid] : 0, pm = tid < nb ? rs.bnm[tid] : 0;
+                    int32_t i0 = a0, i1 = pn, i2 = pm;
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
-                    if (lane == 63) sh.ws[wave] = incl;
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int32_t y0 = __shfl_up(i0, o, 64), y1 = __shfl_up(i1, o, 64), y2 = __shfl_up(i2, o, 64);
+                        if (lane >= o) { i0 += y0; i1 += y1; i2 += y2; }
+                    }
+                    if (lane == 63) { sh.ws[wave] = i0; sh.seg[wave] = i1; sh.seg[16 + wave] = i2; }
                     __syncthreads();
-                    int32_t add = 0;
-                    for (int32_t w = 0; w < wave; w++) add += sh.ws[w];
-                    rs.pre[2 * tid] = add + incl - a0 - a1; rs.pre[2 * tid + 1] = add + incl - a1;
-                    if (tid == KF_NT - 1) rs.m_all = add + incl;
+                    int32_t a_ = 0, b_ = 0, c_ = 0;
+                    for (int32_t w = 0; w < wave; w++) { a_ += sh.ws[w]; b_ += sh.seg[w]; c_ += sh.seg[16 + w]; }
+                    rs.pre[tid] = a_ + i0 - a0;
+                    if (tid < KF_BIG) { rs.bpre[tid] = b_ + i1 - pn; rs.bmpre[tid] = c_ + i2 - pm; }
+                    if (tid == KF_NT - 1) { rs.m_all = a_ + i0; rs.bpre[KF_BIG] = b_ + i1; rs.bmpre[KF_BIG] = c_ + i2; }
                     __syncthreads();
                 }
                 KF_SUB(1);
+                /* 2. the one-parent sets' members */
                 const int32_t M = rs.m_all;
                 for (int32_t m = tid; m < M; m += KF_NT) {
                     int32_t lo = 0, hi = nk - 1;
@@ -2045,70 +2064,88 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                                                        S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, x, false, true, -1, -1,
                                                        HeurArgs{ NULL, NULL, NULL }, sh.thr);
                 }
-                KF_SUB(2);
-                /* the several-parent sets, a wave each (d_dec_resolve_children's rule; the set's header comes from LDS, two runs of 64
-                 * members are in flight at a time) */
+                /* 3. the several-parent sets' propagating parents */
                 {
-                    const int32_t nb = min(rs.nbig, KF_BIG), th = sh.thr[0], pth = sh.thr[1];
-                    int32_t *s_po = rs.rc[wave], *s_pp = s_po + 64, *s_ph = s_po + 128, *s_pr = s_po + 192;
-                    for (int32_t k = wave; k < nb; k += KF_WAVES) {
-                        const int32_t m_lo = rs.bmlo[k], m_hi = rs.bmhi[k], kp0 = rs.bkp0[k], np = rs.bnp[k];
-                        bool qual = false;
-                        int32_t po = 0, g = -1;
-                        if (lane < np) {
-                            g = S.par[kp0 + lane];
-                            if (L.posf[g] == f) {
-                                po = L.outs[NSV(g)];
-                                qual = po >= pth && !(pth < th && L.bests[NSV(g)] < th && L.propf[g] != f);
+                    const int32_t I = rs.bpre[KF_BIG];
+                    for (int32_t it0 = 0; it0 < I; it0 += 2 * KF_NT) {
+                        int32_t sb[2], gp[2], pfv[2];
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            const int32_t it = it0 + u * KF_NT + tid;
+                            sb[u] = -1; gp[u] = -1;
+                            if (it < I) {
+                                int32_t lo = 0, hi = nb - 1;
+                                while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.bpre[mid] <= it) lo = mid; else hi = mid - 1; }
+                                sb[u] = lo; gp[u] = S.par[rs.bkp0[lo] + (it - rs.bpre[lo])];
                             }
                         }
-                        const unsigned long long qm = __ballot(qual);
-                        const int32_t x0 = S.psmem[m_lo], b = S.node_base[S.tree_of[x0]];
-                        if (qual) {
-                            const int32_t at = __popcll(qm & ((1ull << lane) - 1ull));
-                            s_po[at] = po; s_pp[at] = L.pos[g]; s_ph[at] = L.outh[NSV(g)]; s_pr[at] = S.prob[g];
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const int32_t nq = __popcll(qm);
-                        for (int32_t c0 = m_lo; c0 < m_hi; c0 += 128) {
-                            int32_t xx[2], pf[2], i0v[2], pxv[2], jv[2];
 #pragma unroll
-                            for (int u = 0; u < 2; u++) { const int32_t c = c0 + 64 * u + lane; xx[u] = c < m_hi ? S.psmem[c] : -1; }
+                        for (int u = 0; u < 2; u++) pfv[u] = gp[u] >= 0 ? L.posf[gp[u]] : INT_MIN;
 #pragma unroll
-                            for (int u = 0; u < 2; u++) {
-                                pf[u] = xx[u] >= 0 ? L.posf[xx[u]] : INT_MIN;
-                                i0v[u] = xx[u] >= 0 ? L.sc[NSV(xx[u])] : 0; pxv[u] = xx[u] >= 0 ? S.prob[xx[u]] : 0;
-                                jv[u] = xx[u] >= 0 ? L.pos[xx[u]] : 0;
+                        for (int u = 0; u < 2; u++) {
+                            if (pfv[u] != f) continue;
+                            const int32_t g = gp[u], po = L.outs[NSV(g)];
+                            if (po < pth || (pth < th && L.bests[NSV(g)] < th && L.propf[g] != f)) continue;
+                            const int32_t at = atomicAdd(&rs.n_ent, 1);
+                            if (at < KF_ENT) {
+                                int32_t *e = rs.ent[at];
+                                e[0] = po; e[1] = L.pos[g]; e[2] = L.outh[NSV(g)]; e[3] = S.prob[g];
+                                e[4] = atomicExch(&rs.bnq[sb[u]], at);              /* (the chain's order does not matter: maxima with position tie-breaks) */
                             }
-#pragma unroll
-                            for (int u = 0; u < 2; u++) {
-                                if (xx[u] < 0) continue;
-                                const int32_t x = xx[u];
-                                const bool on_list = pf[u] == f;                    /* (the list position pass leaves these members to us) */
-                                if (!on_list && nq == 0) continue;
-                                const int32_t j = on_list ? jv[u] : INT_MAX, in0 = i0v[u], px = pxv[u];
-                                int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
-                                int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
-                                for (int32_t q = 0; q < nq; q++) {
-                                    const int32_t ns = add32(s_po[q], add32(px, -s_pr[q]));
-                                    if (ns < th) continue;
-                                    const int32_t up = s_pp[q];
-                                    if (up < j) {
-                                        if (ns > mE || (ns == mE && up < pE)) { mE = ns; pE = up; hE = s_ph[q]; }
-                                        if (ns > in0 && up < firstE) firstE = up;
-                                    }
-                                    else {
-                                        if (ns > mL || (ns == mL && up < pL)) { mL = ns; pL = up; hL = s_ph[q]; }
-                                        if (up < firstL) firstL = up;
-                                    }
-                                }
-                                d_dec_resolve_finish(S.N, f, th, b, x, on_list, j, in0, mE, hE, firstE, mL, hL, firstL,
-                                                     L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.posout);
-                            }
+                            else atomicMin(&rs.bnq[sb[u]], -2);
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     }
-                    /* (more several-parent sets than headers fit: the rest through the general routine) */
+                    __syncthreads();
+                    /* (a set one of whose parents found no room: its chain may be cut short -- the wave-per-set way) */
+                    if (tid < nb && rs.n_ent > KF_ENT) {
+                        bool cut = rs.bnq[tid] == -2;
+                        for (int32_t e = rs.bnq[tid]; e >= 0 && !cut; e = rs.ent[e][4]) cut = rs.ent[e][4] == -2;
+                        if (cut) { rs.bnq[tid] = -2; rs.leg[atomicAdd(&rs.nleg, 1)] = tid; }
+                    }
+                    __syncthreads();
+                }
+                KF_SUB(2);
+                /* 4. their members */
+                {
+                    const int32_t MB = rs.bmpre[KF_BIG];
+                    for (int32_t m = tid; m < MB; m += KF_NT) {
+                        int32_t lo = 0, hi = nb - 1;
+                        while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.bmpre[mid] <= m) lo = mid; else hi = mid - 1; }
+                        const int32_t k = lo, e0 = rs.bnq[k];
+                        if (e0 == -2) continue;                                 /* the wave-per-set way, below */
+                        const int32_t x = S.psmem[rs.bmlo[k] + (m - rs.bmpre[k])];
+                        const bool on_list = L.posf[x] == f;                    /* (the list position pass leaves these members to us) */
+                        if (!on_list && e0 < 0) continue;
+                        const int32_t j = on_list ? L.pos[x] : INT_MAX, in0 = L.sc[NSV(x)], px = S.prob[x], b = S.node_base[S.tree_of[x]];
+                        int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
+                        int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
+                        for (int32_t q = e0; q >= 0; q = rs.ent[q][4]) {
+                            const int32_t *e = rs.ent[q];
+                            const int32_t ns = add32(e[0], add32(px, -e[3]));
+                            if (ns < th) continue;
+                            const int32_t up = e[1];
+                            if (up < j) {
+                                if (ns > mE || (ns == mE && up < pE)) { mE = ns; pE = up; hE = e[2]; }
+                                if (ns > in0 && up < firstE) firstE = up;
+                            }
+                            else {
+                                if (ns > mL || (ns == mL && up < pL)) { mL = ns; pL = up; hL = e[2]; }
+                                if (up < firstL) firstL = up;
+                            }
+                        }
+                        d_dec_resolve_finish(S.N, f, th, b, x, on_list, j, in0, mE, hE, firstE, mL, hL, firstL,
+                                             L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.posout);
+                    }
+                }
+                /* ... and the sets that have no table, a wave each (d_dec_resolve_children) */
+                if (rs.nleg > 0 || rs.nbig > KF_BIG) {
+                    __syncthreads();
+                    if (tid < rs.nleg) sh.seg[32 + tid] = rs.big[rs.leg[tid]];
+                    __syncthreads();
+                    d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                           L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                           S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, sh.seg + 32, rs.nleg,
+                                                           S.psmem_off, S.psmem, wave, KF_WAVES, HeurArgs{ NULL, NULL, NULL }, rs.rc[wave], sh.thr);
                     if (rs.nbig > KF_BIG)
                         d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
                                                                L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
