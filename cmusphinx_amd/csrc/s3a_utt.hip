@@ -1553,6 +1553,7 @@ struct KfSh {                   /* the workgroup's LDS outside the word level's 
     KfPool pool;
     int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
     int32_t seg[KF_MAXSEG + 1], ws[KF_WAVES + 1], gq[4];    /* lextree_enter: the waves' segments of passing entries, scan scratch */
+    long long kacc[16];         /* the steps' clock of the utterance so far (UCtx.kacc) */
     int32_t thr[4];             /* the frame's thresholds: HMM, phone, word (final once the histogram beam is known) */
     int32_t tp[KF_TP_LDS];      /* the transition matrices (when they fit: 48 of hub4's 3-state topology are 2.3 KB) */
 };
@@ -1669,6 +1670,35 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
     return k;
 }
 
+/* srch_TST_select_active_gmm's step for one node from its packed ids (mark_node_senones with one gather instead of five): a plain
+ * node's senones join the mask, a composite node's composite senones are stamped and -- by whoever stamps one first -- listed */
+template <int NE>
+__device__ __forceinline__ void
+kf_mark_node(int32_t v, const int32_t *__restrict__ nodesen, uint8_t *sen_act, int32_t *cs_need, int32_t stamp, int32_t *cs_wl, int32_t *cs_wn)
+{
+    int32_t id[NE], comp;
+    if (NE == 3) {
+        const int2 a = *(const int2 *)(nodesen + (size_t)v * 2);
+        id[0] = a.x & 0xffff; id[1] = (int32_t)((uint32_t)a.x >> 16); id[2] = a.y & 0xffff; comp = (int32_t)((uint32_t)a.y >> 16);
+    }
+    else {
+        const int4 a = *(const int4 *)(nodesen + (size_t)v * 4);
+        const int32_t h[5] = { a.x & 0xffff, (int32_t)((uint32_t)a.x >> 16), a.y & 0xffff, (int32_t)((uint32_t)a.y >> 16), a.z & 0xffff };
+#pragma unroll
+        for (int st = 0; st < NE; st++) id[st] = h[st];
+        comp = (int32_t)((uint32_t)a.z >> 16);
+    }
+    if (comp) {
+#pragma unroll
+        for (int st = 0; st < NE; st++)
+            if (atomicExch(&cs_need[id[st]], stamp) != stamp) cs_wl[atomicAdd(cs_wn, 1)] = id[st];
+    }
+    else {
+#pragma unroll
+        for (int st = 0; st < NE; st++) sen_act[id[st]] = 1;
+    }
+}
+
 /* frame f of lane z (workgroup r of its C): row / brow = the frame's senone scores and best components */
 template <int NE, bool EXACT>
 __device__ __forceinline__ void
@@ -1679,12 +1709,14 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     const int32_t gtid = r * KF_NT + tid, gstride = C * KF_NT, gwave = r * KF_WAVES + wave, gwaves = C * KF_WAVES;
     /* where the frame's time goes (thread 0 of the cluster's first workgroup: one clock read per step) */
     long long t_prev = 0;
-#define KF_STAMP(i) do { if (r == 0 && tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kacc[i] += t_ - t_prev; t_prev = t_; } } while (0)
+    /* (the clock's sums stay in LDS and go to the lane's context once per utterance / launch: a read-modify-write of HBM by thread 0
+     * in every step was 3 us each on the path to the step's barrier) */
+#define KF_STAMP(i) do { if (r == 0 && tid == 0) { const long long t_ = (long long)wall_clock64(); sh.kacc[i] += t_ - t_prev; t_prev = t_; } } while (0)
     const int32_t cur = f & 1;
     const int32_t *nact_cur = S.nact_all + ((size_t)z * 2 + cur) * WL_MAXT;
     const FrameBeams bm = frame_beams(S, f);
     const int32_t n_ent = ctx->n_ent, n_calls_all = ctx->n_calls, thresh = ctx->thresh;
-    if (r == 0 && tid == 0) { t_prev = (long long)wall_clock64(); ctx->kacc[13]++; }
+    if (r == 0 && tid == 0) { t_prev = (long long)wall_clock64(); sh.kacc[13]++; }
 
     /* ---- lextree_enter (lextree.c:1093-1236; ku_enter1 / 2 / 3 of the launch path): of the frame's ~60 k (call, root) entries a few
      * hundred pass the threshold test, so ONE sweep tests them all (a coalesced load each) and keeps the ones that pass, in entry
@@ -1704,27 +1736,40 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.pool.e1.off[mid] <= e_lo) lo = mid; else hi = mid - 1; }
             c = lo;
         }
-        for (int32_t e0 = e_lo; e0 < e_hi; e0 += 64) {
-            const int32_t e = e0 + lane;
+        /* (four runs of 64 entries per turn: their probabilities, then the passing ones' roots, then those roots' entry scores are asked
+         * for together -- a turn is three round trips whatever it holds; the order of the kept entries is the entries') */
+        for (int32_t e0 = e_lo; e0 < e_hi; e0 += 256) {
             /* an entry counts when it passes the threshold AND improves on its root's entry score: only such an entry can list the
              * root, win it, or tag it (the others pass through lextree_enter without a trace) */
-            bool keep = false;
-            int32_t scr = 0, v = 0;
-            if (e < e_hi) {
-                while (c + 1 < n_calls && sh.pool.e1.off[c + 1] <= e) c++;
-                const int32_t idx = sh.pool.e1.root[c] + (e - sh.pool.e1.off[c]);
-                scr = add32(sh.pool.e1.in[c], S.rootprob[idx]);
-                if (scr >= thresh) { v = S.rootlist[idx]; keep = L.sc[NSV(v)] < scr; }
+            int32_t scr[4], vv[4], cc[4], idx[4], s0[4];
+            bool keep[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int32_t e = e0 + 64 * u + lane;
+                keep[u] = false; scr[u] = INT_MIN; vv[u] = 0; cc[u] = c; idx[u] = 0;
+                if (e < e_hi) {
+                    while (c + 1 < n_calls && sh.pool.e1.off[c + 1] <= e) c++;
+                    cc[u] = c; idx[u] = sh.pool.e1.root[c] + (e - sh.pool.e1.off[c]);
+                    scr[u] = add32(sh.pool.e1.in[c], S.rootprob[idx[u]]);
+                }
             }
-            const unsigned long long m = __ballot(keep);
-            if (keep) {
-                /* (what the later steps need of the entry, side by side: its root, its score, its call) */
-                const int32_t p_ = e_lo + cntw + __popcll(m & ((1ull << lane) - 1ull));
-                L.eflag[p_] = v; L.ent[2 * p_] = scr; L.ent[2 * p_ + 1] = c;
-                atomicMax(&L.key[v], ((unsigned long long)((uint32_t)scr ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - c));
-                atomicMin(&L.first[v], c);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { keep[u] = e0 + 64 * u + lane < e_hi && scr[u] >= thresh; if (keep[u]) vv[u] = S.rootlist[idx[u]]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) s0[u] = keep[u] ? L.sc[NSV(vv[u])] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                keep[u] = keep[u] && s0[u] < scr[u];
+                const unsigned long long m = __ballot(keep[u]);
+                if (keep[u]) {
+                    /* (what the later steps need of the entry, side by side: its root, its score, its call) */
+                    const int32_t p_ = e_lo + cntw + __popcll(m & ((1ull << lane) - 1ull));
+                    L.eflag[p_] = vv[u]; L.ent[2 * p_] = scr[u]; L.ent[2 * p_ + 1] = cc[u];
+                    atomicMax(&L.key[vv[u]], ((unsigned long long)((uint32_t)scr[u] ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - cc[u]));
+                    atomicMin(&L.first[vv[u]], cc[u]);
+                }
+                cntw += __popcll(m);
             }
-            cntw += __popcll(m);
         }
         if (lane == 0) L.ctot[gwave] = cntw;
         kf_barrier(B);
@@ -1781,7 +1826,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 if (fl & 128) {
                     const int32_t k = L.n0[t] + (fl >> 8) - (g ? sh.gq[0] : 0);
                     L.act[cur][S.node_base[t] + k] = v; L.pos[v] = k; L.posf[v] = nf;
-                    mark_node_senones(v, S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, L.cs_need, nf, NE, L.cs_wl, L.cs_wn);
+                    kf_mark_node<NE>(v, S.nodesen, L.sen_act, L.cs_need, nf, L.cs_wl, L.cs_wn);
                 }
                 const unsigned long long key = S3A_ALD(&L.key[v]);
                 const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(key & 0xffffffffu);
@@ -1808,7 +1853,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             const int32_t na = n0[t], b = S.node_base[t];
             /* (the trees laid end to end: thread gtid's positions are gtid, gtid + gstride, ... of the concatenation) */
             for (int32_t i = gtid - a % gstride + (gtid < a % gstride ? gstride : 0); i < na; i += gstride)
-                mark_node_senones(L.act[cur][b + i], S.ssid, S.comp, S.sseq, S.comsseq, S.cs_off, S.cs_list, L.sen_act, L.cs_need, f, NE, L.cs_wl, L.cs_wn);
+                kf_mark_node<NE>(L.act[cur][b + i], S.nodesen, L.sen_act, L.cs_need, f, L.cs_wl, L.cs_wn);
             a += na;
         }
     }
@@ -1997,9 +2042,6 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                                                    HeurArgs{ NULL, NULL, NULL }, sh.thr);
             }
         }
-        if (C == 1) { __syncthreads(); if (tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kdbg[0] += t_ - t_prev; } }
-        long long t_sub = (long long)wall_clock64();
-#define KF_SUB(i) do { if (C == 1) { __syncthreads(); if (tid == 0) { const long long t_ = (long long)wall_clock64(); ctx->kdbg[i] += t_ - t_sub; t_sub = t_; } } } while (0)
         /* the frame's listed parent sets (d_stamp_and_list): this workgroup's share, up to KF_SETS per pass -- everything as flat work
          * items (measured: ~130 listed sets per frame, 87 of them several-parent sets of ~10 members and one or two propagating
          * parents each; a wave per such set was 11 sets in a row per wave, each a chain of five round trips: 98 us of the frame):
@@ -2051,7 +2093,6 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     if (tid == KF_NT - 1) { rs.m_all = a_ + i0; rs.bpre[KF_BIG] = b_ + i1; rs.bmpre[KF_BIG] = c_ + i2; }
                     __syncthreads();
                 }
-                KF_SUB(1);
                 /* 2. the one-parent sets' members */
                 const int32_t M = rs.m_all;
                 for (int32_t m = tid; m < M; m += KF_NT) {
@@ -2104,7 +2145,6 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     }
                     __syncthreads();
                 }
-                KF_SUB(2);
                 /* 4. their members */
                 {
                     const int32_t MB = rs.bmpre[KF_BIG];
@@ -2152,7 +2192,6 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                                                                S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, rs.big + KF_BIG, rs.nbig - KF_BIG,
                                                                S.psmem_off, S.psmem, wave, KF_WAVES, HeurArgs{ NULL, NULL, NULL }, rs.rc[wave], sh.thr);
                 }
-                KF_SUB(3);
                 __syncthreads();
             }
         }
@@ -2211,6 +2250,7 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
     UCtx *ctx = S.ctx_all + z;
     const int32_t tid = threadIdx.x;
     if (tid == 0) sh.dead = 0;
+    if (tid < 16) sh.kacc[tid] = 0;
     if (S.n_tmat * NS_TPW(NE) <= KF_TP_LDS)
         for (int32_t i = tid; i < S.n_tmat * NS_TPW(NE); i += KF_NT) sh.tp[i] = S.tp[i];
     KfBar B = { bar + z, C, 0, &sh.dead };
@@ -2258,6 +2298,7 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
                 if (!((volatile UCtx *)ctx)->active || sh.dead) break;
                 kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, J.scores + (r0 + f) * S.n_sen, J.bests + (r0 + f) * S.n_sen, weak_possible);
             }
+            if (r == 0 && tid < 16 && tid != 12 && tid != 14) { ctx->kacc[tid] += sh.kacc[tid]; sh.kacc[tid] = 0; }
             /* srch_utt_end (srch.c:482-560): the hypothesis goes to the utterance's slot, the lane's lists are cleared */
             static_assert(3 * WL_LDS_EX >= UH_IDS, "d_hyp's backtrace ids borrow the word level's exit area");
             if (r == 0) d_hyp<KF_NT>(L, ctx, lm, dict, J.P, J.hdr + (size_t)(J.u0 + u) * UH_N, J.words, J.wcount, sh.pool.wl.ex);
@@ -2266,7 +2307,8 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
             kf_barrier(B);
         }
     }
-    if (r == 0 && tid == 0) { ctx->kacc[12] += (long long)wall_clock64() - t_launch; ctx->kacc[14]++; }
+    if (r == 0 && tid == 0) { sh.kacc[12] += (long long)wall_clock64() - t_launch; sh.kacc[14]++; }
+    if (r == 0 && tid < 16) ctx->kacc[tid] += sh.kacc[tid];             /* (KF_QUEUE: the lane's last utterance has its frames' share already) */
     if (r == 0 && tid == 0 && J.mode == KF_WINDOW && J.fg0 == 512) {
         ctx->kdbg[0] = t_launch; ctx->kdbg[1] = (long long)wall_clock64();
         ctx->kdbg[2] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4); ctx->kdbg[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);
@@ -2356,7 +2398,8 @@ ku_pack_nodesen(const int32_t *__restrict__ ssid, const uint8_t *__restrict__ co
     const int16_t *row = (comp[v] ? comsseq : sseq) + (size_t)ssid[v] * ne;
     const int32_t sv = ne == 3 ? 2 : 4;
     for (int32_t k = 0; k < sv; k++) {
-        const uint32_t lo = 2 * k < ne ? (uint32_t)(uint16_t)row[2 * k] : 0u, hi = 2 * k + 1 < ne ? (uint32_t)(uint16_t)row[2 * k + 1] : 0u;
+        uint32_t lo = 2 * k < ne ? (uint32_t)(uint16_t)row[2 * k] : 0u, hi = 2 * k + 1 < ne ? (uint32_t)(uint16_t)row[2 * k + 1] : 0u;
+        if (2 * k + 1 == ne) hi = comp[v] ? 1u : 0u;            /* (the half behind the last id: composite?) */
         out[(size_t)v * sv + k] = (int32_t)(lo | (hi << 16));
     }
 }
