@@ -1774,24 +1774,27 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         if (lane == 0) L.ctot[gwave] = cntw;
         kf_barrier(B);
         KF_STAMP(0);
-        /* the entries that passed, by the lane's first workgroup: which of them list their root (the first qualifying call of a node
-         * that is not listed yet), ranked in entry order by a scan; then the listed roots, the winning entries, the frame tags */
-        if (r == 0) {
-            {
-                const int32_t x = tid < gwaves ? L.ctot[tid] : 0;
-                int32_t incl = x;
+        /* the kept entries: (1) the lane's first workgroup finds which of them list their root (the first qualifying call of a node
+         * that is not listed yet), ranked in entry order by a scan -- the others meanwhile mark the senones of the list as it stood
+         * before the entries --; (2) every workgroup applies its share: the listed roots, the winning entries, the frame tags (the
+         * ranking READS the frame tags the applying WRITES: a barrier between them); the roots' scratch is cleaned one step later */
+        {
+            /* (every workgroup: where the waves' stretches of kept entries lie) */
+            const int32_t x = tid < gwaves ? L.ctot[tid] : 0;
+            int32_t incl = x;
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
-                if (lane == 63) sh.ws[wave] = incl;
-                __syncthreads();
-                int32_t add = 0;
-                for (int32_t w = 0; w < wave; w++) add += sh.ws[w];
-                if (tid < gwaves) sh.seg[tid] = add + incl - x;
-                if (tid == gwaves - 1) sh.seg[gwaves] = add + incl;
-                if (tid < 4) sh.gq[tid] = 0;
-                __syncthreads();
-            }
-            const int32_t P = sh.seg[gwaves], c1 = ctx->n_groups > 1 ? ctx->groups[4 + 3] : INT_MAX;      /* (group 1's first call) */
+            for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+            if (lane == 63) sh.ws[wave] = incl;
+            __syncthreads();
+            int32_t add = 0;
+            for (int32_t w = 0; w < wave; w++) add += sh.ws[w];
+            if (tid < gwaves) sh.seg[tid] = add + incl - x;
+            if (tid == gwaves - 1) sh.seg[gwaves] = add + incl;
+            if (tid < 4) sh.gq[tid] = 0;
+            __syncthreads();
+        }
+        const int32_t P = sh.seg[gwaves], c1 = ctx->n_groups > 1 ? ctx->groups[4 + 3] : INT_MAX;      /* (group 1's first call) */
+        if (r == 0) {
             int32_t carry = 0;
             for (int32_t i0 = 0; i0 < P; i0 += KF_NT) {
                 const int32_t i = i0 + tid;
@@ -1814,47 +1817,48 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 __syncthreads();
             }
             /* the groups' new list lengths (group 0 = the unigram tree's calls, group 1 = the filler tree's: consecutive entries) */
-            if (tid == 0) { sh.gq[1] = carry - sh.gq[0]; }
+            if (tid == 0) { sh.gq[1] = carry - sh.gq[0]; L.ctot[KF_MAXSEG] = sh.gq[0]; }
             __syncthreads();
             if (tid < ctx->n_groups) { const int32_t t = ctx->groups[4 * tid]; L.nact[cur][t] = L.n0[t] + sh.gq[tid]; }
-            for (int32_t i = tid; i < P; i += KF_NT) {
-                int32_t lo = 0, hi = gwaves - 1;
-                while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
-                const int32_t p_ = lo * R + (i - sh.seg[lo]);
-                const int32_t v = L.eflag[p_], scr = L.ent[2 * p_], fl = L.ent[2 * p_ + 1], c = fl & 127;
-                const int32_t g = c >= c1 ? 1 : 0, t = ctx->groups[4 * g];
-                if (fl & 128) {
-                    const int32_t k = L.n0[t] + (fl >> 8) - (g ? sh.gq[0] : 0);
-                    L.act[cur][S.node_base[t] + k] = v; L.pos[v] = k; L.posf[v] = nf;
-                    kf_mark_node<NE>(v, S.nodesen, L.sen_act, L.cs_need, nf, L.cs_wl, L.cs_wn);
-                }
-                const unsigned long long key = S3A_ALD(&L.key[v]);
-                const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(key & 0xffffffffu);
-                (void)scr;
-                if (c == win_c) { L.sc[NSV(v)] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); L.hist[NSV(v)] = sh.pool.e1.hist[c]; }
-                if (c == S3A_ALD(&L.first[v])) L.frame[NSV(v)] = nf;
-            }
-            /* lextree_enter's scratch of the roots it touched is clean again (the launch path sweeps all root nodes in its resolve) */
-            __syncthreads();
-            for (int32_t i = tid; i < P; i += KF_NT) {
-                int32_t lo = 0, hi = gwaves - 1;
-                while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
-                const int32_t v = L.eflag[lo * R + (i - sh.seg[lo])];
-                L.key[v] = 0ull; L.first[v] = INT_MAX;
-            }
         }
-        KF_STAMP(1);
     }
-    /* ---- the senone marks of the nodes that were on the frame's list before the entries (srch_TST_select_active_gmm) ---- */
-    {
+    /* ---- the senone marks of the nodes that were on the frame's list before the entries (srch_TST_select_active_gmm): with a
+     * cluster, by the workgroups that do not rank ---- */
+    if (C == 1 || r > 0) {
         const int32_t *n0 = n_ent > 0 ? L.n0 : L.nact[cur];
+        const int32_t mt = C == 1 ? tid : gtid - KF_NT, ms = C == 1 ? KF_NT : gstride - KF_NT;
         int32_t a = 0;
         for (int32_t t = 0; t < T; t++) {
             const int32_t na = n0[t], b = S.node_base[t];
-            /* (the trees laid end to end: thread gtid's positions are gtid, gtid + gstride, ... of the concatenation) */
-            for (int32_t i = gtid - a % gstride + (gtid < a % gstride ? gstride : 0); i < na; i += gstride)
+            /* (the trees laid end to end: a thread's positions are mt, mt + ms, ... of the concatenation) */
+            for (int32_t i = mt - a % ms + (mt < a % ms ? ms : 0); i < na; i += ms)
                 kf_mark_node<NE>(L.act[cur][b + i], S.nodesen, L.sen_act, L.cs_need, f, L.cs_wl, L.cs_wn);
             a += na;
+        }
+    }
+    if (n_ent > 0) {
+        kf_barrier(B);
+        KF_STAMP(1);
+        /* (2) this workgroup's share of the kept entries */
+        const int32_t nf = f, n_calls = min(n_calls_all, WL_MAXCALL);
+        const int32_t R = (((n_ent + gwaves - 1) / gwaves) + 63) & ~63;
+        const int32_t P = sh.seg[gwaves], c1 = ctx->n_groups > 1 ? ctx->groups[4 + 3] : INT_MAX, gq0 = L.ctot[KF_MAXSEG];
+        (void)n_calls;
+        for (int32_t i = gtid; i < P; i += gstride) {
+            int32_t lo = 0, hi = gwaves - 1;
+            while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
+            const int32_t p_ = lo * R + (i - sh.seg[lo]);
+            const int32_t v = L.eflag[p_], fl = L.ent[2 * p_ + 1], c = fl & 127;
+            const int32_t g = c >= c1 ? 1 : 0, t = ctx->groups[4 * g];
+            if (fl & 128) {
+                const int32_t k = L.n0[t] + (fl >> 8) - (g ? gq0 : 0);
+                L.act[cur][S.node_base[t] + k] = v; L.pos[v] = k; L.posf[v] = nf;
+                kf_mark_node<NE>(v, S.nodesen, L.sen_act, L.cs_need, nf, L.cs_wl, L.cs_wn);
+            }
+            const unsigned long long key = S3A_ALD(&L.key[v]);
+            const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(key & 0xffffffffu);
+            if (c == win_c) { L.sc[NSV(v)] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); L.hist[NSV(v)] = sh.pool.e1.hist[c]; }
+            if (c == S3A_ALD(&L.first[v])) L.frame[NSV(v)] = nf;
         }
     }
     kf_barrier(B);
@@ -1864,6 +1868,17 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         int32_t a = 0;
         for (int32_t t = 0; t < T; t++) { sh.pre[t] = a; a += nact_cur[t]; }
         sh.pre[T] = a;
+    }
+    /* (lextree_enter's scratch of the roots it touched is clean again -- every entry's key / first call have been read: the launch path
+     * sweeps all root nodes in its resolve) */
+    if (n_ent > 0) {
+        const int32_t R = (((n_ent + gwaves - 1) / gwaves) + 63) & ~63, P = sh.seg[gwaves];
+        for (int32_t i = gtid; i < P; i += gstride) {
+            int32_t lo = 0, hi = gwaves - 1;
+            while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
+            const int32_t v = L.eflag[lo * R + (i - sh.seg[lo])];
+            L.key[v] = 0ull; L.first[v] = INT_MAX;
+        }
     }
     /* ---- the members of the composite senones wanted in the frame join the mask (ku_comsen_mark): from the frame's list ---- */
     const int32_t n_csw = S3A_ALD(&L.cs_wn[0]);
