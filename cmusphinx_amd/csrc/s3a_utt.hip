@@ -1558,7 +1558,7 @@ struct KfSh {                   /* the workgroup's LDS outside the word level's 
     int32_t tp[KF_TP_LDS];      /* the transition matrices (when they fit: 48 of hub4's 3-state topology are 2.3 KB) */
 };
 
-struct KfBar { int32_t *cnt; int32_t C, target; int32_t *dead; };
+struct KfBar { int32_t *cnt; int32_t C, target; int32_t *dead; int32_t local; };
 
 /* what a call's launch works on besides the lanes (by value) */
 struct KfJob {
@@ -1577,20 +1577,26 @@ struct KfJob {
     int32_t n_word;
 };
 
-/* all workgroups of the lane's cluster have finished the phase and see what the others wrote */
+/* all workgroups of the lane's cluster have finished the phase and see what the others wrote.
+ * Two forms.  The general one: arrive behind an agent-scope release (buffer_wbl2: the L2 writes its dirty lines back -- the XCDs' L2s
+ * are not coherent with each other), leave through an agent-scope acquire.  The XCD-LOCAL one (B.local: every workgroup of the cluster
+ * read the same XCC_ID at the start of the launch -- checked, not assumed): the cluster's CUs share ONE L2, a CU's L1 writes through,
+ * so a store whose wave has counted it down (s_waitcnt vmcnt(0), EVERY wave before the workgroup barrier: __syncthreads() is a bare
+ * s_barrier here) is where the others' loads find it once their L1 is invalidated (buffer_inv sc1); no write-back of the L2. */
 __device__ __forceinline__ void
 kf_barrier(KfBar &B)
 {
+    if (B.C == 1) { __syncthreads(); return; }
+    if (B.local) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    if (B.C == 1) return;
     B.target += B.C;
     if (threadIdx.x == 0 && !*B.dead) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (!B.local) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         (void)__hip_atomic_fetch_add(B.cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int32_t spins = 0;
         while (__hip_atomic_load(B.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B.target) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             if (++spins > KF_SPIN_MAX) { *B.dead = 1; break; }        /* (cannot happen while the cluster is resident: the host sizes the grid) */
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -2250,7 +2256,7 @@ struct KfArgs { UShared S; WLm lm; WDict dict; WPar par; KfJob J; };
 template <int NE, bool EXACT>
 __global__ void __launch_bounds__(KF_NT, 4)
 ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t n_lanes, int32_t C, int32_t *bar,
-          int32_t weak_possible)
+          int32_t weak_possible, int32_t local_ok)
 {
     /* (what every lane shares arrives through memory, not as ~300 words of kernel arguments the compiler then tries to keep in
      * registers for the whole frame loop: SGPR spills 1 493 -> 647, VGPR spills 342 -> 248, scratch 524 -> 308 B per lane) */
@@ -2268,8 +2274,18 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
     if (tid < 16) sh.kacc[tid] = 0;
     if (S.n_tmat * NS_TPW(NE) <= KF_TP_LDS)
         for (int32_t i = tid; i < S.n_tmat * NS_TPW(NE); i += KF_NT) sh.tp[i] = S.tp[i];
-    KfBar B = { bar + z, C, 0, &sh.dead };
+    KfBar B = { bar + 2 * z, C, 0, &sh.dead, 0 };
     __syncthreads();
+    if (C > 1) {
+        /* where the cluster's workgroups run: each leaves its XCD's bit, and behind one general barrier all of them read the same word --
+         * one bit: the cheap barrier serves (the observed placement, block b on XCD b % 8, is what the grid is laid out for) */
+        if (tid == 0) atomicOr(bar + 2 * z + 1, 1 << (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15));
+        kf_barrier(B);
+        if (tid == 0) sh.u = __hip_atomic_load(bar + 2 * z + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        B.local = local_ok && __popc(sh.u) == 1;
+        __syncthreads();
+    }
     const long long t_launch = (long long)wall_clock64();
     if (J.mode == KF_WINDOW) {
         const int32_t f0 = ctx->f0, nfr = ctx->nfr;
@@ -2656,7 +2672,7 @@ struct s3a_uttdec_s {
     int32_t persist;            /* the engine's configuration is served and the option allows it */
     int32_t kf_cluster_opt;     /* s3a_uttdec_opts_t.cluster */
     int32_t kf_slots;           /* workgroups of ku_frames the device holds at once */
-    int32_t *d_kfbar;           /* [n_lanes] the clusters' barrier counters */
+    int32_t *d_kfbar;           /* [n_lanes][2] the clusters' barrier counters, the XCDs their workgroups run on (a bit each) */
     int32_t kf_last_c;          /* workgroups per lane of the last launch (diagnostics) */
     int32_t kf_counted;         /* this engine is counted in g_kf_live */
     int32_t *d_kfnext;          /* [16 + n_lanes] the queue's counter | what a lane's first workgroup took */
@@ -3059,7 +3075,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     if (hipMemset(ud->d_fgbase, 0, 64) != hipSuccess) goto fail;
     ud->S.fgbase = ud->d_fgbase;
     ud->use_graph = O.graph != 0 && !ud->big_wl && !O.framecheck;
-    ud->persist = O.persist >= 0 && !ud->use_graph && !O.framecheck ? (O.persist > 0 ? 2 : 1) : 0;     /* (2: whatever the lane count) */
+    ud->persist = O.persist >= 0 && !ud->use_graph && !O.framecheck ? (O.persist > 1 ? 3 : O.persist > 0 ? 2 : 1) : 0;     /* (2: whatever the lane count; 3: and with the general barrier only) */
     ud->kf_cluster_opt = O.cluster; ud->kf_last_c = 0; ud->kf_slots = 0; ud->d_kfbar = NULL; ud->kf_counted = 0; ud->d_kfnext = NULL; ud->d_kfargs = ud->h_kfargs = NULL; ud->kf_arg_at = 0;
     ud->sb_scores = NULL; ud->sb_bests = NULL; ud->sb_rows_cap = 0; ud->sb_gdesc_d = ud->sb_gdesc_h = NULL; ud->sb_g_cap = 0;
     ud->sb_row0_d = ud->sb_row0_h = NULL; ud->sb_row0_cap = 0;
@@ -3068,8 +3084,8 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         DM(ud->d_kfnext, (size_t)(16 + n_lanes) * 4);
         DM(ud->d_kfargs, sizeof(KfArgs) * KF_ARG_SLOTS);
         if (hipHostMalloc(&ud->h_kfargs, sizeof(KfArgs) * KF_ARG_SLOTS) != hipSuccess) { s3a_set_error("s3a_uttdec_init: pinned allocation failed"); goto fail; }
-        DM(ud->d_kfbar, (size_t)n_lanes * 4);
-        if (hipMemset(ud->d_kfbar, 0, (size_t)n_lanes * 4) != hipSuccess) goto fail;
+        DM(ud->d_kfbar, (size_t)n_lanes * 8);
+        if (hipMemset(ud->d_kfbar, 0, (size_t)n_lanes * 8) != hipSuccess) goto fail;
         if (ud->device >= 0 && ud->device < 64) { g_kf_live[ud->device]++; ud->kf_counted = 1; }
     }
     ud->scan_small_from = O.scan_small_from > 0 ? O.scan_small_from : 64;
@@ -3512,7 +3528,7 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
     C = max(1, min(C, (per_xcd - (per_xcd > 8 ? 4 : 0)) / lanes_per_xcd));
     ud->kf_last_c = C;
     const int32_t grid = C == 1 ? n : 8 * C * lanes_per_xcd;
-    if (C > 1) HIPCHK(hipMemsetAsync(ud->d_kfbar, 0, (size_t)n * 4, ud->stream));
+    if (C > 1) HIPCHK(hipMemsetAsync(ud->d_kfbar, 0, (size_t)n * 8, ud->stream));
     /* the launch's shared arguments: a slot of a small ring (pinned + device) so that launches may queue up behind one another */
     if (ud->kf_arg_at > 0 && ud->kf_arg_at % KF_ARG_SLOTS == 0) HIPCHK(hipStreamSynchronize(ud->stream));
     KfArgs *ha = (KfArgs *)ud->h_kfargs + ud->kf_arg_at % KF_ARG_SLOTS, *da = (KfArgs *)ud->d_kfargs + ud->kf_arg_at % KF_ARG_SLOTS;
@@ -3520,7 +3536,7 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
     ha->S = ud->S; ha->lm = ud->lm->d; ha->dict = ud->dict; ha->par = ud->par; ha->J = J;
     HIPCHK(hipMemcpyAsync(da, ha, sizeof(KfArgs), hipMemcpyHostToDevice, ud->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(KF_NT), 0, ud->stream, ud->d_lanes, (const KfArgs *)da, n, C,
-                       ud->d_kfbar, ud->weak_possible);
+                       ud->d_kfbar, ud->weak_possible, ud->persist < 3 ? 1 : 0);
     HIPCHK(hipGetLastError());
     return S3A_OK;
 }

@@ -740,7 +740,8 @@ typedef struct {
                              * a cluster of them, that walks the frame's steps with barriers instead of launch boundaries -- the
                              * reference's srch.c:746-835 loop has none): 0 = whenever the engine's configuration is served
                              * (look-ahead scoring on, no wide-beam word level, no -pheurtype, no -maxcdsenpf), -1 = never (the twelve
-                             * launches per frame of rounds 2-4), 1 = as 0.  Same bits either way. */
+                             * launches per frame of rounds 2-4), 1 = whatever the lane count (0 keeps the launches for few lanes), 2 = as 1 with
+                             * the clusters' general (agent-scope) barrier only, never the XCD-local one (A/B runs).  Same bits either way. */
     int32_t cluster;        /* workgroups per lane of that launch: 0 = the library's choice (1 when the lanes fill the chip, more
                              * -- on one XCD, with a counter barrier between the steps -- when they do not; only an engine that is
                              * alone on its device chooses more than 1: the clusters of one launch must be resident together);
