@@ -741,7 +741,7 @@ def main():
         # and ku_frames (the lanes decode the part's utterances from their first to their last frame, taking them from the queue
         # themselves).  HIP events on the engine's own stream bracket both (s3a_uttdec_last_parts: of the LAST timed step); inside
         # ku_frames the steps of a frame are clocked by the kernel itself (s3a_uttdec_frame_ticks, workgroup 0 of a lane, summed over
-        # the lane's last utterance).  An engine that kept the launch path (fewer than 96 busy lanes, --variant, S3A_UTT_PERSIST=-1)
+        # the lane's last utterance).  An engine that kept the launch path (fewer than 8 busy lanes, --variant, S3A_UTT_PERSIST=-1)
         # reports no parts: the per-launch profile of rounds 2-4 is then taken instead.
         sched = schedule(my_share(0)[0])
         parts = [dd.ud.last_parts() for dd in decs]
@@ -862,7 +862,7 @@ def main():
                     "note": "one GPU decoding rank 0's share of an 8-rank run of the same batch (hypotheses included, no gather): "
                             "fewer utterances than workgroup slots, so a lane is a cluster of workgroups with a counter barrier between the frame's steps"}
 
-        # ---- configs[2]: ONE utterance alone (an engine of one lane: the frame as launches -- below 96 lanes they beat ku_frames) ----
+        # ---- configs[2]: ONE utterance alone (an engine of one lane: the frame as launches -- below 8 lanes they beat ku_frames) ----
         single = None
         if world == 1 and not args.plain:
             one = bundle.Decoder(bpath, 1, precision=lib.GMM_FAST if args.fast else lib.GMM_EXACT, cand_cap=args.cand_cap, max_frames=max(nfr) + 8)

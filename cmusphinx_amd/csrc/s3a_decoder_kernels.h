@@ -1514,9 +1514,10 @@ d_comsen_wave(int32_t n_cs, const int32_t *__restrict__ cs_need, int32_t stamp, 
     }
 }
 
-/* the same for a LIST of wanted composite senones (ku_frames): 16-lane group `grp` of `n_grp` takes every n_grp-th entry, two entries
- * per turn (their chains list entry -> member range -> member ids -> scores run side by side) */
-template <bool MAXOP>
+/* the same for a LIST of wanted composite senones (ku_frames): 16-lane group `grp` of `n_grp` takes every n_grp-th entry, U entries
+ * per turn and two runs of 16 members of each at a time (the chains list entry -> member range -> member ids -> scores run side by
+ * side: a turn is four round trips whatever it holds) */
+template <bool MAXOP, int U = 4>
 __device__ __forceinline__ void
 d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
               uint8_t *sen_active, const int32_t *__restrict__ raw, int32_t *cs_val, int32_t grp, int32_t n_grp,
@@ -1525,26 +1526,32 @@ d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__rest
     /* (cs_wt: the composite senone's weight is added to the maximum -- add32 wraps, so the evaluation's
      * (score - normaliser) + weight comes out the same whichever is added first) */
     const int32_t l16 = threadIdx.x & 15;
-    for (int32_t j0 = 0; j0 < n_w; j0 += 2 * n_grp) {       /* (trip count uniform over the wave: the shuffles below see all lanes) */
-        int32_t cs[2], lo[2], hi[2], mx[2];
-        bool on[2];
+    for (int32_t j0 = 0; j0 < n_w; j0 += U * n_grp) {       /* (trip count uniform over the wave: the shuffles below see all lanes) */
+        int32_t cs[U], lo[U], hi[U], mx[U];
+        bool on[U];
 #pragma unroll
-        for (int u = 0; u < 2; u++) { const int32_t j = j0 + u * n_grp + grp; on[u] = j < n_w; cs[u] = on[u] ? wl[j] : 0; }
+        for (int u = 0; u < U; u++) { const int32_t j = j0 + u * n_grp + grp; on[u] = j < n_w; cs[u] = on[u] ? wl[j] : 0; }
 #pragma unroll
-        for (int u = 0; u < 2; u++) { lo[u] = on[u] ? cs_off[cs[u]] : 0; hi[u] = on[u] ? cs_off[cs[u] + 1] : 0; mx[u] = INT_MIN; }
-        for (int32_t q0 = 0; ; q0 += 16) {
-            int32_t id[2];
+        for (int u = 0; u < U; u++) { lo[u] = on[u] ? cs_off[cs[u]] : 0; hi[u] = on[u] ? cs_off[cs[u] + 1] : 0; mx[u] = INT_MIN; }
+        for (int32_t q0 = 0; ; q0 += 32) {
+            int32_t id[U][2];
             bool any = false;
 #pragma unroll
-            for (int u = 0; u < 2; u++) { const int32_t q = lo[u] + q0 + l16; id[u] = q < hi[u] ? (int32_t)cs_list[q] : -1; any = any || lo[u] + q0 < hi[u]; }
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) { const int32_t q = lo[u] + q0 + 16 * h + l16; id[u][h] = q < hi[u] ? (int32_t)cs_list[q] : -1; }
+                any = any || lo[u] + q0 < hi[u];
+            }
             if (!any) break;
 #pragma unroll
-            for (int u = 0; u < 2; u++)
-                if (id[u] >= 0) { if (MAXOP) mx[u] = max(mx[u], raw[id[u]]); else sen_active[id[u]] = 1; }
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (id[u][h] >= 0) { if (MAXOP) mx[u] = max(mx[u], raw[id[u][h]]); else sen_active[id[u][h]] = 1; }
         }
         if (MAXOP) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < U; u++) {
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) mx[u] = max(mx[u], __shfl_xor(mx[u], o, 64));
                 if (on[u] && l16 == 0) cs_val[cs[u]] = cs_wt ? add32(mx[u], cs_wt[cs[u]]) : mx[u];

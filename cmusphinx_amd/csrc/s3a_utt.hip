@@ -753,32 +753,52 @@ d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *
     LogAdd la;
     la.tab = S.tab16; la.size = S.tab_size; la.zero = S.lm_zero;
     int32_t rbest = INT_MIN, rns = 0, rng = 0;
-    for (int32_t s0 = S.n_ci_sen + bx * NT; s0 < S.n_sen; s0 += G * NT) {
-        const int32_t sen = s0 + tid;
-        if (sen >= S.n_sen) continue;
-        if (!L.sen_act[sen]) continue;
-        L.sen_act[sen] = 0;                         /* the mask is consumed: clean for the next frame's marks */
-        const int32_t ci_scr = row[S.cd2cisen[sen]];
-        if (ci_scr >= thresh) {                     /* full evaluation */
-            const int32_t bi = (int32_t)brow[sen];
-            L.bstidx[sen] = bi == 255 ? S3A_NO_BSTIDX : bi;
-            L.updatetime[sen] = f;
-            rbest = max(rbest, row[sen]); rns++; rng += (int32_t)S.ncomp[sen];
-            continue;
+    /* (four runs of NT senones per turn: what a senone's decision reads -- its mark, its CI senone's score, its own score and best
+     * component, last frame's best component and when that was -- is asked for together for all four, coalesced; one senone per turn
+     * was a chain of four round trips per turn) */
+    for (int32_t s0 = S.n_ci_sen + bx * NT; s0 < S.n_sen; s0 += 4 * G * NT) {
+        int32_t senq[4], ciq[4], cisq[4], rowq[4], obq[4], utq[4];
+        uint8_t actq[4], nbq[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            senq[u] = s0 + u * G * NT + tid;
+            const bool in = senq[u] < S.n_sen;
+            actq[u] = in ? L.sen_act[senq[u]] : (uint8_t)0;
+            ciq[u] = in ? S.cd2cisen[senq[u]] : 0;
         }
-        const int32_t bi = L.bstidx[sen], ut = L.updatetime[sen];
-        if (bi == S3A_NO_BSTIDX || ut != f - 1) {   /* the CI senone stands in */
-            row[sen] = ci_scr;
-            rbest = max(rbest, ci_scr);
-            continue;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool on = actq[u] != 0;
+            cisq[u] = on ? row[ciq[u]] : 0; rowq[u] = on ? row[senq[u]] : 0; nbq[u] = on ? brow[senq[u]] : (uint8_t)0;
+            obq[u] = on ? L.bstidx[senq[u]] : 0; utq[u] = on ? L.updatetime[senq[u]] : 0;
         }
-        /* the best Gaussian of the previous frame alone */
-        const int32_t v = uw_one_gaussian<EXACT>(S, sen * S.CP + bi, ctx->feat + (size_t)f * S.D4 * 4);
-        int32_t score = la(S3A_LOGPROB_ZERO, v);
-        if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
-        row[sen] = score;
-        rbest = max(rbest, score); rng++;
-        if (is_skip) { L.bstidx[sen] = v > S3A_LOGPROB_ZERO ? bi : S3A_NO_BSTIDX; L.updatetime[sen] = f; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!actq[u]) continue;
+            const int32_t sen = senq[u];
+            L.sen_act[sen] = 0;                         /* the mask is consumed: clean for the next frame's marks */
+            const int32_t ci_scr = cisq[u];
+            if (ci_scr >= thresh) {                     /* full evaluation */
+                const int32_t bi = (int32_t)nbq[u];
+                L.bstidx[sen] = bi == 255 ? S3A_NO_BSTIDX : bi;
+                L.updatetime[sen] = f;
+                rbest = max(rbest, rowq[u]); rns++; rng += (int32_t)S.ncomp[sen];
+                continue;
+            }
+            const int32_t bi = obq[u], ut = utq[u];
+            if (bi == S3A_NO_BSTIDX || ut != f - 1) {   /* the CI senone stands in */
+                row[sen] = ci_scr;
+                rbest = max(rbest, ci_scr);
+                continue;
+            }
+            /* the best Gaussian of the previous frame alone */
+            const int32_t v = uw_one_gaussian<EXACT>(S, sen * S.CP + bi, ctx->feat + (size_t)f * S.D4 * 4);
+            int32_t score = la(S3A_LOGPROB_ZERO, v);
+            if (score <= S3A_LOGPROB_ZERO) score = S3A_LOGPROB_ZERO;
+            row[sen] = score;
+            rbest = max(rbest, score); rng++;
+            if (is_skip) { L.bstidx[sen] = v > S3A_LOGPROB_ZERO ? bi : S3A_NO_BSTIDX; L.updatetime[sen] = f; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1524,6 +1544,8 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_SPIN_MAX (1 << 21)
 #define KF_MAXC 32
 #define KF_MAXSEG (KF_MAXC * KF_WAVES)
+#define KF_SK 8                 /* list positions a thread stamps per pass */
+#define KF_RK 8                 /* kept entries a thread ranks per pass of lextree_enter's ranking */
 #define KF_SETS 512            /* listed parent sets a workgroup takes per pass of the propagation step */
 #define KF_TP_LDS 1024          /* words of transition matrices kept in LDS */
 #define KF_ENT 640              /* propagating parents of a pass's several-parent sets kept in LDS (a set whose parents find no room goes the wave-per-set way) */
@@ -1553,6 +1575,7 @@ struct KfSh {                   /* the workgroup's LDS outside the word level's 
     KfPool pool;
     int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
     int32_t seg[KF_MAXSEG + 1], ws[KF_WAVES + 1], gq[4];    /* lextree_enter: the waves' segments of passing entries, scan scratch */
+    int32_t rk[KF_RK][KF_WAVES];  /* ... the ranking pass's counts per (run, wave) */
     long long kacc[16];         /* the steps' clock of the utterance so far (UCtx.kacc) */
     int32_t thr[4];             /* the frame's thresholds: HMM, phone, word (final once the histogram beam is known) */
     int32_t tp[KF_TP_LDS];      /* the transition matrices (when they fit: 48 of hub4's 3-state topology are 2.3 KB) */
@@ -1624,7 +1647,7 @@ kf_locate(const int32_t *pre, int32_t T, int32_t g, int32_t &t, int32_t &i)
 template <int NE>
 __device__ __forceinline__ int32_t
 kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const int32_t *__restrict__ tp_g, const int32_t *tp_lds, const bool tp_in_lds,
-            const int32_t *__restrict__ raw, int32_t norm,
+            const int32_t *__restrict__ raw, const int32_t *raw_lds, const bool raw_in_lds, int32_t norm,
             const int32_t *__restrict__ cs_valw, int32_t *rec_all, int32_t cf, int32_t &w, int32_t &out)
 {
     constexpr int NV = NE == 3 ? 2 : 3;             /* 16-byte pieces that hold scores, histories, exit score, exit history */
@@ -1658,9 +1681,19 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
     for (int st = 0; st < NE; st++) { r.s[st] = wd[st]; r.h[st] = wd[NE + st]; }
     r.out = wd[2 * NE]; r.outh = wd[2 * NE + 1];
     int32_t e[NE];
-    const int32_t *src = nd.w ? cs_valw : raw;
+    /* (the frame's row of senone scores from LDS when it fits: three gathers less in the CU's address path) */
+    if (nd.w) {
 #pragma unroll
-    for (int st = 0; st < NE; st++) e[st] = add32(src[id[st]], -norm);
+        for (int st = 0; st < NE; st++) e[st] = add32(cs_valw[id[st]], -norm);
+    }
+    else if (raw_in_lds) {
+#pragma unroll
+        for (int st = 0; st < NE; st++) e[st] = add32(raw_lds[id[st]], -norm);
+    }
+    else {
+#pragma unroll
+        for (int st = 0; st < NE; st++) e[st] = add32(raw[id[st]], -norm);
+    }
     int32_t k;
     if (NE == 5) { int32_t out_written = 0; k = vit5(r, tp, e, out_written); (void)out_written; }
     else k = vit3(r, tp, e[0], e[1], e[2]);
@@ -1679,16 +1712,21 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
 /* srch_TST_select_active_gmm's step for one node from its packed ids (mark_node_senones with one gather instead of five): a plain
  * node's senones join the mask, a composite node's composite senones are stamped and -- by whoever stamps one first -- listed */
 template <int NE>
+__device__ __forceinline__ int4
+kf_mark_load(int32_t v, const int32_t *__restrict__ nodesen)
+{
+    if (NE == 3) { const int2 a = *(const int2 *)(nodesen + (size_t)v * 2); return make_int4(a.x, a.y, 0, 0); }
+    return *(const int4 *)(nodesen + (size_t)v * 4);
+}
+template <int NE>
 __device__ __forceinline__ void
-kf_mark_node(int32_t v, const int32_t *__restrict__ nodesen, uint8_t *sen_act, int32_t *cs_need, int32_t stamp, int32_t *cs_wl, int32_t *cs_wn)
+kf_mark_apply(const int4 a, uint8_t *sen_act, int32_t *cs_need, int32_t stamp, int32_t *cs_wl, int32_t *cs_wn)
 {
     int32_t id[NE], comp;
     if (NE == 3) {
-        const int2 a = *(const int2 *)(nodesen + (size_t)v * 2);
         id[0] = a.x & 0xffff; id[1] = (int32_t)((uint32_t)a.x >> 16); id[2] = a.y & 0xffff; comp = (int32_t)((uint32_t)a.y >> 16);
     }
     else {
-        const int4 a = *(const int4 *)(nodesen + (size_t)v * 4);
         const int32_t h[5] = { a.x & 0xffff, (int32_t)((uint32_t)a.x >> 16), a.y & 0xffff, (int32_t)((uint32_t)a.y >> 16), a.z & 0xffff };
 #pragma unroll
         for (int st = 0; st < NE; st++) id[st] = h[st];
@@ -1703,6 +1741,12 @@ kf_mark_node(int32_t v, const int32_t *__restrict__ nodesen, uint8_t *sen_act, i
 #pragma unroll
         for (int st = 0; st < NE; st++) sen_act[id[st]] = 1;
     }
+}
+template <int NE>
+__device__ __forceinline__ void
+kf_mark_node(int32_t v, const int32_t *__restrict__ nodesen, uint8_t *sen_act, int32_t *cs_need, int32_t stamp, int32_t *cs_wl, int32_t *cs_wn)
+{
+    kf_mark_apply<NE>(kf_mark_load<NE>(v, nodesen), sen_act, cs_need, stamp, cs_wl, cs_wn);
 }
 
 /* frame f of lane z (workgroup r of its C): row / brow = the frame's senone scores and best components */
@@ -1801,25 +1845,44 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         }
         const int32_t P = sh.seg[gwaves], c1 = ctx->n_groups > 1 ? ctx->groups[4 + 3] : INT_MAX;      /* (group 1's first call) */
         if (r == 0) {
+            /* (KF_RK entries per thread and pass, their loads asked for together: a pass is two round trips and two barriers whatever
+             * it holds -- one entry per thread and pass was six passes for the usual ~2 600 kept entries, each waiting on its own chain) */
             int32_t carry = 0;
-            for (int32_t i0 = 0; i0 < P; i0 += KF_NT) {
-                const int32_t i = i0 + tid;
-                int32_t q = 0, c = 0, p_ = 0;
-                if (i < P) {
-                    int32_t lo = 0, hi = gwaves - 1;
-                    while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
-                    p_ = lo * R + (i - sh.seg[lo]);
-                    const int32_t v = L.eflag[p_];
-                    c = L.ent[2 * p_ + 1];
-                    q = (S3A_ALD(&L.first[v]) == c && L.frame[NSV(v)] != nf) ? 1 : 0;       /* (sc < scr: true of every kept entry) */
+            for (int32_t i0 = 0; i0 < P; i0 += KF_RK * KF_NT) {
+                int32_t q[KF_RK], c[KF_RK], p_[KF_RK], v[KF_RK], fs[KF_RK], fr[KF_RK];
+#pragma unroll
+                for (int k = 0; k < KF_RK; k++) {
+                    const int32_t i = i0 + k * KF_NT + tid;
+                    p_[k] = -1;
+                    if (i < P) {
+                        int32_t lo = 0, hi = gwaves - 1;
+                        while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
+                        p_[k] = lo * R + (i - sh.seg[lo]);
+                    }
                 }
-                const unsigned long long m = __ballot(q), m0 = __ballot(q && c < c1);
-                if (lane == 0) { sh.ws[wave] = __popcll(m); if (m0) atomicAdd(&sh.gq[0], __popcll(m0)); }
+#pragma unroll
+                for (int k = 0; k < KF_RK; k++) { v[k] = p_[k] >= 0 ? L.eflag[p_[k]] : 0; c[k] = p_[k] >= 0 ? L.ent[2 * p_[k] + 1] : 0; }
+#pragma unroll
+                for (int k = 0; k < KF_RK; k++) { fs[k] = p_[k] >= 0 ? S3A_ALD(&L.first[v[k]]) : -1; fr[k] = p_[k] >= 0 ? L.frame[NSV(v[k])] : nf; }
+                unsigned long long m[KF_RK];
+                int32_t n0 = 0;
+#pragma unroll
+                for (int k = 0; k < KF_RK; k++) {
+                    q[k] = (p_[k] >= 0 && fs[k] == c[k] && fr[k] != nf) ? 1 : 0;       /* (sc < scr: true of every kept entry) */
+                    m[k] = __ballot(q[k]);
+                    n0 += __popcll(__ballot(q[k] && c[k] < c1));
+                    if (lane == 0) sh.rk[k][wave] = __popcll(m[k]);
+                }
+                if (lane == 0 && n0) atomicAdd(&sh.gq[0], n0);
                 __syncthreads();
                 int32_t before = carry;
-                for (int32_t w = 0; w < wave; w++) before += sh.ws[w];
-                if (i < P) L.ent[2 * p_ + 1] = ((before + __popcll(m & ((1ull << lane) - 1ull))) << 8) | (q << 7) | c;
-                for (int32_t w = 0; w < KF_WAVES; w++) carry += sh.ws[w];
+#pragma unroll
+                for (int k = 0; k < KF_RK; k++) {
+                    int32_t mine = before;
+                    for (int32_t w = 0; w < KF_WAVES; w++) { const int32_t x = sh.rk[k][w]; if (w < wave) mine += x; before += x; }
+                    if (p_[k] >= 0) L.ent[2 * p_[k] + 1] = ((mine + __popcll(m[k] & ((1ull << lane) - 1ull))) << 8) | (q[k] << 7) | c[k];
+                }
+                carry = before;
                 __syncthreads();
             }
             /* the groups' new list lengths (group 0 = the unigram tree's calls, group 1 = the filler tree's: consecutive entries) */
@@ -1837,8 +1900,17 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         for (int32_t t = 0; t < T; t++) {
             const int32_t na = n0[t], b = S.node_base[t];
             /* (the trees laid end to end: a thread's positions are mt, mt + ms, ... of the concatenation) */
-            for (int32_t i = mt - a % ms + (mt < a % ms ? ms : 0); i < na; i += ms)
-                kf_mark_node<NE>(L.act[cur][b + i], S.nodesen, L.sen_act, L.cs_need, f, L.cs_wl, L.cs_wn);
+            /* (four nodes per turn: their chains position -> node -> packed ids run side by side) */
+            for (int32_t i = mt - a % ms + (mt < a % ms ? ms : 0); i < na; i += 4 * ms) {
+                int32_t vq[4];
+                int4 aq[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) vq[u] = i + u * ms < na ? L.act[cur][b + i + u * ms] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (vq[u] >= 0) aq[u] = kf_mark_load<NE>(vq[u], S.nodesen);
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (vq[u] >= 0) kf_mark_apply<NE>(aq[u], L.sen_act, L.cs_need, f, L.cs_wl, L.cs_wn);
+            }
             a += na;
         }
     }
@@ -1850,21 +1922,47 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         const int32_t R = (((n_ent + gwaves - 1) / gwaves) + 63) & ~63;
         const int32_t P = sh.seg[gwaves], c1 = ctx->n_groups > 1 ? ctx->groups[4 + 3] : INT_MAX, gq0 = L.ctot[KF_MAXSEG];
         (void)n_calls;
-        for (int32_t i = gtid; i < P; i += gstride) {
-            int32_t lo = 0, hi = gwaves - 1;
-            while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
-            const int32_t p_ = lo * R + (i - sh.seg[lo]);
-            const int32_t v = L.eflag[p_], fl = L.ent[2 * p_ + 1], c = fl & 127;
-            const int32_t g = c >= c1 ? 1 : 0, t = ctx->groups[4 * g];
-            if (fl & 128) {
-                const int32_t k = L.n0[t] + (fl >> 8) - (g ? gq0 : 0);
-                L.act[cur][S.node_base[t] + k] = v; L.pos[v] = k; L.posf[v] = nf;
-                kf_mark_node<NE>(v, S.nodesen, L.sen_act, L.cs_need, nf, L.cs_wl, L.cs_wn);
+        /* (four entries per turn, their loads side by side: entry -> root / flags -> the root's key and first call; what the turn
+         * stores -- list places, scores, tags, senone marks -- none of these loads reads) */
+        for (int32_t i0 = gtid; i0 < P; i0 += 4 * gstride) {
+            int32_t pq[4], vq[4], flq[4], fsq[4];
+            unsigned long long kq[4];
+            int4 aq[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int32_t i = i0 + u * gstride;
+                pq[u] = -1;
+                if (i < P) {
+                    int32_t lo = 0, hi = gwaves - 1;
+                    while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= i) lo = mid; else hi = mid - 1; }
+                    pq[u] = lo * R + (i - sh.seg[lo]);
+                }
             }
-            const unsigned long long key = S3A_ALD(&L.key[v]);
-            const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(key & 0xffffffffu);
-            if (c == win_c) { L.sc[NSV(v)] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); L.hist[NSV(v)] = sh.pool.e1.hist[c]; }
-            if (c == S3A_ALD(&L.first[v])) L.frame[NSV(v)] = nf;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { vq[u] = pq[u] >= 0 ? L.eflag[pq[u]] : 0; flq[u] = pq[u] >= 0 ? L.ent[2 * pq[u] + 1] : 0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                kq[u] = 0ull; fsq[u] = -1;
+                if (pq[u] >= 0) {
+                    kq[u] = S3A_ALD(&L.key[vq[u]]); fsq[u] = S3A_ALD(&L.first[vq[u]]);
+                    if (flq[u] & 128) aq[u] = kf_mark_load<NE>(vq[u], S.nodesen);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (pq[u] < 0) continue;
+                const int32_t v = vq[u], fl = flq[u], c = fl & 127;
+                const int32_t g = c >= c1 ? 1 : 0, t = ctx->groups[4 * g];
+                if (fl & 128) {
+                    const int32_t k = L.n0[t] + (fl >> 8) - (g ? gq0 : 0);
+                    L.act[cur][S.node_base[t] + k] = v; L.pos[v] = k; L.posf[v] = nf;
+                    kf_mark_apply<NE>(aq[u], L.sen_act, L.cs_need, nf, L.cs_wl, L.cs_wn);
+                }
+                const unsigned long long key = kq[u];
+                const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(key & 0xffffffffu);
+                if (c == win_c) { L.sc[NSV(v)] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); L.hist[NSV(v)] = sh.pool.e1.hist[c]; }
+                if (c == fsq[u]) L.frame[NSV(v)] = nf;
+            }
         }
     }
     kf_barrier(B);
@@ -1916,6 +2014,11 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         if (lane == 0) sh.red[wave] = gb;
         if (tid < 2 * T) sh.acc[tid] = INT_MIN;
         if (r == 0 && tid == 0) L.cs_wn[0] = 0;                 /* (the frame's list of composite senones is consumed) */
+        /* the frame's senone scores: into the pool when they fit (no other step's data lives there now) */
+        const bool row_in_lds = (size_t)S.n_sen * 4 <= sizeof(KfPool);
+        int32_t *row_lds = (int32_t *)&sh.pool;
+        if (row_in_lds)
+            for (int32_t i = tid; i < S.n_sen; i += KF_NT) row_lds[i] = row[i];
         __syncthreads();
         int32_t norm = max(L.misc[0], L.misc[5]);               /* the frame's normaliser */
         for (int w = 0; w < KF_WAVES; w++) norm = max(norm, sh.red[w]);
@@ -1943,7 +2046,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             int32_t k = INT_MIN, w = -1;
             if (v0 >= 0) {
                 int32_t out;
-                k = kf_hmm_eval<NE>(v0, nd0, S.nodesen, S.tp, sh.tp, tp_in_lds, row, norm, L.cs_val, L.sc, f, w, out);
+                k = kf_hmm_eval<NE>(v0, nd0, S.nodesen, S.tp, sh.tp, tp_in_lds, row, row_lds, row_in_lds, norm, L.cs_val, L.sc, f, w, out);
                 L.poswid[b0 + i0] = w;
                 L.posout[b0 + i0] = out;
                 L.posbest[b0 + i0] = k;
@@ -1997,16 +2100,49 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         int32_t th, pth;
         frame_thresholds_hb(sh.best, T, bm, 1, th, pth);
         int32_t *pc = &L.pcnt[f & 1];
-        for (int32_t g = gtid; g < n_tot; g += gstride) {
-            int32_t t, i;
-            kf_locate(sh.pre, T, g, t, i);
-            const int32_t b = S.node_base[t];
-            if (L.posout[b + i] < pth) continue;
-            const int32_t u = L.act[cur][b + i];
-            for (int32_t q = S.psof_off[u], q_hi = S.psof_off[u + 1]; q < q_hi; q++) {
-                const int32_t ps = S.psof[q];
-                L.pstamp8[ps] = ps_val<uint8_t>(f);
-                if (atomicExch(&L.claim[ps], f) != f) L.plist[atomicAdd(pc, 1)] = ps;
+        /* (KF_SK positions per thread and pass, stage by stage -- exit scores, the passing HMMs' nodes, their ranges of parent sets, then
+         * set after set: one position per pass was seven passes of up to six dependent round trips; the list's counter is taken once
+         * per wave and stage) */
+        for (int32_t gb = 0; gb < n_tot; gb += KF_SK * gstride) {
+            int32_t ix[KF_SK], q0[KF_SK], q1[KF_SK];
+            bool ok[KF_SK];
+#pragma unroll
+            for (int k = 0; k < KF_SK; k++) {
+                const int32_t g = gb + k * gstride + gtid;
+                ok[k] = g < n_tot; ix[k] = 0;
+                if (ok[k]) { int32_t t, i; kf_locate(sh.pre, T, g, t, i); ix[k] = S.node_base[t] + i; }
+            }
+#pragma unroll
+            for (int k = 0; k < KF_SK; k++) ok[k] = ok[k] && L.posout[ix[k]] >= pth;
+#pragma unroll
+            for (int k = 0; k < KF_SK; k++) ix[k] = ok[k] ? L.act[cur][ix[k]] : 0;
+            int32_t nq = 0;
+#pragma unroll
+            for (int k = 0; k < KF_SK; k++) { q0[k] = ok[k] ? S.psof_off[ix[k]] : 0; q1[k] = ok[k] ? S.psof_off[ix[k] + 1] : 0; nq = max(nq, q1[k] - q0[k]); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nq = max(nq, __shfl_xor(nq, o, 64));      /* (uniform over the wave: the ballots below) */
+            for (int32_t j = 0; j < nq; j++) {
+                int32_t ps[KF_SK], old[KF_SK], at[KF_SK];
+#pragma unroll
+                for (int k = 0; k < KF_SK; k++) ps[k] = q0[k] + j < q1[k] ? S.psof[q0[k] + j] : -1;
+#pragma unroll
+                for (int k = 0; k < KF_SK; k++) {
+                    old[k] = f;
+                    if (ps[k] >= 0) { L.pstamp8[ps[k]] = ps_val<uint8_t>(f); old[k] = atomicExch(&L.claim[ps[k]], f); }
+                }
+                unsigned long long mm[KF_SK];
+#pragma unroll
+                for (int k = 0; k < KF_SK; k++) {
+                    mm[k] = __ballot(old[k] != f);
+                    at[k] = 0;
+                    if (mm[k] && lane == __ffsll((long long)mm[k]) - 1) at[k] = atomicAdd(pc, __popcll(mm[k]));
+                }
+#pragma unroll
+                for (int k = 0; k < KF_SK; k++) {
+                    if (!mm[k]) continue;
+                    const int32_t base = __shfl(at[k], __ffsll((long long)mm[k]) - 1, 64);
+                    if (old[k] != f) L.plist[base + __popcll(mm[k] & ((1ull << lane) - 1ull))] = ps[k];
+                }
             }
         }
     }
@@ -3496,10 +3632,14 @@ q_grow(TP **d, TP **h, size_t *cap, size_t need, const char *what)
 
 /* ---- ku_frames: the frames [fg0, fg0 + nf) of all lanes as ONE launch (behind the look-ahead pass that scores them) ---- */
 /* does this engine, as it is configured now, run its frames through ku_frames? */
-/* (n: the lanes the call keeps busy.  Measured with one engine on the hub4-shaped task, ku_frames : launches -- 256 lanes 443 : 288 k
- * frames/s, 128 lanes (clusters of 3) 272 : 223 k, 64 lanes (7) 128 : 155 k, 32 lanes 58 : 111 k, one lane 5.2 : 9.4 k: a cluster's
- * barrier costs ~8 us against a launch boundary's ~1.5, so below KF_MIN_LANES the launches stay) */
-#define KF_MIN_LANES 96
+/* (n: the lanes the call keeps busy.  Measured with one engine on the hub4-shaped task, ku_frames : launches, k frames/s -- 256 lanes
+ * 443 : 288, 128 lanes (clusters of 3) 407 : 223, 64 lanes (4) 273 : 153, 32 lanes (4) 159 : 110, 16 lanes (8) 91 : 73, 8 lanes (8)
+ * 54.7 : 45.2, 4 lanes (16) 28.2 : 27.7, one lane (16) 7.6 : 9.4 -- with the clusters' XCD-local barrier (the general one, an L2
+ * write-back per workgroup and step: 128 lanes 284, 64 lanes 216, and the launches won below 96 lanes).  Larger clusters do not pay
+ * (32 lanes: 159 / 146 / 94 k with 4 / 8 / 15 workgroups; 64 lanes: 273 / 219 k with 4 / 7): the entry ranking and the word level
+ * stay one workgroup's.  Below KF_MIN_LANES the launches stay) */
+#define KF_MIN_LANES 8
+#define KF_CLUSTER_MAX(n) ((n) <= 16 ? 8 : 4)
 static bool
 kf_served(const s3a_uttdec_t *ud, int32_t n)
 {
@@ -3523,7 +3663,7 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
     const int32_t per_xcd = max(1, ud->kf_slots / 8), lanes_per_xcd = (n + 7) / 8;
     int32_t C = 1;
     if (ud->kf_cluster_opt > 0) C = ud->kf_cluster_opt;
-    else if (ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1) C = min(per_xcd / lanes_per_xcd, 4);
+    else if (ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1) C = min(per_xcd / lanes_per_xcd, KF_CLUSTER_MAX(n));
     /* (a margin per XCD: the occupancy query can be one workgroup per CU high, MI355X_MICROARCH "Residency") */
     C = max(1, min(C, (per_xcd - (per_xcd > 8 ? 4 : 0)) / lanes_per_xcd));
     ud->kf_last_c = C;

@@ -1,6 +1,6 @@
 """ku_frames (s3a_uttdec_opts_t.persist / .cluster, round 5): the lane's frame as the phases of ONE persistent workgroup -- or a
 cluster of them with a counter barrier -- instead of twelve launches per frame, every frame's senone scores computed before the
-search starts, the queue's lanes taking their utterances themselves.  The library chooses it from 96 busy lanes on (below that
+search starts, the queue's lanes taking their utterances themselves.  The library chooses it from 8 busy lanes on (below that
 the launches win); here S3A_UTT_PERSIST=1 forces it for engines of 1 .. 40 lanes so that every mode runs on the small tasks:
 
   KF_STATIC (s3a_uttdec_decode), KF_QUEUE (s3a_uttdec_decode_queue: no schedule, lanes refill themselves, a lane whose utterance
