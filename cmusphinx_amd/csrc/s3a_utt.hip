@@ -51,6 +51,7 @@ struct ULane {
     int32_t *cs_need, *cs_val;  /* [n_cs] composite senones: wanted in frame (stamp) | score of the frame */
     int32_t *cs_wl, *cs_wn;     /* [n_cs + 1], [1] ku_frames: the composite senones wanted in the frame, each once, any order | their number */
     int32_t *posbest;           /* [N] ku_frames: by list position, the HMM's best score of the frame (as poswid / posout) */
+    int32_t *posps;             /* [N] ku_frames, 3-state HMMs: by list position, the parent set of the HMM's node (-1: none; from the packed node) */
     int32_t *ent;               /* [2 ent_cap] ku_frames: lextree_enter's scratch (the entries that pass the threshold test) */
     uint8_t *pstamp8;           /* [n_pset] the parent sets' stamps, the frame number's low 8 bits (a quarter of the
                                  * sweep's gathers' footprint; a stale match costs a walk that finds nothing) */
@@ -82,6 +83,9 @@ struct UShared {
     const int4 *node4;          /* per node: {ssid, tmatid, wid, composite}: ku_hmm_eval's static words as one load */
     const int32_t *nodesen;     /* per node, 2 (3 states) or 4 (5 states) words: its senone ids -- of a composite node its composite-senone ids --
                                  * as 16-bit halves (ku_frames: one load instead of the chain node -> sequence id -> three 2-byte gathers) */
+    const int4 *nodepk;         /* 3-state HMMs, per node ONE 16-byte word for everything ku_frames' steps read of it: senone ids 0 | 1 << 16,
+                                 * id 2 | transition matrix << 16, word id, (parent set + 1) << 1 | composite (what is asked for together
+                                 * lives together: one cache line per visit instead of node4's + nodesen's + ps's three) */
     const float4 *mean4, *prec4;
     const float *lrd;
     const int32_t *mixw;
@@ -1544,6 +1548,7 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_SPIN_MAX (1 << 21)
 #define KF_MAXC 32
 #define KF_MAXSEG (KF_MAXC * KF_WAVES)
+#define KF_PSBITS 8192
 #define KF_SK 8                 /* list positions a thread stamps per pass */
 #define KF_RK 8                 /* kept entries a thread ranks per pass of lextree_enter's ranking */
 #define KF_SETS 512            /* listed parent sets a workgroup takes per pass of the propagation step */
@@ -1576,6 +1581,7 @@ struct KfSh {                   /* the workgroup's LDS outside the word level's 
     int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
     int32_t seg[KF_MAXSEG + 1], ws[KF_WAVES + 1], gq[4];    /* lextree_enter: the waves' segments of passing entries, scan scratch */
     int32_t rk[KF_RK][KF_WAVES];  /* ... the ranking pass's counts per (run, wave) */
+    uint32_t psbits[KF_PSBITS / 32];    /* the frame's stamped parent sets, a bit per set id modulo KF_PSBITS (a filter in front of pstamp8) */
     long long kacc[16];         /* the steps' clock of the utterance so far (UCtx.kacc) */
     int32_t thr[4];             /* the frame's thresholds: HMM, phone, word (final once the histogram beam is known) */
     int32_t tp[KF_TP_LDS];      /* the transition matrices (when they fit: 48 of hub4's 3-state topology are 2.3 KB) */
@@ -1655,24 +1661,25 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
     int32_t wd[4 * NV];
 #pragma unroll
     for (int q = 0; q < NV; q++) { const int4 a = rec[q]; wd[4 * q] = a.x; wd[4 * q + 1] = a.y; wd[4 * q + 2] = a.z; wd[4 * q + 3] = a.w; }
-    int32_t id[NE];
-    if (NE == 3) {
-        const int2 a = *(const int2 *)(nodesen + (size_t)v * 2);
-        id[0] = a.x & 0xffff; id[1] = (int32_t)((uint32_t)a.x >> 16); id[2] = a.y & 0xffff;
+    int32_t id[NE], tmat, wid_, comp;
+    if (NE == 3) {              /* (nd = the node's packed word, UShared.nodepk) */
+        id[0] = nd.x & 0xffff; id[1] = (int32_t)((uint32_t)nd.x >> 16); id[2] = nd.y & 0xffff;
+        tmat = (int32_t)((uint32_t)nd.y >> 16); wid_ = nd.z; comp = nd.w & 1;
     }
-    else {
+    else {                      /* (nd = node4) */
         const int4 a = *(const int4 *)(nodesen + (size_t)v * 4);
         const int32_t h[5] = { a.x & 0xffff, (int32_t)((uint32_t)a.x >> 16), a.y & 0xffff, (int32_t)((uint32_t)a.y >> 16), a.z & 0xffff };
 #pragma unroll
         for (int st = 0; st < NE; st++) id[st] = h[st];
+        tmat = nd.y; wid_ = nd.z; comp = nd.w;
     }
     int32_t tp[NS_TPW(NE)];
     if (tp_in_lds) {
 #pragma unroll
-        for (int q = 0; q < NS_TPW(NE); q++) tp[q] = tp_lds[nd.y * NS_TPW(NE) + q];
+        for (int q = 0; q < NS_TPW(NE); q++) tp[q] = tp_lds[tmat * NS_TPW(NE) + q];
     }
     else {
-        const int4 *tq = (const int4 *)(tp_g + nd.y * NS_TPW(NE));
+        const int4 *tq = (const int4 *)(tp_g + tmat * NS_TPW(NE));
 #pragma unroll
         for (int q = 0; q < NS_TPW(NE) / 4; q++) { const int4 a = tq[q]; tp[4 * q] = a.x; tp[4 * q + 1] = a.y; tp[4 * q + 2] = a.z; tp[4 * q + 3] = a.w; }
     }
@@ -1682,7 +1689,7 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
     r.out = wd[2 * NE]; r.outh = wd[2 * NE + 1];
     int32_t e[NE];
     /* (the frame's row of senone scores from LDS when it fits: three gathers less in the CU's address path) */
-    if (nd.w) {
+    if (comp) {
 #pragma unroll
         for (int st = 0; st < NE; st++) e[st] = add32(cs_valw[id[st]], -norm);
     }
@@ -1705,7 +1712,7 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
     /* the best score and the frame tag (as if the HMM survived the frame: kf_frame's propagation pass corrects the ones it clears) */
     static_assert(2 * 3 + 2 == 8 && 2 * 5 + 2 == 12, "the record's layout: s3a_structs.h");
     rec[NV] = make_int4(k, cf + 1, 0, 0);
-    w = nd.z; out = r.out;
+    w = wid_; out = r.out;
     return k;
 }
 
@@ -1715,7 +1722,8 @@ template <int NE>
 __device__ __forceinline__ int4
 kf_mark_load(int32_t v, const int32_t *__restrict__ nodesen)
 {
-    if (NE == 3) { const int2 a = *(const int2 *)(nodesen + (size_t)v * 2); return make_int4(a.x, a.y, 0, 0); }
+    /* (3 states: `nodesen` is UShared.nodepk, the node's packed word; brought to nodesen's form: ids, then the composite flag) */
+    if (NE == 3) { const int4 a = ((const int4 *)nodesen)[v]; return make_int4(a.x, (a.y & 0xffff) | ((a.w & 1) << 16), 0, 0); }
     return *(const int4 *)(nodesen + (size_t)v * 4);
 }
 template <int NE>
@@ -1907,7 +1915,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
 #pragma unroll
                 for (int u = 0; u < 4; u++) vq[u] = i + u * ms < na ? L.act[cur][b + i + u * ms] : -1;
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (vq[u] >= 0) aq[u] = kf_mark_load<NE>(vq[u], S.nodesen);
+                for (int u = 0; u < 4; u++) if (vq[u] >= 0) aq[u] = kf_mark_load<NE>(vq[u], NE == 3 ? (const int32_t *)S.nodepk : S.nodesen);
 #pragma unroll
                 for (int u = 0; u < 4; u++) if (vq[u] >= 0) kf_mark_apply<NE>(aq[u], L.sen_act, L.cs_need, f, L.cs_wl, L.cs_wn);
             }
@@ -1945,7 +1953,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 kq[u] = 0ull; fsq[u] = -1;
                 if (pq[u] >= 0) {
                     kq[u] = S3A_ALD(&L.key[vq[u]]); fsq[u] = S3A_ALD(&L.first[vq[u]]);
-                    if (flq[u] & 128) aq[u] = kf_mark_load<NE>(vq[u], S.nodesen);
+                    if (flq[u] & 128) aq[u] = kf_mark_load<NE>(vq[u], NE == 3 ? (const int32_t *)S.nodepk : S.nodesen);
                 }
             }
 #pragma unroll
@@ -2032,11 +2040,11 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             const int32_t ga = r * KF_NT + tid, gb_ = ga + gstride;
             if (ga < n_tot) { kf_locate(sh.pre, T, ga, t0, i0); b0 = S.node_base[t0]; v0 = act[b0 + i0]; }
             if (gb_ < n_tot) { kf_locate(sh.pre, T, gb_, t1, i1); b1 = S.node_base[t1]; v1 = act[b1 + i1]; }
-            if (v0 >= 0) nd0 = S.node4[v0];
+            if (v0 >= 0) nd0 = (NE == 3 ? S.nodepk : S.node4)[v0];
         }
         for (int32_t g0 = r * KF_NT; g0 < n_tot; g0 += gstride) {
             int4 nd1 = make_int4(0, 0, 0, 0);
-            if (v1 >= 0) nd1 = S.node4[v1];
+            if (v1 >= 0) nd1 = (NE == 3 ? S.nodepk : S.node4)[v1];
             int32_t t2 = -1, i2 = 0, b2 = 0, v2 = -1;
             {
                 const int32_t gc = g0 + 2 * gstride + tid;
@@ -2050,6 +2058,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 L.poswid[b0 + i0] = w;
                 L.posout[b0 + i0] = out;
                 L.posbest[b0 + i0] = k;
+                if (NE == 3) L.posps[b0 + i0] = (int32_t)((uint32_t)nd0.w >> 1) - 1;
             }
             /* a wave's 64 positions belong to one tree, or to two or three at the seams */
             unsigned long long todo = __ballot(t >= 0);
@@ -2167,6 +2176,17 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         if (r == 0 && hist_frame)
             for (int32_t i = tid; i < NBIN; i += KF_NT) L.hbin[i] = 0;         /* (the bins were consumed by the sort; hbin[NBIN] stays) */
         const int32_t *act = L.act[cur];
+        /* the frame's stamped parent sets as a filter in LDS (every stamp was listed: d_stamp_and_list and the stamping pass above), so
+         * that the usual HMM -- nobody stamped its set -- is settled without a visit to pstamp8; a 3-state HMM's set id came with its
+         * packed node and lies by list position (a histogram frame has reordered the positions: through the node then) */
+        {
+            for (int32_t i = tid; i < KF_PSBITS / 32; i += KF_NT) sh.psbits[i] = 0u;
+            __syncthreads();
+            const int32_t n_pl = S3A_ALD(&L.pcnt[f & 1]);
+            for (int32_t k = tid; k < n_pl; k += KF_NT) { const uint32_t q = (uint32_t)L.plist[k] % KF_PSBITS; atomicOr(&sh.psbits[q >> 5], 1u << (q & 31)); }
+            __syncthreads();
+        }
+        const bool ps_by_pos = NE == 3 && !hist_frame;
         /* the active HMMs by list position, two per thread and turn (their chains of gathers run side by side) */
         for (int32_t g0 = r * 2 * KF_NT; g0 < n_tot; g0 += 2 * gstride) {
             int32_t gg[2] = { g0 + tid, g0 + KF_NT + tid }, tt[2], ii[2], bb[2], vv[2], qq[2], pbv[2];
@@ -2177,9 +2197,15 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 if (gg[u] < n_tot) { kf_locate(sh.pre, T, gg[u], tt[u], ii[u]); bb[u] = S.node_base[tt[u]]; vv[u] = act[bb[u] + ii[u]]; }
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) { qq[u] = vv[u] >= 0 ? S.ps[vv[u]] : -1; pbv[u] = vv[u] >= 0 ? L.posbest[bb[u] + ii[u]] : 0; }
+            for (int u = 0; u < 2; u++) {
+                qq[u] = vv[u] >= 0 ? (ps_by_pos ? L.posps[bb[u] + ii[u]] : S.ps[vv[u]]) : -1;
+                pbv[u] = vv[u] >= 0 ? L.posbest[bb[u] + ii[u]] : 0;
+            }
 #pragma unroll
-            for (int u = 0; u < 2; u++) stv[u] = qq[u] >= 0 ? L.pstamp8[qq[u]] : (uint8_t)(ps_val<uint8_t>(f) + 1);
+            for (int u = 0; u < 2; u++) {
+                const uint32_t qb = (uint32_t)qq[u] % KF_PSBITS;
+                stv[u] = (qq[u] >= 0 && ((sh.psbits[qb >> 5] >> (qb & 31)) & 1u)) ? L.pstamp8[qq[u]] : (uint8_t)(ps_val<uint8_t>(f) + 1);
+            }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 if (vv[u] < 0) continue;
@@ -2555,6 +2581,20 @@ ku_pack_node4(const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmat
     if (v < N) out[v] = make_int4(ssid[v], tmatid[v], wid[v], (int32_t)comp[v]);
 }
 
+/* 3-state HMMs: everything ku_frames reads of a node in one 16-byte word (UShared.nodepk) */
+__global__ void
+ku_pack_nodepk(const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid, const int32_t *__restrict__ wid,
+               const uint8_t *__restrict__ comp, const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
+               const int32_t *__restrict__ ps, int4 *out, int32_t N)
+{
+    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const int16_t *row = (comp[v] ? comsseq : sseq) + (size_t)ssid[v] * 3;
+    const uint32_t i0 = (uint16_t)row[0], i1 = (uint16_t)row[1], i2 = (uint16_t)row[2];
+    out[v] = make_int4((int32_t)(i0 | (i1 << 16)), (int32_t)(i2 | ((uint32_t)tmatid[v] << 16)), wid[v],
+                       (int32_t)(((uint32_t)(ps[v] + 1) << 1) | (comp[v] ? 1u : 0u)));
+}
+
 /* (ne = 3: 2 words per node, ne = 5: 4) */
 __global__ void
 ku_pack_nodesen(const int32_t *__restrict__ ssid, const uint8_t *__restrict__ comp, const int16_t *__restrict__ sseq,
@@ -2894,6 +2934,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.d.cs_wl) (void)hipFree(hl.d.cs_wl);
         if (hl.d.cs_wn) (void)hipFree(hl.d.cs_wn);
         if (hl.d.posbest) (void)hipFree(hl.d.posbest);
+        if (hl.d.posps) (void)hipFree(hl.d.posps);
         if (hl.d.dynbeam) (void)hipFree(hl.d.dynbeam);
         if (hl.d.pstamp8) (void)hipFree(hl.d.pstamp8);
         if (hl.d.plist) (void)hipFree(hl.d.plist);
@@ -2956,6 +2997,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     if (ud->S.rootprob) (void)hipFree((void *)ud->S.rootprob);
     if (ud->S.node4) (void)hipFree((void *)ud->S.node4);
     if (ud->S.nodesen) (void)hipFree((void *)ud->S.nodesen);
+    if (ud->S.nodepk) (void)hipFree((void *)ud->S.nodepk);
     if (ud->S.ctx_all) (void)hipFree(ud->S.ctx_all);
     if (ud->S.nact_all) (void)hipFree(ud->S.nact_all);
     if (ud->d_lcmap) (void)hipFree(ud->d_lcmap);
@@ -3064,6 +3106,13 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         S.nodesen = ns;
         hipLaunchKernelGGL(ku_pack_nodesen, dim3((unsigned)((proto->N + 255) / 256)), dim3(256), 0, ud->stream, proto->d_ssid, proto->d_comp, proto->d_sseq,
                            proto->d_comsseq, ns, proto->N, ne);
+        if (ne == 3 && proto->n_tmat < 65536 && proto->d_ps) {
+            int4 *pk = NULL;
+            DM(pk, (size_t)(proto->N > 0 ? proto->N : 1) * sizeof(int4));
+            S.nodepk = pk;
+            hipLaunchKernelGGL(ku_pack_nodepk, dim3((unsigned)((proto->N + 255) / 256)), dim3(256), 0, ud->stream, proto->d_ssid, proto->d_tmatid, proto->d_wid,
+                               proto->d_comp, proto->d_sseq, proto->d_comsseq, proto->d_ps, pk, proto->N);
+        }
     }
     {   /* the roots' look-ahead probabilities in root-list order (Entries::rootprob) */
         const size_t nr = proto->h_rootlist.size();
@@ -3263,7 +3312,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         u.sen_act = hl.sc->act_d; u.scr = hl.sc->scr_d; u.misc = hl.sc->misc_d; u.bstidx = hl.sc->bstidx_d;
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
         DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4); DM(u.dynbeam, 16);
-        DM(u.cs_wl, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_wn, 16); u.ent = ls->d_ent; DM(u.posbest, (size_t)(proto->N + 64) * 4);
+        DM(u.cs_wl, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_wn, 16); u.ent = ls->d_ent; DM(u.posbest, (size_t)(proto->N + 64) * 4); DM(u.posps, (size_t)(proto->N + 64) * 4);
         if (hipMemset(u.cs_wn, 0, 16) != hipSuccess) goto fail; DM(u.pstamp8, (size_t)proto->n_pset + 64); S.n_pset_bytes = proto->n_pset + 64;
         DM(u.plist, (size_t)(proto->N + 64) * 4); DM(u.pcnt, 16); DM(u.claim, (size_t)(proto->N + 64) * 4);
         if (hipMemset(u.pcnt, 0, 16) != hipSuccess) goto fail;
@@ -3645,7 +3694,7 @@ kf_served(const s3a_uttdec_t *ud, int32_t n)
 {
     const UShared &S = ud->S;
     return ud->persist && (ud->persist > 1 || n >= KF_MIN_LANES) && S.win_K > 0 && !ud->big_wl && S.pheurtype == 0 && S.max_cd >= S.n_sen - S.n_ci_sen && !ud->d_dbg
-        && ud->prof_every == 0 && (S.ne == 3 || S.ne == 5) && S.T <= WL_MAXT;
+        && ud->prof_every == 0 && ((S.ne == 3 && S.nodepk) || S.ne == 5) && S.T <= WL_MAXT;
 }
 
 template <int NE, bool EXACT>
