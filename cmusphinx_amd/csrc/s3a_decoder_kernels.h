@@ -22,6 +22,7 @@
  * hold the line from an earlier plain load): read past the L1 (sc1).  Across a kernel boundary a plain load does; the bodies below
  * also run as phases of one persistent launch (ku_frames, s3a_utt.hip), so they read such words this way. */
 #define S3A_ALD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define S3A_ALDU(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 /* k_dec_scan: workgroups per tree.  One (walking the list 1024 positions at a time) unless the host's bound on the
  * list length is long: a chained multi-workgroup scan costs ~3 us per link, which pays from ~16 k positions on
  * (56 k HMMs per frame: 44 -> 23 us; 3 k HMMs: 14 us either way, and slower when batched) */
@@ -470,7 +471,7 @@ d_dec_hist_sort_ws(const int32_t *__restrict__ node_base, int32_t *act, const in
     for (int32_t i = tid; i < na; i += NT) {
         const int32_t v = tmp[b + i];
         act[b + i] = v;
-        pos[v] = i;
+        pos[PPX(v)] = i;
     }
     __syncthreads();
     return force_tree < 0 ? -(s_i * (-bm.hmmbeam / NBIN)) : 1;      /* the histogram beam (hbin[NBIN]) */
@@ -541,11 +542,11 @@ d_dec_weak_t(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__r
         for (int32_t k = threadIdx.x; k < nw; k += NT) {
             const int32_t v = weaklist[k];
             if (((volatile int32_t *)propf)[v] == cf) continue;
-            const int32_t in0 = sc[NSV(v)], j = pos[v];
+            const int32_t in0 = sc[NSV(v)], j = pos[PPX(v)];
             bool early = false;
             for (int32_t q = par_off[v]; q < par_off[v + 1] && !early; q++) {
                 const int32_t g = par[q];
-                if (posf[g] != cf || pos[g] >= j) continue;
+                if (posf[PPX(g)] != cf || pos[PPX(g)] >= j) continue;
                 const int32_t po = outs[NSV(g)];
                 if (po < pth) continue;
                 if (bests[NSV(g)] < th && ((volatile int32_t *)propf)[g] != cf) continue;
@@ -648,7 +649,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
     }
     if (is_active && !has_par) {
         /* no parent can enter v (the usual active HMM): it survives or is cleared at its own turn -- one gather */
-        const int32_t j = j_known >= 0 ? j_known : pos[v], b = b_known >= 0 ? b_known : node_base[tree_of[v]];
+        const int32_t j = j_known >= 0 ? j_known : pos[PPX(v)], b = b_known >= 0 ? b_known : node_base[tree_of[v]];
         if (bests[NSV(v)] >= th) { selfemit[b + j] = 1; atomicAdd(&cnt[b + j], 1); frame[NSV(v)] = nf; }
         else {
             const int32_t ne = (int32_t)(hist - sc);        /* (the record's layout: s3a_structs.h) */
@@ -663,7 +664,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
         }
         return;
     }
-    const int32_t j = is_active ? (j_known >= 0 ? j_known : pos[v]) : INT_MAX;     /* (known when v was taken from the list) */
+    const int32_t j = is_active ? (j_known >= 0 ? j_known : pos[PPX(v)]) : INT_MAX;     /* (known when v was taken from the list) */
     const int32_t in0 = sc[NSV(v)];
     int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
     int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
@@ -675,7 +676,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
 #pragma unroll
         for (int u = 0; u < 8; u++) pid[u] = (k0 + u < kend) ? par[k0 + u] : -1;
 #pragma unroll
-        for (int u = 0; u < 8; u++) pf[u] = (pid[u] >= 0) ? posf[pid[u]] : INT_MIN;
+        for (int u = 0; u < 8; u++) pf[u] = (pid[u] >= 0) ? posf[PPX(pid[u])] : INT_MIN;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             if (pf[u] != cf || pid[u] < 0) continue;
@@ -689,7 +690,7 @@ d_dec_resolve_node(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_
             if (pth < th && bests[NSV(p)] < th && propf[p] != cf) continue;
             const int32_t ns = add32(po, add32(prob[v], -prob[p]));
             if (ns < th) continue;
-            const int32_t pp = pos[p];
+            const int32_t pp = pos[PPX(p)];
             if (HEUR && add32(ns, hx.heur[hx.node_ci[v]]) < hx.hth_pos[(b_known >= 0 ? b_known : node_base[tree_of[v]]) + pp]) continue;
             if (pp < j) {
                 if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[NSV(p)]; }
@@ -734,7 +735,7 @@ d_dec_resolve(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t *__
         key[r] = 0ull;
         first[r] = INT_MAX;
     }
-    const bool is_active = posf[v] == cf;
+    const bool is_active = posf[PPX(v)] == cf;
     const int32_t q = ps[v];
     const bool has_par = q >= 0 && pstamp[q] == ps_val<PS>(cf); /* some parent may enter v (its parent set is stamped) */
     if (!is_active && !has_par) return;                 /* nothing can happen to v */
@@ -824,7 +825,7 @@ d_dec_resolve_utt(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const int32_t
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int32_t i = threadIdx.x; i < total; i += 64) {
         const int32_t v = s_cand[i];
-        if (posf[v] != cf) d_dec_resolve_node<PS, HEUR>(RS_ARGS, v, false, true, -1, -1, hx);     /* (the active ones: by list position) */
+        if (posf[PPX(v)] != cf) d_dec_resolve_node<PS, HEUR>(RS_ARGS, v, false, true, -1, -1, hx);     /* (the active ones: by list position) */
     }
 #undef RS_ARGS
 }
@@ -882,7 +883,7 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
             int32_t po = 0, pp = 0, ph = 0, pr = 0, ht = INT_MIN, g = -1;
             if (lane < np) {
                 g = par[kp0 + lane];
-                if (posf[g] == cf) {
+                if (posf[PPX(g)] == cf) {
                     po = outs[NSV(g)];
                     qual = po >= pth && !(pth < th && bests[NSV(g)] < th && propf[g] != cf);
                 }
@@ -890,7 +891,7 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
             const unsigned long long qm = __ballot(qual);
             const int32_t b = node_base[tree_of[x0]];
             if (qual) {
-                pp = pos[g]; ph = outh[NSV(g)]; pr = prob[g];
+                pp = pos[PPX(g)]; ph = outh[NSV(g)]; pr = prob[g];
                 if (HEUR) ht = hx.hth_pos[b + pp];
                 const int32_t at = __popcll(qm & ((1ull << lane) - 1ull));
                 s_po[at] = po; s_pp[at] = pp; s_ph[at] = ph; s_pr[at] = pr; s_ht[at] = ht;
@@ -899,9 +900,9 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
             const int32_t nq = __popcll(qm);
             for (int32_t c = m_lo + lane; c < m_hi; c += 64) {
                 const int32_t x = psmem[c];
-                const bool on_list = posf[x] == cf;                         /* (the list position pass leaves these members to us) */
+                const bool on_list = posf[PPX(x)] == cf;                         /* (the list position pass leaves these members to us) */
                 if (!on_list && nq == 0) continue;
-                const int32_t j = on_list ? pos[x] : INT_MAX;
+                const int32_t j = on_list ? pos[PPX(x)] : INT_MAX;
                 const int32_t in0 = sc[NSV(x)], px = prob[x];
                 const int32_t hv = HEUR ? hx.heur[hx.node_ci[x]] : 0;
                 int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
@@ -928,7 +929,7 @@ d_dec_resolve_children(int32_t N, int32_t T, int32_t cf, FrameBeams bm, const in
         }
         for (int32_t c = m_lo + lane; c < m_hi; c += 64) {
             const int32_t x = psmem[c];
-            if (posf[x] == cf) continue;                                    /* on the list: resolved by list position */
+            if (posf[PPX(x)] == cf) continue;                                    /* on the list: resolved by list position */
             d_dec_resolve_node<PS, HEUR>(N, T, cf, bm, best, nact, node_base, tree_of, prob, par_off, par, pos, posf, sc, hist, outs, outh,
                                          bests, frame, turn, selfemit, cnt, key, first, hbin, ps, pstamp, rootnodes, n_rootnodes, propf,
                                          posout, x, false, true, -1, -1, hx, thp);
@@ -1343,7 +1344,7 @@ d_dec_emit_w(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *_
                 /* the node put itself on the list at its own turn: position = its turn's base (the scattered
                  * stores happen here, spread over the sweep's workgroups, not in k_dec_scan's one per tree) */
                 const int32_t u = act[b + i];
-                nxt[b + lo] = u; pos[u] = lo; posf[u] = nf;
+                nxt[b + lo] = u; PP_SET(pos, u, lo, nf);
                 selfemit[b + i] = 0;
                 lo++;
             }
@@ -1363,7 +1364,7 @@ d_dec_emit_w(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *_
 #pragma unroll
                 for (int q = 0; q < EMIT_NARROW; q++)
                     if (cid[q] >= 0 && ct[q] == i && k < hi) {
-                        nxt[b + k] = cid[q]; pos[cid[q]] = k; posf[cid[q]] = nf;
+                        nxt[b + k] = cid[q]; PP_SET(pos, cid[q], k, nf);
                         turn[cid[q]] = -1;
                         k++;
                     }
@@ -1384,7 +1385,7 @@ d_dec_emit_w(int32_t cf, const int32_t *__restrict__ node_base, const int32_t *_
                 const unsigned long long m = __ballot(mine);
                 if (mine) {
                     const int32_t q = k + __popcll(m & ((1ull << lane) - 1ull));
-                    nxt[b + q] = c; pos[c] = q; posf[c] = nf;
+                    nxt[b + q] = c; PP_SET(pos, c, q, nf);
                     turn[c] = -1;
                 }
                 k += __popcll(m);
@@ -1521,9 +1522,9 @@ template <bool MAXOP, int U = 4>
 __device__ __forceinline__ void
 d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__restrict__ cs_off, const int16_t *__restrict__ cs_list,
               uint8_t *sen_active, const int32_t *__restrict__ raw, int32_t *cs_val, int32_t grp, int32_t n_grp,
-              const int32_t *__restrict__ cs_wt = NULL)
+              const int32_t *__restrict__ cs_wt = NULL, uint32_t *actbits = NULL)
 {
-    /* (cs_wt: the composite senone's weight is added to the maximum -- add32 wraps, so the evaluation's
+    /* (actbits: the mask as bits (ku_frames: in LDS) instead of bytes.  cs_wt: the composite senone's weight is added to the maximum -- add32 wraps, so the evaluation's
      * (score - normaliser) + weight comes out the same whichever is added first) */
     const int32_t l16 = threadIdx.x & 15;
     for (int32_t j0 = 0; j0 < n_w; j0 += U * n_grp) {       /* (trip count uniform over the wave: the shuffles below see all lanes) */
@@ -1547,7 +1548,7 @@ d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__rest
             for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int h = 0; h < 2; h++)
-                    if (id[u][h] >= 0) { if (MAXOP) mx[u] = max(mx[u], raw[id[u][h]]); else sen_active[id[u][h]] = 1; }
+                    if (id[u][h] >= 0) { if (MAXOP) mx[u] = max(mx[u], raw[id[u][h]]); else if (actbits) atomicOr(&actbits[id[u][h] >> 5], 1u << (id[u][h] & 31)); else sen_active[id[u][h]] = 1; }
         }
         if (MAXOP) {
 #pragma unroll
@@ -1736,7 +1737,7 @@ d_dec_enter3_mark(int32_t n_ent_blocks, Entries ent, int32_t n_ent,
         if (fl & 1) {
             int32_t k = n0[t] + (fl >> 1);
             for (int32_t cc = c_lo; cc < c; cc++) k += ctot[cc];
-            nxt[node_base[t] + k] = v; pos[v] = k; posf[v] = nf;
+            nxt[node_base[t] + k] = v; PP_SET(pos, v, k, nf);
             mark_node_senones(v, ssid, comp, sseq, comsseq, cs_off, cs_list, sen_active, cs_need, nf, (int32_t)(hist - sc), cs_wl, cs_wn);
         }
         const unsigned long long k = S3A_ALD(&key[v]);                  /* (d_dec_enter1's atomicMax / atomicMin) */

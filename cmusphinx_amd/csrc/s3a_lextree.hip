@@ -132,7 +132,7 @@ k_lt_prop_mark(const int32_t *__restrict__ node_base, const int32_t *__restrict_
     for (int32_t j = child_off[u]; j < child_off[u + 1]; j++) {
         const int32_t c = child[j];
         const int32_t ns = add32(outs[NSV(u)], add32(prob[c], -prob[u]));
-        if (ns >= th && posf[c] != cf && atomicExch(&candf[c], cf) != cf)
+        if (ns >= th && posf[PPX(c)] != cf && atomicExch(&candf[c], cf) != cf)
             cand[node_base[t] + atomicAdd(&ncand[t], 1)] = c;
     }
 }
@@ -164,12 +164,12 @@ k_lt_prop_resolve(const int32_t *__restrict__ node_base, const int32_t *__restri
     int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
     for (int32_t k = par_off[v]; k < par_off[v + 1]; k++) {
         const int32_t p = par[k];
-        if (posf[p] != cf) continue;                /* parent not in this frame's list */
+        if (posf[PPX(p)] != cf) continue;                /* parent not in this frame's list */
         const int32_t po = outs[NSV(p)];
         if (po < pth) continue;
         const int32_t ns = add32(po, add32(prob[v], -prob[p]));
         if (ns < th) continue;
-        const int32_t pp = pos[p];
+        const int32_t pp = pos[PPX(p)];
         if (pp < j) {
             if (ns > mE || (ns == mE && pp < pE)) { mE = ns; pE = pp; hE = outh[NSV(p)]; }
             if (ns > in0 && pp < firstE) firstE = pp;
@@ -223,13 +223,13 @@ k_lt_prop_emit(const int32_t *__restrict__ node_base, const int32_t *__restrict_
         const int32_t u = act[b + i];
         int32_t k = cnt[b + i];
         if (selfemit[b + i]) {
-            nxt[b + k] = u; pos[u] = k; posf[u] = nf; k++;
+            nxt[b + k] = u; PP_SET(pos, u, k, nf); k++;
             selfemit[b + i] = 0;
         }
         for (int32_t j = child_off[u]; j < child_off[u + 1]; j++) {
             const int32_t c = child[j];
             if (turn[c] == i) {
-                nxt[b + k] = c; pos[c] = k; posf[c] = nf; k++;
+                nxt[b + k] = c; PP_SET(pos, c, k, nf); k++;
                 turn[c] = -1;
             }
         }
@@ -401,7 +401,7 @@ k_lt_enter_pass2(const int32_t *__restrict__ ent, int32_t n_ent, const int32_t *
         const int32_t scr = add32(calls[2 * c], prob[v]);
         if (scr >= thresh && sc[NSV(v)] < scr && first[v] == c && frame[NSV(v)] != nf) {
             const int32_t k = n0 + flag[e];
-            nxt[b + k] = v; pos[v] = k; posf[v] = nf;
+            nxt[b + k] = v; PP_SET(pos, v, k, nf);
         }
     }
     __syncthreads();
@@ -499,6 +499,22 @@ fill(s3a_lexsearch_t *ls, int32_t *p, int32_t v, int32_t n)
     return S3A_OK;
 }
 
+/* every second word (one half of the (pos, posf) pairs) */
+__global__ void
+k_fill2_i32(int32_t *p, int32_t v, int32_t n)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[PPX(i)] = v;
+}
+static int32_t
+fill2(s3a_lexsearch_t *ls, int32_t *p, int32_t v, int32_t n)
+{
+    if (n <= 0) return S3A_OK;
+    hipLaunchKernelGGL(k_fill2_i32, dim3((n + 255) / 256), dim3(256), 0, ls->stream, p, v, n);
+    HIPCHK(hipGetLastError());
+    return S3A_OK;
+}
+
 /* the per-decoder half: HMM state, active lists, per-frame scratch, staging buffers */
 static int32_t
 alloc_state(s3a_lexsearch_t *ls)
@@ -508,7 +524,7 @@ alloc_state(s3a_lexsearch_t *ls)
     const int32_t ne = ls->n_emit;
     ls->d_hist = ls->d_sc + NS_HIST(ne); ls->d_outs = ls->d_sc + NS_OUTS(ne); ls->d_outh = ls->d_sc + NS_OUTH(ne);
     ls->d_bests = ls->d_sc + NS_BESTS(ne); ls->d_frame = ls->d_sc + NS_FRAME(ne);
-    DMALLOC(ls->d_pos, (size_t)N * 4); DMALLOC(ls->d_posf, (size_t)N * 4);
+    DMALLOC(ls->d_pos, (size_t)N * 8); ls->d_posf = ls->d_pos + 1;     /* (pairs: PPX, s3a_structs.h) */
     DMALLOC(ls->d_act[0], (size_t)N * 4); DMALLOC(ls->d_act[1], (size_t)N * 4);
     DMALLOC(ls->d_nact[0], (size_t)n_tree * 4); DMALLOC(ls->d_nact[1], (size_t)n_tree * 4);
     DMALLOC(ls->d_cand, (size_t)N * 4); DMALLOC(ls->d_ncand, (size_t)n_tree * 4);
@@ -784,7 +800,7 @@ s3a_lexsearch_free(s3a_lexsearch_t *ls)
         &ls->d_child_off, &ls->d_child, &ls->d_par_off, &ls->d_par, &ls->d_rootlist, &ls->d_tp,
         &ls->d_comstate_off, &ls->d_tree_of, &ls->d_rootnodes, &ls->d_ps, &ls->d_psof_off, &ls->d_psof, &ls->d_psmem_off, &ls->d_psmem };
     int32_t **state[] = { &ls->d_sc,            /* (d_hist, d_outs, d_outh, d_bests, d_frame point into d_sc's records) */
-        &ls->d_pos, &ls->d_posf, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
+        &ls->d_pos, &ls->d_act[0], &ls->d_act[1], &ls->d_nact[0],
         &ls->d_nact[1], &ls->d_cand, &ls->d_ncand, &ls->d_candf, &ls->d_turn, &ls->d_selfemit,
         &ls->d_cnt, &ls->d_best, &ls->d_exit, &ls->d_nexit, &ls->d_calls, &ls->d_ent, &ls->d_eflag,
         &ls->d_first, &ls->d_thr, &ls->d_pack, &ls->d_done, &ls->d_hbin, &ls->d_ctot, &ls->d_n0, &ls->d_pstamp,
@@ -811,7 +827,7 @@ s3a_lexsearch_reset(s3a_lexsearch_t *ls)
 {
     int32_t rc, N = ls->N;
     hipLaunchKernelGGL(k_lt_reset_nodes, dim3((unsigned)((N + LT_BLOCK - 1) / LT_BLOCK)), dim3(LT_BLOCK), 0, ls->stream, ls->d_sc, N, ls->n_emit);
-    if ( (rc = fill(ls, ls->d_pos, -1, N)) || (rc = fill(ls, ls->d_posf, INT_MIN, N))
+    if ( (rc = fill2(ls, ls->d_pos, -1, N)) || (rc = fill2(ls, ls->d_posf, INT_MIN, N))
         || (rc = fill(ls, ls->d_candf, INT_MIN, N)) || (rc = fill(ls, ls->d_pstamp, INT_MIN, ls->n_pset > 0 ? ls->n_pset : 1))
         || (rc = fill(ls, ls->d_turn, -1, N))
         || (rc = fill(ls, ls->d_selfemit, 0, N)) || (rc = fill(ls, ls->d_cnt, 0, N))
@@ -1120,7 +1136,7 @@ s3a_lexsearch_utt_end(s3a_lexsearch_t *ls)
     HIPCHK(hipGetLastError());
     /* frame-tagged scratch must not leak into the next utterance (frames restart at 0) */
     if ((rc = fill(ls, ls->d_nact[0], 0, ls->n_tree)) || (rc = fill(ls, ls->d_nact[1], 0, ls->n_tree))
-        || (rc = fill(ls, ls->d_posf, INT_MIN, ls->N)) || (rc = fill(ls, ls->d_candf, INT_MIN, ls->N))
+        || (rc = fill2(ls, ls->d_posf, INT_MIN, ls->N)) || (rc = fill(ls, ls->d_candf, INT_MIN, ls->N))
         || (rc = fill(ls, ls->d_pstamp, INT_MIN, ls->n_pset > 0 ? ls->n_pset : 1)))
         return rc;
     HIPCHK(hipStreamSynchronize(ls->stream));

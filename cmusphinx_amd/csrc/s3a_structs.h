@@ -44,6 +44,11 @@ struct s3a_scorer_s {
 #define NST 16                                  /* int32 words per node record */
 #define NSI(st, N, v) ((size_t)(v) * NST + (st))
 #define NSV(v) ((size_t)(v) * NST)
+/* a node's place in the active list and the frame that place is valid for (pos, posf) are ONE 8-byte pair per node -- they are
+ * written together (the emission: one scattered store, one dirty line per listed node instead of two) and read together (is the
+ * node on the list, and where): the kernels keep two pointers, posf = pos + 1, and index both with PPX */
+#define PPX(v) ((size_t)(v) * 2)
+#define PP_SET(pos, v, k, f) (*(int2 *)((pos) + PPX(v)) = make_int2((k), (f)))
 /* field offsets for an HMM of ne emitting states (3 or 5): ne scores, ne histories, exit score, exit history, best score,
  * frame tag = 2 ne + 4 <= NST words.  A kernel that holds the derived pointers knows ne as hist - sc. */
 #define NS_HIST(ne) (ne)

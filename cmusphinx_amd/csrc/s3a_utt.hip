@@ -51,6 +51,7 @@ struct ULane {
     int32_t *cs_need, *cs_val;  /* [n_cs] composite senones: wanted in frame (stamp) | score of the frame */
     int32_t *cs_wl, *cs_wn;     /* [n_cs + 1], [1] ku_frames: the composite senones wanted in the frame, each once, any order | their number */
     int32_t *posbest;           /* [N] ku_frames: by list position, the HMM's best score of the frame (as poswid / posout) */
+    uint32_t *senbits;          /* [KF_SENBITS / 32] ku_frames with clusters: the frame's active senones, a bit each (the workgroups' masks OR-ed together; zero between frames) */
     int32_t *posps;             /* [N] ku_frames, 3-state HMMs: by list position, the parent set of the HMM's node (-1: none; from the packed node) */
     int32_t *ent;               /* [2 ent_cap] ku_frames: lextree_enter's scratch (the entries that pass the threshold test) */
     uint8_t *pstamp8;           /* [n_pset] the parent sets' stamps, the frame number's low 8 bits (a quarter of the
@@ -155,7 +156,7 @@ d_lane_end(const ULane &L, const UShared &S, int32_t z, bool scrub, int32_t n_wo
             int32_t *r = L.sc + NSV(v);
             for (int32_t st = 0; st < ne; st++) { r[st] = WORST; r[NS_HIST(ne) + st] = -1; }
             r[NS_OUTS(ne)] = WORST; r[NS_OUTH(ne)] = -1; r[NS_BESTS(ne)] = WORST; r[NS_FRAME(ne)] = -1;
-            L.pos[v] = -1; L.turn[v] = -1; L.selfemit[v] = 0; L.cnt[v] = 0; L.first[v] = INT_MAX; L.key[v] = 0ull;
+            L.pos[PPX(v)] = -1; L.turn[v] = -1; L.selfemit[v] = 0; L.cnt[v] = 0; L.first[v] = INT_MAX; L.key[v] = 0ull;
         }
         for (int32_t i = vt; i <= L.w.hmask; i += vstride) { L.w.hkey[i] = 0ull; L.w.hbest[i] = 0ull; L.w.hfirst[i] = 0xffffffffu; }
         for (int32_t i = vt; i < n_word; i += vstride) { L.w.wfirst[i] = INT_MAX; L.w.wbest[i] = INT_MIN; }
@@ -191,7 +192,7 @@ ku_lanes_end(const ULane *__restrict__ lanes, UShared S, const int32_t *__restri
 __device__ __forceinline__ void
 d_lane_begin(const ULane &L, const UShared &S, const UBegin &B, int32_t z, const UCtx *src, int32_t vt, int32_t vstride, bool lead, int32_t tid, int32_t lead_nt)
 {
-    for (int32_t i = vt; i < S.N; i += vstride) { L.posf[i] = INT_MIN; L.propf[i] = INT_MIN; L.claim[i] = INT_MIN; }
+    for (int32_t i = vt; i < S.N; i += vstride) { L.posf[PPX(i)] = INT_MIN; L.propf[i] = INT_MIN; L.claim[i] = INT_MIN; }
     for (int32_t i = vt; i < B.n_pset; i += vstride) L.pstamp[i] = INT_MIN;
     for (int32_t i = vt; i < S.n_pset_bytes; i += vstride) L.pstamp8[i] = 0xff;
     if (vt == 0) { L.pcnt[0] = 0; L.pcnt[1] = 0; L.cs_wn[0] = 0; }
@@ -242,9 +243,9 @@ ku_framecheck(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t *d
         const int32_t ne = S.ne;
         bool clean = r[NS_OUTS(ne)] == WORST && r[NS_BESTS(ne)] == WORST;
         for (int32_t st = 0; st < ne; st++) clean = clean && r[st] == WORST;
-        const int32_t t = S.tree_of[v], b = S.node_base[t], p = L.pos[v];
+        const int32_t t = S.tree_of[v], b = S.node_base[t], p = L.pos[PPX(v)];
         const int32_t nn = S.nact_all[((size_t)blockIdx.z * 2 + nxt) * WL_MAXT + t];
-        const bool listed = L.posf[v] == nf && p >= 0 && p < nn && L.act[nxt][b + p] == v;
+        const bool listed = L.posf[PPX(v)] == nf && p >= 0 && p < nn && L.act[nxt][b + p] == v;
         /* the propagation scratch must be consumed by the end of the frame: turn by node; selfemit / cnt by list position */
         if (L.turn[v] != -1 || L.selfemit[v] != 0 || L.cnt[v] != 0) {
             if (atomicCAS(&dbg[15], 0, f + 1) == 0) {
@@ -258,7 +259,7 @@ ku_framecheck(const ULane *__restrict__ lanes, UShared S, int32_t fg, int32_t *d
         if ((!clean && !listed) || (listed && r[NS_FRAME(ne)] != nf)) {
             if (atomicCAS(&dbg[0], 0, f + 1) == 0) {
                 dbg[1] = v; dbg[2] = r[0]; dbg[3] = r[1]; dbg[4] = r[NS_OUTS(ne)]; dbg[5] = r[NS_BESTS(ne)]; dbg[6] = r[NS_FRAME(ne)];
-                dbg[7] = L.posf[v]; dbg[8] = p; dbg[9] = L.turn[v]; dbg[10] = nn; dbg[11] = (p >= 0 && p < nn) ? L.act[nxt][b + p] : -7;
+                dbg[7] = L.posf[PPX(v)]; dbg[8] = p; dbg[9] = L.turn[v]; dbg[10] = nn; dbg[11] = (p >= 0 && p < nn) ? L.act[nxt][b + p] : -7;
                 dbg[12] = clean ? 1 : 0; dbg[13] = listed ? 1 : 0; dbg[14] = t;
             }
         }
@@ -731,7 +732,8 @@ uw_one_gaussian(const UShared &S, int32_t g, const float *__restrict__ x)
 /* (NT threads; workgroup bx of G takes every G-th run of NT CD senones and leaves its maxima / counters in column bx of gpart[]) */
 template <bool EXACT, int NT>
 __device__ __forceinline__ void
-d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *row, const uint8_t *brow, int32_t bx, int32_t G)
+d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *row, const uint8_t *brow, int32_t bx, int32_t G,
+         const uint32_t *actbits = NULL)     /* (ku_frames: the mask as bits in LDS, cleared by the caller) */
 {
     __shared__ int32_t red[3][NT / 64];
     __shared__ int32_t s_pb;
@@ -767,7 +769,7 @@ d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *
         for (int u = 0; u < 4; u++) {
             senq[u] = s0 + u * G * NT + tid;
             const bool in = senq[u] < S.n_sen;
-            actq[u] = in ? L.sen_act[senq[u]] : (uint8_t)0;
+            actq[u] = in ? (actbits ? (uint8_t)((actbits[senq[u] >> 5] >> (senq[u] & 31)) & 1u) : L.sen_act[senq[u]]) : (uint8_t)0;
             ciq[u] = in ? S.cd2cisen[senq[u]] : 0;
         }
 #pragma unroll
@@ -780,7 +782,7 @@ d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *
         for (int u = 0; u < 4; u++) {
             if (!actq[u]) continue;
             const int32_t sen = senq[u];
-            L.sen_act[sen] = 0;                         /* the mask is consumed: clean for the next frame's marks */
+            if (!actbits) L.sen_act[sen] = 0;           /* the mask is consumed: clean for the next frame's marks */
             const int32_t ci_scr = cisq[u];
             if (ci_scr >= thresh) {                     /* full evaluation */
                 const int32_t bi = (int32_t)nbq[u];
@@ -1110,8 +1112,8 @@ ku_weak_heur(const ULane *__restrict__ lanes, UShared S, int32_t fg)
                 const int32_t q = q0 + lane;
                 if (q < q_hi) {
                     const int32_t g = S.par[q];
-                    const int32_t pp = L.pos[g];
-                    if (L.posf[g] == f && pp < j) {
+                    const int32_t pp = L.pos[PPX(g)];
+                    if (L.posf[PPX(g)] == f && pp < j) {
                         const int32_t po = L.outs[NSV(g)];
                         if (po >= pth && (L.bests[NSV(g)] >= th || ((volatile int32_t *)L.propf)[g] == f)) {
                             const int32_t nsc = add32(po, add32(S.prob[v], -S.prob[g]));
@@ -1549,6 +1551,7 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_MAXC 32
 #define KF_MAXSEG (KF_MAXC * KF_WAVES)
 #define KF_PSBITS 8192
+#define KF_SENBITS 16384          /* senones ku_frames keeps an activity bit for in LDS (more: the launches stay) */
 #define KF_SK 8                 /* list positions a thread stamps per pass */
 #define KF_RK 8                 /* kept entries a thread ranks per pass of lextree_enter's ranking */
 #define KF_SETS 512            /* listed parent sets a workgroup takes per pass of the propagation step */
@@ -1581,6 +1584,7 @@ struct KfSh {                   /* the workgroup's LDS outside the word level's 
     int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
     int32_t seg[KF_MAXSEG + 1], ws[KF_WAVES + 1], gq[4];    /* lextree_enter: the waves' segments of passing entries, scan scratch */
     int32_t rk[KF_RK][KF_WAVES];  /* ... the ranking pass's counts per (run, wave) */
+    uint32_t senbits[KF_SENBITS / 32];  /* srch_TST_select_active_gmm's mask of the frame, a bit per senone (the launch path: a byte each in HBM) */
     uint32_t psbits[KF_PSBITS / 32];    /* the frame's stamped parent sets, a bit per set id modulo KF_PSBITS (a filter in front of pstamp8) */
     long long kacc[16];         /* the steps' clock of the utterance so far (UCtx.kacc) */
     int32_t thr[4];             /* the frame's thresholds: HMM, phone, word (final once the histogram beam is known) */
@@ -1728,7 +1732,7 @@ kf_mark_load(int32_t v, const int32_t *__restrict__ nodesen)
 }
 template <int NE>
 __device__ __forceinline__ void
-kf_mark_apply(const int4 a, uint8_t *sen_act, int32_t *cs_need, int32_t stamp, int32_t *cs_wl, int32_t *cs_wn)
+kf_mark_apply(const int4 a, uint32_t *senbits, int32_t *cs_need, int32_t stamp, int32_t *cs_wl, int32_t *cs_wn)
 {
     int32_t id[NE], comp;
     if (NE == 3) {
@@ -1747,14 +1751,8 @@ kf_mark_apply(const int4 a, uint8_t *sen_act, int32_t *cs_need, int32_t stamp, i
     }
     else {
 #pragma unroll
-        for (int st = 0; st < NE; st++) sen_act[id[st]] = 1;
+        for (int st = 0; st < NE; st++) atomicOr(&senbits[id[st] >> 5], 1u << (id[st] & 31));       /* (LDS: three scattered stores less per node) */
     }
-}
-template <int NE>
-__device__ __forceinline__ void
-kf_mark_node(int32_t v, const int32_t *__restrict__ nodesen, uint8_t *sen_act, int32_t *cs_need, int32_t stamp, int32_t *cs_wl, int32_t *cs_wn)
-{
-    kf_mark_apply<NE>(kf_mark_load<NE>(v, nodesen), sen_act, cs_need, stamp, cs_wl, cs_wn);
 }
 
 /* frame f of lane z (workgroup r of its C): row / brow = the frame's senone scores and best components */
@@ -1775,6 +1773,11 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     const FrameBeams bm = frame_beams(S, f);
     const int32_t n_ent = ctx->n_ent, n_calls_all = ctx->n_calls, thresh = ctx->thresh;
     if (r == 0 && tid == 0) { t_prev = (long long)wall_clock64(); sh.kacc[13]++; }
+    if (f == 0) {               /* (an utterance that was stopped inside a frame may have left marks behind) */
+        for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) sh.senbits[i] = 0u;
+        if (C > 1 && r == 0) for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) L.senbits[i] = 0u;
+        kf_barrier(B);
+    }
 
     /* ---- lextree_enter (lextree.c:1093-1236; ku_enter1 / 2 / 3 of the launch path): of the frame's ~60 k (call, root) entries a few
      * hundred pass the threshold test, so ONE sweep tests them all (a coalesced load each) and keeps the ones that pass, in entry
@@ -1917,7 +1920,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
 #pragma unroll
                 for (int u = 0; u < 4; u++) if (vq[u] >= 0) aq[u] = kf_mark_load<NE>(vq[u], NE == 3 ? (const int32_t *)S.nodepk : S.nodesen);
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (vq[u] >= 0) kf_mark_apply<NE>(aq[u], L.sen_act, L.cs_need, f, L.cs_wl, L.cs_wn);
+                for (int u = 0; u < 4; u++) if (vq[u] >= 0) kf_mark_apply<NE>(aq[u], sh.senbits, L.cs_need, f, L.cs_wl, L.cs_wn);
             }
             a += na;
         }
@@ -1963,8 +1966,8 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 const int32_t g = c >= c1 ? 1 : 0, t = ctx->groups[4 * g];
                 if (fl & 128) {
                     const int32_t k = L.n0[t] + (fl >> 8) - (g ? gq0 : 0);
-                    L.act[cur][S.node_base[t] + k] = v; L.pos[v] = k; L.posf[v] = nf;
-                    kf_mark_apply<NE>(aq[u], L.sen_act, L.cs_need, nf, L.cs_wl, L.cs_wn);
+                    L.act[cur][S.node_base[t] + k] = v; PP_SET(L.pos, v, k, nf);
+                    kf_mark_apply<NE>(aq[u], sh.senbits, L.cs_need, nf, L.cs_wl, L.cs_wn);
                 }
                 const unsigned long long key = kq[u];
                 const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(key & 0xffffffffu);
@@ -1994,8 +1997,18 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     }
     /* ---- the members of the composite senones wanted in the frame join the mask (ku_comsen_mark): from the frame's list ---- */
     const int32_t n_csw = S3A_ALD(&L.cs_wn[0]);
-    d_comsen_list<false>(L.cs_wl, n_csw, S.cs_off, S.cs_list, L.sen_act, (const int32_t *)NULL, (int32_t *)NULL, gtid >> 4, gstride >> 4);
+    d_comsen_list<false>(L.cs_wl, n_csw, S.cs_off, S.cs_list, (uint8_t *)NULL, (const int32_t *)NULL, (int32_t *)NULL, gtid >> 4, gstride >> 4,
+                         (const int32_t *)NULL, sh.senbits);
+    /* (a cluster's workgroups marked their shares: the masks meet in the lane's words, and every workgroup reads the union back) */
+    if (C > 1) {
+        __syncthreads();
+        for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) if (sh.senbits[i]) atomicOr(&L.senbits[i], sh.senbits[i]);
+    }
     kf_barrier(B);
+    if (C > 1) {
+        for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) sh.senbits[i] = S3A_ALDU(&L.senbits[i]);
+        __syncthreads();
+    }
     KF_STAMP(3);
     const int32_t n_tot = sh.pre[T];
     const bool hist_frame = n_tot > bm.maxhmmpf + (bm.maxhmmpf >> 1);
@@ -2003,10 +2016,13 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
      * cluster does not write are made neutral, so that an engine may take either path from frame to frame ---- */
     {
         const int32_t g_all = max(1, min(USEL_G, min(S.gp_n, (S.n_sen - S.n_ci_sen + 255) / 256))), G = min(C, g_all);
-        if (r < G) d_select<EXACT, KF_NT>(L, S, ctx, f, row, brow, r, G);
+        if (r < G) d_select<EXACT, KF_NT>(L, S, ctx, f, row, brow, r, G, sh.senbits);
         if (r == 0 && tid >= G && tid < g_all) { L.gpart[tid] = INT_MIN; L.gpart[S.gp_n + tid] = 0; L.gpart[2 * S.gp_n + tid] = 0; }
     }
     kf_barrier(B);
+    /* (the mask is consumed: clean for the next frame's marks) */
+    for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) sh.senbits[i] = 0u;
+    if (C > 1 && r == 0) for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) L.senbits[i] = 0u;
     KF_STAMP(4);
     /* ---- the scores of the composite senones wanted in this frame (ku_comsen_max) ---- */
     d_comsen_list<true>(L.cs_wl, n_csw, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, gtid >> 4, gstride >> 4, S.cs_wt);
@@ -2282,7 +2298,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     int32_t lo = 0, hi = nk - 1;
                     while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.pre[mid] <= m) lo = mid; else hi = mid - 1; }
                     const int32_t x = S.psmem[rs.mlo[lo] + (m - rs.pre[lo])];
-                    if (L.posf[x] == f) continue;                               /* on the list: resolved by list position */
+                    if (L.posf[PPX(x)] == f) continue;                               /* on the list: resolved by list position */
                     d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
                                                        L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
                                                        S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, x, false, true, -1, -1,
@@ -2304,7 +2320,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 2; u++) pfv[u] = gp[u] >= 0 ? L.posf[gp[u]] : INT_MIN;
+                        for (int u = 0; u < 2; u++) pfv[u] = gp[u] >= 0 ? L.posf[PPX(gp[u])] : INT_MIN;
 #pragma unroll
                         for (int u = 0; u < 2; u++) {
                             if (pfv[u] != f) continue;
@@ -2313,7 +2329,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                             const int32_t at = atomicAdd(&rs.n_ent, 1);
                             if (at < KF_ENT) {
                                 int32_t *e = rs.ent[at];
-                                e[0] = po; e[1] = L.pos[g]; e[2] = L.outh[NSV(g)]; e[3] = S.prob[g];
+                                e[0] = po; e[1] = L.pos[PPX(g)]; e[2] = L.outh[NSV(g)]; e[3] = S.prob[g];
                                 e[4] = atomicExch(&rs.bnq[sb[u]], at);              /* (the chain's order does not matter: maxima with position tie-breaks) */
                             }
                             else atomicMin(&rs.bnq[sb[u]], -2);
@@ -2337,9 +2353,9 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                         const int32_t k = lo, e0 = rs.bnq[k];
                         if (e0 == -2) continue;                                 /* the wave-per-set way, below */
                         const int32_t x = S.psmem[rs.bmlo[k] + (m - rs.bmpre[k])];
-                        const bool on_list = L.posf[x] == f;                    /* (the list position pass leaves these members to us) */
+                        const bool on_list = L.posf[PPX(x)] == f;                    /* (the list position pass leaves these members to us) */
                         if (!on_list && e0 < 0) continue;
-                        const int32_t j = on_list ? L.pos[x] : INT_MAX, in0 = L.sc[NSV(x)], px = S.prob[x], b = S.node_base[S.tree_of[x]];
+                        const int32_t j = on_list ? L.pos[PPX(x)] : INT_MAX, in0 = L.sc[NSV(x)], px = S.prob[x], b = S.node_base[S.tree_of[x]];
                         int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
                         int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
                         for (int32_t q = e0; q >= 0; q = rs.ent[q][4]) {
@@ -2434,6 +2450,7 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
     const int32_t tid = threadIdx.x;
     if (tid == 0) sh.dead = 0;
     if (tid < 16) sh.kacc[tid] = 0;
+    for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) sh.senbits[i] = 0u;
     if (S.n_tmat * NS_TPW(NE) <= KF_TP_LDS)
         for (int32_t i = tid; i < S.n_tmat * NS_TPW(NE); i += KF_NT) sh.tp[i] = S.tp[i];
     KfBar B = { bar + 2 * z, C, 0, &sh.dead, 0 };
@@ -2449,56 +2466,48 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
         __syncthreads();
     }
     const long long t_launch = (long long)wall_clock64();
-    if (J.mode == KF_WINDOW) {
-        const int32_t f0 = ctx->f0, nfr = ctx->nfr;
-        for (int32_t fg = J.fg0; fg < J.fg0 + J.n_fr; fg++) {
-            const int32_t f = fg - f0;
-            if (f < 0 || f >= nfr) continue;
-            /* (the word level ends an utterance that ran into an error: uniform over the cluster behind the frame's last barrier) */
-            if (!((volatile UCtx *)ctx)->active || sh.dead) break;
-            kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, L.win + (size_t)(f % S.win_K) * S.n_sen,
-                                L.winb + (size_t)(f % S.win_K) * S.n_sen, weak_possible);
-        }
-    }
-    else if (J.mode == KF_STATIC) {
-        const int32_t nfr = ctx->nfr;
-        const size_t r0 = (size_t)J.row0[z];
-        for (int32_t f = 0; f < nfr; f++) {
-            if (!((volatile UCtx *)ctx)->active || sh.dead) break;
-            kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, J.scores + (r0 + f) * S.n_sen, J.bests + (r0 + f) * S.n_sen, weak_possible);
-        }
-    }
-    else {
-        const int32_t gtid = r * KF_NT + tid, gstride = C * KF_NT;
-        for (;;) {
+    /* (ONE call site of the frame for the three modes: the frame's code is ~150 KB, and a copy per mode was three times that in a
+     * kernel whose instruction cache holds 64 KB) */
+    const int32_t mode = J.mode;
+    const int32_t gtid = r * KF_NT + tid, gstride = C * KF_NT;
+    for (;;) {
+        int32_t u = 0, f_lo = 0, f_hi = 0;
+        size_t r0 = 0;
+        if (mode == KF_QUEUE) {
             /* the queue's next utterance: taken by the lane's first workgroup */
             if (r == 0 && tid == 0) {
-                const int32_t u = atomicAdd(J.next, 1);
-                sh.u = u;
-                if (C > 1) __hip_atomic_store(&J.lane_u[z], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int32_t u_ = atomicAdd(J.next, 1);
+                sh.u = u_;
+                if (C > 1) __hip_atomic_store(&J.lane_u[z], u_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             kf_barrier(B);
             if (r > 0 && tid == 0) sh.u = __hip_atomic_load(&J.lane_u[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            const int32_t u = sh.u;
+            u = sh.u;
             if (u >= J.n_utt || sh.dead) break;
             /* srch_utt_begin (srch.c:453-479): every per-utterance state reset, the utterance's context */
             d_lane_begin(L, S, J.B, z, J.stage + J.u0 + u, gtid, gstride, r == 0, tid, KF_NT);
             kf_barrier(B);
-            const int32_t nfr = ctx->nfr;
-            const size_t r0 = (size_t)J.row0[J.u0 + u];
-            for (int32_t f = 0; f < nfr; f++) {
-                if (!((volatile UCtx *)ctx)->active || sh.dead) break;
-                kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, J.scores + (r0 + f) * S.n_sen, J.bests + (r0 + f) * S.n_sen, weak_possible);
-            }
-            if (r == 0 && tid < 16 && tid != 12 && tid != 14) { ctx->kacc[tid] += sh.kacc[tid]; sh.kacc[tid] = 0; }
-            /* srch_utt_end (srch.c:482-560): the hypothesis goes to the utterance's slot, the lane's lists are cleared */
-            static_assert(3 * WL_LDS_EX >= UH_IDS, "d_hyp's backtrace ids borrow the word level's exit area");
-            if (r == 0) d_hyp<KF_NT>(L, ctx, lm, dict, J.P, J.hdr + (size_t)(J.u0 + u) * UH_N, J.words, J.wcount, sh.pool.wl.ex);
-            kf_barrier(B);
-            d_lane_end(L, S, z, ctx->err != 0, J.n_word, gtid, gstride);
-            kf_barrier(B);
+            f_hi = ctx->nfr;
+            r0 = (size_t)J.row0[J.u0 + u];
         }
+        else if (mode == KF_STATIC) { f_hi = ctx->nfr; r0 = (size_t)J.row0[z]; }
+        else { const int32_t f0 = ctx->f0; f_lo = max(0, J.fg0 - f0); f_hi = min(ctx->nfr, J.fg0 + J.n_fr - f0); }
+        for (int32_t f = f_lo; f < f_hi; f++) {
+            /* (the word level ends an utterance that ran into an error: uniform over the cluster behind the frame's last barrier) */
+            if (!((volatile UCtx *)ctx)->active || sh.dead) break;
+            int32_t *row = mode == KF_WINDOW ? L.win + (size_t)(f % S.win_K) * S.n_sen : J.scores + (r0 + f) * S.n_sen;
+            const uint8_t *brow = mode == KF_WINDOW ? L.winb + (size_t)(f % S.win_K) * S.n_sen : J.bests + (r0 + f) * S.n_sen;
+            kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, row, brow, weak_possible);
+        }
+        if (mode != KF_QUEUE) break;
+        if (r == 0 && tid < 16 && tid != 12 && tid != 14) { ctx->kacc[tid] += sh.kacc[tid]; sh.kacc[tid] = 0; }
+        /* srch_utt_end (srch.c:482-560): the hypothesis goes to the utterance's slot, the lane's lists are cleared */
+        static_assert(3 * WL_LDS_EX >= UH_IDS, "d_hyp's backtrace ids borrow the word level's exit area");
+        if (r == 0) d_hyp<KF_NT>(L, ctx, lm, dict, J.P, J.hdr + (size_t)(J.u0 + u) * UH_N, J.words, J.wcount, sh.pool.wl.ex);
+        kf_barrier(B);
+        d_lane_end(L, S, z, ctx->err != 0, J.n_word, gtid, gstride);
+        kf_barrier(B);
     }
     if (r == 0 && tid == 0) { sh.kacc[12] += (long long)wall_clock64() - t_launch; sh.kacc[14]++; }
     if (r == 0 && tid < 16) ctx->kacc[tid] += sh.kacc[tid];             /* (KF_QUEUE: the lane's last utterance has its frames' share already) */
@@ -2935,6 +2944,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.d.cs_wn) (void)hipFree(hl.d.cs_wn);
         if (hl.d.posbest) (void)hipFree(hl.d.posbest);
         if (hl.d.posps) (void)hipFree(hl.d.posps);
+        if (hl.d.senbits) (void)hipFree(hl.d.senbits);
         if (hl.d.dynbeam) (void)hipFree(hl.d.dynbeam);
         if (hl.d.pstamp8) (void)hipFree(hl.d.pstamp8);
         if (hl.d.plist) (void)hipFree(hl.d.plist);
@@ -3313,6 +3323,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         u.bstscr = hl.sc->bstscr_d; u.updatetime = hl.sc->updatetime_d; u.gpart = hl.sc->gpart_d;
         DM(u.cs_need, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_val, (size_t)(cs->n_comstate + 1) * 4); DM(u.dynbeam, 16);
         DM(u.cs_wl, (size_t)(cs->n_comstate + 1) * 4); DM(u.cs_wn, 16); u.ent = ls->d_ent; DM(u.posbest, (size_t)(proto->N + 64) * 4); DM(u.posps, (size_t)(proto->N + 64) * 4);
+        DM(u.senbits, KF_SENBITS / 8); if (hipMemset(u.senbits, 0, KF_SENBITS / 8) != hipSuccess) goto fail;
         if (hipMemset(u.cs_wn, 0, 16) != hipSuccess) goto fail; DM(u.pstamp8, (size_t)proto->n_pset + 64); S.n_pset_bytes = proto->n_pset + 64;
         DM(u.plist, (size_t)(proto->N + 64) * 4); DM(u.pcnt, 16); DM(u.claim, (size_t)(proto->N + 64) * 4);
         if (hipMemset(u.pcnt, 0, 16) != hipSuccess) goto fail;
@@ -3694,7 +3705,7 @@ kf_served(const s3a_uttdec_t *ud, int32_t n)
 {
     const UShared &S = ud->S;
     return ud->persist && (ud->persist > 1 || n >= KF_MIN_LANES) && S.win_K > 0 && !ud->big_wl && S.pheurtype == 0 && S.max_cd >= S.n_sen - S.n_ci_sen && !ud->d_dbg
-        && ud->prof_every == 0 && ((S.ne == 3 && S.nodepk) || S.ne == 5) && S.T <= WL_MAXT;
+        && ud->prof_every == 0 && ((S.ne == 3 && S.nodepk) || S.ne == 5) && S.T <= WL_MAXT && S.n_sen <= KF_SENBITS;
 }
 
 template <int NE, bool EXACT>
