@@ -1531,16 +1531,18 @@ d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__rest
         int32_t cs[U], lo[U], hi[U], mx[U];
         bool on[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int32_t j = j0 + u * n_grp + grp; on[u] = j < n_w; cs[u] = on[u] ? wl[j] : 0; }
+        /* (every load unconditional, at a harmless index for a group without an entry: a load under a condition is a branch with its
+         * own wait inside, and the U chains would run one after the other) */
+        for (int u = 0; u < U; u++) { const int32_t j = j0 + u * n_grp + grp; on[u] = j < n_w; cs[u] = wl[on[u] ? j : 0]; }
 #pragma unroll
-        for (int u = 0; u < U; u++) { lo[u] = on[u] ? cs_off[cs[u]] : 0; hi[u] = on[u] ? cs_off[cs[u] + 1] : 0; mx[u] = INT_MIN; }
+        for (int u = 0; u < U; u++) { const int32_t a0 = cs_off[cs[u]], a1 = cs_off[cs[u] + 1]; lo[u] = on[u] ? a0 : 0; hi[u] = on[u] ? a1 : 0; mx[u] = INT_MIN; }
         for (int32_t q0 = 0; ; q0 += 32) {
             int32_t id[U][2];
             bool any = false;
 #pragma unroll
             for (int u = 0; u < U; u++) {
 #pragma unroll
-                for (int h = 0; h < 2; h++) { const int32_t q = lo[u] + q0 + 16 * h + l16; id[u][h] = q < hi[u] ? (int32_t)cs_list[q] : -1; }
+                for (int h = 0; h < 2; h++) { const int32_t q = lo[u] + q0 + 16 * h + l16; const int32_t x = (int32_t)cs_list[q < hi[u] ? q : 0]; id[u][h] = q < hi[u] ? x : -1; }
                 any = any || lo[u] + q0 < hi[u];
             }
             if (!any) break;
@@ -1548,7 +1550,10 @@ d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__rest
             for (int u = 0; u < U; u++)
 #pragma unroll
                 for (int h = 0; h < 2; h++)
-                    if (id[u][h] >= 0) { if (MAXOP) mx[u] = max(mx[u], raw[id[u][h]]); else if (actbits) atomicOr(&actbits[id[u][h] >> 5], 1u << (id[u][h] & 31)); else sen_active[id[u][h]] = 1; }
+                {
+                    if (MAXOP) { const int32_t x = raw[max(id[u][h], 0)]; if (id[u][h] >= 0) mx[u] = max(mx[u], x); }
+                    else if (id[u][h] >= 0) { if (actbits) atomicOr(&actbits[id[u][h] >> 5], 1u << (id[u][h] & 31)); else sen_active[id[u][h]] = 1; }
+                }
         }
         if (MAXOP) {
 #pragma unroll

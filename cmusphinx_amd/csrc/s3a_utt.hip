@@ -769,14 +769,17 @@ d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *
         for (int u = 0; u < 4; u++) {
             senq[u] = s0 + u * G * NT + tid;
             const bool in = senq[u] < S.n_sen;
-            actq[u] = in ? (actbits ? (uint8_t)((actbits[senq[u] >> 5] >> (senq[u] & 31)) & 1u) : L.sen_act[senq[u]]) : (uint8_t)0;
-            ciq[u] = in ? S.cd2cisen[senq[u]] : 0;
+            const int32_t sq = in ? senq[u] : S.n_ci_sen;            /* (loads unconditional, a thread past the end reads a senone that exists: a load under a
+                                                                       * condition is a branch with its own wait inside) */
+            actq[u] = actbits ? (uint8_t)((actbits[sq >> 5] >> (sq & 31)) & 1u) : L.sen_act[sq];
+            if (!in) actq[u] = 0;
+            ciq[u] = S.cd2cisen[sq];
+            senq[u] = sq;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const bool on = actq[u] != 0;
-            cisq[u] = on ? row[ciq[u]] : 0; rowq[u] = on ? row[senq[u]] : 0; nbq[u] = on ? brow[senq[u]] : (uint8_t)0;
-            obq[u] = on ? L.bstidx[senq[u]] : 0; utq[u] = on ? L.updatetime[senq[u]] : 0;
+            cisq[u] = row[ciq[u]]; rowq[u] = row[senq[u]]; nbq[u] = brow[senq[u]];
+            obq[u] = L.bstidx[senq[u]]; utq[u] = L.updatetime[senq[u]];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -1582,6 +1585,7 @@ union KfPool {                  /* phases that never overlap share this LDS */
 struct KfSh {                   /* the workgroup's LDS outside the word level's own arrays */
     KfPool pool;
     int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
+    int32_t nb[WL_MAXT + 1];    /* the trees' first nodes (UShared.node_base: in LDS, a list position's place in the arrays is then LDS arithmetic only) */
     int32_t seg[KF_MAXSEG + 1], ws[KF_WAVES + 1], gq[4];    /* lextree_enter: the waves' segments of passing entries, scan scratch */
     int32_t rk[KF_RK][KF_WAVES];  /* ... the ranking pass's counts per (run, wave) */
     uint32_t senbits[KF_SENBITS / 32];  /* srch_TST_select_active_gmm's mask of the frame, a bit per senone (the launch path: a byte each in HBM) */
@@ -1662,21 +1666,30 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
 {
     constexpr int NV = NE == 3 ? 2 : 3;             /* 16-byte pieces that hold scores, histories, exit score, exit history */
     int4 *rec = (int4 *)(rec_all + NSV(v));
-    int32_t wd[4 * NV];
-#pragma unroll
-    for (int q = 0; q < NV; q++) { const int4 a = rec[q]; wd[4 * q] = a.x; wd[4 * q + 1] = a.y; wd[4 * q + 2] = a.z; wd[4 * q + 3] = a.w; }
+    /* (order matters to the clock: these are FLAT accesses -- the pointers come out of structures in memory --, a flat load is counted
+     * by the LDS counter too, and a wait for an LDS read therefore waits for every flat load in flight.  So: everything that comes from
+     * memory is asked for first -- the ids are in the packed node --, the transition matrix is read from LDS behind it, and the
+     * scores come through ONE pointer per state, chosen per lane (composite maxima | the row in LDS | the row in memory) */
     int32_t id[NE], tmat, wid_, comp;
+    int4 a5 = make_int4(0, 0, 0, 0);
     if (NE == 3) {              /* (nd = the node's packed word, UShared.nodepk) */
         id[0] = nd.x & 0xffff; id[1] = (int32_t)((uint32_t)nd.x >> 16); id[2] = nd.y & 0xffff;
         tmat = (int32_t)((uint32_t)nd.y >> 16); wid_ = nd.z; comp = nd.w & 1;
     }
     else {                      /* (nd = node4) */
-        const int4 a = *(const int4 *)(nodesen + (size_t)v * 4);
-        const int32_t h[5] = { a.x & 0xffff, (int32_t)((uint32_t)a.x >> 16), a.y & 0xffff, (int32_t)((uint32_t)a.y >> 16), a.z & 0xffff };
+        a5 = *(const int4 *)(nodesen + (size_t)v * 4);
+        const int32_t h[5] = { a5.x & 0xffff, (int32_t)((uint32_t)a5.x >> 16), a5.y & 0xffff, (int32_t)((uint32_t)a5.y >> 16), a5.z & 0xffff };
 #pragma unroll
         for (int st = 0; st < NE; st++) id[st] = h[st];
         tmat = nd.y; wid_ = nd.z; comp = nd.w;
     }
+    const int32_t *src = comp ? cs_valw : (raw_in_lds ? raw_lds : raw);
+    int32_t e[NE];
+#pragma unroll
+    for (int st = 0; st < NE; st++) e[st] = src[id[st]];
+    int32_t wd[4 * NV];
+#pragma unroll
+    for (int q = 0; q < NV; q++) { const int4 a = rec[q]; wd[4 * q] = a.x; wd[4 * q + 1] = a.y; wd[4 * q + 2] = a.z; wd[4 * q + 3] = a.w; }
     int32_t tp[NS_TPW(NE)];
     if (tp_in_lds) {
 #pragma unroll
@@ -1687,24 +1700,12 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
 #pragma unroll
         for (int q = 0; q < NS_TPW(NE) / 4; q++) { const int4 a = tq[q]; tp[4 * q] = a.x; tp[4 * q + 1] = a.y; tp[4 * q + 2] = a.z; tp[4 * q + 3] = a.w; }
     }
+#pragma unroll
+    for (int st = 0; st < NE; st++) e[st] = add32(e[st], -norm);
     HmmRegsT<int32_t> r;
 #pragma unroll
     for (int st = 0; st < NE; st++) { r.s[st] = wd[st]; r.h[st] = wd[NE + st]; }
     r.out = wd[2 * NE]; r.outh = wd[2 * NE + 1];
-    int32_t e[NE];
-    /* (the frame's row of senone scores from LDS when it fits: three gathers less in the CU's address path) */
-    if (comp) {
-#pragma unroll
-        for (int st = 0; st < NE; st++) e[st] = add32(cs_valw[id[st]], -norm);
-    }
-    else if (raw_in_lds) {
-#pragma unroll
-        for (int st = 0; st < NE; st++) e[st] = add32(raw_lds[id[st]], -norm);
-    }
-    else {
-#pragma unroll
-        for (int st = 0; st < NE; st++) e[st] = add32(raw[id[st]], -norm);
-    }
     int32_t k;
     if (NE == 5) { int32_t out_written = 0; k = vit5(r, tp, e, out_written); (void)out_written; }
     else k = vit3(r, tp, e[0], e[1], e[2]);
@@ -1811,13 +1812,21 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 if (e < e_hi) {
                     while (c + 1 < n_calls && sh.pool.e1.off[c + 1] <= e) c++;
                     cc[u] = c; idx[u] = sh.pool.e1.root[c] + (e - sh.pool.e1.off[c]);
-                    scr[u] = add32(sh.pool.e1.in[c], S.rootprob[idx[u]]);
                 }
             }
+            /* (the loads unconditional -- a lane past the end asks for entry 0's words --: a load under a condition is a branch with its
+             * own wait inside, and the four runs' round trips would follow one another instead of running side by side) */
+            int32_t rp[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { keep[u] = e0 + 64 * u + lane < e_hi && scr[u] >= thresh; if (keep[u]) vv[u] = S.rootlist[idx[u]]; }
+            for (int u = 0; u < 4; u++) { rp[u] = S.rootprob[idx[u]]; vv[u] = S.rootlist[idx[u]]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) s0[u] = keep[u] ? L.sc[NSV(vv[u])] : 0;
+            for (int u = 0; u < 4; u++) {
+                if (e0 + 64 * u + lane < e_hi) scr[u] = add32(sh.pool.e1.in[cc[u]], rp[u]);
+                keep[u] = e0 + 64 * u + lane < e_hi && scr[u] >= thresh;
+            }
+            /* (... and an entry under the threshold asks for ONE root's score, its run's first: no line of its own) */
+#pragma unroll
+            for (int u = 0; u < 4; u++) s0[u] = L.sc[NSV(keep[u] ? vv[u] : __shfl(vv[u], 0, 64))];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 keep[u] = keep[u] && s0[u] < scr[u];
@@ -1858,7 +1867,12 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         if (r == 0) {
             /* (KF_RK entries per thread and pass, their loads asked for together: a pass is two round trips and two barriers whatever
              * it holds -- one entry per thread and pass was six passes for the usual ~2 600 kept entries, each waiting on its own chain) */
-            int32_t carry = 0;
+            int32_t carry = 0, p0 = 0;
+            if (P > 0) {            /* (the first kept entry's place: where a thread without an entry of its own sends its loads) */
+                int32_t lo = 0, hi = gwaves - 1;
+                while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= 0) lo = mid; else hi = mid - 1; }
+                p0 = lo * R;
+            }
             for (int32_t i0 = 0; i0 < P; i0 += KF_RK * KF_NT) {
                 int32_t q[KF_RK], c[KF_RK], p_[KF_RK], v[KF_RK], fs[KF_RK], fr[KF_RK];
 #pragma unroll
@@ -1872,9 +1886,11 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < KF_RK; k++) { v[k] = p_[k] >= 0 ? L.eflag[p_[k]] : 0; c[k] = p_[k] >= 0 ? L.ent[2 * p_[k] + 1] : 0; }
+                /* (every load unconditional, at a harmless place for a thread without an entry: a load under a condition is a branch
+                 * with its own wait inside -- eight round trips one after the other instead of one) */
+                for (int k = 0; k < KF_RK; k++) { const int32_t pk = p_[k] >= 0 ? p_[k] : p0; v[k] = L.eflag[pk]; c[k] = L.ent[2 * pk + 1]; }
 #pragma unroll
-                for (int k = 0; k < KF_RK; k++) { fs[k] = p_[k] >= 0 ? S3A_ALD(&L.first[v[k]]) : -1; fr[k] = p_[k] >= 0 ? L.frame[NSV(v[k])] : nf; }
+                for (int k = 0; k < KF_RK; k++) { fs[k] = S3A_ALD(&L.first[v[k]]); fr[k] = L.frame[NSV(v[k])]; }
                 unsigned long long m[KF_RK];
                 int32_t n0 = 0;
 #pragma unroll
@@ -1909,18 +1925,19 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         const int32_t mt = C == 1 ? tid : gtid - KF_NT, ms = C == 1 ? KF_NT : gstride - KF_NT;
         int32_t a = 0;
         for (int32_t t = 0; t < T; t++) {
-            const int32_t na = n0[t], b = S.node_base[t];
+            const int32_t na = n0[t], b = sh.nb[t];
             /* (the trees laid end to end: a thread's positions are mt, mt + ms, ... of the concatenation) */
             /* (four nodes per turn: their chains position -> node -> packed ids run side by side) */
             for (int32_t i = mt - a % ms + (mt < a % ms ? ms : 0); i < na; i += 4 * ms) {
                 int32_t vq[4];
                 int4 aq[4];
+                bool oq[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) vq[u] = i + u * ms < na ? L.act[cur][b + i + u * ms] : -1;
+                for (int u = 0; u < 4; u++) { oq[u] = i + u * ms < na; vq[u] = L.act[cur][b + (oq[u] ? i + u * ms : 0)]; }      /* (loads unconditional: see the ranking) */
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (vq[u] >= 0) aq[u] = kf_mark_load<NE>(vq[u], NE == 3 ? (const int32_t *)S.nodepk : S.nodesen);
+                for (int u = 0; u < 4; u++) aq[u] = kf_mark_load<NE>(vq[u], NE == 3 ? (const int32_t *)S.nodepk : S.nodesen);
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (vq[u] >= 0) kf_mark_apply<NE>(aq[u], sh.senbits, L.cs_need, f, L.cs_wl, L.cs_wn);
+                for (int u = 0; u < 4; u++) if (oq[u]) kf_mark_apply<NE>(aq[u], sh.senbits, L.cs_need, f, L.cs_wl, L.cs_wn);
             }
             a += na;
         }
@@ -1935,6 +1952,12 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         (void)n_calls;
         /* (four entries per turn, their loads side by side: entry -> root / flags -> the root's key and first call; what the turn
          * stores -- list places, scores, tags, senone marks -- none of these loads reads) */
+        int32_t p0 = 0;
+        if (P > 0) {
+            int32_t lo = 0, hi = gwaves - 1;
+            while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= 0) lo = mid; else hi = mid - 1; }
+            p0 = lo * R;
+        }
         for (int32_t i0 = gtid; i0 < P; i0 += 4 * gstride) {
             int32_t pq[4], vq[4], flq[4], fsq[4];
             unsigned long long kq[4];
@@ -1950,14 +1973,11 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { vq[u] = pq[u] >= 0 ? L.eflag[pq[u]] : 0; flq[u] = pq[u] >= 0 ? L.ent[2 * pq[u] + 1] : 0; }
+            for (int u = 0; u < 4; u++) { const int32_t pk = pq[u] >= 0 ? pq[u] : p0; vq[u] = L.eflag[pk]; flq[u] = L.ent[2 * pk + 1]; }       /* (loads unconditional: see the ranking) */
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                kq[u] = 0ull; fsq[u] = -1;
-                if (pq[u] >= 0) {
-                    kq[u] = S3A_ALD(&L.key[vq[u]]); fsq[u] = S3A_ALD(&L.first[vq[u]]);
-                    if (flq[u] & 128) aq[u] = kf_mark_load<NE>(vq[u], NE == 3 ? (const int32_t *)S.nodepk : S.nodesen);
-                }
+                kq[u] = S3A_ALD(&L.key[vq[u]]); fsq[u] = S3A_ALD(&L.first[vq[u]]);
+                aq[u] = kf_mark_load<NE>(vq[u], NE == 3 ? (const int32_t *)S.nodepk : S.nodesen);
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -1966,7 +1986,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 const int32_t g = c >= c1 ? 1 : 0, t = ctx->groups[4 * g];
                 if (fl & 128) {
                     const int32_t k = L.n0[t] + (fl >> 8) - (g ? gq0 : 0);
-                    L.act[cur][S.node_base[t] + k] = v; PP_SET(L.pos, v, k, nf);
+                    L.act[cur][sh.nb[t] + k] = v; PP_SET(L.pos, v, k, nf);
                     kf_mark_apply<NE>(aq[u], sh.senbits, L.cs_need, nf, L.cs_wl, L.cs_wn);
                 }
                 const unsigned long long key = kq[u];
@@ -2054,17 +2074,20 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         int4 nd0 = make_int4(0, 0, 0, 0);
         {
             const int32_t ga = r * KF_NT + tid, gb_ = ga + gstride;
-            if (ga < n_tot) { kf_locate(sh.pre, T, ga, t0, i0); b0 = S.node_base[t0]; v0 = act[b0 + i0]; }
-            if (gb_ < n_tot) { kf_locate(sh.pre, T, gb_, t1, i1); b1 = S.node_base[t1]; v1 = act[b1 + i1]; }
+            if (ga < n_tot) { kf_locate(sh.pre, T, ga, t0, i0); b0 = sh.nb[t0]; v0 = act[b0 + i0]; }
+            if (gb_ < n_tot) { kf_locate(sh.pre, T, gb_, t1, i1); b1 = sh.nb[t1]; v1 = act[b1 + i1]; }
             if (v0 >= 0) nd0 = (NE == 3 ? S.nodepk : S.node4)[v0];
         }
         for (int32_t g0 = r * KF_NT; g0 < n_tot; g0 += gstride) {
-            int4 nd1 = make_int4(0, 0, 0, 0);
-            if (v1 >= 0) nd1 = (NE == 3 ? S.nodepk : S.node4)[v1];
+            /* (unconditional, a thread past the end asks for position 0 / node 0: a load under a condition is a branch with its own wait) */
             int32_t t2 = -1, i2 = 0, b2 = 0, v2 = -1;
+            const int32_t gc = g0 + 2 * gstride + tid;
+            kf_locate(sh.pre, T, gc < n_tot ? gc : 0, t2, i2);          /* (the LDS reads first: a wait for one waits for every flat load in flight) */
+            b2 = sh.nb[t2];
+            const int4 nd1 = (NE == 3 ? S.nodepk : S.node4)[max(v1, 0)];
             {
-                const int32_t gc = g0 + 2 * gstride + tid;
-                if (gc < n_tot) { kf_locate(sh.pre, T, gc, t2, i2); b2 = S.node_base[t2]; v2 = act[b2 + i2]; }
+                const int32_t vx = act[b2 + i2];
+                if (gc < n_tot) v2 = vx; else t2 = -1;
             }
             const int32_t t = t0;
             int32_t k = INT_MIN, w = -1;
@@ -2128,33 +2151,46 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         /* (KF_SK positions per thread and pass, stage by stage -- exit scores, the passing HMMs' nodes, their ranges of parent sets, then
          * set after set: one position per pass was seven passes of up to six dependent round trips; the list's counter is taken once
          * per wave and stage) */
+        int32_t ix0 = 0;
+        if (n_tot > 0) { int32_t t, i; kf_locate(sh.pre, T, 0, t, i); ix0 = sh.nb[t] + i; }       /* (a list position that exists: the loads of threads past the end) */
         for (int32_t gb = 0; gb < n_tot; gb += KF_SK * gstride) {
             int32_t ix[KF_SK], q0[KF_SK], q1[KF_SK];
             bool ok[KF_SK];
+            /* (stage by stage, and no LDS read between the loads of a stage: these are flat loads -- counted by the LDS counter too --,
+             * so waiting for an LDS read waits for all of them) */
 #pragma unroll
             for (int k = 0; k < KF_SK; k++) {
                 const int32_t g = gb + k * gstride + gtid;
-                ok[k] = g < n_tot; ix[k] = 0;
-                if (ok[k]) { int32_t t, i; kf_locate(sh.pre, T, g, t, i); ix[k] = S.node_base[t] + i; }
+                ok[k] = g < n_tot; ix[k] = ix0;
+                if (ok[k]) { int32_t t, i; kf_locate(sh.pre, T, g, t, i); ix[k] = sh.nb[t] + i; }
             }
+            int32_t po[KF_SK];
 #pragma unroll
-            for (int k = 0; k < KF_SK; k++) ok[k] = ok[k] && L.posout[ix[k]] >= pth;
+            for (int k = 0; k < KF_SK; k++) po[k] = L.posout[ix[k]];
 #pragma unroll
-            for (int k = 0; k < KF_SK; k++) ix[k] = ok[k] ? L.act[cur][ix[k]] : 0;
+            for (int k = 0; k < KF_SK; k++) ix[k] = L.act[cur][ix[k]];
+#pragma unroll
+            for (int k = 0; k < KF_SK; k++) ok[k] = ok[k] && po[k] >= pth;
             int32_t nq = 0;
+            {
+                int32_t a0[KF_SK], a1[KF_SK];
 #pragma unroll
-            for (int k = 0; k < KF_SK; k++) { q0[k] = ok[k] ? S.psof_off[ix[k]] : 0; q1[k] = ok[k] ? S.psof_off[ix[k] + 1] : 0; nq = max(nq, q1[k] - q0[k]); }
+                for (int k = 0; k < KF_SK; k++) { a0[k] = S.psof_off[ix[k]]; a1[k] = S.psof_off[ix[k] + 1]; }
+#pragma unroll
+                for (int k = 0; k < KF_SK; k++) { q0[k] = ok[k] ? a0[k] : 0; q1[k] = ok[k] ? a1[k] : 0; nq = max(nq, q1[k] - q0[k]); }
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) nq = max(nq, __shfl_xor(nq, o, 64));      /* (uniform over the wave: the ballots below) */
             for (int32_t j = 0; j < nq; j++) {
                 int32_t ps[KF_SK], old[KF_SK], at[KF_SK];
 #pragma unroll
-                for (int k = 0; k < KF_SK; k++) ps[k] = q0[k] + j < q1[k] ? S.psof[q0[k] + j] : -1;
+                for (int k = 0; k < KF_SK; k++) ps[k] = S.psof[q0[k] + j < q1[k] ? q0[k] + j : 0];
 #pragma unroll
-                for (int k = 0; k < KF_SK; k++) {
-                    old[k] = f;
-                    if (ps[k] >= 0) { L.pstamp8[ps[k]] = ps_val<uint8_t>(f); old[k] = atomicExch(&L.claim[ps[k]], f); }
-                }
+                for (int k = 0; k < KF_SK; k++) if (!(q0[k] + j < q1[k])) ps[k] = -1;
+#pragma unroll
+                for (int k = 0; k < KF_SK; k++) if (ps[k] >= 0) L.pstamp8[ps[k]] = ps_val<uint8_t>(f);
+#pragma unroll
+                for (int k = 0; k < KF_SK; k++) { old[k] = f; if (ps[k] >= 0) old[k] = atomicExch(&L.claim[ps[k]], f); }
                 unsigned long long mm[KF_SK];
 #pragma unroll
                 for (int k = 0; k < KF_SK; k++) {
@@ -2208,15 +2244,23 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             int32_t gg[2] = { g0 + tid, g0 + KF_NT + tid }, tt[2], ii[2], bb[2], vv[2], qq[2], pbv[2];
             uint8_t stv[2];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                tt[u] = 0; ii[u] = 0; bb[u] = 0; vv[u] = -1;
-                if (gg[u] < n_tot) { kf_locate(sh.pre, T, gg[u], tt[u], ii[u]); bb[u] = S.node_base[tt[u]]; vv[u] = act[bb[u] + ii[u]]; }
+            for (int u = 0; u < 2; u++) {           /* (the LDS reads first: a wait for one waits for every flat load in flight) */
+                kf_locate(sh.pre, T, gg[u] < n_tot ? gg[u] : 0, tt[u], ii[u]);
+                bb[u] = sh.nb[tt[u]];
             }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                qq[u] = vv[u] >= 0 ? (ps_by_pos ? L.posps[bb[u] + ii[u]] : S.ps[vv[u]]) : -1;
-                pbv[u] = vv[u] >= 0 ? L.posbest[bb[u] + ii[u]] : 0;
+            for (int u = 0; u < 2; u++) {           /* (loads unconditional, a thread past the end asks for position 0: see the ranking) */
+                const int32_t vx = act[bb[u] + ii[u]];
+                vv[u] = gg[u] < n_tot ? vx : -1;
+                qq[u] = ps_by_pos ? L.posps[bb[u] + ii[u]] : 0;
+                pbv[u] = L.posbest[bb[u] + ii[u]];
             }
+            if (!ps_by_pos) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) qq[u] = S.ps[max(vv[u], 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) if (vv[u] < 0) qq[u] = -1;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const uint32_t qb = (uint32_t)qq[u] % KF_PSBITS;
@@ -2355,7 +2399,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                         const int32_t x = S.psmem[rs.bmlo[k] + (m - rs.bmpre[k])];
                         const bool on_list = L.posf[PPX(x)] == f;                    /* (the list position pass leaves these members to us) */
                         if (!on_list && e0 < 0) continue;
-                        const int32_t j = on_list ? L.pos[PPX(x)] : INT_MAX, in0 = L.sc[NSV(x)], px = S.prob[x], b = S.node_base[S.tree_of[x]];
+                        const int32_t j = on_list ? L.pos[PPX(x)] : INT_MAX, in0 = L.sc[NSV(x)], px = S.prob[x], b = sh.nb[S.tree_of[x]];
                         int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
                         int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
                         for (int32_t q = e0; q >= 0; q = rs.ent[q][4]) {
@@ -2451,6 +2495,7 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
     if (tid == 0) sh.dead = 0;
     if (tid < 16) sh.kacc[tid] = 0;
     for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) sh.senbits[i] = 0u;
+    if (tid <= S.T) sh.nb[tid] = S.node_base[tid];
     if (S.n_tmat * NS_TPW(NE) <= KF_TP_LDS)
         for (int32_t i = tid; i < S.n_tmat * NS_TPW(NE); i += KF_NT) sh.tp[i] = S.tp[i];
     KfBar B = { bar + 2 * z, C, 0, &sh.dead, 0 };
