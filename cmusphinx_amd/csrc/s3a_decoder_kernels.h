@@ -1533,16 +1533,16 @@ d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__rest
 #pragma unroll
         /* (every load unconditional, at a harmless index for a group without an entry: a load under a condition is a branch with its
          * own wait inside, and the U chains would run one after the other) */
-        for (int u = 0; u < U; u++) { const int32_t j = j0 + u * n_grp + grp; on[u] = j < n_w; cs[u] = wl[on[u] ? j : 0]; }
+        for (int u = 0; u < U; u++) { const int32_t j = j0 + u * n_grp + grp; on[u] = j < n_w; cs[u] = ((const __attribute__((address_space(1))) int32_t *)wl)[on[u] ? j : 0]; }
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int32_t a0 = cs_off[cs[u]], a1 = cs_off[cs[u] + 1]; lo[u] = on[u] ? a0 : 0; hi[u] = on[u] ? a1 : 0; mx[u] = INT_MIN; }
+        for (int u = 0; u < U; u++) { const __attribute__((address_space(1))) int32_t *co = (const __attribute__((address_space(1))) int32_t *)cs_off; const int32_t a0 = co[cs[u]], a1 = co[cs[u] + 1]; lo[u] = on[u] ? a0 : 0; hi[u] = on[u] ? a1 : 0; mx[u] = INT_MIN; }
         for (int32_t q0 = 0; ; q0 += 32) {
             int32_t id[U][2];
             bool any = false;
 #pragma unroll
             for (int u = 0; u < U; u++) {
 #pragma unroll
-                for (int h = 0; h < 2; h++) { const int32_t q = lo[u] + q0 + 16 * h + l16; const int32_t x = (int32_t)cs_list[q < hi[u] ? q : 0]; id[u][h] = q < hi[u] ? x : -1; }
+                for (int h = 0; h < 2; h++) { const int32_t q = lo[u] + q0 + 16 * h + l16; const int32_t x = (int32_t)((const __attribute__((address_space(1))) int16_t *)cs_list)[q < hi[u] ? q : 0]; id[u][h] = q < hi[u] ? x : -1; }
                 any = any || lo[u] + q0 < hi[u];
             }
             if (!any) break;
@@ -1551,8 +1551,8 @@ d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__rest
 #pragma unroll
                 for (int h = 0; h < 2; h++)
                 {
-                    if (MAXOP) { const int32_t x = raw[max(id[u][h], 0)]; if (id[u][h] >= 0) mx[u] = max(mx[u], x); }
-                    else if (id[u][h] >= 0) { if (actbits) atomicOr(&actbits[id[u][h] >> 5], 1u << (id[u][h] & 31)); else sen_active[id[u][h]] = 1; }
+                    if (MAXOP) { const int32_t x = ((const __attribute__((address_space(1))) int32_t *)raw)[max(id[u][h], 0)]; if (id[u][h] >= 0) mx[u] = max(mx[u], x); }
+                    else if (id[u][h] >= 0) { if (actbits) (void)__hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t *)&actbits[id[u][h] >> 5], 1u << (id[u][h] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else sen_active[id[u][h]] = 1; }
                 }
         }
         if (MAXOP) {
@@ -1560,7 +1560,7 @@ d_comsen_list(const int32_t *__restrict__ wl, int32_t n_w, const int32_t *__rest
             for (int u = 0; u < U; u++) {
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) mx[u] = max(mx[u], __shfl_xor(mx[u], o, 64));
-                if (on[u] && l16 == 0) cs_val[cs[u]] = cs_wt ? add32(mx[u], cs_wt[cs[u]]) : mx[u];
+                if (on[u] && l16 == 0) ((__attribute__((address_space(1))) int32_t *)cs_val)[cs[u]] = cs_wt ? add32(mx[u], ((const __attribute__((address_space(1))) int32_t *)cs_wt)[cs[u]]) : mx[u];
             }
         }
     }

@@ -39,6 +39,20 @@
 #include "s3a_lm3g.h"
 #include "s3a_dag.h"
 
+/* A pointer that came out of a structure in memory is a GENERIC pointer to the compiler; what it makes of an access through one is
+ * flat_load / flat_store -- counted by the LDS counter as well as the memory counter, so that every wait for an LDS read waits for
+ * all flat accesses in flight (loads AND stores), and a step that mixes LDS reads with gathers runs them one after the other.
+ * Everything the lanes' and the engine's structures point to is device memory: the hot loops of ku_frames say so (GM / GMC: the
+ * same pointer in the global address space -> global_load / global_store, the memory counter only), and read LDS as LDS (LM). */
+#define S3A_AS1 __attribute__((address_space(1)))
+#define S3A_AS3 __attribute__((address_space(3)))
+typedef int s3a_v4i __attribute__((ext_vector_type(4)));
+typedef int s3a_v2i __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ S3A_AS1 T *GM(T *p) { return (S3A_AS1 T *)p; }
+template <class T> __device__ __forceinline__ const S3A_AS1 T *GMC(const T *p) { return (const S3A_AS1 T *)p; }
+template <class T> __device__ __forceinline__ const S3A_AS3 T *LM(const T *p) { return (const S3A_AS3 T *)p; }
+__device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) { (void)__hip_atomic_fetch_or((S3A_AS3 uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 /* one lane: the lextree state of a clone, a private scorer state, its history table */
 struct ULane {
     /* lextree state */
@@ -771,15 +785,15 @@ d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *
             const bool in = senq[u] < S.n_sen;
             const int32_t sq = in ? senq[u] : S.n_ci_sen;            /* (loads unconditional, a thread past the end reads a senone that exists: a load under a
                                                                        * condition is a branch with its own wait inside) */
-            actq[u] = actbits ? (uint8_t)((actbits[sq >> 5] >> (sq & 31)) & 1u) : L.sen_act[sq];
+            actq[u] = actbits ? (uint8_t)((LM(actbits)[sq >> 5] >> (sq & 31)) & 1u) : L.sen_act[sq];
             if (!in) actq[u] = 0;
-            ciq[u] = S.cd2cisen[sq];
+            ciq[u] = GMC(S.cd2cisen)[sq];
             senq[u] = sq;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            cisq[u] = row[ciq[u]]; rowq[u] = row[senq[u]]; nbq[u] = brow[senq[u]];
-            obq[u] = L.bstidx[senq[u]]; utq[u] = L.updatetime[senq[u]];
+            cisq[u] = GMC(row)[ciq[u]]; rowq[u] = GMC(row)[senq[u]]; nbq[u] = GMC(brow)[senq[u]];
+            obq[u] = GMC(L.bstidx)[senq[u]]; utq[u] = GMC(L.updatetime)[senq[u]];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -789,14 +803,14 @@ d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *
             const int32_t ci_scr = cisq[u];
             if (ci_scr >= thresh) {                     /* full evaluation */
                 const int32_t bi = (int32_t)nbq[u];
-                L.bstidx[sen] = bi == 255 ? S3A_NO_BSTIDX : bi;
-                L.updatetime[sen] = f;
-                rbest = max(rbest, rowq[u]); rns++; rng += (int32_t)S.ncomp[sen];
+                GM(L.bstidx)[sen] = bi == 255 ? S3A_NO_BSTIDX : bi;
+                GM(L.updatetime)[sen] = f;
+                rbest = max(rbest, rowq[u]); rns++; rng += (int32_t)GMC(S.ncomp)[sen];
                 continue;
             }
             const int32_t bi = obq[u], ut = utq[u];
             if (bi == S3A_NO_BSTIDX || ut != f - 1) {   /* the CI senone stands in */
-                row[sen] = ci_scr;
+                GM(row)[sen] = ci_scr;
                 rbest = max(rbest, ci_scr);
                 continue;
             }
@@ -1665,41 +1679,44 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
             const int32_t *__restrict__ cs_valw, int32_t *rec_all, int32_t cf, int32_t &w, int32_t &out)
 {
     constexpr int NV = NE == 3 ? 2 : 3;             /* 16-byte pieces that hold scores, histories, exit score, exit history */
-    int4 *rec = (int4 *)(rec_all + NSV(v));
-    /* (order matters to the clock: these are FLAT accesses -- the pointers come out of structures in memory --, a flat load is counted
-     * by the LDS counter too, and a wait for an LDS read therefore waits for every flat load in flight.  So: everything that comes from
-     * memory is asked for first -- the ids are in the packed node --, the transition matrix is read from LDS behind it, and the
-     * scores come through ONE pointer per state, chosen per lane (composite maxima | the row in LDS | the row in memory) */
+    S3A_AS1 s3a_v4i *rec = (S3A_AS1 s3a_v4i *)(rec_all + NSV(v));
+    /* (everything that comes from memory is asked for first -- the ids are in the packed node --, as GLOBAL accesses (GM: above), the
+     * row of scores and the transition matrix come from LDS behind them) */
     int32_t id[NE], tmat, wid_, comp;
-    int4 a5 = make_int4(0, 0, 0, 0);
     if (NE == 3) {              /* (nd = the node's packed word, UShared.nodepk) */
         id[0] = nd.x & 0xffff; id[1] = (int32_t)((uint32_t)nd.x >> 16); id[2] = nd.y & 0xffff;
         tmat = (int32_t)((uint32_t)nd.y >> 16); wid_ = nd.z; comp = nd.w & 1;
     }
     else {                      /* (nd = node4) */
-        a5 = *(const int4 *)(nodesen + (size_t)v * 4);
+        const s3a_v4i a5 = *(const S3A_AS1 s3a_v4i *)(nodesen + (size_t)v * 4);
         const int32_t h[5] = { a5.x & 0xffff, (int32_t)((uint32_t)a5.x >> 16), a5.y & 0xffff, (int32_t)((uint32_t)a5.y >> 16), a5.z & 0xffff };
 #pragma unroll
         for (int st = 0; st < NE; st++) id[st] = h[st];
         tmat = nd.y; wid_ = nd.z; comp = nd.w;
     }
-    const int32_t *src = comp ? cs_valw : (raw_in_lds ? raw_lds : raw);
-    int32_t e[NE];
+    int32_t e[NE], eg[NE];
+    /* (a composite node's maxima from memory; a plain node's scores from the row in LDS, or from memory when the row does not fit:
+     * one global load per state, at a harmless index for the lanes that do not want it) */
+    const S3A_AS1 int32_t *gsrc = GMC(comp ? cs_valw : raw);
 #pragma unroll
-    for (int st = 0; st < NE; st++) e[st] = src[id[st]];
+    for (int st = 0; st < NE; st++) eg[st] = gsrc[(comp || !raw_in_lds) ? id[st] : 0];
     int32_t wd[4 * NV];
 #pragma unroll
-    for (int q = 0; q < NV; q++) { const int4 a = rec[q]; wd[4 * q] = a.x; wd[4 * q + 1] = a.y; wd[4 * q + 2] = a.z; wd[4 * q + 3] = a.w; }
+    for (int q = 0; q < NV; q++) { const s3a_v4i a = rec[q]; wd[4 * q] = a.x; wd[4 * q + 1] = a.y; wd[4 * q + 2] = a.z; wd[4 * q + 3] = a.w; }
+#pragma unroll
+    for (int st = 0; st < NE; st++) e[st] = raw_in_lds ? LM(raw_lds)[comp ? 0 : id[st]] : 0;
     int32_t tp[NS_TPW(NE)];
     if (tp_in_lds) {
 #pragma unroll
-        for (int q = 0; q < NS_TPW(NE); q++) tp[q] = tp_lds[tmat * NS_TPW(NE) + q];
+        for (int q = 0; q < NS_TPW(NE); q++) tp[q] = LM(tp_lds)[tmat * NS_TPW(NE) + q];
     }
     else {
-        const int4 *tq = (const int4 *)(tp_g + tmat * NS_TPW(NE));
+        const S3A_AS1 s3a_v4i *tq = (const S3A_AS1 s3a_v4i *)(tp_g + tmat * NS_TPW(NE));
 #pragma unroll
-        for (int q = 0; q < NS_TPW(NE) / 4; q++) { const int4 a = tq[q]; tp[4 * q] = a.x; tp[4 * q + 1] = a.y; tp[4 * q + 2] = a.z; tp[4 * q + 3] = a.w; }
+        for (int q = 0; q < NS_TPW(NE) / 4; q++) { const s3a_v4i a = tq[q]; tp[4 * q] = a.x; tp[4 * q + 1] = a.y; tp[4 * q + 2] = a.z; tp[4 * q + 3] = a.w; }
     }
+#pragma unroll
+    for (int st = 0; st < NE; st++) if (comp || !raw_in_lds) e[st] = eg[st];
 #pragma unroll
     for (int st = 0; st < NE; st++) e[st] = add32(e[st], -norm);
     HmmRegsT<int32_t> r;
@@ -1713,10 +1730,10 @@ kf_hmm_eval(int32_t v, const int4 nd, const int32_t *__restrict__ nodesen, const
     for (int st = 0; st < NE; st++) { wd[st] = r.s[st]; wd[NE + st] = r.h[st]; }
     wd[2 * NE] = r.out; wd[2 * NE + 1] = r.outh;
 #pragma unroll
-    for (int q = 0; q < NV; q++) rec[q] = make_int4(wd[4 * q], wd[4 * q + 1], wd[4 * q + 2], wd[4 * q + 3]);
+    for (int q = 0; q < NV; q++) { s3a_v4i o; o.x = wd[4 * q]; o.y = wd[4 * q + 1]; o.z = wd[4 * q + 2]; o.w = wd[4 * q + 3]; rec[q] = o; }
     /* the best score and the frame tag (as if the HMM survived the frame: kf_frame's propagation pass corrects the ones it clears) */
     static_assert(2 * 3 + 2 == 8 && 2 * 5 + 2 == 12, "the record's layout: s3a_structs.h");
-    rec[NV] = make_int4(k, cf + 1, 0, 0);
+    { s3a_v4i o; o.x = k; o.y = cf + 1; o.z = 0; o.w = 0; rec[NV] = o; }
     w = wid_; out = r.out;
     return k;
 }
@@ -1728,8 +1745,8 @@ __device__ __forceinline__ int4
 kf_mark_load(int32_t v, const int32_t *__restrict__ nodesen)
 {
     /* (3 states: `nodesen` is UShared.nodepk, the node's packed word; brought to nodesen's form: ids, then the composite flag) */
-    if (NE == 3) { const int4 a = ((const int4 *)nodesen)[v]; return make_int4(a.x, (a.y & 0xffff) | ((a.w & 1) << 16), 0, 0); }
-    return *(const int4 *)(nodesen + (size_t)v * 4);
+    if (NE == 3) { const s3a_v4i a = ((const S3A_AS1 s3a_v4i *)nodesen)[v]; return make_int4(a.x, (a.y & 0xffff) | ((a.w & 1) << 16), 0, 0); }
+    { const s3a_v4i a = *(const S3A_AS1 s3a_v4i *)(nodesen + (size_t)v * 4); return make_int4(a.x, a.y, a.z, a.w); }
 }
 template <int NE>
 __device__ __forceinline__ void
@@ -1752,8 +1769,68 @@ kf_mark_apply(const int4 a, uint32_t *senbits, int32_t *cs_need, int32_t stamp, 
     }
     else {
 #pragma unroll
-        for (int st = 0; st < NE; st++) atomicOr(&senbits[id[st] >> 5], 1u << (id[st] & 31));       /* (LDS: three scattered stores less per node) */
+        for (int st = 0; st < NE; st++) lds_or(&senbits[id[st] >> 5], 1u << (id[st] & 31));       /* (LDS: three scattered stores less per node) */
     }
+}
+
+/* the same for four nodes at once (on[u]: node u counts): the plain nodes' bits; the composite nodes' stamps ALL asked for together,
+ * then the list's counter once per wave and (node, state) -- a composite node taken by itself is three times exchange -> add -> store,
+ * nine dependent round trips, and four of them in a row held a wave for 36 */
+template <int NE>
+__device__ __forceinline__ void
+kf_mark_apply4(const int4 (&a)[4], const bool (&on)[4], uint32_t *senbits, int32_t *cs_need, int32_t stamp, int32_t *cs_wl, int32_t *cs_wn)
+{
+    const int32_t lane = threadIdx.x & 63;
+    int32_t id[4][NE], old[4][NE];
+    bool cp[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        int32_t comp;
+        if (NE == 3) {
+            id[u][0] = a[u].x & 0xffff; id[u][1] = (int32_t)((uint32_t)a[u].x >> 16); id[u][2] = a[u].y & 0xffff; comp = (int32_t)((uint32_t)a[u].y >> 16);
+        }
+        else {
+            const int32_t h[5] = { a[u].x & 0xffff, (int32_t)((uint32_t)a[u].x >> 16), a[u].y & 0xffff, (int32_t)((uint32_t)a[u].y >> 16), a[u].z & 0xffff };
+#pragma unroll
+            for (int st = 0; st < NE; st++) id[u][st] = h[st];
+            comp = (int32_t)((uint32_t)a[u].z >> 16);
+        }
+        cp[u] = on[u] && comp != 0;
+        if (on[u] && !comp) {
+#pragma unroll
+            for (int st = 0; st < NE; st++) lds_or(&senbits[id[u][st] >> 5], 1u << (id[u][st] & 31));
+        }
+    }
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < 4; u++) any = any || cp[u];
+    if (!__ballot(any)) return;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int st = 0; st < NE; st++) {
+            old[u][st] = stamp;
+            if (cp[u]) old[u][st] = __hip_atomic_exchange(GM(cs_need) + id[u][st], stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    int32_t at[4][NE];
+    unsigned long long mm[4][NE];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int st = 0; st < NE; st++) {
+            mm[u][st] = __ballot(old[u][st] != stamp);
+            at[u][st] = 0;
+            if (mm[u][st] && lane == __ffsll((long long)mm[u][st]) - 1)
+                at[u][st] = __hip_atomic_fetch_add(GM(cs_wn), __popcll(mm[u][st]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int st = 0; st < NE; st++) {
+            if (!mm[u][st]) continue;
+            const int32_t base = __shfl(at[u][st], __ffsll((long long)mm[u][st]) - 1, 64);
+            if (old[u][st] != stamp) GM(cs_wl)[base + __popcll(mm[u][st] & ((1ull << lane) - 1ull))] = id[u][st];
+        }
 }
 
 /* frame f of lane z (workgroup r of its C): row / brow = the frame's senone scores and best components */
@@ -1818,7 +1895,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
              * own wait inside, and the four runs' round trips would follow one another instead of running side by side) */
             int32_t rp[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { rp[u] = S.rootprob[idx[u]]; vv[u] = S.rootlist[idx[u]]; }
+            for (int u = 0; u < 4; u++) { rp[u] = GMC(S.rootprob)[idx[u]]; vv[u] = GMC(S.rootlist)[idx[u]]; }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (e0 + 64 * u + lane < e_hi) scr[u] = add32(sh.pool.e1.in[cc[u]], rp[u]);
@@ -1826,7 +1903,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             }
             /* (... and an entry under the threshold asks for ONE root's score, its run's first: no line of its own) */
 #pragma unroll
-            for (int u = 0; u < 4; u++) s0[u] = L.sc[NSV(keep[u] ? vv[u] : __shfl(vv[u], 0, 64))];
+            for (int u = 0; u < 4; u++) s0[u] = GMC(L.sc)[NSV(keep[u] ? vv[u] : __shfl(vv[u], 0, 64))];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 keep[u] = keep[u] && s0[u] < scr[u];
@@ -1834,7 +1911,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 if (keep[u]) {
                     /* (what the later steps need of the entry, side by side: its root, its score, its call) */
                     const int32_t p_ = e_lo + cntw + __popcll(m & ((1ull << lane) - 1ull));
-                    L.eflag[p_] = vv[u]; L.ent[2 * p_] = scr[u]; L.ent[2 * p_ + 1] = cc[u];
+                    GM(L.eflag)[p_] = vv[u]; GM(L.ent)[2 * p_] = scr[u]; GM(L.ent)[2 * p_ + 1] = cc[u];
                     atomicMax(&L.key[vv[u]], ((unsigned long long)((uint32_t)scr[u] ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - cc[u]));
                     atomicMin(&L.first[vv[u]], cc[u]);
                 }
@@ -1888,9 +1965,9 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
 #pragma unroll
                 /* (every load unconditional, at a harmless place for a thread without an entry: a load under a condition is a branch
                  * with its own wait inside -- eight round trips one after the other instead of one) */
-                for (int k = 0; k < KF_RK; k++) { const int32_t pk = p_[k] >= 0 ? p_[k] : p0; v[k] = L.eflag[pk]; c[k] = L.ent[2 * pk + 1]; }
+                for (int k = 0; k < KF_RK; k++) { const int32_t pk = p_[k] >= 0 ? p_[k] : p0; v[k] = GMC(L.eflag)[pk]; c[k] = GMC(L.ent)[2 * pk + 1]; }
 #pragma unroll
-                for (int k = 0; k < KF_RK; k++) { fs[k] = S3A_ALD(&L.first[v[k]]); fr[k] = L.frame[NSV(v[k])]; }
+                for (int k = 0; k < KF_RK; k++) { fs[k] = S3A_ALD(&GM(L.first)[v[k]]); fr[k] = GMC(L.frame)[NSV(v[k])]; }
                 unsigned long long m[KF_RK];
                 int32_t n0 = 0;
 #pragma unroll
@@ -1907,7 +1984,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 for (int k = 0; k < KF_RK; k++) {
                     int32_t mine = before;
                     for (int32_t w = 0; w < KF_WAVES; w++) { const int32_t x = sh.rk[k][w]; if (w < wave) mine += x; before += x; }
-                    if (p_[k] >= 0) L.ent[2 * p_[k] + 1] = ((mine + __popcll(m[k] & ((1ull << lane) - 1ull))) << 8) | (q[k] << 7) | c[k];
+                    if (p_[k] >= 0) GM(L.ent)[2 * p_[k] + 1] = ((mine + __popcll(m[k] & ((1ull << lane) - 1ull))) << 8) | (q[k] << 7) | c[k];
                 }
                 carry = before;
                 __syncthreads();
@@ -1933,11 +2010,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 int4 aq[4];
                 bool oq[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { oq[u] = i + u * ms < na; vq[u] = L.act[cur][b + (oq[u] ? i + u * ms : 0)]; }      /* (loads unconditional: see the ranking) */
+                for (int u = 0; u < 4; u++) { oq[u] = i + u * ms < na; vq[u] = GMC(L.act[cur])[b + (oq[u] ? i + u * ms : 0)]; }      /* (loads unconditional: see the ranking) */
 #pragma unroll
                 for (int u = 0; u < 4; u++) aq[u] = kf_mark_load<NE>(vq[u], NE == 3 ? (const int32_t *)S.nodepk : S.nodesen);
-#pragma unroll
-                for (int u = 0; u < 4; u++) if (oq[u]) kf_mark_apply<NE>(aq[u], sh.senbits, L.cs_need, f, L.cs_wl, L.cs_wn);
+                kf_mark_apply4<NE>(aq, oq, sh.senbits, L.cs_need, f, L.cs_wl, L.cs_wn);
             }
             a += na;
         }
@@ -1973,10 +2049,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int32_t pk = pq[u] >= 0 ? pq[u] : p0; vq[u] = L.eflag[pk]; flq[u] = L.ent[2 * pk + 1]; }       /* (loads unconditional: see the ranking) */
+            for (int u = 0; u < 4; u++) { const int32_t pk = pq[u] >= 0 ? pq[u] : p0; vq[u] = GMC(L.eflag)[pk]; flq[u] = GMC(L.ent)[2 * pk + 1]; }       /* (loads unconditional: see the ranking) */
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                kq[u] = S3A_ALD(&L.key[vq[u]]); fsq[u] = S3A_ALD(&L.first[vq[u]]);
+                kq[u] = S3A_ALD(&GM(L.key)[vq[u]]); fsq[u] = S3A_ALD(&GM(L.first)[vq[u]]);
                 aq[u] = kf_mark_load<NE>(vq[u], NE == 3 ? (const int32_t *)S.nodepk : S.nodesen);
             }
 #pragma unroll
@@ -1986,14 +2062,18 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 const int32_t g = c >= c1 ? 1 : 0, t = ctx->groups[4 * g];
                 if (fl & 128) {
                     const int32_t k = L.n0[t] + (fl >> 8) - (g ? gq0 : 0);
-                    L.act[cur][sh.nb[t] + k] = v; PP_SET(L.pos, v, k, nf);
-                    kf_mark_apply<NE>(aq[u], sh.senbits, L.cs_need, nf, L.cs_wl, L.cs_wn);
+                    GM(L.act[cur])[sh.nb[t] + k] = v; { s3a_v2i o; o.x = k; o.y = nf; *(S3A_AS1 s3a_v2i *)(L.pos + PPX(v)) = o; }
                 }
                 const unsigned long long key = kq[u];
                 const int32_t win_c = 0x7fffffff - (int32_t)(uint32_t)(key & 0xffffffffu);
-                if (c == win_c) { L.sc[NSV(v)] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); L.hist[NSV(v)] = sh.pool.e1.hist[c]; }
-                if (c == fsq[u]) L.frame[NSV(v)] = nf;
+                if (c == win_c) { GM(L.sc)[NSV(v)] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); GM(L.hist)[NSV(v)] = LM(sh.pool.e1.hist)[c]; }
+                if (c == fsq[u]) GM(L.frame)[NSV(v)] = nf;
             }
+            /* (the senone marks of the roots this turn listed: the four together, kf_mark_apply4) */
+            bool lq[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) lq[u] = pq[u] >= 0 && (flq[u] & 128) != 0;
+            kf_mark_apply4<NE>(aq, lq, sh.senbits, L.cs_need, nf, L.cs_wl, L.cs_wn);
         }
     }
     kf_barrier(B);
@@ -2084,9 +2164,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             const int32_t gc = g0 + 2 * gstride + tid;
             kf_locate(sh.pre, T, gc < n_tot ? gc : 0, t2, i2);          /* (the LDS reads first: a wait for one waits for every flat load in flight) */
             b2 = sh.nb[t2];
-            const int4 nd1 = (NE == 3 ? S.nodepk : S.node4)[max(v1, 0)];
+            int4 nd1;
+            { const s3a_v4i a = ((const S3A_AS1 s3a_v4i *)(NE == 3 ? S.nodepk : S.node4))[max(v1, 0)]; nd1 = make_int4(a.x, a.y, a.z, a.w); }
             {
-                const int32_t vx = act[b2 + i2];
+                const int32_t vx = GMC(act)[b2 + i2];
                 if (gc < n_tot) v2 = vx; else t2 = -1;
             }
             const int32_t t = t0;
@@ -2094,10 +2175,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             if (v0 >= 0) {
                 int32_t out;
                 k = kf_hmm_eval<NE>(v0, nd0, S.nodesen, S.tp, sh.tp, tp_in_lds, row, row_lds, row_in_lds, norm, L.cs_val, L.sc, f, w, out);
-                L.poswid[b0 + i0] = w;
-                L.posout[b0 + i0] = out;
-                L.posbest[b0 + i0] = k;
-                if (NE == 3) L.posps[b0 + i0] = (int32_t)((uint32_t)nd0.w >> 1) - 1;
+                GM(L.poswid)[b0 + i0] = w;
+                GM(L.posout)[b0 + i0] = out;
+                GM(L.posbest)[b0 + i0] = k;
+                if (NE == 3) GM(L.posps)[b0 + i0] = (int32_t)((uint32_t)nd0.w >> 1) - 1;
             }
             /* a wave's 64 positions belong to one tree, or to two or three at the seams */
             unsigned long long todo = __ballot(t >= 0);
@@ -2166,45 +2247,74 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             }
             int32_t po[KF_SK];
 #pragma unroll
-            for (int k = 0; k < KF_SK; k++) po[k] = L.posout[ix[k]];
+            for (int k = 0; k < KF_SK; k++) po[k] = GMC(L.posout)[ix[k]];
 #pragma unroll
-            for (int k = 0; k < KF_SK; k++) ix[k] = L.act[cur][ix[k]];
+            for (int k = 0; k < KF_SK; k++) ix[k] = GMC(L.act[cur])[ix[k]];
 #pragma unroll
             for (int k = 0; k < KF_SK; k++) ok[k] = ok[k] && po[k] >= pth;
             int32_t nq = 0;
             {
                 int32_t a0[KF_SK], a1[KF_SK];
 #pragma unroll
-                for (int k = 0; k < KF_SK; k++) { a0[k] = S.psof_off[ix[k]]; a1[k] = S.psof_off[ix[k] + 1]; }
+                for (int k = 0; k < KF_SK; k++) { a0[k] = GMC(S.psof_off)[ix[k]]; a1[k] = GMC(S.psof_off)[ix[k] + 1]; }
 #pragma unroll
                 for (int k = 0; k < KF_SK; k++) { q0[k] = ok[k] ? a0[k] : 0; q1[k] = ok[k] ? a1[k] : 0; nq = max(nq, q1[k] - q0[k]); }
             }
+            (void)nq;
+            /* the passing HMMs' (first set, number of sets) pairs go to a list in LDS, and the workgroup walks all their sets as flat
+             * work items -- a thread per (HMM, set) --: a propagating root variant stamps dozens of sets, and a thread that walked its
+             * own HMMs' sets one after the other held its wave for ~11 turns of three dependent round trips each (measured) */
+            auto &rs = sh.pool.rs;
+            if (tid == 0) rs.nbig = 0;
+            __syncthreads();
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) nq = max(nq, __shfl_xor(nq, o, 64));      /* (uniform over the wave: the ballots below) */
-            for (int32_t j = 0; j < nq; j++) {
-                int32_t ps[KF_SK], old[KF_SK], at[KF_SK];
+            for (int k = 0; k < KF_SK; k++) {
+                const int32_t cnt = q1[k] - q0[k];
+                if (cnt <= 0) continue;
+                const int32_t slot = atomicAdd(&rs.nbig, 1);
+                if (slot < KF_SETS) { rs.mlo[slot] = q0[k]; rs.big[slot] = cnt; }
+                else                /* (no room: this thread walks them itself) */
+                    for (int32_t q = q0[k]; q < q1[k]; q++) {
+                        const int32_t ps = GMC(S.psof)[q];
+                        GM(L.pstamp8)[ps] = ps_val<uint8_t>(f);
+                        if (atomicExch(&L.claim[ps], f) != f) L.plist[atomicAdd(pc, 1)] = ps;
+                    }
+            }
+            __syncthreads();
+            const int32_t n_e = min(rs.nbig, KF_SETS);
+            {
+                static_assert(KF_SETS == KF_NT, "an entry per thread");
+                const int32_t x = tid < n_e ? rs.big[tid] : 0;
+                int32_t incl = x;
 #pragma unroll
-                for (int k = 0; k < KF_SK; k++) ps[k] = S.psof[q0[k] + j < q1[k] ? q0[k] + j : 0];
-#pragma unroll
-                for (int k = 0; k < KF_SK; k++) if (!(q0[k] + j < q1[k])) ps[k] = -1;
-#pragma unroll
-                for (int k = 0; k < KF_SK; k++) if (ps[k] >= 0) L.pstamp8[ps[k]] = ps_val<uint8_t>(f);
-#pragma unroll
-                for (int k = 0; k < KF_SK; k++) { old[k] = f; if (ps[k] >= 0) old[k] = atomicExch(&L.claim[ps[k]], f); }
-                unsigned long long mm[KF_SK];
-#pragma unroll
-                for (int k = 0; k < KF_SK; k++) {
-                    mm[k] = __ballot(old[k] != f);
-                    at[k] = 0;
-                    if (mm[k] && lane == __ffsll((long long)mm[k]) - 1) at[k] = atomicAdd(pc, __popcll(mm[k]));
-                }
-#pragma unroll
-                for (int k = 0; k < KF_SK; k++) {
-                    if (!mm[k]) continue;
-                    const int32_t base = __shfl(at[k], __ffsll((long long)mm[k]) - 1, 64);
-                    if (old[k] != f) L.plist[base + __popcll(mm[k] & ((1ull << lane) - 1ull))] = ps[k];
+                for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+                if (lane == 63) sh.ws[wave] = incl;
+                __syncthreads();
+                int32_t add = 0;
+                for (int32_t w = 0; w < wave; w++) add += sh.ws[w];
+                rs.pre[tid] = add + incl - x;
+                if (tid == KF_NT - 1) rs.m_all = add + incl;
+                __syncthreads();
+            }
+            const int32_t I = rs.m_all;
+            for (int32_t it0 = 0; it0 < I; it0 += KF_NT) {
+                const int32_t it = it0 + tid;
+                int32_t lo = 0, hi = max(n_e - 1, 0);
+                while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.pre[mid] <= it) lo = mid; else hi = mid - 1; }
+                const int32_t qx = it < I ? rs.mlo[lo] + (it - rs.pre[lo]) : rs.mlo[0];
+                const int32_t psx = GMC(S.psof)[qx];
+                const int32_t ps = it < I ? psx : -1;
+                int32_t old = f;
+                if (ps >= 0) { GM(L.pstamp8)[ps] = ps_val<uint8_t>(f); old = atomicExch(&L.claim[ps], f); }
+                const unsigned long long mm = __ballot(old != f);
+                if (mm) {
+                    int32_t at = 0;
+                    if (lane == __ffsll((long long)mm) - 1) at = atomicAdd(pc, __popcll(mm));
+                    const int32_t base = __shfl(at, __ffsll((long long)mm) - 1, 64);
+                    if (old != f) GM(L.plist)[base + __popcll(mm & ((1ull << lane) - 1ull))] = ps;
                 }
             }
+            __syncthreads();
         }
     }
     kf_barrier(B);
@@ -2250,14 +2360,14 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {           /* (loads unconditional, a thread past the end asks for position 0: see the ranking) */
-                const int32_t vx = act[bb[u] + ii[u]];
+                const int32_t vx = GMC(act)[bb[u] + ii[u]];
                 vv[u] = gg[u] < n_tot ? vx : -1;
-                qq[u] = ps_by_pos ? L.posps[bb[u] + ii[u]] : 0;
-                pbv[u] = L.posbest[bb[u] + ii[u]];
+                qq[u] = ps_by_pos ? GMC(L.posps)[bb[u] + ii[u]] : 0;
+                pbv[u] = GMC(L.posbest)[bb[u] + ii[u]];
             }
             if (!ps_by_pos) {
 #pragma unroll
-                for (int u = 0; u < 2; u++) qq[u] = S.ps[max(vv[u], 0)];
+                for (int u = 0; u < 2; u++) qq[u] = GMC(S.ps)[max(vv[u], 0)];
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) if (vv[u] < 0) qq[u] = -1;
@@ -2278,7 +2388,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 }
                 /* the usual active HMM -- no parent can enter it, and it survives: it joins the next list at its own turn; its record
                  * carries the frame tag since the evaluation (a histogram frame has reordered the positions: through the node) */
-                if (!has_par && !hist_frame && pbv[u] >= sh.thr[0]) { L.selfemit[b + i] = 1; atomicAdd(&L.cnt[b + i], 1); continue; }
+                if (!has_par && !hist_frame && pbv[u] >= sh.thr[0]) { GM(L.selfemit)[b + i] = 1; atomicAdd(&L.cnt[b + i], 1); continue; }
                 d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
                                                    L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
                                                    S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b,
@@ -2305,9 +2415,9 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     static_assert(KF_SETS == KF_NT, "a set per thread");
                     int32_t cm = 0, m_lo = 0;
                     if (tid < nk) {
-                        const int32_t q = L.plist[k0 + tid];
-                        m_lo = S.psmem_off[q];
-                        const int32_t m_hi = S.psmem_off[q + 1], x0 = S.psmem[m_lo], kp0 = S.par_off[x0], np = S.par_off[x0 + 1] - kp0;
+                        const int32_t q = GMC(L.plist)[k0 + tid];
+                        m_lo = GMC(S.psmem_off)[q];
+                        const int32_t m_hi = GMC(S.psmem_off)[q + 1], x0 = GMC(S.psmem)[m_lo], kp0 = GMC(S.par_off)[x0], np = GMC(S.par_off)[x0 + 1] - kp0;
                         if (np >= SET_NP_MIN && np <= 64) {
                             const int32_t at = atomicAdd(&rs.nbig, 1);
                             rs.big[at] = q;
@@ -2341,7 +2451,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 for (int32_t m = tid; m < M; m += KF_NT) {
                     int32_t lo = 0, hi = nk - 1;
                     while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.pre[mid] <= m) lo = mid; else hi = mid - 1; }
-                    const int32_t x = S.psmem[rs.mlo[lo] + (m - rs.pre[lo])];
+                    const int32_t x = GMC(S.psmem)[rs.mlo[lo] + (m - rs.pre[lo])];
                     if (L.posf[PPX(x)] == f) continue;                               /* on the list: resolved by list position */
                     d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
                                                        L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
@@ -2360,20 +2470,20 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                             if (it < I) {
                                 int32_t lo = 0, hi = nb - 1;
                                 while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.bpre[mid] <= it) lo = mid; else hi = mid - 1; }
-                                sb[u] = lo; gp[u] = S.par[rs.bkp0[lo] + (it - rs.bpre[lo])];
+                                sb[u] = lo; gp[u] = GMC(S.par)[rs.bkp0[lo] + (it - rs.bpre[lo])];
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < 2; u++) pfv[u] = gp[u] >= 0 ? L.posf[PPX(gp[u])] : INT_MIN;
+                        for (int u = 0; u < 2; u++) pfv[u] = gp[u] >= 0 ? GMC(L.posf)[PPX(gp[u])] : INT_MIN;
 #pragma unroll
                         for (int u = 0; u < 2; u++) {
                             if (pfv[u] != f) continue;
-                            const int32_t g = gp[u], po = L.outs[NSV(g)];
-                            if (po < pth || (pth < th && L.bests[NSV(g)] < th && L.propf[g] != f)) continue;
+                            const int32_t g = gp[u], po = GMC(L.outs)[NSV(g)];
+                            if (po < pth || (pth < th && GMC(L.bests)[NSV(g)] < th && GMC(L.propf)[g] != f)) continue;
                             const int32_t at = atomicAdd(&rs.n_ent, 1);
                             if (at < KF_ENT) {
                                 int32_t *e = rs.ent[at];
-                                e[0] = po; e[1] = L.pos[PPX(g)]; e[2] = L.outh[NSV(g)]; e[3] = S.prob[g];
+                                e[0] = po; e[1] = GMC(L.pos)[PPX(g)]; e[2] = GMC(L.outh)[NSV(g)]; e[3] = GMC(S.prob)[g];
                                 e[4] = atomicExch(&rs.bnq[sb[u]], at);              /* (the chain's order does not matter: maxima with position tie-breaks) */
                             }
                             else atomicMin(&rs.bnq[sb[u]], -2);
@@ -2396,10 +2506,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                         while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.bmpre[mid] <= m) lo = mid; else hi = mid - 1; }
                         const int32_t k = lo, e0 = rs.bnq[k];
                         if (e0 == -2) continue;                                 /* the wave-per-set way, below */
-                        const int32_t x = S.psmem[rs.bmlo[k] + (m - rs.bmpre[k])];
-                        const bool on_list = L.posf[PPX(x)] == f;                    /* (the list position pass leaves these members to us) */
+                        const int32_t x = GMC(S.psmem)[rs.bmlo[k] + (m - rs.bmpre[k])];
+                        const bool on_list = GMC(L.posf)[PPX(x)] == f;                    /* (the list position pass leaves these members to us) */
                         if (!on_list && e0 < 0) continue;
-                        const int32_t j = on_list ? L.pos[PPX(x)] : INT_MAX, in0 = L.sc[NSV(x)], px = S.prob[x], b = sh.nb[S.tree_of[x]];
+                        const int32_t j = on_list ? GMC(L.pos)[PPX(x)] : INT_MAX, in0 = GMC(L.sc)[NSV(x)], px = GMC(S.prob)[x], b = sh.nb[GMC(S.tree_of)[x]];
                         int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
                         int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
                         for (int32_t q = e0; q >= 0; q = rs.ent[q][4]) {
