@@ -1569,6 +1569,8 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_MAXSEG (KF_MAXC * KF_WAVES)
 #define KF_PSBITS 8192
 #define KF_SENBITS 16384          /* senones ku_frames keeps an activity bit for in LDS (more: the launches stay) */
+#define KF_ER 4                 /* runs of 64 entries a wave tests per turn of lextree_enter's sweep */
+#define KF_RL 8                 /* list positions a thread classifies per turn of the propagation step's first pass */
 #define KF_SK 8                 /* list positions a thread stamps per pass */
 #define KF_RK 8                 /* kept entries a thread ranks per pass of lextree_enter's ranking */
 #define KF_SETS 512            /* listed parent sets a workgroup takes per pass of the propagation step */
@@ -1877,13 +1879,13 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         }
         /* (four runs of 64 entries per turn: their probabilities, then the passing ones' roots, then those roots' entry scores are asked
          * for together -- a turn is three round trips whatever it holds; the order of the kept entries is the entries') */
-        for (int32_t e0 = e_lo; e0 < e_hi; e0 += 256) {
+        for (int32_t e0 = e_lo; e0 < e_hi; e0 += 64 * KF_ER) {
             /* an entry counts when it passes the threshold AND improves on its root's entry score: only such an entry can list the
              * root, win it, or tag it (the others pass through lextree_enter without a trace) */
-            int32_t scr[4], vv[4], cc[4], idx[4], s0[4];
-            bool keep[4];
+            int32_t scr[KF_ER], vv[KF_ER], cc[KF_ER], idx[KF_ER], s0[KF_ER];
+            bool keep[KF_ER];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < KF_ER; u++) {
                 const int32_t e = e0 + 64 * u + lane;
                 keep[u] = false; scr[u] = INT_MIN; vv[u] = 0; cc[u] = c; idx[u] = 0;
                 if (e < e_hi) {
@@ -1893,19 +1895,19 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             }
             /* (the loads unconditional -- a lane past the end asks for entry 0's words --: a load under a condition is a branch with its
              * own wait inside, and the four runs' round trips would follow one another instead of running side by side) */
-            int32_t rp[4];
+            int32_t rp[KF_ER];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { rp[u] = GMC(S.rootprob)[idx[u]]; vv[u] = GMC(S.rootlist)[idx[u]]; }
+            for (int u = 0; u < KF_ER; u++) { rp[u] = GMC(S.rootprob)[idx[u]]; vv[u] = GMC(S.rootlist)[idx[u]]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < KF_ER; u++) {
                 if (e0 + 64 * u + lane < e_hi) scr[u] = add32(sh.pool.e1.in[cc[u]], rp[u]);
                 keep[u] = e0 + 64 * u + lane < e_hi && scr[u] >= thresh;
             }
             /* (... and an entry under the threshold asks for ONE root's score, its run's first: no line of its own) */
 #pragma unroll
-            for (int u = 0; u < 4; u++) s0[u] = GMC(L.sc)[NSV(keep[u] ? vv[u] : __shfl(vv[u], 0, 64))];
+            for (int u = 0; u < KF_ER; u++) s0[u] = GMC(L.sc)[NSV(keep[u] ? vv[u] : __shfl(vv[u], 0, 64))];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < KF_ER; u++) {
                 keep[u] = keep[u] && s0[u] < scr[u];
                 const unsigned long long m = __ballot(keep[u]);
                 if (keep[u]) {
@@ -2349,50 +2351,69 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             __syncthreads();
         }
         const bool ps_by_pos = NE == 3 && !hist_frame;
-        /* the active HMMs by list position, two per thread and turn (their chains of gathers run side by side) */
-        for (int32_t g0 = r * 2 * KF_NT; g0 < n_tot; g0 += 2 * gstride) {
-            int32_t gg[2] = { g0 + tid, g0 + KF_NT + tid }, tt[2], ii[2], bb[2], vv[2], qq[2], pbv[2];
-            uint8_t stv[2];
+        /* the active HMMs by list position, in two passes.  (A) KF_RL positions per thread and turn, their words asked for together:
+         * the usual HMM -- nobody stamped its parent set, and it survives -- is settled at once (it joins the next list at its own turn;
+         * its record carries the frame tag since the evaluation); the others -- entered by a parent, or dying -- go to a list in LDS.
+         * (B) a thread per listed HMM walks d_dec_resolve_node's chain: dense waves, once per block, instead of every wave paying the
+         * chain in every turn for the few lanes that need it (two positions per turn were 3.2 turns x ~11 round trips) */
+        {
+            int32_t *wl_ = (int32_t *)&sh.pool;
+            static_assert(sizeof(KfPool) >= KF_RL * KF_NT * 4, "the list pass's work list lives in the pool");
+            for (int32_t g00 = r * KF_RL * KF_NT; g00 < n_tot; g00 += KF_RL * gstride) {
+                if (tid == 0) sh.gq[3] = 0;
+                __syncthreads();
+                {
+                    int32_t gg[KF_RL], ii[KF_RL], bb[KF_RL], vv[KF_RL], qq[KF_RL], pbv[KF_RL];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {           /* (the LDS reads first: a wait for one waits for every flat load in flight) */
-                kf_locate(sh.pre, T, gg[u] < n_tot ? gg[u] : 0, tt[u], ii[u]);
-                bb[u] = sh.nb[tt[u]];
-            }
+                    for (int u = 0; u < KF_RL; u++) {       /* (the LDS reads first: a wait for one waits for every flat load in flight) */
+                        int32_t t_;
+                        gg[u] = g00 + u * KF_NT + tid;
+                        kf_locate(sh.pre, T, gg[u] < n_tot ? gg[u] : 0, t_, ii[u]);
+                        bb[u] = sh.nb[t_];
+                    }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {           /* (loads unconditional, a thread past the end asks for position 0: see the ranking) */
-                const int32_t vx = GMC(act)[bb[u] + ii[u]];
-                vv[u] = gg[u] < n_tot ? vx : -1;
-                qq[u] = ps_by_pos ? GMC(L.posps)[bb[u] + ii[u]] : 0;
-                pbv[u] = GMC(L.posbest)[bb[u] + ii[u]];
-            }
-            if (!ps_by_pos) {
+                    for (int u = 0; u < KF_RL; u++) {       /* (loads unconditional, a thread past the end asks for position 0) */
+                        const int32_t vx = GMC(act)[bb[u] + ii[u]];
+                        vv[u] = gg[u] < n_tot ? vx : -1;
+                        qq[u] = ps_by_pos ? GMC(L.posps)[bb[u] + ii[u]] : 0;
+                        pbv[u] = GMC(L.posbest)[bb[u] + ii[u]];
+                    }
+                    if (!ps_by_pos) {
 #pragma unroll
-                for (int u = 0; u < 2; u++) qq[u] = GMC(S.ps)[max(vv[u], 0)];
-            }
+                        for (int u = 0; u < KF_RL; u++) qq[u] = GMC(S.ps)[max(vv[u], 0)];
+                    }
 #pragma unroll
-            for (int u = 0; u < 2; u++) if (vv[u] < 0) qq[u] = -1;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t qb = (uint32_t)qq[u] % KF_PSBITS;
-                stv[u] = (qq[u] >= 0 && ((sh.psbits[qb >> 5] >> (qb & 31)) & 1u)) ? L.pstamp8[qq[u]] : (uint8_t)(ps_val<uint8_t>(f) + 1);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                if (vv[u] < 0) continue;
-                const int32_t v = vv[u], q = qq[u], i = ii[u], b = bb[u];
-                const bool has_par = q >= 0 && stv[u] == ps_val<uint8_t>(f);
-                /* (the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
-                if (has_par && S3A_ALD(&L.claim[q]) == f) {
-                    const int32_t np = S.par_off[v + 1] - S.par_off[v];
-                    if (np >= SET_NP_MIN && np <= 64) continue;
+                    for (int u = 0; u < KF_RL; u++) {
+                        if (vv[u] < 0) continue;
+                        const uint32_t qb = (uint32_t)qq[u] % KF_PSBITS;
+                        bool has_par = qq[u] >= 0 && ((sh.psbits[qb >> 5] >> (qb & 31)) & 1u);
+                        if (has_par) has_par = GMC(L.pstamp8)[qq[u]] == ps_val<uint8_t>(f);
+                        if (!has_par && !hist_frame && pbv[u] >= sh.thr[0]) { GM(L.selfemit)[bb[u] + ii[u]] = 1; atomicAdd(&L.cnt[bb[u] + ii[u]], 1); continue; }
+                        wl_[atomicAdd(&sh.gq[3], 1)] = gg[u] | (has_par ? (int32_t)0x80000000 : 0);
+                    }
                 }
-                /* the usual active HMM -- no parent can enter it, and it survives: it joins the next list at its own turn; its record
-                 * carries the frame tag since the evaluation (a histogram frame has reordered the positions: through the node) */
-                if (!has_par && !hist_frame && pbv[u] >= sh.thr[0]) { GM(L.selfemit)[b + i] = 1; atomicAdd(&L.cnt[b + i], 1); continue; }
-                d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                                   L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                                   S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b,
-                                                   HeurArgs{ NULL, NULL, NULL }, sh.thr);
+                __syncthreads();
+                const int32_t n_wl = sh.gq[3];
+                for (int32_t k = tid; k < n_wl; k += KF_NT) {
+                    const int32_t e_ = wl_[k], g = e_ & 0x7fffffff;
+                    const bool has_par = e_ < 0;
+                    int32_t t_, i;
+                    kf_locate(sh.pre, T, g, t_, i);
+                    const int32_t b = sh.nb[t_], v = GMC(act)[b + i];
+                    /* (the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
+                    if (has_par) {
+                        const int32_t q = ps_by_pos ? GMC(L.posps)[b + i] : GMC(S.ps)[v];
+                        if (S3A_ALD(&L.claim[q]) == f) {
+                            const int32_t np = S.par_off[v + 1] - S.par_off[v];
+                            if (np >= SET_NP_MIN && np <= 64) continue;
+                        }
+                    }
+                    d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                       L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                       S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b,
+                                                       HeurArgs{ NULL, NULL, NULL }, sh.thr);
+                }
+                __syncthreads();
             }
         }
         /* the frame's listed parent sets (d_stamp_and_list): this workgroup's share, up to KF_SETS per pass -- everything as flat work
