@@ -1570,7 +1570,6 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_PSBITS 8192
 #define KF_SENBITS 16384          /* senones ku_frames keeps an activity bit for in LDS (more: the launches stay) */
 #define KF_ER 4                 /* runs of 64 entries a wave tests per turn of lextree_enter's sweep */
-#define KF_SC 8                 /* list positions a thread takes per pass of the ordered scan */
 #define KF_RL 8                 /* list positions a thread classifies per turn of the propagation step's first pass */
 #define KF_SK 8                 /* list positions a thread stamps per pass */
 #define KF_RK 8                 /* kept entries a thread ranks per pass of lextree_enter's ranking */
@@ -1834,74 +1833,6 @@ kf_mark_apply4(const int4 (&a)[4], const bool (&on)[4], uint32_t *senbits, int32
             const int32_t base = __shfl(at[u][st], __ffsll((long long)mm[u][st]) - 1, 64);
             if (old[u][st] != stamp) GM(cs_wl)[base + __popcll(mm[u][st] & ((1ull << lane) - 1ull))] = id[u][st];
         }
-}
-
-/* d_dec_scan_t as ku_frames runs it (one workgroup per tree): the turn bases of the next list and the word exits in list order, both
- * ordered compactions in ONE scan (the halves of a 64-bit value) -- KF_SC x 512 list positions per pass, their words asked for together
- * and one barrier per pass, instead of a pass per 512 positions with two barriers each (seven in a row for the usual list) */
-__device__ __forceinline__ void
-kf_scan_tree(const ULane &L, const UShared &S, KfSh &sh, int32_t cur, int32_t t, int32_t T, bool reordered, int32_t wth)
-{
-    __shared__ unsigned long long s_ws[KF_SC][KF_WAVES];
-    __shared__ int32_t s_open;
-    const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t b = sh.nb[t], na = L.nact[cur][t], N = S.N;
-    const S3A_AS1 int32_t *act = GMC(L.act[cur]), *poswid = GMC(L.poswid), *posout = GMC(L.posout);
-    S3A_AS1 int32_t *cnt = GM(L.cnt), *base = GM(L.base), *exits = GM(L.exits);
-    if (tid == 0) s_open = 0;
-    unsigned long long carry = 0ull;
-    for (int32_t c0 = 0; c0 < na; c0 += KF_SC * KF_NT) {
-        int32_t u[KF_SC], c[KF_SC], w[KF_SC], os[KF_SC];
-        bool in[KF_SC];
-#pragma unroll
-        for (int k = 0; k < KF_SC; k++) {       /* (loads unconditional, a thread past the end asks for position 0 of the tree: na > 0 here) */
-            const int32_t i = c0 + k * KF_NT + tid;
-            in[k] = i < na;
-            const int32_t ip = in[k] ? i : 0;
-            u[k] = act[b + ip]; c[k] = S3A_ALD(&cnt[b + ip]);      /* (d_dec_resolve_finish's atomicAdd) */
-            w[k] = poswid[b + ip]; os[k] = posout[b + ip];
-        }
-        if (reordered) {                    /* (a histogram frame reordered the positions after the evaluation wrote them: through the node) */
-#pragma unroll
-            for (int k = 0; k < KF_SC; k++) { w[k] = GMC(S.wid)[u[k]]; os[k] = GMC(L.outs)[NSV(u[k])]; }
-        }
-        unsigned long long incl[KF_SC], x[KF_SC];
-        bool ex[KF_SC];
-#pragma unroll
-        for (int k = 0; k < KF_SC; k++) {
-            if (in[k]) cnt[b + c0 + k * KF_NT + tid] = 0;         /* the accumulator of the next frame */
-            ex[k] = in[k] && w[k] >= 0 && os[k] >= wth;
-            x[k] = in[k] ? ((unsigned long long)(uint32_t)c[k] | ((unsigned long long)(ex[k] ? 1u : 0u) << 32)) : 0ull;
-            incl[k] = x[k];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(incl[k], o, 64); if (lane >= o) incl[k] += y; }
-            if (lane == 63) s_ws[k][wave] = incl[k];
-        }
-        __syncthreads();
-        unsigned long long before = carry;
-#pragma unroll
-        for (int k = 0; k < KF_SC; k++) {
-            unsigned long long mine = before;
-            for (int32_t q = 0; q < KF_WAVES; q++) { const unsigned long long y = s_ws[k][q]; if (q < wave) mine += y; before += y; }
-            const unsigned long long excl = mine + incl[k] - x[k];
-            if (in[k]) {
-                base[b + c0 + k * KF_NT + tid] = (int32_t)(uint32_t)excl;
-                if (ex[k]) {
-                    const int32_t e = b + (int32_t)(excl >> 32);
-                    const int32_t oh = GMC(L.outh)[NSV(u[k])];
-                    exits[e] = w[k];
-                    exits[N + e] = add32(os[k], -GMC(S.prob)[u[k]]);
-                    exits[2 * (size_t)N + e] = oh;
-                    if (oh == -1) s_open = 1;
-                }
-            }
-        }
-        carry = before;
-        __syncthreads();
-    }
-    if (tid == 0) { L.nact[cur ^ 1][t] = (int32_t)(uint32_t)carry; L.nexit[t] = (int32_t)(carry >> 32); }
-    __syncthreads();
-    if (tid == 0 && s_open) L.nexit[T + t] = 1;
 }
 
 /* frame f of lane z (workgroup r of its C): row / brow = the frame's senone scores and best components */
@@ -2643,7 +2574,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     KF_STAMP(9);
     /* ---- the ordered compaction of the next list and of the word exits (ku_scan): a tree per workgroup in turn ---- */
     for (int32_t t = r; t < T; t += C) {
-        kf_scan_tree(L, S, sh, cur, t, T, hist_frame, sh.thr[2]);
+        d_dec_scan_t<KF_NT>(S.N, T, f, bm, S.node_base, L.act[cur], L.nact[cur], S.wid, S.prob, L.outs, L.outh, L.selfemit, L.cnt, L.base,
+                            L.act[cur ^ 1], L.nact[cur ^ 1], L.pos, L.posf, sh.best, L.exits, L.nexit, L.hbin, L.misc, (int32_t *)NULL, L.pack,
+                            S.pack_max_exits, L.gpart, S.gp_n, L.poswid, L.posout, hist_frame ? 1 : 0, L.scan_agg, L.scan_pre, L.scan_flag,
+                            S.scan_chunks, 0, 1, 1, t, 0);
         __syncthreads();
     }
     kf_barrier(B);
