@@ -317,7 +317,8 @@ def wide_beam_leg(lib, d, lanes, n_frames, fast, n_check=64):
                              "ku_hist_sort<1024> 44 076 B LDS, <256> 20 028 B",
            "identical_to_reference": {"utterances_checked": n_cmp, "identical": n_ok},
            "cpu_reference": {"frames_per_sec": round(cpu_fps, 1) if cpu_fps else None, "processes": n_cmp, "frames": cpu_frames, "kind": "reference",
-                             "note": "the unmodified sphinx3_decode, one single-utterance process per checked utterance side by side (stat.c xClk of the slowest)"}}
+                             "note": "the unmodified sphinx3_decode, one single-utterance process per checked utterance side by side (stat.c xClk "
+                                     "of the slowest)"}}
     assert n_cmp == 0 or n_ok == n_cmp, "wide-beam decode on the device differs from the unmodified reference"
     return out
 
@@ -408,7 +409,8 @@ def ps_fwdtree_leg(t, lanes, n_cpu=128, n_proc=16):
                                   "algorithmic_bytes_per_frame": alg, "achieved": round(fr * alg / (srch_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
                                   "unit": "GB/s", "frac": round(fr * alg / (srch_ms * 1e-3) / 1e9 / 8000.0, 4),
                                   "traffic_bytes_per_frame": traffic,
-                                  "traffic_source": "profiles/r4_pmc_ps.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 256 utterances over 128 lanes)" if traffic else None,
+                                  "traffic_source": "profiles/r4_pmc_ps.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 256 utterances over 128 "
+                                                    "lanes)" if traffic else None,
                                   "note": "algorithmic = ~1 700 active channels per frame (pocketsphinx's own count: 1 191 - 2 270 per frame) x a 64-byte "
                                           "record read and written + the active senones' int16 scores"}
     assert same_h and same_s, "pocketsphinx first pass on the device differs from the unmodified pocketsphinx"
@@ -455,10 +457,14 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong: the fixed batch is split over the ranks (configs[3] as written); weak: every rank decodes a whole batch")
     ap.add_argument("--lanes", type=int, default=512, help="decoder lanes per GPU (utterances in flight)")
-    ap.add_argument("--engines", type=int, default=1, help="decoder engines per GPU (own stream each) the lanes are split over (1 since round 5: ku_frames keeps every lane on its own workgroup, so one engine fills the chip; the launch path of rounds 2-4 wanted 4)")
+    ap.add_argument("--engines", type=int, default=1, help="decoder engines per GPU (own stream each) the lanes are split over (1 since round 5: "
+                                                           "ku_frames keeps every lane on its own workgroup, so one engine fills the chip; the "
+                                                           "launch path of rounds 2-4 wanted 4)")
     ap.add_argument("--min-group", type=int, default=32, help="a rank's share is cut into groups of at least this many utterances")
     ap.add_argument("--group-fixed", type=int, default=16, help="small shares: the per-frame cost of a group in lane equivalents (sizes the groups so that the engines finish together)")
-    ap.add_argument("--refill", type=int, default=1, help="1: a share of more utterances than lanes is ONE queue per engine, a lane takes the next utterance when its own has ended (s3a_uttdec_decode_queue_dev); 0: groups of similar length, lanes in lock step")
+    ap.add_argument("--refill", type=int, default=1, help="1: a share of more utterances than lanes is ONE queue per engine, a lane takes the next "
+                                                          "utterance when its own has ended (s3a_uttdec_decode_queue_dev); 0: groups of similar "
+                                                          "length, lanes in lock step")
     ap.add_argument("--frames", type=int, default=1000, help="nominal frames per utterance (10 s)")
     ap.add_argument("--cand-cap", type=int, default=0, help="word-level candidate capacity per lane (0: the library's default, 1 << 20)")
     ap.add_argument("--cpu-procs", type=int, default=16, help="processes of the CPU baseline's batch leg (16: where this host's aggregate peaks)")
@@ -466,7 +472,9 @@ def main():
     ap.add_argument("--check-all", action="store_true", help="the reference decodes the WHOLE batch (~3 more minutes of CPU): every utterance is compared")
     ap.add_argument("--cpu-physical", action="store_true", help="add the CPU leg with one process per physical core (~2 minutes)")
     ap.add_argument("--no-scoring", action="store_true", help="skip the scoring-only extra legs")
-    ap.add_argument("--plain", action="store_true", help="the timed steps and the in-bench kernel timing only (no single-engine profile, no 8-GPU projection, no extra legs): the command rocprofv3 wraps for profiles/, so that its per-kernel averages are those of the bench's own regime")
+    ap.add_argument("--plain", action="store_true", help="the timed steps and the in-bench kernel timing only (no single-engine profile, no 8-GPU "
+                                                         "projection, no extra legs): the command rocprofv3 wraps for profiles/, so that its "
+                                                         "per-kernel averages are those of the bench's own regime")
     ap.add_argument("--no-ps", action="store_true", help="skip the pocketsphinx first-pass leg")
     ap.add_argument("--no-wide-beam", action="store_true", help="skip the configs[4] wide-beam leg")
     ap.add_argument("--wide-lanes", type=int, default=64, help="lanes of the wide-beam leg's engine")
@@ -794,8 +802,8 @@ def main():
                     "measured": "HIP events on the engine's stream around ku_frames, last timed step",
                     "note": "the dominant kernel by device time (`kernels`): ONE launch decodes a queue part -- every lane its utterances, frame "
                             "after frame, the twelve steps of a frame as phases of a persistent 512-thread workgroup (`phases_us_per_lane_frame`). "
-                            "Its steps are bound by the NUMBER of scattered accesses (a gather / scatter costs a cycle per lane in the CU's "
-                            "address path whatever it moves: DESIGN.md 4.1), not by bytes: nowhere near the bandwidth roof; the scoring is "
+                            "Its steps WAIT -- on dependent round trips to memory and on the CUs' address path (a wave issues an instruction "
+                            "every ~55 cycles: DESIGN.md 4.1) --, they are not bound by bytes: nowhere near the bandwidth roof; the scoring is "
                             "float64-VALU-bound (bit-exact mode: no FMA)"}
             roof_scoring = {"kernel": "ku_score_window", "bound": "valu-f64", "achieved": round(sc_tfl, 2), "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(sc_tfl / FP64_VEC_PEAK_TFLOPS, 4), "hbm_GBs": round(alg_score / (score_ms * 1e-3) / 1e9, 1),
@@ -810,7 +818,7 @@ def main():
             search = {"ms_per_step": round(frames_ms, 2), "us_per_lane_frame": round(1e3 * frames_ms * lanes_bench * len(decs) / fr_rank, 2) if fr_rank else None,
                       "share_of_step": round(frames_ms / tot_ms, 4), "algorithmic_bytes_per_step": int(fr_rank * lanes_hmm * 84.0),
                       "achieved_GBs": round(fr_rank * lanes_hmm * 84.0 / (frames_ms * 1e-3) / 1e9, 1),
-                      "frac": round(fr_rank * lanes_hmm * 84.0 / (frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": "scattered-access rate (address path of the CUs)",
+                      "frac": round(fr_rank * lanes_hmm * 84.0 / (frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": "latency of dependent scattered accesses (waits), address path of the CUs",
                       "active_hmm_updates_per_s": round(lanes_hmm * value, 0),
                       "active_hmm_updates_per_s_cpu_single_core": round(cpu["active_hmm_per_frame"] * cpu["single_core"], 0) if cpu else None,
                       "phases_us_per_lane_frame": {k: round(v / max(ph_frames, 1), 2) for k, v in sorted(phases.items()) if k != "in_launch"},

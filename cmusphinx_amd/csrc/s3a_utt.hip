@@ -66,7 +66,8 @@ struct ULane {
     int32_t *cs_wl, *cs_wn;     /* [n_cs + 1], [1] ku_frames: the composite senones wanted in the frame, each once, any order | their number */
     int32_t *posbest;           /* [N] ku_frames: by list position, the HMM's best score of the frame (as poswid / posout) */
     uint32_t *senbits;          /* [KF_SENBITS / 32] ku_frames with clusters: the frame's active senones, a bit each (the workgroups' masks OR-ed together; zero between frames) */
-    int32_t *posps;             /* [N] ku_frames, 3-state HMMs: by list position, the parent set of the HMM's node (-1: none; from the packed node) */
+    int32_t *posps;             /* [N] ku_frames, 3-state HMMs: by list position, the node's parent set + 1 (0: none) and, bit 29, whether it is a member of
+                                 * a several-parent set (from the packed node) */
     int32_t *ent;               /* [2 ent_cap] ku_frames: lextree_enter's scratch (the entries that pass the threshold test) */
     uint8_t *pstamp8;           /* [n_pset] the parent sets' stamps, the frame number's low 8 bits (a quarter of the
                                  * sweep's gathers' footprint; a stale match costs a walk that finds nothing) */
@@ -1568,6 +1569,7 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_MAXC 32
 #define KF_MAXSEG (KF_MAXC * KF_WAVES)
 #define KF_PSBITS 8192
+#define KF_PSTAB 512
 #define KF_SENBITS 16384          /* senones ku_frames keeps an activity bit for in LDS (more: the launches stay) */
 #define KF_ER 4                 /* runs of 64 entries a wave tests per turn of lextree_enter's sweep */
 #define KF_RL 8                 /* list positions a thread classifies per turn of the propagation step's first pass */
@@ -1605,6 +1607,8 @@ struct KfSh {                   /* the workgroup's LDS outside the word level's 
     int32_t seg[KF_MAXSEG + 1], ws[KF_WAVES + 1], gq[4];    /* lextree_enter: the waves' segments of passing entries, scan scratch */
     int32_t rk[KF_RK][KF_WAVES];  /* ... the ranking pass's counts per (run, wave) */
     uint32_t senbits[KF_SENBITS / 32];  /* srch_TST_select_active_gmm's mask of the frame, a bit per senone (the launch path: a byte each in HBM) */
+    int32_t pstab[KF_PSTAB];        /* the frame's stamped parent sets, an open-addressed table (-1: free): membership is exact */
+    int32_t ps_exact;               /* ... when they all found room (else the bit filter in front of pstamp8 / claim) */
     uint32_t psbits[KF_PSBITS / 32];    /* the frame's stamped parent sets, a bit per set id modulo KF_PSBITS (a filter in front of pstamp8) */
     long long kacc[16];         /* the steps' clock of the utterance so far (UCtx.kacc) */
     int32_t thr[4];             /* the frame's thresholds: HMM, phone, word (final once the histogram beam is known) */
@@ -2180,7 +2184,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 GM(L.poswid)[b0 + i0] = w;
                 GM(L.posout)[b0 + i0] = out;
                 GM(L.posbest)[b0 + i0] = k;
-                if (NE == 3) GM(L.posps)[b0 + i0] = (int32_t)((uint32_t)nd0.w >> 1) - 1;
+                if (NE == 3) GM(L.posps)[b0 + i0] = (int32_t)((uint32_t)nd0.w >> 1);           /* (parent set + 1, bit 29: member of a several-parent set) */
             }
             /* a wave's 64 positions belong to one tree, or to two or three at the seams */
             unsigned long long todo = __ballot(t >= 0);
@@ -2345,9 +2349,18 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
          * packed node and lies by list position (a histogram frame has reordered the positions: through the node then) */
         {
             for (int32_t i = tid; i < KF_PSBITS / 32; i += KF_NT) sh.psbits[i] = 0u;
+            for (int32_t i = tid; i < KF_PSTAB; i += KF_NT) sh.pstab[i] = -1;
             __syncthreads();
             const int32_t n_pl = S3A_ALD(&L.pcnt[f & 1]);
-            for (int32_t k = tid; k < n_pl; k += KF_NT) { const uint32_t q = (uint32_t)L.plist[k] % KF_PSBITS; atomicOr(&sh.psbits[q >> 5], 1u << (q & 31)); }
+            if (tid == 0) sh.ps_exact = n_pl <= (3 * KF_PSTAB) / 4 ? 1 : 0;
+            for (int32_t k = tid; k < n_pl; k += KF_NT) {
+                const int32_t q_ = L.plist[k];
+                const uint32_t q = (uint32_t)q_ % KF_PSBITS;
+                atomicOr(&sh.psbits[q >> 5], 1u << (q & 31));
+                if (n_pl <= (3 * KF_PSTAB) / 4)         /* (every listed set once: no two threads insert the same id) */
+                    for (uint32_t sl = ((uint32_t)q_ * 2654435761u) >> 23; ; sl = (sl + 1) & (KF_PSTAB - 1))
+                        if (atomicCAS(&sh.pstab[sl], -1, q_) == -1) break;
+            }
             __syncthreads();
         }
         const bool ps_by_pos = NE == 3 && !hist_frame;
@@ -2382,18 +2395,53 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
 #pragma unroll
                         for (int u = 0; u < KF_RL; u++) qq[u] = GMC(S.ps)[max(vv[u], 0)];
                     }
+                    const bool exact = ps_by_pos && sh.ps_exact != 0;       /* (the stamped sets' table is complete: membership decides) */
 #pragma unroll
                     for (int u = 0; u < KF_RL; u++) {
                         if (vv[u] < 0) continue;
-                        const uint32_t qb = (uint32_t)qq[u] % KF_PSBITS;
-                        bool has_par = qq[u] >= 0 && ((sh.psbits[qb >> 5] >> (qb & 31)) & 1u);
-                        if (has_par) has_par = GMC(L.pstamp8)[qq[u]] == ps_val<uint8_t>(f);
-                        if (!has_par && !hist_frame && pbv[u] >= sh.thr[0]) { GM(L.selfemit)[bb[u] + ii[u]] = 1; atomicAdd(&L.cnt[bb[u] + ii[u]], 1); continue; }
+                        /* (by position: parent set + 1, bit 29 = a member of a several-parent set; through the node: the set id) */
+                        const int32_t q = ps_by_pos ? (qq[u] & 0x1fffffff) - 1 : qq[u];
+                        const bool in_set = ps_by_pos && ((qq[u] >> 29) & 1);
+                        bool has_par = false;
+                        if (q >= 0) {
+                            if (exact) {
+                                for (uint32_t sl = ((uint32_t)q * 2654435761u) >> 23; ; sl = (sl + 1) & (KF_PSTAB - 1)) {
+                                    const int32_t x = sh.pstab[sl];
+                                    if (x == q) { has_par = true; break; }
+                                    if (x == -1) break;
+                                }
+                            }
+                            else {
+                                const uint32_t qb = (uint32_t)q % KF_PSBITS;
+                                has_par = ((sh.psbits[qb >> 5] >> (qb & 31)) & 1u) != 0;
+                                if (has_par) has_par = GMC(L.pstamp8)[q] == ps_val<uint8_t>(f);
+                            }
+                        }
+                        if (!hist_frame && !has_par) {
+                            /* the usual active HMM -- no parent can enter it: it survives (it joins the next list at its own turn; its record
+                             * carries the frame tag since the evaluation) or it is cleared (d_dec_resolve_node's first case: stores only) */
+                            if (pbv[u] >= sh.thr[0]) { GM(L.selfemit)[bb[u] + ii[u]] = 1; atomicAdd(&L.cnt[bb[u] + ii[u]], 1); continue; }
+                            if (NE == 3) {
+                                S3A_AS1 s3a_v4i *rec = (S3A_AS1 s3a_v4i *)(L.sc + NSV(vv[u]));
+                                s3a_v4i o0, o1; s3a_v2i o2;
+                                o0.x = WORST; o0.y = WORST; o0.z = WORST; o0.w = -1; o1.x = -1; o1.y = -1; o1.z = WORST; o1.w = -1; o2.x = WORST; o2.y = -1;
+                                static_assert(NS_HIST(3) == 3 && NS_OUTS(3) == 6 && NS_OUTH(3) == 7 && NS_BESTS(3) == 8 && NS_FRAME(3) == 9, "the 3-state record's layout");
+                                rec[0] = o0; rec[1] = o1; *(S3A_AS1 s3a_v2i *)(rec + 2) = o2;
+                                GM(L.posout)[bb[u] + ii[u]] = WORST;
+                                continue;
+                            }
+                        }
+                        /* (the listed sets' members with 2..64 parents, active or not, are the set passes': with the exact table a stamped set IS a
+                         * listed set) */
+                        if (exact && has_par && in_set && !hist_frame) continue;
                         wl_[atomicAdd(&sh.gq[3], 1)] = gg[u] | (has_par ? (int32_t)0x80000000 : 0);
                     }
                 }
                 __syncthreads();
                 const int32_t n_wl = sh.gq[3];
+#if defined(KF_DIAG) && KF_DIAG == 1
+                if (r == 0 && tid == 0) sh.kacc[8] += (long long)n_wl * 100;
+#endif
                 for (int32_t k = tid; k < n_wl; k += KF_NT) {
                     const int32_t e_ = wl_[k], g = e_ & 0x7fffffff;
                     const bool has_par = e_ < 0;
@@ -2402,7 +2450,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     const int32_t b = sh.nb[t_], v = GMC(act)[b + i];
                     /* (the listed sets' members with 2..64 parents, active or not, are d_dec_resolve_children's) */
                     if (has_par) {
-                        const int32_t q = ps_by_pos ? GMC(L.posps)[b + i] : GMC(S.ps)[v];
+                        const int32_t q = ps_by_pos ? (GMC(L.posps)[b + i] & 0x1fffffff) - 1 : GMC(S.ps)[v];
                         if (S3A_ALD(&L.claim[q]) == f) {
                             const int32_t np = S.par_off[v + 1] - S.par_off[v];
                             if (np >= SET_NP_MIN && np <= 64) continue;
@@ -2469,6 +2517,15 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 }
                 /* 2. the one-parent sets' members */
                 const int32_t M = rs.m_all;
+#if defined(KF_DIAG) && KF_DIAG == 2
+                if (r == 0 && tid == 0) sh.kacc[8] += (long long)M * 100;
+#endif
+#if defined(KF_DIAG) && KF_DIAG == 3
+                if (r == 0 && tid == 0) sh.kacc[8] += (long long)(rs.bpre[KF_BIG] + rs.bmpre[KF_BIG]) * 100;
+#endif
+#if defined(KF_DIAG) && KF_DIAG == 4
+                if (r == 0 && tid == 0) sh.kacc[8] += (long long)(rs.nleg + max(0, rs.nbig - KF_BIG)) * 100;
+#endif
                 for (int32_t m = tid; m < M; m += KF_NT) {
                     int32_t lo = 0, hi = nk - 1;
                     while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.pre[mid] <= m) lo = mid; else hi = mid - 1; }
@@ -2770,14 +2827,16 @@ ku_pack_node4(const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmat
 __global__ void
 ku_pack_nodepk(const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmatid, const int32_t *__restrict__ wid,
                const uint8_t *__restrict__ comp, const int16_t *__restrict__ sseq, const int16_t *__restrict__ comsseq,
-               const int32_t *__restrict__ ps, int4 *out, int32_t N)
+               const int32_t *__restrict__ ps, const int32_t *__restrict__ par_off, int4 *out, int32_t N)
 {
     const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
     const int16_t *row = (comp[v] ? comsseq : sseq) + (size_t)ssid[v] * 3;
     const uint32_t i0 = (uint16_t)row[0], i1 = (uint16_t)row[1], i2 = (uint16_t)row[2];
+    /* (bit 30: the node is a member of a several-parent set the set passes resolve -- SET_NP_MIN .. 64 parents) */
+    const int32_t np = par_off[v + 1] - par_off[v];
     out[v] = make_int4((int32_t)(i0 | (i1 << 16)), (int32_t)(i2 | ((uint32_t)tmatid[v] << 16)), wid[v],
-                       (int32_t)(((uint32_t)(ps[v] + 1) << 1) | (comp[v] ? 1u : 0u)));
+                       (int32_t)(((np >= SET_NP_MIN && np <= 64) ? 0x40000000u : 0u) | ((uint32_t)(ps[v] + 1) << 1) | (comp[v] ? 1u : 0u)));
 }
 
 /* (ne = 3: 2 words per node, ne = 5: 4) */
@@ -3292,12 +3351,12 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         S.nodesen = ns;
         hipLaunchKernelGGL(ku_pack_nodesen, dim3((unsigned)((proto->N + 255) / 256)), dim3(256), 0, ud->stream, proto->d_ssid, proto->d_comp, proto->d_sseq,
                            proto->d_comsseq, ns, proto->N, ne);
-        if (ne == 3 && proto->n_tmat < 65536 && proto->d_ps) {
+        if (ne == 3 && proto->n_tmat < 65536 && proto->d_ps && proto->N < (1 << 28)) {
             int4 *pk = NULL;
             DM(pk, (size_t)(proto->N > 0 ? proto->N : 1) * sizeof(int4));
             S.nodepk = pk;
             hipLaunchKernelGGL(ku_pack_nodepk, dim3((unsigned)((proto->N + 255) / 256)), dim3(256), 0, ud->stream, proto->d_ssid, proto->d_tmatid, proto->d_wid,
-                               proto->d_comp, proto->d_sseq, proto->d_comsseq, proto->d_ps, pk, proto->N);
+                               proto->d_comp, proto->d_sseq, proto->d_comsseq, proto->d_ps, proto->d_par_off, pk, proto->N);
         }
     }
     {   /* the roots' look-ahead probabilities in root-list order (Entries::rootprob) */
