@@ -2369,6 +2369,12 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
          * its record carries the frame tag since the evaluation); the others -- entered by a parent, or dying -- go to a list in LDS.
          * (B) a thread per listed HMM walks d_dec_resolve_node's chain: dense waves, once per block, instead of every wave paying the
          * chain in every turn for the few lanes that need it (two positions per turn were 3.2 turns x ~11 round trips) */
+#ifdef KF_DIAG
+        long long td_ = (long long)wall_clock64();
+#define KF_DT(n) do { __syncthreads(); if (KF_DIAG == (n) && r == 0 && tid == 0) { const long long t_ = (long long)wall_clock64(); sh.kacc[8] += t_ - td_; } if (r == 0 && tid == 0) td_ = (long long)wall_clock64(); } while (0)
+#else
+#define KF_DT(n) do { } while (0)
+#endif
         {
             int32_t *wl_ = (int32_t *)&sh.pool;
             static_assert(sizeof(KfPool) >= KF_RL * KF_NT * 4, "the list pass's work list lives in the pool");
@@ -2464,6 +2470,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                 __syncthreads();
             }
         }
+        KF_DT(5);
         /* the frame's listed parent sets (d_stamp_and_list): this workgroup's share, up to KF_SETS per pass -- everything as flat work
          * items (measured: ~130 listed sets per frame, 87 of them several-parent sets of ~10 members and one or two propagating
          * parents each; a wave per such set was 11 sets in a row per wave, each a chain of five round trips: 98 us of the frame):
@@ -2536,6 +2543,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                                                        S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, x, false, true, -1, -1,
                                                        HeurArgs{ NULL, NULL, NULL }, sh.thr);
                 }
+                KF_DT(6);
                 /* 3. the several-parent sets' propagating parents */
                 {
                     const int32_t I = rs.bpre[KF_BIG];
@@ -2576,6 +2584,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     }
                     __syncthreads();
                 }
+                KF_DT(7);
                 /* 4. their members */
                 {
                     const int32_t MB = rs.bmpre[KF_BIG];
@@ -2608,6 +2617,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                                              L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.posout);
                     }
                 }
+                KF_DT(8);
                 /* ... and the sets that have no table, a wave each (d_dec_resolve_children) */
                 if (rs.nleg > 0 || rs.nbig > KF_BIG) {
                     __syncthreads();
