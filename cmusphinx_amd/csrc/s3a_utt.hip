@@ -99,8 +99,6 @@ struct UShared {
     const int4 *node4;          /* per node: {ssid, tmatid, wid, composite}: ku_hmm_eval's static words as one load */
     const int32_t *nodesen;     /* per node, 2 (3 states) or 4 (5 states) words: its senone ids -- of a composite node its composite-senone ids --
                                  * as 16-bit halves (ku_frames: one load instead of the chain node -> sequence id -> three 2-byte gathers) */
-    const int4 *pshdr;          /* per parent set ONE 16-byte word: first member's place and one past the last in psmem, first parent's place in par,
-                                 * number of parents (ku_frames' header pass: one load instead of the chain psmem_off -> psmem -> par_off) */
     const int4 *nodepk;         /* 3-state HMMs, per node ONE 16-byte word for everything ku_frames' steps read of it: senone ids 0 | 1 << 16,
                                  * id 2 | transition matrix << 16, word id, (parent set + 1) << 1 | composite (what is asked for together
                                  * lives together: one cache line per visit instead of node4's + nodesen's + ps's three) */
@@ -2494,14 +2492,8 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     int32_t cm = 0, m_lo = 0;
                     if (tid < nk) {
                         const int32_t q = GMC(L.plist)[k0 + tid];
-                        int32_t m_hi, kp0, np;
-                        if (S.pshdr) { const s3a_v4i h_ = ((const S3A_AS1 s3a_v4i *)S.pshdr)[q]; m_lo = h_.x; m_hi = h_.y; kp0 = h_.z; np = h_.w; }
-                        else {
-                            m_lo = GMC(S.psmem_off)[q];
-                            m_hi = GMC(S.psmem_off)[q + 1];
-                            const int32_t x0 = GMC(S.psmem)[m_lo];
-                            kp0 = GMC(S.par_off)[x0]; np = GMC(S.par_off)[x0 + 1] - kp0;
-                        }
+                        m_lo = GMC(S.psmem_off)[q];
+                        const int32_t m_hi = GMC(S.psmem_off)[q + 1], x0 = GMC(S.psmem)[m_lo], kp0 = GMC(S.par_off)[x0], np = GMC(S.par_off)[x0 + 1] - kp0;
                         if (np >= SET_NP_MIN && np <= 64) {
                             const int32_t at = atomicAdd(&rs.nbig, 1);
                             rs.big[at] = q;
@@ -2839,18 +2831,6 @@ ku_pack_node4(const int32_t *__restrict__ ssid, const int32_t *__restrict__ tmat
 {
     const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < N) out[v] = make_int4(ssid[v], tmatid[v], wid[v], (int32_t)comp[v]);
-}
-
-/* a parent set's header in one 16-byte word (UShared.pshdr) */
-__global__ void
-ku_pack_pshdr(const int32_t *__restrict__ psmem_off, const int32_t *__restrict__ psmem, const int32_t *__restrict__ par_off, int4 *out, int32_t n)
-{
-    const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    const int32_t m_lo = psmem_off[q], m_hi = psmem_off[q + 1];
-    int32_t kp0 = 0, np = 0;
-    if (m_hi > m_lo) { const int32_t x0 = psmem[m_lo]; kp0 = par_off[x0]; np = par_off[x0 + 1] - kp0; }
-    out[q] = make_int4(m_lo, m_hi, kp0, np);
 }
 
 /* 3-state HMMs: everything ku_frames reads of a node in one 16-byte word (UShared.nodepk) */
@@ -3273,7 +3253,6 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     if (ud->S.node4) (void)hipFree((void *)ud->S.node4);
     if (ud->S.nodesen) (void)hipFree((void *)ud->S.nodesen);
     if (ud->S.nodepk) (void)hipFree((void *)ud->S.nodepk);
-    if (ud->S.pshdr) (void)hipFree((void *)ud->S.pshdr);
     if (ud->S.ctx_all) (void)hipFree(ud->S.ctx_all);
     if (ud->S.nact_all) (void)hipFree(ud->S.nact_all);
     if (ud->d_lcmap) (void)hipFree(ud->d_lcmap);
@@ -3382,13 +3361,6 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         S.nodesen = ns;
         hipLaunchKernelGGL(ku_pack_nodesen, dim3((unsigned)((proto->N + 255) / 256)), dim3(256), 0, ud->stream, proto->d_ssid, proto->d_comp, proto->d_sseq,
                            proto->d_comsseq, ns, proto->N, ne);
-        if (proto->n_pset > 0 && proto->d_psmem_off && proto->d_psmem) {
-            int4 *ph = NULL;
-            DM(ph, (size_t)proto->n_pset * sizeof(int4));
-            S.pshdr = ph;
-            hipLaunchKernelGGL(ku_pack_pshdr, dim3((unsigned)((proto->n_pset + 255) / 256)), dim3(256), 0, ud->stream, proto->d_psmem_off, proto->d_psmem,
-                               proto->d_par_off, ph, proto->n_pset);
-        }
         if (ne == 3 && proto->n_tmat < 65536 && proto->d_ps && proto->N < (1 << 28)) {
             int4 *pk = NULL;
             DM(pk, (size_t)(proto->N > 0 ? proto->N : 1) * sizeof(int4));

@@ -50,6 +50,20 @@ def test_queue_lanes_take_their_utterances_themselves(gpu_lib, tidigits_bundle, 
     assert frames > 0 and launches >= 1 and ticks["hmm_eval"] > 0
 
 
+def test_clusters_with_the_general_barrier(gpu_lib, tidigits_bundle, monkeypatch):
+    """S3A_UTT_PERSIST=2: the clusters' agent-scope barrier only (an L2 write-back per workgroup and step) -- what a cluster falls
+    back to when its workgroups do not share an XCD; the default is the XCD-local barrier (checked per launch through XCC_ID)"""
+    monkeypatch.setenv("S3A_UTT_PERSIST", "2")
+    monkeypatch.setenv("S3A_UTT_CLUSTER", "3")
+    dec = bundle.Decoder(tidigits_bundle, 5)
+    utts, feats = TQ.tidigits_feats(gpu_lib)
+    dec.decode_queue(feats)
+    m, s = TQ.queue_lines(dec, utts)
+    rm, rs = TQ.ref_lines()
+    assert m == rm and s == rs
+    assert dec.ud.last_parts()["cluster"] == 3
+
+
 def test_launches_and_ku_frames_leave_the_same_tables(gpu_lib, tidigits_bundle, monkeypatch):
     """s3a_uttdec_decode both ways: every lane's whole history table and frame statistics, word for word"""
     utts, feats = TQ.tidigits_feats(gpu_lib)
