@@ -1568,7 +1568,7 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_SPIN_MAX (1 << 21)
 #define KF_MAXC 32
 #define KF_MAXSEG (KF_MAXC * KF_WAVES)
-#define KF_PSBITS 8192
+#define KF_PSBITS 4096
 #define KF_PSTAB 512
 #define KF_SENBITS 16384          /* senones ku_frames keeps an activity bit for in LDS (more: the launches stay) */
 #define KF_ER 4                 /* runs of 64 entries a wave tests per turn of lextree_enter's sweep */
@@ -1603,6 +1603,9 @@ union KfPool {                  /* phases that never overlap share this LDS */
 struct KfSh {                   /* the workgroup's LDS outside the word level's own arrays */
     KfPool pool;
     int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
+    ULane Lc;                   /* the lane's structure (its ~60 pointers): a copy in LDS -- a field is a ds_read at a constant address; out of
+                                 * memory it was the structure's spilled address back from scratch, then the pointer, then the data: two
+                                 * round trips in front of many a step's first access */
     int32_t nb[WL_MAXT + 1];    /* the trees' first nodes (UShared.node_base: in LDS, a list position's place in the arrays is then LDS arithmetic only) */
     int32_t seg[KF_MAXSEG + 1], ws[KF_WAVES + 1], gq[4];    /* lextree_enter: the waves' segments of passing entries, scan scratch */
     int32_t rk[KF_RK][KF_WAVES];  /* ... the ranking pass's counts per (run, wave) */
@@ -2040,6 +2043,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (sh.seg[mid] <= 0) lo = mid; else hi = mid - 1; }
             p0 = lo * R;
         }
+        /* (the two groups' trees and list lengths once, not per entry: inside the turn they were two dependent loads per entry, under the
+         * entry's condition -- eight round trips in a row per turn) */
+        const int32_t tg0 = ctx->groups[0], tg1 = ctx->n_groups > 1 ? ctx->groups[4] : ctx->groups[0];
+        const int32_t n00 = L.n0[tg0], n01 = L.n0[tg1];
         for (int32_t i0 = gtid; i0 < P; i0 += 4 * gstride) {
             int32_t pq[4], vq[4], flq[4], fsq[4];
             unsigned long long kq[4];
@@ -2065,9 +2072,9 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             for (int u = 0; u < 4; u++) {
                 if (pq[u] < 0) continue;
                 const int32_t v = vq[u], fl = flq[u], c = fl & 127;
-                const int32_t g = c >= c1 ? 1 : 0, t = ctx->groups[4 * g];
+                const int32_t g = c >= c1 ? 1 : 0, t = g ? tg1 : tg0;
                 if (fl & 128) {
-                    const int32_t k = L.n0[t] + (fl >> 8) - (g ? gq0 : 0);
+                    const int32_t k = (g ? n01 : n00) + (fl >> 8) - (g ? gq0 : 0);
                     GM(L.act[cur])[sh.nb[t] + k] = v; { s3a_v2i o; o.x = k; o.y = nf; *(S3A_AS1 s3a_v2i *)(L.pos + PPX(v)) = o; }
                 }
                 const unsigned long long key = kq[u];
@@ -2687,9 +2694,11 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
     if (C == 1) { z = blockIdx.x; r = 0; }
     else { const int32_t b = blockIdx.x, xcd = b & 7, j = b >> 3; z = (j / C) * 8 + xcd; r = j % C; }
     if (z >= n_lanes) return;
-    const ULane &L = lanes[z];
-    UCtx *ctx = S.ctx_all + z;
     const int32_t tid = threadIdx.x;
+    static_assert(sizeof(ULane) % 4 == 0, "the lane's structure is copied to LDS word by word");
+    for (int32_t i = tid; i < (int32_t)(sizeof(ULane) / 4); i += KF_NT) ((int32_t *)&sh.Lc)[i] = ((const int32_t *)&lanes[z])[i];
+    const ULane &L = sh.Lc;
+    UCtx *ctx = S.ctx_all + z;
     if (tid == 0) sh.dead = 0;
     if (tid < 16) sh.kacc[tid] = 0;
     for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) sh.senbits[i] = 0u;
