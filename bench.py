@@ -417,6 +417,20 @@ def ps_fwdtree_leg(t, lanes, n_cpu=128, n_proc=16):
     return out
 
 
+def exchange_run_id(dist, rank, tdev):
+    """the run id of the C exchange's rendezvous (s3a_gather_init_run): the launcher's S3A_RUN_ID (launch_ranks draws one per launch);
+    under a foreign launcher (torch.distributed.run: only MASTER_PORT, the same from run to run) rank 0 draws a number and
+    broadcasts it over the process group that supplies the barrier; one rank alone: its pid"""
+    if os.environ.get("S3A_RUN_ID", "").isdigit() and int(os.environ["S3A_RUN_ID"]) > 0:
+        return int(os.environ["S3A_RUN_ID"])
+    if dist is None:
+        return os.getpid()
+    import torch
+    t = torch.tensor([(time.time_ns() ^ (os.getpid() << 40)) & ((1 << 62) - 1) or 1 if rank == 0 else 0], dtype=torch.int64, device=tdev)
+    dist.broadcast(t, 0)
+    return int(t.item())
+
+
 def launch_ranks(n, cmd=None):
     """`python bench.py --gpus N` without a launcher around it: N ranks of this very command, one per GPU, the way the reference shards a
     control file over processes (-ctloffset / -ctlcount, main_decode.c:164-169).  The children find RANK / LOCAL_RANK / WORLD_SIZE /
@@ -427,9 +441,10 @@ def launch_ranks(n, cmd=None):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     procs = []
+    run_id = (time.time_ns() ^ (os.getpid() << 40)) & ((1 << 62) - 1) or 1     # (the exchange's rendezvous: a number of THIS launch, not the port)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), S3A_RUN_ID=str(run_id), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen(cmd if cmd is not None else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -670,7 +685,7 @@ def main():
         try:
             sys.stdout.flush()
             os.dup2(2, 1)                   # (RCCL prints a version banner to C stdout: keep stdout to the ONE JSON line)
-            cgather = lib.Gather(rank, world, os.path.join(d, "rccl-id"), run_id=int(os.environ.get("MASTER_PORT", "0")) or os.getpid())
+            cgather = lib.Gather(rank, world, os.path.join(d, "rccl-id"), run_id=exchange_run_id(dist, rank, tdev))
         except lib.S3AError as e:
             if world > 1:
                 raise SystemExit(f"bench.py: the C exchange could not start on rank {rank}: {e}")

@@ -217,6 +217,25 @@ gather_init(int32_t rank, int32_t world, const char *rendezvous_arg, unsigned lo
     int r = g->init_rank(&g->comm, world, id, rank);
     if (r != 0) { s3a_set_error("ncclCommInitRank failed: %s", g->errstr ? g->errstr(r) : "?"); g->comm = NULL; s3a_gather_free(g); return NULL; }
     if (st_alloc(g, &g->d_cnt, 2 * sizeof(long long)) != S3A_OK || st_alloc(g, &g->d_all, sizeof(long long) * 2 * world) != S3A_OK) { s3a_gather_free(g); return NULL; }
+    if (world > 1) {
+        /* the rendezvous file has done its work once EVERY rank holds the id: one small all-gather (each rank's pid) is the proof --
+         * nobody returns from it before everybody has entered it, i.e. has read the file --, and rank 0 removes the file right behind
+         * it.  A later run under the same name (a launcher that reuses MASTER_PORT as its run id) then never meets this run's file: its
+         * ranks wait for their own rank 0's. */
+        long long me[2] = { (long long)getpid(), (long long)rank };
+        std::vector<long long> all((size_t)2 * world);
+        int32_t rc = st_put(g, g->d_cnt, me, sizeof me);
+        if (rc == S3A_OK) {
+            const int r2 = g->all_gather(g->d_cnt, g->d_all, sizeof me, 0 /* ncclInt8: bytes */, g->comm, g->stream);
+            if (r2 != 0) { s3a_set_error("s3a_gather_init: the first all-gather failed: %s", g->errstr ? g->errstr(r2) : "?"); rc = S3A_EHIP; }
+        }
+        if (rc == S3A_OK) rc = st_get(g, all.data(), g->d_all, sizeof(long long) * 2 * world);
+        if (rc == S3A_OK) rc = st_sync(g);
+        if (rank == 0) (void)unlink(rendezvous);
+        if (rc != S3A_OK) { s3a_gather_free(g); return NULL; }
+        for (int r = 0; r < world; r++)
+            if (all[2 * r + 1] != r) { s3a_set_error("s3a_gather_init: rank %d answered in rank %d's place (two runs under one rendezvous name?)", (int)all[2 * r + 1], r); s3a_gather_free(g); return NULL; }
+    }
     return g;
 }
 

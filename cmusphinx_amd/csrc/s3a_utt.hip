@@ -30,6 +30,12 @@
 #include <vector>
 #include <map>
 #include <atomic>
+#include <mutex>
+#include <algorithm>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/file.h>
+#include <sys/stat.h>
 
 #include "s3a_device.h"
 #include "s3a_structs.h"
@@ -1625,6 +1631,8 @@ struct KfJob {
     int32_t mode, fg0, n_fr;    /* KF_WINDOW: the engine frames of this launch */
     int32_t n_utt;              /* KF_QUEUE: utterances of this launch (the queue's, or a part of it that fits the score buffer) */
     int32_t u0;                 /* ... the first one's place in the queue */
+    const int32_t *order;       /* ... [queue] which utterance the k-th take of the counter is: a part's utterances longest first (the launch ends with
+                                 * its slowest lane: what is taken last should be short) */
     int32_t *next;              /* ... [1] the counter the lanes take their utterances from */
     int32_t *lane_u;            /* ... [n_lanes] what a lane's first workgroup took (read by the rest of its cluster) */
     const UCtx *stage;          /* ... [queue] the utterances' staged contexts */
@@ -2680,8 +2688,13 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
 struct KfArgs { UShared S; WLm lm; WDict dict; WPar par; KfJob J; };
 #define KF_ARG_SLOTS 8
 
+/* (KF_OCC: waves per SIMD the register budget is set for -- 4 = 128 VGPRs, two lanes per CU; -DKF_OCC=2 = 256 VGPRs, one lane per CU: the
+ * build profiles/r6_experiments.txt uses to tell what the spills cost) */
+#ifndef KF_OCC
+#define KF_OCC 4
+#endif
 template <int NE, bool EXACT>
-__global__ void __launch_bounds__(KF_NT, 4)
+__global__ void __launch_bounds__(KF_NT, KF_OCC)
 ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t n_lanes, int32_t C, int32_t *bar,
           int32_t weak_possible, int32_t local_ok)
 {
@@ -2737,11 +2750,12 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
             __syncthreads();
             u = sh.u;
             if (u >= J.n_utt || sh.dead) break;
+            u = J.order[J.u0 + u];              /* (the take's utterance: its index in the queue) */
             /* srch_utt_begin (srch.c:453-479): every per-utterance state reset, the utterance's context */
-            d_lane_begin(L, S, J.B, z, J.stage + J.u0 + u, gtid, gstride, r == 0, tid, KF_NT);
+            d_lane_begin(L, S, J.B, z, J.stage + u, gtid, gstride, r == 0, tid, KF_NT);
             kf_barrier(B);
             f_hi = ctx->nfr;
-            r0 = (size_t)J.row0[J.u0 + u];
+            r0 = (size_t)J.row0[u];
         }
         else if (mode == KF_STATIC) { f_hi = ctx->nfr; r0 = (size_t)J.row0[z]; }
         else { const int32_t f0 = ctx->f0; f_lo = max(0, J.fg0 - f0); f_hi = min(ctx->nfr, J.fg0 + J.n_fr - f0); }
@@ -2756,7 +2770,7 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
         if (r == 0 && tid < 16 && tid != 12 && tid != 14) { ctx->kacc[tid] += sh.kacc[tid]; sh.kacc[tid] = 0; }
         /* srch_utt_end (srch.c:482-560): the hypothesis goes to the utterance's slot, the lane's lists are cleared */
         static_assert(3 * WL_LDS_EX >= UH_IDS, "d_hyp's backtrace ids borrow the word level's exit area");
-        if (r == 0) d_hyp<KF_NT>(L, ctx, lm, dict, J.P, J.hdr + (size_t)(J.u0 + u) * UH_N, J.words, J.wcount, sh.pool.wl.ex);
+        if (r == 0) d_hyp<KF_NT>(L, ctx, lm, dict, J.P, J.hdr + (size_t)u * UH_N, J.words, J.wcount, sh.pool.wl.ex);
         kf_barrier(B);
         d_lane_end(L, S, z, ctx->err != 0, J.n_word, gtid, gstride);
         kf_barrier(B);
@@ -3119,6 +3133,9 @@ struct s3a_uttdec_s {
     int32_t kf_arg_at;
     /* SCORES FIRST: every frame's senone scores of a call (ku_frames, KF_STATIC / KF_QUEUE) */
     int32_t *sb_scores; uint8_t *sb_bests; size_t sb_rows_cap;
+    size_t sb_rows_max;         /* s3a_uttdec_opts_t.score_rows_max: a cap on the buffer's rows (0: half of the free device memory) */
+    int32_t *kf_order_d, *kf_order_h; size_t kf_order_cap;      /* KF_QUEUE: the order in which the lanes take the queue's utterances (longest first) */
+    int32_t kf_shared;          /* another PROCESS holds this device's cluster lock: this engine's lanes stay one workgroup each */
     UwGroup *sb_gdesc_d, *sb_gdesc_h; size_t sb_g_cap;
     long long *sb_row0_d, *sb_row0_h; size_t sb_row0_cap;
     /* where the last call's device time went: events around the scoring launches and around ku_frames (s3a_uttdec_last_parts) */
@@ -3129,6 +3146,39 @@ struct s3a_uttdec_s {
 
 /* engines with ku_frames alive per device: an engine that is alone on its device may give a lane a cluster of workgroups */
 static std::atomic<int> g_kf_live[64];
+
+/* ... and alone means: no other PROCESS runs clusters there either.  The clusters of a launch spin on one another, so all of them must be
+ * resident at once; two processes that each sized a grid for the whole device would leave each other's clusters half resident (the
+ * spin then runs into KF_SPIN_MAX and the utterances end with WL_E_SCAN).  One advisory lock per device -- a file named by the device's
+ * PCI bus id under /dev/shm, flock()ed exclusively by the first process that creates a ku_frames engine there and kept while it has one --
+ * tells the others: they keep their lanes at one workgroup each (s3a_uttdec_opts_t.cluster still overrides: the caller then answers for
+ * co-residency).  No /dev/shm, no lock: taken as alone, as before. */
+static std::mutex g_kf_lock_mu;
+static int g_kf_lock_fd[64], g_kf_lock_n[64], g_kf_lock_own[64];
+static bool
+kf_device_lock(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_kf_lock_mu);
+    if (g_kf_lock_n[dev]++ > 0) return g_kf_lock_own[dev] != 0;
+    char bus[64] = "", path[160];
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, dev) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", dev);
+    for (char *c = bus; *c; c++) if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+    snprintf(path, sizeof path, "/dev/shm/cmusphinx_amd.kf.%s.lock", bus);
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    g_kf_lock_fd[dev] = fd;
+    if (fd < 0) { g_kf_lock_own[dev] = 1; return true; }
+    (void)fchmod(fd, 0666);
+    g_kf_lock_own[dev] = flock(fd, LOCK_EX | LOCK_NB) == 0 ? 1 : 0;
+    return g_kf_lock_own[dev] != 0;
+}
+static void
+kf_device_unlock(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_kf_lock_mu);
+    if (--g_kf_lock_n[dev] > 0) return;
+    if (g_kf_lock_fd[dev] >= 0) { (void)flock(g_kf_lock_fd[dev], LOCK_UN); (void)close(g_kf_lock_fd[dev]); }
+    g_kf_lock_fd[dev] = -1; g_kf_lock_own[dev] = 0; g_kf_lock_n[dev] = 0;
+}
 
 static int32_t
 fill32(hipStream_t st, int32_t *p, int32_t v, size_t n)
@@ -3221,7 +3271,9 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
         if (hl.sc) s3a_scorer_free(hl.sc);
         if (hl.ls) s3a_lexsearch_free(hl.ls);
     }
-    if (ud->kf_counted) { g_kf_live[ud->device]--; ud->kf_counted = 0; }
+    if (ud->kf_counted) { g_kf_live[ud->device]--; ud->kf_counted = 0; kf_device_unlock(ud->device); }
+    if (ud->kf_order_d) (void)hipFree(ud->kf_order_d);
+    if (ud->kf_order_h) (void)hipHostFree(ud->kf_order_h);
     for (auto e : ud->kf_evs) (void)hipEventDestroy(e);
     ud->kf_evs.clear();
     if (ud->d_kfbar) (void)hipFree(ud->d_kfbar);
@@ -3291,7 +3343,7 @@ s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o)
     o->scan_g = num("S3A_UTT_SCAN_G", 0); o->gy = num("S3A_UTT_GY", 0); o->sweep_k = num("S3A_UTT_URK", 0);
     o->no_multi = getenv("S3A_UTT_NO_MULTI") != NULL; o->framecheck = getenv("S3A_UTT_FRAMECHECK") != NULL;
     o->times = num("S3A_UTT_TIMES", 0); o->graph = num("S3A_UTT_GRAPH", 0); o->window_max = num("S3A_UTT_WIN_MAX", 0); o->scan_small_from = num("S3A_UTT_SCAN_SMALL", 0);
-    o->persist = num("S3A_UTT_PERSIST", 0); o->cluster = num("S3A_UTT_CLUSTER", 0);
+    o->persist = num("S3A_UTT_PERSIST", 0); o->cluster = num("S3A_UTT_CLUSTER", 0); o->score_rows_max = num("S3A_UTT_SCORE_ROWS", 0);
 }
 
 extern "C" s3a_uttdec_t *
@@ -3527,6 +3579,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->persist = O.persist >= 0 && !ud->use_graph && !O.framecheck ? (O.persist > 1 ? 3 : O.persist > 0 ? 2 : 1) : 0;     /* (2: whatever the lane count; 3: and with the general barrier only) */
     ud->kf_cluster_opt = O.cluster; ud->kf_last_c = 0; ud->kf_slots = 0; ud->d_kfbar = NULL; ud->kf_counted = 0; ud->d_kfnext = NULL; ud->d_kfargs = ud->h_kfargs = NULL; ud->kf_arg_at = 0;
     ud->sb_scores = NULL; ud->sb_bests = NULL; ud->sb_rows_cap = 0; ud->sb_gdesc_d = ud->sb_gdesc_h = NULL; ud->sb_g_cap = 0;
+    ud->sb_rows_max = O.score_rows_max > 0 ? (size_t)O.score_rows_max : 0; ud->kf_order_d = ud->kf_order_h = NULL; ud->kf_order_cap = 0; ud->kf_shared = 0;
     ud->sb_row0_d = ud->sb_row0_h = NULL; ud->sb_row0_cap = 0;
     ud->kf_ev_n = ud->kf_n_score = ud->kf_n_frames = 0; ud->kf_score_ms = ud->kf_frames_ms = 0.0;
     if (ud->persist) {
@@ -3535,7 +3588,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         if (hipHostMalloc(&ud->h_kfargs, sizeof(KfArgs) * KF_ARG_SLOTS) != hipSuccess) { s3a_set_error("s3a_uttdec_init: pinned allocation failed"); goto fail; }
         DM(ud->d_kfbar, (size_t)n_lanes * 8);
         if (hipMemset(ud->d_kfbar, 0, (size_t)n_lanes * 8) != hipSuccess) goto fail;
-        if (ud->device >= 0 && ud->device < 64) { g_kf_live[ud->device]++; ud->kf_counted = 1; }
+        if (ud->device >= 0 && ud->device < 64) { g_kf_live[ud->device]++; ud->kf_counted = 1; ud->kf_shared = kf_device_lock(ud->device) ? 0 : 1; }
     }
     ud->scan_small_from = O.scan_small_from > 0 ? O.scan_small_from : 64;
     ud->hyp_wcap = max_frames + 4;
@@ -3977,9 +4030,10 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
     const int32_t per_xcd = max(1, ud->kf_slots / 8), lanes_per_xcd = (n + 7) / 8;
     int32_t C = 1;
     if (ud->kf_cluster_opt > 0) C = ud->kf_cluster_opt;
-    else if (ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1) C = min(per_xcd / lanes_per_xcd, KF_CLUSTER_MAX(n));
-    /* (a margin per XCD: the occupancy query can be one workgroup per CU high, MI355X_MICROARCH "Residency") */
-    C = max(1, min(C, (per_xcd - (per_xcd > 8 ? 4 : 0)) / lanes_per_xcd));
+    else if (ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1 && !ud->kf_shared) C = min(per_xcd / lanes_per_xcd, KF_CLUSTER_MAX(n));
+    /* (a margin per XCD: the occupancy query can be one workgroup per CU high, MI355X_MICROARCH "Residency"; KF_MAXC: what the
+     * kernel's LDS arrays -- the waves' segments, the cluster's scan -- are sized for) */
+    C = max(1, min(min(C, KF_MAXC), (per_xcd - (per_xcd > 8 ? 4 : 0)) / lanes_per_xcd));
     ud->kf_last_c = C;
     const int32_t grid = C == 1 ? n : 8 * C * lanes_per_xcd;
     if (C > 1) HIPCHK(hipMemsetAsync(ud->d_kfbar, 0, (size_t)n * 8, ud->stream));
@@ -4011,6 +4065,7 @@ enqueue_block(s3a_uttdec_t *ud, int32_t n, int32_t fg0, int32_t nf)
     KfJob J;
     memset(&J, 0, sizeof J);
     J.mode = KF_WINDOW; J.fg0 = fg0; J.n_fr = nf;
+    ud->kf_n_score++; ud->kf_n_frames++;            /* (s3a_uttdec_last_parts: a block is a scoring pass + a launch) */
     return kf_launch(ud, n, J);
 }
 
@@ -4046,8 +4101,8 @@ sb_budget_rows(const s3a_uttdec_t *ud)
 {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
-    const size_t per_row = (size_t)ud->S.n_sen * 5;
-    return (fr / 2 + ud->sb_rows_cap * per_row) / per_row;
+    const size_t per_row = (size_t)ud->S.n_sen * 5, rows = (fr / 2 + ud->sb_rows_cap * per_row) / per_row;
+    return ud->sb_rows_max > 0 ? min(rows, ud->sb_rows_max) : rows;
 }
 
 static int32_t
@@ -4158,6 +4213,15 @@ kf_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev, c
     for (size_t k = 0; k + 1 < cut.size(); k++) g_at[k + 1] = g_at[k] + sb_describe(ud, feat_dev, n_frames, cut[k], cut[k + 1], g_at[k]);
     HIPCHK(hipMemcpyAsync(ud->sb_gdesc_d, ud->sb_gdesc_h, g_at.back() * sizeof(UwGroup), hipMemcpyHostToDevice, ud->stream));
     HIPCHK(hipMemcpyAsync(ud->sb_row0_d, ud->sb_row0_h, (size_t)n_utt * 8, hipMemcpyHostToDevice, ud->stream));
+    /* the order of the takes: within a part the longest utterance first (stable: equal lengths in queue order) -- the launch ends with its
+     * slowest lane, and an utterance taken when the counter is nearly through should be a short one */
+    if ((rc = q_grow(&ud->kf_order_d, &ud->kf_order_h, &ud->kf_order_cap, (size_t)n_utt, "queue order")) != S3A_OK) return rc;
+    for (size_t k = 0; k + 1 < cut.size(); k++) {
+        for (int32_t u = cut[k]; u < cut[k + 1]; u++) ud->kf_order_h[u] = u;
+        if (!s3a_variants()->kf_queue_in_order)
+            std::stable_sort(ud->kf_order_h + cut[k], ud->kf_order_h + cut[k + 1], [&](int32_t a, int32_t b) { return n_frames[a] > n_frames[b]; });
+    }
+    HIPCHK(hipMemcpyAsync(ud->kf_order_d, ud->kf_order_h, (size_t)n_utt * 4, hipMemcpyHostToDevice, ud->stream));
     ud->kf_n_score = ud->kf_n_frames = 0;
     for (size_t k = 0; k + 1 < cut.size(); k++) {
         const int32_t u0 = cut[k], nu = cut[k + 1] - cut[k];
@@ -4167,7 +4231,7 @@ kf_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev, c
         HIPCHK(hipMemsetAsync(ud->d_kfnext, 0, 4, ud->stream));
         KfJob J;
         memset(&J, 0, sizeof J);
-        J.mode = KF_QUEUE; J.n_utt = nu; J.u0 = u0; J.next = ud->d_kfnext; J.lane_u = ud->d_kfnext + 16; J.stage = ud->q_ctx_d;
+        J.mode = KF_QUEUE; J.n_utt = nu; J.u0 = u0; J.order = ud->kf_order_d; J.next = ud->d_kfnext; J.lane_u = ud->d_kfnext + 16; J.stage = ud->q_ctx_d;
         J.row0 = ud->sb_row0_d; J.scores = ud->sb_scores; J.bests = ud->sb_bests;
         J.hdr = ud->q_hdr_d; J.words = ud->q_words_d; J.wcount = wcount; J.P = P; J.B = B; J.n_word = ud->cfg.n_word;
         if ((rc = kf_launch(ud, min(ud->n_lanes, nu), J)) != S3A_OK) return rc;
@@ -4262,6 +4326,7 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
     HIPCHK(hipSetDevice(ud->device));
     int32_t rc, maxT = 0;
     ud->q_n = 0;
+    ud->kf_n_score = ud->kf_n_frames = ud->kf_last_c = 0;         /* (s3a_uttdec_last_parts: all zero unless THIS call goes through ku_frames) */
     double tm[6] = { 0, 0, 0, 0, 0, 0 };
     auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
     tm[0] = now();
@@ -4463,6 +4528,7 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
         return S3A_EINVAL;
     }
     HIPCHK(hipSetDevice(ud->device));
+    ud->kf_n_score = ud->kf_n_frames = ud->kf_last_c = 0;
     const UShared &S = ud->S;
     const bool graph_mode = ud->use_graph && ud->prof_every == 0;
     /* ku_frames (KF_QUEUE): the lanes take the utterances themselves -- no schedule, no refill events, no window boundaries */

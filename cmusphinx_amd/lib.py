@@ -1352,7 +1352,8 @@ def dag_cfg(b, keep, bestpathlw=None, min_endfr=None, maxedge=None, maxlmop=None
 
 class Variants(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("scan_chained", "calls_by_copy", "batch_no_shared", "batch_no_multi",
-                                         "no_frame_sync_kernel", "score_nt", "score_fpc", "resolve_sweep", "hist_sort_launch", "ps_overlap", "ps_score_by_gaussian")]
+                                         "no_frame_sync_kernel", "score_nt", "score_fpc", "resolve_sweep", "hist_sort_launch", "ps_overlap", "ps_score_by_gaussian",
+                                         "kf_queue_in_order")]
 
 
 def set_variants(**kw):
@@ -1442,7 +1443,8 @@ class UttResult(C.Structure):
 class UttDecOpts(C.Structure):
     """s3a_uttdec_opts_t: the engine's tuning options (every variant gives the same bits)"""
     _fields_ = [(k, C.c_int32) for k in ("many", "big_wl", "window", "window_fpc", "g_eval", "g_res", "scan_g", "gy", "sweep_k",
-                                         "no_multi", "framecheck", "times", "graph", "window_max", "scan_small_from", "persist", "cluster")] + [("reserved", C.c_int32 * 2)]
+                                         "no_multi", "framecheck", "times", "graph", "window_max", "scan_small_from", "persist", "cluster",
+                                         "score_rows_max")] + [("reserved", C.c_int32 * 1)]
 
 
 class UttDec:

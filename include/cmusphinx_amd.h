@@ -745,8 +745,14 @@ typedef struct {
     int32_t cluster;        /* workgroups per lane of that launch: 0 = the library's choice (1 when the lanes fill the chip, more
                              * -- on one XCD, with a counter barrier between the steps -- when they do not; only an engine that is
                              * alone on its device chooses more than 1: the clusters of one launch must be resident together);
-                             * > 0 = exactly that many where they fit (the caller then answers for co-residency) */
-    int32_t reserved[2];
+                             * > 0 = that many where they fit, at most 32 (the caller then answers for co-residency).  "Alone" counts
+                             * other processes too: the first process with such an engine on a device holds an advisory lock
+                             * (/dev/shm/cmusphinx_amd.kf.<PCI bus id>.lock) and the others keep one workgroup per lane */
+    int32_t score_rows_max; /* > 0: a cap on the rows (frames) of senone scores ku_frames' calls keep on the device at once (default:
+                             * half of the free device memory).  A queue whose frames exceed it goes through in parts (consecutive
+                             * utterances whose rows fit; an utterance longer than the cap is an error); s3a_uttdec_decode falls back
+                             * to window blocks (K frames per launch from the look-ahead rows).  Same bits either way. */
+    int32_t reserved[1];
 } s3a_uttdec_opts_t;
 void s3a_uttdec_opts_default(s3a_uttdec_opts_t *o);
 void s3a_uttdec_opts_from_env(s3a_uttdec_opts_t *o);
@@ -899,12 +905,15 @@ int32_t s3a_wltest_fetch(s3a_wltest_t *wt, int32_t *n_entry, int32_t *n_frm, int
  * without GPUs: tests/test_gather_mock.py.  No product path sets it.) */
 typedef struct s3a_gather_s s3a_gather_t;
 s3a_gather_t *s3a_gather_init(int32_t rank, int32_t world, const char *rendezvous);
-/* The same with a RUN ID (any non-zero number the launcher gives every rank of one run and not to the next: MASTER_PORT, a job id):
+/* The same with a RUN ID (any non-zero number the launcher gives every rank of ONE run and not to the next: a job id, a number drawn
+ * per launch -- NOT a value that repeats from run to run such as a fixed MASTER_PORT):
  * the file is `rendezvous`.<run id>, its first word is the id, rank 0 removes what an earlier run of the same name left, and no
  * clock is compared -- ranks may start at any time after one another (staggered or containerised launches, a restarted worker,
  * a shared file system whose server keeps another time).  s3a_gather_init without an id recognises a stale file by its age: it
  * takes a file written no longer than 120 s before the calling process started, so the ranks of a run must start within that
- * window of one another and see one clock; prefer s3a_gather_init_run. */
+ * window of one another and see one clock; prefer s3a_gather_init_run.
+ * Either way the file lives only until every rank holds the id: the init ends with one small all-gather (nobody leaves it before
+ * everybody has read the file) behind which rank 0 removes the file, so a successful run leaves nothing for the next one to find. */
 s3a_gather_t *s3a_gather_init_run(int32_t rank, int32_t world, const char *rendezvous, unsigned long long run_id);
 void s3a_gather_free(s3a_gather_t *g);
 int32_t s3a_gather_hyps(s3a_gather_t *g, int32_t n_local, const s3a_hyp_header_t *hdr, const s3a_hyp_word_t *words,
@@ -1168,6 +1177,7 @@ typedef struct {
     int32_t hist_sort_launch;       /* whole-utterance engine: the histogram sort as a launch of its own in every frame (default: on the count's launch, when a frame needs it) */
     int32_t ps_overlap;             /* s3a_psfwd_decode_queue: score the queue's later utterances BESIDE the search (second stream) instead of before it */
     int32_t ps_score_by_gaussian;   /* pocketsphinx batch scoring: the lane-per-Gaussian kernel (k_ps_cont_slots) instead of lane-per-frame */
+    int32_t kf_queue_in_order;      /* ku_frames' queue: the lanes take the utterances in queue order (default: each part's longest first) */
 } s3a_variants_t;
 void    s3a_variants_default(s3a_variants_t *v);
 void    s3a_get_variants(s3a_variants_t *v);            /* the variants in force (read-modify-write with s3a_set_variants) */

@@ -930,8 +930,8 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
         char rdv[4400];
         s3a_gather_t *gt;
         snprintf(rdv, sizeof rdv, "%s.rccl-id", g_final[0][0] ? g_final[0] : g_final[1]);
-        if (g_rank == 0) remove(rdv);
-        /* (a launcher that hands its ranks a run id -- MASTER_PORT, S3A_RUN_ID -- gets the rendezvous that compares no clocks) */
+        /* (a launcher that hands its ranks a run id of its own -- S3A_RUN_ID, a number per launch; MASTER_PORT only for want of one --
+         * gets the rendezvous that compares no clocks; the library removes the file, whatever its name, once every rank holds the id) */
         {
             const char *rid = getenv("S3A_RUN_ID") ? getenv("S3A_RUN_ID") : getenv("MASTER_PORT");
             const unsigned long long run_id = rid ? strtoull(rid, NULL, 10) : 0ull;
@@ -964,7 +964,6 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
             if (fh) fclose(fh);
             if (fs) fclose(fs);
             E_INFO("tst shim: rank 0 gathered %d utterances from %d ranks over RCCL and wrote the output files\n", g_rank_total, g_world);
-            remove(rdv);
         }
         s3a_gather_free(gt);
     }

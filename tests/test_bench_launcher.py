@@ -24,7 +24,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "fail" and rank == 1:
 if len(sys.argv) > 3 and sys.argv[3] == "gather":
     import numpy as np
     from cmusphinx_amd import lib
-    g = lib.Gather(rank, world, os.path.join(out, "rccl-id"), run_id=int(os.environ["MASTER_PORT"]))
+    g = lib.Gather(rank, world, os.path.join(out, "rccl-id"), run_id=int(os.environ["S3A_RUN_ID"]))
     recs = []
     for u in range(rank, 10, world):
         h = lib.HypHeader()

@@ -107,3 +107,15 @@ def test_run_id_rendezvous_compares_no_clocks(mock_dir, tmp_path):
     got = run_world(mock_dir, tmp_path, 2, 11, run_id=777, late=2.5)
     assert got[0]["err"] is None and got[0]["res"] == expected(11, 0)
     assert got[1]["err"] is None and got[1]["res"] == expected(11, 1)
+
+
+def test_the_rendezvous_file_does_not_outlive_the_init(mock_dir, tmp_path):
+    """rank 0 removes the file once every rank holds the id (the init's own all-gather is the proof), so the SAME command run again
+    under the SAME run id -- a launcher that reuses its port as the id -- cannot meet the first run's dead communicator id"""
+    for attempt in range(2):
+        got = run_world(mock_dir, tmp_path, 2, 7, run_id=29500)
+        assert got[0]["err"] is None and got[0]["res"] == expected(7, 0), attempt
+        assert got[1]["err"] is None and got[1]["res"] == expected(7, 1), attempt
+        assert not (tmp_path / ("rccl-id.%016x" % 29500)).exists()
+    got = run_world(mock_dir, tmp_path, 2, 5)              # (the id-less form too)
+    assert got[0]["err"] is None and not (tmp_path / "rccl-id").exists()

@@ -93,19 +93,50 @@ def test_second_pass_keeps_window_blocks(gpu_lib, tidigits_bundle, persist):
     TQ.test_second_pass_inside_the_queue_through_the_c_abi(gpu_lib, tidigits_bundle)
 
 
-def test_the_score_buffer_in_parts(gpu_lib, tidigits_bundle, persist):
-    """more utterances than lanes AND a score buffer that must be reused: the queue goes through in parts when its frames outgrow
-    the device's free memory -- forced here by asking twice, the second time with buffers that already exist"""
-    dec = bundle.Decoder(tidigits_bundle, 4)
+def test_the_score_buffer_in_parts(gpu_lib, tidigits_bundle, persist, monkeypatch):
+    """s3a_uttdec_opts_t.score_rows_max (S3A_UTT_SCORE_ROWS in this harness) caps the rows of senone scores a call keeps on the device:
+    the queue then goes through in PARTS -- consecutive utterances whose rows fit, one ku_frames launch per part, the buffer reused,
+    every part's utterances taken longest first -- which an uncapped 288 GB device never does by itself.  At least three parts here;
+    then the same engine uncapped-sized calls again (buffers that already exist), and the cap too small for one utterance is refused"""
     utts, feats = TQ.tidigits_feats(gpu_lib)
     rm, rs = TQ.ref_lines()
+    longest, total = max(len(f) for f in feats), sum(len(f) for f in feats)
+    cap = max(longest, total // 5)
+    monkeypatch.setenv("S3A_UTT_SCORE_ROWS", str(cap))
+    dec = bundle.Decoder(tidigits_bundle, 4)
     for _ in range(2):
-        dec.decode_queue(feats[:9])
-        m, s = TQ.queue_lines(dec, utts[:9])
-        assert m == rm[:9] and s == rs[:9]
-    dec.decode_queue(feats)                     # grows the buffers
-    m, s = TQ.queue_lines(dec, utts)
-    assert m == rm and s == rs
+        dec.decode_queue(feats)
+        m, s = TQ.queue_lines(dec, utts)
+        assert m == rm and s == rs
+        parts = dec.ud.last_parts()
+        assert parts["n_frames"] >= 3 and parts["n_score"] >= parts["n_frames"], parts          # (one ku_frames launch per part)
+    dec.decode_queue(feats[:9])
+    m, s = TQ.queue_lines(dec, utts[:9])
+    assert m == rm[:9] and s == rs[:9]
+    monkeypatch.setenv("S3A_UTT_SCORE_ROWS", str(longest - 1))
+    small = bundle.Decoder(tidigits_bundle, 4)
+    with pytest.raises(Exception, match="do not fit"):
+        small.decode_queue(feats)
+
+
+def test_static_decode_falls_back_to_window_blocks(gpu_lib, tidigits_bundle, persist, monkeypatch):
+    """s3a_uttdec_decode with more frames than the score buffer may hold: kf_decode_static answers S3A_EUNSUP and the lanes' frames go
+    through ku_frames in K-frame window blocks (KF_WINDOW) -- the same tables, word for word, as the uncapped call"""
+    utts, feats = TQ.tidigits_feats(gpu_lib)
+    res = {}
+    for cap in ("0", "64"):
+        monkeypatch.setenv("S3A_UTT_SCORE_ROWS", cap)
+        dec = bundle.Decoder(tidigits_bundle, 6)
+        dec.decode(feats[:6])
+        res[cap] = [dec.ud.result(z) for z in range(6)]
+        parts = dec.ud.last_parts()
+        assert (parts["n_frames"] == 1 if cap == "0" else parts["n_frames"] > 4) and parts["cluster"] >= 1, parts    # (a launch per K-frame block)
+        for z, (u, uid) in enumerate(utts[:6]):
+            rec = dec.hyp(z, uid, z)
+            assert rec.status == 0 and dec.format(rec)[0] == TQ.ref_lines()[0][z]
+    for a, b in zip(res["0"], res["64"]):
+        for k in ("score", "pred", "lw0", "lw1", "wid", "sf", "ef", "ascr", "lscr", "type", "frame_start", "bestscore", "bestvh", "frame_stat"):
+            assert np.array_equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("name,lanes,cluster", [("mode4_trigram", "4", "1"), ("mode4_cibeam_ds2", "4", "2"), ("mode4_cibeam_ds2", "40", "1")])
@@ -134,7 +165,9 @@ def test_histogram_pruning_and_weak_hmms_inside_the_kernel(what, extra, tmp_path
         assert open(hyp).read() == ref_hyp and open(seg).read() == ref_seg
 
 
-@pytest.mark.parametrize("env", [{"S3A_UTT": "4"}, {"S3A_UTT": "3", "S3A_UTT_CLUSTER": "2"}, {"S3A_UTT": "6", "S3A_UTT_QUEUE": "12"}])
+@pytest.mark.parametrize("env", [{"S3A_UTT": "4"}, {"S3A_UTT": "3", "S3A_UTT_CLUSTER": "2"}, {"S3A_UTT": "6", "S3A_UTT_QUEUE": "12"},
+                                 {"S3A_UTT": "2", "S3A_UTT_QUEUE": "6", "S3A_UTT_SCORE_ROWS": "420"},          # the queue in >= 3 parts
+                                 {"S3A_UTT": "6", "S3A_UTT_SCORE_ROWS": "100"}])                               # S3A_EUNSUP -> window blocks
 def test_hub4_shaped_decode_through_ku_frames(env, tmp_path):
     """several-parent sets (46 left-context variants per root), composite senones, ~3000 active HMMs per frame"""
     args = TD.synth_task("hub4", tmp_path, 6, 200)
@@ -146,3 +179,15 @@ def test_hub4_shaped_decode_through_ku_frames(env, tmp_path):
 @pytest.mark.parametrize("env", [{"S3A_UTT": "4"}, {"S3A_UTT": "3", "S3A_UTT_CLUSTER": "2", "S3A_UTT_QUEUE": "8"}])
 def test_five_state_hmms_through_ku_frames(env, task):  # noqa: F811
     T5.test_five_state_decode_matches_reference(task, "kf" + env["S3A_UTT"], dict(FORCE, **env))
+
+
+
+def test_clusters_at_scale_on_the_hub4_shaped_task(tmp_path):
+    """16 lanes x 3 workgroups (48 workgroups, two lanes' clusters per XCD) with the XCD-local barrier on the task that has several-parent
+    sets and composite senones: the barrier's riskiest regime outside the bench's 128-lane projection"""
+    args = TD.synth_task("hub4", tmp_path, 16, 120)
+    ref = TD.decode_task(TD.REFDEC, args, tmp_path, "ref")
+    got = TD.decode_task(TD.TST, args, tmp_path, "kf", dict(FORCE, S3A_UTT="16", S3A_UTT_CLUSTER="3"))
+    assert got[0] == ref[0] and got[1] == ref[1] and ref[0].count("\n") == 16
+    got = TD.decode_task(TD.TST, args, tmp_path, "kfq", dict(FORCE, S3A_UTT="8", S3A_UTT_CLUSTER="4", S3A_UTT_QUEUE="16"))
+    assert got[0] == ref[0] and got[1] == ref[1]
