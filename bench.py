@@ -754,8 +754,25 @@ def main():
         assert hyp_ok and (seg_ok or args.fast), "device hypotheses differ from the unmodified reference decoder's"
         if args.plain:
             # the rocprofv3-wrapped command: the timed regime and nothing else (no lock-step decode for statistics, no profiled step)
+            pp = [dd.ud.last_parts() for dd in decs]
+            ph, fr, busy = {}, 0, []
+            if all(p_["n_frames"] > 0 for p_ in pp):
+                for z in range(0, NLE, max(1, NLE // 16)):
+                    t_, f_, _, _ = decs[0].ud.frame_ticks(z)
+                    fr += f_
+                    for k, v in t_.items():
+                        ph[k] = ph.get(k, 0.0) + v
+                # (how long each lane's workgroup was inside the launches of the last call: the launch ends with the last of them)
+                busy = sorted(decs[0].ud.frame_ticks(z)[0]["in_launch"] / 1e3 for z in range(NLE))
             print(json.dumps({"metric": "decoded_frames_per_sec", "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "plain": True,
+                              "config": {"frames_per_step": frames_step, "lanes_per_gpu": NL},
+                              "kernels": {"ku_frames": {"ms_per_step": round(max(p_["frames_ms"] for p_ in pp), 2), "relay_launches": decs[0].ud.last_relay()},
+                                          "ku_score_window": {"ms_per_step": round(max(p_["score_ms"] for p_ in pp), 2)}},
+                              "lanes_busy_ms": ({"min": round(busy[0], 1), "p10": round(busy[len(busy) // 10], 1), "median": round(busy[len(busy) // 2], 1),
+                                                 "mean": round(sum(busy) / len(busy), 1), "p90": round(busy[(9 * len(busy)) // 10], 1), "max": round(busy[-1], 1)} if busy else None),
+                              "search": {"us_per_lane_frame": round(1e3 * max(p_["frames_ms"] for p_ in pp) * NL / max(frames_step, 1), 2),
+                                         "phases_us_per_lane_frame": {k: round(v / max(fr, 1), 2) for k, v in sorted(ph.items())}},
                               "identical_to_reference": {"hyp": bool(hyp_ok), "hypseg": bool(seg_ok)}}))
             return
 

@@ -1587,6 +1587,8 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_BIG 256              /* ... of which several-parent sets whose headers stay in LDS (the others: d_dec_resolve_children) */
 static_assert(KF_NT == 512, "ku_frames: the word level's workgroup is the frame's workgroup");
 enum { KF_WINDOW, KF_STATIC, KF_QUEUE };
+#define KF_ST_WORDS 8
+#define KF_STAGES 2             /* launches a call's relay may have behind its first */
 
 union KfPool {                  /* phases that never overlap share this LDS */
     struct { int32_t off[WL_MAXCALL], root[WL_MAXCALL], in[WL_MAXCALL], hist[WL_MAXCALL]; } e1;
@@ -1608,7 +1610,7 @@ union KfPool {                  /* phases that never overlap share this LDS */
 
 struct KfSh {                   /* the workgroup's LDS outside the word level's own arrays */
     KfPool pool;
-    int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u;
+    int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u, u2;
     ULane Lc;                   /* the lane's structure (its ~60 pointers): a copy in LDS -- a field is a ds_read at a constant address; out of
                                  * memory it was the structure's spilled address back from scratch, then the pointer, then the data: two
                                  * round trips in front of many a step's first access */
@@ -1633,6 +1635,15 @@ struct KfJob {
     int32_t u0;                 /* ... the first one's place in the queue */
     const int32_t *order;       /* ... [queue] which utterance the k-th take of the counter is: a part's utterances longest first (the launch ends with
                                  * its slowest lane: what is taken last should be short) */
+    /* THE RELAY (KF_QUEUE / KF_STATIC): a launch ends with its slowest lane, and while the last lanes finish their utterances most of the
+     * chip idles.  So the call is a CHAIN of launches: when no utterance is left to take and at most `stop_at` lanes are still decoding,
+     * those lanes leave at their next frame boundary -- everything a frame needs of the last one is in device memory --, hand themselves
+     * over (lane, utterance, next frame), and the next launch of the chain continues them as clusters of more workgroups each. */
+    int32_t stop_at;            /* > 0: hand over when that few lanes are left (0: this launch runs to the end) */
+    int32_t resume;             /* this launch's lanes are the ones the previous launch handed over (st_cur's list) */
+    int32_t *st_cur, *st_next;  /* [KF_ST_WORDS + n_lanes] this launch's / the next one's relay words: [0] lanes still at work, [1] the stop flag,
+                                 * [2] lanes handed TO this launch, [KF_ST_WORDS ...] which */
+    int32_t *lane_f, *lane_uq, *lane_stop;  /* [n_lanes] the frame a handed-over lane goes on with | its utterance | the flag as its cluster saw it */
     int32_t *next;              /* ... [1] the counter the lanes take their utterances from */
     int32_t *lane_u;            /* ... [n_lanes] what a lane's first workgroup took (read by the rest of its cluster) */
     const UCtx *stage;          /* ... [queue] the utterances' staged contexts */
@@ -2707,6 +2718,10 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
     if (C == 1) { z = blockIdx.x; r = 0; }
     else { const int32_t b = blockIdx.x, xcd = b & 7, j = b >> 3; z = (j / C) * 8 + xcd; r = j % C; }
     if (z >= n_lanes) return;
+    if (J.resume) {             /* (the relay: slot z of this launch continues the lane the previous launch listed there) */
+        if (z >= __hip_atomic_load(&J.st_cur[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        z = J.st_cur[KF_ST_WORDS + z];
+    }
     const int32_t tid = threadIdx.x;
     static_assert(sizeof(ULane) % 4 == 0, "the lane's structure is copied to LDS word by word");
     for (int32_t i = tid; i < (int32_t)(sizeof(ULane) / 4); i += KF_NT) ((int32_t *)&sh.Lc)[i] = ((const int32_t *)&lanes[z])[i];
@@ -2735,10 +2750,21 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
      * kernel whose instruction cache holds 64 KB) */
     const int32_t mode = J.mode;
     const int32_t gtid = r * KF_NT + tid, gstride = C * KF_NT;
+    bool resumed = J.resume != 0, handed = false;
+    if (resumed && C > 1) {     /* (the lane's mask of a frame: clean between frames -- unless an utterance once stopped inside one) */
+        if (r == 0) for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) L.senbits[i] = 0u;
+        kf_barrier(B);
+    }
     for (;;) {
         int32_t u = 0, f_lo = 0, f_hi = 0;
         size_t r0 = 0;
-        if (mode == KF_QUEUE) {
+        if (resumed) {          /* the utterance the lane was handed over with, from the frame it had reached */
+            u = mode == KF_QUEUE ? J.lane_uq[z] : z;
+            f_lo = J.lane_f[z]; f_hi = ctx->nfr;
+            r0 = (size_t)J.row0[u];
+            resumed = false;
+        }
+        else if (mode == KF_QUEUE) {
             /* the queue's next utterance: taken by the lane's first workgroup */
             if (r == 0 && tid == 0) {
                 const int32_t u_ = atomicAdd(J.next, 1);
@@ -2751,6 +2777,7 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
             u = sh.u;
             if (u >= J.n_utt || sh.dead) break;
             u = J.order[J.u0 + u];              /* (the take's utterance: its index in the queue) */
+            if (r == 0 && tid == 0) J.lane_uq[z] = u;
             /* srch_utt_begin (srch.c:453-479): every per-utterance state reset, the utterance's context */
             d_lane_begin(L, S, J.B, z, J.stage + u, gtid, gstride, r == 0, tid, KF_NT);
             kf_barrier(B);
@@ -2762,10 +2789,31 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
         for (int32_t f = f_lo; f < f_hi; f++) {
             /* (the word level ends an utterance that ran into an error: uniform over the cluster behind the frame's last barrier) */
             if (!((volatile UCtx *)ctx)->active || sh.dead) break;
+            if (J.stop_at > 0) {
+                /* the relay's stop flag, as ONE thread of the lane read it (a cluster's workgroups must leave at the same frame) */
+                if (r == 0 && tid == 0) {
+                    const int32_t st = __hip_atomic_load(&J.st_cur[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh.u2 = st;
+                    if (C > 1) __hip_atomic_store(&J.lane_stop[z], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                kf_barrier(B);
+                if (C > 1 && r > 0 && tid == 0) sh.u2 = __hip_atomic_load(&J.lane_stop[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (C > 1) __syncthreads();
+                if (sh.u2) {
+                    if (r == 0 && tid == 0) {
+                        J.lane_f[z] = f;
+                        J.st_next[KF_ST_WORDS + atomicAdd(&J.st_next[2], 1)] = z;
+                        atomicAdd(&J.st_next[0], 1);
+                    }
+                    handed = true;
+                    break;
+                }
+            }
             int32_t *row = mode == KF_WINDOW ? L.win + (size_t)(f % S.win_K) * S.n_sen : J.scores + (r0 + f) * S.n_sen;
             const uint8_t *brow = mode == KF_WINDOW ? L.winb + (size_t)(f % S.win_K) * S.n_sen : J.bests + (r0 + f) * S.n_sen;
             kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, row, brow, weak_possible);
         }
+        if (handed) break;
         if (mode != KF_QUEUE) break;
         if (r == 0 && tid < 16 && tid != 12 && tid != 14) { ctx->kacc[tid] += sh.kacc[tid]; sh.kacc[tid] = 0; }
         /* srch_utt_end (srch.c:482-560): the hypothesis goes to the utterance's slot, the lane's lists are cleared */
@@ -2774,6 +2822,11 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
         kf_barrier(B);
         d_lane_end(L, S, z, ctx->err != 0, J.n_word, gtid, gstride);
         kf_barrier(B);
+    }
+    /* (the relay: a lane that is through counts itself out; the one that leaves `stop_at` lanes at work raises the flag for them) */
+    if (J.stop_at > 0 && !handed && r == 0 && tid == 0) {
+        const int32_t left = atomicSub(&J.st_cur[0], 1) - 1;
+        if (left <= J.stop_at && left > 0) __hip_atomic_store(&J.st_cur[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (r == 0 && tid == 0) { sh.kacc[12] += (long long)wall_clock64() - t_launch; sh.kacc[14]++; }
     if (r == 0 && tid < 16) ctx->kacc[tid] += sh.kacc[tid];             /* (KF_QUEUE: the lane's last utterance has its frames' share already) */
@@ -3136,6 +3189,8 @@ struct s3a_uttdec_s {
     size_t sb_rows_max;         /* s3a_uttdec_opts_t.score_rows_max: a cap on the buffer's rows (0: half of the free device memory) */
     int32_t *kf_order_d, *kf_order_h; size_t kf_order_cap;      /* KF_QUEUE: the order in which the lanes take the queue's utterances (longest first) */
     int32_t kf_shared;          /* another PROCESS holds this device's cluster lock: this engine's lanes stay one workgroup each */
+    int32_t *d_kfrelay;         /* [(KF_STAGES + 1) (KF_ST_WORDS + n_lanes) + 3 n_lanes] the relay's words per launch of the chain | lane_f | lane_uq | lane_stop */
+    int32_t kf_n_relay;         /* launches the last call's chain had behind its first (diagnostics) */
     UwGroup *sb_gdesc_d, *sb_gdesc_h; size_t sb_g_cap;
     long long *sb_row0_d, *sb_row0_h; size_t sb_row0_cap;
     /* where the last call's device time went: events around the scoring launches and around ku_frames (s3a_uttdec_last_parts) */
@@ -3277,6 +3332,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     for (auto e : ud->kf_evs) (void)hipEventDestroy(e);
     ud->kf_evs.clear();
     if (ud->d_kfbar) (void)hipFree(ud->d_kfbar);
+    if (ud->d_kfrelay) (void)hipFree(ud->d_kfrelay);
     if (ud->d_kfnext) (void)hipFree(ud->d_kfnext);
     if (ud->d_kfargs) (void)hipFree(ud->d_kfargs);
     if (ud->h_kfargs) (void)hipHostFree(ud->h_kfargs);
@@ -3580,6 +3636,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->kf_cluster_opt = O.cluster; ud->kf_last_c = 0; ud->kf_slots = 0; ud->d_kfbar = NULL; ud->kf_counted = 0; ud->d_kfnext = NULL; ud->d_kfargs = ud->h_kfargs = NULL; ud->kf_arg_at = 0;
     ud->sb_scores = NULL; ud->sb_bests = NULL; ud->sb_rows_cap = 0; ud->sb_gdesc_d = ud->sb_gdesc_h = NULL; ud->sb_g_cap = 0;
     ud->sb_rows_max = O.score_rows_max > 0 ? (size_t)O.score_rows_max : 0; ud->kf_order_d = ud->kf_order_h = NULL; ud->kf_order_cap = 0; ud->kf_shared = 0;
+    ud->d_kfrelay = NULL; ud->kf_n_relay = 0;
     ud->sb_row0_d = ud->sb_row0_h = NULL; ud->sb_row0_cap = 0;
     ud->kf_ev_n = ud->kf_n_score = ud->kf_n_frames = 0; ud->kf_score_ms = ud->kf_frames_ms = 0.0;
     if (ud->persist) {
@@ -3588,6 +3645,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
         if (hipHostMalloc(&ud->h_kfargs, sizeof(KfArgs) * KF_ARG_SLOTS) != hipSuccess) { s3a_set_error("s3a_uttdec_init: pinned allocation failed"); goto fail; }
         DM(ud->d_kfbar, (size_t)n_lanes * 8);
         if (hipMemset(ud->d_kfbar, 0, (size_t)n_lanes * 8) != hipSuccess) goto fail;
+        DM(ud->d_kfrelay, ((size_t)(KF_STAGES + 1) * (KF_ST_WORDS + n_lanes) + (size_t)3 * n_lanes) * 4);
         if (ud->device >= 0 && ud->device < 64) { g_kf_live[ud->device]++; ud->kf_counted = 1; ud->kf_shared = kf_device_lock(ud->device) ? 0 : 1; }
     }
     ud->scan_small_from = O.scan_small_from > 0 ? O.scan_small_from : 64;
@@ -4015,28 +4073,56 @@ kf_served(const s3a_uttdec_t *ud, int32_t n)
         && ud->prof_every == 0 && ((S.ne == 3 && S.nodepk) || S.ne == 5) && S.T <= WL_MAXT && S.n_sen <= KF_SENBITS;
 }
 
+/* workgroups of ku_frames the device holds at once: a cluster's workgroups wait for one another */
 template <int NE, bool EXACT>
-static int32_t
-kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
+static void
+kf_slots_t(s3a_uttdec_t *ud)
 {
-    auto kern = ku_frames<NE, EXACT>;
     if (ud->kf_slots == 0) {
-        /* how many of its workgroups the device holds at once: a cluster's workgroups wait for one another */
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, KF_NT, 0) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ku_frames<NE, EXACT>, KF_NT, 0) != hipSuccess || nb < 1) nb = 1;
         ud->kf_slots = nb * ud->g->dev->n_cu;
     }
-    /* workgroups per lane: the lanes' clusters share the XCDs evenly (lane z on XCD z % 8) and must all be resident */
-    const int32_t per_xcd = max(1, ud->kf_slots / 8), lanes_per_xcd = (n + 7) / 8;
+}
+/* ... per XCD, less a margin (the occupancy query can be one workgroup per CU high, MI355X_MICROARCH "Residency") */
+static int32_t
+kf_usable_per_xcd(s3a_uttdec_t *ud)
+{
+    if (ud->kf_slots == 0) {
+        if (ud->S.ne == 5) { if (ud->exact) kf_slots_t<5, true>(ud); else kf_slots_t<5, false>(ud); }
+        else { if (ud->exact) kf_slots_t<3, true>(ud); else kf_slots_t<3, false>(ud); }
+    }
+    const int32_t per_xcd = max(1, ud->kf_slots / 8);
+    return per_xcd - (per_xcd > 8 ? 4 : 0);
+}
+/* is this engine free to size clusters for the whole device?  (alone in its process AND no other process holds the device's lock) */
+static bool
+kf_alone(const s3a_uttdec_t *ud)
+{
+    return ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1 && !ud->kf_shared;
+}
+/* workgroups per lane for n lanes: the lanes' clusters share the XCDs evenly (lane z on XCD z % 8) and must all be resident */
+static int32_t
+kf_choose_c(s3a_uttdec_t *ud, int32_t n)
+{
+    const int32_t usable = kf_usable_per_xcd(ud), per_xcd = max(1, ud->kf_slots / 8), lanes_per_xcd = (n + 7) / 8;
     int32_t C = 1;
     if (ud->kf_cluster_opt > 0) C = ud->kf_cluster_opt;
-    else if (ud->device >= 0 && ud->device < 64 && g_kf_live[ud->device].load() <= 1 && !ud->kf_shared) C = min(per_xcd / lanes_per_xcd, KF_CLUSTER_MAX(n));
-    /* (a margin per XCD: the occupancy query can be one workgroup per CU high, MI355X_MICROARCH "Residency"; KF_MAXC: what the
-     * kernel's LDS arrays -- the waves' segments, the cluster's scan -- are sized for) */
-    C = max(1, min(min(C, KF_MAXC), (per_xcd - (per_xcd > 8 ? 4 : 0)) / lanes_per_xcd));
-    ud->kf_last_c = C;
+    else if (kf_alone(ud)) C = min(per_xcd / lanes_per_xcd, KF_CLUSTER_MAX(n));
+    /* (KF_MAXC: what the kernel's LDS arrays -- the waves' segments, the cluster's scan -- are sized for) */
+    return max(1, min(min(C, KF_MAXC), usable / lanes_per_xcd));
+}
+
+/* n: lane slots of the launch (lanes 0 .. n - 1, or -- J.resume -- that many places of the relay's list); C: workgroups per lane */
+template <int NE, bool EXACT>
+static int32_t
+kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J, int32_t C)
+{
+    auto kern = ku_frames<NE, EXACT>;
+    const int32_t lanes_per_xcd = (n + 7) / 8;
+    if (!J.resume) ud->kf_last_c = C;
     const int32_t grid = C == 1 ? n : 8 * C * lanes_per_xcd;
-    if (C > 1) HIPCHK(hipMemsetAsync(ud->d_kfbar, 0, (size_t)n * 8, ud->stream));
+    if (C > 1) HIPCHK(hipMemsetAsync(ud->d_kfbar, 0, (size_t)ud->n_lanes * 8, ud->stream));
     /* the launch's shared arguments: a slot of a small ring (pinned + device) so that launches may queue up behind one another */
     if (ud->kf_arg_at > 0 && ud->kf_arg_at % KF_ARG_SLOTS == 0) HIPCHK(hipStreamSynchronize(ud->stream));
     KfArgs *ha = (KfArgs *)ud->h_kfargs + ud->kf_arg_at % KF_ARG_SLOTS, *da = (KfArgs *)ud->d_kfargs + ud->kf_arg_at % KF_ARG_SLOTS;
@@ -4050,10 +4136,52 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
 }
 
 static int32_t
+kf_launch_c(s3a_uttdec_t *ud, int32_t n, const KfJob &J, int32_t C)
+{
+    if (ud->S.ne == 5) return ud->exact ? kf_launch_t<5, true>(ud, n, J, C) : kf_launch_t<5, false>(ud, n, J, C);
+    return ud->exact ? kf_launch_t<3, true>(ud, n, J, C) : kf_launch_t<3, false>(ud, n, J, C);
+}
+
+/* one launch, the cluster size the library's (KF_WINDOW blocks; a call without the relay) */
+static int32_t
 kf_launch(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
 {
-    if (ud->S.ne == 5) return ud->exact ? kf_launch_t<5, true>(ud, n, J) : kf_launch_t<5, false>(ud, n, J);
-    return ud->exact ? kf_launch_t<3, true>(ud, n, J) : kf_launch_t<3, false>(ud, n, J);
+    return kf_launch_c(ud, n, J, kf_choose_c(ud, n));
+}
+
+/* THE RELAY: a KF_QUEUE / KF_STATIC call as a chain of launches (KfJob.stop_at).  The first launch is what kf_launch would have made; when
+ * nothing is left to take and no more lanes are at work than fit the chip as clusters of 2 (then 4) workgroups, they hand themselves over
+ * at their next frame boundary and the next launch -- enqueued here, up front, behind the first -- continues them that way.  A launch of
+ * the chain that is handed nothing ends at once.  Only an engine that may size clusters for the whole device plans a chain (kf_alone; not
+ * with s3a_uttdec_opts_t.cluster set: the caller's cluster size holds for the whole call); s3a_variants_t.kf_no_relay: never. */
+static int32_t
+kf_launch_chain(s3a_uttdec_t *ud, int32_t n, KfJob J)
+{
+    const int32_t C0 = kf_choose_c(ud, n), usable = kf_usable_per_xcd(ud), W = KF_ST_WORDS + ud->n_lanes;
+    int32_t st_c[KF_STAGES], st_cap[KF_STAGES], n_st = 0;
+    /* (kf_relay_at, the tests' switch: the chain whatever else runs on the device -- the caller answers for co-residency, as with .cluster) */
+    if (ud->d_kfrelay && ud->kf_cluster_opt == 0 && (kf_alone(ud) || s3a_variants()->kf_relay_at > 0) && !s3a_variants()->kf_no_relay) {
+        int32_t prev_n = n, prev_c = C0;
+        for (int32_t c = 2; c <= 4 && n_st < KF_STAGES; c *= 2) {
+            int32_t cap = 8 * (usable / c);
+            if (s3a_variants()->kf_relay_at > 0) cap = min(cap, max(1, s3a_variants()->kf_relay_at / (c / 2)));
+            if (c <= prev_c || (long long)cap * 5 > (long long)prev_n * 4) continue;      /* (fewer lanes than 0.8 of the launch before) */
+            st_c[n_st] = c; st_cap[n_st] = cap; n_st++;
+            prev_n = cap; prev_c = c;
+        }
+    }
+    if (n_st == 0) return kf_launch_c(ud, n, J, C0);
+    HIPCHK(hipMemsetAsync(ud->d_kfrelay, 0, ((size_t)(KF_STAGES + 1) * W + (size_t)3 * ud->n_lanes) * 4, ud->stream));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ud->d_kfrelay, n, 1, ud->stream));           /* (the first launch's lanes at work) */
+    J.lane_f = ud->d_kfrelay + (size_t)(KF_STAGES + 1) * W; J.lane_uq = J.lane_f + ud->n_lanes; J.lane_stop = J.lane_uq + ud->n_lanes;
+    int32_t rc = S3A_OK;
+    for (int32_t k = 0; k <= n_st && rc == S3A_OK; k++) {
+        J.resume = k > 0; J.stop_at = k < n_st ? st_cap[k] : 0;
+        J.st_cur = ud->d_kfrelay + (size_t)k * W; J.st_next = ud->d_kfrelay + (size_t)(k + 1) * W;
+        rc = kf_launch_c(ud, k == 0 ? n : st_cap[k - 1], J, k == 0 ? C0 : st_c[k - 1]);
+    }
+    ud->kf_n_relay = n_st;
+    return rc;
 }
 
 /* the frames [fg0, fg0 + nf) of lanes 0 .. n - 1 from their window rows: fg0 is a window boundary, nf at most the window */
@@ -4183,7 +4311,7 @@ kf_decode_static(s3a_uttdec_t *ud, int32_t n_utt, const int32_t *n_frames)
     KfJob J;
     memset(&J, 0, sizeof J);
     J.mode = KF_STATIC; J.row0 = ud->sb_row0_d; J.scores = ud->sb_scores; J.bests = ud->sb_bests;
-    rc = kf_launch(ud, n_utt, J);
+    rc = kf_launch_chain(ud, n_utt, J);
     ud->kf_n_frames++;
     kf_mark(ud);
     return rc;
@@ -4234,7 +4362,7 @@ kf_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat_dev, c
         J.mode = KF_QUEUE; J.n_utt = nu; J.u0 = u0; J.order = ud->kf_order_d; J.next = ud->d_kfnext; J.lane_u = ud->d_kfnext + 16; J.stage = ud->q_ctx_d;
         J.row0 = ud->sb_row0_d; J.scores = ud->sb_scores; J.bests = ud->sb_bests;
         J.hdr = ud->q_hdr_d; J.words = ud->q_words_d; J.wcount = wcount; J.P = P; J.B = B; J.n_word = ud->cfg.n_word;
-        if ((rc = kf_launch(ud, min(ud->n_lanes, nu), J)) != S3A_OK) return rc;
+        if ((rc = kf_launch_chain(ud, min(ud->n_lanes, nu), J)) != S3A_OK) return rc;
         ud->kf_n_frames++;
         kf_mark(ud);
     }
@@ -4326,7 +4454,7 @@ uttdec_decode(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const i
     HIPCHK(hipSetDevice(ud->device));
     int32_t rc, maxT = 0;
     ud->q_n = 0;
-    ud->kf_n_score = ud->kf_n_frames = ud->kf_last_c = 0;         /* (s3a_uttdec_last_parts: all zero unless THIS call goes through ku_frames) */
+    ud->kf_n_score = ud->kf_n_frames = ud->kf_last_c = ud->kf_n_relay = 0;         /* (s3a_uttdec_last_parts: all zero unless THIS call goes through ku_frames) */
     double tm[6] = { 0, 0, 0, 0, 0, 0 };
     auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
     tm[0] = now();
@@ -4528,7 +4656,7 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
         return S3A_EINVAL;
     }
     HIPCHK(hipSetDevice(ud->device));
-    ud->kf_n_score = ud->kf_n_frames = ud->kf_last_c = 0;
+    ud->kf_n_score = ud->kf_n_frames = ud->kf_last_c = ud->kf_n_relay = 0;
     const UShared &S = ud->S;
     const bool graph_mode = ud->use_graph && ud->prof_every == 0;
     /* ku_frames (KF_QUEUE): the lanes take the utterances themselves -- no schedule, no refill events, no window boundaries */
@@ -4842,6 +4970,12 @@ s3a_uttdec_frame_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16, int32_t
 
 /* where the last decode's device time went when it ran through ku_frames: milliseconds and launches of the up-front scoring
  * (ku_score_window) and of ku_frames; cluster = workgroups per lane of its last launch.  All zero: the call ran the frame as launches. */
+extern "C" int32_t
+s3a_uttdec_last_relay(const s3a_uttdec_t *ud)
+{
+    return ud ? ud->kf_n_relay : 0;
+}
+
 extern "C" int32_t
 s3a_uttdec_last_parts(s3a_uttdec_t *ud, double *score_ms, int32_t *n_score, double *frames_ms, int32_t *n_frames, int32_t *cluster)
 {

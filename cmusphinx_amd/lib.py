@@ -206,6 +206,7 @@ _SIGS = {
     "s3a_uttdec_frame_ticks": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "s3a_uttdec_frame_dbg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_last_parts": (C.c_int32, [C.c_void_p] + [C.c_void_p] * 5),
+    "s3a_uttdec_last_relay": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_window": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_enable_pheur": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
@@ -1353,7 +1354,7 @@ def dag_cfg(b, keep, bestpathlw=None, min_endfr=None, maxedge=None, maxlmop=None
 class Variants(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("scan_chained", "calls_by_copy", "batch_no_shared", "batch_no_multi",
                                          "no_frame_sync_kernel", "score_nt", "score_fpc", "resolve_sweep", "hist_sort_launch", "ps_overlap", "ps_score_by_gaussian",
-                                         "kf_queue_in_order")]
+                                         "kf_queue_in_order", "kf_no_relay", "kf_relay_at")]
 
 
 def set_variants(**kw):
@@ -1560,6 +1561,10 @@ class UttDec:
         ns, nf, c = C.c_int32(), C.c_int32(), C.c_int32()
         check(self.L.s3a_uttdec_last_parts(self.h, C.byref(sm), C.byref(ns), C.byref(fm), C.byref(nf), C.byref(c)), self.L)
         return dict(score_ms=sm.value, n_score=ns.value, frames_ms=fm.value, n_frames=nf.value, cluster=c.value)
+
+    def last_relay(self):
+        """launches the last call's relay had behind its first (s3a_uttdec_last_relay)"""
+        return int(self.L.s3a_uttdec_last_relay(self.h))
 
     def frame_dbg(self, lane=0):
         t = (C.c_longlong * 4)()

@@ -805,6 +805,10 @@ int32_t s3a_uttdec_wl_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16);
  * the call ran the frame as separate launches (fewer lanes than pay for ku_frames, an option it does not serve, persist = -1). */
 int32_t s3a_uttdec_last_parts(s3a_uttdec_t *ud, double *score_ms, int32_t *n_score, double *frames_ms, int32_t *n_frames, int32_t *cluster);
 int32_t s3a_uttdec_frame_ticks(s3a_uttdec_t *ud, int32_t lane, long long *out16, int32_t *cluster);
+/* diagnostics: launches the last call's RELAY had behind its first (0: one launch to the end).  A ku_frames call ends with its slowest
+ * lane; when no utterance is left to take and few lanes are still at work, they hand over at a frame boundary to a launch that continues
+ * them as clusters of 2, then 4 workgroups (s3a_variants_t.kf_no_relay switches that off; only an engine alone on its device does it) */
+int32_t s3a_uttdec_last_relay(const s3a_uttdec_t *ud);
 /* diagnostics: where and when the lane's workgroup ran the launch that began at engine frame 512: clock at entry and exit (100 MHz),
  * the hardware's HW_ID and XCC_ID registers (tools/kf_phases.py --placement) */
 int32_t s3a_uttdec_frame_dbg(s3a_uttdec_t *ud, int32_t lane, long long *out4);
@@ -1178,6 +1182,10 @@ typedef struct {
     int32_t ps_overlap;             /* s3a_psfwd_decode_queue: score the queue's later utterances BESIDE the search (second stream) instead of before it */
     int32_t ps_score_by_gaussian;   /* pocketsphinx batch scoring: the lane-per-Gaussian kernel (k_ps_cont_slots) instead of lane-per-frame */
     int32_t kf_queue_in_order;      /* ku_frames' queue: the lanes take the utterances in queue order (default: each part's longest first) */
+    int32_t kf_no_relay;            /* ku_frames: a call is ONE launch to its end (default: the relay -- when no utterance is left to take and few lanes are
+                                     * still at work, they hand over at a frame boundary to a launch that runs them as clusters of 2, then 4 workgroups) */
+    int32_t kf_relay_at;            /* > 0: the relay's first hand-over when that many lanes are left, the second at half of it (default: as many as
+                                     * fill the chip as clusters of 2 / of 4; tests use it to run the chain with a handful of lanes) */
 } s3a_variants_t;
 void    s3a_variants_default(s3a_variants_t *v);
 void    s3a_get_variants(s3a_variants_t *v);            /* the variants in force (read-modify-write with s3a_set_variants) */

@@ -739,6 +739,13 @@ lm_context_init(kb_t *kbp, int with_engines)
             g_gms[e] = gm;
             s3a_uttdec_opts_t uo;
             s3a_uttdec_opts_from_env(&uo);          /* (this program's tuning switches are environment variables; the library takes arguments) */
+            if (getenv("S3A_KF_RELAY_AT") || getenv("S3A_KF_NO_RELAY")) {      /* (the relay of ku_frames' launches: tests run its chain with few lanes) */
+                s3a_variants_t va;
+                s3a_get_variants(&va);
+                va.kf_relay_at = getenv("S3A_KF_RELAY_AT") ? atoi(getenv("S3A_KF_RELAY_AT")) : 0;
+                va.kf_no_relay = getenv("S3A_KF_NO_RELAY") != NULL;
+                if (s3a_set_variants(&va) != S3A_OK) die("s3a_set_variants");
+            }
             g_uds[e] = s3a_uttdec_init_opts(g_ls, gm, mdef->cd2cisen, mdef_n_sen(mdef), mdef->n_ci_sen, cmd_ln_int32_r(config, "-ds"),
                            cmd_ln_int32_r(config, "-cond_ds"), cmd_ln_float64_r(config, "-ci_pbeam"),
                            cmd_ln_float32_r(config, "-tighten_factor"), cmd_ln_int32_r(config, "-maxcdsenpf"), g_cs,

@@ -191,3 +191,39 @@ def test_clusters_at_scale_on_the_hub4_shaped_task(tmp_path):
     assert got[0] == ref[0] and got[1] == ref[1] and ref[0].count("\n") == 16
     got = TD.decode_task(TD.TST, args, tmp_path, "kfq", dict(FORCE, S3A_UTT="8", S3A_UTT_CLUSTER="4", S3A_UTT_QUEUE="16"))
     assert got[0] == ref[0] and got[1] == ref[1]
+
+
+def test_the_relay_hands_lanes_over_to_clusters(gpu_lib, tidigits_bundle):
+    """a call ends with its slowest lane: when no utterance is left to take and few lanes are still at work they leave at a frame
+    boundary and the chain's next launch continues them as clusters of 2, then 4 workgroups (s3a_variants_t.kf_relay_at brings the
+    hand-overs down to 8 and 4 lanes): queue and plain decode, hypotheses and whole tables as without the relay"""
+    from cmusphinx_amd import lib
+    utts, feats = TQ.tidigits_feats(gpu_lib)
+    rm, rs = TQ.ref_lines()
+    res = {}
+    try:
+        for relay_at, no_relay in ((8, 0), (0, 1)):
+            lib.set_variants(kf_relay_at=relay_at, kf_no_relay=no_relay)
+            dec = bundle.Decoder(tidigits_bundle, 16)
+            dec.decode_queue(feats)
+            m, s = TQ.queue_lines(dec, utts)
+            assert m == rm and s == rs
+            assert dec.ud.last_relay() == (2 if relay_at else 0) and dec.ud.last_parts()["n_frames"] == 1
+            dec.decode(feats[:16])
+            assert dec.ud.last_relay() == (2 if relay_at else 0)
+            res[relay_at] = [dec.ud.result(z) for z in range(16)]
+            del dec
+    finally:
+        lib.set_variants()
+    for a, b in zip(res[8], res[0]):
+        for k in ("score", "pred", "lw0", "lw1", "wid", "sf", "ef", "ascr", "lscr", "type", "frame_start", "bestscore", "bestvh", "frame_stat"):
+            assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("env", [{"S3A_UTT": "12"}, {"S3A_UTT": "10", "S3A_UTT_QUEUE": "16"}])
+def test_the_relay_on_the_hub4_shaped_task(env, tmp_path):
+    """several-parent sets, composite senones, ~3000 active HMMs per frame across the hand-overs (12 lanes -> 6 x 2 workgroups -> 3 x 4)"""
+    args = TD.synth_task("hub4", tmp_path, 16, 150)
+    ref = TD.decode_task(TD.REFDEC, args, tmp_path, "ref")
+    got = TD.decode_task(TD.TST, args, tmp_path, "relay", dict(env, S3A_KF_RELAY_AT="6"))
+    assert got[0] == ref[0] and got[1] == ref[1] and ref[0].count("\n") == 16
