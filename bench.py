@@ -299,7 +299,8 @@ def wide_beam_leg(lib, d, lanes, n_frames, fast, n_check=64):
         cpu_wall = max(cpu_wall, sm["frames"] * sm["tot_xclk"] / 100.0)
     if n_cmp:
         cpu_fps = cpu_frames / max(cpu_wall, 1e-9)
-    resrc = json.load(open(os.path.join(ROOT, "profiles", "r4_kernel_resources.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "r4_kernel_resources.json")) else {}
+    resrc = json.load(open(os.path.join(ROOT, "profiles", "r4_kernel_resources.json"))) if os.path.exists(os.path.join(ROOT, "profiles",
+            "r4_kernel_resources.json")) else {}
     hmm = np.concatenate([s_[:, 1] for s_ in stat])
     out = {"workload": f"configs[4]: WSJ-shaped 8000 senones x 32 Gaussians x 39, 20 k-word dictionary, ARPA trigram, -beam 1e-120 -pbeam 1e-100 "
                        f"-wbeam 1e-80 -maxhmmpf 100000; {len(utts)} utterances in one {lanes}-lane engine, whole utterances on the device",
@@ -307,7 +308,8 @@ def wide_beam_leg(lib, d, lanes, n_frames, fast, n_check=64):
            "xRT": round(frames / (ms * 1e-3) / 100.0, 1),
            "per_frame": {"active_hmm_mean": round(float(hmm.mean()), 1), "active_hmm_max": int(hmm.max()),
                          "word_exits_mean": round(float(np.mean([s_[:, 7].mean() for s_ in stat])), 1),
-                         "max_candidates_per_frame": int(max(r_["max_cand"] for r_ in res0)), "max_new_history_entries_per_frame": int(max(r_["max_new"] for r_ in res0)),
+                         "max_candidates_per_frame": int(max(r_["max_cand"] for r_ in res0)),
+                                 "max_new_history_entries_per_frame": int(max(r_["max_new"] for r_ in res0)),
                          "frames_with_histogram_pruning": int(sum(int(s_[:, 6].sum()) for s_ in stat))},
            "kernels_us_per_frame": {k: round(v, 2) for k, v in sorted(pf.items(), key=lambda kv: -kv[1])}, "us_per_frame_all_lanes": round(tot, 1),
            "occupancy": {k: resrc.get(k) for k in ("ku_emit_word", "ku_hist_sort<256>", "ku_hist_sort<1024>") if k in resrc},
@@ -383,9 +385,11 @@ def ps_fwdtree_leg(t, lanes, n_cpu=128, n_proc=16):
            "xRT": round(int(dev.group(2)) / (float(dev.group(3)) * 1e-3) / 100.0, 1),
            "identical_to_pocketsphinx": {"hyp_and_score": same_h, "segmentation": same_s, "utterances_checked": n_cpu},
            "search_space": {"roots": int(tree.group(1)), "interior_channels": int(tree.group(2)), "single_phone_words": int(tree.group(3))} if tree else None,
-           "cpu_pocketsphinx": {"frames": int(cpu.group(1)), "seconds": float(cpu.group(2)), "frames_per_sec": round(int(cpu.group(1)) / max(float(cpu.group(2)), 1e-9), 1),
+           "cpu_pocketsphinx": {"frames": int(cpu.group(1)), "seconds": float(cpu.group(2)),
+                   "frames_per_sec": round(int(cpu.group(1)) / max(float(cpu.group(2)), 1e-9), 1),
                                 "cores": 1, "kind": "reference", "processes_side_by_side": len(cuts),
-                                "aggregate_frames_per_sec": round(sum(int(c_.group(1)) for c_ in cpus if c_) / max(max(float(c_.group(2)) for c_ in cpus if c_), 1e-9), 1)} if cpu else None,
+                                "aggregate_frames_per_sec": round(sum(int(c_.group(1)) for c_ in cpus if c_)
+                                                                   / max(max(float(c_.group(2)) for c_ in cpus if c_), 1e-9), 1)} if cpu else None,
            "timed": "HIP events on the engine's stream around the batch's scoring launch + the search launch (features resident in HBM)"}
     sc = re.search(r"of which scoring ([0-9.]+) ms", alog)
     if sc and float(sc.group(1)) > 0:
@@ -476,7 +480,8 @@ def main():
                                                            "ku_frames keeps every lane on its own workgroup, so one engine fills the chip; the "
                                                            "launch path of rounds 2-4 wanted 4)")
     ap.add_argument("--min-group", type=int, default=32, help="a rank's share is cut into groups of at least this many utterances")
-    ap.add_argument("--group-fixed", type=int, default=16, help="small shares: the per-frame cost of a group in lane equivalents (sizes the groups so that the engines finish together)")
+    ap.add_argument("--group-fixed", type=int, default=16,
+            help="small shares: the per-frame cost of a group in lane equivalents (sizes the groups so that the engines finish together)")
     ap.add_argument("--refill", type=int, default=1, help="1: a share of more utterances than lanes is ONE queue per engine, a lane takes the next "
                                                           "utterance when its own has ended (s3a_uttdec_decode_queue_dev); 0: groups of similar "
                                                           "length, lanes in lock step")
@@ -493,11 +498,14 @@ def main():
     ap.add_argument("--no-ps", action="store_true", help="skip the pocketsphinx first-pass leg")
     ap.add_argument("--no-wide-beam", action="store_true", help="skip the configs[4] wide-beam leg")
     ap.add_argument("--wide-lanes", type=int, default=64, help="lanes of the wide-beam leg's engine")
-    ap.add_argument("--wide-frames", type=int, default=40, help="nominal frames per utterance of the wide-beam leg (utterances follow LM sentences: about twice that)")
-    ap.add_argument("--ps-lanes", type=int, default=512, help="lanes (persistent one-workgroup decoders, two per CU) the pocketsphinx leg runs the batch through as one queue")
+    ap.add_argument("--wide-frames", type=int, default=40,
+            help="nominal frames per utterance of the wide-beam leg (utterances follow LM sentences: about twice that)")
+    ap.add_argument("--ps-lanes", type=int, default=512,
+            help="lanes (persistent one-workgroup decoders, two per CU) the pocketsphinx leg runs the batch through as one queue")
     ap.add_argument("--only-scoring", action="store_true", help="only the scoring legs (PMC passes over the scoring kernels)")
     ap.add_argument("--fast", action="store_true", help="S3A_GMM_FAST (f32, +-2 logs3 units) instead of bit-exact")
-    ap.add_argument("--variant", action="append", default=[], metavar="FIELD=INT", help="a field of s3a_variants_t (s3a_set_variants), e.g. hist_sort_launch=1: A/B runs of kernel variants")
+    ap.add_argument("--variant", action="append", default=[], metavar="FIELD=INT",
+            help="a field of s3a_variants_t (s3a_set_variants), e.g. hist_sort_launch=1: A/B runs of kernel variants")
     args = ap.parse_args()
     if args.plain:
         args.no_cpu = args.no_scoring = args.no_ps = args.no_wide_beam = True
@@ -770,7 +778,8 @@ def main():
                               "kernels": {"ku_frames": {"ms_per_step": round(max(p_["frames_ms"] for p_ in pp), 2), "relay_launches": decs[0].ud.last_relay()},
                                           "ku_score_window": {"ms_per_step": round(max(p_["score_ms"] for p_ in pp), 2)}},
                               "lanes_busy_ms": ({"min": round(busy[0], 1), "p10": round(busy[len(busy) // 10], 1), "median": round(busy[len(busy) // 2], 1),
-                                                 "mean": round(sum(busy) / len(busy), 1), "p90": round(busy[(9 * len(busy)) // 10], 1), "max": round(busy[-1], 1)} if busy else None),
+                                                 "mean": round(sum(busy) / len(busy), 1), "p90": round(busy[(9 * len(busy)) // 10], 1),
+                                                         "max": round(busy[-1], 1)} if busy else None),
                               "search": {"us_per_lane_frame": round(1e3 * max(p_["frames_ms"] for p_ in pp) * NL / max(frames_step, 1), 2),
                                          "phases_us_per_lane_frame": {k: round(v / max(fr, 1), 2) for k, v in sorted(ph.items())}},
                               "identical_to_reference": {"hyp": bool(hyp_ok), "hypseg": bool(seg_ok)}}))
@@ -839,18 +848,23 @@ def main():
                             "float64-VALU-bound (bit-exact mode: no FMA)"}
             roof_scoring = {"kernel": "ku_score_window", "bound": "valu-f64", "achieved": round(sc_tfl, 2), "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(sc_tfl / FP64_VEC_PEAK_TFLOPS, 4), "hbm_GBs": round(alg_score / (score_ms * 1e-3) / 1e9, 1),
-                            "hbm_frac": round(alg_score / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": round(1e3 * score_ms / max(n_score / len(decs), 1), 2),
-                            "launches_timed": int(n_score), "frames_per_launch": round(fr_rank / max(n_score, 1), 1), "share_of_step": round(score_ms / tot_ms, 4),
+                            "hbm_frac": round(alg_score / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "avg_launch_us": round(1e3 * score_ms / max(n_score / len(decs), 1), 2),
+                            "launches_timed": int(n_score), "frames_per_launch": round(fr_rank / max(n_score, 1), 1),
+                                    "share_of_step": round(score_ms / tot_ms, 4),
                             "note": "every frame of the step scored BEFORE the search (rows [frame][senone] in HBM, 5 B per senone and frame); hub4 "
                                     "single-frame scoring (one frame per model pass, HBM-bound) is in `scoring.hub4.frame_sync`: north_star's >= 0.60 "
                                     "of HBM peak is NOT met there at B = 1"}
-            kern = {"ku_frames": {"avg_launch_us": roof["avg_launch_us"], "launches_timed": int(n_kf), "ms_per_step": round(frames_ms, 2), "share": round(frames_ms / tot_ms, 4)},
+            kern = {"ku_frames": {"avg_launch_us": roof["avg_launch_us"], "launches_timed": int(n_kf), "ms_per_step": round(frames_ms, 2),
+                    "share": round(frames_ms / tot_ms, 4)},
                     "ku_score_window": {"avg_launch_us": roof_scoring["avg_launch_us"], "launches_timed": int(n_score), "ms_per_step": round(score_ms, 2),
                                         "share": round(score_ms / tot_ms, 4)}}
-            search = {"ms_per_step": round(frames_ms, 2), "us_per_lane_frame": round(1e3 * frames_ms * lanes_bench * len(decs) / fr_rank, 2) if fr_rank else None,
+            search = {"ms_per_step": round(frames_ms, 2), "us_per_lane_frame": round(1e3 * frames_ms * lanes_bench * len(decs) / fr_rank,
+                    2) if fr_rank else None,
                       "share_of_step": round(frames_ms / tot_ms, 4), "algorithmic_bytes_per_step": int(fr_rank * lanes_hmm * 84.0),
                       "achieved_GBs": round(fr_rank * lanes_hmm * 84.0 / (frames_ms * 1e-3) / 1e9, 1),
-                      "frac": round(fr_rank * lanes_hmm * 84.0 / (frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": "latency of dependent scattered accesses (waits), address path of the CUs",
+                      "frac": round(fr_rank * lanes_hmm * 84.0 / (frames_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                              "bound": "latency of dependent scattered accesses (waits), address path of the CUs",
                       "active_hmm_updates_per_s": round(lanes_hmm * value, 0),
                       "active_hmm_updates_per_s_cpu_single_core": round(cpu["active_hmm_per_frame"] * cpu["single_core"], 0) if cpu else None,
                       "phases_us_per_lane_frame": {k: round(v / max(ph_frames, 1), 2) for k, v in sorted(phases.items()) if k != "in_launch"},
@@ -871,7 +885,8 @@ def main():
             prof = {k: v for k, v in prof.items() if v[1] > 0}
             pf_b = {k: (us / n / (K if k == "ku_score_window" else 1)) for k, (us, n) in prof.items() if n > 0}
             tot = sum(pf_b.values())
-            kern = {k: {"avg_launch_us": round(prof[k][0] / prof[k][1], 2), "us_per_frame": round(v, 2), "share": round(v / tot, 4), "launches_timed": int(prof[k][1])}
+            kern = {k: {"avg_launch_us": round(prof[k][0] / prof[k][1], 2), "us_per_frame": round(v, 2), "share": round(v / tot, 4),
+                    "launches_timed": int(prof[k][1])}
                     for k, v in pf_b.items()}
             dom = max(pf_b, key=lambda k: pf_b[k])
             dom_us = prof[dom][0] / prof[dom][1]
@@ -882,7 +897,8 @@ def main():
                     "measured": f"the launch path: all {NE} engines running, HIP events around every launch of every 8th frame"}
             srch_us = sum(v for k, v in pf_b.items() if k not in ("ku_score_window", "ku_gated_cd", "ku_gated_ci", "ku_comsen_max"))
             search = {"us_per_frame": round(srch_us, 2), "achieved_GBs": round(lanes_bench * lanes_hmm * 84.0 / (srch_us * 1e-6) / 1e9, 1),
-                      "frac": round(lanes_bench * lanes_hmm * 84.0 / (srch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5), "active_hmm_updates_per_s": round(lanes_hmm * value, 0)}
+                      "frac": round(lanes_bench * lanes_hmm * 84.0 / (srch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                              "active_hmm_updates_per_s": round(lanes_hmm * value, 0)}
 
         # ---- what N = 8 gives a GPU: 128 of the 1024 utterances (the engine gives a lane a cluster of workgroups then) ----
         proj = None
@@ -892,13 +908,20 @@ def main():
             run_step(0, sched=sch8)
             lib.check(L.s3a_dev_sync())
             t8 = time.perf_counter()
-            run_step(0, recs=[], sched=sch8)
+            recs8 = []
+            run_step(0, recs=recs8, sched=sch8)
             lib.check(L.s3a_dev_sync())
             t8 = time.perf_counter() - t8
             f8 = sum(nfr[k] for k in ids8)
+            # (the clusters' hypotheses against the reference's lines of the same utterances: the XCD-local barrier at scale)
+            rl8, rs8 = ref[0].splitlines(keepends=True), ref[1].splitlines(keepends=True)
+            cmp8 = [(h.utt_index, dec.format_var(h, w)) for h, w in recs8 if h.utt_index < n_chk]
+            same8 = all(h.status == 0 for h, _ in recs8) and all(m == rl8[k] and sg == rs8[k] for k, (m, sg) in cmp8)
+            assert same8, "the 128-utterance projection's hypotheses differ from the unmodified reference decoder's"
             proj = {"gpus": 8, "utterances_per_gpu": len(ids8), "groups": [len(g) for e in sch8 for g in e],
                     "frames_per_sec_per_gpu": round(f8 / t8, 1), "implied_strong_scaling_efficiency": round(f8 / t8 / value, 3),
-                    "workgroups_per_lane": decs[0].ud.last_parts()["cluster"],
+                    "workgroups_per_lane": decs[0].ud.last_parts()["cluster"], "relay_launches": decs[0].ud.last_relay(),
+                    "identical_to_reference": bool(same8), "utterances_checked_against_reference": len(cmp8),
                     "note": "one GPU decoding rank 0's share of an 8-rank run of the same batch (hypotheses included, no gather): "
                             "fewer utterances than workgroup slots, so a lane is a cluster of workgroups with a counter barrier between the frame's steps"}
 
@@ -915,7 +938,8 @@ def main():
             same = None
             if k1 < n_chk:
                 same = one.format_var(*h1)[0] == ref[0].splitlines(keepends=True)[k1]
-            single = {"frames": nfr[k1], "frames_per_sec": round(nfr[k1] / t1, 1), "xRT": round(nfr[k1] / t1 / 100.0, 1), "us_per_frame_device": round(1e3 * ms1 / nfr[k1], 2),
+            single = {"frames": nfr[k1], "frames_per_sec": round(nfr[k1] / t1, 1), "xRT": round(nfr[k1] / t1 / 100.0, 1),
+                    "us_per_frame_device": round(1e3 * ms1 / nfr[k1], 2),
                       "path": "launches" if one.ud.last_parts()["n_frames"] == 0 else "ku_frames", "identical_to_reference": same,
                       "note": "configs[2]: the batch's longest utterance decoded alone by a one-lane engine, host call to hypothesis (wall clock)"}
             del one
@@ -931,7 +955,8 @@ def main():
             "config": {"workload": f"configs[3]: batch of {U} synthetic 10 s utterances, hub4_cd_continuous shape, full decode (senone "
                                    f"scoring + lextree Viterbi + trigram word level on the device), sharded over {world} GPU(s); a step = "
                                    f"the whole batch once" + (" per rank" if args.scaling == "weak" else ""),
-                       "utterances_per_step": n_total, "frames_per_step": frames_step, "lanes_per_gpu": NL, "engines_per_gpu": NE, "lane_refill": bool(args.refill and len(my_share(0)[0]) > NL),
+                       "utterances_per_step": n_total, "frames_per_step": frames_step, "lanes_per_gpu": NL, "engines_per_gpu": NE,
+                               "lane_refill": bool(args.refill and len(my_share(0)[0]) > NL),
                        "groups_rank0": [len(g) for e in sched for g in e],
                        "beams": "-beam 1e-60 -wbeam 1e-35 -maxhmmpf 20000 -maxwpf 10 -lw 9.5 (the reference's hub4 settings)",
                        "parallelism": f"utterance-sharded x{world} ({args.scaling}), ONE exchange per batch in C (three ncclAllGathers: counts, "
@@ -945,26 +970,29 @@ def main():
             "load_s": round(t_load, 2), "setup_s": round(t_setup, 1),
             "per_frame": {"active_hmm": round(lanes_hmm, 1), "cd_senones_scored": round(lanes_sen, 1), "cd_gaussians": round(lanes_gau, 1),
                           "word_exits": round(lanes_exit, 2), "max_active_hmm": int(max(s_[:, 1].max() for s_ in stat)),
-                          "frames_with_histogram_pruning": int(sum(int(s_[:, 6].sum()) for s_ in stat)), "max_candidates": int(res0["max_cand"]), "tie_frames_lane0": int(res0["n_tie_frames"])},
-            "roofline": roof,
-            "roofline_scoring": roof_scoring,
-            "search": search,
+                          "frames_with_histogram_pruning": int(sum(int(s_[:, 6].sum()) for s_ in stat)), "max_candidates": int(res0["max_cand"]),
+                                  "tie_frames_lane0": int(res0["n_tie_frames"])},
             "kernels": kern,
-            "single_utterance": single,
             "rank_devices": [0 if rehearsal else r_ for r_ in range(world)],
         }
-        if weak:
-            res["weak_scaling"] = weak
-        if proj:
-            res["strong_scaling_projection"] = proj
-        if cpu:
-            res["cpu_baseline"] = cpu
+        # (what a reader of the line's TAIL must find -- the driver stores the end of stdout -- comes last: the extra legs first, then the
+        # baseline, the search's and the scoring's roofline entries, the single utterance, the projection, the dominant kernel's roofline)
         if world == 1 and not args.no_scoring:
             res["scoring"] = scoring_legs(lib, args.fast)
         if world == 1 and not args.no_ps:
             res["ps_fwdtree"] = ps_fwdtree_leg(d, args.ps_lanes)
         if world == 1 and not args.no_wide_beam:
             res["wide_beam"] = wide_beam_leg(lib, d, args.wide_lanes, args.wide_frames, args.fast)
+        if weak:
+            res["weak_scaling"] = weak
+        if cpu:
+            res["cpu_baseline"] = cpu
+        res["search"] = search
+        res["roofline_scoring"] = roof_scoring
+        res["single_utterance"] = single
+        if proj:
+            res["strong_scaling_projection"] = proj
+        res["roofline"] = roof
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

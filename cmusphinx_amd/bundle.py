@@ -79,7 +79,7 @@ class Decoder:
     """bundle -> s3a_uttdec_t with n_lanes lanes (and what formatting a hypothesis needs)"""
 
     def __init__(self, bundle, n_lanes, precision=lib.GMM_EXACT, vh_cap=0, cand_cap=0, max_frames=15000, bestpath=False,
-                 keep_tables=True, link_cap=0, pair_cap=0, bestpathlw=None):
+                 keep_tables=True, link_cap=0, pair_cap=0, bestpathlw=None, opts=None):
         b = self.b = read(bundle) if isinstance(bundle, str) else bundle
         ne = b["n_emit"]
         self.logmath = lib.LogMath(b["logbase"])
@@ -98,7 +98,7 @@ class Decoder:
         cfg.hmmbeam, cfg.pbeam, cfg.wbeam, cfg.ptranskip, cfg.maxhmmpf = b["hmmbeam"], b["pbeam"], b["wbeam"], b["ptranskip"], b["maxhmmpf"]
         self.ud = lib.UttDec(self.proto, self.g, b["cd2cisen"], b["n_ci_sen"], self.comsen, self.lm, cfg, n_lanes, ds=b["ds"],
                              cond_ds=b["cond_ds"], ci_pbeam=b["ci_pbeam"], tighten_factor=b["tighten_factor"],
-                             max_cd=b["maxcdsenpf"], max_frames=max_frames, vh_cap=vh_cap, cand_cap=cand_cap)
+                             max_cd=b["maxcdsenpf"], max_frames=max_frames, vh_cap=vh_cap, cand_cap=cand_cap, opts=opts)
         self.n_lanes = n_lanes
         if b.get("pheurtype", 0) > 0:
             # -pheurtype 1..3: the phoneme look-ahead inside the engine

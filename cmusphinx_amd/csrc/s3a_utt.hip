@@ -1624,6 +1624,10 @@ struct KfSh {                   /* the workgroup's LDS outside the word level's 
     long long kacc[16];         /* the steps' clock of the utterance so far (UCtx.kacc) */
     int32_t thr[4];             /* the frame's thresholds: HMM, phone, word (final once the histogram beam is known) */
     int32_t tp[KF_TP_LDS];      /* the transition matrices (when they fit: 48 of hub4's 3-state topology are 2.3 KB) */
+    /* the frame's operands (KF_CALL: the frame is a function of its own -- its registers are then allocated for the frame alone, not for the
+     * frame inside the kernel's loops over utterances and frames; a function's arguments travel in VGPRs, so what is uniform arrives here
+     * and is read back through readfirstlane) */
+    struct { const void *A; UCtx *ctx; int32_t *row; const uint8_t *brow; int32_t *bar_cnt; int32_t z, r, C, f, weak, bar_target, bar_local; } fa;
 };
 
 struct KfBar { int32_t *cnt; int32_t C, target; int32_t *dead; int32_t local; };
@@ -2699,11 +2703,39 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
 struct KfArgs { UShared S; WLm lm; WDict dict; WPar par; KfJob J; };
 #define KF_ARG_SLOTS 8
 
+/* the workgroup's LDS, one object per instantiation of the kernel (at namespace scope so that the frame's function addresses it as LDS) */
+template <int NE, bool EXACT> __shared__ KfSh g_kfsh;
+
+#ifndef KF_CALL
+#define KF_CALL 0               /* (measured, profiles/r6_experiments.txt 4: the frame as a function has no scratch access in its hot loops and is 0.9 % slower) */
+#endif
+template <class T> __device__ __forceinline__ T *kf_uniform_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    return (T *)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v));
+}
+/* the frame as a function of its own: operands from LDS (KfSh.fa), the cluster barrier's count back there */
+template <int NE, bool EXACT>
+__device__ __noinline__ void
+kf_frame_call()
+{
+    KfSh &sh = g_kfsh<NE, EXACT>;
+    const KfArgs *A = (const KfArgs *)kf_uniform_ptr(sh.fa.A);
+    UCtx *ctx = kf_uniform_ptr(sh.fa.ctx);
+    const int32_t z = __builtin_amdgcn_readfirstlane(sh.fa.z), r = __builtin_amdgcn_readfirstlane(sh.fa.r), C = __builtin_amdgcn_readfirstlane(sh.fa.C),
+        f = __builtin_amdgcn_readfirstlane(sh.fa.f), weak = __builtin_amdgcn_readfirstlane(sh.fa.weak);
+    KfBar B = { kf_uniform_ptr(sh.fa.bar_cnt), C, __builtin_amdgcn_readfirstlane(sh.fa.bar_target), &sh.dead, __builtin_amdgcn_readfirstlane(sh.fa.bar_local) };
+    kf_frame<NE, EXACT>(sh.Lc, A->S, ctx, A->lm, A->dict, A->par, sh, B, z, r, C, f, kf_uniform_ptr(sh.fa.row), kf_uniform_ptr(sh.fa.brow), weak);
+    if (threadIdx.x == 0) sh.fa.bar_target = B.target;
+    __syncthreads();
+}
+
 /* (KF_OCC: waves per SIMD the register budget is set for -- 4 = 128 VGPRs, two lanes per CU; -DKF_OCC=2 = 256 VGPRs, one lane per CU: the
  * build profiles/r6_experiments.txt uses to tell what the spills cost) */
 #ifndef KF_OCC
 #define KF_OCC 4
 #endif
+
 template <int NE, bool EXACT>
 __global__ void __launch_bounds__(KF_NT, KF_OCC)
 ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t n_lanes, int32_t C, int32_t *bar,
@@ -2712,7 +2744,7 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
     /* (what every lane shares arrives through memory, not as ~300 words of kernel arguments the compiler then tries to keep in
      * registers for the whole frame loop: SGPR spills 1 493 -> 647, VGPR spills 342 -> 248, scratch 524 -> 308 B per lane) */
     const UShared &S = A->S; const WLm &lm = A->lm; const WDict &dict = A->dict; const WPar &par = A->par; const KfJob &J = A->J;
-    __shared__ KfSh sh;
+    KfSh &sh = g_kfsh<NE, EXACT>;
     /* the lane and this workgroup's place in its cluster: a cluster's workgroups share an XCD */
     int32_t z, r;
     if (C == 1) { z = blockIdx.x; r = 0; }
@@ -2777,7 +2809,7 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
             u = sh.u;
             if (u >= J.n_utt || sh.dead) break;
             u = J.order[J.u0 + u];              /* (the take's utterance: its index in the queue) */
-            if (r == 0 && tid == 0) J.lane_uq[z] = u;
+            if (r == 0 && tid == 0 && J.lane_uq) J.lane_uq[z] = u;
             /* srch_utt_begin (srch.c:453-479): every per-utterance state reset, the utterance's context */
             d_lane_begin(L, S, J.B, z, J.stage + u, gtid, gstride, r == 0, tid, KF_NT);
             kf_barrier(B);
@@ -2811,7 +2843,17 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
             }
             int32_t *row = mode == KF_WINDOW ? L.win + (size_t)(f % S.win_K) * S.n_sen : J.scores + (r0 + f) * S.n_sen;
             const uint8_t *brow = mode == KF_WINDOW ? L.winb + (size_t)(f % S.win_K) * S.n_sen : J.bests + (r0 + f) * S.n_sen;
+#if KF_CALL
+            if (tid == 0) {
+                sh.fa.A = A; sh.fa.ctx = ctx; sh.fa.row = row; sh.fa.brow = brow; sh.fa.bar_cnt = B.cnt; sh.fa.z = z; sh.fa.r = r; sh.fa.C = C; sh.fa.f = f;
+                sh.fa.weak = weak_possible; sh.fa.bar_target = B.target; sh.fa.bar_local = B.local;
+            }
+            __syncthreads();
+            kf_frame_call<NE, EXACT>();
+            B.target = sh.fa.bar_target;
+#else
             kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, row, brow, weak_possible);
+#endif
         }
         if (handed) break;
         if (mode != KF_QUEUE) break;
@@ -4157,7 +4199,8 @@ kf_launch(s3a_uttdec_t *ud, int32_t n, const KfJob &J)
 static int32_t
 kf_launch_chain(s3a_uttdec_t *ud, int32_t n, KfJob J)
 {
-    const int32_t C0 = kf_choose_c(ud, n), usable = kf_usable_per_xcd(ud), W = KF_ST_WORDS + ud->n_lanes;
+    /* (kf_relay_at, the tests' switch: the chain from one workgroup per lane on, however few the lanes) */
+    const int32_t C0 = s3a_variants()->kf_relay_at > 0 && ud->kf_cluster_opt == 0 ? 1 : kf_choose_c(ud, n), usable = kf_usable_per_xcd(ud), W = KF_ST_WORDS + ud->n_lanes;
     int32_t st_c[KF_STAGES], st_cap[KF_STAGES], n_st = 0;
     /* (kf_relay_at, the tests' switch: the chain whatever else runs on the device -- the caller answers for co-residency, as with .cluster) */
     if (ud->d_kfrelay && ud->kf_cluster_opt == 0 && (kf_alone(ud) || s3a_variants()->kf_relay_at > 0) && !s3a_variants()->kf_no_relay) {
