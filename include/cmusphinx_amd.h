@@ -1003,6 +1003,29 @@ typedef struct {
 int64_t s3a_lattice_format_htk(const char *header, const s3a_htk_opts_t *o, const s3a_lat_info_t *info,
                                const s3a_lat_node_t *nodes, const s3a_lat_link_t *links, const char *const *wordstr,
                                char *buf, int64_t cap);
+/*
+ * N-best lists on such a lattice (srch_TST_nbest_impl, srch_time_switch_tree.c:1442-1492 -> nbest_search, astar.c:656-716): what the
+ * reference does between vithist_dag_build and the list's file -- dag_remove_unreachable, dag_bypass_filler_nodes, dag_compute_hscr,
+ * dag_remove_bypass_links (dag.c:303-365, 1037-1112, 521-587), then the A* search over partial paths with the reference's own heap,
+ * duplicate table and tie order -- in the library, on the arrays s3a_uttdec_lattice / s3a_dagpass_lattice hand out.  Host code (one
+ * best-first chain; the lattice and everything in front of it come from the device).  lm = the engine's trigram; cfg = the second
+ * pass's configuration (word tables, -bestpathlw / -lw as lwf, -maxedge, -maxlmop, -maxlpf); the options: uttid, -beam (float64, and
+ * logs3 of it), -nbest, -maxppath, and what the file's header prints (-logbase, -lw, -wip) / lm_rawscore needs (lm_t.lw, lm_t.wip).
+ * s3a_nbest_result: the file's text as nbest_search writes it (the caller writes the file -- and no file when n_hyp <= 0, as the
+ * reference unlinks it), the hypotheses found, counts4 = {pops, expansions, partial paths, bypass links}; returns S3A_OK, or S3A_ENOMEM
+ * when -maxedge stopped the bypass (the reference then writes no list: n_hyp = -1).
+ */
+typedef struct {
+    const char *uttid;
+    double beam;
+    int32_t beam_logs3, nbest, maxppath, lm_wip;
+    float logbase, lw, wip, lm_lw;
+} s3a_nbest_opts_t;
+typedef struct s3a_nbest_s s3a_nbest_t;
+s3a_nbest_t *s3a_lattice_nbest(const s3a_lm3g_t *lm, const s3a_dag_cfg_t *cfg, const s3a_nbest_opts_t *o, const s3a_lat_info_t *info,
+                               const s3a_lat_node_t *nodes, const s3a_lat_link_t *links, const char *const *wordstr);
+int32_t s3a_nbest_result(const s3a_nbest_t *nb, const char **text, int64_t *len, int32_t *n_hyp, int32_t *counts4);
+void s3a_nbest_free(s3a_nbest_t *nb);
 /* the whole-utterance engine with the second pass: after the frames of every s3a_uttdec_decode* the lanes' tables go
  * through vithist_utt_end and the pass ON THE DEVICE; keep_tables = 0: the history tables are not read back at all
  * (s3a_uttdec_result / s3a_uttdec_hyp then fail; the hypotheses come from s3a_uttdec_bestpath_hyp).
