@@ -638,6 +638,7 @@ s3a_dagpass_init(s3a_lm3g_t *lm, const s3a_dag_cfg_t *cfg, int32_t n_lanes, int3
         s3a_set_error("s3a_dagpass_init: bad arguments");
         return NULL;
     }
+    if (!lm->d.ug_prob) { s3a_set_error("s3a_dagpass_init: the LM handle has no device arrays (s3a_lm3g_init_host)"); return NULL; }
     s3a_dagpass_t *dp = new s3a_dagpass_s();
     dp->lm = lm; dp->n_lanes = n_lanes; dp->max_frames = max_frames; dp->d_lanes = NULL; dp->d_cfg = NULL; dp->d_fill = NULL;
     dp->h_io = dp->h_out = NULL; dp->n_run = 0; dp->lanes_dirty = true; dp->device = 0;

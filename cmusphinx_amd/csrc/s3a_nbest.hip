@@ -39,47 +39,6 @@ namespace {
 
 inline int32_t nb_add32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
 
-/* lm_tg_score / lm_bg_score on the handle's host copy (lm.c:1241-1312, 1661-1833; the device's wl_tg_score, s3a_wordlevel.h) */
-int32_t
-nb_find(const int32_t *v, int32_t n, int32_t w)
-{
-    int32_t lo = 0, hi = n;
-    while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (v[mid] < w) lo = mid + 1; else hi = mid; }
-    return (lo < n && v[lo] == w) ? lo : -1;
-}
-int32_t
-nb_bg_score(const s3a_lm3g_s &lm, int32_t lw1, int32_t lw2, int32_t wid)
-{
-    int32_t s;
-    if (lm.bg_wid.empty() || lw1 < 0) s = lm.ug_prob[lw2];
-    else {
-        const int32_t b0 = lm.ug_firstbg[lw1], n = lm.ug_firstbg[lw1 + 1] - b0;
-        const int32_t i = n > 0 ? nb_find(lm.bg_wid.data() + b0, n, lw2) : -1;
-        s = i >= 0 ? lm.bg_prob[b0 + i] : nb_add32(lm.ug_bowt[lw1], lm.ug_prob[lw2]);
-    }
-    if (!lm.inclass.empty()) s = nb_add32(s, lm.inclass[wid]);
-    return s;
-}
-int32_t
-nb_tg_score(const s3a_lm3g_s &lm, int32_t lw1, int32_t lw2, int32_t lw3, int32_t wid)
-{
-    if (lm.tg_wid.empty() || lw1 < 0) return nb_bg_score(lm, lw2, lw3, wid);
-    const int32_t b0 = lm.ug_firstbg[lw1], nb = lm.ug_firstbg[lw1 + 1] - b0;
-    int32_t b = nb > 0 ? nb_find(lm.bg_wid.data() + b0, nb, lw2) : -1, bowt = 0;
-    if (b >= 0) {
-        b += b0;
-        bowt = lm.bg_bowt[b];
-        const int32_t t0 = lm.bg_firsttg[b], nt = lm.bg_firsttg[b + 1] - t0;
-        const int32_t i = nt > 0 ? nb_find(lm.tg_wid.data() + t0, nt, lw3) : -1;
-        if (i >= 0) {
-            int32_t s = lm.tg_prob[t0 + i];
-            if (!lm.inclass.empty()) s = nb_add32(s, lm.inclass[wid]);
-            return s;
-        }
-    }
-    return nb_add32(bowt, nb_bg_score(lm, lw2, lw3, wid));
-}
-
 struct Edge { int32_t from, to, ascr, hscr, ef, byp, snext, pnext; };          /* snext / pnext: the next link of the source's successor chain / the target's predecessor chain */
 struct PPath { int32_t hist, lmhist, node, lscr, pscr, tscr, pruned, hashnext; uint32_t histhash; };
 struct HeapNode { int32_t pp, nl, nr, left, right; };
@@ -103,7 +62,8 @@ struct Search {
     int32_t base(int32_t w) const { return cfg->basewid[w]; }
     /* lm->dict2lmwid[] with linksilences in force (kbcore.c:191-206): <s> and </s> have LM ids while the second pass runs */
     int32_t lmid(int32_t bw) const { return bw < 0 ? -1 : bw == cfg->startwid ? cfg->start_lwid : bw == cfg->finishwid ? cfg->finish_lwid : cfg->lwid[bw]; }
-    int32_t tg(int32_t bw0, int32_t bw1, int32_t bw2) const { return nb_tg_score(*lm, lmid(bw0), lmid(bw1), lmid(bw2), bw2); }
+    /* lm_tg_score (lm.c:1661-1833) on the handle's host copy */
+    int32_t tg(int32_t bw0, int32_t bw1, int32_t bw2) const { return s3a_lm3g_tg_score(lm, lmid(bw0), lmid(bw1), lmid(bw2), bw2); }
 
     /* dag_link (dag.c:186-237): both chains by head insertion; -1: -maxedge exceeded */
     int32_t link(int32_t pd, int32_t d, int32_t ascr, int32_t ef, int32_t byp)

@@ -3007,8 +3007,9 @@ ku_fill32(int32_t *p, int32_t v, size_t n)
         if ((vec).size() && hipMemcpy((void *)(dst), (vec).data(), (vec).size() * 4, hipMemcpyHostToDevice) != hipSuccess) { \
             s3a_set_error("s3a_utt: upload failed"); goto fail; } } while (0)
 
-extern "C" s3a_lm3g_t *
-s3a_lm3g_init(int32_t n_ug, const int32_t *ug_prob, const int32_t *ug_bowt, const int32_t *ug_firstbg, int32_t n_bg,
+/* the host copy, checked (what the second pass's host side -- s3a_lattice_nbest -- reads; no device needed) */
+static s3a_lm3g_t *
+lm3g_host(int32_t n_ug, const int32_t *ug_prob, const int32_t *ug_bowt, const int32_t *ug_firstbg, int32_t n_bg,
               const int32_t *bg_wid, const int32_t *bg_prob, const int32_t *bg_bowt, const int32_t *bg_firsttg,
               int32_t n_tg, const int32_t *tg_wid, const int32_t *tg_prob, const int32_t *inclass_ugscore,
               int32_t n_dictword)
@@ -3044,6 +3045,26 @@ s3a_lm3g_init(int32_t n_ug, const int32_t *ug_prob, const int32_t *ug_bowt, cons
     }
     memset(&lm->d, 0, sizeof lm->d);
     lm->d.n_ug = n_ug; lm->d.n_bg = n_bg; lm->d.n_tg = n_tg;
+    return lm;
+}
+
+extern "C" s3a_lm3g_t *
+s3a_lm3g_init_host(int32_t n_ug, const int32_t *ug_prob, const int32_t *ug_bowt, const int32_t *ug_firstbg, int32_t n_bg,
+                   const int32_t *bg_wid, const int32_t *bg_prob, const int32_t *bg_bowt, const int32_t *bg_firsttg,
+                   int32_t n_tg, const int32_t *tg_wid, const int32_t *tg_prob, const int32_t *inclass_ugscore,
+                   int32_t n_dictword)
+{
+    return lm3g_host(n_ug, ug_prob, ug_bowt, ug_firstbg, n_bg, bg_wid, bg_prob, bg_bowt, bg_firsttg, n_tg, tg_wid, tg_prob, inclass_ugscore, n_dictword);
+}
+
+extern "C" s3a_lm3g_t *
+s3a_lm3g_init(int32_t n_ug, const int32_t *ug_prob, const int32_t *ug_bowt, const int32_t *ug_firstbg, int32_t n_bg,
+              const int32_t *bg_wid, const int32_t *bg_prob, const int32_t *bg_bowt, const int32_t *bg_firsttg,
+              int32_t n_tg, const int32_t *tg_wid, const int32_t *tg_prob, const int32_t *inclass_ugscore,
+              int32_t n_dictword)
+{
+    s3a_lm3g_t *lm = lm3g_host(n_ug, ug_prob, ug_bowt, ug_firstbg, n_bg, bg_wid, bg_prob, bg_bowt, bg_firsttg, n_tg, tg_wid, tg_prob, inclass_ugscore, n_dictword);
+    if (!lm) return NULL;
     UPV(lm->d.ug_prob, lm->ug_prob); UPV(lm->d.ug_bowt, lm->ug_bowt); UPV(lm->d.ug_firstbg, lm->ug_firstbg);
     UPV(lm->d.bg_wid, lm->bg_wid); UPV(lm->d.bg_prob, lm->bg_prob); UPV(lm->d.bg_bowt, lm->bg_bowt);
     UPV(lm->d.bg_firsttg, lm->bg_firsttg); UPV(lm->d.tg_wid, lm->tg_wid); UPV(lm->d.tg_prob, lm->tg_prob);
@@ -3602,6 +3623,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->h_tree_type.assign(cfg->tree_type, cfg->tree_type + T);
     ud->cfg.lwid = ud->h_lwid.data(); ud->cfg.fillpen = ud->h_fillpen.data(); ud->cfg.last_ci = ud->h_last_ci.data();
     ud->cfg.is_filler = ud->h_is_filler.data(); ud->cfg.tree_type = ud->h_tree_type.data();
+    if (!lm->d.ug_prob) { s3a_set_error("s3a_uttdec_init: the LM handle has no device arrays (s3a_lm3g_init_host)"); goto fail; }
     for (int32_t w = 0; w < cfg->n_word; w++)
         if (cfg->last_ci[w] < 0 || cfg->last_ci[w] >= cfg->n_ci || (cfg->lwid[w] >= lm->d.n_ug)) {
             s3a_set_error("s3a_uttdec_init: dictionary word %d has a bad final phone / LM id", w);

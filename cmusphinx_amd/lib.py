@@ -183,6 +183,11 @@ _SIGS = {
                                                         C.POINTER(C.c_int32)]),
     "s3a_lm3g_init": (C.c_void_p, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_lm3g_init_host": (C.c_void_p, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "s3a_lattice_nbest": (C.c_void_p, [C.c_void_p] * 7),
+    "s3a_nbest_result": (C.c_int32, [C.c_void_p] * 5),
+    "s3a_nbest_free": (None, [C.c_void_p]),
     "s3a_lm3g_free": (None, [C.c_void_p]),
     "s3a_lm3g_tg_score": (C.c_int32, [C.c_void_p] + [C.c_int32] * 4),
     "s3a_uttdec_init": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -1201,14 +1206,16 @@ class WordLevelCfg(C.Structure):
 class Lm3g:
     """lm_t flattened (s3a_lm3g_init); t = dict with the arrays of a word-level trace"""
 
-    def __init__(self, t):
+    def __init__(self, t, host_only=False):
+        """host_only: no device arrays (s3a_lm3g_init_host) -- for the library's host-side consumers on a machine without a GPU"""
         self.L = load()
         g = lambda k: np.ascontiguousarray(t[k], dtype=np.int32) if k in t and len(np.atleast_1d(t[k])) else None
         self.keep = [g(k) for k in ("ug_prob", "ug_bowt", "ug_firstbg", "bg_wid", "bg_prob", "bg_bowt", "bg_firsttg",
                                     "tg_wid", "tg_prob")]
         a = self.keep
-        self.h = self.L.s3a_lm3g_init(int(t["n_ug"]), _p(a[0]), _p(a[1]), _p(a[2]), int(t["n_bg"]), _p(a[3]), _p(a[4]),
-                                      _p(a[5]), _p(a[6]), int(t["n_tg"]), _p(a[7]), _p(a[8]), None, int(t["n_word"]))
+        init = self.L.s3a_lm3g_init_host if host_only else self.L.s3a_lm3g_init
+        self.h = init(int(t["n_ug"]), _p(a[0]), _p(a[1]), _p(a[2]), int(t["n_bg"]), _p(a[3]), _p(a[4]),
+                      _p(a[5]), _p(a[6]), int(t["n_tg"]), _p(a[7]), _p(a[8]), None, int(t["n_word"]))
         if not self.h:
             raise S3AError(_err(self.L))
 
@@ -1312,6 +1319,35 @@ class DagCfg(C.Structure):
     _fields_ = [("n_word", C.c_int32), ("basewid", C.c_void_p), ("is_filler", C.c_void_p), ("lwid", C.c_void_p), ("fillpen", C.c_void_p)] + \
                [(k, C.c_int32) for k in ("startwid", "finishwid", "silwid", "start_lwid", "finish_lwid", "wip")] + [("lwf", C.c_double)] + \
                [(k, C.c_int32) for k in ("min_endfr", "maxedge", "maxlmop", "maxlpf")]
+
+
+class LatInfo(C.Structure):
+    """s3a_lat_info_t"""
+    _fields_ = [(k, C.c_int32) for k in ("status", "n_frames", "n_nodes", "n_links", "initial", "final", "final_ascr")]
+
+
+class NbestOpts(C.Structure):
+    """s3a_nbest_opts_t"""
+    _fields_ = [("uttid", C.c_char_p), ("beam", C.c_double)] + [(k, C.c_int32) for k in ("beam_logs3", "nbest", "maxppath", "lm_wip")] + \
+               [(k, C.c_float) for k in ("logbase", "lw", "wip", "lm_lw")]
+
+
+def lattice_nbest(lm, cfg, opts, info, nodes, links, wordstr):
+    """s3a_lattice_nbest: the N-best list of a lattice (nodes [n, 6], links [m, 5] int32 arrays in the reference's list orders, info a
+    LatInfo, wordstr a list of bytes) -> (text, n_hyp, counts [pops, expansions, partial paths, bypass links], status)"""
+    L = load()
+    nodes = np.ascontiguousarray(nodes, np.int32); links = np.ascontiguousarray(links, np.int32)
+    wp = (C.c_char_p * len(wordstr))(*wordstr)
+    h = L.s3a_lattice_nbest(lm.h, C.byref(cfg), C.byref(opts), C.byref(info), _p(nodes), _p(links) if len(links) else None, wp)
+    if not h:
+        raise S3AError(_err(L))
+    try:
+        txt, ln, nh = C.c_char_p(), C.c_int64(), C.c_int32()
+        cnt = (C.c_int32 * 4)()
+        st = L.s3a_nbest_result(h, C.byref(txt), C.byref(ln), C.byref(nh), cnt)
+        return C.string_at(txt, ln.value), int(nh.value), [int(x) for x in cnt], int(st)
+    finally:
+        L.s3a_nbest_free(h)
 
 
 class DagResult(C.Structure):

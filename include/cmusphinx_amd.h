@@ -667,6 +667,13 @@ s3a_lm3g_t *s3a_lm3g_init(int32_t n_ug, const int32_t *ug_prob, const int32_t *u
                           const int32_t *bg_prob, const int32_t *bg_bowt, const int32_t *bg_firsttg,
                           int32_t n_tg, const int32_t *tg_wid, const int32_t *tg_prob,
                           const int32_t *inclass_ugscore, int32_t n_dictword);
+/* the same without device arrays: for the library's host-side consumers (s3a_lattice_nbest, s3a_lm3g_tg_score) on a machine without
+ * a GPU; the engines refuse such a handle */
+s3a_lm3g_t *s3a_lm3g_init_host(int32_t n_ug, const int32_t *ug_prob, const int32_t *ug_bowt,
+                               const int32_t *ug_firstbg, int32_t n_bg, const int32_t *bg_wid,
+                               const int32_t *bg_prob, const int32_t *bg_bowt, const int32_t *bg_firsttg,
+                               int32_t n_tg, const int32_t *tg_wid, const int32_t *tg_prob,
+                               const int32_t *inclass_ugscore, int32_t n_dictword);
 void s3a_lm3g_free(s3a_lm3g_t *lm);
 int32_t s3a_lm3g_tg_score(const s3a_lm3g_t *lm, int32_t lw1, int32_t lw2, int32_t lw3, int32_t wid);
 

@@ -23,6 +23,7 @@ static s3a_mgau_model_t *g_gms[UTT_MAX_ENGINES];       /* the engines' device mo
 static s3a_uttdec_t *g_ud, *g_uds[UTT_MAX_ENGINES];    /* g_ud = g_uds[0]; S3A_UTT_ENGINES engines of g_lpe lanes each */
 static int32 g_n_eng = 1, g_lpe;
 static s3a_lm3g_t *g_lm3g;
+static s3a_dag_cfg_t g_dag_cfg;         /* what the second pass was enabled with (its word tables stay alive: the library's N-best reads them) */
 static uq_t *g_uq;
 static int32 g_uq_n, g_uq_cap;
 static int g_adcin, g_cmn_current, g_varnorm, g_agc_max;     /* -adcin: features made on the device from the samples */
@@ -208,6 +209,54 @@ utt_dag_dump_slot(void *srch, dag_t *dag)
     fclose_comp(fp, ispipe);
     ckd_free(buf); ckd_free(nodes); ckd_free(links); free(hdr);
     return SRCH_SUCCESS;
+}
+/* nbest_impl (srch.c:604-606; srch_TST_nbest_impl, srch_time_switch_tree.c:1442-1492 -> nbest_search, astar.c:656-716): the list by the
+ * library's own search (s3a_lattice_nbest: unreachable nodes, filler bypass, heuristic scores, A*) on the device's lattice; the file is
+ * written here as nbest_search writes it -- and not left behind when the search found nothing.  S3A_REF_NBEST=1 keeps the reference's
+ * own search on the dag_t that utt_gen_dag_slot pours (A/B in tests/test_gpu_dag.py). */
+static glist_t
+utt_nbest_slot(void *srch, dag_t *dag)
+{
+    srch_t *s = srch;
+    cmd_ln_t *config = kbcore_config(s->kbc);
+    lm_t *lm = kbcore_lm(s->kbc);
+    s3a_uttdec_t *ud = g_uds[g_cur_lane / g_lpe];
+    s3a_lat_info_t info;
+    s3a_lat_node_t *nodes;
+    s3a_lat_link_t *links;
+    s3a_nbest_opts_t o;
+    s3a_nbest_t *nb;
+    const char *text = NULL;
+    int64_t len = 0;
+    int32 n_hyp = 0, cnt[4] = { 0, 0, 0, 0 }, ispipe, st;
+    char str[2048];
+    FILE *fp;
+    (void)dag;
+    if (!cmd_ln_str_r(config, "-nbestdir")) return NULL;
+    if (s3a_uttdec_lattice(ud, g_cur_lane % g_lpe, &info, NULL, 0, NULL, 0) != S3A_OK) { E_ERROR("tst shim: no lattice from the device for %s: %s\n", s->uttid, s3a_last_error()); return NULL; }
+    nodes = ckd_calloc(info.n_nodes + 1, sizeof(*nodes));
+    links = ckd_calloc(info.n_links + 1, sizeof(*links));
+    if (s3a_uttdec_lattice(ud, g_cur_lane % g_lpe, &info, nodes, info.n_nodes, links, info.n_links) != S3A_OK) die("s3a_uttdec_lattice");
+    memset(&o, 0, sizeof o);
+    o.uttid = s->uttid; o.beam = cmd_ln_float64_r(config, "-beam"); o.beam_logs3 = logs3(kbcore_logmath(s->kbc), o.beam);
+    o.nbest = cmd_ln_int32_r(config, "-nbest"); o.maxppath = cmd_ln_int32_r(config, "-maxppath");
+    o.lm_wip = lm->wip; o.lm_lw = lm->lw; o.logbase = cmd_ln_float32_r(config, "-logbase"); o.lw = cmd_ln_float32_r(config, "-lw"); o.wip = cmd_ln_float32_r(config, "-wip");
+    ctl_outfile(str, cmd_ln_str_r(config, "-nbestdir"), cmd_ln_str_r(config, "-nbestext"), (s->uttfile ? s->uttfile : s->uttid), s->uttid,
+                cmd_ln_boolean_r(config, "-build_outdirs"));
+    nb = s3a_lattice_nbest(g_lm3g, &g_dag_cfg, &o, &info, nodes, links, (const char *const *)g_wordstr);
+    if (nb == NULL) die("s3a_lattice_nbest");
+    st = s3a_nbest_result(nb, &text, &len, &n_hyp, cnt);
+    if (st != S3A_OK) E_ERROR("maxedge limit (%d) exceeded\n", g_dag_cfg.maxedge);        /* (srch_TST_nbest_impl: no list then) */
+    else if (n_hyp <= 0) E_ERROR("%s: A* search failed\n", s->uttid);                       /* (nbest_search unlinks the file) */
+    else {
+        E_INFO("Writing N-Best list to %s\n", str);
+        if ((fp = fopen_comp(str, "w", &ispipe)) == NULL) E_ERROR("fopen_comp (%s,w) failed\n", str);
+        else { fwrite(text, 1, (size_t)len, fp); fclose_comp(fp, ispipe); }
+    }
+    E_INFO("N-Best search(%s) in the library: %5d frm %4d hyp %6d pop %6d exp %8d pp, %d bypass links\n", s->uttid, info.n_frames, n_hyp, cnt[0], cnt[1], cnt[2], cnt[3]);
+    s3a_nbest_free(nb);
+    ckd_free(nodes); ckd_free(links);
+    return NULL;
 }
 static glist_t
 utt_bestpath_slot(void *srch, dag_t *dag)
@@ -591,7 +640,7 @@ adc_frontend_init(cmd_ln_t *config, kbcore_t *kbc)
 }
 
 /* (the LM contexts: below, with utt_mode_main) */
-typedef struct { const char *name; flat_t **flat; s3a_lexsearch_t *ls; s3a_lm3g_t *lm3g; wl_flat_t *w; s3a_uttdec_t *uds[UTT_MAX_ENGINES]; } lmctx_t;
+typedef struct { const char *name; flat_t **flat; s3a_lexsearch_t *ls; s3a_lm3g_t *lm3g; wl_flat_t *w; s3a_uttdec_t *uds[UTT_MAX_ENGINES]; s3a_dag_cfg_t dagc; } lmctx_t;
 static lmctx_t *g_ctx;
 static int32 g_n_ctx, g_cur_ctx;
 static void ctx_switch(kb_t *kb, int32 k);
@@ -777,7 +826,7 @@ lm_context_init(kb_t *kbp, int with_engines)
                 dc.maxlmop = cmd_ln_int32_r(config, "-maxlmop"); dc.maxlpf = cmd_ln_int32_r(config, "-maxlpf");
                 if (s3a_uttdec_enable_bestpath(g_uds[e], &dc, getenv("S3A_DAG_LINKS") ? atoi(getenv("S3A_DAG_LINKS")) : 0,
                                                getenv("S3A_DAG_PAIRS") ? atoi(getenv("S3A_DAG_PAIRS")) : 0, 1) != S3A_OK) die("s3a_uttdec_enable_bestpath");
-                ckd_free(base);
+                if (e == 0) g_dag_cfg = dc; else ckd_free(base);      /* (the first engine's copy serves utt_nbest_slot: the library's N-best reads the word tables) */
                 g_dev_dag = 1;
             }
         }
@@ -792,7 +841,7 @@ static void
 ctx_save(int32 k, const char *name)
 {
     int32 e;
-    g_ctx[k].name = name; g_ctx[k].flat = g_flat; g_ctx[k].ls = g_ls; g_ctx[k].lm3g = g_lm3g; g_ctx[k].w = g_w;
+    g_ctx[k].name = name; g_ctx[k].flat = g_flat; g_ctx[k].ls = g_ls; g_ctx[k].lm3g = g_lm3g; g_ctx[k].w = g_w; g_ctx[k].dagc = g_dag_cfg;
     for (e = 0; e < g_n_eng; e++) g_ctx[k].uds[e] = g_uds[e];
 }
 static void
@@ -801,7 +850,7 @@ ctx_switch(kb_t *kb, int32 k)
     int32 e;
     if (k == g_cur_ctx) return;
     srch_set_lm((srch_t *)kb->srch, g_ctx[k].name);
-    g_flat = g_ctx[k].flat; g_ls = g_ctx[k].ls; g_lm3g = g_ctx[k].lm3g; g_w = g_ctx[k].w; g_wflat = g_ctx[k].w;
+    g_flat = g_ctx[k].flat; g_ls = g_ctx[k].ls; g_lm3g = g_ctx[k].lm3g; g_w = g_ctx[k].w; g_wflat = g_ctx[k].w; g_dag_cfg = g_ctx[k].dagc;
     for (e = 0; e < g_n_eng; e++) g_uds[e] = g_ctx[k].uds[e];
     g_ud = g_uds[0];
     g_cur_ctx = k;
@@ -910,6 +959,7 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
             g_wordstr = ckd_calloc(dict_size(dict) + 1, sizeof(*g_wordstr));
             for (i = 0; i < dict_size(dict); i++) g_wordstr[i] = (char *)dict_wordstr(dict, i);
             if (cmd_ln_str_r(config, "-outlatdir") && strcmp(cmd_ln_str_r(config, "-outlatfmt"), "htk") != 0) s->funcs->dag_dump = utt_dag_dump_slot;
+            if (cmd_ln_str_r(config, "-nbestdir") && !getenv("S3A_REF_NBEST")) s->funcs->nbest_impl = utt_nbest_slot;
         }
     }
     g_uq_cap = n_lanes;

@@ -191,22 +191,44 @@ def test_lattice_files_from_the_device_lattice(task, lanes, fmt, extra, tmp_path
             assert lib_htk[k] == lat_ref[k], k
 
 
-@pytest.mark.parametrize("task,lanes,extra", [("tidigits", "8", []), ("rm1", "20", ["-bestpath", "1"])])
+@pytest.mark.parametrize("task,lanes,extra", [("tidigits", "8", []), ("rm1", "20", ["-bestpath", "1"]),
+                                              ("rm1", "7", ["-bestpathlw", "11", "-nbest", "50"])])
 def test_nbest_lists_on_the_device_lattice(task, lanes, extra, tmp_path):
-    """-nbestdir: the reference's own A* (astar.c nbest_search through srch_TST_nbest_impl: remove unreachable nodes, bypass
-    fillers, heuristic scores, search) on a dag_t poured from the device's lattice: the N-best files are the unmodified
-    reference's, line for line.  (The reference's astar.c needs its own pio.h on the compiler's command line to run on a
-    64-bit machine at all: oracle/Makefile.)"""
+    """-nbestdir: N-best lists by the LIBRARY's search (s3a_lattice_nbest, csrc/s3a_nbest.hip: dag_remove_unreachable,
+    dag_bypass_filler_nodes, dag_compute_hscr, dag_remove_bypass_links, then A* with the reference's heap, duplicate table and
+    arithmetic) on the device's lattice: the files are the unmodified reference's, byte for byte -- and so are the ones the
+    reference's OWN search writes on a dag_t poured from the same lattice (S3A_REF_NBEST=1, round 4's form: the A/B).  (The
+    reference's astar.c needs its own pio.h on the compiler's command line to run on a 64-bit machine at all: oracle/Makefile.)"""
     base = tidigits_args() if task == "tidigits" else rm_args()
+    nb = [] if "-nbest" in extra else ["-nbest", "20"]
     outs = {}
-    for tag, exe, env in (("ref", REFDEC, None), ("gpu", TST, dict(os.environ, S3A_UTT=lanes))):
+    for tag, exe, env in (("ref", REFDEC, None), ("gpu", TST, dict(os.environ, S3A_UTT=lanes)),
+                          ("gpu_refsearch", TST, dict(os.environ, S3A_UTT=lanes, S3A_REF_NBEST="1"))):
         d = tmp_path / f"nb_{tag}"
         d.mkdir()
-        outs[tag] = run(exe, base + extra + ["-nbestdir", str(d), "-nbest", "20", "-nbestext", "nbest"], tmp_path, tag, env=env) + (_files(str(d)),)
-    ref, gpu = outs["ref"], outs["gpu"]
+        outs[tag] = run(exe, base + extra + nb + ["-nbestdir", str(d), "-nbestext", "nbest"], tmp_path, tag, env=env) + (_files(str(d)),)
+    ref, gpu, gpu2 = outs["ref"], outs["gpu"], outs["gpu_refsearch"]
+    assert "N-Best search" in gpu[2] and "in the library" in gpu[2] and "in the library" not in gpu2[2]
     assert gpu[0] == ref[0] and gpu[1] == ref[1]
-    assert len(ref[3]) == (31 if task == "tidigits" else 20) and sorted(ref[3]) == sorted(gpu[3])
+    assert len(ref[3]) == (31 if task == "tidigits" else 20) and sorted(ref[3]) == sorted(gpu[3]) == sorted(gpu2[3])
     assert any(v.count(b"\nT ") > 3 for v in ref[3].values())          # (lists with several hypotheses)
+    for k in sorted(ref[3]):
+        assert gpu[3][k] == ref[3][k], k
+        assert gpu2[3][k] == ref[3][k], k
+
+
+def test_nbest_lists_on_the_hub4_shaped_task(tmp_path):
+    """20 k words, trigram, fillers inside the utterances: lattices of thousands of links, lists of 30 hypotheses"""
+    import test_gpu_dropin as TD
+    args = TD.synth_task("hub4", tmp_path, 4, 200)
+    outs = {}
+    for tag, exe, env in (("ref", REFDEC, None), ("gpu", TST, dict(os.environ, S3A_UTT="4"))):
+        d = tmp_path / f"nb_{tag}"
+        d.mkdir()
+        outs[tag] = TD.decode_task(exe, args + ["-nbestdir", str(d), "-nbest", "30", "-nbestext", "nbest"], tmp_path, tag, env) + (_files(str(d)),)
+    ref, gpu = outs["ref"], outs["gpu"]
+    assert gpu[0] == ref[0] and gpu[1] == ref[1] and len(ref[3]) == 4 and sorted(ref[3]) == sorted(gpu[3])
+    assert all(v.count(b"\nT ") >= 10 for v in ref[3].values())
     for k in sorted(ref[3]):
         assert gpu[3][k] == ref[3][k], k
 

@@ -100,3 +100,34 @@ def test_large_frames_prune_by_selection_lockstep(gpu_lib, seed, grid, kw):
     assert len(b["score"]) > 150
     if grid == 10:
         assert b["n_tie_frames"] > 0
+
+
+@pytest.mark.parametrize("seed,kw", [(21, dict(maxwpf=400, maxhist=400)), (22, dict(maxwpf=9, maxhist=30))])
+def test_frames_of_257_to_384_entries_are_ranked_a_thread_per_entry(gpu_lib, seed, kw):
+    """what a 256-thread build of the word level got wrong on RM1 utt_33 (profiles/r4_wl_threads_experiment.txt): a frame with more than
+    256 and at most WL_RANK_MAX = 384 entries above the pruning threshold is ranked all against all with a THREAD PER ENTRY -- the
+    workgroup must be at least that wide (static_assert in s3a_wordlevel.h; 512 threads since round 4, the frame's own workgroup inside
+    ku_frames).  Frames of exactly 260 .. 380 distinct word exits, a wide word beam so that all of them stay above the threshold, scores
+    on a coarse grid (ties inside the ranking)."""
+    rng = np.random.default_rng(seed)
+    t = OW.random_task(rng, n_word=500, n_ci=12, density=0.04, grid=10)
+    t["wbeam"] = -900000
+    tree_type = [0, 0, 0, -1, -1, -1]
+    n_word, n_filler = int(t["n_word"]), int(np.sum(t["is_filler"]))
+
+    def frame(ow, frm, total):
+        n_hist = ow.vh.contents.n_entry
+        wid = rng.permutation(n_word - n_filler)[:total]
+        cut = sorted(int(x) for x in rng.integers(0, total, 2))
+        trees = []
+        for k, (lo, hi) in enumerate(((0, cut[0]), (cut[0], cut[1]), (cut[1], total))):
+            w = wid[lo:hi].astype(np.int32)
+            scr = (rng.integers(-9000, -4000, len(w)) // 10 * 10 - 3000 * frm).astype(np.int32)
+            trees.append((0, w, scr, rng.integers(0, n_hist, len(w)).astype(np.int32)))
+        for k in range(3):
+            trees.append((-1, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)))
+        return trees
+    totals = [260, 300, 340, 380, 257, 384, 383, 258] * 3
+    fr = [((lambda ow, frm, n=n: frame(ow, frm, n)), -800000, -123456 - 7 * i) for i, n in enumerate(totals)]
+    a, b, n_calls = run_lockstep(gpu_lib, t, fr, tree_type, cap=1 << 18, cand_cap=1 << 19, **kw)
+    assert len(b["score"]) > 24 * (9 if "maxwpf" in kw and kw["maxwpf"] < 100 else 200)
