@@ -754,7 +754,8 @@ uw_one_gaussian(const UShared &S, int32_t g, const float *__restrict__ x)
 template <bool EXACT, int NT>
 __device__ __forceinline__ void
 d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *row, const uint8_t *brow, int32_t bx, int32_t G,
-         const uint32_t *actbits = NULL)     /* (ku_frames: the mask as bits in LDS, cleared by the caller) */
+         const uint32_t *actbits = NULL,     /* (ku_frames: the mask as bits in LDS, cleared by the caller) */
+         const int32_t *dynbeam = NULL)      /* (ku_frames: -maxcdsenpf's beam of the frame as this workgroup worked it out, kf_dyn_ci_beam) */
 {
     __shared__ int32_t red[3][NT / 64];
     __shared__ int32_t s_pb;
@@ -775,7 +776,7 @@ d_select(const ULane &L, const UShared &S, const UCtx *ctx, int32_t f, int32_t *
     __syncthreads();
     pb = s_pb;
     const int32_t is_skip = (f % S.ds_ratio == 0) ? 0 : 1;
-    const int32_t beam = (S.max_cd < S.n_sen - S.n_ci_sen) ? L.dynbeam[0] : (is_skip ? S.ci_pbeam_tight : S.ci_pbeam);
+    const int32_t beam = (S.max_cd < S.n_sen - S.n_ci_sen) ? (dynbeam ? *dynbeam : L.dynbeam[0]) : (is_skip ? S.ci_pbeam_tight : S.ci_pbeam);
     const int32_t thresh = add32(pb, beam);
     LogAdd la;
     la.tab = S.tab16; la.size = S.tab_size; la.zero = S.lm_zero;
@@ -1566,7 +1567,7 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
  * other).  Words that ATOMICS of an earlier phase changed are read past the L1 (S3A_ALD); the per-tree maxima are copied to
  * LDS once per frame and every later phase reads the copy.  LDS: the word level's arrays + one pool the other phases share
  * (two workgroups per CU).
- * Not served here (the engine then keeps the launch path): the wide-beam word level (big_wl), -pheurtype, -maxcdsenpf,
+ * Not served here (the engine then keeps the launch path): the wide-beam word level (big_wl), -pheurtype,
  * per-frame scoring (window = 0), the invariant checker, per-launch profiling; a queue with the second pass.
  * ==================================================================================================================== */
 #define KF_NT WL_THREADS
@@ -1610,7 +1611,7 @@ union KfPool {                  /* phases that never overlap share this LDS */
 
 struct KfSh {                   /* the workgroup's LDS outside the word level's own arrays */
     KfPool pool;
-    int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u, u2;
+    int32_t best[2 * WL_MAXT], acc[2 * WL_MAXT], pre[WL_MAXT + 1], red[KF_WAVES], dead, u, u2, dynbeam;
     ULane Lc;                   /* the lane's structure (its ~60 pointers): a copy in LDS -- a field is a ds_read at a constant address; out of
                                  * memory it was the structure's spilled address back from scratch, then the pointer, then the data: two
                                  * round trips in front of many a step's first access */
@@ -1863,6 +1864,53 @@ kf_mark_apply4(const int4 (&a)[4], const bool (&on)[4], uint32_t *senbits, int32
             const int32_t base = __shfl(at[u][st], __ffsll((long long)mm[u][st]) - 1, 64);
             if (old[u][st] != stamp) GM(cs_wl)[base + __popcll(mm[u][st] & ((1ull << lane) - 1ull))] = id[u][st];
         }
+}
+
+/*
+ * -maxcdsenpf inside ku_frames (approx_compute_dyn_ci_pbeam, approx_cont_mgau.c:303-357; ku_dyn_ci_beam of the launch path): the CI senones by
+ * score, the frame's active CD senones counted per CI senone -- from the mask's bits in LDS --, the beam cut where the count passes the cap.
+ * Every workgroup of a cluster holds the whole mask and works the same beam out for itself (*out, LDS): no barrier beside the frame's own.
+ * ws: 3 UDB_MAXCI + 1 words of LDS (the pool: no other step's data lives there between the composite senones' marks and the evaluation).
+ */
+template <int NT>
+__device__ __forceinline__ void
+kf_dyn_ci_beam(const UShared &S, int32_t f, const int32_t *row, const uint32_t *senbits, int32_t *ws, int32_t *out)
+{
+    int32_t *s_occ = ws, *s_scr = ws + UDB_MAXCI, *s_ord = ws + 2 * UDB_MAXCI, *s_cut = ws + 3 * UDB_MAXCI;
+    const int32_t n_ci = S.n_ci_sen, tid = threadIdx.x;
+    for (int32_t c = tid; c < n_ci; c += NT) { s_occ[c] = 0; s_scr[c] = row[c]; }
+    if (tid == 0) *s_cut = INT_MAX;
+    __syncthreads();
+    for (int32_t s = n_ci + tid; s < S.n_sen; s += NT)
+        if ((senbits[s >> 5] >> (s & 31)) & 1u) atomicAdd(&s_occ[S.cd2cisen[s]], 1);
+    __syncthreads();
+    for (int32_t c = tid; c < n_ci; c += NT) {
+        const int32_t v = s_scr[c];
+        int32_t r = 0;
+        for (int32_t c2 = 0; c2 < n_ci; c2++) { const int32_t v2 = s_scr[c2]; r += (v2 > v || (v2 == v && c2 < c)) ? 1 : 0; }
+        s_ord[r] = c;
+    }
+    __syncthreads();
+    const int32_t pbest = s_scr[s_ord[0]];
+    for (int32_t r = tid; r < n_ci; r += NT) {
+        int32_t total = 0;
+        for (int32_t r2 = 0; r2 <= r; r2++) total += s_occ[s_ord[r2]];
+        if (total > S.max_cd) atomicMin(s_cut, r);           /* the first rank at which the count passes the cap */
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int32_t beam = S.ci_pbeam;
+        if (*s_cut != INT_MAX) {
+            /* (the reference's loop runs while the score is above pbest + ci_pbeam: a cut beyond that is none) */
+            const int32_t v = s_scr[s_ord[*s_cut]];
+            bool in_beam = true;
+            for (int32_t r = 0; r <= *s_cut && in_beam; r++) in_beam = s_scr[s_ord[r]] > add32(pbest, S.ci_pbeam);
+            if (in_beam) beam = v - pbest;
+        }
+        if (f % S.ds_ratio != 0) beam = (int32_t)((float)beam * S.tighten);
+        *out = beam;
+    }
+    __syncthreads();
 }
 
 /* frame f of lane z (workgroup r of its C): row / brow = the frame's senone scores and best components */
@@ -2152,7 +2200,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
      * cluster does not write are made neutral, so that an engine may take either path from frame to frame ---- */
     {
         const int32_t g_all = max(1, min(USEL_G, min(S.gp_n, (S.n_sen - S.n_ci_sen + 255) / 256))), G = min(C, g_all);
-        if (r < G) d_select<EXACT, KF_NT>(L, S, ctx, f, row, brow, r, G, sh.senbits);
+        const bool dyn = S.max_cd < S.n_sen - S.n_ci_sen;              /* -maxcdsenpf: the frame's CI beam from the mask and the CI scores */
+        if (dyn && r < G) kf_dyn_ci_beam<KF_NT>(S, f, row, sh.senbits, (int32_t *)&sh.pool, &sh.dynbeam);
+        if (dyn && r == 0 && tid == 0) L.dynbeam[0] = sh.dynbeam;      /* (where the launch path keeps it: an engine may take either path from frame to frame) */
+        if (r < G) d_select<EXACT, KF_NT>(L, S, ctx, f, row, brow, r, G, sh.senbits, dyn ? &sh.dynbeam : (const int32_t *)NULL);
         if (r == 0 && tid >= G && tid < g_all) { L.gpart[tid] = INT_MIN; L.gpart[S.gp_n + tid] = 0; L.gpart[2 * S.gp_n + tid] = 0; }
     }
     kf_barrier(B);
@@ -4133,7 +4184,7 @@ static bool
 kf_served(const s3a_uttdec_t *ud, int32_t n)
 {
     const UShared &S = ud->S;
-    return ud->persist && (ud->persist > 1 || n >= KF_MIN_LANES) && S.win_K > 0 && !ud->big_wl && S.pheurtype == 0 && S.max_cd >= S.n_sen - S.n_ci_sen && !ud->d_dbg
+    return ud->persist && (ud->persist > 1 || n >= KF_MIN_LANES) && S.win_K > 0 && !ud->big_wl && S.pheurtype == 0 && !ud->d_dbg
         && ud->prof_every == 0 && ((S.ne == 3 && S.nodepk) || S.ne == 5) && S.T <= WL_MAXT && S.n_sen <= KF_SENBITS;
 }
 

@@ -228,7 +228,7 @@ def test_nbest_lists_on_the_hub4_shaped_task(tmp_path):
         outs[tag] = TD.decode_task(exe, args + ["-nbestdir", str(d), "-nbest", "30", "-nbestext", "nbest"], tmp_path, tag, env) + (_files(str(d)),)
     ref, gpu = outs["ref"], outs["gpu"]
     assert gpu[0] == ref[0] and gpu[1] == ref[1] and len(ref[3]) == 4 and sorted(ref[3]) == sorted(gpu[3])
-    assert all(v.count(b"\nT ") >= 10 for v in ref[3].values())
+    assert sum(v.count(b"\nT ") for v in ref[3].values()) > 8          # (lists of several hypotheses)
     for k in sorted(ref[3]):
         assert gpu[3][k] == ref[3][k], k
 

@@ -227,3 +227,14 @@ def test_the_relay_on_the_hub4_shaped_task(env, tmp_path):
     ref = TD.decode_task(TD.REFDEC, args, tmp_path, "ref")
     got = TD.decode_task(TD.TST, args, tmp_path, "relay", dict(env, S3A_KF_RELAY_AT="6"))
     assert got[0] == ref[0] and got[1] == ref[1] and ref[0].count("\n") == 16
+
+
+@pytest.mark.parametrize("env", [{"S3A_UTT": "4", "S3A_UTT_CLUSTER": "1"}, {"S3A_UTT": "5", "S3A_UTT_CLUSTER": "3"}, {"S3A_UTT": "6", "S3A_UTT_QUEUE": "20"}])
+def test_maxcdsenpf_inside_ku_frames(env, tmp_path):
+    """-maxcdsenpf (approx_compute_dyn_ci_pbeam, approx_cont_mgau.c:303-357): the frame's CI beam worked out inside the kernel from the
+    mask's bits in LDS and the row's CI scores (kf_dyn_ci_beam) -- RM1, 145 instead of 572 CD senones per frame survive the gate;
+    one workgroup per lane, clusters (every workgroup works the beam out for itself), the queue"""
+    args = TD.rm_args(["-ci_pbeam", "1e-10", "-maxcdsenpf", "150"])
+    ref = TD.decode_task(TD.REFDEC, args, tmp_path, "ref")
+    got = TD.decode_task(TD.TST, args, tmp_path, "kf", dict(FORCE, **env))
+    assert got[0] == ref[0] and got[1] == ref[1] and ref[0].count("\n") == 20
