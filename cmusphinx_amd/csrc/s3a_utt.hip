@@ -1567,7 +1567,7 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
  * other).  Words that ATOMICS of an earlier phase changed are read past the L1 (S3A_ALD); the per-tree maxima are copied to
  * LDS once per frame and every later phase reads the copy.  LDS: the word level's arrays + one pool the other phases share
  * (two workgroups per CU).
- * Not served here (the engine then keeps the launch path): the wide-beam word level (big_wl), -pheurtype,
+ * Not served here (the engine then keeps the launch path): -pheurtype,
  * per-frame scoring (window = 0), the invariant checker, per-launch profiling; a queue with the second pass.
  * ==================================================================================================================== */
 #define KF_NT WL_THREADS
@@ -1917,8 +1917,9 @@ kf_dyn_ci_beam(const UShared &S, int32_t f, const int32_t *row, const uint32_t *
 template <int NE, bool EXACT>
 __device__ __forceinline__ void
 kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict &dict, const WPar &par, KfSh &sh, KfBar &B, int32_t z,
-         int32_t r, int32_t C, int32_t f, int32_t *row, const uint8_t *brow, int32_t weak_possible)
+         int32_t r, int32_t C, int32_t f, int32_t *row, const uint8_t *brow, int32_t weak_flags)
 {
+    const int32_t weak_possible = weak_flags & 1, big_wl = weak_flags & 2;
     const int32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = S.T;
     const int32_t gtid = r * KF_NT + tid, gstride = C * KF_NT, gwave = r * KF_WAVES + wave, gwaves = C * KF_WAVES;
     /* where the frame's time goes (thread 0 of the cluster's first workgroup: one clock read per step) */
@@ -2744,7 +2745,24 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         const long long t_in = (long long)wall_clock64();
         const int32_t nx = d_dec_pack_frame_lds(S.N, T, bm, S.node_base, L.nact[cur], L.best, L.exits, L.nexit, L.hbin, L.misc, L.pack,
                                                 S.pack_max_exits, L.gpart, S.gp_n, L.nact[cur ^ 1], sh.pool.wl.hdr, sh.pool.wl.ex, WL_LDS_EX);
-        d_wordlevel_frame(L.w, ctx, L.pack, sh.pool.wl.hdr, nx <= WL_LDS_EX ? sh.pool.wl.ex : (const int32_t *)NULL, lm, dict, par, f, t_in);
+        if (big_wl) d_wl_big_begin(L.w, ctx, L.pack, dict, par);       /* wide beams: the candidate phases follow, chunked over the cluster */
+        else d_wordlevel_frame(L.w, ctx, L.pack, sh.pool.wl.hdr, nx <= WL_LDS_EX ? sh.pool.wl.ex : (const int32_t *)NULL, lm, dict, par, f, t_in);
+    }
+    if (big_wl) {
+        /* the wide-beam word level (tens of thousands of candidates per frame: configs[4]): the launch path's chip-wide phases
+         * ku_wl_p2 .. ku_wl_finish with the cluster's workgroups as the chunks' owners and the cluster barrier for the launch boundaries */
+        kf_barrier(B);
+        d_wl_big_p2(L.w, ctx, L.pack, lm, dict, par, f, r, C);
+        kf_barrier(B);
+        d_wl_big_p3(L.w, ctx, L.pack, dict, par, f, r, C);
+        kf_barrier(B);
+        d_wl_big_p4a(L.w, ctx, L.pack, par, f, r, C);
+        kf_barrier(B);
+        d_wl_big_p4b(L.w, ctx, L.pack, par, f, r, C);
+        kf_barrier(B);
+        d_wl_big_p5(L.w, ctx, L.pack, dict, par, f, r, C);
+        kf_barrier(B);
+        if (r == 0) d_wl_big_finish(L.w, ctx, L.pack, lm, dict, par, f);
     }
     kf_barrier(B);
     KF_STAMP(11);
@@ -4184,7 +4202,10 @@ static bool
 kf_served(const s3a_uttdec_t *ud, int32_t n)
 {
     const UShared &S = ud->S;
-    return ud->persist && (ud->persist > 1 || n >= KF_MIN_LANES) && S.win_K > 0 && !ud->big_wl && S.pheurtype == 0 && !ud->d_dbg
+    /* (a wide-beam engine -- big_wl, configs[4] -- is SERVED, word level and all, but keeps the launches unless asked: 23 000 HMMs and 300 000
+     * word-level candidates per lane-frame want the whole chip per step, not a cluster of 8 workgroups -- 64 lanes: 10.4 k frames/s through
+     * ku_frames against 30.5 k through the launches, 128 lanes 19.4 k : 36.1 k; profiles/r6_experiments.txt 8) */
+    return ud->persist && (ud->persist > 1 || (n >= KF_MIN_LANES && !ud->big_wl)) && S.win_K > 0 && S.pheurtype == 0 && !ud->d_dbg
         && ud->prof_every == 0 && ((S.ne == 3 && S.nodepk) || S.ne == 5) && S.T <= WL_MAXT && S.n_sen <= KF_SENBITS;
 }
 
@@ -4223,7 +4244,7 @@ kf_choose_c(s3a_uttdec_t *ud, int32_t n)
     const int32_t usable = kf_usable_per_xcd(ud), per_xcd = max(1, ud->kf_slots / 8), lanes_per_xcd = (n + 7) / 8;
     int32_t C = 1;
     if (ud->kf_cluster_opt > 0) C = ud->kf_cluster_opt;
-    else if (kf_alone(ud)) C = min(per_xcd / lanes_per_xcd, KF_CLUSTER_MAX(n));
+    else if (kf_alone(ud)) C = min(per_xcd / lanes_per_xcd, ud->big_wl ? 8 : KF_CLUSTER_MAX(n));     /* (wide beams: seven times the HMMs, a word level in chunks) */
     /* (KF_MAXC: what the kernel's LDS arrays -- the waves' segments, the cluster's scan -- are sized for) */
     return max(1, min(min(C, KF_MAXC), usable / lanes_per_xcd));
 }
@@ -4245,7 +4266,7 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J, int32_t C)
     ha->S = ud->S; ha->lm = ud->lm->d; ha->dict = ud->dict; ha->par = ud->par; ha->J = J;
     HIPCHK(hipMemcpyAsync(da, ha, sizeof(KfArgs), hipMemcpyHostToDevice, ud->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(KF_NT), 0, ud->stream, ud->d_lanes, (const KfArgs *)da, n, C,
-                       ud->d_kfbar, ud->weak_possible, ud->persist < 3 ? 1 : 0);
+                       ud->d_kfbar, (ud->weak_possible ? 1 : 0) | (ud->big_wl ? 2 : 0), ud->persist < 3 ? 1 : 0);
     HIPCHK(hipGetLastError());
     return S3A_OK;
 }

@@ -238,3 +238,16 @@ def test_maxcdsenpf_inside_ku_frames(env, tmp_path):
     ref = TD.decode_task(TD.REFDEC, args, tmp_path, "ref")
     got = TD.decode_task(TD.TST, args, tmp_path, "kf", dict(FORCE, **env))
     assert got[0] == ref[0] and got[1] == ref[1] and ref[0].count("\n") == 20
+
+
+@pytest.mark.parametrize("env", [{"S3A_UTT": "2", "S3A_UTT_CLUSTER": "4"}, {"S3A_UTT": "3", "S3A_UTT_CLUSTER": "1"}, {"S3A_UTT": "2", "S3A_UTT_QUEUE": "3", "S3A_UTT_CLUSTER": "7"}])
+def test_wide_beam_word_level_inside_ku_frames(env, tmp_path):
+    """configs[4] (8000 senones x 32 Gaussians, -beam 1e-120 -pbeam 1e-100 -wbeam 1e-80 -maxhmmpf 100000: > 20 000 word-level candidates
+    per frame): the word level's candidate phases chunked over the lane's cluster with the cluster barrier between them (d_wl_big_p2 ..
+    finish inside kf_frame) -- clusters of 4 and 7, one workgroup alone (every chunk its own), the queue"""
+    args = TD.synth_task("wsj", tmp_path, 3, 50, env=dict(TASK_BEAM="1e-120", TASK_WBEAM="1e-80")) + ["-pbeam", "1e-100", "-maxhmmpf", "100000"]
+    ref = TD.decode_task(TD.REFDEC, args, tmp_path, "ref")
+    got = TD.decode_task(TD.TST, args, tmp_path, "kf", dict(FORCE, **env))
+    assert got[0] == ref[0] and got[1] == ref[1] and ref[0].count("\n") == 3
+    wl = [l for l in got[2] if "word level: at most" in l]
+    assert wl and int(wl[0].split("at most")[1].split()[0]) > 20000, wl
