@@ -63,7 +63,19 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VEC_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak (FMA counted as 2 flops)
 REFDEC = os.path.join(ROOT, "oracle", "_ref", "sphinx3_decode")
 SHIM = os.path.join(ROOT, "oracle", "_ref", "ref_s3amd_tst_decode")
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # tools/pmc_traffic.py: HBM bytes per launch and kernel
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # tools/gpu_round6.sh: HBM bytes per lane-frame of ku_frames (PMC passes)
+
+
+def csrc_hash():
+    """what ties profiles/pmc_traffic.json to the library that runs: sha256 over the kernels' sources (cmusphinx_amd/csrc/*.hip, *.h, *.c) --
+    the PMC passes' script stamps the file with it, and a file whose stamp is another source's is not used"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cmusphinx_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".h", ".c")):
+            h.update(n.encode()); h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def physical_cores():
@@ -260,7 +272,6 @@ def wide_beam_leg(lib, d, lanes, n_frames, fast, n_check=64):
         return {"error": "bundle export failed"}
     ctl = os.path.join(t, "ctl")
     utts = [l.split()[0] for l in open(ctl) if l.strip()]
-    refs = [run_reference(targs, ctl, i, 1, t, f"wref{i}_") for i in range(min(n_check, len(utts)))]     # (runs beside the device legs)
     hfeat = [s3io.read_mfc(os.path.join(t, "feat", u + ".mfc")) for u in utts]
     dec = bundle.Decoder(bpath, lanes, precision=lib.GMM_FAST if fast else lib.GMM_EXACT, max_frames=max(len(f) for f in hfeat) // 39 + 8)
     D4x4 = 4 * ((dec.veclen + 3) // 4)
@@ -280,6 +291,9 @@ def wide_beam_leg(lib, d, lanes, n_frames, fast, n_check=64):
     dec.ud.decode_dev(fdev, nfr, D4x4)
     prof = dec.ud.profile()
     dec.ud.set_profile(0)
+    # (the reference's processes only now: 64 of them beside the timed decode took the launching thread's cores -- the launch path enqueues
+    # ~20 launches per frame -- and cost the leg up to a fifth of its rate from run to run)
+    refs = [run_reference(targs, ctl, i, 1, t, f"wref{i}_") for i in range(min(n_check, len(utts)))]
     K = max(1, dec.ud.window())
     pf = {k: (us / n / (K if k == "ku_score_window" else 1)) for k, (us, n) in prof.items() if n > 0}
     tot = sum(pf.values())
@@ -815,6 +829,9 @@ def main():
         S, Sci, D, Cc = b["n_sen"], b["n_ci_sen"], dec.veclen, dec.g.C
         K = max(1, dec.ud.window())
         pmc = json.load(open(PMC_FILE)) if os.path.exists(PMC_FILE) else {}
+        pmc_stale = bool(pmc) and pmc.get("csrc_hash") != csrc_hash()
+        if pmc_stale:                   # (measured on other kernels than the ones that just ran: no traffic figure rather than a wrong one)
+            pmc = {"source": f"profiles/pmc_traffic.json is stale (its csrc_hash {pmc.get('csrc_hash')} is not this tree's {csrc_hash()}): not used"}
         prof, prof_alone, kern, search, roof, roof_scoring = {}, {}, {}, None, None, None
         fr_rank = sum(nfr[k] for k in my_share(0)[0])           # (this rank's frames of a step: the parts are this rank's engines')
         if persistent:
@@ -832,13 +849,17 @@ def main():
             alg_frames = fr_rank * per_lane_frame
             kf_gbs = alg_frames / (frames_ms * 1e-3) / 1e9
             tr = pmc.get("kernels", {}).get("ku_frames", {})
-            traffic = int(tr["hbm_bytes_per_lane_frame"] * fr_rank / max(n_kf, 1)) if tr.get("hbm_bytes_per_lane_frame") else None
+            # (a call of ku_frames is a chain of launches since round 6 -- the relay --: per-launch figures are averages over the chain's
+            # launches, as rocprofv3's kernel statistics count them)
+            n_disp = max(n_kf, 1) * (1 + decs[0].ud.last_relay())
+            traffic = int(tr["hbm_bytes_per_lane_frame"] * fr_rank / n_disp) if tr.get("hbm_bytes_per_lane_frame") else None
             flops = 4.0 * S * Cc * D * fr_rank
             sc_tfl = flops / (score_ms * 1e-3) / 1e12
             roof = {"kernel": "ku_frames", "bound": "hbm", "achieved": round(kf_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(kf_gbs / HBM_PEAK_GBS, 5), "avg_launch_us": round(1e3 * frames_ms / max(n_kf / len(decs), 1), 1),
-                    "launches_timed": int(n_kf), "traffic": traffic, "traffic_source": pmc.get("source") if traffic is not None else None,
-                    "algorithmic_bytes_per_launch": int(alg_frames / max(n_kf, 1)), "algorithmic_bytes_per_lane_frame": round(per_lane_frame, 1),
+                    "frac": round(kf_gbs / HBM_PEAK_GBS, 5), "avg_launch_us": round(1e3 * frames_ms / max(n_disp / len(decs), 1), 1),
+                    "launches_timed": int(n_disp), "launches_per_call": 1 + decs[0].ud.last_relay(),
+                    "traffic": traffic, "traffic_source": pmc.get("source") if (traffic is not None or pmc_stale) else None,
+                    "algorithmic_bytes_per_launch": int(alg_frames / n_disp), "algorithmic_bytes_per_lane_frame": round(per_lane_frame, 1),
                     "lanes_in_launch": round(lanes_bench, 1), "workgroups_per_lane": parts[0]["cluster"],
                     "measured": "HIP events on the engine's stream around ku_frames, last timed step",
                     "note": "the dominant kernel by device time (`kernels`): ONE launch decodes a queue part -- every lane its utterances, frame "
@@ -855,7 +876,7 @@ def main():
                             "note": "every frame of the step scored BEFORE the search (rows [frame][senone] in HBM, 5 B per senone and frame); hub4 "
                                     "single-frame scoring (one frame per model pass, HBM-bound) is in `scoring.hub4.frame_sync`: north_star's >= 0.60 "
                                     "of HBM peak is NOT met there at B = 1"}
-            kern = {"ku_frames": {"avg_launch_us": roof["avg_launch_us"], "launches_timed": int(n_kf), "ms_per_step": round(frames_ms, 2),
+            kern = {"ku_frames": {"avg_launch_us": roof["avg_launch_us"], "launches_timed": int(n_disp), "ms_per_step": round(frames_ms, 2),
                     "share": round(frames_ms / tot_ms, 4)},
                     "ku_score_window": {"avg_launch_us": roof_scoring["avg_launch_us"], "launches_timed": int(n_score), "ms_per_step": round(score_ms, 2),
                                         "share": round(score_ms / tot_ms, 4)}}
@@ -983,6 +1004,10 @@ def main():
             res["ps_fwdtree"] = ps_fwdtree_leg(d, args.ps_lanes)
         if world == 1 and not args.no_wide_beam:
             res["wide_beam"] = wide_beam_leg(lib, d, args.wide_lanes, args.wide_frames, args.fast)
+            if args.wide_lanes < 128:           # (what more lanes buy the launches of this task: the same leg with 128 utterances, 16 of them compared)
+                w2 = wide_beam_leg(lib, os.path.join(d, "wide128"), 128, args.wide_frames, args.fast, n_check=16)
+                keep = ("lanes", "frames", "device_ms", "frames_per_sec", "xRT", "identical_to_reference", "error")
+                res["wide_beam"]["lanes_128"] = {k: w2[k] for k in keep if k in w2}
         if weak:
             res["weak_scaling"] = weak
         if cpu:

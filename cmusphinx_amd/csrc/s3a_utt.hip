@@ -4798,6 +4798,25 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     const bool graph_mode = ud->use_graph && ud->prof_every == 0;
     /* ku_frames (KF_QUEUE): the lanes take the utterances themselves -- no schedule, no refill events, no window boundaries */
     const bool kfq = !graph_mode && kf_served(ud, min(ud->n_lanes, n_utt)) && !ud->dag;
+    /* ... and with the second pass (round 6): the queue as GROUPS of at most n_lanes utterances, longest first -- a group is lane z = its
+     * z-th utterance from the first frame to the last in ONE ku_frames launch (KF_STATIC, with the relay), then every lane's hypothesis,
+     * vithist_utt_end + the second pass while the tables are still the utterances' own, and lextree_utt_end; everything enqueued, nothing
+     * waited for between groups (utterances of like length share a group, so a group's lanes end together).  Before: the frame as launches
+     * with refill events, or -- asked for -- window blocks, the regime that lost to the launches. */
+    bool kfd = !graph_mode && kf_served(ud, min(ud->n_lanes, n_utt)) && ud->dag != NULL;
+    std::vector<int32_t> kfd_order;
+    if (kfd) {
+        kfd_order.resize((size_t)n_utt);
+        for (int32_t u = 0; u < n_utt; u++) kfd_order[u] = u;
+        std::stable_sort(kfd_order.begin(), kfd_order.end(), [&](int32_t a, int32_t b) { return n_frames[a] > n_frames[b]; });
+        size_t rows = 0, worst = 0;
+        for (int32_t k = 0; k < n_utt; k++) {
+            if (k % ud->n_lanes == 0) rows = 0;
+            rows += (size_t)max(n_frames[kfd_order[k]], 0);
+            worst = max(worst, rows);
+        }
+        if (worst > sb_budget_rows(ud)) kfd = false;            /* (a group's scores do not fit: the launches) */
+    }
     /* utterances begin at window boundaries (the look-ahead pass scores K frames of all lanes); in graph mode at the blocks' */
     const int32_t n = min(ud->n_lanes, n_utt), E = graph_mode ? graph_block_frames(ud) : (S.win_K > 0 ? S.win_K : 1), D4x4 = S.D4 * 4, T = S.T;
     int32_t rc;
@@ -4839,10 +4858,17 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     std::vector<Ev> evs;
     std::vector<int32_t> sched, u_lane((size_t)n_utt), u_f0((size_t)n_utt), last_utt((size_t)n, -1);
     if ((rc = q_grow(&ud->q_ctx_d, &ud->q_ctx_h, &ud->q_ctx_cap, (size_t)n_utt, "contexts")) != S3A_OK) return rc;
-    if (kfq) {
+    if (kfq || kfd) {
         for (int32_t u = 0; u < n_utt; u++)
             if ((rc = utt_context(ud, ud->q_ctx_h[u], fd[u], n_frames[u], 1, 0, u)) != S3A_OK) return rc;
         for (int32_t z = 0; z < n; z++) ud->lane[z].nfr = 0;
+        if (kfd) {              /* the groups' lane / utterance lists: [lanes 0 .. m - 1][their utterances] per group */
+            for (int32_t k0 = 0; k0 < n_utt; k0 += ud->n_lanes) {
+                const int32_t m = min(ud->n_lanes, n_utt - k0);
+                for (int32_t z = 0; z < m; z++) sched.push_back(z);
+                for (int32_t z = 0; z < m; z++) { sched.push_back(kfd_order[k0 + z]); last_utt[z] = kfd_order[k0 + z]; }
+            }
+        }
     }
     else {
         const int32_t fe = s3a_queue_schedule(n, E, n_utt, n_frames, u_lane.data(), u_f0.data());
@@ -4939,6 +4965,46 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     size_t ei = 0;
     if (kfq) {
         if (rc == S3A_OK) rc = kf_decode_queue(ud, n_utt, fd.data(), n_frames, B, P, wcount);
+    }
+    else if (kfd) {
+        /* every group's scoring groups and rows described up front (the pinned tables must not change under the copies in flight) */
+        size_t groups = 0, max_rows = 0;
+        std::vector<size_t> g_at(1, 0);
+        std::vector<const float *> gf((size_t)n_utt);
+        std::vector<int32_t> gn((size_t)n_utt);
+        for (int32_t k = 0; k < n_utt; k++) { gf[k] = fd[kfd_order[k]]; gn[k] = n_frames[kfd_order[k]]; groups += (size_t)(gn[k] + UW_FB - 1) / UW_FB; }
+        for (int32_t k0 = 0; k0 < n_utt; k0 += ud->n_lanes) {
+            size_t rows = 0;
+            for (int32_t k = k0; k < min(n_utt, k0 + ud->n_lanes); k++) rows += (size_t)gn[k];
+            max_rows = max(max_rows, rows);
+        }
+        if (rc == S3A_OK) rc = sb_reserve(ud, max_rows, groups, (size_t)n_utt);
+        for (int32_t k0 = 0; k0 < n_utt && rc == S3A_OK; k0 += ud->n_lanes)         /* (rows restart per group: sb_describe; row0 by position in the order) */
+            g_at.push_back(g_at.back() + sb_describe(ud, gf.data(), gn.data(), k0, min(n_utt, k0 + ud->n_lanes), g_at.back()));
+        if (rc == S3A_OK && (hipMemcpyAsync(ud->sb_gdesc_d, ud->sb_gdesc_h, g_at.back() * sizeof(UwGroup), hipMemcpyHostToDevice, ud->stream) != hipSuccess
+                             || hipMemcpyAsync(ud->sb_row0_d, ud->sb_row0_h, (size_t)n_utt * 8, hipMemcpyHostToDevice, ud->stream) != hipSuccess)) rc = S3A_EHIP;
+        ud->kf_n_score = ud->kf_n_frames = 0;
+        size_t gi = 0;
+        for (int32_t k0 = 0; k0 < n_utt && rc == S3A_OK; k0 += ud->n_lanes, gi++) {
+            const int32_t m = min(ud->n_lanes, n_utt - k0);
+            const int32_t *bl = ud->q_sched_d + (size_t)2 * k0, *bu = bl + m;
+            hipLaunchKernelGGL(ku_lanes_begin, dim3(32, 1, m), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, B, bl, bu, (const UCtx *)ud->q_ctx_d);
+            kf_mark(ud);
+            if ((rc = sb_score(ud, g_at[gi], g_at[gi + 1] - g_at[gi])) != S3A_OK) break;
+            kf_mark(ud);
+            KfJob J;
+            memset(&J, 0, sizeof J);
+            J.mode = KF_STATIC; J.row0 = ud->sb_row0_d + k0; J.scores = ud->sb_scores; J.bests = ud->sb_bests;
+            if ((rc = kf_launch_chain(ud, m, J)) != S3A_OK) break;
+            ud->kf_n_frames++;
+            kf_mark(ud);
+            hipLaunchKernelGGL(ku_hyp, dim3(m), dim3(UH_T), 0, ud->stream, ud->d_lanes, ud->lm->d, ud->dict, P, ud->q_hdr_d, ud->q_words_d, wcount, bl, bu);
+            if ((rc = s3a_dagpass_enqueue_lanes(ud->dag, bl, m, ud->stream)) != S3A_OK) break;
+            hipLaunchKernelGGL(ku_dag_store, dim3(m), dim3(UH_T), 0, ud->stream, ud->d_lanes, s3a_dagpass_dev_lanes(ud->dag), s3a_dagpass_hyp_cap(ud->dag),
+                               ud->q_dio_d, ud->q_dw_d, ud->q_dio_d + (size_t)n_utt * DG_IO_N, (int32_t)wtotal, bl, bu);
+            hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * T, m), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, bl, c.n_word);
+            if (hipGetLastError() != hipSuccess) { s3a_set_error("s3a_uttdec_decode_queue: a launch of the grouped second pass failed"); rc = S3A_EHIP; }
+        }
     }
     else if (graph_mode) {
         hipGraphExec_t ge = NULL;

@@ -234,7 +234,9 @@ def test_nbest_lists_on_the_hub4_shaped_task(tmp_path):
 
 
 @pytest.mark.parametrize("task,lanes,queue,extra", [("tidigits", "4", "31", []), ("tidigits", "7", "16", ["-bestpathlw", "14", "-min_endfr", "1"]),
-                                                     ("rm1", "6", "20", []), ("rm1", "3", "20", ["-maxlpf", "5"])])
+                                                     ("rm1", "6", "20", []), ("rm1", "3", "20", ["-maxlpf", "5"]),
+                                                     # from 8 lanes on (round 6): groups of static ku_frames launches with the pass behind each
+                                                     ("tidigits", "9", "31", ["-bestpathlw", "14", "-min_endfr", "1"]), ("rm1", "8", "20", ["-maxlpf", "5"])])
 def test_second_pass_inside_a_queue_with_lane_refill(task, lanes, queue, extra, tmp_path):
     """-bestpath 1 with S3A_UTT_QUEUE: a lane that has ended runs vithist_utt_end + the second pass at its refill event,
     before its history table is reused; -hyp / -hypseg are the unmodified reference's (ragged utterances, every lane

@@ -88,8 +88,12 @@ def test_queue_reuse_overflow_and_static_decodes(gpu_lib, tidigits_bundle, persi
     TU.test_hypothesis_records_are_fixed_size_and_self_contained(gpu_lib, tidigits_bundle)
 
 
-def test_second_pass_keeps_window_blocks(gpu_lib, tidigits_bundle, persist):
-    """KF_WINDOW: a queue with -bestpath 1 runs ku_frames block by block between the refill events"""
+def test_second_pass_inside_a_queue_as_groups(gpu_lib, tidigits_bundle, persist, monkeypatch):
+    """a queue with -bestpath 1 (round 6): groups of at most n_lanes utterances, longest first, each ONE KF_STATIC launch, then the lanes'
+    hypotheses, vithist_utt_end + the second pass on the lanes' own tables, lextree_utt_end -- nothing waited for between groups; when a
+    group's scores do not fit the score buffer (S3A_UTT_SCORE_ROWS): K-frame window blocks between refill events, as before"""
+    TQ.test_second_pass_inside_the_queue_through_the_c_abi(gpu_lib, tidigits_bundle)
+    monkeypatch.setenv("S3A_UTT_SCORE_ROWS", "90")
     TQ.test_second_pass_inside_the_queue_through_the_c_abi(gpu_lib, tidigits_bundle)
 
 
