@@ -62,6 +62,8 @@ int32_t s3a_dagpass_finish(s3a_dagpass_t *dp, int32_t n, hipStream_t stream);   
 int32_t s3a_dagpass_prepare(s3a_dagpass_t *dp, hipStream_t stream);
 int32_t s3a_dagpass_enqueue_lanes(s3a_dagpass_t *dp, const int32_t *lane_ids_dev, int32_t n, hipStream_t stream);
 const DagLane *s3a_dagpass_dev_lanes(const s3a_dagpass_t *dp);
+int32_t s3a_dagpass_lattice_lane(s3a_dagpass_t *dp, int32_t lane, s3a_lat_info_t *info, s3a_lat_node_t *nodes, int32_t node_cap,
+                                 s3a_lat_link_t *links, int32_t link_cap);
 int32_t s3a_dagpass_hyp_cap(const s3a_dagpass_t *dp);
 
 

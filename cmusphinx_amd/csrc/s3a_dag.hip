@@ -836,6 +836,16 @@ s3a_dagpass_lattice(s3a_dagpass_t *dp, int32_t lane, s3a_lat_info_t *info, s3a_l
                     s3a_lat_link_t *links, int32_t link_cap)
 {
     if (!dp || !info || lane < 0 || lane >= dp->n_run) return S3A_EINVAL;
+    return s3a_dagpass_lattice_lane(dp, lane, info, nodes, node_cap, links, link_cap);
+}
+
+/* the same for any lane whose pass has run and whose stream is synchronised (the engine's queue: a group's lanes, before the next group
+ * takes them) */
+int32_t
+s3a_dagpass_lattice_lane(s3a_dagpass_t *dp, int32_t lane, s3a_lat_info_t *info, s3a_lat_node_t *nodes, int32_t node_cap,
+                         s3a_lat_link_t *links, int32_t link_cap)
+{
+    if (!dp || !info || lane < 0 || lane >= dp->n_lanes) return S3A_EINVAL;
     HIPCHK(hipSetDevice(dp->device));
     const DagLane &L = dp->lane[lane];
     int32_t io[DG_IO_N], st2[2];

@@ -3306,6 +3306,9 @@ struct s3a_uttdec_s {
     int32_t *q_dio_d, *q_dio_h; size_t q_dio_cap;       /* the second pass inside a queue: [n_utt][DG_IO_N] + the word counter */
     int32_t *q_dw_d, *q_dw_h; size_t q_dw_cap, q_dw_hcap;   /* its words, packed */
     int32_t q_dag;              /* the last queue ran the second pass */
+    int32_t q_keep_lat;         /* s3a_uttdec_queue_keep_lattices: the queue's lattices are read back group by group (event by event) */
+    struct QLat { s3a_lat_info_t info; std::vector<s3a_lat_node_t> nodes; std::vector<s3a_lat_link_t> links; int32_t have; };
+    std::vector<QLat> q_lat;    /* [queue] ... and kept per utterance until the next decode */
     /* ku_frames: the frames of a window as one launch */
     int32_t persist;            /* the engine's configuration is served and the option allows it */
     int32_t kf_cluster_opt;     /* s3a_uttdec_opts_t.cluster */
@@ -3577,7 +3580,7 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
     ud->lm = lm; ud->cs = cs; ud->g = g; ud->n_lanes = n_lanes; ud->max_frames = max_frames;
     ud->cfg = *cfg;
     ud->d_lanes = NULL; ud->d_lcmap = NULL; ud->n_utt = 0; ud->last_decode_ms = 0.0; ud->prof_every = 0;
-    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->use_graph = 0; ud->d_fgbase = NULL; ud->q_n = 0; ud->q_feat_d = ud->q_feat_h = NULL; ud->q_ctx_d = ud->q_ctx_h = NULL; ud->q_sched_d = ud->q_sched_h = NULL; ud->q_hdr_d = ud->q_hdr_h = NULL; ud->q_words_d = ud->q_words_h = NULL; ud->q_dio_d = ud->q_dio_h = NULL; ud->q_dw_d = ud->q_dw_h = NULL; ud->q_dio_cap = ud->q_dw_cap = ud->q_dw_hcap = 0; ud->q_dag = 0; ud->q_feat_cap = ud->q_ctx_cap = ud->q_sched_cap = ud->q_hdr_cap = ud->q_words_cap = ud->q_words_hcap = 0; ud->h_ctx_up = NULL; ud->h_ctx_dn = NULL; ud->d_hyp_hdr = ud->h_hyp_hdr = ud->d_hyp_words = ud->h_hyp_words = NULL; ud->hyp_wcap = 0; ud->n_pset = proto->n_pset;
+    ud->device = 0; ud->ev0 = ud->ev1 = NULL; ud->dag = NULL; ud->keep_tables = 1; ud->tables_fetched = 0; ud->use_graph = 0; ud->d_fgbase = NULL; ud->q_n = 0; ud->q_feat_d = ud->q_feat_h = NULL; ud->q_ctx_d = ud->q_ctx_h = NULL; ud->q_sched_d = ud->q_sched_h = NULL; ud->q_hdr_d = ud->q_hdr_h = NULL; ud->q_words_d = ud->q_words_h = NULL; ud->q_dio_d = ud->q_dio_h = NULL; ud->q_dw_d = ud->q_dw_h = NULL; ud->q_dio_cap = ud->q_dw_cap = ud->q_dw_hcap = 0; ud->q_dag = 0; ud->q_keep_lat = 0; ud->q_feat_cap = ud->q_ctx_cap = ud->q_sched_cap = ud->q_hdr_cap = ud->q_words_cap = ud->q_words_hcap = 0; ud->h_ctx_up = NULL; ud->h_ctx_dn = NULL; ud->d_hyp_hdr = ud->h_hyp_hdr = ud->d_hyp_words = ud->h_hyp_words = NULL; ud->hyp_wcap = 0; ud->n_pset = proto->n_pset;
     (void)hipGetDevice(&ud->device);
     memset(ud->prof_us, 0, sizeof ud->prof_us); memset(ud->prof_n, 0, sizeof ud->prof_n);
     memset(&ud->dict, 0, sizeof ud->dict);
@@ -4784,6 +4787,23 @@ s3a_queue_schedule(int32_t n_lanes, int32_t boundary, int32_t n_utt, const int32
     }
 }
 
+/* s3a_uttdec_queue_keep_lattices: the lanes `lanes[0 .. n)` have just gone through the second pass for the utterances utts[]: wait for the
+ * stream and read their lattices back, before the lanes' tables are reused (the price of lattices out of a queue: the host waits once per
+ * group / refill event) */
+static int32_t
+q_keep_lattices(s3a_uttdec_t *ud, const int32_t *lanes, const int32_t *utts, int32_t n)
+{
+    HIPCHK(hipStreamSynchronize(ud->stream));
+    for (int32_t i = 0; i < n; i++) {
+        s3a_uttdec_s::QLat &q = ud->q_lat[(size_t)utts[i]];
+        q.have = 0;
+        if (s3a_dagpass_lattice_lane(ud->dag, lanes[i], &q.info, NULL, 0, NULL, 0) != S3A_OK) continue;      /* (no lattice: the pass's status says why) */
+        q.nodes.resize((size_t)q.info.n_nodes + 1); q.links.resize((size_t)q.info.n_links + 1);
+        if (s3a_dagpass_lattice_lane(ud->dag, lanes[i], &q.info, q.nodes.data(), q.info.n_nodes, q.links.data(), q.info.n_links) == S3A_OK) q.have = 1;
+    }
+    return S3A_OK;
+}
+
 static int32_t
 uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, const int32_t *n_frames, int32_t feat_stride,
                     bool feat_on_device)
@@ -4821,6 +4841,8 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     const int32_t n = min(ud->n_lanes, n_utt), E = graph_mode ? graph_block_frames(ud) : (S.win_K > 0 ? S.win_K : 1), D4x4 = S.D4 * 4, T = S.T;
     int32_t rc;
     ud->n_utt = 0; ud->q_n = 0;
+    ud->q_lat.clear();
+    if (ud->q_keep_lat && ud->dag) { ud->q_lat.resize((size_t)n_utt); for (auto &q : ud->q_lat) q.have = 0; }
     std::vector<size_t> row0((size_t)n_utt + 1, 0);
     for (int32_t u = 0; u < n_utt; u++) {
         if (n_frames[u] <= 0 || n_frames[u] > ud->max_frames) { s3a_set_error("s3a_uttdec_decode_queue: utterance %d has %d frames (1..%d)", u, n_frames[u], ud->max_frames); return S3A_EINVAL; }
@@ -4941,6 +4963,10 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
                 if (drc != S3A_OK) return drc;
                 hipLaunchKernelGGL(ku_dag_store, dim3(e.n_end), dim3(UH_T), 0, ud->stream, ud->d_lanes, s3a_dagpass_dev_lanes(ud->dag), s3a_dagpass_hyp_cap(ud->dag),
                                    ud->q_dio_d, ud->q_dw_d, ud->q_dio_d + (size_t)n_utt * DG_IO_N, (int32_t)wtotal, el, eu);
+                if (ud->q_keep_lat) {
+                    const int32_t krc = q_keep_lattices(ud, sched.data() + e.o_el, sched.data() + e.o_el + e.n_end, e.n_end);
+                    if (krc != S3A_OK) return krc;
+                }
             }
             hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * T, e.n_end), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, el, c.n_word);
         }
@@ -5002,6 +5028,7 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
             if ((rc = s3a_dagpass_enqueue_lanes(ud->dag, bl, m, ud->stream)) != S3A_OK) break;
             hipLaunchKernelGGL(ku_dag_store, dim3(m), dim3(UH_T), 0, ud->stream, ud->d_lanes, s3a_dagpass_dev_lanes(ud->dag), s3a_dagpass_hyp_cap(ud->dag),
                                ud->q_dio_d, ud->q_dw_d, ud->q_dio_d + (size_t)n_utt * DG_IO_N, (int32_t)wtotal, bl, bu);
+            if (ud->q_keep_lat && (rc = q_keep_lattices(ud, sched.data() + (size_t)2 * k0, sched.data() + (size_t)2 * k0 + m, m)) != S3A_OK) break;
             hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * T, m), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, bl, c.n_word);
             if (hipGetLastError() != hipSuccess) { s3a_set_error("s3a_uttdec_decode_queue: a launch of the grouped second pass failed"); rc = S3A_EHIP; }
         }
@@ -5315,6 +5342,34 @@ s3a_uttdec_queue_bestpath_hyp(s3a_uttdec_t *ud, int32_t utt, const char *uttid, 
         s3a_hyp_word_t &o = words[q];
         o.wid = w[6 * q]; o.sf = w[6 * q + 1]; o.ef = w[6 * q + 2]; o.ascr = w[6 * q + 3]; o.lscr = w[6 * q + 4]; o.scale = w[6 * q + 5];
     }
+    return S3A_OK;
+}
+
+/* lattices out of a queue: asked for before s3a_uttdec_decode_queue*, the lanes' lattices are read back behind every group's (refill
+ * event's) second pass and kept per utterance until the next decode */
+extern "C" int32_t
+s3a_uttdec_queue_keep_lattices(s3a_uttdec_t *ud, int32_t on)
+{
+    if (!ud || !ud->dag) { s3a_set_error("s3a_uttdec_queue_keep_lattices: no second pass on this engine (s3a_uttdec_enable_bestpath)"); return S3A_EINVAL; }
+    ud->q_keep_lat = on != 0;
+    return S3A_OK;
+}
+
+extern "C" int32_t
+s3a_uttdec_queue_lattice(s3a_uttdec_t *ud, int32_t utt, s3a_lat_info_t *info, s3a_lat_node_t *nodes, int32_t node_cap, s3a_lat_link_t *links,
+                         int32_t link_cap)
+{
+    if (!ud || !info || utt < 0 || utt >= ud->q_n || (size_t)utt >= ud->q_lat.size()) {
+        s3a_set_error("s3a_uttdec_queue_lattice: no kept lattices (s3a_uttdec_queue_keep_lattices before the queue's decode) or bad utterance");
+        return S3A_EINVAL;
+    }
+    const s3a_uttdec_s::QLat &q = ud->q_lat[(size_t)utt];
+    if (!q.have) { s3a_set_error("s3a_uttdec_queue_lattice: utterance %d has no lattice (its second pass's status says why)", utt); return S3A_EUNSUP; }
+    *info = q.info;
+    if (!nodes || !links) return S3A_OK;
+    if (node_cap < q.info.n_nodes || link_cap < q.info.n_links) { s3a_set_error("s3a_uttdec_queue_lattice: buffers too small"); return S3A_EINVAL; }
+    memcpy(nodes, q.nodes.data(), (size_t)q.info.n_nodes * sizeof(s3a_lat_node_t));
+    memcpy(links, q.links.data(), (size_t)q.info.n_links * sizeof(s3a_lat_link_t));
     return S3A_OK;
 }
 

@@ -212,6 +212,8 @@ _SIGS = {
     "s3a_uttdec_frame_dbg": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_uttdec_last_parts": (C.c_int32, [C.c_void_p] + [C.c_void_p] * 5),
     "s3a_uttdec_last_relay": (C.c_int32, [C.c_void_p]),
+    "s3a_uttdec_queue_keep_lattices": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "s3a_uttdec_queue_lattice": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "s3a_uttdec_n_lanes": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_window": (C.c_int32, [C.c_void_p]),
     "s3a_uttdec_enable_pheur": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),

@@ -1046,11 +1046,18 @@ int32_t s3a_uttdec_enable_bestpath(s3a_uttdec_t *ud, const s3a_dag_cfg_t *cfg, i
 int32_t s3a_uttdec_bestpath_hyp(s3a_uttdec_t *ud, int32_t lane, const char *uttid, int32_t utt_index,
                                 s3a_hyp_header_t *hdr, s3a_hyp_word_t *words, int32_t max_words);
 /* With the second pass enabled, s3a_uttdec_decode_queue* (lane refill) runs it at every refill event for the lanes that have
- * ended, before their history tables are reused; the result is kept per UTTERANCE of the queue (no lattices: s3a_uttdec_lattice
- * needs a lock-step decode).  Same record and status codes as s3a_uttdec_bestpath_hyp. */
+ * ended, before their history tables are reused (from 8 lanes on: per group of n_lanes utterances, each one persistent launch); the
+ * result is kept per UTTERANCE of the queue (lattices: s3a_uttdec_queue_keep_lattices below).  Same record and status codes as s3a_uttdec_bestpath_hyp. */
 int32_t s3a_uttdec_queue_bestpath_hyp(s3a_uttdec_t *ud, int32_t utt, const char *uttid, int32_t utt_index,
                                       s3a_hyp_header_t *hdr, s3a_hyp_word_t *words, int32_t max_words);
 int32_t s3a_uttdec_bestpath_result(s3a_uttdec_t *ud, int32_t lane, s3a_dag_result_t *out);
+/* Lattices out of a QUEUE (round 6): switched on before s3a_uttdec_decode_queue*, the lanes' lattices are read back behind every group's
+ * (below 8 lanes: every refill event's) second pass -- the host waits for the stream there, the price of it -- and kept per UTTERANCE until
+ * the engine's next decode; s3a_uttdec_queue_lattice hands one out as s3a_uttdec_lattice does (nodes = links = NULL: the sizes), for the
+ * lattice formatters and s3a_lattice_nbest.  S3A_EUNSUP: that utterance's pass left no lattice. */
+int32_t s3a_uttdec_queue_keep_lattices(s3a_uttdec_t *ud, int32_t on);
+int32_t s3a_uttdec_queue_lattice(s3a_uttdec_t *ud, int32_t utt, s3a_lat_info_t *info, s3a_lat_node_t *nodes, int32_t node_cap,
+                                 s3a_lat_link_t *links, int32_t link_cap);
 
 double s3a_uttdec_last_decode_ms(const s3a_uttdec_t *ud);    /* HIP-event time of the last decode's frames */
 /* per-kernel timing for roofline arithmetic: every `every`-th frame of the following decodes is bracketed,

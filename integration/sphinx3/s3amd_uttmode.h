@@ -404,6 +404,84 @@ cmp_longest_first(const void *a, const void *b)
     return x - y;
 }
 
+/* -outlatdir / -nbestdir out of a queue (round 6): the utterance's lattice was kept behind its second pass (s3a_uttdec_queue_keep_lattices);
+ * the files by the library's formatters and its N-best search, named and written as srch_utt_end would (srch.c:573-606) */
+static int g_queue_lat;
+static void
+queue_write_lattice_files(kb_t *kb, s3a_uttdec_t *ud, int32 q, const uq_t *uq)
+{
+    kbcore_t *kbc = kb->kbcore;
+    cmd_ln_t *config = kbcore_config(kbc);
+    lm_t *lm = kbcore_lm(kbc);
+    s3a_lat_info_t info;
+    s3a_lat_node_t *nodes;
+    s3a_lat_link_t *links;
+    char str[2048];
+    int32 ispipe;
+    FILE *fp;
+    if (s3a_uttdec_queue_lattice(ud, q, &info, NULL, 0, NULL, 0) != S3A_OK) { E_ERROR("tst shim: no lattice for %s: %s\n", uq->uttid, s3a_last_error()); return; }
+    nodes = ckd_calloc(info.n_nodes + 1, sizeof(*nodes));
+    links = ckd_calloc(info.n_links + 1, sizeof(*links));
+    if (s3a_uttdec_queue_lattice(ud, q, &info, nodes, info.n_nodes, links, info.n_links) != S3A_OK) die("s3a_uttdec_queue_lattice");
+    if (cmd_ln_str_r(config, "-outlatdir")) {
+        char *hdr = NULL, *buf;
+        size_t hl = 0;
+        int64_t need;
+        FILE *hf = open_memstream(&hdr, &hl);
+        const int htk = strcmp(cmd_ln_str_r(config, "-outlatfmt"), "htk") == 0;
+        dag_write_header(hf, config);
+        fclose(hf);
+        if (htk) {
+            dict_t *dict = kbcore_dict(kbc);
+            logmath_t *lmath = kbcore_logmath(kbc);
+            s3a_htk_opts_t ho;
+            int32 nw = dict_size(dict), *base = ckd_calloc(nw + 1, 4), *nalt = ckd_calloc(nw + 1, 4), i;
+            for (i = 0; i < nw; i++) { base[i] = dict_basewid(dict, i); nalt[base[i]]++; }
+            memset(&ho, 0, sizeof ho);
+            ho.uttid = uq->uttid; ho.lmname = lm ? lm->name : NULL; ho.have_lm = lm != NULL; ho.lm_wip = lm ? lm->wip : 0; ho.lm_lw = lm ? lm->lw : 1.0f;
+            ho.frate = cmd_ln_exists_r(config, "-frate") ? cmd_ln_int32_r(config, "-frate") : 0;
+            ho.log_shift = logmath_get_shift(lmath); ho.log_of_base = log(logmath_get_base(lmath));
+            ho.opt_lw = cmd_ln_float32_r(config, "-lw"); ho.opt_wip = cmd_ln_float32_r(config, "-wip");
+            ho.basewid = base; ho.n_alt = nalt;
+            need = s3a_lattice_format_htk(hdr, &ho, &info, nodes, links, (const char *const *)g_wordstr, NULL, 0);
+            buf = ckd_calloc(need + 1, 1);
+            s3a_lattice_format_htk(hdr, &ho, &info, nodes, links, (const char *const *)g_wordstr, buf, need + 1);
+            ckd_free(base); ckd_free(nalt);
+        }
+        else {
+            need = s3a_lattice_format_s3(hdr, &info, nodes, links, (const char *const *)g_wordstr, NULL, 0);
+            buf = ckd_calloc(need + 1, 1);
+            s3a_lattice_format_s3(hdr, &info, nodes, links, (const char *const *)g_wordstr, buf, need + 1);
+        }
+        ctl_outfile(str, cmd_ln_str_r(config, "-outlatdir"), cmd_ln_str_r(config, "-latext"), (uq->uttfile ? uq->uttfile : uq->uttid), uq->uttid,
+                    cmd_ln_boolean_r(config, "-build_outdirs"));
+        if ((fp = fopen_comp(str, "w", &ispipe)) == NULL) E_ERROR("fopen_comp (%s,w) failed\n", str);
+        else { fwrite(buf, 1, need, fp); fclose_comp(fp, ispipe); }
+        ckd_free(buf); free(hdr);
+    }
+    if (cmd_ln_str_r(config, "-nbestdir")) {
+        s3a_nbest_opts_t o;
+        s3a_nbest_t *nb;
+        const char *text = NULL;
+        int64_t len = 0;
+        int32 n_hyp = 0, cnt[4] = { 0, 0, 0, 0 };
+        memset(&o, 0, sizeof o);
+        o.uttid = uq->uttid; o.beam = cmd_ln_float64_r(config, "-beam"); o.beam_logs3 = logs3(kbcore_logmath(kbc), o.beam);
+        o.nbest = cmd_ln_int32_r(config, "-nbest"); o.maxppath = cmd_ln_int32_r(config, "-maxppath");
+        o.lm_wip = lm->wip; o.lm_lw = lm->lw; o.logbase = cmd_ln_float32_r(config, "-logbase"); o.lw = cmd_ln_float32_r(config, "-lw"); o.wip = cmd_ln_float32_r(config, "-wip");
+        ctl_outfile(str, cmd_ln_str_r(config, "-nbestdir"), cmd_ln_str_r(config, "-nbestext"), (uq->uttfile ? uq->uttfile : uq->uttid), uq->uttid,
+                    cmd_ln_boolean_r(config, "-build_outdirs"));
+        nb = s3a_lattice_nbest(g_lm3g, &g_dag_cfg, &o, &info, nodes, links, (const char *const *)g_wordstr);
+        if (nb == NULL) die("s3a_lattice_nbest");
+        if (s3a_nbest_result(nb, &text, &len, &n_hyp, cnt) != S3A_OK) E_ERROR("maxedge limit (%d) exceeded\n", g_dag_cfg.maxedge);
+        else if (n_hyp <= 0) E_ERROR("%s: A* search failed\n", uq->uttid);
+        else if ((fp = fopen_comp(str, "w", &ispipe)) == NULL) E_ERROR("fopen_comp (%s,w) failed\n", str);
+        else { fwrite(text, 1, (size_t)len, fp); fclose_comp(fp, ispipe); }
+        s3a_nbest_free(nb);
+    }
+    ckd_free(nodes); ckd_free(links);
+}
+
 static void
 utt_flush_queue(kb_t *kb)
 {
@@ -471,7 +549,8 @@ utt_flush_queue(kb_t *kb)
         for (;;) {
             if (need > cap) { cap = need + 64; words = ckd_realloc(words, (size_t)cap * sizeof(*words)); }
             /* -bestpath 1: the second pass ran on the device at the lane's refill event; its hypothesis is the utterance's */
-            if ((g_dev_dag ? s3a_uttdec_queue_bestpath_hyp(ud, slot_q[z], g_uq[z].uttid, g_rank_first + g_rec_n, &h, words, cap)
+            /* (-outlatdir / -nbestdir without -bestpath: the pass ran for the lattice, the hypothesis is the first pass's, srch.c:538-552) */
+            if (((g_dev_dag && cmd_ln_boolean_r(config, "-bestpath")) ? s3a_uttdec_queue_bestpath_hyp(ud, slot_q[z], g_uq[z].uttid, g_rank_first + g_rec_n, &h, words, cap)
                            : s3a_uttdec_queue_hyp(ud, slot_q[z], g_uq[z].uttid, g_rank_first + g_rec_n, &h, words, cap)) != S3A_OK) die("hypothesis record");
             if (h.status != -3) break;
             need = h.n_words;
@@ -509,6 +588,7 @@ utt_flush_queue(kb_t *kb)
             if (kb->matchsegfp) fputs(sg, kb->matchsegfp);
             ckd_free(m); ckd_free(sg);
         }
+        if (g_queue_lat && h.status != -1) queue_write_lattice_files(kb, ud, slot_q[z], &g_uq[z]);
         ckd_free(words);
         uq_free(&g_uq[z]);
     }
@@ -966,9 +1046,14 @@ utt_mode_main(int argc, char *argv[], int n_lanes)
     g_wflat = w;
     if (cmd_ln_exists_r(config, "-adcin") && cmd_ln_boolean_r(config, "-adcin")) adc_frontend_init(config, kbc);
     if (getenv("S3A_UTT_QUEUE")) {      /* lane refill: this many control-file entries per queue (at least the lanes) */
-        if (cmd_ln_str_r(config, "-outlatdir") || cmd_ln_str_r(config, "-nbestdir") || (cmd_ln_boolean_r(config, "-bestpath") && !g_dev_dag))
-            E_FATAL("tst shim: S3A_UTT_QUEUE (lane refill) keeps no history tables: no lattices / N-best / host second pass in this mode (-bestpath 1 runs on the device)\n");
+        if ((cmd_ln_str_r(config, "-outlatdir") || cmd_ln_str_r(config, "-nbestdir") || cmd_ln_boolean_r(config, "-bestpath")) && !g_dev_dag)
+            E_FATAL("tst shim: S3A_UTT_QUEUE (lane refill) keeps no history tables: no host second pass / lattices from the host's pass in this mode (the device's second pass serves -bestpath 1, -outlatdir, -nbestdir)\n");
         g_queue = 1;
+        if (cmd_ln_str_r(config, "-outlatdir") || cmd_ln_str_r(config, "-nbestdir")) {      /* (round 6: the lattices are kept behind every group's pass) */
+            int32 e2;
+            g_queue_lat = 1;
+            for (e2 = 0; e2 < g_n_eng; e2++) if (s3a_uttdec_queue_keep_lattices(g_uds[e2], 1) != S3A_OK) die("s3a_uttdec_queue_keep_lattices");
+        }
         if (atoi(getenv("S3A_UTT_QUEUE")) > g_uq_cap) g_uq_cap = atoi(getenv("S3A_UTT_QUEUE"));
     }
     g_uq = ckd_calloc(g_uq_cap, sizeof(*g_uq));

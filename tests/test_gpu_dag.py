@@ -250,6 +250,34 @@ def test_second_pass_inside_a_queue_with_lane_refill(task, lanes, queue, extra, 
         assert 0 < ref[0].count("\n") < 20
 
 
+@pytest.mark.parametrize("task,lanes,queue,extra", [("tidigits", "4", "31", []), ("tidigits", "9", "31", ["-bestpath", "1", "-outlatfmt", "htk"]),
+                                                     ("rm1", "8", "20", ["-bestpath", "1"]), ("rm1", "5", "20", [])])
+def test_lattices_and_nbest_lists_out_of_a_queue(task, lanes, queue, extra, tmp_path):
+    """S3A_UTT_QUEUE with -outlatdir and -nbestdir (round 6): the lanes' lattices are read back behind every group's (below 8 lanes: every
+    refill event's) second pass and kept per utterance (s3a_uttdec_queue_keep_lattices / _queue_lattice); the files -- the library's
+    formatters, the library's N-best search -- and -hyp / -hypseg (the first pass's hypothesis without -bestpath, the second's with it)
+    are the unmodified reference's, byte for byte"""
+    base = tidigits_args() if task == "tidigits" else rm_args()
+    outs = {}
+    for tag, exe, env in (("ref", REFDEC, None), ("gpu", TST, dict(os.environ, S3A_UTT=lanes, S3A_UTT_QUEUE=queue))):
+        dl, dn = tmp_path / f"lat_{tag}", tmp_path / f"nb_{tag}"
+        dl.mkdir(); dn.mkdir()
+        outs[tag] = run(exe, base + extra + ["-outlatdir", str(dl), "-latext", "lat", "-nbestdir", str(dn), "-nbest", "15", "-nbestext", "nbest"],
+                        tmp_path, tag, env=env) + (_files(str(dl)), _files(str(dn)))
+    ref, gpu = outs["ref"], outs["gpu"]
+    assert "lane refill" in gpu[2]
+    assert gpu[0] == ref[0] and gpu[1] == ref[1]
+    n = 31 if task == "tidigits" else 20
+    assert len(ref[3]) == n and sorted(ref[3]) == sorted(gpu[3]) and len(ref[4]) == n and sorted(ref[4]) == sorted(gpu[4])
+    for k in sorted(ref[3]):
+        a, b = ref[3][k], gpu[3][k]
+        if "htk" in extra:          # (the HTK header prints the program's own name and date: compare from the size line on, as the lock-step test does)
+            a, b = a[a.index(b"\nN="):], b[b.index(b"\nN="):]
+        assert a == b, k
+    for k in sorted(ref[4]):
+        assert gpu[4][k] == ref[4][k], k
+
+
 def test_second_pass_through_the_c_abi_alone_tables_stay_on_the_device(gpu_lib, tmp_path):
     """bundle -> s3a_uttdec_init + s3a_uttdec_enable_bestpath(keep_tables = 0): cepstra in, the second pass's hypotheses
     out; the history tables are never read back (s3a_uttdec_result refuses)"""
