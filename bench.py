@@ -1004,10 +1004,10 @@ def main():
             res["ps_fwdtree"] = ps_fwdtree_leg(d, args.ps_lanes)
         if world == 1 and not args.no_wide_beam:
             res["wide_beam"] = wide_beam_leg(lib, d, args.wide_lanes, args.wide_frames, args.fast)
-            if args.wide_lanes < 128:           # (what more lanes buy the launches of this task: the same leg with 128 utterances, 16 of them compared)
-                w2 = wide_beam_leg(lib, os.path.join(d, "wide128"), 128, args.wide_frames, args.fast, n_check=16)
+            if args.wide_lanes < 512:           # (what more lanes buy the launches of this task: the same leg with 512 utterances, 16 of them compared)
+                w2 = wide_beam_leg(lib, os.path.join(d, "wide512"), 512, args.wide_frames, args.fast, n_check=16)
                 keep = ("lanes", "frames", "device_ms", "frames_per_sec", "xRT", "identical_to_reference", "error")
-                res["wide_beam"]["lanes_128"] = {k: w2[k] for k in keep if k in w2}
+                res["wide_beam"]["lanes_512"] = {k: w2[k] for k in keep if k in w2}
         if weak:
             res["weak_scaling"] = weak
         if cpu:
