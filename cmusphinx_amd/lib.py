@@ -1648,6 +1648,24 @@ class UttDec:
             check(self.L.s3a_uttdec_bestpath_hyp(self.h, lane, uttid.encode(), int(utt_index), C.byref(hdr), _p(words), len(words)), self.L)
         return hdr, words[:hdr.n_words if hdr.status == 0 else 0].copy()
 
+    def _lattice(self, fn, k):
+        info = LatInfo()
+        check(fn(self.h, int(k), C.byref(info), None, 0, None, 0), self.L)
+        nodes, links = np.zeros((info.n_nodes, 6), np.int32), np.zeros((max(info.n_links, 1), 5), np.int32)
+        check(fn(self.h, int(k), C.byref(info), _p(nodes), info.n_nodes, _p(links), info.n_links), self.L)
+        return info, nodes, links[:info.n_links]
+
+    def lattice(self, lane):
+        """s3a_uttdec_lattice: (LatInfo, nodes [n, 6] = wid sf fef lef ascr lscr, links [m, 5] = from to ascr lscr ef) of a lock-step decode's lane"""
+        return self._lattice(self.L.s3a_uttdec_lattice, lane)
+
+    def queue_keep_lattices(self, on=True):
+        check(self.L.s3a_uttdec_queue_keep_lattices(self.h, 1 if on else 0), self.L)
+
+    def queue_lattice(self, utt):
+        """s3a_uttdec_queue_lattice: the same for utterance `utt` of the last queue (queue_keep_lattices before the decode)"""
+        return self._lattice(self.L.s3a_uttdec_queue_lattice, utt)
+
     def queue_bestpath_hyp(self, utt, uttid="", utt_index=0):
         """the second pass's hypothesis of utterance `utt` of the last queue: (HypHeader, words int32 [n_words, 6])"""
         hdr = HypHeader()

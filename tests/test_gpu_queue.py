@@ -182,3 +182,30 @@ def test_scan_with_small_workgroups(gpu_lib, tidigits_bundle, monkeypatch):
     dec.decode_queue(feats)
     m, s = queue_lines(dec, utts)
     assert m == rm and s == rs
+
+
+@pytest.mark.parametrize("lanes", [3, 9])
+def test_lattices_out_of_a_queue_through_the_c_abi(gpu_lib, tidigits_bundle, lanes):
+    """s3a_uttdec_queue_keep_lattices + s3a_uttdec_queue_lattice: every utterance's lattice as a lock-step decode's s3a_uttdec_lattice hands
+    it out -- nodes and links in the reference's list orders, word for word --, with 3 lanes (the second pass at refill events) and 9 (groups
+    of static ku_frames launches); without the switch a queue keeps none"""
+    utts, feats = tidigits_feats(gpu_lib)
+    lock = bundle.Decoder(tidigits_bundle, 4, bestpath=True)
+    want = []
+    for i in range(0, 12, 4):
+        lock.decode(feats[i:i + 4])
+        want += [lock.ud.lattice(z) for z in range(4)]
+    dec = bundle.Decoder(tidigits_bundle, lanes, bestpath=True)
+    dec.decode_queue(feats[:12])
+    with pytest.raises(Exception):
+        dec.ud.queue_lattice(0)
+    dec.ud.queue_keep_lattices()
+    dec.decode_queue(feats[:12])
+    for u in range(12):
+        info, nodes, links = dec.ud.queue_lattice(u)
+        wi, wn, wl = want[u]
+        assert (info.n_frames, info.n_nodes, info.n_links, info.initial, info.final, info.final_ascr) == \
+               (wi.n_frames, wi.n_nodes, wi.n_links, wi.initial, wi.final, wi.final_ascr), u
+        assert np.array_equal(nodes, wn) and np.array_equal(links, wl), u
+        h, w = dec.queue_bestpath_hyp(u, utts[u][1], u)
+        assert h.status == 0
