@@ -1578,10 +1578,18 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
 #define KF_PSBITS 4096
 #define KF_PSTAB 512
 #define KF_SENBITS 16384          /* senones ku_frames keeps an activity bit for in LDS (more: the launches stay) */
+#ifndef KF_ER
 #define KF_ER 4                 /* runs of 64 entries a wave tests per turn of lextree_enter's sweep */
+#endif
+#ifndef KF_RL
 #define KF_RL 8                 /* list positions a thread classifies per turn of the propagation step's first pass */
+#endif
+#ifndef KF_SK
 #define KF_SK 8                 /* list positions a thread stamps per pass */
-#define KF_RK 8                 /* kept entries a thread ranks per pass of lextree_enter's ranking */
+#endif
+#ifndef KF_RK
+#define KF_RK 4                 /* kept entries a thread ranks per pass of lextree_enter's ranking (8: 706.6, 4: 713.1, 2: 711.7 k frames/s, same box: profiles/r6_experiments.txt 12) */
+#endif
 #define KF_SETS 512            /* listed parent sets a workgroup takes per pass of the propagation step */
 #define KF_TP_LDS 1024          /* words of transition matrices kept in LDS */
 #define KF_ENT 640              /* propagating parents of a pass's several-parent sets kept in LDS (a set whose parents find no room goes the wave-per-set way) */
