@@ -54,6 +54,7 @@ struct PsfScalars {
     int32_t n_total;            /* frames of the utterance (whole-utterance mode) */
     int32_t exit_bp, exit_score, n_seg, finished;
     int32_t clean;              /* the last utterance was finished without failure: a new decoder's state is a light reset away */
+    int32_t pl_best;            /* -pl_window: phone_loop_search_t.best_score */
 #ifdef PSF_TIMING
     unsigned long long t_phase[16], t_last;     /* wall_clock64 ticks (100 MHz) per phase of the frame; diagnostics build */
 #endif
@@ -77,6 +78,9 @@ struct PsfLane {
     int32_t *arc;                               /* the allocated last-phone channels of the active words, in (word list, right context) order */
     int16_t *senscr;                            /* [n_sen] frame-synchronous mode: acmod_score's output */
     const int16_t *raw;                         /* whole-utterance mode: [window][n_sen] scores before normalisation */
+    int32_t *pl_host;                           /* [n_ci] -pl_window, frame-synchronous mode: phone_loop_search_score of the next step (s3a_psfwd_set_lookahead) */
+    uint32_t *senkeep;                          /* [(n_sen + 31) / 32] -pl_window, whole utterances: acmod->senone_active_vec as the lane's last search step left it
+                                                 * (acmod_start_utt does not clear it: the next utterance's first phone loop steps score those senones too) */
     PsfScalars *sc;
     s3a_psfwd_seg_t *seg;
 };
@@ -103,6 +107,10 @@ struct PsfModel {
     const int32_t *ug_prob, *ug_bowt, *ug_firstbg, *bg_wid, *bg_prob, *bg_bowt, *bg_firsttg, *tg_wid, *tg_prob;
     int32_t beam, pbeam, wbeam, lpbeam, lponlybeam, fillpen, silpen, nwpen, pip, maxwpf, maxhmmpf;
     int32_t bp_cap, bss_cap, max_frames, cand_cap;
+    /* -pl_window > 0 (phone_loop_search.c): the CI phones' HMMs are the channels [pl_base, pl_base + n_ci) of a lane */
+    int32_t pl_window, pl_beam, pl_pbeam, pl_pip, pl_base;
+    const int16_t *ch_ci;                       /* [n_ch] chan_t.ciphone / root_chan_t.ciphone */
+    const int16_t *sp_ci;                       /* [n_1ph] the single-phone words' phone */
 };
 
 /* a channel's record: score[5], history[5], out_score, out_history, bestscore, frame */
@@ -492,6 +500,7 @@ struct FrameShared {
     int32_t pa[4][NT];                          /* a chunk of parents in prune: first item, channel, list position, appends itself */
     uint32_t senbits[SENBITS_WORDS];            /* acmod->senone_active_vec */
     uint32_t rootbits[ROOTBITS_WORDS];          /* roots active in the NEXT frame (set while the frame runs) */
+    int32_t pl[256];                            /* -pl_window: phone_loop_search_score(ci) of the frame (phone_loop_search.h:103-105) */
 };
 
 /* at a kernel's start: the bit vector of the roots active in frame f, from the channels' frame numbers */
@@ -541,7 +550,9 @@ d_frame_word_chans(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f)
     __syncthreads();
 }
 
-template <int NE> __device__ void
+/* PL: -pl_window > 0 -- every transition into a phone adds F.pl[its CI phone] (phone_loop_search_score), and the tests that stand in
+ * front of the transitions' loops in the reference (`pls != NULL || ...`, :745, :765, :824, :847) are not made */
+template <int NE, bool PL> __device__ void
 d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &sen, int32_t n_senone_active)
 {
     PsfScalars &S = F.S;
@@ -644,7 +655,8 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     /* does parent p (position ppos in the list, -1 = root) enter child x?  everything read is immutable in this phase */
     auto enters = [&](int32_t p, int32_t ppos, int32_t x, int32_t *ns_out) -> bool {
         if (!(CH_BE(L, p) > thresh)) return false;
-        const int32_t ns = add32(CH_OS(L, p), M.pip);
+        int32_t ns = add32(CH_OS(L, p), M.pip);
+        if (PL) ns = add32(ns, F.pl[M.ch_ci[x]]);
         *ns_out = ns;
         if (!(ns > newphone_thresh)) return false;
         if (!in_acl(x)) return (CH_FR(L, x) < f) || (ns > CH_SC(L, x, 0));
@@ -678,8 +690,12 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
             }
             if (surv) {
                 const int32_t ns0 = add32(CH_OS(L, c), M.pip);
-                if (ns0 > newphone_thresh) items += M.ch_child_off[c + 1] - M.ch_child_off[c];
-                if (ns0 > lastphn_thresh) cntC = M.ch_pen_off[c + 1] - M.ch_pen_off[c];
+                if (PL || ns0 > newphone_thresh) items += M.ch_child_off[c + 1] - M.ch_child_off[c];
+                if (PL) {       /* (a word is a candidate when its own last phone's look-ahead lets it: :768-772, :850-853) */
+                    for (int32_t e = M.ch_pen_off[c]; e < M.ch_pen_off[c + 1]; e++)
+                        cntC += add32(ns0, F.pl[M.w_last_ci[M.ch_pen_wid[e]]]) > lastphn_thresh ? 1 : 0;
+                }
+                else if (ns0 > lastphn_thresh) cntC = M.ch_pen_off[c + 1] - M.ch_pen_off[c];
             }
         }
         int32_t io, oc, ti, tc;
@@ -689,9 +705,13 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
         if (surv) {
             if (pos < 0) { CH_FR(L, c) = nf; setbit(F.rootbits, c); }                    /* :733 */
             if (cntC > 0) {
-                const int32_t cs = sub32(add32(CH_OS(L, c), M.pip), M.nwpen), ch = CH_OH(L, c);
-                for (int32_t e = M.ch_pen_off[c]; e < M.ch_pen_off[c + 1]; e++, oc++) {
-                    L.cand_wid[oc] = M.ch_pen_wid[e]; L.cand_score[oc] = cs; L.cand_bp[oc] = ch;
+                const int32_t ns0 = add32(CH_OS(L, c), M.pip), ch = CH_OH(L, c);
+                for (int32_t e = M.ch_pen_off[c]; e < M.ch_pen_off[c + 1]; e++) {
+                    const int32_t w = M.ch_pen_wid[e];
+                    int32_t v = ns0;
+                    if (PL) { v = add32(ns0, F.pl[M.w_last_ci[w]]); if (!(v > lastphn_thresh)) continue; }
+                    L.cand_wid[oc] = w; L.cand_score[oc] = sub32(v, M.nwpen); L.cand_bp[oc] = ch;
+                    oc++;
                 }
             }
         }
@@ -965,7 +985,9 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
             const int32_t wthresh = add32(S.best_score, S.dyn_beam);
             /* into the roots (:1301-1317) */
             for (int32_t i = tid; i < M.n_root; i += NT) {
-                const int32_t ci = M.root_ci[i], ns = add32(add32(F.brc_score[ci], M.nwpen), M.pip);
+                const int32_t ci = M.root_ci[i];
+                int32_t ns = add32(add32(F.brc_score[ci], M.nwpen), M.pip);
+                if (PL) ns = add32(ns, F.pl[ci]);
                 if (ns > wthresh && (CH_FR(L, i) < f || ns > CH_SC(L, i, 0))) {
                     CH_SC(L, i, 0) = ns; CH_HI(L, i, 0) = F.brc_path[ci]; CH_FR(L, i) = nf;
                     MPX_ID(L, 0, i) = M.root_lc_ssid[i * M.n_ci + F.brc_lc[ci]];
@@ -997,7 +1019,8 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                     }
                     L.lt_dscr[w] = dscr;
                     if (kind & 1) {
-                        const int32_t ns = add32(dscr, M.pip);
+                        int32_t ns = add32(dscr, M.pip);
+                        if (PL) ns = add32(ns, F.pl[M.sp_ci[i]]);
                         if (ns > wthresh && (CH_FR(L, c) < f || ns > CH_SC(L, c, 0))) {
                             const int32_t pb = L.lt_bp[w];
                             CH_SC(L, c, 0) = ns; CH_HI(L, c, 0) = pb; CH_FR(L, c) = nf;
@@ -1006,7 +1029,8 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
                     }
                 }
                 if (kind & 6) {
-                    const int32_t ns = add32(add32(F.brc_score[M.sil_ci], (kind & 2) ? M.silpen : M.fillpen), M.pip);
+                    int32_t ns = add32(add32(F.brc_score[M.sil_ci], (kind & 2) ? M.silpen : M.fillpen), M.pip);
+                    if (PL) ns = add32(ns, F.pl[M.sp_ci[i]]);
                     if (ns > wthresh && (CH_FR(L, c) < f || ns > CH_SC(L, c, 0))) { CH_SC(L, c, 0) = ns; CH_HI(L, c, 0) = F.brc_path[M.sil_ci]; CH_FR(L, c) = nf; }
                 }
             }
@@ -1021,6 +1045,103 @@ d_frame(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t f, const SenScr &
     if (tid == 0) S.n_frame++;
     __syncthreads();
     TPHASE(S, 9);
+}
+
+/* ------------------------------------------------------------------ */
+/* the phone loop look-ahead (-pl_window; phone_loop_search.c).  Whole-utterance mode: the loop -- one plain HMM per CI    */
+/* phone, all entered at the utterance's start, every exit entering every phone -- runs inside the lane's launch, pl_window */
+/* frames ahead of the search (pocketsphinx.c:704-712: the loop is stepped for frame F, then the search for F - pl_window; */
+/* :823-826: the last pl_window frames of the search see the loop's final state).  Its HMMs are the lane's channels        */
+/* [pl_base, pl_base + n_ci); a thread per phone.  Histories are not kept apart from what hmm_vit_eval moves: nothing      */
+/* reads the loop's backtrace (phone_loop_search_hyp returns nothing).                                                      */
+/* ------------------------------------------------------------------ */
+/* phone_loop_search_start :166-181 */
+template <int NE> __device__ void
+d_pl_start(const PsfModel &M, PsfLane &L, FrameShared &F)
+{
+    for (int32_t i = threadIdx.x; i < M.n_ci; i += NT) {
+        const int32_t c = M.pl_base + i;
+        hmm_clear<NE>(M, L, c);
+        CH_SC(L, c, 0) = 0; CH_HI(L, c, 0) = -1; CH_FR(L, c) = 0;         /* hmm_enter(hmm, 0, -1, 0) */
+    }
+    if (threadIdx.x == 0) F.S.pl_best = 0;
+    __syncthreads();
+}
+
+/* phone_loop_search_step :279-311 for frame fi, whose unnormalised scores are raw[].  F.senbits: acmod->senone_active_vec as the
+ * search's last step left it (nothing clears it in between: acmod_score then lists -- and normalises over -- those senones AND
+ * the loop's, :289-293; ms_mgau.c:219-246); the loop's senones are OR-ed in.  Leaves F.pl[ci] = phone_loop_search_score. */
+template <int NE> __device__ void
+d_pl_step(const PsfModel &M, PsfLane &L, FrameShared &F, int32_t fi, const int16_t *raw, int compallsen)
+{
+    const int tid = threadIdx.x, nf = fi + 1;
+    if (!compallsen) {
+        for (int32_t i = tid; i < M.n_ci; i += NT) activate<NE, false>(M, L, M.pl_base + i, 0, F.senbits);
+        __syncthreads();
+    }
+    int32_t best = 0, count = 0;
+    d_normaliser(M, F.wg, F.sh, F.senbits, raw, compallsen, &best, &count);
+    const SenScr sen = { raw, best, 1 };
+    /* renormalize_hmms :183-197: every phone, whatever its frame */
+    const int32_t old_best = F.S.pl_best;
+    if (add32(old_best, 2 * M.pl_beam) < PS_WORST)
+        for (int32_t i = tid; i < M.n_ci; i += NT) {
+            const int32_t c = M.pl_base + i;
+#pragma unroll
+            for (int k = 0; k < NE; k++) { const int32_t v = CH_SC(L, c, k); if (v > PS_WORST) CH_SC(L, c, k) = sub32(v, old_best); }
+            const int32_t o = CH_OS(L, c);
+            if (o > PS_WORST) CH_OS(L, c) = sub32(o, old_best);
+        }
+    /* evaluate_hmms :199-223 (a thread keeps its phones through the steps below: no barrier between them) */
+    int32_t bs = PS_WORST, d1 = INT_MIN, z0 = 0, z1 = 0;
+    for (int32_t i = tid; i < M.n_ci; i += NT) {
+        const int32_t c = M.pl_base + i;
+        if (CH_FR(L, c) < fi) continue;
+        bs = max(bs, hmm_vit_eval<NE, false>(M, L, c, 0, sen));
+    }
+    wg_reduce4(F.wg, bs, d1, z0, z1);
+    /* prune_hmms :225-244, and who leaves (phone_transition :246-277: out + pip inside the exit beam) */
+    const int32_t thresh = add32(bs, M.pl_beam), xthresh = add32(bs, M.pl_pbeam);
+    int32_t mx = INT_MIN, any = 0;
+    d1 = INT_MIN; z1 = 0;
+    for (int32_t i = tid; i < M.n_ci; i += NT) {
+        const int32_t c = M.pl_base + i;
+        if (CH_FR(L, c) < fi) continue;
+        if (CH_BE(L, c) > thresh) {
+            CH_FR(L, c) = nf;
+            const int32_t ns = add32(CH_OS(L, c), M.pl_pip);
+            if (ns > xthresh) { mx = max(mx, ns); any = 1; }
+        }
+        else hmm_clear_scores<NE>(M, L, c);
+    }
+    wg_reduce4(F.wg, mx, d1, any, z1);
+    if (add32(PS_WORST, M.pl_pip) > xthresh) {
+        /* (a phone that was pruned holds WORST_SCORE as its exit score; entered by an earlier phone of this very loop it is looked
+         * at again, :258, and with an exit threshold below WORST_SCORE + pip it would leave too: the reference's loop as it stands) */
+        if (tid == 0)
+            for (int32_t i = 0; i < M.n_ci; i++) {
+                const int32_t c = M.pl_base + i;
+                if (CH_FR(L, c) != nf) continue;
+                const int32_t ns = add32(CH_OS(L, c), M.pl_pip);
+                if (!(ns > xthresh)) continue;
+                for (int32_t j = 0; j < M.n_ci; j++) {
+                    const int32_t x = M.pl_base + j;
+                    if (CH_FR(L, x) < fi || ns > CH_SC(L, x, 0)) { CH_SC(L, x, 0) = ns; CH_FR(L, x) = nf; }
+                }
+            }
+    }
+    else if (any) {
+        /* every phone is entered with the best of the leaving scores: unconditionally by the first leaving phone when it was not
+         * active in this frame, by a strictly better score otherwise (:268-271) -- the maximum either way */
+        for (int32_t i = tid; i < M.n_ci; i += NT) {
+            const int32_t x = M.pl_base + i;
+            if (CH_FR(L, x) < fi || mx > CH_SC(L, x, 0)) { CH_SC(L, x, 0) = mx; CH_FR(L, x) = nf; }
+        }
+    }
+    __syncthreads();
+    for (int32_t i = tid; i < M.n_ci; i += NT) F.pl[i] = sub32(CH_BE(L, M.pl_base + i), bs);
+    if (tid == 0) F.S.pl_best = bs;
+    __syncthreads();
 }
 
 /* ngram_fwdtree_start :464-507; fresh: what a new decoder's channels look like (init_search_tree :66-148) */
@@ -1153,18 +1274,19 @@ k_psf_sen_active(PsfModel M, PsfLane *lanes, int32_t lane, int32_t f)
 }
 
 /* frame-synchronous: one frame of one lane with the caller's (normalised) senone scores in L.senscr */
-template <int NE> __global__ void __launch_bounds__(NT)
+template <int NE, bool PL> __global__ void __launch_bounds__(NT)
 k_psf_step(PsfModel M, PsfLane *lanes, int32_t lane, int32_t f, int32_t n_senone_active)
 {
     PsfLane L = lanes[lane];
     __shared__ FrameShared F;
     if (threadIdx.x == 0) F.S = *L.sc;
+    if (PL) for (int32_t i = threadIdx.x; i < M.n_ci; i += NT) F.pl[i] = L.pl_host[i];      /* (the decoder's own phone loop: s3a_psfwd_set_lookahead) */
     __syncthreads();
     d_root_bits_from_frames(M, L, F.rootbits, f);
     d_frame_roots(M, L, F);
     d_frame_word_chans(M, L, F, f);
     SenScr sen = { L.senscr, 0, 0 };
-    d_frame<NE>(M, L, F, f, sen, n_senone_active);
+    d_frame<NE, PL>(M, L, F, f, sen, n_senone_active);
     __syncthreads();
     if (threadIdx.x == 0) *L.sc = F.S;
 }
@@ -1184,8 +1306,10 @@ k_psf_finish(PsfModel M, PsfLane *lanes, int32_t lane, int32_t cf)
 }
 
 /* whole utterances: frames [f0, f0 + n_win) of every lane of the batch; a lane's utterance may end inside */
-template <int NE> __global__ void __launch_bounds__(NT, PSF_WPE)
-k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, int32_t n_win, int compallsen)
+/* (PL: the window is the whole utterance, f0 = 0 -- the phone loop reads rows ahead of the search's; pl_fresh: the lane is a new
+ * decoder, whose acmod->senone_active_vec is empty) */
+template <int NE, bool PL> __global__ void __launch_bounds__(NT, PSF_WPE)
+k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, int32_t n_win, int compallsen, int pl_fresh)
 {
     PsfLane L = lanes[lane_ids[blockIdx.x]];
     __shared__ FrameShared F;
@@ -1194,12 +1318,18 @@ k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, in
     const int32_t n_total = F.S.n_total;
     if (F.S.finished) return;
     d_root_bits_from_frames(M, L, F.rootbits, f0);
+    if (PL) {
+        for (int32_t i = threadIdx.x; i < ((M.n_sen + 31) >> 5); i += NT) F.senbits[i] = pl_fresh ? 0u : L.senkeep[i];
+        d_pl_start<NE>(M, L, F);
+        for (int32_t fi = 0; fi < M.pl_window && fi < n_total; fi++) d_pl_step<NE>(M, L, F, fi, L.raw + (size_t)fi * M.n_sen, compallsen);
+    }
     for (int32_t f = f0; f < f0 + n_win && f < n_total; f++) {
         const int16_t *raw = L.raw + (size_t)(f - f0) * M.n_sen;
         int32_t best = 0, count = 0;
 #ifdef PSF_TIMING
         if (threadIdx.x == 0) F.S.t_last = wall_clock64();
 #endif
+        if (PL && f + M.pl_window < n_total) d_pl_step<NE>(M, L, F, f + M.pl_window, L.raw + (size_t)(f + M.pl_window) * M.n_sen, compallsen);
         d_frame_roots(M, L, F);
         d_frame_word_chans(M, L, F, f);
         if (!compallsen) d_sen_active<NE>(M, L, F.S, f, F.senbits, F.n_rl, F.n_arc);
@@ -1207,9 +1337,10 @@ k_psf_window(PsfModel M, PsfLane *lanes, const int32_t *lane_ids, int32_t f0, in
         d_normaliser(M, F.wg, F.sh, F.senbits, raw, compallsen, &best, &count);
         TPHASE(F.S, 1);
         SenScr sen = { raw, best, 1 };
-        d_frame<NE>(M, L, F, f, sen, count);
+        d_frame<NE, PL>(M, L, F, f, sen, count);
         __syncthreads();
     }
+    if (PL && !compallsen) for (int32_t i = threadIdx.x; i < ((M.n_sen + 31) >> 5); i += NT) L.senkeep[i] = F.senbits[i];
     if (f0 + n_win >= n_total) {
         d_finish<NE>(M, L, F.S, n_total);
         __syncthreads();
@@ -1235,7 +1366,7 @@ struct PsfQueue {
     s3a_psfwd_seg_t *seg;           /* [n_utt][seg_cap] */
 };
 
-template <int NE> __global__ void __launch_bounds__(NT, PSF_WPE)
+template <int NE, bool PL> __global__ void __launch_bounds__(NT, PSF_WPE)
 k_psf_queue(PsfModel M, PsfLane *lanes, PsfQueue Q, int compallsen)
 {
     PsfLane L = lanes[blockIdx.x];
@@ -1265,15 +1396,21 @@ k_psf_queue(PsfModel M, PsfLane *lanes, PsfQueue Q, int compallsen)
         __syncthreads();
         d_start<NE>(M, L, F.S, 1);
         d_root_bits_from_frames(M, L, F.rootbits, 0);
+        if (PL) {           /* (every utterance of a queue starts from a new decoder: no senone is flagged yet) */
+            for (int32_t i = threadIdx.x; i < ((M.n_sen + 31) >> 5); i += NT) F.senbits[i] = 0u;
+            d_pl_start<NE>(M, L, F);
+            for (int32_t fi = 0; fi < M.pl_window && fi < n_total; fi++) d_pl_step<NE>(M, L, F, fi, raw0 + (size_t)fi * M.n_sen, compallsen);
+        }
         for (int32_t f = 0; f < n_total; f++) {
             const int16_t *raw = raw0 + (size_t)f * M.n_sen;
             int32_t best = 0, count = 0;
+            if (PL && f + M.pl_window < n_total) d_pl_step<NE>(M, L, F, f + M.pl_window, raw0 + (size_t)(f + M.pl_window) * M.n_sen, compallsen);
             d_frame_roots(M, L, F);
             d_frame_word_chans(M, L, F, f);
             if (!compallsen) d_sen_active<NE>(M, L, F.S, f, F.senbits, F.n_rl, F.n_arc);
             d_normaliser(M, F.wg, F.sh, F.senbits, raw, compallsen, &best, &count);
             SenScr sen = { raw, best, 1 };
-            d_frame<NE>(M, L, F, f, sen, count);
+            d_frame<NE, PL>(M, L, F, f, sen, count);
             __syncthreads();
         }
         d_finish<NE>(M, L, F.S, n_total);
@@ -1424,6 +1561,30 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     }
     M.n_hmm = M.rc_base + n_rc;
     M.cand_cap = n_pen > 0 ? n_pen : 1;
+    /* the phone loop's HMMs behind the search's channels */
+    M.pl_window = d->pl_window; M.pl_beam = d->pl_beam; M.pl_pbeam = d->pl_pbeam; M.pl_pip = d->pl_pip; M.pl_base = M.n_hmm;
+    if (d->pl_window < 0 || (d->pl_window > 0 && (!d->ci_ssid || !d->ci_tmat))) {
+        s3a_set_error("s3a_psfwd_init: pl_window %d needs ci_ssid / ci_tmat", d->pl_window);
+        delete e;
+        return NULL;
+    }
+    std::vector<int16_t> ch_ci(n_ch > 0 ? n_ch : 1, 0);
+    for (int32_t i = 0; i < d->n_root; i++) ch_ci[i] = d->root_ci[i];
+    for (int32_t i = 0; i < d->n_nonroot; i++) ch_ci[d->n_root + i] = d->nr_ci[i];
+    if (d->pl_window > 0) {
+        for (int32_t i = 0; i < d->n_ci; i++) {
+            if (d->ci_ssid[i] >= d->n_sseq || d->ci_tmat[i] < 0 || d->ci_tmat[i] >= d->n_tmat) {
+                s3a_set_error("s3a_psfwd_init: CI phone %d: senone sequence %d / transition matrix %d", i, d->ci_ssid[i], d->ci_tmat[i]);
+                delete e;
+                return NULL;
+            }
+            ch_ssid.push_back(d->ci_ssid[i]); ch_tmat.push_back(d->ci_tmat[i]);
+        }
+        for (int32_t c = 0; c < n_ch; c++)
+            if (ch_ci[c] < 0 || ch_ci[c] >= d->n_ci) { s3a_set_error("s3a_psfwd_init: channel %d: CI phone %d of %d", c, ch_ci[c], d->n_ci); delete e; return NULL; }
+        for (int32_t i = 0; i < d->n_1ph; i++)
+            if (d->sp_ci[i] < 0 || d->sp_ci[i] >= d->n_ci) { s3a_set_error("s3a_psfwd_init: single-phone word %d: CI phone %d of %d", i, d->sp_ci[i], d->n_ci); delete e; return NULL; }
+    }
     std::vector<uint8_t> sp_kind(d->n_1ph > 0 ? d->n_1ph : 1, 0);
     M.sil_sp = -1; M.start_sp = -1;
     for (int32_t i = 0; i < d->n_1ph; i++) {
@@ -1447,6 +1608,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     UP(M.w_flags, d->w_flags, W);
     UP(M.ch_ssid, ch_ssid.data(), ch_ssid.size()); UP(M.ch_tmat, ch_tmat.data(), ch_tmat.size());
     UP(M.ch_par, par.data(), n_ch);
+    UP(M.ch_ci, ch_ci.data(), ch_ci.size()); UP(M.sp_ci, d->sp_ci, d->n_1ph);
     UP(M.root_ci, d->root_ci, d->n_root);
     UP(M.root_lc_ssid, d->root_lc_ssid, (size_t)d->n_root * d->n_ci); UP(M.sp_lc_ssid, d->sp_lc_ssid, (size_t)d->n_1ph * d->n_ci);
     UP(M.root_ssid0, d->root_ssid0, d->n_root); UP(M.sp_ssid0, d->sp_ssid0, d->n_1ph);
@@ -1461,8 +1623,9 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     e->lanes_h.resize(n_lanes);
     for (int32_t z = 0; z < n_lanes; z++) {
         PsfLane &L = e->lanes_h[z];
-        const size_t H = M.n_hmm;
+        const size_t H = (size_t)M.n_hmm + (M.pl_window > 0 ? M.n_ci : 0);
         LANE(L.st, int32_t, CH_STRIDE * H);
+        LANE(L.pl_host, int32_t, M.n_ci); LANE(L.senkeep, uint32_t, (M.n_sen + 31) / 32);
         LANE(L.mpxid, uint16_t, (size_t)MPX_STRIDE * M.n_mpx);
         for (int k = 0; k < 2; k++) { LANE(L.acl[k], int32_t, d->n_nonroot + 1); LANE(L.awl[k], int32_t, M.cand_cap + 1); }
         LANE(L.wstamp, int32_t, W); LANE(L.lt_sf, int32_t, W); LANE(L.lt_dscr, int32_t, W); LANE(L.lt_bp, int32_t, W);
@@ -1498,6 +1661,11 @@ extern "C" double s3a_psfwd_last_decode_ms(const s3a_psfwd_t *e) { return e ? e-
 extern "C" double s3a_psfwd_last_score_ms(const s3a_psfwd_t *e) { return e ? e->last_score_ms : 0.0; }
 
 #define LANECHK(fn) do { if (!e || lane < 0 || lane >= e->n_lanes) { s3a_set_error(fn ": bad lane"); return S3A_EINVAL; } } while (0)
+#define NEPL_LAUNCH(kern, grid, ...) do { const bool pl_ = e->M.pl_window > 0; \
+        if (e->M.n_emit == 3) { if (pl_) hipLaunchKernelGGL((kern<3, true>), grid, dim3(NT), 0, e->stream, __VA_ARGS__); \
+                                else hipLaunchKernelGGL((kern<3, false>), grid, dim3(NT), 0, e->stream, __VA_ARGS__); } \
+        else { if (pl_) hipLaunchKernelGGL((kern<5, true>), grid, dim3(NT), 0, e->stream, __VA_ARGS__); \
+               else hipLaunchKernelGGL((kern<5, false>), grid, dim3(NT), 0, e->stream, __VA_ARGS__); } } while (0)
 #define NE_LAUNCH(kern, grid, ...) do { if (e->M.n_emit == 3) hipLaunchKernelGGL(kern<3>, grid, dim3(NT), 0, e->stream, __VA_ARGS__); \
                                         else hipLaunchKernelGGL(kern<5>, grid, dim3(NT), 0, e->stream, __VA_ARGS__); } while (0)
 
@@ -1549,12 +1717,23 @@ s3a_psfwd_step(s3a_psfwd_t *e, int32_t lane, const int16_t *senscr, int32_t fram
     if (!senscr || frame_idx < 0 || frame_idx >= e->M.max_frames) { s3a_set_error("s3a_psfwd_step: frame %d outside [0, %d)", frame_idx, e->M.max_frames); return S3A_EINVAL; }
     PsfScalars sc;
     HIPCHK(hipMemcpyAsync(e->lanes_h[lane].senscr, senscr, (size_t)e->M.n_sen * 2, hipMemcpyHostToDevice, e->stream));
-    NE_LAUNCH(k_psf_step, dim3(1), e->M, e->lanes_d, lane, frame_idx, n_senone_active);
+    NEPL_LAUNCH(k_psf_step, dim3(1), e->M, e->lanes_d, lane, frame_idx, n_senone_active);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&sc, e->lanes_h[lane].sc, sizeof(sc), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (sc.status != 0) { s3a_set_error("s3a_psfwd_step: the backpointer table (%d entries) or score stack (%d) is full", e->M.bp_cap, e->M.bss_cap); return sc.status; }
     return (sc.best_score == PS_WORST || sc.best_score < PS_WORST) ? 0 : 1;
+}
+
+extern "C" int32_t
+s3a_psfwd_set_lookahead(s3a_psfwd_t *e, int32_t lane, const int32_t *pl_score)
+{
+    LANECHK("s3a_psfwd_set_lookahead");
+    if (e->M.pl_window <= 0) { s3a_set_error("s3a_psfwd_set_lookahead: the engine was built without the phone loop look-ahead (pl_window 0)"); return S3A_EUNSUP; }
+    if (pl_score) HIPCHK(hipMemcpyAsync(e->lanes_h[lane].pl_host, pl_score, (size_t)e->M.n_ci * 4, hipMemcpyHostToDevice, e->stream));
+    else HIPCHK(hipMemsetAsync(e->lanes_h[lane].pl_host, 0, (size_t)e->M.n_ci * 4, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));            /* (pl_score is the caller's) */
+    return S3A_OK;
 }
 
 extern "C" int32_t
@@ -1655,6 +1834,10 @@ s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const flo
     std::vector<size_t> row0(n_utt);
     for (int32_t z = 0; z < n_utt; z++) {
         if (n_frames[z] < 0 || n_frames[z] > M.max_frames) { s3a_set_error("s3a_psfwd_decode: utterance %d has %d frames (max_frames %d)", z, n_frames[z], M.max_frames); return S3A_EINVAL; }
+        if (M.pl_window > 0 && n_frames[z] > 0 && n_frames[z] <= M.pl_window) {
+            s3a_set_error("s3a_psfwd_decode: utterance %d has %d frames, not more than -pl_window %d", z, n_frames[z], M.pl_window);
+            return S3A_EUNSUP;
+        }
         row0[z] = total; total += n_frames[z];
         longest = n_frames[z] > longest ? n_frames[z] : longest;
     }
@@ -1667,7 +1850,7 @@ s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const flo
     /* every lane's senone scores of the WHOLE utterance before its search starts (int16 per senone and frame: 12 MB per
      * 10 s of a 6144-senone model): the lanes then run their utterances from the first frame to the last in ONE launch,
      * none waiting for another at window boundaries (a frame's cost varies several-fold along an utterance) */
-    if (e->win <= 0) W = longest > 0 ? longest : 1;
+    if (e->win <= 0 || M.pl_window > 0) W = longest > 0 ? longest : 1;      /* (the phone loop reads rows ahead of the search's: one window) */
     const size_t n_slots = (size_t)n_utt * W, n_windows = (size_t)(longest + W - 1) / W + 1;
     if (e->slot_cap < n_slots * n_windows) {
         if (e->slot_row_d) (void)hipFree(e->slot_row_d);
@@ -1705,7 +1888,7 @@ s3a_psfwd_decode(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, const flo
     for (int32_t f0 = 0, wi = 0; f0 < (longest > 0 ? longest : 1); f0 += W, wi++) {
         rc = s3a_ps_score_slots_dev(scorer, e->feat_d, e->slot_row_d + (size_t)wi * n_slots, (int32_t)n_slots, e->raw_d, e->stream);
         if (rc != S3A_OK) return rc;
-        NE_LAUNCH(k_psf_window, dim3(n_utt), M, e->lanes_d, e->lane_ids_d, f0, W, compallsen);
+        NEPL_LAUNCH(k_psf_window, dim3(n_utt), M, e->lanes_d, e->lane_ids_d, f0, W, compallsen, fresh ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(e->ev1, e->stream));
@@ -1744,6 +1927,10 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
     std::vector<long long> row0(n_utt);
     for (int32_t z = 0; z < n_utt; z++) {
         if (n_frames[z] < 0 || n_frames[z] > M.max_frames) { s3a_set_error("s3a_psfwd_decode_queue: utterance %d has %d frames (max_frames %d)", z, n_frames[z], M.max_frames); return S3A_EINVAL; }
+        if (M.pl_window > 0 && n_frames[z] > 0 && n_frames[z] <= M.pl_window) {
+            s3a_set_error("s3a_psfwd_decode_queue: utterance %d has %d frames, not more than -pl_window %d", z, n_frames[z], M.pl_window);
+            return S3A_EUNSUP;
+        }
         row0[z] = (long long)total; total += n_frames[z];
     }
     if (e->feat_cap < total * D) {
@@ -1827,7 +2014,7 @@ s3a_psfwd_decode_queue(s3a_psfwd_t *e, s3a_ps_mgau_t *scorer, int32_t n_utt, con
         }
     }
     if (!Q.ready) Q.order = e->q_order_d;
-    NE_LAUNCH(k_psf_queue, dim3(n_wg), M, e->lanes_d, Q, compallsen);
+    NEPL_LAUNCH(k_psf_queue, dim3(n_wg), M, e->lanes_d, Q, compallsen);
     HIPCHK(hipGetLastError());
     if (Q.ready) {                  /* the scoring stream ends before the search can, but the timed region closes on both */
         HIPCHK(hipEventRecord(e->ev_sc, e->stream_sc));

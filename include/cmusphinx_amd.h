@@ -1137,6 +1137,14 @@ typedef struct s3a_psfwd_desc_s {
     const int32_t *bg_wid, *bg_prob, *bg_bowt, *bg_firsttg; /* bg_firsttg [n_bg + 1] */
     const int32_t *tg_wid, *tg_prob;
     int32_t beam, pbeam, wbeam, lpbeam, lponlybeam, fillpen, silpen, nwpen, pip, maxwpf, maxhmmpf;
+    /* phone loop look-ahead (-pl_window > 0: phone_loop_search.c; pocketsphinx.c:242-248, :704-712, :823-826): a loop of the CI
+     * phones' HMMs runs pl_window frames ahead of the search, and every phone / word transition of the search adds
+     * phone_loop_search_score(ci) = the phone's best score - the loop's best score (phone_loop_search.h:103-105).
+     * pl_beam / pl_pbeam / pl_pip: phone_loop_search_t.beam / .pbeam / .pip as the decoder holds them; ci_ssid / ci_tmat
+     * [n_ci]: bin_mdef_pid2ssid / _pid2tmatid of the CI phones (phone_loop_search_reinit :92-98).  pl_window 0: off. */
+    int32_t pl_window, pl_beam, pl_pbeam, pl_pip;
+    const uint16_t *ci_ssid;
+    const int16_t *ci_tmat;
 } s3a_psfwd_desc_t;
 
 /* the finished (or running) backpointer table of a lane: bptbl_t by field, ngs->bscore_stack, ngs->bp_table_idx
@@ -1171,6 +1179,14 @@ int32_t s3a_psfwd_start(s3a_psfwd_t *e, int32_t lane);
 int32_t s3a_psfwd_sen_active(s3a_psfwd_t *e, int32_t lane, int32_t frame_idx, uint8_t *flags);
 int32_t s3a_psfwd_step(s3a_psfwd_t *e, int32_t lane, const int16_t *senscr, int32_t frame_idx, int32_t n_senone_active);
 int32_t s3a_psfwd_finish(s3a_psfwd_t *e, int32_t lane, int32_t n_frames);
+/* frame-synchronous use with -pl_window > 0: the decoder's own phone loop search (an auxiliary ps_search_t that
+ * ps_search_forward steps in front of the N-gram search, pocketsphinx.c:704-712) stays where it is; before every step
+ * the host hands over what the step adds at its transitions, pl_score[ci] = phone_loop_search_score(pls, ci) for the
+ * n_ci CI phones (kept until the next call; NULL: zeros).  S3A_EUNSUP when the engine was built with pl_window 0.
+ * In whole-utterance use (s3a_psfwd_decode / _decode_queue) the loop itself runs on the device, inside the lane's
+ * launch, pl_window frames ahead of the lane's search (utterances of 1 .. pl_window frames are refused: the reference
+ * then steps its search with negative frame numbers, pocketsphinx.c:823-826). */
+int32_t s3a_psfwd_set_lookahead(s3a_psfwd_t *e, int32_t lane, const int32_t *pl_score);
 /* whole utterances: n_utt <= n_lanes utterances, feat[z] = n_frames[z] rows of the scorer's veclen floats (host);
  * scoring (s3a_ps_ms_cont_mgau_frame_eval's arithmetic, active senones only unless compallsen) and the search of
  * every frame of every lane run on the device between one upload and one download of scalars. */

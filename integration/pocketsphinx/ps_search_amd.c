@@ -18,7 +18,9 @@
  *       and segmentations made on the device (s3a_psfwd_decode / _hyp); what ps_decode_raw / ps_process_cep +
  *       ps_get_hyp + ps_seg_iter return for -fwdflat no -bestpath no, for n utterances at a time.
  *
- * Refused (loudly, at install): -pl_window > 0, interpolated or class-based LM sets, topologies other than 3 or 5
+ * -pl_window > 0 (round 6): step hands the decoder's own phone loop scores over (s3a_psfwd_set_lookahead); in whole-utterance
+ * mode the loop runs on the device inside the lane's launch, pl_window frames ahead of the lane's search.
+ * Refused (loudly, at install): interpolated or class-based LM sets, topologies other than 3 or 5
  * emitting states.  -lmname switching and ps_load_dict go through reinit, which re-exports.
  */
 #include <stdio.h>
@@ -29,6 +31,7 @@
 #include <sphinxbase/feat.h>
 #include "pocketsphinx_internal.h"
 #include "ngram_search.h"
+#include "phone_loop_search.h"
 #include "cmusphinx_amd.h"
 
 #define PSAMD_DESC_T s3a_psfwd_desc_t
@@ -50,6 +53,7 @@ typedef struct {
     int32 max_frames;
     uint8 *flags;
     uint16 *sp_ssid;
+    int32 *pl;                      /* [n_ci] -pl_window: the phone loop's scores of the frame */
 } amd_search_t;
 
 #define BINDING(search) ((amd_search_t *)(search)->vt)
@@ -59,8 +63,8 @@ amd_build(amd_search_t *b, ngram_search_t *ngs)
 {
     if (b->e) { s3a_psfwd_free(b->e); b->e = NULL; }
     psamd_pool_free(&b->pool);
-    ckd_free(b->flags); ckd_free(b->sp_ssid);
-    b->flags = NULL; b->sp_ssid = NULL;
+    ckd_free(b->flags); ckd_free(b->sp_ssid); ckd_free(b->pl);
+    b->flags = NULL; b->sp_ssid = NULL; b->pl = NULL;
     if (psamd_export(b->ps, ngs, &b->desc, &b->pool) < 0) return -1;
     {
         /* the lanes' capacities from the configuration: frames per utterance (this program's PSAMD_MAX_FRAMES variable, up to the
@@ -77,6 +81,7 @@ amd_build(amd_search_t *b, ngram_search_t *ngs)
     }
     b->flags = ckd_calloc(b->desc.n_sen, 1);
     b->sp_ssid = ckd_calloc((size_t)b->desc.n_1ph * b->desc.n_emit + 1, sizeof(uint16));
+    b->pl = ckd_calloc(b->desc.n_ci + 1, sizeof(int32));
     return 0;
 }
 
@@ -125,6 +130,14 @@ amd_step(ps_search_t *search, int frame_idx)
             if (b->flags[s]) acmod_activate_sen(acmod, s);
     }
     if ((senscr = acmod_score(acmod, &frame_idx)) == NULL) return 0;
+    if (ps_search_lookahead(search)) {
+        /* -pl_window: the decoder's phone loop (stepped by ps_search_forward in front of this search, pocketsphinx.c:704-712) says
+         * what every transition of this frame adds, phone by phone (phone_loop_search.h:103-105) */
+        phone_loop_search_t *pls = (phone_loop_search_t *)ps_search_lookahead(search);
+        int32 ci;
+        for (ci = 0; ci < b->desc.n_ci; ci++) b->pl[ci] = phone_loop_search_score(pls, ci);
+        if (s3a_psfwd_set_lookahead(b->e, 0, b->pl) != S3A_OK) { E_ERROR("s3a_psfwd_set_lookahead: %s\n", s3a_last_error()); return -1; }
+    }
     if ((rv = s3a_psfwd_step(b->e, 0, senscr, frame_idx, acmod->n_senone_active)) < 0) E_ERROR("s3a_psfwd_step: %s\n", s3a_last_error());
     return rv;
 }
@@ -232,7 +245,7 @@ amd_free(ps_search_t *search)
     if (b->e) s3a_psfwd_free(b->e);
     if (b->scorer) s3a_ps_ms_mgau_free(b->scorer);
     psamd_pool_free(&b->pool);
-    ckd_free(b->flags); ckd_free(b->sp_ssid);
+    ckd_free(b->flags); ckd_free(b->sp_ssid); ckd_free(b->pl);
     ckd_free(b);
     orig->free(search);
 }

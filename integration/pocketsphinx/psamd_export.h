@@ -26,13 +26,14 @@
 #include "lm3g_model.h"                 /* ... and lm3g_model_t's */
 #include "pocketsphinx_internal.h"
 #include "ngram_search.h"
+#include "phone_loop_search.h"
 
 #ifndef PSAMD_DESC_T
 #error "define PSAMD_DESC_T before including psamd_export.h"
 #endif
 
 typedef struct {
-    void *ptr[64];
+    void *ptr[96];
     int n;
 } psamd_pool_t;
 
@@ -40,7 +41,7 @@ static void *
 psamd_alloc(psamd_pool_t *pool, size_t n, size_t sz)
 {
     void *p = ckd_calloc(n ? n : 1, sz);
-    if (pool->n >= 64) E_FATAL("psamd_export: pool exhausted\n");
+    if (pool->n >= 96) E_FATAL("psamd_export: pool exhausted\n");
     pool->ptr[pool->n++] = p;
     return p;
 }
@@ -100,7 +101,6 @@ psamd_export(ps_decoder_t *ps, ngram_search_t *ngs, PSAMD_DESC_T *d, psamd_pool_
     memset(d, 0, sizeof(*d));
     pool->n = 0;
     if (!ngs->fwdtree) { E_ERROR("psamd_export: -fwdtree is off\n"); return -1; }
-    if (ps_search_lookahead(ngs)) { E_ERROR("psamd_export: -pl_window > 0 (phone loop look-ahead) is not served\n"); return -1; }
     if (n_emit != 3 && n_emit != 5) { E_ERROR("psamd_export: %d emitting states (3 or 5 served)\n", n_emit); return -1; }
     if ((lm = ngram_model_set_lookup(ngs->lmset, NULL)) == NULL) {
         E_ERROR("psamd_export: interpolated LM sets are not served\n");
@@ -294,6 +294,16 @@ psamd_export(ps_decoder_t *ps, ngram_search_t *ngs, PSAMD_DESC_T *d, psamd_pool_
     d->beam = ngs->beam; d->pbeam = ngs->pbeam; d->wbeam = ngs->wbeam; d->lpbeam = ngs->lpbeam;
     d->lponlybeam = ngs->lponlybeam; d->fillpen = ngs->fillpen; d->silpen = ngs->silpen; d->nwpen = ngs->nwpen;
     d->pip = ngs->pip; d->maxwpf = ngs->maxwpf; d->maxhmmpf = ngs->maxhmmpf;
+
+    /* ---- phone loop look-ahead (-pl_window; phone_loop_search.c:69-108): the loop's HMMs and beams as the decoder holds them ---- */
+    if (ps_search_lookahead(ngs)) {
+        phone_loop_search_t *pls = (phone_loop_search_t *)ps_search_lookahead(ngs);
+        uint16 *cs = psamd_alloc(pool, n_ci, sizeof(uint16));
+        int16 *ct = psamd_alloc(pool, n_ci, sizeof(int16));
+        for (i = 0; i < n_ci; i++) { cs[i] = bin_mdef_pid2ssid(mdef, i); ct[i] = bin_mdef_pid2tmatid(mdef, i); }
+        d->pl_window = ps->pl_window; d->pl_beam = pls->beam; d->pl_pbeam = pls->pbeam; d->pl_pip = pls->pip;
+        d->ci_ssid = cs; d->ci_tmat = ct;
+    }
     return 0;
 }
 

@@ -16,6 +16,7 @@
 #include <sphinxbase/bitvec.h>
 #include "pocketsphinx_internal.h"
 #include "ngram_search.h"
+#include "phone_loop_search.h"
 #include "s3o_psfwd.h"
 
 #define PSAMD_DESC_T s3o_psfwd_desc_t
@@ -66,6 +67,14 @@ o_step(ps_search_t *search, int frame_idx)
             if (b->flags[s]) acmod_activate_sen(acmod, s);
     }
     if ((senscr = acmod_score(acmod, &frame_idx)) == NULL) return 0;
+    if (ps_search_lookahead(search)) {
+        /* -pl_window: the decoder's own phone loop says what this frame's transitions add (phone_loop_search.h:103-105) */
+        phone_loop_search_t *pls = (phone_loop_search_t *)ps_search_lookahead(search);
+        int32 *pl = ckd_calloc(b->desc.n_ci, sizeof(int32)), ci;
+        for (ci = 0; ci < b->desc.n_ci; ci++) pl[ci] = phone_loop_search_score(pls, ci);
+        s3o_psfwd_set_lookahead(b->o, pl);
+        ckd_free(pl);
+    }
     {
         extern FILE *g_trace;
         s3o_psfwd_t *o = b->o;

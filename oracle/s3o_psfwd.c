@@ -254,6 +254,7 @@ s3o_psfwd_init(const s3o_psfwd_desc_t *d)
     s->cand = calloc(d->n_words + 1, sizeof(*s->cand));
     s->ltrans = calloc(d->n_words, sizeof(*s->ltrans));
     s->bestrc = calloc(d->n_ci, sizeof(*s->bestrc));
+    s->pl = calloc(d->n_ci > 0 ? d->n_ci : 1, 4);
     s->word_lat_idx = malloc(sizeof(int32_t) * d->n_words);
     s->bp_cap = 5000;
     s->bp_frame = malloc(4 * s->bp_cap); s->bp_wid = malloc(4 * s->bp_cap); s->bp_bp = malloc(4 * s->bp_cap);
@@ -293,8 +294,16 @@ s3o_psfwd_free(s3o_psfwd_t *s)
     free(s->word_active); free(s->cand); free(s->ltrans); free(s->bestrc); free(s->word_lat_idx);
     free(s->cand_sf_ef); free(s->cand_sf_cand);
     free(s->bp_frame); free(s->bp_wid); free(s->bp_bp); free(s->bp_score); free(s->bp_sidx); free(s->bp_realwid);
-    free(s->bp_valid); free(s->bss); free(s->bp_table_idx);
+    free(s->bp_valid); free(s->bss); free(s->bp_table_idx); free(s->pl);
     free(s);
+}
+
+/* what the next step adds at its transitions: phone_loop_search_score(pls, ci) of the decoder's phone loop
+ * (phone_loop_search.h:103-105), which ps_search_forward steps in front of this search (pocketsphinx.c:704-712) */
+void
+s3o_psfwd_set_lookahead(s3o_psfwd_t *s, const int32_t *pl)
+{
+    for (int32_t i = 0; i < s->d.n_ci; i++) s->pl[i] = pl ? pl[i] : 0;
 }
 
 /* ngram_fwdtree_start :464-507 */
@@ -416,8 +425,10 @@ evaluate_channels(s3o_psfwd_t *s, int32_t frame_idx)
     s->last_phone_best_score = bs;
 }
 
-/* the successor transitions shared by prune_root_chan :737-784 and prune_nonroot_chan :822-863 (no phone loop:
- * phone_loop_search_score = 0) */
+/* the successor transitions shared by prune_root_chan :737-784 and prune_nonroot_chan :822-863.  With the phone loop
+ * (pls != NULL: d->pl_window > 0) the tests in front of the two loops are not made and every transition adds
+ * phone_loop_search_score of the phone it enters (:745-753, :765-780, :824-840, :847-861); without it s->pl is all zeros
+ * and the tests inside the loops are the ones in front of them. */
 static void
 phone_transitions(s3o_psfwd_t *s, int32_t c, int32_t frame_idx, int is_root, int32_t **nacl)
 {
@@ -426,20 +437,26 @@ phone_transitions(s3o_psfwd_t *s, int32_t c, int32_t frame_idx, int is_root, int
     const int32_t nf = frame_idx + 1;
     const int32_t newphone_thresh = add32(s->best_score, d->pbeam), lastphn_thresh = add32(s->best_score, d->lpbeam);
     const int32_t newphone_score = add32(h->out_score, d->pip);
-    if (newphone_score > newphone_thresh)
+    const int pls = d->pl_window > 0;
+    if (pls || newphone_score > newphone_thresh)
         for (int32_t e = d->ch_child_off[c]; e < d->ch_child_off[c + 1]; e++) {
-            s3o_pshmm_t *nh = &s->hmm[d->ch_child[e]];
-            if (nh->frame < frame_idx || newphone_score > nh->score[0]) {
-                if (is_root || nh->frame != nf) *((*nacl)++) = d->ch_child[e];
-                hmm_enter(nh, newphone_score, h->out_hist, nf);
+            const int32_t x = d->ch_child[e];
+            s3o_pshmm_t *nh = &s->hmm[x];
+            const int32_t pl_score = add32(newphone_score, s->pl[d->nr_ci[x - d->n_root]]);
+            if (pl_score > newphone_thresh && (nh->frame < frame_idx || pl_score > nh->score[0])) {
+                if (is_root || nh->frame != nf) *((*nacl)++) = x;
+                hmm_enter(nh, pl_score, h->out_hist, nf);
             }
         }
-    if (newphone_score > lastphn_thresh)
+    if (pls || newphone_score > lastphn_thresh)
         for (int32_t e = d->ch_pen_off[c]; e < d->ch_pen_off[c + 1]; e++) {
-            s3o_pscand_t *cp = &s->cand[s->n_cand++];
-            cp->wid = d->ch_pen_wid[e];
-            cp->score = sub32(newphone_score, d->nwpen);
-            cp->bp = h->out_hist;
+            const int32_t w = d->ch_pen_wid[e], pl_score = add32(newphone_score, s->pl[d->w_last_ci[w]]);
+            if (pl_score > lastphn_thresh) {
+                s3o_pscand_t *cp = &s->cand[s->n_cand++];
+                cp->wid = w;
+                cp->score = sub32(pl_score, d->nwpen);
+                cp->bp = h->out_hist;
+            }
         }
 }
 
@@ -742,7 +759,7 @@ word_transition(s3o_psfwd_t *s, int32_t frame_idx)
     for (i = 0; i < d->n_root; i++) {
         s3o_pshmm_t *h = &s->hmm[i];
         const s3o_psbestrc_t *b = &s->bestrc[d->root_ci[i]];
-        newscore = add32(add32(b->score, d->nwpen), d->pip);
+        newscore = add32(add32(add32(b->score, d->nwpen), d->pip), s->pl[d->root_ci[i]]);
         if (newscore > thresh && (h->frame < frame_idx || newscore > h->score[0])) {
             hmm_enter(h, newscore, b->path, nf);
             h->senid[0] = d->root_lc_ssid[i * d->n_ci + b->lc];
@@ -764,7 +781,7 @@ word_transition(s3o_psfwd_t *s, int32_t frame_idx)
         const int32_t w = d->sp_wid[i];
         s3o_pshmm_t *h = &s->hmm[s->sp_base + i];
         if (w == d->start_wid) continue;
-        newscore = add32(s->ltrans[w].dscr, d->pip);
+        newscore = add32(add32(s->ltrans[w].dscr, d->pip), s->pl[d->sp_ci[i]]);
         if (newscore > thresh && (h->frame < frame_idx || newscore > h->score[0])) {
             hmm_enter(h, newscore, s->ltrans[w].bp, nf);
             h->senid[0] = d->sp_lc_ssid[i * d->n_ci + d->w_last_ci[s->bp_wid[s->ltrans[w].bp]]];
@@ -773,11 +790,11 @@ word_transition(s3o_psfwd_t *s, int32_t frame_idx)
     {
         const s3o_psbestrc_t *b = &s->bestrc[d->sil_ci];
         s3o_pshmm_t *h = &s->hmm[s->sp_base + s->w_sp[d->silence_wid]];
-        newscore = add32(add32(b->score, d->silpen), d->pip);
+        newscore = add32(add32(add32(b->score, d->silpen), d->pip), s->pl[d->sp_ci[s->w_sp[d->silence_wid]]]);
         if (newscore > thresh && (h->frame < frame_idx || newscore > h->score[0])) hmm_enter(h, newscore, b->path, nf);
         for (i = 0; i < d->n_fill; i++) {
             h = &s->hmm[s->sp_base + d->fill_sp[i]];
-            newscore = add32(add32(b->score, d->fillpen), d->pip);
+            newscore = add32(add32(add32(b->score, d->fillpen), d->pip), s->pl[d->sp_ci[d->fill_sp[i]]]);
             if (newscore > thresh && (h->frame < frame_idx || newscore > h->score[0])) hmm_enter(h, newscore, b->path, nf);
         }
     }

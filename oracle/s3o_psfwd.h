@@ -53,6 +53,9 @@ typedef struct s3o_psfwd_desc_s {
     const int32_t *bg_wid, *bg_prob, *bg_bowt, *bg_firsttg;
     const int32_t *tg_wid, *tg_prob;
     int32_t beam, pbeam, wbeam, lpbeam, lponlybeam, fillpen, silpen, nwpen, pip, maxwpf, maxhmmpf;
+    int32_t pl_window, pl_beam, pl_pbeam, pl_pip;   /* phone loop look-ahead (phone_loop_search.c); 0: off */
+    const uint16_t *ci_ssid;
+    const int16_t *ci_tmat;
 } s3o_psfwd_desc_t;
 
 /* hmm_t (hmm.h:156-173) */
@@ -91,10 +94,12 @@ typedef struct s3o_psfwd_s {
     int32_t st_n_root_chan_eval, st_n_nonroot_chan_eval, st_n_last_chan_eval, st_n_word_lastchan_eval,
         st_n_lastphn_cand_utt, st_n_senone_active_utt;
     const int16_t *senscr;
+    int32_t *pl;                    /* [n_ci] phone_loop_search_score of the frame (zeros without -pl_window) */
 } s3o_psfwd_t;
 
 s3o_psfwd_t *s3o_psfwd_init(const s3o_psfwd_desc_t *d);
 void s3o_psfwd_free(s3o_psfwd_t *s);
+void s3o_psfwd_set_lookahead(s3o_psfwd_t *s, const int32_t *pl);
 void s3o_psfwd_reset(s3o_psfwd_t *s);
 void s3o_psfwd_start(s3o_psfwd_t *s);
 /* compute_sen_active: flags[n_sen] set to 0/1; returns the number of active senones */

@@ -22,10 +22,11 @@ class Desc(C.Structure):
         [("n_1ph", I32), ("n_1ph_lm", I32)] + [(n, P) for n in ("sp_wid", "sp_ssid0", "sp_lc_ssid", "sp_tmat", "sp_ci")] + \
         [("n_fill", I32), ("fill_sp", P)] + [(n, I32) for n in ("lm_order", "lm_n_ug", "lm_n_bg", "lm_n_tg", "lm_zero")] + \
         [(n, P) for n in ("ug_prob", "ug_bowt", "ug_firstbg", "bg_wid", "bg_prob", "bg_bowt", "bg_firsttg", "tg_wid", "tg_prob")] + \
-        [(n, I32) for n in ("beam", "pbeam", "wbeam", "lpbeam", "lponlybeam", "fillpen", "silpen", "nwpen", "pip", "maxwpf", "maxhmmpf")]
+        [(n, I32) for n in ("beam", "pbeam", "wbeam", "lpbeam", "lponlybeam", "fillpen", "silpen", "nwpen", "pip", "maxwpf", "maxhmmpf")] + \
+        [(n, I32) for n in ("pl_window", "pl_beam", "pl_pbeam", "pl_pip")] + [("ci_ssid", P), ("ci_tmat", P)]
 
 
-def make_desc(seed, n_emit=3, n_ci=10, n_real=40, n_sen=160, lm_order=3, maxwpf=-1, maxhmmpf=-1, skips=True, beam=-2500):
+def make_desc(seed, n_emit=3, n_ci=10, n_real=40, n_sen=160, lm_order=3, maxwpf=-1, maxhmmpf=-1, skips=True, beam=-2500, pl_window=0):
     """-> (Desc, dict of the numpy arrays it points into)"""
     r = np.random.default_rng(seed)
     A = {}
@@ -152,7 +153,24 @@ def make_desc(seed, n_emit=3, n_ci=10, n_real=40, n_sen=160, lm_order=3, maxwpf=
     d.lm_order, d.lm_n_ug, d.lm_n_bg, d.lm_n_tg, d.lm_zero = lm_order, V, len(bgw), len(tgw), -(1 << 28)
     d.beam, d.pbeam, d.wbeam, d.lpbeam, d.lponlybeam = beam, beam, int(beam * 0.7), int(beam * 0.8), int(beam * 0.6)
     d.fillpen, d.silpen, d.nwpen, d.pip, d.maxwpf, d.maxhmmpf = -45, -20, -7, -3, maxwpf, maxhmmpf
+    if pl_window > 0:       # the phone loop's HMMs (frame-synchronous use needs only pl_window != 0: the host hands the scores over)
+        A["ci_ssid"] = np.ascontiguousarray(r.integers(0, n_sseq, n_ci).astype(np.uint16))
+        A["ci_tmat"] = np.ascontiguousarray(r.integers(0, n_tmat, n_ci).astype(np.int16))
+        d.ci_ssid, d.ci_tmat = A["ci_ssid"].ctypes.data, A["ci_tmat"].ctypes.data
+        d.pl_window, d.pl_beam, d.pl_pbeam, d.pl_pip = pl_window, 4 * beam, 2 * beam, -2
     return d, A
+
+
+def make_lookahead(seed, n_frames, n_ci):
+    """phone_loop_search_score per frame and CI phone: 0 for the loop's best phone, negative for the others, WORST_SCORE minus
+    the loop's best score for a phone the loop has pruned (hmm_clear_scores)"""
+    r = np.random.default_rng(seed)
+    pl = -r.integers(0, 900, (n_frames, n_ci)).astype(np.int64)
+    for t in range(n_frames):
+        pl[t, r.integers(0, n_ci)] = 0
+        if t % 5 == 2:
+            pl[t, r.integers(0, n_ci)] = -0x20000000 + int(r.integers(0, 100000))
+    return np.ascontiguousarray(pl.astype(np.int32))
 
 
 def make_senscr(seed, n_frames, n_sen):
@@ -191,6 +209,9 @@ class Oracle:
 
     def step(self, senscr, f, n_active):
         return self.L.s3o_psfwd_step(self.h, senscr.ctypes.data_as(P), I32(f), I32(n_active))
+
+    def set_lookahead(self, pl):
+        self.L.s3o_psfwd_set_lookahead(self.h, pl.ctypes.data_as(P) if pl is not None else None)
 
     def finish(self, cf):
         self.L.s3o_psfwd_finish(self.h, I32(cf))
@@ -253,6 +274,9 @@ class Device:
 
     def step(self, senscr, f, n_active, lane=0):
         return self.chk(self.L.s3a_psfwd_step(self.h, lane, senscr.ctypes.data_as(P), f, n_active))
+
+    def set_lookahead(self, pl, lane=0):
+        self.chk(self.L.s3a_psfwd_set_lookahead(self.h, lane, pl.ctypes.data_as(P) if pl is not None else None))
 
     def finish(self, cf, lane=0):
         self.chk(self.L.s3a_psfwd_finish(self.h, lane, cf))

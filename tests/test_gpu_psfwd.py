@@ -63,6 +63,48 @@ def test_whole_utterances_from_a_queue(tmp_path, lanes):
     assert a[0] == r[0] and a[1] == r[1]
 
 
+# ---- -pl_window: the phone loop look-ahead (phone_loop_search.c; pocketsphinx.c:242-248, :704-712, :823-826) ----
+@pytest.mark.parametrize("model,window", [("sc", 3), ("cont", 5)])
+def test_lookahead_frame_synchronous(tmp_path, model, window):
+    """the decoder's own phone loop stays on the host and hands its scores over before every step (s3a_psfwd_set_lookahead)"""
+    args = (P.sc_args if model == "sc" else P.cont_args)(tmp_path) + P.FIRST_PASS_ONLY
+    r, a = pair(args + ["-pl_window", str(window)], tmp_path)
+    P.assert_same(r, a)
+    r0 = P.run("ref_ps_fwd", args, tmp_path, "ref0")
+    assert r0[0] != r[0], "the look-ahead changed no path score: the case does not test it"
+
+
+@pytest.mark.parametrize("lanes,window,extra", [(1, 3, []), (8, 5, []), (31, 1, []), (16, 4, ["-compallsen", "yes"]),
+                                                (8, 2, ["-pl_beam", "1e-3", "-pl_pbeam", "1e-2"])],
+                         ids=["1x3", "8x5", "31x1", "allsen", "narrow_loop_beams"])
+def test_lookahead_whole_utterances(tmp_path, lanes, window, extra):
+    """the phone loop ON THE DEVICE, inside the lane's launch, pl_window frames ahead of the lane's search: tables identical"""
+    args = P.cont_args(tmp_path) + P.FIRST_PASS_ONLY + ["-fresh", "yes", "-pl_window", str(window)] + extra
+    r, a = pair(args, tmp_path, ["-batch", str(lanes)])
+    P.assert_same(r, a)
+
+
+def test_lookahead_whole_utterances_keep_decoder_state(tmp_path):
+    """one lane, no resets: the senones the last utterance's final search step flagged are still flagged when the next
+    utterance's phone loop starts (acmod_start_utt does not clear them) -- they take part in its frames' normalisation"""
+    r, a = pair(P.cont_args(tmp_path) + P.FIRST_PASS_ONLY + ["-pl_window", "4"], tmp_path, ["-batch", "1"])
+    P.assert_same(r, a)
+
+
+@pytest.mark.parametrize("lanes", [4, 31])
+def test_lookahead_from_a_queue(tmp_path, lanes):
+    args = P.cont_args(tmp_path) + P.FIRST_PASS_ONLY + ["-fresh", "yes", "-pl_window", "3"]
+    r = P.run("ref_ps_fwd", args, tmp_path, "ref")
+    a = P.run("ref_ps_amdfwd", args + ["-batch", str(lanes), "-queue", "yes"], tmp_path, "amd")
+    assert a[0] == r[0] and a[1] == r[1]
+
+
+def test_lookahead_default_passes(tmp_path):
+    """fwdflat + bestpath (the reference's host code) on the device's table, the look-ahead on"""
+    r, a = pair(P.sc_args(tmp_path) + ["-pl_window", "2"], tmp_path)
+    P.assert_same(r, a, tables=False)
+
+
 def test_goforward_raw(tmp_path):
     r, a = pair(P.turtle_args(tmp_path, ("goforward", "numbers", "something")) + P.FIRST_PASS_ONLY, tmp_path)
     P.assert_same(r, a)

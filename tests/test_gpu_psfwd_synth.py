@@ -22,13 +22,19 @@ CASES = {
     "unigram": dict(n_emit=5, lm_order=1),
     "renormalize": dict(n_emit=3, n_real=16, beam=-268434000),
     "big": dict(n_emit=3, n_ci=30, n_real=400, n_sen=600, maxwpf=20),
+    # -pl_window (phone loop look-ahead): what the decoder's phone loop adds at every transition, handed over frame by frame
+    "lookahead_3state": dict(n_emit=3, pl_window=3),
+    "lookahead_5state_maxwpf": dict(n_emit=5, maxwpf=3, pl_window=2),
+    "lookahead_big": dict(n_emit=3, n_ci=30, n_real=400, n_sen=600, maxwpf=20, pl_window=4),
 }
 
 
-def decode(o, dev, scr, check_flags=True):
+def decode(o, dev, scr, check_flags=True, pl=None):
     n = len(scr)
     o.start(); dev.start()
     for f in range(n):
+        if pl is not None:
+            o.set_lookahead(pl[f]); dev.set_lookahead(pl[f])
         fo = o.sen_active(f)
         if check_flags:
             fd = dev.sen_active(f)
@@ -48,17 +54,29 @@ def test_device_first_pass_matches_restatement(gpu_lib, case):
     kw = CASES[case]
     desc, keep = S.make_desc(11 + len(case), **kw)
     o, dev = S.Oracle(desc), S.Device(gpu_lib, desc, n_lanes=2, max_frames=128, bp_cap=1 << 18, bss_cap=1 << 22)
-    n = 100 if case != "big" else 60
-    t1 = decode(o, dev, S.make_senscr(5, n, desc.n_sen))
+    n = 100 if "big" not in case else 60
+    pl = S.make_lookahead(9, n, desc.n_ci) if kw.get("pl_window") else None
+    t1 = decode(o, dev, S.make_senscr(5, n, desc.n_sen), pl=pl)
     assert t1["bpidx"] > 50, "the synthetic task must produce word exits"
     if case == "renormalize":
         assert t1["renorm"] == 1
-    t2 = decode(o, dev, S.make_senscr(6, n, desc.n_sen), check_flags=(case != "big"))
+    t2 = decode(o, dev, S.make_senscr(6, n, desc.n_sen), check_flags=("big" not in case), pl=pl)
     # a NEW decoder gives the first result again; a used one need not
     o.reset(); dev.reset()
-    t3 = decode(o, dev, S.make_senscr(5, n, desc.n_sen), check_flags=False)
+    t3 = decode(o, dev, S.make_senscr(5, n, desc.n_sen), check_flags=False, pl=pl)
     assert S.diff_tables(t1, t3) == []
     del t2
+    if pl is not None:      # the look-ahead decides: without it the same frames give another table
+        o.reset(); dev.reset()
+        t4 = decode(o, dev, S.make_senscr(5, n, desc.n_sen), check_flags=False, pl=np.zeros_like(pl))
+        assert S.diff_tables(t1, t4) != []
+
+
+def test_lookahead_needs_an_engine_built_for_it(gpu_lib):
+    desc, keep = S.make_desc(3, n_emit=3)
+    dev = S.Device(gpu_lib, desc, n_lanes=1, max_frames=32)
+    with pytest.raises(gpu_lib.S3AError, match="pl_window 0"):
+        dev.set_lookahead(np.zeros(desc.n_ci, np.int32))
 
 
 def test_table_overflow_is_loud(gpu_lib):

@@ -51,6 +51,17 @@ def test_new_decoder_per_utterance(tmp_path):
     P.assert_same(r, o)
 
 
+@pytest.mark.parametrize("model,window", [("sc", 3), ("cont", 5), ("cont", 1)])
+def test_phone_loop_lookahead(tmp_path, model, window):
+    """-pl_window: the decoder's own phone loop (phone_loop_search.c, stepped in front of the search) hands its scores to the
+    restatement's transitions; whole tables against the unmodified decoder, and the look-ahead must matter"""
+    args = (P.sc_args if model == "sc" else P.cont_args)(tmp_path) + P.FIRST_PASS_ONLY
+    r, o = both(args + ["-pl_window", str(window)], tmp_path)
+    P.assert_same(r, o)
+    r0 = P.run("ref_ps_fwd", args, tmp_path, "ref0")
+    assert r0[0] != r[0], "the look-ahead changed no path score: the case does not test it"
+
+
 def test_goforward_raw(tmp_path):
     r, o = both(P.turtle_args(tmp_path, ("goforward", "numbers", "something")) + P.FIRST_PASS_ONLY, tmp_path)
     P.assert_same(r, o)
