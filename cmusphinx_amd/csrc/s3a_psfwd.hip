@@ -91,6 +91,7 @@ struct PsfModel {
     const uint8_t *tp;
     int32_t n_words, start_wid, finish_wid, silence_wid;
     const int32_t *w_basewid, *w_lmwid, *w_rcsize, *w_rc_base, *w_rc_row;
+    const int32_t *w_lmcw;                      /* class-based LMs: a word's in-class weight (NULL: no class words) */
     const int16_t *w_first_ci, *w_last_ci, *w_last2_ci, *rc_cimap;
     const uint8_t *w_flags;
     int32_t n_root, n_nonroot, n_ch, sp_base, rc_base, n_hmm, n_mpx;
@@ -216,15 +217,18 @@ __device__ int32_t
 lm_tg_score(const PsfModel &M, int32_t w3, int32_t w2, int32_t w1)
 {
     const int32_t m3 = M.w_lmwid[w3], m2 = w2 < 0 ? -1 : M.w_lmwid[w2], m1 = w1 < 0 ? -1 : M.w_lmwid[w1];
-    if (m3 < 0) return M.lm_zero;
-    if (M.lm_order < 2) return M.ug_prob[m3];
-    if (M.lm_order < 3 || m1 < 0 || m2 < 0) return lm_bg(M, m2, m3);
+    /* class-based LMs (ngram_ng_score, sphinxbase ngram_model.c:494-521): a class word's id is its class's TAG word (target and history
+     * alike), its in-class weight is added to the tag's score; weight 1 = not in the class = the LM's zero */
+    const int32_t cw = M.w_lmcw ? M.w_lmcw[w3] : 0;
+    if (m3 < 0 || cw == 1) return M.lm_zero;
+    if (M.lm_order < 2) return add32(M.ug_prob[m3], cw);
+    if (M.lm_order < 3 || m1 < 0 || m2 < 0) return add32(lm_bg(M, m2, m3), cw);
     int32_t bowt = 0, tb = 0, te = 0;
     const int32_t b = lm_find(M.bg_wid, M.ug_firstbg[m1], M.ug_firstbg[m1 + 1], m2);
     if (b >= 0) { bowt = M.bg_bowt[b]; tb = M.bg_firsttg[b]; te = M.bg_firsttg[b + 1]; }
     const int32_t i = lm_find(M.tg_wid, tb, te, m3);
-    if (i >= 0) return M.tg_prob[i];
-    return add32(bowt, lm_bg(M, m2, m3));
+    if (i >= 0) return add32(M.tg_prob[i], cw);
+    return add32(add32(bowt, lm_bg(M, m2, m3)), cw);
 }
 
 /* ngram_search_exit_score, ngram_search.c:601-622 */
@@ -1602,6 +1606,7 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     UP(M.sseq, d->sseq, (size_t)d->n_sseq * NE);
     UP(M.tp, d->tp, (size_t)d->n_tmat * NE * (NE + 1));
     UP(M.w_basewid, d->w_basewid, W); UP(M.w_lmwid, d->w_lmwid, W);
+    if (d->w_lmcw) UP(M.w_lmcw, d->w_lmcw, W);
     UP(M.w_rcsize, rcsize.data(), W); UP(M.w_rc_base, rcbase.data(), W); UP(M.w_rc_row, d->w_rc_row, W);
     UP(M.w_first_ci, d->w_first_ci, W); UP(M.w_last_ci, d->w_last_ci, W); UP(M.w_last2_ci, d->w_last2_ci, W);
     UP(M.rc_cimap, d->rc_cimap, (size_t)d->n_rc_rows * d->n_ci);

@@ -248,6 +248,7 @@ _SIGS = {
     "s3a_psfwd_sen_active": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "s3a_psfwd_step": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
     "s3a_psfwd_finish": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "s3a_psfwd_set_lookahead": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p]),
     "s3a_psfwd_decode": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "s3a_psfwd_decode_queue": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
     "s3a_psfwd_queue_hyp": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p, C.c_int32]),

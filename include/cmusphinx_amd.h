@@ -1145,6 +1145,10 @@ typedef struct s3a_psfwd_desc_s {
     int32_t pl_window, pl_beam, pl_pbeam, pl_pip;
     const uint16_t *ci_ssid;
     const int16_t *ci_tmat;
+    /* class-based LMs (sphinxbase ngram_model.c:494-521, ngram_ng_score): a word of a class scores as the class's tag word -- w_lmwid
+     * holds the TAG's id for it, as target and as history -- plus its in-class weight w_lmcw[w] = ngram_class_prob (0 for a plain
+     * word; 1 = "not in its class": the score is the LM's zero).  NULL: no class words. */
+    const int32_t *w_lmcw;          /* [n_words] */
 } s3a_psfwd_desc_t;
 
 /* the finished (or running) backpointer table of a lane: bptbl_t by field, ngs->bscore_stack, ngs->bp_table_idx

@@ -126,7 +126,7 @@ psamd_export(ps_decoder_t *ps, ngram_search_t *ngs, PSAMD_DESC_T *d, psamd_pool_
     d->n_words = n_words;
     d->start_wid = dict_startwid(dict); d->finish_wid = dict_finishwid(dict); d->silence_wid = dict_silwid(dict);
     {
-        int32 *basewid = psamd_alloc(pool, n_words, sizeof(int32)), *lmwid = psamd_alloc(pool, n_words, sizeof(int32));
+        int32 *basewid = psamd_alloc(pool, n_words, sizeof(int32)), *lmwid = psamd_alloc(pool, n_words, sizeof(int32)), *lmcw = NULL;
         int16 *fci = psamd_alloc(pool, n_words, sizeof(int16)), *lci = psamd_alloc(pool, n_words, sizeof(int16));
         int16 *l2ci = psamd_alloc(pool, n_words, sizeof(int16)), *rctm = psamd_alloc(pool, n_words, sizeof(int16));
         uint8 *flags = psamd_alloc(pool, n_words, 1);
@@ -139,9 +139,13 @@ psamd_export(ps_decoder_t *ps, ngram_search_t *ngs, PSAMD_DESC_T *d, psamd_pool_
         for (w = 0; w < n_words; w++) {
             basewid[w] = dict_basewid(dict, w);
             lmwid[w] = ngram_model_set_current_wid(ngs->lmset, w);
-            if (lmwid[w] != NGRAM_INVALID_WID && (lmwid[w] & 0x80000000)) {
-                E_ERROR("psamd_export: class-based language models are not served\n");
-                return -1;
+            if (lmwid[w] != NGRAM_INVALID_WID && NGRAM_IS_CLASSWID(lmwid[w])) {
+                /* a word of a class (ngram_ng_score, ngram_model.c:505-516): scored -- and looked up as history -- as the class's tag
+                 * word, plus its in-class weight */
+                ngram_class_t *cl = lm->classes[NGRAM_CLASSID(lmwid[w])];
+                if (lmcw == NULL) lmcw = psamd_alloc(pool, n_words, sizeof(int32));
+                lmcw[w] = ngram_class_prob(cl, lmwid[w]);
+                lmwid[w] = cl->tag_wid;
             }
             fci[w] = dict_first_phone(dict, w);
             lci[w] = dict_last_phone(dict, w);
@@ -165,6 +169,7 @@ psamd_export(ps_decoder_t *ps, ngram_search_t *ngs, PSAMD_DESC_T *d, psamd_pool_
             for (i = 0; i < rs->n_ssid; i++) rcssid[rcoff[w] + i] = rs->ssid[i];
             for (i = 0; i < n_ci; i++) cimap[rcrow[w] * n_ci + i] = rs->cimap[i];
         }
+        d->w_lmcw = lmcw;
         d->w_basewid = basewid; d->w_lmwid = lmwid; d->w_first_ci = fci; d->w_last_ci = lci; d->w_last2_ci = l2ci;
         d->w_flags = flags; d->w_rc_off = rcoff; d->rc_ssid = rcssid; d->w_rc_row = rcrow; d->n_rc_rows = n_rows;
         d->rc_cimap = cimap; d->w_rc_tmat = rctm;

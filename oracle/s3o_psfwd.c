@@ -219,10 +219,13 @@ s3o_psfwd_tg_score(const s3o_psfwd_t *s, int32_t w3, int32_t w2, int32_t w1)
 {
     const s3o_psfwd_desc_t *d = &s->d;
     int32_t m3 = d->w_lmwid[w3], m2 = w2 < 0 ? -1 : d->w_lmwid[w2], m1 = w1 < 0 ? -1 : d->w_lmwid[w1];
+    /* a class word: w_lmwid is its class's tag word, the in-class weight is added to the tag's score (ngram_model.c:505-520) */
+    const int32_t cw = d->w_lmcw ? d->w_lmcw[w3] : 0;
     if (m3 < 0) return d->lm_zero;                  /* ngram_ng_score, ngram_model.c:501-502 */
-    if (d->lm_order < 2) return d->ug_prob[m3];     /* history truncated to n - 1 words, ngram_model_set.c:719-720 */
-    if (d->lm_order < 3) return lm_bg_score(d, m2, m3);
-    return lm_tg_score(d, m1, m2, m3);
+    if (cw == 1) return d->lm_zero;                 /* "not found in class" :509-510 */
+    if (d->lm_order < 2) return add32(d->ug_prob[m3], cw);     /* history truncated to n - 1 words, ngram_model_set.c:719-720 */
+    if (d->lm_order < 3) return add32(lm_bg_score(d, m2, m3), cw);
+    return add32(lm_tg_score(d, m1, m2, m3), cw);
 }
 
 /* ------------------------------------------------------------------ */

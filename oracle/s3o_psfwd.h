@@ -56,6 +56,7 @@ typedef struct s3o_psfwd_desc_s {
     int32_t pl_window, pl_beam, pl_pbeam, pl_pip;   /* phone loop look-ahead (phone_loop_search.c); 0: off */
     const uint16_t *ci_ssid;
     const int16_t *ci_tmat;
+    const int32_t *w_lmcw;          /* [n_words] in-class weights of class-based LMs (ngram_class_prob; 1: not in the class); NULL: none */
 } s3o_psfwd_desc_t;
 
 /* hmm_t (hmm.h:156-173) */

@@ -61,6 +61,23 @@ def zh_args(tmp_path, utts=("goforward", "numbers", "something")):
             "-ctl", ctl, "-cepdir", f"{LOCAL}/raw", "-cepext", ".raw", "-adcin", "yes"]
 
 
+def class_lm_args(tmp_path, two=False):
+    """the continuous tidigits model with a CLASS-based bigram through -lmctl / -lmname (tests/golden/tidigits_clm, written for
+    the sphinx3 LM-set tests: its words in this dictionary's upper case); two: a set of two LMs, the class bigram current"""
+    import re
+    src = os.path.join(GOLDEN, "tidigits_clm")
+    up = lambda t: re.sub(r"\b(one|two|three|four|five|six|seven|eight|nine|oh|zero)\b", lambda m: m.group(1).upper(), t)
+    for f in ("digits.probdef", "digits.cls.lm"):
+        (tmp_path / f).write_text(up(open(os.path.join(src, f)).read()))
+    ctl = tmp_path / "set.lmctl"
+    ctl.write_text(f"{{ {tmp_path}/digits.probdef }}\n{tmp_path}/digits.cls.lm digitclass {{\n[low]\n[high]\n}}\n"
+                   + (f"{TD}/tidigits.DMP plain\n" if two else ""))
+    args = cont_args(tmp_path)
+    i = args.index("-lm")
+    del args[i:i + 2]
+    return args + ["-lmctl", str(ctl), "-lmname", "digitclass"]
+
+
 FIRST_PASS_ONLY = ["-fwdflat", "no", "-bestpath", "no"]
 
 

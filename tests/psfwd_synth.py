@@ -23,10 +23,11 @@ class Desc(C.Structure):
         [("n_fill", I32), ("fill_sp", P)] + [(n, I32) for n in ("lm_order", "lm_n_ug", "lm_n_bg", "lm_n_tg", "lm_zero")] + \
         [(n, P) for n in ("ug_prob", "ug_bowt", "ug_firstbg", "bg_wid", "bg_prob", "bg_bowt", "bg_firsttg", "tg_wid", "tg_prob")] + \
         [(n, I32) for n in ("beam", "pbeam", "wbeam", "lpbeam", "lponlybeam", "fillpen", "silpen", "nwpen", "pip", "maxwpf", "maxhmmpf")] + \
-        [(n, I32) for n in ("pl_window", "pl_beam", "pl_pbeam", "pl_pip")] + [("ci_ssid", P), ("ci_tmat", P)]
+        [(n, I32) for n in ("pl_window", "pl_beam", "pl_pbeam", "pl_pip")] + [("ci_ssid", P), ("ci_tmat", P), ("w_lmcw", P)]
 
 
-def make_desc(seed, n_emit=3, n_ci=10, n_real=40, n_sen=160, lm_order=3, maxwpf=-1, maxhmmpf=-1, skips=True, beam=-2500, pl_window=0):
+def make_desc(seed, n_emit=3, n_ci=10, n_real=40, n_sen=160, lm_order=3, maxwpf=-1, maxhmmpf=-1, skips=True, beam=-2500, pl_window=0,
+              classes=False):
     """-> (Desc, dict of the numpy arrays it points into)"""
     r = np.random.default_rng(seed)
     A = {}
@@ -153,6 +154,11 @@ def make_desc(seed, n_emit=3, n_ci=10, n_real=40, n_sen=160, lm_order=3, maxwpf=
     d.lm_order, d.lm_n_ug, d.lm_n_bg, d.lm_n_tg, d.lm_zero = lm_order, V, len(bgw), len(tgw), -(1 << 28)
     d.beam, d.pbeam, d.wbeam, d.lpbeam, d.lponlybeam = beam, beam, int(beam * 0.7), int(beam * 0.8), int(beam * 0.6)
     d.fillpen, d.silpen, d.nwpen, d.pip, d.maxwpf, d.maxhmmpf = -45, -20, -7, -3, maxwpf, maxhmmpf
+    if classes:             # a class-based LM: in-class weights of a third of the words; one word is "not in its class" (weight 1)
+        cw = np.where(r.integers(0, 3, W) == 0, -r.integers(1, 40000, W), 0).astype(np.int32)
+        cw[5] = 1
+        A["w_lmcw"] = np.ascontiguousarray(cw)
+        d.w_lmcw = A["w_lmcw"].ctypes.data
     if pl_window > 0:       # the phone loop's HMMs (frame-synchronous use needs only pl_window != 0: the host hands the scores over)
         A["ci_ssid"] = np.ascontiguousarray(r.integers(0, n_sseq, n_ci).astype(np.uint16))
         A["ci_tmat"] = np.ascontiguousarray(r.integers(0, n_tmat, n_ci).astype(np.int16))

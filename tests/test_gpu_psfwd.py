@@ -105,6 +105,25 @@ def test_lookahead_default_passes(tmp_path):
     P.assert_same(r, a, tables=False)
 
 
+# ---- class-based LMs (-lmctl with class definitions; sphinxbase ngram_model.c:494-521) ----
+def test_class_based_lm_frame_synchronous(tmp_path):
+    r, a = pair(P.class_lm_args(tmp_path) + P.FIRST_PASS_ONLY, tmp_path)
+    P.assert_same(r, a)
+    assert "Added class [low]" in r[3]
+
+
+@pytest.mark.parametrize("lanes,extra", [(8, []), (31, ["-pl_window", "3"])], ids=["8", "31_lookahead"])
+def test_class_based_lm_whole_utterances(tmp_path, lanes, extra):
+    """a set of two LMs, the class bigram the current one; hypotheses (segment LM scores included) made on the device"""
+    r, a = pair(P.class_lm_args(tmp_path, two=True) + P.FIRST_PASS_ONLY + ["-fresh", "yes"] + extra, tmp_path, ["-batch", str(lanes)])
+    P.assert_same(r, a)
+
+
+def test_class_based_lm_default_passes(tmp_path):
+    r, a = pair(P.class_lm_args(tmp_path), tmp_path)
+    P.assert_same(r, a, tables=False)
+
+
 def test_goforward_raw(tmp_path):
     r, a = pair(P.turtle_args(tmp_path, ("goforward", "numbers", "something")) + P.FIRST_PASS_ONLY, tmp_path)
     P.assert_same(r, a)

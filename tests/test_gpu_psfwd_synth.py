@@ -26,6 +26,9 @@ CASES = {
     "lookahead_3state": dict(n_emit=3, pl_window=3),
     "lookahead_5state_maxwpf": dict(n_emit=5, maxwpf=3, pl_window=2),
     "lookahead_big": dict(n_emit=3, n_ci=30, n_real=400, n_sen=600, maxwpf=20, pl_window=4),
+    # class-based LM: in-class weights on top of the tag words' scores (trigram and bigram)
+    "class_lm": dict(n_emit=3, classes=True),
+    "class_lm_bigram_lookahead": dict(n_emit=5, lm_order=2, classes=True, pl_window=2),
 }
 
 

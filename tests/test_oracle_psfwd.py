@@ -62,6 +62,17 @@ def test_phone_loop_lookahead(tmp_path, model, window):
     assert r0[0] != r[0], "the look-ahead changed no path score: the case does not test it"
 
 
+@pytest.mark.parametrize("two", [False, True], ids=["one_lm", "set_of_two"])
+def test_class_based_lm(tmp_path, two):
+    """-lmctl with a class-based LM (ngram_ng_score's declassification, sphinxbase ngram_model.c:494-521): a class word scores as
+    its class's tag word plus its in-class weight"""
+    r, o = both(P.class_lm_args(tmp_path, two) + P.FIRST_PASS_ONLY, tmp_path)
+    P.assert_same(r, o)
+    plain = P.run("ref_ps_fwd", P.cont_args(tmp_path) + P.FIRST_PASS_ONLY, tmp_path, "plain")
+    assert plain[0] != r[0], "the class LM changed no path score: the case does not test it"
+    assert "Added class [low]" in r[3]
+
+
 def test_goforward_raw(tmp_path):
     r, o = both(P.turtle_args(tmp_path, ("goforward", "numbers", "something")) + P.FIRST_PASS_ONLY, tmp_path)
     P.assert_same(r, o)
