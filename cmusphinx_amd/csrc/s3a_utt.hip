@@ -1567,8 +1567,8 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
  * other).  Words that ATOMICS of an earlier phase changed are read past the L1 (S3A_ALD); the per-tree maxima are copied to
  * LDS once per frame and every later phase reads the copy.  LDS: the word level's arrays + one pool the other phases share
  * (two workgroups per CU).
- * Not served here (the engine then keeps the launch path): -pheurtype,
- * per-frame scoring (window = 0), the invariant checker, per-launch profiling; a queue with the second pass.
+ * Not served here (the engine then keeps the launch path): -pheurtype together with weak HMMs (-ptranskip / -pbeam wider than -beam) or
+ * with 5-state models, per-frame scoring (window = 0), the invariant checker, per-launch profiling.
  * ==================================================================================================================== */
 #define KF_NT WL_THREADS
 #define KF_WAVES (KF_NT / 64)
@@ -1922,7 +1922,9 @@ kf_dyn_ci_beam(const UShared &S, int32_t f, const int32_t *row, const uint32_t *
 }
 
 /* frame f of lane z (workgroup r of its C): row / brow = the frame's senone scores and best components */
-template <int NE, bool EXACT>
+/* HEUR: -pheurtype 1..3 (the phoneme look-ahead: the lane's heur_all / hth_pos, s3a_uttdec_enable_pheur) -- kernels of their own, so that the
+ * ones without it are compiled as before */
+template <int NE, bool EXACT, bool HEUR = false>
 __device__ __forceinline__ void
 kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict &dict, const WPar &par, KfSh &sh, KfBar &B, int32_t z,
          int32_t r, int32_t C, int32_t f, int32_t *row, const uint8_t *brow, int32_t weak_flags)
@@ -2434,6 +2436,45 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         if (r == 0 && hist_frame)
             for (int32_t i = tid; i < NBIN; i += KF_NT) L.hbin[i] = 0;         /* (the bins were consumed by the sort; hbin[NBIN] stays) */
         const int32_t *act = L.act[cur];
+        const HeurArgs hx = HEUR ? HeurArgs{ S.node_ci, L.heur_all + (size_t)f * S.n_ci, L.hth_pos } : HeurArgs{ NULL, NULL, NULL };
+        if (HEUR) {
+            /* the heuristic threshold of every propagating HMM by list position (ku_heur_thresh; lextree.c:1443-1462): per tree the running
+             * maximum over the list of max over children (out + (prob(child) - prob) + phn_heur[ci(child)]), plus pl_beam -- a tree per
+             * workgroup in turn, KF_NT positions per pass, the passes' carry through LDS */
+            const int32_t pth_ = sh.thr[1];
+            for (int32_t t = r; t < T; t += C) {
+                const int32_t na = nact_cur[t], b = sh.nb[t];
+                if (tid == 0) sh.gq[2] = INT_MIN;
+                __syncthreads();
+                for (int32_t i0 = 0; i0 < na; i0 += KF_NT) {
+                    const int32_t i = i0 + tid;
+                    int32_t m = INT_MIN;
+                    if (i < na) {
+                        const int32_t p = act[b + i], po = L.outs[NSV(p)];
+                        if (S.wid[p] < 0 && po >= pth_) {
+                            const int32_t pp = S.prob[p];
+                            for (int32_t q = S.child_off[p]; q < S.child_off[p + 1]; q++) {
+                                const int32_t c = S.child[q];
+                                m = max(m, add32(add32(po, add32(S.prob[c], -pp)), hx.heur[hx.node_ci[c]]));
+                            }
+                        }
+                    }
+                    int32_t x = m;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const int32_t y = __shfl_up(x, o, 64); if (lane >= o) x = max(x, y); }
+                    if (lane == 63) sh.ws[wave] = x;
+                    __syncthreads();
+                    int32_t pre = sh.gq[2];
+                    for (int32_t w = 0; w < wave; w++) pre = max(pre, sh.ws[w]);
+                    x = max(x, pre);
+                    if (i < na) L.hth_pos[b + i] = add32(x, S.pl_beam);
+                    __syncthreads();
+                    if (tid == KF_NT - 1) sh.gq[2] = x;
+                    __syncthreads();
+                }
+            }
+            kf_barrier(B);
+        }
         /* the frame's stamped parent sets as a filter in LDS (every stamp was listed: d_stamp_and_list and the stamping pass above), so
          * that the usual HMM -- nobody stamped its set -- is settled without a visit to pstamp8; a 3-state HMM's set id came with its
          * packed node and lies by list position (a histogram frame has reordered the positions: through the node then) */
@@ -2552,10 +2593,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                             if (np >= SET_NP_MIN && np <= 64) continue;
                         }
                     }
-                    d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                                       L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                                       S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b,
-                                                       HeurArgs{ NULL, NULL, NULL }, sh.thr);
+                    d_dec_resolve_node<uint8_t, HEUR>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                      L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                      S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, v, true, has_par, i, b,
+                                                      hx, sh.thr);
                 }
                 __syncthreads();
             }
@@ -2628,10 +2669,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (rs.pre[mid] <= m) lo = mid; else hi = mid - 1; }
                     const int32_t x = GMC(S.psmem)[rs.mlo[lo] + (m - rs.pre[lo])];
                     if (L.posf[PPX(x)] == f) continue;                               /* on the list: resolved by list position */
-                    d_dec_resolve_node<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                                       L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                                       S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, x, false, true, -1, -1,
-                                                       HeurArgs{ NULL, NULL, NULL }, sh.thr);
+                    d_dec_resolve_node<uint8_t, HEUR>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                      L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                      S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, x, false, true, -1, -1,
+                                                      hx, sh.thr);
                 }
                 KF_DT(6);
                 /* 3. the several-parent sets' propagating parents */
@@ -2687,6 +2728,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                         const bool on_list = GMC(L.posf)[PPX(x)] == f;                    /* (the list position pass leaves these members to us) */
                         if (!on_list && e0 < 0) continue;
                         const int32_t j = on_list ? GMC(L.pos)[PPX(x)] : INT_MAX, in0 = GMC(L.sc)[NSV(x)], px = GMC(S.prob)[x], b = sh.nb[GMC(S.tree_of)[x]];
+                        const int32_t hv = HEUR ? hx.heur[hx.node_ci[x]] : 0;
                         int32_t mE = INT_MIN, pE = INT_MAX, hE = -1, firstE = INT_MAX;
                         int32_t mL = INT_MIN, pL = INT_MAX, hL = -1, firstL = INT_MAX;
                         for (int32_t q = e0; q >= 0; q = rs.ent[q][4]) {
@@ -2694,6 +2736,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                             const int32_t ns = add32(e[0], add32(px, -e[3]));
                             if (ns < th) continue;
                             const int32_t up = e[1];
+                            if (HEUR && add32(ns, hv) < GMC(L.hth_pos)[b + up]) continue;       /* (the parent's threshold, by ITS list position) */
                             if (up < j) {
                                 if (ns > mE || (ns == mE && up < pE)) { mE = ns; pE = up; hE = e[2]; }
                                 if (ns > in0 && up < firstE) firstE = up;
@@ -2713,15 +2756,15 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     __syncthreads();
                     if (tid < rs.nleg) sh.seg[32 + tid] = rs.big[rs.leg[tid]];
                     __syncthreads();
-                    d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                                           L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                                           S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, sh.seg + 32, rs.nleg,
-                                                           S.psmem_off, S.psmem, wave, KF_WAVES, HeurArgs{ NULL, NULL, NULL }, rs.rc[wave], sh.thr);
+                    d_dec_resolve_children<uint8_t, HEUR>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                          L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                          S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, sh.seg + 32, rs.nleg,
+                                                          S.psmem_off, S.psmem, wave, KF_WAVES, hx, rs.rc[wave], sh.thr);
                     if (rs.nbig > KF_BIG)
-                        d_dec_resolve_children<uint8_t, false>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
-                                                               L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
-                                                               S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, rs.big + KF_BIG, rs.nbig - KF_BIG,
-                                                               S.psmem_off, S.psmem, wave, KF_WAVES, HeurArgs{ NULL, NULL, NULL }, rs.rc[wave], sh.thr);
+                        d_dec_resolve_children<uint8_t, HEUR>(S.N, T, f, bm, sh.best, nact_cur, S.node_base, S.tree_of, S.prob, S.par_off, S.par, L.pos, L.posf,
+                                                              L.sc, L.hist, L.outs, L.outh, L.bests, L.frame, L.turn, L.selfemit, L.cnt, L.key, L.first, L.hbin,
+                                                              S.ps, L.pstamp8, S.rootnodes, S.n_rootnodes, L.propf, L.posout, rs.big + KF_BIG, rs.nbig - KF_BIG,
+                                                              S.psmem_off, S.psmem, wave, KF_WAVES, hx, rs.rc[wave], sh.thr);
                 }
                 __syncthreads();
             }
@@ -2813,7 +2856,7 @@ kf_frame_call()
 #define KF_OCC 4
 #endif
 
-template <int NE, bool EXACT>
+template <int NE, bool EXACT, bool HEUR = false>
 __global__ void __launch_bounds__(KF_NT, KF_OCC)
 ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t n_lanes, int32_t C, int32_t *bar,
           int32_t weak_possible, int32_t local_ok)
@@ -2929,7 +2972,7 @@ ku_frames(const ULane *__restrict__ lanes, const KfArgs *__restrict__ A, int32_t
             kf_frame_call<NE, EXACT>();
             B.target = sh.fa.bar_target;
 #else
-            kf_frame<NE, EXACT>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, row, brow, weak_possible);
+            kf_frame<NE, EXACT, HEUR>(L, S, ctx, lm, dict, par, sh, B, z, r, C, f, row, brow, weak_possible);
 #endif
         }
         if (handed) break;
@@ -4216,7 +4259,9 @@ kf_served(const s3a_uttdec_t *ud, int32_t n)
     /* (a wide-beam engine -- big_wl, configs[4] -- is SERVED, word level and all, but keeps the launches unless asked: 23 000 HMMs and 300 000
      * word-level candidates per lane-frame want the whole chip per step, not a cluster of 8 workgroups -- 64 lanes: 10.4 k frames/s through
      * ku_frames against 30.5 k through the launches, 128 lanes 19.4 k : 36.1 k; profiles/r6_experiments.txt 8) */
-    return ud->persist && (ud->persist > 1 || (n >= KF_MIN_LANES && !ud->big_wl)) && S.win_K > 0 && S.pheurtype == 0 && !ud->d_dbg
+    /* (-pheurtype: with 3-state models, and not together with weak HMMs -- -ptranskip / -pbeam wider than -beam: ku_weak_heur stays a launch) */
+    return ud->persist && (ud->persist > 1 || (n >= KF_MIN_LANES && !ud->big_wl)) && S.win_K > 0
+        && (S.pheurtype == 0 || (S.ne == 3 && !ud->weak_possible)) && !ud->d_dbg
         && ud->prof_every == 0 && ((S.ne == 3 && S.nodepk) || S.ne == 5) && S.T <= WL_MAXT && S.n_sen <= KF_SENBITS;
 }
 
@@ -4261,11 +4306,11 @@ kf_choose_c(s3a_uttdec_t *ud, int32_t n)
 }
 
 /* n: lane slots of the launch (lanes 0 .. n - 1, or -- J.resume -- that many places of the relay's list); C: workgroups per lane */
-template <int NE, bool EXACT>
+template <int NE, bool EXACT, bool HEUR = false>
 static int32_t
 kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J, int32_t C)
 {
-    auto kern = ku_frames<NE, EXACT>;
+    auto kern = ku_frames<NE, EXACT, HEUR>;
     const int32_t lanes_per_xcd = (n + 7) / 8;
     if (!J.resume) ud->kf_last_c = C;
     const int32_t grid = C == 1 ? n : 8 * C * lanes_per_xcd;
@@ -4286,6 +4331,7 @@ static int32_t
 kf_launch_c(s3a_uttdec_t *ud, int32_t n, const KfJob &J, int32_t C)
 {
     if (ud->S.ne == 5) return ud->exact ? kf_launch_t<5, true>(ud, n, J, C) : kf_launch_t<5, false>(ud, n, J, C);
+    if (ud->S.pheurtype > 0) return ud->exact ? kf_launch_t<3, true, true>(ud, n, J, C) : kf_launch_t<3, false, true>(ud, n, J, C);       /* (kf_served: 3-state models) */
     return ud->exact ? kf_launch_t<3, true>(ud, n, J, C) : kf_launch_t<3, false>(ud, n, J, C);
 }
 
@@ -4825,13 +4871,14 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
     const UShared &S = ud->S;
     const bool graph_mode = ud->use_graph && ud->prof_every == 0;
     /* ku_frames (KF_QUEUE): the lanes take the utterances themselves -- no schedule, no refill events, no window boundaries */
-    const bool kfq = !graph_mode && kf_served(ud, min(ud->n_lanes, n_utt)) && !ud->dag;
+    const bool kfq = !graph_mode && kf_served(ud, min(ud->n_lanes, n_utt)) && !ud->dag && S.pheurtype == 0;
     /* ... and with the second pass (round 6): the queue as GROUPS of at most n_lanes utterances, longest first -- a group is lane z = its
      * z-th utterance from the first frame to the last in ONE ku_frames launch (KF_STATIC, with the relay), then every lane's hypothesis,
      * vithist_utt_end + the second pass while the tables are still the utterances' own, and lextree_utt_end; everything enqueued, nothing
      * waited for between groups (utterances of like length share a group, so a group's lanes end together).  Before: the frame as launches
      * with refill events, or -- asked for -- window blocks, the regime that lost to the launches. */
-    bool kfd = !graph_mode && kf_served(ud, min(ud->n_lanes, n_utt)) && ud->dag != NULL;
+    /* (-pheurtype goes the same way: the look-ahead's tables are a LANE's -- made when the lane begins its utterance, ku_ci_ahead / ku_phn_heur) */
+    bool kfd = !graph_mode && kf_served(ud, min(ud->n_lanes, n_utt)) && (ud->dag != NULL || S.pheurtype > 0);
     std::vector<int32_t> kfd_order;
     if (kfd) {
         kfd_order.resize((size_t)n_utt);
@@ -5023,6 +5070,12 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
             const int32_t m = min(ud->n_lanes, n_utt - k0);
             const int32_t *bl = ud->q_sched_d + (size_t)2 * k0, *bu = bl + m;
             hipLaunchKernelGGL(ku_lanes_begin, dim3(32, 1, m), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, B, bl, bu, (const UCtx *)ud->q_ctx_d);
+            if (S.pheurtype > 0) {      /* (the group's longest utterance is its first) */
+                const dim3 g((S.n_ci_sen * S.CP + 255) / 256, gn[k0], m);
+                if (ud->exact) hipLaunchKernelGGL(ku_ci_ahead<true>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S, bl);
+                else hipLaunchKernelGGL(ku_ci_ahead<false>, g, dim3(256), 0, ud->stream, ud->d_lanes, ud->S, bl);
+                hipLaunchKernelGGL(ku_phn_heur, dim3((gn[k0] + PH_T - 1) / PH_T, 1, m), dim3(PH_T), 0, ud->stream, ud->d_lanes, ud->S, bl);
+            }
             kf_mark(ud);
             if ((rc = sb_score(ud, g_at[gi], g_at[gi + 1] - g_at[gi])) != S3A_OK) break;
             kf_mark(ud);
@@ -5033,10 +5086,12 @@ uttdec_decode_queue(s3a_uttdec_t *ud, int32_t n_utt, const float *const *feat, c
             ud->kf_n_frames++;
             kf_mark(ud);
             hipLaunchKernelGGL(ku_hyp, dim3(m), dim3(UH_T), 0, ud->stream, ud->d_lanes, ud->lm->d, ud->dict, P, ud->q_hdr_d, ud->q_words_d, wcount, bl, bu);
-            if ((rc = s3a_dagpass_enqueue_lanes(ud->dag, bl, m, ud->stream)) != S3A_OK) break;
-            hipLaunchKernelGGL(ku_dag_store, dim3(m), dim3(UH_T), 0, ud->stream, ud->d_lanes, s3a_dagpass_dev_lanes(ud->dag), s3a_dagpass_hyp_cap(ud->dag),
-                               ud->q_dio_d, ud->q_dw_d, ud->q_dio_d + (size_t)n_utt * DG_IO_N, (int32_t)wtotal, bl, bu);
-            if (ud->q_keep_lat && (rc = q_keep_lattices(ud, sched.data() + (size_t)2 * k0, sched.data() + (size_t)2 * k0 + m, m)) != S3A_OK) break;
+            if (ud->dag) {
+                if ((rc = s3a_dagpass_enqueue_lanes(ud->dag, bl, m, ud->stream)) != S3A_OK) break;
+                hipLaunchKernelGGL(ku_dag_store, dim3(m), dim3(UH_T), 0, ud->stream, ud->d_lanes, s3a_dagpass_dev_lanes(ud->dag), s3a_dagpass_hyp_cap(ud->dag),
+                                   ud->q_dio_d, ud->q_dw_d, ud->q_dio_d + (size_t)n_utt * DG_IO_N, (int32_t)wtotal, bl, bu);
+                if (ud->q_keep_lat && (rc = q_keep_lattices(ud, sched.data() + (size_t)2 * k0, sched.data() + (size_t)2 * k0 + m, m)) != S3A_OK) break;
+            }
             hipLaunchKernelGGL(ku_lanes_end, dim3(8, 2 * T, m), dim3(256), 0, ud->stream, ud->d_lanes, ud->S, bl, c.n_word);
             if (hipGetLastError() != hipSuccess) { s3a_set_error("s3a_uttdec_decode_queue: a launch of the grouped second pass failed"); rc = S3A_EHIP; }
         }

@@ -107,6 +107,49 @@ def test_phoneme_lookahead_from_a_bundle(task3, gpu_lib):
     assert "".join(o[0] for o in out) == hyp and "".join(o[1] for o in out) == seg
 
 
+KF = {"S3A_UTT_PERSIST": "1"}
+
+
+@pytest.mark.parametrize("opt", ["t1_w1", "t1_w5", "t2_w3", "t3_w4", "t1_w10_hist"])
+def test_phoneme_lookahead_inside_ku_frames(task3, opt):
+    """round 6: the look-ahead inside the persistent kernel (ku_frames<3, *, HEUR>): the heuristic thresholds by list position as a
+    step of the frame, the extra test at every transition of the propagation's three ways (list pass, one-parent sets, the several-
+    parent sets' tables in LDS) -- one workgroup per lane, clusters of 3, and a queue (groups of static launches: the look-ahead's
+    tables are made when a lane begins its utterance)"""
+    d, args = task3
+    both(d, args, opt, "kf4_" + opt, dict(KF, S3A_UTT="4", S3A_UTT_CLUSTER="1"))
+    both(d, args, opt, "kf5c3_" + opt, dict(KF, S3A_UTT="5", S3A_UTT_CLUSTER="3"))
+    both(d, args, opt, "kfq3_" + opt, dict(KF, S3A_UTT="3", S3A_UTT_QUEUE="8", S3A_UTT_CLUSTER="2"))
+
+
+def test_phoneme_lookahead_ku_frames_is_what_ran(task3, gpu_lib):
+    """the engine reports that the calls went through ku_frames (s3a_uttdec_last_parts), static and as a queue"""
+    d, args = task3
+    opt = "t3_w4"
+    bp = d + "/phkf.bundle"
+    r = subprocess.run([TST] + args + OPTS[opt], env=dict(os.environ, S3A_UTT="1", S3A_EXPORT=bp), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and os.path.exists(bp), r.stderr[-2000:]
+    if not os.path.exists(f"{d}/ref_{opt}.hyp"):
+        r = subprocess.run([REF] + args + OPTS[opt] + ["-hyp", f"{d}/ref_{opt}.hyp", "-hypseg", f"{d}/ref_{opt}.hypseg"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0
+    utts = [l.split()[0] for l in open(os.path.join(d, "ctl")) if l.strip()]
+    feats = [s3io.read_mfc(os.path.join(d, "feat", u + ".mfc")).reshape(-1, 39) for u in utts]
+    dec = bundle.Decoder(bp, 8, opts={"persist": 1, "cluster": 2})
+    dec.decode(feats)
+    parts = dec.ud.last_parts()
+    assert parts["n_frames"] >= 1 and parts["cluster"] == 2, parts
+    out = [dec.format_var(*dec.hyp_var(z, utts[z], z)) for z in range(8)]
+    assert "".join(o[0] for o in out) == open(f"{d}/ref_{opt}.hyp").read()
+    assert "".join(o[1] for o in out) == open(f"{d}/ref_{opt}.hypseg").read()
+    dec3 = bundle.Decoder(bp, 3, opts={"persist": 1})
+    dec3.decode_queue(feats)
+    parts = dec3.ud.last_parts()
+    assert parts["n_frames"] == 3, parts            # 8 utterances over 3 lanes: three groups, a launch (chain) each
+    out = [dec3.format_var(*dec3.queue_hyp(k, utts[k], k)) for k in range(8)]
+    assert "".join(o[0] for o in out) == open(f"{d}/ref_{opt}.hyp").read()
+    assert "".join(o[1] for o in out) == open(f"{d}/ref_{opt}.hypseg").read()
+
+
 def test_lookahead_with_a_wide_phone_beam(task3):
     """-pbeam wider than -beam: every frame has HMMs under the HMM beam that may still propagate (refused until round 4)"""
     d, args = task3
