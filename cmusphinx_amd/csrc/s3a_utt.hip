@@ -1066,26 +1066,30 @@ ku_heur_thresh(const ULane *__restrict__ lanes, UShared S, int32_t fg)
  *   3. hth_pos = max(raw, survivors at or before the position) + pl_beam.
  * Replaces ku_weak + ku_heur_thresh when both options are on (in a frame with the usual geometry no HMM is weak and 2. is empty).
  */
-__global__ void __launch_bounds__(1024)
-ku_weak_heur(const ULane *__restrict__ lanes, UShared S, int32_t fg)
+/* (the body: NT threads of one workgroup for tree t of the lane; best = the trees' best scores of the frame -- the lane's array, or
+ * ku_frames' copy in LDS; s_w / s_c: NT / 64 words each, s_x: 3 words of the caller's LDS) */
+template <int NT>
+__device__ void
+d_weak_heur_t(const ULane &L, const UShared &S, int32_t f, int32_t cur, const int32_t *nact_cur, const int32_t *best, int32_t t,
+              int32_t *s_w, int32_t *s_c, int32_t *s_x)
 {
-    LANE;
-    const int32_t t = blockIdx.x, na = nact_cur[t], b = S.node_base[t], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int32_t na = nact_cur[t], b = S.node_base[t], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (na == 0) return;
     int32_t th, pth;
     {
         int32_t bh, bw, n, wth;
-        (void)frame_thresholds(L.best, nact_cur, S.T, frame_beams(S, f), L.hbin, bh, bw, n, th, pth, wth);
+        (void)frame_thresholds(best, nact_cur, S.T, frame_beams(S, f), L.hbin, bh, bw, n, th, pth, wth);
     }
     const bool weak_frame = pth < th;
     const int32_t *heur = L.heur_all + (size_t)f * S.n_ci;
     const int32_t *act = L.act[cur];
     int32_t *wl_v = L.exits + b, *wl_pos = L.exits + (size_t)S.N + b, *wl_H = L.exits + 2 * (size_t)S.N + b;   /* (free between the histogram and the scan) */
     int32_t *sv_pos = L.hth_pos + (size_t)S.N + b, *sv_max = L.hth_pos + 2 * (size_t)S.N + b;
-    __shared__ int32_t s_w[16], s_c[16], s_carry, s_nw, s_ns;
+    int32_t &s_carry = s_x[0], &s_nw = s_x[1], &s_ns = s_x[2];
+    __syncthreads();
     if (tid == 0) { s_carry = INT_MIN; s_nw = 0; s_ns = 0; }
     __syncthreads();
-    for (int32_t i0 = 0; i0 < na; i0 += 1024) {
+    for (int32_t i0 = 0; i0 < na; i0 += NT) {
         const int32_t i = i0 + tid;
         int32_t m = INT_MIN, p = -1;
         bool wk = false;
@@ -1117,12 +1121,12 @@ ku_weak_heur(const ULane *__restrict__ lanes, UShared S, int32_t fg)
             wl_v[k] = p; wl_pos[k] = i; wl_H[k] = m;
         }
         __syncthreads();
-        if (tid == 1023) { s_carry = x; s_nw = at + s_c[15]; }
+        if (tid == NT - 1) { s_carry = x; s_nw = at + s_c[NT / 64 - 1]; }
         __syncthreads();
     }
     const int32_t nw = s_nw;
     if (nw == 0) {
-        for (int32_t i = tid; i < na; i += 1024) L.hth_pos[b + i] = add32(L.hth_pos[b + i], S.pl_beam);
+        for (int32_t i = tid; i < na; i += NT) L.hth_pos[b + i] = add32(L.hth_pos[b + i], S.pl_beam);
         return;
     }
     __threadfence_block();
@@ -1173,7 +1177,7 @@ ku_weak_heur(const ULane *__restrict__ lanes, UShared S, int32_t fg)
     }
     __syncthreads();
     const int32_t ns = s_ns;
-    for (int32_t i = tid; i < na; i += 1024) {
+    for (int32_t i = tid; i < na; i += NT) {
         int32_t hm = L.hth_pos[b + i];
         if (ns > 0 && sv_pos[0] <= i) {
             int32_t lo = 0, hi = ns - 1;
@@ -1185,6 +1189,14 @@ ku_weak_heur(const ULane *__restrict__ lanes, UShared S, int32_t fg)
         }
         L.hth_pos[b + i] = add32(hm, S.pl_beam);
     }
+}
+
+__global__ void __launch_bounds__(1024)
+ku_weak_heur(const ULane *__restrict__ lanes, UShared S, int32_t fg)
+{
+    LANE;
+    __shared__ int32_t s_w[16], s_c[16], s_x[3];
+    d_weak_heur_t<1024>(L, S, f, cur, nact_cur, L.best, blockIdx.x, s_w, s_c, s_x);
 }
 
 /* ---- lextree_hmm_eval ---- */
@@ -1567,8 +1579,7 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
  * other).  Words that ATOMICS of an earlier phase changed are read past the L1 (S3A_ALD); the per-tree maxima are copied to
  * LDS once per frame and every later phase reads the copy.  LDS: the word level's arrays + one pool the other phases share
  * (two workgroups per CU).
- * Not served here (the engine then keeps the launch path): -pheurtype together with weak HMMs (-ptranskip / -pbeam wider than -beam) or
- * with 5-state models, per-frame scoring (window = 0), the invariant checker, per-launch profiling.
+ * Not served here (the engine then keeps the launch path): -pheurtype with 5-state models, per-frame scoring (window = 0), the invariant checker, per-launch profiling.
  * ==================================================================================================================== */
 #define KF_NT WL_THREADS
 #define KF_WAVES (KF_NT / 64)
@@ -2419,7 +2430,13 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     KF_STAMP(7);
     /* ---- -ptranskip frames / -pbeam wider than -beam: the weak HMMs that a parent earlier in the list re-entered (ku_weak) ---- */
     if (weak_possible && (bm.phone_uses_wbeam || bm.pbeam < bm.hmmbeam)) {
-        if (r == 0)
+        if (HEUR) {
+            /* ... together with the look-ahead (ku_weak_heur): which weak HMMs a parent re-entered AND the heuristic thresholds by list
+             * position, a tree per workgroup in turn */
+            static_assert(KF_WAVES <= 16, "d_weak_heur_t's per-wave words");
+            for (int32_t t = r; t < T; t += C) d_weak_heur_t<KF_NT>(L, S, f, cur, nact_cur, sh.best, t, sh.ws, sh.seg, sh.gq);
+        }
+        else if (r == 0)
             d_dec_weak_t<KF_NT>(S.N, T, f, bm, sh.best, L.nact[cur], S.node_base, L.act[cur], S.prob, S.par_off, S.par, L.pos, L.posf, L.sc, L.outs,
                                 L.bests, S.wid, L.hbin, L.propf, L.exits + 2 * (size_t)S.N, 0, 0);
         kf_barrier(B);
@@ -2437,7 +2454,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
             for (int32_t i = tid; i < NBIN; i += KF_NT) L.hbin[i] = 0;         /* (the bins were consumed by the sort; hbin[NBIN] stays) */
         const int32_t *act = L.act[cur];
         const HeurArgs hx = HEUR ? HeurArgs{ S.node_ci, L.heur_all + (size_t)f * S.n_ci, L.hth_pos } : HeurArgs{ NULL, NULL, NULL };
-        if (HEUR) {
+        if (HEUR && !(weak_possible && (bm.phone_uses_wbeam || bm.pbeam < bm.hmmbeam))) {       /* (a frame with weak HMMs: d_weak_heur_t made them) */
             /* the heuristic threshold of every propagating HMM by list position (ku_heur_thresh; lextree.c:1443-1462): per tree the running
              * maximum over the list of max over children (out + (prob(child) - prob) + phn_heur[ci(child)]), plus pl_beam -- a tree per
              * workgroup in turn, KF_NT positions per pass, the passes' carry through LDS */
@@ -4259,9 +4276,9 @@ kf_served(const s3a_uttdec_t *ud, int32_t n)
     /* (a wide-beam engine -- big_wl, configs[4] -- is SERVED, word level and all, but keeps the launches unless asked: 23 000 HMMs and 300 000
      * word-level candidates per lane-frame want the whole chip per step, not a cluster of 8 workgroups -- 64 lanes: 10.4 k frames/s through
      * ku_frames against 30.5 k through the launches, 128 lanes 19.4 k : 36.1 k; profiles/r6_experiments.txt 8) */
-    /* (-pheurtype: with 3-state models, and not together with weak HMMs -- -ptranskip / -pbeam wider than -beam: ku_weak_heur stays a launch) */
+    /* (-pheurtype: with 3-state models) */
     return ud->persist && (ud->persist > 1 || (n >= KF_MIN_LANES && !ud->big_wl)) && S.win_K > 0
-        && (S.pheurtype == 0 || (S.ne == 3 && !ud->weak_possible)) && !ud->d_dbg
+        && (S.pheurtype == 0 || S.ne == 3) && !ud->d_dbg
         && ud->prof_every == 0 && ((S.ne == 3 && S.nodepk) || S.ne == 5) && S.T <= WL_MAXT && S.n_sen <= KF_SENBITS;
 }
 

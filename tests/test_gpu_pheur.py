@@ -110,7 +110,7 @@ def test_phoneme_lookahead_from_a_bundle(task3, gpu_lib):
 KF = {"S3A_UTT_PERSIST": "1"}
 
 
-@pytest.mark.parametrize("opt", ["t1_w1", "t1_w5", "t2_w3", "t3_w4", "t1_w10_hist"])
+@pytest.mark.parametrize("opt", ["t1_w1", "t1_w5", "t2_w3", "t3_w4", "t1_w10_hist", "t1_w5_skip3", "t3_w4_skip2", "t2_w3_skip1"])
 def test_phoneme_lookahead_inside_ku_frames(task3, opt):
     """round 6: the look-ahead inside the persistent kernel (ku_frames<3, *, HEUR>): the heuristic thresholds by list position as a
     step of the frame, the extra test at every transition of the propagation's three ways (list pass, one-parent sets, the several-
@@ -151,7 +151,8 @@ def test_phoneme_lookahead_ku_frames_is_what_ran(task3, gpu_lib):
 
 
 def test_lookahead_with_a_wide_phone_beam(task3):
-    """-pbeam wider than -beam: every frame has HMMs under the HMM beam that may still propagate (refused until round 4)"""
+    """-pbeam wider than -beam: every frame has HMMs under the HMM beam that may still propagate (refused until round 4); the launches,
+    and (round 6) inside ku_frames -- d_weak_heur_t as a step of the frame, a tree per workgroup of the cluster"""
     d, args = task3
     wide = [a for a in args]
     wide[wide.index("-pbeam") + 1] = "1e-90"               # wider than -beam 1e-70
@@ -159,3 +160,5 @@ def test_lookahead_with_a_wide_phone_beam(task3):
         OPTS[key] = OPTS[opt]
         both(d, wide, key, "u4_" + key, {"S3A_UTT": "4"})
         both(d, wide, key, "u1_" + key, {"S3A_UTT": "1"})
+        both(d, wide, key, "kf4_" + key, dict(KF, S3A_UTT="4", S3A_UTT_CLUSTER="1"))
+        both(d, wide, key, "kf3c4_" + key, dict(KF, S3A_UTT="3", S3A_UTT_CLUSTER="4", S3A_UTT_QUEUE="8"))
