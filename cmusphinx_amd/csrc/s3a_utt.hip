@@ -4317,7 +4317,16 @@ kf_choose_c(s3a_uttdec_t *ud, int32_t n)
     const int32_t usable = kf_usable_per_xcd(ud), per_xcd = max(1, ud->kf_slots / 8), lanes_per_xcd = (n + 7) / 8;
     int32_t C = 1;
     if (ud->kf_cluster_opt > 0) C = ud->kf_cluster_opt;
-    else if (kf_alone(ud)) C = min(per_xcd / lanes_per_xcd, ud->big_wl ? 8 : KF_CLUSTER_MAX(n));     /* (wide beams: seven times the HMMs, a word level in chunks) */
+    else if (kf_alone(ud)) {
+        const int32_t cmax = ud->big_wl ? 8 : KF_CLUSTER_MAX(n);       /* (wide beams: seven times the HMMs, a word level in chunks) */
+        C = min(per_xcd / lanes_per_xcd, cmax);
+        /* ... but an EVEN fill first: a cluster is as fast as its slowest workgroup, and with one and a half workgroups per CU some share
+         * a CU and some do not -- 128 lanes: 429.5 k frames/s as clusters of 2 (one workgroup per CU) against 406.9 k as clusters of 3
+         * (profiles/r6_experiments.txt 16).  So: as many workgroups per lane as still leave every workgroup a CU of its own, when that is
+         * a cluster at all */
+        const int32_t c1 = min(max(1, ud->g->dev->n_cu / 8) / lanes_per_xcd, cmax);
+        if (c1 >= 2) C = c1;
+    }
     /* (KF_MAXC: what the kernel's LDS arrays -- the waves' segments, the cluster's scan -- are sized for) */
     return max(1, min(min(C, KF_MAXC), usable / lanes_per_xcd));
 }
