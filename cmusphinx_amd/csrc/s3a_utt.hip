@@ -1959,9 +1959,12 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
         kf_barrier(B);
     }
 
-    /* ---- lextree_enter (lextree.c:1093-1236; ku_enter1 / 2 / 3 of the launch path): of the frame's ~60 k (call, root) entries a few
-     * hundred pass the threshold test, so ONE sweep tests them all (a coalesced load each) and keeps the ones that pass, in entry
-     * order -- every wave compacts its own stretch --; ranking and applying then only see those.  Key / first: as d_dec_enter1. ---- */
+    /* ---- lextree_enter (lextree.c:1093-1236; ku_enter1 / 2 / 3 of the launch path): the bench's task has ~7 calls (one per tree and
+     * left context that a word left) with ~13.6 k (call, root) entries per frame, ~3 000 of which pass the threshold and ~2 600 improve
+     * on their root -- ONE sweep tests them all (coalesced loads) and keeps those, in entry order -- every wave compacts its own
+     * stretch --; ranking and applying then only see the kept ones.  Key / first: as d_dec_enter1.  (Looking only at the entries
+     * that can pass -- prefixes of the root lists sorted by probability -- was built and is slower: its stages are gathers,
+     * profiles/r6_experiments.txt 18.) ---- */
     if (n_ent > 0) {
         const int32_t n_calls = min(n_calls_all, WL_MAXCALL), nf = f;
         if (tid < n_calls) {
