@@ -105,6 +105,8 @@ struct UShared {
     const int4 *node4;          /* per node: {ssid, tmatid, wid, composite}: ku_hmm_eval's static words as one load */
     const int32_t *nodesen;     /* per node, 2 (3 states) or 4 (5 states) words: its senone ids -- of a composite node its composite-senone ids --
                                  * as 16-bit halves (ku_frames: one load instead of the chain node -> sequence id -> three 2-byte gathers) */
+    const int4 *pshdr;          /* per parent set ONE 16-byte word for what ku_frames' propagation asks of a listed set: its members' run in psmem
+                                 * (first, end), its parents' run in par (first, count) -- instead of the chain set -> psmem_off -> psmem -> par_off */
     const int4 *nodepk;         /* 3-state HMMs, per node ONE 16-byte word for everything ku_frames' steps read of it: senone ids 0 | 1 << 16,
                                  * id 2 | transition matrix << 16, word id, (parent set + 1) << 1 | composite (what is asked for together
                                  * lives together: one cache line per visit instead of node4's + nodesen's + ps's three) */
@@ -306,6 +308,17 @@ ku_selfcheck(const ULane *__restrict__ lanes, UShared S, int32_t lane, int32_t *
         if (bad) atomicMin(&out[6], v);
         if (L.turn[v] != -1 || L.selfemit[v] != 0 || L.cnt[v] != 0) atomicAdd(&out[7], 1);
     }
+}
+
+__global__ void
+ku_pack_pshdr(const int32_t *__restrict__ psmem_off, const int32_t *__restrict__ psmem, const int32_t *__restrict__ par_off, int4 *__restrict__ out, int32_t n_pset)
+{
+    const int32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_pset) return;
+    const int32_t m_lo = psmem_off[q], m_hi = psmem_off[q + 1];
+    int32_t kp0 = 0, np = 0;
+    if (m_hi > m_lo) { const int32_t x0 = psmem[m_lo]; kp0 = par_off[x0]; np = par_off[x0 + 1] - kp0; }
+    out[q] = make_int4(m_lo, m_hi, kp0, np);
 }
 
 /* ---- lextree_enter calls left by the previous frame's word level (or by utterance begin) ---- */
@@ -2643,8 +2656,17 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
                     int32_t cm = 0, m_lo = 0;
                     if (tid < nk) {
                         const int32_t q = GMC(L.plist)[k0 + tid];
+#ifndef KF_PSHDR
+#define KF_PSHDR 1
+#endif
+#if KF_PSHDR
+                        const s3a_v4i h_ = *(const S3A_AS1 s3a_v4i *)(S.pshdr + q);      /* (the set's header in one word: two dependent gathers less than the chain below) */
+                        m_lo = h_.x;
+                        const int32_t m_hi = h_.y, kp0 = h_.z, np = h_.w;
+#else
                         m_lo = GMC(S.psmem_off)[q];
                         const int32_t m_hi = GMC(S.psmem_off)[q + 1], x0 = GMC(S.psmem)[m_lo], kp0 = GMC(S.par_off)[x0], np = GMC(S.par_off)[x0 + 1] - kp0;
+#endif
                         if (np >= SET_NP_MIN && np <= 64) {
                             const int32_t at = atomicAdd(&rs.nbig, 1);
                             rs.big[at] = q;
@@ -3573,6 +3595,7 @@ s3a_uttdec_free(s3a_uttdec_t *ud)
     if (ud->S.node_ci) (void)hipFree((void *)ud->S.node_ci);
     if (ud->S.sen2cimap) (void)hipFree((void *)ud->S.sen2cimap);
     if (ud->S.rootprob) (void)hipFree((void *)ud->S.rootprob);
+    if (ud->S.pshdr) (void)hipFree((void *)ud->S.pshdr);
     if (ud->S.node4) (void)hipFree((void *)ud->S.node4);
     if (ud->S.nodesen) (void)hipFree((void *)ud->S.nodesen);
     if (ud->S.nodepk) (void)hipFree((void *)ud->S.nodepk);
@@ -3691,6 +3714,14 @@ s3a_uttdec_init_opts(const s3a_lexsearch_t *proto, s3a_mgau_model_t *g, const in
             hipLaunchKernelGGL(ku_pack_nodepk, dim3((unsigned)((proto->N + 255) / 256)), dim3(256), 0, ud->stream, proto->d_ssid, proto->d_tmatid, proto->d_wid,
                                proto->d_comp, proto->d_sseq, proto->d_comsseq, proto->d_ps, proto->d_par_off, pk, proto->N);
         }
+    }
+    S.pshdr = NULL;
+    if (proto->d_ps && proto->n_pset > 0) {
+        int4 *ph = NULL;
+        if (hipMalloc((void **)&ph, (size_t)proto->n_pset * sizeof(int4)) != hipSuccess) { s3a_set_error("s3a_uttdec_init: out of device memory"); goto fail; }
+        hipLaunchKernelGGL(ku_pack_pshdr, dim3((unsigned)((proto->n_pset + 255) / 256)), dim3(256), 0, ud->stream, proto->d_psmem_off, proto->d_psmem, proto->d_par_off,
+                           ph, proto->n_pset);
+        S.pshdr = ph;
     }
     {   /* the roots' look-ahead probabilities in root-list order (Entries::rootprob) */
         const size_t nr = proto->h_rootlist.size();
