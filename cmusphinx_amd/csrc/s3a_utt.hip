@@ -2219,7 +2219,10 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     }
     /* ---- the members of the composite senones wanted in the frame join the mask (ku_comsen_mark): from the frame's list ---- */
     const int32_t n_csw = S3A_ALD(&L.cs_wn[0]);
-    d_comsen_list<false>(L.cs_wl, n_csw, S.cs_off, S.cs_list, (uint8_t *)NULL, (const int32_t *)NULL, (int32_t *)NULL, gtid >> 4, gstride >> 4,
+#ifndef KF_CSU
+#define KF_CSU 4                /* composite senones a 16-thread group walks per turn */
+#endif
+    d_comsen_list<false, KF_CSU>(L.cs_wl, n_csw, S.cs_off, S.cs_list, (uint8_t *)NULL, (const int32_t *)NULL, (int32_t *)NULL, gtid >> 4, gstride >> 4,
                          (const int32_t *)NULL, sh.senbits);
     /* (a cluster's workgroups marked their shares: the masks meet in the lane's words, and every workgroup reads the union back) */
     if (C > 1) {
@@ -2250,7 +2253,7 @@ kf_frame(const ULane &L, const UShared &S, UCtx *ctx, const WLm &lm, const WDict
     if (C > 1 && r == 0) for (int32_t i = tid; i < KF_SENBITS / 32; i += KF_NT) L.senbits[i] = 0u;
     KF_STAMP(4);
     /* ---- the scores of the composite senones wanted in this frame (ku_comsen_max) ---- */
-    d_comsen_list<true>(L.cs_wl, n_csw, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, gtid >> 4, gstride >> 4, S.cs_wt);
+    d_comsen_list<true, KF_CSU>(L.cs_wl, n_csw, S.cs_off, S.cs_list, (uint8_t *)NULL, row, L.cs_val, gtid >> 4, gstride >> 4, S.cs_wt);
     kf_barrier(B);
     KF_STAMP(5);
     /* ---- lextree_hmm_eval (ku_hmm_eval): a thread per list position of the trees laid end to end; the per-tree maxima are
