@@ -411,11 +411,11 @@ def ps_fwdtree_leg(t, lanes, n_cpu=128, n_proc=16):
         # half of MI355X_MICROARCH.md's 157.3 TFLOP/s, which counts an FMA as two) and k_psf_queue (the search: one workgroup per lane)
         fr, sms, tms = int(dev.group(2)), float(sc.group(1)), float(dev.group(3))
         flop = fr * 6144 * 8 * 39 * 4.0
-        pmc = os.path.join(ROOT, "profiles", "r4_pmc_ps.json")
+        pmc = os.path.join(ROOT, "profiles", "r6_pmc_ps.json")
         traffic = None
         if os.path.exists(pmc):
-            k = json.load(open(pmc))["kernels"].get("k_psf_queue<3>")
-            traffic = k["bytes_per_frame"] if k else None
+            k = [v for n, v in json.load(open(pmc))["kernels"].items() if n.startswith("k_psf_queue<3")]
+            traffic = k[0]["bytes_per_frame"] if k else None
         srch_ms = tms - sms
         alg = 1700 * 64 * 2 + 2 * 1500
         out["roofline_scoring"] = {"kernel": "k_ps_cont_tr<8,39>", "bound": "valu-f32 (packed, no FMA)", "avg_launch_us": round(sms * 1e3, 1),
@@ -427,8 +427,8 @@ def ps_fwdtree_leg(t, lanes, n_cpu=128, n_proc=16):
                                   "algorithmic_bytes_per_frame": alg, "achieved": round(fr * alg / (srch_ms * 1e-3) / 1e9, 1), "peak": 8000.0,
                                   "unit": "GB/s", "frac": round(fr * alg / (srch_ms * 1e-3) / 1e9 / 8000.0, 4),
                                   "traffic_bytes_per_frame": traffic,
-                                  "traffic_source": "profiles/r4_pmc_ps.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 256 utterances over 128 "
-                                                    "lanes)" if traffic else None,
+                                  "traffic_source": "profiles/r6_pmc_ps.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this very regime: 1024 utterances "
+                                                    "as one queue over 512 lanes, tools/ps_pmc_regime.py)" if traffic else None,
                                   "note": "algorithmic = ~1 700 active channels per frame (pocketsphinx's own count: 1 191 - 2 270 per frame) x a 64-byte "
                                           "record read and written + the active senones' int16 scores"}
     assert same_h and same_s, "pocketsphinx first pass on the device differs from the unmodified pocketsphinx"

@@ -1482,7 +1482,6 @@ up(s3a_psfwd_t *e, const T *src, size_t n, bool lane = false)
 }
 
 #define UP(dst, src, n) do { (dst) = up(e, (src), (size_t)(n)); if (!(dst)) { s3a_set_error("s3a_psfwd_init: device allocation failed"); s3a_psfwd_free(e); return NULL; } } while (0)
-#define LANE(dst, T, n) do { (dst) = up<T>(e, (const T *)NULL, (size_t)(n), true); if (!(dst)) { s3a_set_error("s3a_psfwd_init: device allocation failed (lane state)"); s3a_psfwd_free(e); return NULL; } } while (0)
 
 extern "C" void
 s3a_psfwd_free(s3a_psfwd_t *e)
@@ -1626,22 +1625,44 @@ s3a_psfwd_init(const s3a_psfwd_desc_t *d, int32_t n_lanes, int32_t max_frames, i
     UP(M.tg_wid, d->tg_wid, d->lm_n_tg); UP(M.tg_prob, d->tg_prob, d->lm_n_tg);
 
     e->lanes_h.resize(n_lanes);
-    for (int32_t z = 0; z < n_lanes; z++) {
-        PsfLane &L = e->lanes_h[z];
-        const size_t H = (size_t)M.n_hmm + (M.pl_window > 0 ? M.n_ci : 0);
-        LANE(L.st, int32_t, CH_STRIDE * H);
-        LANE(L.pl_host, int32_t, M.n_ci); LANE(L.senkeep, uint32_t, (M.n_sen + 31) / 32);
-        LANE(L.mpxid, uint16_t, (size_t)MPX_STRIDE * M.n_mpx);
-        for (int k = 0; k < 2; k++) { LANE(L.acl[k], int32_t, d->n_nonroot + 1); LANE(L.awl[k], int32_t, M.cand_cap + 1); }
-        LANE(L.wstamp, int32_t, W); LANE(L.lt_sf, int32_t, W); LANE(L.lt_dscr, int32_t, W); LANE(L.lt_bp, int32_t, W);
-        LANE(L.ent_score, int32_t, d->n_nonroot + 1); LANE(L.ent_hist, int32_t, d->n_nonroot + 1); LANE(L.ent_stamp, int32_t, d->n_nonroot + 1);
-        LANE(L.cand_wid, int32_t, M.cand_cap); LANE(L.cand_score, int32_t, M.cand_cap); LANE(L.cand_bp, int32_t, M.cand_cap); LANE(L.cand_ef, int32_t, M.cand_cap);
-        LANE(L.bp_frame, int32_t, M.bp_cap); LANE(L.bp_wid, int32_t, M.bp_cap); LANE(L.bp_bp, int32_t, M.bp_cap); LANE(L.bp_score, int32_t, M.bp_cap);
-        LANE(L.bp_sidx, int32_t, M.bp_cap); LANE(L.bp_realwid, int32_t, M.bp_cap); LANE(L.bp_valid, uint8_t, M.bp_cap);
-        LANE(L.bss, int32_t, M.bss_cap); LANE(L.bp_idx, int32_t, max_frames + 3);
-        LANE(L.flags, uint8_t, d->n_sen); LANE(L.senscr, int16_t, d->n_sen); LANE(L.rl, int32_t, d->n_root + 1); LANE(L.arc, int32_t, n_rc + 1);
-        LANE(L.sc, PsfScalars, 1); LANE(L.seg, s3a_psfwd_seg_t, MAX_SEG);
-        L.raw = NULL;
+    {
+        /* a lane's arrays as ONE allocation (256-byte aligned pieces, zeroed once): 36 allocations per lane were 18 000 for an engine of
+         * 512 lanes -- slow to make, and more than the profiler's allocation tracking takes (rocprofv3 --pmc did not get through such an
+         * engine's construction: profiles/r6_experiments.txt 10, 21) */
+        auto layout = [&](PsfLane &L, char *base) -> size_t {
+            size_t at = 0;
+            auto take = [&](size_t n, size_t sz) -> char * { char *p_ = base ? base + at : (char *)NULL; at += ((n ? n : 1) * sz + 255) & ~(size_t)255; return p_; };
+#define PIECE(dst, T, n) (dst) = (T *)take((size_t)(n), sizeof(T))
+            const size_t H = (size_t)M.n_hmm + (M.pl_window > 0 ? M.n_ci : 0);
+            PIECE(L.st, int32_t, CH_STRIDE * H);
+            PIECE(L.pl_host, int32_t, M.n_ci); PIECE(L.senkeep, uint32_t, (M.n_sen + 31) / 32);
+            PIECE(L.mpxid, uint16_t, (size_t)MPX_STRIDE * M.n_mpx);
+            for (int k = 0; k < 2; k++) { PIECE(L.acl[k], int32_t, d->n_nonroot + 1); PIECE(L.awl[k], int32_t, M.cand_cap + 1); }
+            PIECE(L.wstamp, int32_t, W); PIECE(L.lt_sf, int32_t, W); PIECE(L.lt_dscr, int32_t, W); PIECE(L.lt_bp, int32_t, W);
+            PIECE(L.ent_score, int32_t, d->n_nonroot + 1); PIECE(L.ent_hist, int32_t, d->n_nonroot + 1); PIECE(L.ent_stamp, int32_t, d->n_nonroot + 1);
+            PIECE(L.cand_wid, int32_t, M.cand_cap); PIECE(L.cand_score, int32_t, M.cand_cap); PIECE(L.cand_bp, int32_t, M.cand_cap); PIECE(L.cand_ef, int32_t, M.cand_cap);
+            PIECE(L.bp_frame, int32_t, M.bp_cap); PIECE(L.bp_wid, int32_t, M.bp_cap); PIECE(L.bp_bp, int32_t, M.bp_cap); PIECE(L.bp_score, int32_t, M.bp_cap);
+            PIECE(L.bp_sidx, int32_t, M.bp_cap); PIECE(L.bp_realwid, int32_t, M.bp_cap); PIECE(L.bp_valid, uint8_t, M.bp_cap);
+            PIECE(L.bss, int32_t, M.bss_cap); PIECE(L.bp_idx, int32_t, max_frames + 3);
+            PIECE(L.flags, uint8_t, d->n_sen); PIECE(L.senscr, int16_t, d->n_sen); PIECE(L.rl, int32_t, d->n_root + 1); PIECE(L.arc, int32_t, n_rc + 1);
+            PIECE(L.sc, PsfScalars, 1); PIECE(L.seg, s3a_psfwd_seg_t, MAX_SEG);
+#undef PIECE
+            L.raw = NULL;
+            return at;
+        };
+        PsfLane probe;
+        const size_t per_lane = layout(probe, (char *)NULL);
+        for (int32_t z = 0; z < n_lanes; z++) {
+            char *slab = NULL;
+            if (hipMalloc((void **)&slab, per_lane) != hipSuccess || hipMemset(slab, 0, per_lane) != hipSuccess) {
+                if (slab) (void)hipFree(slab);
+                s3a_set_error("s3a_psfwd_init: device allocation failed (lane %d: %zu bytes)", z, per_lane);
+                s3a_psfwd_free(e);
+                return NULL;
+            }
+            e->dev_lane.push_back(slab);
+            (void)layout(e->lanes_h[z], slab);
+        }
     }
     if (hipMalloc((void **)&e->lanes_d, sizeof(PsfLane) * n_lanes) != hipSuccess
         || hipMalloc((void **)&e->lane_ids_d, sizeof(int32_t) * n_lanes) != hipSuccess
