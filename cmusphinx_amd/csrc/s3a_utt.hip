@@ -1592,7 +1592,7 @@ ku_hyp(const ULane *__restrict__ lanes, WLm lm, WDict dict, UHypPar P, int32_t *
  * other).  Words that ATOMICS of an earlier phase changed are read past the L1 (S3A_ALD); the per-tree maxima are copied to
  * LDS once per frame and every later phase reads the copy.  LDS: the word level's arrays + one pool the other phases share
  * (two workgroups per CU).
- * Not served here (the engine then keeps the launch path): -pheurtype with 5-state models, per-frame scoring (window = 0), the invariant checker, per-launch profiling.
+ * Not served here (the engine then keeps the launch path): per-frame scoring (window = 0), the invariant checker, per-launch profiling.
  * ==================================================================================================================== */
 #define KF_NT WL_THREADS
 #define KF_WAVES (KF_NT / 64)
@@ -4313,9 +4313,7 @@ kf_served(const s3a_uttdec_t *ud, int32_t n)
     /* (a wide-beam engine -- big_wl, configs[4] -- is SERVED, word level and all, but keeps the launches unless asked: 23 000 HMMs and 300 000
      * word-level candidates per lane-frame want the whole chip per step, not a cluster of 8 workgroups -- 64 lanes: 10.4 k frames/s through
      * ku_frames against 30.5 k through the launches, 128 lanes 19.4 k : 36.1 k; profiles/r6_experiments.txt 8) */
-    /* (-pheurtype: with 3-state models) */
-    return ud->persist && (ud->persist > 1 || (n >= KF_MIN_LANES && !ud->big_wl)) && S.win_K > 0
-        && (S.pheurtype == 0 || S.ne == 3) && !ud->d_dbg
+    return ud->persist && (ud->persist > 1 || (n >= KF_MIN_LANES && !ud->big_wl)) && S.win_K > 0 && !ud->d_dbg
         && ud->prof_every == 0 && ((S.ne == 3 && S.nodepk) || S.ne == 5) && S.T <= WL_MAXT && S.n_sen <= KF_SENBITS;
 }
 
@@ -4393,8 +4391,11 @@ kf_launch_t(s3a_uttdec_t *ud, int32_t n, const KfJob &J, int32_t C)
 static int32_t
 kf_launch_c(s3a_uttdec_t *ud, int32_t n, const KfJob &J, int32_t C)
 {
-    if (ud->S.ne == 5) return ud->exact ? kf_launch_t<5, true>(ud, n, J, C) : kf_launch_t<5, false>(ud, n, J, C);
-    if (ud->S.pheurtype > 0) return ud->exact ? kf_launch_t<3, true, true>(ud, n, J, C) : kf_launch_t<3, false, true>(ud, n, J, C);       /* (kf_served: 3-state models) */
+    if (ud->S.ne == 5) {
+        if (ud->S.pheurtype > 0) return ud->exact ? kf_launch_t<5, true, true>(ud, n, J, C) : kf_launch_t<5, false, true>(ud, n, J, C);
+        return ud->exact ? kf_launch_t<5, true>(ud, n, J, C) : kf_launch_t<5, false>(ud, n, J, C);
+    }
+    if (ud->S.pheurtype > 0) return ud->exact ? kf_launch_t<3, true, true>(ud, n, J, C) : kf_launch_t<3, false, true>(ud, n, J, C);
     return ud->exact ? kf_launch_t<3, true>(ud, n, J, C) : kf_launch_t<3, false>(ud, n, J, C);
 }
 

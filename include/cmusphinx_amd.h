@@ -746,7 +746,7 @@ typedef struct {
     int32_t persist;        /* the frames of a look-ahead window as ONE launch (ku_frames: a lane = a persistent 512-thread workgroup, or
                              * a cluster of them, that walks the frame's steps with barriers instead of launch boundaries -- the
                              * reference's srch.c:746-835 loop has none): 0 = whenever the engine's configuration is served
-                             * (look-ahead scoring on, no wide-beam word level; -pheurtype with 3-state models), -1 = never (the twelve
+                             * (look-ahead scoring on, no wide-beam word level), -1 = never (the twelve
                              * launches per frame of rounds 2-4), 1 = whatever the lane count (0 keeps the launches for few lanes), 2 = as 1 with
                              * the clusters' general (agent-scope) barrier only, never the XCD-local one (A/B runs).  Same bits either way. */
     int32_t cluster;        /* workgroups per lane of that launch: 0 = the library's choice (1 when the lanes fill the chip, more

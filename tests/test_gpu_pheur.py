@@ -79,6 +79,14 @@ def test_phoneme_lookahead_matches_reference_5state(task5, opt):
     both(d, args, opt, "u4_" + opt, {"S3A_UTT": "4"})
 
 
+@pytest.mark.parametrize("opt", ["t1_w5", "t3_w4"])
+def test_phoneme_lookahead_inside_ku_frames_5state(task5, opt):
+    """... and with 5-state HMMs (ku_frames<5, *, HEUR>): one workgroup per lane, clusters of 2 as a queue"""
+    d, args = task5
+    both(d, args, opt, "kf4_" + opt, {"S3A_UTT_PERSIST": "1", "S3A_UTT": "4", "S3A_UTT_CLUSTER": "1"})
+    both(d, args, opt, "kfq3_" + opt, {"S3A_UTT_PERSIST": "1", "S3A_UTT": "3", "S3A_UTT_QUEUE": "8", "S3A_UTT_CLUSTER": "2"})
+
+
 def test_phoneme_lookahead_from_a_bundle(task3, gpu_lib):
     d, args = task3
     opt = "t1_w5"
